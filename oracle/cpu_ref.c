@@ -1,0 +1,292 @@
+/* oracle/cpu_ref.c — TEST INFRASTRUCTURE ONLY (see cpu_ref.h).
+ *
+ * Plain-C restatement of the PAML likelihood hot path: same loop nests, same summation order,
+ * same numeric guards as the reference, written fresh against the behaviour of
+ *   tools.c:516-546 (PMatUVRoot), tools.c:578-604 (PMatK80), baseml.c:1572-1589 (PMatCijk),
+ *   codeml.c:3585-3595 (PMatJC69like), treesub.c:7503-7592 (GetPMatBranch),
+ *   codeml.c:3526-3582 / baseml.c:1517-1570 (ConditionalPNode), treesub.c:7200-7230 (NodeScale),
+ *   treesub.c:7696-7761 (fx_r), treesub.c:7608-7660 (lfundG), treesub.c:7764-7807 (lfun).
+ * It is the checker for the HIP engine and the timed single-thread CPU baseline ("port");
+ * it is never part of the product path.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "cpu_ref.h"
+
+static long g_npmat = 0;
+long orc_last_npmat(void) { return g_npmat; }
+
+/* tools.c:516-546.  P = I + sum_k U[:,k] expm1(t Root_k) V[k,:]; t<1e-100 -> I; entries <0 -> 0.
+ * Accumulation order: k outer, i, j inner — as the reference. */
+void orc_pmat_uvroot(double *P, double t, int n, const double *U, const double *V, const double *Root)
+{
+   int i, j, k;
+   if (t < 1e-100) {
+      memset(P, 0, (size_t)n * n * sizeof(double));
+      for (i = 0; i < n; i++) P[i * n + i] = 1;
+      return;
+   }
+   memset(P, 0, (size_t)n * n * sizeof(double));
+   for (k = 0; k < n; k++) {
+      double e = expm1(t * Root[k]);
+      for (i = 0; i < n; i++) {
+         double ue = U[i * n + k] * e;
+         double *row = P + (size_t)i * n;
+         const double *vr = V + (size_t)k * n;
+         for (j = 0; j < n; j++) row[j] += ue * vr[j];
+      }
+   }
+   for (i = 0; i < n; i++) P[i * n + i] += 1;
+   for (i = 0; i < n * n; i++)
+      if (P[i] < 0) P[i] = 0;
+}
+
+/* baseml.c:1572-1589.  P_ij = delta_ij + sum_{k>=1} Cijk[i][j][k] expm1(t Root_k); k=0 term has exptm1[0]=0.
+ * No clamp and no small-t shortcut. */
+void orc_pmat_cijk(double *P, double t, int n, int nR, const double *Cijk, const double *Root)
+{
+   int i, j, k;
+   double e[64];
+   e[0] = 0;
+   for (k = 1; k < nR; k++) e[k] = expm1(t * Root[k]);
+   for (i = 0; i < n; i++) {
+      for (j = 0; j < n; j++) {
+         double s = 0;
+         for (k = 0; k < nR; k++) s += Cijk[(size_t)i * n * nR + j * nR + k] * e[k];
+         P[i * n + j] = s;
+      }
+      P[i * n + i] += 1;
+   }
+}
+
+/* tools.c:578-604 (state order T,C,A,G: transitions are T<->C and A<->G). */
+void orc_pmat_k80(double *P, double t, double kappa)
+{
+   int i, j;
+   double e1 = expm1(-4 * t / (kappa + 2)), e2;
+   if (fabs(kappa - 1) < 1e-20) {
+      for (i = 0; i < 4; i++)
+         for (j = 0; j < 4; j++) P[i * 4 + j] = (i == j ? 1. + 3 / 4.0 * e1 : -e1 / 4);
+      return;
+   }
+   e2 = expm1(-2 * t * (kappa + 1) / (kappa + 2));
+   for (i = 0; i < 4; i++)
+      for (j = 0; j < 4; j++) {
+         if (i == j) P[i * 4 + j] = 1 + (e1 + 2 * e2) / 4;
+         else if ((i ^ j) == 1) P[i * 4 + j] = (e1 - 2 * e2) / 4;   /* 0<->1, 2<->3 */
+         else P[i * 4 + j] = -e1 / 4;
+      }
+}
+
+/* codeml.c:3585-3595 */
+void orc_pmat_jc69like(double *P, double t, int n)
+{
+   int i;
+   double pii = 1. / n + (1. - 1. / n) * exp(-n / (n - 1.) * t);
+   double pij = (1. - pii) / (n - 1.);
+   for (i = 0; i < n * n; i++) P[i] = pij;
+   for (i = 0; i < n; i++) P[i * n + i] = pii;
+}
+
+/* Branch time (codeml.c:3547-3551) + eigen selection and Qfactor (treesub.c:7547-7588). */
+void orc_pmat_branch(const orc_problem *pb, int gene, int iclass, int node, double *P)
+{
+   int n = pb->n, lab = pb->label ? pb->label[node] : 0;
+   const orc_eigen *es = &pb->eigen[pb->eigen_of[((size_t)gene * pb->K + iclass) * pb->n_labels + lab]];
+   double t = pb->branch[node] * pb->rate[iclass];
+   t *= (pb->gene_rate ? pb->gene_rate[gene] : 1.0);
+   g_npmat++;
+   switch (es->kind) {
+   case ORC_EIGEN_K80: orc_pmat_k80(P, t, es->kappa); break;
+   case ORC_EIGEN_JC69LIKE: orc_pmat_jc69like(P, t, n); break;
+   case ORC_EIGEN_CIJK: orc_pmat_cijk(P, t, n, es->nR, es->Cijk, es->Root); break;
+   default:
+      t *= (pb->qfactor ? pb->qfactor[(size_t)iclass * pb->n_labels + lab] : 1.0);
+      orc_pmat_uvroot(P, t, n, es->U, es->V, es->Root);
+   }
+}
+
+typedef struct {
+   const orc_problem *pb;
+   double *conP;      /* this class's slab: [n_nodes-n_tips][n_patt][n] */
+   double *scalef;    /* this class's slab: [n_scale][n_patt] */
+   double *PMat;
+   double *tiproot;   /* [n_patt][n] partial of a root that is itself an observed sequence ("young ancestor") */
+   int nthreads;
+} ctx_t;
+
+static double *node_conP(const ctx_t *c, int inode)
+{
+   if (inode < c->pb->n_tips) return c->tiproot;
+   return c->conP + (size_t)(inode - c->pb->n_tips) * c->pb->n_patt * c->pb->n;
+}
+
+/* treesub.c:7200-7230 */
+static void node_scale(const ctx_t *c, int inode, int pos0, int pos1)
+{
+   const orc_problem *pb = c->pb;
+   int n = pb->n, j, k = 0, h;
+   double *L = node_conP(c, inode);
+   for (j = 0; j < pb->n_nodes; j++) {
+      if (j == inode) break;
+      if (pb->scale_node[j]) k++;
+   }
+   for (h = pos0; h < pos1; h++) {
+      double t = 0;
+      for (j = 0; j < n; j++)
+         if (L[(size_t)h * n + j] > t) t = L[(size_t)h * n + j];
+      if (t < 1e-300) {
+         for (j = 0; j < n; j++) L[(size_t)h * n + j] = 1;
+         c->scalef[(size_t)k * pb->n_patt + h] = -800;
+      }
+      else {
+         for (j = 0; j < n; j++) L[(size_t)h * n + j] /= t;
+         c->scalef[(size_t)k * pb->n_patt + h] = log(t);
+      }
+   }
+}
+
+/* codeml.c:3526-3582 / baseml.c:1517-1570 */
+static void conditional_p_node(ctx_t *c, int inode, int igene, int iclass)
+{
+   const orc_problem *pb = c->pb;
+   int n = pb->n, np = pb->n_patt, i, pos0 = pb->gene_off[igene], pos1 = pb->gene_off[igene + 1];
+   int s0 = pb->sons_ptr[inode], s1 = pb->sons_ptr[inode + 1];
+   double *L, *P = c->PMat;
+   long h;
+
+   for (i = s0; i < s1; i++) {
+      int son = pb->sons[i];
+      if (pb->sons_ptr[son + 1] > pb->sons_ptr[son]) conditional_p_node(c, son, igene, iclass);
+   }
+   L = node_conP(c, inode);
+   if (inode < pb->n_tips) {   /* young ancestor: codeml.c:3535-3543 (indicator only when cleandata) */
+      const unsigned char *z = pb->z + (size_t)inode * np;
+      for (h = (long)pos0 * n; h < (long)pos1 * n; h++) L[h] = 0;
+      if (pb->cleandata)
+         for (h = pos0; h < pos1; h++) L[h * n + z[h]] = 1;
+   }
+   else
+      for (h = (long)pos0 * n; h < (long)pos1 * n; h++) L[h] = 1;
+
+   for (i = s0; i < s1; i++) {
+      int son = pb->sons[i];
+      int son_is_tip = (pb->sons_ptr[son + 1] == pb->sons_ptr[son]);
+      orc_pmat_branch(pb, igene, iclass, son, P);
+      if (son_is_tip && pb->cleandata) {
+         const unsigned char *z = pb->z + (size_t)son * np;
+#pragma omp parallel for if (c->nthreads > 1) num_threads(c->nthreads) schedule(static)
+         for (h = pos0; h < pos1; h++) {
+            int j;
+            for (j = 0; j < n; j++) L[h * n + j] *= P[j * n + z[h]];
+         }
+      }
+      else if (son_is_tip) {
+         const unsigned char *z = pb->z + (size_t)son * np;
+#pragma omp parallel for if (c->nthreads > 1) num_threads(c->nthreads) schedule(static)
+         for (h = pos0; h < pos1; h++) {
+            int j, k, code = z[h], nc = pb->n_chara[code];
+            const unsigned char *map = pb->chara_map + (size_t)code * n;
+            for (j = 0; j < n; j++) {
+               double t = 0;
+               for (k = 0; k < nc; k++) t += P[j * n + map[k]];
+               L[h * n + j] *= t;
+            }
+         }
+      }
+      else {
+         const double *Ls = node_conP(c, son);
+#pragma omp parallel for if (c->nthreads > 1) num_threads(c->nthreads) schedule(static)
+         for (h = pos0; h < pos1; h++) {
+            int j, k;
+            for (j = 0; j < n; j++) {
+               double t = 0;
+               for (k = 0; k < n; k++) t += P[j * n + k] * Ls[h * n + k];
+               L[h * n + j] *= t;
+            }
+         }
+      }
+   }
+   if (pb->scale_node && pb->scale_node[inode]) node_scale(c, inode, pos0, pos1);
+}
+
+double orc_eval(const orc_problem *pb, double *lnf, double *fhK_out, double *partials, double *scalef_out, int nthreads)
+{
+   int n = pb->n, np = pb->n_patt, K = pb->K, nint = pb->n_nodes - pb->n_tips;
+   int n_scale = 0, i, ir, ig, k;
+   size_t slab = (size_t)nint * np * n;
+   double *conP_own = NULL, *scalef_own = NULL, *fhK, lnL = 0;
+   ctx_t c;
+   long h;
+
+   g_npmat = 0;
+   if (pb->scale_node)
+      for (i = 0; i < pb->n_nodes; i++) n_scale += (pb->scale_node[i] != 0);
+
+   if (!partials) conP_own = (double *)malloc(slab * sizeof(double));
+   if (!scalef_out && n_scale) scalef_own = (double *)calloc((size_t)n_scale * np, sizeof(double));
+   fhK = fhK_out ? fhK_out : (double *)malloc((size_t)K * np * sizeof(double));
+   c.pb = pb;
+   c.PMat = (double *)malloc((size_t)n * n * sizeof(double));
+   c.nthreads = nthreads > 1 ? nthreads : 1;
+   c.tiproot = pb->root < pb->n_tips ? (double *)malloc((size_t)np * n * sizeof(double)) : NULL;
+
+   /* fx_r (treesub.c:7713-7759) — also covers lfun, which is the K=1 case with its own floor */
+   for (ig = 0; ig < pb->n_genes; ig++) {
+      const double *pi = pb->pi + (size_t)(pb->n_pi > 1 ? ig : 0) * n;
+      for (ir = 0; ir < K; ir++) {
+         c.conP = partials ? partials + (size_t)ir * slab : conP_own;
+         c.scalef = scalef_out ? scalef_out + (size_t)ir * n_scale * np : scalef_own;
+         conditional_p_node(&c, pb->root, ig, ir);
+         {
+            const double *Lr = node_conP(&c, pb->root);
+            for (h = pb->gene_off[ig]; h < pb->gene_off[ig + 1]; h++) {
+               double fh = 0;
+               if (pb->weights[h] <= 0) { fhK[(size_t)ir * np + h] = 0; continue; }
+               for (i = 0; i < n; i++) fh += pi[i] * Lr[h * n + i];
+               if (fh <= 0) fh = (pb->mode == ORC_MODE_LFUN ? 1e-80 : 1e-300);  /* treesub.c:7794 / 7741 */
+               if (pb->mode == ORC_MODE_LFUN || n_scale) {
+                  fh = log(fh);
+                  for (k = 0; k < n_scale; k++) fh += c.scalef[(size_t)k * np + h];
+               }
+               fhK[(size_t)ir * np + h] = fh;
+            }
+         }
+      }
+   }
+
+   /* lfun tail (treesub.c:7796-7803) or lfundG (treesub.c:7630-7657) */
+   for (h = 0; h < np; h++) {
+      double fh;
+      if (pb->weights[h] <= 0) { if (lnf) lnf[h] = 0; continue; }
+      if (pb->mode == ORC_MODE_LFUN)
+         fh = fhK[h];
+      else if (n_scale) {
+         int it = 0;
+         double t;
+         for (ir = 1; ir < K; ir++)
+            if (fhK[(size_t)ir * np + h] > fhK[(size_t)it * np + h]) it = ir;
+         t = fhK[(size_t)it * np + h];
+         for (ir = 0, fh = 0; ir < K; ir++) fh += pb->freqK[ir] * exp(fhK[(size_t)ir * np + h] - t);
+         fh = t + log(fh);
+      }
+      else {
+         for (ir = 0, fh = 0; ir < K; ir++) fh += pb->freqK[ir] * fhK[(size_t)ir * np + h];
+         if (fh <= 0) fh = 1e-300;
+         fh = log(fh);
+      }
+      lnL += fh * pb->weights[h];
+      if (lnf) lnf[h] = fh;
+   }
+
+   free(c.PMat);
+   free(c.tiproot);
+   free(conP_own);
+   free(scalef_own);
+   if (!fhK_out) free(fhK);
+   return lnL;
+}

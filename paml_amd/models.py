@@ -1,0 +1,129 @@
+"""Host-side model set-up in numpy: builds the small inputs of the likelihood hot path
+(pi, U/V/Root or Cijk, rate classes) the way the reference's model layer does.
+
+This is the Python mirror of the C host library (paml_amd/host/); it exists so that bench.py,
+the synthetic-data generator and the tests can build engine inputs without a C driver.  It is
+*not* on the device path — the engine only ever sees the arrays produced here.
+
+Reference behaviour restated (never copied): eigenQcodon codeml.c:3229-3321 (codon Q, mean-rate
+scaling), eigenQREV tools.c:5023-5110 (sqrt(pi) symmetrisation, descending roots),
+eigenQREVbase treesub.c:2488-2540 (GTR -> Cijk), DiscreteGamma tools.c:2601-2627,
+F3x4 frequencies codeml.c:3772-3873, state orders tools.c:15-84.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BASES = "TCAG"   # tools.c:15
+AAS = "ARNDCQEGHILKMFPSTWYV"  # tools.c:17
+# standard code (icode 0), codon index = 16*b1 + 4*b2 + b3 with T,C,A,G = 0..3 (tools.c:23-84)
+_STD_CODE = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+
+
+def sense_codons(code: str = _STD_CODE):
+    """FROM61-style table: indices (0..63) of sense codons in order (treesub.c:2344-2349)."""
+    return [i for i in range(64) if code[i] != "*"]
+
+
+def codon_tables(code: str = _STD_CODE):
+    from61 = sense_codons(code)
+    aa = [code[i] for i in from61]
+    return from61, aa
+
+
+def f3x4(fb3x4: np.ndarray, code: str = _STD_CODE) -> np.ndarray:
+    """Codon frequencies from 3x4 position-specific base frequencies, normalised over sense codons."""
+    from61, _ = codon_tables(code)
+    pi = np.array([fb3x4[0, c // 16] * fb3x4[1, (c // 4) % 4] * fb3x4[2, c % 4] for c in from61])
+    return pi / pi.sum()
+
+
+def codon_q(kappa: float, omega: float, pi: np.ndarray, code: str = _STD_CODE):
+    """Q (n x n, rows sum to 0) and mean rate mr = -sum pi_i Q_ii, as eigenQcodon builds them
+    (codeml.c:3274-3315; HKY-style kappa, one omega)."""
+    from61, aa = codon_tables(code)
+    n = len(from61)
+    Q = np.zeros((n, n))
+    for i in range(1, n):
+        c1 = from61[i]
+        f = (c1 // 16, (c1 // 4) % 4, c1 % 4)
+        for j in range(i):
+            c2 = from61[j]
+            t = (c2 // 16, (c2 // 4) % 4, c2 % 4)
+            diff = [k for k in range(3) if f[k] != t[k]]
+            if len(diff) != 1:
+                continue
+            p = diff[0]
+            q = kappa if (f[p] + t[p]) in (1, 5) else 1.0
+            if aa[i] != aa[j]:
+                q *= omega
+            Q[i, j] = Q[j, i] = q
+    Q = Q * pi[None, :]
+    Q[np.diag_indices(n)] = -Q.sum(axis=1)
+    mr = -float(np.dot(pi, np.diag(Q)))
+    return Q, mr
+
+
+def eigen_rev(Q: np.ndarray, pi: np.ndarray):
+    """U, V, Root with Q = U diag(Root) V for a reversible Q (tools.c:5023-5110): symmetrise with
+    sqrt(pi), symmetric eigen-solve, roots sorted descending (Root[0] ~ 0)."""
+    sp = np.sqrt(pi)
+    A = Q * sp[:, None] / sp[None, :]
+    A = 0.5 * (A + A.T)
+    w, R = np.linalg.eigh(A)
+    order = np.argsort(-w)
+    w, R = w[order], R[:, order]
+    U = R / sp[:, None]
+    V = R.T * sp[None, :]
+    return np.ascontiguousarray(U), np.ascontiguousarray(V), np.ascontiguousarray(w)
+
+
+def codon_m0_eigen(kappa: float, omega: float, pi: np.ndarray, scale: float | None = None):
+    """U, V, Root for M0 with Root divided by the mean rate (codeml.c:3316-3321), or by `scale`
+    (= 1/Qfactor_NS under NSsites, treesub.c:7675-7685)."""
+    Q, mr = codon_q(kappa, omega, pi)
+    U, V, root = eigen_rev(Q, pi)
+    return U, V, root / (mr if scale is None else scale), mr
+
+
+def gtr_q(rates5, pi: np.ndarray):
+    """GTR Q in baseml's REV parametrisation: (TC, TA, TG, CA, CG) relative to AG = 1, state order
+    T,C,A,G, scaled so the mean rate is 1 (treesub.c:2499-2518)."""
+    a, b, c, d, e = rates5
+    S = np.array([[0, a, b, c], [a, 0, d, e], [b, d, 0, 1.0], [c, e, 1.0, 0]])
+    Q = S * pi[None, :]
+    Q[np.diag_indices(4)] = -Q.sum(axis=1)
+    mr = -float(np.dot(pi, np.diag(Q)))
+    return Q / mr
+
+
+def cijk_from_uvroot(U, V, root):
+    """Cijk[i][j][k] = U[i,k] V[k,j] with nR = n (treesub.c:2526-2535)."""
+    n = U.shape[0]
+    C = np.einsum("ik,kj->ijk", U, V)
+    return np.ascontiguousarray(C), np.ascontiguousarray(root), n
+
+
+def hky_q(kappa: float, pi: np.ndarray):
+    S = np.ones((4, 4))
+    S[0, 1] = S[1, 0] = S[2, 3] = S[3, 2] = kappa
+    np.fill_diagonal(S, 0)
+    Q = S * pi[None, :]
+    Q[np.diag_indices(4)] = -Q.sum(axis=1)
+    mr = -float(np.dot(pi, np.diag(Q)))
+    return Q / mr
+
+
+def discrete_gamma(alpha: float, K: int):
+    """Mean-of-category discrete gamma with beta = alpha (tools.c:2601-2627, UseMedian = 0)."""
+    from scipy.special import gammainc, gammaincinv
+    cuts = gammaincinv(alpha, np.arange(1, K) / K) / alpha          # quantiles of G(alpha, beta=alpha)
+    cdf1 = gammainc(alpha + 1, cuts * alpha)                          # Eq. 10
+    edges = np.concatenate(([0.0], cdf1, [1.0]))
+    rK = np.diff(edges) * K
+    return np.full(K, 1.0 / K), rK
+
+
+def expm_rev(U, V, root, t):
+    """P(t) = U exp(root t) V (plain numpy; generator use only)."""
+    return (U * np.exp(root * t)[None, :]) @ V

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the UNMODIFIED reference programs
+(oracle/_ref/codeml, oracle/_ref/baseml — built by oracle/Makefile from /root/reference/src) in the
+deterministic single-evaluation mode (`in.codeml` / `in.baseml` starting with -1,
+or fix_blength=2 with every parameter fixed).
+
+Only runs in the build container (needs /root/reference for the example data files and oracle/_ref).
+What is committed is data: each JSON holds the model settings, the parameter vector, the tree with
+branch lengths as the reference printed it, the site patterns with their counts as written to the
+reference's `lnf` file, and the reference's lnL / per-pattern log f_h.
+
+usage: python tests/golden/make_golden.py [case ...]
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from paml_amd import models, synth  # noqa: E402
+
+REF = os.path.join(REPO, "oracle", "_ref")
+EX = "/root/reference/examples"
+DAT = "/root/reference/dat"
+
+CODEML_BASE = dict(noisy=3, verbose=0, runmode=0, seqtype=1, CodonFreq=2, clock=0, aaDist=0, model=0, NSsites=0,
+                   icode=0, Mgene=0, fix_kappa=0, kappa=2, fix_omega=0, omega=0.4, fix_alpha=1, alpha=0, Malpha=0,
+                   ncatG=10, getSE=0, RateAncestor=0, Small_Diff=".5e-6", cleandata=1, fix_blength=0, method=0)
+BASEML_BASE = dict(noisy=3, verbose=0, runmode=0, model=4, Mgene=0, clock=0, fix_kappa=0, kappa=5, fix_alpha=1,
+                   alpha=0, Malpha=0, ncatG=4, nparK=0, nhomo=0, getSE=0, RateAncestor=0, Small_Diff="7e-6",
+                   cleandata=1, method=0)
+
+
+def run_ref(prog, ctl, files, x=None, timeout=3600):
+    d = tempfile.mkdtemp(prefix="golden_")
+    try:
+        for dst, src in files.items():
+            if os.path.exists(str(src)):
+                shutil.copy(src, os.path.join(d, dst))
+            else:
+                with open(os.path.join(d, dst), "w") as f:
+                    f.write(src)
+        with open(os.path.join(d, prog + ".ctl"), "w") as f:
+            for k, v in ctl.items():
+                f.write("%s = %s\n" % (k, v))
+        if x is not None:
+            with open(os.path.join(d, "in." + prog), "w") as f:
+                f.write("-1 " + " ".join("%.6f" % v for v in x) + "\n")
+        out = subprocess.run([os.path.join(REF, prog), prog + ".ctl"], cwd=d, stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, timeout=timeout, input=b"\n" * 50).stdout.decode(errors="replace")
+        m = re.findall(r"lnL\s*=\s*(-?[0-9.]+)", out)
+        if not m:
+            raise RuntimeError("no lnL in reference output:\n" + out[-3000:])
+        lnL = float(m[-1])
+        cnt = re.search(r"(\d+) lfun, (\d+) eigenQcodon, (\d+) P\(t\)", out)
+        qf = re.search(r"Qfactor_NS = ([0-9.]+)", out)
+        with open(os.path.join(d, "lnf")) as f:
+            lnf_lines = f.read().splitlines()
+        main = "mlc" if prog == "codeml" else "mlb"
+        with open(os.path.join(d, main)) as f:
+            mtxt = f.read()
+        return dict(lnL=lnL, stdout=out, lnf=lnf_lines, main=mtxt,
+                    counters=[int(g) for g in cnt.groups()] if cnt else None,
+                    qfactor_ns=float(qf.group(1)) if qf else None)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def parse_lnf(lines, seqtype, n_tips):
+    hdr = None
+    pats = []
+    for ln in lines:
+        t = ln.split()
+        if not t:
+            continue
+        if hdr is None:
+            if len(t) == 3:
+                hdr = [int(v) for v in t]
+            continue
+        if len(t) < 6:
+            continue
+        idx, cnt, logf = int(t[0]), float(t[1]), float(t[2])
+        rest = ln.split(None, 5)[5]
+        if seqtype == "codon":
+            toks = re.findall(r"([A-Z\-\?]{3}) \(.\)", rest)
+        else:
+            toks = list(rest.split()[0])
+        assert len(toks) == n_tips, (ln, toks)
+        pats.append((cnt, logf, toks))
+    assert hdr and len(pats) == hdr[2], (hdr, len(pats))
+    return hdr, pats
+
+
+def tree_from_main(mtxt):
+    """First Newick string after 'tree length =' that carries branch lengths (codeml prints the
+    numbered tree with lengths first; baseml prints the bare topology first, then names + lengths)."""
+    tail = mtxt[mtxt.index("tree length ="):]
+    for m in re.finditer(r"^\(.*;\s*$", tail, re.M):
+        if ":" in m.group(0):
+            return m.group(0).strip()
+    raise RuntimeError("no tree with branch lengths in main output")
+
+
+def encode(pats, seqtype):
+    if seqtype == "codon":
+        from61 = models.sense_codons()
+        lut = {"".join(models.BASES[(c >> s) & 3] for s in (4, 2, 0)): i for i, c in enumerate(from61)}
+    elif seqtype == "nuc":
+        lut = {b: i for i, b in enumerate(models.BASES)}
+    else:
+        lut = {a: i for i, a in enumerate(models.AAS)}
+    z = np.array([[lut.get(tok, 255) for tok in p[2]] for p in pats], dtype=int).T
+    return z
+
+
+def finish(name, res, seqtype, n_tips, extra, keep_raw_patterns=False, sample=None):
+    hdr, pats = parse_lnf(res["lnf"], seqtype, n_tips)
+    z = encode(pats, seqtype)
+    g = dict(name=name, seqtype=seqtype, n_tips=n_tips, ls=hdr[1], n_patt=hdr[2], lnL=res["lnL"],
+             counters=res["counters"], qfactor_ns=res["qfactor_ns"], tree=tree_from_main(res["main"]))
+    g.update(extra)
+    counts = [p[0] for p in pats]
+    logf = [p[1] for p in pats]
+    if sample is None:
+        g["counts"] = counts
+        g["logf"] = logf
+        if (z == 255).any() or keep_raw_patterns:
+            g["patterns_raw"] = ["".join(p[2]) if seqtype != "codon" else " ".join(p[2]) for p in pats]
+        g["z"] = z.tolist()
+    else:   # large synthetic: data are regenerated from the seeded generator; keep a strided sample + checksum
+        idx = list(range(0, hdr[2], sample))
+        g["sample_stride"] = sample
+        g["logf_sample"] = [logf[i] for i in idx]
+        g["logf_sum"] = float(np.sum(logf))
+        g["z_crc"] = int(np.bitwise_xor.reduce((z.astype(np.uint64) + 1).ravel() * np.arange(1, z.size + 1, dtype=np.uint64) % np.uint64(1000003)))
+    path = os.path.join(HERE, name + ".json")
+    with open(path, "w") as f:
+        json.dump(g, f, separators=(",", ":"))
+    print("%-22s lnL %.6f  npatt %d  -> %s (%d bytes)" % (name, g["lnL"], g["n_patt"], os.path.basename(path), os.path.getsize(path)))
+    return g
+
+
+# ---------------------------------------------------------------- cases
+HIV_X = {
+    "m0": (0, "0.023746 0.079178 0.152813 0.023647 0.050407 0.083460 0.028429 0.099890 0.048101 0.131681 0.033695 0.191150 0.064013 0.193336 0.050591 0.034773 0.036688 0.055603 0.018984 0.070370 0.030301 0.061120 0.198346 2.471747 0.901293"),
+    "m1a": (1, "0.024595 0.086392 0.169984 0.024829 0.052083 0.092797 0.029325 0.107730 0.052269 0.144164 0.025220 0.218323 0.067142 0.220681 0.061023 0.022418 0.040795 0.058372 0.019831 0.073759 0.032272 0.063152 0.232592 2.594607 0.484176 0.078848"),
+    "m2a": (2, "0.025590 0.088873 0.175160 0.026711 0.046977 0.105490 0.026404 0.112617 0.055482 0.148326 0.025435 0.246061 0.071540 0.250031 0.071600 0.000645 0.038818 0.058692 0.020604 0.073256 0.033954 0.067258 0.273578 2.785547 0.377120 0.441686 0.059978 3.625638"),
+    "m7": (7, "0.024444 0.085984 0.169100 0.024862 0.052297 0.091846 0.029496 0.107231 0.051525 0.143550 0.027371 0.215468 0.066975 0.219325 0.058436 0.025357 0.040518 0.058555 0.019942 0.074112 0.032282 0.063201 0.229527 2.560660 0.147502 0.118171"),
+    "m8": (8, "0.025623 0.088848 0.175537 0.026537 0.046922 0.104911 0.026895 0.112264 0.055032 0.148482 0.025965 0.245015 0.070339 0.249760 0.071055 0.001661 0.039215 0.058750 0.020579 0.073327 0.033893 0.066500 0.272705 2.786897 0.799504 0.167185 0.148826 3.470359"),
+}
+
+
+def case_hiv(which):
+    ns, xs = HIV_X[which]
+    x = [float(v) for v in xs.split()]
+    ctl = dict(CODEML_BASE, seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", outfile="mlc", NSsites=ns,
+               kappa=.3, omega=1.3, ncatG=10)
+    res = run_ref("codeml", ctl, {"HIVenvSweden.txt": EX + "/HIVNSsites/HIVenvSweden.txt",
+                                  "HIVenvSweden.trees": EX + "/HIVNSsites/HIVenvSweden.trees"}, x=x)
+    classes = None
+    m = re.search(r"\np:\s+([0-9. ]+)\nw:\s+([0-9. ]+)", res["main"])
+    if m:
+        classes = dict(p=[float(v) for v in m.group(1).split()], w=[float(v) for v in m.group(2).split()])
+    finish("hiv_" + which, res, "codon", 13,
+           dict(program="codeml", model=dict(kind="codon_nssites", NSsites=ns, codonfreq="F3x4", ncatG=10), x=x,
+                ntime=23, classes_printed=classes))
+
+
+def case_syn_codon(n_patt=2000, name="syn_codon_m0", sample=None):
+    pb = synth.codon_m0_problem(n_tips=16, n_patt=n_patt, estimate_pi=True)
+    d = tempfile.mkdtemp()
+    synth.write_pattern_file(os.path.join(d, "seq.txt"), pb.z, pb.weights, "codon")
+    tree = " 16 1\n" + pb.tree.newick() + "\n"
+    ctl = dict(CODEML_BASE, seqfile="seq.txt", treefile="tree.txt", outfile="mlc", fix_kappa=1, kappa=2, fix_omega=1,
+               omega=0.4, fix_blength=2)
+    res = run_ref("codeml", ctl, {"seq.txt": os.path.join(d, "seq.txt"), "tree.txt": tree})
+    shutil.rmtree(d)
+    finish(name, res, "codon", 16,
+           dict(program="codeml", model=dict(kind="codon_m0", kappa=2.0, omega=0.4, codonfreq="F3x4"),
+                generator=dict(fn="codon_m0_problem", n_tips=16, n_patt=n_patt, seed=20260926, estimate_pi=True)),
+           sample=sample)
+
+
+def case_syn_nuc(n_patt=5000, name="syn_nuc_gtr_g4", sample=None):
+    pb = synth.nuc_gtr_gamma_problem(n_tips=32, n_patt=n_patt)
+    d = tempfile.mkdtemp()
+    synth.write_pattern_file(os.path.join(d, "seq.txt"), pb.z, pb.weights, "nuc")
+    tree = " 32 1\n" + pb.tree.newick() + "\n"
+    ctl = dict(BASEML_BASE, seqfile="seq.txt", treefile="tree.txt", outfile="mlb", model=7, fix_alpha=0, alpha=0.5,
+               ncatG=4, fix_blength=2)
+    x = list(synth.GTR_RATES) + [0.5]
+    res = run_ref("baseml", ctl, {"seq.txt": os.path.join(d, "seq.txt"), "tree.txt": tree}, x=x)
+    shutil.rmtree(d)
+    finish(name, res, "nuc", 32,
+           dict(program="baseml", model=dict(kind="nuc_rev_gamma", rates=list(synth.GTR_RATES), alpha=0.5, ncatG=4), x=x,
+                generator=dict(fn="nuc_gtr_gamma_problem", n_tips=32, n_patt=n_patt, seed=20260927)),
+           sample=sample)
+
+
+def case_brown():
+    x = [float(v) for v in "0.053057 0.017471 0.041370 0.053761 0.057580 0.100159 0.138990 9.389630".split()]
+    ctl = dict(BASEML_BASE, seqfile="brown.nuc", treefile="brown.trees", outfile="mlb", model=4, ncatG=1)
+    res = run_ref("baseml", ctl, {"brown.nuc": EX + "/brown.nuc", "brown.trees": EX + "/brown.trees"}, x=x)
+    finish("brown_hky85", res, "nuc", 5, dict(program="baseml", model=dict(kind="nuc_hky85", kappa=x[-1]), x=x, ntime=7,
+                                               names=["Human", "Chimpanzee", "Gorilla", "Orangutan", "Gibbon"]))
+
+
+CASES = {
+    "hiv_m0": lambda: case_hiv("m0"), "hiv_m1a": lambda: case_hiv("m1a"), "hiv_m2a": lambda: case_hiv("m2a"),
+    "hiv_m7": lambda: case_hiv("m7"), "hiv_m8": lambda: case_hiv("m8"),
+    "syn_codon_m0": case_syn_codon, "syn_nuc_gtr_g4": case_syn_nuc, "brown_hky85": case_brown,
+}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(CASES)
+    for c in which:
+        CASES[c]()

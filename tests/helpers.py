@@ -1,0 +1,184 @@
+"""Test glue: rebuild engine/oracle inputs (paml_amd.problem.Problem) from the golden JSON fixtures
+written by tests/golden/make_golden.py, using the numpy host-side model set-up (paml_amd.models)."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+if os.path.join(REPO, "oracle") not in sys.path:
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+
+from paml_amd import models, synth  # noqa: E402
+from paml_amd.problem import (EIGEN_CIJK, EIGEN_UVROOT, MODE_LFUN, MODE_LFUNDG, Problem, parse_newick,  # noqa: E402
+                              set_node_scale)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
+        return json.load(f)
+
+
+def nssites_classes(ns, par, ncatG):
+    """freqK, omega per class for NSsites = 0,1,2,7,8 at untransformed parameters
+    (SetParametersNSsites codeml.c:2483-2578 with LASTROUND=1; DiscreteNSsites codeml.c:2846)."""
+    from scipy.special import betaincinv
+    if ns == 0:
+        return np.ones(1), np.array([par[0]])
+    if ns == 1:
+        p0, w0 = par
+        return np.array([p0, 1 - p0]), np.array([w0, 1.0])
+    if ns == 2:
+        p0, p1, w0, w2 = par
+        return np.array([p0, p1, 1 - p0 - p1]), np.array([w0, 1.0, w2])
+    if ns == 7:
+        p, q = par
+        K = ncatG
+        w = betaincinv(p, q, (2 * np.arange(K) + 1) / (2.0 * K))
+        return np.full(K, 1.0 / K), w
+    if ns == 8:
+        p0, p, q, ws = par
+        K = ncatG
+        w = betaincinv(p, q, (2 * np.arange(K) + 1) / (2.0 * K))
+        return np.concatenate((np.full(K, p0 / K), [1 - p0])), np.concatenate((w, [ws]))
+    raise ValueError(ns)
+
+
+def problem_from_golden(g) -> Problem:
+    if "z" in g:
+        z = np.array(g["z"], dtype=np.uint8)
+        w = np.array(g["counts"], dtype=float)
+    else:
+        gen = dict(g["generator"])
+        fn = getattr(synth, gen.pop("fn"))
+        base = fn(**gen)
+        z, w = base.z, base.weights
+    tree = parse_newick(g["tree"], names=g.get("names"))
+    m = g["model"]
+    kind = m["kind"]
+    if kind == "codon_m0":
+        pi = models.f3x4(synth.f3x4_from_codon_tips(z, w))
+        U, V, root, _ = models.codon_m0_eigen(m["kappa"], m["omega"], pi)
+        return Problem(n=61, tree=tree, z=z, weights=w, pi=pi, eigen=[dict(kind=EIGEN_UVROOT, U=U, V=V, Root=root)],
+                       mode=MODE_LFUN)
+    if kind == "codon_nssites":
+        x = g["x"]
+        nt = g["ntime"]
+        kappa = x[nt]
+        pi = models.f3x4(synth.f3x4_from_codon_tips(z, w))
+        freqs, omegas = nssites_classes(m["NSsites"], x[nt + 1:], m["ncatG"])
+        if m["NSsites"] == 0:
+            U, V, root, _ = models.codon_m0_eigen(kappa, omegas[0], pi)
+            return Problem(n=61, tree=tree, z=z, weights=w, pi=pi,
+                           eigen=[dict(kind=EIGEN_UVROOT, U=U, V=V, Root=root)], mode=MODE_LFUN)
+        base = Problem(n=61, tree=tree, z=z, weights=w, pi=pi, eigen=[], mode=MODE_LFUNDG)
+        return synth.codon_nssites_problem(base, kappa, omegas, freqs)
+    if kind == "nuc_rev_gamma":
+        cnt = np.array([((z == b) * w[None, :]).sum() for b in range(4)])
+        pi = cnt / cnt.sum()
+        Q = models.gtr_q(m["rates"], pi)
+        U, V, root = models.eigen_rev(Q, pi)
+        Cijk, rootc, nR = models.cijk_from_uvroot(U, V, root)
+        freqK, rK = models.discrete_gamma(m["alpha"], m["ncatG"])
+        return Problem(n=4, tree=tree, z=z, weights=w, pi=pi, eigen=[dict(kind=EIGEN_CIJK, Cijk=Cijk, Root=rootc, nR=nR)],
+                       mode=MODE_LFUNDG, freqK=freqK, rate=rK)
+    if kind == "nuc_hky85":
+        cnt = np.array([((z == b) * w[None, :]).sum() for b in range(4)])
+        pi = cnt / cnt.sum()
+        Q = models.hky_q(m["kappa"], pi)
+        U, V, root = models.eigen_rev(Q, pi)
+        Cijk, rootc, nR = models.cijk_from_uvroot(U, V, root)
+        return Problem(n=4, tree=tree, z=z, weights=w, pi=pi, eigen=[dict(kind=EIGEN_CIJK, Cijk=Cijk, Root=rootc, nR=nR)],
+                       mode=MODE_LFUN)
+    raise ValueError(kind)
+
+
+def random_problem(n, n_tips, n_patt, K=1, seed=0, ambiguity=False, scale_every=None, n_genes=1, polytomy=False,
+                   mode=None):
+    """Random reversible model + random tree + random tips: a parity case with no biological meaning."""
+    rng = np.random.default_rng(seed)
+    pi = rng.dirichlet(np.full(n, 3.0))
+    S = rng.gamma(1.0, 1.0, size=(n, n))
+    S = np.triu(S, 1)
+    S = S + S.T
+    Q = S * pi[None, :]
+    Q[np.diag_indices(n)] = -Q.sum(axis=1)
+    Q /= -np.dot(pi, np.diag(Q))
+    U, V, root = models.eigen_rev(Q, pi)
+    # random binary tree with trifurcating (or polytomous) root, reference numbering
+    sons = [[] for _ in range(2 * n_tips)]
+    free = list(range(n_tips))
+    rng.shuffle(free)
+    nxt = n_tips + 1
+    nroot = 3 if not polytomy else 4
+    while len(free) > nroot:
+        i = int(rng.integers(len(free)))
+        a = free.pop(i)
+        j = int(rng.integers(len(free)))
+        b = free.pop(j)
+        node = nxt
+        nxt += 1
+        sons[node] = [a, b]
+        free.append(node)
+    root_id = n_tips
+    sons[root_id] = free
+    n_nodes = nxt
+    # renumber internal nodes in '(' order like ReadTreeN
+    order = []
+
+    def pre(i):
+        if i >= n_tips:
+            order.append(i)
+        for c in sons[i]:
+            pre(c)
+    pre(root_id)
+    remap = {old: n_tips + k for k, old in enumerate(order)}
+    new_sons = [[] for _ in range(n_nodes)]
+    for old, new in remap.items():
+        new_sons[new] = [remap.get(c, c) for c in sons[old]]
+    from paml_amd.problem import Tree
+    branch = rng.uniform(0.01, 0.4, size=n_nodes)
+    branch[n_tips] = 0
+    tree = Tree(n_tips, n_nodes, n_tips, new_sons, branch, np.zeros(n_nodes, dtype=np.int32))
+    z = rng.integers(0, n, size=(n_tips, n_patt)).astype(np.uint8)
+    # make neighbouring tips agree often so likelihoods are not absurdly small
+    base = rng.integers(0, n, size=n_patt)
+    keep = rng.random((n_tips, n_patt)) < 0.6
+    z = np.where(keep, base[None, :], z).astype(np.uint8)
+    w = rng.integers(1, 5, size=n_patt).astype(float)
+    kw = {}
+    if ambiguity:
+        n_codes = n + 3
+        n_chara = np.ones(n_codes, dtype=np.int32)
+        cmap = np.zeros((n_codes, n), dtype=np.uint8)
+        cmap[:n, 0] = np.arange(n)
+        n_chara[n] = n
+        cmap[n] = np.arange(n)                    # fully missing
+        n_chara[n + 1] = 2
+        cmap[n + 1, :2] = [1, 3 % n]
+        n_chara[n + 2] = 3
+        cmap[n + 2, :3] = [0, 2 % n, (n - 1)]
+        amb = rng.random((n_tips, n_patt)) < 0.08
+        z = np.where(amb, rng.integers(n, n_codes, size=(n_tips, n_patt)), z).astype(np.uint8)
+        kw.update(cleandata=0, n_chara=n_chara, chara_map=cmap)
+    if K > 1:
+        freqK = rng.dirichlet(np.full(K, 5.0))
+        rate = rng.gamma(2.0, 0.5, size=K)
+        kw.update(freqK=freqK, rate=rate)
+    if n_genes > 1:
+        cuts = np.sort(rng.choice(np.arange(1, n_patt), size=n_genes - 1, replace=False))
+        kw.update(gene_off=np.concatenate(([0], cuts, [n_patt])).astype(np.int32),
+                  gene_rate=rng.uniform(0.5, 1.5, size=n_genes))
+    if scale_every:
+        kw.update(scale_node=set_node_scale(tree, scale_every))
+    if mode is None:
+        mode = MODE_LFUNDG if K > 1 else MODE_LFUN
+    return Problem(n=n, tree=tree, z=z, weights=w, pi=pi, eigen=[dict(kind=EIGEN_UVROOT, U=U, V=V, Root=root)],
+                   mode=mode, **kw)
