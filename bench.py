@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py — site-patterns/sec per lnL evaluation, codeml M0 (61 states), on N MI355X.
+
+A "step" is one com.plfun-equivalent evaluation over the rank's resident pattern shard: batched P(t)
+for all 29 branches, fused FP64-MFMA pruning over every pattern, root/log/weighted-sum reduction,
+(N>1: RCCL all-reduce of the scalar lnL over xGMI), and the scalar read back to the host — i.e. what
+the optimiser in the reference waits for on every function call (codeml.c:748).  Inputs (tip codes,
+weights, tree program) are resident in HBM before the timed region; only branch lengths (232 B) and
+the lnL cross PCIe per step.
+
+Workload (BASELINE.json configs[3]): 16 taxa x 10^6 synthetic codon patterns PER GPU (weak scaling:
+patterns are independent, each rank owns a contiguous shard), M0 kappa=2 omega=0.4, F3x4 pi, fixed
+parameters, seeded generator paml_amd.synth.  launched as
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# FP64 MFMA dense peak of MI355X: 256 CU x 4 SIMD x 32 FLOP/clk (v_mfma_f64_16x16x4_f64 = 2048 FLOP
+# per 64 clk) x 2.4 GHz = 78.6 TFLOP/s (AMD datasheet "FP64 matrix 78.6 TF"); MI355X_MICROARCH.md lists
+# no FP64 row, tools/mfma_f64_peak.hip measures the ceiling on the box.
+FP64_MFMA_PEAK_TFLOPS = 78.6
+
+
+def algorithmic_flops_per_pattern(n, n_tips):
+    """Bi*2n^2 + B*n + 2n with Bi = ns-3 internal-son branches, B = 2ns-3 branches."""
+    return (n_tips - 3) * 2 * n * n + (2 * n_tips - 3) * n + 2 * n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--patterns", type=int, default=1_000_000, help="site patterns per GPU")
+    ap.add_argument("--taxa", type=int, default=16)
+    ap.add_argument("--classes", type=int, default=1, help=">1: NSsites-style omega classes (M0 when 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=100_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (world, args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from paml_amd import engine, synth
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build()
+
+    # this rank's shard: its own seeded block of the synthetic alignment
+    pb = synth.codon_m0_problem(n_tips=args.taxa, n_patt=args.patterns, seed=20260926 + rank)
+    if args.classes > 1:
+        K = args.classes
+        omegas = np.linspace(0.05, 1.5, K)
+        pb = synth.codon_nssites_problem(pb, 2.0, omegas, np.full(K, 1.0 / K))
+    eng = engine.engine_for(pb)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+    d_lnl = torch.zeros(1, dtype=torch.float64, device="cuda")
+    branch = pb.tree.branch.copy()
+
+    def step():
+        if world == 1:
+            return eng.eval(branch)["lnL"]
+        eng.eval_device(branch, d_lnl.data_ptr())
+        dist.all_reduce(d_lnl)
+        return float(d_lnl.item())
+
+    for _ in range(args.warmup):
+        lnl = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lnl = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        total_patterns = args.patterns * world
+        value = total_patterns * args.steps / dt
+        flops_pp = algorithmic_flops_per_pattern(pb.n, args.taxa) * pb.K
+        ms_kernel = prof["ms_prune"] / max(1, prof["n_evals"])
+        achieved = flops_pp * args.patterns / (ms_kernel * 1e-3) / 1e12
+        out = {
+            "metric": "site-patterns/sec per lnL eval (codeml M0, 61 states)",
+            "value": value, "unit": "site-patterns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "codeml M0 61-state, %d taxa x %d synthetic codon patterns per GPU (BASELINE configs[3])"
+                                   % (args.taxa, args.patterns),
+                       "classes": pb.K, "kernel": eng.kernel_name, "parallelism": "pattern-shard x%d" % world},
+            "lnL": lnl,
+            "roofline": {"bound": "mfma", "kernel": "prune_mfma64", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "flop_per_pattern": flops_pp, "kernel_ms": ms_kernel,
+                         "pmat_ms": prof["ms_pmat"] / max(1, prof["n_evals"]),
+                         "reduce_ms": prof["ms_reduce"] / max(1, prof["n_evals"])},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pb, args.cpu_sample)
+            out["speedup_vs_cpu_1core"] = value / world / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pb, sample):
+    """The oracle's single-thread restatement of the reference loop nest (kind "port"), timed on this
+    box's host cores over the first `sample` patterns of the same workload."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle
+    sample = min(sample, pb.n_patt)
+    sub = pb.slice_patterns(0, sample)
+    oracle.evaluate(sub.slice_patterns(0, min(2000, sample)), want_lnf=False)   # warm-up / page-in
+    reps = 0
+    t0 = time.perf_counter()
+    while True:
+        oracle.evaluate(sub, want_lnf=False)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 8:
+            break
+    return {"value": sample * reps / el, "unit": "site-patterns/s", "cores": 1, "kind": "port",
+            "sample": "%d evals over the first %d patterns of the workload, oracle/cpu_ref.c, gcc -O3, 1 thread (%d host cores present)"
+                      % (reps, sample, os.cpu_count() or 0)}
+
+
+if __name__ == "__main__":
+    main()

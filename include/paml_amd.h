@@ -1,0 +1,142 @@
+/* paml_amd.h — C ABI of the MI355X-native likelihood engine (libpaml_amd.so).
+ *
+ * This is the drop-in boundary for PAML's likelihood hot path.  The reference has no plugin/FFI
+ * layer; its de-facto seams are plain C symbols + globals:
+ *     double (*com.plfun)(double x[], int np)           codeml.c:125  / baseml.c:70
+ *     int ConditionalPNode(int inode, int igene, double x[])   codeml.c:3526 / baseml.c:1517
+ *     int GetPMatBranch(double Pt[], double x[], double t, int inode)   treesub.c:7503 / 7534
+ *     int PMatUVRoot(double P[], double t, int n, double U[], double V[], double Root[])  tools.c:516
+ * Each entry point below names the reference interface (file:line under /root/reference/src) whose
+ * role it takes over.  All pointers are host pointers unless the name starts with d_.  Every call
+ * returns 0 on success or a negative PAML_AMD_E* code (the engine never exits the process, unlike
+ * zerror() tools.c:1204); paml_amd_last_error() gives the message.
+ *
+ * Threading: one engine = one GPU + one HIP stream; calls on one engine must be serialised by the
+ * caller, different engines are independent.  Multi-GPU = one engine per rank over a contiguous
+ * pattern shard, the caller sums lnL (RCCL all-reduce).
+ */
+#ifndef PAML_AMD_H
+#define PAML_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct paml_amd_engine paml_amd_engine;
+
+enum {
+   PAML_AMD_OK = 0,
+   PAML_AMD_EINVAL = -1,    /* bad argument / call order */
+   PAML_AMD_ENOMEM = -2,    /* device or host allocation failed */
+   PAML_AMD_EHIP = -3,      /* HIP runtime error (no device, launch failure ...) */
+   PAML_AMD_EUNSUPPORTED = -4
+};
+
+/* create flags */
+enum {
+   PAML_AMD_KEEP_PARTIALS = 1   /* keep every internal node's partials resident: needed by
+                                   paml_amd_get_partials / dirty-node re-evaluation
+                                   (com.conPSiteClass = 1 memory model, codeml.c:2343-2346) */
+};
+
+/* eigen-system kinds = the branches of GetPMatBranch (treesub.c:7503-7592) */
+enum { PAML_AMD_EIGEN_UVROOT = 0, PAML_AMD_EIGEN_CIJK = 1, PAML_AMD_EIGEN_K80 = 2, PAML_AMD_EIGEN_JC69LIKE = 3 };
+
+/* likelihood reduction = which com.plfun the reference would have installed (codeml.c:2338-2340) */
+enum { PAML_AMD_MODE_LFUN = 0 /* treesub.c:7764 */, PAML_AMD_MODE_LFUNDG = 1 /* treesub.c:7608 + fx_r 7696 */ };
+
+/* Once per data set, after the sequence file is read (replaces the conP/fhK/nodeScaleF allocations
+ * of GetInitials codeml.c:2330-2354 and PointconPnodes treesub.c:3518).  n_states = com.ncode (<= 64),
+ * n_tips = com.ns, n_patt = com.npatt, max_classes >= com.ncatG, n_genes = com.ngene.
+ * The engine is created on the calling thread's current HIP device. */
+int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt, int max_classes, int n_genes,
+                    unsigned flags);
+void paml_amd_destroy(paml_amd_engine *e);
+const char *paml_amd_last_error(const paml_amd_engine *e);
+
+/* Launch all work on this hipStream_t (default: the null stream). */
+int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream);
+
+/* com.z (treesub.c:1116 EncodeSeqs), nChara/CharaMap (tools.c:20, treesub.c:1218), com.fpatt, com.posG.
+ * z is row-major [n_tips][n_patt] one byte per character code; with cleandata != 0 codes are states
+ * 0..n-1 and the map may be NULL; otherwise n_chara[code] states listed in chara_map[code*n_states + k].
+ * gene_off has n_genes+1 entries (NULL = one gene covering all patterns).  Uploaded once. */
+int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata, int n_codes, const int *n_chara,
+                      const unsigned char *chara_map, const double *weights, const int *gene_off);
+
+/* nodes[].sons / nson / label (codeml.c:143-147) as CSR, tree.root, com.nodeScale (treesub.c:7177; NULL = none).
+ * Tips are nodes 0..n_tips-1.  The root may be a tip ("young ancestor", codeml.c:3535) and nodes may
+ * have any number of sons.  Replaces the recursion of ConditionalPNode by a flattened post-order
+ * program; send again after ReRootTree (treespace.c:236). */
+int paml_amd_set_tree(paml_amd_engine *e, int n_nodes, int root, const int *sons_ptr, const int *sons,
+                      const int *label, const unsigned char *scale_node);
+
+/* com.pi (n_pi = 1) or com.piG per gene (n_pi = n_genes), row-major [n_pi][n_states]. */
+int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi);
+
+/* Eigen systems, mirroring U,V,Root / _UU,_VV,_Root[NBTYPE+2] (codeml.c:185, treesub.c:9250) and
+ * Cijk,Root,nR (baseml.c:123-124).  set_id is dense from 0.  Small H2D copies, typically per evaluation. */
+int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, const double *V, const double *Root);
+int paml_amd_set_eigen_cijk(paml_amd_engine *e, int set_id, int nR, const double *Cijk, const double *Root);
+int paml_amd_set_eigen_k80(paml_amd_engine *e, int set_id, double kappa);        /* PMatK80 tools.c:578 */
+int paml_amd_set_eigen_jc69like(paml_amd_engine *e, int set_id);                 /* PMatJC69like codeml.c:3585 */
+
+/* Site classes: com.ncatG, com.freqK, per-class _rateSite (treesub.c:7669/7678), and for each
+ * (gene, class, branch label) the eigen set (Set_UVR_BranchSite codeml.c:2663, SetPSiteClass
+ * treesub.c:7663) and for each (class, label) the Qfactor applied to t (treesub.c:7549, 7587).
+ * eigen_of is [n_genes][K][n_labels], qfactor is [K][n_labels] (NULL = all 1).  mode selects the
+ * lfun (K must be 1) or the fx_r + lfundG reduction, including their different f<=0 floors. */
+int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freqK, const double *rate, int n_labels,
+                         const int *eigen_of, const double *qfactor);
+
+/* One com.plfun call (codeml.c:748): batched P(t) for every branch x class x gene, fused pruning,
+ * root / class-mixture / weighted-log reduction.  branch[n_nodes] = nodes[].branch, gene_rate =
+ * com.rgene (NULL = 1).  Returns +lnL (the reference returns -lnL).  lnf[n_patt] (log f_h as
+ * print_lnf_site treesub.c:7598 prints it) and fhK[K*n_patt] (com.fhK, class-major) are optional. */
+int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, double *lnL, double *lnf,
+                  double *fhK);
+
+/* Same evaluation without the final device->host copy or synchronisation: the rank's partial lnL is
+ * left in d_lnL (a device pointer, e.g. a torch tensor) on the engine's stream so the caller can
+ * all-reduce it over RCCL. */
+int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL);
+
+/* Re-evaluate after a change that leaves the partials of the nodes with clean[node] != 0 valid
+ * (com.oldconP, codeml.c:112, treespace.c:250): those subtrees are read back instead of recomputed.
+ * Needs PAML_AMD_KEEP_PARTIALS and one earlier full evaluation with the same classes. */
+int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
+                        double *lnL);
+
+/* Parity / post-processing accessors.
+ * get_pmat: the matrix GetPMatBranch (treesub.c:7534) would have produced for the branch above
+ *   `node`, row-major P[from*n + to], from the last evaluation.
+ * get_partials: nodes[node].conP for class iclass, layout [n_patt][n_states] (PointconPnodes
+ *   treesub.c:3518); needs PAML_AMD_KEEP_PARTIALS.
+ * get_scale: com.nodeScaleF row of a scaling node, [n_patt] (treesub.c:7207-7227). */
+int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double *P);
+int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP);
+int paml_amd_get_scale(paml_amd_engine *e, int node, int iclass, double *scale);
+
+/* Per-kernel timing with HIP events on the engine's stream (bench.py roofline leg).
+ * profile(1) starts recording an event pair around every kernel launch; profile_read sums the
+ * elapsed milliseconds per kernel family since the last read and resets the accumulators. */
+int paml_amd_profile(paml_amd_engine *e, int enable);
+int paml_amd_profile_read(paml_amd_engine *e, double *ms_pmat, double *ms_prune, double *ms_reduce, long *n_evals);
+
+/* Counters mirroring NFunCall / NPMatUVRoot (tools.c:88, printed codeml.c:770). */
+int paml_amd_counters(const paml_amd_engine *e, long *n_eval, long *n_pmat);
+
+/* Host-only introspection (no GPU needed): the flattened post-order program the engine would run for
+ * a tree — 4 ints per op (code, a, b, c; paml_amd/csrc/program.h).  Returns the number of ops (or a
+ * negative error); at most cap ops are written.  Used by the CPU test-suite to check the traversal. */
+int paml_amd_debug_program(int n_tips, int n_nodes, int root, const int *sons_ptr, const int *sons,
+                           const unsigned char *scale_node, int keep_partials, const unsigned char *clean,
+                           int *ops_out, int cap, int *max_stack);
+
+/* Name of the pruning kernel the engine selected ("mfma64", "valu4", "valu20", ...). */
+const char *paml_amd_kernel_name(const paml_amd_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,751 @@
+// engine.hip — C-ABI implementation (include/paml_amd.h) over the HIP kernels in kernels.h.
+// Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC engine.hip
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/paml_amd.h"
+#include "kernels.h"
+#include "program.h"
+
+using namespace paml_amd;
+
+namespace {
+
+enum KernelKind { KK_VALU4, KK_VALU5, KK_VALU20, KK_MFMA64 };
+constexpr int MFMA_WAVES = 4;          // waves per workgroup of the mfma64 kernel (64 patterns)
+constexpr int VALU_MAXD_SMALL = 16, VALU_MAXD_20 = 8;
+
+template <typename T>
+struct DevBuf {
+   T *p = nullptr;
+   size_t cap = 0;
+   hipError_t ensure(size_t n)
+   {
+      if (n <= cap) return hipSuccess;
+      if (p) (void)hipFree(p);
+      p = nullptr;
+      cap = 0;
+      hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
+      if (e == hipSuccess) cap = n;
+      return e;
+   }
+   void release()
+   {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+      cap = 0;
+   }
+};
+
+// Pinned host arena for the small per-evaluation inputs, so the H2D copies are truly asynchronous and
+// the source stays valid until an event says the copies are done.
+struct Staging {
+   char *p = nullptr;
+   size_t cap = 0, used = 0;
+   hipEvent_t ev = nullptr;
+   bool pending = false;
+   hipError_t begin(size_t need)
+   {
+      if (pending) { hipError_t r = hipEventSynchronize(ev); if (r != hipSuccess) return r; pending = false; }
+      if (need > cap) {
+         if (p) (void)hipHostFree(p);
+         p = nullptr; cap = 0;
+         hipError_t r = hipHostMalloc((void **)&p, need * 2, hipHostMallocDefault);
+         if (r != hipSuccess) return r;
+         cap = need * 2;
+      }
+      if (!ev) { hipError_t r = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (r != hipSuccess) return r; }
+      used = 0;
+      return hipSuccess;
+   }
+   template <typename T>
+   T *put(const T *src, size_t n)
+   {
+      used = (used + 15) & ~(size_t)15;
+      T *dst = (T *)(p + used);
+      memcpy(dst, src, n * sizeof(T));
+      used += n * sizeof(T);
+      return dst;
+   }
+   hipError_t end(hipStream_t s) { pending = true; return hipEventRecord(ev, s); }
+   void release()
+   {
+      if (pending && ev) (void)hipEventSynchronize(ev);
+      if (p) (void)hipHostFree(p);
+      if (ev) (void)hipEventDestroy(ev);
+      p = nullptr; ev = nullptr; cap = 0; pending = false;
+   }
+};
+
+struct EigenHost {
+   int kind = -1, nR = 0;
+   double kappa = 0;
+   DevBuf<double> U, V, Root, Cijk;
+};
+
+}  // namespace
+
+struct paml_amd_engine {
+   int n = 0, n_tips = 0, n_patt = 0, max_classes = 0, n_genes = 1;
+   unsigned flags = 0;
+   KernelKind kk = KK_MFMA64;
+   int tile_patt = 64;
+   hipStream_t stream = nullptr;
+   std::string err;
+
+   // data
+   bool have_tips = false, have_tree = false, have_pi = false, have_classes = false;
+   int cleandata = 1, n_codes = 0;
+   DevBuf<unsigned char> d_z, d_chara_map, d_is_leaf;
+   DevBuf<int> d_n_chara, d_gene_off, d_label, d_eigen_of;
+   DevBuf<int2> d_tiles;
+   DevBuf<double> d_weights, d_pi, d_freqK, d_rate, d_qfactor, d_branch, d_gene_rate;
+   std::vector<int> gene_off;
+   int n_tiles = 0, n_pi = 1;
+
+   TreeDesc tree;
+   Program prog;
+   bool prog_valid = false;
+   DevBuf<Op> d_ops;
+   Staging stage;
+
+   std::vector<EigenHost> eigen;
+   DevBuf<EigenDev> d_eigen;
+   bool eigen_dirty = true;
+
+   int mode = PAML_AMD_MODE_LFUN, K = 1, n_labels = 1;
+
+   // per-evaluation buffers
+   DevBuf<double> d_rowmajor, d_pint, d_ptip, d_fhK, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
+   bool partials_valid = false;
+
+   // profiling
+   bool profiling = false;
+   std::vector<hipEvent_t> ev_pool;
+   std::vector<hipEvent_t> ev_used;   // sextuples per eval
+   long prof_evals = 0;
+   long n_eval = 0, n_pmat = 0;
+
+   ~paml_amd_engine()
+   {
+      for (auto &e : eigen) { e.U.release(); e.V.release(); e.Root.release(); e.Cijk.release(); }
+      stage.release();
+      for (auto ev : ev_pool) (void)hipEventDestroy(ev);
+      for (auto ev : ev_used) (void)hipEventDestroy(ev);
+      DevBuf<unsigned char> *b1[] = {&d_z, &d_chara_map, &d_is_leaf};
+      for (auto b : b1) b->release();
+      DevBuf<int> *b2[] = {&d_n_chara, &d_gene_off, &d_label, &d_eigen_of};
+      for (auto b : b2) b->release();
+      d_tiles.release();
+      d_ops.release();
+      d_eigen.release();
+      DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
+                              &d_pint, &d_ptip, &d_fhK, &d_lnf, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack};
+      for (auto b : b3) b->release();
+   }
+};
+
+namespace {
+
+int fail(paml_amd_engine *e, int code, const std::string &msg)
+{
+   if (e) e->err = msg;
+   return code;
+}
+
+#define HIPCHK(call)                                                                                         \
+   do {                                                                                                      \
+      hipError_t _r = (call);                                                                                \
+      if (_r != hipSuccess)                                                                                  \
+         return fail(e, _r == hipErrorOutOfMemory ? PAML_AMD_ENOMEM : PAML_AMD_EHIP,                         \
+                     std::string(#call) + ": " + hipGetErrorString(_r));                                     \
+   } while (0)
+
+template <typename T>
+hipError_t upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s)
+{
+   hipError_t r = b.ensure(n);
+   if (r != hipSuccess) return r;
+   if (n == 0) return hipSuccess;
+   // pageable source: the runtime stages the copy, so the host buffer may be reused on return
+   return hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+}
+
+int tipw(const paml_amd_engine *e) { return e->kk == KK_MFMA64 ? 64 : e->n; }
+int pint_words(const paml_amd_engine *e) { return e->kk == KK_MFMA64 ? 4096 : e->n * e->n; }
+
+hipEvent_t get_event(paml_amd_engine *e)
+{
+   hipEvent_t ev;
+   if (!e->ev_pool.empty()) {
+      ev = e->ev_pool.back();
+      e->ev_pool.pop_back();
+   }
+   else if (hipEventCreate(&ev) != hipSuccess)
+      return nullptr;
+   e->ev_used.push_back(ev);
+   return ev;
+}
+
+void mark(paml_amd_engine *e)
+{
+   if (!e->profiling) return;
+   hipEvent_t ev = get_event(e);
+   if (ev) (void)hipEventRecord(ev, e->stream);
+}
+
+int build_tiles(paml_amd_engine *e)
+{
+   std::vector<int2> tiles;
+   for (int g = 0; g < e->n_genes; g++)
+      for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += e->tile_patt) tiles.push_back(make_int2(g, h));
+   e->n_tiles = (int)tiles.size();
+   HIPCHK(upload(e->d_tiles, tiles.data(), tiles.size(), e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
+int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
+                double *d_lnL_out, bool want_lnf)
+{
+   if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes))
+      return fail(e, PAML_AMD_EINVAL, "eval before set_tips/set_tree/set_pi/set_classes");
+   if (e->eigen.empty()) return fail(e, PAML_AMD_EINVAL, "eval before any set_eigen_*");
+   const bool keep = (e->flags & PAML_AMD_KEEP_PARTIALS) != 0;
+   if (clean && (!keep || !e->partials_valid))
+      return fail(e, PAML_AMD_EINVAL, "eval_dirty needs PAML_AMD_KEEP_PARTIALS and a previous full evaluation");
+   const int n = e->n, nn = e->tree.n_nodes, K = e->K, G = e->n_genes;
+   const int psets = G * K;
+
+   // program (tree walk) — rebuilt when the tree or the clean set changes
+   const bool new_prog = !e->prog_valid || clean;
+   if (new_prog) {
+      e->prog = build_program(e->tree, keep, clean);
+      e->prog_valid = (clean == nullptr);
+      const int maxd = e->kk == KK_VALU20 ? VALU_MAXD_20 : VALU_MAXD_SMALL;
+      if (e->kk != KK_MFMA64 && e->prog.max_stack > maxd) {
+         e->prog_valid = false;
+         return fail(e, PAML_AMD_EUNSUPPORTED, "tree needs a deeper partial stack than this kernel provides");
+      }
+   }
+   std::vector<EigenDev> tab;
+   if (e->eigen_dirty) {
+      tab.resize(e->eigen.size());
+      for (size_t i = 0; i < e->eigen.size(); i++) {
+         const EigenHost &h = e->eigen[i];
+         if (h.kind < 0) return fail(e, PAML_AMD_EINVAL, "eigen set " + std::to_string(i) + " was never set");
+         tab[i] = EigenDev{h.kind, h.nR, h.kappa, h.U.p, h.V.p, h.Root.p, h.Cijk.p};
+      }
+   }
+
+   // small per-evaluation inputs go through the pinned arena: async H2D, no host stall
+   {
+      const size_t need = (size_t)nn * 8 + (size_t)G * 8 + tab.size() * sizeof(EigenDev) +
+                          (new_prog ? e->prog.ops.size() * sizeof(Op) : 0) + 256;
+      HIPCHK(e->stage.begin(need));
+      HIPCHK(e->d_branch.ensure(nn));
+      HIPCHK(e->d_gene_rate.ensure(G));
+      const double *hb = e->stage.put(branch, nn);
+      HIPCHK(hipMemcpyAsync(e->d_branch.p, hb, (size_t)nn * 8, hipMemcpyHostToDevice, e->stream));
+      std::vector<double> gr(G, 1.0);
+      if (gene_rate) gr.assign(gene_rate, gene_rate + G);
+      const double *hg = e->stage.put(gr.data(), G);
+      HIPCHK(hipMemcpyAsync(e->d_gene_rate.p, hg, (size_t)G * 8, hipMemcpyHostToDevice, e->stream));
+      if (!tab.empty()) {
+         HIPCHK(e->d_eigen.ensure(tab.size()));
+         const EigenDev *ht = e->stage.put(tab.data(), tab.size());
+         HIPCHK(hipMemcpyAsync(e->d_eigen.p, ht, tab.size() * sizeof(EigenDev), hipMemcpyHostToDevice, e->stream));
+         e->eigen_dirty = false;
+      }
+      if (new_prog) {
+         HIPCHK(e->d_ops.ensure(e->prog.ops.size()));
+         const Op *ho = e->stage.put(e->prog.ops.data(), e->prog.ops.size());
+         HIPCHK(hipMemcpyAsync(e->d_ops.p, ho, e->prog.ops.size() * sizeof(Op), hipMemcpyHostToDevice, e->stream));
+      }
+      HIPCHK(e->stage.end(e->stream));
+   }
+
+   // P(t) storage
+   HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
+   if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
+   HIPCHK(e->d_ptip.ensure((size_t)psets * nn * e->n_codes * tipw(e)));
+   HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
+   const int n_blocks = e->n_tiles * K;
+   const int n_int = nn - e->n_tips;
+   if (keep) {
+      size_t words = e->kk == KK_MFMA64 ? (size_t)K * n_int * e->n_tiles * MFMA_WAVES * 1024
+                                        : (size_t)K * n_int * e->n_patt * n;
+      HIPCHK(e->d_partials.ensure(words));
+      HIPCHK(e->d_scalef.ensure((size_t)K * std::max(1, e->tree.n_scale) * e->n_patt));
+   }
+   int overflow = 0;
+   if (e->kk == KK_MFMA64 && e->prog.max_stack > MFMA_RS) {
+      overflow = e->prog.max_stack - MFMA_RS;
+      HIPCHK(e->d_stack.ensure((size_t)n_blocks * overflow * MFMA_WAVES * 1024));
+   }
+
+   // Kernel A: batched P(t)
+   PmatArgs pa{};
+   pa.n = n; pa.n_nodes = nn; pa.root = e->tree.root; pa.K = K; pa.n_genes = G; pa.n_labels = e->n_labels;
+   pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : 0;
+   pa.label = e->d_label.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
+   pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
+   pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
+   pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p;
+   mark(e);
+   hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), e->stream, pa);
+   mark(e);
+   e->n_pmat += (long)psets * (nn - 1);
+
+   // Kernel B: fused pruning
+   PruneArgs pr{};
+   pr.ops = e->d_ops.p; pr.z = e->d_z.p; pr.z_stride = e->n_patt; pr.tiles = e->d_tiles.p; pr.n_tiles = e->n_tiles;
+   pr.gene_off = e->d_gene_off.p; pr.weights = e->d_weights.p;
+   pr.n = n; pr.n_tips = e->n_tips; pr.n_nodes = nn; pr.K = K; pr.n_genes = G; pr.n_codes = e->n_codes;
+   pr.cleandata = e->cleandata; pr.n_pi = e->n_pi; pr.mode = e->mode; pr.n_scale = e->tree.n_scale;
+   pr.keep = keep ? 1 : 0; pr.n_patt = e->n_patt;
+   pr.pi = e->d_pi.p; pr.pint = e->kk == KK_MFMA64 ? e->d_pint.p : e->d_rowmajor.p; pr.ptip = e->d_ptip.p;
+   pr.fhK = e->d_fhK.p; pr.partials = e->d_partials.p; pr.scalef = e->d_scalef.p; pr.stack_scratch = e->d_stack.p;
+   pr.stack_overflow_slots = overflow; pr.first_matmul = first_matmul(e->prog); pr.n_int = n_int;
+   mark(e);
+   switch (e->kk) {
+   case KK_MFMA64:
+      hipLaunchKernelGGL(prune_mfma64<MFMA_WAVES>, dim3(n_blocks), dim3(MFMA_WAVES * 64), 0, e->stream, pr);
+      break;
+   case KK_VALU4:
+      hipLaunchKernelGGL((prune_valu<4, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
+      break;
+   case KK_VALU5:
+      hipLaunchKernelGGL((prune_valu<5, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
+      break;
+   case KK_VALU20:
+      hipLaunchKernelGGL((prune_valu<20, VALU_MAXD_20>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
+      break;
+   }
+   mark(e);
+
+   // Kernel C: mixture + log + weighted sum
+   const int chunk = std::max(256, ((e->n_patt + 1023) / 1024 + 255) / 256 * 256);
+   const int nb = (e->n_patt + chunk - 1) / chunk;
+   HIPCHK(e->d_partial.ensure(nb));
+   HIPCHK(e->d_out.ensure(1));
+   if (want_lnf) HIPCHK(e->d_lnf.ensure(e->n_patt));
+   ReduceArgs ra{};
+   ra.fhK = e->d_fhK.p; ra.weights = e->d_weights.p; ra.freqK = e->d_freqK.p; ra.lnf = want_lnf ? e->d_lnf.p : nullptr;
+   ra.partial = e->d_partial.p; ra.out = d_lnL_out ? d_lnL_out : e->d_out.p;
+   ra.n_patt = e->n_patt; ra.K = K; ra.mode = e->mode; ra.n_scale = e->tree.n_scale; ra.chunk = chunk;
+   mark(e);
+   hipLaunchKernelGGL(reduce_stage1, dim3(nb), dim3(256), 0, e->stream, ra);
+   hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(256), 0, e->stream, (const double *)e->d_partial.p, nb, ra.out);
+   mark(e);
+   HIPCHK(hipGetLastError());
+   if (e->profiling) e->prof_evals++;
+   e->n_eval++;
+   if (keep && !clean) e->partials_valid = true;
+   return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt, int max_classes, int n_genes,
+                    unsigned flags)
+{
+   if (!out) return PAML_AMD_EINVAL;
+   *out = nullptr;
+   if (n_states < 2 || n_states > 64 || n_tips < 2 || n_patt < 1 || max_classes < 1 || n_genes < 1) return PAML_AMD_EINVAL;
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return PAML_AMD_EHIP;   // no CPU fallback, by design
+   paml_amd_engine *e = new (std::nothrow) paml_amd_engine();
+   if (!e) return PAML_AMD_ENOMEM;
+   e->n = n_states; e->n_tips = n_tips; e->n_patt = n_patt; e->max_classes = max_classes; e->n_genes = n_genes;
+   e->flags = flags;
+   if (n_states == 4) e->kk = KK_VALU4;
+   else if (n_states == 5) e->kk = KK_VALU5;
+   else if (n_states == 20) e->kk = KK_VALU20;
+   else e->kk = KK_MFMA64;
+   e->tile_patt = e->kk == KK_MFMA64 ? MFMA_WAVES * 16 : 256;
+   *out = e;
+   return 0;
+}
+
+void paml_amd_destroy(paml_amd_engine *e)
+{
+   if (!e) return;
+   (void)hipStreamSynchronize(e->stream);
+   delete e;
+}
+
+const char *paml_amd_last_error(const paml_amd_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+const char *paml_amd_kernel_name(const paml_amd_engine *e)
+{
+   if (!e) return "";
+   switch (e->kk) {
+   case KK_VALU4: return "valu4";
+   case KK_VALU5: return "valu5";
+   case KK_VALU20: return "valu20";
+   default: return "mfma64";
+   }
+}
+
+int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   (void)hipStreamSynchronize(e->stream);
+   e->stream = (hipStream_t)hip_stream;
+   return 0;
+}
+
+int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata, int n_codes, const int *n_chara,
+                      const unsigned char *chara_map, const double *weights, const int *gene_off)
+{
+   if (!e || !z || !weights) return fail(e, PAML_AMD_EINVAL, "set_tips: null argument");
+   const int n = e->n;
+   std::vector<int> nch;
+   std::vector<unsigned char> cmap;
+   if (cleandata || !n_chara || !chara_map) {
+      if (!cleandata) return fail(e, PAML_AMD_EINVAL, "set_tips: cleandata=0 needs n_chara/chara_map");
+      n_codes = n;
+      nch.assign(n, 1);
+      cmap.assign((size_t)n * n, 0);
+      for (int i = 0; i < n; i++) cmap[(size_t)i * n] = (unsigned char)i;
+   }
+   else {
+      if (n_codes < 1 || n_codes > 256) return fail(e, PAML_AMD_EINVAL, "set_tips: n_codes out of range");
+      nch.assign(n_chara, n_chara + n_codes);
+      cmap.assign(chara_map, chara_map + (size_t)n_codes * n);
+      for (int c = 0; c < n_codes; c++) {
+         if (nch[c] < 0 || nch[c] > n) return fail(e, PAML_AMD_EINVAL, "set_tips: n_chara out of range");
+         for (int k = 0; k < nch[c]; k++)
+            if (cmap[(size_t)c * n + k] >= n) return fail(e, PAML_AMD_EINVAL, "set_tips: chara_map state out of range");
+      }
+   }
+   const size_t nz = (size_t)e->n_tips * e->n_patt;
+   for (size_t i = 0; i < nz; i++)
+      if (z[i] >= n_codes) return fail(e, PAML_AMD_EINVAL, "set_tips: character code >= n_codes");
+   e->cleandata = cleandata ? 1 : 0;
+   e->n_codes = n_codes;
+   e->gene_off.assign(e->n_genes + 1, 0);
+   if (gene_off) e->gene_off.assign(gene_off, gene_off + e->n_genes + 1);
+   else {
+      if (e->n_genes != 1) return fail(e, PAML_AMD_EINVAL, "set_tips: gene_off required when n_genes > 1");
+      e->gene_off[1] = e->n_patt;
+   }
+   if (e->gene_off[0] != 0 || e->gene_off[e->n_genes] != e->n_patt)
+      return fail(e, PAML_AMD_EINVAL, "set_tips: gene_off must span [0, n_patt]");
+   for (int g = 0; g < e->n_genes; g++)
+      if (e->gene_off[g + 1] <= e->gene_off[g]) return fail(e, PAML_AMD_EINVAL, "set_tips: empty gene");
+   HIPCHK(upload(e->d_z, z, nz, e->stream));
+   HIPCHK(upload(e->d_weights, weights, (size_t)e->n_patt, e->stream));
+   HIPCHK(upload(e->d_n_chara, nch.data(), nch.size(), e->stream));
+   HIPCHK(upload(e->d_chara_map, cmap.data(), cmap.size(), e->stream));
+   HIPCHK(upload(e->d_gene_off, e->gene_off.data(), e->gene_off.size(), e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   int r = build_tiles(e);
+   if (r) return r;
+   e->have_tips = true;
+   e->partials_valid = false;
+   return 0;
+}
+
+int paml_amd_set_tree(paml_amd_engine *e, int n_nodes, int root, const int *sons_ptr, const int *sons, const int *label,
+                      const unsigned char *scale_node)
+{
+   if (!e || !sons_ptr || !sons) return fail(e, PAML_AMD_EINVAL, "set_tree: null argument");
+   if (n_nodes <= e->n_tips || root < 0 || root >= n_nodes) return fail(e, PAML_AMD_EINVAL, "set_tree: bad sizes");
+   TreeDesc t;
+   t.n_tips = e->n_tips; t.n_nodes = n_nodes; t.root = root;
+   t.sons_ptr.assign(sons_ptr, sons_ptr + n_nodes + 1);
+   if (t.sons_ptr[0] != 0) return fail(e, PAML_AMD_EINVAL, "set_tree: sons_ptr[0] != 0");
+   for (int i = 0; i < n_nodes; i++)
+      if (t.sons_ptr[i + 1] < t.sons_ptr[i]) return fail(e, PAML_AMD_EINVAL, "set_tree: sons_ptr not monotone");
+   t.sons.assign(sons, sons + t.sons_ptr[n_nodes]);
+   std::vector<int> seen(n_nodes, 0);
+   for (int s : t.sons) {
+      if (s < 0 || s >= n_nodes || s == root || seen[s]++) return fail(e, PAML_AMD_EINVAL, "set_tree: bad son index");
+   }
+   for (int i = 0; i < n_nodes; i++) {
+      if (i != root && !seen[i]) return fail(e, PAML_AMD_EINVAL, "set_tree: node without father");
+      if (i >= e->n_tips && t.is_leaf(i)) return fail(e, PAML_AMD_EINVAL, "set_tree: internal node without sons");
+      if (i < e->n_tips && i != root && !t.is_leaf(i)) return fail(e, PAML_AMD_EINVAL, "set_tree: tip with sons");
+   }
+   t.label.assign(n_nodes, 0);
+   if (label) t.label.assign(label, label + n_nodes);
+   t.scale_node.assign(n_nodes, 0);
+   t.scale_slot.assign(n_nodes, -1);
+   if (scale_node) {
+      for (int i = 0; i < n_nodes; i++) {
+         t.scale_node[i] = scale_node[i] ? 1 : 0;
+         if (t.scale_node[i]) t.scale_slot[i] = t.n_scale++;
+      }
+   }
+   std::vector<unsigned char> leaf(n_nodes);
+   for (int i = 0; i < n_nodes; i++) leaf[i] = t.is_leaf(i) ? 1 : 0;
+   e->tree = std::move(t);
+   HIPCHK(upload(e->d_label, e->tree.label.data(), e->tree.label.size(), e->stream));
+   HIPCHK(upload(e->d_is_leaf, leaf.data(), leaf.size(), e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   e->have_tree = true;
+   e->prog_valid = false;
+   e->partials_valid = false;
+   return 0;
+}
+
+int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi)
+{
+   if (!e || !pi || (n_pi != 1 && n_pi != e->n_genes)) return fail(e, PAML_AMD_EINVAL, "set_pi: bad arguments");
+   const int n = e->n;
+   std::vector<double> buf;
+   if (e->kk == KK_MFMA64) {
+      buf.assign((size_t)n_pi * 64, 0.0);
+      for (int g = 0; g < n_pi; g++)
+         for (int j = 0; j < n; j++) buf[(size_t)g * 64 + (j & 3) * 16 + (j >> 2)] = pi[(size_t)g * n + j];
+   }
+   else
+      buf.assign(pi, pi + (size_t)n_pi * n);
+   HIPCHK(upload(e->d_pi, buf.data(), buf.size(), e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   e->n_pi = n_pi;
+   e->have_pi = true;
+   return 0;
+}
+
+static EigenHost *eigen_slot(paml_amd_engine *e, int set_id)
+{
+   if (!e || set_id < 0 || set_id > 4096) return nullptr;
+   if ((size_t)set_id >= e->eigen.size()) e->eigen.resize(set_id + 1);
+   e->eigen_dirty = true;
+   e->partials_valid = false;
+   return &e->eigen[set_id];
+}
+
+int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, const double *V, const double *Root)
+{
+   EigenHost *h = eigen_slot(e, set_id);
+   if (!h || !U || !V || !Root) return fail(e, PAML_AMD_EINVAL, "set_eigen_uvroot: bad arguments");
+   const size_t n = e->n;
+   HIPCHK(upload(h->U, U, n * n, e->stream));
+   HIPCHK(upload(h->V, V, n * n, e->stream));
+   HIPCHK(upload(h->Root, Root, n, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   h->kind = PAML_AMD_EIGEN_UVROOT;
+   return 0;
+}
+
+int paml_amd_set_eigen_cijk(paml_amd_engine *e, int set_id, int nR, const double *Cijk, const double *Root)
+{
+   EigenHost *h = eigen_slot(e, set_id);
+   if (!h || !Cijk || !Root || nR < 1 || nR > 64) return fail(e, PAML_AMD_EINVAL, "set_eigen_cijk: bad arguments");
+   const size_t n = e->n;
+   HIPCHK(upload(h->Cijk, Cijk, n * n * nR, e->stream));
+   HIPCHK(upload(h->Root, Root, (size_t)nR, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   h->kind = PAML_AMD_EIGEN_CIJK;
+   h->nR = nR;
+   return 0;
+}
+
+int paml_amd_set_eigen_k80(paml_amd_engine *e, int set_id, double kappa)
+{
+   if (e && e->n != 4) return fail(e, PAML_AMD_EINVAL, "set_eigen_k80: needs 4 states");
+   EigenHost *h = eigen_slot(e, set_id);
+   if (!h) return fail(e, PAML_AMD_EINVAL, "set_eigen_k80: bad arguments");
+   h->kind = PAML_AMD_EIGEN_K80;
+   h->kappa = kappa;
+   return 0;
+}
+
+int paml_amd_set_eigen_jc69like(paml_amd_engine *e, int set_id)
+{
+   EigenHost *h = eigen_slot(e, set_id);
+   if (!h) return fail(e, PAML_AMD_EINVAL, "set_eigen_jc69like: bad arguments");
+   h->kind = PAML_AMD_EIGEN_JC69LIKE;
+   return 0;
+}
+
+int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freqK, const double *rate, int n_labels,
+                         const int *eigen_of, const double *qfactor)
+{
+   if (!e || K < 1 || K > e->max_classes || n_labels < 1 || !eigen_of)
+      return fail(e, PAML_AMD_EINVAL, "set_classes: bad arguments");
+   if (mode != PAML_AMD_MODE_LFUN && mode != PAML_AMD_MODE_LFUNDG) return fail(e, PAML_AMD_EINVAL, "set_classes: bad mode");
+   if (mode == PAML_AMD_MODE_LFUN && K != 1) return fail(e, PAML_AMD_EINVAL, "set_classes: lfun mode needs K = 1");
+   if (e->have_tree)
+      for (int lab : e->tree.label)
+         if (lab < 0 || lab >= n_labels) return fail(e, PAML_AMD_EINVAL, "set_classes: tree label >= n_labels");
+   std::vector<double> f(K, 1.0), r(K, 1.0), q((size_t)K * n_labels, 1.0);
+   if (freqK) f.assign(freqK, freqK + K);
+   if (rate) r.assign(rate, rate + K);
+   if (qfactor) q.assign(qfactor, qfactor + (size_t)K * n_labels);
+   HIPCHK(upload(e->d_freqK, f.data(), f.size(), e->stream));
+   HIPCHK(upload(e->d_rate, r.data(), r.size(), e->stream));
+   HIPCHK(upload(e->d_qfactor, q.data(), q.size(), e->stream));
+   HIPCHK(upload(e->d_eigen_of, eigen_of, (size_t)e->n_genes * K * n_labels, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   e->mode = mode; e->K = K; e->n_labels = n_labels;
+   e->have_classes = true;
+   e->partials_valid = false;
+   return 0;
+}
+
+int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, double *lnL, double *lnf,
+                  double *fhK)
+{
+   if (!e || !branch || !lnL) return fail(e, PAML_AMD_EINVAL, "eval: null argument");
+   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, lnf != nullptr);
+   if (r) return r;
+   HIPCHK(hipMemcpyAsync(lnL, e->d_out.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   if (lnf) HIPCHK(hipMemcpyAsync(lnf, e->d_lnf.p, (size_t)e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   if (fhK)
+      HIPCHK(hipMemcpyAsync(fhK, e->d_fhK.p, (size_t)e->K * e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
+int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL)
+{
+   if (!e || !branch || !d_lnL) return fail(e, PAML_AMD_EINVAL, "eval_device: null argument");
+   return launch_eval(e, branch, gene_rate, nullptr, d_lnL, false);
+}
+
+int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
+                        double *lnL)
+{
+   if (!e || !branch || !lnL || !clean) return fail(e, PAML_AMD_EINVAL, "eval_dirty: null argument");
+   int r = launch_eval(e, branch, gene_rate, clean, nullptr, false);
+   if (r) return r;
+   HIPCHK(hipMemcpyAsync(lnL, e->d_out.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
+int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double *P)
+{
+   if (!e || !P || !e->d_rowmajor.p) return fail(e, PAML_AMD_EINVAL, "get_pmat: nothing evaluated yet");
+   if (gene < 0 || gene >= e->n_genes || iclass < 0 || iclass >= e->K || node < 0 || node >= e->tree.n_nodes ||
+       node == e->tree.root)
+      return fail(e, PAML_AMD_EINVAL, "get_pmat: index out of range");
+   const size_t nn2 = (size_t)e->n * e->n;
+   const double *src = e->d_rowmajor.p + ((size_t)(gene * e->K + iclass) * e->tree.n_nodes + node) * nn2;
+   HIPCHK(hipMemcpyAsync(P, src, nn2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
+int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP)
+{
+   if (!e || !conP) return fail(e, PAML_AMD_EINVAL, "get_partials: null argument");
+   if (!(e->flags & PAML_AMD_KEEP_PARTIALS) || !e->partials_valid)
+      return fail(e, PAML_AMD_EINVAL, "get_partials: needs PAML_AMD_KEEP_PARTIALS and a completed evaluation");
+   if (node < e->n_tips || node >= e->tree.n_nodes || iclass < 0 || iclass >= e->K)
+      return fail(e, PAML_AMD_EINVAL, "get_partials: index out of range");
+   const int n = e->n, n_int = e->tree.n_nodes - e->n_tips;
+   if (e->kk != KK_MFMA64) {
+      const double *src = e->d_partials.p + ((size_t)iclass * n_int + (node - e->n_tips)) * e->n_patt * n;
+      HIPCHK(hipMemcpyAsync(conP, src, (size_t)e->n_patt * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      return 0;
+   }
+   const size_t groups = (size_t)e->n_tiles * MFMA_WAVES;
+   std::vector<double> raw(groups * 1024);
+   const double *src = e->d_partials.p + ((size_t)iclass * n_int + (node - e->n_tips)) * groups * 1024;
+   HIPCHK(hipMemcpyAsync(raw.data(), src, raw.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   // native [group][m][lane] -> [h][state]; lane = (state & 3) * 16 + (h & 15), m = state >> 2
+   std::vector<int2> tiles;
+   for (int g = 0; g < e->n_genes; g++)
+      for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += e->tile_patt) tiles.push_back(make_int2(g, h));
+   for (size_t t = 0; t < tiles.size(); t++) {
+      const int hend = e->gene_off[tiles[t].x + 1];
+      for (int w = 0; w < MFMA_WAVES; w++)
+         for (int hl = 0; hl < 16; hl++) {
+            const int h = tiles[t].y + w * 16 + hl;
+            if (h >= hend) continue;
+            const double *grp = raw.data() + (t * MFMA_WAVES + w) * 1024;
+            for (int j = 0; j < n; j++) conP[(size_t)h * n + j] = grp[(j >> 2) * 64 + (j & 3) * 16 + hl];
+         }
+   }
+   return 0;
+}
+
+int paml_amd_get_scale(paml_amd_engine *e, int node, int iclass, double *scale)
+{
+   if (!e || !scale) return fail(e, PAML_AMD_EINVAL, "get_scale: null argument");
+   if (!(e->flags & PAML_AMD_KEEP_PARTIALS) || !e->partials_valid)
+      return fail(e, PAML_AMD_EINVAL, "get_scale: needs PAML_AMD_KEEP_PARTIALS and a completed evaluation");
+   if (node < 0 || node >= e->tree.n_nodes || iclass < 0 || iclass >= e->K || e->tree.scale_slot[node] < 0)
+      return fail(e, PAML_AMD_EINVAL, "get_scale: not a scaling node");
+   const double *src = e->d_scalef.p + ((size_t)iclass * e->tree.n_scale + e->tree.scale_slot[node]) * e->n_patt;
+   HIPCHK(hipMemcpyAsync(scale, src, (size_t)e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
+int paml_amd_profile(paml_amd_engine *e, int enable)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   e->profiling = enable != 0;
+   return 0;
+}
+
+int paml_amd_profile_read(paml_amd_engine *e, double *ms_pmat, double *ms_prune, double *ms_reduce, long *n_evals)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   HIPCHK(hipStreamSynchronize(e->stream));
+   double acc[3] = {0, 0, 0};
+   for (size_t i = 0; i + 5 < e->ev_used.size(); i += 6)
+      for (int k = 0; k < 3; k++) {
+         float ms = 0;
+         if (hipEventElapsedTime(&ms, e->ev_used[i + 2 * k], e->ev_used[i + 2 * k + 1]) == hipSuccess) acc[k] += ms;
+      }
+   for (auto ev : e->ev_used) e->ev_pool.push_back(ev);
+   e->ev_used.clear();
+   if (ms_pmat) *ms_pmat = acc[0];
+   if (ms_prune) *ms_prune = acc[1];
+   if (ms_reduce) *ms_reduce = acc[2];
+   if (n_evals) *n_evals = e->prof_evals;
+   e->prof_evals = 0;
+   return 0;
+}
+
+int paml_amd_debug_program(int n_tips, int n_nodes, int root, const int *sons_ptr, const int *sons,
+                           const unsigned char *scale_node, int keep_partials, const unsigned char *clean,
+                           int *ops_out, int cap, int *max_stack)
+{
+   if (!sons_ptr || !sons || n_nodes <= 0 || root < 0 || root >= n_nodes) return PAML_AMD_EINVAL;
+   TreeDesc t;
+   t.n_tips = n_tips; t.n_nodes = n_nodes; t.root = root;
+   t.sons_ptr.assign(sons_ptr, sons_ptr + n_nodes + 1);
+   t.sons.assign(sons, sons + sons_ptr[n_nodes]);
+   t.label.assign(n_nodes, 0);
+   t.scale_node.assign(n_nodes, 0);
+   t.scale_slot.assign(n_nodes, -1);
+   if (scale_node)
+      for (int i = 0; i < n_nodes; i++)
+         if (scale_node[i]) { t.scale_node[i] = 1; t.scale_slot[i] = t.n_scale++; }
+   Program p = build_program(t, keep_partials != 0, clean);
+   if (max_stack) *max_stack = p.max_stack;
+   if (ops_out)
+      for (int i = 0; i < (int)p.ops.size() && i < cap; i++) {
+         ops_out[4 * i] = p.ops[i].code; ops_out[4 * i + 1] = p.ops[i].a;
+         ops_out[4 * i + 2] = p.ops[i].b; ops_out[4 * i + 3] = p.ops[i].c;
+      }
+   return (int)p.ops.size();
+}
+
+int paml_amd_counters(const paml_amd_engine *e, long *n_eval, long *n_pmat)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   if (n_eval) *n_eval = e->n_eval;
+   if (n_pmat) *n_pmat = e->n_pmat;
+   return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,604 @@
+// kernels.h — hand-written HIP kernels for gfx950 (MI355X, CDNA4): batched P(t) construction,
+// fused Felsenstein pruning (FP64 MFMA path for 21..64 states, per-pattern VALU path for 4/5/20
+// states) and the deterministic root/mixture/log reduction.  Wave = 64 lanes throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/paml_amd.h"
+#include "program.h"
+
+namespace paml_amd {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct EigenDev {
+   int kind, nR;
+   double kappa;
+   const double *U, *V, *Root, *Cijk;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Kernel A: batched P(t) — one workgroup per (node, gene x class).
+//   UVROOT : P = I + sum_k (U[:,k] expm1(t Root_k)) V[k,:], t<1e-100 -> I, entries <0 -> 0  (tools.c:516-546)
+//   CIJK   : P_ij = delta_ij + sum_{k>=1} Cijk[i][j][k] expm1(t Root_k), no clamp           (baseml.c:1572-1589)
+//   K80    : closed form (tools.c:578-604);  JC69LIKE: closed form (codeml.c:3585-3595)
+// with t = branch * rateSite * rgene [* Qfactor]  (codeml.c:3547-3551, treesub.c:7587).
+// Outputs, all for the branch above `node`:
+//   rowmajor  [n*n]                P[from*n+to]           (get_pmat; matmul operand of the VALU kernels)
+//   frag      [8][4][64][2]        MFMA A-operand order   (mfma64 kernel; see prune_mfma64)
+//   tip table [n_codes][...]       column sums over each character code's state set
+//                                  (codeml.c:3555-3567), [code][n] for VALU, [code][q][m] for mfma64
+// ------------------------------------------------------------------------------------------------
+struct PmatArgs {
+   int n, n_nodes, root, K, n_genes, n_labels, n_codes, layout;   // layout 0: VALU (row-major), 1: mfma64
+   const int *label;             // [n_nodes]
+   const unsigned char *is_leaf; // [n_nodes]
+   const double *branch;         // [n_nodes]
+   const double *rate;           // [K]
+   const double *gene_rate;      // [n_genes]
+   const int *eigen_of;          // [n_genes][K][n_labels]
+   const double *qfactor;        // [K][n_labels]
+   const EigenDev *eigen;
+   const int *n_chara;           // [n_codes]
+   const unsigned char *chara_map; // [n_codes][n]
+   double *rowmajor;             // [pset][n_nodes][n*n]
+   double *pint;                 // layout 1: [pset][n_nodes][4096]
+   double *ptip;                 // [pset][n_nodes][n_codes*tipw]   tipw = n (VALU) or 64 (mfma64)
+};
+
+__global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
+{
+   extern __shared__ __attribute__((aligned(16))) double smem[];
+   double *sA = smem;            // [64][64]  U*expm1 -> later the finished P (padded with zeros)
+   double *sB = smem + 4096;     // [64][64]  V
+   const int node = blockIdx.x, pset = blockIdx.y;
+   if (node == a.root) return;
+   const int tid = threadIdx.x, n = a.n;
+   const int gene = pset / a.K, iclass = pset % a.K;
+   const int lab = a.label[node];
+   const EigenDev es = a.eigen[a.eigen_of[(gene * a.K + iclass) * a.n_labels + lab]];
+   double t = a.branch[node] * a.rate[iclass];
+   t *= a.gene_rate[gene];
+
+   const int j = tid & 63, rg = tid >> 6;   // this thread: column j, rows rg*16 .. rg*16+15
+   double acc[16];
+#pragma unroll
+   for (int r = 0; r < 16; r++) acc[r] = 0;
+
+   if (es.kind == PAML_AMD_EIGEN_UVROOT) {
+      t *= a.qfactor[iclass * a.n_labels + lab];
+      if (t < 1e-100) {
+#pragma unroll
+         for (int r = 0; r < 16; r++) acc[r] = (rg * 16 + r == j) ? 1.0 : 0.0;
+      }
+      else {
+         for (int idx = tid; idx < 4096; idx += 256) {
+            int i = idx >> 6, k = idx & 63;
+            double ue = 0, v = 0;
+            if (i < n && k < n) {
+               ue = es.U[i * n + k] * expm1(t * es.Root[k]);
+               v = es.V[i * n + k];        // here (i,k) index V as [k'][j'] = [i][k]
+            }
+            sA[idx] = ue;
+            sB[idx] = v;
+         }
+         __syncthreads();
+         for (int k = 0; k < n; k++) {
+            double v = sB[k * 64 + j];
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = fma(sA[(rg * 16 + r) * 64 + k], v, acc[r]);
+         }
+#pragma unroll
+         for (int r = 0; r < 16; r++) {
+            int i = rg * 16 + r;
+            double p = acc[r] + (i == j ? 1.0 : 0.0);
+            acc[r] = (i < n && j < n) ? (p < 0 ? 0.0 : p) : 0.0;
+         }
+         __syncthreads();
+      }
+   }
+   else if (es.kind == PAML_AMD_EIGEN_CIJK) {
+      double e[64];
+      const int nR = es.nR;
+      for (int idx = tid; idx < 64; idx += 256) sB[idx] = (idx >= 1 && idx < nR) ? expm1(t * es.Root[idx]) : 0.0;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+         int i = rg * 16 + r;
+         double s = 0;
+         if (i < n && j < n) {
+            const double *c = es.Cijk + ((long)i * n + j) * nR;
+            for (int k = 0; k < nR; k++) s += c[k] * sB[k];
+            if (i == j) s += 1.0;
+         }
+         acc[r] = s;
+      }
+      (void)e;
+      __syncthreads();
+   }
+   else if (es.kind == PAML_AMD_EIGEN_K80) {
+      const double kappa = es.kappa;
+      const double e1 = expm1(-4 * t / (kappa + 2));
+      const bool jc = fabs(kappa - 1) < 1e-20;
+      const double e2 = jc ? 0.0 : expm1(-2 * t * (kappa + 1) / (kappa + 2));
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+         int i = rg * 16 + r;
+         double p = 0;
+         if (i < 4 && j < 4) {
+            if (jc) p = (i == j) ? 1. + 3 / 4.0 * e1 : -e1 / 4;
+            else if (i == j) p = 1 + (e1 + 2 * e2) / 4;
+            else if ((i ^ j) == 1) p = (e1 - 2 * e2) / 4;
+            else p = -e1 / 4;
+         }
+         acc[r] = p;
+      }
+   }
+   else {   // JC69-like (aa Poisson): no Qfactor (treesub.c:7584-7585)
+      const double pii = 1. / n + (1. - 1. / n) * exp(-n / (n - 1.) * t);
+      const double pij = (1. - pii) / (n - 1.);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+         int i = rg * 16 + r;
+         acc[r] = (i < n && j < n) ? (i == j ? pii : pij) : 0.0;
+      }
+   }
+
+   // finished P (zero padded to 64x64) into LDS
+#pragma unroll
+   for (int r = 0; r < 16; r++) sA[(rg * 16 + r) * 64 + j] = acc[r];
+   __syncthreads();
+
+   const long slot = (long)pset * a.n_nodes + node;
+   double *rm = a.rowmajor + slot * n * n;
+   for (int idx = tid; idx < n * n; idx += 256) rm[idx] = sA[(idx / n) * 64 + (idx % n)];
+
+   const bool leaf = a.is_leaf[node] != 0;
+   if (a.layout == 1 && !leaf) {
+      // MFMA A-operand order: element ((kb2*4 + jb)*64 + lane)*2 + e  =  P[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)]
+      double *pf = a.pint + slot * 4096;
+      for (int idx = tid; idx < 4096; idx += 256) {
+         int e = idx & 1, lane = (idx >> 1) & 63, jb = (idx >> 7) & 3, kb2 = idx >> 9;
+         pf[idx] = sA[(jb * 16 + (lane & 15)) * 64 + 4 * (2 * kb2 + e) + (lane >> 4)];
+      }
+   }
+   if (leaf) {
+      const int tipw = a.layout == 1 ? 64 : n;
+      double *pt = a.ptip + slot * (long)a.n_codes * tipw;
+      for (int idx = tid; idx < a.n_codes * tipw; idx += 256) {
+         int code = idx / tipw, w = idx % tipw, jj;
+         if (a.layout == 1) { int q = w >> 4, m = w & 15; jj = 4 * m + q; }
+         else jj = w;
+         double s = 0;
+         if (jj < n) {
+            const int nc = a.n_chara[code];
+            const unsigned char *map = a.chara_map + code * n;
+            for (int k = 0; k < nc; k++) s += sA[jj * 64 + map[k]];
+         }
+         pt[idx] = s;
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pruning kernels: arguments shared by the MFMA and VALU variants.
+// ------------------------------------------------------------------------------------------------
+struct PruneArgs {
+   const Op *ops;
+   const unsigned char *z;     // [n_tips][z_stride]
+   long z_stride;
+   const int2 *tiles;          // (gene, first pattern) per tile
+   int n_tiles;
+   const int *gene_off;
+   const double *weights;
+   int n, n_tips, n_nodes, K, n_genes, n_codes, cleandata, n_pi, mode, n_scale, keep, n_patt;
+   const double *pi;           // VALU: [n_pi][n];  mfma64: [n_pi][4][16] (q-major, zero padded)
+   const double *pint;         // per (pset, node): n*n row-major (VALU) or 4096 frag (mfma64)
+   const double *ptip;         // per (pset, node): n_codes * tipw
+   double *fhK;                // [K][n_patt]
+   double *partials;           // keep mode
+   double *scalef;             // keep mode: [K][n_scale][n_patt]
+   double *stack_scratch;      // overflow stack (mfma64)
+   int stack_overflow_slots;
+   int first_matmul;
+   int n_int;                  // n_nodes - n_tips
+};
+
+__device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)
+{
+   // fx_r treesub.c:7731-7749 / lfun 7782-7798: floors then log + scale factors
+   if (f <= 0) f = (a.mode == PAML_AMD_MODE_LFUN ? 1e-80 : 1e-300);
+   if (a.mode == PAML_AMD_MODE_LFUN || a.n_scale) f = log(f) + lnscale;
+   return f;
+}
+
+// ---- mfma64: 21..64 states, FP64 MFMA -----------------------------------------------------------
+// One wave owns 16 patterns for the whole tree.  A partial is 16 doubles per lane: lane l holds, for
+// pattern (l & 15), the states 4m + (l >> 4), m = 0..15.  That is simultaneously
+//   * the B operand of v_mfma_f64_16x16x4_f64 for k-block kb = m  (B[k = l>>4][n = l&15]), and
+//   * the D layout of the instruction for row block jb = m>>2, register m&3  (row = (l>>4) + 4 reg),
+// so cur' = P . cur chains from node to node entirely in registers: no transposes, no LDS traffic for
+// partials.  The A operand (P) is staged once per workgroup per branch into LDS in exactly the order
+// lanes consume it (pmat_kernel's `frag` layout), double-buffered so the next branch's P streams in
+// under the current MFMAs.  Tip branches are gathers from L2-resident column tables.
+#define MFMA_RS 3   // register stack slots; deeper slots spill to global scratch
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void prune_mfma64(PruneArgs a)
+{
+   __shared__ __attribute__((aligned(16))) double sP[2][4096];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int q = lane >> 4, hl = lane & 15;
+   const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;
+   const int gene = a.tiles[tile].x, h0 = a.tiles[tile].y;
+   const int hend = a.gene_off[gene + 1];
+   const int h = h0 + wave * 16 + hl;
+   const bool valid = h < hend;
+   const int hc = valid ? h : hend - 1;
+   const long pset = (long)gene * a.K + iclass;
+   const double *Pint = a.pint + pset * a.n_nodes * 4096;
+   const long tipstride = (long)a.n_codes * 64;
+   const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
+   const int n = a.n;
+
+   double cur[16], s0[16], s1[16], s2[16];
+   double lnscale = 0;
+   int buf = 0;
+#pragma unroll
+   for (int m = 0; m < 16; m++) cur[m] = s0[m] = s1[m] = s2[m] = 0;
+
+   constexpr int NT = WAVES * 64;
+   constexpr int STAGE_IT = 2048 / NT;     // double2 elements per thread
+   if (a.first_matmul >= 0) {
+      const double2 *g = (const double2 *)(Pint + (long)a.first_matmul * 4096);
+      double2 *s = (double2 *)sP[0];
+#pragma unroll
+      for (int i = 0; i < STAGE_IT; i++) s[i * NT + tid] = g[i * NT + tid];
+   }
+
+   for (int ip = 0;; ip++) {
+      const Op op = a.ops[ip];
+      if (op.code == OP_END) break;
+      switch (op.code) {
+      case OP_INIT_ONES: {
+#pragma unroll
+         for (int m = 0; m < 16; m++) cur[m] = (4 * m + q < n) ? 1.0 : 0.0;
+      } break;
+      case OP_INIT_TIP: {
+         const int code = a.z[(long)op.a * a.z_stride + hc];
+#pragma unroll
+         for (int m = 0; m < 16; m++) cur[m] = (a.cleandata && 4 * m + q == code) ? 1.0 : 0.0;
+      } break;
+      case OP_MUL_TIP: {
+         const int code = a.z[(long)op.a * a.z_stride + hc];
+         const double2 *pt = (const double2 *)(Ptip + (long)op.a * tipstride + (code * 4 + q) * 16);
+#pragma unroll
+         for (int i = 0; i < 8; i++) {
+            double2 v = pt[i];
+            cur[2 * i] *= v.x;
+            cur[2 * i + 1] *= v.y;
+         }
+      } break;
+      case OP_PUSH: {
+         if (op.b == 0) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) s0[m] = cur[m];
+         }
+         else if (op.b == 1) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) s1[m] = cur[m];
+         }
+         else if (op.b == 2) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) s2[m] = cur[m];
+         }
+         else {
+            double *sp = a.stack_scratch +
+                         (((long)blockIdx.x * a.stack_overflow_slots + (op.b - MFMA_RS)) * WAVES + wave) * 1024;
+#pragma unroll
+            for (int m = 0; m < 16; m++) sp[m * 64 + lane] = cur[m];
+         }
+      } break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         __syncthreads();   // staged P[buf] visible; every wave is done reading P[buf^1]
+         double2 nxt[STAGE_IT];
+         if (op.c >= 0) {
+            const double2 *g = (const double2 *)(Pint + (long)op.c * 4096);
+#pragma unroll
+            for (int i = 0; i < STAGE_IT; i++) nxt[i] = g[i * NT + tid];
+         }
+         v4d acc[4];
+#pragma unroll
+         for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0, 0, 0, 0};
+         const double2 *sp = (const double2 *)sP[buf];
+#pragma unroll
+         for (int kb2 = 0; kb2 < 8; kb2++) {
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++) {
+               const double2 a2 = sp[(kb2 * 4 + jb) * 64 + lane];
+               acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, cur[2 * kb2], acc[jb], 0, 0, 0);
+               acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, cur[2 * kb2 + 1], acc[jb], 0, 0, 0);
+            }
+         }
+         if (op.code == OP_MATMUL) {
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+               for (int r = 0; r < 4; r++) cur[4 * jb + r] = acc[jb][r];
+         }
+         else if (op.b == 0) {
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+               for (int r = 0; r < 4; r++) cur[4 * jb + r] = s0[4 * jb + r] * acc[jb][r];
+         }
+         else if (op.b == 1) {
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+               for (int r = 0; r < 4; r++) cur[4 * jb + r] = s1[4 * jb + r] * acc[jb][r];
+         }
+         else if (op.b == 2) {
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+               for (int r = 0; r < 4; r++) cur[4 * jb + r] = s2[4 * jb + r] * acc[jb][r];
+         }
+         else {
+            const double *sp2 = a.stack_scratch +
+                                (((long)blockIdx.x * a.stack_overflow_slots + (op.b - MFMA_RS)) * WAVES + wave) * 1024;
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+               for (int r = 0; r < 4; r++) cur[4 * jb + r] = sp2[(4 * jb + r) * 64 + lane] * acc[jb][r];
+         }
+         if (op.c >= 0) {
+            double2 *s = (double2 *)sP[buf ^ 1];
+#pragma unroll
+            for (int i = 0; i < STAGE_IT; i++) s[i * NT + tid] = nxt[i];
+         }
+         buf ^= 1;
+      } break;
+      case OP_SCALE: {
+         double mx = 0;
+#pragma unroll
+         for (int m = 0; m < 16; m++) mx = cur[m] > mx ? cur[m] : mx;
+         double o = __shfl_xor(mx, 16);
+         mx = o > mx ? o : mx;
+         o = __shfl_xor(mx, 32);
+         mx = o > mx ? o : mx;
+         double fac;
+         if (mx < 1e-300) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) cur[m] = (4 * m + q < n) ? 1.0 : 0.0;
+            fac = -800;
+         }
+         else {
+#pragma unroll
+            for (int m = 0; m < 16; m++) cur[m] /= mx;
+            fac = log(mx);
+         }
+         lnscale += fac;
+         if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + op.b) * a.n_patt + h] = fac;
+      } break;
+      case OP_STORE: {
+         // native layout [class][node][tile16][m][lane]; n_patt rounded up to tiles of 16 per gene tile table
+         double *dst = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) +
+                                     ((long)tile * WAVES + wave)) * 1024;
+#pragma unroll
+         for (int m = 0; m < 16; m++) dst[m * 64 + lane] = cur[m];
+      } break;
+      case OP_LOAD: {
+         const double *src = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) +
+                                           ((long)tile * WAVES + wave)) * 1024;
+#pragma unroll
+         for (int m = 0; m < 16; m++) cur[m] = src[m * 64 + lane];
+      } break;
+      case OP_ROOT: {
+         const double *pq = a.pi + (long)(a.n_pi > 1 ? gene : 0) * 64 + q * 16;
+         double f = 0;
+#pragma unroll
+         for (int m = 0; m < 16; m++) f = fma(pq[m], cur[m], f);
+         f += __shfl_xor(f, 16);
+         f += __shfl_xor(f, 32);
+         if (a.keep && a.n_scale) {   // sum the stored factors in slot order, as the reference does (treesub.c:7746-7747)
+            lnscale = 0;
+            if (valid)
+               for (int k = 0; k < a.n_scale; k++) lnscale += a.scalef[((long)iclass * a.n_scale + k) * a.n_patt + h];
+         }
+         if (q == 0 && valid) {
+            double out = 0;
+            if (a.weights[h] > 0) out = root_value(a, f, lnscale);
+            a.fhK[(long)iclass * a.n_patt + h] = out;
+         }
+      } break;
+      default: break;
+      }
+   }
+}
+
+// ---- valu<N>: 4 / 5 / 20 states, one pattern per lane ------------------------------------------
+// The partial lives in N registers; P(t) entries are wave-uniform, so the compiler fetches them with
+// scalar loads (s_load) and feeds v_fma_f64 from SGPRs: no LDS, no barriers.  The whole tree is walked
+// per lane, so only tips (1 B) and the result (8 B) touch HBM unless keep-partials is on.
+template <int N, int MAXD>
+__global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
+{
+   const int tid = threadIdx.x;
+   const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;
+   const int gene = a.tiles[tile].x, h0 = a.tiles[tile].y;
+   const int hend = a.gene_off[gene + 1];
+   const int h = h0 + tid;
+   const bool valid = h < hend;
+   const int hc = valid ? h : hend - 1;
+   const long pset = (long)gene * a.K + iclass;
+   const double *Pint = a.pint + pset * a.n_nodes * (N * N);
+   const long tipstride = (long)a.n_codes * N;
+   const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
+
+   double cur[N];
+   double stk[MAXD][N];
+   double lnscale = 0;
+#pragma unroll
+   for (int j = 0; j < N; j++) cur[j] = 0;
+
+   for (int ip = 0;; ip++) {
+      const Op op = a.ops[ip];
+      if (op.code == OP_END) break;
+      switch (op.code) {
+      case OP_INIT_ONES: {
+#pragma unroll
+         for (int j = 0; j < N; j++) cur[j] = 1.0;
+      } break;
+      case OP_INIT_TIP: {
+         const int code = a.z[(long)op.a * a.z_stride + hc];
+#pragma unroll
+         for (int j = 0; j < N; j++) cur[j] = (a.cleandata && j == code) ? 1.0 : 0.0;
+      } break;
+      case OP_MUL_TIP: {
+         const int code = a.z[(long)op.a * a.z_stride + hc];
+         const double *pt = Ptip + (long)op.a * tipstride + code * N;
+#pragma unroll
+         for (int j = 0; j < N; j++) cur[j] *= pt[j];
+      } break;
+      case OP_PUSH: {
+#pragma unroll
+         for (int j = 0; j < N; j++) stk[op.b][j] = cur[j];
+      } break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         const double *P = Pint + (long)op.a * (N * N);
+         double out[N];
+#pragma unroll
+         for (int j = 0; j < N; j++) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) t = fma(P[j * N + k], cur[k], t);
+            out[j] = t;
+         }
+         if (op.code == OP_MATMUL) {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] = out[j];
+         }
+         else {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] = stk[op.b][j] * out[j];
+         }
+      } break;
+      case OP_SCALE: {
+         double mx = 0;
+#pragma unroll
+         for (int j = 0; j < N; j++) mx = cur[j] > mx ? cur[j] : mx;
+         double fac;
+         if (mx < 1e-300) {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] = 1.0;
+            fac = -800;
+         }
+         else {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] /= mx;
+            fac = log(mx);
+         }
+         lnscale += fac;
+         if (a.keep && valid) a.scalef[((long)iclass * a.n_scale + op.b) * a.n_patt + h] = fac;
+      } break;
+      case OP_STORE: {
+         if (valid) {
+            double *dst = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * a.n_patt + h) * N;
+#pragma unroll
+            for (int j = 0; j < N; j++) dst[j] = cur[j];
+         }
+      } break;
+      case OP_LOAD: {
+         const double *src = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * a.n_patt + hc) * N;
+#pragma unroll
+         for (int j = 0; j < N; j++) cur[j] = src[j];
+      } break;
+      case OP_ROOT: {
+         const double *pi = a.pi + (long)(a.n_pi > 1 ? gene : 0) * N;
+         double f = 0;
+#pragma unroll
+         for (int j = 0; j < N; j++) f = fma(pi[j], cur[j], f);
+         if (a.keep && a.n_scale) {
+            lnscale = 0;
+            if (valid)
+               for (int k = 0; k < a.n_scale; k++) lnscale += a.scalef[((long)iclass * a.n_scale + k) * a.n_patt + h];
+         }
+         if (valid) {
+            double out = 0;
+            if (a.weights[h] > 0) out = root_value(a, f, lnscale);
+            a.fhK[(long)iclass * a.n_patt + h] = out;
+         }
+      } break;
+      default: break;
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reduction: per-pattern class mixture + log (lfundG treesub.c:7630-7657, lfun 7796-7800), then a
+// fixed-order two-level sum of w_h * log f_h (deterministic for a given n_patt).
+// ------------------------------------------------------------------------------------------------
+struct ReduceArgs {
+   const double *fhK, *weights, *freqK;
+   double *lnf;        // optional [n_patt]
+   double *partial;    // [gridDim.x]
+   double *out;        // scalar
+   int n_patt, K, mode, n_scale, chunk;
+};
+
+__device__ __forceinline__ double pattern_lnf(const ReduceArgs &a, int h)
+{
+   if (a.mode == PAML_AMD_MODE_LFUN) return a.fhK[h];
+   double fh;
+   if (a.n_scale) {
+      int it = 0;
+      for (int ir = 1; ir < a.K; ir++)
+         if (a.fhK[(long)ir * a.n_patt + h] > a.fhK[(long)it * a.n_patt + h]) it = ir;
+      const double t = a.fhK[(long)it * a.n_patt + h];
+      fh = 0;
+      for (int ir = 0; ir < a.K; ir++) fh += a.freqK[ir] * exp(a.fhK[(long)ir * a.n_patt + h] - t);
+      return t + log(fh);
+   }
+   fh = 0;
+   for (int ir = 0; ir < a.K; ir++) fh += a.freqK[ir] * a.fhK[(long)ir * a.n_patt + h];
+   if (fh <= 0) fh = 1e-300;
+   return log(fh);
+}
+
+__global__ __launch_bounds__(256) void reduce_stage1(ReduceArgs a)
+{
+   __shared__ double sw[4];
+   const int lo = blockIdx.x * a.chunk;
+   const int hi = min(a.n_patt, lo + a.chunk);
+   double acc = 0;
+   for (int h = lo + threadIdx.x; h < hi; h += 256) {
+      double v = 0;
+      if (a.weights[h] > 0) {
+         v = pattern_lnf(a, h);
+         acc += v * a.weights[h];
+      }
+      if (a.lnf) a.lnf[h] = v;
+   }
+#pragma unroll
+   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+   __syncthreads();
+   if (threadIdx.x == 0) a.partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+__global__ __launch_bounds__(256) void reduce_stage2(const double *partial, int nb, double *out)
+{
+   __shared__ double sw[4];
+   double acc = 0;
+   for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
+#pragma unroll
+   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+   __syncthreads();
+   if (threadIdx.x == 0) *out = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+}  // namespace paml_amd

@@ -1,0 +1,132 @@
+// program.h — host side: flatten the post-order recursion of ConditionalPNode (codeml.c:3526-3582)
+// into a linear program for a small stack machine that every pattern executes in lock-step.
+//
+// Machine state per pattern: `cur` (the partial being accumulated) and a stack of saved partials.
+//   INIT_ONES            cur = 1                       (codeml.c:3539-3540)
+//   INIT_TIP  tip        cur = indicator(z[tip][h])    ("young ancestor", codeml.c:3535-3543)
+//   MUL_TIP   tip        cur[j] *= sum_{k in code(z[tip][h])} P_tip[j][k]     (codeml.c:3555-3567)
+//   PUSH      slot       stack[slot] = cur
+//   MATMUL    son        cur = P_son . cur             (cur holds the finished partial of `son`; 3568-3575)
+//   MATMUL_POP son slot  cur = stack[slot] * (P_son . cur)
+//   SCALE     slot node  NodeScale(node)               (treesub.c:7200-7230)
+//   STORE     node       partials[node] = cur          (keep-partials mode)
+//   LOAD      node       cur = partials[node]          (clean subtree, com.oldconP)
+//   ROOT                 f_h = sum_i pi_i cur[i]       (treesub.c:7728-7729)
+//
+// Internal sons are evaluated before tip sons and deepest-first (Sethi–Ullman order), so the first
+// internal son needs no PUSH and the stack depth is <= log2(n_tips); products commute, so only the
+// rounding order differs from the reference's sons[] order.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+namespace paml_amd {
+
+enum OpCode : int {
+   OP_INIT_ONES = 0, OP_INIT_TIP = 1, OP_MUL_TIP = 2, OP_PUSH = 3, OP_MATMUL = 4, OP_MATMUL_POP = 5,
+   OP_SCALE = 6, OP_STORE = 7, OP_LOAD = 8, OP_ROOT = 9, OP_END = 10
+};
+
+struct Op { int code, a, b, c; };   // a: node/tip, b: stack slot / scale slot, c: next MATMUL's son (-1 none)
+
+struct TreeDesc {
+   int n_tips = 0, n_nodes = 0, root = -1;
+   std::vector<int> sons_ptr, sons, label;
+   std::vector<unsigned char> scale_node;
+   std::vector<int> scale_slot;    // rank among scaling nodes (treesub.c:7207-7211), -1 if none
+   int n_scale = 0;
+   bool is_leaf(int i) const { return sons_ptr[i + 1] == sons_ptr[i]; }
+};
+
+struct Program {
+   std::vector<Op> ops;
+   int max_stack = 0;      // stack slots needed
+   int n_matmul = 0;
+};
+
+namespace detail {
+inline int stack_need(const TreeDesc &t, int node, const unsigned char *clean, std::vector<int> &need)
+{
+   if (need[node] >= 0) return need[node];
+   std::vector<int> kids;
+   for (int i = t.sons_ptr[node]; i < t.sons_ptr[node + 1]; i++) {
+      int s = t.sons[i];
+      if (!t.is_leaf(s)) kids.push_back((clean && clean[s]) ? 0 : stack_need(t, s, clean, need));
+   }
+   std::sort(kids.begin(), kids.end(), [](int a, int b) { return a > b; });
+   int d = 0;
+   for (size_t i = 0; i < kids.size(); i++) d = std::max(d, kids[i] + (i > 0 ? 1 : 0));
+   return need[node] = d;
+}
+
+inline void emit(const TreeDesc &t, int node, const unsigned char *clean, bool keep, std::vector<int> &need,
+                 int depth, Program &p)
+{
+   // internal sons, deepest first
+   std::vector<int> kids, tips;
+   for (int i = t.sons_ptr[node]; i < t.sons_ptr[node + 1]; i++) {
+      int s = t.sons[i];
+      (t.is_leaf(s) ? tips : kids).push_back(s);
+   }
+   std::stable_sort(kids.begin(), kids.end(), [&](int a, int b) {
+      int na = (clean && clean[a]) ? 0 : need[a], nb = (clean && clean[b]) ? 0 : need[b];
+      return na > nb;
+   });
+   bool have_cur = false;     // does `cur` already hold factors of this node?
+   if (node < t.n_tips) {     // the root is an observed sequence
+      p.ops.push_back({OP_INIT_TIP, node, 0, -1});
+      have_cur = true;
+   }
+   for (size_t i = 0; i < kids.size(); i++) {
+      int s = kids[i];
+      int slot = -1;
+      if (have_cur) {
+         slot = depth;
+         p.ops.push_back({OP_PUSH, node, slot, -1});
+         p.max_stack = std::max(p.max_stack, slot + 1);
+      }
+      if (clean && clean[s])
+         p.ops.push_back({OP_LOAD, s, 0, -1});
+      else
+         emit(t, s, clean, keep, need, have_cur ? depth + 1 : depth, p);
+      if (have_cur)
+         p.ops.push_back({OP_MATMUL_POP, s, slot, -1});
+      else
+         p.ops.push_back({OP_MATMUL, s, 0, -1});
+      p.n_matmul++;
+      have_cur = true;
+   }
+   if (!have_cur) p.ops.push_back({OP_INIT_ONES, node, 0, -1});
+   for (int s : tips) p.ops.push_back({OP_MUL_TIP, s, 0, -1});
+   if (!t.scale_node.empty() && t.scale_node[node]) p.ops.push_back({OP_SCALE, node, t.scale_slot[node], -1});
+   if (keep && node >= t.n_tips) p.ops.push_back({OP_STORE, node, 0, -1});
+}
+}  // namespace detail
+
+inline Program build_program(const TreeDesc &t, bool keep_partials, const unsigned char *clean)
+{
+   Program p;
+   std::vector<int> need(t.n_nodes, -1);
+   detail::stack_need(t, t.root, clean, need);
+   detail::emit(t, t.root, clean, keep_partials, need, 0, p);
+   p.ops.push_back({OP_ROOT, t.root, 0, -1});
+   p.ops.push_back({OP_END, 0, 0, -1});
+   // link every MATMUL to the next one so the kernel can prefetch its P while computing
+   int next = -1;
+   for (int i = (int)p.ops.size() - 1; i >= 0; i--) {
+      if (p.ops[i].code == OP_MATMUL || p.ops[i].code == OP_MATMUL_POP) {
+         p.ops[i].c = next;
+         next = p.ops[i].a;
+      }
+   }
+   return p;
+}
+
+inline int first_matmul(const Program &p)
+{
+   for (const Op &o : p.ops)
+      if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) return o.a;
+   return -1;
+}
+
+}  // namespace paml_amd

@@ -1,0 +1,255 @@
+"""ctypes binding of libpaml_amd.so (include/paml_amd.h) — thin, no torch types in the ABI.
+
+`Engine` mirrors the call sequence a PAML driver performs around com.plfun: create once per data
+set, upload tips/tree, then per evaluation set eigen systems / classes / branch lengths and evaluate.
+There is no CPU fallback: constructing an Engine without the built HIP library or without a GPU
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .problem import EIGEN_CIJK, EIGEN_JC69LIKE, EIGEN_K80, EIGEN_UVROOT, Problem
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpaml_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+KEEP_PARTIALS = 1
+
+EXPORTS = [
+    "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
+    "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
+    "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_classes", "paml_amd_eval",
+    "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
+    "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program",
+]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.h", "program.h")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "paml_amd.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH,
+           os.path.join(CSRC, "engine.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError("libpaml_amd.so is not built (run python -c 'import __graft_entry__ as g; g.build()')")
+        L = C.CDLL(LIB_PATH)
+        L.paml_amd_last_error.restype = C.c_char_p
+        L.paml_amd_kernel_name.restype = C.c_char_p
+        L.paml_amd_destroy.restype = None
+        L.paml_amd_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]
+        L.paml_amd_destroy.argtypes = [C.c_void_p]
+        L.paml_amd_last_error.argtypes = [C.c_void_p]
+        L.paml_amd_kernel_name.argtypes = [C.c_void_p]
+        L.paml_amd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.paml_amd_set_tips.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.paml_amd_set_tree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.paml_amd_set_pi.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.paml_amd_set_eigen_uvroot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.paml_amd_set_eigen_cijk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.paml_amd_set_eigen_k80.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.paml_amd_set_eigen_jc69like.argtypes = [C.c_void_p, C.c_int]
+        L.paml_amd_set_classes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.paml_amd_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+        L.paml_amd_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.paml_amd_eval_dirty.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.paml_amd_get_pmat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.paml_amd_get_partials.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.paml_amd_get_scale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.paml_amd_profile.argtypes = [C.c_void_p, C.c_int]
+        L.paml_amd_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
+        L.paml_amd_counters.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    def __init__(self, n_states, n_tips, n_patt, max_classes=1, n_genes=1, flags=0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.paml_amd_create(C.byref(h), n_states, n_tips, n_patt, max_classes, n_genes, flags)
+        if rc != 0:
+            raise EngineError("paml_amd_create failed (%d): no MI355X/HIP device visible or bad sizes" % rc)
+        self._h = h
+        self.n, self.n_tips, self.n_patt, self.n_genes = n_states, n_tips, n_patt, n_genes
+        self.K = 1
+        self.n_nodes = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.paml_amd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError("%s (code %d)" % (self._L.paml_amd_last_error(self._h).decode(), rc))
+
+    @property
+    def kernel_name(self):
+        return self._L.paml_amd_kernel_name(self._h).decode()
+
+    def set_stream(self, stream_ptr):
+        self._chk(self._L.paml_amd_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_tips(self, z, weights, cleandata=1, n_chara=None, chara_map=None, gene_off=None):
+        z = np.ascontiguousarray(z, dtype=np.uint8)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        assert z.shape == (self.n_tips, self.n_patt) and w.shape == (self.n_patt,)
+        nch = None if n_chara is None else np.ascontiguousarray(n_chara, dtype=np.int32)
+        cm = None if chara_map is None else np.ascontiguousarray(chara_map, dtype=np.uint8)
+        go = None if gene_off is None else np.ascontiguousarray(gene_off, dtype=np.int32)
+        self._chk(self._L.paml_amd_set_tips(self._h, _p(z), int(cleandata), 0 if nch is None else len(nch), _p(nch), _p(cm),
+                                            _p(w), _p(go)))
+
+    def set_tree(self, tree, scale_node=None):
+        ptr, flat = tree.csr()
+        lab = np.ascontiguousarray(tree.label, dtype=np.int32)
+        sc = None if scale_node is None else np.ascontiguousarray(scale_node, dtype=np.uint8)
+        self.n_nodes = tree.n_nodes
+        self._chk(self._L.paml_amd_set_tree(self._h, tree.n_nodes, tree.root, _p(ptr), _p(flat), _p(lab), _p(sc)))
+
+    def set_pi(self, pi):
+        pi = np.ascontiguousarray(np.atleast_2d(pi), dtype=np.float64)
+        self._chk(self._L.paml_amd_set_pi(self._h, pi.shape[0], _p(pi)))
+
+    def set_eigen(self, set_id, e):
+        k = e["kind"]
+        if k == EIGEN_UVROOT:
+            U, V, R = (np.ascontiguousarray(e[x], dtype=np.float64) for x in ("U", "V", "Root"))
+            self._chk(self._L.paml_amd_set_eigen_uvroot(self._h, set_id, _p(U), _p(V), _p(R)))
+        elif k == EIGEN_CIJK:
+            Cj, R = (np.ascontiguousarray(e[x], dtype=np.float64) for x in ("Cijk", "Root"))
+            self._chk(self._L.paml_amd_set_eigen_cijk(self._h, set_id, int(e["nR"]), _p(Cj), _p(R)))
+        elif k == EIGEN_K80:
+            self._chk(self._L.paml_amd_set_eigen_k80(self._h, set_id, float(e["kappa"])))
+        elif k == EIGEN_JC69LIKE:
+            self._chk(self._L.paml_amd_set_eigen_jc69like(self._h, set_id))
+        else:
+            raise ValueError(k)
+
+    def set_classes(self, mode, freqK, rate, eigen_of, qfactor=None):
+        f = np.ascontiguousarray(freqK, dtype=np.float64)
+        r = np.ascontiguousarray(rate, dtype=np.float64)
+        eo = np.ascontiguousarray(eigen_of, dtype=np.int32)
+        K = len(f)
+        n_labels = eo.size // (self.n_genes * K)
+        q = None if qfactor is None else np.ascontiguousarray(qfactor, dtype=np.float64)
+        self.K = K
+        self._chk(self._L.paml_amd_set_classes(self._h, int(mode), K, _p(f), _p(r), n_labels, _p(eo), _p(q)))
+
+    def load(self, pb: Problem):
+        """Upload everything a Problem holds (tips, tree, pi, eigen systems, classes)."""
+        self.set_tips(pb.z, pb.weights, pb.cleandata, None if pb.cleandata else pb.n_chara,
+                      None if pb.cleandata else pb.chara_map, pb.gene_off if pb.n_genes > 1 else None)
+        self.set_tree(pb.tree, pb.scale_node)
+        self.set_pi(pb.pi)
+        for i, e in enumerate(pb.eigen):
+            self.set_eigen(i, e)
+        self.set_classes(pb.mode, pb.freqK, pb.rate, pb.eigen_of, pb.qfactor)
+        return self
+
+    def eval(self, branch, gene_rate=None, want_lnf=False, want_fhk=False):
+        b = np.ascontiguousarray(branch, dtype=np.float64)
+        g = None if gene_rate is None else np.ascontiguousarray(gene_rate, dtype=np.float64)
+        lnL = C.c_double()
+        lnf = np.zeros(self.n_patt) if want_lnf else None
+        fhk = np.zeros((self.K, self.n_patt)) if want_fhk else None
+        self._chk(self._L.paml_amd_eval(self._h, _p(b), _p(g), C.byref(lnL), _p(lnf), _p(fhk)))
+        return dict(lnL=lnL.value, lnf=lnf, fhK=fhk)
+
+    def eval_device(self, branch, d_lnL_ptr, gene_rate=None):
+        b = np.ascontiguousarray(branch, dtype=np.float64)
+        g = None if gene_rate is None else np.ascontiguousarray(gene_rate, dtype=np.float64)
+        self._chk(self._L.paml_amd_eval_device(self._h, _p(b), _p(g), C.c_void_p(d_lnL_ptr)))
+
+    def eval_dirty(self, branch, clean, gene_rate=None):
+        b = np.ascontiguousarray(branch, dtype=np.float64)
+        c = np.ascontiguousarray(clean, dtype=np.uint8)
+        g = None if gene_rate is None else np.ascontiguousarray(gene_rate, dtype=np.float64)
+        lnL = C.c_double()
+        self._chk(self._L.paml_amd_eval_dirty(self._h, _p(b), _p(g), _p(c), C.byref(lnL)))
+        return lnL.value
+
+    def get_pmat(self, gene, iclass, node):
+        P = np.zeros((self.n, self.n))
+        self._chk(self._L.paml_amd_get_pmat(self._h, gene, iclass, node, _p(P)))
+        return P
+
+    def get_partials(self, node, iclass=0):
+        a = np.zeros((self.n_patt, self.n))
+        self._chk(self._L.paml_amd_get_partials(self._h, node, iclass, _p(a)))
+        return a
+
+    def get_scale(self, node, iclass=0):
+        a = np.zeros(self.n_patt)
+        self._chk(self._L.paml_amd_get_scale(self._h, node, iclass, _p(a)))
+        return a
+
+    def profile(self, on=True):
+        self._chk(self._L.paml_amd_profile(self._h, int(on)))
+
+    def profile_read(self):
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_long()
+        self._chk(self._L.paml_amd_profile_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return dict(ms_pmat=a.value, ms_prune=b.value, ms_reduce=c.value, n_evals=n.value)
+
+    def counters(self):
+        a, b = C.c_long(), C.c_long()
+        self._L.paml_amd_counters(self._h, C.byref(a), C.byref(b))
+        return dict(n_eval=a.value, n_pmat=b.value)
+
+
+def debug_program(tree, scale_node=None, keep=False, clean=None):
+    """Host-only: the flattened tree program (list of (code, a, b, c)) and its stack depth."""
+    L = lib()
+    ptr, flat = tree.csr()
+    sc = None if scale_node is None else np.ascontiguousarray(scale_node, dtype=np.uint8)
+    cl = None if clean is None else np.ascontiguousarray(clean, dtype=np.uint8)
+    cap = 8 * tree.n_nodes + 8
+    ops = np.zeros((cap, 4), dtype=np.int32)
+    ms = C.c_int()
+    L.paml_amd_debug_program.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    nops = L.paml_amd_debug_program(tree.n_tips, tree.n_nodes, tree.root, _p(ptr), _p(flat), _p(sc), int(keep), _p(cl),
+                                    _p(ops), cap, C.byref(ms))
+    if nops < 0:
+        raise EngineError("debug_program failed (%d)" % nops)
+    return [tuple(int(v) for v in r) for r in ops[:nops]], ms.value
+
+
+def engine_for(pb: Problem, flags=0) -> Engine:
+    return Engine(pb.n, pb.tree.n_tips, pb.n_patt, max_classes=pb.K, n_genes=pb.n_genes, flags=flags).load(pb)

@@ -1,0 +1,187 @@
+"""GPU parity tests proper: the HIP engine (through the C ABI) against the oracle on the same seeded
+inputs and against the reference-generated golden vectors.  FP64 throughout; tolerance 1e-10 relative
+on lnL (north_star asks for 1e-6), 1e-9 absolute on per-pattern log f_h."""
+import numpy as np
+import pytest
+
+import helpers
+import oracle
+from paml_amd import synth
+from paml_amd.engine import KEEP_PARTIALS, engine_for
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = ["hiv_m0", "hiv_m1a", "hiv_m2a", "hiv_m7", "hiv_m8", "syn_codon_m0", "syn_nuc_gtr_g4", "brown_hky85"]
+
+
+def check(pb, lnl_rtol=1e-10, lnf_atol=1e-9, flags=0):
+    ref = oracle.evaluate(pb, want_fhk=True)
+    eng = engine_for(pb, flags=flags)
+    out = eng.eval(pb.tree.branch, pb.gene_rate, want_lnf=True, want_fhk=True)
+    assert np.isfinite(out["lnL"])
+    assert abs(out["lnL"] - ref["lnL"]) <= lnl_rtol * abs(ref["lnL"]) + 1e-9, (out["lnL"], ref["lnL"])
+    assert np.max(np.abs(out["lnf"] - ref["lnf"])) < lnf_atol
+    m = pb.weights > 0
+    fk, rk = out["fhK"][:, m], ref["fhK"][:, m]
+    # a class whose f(x|class) is many orders below the dominant class (M7/M8 omega ~ 0) is a sum with heavy
+    # cancellation: compare it relative to the largest class of the same pattern
+    tol = 1e-9 * np.abs(rk) + 1e-12 * np.abs(rk).max(axis=0, keepdims=True)
+    assert (np.abs(fk - rk) <= tol).all(), float(np.max(np.abs(fk - rk) / np.abs(rk).max(axis=0, keepdims=True)))
+    return eng, out, ref
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_golden(name):
+    g = helpers.load_golden(name)
+    pb = helpers.problem_from_golden(g)
+    eng, out, ref = check(pb)
+    assert abs(out["lnL"] - g["lnL"]) <= 2e-6 + 1e-9 * abs(g["lnL"])
+    assert np.max(np.abs(out["lnf"] - np.array(g["logf"]))) < 2e-8
+    if g.get("counters"):
+        assert eng.counters()["n_pmat"] == g["counters"][2]
+
+
+@pytest.mark.parametrize("n,n_tips,n_patt,K", [(4, 5, 100, 1), (4, 32, 3000, 4), (5, 9, 257, 3), (20, 6, 130, 4),
+                                              (20, 24, 1000, 1), (61, 16, 1000, 1), (61, 13, 79, 11), (64, 7, 65, 2),
+                                              (60, 40, 200, 1), (21, 5, 16, 1), (2, 4, 50, 1)])
+def test_random_models(n, n_tips, n_patt, K):
+    pb = helpers.random_problem(n, n_tips, n_patt, K=K, seed=n * 1000 + n_tips)
+    check(pb)
+
+
+@pytest.mark.parametrize("n", [4, 20, 61])
+def test_pmat_matches_oracle(n):
+    pb = helpers.random_problem(n, 8, 40, K=3, seed=5)
+    pb.tree.branch[2] = 0.0            # t < 1e-100 -> identity (tools.c:525)
+    pb.tree.branch[3] = 1e-120
+    eng = engine_for(pb)
+    eng.eval(pb.tree.branch)
+    for node in range(pb.tree.n_nodes):
+        if node == pb.tree.root:
+            continue
+        for ic in range(pb.K):
+            P = eng.get_pmat(0, ic, node)
+            Pr = oracle.pmat_branch(pb, 0, ic, node)
+            assert np.max(np.abs(P - Pr)) < 1e-13
+    assert np.array_equal(eng.get_pmat(0, 0, 2), np.eye(n))
+
+
+@pytest.mark.parametrize("n", [4, 20, 61])
+def test_ambiguity_codes(n):
+    pb = helpers.random_problem(n, 10, 300, K=2, seed=77, ambiguity=True)
+    check(pb)
+
+
+@pytest.mark.parametrize("n,every", [(4, 3), (20, 4), (61, 3)])
+def test_node_scaling(n, every):
+    pb = helpers.random_problem(n, 30, 200, K=1, seed=9, scale_every=every)
+    assert pb.scale_node.sum() >= 2
+    check(pb)
+    pbk = helpers.random_problem(n, 30, 200, K=3, seed=10, scale_every=every)   # lfundG log-sum-exp branch
+    check(pbk)
+
+
+@pytest.mark.parametrize("n", [4, 61])
+def test_scaling_underflow_branch(n):
+    """Force max < 1e-300 at a scaled node (treesub.c:7218-7221: partials := 1, factor := -800)."""
+    pb = helpers.random_problem(n, 12, 64, K=1, seed=3, scale_every=2)
+    for e in pb.eigen:
+        e["U"] = e["U"] * 1e-200          # off-diagonal P entries ~1e-200: partials of mismatching tips underflow
+    rng = np.random.default_rng(0)
+    pb.z[:] = rng.integers(0, n, size=pb.z.shape)
+    ref = oracle.evaluate(pb, want_partials=True)
+    assert (ref["scalef"] == -800).any()
+    check(pb, lnl_rtol=1e-9)
+
+
+@pytest.mark.parametrize("n", [4, 20, 61])
+def test_multigene_and_polytomy(n):
+    pb = helpers.random_problem(n, 11, 500, K=2, seed=21, n_genes=3, polytomy=True)
+    check(pb)
+
+
+@pytest.mark.parametrize("n", [4, 61])
+def test_zero_weight_patterns_skipped(n):
+    pb = helpers.random_problem(n, 6, 90, K=1, seed=4)
+    pb.weights[::7] = 0
+    check(pb)
+
+
+@pytest.mark.parametrize("n", [4, 20, 61])
+def test_keep_partials_and_dirty_eval(n):
+    pb = helpers.random_problem(n, 14, 150, K=2, seed=31, scale_every=4)
+    ref = oracle.evaluate(pb, want_partials=True)
+    eng, out, _ = check(pb, flags=KEEP_PARTIALS)
+    t = pb.tree
+    for node in range(t.n_tips, t.n_nodes):
+        for ic in range(pb.K):
+            got = eng.get_partials(node, ic)
+            assert np.allclose(got, ref["partials"][ic, node - t.n_tips], rtol=1e-11, atol=1e-300)
+    k = 0
+    for node in range(t.n_nodes):
+        if pb.scale_node[node]:
+            assert np.allclose(eng.get_scale(node, 1), ref["scalef"][1, k], rtol=1e-12)
+            k += 1
+    # change one tip branch: every node off the path to the root stays clean (com.oldconP)
+    father = t.father()
+    tip = 3
+    br = t.branch.copy()
+    br[tip] *= 1.7
+    clean = np.ones(t.n_nodes, dtype=np.uint8)
+    node = tip
+    while node != -1:
+        clean[node] = 0
+        node = father[node]
+    lnl_dirty = eng.eval_dirty(br, clean)
+    pb2 = helpers.random_problem(n, 14, 150, K=2, seed=31, scale_every=4)
+    pb2.tree.branch[:] = br
+    ref2 = oracle.evaluate(pb2)
+    assert abs(lnl_dirty - ref2["lnL"]) <= 1e-10 * abs(ref2["lnL"])
+
+
+def test_young_ancestor_root_is_tip():
+    """Rooted tree whose root is an observed sequence (codeml.c:3535-3543)."""
+    from paml_amd.problem import Tree
+    done = 0
+    for n in (4, 61):
+        for seed in range(8, 40):
+            pb = helpers.random_problem(n, 6, 120, K=1, seed=seed)
+            t = pb.tree
+            tip_sons = [s for s in t.sons[t.root] if s < t.n_tips]
+            if not tip_sons:
+                continue
+            tip = tip_sons[0]
+            sons = [list(s) for s in t.sons]
+            sons[t.root].remove(tip)
+            sons[tip] = [t.root]
+            br = t.branch.copy()
+            br[t.root] = br[tip]
+            br[tip] = 0
+            pb.tree = Tree(t.n_tips, t.n_nodes, tip, sons, br, t.label)
+            check(pb)
+            done += 1
+            break
+    assert done == 2
+
+
+def test_full_size_properties_c4():
+    """BASELINE configs[3] at full size (16 taxa x 1e6 codon patterns): size-independent checks —
+    lnL equals the sum of per-pattern log f_h, pattern order does not matter, and a strided sample
+    of patterns agrees with the oracle."""
+    pb = synth.codon_m0_problem(n_tips=16, n_patt=1_000_000)
+    eng = engine_for(pb)
+    out = eng.eval(pb.tree.branch, want_lnf=True)
+    assert abs(out["lnf"].sum() - out["lnL"]) < 1e-9 * abs(out["lnL"])
+    idx = np.arange(0, pb.n_patt, 997)
+    sub = pb.slice_patterns(0, pb.n_patt)
+    sub.z = np.ascontiguousarray(pb.z[:, idx])
+    sub.weights = np.ascontiguousarray(pb.weights[idx])
+    sub.gene_off = np.array([0, len(idx)], dtype=np.int32)
+    ref = oracle.evaluate(sub)
+    assert np.max(np.abs(out["lnf"][idx] - ref["lnf"])) < 1e-9
+    perm = np.random.default_rng(1).permutation(pb.n_patt)
+    pb2 = pb.slice_patterns(0, pb.n_patt)
+    pb2.z = np.ascontiguousarray(pb.z[:, perm])
+    out2 = engine_for(pb2).eval(pb.tree.branch, want_lnf=True)
+    assert np.max(np.abs(out2["lnf"] - out["lnf"][perm])) == 0.0      # per-pattern results are order-independent, bitwise
+    assert abs(out2["lnL"] - out["lnL"]) < 1e-9 * abs(out["lnL"])
