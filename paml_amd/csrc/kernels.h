@@ -221,18 +221,46 @@ __device__ __forceinline__ double root_value(const PruneArgs &a, double f, doubl
 // partials.  The A operand (P) is staged once per workgroup per branch into LDS in exactly the order
 // lanes consume it (pmat_kernel's `frag` layout), double-buffered so the next branch's P streams in
 // under the current MFMAs.  Tip branches are gathers from L2-resident column tables.
-#define MFMA_RS 3   // register stack slots; deeper slots spill to global scratch
+#define MFMA_RS 2      // register stack slots; deeper slots spill to global scratch
+#define MFMA_ZT 128    // tips whose codes are staged in LDS per workgroup
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// Stage one 32 KB P (already in MFMA operand order) global -> LDS with the LDS-DMA path: each wave
+// instruction moves 64 lanes x 16 B = 1 KiB to a wave-uniform LDS base, no VGPR round trip.
+template <int WAVES>
+__device__ __forceinline__ void stage_p(const double *g, double *s, int wave, int lane)
+{
+#pragma unroll
+   for (int c = 0; c < 32 / WAVES; c++) {
+      const int chunk = c * WAVES + wave;   // wave-uniform
+      __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)g + chunk * 1024 + lane * 16),
+                                       (lptr_t *)((char *)s + chunk * 1024), 16, 0, 0);
+   }
+}
+
+__device__ __forceinline__ void tip_load(const double *Ptip, long tipstride, int tip, int code, int q, double2 (&v)[8])
+{
+   const double2 *pt = (const double2 *)(Ptip + (long)tip * tipstride + (code * 4 + q) * 16);
+#pragma unroll
+   for (int i = 0; i < 8; i++) v[i] = pt[i];
+}
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void prune_mfma64(PruneArgs a)
+__global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64(PruneArgs a)
 {
    __shared__ __attribute__((aligned(16))) double sP[2][4096];
-   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   __shared__ unsigned char sZ[MFMA_ZT * WAVES * 16];
+   constexpr int TP = WAVES * 16;     // patterns per workgroup
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int q = lane >> 4, hl = lane & 15;
    const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;
    const int gene = a.tiles[tile].x, h0 = a.tiles[tile].y;
    const int hend = a.gene_off[gene + 1];
-   const int h = h0 + wave * 16 + hl;
+   const int hw = wave * 16 + hl;          // pattern within the tile
+   const int h = h0 + hw;
    const bool valid = h < hend;
    const int hc = valid ? h : hend - 1;
    const long pset = (long)gene * a.K + iclass;
@@ -241,20 +269,24 @@ __global__ __launch_bounds__(WAVES * 64) void prune_mfma64(PruneArgs a)
    const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
    const int n = a.n;
 
-   double cur[16], s0[16], s1[16], s2[16];
+   if (a.first_matmul >= 0) stage_p<WAVES>(Pint + (long)a.first_matmul * 4096, sP[0], wave, lane);
+   {  // character codes of this tile's patterns for the first MFMA_ZT tips -> LDS
+      const int nz = (a.n_tips < MFMA_ZT ? a.n_tips : MFMA_ZT) * TP;
+      for (int idx = tid; idx < nz; idx += WAVES * 64) {
+         const int tip = idx / TP, hh = idx % TP;
+         const int hx = h0 + hh < hend ? h0 + hh : hend - 1;
+         sZ[idx] = a.z[(long)tip * a.z_stride + hx];
+      }
+   }
+   __syncthreads();
+
+   double cur[16], s0[16], s1[16];
    double lnscale = 0;
    int buf = 0;
 #pragma unroll
-   for (int m = 0; m < 16; m++) cur[m] = s0[m] = s1[m] = s2[m] = 0;
+   for (int m = 0; m < 16; m++) cur[m] = s0[m] = s1[m] = 0;
 
-   constexpr int NT = WAVES * 64;
-   constexpr int STAGE_IT = 2048 / NT;     // double2 elements per thread
-   if (a.first_matmul >= 0) {
-      const double2 *g = (const double2 *)(Pint + (long)a.first_matmul * 4096);
-      double2 *s = (double2 *)sP[0];
-#pragma unroll
-      for (int i = 0; i < STAGE_IT; i++) s[i * NT + tid] = g[i * NT + tid];
-   }
+#define TIP_CODE(tip) ((tip) < MFMA_ZT ? (int)sZ[(tip)*TP + hw] : (int)a.z[(long)(tip)*a.z_stride + hc])
 
    for (int ip = 0;; ip++) {
       const Op op = a.ops[ip];
@@ -265,18 +297,37 @@ __global__ __launch_bounds__(WAVES * 64) void prune_mfma64(PruneArgs a)
          for (int m = 0; m < 16; m++) cur[m] = (4 * m + q < n) ? 1.0 : 0.0;
       } break;
       case OP_INIT_TIP: {
-         const int code = a.z[(long)op.a * a.z_stride + hc];
+         const int code = TIP_CODE(op.a);
 #pragma unroll
          for (int m = 0; m < 16; m++) cur[m] = (a.cleandata && 4 * m + q == code) ? 1.0 : 0.0;
       } break;
       case OP_MUL_TIP: {
-         const int code = a.z[(long)op.a * a.z_stride + hc];
-         const double2 *pt = (const double2 *)(Ptip + (long)op.a * tipstride + (code * 4 + q) * 16);
+         double2 v[8];
+         tip_load(Ptip, tipstride, op.a, TIP_CODE(op.a), q, v);
+#pragma unroll
+         for (int i = 0; i < 8; i++) { cur[2 * i] *= v[i].x; cur[2 * i + 1] *= v[i].y; }
+      } break;
+      case OP_SET_TIP: {
+         double2 v[8];
+         tip_load(Ptip, tipstride, op.a, TIP_CODE(op.a), q, v);
+#pragma unroll
+         for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x; cur[2 * i + 1] = v[i].y; }
+      } break;
+      case OP_SET_TIP2: {
+         double2 v[8], w[8];
+         tip_load(Ptip, tipstride, op.a, TIP_CODE(op.a), q, v);
+         tip_load(Ptip, tipstride, op.b, TIP_CODE(op.b), q, w);
+#pragma unroll
+         for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x * w[i].x; cur[2 * i + 1] = v[i].y * w[i].y; }
+      } break;
+      case OP_MUL_TIP2: {
+         double2 v[8], w[8];
+         tip_load(Ptip, tipstride, op.a, TIP_CODE(op.a), q, v);
+         tip_load(Ptip, tipstride, op.b, TIP_CODE(op.b), q, w);
 #pragma unroll
          for (int i = 0; i < 8; i++) {
-            double2 v = pt[i];
-            cur[2 * i] *= v.x;
-            cur[2 * i + 1] *= v.y;
+            cur[2 * i] = (cur[2 * i] * v[i].x) * w[i].x;
+            cur[2 * i + 1] = (cur[2 * i + 1] * v[i].y) * w[i].y;
          }
       } break;
       case OP_PUSH: {
@@ -288,10 +339,6 @@ __global__ __launch_bounds__(WAVES * 64) void prune_mfma64(PruneArgs a)
 #pragma unroll
             for (int m = 0; m < 16; m++) s1[m] = cur[m];
          }
-         else if (op.b == 2) {
-#pragma unroll
-            for (int m = 0; m < 16; m++) s2[m] = cur[m];
-         }
          else {
             double *sp = a.stack_scratch +
                          (((long)blockIdx.x * a.stack_overflow_slots + (op.b - MFMA_RS)) * WAVES + wave) * 1024;
@@ -301,13 +348,8 @@ __global__ __launch_bounds__(WAVES * 64) void prune_mfma64(PruneArgs a)
       } break;
       case OP_MATMUL:
       case OP_MATMUL_POP: {
-         __syncthreads();   // staged P[buf] visible; every wave is done reading P[buf^1]
-         double2 nxt[STAGE_IT];
-         if (op.c >= 0) {
-            const double2 *g = (const double2 *)(Pint + (long)op.c * 4096);
-#pragma unroll
-            for (int i = 0; i < STAGE_IT; i++) nxt[i] = g[i * NT + tid];
-         }
+         __syncthreads();   // this branch's P has landed in sP[buf]; every wave is done reading sP[buf^1]
+         if (op.c >= 0) stage_p<WAVES>(Pint + (long)op.c * 4096, sP[buf ^ 1], wave, lane);
          v4d acc[4];
 #pragma unroll
          for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0, 0, 0, 0};
@@ -339,12 +381,6 @@ __global__ __launch_bounds__(WAVES * 64) void prune_mfma64(PruneArgs a)
 #pragma unroll
                for (int r = 0; r < 4; r++) cur[4 * jb + r] = s1[4 * jb + r] * acc[jb][r];
          }
-         else if (op.b == 2) {
-#pragma unroll
-            for (int jb = 0; jb < 4; jb++)
-#pragma unroll
-               for (int r = 0; r < 4; r++) cur[4 * jb + r] = s2[4 * jb + r] * acc[jb][r];
-         }
          else {
             const double *sp2 = a.stack_scratch +
                                 (((long)blockIdx.x * a.stack_overflow_slots + (op.b - MFMA_RS)) * WAVES + wave) * 1024;
@@ -352,11 +388,6 @@ __global__ __launch_bounds__(WAVES * 64) void prune_mfma64(PruneArgs a)
             for (int jb = 0; jb < 4; jb++)
 #pragma unroll
                for (int r = 0; r < 4; r++) cur[4 * jb + r] = sp2[(4 * jb + r) * 64 + lane] * acc[jb][r];
-         }
-         if (op.c >= 0) {
-            double2 *s = (double2 *)sP[buf ^ 1];
-#pragma unroll
-            for (int i = 0; i < STAGE_IT; i++) s[i * NT + tid] = nxt[i];
          }
          buf ^= 1;
       } break;
@@ -383,7 +414,7 @@ __global__ __launch_bounds__(WAVES * 64) void prune_mfma64(PruneArgs a)
          if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + op.b) * a.n_patt + h] = fac;
       } break;
       case OP_STORE: {
-         // native layout [class][node][tile16][m][lane]; n_patt rounded up to tiles of 16 per gene tile table
+         // native layout [class][node][16-pattern group][m][lane]
          double *dst = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) +
                                      ((long)tile * WAVES + wave)) * 1024;
 #pragma unroll
@@ -416,6 +447,7 @@ __global__ __launch_bounds__(WAVES * 64) void prune_mfma64(PruneArgs a)
       default: break;
       }
    }
+#undef TIP_CODE
 }
 
 // ---- valu<N>: 4 / 5 / 20 states, one pattern per lane ------------------------------------------
@@ -461,6 +493,26 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
          const double *pt = Ptip + (long)op.a * tipstride + code * N;
 #pragma unroll
          for (int j = 0; j < N; j++) cur[j] *= pt[j];
+      } break;
+      case OP_SET_TIP: {
+         const int code = a.z[(long)op.a * a.z_stride + hc];
+         const double *pt = Ptip + (long)op.a * tipstride + code * N;
+#pragma unroll
+         for (int j = 0; j < N; j++) cur[j] = pt[j];
+      } break;
+      case OP_SET_TIP2:
+      case OP_MUL_TIP2: {
+         const int c1 = a.z[(long)op.a * a.z_stride + hc], c2 = a.z[(long)op.b * a.z_stride + hc];
+         const double *p1 = Ptip + (long)op.a * tipstride + c1 * N;
+         const double *p2 = Ptip + (long)op.b * tipstride + c2 * N;
+         if (op.code == OP_SET_TIP2) {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] = p1[j] * p2[j];
+         }
+         else {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] = (cur[j] * p1[j]) * p2[j];
+         }
       } break;
       case OP_PUSH: {
 #pragma unroll

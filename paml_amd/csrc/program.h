@@ -24,7 +24,11 @@ namespace paml_amd {
 
 enum OpCode : int {
    OP_INIT_ONES = 0, OP_INIT_TIP = 1, OP_MUL_TIP = 2, OP_PUSH = 3, OP_MATMUL = 4, OP_MATMUL_POP = 5,
-   OP_SCALE = 6, OP_STORE = 7, OP_LOAD = 8, OP_ROOT = 9, OP_END = 10
+   OP_SCALE = 6, OP_STORE = 7, OP_LOAD = 8, OP_ROOT = 9, OP_END = 10,
+   // fused forms produced by the peephole pass (same arithmetic, fewer dependent memory round trips):
+   OP_SET_TIP = 11,    // cur = tipcol(a)                 == INIT_ONES ; MUL_TIP a
+   OP_SET_TIP2 = 12,   // cur = tipcol(a) * tipcol(b)     == INIT_ONES ; MUL_TIP a ; MUL_TIP b   (a cherry)
+   OP_MUL_TIP2 = 13    // cur *= tipcol(a) * tipcol(b)    == MUL_TIP a ; MUL_TIP b
 };
 
 struct Op { int code, a, b, c; };   // a: node/tip, b: stack slot / scale slot, c: next MATMUL's son (-1 none)
@@ -111,6 +115,20 @@ inline Program build_program(const TreeDesc &t, bool keep_partials, const unsign
    detail::emit(t, t.root, clean, keep_partials, need, 0, p);
    p.ops.push_back({OP_ROOT, t.root, 0, -1});
    p.ops.push_back({OP_END, 0, 0, -1});
+   // peephole: fuse tip factors so their table gathers are issued together
+   {
+      std::vector<Op> f;
+      const std::vector<Op> &o = p.ops;
+      for (size_t i = 0; i < o.size();) {
+         const bool t1 = i + 1 < o.size() && o[i + 1].code == OP_MUL_TIP;
+         const bool t2 = i + 2 < o.size() && o[i + 2].code == OP_MUL_TIP;
+         if (o[i].code == OP_INIT_ONES && t1 && t2) { f.push_back({OP_SET_TIP2, o[i + 1].a, o[i + 2].a, -1}); i += 3; }
+         else if (o[i].code == OP_INIT_ONES && t1) { f.push_back({OP_SET_TIP, o[i + 1].a, 0, -1}); i += 2; }
+         else if (o[i].code == OP_MUL_TIP && t1) { f.push_back({OP_MUL_TIP2, o[i].a, o[i + 1].a, -1}); i += 2; }
+         else { f.push_back(o[i]); i += 1; }
+      }
+      p.ops.swap(f);
+   }
    // link every MATMUL to the next one so the kernel can prefetch its P while computing
    int next = -1;
    for (int i = (int)p.ops.size() - 1; i >= 0; i--) {

@@ -13,7 +13,8 @@ import oracle
 from paml_amd import engine
 from paml_amd.problem import set_node_scale
 
-OP = dict(INIT_ONES=0, INIT_TIP=1, MUL_TIP=2, PUSH=3, MATMUL=4, MATMUL_POP=5, SCALE=6, STORE=7, LOAD=8, ROOT=9, END=10)
+OP = dict(INIT_ONES=0, INIT_TIP=1, MUL_TIP=2, PUSH=3, MATMUL=4, MATMUL_POP=5, SCALE=6, STORE=7, LOAD=8, ROOT=9, END=10,
+          SET_TIP=11, SET_TIP2=12, MUL_TIP2=13)
 
 
 @pytest.fixture(scope="module")
@@ -71,6 +72,12 @@ def interpret(pb, ops, iclass=0, clean_partials=None):
                 cur[np.arange(npatt), pb.z[a]] = 1
         elif code == OP["MUL_TIP"]:
             cur = cur * tipfac(a)
+        elif code == OP["SET_TIP"]:
+            cur = tipfac(a)
+        elif code == OP["SET_TIP2"]:
+            cur = tipfac(a) * tipfac(b)
+        elif code == OP["MUL_TIP2"]:
+            cur = (cur * tipfac(a)) * tipfac(b)
         elif code == OP["PUSH"]:
             stack[b] = cur
         elif code == OP["MATMUL"]:
