@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,7 +18,12 @@ using namespace paml_amd;
 namespace {
 
 enum KernelKind { KK_VALU4, KK_VALU5, KK_VALU20, KK_MFMA64 };
-constexpr int MFMA_WAVES = 4;          // waves per workgroup of the mfma64 kernel (64 patterns)
+#ifndef PAML_AMD_DMA_DBUF
+#define PAML_AMD_DMA_DBUF 0
+#endif
+constexpr bool DMA_DBUF = PAML_AMD_DMA_DBUF != 0;
+constexpr int DMA_WAVES = DMA_DBUF ? 8 : 4;   // mfma64 "dma" kernel: 8 waves + double-buffered P (1 WG/CU) or 4 waves + single P (2 WG/CU)
+constexpr int GATHER_WAVES = 4;        // mfma64 "gather" kernel: 64 patterns per workgroup, 2 per CU
 constexpr int VALU_MAXD_SMALL = 16, VALU_MAXD_20 = 8;
 
 template <typename T>
@@ -94,6 +100,8 @@ struct paml_amd_engine {
    int n = 0, n_tips = 0, n_patt = 0, max_classes = 0, n_genes = 1;
    unsigned flags = 0;
    KernelKind kk = KK_MFMA64;
+   bool mfma_dma = true;     // which mfma64 variant (dma needs n_tips <= MFMA_ZT)
+   int mfma_waves = DMA_WAVES;
    int tile_patt = 64;
    hipStream_t stream = nullptr;
    std::string err;
@@ -275,10 +283,28 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
    HIPCHK(e->d_ptip.ensure((size_t)psets * nn * e->n_codes * tipw(e)));
    HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
+   // the lean dma kernel runs programs made only of INIT / tip / MATMUL / ROOT ops with a register stack;
+   // anything else (node scaling, keep-partials STORE/LOAD, deep stacks, > MFMA_ZT tips) takes the full
+   // "gather" kernel, whose workgroups cover 64 patterns instead of 128
+   if (e->kk == KK_MFMA64) {
+      bool lean = e->prog.max_stack <= MFMA_RS && e->n_tips <= MFMA_ZT && !getenv("PAML_AMD_FORCE_GATHER");
+      for (const Op &o : e->prog.ops)
+         if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
+      if (lean != e->mfma_dma) {
+         e->mfma_dma = lean;
+         e->mfma_waves = lean ? DMA_WAVES : GATHER_WAVES;
+         e->tile_patt = e->mfma_waves * 16;
+         int r = build_tiles(e);
+         if (r) return r;
+         e->partials_valid = false;
+         if (clean) return fail(e, PAML_AMD_EINVAL, "eval_dirty: kernel layout changed; run a full evaluation first");
+      }
+   }
+   const bool use_dma = e->mfma_dma;
    const int n_blocks = e->n_tiles * K;
    const int n_int = nn - e->n_tips;
    if (keep) {
-      size_t words = e->kk == KK_MFMA64 ? (size_t)K * n_int * e->n_tiles * MFMA_WAVES * 1024
+      size_t words = e->kk == KK_MFMA64 ? (size_t)K * n_int * e->n_tiles * e->mfma_waves * 1024
                                         : (size_t)K * n_int * e->n_patt * n;
       HIPCHK(e->d_partials.ensure(words));
       HIPCHK(e->d_scalef.ensure((size_t)K * std::max(1, e->tree.n_scale) * e->n_patt));
@@ -286,7 +312,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    int overflow = 0;
    if (e->kk == KK_MFMA64 && e->prog.max_stack > MFMA_RS) {
       overflow = e->prog.max_stack - MFMA_RS;
-      HIPCHK(e->d_stack.ensure((size_t)n_blocks * overflow * MFMA_WAVES * 1024));
+      HIPCHK(e->d_stack.ensure((size_t)n_blocks * overflow * e->mfma_waves * 1024));
    }
 
    // Kernel A: batched P(t)
@@ -311,11 +337,34 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.keep = keep ? 1 : 0; pr.n_patt = e->n_patt;
    pr.pi = e->d_pi.p; pr.pint = e->kk == KK_MFMA64 ? e->d_pint.p : e->d_rowmajor.p; pr.ptip = e->d_ptip.p;
    pr.fhK = e->d_fhK.p; pr.partials = e->d_partials.p; pr.scalef = e->d_scalef.p; pr.stack_scratch = e->d_stack.p;
-   pr.stack_overflow_slots = overflow; pr.first_matmul = first_matmul(e->prog); pr.n_int = n_int;
+   pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
+   pr.first_tip = e->prog.first_tip;
+#ifdef PROF_OPS
+   static unsigned long long *d_prof = nullptr;
+   const int prof_stride = (int)e->prog.ops.size() + 3;
+   if (getenv("PAML_AMD_PROF_OPS")) {
+      if (d_prof) (void)hipFree(d_prof);
+      HIPCHK(hipMalloc((void **)&d_prof, (size_t)3 * n_blocks * prof_stride * 8));
+      HIPCHK(hipMemsetAsync(d_prof, 0, (size_t)3 * n_blocks * prof_stride * 8, e->stream));
+      pr.prof = d_prof;
+      pr.prof_stride = prof_stride;
+   }
+#endif
    mark(e);
    switch (e->kk) {
    case KK_MFMA64:
-      hipLaunchKernelGGL(prune_mfma64<MFMA_WAVES>, dim3(n_blocks), dim3(MFMA_WAVES * 64), 0, e->stream, pr);
+      if (use_dma) {
+         const size_t lds = (size_t)((DMA_DBUF ? 2 : 1) * 4096 + DMA_WAVES * 1024) * sizeof(double) + (size_t)e->n_tips * DMA_WAVES * 16;
+         static bool attr_set = false;
+         if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute((const void *)(prune_mfma64_dma<DMA_WAVES, DMA_DBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024));
+            attr_set = true;
+         }
+         hipLaunchKernelGGL((prune_mfma64_dma<DMA_WAVES, DMA_DBUF>), dim3(n_blocks), dim3(DMA_WAVES * 64), lds, e->stream, pr);
+      }
+      else
+         hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, e->stream, pr);
       break;
    case KK_VALU4:
       hipLaunchKernelGGL((prune_valu<4, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
@@ -328,6 +377,23 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       break;
    }
    mark(e);
+#ifdef PROF_OPS
+   if (pr.prof) {
+      std::vector<unsigned long long> hp((size_t)3 * n_blocks * prof_stride);
+      HIPCHK(hipMemcpyAsync(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      FILE *f = fopen(getenv("PAML_AMD_PROF_OPS"), "wb");
+      if (f) {
+         int hdr[2] = {n_blocks, prof_stride};
+         fwrite(hdr, sizeof(int), 2, f);
+         std::vector<int> codes;
+         for (auto &o : e->prog.ops) codes.push_back(o.code);
+         fwrite(codes.data(), sizeof(int), codes.size(), f);
+         fwrite(hp.data(), 8, hp.size(), f);
+         fclose(f);
+      }
+   }
+#endif
 
    // Kernel C: mixture + log + weighted sum
    const int chunk = std::max(256, ((e->n_patt + 1023) / 1024 + 255) / 256 * 256);
@@ -370,7 +436,9 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    else if (n_states == 5) e->kk = KK_VALU5;
    else if (n_states == 20) e->kk = KK_VALU20;
    else e->kk = KK_MFMA64;
-   e->tile_patt = e->kk == KK_MFMA64 ? MFMA_WAVES * 16 : 256;
+   e->mfma_dma = n_tips <= MFMA_ZT && !getenv("PAML_AMD_FORCE_GATHER");
+   e->mfma_waves = e->mfma_dma ? DMA_WAVES : GATHER_WAVES;
+   e->tile_patt = e->kk == KK_MFMA64 ? e->mfma_waves * 16 : 256;
    *out = e;
    return 0;
 }
@@ -391,7 +459,7 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
    case KK_VALU4: return "valu4";
    case KK_VALU5: return "valu5";
    case KK_VALU20: return "valu20";
-   default: return "mfma64";
+   default: return e->mfma_dma ? "mfma64_dma" : "mfma64_gather";
    }
 }
 
@@ -653,7 +721,8 @@ int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP
       HIPCHK(hipStreamSynchronize(e->stream));
       return 0;
    }
-   const size_t groups = (size_t)e->n_tiles * MFMA_WAVES;
+   const int MW = e->mfma_waves;
+   const size_t groups = (size_t)e->n_tiles * MW;
    std::vector<double> raw(groups * 1024);
    const double *src = e->d_partials.p + ((size_t)iclass * n_int + (node - e->n_tips)) * groups * 1024;
    HIPCHK(hipMemcpyAsync(raw.data(), src, raw.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -664,11 +733,11 @@ int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP
       for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += e->tile_patt) tiles.push_back(make_int2(g, h));
    for (size_t t = 0; t < tiles.size(); t++) {
       const int hend = e->gene_off[tiles[t].x + 1];
-      for (int w = 0; w < MFMA_WAVES; w++)
+      for (int w = 0; w < MW; w++)
          for (int hl = 0; hl < 16; hl++) {
             const int h = tiles[t].y + w * 16 + hl;
             if (h >= hend) continue;
-            const double *grp = raw.data() + (t * MFMA_WAVES + w) * 1024;
+            const double *grp = raw.data() + (t * MW + w) * 1024;
             for (int j = 0; j < n; j++) conP[(size_t)h * n + j] = grp[(j >> 2) * 64 + (j & 3) * 16 + hl];
          }
    }

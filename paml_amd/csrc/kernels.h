@@ -202,6 +202,9 @@ struct PruneArgs {
    int stack_overflow_slots;
    int first_matmul;
    int n_int;                  // n_nodes - n_tips
+   int first_tip;              // first tip whose column table is consumed (dma kernel prefetch)
+   unsigned long long *prof;   // PROF_OPS builds only: [block][op] s_memtime stamps of thread 0
+   int prof_stride;
 };
 
 __device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)
@@ -222,25 +225,218 @@ __device__ __forceinline__ double root_value(const PruneArgs &a, double f, doubl
 // lanes consume it (pmat_kernel's `frag` layout), double-buffered so the next branch's P streams in
 // under the current MFMAs.  Tip branches are gathers from L2-resident column tables.
 #define MFMA_RS 2      // register stack slots; deeper slots spill to global scratch
-#define MFMA_ZT 128    // tips whose codes are staged in LDS per workgroup
+#define MFMA_ZT 128    // most tips whose codes the dma kernel keeps in LDS
+
+// Wave-uniform, read-only data (the tree program, tile table, P(t) entries of the VALU kernels) is read
+// through the constant address space so the compiler uses scalar loads (s_load, lgkmcnt) instead of a
+// vector load + vmcnt(0) wait that would also drain the in-flight LDS-DMA prefetches.
+#define CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const CONST_AS T *as_const(const T *p)
+{
+   return (const CONST_AS T *)(unsigned long long)p;
+}
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Op fetch_op(const Op *ops, int ip)
+{
+   const v4i o = ((const CONST_AS v4i *)(unsigned long long)ops)[ip];   // one s_load_dwordx4
+   return Op{o.x, o.y, o.z, o.w};
+}
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
+
+// LDS-DMA through a raw buffer descriptor: address = SGPR descriptor base + 32-bit VGPR offset + SGPR
+// offset, so no 64-bit per-lane pointers exist for the compiler to hoist and spill.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+   return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, bytes, 0x00020000);
+}
 
 // Stage one 32 KB P (already in MFMA operand order) global -> LDS with the LDS-DMA path: each wave
 // instruction moves 64 lanes x 16 B = 1 KiB to a wave-uniform LDS base, no VGPR round trip.
 template <int WAVES>
 __device__ __forceinline__ void stage_p(const double *g, double *s, int wave, int lane)
 {
+   const __amdgpu_buffer_rsrc_t r = make_rsrc(g, 32768);
 #pragma unroll
    for (int c = 0; c < 32 / WAVES; c++) {
       const int chunk = c * WAVES + wave;   // wave-uniform
-      __builtin_amdgcn_global_load_lds((gptr_t *)((const char *)g + chunk * 1024 + lane * 16),
-                                       (lptr_t *)((char *)s + chunk * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t *)((char *)s + chunk * 1024), 16, lane * 16, chunk * 1024, 0, 0);
    }
 }
 
-__device__ __forceinline__ void tip_load(const double *Ptip, long tipstride, int tip, int code, int q, double2 (&v)[8])
+// 64 MFMAs: acc = P . cur, with P's fragments read from LDS one k-block pair ahead of their use.
+__device__ __forceinline__ void mfma_matvec(const double *sPbuf, int lane, const double (&cur)[16], v4d (&acc)[4])
+{
+   const double2 *sp = (const double2 *)sPbuf;
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0, 0, 0, 0};
+#ifdef ABL_NO_MFMA
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) {
+      const double2 a2 = sp[jb * 64 + lane];
+      acc[jb] = (v4d){a2.x * cur[4 * jb], a2.y * cur[4 * jb + 1], a2.x * cur[4 * jb + 2], a2.y * cur[4 * jb + 3]};
+   }
+#else
+   double2 af[2][4];
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) af[0][jb] = sp[jb * 64 + lane];
+#pragma unroll
+   for (int kb2 = 0; kb2 < 8; kb2++) {
+      if (kb2 + 1 < 8) {
+#pragma unroll
+         for (int jb = 0; jb < 4; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the next pair's ds_reads ahead of this pair's MFMAs
+#pragma unroll
+      for (int jb = 0; jb < 4; jb++)
+         acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, cur[2 * kb2], acc[jb], 0, 0, 0);
+#pragma unroll
+      for (int jb = 0; jb < 4; jb++)
+         acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, cur[2 * kb2 + 1], acc[jb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+   }
+#endif
+}
+
+// Shared op bodies of the two mfma64 kernels (textual, so every register array keeps static indices).
+#define MFMA_EPI_INTO(DST)                                                                                       \
+   do {                                                                                                         \
+      if (pop < 0) {                                                                                            \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = acc[m >> 2][m & 3];                            \
+      }                                                                                                         \
+      else if (pop == 0) {                                                                                      \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = s0[m] * acc[m >> 2][m & 3];                    \
+      }                                                                                                         \
+      else if (pop == 1) {                                                                                      \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = s1[m] * acc[m >> 2][m & 3];                    \
+      }                                                                                                         \
+      else {                                                                                                    \
+         const double *sp2 = a.stack_scratch +                                                                  \
+                             (((long)blockIdx.x * a.stack_overflow_slots + (pop - MFMA_RS)) * WAVES + wave) * 1024; \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = sp2[m * 64 + lane] * acc[m >> 2][m & 3];       \
+      }                                                                                                         \
+   } while (0)
+
+#define MFMA_EPILOGUE()                                                                                          \
+   do {                                                                                                         \
+      const int pop = mm_pop_slot(op), push = mm_push_slot(op);                                                 \
+      if (push < 0) MFMA_EPI_INTO(cur);                                                                         \
+      else if (push == 0) MFMA_EPI_INTO(s0);                                                                    \
+      else if (push == 1) MFMA_EPI_INTO(s1);                                                                    \
+      else {                                                                                                    \
+         double tmpv[16];                                                                                       \
+         MFMA_EPI_INTO(tmpv);                                                                                   \
+         double *sp3 = a.stack_scratch +                                                                        \
+                       (((long)blockIdx.x * a.stack_overflow_slots + (push - MFMA_RS)) * WAVES + wave) * 1024;  \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) sp3[m * 64 + lane] = tmpv[m];                           \
+      }                                                                                                         \
+   } while (0)
+
+#define MFMA_CORE_CASES()                                                                                        \
+   case OP_INIT_ONES: {                                                                                         \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] = (4 * m + q < n) ? 1.0 : 0.0;                      \
+   } break;                                                                                                     \
+   case OP_INIT_TIP: {                                                                                          \
+      const int code = TIP_CODE(op.a);                                                                          \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] = (a.cleandata && 4 * m + q == code) ? 1.0 : 0.0;   \
+   } break;
+
+#define MFMA_EXT_CASES()                                                                                         \
+   case OP_PUSH: {                                                                                              \
+      if (op.b == 0) { _Pragma("unroll") for (int m = 0; m < 16; m++) s0[m] = cur[m]; }                         \
+      else if (op.b == 1) { _Pragma("unroll") for (int m = 0; m < 16; m++) s1[m] = cur[m]; }                    \
+      else {                                                                                                    \
+         double *sp = a.stack_scratch +                                                                         \
+                      (((long)blockIdx.x * a.stack_overflow_slots + (op.b - MFMA_RS)) * WAVES + wave) * 1024;   \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) sp[m * 64 + lane] = cur[m];                             \
+      }                                                                                                         \
+   } break;                                                                                                     \
+   case OP_SCALE: {                                                                                             \
+      double mx = 0;                                                                                            \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) mx = cur[m] > mx ? cur[m] : mx;                            \
+      double o = __shfl_xor(mx, 16);                                                                            \
+      mx = o > mx ? o : mx;                                                                                     \
+      o = __shfl_xor(mx, 32);                                                                                   \
+      mx = o > mx ? o : mx;                                                                                     \
+      double fac;                                                                                               \
+      if (mx < 1e-300) {                                                                                        \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] = (4 * m + q < n) ? 1.0 : 0.0;                   \
+         fac = -800;                                                                                            \
+      }                                                                                                         \
+      else {                                                                                                    \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] /= mx;                                           \
+         fac = log(mx);                                                                                         \
+      }                                                                                                         \
+      lnscale += fac;                                                                                           \
+      if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + op.b) * a.n_patt + h] = fac;          \
+   } break;                                                                                                     \
+   case OP_STORE: {  /* native layout [class][node][16-pattern group][m][lane] */                               \
+      double *dst = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) +    \
+                                  ((long)tile * WAVES + wave)) * 1024;                                          \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) dst[m * 64 + lane] = cur[m];                               \
+   } break;                                                                                                     \
+   case OP_LOAD: {                                                                                              \
+      const double *src = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) + \
+                                        ((long)tile * WAVES + wave)) * 1024;                                    \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] = src[m * 64 + lane];                               \
+   } break;
+
+#define MFMA_ROOT_CASE()                                                                                         \
+   case OP_ROOT: {                                                                                              \
+      const double *pq = a.pi + (long)(a.n_pi > 1 ? gene : 0) * 64 + q * 16;                                    \
+      double f = 0;                                                                                             \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) f = fma(pq[m], cur[m], f);                                 \
+      f += __shfl_xor(f, 16);                                                                                   \
+      f += __shfl_xor(f, 32);                                                                                   \
+      if (a.keep && a.n_scale) { /* stored factors summed in slot order (treesub.c:7746-7747) */                \
+         lnscale = 0;                                                                                           \
+         if (valid)                                                                                             \
+            for (int k = 0; k < a.n_scale; k++) lnscale += a.scalef[((long)iclass * a.n_scale + k) * a.n_patt + h]; \
+      }                                                                                                         \
+      if (q == 0 && valid) {                                                                                    \
+         double out = 0;                                                                                        \
+         if (a.weights[h] > 0) out = root_value(a, f, lnscale);                                                 \
+         a.fhK[(long)iclass * a.n_patt + h] = out;                                                              \
+      }                                                                                                         \
+   } break;
+
+// register-stack-only epilogue (programs with max_stack <= MFMA_RS)
+#define MFMA_EPI_REG(DST)                                                                                        \
+   do {                                                                                                         \
+      if (pop < 0) {                                                                                            \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = acc[m >> 2][m & 3];                            \
+      }                                                                                                         \
+      else if (pop == 0) {                                                                                      \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = s0[m] * acc[m >> 2][m & 3];                    \
+      }                                                                                                         \
+      else {                                                                                                    \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = s1[m] * acc[m >> 2][m & 3];                    \
+      }                                                                                                         \
+   } while (0)
+#define MFMA_EPILOGUE_REG()                                                                                      \
+   do {                                                                                                         \
+      const int pop = mm_pop_slot(op), push = mm_push_slot(op);                                                 \
+      if (push < 0) MFMA_EPI_REG(cur);                                                                          \
+      else if (push == 0) MFMA_EPI_REG(s0);                                                                     \
+      else MFMA_EPI_REG(s1);                                                                                    \
+   } while (0)
+
+#ifdef PROF_OPS
+#define PROF_STAMP(slot) \
+   if (a.prof && tid == 0) a.prof[(long)blockIdx.x * a.prof_stride + (slot)] = __builtin_amdgcn_s_memtime()
+// sub-stamps inside an op: plane 1 / 2 of the dump (same [block][op] indexing)
+#define PROF_SUB(plane, ip) \
+   if (a.prof && tid == 0) a.prof[((long)(plane)*gridDim.x + blockIdx.x) * a.prof_stride + 1 + (ip)] = __builtin_amdgcn_s_memtime()
+#else
+#define PROF_STAMP(slot)
+#define PROF_SUB(plane, ip)
+#endif
+
+// ---- mfma64 "gather": tip columns gathered straight from the L2-resident tables into registers.
+// Used for trees with more than MFMA_ZT tips; 4 waves (64 patterns) per workgroup, 2 workgroups per CU.
+__device__ __forceinline__ void tip_gather(const double *Ptip, long tipstride, int tip, int code, int q, double2 (&v)[8])
 {
    const double2 *pt = (const double2 *)(Ptip + (long)tip * tipstride + (code * 4 + q) * 16);
 #pragma unroll
@@ -248,19 +444,16 @@ __device__ __forceinline__ void tip_load(const double *Ptip, long tipstride, int
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64(PruneArgs a)
+__global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_gather(PruneArgs a)
 {
    __shared__ __attribute__((aligned(16))) double sP[2][4096];
-   __shared__ unsigned char sZ[MFMA_ZT * WAVES * 16];
-   constexpr int TP = WAVES * 16;     // patterns per workgroup
    const int tid = threadIdx.x, lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int q = lane >> 4, hl = lane & 15;
    const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;
-   const int gene = a.tiles[tile].x, h0 = a.tiles[tile].y;
-   const int hend = a.gene_off[gene + 1];
-   const int hw = wave * 16 + hl;          // pattern within the tile
-   const int h = h0 + hw;
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;
+   const int hend = as_const(a.gene_off)[gene + 1];
+   const int h = h0 + wave * 16 + hl;
    const bool valid = h < hend;
    const int hc = valid ? h : hend - 1;
    const long pset = (long)gene * a.K + iclass;
@@ -269,9 +462,150 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64(PruneArgs a)
    const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
    const int n = a.n;
 
+   PROF_STAMP(a.prof_stride - 1);
    if (a.first_matmul >= 0) stage_p<WAVES>(Pint + (long)a.first_matmul * 4096, sP[0], wave, lane);
-   {  // character codes of this tile's patterns for the first MFMA_ZT tips -> LDS
-      const int nz = (a.n_tips < MFMA_ZT ? a.n_tips : MFMA_ZT) * TP;
+
+   double cur[16], s0[16], s1[16];   // every program writes cur/s0/s1 (INIT/SET/PUSH) before reading them
+   double lnscale = 0;
+   int buf = 0;
+#define TIP_CODE(tip) ((int)a.z[(long)(tip)*a.z_stride + hc])
+   PROF_STAMP(0);
+   const int lane0 = lane;
+   for (int ip = 0;; ip++) {
+      const Op op = fetch_op(a.ops, ip);
+      PROF_STAMP(1 + ip);
+      if (op.code == OP_END) break;
+      int lane = lane0;             // opaque per-iteration copy: keeps LICM from hoisting (and spilling) lane math
+      asm volatile("" : "+v"(lane));
+      const int q = lane >> 4;
+      switch (op.code) {
+         MFMA_CORE_CASES()
+         MFMA_EXT_CASES()
+         MFMA_ROOT_CASE()
+      case OP_MUL_TIP:
+      case OP_SET_TIP: {
+         double2 v[8];
+         tip_gather(Ptip, tipstride, op.a, TIP_CODE(op.a), q, v);
+         if (op.code == OP_SET_TIP) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x; cur[2 * i + 1] = v[i].y; }
+         }
+         else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur[2 * i] *= v[i].x; cur[2 * i + 1] *= v[i].y; }
+         }
+      } break;
+      case OP_SET_TIP2:
+      case OP_MUL_TIP2: {
+         const int c1 = TIP_CODE(op.a), c2 = TIP_CODE(op.b);
+         double2 v[8], w[8];
+         tip_gather(Ptip, tipstride, op.a, c1, q, v);
+         tip_gather(Ptip, tipstride, op.b, c2, q, w);
+         if (op.code == OP_SET_TIP2) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x * w[i].x; cur[2 * i + 1] = v[i].y * w[i].y; }
+         }
+         else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+               cur[2 * i] = (cur[2 * i] * v[i].x) * w[i].x;
+               cur[2 * i + 1] = (cur[2 * i + 1] * v[i].y) * w[i].y;
+            }
+         }
+      } break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+         __syncthreads();   // this branch's P has landed in sP[buf]; every wave is done reading sP[buf^1]
+         if (op.c >= 0) stage_p<WAVES>(Pint + (long)op.c * 4096, sP[buf ^ 1], wave, lane);
+         v4d acc[4];
+         mfma_matvec(sP[buf], lane, cur, acc);
+         MFMA_EPILOGUE();
+         buf ^= 1;
+      } break;
+      default: break;
+      }
+   }
+#undef TIP_CODE
+}
+
+// ---- mfma64 "dma": the production kernel for trees of up to MFMA_ZT tips.
+// 8 waves (128 patterns) per workgroup, one workgroup per CU, 144 KB of LDS:
+//   sP  [2][32 KB]   double-buffered P in MFMA operand order (LDS-DMA, shared by the 8 waves)
+//   sT  [8][8 KB]    one tip column table slice per wave: the 64 cache lines (16 patterns x 4 state
+//                    quarters) this wave needs from a tip's table, fetched by LDS-DMA one tip AHEAD of
+//                    use.  Each DMA instruction covers 8 whole 128-byte lines (8 lanes x 16 B per line),
+//                    so the L1 sees 8 tag look-ups per instruction instead of the 64 of a per-lane
+//                    gather, no VGPRs are tied up while the data is in flight, and the latency hides
+//                    under the preceding MFMAs.  Pieces are XOR-swizzled on the SOURCE side so the
+//                    owner lane's 8 ds_read_b128 are bank-conflict free.
+//   sZ  [n_tips][128] character codes of the tile.
+__device__ __forceinline__ void tip_dma(const double *tab, unsigned tab_bytes, const unsigned char *zrow, double *myT, int lane)
+{
+   const __amdgpu_buffer_rsrc_t r = make_rsrc(tab, tab_bytes);
+#pragma unroll
+   for (int i = 0; i < 8; i++) {
+      const int L = i * 8 + (lane >> 3);              // line == id of the lane that will consume it
+      const int code = zrow[L & 15];
+      const int piece = (lane & 7) ^ ((L >> 1) & 7);
+      const int off = (code * 4 + (L >> 4)) * 128 + piece * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t *)((char *)myT + i * 1024), 16, off, 0, 0, 0);
+   }
+}
+
+__device__ __forceinline__ void tip_read(const double *myT, int lane, double2 (&v)[8])
+{
+   const int swz = (lane >> 1) & 7;
+   const char *base = (const char *)myT + lane * 128;
+#pragma unroll
+   for (int p = 0; p < 8; p++) v[p] = *(const double2 *)(base + ((p ^ swz) * 16));
+}
+
+// Counted waits: LDS-DMA loads retire in issue order, so "everything up to and including load X has landed"
+// is s_waitcnt vmcnt(number of loads issued after X).  Rounding the count DOWN is always safe (stricter).
+__device__ __forceinline__ void wait_vm_upto(int issued_after)
+{
+   if (issued_after >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+   else if (issued_after >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+   else if (issued_after >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// DBUF = true : 8 waves, P double-buffered (64 KB), one workgroup per CU, one barrier per MATMUL.
+// DBUF = false: 4 waves, P single-buffered (32 KB), TWO independent workgroups per CU (72 KB each): the
+//               exposed part of one workgroup (barriers, P/tip DMA latency, epilogues) is covered by the
+//               other one's MFMAs instead of idling the matrix pipe.
+template <int WAVES, bool DBUF>
+__global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_dma(PruneArgs a)
+{
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem_dma[];
+   constexpr int TP = WAVES * 16;     // patterns per workgroup
+   constexpr int PL = 32 / WAVES;     // DMA loads per wave for one P
+   double *sP = (double *)smem_dma;                    // [DBUF ? 2 : 1][4096]
+   double *sT = sP + (DBUF ? 2 : 1) * 4096;            // [WAVES][1024]
+   unsigned char *sZ = (unsigned char *)(sT + WAVES * 1024);   // [n_tips][TP]
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int q = lane >> 4, hl = lane & 15;
+   const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;
+   const int hend = as_const(a.gene_off)[gene + 1];
+   const int hw = wave * 16 + hl;          // pattern within the tile
+   const int h = h0 + hw;
+   const bool valid = h < hend;
+   const long pset = (long)gene * a.K + iclass;
+   const double *Pint = a.pint + pset * a.n_nodes * 4096;
+   const long tipstride = (long)a.n_codes * 64;
+   const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
+   const int n = a.n;
+   double *myT = sT + wave * 1024;
+   const unsigned char *myZ = sZ + wave * 16;
+   const unsigned tipbytes = (unsigned)(tipstride * sizeof(double));
+
+   PROF_STAMP(a.prof_stride - 1);
+   if (a.first_matmul >= 0) stage_p<WAVES>(Pint + (long)a.first_matmul * 4096, sP, wave, lane);
+   {
+      const int nz = a.n_tips * TP;
       for (int idx = tid; idx < nz; idx += WAVES * 64) {
          const int tip = idx / TP, hh = idx % TP;
          const int hx = h0 + hh < hend ? h0 + hh : hend - 1;
@@ -279,170 +613,97 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64(PruneArgs a)
       }
    }
    __syncthreads();
+   if (a.first_tip >= 0) tip_dma(Ptip + (long)a.first_tip * tipstride, tipbytes, myZ + a.first_tip * TP, myT, lane);
 
-   double cur[16], s0[16], s1[16];
+   double cur[16], s0[16], s1[16];   // every program writes cur/s0/s1 (INIT/SET/PUSH) before reading them
    double lnscale = 0;
    int buf = 0;
-#pragma unroll
-   for (int m = 0; m < 16; m++) cur[m] = s0[m] = s1[m] = 0;
-
-#define TIP_CODE(tip) ((tip) < MFMA_ZT ? (int)sZ[(tip)*TP + hw] : (int)a.z[(long)(tip)*a.z_stride + hc])
-
+   // loads issued after the most recent P DMA / after the most recent tip DMA (wave-uniform)
+   int after_p = a.first_tip >= 0 ? 8 : 0, after_t = 0;
+#define TIP_CODE(tip) ((int)sZ[(tip)*TP + hw])
+   PROF_STAMP(0);
+   const int lane0 = lane;
    for (int ip = 0;; ip++) {
-      const Op op = a.ops[ip];
+      const Op op = fetch_op(a.ops, ip);
+      PROF_STAMP(1 + ip);
       if (op.code == OP_END) break;
+      // re-derive every per-lane address from an opaque copy of the lane id inside the loop: cheap VALU,
+      // and nothing loop-invariant is left for LICM to hoist into (spilled) VGPRs
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      const int q = lane >> 4;
       switch (op.code) {
-      case OP_INIT_ONES: {
-#pragma unroll
-         for (int m = 0; m < 16; m++) cur[m] = (4 * m + q < n) ? 1.0 : 0.0;
-      } break;
-      case OP_INIT_TIP: {
-         const int code = TIP_CODE(op.a);
-#pragma unroll
-         for (int m = 0; m < 16; m++) cur[m] = (a.cleandata && 4 * m + q == code) ? 1.0 : 0.0;
-      } break;
-      case OP_MUL_TIP: {
-         double2 v[8];
-         tip_load(Ptip, tipstride, op.a, TIP_CODE(op.a), q, v);
-#pragma unroll
-         for (int i = 0; i < 8; i++) { cur[2 * i] *= v[i].x; cur[2 * i + 1] *= v[i].y; }
-      } break;
+         MFMA_CORE_CASES()
+         MFMA_ROOT_CASE()
+      case OP_MUL_TIP:
       case OP_SET_TIP: {
          double2 v[8];
-         tip_load(Ptip, tipstride, op.a, TIP_CODE(op.a), q, v);
-#pragma unroll
-         for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x; cur[2 * i + 1] = v[i].y; }
-      } break;
-      case OP_SET_TIP2: {
-         double2 v[8], w[8];
-         tip_load(Ptip, tipstride, op.a, TIP_CODE(op.a), q, v);
-         tip_load(Ptip, tipstride, op.b, TIP_CODE(op.b), q, w);
-#pragma unroll
-         for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x * w[i].x; cur[2 * i + 1] = v[i].y * w[i].y; }
-      } break;
-      case OP_MUL_TIP2: {
-         double2 v[8], w[8];
-         tip_load(Ptip, tipstride, op.a, TIP_CODE(op.a), q, v);
-         tip_load(Ptip, tipstride, op.b, TIP_CODE(op.b), q, w);
-#pragma unroll
-         for (int i = 0; i < 8; i++) {
-            cur[2 * i] = (cur[2 * i] * v[i].x) * w[i].x;
-            cur[2 * i + 1] = (cur[2 * i + 1] * v[i].y) * w[i].y;
+         wait_vm_upto(after_t);                              // this tip's table slice has landed in myT
+         tip_read(myT, lane, v);
+         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+         if (op.c >= 0) {
+            tip_dma(Ptip + (long)op.c * tipstride, tipbytes, myZ + op.c * TP, myT, lane);
+            after_p += 8;
+            after_t = 0;
          }
-      } break;
-      case OP_PUSH: {
-         if (op.b == 0) {
+         if (op.code == OP_SET_TIP) {
 #pragma unroll
-            for (int m = 0; m < 16; m++) s0[m] = cur[m];
-         }
-         else if (op.b == 1) {
-#pragma unroll
-            for (int m = 0; m < 16; m++) s1[m] = cur[m];
+            for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x; cur[2 * i + 1] = v[i].y; }
          }
          else {
-            double *sp = a.stack_scratch +
-                         (((long)blockIdx.x * a.stack_overflow_slots + (op.b - MFMA_RS)) * WAVES + wave) * 1024;
 #pragma unroll
-            for (int m = 0; m < 16; m++) sp[m * 64 + lane] = cur[m];
+            for (int i = 0; i < 8; i++) { cur[2 * i] *= v[i].x; cur[2 * i + 1] *= v[i].y; }
+         }
+      } break;
+      case OP_SET_TIP2:
+      case OP_MUL_TIP2: {
+         double2 v[8], w[8];
+         wait_vm_upto(after_t);                              // tip a was fetched ahead
+         tip_read(myT, lane, v);
+         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+         tip_dma(Ptip + (long)op.b * tipstride, tipbytes, myZ + op.b * TP, myT, lane);
+         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // b is the newest load: everything has landed
+         tip_read(myT, lane, w);
+         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+         after_p = 0;
+         after_t = 0;
+         if (op.c >= 0) {
+            tip_dma(Ptip + (long)op.c * tipstride, tipbytes, myZ + op.c * TP, myT, lane);
+            after_p = 8;
+         }
+         if (op.code == OP_SET_TIP2) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x * w[i].x; cur[2 * i + 1] = v[i].y * w[i].y; }
+         }
+         else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+               cur[2 * i] = (cur[2 * i] * v[i].x) * w[i].x;
+               cur[2 * i + 1] = (cur[2 * i + 1] * v[i].y) * w[i].y;
+            }
          }
       } break;
       case OP_MATMUL:
       case OP_MATMUL_POP: {
-         __syncthreads();   // this branch's P has landed in sP[buf]; every wave is done reading sP[buf^1]
-         if (op.c >= 0) stage_p<WAVES>(Pint + (long)op.c * 4096, sP[buf ^ 1], wave, lane);
+         wait_vm_upto(after_p);   // my share of this branch's P has landed (a newer tip prefetch may still fly)
+         __syncthreads();         // ... and everybody else's; DBUF: every wave is also done reading sP[buf^1]
+         PROF_SUB(1, ip);
+         if (DBUF && op.c >= 0) {
+            stage_p<WAVES>(Pint + (long)op.c * 4096, sP + (buf ^ 1) * 4096, wave, lane);
+            after_p = 0;
+            after_t += PL;
+         }
          v4d acc[4];
-#pragma unroll
-         for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0, 0, 0, 0};
-         const double2 *sp = (const double2 *)sP[buf];
-#pragma unroll
-         for (int kb2 = 0; kb2 < 8; kb2++) {
-#pragma unroll
-            for (int jb = 0; jb < 4; jb++) {
-               const double2 a2 = sp[(kb2 * 4 + jb) * 64 + lane];
-               acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, cur[2 * kb2], acc[jb], 0, 0, 0);
-               acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, cur[2 * kb2 + 1], acc[jb], 0, 0, 0);
-            }
-         }
-         if (op.code == OP_MATMUL) {
-#pragma unroll
-            for (int jb = 0; jb < 4; jb++)
-#pragma unroll
-               for (int r = 0; r < 4; r++) cur[4 * jb + r] = acc[jb][r];
-         }
-         else if (op.b == 0) {
-#pragma unroll
-            for (int jb = 0; jb < 4; jb++)
-#pragma unroll
-               for (int r = 0; r < 4; r++) cur[4 * jb + r] = s0[4 * jb + r] * acc[jb][r];
-         }
-         else if (op.b == 1) {
-#pragma unroll
-            for (int jb = 0; jb < 4; jb++)
-#pragma unroll
-               for (int r = 0; r < 4; r++) cur[4 * jb + r] = s1[4 * jb + r] * acc[jb][r];
-         }
-         else {
-            const double *sp2 = a.stack_scratch +
-                                (((long)blockIdx.x * a.stack_overflow_slots + (op.b - MFMA_RS)) * WAVES + wave) * 1024;
-#pragma unroll
-            for (int jb = 0; jb < 4; jb++)
-#pragma unroll
-               for (int r = 0; r < 4; r++) cur[4 * jb + r] = sp2[(4 * jb + r) * 64 + lane] * acc[jb][r];
+         mfma_matvec(sP + (DBUF ? buf * 4096 : 0), lane, cur, acc);
+         PROF_SUB(2, ip);
+         MFMA_EPILOGUE_REG();
+         if (!DBUF && op.c >= 0) {
+            __syncthreads();      // every wave has finished reading P: overwrite it with the next branch's
+            stage_p<WAVES>(Pint + (long)op.c * 4096, sP, wave, lane);
+            after_p = 0;
+            after_t += PL;
          }
          buf ^= 1;
-      } break;
-      case OP_SCALE: {
-         double mx = 0;
-#pragma unroll
-         for (int m = 0; m < 16; m++) mx = cur[m] > mx ? cur[m] : mx;
-         double o = __shfl_xor(mx, 16);
-         mx = o > mx ? o : mx;
-         o = __shfl_xor(mx, 32);
-         mx = o > mx ? o : mx;
-         double fac;
-         if (mx < 1e-300) {
-#pragma unroll
-            for (int m = 0; m < 16; m++) cur[m] = (4 * m + q < n) ? 1.0 : 0.0;
-            fac = -800;
-         }
-         else {
-#pragma unroll
-            for (int m = 0; m < 16; m++) cur[m] /= mx;
-            fac = log(mx);
-         }
-         lnscale += fac;
-         if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + op.b) * a.n_patt + h] = fac;
-      } break;
-      case OP_STORE: {
-         // native layout [class][node][16-pattern group][m][lane]
-         double *dst = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) +
-                                     ((long)tile * WAVES + wave)) * 1024;
-#pragma unroll
-         for (int m = 0; m < 16; m++) dst[m * 64 + lane] = cur[m];
-      } break;
-      case OP_LOAD: {
-         const double *src = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) +
-                                           ((long)tile * WAVES + wave)) * 1024;
-#pragma unroll
-         for (int m = 0; m < 16; m++) cur[m] = src[m * 64 + lane];
-      } break;
-      case OP_ROOT: {
-         const double *pq = a.pi + (long)(a.n_pi > 1 ? gene : 0) * 64 + q * 16;
-         double f = 0;
-#pragma unroll
-         for (int m = 0; m < 16; m++) f = fma(pq[m], cur[m], f);
-         f += __shfl_xor(f, 16);
-         f += __shfl_xor(f, 32);
-         if (a.keep && a.n_scale) {   // sum the stored factors in slot order, as the reference does (treesub.c:7746-7747)
-            lnscale = 0;
-            if (valid)
-               for (int k = 0; k < a.n_scale; k++) lnscale += a.scalef[((long)iclass * a.n_scale + k) * a.n_patt + h];
-         }
-         if (q == 0 && valid) {
-            double out = 0;
-            if (a.weights[h] > 0) out = root_value(a, f, lnscale);
-            a.fhK[(long)iclass * a.n_patt + h] = out;
-         }
       } break;
       default: break;
       }
@@ -459,8 +720,8 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
 {
    const int tid = threadIdx.x;
    const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;
-   const int gene = a.tiles[tile].x, h0 = a.tiles[tile].y;
-   const int hend = a.gene_off[gene + 1];
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;
+   const int hend = as_const(a.gene_off)[gene + 1];
    const int h = h0 + tid;
    const bool valid = h < hend;
    const int hc = valid ? h : hend - 1;
@@ -476,7 +737,7 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
    for (int j = 0; j < N; j++) cur[j] = 0;
 
    for (int ip = 0;; ip++) {
-      const Op op = a.ops[ip];
+      const Op op = fetch_op(a.ops, ip);
       if (op.code == OP_END) break;
       switch (op.code) {
       case OP_INIT_ONES: {
@@ -520,7 +781,7 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
       } break;
       case OP_MATMUL:
       case OP_MATMUL_POP: {
-         const double *P = Pint + (long)op.a * (N * N);
+         const CONST_AS double *P = as_const(Pint + (long)op.a * (N * N));
          double out[N];
 #pragma unroll
          for (int j = 0; j < N; j++) {
@@ -529,13 +790,18 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
             for (int k = 0; k < N; k++) t = fma(P[j * N + k], cur[k], t);
             out[j] = t;
          }
-         if (op.code == OP_MATMUL) {
+         const int pop = mm_pop_slot(op), push = mm_push_slot(op);
+         if (pop >= 0) {
 #pragma unroll
-            for (int j = 0; j < N; j++) cur[j] = out[j];
+            for (int j = 0; j < N; j++) out[j] = stk[pop][j] * out[j];
+         }
+         if (push >= 0) {
+#pragma unroll
+            for (int j = 0; j < N; j++) stk[push][j] = out[j];
          }
          else {
 #pragma unroll
-            for (int j = 0; j < N; j++) cur[j] = stk[op.b][j] * out[j];
+            for (int j = 0; j < N; j++) cur[j] = out[j];
          }
       } break;
       case OP_SCALE: {

@@ -17,6 +17,8 @@
 // internal son needs no PUSH and the stack depth is <= log2(n_tips); products commute, so only the
 // rounding order differs from the reference's sons[] order.
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -31,7 +33,14 @@ enum OpCode : int {
    OP_MUL_TIP2 = 13    // cur *= tipcol(a) * tipcol(b)    == MUL_TIP a ; MUL_TIP b
 };
 
-struct Op { int code, a, b, c; };   // a: node/tip, b: stack slot / scale slot, c: next MATMUL's son (-1 none)
+struct Op { int code, a, b, c; };   // a: node/tip, b: stack slot / scale slot / 2nd tip, c: prefetch link (-1 none)
+// MATMUL / MATMUL_POP encode two stack slots in b: bits 0..7 = (slot popped + 1), bits 8..15 = (slot the
+// result is pushed to + 1); 0 = none.  A push slot means "MATMUL[_POP] ; PUSH" fused: the result goes
+// straight to the stack slot and `cur` is dead until the next INIT/SET op.
+// Prefetch links: for MATMUL ops c = son of the next MATMUL (its P is staged while this one computes);
+// for tip ops c = the next tip in program order (its column table is fetched ahead of use).
+__host__ __device__ inline int mm_pop_slot(const Op &o) { return (o.b & 0xff) - 1; }
+__host__ __device__ inline int mm_push_slot(const Op &o) { return ((o.b >> 8) & 0xff) - 1; }
 
 struct TreeDesc {
    int n_tips = 0, n_nodes = 0, root = -1;
@@ -46,6 +55,8 @@ struct Program {
    std::vector<Op> ops;
    int max_stack = 0;      // stack slots needed
    int n_matmul = 0;
+   int first_matmul = -1;  // son of the first MATMUL (-1: none)
+   int first_tip = -1;     // first tip whose column table is consumed (-1: none)
 };
 
 namespace detail {
@@ -94,7 +105,7 @@ inline void emit(const TreeDesc &t, int node, const unsigned char *clean, bool k
       else
          emit(t, s, clean, keep, need, have_cur ? depth + 1 : depth, p);
       if (have_cur)
-         p.ops.push_back({OP_MATMUL_POP, s, slot, -1});
+         p.ops.push_back({OP_MATMUL_POP, s, slot + 1, -1});
       else
          p.ops.push_back({OP_MATMUL, s, 0, -1});
       p.n_matmul++;
@@ -120,6 +131,14 @@ inline Program build_program(const TreeDesc &t, bool keep_partials, const unsign
       std::vector<Op> f;
       const std::vector<Op> &o = p.ops;
       for (size_t i = 0; i < o.size();) {
+         const bool mm = o[i].code == OP_MATMUL || o[i].code == OP_MATMUL_POP;
+         if (mm && i + 1 < o.size() && o[i + 1].code == OP_PUSH && o[i + 1].b < 255) {
+            Op m = o[i];
+            m.b |= (o[i + 1].b + 1) << 8;
+            f.push_back(m);
+            i += 2;
+            continue;
+         }
          const bool t1 = i + 1 < o.size() && o[i + 1].code == OP_MUL_TIP;
          const bool t2 = i + 2 < o.size() && o[i + 2].code == OP_MUL_TIP;
          if (o[i].code == OP_INIT_ONES && t1 && t2) { f.push_back({OP_SET_TIP2, o[i + 1].a, o[i + 2].a, -1}); i += 3; }
@@ -128,6 +147,21 @@ inline Program build_program(const TreeDesc &t, bool keep_partials, const unsign
          else { f.push_back(o[i]); i += 1; }
       }
       p.ops.swap(f);
+   }
+   // prefetch links (see Op): walk backwards remembering the next MATMUL's son and the next tip
+   {
+      int next_mm = -1, next_tip = -1;
+      for (int i = (int)p.ops.size() - 1; i >= 0; i--) {
+         Op &o = p.ops[i];
+         switch (o.code) {
+         case OP_MATMUL: case OP_MATMUL_POP: o.c = next_mm; next_mm = o.a; break;
+         case OP_MUL_TIP: case OP_SET_TIP: o.c = next_tip; next_tip = o.a; break;
+         case OP_SET_TIP2: case OP_MUL_TIP2: o.c = next_tip; next_tip = o.a; break;   // a is consumed first, then b
+         default: break;
+         }
+      }
+      p.first_matmul = next_mm;
+      p.first_tip = next_tip;
    }
    // link every MATMUL to the next one so the kernel can prefetch its P while computing
    int next = -1;
@@ -140,11 +174,5 @@ inline Program build_program(const TreeDesc &t, bool keep_partials, const unsign
    return p;
 }
 
-inline int first_matmul(const Program &p)
-{
-   for (const Op &o : p.ops)
-      if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) return o.a;
-   return -1;
-}
 
 }  // namespace paml_amd

@@ -16,7 +16,7 @@ import numpy as np
 from .problem import EIGEN_CIJK, EIGEN_JC69LIKE, EIGEN_K80, EIGEN_UVROOT, Problem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpaml_amd.so")
+LIB_PATH = os.environ.get("PAML_AMD_LIB") or os.path.join(_HERE, "lib", "libpaml_amd.so")   # override: kernel experiments
 CSRC = os.path.join(_HERE, "csrc")
 KEEP_PARTIALS = 1
 

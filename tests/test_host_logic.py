@@ -78,12 +78,25 @@ def interpret(pb, ops, iclass=0, clean_partials=None):
             cur = tipfac(a) * tipfac(b)
         elif code == OP["MUL_TIP2"]:
             cur = (cur * tipfac(a)) * tipfac(b)
+        elif code == OP["SET_TIP"]:
+            cur = tipfac(a)
+        elif code == OP["SET_TIP2"]:
+            cur = tipfac(a) * tipfac(b)
+        elif code == OP["MUL_TIP2"]:
+            cur = (cur * tipfac(a)) * tipfac(b)
         elif code == OP["PUSH"]:
             stack[b] = cur
-        elif code == OP["MATMUL"]:
-            cur = cur @ P(a).T
-        elif code == OP["MATMUL_POP"]:
-            cur = stack.pop(b) * (cur @ P(a).T)
+        elif code in (OP["MATMUL"], OP["MATMUL_POP"]):
+            pop, push = (b & 0xff) - 1, ((b >> 8) & 0xff) - 1
+            assert (pop >= 0) == (code == OP["MATMUL_POP"])
+            val = cur @ P(a).T
+            if pop >= 0:
+                val = stack.pop(pop) * val
+            if push >= 0:
+                stack[push] = val
+                cur = None
+            else:
+                cur = val
         elif code == OP["SCALE"]:
             mx = cur.max(axis=1)
             small = mx < 1e-300
@@ -114,6 +127,12 @@ def test_program_reproduces_recursion(lib_path, n_tips, seed, every, poly):
     for cur, nxt in zip(mm, mm[1:]):
         assert cur[3] == nxt[1]
     assert mm[-1][3] == -1
+    # tip prefetch chain: every tip-consuming op names the first tip of the next tip-consuming op
+    tipops = [o for o in ops if o[0] in (OP["MUL_TIP"], OP["SET_TIP"], OP["SET_TIP2"], OP["MUL_TIP2"])]
+    for cur, nxt in zip(tipops, tipops[1:]):
+        assert cur[3] == nxt[1]
+    assert tipops[-1][3] == -1
+    assert not any(o[0] == OP["PUSH"] and i > 0 and ops[i - 1][0] in (OP["MATMUL"], OP["MATMUL_POP"]) for i, o in enumerate(ops))
     f, lnscale, stored = interpret(pb, ops)
     ref = oracle.evaluate(pb, want_fhk=True, want_partials=True)
     assert np.allclose(np.log(f) + lnscale, ref["fhK"][0], rtol=1e-12, atol=1e-12)

@@ -11,7 +11,7 @@ template <int MODE>   // 0: mfma only, 1: valu only, 2: even waves mfma / odd wa
 __global__ __launch_bounds__(512) void k(double *out, int iters, double seed)
 {
    const int wave = threadIdx.x >> 6;
-   const bool do_mfma = MODE == 0 || (MODE == 2 && (wave & 1) == 0);
+   const bool do_mfma = MODE == 0 || (MODE == 2 && (wave & 4) == 0);   // waves 0-3 -> one per SIMD; 4-7 their partners
    double r = 0;
    if (do_mfma) {
       v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
