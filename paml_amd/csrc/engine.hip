@@ -18,11 +18,7 @@ using namespace paml_amd;
 namespace {
 
 enum KernelKind { KK_VALU4, KK_VALU5, KK_VALU20, KK_MFMA64 };
-#ifndef PAML_AMD_DMA_DBUF
-#define PAML_AMD_DMA_DBUF 0
-#endif
-constexpr bool DMA_DBUF = PAML_AMD_DMA_DBUF != 0;
-constexpr int DMA_WAVES = DMA_DBUF ? 8 : 4;   // mfma64 "dma" kernel: 8 waves + double-buffered P (1 WG/CU) or 4 waves + single P (2 WG/CU)
+constexpr int DMA_WAVES = 8;           // mfma64 "stream" kernel: 128 patterns per workgroup, 1 workgroup per CU
 constexpr int GATHER_WAVES = 4;        // mfma64 "gather" kernel: 64 patterns per workgroup, 2 per CU
 constexpr int VALU_MAXD_SMALL = 16, VALU_MAXD_20 = 8;
 
@@ -120,6 +116,7 @@ struct paml_amd_engine {
    Program prog;
    bool prog_valid = false;
    DevBuf<Op> d_ops;
+   DevBuf<int> d_stream;
    Staging stage;
 
    std::vector<EigenHost> eigen;
@@ -151,6 +148,7 @@ struct paml_amd_engine {
       for (auto b : b2) b->release();
       d_tiles.release();
       d_ops.release();
+      d_stream.release();
       d_eigen.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
                               &d_pint, &d_ptip, &d_fhK, &d_lnf, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack};
@@ -185,6 +183,12 @@ hipError_t upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s)
 }
 
 int tipw(const paml_amd_engine *e) { return e->kk == KK_MFMA64 ? 64 : e->n; }
+// doubles per tip table: mfma64 pads tables of <= 64 codes to one 32 KB stream block
+size_t tip_words(const paml_amd_engine *e)
+{
+   if (e->kk != KK_MFMA64) return (size_t)e->n_codes * e->n;
+   return e->n_codes <= 64 ? 4096 : (size_t)e->n_codes * 64;
+}
 int pint_words(const paml_amd_engine *e) { return e->kk == KK_MFMA64 ? 4096 : e->n * e->n; }
 
 hipEvent_t get_event(paml_amd_engine *e)
@@ -254,7 +258,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // small per-evaluation inputs go through the pinned arena: async H2D, no host stall
    {
       const size_t need = (size_t)nn * 8 + (size_t)G * 8 + tab.size() * sizeof(EigenDev) +
-                          (new_prog ? e->prog.ops.size() * sizeof(Op) : 0) + 256;
+                          (new_prog ? e->prog.ops.size() * sizeof(Op) + e->prog.stream.size() * sizeof(int) : 0) + 256;
       HIPCHK(e->stage.begin(need));
       HIPCHK(e->d_branch.ensure(nn));
       HIPCHK(e->d_gene_rate.ensure(G));
@@ -274,6 +278,11 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          HIPCHK(e->d_ops.ensure(e->prog.ops.size()));
          const Op *ho = e->stage.put(e->prog.ops.data(), e->prog.ops.size());
          HIPCHK(hipMemcpyAsync(e->d_ops.p, ho, e->prog.ops.size() * sizeof(Op), hipMemcpyHostToDevice, e->stream));
+         HIPCHK(e->d_stream.ensure(e->prog.stream.size() + 2));
+         if (!e->prog.stream.empty()) {
+            const int *hs = e->stage.put(e->prog.stream.data(), e->prog.stream.size());
+            HIPCHK(hipMemcpyAsync(e->d_stream.p, hs, e->prog.stream.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+         }
       }
       HIPCHK(e->stage.end(e->stream));
    }
@@ -281,13 +290,13 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // P(t) storage
    HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
    if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
-   HIPCHK(e->d_ptip.ensure((size_t)psets * nn * e->n_codes * tipw(e)));
+   HIPCHK(e->d_ptip.ensure((size_t)psets * nn * tip_words(e)));
    HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
    // the lean dma kernel runs programs made only of INIT / tip / MATMUL / ROOT ops with a register stack;
    // anything else (node scaling, keep-partials STORE/LOAD, deep stacks, > MFMA_ZT tips) takes the full
    // "gather" kernel, whose workgroups cover 64 patterns instead of 128
    if (e->kk == KK_MFMA64) {
-      bool lean = e->prog.max_stack <= MFMA_RS && e->n_tips <= MFMA_ZT && !getenv("PAML_AMD_FORCE_GATHER");
+      bool lean = e->prog.max_stack <= MFMA_RS && e->n_tips <= MFMA_ZT && e->n_codes <= 64 && !getenv("PAML_AMD_FORCE_GATHER");
       for (const Op &o : e->prog.ops)
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
       if (lean != e->mfma_dma) {
@@ -322,7 +331,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pa.label = e->d_label.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
    pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
    pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
-   pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p;
+   pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
    mark(e);
    hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), e->stream, pa);
    mark(e);
@@ -339,6 +348,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.fhK = e->d_fhK.p; pr.partials = e->d_partials.p; pr.scalef = e->d_scalef.p; pr.stack_scratch = e->d_stack.p;
    pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
    pr.first_tip = e->prog.first_tip;
+   pr.stream = e->d_stream.p; pr.n_stream = (int)(e->prog.stream.size() / 2); pr.tip_words = (long)tip_words(e);
 #ifdef PROF_OPS
    static unsigned long long *d_prof = nullptr;
    const int prof_stride = (int)e->prog.ops.size() + 3;
@@ -348,20 +358,20 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       HIPCHK(hipMemsetAsync(d_prof, 0, (size_t)3 * n_blocks * prof_stride * 8, e->stream));
       pr.prof = d_prof;
       pr.prof_stride = prof_stride;
+      pr.prof_tid = getenv("PAML_AMD_PROF_TID") ? atoi(getenv("PAML_AMD_PROF_TID")) : 0;
    }
 #endif
    mark(e);
    switch (e->kk) {
    case KK_MFMA64:
       if (use_dma) {
-         const size_t lds = (size_t)((DMA_DBUF ? 2 : 1) * 4096 + DMA_WAVES * 1024) * sizeof(double) + (size_t)e->n_tips * DMA_WAVES * 16;
+         const size_t lds = (size_t)4 * 4096 * sizeof(double) + (size_t)e->n_tips * 128;
          static bool attr_set = false;
          if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute((const void *)(prune_mfma64_dma<DMA_WAVES, DMA_DBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024));
+            HIPCHK(hipFuncSetAttribute((const void *)prune_mfma64_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
          }
-         hipLaunchKernelGGL((prune_mfma64_dma<DMA_WAVES, DMA_DBUF>), dim3(n_blocks), dim3(DMA_WAVES * 64), lds, e->stream, pr);
+         hipLaunchKernelGGL(prune_mfma64_stream, dim3(n_blocks), dim3(512), lds, e->stream, pr);
       }
       else
          hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, e->stream, pr);
@@ -459,7 +469,7 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
    case KK_VALU4: return "valu4";
    case KK_VALU5: return "valu5";
    case KK_VALU20: return "valu20";
-   default: return e->mfma_dma ? "mfma64_dma" : "mfma64_gather";
+   default: return e->mfma_dma ? "mfma64_stream" : "mfma64_gather";
    }
 }
 

@@ -43,7 +43,8 @@ struct PmatArgs {
    const unsigned char *chara_map; // [n_codes][n]
    double *rowmajor;             // [pset][n_nodes][n*n]
    double *pint;                 // layout 1: [pset][n_nodes][4096]
-   double *ptip;                 // [pset][n_nodes][n_codes*tipw]   tipw = n (VALU) or 64 (mfma64)
+   double *ptip;                 // [pset][n_nodes][tip_words]   rows of n (VALU) or 64 (mfma64) doubles per code
+   long tip_words;
 };
 
 __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
@@ -164,10 +165,16 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
    }
    if (leaf) {
       const int tipw = a.layout == 1 ? 64 : n;
-      double *pt = a.ptip + slot * (long)a.n_codes * tipw;
+      double *pt = a.ptip + slot * a.tip_words;
       for (int idx = tid; idx < a.n_codes * tipw; idx += 256) {
          int code = idx / tipw, w = idx % tipw, jj;
-         if (a.layout == 1) { int q = w >> 4, m = w & 15; jj = 4 * m + q; }
+         if (a.layout == 1) {
+            // row (code, q) = 128 bytes = 8 pieces of two states; piece p is stored in slot p ^ ((row >> 1) & 7) so
+            // that lanes gathering different rows from an LDS copy of this table spread over the banks
+            const int q = w >> 4, slot = (w & 15) >> 1, row = code * 4 + q;
+            const int m = ((slot ^ ((row >> 1) & 7)) << 1) | (w & 1);
+            jj = 4 * m + q;
+         }
          else jj = w;
          double s = 0;
          if (jj < n) {
@@ -202,9 +209,12 @@ struct PruneArgs {
    int stack_overflow_slots;
    int first_matmul;
    int n_int;                  // n_nodes - n_tips
-   int first_tip;              // first tip whose column table is consumed (dma kernel prefetch)
+   int first_tip;              // first tip whose column table is consumed
+   const void *stream;         // stream kernel: operand blocks in order of use, {is_tip, node} pairs
+   int n_stream;
+   long tip_words;             // doubles per tip table
    unsigned long long *prof;   // PROF_OPS builds only: [block][op] s_memtime stamps of thread 0
-   int prof_stride;
+   int prof_stride, prof_tid;
 };
 
 __device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)
@@ -258,6 +268,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
 template <int WAVES>
 __device__ __forceinline__ void stage_p(const double *g, double *s, int wave, int lane)
 {
+#ifdef ABL_NO_STAGE
+   return;
+#endif
    const __amdgpu_buffer_rsrc_t r = make_rsrc(g, 32768);
 #pragma unroll
    for (int c = 0; c < 32 / WAVES; c++) {
@@ -425,10 +438,10 @@ __device__ __forceinline__ void mfma_matvec(const double *sPbuf, int lane, const
 
 #ifdef PROF_OPS
 #define PROF_STAMP(slot) \
-   if (a.prof && tid == 0) a.prof[(long)blockIdx.x * a.prof_stride + (slot)] = __builtin_amdgcn_s_memtime()
+   if (a.prof && tid == a.prof_tid) a.prof[(long)blockIdx.x * a.prof_stride + (slot)] = __builtin_amdgcn_s_memtime()
 // sub-stamps inside an op: plane 1 / 2 of the dump (same [block][op] indexing)
 #define PROF_SUB(plane, ip) \
-   if (a.prof && tid == 0) a.prof[((long)(plane)*gridDim.x + blockIdx.x) * a.prof_stride + 1 + (ip)] = __builtin_amdgcn_s_memtime()
+   if (a.prof && tid == a.prof_tid) a.prof[((long)(plane)*gridDim.x + blockIdx.x) * a.prof_stride + 1 + (ip)] = __builtin_amdgcn_s_memtime()
 #else
 #define PROF_STAMP(slot)
 #define PROF_SUB(plane, ip)
@@ -438,9 +451,10 @@ __device__ __forceinline__ void mfma_matvec(const double *sPbuf, int lane, const
 // Used for trees with more than MFMA_ZT tips; 4 waves (64 patterns) per workgroup, 2 workgroups per CU.
 __device__ __forceinline__ void tip_gather(const double *Ptip, long tipstride, int tip, int code, int q, double2 (&v)[8])
 {
-   const double2 *pt = (const double2 *)(Ptip + (long)tip * tipstride + (code * 4 + q) * 16);
+   const int row = code * 4 + q, swz = (row >> 1) & 7;
+   const double2 *pt = (const double2 *)(Ptip + (long)tip * tipstride + row * 16);
 #pragma unroll
-   for (int i = 0; i < 8; i++) v[i] = pt[i];
+   for (int i = 0; i < 8; i++) v[i] = pt[i ^ swz];     // piece i lives in slot i ^ swz (see pmat_kernel)
 }
 
 template <int WAVES>
@@ -458,7 +472,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_gather(PruneArgs a
    const int hc = valid ? h : hend - 1;
    const long pset = (long)gene * a.K + iclass;
    const double *Pint = a.pint + pset * a.n_nodes * 4096;
-   const long tipstride = (long)a.n_codes * 64;
+   const long tipstride = a.tip_words;
    const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
    const int n = a.n;
 
@@ -529,64 +543,46 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_gather(PruneArgs a
 #undef TIP_CODE
 }
 
-// ---- mfma64 "dma": the production kernel for trees of up to MFMA_ZT tips.
-// 8 waves (128 patterns) per workgroup, one workgroup per CU, 144 KB of LDS:
-//   sP  [2][32 KB]   double-buffered P in MFMA operand order (LDS-DMA, shared by the 8 waves)
-//   sT  [8][8 KB]    one tip column table slice per wave: the 64 cache lines (16 patterns x 4 state
-//                    quarters) this wave needs from a tip's table, fetched by LDS-DMA one tip AHEAD of
-//                    use.  Each DMA instruction covers 8 whole 128-byte lines (8 lanes x 16 B per line),
-//                    so the L1 sees 8 tag look-ups per instruction instead of the 64 of a per-lane
-//                    gather, no VGPRs are tied up while the data is in flight, and the latency hides
-//                    under the preceding MFMAs.  Pieces are XOR-swizzled on the SOURCE side so the
-//                    owner lane's 8 ds_read_b128 are bank-conflict free.
-//   sZ  [n_tips][128] character codes of the tile.
-__device__ __forceinline__ void tip_dma(const double *tab, unsigned tab_bytes, const unsigned char *zrow, double *myT, int lane)
+// ---- mfma64 "stream": the production kernel (<= MFMA_ZT tips, <= 64 character codes, register stack).
+// Every operand the tree walk consumes — the P of an internal branch in MFMA order, or the whole column
+// table of a tip branch — is one 32 KB block, and the program fixes the order in which blocks are used.
+// 8 waves (128 patterns) per workgroup share a ring of four 32 KB LDS buffers that a linear LDS-DMA
+// stream keeps filled three blocks ahead of use (4 x buffer_load_dwordx4 ... lds per wave per block),
+// so neither P nor tip data is ever waited for at L2 latency, no VGPRs hold data in flight, and every
+// DMA instruction is a fully coalesced 1 KB line burst.  Tip factors are then LDS gathers (rows are
+// XOR-swizzled by pmat_kernel so random rows spread over the banks); one s_barrier per step.
+struct StreamBlk { int is_tip, node; };
+
+__device__ __forceinline__ void wait_blocks_in_flight(int n)   // allow the n newest blocks (4 loads each) to fly
 {
-   const __amdgpu_buffer_rsrc_t r = make_rsrc(tab, tab_bytes);
-#pragma unroll
-   for (int i = 0; i < 8; i++) {
-      const int L = i * 8 + (lane >> 3);              // line == id of the lane that will consume it
-      const int code = zrow[L & 15];
-      const int piece = (lane & 7) ^ ((L >> 1) & 7);
-      const int off = (code * 4 + (L >> 4)) * 128 + piece * 16;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t *)((char *)myT + i * 1024), 16, off, 0, 0, 0);
-   }
+   if (n >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+   else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+   else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__device__ __forceinline__ void tip_read(const double *myT, int lane, double2 (&v)[8])
+__device__ __forceinline__ void tip_lds(const double *tab, int code, int q, int lane, double2 (&v)[8])
 {
-   const int swz = (lane >> 1) & 7;
-   const char *base = (const char *)myT + lane * 128;
+#ifdef ABL_NO_TIPLOAD
+#pragma unroll
+   for (int p = 0; p < 8; p++) v[p] = make_double2(0.5 + code * 1e-3, 0.25 + q * 1e-3);
+   return;
+#endif
+   const int row = code * 4 + q, swz = (row >> 1) & 7;
+   const char *base = (const char *)tab + row * 128;
 #pragma unroll
    for (int p = 0; p < 8; p++) v[p] = *(const double2 *)(base + ((p ^ swz) * 16));
 }
 
-// Counted waits: LDS-DMA loads retire in issue order, so "everything up to and including load X has landed"
-// is s_waitcnt vmcnt(number of loads issued after X).  Rounding the count DOWN is always safe (stricter).
-__device__ __forceinline__ void wait_vm_upto(int issued_after)
+__global__ __launch_bounds__(512, 2) void prune_mfma64_stream(PruneArgs a)
 {
-   if (issued_after >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-   else if (issued_after >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-   else if (issued_after >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// DBUF = true : 8 waves, P double-buffered (64 KB), one workgroup per CU, one barrier per MATMUL.
-// DBUF = false: 4 waves, P single-buffered (32 KB), TWO independent workgroups per CU (72 KB each): the
-//               exposed part of one workgroup (barriers, P/tip DMA latency, epilogues) is covered by the
-//               other one's MFMAs instead of idling the matrix pipe.
-template <int WAVES, bool DBUF>
-__global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_dma(PruneArgs a)
-{
-   extern __shared__ __attribute__((aligned(16))) unsigned char smem_dma[];
-   constexpr int TP = WAVES * 16;     // patterns per workgroup
-   constexpr int PL = 32 / WAVES;     // DMA loads per wave for one P
-   double *sP = (double *)smem_dma;                    // [DBUF ? 2 : 1][4096]
-   double *sT = sP + (DBUF ? 2 : 1) * 4096;            // [WAVES][1024]
-   unsigned char *sZ = (unsigned char *)(sT + WAVES * 1024);   // [n_tips][TP]
+   constexpr int WAVES = 8, TP = 128;
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem_stream[];
+   double *ring = (double *)smem_stream;                        // [4][4096]
+   unsigned char *sZ = (unsigned char *)(ring + 4 * 4096);      // [n_tips][128]
    const int tid = threadIdx.x, lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-   const int q = lane >> 4, hl = lane & 15;
+   const int hl = lane & 15;
    const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;
    const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;
    const int hend = as_const(a.gene_off)[gene + 1];
@@ -595,15 +591,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_dma(PruneArgs a)
    const bool valid = h < hend;
    const long pset = (long)gene * a.K + iclass;
    const double *Pint = a.pint + pset * a.n_nodes * 4096;
-   const long tipstride = (long)a.n_codes * 64;
+   const long tipstride = 4096;            // one 32 KB block per tip (n_codes <= 64)
    const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
    const int n = a.n;
-   double *myT = sT + wave * 1024;
-   const unsigned char *myZ = sZ + wave * 16;
-   const unsigned tipbytes = (unsigned)(tipstride * sizeof(double));
+   const StreamBlk *stream = (const StreamBlk *)a.stream;
+   const int nblk = a.n_stream;
 
    PROF_STAMP(a.prof_stride - 1);
-   if (a.first_matmul >= 0) stage_p<WAVES>(Pint + (long)a.first_matmul * 4096, sP, wave, lane);
+   int issued = 0, consumed = 0;
+#define STREAM_ISSUE()                                                                                           \
+   do {                                                                                                         \
+      const long long sb = ((const CONST_AS long long *)(unsigned long long)stream)[issued];                    \
+      const int is_tip = (int)(sb & 0xffffffff), node = (int)(sb >> 32);                                        \
+      const double *src = is_tip ? Ptip + (long)node * tipstride : Pint + (long)node * 4096;                    \
+      stage_p<WAVES>(src, ring + (issued & 3) * 4096, wave, lane);                                              \
+      issued++;                                                                                                 \
+   } while (0)
+   for (int i = 0; i < 3; i++)
+      if (issued < nblk) STREAM_ISSUE();
    {
       const int nz = a.n_tips * TP;
       for (int idx = tid; idx < nz; idx += WAVES * 64) {
@@ -612,15 +617,25 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_dma(PruneArgs a)
          sZ[idx] = a.z[(long)tip * a.z_stride + hx];
       }
    }
-   __syncthreads();
-   if (a.first_tip >= 0) tip_dma(Ptip + (long)a.first_tip * tipstride, tipbytes, myZ + a.first_tip * TP, myT, lane);
+   __syncthreads();   // publish sZ (INIT_TIP may read it before the first stream step)
 
    double cur[16], s0[16], s1[16];   // every program writes cur/s0/s1 (INIT/SET/PUSH) before reading them
    double lnscale = 0;
-   int buf = 0;
-   // loads issued after the most recent P DMA / after the most recent tip DMA (wave-uniform)
-   int after_p = a.first_tip >= 0 ? 8 : 0, after_t = 0;
 #define TIP_CODE(tip) ((int)sZ[(tip)*TP + hw])
+   // consume the next c blocks of the stream: they have landed for every wave after this returns, and the
+   // buffers used by the previous step are refilled with the blocks 3..4 ahead
+#ifdef ABL_NO_BARRIER
+#define STREAM_BARRIER()
+#else
+#define STREAM_BARRIER() __syncthreads()
+#endif
+#define STREAM_STEP(c)                                                                                           \
+   do {                                                                                                         \
+      wait_blocks_in_flight(issued - (consumed + (c)));                                                         \
+      STREAM_BARRIER();                                                                                         \
+      while (issued < consumed + 4 && issued < nblk) STREAM_ISSUE();                                            \
+   } while (0)
+
    PROF_STAMP(0);
    const int lane0 = lane;
    for (int ip = 0;; ip++) {
@@ -638,14 +653,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_dma(PruneArgs a)
       case OP_MUL_TIP:
       case OP_SET_TIP: {
          double2 v[8];
-         wait_vm_upto(after_t);                              // this tip's table slice has landed in myT
-         tip_read(myT, lane, v);
-         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-         if (op.c >= 0) {
-            tip_dma(Ptip + (long)op.c * tipstride, tipbytes, myZ + op.c * TP, myT, lane);
-            after_p += 8;
-            after_t = 0;
-         }
+         STREAM_STEP(1);
+         tip_lds(ring + (consumed & 3) * 4096, TIP_CODE(op.a), q, lane, v);
+         consumed += 1;
          if (op.code == OP_SET_TIP) {
 #pragma unroll
             for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x; cur[2 * i + 1] = v[i].y; }
@@ -658,19 +668,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_dma(PruneArgs a)
       case OP_SET_TIP2:
       case OP_MUL_TIP2: {
          double2 v[8], w[8];
-         wait_vm_upto(after_t);                              // tip a was fetched ahead
-         tip_read(myT, lane, v);
-         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-         tip_dma(Ptip + (long)op.b * tipstride, tipbytes, myZ + op.b * TP, myT, lane);
-         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // b is the newest load: everything has landed
-         tip_read(myT, lane, w);
-         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-         after_p = 0;
-         after_t = 0;
-         if (op.c >= 0) {
-            tip_dma(Ptip + (long)op.c * tipstride, tipbytes, myZ + op.c * TP, myT, lane);
-            after_p = 8;
-         }
+         STREAM_STEP(2);
+         tip_lds(ring + (consumed & 3) * 4096, TIP_CODE(op.a), q, lane, v);
+         tip_lds(ring + ((consumed + 1) & 3) * 4096, TIP_CODE(op.b), q, lane, w);
+         consumed += 2;
          if (op.code == OP_SET_TIP2) {
 #pragma unroll
             for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x * w[i].x; cur[2 * i + 1] = v[i].y * w[i].y; }
@@ -685,30 +686,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_dma(PruneArgs a)
       } break;
       case OP_MATMUL:
       case OP_MATMUL_POP: {
-         wait_vm_upto(after_p);   // my share of this branch's P has landed (a newer tip prefetch may still fly)
-         __syncthreads();         // ... and everybody else's; DBUF: every wave is also done reading sP[buf^1]
+         STREAM_STEP(1);
          PROF_SUB(1, ip);
-         if (DBUF && op.c >= 0) {
-            stage_p<WAVES>(Pint + (long)op.c * 4096, sP + (buf ^ 1) * 4096, wave, lane);
-            after_p = 0;
-            after_t += PL;
-         }
          v4d acc[4];
-         mfma_matvec(sP + (DBUF ? buf * 4096 : 0), lane, cur, acc);
+         mfma_matvec(ring + (consumed & 3) * 4096, lane, cur, acc);
+         consumed += 1;
          PROF_SUB(2, ip);
          MFMA_EPILOGUE_REG();
-         if (!DBUF && op.c >= 0) {
-            __syncthreads();      // every wave has finished reading P: overwrite it with the next branch's
-            stage_p<WAVES>(Pint + (long)op.c * 4096, sP, wave, lane);
-            after_p = 0;
-            after_t += PL;
-         }
-         buf ^= 1;
       } break;
       default: break;
       }
    }
 #undef TIP_CODE
+#undef STREAM_STEP
+#undef STREAM_ISSUE
 }
 
 // ---- valu<N>: 4 / 5 / 20 states, one pattern per lane ------------------------------------------
@@ -727,7 +718,7 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
    const int hc = valid ? h : hend - 1;
    const long pset = (long)gene * a.K + iclass;
    const double *Pint = a.pint + pset * a.n_nodes * (N * N);
-   const long tipstride = (long)a.n_codes * N;
+   const long tipstride = a.tip_words;
    const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
 
    double cur[N];

@@ -57,6 +57,7 @@ struct Program {
    int n_matmul = 0;
    int first_matmul = -1;  // son of the first MATMUL (-1: none)
    int first_tip = -1;     // first tip whose column table is consumed (-1: none)
+   std::vector<int> stream;   // operand blocks in order of use: (is_tip, node) pairs
 };
 
 namespace detail {
@@ -162,6 +163,15 @@ inline Program build_program(const TreeDesc &t, bool keep_partials, const unsign
       }
       p.first_matmul = next_mm;
       p.first_tip = next_tip;
+   }
+   for (const Op &o : p.ops) {
+      switch (o.code) {
+      case OP_MATMUL: case OP_MATMUL_POP: p.stream.push_back(0); p.stream.push_back(o.a); break;
+      case OP_MUL_TIP: case OP_SET_TIP: p.stream.push_back(1); p.stream.push_back(o.a); break;
+      case OP_SET_TIP2: case OP_MUL_TIP2:
+         p.stream.push_back(1); p.stream.push_back(o.a); p.stream.push_back(1); p.stream.push_back(o.b); break;
+      default: break;
+      }
    }
    // link every MATMUL to the next one so the kernel can prefetch its P while computing
    int next = -1;
