@@ -34,9 +34,12 @@ enum {
 
 /* create flags */
 enum {
-   PAML_AMD_KEEP_PARTIALS = 1   /* keep every internal node's partials resident: needed by
+   PAML_AMD_KEEP_PARTIALS = 1,  /* keep every internal node's partials resident: needed by
                                    paml_amd_get_partials / dirty-node re-evaluation
                                    (com.conPSiteClass = 1 memory model, codeml.c:2343-2346) */
+   PAML_AMD_JIT = 2             /* compile a pruning kernel specialised for the tree (hiprtc, a few seconds per
+                                   new topology) even for small data sets; large ones do so by default
+                                   (env PAML_AMD_JIT=0/1 overrides) */
 };
 
 /* eigen-system kinds = the branches of GetPMatBranch (treesub.c:7503-7592) */
@@ -132,6 +135,12 @@ int paml_amd_counters(const paml_amd_engine *e, long *n_eval, long *n_pmat);
 int paml_amd_debug_program(int n_tips, int n_nodes, int root, const int *sons_ptr, const int *sons,
                            const unsigned char *scale_node, int keep_partials, const unsigned char *clean,
                            int *ops_out, int cap, int *max_stack);
+
+/* Host-only: generate (and with compile != 0 also hiprtc-compile for gfx950, no GPU needed) the kernel
+ * specialised for a tree (paml_amd/csrc/jit.h).  Returns the source length, or a negative error with the
+ * compiler log in text_out. */
+int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, const int *sons,
+                       const unsigned char *scale_node, char *text_out, int cap, int compile);
 
 /* Name of the pruning kernel the engine selected ("mfma64", "valu4", "valu20", ...). */
 const char *paml_amd_kernel_name(const paml_amd_engine *e);

@@ -1,0 +1,330 @@
+// device_common.h — device-side definitions shared by the ahead-of-time kernels (kernels.h) and the
+// per-tree specialised kernels that jit.h generates and compiles with hiprtc.  No host/STL headers here.
+#pragma once
+#ifndef __HIPCC_RTC__   // hiprtc pre-includes the HIP device runtime
+#include <hip/hip_runtime.h>
+#endif
+
+#include "../../include/paml_amd.h"
+
+namespace paml_amd {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+enum OpCode : int {
+   OP_INIT_ONES = 0, OP_INIT_TIP = 1, OP_MUL_TIP = 2, OP_PUSH = 3, OP_MATMUL = 4, OP_MATMUL_POP = 5,
+   OP_SCALE = 6, OP_STORE = 7, OP_LOAD = 8, OP_ROOT = 9, OP_END = 10,
+   // fused forms produced by the peephole pass (same arithmetic, fewer dependent memory round trips):
+   OP_SET_TIP = 11,    // cur = tipcol(a)                 == INIT_ONES ; MUL_TIP a
+   OP_SET_TIP2 = 12,   // cur = tipcol(a) * tipcol(b)     == INIT_ONES ; MUL_TIP a ; MUL_TIP b   (a cherry)
+   OP_MUL_TIP2 = 13    // cur *= tipcol(a) * tipcol(b)    == MUL_TIP a ; MUL_TIP b
+};
+
+struct Op { int code, a, b, c; };   // a: node/tip, b: stack slot / scale slot / 2nd tip, c: prefetch link (-1 none)
+// MATMUL / MATMUL_POP encode two stack slots in b: bits 0..7 = (slot popped + 1), bits 8..15 = (slot the
+// result is pushed to + 1); 0 = none.  A push slot means "MATMUL[_POP] ; PUSH" fused: the result goes
+// straight to the stack slot and `cur` is dead until the next INIT/SET op.
+// Prefetch links: for MATMUL ops c = son of the next MATMUL (its P is staged while this one computes);
+// for tip ops c = the next tip in program order (its column table is fetched ahead of use).
+__host__ __device__ inline int mm_pop_slot(const Op &o) { return (o.b & 0xff) - 1; }
+__host__ __device__ inline int mm_push_slot(const Op &o) { return ((o.b >> 8) & 0xff) - 1; }
+
+
+struct PruneArgs {
+   const Op *ops;
+   const unsigned char *z;     // [n_tips][z_stride]
+   long z_stride;
+   const int2 *tiles;          // (gene, first pattern) per tile
+   int n_tiles;
+   const int *gene_off;
+   const double *weights;
+   int n, n_tips, n_nodes, K, n_genes, n_codes, cleandata, n_pi, mode, n_scale, keep, n_patt;
+   const double *pi;           // VALU: [n_pi][n];  mfma64: [n_pi][4][16] (q-major, zero padded)
+   const double *pint;         // per (pset, node): n*n row-major (VALU) or 4096 frag (mfma64)
+   const double *ptip;         // per (pset, node): n_codes * tipw
+   double *fhK;                // [K][n_patt]
+   double *partials;           // keep mode
+   double *scalef;             // keep mode: [K][n_scale][n_patt]
+   double *stack_scratch;      // overflow stack (mfma64)
+   int stack_overflow_slots;
+   int first_matmul;
+   int n_int;                  // n_nodes - n_tips
+   int first_tip;              // first tip whose column table is consumed
+   const void *stream;         // stream kernel: operand blocks in order of use, {is_tip, node} pairs
+   int n_stream;
+   long tip_words;             // doubles per tip table
+   unsigned long long *prof;   // PROF_OPS builds only: [block][op] s_memtime stamps of thread 0
+   int prof_stride, prof_tid;
+};
+
+__device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)
+{
+   // fx_r treesub.c:7731-7749 / lfun 7782-7798: floors then log + scale factors
+   if (f <= 0) f = (a.mode == PAML_AMD_MODE_LFUN ? 1e-80 : 1e-300);
+   if (a.mode == PAML_AMD_MODE_LFUN || a.n_scale) f = log(f) + lnscale;
+   return f;
+}
+
+
+#define MFMA_RS 2      // register stack slots; deeper slots spill to global scratch
+#define MFMA_ZT 128    // most tips whose codes the dma kernel keeps in LDS
+
+// Wave-uniform, read-only data (the tree program, tile table, P(t) entries of the VALU kernels) is read
+// through the constant address space so the compiler uses scalar loads (s_load, lgkmcnt) instead of a
+// vector load + vmcnt(0) wait that would also drain the in-flight LDS-DMA prefetches.
+#define CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const CONST_AS T *as_const(const T *p)
+{
+   return (const CONST_AS T *)(unsigned long long)p;
+}
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Op fetch_op(const Op *ops, int ip)
+{
+   const v4i o = ((const CONST_AS v4i *)(unsigned long long)ops)[ip];   // one s_load_dwordx4
+   return Op{o.x, o.y, o.z, o.w};
+}
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// LDS-DMA through a raw buffer descriptor: address = SGPR descriptor base + 32-bit VGPR offset + SGPR
+// offset, so no 64-bit per-lane pointers exist for the compiler to hoist and spill.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+   return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, bytes, 0x00020000);
+}
+
+// Stage one 32 KB P (already in MFMA operand order) global -> LDS with the LDS-DMA path: each wave
+// instruction moves 64 lanes x 16 B = 1 KiB to a wave-uniform LDS base, no VGPR round trip.
+template <int WAVES>
+__device__ __forceinline__ void stage_p(const double *g, double *s, int wave, int lane)
+{
+#ifdef ABL_NO_STAGE
+   return;
+#endif
+   const __amdgpu_buffer_rsrc_t r = make_rsrc(g, 32768);
+#pragma unroll
+   for (int c = 0; c < 32 / WAVES; c++) {
+      const int chunk = c * WAVES + wave;   // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t *)((char *)s + chunk * 1024), 16, lane * 16, chunk * 1024, 0, 0);
+   }
+}
+
+
+// 64 MFMAs: acc = P . cur, with P's fragments read from LDS one k-block pair ahead of their use.
+__device__ __forceinline__ void mfma_matvec(const double *sPbuf, int lane, const double (&cur)[16], v4d (&acc)[4])
+{
+   const double2 *sp = (const double2 *)sPbuf;
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0, 0, 0, 0};
+#ifdef ABL_NO_MFMA
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) {
+      const double2 a2 = sp[jb * 64 + lane];
+      acc[jb] = (v4d){a2.x * cur[4 * jb], a2.y * cur[4 * jb + 1], a2.x * cur[4 * jb + 2], a2.y * cur[4 * jb + 3]};
+   }
+#else
+   double2 af[2][4];
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) af[0][jb] = sp[jb * 64 + lane];
+#pragma unroll
+   for (int kb2 = 0; kb2 < 8; kb2++) {
+      if (kb2 + 1 < 8) {
+#pragma unroll
+         for (int jb = 0; jb < 4; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the next pair's ds_reads ahead of this pair's MFMAs
+#pragma unroll
+      for (int jb = 0; jb < 4; jb++)
+         acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, cur[2 * kb2], acc[jb], 0, 0, 0);
+#pragma unroll
+      for (int jb = 0; jb < 4; jb++)
+         acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, cur[2 * kb2 + 1], acc[jb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+   }
+#endif
+}
+
+
+struct StreamBlk { int is_tip, node; };
+
+__device__ __forceinline__ void wait_blocks_in_flight(int n)   // allow the n newest blocks (4 loads each) to fly
+{
+   if (n >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+   else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+   else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void tip_lds(const double *tab, int code, int q, int lane, double2 (&v)[8])
+{
+#ifdef ABL_NO_TIPLOAD
+#pragma unroll
+   for (int p = 0; p < 8; p++) v[p] = make_double2(0.5 + code * 1e-3, 0.25 + q * 1e-3);
+   return;
+#endif
+   const int row = code * 4 + q, swz = (row >> 1) & 7;
+   const char *base = (const char *)tab + row * 128;
+#pragma unroll
+   for (int p = 0; p < 8; p++) v[p] = *(const double2 *)(base + ((p ^ swz) * 16));
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Building blocks of the per-tree specialised kernel (jit.h emits a straight-line sequence of these).
+// A partial is a v4d[4]: element m (state 4m + q of this lane's pattern) is x[m >> 2][m & 3] — exactly
+// the accumulator tuple of row block jb = m >> 2, so MFMA results are partials with no copies, and the
+// B operand of k-block kb is x[kb >> 2][kb & 3].
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4])
+{
+   const double2 *sp = (const double2 *)sPbuf;
+   double2 af[2][4];
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) af[0][jb] = sp[jb * 64 + lane];
+#pragma unroll
+   for (int kb2 = 0; kb2 < 8; kb2++) {
+      if (kb2 + 1 < 8) {
+#pragma unroll
+         for (int jb = 0; jb < 4; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const double b0 = x[(2 * kb2) >> 2][(2 * kb2) & 3], b1 = x[(2 * kb2 + 1) >> 2][(2 * kb2 + 1) & 3];
+      if (kb2 == 0) {
+#pragma unroll
+         for (int jb = 0; jb < 4; jb++)
+            y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][jb].x, b0, (v4d){0, 0, 0, 0}, 0, 0, 0);
+      }
+      else {
+#pragma unroll
+         for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+   }
+}
+
+__device__ __forceinline__ void jit_mul(v4d (&y)[4], const v4d (&s)[4])   // y = s * y  (codeml.c:3573)
+{
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) y[jb] = s[jb] * y[jb];
+}
+
+__device__ __forceinline__ void jit_init_ones(v4d (&y)[4], int q, int n)
+{
+#pragma unroll
+   for (int m = 0; m < 16; m++) y[m >> 2][m & 3] = (4 * m + q < n) ? 1.0 : 0.0;
+}
+
+__device__ __forceinline__ void jit_init_tip(v4d (&y)[4], int code, int q, int cleandata)
+{
+#pragma unroll
+   for (int m = 0; m < 16; m++) y[m >> 2][m & 3] = (cleandata && 4 * m + q == code) ? 1.0 : 0.0;
+}
+
+__device__ __forceinline__ void jit_tip_set(v4d (&y)[4], const double *tab, int code, int q, int lane)
+{
+   double2 v[8];
+   tip_lds(tab, code, q, lane, v);
+#pragma unroll
+   for (int i = 0; i < 8; i++) { y[i >> 1][(2 * i) & 3] = v[i].x; y[i >> 1][(2 * i + 1) & 3] = v[i].y; }
+}
+
+__device__ __forceinline__ void jit_tip_mul(v4d (&y)[4], const double *tab, int code, int q, int lane)
+{
+   double2 v[8];
+   tip_lds(tab, code, q, lane, v);
+#pragma unroll
+   for (int i = 0; i < 8; i++) { y[i >> 1][(2 * i) & 3] *= v[i].x; y[i >> 1][(2 * i + 1) & 3] *= v[i].y; }
+}
+
+__device__ __forceinline__ void jit_tip2_set(v4d (&y)[4], const double *ta, int ca, const double *tb, int cb, int q, int lane)
+{
+   double2 v[8], w[8];
+   tip_lds(ta, ca, q, lane, v);
+   tip_lds(tb, cb, q, lane, w);
+#pragma unroll
+   for (int i = 0; i < 8; i++) { y[i >> 1][(2 * i) & 3] = v[i].x * w[i].x; y[i >> 1][(2 * i + 1) & 3] = v[i].y * w[i].y; }
+}
+
+__device__ __forceinline__ void jit_tip2_mul(v4d (&y)[4], const double *ta, int ca, const double *tb, int cb, int q, int lane)
+{
+   double2 v[8], w[8];
+   tip_lds(ta, ca, q, lane, v);
+   tip_lds(tb, cb, q, lane, w);
+#pragma unroll
+   for (int i = 0; i < 8; i++) {
+      y[i >> 1][(2 * i) & 3] = (y[i >> 1][(2 * i) & 3] * v[i].x) * w[i].x;
+      y[i >> 1][(2 * i + 1) & 3] = (y[i >> 1][(2 * i + 1) & 3] * v[i].y) * w[i].y;
+   }
+}
+
+__device__ __forceinline__ double jit_scale(v4d (&y)[4], int q, int n)   // NodeScale, treesub.c:7200-7230
+{
+   double mx = 0;
+#pragma unroll
+   for (int m = 0; m < 16; m++) mx = y[m >> 2][m & 3] > mx ? y[m >> 2][m & 3] : mx;
+   double o = __shfl_xor(mx, 16);
+   mx = o > mx ? o : mx;
+   o = __shfl_xor(mx, 32);
+   mx = o > mx ? o : mx;
+   if (mx < 1e-300) {
+      jit_init_ones(y, q, n);
+      return -800;
+   }
+#pragma unroll
+   for (int m = 0; m < 16; m++) y[m >> 2][m & 3] /= mx;
+   return log(mx);
+}
+
+__device__ __forceinline__ void jit_root(const PruneArgs &a, const v4d (&x)[4], double lnscale, int gene, int iclass, int q, int h,
+                                         bool valid)
+{
+   const double *pq = a.pi + (long)(a.n_pi > 1 ? gene : 0) * 64 + q * 16;
+   double f = 0;
+#pragma unroll
+   for (int m = 0; m < 16; m++) f = fma(pq[m], x[m >> 2][m & 3], f);
+   f += __shfl_xor(f, 16);
+   f += __shfl_xor(f, 32);
+   if (q == 0 && valid) {
+      double out = 0;
+      if (a.weights[h] > 0) out = root_value(a, f, lnscale);
+      a.fhK[(long)iclass * a.n_patt + h] = out;
+   }
+}
+
+// Prologue of a specialised kernel: 8 waves x 16 patterns, ring of four 32 KB operand buffers, tip codes in LDS.
+#define JIT_PROLOGUE(NTIPS)                                                                                      \
+   __shared__ __attribute__((aligned(16))) double ring[4 * 4096];                                               \
+   __shared__ unsigned char sZ[(NTIPS)*128];                                                                     \
+   const int tid = threadIdx.x, lane = tid & 63;                                                                \
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                   \
+   const int q = lane >> 4, hl = lane & 15;                                                                     \
+   const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;                                    \
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;                                  \
+   const int hend = as_const(a.gene_off)[gene + 1];                                                             \
+   const int hw = wave * 16 + hl;                                                                               \
+   const int h = h0 + hw;                                                                                       \
+   const bool valid = h < hend;                                                                                 \
+   const long pset = (long)gene * a.K + iclass;                                                                 \
+   const double *Pint = a.pint + pset * a.n_nodes * 4096;                                                       \
+   const double *Ptip = a.ptip + pset * a.n_nodes * 4096;                                                       \
+   const int n = a.n;                                                                                           \
+   double lnscale = 0;                                                                                          \
+   (void)hl; (void)n; (void)lnscale;
+#define JIT_STAGE_Z(NTIPS)                                                                                       \
+   for (int idx = tid; idx < (NTIPS)*128; idx += 512) {                                                          \
+      const int tip = idx >> 7, hh = idx & 127;                                                                 \
+      const int hx = h0 + hh < hend ? h0 + hh : hend - 1;                                                       \
+      sZ[idx] = a.z[(long)tip * a.z_stride + hx];                                                               \
+   }                                                                                                            \
+   __syncthreads();
+#define JIT_ISSUE_P(J, NODE) stage_p<8>(Pint + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)
+#define JIT_ISSUE_T(J, NODE) stage_p<8>(Ptip + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)
+#define JIT_BUF(J) (ring + ((J)&3) * 4096)
+#define JIT_CODE(TIP) ((int)sZ[(TIP)*128 + hw])
+#define JIT_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+}  // namespace paml_amd

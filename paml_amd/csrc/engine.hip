@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/paml_amd.h"
+#include "jit.h"
 #include "kernels.h"
 #include "program.h"
 
@@ -118,6 +119,8 @@ struct paml_amd_engine {
    DevBuf<Op> d_ops;
    DevBuf<int> d_stream;
    Staging stage;
+   JitKernel jit;            // per-tree specialised kernel (jit.h), valid when jit.fn != nullptr
+   bool jit_enabled = false, use_jit = false;
 
    std::vector<EigenHost> eigen;
    DevBuf<EigenDev> d_eigen;
@@ -140,6 +143,7 @@ struct paml_amd_engine {
    {
       for (auto &e : eigen) { e.U.release(); e.V.release(); e.Root.release(); e.Cijk.release(); }
       stage.release();
+      if (jit.mod) (void)hipModuleUnload(jit.mod);
       for (auto ev : ev_pool) (void)hipEventDestroy(ev);
       for (auto ev : ev_used) (void)hipEventDestroy(ev);
       DevBuf<unsigned char> *b1[] = {&d_z, &d_chara_map, &d_is_leaf};
@@ -292,16 +296,43 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
    HIPCHK(e->d_ptip.ensure((size_t)psets * nn * tip_words(e)));
    HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
-   // the lean dma kernel runs programs made only of INIT / tip / MATMUL / ROOT ops with a register stack;
-   // anything else (node scaling, keep-partials STORE/LOAD, deep stacks, > MFMA_ZT tips) takes the full
-   // "gather" kernel, whose workgroups cover 64 patterns instead of 128
+   // kernel choice for the 21..64-state path:
+   //   jit    — straight-line kernel specialised for this tree (jit.h), 128 patterns per workgroup
+   //   stream — the interpreter over the same operand stream (lean programs only), 128 patterns per workgroup
+   //   gather — the full interpreter (keep-partials STORE/LOAD, deep stacks, > MFMA_ZT tips, > 64 codes), 64 per workgroup
    if (e->kk == KK_MFMA64) {
       bool lean = e->prog.max_stack <= MFMA_RS && e->n_tips <= MFMA_ZT && e->n_codes <= 64 && !getenv("PAML_AMD_FORCE_GATHER");
       for (const Op &o : e->prog.ops)
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
-      if (lean != e->mfma_dma) {
-         e->mfma_dma = lean;
-         e->mfma_waves = lean ? DMA_WAVES : GATHER_WAVES;
+      bool jit_ok = false;
+      if (e->jit_enabled && !getenv("PAML_AMD_FORCE_GATHER") && jit_supported(e->prog, e->n_tips, e->n_codes)) {
+         const std::string key = jit_program_key(e->prog, e->n_tips);
+         if (e->jit.fn && e->jit.key == key)
+            jit_ok = true;
+         else {
+            if (e->jit.mod) (void)hipModuleUnload(e->jit.mod);
+            e->jit = JitKernel();
+            std::string log;
+            const std::string src = jit_generate(e->prog, e->n_tips);
+            if (getenv("PAML_AMD_JIT_DUMP")) {
+               FILE *f = fopen(getenv("PAML_AMD_JIT_DUMP"), "w");
+               if (f) { fputs(src.c_str(), f); fclose(f); }
+            }
+            if (jit_compile(src, &e->jit, &log) == 0) {
+               e->jit.key = key;
+               jit_ok = true;
+            }
+            else {
+               e->err = "jit: " + log;      // not fatal: the interpreter kernels take over
+               if (getenv("PAML_AMD_JIT_STRICT")) return fail(e, PAML_AMD_EHIP, e->err);
+            }
+         }
+      }
+      e->use_jit = jit_ok;
+      const bool big_tiles = jit_ok || lean;
+      if (big_tiles != e->mfma_dma) {
+         e->mfma_dma = big_tiles;
+         e->mfma_waves = big_tiles ? DMA_WAVES : GATHER_WAVES;
          e->tile_patt = e->mfma_waves * 16;
          int r = build_tiles(e);
          if (r) return r;
@@ -364,7 +395,11 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    mark(e);
    switch (e->kk) {
    case KK_MFMA64:
-      if (use_dma) {
+      if (e->use_jit) {
+         void *params[] = {&pr};
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, n_blocks, 1, 1, 512, 1, 1, 0, e->stream, params, nullptr));
+      }
+      else if (use_dma) {
          const size_t lds = (size_t)4 * 4096 * sizeof(double) + (size_t)e->n_tips * 128;
          static bool attr_set = false;
          if (!attr_set) {
@@ -446,6 +481,11 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    else if (n_states == 5) e->kk = KK_VALU5;
    else if (n_states == 20) e->kk = KK_VALU20;
    else e->kk = KK_MFMA64;
+   {  // per-tree specialised kernels: on request, or by default once the data set is large enough to repay the compile
+      const char *j = getenv("PAML_AMD_JIT");
+      e->jit_enabled = (flags & PAML_AMD_JIT) != 0 || (j && j[0] == '1') || (!j && (long)n_patt * max_classes >= 65536);
+      if (j && j[0] == '0') e->jit_enabled = false;
+   }
    e->mfma_dma = n_tips <= MFMA_ZT && !getenv("PAML_AMD_FORCE_GATHER");
    e->mfma_waves = e->mfma_dma ? DMA_WAVES : GATHER_WAVES;
    e->tile_patt = e->kk == KK_MFMA64 ? e->mfma_waves * 16 : 256;
@@ -469,7 +509,7 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
    case KK_VALU4: return "valu4";
    case KK_VALU5: return "valu5";
    case KK_VALU20: return "valu20";
-   default: return e->mfma_dma ? "mfma64_stream" : "mfma64_gather";
+   default: return e->use_jit ? "mfma64_jit" : (e->mfma_dma ? "mfma64_stream" : "mfma64_gather");
    }
 }
 
@@ -817,6 +857,40 @@ int paml_amd_debug_program(int n_tips, int n_nodes, int root, const int *sons_pt
          ops_out[4 * i + 2] = p.ops[i].b; ops_out[4 * i + 3] = p.ops[i].c;
       }
    return (int)p.ops.size();
+}
+
+int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, const int *sons,
+                       const unsigned char *scale_node, char *text_out, int cap, int compile)
+{
+   if (!sons_ptr || !sons || n_nodes <= 0 || root < 0 || root >= n_nodes) return PAML_AMD_EINVAL;
+   TreeDesc t;
+   t.n_tips = n_tips; t.n_nodes = n_nodes; t.root = root;
+   t.sons_ptr.assign(sons_ptr, sons_ptr + n_nodes + 1);
+   t.sons.assign(sons, sons + sons_ptr[n_nodes]);
+   t.label.assign(n_nodes, 0);
+   t.scale_node.assign(n_nodes, 0);
+   t.scale_slot.assign(n_nodes, -1);
+   if (scale_node)
+      for (int i = 0; i < n_nodes; i++)
+         if (scale_node[i]) { t.scale_node[i] = 1; t.scale_slot[i] = t.n_scale++; }
+   Program p = build_program(t, false, nullptr);
+   if (!jit_supported(p, n_tips, 61)) return PAML_AMD_EUNSUPPORTED;
+   std::string text = jit_generate(p, n_tips);
+   int rc = (int)text.size();
+   if (compile) {
+      std::vector<char> code;
+      std::string log;
+      if (jit_compile_code(text, &code, &log) != 0) {
+         text = log;
+         rc = PAML_AMD_EHIP;
+      }
+   }
+   if (text_out && cap > 0) {
+      const size_t ncp = std::min((size_t)cap - 1, text.size());
+      memcpy(text_out, text.data(), ncp);
+      text_out[ncp] = 0;
+   }
+   return rc;
 }
 
 int paml_amd_counters(const paml_amd_engine *e, long *n_eval, long *n_pmat)

@@ -1,0 +1,207 @@
+// jit.h — per-tree specialised pruning kernel.
+//
+// The interpreter kernels (kernels.h) pay for their generality on every op: a switch dispatch, scalar
+// loads of the op and stream tables, and — worst on CDNA4, where FP64 MFMA and VALU share the SIMD's
+// issue — dozens of v_mov per op that the compiler needs to merge the loop-carried partials.  For a fixed
+// tree the op sequence is known when paml_amd_set_tree returns, so this header unrolls it: it emits one
+// straight-line HIP kernel (a few dozen calls into the hand-written building blocks of device_common.h,
+// every block index, ring slot, wait count and register array a literal), compiles it for gfx950 with
+// hiprtc and caches the module.  Partials are renamed instead of copied: each MFMA result is a fresh
+// v4d[4] that *is* the next partial.  Same arithmetic, same operand stream, same LDS ring as
+// prune_mfma64_stream; the interpreter remains the fallback (deep stacks, > 64 codes, > 128 tips, no hiprtc).
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "program.h"
+
+namespace paml_amd {
+
+struct JitKernel {
+   hipModule_t mod = nullptr;
+   hipFunction_t fn = nullptr;
+   std::string key;
+   size_t n_ops = 0;
+};
+
+// Which programs the generator covers.
+inline bool jit_supported(const Program &p, int n_tips, int n_codes, int max_arrays = 6)
+{
+   if (n_tips > MFMA_ZT || n_codes > 64 || p.ops.size() > 400) return false;
+   for (const Op &o : p.ops)
+      if (o.code == OP_STORE || o.code == OP_LOAD) return false;   // keep-partials layouts stay with the interpreter
+   return p.max_stack + 2 <= max_arrays;
+}
+
+inline std::string jit_program_key(const Program &p, int n_tips)
+{
+   std::ostringstream k;
+   k << n_tips << ":";
+   for (const Op &o : p.ops) k << o.code << "," << o.a << "," << o.b << ";";
+   return k.str();
+}
+
+// Emit the straight-line kernel for one program.
+inline std::string jit_generate(const Program &p, int n_tips)
+{
+   std::ostringstream s;
+   const int nblk = (int)p.stream.size() / 2;
+   s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
+   s << "extern \"C\" __global__ __launch_bounds__(512, 2) void prune_jit(PruneArgs a)\n{\n";
+   s << "   JIT_PROLOGUE(" << n_tips << ")\n";
+   int issued = 0;
+   auto issue = [&]() {
+      const int is_tip = p.stream[2 * issued], node = p.stream[2 * issued + 1];
+      s << "   " << (is_tip ? "JIT_ISSUE_T(" : "JIT_ISSUE_P(") << issued << ", " << node << ");\n";
+      issued++;
+   };
+   for (int i = 0; i < 3 && issued < nblk; i++) issue();
+   s << "   JIT_STAGE_Z(" << n_tips << ")\n";
+
+   // register arrays: a free list; `cur` names the array holding the partial under construction
+   const int NA = p.max_stack + 2;
+   for (int i = 0; i < NA; i++) s << "   v4d A" << i << "[4];\n";
+   std::vector<int> freeA;
+   for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
+   auto alloc = [&]() { int r = freeA.back(); freeA.pop_back(); return r; };
+   auto release = [&](int r) { freeA.push_back(r); };
+   std::vector<int> slot(256, -1);   // stack slot -> array
+   int cur = -1;
+   int consumed = 0;
+   auto step = [&](int c) {   // make the next c blocks visible, then top the ring up
+      s << "   JIT_WAIT(" << 4 * (issued - (consumed + c)) << "); __syncthreads();\n";
+      while (issued < consumed + 4 && issued < nblk) issue();
+   };
+   auto name = [&](int r) { return "A" + std::to_string(r); };
+
+   for (const Op &o : p.ops) {
+      switch (o.code) {
+      case OP_INIT_ONES:
+         if (cur < 0) cur = alloc();
+         s << "   jit_init_ones(" << name(cur) << ", q, n);\n";
+         break;
+      case OP_INIT_TIP:
+         if (cur < 0) cur = alloc();
+         s << "   jit_init_tip(" << name(cur) << ", JIT_CODE(" << o.a << "), q, a.cleandata);\n";
+         break;
+      case OP_SET_TIP:
+         if (cur < 0) cur = alloc();
+         step(1);
+         s << "   jit_tip_set(" << name(cur) << ", JIT_BUF(" << consumed << "), JIT_CODE(" << o.a << "), q, lane);\n";
+         consumed += 1;
+         break;
+      case OP_MUL_TIP:
+         step(1);
+         s << "   jit_tip_mul(" << name(cur) << ", JIT_BUF(" << consumed << "), JIT_CODE(" << o.a << "), q, lane);\n";
+         consumed += 1;
+         break;
+      case OP_SET_TIP2:
+      case OP_MUL_TIP2:
+         if (cur < 0) cur = alloc();
+         step(2);
+         s << "   " << (o.code == OP_SET_TIP2 ? "jit_tip2_set(" : "jit_tip2_mul(") << name(cur) << ", JIT_BUF(" << consumed
+           << "), JIT_CODE(" << o.a << "), JIT_BUF(" << consumed + 1 << "), JIT_CODE(" << o.b << "), q, lane);\n";
+         consumed += 2;
+         break;
+      case OP_PUSH:
+         slot[o.b] = cur;
+         cur = -1;
+         break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         const int pop = mm_pop_slot(o), push = mm_push_slot(o);
+         const int out = alloc();
+         step(1);
+         s << "   jit_matvec(JIT_BUF(" << consumed << "), lane, " << name(cur) << ", " << name(out) << ");\n";
+         consumed += 1;
+         release(cur);
+         if (pop >= 0) {
+            s << "   jit_mul(" << name(out) << ", " << name(slot[pop]) << ");\n";
+            release(slot[pop]);
+            slot[pop] = -1;
+         }
+         if (push >= 0) {
+            slot[push] = out;
+            cur = -1;
+         }
+         else
+            cur = out;
+      } break;
+      case OP_SCALE:
+         s << "   { const double fac = jit_scale(" << name(cur) << ", q, n); lnscale += fac;\n"
+           << "     if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + " << o.b << ") * a.n_patt + h] = fac; }\n";
+         break;
+      case OP_ROOT:
+         s << "   jit_root(a, " << name(cur) << ", lnscale, gene, iclass, q, h, valid);\n";
+         break;
+      default: break;
+      }
+   }
+   s << "}\n";
+   return s.str();
+}
+
+inline std::string jit_source_dir()
+{
+   Dl_info info;
+   if (dladdr((const void *)&jit_source_dir, &info) && info.dli_fname) {
+      std::string so = info.dli_fname;                 // .../paml_amd/lib/libpaml_amd.so
+      const size_t cut = so.rfind('/');
+      const std::string libdir = cut == std::string::npos ? "." : so.substr(0, cut);
+      return libdir + "/../csrc";
+   }
+   return "paml_amd/csrc";
+}
+
+// Compile `src` for gfx950 (works without a GPU).  Returns 0 on success; `log` gets the compiler output.
+inline int jit_compile_code(const std::string &src, std::vector<char> *code, std::string *log)
+{
+   hiprtcProgram prog;
+   if (hiprtcCreateProgram(&prog, src.c_str(), "prune_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+      *log = "hiprtcCreateProgram failed";
+      return -1;
+   }
+   const std::string inc = "-I" + jit_source_dir();
+   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
+   const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+   size_t ls = 0;
+   hiprtcGetProgramLogSize(prog, &ls);
+   if (ls > 1) {
+      log->resize(ls);
+      hiprtcGetProgramLog(prog, &(*log)[0]);
+   }
+   if (r != HIPRTC_SUCCESS) {
+      hiprtcDestroyProgram(&prog);
+      return -1;
+   }
+   size_t cs = 0;
+   hiprtcGetCodeSize(prog, &cs);
+   code->resize(cs);
+   hiprtcGetCode(prog, code->data());
+   hiprtcDestroyProgram(&prog);
+   return 0;
+}
+
+// Compile and load.
+inline int jit_compile(const std::string &src, JitKernel *out, std::string *log)
+{
+   std::vector<char> code;
+   if (jit_compile_code(src, &code, log) != 0) return -1;
+   if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) {
+      *log = "hipModuleLoadData failed";
+      return -1;
+   }
+   if (hipModuleGetFunction(&out->fn, out->mod, "prune_jit") != hipSuccess) {
+      *log = "hipModuleGetFunction failed";
+      return -1;
+   }
+   return 0;
+}
+
+}  // namespace paml_amd

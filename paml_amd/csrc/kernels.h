@@ -4,12 +4,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "../../include/paml_amd.h"
+#include "device_common.h"
 #include "program.h"
 
 namespace paml_amd {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct EigenDev {
    int kind, nR;
@@ -190,41 +189,6 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
 // ------------------------------------------------------------------------------------------------
 // Pruning kernels: arguments shared by the MFMA and VALU variants.
 // ------------------------------------------------------------------------------------------------
-struct PruneArgs {
-   const Op *ops;
-   const unsigned char *z;     // [n_tips][z_stride]
-   long z_stride;
-   const int2 *tiles;          // (gene, first pattern) per tile
-   int n_tiles;
-   const int *gene_off;
-   const double *weights;
-   int n, n_tips, n_nodes, K, n_genes, n_codes, cleandata, n_pi, mode, n_scale, keep, n_patt;
-   const double *pi;           // VALU: [n_pi][n];  mfma64: [n_pi][4][16] (q-major, zero padded)
-   const double *pint;         // per (pset, node): n*n row-major (VALU) or 4096 frag (mfma64)
-   const double *ptip;         // per (pset, node): n_codes * tipw
-   double *fhK;                // [K][n_patt]
-   double *partials;           // keep mode
-   double *scalef;             // keep mode: [K][n_scale][n_patt]
-   double *stack_scratch;      // overflow stack (mfma64)
-   int stack_overflow_slots;
-   int first_matmul;
-   int n_int;                  // n_nodes - n_tips
-   int first_tip;              // first tip whose column table is consumed
-   const void *stream;         // stream kernel: operand blocks in order of use, {is_tip, node} pairs
-   int n_stream;
-   long tip_words;             // doubles per tip table
-   unsigned long long *prof;   // PROF_OPS builds only: [block][op] s_memtime stamps of thread 0
-   int prof_stride, prof_tid;
-};
-
-__device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)
-{
-   // fx_r treesub.c:7731-7749 / lfun 7782-7798: floors then log + scale factors
-   if (f <= 0) f = (a.mode == PAML_AMD_MODE_LFUN ? 1e-80 : 1e-300);
-   if (a.mode == PAML_AMD_MODE_LFUN || a.n_scale) f = log(f) + lnscale;
-   return f;
-}
-
 // ---- mfma64: 21..64 states, FP64 MFMA -----------------------------------------------------------
 // One wave owns 16 patterns for the whole tree.  A partial is 16 doubles per lane: lane l holds, for
 // pattern (l & 15), the states 4m + (l >> 4), m = 0..15.  That is simultaneously
@@ -234,85 +198,6 @@ __device__ __forceinline__ double root_value(const PruneArgs &a, double f, doubl
 // partials.  The A operand (P) is staged once per workgroup per branch into LDS in exactly the order
 // lanes consume it (pmat_kernel's `frag` layout), double-buffered so the next branch's P streams in
 // under the current MFMAs.  Tip branches are gathers from L2-resident column tables.
-#define MFMA_RS 2      // register stack slots; deeper slots spill to global scratch
-#define MFMA_ZT 128    // most tips whose codes the dma kernel keeps in LDS
-
-// Wave-uniform, read-only data (the tree program, tile table, P(t) entries of the VALU kernels) is read
-// through the constant address space so the compiler uses scalar loads (s_load, lgkmcnt) instead of a
-// vector load + vmcnt(0) wait that would also drain the in-flight LDS-DMA prefetches.
-#define CONST_AS __attribute__((address_space(4)))
-template <typename T>
-__device__ __forceinline__ const CONST_AS T *as_const(const T *p)
-{
-   return (const CONST_AS T *)(unsigned long long)p;
-}
-typedef int v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ Op fetch_op(const Op *ops, int ip)
-{
-   const v4i o = ((const CONST_AS v4i *)(unsigned long long)ops)[ip];   // one s_load_dwordx4
-   return Op{o.x, o.y, o.z, o.w};
-}
-
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
-
-// LDS-DMA through a raw buffer descriptor: address = SGPR descriptor base + 32-bit VGPR offset + SGPR
-// offset, so no 64-bit per-lane pointers exist for the compiler to hoist and spill.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
-{
-   return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, bytes, 0x00020000);
-}
-
-// Stage one 32 KB P (already in MFMA operand order) global -> LDS with the LDS-DMA path: each wave
-// instruction moves 64 lanes x 16 B = 1 KiB to a wave-uniform LDS base, no VGPR round trip.
-template <int WAVES>
-__device__ __forceinline__ void stage_p(const double *g, double *s, int wave, int lane)
-{
-#ifdef ABL_NO_STAGE
-   return;
-#endif
-   const __amdgpu_buffer_rsrc_t r = make_rsrc(g, 32768);
-#pragma unroll
-   for (int c = 0; c < 32 / WAVES; c++) {
-      const int chunk = c * WAVES + wave;   // wave-uniform
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t *)((char *)s + chunk * 1024), 16, lane * 16, chunk * 1024, 0, 0);
-   }
-}
-
-// 64 MFMAs: acc = P . cur, with P's fragments read from LDS one k-block pair ahead of their use.
-__device__ __forceinline__ void mfma_matvec(const double *sPbuf, int lane, const double (&cur)[16], v4d (&acc)[4])
-{
-   const double2 *sp = (const double2 *)sPbuf;
-#pragma unroll
-   for (int jb = 0; jb < 4; jb++) acc[jb] = (v4d){0, 0, 0, 0};
-#ifdef ABL_NO_MFMA
-#pragma unroll
-   for (int jb = 0; jb < 4; jb++) {
-      const double2 a2 = sp[jb * 64 + lane];
-      acc[jb] = (v4d){a2.x * cur[4 * jb], a2.y * cur[4 * jb + 1], a2.x * cur[4 * jb + 2], a2.y * cur[4 * jb + 3]};
-   }
-#else
-   double2 af[2][4];
-#pragma unroll
-   for (int jb = 0; jb < 4; jb++) af[0][jb] = sp[jb * 64 + lane];
-#pragma unroll
-   for (int kb2 = 0; kb2 < 8; kb2++) {
-      if (kb2 + 1 < 8) {
-#pragma unroll
-         for (int jb = 0; jb < 4; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the next pair's ds_reads ahead of this pair's MFMAs
-#pragma unroll
-      for (int jb = 0; jb < 4; jb++)
-         acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, cur[2 * kb2], acc[jb], 0, 0, 0);
-#pragma unroll
-      for (int jb = 0; jb < 4; jb++)
-         acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, cur[2 * kb2 + 1], acc[jb], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-   }
-#endif
-}
-
 // Shared op bodies of the two mfma64 kernels (textual, so every register array keeps static indices).
 #define MFMA_EPI_INTO(DST)                                                                                       \
    do {                                                                                                         \
@@ -551,29 +436,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_gather(PruneArgs a
 // so neither P nor tip data is ever waited for at L2 latency, no VGPRs hold data in flight, and every
 // DMA instruction is a fully coalesced 1 KB line burst.  Tip factors are then LDS gathers (rows are
 // XOR-swizzled by pmat_kernel so random rows spread over the banks); one s_barrier per step.
-struct StreamBlk { int is_tip, node; };
-
-__device__ __forceinline__ void wait_blocks_in_flight(int n)   // allow the n newest blocks (4 loads each) to fly
-{
-   if (n >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-   else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-   else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-__device__ __forceinline__ void tip_lds(const double *tab, int code, int q, int lane, double2 (&v)[8])
-{
-#ifdef ABL_NO_TIPLOAD
-#pragma unroll
-   for (int p = 0; p < 8; p++) v[p] = make_double2(0.5 + code * 1e-3, 0.25 + q * 1e-3);
-   return;
-#endif
-   const int row = code * 4 + q, swz = (row >> 1) & 7;
-   const char *base = (const char *)tab + row * 128;
-#pragma unroll
-   for (int p = 0; p < 8; p++) v[p] = *(const double2 *)(base + ((p ^ swz) * 16));
-}
-
 __global__ __launch_bounds__(512, 2) void prune_mfma64_stream(PruneArgs a)
 {
    constexpr int WAVES = 8, TP = 128;

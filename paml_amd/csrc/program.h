@@ -17,30 +17,12 @@
 // internal son needs no PUSH and the stack depth is <= log2(n_tips); products commute, so only the
 // rounding order differs from the reference's sons[] order.
 #pragma once
-#include <hip/hip_runtime.h>
-
 #include <algorithm>
 #include <vector>
 
+#include "device_common.h"
+
 namespace paml_amd {
-
-enum OpCode : int {
-   OP_INIT_ONES = 0, OP_INIT_TIP = 1, OP_MUL_TIP = 2, OP_PUSH = 3, OP_MATMUL = 4, OP_MATMUL_POP = 5,
-   OP_SCALE = 6, OP_STORE = 7, OP_LOAD = 8, OP_ROOT = 9, OP_END = 10,
-   // fused forms produced by the peephole pass (same arithmetic, fewer dependent memory round trips):
-   OP_SET_TIP = 11,    // cur = tipcol(a)                 == INIT_ONES ; MUL_TIP a
-   OP_SET_TIP2 = 12,   // cur = tipcol(a) * tipcol(b)     == INIT_ONES ; MUL_TIP a ; MUL_TIP b   (a cherry)
-   OP_MUL_TIP2 = 13    // cur *= tipcol(a) * tipcol(b)    == MUL_TIP a ; MUL_TIP b
-};
-
-struct Op { int code, a, b, c; };   // a: node/tip, b: stack slot / scale slot / 2nd tip, c: prefetch link (-1 none)
-// MATMUL / MATMUL_POP encode two stack slots in b: bits 0..7 = (slot popped + 1), bits 8..15 = (slot the
-// result is pushed to + 1); 0 = none.  A push slot means "MATMUL[_POP] ; PUSH" fused: the result goes
-// straight to the stack slot and `cur` is dead until the next INIT/SET op.
-// Prefetch links: for MATMUL ops c = son of the next MATMUL (its P is staged while this one computes);
-// for tip ops c = the next tip in program order (its column table is fetched ahead of use).
-__host__ __device__ inline int mm_pop_slot(const Op &o) { return (o.b & 0xff) - 1; }
-__host__ __device__ inline int mm_push_slot(const Op &o) { return ((o.b >> 8) & 0xff) - 1; }
 
 struct TreeDesc {
    int n_tips = 0, n_nodes = 0, root = -1;

@@ -19,13 +19,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAML_AMD_LIB") or os.path.join(_HERE, "lib", "libpaml_amd.so")   # override: kernel experiments
 CSRC = os.path.join(_HERE, "csrc")
 KEEP_PARTIALS = 1
+JIT = 2
 
 EXPORTS = [
     "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
-    "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program",
+    "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
 
@@ -35,14 +36,14 @@ class EngineError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.h", "program.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.h", "program.h", "device_common.h", "jit.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "paml_amd.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH,
-           os.path.join(CSRC, "engine.hip")]
+           os.path.join(CSRC, "engine.hip"), "-lhiprtc", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -249,6 +250,20 @@ def debug_program(tree, scale_node=None, keep=False, clean=None):
     if nops < 0:
         raise EngineError("debug_program failed (%d)" % nops)
     return [tuple(int(v) for v in r) for r in ops[:nops]], ms.value
+
+
+def debug_jit(tree, scale_node=None, compile=True):
+    """Host-only: source of the kernel specialised for `tree` (hiprtc-compiled for gfx950 when compile=True)."""
+    L = lib()
+    ptr, flat = tree.csr()
+    sc = None if scale_node is None else np.ascontiguousarray(scale_node, dtype=np.uint8)
+    cap = 1 << 20
+    buf = C.create_string_buffer(cap)
+    L.paml_amd_debug_jit.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    rc = L.paml_amd_debug_jit(tree.n_tips, tree.n_nodes, tree.root, _p(ptr), _p(flat), _p(sc), buf, cap, int(compile))
+    if rc < 0:
+        raise EngineError("debug_jit failed (%d): %s" % (rc, buf.value.decode(errors="replace")[-3000:]))
+    return buf.value.decode()
 
 
 def engine_for(pb: Problem, flags=0) -> Engine:
