@@ -95,8 +95,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, bytes, 0x00020000);
 }
 
-// Stage one 32 KB P (already in MFMA operand order) global -> LDS with the LDS-DMA path: each wave
-// instruction moves 64 lanes x 16 B = 1 KiB to a wave-uniform LDS base, no VGPR round trip.
+// One LDS-DMA instruction: 64 lanes x 16 B from (descriptor base + voff + soff) to the wave-uniform LDS
+// address `lds` (+ lane*16).  Issued from inline asm on purpose: hipcc treats a visible LDS-DMA as a pending
+// LDS write and puts s_waitcnt vmcnt(0) in front of EVERY later ds_read and barrier, which would serialise
+// the prefetch stream with its consumers.  All ordering is explicit instead: counted s_waitcnt vmcnt(N)
+// (loads retire in issue order) followed by a workgroup barrier before any wave reads the landed block.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, const void *lds, int voff, int soff)
+{
+   const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)lds;
+   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                :
+                : "s"(la), "v"(voff), "s"(r), "s"(soff)
+                : "memory", "m0");
+}
+
+// Stage one 32 KB block (a P in MFMA operand order, or a tip's column table) global -> LDS: each wave
+// instruction moves 1 KiB to a wave-uniform LDS base, no VGPR round trip.
 template <int WAVES>
 __device__ __forceinline__ void stage_p(const double *g, double *s, int wave, int lane)
 {
@@ -107,10 +121,9 @@ __device__ __forceinline__ void stage_p(const double *g, double *s, int wave, in
 #pragma unroll
    for (int c = 0; c < 32 / WAVES; c++) {
       const int chunk = c * WAVES + wave;   // wave-uniform
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t *)((char *)s + chunk * 1024), 16, lane * 16, chunk * 1024, 0, 0);
+      dma16(r, (const char *)s + chunk * 1024, lane * 16, chunk * 1024);
    }
 }
-
 
 // 64 MFMAs: acc = P . cur, with P's fragments read from LDS one k-block pair ahead of their use.
 __device__ __forceinline__ void mfma_matvec(const double *sPbuf, int lane, const double (&cur)[16], v4d (&acc)[4])

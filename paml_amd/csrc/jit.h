@@ -15,6 +15,7 @@
 #include <hip/hiprtc.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -75,7 +76,7 @@ inline std::string jit_generate(const Program &p, int n_tips)
    int cur = -1;
    int consumed = 0;
    auto step = [&](int c) {   // make the next c blocks visible, then top the ring up
-      s << "   JIT_WAIT(" << 4 * (issued - (consumed + c)) << "); __syncthreads();\n";
+      s << "   JIT_WAIT(" << 4 * (issued - (consumed + c)) << "); " << (getenv("PAML_AMD_JIT_NOBAR") ? "" : "__syncthreads();") << "\n";
       while (issued < consumed + 4 && issued < nblk) issue();
    };
    auto name = [&](int r) { return "A" + std::to_string(r); };
