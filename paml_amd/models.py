@@ -127,3 +127,48 @@ def discrete_gamma(alpha: float, K: int):
 def expm_rev(U, V, root, t):
     """P(t) = U exp(root t) V (plain numpy; generator use only)."""
     return (U * np.exp(root * t)[None, :]) @ V
+
+
+def read_aa_ratefile(path: str):
+    """Empirical amino-acid model file (dat/*.dat): lower-triangle exchangeabilities then 20 frequencies, amino acids in
+    the order ARNDCQEGHILKMFPSTWYV (GetDaa codeml.c:3967-4009).  Returns (S symmetric 20x20, pi)."""
+    toks = []
+    with open(path) as f:
+        for line in f:
+            for t in line.split():
+                try:
+                    toks.append(float(t))
+                except ValueError:
+                    break
+            if len(toks) >= 190 + 20:
+                break
+    S = np.zeros((20, 20))
+    k = 0
+    for i in range(20):
+        for j in range(i):
+            S[i, j] = S[j, i] = toks[k]
+            k += 1
+    pi = np.array(toks[190:210])
+    return S, pi      # used as read, NOT renormalised — the reference only checks |1 - sum| < 1e-5 (codeml.c:4004-4008)
+
+
+def aa_empirical_eigen(S: np.ndarray, pi: np.ndarray):
+    """U, V, Root of the empirical aa model scaled to mean rate 1 (eigenQaa codeml.c:3400-3484)."""
+    Q = S * pi[None, :]
+    np.fill_diagonal(Q, 0.0)
+    Q[np.diag_indices(20)] = -Q.sum(axis=1)
+    mr = -float(np.dot(pi, np.diag(Q)))
+    U, V, root = eigen_rev(Q, pi)
+    return U, V, root / mr
+
+
+def aa_code_map():
+    """nChara / CharaMap for amino acids with cleandata = 0 (SetMapAmbiguity treesub.c:1218-1247): the 20 residues map
+    to themselves, '-', '*', '?', 'X' to all 20 states.  Codes index the string AAs + '-*?X' (tools.c:19)."""
+    n_codes = 24
+    n_chara = np.ones(n_codes, dtype=np.int32)
+    cmap = np.zeros((n_codes, 20), dtype=np.uint8)
+    cmap[:20, 0] = np.arange(20)
+    n_chara[20:] = 20
+    cmap[20:] = np.arange(20)
+    return n_chara, cmap

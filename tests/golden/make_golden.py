@@ -117,7 +117,7 @@ def encode(pats, seqtype):
     elif seqtype == "nuc":
         lut = {b: i for i, b in enumerate(models.BASES)}
     else:
-        lut = {a: i for i, a in enumerate(models.AAS)}
+        lut = {a: i for i, a in enumerate(models.AAS + "-*?X")}
     z = np.array([[lut.get(tok, 255) for tok in p[2]] for p in pats], dtype=int).T
     return z
 
@@ -214,9 +214,41 @@ def case_brown():
                                                names=["Human", "Chimpanzee", "Gorilla", "Orangutan", "Gibbon"]))
 
 
+def case_stewart():
+    x = [float(v) for v in "0.000004 0.019085 0.083331 0.034683 0.067995 0.339072 0.104868 0.276662 0.861606 1.064411".split()]
+    ctl = dict(CODEML_BASE, seqfile="stewart.aa", treefile="stewart.trees", outfile="mlc", seqtype=2, model=2,
+               aaRatefile="lg.dat", fix_alpha=0, alpha=0.5, ncatG=4, cleandata=0)
+    tree1 = " 6 1\n(((Langur, Baboon), Human), Rat, (Cow, Horse));\n"
+    res = run_ref("codeml", ctl, {"stewart.aa": EX + "/stewart.aa", "stewart.trees": tree1, "lg.dat": DAT + "/lg.dat"}, x=x)
+    finish("stewart_lg_g4", res, "aa", 6,
+           dict(program="codeml", model=dict(kind="aa_empirical_gamma", ratefile="lg.dat", alpha=x[-1], ncatG=4), x=x, ntime=9))
+
+
+def case_mhc():
+    """192 taxa: exercises NodeScale (10 scaling nodes).  First the reference optimises kappa/omega with the published
+    fix_blength=2 set-up (README lnL -8225.154790), then the golden is the single evaluation at the 6-decimal MLEs."""
+    files = {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}
+    ctl = dict(CODEML_BASE, seqfile="bigmhc.phy", treefile="bigmhc.trees", outfile="mlc", NSsites=0, kappa=1.6, omega=.9,
+               fix_blength=2, Small_Diff=".1e-6", method=0, cleandata=0)   # cleandata=0 as in the example: ambiguous codons kept
+    res = run_ref("codeml", ctl, files)
+    kap = float(re.search(r"kappa \(ts/tv\) =\s*([0-9.]+)", res["main"]).group(1))
+    omg = float(re.search(r"omega \(dN/dS\) =\s*([0-9.]+)", res["main"]).group(1))
+    xs = re.search(r"lnL\(ntime:[^\n]*\n([^\n]+)\n", res["main"])
+    x = [float(v) for v in xs.group(1).split()]
+    print("   MHC MLE lnL %.6f  x = %s (printed kappa %.5f omega %.5f)" % (res["lnL"], x, kap, omg))
+    ctl1 = dict(ctl, fix_kappa=1, kappa="%.6f" % x[0], fix_omega=1, omega="%.6f" % x[1])
+    res1 = run_ref("codeml", ctl1, files)
+    scal = re.search(r"(\d+) node\(s\) used for scaling.*?\n([ 0-9]+)\n", res1["stdout"])
+    finish("mhc_m0_scaled", res1, "codon", 192,
+           dict(program="codeml", model=dict(kind="codon_m0", kappa=x[0], omega=x[1], codonfreq="F3x4"),
+                published_lnL=-8225.154790, mle_lnL=res["lnL"],
+                scale_nodes=[int(v) for v in scal.group(2).split()] if scal else None))
+
+
 CASES = {
     "hiv_m0": lambda: case_hiv("m0"), "hiv_m1a": lambda: case_hiv("m1a"), "hiv_m2a": lambda: case_hiv("m2a"),
     "hiv_m7": lambda: case_hiv("m7"), "hiv_m8": lambda: case_hiv("m8"),
+    "stewart_lg_g4": case_stewart, "mhc_m0_scaled": case_mhc,
     "syn_codon_m0": case_syn_codon, "syn_nuc_gtr_g4": case_syn_nuc, "brown_hky85": case_brown,
 }
 

@@ -51,8 +51,85 @@ def nssites_classes(ns, par, ncatG):
     raise ValueError(ns)
 
 
+EQUATE_BASE = dict(zip("TCAGUYRMKSWHBVD-N?", ["T", "C", "A", "G", "T", "TC", "AG", "CA", "TG", "CG", "TA", "TCA", "TCG", "CAG", "TAG",
+                                             "TCAG", "TCAG", "TCAG"]))   # tools.c:15-17
+
+
+def codon_codes_with_ambiguity(patterns_raw):
+    """z, n_chara, chara_map for codon patterns that may hold ambiguous codons (EncodeSeqs treesub.c:1145-1172 +
+    SetMapAmbiguity treesub.c:1253-1272): sense codons are codes 0..60, every distinct ambiguous triplet gets the next
+    code and maps to its compatible sense codons in the reference's i0,i1,i2 expansion order."""
+    from61 = models.sense_codons()
+    from64 = {c: i for i, c in enumerate(from61)}
+    sense = {"".join(models.BASES[(c >> s) & 3] for s in (4, 2, 0)): i for i, c in enumerate(from61)}
+    amb = {}
+    rows = []
+    for pat in patterns_raw:
+        row = []
+        for tok in pat.split():
+            if tok in sense:
+                row.append(sense[tok])
+            else:
+                if tok not in amb:
+                    amb[tok] = 61 + len(amb)
+                row.append(amb[tok])
+        rows.append(row)
+    z = np.array(rows, dtype=np.uint8).T
+    n_codes = 61 + len(amb)
+    n_chara = np.ones(n_codes, dtype=np.int32)
+    cmap = np.zeros((n_codes, 61), dtype=np.uint8)
+    cmap[:61, 0] = np.arange(61)
+    for tok, code in amb.items():
+        lst = []
+        for b0 in EQUATE_BASE[tok[0]]:
+            for b1 in EQUATE_BASE[tok[1]]:
+                for b2 in EQUATE_BASE[tok[2]]:
+                    ic = models.BASES.index(b0) * 16 + models.BASES.index(b1) * 4 + models.BASES.index(b2)
+                    if ic in from64:
+                        lst.append(from64[ic])
+        n_chara[code] = len(lst)
+        cmap[code, :len(lst)] = lst
+    return z, n_chara, cmap
+
+
+def f3x4_with_ambiguity(z, w, n_chara, cmap, iters=20):
+    """F3x4 when ambiguous codons are present: the reference resolves them iteratively in proportion to the current
+    codon frequencies (InitializeCodon codeml.c:3800-3850, AddCodonFreqSeqGene); fb3x4 then comes from the resolved counts."""
+    from61 = np.array(models.sense_codons())
+    n_codes = len(n_chara)
+    counts = np.array([(w[None, :] * (z == c)).sum() for c in range(n_codes)])
+    fcod = counts[:61] / counts[:61].sum()
+    fb = None
+    for _ in range(iters):
+        tot = counts[:61].copy()
+        for c in range(61, n_codes):
+            if counts[c] == 0:
+                continue
+            members = cmap[c, :n_chara[c]]
+            p = fcod[members]
+            p = p / p.sum() if p.sum() > 0 else np.full(len(members), 1.0 / len(members))
+            tot[members] += counts[c] * p
+        fnew = tot / tot.sum()
+        cod = from61
+        fb = np.zeros((3, 4))
+        for pos, b in enumerate((cod // 16, (cod // 4) % 4, cod % 4)):
+            for k in range(4):
+                fb[pos, k] = tot[b == k].sum()
+        fb /= fb.sum(axis=1, keepdims=True)
+        if np.abs(fnew - fcod).max() < 1e-10:
+            fcod = fnew
+            break
+        fcod = fnew
+    return fb
+
+
 def problem_from_golden(g) -> Problem:
-    if "z" in g:
+    amb = None
+    if "patterns_raw" in g and g["seqtype"] == "codon":
+        z, nch, cm = codon_codes_with_ambiguity(g["patterns_raw"])
+        w = np.array(g["counts"], dtype=float)
+        amb = (nch, cm)
+    elif "z" in g:
         z = np.array(g["z"], dtype=np.uint8)
         w = np.array(g["counts"], dtype=float)
     else:
@@ -64,10 +141,26 @@ def problem_from_golden(g) -> Problem:
     m = g["model"]
     kind = m["kind"]
     if kind == "codon_m0":
-        pi = models.f3x4(synth.f3x4_from_codon_tips(z, w))
+        kw = {}
+        if amb is not None:
+            pi = models.f3x4(f3x4_with_ambiguity(z, w, *amb))
+            kw = dict(cleandata=0, n_chara=amb[0], chara_map=amb[1])
+        else:
+            pi = models.f3x4(synth.f3x4_from_codon_tips(z, w))
+        if g.get("scale_nodes"):
+            sc = np.zeros(tree.n_nodes, dtype=np.uint8)
+            sc[np.array(g["scale_nodes"]) - 1] = 1          # the reference prints 1-based node numbers
+            kw["scale_node"] = sc
         U, V, root, _ = models.codon_m0_eigen(m["kappa"], m["omega"], pi)
         return Problem(n=61, tree=tree, z=z, weights=w, pi=pi, eigen=[dict(kind=EIGEN_UVROOT, U=U, V=V, Root=root)],
-                       mode=MODE_LFUN)
+                       mode=MODE_LFUN, **kw)
+    if kind == "aa_empirical_gamma":
+        S, pi = models.read_aa_ratefile(os.path.join(GOLDEN, "data", m["ratefile"]))
+        U, V, root = models.aa_empirical_eigen(S, pi)
+        n_chara, cmap = models.aa_code_map()
+        freqK, rK = models.discrete_gamma(m["alpha"], m["ncatG"])
+        return Problem(n=20, tree=tree, z=z, weights=w, pi=pi, eigen=[dict(kind=EIGEN_UVROOT, U=U, V=V, Root=root)],
+                       mode=MODE_LFUNDG, freqK=freqK, rate=rK, cleandata=0, n_chara=n_chara, chara_map=cmap)
     if kind == "codon_nssites":
         x = g["x"]
         nt = g["ntime"]

@@ -11,7 +11,8 @@ from paml_amd.engine import KEEP_PARTIALS, engine_for
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = ["hiv_m0", "hiv_m1a", "hiv_m2a", "hiv_m7", "hiv_m8", "syn_codon_m0", "syn_nuc_gtr_g4", "brown_hky85"]
+GOLDEN = ["hiv_m0", "hiv_m1a", "hiv_m2a", "hiv_m7", "hiv_m8", "syn_codon_m0", "syn_nuc_gtr_g4", "brown_hky85",
+          "stewart_lg_g4", "mhc_m0_scaled"]
 
 
 def check(pb, lnl_rtol=1e-10, lnf_atol=1e-9, flags=0):
