@@ -92,35 +92,37 @@ def codon_codes_with_ambiguity(patterns_raw):
     return z, n_chara, cmap
 
 
-def f3x4_with_ambiguity(z, w, n_chara, cmap, iters=20):
-    """F3x4 when ambiguous codons are present: the reference resolves them iteratively in proportion to the current
-    codon frequencies (InitializeCodon codeml.c:3800-3850, AddCodonFreqSeqGene); fb3x4 then comes from the resolved counts."""
-    from61 = np.array(models.sense_codons())
-    n_codes = len(n_chara)
-    counts = np.array([(w[None, :] * (z == c)).sum() for c in range(n_codes)])
-    fcod = counts[:61] / counts[:61].sum()
-    fb = None
-    for _ in range(iters):
-        tot = counts[:61].copy()
-        for c in range(61, n_codes):
-            if counts[c] == 0:
+def f3x4_with_ambiguity(patterns_raw, w, iters=20):
+    """F3x4 when ambiguous codons are present, as InitializeCodon does it (codeml.c:3772-3850): start from the fully
+    resolved codons only (CountCodons 3671-3690), then up to 20 rounds in which every nucleotide position of every
+    codon adds fpatt * fb3x4_old[pos][b] / sum over its ambiguity set (AddCodonFreqSeqGene 3726-3750, per position,
+    stop codons not considered), renormalise, stop when the change is < 1e-8."""
+    bidx = {b: i for i, b in enumerate(models.BASES)}
+    sets = {c: [bidx[x] for x in EQUATE_BASE[c]] for c in EQUATE_BASE}
+    toks = [p.split() for p in patterns_raw]
+    fb0 = np.zeros((3, 4))
+    for pat, wt in zip(toks, w):
+        for tok in pat:
+            s = [sets[ch] for ch in tok]
+            if len(s[0]) * len(s[1]) * len(s[2]) > 1:
                 continue
-            members = cmap[c, :n_chara[c]]
-            p = fcod[members]
-            p = p / p.sum() if p.sum() > 0 else np.full(len(members), 1.0 / len(members))
-            tot[members] += counts[c] * p
-        fnew = tot / tot.sum()
-        cod = from61
+            for k in range(3):
+                fb0[k, s[k][0]] += wt
+    fb0 /= fb0.sum(axis=1, keepdims=True)
+    for _ in range(iters):
         fb = np.zeros((3, 4))
-        for pos, b in enumerate((cod // 16, (cod // 4) % 4, cod % 4)):
-            for k in range(4):
-                fb[pos, k] = tot[b == k].sum()
+        for pat, wt in zip(toks, w):
+            for tok in pat:
+                for k in range(3):
+                    s = sets[tok[k]]
+                    t = fb0[k, s].sum()
+                    fb[k, s] += wt * fb0[k, s] / t
         fb /= fb.sum(axis=1, keepdims=True)
-        if np.abs(fnew - fcod).max() < 1e-10:
-            fcod = fnew
+        d = np.sqrt(((fb - fb0) ** 2).sum())
+        fb0 = fb
+        if d < 1e-8:
             break
-        fcod = fnew
-    return fb
+    return fb0
 
 
 def problem_from_golden(g) -> Problem:
@@ -143,7 +145,7 @@ def problem_from_golden(g) -> Problem:
     if kind == "codon_m0":
         kw = {}
         if amb is not None:
-            pi = models.f3x4(f3x4_with_ambiguity(z, w, *amb))
+            pi = models.f3x4(f3x4_with_ambiguity(g["patterns_raw"], w))
             kw = dict(cleandata=0, n_chara=amb[0], chara_map=amb[1])
         else:
             pi = models.f3x4(synth.f3x4_from_codon_tips(z, w))
