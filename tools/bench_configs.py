@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the BASELINE.json configs that are parity-test cases rather than bench lines:
+C2 (baseml GTR+G4, 32 taxa x 1e5 nucleotide patterns; contract bound: HBM, algorithmic 7 720 B/pattern),
+C5 (HIV NSsites models: latency per evaluation incl. batched P(t)), and the NSsites sweep on the C4 data
+(K = 1, 2, 3, 10, 11 omega classes over 1e6 codon patterns).  One JSON line per case."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
+from paml_amd import engine, synth  # noqa: E402
+
+
+def timed(eng, branch, steps, warmup=3):
+    for _ in range(warmup):
+        eng.eval(branch)
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = eng.eval(branch)
+    dt = (time.perf_counter() - t0) / steps
+    p = eng.profile_read()
+    eng.profile(False)
+    return dt, {k: p[k] / max(1, p["n_evals"]) for k in ("ms_pmat", "ms_prune", "ms_reduce")}, r["lnL"]
+
+
+def main():
+    out = []
+    # C2
+    pb = synth.nuc_gtr_gamma_problem(n_tips=32, n_patt=100_000)
+    eng = engine.engine_for(pb)
+    dt, prof, lnl = timed(eng, pb.tree.branch, 50)
+    bytes_pp = 8 * 4 * (30 + 29 + 1) * 4 + 32 + 8
+    out.append(dict(case="C2 baseml GTR+G4 32x1e5", kernel=eng.kernel_name, ms_per_eval=dt * 1e3, patterns_per_s=pb.n_patt / dt,
+                    prune_ms=prof["ms_prune"], algorithmic_GBps=bytes_pp * pb.n_patt / (prof["ms_prune"] * 1e-3) / 1e9,
+                    hbm_peak_GBps=8000, lnL=lnl, **prof))
+    # C2 at 1e7 patterns: past launch latency
+    pb = synth.nuc_gtr_gamma_problem(n_tips=32, n_patt=4_000_000)
+    eng = engine.engine_for(pb)
+    dt, prof, lnl = timed(eng, pb.tree.branch, 10)
+    out.append(dict(case="C2-shape 32x4e6", kernel=eng.kernel_name, ms_per_eval=dt * 1e3, patterns_per_s=pb.n_patt / dt,
+                    prune_ms=prof["ms_prune"], algorithmic_GBps=bytes_pp * pb.n_patt / (prof["ms_prune"] * 1e-3) / 1e9,
+                    hbm_peak_GBps=8000, lnL=lnl))
+    # C5: HIV models, latency
+    import helpers
+    for name in ("hiv_m0", "hiv_m2a", "hiv_m8"):
+        g = helpers.load_golden(name)
+        pb = helpers.problem_from_golden(g)
+        eng = engine.engine_for(pb)
+        dt, prof, lnl = timed(eng, pb.tree.branch, 200)
+        out.append(dict(case="C5 " + name, kernel=eng.kernel_name, K=pb.K, ms_per_eval=dt * 1e3, n_pmat=pb.K * 23, lnL=lnl,
+                        golden_lnL=g["lnL"], **prof))
+    # NSsites sweep on C4 data
+    base = synth.codon_m0_problem(n_tips=16, n_patt=1_000_000)
+    for K in (1, 2, 3, 10, 11):
+        pb = base if K == 1 else synth.codon_nssites_problem(base, 2.0, np.linspace(0.05, 1.5, K), np.full(K, 1.0 / K))
+        eng = engine.engine_for(pb)
+        dt, prof, lnl = timed(eng, pb.tree.branch, 5, warmup=2)
+        flops = 98637.0 * K * pb.n_patt
+        out.append(dict(case="C4 NSsites sweep K=%d" % K, kernel=eng.kernel_name, ms_per_eval=dt * 1e3,
+                        pattern_classes_per_s=pb.n_patt * K / dt, tflops=flops / (prof["ms_prune"] * 1e-3) / 1e12, lnL=lnl, **prof))
+        eng.close()
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()
