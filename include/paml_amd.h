@@ -110,6 +110,17 @@ int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double 
 int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
                         double *lnL);
 
+/* Branch-local evaluation = lfuntdd / lfuntdd_SiteClass (treesub.c:8204, 8403; lfunt / lfunt_SiteClass 8127, 8298 are
+ * the lnL-only case), the function minbranches (treesub.c:8039) iterates with Newton steps: for the branch above
+ * node_b, and for each of the n_t (<= 64) trial lengths t[], the log-likelihood and its first two derivatives in t,
+ * all other branch lengths taken from branch[].  Outputs are in lnL convention: lnL = -l, dlnL = -dl, ddlnL = -ddl
+ * of the reference.  Where the reference re-roots the tree at b and updates conP along the path (ReRootTree
+ * treespace.c:236, updateconP treesub.c:7982), the engine evaluates the two partials across the branch directly
+ * (one fused pass over each side), builds P, dP, ddP for all trial lengths in one batched kernel and contracts.
+ * Not yet supported: trees with scaling nodes, K80/JC69-like eigen kinds (PAML_AMD_EUNSUPPORTED). */
+int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *t, const double *branch,
+                         const double *gene_rate, double *lnL, double *dlnL, double *ddlnL);
+
 /* Parity / post-processing accessors.
  * get_pmat: the matrix GetPMatBranch (treesub.c:7534) would have produced for the branch above
  *   `node`, row-major P[from*n + to], from the last evaluation.

@@ -290,3 +290,136 @@ double orc_eval(const orc_problem *pb, double *lnf, double *fhK_out, double *par
    if (!fhK_out) free(fhK);
    return lnL;
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Branch-local lnL(t), dlnL/dt, d2lnL/dt2 (lfuntdd / lfuntdd_SiteClass, treesub.c:8204-8296, 8403-8541).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+   const orc_problem *pb;
+   int *father;
+   double *P;
+} bctx_t;
+
+/* message at x looking away from neighbour `from`: out[h][j], patterns [pos0,pos1) of gene ig, class ir */
+static void msg(const bctx_t *c, int x, int from, int ig, int ir, double *out)
+{
+   const orc_problem *pb = c->pb;
+   int n = pb->n, np = pb->n_patt, pos0 = pb->gene_off[ig], pos1 = pb->gene_off[ig + 1], i, j, k;
+   long h;
+   if (pb->sons_ptr[x + 1] == pb->sons_ptr[x] && x < pb->n_tips) {   /* tip: indicator of its state set */
+      const unsigned char *z = pb->z + (size_t)x * np;
+      for (h = pos0; h < pos1; h++) {
+         int code = z[h], nc = pb->n_chara[code];
+         for (j = 0; j < n; j++) out[h * n + j] = 0;
+         for (k = 0; k < nc; k++) out[h * n + pb->chara_map[(size_t)code * n + k]] = 1;
+      }
+      return;
+   }
+   for (h = (long)pos0 * n; h < (long)pos1 * n; h++) out[h] = 1;
+   {
+      /* neighbours: sons (edge stored at the son) and the father (edge stored at x) */
+      int nn = pb->sons_ptr[x + 1] - pb->sons_ptr[x] + (c->father[x] >= 0 ? 1 : 0);
+      double *tmp = (double *)malloc((size_t)np * n * sizeof(double));
+      double *P = (double *)malloc((size_t)n * n * sizeof(double));
+      for (i = 0; i < nn; i++) {
+         int is_father = (i == nn - 1 && c->father[x] >= 0);
+         int y = is_father ? c->father[x] : pb->sons[pb->sons_ptr[x] + i];
+         int edge = is_father ? x : y;      /* node that carries this edge's branch length / label */
+         if (y == from) continue;
+         msg(c, y, x, ig, ir, tmp);
+         orc_pmat_branch(pb, ig, ir, edge, P);
+         for (h = pos0; h < pos1; h++)
+            for (j = 0; j < n; j++) {
+               double s = 0;
+               for (k = 0; k < n; k++) s += P[j * n + k] * tmp[h * n + k];
+               out[h * n + j] *= s;
+            }
+      }
+      free(tmp);
+      free(P);
+   }
+}
+
+int orc_eval_branch(const orc_problem *pb, int node_b, int n_t, const double *t, double *lnL, double *dlnL, double *ddlnL)
+{
+   int n = pb->n, np = pb->n_patt, K = pb->K, i, j, k, it, ig, ir, a;
+   long h;
+   bctx_t c;
+   double *A, *B, *P, *dP, *ddP, *fh, *dfh, *ddfh;
+   if (pb->scale_node)
+      for (i = 0; i < pb->n_nodes; i++)
+         if (pb->scale_node[i]) return -1;
+   c.pb = pb;
+   c.father = (int *)malloc(pb->n_nodes * sizeof(int));
+   for (i = 0; i < pb->n_nodes; i++) c.father[i] = -1;
+   for (i = 0; i < pb->n_nodes; i++)
+      for (j = pb->sons_ptr[i]; j < pb->sons_ptr[i + 1]; j++) c.father[pb->sons[j]] = i;
+   a = c.father[node_b];
+   if (a < 0) { free(c.father); return -1; }
+   A = (double *)malloc((size_t)K * np * n * sizeof(double));
+   B = (double *)malloc((size_t)K * np * n * sizeof(double));
+   P = (double *)malloc((size_t)3 * n * n * sizeof(double));
+   dP = P + n * n; ddP = dP + n * n;
+   fh = (double *)malloc((size_t)3 * np * sizeof(double));
+   dfh = fh + np; ddfh = dfh + np;
+   for (ir = 0; ir < K; ir++)
+      for (ig = 0; ig < pb->n_genes; ig++) {
+         msg(&c, a, node_b, ig, ir, A + (size_t)ir * np * n);
+         msg(&c, node_b, a, ig, ir, B + (size_t)ir * np * n);
+      }
+   for (it = 0; it < n_t; it++) {
+      double l = 0, dl = 0, ddl = 0;
+      for (h = 0; h < np; h++) fh[h] = dfh[h] = ddfh[h] = 0;
+      for (ir = 0; ir < K; ir++)
+         for (ig = 0; ig < pb->n_genes; ig++) {
+            int lab = pb->label ? pb->label[node_b] : 0;
+            const orc_eigen *es = &pb->eigen[pb->eigen_of[((size_t)ig * K + ir) * pb->n_labels + lab]];
+            const double *pi = pb->pi + (size_t)(pb->n_pi > 1 ? ig : 0) * n;
+            int nroot = es->kind == ORC_EIGEN_CIJK ? es->nR : n;
+            double qf = (es->kind == ORC_EIGEN_UVROOT && pb->qfactor) ? pb->qfactor[(size_t)ir * pb->n_labels + lab] : 1.0;
+            if (es->kind != ORC_EIGEN_UVROOT && es->kind != ORC_EIGEN_CIJK) return -1;
+            for (i = 0; i < 3 * n * n; i++) P[i] = 0;
+            for (k = 0; k < nroot; k++) {
+               /* treesub.c:8479-8483: multiply = rgene * Root[k] * _rateSite [* Qfactor_NS_branch] */
+               double multiply = (pb->gene_rate ? pb->gene_rate[ig] : 1.0) * es->Root[k] * pb->rate[ir] * qf;
+               double expt = k ? exp(t[it] * multiply) : 1.0;
+               for (i = 0; i < n; i++)
+                  for (j = 0; j < n; j++) {
+                     double c0 = es->kind == ORC_EIGEN_CIJK ? es->Cijk[(size_t)i * n * nroot + j * nroot + k] * expt
+                                                            : (es->U[i * n + k] * expt) * es->V[k * n + j];
+                     P[i * n + j] += c0;
+                     if (k) {
+                        dP[i * n + j] += c0 * multiply;
+                        ddP[i * n + j] += c0 * multiply * multiply;
+                     }
+                  }
+            }
+            for (h = pb->gene_off[ig]; h < pb->gene_off[ig + 1]; h++) {
+               const double *Ah = A + ((size_t)ir * np + h) * n, *Bh = B + ((size_t)ir * np + h) * n;
+               for (i = 0; i < n; i++) {
+                  double piqi, pqj = 0, dpqj = 0, ddpqj = 0;
+                  if (Bh[i] == 0) continue;
+                  piqi = pb->freqK[ir] * pi[i] * Bh[i];
+                  for (j = 0; j < n; j++) {
+                     pqj += P[i * n + j] * Ah[j];
+                     dpqj += dP[i * n + j] * Ah[j];
+                     ddpqj += ddP[i * n + j] * Ah[j];
+                  }
+                  fh[h] += piqi * pqj;
+                  dfh[h] += piqi * dpqj;
+                  ddfh[h] += piqi * ddpqj;
+               }
+            }
+         }
+      for (h = 0; h < np; h++) {
+         if (pb->weights[h] <= 0) continue;
+         l += log(fh[h]) * pb->weights[h];
+         dl += dfh[h] / fh[h] * pb->weights[h];
+         ddl += (fh[h] * ddfh[h] - dfh[h] * dfh[h]) / (fh[h] * fh[h]) * pb->weights[h];
+      }
+      lnL[it] = l; dlnL[it] = dl; ddlnL[it] = ddl;
+   }
+   free(c.father); free(A); free(B); free(P); free(fh);
+   return 0;
+}

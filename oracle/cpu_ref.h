@@ -81,6 +81,18 @@ void orc_pmat_branch(const orc_problem *pb, int gene, int iclass, int node, doub
  */
 double orc_eval(const orc_problem *pb, double *lnf, double *fhK, double *partials, double *scalef, int nthreads);
 
+/* Branch-local log-likelihood and its first two derivatives in the branch length, for the branch above `node_b`
+ * (father a), at each of the n_t trial lengths t[]: restates lfuntdd / lfuntdd_SiteClass (treesub.c:8204-8296,
+ * 8403-8541; lfunt / lfunt_SiteClass 8127, 8298 are the l-only special case):
+ *     f_h = sum_ir freqK_ir sum_i pi_i B_i[h] sum_j P_ij(t) A_j[h],   P, dP, ddP = sum_k U[:,k] e^{t mu_k} {1, mu_k, mu_k^2} V[k,:]
+ * with mu_k = rgene * Root_k * rateSite_ir * Qfactor (plain exp, e^{t mu_0} forced to 1, no clamp), A = partial of a
+ * looking away from b, B = partial of b's subtree (or the state set of tip b).  The reference gets A by re-rooting at b
+ * (ReRootTree treespace.c:236 + updateconP treesub.c:7982); here A and B are computed directly as the two messages
+ * across the branch, which is the same product of the same P(t) factors.  Outputs are in lnL convention
+ * (lnL, dlnL/dt, d2lnL/dt2 = -l, -dl, -ddl of the reference).  Node scaling is not supported here (returns -1 when any
+ * scale_node flag is set); UVROOT and CIJK eigen kinds only.  Returns 0 on success. */
+int orc_eval_branch(const orc_problem *pb, int node_b, int n_t, const double *t, double *lnL, double *dlnL, double *ddlnL);
+
 /* Number of (branch, class) P(t) constructions performed by the last orc_eval (mirrors NPMatUVRoot, tools.c:88). */
 long orc_last_npmat(void);
 

@@ -50,6 +50,7 @@ def lib():
         _LIB.orc_eval.argtypes = [C.POINTER(_Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _LIB.orc_pmat_branch.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int, C.c_int, C.c_void_p]
         _LIB.orc_last_npmat.restype = C.c_long
+        _LIB.orc_eval_branch.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return _LIB
 
 
@@ -118,3 +119,15 @@ def pmat_branch(pb, gene, iclass, node):
     P = np.zeros((pb.n, pb.n))
     L.orc_pmat_branch(C.byref(pk.s), gene, iclass, node, _ptr(P))
     return P
+
+
+def eval_branch(pb, node_b, t):
+    """lnL(t), dlnL/dt, d2lnL/dt2 for the branch above node_b at the trial lengths t (lfuntdd restated)."""
+    L = lib()
+    pk = _Packed(pb)
+    t = np.ascontiguousarray(np.atleast_1d(t), dtype=np.float64)
+    l, dl, ddl = np.zeros(len(t)), np.zeros(len(t)), np.zeros(len(t))
+    rc = L.orc_eval_branch(C.byref(pk.s), int(node_b), len(t), _ptr(t), _ptr(l), _ptr(dl), _ptr(ddl))
+    if rc != 0:
+        raise RuntimeError("orc_eval_branch failed (%d)" % rc)
+    return l, dl, ddl

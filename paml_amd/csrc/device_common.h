@@ -17,7 +17,8 @@ enum OpCode : int {
    // fused forms produced by the peephole pass (same arithmetic, fewer dependent memory round trips):
    OP_SET_TIP = 11,    // cur = tipcol(a)                 == INIT_ONES ; MUL_TIP a
    OP_SET_TIP2 = 12,   // cur = tipcol(a) * tipcol(b)     == INIT_ONES ; MUL_TIP a ; MUL_TIP b   (a cherry)
-   OP_MUL_TIP2 = 13    // cur *= tipcol(a) * tipcol(b)    == MUL_TIP a ; MUL_TIP b
+   OP_MUL_TIP2 = 13,   // cur *= tipcol(a) * tipcol(b)    == MUL_TIP a ; MUL_TIP b
+   OP_EXPORT = 14      // write cur as [class][pattern][state] to PruneArgs::export_buf (branch-local evaluation)
 };
 
 struct Op { int code, a, b, c; };   // a: node/tip, b: stack slot / scale slot / 2nd tip, c: prefetch link (-1 none)
@@ -53,6 +54,7 @@ struct PruneArgs {
    const void *stream;         // stream kernel: operand blocks in order of use, {is_tip, node} pairs
    int n_stream;
    long tip_words;             // doubles per tip table
+   double *export_buf;         // OP_EXPORT target: [K][n_patt][n]
    unsigned long long *prof;   // PROF_OPS builds only: [block][op] s_memtime stamps of thread 0
    int prof_stride, prof_tid;
 };

@@ -2,6 +2,7 @@
 // Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC engine.hip
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -108,7 +109,9 @@ struct paml_amd_engine {
    int cleandata = 1, n_codes = 0;
    DevBuf<unsigned char> d_z, d_chara_map, d_is_leaf;
    DevBuf<int> d_n_chara, d_gene_off, d_label, d_eigen_of;
-   DevBuf<int2> d_tiles;
+   DevBuf<int2> d_tiles, d_tiles_full;   // tile table of the selected kernel / of the full (gather or valu) kernel
+   int n_tiles_full = 0;
+   DevBuf<double> d_pi_plain;
    DevBuf<double> d_weights, d_pi, d_freqK, d_rate, d_qfactor, d_branch, d_gene_rate;
    std::vector<int> gene_off;
    int n_tiles = 0, n_pi = 1;
@@ -130,6 +133,9 @@ struct paml_amd_engine {
 
    // per-evaluation buffers
    DevBuf<double> d_rowmajor, d_pint, d_ptip, d_fhK, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
+   DevBuf<double> d_expA, d_expB, d_deriv, d_tt, d_bpartial, d_bout;   // branch-local evaluation
+   DevBuf<int> d_label_eff;
+   DevBuf<Op> d_ops_tmp;
    bool partials_valid = false;
 
    // profiling
@@ -151,11 +157,16 @@ struct paml_amd_engine {
       DevBuf<int> *b2[] = {&d_n_chara, &d_gene_off, &d_label, &d_eigen_of};
       for (auto b : b2) b->release();
       d_tiles.release();
+      d_tiles_full.release();
       d_ops.release();
+      d_ops_tmp.release();
+      d_label_eff.release();
       d_stream.release();
       d_eigen.release();
+      d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_fhK, &d_lnf, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack};
+                              &d_pint, &d_ptip, &d_fhK, &d_lnf, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
+                              &d_expA, &d_expB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
    }
 };
@@ -222,6 +233,12 @@ int build_tiles(paml_amd_engine *e)
       for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += e->tile_patt) tiles.push_back(make_int2(g, h));
    e->n_tiles = (int)tiles.size();
    HIPCHK(upload(e->d_tiles, tiles.data(), tiles.size(), e->stream));
+   const int tf = e->kk == KK_MFMA64 ? GATHER_WAVES * 16 : 256;
+   std::vector<int2> tfull;
+   for (int g = 0; g < e->n_genes; g++)
+      for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += tf) tfull.push_back(make_int2(g, h));
+   e->n_tiles_full = (int)tfull.size();
+   HIPCHK(upload(e->d_tiles_full, tfull.data(), tfull.size(), e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
    return 0;
 }
@@ -461,6 +478,45 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    return 0;
 }
 
+
+// Run `prog` with the full-featured kernels (gather / valu) over all patterns and classes, reading the P(t) buffers
+// of the last pmat launch; OP_EXPORT writes to export_buf.  Used by the branch-local evaluation.
+int run_prune_full(paml_amd_engine *e, const Program &prog, double *export_buf)
+{
+   const int nn = e->tree.n_nodes, K = e->K;
+   HIPCHK(upload(e->d_ops_tmp, prog.ops.data(), prog.ops.size(), e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   const int waves = GATHER_WAVES;
+   const int n_blocks = e->n_tiles_full * K;
+   int overflow = 0;
+   if (e->kk == KK_MFMA64 && prog.max_stack > MFMA_RS) {
+      overflow = prog.max_stack - MFMA_RS;
+      HIPCHK(e->d_stack.ensure((size_t)n_blocks * overflow * waves * 1024));
+   }
+   const int maxd = e->kk == KK_VALU20 ? VALU_MAXD_20 : VALU_MAXD_SMALL;
+   if (e->kk != KK_MFMA64 && prog.max_stack > maxd)
+      return fail(e, PAML_AMD_EUNSUPPORTED, "tree needs a deeper partial stack than this kernel provides");
+   PruneArgs pr{};
+   pr.ops = e->d_ops_tmp.p; pr.z = e->d_z.p; pr.z_stride = e->n_patt; pr.tiles = e->d_tiles_full.p; pr.n_tiles = e->n_tiles_full;
+   pr.gene_off = e->d_gene_off.p; pr.weights = e->d_weights.p;
+   pr.n = e->n; pr.n_tips = e->n_tips; pr.n_nodes = nn; pr.K = K; pr.n_genes = e->n_genes; pr.n_codes = e->n_codes;
+   pr.cleandata = e->cleandata; pr.n_pi = e->n_pi; pr.mode = e->mode; pr.n_scale = 0; pr.keep = 0; pr.n_patt = e->n_patt;
+   pr.pi = e->d_pi.p; pr.pint = e->kk == KK_MFMA64 ? e->d_pint.p : e->d_rowmajor.p; pr.ptip = e->d_ptip.p;
+   pr.fhK = e->d_fhK.p; pr.partials = nullptr; pr.scalef = nullptr; pr.stack_scratch = e->d_stack.p;
+   pr.stack_overflow_slots = overflow; pr.first_matmul = prog.first_matmul; pr.n_int = nn - e->n_tips;
+   pr.first_tip = prog.first_tip; pr.tip_words = (long)tip_words(e); pr.export_buf = export_buf;
+   switch (e->kk) {
+   case KK_MFMA64:
+      hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, e->stream, pr);
+      break;
+   case KK_VALU4: hipLaunchKernelGGL((prune_valu<4, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr); break;
+   case KK_VALU5: hipLaunchKernelGGL((prune_valu<5, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr); break;
+   case KK_VALU20: hipLaunchKernelGGL((prune_valu<20, VALU_MAXD_20>), dim3(n_blocks), dim3(256), 0, e->stream, pr); break;
+   }
+   HIPCHK(hipGetLastError());
+   return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -629,6 +685,7 @@ int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi)
    else
       buf.assign(pi, pi + (size_t)n_pi * n);
    HIPCHK(upload(e->d_pi, buf.data(), buf.size(), e->stream));
+   HIPCHK(upload(e->d_pi_plain, pi, (size_t)n_pi * n, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
    e->n_pi = n_pi;
    e->have_pi = true;
@@ -741,6 +798,140 @@ int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *
    if (r) return r;
    HIPCHK(hipMemcpyAsync(lnL, e->d_out.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
+int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *t, const double *branch,
+                         const double *gene_rate, double *lnL, double *dlnL, double *ddlnL)
+{
+   if (!e || !t || !branch || !lnL || !dlnL || !ddlnL || n_t < 1 || n_t > 64)
+      return fail(e, PAML_AMD_EINVAL, "eval_branch: bad arguments");
+   if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes) || e->eigen.empty())
+      return fail(e, PAML_AMD_EINVAL, "eval_branch before set_tips/set_tree/set_pi/set_classes/set_eigen");
+   const TreeDesc &T = e->tree;
+   const int nn = T.n_nodes, n = e->n, K = e->K, G = e->n_genes, psets = G * K;
+   if (node_b < 0 || node_b >= nn || node_b == T.root) return fail(e, PAML_AMD_EINVAL, "eval_branch: node has no branch");
+   if (T.n_scale > 0) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_branch: node scaling is not supported yet");
+   for (size_t i = 0; i < e->eigen.size(); i++)
+      if (e->eigen[i].kind != PAML_AMD_EIGEN_UVROOT && e->eigen[i].kind != PAML_AMD_EIGEN_CIJK)
+         return fail(e, PAML_AMD_EUNSUPPORTED, "eval_branch: UVROOT / CIJK eigen systems only");
+   std::vector<int> father(nn, -1);
+   for (int i = 0; i < nn; i++)
+      for (int j = T.sons_ptr[i]; j < T.sons_ptr[i + 1]; j++) father[T.sons[j]] = i;
+   const int a = father[node_b];
+
+   // the tree as seen from a with b's subtree cut off: along the path a -> old root every node loses the son it
+   // came from and gains its father; the edge data (length, label) of node p moves to its father (new son of p)
+   std::vector<std::vector<int>> sons(nn);
+   for (int i = 0; i < nn; i++) sons[i].assign(T.sons.begin() + T.sons_ptr[i], T.sons.begin() + T.sons_ptr[i + 1]);
+   std::vector<double> br(branch, branch + nn);
+   std::vector<int> lab(T.label);
+   for (int p = a, prev = node_b; p >= 0; prev = p, p = father[p]) {
+      auto &s = sons[p];
+      s.erase(std::find(s.begin(), s.end(), prev));
+      if (father[p] >= 0) {
+         s.push_back(father[p]);
+         br[father[p]] = branch[p];
+         lab[father[p]] = T.label[p];
+      }
+   }
+   auto make_tree = [&](int root, const std::vector<std::vector<int>> &sv) {
+      TreeDesc t;
+      t.n_tips = T.n_tips; t.n_nodes = nn; t.root = root;
+      t.sons_ptr.assign(nn + 1, 0);
+      for (int i = 0; i < nn; i++) t.sons_ptr[i + 1] = t.sons_ptr[i] + (int)sv[i].size();
+      for (int i = 0; i < nn; i++) t.sons.insert(t.sons.end(), sv[i].begin(), sv[i].end());
+      t.label = lab;
+      t.scale_node.assign(nn, 0);
+      t.scale_slot.assign(nn, -1);
+      return t;
+   };
+   auto export_program = [&](const TreeDesc &t) {
+      Program p = build_program(t, false, nullptr);
+      for (Op &o : p.ops)
+         if (o.code == OP_ROOT) o.code = OP_EXPORT;
+      return p;
+   };
+   const Program progA = export_program(make_tree(a, sons));
+   const bool b_tip = T.is_leaf(node_b);
+
+   // P(t) for every edge in its new orientation (one batched launch, root = a)
+   {
+      std::vector<double> gr(G, 1.0);
+      if (gene_rate) gr.assign(gene_rate, gene_rate + G);
+      HIPCHK(upload(e->d_branch, br.data(), br.size(), e->stream));
+      HIPCHK(upload(e->d_gene_rate, gr.data(), gr.size(), e->stream));
+      HIPCHK(upload(e->d_label_eff, lab.data(), lab.size(), e->stream));
+      std::vector<double> tt(t, t + n_t);
+      HIPCHK(upload(e->d_tt, tt.data(), tt.size(), e->stream));
+      if (e->eigen_dirty) {
+         std::vector<EigenDev> tab(e->eigen.size());
+         for (size_t i = 0; i < e->eigen.size(); i++) {
+            const EigenHost &h = e->eigen[i];
+            tab[i] = EigenDev{h.kind, h.nR, h.kappa, h.U.p, h.V.p, h.Root.p, h.Cijk.p};
+         }
+         HIPCHK(upload(e->d_eigen, tab.data(), tab.size(), e->stream));
+         e->eigen_dirty = false;
+      }
+      HIPCHK(hipStreamSynchronize(e->stream));
+   }
+   HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
+   if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
+   HIPCHK(e->d_ptip.ensure((size_t)psets * nn * tip_words(e)));
+   HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
+   PmatArgs pa{};
+   pa.n = n; pa.n_nodes = nn; pa.root = a; pa.K = K; pa.n_genes = G; pa.n_labels = e->n_labels;
+   pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : 0;
+   pa.label = e->d_label_eff.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
+   pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
+   pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
+   pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
+   hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), e->stream, pa);
+   e->n_pmat += (long)psets * (nn - 1);
+
+   // the two partials across the branch
+   const size_t exp_words = (size_t)K * e->n_patt * n;
+   HIPCHK(e->d_expA.ensure(exp_words));
+   int r = run_prune_full(e, progA, e->d_expA.p);
+   if (r) return r;
+   if (!b_tip) {
+      std::vector<std::vector<int>> s0(nn);
+      for (int i = 0; i < nn; i++) s0[i].assign(T.sons.begin() + T.sons_ptr[i], T.sons.begin() + T.sons_ptr[i + 1]);
+      const Program progB = export_program(make_tree(node_b, s0));
+      HIPCHK(e->d_expB.ensure(exp_words));
+      r = run_prune_full(e, progB, e->d_expB.p);
+      if (r) return r;
+   }
+
+   // P, dP, ddP for every trial length, then the per-pattern contraction and the three weighted sums
+   HIPCHK(e->d_deriv.ensure((size_t)psets * n_t * 3 * n * n));
+   DerivArgs da{};
+   da.n = n; da.K = K; da.n_genes = G; da.n_labels = e->n_labels; da.n_t = n_t; da.label = T.label[node_b];
+   da.t = e->d_tt.p; da.rate = e->d_rate.p; da.gene_rate = e->d_gene_rate.p; da.qfactor = e->d_qfactor.p;
+   da.eigen_of = e->d_eigen_of.p; da.eigen = e->d_eigen.p; da.out = e->d_deriv.p;
+   hipLaunchKernelGGL(pmat_deriv_kernel, dim3(n_t, psets), dim3(256), 0, e->stream, da);
+   const int nb = (e->n_patt + 255) / 256;
+   HIPCHK(e->d_bpartial.ensure((size_t)nb * n_t * 3));
+   HIPCHK(e->d_bout.ensure((size_t)n_t * 3));
+   BranchArgs ba{};
+   ba.n = n; ba.K = K; ba.n_genes = G; ba.n_patt = e->n_patt; ba.n_t = n_t; ba.n_pi = e->n_pi; ba.b_is_tip = b_tip ? 1 : 0;
+   ba.n_codes = e->n_codes; ba.A = e->d_expA.p; ba.B = e->d_expB.p;
+   ba.zb = b_tip ? e->d_z.p + (size_t)node_b * e->n_patt : nullptr;
+   ba.n_chara = e->d_n_chara.p; ba.chara_map = e->d_chara_map.p; ba.freqK = e->d_freqK.p;
+   ba.weights = e->d_weights.p; ba.PdP = e->d_deriv.p; ba.gene_off = e->d_gene_off.p; ba.partial = e->d_bpartial.p;
+   // pi in plain [n_pi][n] order (the mfma engines keep a permuted copy for their kernels): reuse row-major upload
+   HIPCHK(e->d_pi_plain.p ? hipSuccess : hipErrorInvalidValue);
+   ba.pi = e->d_pi_plain.p;
+   hipLaunchKernelGGL(branch_kernel, dim3(nb), dim3(256), 0, e->stream, ba);
+   hipLaunchKernelGGL(branch_reduce_kernel, dim3(1), dim3(256), 0, e->stream, (const double *)e->d_bpartial.p, nb, n_t * 3,
+                      e->d_bout.p);
+   HIPCHK(hipGetLastError());
+   std::vector<double> out((size_t)n_t * 3);
+   HIPCHK(hipMemcpyAsync(out.data(), e->d_bout.p, out.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   for (int i = 0; i < n_t; i++) { lnL[i] = out[3 * i]; dlnL[i] = out[3 * i + 1]; ddlnL[i] = out[3 * i + 2]; }
+   e->prog_valid = false;      // d_branch / P buffers now hold the re-rooted edge data: the next eval rebuilds
+   e->partials_valid = false;
    return 0;
 }
 

@@ -381,6 +381,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_gather(PruneArgs a
          MFMA_CORE_CASES()
          MFMA_EXT_CASES()
          MFMA_ROOT_CASE()
+      case OP_EXPORT: {
+         if (valid) {
+            double *dst = a.export_buf + ((long)iclass * a.n_patt + h) * n;
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+               if (4 * m + q < n) dst[4 * m + q] = cur[m];
+         }
+      } break;
       case OP_MUL_TIP:
       case OP_SET_TIP: {
          double2 v[8];
@@ -687,6 +695,13 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
 #pragma unroll
          for (int j = 0; j < N; j++) cur[j] = src[j];
       } break;
+      case OP_EXPORT: {
+         if (valid) {
+            double *dst = a.export_buf + ((long)iclass * a.n_patt + h) * N;
+#pragma unroll
+            for (int j = 0; j < N; j++) dst[j] = cur[j];
+         }
+      } break;
       case OP_ROOT: {
          const double *pi = a.pi + (long)(a.n_pi > 1 ? gene : 0) * N;
          double f = 0;
@@ -770,6 +785,144 @@ __global__ __launch_bounds__(256) void reduce_stage2(const double *partial, int 
    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
    __syncthreads();
    if (threadIdx.x == 0) *out = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Branch-local evaluation (lfuntdd / lfuntdd_SiteClass, treesub.c:8204-8296, 8403-8541).
+// pmat_deriv_kernel: P, dP, ddP = sum_k U[:,k] e^{t mu_k} {1, mu_k, mu_k^2} V[k,:] (plain exp, k = 0 term forced
+// to 1, no clamp; Cijk form for baseml), mu_k = rgene * Root_k * rateSite * Qfactor, for every trial length,
+// gene and class.  branch_kernel: one pattern per lane,
+//   f = sum_ir freqK_ir sum_{i in B} pi_i B_i sum_j P_ij A_j   (and f', f'' with dP, ddP)
+// from the two partials across the branch (A exported by the pruning kernel run on the re-rooted tree,
+// B = exported partial of the lower node or the state set of a tip), then the weighted sums of
+// log f, f'/f and (f f'' - f'^2)/f^2 with a fixed-order two-level reduction.
+// ------------------------------------------------------------------------------------------------
+struct DerivArgs {
+   int n, K, n_genes, n_labels, n_t, label;
+   const double *t;            // [n_t]
+   const double *rate, *gene_rate, *qfactor;
+   const int *eigen_of;
+   const EigenDev *eigen;
+   double *out;                // [pset][n_t][3][n*n]
+};
+
+__global__ __launch_bounds__(256) void pmat_deriv_kernel(DerivArgs a)
+{
+   const int it = blockIdx.x, pset = blockIdx.y, n = a.n;
+   const int gene = pset / a.K, iclass = pset % a.K;
+   const EigenDev es = a.eigen[a.eigen_of[(gene * a.K + iclass) * a.n_labels + a.label]];
+   const double t = a.t[it];
+   const double qf = es.kind == PAML_AMD_EIGEN_UVROOT ? a.qfactor[iclass * a.n_labels + a.label] : 1.0;
+   const double base = a.gene_rate[gene] * a.rate[iclass] * qf;
+   const int nroot = es.kind == PAML_AMD_EIGEN_CIJK ? es.nR : n;
+   double *P = a.out + ((long)(pset * a.n_t + it) * 3) * n * n, *dP = P + n * n, *ddP = dP + n * n;
+   __shared__ double sE[64], sM[64];
+   for (int k = threadIdx.x; k < nroot; k += 256) {
+      const double mu = base * es.Root[k];     // treesub.c:8479: rgene * Root[k] * _rateSite (* Qfactor)
+      sM[k] = mu;
+      sE[k] = k ? exp(t * mu) : 1.0;
+   }
+   __syncthreads();
+   for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+      const int i = idx / n, j = idx % n;
+      double p = 0, dp = 0, ddp = 0;
+      for (int k = 0; k < nroot; k++) {
+         const double c0 = es.kind == PAML_AMD_EIGEN_CIJK ? es.Cijk[((long)i * n + j) * nroot + k] * sE[k]
+                                                          : (es.U[i * n + k] * sE[k]) * es.V[k * n + j];
+         p += c0;
+         if (k) {
+            dp += c0 * sM[k];
+            ddp += c0 * sM[k] * sM[k];
+         }
+      }
+      P[idx] = p; dP[idx] = dp; ddP[idx] = ddp;
+   }
+}
+
+struct BranchArgs {
+   int n, K, n_genes, n_patt, n_t, n_pi, b_is_tip, n_codes;
+   const double *A, *B;        // [K][n_patt][n]
+   const unsigned char *zb;    // tip b: codes [n_patt]
+   const int *n_chara;
+   const unsigned char *chara_map;
+   const double *pi, *freqK, *weights, *PdP;   // PdP: [pset][n_t][3][n*n]
+   const int *gene_off;
+   double *partial;            // [gridDim.x][n_t][3]
+};
+
+__global__ __launch_bounds__(256) void branch_kernel(BranchArgs a)
+{
+   __shared__ double sw[4][3];
+   const int n = a.n, h = blockIdx.x * 256 + threadIdx.x;
+   const bool valid = h < a.n_patt && a.weights[h < a.n_patt ? h : 0] > 0;
+   int gene = 0;
+   if (valid)
+      while (gene + 1 < a.n_genes && h >= a.gene_off[gene + 1]) gene++;
+   const double *pi = a.pi + (long)(a.n_pi > 1 ? gene : 0) * n;
+   for (int it = 0; it < a.n_t; it++) {
+      double fh = 0, dfh = 0, ddfh = 0;
+      if (valid) {
+         for (int ir = 0; ir < a.K; ir++) {
+            const double *Ah = a.A + ((long)ir * a.n_patt + h) * n;
+            const double *M = a.PdP + ((long)((gene * a.K + ir) * a.n_t + it) * 3) * n * n;
+            const int code = a.b_is_tip ? a.zb[h] : 0;
+            const int n1 = a.b_is_tip ? a.n_chara[code] : n;
+            for (int ii = 0; ii < n1; ii++) {
+               const int i = a.b_is_tip ? a.chara_map[code * n + ii] : ii;
+               const double bi = a.b_is_tip ? 1.0 : a.B[((long)ir * a.n_patt + h) * n + i];
+               const double piqi = a.freqK[ir] * pi[i] * bi;
+               double pq = 0, dpq = 0, ddpq = 0;
+               const double *Pi = M + (long)i * n, *dPi = Pi + n * n, *ddPi = dPi + n * n;
+               for (int j = 0; j < n; j++) {
+                  const double aj = Ah[j];
+                  pq += Pi[j] * aj;
+                  dpq += dPi[j] * aj;
+                  ddpq += ddPi[j] * aj;
+               }
+               fh += piqi * pq;
+               dfh += piqi * dpq;
+               ddfh += piqi * ddpq;
+            }
+         }
+      }
+      double v0 = 0, v1 = 0, v2 = 0;
+      if (valid) {
+         const double w = a.weights[h];
+         v0 = log(fh) * w;
+         v1 = dfh / fh * w;
+         v2 = (fh * ddfh - dfh * dfh) / (fh * fh) * w;
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+         v0 += __shfl_xor(v0, off);
+         v1 += __shfl_xor(v1, off);
+         v2 += __shfl_xor(v2, off);
+      }
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) {
+         sw[threadIdx.x >> 6][0] = v0; sw[threadIdx.x >> 6][1] = v1; sw[threadIdx.x >> 6][2] = v2;
+      }
+      __syncthreads();
+      if (threadIdx.x < 3)
+         a.partial[((long)blockIdx.x * a.n_t + it) * 3 + threadIdx.x] =
+            (sw[0][threadIdx.x] + sw[1][threadIdx.x]) + (sw[2][threadIdx.x] + sw[3][threadIdx.x]);
+   }
+}
+
+__global__ __launch_bounds__(256) void branch_reduce_kernel(const double *partial, int nb, int n_out, double *out)
+{
+   __shared__ double sw[4];
+   for (int o = 0; o < n_out; o++) {
+      double acc = 0;
+      for (int i = threadIdx.x; i < nb; i += 256) acc += partial[(long)i * n_out + o];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+      __syncthreads();
+      if (threadIdx.x == 0) out[o] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+   }
 }
 
 }  // namespace paml_amd

@@ -25,7 +25,7 @@ EXPORTS = [
     "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_classes", "paml_amd_eval",
-    "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
+    "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
@@ -78,6 +78,7 @@ def lib():
         L.paml_amd_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
         L.paml_amd_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.paml_amd_eval_dirty.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.paml_amd_eval_branch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.paml_amd_get_pmat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.paml_amd_get_partials.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.paml_amd_get_scale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -204,6 +205,15 @@ class Engine:
         lnL = C.c_double()
         self._chk(self._L.paml_amd_eval_dirty(self._h, _p(b), _p(g), _p(c), C.byref(lnL)))
         return lnL.value
+
+    def eval_branch(self, node_b, t, branch, gene_rate=None):
+        """lnL(t), dlnL/dt, d2lnL/dt2 of the branch above node_b at the trial lengths t (lfuntdd)."""
+        tt = np.ascontiguousarray(np.atleast_1d(t), dtype=np.float64)
+        b = np.ascontiguousarray(branch, dtype=np.float64)
+        g = None if gene_rate is None else np.ascontiguousarray(gene_rate, dtype=np.float64)
+        l, dl, ddl = np.zeros(len(tt)), np.zeros(len(tt)), np.zeros(len(tt))
+        self._chk(self._L.paml_amd_eval_branch(self._h, int(node_b), len(tt), _p(tt), _p(b), _p(g), _p(l), _p(dl), _p(ddl)))
+        return l, dl, ddl
 
     def get_pmat(self, gene, iclass, node):
         P = np.zeros((self.n, self.n))

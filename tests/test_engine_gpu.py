@@ -186,3 +186,25 @@ def test_full_size_properties_c4():
     out2 = engine_for(pb2).eval(pb.tree.branch, want_lnf=True)
     assert np.max(np.abs(out2["lnf"] - out["lnf"][perm])) == 0.0      # per-pattern results are order-independent, bitwise
     assert abs(out2["lnL"] - out["lnL"]) < 1e-9 * abs(out["lnL"])
+
+
+@pytest.mark.parametrize("n,K,amb,genes", [(4, 1, False, 1), (4, 4, True, 2), (20, 2, False, 1), (61, 1, False, 1), (61, 3, True, 1)])
+def test_eval_branch_matches_oracle(n, K, amb, genes):
+    """paml_amd_eval_branch (lfuntdd / lfuntdd_SiteClass) against the oracle for tip and internal branches, several trial
+    lengths per call; the ordinary evaluation must still work afterwards."""
+    pb = helpers.random_problem(n, 9, 150, K=K, seed=60 + n + K, ambiguity=amb, n_genes=genes)
+    eng = engine_for(pb)
+    base = eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]
+    t = pb.tree
+    for b in (0, 4, t.n_tips + 1, t.n_nodes - 1):
+        if b == t.root:
+            continue
+        ts = np.array([t.branch[b], 0.02, 0.7])
+        l, dl, ddl = eng.eval_branch(b, ts, t.branch, pb.gene_rate)
+        rl, rdl, rddl = oracle.eval_branch(pb, b, ts)
+        assert np.allclose(l, rl, rtol=1e-11, atol=0), (b, l, rl)
+        assert np.allclose(dl, rdl, rtol=1e-9, atol=1e-9)
+        assert np.allclose(ddl, rddl, rtol=1e-9, atol=1e-8)
+        assert abs(l[0] - base) <= 1e-11 * abs(base)           # l(t_current) is the tree's lnL
+    again = eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]
+    assert again == base

@@ -22,3 +22,25 @@ def test_oracle_matches_reference(name):
         assert r["npmat"] == g["counters"][2]          # same number of P(t) constructions as the reference
     if g.get("published_lnL") is not None:             # MHC: the value printed in the reference's own README
         assert abs(r["lnL"] - g["published_lnL"]) < 5e-6
+
+
+@pytest.mark.parametrize("n,K", [(4, 1), (4, 3), (20, 2), (61, 1)])
+def test_oracle_branch_derivatives_match_pinned_lnl(n, K):
+    """orc_eval_branch (lfuntdd restated) against the golden-pinned full evaluation: l(t) equals lnL with that branch
+    length to rounding, and dl / ddl equal its central finite differences."""
+    pb = helpers.random_problem(n, 8, 50, K=K, seed=40 + n, ambiguity=(n == 4))
+    for b in (1, pb.tree.n_tips + 1):
+        t0 = float(pb.tree.branch[b])
+
+        def f(t):
+            pb.tree.branch[b] = t
+            v = oracle.evaluate(pb, want_lnf=False)["lnL"]
+            pb.tree.branch[b] = t0
+            return v
+        ts = np.array([t0, 0.5 * t0 + 0.01, 0.3])
+        l, dl, ddl = oracle.eval_branch(pb, b, ts)
+        for i, t in enumerate(ts):
+            e = 1e-4
+            assert abs(l[i] - f(t)) <= 1e-11 * abs(l[i])
+            assert abs(dl[i] - (f(t + e) - f(t - e)) / (2 * e)) <= 2e-5 * max(1.0, abs(dl[i]))
+            assert abs(ddl[i] - (f(t + e) - 2 * f(t) + f(t - e)) / e ** 2) <= 2e-3 * max(1.0, abs(ddl[i]))
