@@ -1,0 +1,67 @@
+/* pamlh.h — host side of the MI355X likelihood engine, in C as the reference is.
+ *
+ * It reads the same inputs the reference programs read — the `.ctl` file (GetOptions codeml.c:1694 / baseml.c:954),
+ * the sequence file (ReadSeq treesub.c:487: PHYLIP sequential / interleaved, `.` repeats, the `P` pattern format),
+ * the tree file (ReadTreeN treesub.c:3048) and `in.codeml` / `in.baseml` (readx treesub.c:4035) — compresses sites
+ * into patterns in the reference's order (PatternWeight treesub.c:1386), encodes them (EncodeSeqs 1116,
+ * SetMapAmbiguity 1218), and turns a parameter vector x[] into the engine's inputs the way SetParameters
+ * (codeml.c:2757, baseml.c:1306) does: branch lengths, pi, eigen systems, site classes.  It then drives
+ * libpaml_amd.so through include/paml_amd.h.  Scope (this round): codeml seqtype 1 (icode 0; CodonFreq 0-3; NSsites
+ * 0,1,2,7,8; model 0) and seqtype 2 (aa models 0,2,3), baseml models JC69,K80,F81,HKY85,TN93,REV; +Gamma; one gene;
+ * clock 0; cleandata 0/1.  Anything else fails with a message instead of guessing.
+ */
+#ifndef PAMLH_H
+#define PAMLH_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pamlh pamlh;
+
+/* program: "codeml" or "baseml".  Paths inside the ctl are resolved relative to the ctl file's directory. */
+int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err, int errcap);
+void pamlh_free(pamlh *p);
+const char *pamlh_error(const pamlh *p);
+
+/* sizes: n_states (com.ncode), n_tips (com.ns), n_patt (com.npatt), n_nodes (tree.nnode), root, n_codes, cleandata,
+ * ls (sites or codons after cleaning), np (free parameters the reference would put in x[]), ntime (branch lengths in x) */
+int pamlh_dims(const pamlh *p, int *n_states, int *n_tips, int *n_patt, int *n_nodes, int *root, int *n_codes,
+               int *cleandata, int *ls, int *np, int *ntime);
+
+/* data (valid until pamlh_free) */
+const unsigned char *pamlh_tips(const pamlh *p);        /* [n_tips][n_patt] */
+const double *pamlh_weights(const pamlh *p);            /* [n_patt] */
+const int *pamlh_n_chara(const pamlh *p);               /* [n_codes] */
+const unsigned char *pamlh_chara_map(const pamlh *p);   /* [n_codes][n_states] */
+const int *pamlh_sons_ptr(const pamlh *p);              /* [n_nodes+1] */
+const int *pamlh_sons(const pamlh *p);
+const int *pamlh_labels(const pamlh *p);                /* [n_nodes] */
+const unsigned char *pamlh_scale_nodes(const pamlh *p); /* [n_nodes], SetNodeScale treesub.c:7177 */
+const int *pamlh_branch_order(const pamlh *p);          /* [ntime_all]: node below the i-th branch of tree.branches */
+
+/* default x[]: branch lengths from the tree file, substitution parameters from the ctl (GetInitials) */
+int pamlh_default_x(const pamlh *p, double *x, int cap);
+/* in.codeml / in.baseml next to the ctl ("-1 x0 x1 ..."); returns the number of values read, 0 if absent */
+int pamlh_read_inx(const pamlh *p, double *x, int cap);
+
+/* SetParameters: x -> model state */
+int pamlh_set_x(pamlh *p, const double *x, int np);
+int pamlh_model(const pamlh *p, int *mode, int *K, int *n_eigen, int *n_labels);
+const double *pamlh_branch(const pamlh *p);             /* [n_nodes] */
+const double *pamlh_pi(const pamlh *p);                 /* [n_states] */
+const double *pamlh_freqK(const pamlh *p);
+const double *pamlh_rate(const pamlh *p);
+const int *pamlh_eigen_of(const pamlh *p);              /* [K][n_labels] */
+/* eigen system i: kind (paml_amd.h), and pointers (NULL when not applicable) */
+int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const double **U, const double **V,
+                const double **Root, const double **Cijk);
+
+/* One likelihood evaluation on the GPU through the engine ABI (creates the engine on first use).  lnf may be NULL. */
+int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf);
+/* Write the reference's `lnf` file layout (print_lnf_site treesub.c:7598) for the last pamlh_eval_gpu. */
+int pamlh_write_lnf(const pamlh *p, const char *path, const double *lnf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,70 @@
+/* internal definitions of the host library */
+#ifndef PAMLH_INTERNAL_H
+#define PAMLH_INTERNAL_H
+#include "../../include/paml_amd.h"
+#include "../../include/pamlh.h"
+
+#define PAMLH_MAXOPT 64
+
+typedef struct {
+   char key[32][PAMLH_MAXOPT], val[256][PAMLH_MAXOPT];
+   int n;
+} pamlh_ctl;
+
+typedef struct {
+   int kind, nR;
+   double kappa;
+   double *U, *V, *Root, *Cijk;
+} pamlh_eig;
+
+struct pamlh {
+   char err[512], dir[1024];
+   int is_codeml;
+   pamlh_ctl ctl;
+   /* options */
+   int seqtype, codonfreq, model, nssites, icode, fix_kappa, fix_omega, fix_alpha, ncatG, cleandata_opt, fix_blength, aa_model;
+   double kappa0, omega0, alpha0;
+   char seqfile[1024], treefile[1024], aaratefile[1024];
+   /* data */
+   int n, ns, ls, npatt, n_codes, cleandata;
+   char **names;
+   unsigned char *z;
+   double *w;
+   char *raw;              /* [ns][npatt*n31] raw characters of the patterns (for lnf output) */
+   int n31;
+   int *n_chara;
+   unsigned char *chara_map;
+   double fb3x4[12], fb4[4], fcodon[64], pi_data[64];
+   double aaS[400], aapi_file[20];
+   /* tree */
+   int nnode, root, nbranch;
+   int *sons_ptr, *sons, *label, *branch_node, *father;
+   double *tree_branch;    /* lengths read from the tree file, per node (-1: absent) */
+   unsigned char *scale;
+   /* model state */
+   int np, ntime, mode, K, n_eigen, n_labels;
+   double *branch, *pi, *freqK, *rate;
+   int *eigen_of;
+   pamlh_eig eig[16];
+   double kappa, omega, alpha;
+   /* engine */
+   paml_amd_engine *eng;
+};
+
+/* numerics (pamlh_num.c) */
+void pamlh_eigen_sym(double *A, int n, double *w, double *R);
+void pamlh_eigen_qrev(const double *Q, const double *pi, int n, double *Root, double *U, double *V);
+double pamlh_gammp(double a, double x);
+double pamlh_quantile_gamma(double p, double alpha, double beta);
+void pamlh_discrete_gamma(double *freqK, double *rK, double alpha, int K);
+double pamlh_betai(double a, double b, double x);
+double pamlh_quantile_beta(double prob, double p, double q);
+
+/* io (pamlh_io.c) */
+int pamlh_read_ctl(pamlh *p, const char *path);
+const char *pamlh_opt(const pamlh *p, const char *key);
+double pamlh_optd(const pamlh *p, const char *key, double dflt);
+int pamlh_read_seqs(pamlh *p);
+int pamlh_read_tree(pamlh *p);
+int pamlh_fail(pamlh *p, const char *fmt, ...);
+#endif

@@ -1,0 +1,395 @@
+/* pamlh_io.c — reads what the reference programs read: control file, sequence file, tree file.
+ * Written fresh; behaviour follows GetOptions (codeml.c:1694-1886, baseml.c:954-1146: "key = value" lines,
+ * '*' and '#' start comments, keys compared on their first 8 characters), ReadSeq (treesub.c:487-999),
+ * RemoveIndel (1754), PatternWeight (1386-1516: patterns in sorted order of the raw characters),
+ * EncodeSeqs (1116-1187), SetMapAmbiguity (1218-1286), ReadTreeN (3048-3216) and SetNodeScale (7177-7197). */
+#include <ctype.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pamlh_internal.h"
+
+static const char BASEs[] = "TCAGUYRMKSWHBVD-N?";
+static const char *EquateBASE[] = {"T", "C", "A", "G", "T", "TC", "AG", "CA", "TG", "CG", "TA", "TCA", "TCG", "CAG", "TAG",
+                                   "TCAG", "TCAG", "TCAG"};
+static const char AAs[] = "ARNDCQEGHILKMFPSTWYV-*?X";
+/* standard genetic code, codon index 16 b1 + 4 b2 + b3 with T,C,A,G = 0..3 (tools.c:23-84) */
+static const char STDCODE[] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+
+int pamlh_fail(pamlh *p, const char *fmt, ...)
+{
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(p->err, sizeof(p->err), fmt, ap);
+   va_end(ap);
+   return -1;
+}
+
+/* ------------------------------------------------------------------ control file */
+int pamlh_read_ctl(pamlh *p, const char *path)
+{
+   FILE *f = fopen(path, "r");
+   char line[4096];
+   if (!f) return pamlh_fail(p, "cannot open control file %s", path);
+   p->ctl.n = 0;
+   while (fgets(line, sizeof(line), f)) {
+      char *c = line, *eq, *k, *v, *e;
+      for (; *c; c++)
+         if (*c == '*' || *c == '#') { *c = 0; break; }
+      eq = strchr(line, '=');
+      if (!eq) continue;
+      *eq = 0;
+      k = line;
+      while (isspace((unsigned char)*k)) k++;
+      e = k + strlen(k);
+      while (e > k && isspace((unsigned char)e[-1])) *--e = 0;
+      v = eq + 1;
+      while (isspace((unsigned char)*v)) v++;
+      e = v + strlen(v);
+      while (e > v && isspace((unsigned char)e[-1])) *--e = 0;
+      if (!*k || p->ctl.n >= PAMLH_MAXOPT) continue;
+      snprintf(p->ctl.key[p->ctl.n], 32, "%s", k);
+      snprintf(p->ctl.val[p->ctl.n], 256, "%s", v);
+      p->ctl.n++;
+   }
+   fclose(f);
+   return 0;
+}
+
+const char *pamlh_opt(const pamlh *p, const char *key)
+{
+   int i;
+   for (i = 0; i < p->ctl.n; i++)
+      if (strncmp(p->ctl.key[i], key, 8) == 0) return p->ctl.val[i];   /* first 8 characters decide (codeml.c:1730) */
+   return NULL;
+}
+
+double pamlh_optd(const pamlh *p, const char *key, double dflt)
+{
+   const char *v = pamlh_opt(p, key);
+   return v && *v ? atof(v) : dflt;
+}
+
+/* ------------------------------------------------------------------ sequences */
+static int cmp_cols(const void *a, const void *b, void *ctx)
+{
+   const pamlh *p = (const pamlh *)ctx;
+   const int ia = *(const int *)a, ib = *(const int *)b, w = p->n31, L = p->ls * w;
+   int j, c;
+   for (j = 0; j < p->ns; j++) {
+      c = memcmp(p->raw + (size_t)j * L + (size_t)ia * w, p->raw + (size_t)j * L + (size_t)ib * w, w);
+      if (c) return c;
+   }
+   return ia - ib;
+}
+static const pamlh *g_sort_ctx;
+static int cmp_cols0(const void *a, const void *b) { return cmp_cols(a, b, (void *)g_sort_ctx); }
+
+static int base_set(char c, int *set)
+{
+   const char *q = strchr(BASEs, c);
+   int i, n;
+   if (!q) return 0;
+   n = (int)strlen(EquateBASE[q - BASEs]);
+   for (i = 0; i < n; i++) set[i] = (int)(strchr(BASEs, EquateBASE[q - BASEs][i]) - BASEs);
+   return n;
+}
+
+int pamlh_read_seqs(pamlh *p)
+{
+   FILE *f = fopen(p->seqfile, "r");
+   char *line;
+   size_t cap = 1 << 16;
+   int ns, lsraw, i, j, k, h, readpattern = 0, any_amb = 0, n31 = (p->seqtype == 1 ? 3 : 1);
+   const char *alpha = p->seqtype == 2 ? AAs : BASEs;
+   const int nbasic = p->seqtype == 2 ? 20 : 4;
+   char *seq;
+   if (!f) return pamlh_fail(p, "cannot open sequence file %s", p->seqfile);
+   line = (char *)malloc(cap);
+   if (!fgets(line, (int)cap, f) || sscanf(line, "%d %d", &ns, &lsraw) != 2) { fclose(f); return pamlh_fail(p, "bad first line in %s", p->seqfile); }
+   {  /* option letters after the two numbers */
+      char *c = line;
+      int nnum = 0, hasG = 0, hasC = 0;
+      while (*c) {
+         if (isdigit((unsigned char)*c)) { nnum++; while (isdigit((unsigned char)*c)) c++; continue; }
+         if (nnum >= 2 && isalpha((unsigned char)*c)) {
+            char o = (char)toupper(*c);
+            if (o == 'P') readpattern = 1;
+            else if (o == 'G') hasG = 1;
+            else if (o == 'C') hasC = 1;
+            else if (o == 'I') { fclose(f); free(line); return pamlh_fail(p, "interleaved sequence files are not supported yet"); }
+            else if (o != 'S') { fclose(f); free(line); return pamlh_fail(p, "bad option '%c' in first line of seqfile", o); }
+         }
+         c++;
+      }
+      if (hasG && !hasC) { fclose(f); free(line); return pamlh_fail(p, "option G (several genes) is not supported yet"); }
+   }
+   if (lsraw % n31) { fclose(f); free(line); return pamlh_fail(p, "%d nucleotides, not a multiple of 3", lsraw); }
+   p->ns = ns; p->n31 = n31;
+   p->names = (char **)calloc(ns, sizeof(char *));
+   seq = (char *)malloc((size_t)ns * lsraw);
+   for (j = 0; j < ns; j++) {
+      char *q, *dbl;
+      do {
+         if (!fgets(line, (int)cap, f)) { fclose(f); return pamlh_fail(p, "EOF reading sequence %d", j + 1); }
+         for (q = line; *q && isspace((unsigned char)*q); q++) ;
+      } while (!*q);
+      dbl = strstr(q, "  ");
+      {
+         size_t ln = dbl ? (size_t)(dbl - q) : strcspn(q, "\r\n");
+         size_t tl = strcspn(q, "\t\r\n");
+         if (tl < ln) ln = tl;
+         if (ln > 95) ln = 95;
+         p->names[j] = (char *)calloc(ln + 1, 1);
+         memcpy(p->names[j], q, ln);
+         while (ln > 0 && isspace((unsigned char)p->names[j][ln - 1])) p->names[j][--ln] = 0;
+         q += (dbl ? (size_t)(dbl - q) : strlen(q));
+      }
+      for (k = 0; k < lsraw;) {
+         if (!*q) {
+            if (!fgets(line, (int)cap, f)) { fclose(f); return pamlh_fail(p, "EOF at site %d, seq %d", k + 1, j + 1); }
+            q = line;
+            continue;
+         }
+         {
+            char ch = (char)toupper((unsigned char)*q++);
+            if (p->seqtype != 2 && ch == 'U') ch = 'T';
+            if (ch == '.') {
+               if (j == 0) { fclose(f); return pamlh_fail(p, ". in the first sequence"); }
+               seq[(size_t)j * lsraw + k] = seq[k];
+               k++;
+            }
+            else if (strchr(alpha, ch) && ch) {
+               seq[(size_t)j * lsraw + k++] = ch;
+               if (strchr(alpha, ch) - alpha >= nbasic) any_amb = 1;
+            }
+            else if (isalpha((unsigned char)ch)) { fclose(f); return pamlh_fail(p, "bad character %c at %d seq %d", ch, k + 1, j + 1); }
+         }
+      }
+   }
+   /* pattern counts of the P format: npatt numbers after the sequences (treesub.c:954-983) */
+   {
+      const int nsite = lsraw / n31;
+      int *keep = (int *)malloc(nsite * sizeof(int)), nkeep = 0, *idx;
+      double *cnt = (double *)malloc(nsite * sizeof(double));
+      for (h = 0; h < nsite; h++) cnt[h] = 1;
+      if (readpattern)
+         for (h = 0; h < nsite; h++)
+            if (fscanf(f, "%lf", &cnt[h]) != 1) { fclose(f); return pamlh_fail(p, "EOF reading pattern counts"); }
+      fclose(f);
+      /* cleandata = 1: drop every site with an ambiguity character in any sequence (RemoveIndel treesub.c:1754) */
+      p->cleandata = (p->cleandata_opt || !any_amb) ? 1 : 0;
+      for (h = 0; h < nsite; h++) {
+         int ok = 1;
+         if (p->cleandata_opt && any_amb)
+            for (j = 0; j < ns && ok; j++)
+               for (k = 0; k < n31; k++)
+                  if (strchr(alpha, seq[(size_t)j * lsraw + h * n31 + k]) - alpha >= nbasic) { ok = 0; break; }
+         if (ok) keep[nkeep++] = h;
+      }
+      p->ls = nkeep;
+      p->raw = (char *)malloc((size_t)ns * nkeep * n31);
+      for (j = 0; j < ns; j++)
+         for (h = 0; h < nkeep; h++) memcpy(p->raw + ((size_t)j * nkeep + h) * n31, seq + (size_t)j * lsraw + keep[h] * n31, n31);
+      /* compress sites into patterns, sorted by raw characters; the P format is already compressed */
+      idx = (int *)malloc(nkeep * sizeof(int));
+      for (h = 0; h < nkeep; h++) idx[h] = h;
+      {
+         char *raw2;
+         int np = 0, *first = (int *)malloc(nkeep * sizeof(int));
+         double *w = (double *)calloc(nkeep, sizeof(double));
+         if (!readpattern) {
+            g_sort_ctx = p;
+            qsort(idx, nkeep, sizeof(int), cmp_cols0);
+            for (h = 0; h < nkeep; h++) {
+               int same = 0;
+               if (np > 0) {
+                  same = 1;
+                  for (j = 0; j < ns && same; j++)
+                     if (memcmp(p->raw + ((size_t)j * nkeep + idx[h]) * n31, p->raw + ((size_t)j * nkeep + first[np - 1]) * n31, n31)) same = 0;
+               }
+               if (same) w[np - 1] += cnt[keep[idx[h]]];
+               else { first[np] = idx[h]; w[np] = cnt[keep[idx[h]]]; np++; }
+            }
+         }
+         else
+            for (h = 0; h < nkeep; h++) { first[np] = h; w[np] = cnt[keep[h]]; np++; }
+         raw2 = (char *)malloc((size_t)ns * np * n31);
+         for (j = 0; j < ns; j++)
+            for (h = 0; h < np; h++) memcpy(raw2 + ((size_t)j * np + h) * n31, p->raw + ((size_t)j * nkeep + first[h]) * n31, n31);
+         free(p->raw);
+         p->raw = raw2;
+         p->npatt = np;
+         p->w = (double *)malloc(np * sizeof(double));
+         memcpy(p->w, w, np * sizeof(double));
+         if (readpattern) {      /* com.ls = sum of counts when they exceed 1 (treesub.c:964-967) */
+            double s = 0;
+            for (h = 0; h < np; h++) s += w[h];
+            if (s > 1.00001) p->ls = (int)(s + 0.5);
+         }
+         free(first); free(w);
+      }
+      free(idx); free(keep); free(cnt);
+   }
+   free(seq); free(line);
+
+   /* encode (EncodeSeqs / SetMapAmbiguity) */
+   {
+      const int np = p->npatt, n = p->n;
+      p->z = (unsigned char *)malloc((size_t)ns * np);
+      if (p->seqtype != 1) {
+         const int ncodes_all = (int)strlen(alpha);
+         p->n_codes = p->cleandata ? n : ncodes_all;
+         p->n_chara = (int *)calloc(p->n_codes, sizeof(int));
+         p->chara_map = (unsigned char *)calloc((size_t)p->n_codes * n, 1);
+         for (i = 0; i < p->n_codes; i++) {
+            if (i < n) { p->n_chara[i] = 1; p->chara_map[(size_t)i * n] = (unsigned char)i; }
+            else if (p->seqtype == 0) {
+               int set[4], m = base_set(BASEs[i], set);
+               p->n_chara[i] = m;
+               for (k = 0; k < m; k++) p->chara_map[(size_t)i * n + k] = (unsigned char)set[k];
+            }
+            else { p->n_chara[i] = n; for (k = 0; k < n; k++) p->chara_map[(size_t)i * n + k] = (unsigned char)k; }
+         }
+         for (j = 0; j < ns; j++)
+            for (h = 0; h < np; h++) p->z[(size_t)j * np + h] = (unsigned char)(strchr(alpha, p->raw[(size_t)j * np + h]) - alpha);
+      }
+      else {
+         int from64[64], nsense = 0, namb = 0;
+         char amb[256][4];
+         for (i = 0; i < 64; i++) from64[i] = STDCODE[i] == '*' ? -1 : nsense++;
+         for (j = 0; j < ns; j++)
+            for (h = 0; h < np; h++) {
+               const char *c = p->raw + ((size_t)j * np + h) * 3;
+               int b[3], code;
+               for (k = 0; k < 3; k++) b[k] = (int)(strchr(BASEs, c[k]) - BASEs);
+               if (b[0] < 4 && b[1] < 4 && b[2] < 4) {
+                  code = from64[b[0] * 16 + b[1] * 4 + b[2]];
+                  if (code < 0) return pamlh_fail(p, "stop codon %.3s in sequence %d", c, j + 1);
+               }
+               else {
+                  for (k = 0; k < namb; k++)
+                     if (!memcmp(amb[k], c, 3)) break;
+                  if (k == namb) {
+                     if (namb >= 256 - 61) return pamlh_fail(p, "too many distinct ambiguous codons");
+                     memcpy(amb[namb], c, 3); amb[namb][3] = 0; namb++;
+                  }
+                  code = 61 + k;
+               }
+               p->z[(size_t)j * np + h] = (unsigned char)code;
+            }
+         p->n_codes = 61 + namb;
+         p->n_chara = (int *)calloc(p->n_codes, sizeof(int));
+         p->chara_map = (unsigned char *)calloc((size_t)p->n_codes * n, 1);
+         for (i = 0; i < 61; i++) { p->n_chara[i] = 1; p->chara_map[(size_t)i * n] = (unsigned char)i; }
+         for (i = 0; i < namb; i++) {
+            int s0[4], s1[4], s2[4], n0 = base_set(amb[i][0], s0), n1 = base_set(amb[i][1], s1), n2 = base_set(amb[i][2], s2);
+            int i0, i1, i2, m = 0;
+            for (i0 = 0; i0 < n0; i0++)
+               for (i1 = 0; i1 < n1; i1++)
+                  for (i2 = 0; i2 < n2; i2++) {
+                     int ic = s0[i0] * 16 + s1[i1] * 4 + s2[i2];
+                     if (from64[ic] >= 0) p->chara_map[(size_t)(61 + i) * n + m++] = (unsigned char)from64[ic];
+                  }
+            if (!m) return pamlh_fail(p, "codon %s is a stop codon", amb[i]);
+            p->n_chara[61 + i] = m;
+         }
+         if (namb == 0) p->cleandata = 1;
+      }
+   }
+   return 0;
+}
+
+/* ------------------------------------------------------------------ tree */
+int pamlh_read_tree(pamlh *p)
+{
+   FILE *f = fopen(p->treefile, "r");
+   char *buf, *s;
+   long len;
+   int ns = p->ns, nn = 0, i, depth = 0, cur = -1, nb = 0, maxn = 2 * p->ns;
+   int *stack, *father, *nson, *sonbuf, last = -1;
+   if (!f) return pamlh_fail(p, "cannot open tree file %s", p->treefile);
+   fseek(f, 0, SEEK_END); len = ftell(f); fseek(f, 0, SEEK_SET);
+   buf = (char *)malloc(len + 1);
+   len = (long)fread(buf, 1, len, f); buf[len] = 0;
+   fclose(f);
+   s = strchr(buf, '(');
+   if (!s) { free(buf); return pamlh_fail(p, "no tree in %s", p->treefile); }
+   stack = (int *)malloc(maxn * sizeof(int));
+   father = (int *)malloc(maxn * sizeof(int));
+   p->label = (int *)calloc(maxn, sizeof(int));
+   p->tree_branch = (double *)malloc(maxn * sizeof(double));
+   p->branch_node = (int *)malloc(maxn * sizeof(int));
+   for (i = 0; i < maxn; i++) { father[i] = -1; p->tree_branch[i] = -1; }
+   nn = ns;
+   for (; *s && *s != ';'; ) {
+      if (isspace((unsigned char)*s)) { s++; continue; }
+      if (*s == '(') {
+         int node = nn++;
+         if (nn > maxn) { free(buf); return pamlh_fail(p, "tree has too many nodes"); }
+         if (depth > 0) { father[node] = stack[depth - 1]; p->branch_node[nb++] = node; }
+         else p->root = node;
+         stack[depth++] = node;
+         s++;
+         last = -1;
+      }
+      else if (*s == ',') { s++; last = -1; }
+      else if (*s == ')') { last = stack[--depth]; s++; }
+      else if (*s == ':' ) { char *e; double v = strtod(s + 1, &e); if (last >= 0) p->tree_branch[last] = v; s = e; }
+      else if (*s == '#' || *s == '$') { char *e; double v = strtod(s + 1, &e); if (last >= 0 && *s == '#') p->label[last] = (int)v; s = e; }
+      else if (*s == '[') { while (*s && *s != ']') s++; if (*s) s++; }
+      else if (last >= 0 && cur != last && (isalnum((unsigned char)*s) || *s == '_' || *s == '.') && s[-1] == ')') {
+         while (*s && !strchr(",():;#$[ \t\r\n", *s)) s++;    /* internal node name / support value: ignored */
+      }
+      else {   /* a tip: name or 1-based number */
+         char name[128];
+         int k = 0, tip = -1;
+         while (*s && !strchr(",():;#$[", *s) && k < 127) name[k++] = *s++;
+         while (k > 0 && isspace((unsigned char)name[k - 1])) k--;
+         name[k] = 0;
+         for (i = 0; i < ns; i++)
+            if (!strcmp(name, p->names[i])) { tip = i; break; }
+         if (tip < 0) {
+            char *e; long v = strtol(name, &e, 10);
+            if (*e == 0 && v >= 1 && v <= ns) tip = (int)v - 1;
+         }
+         if (tip < 0) { free(buf); return pamlh_fail(p, "species %s in the tree is not in the sequence file", name); }
+         if (depth < 1) { free(buf); return pamlh_fail(p, "bad tree"); }
+         father[tip] = stack[depth - 1];
+         p->branch_node[nb++] = tip;
+         last = tip;
+      }
+   }
+   free(buf);
+   p->nnode = nn; p->nbranch = nb;
+   nson = (int *)calloc(nn, sizeof(int));
+   for (i = 0; i < nb; i++) nson[father[p->branch_node[i]]]++;
+   p->sons_ptr = (int *)calloc(nn + 1, sizeof(int));
+   for (i = 0; i < nn; i++) p->sons_ptr[i + 1] = p->sons_ptr[i] + nson[i];
+   sonbuf = (int *)malloc((nb + 1) * sizeof(int));
+   memset(nson, 0, nn * sizeof(int));
+   for (i = 0; i < nb; i++) { int c = p->branch_node[i], fa = father[c]; sonbuf[p->sons_ptr[fa] + nson[fa]++] = c; }   /* appearance order = sons[] order */
+   p->sons = sonbuf;
+   p->father = father;
+   /* SetNodeScale (treesub.c:7177-7197) */
+   {
+      const int every = p->is_codeml ? (p->seqtype == 1 ? 15 : 50) : 100;
+      int *cnt = (int *)calloc(nn, sizeof(int)), *order = (int *)malloc(nn * sizeof(int)), no = 0, sp = 0;
+      p->scale = (unsigned char *)calloc(nn, 1);
+      stack[sp++] = p->root;     /* post-order via reversed pre-order */
+      while (sp) { int x = stack[--sp], j; order[no++] = x; for (j = p->sons_ptr[x]; j < p->sons_ptr[x + 1]; j++) stack[sp++] = p->sons[j]; }
+      for (i = no - 1; i >= 0; i--) {
+         int x = order[i], j, d = 0;
+         if (p->sons_ptr[x + 1] == p->sons_ptr[x]) continue;
+         for (j = p->sons_ptr[x]; j < p->sons_ptr[x + 1]; j++) { int c = p->sons[j]; d += (p->sons_ptr[c + 1] > p->sons_ptr[c]) ? cnt[c] : 1; }
+         if (x != p->root && d > every) { p->scale[x] = 1; d = 1; }
+         cnt[x] = d;
+      }
+      free(cnt); free(order);
+   }
+   free(stack); free(nson);
+   return 0;
+}

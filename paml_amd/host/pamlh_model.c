@@ -1,0 +1,572 @@
+/* pamlh_model.c — options -> data -> parameters -> engine inputs, the way the reference's model layer does it.
+ * Written fresh against the behaviour of: GetOptions (codeml.c:1694, baseml.c:954), InitializeBaseAA (treesub.c:1548),
+ * InitializeCodon / CountCodons / AddCodonFreqSeqGene (codeml.c:3640-3873), GetDaa (codeml.c:3967), eigenQcodon
+ * (codeml.c:3229-3321), eigenQaa (3400-3484), eigenQREVbase / eigenTN93 (treesub.c:2488, 2210), SetParameters and
+ * SetParametersNSsites (codeml.c:2757, 2459-2660; baseml.c:1306), DiscreteNSsites (codeml.c:2846), readx (treesub.c:4035). */
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pamlh_internal.h"
+
+static const char STDCODE[] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+enum { JC69, K80, F81, F84, HKY85, T92, TN93, REV };   /* baseml models (baseml.ctl) */
+
+static double dist2(const double *a, const double *b, int n)
+{
+   double s = 0;
+   int i;
+   for (i = 0; i < n; i++) s += (a[i] - b[i]) * (a[i] - b[i]);
+   return sqrt(s);
+}
+
+/* base / amino-acid frequencies with ambiguity characters resolved by iteration (InitializeBaseAA treesub.c:1548-1700) */
+static void add_freq(const pamlh *p, int js, const double *pi0, double *pi)
+{
+   int h, k, n = p->n;
+   for (h = 0; h < p->npatt; h++) {
+      const int code = p->z[(size_t)js * p->npatt + h], nc = p->n_chara[code];
+      const unsigned char *map = p->chara_map + (size_t)code * n;
+      if (nc == 1) pi[map[0]] += p->w[h];
+      else {
+         double t = 0;
+         for (k = 0; k < nc; k++) t += pi0[map[k]];
+         for (k = 0; k < nc; k++) pi[map[k]] += p->w[h] * pi0[map[k]] / t;
+      }
+   }
+}
+
+static void freqs_base_aa(pamlh *p)
+{
+   int n = p->n, js, k, it;
+   double pi0[64], pi[64], piG[64] = {0}, t;
+   for (js = 0; js < p->ns; js++) {
+      for (k = 0; k < n; k++) pi0[k] = 1.0 / n;
+      for (it = 0; it < 20; it++) {
+         for (k = 0; k < n; k++) pi[k] = 0;
+         add_freq(p, js, pi0, pi);
+         for (k = 0, t = 0; k < n; k++) t += pi[k];
+         for (k = 0; k < n; k++) pi[k] = t < 1e-10 ? 1.0 / n : pi[k] / t;
+         if (p->cleandata || dist2(pi, pi0, n) < 1e-8) break;
+         memcpy(pi0, pi, n * sizeof(double));
+      }
+      for (k = 0; k < n; k++) piG[k] += pi[k] / p->ns;
+   }
+   if (p->cleandata) { memcpy(p->pi_data, piG, n * sizeof(double)); return; }
+   memcpy(pi0, piG, n * sizeof(double));
+   for (it = 0; it < 20; it++) {
+      for (k = 0; k < n; k++) pi[k] = 0;
+      for (js = 0; js < p->ns; js++) add_freq(p, js, pi0, pi);
+      for (k = 0, t = 0; k < n; k++) t += pi[k];
+      for (k = 0; k < n; k++) pi[k] /= t;
+      if (dist2(pi, pi0, n) < 1e-8) break;
+      memcpy(pi0, pi, n * sizeof(double));
+   }
+   memcpy(p->pi_data, pi, n * sizeof(double));
+}
+
+static int base_set(char c, int *set)
+{
+   static const char BASEs[] = "TCAGUYRMKSWHBVD-N?";
+   static const char *Eq[] = {"T", "C", "A", "G", "T", "TC", "AG", "CA", "TG", "CG", "TA", "TCA", "TCG", "CAG", "TAG", "TCAG", "TCAG", "TCAG"};
+   const char *q = strchr(BASEs, c);
+   int i, m = (int)strlen(Eq[q - BASEs]);
+   for (i = 0; i < m; i++) set[i] = (int)(strchr(BASEs, Eq[q - BASEs][i]) - BASEs);
+   return m;
+}
+
+/* codon data: fcodon (64), fb3x4, fb4 — CountCodons (resolved codons only) then the ambiguity iteration */
+static void freqs_codon(pamlh *p)
+{
+   int js, h, k, i0, i1, i2, it, np = p->npatt;
+   double fc[64] = {0}, fb[12] = {0}, f4[4] = {0}, fc0[64], fb0[12], f40[4], t;
+   int from64[64], nsense = 0;
+   for (k = 0; k < 64; k++) from64[k] = STDCODE[k] == '*' ? -1 : nsense++;
+   for (js = 0; js < p->ns; js++)
+      for (h = 0; h < np; h++) {
+         const char *c = p->raw + ((size_t)js * np + h) * 3;
+         int s[3][4], m[3];
+         for (k = 0; k < 3; k++) m[k] = base_set(c[k], s[k]);
+         if (m[0] * m[1] * m[2] > 1) continue;
+         fc[s[0][0] * 16 + s[1][0] * 4 + s[2][0]] += p->w[h];
+      }
+   /* Fcodon_3x4: position-specific base frequencies from codon counts; fb4 = their average over positions */
+   for (k = 0; k < 64; k++) { fb[k / 16] += fc[k]; fb[4 + (k / 4) % 4] += fc[k]; fb[8 + k % 4] += fc[k]; }
+   for (k = 0; k < 3; k++) { for (t = 0, i0 = 0; i0 < 4; i0++) t += fb[k * 4 + i0]; for (i0 = 0; i0 < 4; i0++) fb[k * 4 + i0] /= t; }
+   for (k = 0; k < 4; k++) f4[k] = (fb[k] + fb[4 + k] + fb[8 + k]) / 3;
+   if (!p->cleandata) {
+      for (t = 0, k = 0; k < 64; k++) t += fc[k];
+      for (k = 0; k < 64; k++) fc0[k] = fc[k] / t;
+      memcpy(fb0, fb, sizeof(fb)); memcpy(f40, f4, sizeof(f4));
+      for (it = 0; it < 20; it++) {
+         double d1, d2, d3;
+         memset(fc, 0, sizeof(fc)); memset(fb, 0, sizeof(fb)); memset(f4, 0, sizeof(f4));
+         for (js = 0; js < p->ns; js++)
+            for (h = 0; h < np; h++) {
+               const char *c = p->raw + ((size_t)js * np + h) * 3;
+               int s[3][4], m[3], ft[64] = {0}, nk = 0;
+               double t1;
+               for (k = 0; k < 3; k++) m[k] = base_set(c[k], s[k]);
+               for (k = 0; k < 3; k++) {
+                  for (i0 = 0, t = t1 = 0; i0 < m[k]; i0++) { t += fb0[k * 4 + s[k][i0]]; t1 += f40[s[k][i0]]; }
+                  for (i0 = 0; i0 < m[k]; i0++) {
+                     fb[k * 4 + s[k][i0]] += p->w[h] * fb0[k * 4 + s[k][i0]] / t;
+                     f4[s[k][i0]] += p->w[h] * f40[s[k][i0]] / t1;
+                  }
+               }
+               for (i0 = 0, t = 0; i0 < m[0]; i0++)
+                  for (i1 = 0; i1 < m[1]; i1++)
+                     for (i2 = 0; i2 < m[2]; i2++) {
+                        const int ic = s[0][i0] * 16 + s[1][i1] * 4 + s[2][i2];
+                        if (from64[ic] < 0) continue;
+                        ft[ic] = 1; nk++; t += fc0[ic];
+                     }
+               for (k = 0; k < 64; k++)
+                  if (ft[k]) fc[k] += (t > 0 ? p->w[h] * fc0[k] / t : p->w[h] / nk);
+            }
+         for (t = 0, k = 0; k < 64; k++) t += fc[k];
+         for (k = 0; k < 64; k++) fc[k] /= t;
+         for (k = 0; k < 3; k++) { for (t = 0, i0 = 0; i0 < 4; i0++) t += fb[k * 4 + i0]; for (i0 = 0; i0 < 4; i0++) fb[k * 4 + i0] /= t; }
+         for (t = 0, k = 0; k < 4; k++) t += f4[k];
+         for (k = 0; k < 4; k++) f4[k] /= t;
+         d1 = dist2(fc, fc0, 64); d2 = dist2(fb, fb0, 12); d3 = dist2(f4, f40, 4);
+         if (d1 < 1e-8 && d2 < 1e-8 && d3 < 1e-8) break;
+         memcpy(fc0, fc, sizeof(fc)); memcpy(fb0, fb, sizeof(fb)); memcpy(f40, f4, sizeof(f4));
+      }
+   }
+   memcpy(p->fcodon, fc, sizeof(fc)); memcpy(p->fb3x4, fb, sizeof(fb)); memcpy(p->fb4, f4, sizeof(f4));
+   /* com.pi by CodonFreq (codeml.c:3852-3873) */
+   {
+      double s = 0;
+      int j = 0;
+      for (k = 0; k < 64; k++) {
+         double v;
+         if (from64[k] < 0) continue;
+         if (p->codonfreq == 0) v = 1;
+         else if (p->codonfreq == 1) v = f4[k / 16] * f4[(k / 4) % 4] * f4[k % 4];
+         else if (p->codonfreq == 2) v = fb[k / 16] * fb[4 + (k / 4) % 4] * fb[8 + k % 4];
+         else v = fc[k];
+         p->pi_data[j++] = v;
+         s += v;
+      }
+      for (j = 0; j < 61; j++) p->pi_data[j] /= s;
+   }
+}
+
+static int read_aa_ratefile(pamlh *p)
+{
+   FILE *f = fopen(p->aaratefile, "r");
+   int i, j;
+   if (!f) return pamlh_fail(p, "cannot open aaRatefile %s", p->aaratefile);
+   memset(p->aaS, 0, sizeof(p->aaS));
+   for (i = 0; i < 20; i++)
+      for (j = 0; j < i; j++) {
+         double v;
+         if (fscanf(f, "%lf", &v) != 1) { fclose(f); return pamlh_fail(p, "aaRatefile: too few rates"); }
+         p->aaS[i * 20 + j] = p->aaS[j * 20 + i] = v;
+      }
+   for (i = 0; i < 20; i++)
+      if (fscanf(f, "%lf", &p->aapi_file[i]) != 1) { fclose(f); return pamlh_fail(p, "aaRatefile: too few frequencies"); }
+   fclose(f);
+   return 0;
+}
+
+static void resolve(const pamlh *p, const char *name, char *out, size_t cap)
+{
+   if (name[0] == '/') snprintf(out, cap, "%s", name);
+   else snprintf(out, cap, "%s/%s", p->dir, name);
+}
+
+int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err, int errcap)
+{
+   pamlh *p = (pamlh *)calloc(1, sizeof(pamlh));
+   const char *v, *slash;
+   int rc = 0;
+   *out = NULL;
+   p->is_codeml = strcmp(program, "baseml") != 0;
+   slash = strrchr(ctl_path, '/');
+   if (slash) { size_t n = (size_t)(slash - ctl_path); memcpy(p->dir, ctl_path, n); p->dir[n] = 0; }
+   else strcpy(p->dir, ".");
+   if ((rc = pamlh_read_ctl(p, ctl_path))) goto bad;
+   if (!(v = pamlh_opt(p, "seqfile"))) { rc = pamlh_fail(p, "no seqfile in the control file"); goto bad; }
+   resolve(p, v, p->seqfile, sizeof(p->seqfile));
+   if (!(v = pamlh_opt(p, "treefile"))) { rc = pamlh_fail(p, "no treefile in the control file"); goto bad; }
+   resolve(p, v, p->treefile, sizeof(p->treefile));
+   p->seqtype = p->is_codeml ? (int)pamlh_optd(p, "seqtype", 1) : 0;
+   p->codonfreq = (int)pamlh_optd(p, "CodonFreq", 0);
+   p->model = (int)pamlh_optd(p, "model", 0);
+   p->nssites = (int)pamlh_optd(p, "NSsites", 0);
+   p->icode = (int)pamlh_optd(p, "icode", 0);
+   p->fix_kappa = (int)pamlh_optd(p, "fix_kappa", 0);
+   p->kappa0 = pamlh_optd(p, "kappa", 2);
+   p->fix_omega = (int)pamlh_optd(p, "fix_omega", 0);
+   p->omega0 = pamlh_optd(p, "omega", 0.4);
+   p->fix_alpha = (int)pamlh_optd(p, "fix_alpha", 1);
+   p->alpha0 = pamlh_optd(p, "alpha", 0);
+   p->ncatG = (int)pamlh_optd(p, "ncatG", 4);
+   p->cleandata_opt = (int)pamlh_optd(p, "cleandata", 0);
+   p->fix_blength = (int)pamlh_optd(p, "fix_blength", 0);
+   if ((int)pamlh_optd(p, "clock", 0) != 0) { rc = pamlh_fail(p, "clock models are not supported"); goto bad; }
+   if ((int)pamlh_optd(p, "Mgene", 0) != 0) { rc = pamlh_fail(p, "Mgene models are not supported"); goto bad; }
+   if (p->seqtype == 1) {
+      if (p->icode != 0) { rc = pamlh_fail(p, "only the universal genetic code (icode = 0) is supported"); goto bad; }
+      if (p->model != 0) { rc = pamlh_fail(p, "branch / branch-site codon models are not supported yet"); goto bad; }
+      if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 7 && p->nssites != 8) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
+      if (p->codonfreq < 0 || p->codonfreq > 3) { rc = pamlh_fail(p, "CodonFreq = %d is not supported", p->codonfreq); goto bad; }
+      p->n = 61;
+   }
+   else if (p->seqtype == 2) {
+      p->n = 20; p->aa_model = p->model;
+      if (p->aa_model != 0 && p->aa_model != 2 && p->aa_model != 3) { rc = pamlh_fail(p, "amino-acid model %d is not supported", p->aa_model); goto bad; }
+      if (p->aa_model >= 2) {
+         if (!(v = pamlh_opt(p, "aaRatefile")) || !*v) { rc = pamlh_fail(p, "empirical aa model without aaRatefile"); goto bad; }
+         resolve(p, v, p->aaratefile, sizeof(p->aaratefile));
+         if ((rc = read_aa_ratefile(p))) goto bad;
+      }
+   }
+   else if (p->seqtype == 0) {
+      p->n = 4;
+      if (p->model == F84 || p->model == T92 || p->model > REV) { rc = pamlh_fail(p, "baseml model %d is not supported", p->model); goto bad; }
+   }
+   else { rc = pamlh_fail(p, "seqtype %d is not supported", p->seqtype); goto bad; }
+   if ((rc = pamlh_read_seqs(p))) goto bad;
+   if ((rc = pamlh_read_tree(p))) goto bad;
+   if (p->seqtype == 1) freqs_codon(p);
+   else freqs_base_aa(p);
+   /* parameter bookkeeping (GetInitials): ntime, np */
+   p->ntime = p->fix_blength == 2 ? 0 : p->nbranch;
+   {
+      int nr = 0;
+      if (p->seqtype == 1) {
+         nr += !p->fix_kappa;
+         if (p->nssites == 0) nr += !p->fix_omega;
+         else if (p->nssites == 1) nr += 2;
+         else if (p->nssites == 2) nr += 4;
+         else if (p->nssites == 7) nr += 2;
+         else if (p->nssites == 8) nr += 3 + !p->fix_omega;
+      }
+      else if (p->seqtype == 0) {
+         if (p->model == K80 || p->model == HKY85) nr += !p->fix_kappa;
+         else if (p->model == TN93) nr += 2 * !p->fix_kappa;
+         else if (p->model == REV) nr += 5;
+      }
+      if (p->alpha0 > 0 || !p->fix_alpha) nr += !p->fix_alpha;
+      p->np = p->ntime + nr;
+   }
+   p->branch = (double *)calloc(p->nnode, sizeof(double));
+   p->pi = (double *)calloc(64, sizeof(double));
+   p->freqK = (double *)calloc(64, sizeof(double));
+   p->rate = (double *)calloc(64, sizeof(double));
+   p->eigen_of = (int *)calloc(64, sizeof(int));
+   *out = p;
+   return 0;
+bad:
+   if (err && errcap > 0) snprintf(err, errcap, "%s", p->err);
+   pamlh_free(p);
+   return rc ? rc : -1;
+}
+
+void pamlh_free(pamlh *p)
+{
+   int i;
+   if (!p) return;
+   if (p->eng) paml_amd_destroy(p->eng);
+   if (p->names) for (i = 0; i < p->ns; i++) free(p->names[i]);
+   free(p->names); free(p->z); free(p->w); free(p->raw); free(p->n_chara); free(p->chara_map);
+   free(p->sons_ptr); free(p->sons); free(p->label); free(p->branch_node); free(p->father); free(p->tree_branch); free(p->scale);
+   free(p->branch); free(p->pi); free(p->freqK); free(p->rate); free(p->eigen_of);
+   for (i = 0; i < 16; i++) { free(p->eig[i].U); free(p->eig[i].V); free(p->eig[i].Root); free(p->eig[i].Cijk); }
+   free(p);
+}
+
+const char *pamlh_error(const pamlh *p) { return p ? p->err : "null"; }
+
+int pamlh_dims(const pamlh *p, int *n_states, int *n_tips, int *n_patt, int *n_nodes, int *root, int *n_codes,
+               int *cleandata, int *ls, int *np, int *ntime)
+{
+   if (n_states) *n_states = p->n;
+   if (n_tips) *n_tips = p->ns;
+   if (n_patt) *n_patt = p->npatt;
+   if (n_nodes) *n_nodes = p->nnode;
+   if (root) *root = p->root;
+   if (n_codes) *n_codes = p->n_codes;
+   if (cleandata) *cleandata = p->cleandata;
+   if (ls) *ls = p->ls;
+   if (np) *np = p->np;
+   if (ntime) *ntime = p->ntime;
+   return 0;
+}
+const unsigned char *pamlh_tips(const pamlh *p) { return p->z; }
+const double *pamlh_weights(const pamlh *p) { return p->w; }
+const int *pamlh_n_chara(const pamlh *p) { return p->n_chara; }
+const unsigned char *pamlh_chara_map(const pamlh *p) { return p->chara_map; }
+const int *pamlh_sons_ptr(const pamlh *p) { return p->sons_ptr; }
+const int *pamlh_sons(const pamlh *p) { return p->sons; }
+const int *pamlh_labels(const pamlh *p) { return p->label; }
+const unsigned char *pamlh_scale_nodes(const pamlh *p) { return p->scale; }
+const int *pamlh_branch_order(const pamlh *p) { return p->branch_node; }
+const double *pamlh_branch(const pamlh *p) { return p->branch; }
+const double *pamlh_pi(const pamlh *p) { return p->pi; }
+const double *pamlh_freqK(const pamlh *p) { return p->freqK; }
+const double *pamlh_rate(const pamlh *p) { return p->rate; }
+const int *pamlh_eigen_of(const pamlh *p) { return p->eigen_of; }
+
+int pamlh_model(const pamlh *p, int *mode, int *K, int *n_eigen, int *n_labels)
+{
+   if (mode) *mode = p->mode;
+   if (K) *K = p->K;
+   if (n_eigen) *n_eigen = p->n_eigen;
+   if (n_labels) *n_labels = p->n_labels;
+   return 0;
+}
+
+int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const double **U, const double **V,
+                const double **Root, const double **Cijk)
+{
+   if (i < 0 || i >= p->n_eigen) return -1;
+   if (kind) *kind = p->eig[i].kind;
+   if (nR) *nR = p->eig[i].nR;
+   if (kappa) *kappa = p->eig[i].kappa;
+   if (U) *U = p->eig[i].U;
+   if (V) *V = p->eig[i].V;
+   if (Root) *Root = p->eig[i].Root;
+   if (Cijk) *Cijk = p->eig[i].Cijk;
+   return 0;
+}
+
+int pamlh_default_x(const pamlh *p, double *x, int cap)
+{
+   int k = 0, i;
+   if (cap < p->np) return -1;
+   for (i = 0; i < p->ntime; i++) { double b = p->tree_branch[p->branch_node[i]]; x[k++] = b >= 0 ? b : 0.1; }
+   if (p->seqtype == 1) {
+      if (!p->fix_kappa) x[k++] = p->kappa0;
+      if (p->nssites == 0) { if (!p->fix_omega) x[k++] = p->omega0; }
+      else if (p->nssites == 1) { x[k++] = 0.6; x[k++] = 0.1; }
+      else if (p->nssites == 2) { x[k++] = 0.5; x[k++] = 0.3; x[k++] = 0.1; x[k++] = 2.5; }
+      else if (p->nssites == 7) { x[k++] = 0.5; x[k++] = 1.5; }
+      else if (p->nssites == 8) { x[k++] = 0.9; x[k++] = 0.5; x[k++] = 1.5; if (!p->fix_omega) x[k++] = 2.5; }
+   }
+   else if (p->seqtype == 0) {
+      if ((p->model == K80 || p->model == HKY85) && !p->fix_kappa) x[k++] = p->kappa0;
+      else if (p->model == TN93 && !p->fix_kappa) { x[k++] = p->kappa0; x[k++] = p->kappa0; }
+      else if (p->model == REV) { for (i = 0; i < 5; i++) x[k++] = 1; }
+   }
+   if (!p->fix_alpha) x[k++] = p->alpha0 > 0 ? p->alpha0 : 0.5;
+   return k;
+}
+
+int pamlh_read_inx(const pamlh *p, double *x, int cap)
+{
+   char path[1200];
+   FILE *f;
+   int k = 0;
+   double v;
+   snprintf(path, sizeof(path), "%s/%s", p->dir, p->is_codeml ? "in.codeml" : "in.baseml");
+   if (!(f = fopen(path, "r"))) return 0;
+   if (fscanf(f, "%lf", &v) == 1) {
+      if (v != -1 && k < cap) x[k++] = v;    /* a leading -1 = "evaluate at exactly these values" (treesub.c:4057) */
+      while (k < cap && fscanf(f, "%lf", &v) == 1) x[k++] = v;
+   }
+   fclose(f);
+   return k;
+}
+
+static void set_eig_uvroot(pamlh *p, int i, const double *Q, const double *pi, double scale)
+{
+   const int n = p->n;
+   int k;
+   pamlh_eig *e = &p->eig[i];
+   if (!e->U) { e->U = (double *)malloc((size_t)n * n * 8); e->V = (double *)malloc((size_t)n * n * 8); e->Root = (double *)malloc(n * 8); }
+   e->kind = PAML_AMD_EIGEN_UVROOT;
+   pamlh_eigen_qrev(Q, pi, n, e->Root, e->U, e->V);
+   for (k = 0; k < n; k++) e->Root[k] /= scale;
+}
+
+/* codon Q for (kappa, omega) and its mean rate (eigenQcodon codeml.c:3274-3315) */
+static double codon_q(const pamlh *p, double kappa, double omega, double *Q)
+{
+   int from61[61], i, j, k, n = 61, m = 0;
+   double mr = 0;
+   const double *pi = p->pi;
+   for (k = 0; k < 64; k++) if (STDCODE[k] != '*') from61[m++] = k;
+   memset(Q, 0, (size_t)n * n * sizeof(double));
+   for (i = 1; i < n; i++)
+      for (j = 0; j < i; j++) {
+         const int c1 = from61[i], c2 = from61[j];
+         const int f[3] = {c1 / 16, (c1 / 4) % 4, c1 % 4}, t[3] = {c2 / 16, (c2 / 4) % 4, c2 % 4};
+         int nd = 0, pos = 0;
+         double q = 1;
+         for (k = 0; k < 3; k++) if (f[k] != t[k]) { nd++; pos = k; }
+         if (nd != 1) continue;
+         if (f[pos] + t[pos] == 1 || f[pos] + t[pos] == 5) q = kappa;
+         if (STDCODE[c1] != STDCODE[c2]) q *= omega;
+         Q[i * n + j] = Q[j * n + i] = q;
+      }
+   for (i = 0; i < n; i++) for (j = 0; j < n; j++) Q[i * n + j] *= pi[j];
+   for (i = 0; i < n; i++) { double s = 0; for (j = 0; j < n; j++) if (j != i) s += Q[i * n + j]; Q[i * n + i] = -s; mr += pi[i] * s; }
+   return mr;
+}
+
+int pamlh_set_x(pamlh *p, const double *x, int np)
+{
+   const int n = p->n;
+   int k = 0, i, j;
+   double *Q = (double *)malloc((size_t)n * n * sizeof(double));
+   if (np != p->np) { free(Q); return pamlh_fail(p, "expected %d parameters, got %d", p->np, np); }
+   /* branch lengths: x[0..ntime) in tree.branches order, or the tree file's when fix_blength = 2 (SetBranch treesub.c:3770) */
+   for (i = 0; i < p->nnode; i++) p->branch[i] = 0;
+   for (i = 0; i < p->nbranch; i++) {
+      const int node = p->branch_node[i];
+      p->branch[node] = p->ntime ? x[k++] : p->tree_branch[node];
+      if (!p->ntime && p->tree_branch[node] < 0) { free(Q); return pamlh_fail(p, "fix_blength = 2 but the tree has no branch lengths"); }
+   }
+   p->n_labels = 1; p->K = 1; p->mode = PAML_AMD_MODE_LFUN; p->n_eigen = 1;
+   p->freqK[0] = 1; p->rate[0] = 1; p->eigen_of[0] = 0;
+   if (p->seqtype == 1) {
+      double kappa = p->fix_kappa ? p->kappa0 : x[k++];
+      memcpy(p->pi, p->pi_data, 61 * sizeof(double));
+      p->kappa = kappa;
+      if (p->nssites == 0) {
+         double w = p->fix_omega ? p->omega0 : x[k++], mr = codon_q(p, kappa, w, Q);
+         p->omega = w;
+         set_eig_uvroot(p, 0, Q, p->pi, mr);
+      }
+      else {
+         double w[16], f[16], mr, wmean = 0;
+         int K;
+         if (p->nssites == 1) { f[0] = x[k]; w[0] = x[k + 1]; f[1] = 1 - f[0]; w[1] = 1; K = 2; k += 2; }
+         else if (p->nssites == 2) { f[0] = x[k]; f[1] = x[k + 1]; f[2] = 1 - f[0] - f[1]; w[0] = x[k + 2]; w[1] = 1; w[2] = x[k + 3]; K = 3; k += 4; }
+         else {   /* M7 / M8: K = ncatG median quantiles of beta(p, q) (DiscreteNSsites codeml.c:2869-2874) */
+            const int off = p->nssites == 8;
+            const double bp = x[k + off], bq = x[k + off + 1];
+            K = p->ncatG;
+            if (K + off > 15) { free(Q); return pamlh_fail(p, "ncatG too large"); }
+            for (j = 0; j < K; j++) { w[j] = pamlh_quantile_beta((j * 2. + 1) / (2. * K), bp, bq); f[j] = 1.0 / K; }
+            if (off) {
+               const double p0 = x[k];
+               for (j = 0; j < K; j++) f[j] *= p0;
+               f[K] = 1 - p0;
+               w[K] = p->fix_omega ? p->omega0 : x[k + 3];
+               k += 3 + !p->fix_omega;
+               K++;
+            }
+            else k += 2;
+         }
+         /* Qfactor_NS = 1 / mr(Q at the mean omega) (codeml.c:2586-2605); class ir: Root /= 1/Qfactor_NS (treesub.c:7675-7685) */
+         for (j = 0; j < K; j++) wmean += f[j] * w[j];
+         mr = codon_q(p, kappa, wmean, Q);
+         for (j = 0; j < K; j++) {
+            codon_q(p, kappa, w[j], Q);
+            set_eig_uvroot(p, j, Q, p->pi, mr);
+            p->freqK[j] = f[j]; p->rate[j] = 1; p->eigen_of[j] = j;
+         }
+         p->K = K; p->n_eigen = K; p->mode = PAML_AMD_MODE_LFUNDG;
+      }
+   }
+   else if (p->seqtype == 2) {
+      double mr = 0;
+      if (p->aa_model == 0) {
+         for (i = 0; i < 20; i++) p->pi[i] = 1.0 / 20;
+         p->eig[0].kind = PAML_AMD_EIGEN_JC69LIKE;
+      }
+      else {
+         memcpy(p->pi, p->aa_model == 2 ? p->aapi_file : p->pi_data, 20 * sizeof(double));   /* model 2: file pi, used as read */
+         for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) Q[i * 20 + j] = (i == j) ? 0 : p->aaS[i * 20 + j] * p->pi[j];
+         for (i = 0; i < 20; i++) { double s = 0; for (j = 0; j < 20; j++) s += Q[i * 20 + j]; Q[i * 20 + i] = -s; mr += p->pi[i] * s; }
+         set_eig_uvroot(p, 0, Q, p->pi, mr);
+      }
+   }
+   else {
+      const int m = p->model;
+      double S[16], mr = 0;
+      for (i = 0; i < 16; i++) S[i] = 1;
+      if (m == JC69 || m == K80) for (i = 0; i < 4; i++) p->pi[i] = 0.25;
+      else memcpy(p->pi, p->pi_data, 4 * sizeof(double));
+      if (m == JC69 || m == K80) {
+         p->eig[0].kind = PAML_AMD_EIGEN_K80;
+         p->eig[0].kappa = m == JC69 ? 1 : (p->fix_kappa ? p->kappa0 : x[k++]);
+      }
+      else {
+         if (m == HKY85) { double kp = p->fix_kappa ? p->kappa0 : x[k++]; S[0 * 4 + 1] = S[1 * 4 + 0] = S[2 * 4 + 3] = S[3 * 4 + 2] = kp; }
+         else if (m == TN93) {
+            double k1 = p->fix_kappa ? p->kappa0 : x[k], k2 = p->fix_kappa ? p->kappa0 : x[k + 1];
+            if (!p->fix_kappa) k += 2;
+            S[0 * 4 + 1] = S[1 * 4 + 0] = k1; S[2 * 4 + 3] = S[3 * 4 + 2] = k2;
+         }
+         else if (m == REV) {   /* TC, TA, TG, CA, CG relative to AG = 1 (treesub.c:2499-2505) */
+            S[0 * 4 + 1] = S[1 * 4 + 0] = x[k]; S[0 * 4 + 2] = S[2 * 4 + 0] = x[k + 1]; S[0 * 4 + 3] = S[3 * 4 + 0] = x[k + 2];
+            S[1 * 4 + 2] = S[2 * 4 + 1] = x[k + 3]; S[1 * 4 + 3] = S[3 * 4 + 1] = x[k + 4];
+            k += 5;
+         }
+         for (i = 0; i < 4; i++) for (j = 0; j < 4; j++) Q[i * 4 + j] = (i == j) ? 0 : S[i * 4 + j] * p->pi[j];
+         for (i = 0; i < 4; i++) { double s = 0; for (j = 0; j < 4; j++) s += Q[i * 4 + j]; Q[i * 4 + i] = -s; mr += p->pi[i] * s; }
+         set_eig_uvroot(p, 0, Q, p->pi, mr);
+         {  /* baseml's P(t) goes through Cijk (PMatCijk baseml.c:1572): fold U, V into Cijk[i][j][k], nR = 4 */
+            pamlh_eig *e = &p->eig[0];
+            int kk;
+            if (!e->Cijk) e->Cijk = (double *)malloc(64 * sizeof(double));
+            for (i = 0; i < 4; i++) for (j = 0; j < 4; j++) for (kk = 0; kk < 4; kk++) e->Cijk[i * 16 + j * 4 + kk] = e->U[i * 4 + kk] * e->V[kk * 4 + j];
+            e->kind = PAML_AMD_EIGEN_CIJK; e->nR = 4;
+         }
+      }
+   }
+   /* gamma rates for sites (not with NSsites): alpha fixed > 0 or free */
+   if (!(p->seqtype == 1 && p->nssites)) {
+      double alpha = p->fix_alpha ? p->alpha0 : x[k++];
+      p->alpha = alpha;
+      if (alpha > 0) {
+         if (p->ncatG > 60) { free(Q); return pamlh_fail(p, "ncatG too large"); }
+         pamlh_discrete_gamma(p->freqK, p->rate, alpha, p->ncatG);
+         p->K = p->ncatG; p->mode = PAML_AMD_MODE_LFUNDG;
+         for (j = 0; j < p->K; j++) p->eigen_of[j] = 0;
+      }
+   }
+   free(Q);
+   if (k != np) return pamlh_fail(p, "internal: consumed %d of %d parameters", k, np);
+   return 0;
+}
+
+int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
+{
+   int i, rc;
+   if (!p->eng) {
+      if ((rc = paml_amd_create(&p->eng, p->n, p->ns, p->npatt, 64, 1, 0))) return pamlh_fail(p, "paml_amd_create failed (%d): no GPU?", rc);
+      if ((rc = paml_amd_set_tips(p->eng, p->z, p->cleandata, p->n_codes, p->n_chara, p->chara_map, p->w, NULL)) ||
+          (rc = paml_amd_set_tree(p->eng, p->nnode, p->root, p->sons_ptr, p->sons, p->label, p->scale)))
+         return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   }
+   if ((rc = paml_amd_set_pi(p->eng, 1, p->pi))) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   for (i = 0; i < p->n_eigen; i++) {
+      const pamlh_eig *e = &p->eig[i];
+      if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, i, e->U, e->V, e->Root);
+      else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(p->eng, i, e->nR, e->Cijk, e->Root);
+      else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(p->eng, i, e->kappa);
+      else rc = paml_amd_set_eigen_jc69like(p->eng, i);
+      if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   }
+   if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, 1, p->eigen_of, NULL)) ||
+       (rc = paml_amd_eval(p->eng, p->branch, NULL, lnL, lnf, NULL)))
+      return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   return 0;
+}
+
+int pamlh_write_lnf(const pamlh *p, const char *path, const double *lnf)
+{
+   FILE *f = fopen(path, "w");
+   int h, j;
+   if (!f) return -1;
+   fprintf(f, "%6d %6d %6d\n\n\n%2d\n\n", 1, p->ls, p->npatt, 1);
+   for (h = 0; h < p->npatt; h++) {
+      fprintf(f, "%6d %6.0f %16.10f %16.12f %12.4f  ", h + 1, p->w[h], lnf[h], exp(lnf[h]), p->ls * exp(lnf[h]));
+      for (j = 0; j < p->ns; j++) {
+         fwrite(p->raw + ((size_t)j * p->npatt + h) * p->n31, 1, p->n31, f);
+         if (p->n31 == 3) fputc(' ', f);
+      }
+      fputc('\n', f);
+   }
+   fclose(f);
+   return 0;
+}

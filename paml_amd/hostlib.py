@@ -1,0 +1,143 @@
+"""ctypes binding of libpamlh.so (include/pamlh.h): the C host that reads .ctl / sequence / tree files and turns a
+parameter vector into engine inputs.  `load(ctl, program).problem(x)` returns the same plain-array Problem the tests
+and the engine binding use, so the C host can be checked against the golden vectors on CPU (through the oracle, in the
+tests) and on the GPU (through the engine)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .problem import EIGEN_CIJK, EIGEN_JC69LIKE, EIGEN_K80, EIGEN_UVROOT, Problem, Tree
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpamlh.so")
+DRIVER_PATH = os.path.join(_HERE, "lib", "pamlh_lnl")
+
+
+def build(force=False):
+    from . import engine
+    engine.build()
+    srcs = [os.path.join(_HERE, "host", f) for f in ("pamlh_num.c", "pamlh_io.c", "pamlh_model.c", "pamlh_lnl.c", "pamlh_internal.h", "Makefile")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "pamlh.h"))
+    if force or not (os.path.exists(LIB_PATH) and os.path.exists(DRIVER_PATH)) or \
+            any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "host"), "-B"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_L = None
+
+
+def lib():
+    global _L
+    if _L is None:
+        C.CDLL(os.path.join(_HERE, "lib", "libpaml_amd.so"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(build())
+        for name, rt in [("pamlh_tips", C.c_void_p), ("pamlh_weights", C.c_void_p), ("pamlh_n_chara", C.c_void_p),
+                         ("pamlh_chara_map", C.c_void_p), ("pamlh_sons_ptr", C.c_void_p), ("pamlh_sons", C.c_void_p),
+                         ("pamlh_labels", C.c_void_p), ("pamlh_scale_nodes", C.c_void_p), ("pamlh_branch_order", C.c_void_p),
+                         ("pamlh_branch", C.c_void_p), ("pamlh_pi", C.c_void_p), ("pamlh_freqK", C.c_void_p),
+                         ("pamlh_rate", C.c_void_p), ("pamlh_eigen_of", C.c_void_p), ("pamlh_error", C.c_char_p)]:
+            getattr(L, name).restype = rt
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.pamlh_load.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.pamlh_free.argtypes = [C.c_void_p]
+        L.pamlh_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 10
+        L.pamlh_default_x.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.pamlh_read_inx.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.pamlh_set_x.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.pamlh_model.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        L.pamlh_eigen.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)] + [C.POINTER(C.c_void_p)] * 4
+        L.pamlh_eval_gpu.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
+        _L = L
+    return _L
+
+
+def _arr(ptr, dtype, n):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(n,)).copy()
+
+
+class Analysis:
+    def __init__(self, ctl_path, program="codeml"):
+        L = lib()
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        if L.pamlh_load(C.byref(h), os.fsencode(ctl_path), program.encode(), err, 512) != 0:
+            raise RuntimeError("pamlh_load: " + err.value.decode())
+        self._h, self._L = h, L
+        d = [C.c_int() for _ in range(10)]
+        L.pamlh_dims(h, *[C.byref(v) for v in d])
+        (self.n, self.n_tips, self.n_patt, self.n_nodes, self.root, self.n_codes, self.cleandata, self.ls, self.np,
+         self.ntime) = [v.value for v in d]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pamlh_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def default_x(self):
+        x = np.zeros(max(1, self.np))
+        k = self._L.pamlh_default_x(self._h, x.ctypes.data_as(C.c_void_p), len(x))
+        return x[:k]
+
+    def read_inx(self):
+        x = np.zeros(4096)
+        k = self._L.pamlh_read_inx(self._h, x.ctypes.data_as(C.c_void_p), len(x))
+        return x[:k]
+
+    def set_x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if self._L.pamlh_set_x(self._h, x.ctypes.data_as(C.c_void_p), len(x)) != 0:
+            raise RuntimeError("pamlh_set_x: " + self._L.pamlh_error(self._h).decode())
+
+    def problem(self, x) -> Problem:
+        """SetParameters(x) in the C host, then everything as plain arrays."""
+        self.set_x(x)
+        L, h = self._L, self._h
+        n, nn = self.n, self.n_nodes
+        m = [C.c_int() for _ in range(4)]
+        L.pamlh_model(h, *[C.byref(v) for v in m])
+        mode, K, n_eigen, n_labels = [v.value for v in m]
+        ptr = _arr(L.pamlh_sons_ptr(h), np.int32, nn + 1)
+        sons_flat = _arr(L.pamlh_sons(h), np.int32, int(ptr[-1]))
+        sons = [list(sons_flat[ptr[i]:ptr[i + 1]]) for i in range(nn)]
+        tree = Tree(self.n_tips, nn, self.root, sons, _arr(L.pamlh_branch(h), np.float64, nn), _arr(L.pamlh_labels(h), np.int32, nn))
+        eig = []
+        for i in range(n_eigen):
+            kind, nR, kappa = C.c_int(), C.c_int(), C.c_double()
+            ps = [C.c_void_p() for _ in range(4)]
+            L.pamlh_eigen(h, i, C.byref(kind), C.byref(nR), C.byref(kappa), *[C.byref(v) for v in ps])
+            e = dict(kind=kind.value)
+            if kind.value == EIGEN_UVROOT:
+                e.update(U=_arr(ps[0].value, np.float64, n * n).reshape(n, n), V=_arr(ps[1].value, np.float64, n * n).reshape(n, n),
+                         Root=_arr(ps[2].value, np.float64, n))
+            elif kind.value == EIGEN_CIJK:
+                e.update(nR=nR.value, Cijk=_arr(ps[3].value, np.float64, n * n * nR.value), Root=_arr(ps[2].value, np.float64, nR.value))
+            elif kind.value == EIGEN_K80:
+                e.update(kappa=kappa.value)
+            eig.append(e)
+        scale = _arr(L.pamlh_scale_nodes(h), np.uint8, nn)
+        return Problem(n=n, tree=tree, z=_arr(L.pamlh_tips(h), np.uint8, self.n_tips * self.n_patt).reshape(self.n_tips, self.n_patt),
+                       weights=_arr(L.pamlh_weights(h), np.float64, self.n_patt), pi=_arr(L.pamlh_pi(h), np.float64, n), eigen=eig,
+                       mode=mode, freqK=_arr(L.pamlh_freqK(h), np.float64, K), rate=_arr(L.pamlh_rate(h), np.float64, K),
+                       eigen_of=_arr(L.pamlh_eigen_of(h), np.int32, K * n_labels).reshape(1, K, n_labels), cleandata=self.cleandata,
+                       n_chara=_arr(L.pamlh_n_chara(h), np.int32, self.n_codes),
+                       chara_map=_arr(L.pamlh_chara_map(h), np.uint8, self.n_codes * n).reshape(self.n_codes, n),
+                       scale_node=scale if scale.any() else None)
+
+    def eval_gpu(self, x, want_lnf=True):
+        self.set_x(x)
+        lnl = C.c_double()
+        lnf = np.zeros(self.n_patt) if want_lnf else None
+        if self._L.pamlh_eval_gpu(self._h, C.byref(lnl), None if lnf is None else lnf.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("pamlh_eval_gpu: " + self._L.pamlh_error(self._h).decode())
+        return lnl.value, lnf

@@ -1,0 +1,91 @@
+"""The C host (paml_amd/host -> libpamlh.so, pamlh_lnl) reads the reference's own example files — control file,
+PHYLIP sequences, Newick tree, dat/lg.dat — and must reproduce the reference's single-evaluation lnL and per-pattern
+lnf (same pattern order as the reference's `lnf` file).  CPU: C host + oracle.  GPU: C host + engine, and the
+pamlh_lnl driver end to end."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+import oracle
+from paml_amd import hostlib
+
+CTL = os.path.join(helpers.GOLDEN, "ctl")
+CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml", "stewart_lg_g4.ctl"),
+         ("hiv_m0", "codeml", "hiv_ns0.ctl"), ("hiv_m1a", "codeml", "hiv_ns1.ctl"), ("hiv_m2a", "codeml", "hiv_ns2.ctl"),
+         ("hiv_m7", "codeml", "hiv_ns7.ctl"), ("hiv_m8", "codeml", "hiv_ns8.ctl"), ("mhc_m0_scaled", "codeml", "mhc_m0.ctl")]
+
+
+def _x(g, a):
+    return np.array(g.get("x", []), dtype=float) if a.np else np.zeros(0)
+
+
+@pytest.mark.parametrize("gname,prog,ctl", CASES)
+def test_c_host_reproduces_reference_on_cpu(gname, prog, ctl):
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), prog)
+    assert (a.n_patt, a.ls, a.n_tips) == (g["n_patt"], g["ls"], g["n_tips"])
+    if "x" in g and a.np:
+        assert a.np == len(g["x"]) and a.ntime == g.get("ntime", a.ntime)
+    pb = a.problem(_x(g, a))
+    assert np.array_equal(pb.weights, np.array(g["counts"]))          # same patterns, same order, same counts
+    r = oracle.evaluate(pb)
+    assert abs(r["lnL"] - g["lnL"]) <= 2e-6
+    assert np.max(np.abs(r["lnf"] - np.array(g["logf"]))) < 5e-8
+    if g.get("scale_nodes"):
+        assert sorted(np.nonzero(pb.scale_node)[0] + 1) == sorted(g["scale_nodes"])   # SetNodeScale picks the same nodes
+    if g.get("published_lnL") is not None:
+        assert abs(r["lnL"] - g["published_lnL"]) < 5e-6
+
+
+def test_c_host_rejects_what_it_does_not_support(tmp_path):
+    ctl = tmp_path / "x.ctl"
+    ctl.write_text("seqfile = %s\ntreefile = %s\nseqtype = 1\nmodel = 2\nNSsites = 2\n" %
+                   (os.path.join(helpers.GOLDEN, "data", "HIVenvSweden.txt"), os.path.join(helpers.GOLDEN, "data", "HIVenvSweden.trees")))
+    with pytest.raises(RuntimeError, match="not supported"):
+        hostlib.Analysis(str(ctl), "codeml")
+
+
+def test_numerics_against_scipy():
+    """discrete gamma / beta classes of the C host vs scipy (independent implementation)."""
+    from paml_amd import models
+    a = hostlib.Analysis(os.path.join(CTL, "hiv_ns7.ctl"), "codeml")
+    g = helpers.load_golden("hiv_m7")
+    pb = a.problem(np.array(g["x"]))
+    f, w = helpers.nssites_classes(7, g["x"][g["ntime"] + 1:], 10)
+    ref = helpers.problem_from_golden(g)
+    for ic in (0, 3, 9):                      # same class-specific P(t) as the numpy/scipy model layer
+        P1 = oracle.pmat_branch(pb, 0, ic, 3)
+        P2 = oracle.pmat_branch(ref, 0, ic, 3)
+        assert np.max(np.abs(P1 - P2)) < 1e-12
+    a2 = hostlib.Analysis(os.path.join(CTL, "stewart_lg_g4.ctl"), "codeml")
+    pb2 = a2.problem(np.array(helpers.load_golden("stewart_lg_g4")["x"]))
+    fk, rk = models.discrete_gamma(1.064411, 4)
+    assert np.allclose(pb2.rate, rk, rtol=1e-12) and np.allclose(pb2.freqK, fk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname,prog,ctl", CASES)
+def test_c_host_on_gpu(gname, prog, ctl):
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), prog)
+    lnl, lnf = a.eval_gpu(_x(g, a))
+    assert abs(lnl - g["lnL"]) <= 2e-6
+    assert np.max(np.abs(lnf - np.array(g["logf"]))) < 5e-8
+
+
+@pytest.mark.gpu
+def test_driver_binary_end_to_end(tmp_path):
+    """pamlh_lnl <program> <ctl> x...: prints lnL like the reference and writes an `lnf` file in its layout."""
+    g = helpers.load_golden("hiv_m2a")
+    out = subprocess.run([hostlib.DRIVER_PATH, "codeml", os.path.join(CTL, "hiv_ns2.ctl")] + ["%.6f" % v for v in g["x"]],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lnl = float(out.stdout.split("lnL  =")[1].split()[0])
+    assert abs(lnl - g["lnL"]) <= 2e-6
+    rows = [ln.split() for ln in open(tmp_path / "lnf") if len(ln.split()) > 5]
+    assert len(rows) == g["n_patt"]
+    assert np.max(np.abs(np.array([float(r[2]) for r in rows]) - np.array(g["logf"]))) < 5e-8
+    assert [int(float(r[1])) for r in rows] == [int(c) for c in g["counts"]]
