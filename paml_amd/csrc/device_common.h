@@ -310,30 +310,53 @@ __device__ __forceinline__ void jit_root(const PruneArgs &a, const v4d (&x)[4], 
    }
 }
 
-// Prologue of a specialised kernel: 8 waves x 16 patterns, ring of four 32 KB operand buffers, tip codes in LDS.
+// Skeleton of a specialised kernel: 8 waves x 16 patterns per tile, ring of four 32 KB operand buffers, tip codes in
+// LDS.  The kernel is persistent: each workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and issues the
+// next tile's first operand blocks and tip-code loads before it finishes the current tile's root stage.
 #define JIT_PROLOGUE(NTIPS)                                                                                      \
    __shared__ __attribute__((aligned(16))) double ring[4 * 4096];                                               \
    __shared__ unsigned char sZ[(NTIPS)*128];                                                                     \
    const int tid = threadIdx.x, lane = tid & 63;                                                                \
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                   \
    const int q = lane >> 4, hl = lane & 15;                                                                     \
-   const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;                                    \
-   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;                                  \
-   const int hend = as_const(a.gene_off)[gene + 1];                                                             \
    const int hw = wave * 16 + hl;                                                                               \
-   const int h = h0 + hw;                                                                                       \
-   const bool valid = h < hend;                                                                                 \
-   const long pset = (long)gene * a.K + iclass;                                                                 \
-   const double *Pint = a.pint + pset * a.n_nodes * 4096;                                                       \
-   const double *Ptip = a.ptip + pset * a.n_nodes * 4096;                                                       \
    const int n = a.n;                                                                                           \
+   const int total_work = a.n_tiles * a.K;                                                                      \
+   int work = blockIdx.x;                                                                                       \
+   int tile, iclass, gene, h0, hend, h;                                                                         \
+   int n_gene = 0, n_iclass = 0, n_h0 = 0, n_hend = 1;   /* the tile this workgroup handles next */             \
+   bool valid, has_next = false;                                                                                \
+   const double *Pint, *Ptip, *nPint = nullptr, *nPtip = nullptr;                                               \
    double lnscale = 0;                                                                                          \
-   (void)hl; (void)n; (void)lnscale;
-#define JIT_STAGE_Z(NTIPS)                                                                                       \
-   for (int idx = tid; idx < (NTIPS)*128; idx += 512) {                                                          \
-      const int tip = idx >> 7, hh = idx & 127;                                                                 \
-      const int hx = h0 + hh < hend ? h0 + hh : hend - 1;                                                       \
-      sZ[idx] = a.z[(long)tip * a.z_stride + hx];                                                               \
+   unsigned char zr[((NTIPS)*128 + 511) / 512];                                                                  \
+   (void)hl; (void)n; (void)lnscale;                                                                            \
+   if (work >= total_work) return;
+/* look up the tile `work` as the NEXT tile (variables n_*), without touching the current one */
+#define JIT_NEXT_SET()                                                                                           \
+   has_next = work < total_work;                                                                                \
+   if (has_next) {                                                                                              \
+      tile = work % a.n_tiles; n_iclass = work / a.n_tiles;                                                     \
+      n_gene = as_const(a.tiles)[tile].x; n_h0 = as_const(a.tiles)[tile].y;                                     \
+      n_hend = as_const(a.gene_off)[n_gene + 1];                                                                \
+      nPint = a.pint + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 4096;                                      \
+      nPtip = a.ptip + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 4096;                                      \
+   }   /* without a next tile n_h0 / n_hend keep their last (valid) values: JIT_ZLOAD stays in bounds */
+/* make the next tile the current one */
+#define JIT_ADVANCE()                                                                                            \
+   iclass = n_iclass; gene = n_gene; h0 = n_h0; hend = n_hend; Pint = nPint; Ptip = nPtip;                      \
+   h = h0 + hw; valid = h < hend; lnscale = 0;
+#define JIT_ZLOAD(NTIPS)                                                                                         \
+   _Pragma("unroll") for (int kz = 0; kz < ((NTIPS)*128 + 511) / 512; kz++) {                                    \
+      const int idx = tid + kz * 512, tip = idx >> 7, hh = idx & 127;                                           \
+      const int hx = n_h0 + hh < n_hend ? n_h0 + hh : n_hend - 1;                                               \
+      zr[kz] = tip < (NTIPS) ? a.z[(long)tip * a.z_stride + hx] : (unsigned char)0;                             \
+   }
+#define JIT_ISSUE_NP(J, NODE) stage_p<8>(nPint + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)
+#define JIT_ISSUE_NT(J, NODE) stage_p<8>(nPtip + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)
+#define JIT_ZSTORE(NTIPS)                                                                                        \
+   _Pragma("unroll") for (int kz = 0; kz < ((NTIPS)*128 + 511) / 512; kz++) {                                    \
+      const int idx = tid + kz * 512;                                                                           \
+      if (idx < (NTIPS)*128) sZ[idx] = zr[kz];                                                                   \
    }                                                                                                            \
    __syncthreads();
 #define JIT_ISSUE_P(J, NODE) stage_p<8>(Pint + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)

@@ -414,7 +414,14 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    case KK_MFMA64:
       if (e->use_jit) {
          void *params[] = {&pr};
-         HIPCHK(hipModuleLaunchKernel(e->jit.fn, n_blocks, 1, 1, 512, 1, 1, 0, e->stream, params, nullptr));
+         static int n_cu = 0;
+         if (!n_cu) {
+            int dev = 0;
+            HIPCHK(hipGetDevice(&dev));
+            HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+         }
+         const int grid = std::min(n_blocks, n_cu);     // persistent: one 130 KB-LDS workgroup per CU walks the tiles
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, grid, 1, 1, 512, 1, 1, 0, e->stream, params, nullptr));
       }
       else if (use_dma) {
          const size_t lds = (size_t)4 * 4096 * sizeof(double) + (size_t)e->n_tips * 128;

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <sstream>
@@ -62,8 +63,23 @@ inline std::string jit_generate(const Program &p, int n_tips)
       s << "   " << (is_tip ? "JIT_ISSUE_T(" : "JIT_ISSUE_P(") << issued << ", " << node << ");\n";
       issued++;
    };
-   for (int i = 0; i < 3 && issued < nblk; i++) issue();
-   s << "   JIT_STAGE_Z(" << n_tips << ")\n";
+   // what starts a tile: tile variables, first operand blocks, tip codes into registers
+   const int n_first = std::min(3, nblk);
+   auto emit_first_blocks = [&](std::ostringstream &o) {      // the next tile's first operand blocks
+      for (int i = 0; i < n_first; i++) {
+         const int is_tip = p.stream[2 * i], node = p.stream[2 * i + 1];
+         o << "      " << (is_tip ? "JIT_ISSUE_NT(" : "JIT_ISSUE_NP(") << i << ", " << node << ");\n";
+      }
+   };
+   s << "   JIT_NEXT_SET()\n   {\n";
+   emit_first_blocks(s);
+   s << "   }\n   JIT_ZLOAD(" << n_tips << ")\n";
+   issued = n_first;
+   s << "   for (;;) {\n";
+   s << "   JIT_ADVANCE()\n   JIT_ZSTORE(" << n_tips << ")\n";
+   int last_mm = -1;
+   for (size_t i = 0; i < p.ops.size(); i++)
+      if (p.ops[i].code == OP_MATMUL || p.ops[i].code == OP_MATMUL_POP) last_mm = (int)i;
 
    // register arrays: a free list; `cur` names the array holding the partial under construction
    const int NA = p.max_stack + 2;
@@ -75,13 +91,18 @@ inline std::string jit_generate(const Program &p, int n_tips)
    std::vector<int> slot(256, -1);   // stack slot -> array
    int cur = -1;
    int consumed = 0;
+   const int ZR = (n_tips * 128 + 511) / 512;     // tip-code loads per thread (JIT_ZLOAD)
+   int extra_loads = 0;                           // ordinary loads issued after the newest DMA that may stay in flight
    auto step = [&](int c) {   // make the next c blocks visible, then top the ring up
-      s << "   JIT_WAIT(" << 4 * (issued - (consumed + c)) << "); " << (getenv("PAML_AMD_JIT_NOBAR") ? "" : "__syncthreads();") << "\n";
+      s << "   JIT_WAIT(" << 4 * (issued - (consumed + c)) + extra_loads << "); " << (getenv("PAML_AMD_JIT_NOBAR") ? "" : "__syncthreads();") << "\n";
       while (issued < consumed + 4 && issued < nblk) issue();
    };
    auto name = [&](int r) { return "A" + std::to_string(r); };
 
-   for (const Op &o : p.ops) {
+   for (size_t iop = 0; iop < p.ops.size(); iop++) {
+      const Op &o = p.ops[iop];
+      if ((int)iop == last_mm)     // the next tile's tip codes travel to registers under this tile's last MFMAs
+         s << "   work += gridDim.x;\n   JIT_NEXT_SET()\n   JIT_ZLOAD(" << n_tips << ")\n";   // unconditional: static load counts
       switch (o.code) {
       case OP_INIT_ONES:
          if (cur < 0) cur = alloc();
@@ -118,7 +139,9 @@ inline std::string jit_generate(const Program &p, int n_tips)
       case OP_MATMUL_POP: {
          const int pop = mm_pop_slot(o), push = mm_push_slot(o);
          const int out = alloc();
+         if ((int)iop == last_mm) extra_loads = ZR;    // the next tile's tip-code loads were just issued
          step(1);
+         extra_loads = 0;
          s << "   jit_matvec(JIT_BUF(" << consumed << "), lane, " << name(cur) << ", " << name(out) << ");\n";
          consumed += 1;
          release(cur);
@@ -133,6 +156,11 @@ inline std::string jit_generate(const Program &p, int n_tips)
          }
          else
             cur = out;
+         if ((int)iop == last_mm) {   // ring is free once every wave has finished this last block
+            s << "   if (has_next) {\n      __syncthreads();\n";
+            emit_first_blocks(s);
+            s << "   }\n";
+         }
       } break;
       case OP_SCALE:
          s << "   { const double fac = jit_scale(" << name(cur) << ", q, n); lnscale += fac;\n"
@@ -140,11 +168,16 @@ inline std::string jit_generate(const Program &p, int n_tips)
          break;
       case OP_ROOT:
          s << "   jit_root(a, " << name(cur) << ", lnscale, gene, iclass, q, h, valid);\n";
+         release(cur);
+         cur = -1;
          break;
       default: break;
       }
    }
-   s << "}\n";
+   // next tile of this persistent workgroup: make sure every wave is done with the ring and the tip codes, then
+   // start its operand stream and tip-code loads before looping
+   if (last_mm < 0) s << "   work += gridDim.x;\n   JIT_NEXT_SET()\n   JIT_ZLOAD(" << n_tips << ")\n";
+   s << "   if (!has_next) break;\n   }\n}\n";
    return s.str();
 }
 
