@@ -162,6 +162,10 @@ __device__ __forceinline__ void mfma_matvec(const double *sPbuf, int lane, const
 }
 
 
+// XOR swizzle of the eight 16-byte pieces of a tip-table row (row = code * 4 + state quarter): lanes of one
+// ds_read_b128 group read rows of 16 different patterns, i.e. random codes; mixing the code's low and middle bits into
+// the slot spreads them over all 8 slots of their bank half instead of 4.
+#define TIP_SWZ(row) ((((row) >> 2) ^ ((row) >> 5)) & 7)
 struct StreamBlk { int is_tip, node; };
 
 __device__ __forceinline__ void wait_blocks_in_flight(int n)   // allow the n newest blocks (4 loads each) to fly
@@ -179,7 +183,7 @@ __device__ __forceinline__ void tip_lds(const double *tab, int code, int q, int 
    for (int p = 0; p < 8; p++) v[p] = make_double2(0.5 + code * 1e-3, 0.25 + q * 1e-3);
    return;
 #endif
-   const int row = code * 4 + q, swz = (row >> 1) & 7;
+   const int row = code * 4 + q, swz = TIP_SWZ(row);
    const char *base = (const char *)tab + row * 128;
 #pragma unroll
    for (int p = 0; p < 8; p++) v[p] = *(const double2 *)(base + ((p ^ swz) * 16));

@@ -397,7 +397,6 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
    pr.first_tip = e->prog.first_tip;
    pr.stream = e->d_stream.p; pr.n_stream = (int)(e->prog.stream.size() / 2); pr.tip_words = (long)tip_words(e);
-#ifdef PROF_OPS
    static unsigned long long *d_prof = nullptr;
    const int prof_stride = (int)e->prog.ops.size() + 3;
    if (getenv("PAML_AMD_PROF_OPS")) {
@@ -408,7 +407,6 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       pr.prof_stride = prof_stride;
       pr.prof_tid = getenv("PAML_AMD_PROF_TID") ? atoi(getenv("PAML_AMD_PROF_TID")) : 0;
    }
-#endif
    mark(e);
    switch (e->kk) {
    case KK_MFMA64:
@@ -446,7 +444,6 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       break;
    }
    mark(e);
-#ifdef PROF_OPS
    if (pr.prof) {
       std::vector<unsigned long long> hp((size_t)3 * n_blocks * prof_stride);
       HIPCHK(hipMemcpyAsync(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost, e->stream));
@@ -462,7 +459,6 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          fclose(f);
       }
    }
-#endif
 
    // Kernel C: mixture + log + weighted sum
    const int chunk = std::max(256, ((e->n_patt + 1023) / 1024 + 255) / 256 * 256);

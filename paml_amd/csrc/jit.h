@@ -75,7 +75,7 @@ inline std::string jit_generate(const Program &p, int n_tips)
    emit_first_blocks(s);
    s << "   }\n   JIT_ZLOAD(" << n_tips << ")\n";
    issued = n_first;
-   s << "   for (;;) {\n";
+   s << "   int ptile = 1;\n   for (;; ptile = 0) {\n";
    s << "   JIT_ADVANCE()\n   JIT_ZSTORE(" << n_tips << ")\n";
    int last_mm = -1;
    for (size_t i = 0; i < p.ops.size(); i++)
@@ -99,8 +99,13 @@ inline std::string jit_generate(const Program &p, int n_tips)
    };
    auto name = [&](int r) { return "A" + std::to_string(r); };
 
+   const bool prof = getenv("PAML_AMD_PROF_OPS") != nullptr;    // kernel experiments: s_memtime stamp after every op
+   if (prof) s << "   if (a.prof && tid == a.prof_tid && ptile) a.prof[(long)blockIdx.x * a.prof_stride] = __builtin_amdgcn_s_memtime();\n";
    for (size_t iop = 0; iop < p.ops.size(); iop++) {
       const Op &o = p.ops[iop];
+      if (prof)
+         s << "   if (a.prof && tid == a.prof_tid && ptile) a.prof[(long)blockIdx.x * a.prof_stride + 1 + " << iop
+           << "] = __builtin_amdgcn_s_memtime();\n";
       if ((int)iop == last_mm)     // the next tile's tip codes travel to registers under this tile's last MFMAs
          s << "   work += gridDim.x;\n   JIT_NEXT_SET()\n   JIT_ZLOAD(" << n_tips << ")\n";   // unconditional: static load counts
       switch (o.code) {

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
             // row (code, q) = 128 bytes = 8 pieces of two states; piece p is stored in slot p ^ ((row >> 1) & 7) so
             // that lanes gathering different rows from an LDS copy of this table spread over the banks
             const int q = w >> 4, slot = (w & 15) >> 1, row = code * 4 + q;
-            const int m = ((slot ^ ((row >> 1) & 7)) << 1) | (w & 1);
+            const int m = ((slot ^ TIP_SWZ(row)) << 1) | (w & 1);
             jj = 4 * m + q;
          }
          else jj = w;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
 // Used for trees with more than MFMA_ZT tips; 4 waves (64 patterns) per workgroup, 2 workgroups per CU.
 __device__ __forceinline__ void tip_gather(const double *Ptip, long tipstride, int tip, int code, int q, double2 (&v)[8])
 {
-   const int row = code * 4 + q, swz = (row >> 1) & 7;
+   const int row = code * 4 + q, swz = TIP_SWZ(row);
    const double2 *pt = (const double2 *)(Ptip + (long)tip * tipstride + row * 16);
 #pragma unroll
    for (int i = 0; i < 8; i++) v[i] = pt[i ^ swz];     // piece i lives in slot i ^ swz (see pmat_kernel)

@@ -12,6 +12,9 @@ codes = np.frombuffer(raw[8:8 + 4 * nops], dtype=np.int32)
 tall = np.frombuffer(raw[8 + 4 * nops:], dtype=np.uint64).astype(np.int64)
 planes = tall.size // (nb * stride)
 tall = tall.reshape(planes, nb, stride)
+keep = tall[0][:, 1] != 0          # persistent kernels stamp only the first tile of each resident workgroup
+tall = tall[:, keep, :]
+nb = int(keep.sum())
 t = tall[0]
 kstart = t[:, stride - 1]
 pro = t[:, 0] - kstart                   # prologue (z staging + first P + barrier)
