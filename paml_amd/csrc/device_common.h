@@ -196,7 +196,11 @@ __device__ __forceinline__ void tip_lds(const double *tab, int code, int q, int 
 // the accumulator tuple of row block jb = m >> 2, so MFMA results are partials with no copies, and the
 // B operand of k-block kb is x[kb >> 2][kb & 3].
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4])
+// `side(kb2)` runs once per k-block pair between the two MFMA groups: the generator puts the ring's refill DMAs there
+// (a few per iteration) so that their issue — which can queue behind the other waves' — never delays the first MFMAs.
+struct JitNoSide { __device__ __forceinline__ void operator()(int) const {} };
+template <class SIDE = JitNoSide>
+__device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4], SIDE side = SIDE())
 {
    const double2 *sp = (const double2 *)sPbuf;
    double2 af[2][4];
@@ -219,9 +223,75 @@ __device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const 
 #pragma unroll
          for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
       }
+      side(kb2);
 #pragma unroll
       for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+   }
+}
+
+// jit_matvec with the next cherry's tip step folded in: y = P x as above, and t = tipA[ca] * tipB[cb] (the SET_TIP2 that
+// follows in the program) gathered from LDS under the second half of the MFMAs, where the matrix pipe hides the
+// ds_read_b128 traffic and its bank conflicts.  The two tip tables are the ring blocks after P; they only have to be
+// resident by the midpoint, so MIDWAIT (outstanding vector-memory ops allowed there) + a barrier sit at kb2 == 4.
+template <int MIDWAIT, class SIDE = JitNoSide>
+__device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4], const double *ta, int ca,
+                                                const double *tb, int cb, int q, v4d (&t)[4], SIDE side = SIDE())
+{
+   const double2 *sp = (const double2 *)sPbuf;
+   double2 af[2][4];
+   const int rowa = ca * 4 + q, rowb = cb * 4 + q, swa = TIP_SWZ(rowa), swb = TIP_SWZ(rowb);
+   const char *pa = (const char *)ta + rowa * 128, *pb = (const char *)tb + rowb * 128;
+   double2 tv[2][2], tw[2][2];
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) af[0][jb] = sp[jb * 64 + lane];
+#pragma unroll
+   for (int kb2 = 0; kb2 < 8; kb2++) {
+      if (kb2 == 4) {
+         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MIDWAIT) : "memory");
+         __syncthreads();
+      }
+      if (kb2 + 1 < 8) {
+#pragma unroll
+         for (int jb = 0; jb < 4; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
+      }
+      if (kb2 >= 4) {
+#pragma unroll
+         for (int e = 0; e < 2; e++) {
+            const int p = 2 * (kb2 - 4) + e;
+            tv[kb2 & 1][e] = *(const double2 *)(pa + ((p ^ swa) * 16));
+            tw[kb2 & 1][e] = *(const double2 *)(pb + ((p ^ swb) * 16));
+         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const double b0 = x[(2 * kb2) >> 2][(2 * kb2) & 3], b1 = x[(2 * kb2 + 1) >> 2][(2 * kb2 + 1) & 3];
+      if (kb2 == 0) {
+#pragma unroll
+         for (int jb = 0; jb < 4; jb++)
+            y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][jb].x, b0, (v4d){0, 0, 0, 0}, 0, 0, 0);
+      }
+      else {
+#pragma unroll
+         for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
+      }
+      if (kb2 >= 5) {      // products of the rows fetched one iteration ago
+#pragma unroll
+         for (int e = 0; e < 2; e++) {
+            const int p = 2 * (kb2 - 5) + e;
+            t[p >> 1][(2 * p) & 3] = tv[(kb2 - 1) & 1][e].x * tw[(kb2 - 1) & 1][e].x;
+            t[p >> 1][(2 * p + 1) & 3] = tv[(kb2 - 1) & 1][e].y * tw[(kb2 - 1) & 1][e].y;
+         }
+      }
+      side(kb2);
+#pragma unroll
+      for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+   }
+#pragma unroll
+   for (int e = 0; e < 2; e++) {
+      const int p = 6 + e;
+      t[p >> 1][(2 * p) & 3] = tv[1][e].x * tw[1][e].x;
+      t[p >> 1][(2 * p + 1) & 3] = tv[1][e].y * tw[1][e].y;
    }
 }
 
@@ -365,6 +435,11 @@ __device__ __forceinline__ void jit_root(const PruneArgs &a, const v4d (&x)[4], 
    __syncthreads();
 #define JIT_ISSUE_P(J, NODE) stage_p<8>(Pint + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)
 #define JIT_ISSUE_T(J, NODE) stage_p<8>(Ptip + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)
+/* one of the four 1 KiB-per-wave pieces (C = 0..3) of block J */
+#define JIT_PIECE(SRC, J, C)                                                                                         \
+   dma16(make_rsrc((SRC), 32768), (const char *)(ring + ((J)&3) * 4096) + ((C)*8 + wave) * 1024, lane * 16, ((C)*8 + wave) * 1024)
+#define JIT_PIECE_P(J, NODE, C) JIT_PIECE(Pint + (long)(NODE)*4096, J, C)
+#define JIT_PIECE_T(J, NODE, C) JIT_PIECE(Ptip + (long)(NODE)*4096, J, C)
 #define JIT_BUF(J) (ring + ((J)&3) * 4096)
 #define JIT_CODE(TIP) ((int)sZ[(TIP)*128 + hw])
 #define JIT_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")

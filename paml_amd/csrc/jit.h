@@ -82,7 +82,8 @@ inline std::string jit_generate(const Program &p, int n_tips)
       if (p.ops[i].code == OP_MATMUL || p.ops[i].code == OP_MATMUL_POP) last_mm = (int)i;
 
    // register arrays: a free list; `cur` names the array holding the partial under construction
-   const int NA = p.max_stack + 2;
+   const bool fuse_tips = !getenv("PAML_AMD_JIT_NOFUSE");   // cherries gathered under the preceding matmul (one more array)
+   const int NA = p.max_stack + 2 + (fuse_tips ? 1 : 0);
    for (int i = 0; i < NA; i++) s << "   v4d A" << i << "[4];\n";
    std::vector<int> freeA;
    for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
@@ -93,9 +94,33 @@ inline std::string jit_generate(const Program &p, int n_tips)
    int consumed = 0;
    const int ZR = (n_tips * 128 + 511) / 512;     // tip-code loads per thread (JIT_ZLOAD)
    int extra_loads = 0;                           // ordinary loads issued after the newest DMA that may stay in flight
-   auto step = [&](int c) {   // make the next c blocks visible, then top the ring up
+   const bool spread = !getenv("PAML_AMD_JIT_NOSPREAD");
+   // make the next c blocks visible, then top the ring up — at once, or (defer) as a `side` functor that spreads the
+   // refill's pieces over the first `iters` k-block pairs of the matmul that follows
+   auto step = [&](int c, bool defer = false, int iters = 8, int now = 1) -> std::string {
       s << "   JIT_WAIT(" << 4 * (issued - (consumed + c)) + extra_loads << "); " << (getenv("PAML_AMD_JIT_NOBAR") ? "" : "__syncthreads();") << "\n";
-      while (issued < consumed + 4 && issued < nblk) issue();
+      if (!defer || !spread) {
+         while (issued < consumed + 4 && issued < nblk) issue();
+         return "JitNoSide()";
+      }
+      while (issued < consumed + now && issued < nblk) issue();   // needed within this very step: no delay
+      std::vector<std::string> pieces;
+      while (issued < consumed + 4 && issued < nblk) {
+         const int is_tip = p.stream[2 * issued], node = p.stream[2 * issued + 1];
+         for (int c4 = 0; c4 < 4; c4++)
+            pieces.push_back(std::string(is_tip ? "JIT_PIECE_T(" : "JIT_PIECE_P(") + std::to_string(issued) + ", " + std::to_string(node) +
+                             ", " + std::to_string(c4) + ");");
+         issued++;
+      }
+      if (pieces.empty()) return "JitNoSide()";
+      const int per = ((int)pieces.size() + iters - 1) / iters;
+      std::string f = "[&](int kb2) {";
+      for (size_t i = 0; i < pieces.size(); i += per) {
+         f += " if (kb2 == " + std::to_string(i / per) + ") {";
+         for (size_t k = i; k < i + per && k < pieces.size(); k++) f += " " + pieces[k];
+         f += " }";
+      }
+      return f + " }";
    };
    auto name = [&](int r) { return "A" + std::to_string(r); };
 
@@ -145,10 +170,24 @@ inline std::string jit_generate(const Program &p, int n_tips)
          const int pop = mm_pop_slot(o), push = mm_push_slot(o);
          const int out = alloc();
          if ((int)iop == last_mm) extra_loads = ZR;    // the next tile's tip-code loads were just issued
-         step(1);
+         // a cherry right after a pushed matmul: its two tip gathers ride under this matmul's second half
+         const bool fuse = fuse_tips && push >= 0 && iop + 1 < p.ops.size() && p.ops[iop + 1].code == OP_SET_TIP2;
+         const std::string side = step(1, true, fuse ? 4 : 8, fuse ? 3 : 1);
+         const int xl = extra_loads;
          extra_loads = 0;
-         s << "   jit_matvec(JIT_BUF(" << consumed << "), lane, " << name(cur) << ", " << name(out) << ");\n";
-         consumed += 1;
+         int tgt = -1;
+         if (fuse) {
+            const Op &nx = p.ops[iop + 1];
+            tgt = alloc();
+            s << "   jit_matvec_tip2<" << 4 * (issued - (consumed + 3)) + xl << ">(JIT_BUF(" << consumed << "), lane, " << name(cur) << ", "
+              << name(out) << ", JIT_BUF(" << consumed + 1 << "), JIT_CODE(" << nx.a << "), JIT_BUF(" << consumed + 2 << "), JIT_CODE("
+              << nx.b << "), q, " << name(tgt) << ", " << side << ");\n";
+            consumed += 3;
+         }
+         else {
+            s << "   jit_matvec(JIT_BUF(" << consumed << "), lane, " << name(cur) << ", " << name(out) << ", " << side << ");\n";
+            consumed += 1;
+         }
          release(cur);
          if (pop >= 0) {
             s << "   jit_mul(" << name(out) << ", " << name(slot[pop]) << ");\n";
@@ -161,10 +200,17 @@ inline std::string jit_generate(const Program &p, int n_tips)
          }
          else
             cur = out;
+         if (fuse) cur = tgt;
          if ((int)iop == last_mm) {   // ring is free once every wave has finished this last block
             s << "   if (has_next) {\n      __syncthreads();\n";
             emit_first_blocks(s);
             s << "   }\n";
+         }
+         if (fuse) {      // the SET_TIP2 is done
+            iop++;
+            if (prof)
+               s << "   if (a.prof && tid == a.prof_tid && ptile) a.prof[(long)blockIdx.x * a.prof_stride + 1 + " << iop
+                 << "] = __builtin_amdgcn_s_memtime();\n";
          }
       } break;
       case OP_SCALE:
