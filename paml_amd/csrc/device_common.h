@@ -57,6 +57,8 @@ struct PruneArgs {
    double *export_buf;         // OP_EXPORT target: [K][n_patt][n]
    unsigned long long *prof;   // PROF_OPS builds only: [block][op] s_memtime stamps of thread 0
    int prof_stride, prof_tid;
+   const unsigned char *ztiles; // jit kernel: per tile, (n_tips + 1) rows of 128 bytes (tip codes of the tile's patterns,
+   int zt_bytes;                // then the weight > 0 flags), zero padded to zt_bytes (a multiple of 2048)
 };
 
 __device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)
@@ -106,6 +108,16 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, const void *lds,
 {
    const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)lds;
    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                :
+                : "s"(la), "v"(voff), "s"(r), "s"(soff)
+                : "memory", "m0");
+}
+
+// Same with one dword per lane (256 B per wave instruction): small blocks such as a tile's tip codes.
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t r, const void *lds, int voff, int soff)
+{
+   const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)lds;
+   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
                 :
                 : "s"(la), "v"(voff), "s"(r), "s"(soff)
                 : "memory", "m0");
@@ -384,6 +396,23 @@ __device__ __forceinline__ void jit_root(const PruneArgs &a, const v4d (&x)[4], 
    }
 }
 
+// Root stage with pi and the weight flag already in LDS (no vector-memory loads whose wait would drain the ring's DMAs).
+__device__ __forceinline__ void jit_root_lds(const PruneArgs &a, const v4d (&x)[4], double lnscale, const double *spi, int flag, int iclass,
+                                             int q, int h, bool valid)
+{
+   const double *pq = spi + q * 16;
+   double f = 0;
+#pragma unroll
+   for (int m = 0; m < 16; m++) f = fma(pq[m], x[m >> 2][m & 3], f);
+   f += __shfl_xor(f, 16);
+   f += __shfl_xor(f, 32);
+   if (q == 0 && valid) {
+      double out = 0;
+      if (flag) out = root_value(a, f, lnscale);
+      a.fhK[(long)iclass * a.n_patt + h] = out;
+   }
+}
+
 // Skeleton of a specialised kernel: 8 waves x 16 patterns per tile, ring of four 32 KB operand buffers, tip codes in
 // LDS.  The kernel is persistent: each workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and issues the
 // next tile's first operand blocks and tip-code loads before it finishes the current tile's root stage.
@@ -443,5 +472,60 @@ __device__ __forceinline__ void jit_root(const PruneArgs &a, const v4d (&x)[4], 
 #define JIT_BUF(J) (ring + ((J)&3) * 4096)
 #define JIT_CODE(TIP) ((int)sZ[(TIP)*128 + hw])
 #define JIT_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+// ---- seamless variant: the operand ring and the tip-code blocks run on across tile boundaries ------------------------
+// The workgroup's blocks are numbered through all its tiles; a tile's block J sits in ring buffer (J + roff) & 3 with
+// roff advancing by the tile's block count, and blocks J >= NBLK are the next tile's (its P pointers).  Tip codes and
+// weight flags of a tile arrive as one small DMA block (PruneArgs::ztiles) in the sZ buffer the previous tile is not
+// using.  Nothing at a tile boundary waits on vector memory.
+#define JIT2_PROLOGUE(ZP)                                                                                        \
+   __shared__ __attribute__((aligned(16))) double ring[4 * 4096];                                               \
+   __shared__ __attribute__((aligned(16))) unsigned char sZ[2 * (ZP)*2048];                                      \
+   __shared__ double sPi[4 * 64];                                                                               \
+   const int tid = threadIdx.x, lane = tid & 63;                                                                \
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                   \
+   const int q = lane >> 4, hl = lane & 15;                                                                     \
+   const int hw = wave * 16 + hl;                                                                               \
+   const int n = a.n;                                                                                           \
+   const int total_work = a.n_tiles * a.K;                                                                      \
+   int work = blockIdx.x;                                                                                       \
+   int iclass = 0, gene = 0, h0 = 0, hend = 1, h = 0;                                                           \
+   int n_tile = 0, n_gene = 0, n_iclass = 0, n_h0 = 0, n_hend = 1;                                              \
+   bool valid = false, has_next = false;                                                                        \
+   const double *Pint = nullptr, *Ptip = nullptr, *nPint = a.pint, *nPtip = a.ptip;                             \
+   double lnscale = 0;                                                                                          \
+   int roff = 0, zsel = 1;                                                                                      \
+   (void)hl; (void)n; (void)lnscale; (void)h0;                                                                  \
+   if (work >= total_work) return;                                                                              \
+   for (int i = tid; i < a.n_pi * 64 && i < 256; i += 512) sPi[i] = a.pi[i];
+#define JIT2_NEXT_SET()                                                                                          \
+   has_next = work < total_work;                                                                                \
+   if (has_next) {                                                                                              \
+      n_tile = work % a.n_tiles; n_iclass = work / a.n_tiles;                                                   \
+      n_gene = as_const(a.tiles)[n_tile].x; n_h0 = as_const(a.tiles)[n_tile].y;                                 \
+      n_hend = as_const(a.gene_off)[n_gene + 1];                                                                \
+      nPint = a.pint + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 4096;                                      \
+      nPtip = a.ptip + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 4096;                                      \
+   }   /* past the last tile the n_* values stay: the (unused) prefetches keep reading valid memory */
+#define JIT2_ADVANCE(NBLK)                                                                                       \
+   iclass = n_iclass; gene = n_gene; h0 = n_h0; hend = n_hend; Pint = nPint; Ptip = nPtip;                      \
+   h = h0 + hw; valid = h < hend; lnscale = 0;                                                                  \
+   roff = (roff + (NBLK)) & 3; zsel ^= 1;
+/* the next tile's code block -> the sZ buffer not in use (ZP dword pieces per thread) */
+#define JIT2_ISSUE_Z(ZP)                                                                                         \
+   {                                                                                                            \
+      const __amdgpu_buffer_rsrc_t zr_ = make_rsrc(a.ztiles + (long)n_tile * ((ZP)*2048), (ZP)*2048);            \
+      _Pragma("unroll") for (int c_ = 0; c_ < (ZP); c_++)                                                       \
+         dma4(zr_, sZ + (zsel ^ 1) * ((ZP)*2048) + (c_ * 8 + wave) * 256, lane * 4, (c_ * 8 + wave) * 256);      \
+   }
+#define JIT2_BUF(J) (ring + (((J) + roff) & 3) * 4096)
+#define JIT2_PIECE(SRC, J, C)                                                                                        \
+   dma16(make_rsrc((SRC), 32768), (const char *)JIT2_BUF(J) + ((C)*8 + wave) * 1024, lane * 16, ((C)*8 + wave) * 1024)
+#define JIT2_PIECE_P(J, NODE, C) JIT2_PIECE(Pint + (long)(NODE)*4096, J, C)
+#define JIT2_PIECE_T(J, NODE, C) JIT2_PIECE(Ptip + (long)(NODE)*4096, J, C)
+#define JIT2_PIECE_NP(J, NODE, C) JIT2_PIECE(nPint + (long)(NODE)*4096, J, C)
+#define JIT2_PIECE_NT(J, NODE, C) JIT2_PIECE(nPtip + (long)(NODE)*4096, J, C)
+#define JIT2_CODE(ZP, TIP) ((int)sZ[zsel * ((ZP)*2048) + (TIP)*128 + hw])
+#define JIT2_NCODE(ZP, TIP) ((int)sZ[(zsel ^ 1) * ((ZP)*2048) + (TIP)*128 + hw])
 
 }  // namespace paml_amd

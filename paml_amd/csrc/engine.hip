@@ -107,7 +107,8 @@ struct paml_amd_engine {
    // data
    bool have_tips = false, have_tree = false, have_pi = false, have_classes = false;
    int cleandata = 1, n_codes = 0;
-   DevBuf<unsigned char> d_z, d_chara_map, d_is_leaf;
+   DevBuf<unsigned char> d_z, d_chara_map, d_is_leaf, d_ztiles;
+   int zt_bytes = 0;
    DevBuf<int> d_n_chara, d_gene_off, d_label, d_eigen_of;
    DevBuf<int2> d_tiles, d_tiles_full;   // tile table of the selected kernel / of the full (gather or valu) kernel
    int n_tiles_full = 0;
@@ -152,7 +153,7 @@ struct paml_amd_engine {
       if (jit.mod) (void)hipModuleUnload(jit.mod);
       for (auto ev : ev_pool) (void)hipEventDestroy(ev);
       for (auto ev : ev_used) (void)hipEventDestroy(ev);
-      DevBuf<unsigned char> *b1[] = {&d_z, &d_chara_map, &d_is_leaf};
+      DevBuf<unsigned char> *b1[] = {&d_z, &d_chara_map, &d_is_leaf, &d_ztiles};
       for (auto b : b1) b->release();
       DevBuf<int> *b2[] = {&d_n_chara, &d_gene_off, &d_label, &d_eigen_of};
       for (auto b : b2) b->release();
@@ -239,6 +240,12 @@ int build_tiles(paml_amd_engine *e)
       for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += tf) tfull.push_back(make_int2(g, h));
    e->n_tiles_full = (int)tfull.size();
    HIPCHK(upload(e->d_tiles_full, tfull.data(), tfull.size(), e->stream));
+   if (e->kk == KK_MFMA64 && e->tile_patt == 128 && e->d_z.p && e->d_weights.p) {   // code blocks of the specialised kernel
+      e->zt_bytes = jit_zpieces(e->n_tips) * 2048;
+      HIPCHK(e->d_ztiles.ensure((size_t)e->n_tiles * e->zt_bytes));
+      hipLaunchKernelGGL(ztile_kernel, dim3(e->n_tiles), dim3(128), 0, e->stream, e->d_tiles.p, e->d_gene_off.p, e->d_z.p, (long)e->n_patt,
+                         e->d_weights.p, e->n_tips, e->zt_bytes, e->d_ztiles.p);
+   }
    HIPCHK(hipStreamSynchronize(e->stream));
    return 0;
 }
@@ -322,7 +329,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       for (const Op &o : e->prog.ops)
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
       bool jit_ok = false;
-      if (e->jit_enabled && !getenv("PAML_AMD_FORCE_GATHER") && jit_supported(e->prog, e->n_tips, e->n_codes)) {
+      if (e->jit_enabled && !getenv("PAML_AMD_FORCE_GATHER") && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi)) {
          const std::string key = jit_program_key(e->prog, e->n_tips);
          if (e->jit.fn && e->jit.key == key)
             jit_ok = true;
@@ -388,7 +395,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // Kernel B: fused pruning
    PruneArgs pr{};
    pr.ops = e->d_ops.p; pr.z = e->d_z.p; pr.z_stride = e->n_patt; pr.tiles = e->d_tiles.p; pr.n_tiles = e->n_tiles;
-   pr.gene_off = e->d_gene_off.p; pr.weights = e->d_weights.p;
+   pr.gene_off = e->d_gene_off.p; pr.weights = e->d_weights.p; pr.ztiles = e->d_ztiles.p; pr.zt_bytes = e->zt_bytes;
    pr.n = n; pr.n_tips = e->n_tips; pr.n_nodes = nn; pr.K = K; pr.n_genes = G; pr.n_codes = e->n_codes;
    pr.cleandata = e->cleandata; pr.n_pi = e->n_pi; pr.mode = e->mode; pr.n_scale = e->tree.n_scale;
    pr.keep = keep ? 1 : 0; pr.n_patt = e->n_patt;

@@ -33,9 +33,13 @@ struct JitKernel {
 };
 
 // Which programs the generator covers.
-inline bool jit_supported(const Program &p, int n_tips, int n_codes, int max_arrays = 6)
+inline int jit_zpieces(int n_tips) { return ((n_tips + 1) * 128 + 2047) / 2048; }   // 2 KB DMA pieces of a tile's code block
+
+inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6)
 {
-   if (n_tips > MFMA_ZT || n_codes > 64 || p.ops.size() > 400) return false;
+   if (n_codes > 64 || p.ops.size() > 400 || n_pi > 4) return false;
+   if (4 * 32768 + 2 * jit_zpieces(n_tips) * 2048 + 4 * 64 * 8 > 160 * 1024) return false;   // LDS: ring + two code blocks + pi
+   if (p.stream.size() / 2 < 4) return false;                       // trees this small go to the interpreter
    for (const Op &o : p.ops)
       if (o.code == OP_STORE || o.code == OP_LOAD) return false;   // keep-partials layouts stay with the interpreter
    return p.max_stack + 2 <= max_arrays;
@@ -50,66 +54,91 @@ inline std::string jit_program_key(const Program &p, int n_tips)
 }
 
 // Emit the straight-line kernel for one program.
-inline std::string jit_generate(const Program &p, int n_tips)
+//
+// Schedule (all static): the program's operand blocks are consumed in stream order through a ring of four LDS buffers
+// that runs on across tiles (JIT2_* in device_common.h).  Every block step is  s_waitcnt vmcnt(N) + barrier  with N =
+// the DMA pieces issued after the block, then the ring is refilled up to three blocks ahead — inside the MFMA loop of
+// the step's matmul where there is one.  A cherry (SET_TIP2) that follows a pushed matmul is gathered under that
+// matmul's second half; the first cherry of the NEXT tile is gathered under the current tile's last matmul (the tile's
+// own first cherry was done that way by its predecessor; the first tile's is peeled in front of the loop).
+// `first` = operand blocks of a tile already requested when the loop body starts (the body's last step leaves the
+// same number of the next tile's in flight; *first_out reports it so that jit_generate can make the two agree).
+inline std::string jit_generate_impl(const Program &p, int n_tips, int first, int *first_out)
 {
    std::ostringstream s;
    const int nblk = (int)p.stream.size() / 2;
+   const int ZP = jit_zpieces(n_tips);
+   const size_t nops = p.ops.size();
+   const bool fuse_tips = !getenv("PAML_AMD_JIT_NOFUSE");   // cherries gathered under the preceding matmul
+   const bool spread = !getenv("PAML_AMD_JIT_NOSPREAD");    // ring refill issued from inside the MFMA loops
+   const bool prof = getenv("PAML_AMD_PROF_OPS") != nullptr; // kernel experiments: s_memtime stamp at every op
+   int last_mm = -1;
+   for (size_t i = 0; i < nops; i++)
+      if (p.ops[i].code == OP_MATMUL || p.ops[i].code == OP_MATMUL_POP) last_mm = (int)i;
+   // the next tile's first cherry rides under this tile's last matmul
+   // (only when that matmul is the tile's last consumer of operand blocks: the ring has no room for more)
+   bool tail_blocks = false;
+   for (size_t i = last_mm + 1; i < nops; i++)
+      if (p.ops[i].code == OP_SET_TIP || p.ops[i].code == OP_MUL_TIP || p.ops[i].code == OP_SET_TIP2 || p.ops[i].code == OP_MUL_TIP2)
+         tail_blocks = true;
+   const bool peel = fuse_tips && !getenv("PAML_AMD_JIT_NOPEEL") && nops > 2 && p.ops[0].code == OP_SET_TIP2 && last_mm > 1 &&
+                     p.ops[1].code != OP_MUL_TIP && p.ops[1].code != OP_MUL_TIP2 && !tail_blocks;
+
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
    s << "extern \"C\" __global__ __launch_bounds__(512, 2) void prune_jit(PruneArgs a)\n{\n";
-   s << "   JIT_PROLOGUE(" << n_tips << ")\n";
-   int issued = 0;
-   auto issue = [&]() {
-      const int is_tip = p.stream[2 * issued], node = p.stream[2 * issued + 1];
-      s << "   " << (is_tip ? "JIT_ISSUE_T(" : "JIT_ISSUE_P(") << issued << ", " << node << ");\n";
+   s << "   JIT2_PROLOGUE(" << ZP << ")\n";
+   s << "   roff = " << ((4 - nblk % 4) & 3) << ";\n";
+
+   // ---- static bookkeeping of what is in flight (per thread: pieces = vector-memory instructions) -------------------
+   struct Item { int id, pieces; };          // id: block number within the tile (>= nblk: next tile's), -1: a code block
+   std::vector<Item> fl;                     // issued, not yet known landed; oldest first
+   int issued = 0, consumed = 0;
+   auto piece = [&](int blk, int c4) {       // source text of one DMA piece of block blk
+      const bool nx = blk >= nblk;
+      const int loc = blk % nblk, is_tip = p.stream[2 * loc], node = p.stream[2 * loc + 1];
+      return std::string("JIT2_PIECE_") + (nx ? "N" : "") + (is_tip ? "T(" : "P(") + std::to_string(blk) + ", " + std::to_string(node) + ", " +
+             std::to_string(c4) + ");";
+   };
+   auto issue_now = [&]() {
+      s << "  ";
+      for (int c4 = 0; c4 < 4; c4++) s << " " << piece(issued, c4);
+      s << "\n";
+      fl.push_back({issued, 4});
       issued++;
    };
-   // what starts a tile: tile variables, first operand blocks, tip codes into registers
-   const int n_first = std::min(3, nblk);
-   auto emit_first_blocks = [&](std::ostringstream &o) {      // the next tile's first operand blocks
-      for (int i = 0; i < n_first; i++) {
-         const int is_tip = p.stream[2 * i], node = p.stream[2 * i + 1];
-         o << "      " << (is_tip ? "JIT_ISSUE_NT(" : "JIT_ISSUE_NP(") << i << ", " << node << ");\n";
-      }
+   auto wait_count = [&](int blk) {          // pieces that may stay in flight once block blk has to be complete
+      int pos = -1;
+      for (size_t i = 0; i < fl.size(); i++)
+         if (fl[i].id == blk) pos = (int)i;
+      if (pos < 0) return -1;                // already covered by an earlier wait
+      int nfl = 0;
+      for (size_t i = pos + 1; i < fl.size(); i++) nfl += fl[i].pieces;
+      fl.erase(fl.begin(), fl.begin() + pos + 1);
+      return nfl;
    };
-   s << "   JIT_NEXT_SET()\n   {\n";
-   emit_first_blocks(s);
-   s << "   }\n   JIT_ZLOAD(" << n_tips << ")\n";
-   issued = n_first;
-   s << "   int ptile = 1;\n   for (;; ptile = 0) {\n";
-   s << "   JIT_ADVANCE()\n   JIT_ZSTORE(" << n_tips << ")\n";
-   int last_mm = -1;
-   for (size_t i = 0; i < p.ops.size(); i++)
-      if (p.ops[i].code == OP_MATMUL || p.ops[i].code == OP_MATMUL_POP) last_mm = (int)i;
-
-   // register arrays: a free list; `cur` names the array holding the partial under construction
-   const bool fuse_tips = !getenv("PAML_AMD_JIT_NOFUSE");   // cherries gathered under the preceding matmul (one more array)
-   const int NA = p.max_stack + 2 + (fuse_tips ? 1 : 0);
-   for (int i = 0; i < NA; i++) s << "   v4d A" << i << "[4];\n";
-   std::vector<int> freeA;
-   for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
-   auto alloc = [&]() { int r = freeA.back(); freeA.pop_back(); return r; };
-   auto release = [&](int r) { freeA.push_back(r); };
-   std::vector<int> slot(256, -1);   // stack slot -> array
-   int cur = -1;
-   int consumed = 0;
-   const int ZR = (n_tips * 128 + 511) / 512;     // tip-code loads per thread (JIT_ZLOAD)
-   int extra_loads = 0;                           // ordinary loads issued after the newest DMA that may stay in flight
-   const bool spread = !getenv("PAML_AMD_JIT_NOSPREAD");
+   bool z_pending = false;                   // the next tile's code block still has to be requested in this tile
    // make the next c blocks visible, then top the ring up — at once, or (defer) as a `side` functor that spreads the
-   // refill's pieces over the first `iters` k-block pairs of the matmul that follows
+   // refill's pieces over the first `iters` k-block pairs of the matmul that follows; the first `now` blocks from
+   // `consumed` are needed within this very step and are never delayed
    auto step = [&](int c, bool defer = false, int iters = 8, int now = 1) -> std::string {
-      s << "   JIT_WAIT(" << 4 * (issued - (consumed + c)) + extra_loads << "); " << (getenv("PAML_AMD_JIT_NOBAR") ? "" : "__syncthreads();") << "\n";
+      const int nw = wait_count(consumed + c - 1);
+      if (nw >= 0) s << "   JIT_WAIT(" << nw << ");";
+      s << "   __syncthreads();\n";
+      if (z_pending) {
+         s << "   JIT2_ISSUE_Z(" << ZP << ")\n";
+         fl.push_back({-1, ZP});
+         z_pending = false;
+      }
+      const int upto = consumed + 4;
       if (!defer || !spread) {
-         while (issued < consumed + 4 && issued < nblk) issue();
+         while (issued < upto) issue_now();
          return "JitNoSide()";
       }
-      while (issued < consumed + now && issued < nblk) issue();   // needed within this very step: no delay
+      while (issued < consumed + now && issued < upto) issue_now();
       std::vector<std::string> pieces;
-      while (issued < consumed + 4 && issued < nblk) {
-         const int is_tip = p.stream[2 * issued], node = p.stream[2 * issued + 1];
-         for (int c4 = 0; c4 < 4; c4++)
-            pieces.push_back(std::string(is_tip ? "JIT_PIECE_T(" : "JIT_PIECE_P(") + std::to_string(issued) + ", " + std::to_string(node) +
-                             ", " + std::to_string(c4) + ");");
+      while (issued < upto) {
+         for (int c4 = 0; c4 < 4; c4++) pieces.push_back(piece(issued, c4));
+         fl.push_back({issued, 4});
          issued++;
       }
       if (pieces.empty()) return "JitNoSide()";
@@ -122,17 +151,53 @@ inline std::string jit_generate(const Program &p, int n_tips)
       }
       return f + " }";
    };
-   auto name = [&](int r) { return "A" + std::to_string(r); };
-
-   const bool prof = getenv("PAML_AMD_PROF_OPS") != nullptr;    // kernel experiments: s_memtime stamp after every op
-   if (prof) s << "   if (a.prof && tid == a.prof_tid && ptile) a.prof[(long)blockIdx.x * a.prof_stride] = __builtin_amdgcn_s_memtime();\n";
-   for (size_t iop = 0; iop < p.ops.size(); iop++) {
-      const Op &o = p.ops[iop];
+   auto stamp = [&](size_t iop) {
       if (prof)
          s << "   if (a.prof && tid == a.prof_tid && ptile) a.prof[(long)blockIdx.x * a.prof_stride + 1 + " << iop
            << "] = __builtin_amdgcn_s_memtime();\n";
-      if ((int)iop == last_mm)     // the next tile's tip codes travel to registers under this tile's last MFMAs
-         s << "   work += gridDim.x;\n   JIT_NEXT_SET()\n   JIT_ZLOAD(" << n_tips << ")\n";   // unconditional: static load counts
+   };
+   auto code = [&](int tip) { return "JIT2_CODE(" + std::to_string(ZP) + ", " + std::to_string(tip) + ")"; };
+   auto ncode = [&](int tip) { return "JIT2_NCODE(" + std::to_string(ZP) + ", " + std::to_string(tip) + ")"; };
+   auto buf = [&](int blk) { return "JIT2_BUF(" + std::to_string(blk) + ")"; };
+
+   // ---- in front of the loop: the first tile is the "next" tile of an empty predecessor ---------------------------
+   const int NA = p.max_stack + 2 + (fuse_tips ? 1 : 0);
+   for (int i = 0; i < NA; i++) s << "   v4d A" << i << "[4];\n";
+   if (peel) s << "   v4d AS[4];\n";       // the first cherry of a tile, produced under the predecessor's last matmul
+   s << "   JIT2_NEXT_SET()\n   JIT2_ISSUE_Z(" << ZP << ")\n";
+   fl.push_back({-1, ZP});
+   issued = nblk;                           // numbered as the blocks after the (empty) predecessor's
+   for (int i = 0; i < first; i++) issue_now();
+   if (peel) {
+      const int nw = wait_count(nblk + 1);
+      s << "   JIT_WAIT(" << nw << "); __syncthreads();\n";
+      s << "   jit_tip2_set(AS, " << buf(nblk) << ", " << ncode(p.ops[0].a) << ", " << buf(nblk + 1) << ", " << ncode(p.ops[0].b) << ", q, lane);\n";
+   }
+   // renumber for the loop body: those three blocks are blocks 0..2 of the tile the loop starts with
+   for (Item &it : fl)
+      if (it.id >= 0) it.id -= nblk;
+   issued = first;
+   consumed = peel ? 2 : 0;
+
+   s << "   int ptile = 1;\n   for (;; ptile = 0) {\n";
+   s << "   JIT2_ADVANCE(" << nblk << ")\n   work += gridDim.x;\n   JIT2_NEXT_SET()\n";
+   z_pending = true;
+
+   // register arrays: a free list; `cur` names the array holding the partial under construction
+   std::vector<int> freeA;
+   for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
+   const int AS = 1000;
+   auto alloc = [&]() { int r = freeA.back(); freeA.pop_back(); return r; };
+   auto release = [&](int r) { if (r != AS) freeA.push_back(r); };
+   auto name = [&](int r) { return r == AS ? std::string("AS") : "A" + std::to_string(r); };
+   std::vector<int> slot(256, -1);   // stack slot -> array
+   int cur = peel ? AS : -1;
+
+   if (prof) s << "   if (a.prof && tid == a.prof_tid && ptile) a.prof[(long)blockIdx.x * a.prof_stride] = __builtin_amdgcn_s_memtime();\n";
+   for (size_t iop = 0; iop < nops; iop++) {
+      const Op &o = p.ops[iop];
+      stamp(iop);
+      if (iop == 0 && peel) continue;      // done by the predecessor
       switch (o.code) {
       case OP_INIT_ONES:
          if (cur < 0) cur = alloc();
@@ -140,25 +205,25 @@ inline std::string jit_generate(const Program &p, int n_tips)
          break;
       case OP_INIT_TIP:
          if (cur < 0) cur = alloc();
-         s << "   jit_init_tip(" << name(cur) << ", JIT_CODE(" << o.a << "), q, a.cleandata);\n";
+         s << "   jit_init_tip(" << name(cur) << ", " << code(o.a) << ", q, a.cleandata);\n";
          break;
       case OP_SET_TIP:
          if (cur < 0) cur = alloc();
          step(1);
-         s << "   jit_tip_set(" << name(cur) << ", JIT_BUF(" << consumed << "), JIT_CODE(" << o.a << "), q, lane);\n";
+         s << "   jit_tip_set(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane);\n";
          consumed += 1;
          break;
       case OP_MUL_TIP:
          step(1);
-         s << "   jit_tip_mul(" << name(cur) << ", JIT_BUF(" << consumed << "), JIT_CODE(" << o.a << "), q, lane);\n";
+         s << "   jit_tip_mul(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane);\n";
          consumed += 1;
          break;
       case OP_SET_TIP2:
       case OP_MUL_TIP2:
          if (cur < 0) cur = alloc();
          step(2);
-         s << "   " << (o.code == OP_SET_TIP2 ? "jit_tip2_set(" : "jit_tip2_mul(") << name(cur) << ", JIT_BUF(" << consumed
-           << "), JIT_CODE(" << o.a << "), JIT_BUF(" << consumed + 1 << "), JIT_CODE(" << o.b << "), q, lane);\n";
+         s << "   " << (o.code == OP_SET_TIP2 ? "jit_tip2_set(" : "jit_tip2_mul(") << name(cur) << ", " << buf(consumed) << ", " << code(o.a)
+           << ", " << buf(consumed + 1) << ", " << code(o.b) << ", q, lane);\n";
          consumed += 2;
          break;
       case OP_PUSH:
@@ -169,23 +234,22 @@ inline std::string jit_generate(const Program &p, int n_tips)
       case OP_MATMUL_POP: {
          const int pop = mm_pop_slot(o), push = mm_push_slot(o);
          const int out = alloc();
-         if ((int)iop == last_mm) extra_loads = ZR;    // the next tile's tip-code loads were just issued
          // a cherry right after a pushed matmul: its two tip gathers ride under this matmul's second half
-         const bool fuse = fuse_tips && push >= 0 && iop + 1 < p.ops.size() && p.ops[iop + 1].code == OP_SET_TIP2;
-         const std::string side = step(1, true, fuse ? 4 : 8, fuse ? 3 : 1);
-         const int xl = extra_loads;
-         extra_loads = 0;
+         const bool fuse = fuse_tips && push >= 0 && iop + 1 < nops && p.ops[iop + 1].code == OP_SET_TIP2;
+         const bool fuse_next = peel && (int)iop == last_mm;     // ... or the next tile's first cherry under the last matmul
+         const std::string side = step(1, true, (fuse || fuse_next) ? 4 : 8, (fuse || fuse_next) ? 3 : 1);
          int tgt = -1;
-         if (fuse) {
-            const Op &nx = p.ops[iop + 1];
-            tgt = alloc();
-            s << "   jit_matvec_tip2<" << 4 * (issued - (consumed + 3)) + xl << ">(JIT_BUF(" << consumed << "), lane, " << name(cur) << ", "
-              << name(out) << ", JIT_BUF(" << consumed + 1 << "), JIT_CODE(" << nx.a << "), JIT_BUF(" << consumed + 2 << "), JIT_CODE("
-              << nx.b << "), q, " << name(tgt) << ", " << side << ");\n";
+         if (fuse || fuse_next) {
+            const Op &nx = fuse ? p.ops[iop + 1] : p.ops[0];
+            tgt = fuse ? alloc() : AS;
+            const int mid = wait_count(consumed + 2);
+            s << "   jit_matvec_tip2<" << (mid < 0 ? 63 : mid) << ">(" << buf(consumed) << ", lane, " << name(cur) << ", " << name(out) << ", "
+              << buf(consumed + 1) << ", " << (fuse ? code(nx.a) : ncode(nx.a)) << ", " << buf(consumed + 2) << ", "
+              << (fuse ? code(nx.b) : ncode(nx.b)) << ", q, " << name(tgt) << ", " << side << ");\n";
             consumed += 3;
          }
          else {
-            s << "   jit_matvec(JIT_BUF(" << consumed << "), lane, " << name(cur) << ", " << name(out) << ", " << side << ");\n";
+            s << "   jit_matvec(" << buf(consumed) << ", lane, " << name(cur) << ", " << name(out) << ", " << side << ");\n";
             consumed += 1;
          }
          release(cur);
@@ -200,17 +264,10 @@ inline std::string jit_generate(const Program &p, int n_tips)
          }
          else
             cur = out;
-         if (fuse) cur = tgt;
-         if ((int)iop == last_mm) {   // ring is free once every wave has finished this last block
-            s << "   if (has_next) {\n      __syncthreads();\n";
-            emit_first_blocks(s);
-            s << "   }\n";
-         }
          if (fuse) {      // the SET_TIP2 is done
+            cur = tgt;
             iop++;
-            if (prof)
-               s << "   if (a.prof && tid == a.prof_tid && ptile) a.prof[(long)blockIdx.x * a.prof_stride + 1 + " << iop
-                 << "] = __builtin_amdgcn_s_memtime();\n";
+            stamp(iop);
          }
       } break;
       case OP_SCALE:
@@ -218,18 +275,33 @@ inline std::string jit_generate(const Program &p, int n_tips)
            << "     if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + " << o.b << ") * a.n_patt + h] = fac; }\n";
          break;
       case OP_ROOT:
-         s << "   jit_root(a, " << name(cur) << ", lnscale, gene, iclass, q, h, valid);\n";
+         s << "   jit_root_lds(a, " << name(cur) << ", lnscale, sPi + (a.n_pi > 1 ? gene : 0) * 64, " << code(n_tips)
+           << ", iclass, q, h, valid);\n";
          release(cur);
          cur = -1;
          break;
       default: break;
       }
    }
-   // next tile of this persistent workgroup: make sure every wave is done with the ring and the tip codes, then
-   // start its operand stream and tip-code loads before looping
-   if (last_mm < 0) s << "   work += gridDim.x;\n   JIT_NEXT_SET()\n   JIT_ZLOAD(" << n_tips << ")\n";
-   s << "   if (!has_next) break;\n   }\n}\n";
+   // programs whose steps never came by a barrier after the tile switch (no operand blocks): request the codes here
+   if (z_pending) {
+      s << "   __syncthreads();\n   JIT2_ISSUE_Z(" << ZP << ")\n";
+      fl.push_back({-1, ZP});
+   }
+   s << "   if (!has_next) break;\n   }\n   JIT_WAIT(0);\n}\n";
+   *first_out = issued - nblk;
    return s.str();
+}
+
+inline std::string jit_generate(const Program &p, int n_tips)
+{
+   int first = 3, got = 3;
+   std::string src = jit_generate_impl(p, n_tips, first, &got);
+   if (got != first) {
+      first = got;
+      src = jit_generate_impl(p, n_tips, first, &got);
+   }
+   return got == first ? src : std::string("#error \"jit schedule does not close\"\n");
 }
 
 inline std::string jit_source_dir()
