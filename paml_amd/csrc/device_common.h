@@ -57,6 +57,7 @@ struct PruneArgs {
    double *export_buf;         // OP_EXPORT target: [K][n_patt][n]
    unsigned long long *prof;   // PROF_OPS builds only: [block][op] s_memtime stamps of thread 0
    int prof_stride, prof_tid;
+   double *fscale;             // jit kernel with scaling nodes: summed scale factors [K][n_patt] (the log is taken later)
    const unsigned char *ztiles; // jit kernel: per tile, (n_tips + 1) rows of 128 bytes (tip codes of the tile's patterns,
    int zt_bytes;                // then the weight > 0 flags), zero padded to zt_bytes (a multiple of 2048)
 };
@@ -407,9 +408,10 @@ __device__ __forceinline__ void jit_root_lds(const PruneArgs &a, const v4d (&x)[
    f += __shfl_xor(f, 16);
    f += __shfl_xor(f, 32);
    if (q == 0 && valid) {
-      double out = 0;
-      if (flag) out = root_value(a, f, lnscale);
-      a.fhK[(long)iclass * a.n_patt + h] = out;
+      // fx_r treesub.c:7731-7749 / lfun 7782-7798: the floor here, log + scale factors in the reduction kernel
+      if (f <= 0) f = (a.mode == PAML_AMD_MODE_LFUN ? 1e-80 : 1e-300);
+      a.fhK[(long)iclass * a.n_patt + h] = flag ? f : 0.0;
+      if (a.n_scale) a.fscale[(long)iclass * a.n_patt + h] = lnscale;
    }
 }
 

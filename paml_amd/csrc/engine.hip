@@ -133,7 +133,7 @@ struct paml_amd_engine {
    int mode = PAML_AMD_MODE_LFUN, K = 1, n_labels = 1;
 
    // per-evaluation buffers
-   DevBuf<double> d_rowmajor, d_pint, d_ptip, d_fhK, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
+   DevBuf<double> d_rowmajor, d_pint, d_ptip, d_fhK, d_fscale, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
    DevBuf<double> d_expA, d_expB, d_deriv, d_tt, d_bpartial, d_bout;   // branch-local evaluation
    DevBuf<int> d_label_eff;
    DevBuf<Op> d_ops_tmp;
@@ -166,7 +166,7 @@ struct paml_amd_engine {
       d_eigen.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_fhK, &d_lnf, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
+                              &d_pint, &d_ptip, &d_fhK, &d_fscale, &d_lnf, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
                               &d_expA, &d_expB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
    }
@@ -400,6 +400,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.cleandata = e->cleandata; pr.n_pi = e->n_pi; pr.mode = e->mode; pr.n_scale = e->tree.n_scale;
    pr.keep = keep ? 1 : 0; pr.n_patt = e->n_patt;
    pr.pi = e->d_pi.p; pr.pint = e->kk == KK_MFMA64 ? e->d_pint.p : e->d_rowmajor.p; pr.ptip = e->d_ptip.p;
+   if (e->use_jit && e->tree.n_scale) HIPCHK(e->d_fscale.ensure((size_t)K * e->n_patt));
+   pr.fscale = e->d_fscale.p;
    pr.fhK = e->d_fhK.p; pr.partials = e->d_partials.p; pr.scalef = e->d_scalef.p; pr.stack_scratch = e->d_stack.p;
    pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
    pr.first_tip = e->prog.first_tip;
@@ -476,6 +478,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    ReduceArgs ra{};
    ra.fhK = e->d_fhK.p; ra.weights = e->d_weights.p; ra.freqK = e->d_freqK.p; ra.lnf = want_lnf ? e->d_lnf.p : nullptr;
    ra.partial = e->d_partial.p; ra.out = d_lnL_out ? d_lnL_out : e->d_out.p;
+   ra.raw = (e->kk == KK_MFMA64 && e->use_jit) ? 1 : 0; ra.fscale = e->d_fscale.p;
    ra.n_patt = e->n_patt; ra.K = K; ra.mode = e->mode; ra.n_scale = e->tree.n_scale; ra.chunk = chunk;
    mark(e);
    hipLaunchKernelGGL(reduce_stage1, dim3(nb), dim3(256), 0, e->stream, ra);

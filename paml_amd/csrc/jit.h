@@ -237,7 +237,8 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int first, in
          // a cherry right after a pushed matmul: its two tip gathers ride under this matmul's second half
          const bool fuse = fuse_tips && push >= 0 && iop + 1 < nops && p.ops[iop + 1].code == OP_SET_TIP2;
          const bool fuse_next = peel && (int)iop == last_mm;     // ... or the next tile's first cherry under the last matmul
-         const std::string side = step(1, true, (fuse || fuse_next) ? 4 : 8, (fuse || fuse_next) ? 3 : 1);
+         // (tip tables the ring could not hold earlier are requested in the first k-block pairs and awaited at the midpoint)
+         const std::string side = step(1, true, (fuse || fuse_next) ? 4 : 8, 1);
          int tgt = -1;
          if (fuse || fuse_next) {
             const Op &nx = fuse ? p.ops[iop + 1] : p.ops[0];

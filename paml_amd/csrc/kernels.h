@@ -728,7 +728,10 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
 // fixed-order two-level sum of w_h * log f_h (deterministic for a given n_patt).
 // ------------------------------------------------------------------------------------------------
 struct ReduceArgs {
-   const double *fhK, *weights, *freqK;
+   double *fhK;        // [K][n_patt]; with `raw` it arrives as floored root sums and leaves as fx_r's values
+   const double *weights, *freqK;
+   const double *fscale; // raw + n_scale: summed scale factors [K][n_patt]
+   int raw;
    double *lnf;        // optional [n_patt]
    double *partial;    // [gridDim.x]
    double *out;        // scalar
@@ -776,6 +779,12 @@ __global__ __launch_bounds__(256) void reduce_stage1(ReduceArgs a)
    for (int h = lo + threadIdx.x; h < hi; h += 256) {
       double v = 0;
       if (a.weights[h] > 0) {
+         if (a.raw && (a.mode == PAML_AMD_MODE_LFUN || a.n_scale)) {   // the log the specialised kernel leaves to us
+            for (int ir = 0; ir < a.K; ir++) {
+               const long ix = (long)ir * a.n_patt + h;
+               a.fhK[ix] = log(a.fhK[ix]) + (a.n_scale ? a.fscale[ix] : 0.0);
+            }
+         }
          v = pattern_lnf(a, h);
          acc += v * a.weights[h];
       }
