@@ -110,6 +110,17 @@ int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double 
 int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
                         double *lnL);
 
+/* n_batch evaluations in one launch: the finite-difference loops of the optimiser (gradientB tools.c:6561, the forward /
+ * central differences of ming2 tools.c:6595 and of the Hessian, HessianSKT2004 treesub.c:7241) call com.plfun np (or 2np,
+ * np^2) times on the same data with one parameter nudged; here those calls become the elements of one batch.  Element b
+ * uses branch[b][n_nodes] and gene_rate[b][n_genes] (NULL = all 1) and, where a non-NULL table is given, its own
+ * eigen_of[b][n_genes][K][n_labels], qfactor[b][K][n_labels], freqK[b][K], rate[b][K] — layouts of one element as in
+ * paml_amd_set_classes; NULL = the tables set there, shared by all elements.  Eigen systems are referenced by set id, so
+ * a nudged kappa / omega is a further paml_amd_set_eigen_* id.  lnL[n_batch] comes back (+lnL each).  pi and the mode
+ * (lfun / lfundG) are those of the engine.  Not with PAML_AMD_KEEP_PARTIALS. */
+int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, const double *gene_rate, const int *eigen_of,
+                        const double *qfactor, const double *freqK, const double *rate, double *lnL);
+
 /* Branch-local evaluation = lfuntdd / lfuntdd_SiteClass (treesub.c:8204, 8403; lfunt / lfunt_SiteClass 8127, 8298 are
  * the lnL-only case), the function minbranches (treesub.c:8039) iterates with Newton steps: for the branch above
  * node_b, and for each of the n_t (<= 64) trial lengths t[], the log-likelihood and its first two derivatives in t,

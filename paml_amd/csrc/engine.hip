@@ -109,7 +109,7 @@ struct paml_amd_engine {
    int cleandata = 1, n_codes = 0;
    DevBuf<unsigned char> d_z, d_chara_map, d_is_leaf, d_ztiles;
    int zt_bytes = 0;
-   DevBuf<int> d_n_chara, d_gene_off, d_label, d_eigen_of;
+   DevBuf<int> d_n_chara, d_gene_off, d_label, d_eigen_of, d_b_eigen_of;
    DevBuf<int2> d_tiles, d_tiles_full;   // tile table of the selected kernel / of the full (gather or valu) kernel
    int n_tiles_full = 0;
    DevBuf<double> d_pi_plain;
@@ -133,6 +133,7 @@ struct paml_amd_engine {
    int mode = PAML_AMD_MODE_LFUN, K = 1, n_labels = 1;
 
    // per-evaluation buffers
+   DevBuf<double> d_b_qfactor, d_b_freqK, d_b_rate;
    DevBuf<double> d_rowmajor, d_pint, d_ptip, d_fhK, d_fscale, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
    DevBuf<double> d_expA, d_expB, d_deriv, d_tt, d_bpartial, d_bout;   // branch-local evaluation
    DevBuf<int> d_label_eff;
@@ -155,7 +156,7 @@ struct paml_amd_engine {
       for (auto ev : ev_used) (void)hipEventDestroy(ev);
       DevBuf<unsigned char> *b1[] = {&d_z, &d_chara_map, &d_is_leaf, &d_ztiles};
       for (auto b : b1) b->release();
-      DevBuf<int> *b2[] = {&d_n_chara, &d_gene_off, &d_label, &d_eigen_of};
+      DevBuf<int> *b2[] = {&d_n_chara, &d_gene_off, &d_label, &d_eigen_of, &d_b_eigen_of};
       for (auto b : b2) b->release();
       d_tiles.release();
       d_tiles_full.release();
@@ -166,7 +167,7 @@ struct paml_amd_engine {
       d_eigen.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_fhK, &d_fscale, &d_lnf, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
+                              &d_pint, &d_ptip, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
                               &d_expA, &d_expB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
    }
@@ -250,8 +251,18 @@ int build_tiles(paml_amd_engine *e)
    return 0;
 }
 
+// Batched evaluations: B parameter sets run as K*B classes of one launch (class index = b*K + iclass), so the pruning
+// kernels are unchanged; P(t) and the reduction index the per-element inputs.  Null members = shared set_classes values.
+struct BatchSpec {
+   int B;
+   const int *eigen_of;      // [B][n_genes][K][n_labels]
+   const double *qfactor;    // [B][K][n_labels]
+   const double *freqK;      // [B][K]
+   const double *rate;       // [B][K]
+};
+
 int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
-                double *d_lnL_out, bool want_lnf)
+                double *d_lnL_out, bool want_lnf, const BatchSpec *bs = nullptr)
 {
    if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes))
       return fail(e, PAML_AMD_EINVAL, "eval before set_tips/set_tree/set_pi/set_classes");
@@ -259,8 +270,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    const bool keep = (e->flags & PAML_AMD_KEEP_PARTIALS) != 0;
    if (clean && (!keep || !e->partials_valid))
       return fail(e, PAML_AMD_EINVAL, "eval_dirty needs PAML_AMD_KEEP_PARTIALS and a previous full evaluation");
-   const int n = e->n, nn = e->tree.n_nodes, K = e->K, G = e->n_genes;
+   const int B = bs ? bs->B : 1, Km = e->K;          // Km: classes of the model; K: classes the kernels see
+   const int n = e->n, nn = e->tree.n_nodes, K = Km * B, G = e->n_genes;
    const int psets = G * K;
+   if (B > 1 && (keep || clean)) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_batch: not with PAML_AMD_KEEP_PARTIALS");
 
    // program (tree walk) — rebuilt when the tree or the clean set changes
    const bool new_prog = !e->prog_valid || clean;
@@ -285,17 +298,39 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
 
    // small per-evaluation inputs go through the pinned arena: async H2D, no host stall
    {
-      const size_t need = (size_t)nn * 8 + (size_t)G * 8 + tab.size() * sizeof(EigenDev) +
+      const size_t L = (size_t)e->n_labels;
+      const size_t need = (size_t)B * nn * 8 + (size_t)B * G * 8 + tab.size() * sizeof(EigenDev) +
+                          (bs ? (size_t)B * (G * Km * L * 4 + Km * L * 8 + 2 * Km * 8) + 64 : 0) +
                           (new_prog ? e->prog.ops.size() * sizeof(Op) + e->prog.stream.size() * sizeof(int) : 0) + 256;
       HIPCHK(e->stage.begin(need));
-      HIPCHK(e->d_branch.ensure(nn));
-      HIPCHK(e->d_gene_rate.ensure(G));
-      const double *hb = e->stage.put(branch, nn);
-      HIPCHK(hipMemcpyAsync(e->d_branch.p, hb, (size_t)nn * 8, hipMemcpyHostToDevice, e->stream));
-      std::vector<double> gr(G, 1.0);
-      if (gene_rate) gr.assign(gene_rate, gene_rate + G);
-      const double *hg = e->stage.put(gr.data(), G);
-      HIPCHK(hipMemcpyAsync(e->d_gene_rate.p, hg, (size_t)G * 8, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(e->d_branch.ensure((size_t)B * nn));
+      HIPCHK(e->d_gene_rate.ensure((size_t)B * G));
+      const double *hb = e->stage.put(branch, (size_t)B * nn);
+      HIPCHK(hipMemcpyAsync(e->d_branch.p, hb, (size_t)B * nn * 8, hipMemcpyHostToDevice, e->stream));
+      std::vector<double> gr((size_t)B * G, 1.0);
+      if (gene_rate) gr.assign(gene_rate, gene_rate + (size_t)B * G);
+      const double *hg = e->stage.put(gr.data(), gr.size());
+      HIPCHK(hipMemcpyAsync(e->d_gene_rate.p, hg, gr.size() * 8, hipMemcpyHostToDevice, e->stream));
+      if (bs) {      // per-element class tables
+         if (bs->eigen_of) {
+            const size_t cnt = (size_t)B * G * Km * L;
+            for (size_t i = 0; i < cnt; i++)
+               if (bs->eigen_of[i] < 0 || bs->eigen_of[i] >= (int)e->eigen.size())
+                  return fail(e, PAML_AMD_EINVAL, "eval_batch: eigen_of entry out of range");
+            HIPCHK(e->d_b_eigen_of.ensure(cnt));
+            const int *h = e->stage.put(bs->eigen_of, cnt);
+            HIPCHK(hipMemcpyAsync(e->d_b_eigen_of.p, h, cnt * 4, hipMemcpyHostToDevice, e->stream));
+         }
+         const double *src[3] = {bs->qfactor, bs->freqK, bs->rate};
+         DevBuf<double> *dst[3] = {&e->d_b_qfactor, &e->d_b_freqK, &e->d_b_rate};
+         const size_t cnt[3] = {(size_t)B * Km * L, (size_t)B * Km, (size_t)B * Km};
+         for (int i = 0; i < 3; i++)
+            if (src[i]) {
+               HIPCHK(dst[i]->ensure(cnt[i]));
+               const double *h = e->stage.put(src[i], cnt[i]);
+               HIPCHK(hipMemcpyAsync(dst[i]->p, h, cnt[i] * 8, hipMemcpyHostToDevice, e->stream));
+            }
+      }
       if (!tab.empty()) {
          HIPCHK(e->d_eigen.ensure(tab.size()));
          const EigenDev *ht = e->stage.put(tab.data(), tab.size());
@@ -381,12 +416,16 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
 
    // Kernel A: batched P(t)
    PmatArgs pa{};
-   pa.n = n; pa.n_nodes = nn; pa.root = e->tree.root; pa.K = K; pa.n_genes = G; pa.n_labels = e->n_labels;
+   pa.n = n; pa.n_nodes = nn; pa.root = e->tree.root; pa.K = Km; pa.n_genes = G; pa.n_labels = e->n_labels;
    pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : 0;
    pa.label = e->d_label.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
    pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
    pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
    pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
+   pa.B = B; pa.branch_bs = nn; pa.gene_rate_bs = G;
+   if (bs && bs->eigen_of) { pa.eigen_of = e->d_b_eigen_of.p; pa.eigen_of_bs = (long)G * Km * e->n_labels; }
+   if (bs && bs->qfactor) { pa.qfactor = e->d_b_qfactor.p; pa.qfactor_bs = (long)Km * e->n_labels; }
+   if (bs && bs->rate) { pa.rate = e->d_b_rate.p; pa.rate_bs = Km; }
    mark(e);
    hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), e->stream, pa);
    mark(e);
@@ -472,17 +511,18 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // Kernel C: mixture + log + weighted sum
    const int chunk = std::max(256, ((e->n_patt + 1023) / 1024 + 255) / 256 * 256);
    const int nb = (e->n_patt + chunk - 1) / chunk;
-   HIPCHK(e->d_partial.ensure(nb));
-   HIPCHK(e->d_out.ensure(1));
+   HIPCHK(e->d_partial.ensure((size_t)nb * B));
+   HIPCHK(e->d_out.ensure(B));
    if (want_lnf) HIPCHK(e->d_lnf.ensure(e->n_patt));
    ReduceArgs ra{};
    ra.fhK = e->d_fhK.p; ra.weights = e->d_weights.p; ra.freqK = e->d_freqK.p; ra.lnf = want_lnf ? e->d_lnf.p : nullptr;
    ra.partial = e->d_partial.p; ra.out = d_lnL_out ? d_lnL_out : e->d_out.p;
    ra.raw = (e->kk == KK_MFMA64 && e->use_jit) ? 1 : 0; ra.fscale = e->d_fscale.p;
-   ra.n_patt = e->n_patt; ra.K = K; ra.mode = e->mode; ra.n_scale = e->tree.n_scale; ra.chunk = chunk;
+   ra.n_patt = e->n_patt; ra.K = Km; ra.mode = e->mode; ra.n_scale = e->tree.n_scale; ra.chunk = chunk;
+   if (bs && bs->freqK) { ra.freqK = e->d_b_freqK.p; ra.freqK_bs = Km; }
    mark(e);
-   hipLaunchKernelGGL(reduce_stage1, dim3(nb), dim3(256), 0, e->stream, ra);
-   hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(256), 0, e->stream, (const double *)e->d_partial.p, nb, ra.out);
+   hipLaunchKernelGGL(reduce_stage1, dim3(nb, B), dim3(256), 0, e->stream, ra);
+   hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)e->d_partial.p, nb, ra.out);
    mark(e);
    HIPCHK(hipGetLastError());
    if (e->profiling) e->prof_evals++;
@@ -797,6 +837,19 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
    return 0;
 }
 
+int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, const double *gene_rate, const int *eigen_of,
+                        const double *qfactor, const double *freqK, const double *rate, double *lnL)
+{
+   if (!e || !branch || !lnL || n_batch < 1) return fail(e, PAML_AMD_EINVAL, "eval_batch: bad arguments");
+   if ((long)n_batch * e->K * e->n_genes > 65535) return fail(e, PAML_AMD_EINVAL, "eval_batch: n_batch * K * n_genes > 65535");
+   BatchSpec bs{n_batch, eigen_of, qfactor, freqK, rate};
+   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, false, &bs);
+   if (r) return r;
+   HIPCHK(hipMemcpyAsync(lnL, e->d_out.p, (size_t)n_batch * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
 int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL)
 {
    if (!e || !branch || !d_lnL) return fail(e, PAML_AMD_EINVAL, "eval_device: null argument");
@@ -899,6 +952,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
    pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
    pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
+   pa.B = 1;
    hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), e->stream, pa);
    e->n_pmat += (long)psets * (nn - 1);
 

@@ -44,6 +44,10 @@ struct PmatArgs {
    double *pint;                 // layout 1: [pset][n_nodes][4096]
    double *ptip;                 // [pset][n_nodes][tip_words]   rows of n (VALU) or 64 (mfma64) doubles per code
    long tip_words;
+   // batched evaluations (paml_amd_eval_batch): B parameter sets in one launch, laid out as K*B classes; element b reads
+   // branch + b*branch_bs etc. (a stride of 0 = shared with the other elements)
+   int B;
+   long branch_bs, gene_rate_bs, eigen_of_bs, qfactor_bs, rate_bs;
 };
 
 __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
@@ -54,11 +58,12 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
    const int node = blockIdx.x, pset = blockIdx.y;
    if (node == a.root) return;
    const int tid = threadIdx.x, n = a.n;
-   const int gene = pset / a.K, iclass = pset % a.K;
+   const int KB = a.K * a.B;
+   const int gene = pset / KB, bat = (pset % KB) / a.K, iclass = pset % a.K;
    const int lab = a.label[node];
-   const EigenDev es = a.eigen[a.eigen_of[(gene * a.K + iclass) * a.n_labels + lab]];
-   double t = a.branch[node] * a.rate[iclass];
-   t *= a.gene_rate[gene];
+   const EigenDev es = a.eigen[a.eigen_of[bat * a.eigen_of_bs + (gene * a.K + iclass) * a.n_labels + lab]];
+   double t = a.branch[bat * a.branch_bs + node] * a.rate[bat * a.rate_bs + iclass];
+   t *= a.gene_rate[bat * a.gene_rate_bs + gene];
 
    const int j = tid & 63, rg = tid >> 6;   // this thread: column j, rows rg*16 .. rg*16+15
    double acc[16];
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
    for (int r = 0; r < 16; r++) acc[r] = 0;
 
    if (es.kind == PAML_AMD_EIGEN_UVROOT) {
-      t *= a.qfactor[iclass * a.n_labels + lab];
+      t *= a.qfactor[bat * a.qfactor_bs + iclass * a.n_labels + lab];
       if (t < 1e-100) {
 #pragma unroll
          for (int r = 0; r < 16; r++) acc[r] = (rg * 16 + r == j) ? 1.0 : 0.0;
@@ -732,6 +737,8 @@ struct ReduceArgs {
    const double *weights, *freqK;
    const double *fscale; // raw + n_scale: summed scale factors [K][n_patt]
    int raw;
+   long freqK_bs;        // batched evaluations: blockIdx.y = batch element; its classes, partial sums and output follow
+                         // element 0's at strides K*n_patt, gridDim.x and 1; freqK at freqK_bs (0 = shared)
    double *lnf;        // optional [n_patt]
    double *partial;    // [gridDim.x]
    double *out;        // scalar
@@ -773,6 +780,14 @@ __global__ __launch_bounds__(128) void ztile_kernel(const int2 *tiles, const int
 __global__ __launch_bounds__(256) void reduce_stage1(ReduceArgs a)
 {
    __shared__ double sw[4];
+   if (blockIdx.y) {
+      const long off = (long)blockIdx.y * a.K * a.n_patt;
+      a.fhK += off;
+      if (a.fscale) a.fscale += off;
+      a.freqK += blockIdx.y * a.freqK_bs;
+      a.partial += blockIdx.y * gridDim.x;
+      a.lnf = nullptr;
+   }
    const int lo = blockIdx.x * a.chunk;
    const int hi = min(a.n_patt, lo + a.chunk);
    double acc = 0;
@@ -801,6 +816,8 @@ __global__ __launch_bounds__(256) void reduce_stage2(const double *partial, int 
 {
    __shared__ double sw[4];
    double acc = 0;
+   partial += (long)blockIdx.x * nb;      // one block per batch element
+   out += blockIdx.x;
    for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
 #pragma unroll
    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);

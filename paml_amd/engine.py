@@ -25,7 +25,7 @@ EXPORTS = [
     "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_classes", "paml_amd_eval",
-    "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
+    "paml_amd_eval_batch", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
@@ -192,6 +192,26 @@ class Engine:
         fhk = np.zeros((self.K, self.n_patt)) if want_fhk else None
         self._chk(self._L.paml_amd_eval(self._h, _p(b), _p(g), C.byref(lnL), _p(lnf), _p(fhk)))
         return dict(lnL=lnL.value, lnf=lnf, fhK=fhk)
+
+    def eval_batch(self, branch, gene_rate=None, eigen_of=None, qfactor=None, freqK=None, rate=None):
+        """lnL of every row of branch[n_batch][n_nodes] in one launch (paml_amd_eval_batch); the optional tables carry
+        one leading batch axis over the layouts of set_classes."""
+        b = np.ascontiguousarray(branch, dtype=np.float64)
+        assert b.ndim == 2
+        nb = b.shape[0]
+
+        def opt(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt)
+            assert a.shape[0] == nb
+            return a
+        g, eo = opt(gene_rate, np.float64), opt(eigen_of, np.int32)
+        qf, fk, rt = opt(qfactor, np.float64), opt(freqK, np.float64), opt(rate, np.float64)
+        out = np.zeros(nb)
+        self._L.paml_amd_eval_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        self._chk(self._L.paml_amd_eval_batch(self._h, nb, _p(b), _p(g), _p(eo), _p(qf), _p(fk), _p(rt), _p(out)))
+        return out
 
     def eval_device(self, branch, d_lnL_ptr, gene_rate=None):
         b = np.ascontiguousarray(branch, dtype=np.float64)

@@ -250,6 +250,9 @@ CASES = {
     "hiv_m7": lambda: case_hiv("m7"), "hiv_m8": lambda: case_hiv("m8"),
     "stewart_lg_g4": case_stewart, "mhc_m0_scaled": case_mhc,
     "syn_codon_m0": case_syn_codon, "syn_nuc_gtr_g4": case_syn_nuc, "brown_hky85": case_brown,
+    # BASELINE configs[3] / configs[1] at full size (reference: ~2 min and 6.8 GB / ~2 s): lnL + strided log f_h sample
+    "syn_codon_m0_full": lambda: case_syn_codon(1_000_000, "syn_codon_m0_full", sample=997),
+    "syn_nuc_gtr_g4_full": lambda: case_syn_nuc(100_000, "syn_nuc_gtr_g4_full", sample=97),
 }
 
 if __name__ == "__main__":

@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP engine (through the C ABI) against the oracle on the same seeded
 inputs and against the reference-generated golden vectors.  FP64 throughout; tolerance 1e-10 relative
 on lnL (north_star asks for 1e-6), 1e-9 absolute on per-pattern log f_h."""
+import copy
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,7 @@ import helpers
 import oracle
 from paml_amd import synth
 from paml_amd.engine import KEEP_PARTIALS, engine_for
+from paml_amd.problem import Tree
 
 pytestmark = pytest.mark.gpu
 
@@ -188,6 +191,19 @@ def test_full_size_properties_c4():
     assert abs(out2["lnL"] - out["lnL"]) < 1e-9 * abs(out["lnL"])
 
 
+@pytest.mark.parametrize("name", ["syn_nuc_gtr_g4_full", "syn_codon_m0_full"])
+def test_full_size_against_reference(name):
+    """BASELINE configs[1] and configs[3] at full size against the reference binary's own numbers for the same seeded
+    data (tests/golden/*_full.json: lnL, sum and a strided sample of per-pattern log f_h)."""
+    g = helpers.load_golden(name)
+    pb = helpers.problem_from_golden(g)
+    out = engine_for(pb).eval(pb.tree.branch, want_lnf=True)
+    assert abs(out["lnL"] - g["lnL"]) <= 2e-6 + 1e-12 * abs(g["lnL"]), (out["lnL"], g["lnL"])      # 6 printed decimals
+    assert abs(out["lnf"].sum() - g["logf_sum"]) < 1e-4
+    idx = np.arange(0, pb.n_patt, g["sample_stride"])
+    assert np.max(np.abs(out["lnf"][idx] - np.array(g["logf_sample"]))) < 2e-8                   # 10 printed decimals
+
+
 @pytest.mark.parametrize("n,K,amb,genes", [(4, 1, False, 1), (4, 4, True, 2), (20, 2, False, 1), (61, 1, False, 1), (61, 3, True, 1)])
 def test_eval_branch_matches_oracle(n, K, amb, genes):
     """paml_amd_eval_branch (lfuntdd / lfuntdd_SiteClass) against the oracle for tip and internal branches, several trial
@@ -208,3 +224,49 @@ def test_eval_branch_matches_oracle(n, K, amb, genes):
         assert abs(l[0] - base) <= 1e-11 * abs(base)           # l(t_current) is the tree's lnL
     again = eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]
     assert again == base
+
+
+@pytest.mark.parametrize("n,K,amb,genes", [(4, 4, False, 2), (20, 2, True, 1), (61, 1, False, 1), (61, 3, True, 1)])
+def test_eval_batch_matches_single_evals(n, K, amb, genes):
+    """paml_amd_eval_batch: every element of a batch (own branch lengths, gene rates, class frequencies / rates) gives
+    exactly the lnL of the corresponding single evaluation, and the oracle's."""
+    pb = helpers.random_problem(n, 10, 300, K=K, seed=80 + n + K, ambiguity=amb, n_genes=genes)
+    eng = engine_for(pb)
+    rng = np.random.default_rng(5)
+    B = 7
+    br = np.abs(pb.tree.branch[None, :] * (1 + 0.3 * rng.standard_normal((B, pb.tree.n_nodes))))
+    br[0] = pb.tree.branch
+    gr = pb.gene_rate[None, :] * (1 + 0.1 * rng.random((B, pb.n_genes)))
+    fk = rng.dirichlet(np.ones(pb.K), size=B)
+    rt = pb.rate[None, :] * (1 + 0.2 * rng.random((B, pb.K)))
+    fk[0], rt[0], gr[0] = pb.freqK, pb.rate, pb.gene_rate
+    got = eng.eval_batch(br, gene_rate=gr, freqK=fk, rate=rt)
+    assert abs(got[0] - oracle.evaluate(pb)["lnL"]) <= 1e-10 * abs(got[0])
+    for b in range(B):
+        q = copy.copy(pb)
+        q.freqK, q.rate, q.gene_rate = fk[b].copy(), rt[b].copy(), gr[b].copy()
+        q.tree = Tree(pb.tree.n_tips, pb.tree.n_nodes, pb.tree.root, pb.tree.sons, br[b].copy(), pb.tree.label)
+        ref = oracle.evaluate(q)["lnL"]
+        assert abs(got[b] - ref) <= 1e-10 * abs(ref), (b, got[b], ref)
+    # shared tables (NULL) and a plain evaluation afterwards
+    got2 = eng.eval_batch(br, gene_rate=np.tile(pb.gene_rate, (B, 1)))
+    one = eng.eval(br[3], pb.gene_rate)["lnL"]
+    assert got2[3] == one
+
+
+def test_eval_batch_per_element_eigen_sets():
+    """Batch elements that point at different eigen systems (a nudged kappa/omega is another set id)."""
+    pb = helpers.random_problem(61, 8, 200, K=1, seed=91)
+    pb2 = helpers.random_problem(61, 8, 200, K=1, seed=92)          # same shapes, different Q
+    both = copy.copy(pb)
+    both.eigen = [pb.eigen[0], pb2.eigen[0]]
+    eng = engine_for(both)
+    br = np.stack([pb.tree.branch, pb.tree.branch * 1.1, pb.tree.branch])
+    eo = np.array([0, 1, 1], dtype=np.int32).reshape(3, 1, 1, 1)
+    got = eng.eval_batch(br, eigen_of=eo)
+    for b in range(3):
+        q = copy.copy(both)
+        q.eigen_of = np.full_like(both.eigen_of, eo[b].ravel()[0])
+        q.tree = Tree(pb.tree.n_tips, pb.tree.n_nodes, pb.tree.root, pb.tree.sons, br[b].copy(), pb.tree.label)
+        ref = oracle.evaluate(q)["lnL"]
+        assert abs(got[b] - ref) <= 1e-10 * abs(ref), (b, got[b], ref)

@@ -44,3 +44,27 @@ def test_oracle_branch_derivatives_match_pinned_lnl(n, K):
             assert abs(l[i] - f(t)) <= 1e-11 * abs(l[i])
             assert abs(dl[i] - (f(t + e) - f(t - e)) / (2 * e)) <= 2e-5 * max(1.0, abs(dl[i]))
             assert abs(ddl[i] - (f(t + e) - 2 * f(t) + f(t - e)) / e ** 2) <= 2e-3 * max(1.0, abs(ddl[i]))
+
+
+@pytest.mark.parametrize("name", ["syn_nuc_gtr_g4_full", "syn_codon_m0_full"])
+def test_oracle_matches_reference_full_size(name):
+    """BASELINE configs[1] / configs[3] at full size (32 taxa x 1e5 nucleotide, 16 taxa x 1e6 codon patterns): the
+    reference binary was run once on the seeded generator's data (make_golden.py); its lnL, the sum and a strided
+    sample of its per-pattern log f_h are committed.  The oracle is checked on the sample (and, for the cheap
+    nucleotide case, on the whole lnL)."""
+    g = helpers.load_golden(name)
+    pb = helpers.problem_from_golden(g)
+    assert pb.n_patt == g["n_patt"]
+    idx = np.arange(0, pb.n_patt, g["sample_stride"])
+    if pb.n == 4:
+        r = oracle.evaluate(pb, nthreads=4)
+        assert abs(r["lnL"] - g["lnL"]) <= 2e-6 + 1e-12 * abs(g["lnL"])
+        assert abs(r["lnf"].sum() - g["logf_sum"]) < 1e-4
+        lnf = r["lnf"][idx]
+    else:
+        sub = pb.slice_patterns(0, pb.n_patt)
+        sub.z = np.ascontiguousarray(pb.z[:, idx])
+        sub.weights = np.ascontiguousarray(pb.weights[idx])
+        sub.gene_off = np.array([0, len(idx)], dtype=np.int32)
+        lnf = oracle.evaluate(sub)["lnf"]
+    assert np.max(np.abs(lnf - np.array(g["logf_sample"]))) < 2e-8
