@@ -54,6 +54,28 @@ def main():
         dt, prof, lnl = timed(eng, pb.tree.branch, 200)
         out.append(dict(case="C5 " + name, kernel=eng.kernel_name, K=pb.K, ms_per_eval=dt * 1e3, n_pmat=pb.K * 23, lnL=lnl,
                         golden_lnL=g["lnL"], **prof))
+    # C5 gradient: np+1 = 26 branch-length sets in one launch (paml_amd_eval_batch) vs 26 single evaluations
+    for name in ("hiv_m0", "hiv_m8"):
+        g = helpers.load_golden(name)
+        pb = helpers.problem_from_golden(g)
+        eng = engine.engine_for(pb)
+        nb = pb.tree.n_nodes
+        br = np.tile(pb.tree.branch, (nb + 1, 1))
+        for i in range(nb):
+            br[i + 1, i] *= 1 + 1e-6
+        for _ in range(3):
+            eng.eval_batch(br)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            lb = eng.eval_batch(br)
+        dtb = (time.perf_counter() - t0) / 50
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ls = [eng.eval(b)["lnL"] for b in br]
+        dts = (time.perf_counter() - t0) / 5
+        out.append(dict(case="C5 %s forward-difference gradient, %d evaluations" % (name, nb + 1), K=pb.K, kernel=eng.kernel_name,
+                        ms_batched=dtb * 1e3, ms_one_by_one=dts * 1e3, us_per_eval_batched=dtb * 1e6 / (nb + 1),
+                        max_abs_diff=float(np.max(np.abs(lb - np.array(ls))))))
     # NSsites sweep on C4 data
     base = synth.codon_m0_problem(n_tips=16, n_patt=1_000_000)
     for K in (1, 2, 3, 10, 11):
