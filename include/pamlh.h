@@ -58,6 +58,16 @@ int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const 
 
 /* One likelihood evaluation on the GPU through the engine ABI (creates the engine on first use).  lnf may be NULL. */
 int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf);
+/* lnL at n_batch parameter vectors xs[n_batch][np] in ONE launch (paml_amd_eval_batch): vectors that differ only in branch
+ * lengths share one model set-up; vectors the model rejects get -1e300. */
+int pamlh_eval_batch_gpu(pamlh *p, int n_batch, const double *xs, double *lnL);
+/* Box constraints of x[] as SetxBound sets them (codeml.c:1880, baseml.c:1100). */
+int pamlh_bounds(const pamlh *p, double *lo, double *hi);
+/* Maximum-likelihood estimation (the job of ming2, tools.c:6595): BFGS in the box, every gradient (2 np central
+ * differences) and every line search (12 trial steps) evaluated as one batch on the GPU.  x: start in, estimate out.
+ * Returns 0 converged, 1 max_iter reached, < 0 error.  n_eval (may be NULL): likelihood evaluations spent. */
+int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, int verbose, int *n_eval);
+
 /* Write the reference's `lnf` file layout (print_lnf_site treesub.c:7598) for the last pamlh_eval_gpu. */
 int pamlh_write_lnf(const pamlh *p, const char *path, const double *lnf);
 

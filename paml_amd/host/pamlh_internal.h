@@ -5,6 +5,7 @@
 #include "../../include/pamlh.h"
 
 #define PAMLH_MAXOPT 64
+enum { JC69, K80, F81, F84, HKY85, T92, TN93, REV };   /* baseml models (baseml.ctl) */
 
 typedef struct {
    char key[32][PAMLH_MAXOPT], val[256][PAMLH_MAXOPT];
@@ -67,4 +68,6 @@ double pamlh_optd(const pamlh *p, const char *key, double dflt);
 int pamlh_read_seqs(pamlh *p);
 int pamlh_read_tree(pamlh *p);
 int pamlh_fail(pamlh *p, const char *fmt, ...);
+int pamlh_engine_ready(pamlh *p);
+int pamlh_model_feasible(const pamlh *p);
 #endif

@@ -1,9 +1,10 @@
 /* pamlh_lnl — command-line driver: one likelihood evaluation of a codeml/baseml analysis on the MI355X.
- *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [x0 x1 ...]
+ *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [x0 x1 ...]
  * Reads the control file, the sequence and tree files it names, and the parameter vector from the command line,
  * else from in.codeml / in.baseml beside the ctl (the reference's "-1 x..." single-evaluation recipe, treesub.c:4057),
  * else the ctl's initial values; evaluates lnL through libpaml_amd.so; prints `lnL = ...` like the reference and
- * writes the per-pattern `lnf` file in the reference's layout. */
+ * writes the per-pattern `lnf` file in the reference's layout.  With --optimize the vector is the starting point of a
+ * maximum-likelihood search (pamlh_optimize: BFGS with batched finite differences) and the estimates are printed. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -15,14 +16,24 @@ int main(int argc, char **argv)
    pamlh *p;
    char err[512];
    double x[4096], lnL, *lnf;
-   int np, ntime, npatt, i, nx = 0;
-   if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [x...]\n", argv[0]); return 2; }
+   int np, ntime, npatt, i, nx = 0, optimize = 0;
+   if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [x...]\n", argv[0]); return 2; }
    if (pamlh_load(&p, argv[2], argv[1], err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
    pamlh_dims(p, NULL, NULL, &npatt, NULL, NULL, NULL, NULL, NULL, &np, &ntime);
-   for (i = 3; i < argc && nx < 4096; i++) x[nx++] = atof(argv[i]);
+   for (i = 3; i < argc && nx < 4096; i++) {
+      if (!strcmp(argv[i], "--optimize")) optimize = 1;
+      else x[nx++] = atof(argv[i]);
+   }
    if (!nx) nx = pamlh_read_inx(p, x, 4096);
    if (!nx) nx = pamlh_default_x(p, x, 4096);
    if (nx != np) { fprintf(stderr, "error: the model has %d parameters (ntime %d) but %d values were given\n", np, ntime, nx); return 1; }
+   if (optimize) {
+      int n_eval = 0, rc = pamlh_optimize(p, x, &lnL, 500, 1e-10, 1, &n_eval);
+      if (rc < 0) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
+      printf("%s after %d likelihood evaluations\nx:", rc ? "iteration limit reached" : "converged", n_eval);
+      for (i = 0; i < np; i++) printf(" %.6f", x[i]);
+      printf("\n");
+   }
    if (pamlh_set_x(p, x, np)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
    lnf = (double *)malloc(npatt * sizeof(double));
    if (pamlh_eval_gpu(p, &lnL, lnf)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }

@@ -12,7 +12,6 @@
 #include "pamlh_internal.h"
 
 static const char STDCODE[] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
-enum { JC69, K80, F81, F84, HKY85, T92, TN93, REV };   /* baseml models (baseml.ctl) */
 
 static double dist2(const double *a, const double *b, int n)
 {
@@ -529,15 +528,31 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
    return 0;
 }
 
+/* the engine for this data set and tree (created on first use) */
+int pamlh_engine_ready(pamlh *p)
+{
+   int rc;
+   if (p->eng) return 0;
+   if ((rc = paml_amd_create(&p->eng, p->n, p->ns, p->npatt, 64, 1, 0))) return pamlh_fail(p, "paml_amd_create failed (%d): no GPU?", rc);
+   if ((rc = paml_amd_set_tips(p->eng, p->z, p->cleandata, p->n_codes, p->n_chara, p->chara_map, p->w, NULL)) ||
+       (rc = paml_amd_set_tree(p->eng, p->nnode, p->root, p->sons_ptr, p->sons, p->label, p->scale)))
+      return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   return 0;
+}
+
+/* class proportions of the current model state are a probability vector */
+int pamlh_model_feasible(const pamlh *p)
+{
+   int i;
+   for (i = 0; i < p->K; i++)
+      if (!(p->freqK[i] >= 0)) return 0;
+   return 1;
+}
+
 int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
 {
    int i, rc;
-   if (!p->eng) {
-      if ((rc = paml_amd_create(&p->eng, p->n, p->ns, p->npatt, 64, 1, 0))) return pamlh_fail(p, "paml_amd_create failed (%d): no GPU?", rc);
-      if ((rc = paml_amd_set_tips(p->eng, p->z, p->cleandata, p->n_codes, p->n_chara, p->chara_map, p->w, NULL)) ||
-          (rc = paml_amd_set_tree(p->eng, p->nnode, p->root, p->sons_ptr, p->sons, p->label, p->scale)))
-         return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
-   }
+   if ((rc = pamlh_engine_ready(p))) return rc;
    if ((rc = paml_amd_set_pi(p->eng, 1, p->pi))) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    for (i = 0; i < p->n_eigen; i++) {
       const pamlh_eig *e = &p->eig[i];

@@ -11,8 +11,12 @@
 
 #include "pamlh_internal.h"
 
-/* Cyclic Jacobi: A (n x n symmetric, destroyed) -> eigenvalues w[n], eigenvectors R[i*n+k] (column k). */
-void pamlh_eigen_sym(double *A, int n, double *w, double *R)
+/* Symmetric eigenproblem: A (n x n symmetric, destroyed) -> eigenvalues w[n], eigenvectors R[i*n+k] (column k).
+ * Householder reduction to tridiagonal form, then QL iterations with implicit Wilkinson shifts on the tridiagonal
+ * matrix, accumulating the rotations into R (O(n^3) with a small constant: ~0.3 ms at n = 61, which matters because
+ * every NSsites class of every trial point of an optimisation needs one).  Falls back to cyclic Jacobi if the QL
+ * iteration does not settle. */
+static void jacobi_sym(double *A, int n, double *w, double *R)
 {
    int i, j, k, sweep;
    for (i = 0; i < n; i++)
@@ -50,6 +54,100 @@ void pamlh_eigen_sym(double *A, int n, double *w, double *R)
          }
    }
    for (i = 0; i < n; i++) w[i] = A[i * n + i];
+}
+
+void pamlh_eigen_sym(double *A, int n, double *w, double *R)
+{
+   double *dg = w, *e = (double *)malloc(n * sizeof(double)), *v = (double *)malloc(n * sizeof(double));
+   double *pv = (double *)malloc(n * sizeof(double)), *A0 = (double *)malloc((size_t)n * n * sizeof(double));
+   int i, j, k, l, m, ok = 1;
+   memcpy(A0, A, (size_t)n * n * sizeof(double));
+   /* R accumulates Q = H_0 H_1 ... with A = Q T Q^T */
+   for (i = 0; i < n; i++)
+      for (j = 0; j < n; j++) R[i * n + j] = (i == j);
+   for (k = 0; k < n - 2; k++) {
+      /* reflector that zeroes column k below the subdiagonal */
+      double alpha, norm2 = 0, vnorm2, beta, kfac = 0;
+      for (i = k + 1; i < n; i++) norm2 += A[i * n + k] * A[i * n + k];
+      if (norm2 == 0) continue;
+      alpha = A[(k + 1) * n + k] > 0 ? -sqrt(norm2) : sqrt(norm2);
+      for (i = 0; i < n; i++) v[i] = 0;
+      v[k + 1] = A[(k + 1) * n + k] - alpha;
+      for (i = k + 2; i < n; i++) v[i] = A[i * n + k];
+      vnorm2 = norm2 - A[(k + 1) * n + k] * A[(k + 1) * n + k] + v[k + 1] * v[k + 1];
+      if (vnorm2 == 0) continue;
+      beta = 2 / vnorm2;
+      /* A <- H A H with H = I - beta v v^T:  p = beta A v,  q = p - (beta/2)(p.v) v,  A -= v q^T + q v^T */
+      /* (rows and columns < k are already tridiagonal and v is zero up to k: only the trailing block changes) */
+      for (i = k; i < n; i++) {
+         double t = 0;
+         for (j = k + 1; j < n; j++) t += A[i * n + j] * v[j];
+         pv[i] = beta * t;
+      }
+      for (i = k + 1; i < n; i++) kfac += pv[i] * v[i];
+      kfac *= beta / 2;
+      for (i = k; i < n; i++) pv[i] -= kfac * v[i];
+      for (i = k; i < n; i++)
+         for (j = k; j < n; j++) A[i * n + j] -= v[i] * pv[j] + pv[i] * v[j];
+      /* R <- R H */
+      for (i = 0; i < n; i++) {
+         double t = 0;
+         for (j = k + 1; j < n; j++) t += R[i * n + j] * v[j];
+         t *= beta;
+         for (j = k + 1; j < n; j++) R[i * n + j] -= t * v[j];
+      }
+   }
+   for (i = 0; i < n; i++) dg[i] = A[i * n + i];
+   for (i = 0; i + 1 < n; i++) e[i] = A[(i + 1) * n + i];
+   if (n > 0) e[n - 1] = 0;
+   /* QL with implicit shifts on (dg, e); rotations act on pairs of eigenvector columns: work on the transpose so that
+    * they are contiguous rows */
+   for (i = 0; i < n; i++)
+      for (j = i + 1; j < n; j++) { const double t = R[i * n + j]; R[i * n + j] = R[j * n + i]; R[j * n + i] = t; }
+   for (l = 0; l < n && ok; l++) {
+      int iter = 0;
+      for (;;) {
+         for (m = l; m + 1 < n; m++) {
+            const double dd = fabs(dg[m]) + fabs(dg[m + 1]);
+            if (fabs(e[m]) <= 2.3e-16 * dd) break;
+         }
+         if (m == l) break;
+         if (++iter > 60) { ok = 0; break; }
+         {
+            double g = (dg[l + 1] - dg[l]) / (2 * e[l]), r = hypot(g, 1.0), s = 1, c = 1, pp = 0;
+            g = dg[m] - dg[l] + e[l] / (g + (g >= 0 ? fabs(r) : -fabs(r)));
+            for (i = m - 1; i >= l; i--) {
+               double f = s * e[i], bb = c * e[i];
+               r = hypot(f, g);
+               e[i + 1] = r;
+               if (r == 0) { dg[i + 1] -= pp; e[m] = 0; break; }
+               s = f / r;
+               c = g / r;
+               g = dg[i + 1] - pp;
+               r = (dg[i] - g) * s + 2 * c * bb;
+               pp = s * r;
+               dg[i + 1] = g + pp;
+               g = c * r - bb;
+               {
+                  double *r0 = R + (size_t)i * n, *r1 = r0 + n;
+                  for (k = 0; k < n; k++) {
+                     const double t = r1[k];
+                     r1[k] = s * r0[k] + c * t;
+                     r0[k] = c * r0[k] - s * t;
+                  }
+               }
+            }
+            if (r == 0 && i >= l) continue;
+            dg[l] -= pp;
+            e[l] = g;
+            e[m] = 0;
+         }
+      }
+   }
+   for (i = 0; i < n; i++)
+      for (j = i + 1; j < n; j++) { const double t = R[i * n + j]; R[i * n + j] = R[j * n + i]; R[j * n + i] = t; }
+   if (!ok) jacobi_sym(A0, n, w, R);
+   free(e); free(v); free(pv); free(A0);
 }
 
 /* Reversible Q = S diag(pi): Root (descending), U, V with Q = U diag(Root) V  (tools.c:5023-5110).

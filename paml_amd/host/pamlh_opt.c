@@ -1,0 +1,271 @@
+/* pamlh_opt.c — maximum-likelihood estimation on top of the batched evaluation of the engine.
+ *
+ * The reference minimises -lnL with ming2 (tools.c:6595): BFGS, gradients by finite differences (gradientB tools.c:6561,
+ * np or 2np calls of com.plfun per gradient, one after the other) and a line search of single evaluations (LineSearch2
+ * tools.c:6279).  On the GPU one evaluation of a small data set is launch-latency bound, so the same mathematics is
+ * arranged around paml_amd_eval_batch: all 2np central-difference points of a gradient are one launch, and all trial
+ * step lengths of a line search are another.  Bounds follow SetxBound (codeml.c:1880, baseml.c:1100).  Written fresh;
+ * only the published algorithm (BFGS with a box) is shared with the reference.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pamlh_internal.h"
+
+static int upload_eigen(pamlh *p, int base)
+{
+   int i, rc = 0;
+   for (i = 0; i < p->n_eigen && !rc; i++) {
+      const pamlh_eig *e = &p->eig[i];
+      if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, base + i, e->U, e->V, e->Root);
+      else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(p->eng, base + i, e->nR, e->Cijk, e->Root);
+      else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(p->eng, base + i, e->kappa);
+      else rc = paml_amd_set_eigen_jc69like(p->eng, base + i);
+   }
+   return rc ? pamlh_fail(p, "%s", paml_amd_last_error(p->eng)) : 0;
+}
+
+/* lnL at nb parameter vectors xs[nb][np] in one launch.  Vectors whose substitution-model part (x[ntime..np)) is equal
+ * share one model set-up (eigen decompositions are the host's expensive part); a vector the model rejects
+ * (e.g. class proportions summing above 1) gets lnL = -1e300. */
+int pamlh_eval_batch_gpu(pamlh *p, int nb, const double *xs, double *lnL)
+{
+   const int np = p->np, nt = p->ntime, nm = np - nt, nn = p->nnode;
+   int *rep_of = (int *)malloc(nb * sizeof(int)), *rep_elem = (int *)malloc(nb * sizeof(int)), nrep = 0, b, r, i, rc = 0;
+   int K = 0, n_eigen = 0, mode = 0;
+   double *br = (double *)calloc((size_t)nb * nn, sizeof(double)), *fk = NULL, *rt = NULL, *rep_fk = NULL, *rep_rt = NULL;
+   int *eo = NULL, *rep_eo = NULL;
+   if ((rc = pamlh_engine_ready(p))) goto done;
+   for (b = 0; b < nb; b++) {
+      const double *x = xs + (size_t)b * np;
+      for (r = 0; r < nrep; r++)
+         if (!nm || !memcmp(x + nt, xs + (size_t)rep_elem[r] * np + nt, nm * sizeof(double))) break;
+      if (r == nrep) {
+         if (pamlh_set_x(p, x, np) || !pamlh_model_feasible(p)) { rep_of[b] = -1; continue; }
+         if (!nrep) {
+            K = p->K; n_eigen = p->n_eigen; mode = p->mode;
+            rep_fk = (double *)malloc((size_t)nb * K * sizeof(double));
+            rep_rt = (double *)malloc((size_t)nb * K * sizeof(double));
+            rep_eo = (int *)malloc((size_t)nb * K * sizeof(int));
+         }
+         else if (p->K != K || p->n_eigen != n_eigen || p->mode != mode) { rc = pamlh_fail(p, "internal: model shape changed inside a batch"); goto done; }
+         if ((nrep + 1) * n_eigen > 4096) { rc = pamlh_fail(p, "batch needs more than 4096 eigen systems"); goto done; }
+         if ((rc = upload_eigen(p, nrep * n_eigen))) goto done;
+         memcpy(rep_fk + (size_t)nrep * K, p->freqK, K * sizeof(double));
+         memcpy(rep_rt + (size_t)nrep * K, p->rate, K * sizeof(double));
+         for (i = 0; i < K; i++) rep_eo[(size_t)nrep * K + i] = nrep * n_eigen + p->eigen_of[i];
+         rep_elem[nrep++] = b;
+      }
+      rep_of[b] = r;
+   }
+   if (!nrep) { for (b = 0; b < nb; b++) lnL[b] = -1e300; goto done; }
+   fk = (double *)malloc((size_t)nb * K * sizeof(double));
+   rt = (double *)malloc((size_t)nb * K * sizeof(double));
+   eo = (int *)malloc((size_t)nb * K * sizeof(int));
+   for (b = 0; b < nb; b++) {
+      const double *x = xs + (size_t)b * np;
+      r = rep_of[b] < 0 ? 0 : rep_of[b];
+      memcpy(fk + (size_t)b * K, rep_fk + (size_t)r * K, K * sizeof(double));
+      memcpy(rt + (size_t)b * K, rep_rt + (size_t)r * K, K * sizeof(double));
+      memcpy(eo + (size_t)b * K, rep_eo + (size_t)r * K, K * sizeof(int));
+      for (i = 0; i < p->nbranch; i++) {
+         const int node = p->branch_node[i];
+         br[(size_t)b * nn + node] = nt ? x[i] : p->tree_branch[node];
+      }
+   }
+   if ((rc = paml_amd_set_pi(p->eng, 1, p->pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, 1, rep_eo, NULL)) ||
+       (rc = paml_amd_eval_batch(p->eng, nb, br, NULL, eo, NULL, fk, rt, lnL))) {
+      rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+      goto done;
+   }
+   for (b = 0; b < nb; b++)
+      if (rep_of[b] < 0 || !(lnL[b] == lnL[b])) lnL[b] = -1e300;
+done:
+   free(rep_of); free(rep_elem); free(br); free(fk); free(rt); free(eo); free(rep_fk); free(rep_rt); free(rep_eo);
+   return rc;
+}
+
+/* Box for x[] (SetxBound codeml.c:1880-1960, baseml.c:1100-1150): branch lengths [4e-6, 50], kappa and omega
+ * [1e-4, 999], proportions (0, 1), beta and gamma shape parameters [0.005, 99], REV rates [1e-4, 999]. */
+int pamlh_bounds(const pamlh *p, double *lo, double *hi)
+{
+   int k = 0, i;
+   for (i = 0; i < p->ntime; i++) { lo[k] = 4e-6; hi[k++] = 50; }
+   if (p->seqtype == 1) {
+      if (!p->fix_kappa) { lo[k] = 1e-4; hi[k++] = 999; }
+      if (p->nssites == 0) { if (!p->fix_omega) { lo[k] = 1e-4; hi[k++] = 999; } }
+      else if (p->nssites == 1) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 1e-6; hi[k++] = 1; }
+      else if (p->nssites == 2) {
+         lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 1e-6; hi[k++] = 1 - 1e-6;
+         lo[k] = 1e-6; hi[k++] = 1; lo[k] = 1; hi[k++] = 999;
+      }
+      else if (p->nssites == 7) { lo[k] = 0.005; hi[k++] = 99; lo[k] = 0.005; hi[k++] = 99; }
+      else if (p->nssites == 8) {
+         lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 0.005; hi[k++] = 99; lo[k] = 0.005; hi[k++] = 99;
+         if (!p->fix_omega) { lo[k] = 1; hi[k++] = 999; }
+      }
+   }
+   else if (p->seqtype == 0) {
+      const int nk = ((p->model == K80 || p->model == HKY85) && !p->fix_kappa) ? 1 : (p->model == TN93 && !p->fix_kappa) ? 2 : p->model == REV ? 5 : 0;
+      for (i = 0; i < nk; i++) { lo[k] = 1e-4; hi[k++] = 999; }
+   }
+   if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) { lo[k] = 0.005; hi[k++] = 99; }
+   return k == p->np ? 0 : -1;
+}
+
+static double dot(const double *a, const double *b, int n)
+{
+   double s = 0;
+   int i;
+   for (i = 0; i < n; i++) s += a[i] * b[i];
+   return s;
+}
+
+/* Central-difference gradient of f = -lnL at x (one batch of <= 2 np points; one-sided where the box is in the way). */
+static int gradient(pamlh *p, const double *x, double f0, const double *lo, const double *hi, double *g, double *xs, double *ls, int *n_eval)
+{
+   const int n = p->np;
+   int i, rc;
+   for (i = 0; i < n; i++) {
+      const double h = 1e-6 * (fabs(x[i]) + 1);
+      double *xp = xs + (size_t)(2 * i) * n, *xm = xp + n;
+      memcpy(xp, x, n * sizeof(double));
+      memcpy(xm, x, n * sizeof(double));
+      if (x[i] + h <= hi[i]) xp[i] = x[i] + h;
+      if (x[i] - h >= lo[i]) xm[i] = x[i] - h;
+   }
+   if ((rc = pamlh_eval_batch_gpu(p, 2 * n, xs, ls))) return rc;
+   *n_eval += 2 * n;
+   for (i = 0; i < n; i++) {
+      const double *xp = xs + (size_t)(2 * i) * n, *xm = xp + n;
+      const double fp = xp[i] != x[i] ? -ls[2 * i] : f0, fm = xm[i] != x[i] ? -ls[2 * i + 1] : f0;
+      g[i] = xp[i] > xm[i] ? (fp - fm) / (xp[i] - xm[i]) : 0;
+   }
+   return 0;
+}
+
+/* Maximise lnL over x (in: start, out: estimate).  Returns 0 when converged, 1 when max_iter was reached, < 0 on error. */
+int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, int verbose, int *n_eval_out)
+{
+   const int n = p->np, NC = 12;
+   double *lo = (double *)malloc(n * sizeof(double)), *hi = (double *)malloc(n * sizeof(double));
+   double *g = (double *)malloc(n * sizeof(double)), *g0 = (double *)malloc(n * sizeof(double)), *d = (double *)malloc(n * sizeof(double));
+   double *s = (double *)malloc(n * sizeof(double)), *y = (double *)malloc(n * sizeof(double)), *Hy = (double *)malloc(n * sizeof(double));
+   double *H = (double *)malloc((size_t)n * n * sizeof(double));
+   double *xs = (double *)malloc((size_t)(2 * n + NC) * n * sizeof(double)), *ls = (double *)malloc((2 * n + NC) * sizeof(double));
+   unsigned char *fixed = (unsigned char *)malloc(n);
+   double f, fnew = 0, as[16];
+   int it, i, j, k, rc = 0, n_eval = 0, reset = 1, small_steps = 0, status = 1;
+   if (n == 0) { rc = pamlh_eval_batch_gpu(p, 1, x, lnL); status = 0; goto done; }
+   if (pamlh_bounds(p, lo, hi)) { rc = pamlh_fail(p, "internal: bounds do not match np"); goto done; }
+   for (i = 0; i < n; i++) x[i] = x[i] < lo[i] ? lo[i] : x[i] > hi[i] ? hi[i] : x[i];
+   if ((rc = pamlh_eval_batch_gpu(p, 1, x, ls))) goto done;
+   n_eval++;
+   f = -ls[0];
+   if (f > 1e299) { rc = pamlh_fail(p, "the starting point is infeasible"); goto done; }
+   for (i = 0; i < n * n; i++) H[i] = 0;
+   for (i = 0; i < n; i++) H[i * n + i] = 1;
+   if ((rc = gradient(p, x, f, lo, hi, g, xs, ls, &n_eval))) goto done;
+   for (it = 0; it < max_iter; it++) {
+      double amax = 1e300, best = f, abest = 0, gd, sy;
+      int nc = 0;
+      /* variables sitting on a bound with the gradient pushing outward stay there this iteration */
+      for (i = 0; i < n; i++) fixed[i] = (x[i] <= lo[i] && g[i] > 0) || (x[i] >= hi[i] && g[i] < 0);
+      for (i = 0; i < n; i++) {
+         d[i] = 0;
+         if (fixed[i]) continue;
+         for (j = 0; j < n; j++)
+            if (!fixed[j]) d[i] -= H[i * n + j] * g[j];
+      }
+      gd = dot(g, d, n);
+      if (!(gd < 0)) {     /* not a descent direction: steepest descent on the free variables */
+         for (i = 0; i < n; i++) d[i] = fixed[i] ? 0 : -g[i];
+         gd = dot(g, d, n);
+         reset = 1;
+         if (!(gd < 0)) { status = 0; break; }     /* projected gradient is zero */
+      }
+      /* the search path is the projection of x + a d on the box: a variable that reaches its bound stays there while the
+       * others move on; amax = the step at which the last one is stopped */
+      amax = 0;
+      for (i = 0; i < n; i++) {
+         const double ai = d[i] > 0 ? (hi[i] - x[i]) / d[i] : d[i] < 0 ? (lo[i] - x[i]) / d[i] : 0;
+         if (ai > amax) amax = ai;
+      }
+      /* line search: NC step lengths in one launch; after a reset the scale of d is unknown, so start lower */
+      for (k = 0; k < 2 && abest == 0; k++) {
+         double a = (reset ? 1.0 / (1 + sqrt(dot(d, d, n))) : 1.0) * 4.0 * (k ? pow(0.5, NC) : 1.0);
+         double prev = -1;
+         nc = 0;
+         for (j = 0; j < NC; j++, a *= 0.5) {
+            const double aa = a < amax ? a : amax;
+            if (aa == prev) continue;
+            prev = aa;
+            for (i = 0; i < n; i++) {
+               double v = x[i] + aa * d[i];
+               xs[(size_t)nc * n + i] = v < lo[i] ? lo[i] : v > hi[i] ? hi[i] : v;
+            }
+            as[nc] = aa;
+            nc++;
+         }
+         if ((rc = pamlh_eval_batch_gpu(p, nc, xs, ls))) goto done;
+         n_eval += nc;
+         for (j = 0; j < nc; j++)
+            if (-ls[j] < best) { best = -ls[j]; abest = as[j]; }
+      }
+      if (abest == 0) {         /* no step length improves f */
+         if (!reset) {          /* distrust the curvature information once before giving up */
+            for (i = 0; i < n * n; i++) H[i] = 0;
+            for (i = 0; i < n; i++) H[i * n + i] = 1;
+            reset = 1;
+            continue;
+         }
+         status = 0;
+         break;
+      }
+      fnew = best;
+      for (i = 0; i < n; i++) {
+         double v = x[i] + abest * d[i];
+         v = v < lo[i] ? lo[i] : v > hi[i] ? hi[i] : v;
+         s[i] = v - x[i];
+         x[i] = v;
+      }
+      memcpy(g0, g, n * sizeof(double));
+      if ((rc = gradient(p, x, fnew, lo, hi, g, xs, ls, &n_eval))) goto done;
+      if (verbose)
+         fprintf(stderr, "iter %3d  lnL %.6f  step %.3g  |g| %.3g  evals %d\n", it + 1, -fnew, abest, sqrt(dot(g, g, n)), n_eval);
+      /* BFGS update of the inverse Hessian */
+      for (i = 0; i < n; i++) y[i] = g[i] - g0[i];
+      sy = dot(s, y, n);
+      if (sy > 1e-14 * sqrt(dot(s, s, n) * dot(y, y, n))) {
+         double yHy;
+         if (reset) {            /* first update after a reset: scale the identity (Nocedal & Wright 6.20) */
+            const double sc = sy / dot(y, y, n);
+            for (i = 0; i < n * n; i++) H[i] = 0;
+            for (i = 0; i < n; i++) H[i * n + i] = sc;
+         }
+         for (i = 0; i < n; i++) { Hy[i] = 0; for (j = 0; j < n; j++) Hy[i] += H[i * n + j] * y[j]; }
+         yHy = dot(y, Hy, n);
+         for (i = 0; i < n; i++)
+            for (j = 0; j < n; j++)
+               H[i * n + j] += (1 + yHy / sy) * s[i] * s[j] / sy - (Hy[i] * s[j] + s[i] * Hy[j]) / sy;
+         reset = 0;
+      }
+      {
+         double smax = 0;
+         for (i = 0; i < n; i++) { const double r = fabs(s[i]) / (fabs(x[i]) + 1); if (r > smax) smax = r; }
+         small_steps = (f - fnew < tol * (fabs(fnew) + 1) && smax < 1e-5) ? small_steps + 1 : 0;
+      }
+      f = fnew;
+      if (small_steps >= 2) { status = 0; break; }
+   }
+   *lnL = -f;
+   /* leave the model state at the estimate */
+   if (pamlh_set_x(p, x, n)) rc = -1;
+done:
+   if (n_eval_out) *n_eval_out = n_eval;
+   free(lo); free(hi); free(g); free(g0); free(d); free(s); free(y); free(Hy); free(H); free(xs); free(ls); free(fixed);
+   return rc ? rc : status;
+}

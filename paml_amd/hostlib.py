@@ -52,6 +52,9 @@ def lib():
         L.pamlh_model.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
         L.pamlh_eigen.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)] + [C.POINTER(C.c_void_p)] * 4
         L.pamlh_eval_gpu.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
+        L.pamlh_eval_batch_gpu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.pamlh_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pamlh_optimize.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]
         _L = L
     return _L
 
@@ -141,3 +144,27 @@ class Analysis:
         if self._L.pamlh_eval_gpu(self._h, C.byref(lnl), None if lnf is None else lnf.ctypes.data_as(C.c_void_p)) != 0:
             raise RuntimeError("pamlh_eval_gpu: " + self._L.pamlh_error(self._h).decode())
         return lnl.value, lnf
+
+    def eval_batch_gpu(self, xs):
+        """lnL at every row of xs[n_batch][np] in one launch (pamlh_eval_batch_gpu)."""
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        assert xs.ndim == 2 and xs.shape[1] == self.np
+        out = np.zeros(xs.shape[0])
+        if self._L.pamlh_eval_batch_gpu(self._h, xs.shape[0], xs.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("pamlh_eval_batch_gpu: " + self._L.pamlh_error(self._h).decode())
+        return out
+
+    def bounds(self):
+        lo, hi = np.zeros(self.np), np.zeros(self.np)
+        if self._L.pamlh_bounds(self._h, lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("pamlh_bounds failed")
+        return lo, hi
+
+    def optimize(self, x0, max_iter=500, tol=1e-10, verbose=False):
+        """Maximum-likelihood estimation from x0 (pamlh_optimize).  Returns dict(x, lnL, converged, n_eval)."""
+        x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+        lnl, nev = C.c_double(), C.c_int()
+        rc = self._L.pamlh_optimize(self._h, x.ctypes.data_as(C.c_void_p), C.byref(lnl), max_iter, tol, int(verbose), C.byref(nev))
+        if rc < 0:
+            raise RuntimeError("pamlh_optimize: " + self._L.pamlh_error(self._h).decode())
+        return dict(x=x, lnL=lnl.value, converged=rc == 0, n_eval=nev.value)

@@ -89,3 +89,40 @@ def test_driver_binary_end_to_end(tmp_path):
     assert len(rows) == g["n_patt"]
     assert np.max(np.abs(np.array([float(r[2]) for r in rows]) - np.array(g["logf"]))) < 5e-8
     assert [int(float(r[1])) for r in rows] == [int(c) for c in g["counts"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname,prog,ctl", [CASES[0], CASES[1], CASES[2]])
+def test_c_host_optimiser_finds_the_reference_mle(gname, prog, ctl):
+    """pamlh_optimize (BFGS, gradients and line searches as batches on the GPU) started from the control file's initial
+    values reaches the lnL the reference's own optimiser reports for the data set (brown HKY85 -2665.422858,
+    stewart LG+G4 -1038.351723, HIV M0 -1137.688190) — the golden x are those MLEs printed with 6 decimals."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), prog)
+    r = a.optimize(a.default_x())
+    assert r["converged"]
+    assert abs(r["lnL"] - g["lnL"]) <= 5e-6, (r["lnL"], g["lnL"])
+    lo, hi = a.bounds()
+    assert ((r["x"] >= lo) & (r["x"] <= hi)).all()
+    gx = np.array(g["x"])
+    free = gx > 1e-5                                   # a zero-length branch sits on the boundary in both programs
+    assert np.max(np.abs(r["x"][free] - gx[free]) / (np.abs(gx[free]) + 0.01)) < 2e-2
+
+
+@pytest.mark.gpu
+def test_c_host_batch_matches_single_evaluations():
+    g = helpers.load_golden("hiv_m2a")
+    a = hostlib.Analysis(os.path.join(CTL, "hiv_ns2.ctl"), "codeml")
+    x = np.array(g["x"])
+    xs = np.tile(x, (6, 1))
+    xs[1, 3] *= 1.01            # a branch length
+    xs[2, a.ntime] *= 1.01      # kappa: a different set of eigen systems
+    xs[3, a.ntime + 1] = 0.9    # p0 + p1 > 1: rejected
+    xs[4, a.ntime + 4] *= 1.1   # omega_2
+    xs[5, 7] *= 0.5
+    got = a.eval_batch_gpu(xs)
+    assert abs(got[0] - g["lnL"]) <= 2e-6
+    assert got[3] == -1e300
+    for b in (1, 2, 4, 5):
+        one, _ = a.eval_gpu(xs[b], want_lnf=False)
+        assert abs(got[b] - one) <= 1e-9 * abs(one)
