@@ -172,3 +172,175 @@ def test_set_node_scale_matches_reference_rule():
     flags = set_node_scale(pb.tree, 15)
     assert flags[pb.tree.root] == 0
     assert flags.sum() >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Static check of the specialised kernel's schedule (jit.h): the generated source is a straight line of building-block
+# calls whose correctness rests on bookkeeping done at generation time — which ring buffer a block sits in, how many
+# DMA pieces may still be in flight at each s_waitcnt, which barrier separates the last reader of a buffer from the
+# DMA that overwrites it.  The checker below replays the emitted statements (prologue + three trips round the tile
+# loop) against an explicit model of the in-order vector-memory queue, the ring and the two tip-code buffers.
+# ---------------------------------------------------------------------------------------------------------------------
+class _Sched:
+    def __init__(self, src):
+        self.zp = int(re.search(r"JIT2_PROLOGUE\((\d+)\)", src).group(1))
+        self.nblk = int(re.search(r"JIT2_ADVANCE\((\d+)\)", src).group(1))
+        body = src[src.index("JIT2_PROLOGUE"):]
+        head, loop = body.split("for (;; ptile = 0) {", 1)
+        loop = loop[:loop.rindex("if (!has_next) break;")]
+        self.head, self.loop = head, loop
+        self.fifo = []                 # in-flight DMA pieces of this thread, oldest first: ("b", G) or ("z", tile)
+        self.landed = {}               # item -> pieces complete (this thread); visible to the others after a barrier
+        self.visible = set()           # items every wave may read
+        self.pending_vis = set()
+        self.epoch = 0                 # barriers passed
+        self.buf_owner = {}            # ring buffer -> global block number of the newest DMA into it
+        self.last_read = {}            # global block / ("z", buffer) -> epoch of its latest read
+        self.zbuf_owner = {}
+        self.tile = -1                 # tile the loop body is working on; blocks are numbered G = tile * nblk + J
+        self.zsel = 1
+        self.pieces = {}
+
+    def G(self, j):
+        return self.tile * self.nblk + j
+
+    def issue_piece(self, j):
+        g = self.G(j)
+        b = g & 3
+        if self.buf_owner.get(b) != g:      # first piece of a new block into this buffer
+            old = self.buf_owner.get(b)
+            if old is not None:
+                assert old == g - 4, "ring slot %d: block %d overwrites %d" % (b, g, old)
+                assert self.last_read.get(old, -1) < self.epoch, "block %d overwritten while block %d may still be read" % (g, old)
+            self.buf_owner[b] = g
+            self.pieces[g] = 0
+        self.pieces[g] += 1
+        self.fifo.append(("b", g))
+
+    def issue_z(self):
+        zb = self.zsel ^ 1
+        assert self.last_read.get(("z", zb), -1) < self.epoch, "tip codes overwritten while still being read"
+        self.zbuf_owner[zb] = self.tile + 1
+        for _ in range(self.zp):
+            self.fifo.append(("z", self.tile + 1))
+        self.pieces[("z", self.tile + 1)] = self.zp
+
+    def wait(self, n):
+        while len(self.fifo) > n:
+            it = self.fifo.pop(0)
+            key = it[1] if it[0] == "b" else it
+            self.landed[key] = self.landed.get(key, 0) + 1
+            if self.landed[key] == self.pieces[key]:
+                self.pending_vis.add(key)
+
+    def barrier(self):
+        self.visible |= self.pending_vis
+        self.pending_vis = set()
+        self.epoch += 1
+
+    def read_block(self, j, what):
+        g = self.G(j)
+        assert g in self.visible, "%s reads block %d before it is known complete" % (what, g)
+        assert self.buf_owner.get(g & 3) == g, "%s reads block %d but its ring slot holds %s" % (what, g, self.buf_owner.get(g & 3))
+        self.last_read[g] = self.epoch
+
+    def read_codes(self, text):
+        for kind in re.findall(r"JIT2_(N?CODE)\(", text):
+            zb = self.zsel ^ 1 if kind == "NCODE" else self.zsel
+            t = self.tile + 1 if kind == "NCODE" else self.tile
+            assert self.zbuf_owner.get(zb) == t and ("z", t) in self.visible, "tip codes of tile %d read before they arrived" % t
+            self.last_read[("z", zb)] = self.epoch
+
+    def side(self, text, reading):
+        for m in re.finditer(r"JIT2_PIECE_N?[TP]\((\d+), \d+, \d\)", text):
+            j = int(m.group(1))
+            assert (self.G(j) & 3) not in [(self.G(r) & 3) for r in reading if r != j], "refill of block %d lands in a buffer this step reads" % j
+            self.issue_piece(j)
+
+    def run(self, text):
+        for line in text.split("\n"):
+            line = line.strip()
+            if line.startswith("JIT2_ADVANCE"):
+                self.tile += 1
+                self.zsel ^= 1
+                continue
+            m = re.match(r"jit_matvec_tip2<(\d+)>\(JIT2_BUF\((\d+)\), lane, \w+, \w+, JIT2_BUF\((\d+)\), (\S+ \S+), JIT2_BUF\((\d+)\), (\S+ \S+), q, \w+, (.*)\);$", line)
+            if m:
+                mid, jp, ja, jb = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(5))
+                self.read_block(jp, "fused matmul")
+                self.side(m.group(7), [jp, ja, jb])
+                self.wait(mid)
+                self.barrier()
+                self.read_block(jp, "fused matmul")
+                self.read_block(ja, "fused tip gather")
+                self.read_block(jb, "fused tip gather")
+                self.read_codes(m.group(4) + m.group(6))
+                continue
+            m = re.match(r"jit_matvec\(JIT2_BUF\((\d+)\), lane, \w+, \w+, (.*)\);$", line)
+            if m:
+                self.read_block(int(m.group(1)), "matmul")
+                self.side(m.group(2), [int(m.group(1))])
+                continue
+            if line.startswith("jit_tip") or line.startswith("jit_init_tip") or line.startswith("jit_root_lds"):
+                for j in re.findall(r"JIT2_BUF\((\d+)\)", line):
+                    self.read_block(int(j), "tip gather")
+                self.read_codes(line)
+                continue
+            # plain statements, possibly several per line
+            for tok in re.finditer(r"JIT_WAIT\((\d+)\)|__syncthreads\(\)|JIT2_ISSUE_Z\(\d+\)|JIT2_PIECE_N?[TP]\((\d+), \d+, \d\)", line):
+                t = tok.group(0)
+                if t.startswith("JIT_WAIT"):
+                    self.wait(int(tok.group(1)))
+                elif t.startswith("__sync"):
+                    self.barrier()
+                elif t.startswith("JIT2_ISSUE_Z"):
+                    self.issue_z()
+                else:
+                    self.issue_piece(int(tok.group(2)))
+
+    def check(self, trips=3):
+        self.run(self.head)
+        for _ in range(trips):
+            self.run(self.loop)
+        assert self.tile == trips - 1
+        return self
+
+
+@pytest.mark.parametrize("shape", ["balanced16", "balanced8", "hiv", "caterpillar", "random23", "scaled"])
+def test_jit_schedule_is_consistent(lib_path, shape):
+    from paml_amd.problem import balanced_tree
+    scale = None
+    if shape.startswith("balanced"):
+        tree = balanced_tree(int(shape[8:]))
+    elif shape == "hiv":
+        tree = helpers.problem_from_golden(helpers.load_golden("hiv_m0")).tree
+    elif shape == "caterpillar":
+        from paml_amd.problem import parse_newick
+        s = "(t1:0.1,t2:0.1)"
+        for i in range(3, 12):
+            s = "(%s:0.05,t%d:0.1)" % (s, i)
+        tree = parse_newick("(%s:0.05,t12:0.1,t13:0.1);" % s)
+    else:
+        pb = helpers.random_problem(61, 23, 10, seed=5, scale_every=6 if shape == "scaled" else None)
+        tree, scale = pb.tree, pb.scale_node
+    src = engine.debug_jit(tree, scale_node=scale, compile=False)
+    assert "prune_jit" in src and "#error" not in src
+    s = _Sched(src).check()
+    assert s.nblk >= 4
+    # every operand block of a tile is consumed exactly once per trip: 2 tips + branches below internal nodes
+    n_int_branches = tree.n_nodes - tree.n_tips - 1
+    assert s.nblk == tree.n_tips + n_int_branches
+
+
+def test_jit_schedule_checker_catches_broken_schedules(lib_path):
+    """The checker itself: a wait that lets one more DMA piece fly, or a missing barrier, must be reported."""
+    from paml_amd.problem import balanced_tree
+    src = engine.debug_jit(balanced_tree(16), compile=False)
+    _Sched(src).check()
+    i = src.index("JIT_WAIT(8)")
+    with pytest.raises(AssertionError):
+        _Sched(src[:i] + "JIT_WAIT(12)" + src[i + 11:]).check()
+    j = src.index("__syncthreads();", src.index("for (;; ptile = 0)"))
+    k = src.index("__syncthreads();", j + 1)
+    with pytest.raises(AssertionError):
+        _Sched(src[:k] + src[k + len("__syncthreads();"):]).check()
