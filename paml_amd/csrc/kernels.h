@@ -392,6 +392,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_gather(PruneArgs a
 #pragma unroll
             for (int m = 0; m < 16; m++)
                if (4 * m + q < n) dst[4 * m + q] = cur[m];
+            if (a.export_scale && q == 0) a.export_scale[(long)iclass * a.n_patt + h] = lnscale;
          }
       } break;
       case OP_MUL_TIP:
@@ -705,6 +706,7 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
             double *dst = a.export_buf + ((long)iclass * a.n_patt + h) * N;
 #pragma unroll
             for (int j = 0; j < N; j++) dst[j] = cur[j];
+            if (a.export_scale) a.export_scale[(long)iclass * a.n_patt + h] = lnscale;
          }
       } break;
       case OP_ROOT: {
@@ -882,6 +884,7 @@ __global__ __launch_bounds__(256) void pmat_deriv_kernel(DerivArgs a)
 struct BranchArgs {
    int n, K, n_genes, n_patt, n_t, n_pi, b_is_tip, n_codes;
    const double *A, *B;        // [K][n_patt][n]
+   const double *SA, *SB;      // summed scale factors of A and B, [K][n_patt] (null: no scaling nodes)
    const unsigned char *zb;    // tip b: codes [n_patt]
    const int *n_chara;
    const unsigned char *chara_map;
@@ -900,9 +903,19 @@ __global__ __launch_bounds__(256) void branch_kernel(BranchArgs a)
       while (gene + 1 < a.n_genes && h >= a.gene_off[gene + 1]) gene++;
    const double *pi = a.pi + (long)(a.n_pi > 1 ? gene : 0) * n;
    for (int it = 0; it < a.n_t; it++) {
-      double fh = 0, dfh = 0, ddfh = 0;
+      double fh = 0, dfh = 0, ddfh = 0, smax = 0;
       if (valid) {
+         // with scaling nodes class ir's sums carry the factor exp(S_ir): bring the classes to the common factor
+         // exp(smax) (lfuntdd_SiteClass treesub.c:8316-8332 does the same with its own pivot)
+         if (a.SA) {
+            smax = -1e300;
+            for (int ir = 0; ir < a.K; ir++) {
+               const double s = a.SA[(long)ir * a.n_patt + h] + (a.SB ? a.SB[(long)ir * a.n_patt + h] : 0.0);
+               smax = s > smax ? s : smax;
+            }
+         }
          for (int ir = 0; ir < a.K; ir++) {
+            const double cs = a.SA ? exp(a.SA[(long)ir * a.n_patt + h] + (a.SB ? a.SB[(long)ir * a.n_patt + h] : 0.0) - smax) : 1.0;
             const double *Ah = a.A + ((long)ir * a.n_patt + h) * n;
             const double *M = a.PdP + ((long)((gene * a.K + ir) * a.n_t + it) * 3) * n * n;
             const int code = a.b_is_tip ? a.zb[h] : 0;
@@ -910,7 +923,7 @@ __global__ __launch_bounds__(256) void branch_kernel(BranchArgs a)
             for (int ii = 0; ii < n1; ii++) {
                const int i = a.b_is_tip ? a.chara_map[code * n + ii] : ii;
                const double bi = a.b_is_tip ? 1.0 : a.B[((long)ir * a.n_patt + h) * n + i];
-               const double piqi = a.freqK[ir] * pi[i] * bi;
+               const double piqi = a.freqK[ir] * pi[i] * bi * cs;
                double pq = 0, dpq = 0, ddpq = 0;
                const double *Pi = M + (long)i * n, *dPi = Pi + n * n, *ddPi = dPi + n * n;
                for (int j = 0; j < n; j++) {
@@ -928,7 +941,7 @@ __global__ __launch_bounds__(256) void branch_kernel(BranchArgs a)
       double v0 = 0, v1 = 0, v2 = 0;
       if (valid) {
          const double w = a.weights[h];
-         v0 = log(fh) * w;
+         v0 = (log(fh) + smax) * w;
          v1 = dfh / fh * w;
          v2 = (fh * ddfh - dfh * dfh) / (fh * fh) * w;
       }

@@ -226,6 +226,27 @@ def test_eval_branch_matches_oracle(n, K, amb, genes):
     assert again == base
 
 
+@pytest.mark.parametrize("n,K", [(4, 3), (61, 2)])
+def test_eval_branch_with_scaling_nodes(n, K):
+    """Trees with NodeScale flags: the exported partials carry their summed scale factors into the branch kernel."""
+    pb = helpers.random_problem(n, 14, 120, K=K, seed=70 + n, scale_every=3)
+    assert pb.scale_node is not None and pb.scale_node.sum() >= 2
+    eng = engine_for(pb)
+    base = eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]
+    t = pb.tree
+    scaled = list(np.nonzero(pb.scale_node)[0])
+    for b in [1, scaled[0], scaled[-1], t.n_nodes - 1]:
+        if b == t.root:
+            continue
+        ts = np.array([t.branch[b], 0.05, 0.9])
+        l, dl, ddl = eng.eval_branch(b, ts, t.branch, pb.gene_rate)
+        rl, rdl, rddl = oracle.eval_branch(pb, b, ts)
+        assert np.allclose(l, rl, rtol=1e-11, atol=0), (b, l, rl)
+        assert np.allclose(dl, rdl, rtol=1e-9, atol=1e-9)
+        assert np.allclose(ddl, rddl, rtol=1e-9, atol=1e-8)
+        assert abs(l[0] - base) <= 1e-11 * abs(base)
+
+
 @pytest.mark.parametrize("n,K,amb,genes", [(4, 4, False, 2), (20, 2, True, 1), (61, 1, False, 1), (61, 3, True, 1)])
 def test_eval_batch_matches_single_evals(n, K, amb, genes):
     """paml_amd_eval_batch: every element of a batch (own branch lengths, gene rates, class frequencies / rates) gives
