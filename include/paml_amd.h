@@ -128,8 +128,7 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
  * of the reference.  Where the reference re-roots the tree at b and updates conP along the path (ReRootTree
  * treespace.c:236, updateconP treesub.c:7982), the engine evaluates the two partials across the branch directly
  * (one fused pass over each side), builds P, dP, ddP for all trial lengths in one batched kernel and contracts.
- * Scaling nodes keep rescaling in the re-rooted walk; their factors travel with the two partials.
- * Not yet supported: K80/JC69-like eigen kinds (PAML_AMD_EUNSUPPORTED). */
+ * Scaling nodes keep rescaling in the re-rooted walk; their factors travel with the two partials. */
 int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *t, const double *branch,
                          const double *gene_rate, double *lnL, double *dlnL, double *ddlnL);
 

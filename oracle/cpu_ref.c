@@ -378,8 +378,26 @@ int orc_eval_branch(const orc_problem *pb, int node_b, int n_t, const double *t,
             const double *pi = pb->pi + (size_t)(pb->n_pi > 1 ? ig : 0) * n;
             int nroot = es->kind == ORC_EIGEN_CIJK ? es->nR : n;
             double qf = (es->kind == ORC_EIGEN_UVROOT && pb->qfactor) ? pb->qfactor[(size_t)ir * pb->n_labels + lab] : 1.0;
-            if (es->kind != ORC_EIGEN_UVROOT && es->kind != ORC_EIGEN_CIJK) return -1;
             for (i = 0; i < 3 * n * n; i++) P[i] = 0;
+            if (es->kind == ORC_EIGEN_K80 || es->kind == ORC_EIGEN_JC69LIKE) {
+               /* the reference reaches these models through Cijk of eigenTN93 (kappa1 = kappa2); the closed forms of
+                * PMatK80 / PMatJC69like are the same functions of t:  P = 1/n + c1 e^{t mu1} + c2 e^{t mu2} */
+               int k80 = es->kind == ORC_EIGEN_K80;
+               double base = (pb->gene_rate ? pb->gene_rate[ig] : 1.0) * pb->rate[ir];
+               double m1 = base * (k80 ? -4 / (es->kappa + 2) : -(double)n / (n - 1));
+               double m2 = base * (k80 ? -2 * (es->kappa + 1) / (es->kappa + 2) : 0.0);
+               double e1 = exp(t[it] * m1), e2 = k80 ? exp(t[it] * m2) : 0.0;
+               for (i = 0; i < n; i++)
+                  for (j = 0; j < n; j++) {
+                     double c1, c2;
+                     if (k80) { c1 = (i == j || (i ^ j) == 1) ? 0.25 : -0.25; c2 = i == j ? 0.5 : ((i ^ j) == 1 ? -0.5 : 0.0); }
+                     else { c1 = i == j ? 1 - 1.0 / n : -1.0 / n; c2 = 0; }
+                     P[i * n + j] = 1.0 / n + c1 * e1 + c2 * e2;
+                     dP[i * n + j] = c1 * e1 * m1 + c2 * e2 * m2;
+                     ddP[i * n + j] = c1 * e1 * m1 * m1 + c2 * e2 * m2 * m2;
+                  }
+               nroot = 0;
+            }
             for (k = 0; k < nroot; k++) {
                /* treesub.c:8479-8483: multiply = rgene * Root[k] * _rateSite [* Qfactor_NS_branch] */
                double multiply = (pb->gene_rate ? pb->gene_rate[ig] : 1.0) * es->Root[k] * pb->rate[ir] * qf;

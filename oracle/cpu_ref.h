@@ -90,7 +90,7 @@ double orc_eval(const orc_problem *pb, double *lnf, double *fhK, double *partial
  * (ReRootTree treespace.c:236 + updateconP treesub.c:7982); here A and B are computed directly as the two messages
  * across the branch, which is the same product of the same P(t) factors.  Outputs are in lnL convention
  * (lnL, dlnL/dt, d2lnL/dt2 = -l, -dl, -ddl of the reference).  scale_node flags are ignored (scaling changes no value,
- * only the exponent range); UVROOT and CIJK eigen kinds only.  Returns 0 on success. */
+ * only the exponent range).  Returns 0 on success. */
 int orc_eval_branch(const orc_problem *pb, int node_b, int n_t, const double *t, double *lnL, double *dlnL, double *ddlnL);
 
 /* Number of (branch, class) P(t) constructions performed by the last orc_eval (mirrors NPMatUVRoot, tools.c:88). */

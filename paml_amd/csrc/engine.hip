@@ -877,9 +877,6 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    const TreeDesc &T = e->tree;
    const int nn = T.n_nodes, n = e->n, K = e->K, G = e->n_genes, psets = G * K;
    if (node_b < 0 || node_b >= nn || node_b == T.root) return fail(e, PAML_AMD_EINVAL, "eval_branch: node has no branch");
-   for (size_t i = 0; i < e->eigen.size(); i++)
-      if (e->eigen[i].kind != PAML_AMD_EIGEN_UVROOT && e->eigen[i].kind != PAML_AMD_EIGEN_CIJK)
-         return fail(e, PAML_AMD_EUNSUPPORTED, "eval_branch: UVROOT / CIJK eigen systems only");
    std::vector<int> father(nn, -1);
    for (int i = 0; i < nn; i++)
       for (int j = T.sons_ptr[i]; j < T.sons_ptr[i + 1]; j++) father[T.sons[j]] = i;

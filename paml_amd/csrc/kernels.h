@@ -859,6 +859,23 @@ __global__ __launch_bounds__(256) void pmat_deriv_kernel(DerivArgs a)
    const int nroot = es.kind == PAML_AMD_EIGEN_CIJK ? es.nR : n;
    double *P = a.out + ((long)(pset * a.n_t + it) * 3) * n * n, *dP = P + n * n, *ddP = dP + n * n;
    __shared__ double sE[64], sM[64];
+   if (es.kind == PAML_AMD_EIGEN_K80 || es.kind == PAML_AMD_EIGEN_JC69LIKE) {
+      // closed forms (PMatK80 tools.c:578, PMatJC69like codeml.c:3585) written with their two / one non-zero rates:
+      //   K80: mu1 = -4/(kappa+2) (all changes), mu2 = -2(kappa+1)/(kappa+2) (within transitions);  JC-like: mu = -n/(n-1)
+      const bool k80 = es.kind == PAML_AMD_EIGEN_K80;
+      const double m1 = base * (k80 ? -4 / (es.kappa + 2) : -(double)n / (n - 1)), m2 = base * (k80 ? -2 * (es.kappa + 1) / (es.kappa + 2) : 0.0);
+      const double e1 = exp(t * m1), e2 = k80 ? exp(t * m2) : 0.0;
+      for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+         const int i = idx / n, j = idx % n;
+         double c1, c2;      // P = 1/n + c1 e1 + c2 e2
+         if (k80) { c1 = (i == j || (i ^ j) == 1) ? 0.25 : -0.25; c2 = i == j ? 0.5 : ((i ^ j) == 1 ? -0.5 : 0.0); }
+         else { c1 = i == j ? 1 - 1.0 / n : -1.0 / n; c2 = 0; }
+         P[idx] = 1.0 / n + c1 * e1 + c2 * e2;
+         dP[idx] = c1 * e1 * m1 + c2 * e2 * m2;
+         ddP[idx] = c1 * e1 * m1 * m1 + c2 * e2 * m2 * m2;
+      }
+      return;
+   }
    for (int k = threadIdx.x; k < nroot; k += 256) {
       const double mu = base * es.Root[k];     // treesub.c:8479: rgene * Root[k] * _rateSite (* Qfactor)
       sM[k] = mu;

@@ -226,6 +226,22 @@ def test_eval_branch_matches_oracle(n, K, amb, genes):
     assert again == base
 
 
+@pytest.mark.parametrize("n,K,kind", [(4, 2, "k80"), (20, 1, "jc")])
+def test_eval_branch_closed_form_models(n, K, kind):
+    """JC69 / K80 (baseml) and the Poisson amino-acid model: P, dP, ddP from the closed forms."""
+    from test_oracle_golden import _closed_form
+    pb = _closed_form(helpers.random_problem(n, 9, 150, K=K, seed=33 + n), kind)
+    eng = engine_for(pb)
+    base = eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]
+    assert abs(base - oracle.evaluate(pb)["lnL"]) <= 1e-10 * abs(base)
+    for b in (2, pb.tree.n_tips + 2):
+        ts = np.array([pb.tree.branch[b], 0.03, 0.6])
+        l, dl, ddl = eng.eval_branch(b, ts, pb.tree.branch, pb.gene_rate)
+        rl, rdl, rddl = oracle.eval_branch(pb, b, ts)
+        assert np.allclose(l, rl, rtol=1e-11, atol=0) and abs(l[0] - base) <= 1e-11 * abs(base)
+        assert np.allclose(dl, rdl, rtol=1e-9, atol=1e-9) and np.allclose(ddl, rddl, rtol=1e-9, atol=1e-8)
+
+
 @pytest.mark.parametrize("n,K", [(4, 3), (61, 2)])
 def test_eval_branch_with_scaling_nodes(n, K):
     """Trees with NodeScale flags: the exported partials carry their summed scale factors into the branch kernel."""

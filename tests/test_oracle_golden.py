@@ -24,11 +24,23 @@ def test_oracle_matches_reference(name):
         assert abs(r["lnL"] - g["published_lnL"]) < 5e-6
 
 
-@pytest.mark.parametrize("n,K", [(4, 1), (4, 3), (20, 2), (61, 1)])
-def test_oracle_branch_derivatives_match_pinned_lnl(n, K):
+def _closed_form(pb, kind):
+    """Swap the random eigen system for one of the closed-form kinds (K80 with kappa = 2.5, or JC69-like)."""
+    from paml_amd.problem import EIGEN_JC69LIKE, EIGEN_K80
+    if kind == "k80":
+        pb.eigen = [dict(kind=EIGEN_K80, kappa=2.5)]
+        pb.pi = np.full((1, 4), 0.25) if pb.pi.ndim == 2 else np.full(4, 0.25)
+    elif kind == "jc":
+        pb.eigen = [dict(kind=EIGEN_JC69LIKE)]
+        pb.pi = np.full_like(pb.pi, 1.0 / pb.n)
+    return pb
+
+
+@pytest.mark.parametrize("n,K,kind", [(4, 1, None), (4, 3, None), (20, 2, None), (61, 1, None), (4, 2, "k80"), (20, 1, "jc")])
+def test_oracle_branch_derivatives_match_pinned_lnl(n, K, kind):
     """orc_eval_branch (lfuntdd restated) against the golden-pinned full evaluation: l(t) equals lnL with that branch
     length to rounding, and dl / ddl equal its central finite differences."""
-    pb = helpers.random_problem(n, 8, 50, K=K, seed=40 + n, ambiguity=(n == 4))
+    pb = _closed_form(helpers.random_problem(n, 8, 50, K=K, seed=40 + n, ambiguity=(n == 4)), kind)
     for b in (1, pb.tree.n_tips + 1):
         t0 = float(pb.tree.branch[b])
 
