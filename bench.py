@@ -166,9 +166,24 @@ def cpu_baseline(pb, sample):
         el = time.perf_counter() - t0
         if el > 10.0 or reps >= 8:
             break
-    return {"value": sample * reps / el, "unit": "site-patterns/s", "cores": 1, "kind": "port",
-            "sample": "%d evals over the first %d patterns of the workload, oracle/cpu_ref.c, gcc -O3, 1 thread (%d host cores present)"
-                      % (reps, sample, os.cpu_count() or 0)}
+    one = {"value": sample * reps / el, "unit": "site-patterns/s", "cores": 1, "kind": "port",
+           "sample": "%d evals over the first %d patterns of the workload, oracle/cpu_ref.c, gcc -O3, 1 thread (%d host cores present)"
+                     % (reps, sample, os.cpu_count() or 0)}
+    # the same code with the patterns cut into blocks spread over every host core, each thread walking the whole tree
+    # for its block; the whole workload, a few evaluations, bounded to ~10 s
+    ncores = os.cpu_count() or 1
+    oracle.evaluate_blocked(pb.slice_patterns(0, min(pb.n_patt, 4096 * ncores)), ncores)      # thread start-up
+    reps = 0
+    t0 = time.perf_counter()
+    while True:
+        oracle.evaluate_blocked(pb, ncores)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 8.0 or reps >= 5:
+            break
+    one["all_cores"] = {"value": pb.n_patt * reps / el, "unit": "site-patterns/s", "cores": ncores,
+                        "sample": "%d evals over all %d patterns, blocks of 2048 patterns over %d OpenMP threads" % (reps, pb.n_patt, ncores)}
+    return one
 
 
 if __name__ == "__main__":

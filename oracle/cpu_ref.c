@@ -17,7 +17,7 @@
 #endif
 #include "cpu_ref.h"
 
-static long g_npmat = 0;
+static __thread long g_npmat = 0;
 long orc_last_npmat(void) { return g_npmat; }
 
 /* tools.c:516-546.  P = I + sum_k U[:,k] expm1(t Root_k) V[k,:]; t<1e-100 -> I; entries <0 -> 0.
@@ -110,6 +110,9 @@ void orc_pmat_branch(const orc_problem *pb, int gene, int iclass, int node, doub
    }
 }
 
+/* row stride of the tip codes: a pattern block of a larger data set keeps the parent's stride */
+#define ZS(pb) ((pb)->z_stride ? (size_t)(pb)->z_stride : (size_t)(pb)->n_patt)
+
 typedef struct {
    const orc_problem *pb;
    double *conP;      /* this class's slab: [n_nodes-n_tips][n_patt][n] */
@@ -165,7 +168,7 @@ static void conditional_p_node(ctx_t *c, int inode, int igene, int iclass)
    }
    L = node_conP(c, inode);
    if (inode < pb->n_tips) {   /* young ancestor: codeml.c:3535-3543 (indicator only when cleandata) */
-      const unsigned char *z = pb->z + (size_t)inode * np;
+      const unsigned char *z = pb->z + (size_t)inode * ZS(pb);
       for (h = (long)pos0 * n; h < (long)pos1 * n; h++) L[h] = 0;
       if (pb->cleandata)
          for (h = pos0; h < pos1; h++) L[h * n + z[h]] = 1;
@@ -178,7 +181,7 @@ static void conditional_p_node(ctx_t *c, int inode, int igene, int iclass)
       int son_is_tip = (pb->sons_ptr[son + 1] == pb->sons_ptr[son]);
       orc_pmat_branch(pb, igene, iclass, son, P);
       if (son_is_tip && pb->cleandata) {
-         const unsigned char *z = pb->z + (size_t)son * np;
+         const unsigned char *z = pb->z + (size_t)son * ZS(pb);
 #pragma omp parallel for if (c->nthreads > 1) num_threads(c->nthreads) schedule(static)
          for (h = pos0; h < pos1; h++) {
             int j;
@@ -186,7 +189,7 @@ static void conditional_p_node(ctx_t *c, int inode, int igene, int iclass)
          }
       }
       else if (son_is_tip) {
-         const unsigned char *z = pb->z + (size_t)son * np;
+         const unsigned char *z = pb->z + (size_t)son * ZS(pb);
 #pragma omp parallel for if (c->nthreads > 1) num_threads(c->nthreads) schedule(static)
          for (h = pos0; h < pos1; h++) {
             int j, k, code = z[h], nc = pb->n_chara[code];
@@ -292,6 +295,32 @@ double orc_eval(const orc_problem *pb, double *lnf, double *fhK_out, double *par
 }
 
 
+/* The same evaluation with the patterns cut into blocks and the blocks spread over the host cores: every thread walks
+ * the whole tree for its own block, so partials stay in its cache (the all-cores CPU baseline of bench.py; the
+ * reference itself is single-threaded).  Single-gene problems.  Returns +lnL. */
+double orc_eval_blocked(const orc_problem *pb, int nthreads, int block)
+{
+   int nb, b;
+   double lnL = 0;
+   if (pb->n_genes != 1 || block < 1) return 0.0 / 0.0;
+   nb = (pb->n_patt + block - 1) / block;
+#pragma omp parallel for num_threads(nthreads > 1 ? nthreads : 1) schedule(dynamic) reduction(+ : lnL)
+   for (b = 0; b < nb; b++) {
+      orc_problem sub = *pb;
+      int off[2];
+      const int lo = b * block, len = lo + block <= pb->n_patt ? block : pb->n_patt - lo;
+      off[0] = 0; off[1] = len;
+      sub.n_patt = len;
+      sub.z = pb->z + lo;
+      sub.z_stride = (long)ZS(pb);
+      sub.weights = pb->weights + lo;
+      sub.gene_off = off;
+      lnL += orc_eval(&sub, NULL, NULL, NULL, NULL, 1);
+   }
+   return lnL;
+}
+
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Branch-local lnL(t), dlnL/dt, d2lnL/dt2 (lfuntdd / lfuntdd_SiteClass, treesub.c:8204-8296, 8403-8541).
  * ------------------------------------------------------------------------------------------------------------- */
@@ -308,7 +337,7 @@ static void msg(const bctx_t *c, int x, int from, int ig, int ir, double *out)
    int n = pb->n, np = pb->n_patt, pos0 = pb->gene_off[ig], pos1 = pb->gene_off[ig + 1], i, j, k;
    long h;
    if (pb->sons_ptr[x + 1] == pb->sons_ptr[x] && x < pb->n_tips) {   /* tip: indicator of its state set */
-      const unsigned char *z = pb->z + (size_t)x * np;
+      const unsigned char *z = pb->z + (size_t)x * ZS(pb);
       for (h = pos0; h < pos1; h++) {
          int code = z[h], nc = pb->n_chara[code];
          for (j = 0; j < n; j++) out[h * n + j] = 0;

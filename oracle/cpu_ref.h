@@ -61,6 +61,7 @@ typedef struct {
    const int *eigen_of;  /* eigen set for (gene, class, label): [n_genes][K][n_labels] */
    const double *qfactor;/* Qfactor for (class, label): [K][n_labels] (treesub.c:7549, 7587) */
    const double *branch; /* nodes[i].branch, [n_nodes] (root entry unused) */
+   long z_stride;        /* row stride of z; 0 = n_patt */
 } orc_problem;
 
 /* P(t) builders */
@@ -80,6 +81,10 @@ void orc_pmat_branch(const orc_problem *pb, int gene, int iclass, int node, doub
  * nthreads>1 shards the pattern loops with OpenMP (the reference itself is single-threaded).
  */
 double orc_eval(const orc_problem *pb, double *lnf, double *fhK, double *partials, double *scalef, int nthreads);
+
+/* orc_eval over pattern blocks spread over nthreads host cores (each thread walks the whole tree for its block; single
+ * gene).  Returns +lnL. */
+double orc_eval_blocked(const orc_problem *pb, int nthreads, int block);
 
 /* Branch-local log-likelihood and its first two derivatives in the branch length, for the branch above `node_b`
  * (father a), at each of the n_t trial lengths t[]: restates lfuntdd / lfuntdd_SiteClass (treesub.c:8204-8296,

@@ -29,7 +29,7 @@ class _Problem(C.Structure):
         ("gene_rate", C.c_void_p), ("n_pi", C.c_int), ("pi", C.c_void_p), ("n_eigen", C.c_int),
         ("eigen", C.POINTER(_Eigen)), ("mode", C.c_int), ("K", C.c_int), ("freqK", C.c_void_p),
         ("rate", C.c_void_p), ("n_labels", C.c_int), ("eigen_of", C.c_void_p), ("qfactor", C.c_void_p),
-        ("branch", C.c_void_p),
+        ("branch", C.c_void_p), ("z_stride", C.c_long),
     ]
 
 
@@ -50,6 +50,8 @@ def lib():
         _LIB.orc_eval.argtypes = [C.POINTER(_Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _LIB.orc_pmat_branch.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int, C.c_int, C.c_void_p]
         _LIB.orc_last_npmat.restype = C.c_long
+        _LIB.orc_eval_blocked.restype = C.c_double
+        _LIB.orc_eval_blocked.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int]
         _LIB.orc_eval_branch.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return _LIB
 
@@ -111,6 +113,12 @@ def evaluate(pb, want_lnf=True, want_fhk=False, want_partials=False, nthreads=1)
     scalef = np.zeros((K, n_scale, np_)) if (want_partials and n_scale) else None
     lnL = L.orc_eval(C.byref(pk.s), _ptr(lnf), _ptr(fhk), _ptr(part), _ptr(scalef), int(nthreads))
     return dict(lnL=lnL, lnf=lnf, fhK=fhk, partials=part, scalef=scalef, npmat=L.orc_last_npmat())
+
+
+def evaluate_blocked(pb, nthreads, block=2048):
+    """lnL with the patterns cut into blocks spread over `nthreads` host cores (each thread walks the whole tree)."""
+    pk = _Packed(pb)
+    return lib().orc_eval_blocked(C.byref(pk.s), int(nthreads), int(block))
 
 
 def pmat_branch(pb, gene, iclass, node):

@@ -476,6 +476,70 @@ __device__ __forceinline__ void jit_root_lds(const PruneArgs &a, const v4d (&x)[
 #define JIT_CODE(TIP) ((int)sZ[(TIP)*128 + hw])
 #define JIT_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
+// ---- building blocks of the specialised one-pattern-per-lane kernels (4 / 5 / 20 states; jit.h: jit_generate_valu) ----
+// Same arithmetic as prune_valu<N>: P(t) entries are wave-uniform and come through the constant address space (s_load ->
+// SGPR operands of v_fma_f64); with the walk unrolled the compiler issues those loads far ahead of their use and the
+// partial stack lives in renamed registers instead of an indexed (scratch) array.
+template <int N>
+__device__ __forceinline__ void jv_matvec(const double *Pg, const double (&x)[N], double (&y)[N])
+{
+   const CONST_AS double *P = as_const(Pg);
+#pragma unroll
+   for (int j = 0; j < N; j++) {
+      double t = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) t = fma(P[j * N + k], x[k], t);
+      y[j] = t;
+   }
+}
+
+template <int N>
+__device__ __forceinline__ double jv_scale(double (&x)[N])      // NodeScale treesub.c:7200-7230
+{
+   double mx = 0;
+#pragma unroll
+   for (int j = 0; j < N; j++) mx = x[j] > mx ? x[j] : mx;
+   if (mx < 1e-300) {
+#pragma unroll
+      for (int j = 0; j < N; j++) x[j] = 1.0;
+      return -800;
+   }
+#pragma unroll
+   for (int j = 0; j < N; j++) x[j] /= mx;
+   return log(mx);
+}
+
+template <int N>
+__device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N], double lnscale, int gene, int iclass, int h, bool valid)
+{
+   const CONST_AS double *pi = as_const(a.pi + (long)(a.n_pi > 1 ? gene : 0) * N);
+   double f = 0;
+#pragma unroll
+   for (int j = 0; j < N; j++) f = fma(pi[j], x[j], f);
+   if (valid) {
+      double out = 0;
+      if (a.weights[h] > 0) out = root_value(a, f, lnscale);
+      a.fhK[(long)iclass * a.n_patt + h] = out;
+   }
+}
+
+#define JV_PROLOGUE(NS)                                                                                          \
+   constexpr int N = NS;                                                                                        \
+   const int tid = threadIdx.x;                                                                                 \
+   const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;                                    \
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;                                  \
+   const int hend = as_const(a.gene_off)[gene + 1];                                                             \
+   const int h = h0 + tid;                                                                                      \
+   const bool valid = h < hend;                                                                                 \
+   const int hc = valid ? h : hend - 1;                                                                         \
+   const long pset = (long)gene * a.K + iclass;                                                                 \
+   const double *Pint = a.pint + pset * a.n_nodes * (N * N);                                                    \
+   const double *Ptip = a.ptip + pset * a.n_nodes * a.tip_words;                                                \
+   double lnscale = 0;                                                                                          \
+   (void)lnscale;
+#define JV_CODE(TIP) ((int)a.z[(long)(TIP)*a.z_stride + hc])
+#define JV_ROW(TIP, CODE) (Ptip + (long)(TIP)*a.tip_words + (CODE)*N)
+
 // ---- seamless variant: the operand ring and the tip-code blocks run on across tile boundaries ------------------------
 // The workgroup's blocks are numbered through all its tiles; a tile's block J sits in ring buffer (J + roff) & 3 with
 // roff advancing by the tile's block count, and blocks J >= NBLK are the next tile's (its P pointers).  Tip codes and

@@ -251,6 +251,32 @@ int build_tiles(paml_amd_engine *e)
    return 0;
 }
 
+// The specialised kernel for `key`: reuse the loaded module or generate + compile + load it.  A compile failure is
+// not fatal (the interpreter kernels take over) unless PAML_AMD_JIT_STRICT is set.
+template <class GEN>
+int ensure_jit(paml_amd_engine *e, const std::string &key, GEN gen, bool *ok)
+{
+   *ok = false;
+   if (e->jit.fn && e->jit.key == key) { *ok = true; return 0; }
+   if (e->jit.mod) (void)hipModuleUnload(e->jit.mod);
+   e->jit = JitKernel();
+   std::string log;
+   const std::string src = gen();
+   if (getenv("PAML_AMD_JIT_DUMP")) {
+      FILE *f = fopen(getenv("PAML_AMD_JIT_DUMP"), "w");
+      if (f) { fputs(src.c_str(), f); fclose(f); }
+   }
+   if (jit_compile(src, &e->jit, &log) == 0) {
+      e->jit.key = key;
+      *ok = true;
+   }
+   else {
+      e->err = "jit: " + log;
+      if (getenv("PAML_AMD_JIT_STRICT")) return fail(e, PAML_AMD_EHIP, e->err);
+   }
+   return 0;
+}
+
 // Batched evaluations: B parameter sets run as K*B classes of one launch (class index = b*K + iclass), so the pruning
 // kernels are unchanged; P(t) and the reduction index the per-element inputs.  Null members = shared set_classes values.
 struct BatchSpec {
@@ -365,27 +391,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
       bool jit_ok = false;
       if (e->jit_enabled && !getenv("PAML_AMD_FORCE_GATHER") && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi)) {
-         const std::string key = jit_program_key(e->prog, e->n_tips);
-         if (e->jit.fn && e->jit.key == key)
-            jit_ok = true;
-         else {
-            if (e->jit.mod) (void)hipModuleUnload(e->jit.mod);
-            e->jit = JitKernel();
-            std::string log;
-            const std::string src = jit_generate(e->prog, e->n_tips);
-            if (getenv("PAML_AMD_JIT_DUMP")) {
-               FILE *f = fopen(getenv("PAML_AMD_JIT_DUMP"), "w");
-               if (f) { fputs(src.c_str(), f); fclose(f); }
-            }
-            if (jit_compile(src, &e->jit, &log) == 0) {
-               e->jit.key = key;
-               jit_ok = true;
-            }
-            else {
-               e->err = "jit: " + log;      // not fatal: the interpreter kernels take over
-               if (getenv("PAML_AMD_JIT_STRICT")) return fail(e, PAML_AMD_EHIP, e->err);
-            }
-         }
+         int r = ensure_jit(e, "m:" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate(e->prog, e->n_tips); }, &jit_ok);
+         if (r) return r;
       }
       e->use_jit = jit_ok;
       const bool big_tiles = jit_ok || lean;
@@ -398,6 +405,16 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          e->partials_valid = false;
          if (clean) return fail(e, PAML_AMD_EINVAL, "eval_dirty: kernel layout changed; run a full evaluation first");
       }
+   }
+   if (e->kk != KK_MFMA64) {      // 4 / 5 / 20 states: the interpreter unrolled for this tree (jit_generate_valu)
+      bool jit_ok = false;
+      // (20 states: the unrolled walk needs > 256 VGPRs and runs at one wave per SIMD, slower than the interpreter)
+      if (e->jit_enabled && !keep && n <= 5 && jit_valu_supported(e->prog)) {
+         int r = ensure_jit(e, "v" + std::to_string(n) + ":" + jit_program_key(e->prog, e->n_tips),
+                            [&]() { return jit_generate_valu(e->prog, n); }, &jit_ok);
+         if (r) return r;
+      }
+      e->use_jit = jit_ok;
    }
    const bool use_dma = e->mfma_dma;
    const int n_blocks = e->n_tiles * K;
@@ -482,13 +499,18 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, e->stream, pr);
       break;
    case KK_VALU4:
-      hipLaunchKernelGGL((prune_valu<4, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
-      break;
    case KK_VALU5:
-      hipLaunchKernelGGL((prune_valu<5, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
-      break;
    case KK_VALU20:
-      hipLaunchKernelGGL((prune_valu<20, VALU_MAXD_20>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
+      if (e->use_jit) {
+         void *params[] = {&pr};
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, n_blocks, 1, 1, 256, 1, 1, 0, e->stream, params, nullptr));
+      }
+      else if (e->kk == KK_VALU4)
+         hipLaunchKernelGGL((prune_valu<4, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
+      else if (e->kk == KK_VALU5)
+         hipLaunchKernelGGL((prune_valu<5, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
+      else
+         hipLaunchKernelGGL((prune_valu<20, VALU_MAXD_20>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
       break;
    }
    mark(e);
@@ -615,9 +637,9 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
 {
    if (!e) return "";
    switch (e->kk) {
-   case KK_VALU4: return "valu4";
-   case KK_VALU5: return "valu5";
-   case KK_VALU20: return "valu20";
+   case KK_VALU4: return e->use_jit ? "valu4_jit" : "valu4";
+   case KK_VALU5: return e->use_jit ? "valu5_jit" : "valu5";
+   case KK_VALU20: return e->use_jit ? "valu20_jit" : "valu20";
    default: return e->use_jit ? "mfma64_jit" : (e->mfma_dma ? "mfma64_stream" : "mfma64_gather");
    }
 }
@@ -1137,8 +1159,17 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
       for (int i = 0; i < n_nodes; i++)
          if (scale_node[i]) { t.scale_node[i] = 1; t.scale_slot[i] = t.n_scale++; }
    Program p = build_program(t, false, nullptr);
-   if (!jit_supported(p, n_tips, 61)) return PAML_AMD_EUNSUPPORTED;
-   std::string text = jit_generate(p, n_tips);
+   const int n_states = compile >> 8;       // 0: the 61-state kernel; 4 / 5 / 20: the one-pattern-per-lane kernels
+   compile &= 1;
+   std::string text;
+   if (n_states == 4 || n_states == 5 || n_states == 20) {
+      if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate_valu(p, n_states);
+   }
+   else {
+      if (!jit_supported(p, n_tips, 61)) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate(p, n_tips);
+   }
    int rc = (int)text.size();
    if (compile) {
       std::vector<char> code;

@@ -305,6 +305,86 @@ inline std::string jit_generate(const Program &p, int n_tips)
    return got == first ? src : std::string("#error \"jit schedule does not close\"\n");
 }
 
+// The one-pattern-per-lane kernels (4 / 5 / 20 states) specialised the same way: the op interpreter of prune_valu<N>
+// unrolled into straight-line code over renamed register arrays.
+inline bool jit_valu_supported(const Program &p, int max_arrays = 8)
+{
+   if (p.ops.size() > 600) return false;
+   for (const Op &o : p.ops)
+      if (o.code == OP_STORE || o.code == OP_LOAD || o.code == OP_EXPORT) return false;
+   return p.max_stack + 2 <= max_arrays;
+}
+
+inline std::string jit_generate_valu(const Program &p, int N)
+{
+   std::ostringstream s;
+   s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
+   s << "extern \"C\" __global__ __launch_bounds__(256) void prune_jit(PruneArgs a)\n{\n   JV_PROLOGUE(" << N << ")\n";
+   const int NA = p.max_stack + 2;
+   for (int i = 0; i < NA; i++) s << "   double A" << i << "[N];\n";
+   std::vector<int> freeA;
+   for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
+   auto alloc = [&]() { int r = freeA.back(); freeA.pop_back(); return r; };
+   auto release = [&](int r) { freeA.push_back(r); };
+   auto name = [&](int r) { return "A" + std::to_string(r); };
+   std::vector<int> slot(256, -1);
+   int cur = -1;
+   const char *LOOP = "_Pragma(\"unroll\") for (int j = 0; j < N; j++) ";
+   for (const Op &o : p.ops) {
+      switch (o.code) {
+      case OP_INIT_ONES:
+         if (cur < 0) cur = alloc();
+         s << "   " << LOOP << name(cur) << "[j] = 1.0;\n";
+         break;
+      case OP_INIT_TIP:
+         if (cur < 0) cur = alloc();
+         s << "   { const int c = JV_CODE(" << o.a << "); " << LOOP << name(cur) << "[j] = (a.cleandata && j == c) ? 1.0 : 0.0; }\n";
+         break;
+      case OP_SET_TIP:
+      case OP_MUL_TIP:
+         if (cur < 0) cur = alloc();
+         s << "   { const double *r = JV_ROW(" << o.a << ", JV_CODE(" << o.a << ")); " << LOOP << name(cur)
+           << (o.code == OP_SET_TIP ? "[j] = r[j]; }\n" : "[j] *= r[j]; }\n");
+         break;
+      case OP_SET_TIP2:
+      case OP_MUL_TIP2:
+         if (cur < 0) cur = alloc();
+         s << "   { const double *r1 = JV_ROW(" << o.a << ", JV_CODE(" << o.a << ")), *r2 = JV_ROW(" << o.b << ", JV_CODE(" << o.b << ")); "
+           << LOOP << name(cur) << (o.code == OP_SET_TIP2 ? "[j] = r1[j] * r2[j]; }\n" : "[j] = (" + name(cur) + "[j] * r1[j]) * r2[j]; }\n");
+         break;
+      case OP_PUSH:
+         slot[o.b] = cur;
+         cur = -1;
+         break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         const int pop = mm_pop_slot(o), push = mm_push_slot(o), out = alloc();
+         s << "   jv_matvec<N>(Pint + " << (long)o.a * N * N << ", " << name(cur) << ", " << name(out) << ");\n";
+         release(cur);
+         if (pop >= 0) {
+            s << "   " << LOOP << name(out) << "[j] = " << name(slot[pop]) << "[j] * " << name(out) << "[j];\n";
+            release(slot[pop]);
+            slot[pop] = -1;
+         }
+         if (push >= 0) { slot[push] = out; cur = -1; }
+         else cur = out;
+      } break;
+      case OP_SCALE:
+         s << "   { const double fac = jv_scale<N>(" << name(cur) << "); lnscale += fac;\n"
+           << "     if (a.keep && valid) a.scalef[((long)iclass * a.n_scale + " << o.b << ") * a.n_patt + h] = fac; }\n";
+         break;
+      case OP_ROOT:
+         s << "   jv_root<N>(a, " << name(cur) << ", lnscale, gene, iclass, h, valid);\n";
+         release(cur);
+         cur = -1;
+         break;
+      default: break;
+      }
+   }
+   s << "}\n";
+   return s.str();
+}
+
 inline std::string jit_source_dir()
 {
    Dl_info info;

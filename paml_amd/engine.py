@@ -282,15 +282,16 @@ def debug_program(tree, scale_node=None, keep=False, clean=None):
     return [tuple(int(v) for v in r) for r in ops[:nops]], ms.value
 
 
-def debug_jit(tree, scale_node=None, compile=True):
-    """Host-only: source of the kernel specialised for `tree` (hiprtc-compiled for gfx950 when compile=True)."""
+def debug_jit(tree, scale_node=None, compile=True, n_states=0):
+    """Host-only: source of the kernel specialised for `tree` (hiprtc-compiled for gfx950 when compile=True);
+    n_states 4 / 5 / 20 selects the one-pattern-per-lane kernels, anything else the 61-state MFMA kernel."""
     L = lib()
     ptr, flat = tree.csr()
     sc = None if scale_node is None else np.ascontiguousarray(scale_node, dtype=np.uint8)
     cap = 1 << 20
     buf = C.create_string_buffer(cap)
     L.paml_amd_debug_jit.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int]
-    rc = L.paml_amd_debug_jit(tree.n_tips, tree.n_nodes, tree.root, _p(ptr), _p(flat), _p(sc), buf, cap, int(compile))
+    rc = L.paml_amd_debug_jit(tree.n_tips, tree.n_nodes, tree.root, _p(ptr), _p(flat), _p(sc), buf, cap, int(bool(compile)) | (int(n_states) << 8))
     if rc < 0:
         raise EngineError("debug_jit failed (%d): %s" % (rc, buf.value.decode(errors="replace")[-3000:]))
     return buf.value.decode()

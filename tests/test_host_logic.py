@@ -344,3 +344,12 @@ def test_jit_schedule_checker_catches_broken_schedules(lib_path):
     k = src.index("__syncthreads();", j + 1)
     with pytest.raises(AssertionError):
         _Sched(src[:k] + src[k + len("__syncthreads();"):]).check()
+
+
+@pytest.mark.parametrize("n_states", [4, 5])
+def test_valu_jit_source_compiles_for_gfx950(lib_path, n_states):
+    """The specialised one-pattern-per-lane kernel (jit_generate_valu) is generated and hiprtc-compiled without a GPU."""
+    pb = helpers.random_problem(4, 19, 10, seed=3, scale_every=5)
+    src = engine.debug_jit(pb.tree, scale_node=pb.scale_node, compile=True, n_states=n_states)
+    assert "JV_PROLOGUE(%d)" % n_states in src and src.count("jv_matvec<N>") == pb.tree.n_nodes - pb.tree.n_tips - 1
+    assert src.count("jv_scale<N>") == int(pb.scale_node.sum())

@@ -45,8 +45,15 @@ def main():
     out.append(dict(case="C2-shape 32x4e6", kernel=eng.kernel_name, ms_per_eval=dt * 1e3, patterns_per_s=pb.n_patt / dt,
                     prune_ms=prof["ms_prune"], algorithmic_GBps=bytes_pp * pb.n_patt / (prof["ms_prune"] * 1e-3) / 1e9,
                     hbm_peak_GBps=8000, lnL=lnl))
-    # C5: HIV models, latency
+    # 20-state at scale (C3's kernel on a synthetic amino-acid-sized problem: 32 taxa x 1e5 patterns, 4 rate classes)
     import helpers
+    pb = helpers.random_problem(20, 32, 100_000, K=4, seed=7)
+    eng = engine.engine_for(pb)
+    dt, prof, lnl = timed(eng, pb.tree.branch, 20)
+    flops20 = (29 * 2 * 400 + 61 * 20 + 40) * 4.0 * pb.n_patt
+    out.append(dict(case="20-state 32x1e5 K=4 (random reversible model)", kernel=eng.kernel_name, ms_per_eval=dt * 1e3,
+                    patterns_per_s=pb.n_patt / dt, tflops=flops20 / (prof["ms_prune"] * 1e-3) / 1e12, fp64_valu_peak_tflops=78.6, lnL=lnl, **prof))
+    # C5: HIV models, latency
     for name in ("hiv_m0", "hiv_m2a", "hiv_m8"):
         g = helpers.load_golden(name)
         pb = helpers.problem_from_golden(g)
