@@ -20,7 +20,7 @@ DRIVER_PATH = os.path.join(_HERE, "lib", "pamlh_lnl")
 def build(force=False):
     from . import engine
     engine.build()
-    srcs = [os.path.join(_HERE, "host", f) for f in ("pamlh_num.c", "pamlh_io.c", "pamlh_model.c", "pamlh_lnl.c", "pamlh_internal.h", "Makefile")]
+    srcs = [os.path.join(_HERE, "host", f) for f in ("pamlh_num.c", "pamlh_io.c", "pamlh_model.c", "pamlh_opt.c", "pamlh_lnl.c", "pamlh_internal.h", "Makefile")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "pamlh.h"))
     if force or not (os.path.exists(LIB_PATH) and os.path.exists(DRIVER_PATH)) or \
             any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
