@@ -251,6 +251,25 @@ int build_tiles(paml_amd_engine *e)
    return 0;
 }
 
+// The one-pattern-per-lane interpreter: the register-stack instantiation that fits the program, else the scratch one.
+void launch_valu(paml_amd_engine *e, int max_stack, int n_blocks, const PruneArgs &pr)
+{
+   const dim3 g(n_blocks), b(256);
+   switch (e->kk) {
+   case KK_VALU4:
+      if (max_stack <= 4) hipLaunchKernelGGL((prune_valu<4, 4, true>), g, b, 0, e->stream, pr);
+      else hipLaunchKernelGGL((prune_valu<4, VALU_MAXD_SMALL>), g, b, 0, e->stream, pr);
+      break;
+   case KK_VALU5:
+      if (max_stack <= 4) hipLaunchKernelGGL((prune_valu<5, 4, true>), g, b, 0, e->stream, pr);
+      else hipLaunchKernelGGL((prune_valu<5, VALU_MAXD_SMALL>), g, b, 0, e->stream, pr);
+      break;
+   default:      // 20 states: a register stack costs > 256 VGPRs (one wave per SIMD) and measures 2x slower than scratch
+      hipLaunchKernelGGL((prune_valu<20, VALU_MAXD_20>), g, b, 0, e->stream, pr);
+      break;
+   }
+}
+
 // The specialised kernel for `key`: reuse the loaded module or generate + compile + load it.  A compile failure is
 // not fatal (the interpreter kernels take over) unless PAML_AMD_JIT_STRICT is set.
 template <class GEN>
@@ -505,12 +524,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          void *params[] = {&pr};
          HIPCHK(hipModuleLaunchKernel(e->jit.fn, n_blocks, 1, 1, 256, 1, 1, 0, e->stream, params, nullptr));
       }
-      else if (e->kk == KK_VALU4)
-         hipLaunchKernelGGL((prune_valu<4, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
-      else if (e->kk == KK_VALU5)
-         hipLaunchKernelGGL((prune_valu<5, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
       else
-         hipLaunchKernelGGL((prune_valu<20, VALU_MAXD_20>), dim3(n_blocks), dim3(256), 0, e->stream, pr);
+         launch_valu(e, e->prog.max_stack, n_blocks, pr);
       break;
    }
    mark(e);
@@ -584,9 +599,7 @@ int run_prune_full(paml_amd_engine *e, const Program &prog, double *export_buf, 
    case KK_MFMA64:
       hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, e->stream, pr);
       break;
-   case KK_VALU4: hipLaunchKernelGGL((prune_valu<4, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr); break;
-   case KK_VALU5: hipLaunchKernelGGL((prune_valu<5, VALU_MAXD_SMALL>), dim3(n_blocks), dim3(256), 0, e->stream, pr); break;
-   case KK_VALU20: hipLaunchKernelGGL((prune_valu<20, VALU_MAXD_20>), dim3(n_blocks), dim3(256), 0, e->stream, pr); break;
+   default: launch_valu(e, prog.max_stack, n_blocks, pr); break;
    }
    HIPCHK(hipGetLastError());
    return 0;

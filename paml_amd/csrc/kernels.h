@@ -582,7 +582,11 @@ __global__ __launch_bounds__(512, 2) void prune_mfma64_stream(PruneArgs a)
 // The partial lives in N registers; P(t) entries are wave-uniform, so the compiler fetches them with
 // scalar loads (s_load) and feeds v_fma_f64 from SGPRs: no LDS, no barriers.  The whole tree is walked
 // per lane, so only tips (1 B) and the result (8 B) touch HBM unless keep-partials is on.
-template <int N, int MAXD>
+// REGSTK: the partial stack is addressed through unrolled wave-uniform compares, so it stays in registers; the plain
+// form indexes stk[op.b] dynamically, which the compiler can only do through scratch memory (measured on the 20-state
+// kernel: 680 MB of scratch writes per launch at 1e5 patterns).  The engine picks the shallowest instantiation that
+// fits the tree's stack depth.
+template <int N, int MAXD, bool REGSTK = false>
 __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
 {
    const int tid = threadIdx.x;
@@ -643,8 +647,18 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
          }
       } break;
       case OP_PUSH: {
+         if constexpr (REGSTK) {
 #pragma unroll
-         for (int j = 0; j < N; j++) stk[op.b][j] = cur[j];
+            for (int d = 0; d < MAXD; d++)
+               if (op.b == d) {
+#pragma unroll
+                  for (int j = 0; j < N; j++) stk[d][j] = cur[j];
+               }
+         }
+         else {
+#pragma unroll
+            for (int j = 0; j < N; j++) stk[op.b][j] = cur[j];
+         }
       } break;
       case OP_MATMUL:
       case OP_MATMUL_POP: {
@@ -658,15 +672,31 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
             out[j] = t;
          }
          const int pop = mm_pop_slot(op), push = mm_push_slot(op);
-         if (pop >= 0) {
+         if constexpr (REGSTK) {
 #pragma unroll
-            for (int j = 0; j < N; j++) out[j] = stk[pop][j] * out[j];
-         }
-         if (push >= 0) {
+            for (int d = 0; d < MAXD; d++)
+               if (pop == d) {
 #pragma unroll
-            for (int j = 0; j < N; j++) stk[push][j] = out[j];
+                  for (int j = 0; j < N; j++) out[j] = stk[d][j] * out[j];
+               }
+#pragma unroll
+            for (int d = 0; d < MAXD; d++)
+               if (push == d) {
+#pragma unroll
+                  for (int j = 0; j < N; j++) stk[d][j] = out[j];
+               }
          }
          else {
+            if (pop >= 0) {
+#pragma unroll
+               for (int j = 0; j < N; j++) out[j] = stk[pop][j] * out[j];
+            }
+            if (push >= 0) {
+#pragma unroll
+               for (int j = 0; j < N; j++) stk[push][j] = out[j];
+            }
+         }
+         if (push < 0) {
 #pragma unroll
             for (int j = 0; j < N; j++) cur[j] = out[j];
          }

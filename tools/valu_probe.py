@@ -1,5 +1,8 @@
-import sys, time, json
-sys.path[:0] = ['.', 'tests']
+"""Kernel probe for the one-pattern-per-lane kernels: BASELINE configs[1] (32 taxa x 1e5 nucleotide patterns, GTR+G4), the same
+shape at 4e6 patterns, and a 20-state problem of 32 taxa x 1e5 patterns."""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, 'tests')]
 import numpy as np
 from paml_amd import engine, synth
 import helpers
