@@ -12,12 +12,14 @@ def timed(eng, branch, steps, warmup=3):
     for _ in range(steps): r = eng.eval(branch)
     dt = (time.perf_counter() - t0) / steps; p = eng.profile_read(); eng.profile(False)
     return dt, p["ms_prune"] / max(1, p["n_evals"]), r["lnL"]
-for npatt in (100_000, 4_000_000):
+cases = sys.argv[1:] or ["c2", "c2big", "aa20"]
+for npatt in [n for c, n in (("c2", 100_000), ("c2big", 4_000_000)) if c in cases]:
     pb = synth.nuc_gtr_gamma_problem(n_tips=32, n_patt=npatt)
     eng = engine.engine_for(pb)
     dt, pr, lnl = timed(eng, pb.tree.branch, 20)
     print("C2 n_patt=%d kernel=%s ms_eval=%.4f prune_ms=%.4f lnL=%.6f GBps=%.0f" % (npatt, eng.kernel_name, dt*1e3, pr, lnl, 7720*npatt/(pr*1e-3)/1e9))
-pb = helpers.random_problem(20, 32, 100_000, K=4, seed=7)
-eng = engine.engine_for(pb)
-dt, pr, lnl = timed(eng, pb.tree.branch, 10)
-print("20-state kernel=%s ms_eval=%.4f prune_ms=%.4f lnL=%.6f" % (eng.kernel_name, dt*1e3, pr, lnl))
+if "aa20" in cases:
+  pb = helpers.random_problem(20, 32, 100_000, K=4, seed=7)
+  eng = engine.engine_for(pb)
+  dt, pr, lnl = timed(eng, pb.tree.branch, 10)
+  print("20-state kernel=%s ms_eval=%.4f prune_ms=%.4f lnL=%.6f" % (eng.kernel_name, dt*1e3, pr, lnl))
