@@ -116,10 +116,12 @@ int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *
  * uses branch[b][n_nodes] and gene_rate[b][n_genes] (NULL = all 1) and, where a non-NULL table is given, its own
  * eigen_of[b][n_genes][K][n_labels], qfactor[b][K][n_labels], freqK[b][K], rate[b][K] — layouts of one element as in
  * paml_amd_set_classes; NULL = the tables set there, shared by all elements.  Eigen systems are referenced by set id, so
- * a nudged kappa / omega is a further paml_amd_set_eigen_* id.  lnL[n_batch] comes back (+lnL each).  pi and the mode
- * (lfun / lfundG) are those of the engine.  Not with PAML_AMD_KEEP_PARTIALS. */
+ * a nudged kappa / omega is a further paml_amd_set_eigen_* id.  lnL[n_batch] comes back (+lnL each), and, when lnf is
+ * not NULL, the per-pattern log f_h of every element, lnf[n_batch][n_patt] — what HessianSKT2004 (treesub.c:7241) collects
+ * in dfsites for its 2 np perturbed evaluations.  pi and the mode (lfun / lfundG) are those of the engine.  Not with
+ * PAML_AMD_KEEP_PARTIALS. */
 int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, const double *gene_rate, const int *eigen_of,
-                        const double *qfactor, const double *freqK, const double *rate, double *lnL);
+                        const double *qfactor, const double *freqK, const double *rate, double *lnL, double *lnf);
 
 /* Branch-local evaluation = lfuntdd / lfuntdd_SiteClass (treesub.c:8204, 8403; lfunt / lfunt_SiteClass 8127, 8298 are
  * the lnL-only case), the function minbranches (treesub.c:8039) iterates with Newton steps: for the branch above

@@ -68,6 +68,12 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi);
  * Returns 0 converged, 1 max_iter reached, < 0 error.  n_eval (may be NULL): likelihood evaluations spent. */
 int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, int verbose, int *n_eval);
 
+/* Standard errors of the estimates (getSE = 1).  method 0: HessianSKT2004 (treesub.c:7241), the outer product of per-pattern
+ * scores that the reference's programs print; method 1: observed information from central second differences of lnL
+ * (Hessian() tools.c:5984).  Either way all perturbed evaluations are one batch.  se[np] (-1: not available, e.g. a parameter
+ * on its bound under method 1); hess: NULL or np x np, the information matrix that was inverted. */
+int pamlh_standard_errors(pamlh *p, const double *x, int method, double *se, double *hess);
+
 /* Write the reference's `lnf` file layout (print_lnf_site treesub.c:7598) for the last pamlh_eval_gpu. */
 int pamlh_write_lnf(const pamlh *p, const char *path, const double *lnf);
 

@@ -550,7 +550,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    const int nb = (e->n_patt + chunk - 1) / chunk;
    HIPCHK(e->d_partial.ensure((size_t)nb * B));
    HIPCHK(e->d_out.ensure(B));
-   if (want_lnf) HIPCHK(e->d_lnf.ensure(e->n_patt));
+   if (want_lnf) HIPCHK(e->d_lnf.ensure((size_t)B * e->n_patt));
    ReduceArgs ra{};
    ra.fhK = e->d_fhK.p; ra.weights = e->d_weights.p; ra.freqK = e->d_freqK.p; ra.lnf = want_lnf ? e->d_lnf.p : nullptr;
    ra.partial = e->d_partial.p; ra.out = d_lnL_out ? d_lnL_out : e->d_out.p;
@@ -873,14 +873,16 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
 }
 
 int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, const double *gene_rate, const int *eigen_of,
-                        const double *qfactor, const double *freqK, const double *rate, double *lnL)
+                        const double *qfactor, const double *freqK, const double *rate, double *lnL, double *lnf)
 {
    if (!e || !branch || !lnL || n_batch < 1) return fail(e, PAML_AMD_EINVAL, "eval_batch: bad arguments");
    if ((long)n_batch * e->K * e->n_genes > 65535) return fail(e, PAML_AMD_EINVAL, "eval_batch: n_batch * K * n_genes > 65535");
    BatchSpec bs{n_batch, eigen_of, qfactor, freqK, rate};
-   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, false, &bs);
+   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, lnf != nullptr, &bs);
    if (r) return r;
    HIPCHK(hipMemcpyAsync(lnL, e->d_out.p, (size_t)n_batch * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   if (lnf)
+      HIPCHK(hipMemcpyAsync(lnf, e->d_lnf.p, (size_t)n_batch * e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
    return 0;
 }

@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void reduce_stage1(ReduceArgs a)
       if (a.fscale) a.fscale += off;
       a.freqK += blockIdx.y * a.freqK_bs;
       a.partial += blockIdx.y * gridDim.x;
-      a.lnf = nullptr;
+      if (a.lnf) a.lnf += (long)blockIdx.y * a.n_patt;
    }
    const int lo = blockIdx.x * a.chunk;
    const int hi = min(a.n_patt, lo + a.chunk);

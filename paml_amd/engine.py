@@ -193,7 +193,7 @@ class Engine:
         self._chk(self._L.paml_amd_eval(self._h, _p(b), _p(g), C.byref(lnL), _p(lnf), _p(fhk)))
         return dict(lnL=lnL.value, lnf=lnf, fhK=fhk)
 
-    def eval_batch(self, branch, gene_rate=None, eigen_of=None, qfactor=None, freqK=None, rate=None):
+    def eval_batch(self, branch, gene_rate=None, eigen_of=None, qfactor=None, freqK=None, rate=None, want_lnf=False):
         """lnL of every row of branch[n_batch][n_nodes] in one launch (paml_amd_eval_batch); the optional tables carry
         one leading batch axis over the layouts of set_classes."""
         b = np.ascontiguousarray(branch, dtype=np.float64)
@@ -209,9 +209,10 @@ class Engine:
         g, eo = opt(gene_rate, np.float64), opt(eigen_of, np.int32)
         qf, fk, rt = opt(qfactor, np.float64), opt(freqK, np.float64), opt(rate, np.float64)
         out = np.zeros(nb)
-        self._L.paml_amd_eval_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
-        self._chk(self._L.paml_amd_eval_batch(self._h, nb, _p(b), _p(g), _p(eo), _p(qf), _p(fk), _p(rt), _p(out)))
-        return out
+        lnf = np.zeros((nb, self.n_patt)) if want_lnf else None
+        self._L.paml_amd_eval_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
+        self._chk(self._L.paml_amd_eval_batch(self._h, nb, _p(b), _p(g), _p(eo), _p(qf), _p(fk), _p(rt), _p(out), _p(lnf)))
+        return (out, lnf) if want_lnf else out
 
     def eval_device(self, branch, d_lnL_ptr, gene_rate=None):
         b = np.ascontiguousarray(branch, dtype=np.float64)

@@ -33,6 +33,15 @@ int main(int argc, char **argv)
       printf("%s after %d likelihood evaluations\nx:", rc ? "iteration limit reached" : "converged", n_eval);
       for (i = 0; i < np; i++) printf(" %.6f", x[i]);
       printf("\n");
+      {
+         double *se = (double *)malloc((np + 1) * sizeof(double));
+         if (!pamlh_standard_errors(p, x, 0, se, NULL)) {
+            printf("SEs for parameters:\n ");
+            for (i = 0; i < np; i++) printf(" %.6f", se[i]);
+            printf("\n");
+         }
+         free(se);
+      }
    }
    if (pamlh_set_x(p, x, np)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
    lnf = (double *)malloc(npatt * sizeof(double));

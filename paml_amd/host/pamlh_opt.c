@@ -31,7 +31,12 @@ static int upload_eigen(pamlh *p, int base)
 /* lnL at nb parameter vectors xs[nb][np] in one launch.  Vectors whose substitution-model part (x[ntime..np)) is equal
  * share one model set-up (eigen decompositions are the host's expensive part); a vector the model rejects
  * (e.g. class proportions summing above 1) gets lnL = -1e300. */
-int pamlh_eval_batch_gpu(pamlh *p, int nb, const double *xs, double *lnL)
+static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, double *lnf);
+
+int pamlh_eval_batch_gpu(pamlh *p, int nb, const double *xs, double *lnL) { return eval_batch_lnf(p, nb, xs, lnL, NULL); }
+
+/* ... with the per-pattern log f_h of every vector, lnf[nb][npatt], when lnf is not NULL */
+static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, double *lnf)
 {
    const int np = p->np, nt = p->ntime, nm = np - nt, nn = p->nnode;
    int *rep_of = (int *)malloc(nb * sizeof(int)), *rep_elem = (int *)malloc(nb * sizeof(int)), nrep = 0, b, r, i, rc = 0;
@@ -77,7 +82,7 @@ int pamlh_eval_batch_gpu(pamlh *p, int nb, const double *xs, double *lnL)
       }
    }
    if ((rc = paml_amd_set_pi(p->eng, 1, p->pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, 1, rep_eo, NULL)) ||
-       (rc = paml_amd_eval_batch(p->eng, nb, br, NULL, eo, NULL, fk, rt, lnL))) {
+       (rc = paml_amd_eval_batch(p->eng, nb, br, NULL, eo, NULL, fk, rt, lnL, lnf))) {
       rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
       goto done;
    }
@@ -268,4 +273,120 @@ done:
    if (n_eval_out) *n_eval_out = n_eval;
    free(lo); free(hi); free(g); free(g0); free(d); free(s); free(y); free(Hy); free(H); free(xs); free(ls); free(fixed);
    return rc ? rc : status;
+}
+
+/* Gauss-Jordan inverse of the nf x nf matrix M (row-major, destroyed); returns 0, or -1 when singular */
+static int invert(double *M, int nf, double *inv)
+{
+   int i, j, k;
+   for (i = 0; i < nf; i++)
+      for (j = 0; j < nf; j++) inv[i * nf + j] = (i == j);
+   for (k = 0; k < nf; k++) {
+      int piv = k;
+      double d;
+      for (i = k + 1; i < nf; i++)
+         if (fabs(M[i * nf + k]) > fabs(M[piv * nf + k])) piv = i;
+      if (fabs(M[piv * nf + k]) < 1e-300) return -1;
+      if (piv != k)
+         for (j = 0; j < nf; j++) {
+            d = M[k * nf + j]; M[k * nf + j] = M[piv * nf + j]; M[piv * nf + j] = d;
+            d = inv[k * nf + j]; inv[k * nf + j] = inv[piv * nf + j]; inv[piv * nf + j] = d;
+         }
+      d = M[k * nf + k];
+      for (j = 0; j < nf; j++) { M[k * nf + j] /= d; inv[k * nf + j] /= d; }
+      for (i = 0; i < nf; i++)
+         if (i != k && M[i * nf + k] != 0) {
+            d = M[i * nf + k];
+            for (j = 0; j < nf; j++) { M[i * nf + j] -= d * M[k * nf + j]; inv[i * nf + j] -= d * inv[k * nf + j]; }
+         }
+   }
+   return 0;
+}
+
+/* Standard errors at the estimate x (getSE = 1).  hess (may be NULL) receives the information matrix used, np x np.
+ *
+ * method 0 — what the reference prints: HessianSKT2004 (treesub.c:7241-7307; Seo, Kishino & Thorne 2004), the outer
+ *   product of per-pattern scores  I_ij = sum_h w_h d_i(h) d_j(h),  d_i(h) = (log f_h(x + e_i) - log f_h(x - e_i)) / (2 e_i),
+ *   e_i = 2 Small_Diff (|x_i| + 1) with Small_Diff = 0.5e-6, inverted as a whole (baseml.c:580-600).  The 2 np perturbed
+ *   evaluations, each with its per-pattern log f_h, are ONE batch on the GPU.
+ * method 1 — the observed information by central second differences of lnL (Hessian() tools.c:5984), the 2 np^2 + 1 point
+ *   stencil again one batch; parameters on a bound are left out and get se = -1. */
+int pamlh_standard_errors(pamlh *p, const double *x, int method, double *se, double *hess)
+{
+   const int n = p->np, npatt = p->npatt;
+   double *lo = (double *)malloc((n + 1) * sizeof(double)), *hi = (double *)malloc((n + 1) * sizeof(double)), *h = (double *)malloc((n + 1) * sizeof(double));
+   double *H = (double *)calloc((size_t)n * n + 1, sizeof(double)), *A = NULL, *Ai = NULL, *xs = NULL, *ls = NULL, *lf = NULL;
+   int *freev = (int *)malloc((n + 1) * sizeof(int)), nf = 0, i, j, rc = 0;
+   if (n == 0) goto done;
+   if (pamlh_bounds(p, lo, hi)) { rc = pamlh_fail(p, "internal: bounds do not match np"); goto done; }
+   for (i = 0; i < n; i++) se[i] = -1;
+   if (method == 0) {
+      int hp;
+      xs = (double *)malloc((size_t)2 * n * n * sizeof(double));
+      ls = (double *)malloc((size_t)2 * n * sizeof(double));
+      lf = (double *)malloc((size_t)2 * n * npatt * sizeof(double));
+      for (i = 0; i < n; i++) {
+         h[i] = 1e-6 * (fabs(x[i]) + 1);
+         memcpy(xs + (size_t)(2 * i) * n, x, n * sizeof(double));
+         memcpy(xs + (size_t)(2 * i + 1) * n, x, n * sizeof(double));
+         xs[(size_t)(2 * i) * n + i] = x[i] - h[i];
+         xs[(size_t)(2 * i + 1) * n + i] = x[i] + h[i];
+      }
+      if ((rc = eval_batch_lnf(p, 2 * n, xs, ls, lf))) goto done;
+      for (i = 0; i < n; i++)         /* scores, in place over the "minus" rows */
+         for (hp = 0; hp < npatt; hp++)
+            lf[(size_t)(2 * i) * npatt + hp] = (lf[(size_t)(2 * i + 1) * npatt + hp] - lf[(size_t)(2 * i) * npatt + hp]) / (2 * h[i]);
+      for (i = 0; i < n; i++)
+         for (j = 0; j <= i; j++) {
+            double s = 0;
+            for (hp = 0; hp < npatt; hp++) s += lf[(size_t)(2 * i) * npatt + hp] * lf[(size_t)(2 * j) * npatt + hp] * p->w[hp];
+            H[i * n + j] = H[j * n + i] = s;
+         }
+      for (i = 0; i < n; i++) freev[nf++] = i;
+   }
+   else {
+      const size_t npts = (size_t)2 * n * n + 1;
+      size_t q = 0;
+      xs = (double *)malloc(npts * n * sizeof(double));
+      ls = (double *)malloc(npts * sizeof(double));
+      for (i = 0; i < n; i++) {
+         h[i] = 1e-4 * (fabs(x[i]) + 1);
+         if (x[i] - h[i] >= lo[i] && x[i] + h[i] <= hi[i]) freev[nf++] = i;
+      }
+#define PT(di, si, dj, sj)                                                                                       \
+   do {                                                                                                          \
+      double *v = xs + q * n;                                                                                    \
+      memcpy(v, x, n * sizeof(double));                                                                          \
+      v[di] += (si) * h[di];                                                                                     \
+      if ((dj) >= 0) v[dj] += (sj) * h[dj];                                                                      \
+      q++;                                                                                                       \
+   } while (0)
+      memcpy(xs, x, n * sizeof(double));
+      q = 1;
+      for (i = 0; i < nf; i++) { PT(freev[i], +1, -1, 0); PT(freev[i], -1, -1, 0); }
+      for (i = 0; i < nf; i++)
+         for (j = i + 1; j < nf; j++) { PT(freev[i], +1, freev[j], +1); PT(freev[i], +1, freev[j], -1); PT(freev[i], -1, freev[j], +1); PT(freev[i], -1, freev[j], -1); }
+#undef PT
+      if ((rc = pamlh_eval_batch_gpu(p, (int)q, xs, ls))) goto done;
+      q = 1;
+      for (i = 0; i < nf; i++, q += 2) {
+         const int a = freev[i];
+         H[a * n + a] = -(ls[q] - 2 * ls[0] + ls[q + 1]) / (h[a] * h[a]);
+      }
+      for (i = 0; i < nf; i++)
+         for (j = i + 1; j < nf; j++, q += 4) {
+            const int a = freev[i], b = freev[j];
+            H[a * n + b] = H[b * n + a] = -(ls[q] - ls[q + 1] - ls[q + 2] + ls[q + 3]) / (4 * h[a] * h[b]);
+         }
+   }
+   if (hess) memcpy(hess, H, (size_t)n * n * sizeof(double));
+   A = (double *)malloc((size_t)nf * nf * sizeof(double) + 8);
+   Ai = (double *)malloc((size_t)nf * nf * sizeof(double) + 8);
+   for (i = 0; i < nf; i++)
+      for (j = 0; j < nf; j++) A[i * nf + j] = H[freev[i] * n + freev[j]];
+   if (invert(A, nf, Ai)) { rc = pamlh_fail(p, "the information matrix is singular"); goto done; }
+   for (i = 0; i < nf; i++) se[freev[i]] = Ai[i * nf + i] > 0 ? sqrt(Ai[i * nf + i]) : -1;
+done:
+   free(lo); free(hi); free(h); free(xs); free(ls); free(lf); free(H); free(A); free(Ai); free(freev);
+   return rc;
 }

@@ -54,6 +54,7 @@ def lib():
         L.pamlh_eval_gpu.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
         L.pamlh_eval_batch_gpu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pamlh_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pamlh_standard_errors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pamlh_optimize.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]
         _L = L
     return _L
@@ -168,3 +169,12 @@ class Analysis:
         if rc < 0:
             raise RuntimeError("pamlh_optimize: " + self._L.pamlh_error(self._h).decode())
         return dict(x=x, lnL=lnl.value, converged=rc == 0, n_eval=nev.value)
+
+    def standard_errors(self, x, method=0):
+        """Standard errors at the estimate x (pamlh_standard_errors): method 0 = the reference's HessianSKT2004 outer
+        product of scores, method 1 = second differences of lnL; -1 marks a parameter without an estimate."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        se, H = np.zeros(self.np), np.zeros((self.np, self.np))
+        if self._L.pamlh_standard_errors(self._h, x.ctypes.data_as(C.c_void_p), int(method), se.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("pamlh_standard_errors: " + self._L.pamlh_error(self._h).decode())
+        return se, H

@@ -286,9 +286,10 @@ def test_eval_batch_matches_single_evals(n, K, amb, genes):
         ref = oracle.evaluate(q)["lnL"]
         assert abs(got[b] - ref) <= 1e-10 * abs(ref), (b, got[b], ref)
     # shared tables (NULL) and a plain evaluation afterwards
-    got2 = eng.eval_batch(br, gene_rate=np.tile(pb.gene_rate, (B, 1)))
-    one = eng.eval(br[3], pb.gene_rate)["lnL"]
-    assert got2[3] == one
+    got2, lnf2 = eng.eval_batch(br, gene_rate=np.tile(pb.gene_rate, (B, 1)), want_lnf=True)
+    one = eng.eval(br[3], pb.gene_rate, want_lnf=True)
+    assert got2[3] == one["lnL"]
+    assert np.array_equal(lnf2[3], one["lnf"])                  # per-pattern log f_h of every element (HessianSKT2004's input)
 
 
 def test_eval_batch_per_element_eigen_sets():

@@ -126,3 +126,19 @@ def test_c_host_batch_matches_single_evaluations():
     for b in (1, 2, 4, 5):
         one, _ = a.eval_gpu(xs[b], want_lnf=False)
         assert abs(got[b] - one) <= 1e-9 * abs(one)
+
+
+@pytest.mark.gpu
+def test_c_host_standard_errors_match_the_reference():
+    """getSE = 1 on brown.nuc / HKY85: the reference binary (run in the build container) prints these SEs for the seven
+    branch lengths and kappa; it gets them from HessianSKT2004's outer product of per-pattern scores (method 0 here, the
+    2 np perturbed evaluations with their per-pattern log f_h being one batch).  Method 1 (second differences of lnL) is
+    the observed information: positive definite at the maximum and within a few per cent of method 0."""
+    ref_se = np.array([0.010924, 0.006479, 0.008301, 0.009329, 0.010454, 0.013492, 0.016238, 1.301409])
+    a = hostlib.Analysis(os.path.join(CTL, "brown_hky85.ctl"), "baseml")
+    r = a.optimize(a.default_x())
+    se0, I0 = a.standard_errors(r["x"], method=0)
+    assert np.max(np.abs(se0 - ref_se) / ref_se) < 2e-4, se0
+    se1, H = a.standard_errors(r["x"], method=1)
+    assert np.allclose(H, H.T) and (np.linalg.eigvalsh(H) > 0).all()
+    assert np.max(np.abs(se1 - se0) / se0) < 0.06
