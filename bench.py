@@ -141,7 +141,7 @@ def main():
                          "pmat_ms": prof["ms_pmat"] / max(1, prof["n_evals"]),
                          "reduce_ms": prof["ms_reduce"] / max(1, prof["n_evals"])},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(pb, args.cpu_sample)
             out["speedup_vs_cpu_1core"] = value / world / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
