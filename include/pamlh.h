@@ -8,7 +8,8 @@
  * (codeml.c:2757, baseml.c:1306) does: branch lengths, pi, eigen systems, site classes.  It then drives
  * libpaml_amd.so through include/paml_amd.h.  Scope (this round): codeml seqtype 1 (icode 0; CodonFreq 0-3; NSsites
  * 0,1,2,7,8; model 0) and seqtype 2 (aa models 0,2,3), baseml models JC69,K80,F81,HKY85,TN93,REV; +Gamma; one gene;
- * clock 0; cleandata 0/1.  Anything else fails with a message instead of guessing.
+ * clock 0; cleandata 0/1; sequential and interleaved (I) PHYLIP, the P pattern format.  Anything else fails with a message
+ * instead of guessing.
  */
 #ifndef PAMLH_H
 #define PAMLH_H

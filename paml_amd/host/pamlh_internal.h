@@ -8,7 +8,7 @@
 enum { JC69, K80, F81, F84, HKY85, T92, TN93, REV };   /* baseml models (baseml.ctl) */
 
 typedef struct {
-   char key[32][PAMLH_MAXOPT], val[256][PAMLH_MAXOPT];
+   char key[PAMLH_MAXOPT][32], val[PAMLH_MAXOPT][1024];   /* up to PAMLH_MAXOPT `key = value` lines */
    int n;
 } pamlh_ctl;
 

@@ -52,7 +52,7 @@ int pamlh_read_ctl(pamlh *p, const char *path)
       while (e > v && isspace((unsigned char)e[-1])) *--e = 0;
       if (!*k || p->ctl.n >= PAMLH_MAXOPT) continue;
       snprintf(p->ctl.key[p->ctl.n], 32, "%s", k);
-      snprintf(p->ctl.val[p->ctl.n], 256, "%s", v);
+      snprintf(p->ctl.val[p->ctl.n], 1024, "%s", v);
       p->ctl.n++;
    }
    fclose(f);
@@ -103,7 +103,8 @@ int pamlh_read_seqs(pamlh *p)
    FILE *f = fopen(p->seqfile, "r");
    char *line;
    size_t cap = 1 << 16;
-   int ns, lsraw, i, j, k, h, readpattern = 0, any_amb = 0, n31 = (p->seqtype == 1 ? 3 : 1);
+   int ns, lsraw, i, j, k, h, readpattern = 0, interleaved = 0, any_amb = 0, n31 = (p->seqtype == 1 ? 3 : 1);
+   int *pos;
    const char *alpha = p->seqtype == 2 ? AAs : BASEs;
    const int nbasic = p->seqtype == 2 ? 20 : 4;
    char *seq;
@@ -120,7 +121,7 @@ int pamlh_read_seqs(pamlh *p)
             if (o == 'P') readpattern = 1;
             else if (o == 'G') hasG = 1;
             else if (o == 'C') hasC = 1;
-            else if (o == 'I') { fclose(f); free(line); return pamlh_fail(p, "interleaved sequence files are not supported yet"); }
+            else if (o == 'I') interleaved = 1;
             else if (o != 'S') { fclose(f); free(line); return pamlh_fail(p, "bad option '%c' in first line of seqfile", o); }
          }
          c++;
@@ -131,6 +132,11 @@ int pamlh_read_seqs(pamlh *p)
    p->ns = ns; p->n31 = n31;
    p->names = (char **)calloc(ns, sizeof(char *));
    seq = (char *)malloc((size_t)ns * lsraw);
+   pos = (int *)calloc(ns, sizeof(int));
+   /* sequential: each sequence runs on over as many lines as it needs.  Interleaved (option I, ReadSeq treesub.c:487):
+    * the first block has name + first stretch of every sequence, one line each; the following blocks continue the
+    * sequences in the same order without names */
+   for (i = 0; i == 0 || (interleaved && pos[ns - 1] < lsraw); i++)
    for (j = 0; j < ns; j++) {
       char *q, *dbl;
       do {
@@ -138,7 +144,7 @@ int pamlh_read_seqs(pamlh *p)
          for (q = line; *q && isspace((unsigned char)*q); q++) ;
       } while (!*q);
       dbl = strstr(q, "  ");
-      {
+      if (i == 0) {
          size_t ln = dbl ? (size_t)(dbl - q) : strcspn(q, "\r\n");
          size_t tl = strcspn(q, "\t\r\n");
          if (tl < ln) ln = tl;
@@ -148,8 +154,9 @@ int pamlh_read_seqs(pamlh *p)
          while (ln > 0 && isspace((unsigned char)p->names[j][ln - 1])) p->names[j][--ln] = 0;
          q += (dbl ? (size_t)(dbl - q) : strlen(q));
       }
-      for (k = 0; k < lsraw;) {
+      for (k = pos[j]; k < lsraw;) {
          if (!*q) {
+            if (interleaved) break;            /* the rest of this sequence is in the next block */
             if (!fgets(line, (int)cap, f)) { fclose(f); return pamlh_fail(p, "EOF at site %d, seq %d", k + 1, j + 1); }
             q = line;
             continue;
@@ -169,7 +176,11 @@ int pamlh_read_seqs(pamlh *p)
             else if (isalpha((unsigned char)ch)) { fclose(f); return pamlh_fail(p, "bad character %c at %d seq %d", ch, k + 1, j + 1); }
          }
       }
+      pos[j] = k;
    }
+   for (j = 0; j < ns; j++)
+      if (pos[j] != lsraw) { fclose(f); return pamlh_fail(p, "sequence %d has %d of %d characters", j + 1, pos[j], lsraw); }
+   free(pos);
    /* pattern counts of the P format: npatt numbers after the sequences (treesub.c:954-983) */
    {
       const int nsite = lsraw / n31;

@@ -142,3 +142,35 @@ def test_c_host_standard_errors_match_the_reference():
     se1, H = a.standard_errors(r["x"], method=1)
     assert np.allclose(H, H.T) and (np.linalg.eigvalsh(H) > 0).all()
     assert np.max(np.abs(se1 - se0) / se0) < 0.06
+
+
+def test_c_host_reads_interleaved_phylip(tmp_path):
+    """Option I (ReadSeq treesub.c:487): the same alignment written in interleaved blocks gives the same patterns."""
+    src = os.path.join(helpers.GOLDEN, "data", "brown.nuc")
+    toks = open(src).read().split()
+    ns, ls = int(toks[0]), int(toks[1])
+    names, seqs, k = [], [], 2
+    for _ in range(ns):
+        names.append(toks[k])
+        k += 1
+        s = ""
+        while len(s) < ls:
+            s += toks[k]
+            k += 1
+        seqs.append(s)
+    with open(tmp_path / "brown_i.nuc", "w") as f:
+        f.write(" %d %d  I\n" % (ns, ls))
+        for b in range(0, ls, 60):
+            for j in range(ns):
+                f.write(("%-12s  " % names[j] if b == 0 else "") + " ".join(seqs[j][b + c:b + c + 10] for c in range(0, min(60, ls - b), 10)) + "\n")
+            f.write("\n")
+    ctl = open(os.path.join(CTL, "brown_hky85.ctl")).read()
+    ctl = ctl.replace("../data/brown.nuc", str(tmp_path / "brown_i.nuc")).replace("../data/brown.trees", os.path.join(helpers.GOLDEN, "data", "brown.trees"))
+    (tmp_path / "b.ctl").write_text(ctl)
+    a = hostlib.Analysis(os.path.join(CTL, "brown_hky85.ctl"), "baseml")
+    b = hostlib.Analysis(str(tmp_path / "b.ctl"), "baseml")
+    g = helpers.load_golden("brown_hky85")
+    x = np.array(g["x"])
+    pa, pb = a.problem(x), b.problem(x)
+    assert np.array_equal(pa.z, pb.z) and np.array_equal(pa.weights, pb.weights) and b.ls == a.ls
+    assert abs(oracle.evaluate(pb)["lnL"] - g["lnL"]) <= 2e-6
