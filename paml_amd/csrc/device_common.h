@@ -58,6 +58,7 @@ struct PruneArgs {
    double *export_scale;       // OP_EXPORT: summed scale factors of the exported partial [K][n_patt] (null: none)
    unsigned long long *prof;   // PROF_OPS builds only: [block][op] s_memtime stamps of thread 0
    int prof_stride, prof_tid;
+   const double *pcol;         // jit kernel, 61 states: column 60 of every P, [pset][n_nodes][q][m] (rank-1 tail of the matmul)
    double *fscale;             // jit kernel with scaling nodes: summed scale factors [K][n_patt] (the log is taken later)
    const unsigned char *ztiles; // jit kernel: per tile, (n_tips + 1) rows of 128 bytes (tip codes of the tile's patterns,
    int zt_bytes;                // then the weight > 0 flags), zero padded to zt_bytes (a multiple of 2048)
@@ -213,10 +214,28 @@ __device__ __forceinline__ void tip_lds(const double *tab, int code, int q, int 
 // `side(kb2)` runs once per k-block pair between the two MFMA groups: the generator puts the ring's refill DMAs there
 // (a few per iteration) so that their issue — which can queue behind the other waves' — never delays the first MFMAs.
 struct JitNoSide { __device__ __forceinline__ void operator()(int) const {} };
-template <class SIDE = JitNoSide>
-__device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4], SIDE side = SIDE())
+// 61 states: the sixteenth k-block of P holds the single column 60.  With `col` (that column as col[q][m] = P[4m+q][60])
+// its contribution y[m] += P[4m+q][60] * x[60] seeds the accumulators as sixteen v_mul_f64 and the four MFMAs of that
+// k-block are skipped (x[60] lives in element 15 of the q = 0 lane of the pattern: one cross-lane read).
+__device__ __forceinline__ void jit_col_seed(const double *col, int lane, const v4d (&x)[4], v4d (&z)[4])
+{
+   const double x60 = __shfl(x[3][3], lane & 15);
+   const double2 *pc = (const double2 *)(col + (lane >> 4) * 16);
+#pragma unroll
+   for (int i = 0; i < 8; i++) {
+      const double2 c = pc[i];
+      z[i >> 1][(2 * i) & 3] = c.x * x60;
+      z[i >> 1][(2 * i + 1) & 3] = c.y * x60;
+   }
+}
+
+template <bool TAIL61 = false, class SIDE = JitNoSide>
+__device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4], SIDE side = SIDE(),
+                                           const double *col = nullptr)
 {
    const double2 *sp = (const double2 *)sPbuf;
+   v4d z[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+   if constexpr (TAIL61) jit_col_seed(col, lane, x, z);
    double2 af[2][4];
 #pragma unroll
    for (int jb = 0; jb < 4; jb++) af[0][jb] = sp[jb * 64 + lane];
@@ -231,15 +250,17 @@ __device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const 
       if (kb2 == 0) {
 #pragma unroll
          for (int jb = 0; jb < 4; jb++)
-            y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][jb].x, b0, (v4d){0, 0, 0, 0}, 0, 0, 0);
+            y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][jb].x, b0, z[jb], 0, 0, 0);
       }
       else {
 #pragma unroll
          for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
       }
       side(kb2);
+      if (!(TAIL61 && kb2 == 7)) {
 #pragma unroll
-      for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+         for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
    }
 }
@@ -248,11 +269,13 @@ __device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const 
 // follows in the program) gathered from LDS under the second half of the MFMAs, where the matrix pipe hides the
 // ds_read_b128 traffic and its bank conflicts.  The two tip tables are the ring blocks after P; they only have to be
 // resident by the midpoint, so MIDWAIT (outstanding vector-memory ops allowed there) + a barrier sit at kb2 == 4.
-template <int MIDWAIT, class SIDE = JitNoSide>
+template <int MIDWAIT, bool TAIL61 = false, class SIDE = JitNoSide>
 __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4], const double *ta, int ca,
-                                                const double *tb, int cb, int q, v4d (&t)[4], SIDE side = SIDE())
+                                                const double *tb, int cb, int q, v4d (&t)[4], SIDE side = SIDE(), const double *col = nullptr)
 {
    const double2 *sp = (const double2 *)sPbuf;
+   v4d z[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+   if constexpr (TAIL61) jit_col_seed(col, lane, x, z);
    double2 af[2][4];
    const int rowa = ca * 4 + q, rowb = cb * 4 + q, swa = TIP_SWZ(rowa), swb = TIP_SWZ(rowb);
    const char *pa = (const char *)ta + rowa * 128, *pb = (const char *)tb + rowb * 128;
@@ -282,7 +305,7 @@ __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, c
       if (kb2 == 0) {
 #pragma unroll
          for (int jb = 0; jb < 4; jb++)
-            y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][jb].x, b0, (v4d){0, 0, 0, 0}, 0, 0, 0);
+            y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][jb].x, b0, z[jb], 0, 0, 0);
       }
       else {
 #pragma unroll
@@ -297,8 +320,10 @@ __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, c
          }
       }
       side(kb2);
+      if (!(TAIL61 && kb2 == 7)) {
 #pragma unroll
-      for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+         for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
    }
 #pragma unroll
@@ -549,6 +574,7 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
    __shared__ __attribute__((aligned(16))) double ring[4 * 4096];                                               \
    __shared__ __attribute__((aligned(16))) unsigned char sZ[2 * (ZP)*2048];                                      \
    __shared__ double sPi[4 * 64];                                                                               \
+   __shared__ __attribute__((aligned(16))) double sCol[4 * 64 + 32];                                            \
    const int tid = threadIdx.x, lane = tid & 63;                                                                \
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                   \
    const int q = lane >> 4, hl = lane & 15;                                                                     \
@@ -556,6 +582,8 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
    const int n = a.n;                                                                                           \
    const int total_work = a.n_tiles * a.K;                                                                      \
    int work = blockIdx.x;                                                                                       \
+   const double *Pcol = a.pcol, *nPcol = a.pcol;                                                                \
+   (void)sCol; (void)Pcol; (void)nPcol;                                                                         \
    int iclass = 0, gene = 0, h0 = 0, hend = 1, h = 0;                                                           \
    int n_tile = 0, n_gene = 0, n_iclass = 0, n_h0 = 0, n_hend = 1;                                              \
    bool valid = false, has_next = false;                                                                        \
@@ -573,9 +601,10 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
       n_hend = as_const(a.gene_off)[n_gene + 1];                                                                \
       nPint = a.pint + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 4096;                                      \
       nPtip = a.ptip + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 4096;                                      \
+      nPcol = a.pcol + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 64;                                        \
    }   /* past the last tile the n_* values stay: the (unused) prefetches keep reading valid memory */
 #define JIT2_ADVANCE(NBLK)                                                                                       \
-   iclass = n_iclass; gene = n_gene; h0 = n_h0; hend = n_hend; Pint = nPint; Ptip = nPtip;                      \
+   iclass = n_iclass; gene = n_gene; h0 = n_h0; hend = n_hend; Pint = nPint; Ptip = nPtip; Pcol = nPcol;        \
    h = h0 + hw; valid = h < hend; lnscale = 0;                                                                  \
    roff = (roff + (NBLK)) & 3; zsel ^= 1;
 /* the next tile's code block -> the sZ buffer not in use (ZP dword pieces per thread) */
@@ -586,6 +615,14 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
          dma4(zr_, sZ + (zsel ^ 1) * ((ZP)*2048) + (c_ * 8 + wave) * 256, lane * 4, (c_ * 8 + wave) * 256);      \
    }
 #define JIT2_BUF(J) (ring + (((J) + roff) & 3) * 4096)
+/* the column-60 table that travels with a P block (61 states): 512 bytes, fetched as one dword DMA piece per thread so
+ * that every wave issues the same number of vector-memory instructions — waves 0 and 1 carry the data, the descriptor
+ * ends after 512 bytes, and the zeros the other waves' lanes read go to a 256-byte dump slot behind the four tables */
+#define JIT2_COL(J) (sCol + (((J) + roff) & 3) * 64)
+#define JIT2_PIECE_C(SRC, J)                                                                                         \
+   dma4(make_rsrc((SRC), 512), wave < 2 ? (const char *)JIT2_COL(J) + wave * 256 : (const char *)(sCol + 256), lane * 4, wave * 256)
+#define JIT2_PIECE_PC(J, NODE) JIT2_PIECE_C(Pcol + (long)(NODE)*64, J)
+#define JIT2_PIECE_NPC(J, NODE) JIT2_PIECE_C(nPcol + (long)(NODE)*64, J)
 #define JIT2_PIECE(SRC, J, C)                                                                                        \
    dma16(make_rsrc((SRC), 32768), (const char *)JIT2_BUF(J) + ((C)*8 + wave) * 1024, lane * 16, ((C)*8 + wave) * 1024)
 #define JIT2_PIECE_P(J, NODE, C) JIT2_PIECE(Pint + (long)(NODE)*4096, J, C)

@@ -134,7 +134,7 @@ struct paml_amd_engine {
 
    // per-evaluation buffers
    DevBuf<double> d_b_qfactor, d_b_freqK, d_b_rate;
-   DevBuf<double> d_rowmajor, d_pint, d_ptip, d_fhK, d_fscale, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
+   DevBuf<double> d_rowmajor, d_pint, d_ptip, d_pcol, d_fhK, d_fscale, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
    DevBuf<double> d_expA, d_expB, d_expSA, d_expSB, d_deriv, d_tt, d_bpartial, d_bout;   // branch-local evaluation
    DevBuf<int> d_label_eff;
    DevBuf<Op> d_ops_tmp;
@@ -167,7 +167,7 @@ struct paml_amd_engine {
       d_eigen.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
+                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
                               &d_expA, &d_expB, &d_expSA, &d_expSB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
    }
@@ -398,6 +398,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // P(t) storage
    HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
    if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
+   if (e->kk == KK_MFMA64) HIPCHK(e->d_pcol.ensure((size_t)psets * nn * 64));
    HIPCHK(e->d_ptip.ensure((size_t)psets * nn * tip_words(e)));
    HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
    // kernel choice for the 21..64-state path:
@@ -410,7 +411,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
       bool jit_ok = false;
       if (e->jit_enabled && !getenv("PAML_AMD_FORCE_GATHER") && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi)) {
-         int r = ensure_jit(e, "m:" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate(e->prog, e->n_tips); }, &jit_ok);
+         int r = ensure_jit(e, "m" + std::to_string(n) + ":" + jit_program_key(e->prog, e->n_tips),
+                            [&]() { return jit_generate(e->prog, e->n_tips, n); }, &jit_ok);
          if (r) return r;
       }
       e->use_jit = jit_ok;
@@ -458,7 +460,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
    pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
    pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
-   pa.B = B; pa.branch_bs = nn; pa.gene_rate_bs = G;
+   pa.B = B; pa.branch_bs = nn; pa.gene_rate_bs = G; pa.pcol = e->kk == KK_MFMA64 ? e->d_pcol.p : nullptr;
    if (bs && bs->eigen_of) { pa.eigen_of = e->d_b_eigen_of.p; pa.eigen_of_bs = (long)G * Km * e->n_labels; }
    if (bs && bs->qfactor) { pa.qfactor = e->d_b_qfactor.p; pa.qfactor_bs = (long)Km * e->n_labels; }
    if (bs && bs->rate) { pa.rate = e->d_b_rate.p; pa.rate_bs = Km; }
@@ -476,7 +478,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.keep = keep ? 1 : 0; pr.n_patt = e->n_patt;
    pr.pi = e->d_pi.p; pr.pint = e->kk == KK_MFMA64 ? e->d_pint.p : e->d_rowmajor.p; pr.ptip = e->d_ptip.p;
    if (e->use_jit && e->tree.n_scale) HIPCHK(e->d_fscale.ensure((size_t)K * e->n_patt));
-   pr.fscale = e->d_fscale.p;
+   pr.fscale = e->d_fscale.p; pr.pcol = e->d_pcol.p;
    pr.fhK = e->d_fhK.p; pr.partials = e->d_partials.p; pr.scalef = e->d_scalef.p; pr.stack_scratch = e->d_stack.p;
    pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
    pr.first_tip = e->prog.first_tip;

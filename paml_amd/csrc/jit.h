@@ -38,7 +38,7 @@ inline int jit_zpieces(int n_tips) { return ((n_tips + 1) * 128 + 2047) / 2048; 
 inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6)
 {
    if (n_codes > 64 || p.ops.size() > 400 || n_pi > 4) return false;
-   if (4 * 32768 + 2 * jit_zpieces(n_tips) * 2048 + 4 * 64 * 8 > 160 * 1024) return false;   // LDS: ring + two code blocks + pi
+   if (4 * 32768 + 2 * jit_zpieces(n_tips) * 2048 + 4 * 64 * 8 + (4 * 64 + 32) * 8 > 160 * 1024) return false;   // LDS: ring, 2 code blocks, pi, column tables (<= 95 tips)
    if (p.stream.size() / 2 < 4) return false;                       // trees this small go to the interpreter
    for (const Op &o : p.ops)
       if (o.code == OP_STORE || o.code == OP_LOAD) return false;   // keep-partials layouts stay with the interpreter
@@ -63,7 +63,7 @@ inline std::string jit_program_key(const Program &p, int n_tips)
 // own first cherry was done that way by its predecessor; the first tile's is peeled in front of the loop).
 // `first` = operand blocks of a tile already requested when the loop body starts (the body's last step leaves the
 // same number of the next tile's in flight; *first_out reports it so that jit_generate can make the two agree).
-inline std::string jit_generate_impl(const Program &p, int n_tips, int first, int *first_out)
+inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states, int first, int *first_out)
 {
    std::ostringstream s;
    const int nblk = (int)p.stream.size() / 2;
@@ -72,6 +72,9 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int first, in
    const bool fuse_tips = !getenv("PAML_AMD_JIT_NOFUSE");   // cherries gathered under the preceding matmul
    const bool spread = !getenv("PAML_AMD_JIT_NOSPREAD");    // ring refill issued from inside the MFMA loops
    const bool prof = getenv("PAML_AMD_PROF_OPS") != nullptr; // kernel experiments: s_memtime stamp at every op
+   // 61 states: the last k-block of P is the single column 60 — its rank-1 term goes through the vector pipe (a 512-byte
+   // column table travels with every P block as a fifth DMA piece) and the k-block's four MFMAs are dropped
+   const bool tail61 = n_states == 61 && !getenv("PAML_AMD_JIT_NOTAIL");
    int last_mm = -1;
    for (size_t i = 0; i < nops; i++)
       if (p.ops[i].code == OP_MATMUL || p.ops[i].code == OP_MATMUL_POP) last_mm = (int)i;
@@ -93,17 +96,19 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int first, in
    struct Item { int id, pieces; };          // id: block number within the tile (>= nblk: next tile's), -1: a code block
    std::vector<Item> fl;                     // issued, not yet known landed; oldest first
    int issued = 0, consumed = 0;
-   auto piece = [&](int blk, int c4) {       // source text of one DMA piece of block blk
+   auto n_pieces = [&](int blk) { return (tail61 && !p.stream[2 * (blk % nblk)]) ? 5 : 4; };
+   auto piece = [&](int blk, int c4) {       // source text of one DMA piece of block blk (piece 4: the column table)
       const bool nx = blk >= nblk;
       const int loc = blk % nblk, is_tip = p.stream[2 * loc], node = p.stream[2 * loc + 1];
+      if (c4 == 4) return std::string("JIT2_PIECE_") + (nx ? "NPC(" : "PC(") + std::to_string(blk) + ", " + std::to_string(node) + ");";
       return std::string("JIT2_PIECE_") + (nx ? "N" : "") + (is_tip ? "T(" : "P(") + std::to_string(blk) + ", " + std::to_string(node) + ", " +
              std::to_string(c4) + ");";
    };
    auto issue_now = [&]() {
       s << "  ";
-      for (int c4 = 0; c4 < 4; c4++) s << " " << piece(issued, c4);
+      for (int c4 = 0; c4 < n_pieces(issued); c4++) s << " " << piece(issued, c4);
       s << "\n";
-      fl.push_back({issued, 4});
+      fl.push_back({issued, n_pieces(issued)});
       issued++;
    };
    auto wait_count = [&](int blk) {          // pieces that may stay in flight once block blk has to be complete
@@ -137,8 +142,8 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int first, in
       while (issued < consumed + now && issued < upto) issue_now();
       std::vector<std::string> pieces;
       while (issued < upto) {
-         for (int c4 = 0; c4 < 4; c4++) pieces.push_back(piece(issued, c4));
-         fl.push_back({issued, 4});
+         for (int c4 = 0; c4 < n_pieces(issued); c4++) pieces.push_back(piece(issued, c4));
+         fl.push_back({issued, n_pieces(issued)});
          issued++;
       }
       if (pieces.empty()) return "JitNoSide()";
@@ -159,6 +164,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int first, in
    auto code = [&](int tip) { return "JIT2_CODE(" + std::to_string(ZP) + ", " + std::to_string(tip) + ")"; };
    auto ncode = [&](int tip) { return "JIT2_NCODE(" + std::to_string(ZP) + ", " + std::to_string(tip) + ")"; };
    auto buf = [&](int blk) { return "JIT2_BUF(" + std::to_string(blk) + ")"; };
+   auto colarg = [&](int blk) { return tail61 ? ", JIT2_COL(" + std::to_string(blk) + ")" : std::string(); };
 
    // ---- in front of the loop: the first tile is the "next" tile of an empty predecessor ---------------------------
    const int NA = p.max_stack + 2 + (fuse_tips ? 1 : 0);
@@ -244,13 +250,14 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int first, in
             const Op &nx = fuse ? p.ops[iop + 1] : p.ops[0];
             tgt = fuse ? alloc() : AS;
             const int mid = wait_count(consumed + 2);
-            s << "   jit_matvec_tip2<" << (mid < 0 ? 63 : mid) << ">(" << buf(consumed) << ", lane, " << name(cur) << ", " << name(out) << ", "
-              << buf(consumed + 1) << ", " << (fuse ? code(nx.a) : ncode(nx.a)) << ", " << buf(consumed + 2) << ", "
-              << (fuse ? code(nx.b) : ncode(nx.b)) << ", q, " << name(tgt) << ", " << side << ");\n";
+            s << "   jit_matvec_tip2<" << (mid < 0 ? 63 : mid) << (tail61 ? ", true" : ", false") << ">(" << buf(consumed) << ", lane, " << name(cur)
+              << ", " << name(out) << ", " << buf(consumed + 1) << ", " << (fuse ? code(nx.a) : ncode(nx.a)) << ", " << buf(consumed + 2) << ", "
+              << (fuse ? code(nx.b) : ncode(nx.b)) << ", q, " << name(tgt) << ", " << side << colarg(consumed) << ");\n";
             consumed += 3;
          }
          else {
-            s << "   jit_matvec(" << buf(consumed) << ", lane, " << name(cur) << ", " << name(out) << ", " << side << ");\n";
+            s << "   jit_matvec<" << (tail61 ? "true" : "false") << ">(" << buf(consumed) << ", lane, " << name(cur) << ", " << name(out) << ", "
+              << side << colarg(consumed) << ");\n";
             consumed += 1;
          }
          release(cur);
@@ -294,13 +301,13 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int first, in
    return s.str();
 }
 
-inline std::string jit_generate(const Program &p, int n_tips)
+inline std::string jit_generate(const Program &p, int n_tips, int n_states = 61)
 {
    int first = 3, got = 3;
-   std::string src = jit_generate_impl(p, n_tips, first, &got);
+   std::string src = jit_generate_impl(p, n_tips, n_states, first, &got);
    if (got != first) {
       first = got;
-      src = jit_generate_impl(p, n_tips, first, &got);
+      src = jit_generate_impl(p, n_tips, n_states, first, &got);
    }
    return got == first ? src : std::string("#error \"jit schedule does not close\"\n");
 }

@@ -44,6 +44,7 @@ struct PmatArgs {
    double *pint;                 // layout 1: [pset][n_nodes][4096]
    double *ptip;                 // [pset][n_nodes][tip_words]   rows of n (VALU) or 64 (mfma64) doubles per code
    long tip_words;
+   double *pcol;                 // layout 1: [pset][n_nodes][64], column 60 per (q, m) (null: not wanted)
    // batched evaluations (paml_amd_eval_batch): B parameter sets in one launch, laid out as K*B classes; element b reads
    // branch + b*branch_bs etc. (a stride of 0 = shared with the other elements)
    int B;
@@ -166,6 +167,10 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
          int e = idx & 1, lane = (idx >> 1) & 63, jb = (idx >> 7) & 3, kb2 = idx >> 9;
          pf[idx] = sA[(jb * 16 + (lane & 15)) * 64 + 4 * (2 * kb2 + e) + (lane >> 4)];
       }
+      // column 60 in the order a lane's accumulators want it, pcol[q][m] = P[4m + q][60]: with 61 states the last
+      // k-block holds this one column, and the specialised kernel adds its rank-1 term on the vector pipe instead of
+      // spending four MFMAs on it
+      if (a.pcol && tid < 64) a.pcol[slot * 64 + tid] = sA[(4 * (tid & 15) + (tid >> 4)) * 64 + 60];
    }
    if (leaf) {
       const int tipw = a.layout == 1 ? 64 : n;

@@ -252,8 +252,8 @@ class _Sched:
             self.last_read[("z", zb)] = self.epoch
 
     def side(self, text, reading):
-        for m in re.finditer(r"JIT2_PIECE_N?[TP]\((\d+), \d+, \d\)", text):
-            j = int(m.group(1))
+        for m in re.finditer(r"JIT2_PIECE_N?(?:[TP]\((\d+), \d+, \d\)|PC\((\d+), \d+\))", text):
+            j = int(m.group(1) or m.group(2))
             assert (self.G(j) & 3) not in [(self.G(r) & 3) for r in reading if r != j], "refill of block %d lands in a buffer this step reads" % j
             self.issue_piece(j)
 
@@ -264,7 +264,7 @@ class _Sched:
                 self.tile += 1
                 self.zsel ^= 1
                 continue
-            m = re.match(r"jit_matvec_tip2<(\d+)>\(JIT2_BUF\((\d+)\), lane, \w+, \w+, JIT2_BUF\((\d+)\), (\S+ \S+), JIT2_BUF\((\d+)\), (\S+ \S+), q, \w+, (.*)\);$", line)
+            m = re.match(r"jit_matvec_tip2<(\d+), (?:true|false)>\(JIT2_BUF\((\d+)\), lane, \w+, \w+, JIT2_BUF\((\d+)\), (\S+ \S+), JIT2_BUF\((\d+)\), (\S+ \S+), q, \w+, (.*)\);$", line)
             if m:
                 mid, jp, ja, jb = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(5))
                 self.read_block(jp, "fused matmul")
@@ -276,7 +276,7 @@ class _Sched:
                 self.read_block(jb, "fused tip gather")
                 self.read_codes(m.group(4) + m.group(6))
                 continue
-            m = re.match(r"jit_matvec\(JIT2_BUF\((\d+)\), lane, \w+, \w+, (.*)\);$", line)
+            m = re.match(r"jit_matvec<(?:true|false)>\(JIT2_BUF\((\d+)\), lane, \w+, \w+, (.*)\);$", line)
             if m:
                 self.read_block(int(m.group(1)), "matmul")
                 self.side(m.group(2), [int(m.group(1))])
@@ -287,7 +287,7 @@ class _Sched:
                 self.read_codes(line)
                 continue
             # plain statements, possibly several per line
-            for tok in re.finditer(r"JIT_WAIT\((\d+)\)|__syncthreads\(\)|JIT2_ISSUE_Z\(\d+\)|JIT2_PIECE_N?[TP]\((\d+), \d+, \d\)", line):
+            for tok in re.finditer(r"JIT_WAIT\((\d+)\)|__syncthreads\(\)|JIT2_ISSUE_Z\(\d+\)|JIT2_PIECE_N?(?:[TP]\((\d+), \d+, \d\)|PC\((\d+), \d+\))", line):
                 t = tok.group(0)
                 if t.startswith("JIT_WAIT"):
                     self.wait(int(tok.group(1)))
@@ -296,7 +296,7 @@ class _Sched:
                 elif t.startswith("JIT2_ISSUE_Z"):
                     self.issue_z()
                 else:
-                    self.issue_piece(int(tok.group(2)))
+                    self.issue_piece(int(tok.group(2) or tok.group(3)))
 
     def check(self, trips=3):
         self.run(self.head)
