@@ -217,9 +217,10 @@ struct JitNoSide { __device__ __forceinline__ void operator()(int) const {} };
 // 61 states: the sixteenth k-block of P holds the single column 60.  With `col` (that column as col[q][m] = P[4m+q][60])
 // its contribution y[m] += P[4m+q][60] * x[60] seeds the accumulators as sixteen v_mul_f64 and the four MFMAs of that
 // k-block are skipped (x[60] lives in element 15 of the q = 0 lane of the pattern: one cross-lane read).
-__device__ __forceinline__ void jit_col_seed(const double *col, int lane, const v4d (&x)[4], v4d (&z)[4])
+__device__ __forceinline__ double jit_x60(const v4d (&x)[4], int lane) { return __shfl(x[3][3], lane & 15); }
+
+__device__ __forceinline__ void jit_col_seed(const double *col, int lane, double x60, v4d (&z)[4])
 {
-   const double x60 = __shfl(x[3][3], lane & 15);
    const double2 *pc = (const double2 *)(col + (lane >> 4) * 16);
 #pragma unroll
    for (int i = 0; i < 8; i++) {
@@ -231,11 +232,11 @@ __device__ __forceinline__ void jit_col_seed(const double *col, int lane, const 
 
 template <bool TAIL61 = false, class SIDE = JitNoSide>
 __device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4], SIDE side = SIDE(),
-                                           const double *col = nullptr)
+                                           const double *col = nullptr, double x60 = 0)
 {
    const double2 *sp = (const double2 *)sPbuf;
    v4d z[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-   if constexpr (TAIL61) jit_col_seed(col, lane, x, z);
+   if constexpr (TAIL61) jit_col_seed(col, lane, x60, z);
    double2 af[2][4];
 #pragma unroll
    for (int jb = 0; jb < 4; jb++) af[0][jb] = sp[jb * 64 + lane];
@@ -271,11 +272,12 @@ __device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const 
 // resident by the midpoint, so MIDWAIT (outstanding vector-memory ops allowed there) + a barrier sit at kb2 == 4.
 template <int MIDWAIT, bool TAIL61 = false, class SIDE = JitNoSide>
 __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4], const double *ta, int ca,
-                                                const double *tb, int cb, int q, v4d (&t)[4], SIDE side = SIDE(), const double *col = nullptr)
+                                                const double *tb, int cb, int q, v4d (&t)[4], SIDE side = SIDE(), const double *col = nullptr,
+                                                double x60 = 0)
 {
    const double2 *sp = (const double2 *)sPbuf;
    v4d z[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-   if constexpr (TAIL61) jit_col_seed(col, lane, x, z);
+   if constexpr (TAIL61) jit_col_seed(col, lane, x60, z);
    double2 af[2][4];
    const int rowa = ca * 4 + q, rowb = cb * 4 + q, swa = TIP_SWZ(rowa), swb = TIP_SWZ(rowb);
    const char *pa = (const char *)ta + rowa * 128, *pb = (const char *)tb + rowb * 128;

@@ -164,7 +164,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    auto code = [&](int tip) { return "JIT2_CODE(" + std::to_string(ZP) + ", " + std::to_string(tip) + ")"; };
    auto ncode = [&](int tip) { return "JIT2_NCODE(" + std::to_string(ZP) + ", " + std::to_string(tip) + ")"; };
    auto buf = [&](int blk) { return "JIT2_BUF(" + std::to_string(blk) + ")"; };
-   auto colarg = [&](int blk) { return tail61 ? ", JIT2_COL(" + std::to_string(blk) + ")" : std::string(); };
+   auto colarg = [&](int blk) { return tail61 ? ", JIT2_COL(" + std::to_string(blk) + "), x60" : std::string(); };
 
    // ---- in front of the loop: the first tile is the "next" tile of an empty predecessor ---------------------------
    const int NA = p.max_stack + 2 + (fuse_tips ? 1 : 0);
@@ -244,6 +244,8 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          const bool fuse = fuse_tips && push >= 0 && iop + 1 < nops && p.ops[iop + 1].code == OP_SET_TIP2;
          const bool fuse_next = peel && (int)iop == last_mm;     // ... or the next tile's first cherry under the last matmul
          // (tip tables the ring could not hold earlier are requested in the first k-block pairs and awaited at the midpoint)
+         // (the cross-lane read of x[60] is issued before the step's wait + barrier so that its latency hides there)
+         if (tail61) s << "   { const double x60 = jit_x60(" << name(cur) << ", lane);\n";
          const std::string side = step(1, true, (fuse || fuse_next) ? 4 : 8, 1);
          int tgt = -1;
          if (fuse || fuse_next) {
@@ -252,12 +254,12 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
             const int mid = wait_count(consumed + 2);
             s << "   jit_matvec_tip2<" << (mid < 0 ? 63 : mid) << (tail61 ? ", true" : ", false") << ">(" << buf(consumed) << ", lane, " << name(cur)
               << ", " << name(out) << ", " << buf(consumed + 1) << ", " << (fuse ? code(nx.a) : ncode(nx.a)) << ", " << buf(consumed + 2) << ", "
-              << (fuse ? code(nx.b) : ncode(nx.b)) << ", q, " << name(tgt) << ", " << side << colarg(consumed) << ");\n";
+              << (fuse ? code(nx.b) : ncode(nx.b)) << ", q, " << name(tgt) << ", " << side << colarg(consumed) << ");" << (tail61 ? " }" : "") << "\n";
             consumed += 3;
          }
          else {
             s << "   jit_matvec<" << (tail61 ? "true" : "false") << ">(" << buf(consumed) << ", lane, " << name(cur) << ", " << name(out) << ", "
-              << side << colarg(consumed) << ");\n";
+              << side << colarg(consumed) << ");" << (tail61 ? " }" : "") << "\n";
             consumed += 1;
          }
          release(cur);
