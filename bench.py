@@ -35,7 +35,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6
 # HBM bytes one launch of the pruning kernel moves at the default workload (16 taxa x 1e6 patterns), from the PMC
 # counters as MI355X_MICROARCH.md prescribes: 2 x FETCH_SIZE (gfx950 wide-read correction, upper bound) + WRITE_SIZE,
 # separate rocprofv3 --pmc passes; numbers and command in profiles/r01_pmc_summary.txt.
-HBM_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 20004.5 + 7812.5) * 1024)
+HBM_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 20058.4 + 7812.5) * 1024)
 
 
 def algorithmic_flops_per_pattern(n, n_tips):
@@ -182,7 +182,7 @@ def cpu_baseline(pb, sample):
         if el > 8.0 or reps >= 5:
             break
     one["all_cores"] = {"value": pb.n_patt * reps / el, "unit": "site-patterns/s", "cores": ncores,
-                        "sample": "%d evals over all %d patterns, blocks of 2048 patterns over %d OpenMP threads" % (reps, pb.n_patt, ncores)}
+                        "sample": "%d evals over all %d patterns, blocks of 512 patterns over %d OpenMP threads" % (reps, pb.n_patt, ncores)}
     return one
 
 

@@ -304,18 +304,25 @@ double orc_eval_blocked(const orc_problem *pb, int nthreads, int block)
    double lnL = 0;
    if (pb->n_genes != 1 || block < 1) return 0.0 / 0.0;
    nb = (pb->n_patt + block - 1) / block;
-#pragma omp parallel for num_threads(nthreads > 1 ? nthreads : 1) schedule(dynamic) reduction(+ : lnL)
-   for (b = 0; b < nb; b++) {
-      orc_problem sub = *pb;
-      int off[2];
-      const int lo = b * block, len = lo + block <= pb->n_patt ? block : pb->n_patt - lo;
-      off[0] = 0; off[1] = len;
-      sub.n_patt = len;
-      sub.z = pb->z + lo;
-      sub.z_stride = (long)ZS(pb);
-      sub.weights = pb->weights + lo;
-      sub.gene_off = off;
-      lnL += orc_eval(&sub, NULL, NULL, NULL, NULL, 1);
+#pragma omp parallel num_threads(nthreads > 1 ? nthreads : 1) reduction(+ : lnL)
+   {
+      /* one set of partial arrays per thread, reused for all its blocks (a fresh multi-megabyte malloc per block would
+       * spend the time in page faults) */
+      double *part = (double *)malloc((size_t)pb->K * (pb->n_nodes - pb->n_tips) * block * pb->n * sizeof(double));
+#pragma omp for schedule(dynamic)
+      for (b = 0; b < nb; b++) {
+         orc_problem sub = *pb;
+         int off[2];
+         const int lo = b * block, len = lo + block <= pb->n_patt ? block : pb->n_patt - lo;
+         off[0] = 0; off[1] = len;
+         sub.n_patt = len;
+         sub.z = pb->z + lo;
+         sub.z_stride = (long)ZS(pb);
+         sub.weights = pb->weights + lo;
+         sub.gene_off = off;
+         lnL += orc_eval(&sub, NULL, NULL, part, NULL, 1);
+      }
+      free(part);
    }
    return lnL;
 }

@@ -115,7 +115,7 @@ def evaluate(pb, want_lnf=True, want_fhk=False, want_partials=False, nthreads=1)
     return dict(lnL=lnL, lnf=lnf, fhK=fhk, partials=part, scalef=scalef, npmat=L.orc_last_npmat())
 
 
-def evaluate_blocked(pb, nthreads, block=2048):
+def evaluate_blocked(pb, nthreads, block=512):
     """lnL with the patterns cut into blocks spread over `nthreads` host cores (each thread walks the whole tree)."""
     pk = _Packed(pb)
     return lib().orc_eval_blocked(C.byref(pk.s), int(nthreads), int(block))
