@@ -87,14 +87,17 @@ def main():
     branch = pb.tree.branch.copy()
 
     def step():
-        if world == 1:
-            return eng.eval(branch)["lnL"]
+        # one likelihood evaluation of the whole alignment: P(t) for every branch, the pruning kernel, the weighted
+        # reduction, and (N > 1) the all-reduce of the scalar.  Everything is enqueued on the stream; the lnL value stays
+        # on the device, so consecutive evaluations run back to back (a gradient's evaluations are independent of each
+        # other's results) and the host only synchronises at the fences around the timed region.
         eng.eval_device(branch, d_lnl.data_ptr())
-        dist.all_reduce(d_lnl)
-        return float(d_lnl.item())
+        if world > 1:
+            dist.all_reduce(d_lnl)
 
     for _ in range(args.warmup):
-        lnl = step()
+        step()
+    lnl_warm = float(d_lnl.item())
 
     def fence():
         torch.cuda.synchronize()
@@ -106,9 +109,12 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lnl = step()
+        step()
     fence()
     dt = time.perf_counter() - t0
+    lnl = float(d_lnl.item())
+    if lnl != lnl_warm:
+        raise SystemExit("bench: lnL changed between evaluations (%r vs %r)" % (lnl, lnl_warm))
     prof = eng.profile_read()
     eng.profile(False)
     if world > 1:

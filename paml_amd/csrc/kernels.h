@@ -66,6 +66,16 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
    double t = a.branch[bat * a.branch_bs + node] * a.rate[bat * a.rate_bs + iclass];
    t *= a.gene_rate[bat * a.gene_rate_bs + gene];
 
+   // tip branches: the ambiguity map (tools.c:20 nChara / CharaMap) comes to LDS now, so that the column-table loop at
+   // the end does not chase two dependent global loads per entry
+   __shared__ unsigned char sMap[256 * 64];
+   __shared__ int sNch[256];
+   const bool leaf = a.is_leaf[node] != 0;
+   if (leaf) {
+      for (int idx = tid; idx < a.n_codes * n; idx += 256) sMap[idx] = a.chara_map[idx];
+      for (int idx = tid; idx < a.n_codes; idx += 256) sNch[idx] = a.n_chara[idx];
+   }
+
    const int j = tid & 63, rg = tid >> 6;   // this thread: column j, rows rg*16 .. rg*16+15
    double acc[16];
 #pragma unroll
@@ -85,14 +95,36 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
                ue = es.U[i * n + k] * expm1(t * es.Root[k]);
                v = es.V[i * n + k];        // here (i,k) index V as [k'][j'] = [i][k]
             }
-            sA[idx] = ue;
+            sA[k * 64 + i] = ue;           // transposed: the four rows of a register tile are contiguous for every k
             sB[idx] = v;
          }
          __syncthreads();
-         for (int k = 0; k < n; k++) {
-            double v = sB[k * 64 + j];
+         {
+            // 4 x 4 register tile per thread: four 16-byte LDS reads feed sixteen FMAs; every element still accumulates
+            // k ascending (PMatUVRoot's order, tools.c:525-537)
+            const int ti = tid >> 4, tj = tid & 15;
+            double c[4][4];
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = fma(sA[(rg * 16 + r) * 64 + k], v, acc[r]);
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+               for (int cc = 0; cc < 4; cc++) c[r][cc] = 0;
+            for (int k = 0; k < n; k++) {
+               const double2 a0 = *(const double2 *)&sA[k * 64 + 4 * ti], a1 = *(const double2 *)&sA[k * 64 + 4 * ti + 2];
+               const double2 b0 = *(const double2 *)&sB[k * 64 + 4 * tj], b1 = *(const double2 *)&sB[k * 64 + 4 * tj + 2];
+               const double av[4] = {a0.x, a0.y, a1.x, a1.y}, bv[4] = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+               for (int r = 0; r < 4; r++)
+#pragma unroll
+                  for (int cc = 0; cc < 4; cc++) c[r][cc] = fma(av[r], bv[cc], c[r][cc]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+               for (int cc = 0; cc < 4; cc++) sA[(4 * ti + r) * 64 + 4 * tj + cc] = c[r][cc];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = sA[(rg * 16 + r) * 64 + j];
          }
 #pragma unroll
          for (int r = 0; r < 16; r++) {
@@ -159,7 +191,6 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
    double *rm = a.rowmajor + slot * n * n;
    for (int idx = tid; idx < n * n; idx += 256) rm[idx] = sA[(idx / n) * 64 + (idx % n)];
 
-   const bool leaf = a.is_leaf[node] != 0;
    if (a.layout == 1 && !leaf) {
       // MFMA A-operand order: element ((kb2*4 + jb)*64 + lane)*2 + e  =  P[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)]
       double *pf = a.pint + slot * 4096;
@@ -187,8 +218,8 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
          else jj = w;
          double s = 0;
          if (jj < n) {
-            const int nc = a.n_chara[code];
-            const unsigned char *map = a.chara_map + code * n;
+            const int nc = sNch[code];
+            const unsigned char *map = sMap + code * n;
             for (int k = 0; k < nc; k++) s += sA[jj * 64 + map[k]];
          }
          pt[idx] = s;
