@@ -33,3 +33,20 @@ def sharded_eval(pb, evaluate_shard, world: int, rank: int):
     if hi > lo:
         local = float(evaluate_shard(pb.slice_patterns(lo, hi)))
     return float(allreduce_lnl(local).item()), (lo, hi)
+
+
+def sharded_eval_branch(pb, eval_branch_shard, node_b, t, world: int, rank: int):
+    """Branch-local lnL(t), dlnL/dt, d2lnL/dt2 (lfuntdd) over pattern shards: each rank's `eval_branch_shard(sub, node_b, t)
+    -> (l, dl, ddl)` arrays are per-pattern sums, so the exchange step is one all-reduce of 3 * len(t) doubles
+    ("count = 3 for eval_branch")."""
+    import torch
+    import torch.distributed as dist
+    t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+    lo, hi = shard_bounds(pb.n_patt, world, rank)
+    acc = np.zeros((3, len(t)))
+    if hi > lo:
+        acc[:] = np.stack(eval_branch_shard(pb.slice_patterns(lo, hi), node_b, t))
+    buf = torch.from_numpy(acc)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf.numpy()[0], buf.numpy()[1], buf.numpy()[2]

@@ -29,7 +29,10 @@ def _worker(rank, world, port, n_patt, out):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     pb = synth.nuc_gtr_gamma_problem(n_tips=12, n_patt=n_patt, seed=5)
     lnl, (lo, hi) = distributed.sharded_eval(pb, lambda sub: orc.evaluate(sub, want_lnf=False)["lnL"], world, rank)
-    out[rank] = (lnl, lo, hi)
+    b = pb.tree.n_tips + 2
+    tt = np.array([pb.tree.branch[b], 0.2])
+    l, dl, ddl = distributed.sharded_eval_branch(pb, lambda sub, nb, ts: orc.eval_branch(sub, nb, ts), b, tt, world, rank)
+    out[rank] = (lnl, lo, hi, l.tolist(), dl.tolist(), ddl.tolist())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,3 +57,10 @@ def test_two_rank_gloo_matches_single():
     for r in (0, 1):
         assert abs(out[r][0] - ref) <= 1e-12 * abs(ref)
     assert out[0][2] == out[1][1]           # shards are contiguous
+    # branch-local evaluation: the 3 x n_t sums all-reduce to the single-process values
+    b = pb.tree.n_tips + 2
+    rl, rdl, rddl = oracle.eval_branch(pb, b, np.array([pb.tree.branch[b], 0.2]))
+    for r in (0, 1):
+        assert np.allclose(out[r][3], rl, rtol=1e-12) and np.allclose(out[r][4], rdl, rtol=1e-9, atol=1e-9)
+        assert np.allclose(out[r][5], rddl, rtol=1e-9, atol=1e-8)
+    assert abs(rl[0] - ref) <= 1e-11 * abs(ref)
