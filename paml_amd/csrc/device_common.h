@@ -230,7 +230,9 @@ __device__ __forceinline__ void jit_col_seed(const double *col, int lane, double
    }
 }
 
-template <bool TAIL61 = false, class SIDE = JitNoSide>
+// RB row blocks of 16 and KB k-blocks of 4 cover the model's states (4, 16 for 61; 2, 5 for 20): blocks beyond them are
+// zero padding in P and are neither fetched nor multiplied; accumulators of skipped row blocks stay 0.
+template <bool TAIL61 = false, int RB = 4, int KB = 16, class SIDE = JitNoSide>
 __device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4], SIDE side = SIDE(),
                                            const double *col = nullptr, double x60 = 0)
 {
@@ -238,29 +240,32 @@ __device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const 
    v4d z[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
    if constexpr (TAIL61) jit_col_seed(col, lane, x60, z);
    double2 af[2][4];
+   constexpr int KB2 = (KB + 1) / 2;
 #pragma unroll
-   for (int jb = 0; jb < 4; jb++) af[0][jb] = sp[jb * 64 + lane];
+   for (int jb = RB; jb < 4; jb++) y[jb] = (v4d){0, 0, 0, 0};
 #pragma unroll
-   for (int kb2 = 0; kb2 < 8; kb2++) {
-      if (kb2 + 1 < 8) {
+   for (int jb = 0; jb < RB; jb++) af[0][jb] = sp[jb * 64 + lane];
 #pragma unroll
-         for (int jb = 0; jb < 4; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
+   for (int kb2 = 0; kb2 < KB2; kb2++) {
+      if (kb2 + 1 < KB2) {
+#pragma unroll
+         for (int jb = 0; jb < RB; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
       }
       __builtin_amdgcn_sched_barrier(0);
       const double b0 = x[(2 * kb2) >> 2][(2 * kb2) & 3], b1 = x[(2 * kb2 + 1) >> 2][(2 * kb2 + 1) & 3];
       if (kb2 == 0) {
 #pragma unroll
-         for (int jb = 0; jb < 4; jb++)
+         for (int jb = 0; jb < RB; jb++)
             y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][jb].x, b0, z[jb], 0, 0, 0);
       }
       else {
 #pragma unroll
-         for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
+         for (int jb = 0; jb < RB; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
       }
       side(kb2);
-      if (!(TAIL61 && kb2 == 7)) {
+      if (!(TAIL61 && kb2 == 7) && 2 * kb2 + 1 < KB) {
 #pragma unroll
-         for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+         for (int jb = 0; jb < RB; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
    }
@@ -269,70 +274,83 @@ __device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const 
 // jit_matvec with the next cherry's tip step folded in: y = P x as above, and t = tipA[ca] * tipB[cb] (the SET_TIP2 that
 // follows in the program) gathered from LDS under the second half of the MFMAs, where the matrix pipe hides the
 // ds_read_b128 traffic and its bank conflicts.  The two tip tables are the ring blocks after P; they only have to be
-// resident by the midpoint, so MIDWAIT (outstanding vector-memory ops allowed there) + a barrier sit at kb2 == 4.
-template <int MIDWAIT, bool TAIL61 = false, class SIDE = JitNoSide>
+// resident by the midpoint MID = KB2 / 2, so MIDWAIT (outstanding vector-memory ops allowed there) + a barrier sit at
+// kb2 == MID (refill pieces handed in through `side` are issued in the iterations before it).  The NP pieces of each tip
+// row are fetched PPI per iteration from MID on, their products formed one iteration later.
+template <int MIDWAIT, bool TAIL61 = false, int RB = 4, int KB = 16, class SIDE = JitNoSide>
 __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4], const double *ta, int ca,
                                                 const double *tb, int cb, int q, v4d (&t)[4], SIDE side = SIDE(), const double *col = nullptr,
                                                 double x60 = 0)
 {
+   constexpr int KB2 = (KB + 1) / 2, NP = KB2, MID = KB2 / 2, GI = KB2 - MID, PPI = (NP + GI - 1) / GI;
    const double2 *sp = (const double2 *)sPbuf;
    v4d z[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
    if constexpr (TAIL61) jit_col_seed(col, lane, x60, z);
    double2 af[2][4];
    const int rowa = ca * 4 + q, rowb = cb * 4 + q, swa = TIP_SWZ(rowa), swb = TIP_SWZ(rowb);
    const char *pa = (const char *)ta + rowa * 128, *pb = (const char *)tb + rowb * 128;
-   double2 tv[2][2], tw[2][2];
+   double2 tv[2][PPI], tw[2][PPI];
 #pragma unroll
-   for (int jb = 0; jb < 4; jb++) af[0][jb] = sp[jb * 64 + lane];
+   for (int jb = RB; jb < 4; jb++) y[jb] = (v4d){0, 0, 0, 0};
 #pragma unroll
-   for (int kb2 = 0; kb2 < 8; kb2++) {
-      if (kb2 == 4) {
+   for (int jb = 0; jb < 4; jb++) t[jb] = (v4d){0, 0, 0, 0};
+#pragma unroll
+   for (int jb = 0; jb < RB; jb++) af[0][jb] = sp[jb * 64 + lane];
+#pragma unroll
+   for (int kb2 = 0; kb2 < KB2; kb2++) {
+      if (kb2 == MID) {
          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MIDWAIT) : "memory");
          __syncthreads();
       }
-      if (kb2 + 1 < 8) {
+      if (kb2 + 1 < KB2) {
 #pragma unroll
-         for (int jb = 0; jb < 4; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
+         for (int jb = 0; jb < RB; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
       }
-      if (kb2 >= 4) {
+      if (kb2 >= MID) {
 #pragma unroll
-         for (int e = 0; e < 2; e++) {
-            const int p = 2 * (kb2 - 4) + e;
-            tv[kb2 & 1][e] = *(const double2 *)(pa + ((p ^ swa) * 16));
-            tw[kb2 & 1][e] = *(const double2 *)(pb + ((p ^ swb) * 16));
+         for (int e = 0; e < PPI; e++) {
+            const int p = PPI * (kb2 - MID) + e;
+            if (p < NP) {
+               tv[kb2 & 1][e] = *(const double2 *)(pa + ((p ^ swa) * 16));
+               tw[kb2 & 1][e] = *(const double2 *)(pb + ((p ^ swb) * 16));
+            }
          }
       }
       __builtin_amdgcn_sched_barrier(0);
       const double b0 = x[(2 * kb2) >> 2][(2 * kb2) & 3], b1 = x[(2 * kb2 + 1) >> 2][(2 * kb2 + 1) & 3];
       if (kb2 == 0) {
 #pragma unroll
-         for (int jb = 0; jb < 4; jb++)
+         for (int jb = 0; jb < RB; jb++)
             y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][jb].x, b0, z[jb], 0, 0, 0);
       }
       else {
 #pragma unroll
-         for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
+         for (int jb = 0; jb < RB; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
       }
-      if (kb2 >= 5) {      // products of the rows fetched one iteration ago
+      if (kb2 > MID) {      // products of the rows fetched one iteration ago
 #pragma unroll
-         for (int e = 0; e < 2; e++) {
-            const int p = 2 * (kb2 - 5) + e;
-            t[p >> 1][(2 * p) & 3] = tv[(kb2 - 1) & 1][e].x * tw[(kb2 - 1) & 1][e].x;
-            t[p >> 1][(2 * p + 1) & 3] = tv[(kb2 - 1) & 1][e].y * tw[(kb2 - 1) & 1][e].y;
+         for (int e = 0; e < PPI; e++) {
+            const int p = PPI * (kb2 - 1 - MID) + e;
+            if (p < NP) {
+               t[p >> 1][(2 * p) & 3] = tv[(kb2 - 1) & 1][e].x * tw[(kb2 - 1) & 1][e].x;
+               t[p >> 1][(2 * p + 1) & 3] = tv[(kb2 - 1) & 1][e].y * tw[(kb2 - 1) & 1][e].y;
+            }
          }
       }
       side(kb2);
-      if (!(TAIL61 && kb2 == 7)) {
+      if (!(TAIL61 && kb2 == 7) && 2 * kb2 + 1 < KB) {
 #pragma unroll
-         for (int jb = 0; jb < 4; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+         for (int jb = 0; jb < RB; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
    }
 #pragma unroll
-   for (int e = 0; e < 2; e++) {
-      const int p = 6 + e;
-      t[p >> 1][(2 * p) & 3] = tv[1][e].x * tw[1][e].x;
-      t[p >> 1][(2 * p + 1) & 3] = tv[1][e].y * tw[1][e].y;
+   for (int e = 0; e < PPI; e++) {
+      const int p = PPI * (KB2 - 1 - MID) + e;
+      if (p < NP) {
+         t[p >> 1][(2 * p) & 3] = tv[(KB2 - 1) & 1][e].x * tw[(KB2 - 1) & 1][e].x;
+         t[p >> 1][(2 * p + 1) & 3] = tv[(KB2 - 1) & 1][e].y * tw[(KB2 - 1) & 1][e].y;
+      }
    }
 }
 
@@ -354,38 +372,53 @@ __device__ __forceinline__ void jit_init_tip(v4d (&y)[4], int code, int q, int c
    for (int m = 0; m < 16; m++) y[m >> 2][m & 3] = (cleandata && 4 * m + q == code) ? 1.0 : 0.0;
 }
 
+// Tip factors: NP = number of 16-byte pieces (two states each) of a table row that carry states of the model (8 at 61
+// states, 3 at 20); the rest of the row is zero padding and is not read.
+template <int NP>
+__device__ __forceinline__ void tip_lds_n(const double *tab, int code, int q, double2 (&v)[8])
+{
+   const int row = code * 4 + q, swz = TIP_SWZ(row);
+   const char *base = (const char *)tab + row * 128;
+#pragma unroll
+   for (int p = 0; p < 8; p++) v[p] = p < NP ? *(const double2 *)(base + ((p ^ swz) * 16)) : make_double2(0.0, 0.0);
+}
+
+template <int NP = 8>
 __device__ __forceinline__ void jit_tip_set(v4d (&y)[4], const double *tab, int code, int q, int lane)
 {
    double2 v[8];
-   tip_lds(tab, code, q, lane, v);
+   tip_lds_n<NP>(tab, code, q, v);
 #pragma unroll
    for (int i = 0; i < 8; i++) { y[i >> 1][(2 * i) & 3] = v[i].x; y[i >> 1][(2 * i + 1) & 3] = v[i].y; }
 }
 
+template <int NP = 8>
 __device__ __forceinline__ void jit_tip_mul(v4d (&y)[4], const double *tab, int code, int q, int lane)
 {
    double2 v[8];
-   tip_lds(tab, code, q, lane, v);
+   tip_lds_n<NP>(tab, code, q, v);
 #pragma unroll
-   for (int i = 0; i < 8; i++) { y[i >> 1][(2 * i) & 3] *= v[i].x; y[i >> 1][(2 * i + 1) & 3] *= v[i].y; }
+   for (int i = 0; i < NP; i++) { y[i >> 1][(2 * i) & 3] *= v[i].x; y[i >> 1][(2 * i + 1) & 3] *= v[i].y; }
 }
 
+template <int NP = 8>
 __device__ __forceinline__ void jit_tip2_set(v4d (&y)[4], const double *ta, int ca, const double *tb, int cb, int q, int lane)
 {
    double2 v[8], w[8];
-   tip_lds(ta, ca, q, lane, v);
-   tip_lds(tb, cb, q, lane, w);
+   tip_lds_n<NP>(ta, ca, q, v);
+   tip_lds_n<NP>(tb, cb, q, w);
 #pragma unroll
    for (int i = 0; i < 8; i++) { y[i >> 1][(2 * i) & 3] = v[i].x * w[i].x; y[i >> 1][(2 * i + 1) & 3] = v[i].y * w[i].y; }
 }
 
+template <int NP = 8>
 __device__ __forceinline__ void jit_tip2_mul(v4d (&y)[4], const double *ta, int ca, const double *tb, int cb, int q, int lane)
 {
    double2 v[8], w[8];
-   tip_lds(ta, ca, q, lane, v);
-   tip_lds(tb, cb, q, lane, w);
+   tip_lds_n<NP>(ta, ca, q, v);
+   tip_lds_n<NP>(tb, cb, q, w);
 #pragma unroll
-   for (int i = 0; i < 8; i++) {
+   for (int i = 0; i < NP; i++) {
       y[i >> 1][(2 * i) & 3] = (y[i >> 1][(2 * i) & 3] * v[i].x) * w[i].x;
       y[i >> 1][(2 * i + 1) & 3] = (y[i >> 1][(2 * i + 1) & 3] * v[i].y) * w[i].y;
    }
@@ -577,6 +610,7 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
    __shared__ __attribute__((aligned(16))) unsigned char sZ[2 * (ZP)*2048];                                      \
    __shared__ double sPi[4 * 64];                                                                               \
    __shared__ __attribute__((aligned(16))) double sCol[4 * 64 + 32];                                            \
+   __shared__ __attribute__((aligned(16))) double sDump[128];                                                   \
    const int tid = threadIdx.x, lane = tid & 63;                                                                \
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                   \
    const int q = lane >> 4, hl = lane & 15;                                                                     \
@@ -585,7 +619,7 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
    const int total_work = a.n_tiles * a.K;                                                                      \
    int work = blockIdx.x;                                                                                       \
    const double *Pcol = a.pcol, *nPcol = a.pcol;                                                                \
-   (void)sCol; (void)Pcol; (void)nPcol;                                                                         \
+   (void)sCol; (void)sDump; (void)Pcol; (void)nPcol;                                                            \
    int iclass = 0, gene = 0, h0 = 0, hend = 1, h = 0;                                                           \
    int n_tile = 0, n_gene = 0, n_iclass = 0, n_h0 = 0, n_hend = 1;                                              \
    bool valid = false, has_next = false;                                                                        \
@@ -625,12 +659,29 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
    dma4(make_rsrc((SRC), 512), wave < 2 ? (const char *)JIT2_COL(J) + wave * 256 : (const char *)(sCol + 256), lane * 4, wave * 256)
 #define JIT2_PIECE_PC(J, NODE) JIT2_PIECE_C(Pcol + (long)(NODE)*64, J)
 #define JIT2_PIECE_NPC(J, NODE) JIT2_PIECE_C(nPcol + (long)(NODE)*64, J)
-#define JIT2_PIECE(SRC, J, C)                                                                                        \
-   dma16(make_rsrc((SRC), 32768), (const char *)JIT2_BUF(J) + ((C)*8 + wave) * 1024, lane * 16, ((C)*8 + wave) * 1024)
-#define JIT2_PIECE_P(J, NODE, C) JIT2_PIECE(Pint + (long)(NODE)*4096, J, C)
-#define JIT2_PIECE_T(J, NODE, C) JIT2_PIECE(Ptip + (long)(NODE)*4096, J, C)
-#define JIT2_PIECE_NP(J, NODE, C) JIT2_PIECE(nPint + (long)(NODE)*4096, J, C)
-#define JIT2_PIECE_NT(J, NODE, C) JIT2_PIECE(nPtip + (long)(NODE)*4096, J, C)
+/* One DMA piece: 1 KB chunk (C*8 + wave) of block J.  Only the chunks that hold states of the model are fetched — of a P,
+ * k-block pairs < JIT_KB2 and row blocks < JIT_RB (chunk = pair * 4 + row block); of a tip table, the first JIT_TCH chunks
+ * (two codes each) — the generator emits only the rounds C that contain such a chunk, and inside a round a wave whose
+ * chunk is padding still issues its instruction (every wave must count the same vector-memory operations) against an
+ * empty descriptor, the zeros going to a dump slot. */
+#ifndef JIT_KB2
+#define JIT_KB2 8
+#define JIT_RB 4
+#define JIT_TCH 32
+#endif
+#define JIT2_PIECE(SRC, J, C, REAL)                                                                                  \
+   {                                                                                                                \
+      const int ch_ = (C)*8 + wave;                                                                                 \
+      const bool real_ = (REAL);                                                                                    \
+      dma16(make_rsrc((SRC), real_ ? 32768 : 0), real_ ? (const char *)JIT2_BUF(J) + ch_ * 1024 : (const char *)sDump, lane * 16,    \
+            ch_ * 1024);                                                                                            \
+   }
+#define JIT2_REAL_P ((ch_ >> 2) < JIT_KB2 && (ch_ & 3) < JIT_RB)
+#define JIT2_REAL_T (ch_ < JIT_TCH)
+#define JIT2_PIECE_P(J, NODE, C) JIT2_PIECE(Pint + (long)(NODE)*4096, J, C, JIT2_REAL_P)
+#define JIT2_PIECE_T(J, NODE, C) JIT2_PIECE(Ptip + (long)(NODE)*4096, J, C, JIT2_REAL_T)
+#define JIT2_PIECE_NP(J, NODE, C) JIT2_PIECE(nPint + (long)(NODE)*4096, J, C, JIT2_REAL_P)
+#define JIT2_PIECE_NT(J, NODE, C) JIT2_PIECE(nPtip + (long)(NODE)*4096, J, C, JIT2_REAL_T)
 #define JIT2_CODE(ZP, TIP) ((int)sZ[zsel * ((ZP)*2048) + (TIP)*128 + hw])
 #define JIT2_NCODE(ZP, TIP) ((int)sZ[(zsel ^ 1) * ((ZP)*2048) + (TIP)*128 + hw])
 

@@ -411,8 +411,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
       bool jit_ok = false;
       if (e->jit_enabled && !getenv("PAML_AMD_FORCE_GATHER") && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi)) {
-         int r = ensure_jit(e, "m" + std::to_string(n) + ":" + jit_program_key(e->prog, e->n_tips),
-                            [&]() { return jit_generate(e->prog, e->n_tips, n); }, &jit_ok);
+         int r = ensure_jit(e, "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips),
+                            [&]() { return jit_generate(e->prog, e->n_tips, n, e->n_codes); }, &jit_ok);
          if (r) return r;
       }
       e->use_jit = jit_ok;
@@ -623,15 +623,18 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    if (!e) return PAML_AMD_ENOMEM;
    e->n = n_states; e->n_tips = n_tips; e->n_patt = n_patt; e->max_classes = max_classes; e->n_genes = n_genes;
    e->flags = flags;
-   if (n_states == 4) e->kk = KK_VALU4;
-   else if (n_states == 5) e->kk = KK_VALU5;
-   else if (n_states == 20) e->kk = KK_VALU20;
-   else e->kk = KK_MFMA64;
    {  // per-tree specialised kernels: on request, or by default once the data set is large enough to repay the compile
       const char *j = getenv("PAML_AMD_JIT");
       e->jit_enabled = (flags & PAML_AMD_JIT) != 0 || (j && j[0] == '1') || (!j && (long)n_patt * max_classes >= 65536);
       if (j && j[0] == '0') e->jit_enabled = false;
    }
+   // 20 states: the specialised MFMA kernel trimmed to 2 row blocks x 5 k-blocks beats the scalar-operand kernel 2-3x; the
+   // MFMA interpreters (64 MFMAs per product whatever n) do not, so small or keep-partials engines stay on valu20
+   const bool mfma20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_tips <= 95 && !getenv("PAML_AMD_VALU20");
+   if (n_states == 4) e->kk = KK_VALU4;
+   else if (n_states == 5) e->kk = KK_VALU5;
+   else if (n_states == 20 && !mfma20) e->kk = KK_VALU20;
+   else e->kk = KK_MFMA64;
    e->mfma_dma = n_tips <= MFMA_ZT && !getenv("PAML_AMD_FORCE_GATHER");
    e->mfma_waves = e->mfma_dma ? DMA_WAVES : GATHER_WAVES;
    e->tile_patt = e->kk == KK_MFMA64 ? e->mfma_waves * 16 : 256;
@@ -1176,10 +1179,14 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
       for (int i = 0; i < n_nodes; i++)
          if (scale_node[i]) { t.scale_node[i] = 1; t.scale_slot[i] = t.n_scale++; }
    Program p = build_program(t, false, nullptr);
-   const int n_states = compile >> 8;       // 0: the 61-state kernel; 4 / 5 / 20: the one-pattern-per-lane kernels
-   compile &= 1;
+   int n_states = compile >> 8;             // 0: the 61-state kernel; 4 / 5 / 20: the one-pattern-per-lane kernels;
+   compile &= 1;                            // 64 + n: the MFMA kernel trimmed to n states
    std::string text;
-   if (n_states == 4 || n_states == 5 || n_states == 20) {
+   if (n_states > 64) {
+      if (!jit_supported(p, n_tips, 61)) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate(p, n_tips, n_states - 64, n_states - 64);
+   }
+   else if (n_states == 4 || n_states == 5 || n_states == 20) {
       if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;
       text = jit_generate_valu(p, n_states);
    }

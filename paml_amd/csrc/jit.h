@@ -38,7 +38,7 @@ inline int jit_zpieces(int n_tips) { return ((n_tips + 1) * 128 + 2047) / 2048; 
 inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6)
 {
    if (n_codes > 64 || p.ops.size() > 400 || n_pi > 4) return false;
-   if (4 * 32768 + 2 * jit_zpieces(n_tips) * 2048 + 4 * 64 * 8 + (4 * 64 + 32) * 8 > 160 * 1024) return false;   // LDS: ring, 2 code blocks, pi, column tables (<= 95 tips)
+   if (4 * 32768 + 2 * jit_zpieces(n_tips) * 2048 + 4 * 64 * 8 + (4 * 64 + 32) * 8 + 1024 > 160 * 1024) return false;   // LDS: ring, 2 code blocks, pi, column tables (<= 95 tips)
    if (p.stream.size() / 2 < 4) return false;                       // trees this small go to the interpreter
    for (const Op &o : p.ops)
       if (o.code == OP_STORE || o.code == OP_LOAD) return false;   // keep-partials layouts stay with the interpreter
@@ -63,13 +63,16 @@ inline std::string jit_program_key(const Program &p, int n_tips)
 // own first cherry was done that way by its predecessor; the first tile's is peeled in front of the loop).
 // `first` = operand blocks of a tile already requested when the loop body starts (the body's last step leaves the
 // same number of the next tile's in flight; *first_out reports it so that jit_generate can make the two agree).
-inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states, int first, int *first_out)
+inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states, int n_codes, int first, int *first_out)
 {
    std::ostringstream s;
    const int nblk = (int)p.stream.size() / 2;
    const int ZP = jit_zpieces(n_tips);
    const size_t nops = p.ops.size();
-   const bool fuse_tips = !getenv("PAML_AMD_JIT_NOFUSE");   // cherries gathered under the preceding matmul
+   // states beyond n are zero padding: only RB row blocks and KB k-blocks of every P take part (4 and 16 at 61 states)
+   const int RB = (n_states + 15) / 16, KB = (n_states + 3) / 4, KB2 = (KB + 1) / 2, NPc = KB2;   // NPc: 16-byte pieces per tip-table row
+   const bool fuse_tips = !getenv("PAML_AMD_JIT_NOFUSE") && KB2 >= 2;   // cherries gathered under the preceding matmul
+   const int MID = KB2 / 2;                                             // ... from this k-block pair on (jit_matvec_tip2)
    const bool spread = !getenv("PAML_AMD_JIT_NOSPREAD");    // ring refill issued from inside the MFMA loops
    const bool prof = getenv("PAML_AMD_PROF_OPS") != nullptr; // kernel experiments: s_memtime stamp at every op
    // 61 states: the last k-block of P is the single column 60 — its rank-1 term goes through the vector pipe (a 512-byte
@@ -87,6 +90,10 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    const bool peel = fuse_tips && !getenv("PAML_AMD_JIT_NOPEEL") && nops > 2 && p.ops[0].code == OP_SET_TIP2 && last_mm > 1 &&
                      p.ops[1].code != OP_MUL_TIP && p.ops[1].code != OP_MUL_TIP2 && !tail_blocks;
 
+   // chunks of a tip table that hold codes of this data set (two codes per 1 KB chunk)
+   const int TCH = (n_codes + 1) / 2 >= 31 ? 32 : (n_codes + 1) / 2;
+   const int P_ROUNDS = (KB2 + 1) / 2, T_ROUNDS = (TCH + 7) / 8;
+   s << "#define JIT_KB2 " << KB2 << "\n#define JIT_RB " << RB << "\n#define JIT_TCH " << TCH << "\n";
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
    s << "extern \"C\" __global__ __launch_bounds__(512, 2) void prune_jit(PruneArgs a)\n{\n";
    s << "   JIT2_PROLOGUE(" << ZP << ")\n";
@@ -96,11 +103,12 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    struct Item { int id, pieces; };          // id: block number within the tile (>= nblk: next tile's), -1: a code block
    std::vector<Item> fl;                     // issued, not yet known landed; oldest first
    int issued = 0, consumed = 0;
-   auto n_pieces = [&](int blk) { return (tail61 && !p.stream[2 * (blk % nblk)]) ? 5 : 4; };
-   auto piece = [&](int blk, int c4) {       // source text of one DMA piece of block blk (piece 4: the column table)
+   auto n_rounds = [&](int blk) { return p.stream[2 * (blk % nblk)] ? T_ROUNDS : P_ROUNDS; };
+   auto n_pieces = [&](int blk) { return n_rounds(blk) + ((tail61 && !p.stream[2 * (blk % nblk)]) ? 1 : 0); };
+   auto piece = [&](int blk, int c4) {       // source text of one DMA piece of block blk (the last one of a P: the column table)
       const bool nx = blk >= nblk;
       const int loc = blk % nblk, is_tip = p.stream[2 * loc], node = p.stream[2 * loc + 1];
-      if (c4 == 4) return std::string("JIT2_PIECE_") + (nx ? "NPC(" : "PC(") + std::to_string(blk) + ", " + std::to_string(node) + ");";
+      if (c4 == n_rounds(blk)) return std::string("JIT2_PIECE_") + (nx ? "NPC(" : "PC(") + std::to_string(blk) + ", " + std::to_string(node) + ");";
       return std::string("JIT2_PIECE_") + (nx ? "N" : "") + (is_tip ? "T(" : "P(") + std::to_string(blk) + ", " + std::to_string(node) + ", " +
              std::to_string(c4) + ");";
    };
@@ -177,7 +185,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    if (peel) {
       const int nw = wait_count(nblk + 1);
       s << "   JIT_WAIT(" << nw << "); __syncthreads();\n";
-      s << "   jit_tip2_set(AS, " << buf(nblk) << ", " << ncode(p.ops[0].a) << ", " << buf(nblk + 1) << ", " << ncode(p.ops[0].b) << ", q, lane);\n";
+      s << "   jit_tip2_set<" << NPc << ">(AS, " << buf(nblk) << ", " << ncode(p.ops[0].a) << ", " << buf(nblk + 1) << ", " << ncode(p.ops[0].b) << ", q, lane);\n";
    }
    // renumber for the loop body: those three blocks are blocks 0..2 of the tile the loop starts with
    for (Item &it : fl)
@@ -216,19 +224,19 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       case OP_SET_TIP:
          if (cur < 0) cur = alloc();
          step(1);
-         s << "   jit_tip_set(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane);\n";
+         s << "   jit_tip_set<" << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane);\n";
          consumed += 1;
          break;
       case OP_MUL_TIP:
          step(1);
-         s << "   jit_tip_mul(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane);\n";
+         s << "   jit_tip_mul<" << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane);\n";
          consumed += 1;
          break;
       case OP_SET_TIP2:
       case OP_MUL_TIP2:
          if (cur < 0) cur = alloc();
          step(2);
-         s << "   " << (o.code == OP_SET_TIP2 ? "jit_tip2_set(" : "jit_tip2_mul(") << name(cur) << ", " << buf(consumed) << ", " << code(o.a)
+         s << "   " << (o.code == OP_SET_TIP2 ? "jit_tip2_set<" : "jit_tip2_mul<") << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a)
            << ", " << buf(consumed + 1) << ", " << code(o.b) << ", q, lane);\n";
          consumed += 2;
          break;
@@ -246,19 +254,20 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          // (tip tables the ring could not hold earlier are requested in the first k-block pairs and awaited at the midpoint)
          // (the cross-lane read of x[60] is issued before the step's wait + barrier so that its latency hides there)
          if (tail61) s << "   { const double x60 = jit_x60(" << name(cur) << ", lane);\n";
-         const std::string side = step(1, true, (fuse || fuse_next) ? 4 : 8, 1);
+         const std::string side = step(1, true, (fuse || fuse_next) ? MID : KB2, 1);
          int tgt = -1;
          if (fuse || fuse_next) {
             const Op &nx = fuse ? p.ops[iop + 1] : p.ops[0];
             tgt = fuse ? alloc() : AS;
             const int mid = wait_count(consumed + 2);
-            s << "   jit_matvec_tip2<" << (mid < 0 ? 63 : mid) << (tail61 ? ", true" : ", false") << ">(" << buf(consumed) << ", lane, " << name(cur)
+            s << "   jit_matvec_tip2<" << (mid < 0 ? 63 : mid) << (tail61 ? ", true, " : ", false, ") << RB << ", " << KB << ">(" << buf(consumed) << ", lane, " << name(cur)
               << ", " << name(out) << ", " << buf(consumed + 1) << ", " << (fuse ? code(nx.a) : ncode(nx.a)) << ", " << buf(consumed + 2) << ", "
               << (fuse ? code(nx.b) : ncode(nx.b)) << ", q, " << name(tgt) << ", " << side << colarg(consumed) << ");" << (tail61 ? " }" : "") << "\n";
             consumed += 3;
          }
          else {
-            s << "   jit_matvec<" << (tail61 ? "true" : "false") << ">(" << buf(consumed) << ", lane, " << name(cur) << ", " << name(out) << ", "
+            s << "   jit_matvec<" << (tail61 ? "true" : "false") << ", " << RB << ", " << KB << ">(" << buf(consumed) << ", lane, " << name(cur) << ", "
+              << name(out) << ", "
               << side << colarg(consumed) << ");" << (tail61 ? " }" : "") << "\n";
             consumed += 1;
          }
@@ -303,13 +312,13 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    return s.str();
 }
 
-inline std::string jit_generate(const Program &p, int n_tips, int n_states = 61)
+inline std::string jit_generate(const Program &p, int n_tips, int n_states = 61, int n_codes = 64)
 {
    int first = 3, got = 3;
-   std::string src = jit_generate_impl(p, n_tips, n_states, first, &got);
+   std::string src = jit_generate_impl(p, n_tips, n_states, n_codes, first, &got);
    if (got != first) {
       first = got;
-      src = jit_generate_impl(p, n_tips, n_states, first, &got);
+      src = jit_generate_impl(p, n_tips, n_states, n_codes, first, &got);
    }
    return got == first ? src : std::string("#error \"jit schedule does not close\"\n");
 }

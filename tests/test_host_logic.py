@@ -264,7 +264,7 @@ class _Sched:
                 self.tile += 1
                 self.zsel ^= 1
                 continue
-            m = re.match(r"jit_matvec_tip2<(\d+), (?:true|false)>\(JIT2_BUF\((\d+)\), lane, \w+, \w+, JIT2_BUF\((\d+)\), (\S+ \S+), JIT2_BUF\((\d+)\), (\S+ \S+), q, \w+, (.*)\);(?: \})?$", line)
+            m = re.match(r"jit_matvec_tip2<(\d+), (?:true|false), \d+, \d+>\(JIT2_BUF\((\d+)\), lane, \w+, \w+, JIT2_BUF\((\d+)\), (\S+ \S+), JIT2_BUF\((\d+)\), (\S+ \S+), q, \w+, (.*)\);(?: \})?$", line)
             if m:
                 mid, jp, ja, jb = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(5))
                 self.read_block(jp, "fused matmul")
@@ -276,7 +276,7 @@ class _Sched:
                 self.read_block(jb, "fused tip gather")
                 self.read_codes(m.group(4) + m.group(6))
                 continue
-            m = re.match(r"jit_matvec<(?:true|false)>\(JIT2_BUF\((\d+)\), lane, \w+, \w+, (.*)\);(?: \})?$", line)
+            m = re.match(r"jit_matvec<(?:true|false), \d+, \d+>\(JIT2_BUF\((\d+)\), lane, \w+, \w+, (.*)\);(?: \})?$", line)
             if m:
                 self.read_block(int(m.group(1)), "matmul")
                 self.side(m.group(2), [int(m.group(1))])
