@@ -324,3 +324,24 @@ def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch
         assert eng.kernel_name == "mfma64_gather"          # beyond the LDS budget of the specialised kernel
     if n == 61 and n_tips == 90 and jit:
         assert eng.kernel_name == "mfma64_jit"
+
+
+@pytest.mark.parametrize("n,n_tips,n_patt,K,genes,amb,every", [(4, 12, 700, 4, 1, True, None), (5, 9, 300, 2, 1, False, None),
+                                                             (20, 14, 400, 3, 2, True, None), (20, 33, 260, 1, 1, False, 9),
+                                                             (33, 10, 200, 2, 1, False, None), (61, 13, 300, 2, 2, True, None),
+                                                             (61, 40, 150, 1, 1, False, 12), (61, 6, 129, 3, 1, False, None)])
+def test_specialised_kernels_via_flag(n, n_tips, n_patt, K, genes, amb, every):
+    """The per-tree specialised kernels (PAML_AMD_JIT flag, independent of the size threshold that turns them on by
+    default): 4 / 5 states unrolled scalar-operand walk, 20 / 33 states the MFMA kernel trimmed to the model's size,
+    61 states the full one — with several genes, ambiguity codes, scaling nodes, and an evaluation batch."""
+    from paml_amd.engine import JIT
+    pb = helpers.random_problem(n, n_tips, n_patt, K=K, seed=900 + n + n_tips, ambiguity=amb, n_genes=genes, scale_every=every)
+    eng, out, ref = check(pb, flags=JIT)
+    assert eng.kernel_name.endswith("_jit"), eng.kernel_name
+    br = np.stack([pb.tree.branch, pb.tree.branch * 1.07])
+    got = eng.eval_batch(br, gene_rate=np.tile(pb.gene_rate, (2, 1)))
+    assert got[0] == out["lnL"]
+    q = copy.copy(pb)
+    q.tree = Tree(pb.tree.n_tips, pb.tree.n_nodes, pb.tree.root, pb.tree.sons, br[1].copy(), pb.tree.label)
+    r1 = oracle.evaluate(q)["lnL"]
+    assert abs(got[1] - r1) <= 1e-10 * abs(r1)
