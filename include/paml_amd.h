@@ -110,6 +110,13 @@ int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double 
 int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
                         double *lnL);
 
+/* lfunAdG (treesub.c:7447-7494), the auto-discrete-gamma model (rho != 0): fx_r runs on the device exactly as for lfundG;
+ * the K-state rate chain with transition matrix MK[K*K] (AutodGamma tools.c:2630, the caller's) is then run over the ls
+ * sites in their original order, pose[site] = pattern index (com.pose) — a sequential recurrence, done on the host from the
+ * device's fhK.  Needs PAML_AMD_MODE_LFUNDG classes.  Returns +lnL. */
+int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *gene_rate, const double *MK, const int *pose, int ls,
+                      double *lnL);
+
 /* n_batch evaluations in one launch: the finite-difference loops of the optimiser (gradientB tools.c:6561, the forward /
  * central differences of ming2 tools.c:6595 and of the Hessian, HessianSKT2004 treesub.c:7241) call com.plfun np (or 2np,
  * np^2) times on the same data with one parameter nudged; here those calls become the elements of one batch.  Element b

@@ -295,6 +295,47 @@ double orc_eval(const orc_problem *pb, double *lnf, double *fhK_out, double *par
 }
 
 
+/* lfunAdG (treesub.c:7447-7494): auto-discrete-gamma rates.  fx_r gives fhK as for lfundG; the likelihood is then a
+ * forward pass of the K-state rate chain with transition matrix MK over the sites in their original order
+ * (pose[site] = pattern), rescaled at every site.  Returns +lnL. */
+double orc_eval_adg(const orc_problem *pb, const double *MK, const int *pose, int ls)
+{
+   int K = pb->K, np = pb->n_patt, n_scale = 0, i, il, ir, j;
+   double *fhK = (double *)malloc((size_t)K * np * sizeof(double)), *b1 = (double *)malloc(2 * K * sizeof(double)), *b2 = b1 + K;
+   double lnL = 0, fh;
+   long h;
+   if (pb->scale_node)
+      for (i = 0; i < pb->n_nodes; i++) n_scale += (pb->scale_node[i] != 0);
+   orc_eval(pb, NULL, fhK, NULL, NULL, 1);
+   if (n_scale)      /* treesub.c:7458-7464: class 0 carries the scale, the others become ratios to it */
+      for (h = 0; h < np; h++) {
+         fh = fhK[h];
+         lnL += fh * pb->weights[h];
+         fhK[h] = 1;
+         for (ir = 1; ir < K; ir++) fhK[(size_t)ir * np + h] = exp(fhK[(size_t)ir * np + h] - fh);
+      }
+   for (il = 0; il < ls; il++) {
+      h = pose[il];
+      if (il == 0)
+         for (ir = 0; ir < K; ir++) b1[ir] = fhK[(size_t)ir * np + h];
+      else {
+         for (ir = 0; ir < K; ir++) {
+            for (j = 0, fh = 0; j < K; j++) fh += MK[ir * K + j] * b1[j];
+            b2[ir] = fh * fhK[(size_t)ir * np + h];
+         }
+         for (ir = 0; ir < K; ir++) b1[ir] = b2[ir];
+      }
+      for (ir = 0, fh = 0; ir < K; ir++) fh += b1[ir];
+      if (fh < 1e-90) fh = 1e-300;
+      for (ir = 0; ir < K; ir++) b1[ir] /= fh;      /* abyx(1/fh, ...) */
+      lnL += log(fh);
+   }
+   for (ir = 0, fh = 0; ir < K; ir++) fh += pb->freqK[ir] * b1[ir];
+   lnL += log(fh);
+   free(fhK); free(b1);
+   return lnL;
+}
+
 /* The same evaluation with the patterns cut into blocks and the blocks spread over the host cores: every thread walks
  * the whole tree for its own block, so partials stay in its cache (the all-cores CPU baseline of bench.py; the
  * reference itself is single-threaded).  Single-gene problems.  Returns +lnL. */

@@ -82,6 +82,10 @@ void orc_pmat_branch(const orc_problem *pb, int gene, int iclass, int node, doub
  */
 double orc_eval(const orc_problem *pb, double *lnf, double *fhK, double *partials, double *scalef, int nthreads);
 
+/* lfunAdG (treesub.c:7447): forward pass of the rate chain MK[K*K] over the ls sites in their original order
+ * (pose[site] = pattern index) on top of fx_r's fhK.  Returns +lnL. */
+double orc_eval_adg(const orc_problem *pb, const double *MK, const int *pose, int ls);
+
 /* orc_eval over pattern blocks spread over nthreads host cores (each thread walks the whole tree for its block; single
  * gene).  Returns +lnL. */
 double orc_eval_blocked(const orc_problem *pb, int nthreads, int block);

@@ -50,6 +50,8 @@ def lib():
         _LIB.orc_eval.argtypes = [C.POINTER(_Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _LIB.orc_pmat_branch.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int, C.c_int, C.c_void_p]
         _LIB.orc_last_npmat.restype = C.c_long
+        _LIB.orc_eval_adg.restype = C.c_double
+        _LIB.orc_eval_adg.argtypes = [C.POINTER(_Problem), C.c_void_p, C.c_void_p, C.c_int]
         _LIB.orc_eval_blocked.restype = C.c_double
         _LIB.orc_eval_blocked.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int]
         _LIB.orc_eval_branch.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -113,6 +115,14 @@ def evaluate(pb, want_lnf=True, want_fhk=False, want_partials=False, nthreads=1)
     scalef = np.zeros((K, n_scale, np_)) if (want_partials and n_scale) else None
     lnL = L.orc_eval(C.byref(pk.s), _ptr(lnf), _ptr(fhk), _ptr(part), _ptr(scalef), int(nthreads))
     return dict(lnL=lnL, lnf=lnf, fhK=fhk, partials=part, scalef=scalef, npmat=L.orc_last_npmat())
+
+
+def evaluate_adg(pb, MK, pose):
+    """lfunAdG: +lnL of the auto-discrete-gamma chain MK[K][K] over the sites pose[ls] (site -> pattern)."""
+    pk = _Packed(pb)
+    MK = np.ascontiguousarray(MK, dtype=np.float64)
+    pose = np.ascontiguousarray(pose, dtype=np.int32)
+    return lib().orc_eval_adg(C.byref(pk.s), _ptr(MK), _ptr(pose), len(pose))
 
 
 def evaluate_blocked(pb, nthreads, block=512):

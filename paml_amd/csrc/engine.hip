@@ -892,6 +892,56 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
    return 0;
 }
 
+int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *gene_rate, const double *MK, const int *pose, int ls,
+                      double *lnL)
+{
+   if (!e || !branch || !MK || !pose || !lnL || ls < 1) return fail(e, PAML_AMD_EINVAL, "eval_adg: bad arguments");
+   if (e->mode != PAML_AMD_MODE_LFUNDG) return fail(e, PAML_AMD_EINVAL, "eval_adg: needs the lfundG class mode");
+   const int K = e->K, np = e->n_patt;
+   for (int i = 0; i < ls; i++)
+      if (pose[i] < 0 || pose[i] >= np) return fail(e, PAML_AMD_EINVAL, "eval_adg: pose entry out of range");
+   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, false);      // fx_r on the device
+   if (r) return r;
+   std::vector<double> fhK((size_t)K * np), w(np), b1(K), b2(K);
+   HIPCHK(hipMemcpyAsync(fhK.data(), e->d_fhK.p, fhK.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipMemcpyAsync(w.data(), e->d_weights.p, w.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   // the chain over sites in their original order is sequential: host (treesub.c:7456-7492)
+   double l = 0;
+   if (e->tree.n_scale)
+      for (int h = 0; h < np; h++) {
+         const double fh = fhK[h];
+         if (!(w[h] > 0)) continue;
+         l += fh * w[h];
+         fhK[h] = 1;
+         for (int ir = 1; ir < K; ir++) fhK[(size_t)ir * np + h] = exp(fhK[(size_t)ir * np + h] - fh);
+      }
+   for (int il = 0; il < ls; il++) {
+      const int h = pose[il];
+      if (il == 0)
+         for (int ir = 0; ir < K; ir++) b1[ir] = fhK[(size_t)ir * np + h];
+      else {
+         for (int ir = 0; ir < K; ir++) {
+            double fh = 0;
+            for (int j = 0; j < K; j++) fh += MK[ir * K + j] * b1[j];
+            b2[ir] = fh * fhK[(size_t)ir * np + h];
+         }
+         b1 = b2;
+      }
+      double fh = 0;
+      for (int ir = 0; ir < K; ir++) fh += b1[ir];
+      if (fh < 1e-90) fh = 1e-300;
+      for (int ir = 0; ir < K; ir++) b1[ir] /= fh;
+      l += log(fh);
+   }
+   std::vector<double> fk(K);
+   HIPCHK(hipMemcpy(fk.data(), e->d_freqK.p, K * sizeof(double), hipMemcpyDeviceToHost));
+   double fh = 0;
+   for (int ir = 0; ir < K; ir++) fh += fk[ir] * b1[ir];
+   *lnL = l + log(fh);
+   return 0;
+}
+
 int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL)
 {
    if (!e || !branch || !d_lnL) return fail(e, PAML_AMD_EINVAL, "eval_device: null argument");

@@ -25,7 +25,7 @@ EXPORTS = [
     "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_classes", "paml_amd_eval",
-    "paml_amd_eval_batch", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
+    "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
@@ -213,6 +213,17 @@ class Engine:
         self._L.paml_amd_eval_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         self._chk(self._L.paml_amd_eval_batch(self._h, nb, _p(b), _p(g), _p(eo), _p(qf), _p(fk), _p(rt), _p(out), _p(lnf)))
         return (out, lnf) if want_lnf else out
+
+    def eval_adg(self, branch, MK, pose, gene_rate=None):
+        """lfunAdG: +lnL of the rate chain MK[K][K] over the sites pose[ls] (site -> pattern), fx_r on the device."""
+        b = np.ascontiguousarray(branch, dtype=np.float64)
+        g = None if gene_rate is None else np.ascontiguousarray(gene_rate, dtype=np.float64)
+        MK = np.ascontiguousarray(MK, dtype=np.float64)
+        pose = np.ascontiguousarray(pose, dtype=np.int32)
+        lnL = C.c_double()
+        self._L.paml_amd_eval_adg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        self._chk(self._L.paml_amd_eval_adg(self._h, _p(b), _p(g), _p(MK), _p(pose), len(pose), C.byref(lnL)))
+        return lnL.value
 
     def eval_device(self, branch, d_lnL_ptr, gene_rate=None):
         b = np.ascontiguousarray(branch, dtype=np.float64)

@@ -345,3 +345,19 @@ def test_specialised_kernels_via_flag(n, n_tips, n_patt, K, genes, amb, every):
     q.tree = Tree(pb.tree.n_tips, pb.tree.n_nodes, pb.tree.root, pb.tree.sons, br[1].copy(), pb.tree.label)
     r1 = oracle.evaluate(q)["lnL"]
     assert abs(got[1] - r1) <= 1e-10 * abs(r1)
+
+
+@pytest.mark.parametrize("n,K,every", [(4, 4, None), (4, 3, 3), (61, 2, None)])
+def test_eval_adg_matches_oracle(n, K, every):
+    """paml_amd_eval_adg (lfunAdG: fx_r on the device, the rate chain over the sites on the host) against the oracle."""
+    from test_oracle_golden import _sites
+    pb = helpers.random_problem(n, 9, 80, K=K, seed=21 + n, scale_every=every)
+    rng = np.random.default_rng(4)
+    pb.weights = rng.integers(1, 4, pb.n_patt).astype(float)
+    pose = _sites(pb, rng)
+    MK = 0.6 * np.eye(K) + 0.4 * rng.dirichlet(np.ones(K), size=K)
+    eng = engine_for(pb)
+    got = eng.eval_adg(pb.tree.branch, MK, pose, pb.gene_rate)
+    ref = oracle.evaluate_adg(pb, MK, pose)
+    assert abs(got - ref) <= 1e-10 * abs(ref), (got, ref)
+    assert abs(eng.eval_adg(pb.tree.branch, np.tile(pb.freqK, (K, 1)), pose, pb.gene_rate) - eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]) <= 1e-10 * abs(ref)

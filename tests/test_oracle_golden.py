@@ -80,3 +80,27 @@ def test_oracle_matches_reference_full_size(name):
         sub.gene_off = np.array([0, len(idx)], dtype=np.int32)
         lnf = oracle.evaluate(sub)["lnf"]
     assert np.max(np.abs(lnf - np.array(g["logf_sample"]))) < 2e-8
+
+
+def _sites(pb, rng):
+    """com.pose for a problem whose weights are site counts: every pattern repeated `weight` times, in random order."""
+    pose = np.repeat(np.arange(pb.n_patt), pb.weights.astype(int))
+    rng.shuffle(pose)
+    return pose.astype(np.int32)
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_oracle_adg_reduces_to_lfundg_for_independent_sites(scaled):
+    """lfunAdG restated (orc_eval_adg): with a rate chain whose rows all equal freqK the sites are independent and the
+    likelihood must equal lfundG's (pinned by the golden vectors); the site order then does not matter either."""
+    pb = helpers.random_problem(4, 10, 60, K=4, seed=11, scale_every=3 if scaled else None)
+    rng = np.random.default_rng(2)
+    pb.weights = rng.integers(1, 4, pb.n_patt).astype(float)
+    MK = np.tile(pb.freqK, (pb.K, 1))
+    ref = oracle.evaluate(pb, want_lnf=False)["lnL"]
+    a = oracle.evaluate_adg(pb, MK, _sites(pb, rng))
+    b = oracle.evaluate_adg(pb, MK, _sites(pb, rng))
+    assert abs(a - ref) <= 1e-11 * abs(ref) and abs(b - ref) <= 1e-11 * abs(ref)
+    # a persistent chain (rates of neighbouring sites correlated) gives a different value that depends on the order
+    MK2 = 0.7 * np.eye(pb.K) + 0.3 * MK
+    assert abs(oracle.evaluate_adg(pb, MK2, _sites(pb, rng)) - ref) > 1e-6
