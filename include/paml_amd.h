@@ -43,7 +43,7 @@ enum {
 };
 
 /* eigen-system kinds = the branches of GetPMatBranch (treesub.c:7503-7592) */
-enum { PAML_AMD_EIGEN_UVROOT = 0, PAML_AMD_EIGEN_CIJK = 1, PAML_AMD_EIGEN_K80 = 2, PAML_AMD_EIGEN_JC69LIKE = 3 };
+enum { PAML_AMD_EIGEN_UVROOT = 0, PAML_AMD_EIGEN_CIJK = 1, PAML_AMD_EIGEN_K80 = 2, PAML_AMD_EIGEN_JC69LIKE = 3, PAML_AMD_EIGEN_QMAT = 4 };
 
 /* likelihood reduction = which com.plfun the reference would have installed (codeml.c:2338-2340) */
 enum { PAML_AMD_MODE_LFUN = 0 /* treesub.c:7764 */, PAML_AMD_MODE_LFUNDG = 1 /* treesub.c:7608 + fx_r 7696 */ };
@@ -83,6 +83,10 @@ int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, c
 int paml_amd_set_eigen_cijk(paml_amd_engine *e, int set_id, int nR, const double *Cijk, const double *Root);
 int paml_amd_set_eigen_k80(paml_amd_engine *e, int set_id, double kappa);        /* PMatK80 tools.c:578 */
 int paml_amd_set_eigen_jc69like(paml_amd_engine *e, int set_id);                 /* PMatJC69like codeml.c:3585 */
+/* No eigen system at all: the rate matrix Q[n*n] itself (baseml UNREST / UNRESTu, QUNREST treesub.c:2543), from which
+ * GetPMatBranch builds P(t) = e^{Qt} with matexp(Qt, n, 7 Taylor terms, 5 squarings) (treesub.c:7524-7526, tools.c:4879).
+ * n_states <= 8.  The branch-local evaluation (eval_branch) is not available for this kind. */
+int paml_amd_set_eigen_qmat(paml_amd_engine *e, int set_id, const double *Q);
 
 /* Site classes: com.ncatG, com.freqK, per-class _rateSite (treesub.c:7669/7678), and for each
  * (gene, class, branch label) the eigen set (Set_UVR_BranchSite codeml.c:2663, SetPSiteClass

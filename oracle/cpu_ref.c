@@ -82,6 +82,36 @@ void orc_pmat_k80(double *P, double t, double kappa)
       }
 }
 
+/* UNREST: GetPMatBranch treesub.c:7524-7526 -> matexp(Q t, n, 7, 5), tools.c:4879-4921:
+ * e^A = (I + A/m + (A/m)^2/2! + ... + (A/m)^7/7!)^m with m = 2^5. */
+void orc_pmat_qmat(double *P, double t, int n, const double *Q)
+{
+   double B[64], T1[64], T2[64], S[64], factor = 1, *Tp = T1, *Tn = T2, *sw;
+   int i, j, k, term, sq;
+   for (i = 0; i < n * n; i++) { B[i] = T1[i] = Q[i] * t * (1.0 / 32); P[i] = B[i]; }
+   for (i = 0; i < n; i++) P[i * n + i] += 1;
+   for (term = 2; term <= 7; term++) {
+      for (i = 0; i < n; i++)
+         for (j = 0; j < n; j++) {
+            double s = 0;
+            for (k = 0; k < n; k++) s += Tp[i * n + k] * B[k * n + j];
+            Tn[i * n + j] = s;
+         }
+      factor /= term;
+      for (i = 0; i < n * n; i++) P[i] += Tn[i] * factor;
+      sw = Tp; Tp = Tn; Tn = sw;
+   }
+   for (sq = 0; sq < 5; sq++) {
+      for (i = 0; i < n; i++)
+         for (j = 0; j < n; j++) {
+            double s = 0;
+            for (k = 0; k < n; k++) s += P[i * n + k] * P[k * n + j];
+            S[i * n + j] = s;
+         }
+      for (i = 0; i < n * n; i++) P[i] = S[i];
+   }
+}
+
 /* codeml.c:3585-3595 */
 void orc_pmat_jc69like(double *P, double t, int n)
 {
@@ -103,6 +133,7 @@ void orc_pmat_branch(const orc_problem *pb, int gene, int iclass, int node, doub
    switch (es->kind) {
    case ORC_EIGEN_K80: orc_pmat_k80(P, t, es->kappa); break;
    case ORC_EIGEN_JC69LIKE: orc_pmat_jc69like(P, t, n); break;
+   case ORC_EIGEN_QMAT: orc_pmat_qmat(P, t, n, es->U); break;      /* U carries Q */
    case ORC_EIGEN_CIJK: orc_pmat_cijk(P, t, n, es->nR, es->Cijk, es->Root); break;
    default:
       t *= (pb->qfactor ? pb->qfactor[(size_t)iclass * pb->n_labels + lab] : 1.0);

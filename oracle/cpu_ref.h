@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-enum { ORC_EIGEN_UVROOT = 0, ORC_EIGEN_CIJK = 1, ORC_EIGEN_K80 = 2, ORC_EIGEN_JC69LIKE = 3 };
+enum { ORC_EIGEN_UVROOT = 0, ORC_EIGEN_CIJK = 1, ORC_EIGEN_K80 = 2, ORC_EIGEN_JC69LIKE = 3, ORC_EIGEN_QMAT = 4 };
 enum { ORC_MODE_LFUN = 0, ORC_MODE_LFUNDG = 1 };
 
 /* One eigen system = what GetPMatBranch (treesub.c:7503 / 7534) picks for a branch. */
@@ -24,7 +24,7 @@ typedef struct {
    int kind;             /* ORC_EIGEN_* */
    int nR;               /* CIJK: number of distinct roots (baseml.c:123 nR) */
    double kappa;         /* K80 */
-   const double *U;      /* UVROOT: U[i*n+k]   (tools.c:516) */
+   const double *U;      /* UVROOT: U[i*n+k]   (tools.c:516);  QMAT: the rate matrix Q[i*n+j] */
    const double *V;      /* UVROOT: V[k*n+j] */
    const double *Root;   /* UVROOT: Root[n];  CIJK: Root[nR] */
    const double *Cijk;   /* CIJK: Cijk[i*n*nR + j*nR + k]  (baseml.c:1572) */
@@ -69,6 +69,7 @@ void orc_pmat_uvroot(double *P, double t, int n, const double *U, const double *
 void orc_pmat_cijk(double *P, double t, int n, int nR, const double *Cijk, const double *Root);
 void orc_pmat_k80(double *P, double t, double kappa);
 void orc_pmat_jc69like(double *P, double t, int n);
+void orc_pmat_qmat(double *P, double t, int n, const double *Q);   /* UNREST: matexp(Qt, n, 7, 5), n <= 8 */
 /* GetPMatBranch restated: P(t) for the branch above `node`, for (gene, class). */
 void orc_pmat_branch(const orc_problem *pb, int gene, int iclass, int node, double *P);
 

@@ -85,6 +85,8 @@ class _Packed:
             for name in ("U", "V", "Root", "Cijk"):
                 if name in e:
                     setattr(eig[i], name, _ptr(k(e[name], np.float64)))
+            if "Q" in e:                      # rate-matrix kind (UNREST): the U slot carries Q
+                eig[i].U = _ptr(k(e["Q"], np.float64))
         self.eig = eig
         s = _Problem()
         s.n, s.n_tips, s.n_nodes, s.root, s.n_patt = pb.n, t.n_tips, t.n_nodes, t.root, pb.n_patt

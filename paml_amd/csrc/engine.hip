@@ -838,6 +838,17 @@ int paml_amd_set_eigen_jc69like(paml_amd_engine *e, int set_id)
    return 0;
 }
 
+int paml_amd_set_eigen_qmat(paml_amd_engine *e, int set_id, const double *Q)
+{
+   EigenHost *h = eigen_slot(e, set_id);
+   if (!h || !Q) return fail(e, PAML_AMD_EINVAL, "set_eigen_qmat: bad arguments");
+   if (e->n > 8) return fail(e, PAML_AMD_EUNSUPPORTED, "set_eigen_qmat: at most 8 states");
+   HIPCHK(upload(h->U, Q, (size_t)e->n * e->n, e->stream));      // the U slot carries Q
+   HIPCHK(hipStreamSynchronize(e->stream));
+   h->kind = PAML_AMD_EIGEN_QMAT;
+   return 0;
+}
+
 int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freqK, const double *rate, int n_labels,
                          const int *eigen_of, const double *qfactor)
 {
@@ -969,6 +980,8 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    const TreeDesc &T = e->tree;
    const int nn = T.n_nodes, n = e->n, K = e->K, G = e->n_genes, psets = G * K;
    if (node_b < 0 || node_b >= nn || node_b == T.root) return fail(e, PAML_AMD_EINVAL, "eval_branch: node has no branch");
+   for (size_t i = 0; i < e->eigen.size(); i++)
+      if (e->eigen[i].kind == PAML_AMD_EIGEN_QMAT) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_branch: not for rate-matrix (UNREST) sets");
    std::vector<int> father(nn, -1);
    for (int i = 0; i < nn; i++)
       for (int j = T.sons_ptr[i]; j < T.sons_ptr[i + 1]; j++) father[T.sons[j]] = i;

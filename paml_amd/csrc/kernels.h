@@ -172,6 +172,46 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
          acc[r] = p;
       }
    }
+   else if (es.kind == PAML_AMD_EIGEN_QMAT) {
+      // UNREST: P = e^{Qt} by matexp(Qt, n, 7, 5) (tools.c:4879): B = Qt/32, e^B by seven Taylor terms, then five squarings.
+      // n <= 8: one thread per entry, four n x n scratch matrices in LDS.
+      double *T0 = sA, *T1 = sA + 64, *T2 = sA + 128, *Bm = sA + 192;
+      const int i = tid / n, jj = tid % n;
+      const bool on = tid < n * n;
+      if (on) {
+         const double v = es.U[tid] * t * (1.0 / 32);
+         Bm[tid] = v; T1[tid] = v;
+         T0[tid] = v + (i == jj ? 1.0 : 0.0);
+      }
+      __syncthreads();
+      double factor = 1;
+      double *Tp = T1, *Tn = T2;              // B^(k-1) and B^k
+      for (int term = 2; term <= 7; term++) {
+         double s = 0;
+         if (on)
+            for (int k2 = 0; k2 < n; k2++) s += Tp[i * n + k2] * Bm[k2 * n + jj];
+         factor /= term;
+         if (on) { Tn[tid] = s; T0[tid] += s * factor; }
+         __syncthreads();
+         double *sw = Tp; Tp = Tn; Tn = sw;
+      }
+      double *Sa = T0, *Sb = T1;
+      for (int sq = 0; sq < 5; sq++) {
+         double s = 0;
+         if (on)
+            for (int k2 = 0; k2 < n; k2++) s += Sa[i * n + k2] * Sa[k2 * n + jj];
+         __syncthreads();
+         if (on) Sb[tid] = s;
+         __syncthreads();
+         double *sw = Sa; Sa = Sb; Sb = sw;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+         const int ii = rg * 16 + r;
+         acc[r] = (ii < n && j < n) ? Sa[ii * n + j] : 0.0;
+      }
+      __syncthreads();
+   }
    else {   // JC69-like (aa Poisson): no Qfactor (treesub.c:7584-7585)
       const double pii = 1. / n + (1. - 1. / n) * exp(-n / (n - 1.) * t);
       const double pij = (1. - pii) / (n - 1.);

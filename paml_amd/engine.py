@@ -13,7 +13,7 @@ import subprocess
 
 import numpy as np
 
-from .problem import EIGEN_CIJK, EIGEN_JC69LIKE, EIGEN_K80, EIGEN_UVROOT, Problem
+from .problem import EIGEN_CIJK, EIGEN_JC69LIKE, EIGEN_K80, EIGEN_QMAT, EIGEN_UVROOT, Problem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAML_AMD_LIB") or os.path.join(_HERE, "lib", "libpaml_amd.so")   # override: kernel experiments
@@ -24,7 +24,7 @@ JIT = 2
 EXPORTS = [
     "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
-    "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_classes", "paml_amd_eval",
+    "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
@@ -160,6 +160,10 @@ class Engine:
             self._chk(self._L.paml_amd_set_eigen_k80(self._h, set_id, float(e["kappa"])))
         elif k == EIGEN_JC69LIKE:
             self._chk(self._L.paml_amd_set_eigen_jc69like(self._h, set_id))
+        elif k == EIGEN_QMAT:
+            Q = np.ascontiguousarray(e["Q"], dtype=np.float64)
+            self._L.paml_amd_set_eigen_qmat.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+            self._chk(self._L.paml_amd_set_eigen_qmat(self._h, set_id, _p(Q)))
         else:
             raise ValueError(k)
 

@@ -9,7 +9,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-EIGEN_UVROOT, EIGEN_CIJK, EIGEN_K80, EIGEN_JC69LIKE = 0, 1, 2, 3
+EIGEN_UVROOT, EIGEN_CIJK, EIGEN_K80, EIGEN_JC69LIKE, EIGEN_QMAT = 0, 1, 2, 3, 4
 MODE_LFUN, MODE_LFUNDG = 0, 1
 
 

@@ -361,3 +361,33 @@ def test_eval_adg_matches_oracle(n, K, every):
     ref = oracle.evaluate_adg(pb, MK, pose)
     assert abs(got - ref) <= 1e-10 * abs(ref), (got, ref)
     assert abs(eng.eval_adg(pb.tree.branch, np.tile(pb.freqK, (K, 1)), pose, pb.gene_rate) - eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]) <= 1e-10 * abs(ref)
+
+
+def _unrest_problem(seed, n_tips=7, n_patt=120, K=1):
+    """baseml UNREST-like: a general (non-reversible) 4 x 4 rate matrix, arbitrary root frequencies, rooted tree."""
+    from paml_amd.problem import EIGEN_QMAT
+    pb = helpers.random_problem(4, n_tips, n_patt, K=K, seed=seed)
+    rng = np.random.default_rng(seed)
+    Q = rng.gamma(1.0, 1.0, size=(4, 4))
+    Q[np.diag_indices(4)] = 0
+    Q[np.diag_indices(4)] = -Q.sum(axis=1)
+    Q /= np.abs(np.diag(Q)).mean()
+    pb.eigen = [dict(kind=EIGEN_QMAT, Q=Q)]
+    pb.pi = rng.dirichlet(np.ones(4) * 3)
+    return pb, Q
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_rate_matrix_kind_unrest(K):
+    """PAML_AMD_EIGEN_QMAT: P(t) = matexp(Qt, n, 7, 5) as GetPMatBranch builds it for UNREST — against the oracle's
+    restatement and (to the method's own accuracy) scipy's expm."""
+    from scipy.linalg import expm
+    pb, Q = _unrest_problem(77, K=K)
+    eng, out, ref = check(pb)
+    node = pb.tree.n_tips + 1
+    P = eng.get_pmat(0, 0, node)
+    assert np.allclose(P, oracle.pmat_branch(pb, 0, 0, node), rtol=0, atol=1e-14)
+    t = pb.tree.branch[node] * pb.rate[0] * pb.gene_rate[0]
+    assert np.allclose(P, expm(Q * t), rtol=0, atol=1e-10) and np.allclose(P.sum(axis=1), 1, atol=1e-12)
+    with pytest.raises(Exception):
+        eng.eval_branch(1, np.array([0.1]), pb.tree.branch, pb.gene_rate)

@@ -104,3 +104,21 @@ def test_oracle_adg_reduces_to_lfundg_for_independent_sites(scaled):
     # a persistent chain (rates of neighbouring sites correlated) gives a different value that depends on the order
     MK2 = 0.7 * np.eye(pb.K) + 0.3 * MK
     assert abs(oracle.evaluate_adg(pb, MK2, _sites(pb, rng)) - ref) > 1e-6
+
+
+def test_oracle_unrest_matexp_matches_scipy():
+    """orc_pmat_qmat (matexp with 7 Taylor terms and 5 squarings, tools.c:4879) against scipy's expm."""
+    from scipy.linalg import expm
+    from paml_amd.problem import EIGEN_QMAT
+    rng = np.random.default_rng(5)
+    pb = helpers.random_problem(4, 6, 30, seed=8)
+    Q = rng.gamma(1.0, 1.0, size=(4, 4))
+    Q[np.diag_indices(4)] = 0
+    Q[np.diag_indices(4)] = -Q.sum(axis=1)
+    pb.eigen = [dict(kind=EIGEN_QMAT, Q=Q)]
+    for node in range(pb.tree.n_nodes):
+        if node == pb.tree.root:
+            continue
+        P = oracle.pmat_branch(pb, 0, 0, node)
+        assert np.allclose(P, expm(Q * pb.tree.branch[node] * pb.rate[0] * pb.gene_rate[0]), rtol=0, atol=1e-9)
+    assert np.isfinite(oracle.evaluate(pb)["lnL"])
