@@ -75,6 +75,13 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
  * on its bound under method 1); hess: NULL or np x np, the information matrix that was inverted. */
 int pamlh_standard_errors(pamlh *p, const double *x, int method, double *se, double *hess);
 
+/* Naive empirical Bayes posterior probabilities of the site classes (lfunNSsites_rate codeml.c:5241) at the model state of
+ * the last pamlh_set_x, from the device's fhK: post[K][n_patt]; mean_w[n_patt] (may be NULL) = posterior mean omega.
+ * pamlh_pose maps a site (after cleaning) to its pattern; pamlh_class_omega gives the omega of every class. */
+int pamlh_neb(pamlh *p, double *post, double *mean_w);
+const int *pamlh_pose(const pamlh *p, int *n_sites);
+const double *pamlh_class_omega(const pamlh *p);
+
 /* Write the reference's `lnf` file layout (print_lnf_site treesub.c:7598) for the last pamlh_eval_gpu. */
 int pamlh_write_lnf(const pamlh *p, const char *path, const double *lnf);
 

@@ -34,6 +34,7 @@ struct pamlh {
    char *raw;              /* [ns][npatt*n31] raw characters of the patterns (for lnf output) */
    int n31;
    int *n_chara;
+   int *pose, n_pose;      /* site (after cleaning) -> pattern index */
    unsigned char *chara_map;
    double fb3x4[12], fb4[4], fcodon[64], pi_data[64];
    double aaS[400], aapi_file[20];
@@ -48,6 +49,7 @@ struct pamlh {
    int *eigen_of;
    pamlh_eig eig[16];
    double kappa, omega, alpha;
+   double class_w[64];     /* NSsites: omega of every site class */
    /* engine */
    paml_amd_engine *eng;
 };

@@ -212,6 +212,7 @@ int pamlh_read_seqs(pamlh *p)
          char *raw2;
          int np = 0, *first = (int *)malloc(nkeep * sizeof(int));
          double *w = (double *)calloc(nkeep, sizeof(double));
+         p->pose = (int *)malloc((nkeep + 1) * sizeof(int));      /* com.pose: site (after cleaning) -> pattern */
          if (!readpattern) {
             g_sort_ctx = p;
             qsort(idx, nkeep, sizeof(int), cmp_cols0);
@@ -224,10 +225,12 @@ int pamlh_read_seqs(pamlh *p)
                }
                if (same) w[np - 1] += cnt[keep[idx[h]]];
                else { first[np] = idx[h]; w[np] = cnt[keep[idx[h]]]; np++; }
+               p->pose[idx[h]] = np - 1;
             }
          }
          else
-            for (h = 0; h < nkeep; h++) { first[np] = h; w[np] = cnt[keep[h]]; np++; }
+            for (h = 0; h < nkeep; h++) { first[np] = h; w[np] = cnt[keep[h]]; p->pose[h] = np; np++; }
+         p->n_pose = nkeep;
          raw2 = (char *)malloc((size_t)ns * np * n31);
          for (j = 0; j < ns; j++)
             for (h = 0; h < np; h++) memcpy(raw2 + ((size_t)j * np + h) * n31, p->raw + ((size_t)j * nkeep + first[h]) * n31, n31);

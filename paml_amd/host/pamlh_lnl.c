@@ -47,6 +47,21 @@ int main(int argc, char **argv)
    lnf = (double *)malloc(npatt * sizeof(double));
    if (pamlh_eval_gpu(p, &lnL, lnf)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
    printf("ntime & np: %d %d   npatt %d\nlnL  = %.6f\n", ntime, np, npatt, lnL);
+   {  /* site-class models: the NEB table the reference prints (sites with Pr(last class) > 0.5 when its omega > 1) */
+      int mode, K, n_sites, h;
+      pamlh_model(p, &mode, &K, NULL, NULL);
+      if (mode == 1 && K > 1 && pamlh_class_omega(p)[K - 1] > 1) {
+         double *post = (double *)malloc((size_t)K * npatt * sizeof(double)), *mw = (double *)malloc(npatt * sizeof(double));
+         const int *pose = pamlh_pose(p, &n_sites);
+         if (!pamlh_neb(p, post, mw)) {
+            printf("\nNaive Empirical Bayes (NEB): sites with Pr(w>1) > 0.5\n   site   Pr(w>1)   post mean w\n");
+            for (h = 0; h < n_sites; h++)
+               if (post[(size_t)(K - 1) * npatt + pose[h]] > 0.5)
+                  printf("%7d   %7.3f   %9.3f\n", h + 1, post[(size_t)(K - 1) * npatt + pose[h]], mw[pose[h]]);
+         }
+         free(post); free(mw);
+      }
+   }
    pamlh_write_lnf(p, "lnf", lnf);
    free(lnf);
    pamlh_free(p);

@@ -269,6 +269,7 @@ bad:
 
 void pamlh_free(pamlh *p)
 {
+   if (p) free(p->pose);
    int i;
    if (!p) return;
    if (p->eng) paml_amd_destroy(p->eng);
@@ -460,7 +461,7 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          for (j = 0; j < K; j++) {
             codon_q(p, kappa, w[j], Q);
             set_eig_uvroot(p, j, Q, p->pi, mr);
-            p->freqK[j] = f[j]; p->rate[j] = 1; p->eigen_of[j] = j;
+            p->freqK[j] = f[j]; p->rate[j] = 1; p->eigen_of[j] = j; p->class_w[j] = w[j];
          }
          p->K = K; p->n_eigen = K; p->mode = PAML_AMD_MODE_LFUNDG;
       }
@@ -567,6 +568,52 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    return 0;
 }
+
+/* Naive empirical Bayes posteriors of the site classes (lfunNSsites_rate codeml.c:5241-5330) at the current model state
+ * (pamlh_set_x): post[k][h] = freqK_k f(x_h | class k) / sum_j freqK_j f(x_h | class j) straight from the device's fhK.
+ * post: [K][npatt].  For NSsites models mean_w[h] (may be NULL) gets the posterior mean omega of the pattern. */
+int pamlh_neb(pamlh *p, double *post, double *mean_w)
+{
+   const int K = p->K, np = p->npatt;
+   double lnL, *fhK = (double *)malloc((size_t)K * np * sizeof(double));
+   int i, h, k, rc;
+   if (p->mode != PAML_AMD_MODE_LFUNDG) { free(fhK); return pamlh_fail(p, "NEB needs a model with site classes"); }
+   if (p->scale) for (i = 0; i < p->nnode; i++) if (p->scale[i]) { free(fhK); return pamlh_fail(p, "NEB with scaling nodes is not supported yet"); }
+   if ((rc = pamlh_engine_ready(p))) { free(fhK); return rc; }
+   if ((rc = paml_amd_set_pi(p->eng, 1, p->pi))) { free(fhK); return pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); }
+   for (i = 0; i < p->n_eigen; i++) {
+      const pamlh_eig *e = &p->eig[i];
+      if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, i, e->U, e->V, e->Root);
+      else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(p->eng, i, e->nR, e->Cijk, e->Root);
+      else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(p->eng, i, e->kappa);
+      else rc = paml_amd_set_eigen_jc69like(p->eng, i);
+      if (rc) { free(fhK); return pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); }
+   }
+   if ((rc = paml_amd_set_classes(p->eng, p->mode, K, p->freqK, p->rate, 1, p->eigen_of, NULL)) ||
+       (rc = paml_amd_eval(p->eng, p->branch, NULL, &lnL, NULL, fhK))) {
+      free(fhK);
+      return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   }
+   for (h = 0; h < np; h++) {
+      double s = 0, mw = 0;
+      for (k = 0; k < K; k++) s += p->freqK[k] * fhK[(size_t)k * np + h];
+      for (k = 0; k < K; k++) {
+         post[(size_t)k * np + h] = s > 0 ? p->freqK[k] * fhK[(size_t)k * np + h] / s : 0;
+         mw += post[(size_t)k * np + h] * p->class_w[k];
+      }
+      if (mean_w) mean_w[h] = mw;
+   }
+   free(fhK);
+   return 0;
+}
+
+const int *pamlh_pose(const pamlh *p, int *n_sites)
+{
+   if (n_sites) *n_sites = p->n_pose;
+   return p->pose;
+}
+
+const double *pamlh_class_omega(const pamlh *p) { return p->class_w; }
 
 int pamlh_write_lnf(const pamlh *p, const char *path, const double *lnf)
 {

@@ -178,3 +178,19 @@ class Analysis:
         if self._L.pamlh_standard_errors(self._h, x.ctypes.data_as(C.c_void_p), int(method), se.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)) != 0:
             raise RuntimeError("pamlh_standard_errors: " + self._L.pamlh_error(self._h).decode())
         return se, H
+
+    def neb(self, x):
+        """NEB site-class posteriors at x: (post[K][n_sites], mean_omega[n_sites]) in the order of the (cleaned) sites."""
+        self.set_x(x)
+        mode, K, ne, nl = (C.c_int(), C.c_int(), C.c_int(), C.c_int())
+        self._L.pamlh_model(self._h, C.byref(mode), C.byref(K), C.byref(ne), C.byref(nl))
+        post, mw = np.zeros((K.value, self.n_patt)), np.zeros(self.n_patt)
+        self._L.pamlh_neb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if self._L.pamlh_neb(self._h, post.ctypes.data_as(C.c_void_p), mw.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("pamlh_neb: " + self._L.pamlh_error(self._h).decode())
+        ns = C.c_int()
+        self._L.pamlh_pose.restype = C.c_void_p
+        self._L.pamlh_pose.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        ptr = self._L.pamlh_pose(self._h, C.byref(ns))
+        pose = _arr(ptr, np.int32, ns.value)
+        return post[:, pose], mw[pose]

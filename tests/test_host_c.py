@@ -174,3 +174,19 @@ def test_c_host_reads_interleaved_phylip(tmp_path):
     pa, pb = a.problem(x), b.problem(x)
     assert np.array_equal(pa.z, pb.z) and np.array_equal(pa.weights, pb.weights) and b.ls == a.ls
     assert abs(oracle.evaluate(pb)["lnL"] - g["lnL"]) <= 2e-6
+
+
+@pytest.mark.gpu
+def test_c_host_neb_matches_the_reference_table():
+    """NEB under M2a on the HIV data at the MLE: Pr(w > 1) and the posterior mean omega of the sites the reference lists in
+    its main output ("Naive Empirical Bayes (NEB) analysis", printed with 3 decimals)."""
+    ref = {9: (0.720, 2.889), 22: (0.796, 3.089), 24: (0.578, 2.517), 26: (0.905, 3.376), 28: (0.999, 3.624), 31: (0.566, 2.486),
+           39: (0.640, 2.681), 51: (0.883, 3.319), 66: (0.998, 3.621), 68: (0.601, 2.578), 69: (0.830, 3.179), 76: (0.671, 2.761),
+           83: (0.811, 3.128), 87: (0.985, 3.587)}
+    g = helpers.load_golden("hiv_m2a")
+    a = hostlib.Analysis(os.path.join(CTL, "hiv_ns2.ctl"), "codeml")
+    post, mw = a.neb(np.array(g["x"]))
+    assert post.shape == (3, 91) and np.allclose(post.sum(axis=0), 1)
+    for site, (pr, m) in ref.items():
+        assert abs(post[2, site - 1] - pr) < 1.5e-3 and abs(mw[site - 1] - m) < 2.5e-3, (site, post[2, site - 1], mw[site - 1])
+    assert sorted(np.nonzero(post[2] > 0.5)[0] + 1) == sorted(ref)          # exactly the sites the reference reports
