@@ -391,3 +391,29 @@ def test_rate_matrix_kind_unrest(K):
     assert np.allclose(P, expm(Q * t), rtol=0, atol=1e-10) and np.allclose(P.sum(axis=1), 1, atol=1e-12)
     with pytest.raises(Exception):
         eng.eval_branch(1, np.array([0.1]), pb.tree.branch, pb.gene_rate)
+
+
+def test_abi_error_behaviour():
+    """The C ABI reports misuse through return codes + paml_amd_last_error (never exit(), unlike the reference's zerror)."""
+    from paml_amd.engine import Engine, EngineError
+    pb = helpers.random_problem(4, 6, 50, K=2, seed=1)
+    eng = Engine(pb.n, pb.tree.n_tips, pb.n_patt, max_classes=2)
+    with pytest.raises(EngineError, match="before set_tips"):
+        eng.eval(pb.tree.branch)
+    with pytest.raises(EngineError, match="code >= n_codes"):
+        bad = pb.z.copy()
+        bad[0, 0] = 200
+        eng.set_tips(bad, pb.weights, cleandata=True)
+    eng.load(pb)
+    assert np.isfinite(eng.eval(pb.tree.branch)["lnL"])
+    with pytest.raises(EngineError, match="KEEP_PARTIALS"):
+        eng.eval_dirty(pb.tree.branch, np.zeros(pb.tree.n_nodes, dtype=np.uint8))
+    with pytest.raises(EngineError, match="KEEP_PARTIALS"):
+        eng.get_partials(pb.tree.n_tips)
+    with pytest.raises(EngineError, match="no branch"):
+        eng.eval_branch(pb.tree.root, np.array([0.1]), pb.tree.branch)
+    with pytest.raises(EngineError):
+        eng.set_classes(pb.mode, np.ones(5) / 5, np.ones(5), np.zeros((1, 5, 1), dtype=np.int32))      # K > max_classes
+    with pytest.raises(EngineError, match="out of range"):
+        eng.eval_batch(np.tile(pb.tree.branch, (2, 1)), eigen_of=np.full((2, 1, 2, 1), 7, dtype=np.int32))
+    assert np.isfinite(eng.eval(pb.tree.branch)["lnL"])          # the engine is still usable after the errors
