@@ -79,6 +79,10 @@ int pamlh_standard_errors(pamlh *p, const double *x, int method, double *se, dou
  * the last pamlh_set_x, from the device's fhK: post[K][n_patt]; mean_w[n_patt] (may be NULL) = posterior mean omega.
  * pamlh_pose maps a site (after cleaning) to its pattern; pamlh_class_omega gives the omega of every class. */
 int pamlh_neb(pamlh *p, double *post, double *mean_w);
+/* Bayes empirical Bayes for M2a / M8 at the estimates x (lfunNSsites_M2M8 codeml.c:6387): posterior probability of the
+ * w > 1 class, posterior mean and sd of omega, per pattern [n_patt].  f(x_h | w) for the grid's omegas is one evaluation on
+ * the device; the 10^4-point grid sums run on the host. */
+int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double *se_w);
 const int *pamlh_pose(const pamlh *p, int *n_sites);
 const double *pamlh_class_omega(const pamlh *p);
 

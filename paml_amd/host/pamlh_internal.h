@@ -47,9 +47,10 @@ struct pamlh {
    int np, ntime, mode, K, n_eigen, n_labels;
    double *branch, *pi, *freqK, *rate;
    int *eigen_of;
-   pamlh_eig eig[16];
+   pamlh_eig eig[64];
    double kappa, omega, alpha;
    double class_w[64];     /* NSsites: omega of every site class */
+   double ns_mr;           /* NSsites: mean rate at the mean omega = 1 / Qfactor_NS of the last pamlh_set_x */
    /* engine */
    paml_amd_engine *eng;
 };

@@ -59,6 +59,15 @@ int main(int argc, char **argv)
                if (post[(size_t)(K - 1) * npatt + pose[h]] > 0.5)
                   printf("%7d   %7.3f   %9.3f\n", h + 1, post[(size_t)(K - 1) * npatt + pose[h]], mw[pose[h]]);
          }
+         {  /* M2a / M8: the BEB table as well */
+            double *pr = (double *)malloc(npatt * sizeof(double)), *sw = (double *)malloc(npatt * sizeof(double));
+            if (!pamlh_beb(p, x, pr, mw, sw)) {
+               printf("\nBayes Empirical Bayes (BEB): sites with Pr(w>1) > 0.5\n   site   Pr(w>1)   post mean +- SE for w\n");
+               for (h = 0; h < n_sites; h++)
+                  if (pr[pose[h]] > 0.5) printf("%7d   %7.3f   %9.3f +- %5.3f\n", h + 1, pr[pose[h]], mw[pose[h]], sw[pose[h]]);
+            }
+            free(pr); free(sw);
+         }
          free(post); free(mw);
       }
    }

@@ -458,6 +458,7 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          /* Qfactor_NS = 1 / mr(Q at the mean omega) (codeml.c:2586-2605); class ir: Root /= 1/Qfactor_NS (treesub.c:7675-7685) */
          for (j = 0; j < K; j++) wmean += f[j] * w[j];
          mr = codon_q(p, kappa, wmean, Q);
+         p->ns_mr = mr;
          for (j = 0; j < K; j++) {
             codon_q(p, kappa, w[j], Q);
             set_eig_uvroot(p, j, Q, p->pi, mr);
@@ -605,6 +606,119 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w)
    }
    free(fhK);
    return 0;
+}
+
+/* Bayes empirical Bayes (Yang, Wong & Nielsen 2005; lfunNSsites_M2M8 codeml.c:6387-6623) for M2a and M8 at the estimates
+ * x: the uncertainty of the class parameters is integrated out over a 10^4-point grid with uniform priors —
+ *   M2a: (p0, p1) on the 100 triangles of the ternary graph (GetIndexTernary tools.c:4602), w0 ~ U(0,1), w2 ~ U(1,11);
+ *   M8:  p0 ~ U(0,1), p, q ~ U(0,2) (class proportions from the beta cdf over ten equal omega bins), ws ~ U(1,11).
+ * Stage 1 — f(x_h | w) for the 21 (20) grid omegas at the estimated branch lengths and kappa, scaled by the model's
+ * Qfactor_NS — is one evaluation on the device; stage 2, the grid sums, runs here on the host.
+ * Outputs per pattern: pr_pos (posterior probability of the w > 1 class), mean_w, se_w. */
+int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double *se_w)
+{
+   enum { N1 = 10 };
+   const int np = p->npatt, m2a = p->nssites == 2;
+   const int ncls = m2a ? 3 : N1 + 1, K = m2a ? 2 * N1 + 1 : 2 * N1, ngrid = N1 * N1 * N1 * N1;
+   double rK[2 * N1 + 1], para[4][N1], lnL, fX, *fhK, *pcl, *lnfXs, *Q, kappa, mr;
+   int *iw, i, k, h, g, rc;
+   if (!(p->seqtype == 1 && (p->nssites == 2 || p->nssites == 8))) return pamlh_fail(p, "BEB is defined for NSsites 2 (M2a) and 8 (M8)");
+   if (p->scale) for (i = 0; i < p->nnode; i++) if (p->scale[i]) return pamlh_fail(p, "BEB with scaling nodes is not supported yet");
+   if ((rc = pamlh_set_x(p, x, p->np))) return rc;
+   kappa = p->kappa; mr = p->ns_mr;
+   /* the grid (get_grid_para_like_M2M8 codeml.c:6250-6275): bin mid-points */
+   for (i = 0; i < N1; i++) {
+      para[0][i] = (i + 0.5) / N1;                       /* p0 (M8) */
+      para[1][i] = 2 * (i + 0.5) / N1;                   /* p of the beta */
+      para[2][i] = m2a ? (i + 0.5) / N1 : 2 * (i + 0.5) / N1;   /* w0 (M2a) or q */
+      para[3][i] = 1 + 10 * (i + 0.5) / N1;              /* w2 / ws */
+   }
+   k = 0;
+   for (i = 0; i < N1; i++) rK[k++] = (i + 0.5) / N1;    /* w0 of M2a, or the beta's omega bins */
+   if (m2a) rK[k++] = 1;
+   for (i = 0; i < N1; i++) rK[k++] = 1 + 10 * (i + 0.5) / N1;
+   /* stage 1: f(x_h | w) for every grid omega (fx_r with BayesEB = 1: the model's branch lengths, kappa and Qfactor_NS) */
+   Q = (double *)malloc((size_t)61 * 61 * sizeof(double));
+   for (k = 0; k < K; k++) {
+      codon_q(p, kappa, rK[k], Q);
+      set_eig_uvroot(p, k, Q, p->pi, mr);
+      p->freqK[k] = 1.0 / K; p->rate[k] = 1; p->eigen_of[k] = k;
+   }
+   free(Q);
+   p->K = K; p->n_eigen = K; p->mode = PAML_AMD_MODE_LFUNDG;
+   fhK = (double *)malloc((size_t)K * np * sizeof(double));
+   if ((rc = pamlh_engine_ready(p))) { free(fhK); return rc; }
+   rc = paml_amd_set_pi(p->eng, 1, p->pi);
+   for (k = 0; k < K && !rc; k++) rc = paml_amd_set_eigen_uvroot(p->eng, k, p->eig[k].U, p->eig[k].V, p->eig[k].Root);
+   if (!rc) rc = paml_amd_set_classes(p->eng, p->mode, K, p->freqK, p->rate, 1, p->eigen_of, NULL);
+   if (!rc) rc = paml_amd_eval(p->eng, p->branch, NULL, &lnL, NULL, fhK);
+   if (rc) { free(fhK); return pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); }
+   for (h = 0; h < np; h++) {       /* scale every pattern by its largest class value (codeml.c:6297-6305) */
+      double fh = fhK[h];
+      for (k = 1; k < K; k++) if (fhK[(size_t)k * np + h] > fh) fh = fhK[(size_t)k * np + h];
+      for (k = 0; k < K; k++) fhK[(size_t)k * np + h] /= fh;
+   }
+   /* class proportions and omega index of every class at every grid point (get_pclassM_iw_M2M8 codeml.c:6340-6383) */
+   pcl = (double *)malloc((size_t)ngrid * ncls * sizeof(double));
+   iw = (int *)malloc((size_t)ngrid * ncls * sizeof(int));
+   lnfXs = (double *)malloc(ngrid * sizeof(double));
+   for (g = 0; g < ngrid; g++) {
+      const int ip0 = g / 1000, ip1 = (g / 100) % 10, ip2 = (g / 10) % 10, ip3 = g % 10;
+      if (m2a) {
+         const int tri = ip0 * N1 + ip1, ix = (int)sqrt((double)tri), iy = tri - ix * ix;
+         const double p0 = (1 + (iy / 2) * 3 + (iy % 2)) / (3.0 * N1), p1 = (1 + (N1 - 1 - ix) * 3 + (iy % 2)) / (3.0 * N1);
+         pcl[g * 3] = p0; pcl[g * 3 + 1] = p1; pcl[g * 3 + 2] = 1 - p0 - p1;
+         iw[g * 3] = ip2; iw[g * 3 + 1] = N1; iw[g * 3 + 2] = N1 + 1 + ip3;
+      }
+      else {
+         const double p0 = para[0][ip0], bp = para[1][ip1], bq = para[2][ip2];
+         for (k = 0; k < N1; k++) {
+            const double c0 = k > 0 ? pamlh_betai(bp, bq, k / (double)N1) : 0, c1 = k < N1 - 1 ? pamlh_betai(bp, bq, (k + 1.0) / N1) : 1;
+            pcl[g * ncls + k] = p0 * (c1 - c0);
+            iw[g * ncls + k] = k;
+         }
+         pcl[g * ncls + N1] = 1 - p0;
+         iw[g * ncls + N1] = N1 + ip3;
+      }
+   }
+   /* log f(X | grid point) and the marginal likelihood over the grid (codeml.c:6482-6528), as a log-sum-exp */
+   {
+      double mx = -1e300, s = 0;
+      for (g = 0; g < ngrid; g++) {
+         double l = 0;
+         for (h = 0; h < np; h++) {
+            double fh = 0;
+            for (k = 0; k < ncls; k++) fh += pcl[g * ncls + k] * fhK[(size_t)iw[g * ncls + k] * np + h];
+            if (fh < 1e-300) continue;
+            l += log(fh) * p->w[h];
+         }
+         lnfXs[g] = l;
+         if (l > mx) mx = l;
+      }
+      for (g = 0; g < ngrid; g++) s += exp(lnfXs[g] - mx);
+      fX = log(s) + mx;
+   }
+   /* posterior of the classes, mean and sd of omega for every pattern (codeml.c:6533-6580) */
+   for (h = 0; h < np; h++) {
+      double post_last = 0, m1 = 0, m2 = 0;
+      for (g = 0; g < ngrid; g++) {
+         double fh = 0, wg;
+         for (k = 0; k < ncls; k++) fh += pcl[g * ncls + k] * fhK[(size_t)iw[g * ncls + k] * np + h];
+         if (fh < 1e-300) continue;
+         wg = exp(lnfXs[g] - fX);
+         for (k = 0; k < ncls; k++) {
+            const double t = pcl[g * ncls + k] * fhK[(size_t)iw[g * ncls + k] * np + h] / fh * wg, w = rK[iw[g * ncls + k]];
+            if (k == ncls - 1) post_last += t;
+            m1 += t * w;
+            m2 += t * w * w;
+         }
+      }
+      pr_pos[h] = post_last;
+      mean_w[h] = m1;
+      se_w[h] = m2 - m1 * m1 > 0 ? sqrt(m2 - m1 * m1) : 0;
+   }
+   free(fhK); free(pcl); free(iw); free(lnfXs);
+   return pamlh_set_x(p, x, p->np);      /* back to the model's own classes */
 }
 
 const int *pamlh_pose(const pamlh *p, int *n_sites)

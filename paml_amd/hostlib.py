@@ -194,3 +194,16 @@ class Analysis:
         ptr = self._L.pamlh_pose(self._h, C.byref(ns))
         pose = _arr(ptr, np.int32, ns.value)
         return post[:, pose], mw[pose]
+
+    def beb(self, x):
+        """BEB under M2a / M8 at x: (Pr(w>1), mean omega, sd omega) per site (pamlh_beb)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        pr, mw, se = np.zeros(self.n_patt), np.zeros(self.n_patt), np.zeros(self.n_patt)
+        self._L.pamlh_beb.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        if self._L.pamlh_beb(self._h, *[a.ctypes.data_as(C.c_void_p) for a in (x, pr, mw, se)]) != 0:
+            raise RuntimeError("pamlh_beb: " + self._L.pamlh_error(self._h).decode())
+        ns = C.c_int()
+        self._L.pamlh_pose.restype = C.c_void_p
+        self._L.pamlh_pose.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        pose = _arr(self._L.pamlh_pose(self._h, C.byref(ns)), np.int32, ns.value)
+        return pr[pose], mw[pose], se[pose]

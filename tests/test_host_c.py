@@ -190,3 +190,30 @@ def test_c_host_neb_matches_the_reference_table():
     for site, (pr, m) in ref.items():
         assert abs(post[2, site - 1] - pr) < 1.5e-3 and abs(mw[site - 1] - m) < 2.5e-3, (site, post[2, site - 1], mw[site - 1])
     assert sorted(np.nonzero(post[2] > 0.5)[0] + 1) == sorted(ref)          # exactly the sites the reference reports
+
+
+BEB_M2A = {1: (0.548, 2.293, 1.292), 9: (0.750, 2.975, 1.428), 22: (0.812, 3.142, 1.329), 24: (0.607, 2.453, 1.297),
+           26: (0.904, 3.408, 1.184), 28: (0.999, 3.729, 1.024), 31: (0.604, 2.481, 1.356), 39: (0.668, 2.674, 1.364),
+           40: (0.512, 2.212, 1.318), 51: (0.872, 3.277, 1.190), 66: (0.998, 3.727, 1.026), 68: (0.632, 2.547, 1.334),
+           69: (0.825, 3.133, 1.247), 76: (0.686, 2.695, 1.313), 83: (0.808, 3.078, 1.263), 87: (0.987, 3.696, 1.062)}
+BEB_M8 = {1: (0.796, 2.627, 1.064), 9: (0.857, 2.819, 1.038), 18: (0.590, 2.093, 1.314), 21: (0.592, 2.090, 1.169),
+          22: (0.917, 2.973, 0.899), 24: (0.850, 2.771, 0.986), 26: (0.972, 3.112, 0.744), 28: (1.000, 3.183, 0.653),
+          31: (0.801, 2.654, 1.086), 39: (0.843, 2.768, 1.032), 40: (0.733, 2.468, 1.146), 46: (0.660, 2.279, 1.226),
+          51: (0.969, 3.100, 0.747), 59: (0.575, 2.049, 1.239), 66: (1.000, 3.183, 0.654), 68: (0.842, 2.758, 1.016),
+          69: (0.949, 3.047, 0.804), 75: (0.551, 1.984, 1.237), 76: (0.889, 2.881, 0.929), 83: (0.941, 3.027, 0.823),
+          84: (0.611, 2.139, 1.173), 87: (0.995, 3.173, 0.670)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname,ctl,table", [("hiv_m2a", "hiv_ns2.ctl", BEB_M2A), ("hiv_m8", "hiv_ns8.ctl", BEB_M8)])
+def test_c_host_beb_matches_the_reference_table(gname, ctl, table):
+    """Bayes empirical Bayes under M2a and M8 on the HIV data: the reference's "BEB analysis" table (Pr(w>1), posterior mean
+    +- SE of omega, 3 printed decimals; the runs were made with the unmodified binary in the build container) — the
+    f(x_h|w) for the grid omegas come from the device, the 10^4-point grid sums from the C host."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), "codeml")
+    pr, mw, se = a.beb(np.array(g["x"]))
+    for site, (p_, m_, s_) in table.items():
+        got = (pr[site - 1], mw[site - 1], se[site - 1])
+        assert abs(got[0] - p_) < 2e-3 and abs(got[1] - m_) < 4e-3 and abs(got[2] - s_) < 4e-3, (site, got)
+    assert sorted(np.nonzero(pr > 0.5)[0] + 1) == sorted(table)
