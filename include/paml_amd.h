@@ -121,6 +121,16 @@ int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *
 int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *gene_rate, const double *MK, const int *pose, int ls,
                       double *lnL);
 
+/* The grid integral of Bayes empirical Bayes (lfunNSsites_M2M8 codeml.c:6482-6580; also the M8 / M2a tables of
+ * get_pclassM_iw_M2M8, 6340) over the class likelihoods fhK of the LAST evaluation (lfundG mode, K <= 32 classes = all the
+ * omega values the grid needs).  Grid point g is a mixture of n_cls classes: proportion pcl[g][c], class iw[g][c] (index into
+ * the K classes); w_class[K] = omega of each class.  For every pattern: pr_last = posterior probability of the last class of
+ * the mixtures, mean_w, sd_w = posterior mean and sd of omega; ln_fx (may be NULL) = log of the marginal likelihood over the
+ * grid (up to the per-pattern scaling constants).  n_grid x n_patt x n_cls terms with a log each — the reference's second
+ * hot loop at scale. */
+int paml_amd_beb_grid(paml_amd_engine *e, int n_grid, int n_cls, const double *pcl, const int *iw, const double *w_class,
+                      double *ln_fx, double *pr_last, double *mean_w, double *sd_w);
+
 /* n_batch evaluations in one launch: the finite-difference loops of the optimiser (gradientB tools.c:6561, the forward /
  * central differences of ming2 tools.c:6595 and of the Hessian, HessianSKT2004 treesub.c:7241) call com.plfun np (or 2np,
  * np^2) times on the same data with one parameter nudged; here those calls become the elements of one batch.  Element b

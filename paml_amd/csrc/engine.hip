@@ -134,6 +134,8 @@ struct paml_amd_engine {
 
    // per-evaluation buffers
    DevBuf<double> d_b_qfactor, d_b_freqK, d_b_rate;
+   DevBuf<double> d_beb_f, d_beb_part, d_beb_g, d_beb_out, d_beb_pcl;      // BEB grid integral
+   DevBuf<int> d_beb_iw;
    DevBuf<double> d_rowmajor, d_pint, d_ptip, d_pcol, d_fhK, d_fscale, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
    DevBuf<double> d_expA, d_expB, d_expSA, d_expSB, d_deriv, d_tt, d_bpartial, d_bout;   // branch-local evaluation
    DevBuf<int> d_label_eff;
@@ -156,7 +158,7 @@ struct paml_amd_engine {
       for (auto ev : ev_used) (void)hipEventDestroy(ev);
       DevBuf<unsigned char> *b1[] = {&d_z, &d_chara_map, &d_is_leaf, &d_ztiles};
       for (auto b : b1) b->release();
-      DevBuf<int> *b2[] = {&d_n_chara, &d_gene_off, &d_label, &d_eigen_of, &d_b_eigen_of};
+      DevBuf<int> *b2[] = {&d_n_chara, &d_gene_off, &d_label, &d_eigen_of, &d_b_eigen_of, &d_beb_iw};
       for (auto b : b2) b->release();
       d_tiles.release();
       d_tiles_full.release();
@@ -167,7 +169,7 @@ struct paml_amd_engine {
       d_eigen.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
+                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
                               &d_expA, &d_expB, &d_expSA, &d_expSB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
    }
@@ -950,6 +952,48 @@ int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *ge
    double fh = 0;
    for (int ir = 0; ir < K; ir++) fh += fk[ir] * b1[ir];
    *lnL = l + log(fh);
+   return 0;
+}
+
+int paml_amd_beb_grid(paml_amd_engine *e, int n_grid, int n_cls, const double *pcl, const int *iw, const double *w_class,
+                      double *ln_fx, double *pr_last, double *mean_w, double *sd_w)
+{
+   if (!e || n_grid < 1 || n_cls < 1 || !pcl || !iw || !w_class || !pr_last || !mean_w || !sd_w)
+      return fail(e, PAML_AMD_EINVAL, "beb_grid: bad arguments");
+   if (e->mode != PAML_AMD_MODE_LFUNDG || e->n_eval == 0 || !e->d_fhK.p)
+      return fail(e, PAML_AMD_EINVAL, "beb_grid: needs a previous evaluation in the lfundG class mode");
+   if (e->tree.n_scale) return fail(e, PAML_AMD_EUNSUPPORTED, "beb_grid: not with scaling nodes yet");
+   if (e->K > BEB_MAXK) return fail(e, PAML_AMD_EUNSUPPORTED, "beb_grid: more than 32 classes");
+   const int K = e->K, np = e->n_patt;
+   for (long i = 0; i < (long)n_grid * n_cls; i++)
+      if (iw[i] < 0 || iw[i] >= K) return fail(e, PAML_AMD_EINVAL, "beb_grid: class index out of range");
+   BebArgs a{};
+   a.n_patt = np; a.K = K; a.n_grid = n_grid; a.n_cls = n_cls;
+   a.patt_per_blk = 4096;
+   a.n_pblk = (np + a.patt_per_blk - 1) / a.patt_per_blk;
+   HIPCHK(e->d_beb_f.ensure((size_t)K * np));
+   HIPCHK(e->d_beb_part.ensure((size_t)n_grid * a.n_pblk));
+   HIPCHK(e->d_beb_g.ensure((size_t)2 * n_grid + K + 1));
+   HIPCHK(e->d_beb_out.ensure((size_t)3 * np));
+   HIPCHK(upload(e->d_beb_pcl, pcl, (size_t)n_grid * n_cls, e->stream));
+   HIPCHK(upload(e->d_beb_iw, iw, (size_t)n_grid * n_cls, e->stream));
+   HIPCHK(hipMemcpyAsync(e->d_beb_g.p + 2 * n_grid + 1, w_class, (size_t)K * sizeof(double), hipMemcpyHostToDevice, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   a.fhK = e->d_fhK.p; a.weights = e->d_weights.p; a.f = e->d_beb_f.p; a.pcl = e->d_beb_pcl.p; a.iw = e->d_beb_iw.p;
+   a.part = e->d_beb_part.p; a.lnfxs = e->d_beb_g.p; a.wg = e->d_beb_g.p + n_grid; a.fx = e->d_beb_g.p + 2 * n_grid;
+   a.w_class = e->d_beb_g.p + 2 * n_grid + 1;
+   a.pr_last = e->d_beb_out.p; a.mean_w = a.pr_last + np; a.sd_w = a.mean_w + np;
+   const int nb = (np + 255) / 256;
+   hipLaunchKernelGGL(beb_scale, dim3(nb), dim3(256), 0, e->stream, a);
+   hipLaunchKernelGGL(beb_lnfx, dim3(a.n_pblk, (n_grid + 63) / 64), dim3(256), 0, e->stream, a);
+   hipLaunchKernelGGL(beb_finish, dim3(1), dim3(256), 0, e->stream, a);
+   hipLaunchKernelGGL(beb_post, dim3(nb), dim3(256), 0, e->stream, a);
+   HIPCHK(hipGetLastError());
+   HIPCHK(hipMemcpyAsync(pr_last, a.pr_last, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipMemcpyAsync(mean_w, a.mean_w, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipMemcpyAsync(sd_w, a.sd_w, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   if (ln_fx) HIPCHK(hipMemcpyAsync(ln_fx, a.fx, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
    return 0;
 }
 

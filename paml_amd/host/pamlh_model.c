@@ -613,7 +613,7 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w)
  *   M2a: (p0, p1) on the 100 triangles of the ternary graph (GetIndexTernary tools.c:4602), w0 ~ U(0,1), w2 ~ U(1,11);
  *   M8:  p0 ~ U(0,1), p, q ~ U(0,2) (class proportions from the beta cdf over ten equal omega bins), ws ~ U(1,11).
  * Stage 1 — f(x_h | w) for the 21 (20) grid omegas at the estimated branch lengths and kappa, scaled by the model's
- * Qfactor_NS — is one evaluation on the device; stage 2, the grid sums, runs here on the host.
+ * Qfactor_NS — is one evaluation on the device; stage 2, the grid sums, is paml_amd_beb_grid on the same device data.
  * Outputs per pattern: pr_pos (posterior probability of the w > 1 class), mean_w, se_w. */
 int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double *se_w)
 {
@@ -621,7 +621,7 @@ int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double 
    const int np = p->npatt, m2a = p->nssites == 2;
    const int ncls = m2a ? 3 : N1 + 1, K = m2a ? 2 * N1 + 1 : 2 * N1, ngrid = N1 * N1 * N1 * N1;
    double rK[2 * N1 + 1], para[4][N1], lnL, fX, *fhK, *pcl, *lnfXs, *Q, kappa, mr;
-   int *iw, i, k, h, g, rc;
+   int *iw, i, k, g, rc;
    if (!(p->seqtype == 1 && (p->nssites == 2 || p->nssites == 8))) return pamlh_fail(p, "BEB is defined for NSsites 2 (M2a) and 8 (M8)");
    if (p->scale) for (i = 0; i < p->nnode; i++) if (p->scale[i]) return pamlh_fail(p, "BEB with scaling nodes is not supported yet");
    if ((rc = pamlh_set_x(p, x, p->np))) return rc;
@@ -651,13 +651,8 @@ int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double 
    rc = paml_amd_set_pi(p->eng, 1, p->pi);
    for (k = 0; k < K && !rc; k++) rc = paml_amd_set_eigen_uvroot(p->eng, k, p->eig[k].U, p->eig[k].V, p->eig[k].Root);
    if (!rc) rc = paml_amd_set_classes(p->eng, p->mode, K, p->freqK, p->rate, 1, p->eigen_of, NULL);
-   if (!rc) rc = paml_amd_eval(p->eng, p->branch, NULL, &lnL, NULL, fhK);
+   if (!rc) rc = paml_amd_eval(p->eng, p->branch, NULL, &lnL, NULL, NULL);      /* fhK stays on the device */
    if (rc) { free(fhK); return pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); }
-   for (h = 0; h < np; h++) {       /* scale every pattern by its largest class value (codeml.c:6297-6305) */
-      double fh = fhK[h];
-      for (k = 1; k < K; k++) if (fhK[(size_t)k * np + h] > fh) fh = fhK[(size_t)k * np + h];
-      for (k = 0; k < K; k++) fhK[(size_t)k * np + h] /= fh;
-   }
    /* class proportions and omega index of every class at every grid point (get_pclassM_iw_M2M8 codeml.c:6340-6383) */
    pcl = (double *)malloc((size_t)ngrid * ncls * sizeof(double));
    iw = (int *)malloc((size_t)ngrid * ncls * sizeof(int));
@@ -681,41 +676,11 @@ int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double 
          iw[g * ncls + N1] = N1 + ip3;
       }
    }
-   /* log f(X | grid point) and the marginal likelihood over the grid (codeml.c:6482-6528), as a log-sum-exp */
-   {
-      double mx = -1e300, s = 0;
-      for (g = 0; g < ngrid; g++) {
-         double l = 0;
-         for (h = 0; h < np; h++) {
-            double fh = 0;
-            for (k = 0; k < ncls; k++) fh += pcl[g * ncls + k] * fhK[(size_t)iw[g * ncls + k] * np + h];
-            if (fh < 1e-300) continue;
-            l += log(fh) * p->w[h];
-         }
-         lnfXs[g] = l;
-         if (l > mx) mx = l;
-      }
-      for (g = 0; g < ngrid; g++) s += exp(lnfXs[g] - mx);
-      fX = log(s) + mx;
-   }
-   /* posterior of the classes, mean and sd of omega for every pattern (codeml.c:6533-6580) */
-   for (h = 0; h < np; h++) {
-      double post_last = 0, m1 = 0, m2 = 0;
-      for (g = 0; g < ngrid; g++) {
-         double fh = 0, wg;
-         for (k = 0; k < ncls; k++) fh += pcl[g * ncls + k] * fhK[(size_t)iw[g * ncls + k] * np + h];
-         if (fh < 1e-300) continue;
-         wg = exp(lnfXs[g] - fX);
-         for (k = 0; k < ncls; k++) {
-            const double t = pcl[g * ncls + k] * fhK[(size_t)iw[g * ncls + k] * np + h] / fh * wg, w = rK[iw[g * ncls + k]];
-            if (k == ncls - 1) post_last += t;
-            m1 += t * w;
-            m2 += t * w * w;
-         }
-      }
-      pr_pos[h] = post_last;
-      mean_w[h] = m1;
-      se_w[h] = m2 - m1 * m1 > 0 ? sqrt(m2 - m1 * m1) : 0;
+   /* stage 2 on the device as well: log f(X | grid point), the marginal likelihood over the grid and the per-pattern
+    * posterior sums (codeml.c:6482-6580) — paml_amd_beb_grid over the fhK the evaluation just left on the device */
+   if ((rc = paml_amd_beb_grid(p->eng, ngrid, ncls, pcl, iw, rK, &fX, pr_pos, mean_w, se_w))) {
+      free(fhK); free(pcl); free(iw); free(lnfXs);
+      return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    }
    free(fhK); free(pcl); free(iw); free(lnfXs);
    return pamlh_set_x(p, x, p->np);      /* back to the model's own classes */

@@ -417,3 +417,33 @@ def test_abi_error_behaviour():
     with pytest.raises(EngineError, match="out of range"):
         eng.eval_batch(np.tile(pb.tree.branch, (2, 1)), eigen_of=np.full((2, 1, 2, 1), 7, dtype=np.int32))
     assert np.isfinite(eng.eval(pb.tree.branch)["lnL"])          # the engine is still usable after the errors
+
+
+def test_beb_grid_matches_numpy_restatement():
+    """paml_amd_beb_grid (the BEB grid integral as device kernels) against a direct numpy restatement of
+    lfunNSsites_M2M8's sums (codeml.c:6482-6580) on a synthetic K-class problem with several thousand patterns; the
+    reference's own BEB tables pin the same code through the C host (test_host_c.py)."""
+    K, ncls, ngrid = 7, 3, 500
+    pb = helpers.random_problem(61, 8, 3000, K=K, seed=31)
+    rng = np.random.default_rng(8)
+    pb.weights = rng.integers(0, 4, pb.n_patt).astype(float)          # some zero-weight patterns too
+    eng = engine_for(pb)
+    out = eng.eval(pb.tree.branch, pb.gene_rate, want_fhk=True)
+    pcl = rng.dirichlet(np.ones(ncls), size=ngrid)
+    iw = rng.integers(0, K, size=(ngrid, ncls)).astype(np.int32)
+    wc = np.linspace(0.1, 4.0, K)
+    got = eng.beb_grid(pcl, iw, wc)
+    m = pb.weights > 0                                            # fx_r leaves fhK = 0 for patterns that do not count
+    f = out["fhK"][:, m] / out["fhK"][:, m].max(axis=0, keepdims=True)                    # [K][patterns with weight]
+    mix = np.einsum("gc,gch->gh", pcl, f[iw])                                             # [ngrid][...]
+    lnfxs = (np.log(mix) * pb.weights[m]).sum(axis=1)
+    fx = np.log(np.exp(lnfxs - lnfxs.max()).sum()) + lnfxs.max()
+    wg = np.exp(lnfxs - fx)
+    t = pcl[:, :, None] * f[iw] / mix[:, None, :] * wg[:, None, None]                    # [ngrid][ncls][n_patt]
+    pr = t[:, -1, :].sum(axis=0)
+    m1 = (t * wc[iw][:, :, None]).sum(axis=(0, 1))
+    m2 = (t * (wc[iw] ** 2)[:, :, None]).sum(axis=(0, 1))
+    assert abs(got["ln_fx"] - fx) <= 1e-9 * abs(fx)
+    assert np.allclose(got["pr_last"][m], pr, rtol=1e-9, atol=1e-12) and np.allclose(got["mean_w"][m], m1, rtol=1e-9, atol=1e-12)
+    assert np.allclose(got["sd_w"][m], np.sqrt(np.maximum(m2 - m1 * m1, 0)), rtol=1e-6, atol=1e-9)
+    assert (got["pr_last"][~m] == 0).all()

@@ -93,6 +93,29 @@ def main():
         out.append(dict(case="C4 NSsites sweep K=%d" % K, kernel=eng.kernel_name, ms_per_eval=dt * 1e3,
                         pattern_classes_per_s=pb.n_patt * K / dt, tflops=flops / (prof["ms_prune"] * 1e-3) / 1e12, lnL=lnl, **prof))
         eng.close()
+    # BEB (M2a) at scale: f(x_h|w) for the grid's 21 omegas (one 21-class evaluation) + the 10^4-point grid integral
+    n1 = 10
+    wgrid = np.concatenate([(np.arange(n1) + 0.5) / n1, [1.0], 1 + 10 * (np.arange(n1) + 0.5) / n1])
+    pb = synth.codon_nssites_problem(base, 2.0, wgrid, np.full(21, 1.0 / 21))
+    eng = engine.engine_for(pb)
+    g = np.arange(n1 ** 4)
+    ip0, ip1, ip2, ip3 = g // 1000, (g // 100) % 10, (g // 10) % 10, g % 10
+    tri = ip0 * n1 + ip1
+    ix = np.floor(np.sqrt(tri)).astype(int)
+    iy = tri - ix * ix
+    p0 = (1 + (iy // 2) * 3 + (iy % 2)) / (3.0 * n1)
+    p1 = (1 + (n1 - 1 - ix) * 3 + (iy % 2)) / (3.0 * n1)
+    pcl = np.stack([p0, p1, 1 - p0 - p1], axis=1)
+    iw = np.stack([ip2, np.full_like(g, n1), n1 + 1 + ip3], axis=1).astype(np.int32)
+    t0 = time.perf_counter()
+    eng.eval(pb.tree.branch)
+    t1 = time.perf_counter()
+    r = eng.beb_grid(pcl, iw, wgrid)
+    t2 = time.perf_counter()
+    out.append(dict(case="BEB M2a on the C4 data (1e6 patterns): 21-class evaluation + 1e4-point grid integral", ms_eval=(t1 - t0) * 1e3,
+                    ms_grid=(t2 - t1) * 1e3, grid_terms=float(n1 ** 4) * pb.n_patt * 3, terms_per_s=float(n1 ** 4) * pb.n_patt * 3 * 2 / (t2 - t1),
+                    ln_fx=r["ln_fx"], sites_pr_gt_95=int((r["pr_last"] > 0.95).sum())))
+    eng.close()
     for o in out:
         print(json.dumps(o))
 
