@@ -155,6 +155,12 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
 int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *t, const double *branch,
                          const double *gene_rate, double *lnL, double *dlnL, double *ddlnL);
 
+/* Marginal ancestral reconstruction (AncestralMarginal treesub.c:6288, PostProbNode 6142): post[n_patt][n_states] =
+ * posterior probabilities of the states at internal node `node` given the data, at the current classes / eigen systems and
+ * the given branch lengths.  The reference re-roots the tree at the node and reuses conP (ReRootTree + updateconP); the
+ * engine walks the tree rooted at the node in one fused pass.  Reversible models only. */
+int paml_amd_node_posterior(paml_amd_engine *e, int node, const double *branch, const double *gene_rate, double *post);
+
 /* Parity / post-processing accessors.
  * get_pmat: the matrix GetPMatBranch (treesub.c:7534) would have produced for the branch above
  *   `node`, row-major P[from*n + to], from the last evaluation.

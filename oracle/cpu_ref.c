@@ -449,6 +449,39 @@ static void msg(const bctx_t *c, int x, int from, int ig, int ir, double *out)
    }
 }
 
+/* Marginal posterior of the states at an internal node (PostProbNode treesub.c:6142-6180 after ReRootTree at the node):
+ * post[h][i] = sum_ir freqK_ir pi_i prod_{neighbours y of node} sum_j P_ij(t_y) M_y[h][j] / (sum over i).  The conditional
+ * at the node is the product of the messages from all its neighbours, computed directly (no scaling: see above). */
+int orc_node_posterior(const orc_problem *pb, int node, double *post)
+{
+   int n = pb->n, np = pb->n_patt, K = pb->K, i, ig, ir;
+   long h;
+   bctx_t c;
+   double *L = (double *)malloc((size_t)np * n * sizeof(double));
+   c.pb = pb;
+   c.father = (int *)malloc(pb->n_nodes * sizeof(int));
+   for (i = 0; i < pb->n_nodes; i++) c.father[i] = -1;
+   for (i = 0; i < pb->n_nodes; i++) {
+      int j;
+      for (j = pb->sons_ptr[i]; j < pb->sons_ptr[i + 1]; j++) c.father[pb->sons[j]] = i;
+   }
+   for (h = 0; h < (long)np * n; h++) post[h] = 0;
+   for (ir = 0; ir < K; ir++)
+      for (ig = 0; ig < pb->n_genes; ig++) {
+         const double *pi = pb->pi + (size_t)(pb->n_pi > 1 ? ig : 0) * n;
+         msg(&c, node, -1, ig, ir, L);
+         for (h = pb->gene_off[ig]; h < pb->gene_off[ig + 1]; h++)
+            for (i = 0; i < n; i++) post[h * n + i] += pb->freqK[ir] * pi[i] * L[h * n + i];
+      }
+   for (h = 0; h < np; h++) {
+      double s = 0;
+      for (i = 0; i < n; i++) s += post[h * n + i];
+      for (i = 0; i < n; i++) post[h * n + i] = s > 0 ? post[h * n + i] / s : 0;
+   }
+   free(L); free(c.father);
+   return 0;
+}
+
 int orc_eval_branch(const orc_problem *pb, int node_b, int n_t, const double *t, double *lnL, double *dlnL, double *ddlnL)
 {
    int n = pb->n, np = pb->n_patt, K = pb->K, i, j, k, it, ig, ir, a;

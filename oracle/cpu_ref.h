@@ -103,6 +103,10 @@ double orc_eval_blocked(const orc_problem *pb, int nthreads, int block);
  * only the exponent range).  Returns 0 on success. */
 int orc_eval_branch(const orc_problem *pb, int node_b, int n_t, const double *t, double *lnL, double *dlnL, double *ddlnL);
 
+/* Marginal posterior probabilities of the states at internal node `node`, post[n_patt][n] (PostProbNode treesub.c:6142 after
+ * re-rooting at the node; reversible models). */
+int orc_node_posterior(const orc_problem *pb, int node, double *post);
+
 /* Number of (branch, class) P(t) constructions performed by the last orc_eval (mirrors NPMatUVRoot, tools.c:88). */
 long orc_last_npmat(void);
 

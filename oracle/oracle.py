@@ -50,6 +50,7 @@ def lib():
         _LIB.orc_eval.argtypes = [C.POINTER(_Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _LIB.orc_pmat_branch.argtypes = [C.POINTER(_Problem), C.c_int, C.c_int, C.c_int, C.c_void_p]
         _LIB.orc_last_npmat.restype = C.c_long
+        _LIB.orc_node_posterior.argtypes = [C.POINTER(_Problem), C.c_int, C.c_void_p]
         _LIB.orc_eval_adg.restype = C.c_double
         _LIB.orc_eval_adg.argtypes = [C.POINTER(_Problem), C.c_void_p, C.c_void_p, C.c_int]
         _LIB.orc_eval_blocked.restype = C.c_double
@@ -117,6 +118,16 @@ def evaluate(pb, want_lnf=True, want_fhk=False, want_partials=False, nthreads=1)
     scalef = np.zeros((K, n_scale, np_)) if (want_partials and n_scale) else None
     lnL = L.orc_eval(C.byref(pk.s), _ptr(lnf), _ptr(fhk), _ptr(part), _ptr(scalef), int(nthreads))
     return dict(lnL=lnL, lnf=lnf, fhK=fhk, partials=part, scalef=scalef, npmat=L.orc_last_npmat())
+
+
+def node_posterior(pb, node):
+    """Marginal posterior probabilities of the states at an internal node, [n_patt][n]."""
+    pk = _Packed(pb)
+    post = np.zeros((pb.n_patt, pb.n))
+    rc = lib().orc_node_posterior(C.byref(pk.s), int(node), _ptr(post))
+    if rc != 0:
+        raise RuntimeError("orc_node_posterior failed (%d)" % rc)
+    return post
 
 
 def evaluate_adg(pb, MK, pose):

@@ -609,6 +609,80 @@ int run_prune_full(paml_amd_engine *e, const Program &prog, double *export_buf, 
    return 0;
 }
 
+// Branch-local evaluation and node posteriors look at the tree from another node: build the tree rooted at `new_root`
+// (along the path new_root -> old root every node loses the son it came from and gains its father; the edge data —
+// length, label — of node p moves to its father, now a son of p; cut_son >= 0: that son of new_root and its subtree are
+// left out), send the re-oriented branch lengths / labels, and compute P(t) for every edge with one batched launch.
+// What ReRootTree (treespace.c:236) + updateconP (treesub.c:7982) do on the host in the reference.
+int rerooted_pmat(paml_amd_engine *e, int new_root, int cut_son, const double *branch, const double *gene_rate, TreeDesc *out)
+{
+   const TreeDesc &T = e->tree;
+   const int nn = T.n_nodes, n = e->n, K = e->K, G = e->n_genes, psets = G * K;
+   std::vector<int> father(nn, -1);
+   for (int i = 0; i < nn; i++)
+      for (int j = T.sons_ptr[i]; j < T.sons_ptr[i + 1]; j++) father[T.sons[j]] = i;
+   std::vector<std::vector<int>> sons(nn);
+   for (int i = 0; i < nn; i++) sons[i].assign(T.sons.begin() + T.sons_ptr[i], T.sons.begin() + T.sons_ptr[i + 1]);
+   std::vector<double> br(branch, branch + nn);
+   std::vector<int> lab(T.label);
+   for (int p = new_root, prev = cut_son; p >= 0; prev = p, p = father[p]) {
+      auto &s = sons[p];
+      if (prev >= 0) s.erase(std::find(s.begin(), s.end(), prev));
+      if (father[p] >= 0) {
+         s.push_back(father[p]);
+         br[father[p]] = branch[p];
+         lab[father[p]] = T.label[p];
+      }
+   }
+   TreeDesc t;
+   t.n_tips = T.n_tips; t.n_nodes = nn; t.root = new_root;
+   t.sons_ptr.assign(nn + 1, 0);
+   for (int i = 0; i < nn; i++) t.sons_ptr[i + 1] = t.sons_ptr[i] + (int)sons[i].size();
+   for (int i = 0; i < nn; i++) t.sons.insert(t.sons.end(), sons[i].begin(), sons[i].end());
+   t.label = lab;
+   // the nodes SetNodeScale marked keep rescaling their partial, whichever subtree it now stands for; the factors
+   // travel with the exported partials
+   t.scale_node.assign(nn, 0);
+   t.scale_slot.assign(nn, -1);
+   if (T.n_scale > 0)
+      for (int i = 0; i < nn; i++)
+         if (T.scale_node[i] && !t.is_leaf(i)) { t.scale_node[i] = 1; t.scale_slot[i] = t.n_scale++; }
+   *out = t;
+
+   std::vector<double> gr(G, 1.0);
+   if (gene_rate) gr.assign(gene_rate, gene_rate + G);
+   HIPCHK(upload(e->d_branch, br.data(), br.size(), e->stream));
+   HIPCHK(upload(e->d_gene_rate, gr.data(), gr.size(), e->stream));
+   HIPCHK(upload(e->d_label_eff, lab.data(), lab.size(), e->stream));
+   if (e->eigen_dirty) {
+      std::vector<EigenDev> tab(e->eigen.size());
+      for (size_t i = 0; i < e->eigen.size(); i++) {
+         const EigenHost &h = e->eigen[i];
+         tab[i] = EigenDev{h.kind, h.nR, h.kappa, h.U.p, h.V.p, h.Root.p, h.Cijk.p};
+      }
+      HIPCHK(upload(e->d_eigen, tab.data(), tab.size(), e->stream));
+      e->eigen_dirty = false;
+   }
+   HIPCHK(hipStreamSynchronize(e->stream));
+   HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
+   if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
+   HIPCHK(e->d_ptip.ensure((size_t)psets * nn * tip_words(e)));
+   HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
+   PmatArgs pa{};
+   pa.n = n; pa.n_nodes = nn; pa.root = new_root; pa.K = K; pa.n_genes = G; pa.n_labels = e->n_labels;
+   pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : 0;
+   pa.label = e->d_label_eff.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
+   pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
+   pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
+   pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
+   pa.B = 1;
+   hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), e->stream, pa);
+   e->n_pmat += (long)psets * (nn - 1);
+   e->prog_valid = false;      // d_branch / P buffers now hold the re-rooted edge data: the next eval rebuilds
+   e->partials_valid = false;
+   return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1030,81 +1104,33 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    for (int i = 0; i < nn; i++)
       for (int j = T.sons_ptr[i]; j < T.sons_ptr[i + 1]; j++) father[T.sons[j]] = i;
    const int a = father[node_b];
-
-   // the tree as seen from a with b's subtree cut off: along the path a -> old root every node loses the son it
-   // came from and gains its father; the edge data (length, label) of node p moves to its father (new son of p)
-   std::vector<std::vector<int>> sons(nn);
-   for (int i = 0; i < nn; i++) sons[i].assign(T.sons.begin() + T.sons_ptr[i], T.sons.begin() + T.sons_ptr[i + 1]);
-   std::vector<double> br(branch, branch + nn);
-   std::vector<int> lab(T.label);
-   for (int p = a, prev = node_b; p >= 0; prev = p, p = father[p]) {
-      auto &s = sons[p];
-      s.erase(std::find(s.begin(), s.end(), prev));
-      if (father[p] >= 0) {
-         s.push_back(father[p]);
-         br[father[p]] = branch[p];
-         lab[father[p]] = T.label[p];
-      }
+   TreeDesc treeA;
+   {
+      int r0 = rerooted_pmat(e, a, node_b, branch, gene_rate, &treeA);
+      if (r0) return r0;
    }
-   auto make_tree = [&](int root, const std::vector<std::vector<int>> &sv) {
-      TreeDesc t;
-      t.n_tips = T.n_tips; t.n_nodes = nn; t.root = root;
-      t.sons_ptr.assign(nn + 1, 0);
-      for (int i = 0; i < nn; i++) t.sons_ptr[i + 1] = t.sons_ptr[i] + (int)sv[i].size();
-      for (int i = 0; i < nn; i++) t.sons.insert(t.sons.end(), sv[i].begin(), sv[i].end());
-      t.label = lab;
-      // the nodes SetNodeScale marked keep rescaling their partial, whichever subtree it now stands for; the factors
-      // travel with the exported partials
-      t.scale_node.assign(nn, 0);
-      t.scale_slot.assign(nn, -1);
-      if (T.n_scale > 0)
-         for (int i = 0; i < nn; i++)
-            if (T.scale_node[i] && !t.is_leaf(i)) { t.scale_node[i] = 1; t.scale_slot[i] = t.n_scale++; }
-      return t;
-   };
    auto export_program = [&](const TreeDesc &t) {
       Program p = build_program(t, false, nullptr);
       for (Op &o : p.ops)
          if (o.code == OP_ROOT) o.code = OP_EXPORT;
       return p;
    };
-   const Program progA = export_program(make_tree(a, sons));
-   const bool b_tip = T.is_leaf(node_b);
-
-   // P(t) for every edge in its new orientation (one batched launch, root = a)
-   {
-      std::vector<double> gr(G, 1.0);
-      if (gene_rate) gr.assign(gene_rate, gene_rate + G);
-      HIPCHK(upload(e->d_branch, br.data(), br.size(), e->stream));
-      HIPCHK(upload(e->d_gene_rate, gr.data(), gr.size(), e->stream));
-      HIPCHK(upload(e->d_label_eff, lab.data(), lab.size(), e->stream));
-      std::vector<double> tt(t, t + n_t);
-      HIPCHK(upload(e->d_tt, tt.data(), tt.size(), e->stream));
-      if (e->eigen_dirty) {
-         std::vector<EigenDev> tab(e->eigen.size());
-         for (size_t i = 0; i < e->eigen.size(); i++) {
-            const EigenHost &h = e->eigen[i];
-            tab[i] = EigenDev{h.kind, h.nR, h.kappa, h.U.p, h.V.p, h.Root.p, h.Cijk.p};
-         }
-         HIPCHK(upload(e->d_eigen, tab.data(), tab.size(), e->stream));
-         e->eigen_dirty = false;
+   auto make_tree_b = [&]() {      // b's own subtree, rooted at b, in the original orientation
+      TreeDesc t = T;
+      t.root = node_b;
+      t.n_scale = 0;
+      t.scale_slot.assign(nn, -1);
+      for (int i = 0; i < nn; i++) {
+         if (!T.scale_node.empty() && T.scale_node[i] && !t.is_leaf(i)) t.scale_slot[i] = t.n_scale++;
+         else if (!t.scale_node.empty()) t.scale_node[i] = 0;
       }
-      HIPCHK(hipStreamSynchronize(e->stream));
-   }
-   HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
-   if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
-   HIPCHK(e->d_ptip.ensure((size_t)psets * nn * tip_words(e)));
-   HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
-   PmatArgs pa{};
-   pa.n = n; pa.n_nodes = nn; pa.root = a; pa.K = K; pa.n_genes = G; pa.n_labels = e->n_labels;
-   pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : 0;
-   pa.label = e->d_label_eff.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
-   pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
-   pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
-   pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
-   pa.B = 1;
-   hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), e->stream, pa);
-   e->n_pmat += (long)psets * (nn - 1);
+      return t;
+   };
+   const Program progA = export_program(treeA);
+   const bool b_tip = T.is_leaf(node_b);
+   std::vector<double> tt(t, t + n_t);
+   HIPCHK(upload(e->d_tt, tt.data(), tt.size(), e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
 
    // the two partials across the branch
    const size_t exp_words = (size_t)K * e->n_patt * n;
@@ -1114,9 +1140,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    int r = run_prune_full(e, progA, e->d_expA.p, scaled ? e->d_expSA.p : nullptr);
    if (r) return r;
    if (!b_tip) {
-      std::vector<std::vector<int>> s0(nn);
-      for (int i = 0; i < nn; i++) s0[i].assign(T.sons.begin() + T.sons_ptr[i], T.sons.begin() + T.sons_ptr[i + 1]);
-      const Program progB = export_program(make_tree(node_b, s0));
+      const Program progB = export_program(make_tree_b());
       HIPCHK(e->d_expB.ensure(exp_words));
       if (scaled) HIPCHK(e->d_expSB.ensure((size_t)K * e->n_patt));
       r = run_prune_full(e, progB, e->d_expB.p, scaled ? e->d_expSB.p : nullptr);
@@ -1153,6 +1177,40 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    for (int i = 0; i < n_t; i++) { lnL[i] = out[3 * i]; dlnL[i] = out[3 * i + 1]; ddlnL[i] = out[3 * i + 2]; }
    e->prog_valid = false;      // d_branch / P buffers now hold the re-rooted edge data: the next eval rebuilds
    e->partials_valid = false;
+   return 0;
+}
+
+int paml_amd_node_posterior(paml_amd_engine *e, int node, const double *branch, const double *gene_rate, double *post)
+{
+   if (!e || !branch || !post) return fail(e, PAML_AMD_EINVAL, "node_posterior: null argument");
+   if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes) || e->eigen.empty())
+      return fail(e, PAML_AMD_EINVAL, "node_posterior before set_tips/set_tree/set_pi/set_classes/set_eigen");
+   const TreeDesc &T = e->tree;
+   const int nn = T.n_nodes, n = e->n, K = e->K;
+   if (node < 0 || node >= nn || T.is_leaf(node)) return fail(e, PAML_AMD_EINVAL, "node_posterior: not an internal node");
+   for (size_t i = 0; i < e->eigen.size(); i++)
+      if (e->eigen[i].kind == PAML_AMD_EIGEN_QMAT)
+         return fail(e, PAML_AMD_EUNSUPPORTED, "node_posterior: moving the root needs a reversible model");
+   TreeDesc tr;
+   int r = rerooted_pmat(e, node, -1, branch, gene_rate, &tr);
+   if (r) return r;
+   Program prog = build_program(tr, false, nullptr);
+   for (Op &o : prog.ops)
+      if (o.code == OP_ROOT) o.code = OP_EXPORT;
+   const bool scaled = T.n_scale > 0;
+   HIPCHK(e->d_expA.ensure((size_t)K * e->n_patt * n));
+   if (scaled) HIPCHK(e->d_expSA.ensure((size_t)K * e->n_patt));
+   r = run_prune_full(e, prog, e->d_expA.p, scaled ? e->d_expSA.p : nullptr);
+   if (r) return r;
+   HIPCHK(e->d_expB.ensure((size_t)e->n_patt * n));
+   PostArgs pa{};
+   pa.n = n; pa.K = K; pa.n_genes = e->n_genes; pa.n_patt = e->n_patt; pa.n_pi = e->n_pi;
+   pa.L = e->d_expA.p; pa.S = scaled ? e->d_expSA.p : nullptr; pa.pi = e->d_pi_plain.p; pa.freqK = e->d_freqK.p;
+   pa.gene_off = e->d_gene_off.p; pa.post = e->d_expB.p;
+   hipLaunchKernelGGL(posterior_kernel, dim3((e->n_patt + 255) / 256), dim3(256), 0, e->stream, pa);
+   HIPCHK(hipGetLastError());
+   HIPCHK(hipMemcpyAsync(post, e->d_expB.p, (size_t)e->n_patt * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
    return 0;
 }
 

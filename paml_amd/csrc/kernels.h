@@ -1101,6 +1101,45 @@ __global__ __launch_bounds__(256) void branch_reduce_kernel(const double *partia
 }
 
 // ------------------------------------------------------------------------------------------------
+// Marginal posterior of the states at a node (PostProbNode treesub.c:6142, AncestralMarginal 6288): with the tree rooted
+// at the node, L[k][h][i] = exported partial of class k; post[h][i] = sum_k freqK_k pi_i L[k][h][i] e^{S_k} / sum_i(...).
+// ------------------------------------------------------------------------------------------------
+struct PostArgs {
+   int n, K, n_genes, n_patt, n_pi;
+   const double *L, *S;        // [K][n_patt][n], summed scale factors [K][n_patt] or null
+   const double *pi, *freqK;
+   const int *gene_off;
+   double *post;               // [n_patt][n]
+};
+
+__global__ __launch_bounds__(256) void posterior_kernel(PostArgs a)
+{
+   const int h = blockIdx.x * 256 + threadIdx.x, n = a.n;
+   if (h >= a.n_patt) return;
+   int gene = 0;
+   while (gene + 1 < a.n_genes && h >= a.gene_off[gene + 1]) gene++;
+   const double *pi = a.pi + (long)(a.n_pi > 1 ? gene : 0) * n;
+   double smax = 0;
+   if (a.S) {
+      smax = -1e300;
+      for (int k = 0; k < a.K; k++) smax = fmax(smax, a.S[(long)k * a.n_patt + h]);
+   }
+   double tot = 0;
+   for (int i = 0; i < n; i++) {
+      double v = 0;
+      for (int k = 0; k < a.K; k++) {
+         const double cs = a.S ? exp(a.S[(long)k * a.n_patt + h] - smax) : 1.0;
+         v += a.freqK[k] * cs * a.L[((long)k * a.n_patt + h) * n + i];
+      }
+      v *= pi[i];
+      a.post[(long)h * n + i] = v;
+      tot += v;
+   }
+   const double inv = tot > 0 ? 1.0 / tot : 0.0;
+   for (int i = 0; i < n; i++) a.post[(long)h * n + i] *= inv;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bayes empirical Bayes grid integral (lfunNSsites_M2M8 codeml.c:6482-6580) over the class likelihoods of the last
 // evaluation: n_grid parameter points, each a mixture of n_cls classes (proportion pcl[g][c], class index iw[g][c] into
 // the K evaluated classes).  n_grid x n_patt x n_cls terms with a log each — 10^11 at 10^6 patterns.

@@ -25,7 +25,7 @@ EXPORTS = [
     "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
-    "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
+    "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
@@ -264,6 +264,15 @@ class Engine:
         l, dl, ddl = np.zeros(len(tt)), np.zeros(len(tt)), np.zeros(len(tt))
         self._chk(self._L.paml_amd_eval_branch(self._h, int(node_b), len(tt), _p(tt), _p(b), _p(g), _p(l), _p(dl), _p(ddl)))
         return l, dl, ddl
+
+    def node_posterior(self, node, branch, gene_rate=None):
+        """Posterior probabilities of the states at an internal node, [n_patt][n] (paml_amd_node_posterior)."""
+        b = np.ascontiguousarray(branch, dtype=np.float64)
+        g = None if gene_rate is None else np.ascontiguousarray(gene_rate, dtype=np.float64)
+        post = np.zeros((self.n_patt, self.n))
+        self._L.paml_amd_node_posterior.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self._L.paml_amd_node_posterior(self._h, int(node), _p(b), _p(g), _p(post)))
+        return post
 
     def get_pmat(self, gene, iclass, node):
         P = np.zeros((self.n, self.n))

@@ -68,7 +68,11 @@ def run_ref(prog, ctl, files, x=None, timeout=3600):
         main = "mlc" if prog == "codeml" else "mlb"
         with open(os.path.join(d, main)) as f:
             mtxt = f.read()
-        return dict(lnL=lnL, stdout=out, lnf=lnf_lines, main=mtxt,
+        rst = ""
+        if os.path.exists(os.path.join(d, "rst")):
+            with open(os.path.join(d, "rst")) as f:
+                rst = f.read()
+        return dict(lnL=lnL, stdout=out, lnf=lnf_lines, main=mtxt, rst=rst,
                     counters=[int(g) for g in cnt.groups()] if cnt else None,
                     qfactor_ns=float(qf.group(1)) if qf else None)
     finally:
@@ -214,6 +218,29 @@ def case_brown():
                                                names=["Human", "Chimpanzee", "Gorilla", "Orangutan", "Gibbon"]))
 
 
+def case_brown_anc():
+    """Marginal ancestral reconstruction (RateAncestor = 1) at the same fixed parameters: the reference's rst file lists,
+    for every site, the most probable state and its posterior probability at each internal node."""
+    x = [float(v) for v in "0.053057 0.017471 0.041370 0.053761 0.057580 0.100159 0.138990 9.389630".split()]
+    ctl = dict(BASEML_BASE, seqfile="brown.nuc", treefile="brown.trees", outfile="mlb", model=4, ncatG=1, RateAncestor=1)
+    res = run_ref("baseml", ctl, {"brown.nuc": EX + "/brown.nuc", "brown.trees": EX + "/brown.trees"}, x=x)
+    rows = {}
+    blk = res["rst"].split("Prob of best state at each node, listed by site")[1].split("Summary of changes")[0]
+    for ln in blk.splitlines():
+        m = re.match(r"\s*(\d+)\s+(\d+)\s+([A-Z?-]+):\s+(.*)$", ln)
+        if not m:
+            continue
+        best = re.findall(r"([A-Z])\(([0-9.]+)\)", m.group(4))
+        rows[m.group(3)] = dict(count=int(m.group(2)), best="".join(b for b, _ in best), prob=[float(v) for _, v in best])
+    nodes = [int(v) for v in re.findall(r"node #(\d+)", res["rst"])]
+    g = dict(name="brown_hky85_anc", program="baseml", x=x, lnL=res["lnL"], nodes_1based=sorted(set(nodes)), patterns=rows,
+             note="nodes in the order of the reference's table (node ns+1 = root first)")
+    path = os.path.join(HERE, "brown_hky85_anc.json")
+    with open(path, "w") as f:
+        json.dump(g, f, separators=(",", ":"))
+    print("%-22s lnL %.6f  %d distinct patterns, nodes %s -> %s" % (g["name"], g["lnL"], len(rows), g["nodes_1based"], os.path.basename(path)))
+
+
 def case_stewart():
     x = [float(v) for v in "0.000004 0.019085 0.083331 0.034683 0.067995 0.339072 0.104868 0.276662 0.861606 1.064411".split()]
     ctl = dict(CODEML_BASE, seqfile="stewart.aa", treefile="stewart.trees", outfile="mlc", seqtype=2, model=2,
@@ -249,7 +276,7 @@ CASES = {
     "hiv_m0": lambda: case_hiv("m0"), "hiv_m1a": lambda: case_hiv("m1a"), "hiv_m2a": lambda: case_hiv("m2a"),
     "hiv_m7": lambda: case_hiv("m7"), "hiv_m8": lambda: case_hiv("m8"),
     "stewart_lg_g4": case_stewart, "mhc_m0_scaled": case_mhc,
-    "syn_codon_m0": case_syn_codon, "syn_nuc_gtr_g4": case_syn_nuc, "brown_hky85": case_brown,
+    "syn_codon_m0": case_syn_codon, "syn_nuc_gtr_g4": case_syn_nuc, "brown_hky85": case_brown, "brown_hky85_anc": case_brown_anc,
     # BASELINE configs[3] / configs[1] at full size (reference: ~2 min and 6.8 GB / ~2 s): lnL + strided log f_h sample
     "syn_codon_m0_full": lambda: case_syn_codon(1_000_000, "syn_codon_m0_full", sample=997),
     "syn_nuc_gtr_g4_full": lambda: case_syn_nuc(100_000, "syn_nuc_gtr_g4_full", sample=97),

@@ -447,3 +447,31 @@ def test_beb_grid_matches_numpy_restatement():
     assert np.allclose(got["pr_last"][m], pr, rtol=1e-9, atol=1e-12) and np.allclose(got["mean_w"][m], m1, rtol=1e-9, atol=1e-12)
     assert np.allclose(got["sd_w"][m], np.sqrt(np.maximum(m2 - m1 * m1, 0)), rtol=1e-6, atol=1e-9)
     assert (got["pr_last"][~m] == 0).all()
+
+
+@pytest.mark.parametrize("n,K,amb,every", [(4, 1, False, None), (4, 3, True, 3), (20, 2, False, None), (61, 2, True, None)])
+def test_node_posterior_matches_oracle(n, K, amb, every):
+    """paml_amd_node_posterior (marginal ancestral reconstruction: one fused walk of the tree rooted at the node) against the
+    oracle's message-passing restatement, for the root, a deep node and a node next to tips; evaluation still fine after."""
+    pb = helpers.random_problem(n, 9, 140, K=K, seed=51 + n, ambiguity=amb, scale_every=every)
+    eng = engine_for(pb)
+    base = eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]
+    for node in (pb.tree.root, pb.tree.n_tips + 1, pb.tree.n_nodes - 1):
+        got = eng.node_posterior(node, pb.tree.branch, pb.gene_rate)
+        ref = oracle.node_posterior(pb, node)
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-13), (node, float(np.max(np.abs(got - ref))))
+        assert np.allclose(got.sum(axis=1), 1)
+    assert eng.eval(pb.tree.branch, pb.gene_rate)["lnL"] == base
+
+
+def test_node_posterior_reproduces_the_reference_reconstruction():
+    """... and against the reference's own marginal reconstruction of brown.nuc (tests/golden/brown_hky85_anc.json)."""
+    from test_oracle_golden import _brown_anc
+    g, pb, raw = _brown_anc()
+    eng = engine_for(pb)
+    for k, node in enumerate(g["nodes_1based"]):
+        post = eng.node_posterior(node - 1, pb.tree.branch)
+        for h, patt in enumerate(raw):
+            row = g["patterns"][patt]
+            i = int(np.argmax(post[h]))
+            assert "TCAG"[i] == row["best"][k] and abs(post[h, i] - row["prob"][k]) < 6e-4

@@ -122,3 +122,27 @@ def test_oracle_unrest_matexp_matches_scipy():
         P = oracle.pmat_branch(pb, 0, 0, node)
         assert np.allclose(P, expm(Q * pb.tree.branch[node] * pb.rate[0] * pb.gene_rate[0]), rtol=0, atol=1e-9)
     assert np.isfinite(oracle.evaluate(pb)["lnL"])
+
+
+def _brown_anc():
+    g = helpers.load_golden("brown_hky85_anc")
+    gb = helpers.load_golden("brown_hky85")
+    pb = helpers.problem_from_golden(gb)
+    raw = ["".join("TCAG"[c] for c in pb.z[:, h]) for h in range(pb.n_patt)]      # baseml's state order T, C, A, G
+    return g, pb, raw
+
+
+def test_oracle_node_posterior_matches_reference_reconstruction():
+    """Marginal ancestral reconstruction: for every site pattern of brown.nuc the reference (RateAncestor = 1, same fixed
+    parameters as the lnL golden) lists the most probable base and its posterior probability at internal nodes 6, 7, 8."""
+    g, pb, raw = _brown_anc()
+    posts = [oracle.node_posterior(pb, node - 1) for node in g["nodes_1based"]]
+    seen = 0
+    for h, patt in enumerate(raw):
+        row = g["patterns"][patt]
+        for post, best, prob in zip(posts, row["best"], row["prob"]):
+            i = int(np.argmax(post[h]))
+            assert "TCAG"[i] == best and abs(post[h, i] - prob) < 6e-4, (patt, post[h], best, prob)
+        seen += 1
+    assert seen == len(g["patterns"]) == pb.n_patt
+    assert np.allclose(posts[0].sum(axis=1), 1)
