@@ -442,22 +442,6 @@ __device__ __forceinline__ double jit_scale(v4d (&y)[4], int q, int n)   // Node
    return log(mx);
 }
 
-__device__ __forceinline__ void jit_root(const PruneArgs &a, const v4d (&x)[4], double lnscale, int gene, int iclass, int q, int h,
-                                         bool valid)
-{
-   const double *pq = a.pi + (long)(a.n_pi > 1 ? gene : 0) * 64 + q * 16;
-   double f = 0;
-#pragma unroll
-   for (int m = 0; m < 16; m++) f = fma(pq[m], x[m >> 2][m & 3], f);
-   f += __shfl_xor(f, 16);
-   f += __shfl_xor(f, 32);
-   if (q == 0 && valid) {
-      double out = 0;
-      if (a.weights[h] > 0) out = root_value(a, f, lnscale);
-      a.fhK[(long)iclass * a.n_patt + h] = out;
-   }
-}
-
 // Root stage with pi and the weight flag already in LDS (no vector-memory loads whose wait would drain the ring's DMAs).
 __device__ __forceinline__ void jit_root_lds(const PruneArgs &a, const v4d (&x)[4], double lnscale, const double *spi, int flag, int iclass,
                                              int q, int h, bool valid)
@@ -476,64 +460,8 @@ __device__ __forceinline__ void jit_root_lds(const PruneArgs &a, const v4d (&x)[
    }
 }
 
-// Skeleton of a specialised kernel: 8 waves x 16 patterns per tile, ring of four 32 KB operand buffers, tip codes in
-// LDS.  The kernel is persistent: each workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and issues the
-// next tile's first operand blocks and tip-code loads before it finishes the current tile's root stage.
-#define JIT_PROLOGUE(NTIPS)                                                                                      \
-   __shared__ __attribute__((aligned(16))) double ring[4 * 4096];                                               \
-   __shared__ unsigned char sZ[(NTIPS)*128];                                                                     \
-   const int tid = threadIdx.x, lane = tid & 63;                                                                \
-   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                   \
-   const int q = lane >> 4, hl = lane & 15;                                                                     \
-   const int hw = wave * 16 + hl;                                                                               \
-   const int n = a.n;                                                                                           \
-   const int total_work = a.n_tiles * a.K;                                                                      \
-   int work = blockIdx.x;                                                                                       \
-   int tile, iclass, gene, h0, hend, h;                                                                         \
-   int n_gene = 0, n_iclass = 0, n_h0 = 0, n_hend = 1;   /* the tile this workgroup handles next */             \
-   bool valid, has_next = false;                                                                                \
-   const double *Pint, *Ptip, *nPint = nullptr, *nPtip = nullptr;                                               \
-   double lnscale = 0;                                                                                          \
-   unsigned char zr[((NTIPS)*128 + 511) / 512];                                                                  \
-   (void)hl; (void)n; (void)lnscale;                                                                            \
-   if (work >= total_work) return;
-/* look up the tile `work` as the NEXT tile (variables n_*), without touching the current one */
-#define JIT_NEXT_SET()                                                                                           \
-   has_next = work < total_work;                                                                                \
-   if (has_next) {                                                                                              \
-      tile = work % a.n_tiles; n_iclass = work / a.n_tiles;                                                     \
-      n_gene = as_const(a.tiles)[tile].x; n_h0 = as_const(a.tiles)[tile].y;                                     \
-      n_hend = as_const(a.gene_off)[n_gene + 1];                                                                \
-      nPint = a.pint + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 4096;                                      \
-      nPtip = a.ptip + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 4096;                                      \
-   }   /* without a next tile n_h0 / n_hend keep their last (valid) values: JIT_ZLOAD stays in bounds */
-/* make the next tile the current one */
-#define JIT_ADVANCE()                                                                                            \
-   iclass = n_iclass; gene = n_gene; h0 = n_h0; hend = n_hend; Pint = nPint; Ptip = nPtip;                      \
-   h = h0 + hw; valid = h < hend; lnscale = 0;
-#define JIT_ZLOAD(NTIPS)                                                                                         \
-   _Pragma("unroll") for (int kz = 0; kz < ((NTIPS)*128 + 511) / 512; kz++) {                                    \
-      const int idx = tid + kz * 512, tip = idx >> 7, hh = idx & 127;                                           \
-      const int hx = n_h0 + hh < n_hend ? n_h0 + hh : n_hend - 1;                                               \
-      zr[kz] = tip < (NTIPS) ? a.z[(long)tip * a.z_stride + hx] : (unsigned char)0;                             \
-   }
-#define JIT_ISSUE_NP(J, NODE) stage_p<8>(nPint + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)
-#define JIT_ISSUE_NT(J, NODE) stage_p<8>(nPtip + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)
-#define JIT_ZSTORE(NTIPS)                                                                                        \
-   _Pragma("unroll") for (int kz = 0; kz < ((NTIPS)*128 + 511) / 512; kz++) {                                    \
-      const int idx = tid + kz * 512;                                                                           \
-      if (idx < (NTIPS)*128) sZ[idx] = zr[kz];                                                                   \
-   }                                                                                                            \
-   __syncthreads();
-#define JIT_ISSUE_P(J, NODE) stage_p<8>(Pint + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)
-#define JIT_ISSUE_T(J, NODE) stage_p<8>(Ptip + (long)(NODE)*4096, ring + ((J)&3) * 4096, wave, lane)
-/* one of the four 1 KiB-per-wave pieces (C = 0..3) of block J */
-#define JIT_PIECE(SRC, J, C)                                                                                         \
-   dma16(make_rsrc((SRC), 32768), (const char *)(ring + ((J)&3) * 4096) + ((C)*8 + wave) * 1024, lane * 16, ((C)*8 + wave) * 1024)
-#define JIT_PIECE_P(J, NODE, C) JIT_PIECE(Pint + (long)(NODE)*4096, J, C)
-#define JIT_PIECE_T(J, NODE, C) JIT_PIECE(Ptip + (long)(NODE)*4096, J, C)
-#define JIT_BUF(J) (ring + ((J)&3) * 4096)
-#define JIT_CODE(TIP) ((int)sZ[(TIP)*128 + hw])
+// Explicit counted wait for the LDS-DMA stream (loads retire in issue order): at most N vector-memory operations of this
+// wave may still be in flight afterwards.
 #define JIT_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // ---- building blocks of the specialised one-pattern-per-lane kernels (4 / 5 / 20 states; jit.h: jit_generate_valu) ----
