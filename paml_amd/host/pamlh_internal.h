@@ -73,4 +73,6 @@ int pamlh_read_tree(pamlh *p);
 int pamlh_fail(pamlh *p, const char *fmt, ...);
 int pamlh_engine_ready(pamlh *p);
 int pamlh_model_feasible(const pamlh *p);
+pamlh *pamlh_state_clone(const pamlh *p);
+void pamlh_state_free(pamlh *q);
 #endif

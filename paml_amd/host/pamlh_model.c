@@ -530,6 +530,34 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
    return 0;
 }
 
+/* A private copy of the model state (what pamlh_set_x writes: branch lengths, pi, class tables, eigen systems) that shares the
+ * data, tree and options read-only with `p`: concurrent pamlh_set_x calls on different copies do not interfere. */
+pamlh *pamlh_state_clone(const pamlh *p)
+{
+   pamlh *q = (pamlh *)malloc(sizeof(pamlh));
+   int i;
+   if (!q) return NULL;
+   *q = *p;
+   q->eng = NULL;
+   q->err[0] = 0;
+   q->branch = (double *)calloc(p->nnode, sizeof(double));
+   q->pi = (double *)calloc(64, sizeof(double));
+   q->freqK = (double *)calloc(64, sizeof(double));
+   q->rate = (double *)calloc(64, sizeof(double));
+   q->eigen_of = (int *)calloc(64, sizeof(int));
+   for (i = 0; i < 64; i++) q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = NULL;
+   return q;
+}
+
+void pamlh_state_free(pamlh *q)
+{
+   int i;
+   if (!q) return;
+   for (i = 0; i < 64; i++) { free(q->eig[i].U); free(q->eig[i].V); free(q->eig[i].Root); free(q->eig[i].Cijk); }
+   free(q->branch); free(q->pi); free(q->freqK); free(q->rate); free(q->eigen_of);
+   free(q);
+}
+
 /* the engine for this data set and tree (created on first use) */
 int pamlh_engine_ready(pamlh *p)
 {

@@ -35,36 +35,51 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
 
 int pamlh_eval_batch_gpu(pamlh *p, int nb, const double *xs, double *lnL) { return eval_batch_lnf(p, nb, xs, lnL, NULL); }
 
-/* ... with the per-pattern log f_h of every vector, lnf[nb][npatt], when lnf is not NULL */
+/* ... with the per-pattern log f_h of every vector, lnf[nb][npatt], when lnf is not NULL.
+ * The model set-ups of the distinct substitution-parameter vectors (eigen decompositions: the host's expensive part, one per
+ * site class) are independent of each other and run on all host cores, each on its own copy of the model state. */
 static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, double *lnf)
 {
    const int np = p->np, nt = p->ntime, nm = np - nt, nn = p->nnode;
-   int *rep_of = (int *)malloc(nb * sizeof(int)), *rep_elem = (int *)malloc(nb * sizeof(int)), nrep = 0, b, r, i, rc = 0;
-   int K = 0, n_eigen = 0, mode = 0;
+   int *cand_of = (int *)malloc(nb * sizeof(int)), *cand_elem = (int *)malloc(nb * sizeof(int)), *cand_rep = (int *)malloc(nb * sizeof(int));
+   int ncand = 0, nrep = 0, b, c, i, rc = 0, K = 0, n_eigen = 0, mode = 0;
+   pamlh **ws = (pamlh **)calloc(nb, sizeof(pamlh *));
    double *br = (double *)calloc((size_t)nb * nn, sizeof(double)), *fk = NULL, *rt = NULL, *rep_fk = NULL, *rep_rt = NULL;
+   const double *pi = NULL;
    int *eo = NULL, *rep_eo = NULL;
    if ((rc = pamlh_engine_ready(p))) goto done;
-   for (b = 0; b < nb; b++) {
+   for (b = 0; b < nb; b++) {          /* distinct model parts */
       const double *x = xs + (size_t)b * np;
-      for (r = 0; r < nrep; r++)
-         if (!nm || !memcmp(x + nt, xs + (size_t)rep_elem[r] * np + nt, nm * sizeof(double))) break;
-      if (r == nrep) {
-         if (pamlh_set_x(p, x, np) || !pamlh_model_feasible(p)) { rep_of[b] = -1; continue; }
-         if (!nrep) {
-            K = p->K; n_eigen = p->n_eigen; mode = p->mode;
-            rep_fk = (double *)malloc((size_t)nb * K * sizeof(double));
-            rep_rt = (double *)malloc((size_t)nb * K * sizeof(double));
-            rep_eo = (int *)malloc((size_t)nb * K * sizeof(int));
-         }
-         else if (p->K != K || p->n_eigen != n_eigen || p->mode != mode) { rc = pamlh_fail(p, "internal: model shape changed inside a batch"); goto done; }
-         if ((nrep + 1) * n_eigen > 4096) { rc = pamlh_fail(p, "batch needs more than 4096 eigen systems"); goto done; }
-         if ((rc = upload_eigen(p, nrep * n_eigen))) goto done;
-         memcpy(rep_fk + (size_t)nrep * K, p->freqK, K * sizeof(double));
-         memcpy(rep_rt + (size_t)nrep * K, p->rate, K * sizeof(double));
-         for (i = 0; i < K; i++) rep_eo[(size_t)nrep * K + i] = nrep * n_eigen + p->eigen_of[i];
-         rep_elem[nrep++] = b;
+      for (c = 0; c < ncand; c++)
+         if (!nm || !memcmp(x + nt, xs + (size_t)cand_elem[c] * np + nt, nm * sizeof(double))) break;
+      if (c == ncand) cand_elem[ncand++] = b;
+      cand_of[b] = c;
+   }
+   /* (a team no larger than the work: waking every core of a large host for a dozen items costs more than it saves) */
+#pragma omp parallel for schedule(dynamic) num_threads(ncand < 16 ? ncand : 16) if (ncand > 2)
+   for (c = 0; c < ncand; c++) {
+      pamlh *q = pamlh_state_clone(p);
+      if (q && (pamlh_set_x(q, xs + (size_t)cand_elem[c] * np, np) || !pamlh_model_feasible(q))) { pamlh_state_free(q); q = NULL; }
+      ws[c] = q;
+   }
+   for (c = 0; c < ncand; c++) {       /* accepted set-ups become the batch's eigen sets and class tables, in order */
+      pamlh *q = ws[c];
+      cand_rep[c] = -1;
+      if (!q) continue;
+      if (!nrep) {
+         K = q->K; n_eigen = q->n_eigen; mode = q->mode; pi = q->pi;
+         rep_fk = (double *)malloc((size_t)ncand * K * sizeof(double));
+         rep_rt = (double *)malloc((size_t)ncand * K * sizeof(double));
+         rep_eo = (int *)malloc((size_t)ncand * K * sizeof(int));
       }
-      rep_of[b] = r;
+      else if (q->K != K || q->n_eigen != n_eigen || q->mode != mode) { rc = pamlh_fail(p, "internal: model shape changed inside a batch"); goto done; }
+      if ((nrep + 1) * n_eigen > 4096) { rc = pamlh_fail(p, "batch needs more than 4096 eigen systems"); goto done; }
+      q->eng = p->eng;
+      if ((rc = upload_eigen(q, nrep * n_eigen))) { pamlh_fail(p, "%s", pamlh_error(q)); goto done; }
+      memcpy(rep_fk + (size_t)nrep * K, q->freqK, K * sizeof(double));
+      memcpy(rep_rt + (size_t)nrep * K, q->rate, K * sizeof(double));
+      for (i = 0; i < K; i++) rep_eo[(size_t)nrep * K + i] = nrep * n_eigen + q->eigen_of[i];
+      cand_rep[c] = nrep++;
    }
    if (!nrep) { for (b = 0; b < nb; b++) lnL[b] = -1e300; goto done; }
    fk = (double *)malloc((size_t)nb * K * sizeof(double));
@@ -72,7 +87,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
    eo = (int *)malloc((size_t)nb * K * sizeof(int));
    for (b = 0; b < nb; b++) {
       const double *x = xs + (size_t)b * np;
-      r = rep_of[b] < 0 ? 0 : rep_of[b];
+      const int r = cand_rep[cand_of[b]] < 0 ? 0 : cand_rep[cand_of[b]];
       memcpy(fk + (size_t)b * K, rep_fk + (size_t)r * K, K * sizeof(double));
       memcpy(rt + (size_t)b * K, rep_rt + (size_t)r * K, K * sizeof(double));
       memcpy(eo + (size_t)b * K, rep_eo + (size_t)r * K, K * sizeof(int));
@@ -81,15 +96,16 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
          br[(size_t)b * nn + node] = nt ? x[i] : p->tree_branch[node];
       }
    }
-   if ((rc = paml_amd_set_pi(p->eng, 1, p->pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, 1, rep_eo, NULL)) ||
+   if ((rc = paml_amd_set_pi(p->eng, 1, pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, 1, rep_eo, NULL)) ||
        (rc = paml_amd_eval_batch(p->eng, nb, br, NULL, eo, NULL, fk, rt, lnL, lnf))) {
       rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
       goto done;
    }
    for (b = 0; b < nb; b++)
-      if (rep_of[b] < 0 || !(lnL[b] == lnL[b])) lnL[b] = -1e300;
+      if (cand_rep[cand_of[b]] < 0 || !(lnL[b] == lnL[b])) lnL[b] = -1e300;
 done:
-   free(rep_of); free(rep_elem); free(br); free(fk); free(rt); free(eo); free(rep_fk); free(rep_rt); free(rep_eo);
+   for (c = 0; c < ncand; c++) pamlh_state_free(ws[c]);
+   free(ws); free(cand_of); free(cand_elem); free(cand_rep); free(br); free(fk); free(rt); free(eo); free(rep_fk); free(rep_rt); free(rep_eo);
    return rc;
 }
 
