@@ -92,11 +92,11 @@ def test_driver_binary_end_to_end(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gname,prog,ctl", [CASES[0], CASES[1], CASES[2]])
+@pytest.mark.parametrize("gname,prog,ctl", [CASES[0], CASES[1], CASES[2], CASES[4]])
 def test_c_host_optimiser_finds_the_reference_mle(gname, prog, ctl):
     """pamlh_optimize (BFGS, gradients and line searches as batches on the GPU) started from the control file's initial
     values reaches the lnL the reference's own optimiser reports for the data set (brown HKY85 -2665.422858,
-    stewart LG+G4 -1038.351723, HIV M0 -1137.688190) — the golden x are those MLEs printed with 6 decimals."""
+    stewart LG+G4 -1038.351723, HIV M0 -1137.688190, HIV M2a -1106.445004) — the golden x are those MLEs printed with 6 decimals."""
     g = helpers.load_golden(gname)
     a = hostlib.Analysis(os.path.join(CTL, ctl), prog)
     r = a.optimize(a.default_x())
