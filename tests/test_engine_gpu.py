@@ -475,3 +475,34 @@ def test_node_posterior_reproduces_the_reference_reconstruction():
             row = g["patterns"][patt]
             i = int(np.argmax(post[h]))
             assert "TCAG"[i] == row["best"][k] and abs(post[h, i] - row["prob"][k]) < 6e-4
+
+
+def _branch_model_problem(n, K, seed, n_labels=3, n_genes=1):
+    """Branch / branch-site-like set-up (Set_UVR_BranchSite codeml.c:2663, Qfactor_NS_branch treesub.c:7549): every branch
+    carries a label, and (gene, class, label) selects one of several eigen systems plus a rate factor."""
+    pb = helpers.random_problem(n, 10, 160, K=K, seed=seed, n_genes=n_genes)
+    rng = np.random.default_rng(seed)
+    pb.tree.label = rng.integers(0, n_labels, pb.tree.n_nodes).astype(np.int32)
+    pb.tree.label[:3] = np.arange(3) % n_labels                       # every label occurs
+    eig = [helpers.random_problem(n, 4, 4, seed=seed + 100 + i).eigen[0] for i in range(K * n_labels)]
+    pb.eigen = [pb.eigen[0]] + eig
+    pb.eigen_of = rng.integers(0, len(pb.eigen), size=(pb.n_genes, K, n_labels)).astype(np.int32)
+    pb.qfactor = 0.5 + rng.random((K, n_labels))
+    return pb
+
+
+@pytest.mark.parametrize("n,K,genes,jit", [(4, 2, 1, False), (61, 3, 1, False), (61, 2, 2, True), (20, 1, 1, False)])
+def test_branch_labels_select_eigen_systems(n, K, genes, jit):
+    """eigen_of[gene][class][label] and qfactor[class][label]: full evaluation, a batch, the branch-local derivatives (the
+    branch's own label picks its eigen system) against the oracle."""
+    from paml_amd.engine import JIT
+    pb = _branch_model_problem(n, K, 300 + n + K, n_genes=genes)
+    eng, out, ref = check(pb, flags=JIT if jit else 0)
+    t = pb.tree
+    for b in (1, t.n_tips + 2):
+        ts = np.array([t.branch[b], 0.3])
+        l, dl, ddl = eng.eval_branch(b, ts, t.branch, pb.gene_rate)
+        rl, rdl, rddl = oracle.eval_branch(pb, b, ts)
+        assert np.allclose(l, rl, rtol=1e-11, atol=0) and np.allclose(dl, rdl, rtol=1e-9, atol=1e-9) and np.allclose(ddl, rddl, rtol=1e-9, atol=1e-8)
+    got = eng.eval_batch(np.stack([t.branch, t.branch]), gene_rate=np.tile(pb.gene_rate, (2, 1)))
+    assert got[0] == got[1] and abs(got[0] - ref["lnL"]) <= 1e-10 * abs(ref["lnL"])
