@@ -6,8 +6,8 @@
  * into patterns in the reference's order (PatternWeight treesub.c:1386), encodes them (EncodeSeqs 1116,
  * SetMapAmbiguity 1218), and turns a parameter vector x[] into the engine's inputs the way SetParameters
  * (codeml.c:2757, baseml.c:1306) does: branch lengths, pi, eigen systems, site classes.  It then drives
- * libpaml_amd.so through include/paml_amd.h.  Scope (this round): codeml seqtype 1 (icode 0; CodonFreq 0-3; NSsites
- * 0,1,2,7,8; model 0) and seqtype 2 (aa models 0,2,3), baseml models JC69,K80,F81,HKY85,TN93,REV; +Gamma; one gene;
+ * libpaml_amd.so through include/paml_amd.h.  Scope (this round): codeml seqtype 1 (icode 0 and 1; CodonFreq 0-3; NSsites
+ * 0,1,2,7,8 with model 0; the branch model, model 2 with '#' labels in the tree, with NSsites 0) and seqtype 2 (aa models 0,2,3), baseml models JC69,K80,F81,HKY85,TN93,REV; +Gamma; one gene;
  * clock 0; cleandata 0/1; sequential and interleaved (I) PHYLIP, the P pattern format.  Anything else fails with a message
  * instead of guessing.
  */

@@ -49,7 +49,9 @@ struct pamlh {
    int *eigen_of;
    pamlh_eig eig[64];
    double kappa, omega, alpha;
-   double class_w[64];     /* NSsites: omega of every site class */
+   double class_w[64];     /* NSsites: omega of every site class; branch model: omega of every label */
+   char code[65];          /* genetic code: amino acid of each of the 64 codons (T, C, A, G order), '*' = stop */
+   int n_omega;            /* branch model: number of branch labels = omegas */
    double ns_mr;           /* NSsites: mean rate at the mean omega = 1 / Qfactor_NS of the last pamlh_set_x */
    /* engine */
    paml_amd_engine *eng;

@@ -17,7 +17,6 @@ static const char *EquateBASE[] = {"T", "C", "A", "G", "T", "TC", "AG", "CA", "T
                                    "TCAG", "TCAG", "TCAG"};
 static const char AAs[] = "ARNDCQEGHILKMFPSTWYV-*?X";
 /* standard genetic code, codon index 16 b1 + 4 b2 + b3 with T,C,A,G = 0..3 (tools.c:23-84) */
-static const char STDCODE[] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
 
 int pamlh_fail(pamlh *p, const char *fmt, ...)
 {
@@ -274,7 +273,7 @@ int pamlh_read_seqs(pamlh *p)
       else {
          int from64[64], nsense = 0, namb = 0;
          char amb[256][4];
-         for (i = 0; i < 64; i++) from64[i] = STDCODE[i] == '*' ? -1 : nsense++;
+         for (i = 0; i < 64; i++) from64[i] = p->code[i] == '*' ? -1 : nsense++;
          for (j = 0; j < ns; j++)
             for (h = 0; h < np; h++) {
                const char *c = p->raw + ((size_t)j * np + h) * 3;
@@ -288,17 +287,17 @@ int pamlh_read_seqs(pamlh *p)
                   for (k = 0; k < namb; k++)
                      if (!memcmp(amb[k], c, 3)) break;
                   if (k == namb) {
-                     if (namb >= 256 - 61) return pamlh_fail(p, "too many distinct ambiguous codons");
+                     if (namb >= 256 - n) return pamlh_fail(p, "too many distinct ambiguous codons");
                      memcpy(amb[namb], c, 3); amb[namb][3] = 0; namb++;
                   }
-                  code = 61 + k;
+                  code = n + k;
                }
                p->z[(size_t)j * np + h] = (unsigned char)code;
             }
-         p->n_codes = 61 + namb;
+         p->n_codes = n + namb;
          p->n_chara = (int *)calloc(p->n_codes, sizeof(int));
          p->chara_map = (unsigned char *)calloc((size_t)p->n_codes * n, 1);
-         for (i = 0; i < 61; i++) { p->n_chara[i] = 1; p->chara_map[(size_t)i * n] = (unsigned char)i; }
+         for (i = 0; i < n; i++) { p->n_chara[i] = 1; p->chara_map[(size_t)i * n] = (unsigned char)i; }
          for (i = 0; i < namb; i++) {
             int s0[4], s1[4], s2[4], n0 = base_set(amb[i][0], s0), n1 = base_set(amb[i][1], s1), n2 = base_set(amb[i][2], s2);
             int i0, i1, i2, m = 0;
@@ -306,10 +305,10 @@ int pamlh_read_seqs(pamlh *p)
                for (i1 = 0; i1 < n1; i1++)
                   for (i2 = 0; i2 < n2; i2++) {
                      int ic = s0[i0] * 16 + s1[i1] * 4 + s2[i2];
-                     if (from64[ic] >= 0) p->chara_map[(size_t)(61 + i) * n + m++] = (unsigned char)from64[ic];
+                     if (from64[ic] >= 0) p->chara_map[(size_t)(n + i) * n + m++] = (unsigned char)from64[ic];
                   }
             if (!m) return pamlh_fail(p, "codon %s is a stop codon", amb[i]);
-            p->n_chara[61 + i] = m;
+            p->n_chara[n + i] = m;
          }
          if (namb == 0) p->cleandata = 1;
       }

@@ -11,7 +11,10 @@
 
 #include "pamlh_internal.h"
 
-static const char STDCODE[] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+/* genetic codes (codons in T, C, A, G order; '*' = stop): icode 0 universal, 1 vertebrate mitochondrial (GeneticCode[][] in
+ * tools.c: TGA Trp, ATA Met, AGA / AGG stop) */
+static const char *const GENETIC_CODES[2] = {"FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+                                             "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG"};
 
 static double dist2(const double *a, const double *b, int n)
 {
@@ -82,7 +85,7 @@ static void freqs_codon(pamlh *p)
    int js, h, k, i0, i1, i2, it, np = p->npatt;
    double fc[64] = {0}, fb[12] = {0}, f4[4] = {0}, fc0[64], fb0[12], f40[4], t;
    int from64[64], nsense = 0;
-   for (k = 0; k < 64; k++) from64[k] = STDCODE[k] == '*' ? -1 : nsense++;
+   for (k = 0; k < 64; k++) from64[k] = p->code[k] == '*' ? -1 : nsense++;
    for (js = 0; js < p->ns; js++)
       for (h = 0; h < np; h++) {
          const char *c = p->raw + ((size_t)js * np + h) * 3;
@@ -150,7 +153,7 @@ static void freqs_codon(pamlh *p)
          p->pi_data[j++] = v;
          s += v;
       }
-      for (j = 0; j < 61; j++) p->pi_data[j] /= s;
+      for (j = 0; j < p->n; j++) p->pi_data[j] /= s;
    }
 }
 
@@ -210,11 +213,13 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    if ((int)pamlh_optd(p, "clock", 0) != 0) { rc = pamlh_fail(p, "clock models are not supported"); goto bad; }
    if ((int)pamlh_optd(p, "Mgene", 0) != 0) { rc = pamlh_fail(p, "Mgene models are not supported"); goto bad; }
    if (p->seqtype == 1) {
-      if (p->icode != 0) { rc = pamlh_fail(p, "only the universal genetic code (icode = 0) is supported"); goto bad; }
-      if (p->model != 0) { rc = pamlh_fail(p, "branch / branch-site codon models are not supported yet"); goto bad; }
+      if (p->icode != 0 && p->icode != 1) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0: universal, 1: vertebrate mt)", p->icode); goto bad; }
+      if (p->model != 0 && !(p->model == 2 && p->nssites == 0)) { rc = pamlh_fail(p, "codon model = %d with NSsites = %d is not supported (model 2 needs NSsites = 0)", p->model, p->nssites); goto bad; }
+      strcpy(p->code, GENETIC_CODES[p->icode]);
       if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 7 && p->nssites != 8) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
       if (p->codonfreq < 0 || p->codonfreq > 3) { rc = pamlh_fail(p, "CodonFreq = %d is not supported", p->codonfreq); goto bad; }
-      p->n = 61;
+      for (p->n = 0, rc = 0; rc < 64; rc++) p->n += p->code[rc] != '*';
+      rc = 0;
    }
    else if (p->seqtype == 2) {
       p->n = 20; p->aa_model = p->model;
@@ -232,6 +237,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    else { rc = pamlh_fail(p, "seqtype %d is not supported", p->seqtype); goto bad; }
    if ((rc = pamlh_read_seqs(p))) goto bad;
    if ((rc = pamlh_read_tree(p))) goto bad;
+   if (!(p->seqtype == 1 && p->model == 2)) memset(p->label, 0, p->nnode * sizeof(int));      /* '#' labels only matter to branch models */
    if (p->seqtype == 1) freqs_codon(p);
    else freqs_base_aa(p);
    /* parameter bookkeeping (GetInitials): ntime, np */
@@ -240,7 +246,12 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       int nr = 0;
       if (p->seqtype == 1) {
          nr += !p->fix_kappa;
-         if (p->nssites == 0) nr += !p->fix_omega;
+         if (p->nssites == 0 && p->model == 2) {      /* branch model: one omega per branch label (codeml.c:2170-2183) */
+            int i;
+            for (p->n_omega = 1, i = 0; i < p->nnode; i++) if (p->label[i] + 1 > p->n_omega) p->n_omega = p->label[i] + 1;
+            nr += p->n_omega;
+         }
+         else if (p->nssites == 0) nr += !p->fix_omega;
          else if (p->nssites == 1) nr += 2;
          else if (p->nssites == 2) nr += 4;
          else if (p->nssites == 7) nr += 2;
@@ -343,7 +354,8 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
    for (i = 0; i < p->ntime; i++) { double b = p->tree_branch[p->branch_node[i]]; x[k++] = b >= 0 ? b : 0.1; }
    if (p->seqtype == 1) {
       if (!p->fix_kappa) x[k++] = p->kappa0;
-      if (p->nssites == 0) { if (!p->fix_omega) x[k++] = p->omega0; }
+      if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) x[k++] = p->omega0; }
+      else if (p->nssites == 0) { if (!p->fix_omega) x[k++] = p->omega0; }
       else if (p->nssites == 1) { x[k++] = 0.6; x[k++] = 0.1; }
       else if (p->nssites == 2) { x[k++] = 0.5; x[k++] = 0.3; x[k++] = 0.1; x[k++] = 2.5; }
       else if (p->nssites == 7) { x[k++] = 0.5; x[k++] = 1.5; }
@@ -388,10 +400,10 @@ static void set_eig_uvroot(pamlh *p, int i, const double *Q, const double *pi, d
 /* codon Q for (kappa, omega) and its mean rate (eigenQcodon codeml.c:3274-3315) */
 static double codon_q(const pamlh *p, double kappa, double omega, double *Q)
 {
-   int from61[61], i, j, k, n = 61, m = 0;
+   int from61[64], i, j, k, n = p->n, m = 0;
    double mr = 0;
    const double *pi = p->pi;
-   for (k = 0; k < 64; k++) if (STDCODE[k] != '*') from61[m++] = k;
+   for (k = 0; k < 64; k++) if (p->code[k] != '*') from61[m++] = k;
    memset(Q, 0, (size_t)n * n * sizeof(double));
    for (i = 1; i < n; i++)
       for (j = 0; j < i; j++) {
@@ -402,7 +414,7 @@ static double codon_q(const pamlh *p, double kappa, double omega, double *Q)
          for (k = 0; k < 3; k++) if (f[k] != t[k]) { nd++; pos = k; }
          if (nd != 1) continue;
          if (f[pos] + t[pos] == 1 || f[pos] + t[pos] == 5) q = kappa;
-         if (STDCODE[c1] != STDCODE[c2]) q *= omega;
+         if (p->code[c1] != p->code[c2]) q *= omega;
          Q[i * n + j] = Q[j * n + i] = q;
       }
    for (i = 0; i < n; i++) for (j = 0; j < n; j++) Q[i * n + j] *= pi[j];
@@ -427,9 +439,20 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
    p->freqK[0] = 1; p->rate[0] = 1; p->eigen_of[0] = 0;
    if (p->seqtype == 1) {
       double kappa = p->fix_kappa ? p->kappa0 : x[k++];
-      memcpy(p->pi, p->pi_data, 61 * sizeof(double));
+      memcpy(p->pi, p->pi_data, p->n * sizeof(double));
       p->kappa = kappa;
-      if (p->nssites == 0) {
+      if (p->nssites == 0 && p->model == 2) {
+         /* branch model: label l has its own omega and its own eigen system, each scaled by its own mean rate
+          * (SetParameters codeml.c:2804-2812 -> _UU[l]; GetPMatBranch treesub.c:7568-7572) */
+         for (j = 0; j < p->n_omega; j++) {
+            const double w = x[k++], mr = codon_q(p, kappa, w, Q);
+            set_eig_uvroot(p, j, Q, p->pi, mr);
+            p->eigen_of[j] = j;
+            p->class_w[j] = w;
+         }
+         p->n_eigen = p->n_labels = p->n_omega;
+      }
+      else if (p->nssites == 0) {
          double w = p->fix_omega ? p->omega0 : x[k++], mr = codon_q(p, kappa, w, Q);
          p->omega = w;
          set_eig_uvroot(p, 0, Q, p->pi, mr);
@@ -592,7 +615,7 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
       else rc = paml_amd_set_eigen_jc69like(p->eng, i);
       if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    }
-   if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, 1, p->eigen_of, NULL)) ||
+   if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->eigen_of, NULL)) ||
        (rc = paml_amd_eval(p->eng, p->branch, NULL, lnL, lnf, NULL)))
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    return 0;
@@ -666,7 +689,7 @@ int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double 
    if (m2a) rK[k++] = 1;
    for (i = 0; i < N1; i++) rK[k++] = 1 + 10 * (i + 0.5) / N1;
    /* stage 1: f(x_h | w) for every grid omega (fx_r with BayesEB = 1: the model's branch lengths, kappa and Qfactor_NS) */
-   Q = (double *)malloc((size_t)61 * 61 * sizeof(double));
+   Q = (double *)malloc((size_t)p->n * p->n * sizeof(double));
    for (k = 0; k < K; k++) {
       codon_q(p, kappa, rK[k], Q);
       set_eig_uvroot(p, k, Q, p->pi, mr);

@@ -42,7 +42,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
 {
    const int np = p->np, nt = p->ntime, nm = np - nt, nn = p->nnode;
    int *cand_of = (int *)malloc(nb * sizeof(int)), *cand_elem = (int *)malloc(nb * sizeof(int)), *cand_rep = (int *)malloc(nb * sizeof(int));
-   int ncand = 0, nrep = 0, b, c, i, rc = 0, K = 0, n_eigen = 0, mode = 0;
+   int ncand = 0, nrep = 0, b, c, i, rc = 0, K = 0, L = 1, n_eigen = 0, mode = 0;
    pamlh **ws = (pamlh **)calloc(nb, sizeof(pamlh *));
    double *br = (double *)calloc((size_t)nb * nn, sizeof(double)), *fk = NULL, *rt = NULL, *rep_fk = NULL, *rep_rt = NULL;
    const double *pi = NULL;
@@ -67,36 +67,36 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       cand_rep[c] = -1;
       if (!q) continue;
       if (!nrep) {
-         K = q->K; n_eigen = q->n_eigen; mode = q->mode; pi = q->pi;
+         K = q->K; L = q->n_labels; n_eigen = q->n_eigen; mode = q->mode; pi = q->pi;
          rep_fk = (double *)malloc((size_t)ncand * K * sizeof(double));
          rep_rt = (double *)malloc((size_t)ncand * K * sizeof(double));
-         rep_eo = (int *)malloc((size_t)ncand * K * sizeof(int));
+         rep_eo = (int *)malloc((size_t)ncand * K * L * sizeof(int));
       }
-      else if (q->K != K || q->n_eigen != n_eigen || q->mode != mode) { rc = pamlh_fail(p, "internal: model shape changed inside a batch"); goto done; }
+      else if (q->K != K || q->n_labels != L || q->n_eigen != n_eigen || q->mode != mode) { rc = pamlh_fail(p, "internal: model shape changed inside a batch"); goto done; }
       if ((nrep + 1) * n_eigen > 4096) { rc = pamlh_fail(p, "batch needs more than 4096 eigen systems"); goto done; }
       q->eng = p->eng;
       if ((rc = upload_eigen(q, nrep * n_eigen))) { pamlh_fail(p, "%s", pamlh_error(q)); goto done; }
       memcpy(rep_fk + (size_t)nrep * K, q->freqK, K * sizeof(double));
       memcpy(rep_rt + (size_t)nrep * K, q->rate, K * sizeof(double));
-      for (i = 0; i < K; i++) rep_eo[(size_t)nrep * K + i] = nrep * n_eigen + q->eigen_of[i];
+      for (i = 0; i < K * L; i++) rep_eo[(size_t)nrep * K * L + i] = nrep * n_eigen + q->eigen_of[i];
       cand_rep[c] = nrep++;
    }
    if (!nrep) { for (b = 0; b < nb; b++) lnL[b] = -1e300; goto done; }
    fk = (double *)malloc((size_t)nb * K * sizeof(double));
    rt = (double *)malloc((size_t)nb * K * sizeof(double));
-   eo = (int *)malloc((size_t)nb * K * sizeof(int));
+   eo = (int *)malloc((size_t)nb * K * L * sizeof(int));
    for (b = 0; b < nb; b++) {
       const double *x = xs + (size_t)b * np;
       const int r = cand_rep[cand_of[b]] < 0 ? 0 : cand_rep[cand_of[b]];
       memcpy(fk + (size_t)b * K, rep_fk + (size_t)r * K, K * sizeof(double));
       memcpy(rt + (size_t)b * K, rep_rt + (size_t)r * K, K * sizeof(double));
-      memcpy(eo + (size_t)b * K, rep_eo + (size_t)r * K, K * sizeof(int));
+      memcpy(eo + (size_t)b * K * L, rep_eo + (size_t)r * K * L, (size_t)K * L * sizeof(int));
       for (i = 0; i < p->nbranch; i++) {
          const int node = p->branch_node[i];
          br[(size_t)b * nn + node] = nt ? x[i] : p->tree_branch[node];
       }
    }
-   if ((rc = paml_amd_set_pi(p->eng, 1, pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, 1, rep_eo, NULL)) ||
+   if ((rc = paml_amd_set_pi(p->eng, 1, pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, L, rep_eo, NULL)) ||
        (rc = paml_amd_eval_batch(p->eng, nb, br, NULL, eo, NULL, fk, rt, lnL, lnf))) {
       rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
       goto done;
@@ -117,7 +117,8 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
    for (i = 0; i < p->ntime; i++) { lo[k] = 4e-6; hi[k++] = 50; }
    if (p->seqtype == 1) {
       if (!p->fix_kappa) { lo[k] = 1e-4; hi[k++] = 999; }
-      if (p->nssites == 0) { if (!p->fix_omega) { lo[k] = 1e-4; hi[k++] = 999; } }
+      if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) { lo[k] = 1e-4; hi[k++] = 999; } }
+      else if (p->nssites == 0) { if (!p->fix_omega) { lo[k] = 1e-4; hi[k++] = 999; } }
       else if (p->nssites == 1) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 1e-6; hi[k++] = 1; }
       else if (p->nssites == 2) {
          lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 1e-6; hi[k++] = 1 - 1e-6;

@@ -217,3 +217,19 @@ def test_c_host_beb_matches_the_reference_table(gname, ctl, table):
         got = (pr[site - 1], mw[site - 1], se[site - 1])
         assert abs(got[0] - p_) < 2e-3 and abs(got[1] - m_) < 4e-3 and abs(got[2] - s_) < 4e-3, (site, got)
     assert sorted(np.nonzero(pr > 0.5)[0] + 1) == sorted(table)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ctl,lnl,est", [("mtcdna_m0.ctl", -20486.034301, {-2: 20.74839, -1: 0.04414}),
+                                          ("mtcdna_branch.ctl", -20444.099676, {-3: 21.59077, -2: 0.28638, -1: 0.03693})])
+def test_c_host_reaches_the_published_mtcdnaape_values(ctl, lnl, est):
+    """examples/mtCDNAape/README.txt:15-17 publishes the maximised lnL and the estimates of kappa and omega for the ape
+    mitochondrial data under M0 and under the two-ratio branch model (model = 2: within- / between-species branches labelled in
+    the tree file; vertebrate mitochondrial code, 60 sense codons).  Control file, PHYLIP reader, '#' labels, F3x4, the
+    per-label eigen systems, the batched optimiser and the 60-state kernels all sit between the files and these numbers."""
+    a = hostlib.Analysis(os.path.join(CTL, ctl), "codeml")
+    assert a.n == 60 and a.n_tips == 6
+    r = a.optimize(a.default_x())
+    assert r["converged"] and abs(r["lnL"] - lnl) < 2e-4, r["lnL"]
+    for k, v in est.items():
+        assert abs(r["x"][k] - v) / v < 5e-3, (k, r["x"][k], v)
