@@ -241,6 +241,17 @@ def case_brown_anc():
     print("%-22s lnL %.6f  %d distinct patterns, nodes %s -> %s" % (g["name"], g["lnL"], len(rows), g["nodes_1based"], os.path.basename(path)))
 
 
+def case_mtcdna_branch():
+    """Two-ratio branch model (model = 2, '#1' labels in the tree file) under the vertebrate mitochondrial code on the
+    reference's mtCDNAape example, single evaluation at round parameter values."""
+    x = [0.02, 0.03, 0.05, 0.04, 0.06, 0.08, 0.07, 0.09, 0.1, 20.0, 0.3, 0.04]
+    ctl = dict(CODEML_BASE, seqfile="mtCDNAape.txt", treefile="mtCDNAape.trees", outfile="mlc", model=2, icode=1, cleandata=0,
+               kappa=1.234567, omega=1.414)
+    res = run_ref("codeml", ctl, {"mtCDNAape.txt": EX + "/mtCDNAape/mtCDNAape.txt", "mtCDNAape.trees": EX + "/mtCDNAape/mtCDNAape.trees"}, x=x)
+    finish("mtcdna_branch", res, "codon", 6, dict(program="codeml", model=dict(kind="codon_branch", icode=1, codonfreq="F3x4"), x=x, ntime=9,
+                                                 published=dict(m0_lnL=-20486.034301, branch_lnL=-20444.099676)), keep_raw_patterns=True)
+
+
 def case_stewart():
     x = [float(v) for v in "0.000004 0.019085 0.083331 0.034683 0.067995 0.339072 0.104868 0.276662 0.861606 1.064411".split()]
     ctl = dict(CODEML_BASE, seqfile="stewart.aa", treefile="stewart.trees", outfile="mlc", seqtype=2, model=2,
@@ -276,7 +287,7 @@ CASES = {
     "hiv_m0": lambda: case_hiv("m0"), "hiv_m1a": lambda: case_hiv("m1a"), "hiv_m2a": lambda: case_hiv("m2a"),
     "hiv_m7": lambda: case_hiv("m7"), "hiv_m8": lambda: case_hiv("m8"),
     "stewart_lg_g4": case_stewart, "mhc_m0_scaled": case_mhc,
-    "syn_codon_m0": case_syn_codon, "syn_nuc_gtr_g4": case_syn_nuc, "brown_hky85": case_brown, "brown_hky85_anc": case_brown_anc,
+    "syn_codon_m0": case_syn_codon, "syn_nuc_gtr_g4": case_syn_nuc, "brown_hky85": case_brown, "brown_hky85_anc": case_brown_anc, "mtcdna_branch": case_mtcdna_branch,
     # BASELINE configs[3] / configs[1] at full size (reference: ~2 min and 6.8 GB / ~2 s): lnL + strided log f_h sample
     "syn_codon_m0_full": lambda: case_syn_codon(1_000_000, "syn_codon_m0_full", sample=997),
     "syn_nuc_gtr_g4_full": lambda: case_syn_nuc(100_000, "syn_nuc_gtr_g4_full", sample=97),

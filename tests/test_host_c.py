@@ -15,7 +15,8 @@ from paml_amd import hostlib
 CTL = os.path.join(helpers.GOLDEN, "ctl")
 CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml", "stewart_lg_g4.ctl"),
          ("hiv_m0", "codeml", "hiv_ns0.ctl"), ("hiv_m1a", "codeml", "hiv_ns1.ctl"), ("hiv_m2a", "codeml", "hiv_ns2.ctl"),
-         ("hiv_m7", "codeml", "hiv_ns7.ctl"), ("hiv_m8", "codeml", "hiv_ns8.ctl"), ("mhc_m0_scaled", "codeml", "mhc_m0.ctl")]
+         ("hiv_m7", "codeml", "hiv_ns7.ctl"), ("hiv_m8", "codeml", "hiv_ns8.ctl"), ("mhc_m0_scaled", "codeml", "mhc_m0.ctl"),
+         ("mtcdna_branch", "codeml", "mtcdna_branch.ctl")]
 
 
 def _x(g, a):
