@@ -234,3 +234,31 @@ def test_c_host_reaches_the_published_mtcdnaape_values(ctl, lnl, est):
     assert r["converged"] and abs(r["lnL"] - lnl) < 2e-4, r["lnL"]
     for k, v in est.items():
         assert abs(r["x"][k] - v) / v < 5e-3, (k, r["x"][k], v)
+
+
+MTCDNAPRI = {0: (-31744.953377, "0.120080 0.058139 0.175107 0.098210 0.072451 0.060123 0.206933 0.224103 0.115862 0.114939 0.408898 7.417478 0.112776"),
+             2: (-29967.856102, "0.261697 0.100524 0.242894 0.120349 0.078171 0.066639 0.286667 0.506947 0.158670 0.142655 0.829442 14.249448 0.041084")}
+
+
+@pytest.mark.parametrize("cf", [0, 2])
+def test_c_host_published_mtcdnapri_values_on_cpu(cf):
+    """examples/mtCDNA/AAcodon.result.txt:15-17, 38-40: lnL and the 13 estimates (branch lengths in tree.branches order, kappa,
+    omega) of codon model M0 on the primate mitochondrial data, Fequal and F3x4 — one evaluation at the printed estimates must
+    give the printed lnL (C host + oracle; the engine does the same on the GPU below)."""
+    lnl, xs = MTCDNAPRI[cf]
+    a = hostlib.Analysis(os.path.join(CTL, "mtcdnapri_cf%d.ctl" % cf), "codeml")
+    assert (a.n, a.n_tips, a.np, a.ntime) == (60, 7, 13, 11)
+    x = np.array([float(v) for v in xs.split()])
+    assert abs(oracle.evaluate(a.problem(x), want_lnf=False)["lnL"] - lnl) < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cf", [0, 2])
+def test_c_host_published_mtcdnapri_values_on_gpu(cf):
+    lnl, xs = MTCDNAPRI[cf]
+    a = hostlib.Analysis(os.path.join(CTL, "mtcdnapri_cf%d.ctl" % cf), "codeml")
+    x = np.array([float(v) for v in xs.split()])
+    assert abs(a.eval_gpu(x, want_lnf=False)[0] - lnl) < 5e-5
+    r = a.optimize(a.default_x())                          # ... and the optimiser finds them from the control file's start
+    assert r["converged"] and abs(r["lnL"] - lnl) < 2e-4
+    assert np.max(np.abs(r["x"] - x) / (np.abs(x) + 0.01)) < 1e-2
