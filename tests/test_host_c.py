@@ -262,3 +262,24 @@ def test_c_host_published_mtcdnapri_values_on_gpu(cf):
     r = a.optimize(a.default_x())                          # ... and the optimiser finds them from the control file's start
     assert r["converged"] and abs(r["lnL"] - lnl) < 2e-4
     assert np.max(np.abs(r["x"] - x) / (np.abs(x) + 0.01)) < 1e-2
+
+
+JTT_LNL, JTT_X = -14717.981418, "0.025579 0.009654 0.022079 0.012328 0.011335 0.010281 0.026980 0.052187 0.026525 0.019651 0.062350"
+
+
+def test_c_host_published_jtt_value_on_cpu():
+    """examples/mtCDNA/AAcodon.result.txt:57-62: AAML with JTT + F (seqtype = 2, model = 3, dat/jones.dat) on the primate
+    proteins: the printed lnL at the printed branch lengths."""
+    a = hostlib.Analysis(os.path.join(CTL, "mtcdnapri_jtt.ctl"), "codeml")
+    assert (a.n, a.n_tips, a.np) == (20, 7, 11)
+    x = np.array([float(v) for v in JTT_X.split()])
+    assert abs(oracle.evaluate(a.problem(x), want_lnf=False)["lnL"] - JTT_LNL) < 5e-5
+
+
+@pytest.mark.gpu
+def test_c_host_published_jtt_value_on_gpu():
+    a = hostlib.Analysis(os.path.join(CTL, "mtcdnapri_jtt.ctl"), "codeml")
+    x = np.array([float(v) for v in JTT_X.split()])
+    assert abs(a.eval_gpu(x, want_lnf=False)[0] - JTT_LNL) < 5e-5
+    r = a.optimize(a.default_x())
+    assert r["converged"] and abs(r["lnL"] - JTT_LNL) < 2e-4 and np.max(np.abs(r["x"] - x)) < 5e-5
