@@ -283,3 +283,16 @@ def test_c_host_published_jtt_value_on_gpu():
     assert abs(a.eval_gpu(x, want_lnf=False)[0] - JTT_LNL) < 5e-5
     r = a.optimize(a.default_x())
     assert r["converged"] and abs(r["lnL"] - JTT_LNL) < 2e-4 and np.max(np.abs(r["x"] - x)) < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns,lnl", [(1, -7490.993363), (2, -7231.154540), (7, -7502.792534), (8, -7238.014961)])
+def test_c_host_reaches_the_published_mhc_site_model_values(ns, lnl):
+    """examples/MHC.Swanson2002MBE/README.txt:26-30: 192 MHC alleles x 270 codons, branch lengths fixed at the tree file's
+    (fix_blength = 2), kappa and the site-class parameters of M1a / M2a / M7 / M8 estimated.  192 taxa means scaling nodes
+    (log-sum-exp class mixing), ambiguity codes, a tree beyond the specialised kernel's tip limit, and batched evaluations
+    through all of that."""
+    a = hostlib.Analysis(os.path.join(CTL, "mhc_ns%d.ctl" % ns), "codeml")
+    assert a.ntime == 0 and a.n_tips == 192
+    r = a.optimize(a.default_x(), max_iter=300)
+    assert r["converged"] and abs(r["lnL"] - lnl) < 5e-4, (ns, r["lnL"], r["x"])
