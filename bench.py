@@ -156,6 +156,18 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota (cpu.max) if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(pb, sample):
     """The oracle's single-thread restatement of the reference loop nest (kind "port"), timed on this
     box's host cores over the first `sample` patterns of the same workload."""
@@ -177,7 +189,7 @@ def cpu_baseline(pb, sample):
                      % (reps, sample, os.cpu_count() or 0)}
     # the same code with the patterns cut into blocks spread over every host core, each thread walking the whole tree
     # for its block; the whole workload, a few evaluations, bounded to ~10 s
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     oracle.evaluate_blocked(pb.slice_patterns(0, min(pb.n_patt, 4096 * ncores)), ncores)      # thread start-up
     reps = 0
     t0 = time.perf_counter()
@@ -188,7 +200,8 @@ def cpu_baseline(pb, sample):
         if el > 8.0 or reps >= 5:
             break
     one["all_cores"] = {"value": pb.n_patt * reps / el, "unit": "site-patterns/s", "cores": ncores,
-                        "sample": "%d evals over all %d patterns, blocks of 512 patterns over %d OpenMP threads" % (reps, pb.n_patt, ncores)}
+                        "sample": "%d evals over all %d patterns, blocks of 512 patterns over %d OpenMP threads (%d logical CPUs visible)"
+                                  % (reps, pb.n_patt, ncores, os.cpu_count() or 0)}
     return one
 
 
