@@ -7,7 +7,8 @@
  * SetMapAmbiguity 1218), and turns a parameter vector x[] into the engine's inputs the way SetParameters
  * (codeml.c:2757, baseml.c:1306) does: branch lengths, pi, eigen systems, site classes.  It then drives
  * libpaml_amd.so through include/paml_amd.h.  Scope (this round): codeml seqtype 1 (icode 0 and 1; CodonFreq 0-3; NSsites
- * 0,1,2,7,8 with model 0; the branch model, model 2 with '#' labels in the tree, with NSsites 0) and seqtype 2 (aa models 0,2,3), baseml models JC69,K80,F81,HKY85,TN93,REV; +Gamma; one gene;
+ * 0,1,2,3,7,8 with model 0; with '#' labels in the tree the branch model (model 2, NSsites 0), the branch-site models A and B
+ * (model 2, NSsites 2 / 3) and the clade models C and D (model 3, NSsites 2 / 3)) and seqtype 2 (aa models 0,2,3), baseml models JC69,K80,F81,HKY85,TN93,REV; +Gamma; one gene;
  * clock 0; cleandata 0/1; sequential and interleaved (I) PHYLIP, the P pattern format.  Anything else fails with a message
  * instead of guessing.
  */
@@ -53,6 +54,7 @@ const double *pamlh_pi(const pamlh *p);                 /* [n_states] */
 const double *pamlh_freqK(const pamlh *p);
 const double *pamlh_rate(const pamlh *p);
 const int *pamlh_eigen_of(const pamlh *p);              /* [K][n_labels] */
+const double *pamlh_qfactor(const pamlh *p);            /* [K][n_labels] time scale per (class, branch type); NULL = all 1 */
 /* eigen system i: kind (paml_amd.h), and pointers (NULL when not applicable) */
 int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const double **U, const double **V,
                 const double **Root, const double **Cijk);
@@ -85,6 +87,7 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w);
 int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double *se_w);
 const int *pamlh_pose(const pamlh *p, int *n_sites);
 const double *pamlh_class_omega(const pamlh *p);
+int pamlh_positive_classes(const pamlh *p);             /* trailing classes that allow omega > 1 (2 for branch-site: 2a + 2b) */
 
 /* Write the reference's `lnf` file layout (print_lnf_site treesub.c:7598) for the last pamlh_eval_gpu. */
 int pamlh_write_lnf(const pamlh *p, const char *path, const double *lnf);

@@ -52,6 +52,8 @@ struct pamlh {
    double class_w[64];     /* NSsites: omega of every site class; branch model: omega of every label */
    char code[65];          /* genetic code: amino acid of each of the 64 codons (T, C, A, G order), '*' = stop */
    int n_omega;            /* branch model: number of branch labels = omegas */
+   double qfactor[64];     /* branch-site / clade models: time scale of (class, branch type), [K][n_labels] */
+   int use_qf;
    double ns_mr;           /* NSsites: mean rate at the mean omega = 1 / Qfactor_NS of the last pamlh_set_x */
    /* engine */
    paml_amd_engine *eng;

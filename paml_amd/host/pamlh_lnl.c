@@ -48,18 +48,19 @@ int main(int argc, char **argv)
    if (pamlh_eval_gpu(p, &lnL, lnf)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
    printf("ntime & np: %d %d   npatt %d\nlnL  = %.6f\n", ntime, np, npatt, lnL);
    {  /* site-class models: the NEB table the reference prints (sites with Pr(last class) > 0.5 when its omega > 1) */
-      int mode, K, n_sites, h;
+      int mode, K, n_sites, h, npos = pamlh_positive_classes(p);
       pamlh_model(p, &mode, &K, NULL, NULL);
-      if (mode == 1 && K > 1 && pamlh_class_omega(p)[K - 1] > 1) {
+      if (mode == 1 && K > 1 && npos && pamlh_class_omega(p)[K - 1] > 1) {
          double *post = (double *)malloc((size_t)K * npatt * sizeof(double)), *mw = (double *)malloc(npatt * sizeof(double));
          const int *pose = pamlh_pose(p, &n_sites);
          if (!pamlh_neb(p, post, mw)) {
             printf("\nNaive Empirical Bayes (NEB): sites with Pr(w>1) > 0.5\n   site   Pr(w>1)   post mean w\n");
-            for (h = 0; h < n_sites; h++)
-               if (post[(size_t)(K - 1) * npatt + pose[h]] > 0.5)
-                  printf("%7d   %7.3f   %9.3f\n", h + 1, post[(size_t)(K - 1) * npatt + pose[h]], mw[pose[h]]);
+            for (h = 0; h < n_sites; h++) {      /* branch-site models: classes 2a + 2b (foreground omega) */
+               const double pr = post[(size_t)(K - 1) * npatt + pose[h]] + (npos == 2 ? post[(size_t)(K - 2) * npatt + pose[h]] : 0);
+               if (pr > 0.5) printf("%7d   %7.3f   %9.3f\n", h + 1, pr, mw[pose[h]]);
+            }
          }
-         {  /* M2a / M8: the BEB table as well */
+         if (npos == 1) {  /* M2a / M8: the BEB table as well */
             double *pr = (double *)malloc(npatt * sizeof(double)), *sw = (double *)malloc(npatt * sizeof(double));
             if (!pamlh_beb(p, x, pr, mw, sw)) {
                printf("\nBayes Empirical Bayes (BEB): sites with Pr(w>1) > 0.5\n   site   Pr(w>1)   post mean +- SE for w\n");

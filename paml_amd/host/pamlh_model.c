@@ -214,9 +214,16 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    if ((int)pamlh_optd(p, "Mgene", 0) != 0) { rc = pamlh_fail(p, "Mgene models are not supported"); goto bad; }
    if (p->seqtype == 1) {
       if (p->icode != 0 && p->icode != 1) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0: universal, 1: vertebrate mt)", p->icode); goto bad; }
-      if (p->model != 0 && !(p->model == 2 && p->nssites == 0)) { rc = pamlh_fail(p, "codon model = %d with NSsites = %d is not supported (model 2 needs NSsites = 0)", p->model, p->nssites); goto bad; }
+      /* model 0: site models; model 2, NSsites 0: branch model; model 2 / 3 with NSsites 2 / 3: branch-site A / B, clade C / D */
+      if (p->model != 0 && !(p->model == 2 && p->nssites == 0) && !((p->model == 2 || p->model == 3) && (p->nssites == 2 || p->nssites == 3))) {
+         rc = pamlh_fail(p, "codon model = %d with NSsites = %d is not supported", p->model, p->nssites); goto bad;
+      }
+      if (p->model == 2 && p->nssites == 3 && p->fix_omega) { rc = pamlh_fail(p, "fix_omega with branch-site model B is not supported"); goto bad; }
+      if (p->model && p->nssites && (p->alpha0 > 0 || !p->fix_alpha)) { rc = pamlh_fail(p, "dN/dS ratios among branches are not supported with gamma rates"); goto bad; }
+      if (p->model == 3) p->ncatG = 3;                /* "ncatG = 3 reset" (codeml.c:1607) */
       strcpy(p->code, GENETIC_CODES[p->icode]);
-      if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 7 && p->nssites != 8) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
+      if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 3 && p->nssites != 7 && p->nssites != 8) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
+      if (p->model == 0 && p->nssites == 3 && (p->fix_omega || p->ncatG < 2 || p->ncatG > 16)) { rc = pamlh_fail(p, "NSsites = 3 needs fix_omega = 0 and 2 <= ncatG <= 16"); goto bad; }
       if (p->codonfreq < 0 || p->codonfreq > 3) { rc = pamlh_fail(p, "CodonFreq = %d is not supported", p->codonfreq); goto bad; }
       for (p->n = 0, rc = 0; rc < 64; rc++) p->n += p->code[rc] != '*';
       rc = 0;
@@ -237,7 +244,13 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    else { rc = pamlh_fail(p, "seqtype %d is not supported", p->seqtype); goto bad; }
    if ((rc = pamlh_read_seqs(p))) goto bad;
    if ((rc = pamlh_read_tree(p))) goto bad;
-   if (!(p->seqtype == 1 && p->model == 2)) memset(p->label, 0, p->nnode * sizeof(int));      /* '#' labels only matter to branch models */
+   if (!(p->seqtype == 1 && p->model >= 2)) memset(p->label, 0, p->nnode * sizeof(int));      /* '#' labels only matter to branch models */
+   if (p->seqtype == 1 && p->model >= 2) {
+      int i;
+      for (p->n_omega = 1, i = 0; i < p->nnode; i++) if (p->label[i] + 1 > p->n_omega) p->n_omega = p->label[i] + 1;
+      if (p->nssites && p->model == 2 && p->n_omega != 2) { rc = pamlh_fail(p, "branch-site models need two branch types (label the foreground branches #1), the tree has %d", p->n_omega); goto bad; }
+      if (p->nssites && p->model == 3 && (p->n_omega < 2 || p->n_omega > 16)) { rc = pamlh_fail(p, "clade models need 2..16 branch types, the tree has %d", p->n_omega); goto bad; }
+   }
    if (p->seqtype == 1) freqs_codon(p);
    else freqs_base_aa(p);
    /* parameter bookkeeping (GetInitials): ntime, np */
@@ -246,11 +259,11 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       int nr = 0;
       if (p->seqtype == 1) {
          nr += !p->fix_kappa;
-         if (p->nssites == 0 && p->model == 2) {      /* branch model: one omega per branch label (codeml.c:2170-2183) */
-            int i;
-            for (p->n_omega = 1, i = 0; i < p->nnode; i++) if (p->label[i] + 1 > p->n_omega) p->n_omega = p->label[i] + 1;
-            nr += p->n_omega;
-         }
+         if (p->nssites == 0 && p->model == 2) nr += p->n_omega;      /* branch model: one omega per branch label (codeml.c:2170-2183) */
+         else if (p->model == 2 && p->nssites == 2) nr += 3 + !p->fix_omega;      /* branch-site A: p0 p1 w0 [w2] (codeml.c:2197-2221) */
+         else if (p->model == 2 && p->nssites == 3) nr += 5;                      /* branch-site B: p0 p1 w0 w1 w2 */
+         else if (p->model == 3) nr += 2 + (p->nssites == 3 ? 2 : 1) + p->n_omega - (p->fix_omega != 0);   /* clade C / D (codeml.c:2222-2233) */
+         else if (p->nssites == 3) nr += 2 * p->ncatG - 1;                        /* M3: K-1 proportions, K omegas */
          else if (p->nssites == 0) nr += !p->fix_omega;
          else if (p->nssites == 1) nr += 2;
          else if (p->nssites == 2) nr += 4;
@@ -355,6 +368,20 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
    if (p->seqtype == 1) {
       if (!p->fix_kappa) x[k++] = p->kappa0;
       if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) x[k++] = p->omega0; }
+      else if (p->model == 2 && p->nssites) {      /* branch-site A / B: p0 p1 w0 [w1] [w2] */
+         x[k++] = 0.6; x[k++] = 0.2; x[k++] = 0.25;
+         if (p->nssites == 3) x[k++] = 0.8;
+         if (p->nssites == 3 || !p->fix_omega) x[k++] = p->omega0 > 1 ? p->omega0 : 2.5;
+      }
+      else if (p->model == 3) {                     /* clade C / D: p0 p1 w0 [w1] then one omega per branch type */
+         x[k++] = 0.5; x[k++] = 0.3; x[k++] = 0.25;
+         if (p->nssites == 3) x[k++] = 0.75;
+         for (i = 0; i < p->n_omega - (p->fix_omega != 0); i++) x[k++] = p->omega0 * (1 + 0.25 * i);
+      }
+      else if (p->nssites == 3) {                   /* M3: K-1 proportions, K omegas */
+         for (i = 0; i < p->ncatG - 1; i++) x[k++] = 1.0 / p->ncatG;
+         for (i = 0; i < p->ncatG; i++) x[k++] = 0.1 + 1.4 * i / (p->ncatG - 1);
+      }
       else if (p->nssites == 0) { if (!p->fix_omega) x[k++] = p->omega0; }
       else if (p->nssites == 1) { x[k++] = 0.6; x[k++] = 0.1; }
       else if (p->nssites == 2) { x[k++] = 0.5; x[k++] = 0.3; x[k++] = 0.1; x[k++] = 2.5; }
@@ -435,7 +462,7 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
       p->branch[node] = p->ntime ? x[k++] : p->tree_branch[node];
       if (!p->ntime && p->tree_branch[node] < 0) { free(Q); return pamlh_fail(p, "fix_blength = 2 but the tree has no branch lengths"); }
    }
-   p->n_labels = 1; p->K = 1; p->mode = PAML_AMD_MODE_LFUN; p->n_eigen = 1;
+   p->n_labels = 1; p->K = 1; p->mode = PAML_AMD_MODE_LFUN; p->n_eigen = 1; p->use_qf = 0;
    p->freqK[0] = 1; p->rate[0] = 1; p->eigen_of[0] = 0;
    if (p->seqtype == 1) {
       double kappa = p->fix_kappa ? p->kappa0 : x[k++];
@@ -452,6 +479,42 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          }
          p->n_eigen = p->n_labels = p->n_omega;
       }
+      else if (p->model >= 2) {
+         /* branch-site models A / B and clade models C / D (SetParametersNSsites codeml.c:2459-2660).  Site classes x branch
+          * types pick one of a few omegas:   A/B: back w0 w1 w0 w1, fore w0 w1 w2 w2;   C/D: type b: w0 w1 w_b.
+          * The eigen systems are those of the unscaled Q (mr = 1); every branch type has its own time scale
+          * Qfactor_NS_branch[b] = 1 / mr(Q at the type's mean omega), applied to t in GetPMatBranch (treesub.c:7547-7554, 7587). */
+         const int bs = p->model == 2, nb = p->n_omega, K = bs ? 4 : 3, L = nb, nset = bs ? 3 : 2 + nb;
+         double f[4], wc[2], wb[16], t, wsets[18];
+         int c, l;
+         f[0] = x[k++]; f[1] = x[k++];
+         wc[0] = x[k++]; wc[1] = p->nssites == 3 ? x[k++] : 1;
+         t = f[0] + f[1];
+         if (bs) {
+            wb[0] = wb[1] = (p->nssites == 2 && p->fix_omega) ? p->omega0 : x[k++];
+            f[2] = t > 1e-100 ? (1 - t) * f[0] / t : -1;
+            f[3] = t > 1e-100 ? (1 - t) * f[1] / t : -1;
+         }
+         else {
+            for (l = 0; l < nb; l++) wb[l] = (l == nb - 1 && p->fix_omega) ? p->omega0 : x[k++];
+            f[2] = 1 - t;
+         }
+         wsets[0] = wc[0]; wsets[1] = wc[1];
+         if (bs) wsets[2] = wb[1]; else for (l = 0; l < nb; l++) wsets[2 + l] = wb[l];
+         for (j = 0; j < nset; j++) { codon_q(p, kappa, wsets[j], Q); set_eig_uvroot(p, j, Q, p->pi, 1.0); }
+         for (l = 0; l < L; l++) {
+            double wm, qf;
+            if (bs) wm = l == 0 ? (t > 1e-100 ? (f[0] * wc[0] + f[1] * wc[1]) / t : 1) : f[0] * wc[0] + f[1] * wc[1] + (1 - t) * wb[1];
+            else wm = f[0] * wc[0] + f[1] * wc[1] + f[2] * wb[l];
+            qf = 1 / codon_q(p, kappa, wm, Q);
+            for (c = 0; c < K; c++) {
+               p->qfactor[c * L + l] = qf;
+               p->eigen_of[c * L + l] = bs ? (l == 0 ? c % 2 : (c <= 1 ? c : 2)) : (c < 2 ? c : 2 + l);
+            }
+         }
+         for (c = 0; c < K; c++) { p->freqK[c] = f[c]; p->rate[c] = 1; p->class_w[c] = c < 2 ? wc[c] : wb[nb - 1]; }
+         p->K = K; p->n_eigen = nset; p->n_labels = L; p->mode = PAML_AMD_MODE_LFUNDG; p->use_qf = 1;
+      }
       else if (p->nssites == 0) {
          double w = p->fix_omega ? p->omega0 : x[k++], mr = codon_q(p, kappa, w, Q);
          p->omega = w;
@@ -462,6 +525,11 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          int K;
          if (p->nssites == 1) { f[0] = x[k]; w[0] = x[k + 1]; f[1] = 1 - f[0]; w[1] = 1; K = 2; k += 2; }
          else if (p->nssites == 2) { f[0] = x[k]; f[1] = x[k + 1]; f[2] = 1 - f[0] - f[1]; w[0] = x[k + 2]; w[1] = 1; w[2] = x[k + 3]; K = 3; k += 4; }
+         else if (p->nssites == 3) {      /* M3 (discrete): K-1 proportions then K omegas */
+            K = p->ncatG;
+            for (j = 0, f[K - 1] = 1; j < K - 1; j++) f[K - 1] -= (f[j] = x[k++]);
+            for (j = 0; j < K; j++) w[j] = x[k++];
+         }
          else {   /* M7 / M8: K = ncatG median quantiles of beta(p, q) (DiscreteNSsites codeml.c:2869-2874) */
             const int off = p->nssites == 8;
             const double bp = x[k + off], bq = x[k + off + 1];
@@ -615,7 +683,7 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
       else rc = paml_amd_set_eigen_jc69like(p->eng, i);
       if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    }
-   if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->eigen_of, NULL)) ||
+   if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->eigen_of, p->use_qf ? p->qfactor : NULL)) ||
        (rc = paml_amd_eval(p->eng, p->branch, NULL, lnL, lnf, NULL)))
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    return 0;
@@ -641,7 +709,7 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w)
       else rc = paml_amd_set_eigen_jc69like(p->eng, i);
       if (rc) { free(fhK); return pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); }
    }
-   if ((rc = paml_amd_set_classes(p->eng, p->mode, K, p->freqK, p->rate, 1, p->eigen_of, NULL)) ||
+   if ((rc = paml_amd_set_classes(p->eng, p->mode, K, p->freqK, p->rate, p->n_labels, p->eigen_of, p->use_qf ? p->qfactor : NULL)) ||
        (rc = paml_amd_eval(p->eng, p->branch, NULL, &lnL, NULL, fhK))) {
       free(fhK);
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
@@ -673,7 +741,7 @@ int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double 
    const int ncls = m2a ? 3 : N1 + 1, K = m2a ? 2 * N1 + 1 : 2 * N1, ngrid = N1 * N1 * N1 * N1;
    double rK[2 * N1 + 1], para[4][N1], lnL, fX, *fhK, *pcl, *lnfXs, *Q, kappa, mr;
    int *iw, i, k, g, rc;
-   if (!(p->seqtype == 1 && (p->nssites == 2 || p->nssites == 8))) return pamlh_fail(p, "BEB is defined for NSsites 2 (M2a) and 8 (M8)");
+   if (!(p->seqtype == 1 && p->model == 0 && (p->nssites == 2 || p->nssites == 8))) return pamlh_fail(p, "BEB is defined for NSsites 2 (M2a) and 8 (M8)");
    if (p->scale) for (i = 0; i < p->nnode; i++) if (p->scale[i]) return pamlh_fail(p, "BEB with scaling nodes is not supported yet");
    if ((rc = pamlh_set_x(p, x, p->np))) return rc;
    kappa = p->kappa; mr = p->ns_mr;
@@ -744,6 +812,17 @@ const int *pamlh_pose(const pamlh *p, int *n_sites)
 }
 
 const double *pamlh_class_omega(const pamlh *p) { return p->class_w; }
+const double *pamlh_qfactor(const pamlh *p) { return p->use_qf ? p->qfactor : NULL; }
+
+/* how many of the last site classes allow omega > 1 (the classes whose posterior the reference's NEB table sums):
+ * 1 for M2a, M8 and the clade models, 2 for the branch-site models (classes 2a + 2b), 0 for models without such a class */
+int pamlh_positive_classes(const pamlh *p)
+{
+   if (p->seqtype != 1 || !p->nssites || p->mode != PAML_AMD_MODE_LFUNDG) return 0;
+   if (p->model == 2) return 2;
+   if (p->model == 3 || p->nssites == 2 || p->nssites == 8 || p->nssites == 3) return 1;
+   return 0;
+}
 
 int pamlh_write_lnf(const pamlh *p, const char *path, const double *lnf)
 {

@@ -46,7 +46,8 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
    pamlh **ws = (pamlh **)calloc(nb, sizeof(pamlh *));
    double *br = (double *)calloc((size_t)nb * nn, sizeof(double)), *fk = NULL, *rt = NULL, *rep_fk = NULL, *rep_rt = NULL;
    const double *pi = NULL;
-   int *eo = NULL, *rep_eo = NULL;
+   int *eo = NULL, *rep_eo = NULL, use_qf = 0;
+   double *qf = NULL, *rep_qf = NULL;
    if ((rc = pamlh_engine_ready(p))) goto done;
    for (b = 0; b < nb; b++) {          /* distinct model parts */
       const double *x = xs + (size_t)b * np;
@@ -71,6 +72,8 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
          rep_fk = (double *)malloc((size_t)ncand * K * sizeof(double));
          rep_rt = (double *)malloc((size_t)ncand * K * sizeof(double));
          rep_eo = (int *)malloc((size_t)ncand * K * L * sizeof(int));
+         rep_qf = (double *)malloc((size_t)ncand * K * L * sizeof(double));
+         use_qf = q->use_qf;
       }
       else if (q->K != K || q->n_labels != L || q->n_eigen != n_eigen || q->mode != mode) { rc = pamlh_fail(p, "internal: model shape changed inside a batch"); goto done; }
       if ((nrep + 1) * n_eigen > 4096) { rc = pamlh_fail(p, "batch needs more than 4096 eigen systems"); goto done; }
@@ -79,25 +82,28 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       memcpy(rep_fk + (size_t)nrep * K, q->freqK, K * sizeof(double));
       memcpy(rep_rt + (size_t)nrep * K, q->rate, K * sizeof(double));
       for (i = 0; i < K * L; i++) rep_eo[(size_t)nrep * K * L + i] = nrep * n_eigen + q->eigen_of[i];
+      for (i = 0; i < K * L; i++) rep_qf[(size_t)nrep * K * L + i] = q->use_qf ? q->qfactor[i] : 1.0;
       cand_rep[c] = nrep++;
    }
    if (!nrep) { for (b = 0; b < nb; b++) lnL[b] = -1e300; goto done; }
    fk = (double *)malloc((size_t)nb * K * sizeof(double));
    rt = (double *)malloc((size_t)nb * K * sizeof(double));
    eo = (int *)malloc((size_t)nb * K * L * sizeof(int));
+   qf = (double *)malloc((size_t)nb * K * L * sizeof(double));
    for (b = 0; b < nb; b++) {
       const double *x = xs + (size_t)b * np;
       const int r = cand_rep[cand_of[b]] < 0 ? 0 : cand_rep[cand_of[b]];
       memcpy(fk + (size_t)b * K, rep_fk + (size_t)r * K, K * sizeof(double));
       memcpy(rt + (size_t)b * K, rep_rt + (size_t)r * K, K * sizeof(double));
       memcpy(eo + (size_t)b * K * L, rep_eo + (size_t)r * K * L, (size_t)K * L * sizeof(int));
+      memcpy(qf + (size_t)b * K * L, rep_qf + (size_t)r * K * L, (size_t)K * L * sizeof(double));
       for (i = 0; i < p->nbranch; i++) {
          const int node = p->branch_node[i];
          br[(size_t)b * nn + node] = nt ? x[i] : p->tree_branch[node];
       }
    }
-   if ((rc = paml_amd_set_pi(p->eng, 1, pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, L, rep_eo, NULL)) ||
-       (rc = paml_amd_eval_batch(p->eng, nb, br, NULL, eo, NULL, fk, rt, lnL, lnf))) {
+   if ((rc = paml_amd_set_pi(p->eng, 1, pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, L, rep_eo, use_qf ? rep_qf : NULL)) ||
+       (rc = paml_amd_eval_batch(p->eng, nb, br, NULL, eo, use_qf ? qf : NULL, fk, rt, lnL, lnf))) {
       rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
       goto done;
    }
@@ -105,7 +111,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       if (cand_rep[cand_of[b]] < 0 || !(lnL[b] == lnL[b])) lnL[b] = -1e300;
 done:
    for (c = 0; c < ncand; c++) pamlh_state_free(ws[c]);
-   free(ws); free(cand_of); free(cand_elem); free(cand_rep); free(br); free(fk); free(rt); free(eo); free(rep_fk); free(rep_rt); free(rep_eo);
+   free(ws); free(cand_of); free(cand_elem); free(cand_rep); free(br); free(fk); free(rt); free(eo); free(rep_fk); free(rep_rt); free(rep_eo); free(qf); free(rep_qf);
    return rc;
 }
 
@@ -118,6 +124,20 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
    if (p->seqtype == 1) {
       if (!p->fix_kappa) { lo[k] = 1e-4; hi[k++] = 999; }
       if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) { lo[k] = 1e-4; hi[k++] = 999; } }
+      else if (p->model >= 2) {      /* branch-site A / B, clade C / D (SetxBound codeml.c:1940-1965; proportions untransformed here) */
+         lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 1e-6; hi[k++] = 1 - 1e-6;
+         if (p->model == 2 && p->nssites == 2) { lo[k] = 1e-6; hi[k++] = 1; if (!p->fix_omega) { lo[k] = 1; hi[k++] = 999; } }
+         else if (p->model == 2) { for (i = 0; i < 3; i++) { lo[k] = 1e-6; hi[k++] = 999; } }
+         else {
+            if (p->nssites == 2) { lo[k] = 1e-6; hi[k++] = 1; }
+            else { lo[k] = 1e-4; hi[k++] = 1; lo[k] = 0.01; hi[k++] = 1.5; }
+            for (i = 0; i < p->n_omega - (p->fix_omega != 0); i++) { lo[k] = 1e-6; hi[k++] = 999; }
+         }
+      }
+      else if (p->nssites == 3) {
+         for (i = 0; i < p->ncatG - 1; i++) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; }
+         for (i = 0; i < p->ncatG; i++) { lo[k] = 1e-6; hi[k++] = 999; }
+      }
       else if (p->nssites == 0) { if (!p->fix_omega) { lo[k] = 1e-4; hi[k++] = 999; } }
       else if (p->nssites == 1) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 1e-6; hi[k++] = 1; }
       else if (p->nssites == 2) {

@@ -130,7 +130,11 @@ class Analysis:
                 e.update(kappa=kappa.value)
             eig.append(e)
         scale = _arr(L.pamlh_scale_nodes(h), np.uint8, nn)
-        return Problem(n=n, tree=tree, z=_arr(L.pamlh_tips(h), np.uint8, self.n_tips * self.n_patt).reshape(self.n_tips, self.n_patt),
+        L.pamlh_qfactor.restype = C.c_void_p
+        L.pamlh_qfactor.argtypes = [C.c_void_p]
+        qf = L.pamlh_qfactor(h)
+        return Problem(qfactor=None if not qf else _arr(qf, np.float64, K * n_labels).reshape(K, n_labels),
+                       n=n, tree=tree, z=_arr(L.pamlh_tips(h), np.uint8, self.n_tips * self.n_patt).reshape(self.n_tips, self.n_patt),
                        weights=_arr(L.pamlh_weights(h), np.float64, self.n_patt), pi=_arr(L.pamlh_pi(h), np.float64, n), eigen=eig,
                        mode=mode, freqK=_arr(L.pamlh_freqK(h), np.float64, K), rate=_arr(L.pamlh_rate(h), np.float64, K),
                        eigen_of=_arr(L.pamlh_eigen_of(h), np.int32, K * n_labels).reshape(1, K, n_labels), cleandata=self.cleandata,

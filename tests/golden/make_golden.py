@@ -283,7 +283,34 @@ def case_mhc():
                 scale_nodes=[int(v) for v in scal.group(2).split()] if scal else None))
 
 
+def case_mle(name, ctl_over, files, n_tips, kind, x0=None):
+    """Branch-site / clade / discrete models: the reference first maximises the likelihood from its own initial values (or x0),
+    then the golden is the single evaluation at the printed 6-decimal estimates (the -1 recipe), whose lnL must agree with
+    the maximised value to ~1e-5."""
+    ctl = dict(CODEML_BASE, outfile="mlc", **ctl_over)
+    res = run_ref("codeml", ctl, files) if x0 is None else run_ref("codeml", ctl, files, x=None)
+    xs = re.search(r"lnL\(ntime:\s*(\d+)[^\n]*\n[^\n]*\n([^\n]+)\n", res["main"])
+    ntime = int(xs.group(1))
+    x = [float(v) for v in xs.group(2).split()]
+    print("   %s: reference MLE lnL %.6f, np %d" % (name, res["lnL"], len(x)))
+    res1 = run_ref("codeml", ctl, files, x=x)
+    finish(name, res1, "codon", n_tips, dict(program="codeml", model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG") if k in ctl_over}),
+                                             x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
+
+
+LYSO = {"lysozymeLarge.nuc": EX + "/lysozyme/lysozymeLarge.nuc", "lysozymeLarge.trees": EX + "/lysozyme/lysozymeLarge.trees"}
+LYSO_CTL = dict(seqfile="lysozymeLarge.nuc", treefile="lysozymeLarge.trees", kappa=3, cleandata=0)
+ECP = {"ECP_EDN_15.nuc": EX + "/CladeModelCD/ECP_EDN_15.nuc", "tree.txt": EX + "/CladeModelCD/tree.txt"}
+ECP_CTL = dict(seqfile="ECP_EDN_15.nuc", treefile="tree.txt", kappa=2.5, omega=0.13579, ncatG=3, cleandata=0, Small_Diff=".2e-6")
+HIVF = {"HIVenvSweden.txt": EX + "/HIVNSsites/HIVenvSweden.txt", "HIVenvSweden.trees": EX + "/HIVNSsites/HIVenvSweden.trees"}
+
 CASES = {
+    "lyso_bsa": lambda: case_mle("lyso_bsa", dict(LYSO_CTL, model=2, NSsites=2, omega=1.5), LYSO, 19, "codon_branchsite"),
+    "lyso_bsa_null": lambda: case_mle("lyso_bsa_null", dict(LYSO_CTL, model=2, NSsites=2, fix_omega=1, omega=1), LYSO, 19, "codon_branchsite"),
+    "lyso_bsb": lambda: case_mle("lyso_bsb", dict(LYSO_CTL, model=2, NSsites=3, omega=1.5), LYSO, 19, "codon_branchsite"),
+    "ecp_cmc": lambda: case_mle("ecp_cmc", dict(ECP_CTL, model=3, NSsites=2), ECP, 15, "codon_clade"),
+    "ecp_cmd": lambda: case_mle("ecp_cmd", dict(ECP_CTL, model=3, NSsites=3), ECP, 15, "codon_clade"),
+    "hiv_m3": lambda: case_mle("hiv_m3", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=3, ncatG=3, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_m0": lambda: case_hiv("m0"), "hiv_m1a": lambda: case_hiv("m1a"), "hiv_m2a": lambda: case_hiv("m2a"),
     "hiv_m7": lambda: case_hiv("m7"), "hiv_m8": lambda: case_hiv("m8"),
     "stewart_lg_g4": case_stewart, "mhc_m0_scaled": case_mhc,

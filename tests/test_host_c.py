@@ -16,7 +16,10 @@ CTL = os.path.join(helpers.GOLDEN, "ctl")
 CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml", "stewart_lg_g4.ctl"),
          ("hiv_m0", "codeml", "hiv_ns0.ctl"), ("hiv_m1a", "codeml", "hiv_ns1.ctl"), ("hiv_m2a", "codeml", "hiv_ns2.ctl"),
          ("hiv_m7", "codeml", "hiv_ns7.ctl"), ("hiv_m8", "codeml", "hiv_ns8.ctl"), ("mhc_m0_scaled", "codeml", "mhc_m0.ctl"),
-         ("mtcdna_branch", "codeml", "mtcdna_branch.ctl")]
+         ("mtcdna_branch", "codeml", "mtcdna_branch.ctl"),
+         # branch-site A (alternative and null), B; clade C, D; M3 — goldens at the reference's own 6-decimal MLEs
+         ("lyso_bsa", "codeml", "lyso_bsa.ctl"), ("lyso_bsa_null", "codeml", "lyso_bsa_null.ctl"), ("lyso_bsb", "codeml", "lyso_bsb.ctl"),
+         ("ecp_cmc", "codeml", "ecp_cmc.ctl"), ("ecp_cmd", "codeml", "ecp_cmd.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl")]
 
 
 def _x(g, a):
@@ -43,7 +46,7 @@ def test_c_host_reproduces_reference_on_cpu(gname, prog, ctl):
 
 def test_c_host_rejects_what_it_does_not_support(tmp_path):
     ctl = tmp_path / "x.ctl"
-    ctl.write_text("seqfile = %s\ntreefile = %s\nseqtype = 1\nmodel = 2\nNSsites = 2\n" %
+    ctl.write_text("seqfile = %s\ntreefile = %s\nseqtype = 1\nmodel = 1\nNSsites = 0\n" %
                    (os.path.join(helpers.GOLDEN, "data", "HIVenvSweden.txt"), os.path.join(helpers.GOLDEN, "data", "HIVenvSweden.trees")))
     with pytest.raises(RuntimeError, match="not supported"):
         hostlib.Analysis(str(ctl), "codeml")
@@ -108,6 +111,22 @@ def test_c_host_optimiser_finds_the_reference_mle(gname, prog, ctl):
     gx = np.array(g["x"])
     free = gx > 1e-5                                   # a zero-length branch sits on the boundary in both programs
     assert np.max(np.abs(r["x"][free] - gx[free]) / (np.abs(gx[free]) + 0.01)) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname,ctl", [("lyso_bsa", "lyso_bsa.ctl"), ("lyso_bsa_null", "lyso_bsa_null.ctl"), ("ecp_cmc", "ecp_cmc.ctl")])
+def test_c_host_optimiser_on_branch_site_and_clade_models(gname, ctl):
+    """Branch-site model A (alternative and null of the branch-site test, lysozyme data of examples/lysozyme) and clade model C
+    (examples/CladeModelCD): four / three site classes x two branch types, eigen systems picked per (class, label) and one
+    time scale per branch type (Qfactor_NS_branch).  The optimiser started from the host's own initial values must end at
+    least as high as the reference's optimiser did (these surfaces have local optima, so "at least", not "equal")."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), "codeml")
+    r = a.optimize(a.default_x())
+    assert r["converged"]
+    assert r["lnL"] >= g["mle_lnL"] - 5e-5, (r["lnL"], g["mle_lnL"])
+    r1 = a.optimize(np.array(g["x"]))                  # and from the reference's estimates nothing is left to gain
+    assert abs(r1["lnL"] - g["mle_lnL"]) < 5e-5, (r1["lnL"], g["mle_lnL"])
 
 
 @pytest.mark.gpu
