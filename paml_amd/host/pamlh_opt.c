@@ -189,6 +189,39 @@ static int gradient(pamlh *p, const double *x, double f0, const double *lo, cons
    return 0;
 }
 
+/* H := diag(1 / f''_ii) from one batch of second differences (step 1e-4 (|x_i| + 1): large enough that curvatures down to
+ * ~1e-3 rise above the rounding of lnL).  The parameters' curvatures span many orders of magnitude (branch lengths ~1e5,
+ * an omega of a small site class ~1e-2), and BFGS started from a multiple of the identity spends dozens of iterations
+ * learning that — or stalls on the flat directions.  Variables on a bound, or with no usable curvature, get the median. */
+static int diag_inverse_hessian(pamlh *p, const double *x, double f0, const double *lo, const double *hi, double *H, double *xs, double *ls, int *n_eval)
+{
+   const int n = p->np;
+   int i, rc, m = 0;
+   double *hd = (double *)malloc(2 * n * sizeof(double)), *srt = hd + n, med;
+   for (i = 0; i < n; i++) {
+      const double h = 1e-4 * (fabs(x[i]) + 1);
+      double *xp = xs + (size_t)(2 * i) * n, *xm = xp + n;
+      memcpy(xp, x, n * sizeof(double));
+      memcpy(xm, x, n * sizeof(double));
+      xp[i] = x[i] + h; xm[i] = x[i] - h;
+      if (xp[i] > hi[i] || xm[i] < lo[i]) xp[i] = xm[i] = x[i];      /* no room for a symmetric difference */
+   }
+   if ((rc = pamlh_eval_batch_gpu(p, 2 * n, xs, ls))) { free(hd); return rc; }
+   *n_eval += 2 * n;
+   for (i = 0; i < n; i++) {
+      const double *xp = xs + (size_t)(2 * i) * n;
+      const double h = xp[i] - x[i], c = h > 0 ? ((-ls[2 * i]) - 2 * f0 + (-ls[2 * i + 1])) / (h * h) : 0;
+      hd[i] = (c > 1e-3 && c < 1e12 && ls[2 * i] > -1e299 && ls[2 * i + 1] > -1e299) ? 1 / c : 0;
+      if (hd[i] > 0) srt[m++] = hd[i];
+   }
+   for (i = 1; i < m; i++) { double v = srt[i]; int j = i - 1; while (j >= 0 && srt[j] > v) { srt[j + 1] = srt[j]; j--; } srt[j + 1] = v; }
+   med = m ? srt[m / 2] : 1;
+   for (i = 0; i < n * n; i++) H[i] = 0;
+   for (i = 0; i < n; i++) H[i * n + i] = hd[i] > 0 ? hd[i] : med;
+   free(hd);
+   return 0;
+}
+
 /* Maximise lnL over x (in: start, out: estimate).  Returns 0 when converged, 1 when max_iter was reached, < 0 on error. */
 int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, int verbose, int *n_eval_out)
 {
@@ -199,8 +232,8 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
    double *H = (double *)malloc((size_t)n * n * sizeof(double));
    double *xs = (double *)malloc((size_t)(2 * n + NC) * n * sizeof(double)), *ls = (double *)malloc((2 * n + NC) * sizeof(double));
    unsigned char *fixed = (unsigned char *)malloc(n);
-   double f, fnew = 0, as[16];
-   int it, i, j, k, rc = 0, n_eval = 0, reset = 1, small_steps = 0, status = 1;
+   double f, fnew = 0, as[16], f_restart = 1e300;
+   int it, i, j, k, rc = 0, n_eval = 0, reset = 1, small_steps = 0, status = 1, restarts = 0, fresh = 1;
    if (n == 0) { rc = pamlh_eval_batch_gpu(p, 1, x, lnL); status = 0; goto done; }
    if (pamlh_bounds(p, lo, hi)) { rc = pamlh_fail(p, "internal: bounds do not match np"); goto done; }
    for (i = 0; i < n; i++) x[i] = x[i] < lo[i] ? lo[i] : x[i] > hi[i] ? hi[i] : x[i];
@@ -208,8 +241,8 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
    n_eval++;
    f = -ls[0];
    if (f > 1e299) { rc = pamlh_fail(p, "the starting point is infeasible"); goto done; }
-   for (i = 0; i < n * n; i++) H[i] = 0;
-   for (i = 0; i < n; i++) H[i * n + i] = 1;
+   if ((rc = diag_inverse_hessian(p, x, f, lo, hi, H, xs, ls, &n_eval))) goto done;
+   reset = 0;
    if ((rc = gradient(p, x, f, lo, hi, g, xs, ls, &n_eval))) goto done;
    for (it = 0; it < max_iter; it++) {
       double amax = 1e300, best = f, abest = 0, gd, sy;
@@ -258,10 +291,9 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
             if (-ls[j] < best) { best = -ls[j]; abest = as[j]; }
       }
       if (abest == 0) {         /* no step length improves f */
-         if (!reset) {          /* distrust the curvature information once before giving up */
-            for (i = 0; i < n * n; i++) H[i] = 0;
-            for (i = 0; i < n; i++) H[i * n + i] = 1;
-            reset = 1;
+         if (!fresh) {          /* distrust the curvature information once before giving up */
+            if ((rc = diag_inverse_hessian(p, x, f, lo, hi, H, xs, ls, &n_eval))) goto done;
+            fresh = 1;
             continue;
          }
          status = 0;
@@ -276,10 +308,15 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
       }
       memcpy(g0, g, n * sizeof(double));
       if ((rc = gradient(p, x, fnew, lo, hi, g, xs, ls, &n_eval))) goto done;
-      if (verbose)
-         fprintf(stderr, "iter %3d  lnL %.6f  step %.3g  |g| %.3g  evals %d\n", it + 1, -fnew, abest, sqrt(dot(g, g, n)), n_eval);
+      if (verbose) {
+         double gf = 0;
+         for (i = 0; i < n; i++) if (!((x[i] <= lo[i] && g[i] > 0) || (x[i] >= hi[i] && g[i] < 0))) gf += g[i] * g[i];
+         fprintf(stderr, "iter %3d  lnL %.6f  step %.3g  |g free| %.3g  evals %d\n", it + 1, -fnew, abest, sqrt(gf), n_eval);
+      }
       /* BFGS update of the inverse Hessian */
-      for (i = 0; i < n; i++) y[i] = g[i] - g0[i];
+      /* (in the subspace of the variables that moved: a variable held on its bound has s = 0, and its gradient change —
+       * often the largest of all, e.g. an omega class pinned at 0 — would only corrupt the curvature of the others) */
+      for (i = 0; i < n; i++) y[i] = fixed[i] ? 0 : g[i] - g0[i];
       sy = dot(s, y, n);
       if (sy > 1e-14 * sqrt(dot(s, s, n) * dot(y, y, n))) {
          double yHy;
@@ -295,13 +332,25 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
                H[i * n + j] += (1 + yHy / sy) * s[i] * s[j] / sy - (Hy[i] * s[j] + s[i] * Hy[j]) / sy;
          reset = 0;
       }
+      fresh = 0;
       {
          double smax = 0;
          for (i = 0; i < n; i++) { const double r = fabs(s[i]) / (fabs(x[i]) + 1); if (r > smax) smax = r; }
          small_steps = (f - fnew < tol * (fabs(fnew) + 1) && smax < 1e-5) ? small_steps + 1 : 0;
       }
       f = fnew;
-      if (small_steps >= 2) { status = 0; break; }
+      if (small_steps >= 2) {
+         /* Two tiny steps in a row: either the maximum, or an inverse Hessian that has gone bad on a ridge (the site-class
+          * models have them: proportions against omegas).  Forget the curvature and go on from steepest descent; stop when
+          * such a restart (from the diagonal second differences) no longer gains anything. */
+         if (restarts < 8 && f_restart - f > 1e-7 * (fabs(f) + 1)) {
+            f_restart = f; restarts++; small_steps = 0; fresh = 1;
+            if ((rc = diag_inverse_hessian(p, x, f, lo, hi, H, xs, ls, &n_eval))) goto done;
+            continue;
+         }
+         status = 0;
+         break;
+      }
    }
    *lnL = -f;
    /* leave the model state at the estimate */
