@@ -131,6 +131,12 @@ int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *ge
 int paml_amd_beb_grid(paml_amd_engine *e, int n_grid, int n_cls, const double *pcl, const int *iw, const double *w_class,
                       double *ln_fx, double *pr_last, double *mean_w, double *sd_w);
 
+/* The same grid integral returning the posterior of EVERY mixture class — what lfunNSsites_ACD (codeml.c:6827-7010) computes
+ * for branch-site model A (4 classes per grid point drawn from 121 evaluated (background, foreground) omega pairs, table 1 of
+ * Yang, Wong & Nielsen 2005) and the clade models.  Any K (the class likelihoods are read from memory), n_cls <= 8.
+ * post[n_cls][n_patt]; ln_fx as above. */
+int paml_amd_beb_grid_classes(paml_amd_engine *e, int n_grid, int n_cls, const double *pcl, const int *iw, double *ln_fx, double *post);
+
 /* n_batch evaluations in one launch: the finite-difference loops of the optimiser (gradientB tools.c:6561, the forward /
  * central differences of ming2 tools.c:6595 and of the Hessian, HessianSKT2004 treesub.c:7241) call com.plfun np (or 2np,
  * np^2) times on the same data with one parameter nudged; here those calls become the elements of one batch.  Element b

@@ -1150,6 +1150,7 @@ __global__ __launch_bounds__(256) void posterior_kernel(PostArgs a)
 // One pattern per lane with its K class values in registers; the grid tables are wave-uniform (scalar loads).
 // ------------------------------------------------------------------------------------------------
 #define BEB_MAXK 32
+#define BEB_MAXCLS 8
 struct BebArgs {
    int n_patt, K, n_grid, n_cls, n_pblk, patt_per_blk;
    const double *fhK, *weights;
@@ -1267,6 +1268,34 @@ __global__ __launch_bounds__(256) void beb_post(BebArgs a)
       const double v = m2 - m1 * m1;
       a.sd_w[h] = v > 0 ? sqrt(v) : 0.0;
    }
+}
+
+// Posterior of every mixture class (lfunNSsites_ACD codeml.c:6970-6985: branch-site model A has 4, its 121 evaluated classes
+// do not fit the register file, so f is read through L2 — the index is wave-uniform, the access coalesced over patterns):
+// post[c][h] = sum_g wg[g] pcl[g][c] f[iw[g][c]][h] / fh(g, h).
+__global__ __launch_bounds__(256) void beb_post_classes(BebArgs a)
+{
+   const int h = blockIdx.x * 256 + threadIdx.x;
+   if (h >= a.n_patt) return;
+   double post[BEB_MAXCLS], t[BEB_MAXCLS];
+#pragma unroll
+   for (int c = 0; c < BEB_MAXCLS; c++) post[c] = 0;
+   for (int g = 0; g < a.n_grid; g++) {
+      const CONST_AS double *pc = as_const(a.pcl + (long)g * a.n_cls);
+      const CONST_AS int *ix = as_const(a.iw + (long)g * a.n_cls);
+      const double wg = as_const(a.wg)[g];
+      double fh = 0;
+#pragma unroll
+      for (int c = 0; c < BEB_MAXCLS; c++) {
+         t[c] = c < a.n_cls ? pc[c] * a.f[(long)ix[c] * a.n_patt + h] : 0.0;
+         fh += t[c];
+      }
+      if (fh < 1e-300) continue;
+      const double inv = wg / fh;
+#pragma unroll
+      for (int c = 0; c < BEB_MAXCLS; c++) post[c] = fma(t[c], inv, post[c]);
+   }
+   for (int c = 0; c < a.n_cls; c++) a.pr_last[(long)c * a.n_patt + h] = post[c];
 }
 
 }  // namespace paml_amd

@@ -25,7 +25,7 @@ EXPORTS = [
     "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
-    "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
+    "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
@@ -242,6 +242,17 @@ class Engine:
                                               C.c_void_p, C.c_void_p, C.c_void_p]
         self._chk(self._L.paml_amd_beb_grid(self._h, pcl.shape[0], pcl.shape[1], _p(pcl), _p(iw), _p(wc), C.byref(lnfx), _p(pr), _p(mw), _p(sd)))
         return dict(ln_fx=lnfx.value, pr_last=pr, mean_w=mw, sd_w=sd)
+
+    def beb_grid_classes(self, pcl, iw):
+        """Posterior of every mixture class over the grid (paml_amd_beb_grid_classes) -> dict(ln_fx, post[n_cls][n_patt])."""
+        pcl = np.ascontiguousarray(pcl, dtype=np.float64)
+        iw = np.ascontiguousarray(iw, dtype=np.int32)
+        assert pcl.shape == iw.shape and pcl.ndim == 2
+        lnfx = C.c_double()
+        post = np.zeros((pcl.shape[1], self.n_patt))
+        self._L.paml_amd_beb_grid_classes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
+        self._chk(self._L.paml_amd_beb_grid_classes(self._h, pcl.shape[0], pcl.shape[1], _p(pcl), _p(iw), C.byref(lnfx), _p(post)))
+        return dict(ln_fx=lnfx.value, post=post)
 
     def eval_device(self, branch, d_lnL_ptr, gene_rate=None):
         b = np.ascontiguousarray(branch, dtype=np.float64)

@@ -60,6 +60,17 @@ int main(int argc, char **argv)
                if (pr > 0.5) printf("%7d   %7.3f   %9.3f\n", h + 1, pr, mw[pose[h]]);
             }
          }
+         if (npos == 2) {  /* branch-site model A: BEB over (p0, p1, w0, w2), classes 2a + 2b */
+            double *bp = (double *)malloc((size_t)4 * npatt * sizeof(double));
+            if (!pamlh_beb_branchsite(p, x, bp)) {
+               printf("\nBayes Empirical Bayes (BEB): positive sites for foreground lineages Prob(w>1) > 0.5\n   site   Pr(w>1)\n");
+               for (h = 0; h < n_sites; h++) {
+                  const double pr = bp[(size_t)2 * npatt + pose[h]] + bp[(size_t)3 * npatt + pose[h]];
+                  if (pr > 0.5) printf("%7d   %7.3f%s\n", h + 1, pr, pr > 0.99 ? "**" : pr > 0.95 ? "*" : "");
+               }
+            }
+            free(bp);
+         }
          if (npos == 1) {  /* M2a / M8: the BEB table as well */
             double *pr = (double *)malloc(npatt * sizeof(double)), *sw = (double *)malloc(npatt * sizeof(double));
             if (!pamlh_beb(p, x, pr, mw, sw)) {

@@ -805,6 +805,65 @@ int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double 
    return pamlh_set_x(p, x, p->np);      /* back to the model's own classes */
 }
 
+/* Bayes empirical Bayes under branch-site model A (lfunNSsites_ACD codeml.c:6827-7010; Yang, Wong & Nielsen 2005 table 1).
+ * Priors p0,p1 ~ Dir(1,1,1) on the ternary grid, w0 ~ U(0,1), w2 ~ U(1,11), ten bins each; branch lengths, kappa and the two
+ * branch-type time scales stay at the estimates x.  f(x_h | background omega, foreground omega) is needed for 121 pairs
+ * (10 w0, w1 = 1, 10 x 10 (w0, w2), 10 (1, w2)): one evaluation with 121 classes over 21 eigen systems, on an engine of its
+ * own (the analysis' engine is sized for the model's classes).  post[4][npatt]: posterior of classes 0, 1, 2a, 2b. */
+int pamlh_beb_branchsite(pamlh *p, const double *x, double *post)
+{
+   enum { N1 = 10, KW = 2 * N1 + 1, KC = N1 + 1 + N1 * N1 + N1, NG = N1 * N1 * N1 * N1 };
+   const int n = p->n;
+   paml_amd_engine *e = NULL;
+   double wv[KW], qf[KC * 2], fk[KC], rt[KC], lnL, fX, *Q, *U, *V, *R, *pcl = NULL, kappa;
+   int eo[KC * 2], *iw = NULL, i, k, g, rc;
+   if (!(p->seqtype == 1 && p->model == 2 && p->nssites == 2)) return pamlh_fail(p, "this BEB is defined for branch-site model A (model 2, NSsites 2)");
+   if (p->scale) for (i = 0; i < p->nnode; i++) if (p->scale[i]) return pamlh_fail(p, "BEB with scaling nodes is not supported yet");
+   if ((rc = pamlh_set_x(p, x, p->np))) return rc;
+   kappa = p->kappa;
+   for (i = 0; i < N1; i++) { wv[i] = (i + 0.5) / N1; wv[N1 + 1 + i] = 1 + 10 * (i + 0.5) / N1; }
+   wv[N1] = 1;
+   for (k = 0; k < KC; k++) {       /* (background, foreground) omega of the 121 evaluated classes (codeml.c:6685-6705) */
+      int b, f;
+      if (k < N1) b = f = k;
+      else if (k == N1) b = f = N1;
+      else if (k < N1 + 1 + N1 * N1) { b = (k - N1 - 1) / N1; f = N1 + 1 + (k - N1 - 1) % N1; }
+      else { b = N1; f = N1 + 1 + (k - N1 - 1 - N1 * N1); }
+      eo[k * 2] = b; eo[k * 2 + 1] = f;
+      qf[k * 2] = p->qfactor[0]; qf[k * 2 + 1] = p->qfactor[1];      /* Qfactor_NS_branch stays at the MLE (treesub.c:7556-7566) */
+      fk[k] = 1.0 / KC; rt[k] = 1;
+   }
+   if ((rc = paml_amd_create(&e, n, p->ns, p->npatt, KC, 1, 0))) return pamlh_fail(p, "paml_amd_create failed (%d)", rc);
+   Q = (double *)malloc((size_t)4 * n * n * sizeof(double)); U = Q + (size_t)n * n; V = U + (size_t)n * n; R = V + (size_t)n * n;
+   rc = paml_amd_set_tips(e, p->z, p->cleandata, p->n_codes, p->n_chara, p->chara_map, p->w, NULL);
+   if (!rc) rc = paml_amd_set_tree(e, p->nnode, p->root, p->sons_ptr, p->sons, p->label, p->scale);
+   if (!rc) rc = paml_amd_set_pi(e, 1, p->pi);
+   for (k = 0; k < KW && !rc; k++) {
+      codon_q(p, kappa, wv[k], Q);
+      pamlh_eigen_qrev(Q, p->pi, n, R, U, V);
+      rc = paml_amd_set_eigen_uvroot(e, k, U, V, R);
+   }
+   if (!rc) rc = paml_amd_set_classes(e, PAML_AMD_MODE_LFUNDG, KC, fk, rt, 2, eo, qf);
+   if (!rc) rc = paml_amd_eval(e, p->branch, NULL, &lnL, NULL, NULL);
+   free(Q);
+   if (rc) { pamlh_fail(p, "%s", paml_amd_last_error(e)); paml_amd_destroy(e); return rc; }
+   /* proportions and class index of the four site classes at every grid point (get_pclassM_iw_ACD codeml.c:6760-6800) */
+   pcl = (double *)malloc((size_t)NG * 4 * sizeof(double));
+   iw = (int *)malloc((size_t)NG * 4 * sizeof(int));
+   for (g = 0; g < NG; g++) {
+      const int ip0 = g / 1000, ip1 = (g / 100) % 10, ip2 = (g / 10) % 10, ip3 = g % 10;
+      const int tri = ip0 * N1 + ip1, ix = (int)sqrt((double)tri), iy = tri - ix * ix;
+      const double p0 = (1 + (iy / 2) * 3 + (iy % 2)) / (3.0 * N1), p1 = (1 + (N1 - 1 - ix) * 3 + (iy % 2)) / (3.0 * N1), p2 = 1 - p0 - p1;
+      pcl[g * 4] = p0; pcl[g * 4 + 1] = p1; pcl[g * 4 + 2] = p2 * p0 / (1 - p2); pcl[g * 4 + 3] = p2 * p1 / (1 - p2);
+      iw[g * 4] = ip2; iw[g * 4 + 1] = N1; iw[g * 4 + 2] = N1 + 1 + ip2 * N1 + ip3; iw[g * 4 + 3] = N1 + 1 + N1 * N1 + ip3;
+   }
+   rc = paml_amd_beb_grid_classes(e, NG, 4, pcl, iw, &fX, post);
+   if (rc) pamlh_fail(p, "%s", paml_amd_last_error(e));
+   free(pcl); free(iw);
+   paml_amd_destroy(e);
+   return rc;
+}
+
 const int *pamlh_pose(const pamlh *p, int *n_sites)
 {
    if (n_sites) *n_sites = p->n_pose;

@@ -199,6 +199,19 @@ class Analysis:
         pose = _arr(ptr, np.int32, ns.value)
         return post[:, pose], mw[pose]
 
+    def beb_branchsite(self, x):
+        """BEB under branch-site model A at x: posterior of site classes 0, 1, 2a, 2b per site, [4][n_sites] (pamlh_beb_branchsite)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        post = np.zeros((4, self.n_patt))
+        self._L.pamlh_beb_branchsite.argtypes = [C.c_void_p] * 3
+        if self._L.pamlh_beb_branchsite(self._h, x.ctypes.data_as(C.c_void_p), post.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("pamlh_beb_branchsite: " + self._L.pamlh_error(self._h).decode())
+        ns = C.c_int()
+        self._L.pamlh_pose.restype = C.c_void_p
+        self._L.pamlh_pose.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        pose = _arr(self._L.pamlh_pose(self._h, C.byref(ns)), np.int32, ns.value)
+        return post[:, pose]
+
     def beb(self, x):
         """BEB under M2a / M8 at x: (Pr(w>1), mean omega, sd omega) per site (pamlh_beb)."""
         x = np.ascontiguousarray(x, dtype=np.float64)

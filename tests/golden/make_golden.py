@@ -294,7 +294,14 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None):
     x = [float(v) for v in xs.group(2).split()]
     print("   %s: reference MLE lnL %.6f, np %d" % (name, res["lnL"], len(x)))
     res1 = run_ref("codeml", ctl, files, x=x)
-    finish(name, res1, "codon", n_tips, dict(program="codeml", model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG") if k in ctl_over}),
+    tables = {}
+    for key, head in (("neb_post", "Naive Empirical Bayes (NEB) probabilities for"), ("beb_post", "Bayes Empirical Bayes (BEB) probabilities for")):
+        if head in res1["rst"]:      # per-site class posteriors as the reference writes them to `rst` (5 decimals)
+            blk = res1["rst"][res1["rst"].index(head):]
+            rows = re.findall(r"^\s*\d+ \S\s+((?:[01]\.\d{5}\s+)+)\(\s*\d+\)", blk, re.M)
+            ls = int([ln for ln in res1["lnf"] if ln.split()][0].split()[1])
+            tables[key] = [[float(v) for v in r.split()] for r in rows[:ls]]
+    finish(name, res1, "codon", n_tips, dict(tables, program="codeml", model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG") if k in ctl_over}),
                                              x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
 
 

@@ -449,6 +449,31 @@ def test_beb_grid_matches_numpy_restatement():
     assert (got["pr_last"][~m] == 0).all()
 
 
+def test_beb_grid_classes_matches_numpy_restatement():
+    """paml_amd_beb_grid_classes (posterior of every mixture class, lfunNSsites_ACD codeml.c:6970-6985) with more evaluated
+    classes than the register-resident kernel takes (K = 40 > 32) against numpy; class posteriors sum to 1 per pattern."""
+    K, ncls, ngrid = 40, 4, 300
+    pb = helpers.random_problem(20, 7, 1500, K=K, seed=33)
+    rng = np.random.default_rng(9)
+    pb.weights = rng.integers(0, 3, pb.n_patt).astype(float)
+    eng = engine_for(pb)
+    out = eng.eval(pb.tree.branch, pb.gene_rate, want_fhk=True)
+    pcl = rng.dirichlet(np.ones(ncls), size=ngrid)
+    iw = rng.integers(0, K, size=(ngrid, ncls)).astype(np.int32)
+    got = eng.beb_grid_classes(pcl, iw)
+    m = pb.weights > 0
+    f = out["fhK"][:, m] / out["fhK"][:, m].max(axis=0, keepdims=True)
+    mix = np.einsum("gc,gch->gh", pcl, f[iw])
+    lnfxs = (np.log(mix) * pb.weights[m]).sum(axis=1)
+    fx = np.log(np.exp(lnfxs - lnfxs.max()).sum()) + lnfxs.max()
+    post = (pcl[:, :, None] * f[iw] / mix[:, None, :] * np.exp(lnfxs - fx)[:, None, None]).sum(axis=0)
+    assert abs(got["ln_fx"] - fx) <= 1e-9 * abs(fx)
+    assert np.allclose(got["post"][:, m], post, rtol=1e-9, atol=1e-12)
+    assert np.allclose(got["post"][:, m].sum(axis=0), 1, atol=1e-9)
+    with pytest.raises(RuntimeError):
+        eng.beb_grid_classes(np.full((2, 9), 1 / 9), np.zeros((2, 9), dtype=np.int32))      # more than 8 mixture classes
+
+
 @pytest.mark.parametrize("n,K,amb,every", [(4, 1, False, None), (4, 3, True, 3), (20, 2, False, None), (61, 2, True, None)])
 def test_node_posterior_matches_oracle(n, K, amb, every):
     """paml_amd_node_posterior (marginal ancestral reconstruction: one fused walk of the tree rooted at the node) against the

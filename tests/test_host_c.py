@@ -134,6 +134,24 @@ def test_c_host_optimiser_on_branch_site_and_clade_models(gname, ctl):
 
 
 @pytest.mark.gpu
+def test_c_host_branch_site_neb_and_beb_match_the_reference_rst():
+    """Branch-site model A on the lysozyme data: the per-site posteriors of the four site classes (0, 1, 2a, 2b) the reference
+    writes to `rst` — naive empirical Bayes at the estimates, and Bayes empirical Bayes over the 10^4-point grid of
+    (p0, p1, w0, w2) with 121 (background, foreground) omega pairs evaluated in one launch (lfunNSsites_ACD) — printed with
+    5 decimals; and the mlc table "Positive sites for foreground lineages" (sites 14 21 23 37 41 50 62 87 126)."""
+    g = helpers.load_golden("lyso_bsa")
+    a = hostlib.Analysis(os.path.join(CTL, "lyso_bsa.ctl"), "codeml")
+    x = np.array(g["x"])
+    post, _ = a.neb(x)
+    assert np.max(np.abs(post.T - np.array(g["neb_post"]))) < 2e-5
+    beb = a.beb_branchsite(x)
+    assert np.max(np.abs(beb.T - np.array(g["beb_post"]))) < 2e-5
+    pos = beb[2] + beb[3]
+    assert [int(i) + 1 for i in np.nonzero(pos > 0.5)[0]] == [14, 21, 23, 37, 41, 50, 62, 87, 126]
+    assert abs(pos[13] - 0.859) < 6e-4 and abs(pos[86] - 0.869) < 6e-4
+
+
+@pytest.mark.gpu
 def test_c_host_batch_matches_single_evaluations():
     g = helpers.load_golden("hiv_m2a")
     a = hostlib.Analysis(os.path.join(CTL, "hiv_ns2.ctl"), "codeml")
