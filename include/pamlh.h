@@ -85,9 +85,10 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w);
  * w > 1 class, posterior mean and sd of omega, per pattern [n_patt].  f(x_h | w) for the grid's omegas is one evaluation on
  * the device; the 10^4-point grid sums run on the host. */
 int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double *se_w);
-/* BEB under branch-site model A (lfunNSsites_ACD codeml.c:6827): post[4][n_patt] = posterior of site classes 0, 1, 2a, 2b;
- * Pr(positive selection on the foreground) = post[2] + post[3]. */
-int pamlh_beb_branchsite(pamlh *p, const double *x, double *post);
+/* BEB under branch-site model A and clade models C / D with two branch types (lfunNSsites_ACD codeml.c:6827):
+ * post[nc][n_patt] = posterior of the site classes; nc = 4 for A (classes 0, 1, 2a, 2b: Pr(positive selection on the foreground)
+ * = post[2] + post[3]), 3 for C and D. */
+int pamlh_beb_acd(pamlh *p, const double *x, double *post);
 const int *pamlh_pose(const pamlh *p, int *n_sites);
 const double *pamlh_class_omega(const pamlh *p);
 int pamlh_positive_classes(const pamlh *p);             /* trailing classes that allow omega > 1 (2 for branch-site: 2a + 2b) */

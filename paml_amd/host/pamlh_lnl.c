@@ -62,7 +62,7 @@ int main(int argc, char **argv)
          }
          if (npos == 2) {  /* branch-site model A: BEB over (p0, p1, w0, w2), classes 2a + 2b */
             double *bp = (double *)malloc((size_t)4 * npatt * sizeof(double));
-            if (!pamlh_beb_branchsite(p, x, bp)) {
+            if (!pamlh_beb_acd(p, x, bp)) {
                printf("\nBayes Empirical Bayes (BEB): positive sites for foreground lineages Prob(w>1) > 0.5\n   site   Pr(w>1)\n");
                for (h = 0; h < n_sites; h++) {
                   const double pr = bp[(size_t)2 * npatt + pose[h]] + bp[(size_t)3 * npatt + pose[h]];

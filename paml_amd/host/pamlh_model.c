@@ -805,30 +805,41 @@ int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double 
    return pamlh_set_x(p, x, p->np);      /* back to the model's own classes */
 }
 
-/* Bayes empirical Bayes under branch-site model A (lfunNSsites_ACD codeml.c:6827-7010; Yang, Wong & Nielsen 2005 table 1).
- * Priors p0,p1 ~ Dir(1,1,1) on the ternary grid, w0 ~ U(0,1), w2 ~ U(1,11), ten bins each; branch lengths, kappa and the two
- * branch-type time scales stay at the estimates x.  f(x_h | background omega, foreground omega) is needed for 121 pairs
- * (10 w0, w1 = 1, 10 x 10 (w0, w2), 10 (1, w2)): one evaluation with 121 classes over 21 eigen systems, on an engine of its
- * own (the analysis' engine is sized for the model's classes).  post[4][npatt]: posterior of classes 0, 1, 2a, 2b. */
-int pamlh_beb_branchsite(pamlh *p, const double *x, double *post)
+/* Bayes empirical Bayes under branch-site model A and clade models C and D with two branch types (lfunNSsites_ACD
+ * codeml.c:6827-7010; Yang, Wong & Nielsen 2005 tables 1 and 2).  Priors: p0,p1 ~ Dir(1,1,1) on the ternary grid; A: w0 ~ U(0,1),
+ * w2 ~ U(1,11); C: w0 ~ U(0,1), w2, w3 ~ U(0,3); D: w0 ~ U(0,1), w1 ~ U(0.01,1.5), w2, w3 ~ U(0,3); ten bins each, so the grid has
+ * 10^4 (A), 10^5 (C) or 10^6 (D) points.  Branch lengths, kappa and the branch-type time scales stay at the estimates x.
+ * f(x_h | omega of type 0, omega of type 1) is needed for 121 (A: 10 w0, w1 = 1, 10 x 10 (w0, w2), 10 (1, w2)), 111 (C: 10 w0, 1,
+ * 10 x 10 (w2, w3)) or 120 (D: 10 w0, 10 w1, 10 x 10) pairs: ONE evaluation with that many classes over 21 / 30 eigen systems, on
+ * an engine of its own (the analysis' engine is sized for the model's classes).
+ * post[nc][npatt], nc = 4 (A: classes 0, 1, 2a, 2b) or 3 (C, D). */
+int pamlh_beb_acd(pamlh *p, const double *x, double *post)
 {
-   enum { N1 = 10, KW = 2 * N1 + 1, KC = N1 + 1 + N1 * N1 + N1, NG = N1 * N1 * N1 * N1 };
-   const int n = p->n;
+   enum { N1 = 10, KWMAX = 3 * N1, KCMAX = 2 * N1 + N1 * N1 + N1 };
+   const int n = p->n, mA = p->model == 2, mD = p->model == 3 && p->nssites == 3;
+   const int nc = mA ? 4 : 3, dim = mA ? 4 : mD ? 6 : 5;
+   const int KW = mA ? 2 * N1 + 1 : mD ? 3 * N1 : 2 * N1 + 1, KC = mA ? N1 + 1 + N1 * N1 + N1 : mD ? 2 * N1 + N1 * N1 : N1 + 1 + N1 * N1;
    paml_amd_engine *e = NULL;
-   double wv[KW], qf[KC * 2], fk[KC], rt[KC], lnL, fX, *Q, *U, *V, *R, *pcl = NULL, kappa;
-   int eo[KC * 2], *iw = NULL, i, k, g, rc;
-   if (!(p->seqtype == 1 && p->model == 2 && p->nssites == 2)) return pamlh_fail(p, "this BEB is defined for branch-site model A (model 2, NSsites 2)");
+   double wv[KWMAX], qf[KCMAX * 2], fk[KCMAX], rt[KCMAX], lnL, fX, *Q, *U, *V, *R, *pcl = NULL, kappa;
+   int eo[KCMAX * 2], *iw = NULL, i, k, rc;
+   long g, ng = 1;
+   if (!(p->seqtype == 1 && ((p->model == 2 && p->nssites == 2) || (p->model == 3 && p->n_omega == 2))))
+      return pamlh_fail(p, "this BEB is defined for branch-site model A and for clade models C and D with two branch types");
    if (p->scale) for (i = 0; i < p->nnode; i++) if (p->scale[i]) return pamlh_fail(p, "BEB with scaling nodes is not supported yet");
    if ((rc = pamlh_set_x(p, x, p->np))) return rc;
    kappa = p->kappa;
-   for (i = 0; i < N1; i++) { wv[i] = (i + 0.5) / N1; wv[N1 + 1 + i] = 1 + 10 * (i + 0.5) / N1; }
-   wv[N1] = 1;
-   for (k = 0; k < KC; k++) {       /* (background, foreground) omega of the 121 evaluated classes (codeml.c:6685-6705) */
+   for (i = 0; i < dim; i++) ng *= N1;
+   /* the omega values on the grid, and the pair of them each evaluated class uses (get_grid_para_like_ACD codeml.c:6629-6720) */
+   for (i = 0; i < N1; i++) wv[i] = (i + 0.5) / N1;                                               /* w0 */
+   if (mD) for (i = 0; i < N1; i++) wv[N1 + i] = 0.01 + (i + 0.5) * 1.49 / N1; else wv[N1] = 1;     /* w1 */
+   for (i = 0; i < N1; i++) wv[KW - N1 + i] = mA ? 1 + 10 * (i + 0.5) / N1 : 3 * (i + 0.5) / N1;   /* w2 (A) / w2, w3 (C, D) */
+   for (k = 0; k < KC; k++) {
+      const int n01 = mD ? 2 * N1 : N1 + 1;      /* classes of the first two site classes */
       int b, f;
-      if (k < N1) b = f = k;
-      else if (k == N1) b = f = N1;
-      else if (k < N1 + 1 + N1 * N1) { b = (k - N1 - 1) / N1; f = N1 + 1 + (k - N1 - 1) % N1; }
-      else { b = N1; f = N1 + 1 + (k - N1 - 1 - N1 * N1); }
+      if (k < n01) b = f = k;                    /* site classes 0 and 1: the same omega on every branch */
+      else if (mA && k < n01 + N1 * N1) { b = (k - n01) / N1; f = KW - N1 + (k - n01) % N1; }   /* 2a: w0 back, w2 fore */
+      else if (mA) { b = N1; f = KW - N1 + (k - n01 - N1 * N1); }                              /* 2b: 1 back, w2 fore */
+      else { b = KW - N1 + (k - n01) / N1; f = KW - N1 + (k - n01) % N1; }                       /* clade: type 0, type 1 */
       eo[k * 2] = b; eo[k * 2 + 1] = f;
       qf[k * 2] = p->qfactor[0]; qf[k * 2 + 1] = p->qfactor[1];      /* Qfactor_NS_branch stays at the MLE (treesub.c:7556-7566) */
       fk[k] = 1.0 / KC; rt[k] = 1;
@@ -847,17 +858,26 @@ int pamlh_beb_branchsite(pamlh *p, const double *x, double *post)
    if (!rc) rc = paml_amd_eval(e, p->branch, NULL, &lnL, NULL, NULL);
    free(Q);
    if (rc) { pamlh_fail(p, "%s", paml_amd_last_error(e)); paml_amd_destroy(e); return rc; }
-   /* proportions and class index of the four site classes at every grid point (get_pclassM_iw_ACD codeml.c:6760-6800) */
-   pcl = (double *)malloc((size_t)NG * 4 * sizeof(double));
-   iw = (int *)malloc((size_t)NG * 4 * sizeof(int));
-   for (g = 0; g < NG; g++) {
-      const int ip0 = g / 1000, ip1 = (g / 100) % 10, ip2 = (g / 10) % 10, ip3 = g % 10;
-      const int tri = ip0 * N1 + ip1, ix = (int)sqrt((double)tri), iy = tri - ix * ix;
-      const double p0 = (1 + (iy / 2) * 3 + (iy % 2)) / (3.0 * N1), p1 = (1 + (N1 - 1 - ix) * 3 + (iy % 2)) / (3.0 * N1), p2 = 1 - p0 - p1;
-      pcl[g * 4] = p0; pcl[g * 4 + 1] = p1; pcl[g * 4 + 2] = p2 * p0 / (1 - p2); pcl[g * 4 + 3] = p2 * p1 / (1 - p2);
-      iw[g * 4] = ip2; iw[g * 4 + 1] = N1; iw[g * 4 + 2] = N1 + 1 + ip2 * N1 + ip3; iw[g * 4 + 3] = N1 + 1 + N1 * N1 + ip3;
+   /* proportions and class index of the site classes at every grid point (get_pclassM_iw_ACD codeml.c:6760-6820) */
+   pcl = (double *)malloc((size_t)ng * nc * sizeof(double));
+   iw = (int *)malloc((size_t)ng * nc * sizeof(int));
+   for (g = 0; g < ng; g++) {
+      int ip[6], j;
+      long it = g;
+      for (j = dim - 1; j >= 0; j--) { ip[j] = (int)(it % N1); it /= N1; }
+      {
+         const int tri = ip[0] * N1 + ip[1], ix = (int)sqrt((double)tri), iy = tri - ix * ix;
+         const double p0 = (1 + (iy / 2) * 3 + (iy % 2)) / (3.0 * N1), p1 = (1 + (N1 - 1 - ix) * 3 + (iy % 2)) / (3.0 * N1), p2 = 1 - p0 - p1;
+         pcl[g * nc] = p0; pcl[g * nc + 1] = p1;
+         if (mA) { pcl[g * nc + 2] = p2 * p0 / (1 - p2); pcl[g * nc + 3] = p2 * p1 / (1 - p2); }
+         else pcl[g * nc + 2] = p2;
+      }
+      iw[g * nc] = ip[2];
+      if (mA) { iw[g * nc + 1] = N1; iw[g * nc + 2] = N1 + 1 + ip[2] * N1 + ip[3]; iw[g * nc + 3] = N1 + 1 + N1 * N1 + ip[3]; }
+      else if (mD) { iw[g * nc + 1] = N1 + ip[3]; iw[g * nc + 2] = 2 * N1 + ip[4] * N1 + ip[5]; }
+      else { iw[g * nc + 1] = N1; iw[g * nc + 2] = N1 + 1 + ip[3] * N1 + ip[4]; }
    }
-   rc = paml_amd_beb_grid_classes(e, NG, 4, pcl, iw, &fX, post);
+   rc = paml_amd_beb_grid_classes(e, (int)ng, nc, pcl, iw, &fX, post);
    if (rc) pamlh_fail(p, "%s", paml_amd_last_error(e));
    free(pcl); free(iw);
    paml_amd_destroy(e);

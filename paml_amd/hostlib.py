@@ -199,13 +199,18 @@ class Analysis:
         pose = _arr(ptr, np.int32, ns.value)
         return post[:, pose], mw[pose]
 
-    def beb_branchsite(self, x):
-        """BEB under branch-site model A at x: posterior of site classes 0, 1, 2a, 2b per site, [4][n_sites] (pamlh_beb_branchsite)."""
+    def _is_branchsite(self):
+        return self._L.pamlh_positive_classes(self._h) == 2
+
+    def beb_acd(self, x):
+        """BEB under branch-site model A (4 site classes: 0, 1, 2a, 2b) or clade model C / D (3) at x: class posteriors per site,
+        [nc][n_sites] (pamlh_beb_acd)."""
         x = np.ascontiguousarray(x, dtype=np.float64)
-        post = np.zeros((4, self.n_patt))
-        self._L.pamlh_beb_branchsite.argtypes = [C.c_void_p] * 3
-        if self._L.pamlh_beb_branchsite(self._h, x.ctypes.data_as(C.c_void_p), post.ctypes.data_as(C.c_void_p)) != 0:
-            raise RuntimeError("pamlh_beb_branchsite: " + self._L.pamlh_error(self._h).decode())
+        self.set_x(x)
+        post = np.zeros((4 if self._is_branchsite() else 3, self.n_patt))
+        self._L.pamlh_beb_acd.argtypes = [C.c_void_p] * 3
+        if self._L.pamlh_beb_acd(self._h, x.ctypes.data_as(C.c_void_p), post.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("pamlh_beb_acd: " + self._L.pamlh_error(self._h).decode())
         ns = C.c_int()
         self._L.pamlh_pose.restype = C.c_void_p
         self._L.pamlh_pose.argtypes = [C.c_void_p, C.POINTER(C.c_int)]

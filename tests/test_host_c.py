@@ -144,11 +144,27 @@ def test_c_host_branch_site_neb_and_beb_match_the_reference_rst():
     x = np.array(g["x"])
     post, _ = a.neb(x)
     assert np.max(np.abs(post.T - np.array(g["neb_post"]))) < 2e-5
-    beb = a.beb_branchsite(x)
+    beb = a.beb_acd(x)
     assert np.max(np.abs(beb.T - np.array(g["beb_post"]))) < 2e-5
     pos = beb[2] + beb[3]
     assert [int(i) + 1 for i in np.nonzero(pos > 0.5)[0]] == [14, 21, 23, 37, 41, 50, 62, 87, 126]
     assert abs(pos[13] - 0.859) < 6e-4 and abs(pos[86] - 0.869) < 6e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname,ctl", [("ecp_cmc", "ecp_cmc.ctl"), ("ecp_cmd", "ecp_cmd.ctl")])
+def test_c_host_clade_model_neb_and_beb_match_the_reference_rst(gname, ctl):
+    """Clade models C and D on examples/CladeModelCD (two branch types): NEB and BEB posteriors of the three site classes at
+    all 161 sites as the reference writes them to `rst`.  BEB: 111 / 120 (type-0 omega, type-1 omega) pairs in one evaluation,
+    then the 10^5- (C) or 10^6-point (D) grid over (p0, p1, w0, [w1,] w2, w3)."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), "codeml")
+    x = np.array(g["x"])
+    post, _ = a.neb(x)
+    assert np.max(np.abs(post.T - np.array(g["neb_post"]))) < 2e-5
+    beb = a.beb_acd(x)
+    assert beb.shape == (3, g["ls"])
+    assert np.max(np.abs(beb.T - np.array(g["beb_post"]))) < 2e-5
 
 
 @pytest.mark.gpu
