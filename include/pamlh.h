@@ -54,7 +54,11 @@ const double *pamlh_pi(const pamlh *p);                 /* [n_states] */
 const double *pamlh_freqK(const pamlh *p);
 const double *pamlh_rate(const pamlh *p);
 const int *pamlh_eigen_of(const pamlh *p);              /* [K][n_labels] */
-const double *pamlh_qfactor(const pamlh *p);            /* [K][n_labels] time scale per (class, branch type); NULL = all 1 */
+const double *pamlh_qfactor(const pamlh *p);
+/* option G (several genes): returns n_genes; gene_off[n_genes + 1] = first pattern of each gene (com.posG), gene_rate[n_genes]
+ * = com.rgene after pamlh_set_x, n_pi = frequency vectors in pamlh_pi (1, or n_genes under Mgene 2 / 4), gene_eigen_of
+ * [n_genes][K] = eigen system of (gene, class) (NULL with one gene).  Any output pointer may be NULL. */
+int pamlh_genes(const pamlh *p, const int **gene_off, const double **gene_rate, int *n_pi, const int **gene_eigen_of);            /* [K][n_labels] time scale per (class, branch type); NULL = all 1 */
 /* eigen system i: kind (paml_amd.h), and pointers (NULL when not applicable) */
 int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const double **U, const double **V,
                 const double **Root, const double **Cijk);

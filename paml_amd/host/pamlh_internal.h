@@ -5,6 +5,7 @@
 #include "../../include/pamlh.h"
 
 #define PAMLH_MAXOPT 64
+#define PAMLH_MAXGENE 16
 enum { JC69, K80, F81, F84, HKY85, T92, TN93, REV };   /* baseml models (baseml.ctl) */
 
 typedef struct {
@@ -35,6 +36,11 @@ struct pamlh {
    int n31;
    int *n_chara;
    int *pose, n_pose;      /* site (after cleaning) -> pattern index */
+   int ngene, posG[PAMLH_MAXGENE + 1], lgene[PAMLH_MAXGENE];   /* option G: first pattern / number of sites of every gene */
+   int mgene;              /* Mgene: 0 rates, 2 different pi, 3 different kappa (& omega), 4 both */
+   double piG[PAMLH_MAXGENE][64];   /* frequencies of every gene (com.piG) */
+   double rgene[PAMLH_MAXGENE];     /* com.rgene: rate of every gene relative to the first */
+   int *gene_eigen_of;     /* [ngene][K][n_labels] when ngene > 1 */
    unsigned char *chara_map;
    double fb3x4[12], fb4[4], fcodon[64], pi_data[64];
    double aaS[400], aapi_file[20];
@@ -44,7 +50,7 @@ struct pamlh {
    double *tree_branch;    /* lengths read from the tree file, per node (-1: absent) */
    unsigned char *scale;
    /* model state */
-   int np, ntime, mode, K, n_eigen, n_labels;
+   int np, ntime, mode, K, n_eigen, n_labels, n_pi;
    double *branch, *pi, *freqK, *rate;
    int *eigen_of;
    pamlh_eig eig[64];

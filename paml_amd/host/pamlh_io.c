@@ -73,11 +73,13 @@ double pamlh_optd(const pamlh *p, const char *key, double dflt)
 }
 
 /* ------------------------------------------------------------------ sequences */
+static const int *g_sort_gene;      /* gene of every (kept) site, NULL with one gene */
 static int cmp_cols(const void *a, const void *b, void *ctx)
 {
    const pamlh *p = (const pamlh *)ctx;
    const int ia = *(const int *)a, ib = *(const int *)b, w = p->n31, L = p->ls * w;
    int j, c;
+   if (g_sort_gene && g_sort_gene[ia] != g_sort_gene[ib]) return g_sort_gene[ia] - g_sort_gene[ib];   /* patterns are sorted within genes */
    for (j = 0; j < p->ns; j++) {
       c = memcmp(p->raw + (size_t)j * L + (size_t)ia * w, p->raw + (size_t)j * L + (size_t)ib * w, w);
       if (c) return c;
@@ -103,7 +105,7 @@ int pamlh_read_seqs(pamlh *p)
    char *line;
    size_t cap = 1 << 16;
    int ns, lsraw, i, j, k, h, readpattern = 0, interleaved = 0, any_amb = 0, n31 = (p->seqtype == 1 ? 3 : 1);
-   int *pos;
+   int *pos, *site_gene = NULL;
    const char *alpha = p->seqtype == 2 ? AAs : BASEs;
    const int nbasic = p->seqtype == 2 ? 20 : 4;
    char *seq;
@@ -125,9 +127,55 @@ int pamlh_read_seqs(pamlh *p)
          }
          c++;
       }
-      if (hasG && !hasC) { fclose(f); free(line); return pamlh_fail(p, "option G (several genes) is not supported yet"); }
+      if (lsraw % n31) { fclose(f); free(line); return pamlh_fail(p, "%d nucleotides, not a multiple of 3", lsraw); }
+      /* option G: sites (codons for codon data) belong to several genes / partitions (ReadSeq treesub.c:590-680).  "GC" is
+       * baseml's shorthand for the three codon positions; codeml ignores it.  Otherwise one option line follows:
+       * "G ngene" + the gene lengths on the same line, or "G ngene" + one gene mark (1..ngene) per site on the next lines. */
+      p->ngene = 1;
+      if (hasG && hasC) {
+         if (p->seqtype == 0) {
+            if (lsraw % 3) { fclose(f); free(line); return pamlh_fail(p, "option GC: %d sites, not a multiple of 3", lsraw); }
+            if (readpattern) { fclose(f); free(line); return pamlh_fail(p, "patterns for coding sequences (G C P) are not supported"); }
+            p->ngene = 3;
+            site_gene = (int *)malloc(lsraw * sizeof(int));
+            for (h = 0; h < lsraw; h++) site_gene[h] = h % 3;
+         }
+      }
+      else if (hasG) {
+         const int nsite = lsraw / n31;
+         int ch, ng = 0, tot = 0;
+         char *q;
+         if (readpattern) { fclose(f); free(line); return pamlh_fail(p, "option G with the P pattern format is not supported"); }
+         do ch = fgetc(f); while (ch != EOF && !isalnum(ch));
+         if (toupper(ch) != 'G' || fscanf(f, "%d", &ng) != 1 || ng < 1 || ng > PAMLH_MAXGENE) { fclose(f); free(line); return pamlh_fail(p, "option G: expecting 'G <number of genes (<= %d)>'", PAMLH_MAXGENE); }
+         site_gene = (int *)malloc(nsite * sizeof(int));
+         if (!fgets(line, (int)cap, f)) line[0] = 0;
+         for (q = line; *q && isspace((unsigned char)*q); q++) ;
+         if (*q) {                               /* gene lengths */
+            for (i = 0; i < ng; i++) {
+               int len;
+               while (*q && !isdigit((unsigned char)*q)) q++;
+               if (*q) { len = atoi(q); while (isdigit((unsigned char)*q)) q++; }
+               else if (fscanf(f, "%d", &len) != 1) { fclose(f); free(line); free(site_gene); return pamlh_fail(p, "option G: EOF reading the gene lengths"); }
+               if (len < 1 || tot + len > nsite) { fclose(f); free(line); free(site_gene); return pamlh_fail(p, "option G: total length over genes is not correct"); }
+               for (h = 0; h < len; h++) site_gene[tot + h] = i;
+               tot += len;
+            }
+            if (tot != nsite) { fclose(f); free(line); free(site_gene); return pamlh_fail(p, "option G: gene lengths sum to %d, not %d%s", tot, nsite, n31 == 3 ? " (gene lengths are in codons)" : ""); }
+         }
+         else {                                  /* one mark per site */
+            for (h = 0; h < nsite; h++) {
+               int m;
+               if (ng > 9) { if (fscanf(f, "%d", &m) != 1) m = -1; }
+               else { do ch = fgetc(f); while (ch != EOF && !isdigit(ch)); m = ch == EOF ? -1 : ch - '0'; }
+               if (m < 1 || m > ng) { fclose(f); free(line); free(site_gene); return pamlh_fail(p, "option G: gene mark %d at site %d?", m, h + 1); }
+               site_gene[h] = m - 1;
+            }
+            if (!fgets(line, (int)cap, f)) line[0] = 0;      /* the rest of the last line of marks */
+         }
+         p->ngene = ng;
+      }
    }
-   if (lsraw % n31) { fclose(f); free(line); return pamlh_fail(p, "%d nucleotides, not a multiple of 3", lsraw); }
    p->ns = ns; p->n31 = n31;
    p->names = (char **)calloc(ns, sizeof(char *));
    seq = (char *)malloc((size_t)ns * lsraw);
@@ -212,12 +260,19 @@ int pamlh_read_seqs(pamlh *p)
          int np = 0, *first = (int *)malloc(nkeep * sizeof(int));
          double *w = (double *)calloc(nkeep, sizeof(double));
          p->pose = (int *)malloc((nkeep + 1) * sizeof(int));      /* com.pose: site (after cleaning) -> pattern */
+         int *kg = NULL;
+         if (site_gene) {
+            kg = (int *)malloc(nkeep * sizeof(int));
+            for (h = 0; h < nkeep; h++) kg[h] = site_gene[keep[h]];
+         }
          if (!readpattern) {
             g_sort_ctx = p;
+            g_sort_gene = kg;
             qsort(idx, nkeep, sizeof(int), cmp_cols0);
+            g_sort_gene = NULL;
             for (h = 0; h < nkeep; h++) {
                int same = 0;
-               if (np > 0) {
+               if (np > 0 && !(kg && kg[idx[h]] != kg[first[np - 1]])) {
                   same = 1;
                   for (j = 0; j < ns && same; j++)
                      if (memcmp(p->raw + ((size_t)j * nkeep + idx[h]) * n31, p->raw + ((size_t)j * nkeep + first[np - 1]) * n31, n31)) same = 0;
@@ -230,6 +285,19 @@ int pamlh_read_seqs(pamlh *p)
          else
             for (h = 0; h < nkeep; h++) { first[np] = h; w[np] = cnt[keep[h]]; p->pose[h] = np; np++; }
          p->n_pose = nkeep;
+         /* com.posG / com.lgene: first pattern and number of sites of every gene (PatternWeight treesub.c:1428, 1466-1472) */
+         p->posG[0] = 0; p->posG[1] = np; p->lgene[0] = nkeep;
+         if (kg) {
+            for (k = 0; k < p->ngene; k++) p->lgene[k] = 0;
+            for (h = 0; h < nkeep; h++) p->lgene[kg[h]]++;
+            for (k = 0, h = 0; k < p->ngene; k++) {
+               if (!p->lgene[k]) return pamlh_fail(p, "gene %d does not have any sites", k + 1);
+               p->posG[k] = h;
+               while (h < np && kg[first[h]] == k) h++;
+            }
+            p->posG[p->ngene] = np;
+            free(kg);
+         }
          raw2 = (char *)malloc((size_t)ns * np * n31);
          for (j = 0; j < ns; j++)
             for (h = 0; h < np; h++) memcpy(raw2 + ((size_t)j * np + h) * n31, p->raw + ((size_t)j * nkeep + first[h]) * n31, n31);
@@ -247,7 +315,7 @@ int pamlh_read_seqs(pamlh *p)
       }
       free(idx); free(keep); free(cnt);
    }
-   free(seq); free(line);
+   free(seq); free(line); free(site_gene);
 
    /* encode (EncodeSeqs / SetMapAmbiguity) */
    {

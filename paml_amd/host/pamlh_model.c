@@ -16,6 +16,7 @@
 static const char *const GENETIC_CODES[2] = {"FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
                                              "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG"};
 
+static int nuc_nkappa(const pamlh *p);
 static double dist2(const double *a, const double *b, int n)
 {
    double s = 0;
@@ -25,10 +26,10 @@ static double dist2(const double *a, const double *b, int n)
 }
 
 /* base / amino-acid frequencies with ambiguity characters resolved by iteration (InitializeBaseAA treesub.c:1548-1700) */
-static void add_freq(const pamlh *p, int js, const double *pi0, double *pi)
+static void add_freq(const pamlh *p, int js, const double *pi0, double *pi, int h0, int h1)
 {
    int h, k, n = p->n;
-   for (h = 0; h < p->npatt; h++) {
+   for (h = h0; h < h1; h++) {
       const int code = p->z[(size_t)js * p->npatt + h], nc = p->n_chara[code];
       const unsigned char *map = p->chara_map + (size_t)code * n;
       if (nc == 1) pi[map[0]] += p->w[h];
@@ -40,7 +41,9 @@ static void add_freq(const pamlh *p, int js, const double *pi0, double *pi)
    }
 }
 
-static void freqs_base_aa(pamlh *p)
+/* frequencies of the patterns [h0, h1): mean over species of the per-species frequencies, then (with ambiguities) resolved
+ * over all species together */
+static void freqs_base_aa_range(pamlh *p, int h0, int h1, double *out)
 {
    int n = p->n, js, k, it;
    double pi0[64], pi[64], piG[64] = {0}, t;
@@ -48,7 +51,7 @@ static void freqs_base_aa(pamlh *p)
       for (k = 0; k < n; k++) pi0[k] = 1.0 / n;
       for (it = 0; it < 20; it++) {
          for (k = 0; k < n; k++) pi[k] = 0;
-         add_freq(p, js, pi0, pi);
+         add_freq(p, js, pi0, pi, h0, h1);
          for (k = 0, t = 0; k < n; k++) t += pi[k];
          for (k = 0; k < n; k++) pi[k] = t < 1e-10 ? 1.0 / n : pi[k] / t;
          if (p->cleandata || dist2(pi, pi0, n) < 1e-8) break;
@@ -56,17 +59,44 @@ static void freqs_base_aa(pamlh *p)
       }
       for (k = 0; k < n; k++) piG[k] += pi[k] / p->ns;
    }
-   if (p->cleandata) { memcpy(p->pi_data, piG, n * sizeof(double)); return; }
+   if (p->cleandata) { memcpy(out, piG, n * sizeof(double)); return; }
    memcpy(pi0, piG, n * sizeof(double));
    for (it = 0; it < 20; it++) {
       for (k = 0; k < n; k++) pi[k] = 0;
-      for (js = 0; js < p->ns; js++) add_freq(p, js, pi0, pi);
+      for (js = 0; js < p->ns; js++) add_freq(p, js, pi0, pi, h0, h1);
       for (k = 0, t = 0; k < n; k++) t += pi[k];
       for (k = 0; k < n; k++) pi[k] /= t;
       if (dist2(pi, pi0, n) < 1e-8) break;
       memcpy(pi0, pi, n * sizeof(double));
    }
-   memcpy(p->pi_data, pi, n * sizeof(double));
+   memcpy(out, pi, n * sizeof(double));
+}
+
+static void freqs_base_aa(pamlh *p)
+{
+   const int n = p->n;
+   int g, k, js, it;
+   if (p->ngene <= 1) { freqs_base_aa_range(p, 0, p->npatt, p->pi_data); memcpy(p->piG[0], p->pi_data, n * sizeof(double)); return; }
+   /* several genes (InitializeBaseAA treesub.c:1582-1668): com.piG[] within each gene; com.pi[] = their length-weighted mean
+    * for clean data, else ambiguities resolved over the whole alignment starting from the plain mean of the genes */
+   for (g = 0; g < p->ngene; g++) freqs_base_aa_range(p, p->posG[g], p->posG[g + 1], p->piG[g]);
+   memset(p->pi_data, 0, sizeof(p->pi_data));
+   if (p->cleandata) {
+      for (g = 0; g < p->ngene; g++) for (k = 0; k < n; k++) p->pi_data[k] += p->piG[g][k] * p->lgene[g] / (double)p->ls;
+   }
+   else {
+      double pi0[64] = {0}, pi[64], t;
+      for (g = 0; g < p->ngene; g++) for (k = 0; k < n; k++) pi0[k] += p->piG[g][k] / p->ngene;
+      for (it = 0; it < 20; it++) {
+         for (k = 0; k < n; k++) pi[k] = 0;
+         for (js = 0; js < p->ns; js++) add_freq(p, js, pi0, pi, 0, p->npatt);
+         for (k = 0, t = 0; k < n; k++) t += pi[k];
+         for (k = 0; k < n; k++) pi[k] /= t;
+         if (dist2(pi, pi0, n) < 1e-8) break;
+         memcpy(pi0, pi, n * sizeof(double));
+      }
+      memcpy(p->pi_data, pi, n * sizeof(double));
+   }
 }
 
 static int base_set(char c, int *set)
@@ -80,14 +110,14 @@ static int base_set(char c, int *set)
 }
 
 /* codon data: fcodon (64), fb3x4, fb4 — CountCodons (resolved codons only) then the ambiguity iteration */
-static void freqs_codon(pamlh *p)
+static void freqs_codon_range(pamlh *p, int h0, int h1, double *pi_out)
 {
    int js, h, k, i0, i1, i2, it, np = p->npatt;
    double fc[64] = {0}, fb[12] = {0}, f4[4] = {0}, fc0[64], fb0[12], f40[4], t;
    int from64[64], nsense = 0;
    for (k = 0; k < 64; k++) from64[k] = p->code[k] == '*' ? -1 : nsense++;
    for (js = 0; js < p->ns; js++)
-      for (h = 0; h < np; h++) {
+      for (h = h0; h < h1; h++) {
          const char *c = p->raw + ((size_t)js * np + h) * 3;
          int s[3][4], m[3];
          for (k = 0; k < 3; k++) m[k] = base_set(c[k], s[k]);
@@ -106,7 +136,7 @@ static void freqs_codon(pamlh *p)
          double d1, d2, d3;
          memset(fc, 0, sizeof(fc)); memset(fb, 0, sizeof(fb)); memset(f4, 0, sizeof(f4));
          for (js = 0; js < p->ns; js++)
-            for (h = 0; h < np; h++) {
+            for (h = h0; h < h1; h++) {
                const char *c = p->raw + ((size_t)js * np + h) * 3;
                int s[3][4], m[3], ft[64] = {0}, nk = 0;
                double t1;
@@ -150,11 +180,20 @@ static void freqs_codon(pamlh *p)
          else if (p->codonfreq == 1) v = f4[k / 16] * f4[(k / 4) % 4] * f4[k % 4];
          else if (p->codonfreq == 2) v = fb[k / 16] * fb[4 + (k / 4) % 4] * fb[8 + k % 4];
          else v = fc[k];
-         p->pi_data[j++] = v;
+         pi_out[j++] = v;
          s += v;
       }
-      for (j = 0; j < p->n; j++) p->pi_data[j] /= s;
+      for (j = 0; j < p->n; j++) pi_out[j] /= s;
    }
+}
+
+/* com.pi over all codons and com.piG within every gene (InitializeCodon codeml.c:3772-3900) */
+static void freqs_codon(pamlh *p)
+{
+   int g;
+   for (g = 0; g < p->ngene && p->ngene > 1; g++) freqs_codon_range(p, p->posG[g], p->posG[g + 1], p->piG[g]);
+   freqs_codon_range(p, 0, p->npatt, p->pi_data);      /* last: leaves the whole-data tables in fb3x4 / fb4 / fcodon */
+   if (p->ngene <= 1) memcpy(p->piG[0], p->pi_data, p->n * sizeof(double));
 }
 
 static int read_aa_ratefile(pamlh *p)
@@ -211,7 +250,10 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    p->cleandata_opt = (int)pamlh_optd(p, "cleandata", 0);
    p->fix_blength = (int)pamlh_optd(p, "fix_blength", 0);
    if ((int)pamlh_optd(p, "clock", 0) != 0) { rc = pamlh_fail(p, "clock models are not supported"); goto bad; }
-   if ((int)pamlh_optd(p, "Mgene", 0) != 0) { rc = pamlh_fail(p, "Mgene models are not supported"); goto bad; }
+   p->mgene = (int)pamlh_optd(p, "Mgene", 0);
+   if (p->mgene == 1) { rc = pamlh_fail(p, "Mgene = 1 (separate analyses) is not supported: run each gene on its own"); goto bad; }
+   if (p->mgene < 0 || p->mgene > 4) { rc = pamlh_fail(p, "Mgene = %d?", p->mgene); goto bad; }
+   if ((int)pamlh_optd(p, "Malpha", 0) != 0) { rc = pamlh_fail(p, "Malpha (one alpha per gene) is not supported"); goto bad; }
    if (p->seqtype == 1) {
       if (p->icode != 0 && p->icode != 1) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0: universal, 1: vertebrate mt)", p->icode); goto bad; }
       /* model 0: site models; model 2, NSsites 0: branch model; model 2 / 3 with NSsites 2 / 3: branch-site A / B, clade C / D */
@@ -244,6 +286,19 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    else { rc = pamlh_fail(p, "seqtype %d is not supported", p->seqtype); goto bad; }
    if ((rc = pamlh_read_seqs(p))) goto bad;
    if ((rc = pamlh_read_tree(p))) goto bad;
+   if (p->ngene <= 1) { if (p->mgene) { rc = pamlh_fail(p, "Mgene = %d but the sequence file has one gene (no option G)", p->mgene); goto bad; } }
+   else {
+      /* what the several-gene set-up covers (the reference's own exclusions: baseml.c:261-265, codeml.c:1534-1544) */
+      if (p->fix_blength == 2) { rc = pamlh_fail(p, "fix_blength = 2 does not work for partitioned data"); goto bad; }
+      if (p->seqtype == 1 && (p->model || p->nssites)) { rc = pamlh_fail(p, "several genes: only the one-ratio codon model (model 0, NSsites 0)"); goto bad; }
+      if (p->mgene >= 3 && (p->fix_kappa || (p->seqtype == 1 && p->fix_omega))) { rc = pamlh_fail(p, "Mgene = %d needs free kappa (and omega)", p->mgene); goto bad; }
+      if (p->seqtype == 2 && p->mgene >= 3) { rc = pamlh_fail(p, "Mgene = %d has no meaning for the amino-acid models here", p->mgene); goto bad; }
+      if (p->seqtype == 2 && p->mgene == 2 && p->aa_model != 3) { rc = pamlh_fail(p, "Mgene = 2 needs the +F model (model 3) for amino acids"); goto bad; }
+      if (p->seqtype == 1 && p->mgene == 2 && p->codonfreq == 0) { rc = pamlh_fail(p, "Mgene = 2 with equal codon frequencies"); goto bad; }
+      if (p->seqtype == 0 && ((p->mgene >= 2 && p->model == JC69) || (p->mgene >= 3 && p->model == F81) || ((p->mgene == 2 || p->mgene == 4) && p->model == K80))) {
+         rc = pamlh_fail(p, "this Mgene option has no meaning for the model"); goto bad;
+      }
+   }
    if (!(p->seqtype == 1 && p->model >= 2)) memset(p->label, 0, p->nnode * sizeof(int));      /* '#' labels only matter to branch models */
    if (p->seqtype == 1 && p->model >= 2) {
       int i;
@@ -256,7 +311,8 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    /* parameter bookkeeping (GetInitials): ntime, np */
    p->ntime = p->fix_blength == 2 ? 0 : p->nbranch;
    {
-      int nr = 0;
+      int nr = p->ngene - 1;       /* rgene */
+      const int rep = p->mgene >= 3 ? p->ngene : 1;
       if (p->seqtype == 1) {
          nr += !p->fix_kappa;
          if (p->nssites == 0 && p->model == 2) nr += p->n_omega;      /* branch model: one omega per branch label (codeml.c:2170-2183) */
@@ -275,14 +331,16 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
          else if (p->model == TN93) nr += 2 * !p->fix_kappa;
          else if (p->model == REV) nr += 5;
       }
+      if (rep > 1) nr += (rep - 1) * (p->seqtype == 1 ? 2 : nuc_nkappa(p));      /* Mgene 3, 4: a parameter set per gene */
       if (p->alpha0 > 0 || !p->fix_alpha) nr += !p->fix_alpha;
       p->np = p->ntime + nr;
    }
    p->branch = (double *)calloc(p->nnode, sizeof(double));
-   p->pi = (double *)calloc(64, sizeof(double));
+   p->pi = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    p->freqK = (double *)calloc(64, sizeof(double));
    p->rate = (double *)calloc(64, sizeof(double));
    p->eigen_of = (int *)calloc(64, sizeof(int));
+   p->n_pi = 1;
    *out = p;
    return 0;
 bad:
@@ -301,7 +359,8 @@ void pamlh_free(pamlh *p)
    free(p->names); free(p->z); free(p->w); free(p->raw); free(p->n_chara); free(p->chara_map);
    free(p->sons_ptr); free(p->sons); free(p->label); free(p->branch_node); free(p->father); free(p->tree_branch); free(p->scale);
    free(p->branch); free(p->pi); free(p->freqK); free(p->rate); free(p->eigen_of);
-   for (i = 0; i < 16; i++) { free(p->eig[i].U); free(p->eig[i].V); free(p->eig[i].Root); free(p->eig[i].Cijk); }
+   for (i = 0; i < 64; i++) { free(p->eig[i].U); free(p->eig[i].V); free(p->eig[i].Root); free(p->eig[i].Cijk); }
+   free(p->gene_eigen_of);
    free(p);
 }
 
@@ -365,6 +424,16 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
    int k = 0, i;
    if (cap < p->np) return -1;
    for (i = 0; i < p->ntime; i++) { double b = p->tree_branch[p->branch_node[i]]; x[k++] = b >= 0 ? b : 0.1; }
+   for (i = 1; i < p->ngene; i++) x[k++] = 1;      /* rgene */
+   if (p->ngene > 1 && p->mgene >= 3) {            /* a parameter set per gene */
+      int g, j;
+      for (g = 0; g < p->ngene; g++) {
+         if (p->seqtype == 1) { x[k++] = p->kappa0; x[k++] = p->omega0; }
+         else for (j = 0; j < nuc_nkappa(p); j++) x[k++] = p->model == REV ? 1 : p->kappa0;
+      }
+      if (!p->fix_alpha) x[k++] = p->alpha0 > 0 ? p->alpha0 : 0.5;
+      return k;
+   }
    if (p->seqtype == 1) {
       if (!p->fix_kappa) x[k++] = p->kappa0;
       if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) x[k++] = p->omega0; }
@@ -425,11 +494,12 @@ static void set_eig_uvroot(pamlh *p, int i, const double *Q, const double *pi, d
 }
 
 /* codon Q for (kappa, omega) and its mean rate (eigenQcodon codeml.c:3274-3315) */
-static double codon_q(const pamlh *p, double kappa, double omega, double *Q)
+static double codon_q_pi(const pamlh *p, const double *pi, double kappa, double omega, double *Q);
+static double codon_q(const pamlh *p, double kappa, double omega, double *Q) { return codon_q_pi(p, p->pi, kappa, omega, Q); }
+static double codon_q_pi(const pamlh *p, const double *pi, double kappa, double omega, double *Q)
 {
    int from61[64], i, j, k, n = p->n, m = 0;
    double mr = 0;
-   const double *pi = p->pi;
    for (k = 0; k < 64; k++) if (p->code[k] != '*') from61[m++] = k;
    memset(Q, 0, (size_t)n * n * sizeof(double));
    for (i = 1; i < n; i++)
@@ -449,6 +519,101 @@ static double codon_q(const pamlh *p, double kappa, double omega, double *Q)
    return mr;
 }
 
+/* number of exchangeability parameters of a baseml model (nkappa[] baseml.c:1311) */
+static int nuc_nkappa(const pamlh *p)
+{
+   const int m = p->model;
+   if (m == REV) return 5;
+   if (m == TN93) return p->fix_kappa ? 0 : 2;
+   if (m == K80 || m == HKY85) return p->fix_kappa ? 0 : 1;
+   return 0;
+}
+
+/* eigen system `iset` of a baseml model with frequencies pi and exchangeability parameters kp (those nuc_nkappa counts) */
+static void nuc_set(pamlh *p, int iset, const double *pi, const double *kp, double *Q)
+{
+   const int m = p->model;
+   double S[16], mr = 0;
+   int i, j, kk;
+   pamlh_eig *e = &p->eig[iset];
+   if (m == JC69 || m == K80) { e->kind = PAML_AMD_EIGEN_K80; e->kappa = m == JC69 ? 1 : (p->fix_kappa ? p->kappa0 : kp[0]); return; }
+   for (i = 0; i < 16; i++) S[i] = 1;
+   if (m == HKY85) { const double v = p->fix_kappa ? p->kappa0 : kp[0]; S[0 * 4 + 1] = S[1 * 4 + 0] = S[2 * 4 + 3] = S[3 * 4 + 2] = v; }
+   else if (m == TN93) {
+      const double k1 = p->fix_kappa ? p->kappa0 : kp[0], k2 = p->fix_kappa ? p->kappa0 : kp[1];
+      S[0 * 4 + 1] = S[1 * 4 + 0] = k1; S[2 * 4 + 3] = S[3 * 4 + 2] = k2;
+   }
+   else if (m == REV) {
+      S[0 * 4 + 1] = S[1 * 4 + 0] = kp[0]; S[0 * 4 + 2] = S[2 * 4 + 0] = kp[1]; S[0 * 4 + 3] = S[3 * 4 + 0] = kp[2];
+      S[1 * 4 + 2] = S[2 * 4 + 1] = kp[3]; S[1 * 4 + 3] = S[3 * 4 + 1] = kp[4];
+   }
+   for (i = 0; i < 4; i++) for (j = 0; j < 4; j++) Q[i * 4 + j] = (i == j) ? 0 : S[i * 4 + j] * pi[j];
+   for (i = 0; i < 4; i++) { double t = 0; for (j = 0; j < 4; j++) t += Q[i * 4 + j]; Q[i * 4 + i] = -t; mr += pi[i] * t; }
+   set_eig_uvroot(p, iset, Q, pi, mr);
+   if (!e->Cijk) e->Cijk = (double *)malloc(64 * sizeof(double));
+   for (i = 0; i < 4; i++) for (j = 0; j < 4; j++) for (kk = 0; kk < 4; kk++) e->Cijk[i * 16 + j * 4 + kk] = e->U[i * 4 + kk] * e->V[kk * 4 + j];
+   e->kind = PAML_AMD_EIGEN_CIJK; e->nR = 4;
+}
+
+/* Several genes (option G).  x = branch lengths, rgene[2..ngene] (rates relative to the first gene, SetParameters
+ * baseml.c:1319 / codeml.c:2768), then the substitution parameters — one set (Mgene 0, 2) or one per gene (Mgene 3, 4:
+ * SetPGene baseml.c:1428 / codeml.c:2420) — then alpha.  Frequencies: com.pi for all genes (Mgene 0, 3) or com.piG (2, 4).
+ * Each gene's Q is scaled to mean rate 1 with its own frequencies and parameters; rgene then multiplies the branch lengths. */
+static int set_x_genes(pamlh *p, const double *x, int np, int k, double *Q)
+{
+   const int n = p->n, G = p->ngene, per_gene = p->mgene >= 3, own_pi = p->mgene == 2 || p->mgene == 4;
+   const int nsets = p->mgene >= 2 ? G : 1;
+   int g, j, K = 1;
+   p->rgene[0] = 1;
+   for (g = 1; g < G; g++) p->rgene[g] = x[k++];
+   for (g = 0; g < nsets; g++) {
+      const double *pi = own_pi ? p->piG[g] : p->pi_data;
+      double *pis = p->pi + (size_t)(own_pi ? g : 0) * n;
+      memcpy(pis, pi, n * sizeof(double));
+      if (p->seqtype == 1) {
+         const double *kp = x + k + (per_gene ? g * 2 : 0);
+         const double kappa = p->fix_kappa ? p->kappa0 : kp[0], w = p->fix_omega ? p->omega0 : kp[!p->fix_kappa];
+         const double mr = codon_q_pi(p, pis, kappa, w, Q);
+         set_eig_uvroot(p, g, Q, pis, mr);
+         p->kappa = kappa; p->omega = w; p->class_w[g] = w;
+      }
+      else if (p->seqtype == 2) {
+         double mr = 0;
+         int i;
+         if (p->aa_model == 0) { for (i = 0; i < 20; i++) pis[i] = 1.0 / 20; p->eig[g].kind = PAML_AMD_EIGEN_JC69LIKE; }
+         else {
+            if (p->aa_model == 2) memcpy(pis, p->aapi_file, 20 * sizeof(double));
+            for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) Q[i * 20 + j] = (i == j) ? 0 : p->aaS[i * 20 + j] * pis[j];
+            for (i = 0; i < 20; i++) { double t = 0; for (j = 0; j < 20; j++) t += Q[i * 20 + j]; Q[i * 20 + i] = -t; mr += pis[i] * t; }
+            set_eig_uvroot(p, g, Q, pis, mr);
+         }
+      }
+      else {
+         if (p->model == JC69 || p->model == K80) for (j = 0; j < 4; j++) pis[j] = 0.25;
+         nuc_set(p, g, pis, x + k + (per_gene ? g * nuc_nkappa(p) : 0), Q);
+      }
+   }
+   if (p->seqtype == 1) k += (per_gene ? G : 1) * (!p->fix_kappa + !p->fix_omega);
+   else if (p->seqtype == 0) k += (per_gene ? G : 1) * nuc_nkappa(p);
+   p->n_pi = own_pi ? G : 1;
+   p->n_eigen = nsets;
+   {
+      const double alpha = p->fix_alpha ? p->alpha0 : x[k++];
+      p->alpha = alpha;
+      if (alpha > 0) {
+         if (p->ncatG > 60) return pamlh_fail(p, "ncatG too large");
+         pamlh_discrete_gamma(p->freqK, p->rate, alpha, p->ncatG);
+         K = p->ncatG; p->mode = PAML_AMD_MODE_LFUNDG;
+      }
+   }
+   p->K = K;
+   free(p->gene_eigen_of);
+   p->gene_eigen_of = (int *)malloc((size_t)G * K * sizeof(int));
+   for (g = 0; g < G; g++) for (j = 0; j < K; j++) p->gene_eigen_of[g * K + j] = p->mgene >= 2 ? g : 0;
+   if (k != np) return pamlh_fail(p, "internal: consumed %d of %d parameters", k, np);
+   return 0;
+}
+
 int pamlh_set_x(pamlh *p, const double *x, int np)
 {
    const int n = p->n;
@@ -462,8 +627,9 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
       p->branch[node] = p->ntime ? x[k++] : p->tree_branch[node];
       if (!p->ntime && p->tree_branch[node] < 0) { free(Q); return pamlh_fail(p, "fix_blength = 2 but the tree has no branch lengths"); }
    }
-   p->n_labels = 1; p->K = 1; p->mode = PAML_AMD_MODE_LFUN; p->n_eigen = 1; p->use_qf = 0;
+   p->n_labels = 1; p->K = 1; p->mode = PAML_AMD_MODE_LFUN; p->n_eigen = 1; p->use_qf = 0; p->n_pi = 1;
    p->freqK[0] = 1; p->rate[0] = 1; p->eigen_of[0] = 0;
+   if (p->ngene > 1) { const int rc = set_x_genes(p, x, np, k, Q); free(Q); return rc; }
    if (p->seqtype == 1) {
       double kappa = p->fix_kappa ? p->kappa0 : x[k++];
       memcpy(p->pi, p->pi_data, p->n * sizeof(double));
@@ -632,7 +798,8 @@ pamlh *pamlh_state_clone(const pamlh *p)
    q->eng = NULL;
    q->err[0] = 0;
    q->branch = (double *)calloc(p->nnode, sizeof(double));
-   q->pi = (double *)calloc(64, sizeof(double));
+   q->pi = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
+   q->gene_eigen_of = NULL;
    q->freqK = (double *)calloc(64, sizeof(double));
    q->rate = (double *)calloc(64, sizeof(double));
    q->eigen_of = (int *)calloc(64, sizeof(int));
@@ -645,7 +812,7 @@ void pamlh_state_free(pamlh *q)
    int i;
    if (!q) return;
    for (i = 0; i < 64; i++) { free(q->eig[i].U); free(q->eig[i].V); free(q->eig[i].Root); free(q->eig[i].Cijk); }
-   free(q->branch); free(q->pi); free(q->freqK); free(q->rate); free(q->eigen_of);
+   free(q->branch); free(q->pi); free(q->freqK); free(q->rate); free(q->eigen_of); free(q->gene_eigen_of);
    free(q);
 }
 
@@ -654,8 +821,8 @@ int pamlh_engine_ready(pamlh *p)
 {
    int rc;
    if (p->eng) return 0;
-   if ((rc = paml_amd_create(&p->eng, p->n, p->ns, p->npatt, 64, 1, 0))) return pamlh_fail(p, "paml_amd_create failed (%d): no GPU?", rc);
-   if ((rc = paml_amd_set_tips(p->eng, p->z, p->cleandata, p->n_codes, p->n_chara, p->chara_map, p->w, NULL)) ||
+   if ((rc = paml_amd_create(&p->eng, p->n, p->ns, p->npatt, 64, p->ngene, 0))) return pamlh_fail(p, "paml_amd_create failed (%d): no GPU?", rc);
+   if ((rc = paml_amd_set_tips(p->eng, p->z, p->cleandata, p->n_codes, p->n_chara, p->chara_map, p->w, p->ngene > 1 ? p->posG : NULL)) ||
        (rc = paml_amd_set_tree(p->eng, p->nnode, p->root, p->sons_ptr, p->sons, p->label, p->scale)))
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    return 0;
@@ -674,7 +841,7 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
 {
    int i, rc;
    if ((rc = pamlh_engine_ready(p))) return rc;
-   if ((rc = paml_amd_set_pi(p->eng, 1, p->pi))) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   if ((rc = paml_amd_set_pi(p->eng, p->n_pi, p->pi))) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    for (i = 0; i < p->n_eigen; i++) {
       const pamlh_eig *e = &p->eig[i];
       if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, i, e->U, e->V, e->Root);
@@ -683,8 +850,9 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
       else rc = paml_amd_set_eigen_jc69like(p->eng, i);
       if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    }
-   if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->eigen_of, p->use_qf ? p->qfactor : NULL)) ||
-       (rc = paml_amd_eval(p->eng, p->branch, NULL, lnL, lnf, NULL)))
+   if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->ngene > 1 ? p->gene_eigen_of : p->eigen_of,
+                                  p->use_qf ? p->qfactor : NULL)) ||
+       (rc = paml_amd_eval(p->eng, p->branch, p->ngene > 1 ? p->rgene : NULL, lnL, lnf, NULL)))
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    return 0;
 }
@@ -892,6 +1060,17 @@ const int *pamlh_pose(const pamlh *p, int *n_sites)
 
 const double *pamlh_class_omega(const pamlh *p) { return p->class_w; }
 const double *pamlh_qfactor(const pamlh *p) { return p->use_qf ? p->qfactor : NULL; }
+
+/* option G: number of genes, first pattern of each (n_genes + 1 entries), their rates (after pamlh_set_x), the number of
+ * frequency vectors pamlh_pi holds (1 or n_genes) and the eigen system of (gene, class) */
+int pamlh_genes(const pamlh *p, const int **gene_off, const double **gene_rate, int *n_pi, const int **gene_eigen_of)
+{
+   if (gene_off) *gene_off = p->posG;
+   if (gene_rate) *gene_rate = p->rgene;
+   if (n_pi) *n_pi = p->n_pi;
+   if (gene_eigen_of) *gene_eigen_of = p->ngene > 1 ? p->gene_eigen_of : NULL;
+   return p->ngene;
+}
 
 /* how many of the last site classes allow omega > 1 (the classes whose posterior the reference's NEB table sums):
  * 1 for M2a, M8 and the clade models, 2 for the branch-site models (classes 2a + 2b), 0 for models without such a class */

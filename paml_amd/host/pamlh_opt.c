@@ -42,12 +42,13 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
 {
    const int np = p->np, nt = p->ntime, nm = np - nt, nn = p->nnode;
    int *cand_of = (int *)malloc(nb * sizeof(int)), *cand_elem = (int *)malloc(nb * sizeof(int)), *cand_rep = (int *)malloc(nb * sizeof(int));
-   int ncand = 0, nrep = 0, b, c, i, rc = 0, K = 0, L = 1, n_eigen = 0, mode = 0;
+   int ncand = 0, nrep = 0, b, c, i, rc = 0, K = 0, L = 1, n_eigen = 0, mode = 0, n_pi = 1;
    pamlh **ws = (pamlh **)calloc(nb, sizeof(pamlh *));
    double *br = (double *)calloc((size_t)nb * nn, sizeof(double)), *fk = NULL, *rt = NULL, *rep_fk = NULL, *rep_rt = NULL;
    const double *pi = NULL;
    int *eo = NULL, *rep_eo = NULL, use_qf = 0;
-   double *qf = NULL, *rep_qf = NULL;
+   double *qf = NULL, *rep_qf = NULL, *gr = NULL;
+   const int G = p->ngene;
    if ((rc = pamlh_engine_ready(p))) goto done;
    for (b = 0; b < nb; b++) {          /* distinct model parts */
       const double *x = xs + (size_t)b * np;
@@ -68,20 +69,20 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       cand_rep[c] = -1;
       if (!q) continue;
       if (!nrep) {
-         K = q->K; L = q->n_labels; n_eigen = q->n_eigen; mode = q->mode; pi = q->pi;
+         K = q->K; L = q->n_labels * G; n_eigen = q->n_eigen; mode = q->mode; pi = q->pi; n_pi = q->n_pi;
          rep_fk = (double *)malloc((size_t)ncand * K * sizeof(double));
          rep_rt = (double *)malloc((size_t)ncand * K * sizeof(double));
          rep_eo = (int *)malloc((size_t)ncand * K * L * sizeof(int));
          rep_qf = (double *)malloc((size_t)ncand * K * L * sizeof(double));
          use_qf = q->use_qf;
       }
-      else if (q->K != K || q->n_labels != L || q->n_eigen != n_eigen || q->mode != mode) { rc = pamlh_fail(p, "internal: model shape changed inside a batch"); goto done; }
+      else if (q->K != K || q->n_labels * G != L || q->n_eigen != n_eigen || q->mode != mode) { rc = pamlh_fail(p, "internal: model shape changed inside a batch"); goto done; }
       if ((nrep + 1) * n_eigen > 4096) { rc = pamlh_fail(p, "batch needs more than 4096 eigen systems"); goto done; }
       q->eng = p->eng;
       if ((rc = upload_eigen(q, nrep * n_eigen))) { pamlh_fail(p, "%s", pamlh_error(q)); goto done; }
       memcpy(rep_fk + (size_t)nrep * K, q->freqK, K * sizeof(double));
       memcpy(rep_rt + (size_t)nrep * K, q->rate, K * sizeof(double));
-      for (i = 0; i < K * L; i++) rep_eo[(size_t)nrep * K * L + i] = nrep * n_eigen + q->eigen_of[i];
+      for (i = 0; i < K * L; i++) rep_eo[(size_t)nrep * K * L + i] = nrep * n_eigen + (G > 1 ? q->gene_eigen_of[i] : q->eigen_of[i]);
       for (i = 0; i < K * L; i++) rep_qf[(size_t)nrep * K * L + i] = q->use_qf ? q->qfactor[i] : 1.0;
       cand_rep[c] = nrep++;
    }
@@ -90,6 +91,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
    rt = (double *)malloc((size_t)nb * K * sizeof(double));
    eo = (int *)malloc((size_t)nb * K * L * sizeof(int));
    qf = (double *)malloc((size_t)nb * K * L * sizeof(double));
+   if (G > 1) gr = (double *)malloc((size_t)nb * G * sizeof(double));
    for (b = 0; b < nb; b++) {
       const double *x = xs + (size_t)b * np;
       const int r = cand_rep[cand_of[b]] < 0 ? 0 : cand_rep[cand_of[b]];
@@ -101,9 +103,11 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
          const int node = p->branch_node[i];
          br[(size_t)b * nn + node] = nt ? x[i] : p->tree_branch[node];
       }
+      if (gr) { gr[(size_t)b * G] = 1; for (i = 1; i < G; i++) gr[(size_t)b * G + i] = x[nt + i - 1]; }
    }
-   if ((rc = paml_amd_set_pi(p->eng, 1, pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, L, rep_eo, use_qf ? rep_qf : NULL)) ||
-       (rc = paml_amd_eval_batch(p->eng, nb, br, NULL, eo, use_qf ? qf : NULL, fk, rt, lnL, lnf))) {
+   /* (with several genes the tables are [gene][class]: one label, and L counts the genes) */
+   if ((rc = paml_amd_set_pi(p->eng, n_pi, pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, G > 1 ? 1 : L, rep_eo, use_qf ? rep_qf : NULL)) ||
+       (rc = paml_amd_eval_batch(p->eng, nb, br, gr, eo, use_qf ? qf : NULL, fk, rt, lnL, lnf))) {
       rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
       goto done;
    }
@@ -111,7 +115,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       if (cand_rep[cand_of[b]] < 0 || !(lnL[b] == lnL[b])) lnL[b] = -1e300;
 done:
    for (c = 0; c < ncand; c++) pamlh_state_free(ws[c]);
-   free(ws); free(cand_of); free(cand_elem); free(cand_rep); free(br); free(fk); free(rt); free(eo); free(rep_fk); free(rep_rt); free(rep_eo); free(qf); free(rep_qf);
+   free(ws); free(cand_of); free(cand_elem); free(cand_rep); free(br); free(fk); free(rt); free(eo); free(rep_fk); free(rep_rt); free(rep_eo); free(qf); free(rep_qf); free(gr);
    return rc;
 }
 
@@ -119,8 +123,11 @@ done:
  * [1e-4, 999], proportions (0, 1), beta and gamma shape parameters [0.005, 99], REV rates [1e-4, 999]. */
 int pamlh_bounds(const pamlh *p, double *lo, double *hi)
 {
-   int k = 0, i;
+   int k = 0, i, g;
+   const int rep = (p->ngene > 1 && p->mgene >= 3) ? p->ngene : 1;
    for (i = 0; i < p->ntime; i++) { lo[k] = 4e-6; hi[k++] = 50; }
+   for (i = 1; i < p->ngene; i++) { lo[k] = p->is_codeml ? 0.01 : 1e-4; hi[k++] = p->is_codeml ? 99 : 999; }      /* rgene (SetxBound) */
+   for (g = 0; g < rep; g++)
    if (p->seqtype == 1) {
       if (!p->fix_kappa) { lo[k] = 1e-4; hi[k++] = 999; }
       if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) { lo[k] = 1e-4; hi[k++] = 999; } }

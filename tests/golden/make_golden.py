@@ -283,17 +283,17 @@ def case_mhc():
                 scale_nodes=[int(v) for v in scal.group(2).split()] if scal else None))
 
 
-def case_mle(name, ctl_over, files, n_tips, kind, x0=None):
+def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtype="codon"):
     """Branch-site / clade / discrete models: the reference first maximises the likelihood from its own initial values (or x0),
     then the golden is the single evaluation at the printed 6-decimal estimates (the -1 recipe), whose lnL must agree with
     the maximised value to ~1e-5."""
-    ctl = dict(CODEML_BASE, outfile="mlc", **ctl_over)
-    res = run_ref("codeml", ctl, files) if x0 is None else run_ref("codeml", ctl, files, x=None)
+    ctl = dict(CODEML_BASE, outfile="mlc", **ctl_over) if prog == "codeml" else dict(BASEML_BASE, outfile="mlb", **ctl_over)
+    res = run_ref(prog, ctl, files)
     xs = re.search(r"lnL\(ntime:\s*(\d+)[^\n]*\n[^\n]*\n([^\n]+)\n", res["main"])
     ntime = int(xs.group(1))
     x = [float(v) for v in xs.group(2).split()]
     print("   %s: reference MLE lnL %.6f, np %d" % (name, res["lnL"], len(x)))
-    res1 = run_ref("codeml", ctl, files, x=x)
+    res1 = run_ref(prog, ctl, files, x=x)
     tables = {}
     for key, head in (("neb_post", "Naive Empirical Bayes (NEB) probabilities for"), ("beb_post", "Bayes Empirical Bayes (BEB) probabilities for")):
         if head in res1["rst"]:      # per-site class posteriors as the reference writes them to `rst` (5 decimals)
@@ -301,7 +301,7 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None):
             rows = re.findall(r"^\s*\d+ \S\s+((?:[01]\.\d{5}\s+)+)\(\s*\d+\)", blk, re.M)
             ls = int([ln for ln in res1["lnf"] if ln.split()][0].split()[1])
             tables[key] = [[float(v) for v in r.split()] for r in rows[:ls]]
-    finish(name, res1, "codon", n_tips, dict(tables, program="codeml", model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG") if k in ctl_over}),
+    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha") if k in ctl_over}),
                                              x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
 
 
@@ -311,7 +311,28 @@ ECP = {"ECP_EDN_15.nuc": EX + "/CladeModelCD/ECP_EDN_15.nuc", "tree.txt": EX + "
 ECP_CTL = dict(seqfile="ECP_EDN_15.nuc", treefile="tree.txt", kappa=2.5, omega=0.13579, ncatG=3, cleandata=0, Small_Diff=".2e-6")
 HIVF = {"HIVenvSweden.txt": EX + "/HIVNSsites/HIVenvSweden.txt", "HIVenvSweden.trees": EX + "/HIVNSsites/HIVenvSweden.trees"}
 
+HORAI = {"horai.nuc": EX + "/horai.nuc", "horai.trees": EX + "/horai.trees"}
+LYSIN = {"lysinYangSwanson2002.nuc": EX + "/lysin/lysinYangSwanson2002.nuc", "lysin.trees": EX + "/lysin/lysin.trees"}
+
+
+def case_horai(mgene, alpha=0):
+    """Option G (4 genes: the three codon positions and a tRNA part) in baseml, HKY85, Mgene = 0 / 2 / 3 / 4."""
+    over = dict(seqfile="horai.nuc", treefile="horai.trees", model=4, Mgene=mgene, kappa=5)
+    if alpha:
+        over.update(fix_alpha=0, alpha=alpha, ncatG=5)
+    case_mle("horai_mg%d%s" % (mgene, "_g5" if alpha else ""), over, HORAI, 6, "nuc_genes", prog="baseml", seqtype="nuc")
+
+
+def case_lysin(mgene):
+    """Option G in codeml (two site partitions of the sperm lysin, Yang & Swanson 2002), M0, Mgene = 0 / 2 / 3 / 4."""
+    over = dict(seqfile="lysinYangSwanson2002.nuc", treefile="lysin.trees", Mgene=mgene, kappa=1.6, omega=.8, cleandata=0, Small_Diff="3e-7")
+    case_mle("lysin_mg%d" % mgene, over, LYSIN, 25, "codon_genes")
+
+
 CASES = {
+    "horai_mg0": lambda: case_horai(0), "horai_mg2": lambda: case_horai(2), "horai_mg3": lambda: case_horai(3), "horai_mg4": lambda: case_horai(4),
+    "horai_mg0_g5": lambda: case_horai(0, 0.5),
+    "lysin_mg0": lambda: case_lysin(0), "lysin_mg2": lambda: case_lysin(2), "lysin_mg3": lambda: case_lysin(3), "lysin_mg4": lambda: case_lysin(4),
     "lyso_bsa": lambda: case_mle("lyso_bsa", dict(LYSO_CTL, model=2, NSsites=2, omega=1.5), LYSO, 19, "codon_branchsite"),
     "lyso_bsa_null": lambda: case_mle("lyso_bsa_null", dict(LYSO_CTL, model=2, NSsites=2, fix_omega=1, omega=1), LYSO, 19, "codon_branchsite"),
     "lyso_bsb": lambda: case_mle("lyso_bsb", dict(LYSO_CTL, model=2, NSsites=3, omega=1.5), LYSO, 19, "codon_branchsite"),

@@ -19,7 +19,12 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("mtcdna_branch", "codeml", "mtcdna_branch.ctl"),
          # branch-site A (alternative and null), B; clade C, D; M3 — goldens at the reference's own 6-decimal MLEs
          ("lyso_bsa", "codeml", "lyso_bsa.ctl"), ("lyso_bsa_null", "codeml", "lyso_bsa_null.ctl"), ("lyso_bsb", "codeml", "lyso_bsb.ctl"),
-         ("ecp_cmc", "codeml", "ecp_cmc.ctl"), ("ecp_cmd", "codeml", "ecp_cmd.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl")]
+         ("ecp_cmc", "codeml", "ecp_cmc.ctl"), ("ecp_cmd", "codeml", "ecp_cmd.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl"),
+         # option G (several genes): rates only (Mgene 0), + frequencies (2), + kappa / omega (3), both (4); one with gamma
+         ("horai_mg0", "baseml", "horai_mg0.ctl"), ("horai_mg2", "baseml", "horai_mg2.ctl"), ("horai_mg3", "baseml", "horai_mg3.ctl"),
+         ("horai_mg4", "baseml", "horai_mg4.ctl"), ("horai_mg0_g5", "baseml", "horai_mg0_g5.ctl"),
+         ("lysin_mg0", "codeml", "lysin_mg0.ctl"), ("lysin_mg2", "codeml", "lysin_mg2.ctl"), ("lysin_mg3", "codeml", "lysin_mg3.ctl"),
+         ("lysin_mg4", "codeml", "lysin_mg4.ctl")]
 
 
 def _x(g, a):
@@ -165,6 +170,20 @@ def test_c_host_clade_model_neb_and_beb_match_the_reference_rst(gname, ctl):
     beb = a.beb_acd(x)
     assert beb.shape == (3, g["ls"])
     assert np.max(np.abs(beb.T - np.array(g["beb_post"]))) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname,prog,ctl", [("horai_mg0_g5", "baseml", "horai_mg0_g5.ctl"), ("horai_mg4", "baseml", "horai_mg4.ctl"),
+                                            ("lysin_mg3", "codeml", "lysin_mg3.ctl")])
+def test_c_host_optimiser_with_several_genes(gname, prog, ctl):
+    """Option G data (examples/horai.nuc: four genes by site marks; lysinYangSwanson2002.nuc: two site partitions): gene rates
+    (rgene), per-gene frequencies and per-gene kappa / omega go through the engine's gene tables (pattern offsets, one pi and
+    one eigen system per gene, gene rates in the batched evaluations); from the control file's initial values the optimiser
+    reaches the reference's maximum."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), prog)
+    r = a.optimize(a.default_x())
+    assert r["converged"] and abs(r["lnL"] - g["mle_lnL"]) < 2e-5, (r["lnL"], g["mle_lnL"])
 
 
 @pytest.mark.gpu
