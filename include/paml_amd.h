@@ -203,6 +203,16 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
 /* Name of the pruning kernel the engine selected ("mfma64", "valu4", "valu20", ...). */
 const char *paml_amd_kernel_name(const paml_amd_engine *e);
 
+/* PatternWeight (treesub.c:1386-1516) on the device, stand-alone (no engine): collapse the n_sites alignment columns of
+ * chars[n_seq][n_sites * width] (raw characters; width = 1, or 3 for codons) into distinct site patterns in the reference's
+ * order — sorted by the characters of sequence 0, then sequence 1, ... (unsigned byte order = the strcmp order of the
+ * reference's char + 1 strings), within genes when gene[n_sites] (com.pose on input) is given.  Out: *n_patt; first_site
+ * [n_patt] = the first site showing each pattern (p2s[]), weights[n_patt] = com.fpatt, pose[n_sites] = pattern of every site
+ * (com.pose on output).  first_site and weights need room for n_sites entries.  A radix sort of the site indices over the
+ * key bytes, then run detection and a scan — HBM / latency-bound byte work.  PAML_AMD_EHIP when no device is visible. */
+int paml_amd_compress_patterns(int n_seq, int n_sites, int width, const unsigned char *chars, const int *gene, int *n_patt,
+                               int *first_site, double *weights, int *pose);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ EXPORTS = [
     "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
-    "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
+    "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
@@ -345,6 +345,23 @@ def debug_jit(tree, scale_node=None, compile=True, n_states=0):
     if rc < 0:
         raise EngineError("debug_jit failed (%d): %s" % (rc, buf.value.decode(errors="replace")[-3000:]))
     return buf.value.decode()
+
+
+def compress_patterns(chars, gene=None):
+    """PatternWeight on the device (paml_amd_compress_patterns): chars uint8 [n_seq][n_sites * width] or [n_seq][n_sites][width].
+    Returns dict(first_site[n_patt], weights[n_patt], pose[n_sites])."""
+    chars = np.ascontiguousarray(chars, dtype=np.uint8)
+    width = 1 if chars.ndim == 2 else chars.shape[2]
+    n_seq, n_sites = chars.shape[0], chars.shape[1]
+    g = None if gene is None else np.ascontiguousarray(gene, dtype=np.int32)
+    npatt = C.c_int()
+    first, w, pose = np.zeros(n_sites, dtype=np.int32), np.zeros(n_sites), np.zeros(n_sites, dtype=np.int32)
+    L = lib()
+    L.paml_amd_compress_patterns.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.paml_amd_compress_patterns(n_seq, n_sites, width, _p(chars), _p(g), C.byref(npatt), _p(first), _p(w), _p(pose))
+    if rc != 0:
+        raise EngineError("paml_amd_compress_patterns failed (%d)" % rc)
+    return dict(first_site=first[:npatt.value].copy(), weights=w[:npatt.value].copy(), pose=pose)
 
 
 def engine_for(pb: Problem, flags=0) -> Engine:

@@ -531,3 +531,42 @@ def test_branch_labels_select_eigen_systems(n, K, genes, jit):
         assert np.allclose(l, rl, rtol=1e-11, atol=0) and np.allclose(dl, rdl, rtol=1e-9, atol=1e-9) and np.allclose(ddl, rddl, rtol=1e-9, atol=1e-8)
     got = eng.eval_batch(np.stack([t.branch, t.branch]), gene_rate=np.tile(pb.gene_rate, (2, 1)))
     assert got[0] == got[1] and abs(got[0] - ref["lnL"]) <= 1e-10 * abs(ref["lnL"])
+
+
+def _lexsort_compress(chars, gene=None):
+    """numpy restatement of PatternWeight's result: patterns in sorted order of (gene, column bytes), first site, count, pose."""
+    n_seq, n_sites = chars.shape[0], chars.shape[1]
+    cols = chars.reshape(n_seq, n_sites, -1).transpose(1, 0, 2).reshape(n_sites, -1)          # [site][key bytes]
+    keys = [cols[:, k] for k in range(cols.shape[1] - 1, -1, -1)]
+    if gene is not None:
+        keys.append(gene)
+    order = np.lexsort(keys)                                                                     # stable: ties stay in site order
+    sc = cols[order]
+    head = np.ones(n_sites, dtype=bool)
+    head[1:] = (sc[1:] != sc[:-1]).any(axis=1)
+    if gene is not None:
+        head[1:] |= gene[order][1:] != gene[order][:-1]
+    pid = np.cumsum(head) - 1
+    pose = np.empty(n_sites, dtype=np.int64)
+    pose[order] = pid
+    return order[head], np.bincount(pid).astype(float), pose
+
+
+@pytest.mark.parametrize("n_seq,n_sites,width,alphabet,genes", [(5, 1000, 1, 4, 0), (16, 200_000, 3, 4, 0), (7, 50_001, 1, 20, 3),
+                                                                 (32, 300_000, 1, 2, 0), (3, 2049, 3, 17, 2), (2, 1, 1, 4, 0)])
+def test_compress_patterns_matches_lexsort(n_seq, n_sites, width, alphabet, genes):
+    """paml_amd_compress_patterns (radix sort of the alignment columns on the device) against numpy's lexsort: the same patterns
+    in the same order, the same first site per pattern, counts and site -> pattern map; few-symbol alignments give heavy
+    duplication, 16 x 3 random bases almost none; tile boundaries (2049 sites), one site, and gene partitions."""
+    rng = np.random.default_rng(n_sites + n_seq)
+    symbols = rng.choice(np.arange(33, 127), size=alphabet, replace=False).astype(np.uint8)
+    base = symbols[rng.integers(0, alphabet, size=(1, n_sites, width))]
+    chars = np.where(rng.random((n_seq, n_sites, width)) < 0.15, symbols[rng.integers(0, alphabet, size=(n_seq, n_sites, width))], base)
+    chars = np.ascontiguousarray(chars.astype(np.uint8))
+    gene = rng.integers(0, genes, n_sites).astype(np.int32) if genes else None
+    from paml_amd.engine import compress_patterns
+    got = compress_patterns(chars if width > 1 else chars[:, :, 0], gene)
+    first, w, pose = _lexsort_compress(chars, gene)
+    assert len(got["first_site"]) == len(first)
+    assert np.array_equal(got["first_site"], first) and np.array_equal(got["weights"], w) and np.array_equal(got["pose"], pose)
+    assert got["weights"].sum() == n_sites
