@@ -27,6 +27,7 @@ struct CompressArgs {
    const int *idx_in;
    int *idx_out;
    int *hist;                     // [256][n_tiles]
+   unsigned char *dig;            // [n_sites] digit of every sorted position, left by the histogram pass for the scatter
    int seq, pos;                  // key byte of this pass: chars[seq][site * width + pos]; seq < 0: the gene id
 };
 
@@ -50,7 +51,11 @@ __global__ __launch_bounds__(CMP_THREADS) void cmp_hist(CompressArgs a)
    const int base = blockIdx.x * CMP_TILE;
    for (int r = 0; r < CMP_TILE / CMP_THREADS; r++) {
       const int e = base + r * CMP_THREADS + threadIdx.x;
-      if (e < a.n_sites) atomicAdd(&h[cmp_digit(a, a.idx_in[e])], 1);
+      if (e < a.n_sites) {
+         const int d = cmp_digit(a, a.idx_in[e]);      // the random gather of the pass: done once, kept for the scatter
+         a.dig[e] = (unsigned char)d;
+         atomicAdd(&h[d], 1);
+      }
    }
    __syncthreads();
    a.hist[(long)threadIdx.x * a.n_tiles + blockIdx.x] = h[threadIdx.x];
@@ -76,6 +81,55 @@ __global__ __launch_bounds__(1024) void cmp_scan1(int *v, long m, int *total)
    if (total && threadIdx.x == 1023) *total = (int)s[1023];
 }
 
+// The [digit][tile] table of one pass has 256 rows of n_tiles counts.  Its exclusive scan in row-major order, coalesced:
+// row sums (one block per digit), a scan of the 256 sums (one wave-sized job), then every row scanned with its base.
+__global__ __launch_bounds__(CMP_THREADS) void cmp_row_sums(const int *hist, int n_tiles, int *rowsum)
+{
+   __shared__ int s[CMP_THREADS];
+   const int *row = hist + (long)blockIdx.x * n_tiles;
+   int t = 0;
+   for (int i = threadIdx.x; i < n_tiles; i += CMP_THREADS) t += row[i];
+   s[threadIdx.x] = t;
+   __syncthreads();
+   for (int st = CMP_THREADS / 2; st >= 1; st >>= 1) {
+      if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) rowsum[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(CMP_THREADS) void cmp_row_scan(int *hist, int n_tiles, const int *rowsum)
+{
+   __shared__ int s[CMP_THREADS], carry;
+   // base of this digit = sum of the rows before it (256 values: every block redoes this small sum)
+   int b = 0;
+   for (int d = threadIdx.x; d < (int)blockIdx.x; d += CMP_THREADS) b += rowsum[d];
+   s[threadIdx.x] = b;
+   __syncthreads();
+   for (int st = CMP_THREADS / 2; st >= 1; st >>= 1) {
+      if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) carry = s[0];
+   __syncthreads();
+   int *row = hist + (long)blockIdx.x * n_tiles;
+   for (int i0 = 0; i0 < n_tiles; i0 += CMP_THREADS) {
+      const int i = i0 + threadIdx.x, v = i < n_tiles ? row[i] : 0;
+      s[threadIdx.x] = v;
+      __syncthreads();
+      for (int off = 1; off < CMP_THREADS; off <<= 1) {
+         const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+         __syncthreads();
+         s[threadIdx.x] += t;
+         __syncthreads();
+      }
+      if (i < n_tiles) row[i] = carry + s[threadIdx.x] - v;
+      __syncthreads();
+      if (threadIdx.x == 0) carry += s[CMP_THREADS - 1];
+      __syncthreads();
+   }
+}
+
 __global__ __launch_bounds__(CMP_THREADS) void cmp_scatter(CompressArgs a)
 {
    __shared__ int base[256], wcnt[4][256];
@@ -88,7 +142,7 @@ __global__ __launch_bounds__(CMP_THREADS) void cmp_scatter(CompressArgs a)
       const int e = t0 + r * CMP_THREADS + threadIdx.x;
       const bool valid = e < a.n_sites;
       const int site = valid ? a.idx_in[e] : 0;
-      const int d = valid ? cmp_digit(a, site) : 0;
+      const int d = valid ? a.dig[e] : 0;
       // lanes of this wave holding the same digit
       unsigned long long m = __ballot(valid);
 #pragma unroll

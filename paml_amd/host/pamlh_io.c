@@ -265,7 +265,13 @@ int pamlh_read_seqs(pamlh *p)
             kg = (int *)malloc(nkeep * sizeof(int));
             for (h = 0; h < nkeep; h++) kg[h] = site_gene[keep[h]];
          }
-         if (!readpattern) {
+         if (!readpattern && getenv("PAMLH_GPU_COMPRESS") && getenv("PAMLH_GPU_COMPRESS")[0] == '1') {
+            /* the same result from the device (paml_amd_compress_patterns: radix sort of the columns); asked for explicitly,
+             * so a failure is an error, not a quiet return to the host sort */
+            const int rc = paml_amd_compress_patterns(ns, nkeep, n31, (const unsigned char *)p->raw, kg, &np, first, w, p->pose);
+            if (rc) return pamlh_fail(p, "PAMLH_GPU_COMPRESS=1 but paml_amd_compress_patterns failed (%d): no GPU?", rc);
+         }
+         else if (!readpattern) {
             g_sort_ctx = p;
             g_sort_gene = kg;
             qsort(idx, nkeep, sizeof(int), cmp_cols0);

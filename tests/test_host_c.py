@@ -188,6 +188,27 @@ def test_c_host_optimiser_with_several_genes(gname, prog, ctl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prog,ctl", [("baseml", "brown_hky85.ctl"), ("codeml", "hiv_ns0.ctl"), ("codeml", "mhc_m0.ctl"), ("codeml", "stewart_lg_g4.ctl"),
+                                      ("baseml", "horai_mg4.ctl"), ("codeml", "lysin_mg2.ctl"), ("codeml", "lyso_bsa.ctl")])
+def test_c_host_device_pattern_compression_gives_the_same_data(prog, ctl, monkeypatch):
+    """PAMLH_GPU_COMPRESS=1 routes PatternWeight through paml_amd_compress_patterns: patterns, their order, counts, the
+    site -> pattern map and everything derived (frequencies, lnL) must equal the host sort's — nucleotide, codon (3 characters
+    per site), amino-acid data with ambiguity characters, 192 taxa, and genes by marks."""
+    a = hostlib.Analysis(os.path.join(CTL, ctl), prog)
+    pa = a.problem(a.default_x())
+    monkeypatch.setenv("PAMLH_GPU_COMPRESS", "1")
+    b = hostlib.Analysis(os.path.join(CTL, ctl), prog)
+    monkeypatch.delenv("PAMLH_GPU_COMPRESS")
+    pb = b.problem(b.default_x())
+    assert (a.n_patt, a.ls) == (b.n_patt, b.ls)
+    assert np.array_equal(pa.z, pb.z) and np.array_equal(pa.weights, pb.weights) and np.array_equal(pa.gene_off, pb.gene_off)
+    assert np.array_equal(pa.pi, pb.pi)
+    la, _ = a.eval_gpu(a.default_x(), want_lnf=False)
+    lb, _ = b.eval_gpu(b.default_x(), want_lnf=False)
+    assert la == lb
+
+
+@pytest.mark.gpu
 def test_c_host_batch_matches_single_evaluations():
     g = helpers.load_golden("hiv_m2a")
     a = hostlib.Analysis(os.path.join(CTL, "hiv_ns2.ctl"), "codeml")
