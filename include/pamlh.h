@@ -89,6 +89,9 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w);
 /* Bayes empirical Bayes for M2a / M8 at the estimates x (lfunNSsites_M2M8 codeml.c:6387): posterior probability of the
  * w > 1 class, posterior mean and sd of omega, per pattern [n_patt].  f(x_h | w) for the grid's omegas is one evaluation on
  * the device; the 10^4-point grid sums run on the host. */
+/* Marginal ancestral reconstruction (RateAncestor = 1; AncestralMarginal treesub.c:6288) at the current model state:
+ * post[n_patt][n_states] = Pr(state at internal node `node` (0-based, >= n_tips) | pattern). */
+int pamlh_node_posterior(pamlh *p, int node, double *post);
 int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double *se_w);
 /* BEB under branch-site model A and clade models C / D with two branch types (lfunNSsites_ACD codeml.c:6827):
  * post[nc][n_patt] = posterior of the site classes; nc = 4 for A (classes 0, 1, 2a, 2b: Pr(positive selection on the foreground)

@@ -37,6 +37,7 @@ struct pamlh {
    int *n_chara;
    int *pose, n_pose;      /* site (after cleaning) -> pattern index */
    int ngene, posG[PAMLH_MAXGENE + 1], lgene[PAMLH_MAXGENE];   /* option G: first pattern / number of sites of every gene */
+   int m2a_rel;            /* NSsites = 22 */
    int mgene;              /* Mgene: 0 rates, 2 different pi, 3 different kappa (& omega), 4 both */
    double piG[PAMLH_MAXGENE][64];   /* frequencies of every gene (com.piG) */
    double rgene[PAMLH_MAXGENE];     /* com.rgene: rate of every gene relative to the first */

@@ -1,5 +1,5 @@
 /* pamlh_lnl — command-line driver: one likelihood evaluation of a codeml/baseml analysis on the MI355X.
- *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [x0 x1 ...]
+ *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [--ancestral] [x0 x1 ...]
  * Reads the control file, the sequence and tree files it names, and the parameter vector from the command line,
  * else from in.codeml / in.baseml beside the ctl (the reference's "-1 x..." single-evaluation recipe, treesub.c:4057),
  * else the ctl's initial values; evaluates lnL through libpaml_amd.so; prints `lnL = ...` like the reference and
@@ -16,12 +16,13 @@ int main(int argc, char **argv)
    pamlh *p;
    char err[512];
    double x[4096], lnL, *lnf;
-   int np, ntime, npatt, i, nx = 0, optimize = 0;
+   int np, ntime, npatt, i, nx = 0, optimize = 0, ancestral = 0;
    if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [x...]\n", argv[0]); return 2; }
    if (pamlh_load(&p, argv[2], argv[1], err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
    pamlh_dims(p, NULL, NULL, &npatt, NULL, NULL, NULL, NULL, NULL, &np, &ntime);
    for (i = 3; i < argc && nx < 4096; i++) {
       if (!strcmp(argv[i], "--optimize")) optimize = 1;
+      else if (!strcmp(argv[i], "--ancestral")) ancestral = 1;
       else x[nx++] = atof(argv[i]);
    }
    if (!nx) nx = pamlh_read_inx(p, x, 4096);
@@ -82,6 +83,37 @@ int main(int argc, char **argv)
          }
          free(post); free(mw);
       }
+   }
+   if (ancestral) {   /* RateAncestor = 1: most probable state and its probability at every internal node, per site (rst's marginal table) */
+      static const char *const alpha[3] = {"TCAG", "", "ARNDCQEGHILKMFPSTWYV"};
+      int n, ns, nnode, seqtype_n, n_sites, h, node, k;
+      const int *pose = pamlh_pose(p, &n_sites);
+      double *post, *best_p;
+      int *best;
+      pamlh_dims(p, &n, &ns, NULL, &nnode, NULL, NULL, NULL, NULL, NULL, NULL);
+      seqtype_n = n == 4 ? 0 : n == 20 ? 2 : 1;
+      post = (double *)malloc((size_t)npatt * n * sizeof(double));
+      best = (int *)malloc((size_t)(nnode - ns) * npatt * sizeof(int));
+      best_p = (double *)malloc((size_t)(nnode - ns) * npatt * sizeof(double));
+      for (node = ns; node < nnode; node++) {
+         if (pamlh_node_posterior(p, node, post)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
+         for (h = 0; h < npatt; h++) {
+            int bi = 0;
+            for (k = 1; k < n; k++) if (post[(size_t)h * n + k] > post[(size_t)h * n + bi]) bi = k;
+            best[(size_t)(node - ns) * npatt + h] = bi; best_p[(size_t)(node - ns) * npatt + h] = post[(size_t)h * n + bi];
+         }
+      }
+      printf("\nMarginal reconstruction of ancestral states: site, then for nodes %d..%d the most probable state (probability)\n", ns + 1, nnode);
+      for (h = 0; h < n_sites; h++) {
+         printf("%6d ", h + 1);
+         for (node = ns; node < nnode; node++) {
+            const int b = best[(size_t)(node - ns) * npatt + pose[h]];
+            if (seqtype_n == 1) printf(" %2d(%.3f)", b, best_p[(size_t)(node - ns) * npatt + pose[h]]);      /* codons: index among the sense codons */
+            else printf(" %c(%.3f)", alpha[seqtype_n][b], best_p[(size_t)(node - ns) * npatt + pose[h]]);
+         }
+         printf("\n");
+      }
+      free(post); free(best); free(best_p);
    }
    pamlh_write_lnf(p, "lnf", lnf);
    free(lnf);

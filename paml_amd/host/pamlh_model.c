@@ -239,6 +239,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    p->codonfreq = (int)pamlh_optd(p, "CodonFreq", 0);
    p->model = (int)pamlh_optd(p, "model", 0);
    p->nssites = (int)pamlh_optd(p, "NSsites", 0);
+   if (p->nssites == 22) { p->m2a_rel = 1; p->nssites = 2; }      /* M2a_rel (NSM2aRel): M2a without the w2 > 1 constraint, the null of clade model C */
    p->icode = (int)pamlh_optd(p, "icode", 0);
    p->fix_kappa = (int)pamlh_optd(p, "fix_kappa", 0);
    p->kappa0 = pamlh_optd(p, "kappa", 2);
@@ -260,6 +261,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->model != 0 && !(p->model == 2 && p->nssites == 0) && !((p->model == 2 || p->model == 3) && (p->nssites == 2 || p->nssites == 3))) {
          rc = pamlh_fail(p, "codon model = %d with NSsites = %d is not supported", p->model, p->nssites); goto bad;
       }
+      if (p->m2a_rel && p->model) { rc = pamlh_fail(p, "NSsites = 22 (M2a_rel) is a site model (model = 0)"); goto bad; }
       if (p->model == 2 && p->nssites == 3 && p->fix_omega) { rc = pamlh_fail(p, "fix_omega with branch-site model B is not supported"); goto bad; }
       if (p->model && p->nssites && (p->alpha0 > 0 || !p->fix_alpha)) { rc = pamlh_fail(p, "dN/dS ratios among branches are not supported with gamma rates"); goto bad; }
       if (p->model == 3) p->ncatG = 3;                /* "ncatG = 3 reset" (codeml.c:1607) */
@@ -857,6 +859,18 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
    return 0;
 }
 
+/* Marginal ancestral reconstruction at one node (PostProbNode treesub.c:6142, AncestralMarginal 6288) at the current model state:
+ * post[npatt][n] = Pr(state at `node` | pattern).  The engine walks the tree rooted at the node in one fused pass. */
+int pamlh_node_posterior(pamlh *p, int node, double *post)
+{
+   double lnL;
+   int rc;
+   if (node < p->ns || node >= p->nnode) return pamlh_fail(p, "node %d is not an internal node", node);
+   if ((rc = pamlh_eval_gpu(p, &lnL, NULL))) return rc;       /* uploads pi, eigen systems and classes of the current state */
+   if ((rc = paml_amd_node_posterior(p->eng, node, p->branch, p->ngene > 1 ? p->rgene : NULL, post))) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   return 0;
+}
+
 /* Naive empirical Bayes posteriors of the site classes (lfunNSsites_rate codeml.c:5241-5330) at the current model state
  * (pamlh_set_x): post[k][h] = freqK_k f(x_h | class k) / sum_j freqK_j f(x_h | class j) straight from the device's fhK.
  * post: [K][npatt].  For NSsites models mean_w[h] (may be NULL) gets the posterior mean omega of the pattern. */
@@ -909,7 +923,7 @@ int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double 
    const int ncls = m2a ? 3 : N1 + 1, K = m2a ? 2 * N1 + 1 : 2 * N1, ngrid = N1 * N1 * N1 * N1;
    double rK[2 * N1 + 1], para[4][N1], lnL, fX, *fhK, *pcl, *lnfXs, *Q, kappa, mr;
    int *iw, i, k, g, rc;
-   if (!(p->seqtype == 1 && p->model == 0 && (p->nssites == 2 || p->nssites == 8))) return pamlh_fail(p, "BEB is defined for NSsites 2 (M2a) and 8 (M8)");
+   if (!(p->seqtype == 1 && p->model == 0 && !p->m2a_rel && (p->nssites == 2 || p->nssites == 8))) return pamlh_fail(p, "BEB is defined for NSsites 2 (M2a) and 8 (M8)");
    if (p->scale) for (i = 0; i < p->nnode; i++) if (p->scale[i]) return pamlh_fail(p, "BEB with scaling nodes is not supported yet");
    if ((rc = pamlh_set_x(p, x, p->np))) return rc;
    kappa = p->kappa; mr = p->ns_mr;

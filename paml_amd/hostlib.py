@@ -210,6 +210,15 @@ class Analysis:
     def _is_branchsite(self):
         return self._L.pamlh_positive_classes(self._h) == 2
 
+    def node_posterior(self, x, node):
+        """Marginal reconstruction at internal node `node` (0-based) at x: post[n_patt][n] (pamlh_node_posterior)."""
+        self.set_x(x)
+        post = np.zeros((self.n_patt, self.n))
+        self._L.pamlh_node_posterior.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        if self._L.pamlh_node_posterior(self._h, int(node), post.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("pamlh_node_posterior: " + self._L.pamlh_error(self._h).decode())
+        return post
+
     def beb_acd(self, x):
         """BEB under branch-site model A (4 site classes: 0, 1, 2a, 2b) or clade model C / D (3) at x: class posteriors per site,
         [nc][n_sites] (pamlh_beb_acd)."""

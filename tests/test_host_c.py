@@ -19,7 +19,7 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("mtcdna_branch", "codeml", "mtcdna_branch.ctl"),
          # branch-site A (alternative and null), B; clade C, D; M3 — goldens at the reference's own 6-decimal MLEs
          ("lyso_bsa", "codeml", "lyso_bsa.ctl"), ("lyso_bsa_null", "codeml", "lyso_bsa_null.ctl"), ("lyso_bsb", "codeml", "lyso_bsb.ctl"),
-         ("ecp_cmc", "codeml", "ecp_cmc.ctl"), ("ecp_cmd", "codeml", "ecp_cmd.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl"),
+         ("ecp_cmc", "codeml", "ecp_cmc.ctl"), ("ecp_cmd", "codeml", "ecp_cmd.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl"), ("ecp_m2arel", "codeml", "ecp_m2arel.ctl"),
          # option G (several genes): rates only (Mgene 0), + frequencies (2), + kappa / omega (3), both (4); one with gamma
          ("horai_mg0", "baseml", "horai_mg0.ctl"), ("horai_mg2", "baseml", "horai_mg2.ctl"), ("horai_mg3", "baseml", "horai_mg3.ctl"),
          ("horai_mg4", "baseml", "horai_mg4.ctl"), ("horai_mg0_g5", "baseml", "horai_mg0_g5.ctl"),
@@ -206,6 +206,24 @@ def test_c_host_device_pattern_compression_gives_the_same_data(prog, ctl, monkey
     la, _ = a.eval_gpu(a.default_x(), want_lnf=False)
     lb, _ = b.eval_gpu(b.default_x(), want_lnf=False)
     assert la == lb
+
+
+@pytest.mark.gpu
+def test_c_host_marginal_reconstruction_matches_the_reference_rst():
+    """RateAncestor = 1 through the C host: most probable base and its probability at the three internal nodes of the brown.nuc
+    tree for every pattern, as the reference's `rst` lists them (tests/golden/brown_hky85_anc.json)."""
+    g = helpers.load_golden("brown_hky85_anc")
+    a = hostlib.Analysis(os.path.join(CTL, "brown_hky85.ctl"), "baseml")
+    raw = ["".join(chr(c) for c in col) for col in a.raw_patterns().T] if hasattr(a, "raw_patterns") else None
+    pb = a.problem(np.array(g["x"]))
+    for k, node in enumerate(g["nodes_1based"]):
+        post = a.node_posterior(np.array(g["x"]), node - 1)
+        assert np.allclose(post.sum(axis=1), 1)
+        for h in range(a.n_patt):
+            patt = "".join("TCAG"[c] for c in pb.z[:, h])
+            row = g["patterns"][patt]
+            i = int(np.argmax(post[h]))
+            assert "TCAG"[i] == row["best"][k] and abs(post[h, i] - row["prob"][k]) < 6e-4
 
 
 @pytest.mark.gpu
