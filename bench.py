@@ -67,7 +67,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # (PAML_AMD_BENCH_FORCE_DIST=1 runs the collective path in a 1-rank group: a check of that code on a single-GPU box)
+    use_dist = world > 1 or os.environ.get("PAML_AMD_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from paml_amd import engine, synth
@@ -83,41 +88,54 @@ def main():
     eng = engine.engine_for(pb)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
-    d_lnl = torch.zeros(1, dtype=torch.float64, device="cuda")
+    d_lnl = torch.zeros(args.warmup + args.steps, dtype=torch.float64, device="cuda")      # one slot per evaluation
     branch = pb.tree.branch.copy()
+    pending = []
 
-    def step():
+    def step(i):
         # one likelihood evaluation of the whole alignment: P(t) for every branch, the pruning kernel, the weighted
         # reduction, and (N > 1) the all-reduce of the scalar.  Everything is enqueued on the stream; the lnL value stays
         # on the device, so consecutive evaluations run back to back (a gradient's evaluations are independent of each
-        # other's results) and the host only synchronises at the fences around the timed region.
-        eng.eval_device(branch, d_lnl.data_ptr())
-        if world > 1:
-            dist.all_reduce(d_lnl)
-
-    for _ in range(args.warmup):
-        step()
-    lnl_warm = float(d_lnl.item())
+        # other's results) and the host only synchronises at the fences around the timed region.  Each evaluation has its
+        # own result slot, so its 8-byte all-reduce (RCCL's stream, ordered after the evaluation by an event) overlaps the
+        # next evaluation instead of stalling the compute stream for a collective's latency.
+        eng.eval_device(branch, d_lnl.data_ptr() + 8 * i)
+        if use_dist:
+            if os.environ.get("PAML_AMD_BENCH_SYNC_ALLREDUCE") == "1":      # A/B switch: the collective in line with the compute stream
+                dist.all_reduce(d_lnl[i:i + 1])
+            else:
+                pending.append(dist.all_reduce(d_lnl[i:i + 1], async_op=True))
 
     def fence():
+        while pending:
+            pending.pop().wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    lnl_warm = float(d_lnl[args.warmup - 1].item()) if args.warmup else None
 
     eng.profile(True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    lnl = float(d_lnl.item())
+    lnl = float(d_lnl[-1].item())
+    if lnl_warm is None:
+        lnl_warm = lnl
+    if not bool(torch.all(torch.abs(d_lnl - lnl) <= 1e-12 * abs(lnl))):
+        raise SystemExit("bench: lnL differs between evaluations: %r" % (d_lnl.tolist(),))
     if not abs(lnl - lnl_warm) <= 1e-12 * abs(lnl_warm):      # same inputs every step (the sum order of an all-reduce may differ)
         raise SystemExit("bench: lnL changed between evaluations (%r vs %r)" % (lnl, lnl_warm))
     prof = eng.profile_read()
     eng.profile(False)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -151,7 +169,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pb, args.cpu_sample)
             out["speedup_vs_cpu_1core"] = value / world / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
