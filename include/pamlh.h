@@ -89,6 +89,10 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w);
 /* Bayes empirical Bayes for M2a / M8 at the estimates x (lfunNSsites_M2M8 codeml.c:6387): posterior probability of the
  * w > 1 class, posterior mean and sd of omega, per pattern [n_patt].  f(x_h | w) for the grid's omegas is one evaluation on
  * the device; the 10^4-point grid sums run on the host. */
+/* com.plfun's calling convention (codeml.c:125 / baseml.c:70): SetParameters(x) + one likelihood evaluation on the GPU,
+ * returns -lnL (what ming2 minimises); +1e300 on error (see pamlh_error). */
+double pamlh_plfun(pamlh *p, const double *x, int np);
+
 /* Marginal ancestral reconstruction (RateAncestor = 1; AncestralMarginal treesub.c:6288) at the current model state:
  * post[n_patt][n_states] = Pr(state at internal node `node` (0-based, >= n_tips) | pattern). */
 int pamlh_node_posterior(pamlh *p, int node, double *post);

@@ -859,6 +859,16 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
    return 0;
 }
 
+/* The reference's objective-function seam, `double (*com.plfun)(double x[], int np)` (codeml.c:125, baseml.c:70): SetParameters(x)
+ * followed by the likelihood evaluation, returning MINUS lnL — the value ming2 minimises — so a driver written against com.plfun
+ * can call this instead.  Errors (a parameter vector the model rejects, no GPU) give +1e300 with the message in pamlh_error. */
+double pamlh_plfun(pamlh *p, const double *x, int np)
+{
+   double lnL;
+   if (pamlh_set_x(p, x, np) || !pamlh_model_feasible(p) || pamlh_eval_gpu(p, &lnL, NULL)) return 1e300;
+   return -lnL;
+}
+
 /* Marginal ancestral reconstruction at one node (PostProbNode treesub.c:6142, AncestralMarginal 6288) at the current model state:
  * post[npatt][n] = Pr(state at `node` | pattern).  The engine walks the tree rooted at the node in one fused pass. */
 int pamlh_node_posterior(pamlh *p, int node, double *post)

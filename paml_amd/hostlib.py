@@ -210,6 +210,13 @@ class Analysis:
     def _is_branchsite(self):
         return self._L.pamlh_positive_classes(self._h) == 2
 
+    def plfun(self, x):
+        """-lnL at x with com.plfun's convention (pamlh_plfun)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        self._L.pamlh_plfun.restype = C.c_double
+        self._L.pamlh_plfun.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        return self._L.pamlh_plfun(self._h, x.ctypes.data_as(C.c_void_p), len(x))
+
     def node_posterior(self, x, node):
         """Marginal reconstruction at internal node `node` (0-based) at x: post[n_patt][n] (pamlh_node_posterior)."""
         self.set_x(x)

@@ -227,6 +227,18 @@ def test_c_host_marginal_reconstruction_matches_the_reference_rst():
 
 
 @pytest.mark.gpu
+def test_c_host_plfun_seam():
+    """pamlh_plfun has com.plfun's convention: x in, MINUS lnL out; a vector the model rejects gives +1e300, not an exit."""
+    g = helpers.load_golden("hiv_m2a")
+    a = hostlib.Analysis(os.path.join(CTL, "hiv_ns2.ctl"), "codeml")
+    x = np.array(g["x"])
+    assert abs(a.plfun(x) + g["lnL"]) <= 2e-6
+    x[a.ntime + 1] = 0.9          # p0 + p1 > 1
+    assert a.plfun(x) == 1e300
+    assert a.plfun(x[:-1]) == 1e300
+
+
+@pytest.mark.gpu
 def test_c_host_batch_matches_single_evaluations():
     g = helpers.load_golden("hiv_m2a")
     a = hostlib.Analysis(os.path.join(CTL, "hiv_ns2.ctl"), "codeml")
