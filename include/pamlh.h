@@ -89,6 +89,11 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w);
 /* Bayes empirical Bayes for M2a / M8 at the estimates x (lfunNSsites_M2M8 codeml.c:6387): posterior probability of the
  * w > 1 class, posterior mean and sd of omega, per pattern [n_patt].  f(x_h | w) for the grid's omegas is one evaluation on
  * the device; the 10^4-point grid sums run on the host. */
+/* Reporting: the name of parameter i of x[] ("t 6..7", "kappa", "p0", "w2 (foreground)", ...), and the tree in Newick form with
+ * the branch lengths of the current model state (buf needs 64 bytes per node + 128). */
+int pamlh_param_name(const pamlh *p, int i, char *buf, int cap);
+int pamlh_newick(const pamlh *p, char *buf, int cap);
+
 /* com.plfun's calling convention (codeml.c:125 / baseml.c:70): SetParameters(x) + one likelihood evaluation on the GPU,
  * returns -lnL (what ming2 minimises); +1e300 on error (see pamlh_error). */
 double pamlh_plfun(pamlh *p, const double *x, int np);

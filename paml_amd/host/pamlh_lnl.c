@@ -34,6 +34,15 @@ int main(int argc, char **argv)
       printf("%s after %d likelihood evaluations\nx:", rc ? "iteration limit reached" : "converged", n_eval);
       for (i = 0; i < np; i++) printf(" %.6f", x[i]);
       printf("\n");
+      for (i = ntime; i < np; i++) { char nm[64]; pamlh_param_name(p, i, nm, sizeof(nm)); printf("  %-24s %12.6f\n", nm, x[i]); }
+      {
+         int nnode = 0;
+         char *nw;
+         pamlh_dims(p, NULL, NULL, NULL, &nnode, NULL, NULL, NULL, NULL, NULL, NULL);
+         nw = (char *)malloc((size_t)160 * nnode + 256);
+         if (!pamlh_set_x(p, x, np) && !pamlh_newick(p, nw, 160 * nnode + 256)) printf("%s\n", nw);
+         free(nw);
+      }
       {
          double *se = (double *)malloc((np + 1) * sizeof(double));
          if (!pamlh_standard_errors(p, x, 0, se, NULL)) {

@@ -859,6 +859,75 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
    return 0;
 }
 
+/* Name of parameter i of x[] (branch lengths are "t <node>..<node>" in the reference's numbering, tree.branches order). */
+int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
+{
+   int k = p->ntime, g, j;
+   const int rep = (p->ngene > 1 && p->mgene >= 3) ? p->ngene : 1;
+   if (i < 0 || i >= p->np) return -1;
+   if (i < p->ntime) { const int node = p->branch_node[i]; snprintf(buf, cap, "t %d..%d", p->father[node] + 1, node + 1); return 0; }
+   if (i < k + p->ngene - 1) { snprintf(buf, cap, "rgene%d", i - k + 2); return 0; }
+   k += p->ngene - 1;
+#define NAME(...) do { if (i == k) { snprintf(buf, cap, __VA_ARGS__); return 0; } k++; } while (0)
+   for (g = 0; g < rep; g++) {
+      char sfx[16] = "";
+      if (rep > 1) snprintf(sfx, sizeof(sfx), " (gene %d)", g + 1);
+      if (p->seqtype == 1) {
+         if (!p->fix_kappa) NAME("kappa%s", sfx);
+         if (p->nssites == 0 && p->model == 2) { for (j = 0; j < p->n_omega; j++) NAME("omega #%d", j); }
+         else if (p->model >= 2) {
+            NAME("p0"); NAME("p1"); NAME("w0");
+            if (p->nssites == 3) NAME("w1");
+            if (p->model == 2) { if (p->nssites == 3 || !p->fix_omega) NAME("w2 (foreground)"); }
+            else for (j = 0; j < p->n_omega - (p->fix_omega != 0); j++) NAME("w%d (branch type %d)", 2 + j, j);
+         }
+         else if (p->nssites == 0) { if (!p->fix_omega) NAME("omega%s", sfx); }
+         else if (p->nssites == 1) { NAME("p0"); NAME("w0"); }
+         else if (p->nssites == 2) { NAME("p0"); NAME("p1"); NAME("w0"); NAME("w2"); }
+         else if (p->nssites == 3) { for (j = 0; j < p->ncatG - 1; j++) NAME("p%d", j); for (j = 0; j < p->ncatG; j++) NAME("w%d", j); }
+         else if (p->nssites == 7) { NAME("p (beta)"); NAME("q (beta)"); }
+         else if (p->nssites == 8) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); if (!p->fix_omega) NAME("ws"); }
+      }
+      else if (p->seqtype == 0) {
+         if (p->model == REV) { static const char *const r[5] = {"a (TC)", "b (TA)", "c (TG)", "d (CA)", "e (CG)"}; for (j = 0; j < 5; j++) NAME("%s%s", r[j], sfx); }
+         else if (p->model == TN93 && !p->fix_kappa) { NAME("kappa1%s", sfx); NAME("kappa2%s", sfx); }
+         else if ((p->model == K80 || p->model == HKY85) && !p->fix_kappa) NAME("kappa%s", sfx);
+      }
+   }
+   if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) NAME("alpha");
+#undef NAME
+   snprintf(buf, cap, "x%d", i);
+   return 0;
+}
+
+static void newick_rec(const pamlh *p, int node, char **w, char *end)
+{
+   int j;
+   if (node < p->ns) *w += snprintf(*w, end - *w, "%s", p->names[node]);
+   else {
+      *w += snprintf(*w, end - *w, "(");
+      for (j = p->sons_ptr[node]; j < p->sons_ptr[node + 1]; j++) {
+         if (j > p->sons_ptr[node]) *w += snprintf(*w, end - *w, ", ");
+         newick_rec(p, p->sons[j], w, end);
+      }
+      *w += snprintf(*w, end - *w, ")");
+   }
+   if (node != p->root) {
+      if (p->label[node]) *w += snprintf(*w, end - *w, " #%d", p->label[node]);
+      *w += snprintf(*w, end - *w, ": %.6f", p->branch[node]);
+   }
+}
+
+/* The tree in Newick form with the branch lengths of the current model state (pamlh_set_x) and the '#' labels it was read with. */
+int pamlh_newick(const pamlh *p, char *buf, int cap)
+{
+   char *w = buf;
+   if (cap < 64 * p->nnode + 128) return -1;
+   newick_rec(p, p->root, &w, buf + cap);
+   snprintf(w, buf + cap - w, ";");
+   return 0;
+}
+
 /* The reference's objective-function seam, `double (*com.plfun)(double x[], int np)` (codeml.c:125, baseml.c:70): SetParameters(x)
  * followed by the likelihood evaluation, returning MINUS lnL — the value ming2 minimises — so a driver written against com.plfun
  * can call this instead.  Errors (a parameter vector the model rejects, no GPU) give +1e300 with the message in pamlh_error. */
