@@ -1,7 +1,8 @@
 /* pamlh.h — host side of the MI355X likelihood engine, in C as the reference is.
  *
  * It reads the same inputs the reference programs read — the `.ctl` file (GetOptions codeml.c:1694 / baseml.c:954),
- * the sequence file (ReadSeq treesub.c:487: PHYLIP sequential / interleaved, `.` repeats, the `P` pattern format),
+ * the sequence file (ReadSeq treesub.c:487: PHYLIP sequential / interleaved, `.` repeats, the `P` pattern format, options G / GC;
+ * aligned FASTA and NEXUS, GetSeqFileType treesub.c:367),
  * the tree file (ReadTreeN treesub.c:3048) and `in.codeml` / `in.baseml` (readx treesub.c:4035) — compresses sites
  * into patterns in the reference's order (PatternWeight treesub.c:1386), encodes them (EncodeSeqs 1116,
  * SetMapAmbiguity 1218), and turns a parameter vector x[] into the engine's inputs the way SetParameters

@@ -99,9 +99,77 @@ static int base_set(char c, int *set)
    return n;
 }
 
-int pamlh_read_seqs(pamlh *p)
+/* The sequence file as a stream in the native format.  Aligned FASTA ('>' first) and NEXUS ("begin data" ... ntax= nchar= ...
+ * "matrix") files (GetSeqFileType / ScanFastaFile treesub.c:367-419) are rewritten in memory as "ns ls" + one
+ * "name  sequence" line per sequence, which the reader below takes as sequential PHYLIP. */
+static FILE *open_seqfile(pamlh *p, char **mem)
 {
    FILE *f = fopen(p->seqfile, "r");
+   long len;
+   char *txt, *out, *q, *w;
+   int ns = 0, ls = -1, a, b;
+   *mem = NULL;
+   if (!f) return NULL;
+   fseek(f, 0, SEEK_END); len = ftell(f); rewind(f);
+   txt = (char *)malloc(len + 1);
+   if (fread(txt, 1, len, f) != (size_t)len) { free(txt); rewind(f); return f; }
+   txt[len] = 0;
+   for (q = txt; *q && isspace((unsigned char)*q); q++) ;
+   if (*q != '>' && sscanf(q, "%d%d", &a, &b) == 2) { free(txt); rewind(f); return f; }      /* native format */
+   fclose(f);
+   out = (char *)malloc(2 * len + 64);
+   w = out + 32;                        /* room for the "ns ls" line in front */
+   if (*q == '>') {                     /* FASTA: >name, then the sequence over any number of lines */
+      while (*q == '>') {
+         int n = 0;
+         for (q++; *q && *q != '\n' && *q != '\r'; q++) *w++ = isspace((unsigned char)*q) ? '_' : *q;
+         *w++ = ' '; *w++ = ' ';
+         for (; *q && *q != '>'; q++)
+            if (!isspace((unsigned char)*q)) { *w++ = *q; n++; }
+         *w++ = '\n';
+         if (ls >= 0 && n != ls) { pamlh_fail(p, "the seq file appears to be in fasta format, but not aligned (sequence %d has %d characters, the first %d)", ns + 1, n, ls); free(txt); free(out); return NULL; }
+         ls = n; ns++;
+      }
+   }
+   else {                               /* NEXUS */
+      char *low = (char *)malloc(len + 1), *m, *e;
+      for (a = 0; a <= len; a++) low[a] = (char)tolower((unsigned char)txt[a]);
+      m = strstr(low, "begin data");
+      if (m && (e = strstr(m, "ntax"))) { e = strchr(e, '='); if (e) ns = atoi(e + 1); }
+      if (m && (e = strstr(m, "nchar"))) { e = strchr(e, '='); if (e) ls = atoi(e + 1); }
+      m = m ? strstr(m, "matrix") : NULL;
+      if (!m || ns < 1 || ls < 1) { pamlh_fail(p, "%s is neither PHYLIP, FASTA nor NEXUS (begin data / ntax= nchar= / matrix)", p->seqfile); free(txt); free(out); free(low); return NULL; }
+      q = txt + (m - low) + 6;
+      while (*q && *q != '\n') q++;     /* the rest of the "matrix" line */
+      for (a = 0; a < ns; a++) {        /* name, then characters until ls are in; [comments] skipped */
+         int n = 0;
+         while (*q && isspace((unsigned char)*q)) q++;
+         while (*q && !isspace((unsigned char)*q)) *w++ = *q++;
+         *w++ = ' '; *w++ = ' ';
+         for (; *q && n < ls; q++) {
+            if (*q == '[') { while (*q && *q != ']') q++; continue; }
+            if (!isspace((unsigned char)*q)) { *w++ = *q; n++; }
+         }
+         *w++ = '\n';
+         if (n != ls) { pamlh_fail(p, "NEXUS matrix: sequence %d has %d of %d characters", a + 1, n, ls); free(txt); free(out); free(low); return NULL; }
+      }
+      free(low);
+   }
+   *w = 0;
+   {
+      char head[32];
+      const int hl = snprintf(head, sizeof(head), "%d %d\n", ns, ls);
+      memcpy(out + 32 - hl, head, hl);
+      *mem = out;
+      free(txt);
+      return fmemopen(out + 32 - hl, (size_t)(w - (out + 32 - hl)), "r");
+   }
+}
+
+int pamlh_read_seqs(pamlh *p)
+{
+   char *seqmem = NULL;
+   FILE *f = open_seqfile(p, &seqmem);
    char *line;
    size_t cap = 1 << 16;
    int ns, lsraw, i, j, k, h, readpattern = 0, interleaved = 0, any_amb = 0, n31 = (p->seqtype == 1 ? 3 : 1);
@@ -109,7 +177,7 @@ int pamlh_read_seqs(pamlh *p)
    const char *alpha = p->seqtype == 2 ? AAs : BASEs;
    const int nbasic = p->seqtype == 2 ? 20 : 4;
    char *seq;
-   if (!f) return pamlh_fail(p, "cannot open sequence file %s", p->seqfile);
+   if (!f) return p->err[0] ? -1 : pamlh_fail(p, "cannot open sequence file %s", p->seqfile);
    line = (char *)malloc(cap);
    if (!fgets(line, (int)cap, f) || sscanf(line, "%d %d", &ns, &lsraw) != 2) { fclose(f); return pamlh_fail(p, "bad first line in %s", p->seqfile); }
    {  /* option letters after the two numbers */
@@ -321,7 +389,7 @@ int pamlh_read_seqs(pamlh *p)
       }
       free(idx); free(keep); free(cnt);
    }
-   free(seq); free(line); free(site_gene);
+   free(seq); free(line); free(site_gene); free(seqmem);
 
    /* encode (EncodeSeqs / SetMapAmbiguity) */
    {

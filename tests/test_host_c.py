@@ -49,6 +49,45 @@ def test_c_host_reproduces_reference_on_cpu(gname, prog, ctl):
         assert abs(r["lnL"] - g["published_lnL"]) < 5e-6
 
 
+def _brown_sequences():
+    txt = open(os.path.join(helpers.GOLDEN, "data", "brown.nuc")).read().split("\n")
+    ns, ls = [int(v) for v in txt[0].split()[:2]]
+    names, seqs = [], []
+    for ln in txt[1:]:
+        if not ln.strip():
+            continue
+        if len(names) == ns and len(seqs[-1]) >= ls:
+            break
+        toks = ln.split()
+        if not names or len(seqs[-1]) >= ls:
+            names.append(toks[0]); seqs.append("".join(toks[1:]))
+        else:
+            seqs[-1] += "".join(toks)
+    return names, seqs, ls
+
+
+@pytest.mark.parametrize("fmt", ["fasta", "nexus"])
+def test_c_host_reads_fasta_and_nexus(tmp_path, fmt):
+    """Aligned FASTA and NEXUS sequence files (GetSeqFileType treesub.c:367; the reference binary gives -2665.422858 on these
+    renderings of brown.nuc as on the original): the same patterns, counts and lnL as the native file."""
+    names, seqs, ls = _brown_sequences()
+    f = tmp_path / ("brown." + fmt)
+    if fmt == "fasta":
+        f.write_text("".join(">%s\n%s\n" % (n, "\n".join(s[i:i + 70] for i in range(0, ls, 70))) for n, s in zip(names, seqs)))
+    else:
+        f.write_text("#NEXUS\n\nBegin Data;\n  Dimensions ntax=%d nchar=%d;\n  Format datatype=dna missing=? gap=-;\n  Matrix\n" % (len(names), ls) +
+                     "".join("%s   %s [a comment]\n" % (n, s) for n, s in zip(names, seqs)) + ";\nEnd;\n")
+    ctl = tmp_path / "baseml.ctl"
+    ctl.write_text(open(os.path.join(CTL, "brown_hky85.ctl")).read().replace("../data/brown.nuc", str(f))
+                   .replace("../data/brown.trees", os.path.join(helpers.GOLDEN, "data", "brown.trees")))
+    g = helpers.load_golden("brown_hky85")
+    a = hostlib.Analysis(str(ctl), "baseml")
+    b = hostlib.Analysis(os.path.join(CTL, "brown_hky85.ctl"), "baseml")
+    pa, pb = a.problem(np.array(g["x"])), b.problem(np.array(g["x"]))
+    assert np.array_equal(pa.z, pb.z) and np.array_equal(pa.weights, pb.weights) and np.array_equal(pa.pi, pb.pi)
+    assert abs(oracle.evaluate(pa)["lnL"] - g["lnL"]) <= 2e-6
+
+
 def test_c_host_rejects_what_it_does_not_support(tmp_path):
     ctl = tmp_path / "x.ctl"
     ctl.write_text("seqfile = %s\ntreefile = %s\nseqtype = 1\nmodel = 1\nNSsites = 0\n" %
