@@ -143,7 +143,12 @@ static FILE *open_seqfile(pamlh *p, char **mem)
       while (*q && *q != '\n') q++;     /* the rest of the "matrix" line */
       for (a = 0; a < ns; a++) {        /* name, then characters until ls are in; [comments] skipped */
          int n = 0;
-         while (*q && isspace((unsigned char)*q)) q++;
+         for (;;) {                     /* white space and [comments] in front of the name */
+            while (*q && isspace((unsigned char)*q)) q++;
+            if (*q != '[') break;
+            while (*q && *q != ']') q++;
+            if (*q) q++;
+         }
          while (*q && !isspace((unsigned char)*q)) *w++ = *q++;
          *w++ = ' '; *w++ = ' ';
          for (; *q && n < ls; q++) {
