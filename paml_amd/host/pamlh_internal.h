@@ -37,6 +37,7 @@ struct pamlh {
    int *n_chara;
    int *pose, n_pose;      /* site (after cleaning) -> pattern index */
    int ngene, posG[PAMLH_MAXGENE + 1], lgene[PAMLH_MAXGENE];   /* option G: first pattern / number of sites of every gene */
+   int clock;              /* 1: global clock, x holds the internal node ages */
    int m2a_rel;            /* NSsites = 22 */
    int mgene;              /* Mgene: 0 rates, 2 different pi, 3 different kappa (& omega), 4 both */
    double piG[PAMLH_MAXGENE][64];   /* frequencies of every gene (com.piG) */
@@ -84,6 +85,7 @@ int pamlh_read_tree(pamlh *p);
 int pamlh_fail(pamlh *p, const char *fmt, ...);
 int pamlh_engine_ready(pamlh *p);
 int pamlh_model_feasible(const pamlh *p);
+int pamlh_x_to_branches(const pamlh *p, const double *x, double *branch);
 pamlh *pamlh_state_clone(const pamlh *p);
 void pamlh_state_free(pamlh *q);
 #endif

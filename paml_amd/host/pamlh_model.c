@@ -250,7 +250,8 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    p->ncatG = (int)pamlh_optd(p, "ncatG", 4);
    p->cleandata_opt = (int)pamlh_optd(p, "cleandata", 0);
    p->fix_blength = (int)pamlh_optd(p, "fix_blength", 0);
-   if ((int)pamlh_optd(p, "clock", 0) != 0) { rc = pamlh_fail(p, "clock models are not supported"); goto bad; }
+   p->clock = (int)pamlh_optd(p, "clock", 0);
+   if (p->clock != 0 && p->clock != 1) { rc = pamlh_fail(p, "clock = %d is not supported (0: no clock, 1: global clock)", p->clock); goto bad; }
    p->mgene = (int)pamlh_optd(p, "Mgene", 0);
    if (p->mgene == 1) { rc = pamlh_fail(p, "Mgene = 1 (separate analyses) is not supported: run each gene on its own"); goto bad; }
    if (p->mgene < 0 || p->mgene > 4) { rc = pamlh_fail(p, "Mgene = %d?", p->mgene); goto bad; }
@@ -312,6 +313,14 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    else freqs_base_aa(p);
    /* parameter bookkeeping (GetInitials): ntime, np */
    p->ntime = p->fix_blength == 2 ? 0 : p->nbranch;
+   if (p->clock) {
+      /* global clock (SetBranch treesub.c:3793-3809, GetInitialsTimes 3814): a rooted binary tree, the parameters are the ages
+       * of the ns - 1 internal nodes (in node order; this is the reference's layout once LASTROUND is set), tips at age 0 */
+      if (p->fix_blength == 2) { rc = pamlh_fail(p, "clock with fix_blength = 2"); goto bad; }
+      if (p->sons_ptr[p->root + 1] - p->sons_ptr[p->root] != 2 || p->nnode != 2 * p->ns - 1) { rc = pamlh_fail(p, "clock = 1 needs a rooted binary tree"); goto bad; }
+      if (p->seqtype == 1 && p->model) { rc = pamlh_fail(p, "model and clock do not work together"); goto bad; }
+      p->ntime = p->ns - 1;
+   }
    {
       int nr = p->ngene - 1;       /* rgene */
       const int rep = p->mgene >= 3 ? p->ngene : 1;
@@ -425,6 +434,15 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
 {
    int k = 0, i;
    if (cap < p->np) return -1;
+   if (p->clock) {         /* ages: 0.04 per level above the deepest tip */
+      int node, changed = 1, *hgt = (int *)calloc(p->nnode, sizeof(int));
+      while (changed)
+         for (changed = 0, node = 0; node < p->nnode; node++)
+            if (node != p->root && hgt[p->father[node]] < hgt[node] + 1) { hgt[p->father[node]] = hgt[node] + 1; changed = 1; }
+      for (node = p->ns; node < p->nnode; node++) x[k++] = 0.04 * hgt[node];
+      free(hgt);
+   }
+   else
    for (i = 0; i < p->ntime; i++) { double b = p->tree_branch[p->branch_node[i]]; x[k++] = b >= 0 ? b : 0.1; }
    for (i = 1; i < p->ngene; i++) x[k++] = 1;      /* rgene */
    if (p->ngene > 1 && p->mgene >= 3) {            /* a parameter set per gene */
@@ -616,6 +634,30 @@ static int set_x_genes(pamlh *p, const double *x, int np, int k, double *Q)
    return 0;
 }
 
+/* nodes[].branch from the first ntime entries of x (SetBranch treesub.c:3770): the lengths themselves in tree.branches order, the
+ * tree file's under fix_blength = 2, or — global clock — age(father) - age(node) from the internal node ages.  -1: not usable. */
+int pamlh_x_to_branches(const pamlh *p, const double *x, double *branch)
+{
+   int i;
+   for (i = 0; i < p->nnode; i++) branch[i] = 0;
+   if (p->clock) {
+      for (i = 0; i < p->nnode; i++) {
+         double b;
+         if (i == p->root) continue;
+         b = x[p->father[i] - p->ns] - (i < p->ns ? 0 : x[i - p->ns]);
+         if (b < -1e-5) return -1;
+         branch[i] = b < 0 ? 0 : b;
+      }
+      return 0;
+   }
+   for (i = 0; i < p->nbranch; i++) {
+      const int node = p->branch_node[i];
+      branch[node] = p->ntime ? x[i] : p->tree_branch[node];
+      if (!p->ntime && p->tree_branch[node] < 0) return -1;
+   }
+   return 0;
+}
+
 int pamlh_set_x(pamlh *p, const double *x, int np)
 {
    const int n = p->n;
@@ -623,12 +665,8 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
    double *Q = (double *)malloc((size_t)n * n * sizeof(double));
    if (np != p->np) { free(Q); return pamlh_fail(p, "expected %d parameters, got %d", p->np, np); }
    /* branch lengths: x[0..ntime) in tree.branches order, or the tree file's when fix_blength = 2 (SetBranch treesub.c:3770) */
-   for (i = 0; i < p->nnode; i++) p->branch[i] = 0;
-   for (i = 0; i < p->nbranch; i++) {
-      const int node = p->branch_node[i];
-      p->branch[node] = p->ntime ? x[k++] : p->tree_branch[node];
-      if (!p->ntime && p->tree_branch[node] < 0) { free(Q); return pamlh_fail(p, "fix_blength = 2 but the tree has no branch lengths"); }
-   }
+   if (pamlh_x_to_branches(p, x, p->branch)) { free(Q); return pamlh_fail(p, p->clock ? "a node is older than its ancestor" : "fix_blength = 2 but the tree has no branch lengths"); }
+   k = p->ntime;
    p->n_labels = 1; p->K = 1; p->mode = PAML_AMD_MODE_LFUN; p->n_eigen = 1; p->use_qf = 0; p->n_pi = 1;
    p->freqK[0] = 1; p->rate[0] = 1; p->eigen_of[0] = 0;
    if (p->ngene > 1) { const int rc = set_x_genes(p, x, np, k, Q); free(Q); return rc; }
@@ -865,6 +903,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
    int k = p->ntime, g, j;
    const int rep = (p->ngene > 1 && p->mgene >= 3) ? p->ngene : 1;
    if (i < 0 || i >= p->np) return -1;
+   if (i < p->ntime && p->clock) { snprintf(buf, cap, "age of node %d", p->ns + i + 1); return 0; }
    if (i < p->ntime) { const int node = p->branch_node[i]; snprintf(buf, cap, "t %d..%d", p->father[node] + 1, node + 1); return 0; }
    if (i < k + p->ngene - 1) { snprintf(buf, cap, "rgene%d", i - k + 2); return 0; }
    k += p->ngene - 1;

@@ -94,14 +94,15 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
    if (G > 1) gr = (double *)malloc((size_t)nb * G * sizeof(double));
    for (b = 0; b < nb; b++) {
       const double *x = xs + (size_t)b * np;
-      const int r = cand_rep[cand_of[b]] < 0 ? 0 : cand_rep[cand_of[b]];
+      const int cb = cand_of[b] < 0 ? -1 - cand_of[b] : cand_of[b];
+      const int r = cand_rep[cb] < 0 ? 0 : cand_rep[cb];
       memcpy(fk + (size_t)b * K, rep_fk + (size_t)r * K, K * sizeof(double));
       memcpy(rt + (size_t)b * K, rep_rt + (size_t)r * K, K * sizeof(double));
       memcpy(eo + (size_t)b * K * L, rep_eo + (size_t)r * K * L, (size_t)K * L * sizeof(int));
       memcpy(qf + (size_t)b * K * L, rep_qf + (size_t)r * K * L, (size_t)K * L * sizeof(double));
-      for (i = 0; i < p->nbranch; i++) {
-         const int node = p->branch_node[i];
-         br[(size_t)b * nn + node] = nt ? x[i] : p->tree_branch[node];
+      if (pamlh_x_to_branches(p, x, br + (size_t)b * nn)) {      /* (clock: a node older than its ancestor) */
+         for (i = 0; i < nn; i++) br[(size_t)b * nn + i] = 0.1;
+         cand_of[b] = -1 - cand_of[b];
       }
       if (gr) { gr[(size_t)b * G] = 1; for (i = 1; i < G; i++) gr[(size_t)b * G + i] = x[nt + i - 1]; }
    }
@@ -112,10 +113,48 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       goto done;
    }
    for (b = 0; b < nb; b++)
-      if (cand_rep[cand_of[b]] < 0 || !(lnL[b] == lnL[b])) lnL[b] = -1e300;
+      if (cand_of[b] < 0 || cand_rep[cand_of[b]] < 0 || !(lnL[b] == lnL[b])) lnL[b] = -1e300;
 done:
    for (c = 0; c < ncand; c++) pamlh_state_free(ws[c]);
    free(ws); free(cand_of); free(cand_elem); free(cand_rep); free(br); free(fk); free(rt); free(eo); free(rep_fk); free(rep_rt); free(rep_eo); free(qf); free(rep_qf); free(gr);
+   return rc;
+}
+
+/* Global clock: the optimiser works on y = (root age, age / father's age for the other internal nodes), where the ordering of
+ * the ages is a box (the reference's own transformation while iterating, SetAge treesub.c:3794-3797); x holds the ages. */
+static void clock_rec_y_to_x(const pamlh *p, int node, const double *y, double *x)
+{
+   int j;
+   if (node < p->ns) return;
+   x[node - p->ns] = node == p->root ? y[node - p->ns] : x[p->father[node] - p->ns] * y[node - p->ns];
+   for (j = p->sons_ptr[node]; j < p->sons_ptr[node + 1]; j++) clock_rec_y_to_x(p, p->sons[j], y, x);
+}
+
+static void clock_y_to_x(const pamlh *p, const double *y, double *x)
+{
+   memcpy(x, y, p->np * sizeof(double));
+   if (p->clock) clock_rec_y_to_x(p, p->root, y, x);
+}
+
+static void clock_x_to_y(const pamlh *p, const double *x, double *y)
+{
+   int node;
+   memcpy(y, x, p->np * sizeof(double));
+   if (!p->clock) return;
+   for (node = p->ns; node < p->nnode; node++)
+      if (node != p->root) { const double fa = x[p->father[node] - p->ns]; y[node - p->ns] = fa > 0 ? x[node - p->ns] / fa : 0; }
+}
+
+/* lnL at nb vectors in the optimiser's variables */
+static int batch_eval(pamlh *p, int nb, const double *ys, double *lnL)
+{
+   double *xs;
+   int b, rc;
+   if (!p->clock) return pamlh_eval_batch_gpu(p, nb, ys, lnL);
+   xs = (double *)malloc((size_t)nb * p->np * sizeof(double));
+   for (b = 0; b < nb; b++) clock_y_to_x(p, ys + (size_t)b * p->np, xs + (size_t)b * p->np);
+   rc = pamlh_eval_batch_gpu(p, nb, xs, lnL);
+   free(xs);
    return rc;
 }
 
@@ -125,7 +164,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
 {
    int k = 0, i, g;
    const int rep = (p->ngene > 1 && p->mgene >= 3) ? p->ngene : 1;
-   for (i = 0; i < p->ntime; i++) { lo[k] = 4e-6; hi[k++] = 50; }
+   for (i = 0; i < p->ntime; i++) { lo[k] = p->clock ? 0 : 4e-6; hi[k++] = 50; }
    for (i = 1; i < p->ngene; i++) { lo[k] = p->is_codeml ? 0.01 : 1e-4; hi[k++] = p->is_codeml ? 99 : 999; }      /* rgene (SetxBound) */
    for (g = 0; g < rep; g++)
    if (p->seqtype == 1) {
@@ -186,7 +225,7 @@ static int gradient(pamlh *p, const double *x, double f0, const double *lo, cons
       if (x[i] + h <= hi[i]) xp[i] = x[i] + h;
       if (x[i] - h >= lo[i]) xm[i] = x[i] - h;
    }
-   if ((rc = pamlh_eval_batch_gpu(p, 2 * n, xs, ls))) return rc;
+   if ((rc = batch_eval(p, 2 * n, xs, ls))) return rc;
    *n_eval += 2 * n;
    for (i = 0; i < n; i++) {
       const double *xp = xs + (size_t)(2 * i) * n, *xm = xp + n;
@@ -213,7 +252,7 @@ static int diag_inverse_hessian(pamlh *p, const double *x, double f0, const doub
       xp[i] = x[i] + h; xm[i] = x[i] - h;
       if (xp[i] > hi[i] || xm[i] < lo[i]) xp[i] = xm[i] = x[i];      /* no room for a symmetric difference */
    }
-   if ((rc = pamlh_eval_batch_gpu(p, 2 * n, xs, ls))) { free(hd); return rc; }
+   if ((rc = batch_eval(p, 2 * n, xs, ls))) { free(hd); return rc; }
    *n_eval += 2 * n;
    for (i = 0; i < n; i++) {
       const double *xp = xs + (size_t)(2 * i) * n;
@@ -241,10 +280,17 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
    unsigned char *fixed = (unsigned char *)malloc(n);
    double f, fnew = 0, as[16], f_restart = 1e300;
    int it, i, j, k, rc = 0, n_eval = 0, reset = 1, small_steps = 0, status = 1, restarts = 0, fresh = 1;
-   if (n == 0) { rc = pamlh_eval_batch_gpu(p, 1, x, lnL); status = 0; goto done; }
+   if (n == 0) { rc = batch_eval(p, 1, x, lnL); status = 0; goto done; }
    if (pamlh_bounds(p, lo, hi)) { rc = pamlh_fail(p, "internal: bounds do not match np"); goto done; }
+   if (p->clock) {         /* iterate on (root age, age ratios): see clock_y_to_x */
+      double *y = (double *)malloc(n * sizeof(double));
+      clock_x_to_y(p, x, y);
+      memcpy(x, y, n * sizeof(double));
+      free(y);
+      for (i = 0; i < p->ntime; i++) { lo[i] = (p->ns + i == p->root) ? 1e-5 : 1e-8; hi[i] = (p->ns + i == p->root) ? 50 : 1; }
+   }
    for (i = 0; i < n; i++) x[i] = x[i] < lo[i] ? lo[i] : x[i] > hi[i] ? hi[i] : x[i];
-   if ((rc = pamlh_eval_batch_gpu(p, 1, x, ls))) goto done;
+   if ((rc = batch_eval(p, 1, x, ls))) goto done;
    n_eval++;
    f = -ls[0];
    if (f > 1e299) { rc = pamlh_fail(p, "the starting point is infeasible"); goto done; }
@@ -292,7 +338,7 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
             as[nc] = aa;
             nc++;
          }
-         if ((rc = pamlh_eval_batch_gpu(p, nc, xs, ls))) goto done;
+         if ((rc = batch_eval(p, nc, xs, ls))) goto done;
          n_eval += nc;
          for (j = 0; j < nc; j++)
             if (-ls[j] < best) { best = -ls[j]; abest = as[j]; }
@@ -360,6 +406,7 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
       }
    }
    *lnL = -f;
+   if (p->clock) { double *y = (double *)malloc(n * sizeof(double)); memcpy(y, x, n * sizeof(double)); clock_y_to_x(p, y, x); free(y); }
    /* leave the model state at the estimate */
    if (pamlh_set_x(p, x, n)) rc = -1;
 done:

@@ -329,7 +329,15 @@ def case_lysin(mgene):
     case_mle("lysin_mg%d" % mgene, over, LYSIN, 25, "codon_genes")
 
 
+def case_brown_clock():
+    """Global clock (clock = 1) on the first rooted tree of examples/brown.rooted.trees, HKY85: x holds the four node ages."""
+    tree1 = "  5  1\n\n((((1,2),3),4),5);\n"
+    case_mle("brown_hky85_clock", dict(seqfile="brown.nuc", treefile="brown.rooted.trees", model=4, clock=1, kappa=5),
+             {"brown.nuc": EX + "/brown.nuc", "brown.rooted.trees": tree1}, 5, "nuc_clock", prog="baseml", seqtype="nuc")
+
+
 CASES = {
+    "brown_hky85_clock": case_brown_clock,
     "horai_mg0": lambda: case_horai(0), "horai_mg2": lambda: case_horai(2), "horai_mg3": lambda: case_horai(3), "horai_mg4": lambda: case_horai(4),
     "horai_mg0_g5": lambda: case_horai(0, 0.5),
     "lysin_mg0": lambda: case_lysin(0), "lysin_mg2": lambda: case_lysin(2), "lysin_mg3": lambda: case_lysin(3), "lysin_mg4": lambda: case_lysin(4),

@@ -20,6 +20,7 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          # branch-site A (alternative and null), B; clade C, D; M3 — goldens at the reference's own 6-decimal MLEs
          ("lyso_bsa", "codeml", "lyso_bsa.ctl"), ("lyso_bsa_null", "codeml", "lyso_bsa_null.ctl"), ("lyso_bsb", "codeml", "lyso_bsb.ctl"),
          ("ecp_cmc", "codeml", "ecp_cmc.ctl"), ("ecp_cmd", "codeml", "ecp_cmd.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl"), ("ecp_m2arel", "codeml", "ecp_m2arel.ctl"),
+         ("brown_hky85_clock", "baseml", "brown_hky85_clock.ctl"),      # global clock: x holds the node ages
          # option G (several genes): rates only (Mgene 0), + frequencies (2), + kappa / omega (3), both (4); one with gamma
          ("horai_mg0", "baseml", "horai_mg0.ctl"), ("horai_mg2", "baseml", "horai_mg2.ctl"), ("horai_mg3", "baseml", "horai_mg3.ctl"),
          ("horai_mg4", "baseml", "horai_mg4.ctl"), ("horai_mg0_g5", "baseml", "horai_mg0_g5.ctl"),
@@ -263,6 +264,20 @@ def test_c_host_marginal_reconstruction_matches_the_reference_rst():
             row = g["patterns"][patt]
             i = int(np.argmax(post[h]))
             assert "TCAG"[i] == row["best"][k] and abs(post[h, i] - row["prob"][k]) < 6e-4
+
+
+@pytest.mark.gpu
+def test_c_host_optimiser_under_the_global_clock():
+    """clock = 1 on the rooted brown tree: the optimiser iterates on (root age, age ratios), reports ages, and reaches the
+    reference's -2666.330289 with its node ages and kappa; the likelihood-ratio statistic against the unrooted fit
+    (-2665.422858) is the molecular-clock test's 2 x 0.907."""
+    g = helpers.load_golden("brown_hky85_clock")
+    a = hostlib.Analysis(os.path.join(CTL, "brown_hky85_clock.ctl"), "baseml")
+    assert (a.np, a.ntime) == (5, 4)
+    r = a.optimize(a.default_x())
+    assert r["converged"] and abs(r["lnL"] - g["mle_lnL"]) < 5e-6, (r["lnL"], g["mle_lnL"])
+    assert np.max(np.abs(r["x"] - np.array(g["x"])) / np.array(g["x"])) < 5e-3
+    assert np.all(np.diff(r["x"][:4]) < 0)               # ages decrease from the root down this ladder tree
 
 
 @pytest.mark.gpu
