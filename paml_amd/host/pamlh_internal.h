@@ -37,6 +37,7 @@ struct pamlh {
    int *n_chara;
    int *pose, n_pose;      /* site (after cleaning) -> pattern index */
    int ngene, posG[PAMLH_MAXGENE + 1], lgene[PAMLH_MAXGENE];   /* option G: first pattern / number of sites of every gene */
+   int mg;                 /* CodonFreq 4 / 5: F1x4MG / F3x4MG */
    int clock;              /* 1: global clock, x holds the internal node ages */
    int m2a_rel;            /* NSsites = 22 */
    int mgene;              /* Mgene: 0 rates, 2 different pi, 3 different kappa (& omega), 4 both */

@@ -269,7 +269,9 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       strcpy(p->code, GENETIC_CODES[p->icode]);
       if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 3 && p->nssites != 7 && p->nssites != 8) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
       if (p->model == 0 && p->nssites == 3 && (p->fix_omega || p->ncatG < 2 || p->ncatG > 16)) { rc = pamlh_fail(p, "NSsites = 3 needs fix_omega = 0 and 2 <= ncatG <= 16"); goto bad; }
-      if (p->codonfreq < 0 || p->codonfreq > 3) { rc = pamlh_fail(p, "CodonFreq = %d is not supported", p->codonfreq); goto bad; }
+      if (p->codonfreq < 0 || p->codonfreq > 5) { rc = pamlh_fail(p, "CodonFreq = %d is not supported", p->codonfreq); goto bad; }
+      /* F1x4MG / F3x4MG (4, 5): the frequencies of F1x4 / F3x4, Muse-Gaut style rates (GetMutationMultiplier codeml.c:3060) */
+      if (p->codonfreq >= 4) { p->mg = 1; p->codonfreq -= 3; }
       for (p->n = 0, rc = 0; rc < 64; rc++) p->n += p->code[rc] != '*';
       rc = 0;
    }
@@ -297,6 +299,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->mgene >= 3 && (p->fix_kappa || (p->seqtype == 1 && p->fix_omega))) { rc = pamlh_fail(p, "Mgene = %d needs free kappa (and omega)", p->mgene); goto bad; }
       if (p->seqtype == 2 && p->mgene >= 3) { rc = pamlh_fail(p, "Mgene = %d has no meaning for the amino-acid models here", p->mgene); goto bad; }
       if (p->seqtype == 2 && p->mgene == 2 && p->aa_model != 3) { rc = pamlh_fail(p, "Mgene = 2 needs the +F model (model 3) for amino acids"); goto bad; }
+      if (p->seqtype == 1 && p->mg && p->mgene >= 2) { rc = pamlh_fail(p, "F1x4MG / F3x4MG with gene-specific frequencies is not supported"); goto bad; }
       if (p->seqtype == 1 && p->mgene == 2 && p->codonfreq == 0) { rc = pamlh_fail(p, "Mgene = 2 with equal codon frequencies"); goto bad; }
       if (p->seqtype == 0 && ((p->mgene >= 2 && p->model == JC69) || (p->mgene >= 3 && p->model == F81) || ((p->mgene == 2 || p->mgene == 4) && p->model == K80))) {
          rc = pamlh_fail(p, "this Mgene option has no meaning for the model"); goto bad;
@@ -531,6 +534,10 @@ static double codon_q_pi(const pamlh *p, const double *pi, double kappa, double 
          for (k = 0; k < 3; k++) if (f[k] != t[k]) { nd++; pos = k; }
          if (nd != 1) continue;
          if (f[pos] + t[pos] == 1 || f[pos] + t[pos] == 5) q = kappa;
+         if (p->mg) {      /* divide by the frequencies of the two unchanged nucleotides: the rate depends on the target nucleotide only */
+            const int b1 = (pos + 1) % 3, b2 = (pos + 2) % 3;
+            q /= (p->codonfreq == 2 ? p->fb3x4[b1 * 4 + t[b1]] * p->fb3x4[b2 * 4 + t[b2]] : p->fb4[t[b1]] * p->fb4[t[b2]]);
+         }
          if (p->code[c1] != p->code[c2]) q *= omega;
          Q[i * n + j] = Q[j * n + i] = q;
       }

@@ -338,6 +338,8 @@ def case_brown_clock():
 
 CASES = {
     "brown_hky85_clock": case_brown_clock,
+    "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
+    "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "horai_mg0": lambda: case_horai(0), "horai_mg2": lambda: case_horai(2), "horai_mg3": lambda: case_horai(3), "horai_mg4": lambda: case_horai(4),
     "horai_mg0_g5": lambda: case_horai(0, 0.5),
     "lysin_mg0": lambda: case_lysin(0), "lysin_mg2": lambda: case_lysin(2), "lysin_mg3": lambda: case_lysin(3), "lysin_mg4": lambda: case_lysin(4),
