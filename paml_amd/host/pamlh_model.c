@@ -286,7 +286,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    }
    else if (p->seqtype == 0) {
       p->n = 4;
-      if (p->model == F84 || p->model == T92 || p->model > REV) { rc = pamlh_fail(p, "baseml model %d is not supported", p->model); goto bad; }
+      if (p->model > REV) { rc = pamlh_fail(p, "baseml model %d is not supported", p->model); goto bad; }
    }
    else { rc = pamlh_fail(p, "seqtype %d is not supported", p->seqtype); goto bad; }
    if ((rc = pamlh_read_seqs(p))) goto bad;
@@ -314,6 +314,13 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    }
    if (p->seqtype == 1) freqs_codon(p);
    else freqs_base_aa(p);
+   if (p->seqtype == 0 && p->model == T92) {      /* one GC-content parameter: T = A, C = G (InitializeBaseAA treesub.c:1684-1691) */
+      int g;
+      p->pi_data[0] = p->pi_data[2] = (p->pi_data[0] + p->pi_data[2]) / 2; p->pi_data[1] = p->pi_data[3] = (p->pi_data[1] + p->pi_data[3]) / 2;
+      for (g = 0; g < p->ngene; g++) {
+         p->piG[g][0] = p->piG[g][2] = (p->piG[g][0] + p->piG[g][2]) / 2; p->piG[g][1] = p->piG[g][3] = (p->piG[g][1] + p->piG[g][3]) / 2;
+      }
+   }
    /* parameter bookkeeping (GetInitials): ntime, np */
    p->ntime = p->fix_blength == 2 ? 0 : p->nbranch;
    if (p->clock) {
@@ -341,7 +348,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
          else if (p->nssites == 8) nr += 3 + !p->fix_omega;
       }
       else if (p->seqtype == 0) {
-         if (p->model == K80 || p->model == HKY85) nr += !p->fix_kappa;
+         if (p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) nr += !p->fix_kappa;
          else if (p->model == TN93) nr += 2 * !p->fix_kappa;
          else if (p->model == REV) nr += 5;
       }
@@ -481,7 +488,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       else if (p->nssites == 8) { x[k++] = 0.9; x[k++] = 0.5; x[k++] = 1.5; if (!p->fix_omega) x[k++] = 2.5; }
    }
    else if (p->seqtype == 0) {
-      if ((p->model == K80 || p->model == HKY85) && !p->fix_kappa) x[k++] = p->kappa0;
+      if ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) x[k++] = p->kappa0;
       else if (p->model == TN93 && !p->fix_kappa) { x[k++] = p->kappa0; x[k++] = p->kappa0; }
       else if (p->model == REV) { for (i = 0; i < 5; i++) x[k++] = 1; }
    }
@@ -552,7 +559,7 @@ static int nuc_nkappa(const pamlh *p)
    const int m = p->model;
    if (m == REV) return 5;
    if (m == TN93) return p->fix_kappa ? 0 : 2;
-   if (m == K80 || m == HKY85) return p->fix_kappa ? 0 : 1;
+   if (m == K80 || m == HKY85 || m == F84 || m == T92) return p->fix_kappa ? 0 : 1;
    return 0;
 }
 
@@ -565,7 +572,11 @@ static void nuc_set(pamlh *p, int iset, const double *pi, const double *kp, doub
    pamlh_eig *e = &p->eig[iset];
    if (m == JC69 || m == K80) { e->kind = PAML_AMD_EIGEN_K80; e->kappa = m == JC69 ? 1 : (p->fix_kappa ? p->kappa0 : kp[0]); return; }
    for (i = 0; i < 16; i++) S[i] = 1;
-   if (m == HKY85) { const double v = p->fix_kappa ? p->kappa0 : kp[0]; S[0 * 4 + 1] = S[1 * 4 + 0] = S[2 * 4 + 3] = S[3 * 4 + 2] = v; }
+   if (m == HKY85 || m == T92) { const double v = p->fix_kappa ? p->kappa0 : kp[0]; S[0 * 4 + 1] = S[1 * 4 + 0] = S[2 * 4 + 3] = S[3 * 4 + 2] = v; }
+   else if (m == F84) {       /* TN93 with kappa1 = 1 + kappa / Y, kappa2 = 1 + kappa / R (QTN93 treesub.c:2179) */
+      const double v = p->fix_kappa ? p->kappa0 : kp[0];
+      S[0 * 4 + 1] = S[1 * 4 + 0] = 1 + v / (pi[0] + pi[1]); S[2 * 4 + 3] = S[3 * 4 + 2] = 1 + v / (pi[2] + pi[3]);
+   }
    else if (m == TN93) {
       const double k1 = p->fix_kappa ? p->kappa0 : kp[0], k2 = p->fix_kappa ? p->kappa0 : kp[1];
       S[0 * 4 + 1] = S[1 * 4 + 0] = k1; S[2 * 4 + 3] = S[3 * 4 + 2] = k2;
@@ -795,7 +806,11 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          p->eig[0].kappa = m == JC69 ? 1 : (p->fix_kappa ? p->kappa0 : x[k++]);
       }
       else {
-         if (m == HKY85) { double kp = p->fix_kappa ? p->kappa0 : x[k++]; S[0 * 4 + 1] = S[1 * 4 + 0] = S[2 * 4 + 3] = S[3 * 4 + 2] = kp; }
+         if (m == HKY85 || m == T92) { double kp = p->fix_kappa ? p->kappa0 : x[k++]; S[0 * 4 + 1] = S[1 * 4 + 0] = S[2 * 4 + 3] = S[3 * 4 + 2] = kp; }
+         else if (m == F84) {
+            double kp = p->fix_kappa ? p->kappa0 : x[k++];
+            S[0 * 4 + 1] = S[1 * 4 + 0] = 1 + kp / (p->pi[0] + p->pi[1]); S[2 * 4 + 3] = S[3 * 4 + 2] = 1 + kp / (p->pi[2] + p->pi[3]);
+         }
          else if (m == TN93) {
             double k1 = p->fix_kappa ? p->kappa0 : x[k], k2 = p->fix_kappa ? p->kappa0 : x[k + 1];
             if (!p->fix_kappa) k += 2;
@@ -937,7 +952,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
       else if (p->seqtype == 0) {
          if (p->model == REV) { static const char *const r[5] = {"a (TC)", "b (TA)", "c (TG)", "d (CA)", "e (CG)"}; for (j = 0; j < 5; j++) NAME("%s%s", r[j], sfx); }
          else if (p->model == TN93 && !p->fix_kappa) { NAME("kappa1%s", sfx); NAME("kappa2%s", sfx); }
-         else if ((p->model == K80 || p->model == HKY85) && !p->fix_kappa) NAME("kappa%s", sfx);
+         else if ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) NAME("kappa%s", sfx);
       }
    }
    if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) NAME("alpha");

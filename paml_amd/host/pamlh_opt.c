@@ -197,7 +197,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
       }
    }
    else if (p->seqtype == 0) {
-      const int nk = ((p->model == K80 || p->model == HKY85) && !p->fix_kappa) ? 1 : (p->model == TN93 && !p->fix_kappa) ? 2 : p->model == REV ? 5 : 0;
+      const int nk = ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) ? 1 : (p->model == TN93 && !p->fix_kappa) ? 2 : p->model == REV ? 5 : 0;
       for (i = 0; i < nk; i++) { lo[k] = 1e-4; hi[k++] = 999; }
    }
    if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) { lo[k] = 0.005; hi[k++] = 99; }
