@@ -6,7 +6,7 @@
 
 #define PAMLH_MAXOPT 64
 #define PAMLH_MAXGENE 16
-enum { JC69, K80, F81, F84, HKY85, T92, TN93, REV };   /* baseml models (baseml.ctl) */
+enum { JC69, K80, F81, F84, HKY85, T92, TN93, REV, UNREST };   /* baseml models (baseml.ctl) */
 
 typedef struct {
    char key[PAMLH_MAXOPT][32], val[PAMLH_MAXOPT][1024];   /* up to PAMLH_MAXOPT `key = value` lines */

@@ -277,7 +277,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    }
    else if (p->seqtype == 2) {
       p->n = 20; p->aa_model = p->model;
-      if (p->aa_model != 0 && p->aa_model != 2 && p->aa_model != 3) { rc = pamlh_fail(p, "amino-acid model %d is not supported", p->aa_model); goto bad; }
+      if (p->aa_model < 0 || p->aa_model > 3) { rc = pamlh_fail(p, "amino-acid model %d is not supported", p->aa_model); goto bad; }
       if (p->aa_model >= 2) {
          if (!(v = pamlh_opt(p, "aaRatefile")) || !*v) { rc = pamlh_fail(p, "empirical aa model without aaRatefile"); goto bad; }
          resolve(p, v, p->aaratefile, sizeof(p->aaratefile));
@@ -286,7 +286,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    }
    else if (p->seqtype == 0) {
       p->n = 4;
-      if (p->model > REV) { rc = pamlh_fail(p, "baseml model %d is not supported", p->model); goto bad; }
+      if (p->model > UNREST) { rc = pamlh_fail(p, "baseml model %d is not supported", p->model); goto bad; }
    }
    else { rc = pamlh_fail(p, "seqtype %d is not supported", p->seqtype); goto bad; }
    if ((rc = pamlh_read_seqs(p))) goto bad;
@@ -298,9 +298,10 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->seqtype == 1 && (p->model || p->nssites)) { rc = pamlh_fail(p, "several genes: only the one-ratio codon model (model 0, NSsites 0)"); goto bad; }
       if (p->mgene >= 3 && (p->fix_kappa || (p->seqtype == 1 && p->fix_omega))) { rc = pamlh_fail(p, "Mgene = %d needs free kappa (and omega)", p->mgene); goto bad; }
       if (p->seqtype == 2 && p->mgene >= 3) { rc = pamlh_fail(p, "Mgene = %d has no meaning for the amino-acid models here", p->mgene); goto bad; }
-      if (p->seqtype == 2 && p->mgene == 2 && p->aa_model != 3) { rc = pamlh_fail(p, "Mgene = 2 needs the +F model (model 3) for amino acids"); goto bad; }
+      if (p->seqtype == 2 && p->mgene == 2 && p->aa_model != 3 && p->aa_model != 1) { rc = pamlh_fail(p, "Mgene = 2 needs frequencies from the data (amino-acid model 1 or 3)"); goto bad; }
       if (p->seqtype == 1 && p->mg && p->mgene >= 2) { rc = pamlh_fail(p, "F1x4MG / F3x4MG with gene-specific frequencies is not supported"); goto bad; }
       if (p->seqtype == 1 && p->mgene == 2 && p->codonfreq == 0) { rc = pamlh_fail(p, "Mgene = 2 with equal codon frequencies"); goto bad; }
+      if (p->seqtype == 0 && p->mgene >= 2 && p->model == UNREST) { rc = pamlh_fail(p, "Mgene >= 2 does not work with UNREST"); goto bad; }
       if (p->seqtype == 0 && ((p->mgene >= 2 && p->model == JC69) || (p->mgene >= 3 && p->model == F81) || ((p->mgene == 2 || p->mgene == 4) && p->model == K80))) {
          rc = pamlh_fail(p, "this Mgene option has no meaning for the model"); goto bad;
       }
@@ -351,6 +352,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
          if (p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) nr += !p->fix_kappa;
          else if (p->model == TN93) nr += 2 * !p->fix_kappa;
          else if (p->model == REV) nr += 5;
+         else if (p->model == UNREST) nr += 11;
       }
       if (rep > 1) nr += (rep - 1) * (p->seqtype == 1 ? 2 : nuc_nkappa(p));      /* Mgene 3, 4: a parameter set per gene */
       if (p->alpha0 > 0 || !p->fix_alpha) nr += !p->fix_alpha;
@@ -491,6 +493,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       if ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) x[k++] = p->kappa0;
       else if (p->model == TN93 && !p->fix_kappa) { x[k++] = p->kappa0; x[k++] = p->kappa0; }
       else if (p->model == REV) { for (i = 0; i < 5; i++) x[k++] = 1; }
+      else if (p->model == UNREST) { for (i = 0; i < 11; i++) x[k++] = (i == 0 || i == 3 || i == 8) ? 0.9 : 0.5; }
    }
    if (!p->fix_alpha) x[k++] = p->alpha0 > 0 ? p->alpha0 : 0.5;
    return k;
@@ -558,9 +561,35 @@ static int nuc_nkappa(const pamlh *p)
 {
    const int m = p->model;
    if (m == REV) return 5;
+   if (m == UNREST) return 11;
    if (m == TN93) return p->fix_kappa ? 0 : 2;
    if (m == K80 || m == HKY85 || m == F84 || m == T92) return p->fix_kappa ? 0 : 1;
    return 0;
+}
+
+/* UNREST (QUNREST treesub.c:2543): the 11 free off-diagonal rates (row-major, Q[G][A] = 1), pi = the stationary distribution
+ * of Q (returned in pi), Q scaled to mean rate 1.  No eigen system: P(t) = matexp(Qt) on the device (PAML_AMD_EIGEN_QMAT). */
+static void unrest_set(pamlh *p, int iset, double *pi, const double *rate)
+{
+   pamlh_eig *e = &p->eig[iset];
+   double Q[16], A[5][5], mr = 0;
+   int i, j, k = 0, r, c;
+   for (i = 0; i < 4; i++) for (j = 0; j < 4; j++) Q[i * 4 + j] = i == j ? 0 : (i * 4 + j == 14 ? 1 : rate[k++]);
+   for (i = 0; i < 4; i++) { double t = 0; for (j = 0; j < 4; j++) t += Q[i * 4 + j]; Q[i * 4 + i] = -t; }
+   /* pi Q = 0 with sum(pi) = 1: replace the last equation by the normalisation, Gaussian elimination with pivoting */
+   for (i = 0; i < 4; i++) { for (j = 0; j < 4; j++) A[i][j] = i < 3 ? Q[j * 4 + i] : 1; A[i][4] = i < 3 ? 0 : 1; }
+   for (c = 0; c < 4; c++) {
+      int piv = c;
+      for (r = c + 1; r < 4; r++) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+      for (j = 0; j < 5; j++) { const double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+      for (r = 0; r < 4; r++)
+         if (r != c) { const double f = A[r][c] / A[c][c]; for (j = c; j < 5; j++) A[r][j] -= f * A[c][j]; }
+   }
+   for (i = 0; i < 4; i++) pi[i] = A[i][4] / A[i][i];
+   for (i = 0; i < 4; i++) mr -= pi[i] * Q[i * 4 + i];
+   if (!e->U) { e->U = (double *)malloc(16 * 8); e->V = (double *)malloc(16 * 8); e->Root = (double *)malloc(4 * 8); }
+   for (i = 0; i < 16; i++) e->U[i] = Q[i] / mr;
+   e->kind = PAML_AMD_EIGEN_QMAT;
 }
 
 /* eigen system `iset` of a baseml model with frequencies pi and exchangeability parameters kp (those nuc_nkappa counts) */
@@ -571,6 +600,7 @@ static void nuc_set(pamlh *p, int iset, const double *pi, const double *kp, doub
    int i, j, kk;
    pamlh_eig *e = &p->eig[iset];
    if (m == JC69 || m == K80) { e->kind = PAML_AMD_EIGEN_K80; e->kappa = m == JC69 ? 1 : (p->fix_kappa ? p->kappa0 : kp[0]); return; }
+   if (m == UNREST) { unrest_set(p, iset, (double *)pi, kp); return; }
    for (i = 0; i < 16; i++) S[i] = 1;
    if (m == HKY85 || m == T92) { const double v = p->fix_kappa ? p->kappa0 : kp[0]; S[0 * 4 + 1] = S[1 * 4 + 0] = S[2 * 4 + 3] = S[3 * 4 + 2] = v; }
    else if (m == F84) {       /* TN93 with kappa1 = 1 + kappa / Y, kappa2 = 1 + kappa / R (QTN93 treesub.c:2179) */
@@ -621,7 +651,7 @@ static int set_x_genes(pamlh *p, const double *x, int np, int k, double *Q)
          if (p->aa_model == 0) { for (i = 0; i < 20; i++) pis[i] = 1.0 / 20; p->eig[g].kind = PAML_AMD_EIGEN_JC69LIKE; }
          else {
             if (p->aa_model == 2) memcpy(pis, p->aapi_file, 20 * sizeof(double));
-            for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) Q[i * 20 + j] = (i == j) ? 0 : p->aaS[i * 20 + j] * pis[j];
+            for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) Q[i * 20 + j] = (i == j) ? 0 : (p->aa_model == 1 ? 1 : p->aaS[i * 20 + j]) * pis[j];      /* model 1: equal exchangeabilities */
             for (i = 0; i < 20; i++) { double t = 0; for (j = 0; j < 20; j++) t += Q[i * 20 + j]; Q[i * 20 + i] = -t; mr += pis[i] * t; }
             set_eig_uvroot(p, g, Q, pis, mr);
          }
@@ -790,7 +820,7 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
       }
       else {
          memcpy(p->pi, p->aa_model == 2 ? p->aapi_file : p->pi_data, 20 * sizeof(double));   /* model 2: file pi, used as read */
-         for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) Q[i * 20 + j] = (i == j) ? 0 : p->aaS[i * 20 + j] * p->pi[j];
+         for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) Q[i * 20 + j] = (i == j) ? 0 : (p->aa_model == 1 ? 1 : p->aaS[i * 20 + j]) * p->pi[j];   /* model 1 (EqualInput): rates proportional to the target frequency */
          for (i = 0; i < 20; i++) { double s = 0; for (j = 0; j < 20; j++) s += Q[i * 20 + j]; Q[i * 20 + i] = -s; mr += p->pi[i] * s; }
          set_eig_uvroot(p, 0, Q, p->pi, mr);
       }
@@ -801,7 +831,8 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
       for (i = 0; i < 16; i++) S[i] = 1;
       if (m == JC69 || m == K80) for (i = 0; i < 4; i++) p->pi[i] = 0.25;
       else memcpy(p->pi, p->pi_data, 4 * sizeof(double));
-      if (m == JC69 || m == K80) {
+      if (m == UNREST) { unrest_set(p, 0, p->pi, x + k); k += 11; }
+      else if (m == JC69 || m == K80) {
          p->eig[0].kind = PAML_AMD_EIGEN_K80;
          p->eig[0].kappa = m == JC69 ? 1 : (p->fix_kappa ? p->kappa0 : x[k++]);
       }
@@ -909,6 +940,7 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
       if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, i, e->U, e->V, e->Root);
       else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(p->eng, i, e->nR, e->Cijk, e->Root);
       else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(p->eng, i, e->kappa);
+      else if (e->kind == PAML_AMD_EIGEN_QMAT) rc = paml_amd_set_eigen_qmat(p->eng, i, e->U);
       else rc = paml_amd_set_eigen_jc69like(p->eng, i);
       if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    }
@@ -950,7 +982,8 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
          else if (p->nssites == 8) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); if (!p->fix_omega) NAME("ws"); }
       }
       else if (p->seqtype == 0) {
-         if (p->model == REV) { static const char *const r[5] = {"a (TC)", "b (TA)", "c (TG)", "d (CA)", "e (CG)"}; for (j = 0; j < 5; j++) NAME("%s%s", r[j], sfx); }
+         if (p->model == UNREST) { for (j = 0; j < 11; j++) NAME("rate %d%s", j + 1, sfx); }
+         else if (p->model == REV) { static const char *const r[5] = {"a (TC)", "b (TA)", "c (TG)", "d (CA)", "e (CG)"}; for (j = 0; j < 5; j++) NAME("%s%s", r[j], sfx); }
          else if (p->model == TN93 && !p->fix_kappa) { NAME("kappa1%s", sfx); NAME("kappa2%s", sfx); }
          else if ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) NAME("kappa%s", sfx);
       }

@@ -23,6 +23,7 @@ static int upload_eigen(pamlh *p, int base)
       if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, base + i, e->U, e->V, e->Root);
       else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(p->eng, base + i, e->nR, e->Cijk, e->Root);
       else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(p->eng, base + i, e->kappa);
+      else if (e->kind == PAML_AMD_EIGEN_QMAT) rc = paml_amd_set_eigen_qmat(p->eng, base + i, e->U);
       else rc = paml_amd_set_eigen_jc69like(p->eng, base + i);
    }
    return rc ? pamlh_fail(p, "%s", paml_amd_last_error(p->eng)) : 0;
@@ -197,7 +198,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
       }
    }
    else if (p->seqtype == 0) {
-      const int nk = ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) ? 1 : (p->model == TN93 && !p->fix_kappa) ? 2 : p->model == REV ? 5 : 0;
+      const int nk = ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) ? 1 : (p->model == TN93 && !p->fix_kappa) ? 2 : p->model == REV ? 5 : p->model == UNREST ? 11 : 0;
       for (i = 0; i < nk; i++) { lo[k] = 1e-4; hi[k++] = 999; }
    }
    if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) { lo[k] = 0.005; hi[k++] = 99; }

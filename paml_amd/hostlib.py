@@ -10,7 +10,7 @@ import subprocess
 
 import numpy as np
 
-from .problem import EIGEN_CIJK, EIGEN_JC69LIKE, EIGEN_K80, EIGEN_UVROOT, Problem, Tree
+from .problem import EIGEN_CIJK, EIGEN_JC69LIKE, EIGEN_K80, EIGEN_QMAT, EIGEN_UVROOT, Problem, Tree
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpamlh.so")
@@ -128,6 +128,8 @@ class Analysis:
                 e.update(nR=nR.value, Cijk=_arr(ps[3].value, np.float64, n * n * nR.value), Root=_arr(ps[2].value, np.float64, nR.value))
             elif kind.value == EIGEN_K80:
                 e.update(kappa=kappa.value)
+            elif kind.value == EIGEN_QMAT:
+                e.update(Q=_arr(ps[0].value, np.float64, n * n).reshape(n, n))
             eig.append(e)
         scale = _arr(L.pamlh_scale_nodes(h), np.uint8, nn)
         L.pamlh_qfactor.restype = C.c_void_p

@@ -341,6 +341,9 @@ BROWN = {"brown.nuc": EX + "/brown.nuc", "brown.trees": EX + "/brown.trees"}
 CASES = {
     "brown_f84": lambda: case_mle("brown_f84", dict(seqfile="brown.nuc", treefile="brown.trees", model=3, kappa=5), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
     "brown_t92_g4": lambda: case_mle("brown_t92_g4", dict(seqfile="brown.nuc", treefile="brown.trees", model=5, kappa=5, fix_alpha=0, alpha=0.5, ncatG=4), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
+    "brown_unrest": lambda: case_mle("brown_unrest", dict(seqfile="brown.nuc", treefile="brown.trees", model=8), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
+    "stewart_eqinput": lambda: case_mle("stewart_eqinput", dict(seqfile="stewart.aa", treefile="stewart.trees", seqtype=2, model=1, cleandata=0),
+                                        {"stewart.aa": EX + "/stewart.aa", "stewart.trees": " 6 1\n(((Langur, Baboon), Human), Rat, (Cow, Horse));\n"}, 6, "aa", seqtype="aa"),
     "brown_hky85_clock": case_brown_clock,
     "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
