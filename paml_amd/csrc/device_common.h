@@ -533,9 +533,14 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
 // roff advancing by the tile's block count, and blocks J >= NBLK are the next tile's (its P pointers).  Tip codes and
 // weight flags of a tile arrive as one small DMA block (PruneArgs::ztiles) in the sZ buffer the previous tile is not
 // using.  Nothing at a tile boundary waits on vector memory.
+/* JIT_ZB: buffers for the tiles' tip-code blocks.  2 = the next tile's codes arrive while the current tile is walked; 1 = trees
+ * whose code block (128 bytes per tip) leaves no room for a second one: the block is replaced between tiles. */
+#ifndef JIT_ZB
+#define JIT_ZB 2
+#endif
 #define JIT2_PROLOGUE(ZP)                                                                                        \
    __shared__ __attribute__((aligned(16))) double ring[4 * 4096];                                               \
-   __shared__ __attribute__((aligned(16))) unsigned char sZ[2 * (ZP)*2048];                                      \
+   __shared__ __attribute__((aligned(16))) unsigned char sZ[JIT_ZB * (ZP)*2048];                                 \
    __shared__ double sPi[4 * 64];                                                                               \
    __shared__ __attribute__((aligned(16))) double sCol[4 * 64 + 32];                                            \
    __shared__ __attribute__((aligned(16))) double sDump[128];                                                   \
@@ -553,7 +558,7 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
    bool valid = false, has_next = false;                                                                        \
    const double *Pint = nullptr, *Ptip = nullptr, *nPint = a.pint, *nPtip = a.ptip;                             \
    double lnscale = 0;                                                                                          \
-   int roff = 0, zsel = 1;                                                                                      \
+   int roff = 0, zsel = JIT_ZB - 1;                                                                             \
    (void)hl; (void)n; (void)lnscale; (void)h0;                                                                  \
    if (work >= total_work) return;                                                                              \
    for (int i = tid; i < a.n_pi * 64 && i < 256; i += 512) sPi[i] = a.pi[i];
@@ -570,13 +575,13 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
 #define JIT2_ADVANCE(NBLK)                                                                                       \
    iclass = n_iclass; gene = n_gene; h0 = n_h0; hend = n_hend; Pint = nPint; Ptip = nPtip; Pcol = nPcol;        \
    h = h0 + hw; valid = h < hend; lnscale = 0;                                                                  \
-   roff = (roff + (NBLK)) & 3; zsel ^= 1;
+   roff = (roff + (NBLK)) & 3; zsel ^= JIT_ZB - 1;
 /* the next tile's code block -> the sZ buffer not in use (ZP dword pieces per thread) */
 #define JIT2_ISSUE_Z(ZP)                                                                                         \
    {                                                                                                            \
       const __amdgpu_buffer_rsrc_t zr_ = make_rsrc(a.ztiles + (long)n_tile * ((ZP)*2048), (ZP)*2048);            \
       _Pragma("unroll") for (int c_ = 0; c_ < (ZP); c_++)                                                       \
-         dma4(zr_, sZ + (zsel ^ 1) * ((ZP)*2048) + (c_ * 8 + wave) * 256, lane * 4, (c_ * 8 + wave) * 256);      \
+         dma4(zr_, sZ + ((zsel ^ 1) & (JIT_ZB - 1)) * ((ZP)*2048) + (c_ * 8 + wave) * 256, lane * 4, (c_ * 8 + wave) * 256);      \
    }
 #define JIT2_BUF(J) (ring + (((J) + roff) & 3) * 4096)
 /* the column-60 table that travels with a P block (61 states): 512 bytes, fetched as one dword DMA piece per thread so
@@ -611,6 +616,6 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
 #define JIT2_PIECE_NP(J, NODE, C) JIT2_PIECE(nPint + (long)(NODE)*4096, J, C, JIT2_REAL_P)
 #define JIT2_PIECE_NT(J, NODE, C) JIT2_PIECE(nPtip + (long)(NODE)*4096, J, C, JIT2_REAL_T)
 #define JIT2_CODE(ZP, TIP) ((int)sZ[zsel * ((ZP)*2048) + (TIP)*128 + hw])
-#define JIT2_NCODE(ZP, TIP) ((int)sZ[(zsel ^ 1) * ((ZP)*2048) + (TIP)*128 + hw])
+#define JIT2_NCODE(ZP, TIP) ((int)sZ[((zsel ^ 1) & (JIT_ZB - 1)) * ((ZP)*2048) + (TIP)*128 + hw])
 
 }  // namespace paml_amd

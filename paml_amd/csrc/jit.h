@@ -35,10 +35,14 @@ struct JitKernel {
 // Which programs the generator covers.
 inline int jit_zpieces(int n_tips) { return ((n_tips + 1) * 128 + 2047) / 2048; }   // 2 KB DMA pieces of a tile's code block
 
+// LDS: ring, zb code blocks, pi, column tables, dump slot.  Two code blocks fit up to 95 tips, one up to 207.
+inline bool jit_lds_fits(int n_tips, int zb) { return 4 * 32768 + zb * jit_zpieces(n_tips) * 2048 + 4 * 64 * 8 + (4 * 64 + 32) * 8 + 1024 <= 160 * 1024; }
+inline int jit_zbuffers(int n_tips) { return jit_lds_fits(n_tips, 2) ? 2 : 1; }
+
 inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6)
 {
-   if (n_codes > 64 || p.ops.size() > 400 || n_pi > 4) return false;
-   if (4 * 32768 + 2 * jit_zpieces(n_tips) * 2048 + 4 * 64 * 8 + (4 * 64 + 32) * 8 + 1024 > 160 * 1024) return false;   // LDS: ring, 2 code blocks, pi, column tables (<= 95 tips)
+   if (n_codes > 64 || p.ops.size() > 1000 || n_pi > 4) return false;
+   if (!jit_lds_fits(n_tips, jit_zbuffers(n_tips))) return false;
    if (p.stream.size() / 2 < 4) return false;                       // trees this small go to the interpreter
    for (const Op &o : p.ops)
       if (o.code == OP_STORE || o.code == OP_LOAD) return false;   // keep-partials layouts stay with the interpreter
@@ -87,13 +91,16 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    for (size_t i = last_mm + 1; i < nops; i++)
       if (p.ops[i].code == OP_SET_TIP || p.ops[i].code == OP_MUL_TIP || p.ops[i].code == OP_SET_TIP2 || p.ops[i].code == OP_MUL_TIP2)
          tail_blocks = true;
+   // one code block only (large trees): it is replaced between tiles, so nothing of the next tile can start early
+   const bool zsingle = jit_zbuffers(n_tips) == 1;
    const bool peel = fuse_tips && !getenv("PAML_AMD_JIT_NOPEEL") && nops > 2 && p.ops[0].code == OP_SET_TIP2 && last_mm > 1 &&
-                     p.ops[1].code != OP_MUL_TIP && p.ops[1].code != OP_MUL_TIP2 && !tail_blocks;
+                     p.ops[1].code != OP_MUL_TIP && p.ops[1].code != OP_MUL_TIP2 && !tail_blocks && !zsingle;
 
    // chunks of a tip table that hold codes of this data set (two codes per 1 KB chunk)
    const int TCH = (n_codes + 1) / 2 >= 31 ? 32 : (n_codes + 1) / 2;
    const int P_ROUNDS = (KB2 + 1) / 2, T_ROUNDS = (TCH + 7) / 8;
    s << "#define JIT_KB2 " << KB2 << "\n#define JIT_RB " << RB << "\n#define JIT_TCH " << TCH << "\n";
+   if (zsingle) s << "#define JIT_ZB 1\n";
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
    s << "extern \"C\" __global__ __launch_bounds__(512, 2) void prune_jit(PruneArgs a)\n{\n";
    s << "   JIT2_PROLOGUE(" << ZP << ")\n";
@@ -187,6 +194,10 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       s << "   JIT_WAIT(" << nw << "); __syncthreads();\n";
       s << "   jit_tip2_set<" << NPc << ">(AS, " << buf(nblk) << ", " << ncode(p.ops[0].a) << ", " << buf(nblk + 1) << ", " << ncode(p.ops[0].b) << ", q, lane);\n";
    }
+   if (zsingle) {      // everything requested so far has to be there when the loop starts: the same state the loop's end leaves
+      s << "   JIT_WAIT(0); __syncthreads();\n";
+      fl.clear();
+   }
    // renumber for the loop body: those three blocks are blocks 0..2 of the tile the loop starts with
    for (Item &it : fl)
       if (it.id >= 0) it.id -= nblk;
@@ -195,7 +206,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
 
    s << "   int ptile = 1;\n   for (;; ptile = 0) {\n";
    s << "   JIT2_ADVANCE(" << nblk << ")\n   work += gridDim.x;\n   JIT2_NEXT_SET()\n";
-   z_pending = true;
+   z_pending = !zsingle;
 
    // register arrays: a free list; `cur` names the array holding the partial under construction
    std::vector<int> freeA;
@@ -306,6 +317,10 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    if (z_pending) {
       s << "   __syncthreads();\n   JIT2_ISSUE_Z(" << ZP << ")\n";
       fl.push_back({-1, ZP});
+   }
+   if (zsingle) {      // all waves are done with this tile's codes: fetch the next tile's over them, and wait (once per tile)
+      s << "   __syncthreads();\n   JIT2_ISSUE_Z(" << ZP << ")\n   JIT_WAIT(0); __syncthreads();\n";
+      fl.clear();
    }
    s << "   if (!has_next) break;\n   }\n   JIT_WAIT(0);\n}\n";
    *first_out = issued - nblk;

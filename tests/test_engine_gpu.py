@@ -310,17 +310,19 @@ def test_eval_batch_per_element_eigen_sets():
         assert abs(got[b] - ref) <= 1e-10 * abs(ref), (b, got[b], ref)
 
 
-@pytest.mark.parametrize("n,n_tips,n_patt,K,jit", [(61, 90, 300, 1, True), (61, 130, 140, 1, True), (61, 7, 1, 2, False),
+@pytest.mark.parametrize("n,n_tips,n_patt,K,jit", [(61, 90, 300, 1, True), (61, 130, 140, 1, True), (61, 200, 300, 2, True), (61, 230, 130, 1, True), (61, 7, 1, 2, False),
                                                    (61, 12, 129, 20, True), (33, 9, 200, 2, False), (4, 150, 1000, 1, True),
                                                    (5, 40, 777, 2, True), (20, 60, 500, 1, False)])
 def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch):
-    """Edges of the kernel selection: many tips (the specialised 61-state kernel keeps two tip-code blocks in LDS and
-    hands trees beyond 95 tips to the interpreter), one pattern, many classes, a state count between the
+    """Edges of the kernel selection: many tips (the specialised 61-state kernel keeps two tip-code blocks in LDS up to 95 tips,
+    one — replaced between tiles — up to 207, and hands larger trees to the interpreter), one pattern, many classes, a state count between the
     specialised sizes (padded MFMA path), ragged last tiles — each with the specialised kernels forced on or off."""
     monkeypatch.setenv("PAML_AMD_JIT", "1" if jit else "0")
     pb = helpers.random_problem(n, n_tips, n_patt, K=K, seed=500 + n + n_tips, ambiguity=(n_patt % 2 == 1), scale_every=40 if n_tips > 90 else None)
     eng, out, ref = check(pb)
-    if n == 61 and n_tips == 130:
+    if n == 61 and n_tips in (130, 200):
+        assert eng.kernel_name == "mfma64_jit"             # one tip-code block
+    if n == 61 and n_tips == 230:
         assert eng.kernel_name == "mfma64_gather"          # beyond the LDS budget of the specialised kernel
     if n == 61 and n_tips == 90 and jit:
         assert eng.kernel_name == "mfma64_jit"

@@ -184,6 +184,7 @@ def test_set_node_scale_matches_reference_rule():
 class _Sched:
     def __init__(self, src):
         self.zp = int(re.search(r"JIT2_PROLOGUE\((\d+)\)", src).group(1))
+        self.zb = 1 if "#define JIT_ZB 1" in src else 2      # one code block: replaced between tiles
         self.nblk = int(re.search(r"JIT2_ADVANCE\((\d+)\)", src).group(1))
         body = src[src.index("JIT2_PROLOGUE"):]
         head, loop = body.split("for (;; ptile = 0) {", 1)
@@ -198,7 +199,7 @@ class _Sched:
         self.last_read = {}            # global block / ("z", buffer) -> epoch of its latest read
         self.zbuf_owner = {}
         self.tile = -1                 # tile the loop body is working on; blocks are numbered G = tile * nblk + J
-        self.zsel = 1
+        self.zsel = self.zb - 1
         self.pieces = {}
 
     def G(self, j):
@@ -218,7 +219,7 @@ class _Sched:
         self.fifo.append(("b", g))
 
     def issue_z(self):
-        zb = self.zsel ^ 1
+        zb = (self.zsel ^ 1) & (self.zb - 1)
         assert self.last_read.get(("z", zb), -1) < self.epoch, "tip codes overwritten while still being read"
         self.zbuf_owner[zb] = self.tile + 1
         for _ in range(self.zp):
@@ -246,7 +247,7 @@ class _Sched:
 
     def read_codes(self, text):
         for kind in re.findall(r"JIT2_(N?CODE)\(", text):
-            zb = self.zsel ^ 1 if kind == "NCODE" else self.zsel
+            zb = (self.zsel ^ 1) & (self.zb - 1) if kind == "NCODE" else self.zsel
             t = self.tile + 1 if kind == "NCODE" else self.tile
             assert self.zbuf_owner.get(zb) == t and ("z", t) in self.visible, "tip codes of tile %d read before they arrived" % t
             self.last_read[("z", zb)] = self.epoch
@@ -262,7 +263,7 @@ class _Sched:
             line = line.strip()
             if line.startswith("JIT2_ADVANCE"):
                 self.tile += 1
-                self.zsel ^= 1
+                self.zsel ^= self.zb - 1
                 continue
             m = re.match(r"jit_matvec_tip2<(\d+), (?:true|false), \d+, \d+>\(JIT2_BUF\((\d+)\), lane, \w+, \w+, JIT2_BUF\((\d+)\), (\S+ \S+), JIT2_BUF\((\d+)\), (\S+ \S+), q, \w+, (.*)\);(?: \})?$", line)
             if m:
@@ -306,7 +307,7 @@ class _Sched:
         return self
 
 
-@pytest.mark.parametrize("shape", ["balanced16", "balanced8", "hiv", "caterpillar", "random23", "scaled"])
+@pytest.mark.parametrize("shape", ["balanced16", "balanced8", "hiv", "caterpillar", "random23", "scaled", "random120", "random200"])
 def test_jit_schedule_is_consistent(lib_path, shape):
     from paml_amd.problem import balanced_tree
     scale = None
@@ -320,11 +321,14 @@ def test_jit_schedule_is_consistent(lib_path, shape):
         for i in range(3, 12):
             s = "(%s:0.05,t%d:0.1)" % (s, i)
         tree = parse_newick("(%s:0.05,t12:0.1,t13:0.1);" % s)
+    elif shape in ("random120", "random200"):      # beyond 95 tips: one tip-code block, replaced between tiles
+        tree = helpers.random_problem(61, int(shape[6:]), 10, seed=7).tree
     else:
         pb = helpers.random_problem(61, 23, 10, seed=5, scale_every=6 if shape == "scaled" else None)
         tree, scale = pb.tree, pb.scale_node
     src = engine.debug_jit(tree, scale_node=scale, compile=False)
     assert "prune_jit" in src and "#error" not in src
+    assert ("#define JIT_ZB 1" in src) == (tree.n_tips > 95)
     s = _Sched(src).check()
     assert s.nblk >= 4
     # every operand block of a tile is consumed exactly once per trip: 2 tips + branches below internal nodes
