@@ -354,6 +354,23 @@ __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, c
    }
 }
 
+// Partials of stack slots beyond the register arrays live in global scratch (trees with a deep partial stack): one coalesced
+// 512-byte store / load per register of the wave.  These are ordinary (compiler-visible) memory operations; the counted waits of
+// the operand ring stay valid because loads complete in order and a wait that also covers younger operations only waits longer.
+#define JIT_SPILL_PTR(K) (a.stack_scratch + (((long)blockIdx.x * a.stack_overflow_slots + (K)) * 8 + wave) * 1024 + lane)
+__device__ __forceinline__ void jit_spill(const v4d (&y)[4], double *sp)
+{
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) { sp[(jb * 4 + 0) * 64] = y[jb].x; sp[(jb * 4 + 1) * 64] = y[jb].y; sp[(jb * 4 + 2) * 64] = y[jb].z; sp[(jb * 4 + 3) * 64] = y[jb].w; }
+}
+__device__ __forceinline__ void jit_mul_mem(v4d (&y)[4], const double *sp)   // y = (spilled s) * y
+{
+#pragma unroll
+   for (int jb = 0; jb < 4; jb++) {
+      y[jb].x *= sp[(jb * 4 + 0) * 64]; y[jb].y *= sp[(jb * 4 + 1) * 64]; y[jb].z *= sp[(jb * 4 + 2) * 64]; y[jb].w *= sp[(jb * 4 + 3) * 64];
+   }
+}
+
 __device__ __forceinline__ void jit_mul(v4d (&y)[4], const v4d (&s)[4])   // y = s * y  (codeml.c:3573)
 {
 #pragma unroll

@@ -16,6 +16,7 @@
 #include "program.h"
 
 using namespace paml_amd;
+static_assert(JIT_SCRATCH_BASE == MFMA_RS, "the per-tree kernel addresses the interpreter's overflow-stack scratch");
 
 namespace {
 

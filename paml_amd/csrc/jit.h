@@ -32,6 +32,11 @@ struct JitKernel {
    size_t n_ops = 0;
 };
 
+// Stack slots of the 61-state kernel that live in register arrays (each 32 VGPRs); deeper slots are spilled to global scratch.
+// MFMA_RS (the interpreter's register slots) sizes the scratch: the engine allocates max_stack - MFMA_RS slots per workgroup.
+constexpr int JIT_REG_SLOTS = 4;
+constexpr int JIT_SCRATCH_BASE = 2;      // = MFMA_RS (checked in engine.hip): scratch slot k holds stack slot k + 2
+
 // Which programs the generator covers.
 inline int jit_zpieces(int n_tips) { return ((n_tips + 1) * 128 + 2047) / 2048; }   // 2 KB DMA pieces of a tile's code block
 
@@ -46,7 +51,8 @@ inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 
    if (p.stream.size() / 2 < 4) return false;                       // trees this small go to the interpreter
    for (const Op &o : p.ops)
       if (o.code == OP_STORE || o.code == OP_LOAD) return false;   // keep-partials layouts stay with the interpreter
-   return p.max_stack + 2 <= max_arrays;
+   (void)max_arrays;      // stack slots beyond JIT_REG_SLOTS register arrays go to global scratch
+   return true;
 }
 
 inline std::string jit_program_key(const Program &p, int n_tips)
@@ -182,7 +188,10 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    auto colarg = [&](int blk) { return tail61 ? ", JIT2_COL(" + std::to_string(blk) + "), x60" : std::string(); };
 
    // ---- in front of the loop: the first tile is the "next" tile of an empty predecessor ---------------------------
-   const int NA = p.max_stack + 2 + (fuse_tips ? 1 : 0);
+   const int reg_slots = std::min(p.max_stack, JIT_REG_SLOTS);
+   const int NA = reg_slots + 2 + (fuse_tips ? 1 : 0);
+   const int SPILLED = -2;
+   auto spill_ptr = [&](int slot_no) { return "JIT_SPILL_PTR(" + std::to_string(slot_no - JIT_SCRATCH_BASE) + ")"; };
    for (int i = 0; i < NA; i++) s << "   v4d A" << i << "[4];\n";
    if (peel) s << "   v4d AS[4];\n";       // the first cherry of a tile, produced under the predecessor's last matmul
    s << "   JIT2_NEXT_SET()\n   JIT2_ISSUE_Z(" << ZP << ")\n";
@@ -252,7 +261,13 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          consumed += 2;
          break;
       case OP_PUSH:
-         slot[o.b] = cur;
+         if (o.b >= JIT_REG_SLOTS) {
+            s << "   jit_spill(" << name(cur) << ", " << spill_ptr(o.b) << ");\n";
+            release(cur);
+            slot[o.b] = SPILLED;
+         }
+         else
+            slot[o.b] = cur;
          cur = -1;
          break;
       case OP_MATMUL:
@@ -284,11 +299,21 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          }
          release(cur);
          if (pop >= 0) {
-            s << "   jit_mul(" << name(out) << ", " << name(slot[pop]) << ");\n";
-            release(slot[pop]);
+            if (slot[pop] == SPILLED)
+               s << "   jit_mul_mem(" << name(out) << ", " << spill_ptr(pop) << ");\n";
+            else {
+               s << "   jit_mul(" << name(out) << ", " << name(slot[pop]) << ");\n";
+               release(slot[pop]);
+            }
             slot[pop] = -1;
          }
-         if (push >= 0) {
+         if (push >= JIT_REG_SLOTS) {
+            s << "   jit_spill(" << name(out) << ", " << spill_ptr(push) << ");\n";
+            release(out);
+            slot[push] = SPILLED;
+            cur = -1;
+         }
+         else if (push >= 0) {
             slot[push] = out;
             cur = -1;
          }

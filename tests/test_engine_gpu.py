@@ -310,6 +310,22 @@ def test_eval_batch_per_element_eigen_sets():
         assert abs(got[b] - ref) <= 1e-10 * abs(ref), (b, got[b], ref)
 
 
+def test_per_tree_kernel_spills_deep_stacks(monkeypatch):
+    """A balanced 128-tip tree needs six partial-stack slots; the per-tree 61-state kernel keeps four in registers and moves
+    the deeper ones through global scratch (jit_spill / jit_mul_mem) — same lnL and log f_h as the oracle."""
+    from paml_amd.problem import balanced_tree
+    monkeypatch.setenv("PAML_AMD_JIT", "1")
+    pb = helpers.random_problem(61, 128, 300, K=2, seed=77)
+    t = balanced_tree(128)
+    rng = np.random.default_rng(3)
+    t.branch = rng.uniform(0.01, 0.2, t.n_nodes); t.branch[t.root] = 0
+    pb.tree = t
+    eng, out, ref = check(pb)
+    assert eng.kernel_name == "mfma64_jit"
+    from paml_amd import engine as _engine
+    assert "jit_spill(" in _engine.debug_jit(t, compile=False)
+
+
 @pytest.mark.parametrize("n,n_tips,n_patt,K,jit", [(61, 90, 300, 1, True), (61, 130, 140, 1, True), (61, 200, 300, 2, True), (61, 230, 130, 1, True), (61, 7, 1, 2, False),
                                                    (61, 12, 129, 20, True), (33, 9, 200, 2, False), (4, 150, 1000, 1, True),
                                                    (5, 40, 777, 2, True), (20, 60, 500, 1, False)])

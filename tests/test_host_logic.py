@@ -307,7 +307,7 @@ class _Sched:
         return self
 
 
-@pytest.mark.parametrize("shape", ["balanced16", "balanced8", "hiv", "caterpillar", "random23", "scaled", "random120", "random200"])
+@pytest.mark.parametrize("shape", ["balanced16", "balanced8", "hiv", "caterpillar", "random23", "scaled", "random120", "random200", "balanced128"])
 def test_jit_schedule_is_consistent(lib_path, shape):
     from paml_amd.problem import balanced_tree
     scale = None
@@ -329,6 +329,7 @@ def test_jit_schedule_is_consistent(lib_path, shape):
     src = engine.debug_jit(tree, scale_node=scale, compile=False)
     assert "prune_jit" in src and "#error" not in src
     assert ("#define JIT_ZB 1" in src) == (tree.n_tips > 95)
+    assert ("jit_spill(" in src) == (shape == "balanced128") and src.count("jit_spill(") == src.count("jit_mul_mem(")   # deep stacks spill
     s = _Sched(src).check()
     assert s.nblk >= 4
     # every operand block of a tile is consumed exactly once per trip: 2 tips + branches below internal nodes
