@@ -8,6 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/paml_amd.h"
@@ -126,6 +129,17 @@ struct paml_amd_engine {
    Staging stage;
    JitKernel jit;            // per-tree specialised kernel (jit.h), valid when jit.fn != nullptr
    bool jit_enabled = false, use_jit = false;
+   bool jit_forced = false;  // asked for by flag / environment (as opposed to switched on by the problem's size)
+   // a large tree's kernel takes many seconds to compile: that happens on a worker thread while the interpreter kernels
+   // serve the evaluations, and the engine changes over when the code object is there
+   struct JitJob {
+      std::thread th;
+      std::atomic<int> state{0};      // 0 idle, 1 compiling, 2 code ready, 3 failed
+      std::string key, src, log;
+      std::vector<char> code;
+   };
+   std::unique_ptr<JitJob> jit_job;
+   std::string jit_failed_key;
 
    std::vector<EigenHost> eigen;
    DevBuf<EigenDev> d_eigen;
@@ -414,9 +428,39 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
       bool jit_ok = false;
       if (e->jit_enabled && !getenv("PAML_AMD_FORCE_GATHER") && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi)) {
-         int r = ensure_jit(e, "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips),
-                            [&]() { return jit_generate(e->prog, e->n_tips, n, e->n_codes); }, &jit_ok);
-         if (r) return r;
+         const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips);
+         const bool background = e->prog.ops.size() > 200 && !e->jit_forced && !getenv("PAML_AMD_JIT_SYNC") && !(e->jit.fn && e->jit.key == key);
+         if (!background) {
+            int r = ensure_jit(e, key, [&]() { return jit_generate(e->prog, e->n_tips, n, e->n_codes); }, &jit_ok);
+            if (r) return r;
+         }
+         else {
+            paml_amd_engine::JitJob *job = e->jit_job.get();
+            if (job && job->state.load() >= 2 && job->th.joinable()) job->th.join();
+            if (job && job->state.load() == 2 && job->key == key) {          // the code object is there: load it and change over
+               if (e->jit.mod) (void)hipModuleUnload(e->jit.mod);
+               e->jit = JitKernel();
+               if (hipModuleLoadData(&e->jit.mod, job->code.data()) == hipSuccess && hipModuleGetFunction(&e->jit.fn, e->jit.mod, "prune_jit") == hipSuccess) {
+                  e->jit.key = key;
+                  jit_ok = true;
+               }
+               else e->jit_failed_key = key;
+               e->jit_job.reset();
+            }
+            else if (job && job->state.load() >= 2) {                        // failed, or compiled for another tree
+               if (job->state.load() == 3 && job->key == key) { e->jit_failed_key = key; e->err = "jit: " + job->log; }
+               e->jit_job.reset();
+               job = nullptr;
+            }
+            if (!jit_ok && !e->jit_job && e->jit_failed_key != key) {
+               e->jit_job.reset(new paml_amd_engine::JitJob());
+               job = e->jit_job.get();
+               job->key = key;
+               job->src = jit_generate(e->prog, e->n_tips, n, e->n_codes);
+               job->state.store(1);
+               job->th = std::thread([job]() { job->state.store(jit_compile_code(job->src, &job->code, &job->log) == 0 ? 2 : 3); });
+            }
+         }
       }
       e->use_jit = jit_ok;
       const bool big_tiles = jit_ok || lean;
@@ -703,6 +747,7 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    {  // per-tree specialised kernels: on request, or by default once the data set is large enough to repay the compile
       const char *j = getenv("PAML_AMD_JIT");
       e->jit_enabled = (flags & PAML_AMD_JIT) != 0 || (j && j[0] == '1') || (!j && (long)n_patt * max_classes >= 65536);
+      e->jit_forced = (flags & PAML_AMD_JIT) != 0 || (j && j[0] == '1');
       if (j && j[0] == '0') e->jit_enabled = false;
    }
    // 20 states: the specialised MFMA kernel trimmed to 2 row blocks x 5 k-blocks beats the scalar-operand kernel 2-3x; the
@@ -723,6 +768,7 @@ void paml_amd_destroy(paml_amd_engine *e)
 {
    if (!e) return;
    (void)hipStreamSynchronize(e->stream);
+   if (e->jit_job && e->jit_job->th.joinable()) e->jit_job->th.join();
    delete e;
 }
 
