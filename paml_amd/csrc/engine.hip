@@ -429,7 +429,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       bool jit_ok = false;
       if (e->jit_enabled && !getenv("PAML_AMD_FORCE_GATHER") && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi)) {
          const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips);
-         const bool background = e->prog.ops.size() > 200 && !e->jit_forced && !getenv("PAML_AMD_JIT_SYNC") && !(e->jit.fn && e->jit.key == key);
+         const bool background = e->prog.ops.size() > 120 &&      /* (roughly: more than 60 taxa, more than 3 s of compilation) */ !e->jit_forced && !getenv("PAML_AMD_JIT_SYNC") && !(e->jit.fn && e->jit.key == key);
          if (!background) {
             int r = ensure_jit(e, key, [&]() { return jit_generate(e->prog, e->n_tips, n, e->n_codes); }, &jit_ok);
             if (r) return r;
