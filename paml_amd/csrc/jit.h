@@ -14,8 +14,11 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <sstream>
 #include <string>
@@ -456,8 +459,43 @@ inline std::string jit_source_dir()
 }
 
 // Compile `src` for gfx950 (works without a GPU).  Returns 0 on success; `log` gets the compiler output.
+// Code objects are kept on disk, keyed by a hash of the generated source and of the header it includes: a tree seen before
+// (another run of the same analysis) costs a file read instead of seconds of hiprtc.  Opt-in: PAML_AMD_JIT_CACHE names the
+// directory (unset, "" or "0": no cache — the library writes nothing outside what the caller asked for).
+inline std::string jit_cache_path(const std::string &src)
+{
+   const char *c = getenv("PAML_AMD_JIT_CACHE");
+   std::string dir;
+   if (!c || !*c || !strcmp(c, "0")) return "";
+   dir = c;
+   unsigned long long h = 1469598103934665603ull;
+   auto mix = [&](const std::string &t) { for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; } };
+   mix(src);
+   {  // the header the source includes is part of the program
+      FILE *f = fopen((jit_source_dir() + "/device_common.h").c_str(), "rb");
+      if (f) { char buf[4096]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) mix(std::string(buf, n)); fclose(f); }
+   }
+   char name[64];
+   snprintf(name, sizeof(name), "/%016llx.gfx950.hsaco", h);
+   (void)!system(("mkdir -p '" + dir + "' 2>/dev/null").c_str());
+   return dir + name;
+}
+
 inline int jit_compile_code(const std::string &src, std::vector<char> *code, std::string *log)
 {
+   const std::string cached = jit_cache_path(src);
+   if (!cached.empty()) {
+      FILE *f = fopen(cached.c_str(), "rb");
+      if (f) {
+         fseek(f, 0, SEEK_END);
+         const long n = ftell(f);
+         rewind(f);
+         code->resize(n > 0 ? n : 0);
+         const bool ok = n > 0 && fread(code->data(), 1, n, f) == (size_t)n;
+         fclose(f);
+         if (ok) return 0;
+      }
+   }
    hiprtcProgram prog;
    if (hiprtcCreateProgram(&prog, src.c_str(), "prune_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
       *log = "hiprtcCreateProgram failed";
@@ -481,6 +519,15 @@ inline int jit_compile_code(const std::string &src, std::vector<char> *code, std
    code->resize(cs);
    hiprtcGetCode(prog, code->data());
    hiprtcDestroyProgram(&prog);
+   if (!cached.empty()) {      // write beside, then rename: readers never see a partial file
+      const std::string tmp = cached + ".tmp" + std::to_string((long)getpid());
+      FILE *f = fopen(tmp.c_str(), "wb");
+      if (f) {
+         const bool ok = fwrite(code->data(), 1, cs, f) == cs;
+         fclose(f);
+         if (!ok || rename(tmp.c_str(), cached.c_str()) != 0) remove(tmp.c_str());
+      }
+   }
    return 0;
 }
 

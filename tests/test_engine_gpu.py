@@ -337,6 +337,22 @@ def test_large_tree_kernel_is_compiled_in_the_background(monkeypatch):
     eng2.close()
 
 
+def test_compiled_kernels_are_cached_on_disk(monkeypatch, tmp_path):
+    """PAML_AMD_JIT_CACHE: the code object of a tree's kernel is written once and read back by the next engine (same lnL)."""
+    import time
+    monkeypatch.setenv("PAML_AMD_JIT", "1")
+    monkeypatch.setenv("PAML_AMD_JIT_CACHE", str(tmp_path))
+    pb = helpers.random_problem(61, 40, 200, K=1, seed=93)
+    t0 = time.time(); eng, out, ref = check(pb); t_cold = time.time() - t0
+    assert eng.kernel_name == "mfma64_jit"
+    files = list(tmp_path.glob("*.hsaco"))
+    assert len(files) == 1 and files[0].stat().st_size > 1000
+    eng.close()
+    t0 = time.time(); eng2, out2, _ = check(pb); t_warm = time.time() - t0
+    assert eng2.kernel_name == "mfma64_jit" and out2["lnL"] == out["lnL"]
+    assert len(list(tmp_path.glob("*.hsaco"))) == 1 and t_warm < t_cold
+
+
 def test_per_tree_kernel_spills_deep_stacks(monkeypatch):
     """A balanced 128-tip tree needs six partial-stack slots; the per-tree 61-state kernel keeps four in registers and moves
     the deeper ones through global scratch (jit_spill / jit_mul_mem) — same lnL and log f_h as the oracle."""
