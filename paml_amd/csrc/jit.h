@@ -502,7 +502,8 @@ inline int jit_compile_code(const std::string &src, std::vector<char> *code, std
       return -1;
    }
    const std::string inc = "-I" + jit_source_dir();
-   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
+   const char *olevel = getenv("PAML_AMD_JIT_OPT") ? getenv("PAML_AMD_JIT_OPT") : "-O3";      // experiments: -O1 / -O2
+   const char *opts[] = {"--offload-arch=gfx950", olevel, "-std=c++17", inc.c_str()};
    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
    size_t ls = 0;
    hiprtcGetProgramLogSize(prog, &ls);
