@@ -186,6 +186,49 @@ def usable_cores():
     return n
 
 
+def reference_binary_rate(pb):
+    """The unmodified reference program (oracle/_ref/codeml, built by oracle/Makefile from the reference's own sources) on the
+    first patterns of the same workload: one likelihood evaluation at fixed parameters (fix_blength = 2, kappa and omega fixed),
+    wall time of two sample sizes, their difference isolating the per-pattern cost from start-up and file I/O.
+    None when the binary is not there (it is git-ignored and travels only as a built file)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(REPO, "oracle", "_ref", "codeml")
+    if not (os.path.isfile(exe) and os.access(exe, os.X_OK)) or pb.n != 61 or pb.K != 1:
+        return None
+    from paml_amd import synth
+    times = {}
+    try:
+        for n in (5000, 40000):
+            n = min(n, pb.n_patt)
+            sub = pb.slice_patterns(0, n)
+            d = tempfile.mkdtemp(prefix="paml_amd_ref_")
+            try:
+                synth.write_pattern_file(os.path.join(d, "seq.txt"), sub.z, sub.weights, "codon")
+                with open(os.path.join(d, "tree.txt"), "w") as f:
+                    f.write(" %d 1\n%s\n" % (pb.tree.n_tips, pb.tree.newick()))
+                with open(os.path.join(d, "codeml.ctl"), "w") as f:
+                    f.write("seqfile = seq.txt\ntreefile = tree.txt\noutfile = mlc\nnoisy = 0\nverbose = 0\nrunmode = 0\nseqtype = 1\n"
+                            "CodonFreq = 2\nmodel = 0\nNSsites = 0\nicode = 0\nfix_kappa = 1\nkappa = 2\nfix_omega = 1\nomega = 0.4\n"
+                            "fix_alpha = 1\nalpha = 0\ngetSE = 0\nRateAncestor = 0\ncleandata = 1\nfix_blength = 2\nmethod = 0\n")
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "codeml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 20, timeout=300)
+                times[n] = time.perf_counter() - t0
+                if b"lnL" not in r.stdout and not os.path.exists(os.path.join(d, "mlc")):
+                    return None
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    except Exception:
+        return None
+    (n0, t0), (n1, t1) = sorted(times.items())
+    if n1 <= n0 or t1 <= t0:
+        return None
+    return {"value": (n1 - n0) / (t1 - t0), "unit": "site-patterns/s", "cores": 1,
+            "sample": "oracle/_ref/codeml (the unmodified reference, gcc -O3), one lnL evaluation at fixed parameters: wall time of %d "
+                      "patterns (%.2f s) minus that of %d (%.2f s)" % (n1, t1, n0, t0)}
+
+
 def cpu_baseline(pb, sample):
     """The oracle's single-thread restatement of the reference loop nest (kind "port"), timed on this
     box's host cores over the first `sample` patterns of the same workload."""
@@ -220,6 +263,14 @@ def cpu_baseline(pb, sample):
     one["all_cores"] = {"value": pb.n_patt * reps / el, "unit": "site-patterns/s", "cores": ncores,
                         "sample": "%d evals over all %d patterns, blocks of 512 patterns over %d OpenMP threads (%d logical CPUs visible)"
                                   % (reps, pb.n_patt, ncores, os.cpu_count() or 0)}
+    # the reference program itself, when its built binary travelled with the repository: that is the baseline then, and the
+    # port's single-thread figure stays beside it
+    ref = reference_binary_rate(pb)
+    if ref is not None:
+        port = {k: one[k] for k in ("value", "unit", "cores", "sample")}
+        one.update(ref)
+        one["kind"] = "reference"
+        one["port_1core"] = port
     return one
 
 
