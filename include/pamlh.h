@@ -57,6 +57,7 @@ const double *pamlh_freqK(const pamlh *p);
 const double *pamlh_rate(const pamlh *p);
 const int *pamlh_eigen_of(const pamlh *p);              /* [K][n_labels] */
 const double *pamlh_qfactor(const pamlh *p);
+const double *pamlh_adg_matrix(const pamlh *p);         /* [K][K] auto-discrete-gamma transition matrix (rho != 0), else NULL */
 /* option G (several genes): returns n_genes; gene_off[n_genes + 1] = first pattern of each gene (com.posG), gene_rate[n_genes]
  * = com.rgene after pamlh_set_x, n_pi = frequency vectors in pamlh_pi (1, or n_genes under Mgene 2 / 4), gene_eigen_of
  * [n_genes][K] = eigen system of (gene, class) (NULL with one gene).  Any output pointer may be NULL. */

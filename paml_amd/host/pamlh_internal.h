@@ -38,6 +38,8 @@ struct pamlh {
    int *pose, n_pose;      /* site (after cleaning) -> pattern index */
    int ngene, posG[PAMLH_MAXGENE + 1], lgene[PAMLH_MAXGENE];   /* option G: first pattern / number of sites of every gene */
    int mg;                 /* CodonFreq 4 / 5: F1x4MG / F3x4MG */
+   int fix_rho, adg;       /* auto-discrete-gamma: rho free or fixed != 0; adg: the current model state uses lfunAdG with MK */
+   double rho0, rho, MK[64 * 64 / 4];
    int clock;              /* 1: global clock, x holds the internal node ages */
    int m2a_rel;            /* NSsites = 22 */
    int mgene;              /* Mgene: 0 rates, 2 different pi, 3 different kappa (& omega), 4 both */
@@ -75,6 +77,10 @@ double pamlh_gammp(double a, double x);
 double pamlh_quantile_gamma(double p, double alpha, double beta);
 void pamlh_discrete_gamma(double *freqK, double *rK, double alpha, int K);
 double pamlh_betai(double a, double b, double x);
+double pamlh_quantile_normal(double prob);
+double pamlh_cdf_normal(double x);
+double pamlh_lbinormal(double h, double k, double r);
+void pamlh_autod_gamma(double *M, double *freqK, double *rK, double alpha, double rho, int K);
 double pamlh_quantile_beta(double prob, double p, double q);
 
 /* io (pamlh_io.c) */

@@ -250,6 +250,14 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    p->ncatG = (int)pamlh_optd(p, "ncatG", 4);
    p->cleandata_opt = (int)pamlh_optd(p, "cleandata", 0);
    p->fix_blength = (int)pamlh_optd(p, "fix_blength", 0);
+   p->fix_rho = (int)pamlh_optd(p, "fix_rho", 1);
+   p->rho0 = pamlh_optd(p, "rho", 0);
+   if (!p->fix_rho && p->rho0 == 0) p->rho0 = 0.001;      /* "init rho reset" (baseml.c:1087) */
+   if (!p->fix_rho || p->rho0 != 0) {
+      /* auto-discrete-gamma (lfunAdG): neighbouring sites' rate classes form a Markov chain with correlation rho */
+      if (p->fix_alpha && p->alpha0 <= 0) { rc = pamlh_fail(p, "fix rho to 0 if alpha = 0"); goto bad; }
+      if (p->nssites) { rc = pamlh_fail(p, "rho does not go with NSsites models"); goto bad; }
+   }
    p->clock = (int)pamlh_optd(p, "clock", 0);
    if (p->clock != 0 && p->clock != 1) { rc = pamlh_fail(p, "clock = %d is not supported (0: no clock, 1: global clock)", p->clock); goto bad; }
    p->mgene = (int)pamlh_optd(p, "Mgene", 0);
@@ -295,6 +303,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    else {
       /* what the several-gene set-up covers (the reference's own exclusions: baseml.c:261-265, codeml.c:1534-1544) */
       if (p->fix_blength == 2) { rc = pamlh_fail(p, "fix_blength = 2 does not work for partitioned data"); goto bad; }
+      if (!p->fix_rho || p->rho0 != 0) { rc = pamlh_fail(p, "rho with several genes is not supported"); goto bad; }
       if (p->seqtype == 1 && (p->model || p->nssites)) { rc = pamlh_fail(p, "several genes: only the one-ratio codon model (model 0, NSsites 0)"); goto bad; }
       if (p->mgene >= 3 && (p->fix_kappa || (p->seqtype == 1 && p->fix_omega))) { rc = pamlh_fail(p, "Mgene = %d needs free kappa (and omega)", p->mgene); goto bad; }
       if (p->seqtype == 2 && p->mgene >= 3) { rc = pamlh_fail(p, "Mgene = %d has no meaning for the amino-acid models here", p->mgene); goto bad; }
@@ -356,6 +365,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       }
       if (rep > 1) nr += (rep - 1) * (p->seqtype == 1 ? 2 : nuc_nkappa(p));      /* Mgene 3, 4: a parameter set per gene */
       if (p->alpha0 > 0 || !p->fix_alpha) nr += !p->fix_alpha;
+      nr += !p->fix_rho;
       p->np = p->ntime + nr;
    }
    p->branch = (double *)calloc(p->nnode, sizeof(double));
@@ -496,6 +506,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       else if (p->model == UNREST) { for (i = 0; i < 11; i++) x[k++] = (i == 0 || i == 3 || i == 8) ? 0.9 : 0.5; }
    }
    if (!p->fix_alpha) x[k++] = p->alpha0 > 0 ? p->alpha0 : 0.5;
+   if (!p->fix_rho) x[k++] = p->rho0;
    return k;
 }
 
@@ -874,6 +885,15 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          p->K = p->ncatG; p->mode = PAML_AMD_MODE_LFUNDG;
          for (j = 0; j < p->K; j++) p->eigen_of[j] = 0;
       }
+      p->adg = 0;
+      if (!p->fix_rho || p->rho0 != 0) {      /* AutodGamma: MK and the same class rates (SetParameters baseml.c:1388-1391) */
+         p->rho = p->fix_rho ? p->rho0 : x[k++];
+         if (alpha > 0 && p->rho != 0) {
+            if (p->ncatG > 32) { free(Q); return pamlh_fail(p, "ncatG too large for the auto-discrete-gamma model"); }
+            pamlh_autod_gamma(p->MK, p->freqK, p->rate, alpha, p->rho, p->ncatG);
+            p->adg = 1;
+         }
+      }
    }
    free(Q);
    if (k != np) return pamlh_fail(p, "internal: consumed %d of %d parameters", k, np);
@@ -945,9 +965,14 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
       if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    }
    if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->ngene > 1 ? p->gene_eigen_of : p->eigen_of,
-                                  p->use_qf ? p->qfactor : NULL)) ||
-       (rc = paml_amd_eval(p->eng, p->branch, p->ngene > 1 ? p->rgene : NULL, lnL, lnf, NULL)))
+                                  p->use_qf ? p->qfactor : NULL)))
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   if (p->adg) {      /* lfunAdG: fx_r on the device, the rate chain over the sites in their original order on the host */
+      if (lnf) for (i = 0; i < p->npatt; i++) lnf[i] = 0;      /* sites are not independent: no per-pattern log f */
+      rc = paml_amd_eval_adg(p->eng, p->branch, NULL, p->MK, p->pose, p->n_pose, lnL);
+   }
+   else rc = paml_amd_eval(p->eng, p->branch, p->ngene > 1 ? p->rgene : NULL, lnL, lnf, NULL);
+   if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    return 0;
 }
 
@@ -989,6 +1014,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
       }
    }
    if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) NAME("alpha");
+   if (!p->fix_rho) NAME("rho");
 #undef NAME
    snprintf(buf, cap, "x%d", i);
    return 0;
@@ -1247,6 +1273,8 @@ const int *pamlh_pose(const pamlh *p, int *n_sites)
 
 const double *pamlh_class_omega(const pamlh *p) { return p->class_w; }
 const double *pamlh_qfactor(const pamlh *p) { return p->use_qf ? p->qfactor : NULL; }
+/* auto-discrete-gamma: the K x K rate-class transition matrix of the current model state (NULL when the model has none) */
+const double *pamlh_adg_matrix(const pamlh *p) { return p->adg ? p->MK : NULL; }
 
 /* option G: number of genes, first pattern of each (n_genes + 1 entries), their rates (after pamlh_set_x), the number of
  * frequency vectors pamlh_pi holds (1 or n_genes) and the eigen system of (gene, class) */

@@ -286,3 +286,120 @@ double pamlh_quantile_beta(double prob, double p, double q)
    }
    return 0.5 * (lo + hi);
 }
+
+/* ------------------------------------------------------------------ auto-discrete-gamma (AutodGamma tools.c:2630)
+ * The K x K transition matrix between the rate classes of neighbouring sites: the K equal-probability classes are cut on a
+ * standard normal scale, and M[i][j] = K * Pr(class i at one site, class j at the next) under a bivariate normal with
+ * correlation rho.  The reference builds it from the published approximations restated here — Odeh & Evans (1974, AS 70) for
+ * the normal quantile, Adams (1969) / Hill (1973, AS 66) for the normal integral, and Genz (2004) for the bivariate normal
+ * tail L(h, k, r) with 16 / 32-point Gauss-Legendre rules — so that the same rho gives the same M to rounding. */
+double pamlh_quantile_normal(double prob)
+{
+   static const double a[5] = {-.322232431088, -1, -.342242088547, -.0204231210245, -.453642210148e-4};
+   static const double b[5] = {.0993484626060, .588581570495, .531103462366, .103537752850, .0038560700634};
+   const double p1 = prob < 0.5 ? prob : 1 - prob;
+   double y, z;
+   if (p1 < 1e-20) z = 999;
+   else {
+      y = sqrt(log(1 / (p1 * p1)));
+      z = y + ((((y * a[4] + a[3]) * y + a[2]) * y + a[1]) * y + a[0]) / ((((y * b[4] + b[3]) * y + b[2]) * y + b[1]) * y + b[0]);
+   }
+   return prob < 0.5 ? -z : z;
+}
+
+double pamlh_cdf_normal(double x)
+{
+   const double ax = fabs(x), y = x * x / 2;
+   double p;
+   if (ax < 1.28)
+      p = .5 - ax * (.398942280444 - .399903438504 * y / (y + 5.75885480458 - 29.8213557808 / (y + 2.62433121679 + 48.6959930692 / (y + 5.92885724438))));
+   else
+      p = 0.398942280385 * exp(-y) /
+          (ax - 3.8052e-8 + 1.00000615302 / (ax + 3.98064794e-4 + 1.98615381364 / (ax - 0.151679116635 + 5.29330324926 /
+          (ax + 4.8385912808 - 15.1508972451 / (ax + 0.742380924027 + 30.789933034 / (ax + 3.99019417011))))));
+   return x < 0 ? p : 1 - p;
+}
+
+/* positive nodes and weights of the n-point Gauss-Legendre rule (n even): Newton on P_n */
+static void gauss_legendre_half(int n, double *x, double *w)
+{
+   int i, k, it;
+   for (i = 0; i < n / 2; i++) {
+      double z = cos(M_PI * (i + 0.75) / (n + 0.5)), pp = 1;
+      for (it = 0; it < 100; it++) {
+         double p1 = 1, p2 = 0, p3, dz;
+         for (k = 1; k <= n; k++) { p3 = p2; p2 = p1; p1 = ((2.0 * k - 1) * z * p2 - (k - 1.0) * p3) / k; }
+         pp = n * (z * p1 - p2) / (z * z - 1);
+         dz = p1 / pp;
+         z -= dz;
+         if (fabs(dz) < 1e-16) break;
+      }
+      x[i] = z;
+      w[i] = 2 / ((1 - z * z) * pp * pp);
+   }
+}
+
+/* L(h, k, r) = Pr(X > h, Y > k) for a standard bivariate normal with correlation r (Genz 2004, equations 3 and 6) */
+double pamlh_lbinormal(double h0, double k0, double r)
+{
+   const int n = fabs(r) < 0.3 ? 16 : 32;
+   double x[16], w[16], L = 0;
+   const double h = h0 < k0 ? h0 : k0, k = h0 < k0 ? k0 : h0;
+   int i, j;
+   gauss_legendre_half(n, x, w);
+   if (fabs(r) < 0.925) {
+      if (fabs(r) > 1e-10) {
+         const double hk2 = (h * h + k * k) / 2, a = asin(r) / 2;
+         for (i = 0; i < n / 2; i++)
+            for (j = 0; j < 2; j++) {
+               const double sn = sin(a * (j ? 1 + x[i] : 1 - x[i]));
+               L += w[i] * exp((sn * h * k - hk2) / (1 - sn * sn));
+            }
+         L *= a / (2 * M_PI);
+      }
+      L += pamlh_cdf_normal(-h) * pamlh_cdf_normal(-k);
+   }
+   else {
+      const double sk = r >= 0 ? k : -k, shk = r >= 0 ? h * k : -h * k;
+      if (fabs(r) < 1) {
+         const double as = 1 - r * r, b = fabs(h - sk), bs = b * b, c = (4 - shk) / 8, d = (12 - shk) / 16;
+         double a = sqrt(as), y = -(bs / as + shk) / 2;
+         if (y > -500) L = a * exp(y) * (1 - c * (bs - as) * (1 - d * bs / 5) / 3 + c * d * as * as / 5);
+         if (shk > -500) L -= exp(-shk / 2) * sqrt(2 * M_PI) * pamlh_cdf_normal(-b / a) * b * (1 - c * bs * (1 - d * bs / 5) / 3);
+         a /= 2;
+         for (i = 0; i < n / 2; i++)
+            for (j = 0; j < 2; j++) {
+               const double u = a * (j ? 1 + x[i] : 1 - x[i]), t = u * u, rs = sqrt(1 - t);
+               y = -(bs / t + shk) / 2;
+               if (y > -500) L += a * w[i] * exp(y) * (exp(-shk * (1 - rs) / (2 * (1 + rs))) / rs - (1 + c * t * (1 + d * t)));
+            }
+         L /= -2 * M_PI;
+      }
+      if (r > 0) L += pamlh_cdf_normal(-(h > k ? h : k));
+      else if (r < 0) {
+         L = -L;
+         if (h + k < 0) L += pamlh_cdf_normal(-h) - pamlh_cdf_normal(k);
+      }
+   }
+   return L < 0 ? 0 : L;
+}
+
+void pamlh_autod_gamma(double *M, double *freqK, double *rK, double alpha, double rho, int K)
+{
+   double pt[64];
+   int i, j, s;
+   for (i = 0; i < K - 1; i++) pt[i] = pamlh_quantile_normal((i + 1.0) / K);
+   for (i = 0; i < K; i++)
+      for (j = 0; j < K; j++) M[i * K + j] = pamlh_lbinormal(-(i < K - 1 ? pt[i] : 20), -(j < K - 1 ? pt[j] : 20), rho);      /* cumulative */
+   for (s = 2 * (K - 1); s >= 0; s--)         /* cumulative -> cell probability x K, from the far corner inwards */
+      for (i = 0; i < K; i++) {
+         double y = 0;
+         j = s - i;
+         if (j < 0 || j >= K) continue;
+         if (i > 0) y -= M[(i - 1) * K + j];
+         if (j > 0) y -= M[i * K + j - 1];
+         if (i > 0 && j > 0) y += M[(i - 1) * K + j - 1];
+         M[i * K + j] = (M[i * K + j] + y) * K;
+      }
+   pamlh_discrete_gamma(freqK, rK, alpha, K);
+}

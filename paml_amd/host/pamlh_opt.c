@@ -51,6 +51,13 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
    double *qf = NULL, *rep_qf = NULL, *gr = NULL;
    const int G = p->ngene;
    if ((rc = pamlh_engine_ready(p))) goto done;
+   if (!p->fix_rho || p->rho0 != 0) {      /* lfunAdG ends in a sequential chain over the sites on the host: one evaluation at a time */
+      for (b = 0; b < nb; b++) {
+         if (pamlh_set_x(p, xs + (size_t)b * np, np) || !pamlh_model_feasible(p)) { lnL[b] = -1e300; continue; }
+         if ((rc = pamlh_eval_gpu(p, &lnL[b], lnf ? lnf + (size_t)b * p->npatt : NULL))) goto done;
+      }
+      goto done;
+   }
    for (b = 0; b < nb; b++) {          /* distinct model parts */
       const double *x = xs + (size_t)b * np;
       for (c = 0; c < ncand; c++)
@@ -202,6 +209,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
       for (i = 0; i < nk; i++) { lo[k] = 1e-4; hi[k++] = 999; }
    }
    if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) { lo[k] = 0.005; hi[k++] = 99; }
+   if (!p->fix_rho) { lo[k] = -0.2; hi[k++] = 0.99; }
    return k == p->np ? 0 : -1;
 }
 

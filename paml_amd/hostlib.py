@@ -212,6 +212,24 @@ class Analysis:
     def _is_branchsite(self):
         return self._L.pamlh_positive_classes(self._h) == 2
 
+    def pose(self):
+        """com.pose: pattern of every (cleaned) site, in site order."""
+        ns = C.c_int()
+        self._L.pamlh_pose.restype = C.c_void_p
+        self._L.pamlh_pose.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        return _arr(self._L.pamlh_pose(self._h, C.byref(ns)), np.int32, ns.value)
+
+    def adg_matrix(self, x):
+        """Auto-discrete-gamma transition matrix MK[K][K] of the model at x (None when the model has no rho)."""
+        self.set_x(x)
+        m = [C.c_int() for _ in range(4)]
+        self._L.pamlh_model(self._h, *[C.byref(v) for v in m])
+        K = m[1].value
+        self._L.pamlh_adg_matrix.restype = C.c_void_p
+        self._L.pamlh_adg_matrix.argtypes = [C.c_void_p]
+        ptr = self._L.pamlh_adg_matrix(self._h)
+        return _arr(ptr, np.float64, K * K).reshape(K, K) if ptr else None
+
     def plfun(self, x):
         """-lnL at x with com.plfun's convention (pamlh_plfun)."""
         x = np.ascontiguousarray(x, dtype=np.float64)

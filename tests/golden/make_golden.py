@@ -338,12 +338,30 @@ def case_brown_clock():
 
 BROWN = {"brown.nuc": EX + "/brown.nuc", "brown.trees": EX + "/brown.trees"}
 
+
+def case_brown_adg():
+    """Auto-discrete-gamma (lfunAdG: alpha and rho free, 4 rate classes) on brown.nuc, HKY85.  Sites are not independent under this
+    model, so the reference writes no per-pattern values: the golden is lnL at the printed estimates (and the maximised value)."""
+    ctl = dict(BASEML_BASE, outfile="mlb", seqfile="brown.nuc", treefile="brown.trees", model=4, kappa=5, fix_alpha=0, alpha=0.5, ncatG=4,
+               fix_rho=0, rho=0.3)
+    res = run_ref("baseml", ctl, BROWN)
+    xs = re.search(r"lnL\(ntime:\s*(\d+)[^\n]*\n[^\n]*\n([^\n]+)\n", res["main"])
+    x = [float(v) for v in xs.group(2).split()]
+    res1 = run_ref("baseml", ctl, BROWN, x=x)
+    hdr = [int(v) for v in [ln for ln in res1["lnf"] if ln.split()][0].split()]
+    g = dict(name="brown_hky85_adg", seqtype="nuc", program="baseml", n_tips=5, ls=hdr[1], n_patt=hdr[2], lnL=res1["lnL"], mle_lnL=res["lnL"], x=x,
+             ntime=int(xs.group(1)), model=dict(kind="nuc_adg", ncatG=4))
+    with open(os.path.join(HERE, "brown_hky85_adg.json"), "w") as f:
+        json.dump(g, f, separators=(",", ":"))
+    print("brown_hky85_adg        lnL %.6f (maximised %.6f)  x = %s" % (g["lnL"], g["mle_lnL"], x))
+
 CASES = {
     "brown_f84": lambda: case_mle("brown_f84", dict(seqfile="brown.nuc", treefile="brown.trees", model=3, kappa=5), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
     "brown_t92_g4": lambda: case_mle("brown_t92_g4", dict(seqfile="brown.nuc", treefile="brown.trees", model=5, kappa=5, fix_alpha=0, alpha=0.5, ncatG=4), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
     "brown_unrest": lambda: case_mle("brown_unrest", dict(seqfile="brown.nuc", treefile="brown.trees", model=8), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
     "stewart_eqinput": lambda: case_mle("stewart_eqinput", dict(seqfile="stewart.aa", treefile="stewart.trees", seqtype=2, model=1, cleandata=0),
                                         {"stewart.aa": EX + "/stewart.aa", "stewart.trees": " 6 1\n(((Langur, Baboon), Human), Rat, (Cow, Horse));\n"}, 6, "aa", seqtype="aa"),
+    "brown_hky85_adg": lambda: case_brown_adg(),
     "brown_hky85_clock": case_brown_clock,
     "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),

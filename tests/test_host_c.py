@@ -52,6 +52,33 @@ def test_c_host_reproduces_reference_on_cpu(gname, prog, ctl):
         assert abs(r["lnL"] - g["published_lnL"]) < 5e-6
 
 
+def test_c_host_auto_discrete_gamma_on_cpu():
+    """lfunAdG pinned to the reference binary: brown.nuc, HKY85 + auto-discrete-gamma (alpha and rho free, 4 classes), one
+    evaluation at the reference's printed estimates gives its lnL -2620.901026.  The host builds MK from rho the way AutodGamma
+    does (AS 70 normal quantile, AS 66 normal integral, Genz's bivariate normal tail); the oracle runs the site chain."""
+    g = helpers.load_golden("brown_hky85_adg")
+    a = hostlib.Analysis(os.path.join(CTL, "brown_hky85_adg.ctl"), "baseml")
+    assert (a.np, a.ntime, a.n_patt, a.ls) == (len(g["x"]), g["ntime"], g["n_patt"], g["ls"])
+    x = np.array(g["x"])
+    MK = a.adg_matrix(x)
+    assert MK.shape == (4, 4) and np.allclose(MK.sum(axis=1), 1, atol=1e-6) and np.allclose(MK, MK.T, atol=1e-7)
+    assert abs(oracle.evaluate_adg(a.problem(x), MK, a.pose()) - g["lnL"]) <= 2e-6
+    x0 = x.copy(); x0[-1] = 0.0                       # rho = 0: the chain forgets, lfundG's value
+    b = hostlib.Analysis(os.path.join(CTL, "brown_hky85_adg.ctl"), "baseml")
+    assert b.adg_matrix(x0) is None
+
+
+@pytest.mark.gpu
+def test_c_host_auto_discrete_gamma_on_gpu():
+    """... and through the engine (fx_r on the device, the chain over the 895 sites on the host), including the optimiser."""
+    g = helpers.load_golden("brown_hky85_adg")
+    a = hostlib.Analysis(os.path.join(CTL, "brown_hky85_adg.ctl"), "baseml")
+    lnl, _ = a.eval_gpu(np.array(g["x"]), want_lnf=False)
+    assert abs(lnl - g["lnL"]) <= 2e-6
+    r = a.optimize(a.default_x())
+    assert r["converged"] and abs(r["lnL"] - g["mle_lnL"]) < 2e-5, (r["lnL"], g["mle_lnL"])
+
+
 def _brown_sequences():
     txt = open(os.path.join(helpers.GOLDEN, "data", "brown.nuc")).read().split("\n")
     ns, ls = [int(v) for v in txt[0].split()[:2]]
