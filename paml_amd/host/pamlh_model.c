@@ -1100,7 +1100,7 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w)
       for (k = 0; k < K; k++) s += p->freqK[k] * fhK[(size_t)k * np + h];
       for (k = 0; k < K; k++) {
          post[(size_t)k * np + h] = s > 0 ? p->freqK[k] * fhK[(size_t)k * np + h] / s : 0;
-         mw += post[(size_t)k * np + h] * p->class_w[k];
+         mw += post[(size_t)k * np + h] * ((p->seqtype == 1 && p->nssites) ? p->class_w[k] : p->rate[k]);      /* omega classes, or gamma rate classes (lfunRates treesub.c:5850) */
       }
       if (mean_w) mean_w[h] = mw;
    }

@@ -339,6 +339,30 @@ def case_brown_clock():
 BROWN = {"brown.nuc": EX + "/brown.nuc", "brown.trees": EX + "/brown.trees"}
 
 
+def case_brown_rates():
+    """Posterior mean rates per site under HKY85 + G4 (RateAncestor = 1: the reference's `rates` file) at its own estimates."""
+    d = tempfile.mkdtemp(prefix="golden_")
+    try:
+        for f in ("brown.nuc", "brown.trees"):
+            shutil.copy(EX + "/" + f, os.path.join(d, f))
+        ctl = dict(BASEML_BASE, outfile="mlb", seqfile="brown.nuc", treefile="brown.trees", model=4, kappa=5, fix_alpha=0, alpha=0.5, ncatG=4, RateAncestor=1, noisy=0)
+        with open(os.path.join(d, "baseml.ctl"), "w") as f:
+            for k, v in ctl.items():
+                f.write("%s = %s\n" % (k, v))
+        subprocess.run([os.path.join(REF, "baseml"), "baseml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=600)
+        main = open(os.path.join(d, "mlb")).read()
+        xs = re.search(r"lnL\(ntime:\s*(\d+)[^\n]*:\s*(-[0-9.]+)[^\n]*\n[^\n]*\n([^\n]+)\n", main)
+        rows = re.findall(r"^\s*(\d+)\s+\d+\s+[A-Z\-\?]+\s+([0-9.]+)\s+(\d+)\s*$", open(os.path.join(d, "rates")).read(), re.M)
+        g = dict(name="brown_hky85_g4_rates", program="baseml", lnL=float(xs.group(2)), ntime=int(xs.group(1)), x=[float(v) for v in xs.group(3).split()],
+                 rate_mean=[float(r[1]) for r in rows], rate_class=[int(r[2]) for r in rows])
+        assert len(rows) == 895
+        with open(os.path.join(HERE, "brown_hky85_g4_rates.json"), "w") as f:
+            json.dump(g, f, separators=(",", ":"))
+        print("brown_hky85_g4_rates   lnL %.6f  %d sites" % (g["lnL"], len(rows)))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def case_brown_adg():
     """Auto-discrete-gamma (lfunAdG: alpha and rho free, 4 rate classes) on brown.nuc, HKY85.  Sites are not independent under this
     model, so the reference writes no per-pattern values: the golden is lnL at the printed estimates (and the maximised value)."""
@@ -362,6 +386,7 @@ CASES = {
     "stewart_eqinput": lambda: case_mle("stewart_eqinput", dict(seqfile="stewart.aa", treefile="stewart.trees", seqtype=2, model=1, cleandata=0),
                                         {"stewart.aa": EX + "/stewart.aa", "stewart.trees": " 6 1\n(((Langur, Baboon), Human), Rat, (Cow, Horse));\n"}, 6, "aa", seqtype="aa"),
     "brown_hky85_adg": lambda: case_brown_adg(),
+    "brown_hky85_g4_rates": case_brown_rates,
     "brown_hky85_clock": case_brown_clock,
     "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),

@@ -310,6 +310,21 @@ def test_c_host_optimiser_under_the_global_clock():
 
 
 @pytest.mark.gpu
+def test_c_host_site_rates_match_the_reference_rates_file():
+    """RateAncestor = 1 under HKY85 + G4: posterior mean rate and most probable rate class of every site of brown.nuc as the
+    reference writes them to `rates` (3 decimals) — class posteriors from the device's fhK (lfunRates)."""
+    g = helpers.load_golden("brown_hky85_g4_rates")
+    a = hostlib.Analysis(os.path.join(CTL, "brown_hky85_g4.ctl"), "baseml")
+    x = np.array(g["x"])
+    lnl, _ = a.eval_gpu(x, want_lnf=False)
+    assert abs(lnl - g["lnL"]) < 5e-6
+    post, mean = a.neb(x)
+    assert post.shape == (4, 895)
+    assert np.max(np.abs(mean - np.array(g["rate_mean"]))) < 6e-4
+    assert np.array_equal(np.argmax(post, axis=0) + 1, np.array(g["rate_class"]))
+
+
+@pytest.mark.gpu
 def test_c_host_plfun_seam():
     """pamlh_plfun has com.plfun's convention: x in, MINUS lnL out; a vector the model rejects gives +1e300, not an exit."""
     g = helpers.load_golden("hiv_m2a")
