@@ -103,6 +103,9 @@ double pamlh_plfun(pamlh *p, const double *x, int np);
 /* Marginal ancestral reconstruction (RateAncestor = 1; AncestralMarginal treesub.c:6288) at the current model state:
  * post[n_patt][n_states] = Pr(state at internal node `node` (0-based, >= n_tips) | pattern). */
 int pamlh_node_posterior(pamlh *p, int node, double *post);
+/* Joint ancestral reconstruction (Pupko et al. 2000; the reference's "(2) Joint reconstruction" in rst): the most probable
+ * assignment of states to all internal nodes per pattern — states[n_patt][n_nodes - n_tips] in node order — and its probability. */
+int pamlh_joint_reconstruction(pamlh *p, int *states, double *prob);
 int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double *se_w);
 /* BEB under branch-site model A and clade models C / D with two branch types (lfunNSsites_ACD codeml.c:6827):
  * post[nc][n_patt] = posterior of the site classes; nc = 4 for A (classes 0, 1, 2a, 2b: Pr(positive selection on the foreground)

@@ -1070,6 +1070,76 @@ int pamlh_node_posterior(pamlh *p, int node, double *post)
    return 0;
 }
 
+/* Joint ancestral reconstruction (AncestralJointPPSG2000 treesub.c; Pupko et al. 2000): for every pattern the assignment of
+ * states to ALL internal nodes with the highest probability, and that probability.  Max-product dynamic programming over the
+ * tree with the P(t) the device built for the current model state (paml_amd_get_pmat) and the pattern likelihoods of the
+ * same evaluation; one rate class only, as in the reference.  O(n_patt x nodes x n^2) on the host — the reconstruction
+ * itself is a table walk, not a hot loop.  states[n_patt][n_nodes - n_tips] (internal nodes in node order), prob[n_patt]. */
+int pamlh_joint_reconstruction(pamlh *p, int *states, double *prob)
+{
+   const int n = p->n, ns = p->ns, nn = p->nnode, np = p->npatt, ni = nn - ns;
+   double lnL, *lnf, *P, *L, *best_of;
+   int *choice, *order, no = 0, h, i, x, y, j, rc;
+   if (p->K != 1 || p->ngene > 1) return pamlh_fail(p, "the joint reconstruction needs a model with one rate class and one gene");
+   lnf = (double *)malloc(np * sizeof(double));
+   if ((rc = pamlh_eval_gpu(p, &lnL, lnf))) { free(lnf); return rc; }
+   P = (double *)malloc((size_t)nn * n * n * sizeof(double));
+   for (i = 0; i < nn; i++)
+      if (i != p->root && (rc = paml_amd_get_pmat(p->eng, 0, 0, i, P + (size_t)i * n * n))) { free(lnf); free(P); return pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); }
+   L = (double *)malloc((size_t)nn * n * sizeof(double));        /* L[node][x]: best of the subtree below `node` given state x above it */
+   choice = (int *)malloc((size_t)nn * n * sizeof(int));
+   best_of = (double *)malloc(n * sizeof(double));
+   order = (int *)malloc(nn * sizeof(int));                      /* post-order */
+   {
+      int *stack = (int *)malloc(2 * nn * sizeof(int)), sp = 0;
+      stack[sp++] = p->root;
+      while (sp) {                                               /* reverse pre-order = a post-order */
+         const int v = stack[--sp];
+         order[no++] = v;
+         for (j = p->sons_ptr[v]; j < p->sons_ptr[v + 1]; j++) stack[sp++] = p->sons[j];
+      }
+      free(stack);
+   }
+   for (h = 0; h < np; h++) {
+      for (i = no - 1; i >= 0; i--) {                            /* children before parents */
+         const int v = order[i];
+         if (v < ns) {                                           /* tip: its state, or the best of its ambiguity set */
+            const int code = p->z[(size_t)v * np + h], nc = p->n_chara[code];
+            const unsigned char *set = p->chara_map + (size_t)code * n;
+            for (x = 0; x < n; x++) {
+               double b = -1; int by = 0;
+               for (j = 0; j < nc; j++) { const double t = P[((size_t)v * n + x) * n + set[j]]; if (t > b) { b = t; by = set[j]; } }
+               L[(size_t)v * n + x] = b; choice[(size_t)v * n + x] = by;
+            }
+            continue;
+         }
+         for (y = 0; y < n; y++) {                               /* product over the sons given this node is in state y */
+            double t = 1;
+            for (j = p->sons_ptr[v]; j < p->sons_ptr[v + 1]; j++) t *= L[(size_t)p->sons[j] * n + y];
+            best_of[y] = t;
+         }
+         if (v == p->root) {
+            double b = -1; int by = 0;
+            for (y = 0; y < n; y++) { const double t = p->pi[y] * best_of[y]; if (t > b) { b = t; by = y; } }
+            prob[h] = b / exp(lnf[h]);
+            states[(size_t)h * ni + (v - ns)] = by;
+         }
+         else
+            for (x = 0; x < n; x++) {
+               double b = -1; int by = 0;
+               for (y = 0; y < n; y++) { const double t = P[((size_t)v * n + x) * n + y] * best_of[y]; if (t > b) { b = t; by = y; } }
+               L[(size_t)v * n + x] = b; choice[(size_t)v * n + x] = by;
+            }
+      }
+      for (i = 1; i < no; i++) {                                 /* trace back, parents before children */
+         const int v = order[i];
+         if (v >= ns) states[(size_t)h * ni + (v - ns)] = choice[(size_t)v * n + states[(size_t)h * ni + (p->father[v] - ns)]];
+      }
+   }
+   free(lnf); free(P); free(L); free(choice); free(best_of); free(order);
+   return 0;
+}
+
 /* Naive empirical Bayes posteriors of the site classes (lfunNSsites_rate codeml.c:5241-5330) at the current model state
  * (pamlh_set_x): post[k][h] = freqK_k f(x_h | class k) / sum_j freqK_j f(x_h | class j) straight from the device's fhK.
  * post: [K][npatt].  For NSsites models mean_w[h] (may be NULL) gets the posterior mean omega of the pattern. */

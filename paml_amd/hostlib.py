@@ -246,6 +246,16 @@ class Analysis:
             raise RuntimeError("pamlh_node_posterior: " + self._L.pamlh_error(self._h).decode())
         return post
 
+    def joint_reconstruction(self, x):
+        """Best joint assignment of states to the internal nodes per pattern and its probability (pamlh_joint_reconstruction)."""
+        self.set_x(x)
+        ni = self.n_nodes - self.n_tips
+        st, pr = np.zeros((self.n_patt, ni), dtype=np.int32), np.zeros(self.n_patt)
+        self._L.pamlh_joint_reconstruction.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        if self._L.pamlh_joint_reconstruction(self._h, st.ctypes.data_as(C.c_void_p), pr.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("pamlh_joint_reconstruction: " + self._L.pamlh_error(self._h).decode())
+        return st, pr
+
     def beb_acd(self, x):
         """BEB under branch-site model A (4 site classes: 0, 1, 2a, 2b) or clade model C / D (3) at x: class posteriors per site,
         [nc][n_sites] (pamlh_beb_acd)."""

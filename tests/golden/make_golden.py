@@ -363,6 +363,33 @@ def case_brown_rates():
         shutil.rmtree(d, ignore_errors=True)
 
 
+def case_brown_joint():
+    """"(2) Joint reconstruction of ancestral sequences" of the reference's rst for brown.nuc under HKY85 (no rate classes): per
+    pattern the best reconstruction of nodes 6-8 and its probability, at the reference's own estimates."""
+    d = tempfile.mkdtemp(prefix="golden_")
+    try:
+        for f in ("brown.nuc", "brown.trees"):
+            shutil.copy(EX + "/" + f, os.path.join(d, f))
+        ctl = dict(BASEML_BASE, outfile="mlb", seqfile="brown.nuc", treefile="brown.trees", model=4, kappa=5, RateAncestor=1, noisy=0)
+        with open(os.path.join(d, "baseml.ctl"), "w") as f:
+            for k, v in ctl.items():
+                f.write("%s = %s\n" % (k, v))
+        subprocess.run([os.path.join(REF, "baseml"), "baseml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=600)
+        main = open(os.path.join(d, "mlb")).read()
+        xs = re.search(r"lnL\(ntime:\s*(\d+)[^\n]*:\s*(-[0-9.]+)[^\n]*\n[^\n]*\n([^\n]+)\n", main)
+        rst = open(os.path.join(d, "rst")).read()
+        blk = rst[rst.index("(2) Joint reconstruction"):]
+        rows = re.findall(r"^\s*\d+\s+(\d+)\s+([TCAG]{5}): ([TCAG]{3}) \(([0-9.]+)\)", blk, re.M)
+        g = dict(name="brown_hky85_joint", program="baseml", lnL=float(xs.group(2)), ntime=int(xs.group(1)), x=[float(v) for v in xs.group(3).split()],
+                 patterns={r[1]: dict(count=int(r[0]), best=r[2], prob=float(r[3])) for r in rows})
+        assert len(rows) == 85
+        with open(os.path.join(HERE, "brown_hky85_joint.json"), "w") as f:
+            json.dump(g, f, separators=(",", ":"))
+        print("brown_hky85_joint      lnL %.6f  %d patterns" % (g["lnL"], len(rows)))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def case_brown_adg():
     """Auto-discrete-gamma (lfunAdG: alpha and rho free, 4 rate classes) on brown.nuc, HKY85.  Sites are not independent under this
     model, so the reference writes no per-pattern values: the golden is lnL at the printed estimates (and the maximised value)."""
@@ -387,6 +414,7 @@ CASES = {
                                         {"stewart.aa": EX + "/stewart.aa", "stewart.trees": " 6 1\n(((Langur, Baboon), Human), Rat, (Cow, Horse));\n"}, 6, "aa", seqtype="aa"),
     "brown_hky85_adg": lambda: case_brown_adg(),
     "brown_hky85_g4_rates": case_brown_rates,
+    "brown_hky85_joint": case_brown_joint,
     "brown_hky85_clock": case_brown_clock,
     "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),

@@ -325,6 +325,26 @@ def test_c_host_site_rates_match_the_reference_rates_file():
 
 
 @pytest.mark.gpu
+def test_c_host_joint_reconstruction_matches_the_reference_rst():
+    """The best joint reconstruction of the three internal nodes of the brown.nuc tree and its probability for every pattern, as
+    in "(2) Joint reconstruction of ancestral sequences" of the reference's rst (Pupko's algorithm; probabilities to 3 decimals;
+    patterns whose two best reconstructions are within the printed precision of each other may swap)."""
+    g = helpers.load_golden("brown_hky85_joint")
+    a = hostlib.Analysis(os.path.join(CTL, "brown_hky85.ctl"), "baseml")
+    x = np.array(g["x"])
+    st, pr = a.joint_reconstruction(x)
+    pb = a.problem(x)
+    swaps = 0
+    for h in range(a.n_patt):
+        row = g["patterns"]["".join("TCAG"[c] for c in pb.z[:, h])]
+        mine = "".join("TCAG"[c] for c in st[h])
+        assert abs(pr[h] - row["prob"]) < 6e-4, (h, pr[h], row)
+        swaps += mine != row["best"]
+        assert mine == row["best"] or row["prob"] < 0.51
+    assert swaps <= 1
+
+
+@pytest.mark.gpu
 def test_c_host_plfun_seam():
     """pamlh_plfun has com.plfun's convention: x in, MINUS lnL out; a vector the model rejects gives +1e300, not an exit."""
     g = helpers.load_golden("hiv_m2a")
