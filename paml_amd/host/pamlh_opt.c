@@ -188,6 +188,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
             for (i = 0; i < p->n_omega - (p->fix_omega != 0); i++) { lo[k] = 1e-6; hi[k++] = 999; }
          }
       }
+      else if (p->nssites == 4) { for (i = 0; i < 4; i++) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; } }
       else if (p->nssites == 3) {
          for (i = 0; i < p->ncatG - 1; i++) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; }
          for (i = 0; i < p->ncatG; i++) { lo[k] = 1e-6; hi[k++] = 999; }
