@@ -276,7 +276,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->model == 3) p->ncatG = 3;                /* "ncatG = 3 reset" (codeml.c:1607) */
       strcpy(p->code, GENETIC_CODES[p->icode]);
       if (p->nssites == 4) p->ncatG = 5;      /* M4 (freqs): omega = 0, 1/3, 2/3, 1, 3 with free proportions */
-      if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 3 && p->nssites != 4 && p->nssites != 7 && p->nssites != 8) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
+      if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 3 && p->nssites != 4 && p->nssites != 5 && p->nssites != 7 && p->nssites != 8) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
       if (p->model == 0 && p->nssites == 3 && (p->fix_omega || p->ncatG < 2 || p->ncatG > 16)) { rc = pamlh_fail(p, "NSsites = 3 needs fix_omega = 0 and 2 <= ncatG <= 16"); goto bad; }
       if (p->codonfreq < 0 || p->codonfreq > 5) { rc = pamlh_fail(p, "CodonFreq = %d is not supported", p->codonfreq); goto bad; }
       /* F1x4MG / F3x4MG (4, 5): the frequencies of F1x4 / F3x4, Muse-Gaut style rates (GetMutationMultiplier codeml.c:3060) */
@@ -353,6 +353,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
          else if (p->model == 3) nr += 2 + (p->nssites == 3 ? 2 : 1) + p->n_omega - (p->fix_omega != 0);   /* clade C / D (codeml.c:2222-2233) */
          else if (p->nssites == 3) nr += 2 * p->ncatG - 1;                        /* M3: K-1 proportions, K omegas */
          else if (p->nssites == 4) nr += 4;                                       /* M4: 4 proportions */
+         else if (p->nssites == 5) nr += 2;                                       /* M5: gamma(a, b) */
          else if (p->nssites == 0) nr += !p->fix_omega;
          else if (p->nssites == 1) nr += 2;
          else if (p->nssites == 2) nr += 4;
@@ -492,6 +493,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
          for (i = 0; i < p->n_omega - (p->fix_omega != 0); i++) x[k++] = p->omega0 * (1 + 0.25 * i);
       }
       else if (p->nssites == 4) { for (i = 0; i < 4; i++) x[k++] = 0.2; }
+      else if (p->nssites == 5) { x[k++] = 0.5; x[k++] = 1.0; }
       else if (p->nssites == 3) {                   /* M3: K-1 proportions, K omegas */
          for (i = 0; i < p->ncatG - 1; i++) x[k++] = 1.0 / p->ncatG;
          for (i = 0; i < p->ncatG; i++) x[k++] = 0.1 + 1.4 * i / (p->ncatG - 1);
@@ -793,6 +795,16 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          int K;
          if (p->nssites == 1) { f[0] = x[k]; w[0] = x[k + 1]; f[1] = 1 - f[0]; w[1] = 1; K = 2; k += 2; }
          else if (p->nssites == 2) { f[0] = x[k]; f[1] = x[k + 1]; f[2] = 1 - f[0] - f[1]; w[0] = x[k + 2]; w[1] = 1; w[2] = x[k + 3]; K = 3; k += 4; }
+         else if (p->nssites == 5) {      /* M5 (gamma): medians of K equal-probability bins of gamma(a, b), kept inside (1e-7, 99) (DiscreteNSsites codeml.c:2873-2880) */
+            K = p->ncatG;
+            if (K > 16) { free(Q); return pamlh_fail(p, "ncatG too large"); }
+            for (j = 0; j < K; j++) {
+               w[j] = pamlh_quantile_gamma((j * 2. + 1) / (2. * K), x[k], x[k + 1]);
+               w[j] = w[j] < 1e-7 ? 1e-7 : w[j] > 99 ? 99 : w[j];
+               f[j] = 1.0 / K;
+            }
+            k += 2;
+         }
          else if (p->nssites == 4) {      /* M4 (freqs, NSfreqs codeml.c:2531-2538) */
             static const double w4[5] = {0, 1. / 3, 2. / 3, 1, 3};
             K = 5;
@@ -1013,6 +1025,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
          else if (p->nssites == 2) { NAME("p0"); NAME("p1"); NAME("w0"); NAME("w2"); }
          else if (p->nssites == 3) { for (j = 0; j < p->ncatG - 1; j++) NAME("p%d", j); for (j = 0; j < p->ncatG; j++) NAME("w%d", j); }
          else if (p->nssites == 4) { for (j = 0; j < 4; j++) NAME("p%d", j); }
+         else if (p->nssites == 5) { NAME("a (gamma)"); NAME("b (gamma)"); }
          else if (p->nssites == 7) { NAME("p (beta)"); NAME("q (beta)"); }
          else if (p->nssites == 8) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); if (!p->fix_omega) NAME("ws"); }
       }

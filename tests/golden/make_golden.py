@@ -429,6 +429,7 @@ CASES = {
     "ecp_m2arel": lambda: case_mle("ecp_m2arel", dict(ECP_CTL, model=0, NSsites=22), ECP, 15, "codon_nssites"),
     "hiv_m3": lambda: case_mle("hiv_m3", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=3, ncatG=3, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_m4": lambda: case_mle("hiv_m4", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=4, ncatG=5, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
+    "hiv_m5": lambda: case_mle("hiv_m5", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=5, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_m0": lambda: case_hiv("m0"), "hiv_m1a": lambda: case_hiv("m1a"), "hiv_m2a": lambda: case_hiv("m2a"),
     "hiv_m7": lambda: case_hiv("m7"), "hiv_m8": lambda: case_hiv("m8"),
     "stewart_lg_g4": case_stewart, "mhc_m0_scaled": case_mhc,
