@@ -162,7 +162,9 @@ def main():
                          "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
                                          "separate passes: profiles/r01_pmc_summary.txt",
                          "flop_per_pattern": flops_pp, "kernel_ms": ms_kernel,
-                         "pmat_ms": prof["ms_pmat"] / max(1, prof["n_evals"]),
+                         # (consecutive evaluations build P(t) on a side stream under the previous kernel's last round: the
+                         #  event pair around it then spans its wait for free CUs, which is not kernel time)
+                         "pmat_ms": (prof["ms_pmat"] / max(1, prof["n_evals"])) if prof["ms_pmat"] < 0.5 * prof["ms_prune"] else None,
                          "reduce_ms": prof["ms_reduce"] / max(1, prof["n_evals"])},
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only

@@ -129,6 +129,17 @@ struct paml_amd_engine {
    Staging stage;
    JitKernel jit;            // per-tree specialised kernel (jit.h), valid when jit.fn != nullptr
    bool jit_enabled = false, use_jit = false;
+   // Consecutive paml_amd_eval_device calls (the loop of a benchmark or of an optimiser's independent evaluations) build the
+   // NEXT evaluation's P(t) on a side stream while the previous pruning kernel is still running: its few workgroups fit the CUs
+   // that go idle in that kernel's last round.  Two sets of P buffers alternate; the side stream waits for everything the main
+   // stream had queued before the previous evaluation (the last readers of the set it is about to overwrite).  Any other API
+   // call switches the fast path off until the next eval_device has run in order.
+   bool pipe_ok = false;
+   hipStream_t s2 = nullptr;
+   hipEvent_t ev_entry[2] = {nullptr, nullptr}, ev_pmat = nullptr;
+   int entry_sel = 0;
+   bool have_prev_entry = false;
+   DevBuf<double> d2_rowmajor, d2_pint, d2_ptip, d2_pcol, d2_branch, d2_gene_rate;
    bool jit_forced = false;  // asked for by flag / environment (as opposed to switched on by the problem's size)
    // a large tree's kernel takes many seconds to compile: that happens on a worker thread while the interpreter kernels
    // serve the evaluations, and the engine changes over when the code object is there
@@ -184,7 +195,7 @@ struct paml_amd_engine {
       d_eigen.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack,
+                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_rowmajor, &d2_pint, &d2_ptip, &d2_pcol, &d2_branch, &d2_gene_rate,
                               &d_expA, &d_expB, &d_expSA, &d_expSB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
    }
@@ -238,12 +249,13 @@ hipEvent_t get_event(paml_amd_engine *e)
    return ev;
 }
 
-void mark(paml_amd_engine *e)
+void mark_on(paml_amd_engine *e, hipStream_t s)
 {
    if (!e->profiling) return;
    hipEvent_t ev = get_event(e);
-   if (ev) (void)hipEventRecord(ev, e->stream);
+   if (ev) (void)hipEventRecord(ev, s);
 }
+void mark(paml_amd_engine *e) { mark_on(e, e->stream); }
 
 int build_tiles(paml_amd_engine *e)
 {
@@ -324,7 +336,7 @@ struct BatchSpec {
 };
 
 int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
-                double *d_lnL_out, bool want_lnf, const BatchSpec *bs = nullptr)
+                double *d_lnL_out, bool want_lnf, const BatchSpec *bs = nullptr, bool want_pipe = false)
 {
    if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes))
       return fail(e, PAML_AMD_EINVAL, "eval before set_tips/set_tree/set_pi/set_classes");
@@ -348,6 +360,26 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          return fail(e, PAML_AMD_EUNSUPPORTED, "tree needs a deeper partial stack than this kernel provides");
       }
    }
+   // the fast path of consecutive eval_device calls (see pipe_ok): nothing but branch lengths / gene rates may have changed
+   const bool pipe = want_pipe && e->pipe_ok && !bs && !clean && !keep && !new_prog && !e->eigen_dirty && !getenv("PAML_AMD_NO_PIPELINE");
+   if (want_pipe && !e->s2) {
+      HIPCHK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&e->ev_entry[0], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->ev_entry[1], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->ev_pmat, hipEventDisableTiming));
+   }
+   hipStream_t ps = e->stream;                    // stream of the uploads and of the P(t) kernel
+   if (want_pipe) {
+      // "everything the main stream held before this evaluation": what the NEXT pipelined evaluation's side stream will wait for
+      const int cur = e->entry_sel;
+      if (pipe) {
+         ps = e->s2;
+         if (e->have_prev_entry) HIPCHK(hipStreamWaitEvent(e->s2, e->ev_entry[cur ^ 1], 0));
+      }
+      HIPCHK(hipEventRecord(e->ev_entry[cur], e->stream));
+      e->entry_sel = cur ^ 1;
+      e->have_prev_entry = true;
+   }
    std::vector<EigenDev> tab;
    if (e->eigen_dirty) {
       tab.resize(e->eigen.size());
@@ -365,14 +397,15 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
                           (bs ? (size_t)B * (G * Km * L * 4 + Km * L * 8 + 2 * Km * 8) + 64 : 0) +
                           (new_prog ? e->prog.ops.size() * sizeof(Op) + e->prog.stream.size() * sizeof(int) : 0) + 256;
       HIPCHK(e->stage.begin(need));
-      HIPCHK(e->d_branch.ensure((size_t)B * nn));
-      HIPCHK(e->d_gene_rate.ensure((size_t)B * G));
+      DevBuf<double> &dbr = pipe ? e->d2_branch : e->d_branch, &dgr = pipe ? e->d2_gene_rate : e->d_gene_rate;   // (the side stream has its own)
+      HIPCHK(dbr.ensure((size_t)B * nn));
+      HIPCHK(dgr.ensure((size_t)B * G));
       const double *hb = e->stage.put(branch, (size_t)B * nn);
-      HIPCHK(hipMemcpyAsync(e->d_branch.p, hb, (size_t)B * nn * 8, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(dbr.p, hb, (size_t)B * nn * 8, hipMemcpyHostToDevice, ps));
       std::vector<double> gr((size_t)B * G, 1.0);
       if (gene_rate) gr.assign(gene_rate, gene_rate + (size_t)B * G);
       const double *hg = e->stage.put(gr.data(), gr.size());
-      HIPCHK(hipMemcpyAsync(e->d_gene_rate.p, hg, gr.size() * 8, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(dgr.p, hg, gr.size() * 8, hipMemcpyHostToDevice, ps));
       if (bs) {      // per-element class tables
          if (bs->eigen_of) {
             const size_t cnt = (size_t)B * G * Km * L;
@@ -409,10 +442,13 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
             HIPCHK(hipMemcpyAsync(e->d_stream.p, hs, e->prog.stream.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
          }
       }
-      HIPCHK(e->stage.end(e->stream));
+      HIPCHK(e->stage.end(ps));
    }
 
-   // P(t) storage
+   // P(t) storage (pipelined: the set the previous evaluation did not use)
+   if (pipe) {
+      std::swap(e->d_rowmajor, e->d2_rowmajor); std::swap(e->d_pint, e->d2_pint); std::swap(e->d_ptip, e->d2_ptip); std::swap(e->d_pcol, e->d2_pcol);
+   }
    HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
    if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
    if (e->kk == KK_MFMA64) HIPCHK(e->d_pcol.ensure((size_t)psets * nn * 64));
@@ -503,17 +539,21 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    PmatArgs pa{};
    pa.n = n; pa.n_nodes = nn; pa.root = e->tree.root; pa.K = Km; pa.n_genes = G; pa.n_labels = e->n_labels;
    pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : 0;
-   pa.label = e->d_label.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
-   pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
+   pa.label = e->d_label.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = pipe ? e->d2_branch.p : e->d_branch.p; pa.rate = e->d_rate.p;
+   pa.gene_rate = pipe ? e->d2_gene_rate.p : e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
    pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
    pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
    pa.B = B; pa.branch_bs = nn; pa.gene_rate_bs = G; pa.pcol = e->kk == KK_MFMA64 ? e->d_pcol.p : nullptr;
    if (bs && bs->eigen_of) { pa.eigen_of = e->d_b_eigen_of.p; pa.eigen_of_bs = (long)G * Km * e->n_labels; }
    if (bs && bs->qfactor) { pa.qfactor = e->d_b_qfactor.p; pa.qfactor_bs = (long)Km * e->n_labels; }
    if (bs && bs->rate) { pa.rate = e->d_b_rate.p; pa.rate_bs = Km; }
-   mark(e);
-   hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), e->stream, pa);
-   mark(e);
+   mark_on(e, ps);
+   hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), ps, pa);
+   mark_on(e, ps);
+   if (pipe) {      // the pruning kernel (main stream) starts when this P(t) is there
+      HIPCHK(hipEventRecord(e->ev_pmat, e->s2));
+      HIPCHK(hipStreamWaitEvent(e->stream, e->ev_pmat, 0));
+   }
    e->n_pmat += (long)psets * (nn - 1);
 
    // Kernel B: fused pruning
@@ -614,6 +654,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    if (e->profiling) e->prof_evals++;
    e->n_eval++;
    if (keep && !clean) e->partials_valid = true;
+   e->pipe_ok = want_pipe;      // (every other entry point clears it)
    return 0;
 }
 
@@ -769,6 +810,11 @@ void paml_amd_destroy(paml_amd_engine *e)
    if (!e) return;
    (void)hipStreamSynchronize(e->stream);
    if (e->jit_job && e->jit_job->th.joinable()) e->jit_job->th.join();
+   if (e->s2) {
+      (void)hipStreamSynchronize(e->s2);
+      (void)hipStreamDestroy(e->s2);
+      for (hipEvent_t ev : {e->ev_entry[0], e->ev_entry[1], e->ev_pmat}) if (ev) (void)hipEventDestroy(ev);
+   }
    delete e;
 }
 
@@ -787,6 +833,7 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
 
 int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream)
 {
+   if (e) e->pipe_ok = false;
    if (!e) return PAML_AMD_EINVAL;
    (void)hipStreamSynchronize(e->stream);
    e->stream = (hipStream_t)hip_stream;
@@ -796,6 +843,7 @@ int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream)
 int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata, int n_codes, const int *n_chara,
                       const unsigned char *chara_map, const double *weights, const int *gene_off)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !z || !weights) return fail(e, PAML_AMD_EINVAL, "set_tips: null argument");
    const int n = e->n;
    std::vector<int> nch;
@@ -848,6 +896,7 @@ int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata,
 int paml_amd_set_tree(paml_amd_engine *e, int n_nodes, int root, const int *sons_ptr, const int *sons, const int *label,
                       const unsigned char *scale_node)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !sons_ptr || !sons) return fail(e, PAML_AMD_EINVAL, "set_tree: null argument");
    if (n_nodes <= e->n_tips || root < 0 || root >= n_nodes) return fail(e, PAML_AMD_EINVAL, "set_tree: bad sizes");
    TreeDesc t;
@@ -890,6 +939,7 @@ int paml_amd_set_tree(paml_amd_engine *e, int n_nodes, int root, const int *sons
 
 int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !pi || (n_pi != 1 && n_pi != e->n_genes)) return fail(e, PAML_AMD_EINVAL, "set_pi: bad arguments");
    const int n = e->n;
    std::vector<double> buf;
@@ -919,6 +969,7 @@ static EigenHost *eigen_slot(paml_amd_engine *e, int set_id)
 
 int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, const double *V, const double *Root)
 {
+   if (e) e->pipe_ok = false;
    EigenHost *h = eigen_slot(e, set_id);
    if (!h || !U || !V || !Root) return fail(e, PAML_AMD_EINVAL, "set_eigen_uvroot: bad arguments");
    const size_t n = e->n;
@@ -932,6 +983,7 @@ int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, c
 
 int paml_amd_set_eigen_cijk(paml_amd_engine *e, int set_id, int nR, const double *Cijk, const double *Root)
 {
+   if (e) e->pipe_ok = false;
    EigenHost *h = eigen_slot(e, set_id);
    if (!h || !Cijk || !Root || nR < 1 || nR > 64) return fail(e, PAML_AMD_EINVAL, "set_eigen_cijk: bad arguments");
    const size_t n = e->n;
@@ -945,6 +997,7 @@ int paml_amd_set_eigen_cijk(paml_amd_engine *e, int set_id, int nR, const double
 
 int paml_amd_set_eigen_k80(paml_amd_engine *e, int set_id, double kappa)
 {
+   if (e) e->pipe_ok = false;
    if (e && e->n != 4) return fail(e, PAML_AMD_EINVAL, "set_eigen_k80: needs 4 states");
    EigenHost *h = eigen_slot(e, set_id);
    if (!h) return fail(e, PAML_AMD_EINVAL, "set_eigen_k80: bad arguments");
@@ -955,6 +1008,7 @@ int paml_amd_set_eigen_k80(paml_amd_engine *e, int set_id, double kappa)
 
 int paml_amd_set_eigen_jc69like(paml_amd_engine *e, int set_id)
 {
+   if (e) e->pipe_ok = false;
    EigenHost *h = eigen_slot(e, set_id);
    if (!h) return fail(e, PAML_AMD_EINVAL, "set_eigen_jc69like: bad arguments");
    h->kind = PAML_AMD_EIGEN_JC69LIKE;
@@ -963,6 +1017,7 @@ int paml_amd_set_eigen_jc69like(paml_amd_engine *e, int set_id)
 
 int paml_amd_set_eigen_qmat(paml_amd_engine *e, int set_id, const double *Q)
 {
+   if (e) e->pipe_ok = false;
    EigenHost *h = eigen_slot(e, set_id);
    if (!h || !Q) return fail(e, PAML_AMD_EINVAL, "set_eigen_qmat: bad arguments");
    if (e->n > 8) return fail(e, PAML_AMD_EUNSUPPORTED, "set_eigen_qmat: at most 8 states");
@@ -975,6 +1030,7 @@ int paml_amd_set_eigen_qmat(paml_amd_engine *e, int set_id, const double *Q)
 int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freqK, const double *rate, int n_labels,
                          const int *eigen_of, const double *qfactor)
 {
+   if (e) e->pipe_ok = false;
    if (!e || K < 1 || K > e->max_classes || n_labels < 1 || !eigen_of)
       return fail(e, PAML_AMD_EINVAL, "set_classes: bad arguments");
    if (mode != PAML_AMD_MODE_LFUN && mode != PAML_AMD_MODE_LFUNDG) return fail(e, PAML_AMD_EINVAL, "set_classes: bad mode");
@@ -1000,6 +1056,7 @@ int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freq
 int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, double *lnL, double *lnf,
                   double *fhK)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !branch || !lnL) return fail(e, PAML_AMD_EINVAL, "eval: null argument");
    int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, lnf != nullptr);
    if (r) return r;
@@ -1014,6 +1071,7 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
 int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, const double *gene_rate, const int *eigen_of,
                         const double *qfactor, const double *freqK, const double *rate, double *lnL, double *lnf)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !branch || !lnL || n_batch < 1) return fail(e, PAML_AMD_EINVAL, "eval_batch: bad arguments");
    if ((long)n_batch * e->K * e->n_genes > 65535) return fail(e, PAML_AMD_EINVAL, "eval_batch: n_batch * K * n_genes > 65535");
    BatchSpec bs{n_batch, eigen_of, qfactor, freqK, rate};
@@ -1029,6 +1087,7 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
 int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *gene_rate, const double *MK, const int *pose, int ls,
                       double *lnL)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !branch || !MK || !pose || !lnL || ls < 1) return fail(e, PAML_AMD_EINVAL, "eval_adg: bad arguments");
    if (e->mode != PAML_AMD_MODE_LFUNDG) return fail(e, PAML_AMD_EINVAL, "eval_adg: needs the lfundG class mode");
    const int K = e->K, np = e->n_patt;
@@ -1108,6 +1167,7 @@ static int beb_front(paml_amd_engine *e, const char *who, int n_grid, int n_cls,
 int paml_amd_beb_grid(paml_amd_engine *e, int n_grid, int n_cls, const double *pcl, const int *iw, const double *w_class,
                       double *ln_fx, double *pr_last, double *mean_w, double *sd_w)
 {
+   if (e) e->pipe_ok = false;
    if (!e || n_grid < 1 || n_cls < 1 || !pcl || !iw || !w_class || !pr_last || !mean_w || !sd_w)
       return fail(e, PAML_AMD_EINVAL, "beb_grid: bad arguments");
    if (e->K > BEB_MAXK) return fail(e, PAML_AMD_EUNSUPPORTED, "beb_grid: more than 32 classes");
@@ -1127,6 +1187,7 @@ int paml_amd_beb_grid(paml_amd_engine *e, int n_grid, int n_cls, const double *p
 
 int paml_amd_beb_grid_classes(paml_amd_engine *e, int n_grid, int n_cls, const double *pcl, const int *iw, double *ln_fx, double *post)
 {
+   if (e) e->pipe_ok = false;
    if (!e || n_grid < 1 || n_cls < 1 || n_cls > BEB_MAXCLS || !pcl || !iw || !post)
       return fail(e, PAML_AMD_EINVAL, "beb_grid_classes: bad arguments (at most 8 mixture classes per grid point)");
    BebArgs a;
@@ -1143,12 +1204,13 @@ int paml_amd_beb_grid_classes(paml_amd_engine *e, int n_grid, int n_cls, const d
 int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL)
 {
    if (!e || !branch || !d_lnL) return fail(e, PAML_AMD_EINVAL, "eval_device: null argument");
-   return launch_eval(e, branch, gene_rate, nullptr, d_lnL, false);
+   return launch_eval(e, branch, gene_rate, nullptr, d_lnL, false, nullptr, true);
 }
 
 int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
                         double *lnL)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !branch || !lnL || !clean) return fail(e, PAML_AMD_EINVAL, "eval_dirty: null argument");
    int r = launch_eval(e, branch, gene_rate, clean, nullptr, false);
    if (r) return r;
@@ -1160,6 +1222,7 @@ int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *
 int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *t, const double *branch,
                          const double *gene_rate, double *lnL, double *dlnL, double *ddlnL)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !t || !branch || !lnL || !dlnL || !ddlnL || n_t < 1 || n_t > 64)
       return fail(e, PAML_AMD_EINVAL, "eval_branch: bad arguments");
    if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes) || e->eigen.empty())
@@ -1251,6 +1314,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
 
 int paml_amd_node_posterior(paml_amd_engine *e, int node, const double *branch, const double *gene_rate, double *post)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !branch || !post) return fail(e, PAML_AMD_EINVAL, "node_posterior: null argument");
    if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes) || e->eigen.empty())
       return fail(e, PAML_AMD_EINVAL, "node_posterior before set_tips/set_tree/set_pi/set_classes/set_eigen");
@@ -1285,6 +1349,7 @@ int paml_amd_node_posterior(paml_amd_engine *e, int node, const double *branch, 
 
 int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double *P)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !P || !e->d_rowmajor.p) return fail(e, PAML_AMD_EINVAL, "get_pmat: nothing evaluated yet");
    if (gene < 0 || gene >= e->n_genes || iclass < 0 || iclass >= e->K || node < 0 || node >= e->tree.n_nodes ||
        node == e->tree.root)
@@ -1298,6 +1363,7 @@ int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double
 
 int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !conP) return fail(e, PAML_AMD_EINVAL, "get_partials: null argument");
    if (!(e->flags & PAML_AMD_KEEP_PARTIALS) || !e->partials_valid)
       return fail(e, PAML_AMD_EINVAL, "get_partials: needs PAML_AMD_KEEP_PARTIALS and a completed evaluation");
@@ -1335,6 +1401,7 @@ int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP
 
 int paml_amd_get_scale(paml_amd_engine *e, int node, int iclass, double *scale)
 {
+   if (e) e->pipe_ok = false;
    if (!e || !scale) return fail(e, PAML_AMD_EINVAL, "get_scale: null argument");
    if (!(e->flags & PAML_AMD_KEEP_PARTIALS) || !e->partials_valid)
       return fail(e, PAML_AMD_EINVAL, "get_scale: needs PAML_AMD_KEEP_PARTIALS and a completed evaluation");

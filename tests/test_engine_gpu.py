@@ -631,3 +631,30 @@ def test_compress_patterns_matches_lexsort(n_seq, n_sites, width, alphabet, gene
     assert len(got["first_site"]) == len(first)
     assert np.array_equal(got["first_site"], first) and np.array_equal(got["weights"], w) and np.array_equal(got["pose"], pose)
     assert got["weights"].sum() == n_sites
+
+
+def test_eval_device_pipeline_matches_in_order_evaluations():
+    """Consecutive eval_device calls overlap the next evaluation's P(t) kernel (side stream, alternate P buffers) with the
+    previous pruning kernel.  Twelve evaluations with different branch lengths queued without any host synchronisation, other
+    entry points interleaved (they drop the engine back to in-order execution), must each equal the plain evaluation."""
+    import torch
+    pb = helpers.random_problem(61, 12, 3000, K=2, seed=123)
+    eng = engine_for(pb)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(5)
+    brs = [pb.tree.branch * rng.uniform(0.5, 1.5, pb.tree.n_nodes) for _ in range(12)]
+    want = [eng.eval(b, pb.gene_rate)["lnL"] for b in brs]
+    out = torch.zeros(12, dtype=torch.float64, device="cuda")
+    for i, b in enumerate(brs):
+        eng.eval_device(b, out.data_ptr() + 8 * i, pb.gene_rate)
+        if i == 4:
+            eng.get_pmat(0, 0, 3)                       # another entry point in between: back to in-order for one call
+        if i == 8:
+            assert abs(eng.eval(brs[2], pb.gene_rate)["lnL"] - want[2]) <= 1e-12 * abs(want[2])
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.max(np.abs(got - np.array(want)) / np.abs(want)) <= 1e-13
+    # the P(t) a caller reads back is the last evaluation's, whichever buffer set it landed in
+    P = eng.get_pmat(0, 0, 3)
+    eng.eval(brs[-1], pb.gene_rate)
+    assert np.array_equal(P, eng.get_pmat(0, 0, 3))
