@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--classes", type=int, default=1, help=">1: NSsites-style omega classes (M0 when 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--allreduce-bucket", type=int, default=8,
+                    help="N > 1: lnL values of this many consecutive evaluations share one all-reduce (1 = one collective per evaluation)")
     args = ap.parse_args()
 
     import torch
@@ -91,20 +93,30 @@ def main():
     d_lnl = torch.zeros(args.warmup + args.steps, dtype=torch.float64, device="cuda")      # one slot per evaluation
     branch = pb.tree.branch.copy()
     pending = []
+    bucket = max(1, args.allreduce_bucket)
+    unsent = [0]                                   # first slot not yet handed to a collective
+
+    def flush(upto):
+        # the exchange step: sum the ranks' partial lnL of the evaluations [unsent, upto) — a bucket of 8-byte scalars, as a
+        # gradient's independent evaluations need their totals only together
+        if use_dist and upto > unsent[0]:
+            if os.environ.get("PAML_AMD_BENCH_SYNC_ALLREDUCE") == "1":      # A/B switch: the collective in line with the compute stream
+                dist.all_reduce(d_lnl[unsent[0]:upto])
+            else:
+                pending.append(dist.all_reduce(d_lnl[unsent[0]:upto], async_op=True))
+        unsent[0] = upto
 
     def step(i):
         # one likelihood evaluation of the whole alignment: P(t) for every branch, the pruning kernel, the weighted
         # reduction, and (N > 1) the all-reduce of the scalar.  Everything is enqueued on the stream; the lnL value stays
         # on the device, so consecutive evaluations run back to back (a gradient's evaluations are independent of each
         # other's results) and the host only synchronises at the fences around the timed region.  Each evaluation has its
-        # own result slot, so its 8-byte all-reduce (RCCL's stream, ordered after the evaluation by an event) overlaps the
-        # next evaluation instead of stalling the compute stream for a collective's latency.
+        # own result slot; the slots of `bucket` consecutive evaluations go through one asynchronous all-reduce (RCCL's
+        # stream, ordered after the last of them by an event), so neither the collective's latency nor its kernel sits
+        # between two evaluations.
         eng.eval_device(branch, d_lnl.data_ptr() + 8 * i)
-        if use_dist:
-            if os.environ.get("PAML_AMD_BENCH_SYNC_ALLREDUCE") == "1":      # A/B switch: the collective in line with the compute stream
-                dist.all_reduce(d_lnl[i:i + 1])
-            else:
-                pending.append(dist.all_reduce(d_lnl[i:i + 1], async_op=True))
+        if i + 1 - unsent[0] >= bucket:
+            flush(i + 1)
 
     def fence():
         while pending:
@@ -116,6 +128,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    flush(args.warmup)
     fence()
     lnl_warm = float(d_lnl[args.warmup - 1].item()) if args.warmup else None
 
@@ -124,6 +137,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    flush(args.warmup + args.steps)
     fence()
     dt = time.perf_counter() - t0
     lnl = float(d_lnl[-1].item())
