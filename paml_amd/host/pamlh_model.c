@@ -276,7 +276,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->model == 3) p->ncatG = 3;                /* "ncatG = 3 reset" (codeml.c:1607) */
       strcpy(p->code, GENETIC_CODES[p->icode]);
       if (p->nssites == 4) p->ncatG = 5;      /* M4 (freqs): omega = 0, 1/3, 2/3, 1, 3 with free proportions */
-      if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 3 && p->nssites != 4 && p->nssites != 5 && p->nssites != 7 && p->nssites != 8) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
+      if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 3 && p->nssites != 4 && p->nssites != 5 && p->nssites != 6 && p->nssites != 7 && p->nssites != 8 && p->nssites != 9 && p->nssites != 10) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
       if (p->model == 0 && p->nssites == 3 && (p->fix_omega || p->ncatG < 2 || p->ncatG > 16)) { rc = pamlh_fail(p, "NSsites = 3 needs fix_omega = 0 and 2 <= ncatG <= 16"); goto bad; }
       if (p->codonfreq < 0 || p->codonfreq > 5) { rc = pamlh_fail(p, "CodonFreq = %d is not supported", p->codonfreq); goto bad; }
       /* F1x4MG / F3x4MG (4, 5): the frequencies of F1x4 / F3x4, Muse-Gaut style rates (GetMutationMultiplier codeml.c:3060) */
@@ -354,6 +354,8 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
          else if (p->nssites == 3) nr += 2 * p->ncatG - 1;                        /* M3: K-1 proportions, K omegas */
          else if (p->nssites == 4) nr += 4;                                       /* M4: 4 proportions */
          else if (p->nssites == 5) nr += 2;                                       /* M5: gamma(a, b) */
+         else if (p->nssites == 6) nr += 4;                                       /* M6: p0, a1, b1, a2 */
+         else if (p->nssites == 9 || p->nssites == 10) nr += 5;                   /* M9 / M10: p0, p, q, a, b */
          else if (p->nssites == 0) nr += !p->fix_omega;
          else if (p->nssites == 1) nr += 2;
          else if (p->nssites == 2) nr += 4;
@@ -494,6 +496,8 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       }
       else if (p->nssites == 4) { for (i = 0; i < 4; i++) x[k++] = 0.2; }
       else if (p->nssites == 5) { x[k++] = 0.5; x[k++] = 1.0; }
+      else if (p->nssites == 6) { x[k++] = 0.6; x[k++] = 0.5; x[k++] = 1.5; x[k++] = 2.0; }
+      else if (p->nssites == 9 || p->nssites == 10) { x[k++] = 0.8; x[k++] = 0.5; x[k++] = 1.5; x[k++] = 1.0; x[k++] = 1.0; }
       else if (p->nssites == 3) {                   /* M3: K-1 proportions, K omegas */
          for (i = 0; i < p->ncatG - 1; i++) x[k++] = 1.0 / p->ncatG;
          for (i = 0; i < p->ncatG; i++) x[k++] = 0.1 + 1.4 * i / (p->ncatG - 1);
@@ -570,6 +574,34 @@ static double codon_q_pi(const pamlh *p, const double *pi, double kappa, double 
    for (i = 0; i < n; i++) for (j = 0; j < n; j++) Q[i * n + j] *= pi[j];
    for (i = 0; i < n; i++) { double s = 0; for (j = 0; j < n; j++) if (j != i) s += Q[i * n + j]; Q[i * n + i] = -s; mr += pi[i] * s; }
    return mr;
+}
+
+/* CDF of the omega distribution of the continuous site models M6 (2 gammas), M9 (beta & gamma), M10 (beta & 1 + gamma)
+ * (CDFdN_dS codeml.c:2913-2975; parameters in the order of x[]), and the medians of K equal-probability bins inside (1e-7, 99)
+ * (DiscreteNSsites codeml.c:2872-2880; the reference's line search to 1e-15 and this bisection find the same roots). */
+static double cdf_omega(int nssites, double x, const double *par)
+{
+   if (nssites == 6) return par[0] * pamlh_gammp(par[1], par[2] * x) + (1 - par[0]) * pamlh_gammp(par[3], par[3] * x);
+   if (nssites == 9) return par[0] * (x >= 1 ? 1 : pamlh_betai(par[1], par[2], x)) + (1 - par[0]) * pamlh_gammp(par[3], par[4] * x);
+   /* 10 */
+   if (x <= 1) return par[0] * pamlh_betai(par[1], par[2], x);
+   return par[0] + (1 - par[0]) * pamlh_gammp(par[3], par[4] * (x - 1));
+}
+
+static void omega_medians(int nssites, const double *par, int K, double *w)
+{
+   int j, it;
+   for (j = 0; j < K; j++) {
+      const double pr = (j * 2. + 1) / (2. * K);
+      double lo = 1e-7, hi = 99;
+      if (cdf_omega(nssites, lo, par) >= pr) { w[j] = lo; continue; }
+      if (cdf_omega(nssites, hi, par) <= pr) { w[j] = hi; continue; }
+      for (it = 0; it < 200 && hi - lo > 1e-15 * (1 + hi); it++) {
+         const double mid = 0.5 * (lo + hi);
+         if (cdf_omega(nssites, mid, par) < pr) lo = mid; else hi = mid;
+      }
+      w[j] = 0.5 * (lo + hi);
+   }
 }
 
 /* number of exchangeability parameters of a baseml model (nkappa[] baseml.c:1311) */
@@ -805,6 +837,14 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
             }
             k += 2;
          }
+         else if (p->nssites == 6 || p->nssites == 9 || p->nssites == 10) {
+            const int npar = p->nssites == 6 ? 4 : 5;
+            K = p->ncatG;
+            if (K > 16) { free(Q); return pamlh_fail(p, "ncatG too large"); }
+            omega_medians(p->nssites, x + k, K, w);
+            for (j = 0; j < K; j++) f[j] = 1.0 / K;
+            k += npar;
+         }
          else if (p->nssites == 4) {      /* M4 (freqs, NSfreqs codeml.c:2531-2538) */
             static const double w4[5] = {0, 1. / 3, 2. / 3, 1, 3};
             K = 5;
@@ -1026,6 +1066,8 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
          else if (p->nssites == 3) { for (j = 0; j < p->ncatG - 1; j++) NAME("p%d", j); for (j = 0; j < p->ncatG; j++) NAME("w%d", j); }
          else if (p->nssites == 4) { for (j = 0; j < 4; j++) NAME("p%d", j); }
          else if (p->nssites == 5) { NAME("a (gamma)"); NAME("b (gamma)"); }
+         else if (p->nssites == 6) { NAME("p0"); NAME("a1"); NAME("b1"); NAME("a2"); }
+         else if (p->nssites == 9 || p->nssites == 10) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); NAME("a (gamma)"); NAME("b (gamma)"); }
          else if (p->nssites == 7) { NAME("p (beta)"); NAME("q (beta)"); }
          else if (p->nssites == 8) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); if (!p->fix_omega) NAME("ws"); }
       }

@@ -190,6 +190,8 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
       }
       else if (p->nssites == 4) { for (i = 0; i < 4; i++) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; } }
       else if (p->nssites == 5) { lo[k] = 0.005; hi[k++] = 99; lo[k] = 0.005; hi[k++] = 99; }
+      else if (p->nssites == 6) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; for (i = 0; i < 3; i++) { lo[k] = 0.005; hi[k++] = 99; } }
+      else if (p->nssites == 9 || p->nssites == 10) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; for (i = 0; i < 4; i++) { lo[k] = 0.005; hi[k++] = 99; } }
       else if (p->nssites == 3) {
          for (i = 0; i < p->ncatG - 1; i++) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; }
          for (i = 0; i < p->ncatG; i++) { lo[k] = 1e-6; hi[k++] = 999; }

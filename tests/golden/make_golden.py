@@ -430,6 +430,9 @@ CASES = {
     "hiv_m3": lambda: case_mle("hiv_m3", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=3, ncatG=3, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_m4": lambda: case_mle("hiv_m4", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=4, ncatG=5, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_m5": lambda: case_mle("hiv_m5", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=5, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
+    "hiv_m6": lambda: case_mle("hiv_m6", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=6, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
+    "hiv_m9": lambda: case_mle("hiv_m9", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=9, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
+    "hiv_m10": lambda: case_mle("hiv_m10", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=10, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_m0": lambda: case_hiv("m0"), "hiv_m1a": lambda: case_hiv("m1a"), "hiv_m2a": lambda: case_hiv("m2a"),
     "hiv_m7": lambda: case_hiv("m7"), "hiv_m8": lambda: case_hiv("m8"),
     "stewart_lg_g4": case_stewart, "mhc_m0_scaled": case_mhc,
