@@ -276,7 +276,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->model == 3) p->ncatG = 3;                /* "ncatG = 3 reset" (codeml.c:1607) */
       strcpy(p->code, GENETIC_CODES[p->icode]);
       if (p->nssites == 4) p->ncatG = 5;      /* M4 (freqs): omega = 0, 1/3, 2/3, 1, 3 with free proportions */
-      if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 3 && p->nssites != 4 && p->nssites != 5 && p->nssites != 6 && p->nssites != 7 && p->nssites != 8 && p->nssites != 9 && p->nssites != 10) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
+      if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 3 && p->nssites != 4 && p->nssites != 5 && p->nssites != 6 && p->nssites != 7 && p->nssites != 8 && !(p->nssites >= 9 && p->nssites <= 13)) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
       if (p->model == 0 && p->nssites == 3 && (p->fix_omega || p->ncatG < 2 || p->ncatG > 16)) { rc = pamlh_fail(p, "NSsites = 3 needs fix_omega = 0 and 2 <= ncatG <= 16"); goto bad; }
       if (p->codonfreq < 0 || p->codonfreq > 5) { rc = pamlh_fail(p, "CodonFreq = %d is not supported", p->codonfreq); goto bad; }
       /* F1x4MG / F3x4MG (4, 5): the frequencies of F1x4 / F3x4, Muse-Gaut style rates (GetMutationMultiplier codeml.c:3060) */
@@ -355,7 +355,8 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
          else if (p->nssites == 4) nr += 4;                                       /* M4: 4 proportions */
          else if (p->nssites == 5) nr += 2;                                       /* M5: gamma(a, b) */
          else if (p->nssites == 6) nr += 4;                                       /* M6: p0, a1, b1, a2 */
-         else if (p->nssites == 9 || p->nssites == 10) nr += 5;                   /* M9 / M10: p0, p, q, a, b */
+         else if (p->nssites >= 9 && p->nssites <= 12) nr += 5;                   /* M9 - M12: five parameters (CDFdN_dS codeml.c:2925-2934) */
+         else if (p->nssites == 13) nr += 6;                                      /* M13: p0, p1, mu2, s0, s1, s2 */
          else if (p->nssites == 0) nr += !p->fix_omega;
          else if (p->nssites == 1) nr += 2;
          else if (p->nssites == 2) nr += 4;
@@ -498,6 +499,9 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       else if (p->nssites == 5) { x[k++] = 0.5; x[k++] = 1.0; }
       else if (p->nssites == 6) { x[k++] = 0.6; x[k++] = 0.5; x[k++] = 1.5; x[k++] = 2.0; }
       else if (p->nssites == 9 || p->nssites == 10) { x[k++] = 0.8; x[k++] = 0.5; x[k++] = 1.5; x[k++] = 1.0; x[k++] = 1.0; }
+      else if (p->nssites == 11) { x[k++] = 0.8; x[k++] = 0.5; x[k++] = 1.5; x[k++] = 2.0; x[k++] = 1.0; }
+      else if (p->nssites == 12) { x[k++] = 0.3; x[k++] = 0.6; x[k++] = 2.0; x[k++] = 0.5; x[k++] = 1.0; }
+      else if (p->nssites == 13) { x[k++] = 0.4; x[k++] = 0.4; x[k++] = 2.0; x[k++] = 0.3; x[k++] = 0.5; x[k++] = 1.0; }
       else if (p->nssites == 3) {                   /* M3: K-1 proportions, K omegas */
          for (i = 0; i < p->ncatG - 1; i++) x[k++] = 1.0 / p->ncatG;
          for (i = 0; i < p->ncatG; i++) x[k++] = 0.1 + 1.4 * i / (p->ncatG - 1);
@@ -583,9 +587,26 @@ static double cdf_omega(int nssites, double x, const double *par)
 {
    if (nssites == 6) return par[0] * pamlh_gammp(par[1], par[2] * x) + (1 - par[0]) * pamlh_gammp(par[3], par[3] * x);
    if (nssites == 9) return par[0] * (x >= 1 ? 1 : pamlh_betai(par[1], par[2], x)) + (1 - par[0]) * pamlh_gammp(par[3], par[4] * x);
-   /* 10 */
-   if (x <= 1) return par[0] * pamlh_betai(par[1], par[2], x);
-   return par[0] + (1 - par[0]) * pamlh_gammp(par[3], par[4] * (x - 1));
+   if (nssites == 10) {
+      if (x <= 1) return par[0] * pamlh_betai(par[1], par[2], x);
+      return par[0] + (1 - par[0]) * pamlh_gammp(par[3], par[4] * (x - 1));
+   }
+   if (nssites == 11) {      /* beta & normal truncated to > 1: p0, p, q, mu, s */
+      double c;
+      if (x <= 1) return par[0] * pamlh_betai(par[1], par[2], x);
+      c = pamlh_cdf_normal((par[3] - 1) / par[4]);
+      return par[0] + (1 - par[0]) * (1 - pamlh_cdf_normal((par[3] - x) / par[4]) / c);
+   }
+   if (nssites == 12) {      /* (spike at 0 handled outside) two normals truncated to > 0, means 1 and mu2: p0, p1, mu2, s1, s2 */
+      const double f1 = par[1], f2 = 1 - par[1];
+      return 1 - f1 * pamlh_cdf_normal(-(x - 1) / par[3]) / pamlh_cdf_normal(1 / par[3])
+               - f2 * pamlh_cdf_normal(-(x - par[2]) / par[4]) / pamlh_cdf_normal(par[2] / par[4]);
+   }
+   {                         /* 13: three normals truncated to > 0, means 0, 1, mu2: p0, p1, mu2, s0, s1, s2 */
+      const double f0 = par[0], f1 = par[1], f2 = 1 - f0 - f1;
+      return 1 - f0 * 2 * pamlh_cdf_normal(-x / par[3]) - f1 * pamlh_cdf_normal(-(x - 1) / par[4]) / pamlh_cdf_normal(1 / par[4])
+               - f2 * pamlh_cdf_normal(-(x - par[2]) / par[5]) / pamlh_cdf_normal(par[2] / par[5]);
+   }
 }
 
 static void omega_medians(int nssites, const double *par, int K, double *w)
@@ -837,12 +858,22 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
             }
             k += 2;
          }
-         else if (p->nssites == 6 || p->nssites == 9 || p->nssites == 10) {
-            const int npar = p->nssites == 6 ? 4 : 5;
+         else if (p->nssites == 6 || (p->nssites >= 9 && p->nssites <= 13)) {
+            const int npar = p->nssites == 6 ? 4 : p->nssites == 13 ? 6 : 5;
             K = p->ncatG;
             if (K > 16) { free(Q); return pamlh_fail(p, "ncatG too large"); }
-            omega_medians(p->nssites, x + k, K, w);
-            for (j = 0; j < K; j++) f[j] = 1.0 / K;
+            if (p->nssites == 12) {      /* a spike at omega = 0 (proportion p0) + ncatG classes of the normal mixture, as M8 adds its class to
+                                          * the ncatG of the control file (codeml.c:2888-2895) */
+               if (K > 15) { free(Q); return pamlh_fail(p, "ncatG too large"); }
+               omega_medians(12, x + k, K, w + 1);
+               w[0] = 0; f[0] = x[k];
+               for (j = 1; j <= K; j++) f[j] = (1 - x[k]) / K;
+               K++;
+            }
+            else {
+               omega_medians(p->nssites, x + k, K, w);
+               for (j = 0; j < K; j++) f[j] = 1.0 / K;
+            }
             k += npar;
          }
          else if (p->nssites == 4) {      /* M4 (freqs, NSfreqs codeml.c:2531-2538) */
@@ -1068,6 +1099,9 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
          else if (p->nssites == 5) { NAME("a (gamma)"); NAME("b (gamma)"); }
          else if (p->nssites == 6) { NAME("p0"); NAME("a1"); NAME("b1"); NAME("a2"); }
          else if (p->nssites == 9 || p->nssites == 10) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); NAME("a (gamma)"); NAME("b (gamma)"); }
+         else if (p->nssites == 11) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); NAME("mu"); NAME("s"); }
+         else if (p->nssites == 12) { NAME("p0"); NAME("p1"); NAME("mu2"); NAME("s1"); NAME("s2"); }
+         else if (p->nssites == 13) { NAME("p0"); NAME("p1"); NAME("mu2"); NAME("s0"); NAME("s1"); NAME("s2"); }
          else if (p->nssites == 7) { NAME("p (beta)"); NAME("q (beta)"); }
          else if (p->nssites == 8) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); if (!p->fix_omega) NAME("ws"); }
       }

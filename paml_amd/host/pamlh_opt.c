@@ -192,6 +192,9 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
       else if (p->nssites == 5) { lo[k] = 0.005; hi[k++] = 99; lo[k] = 0.005; hi[k++] = 99; }
       else if (p->nssites == 6) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; for (i = 0; i < 3; i++) { lo[k] = 0.005; hi[k++] = 99; } }
       else if (p->nssites == 9 || p->nssites == 10) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; for (i = 0; i < 4; i++) { lo[k] = 0.005; hi[k++] = 99; } }
+      else if (p->nssites == 11) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 0.005; hi[k++] = 99; lo[k] = 0.005; hi[k++] = 99; lo[k] = 1; hi[k++] = 9; lo[k] = 0.005; hi[k++] = 99; }
+      else if (p->nssites == 12) { for (i = 0; i < 2; i++) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; } for (i = 0; i < 3; i++) { lo[k] = 1e-4; hi[k++] = 29; } }
+      else if (p->nssites == 13) { for (i = 0; i < 2; i++) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; } for (i = 0; i < 4; i++) { lo[k] = 1e-4; hi[k++] = 29; } }
       else if (p->nssites == 3) {
          for (i = 0; i < p->ncatG - 1; i++) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; }
          for (i = 0; i < p->ncatG; i++) { lo[k] = 1e-6; hi[k++] = 999; }

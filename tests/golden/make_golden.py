@@ -305,6 +305,26 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtyp
                                              x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
 
 
+def case_at(name, ctl_over, files, n_tips, kind, x, ntime):
+    """Single evaluation at chosen parameter values (the -1 recipe): for models whose maximum sits at degenerate values where the
+    reference's own discretisation (a line search on (CDF - p)^2) is only accurate to ~1e-5."""
+    ctl = dict(CODEML_BASE, outfile="mlc", **ctl_over)
+    res1 = run_ref("codeml", ctl, files, x=x)
+    g = finish(name, res1, "codon", n_tips, dict(program="codeml", model=dict(kind=kind, **{k: ctl_over[k] for k in ("NSsites", "ncatG") if k in ctl_over}),
+                                                 x=x, ntime=ntime), keep_raw_patterns=True)
+    # The reference evaluates the likelihood twice (once for the printed lnL, once for the lnf file), and its discretisation of the
+    # omega distribution starts each line search from the previous call's classes: under M11 the two calls differ by ~3e-3.  The
+    # per-pattern values are the ones a second program can be compared with; lnL is their weighted sum.
+    s_lnf = float(np.dot(g["counts"], g["logf"]))
+    if abs(s_lnf - g["lnL"]) > 1e-5:
+        g["lnL_printed"] = g["lnL"]
+        g["lnL"] = round(s_lnf, 6)
+        g["note"] = "lnL = sum of counts x log f_h of the lnf file; the reference's printed lnL (lnL_printed) comes from a separate call with a different discretisation"
+        with open(os.path.join(HERE, name + ".json"), "w") as f:
+            json.dump(g, f, separators=(",", ":"))
+        print("   %s: printed lnL %.6f, lnf-file sum %.6f" % (name, g["lnL_printed"], g["lnL"]))
+
+
 LYSO = {"lysozymeLarge.nuc": EX + "/lysozyme/lysozymeLarge.nuc", "lysozymeLarge.trees": EX + "/lysozyme/lysozymeLarge.trees"}
 LYSO_CTL = dict(seqfile="lysozymeLarge.nuc", treefile="lysozymeLarge.trees", kappa=3, cleandata=0)
 ECP = {"ECP_EDN_15.nuc": EX + "/CladeModelCD/ECP_EDN_15.nuc", "tree.txt": EX + "/CladeModelCD/tree.txt"}
@@ -433,6 +453,11 @@ CASES = {
     "hiv_m6": lambda: case_mle("hiv_m6", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=6, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_m9": lambda: case_mle("hiv_m9", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=9, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_m10": lambda: case_mle("hiv_m10", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=10, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
+    "hiv_m11": lambda: case_at("hiv_m11", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=11, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites",
+                               [float(v) for v in HIV_X["m7"][1].split()[:24]] + [0.8, 0.4, 1.2, 2.0, 0.9], 23),
+    "hiv_m12": lambda: case_mle("hiv_m12", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=12, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
+    "hiv_m13": lambda: case_at("hiv_m13", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=13, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites",
+                               [float(v) for v in HIV_X["m7"][1].split()[:24]] + [0.3, 0.4, 2.5, 0.3, 0.5, 1.2], 23),
     "hiv_m0": lambda: case_hiv("m0"), "hiv_m1a": lambda: case_hiv("m1a"), "hiv_m2a": lambda: case_hiv("m2a"),
     "hiv_m7": lambda: case_hiv("m7"), "hiv_m8": lambda: case_hiv("m8"),
     "stewart_lg_g4": case_stewart, "mhc_m0_scaled": case_mhc,

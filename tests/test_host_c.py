@@ -20,7 +20,8 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          # branch-site A (alternative and null), B; clade C, D; M3 — goldens at the reference's own 6-decimal MLEs
          ("lyso_bsa", "codeml", "lyso_bsa.ctl"), ("lyso_bsa_null", "codeml", "lyso_bsa_null.ctl"), ("lyso_bsb", "codeml", "lyso_bsb.ctl"),
          ("ecp_cmc", "codeml", "ecp_cmc.ctl"), ("ecp_cmd", "codeml", "ecp_cmd.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl"), ("hiv_m4", "codeml", "hiv_ns4.ctl"), ("hiv_m5", "codeml", "hiv_ns5.ctl"), ("hiv_m6", "codeml", "hiv_ns6.ctl"), ("hiv_m9", "codeml", "hiv_ns9.ctl"),
-         ("hiv_m10", "codeml", "hiv_ns10.ctl"), ("ecp_m2arel", "codeml", "ecp_m2arel.ctl"),
+         ("hiv_m10", "codeml", "hiv_ns10.ctl"), ("hiv_m11", "codeml", "hiv_ns11.ctl"), ("hiv_m12", "codeml", "hiv_ns12.ctl"),
+         ("hiv_m13", "codeml", "hiv_ns13.ctl"), ("ecp_m2arel", "codeml", "ecp_m2arel.ctl"),
          ("brown_hky85_clock", "baseml", "brown_hky85_clock.ctl"),      # global clock: x holds the node ages
          ("brown_f84", "baseml", "brown_f84.ctl"), ("brown_t92_g4", "baseml", "brown_t92_g4.ctl"), ("brown_unrest", "baseml", "brown_unrest.ctl"), ("stewart_eqinput", "codeml", "stewart_eqinput.ctl"),
          ("hiv_m0_f3x4mg", "codeml", "hiv_ns0_cf5.ctl"), ("hiv_m0_f1x4mg", "codeml", "hiv_ns0_cf4.ctl"),      # Muse-Gaut style rates
