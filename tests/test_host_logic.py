@@ -358,3 +358,28 @@ def test_valu_jit_source_compiles_for_gfx950(lib_path, n_states):
     src = engine.debug_jit(pb.tree, scale_node=pb.scale_node, compile=True, n_states=n_states)
     assert "JV_PROLOGUE(%d)" % n_states in src and src.count("jv_matvec<N>") == pb.tree.n_nodes - pb.tree.n_tips - 1
     assert src.count("jv_scale<N>") == int(pb.scale_node.sum())
+
+
+def test_product_paths_fail_loudly_without_a_gpu(lib_path):
+    """No CPU fallback anywhere in the product: on a host without a HIP device (this test's container) engine creation, the C
+    host's evaluation and the device pattern compression all return an error instead of computing something else."""
+    import ctypes as C
+    import subprocess
+    from paml_amd import hostlib
+    from paml_amd.engine import Engine, EngineError, compress_patterns
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is visible: nothing to check here")
+    except ImportError:
+        pass
+    with pytest.raises(EngineError, match="paml_amd_create failed"):
+        Engine(61, 8, 100)
+    with pytest.raises(EngineError, match="compress_patterns failed"):
+        compress_patterns(np.zeros((3, 10), dtype=np.uint8))
+    a = hostlib.Analysis(os.path.join(helpers.GOLDEN, "ctl", "hiv_ns0.ctl"), "codeml")
+    with pytest.raises(RuntimeError, match="no GPU"):
+        a.eval_gpu(a.default_x())
+    assert a.plfun(a.default_x()) == 1e300
+    r = subprocess.run([hostlib.DRIVER_PATH, "codeml", os.path.join(helpers.GOLDEN, "ctl", "hiv_ns0.ctl")], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "no GPU" in r.stderr
