@@ -544,3 +544,30 @@ def test_c_host_reaches_the_published_mhc_site_model_values(ns, lnl):
     assert a.ntime == 0 and a.n_tips == 192
     r = a.optimize(a.default_x(), max_iter=300)
     assert r["converged"] and abs(r["lnL"] - lnl) < 5e-4, (ns, r["lnL"], r["x"])
+
+
+def test_host_bivariate_normal_and_autod_gamma_numerics():
+    """The numerics behind AutodGamma, restated from the published approximations the reference uses: L(h, k, r) (Genz 2004) against
+    scipy's bivariate normal over both branches of the algorithm (|r| < 0.925 and above), the AS 70 quantile against scipy to its
+    stated accuracy, and the transition matrix: rows sum to 1, symmetric, uniform stationary distribution, identity-like for rho -> 1."""
+    import ctypes as C
+    from scipy.stats import multivariate_normal, norm
+    L = hostlib.lib()
+    L.pamlh_lbinormal.restype = C.c_double
+    L.pamlh_lbinormal.argtypes = [C.c_double] * 3
+    L.pamlh_quantile_normal.restype = C.c_double
+    L.pamlh_quantile_normal.argtypes = [C.c_double]
+    L.pamlh_autod_gamma.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int]
+    for r in (-0.6, -0.1, 0.0, 0.25, 0.7, 0.93, 0.99, -0.95):
+        for h, k in ((-1.0, 0.5), (0.3, 0.3), (1.5, -0.7), (-2.0, -1.0), (0.0, 2.0)):
+            want = multivariate_normal(mean=[0, 0], cov=[[1, r], [r, 1]]).cdf([-h, -k])        # Pr(X > h, Y > k) by symmetry
+            assert abs(L.pamlh_lbinormal(h, k, r) - want) < 5e-7, (h, k, r)
+    for p in (0.001, 0.1, 0.25, 0.5, 0.9, 0.999):
+        assert abs(L.pamlh_quantile_normal(p) - norm.ppf(p)) < 5e-7 * max(1, abs(norm.ppf(p)) ** 2) + 5e-7
+    for K, rho in ((4, 0.3), (5, -0.15), (8, 0.8), (3, 0.98)):
+        M, f, rk = np.zeros((K, K)), np.zeros(K), np.zeros(K)
+        L.pamlh_autod_gamma(M.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p), rk.ctypes.data_as(C.c_void_p), 0.6, rho, K)
+        assert np.allclose(M.sum(axis=1), 1, atol=2e-6) and np.allclose(M, M.T, atol=1e-7) and (M > -1e-9).all()
+        assert np.allclose(f, 1.0 / K) and abs(np.dot(f, rk) - 1) < 1e-9
+        if rho > 0.9:
+            assert np.all(np.diag(M) > 0.75)
