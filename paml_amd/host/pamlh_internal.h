@@ -37,6 +37,7 @@ struct pamlh {
    int *n_chara;
    int *pose, n_pose;      /* site (after cleaning) -> pattern index */
    int ngene, posG[PAMLH_MAXGENE + 1], lgene[PAMLH_MAXGENE];   /* option G: first pattern / number of sites of every gene */
+   int nhomo;              /* baseml: 1 = base frequencies are parameters */
    int mg;                 /* CodonFreq 4 / 5: F1x4MG / F3x4MG */
    int fix_rho, adg;       /* auto-discrete-gamma: rho free or fixed != 0; adg: the current model state uses lfunAdG with MK */
    double rho0, rho, MK[64 * 64 / 4];

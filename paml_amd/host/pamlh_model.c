@@ -258,6 +258,8 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->fix_alpha && p->alpha0 <= 0) { rc = pamlh_fail(p, "fix rho to 0 if alpha = 0"); goto bad; }
       if (p->nssites) { rc = pamlh_fail(p, "rho does not go with NSsites models"); goto bad; }
    }
+   p->nhomo = p->is_codeml ? 0 : (int)pamlh_optd(p, "nhomo", 0);
+   if (p->nhomo != 0 && p->nhomo != 1) { rc = pamlh_fail(p, "nhomo = %d is not supported (0: frequencies from the data, 1: frequencies as parameters)", p->nhomo); goto bad; }
    p->clock = (int)pamlh_optd(p, "clock", 0);
    if (p->clock != 0 && p->clock != 1) { rc = pamlh_fail(p, "clock = %d is not supported (0: no clock, 1: global clock)", p->clock); goto bad; }
    p->mgene = (int)pamlh_optd(p, "Mgene", 0);
@@ -300,6 +302,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    else { rc = pamlh_fail(p, "seqtype %d is not supported", p->seqtype); goto bad; }
    if ((rc = pamlh_read_seqs(p))) goto bad;
    if ((rc = pamlh_read_tree(p))) goto bad;
+   if (p->nhomo == 1 && (p->ngene > 1 || p->model < F81 || p->model > REV)) { rc = pamlh_fail(p, "nhomo = 1 needs one gene and a model with base frequencies (F81 ... REV)"); goto bad; }
    if (p->ngene <= 1) { if (p->mgene) { rc = pamlh_fail(p, "Mgene = %d but the sequence file has one gene (no option G)", p->mgene); goto bad; } }
    else {
       /* what the several-gene set-up covers (the reference's own exclusions: baseml.c:261-265, codeml.c:1534-1544) */
@@ -368,6 +371,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
          else if (p->model == TN93) nr += 2 * !p->fix_kappa;
          else if (p->model == REV) nr += 5;
          else if (p->model == UNREST) nr += 11;
+         if (p->nhomo == 1) nr += p->model == T92 ? 1 : 3;
       }
       if (rep > 1) nr += (rep - 1) * (p->seqtype == 1 ? 2 : nuc_nkappa(p));      /* Mgene 3, 4: a parameter set per gene */
       if (p->alpha0 > 0 || !p->fix_alpha) nr += !p->fix_alpha;
@@ -517,6 +521,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       else if (p->model == TN93 && !p->fix_kappa) { x[k++] = p->kappa0; x[k++] = p->kappa0; }
       else if (p->model == REV) { for (i = 0; i < 5; i++) x[k++] = 1; }
       else if (p->model == UNREST) { for (i = 0; i < 11; i++) x[k++] = (i == 0 || i == 3 || i == 8) ? 0.9 : 0.5; }
+      if (p->nhomo == 1) { if (p->model == T92) x[k++] = p->pi_data[1] + p->pi_data[3]; else for (i = 0; i < 3; i++) x[k++] = p->pi_data[i]; }
    }
    if (!p->fix_alpha) x[k++] = p->alpha0 > 0 ? p->alpha0 : 0.5;
    if (!p->fix_rho) x[k++] = p->rho0;
@@ -934,6 +939,12 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
       for (i = 0; i < 16; i++) S[i] = 1;
       if (m == JC69 || m == K80) for (i = 0; i < 4; i++) p->pi[i] = 0.25;
       else memcpy(p->pi, p->pi_data, 4 * sizeof(double));
+      if (p->nhomo == 1) {       /* base frequencies are parameters, after the rate parameters in x (SetParameters baseml.c:1328-1341) */
+         const double *px = x + k + nuc_nkappa(p);
+         if (m == T92) { p->pi[0] = p->pi[2] = (1 - px[0]) / 2; p->pi[1] = p->pi[3] = px[0] / 2; }
+         else { p->pi[0] = px[0]; p->pi[1] = px[1]; p->pi[2] = px[2]; p->pi[3] = 1 - px[0] - px[1] - px[2]; }
+         if (!(p->pi[3] > 1e-9)) { free(Q); return pamlh_fail(p, "base frequencies sum above 1"); }
+      }
       if (m == UNREST) { unrest_set(p, 0, p->pi, x + k); k += 11; }
       else if (m == JC69 || m == K80) {
          p->eig[0].kind = PAML_AMD_EIGEN_K80;
@@ -967,6 +978,7 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          }
       }
    }
+   if (p->seqtype == 0 && p->nhomo == 1) k += p->model == T92 ? 1 : 3;
    /* gamma rates for sites (not with NSsites): alpha fixed > 0 or free */
    if (!(p->seqtype == 1 && p->nssites)) {
       double alpha = p->fix_alpha ? p->alpha0 : x[k++];
@@ -1112,6 +1124,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
          else if ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) NAME("kappa%s", sfx);
       }
    }
+   if (p->seqtype == 0 && p->nhomo == 1) { if (p->model == T92) NAME("GC content"); else { NAME("pi_T"); NAME("pi_C"); NAME("pi_A"); } }
    if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) NAME("alpha");
    if (!p->fix_rho) NAME("rho");
 #undef NAME

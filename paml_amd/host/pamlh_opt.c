@@ -215,6 +215,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
       const int nk = ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) ? 1 : (p->model == TN93 && !p->fix_kappa) ? 2 : p->model == REV ? 5 : p->model == UNREST ? 11 : 0;
       for (i = 0; i < nk; i++) { lo[k] = 1e-4; hi[k++] = 999; }
    }
+   if (p->seqtype == 0 && p->nhomo == 1) for (i = 0; i < (p->model == T92 ? 1 : 3); i++) { lo[k] = 1e-5; hi[k++] = 0.99999; }
    if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) { lo[k] = 0.005; hi[k++] = 99; }
    if (!p->fix_rho) { lo[k] = -0.2; hi[k++] = 0.99; }
    return k == p->np ? 0 : -1;

@@ -435,6 +435,7 @@ CASES = {
     "brown_hky85_adg": lambda: case_brown_adg(),
     "brown_hky85_g4_rates": case_brown_rates,
     "brown_hky85_joint": case_brown_joint,
+    "brown_hky85_nhomo1": lambda: case_mle("brown_hky85_nhomo1", dict(seqfile="brown.nuc", treefile="brown.trees", model=4, kappa=5, nhomo=1), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
     "brown_hky85_clock": case_brown_clock,
     "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
