@@ -306,7 +306,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    if (p->ngene <= 1) { if (p->mgene) { rc = pamlh_fail(p, "Mgene = %d but the sequence file has one gene (no option G)", p->mgene); goto bad; } }
    else {
       /* what the several-gene set-up covers (the reference's own exclusions: baseml.c:261-265, codeml.c:1534-1544) */
-      if (p->fix_blength == 2) { rc = pamlh_fail(p, "fix_blength = 2 does not work for partitioned data"); goto bad; }
+      if (p->fix_blength >= 2) { rc = pamlh_fail(p, "fix_blength = 2 or 3 does not work for partitioned data"); goto bad; }
       if (!p->fix_rho || p->rho0 != 0) { rc = pamlh_fail(p, "rho with several genes is not supported"); goto bad; }
       if (p->seqtype == 1 && (p->model || p->nssites)) { rc = pamlh_fail(p, "several genes: only the one-ratio codon model (model 0, NSsites 0)"); goto bad; }
       if (p->mgene >= 3 && (p->fix_kappa || (p->seqtype == 1 && p->fix_omega))) { rc = pamlh_fail(p, "Mgene = %d needs free kappa (and omega)", p->mgene); goto bad; }
@@ -336,11 +336,11 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       }
    }
    /* parameter bookkeeping (GetInitials): ntime, np */
-   p->ntime = p->fix_blength == 2 ? 0 : p->nbranch;
+   p->ntime = p->fix_blength == 2 ? 0 : p->fix_blength == 3 ? 1 : p->nbranch;      /* 3: the tree file's lengths times one free factor */
    if (p->clock) {
       /* global clock (SetBranch treesub.c:3793-3809, GetInitialsTimes 3814): a rooted binary tree, the parameters are the ages
        * of the ns - 1 internal nodes (in node order; this is the reference's layout once LASTROUND is set), tips at age 0 */
-      if (p->fix_blength == 2) { rc = pamlh_fail(p, "clock with fix_blength = 2"); goto bad; }
+      if (p->fix_blength >= 2) { rc = pamlh_fail(p, "clock with fix_blength = %d", p->fix_blength); goto bad; }
       if (p->sons_ptr[p->root + 1] - p->sons_ptr[p->root] != 2 || p->nnode != 2 * p->ns - 1) { rc = pamlh_fail(p, "clock = 1 needs a rooted binary tree"); goto bad; }
       if (p->seqtype == 1 && p->model) { rc = pamlh_fail(p, "model and clock do not work together"); goto bad; }
       p->ntime = p->ns - 1;
@@ -466,7 +466,8 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
 {
    int k = 0, i;
    if (cap < p->np) return -1;
-   if (p->clock) {         /* ages: 0.04 per level above the deepest tip */
+   if (p->fix_blength == 3) x[k++] = 1;
+   else if (p->clock) {         /* ages: 0.04 per level above the deepest tip */
       int node, changed = 1, *hgt = (int *)calloc(p->nnode, sizeof(int));
       while (changed)
          for (changed = 0, node = 0; node < p->nnode; node++)
@@ -774,8 +775,9 @@ int pamlh_x_to_branches(const pamlh *p, const double *x, double *branch)
    }
    for (i = 0; i < p->nbranch; i++) {
       const int node = p->branch_node[i];
-      branch[node] = p->ntime ? x[i] : p->tree_branch[node];
-      if (!p->ntime && p->tree_branch[node] < 0) return -1;
+      if (p->fix_blength == 3) branch[node] = p->tree_branch[node] * x[0];      /* proportional branch lengths (SetBranch treesub.c:3778) */
+      else branch[node] = p->ntime ? x[i] : p->tree_branch[node];
+      if ((!p->ntime || p->fix_blength == 3) && p->tree_branch[node] < 0) return -1;
    }
    return 0;
 }
@@ -1086,6 +1088,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
    int k = p->ntime, g, j;
    const int rep = (p->ngene > 1 && p->mgene >= 3) ? p->ngene : 1;
    if (i < 0 || i >= p->np) return -1;
+   if (i < p->ntime && p->fix_blength == 3) { snprintf(buf, cap, "branch-length scale"); return 0; }
    if (i < p->ntime && p->clock) { snprintf(buf, cap, "age of node %d", p->ns + i + 1); return 0; }
    if (i < p->ntime) { const int node = p->branch_node[i]; snprintf(buf, cap, "t %d..%d", p->father[node] + 1, node + 1); return 0; }
    if (i < k + p->ngene - 1) { snprintf(buf, cap, "rgene%d", i - k + 2); return 0; }

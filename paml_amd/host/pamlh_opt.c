@@ -172,7 +172,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
 {
    int k = 0, i, g;
    const int rep = (p->ngene > 1 && p->mgene >= 3) ? p->ngene : 1;
-   for (i = 0; i < p->ntime; i++) { lo[k] = p->clock ? 0 : 4e-6; hi[k++] = 50; }
+   for (i = 0; i < p->ntime; i++) { lo[k] = p->clock ? 0 : p->fix_blength == 3 ? 1e-4 : 4e-6; hi[k++] = 50; }
    for (i = 1; i < p->ngene; i++) { lo[k] = p->is_codeml ? 0.01 : 1e-4; hi[k++] = p->is_codeml ? 99 : 999; }      /* rgene (SetxBound) */
    for (g = 0; g < rep; g++)
    if (p->seqtype == 1) {

@@ -289,7 +289,7 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtyp
     the maximised value to ~1e-5."""
     ctl = dict(CODEML_BASE, outfile="mlc", **ctl_over) if prog == "codeml" else dict(BASEML_BASE, outfile="mlb", **ctl_over)
     res = run_ref(prog, ctl, files)
-    xs = re.search(r"lnL\(ntime:\s*(\d+)[^\n]*\n[^\n]*\n([^\n]+)\n", res["main"])
+    xs = re.search(r"lnL\(ntime:\s*(\d+)[^\n]*\n(?:[^\n]*\.\.[^\n]*\n)?([^\n]+)\n", res["main"])      # (no branch header line under fix_blength = 3)
     ntime = int(xs.group(1))
     x = [float(v) for v in xs.group(2).split()]
     print("   %s: reference MLE lnL %.6f, np %d" % (name, res["lnL"], len(x)))
@@ -436,6 +436,8 @@ CASES = {
     "brown_hky85_g4_rates": case_brown_rates,
     "brown_hky85_joint": case_brown_joint,
     "brown_hky85_nhomo1": lambda: case_mle("brown_hky85_nhomo1", dict(seqfile="brown.nuc", treefile="brown.trees", model=4, kappa=5, nhomo=1), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
+    "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
+                                    {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,
     "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),

@@ -23,7 +23,7 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("hiv_m10", "codeml", "hiv_ns10.ctl"), ("hiv_m11", "codeml", "hiv_ns11.ctl"), ("hiv_m12", "codeml", "hiv_ns12.ctl"),
          ("hiv_m13", "codeml", "hiv_ns13.ctl"), ("ecp_m2arel", "codeml", "ecp_m2arel.ctl"),
          ("brown_hky85_clock", "baseml", "brown_hky85_clock.ctl"),      # global clock: x holds the node ages
-         ("brown_f84", "baseml", "brown_f84.ctl"), ("brown_t92_g4", "baseml", "brown_t92_g4.ctl"), ("brown_unrest", "baseml", "brown_unrest.ctl"), ("brown_hky85_nhomo1", "baseml", "brown_hky85_nhomo1.ctl"), ("stewart_eqinput", "codeml", "stewart_eqinput.ctl"),
+         ("brown_f84", "baseml", "brown_f84.ctl"), ("brown_t92_g4", "baseml", "brown_t92_g4.ctl"), ("brown_unrest", "baseml", "brown_unrest.ctl"), ("brown_hky85_nhomo1", "baseml", "brown_hky85_nhomo1.ctl"), ("mhc_m0_prop", "codeml", "mhc_m0_prop.ctl"), ("stewart_eqinput", "codeml", "stewart_eqinput.ctl"),
          ("hiv_m0_f3x4mg", "codeml", "hiv_ns0_cf5.ctl"), ("hiv_m0_f1x4mg", "codeml", "hiv_ns0_cf4.ctl"),      # Muse-Gaut style rates
          # option G (several genes): rates only (Mgene 0), + frequencies (2), + kappa / omega (3), both (4); one with gamma
          ("horai_mg0", "baseml", "horai_mg0.ctl"), ("horai_mg2", "baseml", "horai_mg2.ctl"), ("horai_mg3", "baseml", "horai_mg3.ctl"),
