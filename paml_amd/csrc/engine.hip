@@ -369,16 +369,11 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       HIPCHK(hipEventCreateWithFlags(&e->ev_pmat, hipEventDisableTiming));
    }
    hipStream_t ps = e->stream;                    // stream of the uploads and of the P(t) kernel
-   if (want_pipe) {
-      // "everything the main stream held before this evaluation": what the NEXT pipelined evaluation's side stream will wait for
-      const int cur = e->entry_sel;
-      if (pipe) {
-         ps = e->s2;
-         if (e->have_prev_entry) HIPCHK(hipStreamWaitEvent(e->s2, e->ev_entry[cur ^ 1], 0));
-      }
-      HIPCHK(hipEventRecord(e->ev_entry[cur], e->stream));
-      e->entry_sel = cur ^ 1;
-      e->have_prev_entry = true;
+   if (pipe) {
+      // the side stream may overwrite the other P set once everything the main stream held in front of the PREVIOUS pruning
+      // kernel is done: that set's last reader (the kernel before it), and the previous evaluation's own uploads and P(t)
+      ps = e->s2;
+      if (e->have_prev_entry) HIPCHK(hipStreamWaitEvent(e->s2, e->ev_entry[e->entry_sel ^ 1], 0));
    }
    std::vector<EigenDev> tab;
    if (e->eigen_dirty) {
@@ -553,6 +548,11 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    if (pipe) {      // the pruning kernel (main stream) starts when this P(t) is there
       HIPCHK(hipEventRecord(e->ev_pmat, e->s2));
       HIPCHK(hipStreamWaitEvent(e->stream, e->ev_pmat, 0));
+   }
+   if (want_pipe) {      // "everything on the main stream in front of this pruning kernel": what the next pipelined evaluation waits for
+      HIPCHK(hipEventRecord(e->ev_entry[e->entry_sel], e->stream));
+      e->entry_sel ^= 1;
+      e->have_prev_entry = true;
    }
    e->n_pmat += (long)psets * (nn - 1);
 
