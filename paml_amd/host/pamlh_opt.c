@@ -477,6 +477,7 @@ int pamlh_standard_errors(pamlh *p, const double *x, int method, double *se, dou
    if (n == 0) goto done;
    if (pamlh_bounds(p, lo, hi)) { rc = pamlh_fail(p, "internal: bounds do not match np"); goto done; }
    for (i = 0; i < n; i++) se[i] = -1;
+   if (method == 0 && (!p->fix_rho || p->rho0 != 0)) method = 1;      /* lfunAdG has no per-pattern log f_h: the outer product of scores does not exist */
    if (method == 0) {
       int hp;
       xs = (double *)malloc((size_t)2 * n * n * sizeof(double));
