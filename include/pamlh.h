@@ -10,7 +10,7 @@
  * libpaml_amd.so through include/paml_amd.h.  Scope (this round): codeml seqtype 1 (icode 0 and 1; CodonFreq 0-5 (incl. F1x4MG / F3x4MG); NSsites
  * 0-13 and 22 with model 0; with '#' labels in the tree the branch model (model 2, NSsites 0), the branch-site models A and B
  * (model 2, NSsites 2 / 3) and the clade models C and D (model 3, NSsites 2 / 3)) and seqtype 2 (aa models 0,1,2,3), baseml models JC69,K80,F81,F84,HKY85,T92,TN93,REV,UNREST; +Gamma, auto-discrete-gamma (rho), nhomo 1 (base frequencies as parameters); several genes
- * (option G / GC of the sequence file) with Mgene 0,2,3,4 for baseml, codeml M0 and aaml;
+ * (option G / GC of the sequence file) with Mgene 0,1,2,3,4 for baseml, codeml M0 and aaml;
  * clock 0 and 1 (global clock: x holds the internal node ages); fix_blength 0, 2 (fixed) and 3 (proportional); cleandata 0/1; sequential and interleaved (I) PHYLIP, the P pattern format.  Anything else fails with a message
  * instead of guessing.
  */
@@ -61,6 +61,10 @@ const double *pamlh_adg_matrix(const pamlh *p);         /* [K][K] auto-discrete-
 /* option G (several genes): returns n_genes; gene_off[n_genes + 1] = first pattern of each gene (com.posG), gene_rate[n_genes]
  * = com.rgene after pamlh_set_x, n_pi = frequency vectors in pamlh_pi (1, or n_genes under Mgene 2 / 4), gene_eigen_of
  * [n_genes][K] = eigen system of (gene, class) (NULL with one gene).  Any output pointer may be NULL. */
+/* Mgene = 1 (separate analyses): gene g of the data set as an independent analysis (own patterns, frequencies, parameters); the
+ * caller frees it with pamlh_free. */
+int pamlh_gene_subset(const pamlh *p, int g, pamlh **out);
+int pamlh_mgene(const pamlh *p);                       /* the Mgene option in effect (0 with one gene) */
 int pamlh_genes(const pamlh *p, const int **gene_off, const double **gene_rate, int *n_pi, const int **gene_eigen_of);            /* [K][n_labels] time scale per (class, branch type); NULL = all 1 */
 /* eigen system i: kind (paml_amd.h), and pointers (NULL when not applicable) */
 int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const double **U, const double **V,

@@ -25,6 +25,29 @@ int main(int argc, char **argv)
       else if (!strcmp(argv[i], "--ancestral")) ancestral = 1;
       else x[nx++] = atof(argv[i]);
    }
+   if (pamlh_mgene(p) == 1) {      /* separate analyses: every gene on its own (start values: the control file's), lnL summed */
+      const int ng = pamlh_genes(p, NULL, NULL, NULL, NULL);
+      double sum = 0;
+      int g;
+      for (g = 0; g < ng; g++) {
+         pamlh *q;
+         int npg, n_eval = 0, lsg, npattg;
+         if (pamlh_gene_subset(p, g, &q)) { fprintf(stderr, "error: gene %d\n", g + 1); return 1; }
+         pamlh_dims(q, NULL, NULL, &npattg, NULL, NULL, NULL, NULL, &lsg, &npg, NULL);
+         pamlh_default_x(q, x, 4096);
+         if (optimize ? pamlh_optimize(q, x, &lnL, 500, 1e-10, 0, &n_eval) < 0 : (pamlh_set_x(q, x, npg) || pamlh_eval_gpu(q, &lnL, NULL))) {
+            fprintf(stderr, "error: %s\n", pamlh_error(q)); return 1;
+         }
+         printf("Gene %2d  ls:%5d  npatt:%4d  lnL = %.6f\nx:", g + 1, lsg, npattg, lnL);
+         for (i = 0; i < npg; i++) printf(" %.6f", x[i]);
+         printf("\n");
+         sum += lnL;
+         pamlh_free(q);
+      }
+      printf("Sum of lnL over the %d genes = %.6f\n", ng, sum);
+      pamlh_free(p);
+      return 0;
+   }
    if (!nx) nx = pamlh_read_inx(p, x, 4096);
    if (!nx) nx = pamlh_default_x(p, x, 4096);
    if (nx != np) { fprintf(stderr, "error: the model has %d parameters (ntime %d) but %d values were given\n", np, ntime, nx); return 1; }

@@ -263,7 +263,8 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    p->clock = (int)pamlh_optd(p, "clock", 0);
    if (p->clock != 0 && p->clock != 1) { rc = pamlh_fail(p, "clock = %d is not supported (0: no clock, 1: global clock)", p->clock); goto bad; }
    p->mgene = (int)pamlh_optd(p, "Mgene", 0);
-   if (p->mgene == 1) { rc = pamlh_fail(p, "Mgene = 1 (separate analyses) is not supported: run each gene on its own"); goto bad; }
+   /* Mgene = 1 (separate analyses, MultipleGenes baseml.c:392 / codeml.c:570): the data set itself is not evaluated; every gene
+    * is taken out as an analysis of its own with pamlh_gene_subset */
    if (p->mgene < 0 || p->mgene > 4) { rc = pamlh_fail(p, "Mgene = %d?", p->mgene); goto bad; }
    if ((int)pamlh_optd(p, "Malpha", 0) != 0) { rc = pamlh_fail(p, "Malpha (one alpha per gene) is not supported"); goto bad; }
    if (p->seqtype == 1) {
@@ -309,6 +310,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->fix_blength >= 2) { rc = pamlh_fail(p, "fix_blength = 2 or 3 does not work for partitioned data"); goto bad; }
       if (!p->fix_rho || p->rho0 != 0) { rc = pamlh_fail(p, "rho with several genes is not supported"); goto bad; }
       if (p->seqtype == 1 && (p->model || p->nssites)) { rc = pamlh_fail(p, "several genes: only the one-ratio codon model (model 0, NSsites 0)"); goto bad; }
+      if (p->mgene == 1) goto genes_ok;
       if (p->mgene >= 3 && (p->fix_kappa || (p->seqtype == 1 && p->fix_omega))) { rc = pamlh_fail(p, "Mgene = %d needs free kappa (and omega)", p->mgene); goto bad; }
       if (p->seqtype == 2 && p->mgene >= 3) { rc = pamlh_fail(p, "Mgene = %d has no meaning for the amino-acid models here", p->mgene); goto bad; }
       if (p->seqtype == 2 && p->mgene == 2 && p->aa_model != 3 && p->aa_model != 1) { rc = pamlh_fail(p, "Mgene = 2 needs frequencies from the data (amino-acid model 1 or 3)"); goto bad; }
@@ -319,6 +321,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
          rc = pamlh_fail(p, "this Mgene option has no meaning for the model"); goto bad;
       }
    }
+genes_ok:
    if (!(p->seqtype == 1 && p->model >= 2)) memset(p->label, 0, p->nnode * sizeof(int));      /* '#' labels only matter to branch models */
    if (p->seqtype == 1 && p->model >= 2) {
       int i;
@@ -785,6 +788,7 @@ int pamlh_x_to_branches(const pamlh *p, const double *x, double *branch)
 int pamlh_set_x(pamlh *p, const double *x, int np)
 {
    const int n = p->n;
+   if (p->ngene > 1 && p->mgene == 1) return pamlh_fail(p, "Mgene = 1: the genes are analysed separately (pamlh_gene_subset)");
    int k = 0, i, j;
    double *Q = (double *)malloc((size_t)n * n * sizeof(double));
    if (np != p->np) { free(Q); return pamlh_fail(p, "expected %d parameters, got %d", p->np, np); }
@@ -1003,6 +1007,57 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
    }
    free(Q);
    if (k != np) return pamlh_fail(p, "internal: consumed %d of %d parameters", k, np);
+   return 0;
+}
+
+int pamlh_mgene(const pamlh *p) { return p->ngene > 1 ? p->mgene : 0; }
+
+/* Mgene = 1: gene g of the data set as an analysis of its own — its patterns, weights and site map, frequencies counted from
+ * its sites, the same tree and options, one gene, its own parameter vector (MultipleGenes / GetSubSeqs in the reference).
+ * Free with pamlh_free. */
+int pamlh_gene_subset(const pamlh *p, int g, pamlh **out)
+{
+   pamlh *q;
+   int i, j, h0, h1, np1, nsite = 0;
+   *out = NULL;
+   if (g < 0 || g >= p->ngene) return -1;
+   h0 = p->posG[g]; h1 = p->posG[g + 1]; np1 = h1 - h0;
+   q = (pamlh *)malloc(sizeof(pamlh));
+   *q = *p;
+   q->eng = NULL; q->err[0] = 0; q->gene_eigen_of = NULL;
+   q->ngene = 1; q->mgene = 0; q->npatt = np1; q->posG[0] = 0; q->posG[1] = np1;
+   q->names = (char **)calloc(p->ns, sizeof(char *));
+   for (i = 0; i < p->ns; i++) { q->names[i] = (char *)malloc(strlen(p->names[i]) + 1); strcpy(q->names[i], p->names[i]); }
+   q->z = (unsigned char *)malloc((size_t)p->ns * np1);
+   q->raw = (char *)malloc((size_t)p->ns * np1 * p->n31);
+   for (i = 0; i < p->ns; i++) {
+      memcpy(q->z + (size_t)i * np1, p->z + (size_t)i * p->npatt + h0, np1);
+      memcpy(q->raw + (size_t)i * np1 * p->n31, p->raw + ((size_t)i * p->npatt + h0) * p->n31, (size_t)np1 * p->n31);
+   }
+   q->w = (double *)malloc(np1 * sizeof(double));
+   memcpy(q->w, p->w + h0, np1 * sizeof(double));
+   q->pose = (int *)malloc((p->n_pose + 1) * sizeof(int));
+   for (i = 0; i < p->n_pose; i++) if (p->pose[i] >= h0 && p->pose[i] < h1) q->pose[nsite++] = p->pose[i] - h0;
+   q->n_pose = nsite; q->ls = nsite; q->lgene[0] = nsite;
+   q->n_chara = (int *)malloc(p->n_codes * sizeof(int)); memcpy(q->n_chara, p->n_chara, p->n_codes * sizeof(int));
+   q->chara_map = (unsigned char *)malloc((size_t)p->n_codes * p->n); memcpy(q->chara_map, p->chara_map, (size_t)p->n_codes * p->n);
+#define DUP(field, count, type) do { q->field = (type *)malloc((size_t)(count) * sizeof(type)); memcpy(q->field, p->field, (size_t)(count) * sizeof(type)); } while (0)
+   DUP(sons_ptr, p->nnode + 1, int); DUP(sons, p->sons_ptr[p->nnode], int); DUP(label, p->nnode, int); DUP(branch_node, 2 * p->ns, int);
+   DUP(father, 2 * p->ns, int); DUP(tree_branch, 2 * p->ns, double);
+   if (p->scale) DUP(scale, p->nnode, unsigned char);
+#undef DUP
+   q->branch = (double *)calloc(p->nnode, sizeof(double));
+   q->pi = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
+   q->freqK = (double *)calloc(64, sizeof(double));
+   q->rate = (double *)calloc(64, sizeof(double));
+   q->eigen_of = (int *)calloc(64, sizeof(int));
+   for (i = 0; i < 64; i++) q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = NULL;
+   /* frequencies of this gene alone, then the one-gene parameter count */
+   if (q->seqtype == 1) freqs_codon(q); else freqs_base_aa(q);
+   if (q->seqtype == 0 && q->model == T92) { q->pi_data[0] = q->pi_data[2] = (q->pi_data[0] + q->pi_data[2]) / 2; q->pi_data[1] = q->pi_data[3] = (q->pi_data[1] + q->pi_data[3]) / 2; }
+   q->np = p->np - (p->ngene - 1);      /* no rgene */
+   j = 0; (void)j;
+   *out = q;
    return 0;
 }
 

@@ -77,6 +77,23 @@ class Analysis:
         (self.n, self.n_tips, self.n_patt, self.n_nodes, self.root, self.n_codes, self.cleandata, self.ls, self.np,
          self.ntime) = [v.value for v in d]
 
+    def gene_subset(self, g):
+        """Mgene = 1: gene g as an analysis of its own (pamlh_gene_subset)."""
+        h = C.c_void_p()
+        self._L.pamlh_gene_subset.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        if self._L.pamlh_gene_subset(self._h, int(g), C.byref(h)) != 0:
+            raise RuntimeError("pamlh_gene_subset failed")
+        a = Analysis.__new__(Analysis)
+        a._h, a._L = h, self._L
+        d = [C.c_int() for _ in range(10)]
+        self._L.pamlh_dims(h, *[C.byref(v) for v in d])
+        (a.n, a.n_tips, a.n_patt, a.n_nodes, a.root, a.n_codes, a.cleandata, a.ls, a.np, a.ntime) = [v.value for v in d]
+        return a
+
+    def n_genes(self):
+        self._L.pamlh_genes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        return self._L.pamlh_genes(self._h, None, None, None, None)
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.pamlh_free(self._h)

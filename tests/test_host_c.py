@@ -3,6 +3,7 @@ PHYLIP sequences, Newick tree, dat/lg.dat — and must reproduce the reference's
 lnf (same pattern order as the reference's `lnf` file).  CPU: C host + oracle.  GPU: C host + engine, and the
 pamlh_lnl driver end to end."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -52,6 +53,29 @@ def test_c_host_reproduces_reference_on_cpu(gname, prog, ctl):
         assert sorted(np.nonzero(pb.scale_node)[0] + 1) == sorted(g["scale_nodes"])   # SetNodeScale picks the same nodes
     if g.get("published_lnL") is not None:
         assert abs(r["lnL"] - g["published_lnL"]) < 5e-6
+
+
+HORAI_SEPARATE = [(1367, 91, -3355.227556, "0.029574 0.015898 0.019903 0.007940 0.007923 0.006142 0.027475 0.070614 0.052709 11.268489"),
+                  (1367, 53, -2459.021781, "0.010783 0.003663 0.007261 0.003622 0.001699 0.003451 0.008605 0.030564 0.022597 9.272028"),
+                  (1367, 203, -5637.976052, "0.151172 0.089850 0.194491 0.092983 0.065257 0.039448 0.206379 0.467630 0.746578 29.275418"),
+                  (759, 62, -1794.493564, "0.015755 0.008194 0.023548 0.007091 0.008929 0.007257 0.032252 0.061925 0.073694 27.574639")]
+
+
+def test_c_host_separate_gene_analyses_on_cpu(tmp_path):
+    """Mgene = 1 on examples/horai.nuc (HKY85): every gene as an analysis of its own — its sites, patterns, frequencies and ten
+    parameters.  The reference's per-gene output (ls, npatt, lnL, estimates) is reproduced by one evaluation at its estimates."""
+    ctl = tmp_path / "horai_mg1.ctl"
+    ctl.write_text(open(os.path.join(CTL, "horai_mg0.ctl")).read().replace("../data/", os.path.join(helpers.GOLDEN, "data") + "/").replace("Mgene = 0", "Mgene = 1"))
+    a = hostlib.Analysis(str(ctl), "baseml")
+    assert a.n_genes() == 4
+    with pytest.raises(RuntimeError, match="separately"):
+        a.set_x(np.ones(a.np))
+    for g, (ls, npatt, lnl, xs) in enumerate(HORAI_SEPARATE):
+        b = a.gene_subset(g)
+        assert (b.ls, b.n_patt, b.np, b.ntime) == (ls, npatt, 10, 9)
+        x = np.array([float(v) for v in xs.split()])
+        assert abs(oracle.evaluate(b.problem(x), want_lnf=False)["lnL"] - lnl) < 5e-5
+        b.close()
 
 
 def test_c_host_auto_discrete_gamma_on_cpu():
@@ -344,6 +368,20 @@ def test_c_host_joint_reconstruction_matches_the_reference_rst():
         swaps += mine != row["best"]
         assert mine == row["best"] or row["prob"] < 0.51
     assert swaps <= 1
+
+
+@pytest.mark.gpu
+def test_driver_separate_gene_analyses(tmp_path):
+    """pamlh_lnl with Mgene = 1 and --optimize: four independent searches on horai.nuc end at the reference's per-gene maxima."""
+    ctl = tmp_path / "horai_mg1.ctl"
+    ctl.write_text(open(os.path.join(CTL, "horai_mg0.ctl")).read().replace("../data/", os.path.join(helpers.GOLDEN, "data") + "/").replace("Mgene = 0", "Mgene = 1"))
+    out = subprocess.run([hostlib.DRIVER_PATH, "baseml", str(ctl), "--optimize"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    got = [float(v) for v in re.findall(r"npatt:\s*\d+\s+lnL = (-[0-9.]+)", out.stdout)]
+    assert len(got) == 4
+    for v, (_, _, lnl, _) in zip(got, HORAI_SEPARATE):
+        assert abs(v - lnl) < 5e-5, (v, lnl)
+    assert abs(float(re.search(r"Sum of lnL over the 4 genes = (-[0-9.]+)", out.stdout).group(1)) - sum(r[2] for r in HORAI_SEPARATE)) < 2e-4
 
 
 @pytest.mark.gpu
