@@ -339,49 +339,58 @@ static void gauss_legendre_half(int n, double *x, double *w)
    }
 }
 
-/* L(h, k, r) = Pr(X > h, Y > k) for a standard bivariate normal with correlation r (Genz 2004, equations 3 and 6) */
-double pamlh_lbinormal(double h0, double k0, double r)
+/* Bivariate normal upper-tail probability L(lo, up, r) = Pr(X > lo, Y > up), lo <= up, after Genz (2004).
+ * Moderate correlation: the single-integral form over the arcsine of the correlation (his equation 3).  High correlation
+ * (|r| >= 0.925): the expansion around |r| = 1 — an analytic part plus a Gauss-Legendre integral of the remainder (equation 6). */
+static double bvn_tail_moderate(double lo, double up, double r, int n, const double *node, const double *wt)
 {
-   const int n = fabs(r) < 0.3 ? 16 : 32;
-   double x[16], w[16], L = 0;
-   const double h = h0 < k0 ? h0 : k0, k = h0 < k0 ? k0 : h0;
-   int i, j;
-   gauss_legendre_half(n, x, w);
-   if (fabs(r) < 0.925) {
-      if (fabs(r) > 1e-10) {
-         const double hk2 = (h * h + k * k) / 2, a = asin(r) / 2;
-         for (i = 0; i < n / 2; i++)
-            for (j = 0; j < 2; j++) {
-               const double sn = sin(a * (j ? 1 + x[i] : 1 - x[i]));
-               L += w[i] * exp((sn * h * k - hk2) / (1 - sn * sn));
-            }
-         L *= a / (2 * M_PI);
-      }
-      L += pamlh_cdf_normal(-h) * pamlh_cdf_normal(-k);
+   double acc = 0;
+   if (fabs(r) > 1e-10) {
+      const double half_asin = asin(r) / 2, q = (lo * lo + up * up) / 2;
+      int i, side;
+      for (i = 0; i < n / 2; i++)
+         for (side = -1; side <= 1; side += 2) {
+            const double sn = sin(half_asin * (1 + side * node[i]));
+            acc += wt[i] * exp((sn * lo * up - q) / (1 - sn * sn));
+         }
+      acc *= half_asin / (2 * M_PI);
    }
-   else {
-      const double sk = r >= 0 ? k : -k, shk = r >= 0 ? h * k : -h * k;
-      if (fabs(r) < 1) {
-         const double as = 1 - r * r, b = fabs(h - sk), bs = b * b, c = (4 - shk) / 8, d = (12 - shk) / 16;
-         double a = sqrt(as), y = -(bs / as + shk) / 2;
-         if (y > -500) L = a * exp(y) * (1 - c * (bs - as) * (1 - d * bs / 5) / 3 + c * d * as * as / 5);
-         if (shk > -500) L -= exp(-shk / 2) * sqrt(2 * M_PI) * pamlh_cdf_normal(-b / a) * b * (1 - c * bs * (1 - d * bs / 5) / 3);
-         a /= 2;
-         for (i = 0; i < n / 2; i++)
-            for (j = 0; j < 2; j++) {
-               const double u = a * (j ? 1 + x[i] : 1 - x[i]), t = u * u, rs = sqrt(1 - t);
-               y = -(bs / t + shk) / 2;
-               if (y > -500) L += a * w[i] * exp(y) * (exp(-shk * (1 - rs) / (2 * (1 + rs))) / rs - (1 + c * t * (1 + d * t)));
-            }
-         L /= -2 * M_PI;
-      }
-      if (r > 0) L += pamlh_cdf_normal(-(h > k ? h : k));
-      else if (r < 0) {
-         L = -L;
-         if (h + k < 0) L += pamlh_cdf_normal(-h) - pamlh_cdf_normal(k);
-      }
+   return acc + pamlh_cdf_normal(-lo) * pamlh_cdf_normal(-up);
+}
+
+static double bvn_tail_high(double lo, double up, double r, int n, const double *node, const double *wt)
+{
+   const double up_s = r >= 0 ? up : -up, prod = r >= 0 ? lo * up : -lo * up;      /* reflected for negative correlation */
+   double tail = 0;
+   if (fabs(r) < 1) {
+      const double one_m_r2 = 1 - r * r, root = sqrt(one_m_r2), gap = fabs(lo - up_s), gap2 = gap * gap;
+      const double c1 = (4 - prod) / 8, c2 = (12 - prod) / 16;
+      double ex = -(gap2 / one_m_r2 + prod) / 2;
+      int i, side;
+      if (ex > -500) tail = root * exp(ex) * (1 - c1 * (gap2 - one_m_r2) * (1 - c2 * gap2 / 5) / 3 + c1 * c2 * one_m_r2 * one_m_r2 / 5);
+      if (prod > -500) tail -= exp(-prod / 2) * sqrt(2 * M_PI) * pamlh_cdf_normal(-gap / root) * gap * (1 - c1 * gap2 * (1 - c2 * gap2 / 5) / 3);
+      for (i = 0; i < n / 2; i++)
+         for (side = -1; side <= 1; side += 2) {
+            const double u = root / 2 * (1 + side * node[i]), u2 = u * u, rs = sqrt(1 - u2);
+            ex = -(gap2 / u2 + prod) / 2;
+            if (ex > -500) tail += root / 2 * wt[i] * exp(ex) * (exp(-prod * (1 - rs) / (2 * (1 + rs))) / rs - (1 + c1 * u2 * (1 + c2 * u2)));
+         }
+      tail /= -2 * M_PI;
    }
-   return L < 0 ? 0 : L;
+   if (r > 0) return tail + pamlh_cdf_normal(-(lo > up ? lo : up));
+   tail = -tail;
+   if (r < 0 && lo + up < 0) tail += pamlh_cdf_normal(-lo) - pamlh_cdf_normal(up);
+   return tail;
+}
+
+double pamlh_lbinormal(double h, double k, double r)
+{
+   const int n = fabs(r) < 0.3 ? 16 : 32;      /* the rule sizes the reference uses */
+   const double lo = h < k ? h : k, up = h < k ? k : h;
+   double node[16], wt[16], v;
+   gauss_legendre_half(n, node, wt);
+   v = fabs(r) < 0.925 ? bvn_tail_moderate(lo, up, r, n, node, wt) : bvn_tail_high(lo, up, r, n, node, wt);
+   return v < 0 ? 0 : v;
 }
 
 void pamlh_autod_gamma(double *M, double *freqK, double *rK, double alpha, double rho, int K)
