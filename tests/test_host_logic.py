@@ -383,3 +383,26 @@ def test_product_paths_fail_loudly_without_a_gpu(lib_path):
     assert a.plfun(a.default_x()) == 1e300
     r = subprocess.run([hostlib.DRIVER_PATH, "codeml", os.path.join(helpers.GOLDEN, "ctl", "hiv_ns0.ctl")], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "no GPU" in r.stderr
+
+
+def test_plfun_seam_example_compiles_and_links(tmp_path):
+    """paml_amd/host/examples/plfun_seam.c — the assignment to com.plfun a maintainer would make — builds against include/pamlh.h and
+    the shared libraries; without a GPU its one call of the objective function reports the missing device."""
+    import subprocess
+    from paml_amd import hostlib
+    lib = os.path.dirname(hostlib.LIB_PATH)
+    exe = str(tmp_path / "plfun_seam")
+    src = os.path.join(os.path.dirname(lib), "host", "examples", "plfun_seam.c")
+    r = subprocess.run(["cc", "-O2", "-Wall", "-I" + os.path.join(helpers.REPO, "include"), src, "-L" + lib, "-lpamlh", "-lpaml_amd", "-lm",
+                        "-Wl,-rpath," + lib, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([exe, "codeml", os.path.join(helpers.GOLDEN, "ctl", "hiv_ns0.ctl")], capture_output=True, text=True, timeout=120)
+    try:
+        import torch
+        gpu = torch.cuda.is_available()
+    except ImportError:
+        gpu = False
+    if gpu:
+        assert run.returncode == 0 and "-lnL =" in run.stdout
+    else:
+        assert run.returncode == 1 and "no GPU" in run.stderr
