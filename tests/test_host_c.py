@@ -609,3 +609,32 @@ def test_host_bivariate_normal_and_autod_gamma_numerics():
         assert np.allclose(f, 1.0 / K) and abs(np.dot(f, rk) - 1) < 1e-9
         if rho > 0.9:
             assert np.all(np.diag(M) > 0.75)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ctl,prog,seed", [("hiv_ns2.ctl", "codeml", 1), ("hiv_ns8.ctl", "codeml", 2), ("lyso_bsa.ctl", "codeml", 3),
+                                           ("horai_mg4.ctl", "baseml", 4), ("brown_hky85_g4.ctl", "baseml", 5)])
+def test_differential_against_the_reference_binary_at_random_parameters(ctl, prog, seed, tmp_path):
+    """Beyond the committed vectors: the unmodified reference binary (oracle/_ref, when it travelled with the repository) and the
+    engine evaluate the same control file at a RANDOM parameter vector inside the bounds; lnL must agree to the printed digits."""
+    import shutil
+    exe = os.path.join(helpers.REPO, "oracle", "_ref", prog)
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/%s is not here (it is built from /root/reference in the build container)" % prog)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), prog)
+    lo, hi = a.bounds()
+    rng = np.random.default_rng(seed)
+    x = a.default_x() * np.where(hi <= 1, rng.uniform(0.7, 1.0, a.np), rng.uniform(0.7, 1.4, a.np))     # (proportions only shrink: they stay feasible)
+    x = np.round(np.clip(x, lo * 1.5, np.minimum(hi * 0.9, 50)), 6)           # in.codeml carries six decimals
+    text = open(os.path.join(CTL, ctl)).read()
+    for name in re.findall(r"\\.\\./data/(\\S+)", text):
+        shutil.copy(os.path.join(helpers.GOLDEN, "data", name), tmp_path / name)
+    main = "mlc" if prog == "codeml" else "mlb"
+    (tmp_path / (prog + ".ctl")).write_text(text.replace("../data/", "") + "\\noutfile = %s\\nnoisy = 0\\nverbose = 0\\nrunmode = 0\\ngetSE = 0\\nRateAncestor = 0\\n" % main)
+    (tmp_path / ("in." + prog)).write_text("-1 " + " ".join("%.6f" % v for v in x) + "\\n")
+    r = subprocess.run([exe, prog + ".ctl"], cwd=tmp_path, capture_output=True, text=True, input="\\n" * 50, timeout=600)
+    m = re.findall(r"lnL\\(ntime:[^\\n]*?(-[0-9]+\\.[0-9]+)", open(tmp_path / main).read())
+    assert m, r.stdout[-2000:]
+    ref = float(m[-1])
+    got, _ = a.eval_gpu(x, want_lnf=False)
+    assert abs(got - ref) <= 2e-6 * max(1.0, abs(ref) / 1000), (got, ref)
