@@ -627,13 +627,13 @@ def test_differential_against_the_reference_binary_at_random_parameters(ctl, pro
     x = a.default_x() * np.where(hi <= 1, rng.uniform(0.7, 1.0, a.np), rng.uniform(0.7, 1.4, a.np))     # (proportions only shrink: they stay feasible)
     x = np.round(np.clip(x, lo * 1.5, np.minimum(hi * 0.9, 50)), 6)           # in.codeml carries six decimals
     text = open(os.path.join(CTL, ctl)).read()
-    for name in re.findall(r"\\.\\./data/(\\S+)", text):
+    for name in re.findall(r"\.\./data/(\S+)", text):
         shutil.copy(os.path.join(helpers.GOLDEN, "data", name), tmp_path / name)
     main = "mlc" if prog == "codeml" else "mlb"
-    (tmp_path / (prog + ".ctl")).write_text(text.replace("../data/", "") + "\\noutfile = %s\\nnoisy = 0\\nverbose = 0\\nrunmode = 0\\ngetSE = 0\\nRateAncestor = 0\\n" % main)
-    (tmp_path / ("in." + prog)).write_text("-1 " + " ".join("%.6f" % v for v in x) + "\\n")
-    r = subprocess.run([exe, prog + ".ctl"], cwd=tmp_path, capture_output=True, text=True, input="\\n" * 50, timeout=600)
-    m = re.findall(r"lnL\\(ntime:[^\\n]*?(-[0-9]+\\.[0-9]+)", open(tmp_path / main).read())
+    (tmp_path / (prog + ".ctl")).write_text(text.replace("../data/", "") + "\noutfile = %s\nnoisy = 0\nverbose = 0\nrunmode = 0\ngetSE = 0\nRateAncestor = 0\n" % main)
+    (tmp_path / ("in." + prog)).write_text("-1 " + " ".join("%.6f" % v for v in x) + "\n")
+    r = subprocess.run([exe, prog + ".ctl"], cwd=tmp_path, capture_output=True, text=True, input="\n" * 50, timeout=600)
+    m = re.findall(r"lnL\(ntime:[^\n]*?(-[0-9]+\.[0-9]+)", open(tmp_path / main).read())
     assert m, r.stdout[-2000:]
     ref = float(m[-1])
     got, _ = a.eval_gpu(x, want_lnf=False)
