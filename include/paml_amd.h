@@ -12,8 +12,11 @@
  * zerror() tools.c:1204); paml_amd_last_error() gives the message.
  *
  * Threading: one engine = one GPU + one HIP stream; calls on one engine must be serialised by the
- * caller, different engines are independent.  Multi-GPU = one engine per rank over a contiguous
- * pattern shard, the caller sums lnL (RCCL all-reduce).
+ * caller, different engines (also on different devices and host threads) are independent.
+ * Multi-GPU = one process and one engine per GPU over a contiguous pattern shard; after
+ * paml_amd_comm_init every evaluation entry point returns the TOTAL over all ranks (the one
+ * exchange step, an RCCL all-reduce over xGMI, runs inside the call on the engine's stream) — as the
+ * reference's one com.plfun call returns the lnL of the whole alignment (codeml.c:748).
  */
 #ifndef PAML_AMD_H
 #define PAML_AMD_H
@@ -56,6 +59,28 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
                     unsigned flags);
 void paml_amd_destroy(paml_amd_engine *e);
 const char *paml_amd_last_error(const paml_amd_engine *e);
+
+/* ---- Pattern shards over several GPUs (site patterns are independent given the tree, P(t), pi and the class
+ * table; the reference has no counterpart — its lfun loops over all of com.npatt on one core, treesub.c:7764-7800).
+ *
+ * paml_amd_shard_bounds (host only, no GPU): the contiguous block [*first, *first + *count) of n_patt_global patterns that
+ *   rank `rank` of `world` owns.  Blocks are cut at multiples of the reduction chunk (a function of n_patt_global alone,
+ *   >= 256 patterns), so the partial sums of every rank are entries of ONE global array.
+ * paml_amd_comm_unique_id: rank 0 obtains the 128-byte RCCL id (ncclGetUniqueId) and hands it to the other ranks by any
+ *   means (a pipe, a file, MPI, torch.distributed's store).
+ * paml_amd_comm_init: collective over the ranks (ncclCommInitRank).  The engine was created for its shard's n_patt and holds
+ *   patterns [first_pattern, first_pattern + n_patt) of n_patt_global.  From then on eval / eval_device / eval_batch /
+ *   eval_dirty / eval_branch return totals over all ranks, identical bits on every rank; the lnL of eval* is moreover
+ *   independent of `world` (the ranks' zero-padded partial-sum arrays are added — exact — and summed in one fixed order).
+ *   lnf / fhK / partials / posteriors stay per-shard.  world = 1 with a non-NULL id makes a one-rank communicator (the
+ *   collective path on a single GPU); world = 1 with id = NULL only sets the global chunking.  eval_adg does not shard.
+ * The RCCL library (librccl.so.1) is bound at run time on first use; PAML_AMD_EUNSUPPORTED when it is not installed. */
+#define PAML_AMD_COMM_ID_BYTES 128
+int paml_amd_shard_bounds(long n_patt_global, int world, int rank, long *first, long *count);
+int paml_amd_comm_unique_id(void *id128);
+int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id128, long n_patt_global, long first_pattern);
+int paml_amd_comm_destroy(paml_amd_engine *e);
+int paml_amd_comm_info(const paml_amd_engine *e, int *rank, int *world, long *n_patt_global, long *first_pattern, int *chunk);
 
 /* Launch all work on this hipStream_t (default: the null stream). */
 int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream);
@@ -103,9 +128,9 @@ int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freq
 int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, double *lnL, double *lnf,
                   double *fhK);
 
-/* Same evaluation without the final device->host copy or synchronisation: the rank's partial lnL is
- * left in d_lnL (a device pointer, e.g. a torch tensor) on the engine's stream so the caller can
- * all-reduce it over RCCL. */
+/* Same evaluation without the final device->host copy or synchronisation: lnL (the total over the
+ * ranks when the engine has a communicator) is left in d_lnL (a device pointer, e.g. a torch tensor)
+ * on the engine's stream. */
 int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL);
 
 /* Re-evaluate after a change that leaves the partials of the nodes with clean[node] != 0 valid
@@ -176,6 +201,10 @@ int paml_amd_node_posterior(paml_amd_engine *e, int node, const double *branch, 
 int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double *P);
 int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP);
 int paml_amd_get_scale(paml_amd_engine *e, int node, int iclass, double *scale);
+/* The partial sums sum_h w_h log f_h of the last evaluation, one per reduction chunk of the GLOBAL pattern range (zero for
+ * chunks other ranks own when there is no communicator; the all-reduced array when there is one): the quantities of lfun's
+ * accumulation loop (treesub.c:7796-7800) before the final total.  Returns the number of chunks. */
+int paml_amd_get_partial_sums(paml_amd_engine *e, double *out, int cap);
 
 /* Per-kernel timing with HIP events on the engine's stream (bench.py roofline leg).
  * profile(1) starts recording an event pair around every kernel launch; profile_read sums the

@@ -13,6 +13,9 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed by paml_amd_comm_* (see Rccl below)
+
 #include "../../include/paml_amd.h"
 #include "jit.h"
 #include "kernels.h"
@@ -96,6 +99,66 @@ struct EigenHost {
    DevBuf<double> U, V, Root, Cijk;
 };
 
+// RCCL, bound at run time: libpaml_amd.so keeps loading on hosts without the collective library (single-GPU use needs none
+// of it), and a process that already holds a copy of librccl.so.1 (PyTorch ships one) shares that copy — dlopen matches by
+// soname — instead of getting a second one.
+struct Rccl {
+   void *h = nullptr;
+   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+   decltype(&ncclCommInitRank) CommInitRank = nullptr;
+   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+   decltype(&ncclAllReduce) AllReduce = nullptr;
+   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+   std::string err;
+   bool load()
+   {
+      if (h) return true;
+      const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+      for (const char *nm : names)
+         if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+      if (!h) { err = std::string("dlopen librccl.so.1: ") + dlerror(); return false; }
+      GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+      CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+      CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+      AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+      GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+      if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
+         err = "librccl.so.1 lacks an expected symbol";
+         h = nullptr;
+         return false;
+      }
+      return true;
+   }
+};
+Rccl &rccl()
+{
+   static Rccl r;      // (process-wide on purpose: one binding of the library, no engine state)
+   return r;
+}
+
+// Patterns per partial sum of the lnL reduction.  A function of the GLOBAL pattern count only: with shards cut at multiples
+// of it, every rank's partial sums are entries of one global array whose fixed-order total does not depend on the number
+// of ranks (paml_amd_comm_init).  At most ~1024 partials.
+inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global + 1023) / 1024 + 255) / 256 * 256); }
+
+// Environment switches, read once when the engine is created.
+struct EnvCfg {
+   bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false;
+   std::string jit_dump, prof_ops;
+   int prof_tid = 0;
+   void read()
+   {
+      no_pipeline = getenv("PAML_AMD_NO_PIPELINE") != nullptr;
+      force_gather = getenv("PAML_AMD_FORCE_GATHER") != nullptr;
+      jit_sync = getenv("PAML_AMD_JIT_SYNC") != nullptr;
+      jit_strict = getenv("PAML_AMD_JIT_STRICT") != nullptr;
+      valu20 = getenv("PAML_AMD_VALU20") != nullptr;
+      if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
+      if (const char *v = getenv("PAML_AMD_PROF_OPS")) prof_ops = v;
+      if (const char *v = getenv("PAML_AMD_PROF_TID")) prof_tid = atoi(v);
+   }
+};
+
 }  // namespace
 
 struct paml_amd_engine {
@@ -107,6 +170,19 @@ struct paml_amd_engine {
    int tile_patt = 64;
    hipStream_t stream = nullptr;
    std::string err;
+   EnvCfg env;
+   int device = 0, n_cu = 0;          // the device the engine was created on, its CU count (persistent grids)
+   bool stream_attr_set = false;      // > 64 KB dynamic LDS of prune_mfma64_stream requested on this device
+   unsigned long long *d_prof = nullptr;   // PAML_AMD_PROF_OPS stamps
+
+   // pattern shards over several GPUs (paml_amd_comm_init): this engine holds patterns [first_patt, first_patt + n_patt) of
+   // n_patt_global; the reduction's partial sums live at their global positions and are summed over the ranks
+   ncclComm_t comm = nullptr;
+   int rank = 0, world = 1;
+   long n_patt_global = 0, first_patt = 0;
+   int chunk = 256, nb_global = 1, first_chunk = 0;
+   DevBuf<double> d_partial_tot, d_btot;
+   bool pmat_valid = false;           // d_rowmajor holds the P(t) of an evaluation in the tree's own orientation
 
    // data
    bool have_tips = false, have_tree = false, have_pi = false, have_classes = false;
@@ -179,6 +255,8 @@ struct paml_amd_engine {
    {
       for (auto &e : eigen) { e.U.release(); e.V.release(); e.Root.release(); e.Cijk.release(); }
       stage.release();
+      if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
+      if (d_prof) (void)hipFree(d_prof);
       if (jit.mod) (void)hipModuleUnload(jit.mod);
       for (auto ev : ev_pool) (void)hipEventDestroy(ev);
       for (auto ev : ev_used) (void)hipEventDestroy(ev);
@@ -195,7 +273,7 @@ struct paml_amd_engine {
       d_eigen.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_rowmajor, &d2_pint, &d2_ptip, &d2_pcol, &d2_branch, &d2_gene_rate,
+                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_rowmajor, &d2_pint, &d2_ptip, &d2_pcol, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot,
                               &d_expA, &d_expB, &d_expSA, &d_expSB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
    }
@@ -310,8 +388,8 @@ int ensure_jit(paml_amd_engine *e, const std::string &key, GEN gen, bool *ok)
    e->jit = JitKernel();
    std::string log;
    const std::string src = gen();
-   if (getenv("PAML_AMD_JIT_DUMP")) {
-      FILE *f = fopen(getenv("PAML_AMD_JIT_DUMP"), "w");
+   if (!e->env.jit_dump.empty()) {
+      FILE *f = fopen(e->env.jit_dump.c_str(), "w");
       if (f) { fputs(src.c_str(), f); fclose(f); }
    }
    if (jit_compile(src, &e->jit, &log) == 0) {
@@ -320,7 +398,7 @@ int ensure_jit(paml_amd_engine *e, const std::string &key, GEN gen, bool *ok)
    }
    else {
       e->err = "jit: " + log;
-      if (getenv("PAML_AMD_JIT_STRICT")) return fail(e, PAML_AMD_EHIP, e->err);
+      if (e->env.jit_strict) return fail(e, PAML_AMD_EHIP, e->err);
    }
    return 0;
 }
@@ -361,7 +439,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
    }
    // the fast path of consecutive eval_device calls (see pipe_ok): nothing but branch lengths / gene rates may have changed
-   const bool pipe = want_pipe && e->pipe_ok && !bs && !clean && !keep && !new_prog && !e->eigen_dirty && !getenv("PAML_AMD_NO_PIPELINE");
+   const bool pipe = want_pipe && e->pipe_ok && !bs && !clean && !keep && !new_prog && !e->eigen_dirty && !e->env.no_pipeline;
    if (want_pipe && !e->s2) {
       HIPCHK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&e->ev_entry[0], hipEventDisableTiming));
@@ -454,13 +532,13 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    //   stream — the interpreter over the same operand stream (lean programs only), 128 patterns per workgroup
    //   gather — the full interpreter (keep-partials STORE/LOAD, deep stacks, > MFMA_ZT tips, > 64 codes), 64 per workgroup
    if (e->kk == KK_MFMA64) {
-      bool lean = e->prog.max_stack <= MFMA_RS && e->n_tips <= MFMA_ZT && e->n_codes <= 64 && !getenv("PAML_AMD_FORCE_GATHER");
+      bool lean = e->prog.max_stack <= MFMA_RS && e->n_tips <= MFMA_ZT && e->n_codes <= 64 && !e->env.force_gather;
       for (const Op &o : e->prog.ops)
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
       bool jit_ok = false;
-      if (e->jit_enabled && !getenv("PAML_AMD_FORCE_GATHER") && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi)) {
+      if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi)) {
          const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips);
-         const bool background = e->prog.ops.size() > 120 &&      /* (roughly: more than 60 taxa, more than 3 s of compilation) */ !e->jit_forced && !getenv("PAML_AMD_JIT_SYNC") && !(e->jit.fn && e->jit.key == key);
+         const bool background = e->prog.ops.size() > 120 &&      /* (roughly: more than 60 taxa, more than 3 s of compilation) */ !e->jit_forced && !e->env.jit_sync && !(e->jit.fn && e->jit.key == key);
          if (!background) {
             int r = ensure_jit(e, key, [&]() { return jit_generate(e->prog, e->n_tips, n, e->n_codes); }, &jit_ok);
             if (r) return r;
@@ -570,36 +648,29 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
    pr.first_tip = e->prog.first_tip;
    pr.stream = e->d_stream.p; pr.n_stream = (int)(e->prog.stream.size() / 2); pr.tip_words = (long)tip_words(e);
-   static unsigned long long *d_prof = nullptr;
    const int prof_stride = (int)e->prog.ops.size() + 3;
-   if (getenv("PAML_AMD_PROF_OPS")) {
-      if (d_prof) (void)hipFree(d_prof);
-      HIPCHK(hipMalloc((void **)&d_prof, (size_t)3 * n_blocks * prof_stride * 8));
-      HIPCHK(hipMemsetAsync(d_prof, 0, (size_t)3 * n_blocks * prof_stride * 8, e->stream));
-      pr.prof = d_prof;
+   if (!e->env.prof_ops.empty()) {
+      if (e->d_prof) (void)hipFree(e->d_prof);
+      e->d_prof = nullptr;
+      HIPCHK(hipMalloc((void **)&e->d_prof, (size_t)3 * n_blocks * prof_stride * 8));
+      HIPCHK(hipMemsetAsync(e->d_prof, 0, (size_t)3 * n_blocks * prof_stride * 8, e->stream));
+      pr.prof = e->d_prof;
       pr.prof_stride = prof_stride;
-      pr.prof_tid = getenv("PAML_AMD_PROF_TID") ? atoi(getenv("PAML_AMD_PROF_TID")) : 0;
+      pr.prof_tid = e->env.prof_tid;
    }
    mark(e);
    switch (e->kk) {
    case KK_MFMA64:
       if (e->use_jit) {
          void *params[] = {&pr};
-         static int n_cu = 0;
-         if (!n_cu) {
-            int dev = 0;
-            HIPCHK(hipGetDevice(&dev));
-            HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-         }
-         const int grid = std::min(n_blocks, n_cu);     // persistent: one 130 KB-LDS workgroup per CU walks the tiles
+         const int grid = std::min(n_blocks, e->n_cu);     // persistent: one 130 KB-LDS workgroup per CU walks the tiles
          HIPCHK(hipModuleLaunchKernel(e->jit.fn, grid, 1, 1, 512, 1, 1, 0, e->stream, params, nullptr));
       }
       else if (use_dma) {
          const size_t lds = (size_t)4 * 4096 * sizeof(double) + (size_t)e->n_tips * 128;
-         static bool attr_set = false;
-         if (!attr_set) {
+         if (!e->stream_attr_set) {
             HIPCHK(hipFuncSetAttribute((const void *)prune_mfma64_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            e->stream_attr_set = true;
          }
          hipLaunchKernelGGL(prune_mfma64_stream, dim3(n_blocks), dim3(512), lds, e->stream, pr);
       }
@@ -620,9 +691,9 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    mark(e);
    if (pr.prof) {
       std::vector<unsigned long long> hp((size_t)3 * n_blocks * prof_stride);
-      HIPCHK(hipMemcpyAsync(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(hp.data(), e->d_prof, hp.size() * 8, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
-      FILE *f = fopen(getenv("PAML_AMD_PROF_OPS"), "wb");
+      FILE *f = fopen(e->env.prof_ops.c_str(), "wb");
       if (f) {
          int hdr[2] = {n_blocks, prof_stride};
          fwrite(hdr, sizeof(int), 2, f);
@@ -634,10 +705,15 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
    }
 
-   // Kernel C: mixture + log + weighted sum
-   const int chunk = std::max(256, ((e->n_patt + 1023) / 1024 + 255) / 256 * 256);
+   // Kernel C: mixture + log + weighted sum.  Stage 1 leaves one partial sum per chunk of patterns at the chunk's global
+   // position; with a communicator the ranks' (disjoint, zero elsewhere) arrays are summed over RCCL — adding zeros is exact,
+   // so every rank then holds the same array whatever the number of ranks — and stage 2 adds it up in a fixed order.
+   const int chunk = e->chunk, nbg = e->nb_global;
    const int nb = (e->n_patt + chunk - 1) / chunk;
-   HIPCHK(e->d_partial.ensure((size_t)nb * B));
+   if ((size_t)nbg * B > e->d_partial.cap) {
+      HIPCHK(e->d_partial.ensure((size_t)nbg * B));
+      HIPCHK(hipMemsetAsync(e->d_partial.p, 0, e->d_partial.cap * sizeof(double), e->stream));
+   }
    HIPCHK(e->d_out.ensure(B));
    if (want_lnf) HIPCHK(e->d_lnf.ensure((size_t)B * e->n_patt));
    ReduceArgs ra{};
@@ -645,15 +721,24 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    ra.partial = e->d_partial.p; ra.out = d_lnL_out ? d_lnL_out : e->d_out.p;
    ra.raw = (e->kk == KK_MFMA64 && e->use_jit) ? 1 : 0; ra.fscale = e->d_fscale.p;
    ra.n_patt = e->n_patt; ra.K = Km; ra.mode = e->mode; ra.n_scale = e->tree.n_scale; ra.chunk = chunk;
+   ra.first_chunk = e->first_chunk; ra.nb_stride = nbg;
    if (bs && bs->freqK) { ra.freqK = e->d_b_freqK.p; ra.freqK_bs = Km; }
    mark(e);
    hipLaunchKernelGGL(reduce_stage1, dim3(nb, B), dim3(256), 0, e->stream, ra);
-   hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)e->d_partial.p, nb, ra.out);
+   const double *tot = e->d_partial.p;
+   if (e->comm) {
+      HIPCHK(e->d_partial_tot.ensure((size_t)nbg * B));
+      const ncclResult_t nr = rccl().AllReduce(e->d_partial.p, e->d_partial_tot.p, (size_t)nbg * B, ncclDouble, ncclSum, e->comm, e->stream);
+      if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
+      tot = e->d_partial_tot.p;
+   }
+   hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, tot, nbg, ra.out);
    mark(e);
    HIPCHK(hipGetLastError());
    if (e->profiling) e->prof_evals++;
    e->n_eval++;
    if (keep && !clean) e->partials_valid = true;
+   e->pmat_valid = true;
    e->pipe_ok = want_pipe;      // (every other entry point clears it)
    return 0;
 }
@@ -766,6 +851,7 @@ int rerooted_pmat(paml_amd_engine *e, int new_root, int cut_son, const double *b
    e->n_pmat += (long)psets * (nn - 1);
    e->prog_valid = false;      // d_branch / P buffers now hold the re-rooted edge data: the next eval rebuilds
    e->partials_valid = false;
+   e->pmat_valid = false;
    return 0;
 }
 
@@ -785,6 +871,15 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    if (!e) return PAML_AMD_ENOMEM;
    e->n = n_states; e->n_tips = n_tips; e->n_patt = n_patt; e->max_classes = max_classes; e->n_genes = n_genes;
    e->flags = flags;
+   e->env.read();
+   if (hipGetDevice(&e->device) != hipSuccess ||
+       hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || e->n_cu < 1) {
+      delete e;
+      return PAML_AMD_EHIP;
+   }
+   e->n_patt_global = n_patt;
+   e->chunk = red_chunk(n_patt);
+   e->nb_global = (n_patt + e->chunk - 1) / e->chunk;
    {  // per-tree specialised kernels: on request, or by default once the data set is large enough to repay the compile
       const char *j = getenv("PAML_AMD_JIT");
       e->jit_enabled = (flags & PAML_AMD_JIT) != 0 || (j && j[0] == '1') || (!j && (long)n_patt * max_classes >= 65536);
@@ -793,12 +888,12 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    }
    // 20 states: the specialised MFMA kernel trimmed to 2 row blocks x 5 k-blocks beats the scalar-operand kernel 2-3x; the
    // MFMA interpreters (64 MFMAs per product whatever n) do not, so small or keep-partials engines stay on valu20
-   const bool mfma20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_tips <= 95 && !getenv("PAML_AMD_VALU20");
+   const bool mfma20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_tips <= 95 && !e->env.valu20;
    if (n_states == 4) e->kk = KK_VALU4;
    else if (n_states == 5) e->kk = KK_VALU5;
    else if (n_states == 20 && !mfma20) e->kk = KK_VALU20;
    else e->kk = KK_MFMA64;
-   e->mfma_dma = n_tips <= MFMA_ZT && !getenv("PAML_AMD_FORCE_GATHER");
+   e->mfma_dma = n_tips <= MFMA_ZT && !e->env.force_gather;
    e->mfma_waves = e->mfma_dma ? DMA_WAVES : GATHER_WAVES;
    e->tile_patt = e->kk == KK_MFMA64 ? e->mfma_waves * 16 : 256;
    *out = e;
@@ -829,6 +924,94 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
    case KK_VALU20: return e->use_jit ? "valu20_jit" : "valu20";
    default: return e->use_jit ? "mfma64_jit" : (e->mfma_dma ? "mfma64_stream" : "mfma64_gather");
    }
+}
+
+// ---- pattern shards over several GPUs ---------------------------------------------------------------------------------
+int paml_amd_shard_bounds(long n_patt_global, int world, int rank, long *first, long *count)
+{
+   if (n_patt_global < 1 || world < 1 || rank < 0 || rank >= world || !first || !count) return PAML_AMD_EINVAL;
+   const long chunk = red_chunk(n_patt_global), nb = (n_patt_global + chunk - 1) / chunk;
+   const long c0 = nb * rank / world, c1 = nb * (rank + 1) / world;      // chunks [c0, c1): as even as whole chunks allow
+   *first = std::min(n_patt_global, c0 * chunk);
+   *count = std::min(n_patt_global, c1 * chunk) - *first;
+   return 0;
+}
+
+int paml_amd_comm_unique_id(void *id128)
+{
+   if (!id128) return PAML_AMD_EINVAL;
+   static_assert(sizeof(ncclUniqueId) == PAML_AMD_COMM_ID_BYTES, "paml_amd.h states the size of ncclUniqueId");
+   if (!rccl().load()) return PAML_AMD_EUNSUPPORTED;
+   ncclUniqueId id;
+   if (rccl().GetUniqueId(&id) != ncclSuccess) return PAML_AMD_EHIP;
+   memcpy(id128, &id, sizeof(id));
+   return 0;
+}
+
+int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id128, long n_patt_global, long first_pattern)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return fail(e, PAML_AMD_EINVAL, "comm_init: bad arguments");
+   if (e->comm) return fail(e, PAML_AMD_EINVAL, "comm_init: the engine already has a communicator");
+   if (e->n_genes > 1 && world > 1) return fail(e, PAML_AMD_EUNSUPPORTED, "comm_init: several genes are not sharded yet");
+   const int chunk = red_chunk(n_patt_global);
+   if (first_pattern < 0 || first_pattern + e->n_patt > n_patt_global || first_pattern % chunk != 0 ||
+       (first_pattern + e->n_patt != n_patt_global && e->n_patt % chunk != 0))
+      return fail(e, PAML_AMD_EINVAL, "comm_init: the shard must start and (unless it is the last) end at multiples of " +
+                                         std::to_string(chunk) + " patterns (paml_amd_shard_bounds)");
+   HIPCHK(hipStreamSynchronize(e->stream));
+   if (id128) {      // world == 1 with an id: a one-rank communicator (exercises the collective path on a single GPU)
+      if (!rccl().load()) return fail(e, PAML_AMD_EUNSUPPORTED, "comm_init: " + rccl().err);
+      ncclUniqueId id;
+      memcpy(&id, id128, sizeof(id));
+      const ncclResult_t nr = rccl().CommInitRank(&e->comm, world, id, rank);
+      if (nr != ncclSuccess) {
+         e->comm = nullptr;
+         return fail(e, PAML_AMD_EHIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(nr));
+      }
+   }
+   e->rank = rank; e->world = world;
+   e->n_patt_global = n_patt_global; e->first_patt = first_pattern;
+   e->chunk = chunk;
+   e->nb_global = (int)((n_patt_global + chunk - 1) / chunk);
+   e->first_chunk = (int)(first_pattern / chunk);
+   e->d_partial.release();      // re-zeroed at its new size by the next evaluation
+   return 0;
+}
+
+int paml_amd_comm_destroy(paml_amd_engine *e)
+{
+   if (e) e->pipe_ok = false;
+   if (!e) return PAML_AMD_EINVAL;
+   HIPCHK(hipStreamSynchronize(e->stream));
+   if (e->comm) (void)rccl().CommDestroy(e->comm);
+   e->comm = nullptr;
+   e->rank = 0; e->world = 1; e->n_patt_global = e->n_patt; e->first_patt = 0;
+   e->chunk = red_chunk(e->n_patt); e->nb_global = (e->n_patt + e->chunk - 1) / e->chunk; e->first_chunk = 0;
+   e->d_partial.release();
+   return 0;
+}
+
+int paml_amd_get_partial_sums(paml_amd_engine *e, double *out, int cap)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !out) return fail(e, PAML_AMD_EINVAL, "get_partial_sums: null argument");
+   if (e->n_eval == 0 || !e->d_partial.p || cap < e->nb_global) return fail(e, PAML_AMD_EINVAL, "get_partial_sums: nothing evaluated yet, or cap < number of chunks");
+   const double *src = e->comm ? e->d_partial_tot.p : e->d_partial.p;
+   HIPCHK(hipMemcpyAsync(out, src, (size_t)e->nb_global * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return e->nb_global;
+}
+
+int paml_amd_comm_info(const paml_amd_engine *e, int *rank, int *world, long *n_patt_global, long *first_pattern, int *chunk)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   if (rank) *rank = e->rank;
+   if (world) *world = e->world;
+   if (n_patt_global) *n_patt_global = e->n_patt_global;
+   if (first_pattern) *first_pattern = e->first_patt;
+   if (chunk) *chunk = e->chunk;
+   return 0;
 }
 
 int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream)
@@ -1090,6 +1273,7 @@ int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *ge
    if (e) e->pipe_ok = false;
    if (!e || !branch || !MK || !pose || !lnL || ls < 1) return fail(e, PAML_AMD_EINVAL, "eval_adg: bad arguments");
    if (e->mode != PAML_AMD_MODE_LFUNDG) return fail(e, PAML_AMD_EINVAL, "eval_adg: needs the lfundG class mode");
+   if (e->world > 1) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_adg: the rate chain runs over the sites in order and does not shard (SURVEY 8e)");
    const int K = e->K, np = e->n_patt;
    for (int i = 0; i < ls; i++)
       if (pose[i] < 0 || pose[i] >= np) return fail(e, PAML_AMD_EINVAL, "eval_adg: pose entry out of range");
@@ -1303,6 +1487,10 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    hipLaunchKernelGGL(branch_reduce_kernel, dim3(1), dim3(256), 0, e->stream, (const double *)e->d_bpartial.p, nb, n_t * 3,
                       e->d_bout.p);
    HIPCHK(hipGetLastError());
+   if (e->comm) {      // the exchange step of the branch-local evaluation: 3 n_t sums
+      const ncclResult_t nr = rccl().AllReduce(e->d_bout.p, e->d_bout.p, (size_t)n_t * 3, ncclDouble, ncclSum, e->comm, e->stream);
+      if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
+   }
    std::vector<double> out((size_t)n_t * 3);
    HIPCHK(hipMemcpyAsync(out.data(), e->d_bout.p, out.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
@@ -1351,6 +1539,8 @@ int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double
 {
    if (e) e->pipe_ok = false;
    if (!e || !P || !e->d_rowmajor.p) return fail(e, PAML_AMD_EINVAL, "get_pmat: nothing evaluated yet");
+   if (!e->pmat_valid)
+      return fail(e, PAML_AMD_EINVAL, "get_pmat: the P(t) buffers hold the re-rooted matrices of eval_branch / node_posterior; run an evaluation first");
    if (gene < 0 || gene >= e->n_genes || iclass < 0 || iclass >= e->K || node < 0 || node >= e->tree.n_nodes ||
        node == e->tree.root)
       return fail(e, PAML_AMD_EINVAL, "get_pmat: index out of range");

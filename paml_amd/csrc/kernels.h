@@ -848,9 +848,11 @@ struct ReduceArgs {
    long freqK_bs;        // batched evaluations: blockIdx.y = batch element; its classes, partial sums and output follow
                          // element 0's at strides K*n_patt, gridDim.x and 1; freqK at freqK_bs (0 = shared)
    double *lnf;        // optional [n_patt]
-   double *partial;    // [gridDim.x]
+   double *partial;    // partial sums at their GLOBAL positions: element (batch b, chunk first_chunk + blockIdx.x) at
+                       // b * nb_stride + first_chunk + blockIdx.x (one engine: first_chunk = 0, nb_stride = gridDim.x)
    double *out;        // scalar
    int n_patt, K, mode, n_scale, chunk;
+   int first_chunk, nb_stride;
 };
 
 __device__ __forceinline__ double pattern_lnf(const ReduceArgs &a, int h)
@@ -893,7 +895,7 @@ __global__ __launch_bounds__(256) void reduce_stage1(ReduceArgs a)
       a.fhK += off;
       if (a.fscale) a.fscale += off;
       a.freqK += blockIdx.y * a.freqK_bs;
-      a.partial += blockIdx.y * gridDim.x;
+      a.partial += (long)blockIdx.y * a.nb_stride;
       if (a.lnf) a.lnf += (long)blockIdx.y * a.n_patt;
    }
    const int lo = blockIdx.x * a.chunk;
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(256) void reduce_stage1(ReduceArgs a)
    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
    __syncthreads();
-   if (threadIdx.x == 0) a.partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+   if (threadIdx.x == 0) a.partial[a.first_chunk + blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
 
 __global__ __launch_bounds__(256) void reduce_stage2(const double *partial, int nb, double *out)

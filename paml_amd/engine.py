@@ -26,6 +26,7 @@ EXPORTS = [
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
+    "paml_amd_shard_bounds", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_get_partial_sums",
     "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
@@ -85,6 +86,11 @@ def lib():
         L.paml_amd_profile.argtypes = [C.c_void_p, C.c_int]
         L.paml_amd_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
         L.paml_amd_counters.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.paml_amd_shard_bounds.argtypes = [C.c_long, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.paml_amd_comm_unique_id.argtypes = [C.c_void_p]
+        L.paml_amd_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long]
+        L.paml_amd_comm_destroy.argtypes = [C.c_void_p]
+        L.paml_amd_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
 
@@ -123,6 +129,32 @@ class Engine:
     @property
     def kernel_name(self):
         return self._L.paml_amd_kernel_name(self._h).decode()
+
+    # ---- pattern shards over several GPUs (paml_amd_comm_*) ----
+    def comm_init(self, rank, world, unique_id, n_patt_global, first_pattern):
+        """Collective: join the RCCL communicator of the ranks' engines.  `unique_id` = the 128 bytes rank 0 got from
+        comm_unique_id() (None with world = 1: global chunking only, no communicator)."""
+        buf = None if unique_id is None else C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        self._chk(self._L.paml_amd_comm_init(self._h, int(rank), int(world), buf, int(n_patt_global), int(first_pattern)))
+
+    def comm_destroy(self):
+        self._chk(self._L.paml_amd_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w, ch = C.c_int(), C.c_int(), C.c_int()
+        ng, fp = C.c_long(), C.c_long()
+        self._L.paml_amd_comm_info(self._h, C.byref(r), C.byref(w), C.byref(ng), C.byref(fp), C.byref(ch))
+        return dict(rank=r.value, world=w.value, n_patt_global=ng.value, first_pattern=fp.value, chunk=ch.value)
+
+    def partial_sums(self):
+        """Per-chunk partial sums of the last evaluation at their global positions (paml_amd_get_partial_sums)."""
+        cap = 1 << 14
+        out = np.zeros(cap)
+        self._L.paml_amd_get_partial_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        n = self._L.paml_amd_get_partial_sums(self._h, _p(out), cap)
+        if n < 0:
+            self._chk(n)
+        return out[:n].copy()
 
     def set_stream(self, stream_ptr):
         self._chk(self._L.paml_amd_set_stream(self._h, C.c_void_p(stream_ptr)))
@@ -312,6 +344,27 @@ class Engine:
         a, b = C.c_long(), C.c_long()
         self._L.paml_amd_counters(self._h, C.byref(a), C.byref(b))
         return dict(n_eval=a.value, n_pmat=b.value)
+
+
+COMM_ID_BYTES = 128
+
+
+def shard_bounds(n_patt_global, world, rank):
+    """(first, count) of rank's contiguous pattern shard — paml_amd_shard_bounds, host only (no GPU needed)."""
+    first, count = C.c_long(), C.c_long()
+    rc = lib().paml_amd_shard_bounds(int(n_patt_global), int(world), int(rank), C.byref(first), C.byref(count))
+    if rc != 0:
+        raise EngineError("paml_amd_shard_bounds failed (%d)" % rc)
+    return first.value, count.value
+
+
+def comm_unique_id():
+    """The 128-byte RCCL id rank 0 creates and passes to the other ranks (paml_amd_comm_unique_id)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().paml_amd_comm_unique_id(buf)
+    if rc != 0:
+        raise EngineError("paml_amd_comm_unique_id failed (%d): librccl.so.1 not found?" % rc)
+    return buf.raw
 
 
 def debug_program(tree, scale_node=None, keep=False, clean=None):

@@ -172,3 +172,33 @@ def aa_code_map():
     n_chara[20:] = 20
     cmap[20:] = np.arange(20)
     return n_chara, cmap
+
+
+def nssites_classes(ns, par, ncatG):
+    """freqK, omega per class for NSsites = 0, 1, 2, 3, 7, 8 at untransformed parameters (SetParametersNSsites
+    codeml.c:2483-2578 with LASTROUND = 1; DiscreteNSsites codeml.c:2846: M7 / M8 take the beta quantiles at the K bin
+    mid-points)."""
+    par = [float(v) for v in par]
+    if ns == 0:
+        return np.ones(1), np.array([par[0]])
+    if ns == 1:
+        p0, w0 = par[:2]
+        return np.array([p0, 1 - p0]), np.array([w0, 1.0])
+    if ns == 2:
+        p0, p1, w0, w2 = par[:4]
+        return np.array([p0, p1, 1 - p0 - p1]), np.array([w0, 1.0, w2])
+    if ns == 3:
+        K = ncatG
+        p = np.array(par[:K - 1])
+        return np.concatenate((p, [1 - p.sum()])), np.array(par[K - 1:2 * K - 1])
+    from scipy.special import betaincinv
+    if ns == 7:
+        p, q = par[:2]
+        K = ncatG
+        return np.full(K, 1.0 / K), betaincinv(p, q, (2 * np.arange(K) + 1) / (2.0 * K))
+    if ns == 8:
+        p0, p, q, ws = par[:4]
+        K = ncatG
+        w = betaincinv(p, q, (2 * np.arange(K) + 1) / (2.0 * K))
+        return np.concatenate((np.full(K, p0 / K), [1 - p0])), np.concatenate((w, [ws]))
+    raise ValueError(ns)

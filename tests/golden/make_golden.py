@@ -325,6 +325,111 @@ def case_at(name, ctl_over, files, n_tips, kind, x, ntime):
         print("   %s: printed lnL %.6f, lnf-file sum %.6f" % (name, g["lnL_printed"], g["lnL"]))
 
 
+
+# ---- the north_star workload: the NSsites sweep on the C4 data (16 taxa x 10^6 codon patterns) -----------------------------
+# Class tables at fixed values: M1a (K = 2), M2a (K = 3), M7 (K = 10), M8 (K = 11).  The reference writes its `lnf`
+# file only AFTER the NEB / BEB post-processing (codeml.c:895-904), and BEB for M2a / M8 (lfunNSsites_M2M8, 10^4 grid points x
+# npatt) would take hours at 10^6 patterns.  So for M2a / M8 proper the reference is stopped once it has printed the lnL of its
+# single evaluation (golden = lnL only), and the SAME class tables are run to completion through NSsites = 3 (M3 "discrete" with
+# K = 3 / 11 classes given as untransformed p's and w's, no BEB) for lnL + the per-pattern log f_h sample.
+NS_FULL = {
+    # name: (NSsites, ncatG, x after the fixed kappa, stop once lnL is printed)
+    "m1a": (1, 2, [0.7, 0.1], False),
+    "m2a": (2, 3, [0.6, 0.3, 0.1, 2.5], True),
+    "m7": (7, 10, [0.5, 1.2], False),
+    "m8": (8, 10, [0.9, 0.5, 1.2, 2.5], True),
+}
+
+
+def _beta_medians(p, q, K):
+    from scipy.stats import beta
+    return [round(float(beta.ppf((i + 0.5) / K, p, q)), 6) for i in range(K)]
+
+
+def run_ref_until_lnl(prog, ctl, files, x, timeout=7200):
+    """Start the reference, return the lnL it prints after its single evaluation ("lnL  = ..."), then stop it."""
+    import time
+    d = tempfile.mkdtemp(prefix="golden_")
+    try:
+        for dst, src in files.items():
+            if os.path.exists(str(src)):
+                os.symlink(src, os.path.join(d, dst))
+            else:
+                with open(os.path.join(d, dst), "w") as f:
+                    f.write(src)
+        with open(os.path.join(d, prog + ".ctl"), "w") as f:
+            for k, v in ctl.items():
+                f.write("%s = %s\n" % (k, v))
+        with open(os.path.join(d, "in." + prog), "w") as f:
+            f.write("-1 " + " ".join("%.6f" % v for v in x) + "\n")
+        log = open(os.path.join(d, "stdout.txt"), "wb")
+        pr = subprocess.Popen([os.path.join(REF, prog), prog + ".ctl"], cwd=d, stdout=log, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL)
+        t0 = time.time()
+        try:
+            while True:
+                time.sleep(5)
+                out = open(os.path.join(d, "stdout.txt"), errors="replace").read()
+                m = re.findall(r"^lnL\s+=\s*(-?[0-9.]+)", out, re.M)
+                if m:
+                    return dict(lnL=float(m[-1]), stdout=out)
+                if pr.poll() is not None:
+                    raise RuntimeError("reference ended without lnL:\n" + out[-2000:])
+                if time.time() - t0 > timeout:
+                    raise RuntimeError("timeout")
+        finally:
+            if pr.poll() is None:
+                pr.kill()
+            pr.wait()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def case_syn_codon_ns(tag, n_patt=1_000_000, sample=997):
+    pb = synth.codon_m0_problem(n_tips=16, n_patt=n_patt, estimate_pi=True)
+    d = tempfile.mkdtemp()
+    seq = os.path.join(d, "seq.txt")
+    synth.write_pattern_file(seq, pb.z, pb.weights, "codon")
+    tree = " 16 1\n" + pb.tree.newick() + "\n"
+    suffix = "_full" if n_patt == 1_000_000 else "_%d" % n_patt
+    gen = dict(fn="codon_m0_problem", n_tips=16, n_patt=n_patt, seed=20260926, estimate_pi=True)
+    try:
+        if tag in NS_FULL:
+            ns, ncat, x, stop = NS_FULL[tag]
+            ctl = dict(CODEML_BASE, seqfile="seq.txt", treefile="tree.txt", outfile="mlc", fix_kappa=1, kappa=2, NSsites=ns, ncatG=ncat,
+                       omega=1.3, fix_blength=2)
+            model = dict(kind="codon_nssites", NSsites=ns, ncatG=ncat, kappa=2.0, codonfreq="F3x4")
+            if stop:
+                res = run_ref_until_lnl("codeml", ctl, {"seq.txt": seq, "tree.txt": tree}, x)
+                g = dict(name="syn_codon_%s%s" % (tag, suffix), seqtype="codon", n_tips=16, n_patt=n_patt, lnL=res["lnL"], program="codeml",
+                         model=model, x=x, ntime=0, generator=gen, tree=pb.tree.newick(),
+                         note="lnL of the reference's single evaluation; the program was stopped before its BEB post-processing, so no lnf sample "
+                              "(see syn_codon_%s_as_m3%s for the same class table run to completion through NSsites = 3)" % (tag, suffix))
+                path = os.path.join(HERE, g["name"] + ".json")
+                with open(path, "w") as f:
+                    json.dump(g, f, separators=(",", ":"))
+                print("%-22s lnL %.6f (lnL only) -> %s" % (g["name"], g["lnL"], os.path.basename(path)))
+            else:
+                res = run_ref("codeml", ctl, {"seq.txt": seq, "tree.txt": tree}, x=x, timeout=4 * 3600)
+                finish("syn_codon_%s%s" % (tag, suffix), res, "codon", 16, dict(program="codeml", model=model, x=x, ntime=0, generator=gen), sample=sample)
+        else:      # "m2a_as_m3" / "m8_as_m3"
+            src = tag.split("_")[0]
+            ns, ncat, xs, _ = NS_FULL[src]
+            if src == "m2a":
+                p, w = [xs[0], xs[1]], [xs[2], 1.0, xs[3]]
+            else:
+                p, w = [round(xs[0] / 10, 6)] * 10, _beta_medians(xs[1], xs[2], 10) + [xs[3]]
+            K = len(w)
+            x = p + w
+            ctl = dict(CODEML_BASE, seqfile="seq.txt", treefile="tree.txt", outfile="mlc", fix_kappa=1, kappa=2, NSsites=3, ncatG=K, omega=1.3,
+                       fix_blength=2)
+            res = run_ref("codeml", ctl, {"seq.txt": seq, "tree.txt": tree}, x=x, timeout=4 * 3600)
+            finish("syn_codon_%s%s" % (tag, suffix), res, "codon", 16,
+                   dict(program="codeml", model=dict(kind="codon_nssites", NSsites=3, ncatG=K, kappa=2.0, codonfreq="F3x4"), x=x, ntime=0,
+                        generator=gen, classes=dict(p=p + [round(1 - sum(p), 6)], w=w)), sample=sample)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 LYSO = {"lysozymeLarge.nuc": EX + "/lysozyme/lysozymeLarge.nuc", "lysozymeLarge.trees": EX + "/lysozyme/lysozymeLarge.trees"}
 LYSO_CTL = dict(seqfile="lysozymeLarge.nuc", treefile="lysozymeLarge.trees", kappa=3, cleandata=0)
 ECP = {"ECP_EDN_15.nuc": EX + "/CladeModelCD/ECP_EDN_15.nuc", "tree.txt": EX + "/CladeModelCD/tree.txt"}
@@ -468,6 +573,13 @@ CASES = {
     # BASELINE configs[3] / configs[1] at full size (reference: ~2 min and 6.8 GB / ~2 s): lnL + strided log f_h sample
     "syn_codon_m0_full": lambda: case_syn_codon(1_000_000, "syn_codon_m0_full", sample=997),
     "syn_nuc_gtr_g4_full": lambda: case_syn_nuc(100_000, "syn_nuc_gtr_g4_full", sample=97),
+    # the NSsites sweep on the C4 data at full size (reference: 3 min ... 20 min each, 7 GB)
+    "syn_codon_m1a_full": lambda: case_syn_codon_ns("m1a"), "syn_codon_m2a_full": lambda: case_syn_codon_ns("m2a"),
+    "syn_codon_m7_full": lambda: case_syn_codon_ns("m7"), "syn_codon_m8_full": lambda: case_syn_codon_ns("m8"),
+    "syn_codon_m2a_as_m3_full": lambda: case_syn_codon_ns("m2a_as_m3"), "syn_codon_m8_as_m3_full": lambda: case_syn_codon_ns("m8_as_m3"),
+    # small versions of the same (CPU oracle test)
+    "syn_codon_m2a_as_m3_4000": lambda: case_syn_codon_ns("m2a_as_m3", 4000, None), "syn_codon_m8_as_m3_4000": lambda: case_syn_codon_ns("m8_as_m3", 4000, None),
+    "syn_codon_m7_4000": lambda: case_syn_codon_ns("m7", 4000, None),
 }
 
 if __name__ == "__main__":

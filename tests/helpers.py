@@ -26,29 +26,7 @@ def load_golden(name):
         return json.load(f)
 
 
-def nssites_classes(ns, par, ncatG):
-    """freqK, omega per class for NSsites = 0,1,2,7,8 at untransformed parameters
-    (SetParametersNSsites codeml.c:2483-2578 with LASTROUND=1; DiscreteNSsites codeml.c:2846)."""
-    from scipy.special import betaincinv
-    if ns == 0:
-        return np.ones(1), np.array([par[0]])
-    if ns == 1:
-        p0, w0 = par
-        return np.array([p0, 1 - p0]), np.array([w0, 1.0])
-    if ns == 2:
-        p0, p1, w0, w2 = par
-        return np.array([p0, p1, 1 - p0 - p1]), np.array([w0, 1.0, w2])
-    if ns == 7:
-        p, q = par
-        K = ncatG
-        w = betaincinv(p, q, (2 * np.arange(K) + 1) / (2.0 * K))
-        return np.full(K, 1.0 / K), w
-    if ns == 8:
-        p0, p, q, ws = par
-        K = ncatG
-        w = betaincinv(p, q, (2 * np.arange(K) + 1) / (2.0 * K))
-        return np.concatenate((np.full(K, p0 / K), [1 - p0])), np.concatenate((w, [ws]))
-    raise ValueError(ns)
+nssites_classes = models.nssites_classes
 
 
 EQUATE_BASE = dict(zip("TCAGUYRMKSWHBVD-N?", ["T", "C", "A", "G", "T", "TC", "AG", "CA", "TG", "CG", "TA", "TCA", "TCG", "CAG", "TAG",

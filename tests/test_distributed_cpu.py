@@ -1,5 +1,7 @@
-"""N>1 path on CPU: world_size-2 gloo run of the pattern-sharding + scalar all-reduce logic used by bench.py and the
-multi-GPU integration (the per-shard evaluator here is the oracle; on the GPU box it is the engine)."""
+"""N>1 path on CPU: world_size-2 gloo runs of the pattern-sharding and reduction scheme the engine uses across GPUs
+(paml_amd_shard_bounds from the C ABI; per-chunk partial sums at global positions, the ranks' zero-padded arrays added, one
+fixed-order total).  The per-shard evaluator here is the oracle; on the GPU box it is the engine (tests/test_engine_gpu.py
+runs the RCCL path in a one-rank communicator)."""
 import os
 import socket
 import sys
@@ -9,7 +11,7 @@ import torch.multiprocessing as mp
 
 import helpers
 import oracle
-from paml_amd import distributed, synth
+from paml_amd import distributed, engine, synth
 
 
 def _free_port():
@@ -20,15 +22,22 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_patt, out):
+N_PATT = 3000      # chunk 256 -> 12 chunks, 6 per rank
+
+
+def _problem():
+    return synth.nuc_gtr_gamma_problem(n_tips=12, n_patt=N_PATT, seed=5)
+
+
+def _worker(rank, world, port, out):
     import torch.distributed as dist
     for p in (helpers.REPO, os.path.join(helpers.REPO, "oracle"), os.path.join(helpers.REPO, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import oracle as orc
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    pb = synth.nuc_gtr_gamma_problem(n_tips=12, n_patt=n_patt, seed=5)
-    lnl, (lo, hi) = distributed.sharded_eval(pb, lambda sub: orc.evaluate(sub, want_lnf=False)["lnL"], world, rank)
+    pb = _problem()
+    lnl, (lo, hi) = distributed.sharded_lnl(pb, lambda sub: orc.evaluate(sub, want_lnf=True)["lnf"], world, rank)
     b = pb.tree.n_tips + 2
     tt = np.array([pb.tree.branch[b], 0.2])
     l, dl, ddl = distributed.sharded_eval_branch(pb, lambda sub, nb, ts: orc.eval_branch(sub, nb, ts), b, tt, world, rank)
@@ -38,29 +47,51 @@ def _worker(rank, world, port, n_patt, out):
 
 
 def test_shard_bounds_cover_and_align():
-    for n, w in [(1000, 2), (1_000_000, 8), (79, 4), (129, 2)]:
+    for n, w in [(1000, 2), (1_000_000, 8), (1_000_000, 3), (79, 4), (129, 2), (4_000_000, 8), (100_000, 8)]:
+        ch = distributed.red_chunk(n)
+        assert ch % 256 == 0 and -(-n // ch) <= 1024
         spans = [distributed.shard_bounds(n, w, r) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         for (a, b), (c, d) in zip(spans, spans[1:]):
             assert b == c and a <= b
-        assert all(lo % 128 == 0 for lo, hi in spans if hi > lo)
+        assert all(lo % ch == 0 for lo, hi in spans if hi > lo)
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= ch or n < ch * w      # as even as whole chunks allow
+    # the C ABI rejects nonsense
+    assert engine.lib().paml_amd_shard_bounds(0, 1, 0, None, None) != 0
+
+
+def test_reduction_scheme_is_independent_of_world_size():
+    """Summing the ranks' zero-padded chunk-partial arrays and taking one fixed-order total gives the SAME bits for 1, 2, 3, 5 ranks."""
+    pb = _problem()
+    lnf = oracle.evaluate(pb, want_lnf=True)["lnf"]
+    ref = distributed.total_fixed_order(distributed.chunk_partials(lnf, pb.weights, 0, pb.n_patt))
+    for world in (2, 3, 5):
+        tot = np.zeros(-(-pb.n_patt // distributed.red_chunk(pb.n_patt)))
+        for r in range(world):
+            lo, hi = distributed.shard_bounds(pb.n_patt, world, r)
+            if hi > lo:
+                tot += distributed.chunk_partials(lnf[lo:hi], pb.weights[lo:hi], lo, pb.n_patt)
+        assert distributed.total_fixed_order(tot) == ref      # bit-identical
+    assert abs(ref - float(np.dot(lnf, pb.weights))) <= 1e-12 * abs(ref)
 
 
 def test_two_rank_gloo_matches_single():
-    n_patt = 1000
-    pb = synth.nuc_gtr_gamma_problem(n_tips=12, n_patt=n_patt, seed=5)
-    ref = oracle.evaluate(pb, want_lnf=False)["lnL"]
+    pb = _problem()
+    res = oracle.evaluate(pb, want_lnf=True)
+    single = distributed.total_fixed_order(distributed.chunk_partials(res["lnf"], pb.weights, 0, pb.n_patt))
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), n_patt, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert set(out.keys()) == {0, 1}
     for r in (0, 1):
-        assert abs(out[r][0] - ref) <= 1e-12 * abs(ref)
-    assert out[0][2] == out[1][1]           # shards are contiguous
+        assert out[r][0] == single                                     # bit-identical to the one-rank total
+        assert abs(out[r][0] - res["lnL"]) <= 1e-12 * abs(res["lnL"])
+    assert out[0][2] == out[1][1] and out[0][2] % distributed.red_chunk(pb.n_patt) == 0      # contiguous, chunk-aligned
     # branch-local evaluation: the 3 x n_t sums all-reduce to the single-process values
     b = pb.tree.n_tips + 2
     rl, rdl, rddl = oracle.eval_branch(pb, b, np.array([pb.tree.branch[b], 0.2]))
     for r in (0, 1):
         assert np.allclose(out[r][3], rl, rtol=1e-12) and np.allclose(out[r][4], rdl, rtol=1e-9, atol=1e-9)
         assert np.allclose(out[r][5], rddl, rtol=1e-9, atol=1e-8)
-    assert abs(rl[0] - ref) <= 1e-11 * abs(ref)
+    assert abs(rl[0] - res["lnL"]) <= 1e-11 * abs(res["lnL"])

@@ -658,3 +658,95 @@ def test_eval_device_pipeline_matches_in_order_evaluations():
     P = eng.get_pmat(0, 0, 3)
     eng.eval(brs[-1], pb.gene_rate)
     assert np.array_equal(P, eng.get_pmat(0, 0, 3))
+
+
+# ---- pattern shards over several GPUs: the engine's own exchange step (paml_amd_comm_*) ------------------------------------
+def _stage2(partials):
+    """reduce_stage2's fixed-order total (pure additions: exactly reproducible on the host)."""
+    from paml_amd import distributed
+    return distributed.total_fixed_order(partials)
+
+
+@pytest.mark.parametrize("n,K", [(61, 1), (4, 4), (20, 2)])
+def test_sharded_partial_sums_are_world_size_invariant(n, K):
+    """Shard engines that know the global pattern range leave their partial sums at global positions; added up (disjoint,
+    zero elsewhere: exact) and totalled in the fixed order they give the one-engine lnL bit for bit, for 2, 3 and 5 shards."""
+    from paml_amd import distributed
+    pb = helpers.random_problem(n, 10, 3000, K=K, seed=400 + n)
+    full = engine_for(pb)
+    lnl = full.eval(pb.tree.branch)["lnL"]
+    pf = full.partial_sums()
+    assert len(pf) == -(-pb.n_patt // distributed.red_chunk(pb.n_patt)) and _stage2(pf) == lnl
+    for world in (2, 3, 5):
+        tot = np.zeros_like(pf)
+        for r in range(world):
+            lo, hi = distributed.shard_bounds(pb.n_patt, world, r)
+            sub = pb.slice_patterns(lo, hi)
+            e = engine_for(sub)
+            e.comm_init(0, 1, None, pb.n_patt, lo)      # global chunking only: no communicator on a one-GPU box
+            local = e.eval(sub.tree.branch)["lnL"]
+            ps = e.partial_sums()
+            assert _stage2(ps) == local
+            assert np.count_nonzero(ps) <= -(-(hi - lo) // distributed.red_chunk(pb.n_patt))
+            tot += ps
+            e.close()
+        assert np.array_equal(tot, pf)
+        assert _stage2(tot) == lnl
+
+
+def test_one_rank_rccl_communicator_matches_golden():
+    """The RCCL path in a one-rank communicator: ncclCommInitRank + ncclAllReduce on the engine's stream, same bits as the
+    plain engine, and the reference's lnL for the golden data."""
+    from paml_amd import engine as E
+    g = helpers.load_golden("syn_codon_m0")
+    pb = helpers.problem_from_golden(g)
+    plain = engine_for(pb).eval(pb.tree.branch)["lnL"]
+    eng = engine_for(pb)
+    eng.comm_init(0, 1, E.comm_unique_id(), pb.n_patt, 0)
+    out = eng.eval(pb.tree.branch, want_lnf=True)
+    assert out["lnL"] == plain
+    assert abs(out["lnL"] - g["lnL"]) <= 2e-6 + 1e-9 * abs(g["lnL"])
+    # batched evaluations and the branch-local evaluation go through the collective too
+    B = np.stack([pb.tree.branch, pb.tree.branch * 1.1])
+    lb = eng.eval_batch(B)
+    assert lb[0] == plain and lb[1] != plain
+    b = pb.tree.n_tips + 1
+    l, dl, ddl = eng.eval_branch(b, np.array([pb.tree.branch[b]]), pb.tree.branch)
+    assert abs(l[0] - plain) <= 1e-11 * abs(plain)
+    info = eng.comm_info()
+    assert info["world"] == 1 and info["n_patt_global"] == pb.n_patt
+    eng.comm_destroy()
+    assert eng.eval(pb.tree.branch)["lnL"] == plain
+    # misaligned shards are refused
+    e2 = engine_for(pb.slice_patterns(0, 300))
+    assert e2._L.paml_amd_comm_init(e2._h, 0, 2, None, pb.n_patt, 0) != 0
+
+
+def test_two_engines_on_two_threads_and_streams():
+    """include/paml_amd.h: different engines are independent — two host threads, each with its own engine and HIP stream,
+    evaluating concurrently (ctypes releases the GIL) get the values a single thread gets."""
+    import threading
+    import torch
+    pbs = [helpers.random_problem(61, 12, 20000, K=1, seed=71), helpers.random_problem(4, 20, 50000, K=4, seed=72)]
+    want = [engine_for(p).eval(p.tree.branch)["lnL"] for p in pbs]
+    got = [[], []]
+    errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            e = engine_for(pbs[i])
+            e.set_stream(st.cuda_stream)
+            for _ in range(30):
+                got[i].append(e.eval(pbs[i].tree.branch)["lnL"])
+            e.close()
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert got[i] == [want[i]] * 30
