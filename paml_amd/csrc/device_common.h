@@ -62,6 +62,19 @@ struct PruneArgs {
    double *fscale;             // jit kernel with scaling nodes: summed scale factors [K][n_patt] (the log is taken later)
    const unsigned char *ztiles; // jit kernel: per tile, (n_tips + 1) rows of 128 bytes (tip codes of the tile's patterns,
    int zt_bytes;                // then the weight > 0 flags), zero padded to zt_bytes (a multiple of 2048)
+   // ---- kernels with the reduction fused in (one workgroup = one reduction chunk of patterns; jit_generate_valu_fused) ----
+   const unsigned int *zpm;     // tip codes pattern-major: [n_patt][zpm_words] dwords, 4 codes per dword (tip t = byte t)
+   int zpm_words;               // dwords per pattern (a multiple of 4)
+   int Km;                      // classes of the model (K = Km x batch elements; blockIdx.y = batch element)
+   int chunk;                   // patterns per workgroup = per partial sum
+   int first_chunk, nb_stride;  // partial sum of (batch b, chunk c) lives at red_partial[b * nb_stride + first_chunk + c]
+   int want_fhk;                // store fhK (always stored with scaling nodes: the class mixture needs the logs)
+   const double *freqK;         // [Km] (+ b * freqK_bs)
+   long freqK_bs;
+   double *lnf;                 // optional [batch][n_patt]
+   double *red_partial;
+   double *red_out;             // [batch]
+   int *red_counter;            // [batch] zeroed; non-null: the last workgroup to finish adds the partials up (one GPU)
 };
 
 __device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)
@@ -527,6 +540,81 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
       a.fhK[(long)iclass * a.n_patt + h] = out;
    }
 }
+
+// ---- the reduction's tail, shared by every kernel that forms partial sums ---------------------------------------------
+// Fixed-order total of nb partial sums by one 256-thread workgroup (what reduce_stage2 does): lane sums over i, i + 256, ...
+// then the butterfly and the four waves.  `coherent`: the partials were written by other workgroups of the SAME launch —
+// read them past the (non-coherent) L1.
+__device__ __forceinline__ double red_total256(const double *partial, int nb, bool coherent, double *sw4)
+{
+   double acc = 0;
+   for (int i = threadIdx.x; i < nb; i += 256) {
+      double v;
+      if (coherent) {
+         const unsigned long long u = __hip_atomic_load((const unsigned long long *)(partial + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         v = __longlong_as_double((long long)u);
+      }
+      else v = partial[i];
+      acc += v;
+   }
+#pragma unroll
+   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+   __syncthreads();
+   if ((threadIdx.x & 63) == 0) sw4[threadIdx.x >> 6] = acc;
+   __syncthreads();
+   return (sw4[0] + sw4[1]) + (sw4[2] + sw4[3]);
+}
+
+// A workgroup's weighted sum -> its slot of the global partial array; with a counter, the workgroup that finishes last also
+// forms the total (single GPU: no separate stage-2 launch).  The order of every sum is fixed, so the result is deterministic.
+__device__ __forceinline__ void red_block_finish(double acc, double *partial_row, int slot, int nb_total, double *out, int *counter)
+{
+   __shared__ double sw[4];
+   __shared__ int s_last;
+#pragma unroll
+   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      partial_row[slot] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+      int last = 0;
+      if (counter) {
+         __threadfence();
+         last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+      }
+      s_last = last;
+   }
+   __syncthreads();
+   if (s_last) {
+      __threadfence();
+      const double tot = red_total256(partial_row, nb_total, true, sw);
+      if (threadIdx.x == 0) {
+         *out = tot;
+         *counter = 0;      // ready for the next launch on this stream
+      }
+   }
+}
+
+// ---- fused one-pattern-per-lane kernel (4 / 5 states; jit.h: jit_generate_valu_fused) ---------------------------------------
+// One workgroup owns one reduction chunk of patterns and walks it 256 patterns at a time.  Per pattern the tip codes are read
+// ONCE (pattern-major, 4 codes per dword), the classes are the INNER loop — the class likelihoods never leave registers unless
+// asked for — and the mixture, log, weight and the chunk's partial sum are formed in the same kernel.  Tip factors come from
+// LDS tables (rows of the tips' P summed over each code's state set; for a cherry of two tips the products of their rows),
+// filled once per workgroup from pmat's tables: gathering them from L2 instead made the texture path, not the FP64 pipe, the
+// limit of the round-1 kernel (two 16-byte gathers per tip and lane against sixteen DFMAs).
+template <int N>
+__device__ __forceinline__ void jvf_row_set(double (&x)[N], const double *row)
+{
+#pragma unroll
+   for (int j = 0; j < N; j++) x[j] = row[j];
+}
+template <int N>
+__device__ __forceinline__ void jvf_row_mul(double (&x)[N], const double *row)
+{
+#pragma unroll
+   for (int j = 0; j < N; j++) x[j] *= row[j];
+}
+#define JVF_CODE(T) ((int)((zw[(T) >> 2] >> (((T) & 3) * 8)) & 0xffu))
 
 #define JV_PROLOGUE(NS)                                                                                          \
    constexpr int N = NS;                                                                                        \

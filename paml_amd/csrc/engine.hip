@@ -143,7 +143,7 @@ inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global
 
 // Environment switches, read once when the engine is created.
 struct EnvCfg {
-   bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false;
+   bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false;
    std::string jit_dump, prof_ops;
    int prof_tid = 0;
    void read()
@@ -153,6 +153,7 @@ struct EnvCfg {
       jit_sync = getenv("PAML_AMD_JIT_SYNC") != nullptr;
       jit_strict = getenv("PAML_AMD_JIT_STRICT") != nullptr;
       valu20 = getenv("PAML_AMD_VALU20") != nullptr;
+      no_fused = getenv("PAML_AMD_NO_FUSED") != nullptr;
       if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
       if (const char *v = getenv("PAML_AMD_PROF_OPS")) prof_ops = v;
       if (const char *v = getenv("PAML_AMD_PROF_TID")) prof_tid = atoi(v);
@@ -182,6 +183,10 @@ struct paml_amd_engine {
    long n_patt_global = 0, first_patt = 0;
    int chunk = 256, nb_global = 1, first_chunk = 0;
    DevBuf<double> d_partial_tot, d_btot;
+   DevBuf<unsigned int> d_zpm;        // fused 4 / 5-state kernel: tip codes pattern-major
+   int zpm_words = 0;
+   DevBuf<int> d_red_counter;         // "last workgroup adds up the partial sums" tickets, one per batch element
+   bool fused = false;                // the selected kernel forms the reduction itself
    bool pmat_valid = false;           // d_rowmajor holds the P(t) of an evaluation in the tree's own orientation
 
    // data
@@ -266,6 +271,8 @@ struct paml_amd_engine {
       for (auto b : b2) b->release();
       d_tiles.release();
       d_tiles_full.release();
+      d_zpm.release();
+      d_red_counter.release();
       d_ops.release();
       d_ops_tmp.release();
       d_label_eff.release();
@@ -414,7 +421,7 @@ struct BatchSpec {
 };
 
 int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
-                double *d_lnL_out, bool want_lnf, const BatchSpec *bs = nullptr, bool want_pipe = false)
+                double *d_lnL_out, bool want_lnf, const BatchSpec *bs = nullptr, bool want_pipe = false, bool want_fhk = true)
 {
    if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes))
       return fail(e, PAML_AMD_EINVAL, "eval before set_tips/set_tree/set_pi/set_classes");
@@ -583,15 +590,26 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          if (clean) return fail(e, PAML_AMD_EINVAL, "eval_dirty: kernel layout changed; run a full evaluation first");
       }
    }
-   if (e->kk != KK_MFMA64) {      // 4 / 5 / 20 states: the interpreter unrolled for this tree (jit_generate_valu)
-      bool jit_ok = false;
+   if (e->kk != KK_MFMA64) {      // 4 / 5 / 20 states: the interpreter unrolled for this tree
+      bool jit_ok = false, fused = false;
       // (20 states: the unrolled walk needs > 256 VGPRs and runs at one wave per SIMD, slower than the interpreter)
       if (e->jit_enabled && !keep && n <= 5 && jit_valu_supported(e->prog)) {
-         int r = ensure_jit(e, "v" + std::to_string(n) + ":" + jit_program_key(e->prog, e->n_tips),
-                            [&]() { return jit_generate_valu(e->prog, n); }, &jit_ok);
-         if (r) return r;
+         // the fused form (classes inside, LDS tip tables, reduction in the epilogue) when the model fits it
+         const ValuFusedPlan pl = jit_valu_fused_plan(e->prog, n, e->n_tips, e->n_codes, Km);
+         if (pl.ok && G == 1 && e->n_pi == 1 && e->d_zpm.p && !e->env.no_fused) {
+            int r = ensure_jit(e, "vf" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "k" + std::to_string(Km) + ":" + jit_program_key(e->prog, e->n_tips),
+                               [&]() { return jit_generate_valu_fused(e->prog, n, e->n_tips, e->n_codes, Km); }, &jit_ok);
+            if (r) return r;
+            fused = jit_ok;
+         }
+         if (!jit_ok) {
+            int r = ensure_jit(e, "v" + std::to_string(n) + ":" + jit_program_key(e->prog, e->n_tips),
+                               [&]() { return jit_generate_valu(e->prog, n); }, &jit_ok);
+            if (r) return r;
+         }
       }
       e->use_jit = jit_ok;
+      e->fused = fused;
    }
    const bool use_dma = e->mfma_dma;
    const int n_blocks = e->n_tiles * K;
@@ -648,6 +666,29 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
    pr.first_tip = e->prog.first_tip;
    pr.stream = e->d_stream.p; pr.n_stream = (int)(e->prog.stream.size() / 2); pr.tip_words = (long)tip_words(e);
+   // the reduction's geometry (the fused kernels form the partial sums themselves; the others leave them to reduce_stage1)
+   const int chunk = e->chunk, nbg = e->nb_global;
+   const int nb = (e->n_patt + chunk - 1) / chunk;
+   if ((size_t)nbg * B > e->d_partial.cap) {
+      HIPCHK(e->d_partial.ensure((size_t)nbg * B));
+      HIPCHK(hipMemsetAsync(e->d_partial.p, 0, e->d_partial.cap * sizeof(double), e->stream));
+   }
+   if ((size_t)B > e->d_red_counter.cap) {
+      HIPCHK(e->d_red_counter.ensure(std::max(B, 64)));
+      HIPCHK(hipMemsetAsync(e->d_red_counter.p, 0, e->d_red_counter.cap * sizeof(int), e->stream));
+   }
+   HIPCHK(e->d_out.ensure(B));
+   if (want_lnf) HIPCHK(e->d_lnf.ensure((size_t)B * e->n_patt));
+   double *const lnl_out = d_lnL_out ? d_lnL_out : e->d_out.p;
+   const bool fused = e->kk != KK_MFMA64 && e->use_jit && e->fused;
+   if (fused) {
+      pr.zpm = e->d_zpm.p; pr.zpm_words = e->zpm_words; pr.Km = Km; pr.chunk = chunk; pr.first_chunk = e->first_chunk; pr.nb_stride = nbg;
+      pr.want_fhk = (want_fhk || e->tree.n_scale) ? 1 : 0;
+      pr.freqK = (bs && bs->freqK) ? e->d_b_freqK.p : e->d_freqK.p; pr.freqK_bs = (bs && bs->freqK) ? Km : 0;
+      pr.lnf = want_lnf ? e->d_lnf.p : nullptr;
+      pr.red_partial = e->d_partial.p; pr.red_out = lnl_out;
+      pr.red_counter = e->comm ? nullptr : e->d_red_counter.p;      // several ranks: the total is formed after the all-reduce
+   }
    const int prof_stride = (int)e->prog.ops.size() + 3;
    if (!e->env.prof_ops.empty()) {
       if (e->d_prof) (void)hipFree(e->d_prof);
@@ -680,7 +721,11 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    case KK_VALU4:
    case KK_VALU5:
    case KK_VALU20:
-      if (e->use_jit) {
+      if (fused) {
+         void *params[] = {&pr};
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, nb, B, 1, 256, 1, 1, 0, e->stream, params, nullptr));
+      }
+      else if (e->use_jit) {
          void *params[] = {&pr};
          HIPCHK(hipModuleLaunchKernel(e->jit.fn, n_blocks, 1, 1, 256, 1, 1, 0, e->stream, params, nullptr));
       }
@@ -707,32 +752,24 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
 
    // Kernel C: mixture + log + weighted sum.  Stage 1 leaves one partial sum per chunk of patterns at the chunk's global
    // position; with a communicator the ranks' (disjoint, zero elsewhere) arrays are summed over RCCL — adding zeros is exact,
-   // so every rank then holds the same array whatever the number of ranks — and stage 2 adds it up in a fixed order.
-   const int chunk = e->chunk, nbg = e->nb_global;
-   const int nb = (e->n_patt + chunk - 1) / chunk;
-   if ((size_t)nbg * B > e->d_partial.cap) {
-      HIPCHK(e->d_partial.ensure((size_t)nbg * B));
-      HIPCHK(hipMemsetAsync(e->d_partial.p, 0, e->d_partial.cap * sizeof(double), e->stream));
-   }
-   HIPCHK(e->d_out.ensure(B));
-   if (want_lnf) HIPCHK(e->d_lnf.ensure((size_t)B * e->n_patt));
+   // so every rank then holds the same array whatever the number of ranks — and stage 2 adds it up in a fixed order.  On one
+   // GPU the workgroup that finishes last forms the total itself (red_block_finish): no second launch.
    ReduceArgs ra{};
    ra.fhK = e->d_fhK.p; ra.weights = e->d_weights.p; ra.freqK = e->d_freqK.p; ra.lnf = want_lnf ? e->d_lnf.p : nullptr;
-   ra.partial = e->d_partial.p; ra.out = d_lnL_out ? d_lnL_out : e->d_out.p;
+   ra.partial = e->d_partial.p; ra.out = lnl_out;
    ra.raw = (e->kk == KK_MFMA64 && e->use_jit) ? 1 : 0; ra.fscale = e->d_fscale.p;
    ra.n_patt = e->n_patt; ra.K = Km; ra.mode = e->mode; ra.n_scale = e->tree.n_scale; ra.chunk = chunk;
    ra.first_chunk = e->first_chunk; ra.nb_stride = nbg;
+   ra.counter = e->comm ? nullptr : e->d_red_counter.p;
    if (bs && bs->freqK) { ra.freqK = e->d_b_freqK.p; ra.freqK_bs = Km; }
    mark(e);
-   hipLaunchKernelGGL(reduce_stage1, dim3(nb, B), dim3(256), 0, e->stream, ra);
-   const double *tot = e->d_partial.p;
+   if (!fused) hipLaunchKernelGGL(reduce_stage1, dim3(nb, B), dim3(256), 0, e->stream, ra);
    if (e->comm) {
       HIPCHK(e->d_partial_tot.ensure((size_t)nbg * B));
       const ncclResult_t nr = rccl().AllReduce(e->d_partial.p, e->d_partial_tot.p, (size_t)nbg * B, ncclDouble, ncclSum, e->comm, e->stream);
       if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
-      tot = e->d_partial_tot.p;
+      hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)e->d_partial_tot.p, nbg, ra.out);
    }
-   hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, tot, nbg, ra.out);
    mark(e);
    HIPCHK(hipGetLastError());
    if (e->profiling) e->prof_evals++;
@@ -1068,6 +1105,12 @@ int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata,
    HIPCHK(upload(e->d_n_chara, nch.data(), nch.size(), e->stream));
    HIPCHK(upload(e->d_chara_map, cmap.data(), cmap.size(), e->stream));
    HIPCHK(upload(e->d_gene_off, e->gene_off.data(), e->gene_off.size(), e->stream));
+   if (e->kk == KK_VALU4 || e->kk == KK_VALU5) {      // pattern-major copy of the codes for the fused kernel
+      e->zpm_words = ((e->n_tips + 3) / 4 + 3) / 4 * 4;
+      HIPCHK(e->d_zpm.ensure((size_t)e->n_patt * e->zpm_words));
+      hipLaunchKernelGGL(zpm_kernel, dim3((e->n_patt + 255) / 256), dim3(256), 0, e->stream, e->d_z.p, (long)e->n_patt, e->n_tips, e->n_patt,
+                         e->zpm_words, e->d_zpm.p);
+   }
    HIPCHK(hipStreamSynchronize(e->stream));
    int r = build_tiles(e);
    if (r) return r;
@@ -1241,7 +1284,7 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
 {
    if (e) e->pipe_ok = false;
    if (!e || !branch || !lnL) return fail(e, PAML_AMD_EINVAL, "eval: null argument");
-   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, lnf != nullptr);
+   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, lnf != nullptr, nullptr, false, fhK != nullptr);
    if (r) return r;
    HIPCHK(hipMemcpyAsync(lnL, e->d_out.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
    if (lnf) HIPCHK(hipMemcpyAsync(lnf, e->d_lnf.p, (size_t)e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1258,7 +1301,7 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
    if (!e || !branch || !lnL || n_batch < 1) return fail(e, PAML_AMD_EINVAL, "eval_batch: bad arguments");
    if ((long)n_batch * e->K * e->n_genes > 65535) return fail(e, PAML_AMD_EINVAL, "eval_batch: n_batch * K * n_genes > 65535");
    BatchSpec bs{n_batch, eigen_of, qfactor, freqK, rate};
-   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, lnf != nullptr, &bs);
+   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, lnf != nullptr, &bs, false, false);
    if (r) return r;
    HIPCHK(hipMemcpyAsync(lnL, e->d_out.p, (size_t)n_batch * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    if (lnf)
@@ -1388,7 +1431,7 @@ int paml_amd_beb_grid_classes(paml_amd_engine *e, int n_grid, int n_cls, const d
 int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL)
 {
    if (!e || !branch || !d_lnL) return fail(e, PAML_AMD_EINVAL, "eval_device: null argument");
-   return launch_eval(e, branch, gene_rate, nullptr, d_lnL, false, nullptr, true);
+   return launch_eval(e, branch, gene_rate, nullptr, d_lnL, false, nullptr, true, false);
 }
 
 int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
@@ -1670,12 +1713,17 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
       for (int i = 0; i < n_nodes; i++)
          if (scale_node[i]) { t.scale_node[i] = 1; t.scale_slot[i] = t.n_scale++; }
    Program p = build_program(t, false, nullptr);
-   int n_states = compile >> 8;             // 0: the 61-state kernel; 4 / 5 / 20: the one-pattern-per-lane kernels;
+   const int fusedK = (compile & 2) ? (compile >> 16) & 0xff : 0, fusedNC = (compile >> 24) & 0xff;      // bit 1: the fused 4 / 5-state kernel
+   int n_states = (compile >> 8) & 0xff;    // 0: the 61-state kernel; 4 / 5 / 20: the one-pattern-per-lane kernels;
    compile &= 1;                            // 64 + n: the MFMA kernel trimmed to n states
    std::string text;
    if (n_states > 64) {
       if (!jit_supported(p, n_tips, 61)) return PAML_AMD_EUNSUPPORTED;
       text = jit_generate(p, n_tips, n_states - 64, n_states - 64);
+   }
+   else if (fusedK) {
+      if (!jit_valu_fused_plan(p, n_states, n_tips, fusedNC, fusedK).ok) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate_valu_fused(p, n_states, n_tips, fusedNC, fusedK);
    }
    else if (n_states == 4 || n_states == 5 || n_states == 20) {
       if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;

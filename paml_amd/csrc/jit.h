@@ -446,6 +446,193 @@ inline std::string jit_generate_valu(const Program &p, int N)
    return s.str();
 }
 
+// ---- fused variant (4 / 5 states): classes as the inner loop, tip factors from LDS tables, reduction in the epilogue --------
+// Specialised on the program, the number of states N, of character codes NC, of classes K and on whether the cherries' product
+// tables fit in LDS.  See the block comment at jvf_row_set (device_common.h) for the design.
+struct ValuFusedPlan {
+   bool ok = false;
+   bool cherry = false;      // product tables for SET_TIP2 cherries
+   int n_cherry = 0;
+   size_t lds_bytes = 0;
+};
+
+inline ValuFusedPlan jit_valu_fused_plan(const Program &p, int N, int n_tips, int n_codes, int K)
+{
+   ValuFusedPlan pl;
+   if (!jit_valu_supported(p) || (N != 4 && N != 5) || n_tips > 255 || K < 1) return pl;
+   for (const Op &o : p.ops)
+      if (o.code == OP_SET_TIP2) pl.n_cherry++;
+   const size_t rows = (size_t)K * n_tips * n_codes * N * 8;
+   const size_t ch = (size_t)K * pl.n_cherry * n_codes * n_codes * N * 8;
+   if (rows > 60 * 1024) return pl;                     // (the unfused kernel, gathering from L2, takes such models)
+   pl.ok = true;
+   pl.cherry = pl.n_cherry > 0 && n_codes <= 8 && rows + ch <= 56 * 1024;
+   pl.lds_bytes = rows + (pl.cherry ? ch : 0);
+   return pl;
+}
+
+inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, int n_codes, int K)
+{
+   const ValuFusedPlan pl = jit_valu_fused_plan(p, N, n_tips, n_codes, K);
+   std::ostringstream s;
+   const int NC = n_codes, ROWW = n_tips * NC * N, CHW = pl.cherry ? pl.n_cherry * NC * NC * N : 0, TABW = ROWW + CHW;   // doubles per class
+   const int ZW = ((n_tips + 3) / 4 + 3) / 4 * 4;      // dwords of packed codes per pattern
+   s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
+   s << "extern \"C\" __global__ __launch_bounds__(256) void prune_jit(PruneArgs a)\n{\n";
+   s << "   constexpr int N = " << N << ", NC = " << NC << ", K = " << K << ", NT = " << n_tips << ", ROWW = " << ROWW << ", TABW = " << TABW
+     << ", ZW = " << ZW << ";\n";
+   s << "   __shared__ __attribute__((aligned(16))) double sTab[K * TABW];\n";
+   s << "   const int tid = threadIdx.x, bat = blockIdx.y;\n";
+   s << "   const long cls0 = (long)bat * K;\n";
+   // tables: the tips are nodes 0 .. NT-1, so a class's rows are one contiguous run of pmat's output
+   s << "   for (int ir = 0; ir < K; ir++) {\n"
+        "      const double *src = a.ptip + (cls0 + ir) * a.n_nodes * a.tip_words;\n"
+        "      for (int i = tid; i < ROWW; i += 256) sTab[ir * TABW + i] = src[i];\n"
+        "   }\n   __syncthreads();\n";
+   if (pl.cherry) {
+      int c = 0;
+      s << "   for (int i = tid; i < K * NC * NC * N; i += 256) {\n"
+           "      const int ir = i / (NC * NC * N), r = i % (NC * NC * N), ca = r / (NC * N), cb = (r / N) % NC, j = r % N;\n"
+           "      const double *rw = sTab + ir * TABW;\n";
+      for (const Op &o : p.ops)
+         if (o.code == OP_SET_TIP2) {
+            s << "      sTab[ir * TABW + ROWW + " << c * NC * NC * N << " + r] = rw[(" << o.a << " * NC + ca) * N + j] * rw[(" << o.b << " * NC + cb) * N + j];\n";
+            c++;
+         }
+      s << "   }\n   __syncthreads();\n";
+   }
+   s << "   const long c_lo = (long)blockIdx.x * a.chunk, c_hi = (c_lo + a.chunk < (long)a.n_patt) ? c_lo + a.chunk : (long)a.n_patt;\n";
+   s << "   const CONST_AS double *fK = as_const(a.freqK + bat * a.freqK_bs);\n";
+   s << "   const CONST_AS double *pi = as_const(a.pi);\n";
+   s << "   double acc = 0;\n";
+   s << "   for (long h0 = c_lo; h0 < c_hi; h0 += 256) {\n";
+   s << "      const long h = h0 + tid;\n      const bool valid = h < c_hi;\n      const long hc = valid ? h : c_hi - 1;\n";
+   s << "      unsigned int zw[ZW];\n";
+   s << "      { const uint4 *zp = (const uint4 *)(a.zpm + hc * ZW);\n";
+   for (int i = 0; i < ZW / 4; i++)
+      s << "        { const uint4 t = zp[" << i << "]; zw[" << 4 * i << "] = t.x; zw[" << 4 * i + 1 << "] = t.y; zw[" << 4 * i + 2 << "] = t.z; zw[" << 4 * i + 3 << "] = t.w; }\n";
+   s << "      }\n";
+   s << "      const double wt = a.weights[hc];\n";
+   // per-pattern table offsets (in doubles), formed once and used by every class
+   {
+      int c = 0;
+      std::vector<char> in_cherry(n_tips, 0);
+      for (const Op &o : p.ops)
+         if (o.code == OP_SET_TIP2 && pl.cherry) {
+            s << "      const int oc" << c << " = ROWW + " << c * NC * NC * N << " + (JVF_CODE(" << o.a << ") * NC + JVF_CODE(" << o.b << ")) * N;\n";
+            in_cherry[o.a] = in_cherry[o.b] = 1;
+            c++;
+         }
+      for (const Op &o : p.ops) {
+         auto tipoff = [&](int t) {
+            if (!in_cherry[t]) { s << "      const int ot" << t << " = (" << t << " * NC + JVF_CODE(" << t << ")) * N;\n"; in_cherry[t] = 2; }
+         };
+         switch (o.code) {
+         case OP_SET_TIP: case OP_MUL_TIP: tipoff(o.a); break;
+         case OP_MUL_TIP2: tipoff(o.a); tipoff(o.b); break;
+         case OP_SET_TIP2: if (!pl.cherry) { tipoff(o.a); tipoff(o.b); } break;
+         default: break;
+         }
+      }
+   }
+   s << "      double fh = 0, v = 0;\n";
+   s << "      _Pragma(\"unroll 1\") for (int ir = 0; ir < K; ir++) {\n";
+   s << "         const double *Pint = a.pint + (cls0 + ir) * a.n_nodes * (N * N);\n";
+   s << "         const double *tab = sTab + ir * TABW;\n";
+   s << "         double lnscale = 0;\n         (void)lnscale;\n";
+   const int NA = p.max_stack + 2;
+   for (int i = 0; i < NA; i++) s << "         double A" << i << "[N];\n";
+   std::vector<int> freeA;
+   for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
+   auto alloc = [&]() { int r = freeA.back(); freeA.pop_back(); return r; };
+   auto release = [&](int r) { freeA.push_back(r); };
+   auto name = [&](int r) { return "A" + std::to_string(r); };
+   std::vector<int> slot(256, -1);
+   int cur = -1, ich = 0;
+   const char *LOOP = "_Pragma(\"unroll\") for (int j = 0; j < N; j++) ";
+   for (const Op &o : p.ops) {
+      switch (o.code) {
+      case OP_INIT_ONES:
+         if (cur < 0) cur = alloc();
+         s << "         " << LOOP << name(cur) << "[j] = 1.0;\n";
+         break;
+      case OP_INIT_TIP:
+         if (cur < 0) cur = alloc();
+         s << "         { const int c = JVF_CODE(" << o.a << "); " << LOOP << name(cur) << "[j] = (a.cleandata && j == c) ? 1.0 : 0.0; }\n";
+         break;
+      case OP_SET_TIP:
+         if (cur < 0) cur = alloc();
+         s << "         jvf_row_set<N>(" << name(cur) << ", tab + ot" << o.a << ");\n";
+         break;
+      case OP_MUL_TIP:
+         s << "         jvf_row_mul<N>(" << name(cur) << ", tab + ot" << o.a << ");\n";
+         break;
+      case OP_SET_TIP2:
+         if (cur < 0) cur = alloc();
+         if (pl.cherry) s << "         jvf_row_set<N>(" << name(cur) << ", tab + oc" << ich++ << ");\n";
+         else
+            s << "         { const double *r1 = tab + ot" << o.a << ", *r2 = tab + ot" << o.b << "; " << LOOP << name(cur) << "[j] = r1[j] * r2[j]; }\n";
+         break;
+      case OP_MUL_TIP2:
+         s << "         { const double *r1 = tab + ot" << o.a << ", *r2 = tab + ot" << o.b << "; " << LOOP << name(cur) << "[j] = (" << name(cur)
+           << "[j] * r1[j]) * r2[j]; }\n";
+         break;
+      case OP_PUSH:
+         slot[o.b] = cur;
+         cur = -1;
+         break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         const int pop = mm_pop_slot(o), push = mm_push_slot(o), out = alloc();
+         s << "         jv_matvec<N>(Pint + " << (long)o.a * N * N << ", " << name(cur) << ", " << name(out) << ");\n";
+         release(cur);
+         if (pop >= 0) {
+            s << "         " << LOOP << name(out) << "[j] = " << name(slot[pop]) << "[j] * " << name(out) << "[j];\n";
+            release(slot[pop]);
+            slot[pop] = -1;
+         }
+         if (push >= 0) { slot[push] = out; cur = -1; }
+         else cur = out;
+      } break;
+      case OP_SCALE:
+         s << "         lnscale += jv_scale<N>(" << name(cur) << ");\n";
+         break;
+      case OP_ROOT:
+         // fx_r treesub.c:7728-7749 / lfun 7780-7798, then this class's term of lfundG's mixture (7632-7652)
+         s << "         { double f = 0;\n            " << LOOP << "f = fma(pi[j], " << name(cur) << "[j], f);\n"
+           << "            if (a.mode == PAML_AMD_MODE_LFUN) { if (f <= 0) f = 1e-80; v = log(f) + lnscale; if (a.want_fhk && valid) a.fhK[(cls0 + ir) * a.n_patt + h] = wt > 0 ? v : 0.0; }\n"
+           << "            else {\n"
+           << "               if (f <= 0) f = 1e-300;\n"
+           << "               if (a.n_scale) { if (valid) a.fhK[(cls0 + ir) * a.n_patt + h] = wt > 0 ? log(f) + lnscale : 0.0; }\n"
+           << "               else { fh += fK[ir] * f; if (a.want_fhk && valid) a.fhK[(cls0 + ir) * a.n_patt + h] = wt > 0 ? f : 0.0; }\n"
+           << "            } }\n";
+         release(cur);
+         cur = -1;
+         break;
+      default: break;
+      }
+   }
+   s << "      }\n";      // classes
+   s << "      if (a.mode != PAML_AMD_MODE_LFUN) {\n"
+        "         if (a.n_scale) {      /* log-sum-exp around the first maximum (treesub.c:7640-7649) */\n"
+        "            const double *fk = a.fhK + cls0 * a.n_patt + hc;\n"
+        "            int it = 0;\n"
+        "            for (int ir = 1; ir < K; ir++) if (fk[(long)ir * a.n_patt] > fk[(long)it * a.n_patt]) it = ir;\n"
+        "            const double t = fk[(long)it * a.n_patt];\n"
+        "            fh = 0;\n"
+        "            for (int ir = 0; ir < K; ir++) fh += fK[ir] * exp(fk[(long)ir * a.n_patt] - t);\n"
+        "            v = t + log(fh);\n"
+        "         }\n"
+        "         else { if (fh <= 0) fh = 1e-300; v = log(fh); }\n"
+        "      }\n";
+   s << "      if (!(valid && wt > 0)) v = 0;\n";
+   s << "      if (valid) { acc += v * wt; if (a.lnf) a.lnf[(long)bat * a.n_patt + h] = v; }\n";
+   s << "   }\n";      // sub-tiles
+   s << "   red_block_finish(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + blockIdx.x, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat : nullptr);\n";
+   s << "}\n";
+   return s.str();
+}
+
 inline std::string jit_source_dir()
 {
    Dl_info info;

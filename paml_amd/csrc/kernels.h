@@ -853,6 +853,7 @@ struct ReduceArgs {
    double *out;        // scalar
    int n_patt, K, mode, n_scale, chunk;
    int first_chunk, nb_stride;
+   int *counter;       // [batch] tickets of red_block_finish (null: the total is formed by reduce_stage2 after the all-reduce)
 };
 
 __device__ __forceinline__ double pattern_lnf(const ReduceArgs &a, int h)
@@ -887,9 +888,23 @@ __global__ __launch_bounds__(128) void ztile_kernel(const int2 *tiles, const int
    for (int k = (n_tips + 1) * 128 + i; k < zt_bytes; k += 128) o[k] = 0;
 }
 
+// Tip codes pattern-major for the fused one-pattern-per-lane kernels: row h = zw dwords, byte t = code of tip t.
+__global__ __launch_bounds__(256) void zpm_kernel(const unsigned char *z, long z_stride, int n_tips, int n_patt, int zw, unsigned int *out)
+{
+   const long h = (long)blockIdx.x * 256 + threadIdx.x;
+   if (h >= n_patt) return;
+   for (int w = 0; w < zw; w++) {
+      unsigned int v = 0;
+      for (int b = 0; b < 4; b++) {
+         const int t = 4 * w + b;
+         if (t < n_tips) v |= (unsigned int)z[t * z_stride + h] << (8 * b);
+      }
+      out[h * zw + w] = v;
+   }
+}
+
 __global__ __launch_bounds__(256) void reduce_stage1(ReduceArgs a)
 {
-   __shared__ double sw[4];
    if (blockIdx.y) {
       const long off = (long)blockIdx.y * a.K * a.n_patt;
       a.fhK += off;
@@ -915,11 +930,7 @@ __global__ __launch_bounds__(256) void reduce_stage1(ReduceArgs a)
       }
       if (a.lnf) a.lnf[h] = v;
    }
-#pragma unroll
-   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
-   __syncthreads();
-   if (threadIdx.x == 0) a.partial[a.first_chunk + blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+   red_block_finish(acc, a.partial, a.first_chunk + blockIdx.x, a.nb_stride, a.out + blockIdx.y, a.counter ? a.counter + blockIdx.y : nullptr);
 }
 
 __global__ __launch_bounds__(256) void reduce_stage2(const double *partial, int nb, double *out)

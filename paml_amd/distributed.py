@@ -69,13 +69,21 @@ def chunk_partials(lnf, weights, first_pattern, n_patt_global):
 
 
 def total_fixed_order(partials):
-    """The fixed-order total of the (summed) partial array, as reduce_stage2 forms it: 256 strided lane sums, then a tree."""
+    """The fixed-order total of the (summed) partial array exactly as reduce_stage2 forms it on the device: 256 lanes sum the
+    entries i, i + 256, ... in turn; each 64-lane wave then runs the xor butterfly (offsets 32 ... 1; every lane ends with the
+    same bits, addition being commutative), and the four wave sums are combined as (w0 + w1) + (w2 + w3).  Pure additions, so
+    the host reproduces the device's bits."""
     lanes = np.zeros(256)
-    for i, v in enumerate(partials):
+    for i, v in enumerate(np.asarray(partials, dtype=np.float64)):
         lanes[i % 256] += v
-    while len(lanes) > 1:
-        lanes = lanes[0::2] + lanes[1::2]
-    return float(lanes[0])
+    waves = []
+    for w in range(4):
+        v = lanes[64 * w:64 * w + 64].copy()
+        idx = np.arange(64)
+        for off in (32, 16, 8, 4, 2, 1):
+            v = v + v[idx ^ off]
+        waves.append(v[0])
+    return float((waves[0] + waves[1]) + (waves[2] + waves[3]))
 
 
 def sharded_lnl(pb, lnf_of_shard, world: int, rank: int):

@@ -385,7 +385,7 @@ def debug_program(tree, scale_node=None, keep=False, clean=None):
     return [tuple(int(v) for v in r) for r in ops[:nops]], ms.value
 
 
-def debug_jit(tree, scale_node=None, compile=True, n_states=0):
+def debug_jit(tree, scale_node=None, compile=True, n_states=0, fused=None):
     """Host-only: source of the kernel specialised for `tree` (hiprtc-compiled for gfx950 when compile=True);
     n_states 4 / 5 / 20 selects the one-pattern-per-lane kernels, anything else the 61-state MFMA kernel."""
     L = lib()
@@ -394,7 +394,10 @@ def debug_jit(tree, scale_node=None, compile=True, n_states=0):
     cap = 1 << 20
     buf = C.create_string_buffer(cap)
     L.paml_amd_debug_jit.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int]
-    rc = L.paml_amd_debug_jit(tree.n_tips, tree.n_nodes, tree.root, _p(ptr), _p(flat), _p(sc), buf, cap, int(bool(compile)) | (int(n_states) << 8))
+    flags = int(bool(compile)) | (int(n_states) << 8)
+    if fused:      # (K classes, n_codes): the fused 4 / 5-state kernel
+        flags |= 2 | (int(fused[0]) << 16) | (int(fused[1]) << 24)
+    rc = L.paml_amd_debug_jit(tree.n_tips, tree.n_nodes, tree.root, _p(ptr), _p(flat), _p(sc), buf, cap, flags)
     if rc < 0:
         raise EngineError("debug_jit failed (%d): %s" % (rc, buf.value.decode(errors="replace")[-3000:]))
     return buf.value.decode()
