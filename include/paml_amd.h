@@ -225,7 +225,7 @@ int paml_amd_debug_program(int n_tips, int n_nodes, int root, const int *sons_pt
 /* Host-only: generate (and with compile != 0 also hiprtc-compile for gfx950, no GPU needed) the kernel
  * specialised for a tree (paml_amd/csrc/jit.h).  compile: bit 0 = compile; bits 8..15 = n_states (4, 5 or 20 select the
  * one-pattern-per-lane kernel, 64 + n the MFMA kernel trimmed to n states, anything else the 61-state MFMA kernel); bit 1 = the
- * fused 4 / 5-state kernel for K = bits 16..23 classes and bits 24..31 character codes.  Returns the source length, or a negative error
+ * fused 4 / 5-state kernel for K = bits 16..23 classes, bits 24..31 character codes and a reduction chunk of 256 x bits 2..7 patterns.  Returns the source length, or a negative error
  * with the compiler log in text_out. */
 int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, const int *sons,
                        const unsigned char *scale_node, char *text_out, int cap, int compile);

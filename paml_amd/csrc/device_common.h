@@ -545,35 +545,39 @@ __device__ __forceinline__ void jv_root(const PruneArgs &a, const double (&x)[N]
 // Fixed-order total of nb partial sums by one 256-thread workgroup (what reduce_stage2 does): lane sums over i, i + 256, ...
 // then the butterfly and the four waves.  `coherent`: the partials were written by other workgroups of the SAME launch —
 // read them past the (non-coherent) L1.
+template <int GROUPS = 1>
 __device__ __forceinline__ double red_total256(const double *partial, int nb, bool coherent, double *sw4)
 {
    double acc = 0;
-   for (int i = threadIdx.x; i < nb; i += 256) {
-      double v;
-      if (coherent) {
-         const unsigned long long u = __hip_atomic_load((const unsigned long long *)(partial + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-         v = __longlong_as_double((long long)u);
+   if (GROUPS == 1 || threadIdx.x < 256)      // (GROUPS > 1: a workgroup of 256 x GROUPS threads; the first 256 do the sums,
+      for (int i = threadIdx.x; i < nb; i += 256) {      //  all of them take part in the barriers)
+         double v;
+         if (coherent) {
+            const unsigned long long u = __hip_atomic_load((const unsigned long long *)(partial + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __longlong_as_double((long long)u);
+         }
+         else v = partial[i];
+         acc += v;
       }
-      else v = partial[i];
-      acc += v;
-   }
 #pragma unroll
    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
    __syncthreads();
-   if ((threadIdx.x & 63) == 0) sw4[threadIdx.x >> 6] = acc;
+   if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) sw4[threadIdx.x >> 6] = acc;
    __syncthreads();
    return (sw4[0] + sw4[1]) + (sw4[2] + sw4[3]);
 }
 
 // A workgroup's weighted sum -> its slot of the global partial array; with a counter, the workgroup that finishes last also
 // forms the total (single GPU: no separate stage-2 launch).  The order of every sum is fixed, so the result is deterministic.
+// (GROUPS > 1: a workgroup of 256 x GROUPS threads whose first 256 hold the sums; the others only take part in the barriers.)
+template <int GROUPS = 1>
 __device__ __forceinline__ void red_block_finish(double acc, double *partial_row, int slot, int nb_total, double *out, int *counter)
 {
    __shared__ double sw[4];
    __shared__ int s_last;
 #pragma unroll
    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+   if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) sw[threadIdx.x >> 6] = acc;
    __syncthreads();
    if (threadIdx.x == 0) {
       partial_row[slot] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
@@ -587,7 +591,7 @@ __device__ __forceinline__ void red_block_finish(double acc, double *partial_row
    __syncthreads();
    if (s_last) {
       __threadfence();
-      const double tot = red_total256(partial_row, nb_total, true, sw);
+      const double tot = red_total256<GROUPS>(partial_row, nb_total, true, sw);
       if (threadIdx.x == 0) {
          *out = tot;
          *counter = 0;      // ready for the next launch on this stream

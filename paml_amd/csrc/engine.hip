@@ -186,7 +186,10 @@ struct paml_amd_engine {
    DevBuf<unsigned int> d_zpm;        // fused 4 / 5-state kernel: tip codes pattern-major
    int zpm_words = 0;
    DevBuf<int> d_red_counter;         // "last workgroup adds up the partial sums" tickets, one per batch element
+   double *h_out = nullptr;           // pinned, device-visible: the synchronous entry points have lnL written straight to the host
+   size_t h_out_cap = 0;
    bool fused = false;                // the selected kernel forms the reduction itself
+   int fused_threads = 256;
    bool pmat_valid = false;           // d_rowmajor holds the P(t) of an evaluation in the tree's own orientation
 
    // data
@@ -261,6 +264,7 @@ struct paml_amd_engine {
       for (auto &e : eigen) { e.U.release(); e.V.release(); e.Root.release(); e.Cijk.release(); }
       stage.release();
       if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
+      if (h_out) (void)hipHostFree(h_out);
       if (d_prof) (void)hipFree(d_prof);
       if (jit.mod) (void)hipModuleUnload(jit.mod);
       for (auto ev : ev_pool) (void)hipEventDestroy(ev);
@@ -341,6 +345,17 @@ void mark_on(paml_amd_engine *e, hipStream_t s)
    if (ev) (void)hipEventRecord(ev, s);
 }
 void mark(paml_amd_engine *e) { mark_on(e, e->stream); }
+
+// Pinned host memory the kernels can write: the synchronous entry points get their scalars without a device-to-host copy.
+int ensure_hout(paml_amd_engine *e, size_t n)
+{
+   if (n <= e->h_out_cap) return 0;
+   if (e->h_out) (void)hipHostFree(e->h_out);
+   e->h_out = nullptr; e->h_out_cap = 0;
+   HIPCHK(hipHostMalloc((void **)&e->h_out, std::max<size_t>(n, 64) * sizeof(double), hipHostMallocDefault));
+   e->h_out_cap = std::max<size_t>(n, 64);
+   return 0;
+}
 
 int build_tiles(paml_amd_engine *e)
 {
@@ -446,6 +461,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
    }
    // the fast path of consecutive eval_device calls (see pipe_ok): nothing but branch lengths / gene rates may have changed
+   // (worth its event traffic only where the pruning kernel is long: the 21..64-state kernels on >= 10^5 pattern-classes)
+   want_pipe = want_pipe && e->kk == KK_MFMA64 && (long)e->n_patt * e->K >= 100000;
    const bool pipe = want_pipe && e->pipe_ok && !bs && !clean && !keep && !new_prog && !e->eigen_dirty && !e->env.no_pipeline;
    if (want_pipe && !e->s2) {
       HIPCHK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
@@ -470,8 +487,17 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
    }
 
-   // small per-evaluation inputs go through the pinned arena: async H2D, no host stall
-   {
+   // branch lengths and gene rates of a single evaluation ride in the kernel arguments of P(t) (InlineVec): no copy at all
+   InlineVec iv;
+   iv.n_branch = iv.n_rate = 0;
+   const bool use_inline = B == 1 && nn + G <= PMAT_INLINE_MAX;
+   if (use_inline) {
+      iv.n_branch = nn; iv.n_rate = G;
+      memcpy(iv.v, branch, (size_t)nn * sizeof(double));
+      for (int g = 0; g < G; g++) iv.v[nn + g] = gene_rate ? gene_rate[g] : 1.0;
+   }
+   // the other small inputs (and the batched ones) go through the pinned arena: async H2D, no host stall
+   if (!use_inline || bs || !tab.empty() || new_prog) {
       const size_t L = (size_t)e->n_labels;
       const size_t need = (size_t)B * nn * 8 + (size_t)B * G * 8 + tab.size() * sizeof(EigenDev) +
                           (bs ? (size_t)B * (G * Km * L * 4 + Km * L * 8 + 2 * Km * 8) + 64 : 0) +
@@ -480,12 +506,14 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       DevBuf<double> &dbr = pipe ? e->d2_branch : e->d_branch, &dgr = pipe ? e->d2_gene_rate : e->d_gene_rate;   // (the side stream has its own)
       HIPCHK(dbr.ensure((size_t)B * nn));
       HIPCHK(dgr.ensure((size_t)B * G));
-      const double *hb = e->stage.put(branch, (size_t)B * nn);
-      HIPCHK(hipMemcpyAsync(dbr.p, hb, (size_t)B * nn * 8, hipMemcpyHostToDevice, ps));
-      std::vector<double> gr((size_t)B * G, 1.0);
-      if (gene_rate) gr.assign(gene_rate, gene_rate + (size_t)B * G);
-      const double *hg = e->stage.put(gr.data(), gr.size());
-      HIPCHK(hipMemcpyAsync(dgr.p, hg, gr.size() * 8, hipMemcpyHostToDevice, ps));
+      if (!use_inline) {
+         const double *hb = e->stage.put(branch, (size_t)B * nn);
+         HIPCHK(hipMemcpyAsync(dbr.p, hb, (size_t)B * nn * 8, hipMemcpyHostToDevice, ps));
+         std::vector<double> gr((size_t)B * G, 1.0);
+         if (gene_rate) gr.assign(gene_rate, gene_rate + (size_t)B * G);
+         const double *hg = e->stage.put(gr.data(), gr.size());
+         HIPCHK(hipMemcpyAsync(dgr.p, hg, gr.size() * 8, hipMemcpyHostToDevice, ps));
+      }
       if (bs) {      // per-element class tables
          if (bs->eigen_of) {
             const size_t cnt = (size_t)B * G * Km * L;
@@ -595,12 +623,14 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       // (20 states: the unrolled walk needs > 256 VGPRs and runs at one wave per SIMD, slower than the interpreter)
       if (e->jit_enabled && !keep && n <= 5 && jit_valu_supported(e->prog)) {
          // the fused form (classes inside, LDS tip tables, reduction in the epilogue) when the model fits it
-         const ValuFusedPlan pl = jit_valu_fused_plan(e->prog, n, e->n_tips, e->n_codes, Km);
+         const ValuFusedPlan pl = jit_valu_fused_plan(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk);
          if (pl.ok && G == 1 && e->n_pi == 1 && e->d_zpm.p && !e->env.no_fused) {
-            int r = ensure_jit(e, "vf" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "k" + std::to_string(Km) + ":" + jit_program_key(e->prog, e->n_tips),
-                               [&]() { return jit_generate_valu_fused(e->prog, n, e->n_tips, e->n_codes, Km); }, &jit_ok);
+            int r = ensure_jit(e, "vf" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "k" + std::to_string(Km) + "r" + std::to_string(pl.R) + "w" +
+                                     std::to_string(pl.CW) + (pl.cherry ? "y:" : "n:") + jit_program_key(e->prog, e->n_tips),
+                               [&]() { return jit_generate_valu_fused(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk); }, &jit_ok);
             if (r) return r;
             fused = jit_ok;
+            e->fused_threads = 256 * pl.CW;
          }
          if (!jit_ok) {
             int r = ensure_jit(e, "v" + std::to_string(n) + ":" + jit_program_key(e->prog, e->n_tips),
@@ -639,7 +669,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    if (bs && bs->qfactor) { pa.qfactor = e->d_b_qfactor.p; pa.qfactor_bs = (long)Km * e->n_labels; }
    if (bs && bs->rate) { pa.rate = e->d_b_rate.p; pa.rate_bs = Km; }
    mark_on(e, ps);
-   hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), ps, pa);
+   bool small_pmat = e->kk != KK_MFMA64 && n <= 5;
+   for (const EigenHost &h : e->eigen) small_pmat = small_pmat && h.kind != PAML_AMD_EIGEN_QMAT;
+   if (small_pmat) hipLaunchKernelGGL(pmat_small_kernel, dim3((nn * psets + 7) / 8), dim3(256), 0, ps, pa, iv);
+   else hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), ps, pa, iv);
    mark_on(e, ps);
    if (pipe) {      // the pruning kernel (main stream) starts when this P(t) is there
       HIPCHK(hipEventRecord(e->ev_pmat, e->s2));
@@ -723,7 +756,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    case KK_VALU20:
       if (fused) {
          void *params[] = {&pr};
-         HIPCHK(hipModuleLaunchKernel(e->jit.fn, nb, B, 1, 256, 1, 1, 0, e->stream, params, nullptr));
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, nb, B, 1, e->fused_threads, 1, 1, 0, e->stream, params, nullptr));
       }
       else if (e->use_jit) {
          void *params[] = {&pr};
@@ -884,7 +917,11 @@ int rerooted_pmat(paml_amd_engine *e, int new_root, int cut_son, const double *b
    pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
    pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
    pa.B = 1;
-   hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), e->stream, pa);
+   {
+      InlineVec iv;
+      iv.n_branch = iv.n_rate = 0;
+      hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), e->stream, pa, iv);
+   }
    e->n_pmat += (long)psets * (nn - 1);
    e->prog_valid = false;      // d_branch / P buffers now hold the re-rooted edge data: the next eval rebuilds
    e->partials_valid = false;
@@ -1284,13 +1321,15 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
 {
    if (e) e->pipe_ok = false;
    if (!e || !branch || !lnL) return fail(e, PAML_AMD_EINVAL, "eval: null argument");
-   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, lnf != nullptr, nullptr, false, fhK != nullptr);
+   int r = ensure_hout(e, 1);
    if (r) return r;
-   HIPCHK(hipMemcpyAsync(lnL, e->d_out.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   r = launch_eval(e, branch, gene_rate, nullptr, e->h_out, lnf != nullptr, nullptr, false, fhK != nullptr);
+   if (r) return r;
    if (lnf) HIPCHK(hipMemcpyAsync(lnf, e->d_lnf.p, (size_t)e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    if (fhK)
       HIPCHK(hipMemcpyAsync(fhK, e->d_fhK.p, (size_t)e->K * e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
+   *lnL = e->h_out[0];
    return 0;
 }
 
@@ -1301,12 +1340,14 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
    if (!e || !branch || !lnL || n_batch < 1) return fail(e, PAML_AMD_EINVAL, "eval_batch: bad arguments");
    if ((long)n_batch * e->K * e->n_genes > 65535) return fail(e, PAML_AMD_EINVAL, "eval_batch: n_batch * K * n_genes > 65535");
    BatchSpec bs{n_batch, eigen_of, qfactor, freqK, rate};
-   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, lnf != nullptr, &bs, false, false);
+   int r = ensure_hout(e, n_batch);
    if (r) return r;
-   HIPCHK(hipMemcpyAsync(lnL, e->d_out.p, (size_t)n_batch * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   r = launch_eval(e, branch, gene_rate, nullptr, e->h_out, lnf != nullptr, &bs, false, false);
+   if (r) return r;
    if (lnf)
       HIPCHK(hipMemcpyAsync(lnf, e->d_lnf.p, (size_t)n_batch * e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
+   memcpy(lnL, e->h_out, (size_t)n_batch * sizeof(double));
    return 0;
 }
 
@@ -1439,10 +1480,12 @@ int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *
 {
    if (e) e->pipe_ok = false;
    if (!e || !branch || !lnL || !clean) return fail(e, PAML_AMD_EINVAL, "eval_dirty: null argument");
-   int r = launch_eval(e, branch, gene_rate, clean, nullptr, false);
+   int r = ensure_hout(e, 1);
    if (r) return r;
-   HIPCHK(hipMemcpyAsync(lnL, e->d_out.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   r = launch_eval(e, branch, gene_rate, clean, e->h_out, false);
+   if (r) return r;
    HIPCHK(hipStreamSynchronize(e->stream));
+   *lnL = e->h_out[0];
    return 0;
 }
 
@@ -1715,15 +1758,17 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
    Program p = build_program(t, false, nullptr);
    const int fusedK = (compile & 2) ? (compile >> 16) & 0xff : 0, fusedNC = (compile >> 24) & 0xff;      // bit 1: the fused 4 / 5-state kernel
    int n_states = (compile >> 8) & 0xff;    // 0: the 61-state kernel; 4 / 5 / 20: the one-pattern-per-lane kernels;
-   compile &= 1;                            // 64 + n: the MFMA kernel trimmed to n states
+   const int compile_all = compile;         // 64 + n: the MFMA kernel trimmed to n states
+   compile &= 1;
    std::string text;
    if (n_states > 64) {
       if (!jit_supported(p, n_tips, 61)) return PAML_AMD_EUNSUPPORTED;
       text = jit_generate(p, n_tips, n_states - 64, n_states - 64);
    }
    else if (fusedK) {
-      if (!jit_valu_fused_plan(p, n_states, n_tips, fusedNC, fusedK).ok) return PAML_AMD_EUNSUPPORTED;
-      text = jit_generate_valu_fused(p, n_states, n_tips, fusedNC, fusedK);
+      const int chunk = (compile_all >> 2) & 0x3f ? ((compile_all >> 2) & 0x3f) * 256 : 256;      // bits 2..7: reduction chunk / 256
+      if (!jit_valu_fused_plan(p, n_states, n_tips, fusedNC, fusedK, chunk).ok) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate_valu_fused(p, n_states, n_tips, fusedNC, fusedK, chunk);
    }
    else if (n_states == 4 || n_states == 5 || n_states == 20) {
       if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;

@@ -447,51 +447,71 @@ inline std::string jit_generate_valu(const Program &p, int N)
 }
 
 // ---- fused variant (4 / 5 states): classes as the inner loop, tip factors from LDS tables, reduction in the epilogue --------
-// Specialised on the program, the number of states N, of character codes NC, of classes K and on whether the cherries' product
-// tables fit in LDS.  See the block comment at jvf_row_set (device_common.h) for the design.
+// Specialised on the program, the number of states N, of character codes NC, of classes K and on the shape below.
+// See the block comment at jvf_row_set (device_common.h) for the design.
+//   R  = patterns per lane (1 or 2): with two, every P(t) entry fetched through the scalar cache feeds two FMAs and the
+//        waits on those fetches come half as often — the big-problem shape;
+//   CW = class groups per workgroup (1, 2 or 4): the workgroup has 256 x CW threads, group g walks the classes g, g + CW, ...
+//        of the chunk's 256 patterns and the mixture is summed (in class order) by group 0 from an LDS exchange — the
+//        small-problem shape: a data set of 10^5 patterns is only ~1.5 waves per SIMD otherwise.
 struct ValuFusedPlan {
    bool ok = false;
    bool cherry = false;      // product tables for SET_TIP2 cherries
-   int n_cherry = 0;
+   int n_cherry = 0, R = 1, CW = 1;
    size_t lds_bytes = 0;
 };
 
-inline ValuFusedPlan jit_valu_fused_plan(const Program &p, int N, int n_tips, int n_codes, int K)
+inline ValuFusedPlan jit_valu_fused_plan(const Program &p, int N, int n_tips, int n_codes, int K, int chunk)
 {
    ValuFusedPlan pl;
    if (!jit_valu_supported(p) || (N != 4 && N != 5) || n_tips > 255 || K < 1) return pl;
    for (const Op &o : p.ops)
       if (o.code == OP_SET_TIP2) pl.n_cherry++;
+   // shape: a function of the (global) chunk size only, so that every rank of a sharded evaluation picks the same kernel
+   // (measured on MI355X, 32 taxa x Gamma-4: two class groups beat one and four at 10^5 and at 4 x 10^6 patterns — more waves to
+   //  hide the scalar-cache latency of the P(t) fetches than one group, a smaller P(t) working set than four; two patterns per
+   //  lane cost more in registers than they save: profiles/r02_valu_fused_shapes.txt)
+   (void)chunk;
+   pl.CW = K >= 2 ? 2 : 1;
+   pl.R = 1;
+   if (const char *v = getenv("PAML_AMD_VF_R")) pl.R = atoi(v) == 2 && chunk >= 512 ? 2 : 1;
+   if (const char *v = getenv("PAML_AMD_VF_CW")) pl.CW = std::max(1, std::min(std::min(4, K), atoi(v)));
+   if (pl.CW == 3) pl.CW = 2;
+   if (pl.CW > 1) pl.R = 1;
    const size_t rows = (size_t)K * n_tips * n_codes * N * 8;
    const size_t ch = (size_t)K * pl.n_cherry * n_codes * n_codes * N * 8;
-   if (rows > 60 * 1024) return pl;                     // (the unfused kernel, gathering from L2, takes such models)
+   const size_t xch = pl.CW > 1 ? (size_t)K * 256 * 8 : 0;
+   if (rows + xch > 60 * 1024) return pl;               // (the unfused kernel, gathering from L2, takes such models)
    pl.ok = true;
-   pl.cherry = pl.n_cherry > 0 && n_codes <= 8 && rows + ch <= 56 * 1024;
-   pl.lds_bytes = rows + (pl.cherry ? ch : 0);
+   pl.cherry = pl.n_cherry > 0 && n_codes <= 8 && rows + ch + xch <= 56 * 1024 && !getenv("PAML_AMD_VF_NOCHERRY");
+   pl.lds_bytes = rows + (pl.cherry ? ch : 0) + xch;
    return pl;
 }
 
-inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, int n_codes, int K)
+inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, int n_codes, int K, int chunk)
 {
-   const ValuFusedPlan pl = jit_valu_fused_plan(p, N, n_tips, n_codes, K);
+   const ValuFusedPlan pl = jit_valu_fused_plan(p, N, n_tips, n_codes, K, chunk);
    std::ostringstream s;
+   const int R = pl.R, CW = pl.CW;
    const int NC = n_codes, ROWW = n_tips * NC * N, CHW = pl.cherry ? pl.n_cherry * NC * NC * N : 0, TABW = ROWW + CHW;   // doubles per class
    const int ZW = ((n_tips + 3) / 4 + 3) / 4 * 4;      // dwords of packed codes per pattern
+   const int NTH = 256 * CW;
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
-   s << "extern \"C\" __global__ __launch_bounds__(256) void prune_jit(PruneArgs a)\n{\n";
+   s << "extern \"C\" __global__ __launch_bounds__(" << NTH << (R > 1 ? ", 2" : "") << ") void prune_jit(PruneArgs a)\n{\n";
    s << "   constexpr int N = " << N << ", NC = " << NC << ", K = " << K << ", NT = " << n_tips << ", ROWW = " << ROWW << ", TABW = " << TABW
-     << ", ZW = " << ZW << ";\n";
+     << ", ZW = " << ZW << ", CW = " << CW << ", NTH = " << NTH << ";\n   (void)NT;\n";
    s << "   __shared__ __attribute__((aligned(16))) double sTab[K * TABW];\n";
-   s << "   const int tid = threadIdx.x, bat = blockIdx.y;\n";
+   if (CW > 1) s << "   __shared__ double sF[K * 256];\n";
+   s << "   const int tid = threadIdx.x & 255, cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), bat = blockIdx.y;\n   (void)cw;\n";
    s << "   const long cls0 = (long)bat * K;\n";
    // tables: the tips are nodes 0 .. NT-1, so a class's rows are one contiguous run of pmat's output
    s << "   for (int ir = 0; ir < K; ir++) {\n"
         "      const double *src = a.ptip + (cls0 + ir) * a.n_nodes * a.tip_words;\n"
-        "      for (int i = tid; i < ROWW; i += 256) sTab[ir * TABW + i] = src[i];\n"
+        "      for (int i = threadIdx.x; i < ROWW; i += NTH) sTab[ir * TABW + i] = src[i];\n"
         "   }\n   __syncthreads();\n";
    if (pl.cherry) {
       int c = 0;
-      s << "   for (int i = tid; i < K * NC * NC * N; i += 256) {\n"
+      s << "   for (int i = threadIdx.x; i < K * NC * NC * N; i += NTH) {\n"
            "      const int ir = i / (NC * NC * N), r = i % (NC * NC * N), ca = r / (NC * N), cb = (r / N) % NC, j = r % N;\n"
            "      const double *rw = sTab + ir * TABW;\n";
       for (const Op &o : p.ops)
@@ -505,130 +525,143 @@ inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, 
    s << "   const CONST_AS double *fK = as_const(a.freqK + bat * a.freqK_bs);\n";
    s << "   const CONST_AS double *pi = as_const(a.pi);\n";
    s << "   double acc = 0;\n";
-   s << "   for (long h0 = c_lo; h0 < c_hi; h0 += 256) {\n";
-   s << "      const long h = h0 + tid;\n      const bool valid = h < c_hi;\n      const long hc = valid ? h : c_hi - 1;\n";
-   s << "      unsigned int zw[ZW];\n";
-   s << "      { const uint4 *zp = (const uint4 *)(a.zpm + hc * ZW);\n";
-   for (int i = 0; i < ZW / 4; i++)
-      s << "        { const uint4 t = zp[" << i << "]; zw[" << 4 * i << "] = t.x; zw[" << 4 * i + 1 << "] = t.y; zw[" << 4 * i + 2 << "] = t.z; zw[" << 4 * i + 3 << "] = t.w; }\n";
-   s << "      }\n";
-   s << "      const double wt = a.weights[hc];\n";
-   // per-pattern table offsets (in doubles), formed once and used by every class
-   {
+   s << "   for (long h0 = c_lo; h0 < c_hi; h0 += " << 256 * R << ") {\n";
+   auto sfx = [&](int r) { return R > 1 ? "_" + std::to_string(r) : std::string(); };
+   for (int r = 0; r < R; r++) {
+      const std::string x = sfx(r);
+      s << "      const long h" << x << " = h0 + " << 256 * r << " + tid;\n      const bool valid" << x << " = h" << x << " < c_hi;\n      const long hc" << x
+        << " = valid" << x << " ? h" << x << " : c_hi - 1;\n";
+      s << "      unsigned int zw" << x << "[ZW];\n";
+      s << "      { const uint4 *zp = (const uint4 *)(a.zpm + hc" << x << " * ZW);\n";
+      for (int i = 0; i < ZW / 4; i++)
+         s << "        { const uint4 t = zp[" << i << "]; zw" << x << "[" << 4 * i << "] = t.x; zw" << x << "[" << 4 * i + 1 << "] = t.y; zw" << x << "[" << 4 * i + 2
+           << "] = t.z; zw" << x << "[" << 4 * i + 3 << "] = t.w; }\n";
+      s << "      }\n";
+      s << "      const double wt" << x << " = a.weights[hc" << x << "];\n";
+      // per-pattern table offsets (in doubles), formed once and used by every class
+      s << "#define zw zw" << x << "\n";
       int c = 0;
-      std::vector<char> in_cherry(n_tips, 0);
+      std::vector<char> seen(n_tips, 0);
       for (const Op &o : p.ops)
          if (o.code == OP_SET_TIP2 && pl.cherry) {
-            s << "      const int oc" << c << " = ROWW + " << c * NC * NC * N << " + (JVF_CODE(" << o.a << ") * NC + JVF_CODE(" << o.b << ")) * N;\n";
-            in_cherry[o.a] = in_cherry[o.b] = 1;
+            s << "      const int oc" << c << x << " = ROWW + " << c * NC * NC * N << " + (JVF_CODE(" << o.a << ") * NC + JVF_CODE(" << o.b << ")) * N;\n";
+            seen[o.a] = seen[o.b] = 1;
             c++;
          }
       for (const Op &o : p.ops) {
          auto tipoff = [&](int t) {
-            if (!in_cherry[t]) { s << "      const int ot" << t << " = (" << t << " * NC + JVF_CODE(" << t << ")) * N;\n"; in_cherry[t] = 2; }
+            if (!seen[t]) { s << "      const int ot" << t << x << " = (" << t << " * NC + JVF_CODE(" << t << ")) * N;\n"; seen[t] = 2; }
          };
          switch (o.code) {
          case OP_SET_TIP: case OP_MUL_TIP: tipoff(o.a); break;
          case OP_MUL_TIP2: tipoff(o.a); tipoff(o.b); break;
          case OP_SET_TIP2: if (!pl.cherry) { tipoff(o.a); tipoff(o.b); } break;
+         case OP_INIT_TIP: s << "      const int ci" << o.a << x << " = JVF_CODE(" << o.a << ");\n"; break;
          default: break;
          }
       }
+      s << "#undef zw\n";
+      s << "      double fh" << x << " = 0, v" << x << " = 0;\n";
    }
-   s << "      double fh = 0, v = 0;\n";
-   s << "      _Pragma(\"unroll 1\") for (int ir = 0; ir < K; ir++) {\n";
+   s << "      _Pragma(\"unroll 1\") for (int ir = " << (CW > 1 ? "cw" : "0") << "; ir < K; ir += CW) {\n";
    s << "         const double *Pint = a.pint + (cls0 + ir) * a.n_nodes * (N * N);\n";
    s << "         const double *tab = sTab + ir * TABW;\n";
-   s << "         double lnscale = 0;\n         (void)lnscale;\n";
    const int NA = p.max_stack + 2;
-   for (int i = 0; i < NA; i++) s << "         double A" << i << "[N];\n";
+   for (int r = 0; r < R; r++) {
+      s << "         double lnscale" << sfx(r) << " = 0;\n         (void)lnscale" << sfx(r) << ";\n";
+      for (int i = 0; i < NA; i++) s << "         double A" << i << sfx(r) << "[N];\n";
+   }
    std::vector<int> freeA;
    for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
    auto alloc = [&]() { int r = freeA.back(); freeA.pop_back(); return r; };
    auto release = [&](int r) { freeA.push_back(r); };
-   auto name = [&](int r) { return "A" + std::to_string(r); };
+   auto name = [&](int a, int r) { return "A" + std::to_string(a) + sfx(r); };
    std::vector<int> slot(256, -1);
    int cur = -1, ich = 0;
    const char *LOOP = "_Pragma(\"unroll\") for (int j = 0; j < N; j++) ";
    for (const Op &o : p.ops) {
-      switch (o.code) {
-      case OP_INIT_ONES:
+      int out = -1, pop = -1, push = -1, curin = cur;
+      if (o.code == OP_INIT_ONES || o.code == OP_INIT_TIP || o.code == OP_SET_TIP || o.code == OP_SET_TIP2) {
          if (cur < 0) cur = alloc();
-         s << "         " << LOOP << name(cur) << "[j] = 1.0;\n";
-         break;
-      case OP_INIT_TIP:
-         if (cur < 0) cur = alloc();
-         s << "         { const int c = JVF_CODE(" << o.a << "); " << LOOP << name(cur) << "[j] = (a.cleandata && j == c) ? 1.0 : 0.0; }\n";
-         break;
-      case OP_SET_TIP:
-         if (cur < 0) cur = alloc();
-         s << "         jvf_row_set<N>(" << name(cur) << ", tab + ot" << o.a << ");\n";
-         break;
-      case OP_MUL_TIP:
-         s << "         jvf_row_mul<N>(" << name(cur) << ", tab + ot" << o.a << ");\n";
-         break;
-      case OP_SET_TIP2:
-         if (cur < 0) cur = alloc();
-         if (pl.cherry) s << "         jvf_row_set<N>(" << name(cur) << ", tab + oc" << ich++ << ");\n";
-         else
-            s << "         { const double *r1 = tab + ot" << o.a << ", *r2 = tab + ot" << o.b << "; " << LOOP << name(cur) << "[j] = r1[j] * r2[j]; }\n";
-         break;
-      case OP_MUL_TIP2:
-         s << "         { const double *r1 = tab + ot" << o.a << ", *r2 = tab + ot" << o.b << "; " << LOOP << name(cur) << "[j] = (" << name(cur)
-           << "[j] * r1[j]) * r2[j]; }\n";
-         break;
-      case OP_PUSH:
-         slot[o.b] = cur;
-         cur = -1;
-         break;
-      case OP_MATMUL:
-      case OP_MATMUL_POP: {
-         const int pop = mm_pop_slot(o), push = mm_push_slot(o), out = alloc();
-         s << "         jv_matvec<N>(Pint + " << (long)o.a * N * N << ", " << name(cur) << ", " << name(out) << ");\n";
-         release(cur);
-         if (pop >= 0) {
-            s << "         " << LOOP << name(out) << "[j] = " << name(slot[pop]) << "[j] * " << name(out) << "[j];\n";
-            release(slot[pop]);
-            slot[pop] = -1;
+         curin = cur;
+      }
+      if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) { pop = mm_pop_slot(o); push = mm_push_slot(o); out = alloc(); }
+      for (int r = 0; r < R; r++) {
+         const std::string x = sfx(r), C = name(curin, r);
+         switch (o.code) {
+         case OP_INIT_ONES: s << "         " << LOOP << C << "[j] = 1.0;\n"; break;
+         case OP_INIT_TIP: s << "         " << LOOP << C << "[j] = (a.cleandata && j == ci" << o.a << x << ") ? 1.0 : 0.0;\n"; break;
+         case OP_SET_TIP: s << "         jvf_row_set<N>(" << C << ", tab + ot" << o.a << x << ");\n"; break;
+         case OP_MUL_TIP: s << "         jvf_row_mul<N>(" << C << ", tab + ot" << o.a << x << ");\n"; break;
+         case OP_SET_TIP2:
+            if (pl.cherry) s << "         jvf_row_set<N>(" << C << ", tab + oc" << ich << x << ");\n";
+            else
+               s << "         { const double *r1 = tab + ot" << o.a << x << ", *r2 = tab + ot" << o.b << x << "; " << LOOP << C << "[j] = r1[j] * r2[j]; }\n";
+            break;
+         case OP_MUL_TIP2:
+            s << "         { const double *r1 = tab + ot" << o.a << x << ", *r2 = tab + ot" << o.b << x << "; " << LOOP << C << "[j] = (" << C << "[j] * r1[j]) * r2[j]; }\n";
+            break;
+         case OP_MATMUL:
+         case OP_MATMUL_POP:
+            s << "         jv_matvec<N>(Pint + " << (long)o.a * N * N << ", " << C << ", " << name(out, r) << ");\n";
+            if (pop >= 0) s << "         " << LOOP << name(out, r) << "[j] = " << name(slot[pop], r) << "[j] * " << name(out, r) << "[j];\n";
+            break;
+         case OP_SCALE: s << "         lnscale" << x << " += jv_scale<N>(" << C << ");\n"; break;
+         case OP_ROOT:
+            // fx_r treesub.c:7728-7749 / lfun 7780-7798, then this class's term of lfundG's mixture (7632-7652)
+            s << "         { double f = 0;\n            " << LOOP << "f = fma(pi[j], " << C << "[j], f);\n"
+              << "            if (a.mode == PAML_AMD_MODE_LFUN) { if (f <= 0) f = 1e-80; v" << x << " = log(f) + lnscale" << x << "; if (a.want_fhk && valid" << x
+              << ") a.fhK[(cls0 + ir) * a.n_patt + h" << x << "] = wt" << x << " > 0 ? v" << x << " : 0.0; }\n"
+              << "            else {\n"
+              << "               if (f <= 0) f = 1e-300;\n"
+              << "               if (a.n_scale) { if (valid" << x << ") a.fhK[(cls0 + ir) * a.n_patt + h" << x << "] = wt" << x << " > 0 ? log(f) + lnscale" << x << " : 0.0; }\n"
+              << "               else {\n";
+            if (CW > 1) s << "                  sF[ir * 256 + tid] = f;\n";
+            else s << "                  fh" << x << " += fK[ir] * f;\n";
+            s << "                  if (a.want_fhk && valid" << x << ") a.fhK[(cls0 + ir) * a.n_patt + h" << x << "] = wt" << x << " > 0 ? f : 0.0; }\n"
+              << "            } }\n";
+            break;
+         default: break;
          }
+      }
+      switch (o.code) {
+      case OP_SET_TIP2: if (pl.cherry) ich++; break;
+      case OP_PUSH: slot[o.b] = cur; cur = -1; break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP:
+         release(curin);
+         if (pop >= 0) { release(slot[pop]); slot[pop] = -1; }
          if (push >= 0) { slot[push] = out; cur = -1; }
          else cur = out;
-      } break;
-      case OP_SCALE:
-         s << "         lnscale += jv_scale<N>(" << name(cur) << ");\n";
          break;
-      case OP_ROOT:
-         // fx_r treesub.c:7728-7749 / lfun 7780-7798, then this class's term of lfundG's mixture (7632-7652)
-         s << "         { double f = 0;\n            " << LOOP << "f = fma(pi[j], " << name(cur) << "[j], f);\n"
-           << "            if (a.mode == PAML_AMD_MODE_LFUN) { if (f <= 0) f = 1e-80; v = log(f) + lnscale; if (a.want_fhk && valid) a.fhK[(cls0 + ir) * a.n_patt + h] = wt > 0 ? v : 0.0; }\n"
-           << "            else {\n"
-           << "               if (f <= 0) f = 1e-300;\n"
-           << "               if (a.n_scale) { if (valid) a.fhK[(cls0 + ir) * a.n_patt + h] = wt > 0 ? log(f) + lnscale : 0.0; }\n"
-           << "               else { fh += fK[ir] * f; if (a.want_fhk && valid) a.fhK[(cls0 + ir) * a.n_patt + h] = wt > 0 ? f : 0.0; }\n"
-           << "            } }\n";
-         release(cur);
-         cur = -1;
-         break;
+      case OP_ROOT: release(cur); cur = -1; break;
       default: break;
       }
    }
    s << "      }\n";      // classes
-   s << "      if (a.mode != PAML_AMD_MODE_LFUN) {\n"
-        "         if (a.n_scale) {      /* log-sum-exp around the first maximum (treesub.c:7640-7649) */\n"
-        "            const double *fk = a.fhK + cls0 * a.n_patt + hc;\n"
-        "            int it = 0;\n"
-        "            for (int ir = 1; ir < K; ir++) if (fk[(long)ir * a.n_patt] > fk[(long)it * a.n_patt]) it = ir;\n"
-        "            const double t = fk[(long)it * a.n_patt];\n"
-        "            fh = 0;\n"
-        "            for (int ir = 0; ir < K; ir++) fh += fK[ir] * exp(fk[(long)ir * a.n_patt] - t);\n"
-        "            v = t + log(fh);\n"
-        "         }\n"
-        "         else { if (fh <= 0) fh = 1e-300; v = log(fh); }\n"
-        "      }\n";
-   s << "      if (!(valid && wt > 0)) v = 0;\n";
-   s << "      if (valid) { acc += v * wt; if (a.lnf) a.lnf[(long)bat * a.n_patt + h] = v; }\n";
+   if (CW > 1) s << "      __syncthreads();\n";
+   for (int r = 0; r < R; r++) {
+      const std::string x = sfx(r);
+      s << "      if (a.mode != PAML_AMD_MODE_LFUN" << (CW > 1 ? " && cw == 0" : "") << ") {\n"
+           "         if (a.n_scale) {      /* log-sum-exp around the first maximum (treesub.c:7640-7649) */\n"
+           "            const double *fk = a.fhK + cls0 * a.n_patt + hc" << x << ";\n"
+           "            int it = 0;\n"
+           "            for (int ir = 1; ir < K; ir++) if (fk[(long)ir * a.n_patt] > fk[(long)it * a.n_patt]) it = ir;\n"
+           "            const double t = fk[(long)it * a.n_patt];\n"
+           "            double fh = 0;\n"
+           "            for (int ir = 0; ir < K; ir++) fh += fK[ir] * exp(fk[(long)ir * a.n_patt] - t);\n"
+           "            v" << x << " = t + log(fh);\n"
+           "         }\n"
+           "         else {\n";
+      if (CW > 1) s << "            for (int ir = 0; ir < K; ir++) fh" << x << " += fK[ir] * sF[ir * 256 + tid];\n";
+      s << "            if (fh" << x << " <= 0) fh" << x << " = 1e-300;\n            v" << x << " = log(fh" << x << ");\n         }\n      }\n";
+      s << "      if (!(valid" << x << " && wt" << x << " > 0)) v" << x << " = 0;\n";
+      s << "      if (valid" << x << (CW > 1 ? " && cw == 0" : "") << ") { acc += v" << x << " * wt" << x << "; if (a.lnf) a.lnf[(long)bat * a.n_patt + h" << x << "] = v" << x << "; }\n";
+   }
+   if (CW > 1) s << "      __syncthreads();\n";      // sF is reused by the next sub-tile
    s << "   }\n";      // sub-tiles
-   s << "   red_block_finish(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + blockIdx.x, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat : nullptr);\n";
+   if (CW > 1) s << "   if (cw > 0) acc = 0;\n";
+   s << "   red_block_finish<" << CW << ">(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + blockIdx.x, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat : nullptr);\n";
    s << "}\n";
    return s.str();
 }

@@ -51,7 +51,94 @@ struct PmatArgs {
    long branch_bs, gene_rate_bs, eigen_of_bs, qfactor_bs, rate_bs;
 };
 
-__global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
+// Branch lengths and gene rates handed over INSIDE the kernel arguments (single evaluations of trees with up to ~440 nodes):
+// the launch itself carries them, so an evaluation needs no host-to-device copy and no staging buffer to keep alive.
+#define PMAT_INLINE_MAX 440
+struct InlineVec {
+   int n_branch, n_rate;          // 0, 0: read PmatArgs::branch / gene_rate instead
+   double v[PMAT_INLINE_MAX];     // branch[n_branch], then gene_rate[n_rate]
+};
+
+__device__ __forceinline__ double pmat_time(const PmatArgs &a, const InlineVec &iv, int bat, int node, int gene, int iclass)
+{
+   // t = branch * rateSite * rgene (codeml.c:3547-3551)
+   const double br = iv.n_branch ? iv.v[node] : a.branch[bat * a.branch_bs + node];
+   const double gr = iv.n_branch ? iv.v[iv.n_branch + gene] : a.gene_rate[bat * a.gene_rate_bs + gene];
+   return (br * a.rate[bat * a.rate_bs + iclass]) * gr;
+}
+
+// Models with at most 5 states (the one-pattern-per-lane kernels): 32 threads per matrix, eight matrices per workgroup, no
+// 64 x 64 staging — the general kernel below spends 9 us on the 244 4 x 4 matrices of a 32-taxon Gamma-4 evaluation.
+// Same arithmetic and summation order as pmat_kernel.  Rate-matrix (UNREST) sets stay with the general kernel.
+__global__ __launch_bounds__(256) void pmat_small_kernel(PmatArgs a, InlineVec iv)
+{
+   __shared__ double sP[8][32];
+   const int n = a.n, sub = threadIdx.x >> 5, t5 = threadIdx.x & 31;
+   const int KB = a.K * a.B, n_mat = a.n_nodes * a.n_genes * KB;
+   const int m = blockIdx.x * 8 + sub;
+   const bool on = m < n_mat;
+   const int node = on ? m % a.n_nodes : 0, pset = on ? m / a.n_nodes : 0;
+   const int gene = pset / KB, bat = (pset % KB) / a.K, iclass = pset % a.K;
+   const bool active = on && node != a.root;
+   const int i = t5 / n, j = t5 % n;
+   const bool ent = active && t5 < n * n;
+   double p = 0;
+   int lab = 0;
+   if (active) lab = a.label[node];
+   if (ent) {
+      const EigenDev es = a.eigen[a.eigen_of[bat * a.eigen_of_bs + (gene * a.K + iclass) * a.n_labels + lab]];
+      double t = pmat_time(a, iv, bat, node, gene, iclass);
+      if (es.kind == PAML_AMD_EIGEN_UVROOT) {
+         t *= a.qfactor[bat * a.qfactor_bs + iclass * a.n_labels + lab];
+         if (t < 1e-100) p = (i == j) ? 1.0 : 0.0;
+         else {
+            double acc = 0;
+            for (int k = 0; k < n; k++) acc = fma(es.U[i * n + k] * expm1(t * es.Root[k]), es.V[k * n + j], acc);
+            p = acc + (i == j ? 1.0 : 0.0);
+            p = p < 0 ? 0.0 : p;
+         }
+      }
+      else if (es.kind == PAML_AMD_EIGEN_CIJK) {
+         const double *c = es.Cijk + ((long)i * n + j) * es.nR;
+         double sacc = 0;
+         for (int k = 0; k < es.nR; k++) sacc += c[k] * (k >= 1 ? expm1(t * es.Root[k]) : 0.0);
+         if (i == j) sacc += 1.0;
+         p = sacc;
+      }
+      else if (es.kind == PAML_AMD_EIGEN_K80) {
+         const double kappa = es.kappa;
+         const double e1 = expm1(-4 * t / (kappa + 2));
+         const bool jc = fabs(kappa - 1) < 1e-20;
+         const double e2 = jc ? 0.0 : expm1(-2 * t * (kappa + 1) / (kappa + 2));
+         if (jc) p = (i == j) ? 1. + 3 / 4.0 * e1 : -e1 / 4;
+         else if (i == j) p = 1 + (e1 + 2 * e2) / 4;
+         else if ((i ^ j) == 1) p = (e1 - 2 * e2) / 4;
+         else p = -e1 / 4;
+      }
+      else {   // JC69-like
+         const double pii = 1. / n + (1. - 1. / n) * exp(-n / (n - 1.) * t);
+         p = i == j ? pii : (1. - pii) / (n - 1.);
+      }
+   }
+   sP[sub][t5] = p;
+   __syncthreads();
+   if (!active) return;
+   const long slot = (long)pset * a.n_nodes + node;
+   if (ent) a.rowmajor[slot * n * n + t5] = p;
+   if (a.is_leaf[node]) {
+      double *pt = a.ptip + slot * a.tip_words;
+      for (int idx = t5; idx < a.n_codes * n; idx += 32) {
+         const int code = idx / n, jj = idx % n;
+         const int nc = a.n_chara[code];
+         const unsigned char *map = a.chara_map + code * n;
+         double s2 = 0;
+         for (int k = 0; k < nc; k++) s2 += sP[sub][jj * n + map[k]];
+         pt[idx] = s2;
+      }
+   }
+}
+
+__global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a, InlineVec iv)
 {
    extern __shared__ __attribute__((aligned(16))) double smem[];
    double *sA = smem;            // [64][64]  U*expm1 -> later the finished P (padded with zeros)
@@ -63,8 +150,7 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a)
    const int gene = pset / KB, bat = (pset % KB) / a.K, iclass = pset % a.K;
    const int lab = a.label[node];
    const EigenDev es = a.eigen[a.eigen_of[bat * a.eigen_of_bs + (gene * a.K + iclass) * a.n_labels + lab]];
-   double t = a.branch[bat * a.branch_bs + node] * a.rate[bat * a.rate_bs + iclass];
-   t *= a.gene_rate[bat * a.gene_rate_bs + gene];
+   double t = pmat_time(a, iv, bat, node, gene, iclass);
 
    // tip branches: the ambiguity map (tools.c:20 nChara / CharaMap) comes to LDS now, so that the column-table loop at
    // the end does not chase two dependent global loads per entry

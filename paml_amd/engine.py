@@ -395,8 +395,8 @@ def debug_jit(tree, scale_node=None, compile=True, n_states=0, fused=None):
     buf = C.create_string_buffer(cap)
     L.paml_amd_debug_jit.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int]
     flags = int(bool(compile)) | (int(n_states) << 8)
-    if fused:      # (K classes, n_codes): the fused 4 / 5-state kernel
-        flags |= 2 | (int(fused[0]) << 16) | (int(fused[1]) << 24)
+    if fused:      # (K classes, n_codes[, reduction chunk]): the fused 4 / 5-state kernel
+        flags |= 2 | (int(fused[0]) << 16) | (int(fused[1]) << 24) | ((int(fused[2]) // 256 if len(fused) > 2 else 1) << 2)
     rc = L.paml_amd_debug_jit(tree.n_tips, tree.n_nodes, tree.root, _p(ptr), _p(flat), _p(sc), buf, cap, flags)
     if rc < 0:
         raise EngineError("debug_jit failed (%d): %s" % (rc, buf.value.decode(errors="replace")[-3000:]))

@@ -7,10 +7,30 @@
 #include <cstdio>
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <int MODE>   // 0: mfma only, 1: valu only, 2: even waves mfma / odd waves valu
+template <int MODE>   // 0: mfma only, 1: valu only, 2: even waves mfma / odd waves valu, 3: v_mfma_f64_4x4x4_4b_f64 only
 __global__ __launch_bounds__(512) void k(double *out, int iters, double seed)
 {
    const int wave = threadIdx.x >> 6;
+   if (MODE == 3) {      // four 4x4x4 blocks per instruction: 4 x 64 MACs = 512 FLOP
+      double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+      double x = seed + threadIdx.x * 1e-9, y = 1.0 - seed;
+      for (int i = 0; i < iters; i++) {
+#pragma unroll
+         for (int u = 0; u < 4; u++) {
+            a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, a3, 0, 0, 0);
+            a4 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, a4, 0, 0, 0);
+            a5 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, a5, 0, 0, 0);
+            a6 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, a6, 0, 0, 0);
+            a7 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, a7, 0, 0, 0);
+         }
+      }
+      const double r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+      if (r == 12345.678) out[0] = r;
+      return;
+   }
    const bool do_mfma = MODE == 0 || (MODE == 2 && (wave & 4) == 0);   // waves 0-3 -> one per SIMD; 4-7 their partners
    double r = 0;
    if (do_mfma) {
@@ -61,6 +81,7 @@ double run(int blocks, int threads, int iters, double *d, const char *name)
    if (MODE == 0) mf = waves * iters * 32.0 * 2048;
    if (MODE == 1) vf = waves * iters * 128.0 * 64 * 2;
    if (MODE == 2) { mf = waves / 2 * iters * 32.0 * 2048; vf = waves / 2 * iters * 128.0 * 64 * 2; }
+   if (MODE == 3) mf = waves * iters * 32.0 * 512;
    printf("%-34s blocks=%d thr=%d  %.3f ms  mfma %.1f TF  valu %.1f TF  total %.1f TF\n", name, blocks, threads, ms,
           mf / ms / 1e9, vf / ms / 1e9, (mf + vf) / ms / 1e9);
    return ms;
@@ -78,6 +99,8 @@ int main()
    run<1>(cu, 256, 4000, d, "v_fma_f64, 1 wave/SIMD");
    run<1>(cu, 512, 4000, d, "v_fma_f64, 2 waves/SIMD");
    run<1>(cu * 2, 512, 4000, d, "v_fma_f64, 4 waves/SIMD");
+   run<3>(cu, 256, 4000, d, "mfma f64 4x4x4 (4 blocks), 1 wave/SIMD");
+   run<3>(cu * 2, 512, 4000, d, "mfma f64 4x4x4 (4 blocks), 4 waves/SIMD");
    run<2>(cu, 512, 4000, d, "mixed: 1 mfma + 1 valu wave/SIMD");
    run<2>(cu * 2, 512, 4000, d, "mixed: 2 mfma + 2 valu waves/SIMD");
    return 0;
