@@ -179,12 +179,17 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
  * the lnL-only case), the function minbranches (treesub.c:8039) iterates with Newton steps: for the branch above
  * node_b, and for each of the n_t (<= 64) trial lengths t[], the log-likelihood and its first two derivatives in t,
  * all other branch lengths taken from branch[].  Outputs are in lnL convention: lnL = -l, dlnL = -dl, ddlnL = -ddl
- * of the reference.  Where the reference re-roots the tree at b and updates conP along the path (ReRootTree
- * treespace.c:236, updateconP treesub.c:7982), the engine evaluates the two partials across the branch directly
- * (one fused pass over each side), builds P, dP, ddP for all trial lengths in one batched kernel and contracts.
- * Scaling nodes keep rescaling in the re-rooted walk; their factors travel with the two partials. */
+ * of the reference.  Like the reference (ReRootTree treespace.c:236 marks the nodes on the path, com.oldconP[a] = 0 at
+ * line 250; updateconP treesub.c:7982 recomputes only those), the engine keeps the partials of BOTH sides of every edge
+ * it has visited resident in HBM between calls: moving to a neighbouring branch recomputes the one or two nodes on the
+ * path, a changed branch length only the partials that look across it.  The contraction reads the two resident partials
+ * (on the matrix cores for 21..64 states), builds P, dP, ddP for all trial lengths in one batched kernel, and there is
+ * one host synchronisation per call.  Scaling nodes keep rescaling; their factors are stored with the partials.
+ * Any set_tips / set_tree / set_eigen_* / set_classes call drops the resident partials. */
 int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *t, const double *branch,
                          const double *gene_rate, double *lnL, double *dlnL, double *ddlnL);
+/* Work done by paml_amd_eval_branch so far: calls, and internal-node partials recomputed (a full tree costs n_nodes - n_tips). */
+int paml_amd_branch_counters(const paml_amd_engine *e, long *n_calls, long *n_nodes_recomputed);
 
 /* Marginal ancestral reconstruction (AncestralMarginal treesub.c:6288, PostProbNode 6142): post[n_patt][n_states] =
  * posterior probabilities of the states at internal node `node` given the data, at the current classes / eigen systems and

@@ -191,6 +191,17 @@ struct paml_amd_engine {
    bool fused = false;                // the selected kernel forms the reduction itself
    int fused_threads = 256;
    bool pmat_valid = false;           // d_rowmajor holds the P(t) of an evaluation in the tree's own orientation
+   // branch-local evaluation: resident partials on both sides of every edge, re-used from call to call (eval_branch)
+   struct BranchCache {
+      bool valid = false;
+      int K = 0;
+      std::vector<int> up;            // up[v]: the neighbour v's stored partial looks away from
+      std::vector<char> ok;           // the stored partial of internal node v is current
+      std::vector<double> br, gr;     // branch lengths (by lower node) and gene rates the partials were formed with
+   } bl;
+   DevBuf<double> d_bl_partials, d_bl_scalef, d_bl_frag;
+   DevBuf<unsigned long long> d_code_mask;      // per character code: bit s = state s belongs to it
+   long n_branch_eval = 0, n_branch_nodes = 0;
 
    // data
    bool have_tips = false, have_tree = false, have_pi = false, have_classes = false;
@@ -277,6 +288,7 @@ struct paml_amd_engine {
       d_tiles_full.release();
       d_zpm.release();
       d_red_counter.release();
+      d_bl_partials.release(); d_bl_scalef.release(); d_bl_frag.release(); d_code_mask.release();
       d_ops.release();
       d_ops_tmp.release();
       d_label_eff.release();
@@ -1151,8 +1163,16 @@ int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata,
    HIPCHK(hipStreamSynchronize(e->stream));
    int r = build_tiles(e);
    if (r) return r;
+   {  // state sets of the character codes as bit masks (tip ends of a branch in the branch-local evaluation)
+      std::vector<unsigned long long> mask(n_codes, 0);
+      for (int c = 0; c < n_codes; c++)
+         for (int k = 0; k < nch[c]; k++) mask[c] |= 1ull << cmap[(size_t)c * n + k];
+      HIPCHK(upload(e->d_code_mask, mask.data(), mask.size(), e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+   }
    e->have_tips = true;
    e->partials_valid = false;
+   e->bl.valid = false;
    return 0;
 }
 
@@ -1197,6 +1217,7 @@ int paml_amd_set_tree(paml_amd_engine *e, int n_nodes, int root, const int *sons
    e->have_tree = true;
    e->prog_valid = false;
    e->partials_valid = false;
+   e->bl.valid = false;
    return 0;
 }
 
@@ -1227,6 +1248,7 @@ static EigenHost *eigen_slot(paml_amd_engine *e, int set_id)
    if ((size_t)set_id >= e->eigen.size()) e->eigen.resize(set_id + 1);
    e->eigen_dirty = true;
    e->partials_valid = false;
+   e->bl.valid = false;
    return &e->eigen[set_id];
 }
 
@@ -1313,6 +1335,7 @@ int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freq
    e->mode = mode; e->K = K; e->n_labels = n_labels;
    e->have_classes = true;
    e->partials_valid = false;
+   e->bl.valid = false;
    return 0;
 }
 
@@ -1498,91 +1521,247 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes) || e->eigen.empty())
       return fail(e, PAML_AMD_EINVAL, "eval_branch before set_tips/set_tree/set_pi/set_classes/set_eigen");
    const TreeDesc &T = e->tree;
-   const int nn = T.n_nodes, n = e->n, K = e->K, G = e->n_genes, psets = G * K;
+   const int nn = T.n_nodes, n = e->n, K = e->K, G = e->n_genes, psets = G * K, n_int = nn - e->n_tips;
    if (node_b < 0 || node_b >= nn || node_b == T.root) return fail(e, PAML_AMD_EINVAL, "eval_branch: node has no branch");
    for (size_t i = 0; i < e->eigen.size(); i++)
       if (e->eigen[i].kind == PAML_AMD_EIGEN_QMAT) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_branch: not for rate-matrix (UNREST) sets");
+   const bool mfma = e->kk == KK_MFMA64;
    std::vector<int> father(nn, -1);
+   std::vector<std::vector<int>> nbr(nn);
    for (int i = 0; i < nn; i++)
-      for (int j = T.sons_ptr[i]; j < T.sons_ptr[i + 1]; j++) father[T.sons[j]] = i;
-   const int a = father[node_b];
-   TreeDesc treeA;
-   {
-      int r0 = rerooted_pmat(e, a, node_b, branch, gene_rate, &treeA);
-      if (r0) return r0;
-   }
-   auto export_program = [&](const TreeDesc &t) {
-      Program p = build_program(t, false, nullptr);
-      for (Op &o : p.ops)
-         if (o.code == OP_ROOT) o.code = OP_EXPORT;
-      return p;
-   };
-   auto make_tree_b = [&]() {      // b's own subtree, rooted at b, in the original orientation
-      TreeDesc t = T;
-      t.root = node_b;
-      t.n_scale = 0;
-      t.scale_slot.assign(nn, -1);
-      for (int i = 0; i < nn; i++) {
-         if (!T.scale_node.empty() && T.scale_node[i] && !t.is_leaf(i)) t.scale_slot[i] = t.n_scale++;
-         else if (!t.scale_node.empty()) t.scale_node[i] = 0;
+      for (int j = T.sons_ptr[i]; j < T.sons_ptr[i + 1]; j++) {
+         father[T.sons[j]] = i;
+         nbr[i].push_back(T.sons[j]);
+         nbr[T.sons[j]].push_back(i);
       }
-      return t;
-   };
-   const Program progA = export_program(treeA);
-   const bool b_tip = T.is_leaf(node_b);
-   std::vector<double> tt(t, t + n_t);
-   HIPCHK(upload(e->d_tt, tt.data(), tt.size(), e->stream));
-   HIPCHK(hipStreamSynchronize(e->stream));
+   auto edge_id = [&](int u, int v) { return father[u] == v ? u : v; };      // an edge is named by its lower node in the tree as set
+   // the two ends of the branch; the end that may be a tip is "b" (the contraction is symmetric for reversible models:
+   // pi_i P_ij = pi_j P_ji)
+   int A = father[node_b], Bn = node_b;
+   if (T.is_leaf(A)) std::swap(A, Bn);
+   if (T.is_leaf(A)) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_branch: a branch between two tips");
+   const bool b_tip = T.is_leaf(Bn);
 
-   // the two partials across the branch
-   const size_t exp_words = (size_t)K * e->n_patt * n;
+   // ---- the message cache: what updateconP (treesub.c:7982) + com.oldconP (treespace.c:250) save the reference --------
+   // Every internal node v keeps one partial M[v]: the likelihood of everything on v's side of the edge (v, up[v]).  With
+   // all up[] pointing towards the branch being worked on, M[A] and M[B] are the two partials across it.  Moving to another
+   // branch re-orients only the nodes on the path between the two branches; a changed branch length invalidates only the
+   // partials that look across it.  Nothing else is recomputed.
+   paml_amd_engine::BranchCache &bc = e->bl;
+   const size_t words = mfma ? (size_t)K * n_int * e->n_tiles_full * GATHER_WAVES * 1024 : (size_t)K * n_int * e->n_patt * n;
+   if (words > e->d_bl_partials.cap) { HIPCHK(e->d_bl_partials.ensure(words)); bc.valid = false; }
    const bool scaled = T.n_scale > 0;
-   HIPCHK(e->d_expA.ensure(exp_words));
-   if (scaled) HIPCHK(e->d_expSA.ensure((size_t)K * e->n_patt));
-   int r = run_prune_full(e, progA, e->d_expA.p, scaled ? e->d_expSA.p : nullptr);
-   if (r) return r;
-   if (!b_tip) {
-      const Program progB = export_program(make_tree_b());
-      HIPCHK(e->d_expB.ensure(exp_words));
-      if (scaled) HIPCHK(e->d_expSB.ensure((size_t)K * e->n_patt));
-      r = run_prune_full(e, progB, e->d_expB.p, scaled ? e->d_expSB.p : nullptr);
-      if (r) return r;
+   if (scaled && (size_t)K * T.n_scale * e->n_patt > e->d_bl_scalef.cap) { HIPCHK(e->d_bl_scalef.ensure((size_t)K * T.n_scale * e->n_patt)); bc.valid = false; }
+   std::vector<double> gr(G, 1.0);
+   if (gene_rate) gr.assign(gene_rate, gene_rate + G);
+   if (!bc.valid || (int)bc.up.size() != nn || bc.K != K || bc.gr != gr) {
+      bc.up.assign(nn, -2); bc.ok.assign(nn, 0); bc.br.assign(nn, -1.0); bc.gr = gr; bc.K = K;
+      bc.valid = true;
+   }
+   {  // branch lengths that changed since the partials were formed
+      std::vector<int> changed;
+      for (int x = 0; x < nn; x++)
+         if (x != T.root && branch[x] != bc.br[x]) { changed.push_back(x); bc.br[x] = branch[x]; }
+      if (!changed.empty()) {
+         std::vector<char> in(nn);
+         std::vector<int> stack;
+         for (int v = e->n_tips; v < nn; v++) {
+            if (!bc.ok[v]) continue;
+            std::fill(in.begin(), in.end(), 0);      // v's side of the edge (v, up[v])
+            stack.assign(1, v);
+            in[v] = 1;
+            while (!stack.empty()) {
+               const int u = stack.back();
+               stack.pop_back();
+               for (int w : nbr[u])
+                  if (!in[w] && !(u == v && w == bc.up[v])) { in[w] = 1; stack.push_back(w); }
+            }
+            for (int x : changed)
+               if (in[x] && in[father[x]]) { bc.ok[v] = 0; break; }
+         }
+      }
+   }
+   // orientation towards the branch
+   std::vector<int> up(nn, -1);
+   {
+      std::vector<int> queue;
+      up[A] = Bn; up[Bn] = A;
+      queue.push_back(A); queue.push_back(Bn);
+      for (size_t qi = 0; qi < queue.size(); qi++) {
+         const int u = queue[qi];
+         for (int w : nbr[u])
+            if (w != up[u] && up[w] < 0) { up[w] = u; queue.push_back(w); }
+      }
+   }
+   std::vector<unsigned char> clean(nn, 0);
+   bool any_dirty = false;
+   for (int v = e->n_tips; v < nn; v++) {
+      clean[v] = bc.ok[v] && bc.up[v] == up[v];
+      any_dirty = any_dirty || !clean[v];
+   }
+   // the tree seen from the branch: sons = neighbours other than up[]; the edge data of (v, up[v]) sits at index v
+   TreeDesc tr;
+   tr.n_tips = T.n_tips; tr.n_nodes = nn; tr.root = A;
+   tr.sons_ptr.assign(nn + 1, 0);
+   std::vector<double> br_eff(nn, 0.0);
+   std::vector<int> lab_eff(nn, 0);
+   for (int v = 0; v < nn; v++) {
+      for (int w : nbr[v])
+         if (w != up[v]) tr.sons.push_back(w);
+      tr.sons_ptr[v + 1] = (int)tr.sons.size();
+      if (v != A && v != Bn) { const int x = edge_id(v, up[v]); br_eff[v] = branch[x]; lab_eff[v] = T.label[x]; }
+   }
+   tr.label = lab_eff;
+   tr.scale_node.assign(nn, 0);
+   tr.scale_slot.assign(nn, -1);
+   if (scaled)
+      for (int i = 0; i < nn; i++)
+         if (T.scale_node[i] && !tr.is_leaf(i)) { tr.scale_node[i] = 1; tr.scale_slot[i] = T.scale_slot[i]; tr.n_scale = T.n_scale; }
+
+   hipStream_t st = e->stream;
+   if (e->eigen_dirty) {
+      std::vector<EigenDev> tab(e->eigen.size());
+      for (size_t i = 0; i < e->eigen.size(); i++) {
+         const EigenHost &h = e->eigen[i];
+         if (h.kind < 0) return fail(e, PAML_AMD_EINVAL, "eigen set " + std::to_string(i) + " was never set");
+         tab[i] = EigenDev{h.kind, h.nR, h.kappa, h.U.p, h.V.p, h.Root.p, h.Cijk.p};
+      }
+      HIPCHK(upload(e->d_eigen, tab.data(), tab.size(), st));
+      e->eigen_dirty = false;
+   }
+   HIPCHK(upload(e->d_gene_rate, gr.data(), gr.size(), st));
+   if (any_dirty) {
+      // the dirty partials: one program per side, run back to back in one launch of the full-featured kernels
+      Program prog;
+      for (int side = 0; side < 2; side++) {
+         const int rt = side ? Bn : A;
+         if (T.is_leaf(rt) || clean[rt]) continue;
+         tr.root = rt;
+         Program ps = build_program(tr, true, clean.data());
+         for (const Op &o : ps.ops)
+            if (o.code != OP_ROOT && o.code != OP_END) prog.ops.push_back(o);
+         prog.max_stack = std::max(prog.max_stack, ps.max_stack);
+         if (prog.first_matmul < 0) prog.first_matmul = ps.first_matmul;
+      }
+      prog.ops.push_back({OP_END, 0, 0, -1});
+      // (prefetch links of the concatenated program: every MATMUL names the next one)
+      {
+         int next = -1;
+         for (int i = (int)prog.ops.size() - 1; i >= 0; i--)
+            if (prog.ops[i].code == OP_MATMUL || prog.ops[i].code == OP_MATMUL_POP) { prog.ops[i].c = next; next = prog.ops[i].a; }
+         prog.first_matmul = next;
+      }
+      const int maxd = e->kk == KK_VALU20 ? VALU_MAXD_20 : VALU_MAXD_SMALL;
+      if (!mfma && prog.max_stack > maxd) return fail(e, PAML_AMD_EUNSUPPORTED, "tree needs a deeper partial stack than this kernel provides");
+      // P(t) of every edge in its new orientation
+      HIPCHK(upload(e->d_label_eff, lab_eff.data(), lab_eff.size(), st));
+      HIPCHK(upload(e->d_branch, br_eff.data(), br_eff.size(), st));
+      HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
+      if (mfma) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
+      HIPCHK(e->d_ptip.ensure((size_t)psets * nn * tip_words(e)));
+      PmatArgs pa{};
+      pa.n = n; pa.n_nodes = nn; pa.root = A; pa.K = K; pa.n_genes = G; pa.n_labels = e->n_labels;
+      pa.n_codes = e->n_codes; pa.layout = mfma ? 1 : 0;
+      pa.label = e->d_label_eff.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
+      pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
+      pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
+      pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
+      pa.B = 1;
+      {
+         InlineVec iv;
+         iv.n_branch = iv.n_rate = 0;
+         hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), st, pa, iv);
+      }
+      e->n_pmat += (long)psets * (nn - 2);
+      e->prog_valid = false;      // d_branch / P buffers now hold re-oriented edge data: the next eval rebuilds
+      e->pmat_valid = false;
+      HIPCHK(upload(e->d_ops_tmp, prog.ops.data(), prog.ops.size(), st));
+      const int n_blocks = e->n_tiles_full * K;
+      int overflow = 0;
+      if (mfma && prog.max_stack > MFMA_RS) {
+         overflow = prog.max_stack - MFMA_RS;
+         HIPCHK(e->d_stack.ensure((size_t)n_blocks * overflow * GATHER_WAVES * 1024));
+      }
+      PruneArgs pr{};
+      pr.ops = e->d_ops_tmp.p; pr.z = e->d_z.p; pr.z_stride = e->n_patt; pr.tiles = e->d_tiles_full.p; pr.n_tiles = e->n_tiles_full;
+      pr.gene_off = e->d_gene_off.p; pr.weights = e->d_weights.p;
+      pr.n = n; pr.n_tips = e->n_tips; pr.n_nodes = nn; pr.K = K; pr.n_genes = G; pr.n_codes = e->n_codes;
+      pr.cleandata = e->cleandata; pr.n_pi = e->n_pi; pr.mode = e->mode; pr.n_scale = T.n_scale; pr.keep = 1; pr.n_patt = e->n_patt;
+      pr.pi = e->d_pi.p; pr.pint = mfma ? e->d_pint.p : e->d_rowmajor.p; pr.ptip = e->d_ptip.p;
+      pr.fhK = e->d_fhK.p; pr.partials = e->d_bl_partials.p; pr.scalef = e->d_bl_scalef.p; pr.stack_scratch = e->d_stack.p;
+      pr.stack_overflow_slots = overflow; pr.first_matmul = prog.first_matmul; pr.n_int = n_int;
+      pr.first_tip = -1; pr.tip_words = (long)tip_words(e);
+      if (mfma) hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, st, pr);
+      else launch_valu(e, prog.max_stack, n_blocks, pr);
+      HIPCHK(hipGetLastError());
+      for (int v = e->n_tips; v < nn; v++) { bc.up[v] = up[v]; bc.ok[v] = 1; }
+      e->n_branch_nodes += (long)std::count(clean.begin() + e->n_tips, clean.end(), 0);
    }
 
    // P, dP, ddP for every trial length, then the per-pattern contraction and the three weighted sums
+   std::vector<double> tt(t, t + n_t);
+   HIPCHK(upload(e->d_tt, tt.data(), tt.size(), st));
    HIPCHK(e->d_deriv.ensure((size_t)psets * n_t * 3 * n * n));
+   if (mfma) HIPCHK(e->d_bl_frag.ensure((size_t)psets * n_t * 3 * 4096));
    DerivArgs da{};
    da.n = n; da.K = K; da.n_genes = G; da.n_labels = e->n_labels; da.n_t = n_t; da.label = T.label[node_b];
    da.t = e->d_tt.p; da.rate = e->d_rate.p; da.gene_rate = e->d_gene_rate.p; da.qfactor = e->d_qfactor.p;
-   da.eigen_of = e->d_eigen_of.p; da.eigen = e->d_eigen.p; da.out = e->d_deriv.p;
-   hipLaunchKernelGGL(pmat_deriv_kernel, dim3(n_t, psets), dim3(256), 0, e->stream, da);
-   const int nb = (e->n_patt + 255) / 256;
-   HIPCHK(e->d_bpartial.ensure((size_t)nb * n_t * 3));
+   da.eigen_of = e->d_eigen_of.p; da.eigen = e->d_eigen.p; da.out = e->d_deriv.p; da.frag = mfma ? e->d_bl_frag.p : nullptr;
+   hipLaunchKernelGGL(pmat_deriv_kernel, dim3(n_t, psets), dim3(256), 0, st, da);
    HIPCHK(e->d_bout.ensure((size_t)n_t * 3));
-   BranchArgs ba{};
-   ba.n = n; ba.K = K; ba.n_genes = G; ba.n_patt = e->n_patt; ba.n_t = n_t; ba.n_pi = e->n_pi; ba.b_is_tip = b_tip ? 1 : 0;
-   ba.n_codes = e->n_codes; ba.A = e->d_expA.p; ba.B = e->d_expB.p;
-   ba.SA = scaled ? e->d_expSA.p : nullptr; ba.SB = (scaled && !b_tip) ? e->d_expSB.p : nullptr;
-   ba.zb = b_tip ? e->d_z.p + (size_t)node_b * e->n_patt : nullptr;
-   ba.n_chara = e->d_n_chara.p; ba.chara_map = e->d_chara_map.p; ba.freqK = e->d_freqK.p;
-   ba.weights = e->d_weights.p; ba.PdP = e->d_deriv.p; ba.gene_off = e->d_gene_off.p; ba.partial = e->d_bpartial.p;
-   // pi in plain [n_pi][n] order (the mfma engines keep a permuted copy for their kernels): reuse row-major upload
-   HIPCHK(e->d_pi_plain.p ? hipSuccess : hipErrorInvalidValue);
-   ba.pi = e->d_pi_plain.p;
-   hipLaunchKernelGGL(branch_kernel, dim3(nb), dim3(256), 0, e->stream, ba);
-   hipLaunchKernelGGL(branch_reduce_kernel, dim3(1), dim3(256), 0, e->stream, (const double *)e->d_bpartial.p, nb, n_t * 3,
-                      e->d_bout.p);
+   if (mfma) {
+      const int nb = e->n_tiles_full;
+      HIPCHK(e->d_bpartial.ensure((size_t)nb * 3));
+      BranchMfmaArgs ba{};
+      ba.n = n; ba.K = K; ba.n_genes = G; ba.n_patt = e->n_patt; ba.n_pi = e->n_pi; ba.n_tips = e->n_tips; ba.n_int = n_int;
+      ba.n_tiles = nb; ba.n_scale = T.n_scale; ba.n_t = n_t; ba.a_node = A; ba.b_node = Bn;
+      ba.tiles = e->d_tiles_full.p; ba.gene_off = e->d_gene_off.p; ba.partials = e->d_bl_partials.p;
+      ba.scalef = scaled ? e->d_bl_scalef.p : nullptr; ba.zb = b_tip ? e->d_z.p + (size_t)Bn * e->n_patt : nullptr;
+      ba.code_mask = e->d_code_mask.p; ba.pi = e->d_pi.p; ba.freqK = e->d_freqK.p; ba.weights = e->d_weights.p;
+      ba.frag = e->d_bl_frag.p; ba.partial = e->d_bpartial.p;
+      for (int it = 0; it < n_t; it++) {      // (stream order keeps the partial buffer safe between the pairs of launches)
+         ba.it = it;
+         hipLaunchKernelGGL(branch_mfma_kernel, dim3(nb), dim3(256), 0, st, ba);
+         hipLaunchKernelGGL(branch_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)e->d_bpartial.p, nb, 3, e->d_bout.p + 3 * it);
+      }
+   }
+   else {
+      const int nb = (e->n_patt + 255) / 256;
+      HIPCHK(e->d_bpartial.ensure((size_t)nb * n_t * 3));
+      BranchArgs ba{};
+      ba.n = n; ba.K = K; ba.n_genes = G; ba.n_patt = e->n_patt; ba.n_t = n_t; ba.n_pi = e->n_pi; ba.b_is_tip = b_tip ? 1 : 0;
+      ba.n_codes = e->n_codes; ba.cls_stride = (long)n_int * e->n_patt * n;
+      ba.A = e->d_bl_partials.p + (size_t)(A - e->n_tips) * e->n_patt * n;
+      ba.B = b_tip ? nullptr : e->d_bl_partials.p + (size_t)(Bn - e->n_tips) * e->n_patt * n;
+      ba.SA = scaled ? e->d_bl_scalef.p : nullptr; ba.SB = nullptr; ba.n_scale = T.n_scale;
+      ba.zb = b_tip ? e->d_z.p + (size_t)Bn * e->n_patt : nullptr;
+      ba.n_chara = e->d_n_chara.p; ba.chara_map = e->d_chara_map.p; ba.freqK = e->d_freqK.p;
+      ba.weights = e->d_weights.p; ba.PdP = e->d_deriv.p; ba.gene_off = e->d_gene_off.p; ba.partial = e->d_bpartial.p;
+      ba.pi = e->d_pi_plain.p;
+      hipLaunchKernelGGL(branch_kernel, dim3(nb), dim3(256), 0, st, ba);
+      hipLaunchKernelGGL(branch_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)e->d_bpartial.p, nb, n_t * 3, e->d_bout.p);
+   }
    HIPCHK(hipGetLastError());
    if (e->comm) {      // the exchange step of the branch-local evaluation: 3 n_t sums
-      const ncclResult_t nr = rccl().AllReduce(e->d_bout.p, e->d_bout.p, (size_t)n_t * 3, ncclDouble, ncclSum, e->comm, e->stream);
+      const ncclResult_t nr = rccl().AllReduce(e->d_bout.p, e->d_bout.p, (size_t)n_t * 3, ncclDouble, ncclSum, e->comm, st);
       if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
    }
-   std::vector<double> out((size_t)n_t * 3);
-   HIPCHK(hipMemcpyAsync(out.data(), e->d_bout.p, out.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-   HIPCHK(hipStreamSynchronize(e->stream));
-   for (int i = 0; i < n_t; i++) { lnL[i] = out[3 * i]; dlnL[i] = out[3 * i + 1]; ddlnL[i] = out[3 * i + 2]; }
-   e->prog_valid = false;      // d_branch / P buffers now hold the re-rooted edge data: the next eval rebuilds
-   e->partials_valid = false;
+   {
+      int r = ensure_hout(e, (size_t)n_t * 3);
+      if (r) return r;
+   }
+   HIPCHK(hipMemcpyAsync(e->h_out, e->d_bout.p, (size_t)n_t * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+   HIPCHK(hipStreamSynchronize(st));      // the one host synchronisation of the call
+   for (int i = 0; i < n_t; i++) { lnL[i] = e->h_out[3 * i]; dlnL[i] = e->h_out[3 * i + 1]; ddlnL[i] = e->h_out[3 * i + 2]; }
+   e->n_branch_eval++;
+   return 0;
+}
+
+int paml_amd_branch_counters(const paml_amd_engine *e, long *n_calls, long *n_nodes_recomputed)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   if (n_calls) *n_calls = e->n_branch_eval;
+   if (n_nodes_recomputed) *n_nodes_recomputed = e->n_branch_nodes;
    return 0;
 }
 

@@ -1051,6 +1051,7 @@ struct DerivArgs {
    const int *eigen_of;
    const EigenDev *eigen;
    double *out;                // [pset][n_t][3][n*n]
+   double *frag;               // non-null: also [pset][n_t][3][4096], each matrix in MFMA A-operand order (as pmat_kernel's pint)
 };
 
 __global__ __launch_bounds__(256) void pmat_deriv_kernel(DerivArgs a)
@@ -1079,34 +1080,50 @@ __global__ __launch_bounds__(256) void pmat_deriv_kernel(DerivArgs a)
          dP[idx] = c1 * e1 * m1 + c2 * e2 * m2;
          ddP[idx] = c1 * e1 * m1 * m1 + c2 * e2 * m2 * m2;
       }
-      return;
    }
-   for (int k = threadIdx.x; k < nroot; k += 256) {
-      const double mu = base * es.Root[k];     // treesub.c:8479: rgene * Root[k] * _rateSite (* Qfactor)
-      sM[k] = mu;
-      sE[k] = k ? exp(t * mu) : 1.0;
+   else {
+      for (int k = threadIdx.x; k < nroot; k += 256) {
+         const double mu = base * es.Root[k];     // treesub.c:8479: rgene * Root[k] * _rateSite (* Qfactor)
+         sM[k] = mu;
+         sE[k] = k ? exp(t * mu) : 1.0;
+      }
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+         const int i = idx / n, j = idx % n;
+         double p = 0, dp = 0, ddp = 0;
+         for (int k = 0; k < nroot; k++) {
+            const double c0 = es.kind == PAML_AMD_EIGEN_CIJK ? es.Cijk[((long)i * n + j) * nroot + k] * sE[k]
+                                                             : (es.U[i * n + k] * sE[k]) * es.V[k * n + j];
+            p += c0;
+            if (k) {
+               dp += c0 * sM[k];
+               ddp += c0 * sM[k] * sM[k];
+            }
+         }
+         P[idx] = p; dP[idx] = dp; ddP[idx] = ddp;
+      }
    }
-   __syncthreads();
-   for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-      const int i = idx / n, j = idx % n;
-      double p = 0, dp = 0, ddp = 0;
-      for (int k = 0; k < nroot; k++) {
-         const double c0 = es.kind == PAML_AMD_EIGEN_CIJK ? es.Cijk[((long)i * n + j) * nroot + k] * sE[k]
-                                                          : (es.U[i * n + k] * sE[k]) * es.V[k * n + j];
-         p += c0;
-         if (k) {
-            dp += c0 * sM[k];
-            ddp += c0 * sM[k] * sM[k];
+   if (a.frag) {      // element ((kb2*4 + jb)*64 + lane)*2 + e  =  M[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)], zero padded
+      __syncthreads();
+      __threadfence_block();
+      for (int d = 0; d < 3; d++) {
+         const double *M = P + (long)d * n * n;
+         double *pf = a.frag + ((long)(pset * a.n_t + it) * 3 + d) * 4096;
+         for (int idx = threadIdx.x; idx < 4096; idx += 256) {
+            const int e = idx & 1, lane = (idx >> 1) & 63, jb = (idx >> 7) & 3, kb2 = idx >> 9;
+            const int r = jb * 16 + (lane & 15), c = 4 * (2 * kb2 + e) + (lane >> 4);
+            pf[idx] = (r < n && c < n) ? M[r * n + c] : 0.0;
          }
       }
-      P[idx] = p; dP[idx] = dp; ddP[idx] = ddp;
    }
 }
 
 struct BranchArgs {
    int n, K, n_genes, n_patt, n_t, n_pi, b_is_tip, n_codes;
-   const double *A, *B;        // [K][n_patt][n]
-   const double *SA, *SB;      // summed scale factors of A and B, [K][n_patt] (null: no scaling nodes)
+   const double *A, *B;        // partial of class ir: A + ir * cls_stride, layout [n_patt][n] (the keep-partials layout of prune_valu)
+   long cls_stride;
+   const double *SA, *SB;      // scale factors: SA[(ir * n_scale + k) * n_patt + h] summed over the n_scale slots (SB unused) — null: none
+   int n_scale;
    const unsigned char *zb;    // tip b: codes [n_patt]
    const int *n_chara;
    const unsigned char *chara_map;
@@ -1132,19 +1149,25 @@ __global__ __launch_bounds__(256) void branch_kernel(BranchArgs a)
          if (a.SA) {
             smax = -1e300;
             for (int ir = 0; ir < a.K; ir++) {
-               const double s = a.SA[(long)ir * a.n_patt + h] + (a.SB ? a.SB[(long)ir * a.n_patt + h] : 0.0);
+               double s = 0;
+               for (int k = 0; k < a.n_scale; k++) s += a.SA[((long)ir * a.n_scale + k) * a.n_patt + h];
                smax = s > smax ? s : smax;
             }
          }
          for (int ir = 0; ir < a.K; ir++) {
-            const double cs = a.SA ? exp(a.SA[(long)ir * a.n_patt + h] + (a.SB ? a.SB[(long)ir * a.n_patt + h] : 0.0) - smax) : 1.0;
-            const double *Ah = a.A + ((long)ir * a.n_patt + h) * n;
+            double cs = 1.0;
+            if (a.SA) {
+               double s = 0;
+               for (int k = 0; k < a.n_scale; k++) s += a.SA[((long)ir * a.n_scale + k) * a.n_patt + h];
+               cs = exp(s - smax);
+            }
+            const double *Ah = a.A + (long)ir * a.cls_stride + (long)h * n;
             const double *M = a.PdP + ((long)((gene * a.K + ir) * a.n_t + it) * 3) * n * n;
             const int code = a.b_is_tip ? a.zb[h] : 0;
             const int n1 = a.b_is_tip ? a.n_chara[code] : n;
             for (int ii = 0; ii < n1; ii++) {
                const int i = a.b_is_tip ? a.chara_map[code * n + ii] : ii;
-               const double bi = a.b_is_tip ? 1.0 : a.B[((long)ir * a.n_patt + h) * n + i];
+               const double bi = a.b_is_tip ? 1.0 : a.B[(long)ir * a.cls_stride + (long)h * n + i];
                const double piqi = a.freqK[ir] * pi[i] * bi * cs;
                double pq = 0, dpq = 0, ddpq = 0;
                const double *Pi = M + (long)i * n, *dPi = Pi + n * n, *ddPi = dPi + n * n;
@@ -1182,6 +1205,119 @@ __global__ __launch_bounds__(256) void branch_kernel(BranchArgs a)
          a.partial[((long)blockIdx.x * a.n_t + it) * 3 + threadIdx.x] =
             (sw[0][threadIdx.x] + sw[1][threadIdx.x]) + (sw[2][threadIdx.x] + sw[3][threadIdx.x]);
    }
+}
+
+// ---- the same contraction for the 21..64-state engines, on the matrix cores ---------------------------------------------------
+// The two partials across the branch are resident in the pruning kernels' own layout ([class][node][16-pattern group][m][lane],
+// OP_STORE), so a wave reads its 16 patterns' A and B as sixteen coalesced 512-byte loads each; P, dP and ddP arrive in MFMA
+// A-operand order (pmat_deriv_kernel's frag output), are staged through LDS by LDS-DMA exactly as the pruning kernel stages a
+// branch's P, and y = M . A is the pruning kernel's 64-MFMA matvec.  f, f', f'' = sum_i pi_i B_i y_i: sixteen FMAs per lane and
+// two cross-lane adds.  One launch per trial length; all classes inside (their mixture is per pattern).
+struct BranchMfmaArgs {
+   int n, K, n_genes, n_patt, n_pi, n_tips, n_int, n_tiles, n_scale, n_t, it;
+   int a_node, b_node;                 // the branch's two ends; b may be a tip (then its "partial" is the code's state set)
+   const int2 *tiles;                  // 64-pattern tiles (gene, first pattern)
+   const int *gene_off;
+   const double *partials;             // [K][n_int][n_tiles * 4][1024]
+   const double *scalef;               // [K][n_scale][n_patt] or null
+   const unsigned char *zb;            // tip b: codes [n_patt]
+   const unsigned long long *code_mask; // tip b: bit s set = state s belongs to the code
+   const double *pi;                   // [n_pi][4][16]
+   const double *freqK, *weights;
+   const double *frag;                 // [pset][n_t][3][4096]
+   double *partial;                    // [n_tiles][3]
+};
+
+__global__ __launch_bounds__(256, 2) void branch_mfma_kernel(BranchMfmaArgs a)
+{
+   constexpr int WAVES = 4;
+   __shared__ __attribute__((aligned(16))) double sP[2][4096];
+   __shared__ double sw[4][3];
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int q = lane >> 4, hl = lane & 15;
+   const int tile = blockIdx.x;
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;
+   const int hend = as_const(a.gene_off)[gene + 1];
+   const int h = h0 + wave * 16 + hl;
+   const bool valid = h < hend;
+   const int hc = valid ? h : hend - 1;
+   const double *pq = a.pi + (long)(a.n_pi > 1 ? gene : 0) * 64 + q * 16;
+   const long groups = (long)a.n_tiles * WAVES, grp = (long)tile * WAVES + wave;
+   const bool b_tip = a.b_node < a.n_tips;
+
+   // first matrix in flight while the scale factors are read
+   const double *frag0 = a.frag + (((long)gene * a.K * a.n_t + a.it) * 3) * 4096;      // class 0, derivative 0
+   stage_p<WAVES>(frag0, sP[0], wave, lane);
+   double smax = 0;
+   if (a.scalef) {
+      smax = -1e300;
+      for (int ir = 0; ir < a.K; ir++) {
+         double s = 0;
+         for (int k = 0; k < a.n_scale; k++) s += a.scalef[((long)ir * a.n_scale + k) * a.n_patt + hc];
+         smax = s > smax ? s : smax;
+      }
+   }
+   double f[3] = {0, 0, 0};
+   int buf = 0;
+   for (int ir = 0; ir < a.K; ir++) {
+      double cur[16], bv[16];
+      const double *pa = a.partials + (((long)ir * a.n_int + (a.a_node - a.n_tips)) * groups + grp) * 1024;
+#pragma unroll
+      for (int m = 0; m < 16; m++) cur[m] = pa[m * 64 + lane];
+      if (b_tip) {
+         const unsigned long long mask = a.code_mask[a.zb[hc]];
+#pragma unroll
+         for (int m = 0; m < 16; m++) bv[m] = ((mask >> (4 * m + q)) & 1ull) ? 1.0 : 0.0;
+      }
+      else {
+         const double *pb = a.partials + (((long)ir * a.n_int + (a.b_node - a.n_tips)) * groups + grp) * 1024;
+#pragma unroll
+         for (int m = 0; m < 16; m++) bv[m] = pb[m * 64 + lane];
+      }
+#pragma unroll
+      for (int m = 0; m < 16; m++) bv[m] *= pq[m];
+      double cs = 1.0;
+      if (a.scalef) {
+         double s = 0;
+         for (int k = 0; k < a.n_scale; k++) s += a.scalef[((long)ir * a.n_scale + k) * a.n_patt + hc];
+         cs = exp(s - smax);
+      }
+      const double wgt = a.freqK[ir] * cs;
+      for (int d = 0; d < 3; d++) {
+         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+         __syncthreads();      // this matrix has landed in sP[buf]; every wave is done with sP[buf ^ 1]
+         const int nd = d == 2 ? 0 : d + 1, nir = d == 2 ? ir + 1 : ir;
+         if (nir < a.K)
+            stage_p<WAVES>(a.frag + ((((long)gene * a.K + nir) * a.n_t + a.it) * 3 + nd) * 4096, sP[buf ^ 1], wave, lane);
+         v4d acc[4];
+         mfma_matvec(sP[buf], lane, cur, acc);
+         double g = 0;
+#pragma unroll
+         for (int m = 0; m < 16; m++) g = fma(bv[m], acc[m >> 2][m & 3], g);
+         g += __shfl_xor(g, 16);
+         g += __shfl_xor(g, 32);
+         f[d] = fma(wgt, g, f[d]);
+         buf ^= 1;
+      }
+   }
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+   double v0 = 0, v1 = 0, v2 = 0;
+   if (valid && q == 0 && a.weights[hc] > 0) {
+      const double w = a.weights[hc];
+      v0 = (log(f[0]) + smax) * w;
+      v1 = f[1] / f[0] * w;
+      v2 = (f[0] * f[2] - f[1] * f[1]) / (f[0] * f[0]) * w;
+   }
+#pragma unroll
+   for (int off = 32; off >= 1; off >>= 1) {
+      v0 += __shfl_xor(v0, off);
+      v1 += __shfl_xor(v1, off);
+      v2 += __shfl_xor(v2, off);
+   }
+   if (lane == 0) { sw[wave][0] = v0; sw[wave][1] = v1; sw[wave][2] = v2; }
+   __syncthreads();
+   if (tid < 3) a.partial[(long)tile * 3 + tid] = (sw[0][tid] + sw[1][tid]) + (sw[2][tid] + sw[3][tid]);
 }
 
 __global__ __launch_bounds__(256) void branch_reduce_kernel(const double *partial, int nb, int n_out, double *out)

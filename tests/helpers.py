@@ -144,9 +144,12 @@ def problem_from_golden(g) -> Problem:
     if kind == "codon_nssites":
         x = g["x"]
         nt = g["ntime"]
-        kappa = x[nt]
+        if "kappa" in m:                      # kappa fixed in the control file: x holds the class parameters only
+            kappa, par = m["kappa"], x[nt:]
+        else:
+            kappa, par = x[nt], x[nt + 1:]
         pi = models.f3x4(synth.f3x4_from_codon_tips(z, w))
-        freqs, omegas = nssites_classes(m["NSsites"], x[nt + 1:], m["ncatG"])
+        freqs, omegas = nssites_classes(m["NSsites"], par, m["ncatG"])
         if m["NSsites"] == 0:
             U, V, root, _ = models.codon_m0_eigen(kappa, omegas[0], pi)
             return Problem(n=61, tree=tree, z=z, weights=w, pi=pi,

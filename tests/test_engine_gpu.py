@@ -9,7 +9,7 @@ import pytest
 import helpers
 import oracle
 from paml_amd import synth
-from paml_amd.engine import KEEP_PARTIALS, engine_for
+from paml_amd.engine import JIT, KEEP_PARTIALS, engine_for
 from paml_amd.problem import Tree
 
 pytestmark = pytest.mark.gpu
@@ -202,6 +202,54 @@ def test_full_size_against_reference(name):
     assert abs(out["lnf"].sum() - g["logf_sum"]) < 1e-4
     idx = np.arange(0, pb.n_patt, g["sample_stride"])
     assert np.max(np.abs(out["lnf"][idx] - np.array(g["logf_sample"]))) < 2e-8                   # 10 printed decimals
+
+
+@pytest.mark.parametrize("name", ["syn_codon_m1a_full", "syn_codon_m2a_as_m3_full", "syn_codon_m7_full", "syn_codon_m8_as_m3_full",
+                                  "syn_codon_m2a_full", "syn_codon_m8_full"])
+def test_nssites_sweep_full_size_against_reference(name):
+    """The north_star's target workload pinned at scale: the NSsites class tables (K = 2, 3, 10, 11) on the C4 data, 16 taxa x
+    10^6 codon patterns, against the unmodified reference program's lnL (and, where it wrote its lnf file, a strided sample
+    of per-pattern log f_h).  M2a / M8 proper hold the lnL only — the reference was stopped before its hours of BEB — and
+    their class tables are also run through NSsites = 3 (the `_as_m3` goldens), which must give the same lnL."""
+    import os
+    if not os.path.exists(os.path.join(helpers.GOLDEN, name + ".json")):
+        pytest.skip("golden not generated")
+    g = helpers.load_golden(name)
+    pb = helpers.problem_from_golden(g)
+    assert pb.n_patt == 1_000_000 and pb.K == {"m1a": 2, "m2a": 3, "m7": 10, "m8": 11}[name.split("_")[2]]
+    out = engine_for(pb).eval(pb.tree.branch, want_lnf="logf_sample" in g)
+    assert abs(out["lnL"] - g["lnL"]) <= 2e-6 + 1e-12 * abs(g["lnL"]), (out["lnL"], g["lnL"])      # 6 printed decimals
+    if "logf_sample" in g:
+        assert abs(out["lnf"].sum() - g["logf_sum"]) < 1e-4
+        idx = np.arange(0, pb.n_patt, g["sample_stride"])
+        assert np.max(np.abs(out["lnf"][idx] - np.array(g["logf_sample"]))) < 2e-8               # 10 printed decimals
+    else:
+        twin = helpers.load_golden(name.replace("_full", "_as_m3_full"))
+        if name == "syn_codon_m2a_full":      # the same table through NSsites = 3: the reference agrees with itself
+            assert twin["lnL"] == g["lnL"]
+
+
+@pytest.mark.parametrize("n,K,flags", [(4, 1, 0), (4, 3, 0), (4, 3, JIT), (5, 2, JIT), (20, 1, 0), (20, 2, JIT), (61, 1, 0), (61, 3, 0),
+                                       (61, 1, JIT), (61, 3, JIT)])
+def test_numeric_floors(n, K, flags):
+    """lfun's `fh <= 0 -> 1e-80` (treesub.c:7794) and fx_r's `fh <= 0 -> 1e-300` (treesub.c:7741) on the HIP path: with every
+    branch length 0, P(t) is the identity (tools.c:525), so a pattern whose tips disagree has a root sum of exactly 0 in
+    every class; the lnL must carry log(1e-80) (one class) or log(sum_k freqK_k 1e-300) (lfundG) for it, as the oracle's
+    restatement of the floors does."""
+    pb = helpers.random_problem(n, 8, 300, K=K, seed=900 + n + K)
+    pb.tree.branch[:] = 0.0
+    pb.z[:, 1::2] = pb.z[0:1, 1::2]              # odd patterns: all tips equal -> f = pi_state
+    assert (pb.z[:, 0::2].min(axis=0) != pb.z[:, 0::2].max(axis=0)).any()
+    ref = oracle.evaluate(pb)
+    floor = np.log(1e-80) if K == 1 else np.log(1e-300)
+    hit = np.isclose(ref["lnf"], floor, rtol=0, atol=1e-9)
+    assert hit.any() and not hit.all()
+    eng = engine_for(pb, flags=flags)
+    out = eng.eval(pb.tree.branch, want_lnf=True, want_fhk=True)
+    assert np.max(np.abs(out["lnf"] - ref["lnf"])) < 1e-9
+    assert abs(out["lnL"] - ref["lnL"]) <= 1e-10 * abs(ref["lnL"])
+    if K > 1:
+        assert (out["fhK"][:, hit] == 1e-300).all()      # fx_r stores the floored class likelihoods
 
 
 @pytest.mark.parametrize("n,K,amb,genes", [(4, 1, False, 1), (4, 4, True, 2), (20, 2, False, 1), (61, 1, False, 1), (61, 3, True, 1)])
@@ -750,3 +798,51 @@ def test_two_engines_on_two_threads_and_streams():
     assert not errs, errs
     for i in range(2):
         assert got[i] == [want[i]] * 30
+
+
+@pytest.mark.parametrize("n,K,scale", [(4, 3, None), (61, 2, None), (61, 1, 3), (20, 2, None)])
+def test_eval_branch_partial_cache_cycles_like_minbranches(n, K, scale):
+    """The resident partials of paml_amd_eval_branch (what updateconP + com.oldconP save the reference, treesub.c:7982,
+    treespace.c:250): cycling through the branches as minbranches does (treesub.c:8081-8095), changing one length after
+    another, every l / dl / ddl equals the oracle's for the current lengths, and after the first call only the nodes on the
+    path between consecutive branches are recomputed — far fewer than a full tree per call."""
+    pb = helpers.random_problem(n, 14, 200, K=K, seed=300 + n + K, scale_every=scale)
+    eng = engine_for(pb)
+    t = pb.tree
+    order = []
+
+    def pre(i):                       # tree.branches order: first appearance in the Newick string = pre-order
+        for c in t.sons[i]:
+            order.append(c)
+            pre(c)
+    pre(t.root)
+    rng = np.random.default_rng(1)
+    n_int = t.n_nodes - t.n_tips
+    first = None
+    for cycle in range(2):
+        for b in order:
+            ts = np.array([t.branch[b], t.branch[b] * 1.3 + 0.01])
+            l, dl, ddl = eng.eval_branch(b, ts, t.branch, pb.gene_rate)
+            rl, rdl, rddl = oracle.eval_branch(pb, b, ts)
+            assert np.allclose(l, rl, rtol=1e-11, atol=0), (cycle, b, l, rl)
+            assert np.allclose(dl, rdl, rtol=1e-9, atol=1e-9)
+            assert np.allclose(ddl, rddl, rtol=1e-9, atol=1e-8)
+            if first is None:
+                first = eng.branch_counters()["n_nodes"]
+                assert first == n_int                      # the first call forms every partial once
+            t.branch[b] = float(ts[1]) if rng.random() < 0.7 else t.branch[b]      # "Newton step": the length moves on
+    c = eng.branch_counters()
+    calls_after_first = c["n_calls"] - 1
+    assert c["n_nodes"] - first <= 2.5 * calls_after_first < n_int * calls_after_first / 2, c
+    # an ordinary evaluation still works and agrees with the branch-local value at the current lengths
+    base = eng.eval(t.branch, pb.gene_rate)["lnL"]
+    b = order[3]
+    l, _, _ = eng.eval_branch(b, np.array([t.branch[b]]), t.branch, pb.gene_rate)
+    assert abs(l[0] - base) <= 1e-11 * abs(base)
+    # changing a far-away length invalidates only the partials that look across that branch
+    far = order[-1]
+    t.branch[far] *= 1.5
+    before = eng.branch_counters()["n_nodes"]
+    l, _, _ = eng.eval_branch(b, np.array([t.branch[b]]), t.branch, pb.gene_rate)
+    assert abs(l[0] - oracle.eval_branch(pb, b, np.array([t.branch[b]]))[0][0]) <= 1e-11 * abs(base)
+    assert 0 < eng.branch_counters()["n_nodes"] - before < n_int

@@ -7,7 +7,9 @@ import helpers
 import oracle
 
 CASES = ["hiv_m0", "hiv_m1a", "hiv_m2a", "hiv_m7", "hiv_m8", "syn_codon_m0", "syn_nuc_gtr_g4", "brown_hky85",
-         "stewart_lg_g4", "mhc_m0_scaled"]
+         "stewart_lg_g4", "mhc_m0_scaled",
+         # 4000-pattern versions of the north_star sweep's class tables (M2a's and M8's run through NSsites = 3, M7)
+         "syn_codon_m2a_as_m3_4000", "syn_codon_m8_as_m3_4000", "syn_codon_m7_4000"]
 
 
 @pytest.mark.parametrize("name", CASES)
