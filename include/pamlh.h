@@ -70,6 +70,9 @@ int pamlh_genes(const pamlh *p, const int **gene_off, const double **gene_rate, 
 int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const double **U, const double **V,
                 const double **Root, const double **Cijk);
 
+/* The paml_amd_engine behind this analysis (NULL before the first evaluation). */
+void *pamlh_engine_handle(const pamlh *p);
+
 /* One likelihood evaluation on the GPU through the engine ABI (creates the engine on first use).  lnf may be NULL. */
 int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf);
 /* lnL at n_batch parameter vectors xs[n_batch][np] in ONE launch (paml_amd_eval_batch): vectors that differ only in branch
@@ -81,6 +84,15 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi);
  * differences) and every line search (12 trial steps) evaluated as one batch on the GPU.  x: start in, estimate out.
  * Returns 0 converged, 1 max_iter reached, < 0 error.  n_eval (may be NULL): likelihood evaluations spent. */
 int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, int verbose, int *n_eval);
+
+/* method = 1 of the control file: minB / minbranches (treesub.c:7826, 8039) — the branch lengths are optimised one at a time
+ * by Newton steps on the branch-local lnL, dlnL/dt, d2lnL/dt2 (paml_amd_eval_branch; the engine keeps the partials of both
+ * sides of every edge resident, so a step along the tree costs the nodes on the path, not the tree), alternating with BFGS
+ * on the other parameters.  pamlh_minbranches: one such pass over the branch lengths in x (tolerance e), the rest of x held.
+ * pamlh_optimize_minb: the alternation until |delta lnL| < e0.  n_eval: full evaluations spent on the other parameters. */
+int pamlh_method(const pamlh *p);      /* the control file's `method` */
+int pamlh_minbranches(pamlh *p, double *x, double e, double *lnL, int verbose);
+int pamlh_optimize_minb(pamlh *p, double *x, double *lnL, double e0, int verbose, int *n_eval);
 
 /* Standard errors of the estimates (getSE = 1).  method 0: HessianSKT2004 (treesub.c:7241), the outer product of per-pattern
  * scores that the reference's programs print; method 1: observed information from central second differences of lnL

@@ -67,6 +67,9 @@ struct pamlh {
    double qfactor[64];     /* branch-site / clade models: time scale of (class, branch type), [K][n_labels] */
    int use_qf;
    double ns_mr;           /* NSsites: mean rate at the mean omega = 1 / Qfactor_NS of the last pamlh_set_x */
+   /* optimiser state (pamlh_opt.c) */
+   unsigned char *frozen;  /* NULL, or [np]: parameters pamlh_optimize leaves where they are (minB holds the branch lengths) */
+   int opt_lean;           /* 1: fewer trial points per line search, no curvature pre-pass (the inner ming2 of minB) */
    /* engine */
    paml_amd_engine *eng;
 };
@@ -92,6 +95,7 @@ int pamlh_read_seqs(pamlh *p);
 int pamlh_read_tree(pamlh *p);
 int pamlh_fail(pamlh *p, const char *fmt, ...);
 int pamlh_engine_ready(pamlh *p);
+int pamlh_engine_model(pamlh *p);      /* pi, eigen systems and class tables of the current model state -> engine */
 int pamlh_model_feasible(const pamlh *p);
 int pamlh_x_to_branches(const pamlh *p, const double *x, double *branch);
 pamlh *pamlh_state_clone(const pamlh *p);

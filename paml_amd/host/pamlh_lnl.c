@@ -52,7 +52,9 @@ int main(int argc, char **argv)
    if (!nx) nx = pamlh_default_x(p, x, 4096);
    if (nx != np) { fprintf(stderr, "error: the model has %d parameters (ntime %d) but %d values were given\n", np, ntime, nx); return 1; }
    if (optimize) {
-      int n_eval = 0, rc = pamlh_optimize(p, x, &lnL, 500, 1e-10, 1, &n_eval);
+      /* method = 1 in the control file: minB / minbranches (one branch at a time on the branch-local derivatives) */
+      const int method1 = pamlh_method(p) == 1;
+      int n_eval = 0, rc = method1 ? pamlh_optimize_minb(p, x, &lnL, 1e-6, 1, &n_eval) : pamlh_optimize(p, x, &lnL, 500, 1e-10, 1, &n_eval);
       if (rc < 0) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
       printf("%s after %d likelihood evaluations\nx:", rc ? "iteration limit reached" : "converged", n_eval);
       for (i = 0; i < np; i++) printf(" %.6f", x[i]);

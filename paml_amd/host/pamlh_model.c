@@ -1111,6 +1111,32 @@ int pamlh_model_feasible(const pamlh *p)
    return 1;
 }
 
+/* `method` of the control file (0: all parameters at once, 1: one branch at a time) */
+int pamlh_method(const pamlh *p) { return (int)pamlh_optd(p, "method", 0); }
+
+/* the engine behind this analysis (NULL before the first evaluation): counters, profiling */
+void *pamlh_engine_handle(const pamlh *p) { return p ? (void *)p->eng : NULL; }
+
+int pamlh_engine_model(pamlh *p)
+{
+   int i, rc;
+   if ((rc = pamlh_engine_ready(p))) return rc;
+   if ((rc = paml_amd_set_pi(p->eng, p->n_pi, p->pi))) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   for (i = 0; i < p->n_eigen; i++) {
+      const pamlh_eig *e = &p->eig[i];
+      if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, i, e->U, e->V, e->Root);
+      else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(p->eng, i, e->nR, e->Cijk, e->Root);
+      else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(p->eng, i, e->kappa);
+      else if (e->kind == PAML_AMD_EIGEN_QMAT) rc = paml_amd_set_eigen_qmat(p->eng, i, e->U);
+      else rc = paml_amd_set_eigen_jc69like(p->eng, i);
+      if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   }
+   if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->ngene > 1 ? p->gene_eigen_of : p->eigen_of,
+                                  p->use_qf ? p->qfactor : NULL)))
+      return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   return 0;
+}
+
 int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
 {
    int i, rc;

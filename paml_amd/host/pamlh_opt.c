@@ -229,26 +229,39 @@ static double dot(const double *a, const double *b, int n)
    return s;
 }
 
-/* Central-difference gradient of f = -lnL at x (one batch of <= 2 np points; one-sided where the box is in the way). */
+/* Central-difference gradient of f = -lnL at x (one batch of <= 2 np points; one-sided where the box is in the way, or where
+ * the model rejects the nudged vector — class proportions are iterated untransformed, so next to p0 + p1 = 1 a side can be
+ * infeasible and comes back as the -1e300 marker: it is a blocked side, not a value).  Frozen parameters are not nudged. */
 static int gradient(pamlh *p, const double *x, double f0, const double *lo, const double *hi, double *g, double *xs, double *ls, int *n_eval)
 {
    const int n = p->np;
-   int i, rc;
+   int i, rc, na = 0;
+   int *act = (int *)malloc((n + 1) * sizeof(int));
    for (i = 0; i < n; i++) {
       const double h = 1e-6 * (fabs(x[i]) + 1);
-      double *xp = xs + (size_t)(2 * i) * n, *xm = xp + n;
+      double *xp, *xm;
+      g[i] = 0;
+      if (p->frozen && p->frozen[i]) continue;
+      xp = xs + (size_t)(2 * na) * n; xm = xp + n;
       memcpy(xp, x, n * sizeof(double));
       memcpy(xm, x, n * sizeof(double));
       if (x[i] + h <= hi[i]) xp[i] = x[i] + h;
       if (x[i] - h >= lo[i]) xm[i] = x[i] - h;
+      act[na++] = i;
    }
-   if ((rc = batch_eval(p, 2 * n, xs, ls))) return rc;
-   *n_eval += 2 * n;
-   for (i = 0; i < n; i++) {
-      const double *xp = xs + (size_t)(2 * i) * n, *xm = xp + n;
-      const double fp = xp[i] != x[i] ? -ls[2 * i] : f0, fm = xm[i] != x[i] ? -ls[2 * i + 1] : f0;
-      g[i] = xp[i] > xm[i] ? (fp - fm) / (xp[i] - xm[i]) : 0;
+   if (na && (rc = batch_eval(p, 2 * na, xs, ls))) { free(act); return rc; }
+   *n_eval += 2 * na;
+   for (int a = 0; a < na; a++) {
+      const double *xp = xs + (size_t)(2 * a) * n, *xm = xp + n;
+      i = act[a];
+      {
+         const int okp = xp[i] != x[i] && ls[2 * a] > -1e299, okm = xm[i] != x[i] && ls[2 * a + 1] > -1e299;
+         const double fp = okp ? -ls[2 * a] : f0, fm = okm ? -ls[2 * a + 1] : f0;
+         const double vp = okp ? xp[i] : x[i], vm = okm ? xm[i] : x[i];
+         g[i] = vp > vm ? (fp - fm) / (vp - vm) : 0;
+      }
    }
+   free(act);
    return 0;
 }
 
@@ -267,7 +280,7 @@ static int diag_inverse_hessian(pamlh *p, const double *x, double f0, const doub
       memcpy(xp, x, n * sizeof(double));
       memcpy(xm, x, n * sizeof(double));
       xp[i] = x[i] + h; xm[i] = x[i] - h;
-      if (xp[i] > hi[i] || xm[i] < lo[i]) xp[i] = xm[i] = x[i];      /* no room for a symmetric difference */
+      if (xp[i] > hi[i] || xm[i] < lo[i] || (p->frozen && p->frozen[i])) xp[i] = xm[i] = x[i];      /* no room for a symmetric difference */
    }
    if ((rc = batch_eval(p, 2 * n, xs, ls))) { free(hd); return rc; }
    *n_eval += 2 * n;
@@ -288,7 +301,7 @@ static int diag_inverse_hessian(pamlh *p, const double *x, double f0, const doub
 /* Maximise lnL over x (in: start, out: estimate).  Returns 0 when converged, 1 when max_iter was reached, < 0 on error. */
 int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, int verbose, int *n_eval_out)
 {
-   const int n = p->np, NC = 12;
+   const int n = p->np, NC = p->opt_lean ? 6 : 12;
    double *lo = (double *)malloc(n * sizeof(double)), *hi = (double *)malloc(n * sizeof(double));
    double *g = (double *)malloc(n * sizeof(double)), *g0 = (double *)malloc(n * sizeof(double)), *d = (double *)malloc(n * sizeof(double));
    double *s = (double *)malloc(n * sizeof(double)), *y = (double *)malloc(n * sizeof(double)), *Hy = (double *)malloc(n * sizeof(double));
@@ -311,14 +324,17 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
    n_eval++;
    f = -ls[0];
    if (f > 1e299) { rc = pamlh_fail(p, "the starting point is infeasible"); goto done; }
-   if ((rc = diag_inverse_hessian(p, x, f, lo, hi, H, xs, ls, &n_eval))) goto done;
-   reset = 0;
+   if (p->opt_lean) { for (i = 0; i < n * n; i++) H[i] = 0; for (i = 0; i < n; i++) H[i * n + i] = 1; reset = 1; }
+   else {
+      if ((rc = diag_inverse_hessian(p, x, f, lo, hi, H, xs, ls, &n_eval))) goto done;
+      reset = 0;
+   }
    if ((rc = gradient(p, x, f, lo, hi, g, xs, ls, &n_eval))) goto done;
    for (it = 0; it < max_iter; it++) {
       double amax = 1e300, best = f, abest = 0, gd, sy;
       int nc = 0;
       /* variables sitting on a bound with the gradient pushing outward stay there this iteration */
-      for (i = 0; i < n; i++) fixed[i] = (x[i] <= lo[i] && g[i] > 0) || (x[i] >= hi[i] && g[i] < 0);
+      for (i = 0; i < n; i++) fixed[i] = (x[i] <= lo[i] && g[i] > 0) || (x[i] >= hi[i] && g[i] < 0) || (p->frozen && p->frozen[i]);
       for (i = 0; i < n; i++) {
          d[i] = 0;
          if (fixed[i]) continue;
@@ -361,7 +377,7 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
             if (-ls[j] < best) { best = -ls[j]; abest = as[j]; }
       }
       if (abest == 0) {         /* no step length improves f */
-         if (!fresh) {          /* distrust the curvature information once before giving up */
+         if (!fresh && !p->opt_lean) {          /* distrust the curvature information once before giving up */
             if ((rc = diag_inverse_hessian(p, x, f, lo, hi, H, xs, ls, &n_eval))) goto done;
             fresh = 1;
             continue;
@@ -413,7 +429,7 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
          /* Two tiny steps in a row: either the maximum, or an inverse Hessian that has gone bad on a ridge (the site-class
           * models have them: proportions against omegas).  Forget the curvature and go on from steepest descent; stop when
           * such a restart (from the diagonal second differences) no longer gains anything. */
-         if (restarts < 8 && f_restart - f > 1e-7 * (fabs(f) + 1)) {
+         if (!p->opt_lean && restarts < 8 && f_restart - f > 1e-7 * (fabs(f) + 1)) {
             f_restart = f; restarts++; small_steps = 0; fresh = 1;
             if ((rc = diag_inverse_hessian(p, x, f, lo, hi, H, xs, ls, &n_eval))) goto done;
             continue;
@@ -429,6 +445,111 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
 done:
    if (n_eval_out) *n_eval_out = n_eval;
    free(lo); free(hi); free(g); free(g0); free(d); free(s); free(y); free(Hy); free(H); free(xs); free(ls); free(fixed);
+   return rc ? rc : status;
+}
+
+/* ---- method = 1: one branch at a time ----------------------------------------------------------------------------------------
+ * minbranches (treesub.c:8039-8117) restated on paml_amd_eval_branch: cycle through the branches in tree.branches order; for
+ * each, Newton's direction p = -l' / |l''| from the branch-local l, l', l'' (lfuntdd), cut to the interval [1e-8, 50], and
+ * the step length quartered until lnL improves (lfunt) — here the trial lengths t0 + s p, s = step, step / 4, step / 16,
+ * step / 64 are ONE call.  The engine keeps the partials of both sides of every edge resident, so moving on to the next
+ * branch recomputes only the nodes between the two (updateconP treesub.c:7982; com.oldconP treespace.c:250).
+ * x[0 .. ntime) are updated in place; returns +lnL in *lnL.  e = convergence tolerance of a cycle (e_minbranches). */
+int pamlh_minbranches(pamlh *p, double *x, double e, double *lnL, int verbose)
+{
+   const double tb0 = 1e-8, tb1 = 50, smallv = 1e-20;
+   const int maxcycle = 500, ncycleb = 10;
+   double *br;
+   double L = 0, Lcycle = 0, y[4], dy[4], ddy[4], ts[4];
+   int icycle, ib, icb, i, rc = 0, have_L = 0;
+   if (p->clock || p->fix_blength || !p->ntime || p->ntime != p->nbranch || p->adg)
+      return pamlh_fail(p, "minbranches needs free, unconstrained branch lengths (clock = 0, fix_blength = 0) and no rho");
+   if (pamlh_set_x(p, x, p->np) || !pamlh_model_feasible(p)) return pamlh_fail(p, "minbranches: the model rejects x");
+   if ((rc = pamlh_engine_model(p))) return rc;
+   br = (double *)malloc(p->nnode * sizeof(double));
+   memcpy(br, p->branch, p->nnode * sizeof(double));
+   for (icycle = 0; icycle < maxcycle; icycle++) {
+      for (ib = 0; ib < p->nbranch; ib++) {
+         const int b = p->branch_node[ib];
+         double t0 = br[b], t = t0, L0 = 0, Lt = 0;
+         for (icb = 0; icb < ncycleb; icb++) {
+            double pn, step, s;
+            int found = 0;
+            ts[0] = t0;
+            if (paml_amd_eval_branch(p->eng, b, 1, ts, br, p->ngene > 1 ? p->rgene : NULL, y, dy, ddy)) { rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); goto done; }
+            L0 = y[0];
+            pn = dy[0] / fabs(ddy[0]);                       /* = -dl / |ddl| with l = -lnL */
+            if (!(fabs(pn) >= smallv)) step = 0;             /* (also catches NaN) */
+            else if (pn < 0) step = fmin(1, (tb0 - t0) / pn);
+            else step = fmin(1, (tb1 - t0) / pn);
+            if (icycle == 0 && step != 1 && step != 0) step *= 0.99;      /* keep off the border */
+            for (s = step; s > smallv && !found; s /= 256) {
+               int k, nt = 0;
+               double sk = s;
+               for (k = 0; k < 4 && sk > smallv; k++, sk /= 4) ts[nt++] = t0 + sk * pn;
+               if (paml_amd_eval_branch(p->eng, b, nt, ts, br, p->ngene > 1 ? p->rgene : NULL, y, dy, ddy)) { rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); goto done; }
+               for (k = 0; k < nt; k++)
+                  if (y[k] > L0) { t = ts[k]; Lt = y[k]; found = 1; break; }
+            }
+            if (!found) { t = t0; Lt = L0; break; }
+            if (fabs(t - t0) < e * fabs(1 + t) && fabs(Lt - L0) < e) break;
+            t0 = t; L0 = Lt;
+         }
+         br[b] = t;
+         L = Lt; have_L = 1;
+      }
+      if (verbose) fprintf(stderr, "\tminbranches cycle %2d: lnL %.6f\n", icycle + 1, L);
+      if (icycle && fabs(L - Lcycle) < e) break;
+      if (!icycle && !have_L) break;
+      Lcycle = L;
+   }
+   for (i = 0; i < p->ntime; i++) x[i] = br[p->branch_node[i]];
+   *lnL = L;
+done:
+   free(br);
+   return rc;
+}
+
+/* minB (treesub.c:7826-7941): alternate between the substitution parameters (ming2 on x[ntime..np) with the branch lengths
+ * held; here pamlh_optimize with those frozen) and minbranches, tightening the tolerances as the improvement per round falls.
+ * Returns 0 converged, 1 round limit, < 0 error.  n_eval: full likelihood evaluations spent by the parameter steps. */
+int pamlh_optimize_minb(pamlh *p, double *x, double *lnL, double e0, int verbose, int *n_eval_out)
+{
+   const int np = p->np, npcom = np - p->ntime, maxr = npcom ? 200 : 1;
+   double e = npcom ? 5.0 : e0, e_mb = e, L = 0, L0 = -1e300, dl;
+   int ir, i, rc = 0, status = 1, n_eval = 0, ne;
+   unsigned char *frozen = (unsigned char *)calloc(np ? np : 1, 1);
+   for (i = 0; i < p->ntime; i++) frozen[i] = 1;
+   for (ir = 0; ir < maxr; ir++) {
+      if (npcom) {
+         p->frozen = frozen; p->opt_lean = 1;
+         rc = pamlh_optimize(p, x, &L, e > 0.05 ? 2 : 30, fmax(1e-10, e * 1e-7), 0, &ne);
+         p->frozen = NULL; p->opt_lean = 0;
+         n_eval += ne;
+         if (rc < 0) goto done;
+         if (verbose) fprintf(stderr, "round %da: parameters, lnL %.6f (%d evaluations)\n", ir + 1, L, ne);
+      }
+      if ((rc = pamlh_minbranches(p, x, e_mb, &L, verbose > 1))) goto done;
+      if (verbose) fprintf(stderr, "round %db: branch lengths, lnL %.6f (e = %.3g)\n", ir + 1, L, e_mb);
+      dl = fabs(L - L0);
+      if (dl < e0 && e <= 0.02) { status = 0; break; }
+      e /= 2; if (dl < 1) e /= 2;
+      if (dl < 0.5) e = fmin(e, 1e-3);
+      else if (dl > 10) e = fmax(e, 0.1);
+      e_mb = fmax(e, 1e-6);
+      e = fmax(e, 1e-6);
+      L0 = L;
+   }
+   if (!npcom) status = 0;
+   /* "restore things": one ordinary evaluation at the estimate (also leaves the model state there) */
+   if (pamlh_set_x(p, x, np)) { rc = -1; goto done; }
+   if ((rc = pamlh_eval_gpu(p, lnL, NULL))) goto done;
+   n_eval++;
+   if (fabs(*lnL - L) > 1e-6 * (fabs(L) + 1)) rc = pamlh_fail(p, "minB: lnL %.9f after the last round, %.9f on re-evaluation", L, *lnL);
+done:
+   free(frozen);
+   p->frozen = NULL; p->opt_lean = 0;
+   if (n_eval_out) *n_eval_out = n_eval;
    return rc ? rc : status;
 }
 

@@ -201,6 +201,24 @@ class Analysis:
             raise RuntimeError("pamlh_optimize: " + self._L.pamlh_error(self._h).decode())
         return dict(x=x, lnL=lnl.value, converged=rc == 0, n_eval=nev.value)
 
+    def optimize_minb(self, x0, e0=1e-6, verbose=0):
+        """method = 1 (pamlh_optimize_minb): branch lengths one at a time by Newton steps on the branch-local derivatives, the
+        other parameters by BFGS in between.  Returns dict(x, lnL, converged, n_eval, branch_calls, nodes_recomputed)."""
+        from . import engine
+        x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+        lnl, nev = C.c_double(), C.c_int()
+        self._L.pamlh_optimize_minb.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_int, C.POINTER(C.c_int)]
+        rc = self._L.pamlh_optimize_minb(self._h, x.ctypes.data_as(C.c_void_p), C.byref(lnl), float(e0), int(verbose), C.byref(nev))
+        if rc < 0:
+            raise RuntimeError("pamlh_optimize_minb: " + self._L.pamlh_error(self._h).decode())
+        a, b = C.c_long(), C.c_long()
+        self._L.pamlh_engine_handle.restype = C.c_void_p
+        self._L.pamlh_engine_handle.argtypes = [C.c_void_p]
+        L = engine.lib()
+        L.paml_amd_branch_counters.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.paml_amd_branch_counters(C.c_void_p(self._L.pamlh_engine_handle(self._h)), C.byref(a), C.byref(b))
+        return dict(x=x, lnL=lnl.value, converged=rc == 0, n_eval=nev.value, branch_calls=a.value, nodes_recomputed=b.value)
+
     def standard_errors(self, x, method=0):
         """Standard errors at the estimate x (pamlh_standard_errors): method 0 = the reference's HessianSKT2004 outer
         product of scores, method 1 = second differences of lnL; -1 marks a parameter without an estimate."""

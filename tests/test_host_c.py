@@ -214,6 +214,29 @@ def test_c_host_optimiser_finds_the_reference_mle(gname, prog, ctl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gname,prog,ctl", [CASES[2], CASES[0], CASES[4]])
+def test_c_host_method1_minbranches(gname, prog, ctl):
+    """method = 1 (minB / minbranches, treesub.c:7826-8117) on the engine's branch-local path: from the control file's
+    initial values the reference's MLE lnL is reached (HIV M0 -1137.688190, brown HKY85 -2665.422858, HIV M2a -1106.445004),
+    and — the point of the method — with few full-tree evaluations: the branch steps recompute only the nodes on the path
+    between consecutive branches.  BASELINE.md section 3: the reference spends 122 lfun on HIV M0 with method = 1."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), prog)
+    r = a.optimize_minb(a.default_x())
+    assert r["converged"], r
+    assert abs(r["lnL"] - g["lnL"]) <= 5e-6, (r["lnL"], g["lnL"])
+    n_int = a.n_nodes - a.n_tips
+    # work in full-tree equivalents: the parameter steps' evaluations + the partials recomputed by the branch steps
+    # (a full tree = n_int internal-node partials) + one matrix product per trial length evaluated (1 / n_int of a tree each)
+    equiv = r["n_eval"] + r["nodes_recomputed"] / n_int
+    print("%s: %d full evaluations + %d branch calls recomputing %d node partials = %.1f full-tree equivalents"
+          % (gname, r["n_eval"], r["branch_calls"], r["nodes_recomputed"], equiv))
+    assert r["nodes_recomputed"] < 3 * r["branch_calls"] + n_int
+    if gname == "hiv_m0":
+        assert equiv <= 200, equiv
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("gname,ctl", [("lyso_bsa", "lyso_bsa.ctl"), ("lyso_bsa_null", "lyso_bsa_null.ctl"), ("ecp_cmc", "ecp_cmc.ctl")])
 def test_c_host_optimiser_on_branch_site_and_clade_models(gname, ctl):
     """Branch-site model A (alternative and null of the branch-site test, lysozyme data of examples/lysozyme) and clade model C
