@@ -70,6 +70,7 @@ struct pamlh {
    /* optimiser state (pamlh_opt.c) */
    unsigned char *frozen;  /* NULL, or [np]: parameters pamlh_optimize leaves where they are (minB holds the branch lengths) */
    int opt_lean;           /* 1: fewer trial points per line search, no curvature pre-pass (the inner ming2 of minB) */
+   double opt_abs_tol;     /* > 0 (lean mode): stop as soon as an iteration gains less than this in lnL (ming2's e) */
    /* engine */
    paml_amd_engine *eng;
 };

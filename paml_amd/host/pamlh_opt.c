@@ -424,6 +424,7 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
          for (i = 0; i < n; i++) { const double r = fabs(s[i]) / (fabs(x[i]) + 1); if (r > smax) smax = r; }
          small_steps = (f - fnew < tol * (fabs(fnew) + 1) && smax < 1e-5) ? small_steps + 1 : 0;
       }
+      if (p->opt_lean && p->opt_abs_tol > 0 && f - fnew < p->opt_abs_tol) { f = fnew; status = 0; break; }
       f = fnew;
       if (small_steps >= 2) {
          /* Two tiny steps in a row: either the maximum, or an inverse Hessian that has gone bad on a ridge (the site-class
@@ -522,9 +523,9 @@ int pamlh_optimize_minb(pamlh *p, double *x, double *lnL, double e0, int verbose
    for (i = 0; i < p->ntime; i++) frozen[i] = 1;
    for (ir = 0; ir < maxr; ir++) {
       if (npcom) {
-         p->frozen = frozen; p->opt_lean = 1;
-         rc = pamlh_optimize(p, x, &L, e > 0.05 ? 2 : 30, fmax(1e-10, e * 1e-7), 0, &ne);
-         p->frozen = NULL; p->opt_lean = 0;
+         p->frozen = frozen; p->opt_lean = 1; p->opt_abs_tol = e;
+         rc = pamlh_optimize(p, x, &L, e > 0.05 ? 2 : 30, 1e-10, 0, &ne);
+         p->frozen = NULL; p->opt_lean = 0; p->opt_abs_tol = 0;
          n_eval += ne;
          if (rc < 0) goto done;
          if (verbose) fprintf(stderr, "round %da: parameters, lnL %.6f (%d evaluations)\n", ir + 1, L, ne);
@@ -548,7 +549,7 @@ int pamlh_optimize_minb(pamlh *p, double *x, double *lnL, double e0, int verbose
    if (fabs(*lnL - L) > 1e-6 * (fabs(L) + 1)) rc = pamlh_fail(p, "minB: lnL %.9f after the last round, %.9f on re-evaluation", L, *lnL);
 done:
    free(frozen);
-   p->frozen = NULL; p->opt_lean = 0;
+   p->frozen = NULL; p->opt_lean = 0; p->opt_abs_tol = 0;
    if (n_eval_out) *n_eval_out = n_eval;
    return rc ? rc : status;
 }
