@@ -235,6 +235,13 @@ int paml_amd_debug_program(int n_tips, int n_nodes, int root, const int *sons_pt
 int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, const int *sons,
                        const unsigned char *scale_node, char *text_out, int cap, int compile);
 
+/* Host-only (hiprtc cross-compiles without a GPU): compile the per-tree kernel an engine of these sizes would select for this tree
+ * and keep the code object in `dir` (the library's read-only lib/jit directory, or a user cache), so that the first evaluation on
+ * a fresh machine does not start with seconds of compilation.  n_patt_global fixes the reduction chunk the 4 / 5-state kernel is
+ * specialised on; K = site classes. */
+int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_patt_global, int n_nodes, int root, const int *sons_ptr,
+                          const int *sons, const unsigned char *scale_node, const char *dir, char *log_out, int log_cap);
+
 /* Name of the pruning kernel the engine selected ("mfma64", "valu4", "valu20", ...). */
 const char *paml_amd_kernel_name(const paml_amd_engine *e);
 

@@ -224,6 +224,11 @@ __device__ __forceinline__ void tip_lds(const double *tab, int code, int q, int 
 // the accumulator tuple of row block jb = m >> 2, so MFMA results are partials with no copies, and the
 // B operand of k-block kb is x[kb >> 2][kb & 3].
 // ------------------------------------------------------------------------------------------------
+#ifdef JIT_ABL_NOBAR
+#define JIT_SYNC() ((void)0)
+#else
+#define JIT_SYNC() __syncthreads()
+#endif
 // `side(kb2)` runs once per k-block pair between the two MFMA groups: the generator puts the ring's refill DMAs there
 // (a few per iteration) so that their issue — which can queue behind the other waves' — never delays the first MFMAs.
 struct JitNoSide { __device__ __forceinline__ void operator()(int) const {} };
@@ -313,7 +318,7 @@ __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, c
    for (int kb2 = 0; kb2 < KB2; kb2++) {
       if (kb2 == MID) {
          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MIDWAIT) : "memory");
-         __syncthreads();
+         JIT_SYNC();
       }
       if (kb2 + 1 < KB2) {
 #pragma unroll

@@ -143,7 +143,7 @@ inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global
 
 // Environment switches, read once when the engine is created.
 struct EnvCfg {
-   bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false;
+   bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, no_mfma4 = false;
    std::string jit_dump, prof_ops;
    int prof_tid = 0;
    void read()
@@ -154,6 +154,7 @@ struct EnvCfg {
       jit_strict = getenv("PAML_AMD_JIT_STRICT") != nullptr;
       valu20 = getenv("PAML_AMD_VALU20") != nullptr;
       no_fused = getenv("PAML_AMD_NO_FUSED") != nullptr;
+      no_mfma4 = getenv("PAML_AMD_NO_MFMA4") != nullptr;
       if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
       if (const char *v = getenv("PAML_AMD_PROF_OPS")) prof_ops = v;
       if (const char *v = getenv("PAML_AMD_PROF_TID")) prof_tid = atoi(v);
@@ -189,6 +190,7 @@ struct paml_amd_engine {
    double *h_out = nullptr;           // pinned, device-visible: the synchronous entry points have lnL written straight to the host
    size_t h_out_cap = 0;
    bool fused = false;                // the selected kernel forms the reduction itself
+   bool fused_mfma4 = false;
    int fused_threads = 256;
    bool pmat_valid = false;           // d_rowmajor holds the P(t) of an evaluation in the tree's own orientation
    // branch-local evaluation: resident partials on both sides of every edge, re-used from call to call (eval_branch)
@@ -637,9 +639,13 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          // the fused form (classes inside, LDS tip tables, reduction in the epilogue) when the model fits it
          const ValuFusedPlan pl = jit_valu_fused_plan(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk);
          if (pl.ok && G == 1 && e->n_pi == 1 && e->d_zpm.p && !e->env.no_fused) {
-            int r = ensure_jit(e, "vf" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "k" + std::to_string(Km) + "r" + std::to_string(pl.R) + "w" +
+            // 4 states: the matrix-core form (v_mfma_f64_4x4x4) unless switched off
+            const bool m4 = n == 4 && !e->env.no_mfma4;
+            int r = ensure_jit(e, std::string(m4 ? "m4" : "vf") + std::to_string(n) + "c" + std::to_string(e->n_codes) + "k" + std::to_string(Km) + "r" + std::to_string(pl.R) + "w" +
                                      std::to_string(pl.CW) + (pl.cherry ? "y:" : "n:") + jit_program_key(e->prog, e->n_tips),
-                               [&]() { return jit_generate_valu_fused(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk); }, &jit_ok);
+                               [&]() { return m4 ? jit_generate_mfma4(e->prog, e->n_tips, e->n_codes, Km, e->chunk)
+                                                 : jit_generate_valu_fused(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk); }, &jit_ok);
+            e->fused_mfma4 = jit_ok && m4;
             if (r) return r;
             fused = jit_ok;
             e->fused_threads = 256 * pl.CW;
@@ -1005,7 +1011,7 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
 {
    if (!e) return "";
    switch (e->kk) {
-   case KK_VALU4: return e->use_jit ? "valu4_jit" : "valu4";
+   case KK_VALU4: return e->use_jit ? (e->fused && e->fused_mfma4 ? "mfma4_jit" : "valu4_jit") : "valu4";
    case KK_VALU5: return e->use_jit ? "valu5_jit" : "valu5";
    case KK_VALU20: return e->use_jit ? "valu20_jit" : "valu20";
    default: return e->use_jit ? "mfma64_jit" : (e->mfma_dma ? "mfma64_stream" : "mfma64_gather");
@@ -1947,7 +1953,8 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
    else if (fusedK) {
       const int chunk = (compile_all >> 2) & 0x3f ? ((compile_all >> 2) & 0x3f) * 256 : 256;      // bits 2..7: reduction chunk / 256
       if (!jit_valu_fused_plan(p, n_states, n_tips, fusedNC, fusedK, chunk).ok) return PAML_AMD_EUNSUPPORTED;
-      text = jit_generate_valu_fused(p, n_states, n_tips, fusedNC, fusedK, chunk);
+      text = (n_states == 4 && !getenv("PAML_AMD_NO_MFMA4")) ? jit_generate_mfma4(p, n_tips, fusedNC, fusedK, chunk)
+                                                              : jit_generate_valu_fused(p, n_states, n_tips, fusedNC, fusedK, chunk);
    }
    else if (n_states == 4 || n_states == 5 || n_states == 20) {
       if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;
@@ -1961,7 +1968,8 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
    if (compile) {
       std::vector<char> code;
       std::string log;
-      if (jit_compile_code(text, &code, &log) != 0) {
+      // PAML_AMD_JIT_SHIP=dir: keep the code object there (the library's read-only lib/jit directory is filled this way at build time)
+      if (jit_compile_code(text, &code, &log, getenv("PAML_AMD_JIT_SHIP")) != 0) {
          text = log;
          rc = PAML_AMD_EHIP;
       }
@@ -1972,6 +1980,41 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
       text_out[ncp] = 0;
    }
    return rc;
+}
+
+int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_patt_global, int n_nodes, int root, const int *sons_ptr,
+                          const int *sons, const unsigned char *scale_node, const char *dir, char *log_out, int log_cap)
+{
+   if (!sons_ptr || !sons || !dir || n_nodes <= 0 || root < 0 || root >= n_nodes || n_states < 2 || n_states > 64) return PAML_AMD_EINVAL;
+   TreeDesc t;
+   t.n_tips = n_tips; t.n_nodes = n_nodes; t.root = root;
+   t.sons_ptr.assign(sons_ptr, sons_ptr + n_nodes + 1);
+   t.sons.assign(sons, sons + sons_ptr[n_nodes]);
+   t.label.assign(n_nodes, 0);
+   t.scale_node.assign(n_nodes, 0);
+   t.scale_slot.assign(n_nodes, -1);
+   if (scale_node)
+      for (int i = 0; i < n_nodes; i++)
+         if (scale_node[i]) { t.scale_node[i] = 1; t.scale_slot[i] = t.n_scale++; }
+   const Program p = build_program(t, false, nullptr);
+   std::string text;
+   // the same choices launch_eval makes for an engine of these sizes
+   if (n_states <= 5) {
+      if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;
+      const int chunk = red_chunk(n_patt_global);
+      text = !jit_valu_fused_plan(p, n_states, n_tips, n_codes, K, chunk).ok ? jit_generate_valu(p, n_states)
+             : (n_states == 4 && !getenv("PAML_AMD_NO_MFMA4"))                 ? jit_generate_mfma4(p, n_tips, n_codes, K, chunk)
+                                                                               : jit_generate_valu_fused(p, n_states, n_tips, n_codes, K, chunk);
+   }
+   else {
+      if (!jit_supported(p, n_tips, n_codes, 1)) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate(p, n_tips, n_states, n_codes);
+   }
+   std::vector<char> code;
+   std::string log;
+   const int rc = jit_compile_code(text, &code, &log, dir);
+   if (log_out && log_cap > 0) { strncpy(log_out, log.c_str(), log_cap - 1); log_out[log_cap - 1] = 0; }
+   return rc ? PAML_AMD_EHIP : 0;
 }
 
 int paml_amd_counters(const paml_amd_engine *e, long *n_eval, long *n_pmat)

@@ -14,7 +14,11 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <sys/stat.h>
+#include <sys/types.h>
 #include <unistd.h>
+
+#include <cerrno>
 
 #include <algorithm>
 #include <cstdio>
@@ -109,6 +113,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    const int TCH = (n_codes + 1) / 2 >= 31 ? 32 : (n_codes + 1) / 2;
    const int P_ROUNDS = (KB2 + 1) / 2, T_ROUNDS = (TCH + 7) / 8;
    s << "#define JIT_KB2 " << KB2 << "\n#define JIT_RB " << RB << "\n#define JIT_TCH " << TCH << "\n";
+   if (getenv("PAML_AMD_JIT_ABL_NOBAR")) s << "#define JIT_ABL_NOBAR 1\n";      // timing experiment: no workgroup barriers (results are garbage)
    if (zsingle) s << "#define JIT_ZB 1\n";
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
    s << "extern \"C\" __global__ __launch_bounds__(512, 2) void prune_jit(PruneArgs a)\n{\n";
@@ -152,7 +157,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    auto step = [&](int c, bool defer = false, int iters = 8, int now = 1) -> std::string {
       const int nw = wait_count(consumed + c - 1);
       if (nw >= 0) s << "   JIT_WAIT(" << nw << ");";
-      s << "   __syncthreads();\n";
+      s << "   JIT_SYNC();\n";
       if (z_pending) {
          s << "   JIT2_ISSUE_Z(" << ZP << ")\n";
          fl.push_back({-1, ZP});
@@ -666,6 +671,202 @@ inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, 
    return s.str();
 }
 
+// ---- 4-state models on the matrix cores: v_mfma_f64_4x4x4_4b_f64 (jit_generate_mfma4) -------------------------------------------
+// Measured on MI355X (profiles/r02_mfma4_layout.txt): the instruction runs at the full FP64 rate with a single wave per SIMD, and
+// its result layout equals its B-operand layout — lane = 16 i + 4 b + j holds row i of column (b, j).  So a partial is ONE double
+// per lane: state = lane >> 4, pattern = lane & 15 (four blocks of four patterns, all with the same A = P), and L' = P . L is one
+// instruction per 16 patterns whose result is the next B operand.  P arrives as a per-lane vector operand (lane (k, b, i) holds
+// P[i][k], a 128-byte line of the row-major matrix): no scalar-cache traffic, no lgkmcnt coupling with the LDS tip tables, which
+// is what held the one-pattern-per-lane kernel at 0.51 - 0.63 of the FP64 peak.  Everything else is the fused kernel's frame:
+// tip (and cherry) tables in LDS, classes inside, mixture + log + weighted chunk sum in the epilogue, CW class groups.
+// A wave owns 64 patterns as G = 4 independent groups of 16 (four MFMA chains in flight); elementwise products, tip factors and
+// the root stage use all 64 lanes (4 states x 16 patterns).
+inline std::string jit_generate_mfma4(const Program &p, int n_tips, int n_codes, int K, int chunk)
+{
+   const ValuFusedPlan pl = jit_valu_fused_plan(p, 4, n_tips, n_codes, K, chunk);
+   std::ostringstream s;
+   const int N = 4, G = 4, CW = pl.CW;
+   const int NC = n_codes, ROWW = n_tips * NC * N, CHW = pl.cherry ? pl.n_cherry * NC * NC * N : 0, TABW = ROWW + CHW;   // doubles per class
+   const int ZW = ((n_tips + 3) / 4 + 3) / 4 * 4;
+   const int NTH = 256 * CW;
+   s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
+   s << "extern \"C\" __global__ __launch_bounds__(" << NTH << ") void prune_jit(PruneArgs a)\n{\n";
+   s << "   constexpr int N = 4, NC = " << NC << ", K = " << K << ", ROWW = " << ROWW << ", TABW = " << TABW << ", ZW = " << ZW << ", CW = " << CW
+     << ", NTH = " << NTH << ";\n";
+   s << "   __shared__ __attribute__((aligned(16))) double sTab[K * TABW];\n   __shared__ double sV[256];\n";
+   if (CW > 1) s << "   __shared__ double sF[K * 256];\n";
+   s << "   const int tid = threadIdx.x & 255, cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), bat = blockIdx.y;\n   (void)cw;\n";
+   s << "   const int lane = tid & 63, wv = tid >> 6, st = lane >> 4, col = lane & 15;\n";
+   s << "   const long cls0 = (long)bat * K;\n";
+   s << "   for (int ir = 0; ir < K; ir++) {\n"
+        "      const double *src = a.ptip + (cls0 + ir) * a.n_nodes * a.tip_words;\n"
+        "      for (int i = threadIdx.x; i < ROWW; i += NTH) sTab[ir * TABW + i] = src[i];\n"
+        "   }\n   __syncthreads();\n";
+   if (pl.cherry) {
+      int c = 0;
+      s << "   for (int i = threadIdx.x; i < K * NC * NC * N; i += NTH) {\n"
+           "      const int ir = i / (NC * NC * N), r = i % (NC * NC * N), ca = r / (NC * N), cb = (r / N) % NC, j = r % N;\n"
+           "      const double *rw = sTab + ir * TABW;\n";
+      for (const Op &o : p.ops)
+         if (o.code == OP_SET_TIP2) {
+            s << "      sTab[ir * TABW + ROWW + " << c * NC * NC * N << " + r] = rw[(" << o.a << " * NC + ca) * N + j] * rw[(" << o.b << " * NC + cb) * N + j];\n";
+            c++;
+         }
+      s << "   }\n   __syncthreads();\n";
+   }
+   s << "   const long c_lo = (long)blockIdx.x * a.chunk, c_hi = (c_lo + a.chunk < (long)a.n_patt) ? c_lo + a.chunk : (long)a.n_patt;\n";
+   s << "   const CONST_AS double *fK = as_const(a.freqK + bat * a.freqK_bs);\n";
+   s << "   const double pis = a.pi[st];\n";
+   s << "   const int aidx = (lane & 3) * 4 + (lane >> 4);      /* A operand: lane (k, b, i) <- P[i][k] */\n";
+   s << "   double acc = 0;\n";
+   s << "   for (long h0 = c_lo; h0 < c_hi; h0 += 256) {\n";
+   auto gx = [&](int g) { return "_" + std::to_string(g); };
+   for (int g = 0; g < G; g++) {
+      const std::string x = gx(g);
+      s << "      const long h" << x << " = h0 + wv * 64 + " << 16 * g << " + col;\n      const bool valid" << x << " = h" << x << " < c_hi;\n";
+      s << "      unsigned int zw" << x << "[ZW];\n      { const uint4 *zp = (const uint4 *)(a.zpm + (valid" << x << " ? h" << x << " : c_hi - 1) * ZW);\n";
+      for (int i = 0; i < ZW / 4; i++)
+         s << "        { const uint4 t = zp[" << i << "]; zw" << x << "[" << 4 * i << "] = t.x; zw" << x << "[" << 4 * i + 1 << "] = t.y; zw" << x << "[" << 4 * i + 2
+           << "] = t.z; zw" << x << "[" << 4 * i + 3 << "] = t.w; }\n";
+      s << "      }\n";
+      s << "#define zw zw" << x << "\n";
+      int c = 0;
+      std::vector<char> seen(n_tips, 0);
+      for (const Op &o : p.ops)
+         if (o.code == OP_SET_TIP2 && pl.cherry) {
+            s << "      const int oc" << c << x << " = ROWW + " << c * NC * NC * N << " + (JVF_CODE(" << o.a << ") * NC + JVF_CODE(" << o.b << ")) * N + st;\n";
+            seen[o.a] = seen[o.b] = 1;
+            c++;
+         }
+      for (const Op &o : p.ops) {
+         auto tipoff = [&](int t) {
+            if (!seen[t]) { s << "      const int ot" << t << x << " = (" << t << " * NC + JVF_CODE(" << t << ")) * N + st;\n"; seen[t] = 2; }
+         };
+         switch (o.code) {
+         case OP_SET_TIP: case OP_MUL_TIP: tipoff(o.a); break;
+         case OP_MUL_TIP2: tipoff(o.a); tipoff(o.b); break;
+         case OP_SET_TIP2: if (!pl.cherry) { tipoff(o.a); tipoff(o.b); } break;
+         case OP_INIT_TIP: s << "      const int ci" << o.a << x << " = JVF_CODE(" << o.a << ");\n"; break;
+         default: break;
+         }
+      }
+      s << "#undef zw\n";
+      s << "      double fh" << x << " = 0, v" << x << " = 0;\n";
+   }
+   s << "      _Pragma(\"unroll 1\") for (int ir = " << (CW > 1 ? "cw" : "0") << "; ir < K; ir += CW) {\n";
+   s << "         const double *Pint = a.pint + (cls0 + ir) * a.n_nodes * (N * N) + aidx;\n";
+   s << "         const double *tab = sTab + ir * TABW;\n";
+   const int NA = p.max_stack + 2;
+   for (int g = 0; g < G; g++) {
+      s << "         double lnscale" << gx(g) << " = 0;\n         (void)lnscale" << gx(g) << ";\n";
+      s << "         double";
+      for (int i = 0; i < NA; i++) s << (i ? ", " : " ") << "A" << i << gx(g) << " = 0";
+      s << ";\n";
+   }
+   std::vector<int> freeA;
+   for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
+   auto alloc = [&]() { int r = freeA.back(); freeA.pop_back(); return r; };
+   auto release = [&](int r) { freeA.push_back(r); };
+   auto name = [&](int a, int g) { return "A" + std::to_string(a) + gx(g); };
+   std::vector<int> slot(256, -1);
+   int cur = -1, ich = 0;
+   for (const Op &o : p.ops) {
+      int out = -1, pop = -1, push = -1, curin = cur;
+      if (o.code == OP_INIT_ONES || o.code == OP_INIT_TIP || o.code == OP_SET_TIP || o.code == OP_SET_TIP2) {
+         if (cur < 0) cur = alloc();
+         curin = cur;
+      }
+      if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) {
+         pop = mm_pop_slot(o); push = mm_push_slot(o); out = alloc();
+         s << "         { const double pa = Pint[" << (long)o.a * N * N << "];\n";
+      }
+      for (int g = 0; g < G; g++) {
+         const std::string x = gx(g), C = name(curin, g);
+         switch (o.code) {
+         case OP_INIT_ONES: s << "         " << C << " = 1.0;\n"; break;
+         case OP_INIT_TIP: s << "         " << C << " = (a.cleandata && st == ci" << o.a << x << ") ? 1.0 : 0.0;\n"; break;
+         case OP_SET_TIP: s << "         " << C << " = tab[ot" << o.a << x << "];\n"; break;
+         case OP_MUL_TIP: s << "         " << C << " *= tab[ot" << o.a << x << "];\n"; break;
+         case OP_SET_TIP2:
+            if (pl.cherry) s << "         " << C << " = tab[oc" << ich << x << "];\n";
+            else s << "         " << C << " = tab[ot" << o.a << x << "] * tab[ot" << o.b << x << "];\n";
+            break;
+         case OP_MUL_TIP2: s << "         " << C << " = (" << C << " * tab[ot" << o.a << x << "]) * tab[ot" << o.b << x << "];\n"; break;
+         case OP_MATMUL:
+         case OP_MATMUL_POP:
+            s << "           " << name(out, g) << " = __builtin_amdgcn_mfma_f64_4x4x4f64(pa, " << C << ", 0.0, 0, 0, 0);\n";
+            break;
+         case OP_SCALE:      // NodeScale treesub.c:7200-7230: the maximum over the four states sits on lane bits 4-5
+            s << "         { double mx = " << C << " > 0 ? " << C << " : 0; { const double o1 = __shfl_xor(mx, 16); mx = o1 > mx ? o1 : mx; } { const double o2 = __shfl_xor(mx, 32); mx = o2 > mx ? o2 : mx; }\n"
+              << "           if (mx < 1e-300) { " << C << " = 1.0; lnscale" << x << " += -800; } else { " << C << " /= mx; lnscale" << x << " += log(mx); } }\n";
+            break;
+         case OP_ROOT:
+            s << "         { double f = pis * " << C << "; f += __shfl_xor(f, 16); f += __shfl_xor(f, 32);\n"
+              << "            const bool own = st == 0 && valid" << x << ";\n"
+              << "            const double wtz = own ? a.weights[h" << x << "] : 0.0;\n"
+              << "            if (a.mode == PAML_AMD_MODE_LFUN) { if (f <= 0) f = 1e-80; v" << x << " = log(f) + lnscale" << x << "; if (a.want_fhk && own) a.fhK[(cls0 + ir) * a.n_patt + h" << x
+              << "] = wtz > 0 ? v" << x << " : 0.0; }\n"
+              << "            else {\n"
+              << "               if (f <= 0) f = 1e-300;\n"
+              << "               if (a.n_scale) { if (own) a.fhK[(cls0 + ir) * a.n_patt + h" << x << "] = wtz > 0 ? log(f) + lnscale" << x << " : 0.0; }\n"
+              << "               else {\n";
+            if (CW > 1) s << "                  if (st == 0) sF[ir * 256 + wv * 64 + " << 16 * g << " + col] = f;\n";
+            else s << "                  fh" << x << " += fK[ir] * f;\n";
+            s << "                  if (a.want_fhk && own) a.fhK[(cls0 + ir) * a.n_patt + h" << x << "] = wtz > 0 ? f : 0.0; }\n"
+              << "            } }\n";
+            break;
+         default: break;
+         }
+      }
+      if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) {
+         s << "         }\n";
+         if (pop >= 0)
+            for (int g = 0; g < G; g++) s << "         " << name(out, g) << " = " << name(slot[pop], g) << " * " << name(out, g) << ";\n";
+      }
+      switch (o.code) {
+      case OP_SET_TIP2: if (pl.cherry) ich++; break;
+      case OP_PUSH: slot[o.b] = cur; cur = -1; break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP:
+         release(curin);
+         if (pop >= 0) { release(slot[pop]); slot[pop] = -1; }
+         if (push >= 0) { slot[push] = out; cur = -1; }
+         else cur = out;
+         break;
+      case OP_ROOT: release(cur); cur = -1; break;
+      default: break;
+      }
+   }
+   s << "      }\n";      // classes
+   if (CW > 1) s << "      __syncthreads();\n";
+   for (int g = 0; g < G; g++) {
+      const std::string x = gx(g);
+      s << "      if (a.mode != PAML_AMD_MODE_LFUN" << (CW > 1 ? " && cw == 0" : "") << ") {\n"
+           "         if (a.n_scale) {      /* log-sum-exp around the first maximum (treesub.c:7640-7649) */\n"
+           "            const double *fk = a.fhK + cls0 * a.n_patt + (valid" << x << " ? h" << x << " : c_hi - 1);\n"
+           "            int it = 0;\n"
+           "            for (int ir = 1; ir < K; ir++) if (fk[(long)ir * a.n_patt] > fk[(long)it * a.n_patt]) it = ir;\n"
+           "            const double t = fk[(long)it * a.n_patt];\n"
+           "            double fh = 0;\n"
+           "            for (int ir = 0; ir < K; ir++) fh += fK[ir] * exp(fk[(long)ir * a.n_patt] - t);\n"
+           "            v" << x << " = t + log(fh);\n"
+           "         }\n"
+           "         else {\n";
+      if (CW > 1) s << "            for (int ir = 0; ir < K; ir++) fh" << x << " += fK[ir] * sF[ir * 256 + wv * 64 + " << 16 * g << " + col];\n";
+      s << "            if (fh" << x << " <= 0) fh" << x << " = 1e-300;\n            v" << x << " = log(fh" << x << ");\n         }\n      }\n";
+      s << "      if (st == 0" << (CW > 1 ? " && cw == 0" : "") << ") sV[wv * 64 + " << 16 * g << " + col] = v" << x << ";\n";
+   }
+   s << "      __syncthreads();\n";
+   // the chunk's weighted sum in reduce_stage1's order: thread t adds pattern h0 + t
+   s << "      if (" << (CW > 1 ? "cw == 0 && " : "") << "h0 + tid < c_hi) { const double wt = a.weights[h0 + tid]; const double v = wt > 0 ? sV[tid] : 0.0; acc += v * wt; if (a.lnf) a.lnf[(long)bat * a.n_patt + h0 + tid] = v; }\n";
+   s << "      __syncthreads();\n";
+   s << "   }\n";      // sub-tiles
+   if (CW > 1) s << "   if (cw > 0) acc = 0;\n";
+   s << "   red_block_finish<" << CW << ">(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + blockIdx.x, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat : nullptr);\n";
+   s << "}\n";
+   return s.str();
+}
+
 inline std::string jit_source_dir()
 {
    Dl_info info;
@@ -679,15 +880,17 @@ inline std::string jit_source_dir()
 }
 
 // Compile `src` for gfx950 (works without a GPU).  Returns 0 on success; `log` gets the compiler output.
-// Code objects are kept on disk, keyed by a hash of the generated source and of the header it includes: a tree seen before
-// (another run of the same analysis) costs a file read instead of seconds of hiprtc.  Opt-in: PAML_AMD_JIT_CACHE names the
-// directory (unset, "" or "0": no cache — the library writes nothing outside what the caller asked for).
-inline std::string jit_cache_path(const std::string &src)
+// Code objects are kept on disk, keyed by a hash of the generated source, of the header it includes, of the optimisation
+// level and of the hiprtc version: a tree seen before (another run of the same analysis) costs a file read instead of
+// seconds of hiprtc (0.2 - 19 s per topology, profiles/r01_big_trees.jsonl).  Two places are looked at:
+//   <library dir>/jit/         read-only: code objects built together with the library (__graft_entry__.build() fills it for
+//                              the benchmark's trees), so a fresh machine does not start with a compile;
+//   the user's cache           read-write: $PAML_AMD_JIT_CACHE, else $XDG_CACHE_HOME/paml_amd/jit, else $HOME/.cache/paml_amd/jit;
+//                              PAML_AMD_JIT_CACHE=0 (or empty) switches it off.
+inline const char *jit_opt_level() { return getenv("PAML_AMD_JIT_OPT") ? getenv("PAML_AMD_JIT_OPT") : "-O3"; }      // experiments: -O1 / -O2
+
+inline std::string jit_cache_name(const std::string &src)
 {
-   const char *c = getenv("PAML_AMD_JIT_CACHE");
-   std::string dir;
-   if (!c || !*c || !strcmp(c, "0")) return "";
-   dir = c;
    unsigned long long h = 1469598103934665603ull;
    auto mix = [&](const std::string &t) { for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; } };
    mix(src);
@@ -695,26 +898,68 @@ inline std::string jit_cache_path(const std::string &src)
       FILE *f = fopen((jit_source_dir() + "/device_common.h").c_str(), "rb");
       if (f) { char buf[4096]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) mix(std::string(buf, n)); fclose(f); }
    }
+   mix(jit_opt_level());
+   int major = 0, minor = 0;
+   (void)hiprtcVersion(&major, &minor);
+   mix("hiprtc" + std::to_string(major) + "." + std::to_string(minor));
    char name[64];
-   snprintf(name, sizeof(name), "/%016llx.gfx950.hsaco", h);
-   (void)!system(("mkdir -p '" + dir + "' 2>/dev/null").c_str());
-   return dir + name;
+   snprintf(name, sizeof(name), "%016llx.gfx950.hsaco", h);
+   return name;
 }
 
-inline int jit_compile_code(const std::string &src, std::vector<char> *code, std::string *log)
+inline bool jit_mkdirs(const std::string &dir)      // mkdir -p without a shell
 {
-   const std::string cached = jit_cache_path(src);
-   if (!cached.empty()) {
-      FILE *f = fopen(cached.c_str(), "rb");
-      if (f) {
-         fseek(f, 0, SEEK_END);
-         const long n = ftell(f);
-         rewind(f);
-         code->resize(n > 0 ? n : 0);
-         const bool ok = n > 0 && fread(code->data(), 1, n, f) == (size_t)n;
-         fclose(f);
-         if (ok) return 0;
+   for (size_t i = 1; i <= dir.size(); i++)
+      if (i == dir.size() || dir[i] == '/') {
+         const std::string sub = dir.substr(0, i);
+         if (mkdir(sub.c_str(), 0777) != 0 && errno != EEXIST) return false;
       }
+   return true;
+}
+
+inline std::string jit_shipped_dir() { return jit_source_dir() + "/../lib/jit"; }
+
+inline std::string jit_user_cache_dir()
+{
+   const char *c = getenv("PAML_AMD_JIT_CACHE");
+   if (c) return (!*c || !strcmp(c, "0")) ? std::string() : std::string(c);
+   if (const char *x = getenv("XDG_CACHE_HOME"))
+      if (*x) return std::string(x) + "/paml_amd/jit";
+   if (const char *hm = getenv("HOME"))
+      if (*hm) return std::string(hm) + "/.cache/paml_amd/jit";
+   return std::string();
+}
+
+inline bool jit_read_file(const std::string &path, std::vector<char> *code)
+{
+   FILE *f = fopen(path.c_str(), "rb");
+   if (!f) return false;
+   fseek(f, 0, SEEK_END);
+   const long n = ftell(f);
+   rewind(f);
+   code->resize(n > 0 ? n : 0);
+   const bool ok = n > 0 && fread(code->data(), 1, n, f) == (size_t)n;
+   fclose(f);
+   return ok;
+}
+
+inline void jit_write_file(const std::string &dir, const std::string &name, const std::vector<char> &code)
+{
+   if (dir.empty() || !jit_mkdirs(dir)) return;
+   const std::string path = dir + "/" + name, tmp = path + ".tmp" + std::to_string((long)getpid());      // write beside, then rename:
+   FILE *f = fopen(tmp.c_str(), "wb");                                                                    // readers never see a partial file
+   if (!f) return;
+   const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+   fclose(f);
+   if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+}
+
+inline int jit_compile_code(const std::string &src, std::vector<char> *code, std::string *log, const char *store_dir = nullptr)
+{
+   const std::string name = jit_cache_name(src), user = jit_user_cache_dir();
+   if (!store_dir) {
+      if (jit_read_file(jit_shipped_dir() + "/" + name, code)) return 0;
+      if (!user.empty() && jit_read_file(user + "/" + name, code)) return 0;
    }
    hiprtcProgram prog;
    if (hiprtcCreateProgram(&prog, src.c_str(), "prune_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -722,8 +967,7 @@ inline int jit_compile_code(const std::string &src, std::vector<char> *code, std
       return -1;
    }
    const std::string inc = "-I" + jit_source_dir();
-   const char *olevel = getenv("PAML_AMD_JIT_OPT") ? getenv("PAML_AMD_JIT_OPT") : "-O3";      // experiments: -O1 / -O2
-   const char *opts[] = {"--offload-arch=gfx950", olevel, "-std=c++17", inc.c_str()};
+   const char *opts[] = {"--offload-arch=gfx950", jit_opt_level(), "-std=c++17", inc.c_str()};
    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
    size_t ls = 0;
    hiprtcGetProgramLogSize(prog, &ls);
@@ -740,15 +984,7 @@ inline int jit_compile_code(const std::string &src, std::vector<char> *code, std
    code->resize(cs);
    hiprtcGetCode(prog, code->data());
    hiprtcDestroyProgram(&prog);
-   if (!cached.empty()) {      // write beside, then rename: readers never see a partial file
-      const std::string tmp = cached + ".tmp" + std::to_string((long)getpid());
-      FILE *f = fopen(tmp.c_str(), "wb");
-      if (f) {
-         const bool ok = fwrite(code->data(), 1, cs, f) == cs;
-         fclose(f);
-         if (!ok || rename(tmp.c_str(), cached.c_str()) != 0) remove(tmp.c_str());
-      }
-   }
+   jit_write_file(store_dir ? std::string(store_dir) : user, name, *code);
    return 0;
 }
 

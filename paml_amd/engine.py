@@ -27,7 +27,7 @@ EXPORTS = [
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_shard_bounds", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_get_partial_sums", "paml_amd_branch_counters",
-    "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
+    "paml_amd_jit_prebuild", "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
 
@@ -407,6 +407,25 @@ def debug_jit(tree, scale_node=None, compile=True, n_states=0, fused=None):
     if rc < 0:
         raise EngineError("debug_jit failed (%d): %s" % (rc, buf.value.decode(errors="replace")[-3000:]))
     return buf.value.decode()
+
+
+JIT_SHIPPED_DIR = os.path.join(_HERE, "lib", "jit")
+
+
+def jit_prebuild(tree, n_states, n_codes, K=1, n_patt_global=1_000_000, scale_node=None, directory=None):
+    """Host-only: compile the per-tree kernel for (tree, sizes) into `directory` (default: the library's lib/jit)."""
+    L = lib()
+    ptr, flat = tree.csr()
+    sc = None if scale_node is None else np.ascontiguousarray(scale_node, dtype=np.uint8)
+    d = directory or JIT_SHIPPED_DIR
+    os.makedirs(d, exist_ok=True)
+    log = C.create_string_buffer(1 << 16)
+    L.paml_amd_jit_prebuild.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_char_p, C.c_char_p, C.c_int]
+    rc = L.paml_amd_jit_prebuild(int(n_states), tree.n_tips, int(n_codes), int(K), int(n_patt_global), tree.n_nodes, tree.root, _p(ptr), _p(flat),
+                                 _p(sc), os.fsencode(d), log, len(log))
+    if rc != 0:
+        raise EngineError("jit_prebuild failed (%d): %s" % (rc, log.value.decode(errors="replace")[-2000:]))
 
 
 def compress_patterns(chars, gene=None):
