@@ -143,7 +143,7 @@ inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global
 
 // Environment switches, read once when the engine is created.
 struct EnvCfg {
-   bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, no_mfma4 = false;
+   bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false;
    std::string jit_dump, prof_ops;
    int prof_tid = 0;
    void read()
@@ -154,7 +154,7 @@ struct EnvCfg {
       jit_strict = getenv("PAML_AMD_JIT_STRICT") != nullptr;
       valu20 = getenv("PAML_AMD_VALU20") != nullptr;
       no_fused = getenv("PAML_AMD_NO_FUSED") != nullptr;
-      no_mfma4 = getenv("PAML_AMD_NO_MFMA4") != nullptr;
+      mfma4 = getenv("PAML_AMD_MFMA4") != nullptr;
       if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
       if (const char *v = getenv("PAML_AMD_PROF_OPS")) prof_ops = v;
       if (const char *v = getenv("PAML_AMD_PROF_TID")) prof_tid = atoi(v);
@@ -639,8 +639,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          // the fused form (classes inside, LDS tip tables, reduction in the epilogue) when the model fits it
          const ValuFusedPlan pl = jit_valu_fused_plan(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk);
          if (pl.ok && G == 1 && e->n_pi == 1 && e->d_zpm.p && !e->env.no_fused) {
-            // 4 states: the matrix-core form (v_mfma_f64_4x4x4) unless switched off
-            const bool m4 = n == 4 && !e->env.no_mfma4;
+            // 4 states: the matrix-core form (v_mfma_f64_4x4x4) is an experiment kept behind PAML_AMD_MFMA4=1 — same issue slots as
+            // the FMA form (an FP64 MFMA of 256 MACs takes 16 cycles, sixteen v_fma_f64 of a wave 64) and four times the
+            // integer work per pattern (a lane is a (state, pattern) pair): 0.32 of peak against 0.64, profiles/r02_valu_fused_shapes.txt
+            const bool m4 = n == 4 && e->env.mfma4;
             int r = ensure_jit(e, std::string(m4 ? "m4" : "vf") + std::to_string(n) + "c" + std::to_string(e->n_codes) + "k" + std::to_string(Km) + "r" + std::to_string(pl.R) + "w" +
                                      std::to_string(pl.CW) + (pl.cherry ? "y:" : "n:") + jit_program_key(e->prog, e->n_tips),
                                [&]() { return m4 ? jit_generate_mfma4(e->prog, e->n_tips, e->n_codes, Km, e->chunk)
@@ -1953,7 +1955,7 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
    else if (fusedK) {
       const int chunk = (compile_all >> 2) & 0x3f ? ((compile_all >> 2) & 0x3f) * 256 : 256;      // bits 2..7: reduction chunk / 256
       if (!jit_valu_fused_plan(p, n_states, n_tips, fusedNC, fusedK, chunk).ok) return PAML_AMD_EUNSUPPORTED;
-      text = (n_states == 4 && !getenv("PAML_AMD_NO_MFMA4")) ? jit_generate_mfma4(p, n_tips, fusedNC, fusedK, chunk)
+      text = (n_states == 4 && getenv("PAML_AMD_MFMA4")) ? jit_generate_mfma4(p, n_tips, fusedNC, fusedK, chunk)
                                                               : jit_generate_valu_fused(p, n_states, n_tips, fusedNC, fusedK, chunk);
    }
    else if (n_states == 4 || n_states == 5 || n_states == 20) {
@@ -2003,7 +2005,7 @@ int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_p
       if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;
       const int chunk = red_chunk(n_patt_global);
       text = !jit_valu_fused_plan(p, n_states, n_tips, n_codes, K, chunk).ok ? jit_generate_valu(p, n_states)
-             : (n_states == 4 && !getenv("PAML_AMD_NO_MFMA4"))                 ? jit_generate_mfma4(p, n_tips, n_codes, K, chunk)
+             : (n_states == 4 && getenv("PAML_AMD_MFMA4"))                     ? jit_generate_mfma4(p, n_tips, n_codes, K, chunk)
                                                                                : jit_generate_valu_fused(p, n_states, n_tips, n_codes, K, chunk);
    }
    else {

@@ -288,11 +288,11 @@ class _Sched:
                 self.read_codes(line)
                 continue
             # plain statements, possibly several per line
-            for tok in re.finditer(r"JIT_WAIT\((\d+)\)|__syncthreads\(\)|JIT2_ISSUE_Z\(\d+\)|JIT2_PIECE_N?(?:[TP]\((\d+), \d+, \d\)|PC\((\d+), \d+\))", line):
+            for tok in re.finditer(r"JIT_WAIT\((\d+)\)|__syncthreads\(\)|JIT_SYNC\(\)|JIT2_ISSUE_Z\(\d+\)|JIT2_PIECE_N?(?:[TP]\((\d+), \d+, \d\)|PC\((\d+), \d+\))", line):
                 t = tok.group(0)
                 if t.startswith("JIT_WAIT"):
                     self.wait(int(tok.group(1)))
-                elif t.startswith("__sync"):
+                elif t.startswith("__sync") or t.startswith("JIT_SYNC"):
                     self.barrier()
                 elif t.startswith("JIT2_ISSUE_Z"):
                     self.issue_z()
@@ -345,10 +345,10 @@ def test_jit_schedule_checker_catches_broken_schedules(lib_path):
     i = src.index("JIT_WAIT(8)")
     with pytest.raises(AssertionError):
         _Sched(src[:i] + "JIT_WAIT(12)" + src[i + 11:]).check()
-    j = src.index("__syncthreads();", src.index("for (;; ptile = 0)"))
-    k = src.index("__syncthreads();", j + 1)
+    j = src.index("JIT_SYNC();", src.index("for (;; ptile = 0)"))
+    k = src.index("JIT_SYNC();", j + 1)
     with pytest.raises(AssertionError):
-        _Sched(src[:k] + src[k + len("__syncthreads();"):]).check()
+        _Sched(src[:k] + src[k + len("JIT_SYNC();"):]).check()
 
 
 @pytest.mark.parametrize("n_states", [4, 5])
