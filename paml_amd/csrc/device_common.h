@@ -574,7 +574,12 @@ __device__ __forceinline__ double red_total256(const double *partial, int nb, bo
 
 // A workgroup's weighted sum -> its slot of the global partial array; with a counter, the workgroup that finishes last also
 // forms the total (single GPU: no separate stage-2 launch).  The order of every sum is fixed, so the result is deterministic.
+// "Last" is found with two levels of tickets — groups of RED_TICKET_GROUP workgroups, then the groups — so that a thousand
+// workgroups finishing together do not queue on one L2 atomic (measured: 35 us for 977 tickets on a single counter).
+// counter[0] = groups done, counter[1 + g] = workgroups of group g done; all return to zero for the next launch.
 // (GROUPS > 1: a workgroup of 256 x GROUPS threads whose first 256 hold the sums; the others only take part in the barriers.)
+#define RED_TICKET_GROUP 32
+#define RED_TICKET_WORDS 40      /* ints per batch element: 1 + ceil(1024 / 32) groups, padded */
 template <int GROUPS = 1>
 __device__ __forceinline__ void red_block_finish(double acc, double *partial_row, int slot, int nb_total, double *out, int *counter)
 {
@@ -588,8 +593,15 @@ __device__ __forceinline__ void red_block_finish(double acc, double *partial_row
       partial_row[slot] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
       int last = 0;
       if (counter) {
+         const int nb = (int)gridDim.x, g = (int)blockIdx.x / RED_TICKET_GROUP, ng = (nb + RED_TICKET_GROUP - 1) / RED_TICKET_GROUP;
+         const int gsize = min(RED_TICKET_GROUP, nb - g * RED_TICKET_GROUP);
          __threadfence();
-         last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+         if (ng > RED_TICKET_WORDS - 1) last = atomicAdd(counter, 1) == nb - 1;      // (more groups than ticket words: one level)
+         else if (atomicAdd(counter + 1 + g, 1) == gsize - 1) {
+            counter[1 + g] = 0;
+            __threadfence();
+            last = atomicAdd(counter, 1) == ng - 1;
+         }
       }
       s_last = last;
    }

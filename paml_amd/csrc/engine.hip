@@ -726,8 +726,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       HIPCHK(e->d_partial.ensure((size_t)nbg * B));
       HIPCHK(hipMemsetAsync(e->d_partial.p, 0, e->d_partial.cap * sizeof(double), e->stream));
    }
-   if ((size_t)B > e->d_red_counter.cap) {
-      HIPCHK(e->d_red_counter.ensure(std::max(B, 64)));
+   if ((size_t)B * RED_TICKET_WORDS > e->d_red_counter.cap) {
+      HIPCHK(e->d_red_counter.ensure((size_t)std::max(B, 64) * RED_TICKET_WORDS));
       HIPCHK(hipMemsetAsync(e->d_red_counter.p, 0, e->d_red_counter.cap * sizeof(int), e->stream));
    }
    HIPCHK(e->d_out.ensure(B));

@@ -666,7 +666,7 @@ inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, 
    if (CW > 1) s << "      __syncthreads();\n";      // sF is reused by the next sub-tile
    s << "   }\n";      // sub-tiles
    if (CW > 1) s << "   if (cw > 0) acc = 0;\n";
-   s << "   red_block_finish<" << CW << ">(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + blockIdx.x, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat : nullptr);\n";
+   s << "   red_block_finish<" << CW << ">(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + blockIdx.x, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat * RED_TICKET_WORDS : nullptr);\n";
    s << "}\n";
    return s.str();
 }
@@ -862,7 +862,7 @@ inline std::string jit_generate_mfma4(const Program &p, int n_tips, int n_codes,
    s << "      __syncthreads();\n";
    s << "   }\n";      // sub-tiles
    if (CW > 1) s << "   if (cw > 0) acc = 0;\n";
-   s << "   red_block_finish<" << CW << ">(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + blockIdx.x, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat : nullptr);\n";
+   s << "   red_block_finish<" << CW << ">(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + blockIdx.x, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat * RED_TICKET_WORDS : nullptr);\n";
    s << "}\n";
    return s.str();
 }

@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256) void reduce_stage1(ReduceArgs a)
       }
       if (a.lnf) a.lnf[h] = v;
    }
-   red_block_finish(acc, a.partial, a.first_chunk + blockIdx.x, a.nb_stride, a.out + blockIdx.y, a.counter ? a.counter + blockIdx.y : nullptr);
+   red_block_finish(acc, a.partial, a.first_chunk + blockIdx.x, a.nb_stride, a.out + blockIdx.y, a.counter ? a.counter + blockIdx.y * RED_TICKET_WORDS : nullptr);
 }
 
 __global__ __launch_bounds__(256) void reduce_stage2(const double *partial, int nb, double *out)
