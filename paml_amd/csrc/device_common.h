@@ -590,28 +590,34 @@ __device__ __forceinline__ void red_block_finish(double acc, double *partial_row
    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) sw[threadIdx.x >> 6] = acc;
    __syncthreads();
    if (threadIdx.x == 0) {
-      partial_row[slot] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+      const double part = (sw[0] + sw[1]) + (sw[2] + sw[3]);
       int last = 0;
       if (counter) {
+         // The partial sum has to be visible to whichever workgroup ends up last, possibly on another XCD (each XCD has its own
+         // L2).  A __threadfence() would do it — by writing back EVERY dirty line of this XCD's L2 (the 8 MB of class likelihoods
+         // the kernel has just stored): 35 us for a 5 us kernel.  Instead the one value goes out as an agent-scope store (written
+         // through), its completion is awaited, and only then is the ticket drawn; the reader uses agent-scope loads.
          const int nb = (int)gridDim.x, g = (int)blockIdx.x / RED_TICKET_GROUP, ng = (nb + RED_TICKET_GROUP - 1) / RED_TICKET_GROUP;
          const int gsize = min(RED_TICKET_GROUP, nb - g * RED_TICKET_GROUP);
-         __threadfence();
-         if (ng > RED_TICKET_WORDS - 1) last = atomicAdd(counter, 1) == nb - 1;      // (more groups than ticket words: one level)
-         else if (atomicAdd(counter + 1 + g, 1) == gsize - 1) {
-            counter[1 + g] = 0;
-            __threadfence();
-            last = atomicAdd(counter, 1) == ng - 1;
+         __hip_atomic_store((unsigned long long *)(partial_row + slot), (unsigned long long)__double_as_longlong(part), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+         if (ng > RED_TICKET_WORDS - 1)      // (more groups than ticket words: one level)
+            last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
+         else if (__hip_atomic_fetch_add(counter + 1 + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+            __hip_atomic_store(counter + 1 + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1;
          }
       }
+      else partial_row[slot] = part;
       s_last = last;
    }
    __syncthreads();
    if (s_last) {
-      __threadfence();
       const double tot = red_total256<GROUPS>(partial_row, nb_total, true, sw);
       if (threadIdx.x == 0) {
          *out = tot;
-         *counter = 0;      // ready for the next launch on this stream
+         __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
       }
    }
 }

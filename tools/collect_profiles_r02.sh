@@ -1,26 +1,29 @@
 #!/bin/bash
-# Round-2 profile collection on the GPU box (run through gpurun): kernel-trace stats of the default bench command, then the
-# HBM counters in their own passes (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE in separate --pmc runs, no other trace domains).
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r2prof
-mkdir -p $OUT
-CMD="python bench.py --no-extras --no-cpu-baseline --steps 12 --warmup 3"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o pmc -- $CMD > /dev/null 2> $OUT/pmc_$c.err
-  find $OUT/pmc_$c -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $OUT/pmc_$c.csv
-done
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $OUT/pmc_sq -o pmc -- $CMD > /dev/null 2> $OUT/pmc_sq.err
-find $OUT/pmc_sq -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $OUT/pmc_sq.csv
-# C2 (4-state) the same way
-CMD2="python tools/c2_probe.py"
-rocprofv3 --kernel-trace --stats -d $OUT/trace_c2 -o c2 -- $CMD2 > $OUT/c2_under_rocprof.jsonl 2> $OUT/trace_c2.err
-find $OUT/trace_c2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/c2_kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_c2_$c -o pmc -- $CMD2 > /dev/null 2> $OUT/pmc_c2_$c.err
-  find $OUT/pmc_c2_$c -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $OUT/pmc_c2_$c.csv
-done
-rm -rf $OUT/trace $OUT/trace_c2 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq $OUT/pmc_c2_FETCH_SIZE $OUT/pmc_c2_WRITE_SIZE
-ls -la $OUT
-head -5 $OUT/kernel_stats.csv
+# Round-2 evidence, run on the GPU box through gpurun:  tools/collect_profiles_r02.sh  -> gpurun_out/r2prof/
+# kernel-trace stats of the bench's headline command, the HBM traffic counters in separate --pmc passes (MI355X_MICROARCH.md:
+# FETCH_SIZE / WRITE_SIZE each in its own run, with --kernel-trace only), MFMA / LDS counters, and the same for the 4-state probe.
+out=$PWD/gpurun_out/r2prof
+mkdir -p $out
+export TMPDIR=/tmp
+B="python $PWD/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-extras"
+C2="python $PWD/tools/c2_probe.py"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $B > $out/bench_under_rocprof.json 2>$out/stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o f -- $B > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o w -- $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d $out/pmc_mfma -o m -- $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $out/pmc_lds -o l -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c2 -o s -- $C2 > $out/c2_under_rocprof.jsonl 2>$out/stats_c2.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_c2_fetch -o f -- $C2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_c2_write -o w -- $C2 > /dev/null 2>&1
+cd - > /dev/null
+{
+  echo "# bench.py headline (16 taxa x 1e6 codon patterns, M0): FETCH_SIZE / WRITE_SIZE (KiB per dispatch, separate passes)"; python tools/pmc_summary.py $out/pmc_fetch; python tools/pmc_summary.py $out/pmc_write
+  echo "# MFMA"; python tools/pmc_summary.py $out/pmc_mfma
+  echo "# LDS"; python tools/pmc_summary.py $out/pmc_lds
+  echo "# tools/c2_probe.py (32 taxa x 1e5 and x 4e6 nucleotide patterns, GTR+G4): FETCH_SIZE / WRITE_SIZE"; python tools/pmc_summary.py $out/pmc_c2_fetch; python tools/pmc_summary.py $out/pmc_c2_write
+} > $out/pmc_summary.txt 2>&1
+find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+find $out/stats_c2 -name "*kernel_stats.csv" -exec cp {} $out/c2_kernel_stats.csv \;
+rm -rf $out/stats $out/stats_c2 $out/pmc_fetch $out/pmc_write $out/pmc_mfma $out/pmc_lds $out/pmc_c2_fetch $out/pmc_c2_write
+head -6 $out/kernel_stats.csv; head -8 $out/c2_kernel_stats.csv; cat $out/pmc_summary.txt
