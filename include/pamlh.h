@@ -116,6 +116,11 @@ int pamlh_newick(const pamlh *p, char *buf, int cap);
  * returns -lnL (what ming2 minimises); +1e300 on error (see pamlh_error). */
 double pamlh_plfun(pamlh *p, const double *x, int np);
 
+/* mcmctree's exact-likelihood seam (usedata = 1; lnpD_locus mcmctree.c:1130-1166 -> com.plfun(NULL, -1)): lnL of the locus for
+ * node ages age[n_nodes] and either the locus rate rgene (clock = 1) or per-branch rates rate[n_nodes] (clock = 2 / 3), at the
+ * substitution parameters of the last pamlh_set_x.  model_changed = 0: only the branch lengths are sent. */
+int pamlh_lnpd_locus(pamlh *p, const double *age, double rgene, const double *rate, int model_changed, double *lnL);
+
 /* Marginal ancestral reconstruction (RateAncestor = 1; AncestralMarginal treesub.c:6288) at the current model state:
  * post[n_patt][n_states] = Pr(state at internal node `node` (0-based, >= n_tips) | pattern). */
 int pamlh_node_posterior(pamlh *p, int node, double *post);

@@ -1163,6 +1163,32 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
    return 0;
 }
 
+/* The exact-likelihood consumer of mcmctree (usedata = 1): lnpD_locus (mcmctree.c:1130-1166) turns the sampled node ages and
+ * rates into the gene tree's branch lengths — global clock: (age of the father - age of the node) x rgene[locus]; independent /
+ * correlated rates: (age difference) x the branch's own rate (every species sampled once: the species-tree path of a gene-tree
+ * branch is that branch) — and calls com.plfun(NULL, -1): one likelihood evaluation at those lengths, the substitution model
+ * untouched.  Here: age[nnode] (tips too: 0, or their sampling dates), rate = NULL with rgene for the clock, or rate[nnode] per
+ * branch.  The model state is the last pamlh_set_x (kappa, alpha ...); model_changed = 0 skips re-sending the eigen systems —
+ * an MCMC proposal that moves ages or rates only costs the branch lengths (232 bytes) and one evaluation. */
+int pamlh_lnpd_locus(pamlh *p, const double *age, double rgene, const double *rate, int model_changed, double *lnL)
+{
+   int i, rc;
+   double *br;
+   if (!p || !age || !lnL) return -1;
+   if (p->adg) return pamlh_fail(p, "lnpd_locus: not with rho");
+   if (model_changed || !p->eng) { if ((rc = pamlh_engine_model(p))) return rc; }
+   br = (double *)malloc(p->nnode * sizeof(double));
+   for (i = 0; i < p->nnode; i++) {
+      br[i] = 0;
+      if (i == p->root) continue;
+      br[i] = (age[p->father[i]] - age[i]) * (rate ? rate[i] : rgene);
+      if (br[i] < 0) { free(br); return pamlh_fail(p, "lnpd_locus: node %d is older than its father (blength < 0, mcmctree.c:1150)", i + 1); }
+   }
+   rc = paml_amd_eval(p->eng, br, p->ngene > 1 ? p->rgene : NULL, lnL, NULL, NULL);
+   free(br);
+   return rc ? pamlh_fail(p, "%s", paml_amd_last_error(p->eng)) : 0;
+}
+
 /* Name of parameter i of x[] (branch lengths are "t <node>..<node>" in the reference's numbering, tree.branches order). */
 int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
 {

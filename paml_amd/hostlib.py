@@ -219,6 +219,18 @@ class Analysis:
         L.paml_amd_branch_counters(C.c_void_p(self._L.pamlh_engine_handle(self._h)), C.byref(a), C.byref(b))
         return dict(x=x, lnL=lnl.value, converged=rc == 0, n_eval=nev.value, branch_calls=a.value, nodes_recomputed=b.value)
 
+    def lnpd_locus(self, age, rgene=1.0, rate=None, model_changed=True):
+        """mcmctree's lnpD_locus on the GPU (pamlh_lnpd_locus): lnL for node ages age[n_nodes] and a locus rate / branch rates."""
+        a = np.ascontiguousarray(age, dtype=np.float64)
+        assert a.shape == (self.n_nodes,)
+        r = None if rate is None else np.ascontiguousarray(rate, dtype=np.float64)
+        lnl = C.c_double()
+        self._L.pamlh_lnpd_locus.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        if self._L.pamlh_lnpd_locus(self._h, a.ctypes.data_as(C.c_void_p), float(rgene), None if r is None else r.ctypes.data_as(C.c_void_p),
+                                    int(model_changed), C.byref(lnl)) != 0:
+            raise RuntimeError("pamlh_lnpd_locus: " + self._L.pamlh_error(self._h).decode())
+        return lnl.value
+
     def standard_errors(self, x, method=0):
         """Standard errors at the estimate x (pamlh_standard_errors): method 0 = the reference's HessianSKT2004 outer
         product of scores, method 1 = second differences of lnL; -1 marks a parameter without an estimate."""

@@ -430,6 +430,44 @@ def case_syn_codon_ns(tag, n_patt=1_000_000, sample=997):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def case_mcmctree():
+    """The mcmctree exact-likelihood consumer (usedata = 1; lnpD_locus mcmctree.c:1130-1166 -> com.plfun(NULL, -1)): a short chain
+    of the reference on the first locus of examples/DatingSoftBound (7 primates, 1st codon positions), global clock, JC69, no
+    gamma — so the sampled lnL is a function of the sampled node ages and rate alone.  mcmc.txt holds, per sample, the ages
+    t_n8 .. t_n13 (7 decimals), the rate mu and lnL (3 decimals): the golden."""
+    d = tempfile.mkdtemp(prefix="golden_")
+    try:
+        lines = open(EX + "/DatingSoftBound/mtCDNApri123.txt").read().splitlines()
+        first = [ln for ln in lines if ln.strip()][:8]          # header + 7 sequences = the first locus
+        with open(os.path.join(d, "locus1.txt"), "w") as f:
+            f.write("\n".join(first) + "\n")
+        shutil.copy(os.path.join(d, "locus1.txt"), os.path.join(HERE, "data", "mtCDNApri_locus1.txt"))
+        tree = "((((human, (chimpanzee, bonobo)) '>.06<.08', gorilla), (orangutan, sumatran)) '>.12<.16', gibbon);"
+        with open(os.path.join(d, "tree.txt"), "w") as f:
+            f.write(" 7 1\n" + tree + "\n")
+        ctl = dict(seed=12345, seqfile="locus1.txt", treefile="tree.txt", mcmcfile="mcmc.txt", outfile="out.txt", ndata=1, seqtype=0, usedata=1,
+                   clock=1, RootAge="'<1.0'", model=0, alpha=0, ncatG=5, cleandata=0, BDparas="1 1 0.1 multiplicative", kappa_gamma="6 2",
+                   alpha_gamma="1 1", rgene_gamma="2 20 1", sigma2_gamma="1 10 1", finetune="1: .1 .1 .1 .1 .1 .1", print=1, burnin=200,
+                   sampfreq=5, nsample=30)
+        with open(os.path.join(d, "mcmctree.ctl"), "w") as f:
+            for k, v in ctl.items():
+                f.write("%s = %s\n" % (k, v))
+        subprocess.run([os.path.join(REF, "mcmctree"), "mcmctree.ctl"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT, timeout=600, check=True)
+        rows = [ln.split() for ln in open(os.path.join(d, "mcmc.txt")).read().splitlines()]
+        hdr, rows = rows[0], rows[1:]
+        assert hdr[1:7] == ["t_n8", "t_n9", "t_n10", "t_n11", "t_n12", "t_n13"] and hdr[7] == "mu" and hdr[8] == "lnL", hdr
+        g = dict(name="mcmctree_jc_clock1", program="mcmctree", tree="((((human,(chimpanzee,bonobo)),gorilla),(orangutan,sumatran)),gibbon);",
+                 names=["human", "chimpanzee", "bonobo", "gorilla", "orangutan", "sumatran", "gibbon"], seqfile="mtCDNApri_locus1.txt",
+                 node_labels=hdr[1:7], samples=[dict(age=[float(v) for v in r[1:7]], mu=float(r[7]), lnL=float(r[8])) for r in rows],
+                 note="node t_n<k> = node k (1-based) of the reference's tree numbering: 8 = root, then the internal nodes in the order of their "
+                      "opening brackets; branch length of node i = (age of its father - age of i) x mu (lnpD_locus, global clock)")
+        with open(os.path.join(HERE, "mcmctree_jc_clock1.json"), "w") as f:
+            json.dump(g, f, separators=(",", ":"))
+        print("mcmctree_jc_clock1     %d samples, lnL %.3f .. %.3f" % (len(rows), min(s["lnL"] for s in g["samples"]), max(s["lnL"] for s in g["samples"])))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 LYSO = {"lysozymeLarge.nuc": EX + "/lysozyme/lysozymeLarge.nuc", "lysozymeLarge.trees": EX + "/lysozyme/lysozymeLarge.trees"}
 LYSO_CTL = dict(seqfile="lysozymeLarge.nuc", treefile="lysozymeLarge.trees", kappa=3, cleandata=0)
 ECP = {"ECP_EDN_15.nuc": EX + "/CladeModelCD/ECP_EDN_15.nuc", "tree.txt": EX + "/CladeModelCD/tree.txt"}
@@ -577,6 +615,7 @@ CASES = {
     "syn_codon_m1a_full": lambda: case_syn_codon_ns("m1a"), "syn_codon_m2a_full": lambda: case_syn_codon_ns("m2a"),
     "syn_codon_m7_full": lambda: case_syn_codon_ns("m7"), "syn_codon_m8_full": lambda: case_syn_codon_ns("m8"),
     "syn_codon_m2a_as_m3_full": lambda: case_syn_codon_ns("m2a_as_m3"), "syn_codon_m8_as_m3_full": lambda: case_syn_codon_ns("m8_as_m3"),
+    "mcmctree_jc_clock1": case_mcmctree,
     # small versions of the same (CPU oracle test)
     "syn_codon_m2a_as_m3_4000": lambda: case_syn_codon_ns("m2a_as_m3", 4000, None), "syn_codon_m8_as_m3_4000": lambda: case_syn_codon_ns("m8_as_m3", 4000, None),
     "syn_codon_m7_4000": lambda: case_syn_codon_ns("m7", 4000, None),

@@ -419,6 +419,52 @@ def test_c_host_plfun_seam():
     assert a.plfun(x[:-1]) == 1e300
 
 
+def _mcmctree_ages(a, sample):
+    """node ages [n_nodes] for one mcmc.txt sample: tips 0, internal nodes in the reference's numbering (root first)."""
+    age = np.zeros(a.n_nodes)
+    age[a.n_tips:] = sample["age"]
+    return age
+
+
+def test_mcmctree_exact_likelihood_seam_on_cpu():
+    """The mcmctree consumer's arithmetic (lnpD_locus mcmctree.c:1130-1166: branch = (age of father - age) x mu, then one plfun),
+    restated by the host's clock = 1 parameterisation + the oracle, against the lnL column of the reference's own MCMC samples
+    (usedata = 1, JC69; 3 printed decimals, ages printed with 7)."""
+    g = helpers.load_golden("mcmctree_jc_clock1")
+    a = hostlib.Analysis(os.path.join(CTL, "mcmctree_locus1.ctl"), "baseml")
+    assert a.n_tips == 7 and a.np == a.ntime == 6          # clock = 1, JC69: x = the six internal node ages
+    for smp in g["samples"]:
+        pb = a.problem(np.array(smp["age"]) * smp["mu"])   # ages x rate: the branch lengths lnpD_locus forms
+        assert abs(oracle.evaluate(pb, want_lnf=False)["lnL"] - smp["lnL"]) < 2e-3, smp
+
+
+@pytest.mark.gpu
+def test_mcmctree_exact_likelihood_seam_on_gpu(tmp_path):
+    """pamlh_lnpd_locus — ages and rate in, lnL out, only branch lengths re-sent after the first call — reproduces the lnL
+    column of the reference's mcmc.txt; so does the C example a maintainer would start from (mcmctree_seam.c), and per-branch
+    rates (clock = 2 / 3) equal to the locus rate give the same value."""
+    g = helpers.load_golden("mcmctree_jc_clock1")
+    a = hostlib.Analysis(os.path.join(CTL, "mcmctree_locus1.ctl"), "baseml")
+    a.set_x(a.default_x())
+    got = [a.lnpd_locus(_mcmctree_ages(a, s), rgene=s["mu"], model_changed=(i == 0)) for i, s in enumerate(g["samples"])]
+    want = [s["lnL"] for s in g["samples"]]
+    assert np.max(np.abs(np.array(got) - np.array(want))) < 2e-3, (got[:3], want[:3])
+    s0 = g["samples"][0]
+    assert abs(a.lnpd_locus(_mcmctree_ages(a, s0), rate=np.full(a.n_nodes, s0["mu"]), model_changed=False) - got[0]) < 1e-9
+    with pytest.raises(RuntimeError):                       # a son older than its father: "blength < 0" (mcmctree.c:1150)
+        bad = _mcmctree_ages(a, s0)
+        bad[a.n_tips + 1] = bad[a.n_tips] * 1.1
+        a.lnpd_locus(bad, rgene=s0["mu"])
+    exe = tmp_path / "mcmctree_seam"
+    inc, libdir = os.path.join(helpers.REPO, "include"), os.path.join(helpers.REPO, "paml_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I", inc, os.path.join(helpers.REPO, "paml_amd", "host", "examples", "mcmctree_seam.c"), "-o", str(exe),
+                           "-L", libdir, "-lpamlh", "-lpaml_amd", "-lm", "-Wl,-rpath," + libdir])
+    states = "".join(" ".join("%.7f" % v for v in s["age"]) + " %.7f\n" % s["mu"] for s in g["samples"])
+    out = subprocess.run([str(exe), os.path.join(CTL, "mcmctree_locus1.ctl")], input=states.encode(), stdout=subprocess.PIPE, check=True)
+    vals = [float(v) for v in out.stdout.split()]
+    assert len(vals) == len(want) and np.max(np.abs(np.array(vals) - np.array(want))) < 2e-3
+
+
 @pytest.mark.gpu
 def test_c_host_batch_matches_single_evaluations():
     g = helpers.load_golden("hiv_m2a")
