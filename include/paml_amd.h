@@ -75,6 +75,10 @@ const char *paml_amd_last_error(const paml_amd_engine *e);
  *   lnf / fhK / partials / posteriors stay per-shard.  world = 1 with a non-NULL id makes a one-rank communicator (the
  *   collective path on a single GPU); world = 1 with id = NULL only sets the global chunking.  eval_adg does not shard.
  * The RCCL library (librccl.so.1) is bound at run time on first use; PAML_AMD_EUNSUPPORTED when it is not installed. */
+/* GPUs visible to this process, and the one the calling thread's next paml_amd_create uses (hipSetDevice): a host written in C
+ * — one process per GPU, as `pamlh_lnl --gpus N` forks them — needs no HIP headers. */
+int paml_amd_device_count(void);
+int paml_amd_set_device(int device);
 #define PAML_AMD_COMM_ID_BYTES 128
 int paml_amd_shard_bounds(long n_patt_global, int world, int rank, long *first, long *count);
 int paml_amd_comm_unique_id(void *id128);

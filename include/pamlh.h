@@ -70,6 +70,11 @@ int pamlh_genes(const pamlh *p, const int **gene_off, const double **gene_rate, 
 int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const double **U, const double **V,
                 const double **Root, const double **Cijk);
 
+/* Multi-GPU, one process per GPU: keep this rank's contiguous block of site patterns and join the ranks' RCCL communicator when the
+ * engine is created (id128 = rank 0's paml_amd_comm_unique_id, handed over by any means); every evaluation then returns the
+ * lnL of the WHOLE alignment on every rank, bit for bit the same for any number of ranks.  `pamlh_lnl --gpus N` is the driver. */
+int pamlh_set_shard(pamlh *p, int rank, int world, const void *id128);
+
 /* The paml_amd_engine behind this analysis (NULL before the first evaluation). */
 void *pamlh_engine_handle(const pamlh *p);
 

@@ -1027,6 +1027,14 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
 }
 
 // ---- pattern shards over several GPUs ---------------------------------------------------------------------------------
+int paml_amd_device_count(void)
+{
+   int n = 0;
+   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int paml_amd_set_device(int device) { return hipSetDevice(device) == hipSuccess ? 0 : PAML_AMD_EHIP; }
+
 int paml_amd_shard_bounds(long n_patt_global, int world, int rank, long *first, long *count)
 {
    if (n_patt_global < 1 || world < 1 || rank < 0 || rank >= world || !first || !count) return PAML_AMD_EINVAL;

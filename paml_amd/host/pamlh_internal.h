@@ -71,6 +71,10 @@ struct pamlh {
    unsigned char *frozen;  /* NULL, or [np]: parameters pamlh_optimize leaves where they are (minB holds the branch lengths) */
    int opt_lean;           /* 1: fewer trial points per line search, no curvature pre-pass (the inner ming2 of minB) */
    double opt_abs_tol;     /* > 0 (lean mode): stop as soon as an iteration gains less than this in lnL (ming2's e) */
+   /* pattern shard of a multi-GPU run (pamlh_set_shard): this process holds patterns [shard_first, shard_first + npatt) of npatt_global */
+   int shard_rank, shard_world, shard_have_id;
+   long npatt_global, shard_first;
+   unsigned char shard_id[PAML_AMD_COMM_ID_BYTES];
    /* engine */
    paml_amd_engine *eng;
 };

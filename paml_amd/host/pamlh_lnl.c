@@ -1,5 +1,5 @@
 /* pamlh_lnl — command-line driver: one likelihood evaluation of a codeml/baseml analysis on the MI355X.
- *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [--ancestral] [x0 x1 ...]
+ *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [--ancestral] [--gpus N] [x0 x1 ...]
  * Reads the control file, the sequence and tree files it names, and the parameter vector from the command line,
  * else from in.codeml / in.baseml beside the ctl (the reference's "-1 x..." single-evaluation recipe, treesub.c:4057),
  * else the ctl's initial values; evaluates lnL through libpaml_amd.so; prints `lnL = ...` like the reference and
@@ -8,23 +8,66 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
+#include "../../include/paml_amd.h"
 #include "../../include/pamlh.h"
+
+/* --gpus N: one process per GPU.  The parent becomes rank 0; it forks ranks 1 .. N-1 BEFORE anything touches the GPU, obtains the
+ * RCCL id and hands it to them through pipes.  Every rank reads the same files, keeps its block of site patterns
+ * (pamlh_set_shard) and runs the same code: the all-reduced lnL has the same bits on every rank, so the ranks stay in step
+ * without further communication.  Only rank 0 prints. */
+static int spawn_ranks(int world, int *rank_out, unsigned char *id)
+{
+   int r, fds[64][2];
+   pid_t pid;
+   *rank_out = 0;
+   if (world > 64) world = 64;
+   for (r = 1; r < world; r++) {
+      if (pipe(fds[r])) return -1;
+      pid = fork();
+      if (pid < 0) return -1;
+      if (pid == 0) {            /* child = rank r: wait for the id */
+         int k;
+         for (k = 1; k <= r; k++) close(fds[k][1]);
+         *rank_out = r;
+         if (paml_amd_set_device(r)) { fprintf(stderr, "rank %d: no GPU %d\n", r, r); _exit(1); }
+         if (read(fds[r][0], id, PAML_AMD_COMM_ID_BYTES) != PAML_AMD_COMM_ID_BYTES) _exit(1);
+         close(fds[r][0]);
+         if (!freopen("/dev/null", "w", stdout)) _exit(1);
+         return 0;
+      }
+      close(fds[r][0]);
+   }
+   if (paml_amd_set_device(0)) return -1;
+   if (paml_amd_comm_unique_id(id)) return -1;
+   for (r = 1; r < world; r++) {
+      if (write(fds[r][1], id, PAML_AMD_COMM_ID_BYTES) != PAML_AMD_COMM_ID_BYTES) return -1;
+      close(fds[r][1]);
+   }
+   return 0;
+}
 
 int main(int argc, char **argv)
 {
    pamlh *p;
    char err[512];
    double x[4096], lnL, *lnf;
-   int np, ntime, npatt, i, nx = 0, optimize = 0, ancestral = 0;
-   if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [x...]\n", argv[0]); return 2; }
-   if (pamlh_load(&p, argv[2], argv[1], err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
-   pamlh_dims(p, NULL, NULL, &npatt, NULL, NULL, NULL, NULL, NULL, &np, &ntime);
+   int np, ntime, npatt, i, nx = 0, optimize = 0, ancestral = 0, gpus = 0, rank = 0;
+   unsigned char comm_id[PAML_AMD_COMM_ID_BYTES];
+   if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [--gpus N] [x...]\n", argv[0]); return 2; }
    for (i = 3; i < argc && nx < 4096; i++) {
       if (!strcmp(argv[i], "--optimize")) optimize = 1;
       else if (!strcmp(argv[i], "--ancestral")) ancestral = 1;
+      else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
       else x[nx++] = atof(argv[i]);
    }
+   if (gpus > 0 && spawn_ranks(gpus, &rank, comm_id)) { fprintf(stderr, "error: could not start %d ranks (GPUs visible: %d; librccl.so.1 present?)\n", gpus, paml_amd_device_count()); return 1; }
+   if (pamlh_load(&p, argv[2], argv[1], err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
+   if (gpus > 0 && pamlh_set_shard(p, rank, gpus, comm_id)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
+   pamlh_dims(p, NULL, NULL, &npatt, NULL, NULL, NULL, NULL, NULL, &np, &ntime);
+   if (gpus > 0 && (ancestral || pamlh_mgene(p) == 1)) { fprintf(stderr, "error: --gpus gives lnL and estimates; per-site outputs and Mgene = 1 need the whole alignment on one GPU\n"); return 1; }
    if (pamlh_mgene(p) == 1) {      /* separate analyses: every gene on its own (start values: the control file's), lnL summed */
       const int ng = pamlh_genes(p, NULL, NULL, NULL, NULL);
       double sum = 0;
@@ -68,7 +111,7 @@ int main(int argc, char **argv)
          if (!pamlh_set_x(p, x, np) && !pamlh_newick(p, nw, 160 * nnode + 256)) printf("%s\n", nw);
          free(nw);
       }
-      {
+      if (!gpus) {      /* (the scores' outer product is a sum over all site patterns: one GPU holds them all) */
          double *se = (double *)malloc((np + 1) * sizeof(double));
          if (!pamlh_standard_errors(p, x, 0, se, NULL)) {
             printf("SEs for parameters:\n ");
@@ -82,6 +125,16 @@ int main(int argc, char **argv)
    lnf = (double *)malloc(npatt * sizeof(double));
    if (pamlh_eval_gpu(p, &lnL, lnf)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
    printf("ntime & np: %d %d   npatt %d\nlnL  = %.6f\n", ntime, np, npatt, lnL);
+   if (gpus > 0) {      /* sharded run: lnL (the total over the ranks) and the estimates are the output */
+      int st = 0, bad = 0;
+      printf("(site patterns sharded over %d GPUs, %d on rank 0; lnL is the all-reduced total)\n", gpus, npatt);
+      fflush(stdout);
+      free(lnf);
+      pamlh_free(p);
+      if (rank == 0)
+         while (wait(&st) > 0) bad |= !WIFEXITED(st) || WEXITSTATUS(st);
+      return bad ? 1 : 0;
+   }
    {  /* site-class models: the NEB table the reference prints (sites with Pr(last class) > 0.5 when its omega > 1) */
       int mode, K, n_sites, h, npos = pamlh_positive_classes(p);
       pamlh_model(p, &mode, &K, NULL, NULL);

@@ -1091,6 +1091,33 @@ void pamlh_state_free(pamlh *q)
 }
 
 /* the engine for this data set and tree (created on first use) */
+/* Multi-GPU (one process per GPU): keep only this rank's contiguous block of site patterns (paml_amd_shard_bounds) and remember
+ * the communicator's id; the engine joins it when it is created, and from then on every evaluation returns the total over the
+ * ranks (paml_amd_comm_init) — every rank sees the same lnL bits, so they all take the same optimisation steps.  Call after
+ * pamlh_load (frequencies were estimated from the whole alignment there) and before the first evaluation.  Per-site outputs (lnf,
+ * NEB / BEB, ancestral states) are not available on a shard.  id128: the 128 bytes of paml_amd_comm_unique_id from rank 0
+ * (NULL with world = 1: no communicator). */
+int pamlh_set_shard(pamlh *p, int rank, int world, const void *id128)
+{
+   long first = 0, count = 0;
+   int i;
+   unsigned char *z;
+   if (p->eng) return pamlh_fail(p, "set_shard: call before the first evaluation");
+   if (p->ngene > 1 && world > 1) return pamlh_fail(p, "set_shard: several genes are not sharded yet");
+   if (paml_amd_shard_bounds(p->npatt, world, rank, &first, &count) || count < 1) return pamlh_fail(p, "set_shard: rank %d of %d gets no patterns (%d in all)", rank, world, p->npatt);
+   z = (unsigned char *)malloc((size_t)p->ns * count);
+   for (i = 0; i < p->ns; i++) memcpy(z + (size_t)i * count, p->z + (size_t)i * p->npatt + first, count);
+   memmove(p->w, p->w + first, count * sizeof(double));
+   free(p->z);
+   p->z = z;
+   p->npatt_global = p->npatt; p->shard_first = first; p->shard_rank = rank; p->shard_world = world;
+   p->npatt = (int)count;
+   p->shard_have_id = id128 != NULL;
+   if (id128) memcpy(p->shard_id, id128, PAML_AMD_COMM_ID_BYTES);
+   if (p->ngene == 1) p->posG[1] = p->npatt;
+   return 0;
+}
+
 int pamlh_engine_ready(pamlh *p)
 {
    int rc;
@@ -1098,6 +1125,9 @@ int pamlh_engine_ready(pamlh *p)
    if ((rc = paml_amd_create(&p->eng, p->n, p->ns, p->npatt, 64, p->ngene, 0))) return pamlh_fail(p, "paml_amd_create failed (%d): no GPU?", rc);
    if ((rc = paml_amd_set_tips(p->eng, p->z, p->cleandata, p->n_codes, p->n_chara, p->chara_map, p->w, p->ngene > 1 ? p->posG : NULL)) ||
        (rc = paml_amd_set_tree(p->eng, p->nnode, p->root, p->sons_ptr, p->sons, p->label, p->scale)))
+      return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+   if (p->shard_world > 0 &&
+       (rc = paml_amd_comm_init(p->eng, p->shard_rank, p->shard_world, p->shard_have_id ? p->shard_id : NULL, p->npatt_global, p->shard_first)))
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    return 0;
 }

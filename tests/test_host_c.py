@@ -419,6 +419,26 @@ def test_c_host_plfun_seam():
     assert a.plfun(x[:-1]) == 1e300
 
 
+@pytest.mark.gpu
+def test_driver_gpus_flag_one_rank(tmp_path):
+    """`pamlh_lnl --gpus 1`: the multi-GPU driver path (rank set-up, pattern shard, RCCL communicator joined inside the engine,
+    all-reduced lnL) with a single rank — the only size a one-GPU box can run — gives the single-process lnL; --optimize on it
+    reaches the reference's MLE."""
+    g = helpers.load_golden("hiv_m0")
+    exe = hostlib.DRIVER_PATH
+    x = " ".join("%.6f" % v for v in g["x"]).split()
+    out = subprocess.run([exe, "codeml", os.path.join(CTL, "hiv_ns0.ctl"), "--gpus", "1"] + x, cwd=tmp_path, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    txt = out.stdout.decode()
+    assert "sharded over 1 GPUs" in txt
+    assert abs(float(txt.split("lnL  =")[1].split()[0]) - g["lnL"]) <= 2e-6
+    out = subprocess.run([exe, "codeml", os.path.join(CTL, "hiv_ns0.ctl"), "--gpus", "1", "--optimize"], cwd=tmp_path, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    assert abs(float(out.stdout.decode().split("lnL  =")[1].split()[0]) - g["lnL"]) <= 5e-6
+
+
 def _mcmctree_ages(a, sample):
     """node ages [n_nodes] for one mcmc.txt sample: tips 0, internal nodes in the reference's numbering (root first)."""
     age = np.zeros(a.n_nodes)
