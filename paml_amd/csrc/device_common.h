@@ -643,6 +643,68 @@ __device__ __forceinline__ void jvf_row_mul(double (&x)[N], const double *row)
 }
 #define JVF_CODE(T) ((int)((zw[(T) >> 2] >> (((T) & 3) * 8)) & 0xffu))
 
+// ---- 20-state models on v_mfma_f64_4x4x4_4b_f64 (jit.h: jit_generate_m20) --------------------------------------------------------
+// 20 = 5 blocks of 4 states: with the 4x4x4 instruction P . L has NO padding (25 products of 4 x 4 blocks per 16 patterns = 800
+// FLOP per pattern, the algorithmic count), where v_mfma_f64_16x16x4 spends 10 instructions of which 37.5 % of the rows are
+// zeros.  The instruction runs at the full FP64 rate with one wave per SIMD and its result layout is its B-operand layout
+// (profiles/r02_mfma4_layout.txt), so a partial is FIVE doubles per lane — block m holds state 4 m + (lane >> 4) of pattern
+// lane & 15 — and chains from node to node in registers.  The A operand of block (I, K) is P[4I + i][4K + k] in lane
+// 16 k + 4 b + i: one ds_read_b64 from the row-major P(t) of the branch in LDS (sixteen distinct 8-byte words, each read by the
+// four lanes of the same (i, k): conflict-free), shared by the wave's two pattern groups.
+#define M20_MFMA(A, B, C) __builtin_amdgcn_mfma_f64_4x4x4f64((A), (B), (C), 0, 0, 0)
+__device__ __forceinline__ void m20_matvec2(const double *sPn, int aoff, const double (&x0)[5], double (&y0)[5], const double (&x1)[5], double (&y1)[5])
+{
+#pragma unroll
+   for (int I = 0; I < 5; I++) { y0[I] = 0; y1[I] = 0; }
+#pragma unroll
+   for (int K = 0; K < 5; K++)
+#pragma unroll
+      for (int I = 0; I < 5; I++) {
+         const double A = sPn[aoff + (4 * I) * 20 + 4 * K];
+         y0[I] = M20_MFMA(A, x0[K], y0[I]);
+         y1[I] = M20_MFMA(A, x1[K], y1[I]);
+      }
+}
+// tip factors: row `code` of the tip's table [code][20] (pmat_kernel's layout for the one-pattern-per-lane kernels), this lane's
+// five states 4 m + st
+__device__ __forceinline__ void m20_tip(const double *T, int code, int st, double (&v)[5])
+{
+   const double *r = T + code * 20 + st;
+#pragma unroll
+   for (int m = 0; m < 5; m++) v[m] = r[4 * m];
+}
+__device__ __forceinline__ double m20_scale(double (&x)[5])      // NodeScale treesub.c:7200-7230 (maximum over the 20 states: 5 registers x lane bits 4-5)
+{
+   double mx = 0;
+#pragma unroll
+   for (int m = 0; m < 5; m++) mx = x[m] > mx ? x[m] : mx;
+   double o = __shfl_xor(mx, 16);
+   mx = o > mx ? o : mx;
+   o = __shfl_xor(mx, 32);
+   mx = o > mx ? o : mx;
+   if (mx < 1e-300) {
+#pragma unroll
+      for (int m = 0; m < 5; m++) x[m] = 1.0;
+      return -800;
+   }
+#pragma unroll
+   for (int m = 0; m < 5; m++) x[m] /= mx;
+   return log(mx);
+}
+__device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5], const double (&pis)[5], double lnscale, int iclass, long h, bool own)
+{
+   double f = 0;
+#pragma unroll
+   for (int m = 0; m < 5; m++) f = fma(pis[m], x[m], f);
+   f += __shfl_xor(f, 16);
+   f += __shfl_xor(f, 32);
+   if (own) {
+      double out = 0;
+      if (a.weights[h] > 0) out = root_value(a, f, lnscale);
+      a.fhK[(long)iclass * a.n_patt + h] = out;
+   }
+}
+
 #define JV_PROLOGUE(NS)                                                                                          \
    constexpr int N = NS;                                                                                        \
    const int tid = threadIdx.x;                                                                                 \

@@ -143,7 +143,7 @@ inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global
 
 // Environment switches, read once when the engine is created.
 struct EnvCfg {
-   bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false;
+   bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false, no_m20 = false;
    std::string jit_dump, prof_ops;
    int prof_tid = 0;
    void read()
@@ -155,6 +155,7 @@ struct EnvCfg {
       valu20 = getenv("PAML_AMD_VALU20") != nullptr;
       no_fused = getenv("PAML_AMD_NO_FUSED") != nullptr;
       mfma4 = getenv("PAML_AMD_MFMA4") != nullptr;
+      no_m20 = getenv("PAML_AMD_NO_M20") != nullptr;
       tail = getenv("PAML_AMD_TAIL") != nullptr;        // experiment: the last workgroup forms the total instead of a stage-2 launch
       if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
       if (const char *v = getenv("PAML_AMD_PROF_OPS")) prof_ops = v;
@@ -192,6 +193,7 @@ struct paml_amd_engine {
    size_t h_out_cap = 0;
    bool fused = false;                // the selected kernel forms the reduction itself
    bool fused_mfma4 = false;
+   bool want_m20 = false, m20 = false;      // 20 states on v_mfma_f64_4x4x4 (jit_generate_m20)
    int fused_threads = 256;
    bool pmat_valid = false;           // d_rowmajor holds the P(t) of an evaluation in the tree's own orientation
    // branch-local evaluation: resident partials on both sides of every edge, re-used from call to call (eval_branch)
@@ -659,6 +661,12 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
             if (r) return r;
          }
       }
+      e->m20 = false;
+      if (e->want_m20 && !clean && jit_m20_supported(e->prog, e->n_tips, G)) {
+         int r = ensure_jit(e, "m20:" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate_m20(e->prog, e->n_tips); }, &jit_ok);
+         if (r) return r;
+         e->m20 = jit_ok;
+      }
       e->use_jit = jit_ok;
       e->fused = fused;
    }
@@ -779,6 +787,11 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       if (fused) {
          void *params[] = {&pr};
          HIPCHK(hipModuleLaunchKernel(e->jit.fn, nb, B, 1, e->fused_threads, 1, 1, 0, e->stream, params, nullptr));
+      }
+      else if (e->use_jit && e->m20) {      // persistent: a multiple of the class count, every workgroup keeps its class's P(t) in LDS
+         void *params[] = {&pr};
+         const int grid = std::min(std::max(K, e->n_cu / K * K), e->n_tiles * K);
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::max(grid / K, 1) * K, 1, 1, 512, 1, 1, 0, e->stream, params, nullptr));
       }
       else if (e->use_jit) {
          void *params[] = {&pr};
@@ -988,7 +1001,11 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    }
    // 20 states: the specialised MFMA kernel trimmed to 2 row blocks x 5 k-blocks beats the scalar-operand kernel 2-3x; the
    // MFMA interpreters (64 MFMAs per product whatever n) do not, so small or keep-partials engines stay on valu20
-   const bool mfma20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_tips <= 95 && !e->env.valu20;
+   // 20 states: the per-tree kernel on v_mfma_f64_4x4x4 (no padding: 25 block products per 16 patterns) for one gene and trees whose
+   // internal branches' P(t) fit in LDS; else the 16x16x4 kernel trimmed to 2 row blocks x 5 k-blocks (2-3x the scalar-operand
+   // kernel); the MFMA interpreters (64 MFMAs per product whatever n) do not pay, so small or keep-partials engines stay on valu20
+   e->want_m20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_genes == 1 && n_tips <= 49 && !e->env.no_m20 && !e->env.valu20;
+   const bool mfma20 = n_states == 20 && !e->want_m20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_tips <= 95 && !e->env.valu20;
    if (n_states == 4) e->kk = KK_VALU4;
    else if (n_states == 5) e->kk = KK_VALU5;
    else if (n_states == 20 && !mfma20) e->kk = KK_VALU20;
@@ -1021,7 +1038,7 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
    switch (e->kk) {
    case KK_VALU4: return e->use_jit ? (e->fused && e->fused_mfma4 ? "mfma4_jit" : "valu4_jit") : "valu4";
    case KK_VALU5: return e->use_jit ? "valu5_jit" : "valu5";
-   case KK_VALU20: return e->use_jit ? "valu20_jit" : "valu20";
+   case KK_VALU20: return e->use_jit ? (e->m20 ? "mfma4x20_jit" : "valu20_jit") : "valu20";
    default: return e->use_jit ? "mfma64_jit" : (e->mfma_dma ? "mfma64_stream" : "mfma64_gather");
    }
 }
@@ -1966,6 +1983,10 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
       if (!jit_supported(p, n_tips, 61)) return PAML_AMD_EUNSUPPORTED;
       text = jit_generate(p, n_tips, n_states - 64, n_states - 64);
    }
+   else if (fusedK && n_states == 20) {
+      if (!jit_m20_supported(p, n_tips, 1)) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate_m20(p, n_tips);
+   }
    else if (fusedK) {
       const int chunk = (compile_all >> 2) & 0x3f ? ((compile_all >> 2) & 0x3f) * 256 : 256;      // bits 2..7: reduction chunk / 256
       if (!jit_valu_fused_plan(p, n_states, n_tips, fusedNC, fusedK, chunk).ok) return PAML_AMD_EUNSUPPORTED;
@@ -2015,7 +2036,8 @@ int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_p
    const Program p = build_program(t, false, nullptr);
    std::string text;
    // the same choices launch_eval makes for an engine of these sizes
-   if (n_states <= 5) {
+   if (n_states == 20 && jit_m20_supported(p, n_tips, 1)) text = jit_generate_m20(p, n_tips);
+   else if (n_states <= 5) {
       if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;
       const int chunk = red_chunk(n_patt_global);
       text = !jit_valu_fused_plan(p, n_states, n_tips, n_codes, K, chunk).ok ? jit_generate_valu(p, n_states)

@@ -867,6 +867,142 @@ inline std::string jit_generate_mfma4(const Program &p, int n_tips, int n_codes,
    return s.str();
 }
 
+// ---- 20 states on v_mfma_f64_4x4x4 (m20_* in device_common.h) -----------------------------------------------------------------
+// One class per workgroup (grid = a multiple of the class count, persistent over the 256-pattern tiles of its class): the
+// row-major P(t) of every internal branch of that class sits in LDS (3 200 bytes each) for the whole launch; 8 waves x 2 groups
+// of 16 patterns; tip rows are gathered from pmat's tables (L1 / L2 resident); fx_r's value per class goes to fhK and the usual
+// reduction kernel does the mixture.  One gene; trees whose internal branches fit in LDS (<= 46).
+inline bool jit_m20_supported(const Program &p, int n_tips, int n_genes, int *n_slots = nullptr)
+{
+   if (!jit_valu_supported(p, 64) || n_genes != 1) return false;
+   int nmm = 0;
+   for (const Op &o : p.ops) {
+      if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) nmm++;
+      if (o.code == OP_INIT_TIP) return false;
+   }
+   if (n_slots) *n_slots = nmm;
+   return nmm >= 1 && nmm * 3200 <= 150 * 1024 && p.max_stack + 2 <= 9;
+}
+
+inline std::string jit_generate_m20(const Program &p, int n_tips)
+{
+   std::ostringstream s;
+   int nmm = 0;
+   std::vector<int> mm_nodes;
+   for (const Op &o : p.ops)
+      if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) { mm_nodes.push_back(o.a); nmm++; }
+   s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
+   s << "extern \"C\" __global__ __launch_bounds__(512) void prune_jit(PruneArgs a)\n{\n";
+   s << "   constexpr int NMM = " << nmm << ";\n";
+   s << "   __shared__ __attribute__((aligned(16))) double sP[NMM * 400];\n";
+   s << "   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, st = lane >> 4, col = lane & 15;\n";
+   s << "   const int iclass = blockIdx.x % a.K, first = blockIdx.x / a.K, stride = gridDim.x / a.K;\n";
+   s << "   const double *Pall = a.pint + (long)iclass * a.n_nodes * 400;\n";
+   s << "   const double *Ptip = a.ptip + (long)iclass * a.n_nodes * a.tip_words;\n";
+   for (int k = 0; k < nmm; k++)
+      s << "   for (int i = tid; i < 400; i += 512) sP[" << k * 400 << " + i] = Pall[" << (long)mm_nodes[k] * 400 << " + i];\n";
+   s << "   __syncthreads();\n";
+   s << "   const int aoff = (lane & 3) * 20 + (lane >> 4);      /* A operand: lane 16 k + 4 b + i <- P[4I + i][4K + k] */\n";
+   s << "   double pis[5];\n   _Pragma(\"unroll\") for (int m = 0; m < 5; m++) pis[m] = a.pi[4 * m + st];\n";
+   s << "   for (int tile = first; tile < a.n_tiles; tile += stride) {\n";
+   s << "      const int h0 = as_const(a.tiles)[tile].y, hend = as_const(a.gene_off)[1];\n";
+   for (int g = 0; g < 2; g++) {
+      s << "      const long h_" << g << " = h0 + wv * 32 + " << 16 * g << " + col;\n      const bool valid_" << g << " = h_" << g << " < hend;\n";
+      s << "      const long hc_" << g << " = valid_" << g << " ? h_" << g << " : hend - 1;\n      double lnscale_" << g << " = 0;\n      (void)lnscale_" << g << ";\n";
+   }
+   const int NA = p.max_stack + 2;
+   for (int g = 0; g < 2; g++)
+      for (int i = 0; i < NA; i++) s << "      double A" << i << "_" << g << "[5];\n";
+   std::vector<int> freeA;
+   for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
+   auto alloc = [&]() { int r = freeA.back(); freeA.pop_back(); return r; };
+   auto release = [&](int r) { freeA.push_back(r); };
+   auto name = [&](int a, int g) { return "A" + std::to_string(a) + "_" + std::to_string(g); };
+   const char *LOOP = "_Pragma(\"unroll\") for (int m = 0; m < 5; m++) ";
+   // Tip rows are gathered from global memory: the loads of the tip steps that follow a matrix product are issued BEFORE that
+   // product (its 50 MFMAs cover their latency) and nothing else is allowed to move across a step (sched_barrier): left to
+   // itself the compiler hoists every tip load of the tile to the top and spills.
+   const size_t nops = p.ops.size();
+   auto is_tip = [&](const Op &o) { return o.code == OP_SET_TIP || o.code == OP_MUL_TIP || o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2; };
+   auto is_mm = [&](const Op &o) { return o.code == OP_MATMUL || o.code == OP_MATMUL_POP; };
+   std::vector<char> loaded(nops, 0);
+   auto emit_loads = [&](size_t i) {      // the rows of tip step i -> T<i>a_<g>, T<i>b_<g>
+      const Op &o = p.ops[i];
+      const bool two = o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2;
+      for (int g = 0; g < 2; g++) {
+         s << "      double T" << i << "a_" << g << "[5]; m20_tip(Ptip + (long)" << o.a << " * a.tip_words, (int)a.z[(long)" << o.a << " * a.z_stride + hc_" << g << "], st, T" << i
+           << "a_" << g << ");\n";
+         if (two)
+            s << "      double T" << i << "b_" << g << "[5]; m20_tip(Ptip + (long)" << o.b << " * a.tip_words, (int)a.z[(long)" << o.b << " * a.z_stride + hc_" << g << "], st, T" << i
+              << "b_" << g << ");\n";
+      }
+      loaded[i] = 1;
+   };
+   for (size_t i = 0; i < nops && !is_mm(p.ops[i]); i++)      // in front of the first product
+      if (is_tip(p.ops[i])) emit_loads(i);
+   std::vector<int> slot(256, -1);
+   int cur = -1, imm = 0;
+   for (size_t iop = 0; iop < nops; iop++) {
+      const Op &o = p.ops[iop];
+      int out = -1, pop = -1, push = -1, curin = cur;
+      if (o.code == OP_INIT_ONES || o.code == OP_SET_TIP || o.code == OP_SET_TIP2) {
+         if (cur < 0) cur = alloc();
+         curin = cur;
+      }
+      switch (o.code) {
+      case OP_INIT_ONES:
+         for (int g = 0; g < 2; g++) s << "      " << LOOP << name(curin, g) << "[m] = 1.0;\n";
+         break;
+      case OP_SET_TIP:
+         for (int g = 0; g < 2; g++) s << "      " << LOOP << name(curin, g) << "[m] = T" << iop << "a_" << g << "[m];\n";
+         break;
+      case OP_MUL_TIP:
+         for (int g = 0; g < 2; g++) s << "      " << LOOP << name(curin, g) << "[m] *= T" << iop << "a_" << g << "[m];\n";
+         break;
+      case OP_SET_TIP2:
+         for (int g = 0; g < 2; g++) s << "      " << LOOP << name(curin, g) << "[m] = T" << iop << "a_" << g << "[m] * T" << iop << "b_" << g << "[m];\n";
+         break;
+      case OP_MUL_TIP2:
+         for (int g = 0; g < 2; g++)
+            s << "      " << LOOP << name(curin, g) << "[m] = (" << name(curin, g) << "[m] * T" << iop << "a_" << g << "[m]) * T" << iop << "b_" << g << "[m];\n";
+         break;
+      case OP_PUSH: slot[o.b] = cur; cur = -1; break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP:
+         pop = mm_pop_slot(o); push = mm_push_slot(o); out = alloc();
+         for (size_t j = iop + 1; j < nops && !is_mm(p.ops[j]); j++)
+            if (is_tip(p.ops[j]) && !loaded[j]) emit_loads(j);
+         s << "      __builtin_amdgcn_sched_barrier(0);\n";
+         s << "      m20_matvec2(sP + " << imm * 400 << ", aoff, " << name(curin, 0) << ", " << name(out, 0) << ", " << name(curin, 1) << ", " << name(out, 1) << ");\n";
+         s << "      __builtin_amdgcn_sched_barrier(0);\n";
+         imm++;
+         release(curin);
+         if (pop >= 0) {
+            for (int g = 0; g < 2; g++) s << "      " << LOOP << name(out, g) << "[m] = " << name(slot[pop], g) << "[m] * " << name(out, g) << "[m];\n";
+            release(slot[pop]);
+            slot[pop] = -1;
+         }
+         if (push >= 0) { slot[push] = out; cur = -1; }
+         else cur = out;
+         break;
+      case OP_SCALE:
+         for (int g = 0; g < 2; g++)
+            s << "      { const double fac = m20_scale(" << name(curin, g) << "); lnscale_" << g << " += fac;\n"
+              << "        if (a.keep && st == 0 && valid_" << g << ") a.scalef[((long)iclass * a.n_scale + " << o.b << ") * a.n_patt + h_" << g << "] = fac; }\n";
+         break;
+      case OP_ROOT:
+         for (int g = 0; g < 2; g++)
+            s << "      m20_root(a, " << name(curin, g) << ", pis, lnscale_" << g << ", iclass, h_" << g << ", st == 0 && valid_" << g << ");\n";
+         release(cur);
+         cur = -1;
+         break;
+      default: break;
+      }
+   }
+   s << "   }\n}\n";
+   return s.str();
+}
+
 inline std::string jit_source_dir()
 {
    Dl_info info;
