@@ -652,26 +652,76 @@ __device__ __forceinline__ void jvf_row_mul(double (&x)[N], const double *row)
 // 16 k + 4 b + i: one ds_read_b64 from the row-major P(t) of the branch in LDS (sixteen distinct 8-byte words, each read by the
 // four lanes of the same (i, k): conflict-free), shared by the wave's two pattern groups.
 #define M20_MFMA(A, B, C) __builtin_amdgcn_mfma_f64_4x4x4f64((A), (B), (C), 0, 0, 0)
-__device__ __forceinline__ void m20_matvec2(const double *sPn, int aoff, const double (&x0)[5], double (&y0)[5], const double (&x1)[5], double (&y1)[5])
+// The A blocks are fetched with ds_read_b64 issued from inline asm: left to the compiler, neighbouring reads are merged into
+// ds_read2_b64, which moves 128 bytes per LDS cycle where ds_read_b64 moves 256 (MI355X_MICROARCH.md, LDS table) — with eight waves
+// reading twenty-five blocks per product plus the tip rows, the merged form keeps the LDS busy for as long as the MFMAs take.
+// Column K + 1 is requested before column K's MFMAs; LDS returns in order, so "at most five LGKM operations outstanding"
+// (s_waitcnt lgkmcnt(5)) means column K has arrived whatever else the compiler has in flight.  The first column of the NEXT
+// product (sPnext) is requested under the last column, so a product never starts by waiting for LDS.
+template <int OFF>
+__device__ __forceinline__ double m20_lds64(unsigned addr)
+{
+   double v;
+   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+   return v;
+}
+template <int K>
+__device__ __forceinline__ void m20_acol_asm(unsigned base, double (&A)[5])
+{
+   A[0] = m20_lds64<(0 * 20 + 4 * K) * 8>(base);
+   A[1] = m20_lds64<(4 * 20 + 4 * K) * 8>(base);
+   A[2] = m20_lds64<(8 * 20 + 4 * K) * 8>(base);
+   A[3] = m20_lds64<(12 * 20 + 4 * K) * 8>(base);
+   A[4] = m20_lds64<(16 * 20 + 4 * K) * 8>(base);
+}
+// wait until at most N LGKM operations are outstanding and tie the five values to the wait, so that nothing using them moves above it
+template <int N>
+__device__ __forceinline__ void m20_wait(double (&A)[5])
+{
+   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]) : "n"(N));
+}
+__device__ __forceinline__ unsigned m20_lds_addr(const double *p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)p; }
+__device__ __forceinline__ void m20_acol(const double *sPn, int aoff, int K, double (&A)[5])
+{
+#pragma unroll
+   for (int I = 0; I < 5; I++) A[I] = sPn[aoff + (4 * I) * 20 + 4 * K];
+}
+template <int K>
+__device__ __forceinline__ void m20_column(const double (&A)[5], const double (&x0)[5], double (&y0)[5], const double (&x1)[5], double (&y1)[5])
+{
+#pragma unroll
+   for (int I = 0; I < 5; I++) {
+      y0[I] = M20_MFMA(A[I], x0[K], y0[I]);
+      y1[I] = M20_MFMA(A[I], x1[K], y1[I]);
+   }
+}
+__device__ __forceinline__ void m20_matvec2(const double *sPn, const double *sPnext, int aoff, double (&A0)[5], const double (&x0)[5], double (&y0)[5],
+                                            const double (&x1)[5], double (&y1)[5])
 {
 #pragma unroll
    for (int I = 0; I < 5; I++) { y0[I] = 0; y1[I] = 0; }
+   const unsigned base = m20_lds_addr(sPn) + aoff * 8, nbase = m20_lds_addr(sPnext) + aoff * 8;
+   double A1[5];
+   m20_acol_asm<1>(base, A1);  m20_wait<5>(A0);  m20_column<0>(A0, x0, y0, x1, y1);
+   m20_acol_asm<2>(base, A0);  m20_wait<5>(A1);  m20_column<1>(A1, x0, y0, x1, y1);
+   m20_acol_asm<3>(base, A1);  m20_wait<5>(A0);  m20_column<2>(A0, x0, y0, x1, y1);
+   m20_acol_asm<4>(base, A0);  m20_wait<5>(A1);  m20_column<3>(A1, x0, y0, x1, y1);
+   m20_acol_asm<0>(nbase, A1); m20_wait<5>(A0);  m20_column<4>(A0, x0, y0, x1, y1);
 #pragma unroll
-   for (int K = 0; K < 5; K++)
-#pragma unroll
-      for (int I = 0; I < 5; I++) {
-         const double A = sPn[aoff + (4 * I) * 20 + 4 * K];
-         y0[I] = M20_MFMA(A, x0[K], y0[I]);
-         y1[I] = M20_MFMA(A, x1[K], y1[I]);
-      }
+   for (int I = 0; I < 5; I++) A0[I] = A1[I];      // the next product's first column, possibly still in flight: its wait comes first there
 }
-// tip factors: row `code` of the tip's table [code][20] (pmat_kernel's layout for the one-pattern-per-lane kernels), this lane's
-// five states 4 m + st
-__device__ __forceinline__ void m20_tip(const double *T, int code, int st, double (&v)[5])
+// tip factors: row `code` of the tip's table, stored [code][st][m] (pmat_kernel layout 2) so that this lane's five states
+// 4 m + st are 40 contiguous bytes and the four lanes of a pattern read one 160-byte row
+__device__ __forceinline__ void m20_tip(const double *T, int row, int code, int st, double (&v)[5])      // row = doubles per code (20, or 21 in LDS)
 {
-   const double *r = T + code * 20 + st;
+#ifdef M20_ABL_NOTIP
 #pragma unroll
-   for (int m = 0; m < 5; m++) v[m] = r[4 * m];
+   for (int m = 0; m < 5; m++) v[m] = 0.05 + 0.001 * code;
+   return;
+#endif
+   const double *r = T + code * row + st * 5;
+#pragma unroll
+   for (int m = 0; m < 5; m++) v[m] = r[m];
 }
 __device__ __forceinline__ double m20_scale(double (&x)[5])      // NodeScale treesub.c:7200-7230 (maximum over the 20 states: 5 registers x lane bits 4-5)
 {

@@ -663,7 +663,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
       e->m20 = false;
       if (e->want_m20 && !clean && jit_m20_supported(e->prog, e->n_tips, G)) {
-         int r = ensure_jit(e, "m20:" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate_m20(e->prog, e->n_tips); }, &jit_ok);
+         int r = ensure_jit(e, "m20c" + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate_m20(e->prog, e->n_tips, e->n_codes); }, &jit_ok);
          if (r) return r;
          e->m20 = jit_ok;
       }
@@ -688,7 +688,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // Kernel A: batched P(t)
    PmatArgs pa{};
    pa.n = n; pa.n_nodes = nn; pa.root = e->tree.root; pa.K = Km; pa.n_genes = G; pa.n_labels = e->n_labels;
-   pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : 0;
+   pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : ((e->kk == KK_VALU20 && e->use_jit && e->m20) ? 2 : 0);
    pa.label = e->d_label.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = pipe ? e->d2_branch.p : e->d_branch.p; pa.rate = e->d_rate.p;
    pa.gene_rate = pipe ? e->d2_gene_rate.p : e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
    pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
@@ -743,6 +743,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    if (want_lnf) HIPCHK(e->d_lnf.ensure((size_t)B * e->n_patt));
    double *const lnl_out = d_lnL_out ? d_lnL_out : e->d_out.p;
    const bool fused = e->kk != KK_MFMA64 && e->use_jit && e->fused;
+   pr.zpm = e->d_zpm.p; pr.zpm_words = e->zpm_words;
    if (fused) {
       pr.zpm = e->d_zpm.p; pr.zpm_words = e->zpm_words; pr.Km = Km; pr.chunk = chunk; pr.first_chunk = e->first_chunk; pr.nb_stride = nbg;
       pr.want_fhk = (want_fhk || e->tree.n_scale) ? 1 : 0;
@@ -1193,7 +1194,7 @@ int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata,
    HIPCHK(upload(e->d_n_chara, nch.data(), nch.size(), e->stream));
    HIPCHK(upload(e->d_chara_map, cmap.data(), cmap.size(), e->stream));
    HIPCHK(upload(e->d_gene_off, e->gene_off.data(), e->gene_off.size(), e->stream));
-   if (e->kk == KK_VALU4 || e->kk == KK_VALU5) {      // pattern-major copy of the codes for the fused kernel
+   if (e->kk == KK_VALU4 || e->kk == KK_VALU5 || e->kk == KK_VALU20) {      // pattern-major copy of the codes for the per-tree kernels
       e->zpm_words = ((e->n_tips + 3) / 4 + 3) / 4 * 4;
       HIPCHK(e->d_zpm.ensure((size_t)e->n_patt * e->zpm_words));
       hipLaunchKernelGGL(zpm_kernel, dim3((e->n_patt + 255) / 256), dim3(256), 0, e->stream, e->d_z.p, (long)e->n_patt, e->n_tips, e->n_patt,
@@ -1985,7 +1986,7 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
    }
    else if (fusedK && n_states == 20) {
       if (!jit_m20_supported(p, n_tips, 1)) return PAML_AMD_EUNSUPPORTED;
-      text = jit_generate_m20(p, n_tips);
+      text = jit_generate_m20(p, n_tips, fusedNC);
    }
    else if (fusedK) {
       const int chunk = (compile_all >> 2) & 0x3f ? ((compile_all >> 2) & 0x3f) * 256 : 256;      // bits 2..7: reduction chunk / 256
@@ -2036,7 +2037,7 @@ int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_p
    const Program p = build_program(t, false, nullptr);
    std::string text;
    // the same choices launch_eval makes for an engine of these sizes
-   if (n_states == 20 && jit_m20_supported(p, n_tips, 1)) text = jit_generate_m20(p, n_tips);
+   if (n_states == 20 && jit_m20_supported(p, n_tips, 1)) text = jit_generate_m20(p, n_tips, n_codes);
    else if (n_states <= 5) {
       if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;
       const int chunk = red_chunk(n_patt_global);

@@ -884,31 +884,66 @@ inline bool jit_m20_supported(const Program &p, int n_tips, int n_genes, int *n_
    return nmm >= 1 && nmm * 3200 <= 150 * 1024 && p.max_stack + 2 <= 9;
 }
 
-inline std::string jit_generate_m20(const Program &p, int n_tips)
+inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
 {
    std::ostringstream s;
    int nmm = 0;
    std::vector<int> mm_nodes;
    for (const Op &o : p.ops)
       if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) { mm_nodes.push_back(o.a); nmm++; }
+   if (const char *abl = getenv("PAML_AMD_M20_ABL")) {      // timing experiments (results are garbage)
+      if (strstr(abl, "notip")) s << "#define M20_ABL_NOTIP 1\n";
+      if (strstr(abl, "noa")) s << "#define M20_ABL_NOA 1\n";
+   }
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
    s << "extern \"C\" __global__ __launch_bounds__(512) void prune_jit(PruneArgs a)\n{\n";
-   s << "   constexpr int NMM = " << nmm << ";\n";
+   // tip tables: as many as fit beside the P(t) blocks go to LDS (in order of use), the others are gathered from L1 / L2
+   const int tip_bytes = n_codes * 168;      // rows padded to 21 doubles in LDS: with 20, codes c and c + 8 share all their banks
+   const int room = 158 * 1024 - nmm * 3200;
+   const int n_lds_max = getenv("PAML_AMD_M20_NOLDSTIP") ? 0 : std::max(0, room / tip_bytes);
+   std::vector<int> lds_slot(n_tips, -1);
+   int n_lds = 0;
+   for (const Op &o : p.ops) {
+      auto take = [&](int t) { if (t >= 0 && t < n_tips && lds_slot[t] < 0 && n_lds < n_lds_max) lds_slot[t] = n_lds++; };
+      if (o.code == OP_SET_TIP || o.code == OP_MUL_TIP) take(o.a);
+      if (o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2) { take(o.a); take(o.b); }
+   }
+   s << "   constexpr int NMM = " << nmm << ", NC = " << n_codes << ", NLT = " << std::max(1, n_lds) << ";\n";
    s << "   __shared__ __attribute__((aligned(16))) double sP[NMM * 400];\n";
+   s << "   __shared__ __attribute__((aligned(16))) double sT[NLT * NC * 21];\n";
    s << "   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, st = lane >> 4, col = lane & 15;\n";
    s << "   const int iclass = blockIdx.x % a.K, first = blockIdx.x / a.K, stride = gridDim.x / a.K;\n";
    s << "   const double *Pall = a.pint + (long)iclass * a.n_nodes * 400;\n";
    s << "   const double *Ptip = a.ptip + (long)iclass * a.n_nodes * a.tip_words;\n";
    for (int k = 0; k < nmm; k++)
       s << "   for (int i = tid; i < 400; i += 512) sP[" << k * 400 << " + i] = Pall[" << (long)mm_nodes[k] * 400 << " + i];\n";
+   for (int t = 0; t < n_tips; t++)
+      if (lds_slot[t] >= 0)
+         s << "   for (int i = tid; i < NC * 20; i += 512) sT[" << lds_slot[t] << " * NC * 21 + (i / 20) * 21 + i % 20] = Ptip[(long)" << t << " * a.tip_words + i];\n";
    s << "   __syncthreads();\n";
    s << "   const int aoff = (lane & 3) * 20 + (lane >> 4);      /* A operand: lane 16 k + 4 b + i <- P[4I + i][4K + k] */\n";
    s << "   double pis[5];\n   _Pragma(\"unroll\") for (int m = 0; m < 5; m++) pis[m] = a.pi[4 * m + st];\n";
+   // tip codes: pattern-major, four per dword (PruneArgs::zpm); the NEXT tile's are fetched while this tile is walked, so that no
+   // tip row's address waits on a global load
+   const int ZW = ((n_tips + 3) / 4 + 3) / 4 * 4;
+   s << "   constexpr int ZW = " << ZW << ";\n";
+   s << "   const int hend = as_const(a.gene_off)[1];\n";
+   s << "   unsigned int zn_0[ZW], zn_1[ZW];\n";
+   s << "#define M20_FETCH_CODES(TILE) { const int h0n = as_const(a.tiles)[(TILE) < a.n_tiles ? (TILE) : a.n_tiles - 1].y; \\\n"
+        "      long hn = h0n + wv * 32 + col; if (hn >= hend) hn = hend - 1; const uint4 *zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
+        "      _Pragma(\"unroll\") for (int i = 0; i < ZW / 4; i++) { const uint4 t = zp[i]; zn_0[4 * i] = t.x; zn_0[4 * i + 1] = t.y; zn_0[4 * i + 2] = t.z; zn_0[4 * i + 3] = t.w; } \\\n"
+        "      hn = h0n + wv * 32 + 16 + col; if (hn >= hend) hn = hend - 1; zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
+        "      _Pragma(\"unroll\") for (int i = 0; i < ZW / 4; i++) { const uint4 t = zp[i]; zn_1[4 * i] = t.x; zn_1[4 * i + 1] = t.y; zn_1[4 * i + 2] = t.z; zn_1[4 * i + 3] = t.w; } }\n";
+   s << "   double Acol[5];\n   m20_acol_asm<0>(m20_lds_addr(sP) + aoff * 8, Acol);      /* first column of the first product (a tile's last product fetches it for the next tile) */\n";
+   s << "   M20_FETCH_CODES(first)\n";
    s << "   for (int tile = first; tile < a.n_tiles; tile += stride) {\n";
-   s << "      const int h0 = as_const(a.tiles)[tile].y, hend = as_const(a.gene_off)[1];\n";
+   s << "      const int h0 = as_const(a.tiles)[tile].y;\n";
+   s << "      unsigned int zw_0[ZW], zw_1[ZW];\n";
+   s << "      _Pragma(\"unroll\") for (int i = 0; i < ZW; i++) { zw_0[i] = zn_0[i]; zw_1[i] = zn_1[i]; }\n";
+   s << "      M20_FETCH_CODES(tile + stride)\n";
    for (int g = 0; g < 2; g++) {
       s << "      const long h_" << g << " = h0 + wv * 32 + " << 16 * g << " + col;\n      const bool valid_" << g << " = h_" << g << " < hend;\n";
-      s << "      const long hc_" << g << " = valid_" << g << " ? h_" << g << " : hend - 1;\n      double lnscale_" << g << " = 0;\n      (void)lnscale_" << g << ";\n";
+      s << "      double lnscale_" << g << " = 0;\n      (void)lnscale_" << g << ";\n";
    }
    const int NA = p.max_stack + 2;
    for (int g = 0; g < 2; g++)
@@ -926,20 +961,32 @@ inline std::string jit_generate_m20(const Program &p, int n_tips)
    auto is_tip = [&](const Op &o) { return o.code == OP_SET_TIP || o.code == OP_MUL_TIP || o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2; };
    auto is_mm = [&](const Op &o) { return o.code == OP_MATMUL || o.code == OP_MATMUL_POP; };
    std::vector<char> loaded(nops, 0);
+   auto tip_src = [&](int t) {
+      return lds_slot[t] >= 0 ? "sT + " + std::to_string(lds_slot[t]) + " * NC * 21, 21" : "Ptip + (long)" + std::to_string(t) + " * a.tip_words, 20";
+   };
    auto emit_loads = [&](size_t i) {      // the rows of tip step i -> T<i>a_<g>, T<i>b_<g>
       const Op &o = p.ops[i];
       const bool two = o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2;
       for (int g = 0; g < 2; g++) {
-         s << "      double T" << i << "a_" << g << "[5]; m20_tip(Ptip + (long)" << o.a << " * a.tip_words, (int)a.z[(long)" << o.a << " * a.z_stride + hc_" << g << "], st, T" << i
-           << "a_" << g << ");\n";
-         if (two)
-            s << "      double T" << i << "b_" << g << "[5]; m20_tip(Ptip + (long)" << o.b << " * a.tip_words, (int)a.z[(long)" << o.b << " * a.z_stride + hc_" << g << "], st, T" << i
-              << "b_" << g << ");\n";
+         auto codeof = [&](int t) {
+            return "(int)((zw_" + std::to_string(g) + "[" + std::to_string(t >> 2) + "] >> " + std::to_string((t & 3) * 8) + ") & 0xffu)";
+         };
+         s << "      double T" << i << "a_" << g << "[5]; m20_tip(" << tip_src(o.a) << ", " << codeof(o.a) << ", st, T" << i << "a_" << g << ");\n";
+         if (two) s << "      double T" << i << "b_" << g << "[5]; m20_tip(" << tip_src(o.b) << ", " << codeof(o.b) << ", st, T" << i << "b_" << g << ");\n";
       }
       loaded[i] = 1;
    };
-   for (size_t i = 0; i < nops && !is_mm(p.ops[i]); i++)      // in front of the first product
-      if (is_tip(p.ops[i])) emit_loads(i);
+   // loads run TWO products ahead of their use
+   std::vector<size_t> mm_at;
+   for (size_t i = 0; i < nops; i++)
+      if (is_mm(p.ops[i])) mm_at.push_back(i);
+   auto emit_loads_after = [&](int k) {      // the tip steps between product k and product k + 1 (k = -1: in front of the first)
+      const size_t lo = k < 0 ? 0 : (k < (int)mm_at.size() ? mm_at[k] + 1 : nops), hi = k + 1 < (int)mm_at.size() ? mm_at[k + 1] : nops;
+      for (size_t j = lo; j < hi; j++)
+         if (is_tip(p.ops[j]) && !loaded[j]) emit_loads(j);
+   };
+   emit_loads_after(-1);
+   emit_loads_after(0);
    std::vector<int> slot(256, -1);
    int cur = -1, imm = 0;
    for (size_t iop = 0; iop < nops; iop++) {
@@ -970,10 +1017,10 @@ inline std::string jit_generate_m20(const Program &p, int n_tips)
       case OP_MATMUL:
       case OP_MATMUL_POP:
          pop = mm_pop_slot(o); push = mm_push_slot(o); out = alloc();
-         for (size_t j = iop + 1; j < nops && !is_mm(p.ops[j]); j++)
-            if (is_tip(p.ops[j]) && !loaded[j]) emit_loads(j);
+         emit_loads_after(imm + 1);
          s << "      __builtin_amdgcn_sched_barrier(0);\n";
-         s << "      m20_matvec2(sP + " << imm * 400 << ", aoff, " << name(curin, 0) << ", " << name(out, 0) << ", " << name(curin, 1) << ", " << name(out, 1) << ");\n";
+         s << "      m20_matvec2(sP + " << imm * 400 << ", sP + " << ((imm + 1) % nmm) * 400 << ", aoff, Acol, " << name(curin, 0) << ", " << name(out, 0) << ", "
+           << name(curin, 1) << ", " << name(out, 1) << ");\n";
          s << "      __builtin_amdgcn_sched_barrier(0);\n";
          imm++;
          release(curin);

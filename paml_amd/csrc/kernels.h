@@ -29,7 +29,7 @@ struct EigenDev {
 //                                  (codeml.c:3555-3567), [code][n] for VALU, [code][q][m] for mfma64
 // ------------------------------------------------------------------------------------------------
 struct PmatArgs {
-   int n, n_nodes, root, K, n_genes, n_labels, n_codes, layout;   // layout 0: VALU (row-major), 1: mfma64
+   int n, n_nodes, root, K, n_genes, n_labels, n_codes, layout;   // layout 0: VALU (row-major), 1: mfma64, 2: as 0 with the tip rows in m20 order
    const int *label;             // [n_nodes]
    const unsigned char *is_leaf; // [n_nodes]
    const double *branch;         // [n_nodes]
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a, InlineVec iv)
             const int m = ((slot ^ TIP_SWZ(row)) << 1) | (w & 1);
             jj = 4 * m + q;
          }
+         else if (a.layout == 2) jj = 4 * (w % 5) + w / 5;      // 20 states on 4x4x4 MFMAs: [code][state & 3][state >> 2], a lane's five states contiguous
          else jj = w;
          double s = 0;
          if (jj < n) {
