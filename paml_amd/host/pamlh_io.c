@@ -37,7 +37,7 @@ int pamlh_read_ctl(pamlh *p, const char *path)
    while (fgets(line, sizeof(line), f)) {
       char *c = line, *eq, *k, *v, *e;
       for (; *c; c++)
-         if (*c == '*' || *c == '#') { *c = 0; break; }
+         if (*c == '*') { *c = 0; break; }      /* '*' starts a comment (the reference's GetOptions, codeml.c:1722); '#' does not */
       eq = strchr(line, '=');
       if (!eq) continue;
       *eq = 0;
