@@ -224,6 +224,13 @@ __device__ __forceinline__ void tip_lds(const double *tab, int code, int q, int 
 // the accumulator tuple of row block jb = m >> 2, so MFMA results are partials with no copies, and the
 // B operand of k-block kb is x[kb >> 2][kb & 3].
 // ------------------------------------------------------------------------------------------------
+/* Waves per workgroup of the per-tree kernel = 16-pattern groups per tile.  8 (two per SIMD) or 12 (three per SIMD, <= 168
+ * VGPRs): with three, a SIMD's matrix pipe finds a wave with an MFMA ready more often, and the per-step synchronisation is
+ * spread over half as much again of arithmetic. */
+#ifndef JIT_WAVES
+#define JIT_WAVES 8
+#endif
+#define JIT_TP (JIT_WAVES * 16)
 #ifdef JIT_ABL_NOBAR
 #define JIT_SYNC() ((void)0)
 #else
@@ -375,7 +382,7 @@ __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, c
 // Partials of stack slots beyond the register arrays live in global scratch (trees with a deep partial stack): one coalesced
 // 512-byte store / load per register of the wave.  These are ordinary (compiler-visible) memory operations; the counted waits of
 // the operand ring stay valid because loads complete in order and a wait that also covers younger operations only waits longer.
-#define JIT_SPILL_PTR(K) (a.stack_scratch + (((long)blockIdx.x * a.stack_overflow_slots + (K)) * 8 + wave) * 1024 + lane)
+#define JIT_SPILL_PTR(K) (a.stack_scratch + (((long)blockIdx.x * a.stack_overflow_slots + (K)) * JIT_WAVES + wave) * 1024 + lane)
 __device__ __forceinline__ void jit_spill(const v4d (&y)[4], double *sp)
 {
 #pragma unroll
@@ -805,7 +812,7 @@ __device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5
    int roff = 0, zsel = JIT_ZB - 1;                                                                             \
    (void)hl; (void)n; (void)lnscale; (void)h0;                                                                  \
    if (work >= total_work) return;                                                                              \
-   for (int i = tid; i < a.n_pi * 64 && i < 256; i += 512) sPi[i] = a.pi[i];
+   for (int i = tid; i < a.n_pi * 64 && i < 256; i += JIT_WAVES * 64) sPi[i] = a.pi[i];
 #define JIT2_NEXT_SET()                                                                                          \
    has_next = work < total_work;                                                                                \
    if (has_next) {                                                                                              \
@@ -823,9 +830,14 @@ __device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5
 /* the next tile's code block -> the sZ buffer not in use (ZP dword pieces per thread) */
 #define JIT2_ISSUE_Z(ZP)                                                                                         \
    {                                                                                                            \
-      const __amdgpu_buffer_rsrc_t zr_ = make_rsrc(a.ztiles + (long)n_tile * ((ZP)*2048), (ZP)*2048);            \
-      _Pragma("unroll") for (int c_ = 0; c_ < (ZP); c_++)                                                       \
-         dma4(zr_, sZ + ((zsel ^ 1) & (JIT_ZB - 1)) * ((ZP)*2048) + (c_ * 8 + wave) * 256, lane * 4, (c_ * 8 + wave) * 256);      \
+      /* (ZP)*8 pieces of 256 bytes over JIT_WAVES waves; a wave without a piece in the last round still issues one (every  \
+       * wave must count the same vector-memory operations) against an empty descriptor, into the dump slot */          \
+      _Pragma("unroll") for (int c_ = 0; c_ < ((ZP)*8 + JIT_WAVES - 1) / JIT_WAVES; c_++) {                      \
+         const int pi_ = c_ * JIT_WAVES + wave;                                                                 \
+         const bool rz_ = pi_ < (ZP)*8;                                                                         \
+         dma4(make_rsrc(a.ztiles + (long)n_tile * ((ZP)*2048), rz_ ? (ZP)*2048 : 0),                            \
+              rz_ ? (const void *)(sZ + ((zsel ^ 1) & (JIT_ZB - 1)) * ((ZP)*2048) + pi_ * 256) : (const void *)sDump, lane * 4, pi_ * 256);  \
+      }                                                                                                         \
    }
 #define JIT2_BUF(J) (ring + (((J) + roff) & 3) * 4096)
 /* the column-60 table that travels with a P block (61 states): 512 bytes, fetched as one dword DMA piece per thread so
@@ -848,8 +860,8 @@ __device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5
 #endif
 #define JIT2_PIECE(SRC, J, C, REAL)                                                                                  \
    {                                                                                                                \
-      const int ch_ = (C)*8 + wave;                                                                                 \
-      const bool real_ = (REAL);                                                                                    \
+      const int ch_ = (C)*JIT_WAVES + wave;                                                                         \
+      const bool real_ = ch_ < 32 && (REAL);                                                                                    \
       dma16(make_rsrc((SRC), real_ ? 32768 : 0), real_ ? (const char *)JIT2_BUF(J) + ch_ * 1024 : (const char *)sDump, lane * 16,    \
             ch_ * 1024);                                                                                            \
    }
@@ -859,7 +871,7 @@ __device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5
 #define JIT2_PIECE_T(J, NODE, C) JIT2_PIECE(Ptip + (long)(NODE)*4096, J, C, JIT2_REAL_T)
 #define JIT2_PIECE_NP(J, NODE, C) JIT2_PIECE(nPint + (long)(NODE)*4096, J, C, JIT2_REAL_P)
 #define JIT2_PIECE_NT(J, NODE, C) JIT2_PIECE(nPtip + (long)(NODE)*4096, J, C, JIT2_REAL_T)
-#define JIT2_CODE(ZP, TIP) ((int)sZ[zsel * ((ZP)*2048) + (TIP)*128 + hw])
-#define JIT2_NCODE(ZP, TIP) ((int)sZ[((zsel ^ 1) & (JIT_ZB - 1)) * ((ZP)*2048) + (TIP)*128 + hw])
+#define JIT2_CODE(ZP, TIP) ((int)sZ[zsel * ((ZP)*2048) + (TIP)*JIT_TP + hw])
+#define JIT2_NCODE(ZP, TIP) ((int)sZ[((zsel ^ 1) & (JIT_ZB - 1)) * ((ZP)*2048) + (TIP)*JIT_TP + hw])
 
 }  // namespace paml_amd

@@ -144,6 +144,7 @@ inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global
 // Environment switches, read once when the engine is created.
 struct EnvCfg {
    bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false, no_m20 = false;
+   int jit_waves = 0;
    std::string jit_dump, prof_ops;
    int prof_tid = 0;
    void read()
@@ -156,7 +157,8 @@ struct EnvCfg {
       no_fused = getenv("PAML_AMD_NO_FUSED") != nullptr;
       mfma4 = getenv("PAML_AMD_MFMA4") != nullptr;
       no_m20 = getenv("PAML_AMD_NO_M20") != nullptr;
-      tail = getenv("PAML_AMD_TAIL") != nullptr;        // experiment: the last workgroup forms the total instead of a stage-2 launch
+      tail = getenv("PAML_AMD_TAIL") != nullptr;
+      if (const char *v = getenv("PAML_AMD_JIT_WAVES")) jit_waves = atoi(v);        // experiment: the last workgroup forms the total instead of a stage-2 launch
       if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
       if (const char *v = getenv("PAML_AMD_PROF_OPS")) prof_ops = v;
       if (const char *v = getenv("PAML_AMD_PROF_TID")) prof_tid = atoi(v);
@@ -387,10 +389,10 @@ int build_tiles(paml_amd_engine *e)
       for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += tf) tfull.push_back(make_int2(g, h));
    e->n_tiles_full = (int)tfull.size();
    HIPCHK(upload(e->d_tiles_full, tfull.data(), tfull.size(), e->stream));
-   if (e->kk == KK_MFMA64 && e->tile_patt == 128 && e->d_z.p && e->d_weights.p) {   // code blocks of the specialised kernel
-      e->zt_bytes = jit_zpieces(e->n_tips) * 2048;
+   if (e->kk == KK_MFMA64 && e->tile_patt >= 128 && e->d_z.p && e->d_weights.p) {   // code blocks of the specialised kernel
+      e->zt_bytes = jit_zpieces(e->n_tips, e->tile_patt) * 2048;
       HIPCHK(e->d_ztiles.ensure((size_t)e->n_tiles * e->zt_bytes));
-      hipLaunchKernelGGL(ztile_kernel, dim3(e->n_tiles), dim3(128), 0, e->stream, e->d_tiles.p, e->d_gene_off.p, e->d_z.p, (long)e->n_patt,
+      hipLaunchKernelGGL(ztile_kernel, dim3(e->n_tiles), dim3(e->tile_patt), 0, e->stream, e->d_tiles.p, e->d_gene_off.p, e->d_z.p, (long)e->n_patt,
                          e->d_weights.p, e->n_tips, e->zt_bytes, e->d_ztiles.p);
    }
    HIPCHK(hipStreamSynchronize(e->stream));
@@ -588,11 +590,15 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       for (const Op &o : e->prog.ops)
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
       bool jit_ok = false;
-      if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi)) {
-         const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips);
+      // waves per workgroup of the per-tree kernel: 12 (three per SIMD, 192 patterns per tile) for the full-size models when the tile's
+      // code blocks leave room in LDS, else 8; PAML_AMD_JIT_WAVES overrides
+      int jw = (n > 32 && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, 192) && jit_zbuffers(e->n_tips, 192) == 2) ? 12 : 8;
+      if (e->env.jit_waves == 8 || e->env.jit_waves == 12) jw = e->env.jit_waves;
+      if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16)) {
+         const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "w" + std::to_string(jw) + ":" + jit_program_key(e->prog, e->n_tips);
          const bool background = e->prog.ops.size() > 120 &&      /* (roughly: more than 60 taxa, more than 3 s of compilation) */ !e->jit_forced && !e->env.jit_sync && !(e->jit.fn && e->jit.key == key);
          if (!background) {
-            int r = ensure_jit(e, key, [&]() { return jit_generate(e->prog, e->n_tips, n, e->n_codes); }, &jit_ok);
+            int r = ensure_jit(e, key, [&]() { return jit_generate(e->prog, e->n_tips, n, e->n_codes, jw); }, &jit_ok);
             if (r) return r;
          }
          else {
@@ -617,7 +623,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
                e->jit_job.reset(new paml_amd_engine::JitJob());
                job = e->jit_job.get();
                job->key = key;
-               job->src = jit_generate(e->prog, e->n_tips, n, e->n_codes);
+               job->src = jit_generate(e->prog, e->n_tips, n, e->n_codes, jw);
                job->state.store(1);
                job->th = std::thread([job]() { job->state.store(jit_compile_code(job->src, &job->code, &job->log) == 0 ? 2 : 3); });
             }
@@ -625,9 +631,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
       e->use_jit = jit_ok;
       const bool big_tiles = jit_ok || lean;
-      if (big_tiles != e->mfma_dma) {
+      const int want_waves = jit_ok ? jw : (lean ? DMA_WAVES : GATHER_WAVES);
+      if (big_tiles != e->mfma_dma || want_waves != e->mfma_waves) {
          e->mfma_dma = big_tiles;
-         e->mfma_waves = big_tiles ? DMA_WAVES : GATHER_WAVES;
+         e->mfma_waves = want_waves;
          e->tile_patt = e->mfma_waves * 16;
          int r = build_tiles(e);
          if (r) return r;
@@ -769,7 +776,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       if (e->use_jit) {
          void *params[] = {&pr};
          const int grid = std::min(n_blocks, e->n_cu);     // persistent: one 130 KB-LDS workgroup per CU walks the tiles
-         HIPCHK(hipModuleLaunchKernel(e->jit.fn, grid, 1, 1, 512, 1, 1, 0, e->stream, params, nullptr));
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, grid, 1, 1, e->mfma_waves * 64, 1, 1, 0, e->stream, params, nullptr));
       }
       else if (use_dma) {
          const size_t lds = (size_t)4 * 4096 * sizeof(double) + (size_t)e->n_tips * 128;
@@ -1999,8 +2006,10 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
       text = jit_generate_valu(p, n_states);
    }
    else {
-      if (!jit_supported(p, n_tips, 61)) return PAML_AMD_EUNSUPPORTED;
-      text = jit_generate(p, n_tips);
+      int jw = (jit_supported(p, n_tips, 61, 1, 6, 192) && jit_zbuffers(n_tips, 192) == 2) ? 12 : 8;      // the engine's rule for full-size models
+      if (const char *v = getenv("PAML_AMD_JIT_WAVES")) if (atoi(v) == 8 || atoi(v) == 12) jw = atoi(v);
+      if (!jit_supported(p, n_tips, 61, 1, 6, jw * 16)) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate(p, n_tips, 61, 64, jw);
    }
    int rc = (int)text.size();
    if (compile) {
@@ -2046,8 +2055,10 @@ int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_p
                                                                                : jit_generate_valu_fused(p, n_states, n_tips, n_codes, K, chunk);
    }
    else {
-      if (!jit_supported(p, n_tips, n_codes, 1)) return PAML_AMD_EUNSUPPORTED;
-      text = jit_generate(p, n_tips, n_states, n_codes);
+      int jw = (n_states > 32 && jit_supported(p, n_tips, n_codes, 1, 6, 192) && jit_zbuffers(n_tips, 192) == 2) ? 12 : 8;
+      if (const char *v = getenv("PAML_AMD_JIT_WAVES")) if (atoi(v) == 8 || atoi(v) == 12) jw = atoi(v);
+      if (!jit_supported(p, n_tips, n_codes, 1, 6, jw * 16)) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate(p, n_tips, n_states, n_codes, jw);
    }
    std::vector<char> code;
    std::string log;

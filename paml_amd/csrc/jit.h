@@ -45,16 +45,16 @@ constexpr int JIT_REG_SLOTS = 4;
 constexpr int JIT_SCRATCH_BASE = 2;      // = MFMA_RS (checked in engine.hip): scratch slot k holds stack slot k + 2
 
 // Which programs the generator covers.
-inline int jit_zpieces(int n_tips) { return ((n_tips + 1) * 128 + 2047) / 2048; }   // 2 KB DMA pieces of a tile's code block
+inline int jit_zpieces(int n_tips, int tp = 128) { return ((n_tips + 1) * tp + 2047) / 2048; }   // 2 KB units of a tile's code block (tp patterns per tile)
 
 // LDS: ring, zb code blocks, pi, column tables, dump slot.  Two code blocks fit up to 95 tips, one up to 207.
-inline bool jit_lds_fits(int n_tips, int zb) { return 4 * 32768 + zb * jit_zpieces(n_tips) * 2048 + 4 * 64 * 8 + (4 * 64 + 32) * 8 + 1024 <= 160 * 1024; }
-inline int jit_zbuffers(int n_tips) { return jit_lds_fits(n_tips, 2) ? 2 : 1; }
+inline bool jit_lds_fits(int n_tips, int zb, int tp = 128) { return 4 * 32768 + zb * jit_zpieces(n_tips, tp) * 2048 + 4 * 64 * 8 + (4 * 64 + 32) * 8 + 1024 <= 160 * 1024; }
+inline int jit_zbuffers(int n_tips, int tp = 128) { return jit_lds_fits(n_tips, 2, tp) ? 2 : 1; }
 
-inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6)
+inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6, int tp = 128)
 {
    if (n_codes > 64 || p.ops.size() > 1000 || n_pi > 4) return false;
-   if (!jit_lds_fits(n_tips, jit_zbuffers(n_tips))) return false;
+   if (!jit_lds_fits(n_tips, jit_zbuffers(n_tips, tp), tp)) return false;
    if (p.stream.size() / 2 < 4) return false;                       // trees this small go to the interpreter
    for (const Op &o : p.ops)
       if (o.code == OP_STORE || o.code == OP_LOAD) return false;   // keep-partials layouts stay with the interpreter
@@ -80,11 +80,12 @@ inline std::string jit_program_key(const Program &p, int n_tips)
 // own first cherry was done that way by its predecessor; the first tile's is peeled in front of the loop).
 // `first` = operand blocks of a tile already requested when the loop body starts (the body's last step leaves the
 // same number of the next tile's in flight; *first_out reports it so that jit_generate can make the two agree).
-inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states, int n_codes, int first, int *first_out)
+inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states, int n_codes, int first, int *first_out, int waves = 8)
 {
    std::ostringstream s;
    const int nblk = (int)p.stream.size() / 2;
-   const int ZP = jit_zpieces(n_tips);
+   const int TP = waves * 16;
+   const int ZP = jit_zpieces(n_tips, TP), ZR = (ZP * 8 + waves - 1) / waves;      // code block: 2 KB units; DMA rounds per wave
    const size_t nops = p.ops.size();
    // states beyond n are zero padding: only RB row blocks and KB k-blocks of every P take part (4 and 16 at 61 states)
    const int RB = (n_states + 15) / 16, KB = (n_states + 3) / 4, KB2 = (KB + 1) / 2, NPc = KB2;   // NPc: 16-byte pieces per tip-table row
@@ -105,19 +106,22 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       if (p.ops[i].code == OP_SET_TIP || p.ops[i].code == OP_MUL_TIP || p.ops[i].code == OP_SET_TIP2 || p.ops[i].code == OP_MUL_TIP2)
          tail_blocks = true;
    // one code block only (large trees): it is replaced between tiles, so nothing of the next tile can start early
-   const bool zsingle = jit_zbuffers(n_tips) == 1;
+   const bool zsingle = jit_zbuffers(n_tips, TP) == 1;
    const bool peel = fuse_tips && !getenv("PAML_AMD_JIT_NOPEEL") && nops > 2 && p.ops[0].code == OP_SET_TIP2 && last_mm > 1 &&
                      p.ops[1].code != OP_MUL_TIP && p.ops[1].code != OP_MUL_TIP2 && !tail_blocks && !zsingle;
 
    // chunks of a tip table that hold codes of this data set (two codes per 1 KB chunk)
    const int TCH = (n_codes + 1) / 2 >= 31 ? 32 : (n_codes + 1) / 2;
-   const int P_ROUNDS = (KB2 + 1) / 2, T_ROUNDS = (TCH + 7) / 8;
-   s << "#define JIT_KB2 " << KB2 << "\n#define JIT_RB " << RB << "\n#define JIT_TCH " << TCH << "\n";
+   // DMA rounds per block: a P has chunks pair * 4 + row block (< KB2 * 4 used), a tip table TCH chunks; `waves` chunks per round
+   const int P_ROUNDS = (KB2 * 4 + waves - 1) / waves, T_ROUNDS = (TCH + waves - 1) / waves;
+   s << "#define JIT_KB2 " << KB2 << "\n#define JIT_RB " << RB << "\n#define JIT_TCH " << TCH << "\n#define JIT_WAVES " << waves << "\n";
    if (getenv("PAML_AMD_JIT_ABL_NOBAR")) s << "#define JIT_ABL_NOBAR 1\n";      // timing experiment: no workgroup barriers (results are garbage)
+   const char *abl_skew = getenv("PAML_AMD_JIT_ABL_SKEW");                       // ... and waves 4-7 start this many x 64 cycles late
    if (zsingle) s << "#define JIT_ZB 1\n";
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
-   s << "extern \"C\" __global__ __launch_bounds__(512, 2) void prune_jit(PruneArgs a)\n{\n";
+   s << "extern \"C\" __global__ __launch_bounds__(" << waves * 64 << ", " << waves / 4 << ") void prune_jit(PruneArgs a)\n{\n";
    s << "   JIT2_PROLOGUE(" << ZP << ")\n";
+   if (abl_skew) s << "   if (wave >= 4) { for (int i_ = 0; i_ < " << atoi(abl_skew) << "; i_++) __builtin_amdgcn_s_sleep(1); }\n";
    s << "   roff = " << ((4 - nblk % 4) & 3) << ";\n";
 
    // ---- static bookkeeping of what is in flight (per thread: pieces = vector-memory instructions) -------------------
@@ -160,7 +164,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       s << "   JIT_SYNC();\n";
       if (z_pending) {
          s << "   JIT2_ISSUE_Z(" << ZP << ")\n";
-         fl.push_back({-1, ZP});
+         fl.push_back({-1, ZR});
          z_pending = false;
       }
       const int upto = consumed + 4;
@@ -203,7 +207,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    for (int i = 0; i < NA; i++) s << "   v4d A" << i << "[4];\n";
    if (peel) s << "   v4d AS[4];\n";       // the first cherry of a tile, produced under the predecessor's last matmul
    s << "   JIT2_NEXT_SET()\n   JIT2_ISSUE_Z(" << ZP << ")\n";
-   fl.push_back({-1, ZP});
+   fl.push_back({-1, ZR});
    issued = nblk;                           // numbered as the blocks after the (empty) predecessor's
    for (int i = 0; i < first; i++) issue_now();
    if (peel) {
@@ -349,7 +353,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    // programs whose steps never came by a barrier after the tile switch (no operand blocks): request the codes here
    if (z_pending) {
       s << "   __syncthreads();\n   JIT2_ISSUE_Z(" << ZP << ")\n";
-      fl.push_back({-1, ZP});
+      fl.push_back({-1, ZR});
    }
    if (zsingle) {      // all waves are done with this tile's codes: fetch the next tile's over them, and wait (once per tile)
       s << "   __syncthreads();\n   JIT2_ISSUE_Z(" << ZP << ")\n   JIT_WAIT(0); __syncthreads();\n";
@@ -360,13 +364,13 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    return s.str();
 }
 
-inline std::string jit_generate(const Program &p, int n_tips, int n_states = 61, int n_codes = 64)
+inline std::string jit_generate(const Program &p, int n_tips, int n_states = 61, int n_codes = 64, int waves = 8)
 {
    int first = 3, got = 3;
-   std::string src = jit_generate_impl(p, n_tips, n_states, n_codes, first, &got);
+   std::string src = jit_generate_impl(p, n_tips, n_states, n_codes, first, &got, waves);
    if (got != first) {
       first = got;
-      src = jit_generate_impl(p, n_tips, n_states, n_codes, first, &got);
+      src = jit_generate_impl(p, n_tips, n_states, n_codes, first, &got, waves);
    }
    return got == first ? src : std::string("#error \"jit schedule does not close\"\n");
 }

@@ -964,15 +964,15 @@ __device__ __forceinline__ double pattern_lnf(const ReduceArgs &a, int h)
 
 // Tile blocks of the specialised kernel (PruneArgs::ztiles): per 128-pattern tile the tip codes of its patterns, one
 // 128-byte row per tip, then a row of weight > 0 flags; patterns past the tile's gene read as code 0 / flag 0.
-__global__ __launch_bounds__(128) void ztile_kernel(const int2 *tiles, const int *gene_off, const unsigned char *z, long z_stride,
+__global__ __launch_bounds__(256) void ztile_kernel(const int2 *tiles, const int *gene_off, const unsigned char *z, long z_stride,
                                                     const double *weights, int n_tips, int zt_bytes, unsigned char *out)
 {
-   const int t = blockIdx.x, i = threadIdx.x;
+   const int t = blockIdx.x, i = threadIdx.x, tp = blockDim.x;      // one thread per pattern of the tile (128 or 192)
    const int g = tiles[t].x, h = tiles[t].y + i, hend = gene_off[g + 1];
    unsigned char *o = out + (long)t * zt_bytes;
-   for (int tip = 0; tip < n_tips; tip++) o[tip * 128 + i] = h < hend ? z[tip * z_stride + h] : (unsigned char)0;
-   o[n_tips * 128 + i] = (h < hend && weights[h] > 0) ? 1 : 0;
-   for (int k = (n_tips + 1) * 128 + i; k < zt_bytes; k += 128) o[k] = 0;
+   for (int tip = 0; tip < n_tips; tip++) o[tip * tp + i] = h < hend ? z[tip * z_stride + h] : (unsigned char)0;
+   o[n_tips * tp + i] = (h < hend && weights[h] > 0) ? 1 : 0;
+   for (int k = (n_tips + 1) * tp + i; k < zt_bytes; k += tp) o[k] = 0;
 }
 
 // Tip codes pattern-major for the fused one-pattern-per-lane kernels: row h = zw dwords, byte t = code of tip t.

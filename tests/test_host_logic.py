@@ -342,9 +342,10 @@ def test_jit_schedule_checker_catches_broken_schedules(lib_path):
     from paml_amd.problem import balanced_tree
     src = engine.debug_jit(balanced_tree(16), compile=False)
     _Sched(src).check()
-    i = src.index("JIT_WAIT(8)")
-    with pytest.raises(AssertionError):
-        _Sched(src[:i] + "JIT_WAIT(12)" + src[i + 11:]).check()
+    m = next(m for m in re.finditer(r"JIT_WAIT\((\d+)\)", src[src.index("for (;; ptile = 0)"):]) if int(m.group(1)) >= 3)      # a wait in the loop that leaves pieces in flight
+    i, n = src.index("for (;; ptile = 0)") + m.start(), int(m.group(1))
+    with pytest.raises(AssertionError):      # ... relaxed by more than a block's pieces
+        _Sched(src[:i] + "JIT_WAIT(%d)" % (n + 5) + src[i + len(m.group(0)):]).check()
     j = src.index("JIT_SYNC();", src.index("for (;; ptile = 0)"))
     k = src.index("JIT_SYNC();", j + 1)
     with pytest.raises(AssertionError):
