@@ -590,10 +590,11 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       for (const Op &o : e->prog.ops)
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
       bool jit_ok = false;
-      // waves per workgroup of the per-tree kernel: 12 (three per SIMD, 192 patterns per tile) for the full-size models when the tile's
-      // code blocks leave room in LDS, else 8; PAML_AMD_JIT_WAVES overrides
-      int jw = (n > 32 && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, 192) && jit_zbuffers(e->n_tips, 192) == 2) ? 12 : 8;
-      if (e->env.jit_waves == 8 || e->env.jit_waves == 12) jw = e->env.jit_waves;
+      // waves per workgroup of the per-tree kernel: 8 (two per SIMD, 128 patterns per tile).  PAML_AMD_JIT_WAVES=12 builds the
+      // three-per-SIMD variant (192-pattern tiles, <= 168 VGPRs): measured SLOWER on MI355X (1.659 against 1.622 ms at C4, 4.73 against
+      // 4.63 ms with three classes — 40 spilled dwords and a third more LDS / DMA traffic per step), kept as a generator parameter
+      int jw = 8;
+      if (e->env.jit_waves == 12 && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, 192) && jit_zbuffers(e->n_tips, 192) == 2) jw = 12;
       if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16)) {
          const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "w" + std::to_string(jw) + ":" + jit_program_key(e->prog, e->n_tips);
          const bool background = e->prog.ops.size() > 120 &&      /* (roughly: more than 60 taxa, more than 3 s of compilation) */ !e->jit_forced && !e->env.jit_sync && !(e->jit.fn && e->jit.key == key);
@@ -2006,8 +2007,8 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
       text = jit_generate_valu(p, n_states);
    }
    else {
-      int jw = (jit_supported(p, n_tips, 61, 1, 6, 192) && jit_zbuffers(n_tips, 192) == 2) ? 12 : 8;      // the engine's rule for full-size models
-      if (const char *v = getenv("PAML_AMD_JIT_WAVES")) if (atoi(v) == 8 || atoi(v) == 12) jw = atoi(v);
+      int jw = 8;
+      if (const char *v = getenv("PAML_AMD_JIT_WAVES")) if (atoi(v) == 12 && jit_zbuffers(n_tips, 192) == 2) jw = 12;
       if (!jit_supported(p, n_tips, 61, 1, 6, jw * 16)) return PAML_AMD_EUNSUPPORTED;
       text = jit_generate(p, n_tips, 61, 64, jw);
    }
@@ -2055,8 +2056,8 @@ int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_p
                                                                                : jit_generate_valu_fused(p, n_states, n_tips, n_codes, K, chunk);
    }
    else {
-      int jw = (n_states > 32 && jit_supported(p, n_tips, n_codes, 1, 6, 192) && jit_zbuffers(n_tips, 192) == 2) ? 12 : 8;
-      if (const char *v = getenv("PAML_AMD_JIT_WAVES")) if (atoi(v) == 8 || atoi(v) == 12) jw = atoi(v);
+      int jw = 8;
+      if (const char *v = getenv("PAML_AMD_JIT_WAVES")) if (atoi(v) == 12 && jit_zbuffers(n_tips, 192) == 2) jw = 12;
       if (!jit_supported(p, n_tips, n_codes, 1, 6, jw * 16)) return PAML_AMD_EUNSUPPORTED;
       text = jit_generate(p, n_tips, n_states, n_codes, jw);
    }
