@@ -49,6 +49,7 @@ struct pamlh {
    int *gene_eigen_of;     /* [ngene][K][n_labels] when ngene > 1 */
    unsigned char *chara_map;
    double fb3x4[12], fb4[4], fcodon[64], pi_data[64];
+   double fb61[64];      /* codon frequencies implied by the amino-acid frequencies (aa models 5, 6) */
    double aaS[400], aapi_file[20];
    /* tree */
    int nnode, root, nbranch;
@@ -67,6 +68,9 @@ struct pamlh {
    double qfactor[64];     /* branch-site / clade models: time scale of (class, branch type), [K][n_labels] */
    int use_qf;
    double ns_mr;           /* NSsites: mean rate at the mean omega = 1 / Qfactor_NS of the last pamlh_set_x */
+   /* aaDist = 7 (AAClasses, codeml.c:4079 GetOmegaAA): dN/dS classes of amino-acid pairs, from OmegaAA.dat beside the ctl */
+   int aadist, n_omega_type;
+   signed char omega_class[26][26];   /* by amino-acid letters: class of the pair, -1 = no one-step change under the code */
    /* optimiser state (pamlh_opt.c) */
    unsigned char *frozen;  /* NULL, or [np]: parameters pamlh_optimize leaves where they are (minB holds the branch lengths) */
    int opt_lean;           /* 1: fewer trial points per line search, no curvature pre-pass (the inner ming2 of minB) */

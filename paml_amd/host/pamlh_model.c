@@ -220,6 +220,41 @@ static void resolve(const pamlh *p, const char *name, char *out, size_t cap)
    else snprintf(out, cap, "%s/%s", p->dir, name);
 }
 
+static int read_omega_aa(pamlh *p);
+
+static int aa_of_codon(const pamlh *p, int c64) { static const char AAS[] = "ARNDCQEGHILKMFPSTWYV"; return (int)(strchr(AAS, p->code[c64]) - AAS); }
+
+/* codon frequencies from amino-acid frequencies, synonymous codons sharing equally (AA2Codonf codeml.c:3922) */
+static void aa_to_codon_freqs(const pamlh *p, const double *faa, double *fc)
+{
+   int nsyn[20] = {0}, c, m = 0;
+   for (c = 0; c < 64; c++) if (p->code[c] != '*') nsyn[aa_of_codon(p, c)]++;
+   for (c = 0; c < 64; c++) if (p->code[c] != '*') { const int a = aa_of_codon(p, c); fc[m++] = faa[a] / nsyn[a]; }
+}
+
+/* model 5 (FromCodon0): from here on the data are codon data — every amino acid is the ambiguity code of its codons
+ * (SetMapAmbiguity(.., 1) treesub.c:1274-1283, codeml.c:544-556), the frequencies those of aa_to_codon_freqs.  The reference
+ * gives '?' / '-' an empty set there (such sites must be removed with cleandata = 1); here they stand for every codon. */
+static void aa_as_codon_sets(pamlh *p)
+{
+   int from61[64], n = 0, c, a, k;
+   size_t h;
+   for (c = 0; c < 64; c++) if (p->code[c] != '*') from61[n++] = c;
+   for (h = 0; h < (size_t)p->ns * p->npatt; h++) p->z[h] = (unsigned char)(n + (p->z[h] < 20 ? p->z[h] : 20));
+   free(p->n_chara); free(p->chara_map);
+   p->n_codes = n + 21;
+   p->n_chara = (int *)calloc(p->n_codes, sizeof(int));
+   p->chara_map = (unsigned char *)calloc((size_t)p->n_codes * n, 1);
+   for (c = 0; c < n; c++) { p->n_chara[c] = 1; p->chara_map[(size_t)c * n] = (unsigned char)c; }
+   for (a = 0; a < 20; a++)
+      for (c = 0; c < n; c++) if (aa_of_codon(p, from61[c]) == a) p->chara_map[(size_t)(n + a) * n + p->n_chara[n + a]++] = (unsigned char)c;
+   for (k = 0; k < n; k++) p->chara_map[(size_t)(n + 20) * n + k] = (unsigned char)k;
+   p->n_chara[n + 20] = n;
+   p->seqtype = 1; p->n = n; p->cleandata = 0; p->mg = 0;
+   memcpy(p->pi_data, p->fb61, n * sizeof(double));
+   memcpy(p->piG[0], p->fb61, n * sizeof(double));
+}
+
 int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err, int errcap)
 {
    pamlh *p = (pamlh *)calloc(1, sizeof(pamlh));
@@ -286,11 +321,30 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->codonfreq >= 4) { p->mg = 1; p->codonfreq -= 3; }
       for (p->n = 0, rc = 0; rc < 64; rc++) p->n += p->code[rc] != '*';
       rc = 0;
+      p->aadist = (int)pamlh_optd(p, "aaDist", 0);
+      if (p->aadist != 0 && p->aadist != 7) { rc = pamlh_fail(p, "aaDist = %d is not supported (0, or 7 = AAClasses)", p->aadist); goto bad; }
+      if (p->aadist == 7) {
+         if (p->nssites || (p->model != 0 && p->model != 2) || p->mg) { rc = pamlh_fail(p, "aaDist = 7 goes with NSsites = 0, model 0 or 2 and CodonFreq <= 3"); goto bad; }
+         if ((rc = read_omega_aa(p))) goto bad;
+      }
    }
    else if (p->seqtype == 2) {
       p->n = 20; p->aa_model = p->model;
-      if (p->aa_model < 0 || p->aa_model > 3) { rc = pamlh_fail(p, "amino-acid model %d is not supported", p->aa_model); goto bad; }
-      if (p->aa_model >= 2) {
+      if ((p->aa_model < 0 || p->aa_model > 3) && p->aa_model != 5 && p->aa_model != 6) { rc = pamlh_fail(p, "amino-acid model %d is not supported", p->aa_model); goto bad; }
+      if (p->aa_model >= 5) {
+         /* codon-based amino-acid models (Yang, Nielsen & Hasegawa 1998): 6 (FromCodon) a 20-state chain whose rates are the
+          * codon chain's aggregated over synonymous codons, 5 (FromCodon0) the codon chain itself with every amino acid read as
+          * the set of its codons (codeml.c:1513-1531, 498-503, 544-556) */
+         if (p->icode != 0 && p->icode != 1) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0: universal, 1: vertebrate mt)", p->icode); goto bad; }
+         if (p->nssites) { rc = pamlh_fail(p, "use NSsites = 0 for amino acids"); goto bad; }
+         if ((int)pamlh_optd(p, "aaDist", 0)) { rc = pamlh_fail(p, "aaDist with the codon-based amino-acid models is not supported"); goto bad; }
+         if (p->aa_model == 6 && p->fix_omega) { rc = pamlh_fail(p, "fix_omega = 1?  omega is not estimable!"); goto bad; }
+         if (p->clock) { rc = pamlh_fail(p, "model and clock do not work together"); goto bad; }
+         strcpy(p->code, GENETIC_CODES[p->icode]);
+         p->codonfreq = 0;       /* "CodonFreq=0 reset": the codon frequencies come from the amino-acid frequencies */
+         p->model = 0;
+      }
+      if (p->aa_model == 2 || p->aa_model == 3) {
          if (!(v = pamlh_opt(p, "aaRatefile")) || !*v) { rc = pamlh_fail(p, "empirical aa model without aaRatefile"); goto bad; }
          resolve(p, v, p->aaratefile, sizeof(p->aaratefile));
          if ((rc = read_aa_ratefile(p))) goto bad;
@@ -331,6 +385,11 @@ genes_ok:
    }
    if (p->seqtype == 1) freqs_codon(p);
    else freqs_base_aa(p);
+   if (p->seqtype == 2 && p->aa_model >= 5) {
+      if (p->ngene > 1) { rc = pamlh_fail(p, "the codon-based amino-acid models take one gene"); goto bad; }
+      aa_to_codon_freqs(p, p->pi_data, p->fb61);
+      if (p->aa_model == 5) aa_as_codon_sets(p);
+   }
    if (p->seqtype == 0 && p->model == T92) {      /* one GC-content parameter: T = A, C = G (InitializeBaseAA treesub.c:1684-1691) */
       int g;
       p->pi_data[0] = p->pi_data[2] = (p->pi_data[0] + p->pi_data[2]) / 2; p->pi_data[1] = p->pi_data[3] = (p->pi_data[1] + p->pi_data[3]) / 2;
@@ -353,7 +412,8 @@ genes_ok:
       const int rep = p->mgene >= 3 ? p->ngene : 1;
       if (p->seqtype == 1) {
          nr += !p->fix_kappa;
-         if (p->nssites == 0 && p->model == 2) nr += p->n_omega;      /* branch model: one omega per branch label (codeml.c:2170-2183) */
+         if (p->aadist == 7) nr += p->n_omega_type * (p->model == 2 ? p->n_omega : 1);      /* AAClasses: a set of class omegas (per branch label) */
+         else if (p->nssites == 0 && p->model == 2) nr += p->n_omega;      /* branch model: one omega per branch label (codeml.c:2170-2183) */
          else if (p->model == 2 && p->nssites == 2) nr += 3 + !p->fix_omega;      /* branch-site A: p0 p1 w0 [w2] (codeml.c:2197-2221) */
          else if (p->model == 2 && p->nssites == 3) nr += 5;                      /* branch-site B: p0 p1 w0 w1 w2 */
          else if (p->model == 3) nr += 2 + (p->nssites == 3 ? 2 : 1) + p->n_omega - (p->fix_omega != 0);   /* clade C / D (codeml.c:2222-2233) */
@@ -369,6 +429,7 @@ genes_ok:
          else if (p->nssites == 7) nr += 2;
          else if (p->nssites == 8) nr += 3 + !p->fix_omega;
       }
+      else if (p->seqtype == 2 && p->aa_model == 6) nr += !p->fix_kappa;
       else if (p->seqtype == 0) {
          if (p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) nr += !p->fix_kappa;
          else if (p->model == TN93) nr += 2 * !p->fix_kappa;
@@ -492,7 +553,8 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
    }
    if (p->seqtype == 1) {
       if (!p->fix_kappa) x[k++] = p->kappa0;
-      if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) x[k++] = p->omega0; }
+      if (p->aadist == 7) { for (i = 0; i < p->n_omega_type * (p->model == 2 ? p->n_omega : 1); i++) x[k++] = 0.15 + 0.02 * (i % 4); }
+      else if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) x[k++] = p->omega0; }
       else if (p->model == 2 && p->nssites) {      /* branch-site A / B: p0 p1 w0 [w1] [w2] */
          x[k++] = 0.6; x[k++] = 0.2; x[k++] = 0.25;
          if (p->nssites == 3) x[k++] = 0.8;
@@ -521,7 +583,8 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       else if (p->nssites == 8) { x[k++] = 0.9; x[k++] = 0.5; x[k++] = 1.5; if (!p->fix_omega) x[k++] = 2.5; }
    }
    else if (p->seqtype == 0) {
-      if ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) x[k++] = p->kappa0;
+      if (p->seqtype == 2) { if (p->aa_model == 6 && !p->fix_kappa) x[k++] = p->kappa0; }
+      else if ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) x[k++] = p->kappa0;
       else if (p->model == TN93 && !p->fix_kappa) { x[k++] = p->kappa0; x[k++] = p->kappa0; }
       else if (p->model == REV) { for (i = 0; i < 5; i++) x[k++] = 1; }
       else if (p->model == UNREST) { for (i = 0; i < 11; i++) x[k++] = (i == 0 || i == 3 || i == 8) ? 0.9 : 0.5; }
@@ -559,10 +622,48 @@ static void set_eig_uvroot(pamlh *p, int i, const double *Q, const double *pi, d
    for (k = 0; k < n; k++) e->Root[k] /= scale;
 }
 
+/* aaDist = 7 (AAClasses): OmegaAA.dat beside the control file — "nclass", then for classes 1 .. nclass-1 a line "k: XY XY ...",
+ * every other pair that can change in one step being class 0 (GetOmegaAA codeml.c:4079-4150; pairs that cannot change in one
+ * step under the genetic code are ignored, a pair listed twice is an error). */
+static int read_omega_aa(pamlh *p)
+{
+   char path[1200], line[4096];
+   FILE *f;
+   int i, j, k, c1, c2, ncls = 0, cls;
+   memset(p->omega_class, -1, sizeof(p->omega_class));
+   for (c1 = 0; c1 < 64; c1++)            /* AA1STEP: amino acids joined by a single nucleotide change between sense codons */
+      for (c2 = 0; c2 < 64; c2++) {
+         int nd = (c1 / 16 != c2 / 16) + ((c1 / 4) % 4 != (c2 / 4) % 4) + (c1 % 4 != c2 % 4);
+         if (nd == 1 && p->code[c1] != '*' && p->code[c2] != '*' && p->code[c1] != p->code[c2])
+            p->omega_class[p->code[c1] - 'A'][p->code[c2] - 'A'] = 0;
+      }
+   snprintf(path, sizeof(path), "%s/OmegaAA.dat", p->dir);
+   if (!(f = fopen(path, "r"))) return pamlh_fail(p, "aaDist = 7 needs OmegaAA.dat beside the control file (%s)", path);
+   if (fscanf(f, "%d", &ncls) != 1 || ncls < 1 || ncls > 64) { fclose(f); return pamlh_fail(p, "OmegaAA.dat: bad number of classes"); }
+   for (cls = 1; cls < ncls; cls++) {
+      if (fscanf(f, "%d", &k) != 1 || k != cls || fgetc(f) != ':' || !fgets(line, sizeof(line), f)) { fclose(f); return pamlh_fail(p, "OmegaAA.dat: expected \"%d: pairs\"", cls); }
+      for (i = 0; line[i] && line[i] != '\n'; i++) {
+         if (!isalpha((unsigned char)line[i])) continue;
+         j = i + 1;
+         if (!isalpha((unsigned char)line[j])) { fclose(f); return pamlh_fail(p, "OmegaAA.dat: amino acids come in pairs"); }
+         c1 = toupper((unsigned char)line[i]) - 'A'; c2 = toupper((unsigned char)line[j]) - 'A';
+         i = j;
+         if (p->omega_class[c1][c2] == -1) continue;      /* cannot change in one step: ignored, as the reference does */
+         if (p->omega_class[c1][c2] > 0) { fclose(f); return pamlh_fail(p, "OmegaAA.dat: pair %c%c listed twice", c1 + 'A', c2 + 'A'); }
+         p->omega_class[c1][c2] = p->omega_class[c2][c1] = (signed char)cls;
+      }
+   }
+   fclose(f);
+   p->n_omega_type = ncls;
+   return 0;
+}
+
 /* codon Q for (kappa, omega) and its mean rate (eigenQcodon codeml.c:3274-3315) */
-static double codon_q_pi(const pamlh *p, const double *pi, double kappa, double omega, double *Q);
-static double codon_q(const pamlh *p, double kappa, double omega, double *Q) { return codon_q_pi(p, p->pi, kappa, omega, Q); }
-static double codon_q_pi(const pamlh *p, const double *pi, double kappa, double omega, double *Q)
+static double codon_q_cls(const pamlh *p, const double *pi, double kappa, double omega, const double *wcls, double *Q);
+static double codon_q_pi(const pamlh *p, const double *pi, double kappa, double omega, double *Q) { return codon_q_cls(p, pi, kappa, omega, NULL, Q); }
+static double codon_q(const pamlh *p, double kappa, double omega, double *Q) { return codon_q_cls(p, p->pi, kappa, omega, NULL, Q); }
+/* wcls != NULL (aaDist = 7): omega of a nonsynonymous change = wcls[class of its amino-acid pair] (GetOmega codeml.c:3020) */
+static double codon_q_cls(const pamlh *p, const double *pi, double kappa, double omega, const double *wcls, double *Q)
 {
    int from61[64], i, j, k, n = p->n, m = 0;
    double mr = 0;
@@ -581,7 +682,7 @@ static double codon_q_pi(const pamlh *p, const double *pi, double kappa, double 
             const int b1 = (pos + 1) % 3, b2 = (pos + 2) % 3;
             q /= (p->codonfreq == 2 ? p->fb3x4[b1 * 4 + t[b1]] * p->fb3x4[b2 * 4 + t[b2]] : p->fb4[t[b1]] * p->fb4[t[b2]]);
          }
-         if (p->code[c1] != p->code[c2]) q *= omega;
+         if (p->code[c1] != p->code[c2]) q *= wcls ? wcls[(int)p->omega_class[p->code[c1] - 'A'][p->code[c2] - 'A']] : omega;
          Q[i * n + j] = Q[j * n + i] = q;
       }
    for (i = 0; i < n; i++) for (j = 0; j < n; j++) Q[i * n + j] *= pi[j];
@@ -802,7 +903,20 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
       double kappa = p->fix_kappa ? p->kappa0 : x[k++];
       memcpy(p->pi, p->pi_data, p->n * sizeof(double));
       p->kappa = kappa;
-      if (p->nssites == 0 && p->model == 2) {
+      if (p->aadist == 7) {
+         /* AAClasses: omega by the class of the amino-acid pair; with branch labels every label has its own set of class omegas
+          * and its own eigen system (SetParameters codeml.c:2804-2812: com.pomega moves on by nOmegaType per label) */
+         const int nl = p->model == 2 ? p->n_omega : 1;
+         for (j = 0; j < nl; j++) {
+            const double mr = codon_q_cls(p, p->pi, kappa, 1, x + k, Q);
+            set_eig_uvroot(p, j, Q, p->pi, mr);
+            p->eigen_of[j] = j;
+            p->class_w[j] = x[k];
+            k += p->n_omega_type;
+         }
+         p->n_eigen = p->n_labels = nl;
+      }
+      else if (p->nssites == 0 && p->model == 2) {
          /* branch model: label l has its own omega and its own eigen system, each scaled by its own mean rate
           * (SetParameters codeml.c:2804-2812 -> _UU[l]; GetPMatBranch treesub.c:7568-7572) */
          for (j = 0; j < p->n_omega; j++) {
@@ -931,6 +1045,36 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
       if (p->aa_model == 0) {
          for (i = 0; i < 20; i++) p->pi[i] = 1.0 / 20;
          p->eig[0].kind = PAML_AMD_EIGEN_JC69LIKE;
+      }
+      else if (p->aa_model == 6) {
+         /* FromCodon: exchangeability of two amino acids = the codon chain's flow between their codon sets, under codon
+          * frequencies fb61 and kappa, over the product of the two amino-acid frequencies (Qcodon2aa codeml.c:3487-3523;
+          * eigenQaa 3418-3422, 3441-3447); omega cancels in the scaling */
+         const double kappa = p->fix_kappa ? p->kappa0 : x[k++];
+         double S[400] = {0}, piaa[20] = {0};
+         int from61[64], nc = 0, c, a, b;
+         memcpy(p->pi, p->pi_data, 20 * sizeof(double));
+         for (c = 0; c < 64; c++) if (p->code[c] != '*') from61[nc++] = c;
+         for (c = 0; c < nc; c++) piaa[aa_of_codon(p, from61[c])] += p->fb61[c];
+         for (i = 0; i < nc; i++) {
+            a = aa_of_codon(p, from61[i]);
+            for (j = 0; j < i; j++) {
+               const int c1 = from61[i], c2 = from61[j];
+               const int f[3] = {c1 / 16, (c1 / 4) % 4, c1 % 4}, t[3] = {c2 / 16, (c2 / 4) % 4, c2 % 4};
+               int nd = 0, pos = 0, q;
+               double v;
+               b = aa_of_codon(p, c2);
+               for (q = 0; q < 3; q++) if (f[q] != t[q]) { nd++; pos = q; }
+               if (nd != 1 || a == b || piaa[a] == 0 || piaa[b] == 0) continue;
+               v = (f[pos] + t[pos] == 1 || f[pos] + t[pos] == 5) ? kappa : 1;
+               v *= p->fb61[i] / piaa[a] * p->fb61[j] / piaa[b];
+               S[a * 20 + b] += v; S[b * 20 + a] += v;
+            }
+         }
+         for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) Q[i * 20 + j] = (i == j) ? 0 : S[i * 20 + j] * p->pi[j];
+         for (i = 0; i < 20; i++) { double s = 0; for (j = 0; j < 20; j++) s += Q[i * 20 + j]; Q[i * 20 + i] = -s; mr += p->pi[i] * s; }
+         set_eig_uvroot(p, 0, Q, p->pi, mr);
+         p->kappa = kappa;
       }
       else {
          memcpy(p->pi, p->aa_model == 2 ? p->aapi_file : p->pi_data, 20 * sizeof(double));   /* model 2: file pi, used as read */
@@ -1236,7 +1380,8 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
       if (rep > 1) snprintf(sfx, sizeof(sfx), " (gene %d)", g + 1);
       if (p->seqtype == 1) {
          if (!p->fix_kappa) NAME("kappa%s", sfx);
-         if (p->nssites == 0 && p->model == 2) { for (j = 0; j < p->n_omega; j++) NAME("omega #%d", j); }
+         if (p->aadist == 7) { int l; for (l = 0; l < (p->model == 2 ? p->n_omega : 1); l++) for (j = 0; j < p->n_omega_type; j++) NAME("omega class %d (branch type %d)", j, l); }
+         else if (p->nssites == 0 && p->model == 2) { for (j = 0; j < p->n_omega; j++) NAME("omega #%d", j); }
          else if (p->model >= 2) {
             NAME("p0"); NAME("p1"); NAME("w0");
             if (p->nssites == 3) NAME("w1");
@@ -1257,6 +1402,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
          else if (p->nssites == 7) { NAME("p (beta)"); NAME("q (beta)"); }
          else if (p->nssites == 8) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); if (!p->fix_omega) NAME("ws"); }
       }
+      else if (p->seqtype == 2) { if (p->aa_model == 6 && !p->fix_kappa) NAME("kappa"); }
       else if (p->seqtype == 0) {
          if (p->model == UNREST) { for (j = 0; j < 11; j++) NAME("rate %d%s", j + 1, sfx); }
          else if (p->model == REV) { static const char *const r[5] = {"a (TC)", "b (TA)", "c (TG)", "d (CA)", "e (CG)"}; for (j = 0; j < 5; j++) NAME("%s%s", r[j], sfx); }

@@ -177,7 +177,8 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
    for (g = 0; g < rep; g++)
    if (p->seqtype == 1) {
       if (!p->fix_kappa) { lo[k] = 1e-4; hi[k++] = 999; }
-      if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) { lo[k] = 1e-4; hi[k++] = 999; } }
+      if (p->aadist == 7) { for (i = 0; i < p->n_omega_type * (p->model == 2 ? p->n_omega : 1); i++) { lo[k] = 1e-4; hi[k++] = 999; } }
+      else if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) { lo[k] = 1e-4; hi[k++] = 999; } }
       else if (p->model >= 2) {      /* branch-site A / B, clade C / D (SetxBound codeml.c:1940-1965; proportions untransformed here) */
          lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 1e-6; hi[k++] = 1 - 1e-6;
          if (p->model == 2 && p->nssites == 2) { lo[k] = 1e-6; hi[k++] = 1; if (!p->fix_omega) { lo[k] = 1; hi[k++] = 999; } }
@@ -211,6 +212,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
          if (!p->fix_omega) { lo[k] = 1; hi[k++] = 999; }
       }
    }
+   else if (p->seqtype == 2) { if (p->aa_model == 6 && !p->fix_kappa) { lo[k] = 1e-4; hi[k++] = 999; } }
    else if (p->seqtype == 0) {
       const int nk = ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) ? 1 : (p->model == TN93 && !p->fix_kappa) ? 2 : p->model == REV ? 5 : p->model == UNREST ? 11 : 0;
       for (i = 0; i < nk; i++) { lo[k] = 1e-4; hi[k++] = 999; }

@@ -79,6 +79,9 @@ def run_ref(prog, ctl, files, x=None, timeout=3600):
         shutil.rmtree(d, ignore_errors=True)
 
 
+AA3 = dict(zip("Ala Arg Asn Asp Cys Gln Glu Gly His Ile Leu Lys Met Phe Pro Ser Thr Trp Tyr Val".split(), "ARNDCQEGHILKMFPSTWYV"))
+
+
 def parse_lnf(lines, seqtype, n_tips):
     hdr = None
     pats = []
@@ -94,7 +97,9 @@ def parse_lnf(lines, seqtype, n_tips):
             continue
         idx, cnt, logf = int(t[0]), float(t[1]), float(t[2])
         rest = ln.split(None, 5)[5]
-        if seqtype == "codon":
+        if seqtype == "aa3":      # aa model 5: the reference prints the data as three-letter amino-acid names
+            toks = [AA3[t3] for t3 in rest.split()]
+        elif seqtype == "codon":
             toks = re.findall(r"([A-Z\-\?]{3}) \(.\)", rest)
         else:
             toks = list(rest.split()[0])
@@ -239,6 +244,10 @@ def case_brown_anc():
     with open(path, "w") as f:
         json.dump(g, f, separators=(",", ":"))
     print("%-22s lnL %.6f  %d distinct patterns, nodes %s -> %s" % (g["name"], g["lnL"], len(rows), g["nodes_1based"], os.path.basename(path)))
+
+
+MTPRI_AA = {"mtCDNApri.aa": EX + "/mtCDNA/mtCDNApri.aa", "mtCDNApri.trees": EX + "/mtCDNA/mtCDNApri.trees"}
+MTAPE = {"mtCDNAape.txt": EX + "/mtCDNAape/mtCDNAape.txt", "mtCDNAape.trees": EX + "/mtCDNAape/mtCDNAape.trees"}
 
 
 def case_mtcdna_branch():
@@ -593,6 +602,18 @@ CASES = {
     "ecp_cmc": lambda: case_mle("ecp_cmc", dict(ECP_CTL, model=3, NSsites=2), ECP, 15, "codon_clade"),
     "ecp_cmd": lambda: case_mle("ecp_cmd", dict(ECP_CTL, model=3, NSsites=3), ECP, 15, "codon_clade"),
     "ecp_m2arel": lambda: case_mle("ecp_m2arel", dict(ECP_CTL, model=0, NSsites=22), ECP, 15, "codon_nssites"),
+    # aaDist = 7 (AAClasses, OmegaAA.dat: radical / conserved changes) under M0 and under the two-ratio branch model
+    # (examples/mtCDNAape/README.txt:19-21 publishes both maxima)
+    "mtcdna_aaclass_m0": lambda: case_mle("mtcdna_aaclass_m0", dict(seqfile="mtCDNAape.txt", treefile="mtCDNAape.trees", model=0, NSsites=0, icode=1, aaDist=7, cleandata=0, kappa=2, omega=.4),
+                                          dict(MTAPE, **{"OmegaAA.dat": EX + "/mtCDNAape/OmegaAA.dat"}), 6, "codon_aaclasses"),
+    "mtcdna_aaclass_branch": lambda: case_mle("mtcdna_aaclass_branch", dict(seqfile="mtCDNAape.txt", treefile="mtCDNAape.trees", model=2, NSsites=0, icode=1, aaDist=7, cleandata=0, kappa=2, omega=.4),
+                                              dict(MTAPE, **{"OmegaAA.dat": EX + "/mtCDNAape/OmegaAA.dat"}), 6, "codon_aaclasses"),
+    # codon-based amino-acid models on the 7-ape mitochondrial proteins (examples/mtCDNA/AAcodon.result.txt:75-97 publishes both
+    # maxima): 6 = FromCodon (20 states, rates aggregated from the codon chain), 5 = FromCodon0 (codon chain, amino acids as codon sets)
+    "mtcdnapri_fromcodon": lambda: case_mle("mtcdnapri_fromcodon", dict(seqfile="mtCDNApri.aa", treefile="mtCDNApri.trees", seqtype=2, model=6, icode=1, CodonFreq=0, kappa=3, omega=1.5, cleandata=1),
+                                            MTPRI_AA, 7, "aa_fromcodon", seqtype="aa"),
+    "mtcdnapri_fromcodon0": lambda: case_mle("mtcdnapri_fromcodon0", dict(seqfile="mtCDNApri.aa", treefile="mtCDNApri.trees", seqtype=2, model=5, icode=1, CodonFreq=0, kappa=3, omega=1.5, cleandata=1),
+                                             MTPRI_AA, 7, "aa_fromcodon0", seqtype="aa3"),
     "hiv_m3": lambda: case_mle("hiv_m3", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=3, ncatG=3, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_m4": lambda: case_mle("hiv_m4", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=4, ncatG=5, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_m5": lambda: case_mle("hiv_m5", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=5, ncatG=10, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),

@@ -18,6 +18,10 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("hiv_m0", "codeml", "hiv_ns0.ctl"), ("hiv_m1a", "codeml", "hiv_ns1.ctl"), ("hiv_m2a", "codeml", "hiv_ns2.ctl"),
          ("hiv_m7", "codeml", "hiv_ns7.ctl"), ("hiv_m8", "codeml", "hiv_ns8.ctl"), ("mhc_m0_scaled", "codeml", "mhc_m0.ctl"),
          ("mtcdna_branch", "codeml", "mtcdna_branch.ctl"),
+         # aaDist = 7 (AAClasses): omega by class of amino-acid pair (ctl/OmegaAA.dat), alone and per branch label
+         ("mtcdna_aaclass_m0", "codeml", "mtcdna_aaclass_m0.ctl"), ("mtcdna_aaclass_branch", "codeml", "mtcdna_aaclass_branch.ctl"),
+         # codon-based amino-acid models: 6 = FromCodon (20 states), 5 = FromCodon0 (60 codon states, amino acids as codon sets)
+         ("mtcdnapri_fromcodon", "codeml", "mtcdnapri_fromcodon.ctl"), ("mtcdnapri_fromcodon0", "codeml", "mtcdnapri_fromcodon0.ctl"),
          # branch-site A (alternative and null), B; clade C, D; M3 — goldens at the reference's own 6-decimal MLEs
          ("lyso_bsa", "codeml", "lyso_bsa.ctl"), ("lyso_bsa_null", "codeml", "lyso_bsa_null.ctl"), ("lyso_bsb", "codeml", "lyso_bsb.ctl"),
          ("ecp_cmc", "codeml", "ecp_cmc.ctl"), ("ecp_cmd", "codeml", "ecp_cmd.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl"), ("hiv_m4", "codeml", "hiv_ns4.ctl"), ("hiv_m5", "codeml", "hiv_ns5.ctl"), ("hiv_m6", "codeml", "hiv_ns6.ctl"), ("hiv_m9", "codeml", "hiv_ns9.ctl"),
@@ -597,7 +601,10 @@ def test_c_host_beb_matches_the_reference_table(gname, ctl, table):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ctl,lnl,est", [("mtcdna_m0.ctl", -20486.034301, {-2: 20.74839, -1: 0.04414}),
-                                          ("mtcdna_branch.ctl", -20444.099676, {-3: 21.59077, -2: 0.28638, -1: 0.03693})])
+                                          ("mtcdna_branch.ctl", -20444.099676, {-3: 21.59077, -2: 0.28638, -1: 0.03693}),
+                                          # aaDist = 7: radical (class 0) / conserved (class 1) omegas, README.txt:19-21
+                                          ("mtcdna_aaclass_m0.ctl", -20482.229434, {-3: 20.52018, -2: 0.02745, -1: 0.04658}),
+                                          ("mtcdna_aaclass_branch.ctl", -20440.382774, {-5: 21.36004, -4: 0.15012, -3: 0.30470, -2: 0.02380, -1: 0.03885})])
 def test_c_host_reaches_the_published_mtcdnaape_values(ctl, lnl, est):
     """examples/mtCDNAape/README.txt:15-17 publishes the maximised lnL and the estimates of kappa and omega for the ape
     mitochondrial data under M0 and under the two-ratio branch model (model = 2: within- / between-species branches labelled in
@@ -609,6 +616,37 @@ def test_c_host_reaches_the_published_mtcdnaape_values(ctl, lnl, est):
     assert r["converged"] and abs(r["lnL"] - lnl) < 2e-4, r["lnL"]
     for k, v in est.items():
         assert abs(r["x"][k] - v) / v < 5e-3, (k, r["x"][k], v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ctl,lnl,n,est", [("mtcdnapri_fromcodon.ctl", -14718.224885, 20, {-1: 9.156815}),
+                                            ("mtcdnapri_fromcodon0.ctl", -14707.663779, 60, {-2: 9.246897, -1: 0.031208})])
+def test_c_host_reaches_the_published_codon_based_aa_values(ctl, lnl, n, est):
+    """examples/mtCDNA/AAcodon.result.txt:75-97: the maxima of the two codon-based amino-acid models on the 7-ape
+    mitochondrial proteins (vertebrate mt code) — model 6 on the 20-state kernels, model 5 on the 60-state kernels with 21
+    ambiguity codes (an amino acid = the set of its codons)."""
+    a = hostlib.Analysis(os.path.join(CTL, ctl), "codeml")
+    assert a.n == n and a.n_tips == 7
+    r = a.optimize(a.default_x())
+    assert r["converged"] and abs(r["lnL"] - lnl) < 3e-4, r["lnL"]
+    for k, v in est.items():
+        assert abs(r["x"][k] - v) / v < 1e-2, (k, r["x"][k], v)
+
+
+def test_c_host_aaclasses_needs_its_class_file(tmp_path):
+    """aaDist = 7 reads OmegaAA.dat from the control file's directory; a missing file, a pair listed twice and a bad class count are
+    errors, a pair that cannot change in one step under the genetic code is ignored (as the reference does)."""
+    data = os.path.join(helpers.GOLDEN, "data") + "/"
+    ctl = tmp_path / "a.ctl"
+    ctl.write_text(open(os.path.join(CTL, "mtcdna_aaclass_m0.ctl")).read().replace("../data/", data))
+    with pytest.raises(RuntimeError, match="OmegaAA.dat"):
+        hostlib.Analysis(str(ctl), "codeml")
+    (tmp_path / "OmegaAA.dat").write_text("2\n1: RH RK HR\n0: all others\n")
+    with pytest.raises(RuntimeError, match="listed twice"):
+        hostlib.Analysis(str(ctl), "codeml")
+    (tmp_path / "OmegaAA.dat").write_text("3\n1: RH RK AW\n2: DE\n")      # A <-> W needs two changes: ignored
+    a = hostlib.Analysis(str(ctl), "codeml")
+    assert a.np == 9 + 1 + 3
 
 
 MTCDNAPRI = {0: (-31744.953377, "0.120080 0.058139 0.175107 0.098210 0.072451 0.060123 0.206933 0.224103 0.115862 0.114939 0.408898 7.417478 0.112776"),
