@@ -86,7 +86,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline only: no sweep / c2 / weak / read-back blocks")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--sweep-steps", type=int, default=5)
+    ap.add_argument("--clock-probe", action="store_true", help="(internal) the headline kernel with timeline stamps: shader clock under load")
     args = ap.parse_args()
+    if args.clock_probe:
+        return clock_probe(args)
 
     import torch
     import torch.distributed as dist
@@ -251,6 +254,13 @@ def main():
                            "unit": "site-patterns/s", "ms_per_step": dtw / args.steps * 1e3, "lnL": lw}
 
     # ---- N = 1: the 4-state configuration and the CPU baseline -----------------------------------------------------------
+    if rank == 0 and world == 1 and extras and pb.n == 61:
+        ck = run_clock_probe(args)
+        if "shader_mhz" in ck:
+            ck["peak_at_this_clock_tflops"] = FP64_PEAK_TFLOPS * ck["shader_mhz"] / 2400.0
+            ck["frac_at_this_clock"] = out["roofline"]["achieved"] / ck["peak_at_this_clock_tflops"]
+            ck["note"] = "78.6 TFLOP/s is the FP64 peak at 2400 MHz; this is the clock the chip held while the kernel ran (instrumented build, same box)"
+        out["roofline"]["clock"] = ck
     if rank == 0 and world == 1 and extras:
         out["c2"] = bench_c2(engine, synth, timed, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -302,6 +312,52 @@ def bench_c2(engine, synth, timed, args):
                          "note": "materialised-partials bytes (SURVEY 8d): the fused kernel keeps partials in registers, so this exceeds the HBM "
                                  "peak; real traffic is in profiles/",
                          "valu_tflops": fpp * pb.n_patt / (kms * 1e-3) / 1e12, "valu_frac": fpp * pb.n_patt / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}}
+
+
+def clock_probe(args):
+    """The headline kernel built with its timeline stamps (PAML_AMD_PROF_TILES: s_memrealtime and s_memtime at workgroup start and
+    at the end of each tile; a few scalar stores per 55 us tile): the shader clock the chip holds while THIS kernel runs, and the
+    kernel's MFMA issue rate in cycles.  Run as a child process: the environment has to be there when the kernel is generated."""
+    import numpy as np
+    import torch  # noqa: F401
+    from paml_amd import engine, synth
+    dump = os.environ["PAML_AMD_PROF_OPS"]
+    pb = synth.codon_m0_problem(n_tips=args.taxa, n_patt=args.patterns, estimate_pi=True)
+    eng = engine.engine_for(pb)
+    d = torch.zeros(64, dtype=torch.float64, device="cuda")
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    for i in range(40):      # back to back like the timed loop; the dump (written when the engine goes) holds the last launch
+        eng.eval_device(pb.tree.branch, d.data_ptr() + 8 * i)
+    torch.cuda.synchronize()
+    eng.close()
+    raw = open(dump, "rb").read()
+    nb, stride = np.frombuffer(raw[:8], dtype=np.int32)
+    t = np.frombuffer(raw[8 + 4 * (stride - 3):], dtype=np.uint64).astype(np.int64).reshape(-1, nb, stride)[0]
+    t = t[t[:, 0] > 0]
+    ends = t[:, 1:-2]
+    ntile = (ends > 0).sum(axis=1)
+    last = np.array([ends[b, ntile[b] - 1] for b in range(t.shape[0])])
+    mhz = (t[:, -1] - t[:, -2]) / (last - t[:, 0]) * 100.0
+    tile_us = float(np.median((last - t[:, 0]) / ntile / 100.0))
+    n_int = args.taxa - 3
+    mfma_cycles = n_int * 60 * 64 * 2          # per tile and SIMD: 60 MFMAs of 64 cycles per product, two waves per SIMD
+    print(json.dumps({"shader_mhz": float(np.median(mhz)), "tile_us": tile_us, "tiles_per_workgroup": [int(ntile.min()), int(ntile.max())],
+                      "span_us": float((last.max() - t[:, 0].min()) / 100.0), "mfma_issue_frac_of_cycles": mfma_cycles / (tile_us * float(np.median(mhz)))}))
+
+
+def run_clock_probe(args):
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, PAML_AMD_PROF_TILES="1", PAML_AMD_PROF_OPS=os.path.join(d, "tl.bin"))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--clock-probe", "--taxa", str(args.taxa), "--patterns", str(args.patterns)],
+                               env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+            return json.loads(r.stdout.decode().strip().splitlines()[-1])
+        except Exception as e:      # an experiment's figure: its absence does not fail the bench
+            return {"error": repr(e)}
 
 
 def profiles_evidence(flop_per_launch):

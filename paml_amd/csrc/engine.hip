@@ -147,6 +147,7 @@ struct EnvCfg {
    int jit_waves = 0;
    std::string jit_dump, prof_ops;
    int prof_tid = 0;
+   bool prof_tiles = false;      // the dump is a workgroup timeline (jit.h proft) instead of per-op stamps
    void read()
    {
       no_pipeline = getenv("PAML_AMD_NO_PIPELINE") != nullptr;
@@ -162,6 +163,7 @@ struct EnvCfg {
       if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
       if (const char *v = getenv("PAML_AMD_PROF_OPS")) prof_ops = v;
       if (const char *v = getenv("PAML_AMD_PROF_TID")) prof_tid = atoi(v);
+      prof_tiles = getenv("PAML_AMD_PROF_TILES") != nullptr;
    }
 };
 
@@ -180,6 +182,8 @@ struct paml_amd_engine {
    int device = 0, n_cu = 0;          // the device the engine was created on, its CU count (persistent grids)
    bool stream_attr_set = false;      // > 64 KB dynamic LDS of prune_mfma64_stream requested on this device
    unsigned long long *d_prof = nullptr;   // PAML_AMD_PROF_OPS stamps
+   size_t prof_words = 0;
+   int prof_blocks = 0, prof_stride = 0;
 
    // pattern shards over several GPUs (paml_amd_comm_init): this engine holds patterns [first_patt, first_patt + n_patt) of
    // n_patt_global; the reduction's partial sums live at their global positions and are summed over the ranks
@@ -283,6 +287,18 @@ struct paml_amd_engine {
       stage.release();
       if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
       if (h_out) (void)hipHostFree(h_out);
+      if (d_prof && env.prof_tiles && prof_words) {      // the last launch's workgroup timeline
+         std::vector<unsigned long long> hp(prof_words);
+         if (hipMemcpy(hp.data(), d_prof, prof_words * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = fopen(env.prof_ops.c_str(), "wb")) {
+               const int hdr[2] = {prof_blocks, prof_stride};
+               fwrite(hdr, sizeof(int), 2, f);
+               std::vector<int> codes(prof_stride - 3, 0);
+               fwrite(codes.data(), sizeof(int), codes.size(), f);
+               fwrite(hp.data(), 8, hp.size(), f);
+               fclose(f);
+            }
+      }
       if (d_prof) (void)hipFree(d_prof);
       if (jit.mod) (void)hipModuleUnload(jit.mod);
       for (auto ev : ev_pool) (void)hipEventDestroy(ev);
@@ -761,12 +777,18 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       // the total: a one-block stage-2 launch (default), or PAML_AMD_TAIL=1: the workgroup that finishes last forms it (tickets)
       pr.red_counter = (e->comm || !e->env.tail) ? nullptr : e->d_red_counter.p;
    }
-   const int prof_stride = (int)e->prog.ops.size() + 3;
+   const int prof_stride = std::max((int)e->prog.ops.size() + 3, e->env.prof_tiles ? 96 : 0);      // experiments only
    if (!e->env.prof_ops.empty()) {
-      if (e->d_prof) (void)hipFree(e->d_prof);
-      e->d_prof = nullptr;
-      HIPCHK(hipMalloc((void **)&e->d_prof, (size_t)3 * n_blocks * prof_stride * 8));
-      HIPCHK(hipMemsetAsync(e->d_prof, 0, (size_t)3 * n_blocks * prof_stride * 8, e->stream));
+      // per-op stamps: a fresh buffer and a dump after every launch; the workgroup timeline: one buffer, overwritten by every
+      // launch and written out when the engine goes (nothing between the launches, so that the clock is the production clock)
+      const size_t words = (size_t)3 * n_blocks * prof_stride;
+      if (!e->env.prof_tiles || words != e->prof_words) {
+         if (e->d_prof) (void)hipFree(e->d_prof);
+         e->d_prof = nullptr;
+         HIPCHK(hipMalloc((void **)&e->d_prof, words * 8));
+         HIPCHK(hipMemsetAsync(e->d_prof, 0, words * 8, e->stream));
+         e->prof_words = words; e->prof_blocks = n_blocks; e->prof_stride = prof_stride;
+      }
       pr.prof = e->d_prof;
       pr.prof_stride = prof_stride;
       pr.prof_tid = e->env.prof_tid;
@@ -811,7 +833,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       break;
    }
    mark(e);
-   if (pr.prof) {
+   if (pr.prof && !e->env.prof_tiles) {
       std::vector<unsigned long long> hp((size_t)3 * n_blocks * prof_stride);
       HIPCHK(hipMemcpyAsync(hp.data(), e->d_prof, hp.size() * 8, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
@@ -821,6 +843,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          fwrite(hdr, sizeof(int), 2, f);
          std::vector<int> codes;
          for (auto &o : e->prog.ops) codes.push_back(o.code);
+         codes.resize(prof_stride - 3, 0);
          fwrite(codes.data(), sizeof(int), codes.size(), f);
          fwrite(hp.data(), 8, hp.size(), f);
          fclose(f);
@@ -2060,6 +2083,10 @@ int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_p
       if (const char *v = getenv("PAML_AMD_JIT_WAVES")) if (atoi(v) == 12 && jit_zbuffers(n_tips, 192) == 2) jw = 12;
       if (!jit_supported(p, n_tips, n_codes, 1, 6, jw * 16)) return PAML_AMD_EUNSUPPORTED;
       text = jit_generate(p, n_tips, n_states, n_codes, jw);
+   }
+   if (const char *dump = getenv("PAML_AMD_JIT_DUMP")) {
+      FILE *f = fopen(dump, "w");
+      if (f) { fputs(text.c_str(), f); fclose(f); }
    }
    std::vector<char> code;
    std::string log;

@@ -92,7 +92,8 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    const bool fuse_tips = !getenv("PAML_AMD_JIT_NOFUSE") && KB2 >= 2;   // cherries gathered under the preceding matmul
    const int MID = KB2 / 2;                                             // ... from this k-block pair on (jit_matvec_tip2)
    const bool spread = !getenv("PAML_AMD_JIT_NOSPREAD");    // ring refill issued from inside the MFMA loops
-   const bool prof = getenv("PAML_AMD_PROF_OPS") != nullptr; // kernel experiments: s_memtime stamp at every op
+   const bool proft = getenv("PAML_AMD_PROF_TILES") != nullptr;            // kernel experiments: s_memrealtime (100 MHz) at workgroup start and at the end of each of its tiles
+   const bool prof = !proft && getenv("PAML_AMD_PROF_OPS") != nullptr;      // kernel experiments: s_memtime stamp at every op
    // 61 states: the last k-block of P is the single column 60 — its rank-1 term goes through the vector pipe (a 512-byte
    // column table travels with every P block as a fifth DMA piece) and the k-block's four MFMAs are dropped
    const bool tail61 = n_states == 61 && !getenv("PAML_AMD_JIT_NOTAIL");
@@ -225,6 +226,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    issued = first;
    consumed = peel ? 2 : 0;
 
+   if (proft) s << "   int ptc = 0; if (a.prof && tid == 0) { a.prof[(long)blockIdx.x * a.prof_stride] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 2] = __builtin_amdgcn_s_memtime(); }\n";
    s << "   int ptile = 1;\n   for (;; ptile = 0) {\n";
    s << "   JIT2_ADVANCE(" << nblk << ")\n   work += gridDim.x;\n   JIT2_NEXT_SET()\n";
    z_pending = !zsingle;
@@ -359,6 +361,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       s << "   __syncthreads();\n   JIT2_ISSUE_Z(" << ZP << ")\n   JIT_WAIT(0); __syncthreads();\n";
       fl.clear();
    }
+   if (proft) s << "   if (a.prof && tid == 0 && ptc < a.prof_stride - 3) { a.prof[(long)blockIdx.x * a.prof_stride + 1 + ptc] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 1] = __builtin_amdgcn_s_memtime(); }\n   ptc++;\n";
    s << "   if (!has_next) break;\n   }\n   JIT_WAIT(0);\n}\n";
    *first_out = issued - nblk;
    return s.str();

@@ -582,9 +582,9 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       else if (p->nssites == 7) { x[k++] = 0.5; x[k++] = 1.5; }
       else if (p->nssites == 8) { x[k++] = 0.9; x[k++] = 0.5; x[k++] = 1.5; if (!p->fix_omega) x[k++] = 2.5; }
    }
+   else if (p->seqtype == 2) { if (p->aa_model == 6 && !p->fix_kappa) x[k++] = p->kappa0; }
    else if (p->seqtype == 0) {
-      if (p->seqtype == 2) { if (p->aa_model == 6 && !p->fix_kappa) x[k++] = p->kappa0; }
-      else if ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) x[k++] = p->kappa0;
+      if ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) x[k++] = p->kappa0;
       else if (p->model == TN93 && !p->fix_kappa) { x[k++] = p->kappa0; x[k++] = p->kappa0; }
       else if (p->model == REV) { for (i = 0; i < 5; i++) x[k++] = 1; }
       else if (p->model == UNREST) { for (i = 0; i < 11; i++) x[k++] = (i == 0 || i == 3 || i == 8) ? 0.9 : 0.5; }

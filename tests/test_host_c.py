@@ -48,6 +48,7 @@ def test_c_host_reproduces_reference_on_cpu(gname, prog, ctl):
     assert (a.n_patt, a.ls, a.n_tips) == (g["n_patt"], g["ls"], g["n_tips"])
     if "x" in g and a.np:
         assert a.np == len(g["x"]) and a.ntime == g.get("ntime", a.ntime)
+    assert len(a.default_x()) == a.np      # initial values, bounds and names cover every parameter
     pb = a.problem(_x(g, a))
     assert np.array_equal(pb.weights, np.array(g["counts"]))          # same patterns, same order, same counts
     r = oracle.evaluate(pb)

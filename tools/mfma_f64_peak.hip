@@ -11,6 +11,9 @@ template <int MODE>   // 0: mfma only, 1: valu only, 2: even waves mfma / odd wa
 __global__ __launch_bounds__(512) void k(double *out, int iters, double seed)
 {
    const int wave = threadIdx.x >> 6;
+   // shader clock over the kernel's run: s_memtime (core clock) against s_memrealtime (100 MHz), workgroup 0
+   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+   struct Stamp { double *o; unsigned long long c0, r0; __device__ ~Stamp() { if (blockIdx.x == 0 && threadIdx.x == 0) { o[1] = (double)(__builtin_amdgcn_s_memtime() - c0); o[2] = (double)(__builtin_amdgcn_s_memrealtime() - r0); } } } stamp{out, c0, r0};
    if (MODE == 3) {      // four 4x4x4 blocks per instruction: 4 x 64 MACs = 512 FLOP
       double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
       double x = seed + threadIdx.x * 1e-9, y = 1.0 - seed;
@@ -82,8 +85,10 @@ double run(int blocks, int threads, int iters, double *d, const char *name)
    if (MODE == 1) vf = waves * iters * 128.0 * 64 * 2;
    if (MODE == 2) { mf = waves / 2 * iters * 32.0 * 2048; vf = waves / 2 * iters * 128.0 * 64 * 2; }
    if (MODE == 3) mf = waves * iters * 32.0 * 512;
-   printf("%-34s blocks=%d thr=%d  %.3f ms  mfma %.1f TF  valu %.1f TF  total %.1f TF\n", name, blocks, threads, ms,
-          mf / ms / 1e9, vf / ms / 1e9, (mf + vf) / ms / 1e9);
+   double h[3] = {0, 0, 0};
+   hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+   printf("%-34s blocks=%d thr=%d  %.3f ms  mfma %.1f TF  valu %.1f TF  total %.1f TF  shader clock %.0f MHz\n", name, blocks, threads, ms,
+          mf / ms / 1e9, vf / ms / 1e9, (mf + vf) / ms / 1e9, h[2] > 0 ? h[1] / h[2] * 100.0 : 0.0);
    return ms;
 }
 
