@@ -13,6 +13,7 @@ typedef struct {
    int n;
 } pamlh_ctl;
 
+#define PAMLH_MAXEIG 512      /* eigen systems: site classes x branch types, or one per node (nhomo >= 2) */
 typedef struct {
    int kind, nR;
    double kappa;
@@ -37,7 +38,7 @@ struct pamlh {
    int *n_chara;
    int *pose, n_pose;      /* site (after cleaning) -> pattern index */
    int ngene, posG[PAMLH_MAXGENE + 1], lgene[PAMLH_MAXGENE];   /* option G: first pattern / number of sites of every gene */
-   int nhomo;              /* baseml: 1 = base frequencies are parameters */
+   int nhomo;              /* baseml: 1 = base frequencies are parameters; 2 = a kappa per branch; 3, 4 = frequency sets (and kappas) per branch */
    int mg;                 /* CodonFreq 4 / 5: F1x4MG / F3x4MG */
    int fix_rho, adg;       /* auto-discrete-gamma: rho free or fixed != 0; adg: the current model state uses lfunAdG with MK */
    double rho0, rho, MK[64 * 64 / 4];
@@ -60,7 +61,7 @@ struct pamlh {
    int np, ntime, mode, K, n_eigen, n_labels, n_pi;
    double *branch, *pi, *freqK, *rate;
    int *eigen_of;
-   pamlh_eig eig[64];
+   pamlh_eig eig[PAMLH_MAXEIG];
    double kappa, omega, alpha;
    double class_w[64];     /* NSsites: omega of every site class; branch model: omega of every label */
    char code[65];          /* genetic code: amino acid of each of the 64 codons (T, C, A, G order), '*' = stop */
@@ -84,6 +85,8 @@ struct pamlh {
 };
 
 /* numerics (pamlh_num.c) */
+int pamlh_nh_nrate(const pamlh *p);      /* nhomo >= 2: rate parameters, frequency sets (baseml.c:1201-1232) */
+int pamlh_nh_npi(const pamlh *p);
 void pamlh_eigen_sym(double *A, int n, double *w, double *R);
 void pamlh_eigen_qrev(const double *Q, const double *pi, int n, double *Root, double *U, double *V);
 double pamlh_gammp(double a, double x);

@@ -294,7 +294,10 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->nssites) { rc = pamlh_fail(p, "rho does not go with NSsites models"); goto bad; }
    }
    p->nhomo = p->is_codeml ? 0 : (int)pamlh_optd(p, "nhomo", 0);
-   if (p->nhomo != 0 && p->nhomo != 1) { rc = pamlh_fail(p, "nhomo = %d is not supported (0: frequencies from the data, 1: frequencies as parameters)", p->nhomo); goto bad; }
+   /* nhomo (baseml.c:1748-1760): 0 frequencies from the data, 1 as parameters, 2 a kappa per branch, 3 a frequency set for every
+    * tip branch, one for the internal branches and one at the root, 4 a set for every node; 3 and 4 with a kappa per branch
+    * (fix_kappa = 0) or one kappa for all (fix_kappa = 1).  5 (sets by labels in the tree file) is not supported. */
+   if (p->nhomo < 0 || p->nhomo > 4) { rc = pamlh_fail(p, "nhomo = %d is not supported (0 ... 4)", p->nhomo); goto bad; }
    p->clock = (int)pamlh_optd(p, "clock", 0);
    if (p->clock != 0 && p->clock != 1) { rc = pamlh_fail(p, "clock = %d is not supported (0: no clock, 1: global clock)", p->clock); goto bad; }
    p->mgene = (int)pamlh_optd(p, "Mgene", 0);
@@ -358,6 +361,14 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    if ((rc = pamlh_read_seqs(p))) goto bad;
    if ((rc = pamlh_read_tree(p))) goto bad;
    if (p->nhomo == 1 && (p->ngene > 1 || p->model < F81 || p->model > REV)) { rc = pamlh_fail(p, "nhomo = 1 needs one gene and a model with base frequencies (F81 ... REV)"); goto bad; }
+   if (p->nhomo >= 2) {
+      if (p->ngene > 1) { rc = pamlh_fail(p, "nhomo for several genes?"); goto bad; }
+      if (p->nhomo == 2 && p->model != K80 && p->model != F84 && p->model != HKY85) { rc = pamlh_fail(p, "nhomo = 2 works with K80, F84 or HKY85"); goto bad; }
+      if (p->nhomo > 2 && (p->model < F84 || p->model > REV)) { rc = pamlh_fail(p, "nhomo = %d needs a model with base frequencies and rate parameters (F84 ... REV)", p->nhomo); goto bad; }
+      if (p->nhomo > 2 && p->fix_kappa > 1) { rc = pamlh_fail(p, "nhomo with fix_kappa = 2 (rate sets by branch labels) is not supported"); goto bad; }
+      if (p->nnode > PAMLH_MAXEIG) { rc = pamlh_fail(p, "nhomo >= 2: more than %d nodes", PAMLH_MAXEIG); goto bad; }
+      if (!p->fix_rho || p->rho0 != 0) { rc = pamlh_fail(p, "nhomo with rho is not supported"); goto bad; }
+   }
    if (p->ngene <= 1) { if (p->mgene) { rc = pamlh_fail(p, "Mgene = %d but the sequence file has one gene (no option G)", p->mgene); goto bad; } }
    else {
       /* what the several-gene set-up covers (the reference's own exclusions: baseml.c:261-265, codeml.c:1534-1544) */
@@ -377,6 +388,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    }
 genes_ok:
    if (!(p->seqtype == 1 && p->model >= 2)) memset(p->label, 0, p->nnode * sizeof(int));      /* '#' labels only matter to branch models */
+   if (p->seqtype == 0 && p->nhomo >= 2) { int v; for (v = 0; v < p->nnode; v++) p->label[v] = v; }      /* every branch has its own P(t) family */
    if (p->seqtype == 1 && p->model >= 2) {
       int i;
       for (p->n_omega = 1, i = 0; i < p->nnode; i++) if (p->label[i] + 1 > p->n_omega) p->n_omega = p->label[i] + 1;
@@ -436,6 +448,7 @@ genes_ok:
          else if (p->model == REV) nr += 5;
          else if (p->model == UNREST) nr += 11;
          if (p->nhomo == 1) nr += p->model == T92 ? 1 : 3;
+         if (p->nhomo >= 2) nr = pamlh_nh_nrate(p) + (p->nhomo > 2 ? pamlh_nh_npi(p) * (p->model == T92 ? 1 : 3) : 0);
       }
       if (rep > 1) nr += (rep - 1) * (p->seqtype == 1 ? 2 : nuc_nkappa(p));      /* Mgene 3, 4: a parameter set per gene */
       if (p->alpha0 > 0 || !p->fix_alpha) nr += !p->fix_alpha;
@@ -446,7 +459,7 @@ genes_ok:
    p->pi = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    p->freqK = (double *)calloc(64, sizeof(double));
    p->rate = (double *)calloc(64, sizeof(double));
-   p->eigen_of = (int *)calloc(64, sizeof(int));
+   p->eigen_of = (int *)calloc(64 * PAMLH_MAXEIG, sizeof(int));
    p->n_pi = 1;
    *out = p;
    return 0;
@@ -466,7 +479,7 @@ void pamlh_free(pamlh *p)
    free(p->names); free(p->z); free(p->w); free(p->raw); free(p->n_chara); free(p->chara_map);
    free(p->sons_ptr); free(p->sons); free(p->label); free(p->branch_node); free(p->father); free(p->tree_branch); free(p->scale);
    free(p->branch); free(p->pi); free(p->freqK); free(p->rate); free(p->eigen_of);
-   for (i = 0; i < 64; i++) { free(p->eig[i].U); free(p->eig[i].V); free(p->eig[i].Root); free(p->eig[i].Cijk); }
+   for (i = 0; i < PAMLH_MAXEIG; i++) { free(p->eig[i].U); free(p->eig[i].V); free(p->eig[i].Root); free(p->eig[i].Cijk); }
    free(p->gene_eigen_of);
    free(p);
 }
@@ -589,6 +602,12 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       else if (p->model == REV) { for (i = 0; i < 5; i++) x[k++] = 1; }
       else if (p->model == UNREST) { for (i = 0; i < 11; i++) x[k++] = (i == 0 || i == 3 || i == 8) ? 0.9 : 0.5; }
       if (p->nhomo == 1) { if (p->model == T92) x[k++] = p->pi_data[1] + p->pi_data[3]; else for (i = 0; i < 3; i++) x[k++] = p->pi_data[i]; }
+      if (p->nhomo >= 2) {
+         int j;
+         k = p->ntime;
+         for (i = 0; i < pamlh_nh_nrate(p); i++) x[k++] = p->model == REV ? 1 : p->kappa0;
+         for (j = 0; j < (p->nhomo > 2 ? pamlh_nh_npi(p) : 0); j++) { if (p->model == T92) x[k++] = p->pi_data[1] + p->pi_data[3]; else for (i = 0; i < 3; i++) x[k++] = p->pi_data[i]; }
+      }
    }
    if (!p->fix_alpha) x[k++] = p->alpha0 > 0 ? p->alpha0 : 0.5;
    if (!p->fix_rho) x[k++] = p->rho0;
@@ -800,6 +819,51 @@ static void nuc_set(pamlh *p, int iset, const double *pi, const double *kp, doub
    if (!e->Cijk) e->Cijk = (double *)malloc(64 * sizeof(double));
    for (i = 0; i < 4; i++) for (j = 0; j < 4; j++) for (kk = 0; kk < 4; kk++) e->Cijk[i * 16 + j * 4 + kk] = e->U[i * 4 + kk] * e->V[kk * 4 + j];
    e->kind = PAML_AMD_EIGEN_CIJK; e->nR = 4;
+}
+
+/* nhomo >= 2 (GetInitials baseml.c:1201-1232, SetParameters 1341-1370, GetPMatBranch treesub.c:7503-7519): the branch to node v
+ * has its own rate parameters (nhomo 2: kappa; 3, 4 with fix_kappa = 0: the model's kappa / abcde) and, for 3 and 4, the Q of
+ * the frequency set of node v; the root's set gives the root distribution.  x after the branch lengths: the rate parameters in
+ * tree.branches order, then the frequency sets (3 frequencies each, T92: the GC content) as frequencies (LASTROUND). */
+static int nh_nk(const pamlh *p)
+{
+   static const int nkappa[] = {0, 1, 0, 1, 1, 1, 2, 5, 11};
+   return nkappa[p->model];
+}
+int pamlh_nh_nrate(const pamlh *p) { return p->nhomo == 2 ? p->nbranch : nh_nk(p) * (p->fix_kappa ? 1 : p->nbranch); }
+int pamlh_nh_npi(const pamlh *p) { return p->nhomo == 4 ? p->nnode : p->nhomo == 3 ? p->ns + 1 + (p->root >= p->ns) : 0; }
+static int nh_piset(const pamlh *p, int v) { return p->nhomo == 4 ? v : (v < p->ns ? v : (v == p->root ? p->ns + 1 : p->ns)); }
+
+static int set_x_nhomo(pamlh *p, const double *x, int *kio, double *Q)
+{
+   const int nk = nh_nk(p), n31 = p->model == T92 ? 1 : 3, fix = p->fix_kappa;
+   const double *rates = x + *kio, *pis = rates + pamlh_nh_nrate(p);
+   int i, v;
+   for (v = 0; v < p->nnode; v++) {
+      double pi[4];
+      if (p->nhomo == 2) { for (i = 0; i < 4; i++) pi[i] = p->model == K80 ? 0.25 : p->pi_data[i]; }
+      else {
+         const double *px = pis + nh_piset(p, v) * n31;
+         if (p->model == T92) { pi[0] = pi[2] = (1 - px[0]) / 2; pi[1] = pi[3] = px[0] / 2; }
+         else { pi[0] = px[0]; pi[1] = px[1]; pi[2] = px[2]; pi[3] = 1 - px[0] - px[1] - px[2]; }
+         if (!(pi[3] > -1e-9)) return pamlh_fail(p, "base frequencies of set %d sum above 1", nh_piset(p, v) + 1);
+         /* an estimate on the boundary (the reference prints 0.000000): the symmetrised eigen problem needs pi > 0, P(t) is continuous there */
+         for (i = 0; i < 4; i++) if (!(pi[i] > 1e-15)) pi[i] = 1e-15;
+      }
+      p->eigen_of[v] = v;
+      if (v == p->root) {      /* no branch: the set gives com.pi; a placeholder keeps the eigen systems dense */
+         memcpy(p->pi, pi, sizeof(pi));
+         p->eig[v].kind = PAML_AMD_EIGEN_K80; p->eig[v].kappa = 1;
+         continue;
+      }
+      for (i = 0; i < p->nbranch && p->branch_node[i] != v; i++) ;
+      p->fix_kappa = 0;      /* the rate parameters of this branch are always read from x */
+      nuc_set(p, v, pi, p->nhomo == 2 ? rates + i : (fix ? rates : rates + (size_t)i * nk), Q);
+      p->fix_kappa = fix;
+   }
+   p->n_labels = p->n_eigen = p->nnode;
+   *kio += pamlh_nh_nrate(p) + (p->nhomo > 2 ? pamlh_nh_npi(p) * n31 : 0);
+   return 0;
 }
 
 /* Several genes (option G).  x = branch lengths, rgene[2..ngene] (rates relative to the first gene, SetParameters
@@ -1089,6 +1153,8 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
       for (i = 0; i < 16; i++) S[i] = 1;
       if (m == JC69 || m == K80) for (i = 0; i < 4; i++) p->pi[i] = 0.25;
       else memcpy(p->pi, p->pi_data, 4 * sizeof(double));
+      if (p->nhomo >= 2) { const int rc = set_x_nhomo(p, x, &k, Q); if (rc) { free(Q); return rc; } }
+      else {
       if (p->nhomo == 1) {       /* base frequencies are parameters, after the rate parameters in x (SetParameters baseml.c:1328-1341) */
          const double *px = x + k + nuc_nkappa(p);
          if (m == T92) { p->pi[0] = p->pi[2] = (1 - px[0]) / 2; p->pi[1] = p->pi[3] = px[0] / 2; }
@@ -1127,6 +1193,7 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
             e->kind = PAML_AMD_EIGEN_CIJK; e->nR = 4;
          }
       }
+      }
    }
    if (p->seqtype == 0 && p->nhomo == 1) k += p->model == T92 ? 1 : 3;
    /* gamma rates for sites (not with NSsites): alpha fixed > 0 or free */
@@ -1137,7 +1204,7 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          if (p->ncatG > 60) { free(Q); return pamlh_fail(p, "ncatG too large"); }
          pamlh_discrete_gamma(p->freqK, p->rate, alpha, p->ncatG);
          p->K = p->ncatG; p->mode = PAML_AMD_MODE_LFUNDG;
-         for (j = 0; j < p->K; j++) p->eigen_of[j] = 0;
+         for (j = 0; j < p->K; j++) { int l; for (l = 0; l < p->n_labels; l++) p->eigen_of[j * p->n_labels + l] = p->n_labels > 1 ? l : 0; }
       }
       p->adg = 0;
       if (!p->fix_rho || p->rho0 != 0) {      /* AutodGamma: MK and the same class rates (SetParameters baseml.c:1388-1391) */
@@ -1194,8 +1261,8 @@ int pamlh_gene_subset(const pamlh *p, int g, pamlh **out)
    q->pi = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    q->freqK = (double *)calloc(64, sizeof(double));
    q->rate = (double *)calloc(64, sizeof(double));
-   q->eigen_of = (int *)calloc(64, sizeof(int));
-   for (i = 0; i < 64; i++) q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = NULL;
+   q->eigen_of = (int *)calloc(64 * PAMLH_MAXEIG, sizeof(int));
+   for (i = 0; i < PAMLH_MAXEIG; i++) q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = NULL;
    /* frequencies of this gene alone, then the one-gene parameter count */
    if (q->seqtype == 1) freqs_codon(q); else freqs_base_aa(q);
    if (q->seqtype == 0 && q->model == T92) { q->pi_data[0] = q->pi_data[2] = (q->pi_data[0] + q->pi_data[2]) / 2; q->pi_data[1] = q->pi_data[3] = (q->pi_data[1] + q->pi_data[3]) / 2; }
@@ -1220,8 +1287,8 @@ pamlh *pamlh_state_clone(const pamlh *p)
    q->gene_eigen_of = NULL;
    q->freqK = (double *)calloc(64, sizeof(double));
    q->rate = (double *)calloc(64, sizeof(double));
-   q->eigen_of = (int *)calloc(64, sizeof(int));
-   for (i = 0; i < 64; i++) q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = NULL;
+   q->eigen_of = (int *)calloc(64 * PAMLH_MAXEIG, sizeof(int));
+   for (i = 0; i < PAMLH_MAXEIG; i++) q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = NULL;
    return q;
 }
 
@@ -1229,7 +1296,7 @@ void pamlh_state_free(pamlh *q)
 {
    int i;
    if (!q) return;
-   for (i = 0; i < 64; i++) { free(q->eig[i].U); free(q->eig[i].V); free(q->eig[i].Root); free(q->eig[i].Cijk); }
+   for (i = 0; i < PAMLH_MAXEIG; i++) { free(q->eig[i].U); free(q->eig[i].V); free(q->eig[i].Root); free(q->eig[i].Cijk); }
    free(q->branch); free(q->pi); free(q->freqK); free(q->rate); free(q->eigen_of); free(q->gene_eigen_of);
    free(q);
 }
@@ -1403,7 +1470,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
          else if (p->nssites == 8) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); if (!p->fix_omega) NAME("ws"); }
       }
       else if (p->seqtype == 2) { if (p->aa_model == 6 && !p->fix_kappa) NAME("kappa"); }
-      else if (p->seqtype == 0) {
+      else if (p->seqtype == 0 && p->nhomo < 2) {
          if (p->model == UNREST) { for (j = 0; j < 11; j++) NAME("rate %d%s", j + 1, sfx); }
          else if (p->model == REV) { static const char *const r[5] = {"a (TC)", "b (TA)", "c (TG)", "d (CA)", "e (CG)"}; for (j = 0; j < 5; j++) NAME("%s%s", r[j], sfx); }
          else if (p->model == TN93 && !p->fix_kappa) { NAME("kappa1%s", sfx); NAME("kappa2%s", sfx); }
@@ -1411,6 +1478,10 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
       }
    }
    if (p->seqtype == 0 && p->nhomo == 1) { if (p->model == T92) NAME("GC content"); else { NAME("pi_T"); NAME("pi_C"); NAME("pi_A"); } }
+   if (p->seqtype == 0 && p->nhomo >= 2) {
+      for (j = 0; j < pamlh_nh_nrate(p); j++) NAME("rate parameter %d", j + 1);
+      for (j = 0; j < (p->nhomo > 2 ? pamlh_nh_npi(p) : 0); j++) { if (p->model == T92) NAME("GC content (set %d)", j + 1); else { NAME("pi_T (set %d)", j + 1); NAME("pi_C (set %d)", j + 1); NAME("pi_A (set %d)", j + 1); } }
+   }
    if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) NAME("alpha");
    if (!p->fix_rho) NAME("rho");
 #undef NAME

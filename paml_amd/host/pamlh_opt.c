@@ -218,6 +218,11 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
       for (i = 0; i < nk; i++) { lo[k] = 1e-4; hi[k++] = 999; }
    }
    if (p->seqtype == 0 && p->nhomo == 1) for (i = 0; i < (p->model == T92 ? 1 : 3); i++) { lo[k] = 1e-5; hi[k++] = 0.99999; }
+   if (p->seqtype == 0 && p->nhomo >= 2) {      /* replaces the homogeneous model's rate parameters */
+      k = p->ntime;
+      for (i = 0; i < pamlh_nh_nrate(p); i++) { lo[k] = 1e-4; hi[k++] = 999; }
+      for (i = 0; i < (p->nhomo > 2 ? pamlh_nh_npi(p) * (p->model == T92 ? 1 : 3) : 0); i++) { lo[k] = 1e-5; hi[k++] = 0.99999; }
+   }
    if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) { lo[k] = 0.005; hi[k++] = 99; }
    if (!p->fix_rho) { lo[k] = -0.2; hi[k++] = 0.99; }
    return k == p->np ? 0 : -1;

@@ -310,7 +310,7 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtyp
             rows = re.findall(r"^\s*\d+ \S\s+((?:[01]\.\d{5}\s+)+)\(\s*\d+\)", blk, re.M)
             ls = int([ln for ln in res1["lnf"] if ln.split()][0].split()[1])
             tables[key] = [[float(v) for v in r.split()] for r in rows[:ls]]
-    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha") if k in ctl_over}),
+    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa") if k in ctl_over}),
                                              x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
 
 
@@ -588,6 +588,12 @@ CASES = {
     "brown_hky85_g4_rates": case_brown_rates,
     "brown_hky85_joint": case_brown_joint,
     "brown_hky85_nhomo1": lambda: case_mle("brown_hky85_nhomo1", dict(seqfile="brown.nuc", treefile="brown.trees", model=4, kappa=5, nhomo=1), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
+    # non-homogeneous models (Yang & Roberts 1995): a kappa per branch (2); frequency sets per tip branch / internal branches / root
+    # with a kappa per branch (3, N1); a frequency set at every node with one kappa (4, N2 with fix_kappa = 1)
+    "brown_hky85_nhomo2": lambda: case_mle("brown_hky85_nhomo2", dict(seqfile="brown.nuc", treefile="brown.trees", model=4, kappa=5, nhomo=2), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
+    "brown_hky85_nhomo3": lambda: case_mle("brown_hky85_nhomo3", dict(seqfile="brown.nuc", treefile="brown.trees", model=4, kappa=5, nhomo=3), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
+    "brown_f84_nhomo4": lambda: case_mle("brown_f84_nhomo4", dict(seqfile="brown.nuc", treefile="brown.trees", model=3, kappa=5, nhomo=4, fix_kappa=1), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
+    "brown_t92_nhomo3_g4": lambda: case_mle("brown_t92_nhomo3_g4", dict(seqfile="brown.nuc", treefile="brown.trees", model=5, kappa=5, nhomo=3, fix_kappa=1, fix_alpha=0, alpha=0.5, ncatG=4), BROWN, 5, "nuc", prog="baseml", seqtype="nuc"),
     "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
                                     {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,

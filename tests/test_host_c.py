@@ -28,7 +28,11 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("hiv_m10", "codeml", "hiv_ns10.ctl"), ("hiv_m11", "codeml", "hiv_ns11.ctl"), ("hiv_m12", "codeml", "hiv_ns12.ctl"),
          ("hiv_m13", "codeml", "hiv_ns13.ctl"), ("ecp_m2arel", "codeml", "ecp_m2arel.ctl"),
          ("brown_hky85_clock", "baseml", "brown_hky85_clock.ctl"),      # global clock: x holds the node ages
-         ("brown_f84", "baseml", "brown_f84.ctl"), ("brown_t92_g4", "baseml", "brown_t92_g4.ctl"), ("brown_unrest", "baseml", "brown_unrest.ctl"), ("brown_hky85_nhomo1", "baseml", "brown_hky85_nhomo1.ctl"), ("mhc_m0_prop", "codeml", "mhc_m0_prop.ctl"), ("stewart_eqinput", "codeml", "stewart_eqinput.ctl"),
+         ("brown_f84", "baseml", "brown_f84.ctl"), ("brown_t92_g4", "baseml", "brown_t92_g4.ctl"), ("brown_unrest", "baseml", "brown_unrest.ctl"), ("brown_hky85_nhomo1", "baseml", "brown_hky85_nhomo1.ctl"),
+         # non-homogeneous models: a kappa per branch (2); frequency sets per branch (3: tips / internal / root, 4: every node), every
+         # branch with its own eigen system (one label per node); the nhomo3 estimate has a frequency on the boundary (0.000000)
+         ("brown_hky85_nhomo2", "baseml", "brown_hky85_nhomo2.ctl"), ("brown_hky85_nhomo3", "baseml", "brown_hky85_nhomo3.ctl"),
+         ("brown_f84_nhomo4", "baseml", "brown_f84_nhomo4.ctl"), ("brown_t92_nhomo3_g4", "baseml", "brown_t92_nhomo3_g4.ctl"), ("mhc_m0_prop", "codeml", "mhc_m0_prop.ctl"), ("stewart_eqinput", "codeml", "stewart_eqinput.ctl"),
          ("hiv_m0_f3x4mg", "codeml", "hiv_ns0_cf5.ctl"), ("hiv_m0_f1x4mg", "codeml", "hiv_ns0_cf4.ctl"),      # Muse-Gaut style rates
          # option G (several genes): rates only (Mgene 0), + frequencies (2), + kappa / omega (3), both (4); one with gamma
          ("horai_mg0", "baseml", "horai_mg0.ctl"), ("horai_mg2", "baseml", "horai_mg2.ctl"), ("horai_mg3", "baseml", "horai_mg3.ctl"),
@@ -293,6 +297,19 @@ def test_c_host_clade_model_neb_and_beb_match_the_reference_rst(gname, ctl):
     beb = a.beb_acd(x)
     assert beb.shape == (3, g["ls"])
     assert np.max(np.abs(beb.T - np.array(g["beb_post"]))) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname", ["brown_hky85_nhomo2", "brown_t92_nhomo3_g4", "brown_f84_nhomo4"])
+def test_c_host_optimiser_on_nonhomogeneous_models(gname):
+    """nhomo = 2 (seven kappas), 3 with T92 + gamma (seven GC contents, one kappa, alpha) and 4 with F84 (eight frequency sets):
+    one eigen system per branch, selected through the engine's branch labels; from the control file's initial values the
+    optimiser reaches the reference's maximum (or a slightly better point: these surfaces are flat in the frequency sets)."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, gname + ".ctl"), "baseml")
+    r = a.optimize(a.default_x(), max_iter=2000)
+    assert r["lnL"] - g["mle_lnL"] > -2e-3, (r["lnL"], g["mle_lnL"], r["converged"])
+    assert r["lnL"] - g["mle_lnL"] < 0.5
 
 
 @pytest.mark.gpu
