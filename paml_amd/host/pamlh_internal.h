@@ -70,6 +70,7 @@ struct pamlh {
    int use_qf;
    double ns_mr;           /* NSsites: mean rate at the mean omega = 1 / Qfactor_NS of the last pamlh_set_x */
    /* aaDist = 7 (AAClasses, codeml.c:4079 GetOmegaAA): dN/dS classes of amino-acid pairs, from OmegaAA.dat beside the ctl */
+   int opt_transformed;      /* pamlh_optimize is iterating on transformed proportions (pamlh_opt.c) */
    int aadist, n_omega_type;
    signed char omega_class[26][26];   /* by amino-acid letters: class of the pair, -1 = no one-step change under the code */
    /* optimiser state (pamlh_opt.c) */
@@ -85,6 +86,7 @@ struct pamlh {
 };
 
 /* numerics (pamlh_num.c) */
+int pamlh_simplex_groups(const pamlh *p, int *start, int *len, int cap);
 int pamlh_nh_nrate(const pamlh *p);      /* nhomo >= 2: rate parameters, frequency sets (baseml.c:1201-1232) */
 int pamlh_nh_npi(const pamlh *p);
 void pamlh_eigen_sym(double *A, int n, double *w, double *R);

@@ -115,10 +115,55 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       if (gr) { gr[(size_t)b * G] = 1; for (i = 1; i < G; i++) gr[(size_t)b * G + i] = x[nt + i - 1]; }
    }
    /* (with several genes the tables are [gene][class]: one label, and L counts the genes) */
-   if ((rc = paml_amd_set_pi(p->eng, n_pi, pi)) || (rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, G > 1 ? 1 : L, rep_eo, use_qf ? rep_qf : NULL)) ||
-       (rc = paml_amd_eval_batch(p->eng, nb, br, gr, eo, use_qf ? qf : NULL, fk, rt, lnL, lnf))) {
-      rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
-      goto done;
+   if ((rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, G > 1 ? 1 : L, rep_eo, use_qf ? rep_qf : NULL))) { rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); goto done; }
+   {
+      /* The engine evaluates a batch under ONE set of root frequencies (paml_amd_set_pi).  Where the frequencies are parameters
+       * (nhomo = 1, 3, 4: com.pi is part of x) the elements are evaluated in groups of equal frequencies: a gradient batch is one
+       * group for all the branch-length elements and one small group per perturbed model parameter. */
+      const size_t pib = (size_t)n_pi * p->n * sizeof(double);
+      int *grp = (int *)malloc(nb * sizeof(int)), ngrp = 0, gsel;
+      const double **gpi = (const double **)malloc(nb * sizeof(double *));
+      for (b = 0; b < nb; b++) {
+         const int cb = cand_of[b] < 0 ? -1 - cand_of[b] : cand_of[b];
+         const double *mypi = ws[cb] ? ws[cb]->pi : pi;
+         for (gsel = 0; gsel < ngrp; gsel++) if (!memcmp(gpi[gsel], mypi, pib)) break;
+         if (gsel == ngrp) gpi[ngrp++] = mypi;
+         grp[b] = gsel;
+      }
+      if (ngrp == 1) {
+         if ((rc = paml_amd_set_pi(p->eng, n_pi, gpi[0])) || (rc = paml_amd_eval_batch(p->eng, nb, br, gr, eo, use_qf ? qf : NULL, fk, rt, lnL, lnf)))
+            rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+      }
+      else {
+         double *sbr = (double *)malloc((size_t)nb * nn * sizeof(double)), *sfk = (double *)malloc((size_t)nb * K * sizeof(double)), *srt = (double *)malloc((size_t)nb * K * sizeof(double));
+         double *sqf = (double *)malloc((size_t)nb * K * L * sizeof(double)), *sgr = gr ? (double *)malloc((size_t)nb * G * sizeof(double)) : NULL;
+         double *sl = (double *)malloc(nb * sizeof(double)), *slf = lnf ? (double *)malloc((size_t)nb * p->npatt * sizeof(double)) : NULL;
+         int *seo = (int *)malloc((size_t)nb * K * L * sizeof(int)), *idx = (int *)malloc(nb * sizeof(int));
+         for (gsel = 0; gsel < ngrp && !rc; gsel++) {
+            int m = 0;
+            for (b = 0; b < nb; b++) {
+               if (grp[b] != gsel) continue;
+               memcpy(sbr + (size_t)m * nn, br + (size_t)b * nn, nn * sizeof(double));
+               memcpy(sfk + (size_t)m * K, fk + (size_t)b * K, K * sizeof(double));
+               memcpy(srt + (size_t)m * K, rt + (size_t)b * K, K * sizeof(double));
+               memcpy(sqf + (size_t)m * K * L, qf + (size_t)b * K * L, (size_t)K * L * sizeof(double));
+               memcpy(seo + (size_t)m * K * L, eo + (size_t)b * K * L, (size_t)K * L * sizeof(int));
+               if (sgr) memcpy(sgr + (size_t)m * G, gr + (size_t)b * G, G * sizeof(double));
+               idx[m++] = b;
+            }
+            if ((rc = paml_amd_set_pi(p->eng, n_pi, gpi[gsel])) || (rc = paml_amd_eval_batch(p->eng, m, sbr, sgr, seo, use_qf ? sqf : NULL, sfk, srt, sl, slf))) {
+               rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+               break;
+            }
+            for (i = 0; i < m; i++) {
+               lnL[idx[i]] = sl[i];
+               if (lnf) memcpy(lnf + (size_t)idx[i] * p->npatt, slf + (size_t)i * p->npatt, p->npatt * sizeof(double));
+            }
+         }
+         free(sbr); free(sfk); free(srt); free(sqf); free(sgr); free(sl); free(slf); free(seo); free(idx);
+      }
+      free(grp); free(gpi);
+      if (rc) goto done;
    }
    for (b = 0; b < nb; b++)
       if (cand_of[b] < 0 || cand_rep[cand_of[b]] < 0 || !(lnL[b] == lnL[b])) lnL[b] = -1e300;
@@ -138,16 +183,75 @@ static void clock_rec_y_to_x(const pamlh *p, int node, const double *y, double *
    for (j = p->sons_ptr[node]; j < p->sons_ptr[node + 1]; j++) clock_rec_y_to_x(p, p->sons[j], y, x);
 }
 
+/* Proportions that sum to at most 1 (site-class proportions, base-frequency sets: k free values, the last category takes the
+ * rest) are iterated on as y_i = log(p_i / p_last), p_i = e^{y_i} / (1 + sum_j e^{y_j}) — the reference's own transformation while
+ * it iterates (f_and_x tools.c:2016, LASTROUND = 0): no point of the box is infeasible and a class that vanishes at the maximum
+ * is a bound of the box.  Groups as (first index, k) in x. */
+#define Y_SIMPLEX 30.0
+int pamlh_simplex_groups(const pamlh *p, int *start, int *len, int cap)
+{
+   int n = 0, j;
+   const int k0 = p->ntime + (p->ngene - 1);
+   if (p->ngene > 1) return 0;
+   if (p->seqtype == 1) {
+      const int k = k0 + !p->fix_kappa;
+      int m = 0;
+      if (p->aadist == 7) m = 0;
+      else if (p->model >= 2 && p->nssites) m = 2;
+      else if (p->model == 0 && (p->nssites == 2 || p->nssites == 12 || p->nssites == 13)) m = 2;
+      else if (p->model == 0 && p->nssites == 3) m = p->ncatG - 1;
+      else if (p->model == 0 && p->nssites == 4) m = 4;
+      if (m >= 2 && n < cap) { start[n] = k; len[n++] = m; }
+   }
+   else if (p->seqtype == 0 && p->model != T92) {
+      if (p->nhomo == 1 && n < cap) {
+         const int nk = ((p->model == K80 || p->model == HKY85 || p->model == F84) && !p->fix_kappa) ? 1 : (p->model == TN93 && !p->fix_kappa) ? 2 : p->model == REV ? 5 : 0;
+         start[n] = k0 + nk; len[n++] = 3;
+      }
+      if (p->nhomo > 2)
+         for (j = 0; j < pamlh_nh_npi(p) && n < cap; j++) { start[n] = p->ntime + pamlh_nh_nrate(p) + 3 * j; len[n++] = 3; }
+   }
+   return n;
+}
+
+static void simplex_y_to_x(const pamlh *p, double *x)      /* in place */
+{
+   int start[PAMLH_MAXEIG + 4], len[PAMLH_MAXEIG + 4], n = pamlh_simplex_groups(p, start, len, PAMLH_MAXEIG + 4), g, i;
+   for (g = 0; g < n; g++) {
+      double *v = x + start[g], t = 1, mx = 0;
+      for (i = 0; i < len[g]; i++) if (v[i] > mx) mx = v[i];
+      t = exp(-mx);
+      for (i = 0; i < len[g]; i++) { v[i] = exp(v[i] - mx); t += v[i]; }
+      for (i = 0; i < len[g]; i++) v[i] /= t;
+   }
+}
+
+static void simplex_x_to_y(const pamlh *p, double *x)      /* in place */
+{
+   int start[PAMLH_MAXEIG + 4], len[PAMLH_MAXEIG + 4], n = pamlh_simplex_groups(p, start, len, PAMLH_MAXEIG + 4), g, i;
+   for (g = 0; g < n; g++) {
+      double *v = x + start[g], last = 1;
+      for (i = 0; i < len[g]; i++) last -= v[i];
+      if (last < 1e-15) last = 1e-15;      /* (the difference of doubles near 1 resolves no less) */
+      for (i = 0; i < len[g]; i++) {
+         const double y = log((v[i] > 1e-300 ? v[i] : 1e-300) / last);
+         v[i] = y < -Y_SIMPLEX ? -Y_SIMPLEX : y > Y_SIMPLEX ? Y_SIMPLEX : y;
+      }
+   }
+}
+
 static void clock_y_to_x(const pamlh *p, const double *y, double *x)
 {
    memcpy(x, y, p->np * sizeof(double));
    if (p->clock) clock_rec_y_to_x(p, p->root, y, x);
+   simplex_y_to_x(p, x);
 }
 
 static void clock_x_to_y(const pamlh *p, const double *x, double *y)
 {
    int node;
    memcpy(y, x, p->np * sizeof(double));
+   simplex_x_to_y(p, y);
    if (!p->clock) return;
    for (node = p->ns; node < p->nnode; node++)
       if (node != p->root) { const double fa = x[p->father[node] - p->ns]; y[node - p->ns] = fa > 0 ? x[node - p->ns] / fa : 0; }
@@ -158,7 +262,7 @@ static int batch_eval(pamlh *p, int nb, const double *ys, double *lnL)
 {
    double *xs;
    int b, rc;
-   if (!p->clock) return pamlh_eval_batch_gpu(p, nb, ys, lnL);
+   if (!p->clock && !p->opt_transformed) return pamlh_eval_batch_gpu(p, nb, ys, lnL);
    xs = (double *)malloc((size_t)nb * p->np * sizeof(double));
    for (b = 0; b < nb; b++) clock_y_to_x(p, ys + (size_t)b * p->np, xs + (size_t)b * p->np);
    rc = pamlh_eval_batch_gpu(p, nb, xs, lnL);
@@ -279,29 +383,36 @@ static int gradient(pamlh *p, const double *x, double f0, const double *lo, cons
 static int diag_inverse_hessian(pamlh *p, const double *x, double f0, const double *lo, const double *hi, double *H, double *xs, double *ls, int *n_eval)
 {
    const int n = p->np;
-   int i, rc, m = 0;
+   int i, rc, m = 0, nq = 0;
    double *hd = (double *)malloc(2 * n * sizeof(double)), *srt = hd + n, med;
+   int *slot = (int *)malloc(n * sizeof(int));
    for (i = 0; i < n; i++) {
       const double h = 1e-4 * (fabs(x[i]) + 1);
-      double *xp = xs + (size_t)(2 * i) * n, *xm = xp + n;
+      double *xp, *xm;
+      slot[i] = -1;
+      if (x[i] + h > hi[i] || x[i] - h < lo[i] || (p->frozen && p->frozen[i])) continue;      /* no room for a symmetric difference / held */
+      slot[i] = nq;
+      xp = xs + (size_t)(2 * nq) * n; xm = xp + n;
       memcpy(xp, x, n * sizeof(double));
       memcpy(xm, x, n * sizeof(double));
       xp[i] = x[i] + h; xm[i] = x[i] - h;
-      if (xp[i] > hi[i] || xm[i] < lo[i] || (p->frozen && p->frozen[i])) xp[i] = xm[i] = x[i];      /* no room for a symmetric difference */
+      nq++;
    }
-   if ((rc = batch_eval(p, 2 * n, xs, ls))) { free(hd); return rc; }
-   *n_eval += 2 * n;
+   if (nq && (rc = batch_eval(p, 2 * nq, xs, ls))) { free(hd); free(slot); return rc; }
+   *n_eval += 2 * nq;
    for (i = 0; i < n; i++) {
-      const double *xp = xs + (size_t)(2 * i) * n;
-      const double h = xp[i] - x[i], c = h > 0 ? ((-ls[2 * i]) - 2 * f0 + (-ls[2 * i + 1])) / (h * h) : 0;
-      hd[i] = (c > 1e-3 && c < 1e12 && ls[2 * i] > -1e299 && ls[2 * i + 1] > -1e299) ? 1 / c : 0;
+      hd[i] = 0;
+      if (slot[i] >= 0) {
+         const double h = 1e-4 * (fabs(x[i]) + 1), lp = ls[2 * slot[i]], lm = ls[2 * slot[i] + 1], c = ((-lp) - 2 * f0 + (-lm)) / (h * h);
+         hd[i] = (c > 1e-3 && c < 1e12 && lp > -1e299 && lm > -1e299) ? 1 / c : 0;
+      }
       if (hd[i] > 0) srt[m++] = hd[i];
    }
    for (i = 1; i < m; i++) { double v = srt[i]; int j = i - 1; while (j >= 0 && srt[j] > v) { srt[j + 1] = srt[j]; j--; } srt[j + 1] = v; }
    med = m ? srt[m / 2] : 1;
    for (i = 0; i < n * n; i++) H[i] = 0;
    for (i = 0; i < n; i++) H[i * n + i] = hd[i] > 0 ? hd[i] : med;
-   free(hd);
+   free(hd); free(slot);
    return 0;
 }
 
@@ -319,19 +430,31 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
    int it, i, j, k, rc = 0, n_eval = 0, reset = 1, small_steps = 0, status = 1, restarts = 0, fresh = 1;
    if (n == 0) { rc = batch_eval(p, 1, x, lnL); status = 0; goto done; }
    if (pamlh_bounds(p, lo, hi)) { rc = pamlh_fail(p, "internal: bounds do not match np"); goto done; }
-   if (p->clock) {         /* iterate on (root age, age ratios): see clock_y_to_x */
-      double *y = (double *)malloc(n * sizeof(double));
-      clock_x_to_y(p, x, y);
-      memcpy(x, y, n * sizeof(double));
-      free(y);
-      for (i = 0; i < p->ntime; i++) { lo[i] = (p->ns + i == p->root) ? 1e-5 : 1e-8; hi[i] = (p->ns + i == p->root) ? 50 : 1; }
+   {
+      int start[PAMLH_MAXEIG + 4], len[PAMLH_MAXEIG + 4];
+      const int ng = pamlh_simplex_groups(p, start, len, PAMLH_MAXEIG + 4);
+      p->opt_transformed = ng > 0;
+      if (p->clock || ng) {         /* iterate on (root age, age ratios) and on log-ratios of proportions: see clock_y_to_x */
+         double *y = (double *)malloc(n * sizeof(double));
+         for (i = 0; i < n; i++) {      /* (not the proportions: their box is that of the transformed variables) */
+            int in_group = 0;
+            for (j = 0; j < ng; j++) if (i >= start[j] && i < start[j] + len[j]) in_group = 1;
+            if (!in_group) x[i] = x[i] < lo[i] ? lo[i] : x[i] > hi[i] ? hi[i] : x[i];
+         }
+         clock_x_to_y(p, x, y);
+         memcpy(x, y, n * sizeof(double));
+         free(y);
+         if (p->clock) for (i = 0; i < p->ntime; i++) { lo[i] = (p->ns + i == p->root) ? 1e-5 : 1e-8; hi[i] = (p->ns + i == p->root) ? 50 : 1; }
+         for (j = 0; j < ng; j++) for (i = 0; i < len[j]; i++) { lo[start[j] + i] = -Y_SIMPLEX; hi[start[j] + i] = Y_SIMPLEX; }
+      }
    }
    for (i = 0; i < n; i++) x[i] = x[i] < lo[i] ? lo[i] : x[i] > hi[i] ? hi[i] : x[i];
    if ((rc = batch_eval(p, 1, x, ls))) goto done;
    n_eval++;
    f = -ls[0];
    if (f > 1e299) { rc = pamlh_fail(p, "the starting point is infeasible"); goto done; }
-   if (p->opt_lean) { for (i = 0; i < n * n; i++) H[i] = 0; for (i = 0; i < n; i++) H[i * n + i] = 1; reset = 1; }
+   if (verbose) printf("start     lnL %.6f\n", -f);
+   if (p->opt_lean == 1) { for (i = 0; i < n * n; i++) H[i] = 0; for (i = 0; i < n; i++) H[i * n + i] = 1; reset = 1; }      /* (2: lean, but from second differences) */
    else {
       if ((rc = diag_inverse_hessian(p, x, f, lo, hi, H, xs, ls, &n_eval))) goto done;
       reset = 0;
@@ -447,10 +570,12 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
       }
    }
    *lnL = -f;
-   if (p->clock) { double *y = (double *)malloc(n * sizeof(double)); memcpy(y, x, n * sizeof(double)); clock_y_to_x(p, y, x); free(y); }
+   if (p->clock || p->opt_transformed) { double *y = (double *)malloc(n * sizeof(double)); memcpy(y, x, n * sizeof(double)); clock_y_to_x(p, y, x); free(y); }
+   p->opt_transformed = 0;
    /* leave the model state at the estimate */
    if (pamlh_set_x(p, x, n)) rc = -1;
 done:
+   p->opt_transformed = 0;
    if (n_eval_out) *n_eval_out = n_eval;
    free(lo); free(hi); free(g); free(g0); free(d); free(s); free(y); free(Hy); free(H); free(xs); free(ls); free(fixed);
    return rc ? rc : status;
@@ -525,12 +650,14 @@ int pamlh_optimize_minb(pamlh *p, double *x, double *lnL, double e0, int verbose
 {
    const int np = p->np, npcom = np - p->ntime, maxr = npcom ? 200 : 1;
    double e = npcom ? 5.0 : e0, e_mb = e, L = 0, L0 = -1e300, dl;
-   int ir, i, rc = 0, status = 1, n_eval = 0, ne;
+   int ir, i, rc = 0, status = 1, n_eval = 0, ne, calm = 0;
    unsigned char *frozen = (unsigned char *)calloc(np ? np : 1, 1);
    for (i = 0; i < p->ntime; i++) frozen[i] = 1;
    for (ir = 0; ir < maxr; ir++) {
       if (npcom) {
-         p->frozen = frozen; p->opt_lean = 1; p->opt_abs_tol = e;
+         /* (a round that gained less than the tolerance is checked by one that starts from second differences instead of the
+          *  identity: it must have been the maximum, not a badly scaled first step) */
+         p->frozen = frozen; p->opt_lean = calm ? 2 : 1; p->opt_abs_tol = e;
          rc = pamlh_optimize(p, x, &L, e > 0.05 ? 2 : 30, 1e-10, 0, &ne);
          p->frozen = NULL; p->opt_lean = 0; p->opt_abs_tol = 0;
          n_eval += ne;
@@ -540,7 +667,8 @@ int pamlh_optimize_minb(pamlh *p, double *x, double *lnL, double e0, int verbose
       if ((rc = pamlh_minbranches(p, x, e_mb, &L, verbose > 1))) goto done;
       if (verbose) fprintf(stderr, "round %db: branch lengths, lnL %.6f (e = %.3g)\n", ir + 1, L, e_mb);
       dl = fabs(L - L0);
-      if (dl < e0 && e <= 0.02) { status = 0; break; }
+      calm = (dl < e0 && e <= 0.02) ? calm + 1 : 0;
+      if (calm >= 2 || (calm && !npcom)) { status = 0; break; }
       e /= 2; if (dl < 1) e /= 2;
       if (dl < 0.5) e = fmin(e, 1e-3);
       else if (dl > 10) e = fmax(e, 0.1);
