@@ -125,6 +125,11 @@ int paml_amd_set_eigen_qmat(paml_amd_engine *e, int set_id, const double *Q);
 int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freqK, const double *rate, int n_labels,
                          const int *eigen_of, const double *qfactor);
 
+/* Malpha = 1 (a gamma shape per gene: lfundG calls SetPGene for every gene, which runs DiscreteGamma with that gene's alpha,
+ * treesub.c:7627-7629, codeml.c:2441 / baseml.c:1460): class rates per gene, rate[n_genes][K], replacing the rate[K] of the
+ * last set_classes (which also switches back).  With it, the `rate` argument of paml_amd_eval_batch is [n_batch][n_genes][K]. */
+int paml_amd_set_gene_class_rates(paml_amd_engine *e, const double *rate);
+
 /* One com.plfun call (codeml.c:748): batched P(t) for every branch x class x gene, fused pruning,
  * root / class-mixture / weighted-log reduction.  branch[n_nodes] = nodes[].branch, gene_rate =
  * com.rgene (NULL = 1).  Returns +lnL (the reference returns -lnL).  lnf[n_patt] (log f_h as

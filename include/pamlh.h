@@ -65,6 +65,7 @@ const double *pamlh_adg_matrix(const pamlh *p);         /* [K][K] auto-discrete-
  * caller frees it with pamlh_free. */
 int pamlh_gene_subset(const pamlh *p, int g, pamlh **out);
 int pamlh_mgene(const pamlh *p);                       /* the Mgene option in effect (0 with one gene) */
+int pamlh_malpha(const pamlh *p);      /* 1: a gamma shape per gene (Malpha); pamlh_rate() then returns [n_genes][K] */
 int pamlh_genes(const pamlh *p, const int **gene_off, const double **gene_rate, int *n_pi, const int **gene_eigen_of);            /* [K][n_labels] time scale per (class, branch type); NULL = all 1 */
 /* eigen system i: kind (paml_amd.h), and pointers (NULL when not applicable) */
 int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const double **U, const double **V,

@@ -127,7 +127,7 @@ void orc_pmat_branch(const orc_problem *pb, int gene, int iclass, int node, doub
 {
    int n = pb->n, lab = pb->label ? pb->label[node] : 0;
    const orc_eigen *es = &pb->eigen[pb->eigen_of[((size_t)gene * pb->K + iclass) * pb->n_labels + lab]];
-   double t = pb->branch[node] * pb->rate[iclass];
+   double t = pb->branch[node] * pb->rate[gene * pb->rate_gs + iclass];
    t *= (pb->gene_rate ? pb->gene_rate[gene] : 1.0);
    g_npmat++;
    switch (es->kind) {
@@ -524,7 +524,7 @@ int orc_eval_branch(const orc_problem *pb, int node_b, int n_t, const double *t,
                /* the reference reaches these models through Cijk of eigenTN93 (kappa1 = kappa2); the closed forms of
                 * PMatK80 / PMatJC69like are the same functions of t:  P = 1/n + c1 e^{t mu1} + c2 e^{t mu2} */
                int k80 = es->kind == ORC_EIGEN_K80;
-               double base = (pb->gene_rate ? pb->gene_rate[ig] : 1.0) * pb->rate[ir];
+               double base = (pb->gene_rate ? pb->gene_rate[ig] : 1.0) * pb->rate[ig * pb->rate_gs + ir];
                double m1 = base * (k80 ? -4 / (es->kappa + 2) : -(double)n / (n - 1));
                double m2 = base * (k80 ? -2 * (es->kappa + 1) / (es->kappa + 2) : 0.0);
                double e1 = exp(t[it] * m1), e2 = k80 ? exp(t[it] * m2) : 0.0;
@@ -541,7 +541,7 @@ int orc_eval_branch(const orc_problem *pb, int node_b, int n_t, const double *t,
             }
             for (k = 0; k < nroot; k++) {
                /* treesub.c:8479-8483: multiply = rgene * Root[k] * _rateSite [* Qfactor_NS_branch] */
-               double multiply = (pb->gene_rate ? pb->gene_rate[ig] : 1.0) * es->Root[k] * pb->rate[ir] * qf;
+               double multiply = (pb->gene_rate ? pb->gene_rate[ig] : 1.0) * es->Root[k] * pb->rate[ig * pb->rate_gs + ir] * qf;
                double expt = k ? exp(t[it] * multiply) : 1.0;
                for (i = 0; i < n; i++)
                   for (j = 0; j < n; j++) {

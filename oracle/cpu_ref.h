@@ -62,6 +62,7 @@ typedef struct {
    const double *qfactor;/* Qfactor for (class, label): [K][n_labels] (treesub.c:7549, 7587) */
    const double *branch; /* nodes[i].branch, [n_nodes] (root entry unused) */
    long z_stride;        /* row stride of z; 0 = n_patt */
+   int rate_gs;          /* Malpha (a gamma shape per gene, SetPGene baseml.c:1460): rate is [n_genes][K] and this is K; else 0 */
 } orc_problem;
 
 /* P(t) builders */

@@ -29,7 +29,7 @@ class _Problem(C.Structure):
         ("gene_rate", C.c_void_p), ("n_pi", C.c_int), ("pi", C.c_void_p), ("n_eigen", C.c_int),
         ("eigen", C.POINTER(_Eigen)), ("mode", C.c_int), ("K", C.c_int), ("freqK", C.c_void_p),
         ("rate", C.c_void_p), ("n_labels", C.c_int), ("eigen_of", C.c_void_p), ("qfactor", C.c_void_p),
-        ("branch", C.c_void_p), ("z_stride", C.c_long),
+        ("branch", C.c_void_p), ("z_stride", C.c_long), ("rate_gs", C.c_int),
     ]
 
 
@@ -102,6 +102,7 @@ class _Packed:
         s.mode, s.K, s.freqK, s.rate = int(pb.mode), pb.K, _ptr(pb.freqK), _ptr(pb.rate)
         s.n_labels, s.eigen_of, s.qfactor = pb.n_labels, _ptr(pb.eigen_of), _ptr(pb.qfactor)
         s.branch = _ptr(branch)
+        s.rate_gs = pb.K if getattr(pb, "rate_per_gene", False) else 0
         self.s = s
 
 

@@ -199,6 +199,7 @@ struct paml_amd_engine {
    size_t h_out_cap = 0;
    bool fused = false;                // the selected kernel forms the reduction itself
    bool fused_mfma4 = false;
+   bool rate_per_gene = false;      // paml_amd_set_gene_class_rates: class rates [n_genes][K]
    bool want_m20 = false, m20 = false;      // 20 states on v_mfma_f64_4x4x4 (jit_generate_m20)
    int fused_threads = 256;
    bool pmat_valid = false;           // d_rowmajor holds the P(t) of an evaluation in the tree's own orientation
@@ -561,7 +562,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          }
          const double *src[3] = {bs->qfactor, bs->freqK, bs->rate};
          DevBuf<double> *dst[3] = {&e->d_b_qfactor, &e->d_b_freqK, &e->d_b_rate};
-         const size_t cnt[3] = {(size_t)B * Km * L, (size_t)B * Km, (size_t)B * Km};
+         const size_t cnt[3] = {(size_t)B * Km * L, (size_t)B * Km, (size_t)B * Km * (e->rate_per_gene ? G : 1)};
          for (int i = 0; i < 3; i++)
             if (src[i]) {
                HIPCHK(dst[i]->ensure(cnt[i]));
@@ -720,7 +721,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pa.B = B; pa.branch_bs = nn; pa.gene_rate_bs = G; pa.pcol = e->kk == KK_MFMA64 ? e->d_pcol.p : nullptr;
    if (bs && bs->eigen_of) { pa.eigen_of = e->d_b_eigen_of.p; pa.eigen_of_bs = (long)G * Km * e->n_labels; }
    if (bs && bs->qfactor) { pa.qfactor = e->d_b_qfactor.p; pa.qfactor_bs = (long)Km * e->n_labels; }
-   if (bs && bs->rate) { pa.rate = e->d_b_rate.p; pa.rate_bs = Km; }
+   pa.rate_gs = e->rate_per_gene ? Km : 0;
+   if (bs && bs->rate) { pa.rate = e->d_b_rate.p; pa.rate_bs = e->rate_per_gene ? (long)G * Km : Km; }
    mark_on(e, ps);
    bool small_pmat = e->kk != KK_MFMA64 && n <= 5;
    for (const EigenHost &h : e->eigen) small_pmat = small_pmat && h.kind != PAML_AMD_EIGEN_QMAT;
@@ -987,7 +989,7 @@ int rerooted_pmat(paml_amd_engine *e, int new_root, int cut_son, const double *b
    pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
    pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
    pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
-   pa.B = 1;
+   pa.B = 1; pa.rate_gs = e->rate_per_gene ? K : 0;
    {
       InlineVec iv;
       iv.n_branch = iv.n_rate = 0;
@@ -1400,11 +1402,25 @@ int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freq
    if (qfactor) q.assign(qfactor, qfactor + (size_t)K * n_labels);
    HIPCHK(upload(e->d_freqK, f.data(), f.size(), e->stream));
    HIPCHK(upload(e->d_rate, r.data(), r.size(), e->stream));
+   e->rate_per_gene = false;
    HIPCHK(upload(e->d_qfactor, q.data(), q.size(), e->stream));
    HIPCHK(upload(e->d_eigen_of, eigen_of, (size_t)e->n_genes * K * n_labels, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
    e->mode = mode; e->K = K; e->n_labels = n_labels;
    e->have_classes = true;
+   e->partials_valid = false;
+   e->bl.valid = false;
+   return 0;
+}
+
+int paml_amd_set_gene_class_rates(paml_amd_engine *e, const double *rate)
+{
+   if (!e || !e->have_classes) return fail(e, PAML_AMD_EINVAL, "set_gene_class_rates before set_classes");
+   e->pipe_ok = false;
+   if (!rate) { e->rate_per_gene = false; return 0; }      // back to the rates of set_classes needs a new set_classes
+   HIPCHK(upload(e->d_rate, rate, (size_t)e->n_genes * e->K, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   e->rate_per_gene = true;
    e->partials_valid = false;
    e->bl.valid = false;
    return 0;
@@ -1737,7 +1753,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
       pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
       pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
-      pa.B = 1;
+      pa.B = 1; pa.rate_gs = e->rate_per_gene ? K : 0;
       {
          InlineVec iv;
          iv.n_branch = iv.n_rate = 0;
@@ -1776,6 +1792,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    if (mfma) HIPCHK(e->d_bl_frag.ensure((size_t)psets * n_t * 3 * 4096));
    DerivArgs da{};
    da.n = n; da.K = K; da.n_genes = G; da.n_labels = e->n_labels; da.n_t = n_t; da.label = T.label[node_b];
+   da.rate_gs = e->rate_per_gene ? K : 0;
    da.t = e->d_tt.p; da.rate = e->d_rate.p; da.gene_rate = e->d_gene_rate.p; da.qfactor = e->d_qfactor.p;
    da.eigen_of = e->d_eigen_of.p; da.eigen = e->d_eigen.p; da.out = e->d_deriv.p; da.frag = mfma ? e->d_bl_frag.p : nullptr;
    hipLaunchKernelGGL(pmat_deriv_kernel, dim3(n_t, psets), dim3(256), 0, st, da);

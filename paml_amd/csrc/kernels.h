@@ -49,6 +49,7 @@ struct PmatArgs {
    // branch + b*branch_bs etc. (a stride of 0 = shared with the other elements)
    int B;
    long branch_bs, gene_rate_bs, eigen_of_bs, qfactor_bs, rate_bs;
+   int rate_gs;                   // class rates per gene (Malpha: a gamma shape per gene): rate[bat][gene][class], else 0
 };
 
 // Branch lengths and gene rates handed over INSIDE the kernel arguments (single evaluations of trees with up to ~440 nodes):
@@ -64,7 +65,7 @@ __device__ __forceinline__ double pmat_time(const PmatArgs &a, const InlineVec &
    // t = branch * rateSite * rgene (codeml.c:3547-3551)
    const double br = iv.n_branch ? iv.v[node] : a.branch[bat * a.branch_bs + node];
    const double gr = iv.n_branch ? iv.v[iv.n_branch + gene] : a.gene_rate[bat * a.gene_rate_bs + gene];
-   return (br * a.rate[bat * a.rate_bs + iclass]) * gr;
+   return (br * a.rate[bat * a.rate_bs + gene * a.rate_gs + iclass]) * gr;
 }
 
 // Models with at most 5 states (the one-pattern-per-lane kernels): 32 threads per matrix, eight matrices per workgroup, no
@@ -1046,7 +1047,7 @@ __global__ __launch_bounds__(256) void reduce_stage2(const double *partial, int 
 // log f, f'/f and (f f'' - f'^2)/f^2 with a fixed-order two-level reduction.
 // ------------------------------------------------------------------------------------------------
 struct DerivArgs {
-   int n, K, n_genes, n_labels, n_t, label;
+   int n, K, n_genes, n_labels, n_t, label, rate_gs;      // rate_gs: as PmatArgs
    const double *t;            // [n_t]
    const double *rate, *gene_rate, *qfactor;
    const int *eigen_of;
@@ -1062,7 +1063,7 @@ __global__ __launch_bounds__(256) void pmat_deriv_kernel(DerivArgs a)
    const EigenDev es = a.eigen[a.eigen_of[(gene * a.K + iclass) * a.n_labels + a.label]];
    const double t = a.t[it];
    const double qf = es.kind == PAML_AMD_EIGEN_UVROOT ? a.qfactor[iclass * a.n_labels + a.label] : 1.0;
-   const double base = a.gene_rate[gene] * a.rate[iclass] * qf;
+   const double base = a.gene_rate[gene] * a.rate[gene * a.rate_gs + iclass] * qf;
    const int nroot = es.kind == PAML_AMD_EIGEN_CIJK ? es.nR : n;
    double *P = a.out + ((long)(pset * a.n_t + it) * 3) * n * n, *dP = P + n * n, *ddP = dP + n * n;
    __shared__ double sE[64], sM[64];

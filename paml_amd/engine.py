@@ -22,7 +22,7 @@ KEEP_PARTIALS = 1
 JIT = 2
 
 EXPORTS = [
-    "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
+    "paml_amd_set_gene_class_rates", "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
@@ -217,7 +217,11 @@ class Engine:
         self.set_pi(pb.pi)
         for i, e in enumerate(pb.eigen):
             self.set_eigen(i, e)
-        self.set_classes(pb.mode, pb.freqK, pb.rate, pb.eigen_of, pb.qfactor)
+        self.set_classes(pb.mode, pb.freqK, pb.rate[:pb.K] if getattr(pb, "rate_per_gene", False) else pb.rate, pb.eigen_of, pb.qfactor)
+        if getattr(pb, "rate_per_gene", False):
+            r = np.ascontiguousarray(pb.rate, dtype=np.float64).reshape(pb.n_genes * pb.K)
+            self._L.paml_amd_set_gene_class_rates.argtypes = [C.c_void_p, C.c_void_p]
+            self._chk(self._L.paml_amd_set_gene_class_rates(self._h, _p(r)))
         return self
 
     def eval(self, branch, gene_rate=None, want_lnf=False, want_fhk=False):

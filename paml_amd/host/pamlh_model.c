@@ -304,7 +304,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    /* Mgene = 1 (separate analyses, MultipleGenes baseml.c:392 / codeml.c:570): the data set itself is not evaluated; every gene
     * is taken out as an analysis of its own with pamlh_gene_subset */
    if (p->mgene < 0 || p->mgene > 4) { rc = pamlh_fail(p, "Mgene = %d?", p->mgene); goto bad; }
-   if ((int)pamlh_optd(p, "Malpha", 0) != 0) { rc = pamlh_fail(p, "Malpha (one alpha per gene) is not supported"); goto bad; }
+   p->malpha = (int)pamlh_optd(p, "Malpha", 0) != 0;      /* a gamma shape per gene (checked against the data below) */
    if (p->seqtype == 1) {
       if (p->icode != 0 && p->icode != 1) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0: universal, 1: vertebrate mt)", p->icode); goto bad; }
       /* model 0: site models; model 2, NSsites 0: branch model; model 2 / 3 with NSsites 2 / 3: branch-site A / B, clade C / D */
@@ -369,6 +369,11 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->nnode > PAMLH_MAXEIG) { rc = pamlh_fail(p, "nhomo >= 2: more than %d nodes", PAMLH_MAXEIG); goto bad; }
       if (!p->fix_rho || p->rho0 != 0) { rc = pamlh_fail(p, "nhomo with rho is not supported"); goto bad; }
    }
+   if (p->malpha && (p->ngene <= 1 || p->fix_alpha || !(p->alpha0 > 0) || p->mgene == 1)) {
+      if (p->mgene == 1 && p->ngene > 1) p->malpha = 0;      /* separate analyses: every gene has its own alpha anyway */
+      else { rc = pamlh_fail(p, "Malpha needs several genes (option G) and a free alpha > 0"); goto bad; }
+   }
+   if (p->malpha && (!p->fix_rho || p->rho0 != 0)) { rc = pamlh_fail(p, "Malpha or rho"); goto bad; }
    if (p->ngene <= 1) { if (p->mgene) { rc = pamlh_fail(p, "Mgene = %d but the sequence file has one gene (no option G)", p->mgene); goto bad; } }
    else {
       /* what the several-gene set-up covers (the reference's own exclusions: baseml.c:261-265, codeml.c:1534-1544) */
@@ -451,14 +456,14 @@ genes_ok:
          if (p->nhomo >= 2) nr = pamlh_nh_nrate(p) + (p->nhomo > 2 ? pamlh_nh_npi(p) * (p->model == T92 ? 1 : 3) : 0);
       }
       if (rep > 1) nr += (rep - 1) * (p->seqtype == 1 ? 2 : nuc_nkappa(p));      /* Mgene 3, 4: a parameter set per gene */
-      if (p->alpha0 > 0 || !p->fix_alpha) nr += !p->fix_alpha;
+      if (p->alpha0 > 0 || !p->fix_alpha) nr += p->malpha ? p->ngene : !p->fix_alpha;
       nr += !p->fix_rho;
       p->np = p->ntime + nr;
    }
    p->branch = (double *)calloc(p->nnode, sizeof(double));
    p->pi = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    p->freqK = (double *)calloc(64, sizeof(double));
-   p->rate = (double *)calloc(64, sizeof(double));
+   p->rate = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    p->eigen_of = (int *)calloc(64 * PAMLH_MAXEIG, sizeof(int));
    p->n_pi = 1;
    *out = p;
@@ -561,7 +566,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
          if (p->seqtype == 1) { x[k++] = p->kappa0; x[k++] = p->omega0; }
          else for (j = 0; j < nuc_nkappa(p); j++) x[k++] = p->model == REV ? 1 : p->kappa0;
       }
-      if (!p->fix_alpha) x[k++] = p->alpha0 > 0 ? p->alpha0 : 0.5;
+      if (!p->fix_alpha) { int ga; for (ga = 0; ga < (p->malpha ? p->ngene : 1); ga++) x[k++] = p->alpha0 > 0 ? p->alpha0 : 0.5; }
       return k;
    }
    if (p->seqtype == 1) {
@@ -609,7 +614,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
          for (j = 0; j < (p->nhomo > 2 ? pamlh_nh_npi(p) : 0); j++) { if (p->model == T92) x[k++] = p->pi_data[1] + p->pi_data[3]; else for (i = 0; i < 3; i++) x[k++] = p->pi_data[i]; }
       }
    }
-   if (!p->fix_alpha) x[k++] = p->alpha0 > 0 ? p->alpha0 : 0.5;
+   if (!p->fix_alpha) { int ga; for (ga = 0; ga < (p->malpha ? p->ngene : 1); ga++) x[k++] = p->alpha0 > 0 ? p->alpha0 : 0.5; }
    if (!p->fix_rho) x[k++] = p->rho0;
    return k;
 }
@@ -908,7 +913,17 @@ static int set_x_genes(pamlh *p, const double *x, int np, int k, double *Q)
    else if (p->seqtype == 0) k += (per_gene ? G : 1) * nuc_nkappa(p);
    p->n_pi = own_pi ? G : 1;
    p->n_eigen = nsets;
-   {
+   if (p->malpha) {      /* a gamma shape per gene: class rates [gene][class] (SetPGene(.., _alpha = 1, ..) baseml.c:1460-1463) */
+      if (p->ncatG > 60) return pamlh_fail(p, "ncatG too large");
+      for (g = 0; g < G; g++) {
+         const double alpha = x[k++];
+         if (!(alpha > 0)) return pamlh_fail(p, "alpha of gene %d is not positive", g + 1);
+         pamlh_discrete_gamma(p->freqK, p->rate + (size_t)g * p->ncatG, alpha, p->ncatG);
+         if (g == 0) p->alpha = alpha;
+      }
+      K = p->ncatG; p->mode = PAML_AMD_MODE_LFUNDG;
+   }
+   else {
       const double alpha = p->fix_alpha ? p->alpha0 : x[k++];
       p->alpha = alpha;
       if (alpha > 0) {
@@ -1222,6 +1237,7 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
 }
 
 int pamlh_mgene(const pamlh *p) { return p->ngene > 1 ? p->mgene : 0; }
+int pamlh_malpha(const pamlh *p) { return p->malpha; }
 
 /* Mgene = 1: gene g of the data set as an analysis of its own — its patterns, weights and site map, frequencies counted from
  * its sites, the same tree and options, one gene, its own parameter vector (MultipleGenes / GetSubSeqs in the reference).
@@ -1260,7 +1276,7 @@ int pamlh_gene_subset(const pamlh *p, int g, pamlh **out)
    q->branch = (double *)calloc(p->nnode, sizeof(double));
    q->pi = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    q->freqK = (double *)calloc(64, sizeof(double));
-   q->rate = (double *)calloc(64, sizeof(double));
+   q->rate = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    q->eigen_of = (int *)calloc(64 * PAMLH_MAXEIG, sizeof(int));
    for (i = 0; i < PAMLH_MAXEIG; i++) q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = NULL;
    /* frequencies of this gene alone, then the one-gene parameter count */
@@ -1286,7 +1302,7 @@ pamlh *pamlh_state_clone(const pamlh *p)
    q->pi = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    q->gene_eigen_of = NULL;
    q->freqK = (double *)calloc(64, sizeof(double));
-   q->rate = (double *)calloc(64, sizeof(double));
+   q->rate = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    q->eigen_of = (int *)calloc(64 * PAMLH_MAXEIG, sizeof(int));
    for (i = 0; i < PAMLH_MAXEIG; i++) q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = NULL;
    return q;
@@ -1373,7 +1389,8 @@ int pamlh_engine_model(pamlh *p)
       if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    }
    if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->ngene > 1 ? p->gene_eigen_of : p->eigen_of,
-                                  p->use_qf ? p->qfactor : NULL)))
+                                  p->use_qf ? p->qfactor : NULL)) ||
+       (p->malpha && (rc = paml_amd_set_gene_class_rates(p->eng, p->rate))))
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    return 0;
 }
@@ -1393,7 +1410,8 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
       if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    }
    if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->ngene > 1 ? p->gene_eigen_of : p->eigen_of,
-                                  p->use_qf ? p->qfactor : NULL)))
+                                  p->use_qf ? p->qfactor : NULL)) ||
+       (p->malpha && (rc = paml_amd_set_gene_class_rates(p->eng, p->rate))))
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    if (p->adg) {      /* lfunAdG: fx_r on the device, the rate chain over the sites in their original order on the host */
       if (lnf) for (i = 0; i < p->npatt; i++) lnf[i] = 0;      /* sites are not independent: no per-pattern log f */
@@ -1482,7 +1500,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
       for (j = 0; j < pamlh_nh_nrate(p); j++) NAME("rate parameter %d", j + 1);
       for (j = 0; j < (p->nhomo > 2 ? pamlh_nh_npi(p) : 0); j++) { if (p->model == T92) NAME("GC content (set %d)", j + 1); else { NAME("pi_T (set %d)", j + 1); NAME("pi_C (set %d)", j + 1); NAME("pi_A (set %d)", j + 1); } }
    }
-   if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) NAME("alpha");
+   if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) { if (p->malpha) { for (j = 0; j < p->ngene; j++) NAME("alpha (gene %d)", j + 1); } else NAME("alpha"); }
    if (!p->fix_rho) NAME("rho");
 #undef NAME
    snprintf(buf, cap, "x%d", i);

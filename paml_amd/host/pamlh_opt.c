@@ -43,7 +43,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
 {
    const int np = p->np, nt = p->ntime, nm = np - nt, nn = p->nnode;
    int *cand_of = (int *)malloc(nb * sizeof(int)), *cand_elem = (int *)malloc(nb * sizeof(int)), *cand_rep = (int *)malloc(nb * sizeof(int));
-   int ncand = 0, nrep = 0, b, c, i, rc = 0, K = 0, L = 1, n_eigen = 0, mode = 0, n_pi = 1;
+   int ncand = 0, nrep = 0, b, c, i, rc = 0, K = 0, L = 1, n_eigen = 0, mode = 0, n_pi = 1, RK = 0;
    pamlh **ws = (pamlh **)calloc(nb, sizeof(pamlh *));
    double *br = (double *)calloc((size_t)nb * nn, sizeof(double)), *fk = NULL, *rt = NULL, *rep_fk = NULL, *rep_rt = NULL;
    const double *pi = NULL;
@@ -79,7 +79,8 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       if (!nrep) {
          K = q->K; L = q->n_labels * G; n_eigen = q->n_eigen; mode = q->mode; pi = q->pi; n_pi = q->n_pi;
          rep_fk = (double *)malloc((size_t)ncand * K * sizeof(double));
-         rep_rt = (double *)malloc((size_t)ncand * K * sizeof(double));
+         RK = (p->malpha ? G : 1) * K;
+         rep_rt = (double *)malloc((size_t)ncand * RK * sizeof(double));
          rep_eo = (int *)malloc((size_t)ncand * K * L * sizeof(int));
          rep_qf = (double *)malloc((size_t)ncand * K * L * sizeof(double));
          use_qf = q->use_qf;
@@ -89,14 +90,14 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       q->eng = p->eng;
       if ((rc = upload_eigen(q, nrep * n_eigen))) { pamlh_fail(p, "%s", pamlh_error(q)); goto done; }
       memcpy(rep_fk + (size_t)nrep * K, q->freqK, K * sizeof(double));
-      memcpy(rep_rt + (size_t)nrep * K, q->rate, K * sizeof(double));
+      memcpy(rep_rt + (size_t)nrep * RK, q->rate, RK * sizeof(double));
       for (i = 0; i < K * L; i++) rep_eo[(size_t)nrep * K * L + i] = nrep * n_eigen + (G > 1 ? q->gene_eigen_of[i] : q->eigen_of[i]);
       for (i = 0; i < K * L; i++) rep_qf[(size_t)nrep * K * L + i] = q->use_qf ? q->qfactor[i] : 1.0;
       cand_rep[c] = nrep++;
    }
    if (!nrep) { for (b = 0; b < nb; b++) lnL[b] = -1e300; goto done; }
    fk = (double *)malloc((size_t)nb * K * sizeof(double));
-   rt = (double *)malloc((size_t)nb * K * sizeof(double));
+   rt = (double *)malloc((size_t)nb * RK * sizeof(double));
    eo = (int *)malloc((size_t)nb * K * L * sizeof(int));
    qf = (double *)malloc((size_t)nb * K * L * sizeof(double));
    if (G > 1) gr = (double *)malloc((size_t)nb * G * sizeof(double));
@@ -105,7 +106,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       const int cb = cand_of[b] < 0 ? -1 - cand_of[b] : cand_of[b];
       const int r = cand_rep[cb] < 0 ? 0 : cand_rep[cb];
       memcpy(fk + (size_t)b * K, rep_fk + (size_t)r * K, K * sizeof(double));
-      memcpy(rt + (size_t)b * K, rep_rt + (size_t)r * K, K * sizeof(double));
+      memcpy(rt + (size_t)b * RK, rep_rt + (size_t)r * RK, RK * sizeof(double));
       memcpy(eo + (size_t)b * K * L, rep_eo + (size_t)r * K * L, (size_t)K * L * sizeof(int));
       memcpy(qf + (size_t)b * K * L, rep_qf + (size_t)r * K * L, (size_t)K * L * sizeof(double));
       if (pamlh_x_to_branches(p, x, br + (size_t)b * nn)) {      /* (clock: a node older than its ancestor) */
@@ -115,7 +116,8 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       if (gr) { gr[(size_t)b * G] = 1; for (i = 1; i < G; i++) gr[(size_t)b * G + i] = x[nt + i - 1]; }
    }
    /* (with several genes the tables are [gene][class]: one label, and L counts the genes) */
-   if ((rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, G > 1 ? 1 : L, rep_eo, use_qf ? rep_qf : NULL))) { rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); goto done; }
+   if ((rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, G > 1 ? 1 : L, rep_eo, use_qf ? rep_qf : NULL)) ||
+       (p->malpha && (rc = paml_amd_set_gene_class_rates(p->eng, rep_rt)))) { rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); goto done; }
    {
       /* The engine evaluates a batch under ONE set of root frequencies (paml_amd_set_pi).  Where the frequencies are parameters
        * (nhomo = 1, 3, 4: com.pi is part of x) the elements are evaluated in groups of equal frequencies: a gradient batch is one
@@ -135,7 +137,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
             rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
       }
       else {
-         double *sbr = (double *)malloc((size_t)nb * nn * sizeof(double)), *sfk = (double *)malloc((size_t)nb * K * sizeof(double)), *srt = (double *)malloc((size_t)nb * K * sizeof(double));
+         double *sbr = (double *)malloc((size_t)nb * nn * sizeof(double)), *sfk = (double *)malloc((size_t)nb * K * sizeof(double)), *srt = (double *)malloc((size_t)nb * RK * sizeof(double));
          double *sqf = (double *)malloc((size_t)nb * K * L * sizeof(double)), *sgr = gr ? (double *)malloc((size_t)nb * G * sizeof(double)) : NULL;
          double *sl = (double *)malloc(nb * sizeof(double)), *slf = lnf ? (double *)malloc((size_t)nb * p->npatt * sizeof(double)) : NULL;
          int *seo = (int *)malloc((size_t)nb * K * L * sizeof(int)), *idx = (int *)malloc(nb * sizeof(int));
@@ -145,7 +147,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
                if (grp[b] != gsel) continue;
                memcpy(sbr + (size_t)m * nn, br + (size_t)b * nn, nn * sizeof(double));
                memcpy(sfk + (size_t)m * K, fk + (size_t)b * K, K * sizeof(double));
-               memcpy(srt + (size_t)m * K, rt + (size_t)b * K, K * sizeof(double));
+               memcpy(srt + (size_t)m * RK, rt + (size_t)b * RK, RK * sizeof(double));
                memcpy(sqf + (size_t)m * K * L, qf + (size_t)b * K * L, (size_t)K * L * sizeof(double));
                memcpy(seo + (size_t)m * K * L, eo + (size_t)b * K * L, (size_t)K * L * sizeof(int));
                if (sgr) memcpy(sgr + (size_t)m * G, gr + (size_t)b * G, G * sizeof(double));
@@ -327,7 +329,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
       for (i = 0; i < pamlh_nh_nrate(p); i++) { lo[k] = 1e-4; hi[k++] = 999; }
       for (i = 0; i < (p->nhomo > 2 ? pamlh_nh_npi(p) * (p->model == T92 ? 1 : 3) : 0); i++) { lo[k] = 1e-5; hi[k++] = 0.99999; }
    }
-   if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) { lo[k] = 0.005; hi[k++] = 99; }
+   if (!p->fix_alpha && !(p->seqtype == 1 && p->nssites)) for (i = 0; i < (p->malpha ? p->ngene : 1); i++) { lo[k] = 0.005; hi[k++] = 99; }
    if (!p->fix_rho) { lo[k] = -0.2; hi[k++] = 0.99; }
    return k == p->np ? 0 : -1;
 }

@@ -156,13 +156,14 @@ class Analysis:
         go, gr, geo, npi = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
         L.pamlh_genes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
         G = L.pamlh_genes(h, C.byref(go), C.byref(gr), C.byref(npi), C.byref(geo))
+        malpha = bool(L.pamlh_malpha(h)) and G > 1
         genes = {}
         if G > 1:
             genes = dict(gene_off=_arr(go.value, np.int32, G + 1), gene_rate=_arr(gr.value, np.float64, G))
         return Problem(qfactor=None if not qf else _arr(qf, np.float64, K * n_labels).reshape(K, n_labels), **genes,
                        n=n, tree=tree, z=_arr(L.pamlh_tips(h), np.uint8, self.n_tips * self.n_patt).reshape(self.n_tips, self.n_patt),
                        weights=_arr(L.pamlh_weights(h), np.float64, self.n_patt), pi=_arr(L.pamlh_pi(h), np.float64, n * npi.value).reshape(npi.value, n), eigen=eig,
-                       mode=mode, freqK=_arr(L.pamlh_freqK(h), np.float64, K), rate=_arr(L.pamlh_rate(h), np.float64, K),
+                       mode=mode, freqK=_arr(L.pamlh_freqK(h), np.float64, K), rate=_arr(L.pamlh_rate(h), np.float64, K * (G if malpha else 1)), rate_per_gene=malpha,
                        eigen_of=(_arr(geo.value, np.int32, G * K).reshape(G, K, 1) if G > 1 else
                                  _arr(L.pamlh_eigen_of(h), np.int32, K * n_labels).reshape(1, K, n_labels)), cleandata=self.cleandata,
                        n_chara=_arr(L.pamlh_n_chara(h), np.int32, self.n_codes),

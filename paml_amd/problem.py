@@ -203,6 +203,7 @@ class Problem:
     gene_off: np.ndarray | None = None   # int32 [n_genes+1]
     gene_rate: np.ndarray | None = None  # [n_genes]
     scale_node: np.ndarray | None = None # uint8 [n_nodes]
+    rate_per_gene: bool = False          # Malpha: rate is [n_genes, K] (a gamma shape per gene)
 
     def __post_init__(self):
         self.z = np.ascontiguousarray(self.z, dtype=np.uint8)

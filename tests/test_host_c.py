@@ -37,6 +37,7 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          # option G (several genes): rates only (Mgene 0), + frequencies (2), + kappa / omega (3), both (4); one with gamma
          ("horai_mg0", "baseml", "horai_mg0.ctl"), ("horai_mg2", "baseml", "horai_mg2.ctl"), ("horai_mg3", "baseml", "horai_mg3.ctl"),
          ("horai_mg4", "baseml", "horai_mg4.ctl"), ("horai_mg0_g5", "baseml", "horai_mg0_g5.ctl"),
+         ("horai_mg0_malpha", "baseml", "horai_mg0_malpha.ctl"), ("horai_mg4_malpha", "baseml", "horai_mg4_malpha.ctl"),      # Malpha: a gamma shape per gene
          ("lysin_mg0", "codeml", "lysin_mg0.ctl"), ("lysin_mg2", "codeml", "lysin_mg2.ctl"), ("lysin_mg3", "codeml", "lysin_mg3.ctl"),
          ("lysin_mg4", "codeml", "lysin_mg4.ctl")]
 
@@ -300,7 +301,7 @@ def test_c_host_clade_model_neb_and_beb_match_the_reference_rst(gname, ctl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gname", ["brown_hky85_nhomo2", "brown_t92_nhomo3_g4", "brown_f84_nhomo4"])
+@pytest.mark.parametrize("gname", ["brown_hky85_nhomo1", "brown_hky85_nhomo2", "brown_t92_nhomo3_g4", "brown_f84_nhomo4"])
 def test_c_host_optimiser_on_nonhomogeneous_models(gname):
     """nhomo = 2 (seven kappas), 3 with T92 + gamma (seven GC contents, one kappa, alpha) and 4 with F84 (eight frequency sets):
     one eigen system per branch, selected through the engine's branch labels; from the control file's initial values the
@@ -314,6 +315,7 @@ def test_c_host_optimiser_on_nonhomogeneous_models(gname):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("gname,prog,ctl", [("horai_mg0_g5", "baseml", "horai_mg0_g5.ctl"), ("horai_mg4", "baseml", "horai_mg4.ctl"),
+                                            ("horai_mg0_malpha", "baseml", "horai_mg0_malpha.ctl"), ("horai_mg4_malpha", "baseml", "horai_mg4_malpha.ctl"),
                                             ("lysin_mg3", "codeml", "lysin_mg3.ctl")])
 def test_c_host_optimiser_with_several_genes(gname, prog, ctl):
     """Option G data (examples/horai.nuc: four genes by site marks; lysinYangSwanson2002.nuc: two site partitions): gene rates
