@@ -415,7 +415,7 @@ def reference_binary_rate(pb):
     from paml_amd import synth
     times = {}
     try:
-        for n in (5000, 40000):
+        for n in (40000, 400000):      # ~1 s and ~11 s of the reference's time
             n = min(n, pb.n_patt)
             sub = pb.slice_patterns(0, n)
             d = tempfile.mkdtemp(prefix="paml_amd_ref_")
