@@ -299,7 +299,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
     * (fix_kappa = 0) or one kappa for all (fix_kappa = 1).  5 (sets by labels in the tree file) is not supported. */
    if (p->nhomo < 0 || p->nhomo > 4) { rc = pamlh_fail(p, "nhomo = %d is not supported (0 ... 4)", p->nhomo); goto bad; }
    p->clock = (int)pamlh_optd(p, "clock", 0);
-   if (p->clock != 0 && p->clock != 1) { rc = pamlh_fail(p, "clock = %d is not supported (0: no clock, 1: global clock)", p->clock); goto bad; }
+   if (p->clock < 0 || p->clock > 2) { rc = pamlh_fail(p, "clock = %d is not supported (0: no clock, 1: global clock, 2: local clocks by '#' rate labels in the tree)", p->clock); goto bad; }
    p->mgene = (int)pamlh_optd(p, "Mgene", 0);
    /* Mgene = 1 (separate analyses, MultipleGenes baseml.c:392 / codeml.c:570): the data set itself is not evaluated; every gene
     * is taken out as an analysis of its own with pamlh_gene_subset */
@@ -392,6 +392,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       }
    }
 genes_ok:
+   if (p->clock == 2) { p->rate_label = (int *)malloc(p->nnode * sizeof(int)); memcpy(p->rate_label, p->label, p->nnode * sizeof(int)); }      /* local clocks: '#' = rate class */
    if (!(p->seqtype == 1 && p->model >= 2)) memset(p->label, 0, p->nnode * sizeof(int));      /* '#' labels only matter to branch models */
    if (p->seqtype == 0 && p->nhomo >= 2) { int v; for (v = 0; v < p->nnode; v++) p->label[v] = v; }      /* every branch has its own P(t) family */
    if (p->seqtype == 1 && p->model >= 2) {
@@ -423,6 +424,21 @@ genes_ok:
       if (p->sons_ptr[p->root + 1] - p->sons_ptr[p->root] != 2 || p->nnode != 2 * p->ns - 1) { rc = pamlh_fail(p, "clock = 1 needs a rooted binary tree"); goto bad; }
       if (p->seqtype == 1 && p->model) { rc = pamlh_fail(p, "model and clock do not work together"); goto bad; }
       p->ntime = p->ns - 1;
+      if (p->clock == 2) {
+         /* local clocks (GetInitialsTimes treesub.c:3866-3886, GetBranchRate 3678-3700): the '#' labels of the tree file are rate
+          * classes — class 0 runs at rate 1, the rates of classes 1 .. nbtype-1 follow the ages in x; the length of a branch is its
+          * time span times the rate of its class */
+         int v;
+         if (p->nhomo >= 2) { rc = pamlh_fail(p, "clock = 2 and nhomo are incompatible"); goto bad; }
+         for (p->n_brate = 1, v = 0; v < p->nnode; v++) if (v != p->root && p->rate_label[v] + 1 > p->n_brate) p->n_brate = p->rate_label[v] + 1;
+         if (p->n_brate <= 1) { rc = pamlh_fail(p, "use clock = 1 or add branch rate labels (#1 ...) in the tree"); goto bad; }
+         for (v = 1; v < p->n_brate; v++) {
+            int w, found = 0;
+            for (w = 0; w < p->nnode; w++) if (w != p->root && p->rate_label[w] == v) found = 1;
+            if (!found) { rc = pamlh_fail(p, "not all branch rate labels 0 ... %d are on the tree", p->n_brate - 1); goto bad; }
+         }
+         p->ntime += p->n_brate - 1;
+      }
    }
    {
       int nr = p->ngene - 1;       /* rgene */
@@ -482,6 +498,7 @@ void pamlh_free(pamlh *p)
    if (p->eng) paml_amd_destroy(p->eng);
    if (p->names) for (i = 0; i < p->ns; i++) free(p->names[i]);
    free(p->names); free(p->z); free(p->w); free(p->raw); free(p->n_chara); free(p->chara_map);
+   free(p->rate_label);
    free(p->sons_ptr); free(p->sons); free(p->label); free(p->branch_node); free(p->father); free(p->tree_branch); free(p->scale);
    free(p->branch); free(p->pi); free(p->freqK); free(p->rate); free(p->eigen_of);
    for (i = 0; i < PAMLH_MAXEIG; i++) { free(p->eig[i].U); free(p->eig[i].V); free(p->eig[i].Root); free(p->eig[i].Cijk); }
@@ -556,6 +573,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
             if (node != p->root && hgt[p->father[node]] < hgt[node] + 1) { hgt[p->father[node]] = hgt[node] + 1; changed = 1; }
       for (node = p->ns; node < p->nnode; node++) x[k++] = 0.04 * hgt[node];
       free(hgt);
+      for (node = 1; node < (p->clock == 2 ? p->n_brate : 1); node++) x[k++] = 1;      /* branch rates */
    }
    else
    for (i = 0; i < p->ntime; i++) { double b = p->tree_branch[p->branch_node[i]]; x[k++] = b >= 0 ? b : 0.1; }
@@ -953,6 +971,7 @@ int pamlh_x_to_branches(const pamlh *p, const double *x, double *branch)
          b = x[p->father[i] - p->ns] - (i < p->ns ? 0 : x[i - p->ns]);
          if (b < -1e-5) return -1;
          branch[i] = b < 0 ? 0 : b;
+         if (p->clock == 2 && p->rate_label[i] > 0) branch[i] *= x[p->ns - 1 + p->rate_label[i] - 1];
       }
       return 0;
    }
@@ -1272,6 +1291,7 @@ int pamlh_gene_subset(const pamlh *p, int g, pamlh **out)
    DUP(sons_ptr, p->nnode + 1, int); DUP(sons, p->sons_ptr[p->nnode], int); DUP(label, p->nnode, int); DUP(branch_node, 2 * p->ns, int);
    DUP(father, 2 * p->ns, int); DUP(tree_branch, 2 * p->ns, double);
    if (p->scale) DUP(scale, p->nnode, unsigned char);
+   if (p->rate_label) DUP(rate_label, p->nnode, int);
 #undef DUP
    q->branch = (double *)calloc(p->nnode, sizeof(double));
    q->pi = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
@@ -1455,7 +1475,8 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
    const int rep = (p->ngene > 1 && p->mgene >= 3) ? p->ngene : 1;
    if (i < 0 || i >= p->np) return -1;
    if (i < p->ntime && p->fix_blength == 3) { snprintf(buf, cap, "branch-length scale"); return 0; }
-   if (i < p->ntime && p->clock) { snprintf(buf, cap, "age of node %d", p->ns + i + 1); return 0; }
+   if (i < p->ns - 1 && p->clock) { snprintf(buf, cap, "age of node %d", p->ns + i + 1); return 0; }
+   if (i < p->ntime && p->clock) { snprintf(buf, cap, "rate of branch class %d", i - (p->ns - 1) + 1); return 0; }
    if (i < p->ntime) { const int node = p->branch_node[i]; snprintf(buf, cap, "t %d..%d", p->father[node] + 1, node + 1); return 0; }
    if (i < k + p->ngene - 1) { snprintf(buf, cap, "rgene%d", i - k + 2); return 0; }
    k += p->ngene - 1;

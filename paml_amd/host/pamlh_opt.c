@@ -278,7 +278,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
 {
    int k = 0, i, g;
    const int rep = (p->ngene > 1 && p->mgene >= 3) ? p->ngene : 1;
-   for (i = 0; i < p->ntime; i++) { lo[k] = p->clock ? 0 : p->fix_blength == 3 ? 1e-4 : 4e-6; hi[k++] = 50; }
+   for (i = 0; i < p->ntime; i++) { lo[k] = p->clock ? (i >= p->ns - 1 ? 1e-4 : 0) : p->fix_blength == 3 ? 1e-4 : 4e-6; hi[k++] = (p->clock && i >= p->ns - 1) ? 99 : 50; }
    for (i = 1; i < p->ngene; i++) { lo[k] = p->is_codeml ? 0.01 : 1e-4; hi[k++] = p->is_codeml ? 99 : 999; }      /* rgene (SetxBound) */
    for (g = 0; g < rep; g++)
    if (p->seqtype == 1) {
@@ -446,7 +446,7 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
          clock_x_to_y(p, x, y);
          memcpy(x, y, n * sizeof(double));
          free(y);
-         if (p->clock) for (i = 0; i < p->ntime; i++) { lo[i] = (p->ns + i == p->root) ? 1e-5 : 1e-8; hi[i] = (p->ns + i == p->root) ? 50 : 1; }
+         if (p->clock) for (i = 0; i < p->ns - 1; i++) { lo[i] = (p->ns + i == p->root) ? 1e-5 : 1e-8; hi[i] = (p->ns + i == p->root) ? 50 : 1; }
          for (j = 0; j < ng; j++) for (i = 0; i < len[j]; i++) { lo[start[j] + i] = -Y_SIMPLEX; hi[start[j] + i] = Y_SIMPLEX; }
       }
    }

@@ -310,7 +310,7 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtyp
             rows = re.findall(r"^\s*\d+ \S\s+((?:[01]\.\d{5}\s+)+)\(\s*\d+\)", blk, re.M)
             ls = int([ln for ln in res1["lnf"] if ln.split()][0].split()[1])
             tables[key] = [[float(v) for v in r.split()] for r in rows[:ls]]
-    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha") if k in ctl_over}),
+    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha", "clock") if k in ctl_over}),
                                              x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
 
 
@@ -597,6 +597,9 @@ CASES = {
     # Malpha: a gamma shape per gene (class rates per gene), with shared kappa (Mgene 0) and with everything per gene (Mgene 4)
     "horai_mg0_malpha": lambda: case_mle("horai_mg0_malpha", dict(seqfile="horai.nuc", treefile="horai.trees", model=4, kappa=5, Mgene=0, fix_alpha=0, alpha=0.5, Malpha=1, ncatG=5), HORAI, 6, "nuc_genes", prog="baseml", seqtype="nuc"),
     "horai_mg4_malpha": lambda: case_mle("horai_mg4_malpha", dict(seqfile="horai.nuc", treefile="horai.trees", model=4, kappa=5, Mgene=4, fix_alpha=0, alpha=0.5, Malpha=1, ncatG=4), HORAI, 6, "nuc_genes", prog="baseml", seqtype="nuc"),
+    # local clocks (clock = 2): the '#' labels of a rooted tree are rate classes, the rates of classes 1, 2 follow the node ages in x
+    "brown_hky85_clock2": lambda: case_mle("brown_hky85_clock2", dict(seqfile="brown.nuc", treefile="brown.clock2.trees", model=4, clock=2, kappa=5),
+                                           {"brown.nuc": EX + "/brown.nuc", "brown.clock2.trees": "  5  1\n\n((((1,2) #1,3),4 #2),5);\n"}, 5, "nuc_clock", prog="baseml", seqtype="nuc"),
     "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
                                     {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,
