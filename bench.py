@@ -334,7 +334,7 @@ def clock_probe(args):
     nb, stride = np.frombuffer(raw[:8], dtype=np.int32)
     t = np.frombuffer(raw[8 + 4 * (stride - 3):], dtype=np.uint64).astype(np.int64).reshape(-1, nb, stride)[0]
     t = t[t[:, 0] > 0]
-    ends = t[:, 1:-2]
+    ends = t[:, 1:-3]
     ntile = (ends > 0).sum(axis=1)
     last = np.array([ends[b, ntile[b] - 1] for b in range(t.shape[0])])
     mhz = (t[:, -1] - t[:, -2]) / (last - t[:, 0]) * 100.0

@@ -717,6 +717,53 @@ __device__ __forceinline__ void m20_matvec2(const double *sPn, const double *sPn
 #pragma unroll
    for (int I = 0; I < 5; I++) A0[I] = A1[I];      // the next product's first column, possibly still in flight: its wait comes first there
 }
+// ---- hybrid product (jit_generate_m20, default): rows 0-15 of P on v_mfma_f64_16x16x4 (one row block, no padding: its A operand
+// is P[lane & 15][4 kb + (lane >> 4)], its accumulator tuple is blocks 0..3 of the partial), rows 16-19 on v_mfma_f64_4x4x4 as
+// above.  Same matrix-pipe time (5 x 64 + 5 x 16 cycles per 16 patterns = 25 x 16), but TEN operand fetches per product instead of
+// twenty-five: the LDS pipe, which the 4x4x4-only product kept 60 % busy (485 reads per 650 MFMAs with the tip rows, every one
+// delivering a 4-fold replicated block), stops being what the MFMAs wait for.  P(t) of a branch in LDS: [kb][lane] in A-operand
+// order for the big part (320 doubles), then [kb][k][i] for rows 16-19 (80 doubles).
+// Fetch discipline as above (asm ds_read_b64, counted lgkmcnt waits, LDS returns in order): entering a product its five big
+// operands are already requested; it requests its five small ones and then the NEXT product's big ones, waits for "all but those
+// ten", runs the big MFMAs of both pattern groups, waits for "all but the last five" and runs the small ones in between.
+typedef double m20_v4d __attribute__((ext_vector_type(4)));
+#define M20_MFMA16(A, B, C) __builtin_amdgcn_mfma_f64_16x16x4f64((A), (B), (C), 0, 0, 0)
+__device__ __forceinline__ void m20h_read_big(unsigned base, int lane, double (&A)[5])      // base: LDS byte address of the node's block
+{
+   const unsigned a = base + lane * 8;
+   A[0] = m20_lds64<0 * 512>(a); A[1] = m20_lds64<1 * 512>(a); A[2] = m20_lds64<2 * 512>(a); A[3] = m20_lds64<3 * 512>(a); A[4] = m20_lds64<4 * 512>(a);
+}
+__device__ __forceinline__ void m20h_read_small(unsigned base, int lane, double (&A)[5])
+{
+   const unsigned a = base + 2560 + (((lane >> 4) << 2) + (lane & 3)) * 8;
+   A[0] = m20_lds64<0 * 128>(a); A[1] = m20_lds64<1 * 128>(a); A[2] = m20_lds64<2 * 128>(a); A[3] = m20_lds64<3 * 128>(a); A[4] = m20_lds64<4 * 128>(a);
+}
+__device__ __forceinline__ void m20h_matvec2(const double *sPn, const double *sPnext, int lane, double (&Ab)[5], const double (&x0)[5], double (&y0)[5],
+                                             const double (&x1)[5], double (&y1)[5])
+{
+   double As[5], An[5];
+   m20h_read_small(m20_lds_addr(sPn), lane, As);
+   m20h_read_big(m20_lds_addr(sPnext), lane, An);
+   m20_wait<10>(Ab);
+   m20_v4d b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+   double s0 = 0, s1 = 0;
+   b0 = M20_MFMA16(Ab[0], x0[0], b0); b1 = M20_MFMA16(Ab[0], x1[0], b1);
+   b0 = M20_MFMA16(Ab[1], x0[1], b0); b1 = M20_MFMA16(Ab[1], x1[1], b1);
+   m20_wait<5>(As);
+   s0 = M20_MFMA(As[0], x0[0], s0); s1 = M20_MFMA(As[0], x1[0], s1);
+   b0 = M20_MFMA16(Ab[2], x0[2], b0); b1 = M20_MFMA16(Ab[2], x1[2], b1);
+   s0 = M20_MFMA(As[1], x0[1], s0); s1 = M20_MFMA(As[1], x1[1], s1);
+   b0 = M20_MFMA16(Ab[3], x0[3], b0); b1 = M20_MFMA16(Ab[3], x1[3], b1);
+   s0 = M20_MFMA(As[2], x0[2], s0); s1 = M20_MFMA(As[2], x1[2], s1);
+   b0 = M20_MFMA16(Ab[4], x0[4], b0); b1 = M20_MFMA16(Ab[4], x1[4], b1);
+   s0 = M20_MFMA(As[3], x0[3], s0); s1 = M20_MFMA(As[3], x1[3], s1);
+   s0 = M20_MFMA(As[4], x0[4], s0); s1 = M20_MFMA(As[4], x1[4], s1);
+#pragma unroll
+   for (int m = 0; m < 4; m++) { y0[m] = b0[m]; y1[m] = b1[m]; }
+   y0[4] = s0; y1[4] = s1;
+#pragma unroll
+   for (int I = 0; I < 5; I++) Ab[I] = An[I];      // the next product's big operands, possibly still in flight: its wait comes first there
+}
 // tip factors: row `code` of the tip's table, stored [code][st][m] (pmat_kernel layout 2) so that this lane's five states
 // 4 m + st are 40 contiguous bytes and the four lanes of a pattern read one 160-byte row
 __device__ __forceinline__ void m20_tip(const double *T, int row, int code, int st, double (&v)[5])      // row = doubles per code (20, or 21 in LDS)
@@ -756,9 +803,11 @@ __device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5
    f += __shfl_xor(f, 16);
    f += __shfl_xor(f, 32);
    if (own) {
-      double out = 0;
-      if (a.weights[h] > 0) out = root_value(a, f, lnscale);
-      a.fhK[(long)iclass * a.n_patt + h] = out;
+      // fx_r treesub.c:7731-7749 / lfun 7782-7798: the floor here, log + scale factors in the reduction kernel (ReduceArgs::raw):
+      // a log here runs for the whole wave with 16 useful lanes, on the pipe the MFMAs use
+      if (f <= 0) f = (a.mode == PAML_AMD_MODE_LFUN ? 1e-80 : 1e-300);
+      a.fhK[(long)iclass * a.n_patt + h] = a.weights[h] > 0 ? f : 0.0;
+      if (a.n_scale) a.fscale[(long)iclass * a.n_patt + h] = lnscale;
    }
 }
 

@@ -859,7 +859,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    ReduceArgs ra{};
    ra.fhK = e->d_fhK.p; ra.weights = e->d_weights.p; ra.freqK = e->d_freqK.p; ra.lnf = want_lnf ? e->d_lnf.p : nullptr;
    ra.partial = e->d_partial.p; ra.out = lnl_out;
-   ra.raw = (e->kk == KK_MFMA64 && e->use_jit) ? 1 : 0; ra.fscale = e->d_fscale.p;
+   ra.raw = ((e->kk == KK_MFMA64 && e->use_jit) || (e->kk == KK_VALU20 && e->use_jit && e->m20)) ? 1 : 0; ra.fscale = e->d_fscale.p;
    ra.n_patt = e->n_patt; ra.K = Km; ra.mode = e->mode; ra.n_scale = e->tree.n_scale; ra.chunk = chunk;
    ra.first_chunk = e->first_chunk; ra.nb_stride = nbg;
    // (measured on MI355X, 32 taxa x 10^5 nucleotide patterns: 28.2 us per evaluation with the separate one-block launch against

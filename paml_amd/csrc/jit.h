@@ -361,7 +361,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       s << "   __syncthreads();\n   JIT2_ISSUE_Z(" << ZP << ")\n   JIT_WAIT(0); __syncthreads();\n";
       fl.clear();
    }
-   if (proft) s << "   if (a.prof && tid == 0 && ptc < a.prof_stride - 3) { a.prof[(long)blockIdx.x * a.prof_stride + 1 + ptc] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 1] = __builtin_amdgcn_s_memtime(); }\n   ptc++;\n";
+   if (proft) s << "   if (a.prof && tid == 0 && ptc < a.prof_stride - 4) { a.prof[(long)blockIdx.x * a.prof_stride + 1 + ptc] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 1] = __builtin_amdgcn_s_memtime(); }\n   ptc++;\n";
    s << "   if (!has_next) break;\n   }\n   JIT_WAIT(0);\n}\n";
    *first_out = issued - nblk;
    return s.str();
@@ -918,10 +918,19 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    s << "   constexpr int NMM = " << nmm << ", NC = " << n_codes << ", NLT = " << std::max(1, n_lds) << ";\n";
    s << "   __shared__ __attribute__((aligned(16))) double sP[NMM * 400];\n";
    s << "   __shared__ __attribute__((aligned(16))) double sT[NLT * NC * 21];\n";
+   s << "   __shared__ int sTicket;\n   if (threadIdx.x == 0) sTicket = 8;      /* units 0..7 are the waves' own first ones */\n";
    s << "   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, st = lane >> 4, col = lane & 15;\n";
+   if (getenv("PAML_AMD_PROF_TILES")) s << "   if (a.prof && tid == 0) a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 3] = __builtin_amdgcn_s_memrealtime();      /* kernel entry, before the LDS fill */\n";
    s << "   const int iclass = blockIdx.x % a.K, first = blockIdx.x / a.K, stride = gridDim.x / a.K;\n";
    s << "   const double *Pall = a.pint + (long)iclass * a.n_nodes * 400;\n";
    s << "   const double *Ptip = a.ptip + (long)iclass * a.n_nodes * a.tip_words;\n";
+   const bool hybrid = !getenv("PAML_AMD_M20_NOHYBRID");      // rows 0-15 on v_mfma_f64_16x16x4, rows 16-19 on 4x4x4 (m20h_matvec2); else all on 4x4x4
+   if (hybrid) {      // operand order: [kb][lane] <- P[lane & 15][4 kb + (lane >> 4)], then [kb][k][i] <- P[16 + i][4 kb + k]
+      s << "   const int fsrc = tid < 320 ? (tid & 15) * 20 + 4 * (tid >> 6) + ((tid >> 4) & 3) : (16 + ((tid - 320) & 3)) * 20 + 4 * ((tid - 320) >> 4) + (((tid - 320) >> 2) & 3);\n";
+      for (int k = 0; k < nmm; k++)
+         s << "   if (tid < 400) sP[" << k * 400 << " + tid] = Pall[" << (long)mm_nodes[k] * 400 << " + fsrc];\n";
+   }
+   else
    for (int k = 0; k < nmm; k++)
       s << "   for (int i = tid; i < 400; i += 512) sP[" << k * 400 << " + i] = Pall[" << (long)mm_nodes[k] * 400 << " + i];\n";
    for (int t = 0; t < n_tips; t++)
@@ -936,20 +945,33 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    s << "   constexpr int ZW = " << ZW << ";\n";
    s << "   const int hend = as_const(a.gene_off)[1];\n";
    s << "   unsigned int zn_0[ZW], zn_1[ZW];\n";
-   s << "#define M20_FETCH_CODES(TILE) { const int h0n = as_const(a.tiles)[(TILE) < a.n_tiles ? (TILE) : a.n_tiles - 1].y; \\\n"
-        "      long hn = h0n + wv * 32 + col; if (hn >= hend) hn = hend - 1; const uint4 *zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
+   // Work inside a workgroup is handed out per wave in units of 32 patterns (unit u = the workgroup's tile u >> 3, wave slot u & 7)
+   // from an LDS ticket: the two waves of a SIMD do not advance at the same pace (the older wave wins the MFMA arbitration), and
+   // with fixed slots the kernel ended 20 % after its fastest waves had finished.  The first unit of a wave is its own slot; the
+   // next one is drawn a unit ahead, so that its tip codes arrive while the current unit is walked.
+   s << "#define M20_FETCH_CODES(U) { const int un_ = (U) < n_units ? (U) : n_units - 1; const int h0n = as_const(a.tiles)[first + (un_ >> 3) * stride].y + (un_ & 7) * 32; \\\n"
+        "      long hn = h0n + col; if (hn >= hend) hn = hend - 1; const uint4 *zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
         "      _Pragma(\"unroll\") for (int i = 0; i < ZW / 4; i++) { const uint4 t = zp[i]; zn_0[4 * i] = t.x; zn_0[4 * i + 1] = t.y; zn_0[4 * i + 2] = t.z; zn_0[4 * i + 3] = t.w; } \\\n"
-        "      hn = h0n + wv * 32 + 16 + col; if (hn >= hend) hn = hend - 1; zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
+        "      hn = h0n + 16 + col; if (hn >= hend) hn = hend - 1; zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
         "      _Pragma(\"unroll\") for (int i = 0; i < ZW / 4; i++) { const uint4 t = zp[i]; zn_1[4 * i] = t.x; zn_1[4 * i + 1] = t.y; zn_1[4 * i + 2] = t.z; zn_1[4 * i + 3] = t.w; } }\n";
-   s << "   double Acol[5];\n   m20_acol_asm<0>(m20_lds_addr(sP) + aoff * 8, Acol);      /* first column of the first product (a tile's last product fetches it for the next tile) */\n";
-   s << "   M20_FETCH_CODES(first)\n";
-   s << "   for (int tile = first; tile < a.n_tiles; tile += stride) {\n";
-   s << "      const int h0 = as_const(a.tiles)[tile].y;\n";
+   s << "#define M20_TICKET() __builtin_amdgcn_readfirstlane(lane == 0 ? __hip_atomic_fetch_add(&sTicket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0)\n";
+   if (hybrid) s << "   double Acol[5];\n   m20h_read_big(m20_lds_addr(sP), lane, Acol);      /* the first product's big operands (a unit's last product fetches them for the next unit) */\n   (void)aoff;\n";
+   else s << "   double Acol[5];\n   m20_acol_asm<0>(m20_lds_addr(sP) + aoff * 8, Acol);      /* first column of the first product (a unit's last product fetches it for the next unit) */\n";
+   const bool proft = getenv("PAML_AMD_PROF_TILES") != nullptr;      // experiments: workgroup timeline (tools/prof_tiles.py)
+   const char *ptid = getenv("PAML_AMD_PROF_TID");                   // ... stamped by this thread (default 0)
+   const std::string pt = ptid ? ptid : "0";
+   if (proft) s << "   int ptc = 0; if (a.prof && tid == " << pt << ") { a.prof[(long)blockIdx.x * a.prof_stride] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 2] = __builtin_amdgcn_s_memtime(); }\n";
+   s << "   const int n_units = first < a.n_tiles ? ((a.n_tiles - first + stride - 1) / stride) * 8 : 0;\n";
+   s << "   int u = wv, unext = M20_TICKET();\n";
+   s << "   M20_FETCH_CODES(u)\n";
+   s << "   while (u < n_units) {\n";
+   s << "      const int h0 = as_const(a.tiles)[first + (u >> 3) * stride].y + (u & 7) * 32;\n";
    s << "      unsigned int zw_0[ZW], zw_1[ZW];\n";
    s << "      _Pragma(\"unroll\") for (int i = 0; i < ZW; i++) { zw_0[i] = zn_0[i]; zw_1[i] = zn_1[i]; }\n";
-   s << "      M20_FETCH_CODES(tile + stride)\n";
+   s << "      M20_FETCH_CODES(unext)\n";
+   s << "      const int unext2 = M20_TICKET();\n";
    for (int g = 0; g < 2; g++) {
-      s << "      const long h_" << g << " = h0 + wv * 32 + " << 16 * g << " + col;\n      const bool valid_" << g << " = h_" << g << " < hend;\n";
+      s << "      const long h_" << g << " = h0 + " << 16 * g << " + col;\n      const bool valid_" << g << " = h_" << g << " < hend;\n";
       s << "      double lnscale_" << g << " = 0;\n      (void)lnscale_" << g << ";\n";
    }
    const int NA = p.max_stack + 2;
@@ -1026,7 +1048,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
          pop = mm_pop_slot(o); push = mm_push_slot(o); out = alloc();
          emit_loads_after(imm + 1);
          s << "      __builtin_amdgcn_sched_barrier(0);\n";
-         s << "      m20_matvec2(sP + " << imm * 400 << ", sP + " << ((imm + 1) % nmm) * 400 << ", aoff, Acol, " << name(curin, 0) << ", " << name(out, 0) << ", "
+         s << "      " << (hybrid ? "m20h_matvec2" : "m20_matvec2") << "(sP + " << imm * 400 << ", sP + " << ((imm + 1) % nmm) * 400 << ", " << (hybrid ? "lane" : "aoff") << ", Acol, " << name(curin, 0) << ", " << name(out, 0) << ", "
            << name(curin, 1) << ", " << name(out, 1) << ");\n";
          s << "      __builtin_amdgcn_sched_barrier(0);\n";
          imm++;
@@ -1053,6 +1075,8 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       default: break;
       }
    }
+   if (proft) s << "      if (a.prof && tid == " << pt << " && ptc < a.prof_stride - 4) { a.prof[(long)blockIdx.x * a.prof_stride + 1 + ptc] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 1] = __builtin_amdgcn_s_memtime(); }\n      ptc++;\n";
+   s << "      u = unext; unext = unext2;\n";
    s << "   }\n}\n";
    return s.str();
 }

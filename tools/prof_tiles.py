@@ -10,13 +10,16 @@ t = np.frombuffer(raw[8 + 4 * nops:], dtype=np.uint64).astype(np.int64).reshape(
 t = t[t[:, 0] > 0]      # the persistent grid is smaller than the number of tiles the buffer is sized for
 nb = t.shape[0]
 start = t[:, 0]
-ends = t[:, 1:-2]
+ends = t[:, 1:-3]
+entry = t[:, -3]      # kernel entry (kernels with a prologue in front of the first stamp), else 0
 core = t[:, -1] - t[:, -2]      # s_memtime (shader clock) between the workgroup's start and the end of its last tile
 ntile = (ends > 0).sum(axis=1)
 t0 = start.min()
 us = lambda x: x / 100.0
 last = np.array([ends[b, ntile[b] - 1] for b in range(nb)])
 print("workgroups %d, tiles per workgroup %d..%d, span %.1f us" % (nb, ntile.min(), ntile.max(), us(last.max() - t0)))
+if entry.any():
+    print("prologue (kernel entry -> first stamp): median %.1f us, max %.1f us; entry skew max %.1f us" % (us(np.median(start - entry)), us((start - entry).max()), us(entry.max() - entry.min())))
 print("start skew: median %.1f us, max %.1f us" % (us(np.median(start - t0)), us((start - t0).max())))
 print("end: first workgroup done at %.1f us, median %.1f, last %.1f" % (us(last.min() - t0), us(np.median(last - t0)), us(last.max() - t0)))
 dur = np.diff(np.concatenate([start[:, None], ends], axis=1), axis=1).astype(float)
