@@ -726,6 +726,7 @@ __device__ __forceinline__ void m20_matvec2(const double *sPn, const double *sPn
 // Fetch discipline as above (asm ds_read_b64, counted lgkmcnt waits, LDS returns in order): entering a product its five big
 // operands are already requested; it requests its five small ones and then the NEXT product's big ones, waits for "all but those
 // ten", runs the big MFMAs of both pattern groups, waits for "all but the last five" and runs the small ones in between.
+// (As built: the next product's big operands are requested after this product's last big MFMA, into the same registers.)
 typedef double m20_v4d __attribute__((ext_vector_type(4)));
 #define M20_MFMA16(A, B, C) __builtin_amdgcn_mfma_f64_16x16x4f64((A), (B), (C), 0, 0, 0)
 __device__ __forceinline__ void m20h_read_big(unsigned base, int lane, double (&A)[5])      // base: LDS byte address of the node's block
@@ -741,28 +742,28 @@ __device__ __forceinline__ void m20h_read_small(unsigned base, int lane, double 
 __device__ __forceinline__ void m20h_matvec2(const double *sPn, const double *sPnext, int lane, double (&Ab)[5], const double (&x0)[5], double (&y0)[5],
                                              const double (&x1)[5], double (&y1)[5])
 {
-   double As[5], An[5];
+   double As[5];
    m20h_read_small(m20_lds_addr(sPn), lane, As);
-   m20h_read_big(m20_lds_addr(sPnext), lane, An);
-   m20_wait<10>(Ab);
+   m20_wait<5>(Ab);
    m20_v4d b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
    double s0 = 0, s1 = 0;
    b0 = M20_MFMA16(Ab[0], x0[0], b0); b1 = M20_MFMA16(Ab[0], x1[0], b1);
    b0 = M20_MFMA16(Ab[1], x0[1], b0); b1 = M20_MFMA16(Ab[1], x1[1], b1);
-   m20_wait<5>(As);
+   m20_wait<0>(As);
    s0 = M20_MFMA(As[0], x0[0], s0); s1 = M20_MFMA(As[0], x1[0], s1);
    b0 = M20_MFMA16(Ab[2], x0[2], b0); b1 = M20_MFMA16(Ab[2], x1[2], b1);
    s0 = M20_MFMA(As[1], x0[1], s0); s1 = M20_MFMA(As[1], x1[1], s1);
    b0 = M20_MFMA16(Ab[3], x0[3], b0); b1 = M20_MFMA16(Ab[3], x1[3], b1);
    s0 = M20_MFMA(As[2], x0[2], s0); s1 = M20_MFMA(As[2], x1[2], s1);
    b0 = M20_MFMA16(Ab[4], x0[4], b0); b1 = M20_MFMA16(Ab[4], x1[4], b1);
+   // the big operands have been read by the MFMAs above (sources are read at issue): their registers take the NEXT product's
+   // big operands now, which arrive under the remaining small MFMAs and the steps between the products
+   m20h_read_big(m20_lds_addr(sPnext), lane, Ab);
    s0 = M20_MFMA(As[3], x0[3], s0); s1 = M20_MFMA(As[3], x1[3], s1);
    s0 = M20_MFMA(As[4], x0[4], s0); s1 = M20_MFMA(As[4], x1[4], s1);
 #pragma unroll
    for (int m = 0; m < 4; m++) { y0[m] = b0[m]; y1[m] = b1[m]; }
    y0[4] = s0; y1[4] = s1;
-#pragma unroll
-   for (int I = 0; I < 5; I++) Ab[I] = An[I];      // the next product's big operands, possibly still in flight: its wait comes first there
 }
 // tip factors: row `code` of the tip's table, stored [code][st][m] (pmat_kernel layout 2) so that this lane's five states
 // 4 m + st are 40 contiguous bytes and the four lanes of a pattern read one 160-byte row

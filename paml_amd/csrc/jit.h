@@ -918,7 +918,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    s << "   constexpr int NMM = " << nmm << ", NC = " << n_codes << ", NLT = " << std::max(1, n_lds) << ";\n";
    s << "   __shared__ __attribute__((aligned(16))) double sP[NMM * 400];\n";
    s << "   __shared__ __attribute__((aligned(16))) double sT[NLT * NC * 21];\n";
-   s << "   __shared__ int sTicket;\n   if (threadIdx.x == 0) sTicket = 8;      /* units 0..7 are the waves' own first ones */\n";
+   s << "   __shared__ int sTicket;\n";
    s << "   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, st = lane >> 4, col = lane & 15;\n";
    if (getenv("PAML_AMD_PROF_TILES")) s << "   if (a.prof && tid == 0) a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 3] = __builtin_amdgcn_s_memrealtime();      /* kernel entry, before the LDS fill */\n";
    s << "   const int iclass = blockIdx.x % a.K, first = blockIdx.x / a.K, stride = gridDim.x / a.K;\n";
@@ -945,11 +945,11 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    s << "   constexpr int ZW = " << ZW << ";\n";
    s << "   const int hend = as_const(a.gene_off)[1];\n";
    s << "   unsigned int zn_0[ZW], zn_1[ZW];\n";
-   // Work inside a workgroup is handed out per wave in units of 32 patterns (unit u = the workgroup's tile u >> 3, wave slot u & 7)
+   // Work inside a workgroup is handed out per wave in units of 32 patterns
    // from an LDS ticket: the two waves of a SIMD do not advance at the same pace (the older wave wins the MFMA arbitration), and
    // with fixed slots the kernel ended 20 % after its fastest waves had finished.  The first unit of a wave is its own slot; the
    // next one is drawn a unit ahead, so that its tip codes arrive while the current unit is walked.
-   s << "#define M20_FETCH_CODES(U) { const int un_ = (U) < n_units ? (U) : n_units - 1; const int h0n = as_const(a.tiles)[first + (un_ >> 3) * stride].y + (un_ & 7) * 32; \\\n"
+   s << "#define M20_FETCH_CODES(U) { int un_ = (U) < uend ? (U) : uend - 1; un_ = un_ < 0 ? 0 : un_; const int h0n = as_const(a.tiles)[un_ >> 3].y + (un_ & 7) * 32; \\\n"
         "      long hn = h0n + col; if (hn >= hend) hn = hend - 1; const uint4 *zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
         "      _Pragma(\"unroll\") for (int i = 0; i < ZW / 4; i++) { const uint4 t = zp[i]; zn_0[4 * i] = t.x; zn_0[4 * i + 1] = t.y; zn_0[4 * i + 2] = t.z; zn_0[4 * i + 3] = t.w; } \\\n"
         "      hn = h0n + 16 + col; if (hn >= hend) hn = hend - 1; zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
@@ -961,11 +961,15 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    const char *ptid = getenv("PAML_AMD_PROF_TID");                   // ... stamped by this thread (default 0)
    const std::string pt = ptid ? ptid : "0";
    if (proft) s << "   int ptc = 0; if (a.prof && tid == " << pt << ") { a.prof[(long)blockIdx.x * a.prof_stride] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 2] = __builtin_amdgcn_s_memtime(); }\n";
-   s << "   const int n_units = first < a.n_tiles ? ((a.n_tiles - first + stride - 1) / stride) * 8 : 0;\n";
-   s << "   int u = wv, unext = M20_TICKET();\n";
+   // the class's units (32 patterns each, numbered through its 256-pattern tiles) are cut into one contiguous range per workgroup:
+   // 10^5 patterns over 64 workgroups are 48 or 49 units each, where whole tiles were 48 or 56
+   s << "   const int total_units = min(a.n_tiles * 8, (hend + 31) / 32);\n";
+   s << "   const int ubase = (int)((long)first * total_units / stride), uend = (int)((long)(first + 1) * total_units / stride);\n";
+   s << "   if (threadIdx.x == 0) sTicket = ubase + 8;      /* units ubase .. ubase + 7 are the waves' own first ones */\n   __syncthreads();\n";
+   s << "   int u = ubase + wv, unext = M20_TICKET();\n";
    s << "   M20_FETCH_CODES(u)\n";
-   s << "   while (u < n_units) {\n";
-   s << "      const int h0 = as_const(a.tiles)[first + (u >> 3) * stride].y + (u & 7) * 32;\n";
+   s << "   while (u < uend) {\n";
+   s << "      const int h0 = as_const(a.tiles)[u >> 3].y + (u & 7) * 32;\n";
    s << "      unsigned int zw_0[ZW], zw_1[ZW];\n";
    s << "      _Pragma(\"unroll\") for (int i = 0; i < ZW; i++) { zw_0[i] = zn_0[i]; zw_1[i] = zn_1[i]; }\n";
    s << "      M20_FETCH_CODES(unext)\n";
@@ -1009,13 +1013,19 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    std::vector<size_t> mm_at;
    for (size_t i = 0; i < nops; i++)
       if (is_mm(p.ops[i])) mm_at.push_back(i);
-   auto emit_loads_after = [&](int k) {      // the tip steps between product k and product k + 1 (k = -1: in front of the first)
+   // ... rows gathered from L1 / L2 run TWO products ahead of their use, rows in LDS one (their latency is a fraction of a
+   // product, and every step in flight holds 20 - 40 registers)
+   auto all_lds = [&](const Op &o) {
+      const bool two = o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2;
+      return lds_slot[o.a] >= 0 && (!two || lds_slot[o.b] >= 0);
+   };
+   auto emit_loads_after = [&](int k, int which) {      // the tip steps between product k and product k + 1 (k = -1: in front of the first); which: 1 = LDS rows, 2 = the others, 3 = all
       const size_t lo = k < 0 ? 0 : (k < (int)mm_at.size() ? mm_at[k] + 1 : nops), hi = k + 1 < (int)mm_at.size() ? mm_at[k + 1] : nops;
       for (size_t j = lo; j < hi; j++)
-         if (is_tip(p.ops[j]) && !loaded[j]) emit_loads(j);
+         if (is_tip(p.ops[j]) && !loaded[j] && (which & (all_lds(p.ops[j]) ? 1 : 2))) emit_loads(j);
    };
-   emit_loads_after(-1);
-   emit_loads_after(0);
+   emit_loads_after(-1, 3);
+   emit_loads_after(0, 2);
    std::vector<int> slot(256, -1);
    int cur = -1, imm = 0;
    for (size_t iop = 0; iop < nops; iop++) {
@@ -1046,7 +1056,8 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       case OP_MATMUL:
       case OP_MATMUL_POP:
          pop = mm_pop_slot(o); push = mm_push_slot(o); out = alloc();
-         emit_loads_after(imm + 1);
+         emit_loads_after(imm, 1);
+         emit_loads_after(imm + 1, 2);
          s << "      __builtin_amdgcn_sched_barrier(0);\n";
          s << "      " << (hybrid ? "m20h_matvec2" : "m20_matvec2") << "(sP + " << imm * 400 << ", sP + " << ((imm + 1) % nmm) * 400 << ", " << (hybrid ? "lane" : "aoff") << ", Acol, " << name(curin, 0) << ", " << name(out, 0) << ", "
            << name(curin, 1) << ", " << name(out, 1) << ");\n";
