@@ -70,6 +70,8 @@ struct pamlh {
    int use_qf;
    double ns_mr;           /* NSsites: mean rate at the mean omega = 1 / Qfactor_NS of the last pamlh_set_x */
    /* aaDist = 7 (AAClasses, codeml.c:4079 GetOmegaAA): dN/dS classes of amino-acid pairs, from OmegaAA.dat beside the ctl */
+   int tipdate;                /* TipDate: the sequence names end in sampling dates; x has the mutation rate after the node ages */
+   double tip_timeunit, *tip_age, *age_low;   /* ages of the tips (0 = the youngest) in time units; lowest possible age of every node */
    int *rate_label, n_brate;   /* clock = 2: rate class of the branch above every node, number of classes */
    int malpha;               /* Malpha: a gamma shape per gene; rate[] then holds [gene][class] */
    int opt_transformed;      /* pamlh_optimize is iterating on transformed proportions (pamlh_opt.c) */

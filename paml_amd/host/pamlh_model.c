@@ -300,6 +300,13 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    if (p->nhomo < 0 || p->nhomo > 4) { rc = pamlh_fail(p, "nhomo = %d is not supported (0 ... 4)", p->nhomo); goto bad; }
    p->clock = (int)pamlh_optd(p, "clock", 0);
    if (p->clock < 0 || p->clock > 2) { rc = pamlh_fail(p, "clock = %d is not supported (0: no clock, 1: global clock, 2: local clocks by '#' rate labels in the tree)", p->clock); goto bad; }
+   if ((v = pamlh_opt(p, "TipDate")) && atoi(v) != 0) {      /* "TipDate = 1 100": flag and time unit (GetOptions baseml.c / codeml.c) */
+      double unit = -1;
+      int flag = 0;
+      sscanf(v, "%d %lf", &flag, &unit);
+      p->tipdate = flag != 0; p->tip_timeunit = unit;
+      if (!p->clock) p->tipdate = 0;      /* dates only matter to the clock models */
+   }
    p->mgene = (int)pamlh_optd(p, "Mgene", 0);
    /* Mgene = 1 (separate analyses, MultipleGenes baseml.c:392 / codeml.c:570): the data set itself is not evaluated; every gene
     * is taken out as an analysis of its own with pamlh_gene_subset */
@@ -439,6 +446,32 @@ genes_ok:
          }
          p->ntime += p->n_brate - 1;
       }
+      if (p->tipdate) {
+         /* TipDate (GetTipDate treesub.c:3552-3622, GetAgeLow 3750, GetBranchRate 3678): the last field of every sequence name is its
+          * sampling date; tip age = (youngest date - date) / time unit; x = node ages, then the mutation rate per time unit (the rate
+          * of branch class 0), then the other classes' rates; a node cannot be younger than the oldest tip below it */
+         double young = 0, old = 0;
+         int v, changed = 1;
+         p->tip_age = (double *)calloc(p->nnode, sizeof(double));
+         p->age_low = (double *)calloc(p->nnode, sizeof(double));
+         for (v = 0; v < p->ns; v++) {
+            const char *nm = p->names[v], *q = nm + strlen(nm);
+            double d = 0;
+            while (q > nm && (isdigit((unsigned char)q[-1]) || q[-1] == '.')) q--;
+            if (q > nm && q[-1] == '-' ) { rc = pamlh_fail(p, "TipDate: yyyy-mm-dd dates are not supported (%s)", nm); goto bad; }
+            if (!*q || sscanf(q, "%lf", &d) != 1 || d <= 0) { rc = pamlh_fail(p, "TipDate: no sampling date at the end of the name %s", nm); goto bad; }
+            p->tip_age[v] = d;
+            if (v == 0 || d > young) young = d;
+            if (v == 0 || d < old) old = d;
+         }
+         if (young - old < 1e-100) { rc = pamlh_fail(p, "TipDate: all sequences are of the same age?"); goto bad; }
+         if (p->tip_timeunit <= 0) p->tip_timeunit = (young - old) * 2.5;
+         for (v = 0; v < p->ns; v++) { p->tip_age[v] = (young - p->tip_age[v]) / p->tip_timeunit; if (p->tip_age[v] < 1e-100) p->tip_age[v] = 0; p->age_low[v] = p->tip_age[v]; }
+         while (changed)
+            for (changed = 0, v = 0; v < p->nnode; v++)
+               if (v != p->root && p->age_low[p->father[v]] < p->age_low[v]) { p->age_low[p->father[v]] = p->age_low[v]; changed = 1; }
+         p->ntime += 1;
+      }
    }
    {
       int nr = p->ngene - 1;       /* rgene */
@@ -498,7 +531,7 @@ void pamlh_free(pamlh *p)
    if (p->eng) paml_amd_destroy(p->eng);
    if (p->names) for (i = 0; i < p->ns; i++) free(p->names[i]);
    free(p->names); free(p->z); free(p->w); free(p->raw); free(p->n_chara); free(p->chara_map);
-   free(p->rate_label);
+   free(p->rate_label); free(p->tip_age); free(p->age_low);
    free(p->sons_ptr); free(p->sons); free(p->label); free(p->branch_node); free(p->father); free(p->tree_branch); free(p->scale);
    free(p->branch); free(p->pi); free(p->freqK); free(p->rate); free(p->eigen_of);
    for (i = 0; i < PAMLH_MAXEIG; i++) { free(p->eig[i].U); free(p->eig[i].V); free(p->eig[i].Root); free(p->eig[i].Cijk); }
@@ -572,8 +605,17 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
          for (changed = 0, node = 0; node < p->nnode; node++)
             if (node != p->root && hgt[p->father[node]] < hgt[node] + 1) { hgt[p->father[node]] = hgt[node] + 1; changed = 1; }
       for (node = p->ns; node < p->nnode; node++) x[k++] = 0.04 * hgt[node];
+      if (p->tipdate) {      /* above the oldest tip below: the root 1.5 times that age (at least 0.1 more), the others 60 % of the way up */
+         int changed2 = 1, *done = (int *)calloc(p->nnode, sizeof(int));
+         x[p->root - p->ns] = p->age_low[p->root] * 1.5 + 0.1; done[p->root] = 1;
+         while (changed2)
+            for (changed2 = 0, node = p->ns; node < p->nnode; node++)
+               if (!done[node] && done[p->father[node]]) { x[node - p->ns] = p->age_low[node] + (x[p->father[node] - p->ns] - p->age_low[node]) * 0.6; done[node] = 1; changed2 = 1; }
+         free(done);
+         x[k++] = 0.1;      /* mutation rate per time unit */
+      }
       free(hgt);
-      for (node = 1; node < (p->clock == 2 ? p->n_brate : 1); node++) x[k++] = 1;      /* branch rates */
+      for (node = 1; node < (p->clock == 2 ? p->n_brate : 1); node++) x[k++] = p->tipdate ? 0.1 : 1;      /* branch rates */
    }
    else
    for (i = 0; i < p->ntime; i++) { double b = p->tree_branch[p->branch_node[i]]; x[k++] = b >= 0 ? b : 0.1; }
@@ -968,10 +1010,11 @@ int pamlh_x_to_branches(const pamlh *p, const double *x, double *branch)
       for (i = 0; i < p->nnode; i++) {
          double b;
          if (i == p->root) continue;
-         b = x[p->father[i] - p->ns] - (i < p->ns ? 0 : x[i - p->ns]);
+         b = x[p->father[i] - p->ns] - (i < p->ns ? (p->tipdate ? p->tip_age[i] : 0) : x[i - p->ns]);
          if (b < -1e-5) return -1;
          branch[i] = b < 0 ? 0 : b;
-         if (p->clock == 2 && p->rate_label[i] > 0) branch[i] *= x[p->ns - 1 + p->rate_label[i] - 1];
+         if (p->clock == 2 && p->rate_label[i] > 0) branch[i] *= x[p->ns - 1 + p->tipdate + p->rate_label[i] - 1];
+         else if (p->tipdate) branch[i] *= x[p->ns - 1];      /* the mutation rate (com.rgene[0] in the reference's likelihood) */
       }
       return 0;
    }
@@ -1292,6 +1335,7 @@ int pamlh_gene_subset(const pamlh *p, int g, pamlh **out)
    DUP(father, 2 * p->ns, int); DUP(tree_branch, 2 * p->ns, double);
    if (p->scale) DUP(scale, p->nnode, unsigned char);
    if (p->rate_label) DUP(rate_label, p->nnode, int);
+   if (p->tip_age) { DUP(tip_age, p->nnode, double); DUP(age_low, p->nnode, double); }
 #undef DUP
    q->branch = (double *)calloc(p->nnode, sizeof(double));
    q->pi = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
@@ -1476,7 +1520,8 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
    if (i < 0 || i >= p->np) return -1;
    if (i < p->ntime && p->fix_blength == 3) { snprintf(buf, cap, "branch-length scale"); return 0; }
    if (i < p->ns - 1 && p->clock) { snprintf(buf, cap, "age of node %d", p->ns + i + 1); return 0; }
-   if (i < p->ntime && p->clock) { snprintf(buf, cap, "rate of branch class %d", i - (p->ns - 1) + 1); return 0; }
+   if (i == p->ns - 1 && p->clock && p->tipdate) { snprintf(buf, cap, "mutation rate per time unit"); return 0; }
+   if (i < p->ntime && p->clock) { snprintf(buf, cap, "rate of branch class %d", i - (p->ns - 1) - p->tipdate + 1); return 0; }
    if (i < p->ntime) { const int node = p->branch_node[i]; snprintf(buf, cap, "t %d..%d", p->father[node] + 1, node + 1); return 0; }
    if (i < k + p->ngene - 1) { snprintf(buf, cap, "rgene%d", i - k + 2); return 0; }
    k += p->ngene - 1;

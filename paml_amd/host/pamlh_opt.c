@@ -181,7 +181,11 @@ static void clock_rec_y_to_x(const pamlh *p, int node, const double *y, double *
 {
    int j;
    if (node < p->ns) return;
-   x[node - p->ns] = node == p->root ? y[node - p->ns] : x[p->father[node] - p->ns] * y[node - p->ns];
+   if (node == p->root) x[node - p->ns] = y[node - p->ns];
+   else {      /* between the lowest possible age (0, or the oldest dated tip below) and the father's (SetAge treesub.c:3723-3730) */
+      const double low = p->tipdate ? p->age_low[node] : 0;
+      x[node - p->ns] = low + (x[p->father[node] - p->ns] - low) * y[node - p->ns];
+   }
    for (j = p->sons_ptr[node]; j < p->sons_ptr[node + 1]; j++) clock_rec_y_to_x(p, p->sons[j], y, x);
 }
 
@@ -256,7 +260,10 @@ static void clock_x_to_y(const pamlh *p, const double *x, double *y)
    simplex_x_to_y(p, y);
    if (!p->clock) return;
    for (node = p->ns; node < p->nnode; node++)
-      if (node != p->root) { const double fa = x[p->father[node] - p->ns]; y[node - p->ns] = fa > 0 ? x[node - p->ns] / fa : 0; }
+      if (node != p->root) {
+         const double low = p->tipdate ? p->age_low[node] : 0, fa = x[p->father[node] - p->ns] - low;
+         y[node - p->ns] = fa > 0 ? (x[node - p->ns] - low) / fa : 0;
+      }
 }
 
 /* lnL at nb vectors in the optimiser's variables */
@@ -446,7 +453,7 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
          clock_x_to_y(p, x, y);
          memcpy(x, y, n * sizeof(double));
          free(y);
-         if (p->clock) for (i = 0; i < p->ns - 1; i++) { lo[i] = (p->ns + i == p->root) ? 1e-5 : 1e-8; hi[i] = (p->ns + i == p->root) ? 50 : 1; }
+         if (p->clock) for (i = 0; i < p->ns - 1; i++) { lo[i] = (p->ns + i == p->root) ? (p->tipdate ? p->age_low[p->root] : 0) + 1e-5 : 1e-8; hi[i] = (p->ns + i == p->root) ? 50 : 1; }
          for (j = 0; j < ng; j++) for (i = 0; i < len[j]; i++) { lo[start[j] + i] = -Y_SIMPLEX; hi[start[j] + i] = Y_SIMPLEX; }
       }
    }

@@ -112,6 +112,8 @@ def parse_lnf(lines, seqtype, n_tips):
 def tree_from_main(mtxt):
     """First Newick string after 'tree length =' that carries branch lengths (codeml prints the
     numbered tree with lengths first; baseml prints the bare topology first, then names + lengths)."""
+    if "tree length =" not in mtxt:      # (TipDate output has no such line)
+        return None
     tail = mtxt[mtxt.index("tree length ="):]
     for m in re.finditer(r"^\(.*;\s*$", tail, re.M):
         if ":" in m.group(0):
@@ -310,7 +312,7 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtyp
             rows = re.findall(r"^\s*\d+ \S\s+((?:[01]\.\d{5}\s+)+)\(\s*\d+\)", blk, re.M)
             ls = int([ln for ln in res1["lnf"] if ln.split()][0].split()[1])
             tables[key] = [[float(v) for v in r.split()] for r in rows[:ls]]
-    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha", "clock") if k in ctl_over}),
+    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha", "clock", "TipDate") if k in ctl_over}),
                                              x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
 
 
@@ -600,6 +602,10 @@ CASES = {
     # local clocks (clock = 2): the '#' labels of a rooted tree are rate classes, the rates of classes 1, 2 follow the node ages in x
     "brown_hky85_clock2": lambda: case_mle("brown_hky85_clock2", dict(seqfile="brown.nuc", treefile="brown.clock2.trees", model=4, clock=2, kappa=5),
                                            {"brown.nuc": EX + "/brown.nuc", "brown.clock2.trees": "  5  1\n\n((((1,2) #1,3),4 #2),5);\n"}, 5, "nuc_clock", prog="baseml", seqtype="nuc"),
+    # TipDate (Stadler & Yang 2012, examples/TipDate.HIV2): 33 dated HIV-2 / SIV sequences, global clock, HKY85 + G5; x = 32 node ages in
+    # units of 100 years before the youngest sample, the mutation rate per unit, kappa, alpha
+    "hiv2_tipdate": lambda: case_mle("hiv2_tipdate", dict(seqfile="HIV2ge.txt", treefile="HIV2ge.tree1", model=4, clock=1, TipDate="1 100", kappa=2, fix_alpha=0, alpha=0.5, ncatG=5, cleandata=0),
+                                     {"HIV2ge.txt": EX + "/TipDate.HIV2/HIV2ge.txt", "HIV2ge.tree1": os.path.join(HERE, "data", "HIV2ge.tree1")}, 33, "nuc_tipdate", prog="baseml", seqtype="nuc"),
     "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
                                     {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,

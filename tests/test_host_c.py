@@ -29,6 +29,7 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("hiv_m13", "codeml", "hiv_ns13.ctl"), ("ecp_m2arel", "codeml", "ecp_m2arel.ctl"),
          ("brown_hky85_clock", "baseml", "brown_hky85_clock.ctl"),      # global clock: x holds the node ages
          ("brown_hky85_clock2", "baseml", "brown_hky85_clock2.ctl"),    # local clocks: ages, then the rates of the '#' branch classes
+         ("hiv2_tipdate", "baseml", "hiv2_tipdate.ctl"),                # TipDate: dated tips, ages in time units, then the mutation rate
          ("brown_f84", "baseml", "brown_f84.ctl"), ("brown_t92_g4", "baseml", "brown_t92_g4.ctl"), ("brown_unrest", "baseml", "brown_unrest.ctl"), ("brown_hky85_nhomo1", "baseml", "brown_hky85_nhomo1.ctl"),
          # non-homogeneous models: a kappa per branch (2); frequency sets per branch (3: tips / internal / root, 4: every node), every
          # branch with its own eigen system (one label per node); the nhomo3 estimate has a frequency on the boundary (0.000000)
@@ -395,6 +396,20 @@ def test_c_host_optimiser_under_local_clocks():
     assert r["converged"] and abs(r["lnL"] - g["mle_lnL"]) < 2e-5, (r["lnL"], g["mle_lnL"])
     gx = np.array(g["x"])
     assert np.max(np.abs(r["x"][[0, 1, 2, 3, 6]] - gx[[0, 1, 2, 3, 6]]) / gx[[0, 1, 2, 3, 6]]) < 2e-2
+
+
+@pytest.mark.gpu
+def test_c_host_optimiser_with_dated_tips():
+    """TipDate (examples/TipDate.HIV2, Stadler & Yang 2012): 33 sequences sampled 1982-1995, global clock, HKY85 + G5.  The
+    optimiser iterates on (root age, position of every other node between the oldest tip below it and its father) and reaches
+    the reference's -12352.105674, its mutation rate (0.2329 per site per 100 years) and root age."""
+    g = helpers.load_golden("hiv2_tipdate")
+    a = hostlib.Analysis(os.path.join(CTL, "hiv2_tipdate.ctl"), "baseml")
+    assert (a.np, a.ntime) == (35, 33)
+    r = a.optimize(a.default_x(), max_iter=2000)
+    assert r["converged"] and abs(r["lnL"] - g["mle_lnL"]) < 5e-4, (r["lnL"], g["mle_lnL"])
+    gx = np.array(g["x"])
+    assert abs(r["x"][32] - gx[32]) / gx[32] < 2e-2 and abs(r["x"][0] - gx[0]) / gx[0] < 2e-2
 
 
 @pytest.mark.gpu
