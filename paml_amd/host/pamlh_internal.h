@@ -76,7 +76,9 @@ struct pamlh {
    int malpha;               /* Malpha: a gamma shape per gene; rate[] then holds [gene][class] */
    int opt_transformed;      /* pamlh_optimize is iterating on transformed proportions (pamlh_opt.c) */
    int aadist, n_omega_type;
-   signed char omega_class[26][26];   /* by amino-acid letters: class of the pair, -1 = no one-step change under the code */
+   signed char omega_class[26][26];
+   double aa_dist[26][26];           /* aaDist 1..6 / -1..-6: amino-acid distances over their maximum, by letters (GetDaa codeml.c:3967-3993) */
+   double aa_omega[26][26];          /* omega of every amino-acid pair at the current parameters (GetOmega codeml.c:3020) */   /* by amino-acid letters: class of the pair, -1 = no one-step change under the code */
    /* optimiser state (pamlh_opt.c) */
    unsigned char *frozen;  /* NULL, or [np]: parameters pamlh_optimize leaves where they are (minB holds the branch lengths) */
    int opt_lean;           /* 1: fewer trial points per line search, no curvature pre-pass (the inner ming2 of minB) */

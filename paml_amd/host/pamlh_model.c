@@ -221,6 +221,7 @@ static void resolve(const pamlh *p, const char *name, char *out, size_t cap)
 }
 
 static int read_omega_aa(pamlh *p);
+static int read_aa_dist(pamlh *p);
 
 static int aa_of_codon(const pamlh *p, int c64) { static const char AAS[] = "ARNDCQEGHILKMFPSTWYV"; return (int)(strchr(AAS, p->code[c64]) - AAS); }
 
@@ -332,10 +333,16 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       for (p->n = 0, rc = 0; rc < 64; rc++) p->n += p->code[rc] != '*';
       rc = 0;
       p->aadist = (int)pamlh_optd(p, "aaDist", 0);
-      if (p->aadist != 0 && p->aadist != 7) { rc = pamlh_fail(p, "aaDist = %d is not supported (0, or 7 = AAClasses)", p->aadist); goto bad; }
+      if (p->aadist < -6 || p->aadist > 7) { rc = pamlh_fail(p, "aaDist = %d is not supported (1..6 / -1..-6: distance files, 7: AAClasses)", p->aadist); goto bad; }
       if (p->aadist == 7) {
          if (p->nssites || (p->model != 0 && p->model != 2) || p->mg) { rc = pamlh_fail(p, "aaDist = 7 goes with NSsites = 0, model 0 or 2 and CodonFreq <= 3"); goto bad; }
          if ((rc = read_omega_aa(p))) goto bad;
+      }
+      else if (p->aadist) {
+         /* omega_ij = b exp(-a d_ij) (aaDist > 0) or b (1 - a d_ij) (< 0), d = the chosen amino-acid distance over its maximum */
+         if (p->nssites || p->model || p->mg) { rc = pamlh_fail(p, "aaDist & NSsites / model don't work together"); goto bad; }
+         if (p->fix_omega) { rc = pamlh_fail(p, "can't fix_omega for aaDist models"); goto bad; }
+         if ((rc = read_aa_dist(p))) goto bad;
       }
    }
    else if (p->seqtype == 2) {
@@ -479,6 +486,7 @@ genes_ok:
       if (p->seqtype == 1) {
          nr += !p->fix_kappa;
          if (p->aadist == 7) nr += p->n_omega_type * (p->model == 2 ? p->n_omega : 1);      /* AAClasses: a set of class omegas (per branch label) */
+         else if (p->aadist) nr += 2;                                                          /* a, b of omega(d) */
          else if (p->nssites == 0 && p->model == 2) nr += p->n_omega;      /* branch model: one omega per branch label (codeml.c:2170-2183) */
          else if (p->model == 2 && p->nssites == 2) nr += 3 + !p->fix_omega;      /* branch-site A: p0 p1 w0 [w2] (codeml.c:2197-2221) */
          else if (p->model == 2 && p->nssites == 3) nr += 5;                      /* branch-site B: p0 p1 w0 w1 w2 */
@@ -632,6 +640,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
    if (p->seqtype == 1) {
       if (!p->fix_kappa) x[k++] = p->kappa0;
       if (p->aadist == 7) { for (i = 0; i < p->n_omega_type * (p->model == 2 ? p->n_omega : 1); i++) x[k++] = 0.15 + 0.02 * (i % 4); }
+      else if (p->aadist) { x[k++] = 0.15; x[k++] = 0.25; }
       else if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) x[k++] = p->omega0; }
       else if (p->model == 2 && p->nssites) {      /* branch-site A / B: p0 p1 w0 [w1] [w2] */
          x[k++] = 0.6; x[k++] = 0.2; x[k++] = 0.25;
@@ -742,11 +751,36 @@ static int read_omega_aa(pamlh *p)
    return 0;
 }
 
+/* aaDist 1 .. 6 (and their negatives): grantham.dat, miyata.dat, g1974c / p / v / a.dat beside the control file — the lower triangle
+ * of a 20 x 20 table in the order ARNDCQEGHILKMFPSTWYV, divided by its largest entry (GetDaa codeml.c:3967-3993) */
+static int read_aa_dist(pamlh *p)
+{
+   static const char *const files[] = {"", "grantham.dat", "miyata.dat", "g1974c.dat", "g1974p.dat", "g1974v.dat", "g1974a.dat"};
+   static const char AAS[] = "ARNDCQEGHILKMFPSTWYV";
+   char path[1200];
+   double d[400], dmax = 0;
+   int i, j;
+   FILE *f;
+   snprintf(path, sizeof(path), "%s/%s", p->dir, files[abs(p->aadist)]);
+   if (!(f = fopen(path, "r"))) return pamlh_fail(p, "aaDist = %d needs %s beside the control file", p->aadist, files[abs(p->aadist)]);
+   for (i = 0; i < 20; i++)
+      for (j = 0, d[i * 20 + i] = 0; j < i; j++) {
+         if (fscanf(f, "%lf", &d[i * 20 + j]) != 1) { fclose(f); return pamlh_fail(p, "%s: too few distances", path); }
+         d[j * 20 + i] = d[i * 20 + j];
+         if (d[i * 20 + j] > dmax) dmax = d[i * 20 + j];
+      }
+   fclose(f);
+   memset(p->aa_dist, 0, sizeof(p->aa_dist));
+   for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) p->aa_dist[AAS[i] - 'A'][AAS[j] - 'A'] = d[i * 20 + j] / dmax;
+   return 0;
+}
+
 /* codon Q for (kappa, omega) and its mean rate (eigenQcodon codeml.c:3274-3315) */
 static double codon_q_cls(const pamlh *p, const double *pi, double kappa, double omega, const double *wcls, double *Q);
 static double codon_q_pi(const pamlh *p, const double *pi, double kappa, double omega, double *Q) { return codon_q_cls(p, pi, kappa, omega, NULL, Q); }
 static double codon_q(const pamlh *p, double kappa, double omega, double *Q) { return codon_q_cls(p, p->pi, kappa, omega, NULL, Q); }
-/* wcls != NULL (aaDist = 7): omega of a nonsynonymous change = wcls[class of its amino-acid pair] (GetOmega codeml.c:3020) */
+/* wcls != NULL: aaDist = 7, omega of a nonsynonymous change = wcls[class of its amino-acid pair]; aaDist 1..6 / -1..-6, wcls = (a, b) of
+ * omega = b exp(-a d) / b (1 - a d) (GetOmega codeml.c:3020) */
 static double codon_q_cls(const pamlh *p, const double *pi, double kappa, double omega, const double *wcls, double *Q)
 {
    int from61[64], i, j, k, n = p->n, m = 0;
@@ -766,7 +800,12 @@ static double codon_q_cls(const pamlh *p, const double *pi, double kappa, double
             const int b1 = (pos + 1) % 3, b2 = (pos + 2) % 3;
             q /= (p->codonfreq == 2 ? p->fb3x4[b1 * 4 + t[b1]] * p->fb3x4[b2 * 4 + t[b2]] : p->fb4[t[b1]] * p->fb4[t[b2]]);
          }
-         if (p->code[c1] != p->code[c2]) q *= wcls ? wcls[(int)p->omega_class[p->code[c1] - 'A'][p->code[c2] - 'A']] : omega;
+         if (p->code[c1] != p->code[c2]) {
+            const int a1 = p->code[c1] - 'A', a2 = p->code[c2] - 'A';
+            if (!wcls) q *= omega;
+            else if (p->aadist == 7) q *= wcls[(int)p->omega_class[a1][a2]];
+            else { const double w = wcls[0] * p->aa_dist[a1][a2]; q *= (p->aadist > 0 ? exp(-w) : 1 - w) * wcls[1]; }      /* GetOmega codeml.c:3043-3048 */
+         }
          Q[i * n + j] = Q[j * n + i] = q;
       }
    for (i = 0; i < n; i++) for (j = 0; j < n; j++) Q[i * n + j] *= pi[j];
@@ -1044,7 +1083,14 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
       double kappa = p->fix_kappa ? p->kappa0 : x[k++];
       memcpy(p->pi, p->pi_data, p->n * sizeof(double));
       p->kappa = kappa;
-      if (p->aadist == 7) {
+      if (p->aadist && p->aadist != 7) {      /* omega a function of the amino-acid distance: x holds a, b */
+         const double mr = codon_q_cls(p, p->pi, kappa, 1, x + k, Q);
+         if (p->aadist < 0 && !(x[k] <= 1)) { free(Q); return pamlh_fail(p, "aaDist < 0 needs a <= 1"); }
+         set_eig_uvroot(p, 0, Q, p->pi, mr);
+         p->class_w[0] = x[k + 1];
+         k += 2;
+      }
+      else if (p->aadist == 7) {
          /* AAClasses: omega by the class of the amino-acid pair; with branch labels every label has its own set of class omegas
           * and its own eigen system (SetParameters codeml.c:2804-2812: com.pomega moves on by nOmegaType per label) */
          const int nl = p->model == 2 ? p->n_omega : 1;
@@ -1532,6 +1578,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
       if (p->seqtype == 1) {
          if (!p->fix_kappa) NAME("kappa%s", sfx);
          if (p->aadist == 7) { int l; for (l = 0; l < (p->model == 2 ? p->n_omega : 1); l++) for (j = 0; j < p->n_omega_type; j++) NAME("omega class %d (branch type %d)", j, l); }
+         else if (p->aadist) { NAME("a (omega against amino-acid distance)"); NAME("b"); }
          else if (p->nssites == 0 && p->model == 2) { for (j = 0; j < p->n_omega; j++) NAME("omega #%d", j); }
          else if (p->model >= 2) {
             NAME("p0"); NAME("p1"); NAME("w0");

@@ -248,6 +248,7 @@ def case_brown_anc():
     print("%-22s lnL %.6f  %d distinct patterns, nodes %s -> %s" % (g["name"], g["lnL"], len(rows), g["nodes_1based"], os.path.basename(path)))
 
 
+MTPRI_NUC = {"mtCDNApri.nuc": EX + "/mtCDNA/mtCDNApri.nuc", "mtCDNApri.trees": EX + "/mtCDNA/mtCDNApri.trees"}
 MTPRI_AA = {"mtCDNApri.aa": EX + "/mtCDNA/mtCDNApri.aa", "mtCDNApri.trees": EX + "/mtCDNA/mtCDNApri.trees"}
 MTAPE = {"mtCDNAape.txt": EX + "/mtCDNAape/mtCDNAape.txt", "mtCDNAape.trees": EX + "/mtCDNAape/mtCDNAape.trees"}
 
@@ -312,7 +313,7 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtyp
             rows = re.findall(r"^\s*\d+ \S\s+((?:[01]\.\d{5}\s+)+)\(\s*\d+\)", blk, re.M)
             ls = int([ln for ln in res1["lnf"] if ln.split()][0].split()[1])
             tables[key] = [[float(v) for v in r.split()] for r in rows[:ls]]
-    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha", "clock", "TipDate") if k in ctl_over}),
+    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha", "clock", "TipDate", "aaDist") if k in ctl_over}),
                                              x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
 
 
@@ -606,6 +607,11 @@ CASES = {
     # units of 100 years before the youngest sample, the mutation rate per unit, kappa, alpha
     "hiv2_tipdate": lambda: case_mle("hiv2_tipdate", dict(seqfile="HIV2ge.txt", treefile="HIV2ge.tree1", model=4, clock=1, TipDate="1 100", kappa=2, fix_alpha=0, alpha=0.5, ncatG=5, cleandata=0),
                                      {"HIV2ge.txt": EX + "/TipDate.HIV2/HIV2ge.txt", "HIV2ge.tree1": os.path.join(HERE, "data", "HIV2ge.tree1")}, 33, "nuc_tipdate", prog="baseml", seqtype="nuc"),
+    # omega as a function of an amino-acid distance (Yang, Nielsen & Hasegawa 1998, table 4): geometric on Grantham's distances, linear on Miyata's
+    "mtcdnapri_aadist1": lambda: case_mle("mtcdnapri_aadist1", dict(seqfile="mtCDNApri.nuc", treefile="mtCDNApri.trees", model=0, NSsites=0, icode=1, CodonFreq=2, aaDist=1, kappa=3, omega=.4),
+                                          dict(MTPRI_NUC, **{"grantham.dat": DAT + "/grantham.dat"}), 7, "codon_aadist"),
+    "mtcdnapri_aadist_m2": lambda: case_mle("mtcdnapri_aadist_m2", dict(seqfile="mtCDNApri.nuc", treefile="mtCDNApri.trees", model=0, NSsites=0, icode=1, CodonFreq=2, aaDist=-2, kappa=3, omega=.4),
+                                            dict(MTPRI_NUC, **{"miyata.dat": DAT + "/miyata.dat"}), 7, "codon_aadist"),
     "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
                                     {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,

@@ -20,6 +20,8 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("mtcdna_branch", "codeml", "mtcdna_branch.ctl"),
          # aaDist = 7 (AAClasses): omega by class of amino-acid pair (ctl/OmegaAA.dat), alone and per branch label
          ("mtcdna_aaclass_m0", "codeml", "mtcdna_aaclass_m0.ctl"), ("mtcdna_aaclass_branch", "codeml", "mtcdna_aaclass_branch.ctl"),
+         # omega as a function of an amino-acid distance: geometric on Grantham's (aaDist = 1), linear on Miyata's (-2; its slope ends on the bound 1)
+         ("mtcdnapri_aadist1", "codeml", "mtcdnapri_aadist1.ctl"), ("mtcdnapri_aadist_m2", "codeml", "mtcdnapri_aadist_m2.ctl"),
          # codon-based amino-acid models: 6 = FromCodon (20 states), 5 = FromCodon0 (60 codon states, amino acids as codon sets)
          ("mtcdnapri_fromcodon", "codeml", "mtcdnapri_fromcodon.ctl"), ("mtcdnapri_fromcodon0", "codeml", "mtcdnapri_fromcodon0.ctl"),
          # branch-site A (alternative and null), B; clade C, D; M3 — goldens at the reference's own 6-decimal MLEs
@@ -681,6 +683,17 @@ def test_c_host_reaches_the_published_codon_based_aa_values(ctl, lnl, n, est):
     assert r["converged"] and abs(r["lnL"] - lnl) < 3e-4, r["lnL"]
     for k, v in est.items():
         assert abs(r["x"][k] - v) / v < 1e-2, (k, r["x"][k], v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname", ["mtcdnapri_aadist1", "mtcdnapri_aadist_m2"])
+def test_c_host_optimiser_with_amino_acid_distances(gname):
+    """aaDist = 1 / -2 on the 7-ape mitochondrial genes (60-state kernels, vertebrate mt code): kappa and the two parameters of
+    omega(d) from the host's initial values to the reference's maximum."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, gname + ".ctl"), "codeml")
+    r = a.optimize(a.default_x())
+    assert r["converged"] and abs(r["lnL"] - g["mle_lnL"]) < 2e-4, (r["lnL"], g["mle_lnL"])
 
 
 def test_c_host_aaclasses_needs_its_class_file(tmp_path):
