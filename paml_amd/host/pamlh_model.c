@@ -327,11 +327,23 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->nssites == 4) p->ncatG = 5;      /* M4 (freqs): omega = 0, 1/3, 2/3, 1, 3 with free proportions */
       if (p->nssites != 0 && p->nssites != 1 && p->nssites != 2 && p->nssites != 3 && p->nssites != 4 && p->nssites != 5 && p->nssites != 6 && p->nssites != 7 && p->nssites != 8 && !(p->nssites >= 9 && p->nssites <= 13)) { rc = pamlh_fail(p, "NSsites = %d is not supported", p->nssites); goto bad; }
       if (p->model == 0 && p->nssites == 3 && (p->fix_omega || p->ncatG < 2 || p->ncatG > 16)) { rc = pamlh_fail(p, "NSsites = 3 needs fix_omega = 0 and 2 <= ncatG <= 16"); goto bad; }
-      if (p->codonfreq < 0 || p->codonfreq > 5) { rc = pamlh_fail(p, "CodonFreq = %d is not supported", p->codonfreq); goto bad; }
-      /* F1x4MG / F3x4MG (4, 5): the frequencies of F1x4 / F3x4, Muse-Gaut style rates (GetMutationMultiplier codeml.c:3060) */
-      if (p->codonfreq >= 4) { p->mg = 1; p->codonfreq -= 3; }
+      if (p->codonfreq < 0 || p->codonfreq > 7) { rc = pamlh_fail(p, "CodonFreq = %d is not supported", p->codonfreq); goto bad; }
+      p->codonf_model = p->codonfreq;
+      p->est_freq = (int)pamlh_optd(p, "estFreq", 0) != 0;
+      /* F1x4MG / F3x4MG (4, 5): the frequencies of F1x4 / F3x4, Muse-Gaut style rates (GetMutationMultiplier codeml.c:3060);
+       * FMutSel0 / FMutSel (6, 7; Yang & Nielsen 2008): mutation bias pi_T, pi_C, pi_A (always parameters) and amino-acid / codon
+       * fitnesses — estimated (estFreq = 1) or implied by the observed frequencies; the codon table is the observed one */
+      if (p->codonfreq >= 6) { p->mg = 1; p->mutsel = p->codonfreq - 5; p->codonfreq = 3; }
+      else if (p->codonfreq >= 4) { p->mg = 1; p->codonfreq -= 3; }
+      /* frequency parameters in x (GetOptions codeml.c:1574-1588) */
+      if (p->mutsel == 1) p->npi = 3 + (p->est_freq ? 19 : 0);
+      else if (p->mutsel == 2) p->npi = 3 + (p->est_freq ? -1 : 0);      /* + ncode - 1 once the code is known (below) */
+      else if (p->est_freq && p->codonfreq) p->npi = p->codonfreq == 1 ? 3 : p->codonfreq == 2 ? 9 : -1;
       for (p->n = 0, rc = 0; rc < 64; rc++) p->n += p->code[rc] != '*';
       rc = 0;
+      if (p->npi == 2) p->npi = 3 + p->n - 1;      /* FMutSel with estFreq: the codon fitnesses */
+      else if (p->npi == -1) p->npi = p->n - 1;    /* Fcodon with estFreq */
+      if (p->npi && (p->model || p->nssites)) { rc = pamlh_fail(p, "estFreq / FMutSel: only the one-ratio model (model 0, NSsites 0)"); goto bad; }
       p->aadist = (int)pamlh_optd(p, "aaDist", 0);
       if (p->aadist < -6 || p->aadist > 7) { rc = pamlh_fail(p, "aaDist = %d is not supported (1..6 / -1..-6: distance files, 7: AAClasses)", p->aadist); goto bad; }
       if (p->aadist == 7) {
@@ -417,6 +429,13 @@ genes_ok:
    }
    if (p->seqtype == 1) freqs_codon(p);
    else freqs_base_aa(p);
+   if (p->seqtype == 1 && p->npi) {
+      int c, m = 0;
+      if (p->ngene > 1) { rc = pamlh_fail(p, "codon models (estFreq) not implemented for ngene > 1"); goto bad; }
+      if (p->aadist) { rc = pamlh_fail(p, "estFreq / FMutSel with aaDist is not supported"); goto bad; }
+      memset(p->pi_aa, 0, sizeof(p->pi_aa));
+      for (c = 0; c < 64; c++) if (p->code[c] != '*') p->pi_aa[aa_of_codon(p, c)] += p->pi_data[m++];
+   }
    if (p->seqtype == 2 && p->aa_model >= 5) {
       if (p->ngene > 1) { rc = pamlh_fail(p, "the codon-based amino-acid models take one gene"); goto bad; }
       aa_to_codon_freqs(p, p->pi_data, p->fb61);
@@ -485,6 +504,7 @@ genes_ok:
       const int rep = p->mgene >= 3 ? p->ngene : 1;
       if (p->seqtype == 1) {
          nr += !p->fix_kappa;
+         nr += p->npi;
          if (p->aadist == 7) nr += p->n_omega_type * (p->model == 2 ? p->n_omega : 1);      /* AAClasses: a set of class omegas (per branch label) */
          else if (p->aadist) nr += 2;                                                          /* a, b of omega(d) */
          else if (p->nssites == 0 && p->model == 2) nr += p->n_omega;      /* branch model: one omega per branch label (codeml.c:2170-2183) */
@@ -602,6 +622,58 @@ int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const 
    return 0;
 }
 
+/* ---- codon frequencies as parameters (estFreq = 1) and FMutSel0 / FMutSel ----------------------------------------------------------
+ * x after kappa (GetInitials codeml.c:2107-2134): pi_T / pi_G, pi_C / pi_G, pi_A / pi_G (F1x4 types and both FMutSel models; one triple
+ * per codon position for the F3x4 types), then — FMutSel0 with estFreq — 19 amino-acid fitnesses, or — FMutSel / Fcodon with
+ * estFreq — ncode - 1 codon fitnesses (logs, the last amino acid / codon at 0).  GetCodonFreqs (codeml.c:2690-2755) turns them into
+ * com.pf3x4 and com.pi. */
+static int codon_freq_initials(const pamlh *p, double *x)
+{
+   int k = 0, i, j, c, m;
+   if (p->mutsel || p->codonfreq == 1) for (i = 0; i < 3; i++) x[k++] = p->fb4[i] / p->fb4[3];
+   else if (p->codonfreq == 2) for (j = 0; j < 3; j++) for (i = 0; i < 3; i++) x[k++] = p->fb3x4[j * 4 + i] / p->fb3x4[j * 4 + 3];
+   if (p->mutsel == 1 && p->npi > 3) {
+      int nsyn[20] = {0};
+      for (c = 0; c < 64; c++) if (p->code[c] != '*') nsyn[aa_of_codon(p, c)]++;
+      for (i = 0; i < 19; i++) x[k++] = log((p->pi_aa[i] / nsyn[i] + .001) / (p->pi_aa[19] / nsyn[19] + .001));
+   }
+   else if ((p->mutsel == 2 && p->npi > 3) || (!p->mutsel && p->codonfreq == 3))
+      for (m = 0; m < p->n - 1; m++) x[k++] = log((p->pi_data[m] + .001) / (p->pi_data[p->n - 1] + .001));
+   return k;
+}
+
+static void codon_freqs_from_x(pamlh *p, const double *ppi)
+{
+   const int n = p->n;
+   int from61[64], m = 0, c, i, j, b[3];
+   double t;
+   for (c = 0; c < 64; c++) if (p->code[c] != '*') from61[m++] = c;
+   if (!p->mutsel && p->codonfreq == 3) {      /* Fcodon */
+      for (t = 0, i = 0; i < n; i++) { p->pi[i] = i == n - 1 ? 1 : exp(ppi[i]); t += p->pi[i]; }
+      for (i = 0; i < n; i++) p->pi[i] /= t;
+      return;
+   }
+   for (j = 0; j < 3; j++) {
+      for (t = 1, i = 0; i < 3; i++) { p->pf3x4[j * 4 + i] = ppi[i]; t += ppi[i]; }
+      p->pf3x4[j * 4 + 3] = 1;
+      for (i = 0; i < 4; i++) p->pf3x4[j * 4 + i] /= t;
+      if (!p->mutsel && p->codonfreq == 2) ppi += 3;
+   }
+   if (p->mutsel == 2 && p->npi == 3) { memcpy(p->pi, p->pi_data, n * sizeof(double)); return; }      /* the observed codon table */
+   if (p->mutsel == 1 && p->npi == 3) {      /* amino-acid frequencies as observed, synonymous codons by the mutation bias */
+      double mutbias[20] = {0};
+      for (i = 0; i < n; i++) { c = from61[i]; mutbias[aa_of_codon(p, c)] += p->pf3x4[c / 16] * p->pf3x4[(c / 4) % 4] * p->pf3x4[c % 4]; }
+      for (i = 0; i < n; i++) { c = from61[i]; p->pi[i] = p->pf3x4[c / 16] * p->pf3x4[(c / 4) % 4] * p->pf3x4[c % 4] / mutbias[aa_of_codon(p, c)] * p->pi_aa[aa_of_codon(p, c)]; }
+   }
+   else {
+      for (i = 0; i < n; i++) { c = from61[i]; b[0] = c / 16; b[1] = (c / 4) % 4; b[2] = c % 4; p->pi[i] = p->pf3x4[b[0]] * p->pf3x4[4 + b[1]] * p->pf3x4[8 + b[2]]; }
+      if (p->mutsel == 2) for (i = 0; i < n - 1; i++) p->pi[i] *= exp(ppi[3 + i]);
+      else if (p->mutsel == 1) for (i = 0; i < n; i++) { const int a = aa_of_codon(p, from61[i]); if (a < 19) p->pi[i] *= exp(ppi[3 + a]); }
+   }
+   for (t = 0, i = 0; i < n; i++) t += p->pi[i];
+   for (i = 0; i < n; i++) p->pi[i] /= t;
+}
+
 int pamlh_default_x(const pamlh *p, double *x, int cap)
 {
    int k = 0, i;
@@ -639,6 +711,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
    }
    if (p->seqtype == 1) {
       if (!p->fix_kappa) x[k++] = p->kappa0;
+      if (p->npi) k += codon_freq_initials(p, x + k);
       if (p->aadist == 7) { for (i = 0; i < p->n_omega_type * (p->model == 2 ? p->n_omega : 1); i++) x[k++] = 0.15 + 0.02 * (i % 4); }
       else if (p->aadist) { x[k++] = 0.15; x[k++] = 0.25; }
       else if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) x[k++] = p->omega0; }
@@ -798,7 +871,17 @@ static double codon_q_cls(const pamlh *p, const double *pi, double kappa, double
          if (f[pos] + t[pos] == 1 || f[pos] + t[pos] == 5) q = kappa;
          if (p->mg) {      /* divide by the frequencies of the two unchanged nucleotides: the rate depends on the target nucleotide only */
             const int b1 = (pos + 1) % 3, b2 = (pos + 2) % 3;
-            q /= (p->codonfreq == 2 ? p->fb3x4[b1 * 4 + t[b1]] * p->fb3x4[b2 * 4 + t[b2]] : p->fb4[t[b1]] * p->fb4[t[b2]]);
+            if (p->npi) q /= p->pf3x4[b1 * 4 + t[b1]] * p->pf3x4[b2 * 4 + t[b2]];      /* the tables in effect (parameters) */
+            else q /= (p->codonfreq == 2 ? p->fb3x4[b1 * 4 + t[b1]] * p->fb3x4[b2 * 4 + t[b2]] : p->fb4[t[b1]] * p->fb4[t[b2]]);
+            if (p->mutsel) {
+               /* fixation probability of a mutant of fitness F_j in a population of F_i, up to a constant (Yang & Nielsen 2008 eq. 2-4;
+                * GetMutationMultiplier codeml.c:3074-3084): e^F = pi / (mutation-bias product) */
+               const double small = 1e-6 < 1.0 / p->ls ? 1e-6 : 1.0 / p->ls;
+               double e1 = (pi[i] > small ? pi[i] : small) / (p->pf3x4[f[0]] * p->pf3x4[f[1]] * p->pf3x4[f[2]]);
+               double e2 = (pi[j] > small ? pi[j] : small) / (p->pf3x4[t[0]] * p->pf3x4[t[1]] * p->pf3x4[t[2]]);
+               if (fabs(e2 - e1) > 1e-10) q *= (log(e2) - log(e1)) / (e2 - e1);
+               else q /= e2;
+            }
          }
          if (p->code[c1] != p->code[c2]) {
             const int a1 = p->code[c1] - 'A', a2 = p->code[c2] - 'A';
@@ -1083,6 +1166,12 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
       double kappa = p->fix_kappa ? p->kappa0 : x[k++];
       memcpy(p->pi, p->pi_data, p->n * sizeof(double));
       p->kappa = kappa;
+      if (p->npi) {      /* frequency parameters: com.pi and com.pf3x4 from x (SetParameters codeml.c:2782-2785) */
+         for (i = 0; i < ((p->mutsel || p->codonfreq == 1) ? 3 : p->codonfreq == 2 ? 9 : 0); i++)
+            if (!(x[k + i] > 0)) { free(Q); return pamlh_fail(p, "frequency ratio %d is not positive", i + 1); }
+         codon_freqs_from_x(p, x + k);
+         k += p->npi;
+      }
       if (p->aadist && p->aadist != 7) {      /* omega a function of the amino-acid distance: x holds a, b */
          const double mr = codon_q_cls(p, p->pi, kappa, 1, x + k, Q);
          if (p->aadist < 0 && !(x[k] <= 1)) { free(Q); return pamlh_fail(p, "aaDist < 0 needs a <= 1"); }
@@ -1577,6 +1666,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
       if (rep > 1) snprintf(sfx, sizeof(sfx), " (gene %d)", g + 1);
       if (p->seqtype == 1) {
          if (!p->fix_kappa) NAME("kappa%s", sfx);
+         for (j = 0; j < p->npi; j++) NAME("codon frequency parameter %d", j + 1);
          if (p->aadist == 7) { int l; for (l = 0; l < (p->model == 2 ? p->n_omega : 1); l++) for (j = 0; j < p->n_omega_type; j++) NAME("omega class %d (branch type %d)", j, l); }
          else if (p->aadist) { NAME("a (omega against amino-acid distance)"); NAME("b"); }
          else if (p->nssites == 0 && p->model == 2) { for (j = 0; j < p->n_omega; j++) NAME("omega #%d", j); }

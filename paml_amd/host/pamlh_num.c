@@ -152,7 +152,7 @@ void pamlh_eigen_sym(double *A, int n, double *w, double *R)
 
 /* Reversible Q = S diag(pi): Root (descending), U, V with Q = U diag(Root) V  (tools.c:5023-5110).
  * States with pi == 0 are not expected here (the callers use strictly positive frequencies). */
-void pamlh_eigen_qrev(const double *Q, const double *pi, int n, double *Root, double *U, double *V)
+static void eigen_qrev_positive(const double *Q, const double *pi, int n, double *Root, double *U, double *V)
 {
    double *A = (double *)malloc((size_t)n * n * sizeof(double)), *R = (double *)malloc((size_t)n * n * sizeof(double));
    double *w = (double *)malloc(n * sizeof(double)), *sp = (double *)malloc(n * sizeof(double));
@@ -175,6 +175,28 @@ void pamlh_eigen_qrev(const double *Q, const double *pi, int n, double *Root, do
       }
    }
    free(A); free(R); free(w); free(sp); free(ord);
+}
+
+/* Q = S diag(pi) = U diag(Root) V.  States of frequency zero (an observed codon table of a small data set) are left out of the
+ * eigen problem and get Root = 0 and unit rows / columns of U and V — the chain never enters or leaves them (eigenQREV tools.c:5040-5105). */
+void pamlh_eigen_qrev(const double *Q, const double *pi, int n, double *Root, double *U, double *V)
+{
+   int *idx = (int *)malloc(n * sizeof(int)), m = 0, i, j;
+   for (i = 0; i < n; i++) if (pi[i] > 1e-100) idx[m++] = i;
+   if (m == n) eigen_qrev_positive(Q, pi, n, Root, U, V);
+   else {
+      double *Qr = (double *)malloc((size_t)m * m * sizeof(double)), *pr = (double *)malloc(m * sizeof(double));
+      double *Rr = (double *)malloc(m * sizeof(double)), *Ur = (double *)malloc((size_t)m * m * sizeof(double)), *Vr = (double *)malloc((size_t)m * m * sizeof(double));
+      for (i = 0; i < m; i++) { pr[i] = pi[idx[i]]; for (j = 0; j < m; j++) Qr[i * m + j] = Q[idx[i] * n + idx[j]]; }
+      eigen_qrev_positive(Qr, pr, m, Rr, Ur, Vr);
+      for (i = 0; i < n; i++) { Root[i] = 0; for (j = 0; j < n; j++) U[i * n + j] = V[i * n + j] = (i == j); }
+      for (i = 0; i < m; i++) {
+         Root[idx[i]] = Rr[i];
+         for (j = 0; j < m; j++) { U[idx[i] * n + idx[j]] = Ur[i * m + j]; V[idx[i] * n + idx[j]] = Vr[i * m + j]; }
+      }
+      free(Qr); free(pr); free(Rr); free(Ur); free(Vr);
+   }
+   free(idx);
 }
 
 /* regularised lower incomplete gamma P(a, x) */

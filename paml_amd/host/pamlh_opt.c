@@ -290,6 +290,10 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
    for (g = 0; g < rep; g++)
    if (p->seqtype == 1) {
       if (!p->fix_kappa) { lo[k] = 1e-4; hi[k++] = 999; }
+      for (i = 0; i < p->npi; i++) {      /* frequency ratios, then log fitnesses (SetxBound codeml.c:1921-1928) */
+         const int nratio = (p->mutsel || p->codonfreq == 1) ? 3 : p->codonfreq == 2 ? 9 : 0;
+         lo[k] = i < nratio ? 1e-4 : -29; hi[k++] = i < nratio ? 999 : 29;
+      }
       if (p->aadist == 7) { for (i = 0; i < p->n_omega_type * (p->model == 2 ? p->n_omega : 1); i++) { lo[k] = 1e-4; hi[k++] = 999; } }
       else if (p->aadist) { lo[k] = 1e-4; hi[k++] = p->aadist < 0 ? 1 : 999; lo[k] = 1e-4; hi[k++] = 999; }
       else if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) { lo[k] = 1e-4; hi[k++] = 999; } }

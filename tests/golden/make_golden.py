@@ -313,7 +313,7 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtyp
             rows = re.findall(r"^\s*\d+ \S\s+((?:[01]\.\d{5}\s+)+)\(\s*\d+\)", blk, re.M)
             ls = int([ln for ln in res1["lnf"] if ln.split()][0].split()[1])
             tables[key] = [[float(v) for v in r.split()] for r in rows[:ls]]
-    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha", "clock", "TipDate", "aaDist") if k in ctl_over}),
+    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha", "clock", "TipDate", "aaDist", "CodonFreq", "estFreq") if k in ctl_over}),
                                              x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
 
 
@@ -612,6 +612,13 @@ CASES = {
                                           dict(MTPRI_NUC, **{"grantham.dat": DAT + "/grantham.dat"}), 7, "codon_aadist"),
     "mtcdnapri_aadist_m2": lambda: case_mle("mtcdnapri_aadist_m2", dict(seqfile="mtCDNApri.nuc", treefile="mtCDNApri.trees", model=0, NSsites=0, icode=1, CodonFreq=2, aaDist=-2, kappa=3, omega=.4),
                                             dict(MTPRI_NUC, **{"miyata.dat": DAT + "/miyata.dat"}), 7, "codon_aadist"),
+    # codon frequencies as parameters (estFreq = 1) and the mutation-selection models FMutSel0 / FMutSel (CodonFreq 6, 7; Yang & Nielsen 2008)
+    "hiv_fmutsel0": lambda: case_mle("hiv_fmutsel0", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=6, estFreq=0, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
+    "hiv_fmutsel0_est": lambda: case_mle("hiv_fmutsel0_est", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=6, estFreq=1, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
+    "hiv_fmutsel": lambda: case_mle("hiv_fmutsel", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=7, estFreq=0, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
+    "hiv_fmutsel_est": lambda: case_mle("hiv_fmutsel_est", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=7, estFreq=1, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
+    "hiv_f3x4_est": lambda: case_mle("hiv_f3x4_est", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=2, estFreq=1, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
+    "hiv_f1x4mg_est": lambda: case_mle("hiv_f1x4mg_est", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, estFreq=1, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
                                     {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,

@@ -38,6 +38,10 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("brown_hky85_nhomo2", "baseml", "brown_hky85_nhomo2.ctl"), ("brown_hky85_nhomo3", "baseml", "brown_hky85_nhomo3.ctl"),
          ("brown_f84_nhomo4", "baseml", "brown_f84_nhomo4.ctl"), ("brown_t92_nhomo3_g4", "baseml", "brown_t92_nhomo3_g4.ctl"), ("mhc_m0_prop", "codeml", "mhc_m0_prop.ctl"), ("stewart_eqinput", "codeml", "stewart_eqinput.ctl"),
          ("hiv_m0_f3x4mg", "codeml", "hiv_ns0_cf5.ctl"), ("hiv_m0_f1x4mg", "codeml", "hiv_ns0_cf4.ctl"),      # Muse-Gaut style rates
+         # mutation-selection models FMutSel0 / FMutSel (mutation bias + amino-acid / codon fitnesses, implied by the observed frequencies or
+         # estimated) and codon frequencies as parameters (estFreq = 1); the observed codon table of these 91 codons has 12 zeros
+         ("hiv_fmutsel0", "codeml", "hiv_fmutsel0.ctl"), ("hiv_fmutsel0_est", "codeml", "hiv_fmutsel0_est.ctl"), ("hiv_fmutsel", "codeml", "hiv_fmutsel.ctl"),
+         ("hiv_fmutsel_est", "codeml", "hiv_fmutsel_est.ctl"), ("hiv_f3x4_est", "codeml", "hiv_f3x4_est.ctl"), ("hiv_f1x4mg_est", "codeml", "hiv_f1x4mg_est.ctl"),
          # option G (several genes): rates only (Mgene 0), + frequencies (2), + kappa / omega (3), both (4); one with gamma
          ("horai_mg0", "baseml", "horai_mg0.ctl"), ("horai_mg2", "baseml", "horai_mg2.ctl"), ("horai_mg3", "baseml", "horai_mg3.ctl"),
          ("horai_mg4", "baseml", "horai_mg4.ctl"), ("horai_mg0_g5", "baseml", "horai_mg0_g5.ctl"),
@@ -694,6 +698,19 @@ def test_c_host_optimiser_with_amino_acid_distances(gname):
     a = hostlib.Analysis(os.path.join(CTL, gname + ".ctl"), "codeml")
     r = a.optimize(a.default_x())
     assert r["converged"] and abs(r["lnL"] - g["mle_lnL"]) < 2e-4, (r["lnL"], g["mle_lnL"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname", ["hiv_fmutsel0", "hiv_fmutsel", "hiv_f3x4_est", "hiv_fmutsel0_est"])
+def test_c_host_optimiser_with_frequency_parameters(gname):
+    """FMutSel0 / FMutSel with three mutation-bias parameters, F3x4 with its nine frequency ratios estimated, FMutSel0 with the 19
+    amino-acid fitnesses as well: every trial point has its own codon frequencies (root distribution, rates and mutation
+    multipliers), so the batches are evaluated in groups of equal frequencies; from the host's initial values the optimiser
+    reaches the reference's maximum (flat directions in the fitnesses: not lower, possibly slightly higher)."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, gname + ".ctl"), "codeml")
+    r = a.optimize(a.default_x(), max_iter=3000)
+    assert -2e-3 < r["lnL"] - g["mle_lnL"] < 0.05, (r["lnL"], g["mle_lnL"], r["converged"])
 
 
 def test_c_host_aaclasses_needs_its_class_file(tmp_path):
