@@ -54,10 +54,12 @@ def test_random_models(n, n_tips, n_patt, K):
 
 
 @pytest.mark.parametrize("n_tips,n_patt,K,kw", [(6, 98, 4, {}), (24, 1000, 1, {}), (40, 700, 3, dict(ambiguity=True)), (30, 300, 2, dict(scale_every=4)),
-                                                 (11, 513, 2, dict(polytomy=True)), (49, 260, 1, {}), (3, 40, 2, {})])
+                                                 (11, 513, 2, dict(polytomy=True)), (49, 260, 1, {}), (3, 40, 2, {}),
+                                                 (12, 20011, 2, {}), (9, 70001, 1, dict(ambiguity=True))])      # many units per workgroup: ranges, tickets, a ragged last unit
 def test_20_state_kernel_on_4x4x4_mfma(n_tips, n_patt, K, kw):
-    """The per-tree 20-state kernel on v_mfma_f64_4x4x4 (jit_generate_m20: five 4-state blocks per partial, P(t) of every
-    internal branch in LDS) against the oracle: clean and ambiguous tips, scaling nodes, polytomies, the largest tree it takes."""
+    """The per-tree 20-state kernel (jit_generate_m20: five 4-state blocks per partial, rows 0-15 of every product on
+    v_mfma_f64_16x16x4 and rows 16-19 on v_mfma_f64_4x4x4, P(t) of every internal branch in LDS, units of 32 patterns handed out by
+    an LDS ticket) against the oracle: clean and ambiguous tips, scaling nodes, polytomies, the largest tree it takes."""
     pb = helpers.random_problem(20, n_tips, n_patt, K=K, seed=500 + n_tips, **kw)
     eng, out, ref = check(pb, flags=JIT)
     assert eng.kernel_name == ("mfma4x20_jit" if n_tips > 3 else eng.kernel_name)
