@@ -619,6 +619,8 @@ CASES = {
     "hiv_fmutsel_est": lambda: case_mle("hiv_fmutsel_est", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=7, estFreq=1, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_f3x4_est": lambda: case_mle("hiv_f3x4_est", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=2, estFreq=1, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_f1x4mg_est": lambda: case_mle("hiv_f1x4mg_est", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, estFreq=1, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
+    "hiv_fmutsel0_m2a": lambda: case_mle("hiv_fmutsel0_m2a", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=2, CodonFreq=6, estFreq=0, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
+    "hiv_f3x4_est_m7": lambda: case_mle("hiv_f3x4_est_m7", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=7, ncatG=10, CodonFreq=2, estFreq=1, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
                                     {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,

@@ -42,6 +42,7 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          # estimated) and codon frequencies as parameters (estFreq = 1); the observed codon table of these 91 codons has 12 zeros
          ("hiv_fmutsel0", "codeml", "hiv_fmutsel0.ctl"), ("hiv_fmutsel0_est", "codeml", "hiv_fmutsel0_est.ctl"), ("hiv_fmutsel", "codeml", "hiv_fmutsel.ctl"),
          ("hiv_fmutsel_est", "codeml", "hiv_fmutsel_est.ctl"), ("hiv_f3x4_est", "codeml", "hiv_f3x4_est.ctl"), ("hiv_f1x4mg_est", "codeml", "hiv_f1x4mg_est.ctl"),
+         ("hiv_fmutsel0_m2a", "codeml", "hiv_fmutsel0_m2a.ctl"), ("hiv_f3x4_est_m7", "codeml", "hiv_f3x4_est_m7.ctl"),      # ... under site models
          # option G (several genes): rates only (Mgene 0), + frequencies (2), + kappa / omega (3), both (4); one with gamma
          ("horai_mg0", "baseml", "horai_mg0.ctl"), ("horai_mg2", "baseml", "horai_mg2.ctl"), ("horai_mg3", "baseml", "horai_mg3.ctl"),
          ("horai_mg4", "baseml", "horai_mg4.ctl"), ("horai_mg0_g5", "baseml", "horai_mg0_g5.ctl"),
