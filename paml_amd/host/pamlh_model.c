@@ -297,8 +297,9 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    p->nhomo = p->is_codeml ? 0 : (int)pamlh_optd(p, "nhomo", 0);
    /* nhomo (baseml.c:1748-1760): 0 frequencies from the data, 1 as parameters, 2 a kappa per branch, 3 a frequency set for every
     * tip branch, one for the internal branches and one at the root, 4 a set for every node; 3 and 4 with a kappa per branch
-    * (fix_kappa = 0) or one kappa for all (fix_kappa = 1).  5 (sets by labels in the tree file) is not supported. */
-   if (p->nhomo < 0 || p->nhomo > 4) { rc = pamlh_fail(p, "nhomo = %d is not supported (0 ... 4)", p->nhomo); goto bad; }
+    * (fix_kappa = 0), one kappa for all (fix_kappa = 1) or one per branch label (fix_kappa = 2); 5 the frequency sets by the '#'
+    * labels of the tree file (the root takes a set of its own when it carries the next unused label). */
+   if (p->nhomo < 0 || p->nhomo > 5) { rc = pamlh_fail(p, "nhomo = %d is not supported (0 ... 5)", p->nhomo); goto bad; }
    p->clock = (int)pamlh_optd(p, "clock", 0);
    if (p->clock < 0 || p->clock > 2) { rc = pamlh_fail(p, "clock = %d is not supported (0: no clock, 1: global clock, 2: local clocks by '#' rate labels in the tree)", p->clock); goto bad; }
    if ((v = pamlh_opt(p, "TipDate")) && atoi(v) != 0) {      /* "TipDate = 1 100": flag and time unit (GetOptions baseml.c / codeml.c) */
@@ -391,7 +392,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
       if (p->ngene > 1) { rc = pamlh_fail(p, "nhomo for several genes?"); goto bad; }
       if (p->nhomo == 2 && p->model != K80 && p->model != F84 && p->model != HKY85) { rc = pamlh_fail(p, "nhomo = 2 works with K80, F84 or HKY85"); goto bad; }
       if (p->nhomo > 2 && (p->model < F84 || p->model > REV)) { rc = pamlh_fail(p, "nhomo = %d needs a model with base frequencies and rate parameters (F84 ... REV)", p->nhomo); goto bad; }
-      if (p->nhomo > 2 && p->fix_kappa > 1) { rc = pamlh_fail(p, "nhomo with fix_kappa = 2 (rate sets by branch labels) is not supported"); goto bad; }
+      if (p->nhomo > 2 && (p->fix_kappa < 0 || p->fix_kappa > 2)) { rc = pamlh_fail(p, "nhomo: fix_kappa = %d?", p->fix_kappa); goto bad; }
       if (p->nnode > PAMLH_MAXEIG) { rc = pamlh_fail(p, "nhomo >= 2: more than %d nodes", PAMLH_MAXEIG); goto bad; }
       if (!p->fix_rho || p->rho0 != 0) { rc = pamlh_fail(p, "nhomo with rho is not supported"); goto bad; }
    }
@@ -419,6 +420,12 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    }
 genes_ok:
    if (p->clock == 2) { p->rate_label = (int *)malloc(p->nnode * sizeof(int)); memcpy(p->rate_label, p->label, p->nnode * sizeof(int)); }      /* local clocks: '#' = rate class */
+   if (p->seqtype == 0 && p->nhomo >= 3) {      /* nhomo 5 / fix_kappa 2: '#' = set (ReadTreeN treesub.c:8878-8885: branch types = largest label + 1, the root aside) */
+      int v;
+      p->nh_label = (int *)malloc(p->nnode * sizeof(int)); memcpy(p->nh_label, p->label, p->nnode * sizeof(int));
+      for (p->nh_nbtype = 0, v = 0; v < p->nnode; v++) if (v != p->root && p->nh_label[v] + 1 > p->nh_nbtype) p->nh_nbtype = p->nh_label[v] + 1;
+      if (p->nhomo == 5 && (p->nh_label[p->root] < 0 || p->nh_label[p->root] > p->nh_nbtype)) { rc = pamlh_fail(p, "nhomo = 5: label for root strange?"); goto bad; }
+   }
    if (!(p->seqtype == 1 && p->model >= 2)) memset(p->label, 0, p->nnode * sizeof(int));      /* '#' labels only matter to branch models */
    if (p->seqtype == 0 && p->nhomo >= 2) { int v; for (v = 0; v < p->nnode; v++) p->label[v] = v; }      /* every branch has its own P(t) family */
    if (p->seqtype == 1 && p->model >= 2) {
@@ -559,7 +566,7 @@ void pamlh_free(pamlh *p)
    if (p->eng) paml_amd_destroy(p->eng);
    if (p->names) for (i = 0; i < p->ns; i++) free(p->names[i]);
    free(p->names); free(p->z); free(p->w); free(p->raw); free(p->n_chara); free(p->chara_map);
-   free(p->rate_label); free(p->tip_age); free(p->age_low);
+   free(p->rate_label); free(p->nh_label); free(p->tip_age); free(p->age_low);
    free(p->sons_ptr); free(p->sons); free(p->label); free(p->branch_node); free(p->father); free(p->tree_branch); free(p->scale);
    free(p->branch); free(p->pi); free(p->freqK); free(p->rate); free(p->eigen_of);
    for (i = 0; i < PAMLH_MAXEIG; i++) { free(p->eig[i].U); free(p->eig[i].V); free(p->eig[i].Root); free(p->eig[i].Cijk); }
@@ -1017,9 +1024,17 @@ static int nh_nk(const pamlh *p)
    static const int nkappa[] = {0, 1, 0, 1, 1, 1, 2, 5, 11};
    return nkappa[p->model];
 }
-int pamlh_nh_nrate(const pamlh *p) { return p->nhomo == 2 ? p->nbranch : nh_nk(p) * (p->fix_kappa ? 1 : p->nbranch); }
-int pamlh_nh_npi(const pamlh *p) { return p->nhomo == 4 ? p->nnode : p->nhomo == 3 ? p->ns + 1 + (p->root >= p->ns) : 0; }
-static int nh_piset(const pamlh *p, int v) { return p->nhomo == 4 ? v : (v < p->ns ? v : (v == p->root ? p->ns + 1 : p->ns)); }
+int pamlh_nh_nrate(const pamlh *p) { return p->nhomo == 2 ? p->nbranch : nh_nk(p) * (p->fix_kappa == 0 ? p->nbranch : p->fix_kappa == 1 ? 1 : p->nh_nbtype); }
+int pamlh_nh_npi(const pamlh *p)
+{
+   if (p->nhomo == 5) return p->nh_nbtype + (p->root >= p->ns && p->nh_label[p->root] == p->nh_nbtype);
+   return p->nhomo == 4 ? p->nnode : p->nhomo == 3 ? p->ns + 1 + (p->root >= p->ns) : 0;
+}
+static int nh_piset(const pamlh *p, int v)
+{
+   if (p->nhomo == 5) return p->nh_label[v];
+   return p->nhomo == 4 ? v : (v < p->ns ? v : (v == p->root ? p->ns + 1 : p->ns));
+}
 
 static int set_x_nhomo(pamlh *p, const double *x, int *kio, double *Q)
 {
@@ -1045,7 +1060,7 @@ static int set_x_nhomo(pamlh *p, const double *x, int *kio, double *Q)
       }
       for (i = 0; i < p->nbranch && p->branch_node[i] != v; i++) ;
       p->fix_kappa = 0;      /* the rate parameters of this branch are always read from x */
-      nuc_set(p, v, pi, p->nhomo == 2 ? rates + i : (fix ? rates : rates + (size_t)i * nk), Q);
+      nuc_set(p, v, pi, p->nhomo == 2 ? rates + i : (fix == 0 ? rates + (size_t)i * nk : fix == 1 ? rates : rates + (size_t)p->nh_label[v] * nk), Q);
       p->fix_kappa = fix;
    }
    p->n_labels = p->n_eigen = p->nnode;
@@ -1470,6 +1485,7 @@ int pamlh_gene_subset(const pamlh *p, int g, pamlh **out)
    DUP(father, 2 * p->ns, int); DUP(tree_branch, 2 * p->ns, double);
    if (p->scale) DUP(scale, p->nnode, unsigned char);
    if (p->rate_label) DUP(rate_label, p->nnode, int);
+   if (p->nh_label) DUP(nh_label, p->nnode, int);
    if (p->tip_age) { DUP(tip_age, p->nnode, double); DUP(age_low, p->nnode, double); }
 #undef DUP
    q->branch = (double *)calloc(p->nnode, sizeof(double));

@@ -621,6 +621,9 @@ CASES = {
     "hiv_f1x4mg_est": lambda: case_mle("hiv_f1x4mg_est", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, estFreq=1, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_fmutsel0_m2a": lambda: case_mle("hiv_fmutsel0_m2a", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=2, CodonFreq=6, estFreq=0, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
     "hiv_f3x4_est_m7": lambda: case_mle("hiv_f3x4_est_m7", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=7, ncatG=10, CodonFreq=2, estFreq=1, kappa=.3, omega=1.3), HIVF, 13, "codon_nssites"),
+    # nhomo = 5: frequency sets by the tree's '#' labels (two branch types, the root a third set), with a kappa per label (fix_kappa = 2)
+    "brown_hky85_nhomo5": lambda: case_mle("brown_hky85_nhomo5", dict(seqfile="brown.nuc", treefile="brown.nhomo5.trees", model=4, kappa=5, nhomo=5, fix_kappa=2),
+                                           {"brown.nuc": EX + "/brown.nuc", "brown.nhomo5.trees": "  5  1\n\n((1,2) #1, 3 #1, (4,5)) #2;\n"}, 5, "nuc", prog="baseml", seqtype="nuc"),
     "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
                                     {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,

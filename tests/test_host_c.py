@@ -36,7 +36,8 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          # non-homogeneous models: a kappa per branch (2); frequency sets per branch (3: tips / internal / root, 4: every node), every
          # branch with its own eigen system (one label per node); the nhomo3 estimate has a frequency on the boundary (0.000000)
          ("brown_hky85_nhomo2", "baseml", "brown_hky85_nhomo2.ctl"), ("brown_hky85_nhomo3", "baseml", "brown_hky85_nhomo3.ctl"),
-         ("brown_f84_nhomo4", "baseml", "brown_f84_nhomo4.ctl"), ("brown_t92_nhomo3_g4", "baseml", "brown_t92_nhomo3_g4.ctl"), ("mhc_m0_prop", "codeml", "mhc_m0_prop.ctl"), ("stewart_eqinput", "codeml", "stewart_eqinput.ctl"),
+         ("brown_f84_nhomo4", "baseml", "brown_f84_nhomo4.ctl"), ("brown_t92_nhomo3_g4", "baseml", "brown_t92_nhomo3_g4.ctl"),
+         ("brown_hky85_nhomo5", "baseml", "brown_hky85_nhomo5.ctl"),      # frequency sets and kappas by the tree's '#' labels, the root a set of its own ("mhc_m0_prop", "codeml", "mhc_m0_prop.ctl"), ("stewart_eqinput", "codeml", "stewart_eqinput.ctl"),
          ("hiv_m0_f3x4mg", "codeml", "hiv_ns0_cf5.ctl"), ("hiv_m0_f1x4mg", "codeml", "hiv_ns0_cf4.ctl"),      # Muse-Gaut style rates
          # mutation-selection models FMutSel0 / FMutSel (mutation bias + amino-acid / codon fitnesses, implied by the observed frequencies or
          # estimated) and codon frequencies as parameters (estFreq = 1); the observed codon table of these 91 codons has 12 zeros
@@ -310,7 +311,7 @@ def test_c_host_clade_model_neb_and_beb_match_the_reference_rst(gname, ctl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gname", ["brown_hky85_nhomo1", "brown_hky85_nhomo2", "brown_t92_nhomo3_g4", "brown_f84_nhomo4"])
+@pytest.mark.parametrize("gname", ["brown_hky85_nhomo1", "brown_hky85_nhomo2", "brown_t92_nhomo3_g4", "brown_f84_nhomo4", "brown_hky85_nhomo5"])
 def test_c_host_optimiser_on_nonhomogeneous_models(gname):
     """nhomo = 2 (seven kappas), 3 with T92 + gamma (seven GC contents, one kappa, alpha) and 4 with F84 (eight frequency sets):
     one eigen system per branch, selected through the engine's branch labels; from the control file's initial values the
