@@ -75,6 +75,8 @@ struct pamlh {
    /* aaDist = 7 (AAClasses, codeml.c:4079 GetOmegaAA): dN/dS classes of amino-acid pairs, from OmegaAA.dat beside the ctl */
    int tipdate;                /* TipDate: the sequence names end in sampling dates; x has the mutation rate after the node ages */
    double tip_timeunit, *tip_age, *age_low;   /* ages of the tips (0 = the youngest) in time units; lowest possible age of every node */
+   unsigned char aa1step[400];   /* aa models 8, 9 (REVaa_0 / REVaa): the exchangeabilities that are parameters (i > j), in x's order */
+   int n_aarate;
    int *nh_label, nh_nbtype;   /* nhomo = 5 / fix_kappa = 2: the tree file's '#' labels name the frequency / rate sets; number of branch types */
    int *rate_label, n_brate;   /* clock = 2: rate class of the branch above every node, number of classes */
    int malpha;               /* Malpha: a gamma shape per gene; rate[] then holds [gene][class] */

@@ -360,7 +360,28 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    }
    else if (p->seqtype == 2) {
       p->n = 20; p->aa_model = p->model;
-      if ((p->aa_model < 0 || p->aa_model > 3) && p->aa_model != 5 && p->aa_model != 6) { rc = pamlh_fail(p, "amino-acid model %d is not supported", p->aa_model); goto bad; }
+      if ((p->aa_model < 0 || p->aa_model > 3) && p->aa_model != 5 && p->aa_model != 6 && p->aa_model != 8 && p->aa_model != 9) { rc = pamlh_fail(p, "amino-acid model %d is not supported", p->aa_model); goto bad; }
+      if (p->aa_model >= 8) {
+         /* REVaa_0 (8): an exchangeability for every pair of amino acids one nucleotide change apart under the genetic code, the others 0;
+          * REVaa (9): all 190; the pair V-I is the unit (ijAAref codeml.c:1091, SetAA1STEP 4044, eigenQaa 3423-3436) */
+         int i, j, c1, c2, step[400] = {0};
+         if (p->icode != 0 && p->icode != 1) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0: universal, 1: vertebrate mt)", p->icode); goto bad; }
+         strcpy(p->code, GENETIC_CODES[p->icode]);
+         for (c1 = 0; c1 < 64; c1++)
+            for (c2 = 0; c2 < c1; c2++) {
+               const int nd = (c1 / 16 != c2 / 16) + ((c1 / 4) % 4 != (c2 / 4) % 4) + (c1 % 4 != c2 % 4);
+               if (nd == 1 && p->code[c1] != '*' && p->code[c2] != '*') { const int a = aa_of_codon(p, c1), b = aa_of_codon(p, c2); step[a * 20 + b] = step[b * 20 + a] = 1; }
+            }
+         memset(p->aa1step, 0, sizeof(p->aa1step));
+         for (p->n_aarate = 0, i = 1; i < 20; i++)
+            for (j = 0; j < i; j++)
+               if ((p->aa_model == 9 || step[i * 20 + j]) && i * 20 + j != 19 * 20 + 9) { p->aa1step[i * 20 + j] = 1; p->n_aarate++; }
+         if ((v = pamlh_opt(p, "aaRatefile")) && *v) {      /* initial values */
+            resolve(p, v, p->aaratefile, sizeof(p->aaratefile));
+            if ((rc = read_aa_ratefile(p))) goto bad;
+         }
+         else { for (i = 0; i < 400; i++) p->aaS[i] = 1; }
+      }
       if (p->aa_model >= 5) {
          /* codon-based amino-acid models (Yang, Nielsen & Hasegawa 1998): 6 (FromCodon) a 20-state chain whose rates are the
           * codon chain's aggregated over synonymous codons, 5 (FromCodon0) the codon chain itself with every amino acid read as
@@ -531,6 +552,7 @@ genes_ok:
          else if (p->nssites == 8) nr += 3 + !p->fix_omega;
       }
       else if (p->seqtype == 2 && p->aa_model == 6) nr += !p->fix_kappa;
+      else if (p->seqtype == 2 && p->aa_model >= 8) nr += p->n_aarate;
       else if (p->seqtype == 0) {
          if (p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) nr += !p->fix_kappa;
          else if (p->model == TN93) nr += 2 * !p->fix_kappa;
@@ -749,7 +771,10 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       else if (p->nssites == 7) { x[k++] = 0.5; x[k++] = 1.5; }
       else if (p->nssites == 8) { x[k++] = 0.9; x[k++] = 0.5; x[k++] = 1.5; if (!p->fix_omega) x[k++] = 2.5; }
    }
-   else if (p->seqtype == 2) { if (p->aa_model == 6 && !p->fix_kappa) x[k++] = p->kappa0; }
+   else if (p->seqtype == 2) {
+      if (p->aa_model == 6 && !p->fix_kappa) x[k++] = p->kappa0;
+      if (p->aa_model >= 8) { int a, b; for (a = 1; a < 20; a++) for (b = 0; b < a; b++) if (p->aa1step[a * 20 + b]) { const double u = p->aaS[19 * 20 + 9] > 0 ? p->aaS[a * 20 + b] / p->aaS[19 * 20 + 9] : 1; x[k++] = u > 1e-3 ? u : 1e-3; } }
+   }
    else if (p->seqtype == 0) {
       if ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) x[k++] = p->kappa0;
       else if (p->model == TN93 && !p->fix_kappa) { x[k++] = p->kappa0; x[k++] = p->kappa0; }
@@ -1337,6 +1362,15 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          for (i = 0; i < 20; i++) p->pi[i] = 1.0 / 20;
          p->eig[0].kind = PAML_AMD_EIGEN_JC69LIKE;
       }
+      else if (p->aa_model >= 8) {
+         double S[400] = {0};
+         memcpy(p->pi, p->pi_data, 20 * sizeof(double));
+         for (i = 1; i < 20; i++) for (j = 0; j < i; j++) if (p->aa1step[i * 20 + j]) S[i * 20 + j] = S[j * 20 + i] = x[k++];
+         S[19 * 20 + 9] = S[9 * 20 + 19] = 1;
+         for (i = 0; i < 20; i++) for (j = 0; j < 20; j++) Q[i * 20 + j] = (i == j) ? 0 : S[i * 20 + j] * p->pi[j];
+         for (i = 0; i < 20; i++) { double sm = 0; for (j = 0; j < 20; j++) sm += Q[i * 20 + j]; Q[i * 20 + i] = -sm; mr += p->pi[i] * sm; }
+         set_eig_uvroot(p, 0, Q, p->pi, mr);
+      }
       else if (p->aa_model == 6) {
          /* FromCodon: exchangeability of two amino acids = the codon chain's flow between their codon sets, under codon
           * frequencies fb61 and kappa, over the product of the two amino-acid frequencies (Qcodon2aa codeml.c:3487-3523;
@@ -1706,7 +1740,10 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
          else if (p->nssites == 7) { NAME("p (beta)"); NAME("q (beta)"); }
          else if (p->nssites == 8) { NAME("p0"); NAME("p (beta)"); NAME("q (beta)"); if (!p->fix_omega) NAME("ws"); }
       }
-      else if (p->seqtype == 2) { if (p->aa_model == 6 && !p->fix_kappa) NAME("kappa"); }
+      else if (p->seqtype == 2) {
+         if (p->aa_model == 6 && !p->fix_kappa) NAME("kappa");
+         if (p->aa_model >= 8) { static const char AAS[] = "ARNDCQEGHILKMFPSTWYV"; int a, b; for (a = 1; a < 20; a++) for (b = 0; b < a; b++) if (p->aa1step[a * 20 + b]) NAME("exchangeability %c-%c", AAS[a], AAS[b]); }
+      }
       else if (p->seqtype == 0 && p->nhomo < 2) {
          if (p->model == UNREST) { for (j = 0; j < 11; j++) NAME("rate %d%s", j + 1, sfx); }
          else if (p->model == REV) { static const char *const r[5] = {"a (TC)", "b (TA)", "c (TG)", "d (CA)", "e (CG)"}; for (j = 0; j < 5; j++) NAME("%s%s", r[j], sfx); }

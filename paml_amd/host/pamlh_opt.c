@@ -330,7 +330,10 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
          if (!p->fix_omega) { lo[k] = 1; hi[k++] = 999; }
       }
    }
-   else if (p->seqtype == 2) { if (p->aa_model == 6 && !p->fix_kappa) { lo[k] = 1e-4; hi[k++] = 999; } }
+   else if (p->seqtype == 2) {
+      if (p->aa_model == 6 && !p->fix_kappa) { lo[k] = 1e-4; hi[k++] = 999; }
+      if (p->aa_model >= 8) for (i = 0; i < p->n_aarate; i++) { lo[k] = 1e-5; hi[k++] = 999; }
+   }
    else if (p->seqtype == 0) {
       const int nk = ((p->model == K80 || p->model == HKY85 || p->model == F84 || p->model == T92) && !p->fix_kappa) ? 1 : (p->model == TN93 && !p->fix_kappa) ? 2 : p->model == REV ? 5 : p->model == UNREST ? 11 : 0;
       for (i = 0; i < nk; i++) { lo[k] = 1e-4; hi[k++] = 999; }

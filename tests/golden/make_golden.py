@@ -624,6 +624,12 @@ CASES = {
     # nhomo = 5: frequency sets by the tree's '#' labels (two branch types, the root a third set), with a kappa per label (fix_kappa = 2)
     "brown_hky85_nhomo5": lambda: case_mle("brown_hky85_nhomo5", dict(seqfile="brown.nuc", treefile="brown.nhomo5.trees", model=4, kappa=5, nhomo=5, fix_kappa=2),
                                            {"brown.nuc": EX + "/brown.nuc", "brown.nhomo5.trees": "  5  1\n\n((1,2) #1, 3 #1, (4,5)) #2;\n"}, 5, "nuc", prog="baseml", seqtype="nuc"),
+    # general reversible amino-acid models: REVaa_0 (exchangeabilities of the amino-acid pairs one nucleotide change apart: 74 under the
+    # universal code) and REVaa (all 189), initial values from jones.dat
+    "mtcdnapri_revaa0": lambda: case_mle("mtcdnapri_revaa0", dict(seqfile="mtCDNApri.aa", treefile="mtCDNApri.trees", seqtype=2, model=8, aaRatefile="jones.dat", icode=1, cleandata=1),
+                                         dict(MTPRI_AA, **{"jones.dat": DAT + "/jones.dat"}), 7, "aa_revaa", seqtype="aa"),
+    "mtcdnapri_revaa": lambda: case_mle("mtcdnapri_revaa", dict(seqfile="mtCDNApri.aa", treefile="mtCDNApri.trees", seqtype=2, model=9, aaRatefile="jones.dat", icode=1, cleandata=1),
+                                        dict(MTPRI_AA, **{"jones.dat": DAT + "/jones.dat"}), 7, "aa_revaa", seqtype="aa"),
     "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
                                     {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,

@@ -24,6 +24,8 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("mtcdnapri_aadist1", "codeml", "mtcdnapri_aadist1.ctl"), ("mtcdnapri_aadist_m2", "codeml", "mtcdnapri_aadist_m2.ctl"),
          # codon-based amino-acid models: 6 = FromCodon (20 states), 5 = FromCodon0 (60 codon states, amino acids as codon sets)
          ("mtcdnapri_fromcodon", "codeml", "mtcdnapri_fromcodon.ctl"), ("mtcdnapri_fromcodon0", "codeml", "mtcdnapri_fromcodon0.ctl"),
+         # general reversible amino-acid models: REVaa_0 (69 exchangeabilities under the mt code) and REVaa (189)
+         ("mtcdnapri_revaa0", "codeml", "mtcdnapri_revaa0.ctl"), ("mtcdnapri_revaa", "codeml", "mtcdnapri_revaa.ctl"),
          # branch-site A (alternative and null), B; clade C, D; M3 — goldens at the reference's own 6-decimal MLEs
          ("lyso_bsa", "codeml", "lyso_bsa.ctl"), ("lyso_bsa_null", "codeml", "lyso_bsa_null.ctl"), ("lyso_bsb", "codeml", "lyso_bsb.ctl"),
          ("ecp_cmc", "codeml", "ecp_cmc.ctl"), ("ecp_cmd", "codeml", "ecp_cmd.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl"), ("hiv_m4", "codeml", "hiv_ns4.ctl"), ("hiv_m5", "codeml", "hiv_ns5.ctl"), ("hiv_m6", "codeml", "hiv_ns6.ctl"), ("hiv_m9", "codeml", "hiv_ns9.ctl"),
@@ -713,6 +715,17 @@ def test_c_host_optimiser_with_frequency_parameters(gname):
     a = hostlib.Analysis(os.path.join(CTL, gname + ".ctl"), "codeml")
     r = a.optimize(a.default_x(), max_iter=3000)
     assert -2e-3 < r["lnL"] - g["mle_lnL"] < 0.05, (r["lnL"], g["mle_lnL"], r["converged"])
+
+
+@pytest.mark.gpu
+def test_c_host_optimiser_with_69_exchangeabilities():
+    """REVaa_0 on the 7-ape mitochondrial proteins: 11 branch lengths + the exchangeabilities of the amino-acid pairs one nucleotide
+    change apart, from jones.dat's values to the reference's maximum (a gradient is one batch of 2 x 80 evaluations)."""
+    g = helpers.load_golden("mtcdnapri_revaa0")
+    a = hostlib.Analysis(os.path.join(CTL, "mtcdnapri_revaa0.ctl"), "codeml")
+    assert a.np == 80
+    r = a.optimize(a.default_x(), max_iter=3000)
+    assert -5e-3 < r["lnL"] - g["mle_lnL"] < 0.5, (r["lnL"], g["mle_lnL"], r["converged"])
 
 
 def test_c_host_aaclasses_needs_its_class_file(tmp_path):
