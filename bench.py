@@ -77,8 +77,8 @@ def check_lnl(what, lnl, name, n_patt, seed_default):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10, help="untimed evaluations first (the chip reaches its sustained clock over the first few)")
     ap.add_argument("--patterns", type=int, default=1_000_000, help="site patterns (strong: in all; weak: per GPU)")
     ap.add_argument("--taxa", type=int, default=16)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")

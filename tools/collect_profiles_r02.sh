@@ -5,7 +5,7 @@
 out=$PWD/gpurun_out/r2prof
 mkdir -p $out
 export TMPDIR=/tmp
-B="python $PWD/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras"      # bench.py's default step counts, headline only
+B="python $PWD/bench.py --no-cpu-baseline --no-extras"      # bench.py with its default step counts, headline only
 C2="python $PWD/tools/c2_probe.py"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $B > $out/bench_under_rocprof.json 2>$out/stats.err
