@@ -728,6 +728,34 @@ def test_c_host_optimiser_with_69_exchangeabilities():
     assert -5e-3 < r["lnL"] - g["mle_lnL"] < 0.5, (r["lnL"], g["mle_lnL"], r["converged"])
 
 
+def test_c_host_rejects_option_combinations_it_does_not_cover(tmp_path):
+    """Options outside what the host implements are refused with a message, not evaluated under another model."""
+    data = os.path.join(helpers.GOLDEN, "data") + "/"
+
+    def load(base, prog, **over):
+        txt = open(os.path.join(CTL, base)).read().replace("../data/", data)
+        for k, v in over.items():
+            txt = re.sub(r"^\s*%s\s*=.*$" % k, "", txt, flags=re.M) + "\n %s = %s\n" % (k, v)
+        f = tmp_path / "x.ctl"
+        f.write_text(txt)
+        return hostlib.Analysis(str(f), prog)
+
+    with pytest.raises(RuntimeError, match="sampling date"):
+        load("brown_hky85_clock.ctl", "baseml", TipDate="1 100")             # names without dates
+    with pytest.raises(RuntimeError, match="branch rate labels"):
+        load("brown_hky85_clock.ctl", "baseml", clock=2)                     # local clocks without '#' labels
+    with pytest.raises(RuntimeError, match="branch models"):
+        load("mtcdna_branch.ctl", "codeml", CodonFreq=6)                      # FMutSel0 + branch model
+    with pytest.raises(RuntimeError, match="Malpha"):
+        load("brown_hky85_g4.ctl", "baseml", Malpha=1)                        # one gene
+    with pytest.raises(RuntimeError, match="nhomo"):
+        load("brown_hky85.ctl", "baseml", nhomo=2, model=7)                   # a kappa per branch needs K80 / F84 / HKY85
+    with pytest.raises(RuntimeError, match="grantham.dat"):
+        load("hiv_ns0.ctl", "codeml", aaDist=1)                               # distance file not beside the control file
+    a = load("hiv_ns0.ctl", "codeml", CodonFreq=7, estFreq=1)                 # and one that is covered: 23 + kappa + 3 + 60 + omega
+    assert a.np == 23 + 1 + 3 + 60 + 1
+
+
 def test_c_host_aaclasses_needs_its_class_file(tmp_path):
     """aaDist = 7 reads OmegaAA.dat from the control file's directory; a missing file, a pair listed twice and a bad class count are
     errors, a pair that cannot change in one step under the genetic code is ignored (as the reference does)."""
