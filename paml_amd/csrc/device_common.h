@@ -246,6 +246,11 @@ __device__ __forceinline__ double jit_x60(const v4d (&x)[4], int lane) { return 
 
 __device__ __forceinline__ void jit_col_seed(const double *col, int lane, double x60, v4d (&z)[4])
 {
+#ifdef JIT_ABL_NOSEED      // timing experiment (results are garbage): no column reads, no dependent multiplies in front of the first MFMAs
+#pragma unroll
+   for (int i = 0; i < 4; i++) z[i] = (v4d){x60, x60, x60, x60};
+   return;
+#endif
    const double2 *pc = (const double2 *)(col + (lane >> 4) * 16);
 #pragma unroll
    for (int i = 0; i < 8; i++) {
