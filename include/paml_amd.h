@@ -199,6 +199,10 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
                          const double *gene_rate, double *lnL, double *dlnL, double *ddlnL);
 /* Work done by paml_amd_eval_branch so far: calls, and internal-node partials recomputed (a full tree costs n_nodes - n_tips). */
 int paml_amd_branch_counters(const paml_amd_engine *e, long *n_calls, long *n_nodes_recomputed);
+/* Parity accessor: the per-block partial sums of the last eval_branch, [rows][cols = 3 n_t] at their global block positions
+ * (after the all-reduce when a communicator is attached) — summed in a fixed order they give lnL, dlnL, ddlnL with the same bits
+ * for every number of ranks.  out = NULL: the shape only. */
+int paml_amd_get_branch_partials(paml_amd_engine *e, double *out, long cap, long *rows, int *cols);
 
 /* Marginal ancestral reconstruction (AncestralMarginal treesub.c:6288, PostProbNode 6142): post[n_patt][n_states] =
  * posterior probabilities of the states at internal node `node` given the data, at the current classes / eigen systems and

@@ -195,6 +195,7 @@ struct paml_amd_engine {
    DevBuf<unsigned int> d_zpm;        // fused 4 / 5-state kernel: tip codes pattern-major
    int zpm_words = 0;
    DevBuf<int> d_red_counter;         // "last workgroup adds up the partial sums" tickets, one per batch element
+   long bpart_rows = 0; int bpart_cols = 0;      // shape of the last eval_branch's partial-sum array
    double *h_out = nullptr;           // pinned, device-visible: the synchronous entry points have lnL written straight to the host
    size_t h_out_cap = 0;
    bool fused = false;                // the selected kernel forms the reduction itself
@@ -1797,25 +1798,33 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    da.eigen_of = e->d_eigen_of.p; da.eigen = e->d_eigen.p; da.out = e->d_deriv.p; da.frag = mfma ? e->d_bl_frag.p : nullptr;
    hipLaunchKernelGGL(pmat_deriv_kernel, dim3(n_t, psets), dim3(256), 0, st, da);
    HIPCHK(e->d_bout.ensure((size_t)n_t * 3));
+   // The 3 n_t sums (lnL, dlnL, ddlnL per trial length) are formed like the evaluation's total: one partial per block of patterns
+   // at the block's GLOBAL position, the ranks' (disjoint, zero elsewhere) arrays summed over RCCL, then one fixed-order pass —
+   // the same bits whatever the number of ranks.  Blocks: 64 patterns (matrix-core contraction) or 256.
+   const int blk = mfma ? 64 : 256, n_out = 3 * n_t;
+   const long nb_local = mfma ? e->n_tiles_full : (e->n_patt + 255) / 256;
+   const bool sharded = e->comm != nullptr || e->n_patt_global != e->n_patt;      // (also: shard geometry without a communicator, for tests)
+   const long nbg = sharded ? (e->n_patt_global + blk - 1) / blk : nb_local, fb = sharded ? e->first_patt / blk : 0;
+   HIPCHK(e->d_bpartial.ensure((size_t)nbg * n_out));
+   e->bpart_rows = nbg; e->bpart_cols = n_out;
+   if (sharded) HIPCHK(hipMemsetAsync(e->d_bpartial.p, 0, (size_t)nbg * n_out * sizeof(double), st));
+   double *const bpart = e->d_bpartial.p + (size_t)fb * n_out;
    if (mfma) {
       const int nb = e->n_tiles_full;
-      HIPCHK(e->d_bpartial.ensure((size_t)nb * 3));
       BranchMfmaArgs ba{};
       ba.n = n; ba.K = K; ba.n_genes = G; ba.n_patt = e->n_patt; ba.n_pi = e->n_pi; ba.n_tips = e->n_tips; ba.n_int = n_int;
       ba.n_tiles = nb; ba.n_scale = T.n_scale; ba.n_t = n_t; ba.a_node = A; ba.b_node = Bn;
       ba.tiles = e->d_tiles_full.p; ba.gene_off = e->d_gene_off.p; ba.partials = e->d_bl_partials.p;
       ba.scalef = scaled ? e->d_bl_scalef.p : nullptr; ba.zb = b_tip ? e->d_z.p + (size_t)Bn * e->n_patt : nullptr;
       ba.code_mask = e->d_code_mask.p; ba.pi = e->d_pi.p; ba.freqK = e->d_freqK.p; ba.weights = e->d_weights.p;
-      ba.frag = e->d_bl_frag.p; ba.partial = e->d_bpartial.p;
-      for (int it = 0; it < n_t; it++) {      // (stream order keeps the partial buffer safe between the pairs of launches)
+      ba.frag = e->d_bl_frag.p; ba.partial = bpart;
+      for (int it = 0; it < n_t; it++) {
          ba.it = it;
          hipLaunchKernelGGL(branch_mfma_kernel, dim3(nb), dim3(256), 0, st, ba);
-         hipLaunchKernelGGL(branch_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)e->d_bpartial.p, nb, 3, e->d_bout.p + 3 * it);
       }
    }
    else {
       const int nb = (e->n_patt + 255) / 256;
-      HIPCHK(e->d_bpartial.ensure((size_t)nb * n_t * 3));
       BranchArgs ba{};
       ba.n = n; ba.K = K; ba.n_genes = G; ba.n_patt = e->n_patt; ba.n_t = n_t; ba.n_pi = e->n_pi; ba.b_is_tip = b_tip ? 1 : 0;
       ba.n_codes = e->n_codes; ba.cls_stride = (long)n_int * e->n_patt * n;
@@ -1824,16 +1833,17 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       ba.SA = scaled ? e->d_bl_scalef.p : nullptr; ba.SB = nullptr; ba.n_scale = T.n_scale;
       ba.zb = b_tip ? e->d_z.p + (size_t)Bn * e->n_patt : nullptr;
       ba.n_chara = e->d_n_chara.p; ba.chara_map = e->d_chara_map.p; ba.freqK = e->d_freqK.p;
-      ba.weights = e->d_weights.p; ba.PdP = e->d_deriv.p; ba.gene_off = e->d_gene_off.p; ba.partial = e->d_bpartial.p;
+      ba.weights = e->d_weights.p; ba.PdP = e->d_deriv.p; ba.gene_off = e->d_gene_off.p; ba.partial = bpart;
       ba.pi = e->d_pi_plain.p;
       hipLaunchKernelGGL(branch_kernel, dim3(nb), dim3(256), 0, st, ba);
-      hipLaunchKernelGGL(branch_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)e->d_bpartial.p, nb, n_t * 3, e->d_bout.p);
    }
    HIPCHK(hipGetLastError());
-   if (e->comm) {      // the exchange step of the branch-local evaluation: 3 n_t sums
-      const ncclResult_t nr = rccl().AllReduce(e->d_bout.p, e->d_bout.p, (size_t)n_t * 3, ncclDouble, ncclSum, e->comm, st);
+   if (e->comm) {      // the exchange step of the branch-local evaluation
+      const ncclResult_t nr = rccl().AllReduce(e->d_bpartial.p, e->d_bpartial.p, (size_t)nbg * n_out, ncclDouble, ncclSum, e->comm, st);
       if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
    }
+   hipLaunchKernelGGL(branch_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)e->d_bpartial.p, (int)nbg, n_out, e->d_bout.p);
+   HIPCHK(hipGetLastError());
    {
       int r = ensure_hout(e, (size_t)n_t * 3);
       if (r) return r;
@@ -1850,6 +1860,16 @@ int paml_amd_branch_counters(const paml_amd_engine *e, long *n_calls, long *n_no
    if (!e) return PAML_AMD_EINVAL;
    if (n_calls) *n_calls = e->n_branch_eval;
    if (n_nodes_recomputed) *n_nodes_recomputed = e->n_branch_nodes;
+   return 0;
+}
+
+int paml_amd_get_branch_partials(paml_amd_engine *e, double *out, long cap, long *rows, int *cols)
+{
+   if (!e || !rows || !cols) return PAML_AMD_EINVAL;
+   *rows = e->bpart_rows; *cols = e->bpart_cols;
+   if (!out) return 0;
+   if (cap < e->bpart_rows * e->bpart_cols || !e->d_bpartial.p) return fail(e, PAML_AMD_EINVAL, "get_branch_partials: no branch evaluation yet, or the buffer is too small");
+   HIPCHK(hipMemcpy(out, e->d_bpartial.p, (size_t)e->bpart_rows * e->bpart_cols * sizeof(double), hipMemcpyDeviceToHost));
    return 0;
 }
 

@@ -1227,7 +1227,7 @@ struct BranchMfmaArgs {
    const double *pi;                   // [n_pi][4][16]
    const double *freqK, *weights;
    const double *frag;                 // [pset][n_t][3][4096]
-   double *partial;                    // [n_tiles][3]
+   double *partial;                    // [n_tiles][n_t][3] (this launch fills trial length `it`)
 };
 
 __global__ __launch_bounds__(256, 2) void branch_mfma_kernel(BranchMfmaArgs a)
@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(256, 2) void branch_mfma_kernel(BranchMfmaArgs a)
    }
    if (lane == 0) { sw[wave][0] = v0; sw[wave][1] = v1; sw[wave][2] = v2; }
    __syncthreads();
-   if (tid < 3) a.partial[(long)tile * 3 + tid] = (sw[0][tid] + sw[1][tid]) + (sw[2][tid] + sw[3][tid]);
+   if (tid < 3) a.partial[((long)tile * a.n_t + a.it) * 3 + tid] = (sw[0][tid] + sw[1][tid]) + (sw[2][tid] + sw[3][tid]);
 }
 
 __global__ __launch_bounds__(256) void branch_reduce_kernel(const double *partial, int nb, int n_out, double *out)

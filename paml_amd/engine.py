@@ -22,7 +22,7 @@ KEEP_PARTIALS = 1
 JIT = 2
 
 EXPORTS = [
-    "paml_amd_set_gene_class_rates", "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
+    "paml_amd_set_gene_class_rates", "paml_amd_get_branch_partials", "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
@@ -311,6 +311,15 @@ class Engine:
         l, dl, ddl = np.zeros(len(tt)), np.zeros(len(tt)), np.zeros(len(tt))
         self._chk(self._L.paml_amd_eval_branch(self._h, int(node_b), len(tt), _p(tt), _p(b), _p(g), _p(l), _p(dl), _p(ddl)))
         return l, dl, ddl
+
+    def branch_partials(self):
+        """Per-block partial sums of the last eval_branch: array [rows, 3 n_t] (paml_amd_get_branch_partials)."""
+        rows, cols = C.c_long(), C.c_int()
+        self._L.paml_amd_get_branch_partials.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_int)]
+        self._chk(self._L.paml_amd_get_branch_partials(self._h, None, 0, C.byref(rows), C.byref(cols)))
+        out = np.zeros((rows.value, cols.value))
+        self._chk(self._L.paml_amd_get_branch_partials(self._h, _p(out), out.size, C.byref(rows), C.byref(cols)))
+        return out
 
     def branch_counters(self):
         a, b = C.c_long(), C.c_long()

@@ -754,6 +754,41 @@ def test_sharded_partial_sums_are_world_size_invariant(n, K):
         assert _stage2(tot) == lnl
 
 
+@pytest.mark.parametrize("n,n_tips,n_patt,K", [(61, 10, 9000, 2), (4, 14, 40000, 3), (20, 9, 12000, 1)])
+def test_branch_local_sums_are_world_size_invariant(n, n_tips, n_patt, K):
+    """eval_branch forms lnL, dlnL, ddlnL from per-block partial sums at global block positions: the arrays of the shards of a
+    2- and a 3-way split add up (adding zeros is exact) to the one-GPU array, so the fixed-order total has the same bits for
+    every number of ranks; and the one-rank RCCL path returns those bits."""
+    from paml_amd import distributed, engine as E
+    pb = helpers.random_problem(n, n_tips, n_patt, K=K, seed=910 + n)
+    b = pb.tree.n_tips + 2
+    ts = np.array([pb.tree.branch[b], pb.tree.branch[b] * 1.7 + 0.01])
+    e0 = engine_for(pb)
+    want = e0.eval_branch(b, ts, pb.tree.branch)
+    full = e0.branch_partials()
+    assert full.shape[1] == 6
+    for o in range(6):
+        assert distributed.total_fixed_order(full[:, o]) == (want[o % 3][o // 3])
+    for world in (2, 3):
+        tot = np.zeros_like(full)
+        for rank in range(world):
+            lo, hi = distributed.shard_bounds(pb.n_patt, world, rank)
+            if hi == lo:
+                continue
+            sub = pb.slice_patterns(lo, hi)
+            e = engine_for(sub)
+            e.comm_init(0, 1, None, pb.n_patt, lo)      # shard geometry only
+            e.eval_branch(b, ts, sub.tree.branch)
+            tot += e.branch_partials()
+            e.close()
+        assert np.array_equal(tot, full)
+    e1 = engine_for(pb)
+    e1.comm_init(0, 1, E.comm_unique_id(), pb.n_patt, 0)
+    got = e1.eval_branch(b, ts, pb.tree.branch)
+    for o in range(3):
+        assert np.array_equal(got[o], want[o])
+
+
 def test_one_rank_rccl_communicator_matches_golden():
     """The RCCL path in a one-rank communicator: ncclCommInitRank + ncclAllReduce on the engine's stream, same bits as the
     plain engine, and the reference's lnL for the golden data."""
