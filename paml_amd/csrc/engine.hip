@@ -143,6 +143,7 @@ inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global
 
 // Environment switches, read once when the engine is created.
 struct EnvCfg {
+   bool force_stream = false;
    bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false, no_m20 = false;
    int jit_waves = 0;
    std::string jit_dump, prof_ops;
@@ -152,6 +153,7 @@ struct EnvCfg {
    {
       no_pipeline = getenv("PAML_AMD_NO_PIPELINE") != nullptr;
       force_gather = getenv("PAML_AMD_FORCE_GATHER") != nullptr;
+      force_stream = getenv("PAML_AMD_FORCE_STREAM") != nullptr;      // experiments: the stream interpreter also on small data sets
       jit_sync = getenv("PAML_AMD_JIT_SYNC") != nullptr;
       jit_strict = getenv("PAML_AMD_JIT_STRICT") != nullptr;
       valu20 = getenv("PAML_AMD_VALU20") != nullptr;
@@ -605,6 +607,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    //   gather — the full interpreter (keep-partials STORE/LOAD, deep stacks, > MFMA_ZT tips, > 64 codes), 64 per workgroup
    if (e->kk == KK_MFMA64) {
       bool lean = e->prog.max_stack <= MFMA_RS && e->n_tips <= MFMA_ZT && e->n_codes <= 64 && !e->env.force_gather;
+      // small data sets (at most a quarter of the CUs get a 128-pattern tile): the 64-pattern workgroups of the gather kernel —
+      // one wave per SIMD, twice as many workgroups — finish a tile in 0.63 of the time (13 taxa x 79 codon patterns: 42 against 66 us,
+      // a batched gradient of 25 evaluations 0.125 against 0.151 ms; profiles/r02_small_latency.jsonl)
+      if ((e->n_patt + 127) / 128 <= e->n_cu / 4 && !e->env.force_stream) lean = false;
       for (const Op &o : e->prog.ops)
          if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
       bool jit_ok = false;
