@@ -621,7 +621,10 @@ __device__ __forceinline__ void red_block_finish(double acc, double *partial_row
             last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1;
          }
       }
-      else partial_row[slot] = part;
+      else {
+         partial_row[slot] = part;
+         if (nb_total == 1) *out = part;      // a single block: its sum is the total (what the fixed-order pass over one value returns), no second launch
+      }
       s_last = last;
    }
    __syncthreads();

@@ -882,7 +882,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
       hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)e->d_partial_tot.p, nbg, ra.out);
    }
-   else if (!tail) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)e->d_partial.p, nbg, ra.out);
+   else if (!tail && nbg > 1) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)e->d_partial.p, nbg, ra.out);      // (one block per element: stage 1 wrote the total)
    mark(e);
    HIPCHK(hipGetLastError());
    if (e->profiling) e->prof_evals++;
