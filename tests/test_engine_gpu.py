@@ -203,6 +203,31 @@ def test_full_size_properties_c4():
     assert abs(out2["lnL"] - out["lnL"]) < 1e-9 * abs(out["lnL"])
 
 
+def test_large_size_properties_20_states():
+    """The 20-state kernel at 16 taxa x 400 000 patterns x 4 classes (units per workgroup in the dozens, the LDS tickets and the
+    contiguous ranges at work): lnL = sum of log f_h, a strided sample against the oracle, and per-pattern results that do not
+    depend on the order of the patterns — bitwise."""
+    pb = helpers.random_problem(20, 16, 400_000, K=4, seed=2020)
+    eng = engine_for(pb)
+    out = eng.eval(pb.tree.branch, want_lnf=True)
+    assert eng.kernel_name == "mfma4x20_jit"
+    assert abs(float(np.dot(out["lnf"], pb.weights)) - out["lnL"]) < 1e-9 * abs(out["lnL"])
+    idx = np.arange(0, pb.n_patt, 1999)
+    sub = pb.slice_patterns(0, pb.n_patt)
+    sub.z = np.ascontiguousarray(pb.z[:, idx])
+    sub.weights = np.ascontiguousarray(pb.weights[idx])
+    sub.gene_off = np.array([0, len(idx)], dtype=np.int32)
+    ref = oracle.evaluate(sub)
+    assert np.max(np.abs(out["lnf"][idx] - ref["lnf"])) < 1e-10
+    perm = np.random.default_rng(2).permutation(pb.n_patt)
+    pb2 = pb.slice_patterns(0, pb.n_patt)
+    pb2.z = np.ascontiguousarray(pb.z[:, perm])
+    pb2.weights = np.ascontiguousarray(pb.weights[perm])
+    out2 = engine_for(pb2).eval(pb.tree.branch, want_lnf=True)
+    assert np.max(np.abs(out2["lnf"] - out["lnf"][perm])) == 0.0
+    assert abs(out2["lnL"] - out["lnL"]) < 1e-9 * abs(out["lnL"])
+
+
 @pytest.mark.parametrize("name", ["syn_nuc_gtr_g4_full", "syn_codon_m0_full"])
 def test_full_size_against_reference(name):
     """BASELINE configs[1] and configs[3] at full size against the reference binary's own numbers for the same seeded
