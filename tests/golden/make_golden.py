@@ -630,6 +630,9 @@ CASES = {
                                          dict(MTPRI_AA, **{"jones.dat": DAT + "/jones.dat"}), 7, "aa_revaa", seqtype="aa"),
     "mtcdnapri_revaa": lambda: case_mle("mtcdnapri_revaa", dict(seqfile="mtCDNApri.aa", treefile="mtCDNApri.trees", seqtype=2, model=9, aaRatefile="jones.dat", icode=1, cleandata=1),
                                         dict(MTPRI_AA, **{"jones.dat": DAT + "/jones.dat"}), 7, "aa_revaa", seqtype="aa"),
+    # TipDate with local clocks: a second rate for the (Lib1sm, FO784h, SIVMNE) clade
+    "hiv2_tipdate_clock2": lambda: case_mle("hiv2_tipdate_clock2", dict(seqfile="HIV2ge.txt", treefile="HIV2ge.clock2.tree", model=4, clock=2, TipDate="1 100", kappa=2, fix_alpha=0, alpha=0.5, ncatG=5, cleandata=0),
+                                            {"HIV2ge.txt": EX + "/TipDate.HIV2/HIV2ge.txt", "HIV2ge.clock2.tree": os.path.join(HERE, "data", "HIV2ge.clock2.tree")}, 33, "nuc_tipdate", prog="baseml", seqtype="nuc"),
     "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
                                     {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,

@@ -34,6 +34,7 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("brown_hky85_clock", "baseml", "brown_hky85_clock.ctl"),      # global clock: x holds the node ages
          ("brown_hky85_clock2", "baseml", "brown_hky85_clock2.ctl"),    # local clocks: ages, then the rates of the '#' branch classes
          ("hiv2_tipdate", "baseml", "hiv2_tipdate.ctl"),                # TipDate: dated tips, ages in time units, then the mutation rate
+         ("hiv2_tipdate_clock2", "baseml", "hiv2_tipdate_clock2.ctl"),  # ... and a second (absolute) rate for a labelled clade
          ("brown_f84", "baseml", "brown_f84.ctl"), ("brown_t92_g4", "baseml", "brown_t92_g4.ctl"), ("brown_unrest", "baseml", "brown_unrest.ctl"), ("brown_hky85_nhomo1", "baseml", "brown_hky85_nhomo1.ctl"),
          # non-homogeneous models: a kappa per branch (2); frequency sets per branch (3: tips / internal / root, 4: every node), every
          # branch with its own eigen system (one label per node); the nhomo3 estimate has a frequency on the boundary (0.000000)
