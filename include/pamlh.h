@@ -24,6 +24,10 @@ typedef struct pamlh pamlh;
 
 /* program: "codeml" or "baseml".  Paths inside the ctl are resolved relative to the ctl file's directory. */
 int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err, int errcap);
+/* the same with the tree_index-th (0-based) tree of the tree file — the reference evaluates the trees of the file one after the
+ * other (Forestry codeml.c:635, baseml.c:451) — and the number of trees the file holds */
+int pamlh_load_tree(pamlh **out, const char *ctl_path, const char *program, int tree_index, char *err, int errcap);
+int pamlh_n_trees(const pamlh *p);
 void pamlh_free(pamlh *p);
 const char *pamlh_error(const pamlh *p);
 

@@ -1525,12 +1525,12 @@ static int beb_front(paml_amd_engine *e, const char *who, int n_grid, int n_cls,
 {
    if (e->mode != PAML_AMD_MODE_LFUNDG || e->n_eval == 0 || !e->d_fhK.p)
       return fail(e, PAML_AMD_EINVAL, std::string(who) + ": needs a previous evaluation in the lfundG class mode");
-   if (e->tree.n_scale) return fail(e, PAML_AMD_EUNSUPPORTED, std::string(who) + ": not with scaling nodes yet");
    const int K = e->K, np = e->n_patt;
    for (long i = 0; i < (long)n_grid * n_cls; i++)
       if (iw[i] < 0 || iw[i] >= K) return fail(e, PAML_AMD_EINVAL, std::string(who) + ": class index out of range");
    a = BebArgs{};
    a.n_patt = np; a.K = K; a.n_grid = n_grid; a.n_cls = n_cls;
+   a.log_form = e->tree.n_scale > 0;      // root_value: with scaling nodes fhK = log f + scale factors
    a.patt_per_blk = 4096;
    a.n_pblk = (np + a.patt_per_blk - 1) / a.patt_per_blk;
    HIPCHK(e->d_beb_f.ensure((size_t)K * np));

@@ -1380,7 +1380,8 @@ __global__ __launch_bounds__(256) void posterior_kernel(PostArgs a)
 // Bayes empirical Bayes grid integral (lfunNSsites_M2M8 codeml.c:6482-6580) over the class likelihoods of the last
 // evaluation: n_grid parameter points, each a mixture of n_cls classes (proportion pcl[g][c], class index iw[g][c] into
 // the K evaluated classes).  n_grid x n_patt x n_cls terms with a log each — 10^11 at 10^6 patterns.
-//   beb_scale:   f[k][h] = fhK[k][h] / max_k fhK[k][h]                       (codeml.c:6297-6305)
+//   beb_scale:   f[k][h] = fhK[k][h] / max_k fhK[k][h]                       (codeml.c:6297-6305); with scaling nodes fhK holds
+//                log f + the scale factors and f[k][h] = exp(fhK[k][h] - max_k fhK[k][h])            (codeml.c:6286-6294)
 //   beb_lnfx:    part[g][b] = sum over block b's patterns of w_h log sum_c pcl[g][c] f[iw[g][c]][h]
 //   beb_finish:  lnfXs[g] = sum_b part[g][b] (fixed order);  fX = log sum_g exp(lnfXs[g]);  wg[g] = exp(lnfXs[g] - fX)
 //   beb_post:    per pattern, sums over the grid of the class posteriors, omega and omega^2
@@ -1390,6 +1391,7 @@ __global__ __launch_bounds__(256) void posterior_kernel(PostArgs a)
 #define BEB_MAXCLS 8
 struct BebArgs {
    int n_patt, K, n_grid, n_cls, n_pblk, patt_per_blk;
+   int log_form;             // fhK holds logarithms (trees with scaling nodes)
    const double *fhK, *weights;
    double *f;                // [K][n_patt] scaled copy
    const double *pcl;        // [n_grid][n_cls]
@@ -1406,7 +1408,10 @@ __global__ __launch_bounds__(256) void beb_scale(BebArgs a)
    if (h >= a.n_patt) return;
    double mx = a.fhK[h];
    for (int k = 1; k < a.K; k++) mx = fmax(mx, a.fhK[(long)k * a.n_patt + h]);
-   for (int k = 0; k < a.K; k++) a.f[(long)k * a.n_patt + h] = mx > 0 ? a.fhK[(long)k * a.n_patt + h] / mx : 0.0;
+   if (a.log_form)      // (patterns that do not count have no fhK: f = 0 as in the other branch)
+      for (int k = 0; k < a.K; k++) a.f[(long)k * a.n_patt + h] = a.weights[h] > 0 ? exp(a.fhK[(long)k * a.n_patt + h] - mx) : 0.0;
+   else
+      for (int k = 0; k < a.K; k++) a.f[(long)k * a.n_patt + h] = mx > 0 ? a.fhK[(long)k * a.n_patt + h] / mx : 0.0;
 }
 
 __global__ __launch_bounds__(256) void beb_lnfx(BebArgs a)      // grid: (n_pblk, ceil(n_grid / 64))

@@ -478,6 +478,20 @@ int pamlh_read_tree(pamlh *p)
    fclose(f);
    s = strchr(buf, '(');
    if (!s) { free(buf); return pamlh_fail(p, "no tree in %s", p->treefile); }
+   {      /* trees end with ';' (the last one may lack it) */
+      char *q = s;
+      p->ntrees = 0;
+      while (q && *q) { char *e = strchr(q, ';'); p->ntrees++; q = e ? strchr(e + 1, '(') : NULL; }
+      {      /* an "ns ntree" line in front of the trees limits the count (the reference reads that many: GetTreeFileType, codeml.c:617) */
+         int hns = 0, hnt = 0;
+         char c = *s;
+         *s = 0;
+         if (sscanf(buf, "%d%d", &hns, &hnt) == 2 && hnt >= 1 && hnt < p->ntrees) p->ntrees = hnt;
+         *s = c;
+      }
+      if (p->itree < 0 || p->itree >= p->ntrees) { free(buf); return pamlh_fail(p, "tree %d asked for, %s holds %d", p->itree + 1, p->treefile, p->ntrees); }
+      for (i = 0; i < p->itree; i++) s = strchr(strchr(s, ';') + 1, '(');
+   }
    stack = (int *)malloc(maxn * sizeof(int));
    father = (int *)malloc(maxn * sizeof(int));
    p->label = (int *)calloc(maxn, sizeof(int));

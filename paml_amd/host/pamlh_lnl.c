@@ -1,5 +1,6 @@
 /* pamlh_lnl — command-line driver: one likelihood evaluation of a codeml/baseml analysis on the MI355X.
- *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [--ancestral] [--gpus N] [x0 x1 ...]
+ *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [--ancestral] [--gpus N] [--tree K] [x0 x1 ...]
+ *   (--tree K: the K-th tree of the tree file, 1-based; the reference walks through all of them, Forestry codeml.c:635)
  * Reads the control file, the sequence and tree files it names, and the parameter vector from the command line,
  * else from in.codeml / in.baseml beside the ctl (the reference's "-1 x..." single-evaluation recipe, treesub.c:4057),
  * else the ctl's initial values; evaluates lnL through libpaml_amd.so; prints `lnL = ...` like the reference and
@@ -54,17 +55,18 @@ int main(int argc, char **argv)
    pamlh *p;
    char err[512];
    double x[4096], lnL, *lnf;
-   int np, ntime, npatt, i, nx = 0, optimize = 0, ancestral = 0, gpus = 0, rank = 0;
+   int np, ntime, npatt, i, nx = 0, optimize = 0, ancestral = 0, gpus = 0, rank = 0, itree = 0;
    unsigned char comm_id[PAML_AMD_COMM_ID_BYTES];
-   if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [--gpus N] [x...]\n", argv[0]); return 2; }
+   if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [--ancestral] [--gpus N] [--tree K] [x...]\n", argv[0]); return 2; }
    for (i = 3; i < argc && nx < 4096; i++) {
       if (!strcmp(argv[i], "--optimize")) optimize = 1;
       else if (!strcmp(argv[i], "--ancestral")) ancestral = 1;
       else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+      else if (!strcmp(argv[i], "--tree") && i + 1 < argc) itree = atoi(argv[++i]) - 1;
       else x[nx++] = atof(argv[i]);
    }
    if (gpus > 0 && spawn_ranks(gpus, &rank, comm_id)) { fprintf(stderr, "error: could not start %d ranks (GPUs visible: %d; librccl.so.1 present?)\n", gpus, paml_amd_device_count()); return 1; }
-   if (pamlh_load(&p, argv[2], argv[1], err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
+   if (pamlh_load_tree(&p, argv[2], argv[1], itree, err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
    if (gpus > 0 && pamlh_set_shard(p, rank, gpus, comm_id)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
    pamlh_dims(p, NULL, NULL, &npatt, NULL, NULL, NULL, NULL, NULL, &np, &ntime);
    if (gpus > 0 && (ancestral || pamlh_mgene(p) == 1)) { fprintf(stderr, "error: --gpus gives lnL and estimates; per-site outputs and Mgene = 1 need the whole alignment on one GPU\n"); return 1; }

@@ -11,10 +11,18 @@
 
 #include "pamlh_internal.h"
 
-/* genetic codes (codons in T, C, A, G order; '*' = stop): icode 0 universal, 1 vertebrate mitochondrial (GeneticCode[][] in
- * tools.c: TGA Trp, ATA Met, AGA / AGG stop) */
-static const char *const GENETIC_CODES[2] = {"FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
-                                             "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG"};
+/* genetic codes (codons in T, C, A, G order; '*' = stop) in the order of codeml's icode (GeneticCode[][] in tools.c:23-84): the NCBI
+ * translation tables 1 (universal), 2 (vertebrate mt), 3 (yeast mt), 4 (mold mt), 5 (invertebrate mt), 6 (ciliate nuclear), 9 (echinoderm
+ * mt), 10 (euplotid nuclear), 12 (alternative yeast nuclear), 13 (ascidian mt), 15 (blepharisma nuclear) — 60 to 63 sense codons.
+ * icode 11 is the reference's "regularised" code: 64 sense codons, sixteen amino acids (ARNDCQEGHILKMFPST) with four codons each. */
+#define N_GENETIC_CODES 12
+static const char *const GENETIC_CODES[N_GENETIC_CODES] = {
+   "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG", "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG",
+   "FFLLSSSSYY**CCWWTTTTPPPPHHQQRRRRIIMMTTTTNNKKSSRRVVVVAAAADDEEGGGG", "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+   "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSSSVVVVAAAADDEEGGGG", "FFLLSSSSYYQQCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+   "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG", "FFLLSSSSYY**CCCWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+   "FFLLSSSSYY**CC*WLLLSPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG", "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSGGVVVVAAAADDEEGGGG",
+   "FFLLSSSSYY*QCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG", "RRRRNNNNDDDDCCCCQQQQEEEEGGGGHHHHIIIILLLLKKKKMMMMFFFFPPPPSSSSTTTT"};
 
 static int nuc_nkappa(const pamlh *p);
 static double dist2(const double *a, const double *b, int n)
@@ -258,10 +266,18 @@ static void aa_as_codon_sets(pamlh *p)
 
 int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err, int errcap)
 {
+   return pamlh_load_tree(out, ctl_path, program, 0, err, errcap);
+}
+
+/* ... with the tree_index-th (0-based) tree of the tree file: the reference walks through all of them in turn (runmode = 0,
+ * the loop over trees in Forestry codeml.c:635 / baseml.c:451); here every tree is an analysis of its own */
+int pamlh_load_tree(pamlh **out, const char *ctl_path, const char *program, int tree_index, char *err, int errcap)
+{
    pamlh *p = (pamlh *)calloc(1, sizeof(pamlh));
    const char *v, *slash;
    int rc = 0;
    *out = NULL;
+   p->itree = tree_index;
    p->is_codeml = strcmp(program, "baseml") != 0;
    slash = strrchr(ctl_path, '/');
    if (slash) { size_t n = (size_t)(slash - ctl_path); memcpy(p->dir, ctl_path, n); p->dir[n] = 0; }
@@ -315,7 +331,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
    if (p->mgene < 0 || p->mgene > 4) { rc = pamlh_fail(p, "Mgene = %d?", p->mgene); goto bad; }
    p->malpha = (int)pamlh_optd(p, "Malpha", 0) != 0;      /* a gamma shape per gene (checked against the data below) */
    if (p->seqtype == 1) {
-      if (p->icode != 0 && p->icode != 1) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0: universal, 1: vertebrate mt)", p->icode); goto bad; }
+      if (p->icode < 0 || p->icode >= N_GENETIC_CODES) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0 ... 11)", p->icode); goto bad; }
       /* model 0: site models; model 2, NSsites 0: branch model; model 2 / 3 with NSsites 2 / 3: branch-site A / B, clade C / D */
       if (p->model != 0 && !(p->model == 2 && p->nssites == 0) && !((p->model == 2 || p->model == 3) && (p->nssites == 2 || p->nssites == 3))) {
          rc = pamlh_fail(p, "codon model = %d with NSsites = %d is not supported", p->model, p->nssites); goto bad;
@@ -365,7 +381,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
          /* REVaa_0 (8): an exchangeability for every pair of amino acids one nucleotide change apart under the genetic code, the others 0;
           * REVaa (9): all 190; the pair V-I is the unit (ijAAref codeml.c:1091, SetAA1STEP 4044, eigenQaa 3423-3436) */
          int i, j, c1, c2, step[400] = {0};
-         if (p->icode != 0 && p->icode != 1) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0: universal, 1: vertebrate mt)", p->icode); goto bad; }
+         if (p->icode < 0 || p->icode >= N_GENETIC_CODES) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0 ... 11)", p->icode); goto bad; }
          strcpy(p->code, GENETIC_CODES[p->icode]);
          for (c1 = 0; c1 < 64; c1++)
             for (c2 = 0; c2 < c1; c2++) {
@@ -386,7 +402,7 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
          /* codon-based amino-acid models (Yang, Nielsen & Hasegawa 1998): 6 (FromCodon) a 20-state chain whose rates are the
           * codon chain's aggregated over synonymous codons, 5 (FromCodon0) the codon chain itself with every amino acid read as
           * the set of its codons (codeml.c:1513-1531, 498-503, 544-556) */
-         if (p->icode != 0 && p->icode != 1) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0: universal, 1: vertebrate mt)", p->icode); goto bad; }
+         if (p->icode < 0 || p->icode >= N_GENETIC_CODES) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0 ... 11)", p->icode); goto bad; }
          if (p->nssites) { rc = pamlh_fail(p, "use NSsites = 0 for amino acids"); goto bad; }
          if ((int)pamlh_optd(p, "aaDist", 0)) { rc = pamlh_fail(p, "aaDist with the codon-based amino-acid models is not supported"); goto bad; }
          if (p->aa_model == 6 && p->fix_omega) { rc = pamlh_fail(p, "fix_omega = 1?  omega is not estimable!"); goto bad; }
@@ -1618,6 +1634,7 @@ int pamlh_model_feasible(const pamlh *p)
 }
 
 /* `method` of the control file (0: all parameters at once, 1: one branch at a time) */
+int pamlh_n_trees(const pamlh *p) { return p->ntrees; }
 int pamlh_method(const pamlh *p) { return (int)pamlh_optd(p, "method", 0); }
 
 /* the engine behind this analysis (NULL before the first evaluation): counters, profiling */
@@ -1890,9 +1907,9 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w)
 {
    const int K = p->K, np = p->npatt;
    double lnL, *fhK = (double *)malloc((size_t)K * np * sizeof(double));
-   int i, h, k, rc;
+   int i, h, k, rc, logf = 0;
    if (p->mode != PAML_AMD_MODE_LFUNDG) { free(fhK); return pamlh_fail(p, "NEB needs a model with site classes"); }
-   if (p->scale) for (i = 0; i < p->nnode; i++) if (p->scale[i]) { free(fhK); return pamlh_fail(p, "NEB with scaling nodes is not supported yet"); }
+   for (i = 0; p->scale && i < p->nnode; i++) if (p->scale[i]) logf = 1;      /* fhK = log f + scale factors (fx_r treesub.c:7744-7749) */
    if ((rc = pamlh_engine_ready(p))) { free(fhK); return rc; }
    if ((rc = paml_amd_set_pi(p->eng, 1, p->pi))) { free(fhK); return pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); }
    for (i = 0; i < p->n_eigen; i++) {
@@ -1910,6 +1927,11 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w)
    }
    for (h = 0; h < np; h++) {
       double s = 0, mw = 0;
+      if (logf) {      /* lfunNSsites_rate codeml.c:5277-5284: relative to the largest class */
+         double mx = fhK[h];
+         for (k = 1; k < K; k++) if (fhK[(size_t)k * np + h] > mx) mx = fhK[(size_t)k * np + h];
+         for (k = 0; k < K; k++) fhK[(size_t)k * np + h] = exp(fhK[(size_t)k * np + h] - mx);
+      }
       for (k = 0; k < K; k++) s += p->freqK[k] * fhK[(size_t)k * np + h];
       for (k = 0; k < K; k++) {
          post[(size_t)k * np + h] = s > 0 ? p->freqK[k] * fhK[(size_t)k * np + h] / s : 0;
@@ -1936,7 +1958,6 @@ int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double 
    double rK[2 * N1 + 1], para[4][N1], lnL, fX, *fhK, *pcl, *lnfXs, *Q, kappa, mr;
    int *iw, i, k, g, rc;
    if (!(p->seqtype == 1 && p->model == 0 && !p->m2a_rel && (p->nssites == 2 || p->nssites == 8))) return pamlh_fail(p, "BEB is defined for NSsites 2 (M2a) and 8 (M8)");
-   if (p->scale) for (i = 0; i < p->nnode; i++) if (p->scale[i]) return pamlh_fail(p, "BEB with scaling nodes is not supported yet");
    if ((rc = pamlh_set_x(p, x, p->np))) return rc;
    kappa = p->kappa; mr = p->ns_mr;
    /* the grid (get_grid_para_like_M2M8 codeml.c:6250-6275): bin mid-points */
@@ -2019,7 +2040,6 @@ int pamlh_beb_acd(pamlh *p, const double *x, double *post)
    long g, ng = 1;
    if (!(p->seqtype == 1 && ((p->model == 2 && p->nssites == 2) || (p->model == 3 && p->n_omega == 2))))
       return pamlh_fail(p, "this BEB is defined for branch-site model A and for clade models C and D with two branch types");
-   if (p->scale) for (i = 0; i < p->nnode; i++) if (p->scale[i]) return pamlh_fail(p, "BEB with scaling nodes is not supported yet");
    if ((rc = pamlh_set_x(p, x, p->np))) return rc;
    kappa = p->kappa;
    for (i = 0; i < dim; i++) ng *= N1;

@@ -185,7 +185,7 @@ void pamlh_eigen_qrev(const double *Q, const double *pi, int n, double *Root, do
    for (i = 0; i < n; i++) if (pi[i] > 1e-100) idx[m++] = i;
    if (m == n) eigen_qrev_positive(Q, pi, n, Root, U, V);
    else {
-      double *Qr = (double *)malloc((size_t)m * m * sizeof(double)), *pr = (double *)malloc(m * sizeof(double));
+      double *Qr = (double *)calloc((size_t)m * m + 1, sizeof(double)), *pr = (double *)calloc((size_t)m + 1, sizeof(double));
       double *Rr = (double *)malloc(m * sizeof(double)), *Ur = (double *)malloc((size_t)m * m * sizeof(double)), *Vr = (double *)malloc((size_t)m * m * sizeof(double));
       for (i = 0; i < m; i++) { pr[i] = pi[idx[i]]; for (j = 0; j < m; j++) Qr[i * m + j] = Q[idx[i] * n + idx[j]]; }
       eigen_qrev_positive(Qr, pr, m, Rr, Ur, Vr);

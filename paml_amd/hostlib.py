@@ -44,6 +44,8 @@ def lib():
             getattr(L, name).restype = rt
             getattr(L, name).argtypes = [C.c_void_p]
         L.pamlh_load.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.pamlh_load_tree.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.pamlh_n_trees.argtypes = [C.c_void_p]
         L.pamlh_free.argtypes = [C.c_void_p]
         L.pamlh_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 10
         L.pamlh_default_x.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -65,17 +67,20 @@ def _arr(ptr, dtype, n):
 
 
 class Analysis:
-    def __init__(self, ctl_path, program="codeml"):
+    def __init__(self, ctl_path, program="codeml", tree_index=0):
         L = lib()
         h = C.c_void_p()
         err = C.create_string_buffer(512)
-        if L.pamlh_load(C.byref(h), os.fsencode(ctl_path), program.encode(), err, 512) != 0:
+        if L.pamlh_load_tree(C.byref(h), os.fsencode(ctl_path), program.encode(), tree_index, err, 512) != 0:
             raise RuntimeError("pamlh_load: " + err.value.decode())
         self._h, self._L = h, L
         d = [C.c_int() for _ in range(10)]
         L.pamlh_dims(h, *[C.byref(v) for v in d])
         (self.n, self.n_tips, self.n_patt, self.n_nodes, self.root, self.n_codes, self.cleandata, self.ls, self.np,
          self.ntime) = [v.value for v in d]
+
+    def n_trees(self):
+        return self._L.pamlh_n_trees(self._h)
 
     def gene_subset(self, g):
         """Mgene = 1: gene g as an analysis of its own (pamlh_gene_subset)."""

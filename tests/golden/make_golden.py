@@ -313,7 +313,7 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtyp
             rows = re.findall(r"^\s*\d+ \S\s+((?:[01]\.\d{5}\s+)+)\(\s*\d+\)", blk, re.M)
             ls = int([ln for ln in res1["lnf"] if ln.split()][0].split()[1])
             tables[key] = [[float(v) for v in r.split()] for r in rows[:ls]]
-    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha", "clock", "TipDate", "aaDist", "CodonFreq", "estFreq") if k in ctl_over}),
+    finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha", "clock", "TipDate", "aaDist", "CodonFreq", "estFreq", "icode") if k in ctl_over}),
                                              x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
 
 
@@ -635,6 +635,21 @@ CASES = {
                                             {"HIV2ge.txt": EX + "/TipDate.HIV2/HIV2ge.txt", "HIV2ge.clock2.tree": os.path.join(HERE, "data", "HIV2ge.clock2.tree")}, 33, "nuc_tipdate", prog="baseml", seqtype="nuc"),
     "mhc_m0_prop": lambda: case_mle("mhc_m0_prop", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=0, kappa=1.6, omega=.9, fix_blength=3, cleandata=0, Small_Diff=".1e-6"),
                                     {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_m0"),
+    # the published MHC site-model runs (examples/MHC.Swanson2002MBE/README.txt:25-30: M1a -7490.993363, M2a -7231.154540, M7 -7502.792534,
+    # M8 -7238.014961; 192 taxa, branch lengths fixed at the tree file's, ten scaling nodes) with their NEB / BEB tables
+    "mhc_m1a": lambda: case_mle("mhc_m1a", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=1, ncatG=2, kappa=1.6, omega=.9, fix_blength=2, cleandata=0, Small_Diff=".1e-6"),
+                                 {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_nssites"),
+    "mhc_m2a": lambda: case_mle("mhc_m2a", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=2, ncatG=3, kappa=1.6, omega=.9, fix_blength=2, cleandata=0, Small_Diff=".1e-6"),
+                                 {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_nssites"),
+    "mhc_m7": lambda: case_mle("mhc_m7", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=7, ncatG=10, kappa=1.6, omega=.9, fix_blength=2, cleandata=0, Small_Diff=".1e-6"),
+                                 {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_nssites"),
+    "mhc_m8": lambda: case_mle("mhc_m8", dict(seqfile="bigmhc.phy", treefile="bigmhc.trees", NSsites=8, ncatG=10, kappa=1.6, omega=.9, fix_blength=2, cleandata=0, Small_Diff=".1e-6"),
+                                 {"bigmhc.phy": EX + "/MHC.Swanson2002MBE/bigmhc.phy", "bigmhc.trees": EX + "/MHC.Swanson2002MBE/bigmhc.trees"}, 192, "codon_nssites"),
+    # the other genetic codes: invertebrate mt (icode 4, 62 sense codons), ciliate nuclear (5, 63) and the "regularised" code (11, 64) on the
+    # HIV data (no TAA / TAG / TGA in it, so the alignment is legal under each)
+    "hiv_m0_icode4": lambda: case_mle("hiv_m0_icode4", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, icode=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
+    "hiv_m0_icode5": lambda: case_mle("hiv_m0_icode5", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, icode=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
+    "hiv_m0_icode11": lambda: case_mle("hiv_m0_icode11", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, icode=11, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "brown_hky85_clock": case_brown_clock,
     "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),

@@ -565,12 +565,14 @@ def test_abi_error_behaviour():
     assert np.isfinite(eng.eval(pb.tree.branch)["lnL"])          # the engine is still usable after the errors
 
 
-def test_beb_grid_matches_numpy_restatement():
+@pytest.mark.parametrize("every", [None, 2])
+def test_beb_grid_matches_numpy_restatement(every):
     """paml_amd_beb_grid (the BEB grid integral as device kernels) against a direct numpy restatement of
     lfunNSsites_M2M8's sums (codeml.c:6482-6580) on a synthetic K-class problem with several thousand patterns; the
-    reference's own BEB tables pin the same code through the C host (test_host_c.py)."""
+    reference's own BEB tables pin the same code through the C host (test_host_c.py).  With scaling nodes fhK holds
+    log f + scale factors and the classes are compared through exp(fhK - max) (codeml.c:6286-6294)."""
     K, ncls, ngrid = 7, 3, 500
-    pb = helpers.random_problem(61, 8, 3000, K=K, seed=31)
+    pb = helpers.random_problem(61, 8, 3000, K=K, seed=31, scale_every=every)
     rng = np.random.default_rng(8)
     pb.weights = rng.integers(0, 4, pb.n_patt).astype(float)          # some zero-weight patterns too
     eng = engine_for(pb)
@@ -580,7 +582,11 @@ def test_beb_grid_matches_numpy_restatement():
     wc = np.linspace(0.1, 4.0, K)
     got = eng.beb_grid(pcl, iw, wc)
     m = pb.weights > 0                                            # fx_r leaves fhK = 0 for patterns that do not count
-    f = out["fhK"][:, m] / out["fhK"][:, m].max(axis=0, keepdims=True)                    # [K][patterns with weight]
+    if every:
+        assert (out["fhK"][:, m] < 0).all()                       # logarithms
+        f = np.exp(out["fhK"][:, m] - out["fhK"][:, m].max(axis=0, keepdims=True))
+    else:
+        f = out["fhK"][:, m] / out["fhK"][:, m].max(axis=0, keepdims=True)                # [K][patterns with weight]
     mix = np.einsum("gc,gch->gh", pcl, f[iw])                                             # [ngrid][...]
     lnfxs = (np.log(mix) * pb.weights[m]).sum(axis=1)
     fx = np.log(np.exp(lnfxs - lnfxs.max()).sum()) + lnfxs.max()

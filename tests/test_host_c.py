@@ -17,7 +17,10 @@ CTL = os.path.join(helpers.GOLDEN, "ctl")
 CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml", "stewart_lg_g4.ctl"),
          ("hiv_m0", "codeml", "hiv_ns0.ctl"), ("hiv_m1a", "codeml", "hiv_ns1.ctl"), ("hiv_m2a", "codeml", "hiv_ns2.ctl"),
          ("hiv_m7", "codeml", "hiv_ns7.ctl"), ("hiv_m8", "codeml", "hiv_ns8.ctl"), ("mhc_m0_scaled", "codeml", "mhc_m0.ctl"),
+         ("mhc_m2a", "codeml", "mhc_ns2.ctl"), ("mhc_m8", "codeml", "mhc_ns8.ctl"),      # site classes on a tree with ten scaling nodes
          ("mtcdna_branch", "codeml", "mtcdna_branch.ctl"),
+         # other genetic codes: invertebrate mt (62 sense codons), ciliate nuclear (63), the reference's "regularised" code (64)
+         ("hiv_m0_icode4", "codeml", "hiv_ns0_icode4.ctl"), ("hiv_m0_icode5", "codeml", "hiv_ns0_icode5.ctl"), ("hiv_m0_icode11", "codeml", "hiv_ns0_icode11.ctl"),
          # aaDist = 7 (AAClasses): omega by class of amino-acid pair (ctl/OmegaAA.dat), alone and per branch label
          ("mtcdna_aaclass_m0", "codeml", "mtcdna_aaclass_m0.ctl"), ("mtcdna_aaclass_branch", "codeml", "mtcdna_aaclass_branch.ctl"),
          # omega as a function of an amino-acid distance: geometric on Grantham's (aaDist = 1), linear on Miyata's (-2; its slope ends on the bound 1)
@@ -165,6 +168,34 @@ def test_c_host_reads_fasta_and_nexus(tmp_path, fmt):
     pa, pb = a.problem(np.array(g["x"])), b.problem(np.array(g["x"]))
     assert np.array_equal(pa.z, pb.z) and np.array_equal(pa.weights, pb.weights) and np.array_equal(pa.pi, pb.pi)
     assert abs(oracle.evaluate(pa)["lnL"] - g["lnL"]) <= 2e-6
+
+
+def test_c_host_picks_a_tree_of_a_file_with_several(tmp_path):
+    """The reference evaluates the trees of the tree file one after the other (Forestry codeml.c:635); here every tree is an
+    analysis of its own (pamlh_load_tree).  stewart.trees holds two trees behind a header that announces one: the header wins, as
+    in the reference.  With the header corrected the second tree loads and is the same problem as a file that holds only it."""
+    data = os.path.join(helpers.GOLDEN, "data")
+    base = open(os.path.join(CTL, "stewart_lg_g4.ctl")).read().replace("../data/stewart.aa", os.path.join(data, "stewart.aa")).replace("../data/lg.dat", os.path.join(data, "lg.dat"))
+    a = hostlib.Analysis(os.path.join(CTL, "stewart_lg_g4.ctl"), "codeml")
+    assert a.n_trees() == 1
+    with pytest.raises(RuntimeError, match="holds 1"):
+        hostlib.Analysis(os.path.join(CTL, "stewart_lg_g4.ctl"), "codeml", tree_index=1)
+    two = open(os.path.join(data, "stewart.trees")).read().replace("6  1", "6  2", 1)
+    (tmp_path / "two.trees").write_text(two)
+    (tmp_path / "second.trees").write_text(" 6 1\n(((Rat, Horse), Human), Baboon, (Cow, Langur));\n")
+    (tmp_path / "two.ctl").write_text(base.replace("../data/stewart.trees", str(tmp_path / "two.trees")))
+    (tmp_path / "second.ctl").write_text(base.replace("../data/stewart.trees", str(tmp_path / "second.trees")))
+    t0 = hostlib.Analysis(str(tmp_path / "two.ctl"), "codeml")
+    t1 = hostlib.Analysis(str(tmp_path / "two.ctl"), "codeml", tree_index=1)
+    only = hostlib.Analysis(str(tmp_path / "second.ctl"), "codeml")
+    assert t0.n_trees() == t1.n_trees() == 2 and only.n_trees() == 1
+    g = helpers.load_golden("stewart_lg_g4")
+    x = np.array(g["x"])
+    assert abs(oracle.evaluate(t0.problem(x))["lnL"] - g["lnL"]) <= 2e-6          # the first tree is the golden's
+    p1, p2 = t1.problem(x), only.problem(x)
+    assert [[int(c) for c in ss] for ss in p1.tree.sons] == [[int(c) for c in ss] for ss in p2.tree.sons]
+    l1, l2 = oracle.evaluate(p1)["lnL"], oracle.evaluate(p2)["lnL"]
+    assert l1 == l2 and abs(l1 - g["lnL"]) > 1e-3                                     # a different topology
 
 
 def test_c_host_rejects_what_it_does_not_support(tmp_path):
@@ -658,6 +689,26 @@ def test_c_host_beb_matches_the_reference_table(gname, ctl, table):
         got = (pr[site - 1], mw[site - 1], se[site - 1])
         assert abs(got[0] - p_) < 2e-3 and abs(got[1] - m_) < 4e-3 and abs(got[2] - s_) < 4e-3, (site, got)
     assert sorted(np.nonzero(pr > 0.5)[0] + 1) == sorted(table)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname,ctl", [("mhc_m2a", "mhc_ns2.ctl"), ("mhc_m8", "mhc_ns8.ctl")])
+def test_c_host_neb_and_beb_on_a_tree_with_scaling_nodes(gname, ctl):
+    """NEB and BEB on the 192-taxon MHC data (examples/MHC.Swanson2002MBE; ten scaling nodes): with NodeScale fx_r leaves
+    log f(x_h | class) + the scale factors in fhK, and both analyses work with exp(fhK - max over classes)
+    (lfunNSsites_rate codeml.c:5269-5276, get_grid_para_like_M2M8 codeml.c:6286-6294).  Compared with the class posteriors the
+    reference writes to `rst` at all 270 sites (5 decimals): NEB every class, BEB the w > 1 class."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), "codeml")
+    x = np.array(g["x"])
+    post, mw = a.neb(x)
+    ref = np.array(g["neb_post"])
+    assert post.shape == ref.T.shape and np.max(np.abs(post.T - ref)) < 2e-5
+    pr, mwb, se = a.beb(x)
+    refb = np.array(g["beb_post"])
+    assert np.max(np.abs(pr - refb[:, -1])) < 2e-5
+    assert (pr > 0.95).sum() == (refb[:, -1] > 0.95).sum() > 0          # the MHC peptide-binding sites
+    assert np.isfinite(mwb).all() and (se >= 0).all()
 
 
 @pytest.mark.gpu
