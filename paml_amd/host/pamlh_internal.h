@@ -51,6 +51,7 @@ struct pamlh {
    unsigned char *chara_map;
    double fb3x4[12], fb4[4], fcodon[64], pi_data[64];
    double fb61[64];
+   int free_ratio;         /* codeml model = 1: run as the branch model with every branch its own label */
    int itree, ntrees;      /* which tree of the tree file this analysis uses; how many the file holds */
    /* codon frequencies as parameters (estFreq = 1) and the mutation-selection models FMutSel0 / FMutSel (CodonFreq 6, 7) */
    int codonf_model, est_freq, npi, mutsel;      /* CodonFreq as given (0..7); estFreq; frequency parameters in x; 0 / 1 = FMutSel0 / 2 = FMutSel */

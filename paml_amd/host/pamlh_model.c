@@ -333,6 +333,7 @@ int pamlh_load_tree(pamlh **out, const char *ctl_path, const char *program, int 
    if (p->seqtype == 1) {
       if (p->icode < 0 || p->icode >= N_GENETIC_CODES) { rc = pamlh_fail(p, "genetic code icode = %d is not supported (0 ... 11)", p->icode); goto bad; }
       /* model 0: site models; model 2, NSsites 0: branch model; model 2 / 3 with NSsites 2 / 3: branch-site A / B, clade C / D */
+      if (p->model == 1 && p->nssites == 0) { p->free_ratio = 1; p->model = 2; p->fix_omega = 0; }      /* an omega for every branch: the branch model with one label per branch (below) */
       if (p->model != 0 && !(p->model == 2 && p->nssites == 0) && !((p->model == 2 || p->model == 3) && (p->nssites == 2 || p->nssites == 3))) {
          rc = pamlh_fail(p, "codon model = %d with NSsites = %d is not supported", p->model, p->nssites); goto bad;
       }
@@ -465,6 +466,7 @@ genes_ok:
    }
    if (!(p->seqtype == 1 && p->model >= 2)) memset(p->label, 0, p->nnode * sizeof(int));      /* '#' labels only matter to branch models */
    if (p->seqtype == 0 && p->nhomo >= 2) { int v; for (v = 0; v < p->nnode; v++) p->label[v] = v; }      /* every branch has its own P(t) family */
+   if (p->free_ratio) { int b; for (b = 0; b < p->nbranch; b++) p->label[p->branch_node[b]] = b; }      /* free-ratio model: nodes[tree.branches[i][1]].label = i (codeml.c:2171-2175) */
    if (p->seqtype == 1 && p->model >= 2) {
       int i;
       for (p->n_omega = 1, i = 0; i < p->nnode; i++) if (p->label[i] + 1 > p->n_omega) p->n_omega = p->label[i] + 1;
@@ -551,7 +553,7 @@ genes_ok:
          nr += p->npi;
          if (p->aadist == 7) nr += p->n_omega_type * (p->model == 2 ? p->n_omega : 1);      /* AAClasses: a set of class omegas (per branch label) */
          else if (p->aadist) nr += 2;                                                          /* a, b of omega(d) */
-         else if (p->nssites == 0 && p->model == 2) nr += p->n_omega;      /* branch model: one omega per branch label (codeml.c:2170-2183) */
+         else if (p->nssites == 0 && p->model == 2) nr += p->n_omega - (p->fix_omega != 0);      /* branch model: one omega per branch label, the last one fixed under fix_omega (codeml.c:2170-2183) */
          else if (p->model == 2 && p->nssites == 2) nr += 3 + !p->fix_omega;      /* branch-site A: p0 p1 w0 [w2] (codeml.c:2197-2221) */
          else if (p->model == 2 && p->nssites == 3) nr += 5;                      /* branch-site B: p0 p1 w0 w1 w2 */
          else if (p->model == 3) nr += 2 + (p->nssites == 3 ? 2 : 1) + p->n_omega - (p->fix_omega != 0);   /* clade C / D (codeml.c:2222-2233) */
@@ -759,7 +761,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       if (p->npi) k += codon_freq_initials(p, x + k);
       if (p->aadist == 7) { for (i = 0; i < p->n_omega_type * (p->model == 2 ? p->n_omega : 1); i++) x[k++] = 0.15 + 0.02 * (i % 4); }
       else if (p->aadist) { x[k++] = 0.15; x[k++] = 0.25; }
-      else if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) x[k++] = p->omega0; }
+      else if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega - (p->fix_omega != 0); i++) x[k++] = p->fix_omega ? 0.4 : p->omega0; }
       else if (p->model == 2 && p->nssites) {      /* branch-site A / B: p0 p1 w0 [w1] [w2] */
          x[k++] = 0.6; x[k++] = 0.2; x[k++] = 0.25;
          if (p->nssites == 3) x[k++] = 0.8;
@@ -1252,7 +1254,7 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          /* branch model: label l has its own omega and its own eigen system, each scaled by its own mean rate
           * (SetParameters codeml.c:2804-2812 -> _UU[l]; GetPMatBranch treesub.c:7568-7572) */
          for (j = 0; j < p->n_omega; j++) {
-            const double w = x[k++], mr = codon_q(p, kappa, w, Q);
+            const double w = (j == p->n_omega - 1 && p->fix_omega) ? p->omega0 : x[k++], mr = codon_q(p, kappa, w, Q);      /* omega_fix: SetParameters codeml.c:2810 */
             set_eig_uvroot(p, j, Q, p->pi, mr);
             p->eigen_of[j] = j;
             p->class_w[j] = w;
@@ -1736,7 +1738,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
          for (j = 0; j < p->npi; j++) NAME("codon frequency parameter %d", j + 1);
          if (p->aadist == 7) { int l; for (l = 0; l < (p->model == 2 ? p->n_omega : 1); l++) for (j = 0; j < p->n_omega_type; j++) NAME("omega class %d (branch type %d)", j, l); }
          else if (p->aadist) { NAME("a (omega against amino-acid distance)"); NAME("b"); }
-         else if (p->nssites == 0 && p->model == 2) { for (j = 0; j < p->n_omega; j++) NAME("omega #%d", j); }
+         else if (p->nssites == 0 && p->model == 2) { for (j = 0; j < p->n_omega - (p->fix_omega != 0); j++) NAME("omega #%d", j); }
          else if (p->model >= 2) {
             NAME("p0"); NAME("p1"); NAME("w0");
             if (p->nssites == 3) NAME("w1");

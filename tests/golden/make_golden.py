@@ -650,6 +650,12 @@ CASES = {
     "hiv_m0_icode4": lambda: case_mle("hiv_m0_icode4", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, icode=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_icode5": lambda: case_mle("hiv_m0_icode5", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, icode=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_icode11": lambda: case_mle("hiv_m0_icode11", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, icode=11, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
+    # the free-ratio model (model = 1: an omega for every branch; Yang 1998) on the small lysozyme data set, and the one-ratio model next to it
+    "lysos_free": lambda: case_mle("lysos_free", dict(seqfile="lysozymeSmall.txt", treefile="lysozymeSmall.free.trees", model=1, NSsites=0, kappa=2, omega=.4, cleandata=0),
+                                   {"lysozymeSmall.txt": EX + "/lysozyme/lysozymeSmall.txt", "lysozymeSmall.free.trees": os.path.join(HERE, "data", "lysozymeSmall.free.trees")}, 7, "codon_branch"),
+    # ... and the three-ratio branch model with the last omega fixed at 1 (examples/lysozyme/README.txt: table 1 E & J of Yang 1998)
+    "lysos_branch_fix": lambda: case_mle("lysos_branch_fix", dict(seqfile="lysozymeSmall.txt", treefile="lysozymeSmall.EJ.trees", model=2, NSsites=0, kappa=2, fix_omega=1, omega=1, cleandata=0),
+                                         {"lysozymeSmall.txt": EX + "/lysozyme/lysozymeSmall.txt", "lysozymeSmall.EJ.trees": os.path.join(HERE, "data", "lysozymeSmall.EJ.trees")}, 7, "codon_branch"),
     "brown_hky85_clock": case_brown_clock,
     "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),

@@ -19,6 +19,7 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("hiv_m7", "codeml", "hiv_ns7.ctl"), ("hiv_m8", "codeml", "hiv_ns8.ctl"), ("mhc_m0_scaled", "codeml", "mhc_m0.ctl"),
          ("mhc_m2a", "codeml", "mhc_ns2.ctl"), ("mhc_m8", "codeml", "mhc_ns8.ctl"),      # site classes on a tree with ten scaling nodes
          ("mtcdna_branch", "codeml", "mtcdna_branch.ctl"),
+         ("lysos_free", "codeml", "lysos_free.ctl"), ("lysos_branch_fix", "codeml", "lysos_branch_fix.ctl"),      # free-ratio model (model = 1): an omega and an eigen system for each of the 11 branches
          # other genetic codes: invertebrate mt (62 sense codons), ciliate nuclear (63), the reference's "regularised" code (64)
          ("hiv_m0_icode4", "codeml", "hiv_ns0_icode4.ctl"), ("hiv_m0_icode5", "codeml", "hiv_ns0_icode5.ctl"), ("hiv_m0_icode11", "codeml", "hiv_ns0_icode11.ctl"),
          # aaDist = 7 (AAClasses): omega by class of amino-acid pair (ctl/OmegaAA.dat), alone and per branch label
@@ -200,7 +201,7 @@ def test_c_host_picks_a_tree_of_a_file_with_several(tmp_path):
 
 def test_c_host_rejects_what_it_does_not_support(tmp_path):
     ctl = tmp_path / "x.ctl"
-    ctl.write_text("seqfile = %s\ntreefile = %s\nseqtype = 1\nmodel = 1\nNSsites = 0\n" %
+    ctl.write_text("seqfile = %s\ntreefile = %s\nseqtype = 1\nmodel = 1\nNSsites = 2\n" %
                    (os.path.join(helpers.GOLDEN, "data", "HIVenvSweden.txt"), os.path.join(helpers.GOLDEN, "data", "HIVenvSweden.trees")))
     with pytest.raises(RuntimeError, match="not supported"):
         hostlib.Analysis(str(ctl), "codeml")
@@ -308,6 +309,21 @@ def test_c_host_optimiser_on_branch_site_and_clade_models(gname, ctl):
     assert r1["converged"] and abs(r1["lnL"] - g["mle_lnL"]) < 5e-5, (r1["lnL"], g["mle_lnL"])
     r = a.optimize(a.default_x())
     assert r["converged"] and g["mle_lnL"] - 2.0 < r["lnL"] < g["mle_lnL"] + 5e-5, (r["lnL"], g["mle_lnL"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname,np_,tol", [("lysos_free", 23, 1e-3), ("lysos_branch_fix", 14, 2e-5)])
+def test_c_host_optimiser_on_the_free_ratio_and_fixed_omega_branch_models(gname, np_, tol):
+    """model = 1 (Yang 1998): one omega per branch of the small lysozyme tree — 11 branch lengths, kappa, 11 omegas, 11 eigen systems
+    selected through the engine's branch labels.  From the control file's initial values the search reaches the reference's maximum
+    (-896.412472; two of its omegas sit on the bound 999 — no synonymous change on the branch — where the surface is flat).
+    model = 2 with fix_omega = 1: three branch types, the last omega fixed at 1 (the likelihood-ratio test of omega = 1 on a branch,
+    examples/lysozyme/README.txt "table 1E&J"): -903.482633."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, gname + ".ctl"), "codeml")
+    assert (a.np, a.ntime) == (np_, 11)
+    r = a.optimize(a.default_x())
+    assert r["converged"] and r["lnL"] > g["mle_lnL"] - tol and r["lnL"] < g["mle_lnL"] + 0.05, (r["lnL"], g["mle_lnL"])
 
 
 @pytest.mark.gpu
