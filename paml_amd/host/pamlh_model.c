@@ -25,6 +25,17 @@ static const char *const GENETIC_CODES[N_GENETIC_CODES] = {
    "FFLLSSSSYY*QCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG", "RRRRNNNNDDDDCCCCQQQQEEEEGGGGHHHHIIIILLLLKKKKMMMMFFFFPPPPSSSSTTTT"};
 
 static int nuc_nkappa(const pamlh *p);
+/* days from 1970-01-01 to y-m-d in the proleptic Gregorian calendar (era arithmetic: 400-year cycles of 146 097 days, years starting in March) */
+static long days_from_civil(int y, int m, int d)
+{
+   long era, yoe, doy, doe;
+   y -= m <= 2;
+   era = (y >= 0 ? y : y - 399) / 400;
+   yoe = y - era * 400;
+   doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+   doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+   return era * 146097 + doe - 719468;
+}
 static double dist2(const double *a, const double *b, int n)
 {
    double s = 0;
@@ -529,9 +540,17 @@ genes_ok:
          for (v = 0; v < p->ns; v++) {
             const char *nm = p->names[v], *q = nm + strlen(nm);
             double d = 0;
-            while (q > nm && (isdigit((unsigned char)q[-1]) || q[-1] == '.')) q--;
-            if (q > nm && q[-1] == '-' ) { rc = pamlh_fail(p, "TipDate: yyyy-mm-dd dates are not supported (%s)", nm); goto bad; }
-            if (!*q || sscanf(q, "%lf", &d) != 1 || d <= 0) { rc = pamlh_fail(p, "TipDate: no sampling date at the end of the name %s", nm); goto bad; }
+            while (q > nm && (isdigit((unsigned char)q[-1]) || q[-1] == '.' || q[-1] == '-')) q--;
+            if (strchr(q, '-')) {
+               /* yyyy-mm-dd (or yyyy-mm: the 15th): days since 1970-01-01.  The reference takes mktime() / 86400 (treesub.c:3573-3582),
+                * i.e. the same count shifted by the local time zone; differences of dates are what enters the model */
+               int y = 0, mo = 0, dd = 0, nf = sscanf(q, "%d-%d-%d", &y, &mo, &dd);
+               if (nf < 2 || mo < 1 || mo > 12) { rc = pamlh_fail(p, "TipDate: date format wrong in the name %s (yyyy-mm-dd)", nm); goto bad; }
+               if (nf < 3 || dd < 1) dd = 15;
+               d = (double)days_from_civil(y, mo, dd);
+            }
+            else if (!*q || sscanf(q, "%lf", &d) != 1) d = 0;
+            if (d <= 0) { rc = pamlh_fail(p, "TipDate: no sampling date at the end of the name %s", nm); goto bad; }
             p->tip_age[v] = d;
             if (v == 0 || d > young) young = d;
             if (v == 0 || d < old) old = d;

@@ -295,6 +295,11 @@ def case_mhc():
                 scale_nodes=[int(v) for v in scal.group(2).split()] if scal else None))
 
 
+
+sys.path.insert(0, os.path.dirname(HERE))
+from helpers import ymd_names  # noqa: E402  (the tests rebuild the same files)
+
+
 def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtype="codon"):
     """Branch-site / clade / discrete models: the reference first maximises the likelihood from its own initial values (or x0),
     then the golden is the single evaluation at the printed 6-decimal estimates (the -1 recipe), whose lnL must agree with
@@ -656,6 +661,11 @@ CASES = {
     # ... and the three-ratio branch model with the last omega fixed at 1 (examples/lysozyme/README.txt: table 1 E & J of Yang 1998)
     "lysos_branch_fix": lambda: case_mle("lysos_branch_fix", dict(seqfile="lysozymeSmall.txt", treefile="lysozymeSmall.EJ.trees", model=2, NSsites=0, kappa=2, fix_omega=1, omega=1, cleandata=0),
                                          {"lysozymeSmall.txt": EX + "/lysozyme/lysozymeSmall.txt", "lysozymeSmall.EJ.trees": os.path.join(HERE, "data", "lysozymeSmall.EJ.trees")}, 7, "codon_branch"),
+    # TipDate with yyyy-mm-dd dates: the HIV-2 data with every name's year turned into a calendar date (ymd_names below; the tests rebuild the
+    # same files); dates become days since 1970-01-01 (mktime — run with TZ=UTC), so the time unit is 36 500 days
+    "hiv2_tipdate_ymd": lambda: case_mle("hiv2_tipdate_ymd", dict(seqfile="HIV2ge.ymd.txt", treefile="HIV2ge.ymd.tree", model=4, clock=1, TipDate="1 36500", kappa=2, fix_alpha=0, alpha=0.5, ncatG=5, cleandata=0),
+                                         {"HIV2ge.ymd.txt": ymd_names(open(EX + "/TipDate.HIV2/HIV2ge.txt").read()), "HIV2ge.ymd.tree": ymd_names(open(os.path.join(HERE, "data", "HIV2ge.tree1")).read())},
+                                         33, "nuc_tipdate", prog="baseml", seqtype="nuc"),
     "brown_hky85_clock": case_brown_clock,
     "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),

@@ -258,3 +258,16 @@ def random_problem(n, n_tips, n_patt, K=1, seed=0, ambiguity=False, scale_every=
         mode = MODE_LFUNDG if K > 1 else MODE_LFUN
     return Problem(n=n, tree=tree, z=z, weights=w, pi=pi, eigen=[dict(kind=EIGEN_UVROOT, U=U, V=V, Root=root)],
                    mode=mode, **kw)
+
+
+def ymd_names(text):
+    """The HIV-2 TipDate data (tests/golden/data/HIV2ge.*) name their sequences by isolate + sampling year (P03h1995): turn the year into a
+    calendar date, P03h_1995-MM-DD, month and day drawn from the name — the yyyy-mm-dd flavour of TipDate (golden hiv2_tipdate_ymd was
+    generated by the reference from files renamed by this same function)."""
+    import re
+
+    def sub(m):
+        name, year = m.group(1), m.group(2)
+        k = sum(ord(c) for c in name)
+        return "%s_%s-%02d-%02d" % (name, year, 1 + k % 12, 1 + k % 28)
+    return re.sub(r"\b([A-Za-z0-9]*?[A-Za-z])((?:19|20)\d\d)\b", sub, text)
