@@ -296,7 +296,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
       }
       if (p->aadist == 7) { for (i = 0; i < p->n_omega_type * (p->model == 2 ? p->n_omega : 1); i++) { lo[k] = 1e-4; hi[k++] = 999; } }
       else if (p->aadist) { lo[k] = 1e-4; hi[k++] = p->aadist < 0 ? 1 : 999; lo[k] = 1e-4; hi[k++] = 999; }
-      else if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega; i++) { lo[k] = 1e-4; hi[k++] = 999; } }
+      else if (p->nssites == 0 && p->model == 2) { for (i = 0; i < p->n_omega - (p->fix_omega != 0); i++) { lo[k] = 1e-4; hi[k++] = 999; } }
       else if (p->model >= 2) {      /* branch-site A / B, clade C / D (SetxBound codeml.c:1940-1965; proportions untransformed here) */
          lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 1e-6; hi[k++] = 1 - 1e-6;
          if (p->model == 2 && p->nssites == 2) { lo[k] = 1e-6; hi[k++] = 1; if (!p->fix_omega) { lo[k] = 1; hi[k++] = 999; } }

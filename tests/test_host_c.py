@@ -71,6 +71,8 @@ def test_c_host_reproduces_reference_on_cpu(gname, prog, ctl):
     if "x" in g and a.np:
         assert a.np == len(g["x"]) and a.ntime == g.get("ntime", a.ntime)
     assert len(a.default_x()) == a.np      # initial values, bounds and names cover every parameter
+    lo, hi = a.bounds()
+    assert len(lo) == len(hi) == a.np and (lo <= hi).all()
     pb = a.problem(_x(g, a))
     assert np.array_equal(pb.weights, np.array(g["counts"]))          # same patterns, same order, same counts
     r = oracle.evaluate(pb)
