@@ -28,6 +28,9 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
  * other (Forestry codeml.c:635, baseml.c:451) — and the number of trees the file holds */
 int pamlh_load_tree(pamlh **out, const char *ctl_path, const char *program, int tree_index, char *err, int errcap);
 int pamlh_n_trees(const pamlh *p);
+/* "dN & dS for each branch" (DetailOutput codeml.c:1349-1404) under the codon models without site classes: out[n_branches][6] = t, N, S,
+ * omega, dN, dS at the parameter vector x; n_branches = n_nodes - 1, in the order of the branch lengths in x (first appearance in the tree file) */
+int pamlh_dnds(pamlh *p, const double *x, double *out);
 void pamlh_free(pamlh *p);
 const char *pamlh_error(const pamlh *p);
 

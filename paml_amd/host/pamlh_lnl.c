@@ -137,6 +137,24 @@ int main(int argc, char **argv)
          while (wait(&st) > 0) bad |= !WIFEXITED(st) || WEXITSTATUS(st);
       return bad ? 1 : 0;
    }
+   {  /* codon models without site classes: the reference's "dN & dS for each branch" table (codeml.c:1361-1404) */
+      int nn = 0, b;
+      double *tab;
+      pamlh_dims(p, NULL, NULL, NULL, &nn, NULL, NULL, NULL, NULL, NULL, NULL);
+      tab = (double *)malloc((size_t)nn * 6 * sizeof(double));
+      if (!strcmp(argv[1], "codeml") && !pamlh_dnds(p, x, tab)) {
+         double dnt = 0, dst = 0;
+         printf("\ndN & dS for each branch\n\n%7s%11s%8s%8s%8s%8s%8s\n\n", "branch", "t", "N", "S", "dN/dS", "dN", "dS");
+         for (b = 0; b < nn - 1; b++) {
+            const double *r = tab + b * 6;
+            printf("%7d %10.3f %7.1f %7.1f %7.4f %7.4f %7.4f\n", b + 1, r[0], r[1], r[2], r[3], r[4], r[5]);
+            dnt += r[4]; dst += r[5];
+         }
+         printf("\ntree length for dN: %12.4f\ntree length for dS: %12.4f\n", dnt, dst);
+      }
+      free(tab);
+      if (pamlh_set_x(p, x, np)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
+   }
    {  /* site-class models: the NEB table the reference prints (sites with Pr(last class) > 0.5 when its omega > 1) */
       int mode, K, n_sites, h, npos = pamlh_positive_classes(p);
       pamlh_model(p, &mode, &K, NULL, NULL);

@@ -2119,6 +2119,46 @@ int pamlh_beb_acd(pamlh *p, const double *x, double *post)
    return rc;
 }
 
+/* dN and dS of every branch under the codon models without site classes — M0, the branch models, the free-ratio model — as the
+ * reference's "dN & dS for each branch" table (DetailOutput codeml.c:1349-1404; eigenQcodon mode 2 codeml.c:3318-3365): with rs / ra
+ * the synonymous / nonsynonymous shares of the mean rate under the branch's omega and rs0 / ra0 the shares at omega = 1,
+ *    S = 3 ls rs0,  N = 3 ls - S,  dS = t rs / (3 rs0),  dN = t ra / (3 ra0).
+ * out: [n_branches][6] = t, N, S, omega, dN, dS in the order of the branch lengths in x. */
+int pamlh_dnds(pamlh *p, const double *x, double *out)
+{
+   const int n = p->n;
+   double *Q, *Q1;
+   int from61[64], b, i, j, m = 0, rc;
+   if (p->seqtype != 1 || p->nssites || p->aadist || p->ngene > 1 || !(p->model == 0 || p->model == 2))
+      return pamlh_fail(p, "dN and dS per branch are defined for the codon models without site classes (one gene)");
+   if ((rc = pamlh_set_x(p, x, p->np))) return rc;
+   for (i = 0; i < 64; i++) if (p->code[i] != '*') from61[m++] = i;
+   Q = (double *)malloc((size_t)2 * n * n * sizeof(double)); Q1 = Q + (size_t)n * n;
+   codon_q(p, p->kappa, 1, Q1);
+   for (b = 0; b < p->nbranch; b++) {
+      const int node = p->branch_node[b];
+      const double w = p->model == 2 ? p->class_w[p->label[node]] : p->omega, t = p->branch[node];
+      double rs = 0, ra = 0, ra0 = 0, mr, rs0;
+      codon_q(p, p->kappa, w, Q);
+      for (i = 0; i < n; i++)
+         for (j = 0; j < n; j++) {
+            if (i == j) continue;
+            if (p->code[from61[i]] == p->code[from61[j]]) rs += p->pi[i] * Q[i * n + j];
+            else { ra += p->pi[i] * Q[i * n + j]; ra0 += p->pi[i] * Q1[i * n + j]; }
+         }
+      mr = rs + ra;
+      rs0 = rs / (rs + ra0); ra0 = ra0 / (rs + ra0);
+      out[b * 6 + 0] = t;
+      out[b * 6 + 2] = 3 * p->ls * rs0;
+      out[b * 6 + 1] = 3 * p->ls - out[b * 6 + 2];
+      out[b * 6 + 3] = w;
+      out[b * 6 + 4] = t * (ra / mr) / (3 * ra0);
+      out[b * 6 + 5] = t * (rs / mr) / (3 * rs0);
+   }
+   free(Q);
+   return 0;
+}
+
 const int *pamlh_pose(const pamlh *p, int *n_sites)
 {
    if (n_sites) *n_sites = p->n_pose;

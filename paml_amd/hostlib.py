@@ -46,6 +46,7 @@ def lib():
         L.pamlh_load.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.pamlh_load_tree.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
         L.pamlh_n_trees.argtypes = [C.c_void_p]
+        L.pamlh_dnds.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.pamlh_free.argtypes = [C.c_void_p]
         L.pamlh_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 10
         L.pamlh_default_x.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -78,6 +79,14 @@ class Analysis:
         L.pamlh_dims(h, *[C.byref(v) for v in d])
         (self.n, self.n_tips, self.n_patt, self.n_nodes, self.root, self.n_codes, self.cleandata, self.ls, self.np,
          self.ntime) = [v.value for v in d]
+
+    def dnds(self, x):
+        """[n_branches][6] = t, N, S, omega, dN, dS (the reference's "dN & dS for each branch" table)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros((self.n_nodes - 1, 6))
+        if self._L.pamlh_dnds(self._h, x.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double))) != 0:
+            raise RuntimeError("pamlh_dnds: " + self._L.pamlh_error(self._h).decode())
+        return out
 
     def n_trees(self):
         return self._L.pamlh_n_trees(self._h)

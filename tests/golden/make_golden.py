@@ -318,6 +318,10 @@ def case_mle(name, ctl_over, files, n_tips, kind, x0=None, prog="codeml", seqtyp
             rows = re.findall(r"^\s*\d+ \S\s+((?:[01]\.\d{5}\s+)+)\(\s*\d+\)", blk, re.M)
             ls = int([ln for ln in res1["lnf"] if ln.split()][0].split()[1])
             tables[key] = [[float(v) for v in r.split()] for r in rows[:ls]]
+    if "dN & dS for each branch" in res1["main"]:      # branch, t, N, S, dN/dS, dN, dS (+ N*dN, S*dS) as printed in the main result file
+        blk = res1["main"][res1["main"].index("dN & dS for each branch"):]
+        rows = re.findall(r"^\s*(\d+)\.\.(\d+)\s+([-0-9.]+)\s+([-0-9.]+)\s+([-0-9.]+)\s+([-0-9.]+)\s+([-0-9.]+)\s+([-0-9.]+)", blk, re.M)
+        tables["dnds"] = [[int(r[0]), int(r[1])] + [float(v) for v in r[2:]] for r in rows]
     finish(name, res1, seqtype, n_tips, dict(tables, program=prog, model=dict(kind=kind, **{k: ctl_over[k] for k in ("model", "NSsites", "fix_omega", "omega", "ncatG", "Mgene", "alpha", "nhomo", "fix_kappa", "Malpha", "clock", "TipDate", "aaDist", "CodonFreq", "estFreq", "icode") if k in ctl_over}),
                                              x=x, ntime=ntime, mle_lnL=res["lnL"]), keep_raw_patterns=True)
 

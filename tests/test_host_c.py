@@ -201,6 +201,23 @@ def test_c_host_picks_a_tree_of_a_file_with_several(tmp_path):
     assert l1 == l2 and abs(l1 - g["lnL"]) > 1e-3                                     # a different topology
 
 
+@pytest.mark.parametrize("gname,ctl", [("lysos_free", "lysos_free.ctl"), ("lysos_branch_fix", "lysos_branch_fix.ctl"), ("hiv_m0_icode4", "hiv_ns0_icode4.ctl")])
+def test_c_host_dn_ds_per_branch_match_the_reference_table(gname, ctl):
+    """"dN & dS for each branch" of the reference's main result file (DetailOutput codeml.c:1349-1404: t, N, S, dN/dS, dN, dS printed with
+    3 / 1 / 1 / 4 / 4 / 4 decimals) at its estimates: the free-ratio model (eleven omegas, two of them on the bound 999), the three-ratio
+    model with the last omega fixed at 1, and M0 under the invertebrate mitochondrial code."""
+    g = helpers.load_golden(gname)
+    a = hostlib.Analysis(os.path.join(CTL, ctl), "codeml")
+    got = a.dnds(np.array(g["x"]))
+    ref = np.array(g["dnds"])[:, 2:]
+    assert got.shape == ref.shape == (a.n_nodes - 1, 6)
+    for col, tol in enumerate((6e-4, 0.06, 0.06, 6e-5, 6e-5, 6e-5)):
+        assert np.max(np.abs(got[:, col] - ref[:, col])) < tol, (col, got[:, col], ref[:, col])
+    b = hostlib.Analysis(os.path.join(CTL, "hiv_ns2.ctl"), "codeml")
+    with pytest.raises(RuntimeError, match="without site classes"):
+        b.dnds(b.default_x())
+
+
 def test_c_host_rejects_what_it_does_not_support(tmp_path):
     ctl = tmp_path / "x.ctl"
     ctl.write_text("seqfile = %s\ntreefile = %s\nseqtype = 1\nmodel = 1\nNSsites = 2\n" %
