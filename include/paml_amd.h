@@ -92,7 +92,8 @@ int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream);
 /* com.z (treesub.c:1116 EncodeSeqs), nChara/CharaMap (tools.c:20, treesub.c:1218), com.fpatt, com.posG.
  * z is row-major [n_tips][n_patt] one byte per character code; with cleandata != 0 codes are states
  * 0..n-1 and the map may be NULL; otherwise n_chara[code] states listed in chara_map[code*n_states + k].
- * gene_off has n_genes+1 entries (NULL = one gene covering all patterns).  Uploaded once. */
+ * gene_off has n_genes+1 non-decreasing entries from 0 to n_patt (NULL = one gene covering all patterns; a pattern shard of a
+ * multi-GPU run may hold nothing of a gene: equal neighbours).  Uploaded once. */
 int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata, int n_codes, const int *n_chara,
                       const unsigned char *chara_map, const double *weights, const int *gene_off);
 

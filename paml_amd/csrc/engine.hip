@@ -1119,7 +1119,6 @@ int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id12
    if (e) e->pipe_ok = false;
    if (!e || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return fail(e, PAML_AMD_EINVAL, "comm_init: bad arguments");
    if (e->comm) return fail(e, PAML_AMD_EINVAL, "comm_init: the engine already has a communicator");
-   if (e->n_genes > 1 && world > 1) return fail(e, PAML_AMD_EUNSUPPORTED, "comm_init: several genes are not sharded yet");
    const int chunk = red_chunk(n_patt_global);
    if (first_pattern < 0 || first_pattern + e->n_patt > n_patt_global || first_pattern % chunk != 0 ||
        (first_pattern + e->n_patt != n_patt_global && e->n_patt % chunk != 0))
@@ -1228,7 +1227,7 @@ int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata,
    if (e->gene_off[0] != 0 || e->gene_off[e->n_genes] != e->n_patt)
       return fail(e, PAML_AMD_EINVAL, "set_tips: gene_off must span [0, n_patt]");
    for (int g = 0; g < e->n_genes; g++)
-      if (e->gene_off[g + 1] <= e->gene_off[g]) return fail(e, PAML_AMD_EINVAL, "set_tips: empty gene");
+      if (e->gene_off[g + 1] < e->gene_off[g]) return fail(e, PAML_AMD_EINVAL, "set_tips: gene_off must not decrease");      // (a pattern shard may hold nothing of a gene)
    HIPCHK(upload(e->d_z, z, nz, e->stream));
    HIPCHK(upload(e->d_weights, weights, (size_t)e->n_patt, e->stream));
    HIPCHK(upload(e->d_n_chara, nch.data(), nch.size(), e->stream));

@@ -1616,7 +1616,6 @@ int pamlh_set_shard(pamlh *p, int rank, int world, const void *id128)
    int i;
    unsigned char *z;
    if (p->eng) return pamlh_fail(p, "set_shard: call before the first evaluation");
-   if (p->ngene > 1 && world > 1) return pamlh_fail(p, "set_shard: several genes are not sharded yet");
    if (paml_amd_shard_bounds(p->npatt, world, rank, &first, &count) || count < 1) return pamlh_fail(p, "set_shard: rank %d of %d gets no patterns (%d in all)", rank, world, p->npatt);
    z = (unsigned char *)malloc((size_t)p->ns * count);
    for (i = 0; i < p->ns; i++) memcpy(z + (size_t)i * count, p->z + (size_t)i * p->npatt + first, count);
@@ -1627,7 +1626,8 @@ int pamlh_set_shard(pamlh *p, int rank, int world, const void *id128)
    p->npatt = (int)count;
    p->shard_have_id = id128 != NULL;
    if (id128) memcpy(p->shard_id, id128, PAML_AMD_COMM_ID_BYTES);
-   if (p->ngene == 1) p->posG[1] = p->npatt;
+   /* gene boundaries stay where they are in the global range: a shard holds the part of each gene inside it, possibly nothing */
+   for (i = 0; i <= p->ngene; i++) { long b = (long)p->posG[i] - first; p->posG[i] = (int)(b < 0 ? 0 : b > count ? count : b); }
    return 0;
 }
 

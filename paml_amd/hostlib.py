@@ -46,6 +46,7 @@ def lib():
         L.pamlh_load.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.pamlh_load_tree.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
         L.pamlh_n_trees.argtypes = [C.c_void_p]
+        L.pamlh_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.pamlh_dnds.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.pamlh_free.argtypes = [C.c_void_p]
         L.pamlh_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 10
@@ -87,6 +88,16 @@ class Analysis:
         if self._L.pamlh_dnds(self._h, x.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double))) != 0:
             raise RuntimeError("pamlh_dnds: " + self._L.pamlh_error(self._h).decode())
         return out
+
+    def set_shard(self, rank, world, comm_id=None):
+        """Keep this rank's block of site patterns (pamlh_set_shard; before the first evaluation).  comm_id: the 128-byte RCCL id, or
+        None for the sharding alone (CPU tests; one-GPU emulation of the ranks)."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(comm_id) if comm_id is not None else None
+        if self._L.pamlh_set_shard(self._h, rank, world, buf) != 0:
+            raise RuntimeError("pamlh_set_shard: " + self._L.pamlh_error(self._h).decode())
+        d = [C.c_int() for _ in range(10)]
+        self._L.pamlh_dims(self._h, *[C.byref(v) for v in d])
+        self.n_patt = d[2].value
 
     def n_trees(self):
         return self._L.pamlh_n_trees(self._h)

@@ -256,11 +256,11 @@ class Problem:
         return len(self.n_chara)
 
     def slice_patterns(self, lo: int, hi: int) -> "Problem":
-        """Contiguous pattern shard [lo, hi) (multi-GPU sharding). Single-gene only."""
-        assert self.n_genes == 1
+        """Contiguous pattern shard [lo, hi) (multi-GPU sharding).  Gene boundaries stay where they are in the global
+        range: the shard holds the part of every gene inside it (possibly none of it)."""
         import copy
         p = copy.copy(self)
         p.z = np.ascontiguousarray(self.z[:, lo:hi])
         p.weights = np.ascontiguousarray(self.weights[lo:hi])
-        p.gene_off = np.array([0, hi - lo], dtype=np.int32)
+        p.gene_off = np.clip(np.asarray(self.gene_off, dtype=np.int64) - lo, 0, hi - lo).astype(np.int32)
         return p

@@ -25,23 +25,30 @@ def _free_port():
 N_PATT = 3000      # chunk 256 -> 12 chunks, 6 per rank
 
 
-def _problem():
+def _problem(genes=1):
+    if genes > 1:      # option G: three genes with their own frequencies, rates and eigen systems
+        pb = helpers.random_problem(4, 9, N_PATT, K=2, seed=17, n_genes=genes)
+        pb.gene_off = np.array([0, 700, 1500, N_PATT], dtype=np.int32)      # the first two genes end inside rank 0's block [0, 1536)
+        return pb
     return synth.nuc_gtr_gamma_problem(n_tips=12, n_patt=N_PATT, seed=5)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, genes=1):
     import torch.distributed as dist
     for p in (helpers.REPO, os.path.join(helpers.REPO, "oracle"), os.path.join(helpers.REPO, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import oracle as orc
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    pb = _problem()
+    pb = _problem(genes)
     lnl, (lo, hi) = distributed.sharded_lnl(pb, lambda sub: orc.evaluate(sub, want_lnf=True)["lnf"], world, rank)
-    b = pb.tree.n_tips + 2
-    tt = np.array([pb.tree.branch[b], 0.2])
-    l, dl, ddl = distributed.sharded_eval_branch(pb, lambda sub, nb, ts: orc.eval_branch(sub, nb, ts), b, tt, world, rank)
-    out[rank] = (lnl, lo, hi, l.tolist(), dl.tolist(), ddl.tolist())
+    if genes > 1:
+        out[rank] = (lnl, lo, hi)
+    else:
+        b = pb.tree.n_tips + 2
+        tt = np.array([pb.tree.branch[b], 0.2])
+        l, dl, ddl = distributed.sharded_eval_branch(pb, lambda sub, nb, ts: orc.eval_branch(sub, nb, ts), b, tt, world, rank)
+        out[rank] = (lnl, lo, hi, l.tolist(), dl.tolist(), ddl.tolist())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -95,3 +102,21 @@ def test_two_rank_gloo_matches_single():
         assert np.allclose(out[r][3], rl, rtol=1e-12) and np.allclose(out[r][4], rdl, rtol=1e-9, atol=1e-9)
         assert np.allclose(out[r][5], rddl, rtol=1e-9, atol=1e-8)
     assert abs(rl[0] - res["lnL"]) <= 1e-11 * abs(res["lnL"])
+
+
+def test_two_rank_gloo_with_several_genes():
+    """Option G data shard the same way (gene boundaries stay where they are in the global pattern range): a rank holds the
+    part of every gene inside its block — here rank 1 holds nothing of the first gene — and the total is the one-rank total bit for bit."""
+    pb = _problem(3)
+    assert pb.n_genes == 3
+    res = oracle.evaluate(pb, want_lnf=True)
+    single = distributed.total_fixed_order(distributed.chunk_partials(res["lnf"], pb.weights, 0, pb.n_patt))
+    lo1, hi1 = distributed.shard_bounds(pb.n_patt, 2, 1)
+    sub = pb.slice_patterns(lo1, hi1)
+    assert sub.gene_off[0] == 0 and sub.gene_off[-1] == hi1 - lo1 and sub.gene_off[1] == 0 and (np.diff(sub.gene_off) >= 0).all()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out, 3), nprocs=2, join=True)
+    for r in (0, 1):
+        assert out[r][0] == single
+        assert abs(out[r][0] - res["lnL"]) <= 1e-12 * abs(res["lnL"])

@@ -758,14 +758,19 @@ def _stage2(partials):
     return distributed.total_fixed_order(partials)
 
 
-@pytest.mark.parametrize("n,K", [(61, 1), (4, 4), (20, 2)])
-def test_sharded_partial_sums_are_world_size_invariant(n, K):
+@pytest.mark.parametrize("n,K,genes", [(61, 1, 1), (4, 4, 1), (20, 2, 1), (4, 2, 3), (61, 2, 2)])
+def test_sharded_partial_sums_are_world_size_invariant(n, K, genes):
     """Shard engines that know the global pattern range leave their partial sums at global positions; added up (disjoint,
-    zero elsewhere: exact) and totalled in the fixed order they give the one-engine lnL bit for bit, for 2, 3 and 5 shards."""
+    zero elsewhere: exact) and totalled in the fixed order they give the one-engine lnL bit for bit, for 2, 3 and 5 shards.
+    With several genes (option G) the gene boundaries stay where they are in the global range: a shard holds the part of every
+    gene inside it, for some shards nothing of a gene."""
     from paml_amd import distributed
-    pb = helpers.random_problem(n, 10, 3000, K=K, seed=400 + n)
+    pb = helpers.random_problem(n, 10, 3000, K=K, seed=400 + n, n_genes=genes)
+    if genes > 1:
+        pb.gene_off = np.array([0, 450, 3000] if genes == 2 else [0, 450, 1100, 3000], dtype=np.int32)
     full = engine_for(pb)
-    lnl = full.eval(pb.tree.branch)["lnL"]
+    lnl = full.eval(pb.tree.branch, pb.gene_rate)["lnL"]
+    assert abs(lnl - oracle.evaluate(pb, want_lnf=False)["lnL"]) <= 1e-10 * abs(lnl)
     pf = full.partial_sums()
     assert len(pf) == -(-pb.n_patt // distributed.red_chunk(pb.n_patt)) and _stage2(pf) == lnl
     for world in (2, 3, 5):
@@ -775,7 +780,7 @@ def test_sharded_partial_sums_are_world_size_invariant(n, K):
             sub = pb.slice_patterns(lo, hi)
             e = engine_for(sub)
             e.comm_init(0, 1, None, pb.n_patt, lo)      # global chunking only: no communicator on a one-GPU box
-            local = e.eval(sub.tree.branch)["lnL"]
+            local = e.eval(sub.tree.branch, sub.gene_rate)["lnL"]
             ps = e.partial_sums()
             assert _stage2(ps) == local
             assert np.count_nonzero(ps) <= -(-(hi - lo) // distributed.red_chunk(pb.n_patt))

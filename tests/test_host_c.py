@@ -218,6 +218,33 @@ def test_c_host_dn_ds_per_branch_match_the_reference_table(gname, ctl):
         b.dnds(b.default_x())
 
 
+def test_c_host_shards_an_alignment_with_several_genes_on_cpu():
+    """pamlh_set_shard on option-G data (horai.nuc: four genes, Mgene = 4: rates, frequencies and kappa per gene): every rank keeps
+    its block of the global pattern range with the gene boundaries clipped to it — frequencies and everything else
+    estimated from the data were computed from the whole alignment before — and the ranks' per-chunk partial sums add up to the
+    one-rank total bit for bit."""
+    from paml_amd import distributed
+    g = helpers.load_golden("horai_mg4")
+    x = np.array(g["x"])
+    full = hostlib.Analysis(os.path.join(CTL, "horai_mg4.ctl"), "baseml").problem(x)
+    lnf = oracle.evaluate(full)["lnf"]
+    ref = distributed.total_fixed_order(distributed.chunk_partials(lnf, full.weights, 0, full.n_patt))
+    assert abs(ref - g["lnL"]) <= 2e-6
+    for world in (2,):      # 409 patterns are two reduction chunks of 256
+        tot = np.zeros(-(-full.n_patt // distributed.red_chunk(full.n_patt)))
+        for r in range(world):
+            lo, hi = distributed.shard_bounds(full.n_patt, world, r)
+            a = hostlib.Analysis(os.path.join(CTL, "horai_mg4.ctl"), "baseml")
+            a.set_shard(r, world)
+            assert a.n_patt == hi - lo
+            pb = a.problem(x)
+            want = full.slice_patterns(lo, hi)
+            assert np.array_equal(pb.z, want.z) and np.array_equal(pb.weights, want.weights) and np.array_equal(pb.gene_off, want.gene_off)
+            assert np.array_equal(pb.pi, full.pi)
+            tot += distributed.chunk_partials(oracle.evaluate(pb)["lnf"], pb.weights, lo, full.n_patt)
+        assert distributed.total_fixed_order(tot) == ref
+
+
 def test_c_host_rejects_what_it_does_not_support(tmp_path):
     ctl = tmp_path / "x.ctl"
     ctl.write_text("seqfile = %s\ntreefile = %s\nseqtype = 1\nmodel = 1\nNSsites = 2\n" %
