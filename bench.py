@@ -17,7 +17,7 @@ program) every run is checked against.  Default `--scaling strong`: the SAME 10^
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 Rank 0 prints ONE JSON line; beside the headline it carries `roofline`, `cpu_baseline` (N = 1), the NSsites `sweep`
-(K = 1, 2, 3, 10, 11 classes with the M0 / M1a / M2a / M7 / M8 tables of the goldens) and, at N = 1, the 4-state `c2`
+(K = 1, 2, 3, 10, 11 classes with the M0 / M1a / M2a / M7 / M8 tables of the goldens) and, at N = 1, the 20-state `aa20` and the 4-state `c2`
 configuration (BASELINE configs[1]).
 """
 from __future__ import annotations
@@ -263,6 +263,7 @@ def main():
         out["roofline"]["clock"] = ck
     if rank == 0 and world == 1 and extras:
         out["c2"] = bench_c2(engine, synth, timed, args)
+        out["aa20"] = bench_aa20(engine, synth, timed, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         pbc = pb if pb.K == 1 else None
         out["cpu_baseline"] = cpu_baseline(pbc, args.cpu_sample)
@@ -312,6 +313,28 @@ def bench_c2(engine, synth, timed, args):
                          "note": "materialised-partials bytes (SURVEY 8d): the fused kernel keeps partials in registers, so this exceeds the HBM "
                                  "peak; real traffic is in profiles/",
                          "valu_tflops": fpp * pb.n_patt / (kms * 1e-3) / 1e12, "valu_frac": fpp * pb.n_patt / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}}
+
+
+def bench_aa20(engine, synth, timed, args):
+    """The 20-state configuration at scale (BASELINE configs[2]'s model class — codeml seqtype 2, a rate file, Gamma4 — on 32 taxa x 10^5
+    synthetic amino-acid patterns; configs[2] itself, stewart.aa, has 98 patterns)."""
+    pb = synth.aa_gamma_problem(n_tips=32, n_patt=100_000)
+    eng = engine.engine_for(pb)
+    steps = max(100, args.steps)
+    dt, lnl, _ = timed(eng, pb.tree.branch.copy(), steps, 10)
+    _, _, prof = timed(eng, pb.tree.branch.copy(), 20, 0, profile=True)
+    name = eng.kernel_name
+    eng.close()
+    ref = golden_lnl("syn_aa_g4_full")
+    if ref is not None and not abs(lnl - ref) <= 2e-6 + 1e-12 * abs(ref):
+        raise SystemExit("bench: 20-state lnL %.9f differs from the reference's %.6f" % (lnl, ref))
+    kms = prof["ms_prune"] / max(1, prof["n_evals"])
+    fpp = algorithmic_flops_per_pattern(20, 32) * pb.K
+    return {"workload": "codeml seqtype 2 (rate file) + G4, 32 taxa x 100000 synthetic amino-acid patterns", "kernel": name, "lnL": lnl,
+            "lnL_reference": ref, "ms_per_eval": dt / steps * 1e3, "site_patterns_per_s": pb.n_patt * steps / dt, "kernel_ms": kms,
+            "roofline": {"bound": "mfma", "achieved": fpp * pb.n_patt / (dt / steps) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fpp * pb.n_patt / (dt / steps) / 1e12 / FP64_PEAK_TFLOPS, "algorithmic_flop_per_pattern": fpp,
+                         "note": "whole evaluation back to back (P(t), pruning, reduction); kernel_ms is the pruning kernel alone under stage events"}}
 
 
 def clock_probe(args):

@@ -142,6 +142,46 @@ def nuc_gtr_gamma_problem(n_tips=32, n_patt=1000, alpha=0.5, K=4, seed=20260927,
                    freqK=freqK, rate=rK)
 
 
+def aa_model_tables(seed=20260928):
+    """Exchangeabilities S (symmetric, zero diagonal) and frequencies pi of the synthetic 20-state model, rounded to 8 decimals so that
+    a rate file written with 8 decimals (write_aa_ratefile) gives the reference exactly these numbers."""
+    rng = np.random.default_rng(seed)
+    pi = np.round(rng.dirichlet(np.full(20, 5.0)), 8)
+    pi[-1] = np.round(1 - pi[:-1].sum(), 8)
+    S = np.round(np.triu(rng.gamma(0.8, 1.0, size=(20, 20)) + 0.01, 1), 8)
+    return S + S.T, pi
+
+
+def write_aa_ratefile(path: str, S: np.ndarray, pi: np.ndarray):
+    """An amino-acid rate file in the layout of dat/*.dat (GetDaa codeml.c:3967-4009): the lower triangle of the exchangeabilities row by
+    row, then the 20 frequencies; amino acids in the order ARNDCQEGHILKMFPSTWYV."""
+    with open(path, "w") as f:
+        for i in range(1, 20):
+            f.write(" ".join("%.8f" % S[i, j] for j in range(i)) + "\n")
+        f.write("\n" + " ".join("%.8f" % v for v in pi) + "\n")
+
+
+def aa_gamma_problem(n_tips=32, n_patt=1000, alpha=0.5, K=4, seed=20260928) -> Problem:
+    """C3-shaped problem at scale: codeml seqtype 2, model 2 (an amino-acid rate file) + Gamma_K on a balanced-ish tree; P(t) through
+    U, V, Root as for the empirical amino-acid models (codeml.c:4001-4009).  The exchangeabilities are seeded gamma draws and the
+    frequencies a seeded Dirichlet draw — no empirical matrix is shipped in the package — and the columns are simulated down the tree
+    class by class like the other generators."""
+    tree = balanced_tree(n_tips)
+    S, pi = aa_model_tables(seed)
+    U, V, root = models.aa_empirical_eigen(S, pi)
+    freqK, rK = models.discrete_gamma(alpha, K)
+    rng = np.random.default_rng(seed + 1)
+    cls = rng.integers(0, K, size=n_patt)
+    z = np.zeros((n_tips, n_patt), dtype=np.uint8)
+    for k in range(K):
+        idx = np.nonzero(cls == k)[0]
+        if len(idx):
+            z[:, idx] = simulate_tips(tree, pi, lambda nd: np.clip(models.expm_rev(U, V, root, tree.branch[nd] * rK[k]), 0, None),
+                                      len(idx), seed + 17 * (k + 1))
+    return Problem(n=20, tree=tree, z=z, weights=np.ones(n_patt), pi=pi, eigen=[dict(kind=EIGEN_UVROOT, U=U, V=V, Root=root)],
+                   mode=MODE_LFUNDG, freqK=freqK, rate=rK)
+
+
 def write_pattern_file(path: str, z: np.ndarray, weights: np.ndarray, seqtype: str):
     """The reference's `P` (pre-compressed patterns) sequence format (treesub.c:549, 951-983)."""
     n_tips, n_patt = z.shape

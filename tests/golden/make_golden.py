@@ -217,6 +217,27 @@ def case_syn_nuc(n_patt=5000, name="syn_nuc_gtr_g4", sample=None):
            sample=sample)
 
 
+def case_syn_aa(n_patt=100_000, name="syn_aa_g4_full", sample=97):
+    """The 20-state configuration at scale (C3's model class on 32 taxa x 10^5 patterns): codeml seqtype 2, model 2 with the synthetic rate
+    file, gamma with four classes, alpha fixed at the generating value, branch lengths fixed at the tree file's."""
+    pb = synth.aa_gamma_problem(n_tips=32, n_patt=n_patt)
+    d = tempfile.mkdtemp()
+    synth.write_pattern_file(os.path.join(d, "seq.txt"), pb.z, pb.weights, "aa")
+    S, pi = synth.aa_model_tables()
+    synth.write_aa_ratefile(os.path.join(d, "rand.dat"), S, pi)
+    tree = " 32 1\n" + pb.tree.newick() + "\n"
+    ctl = dict(CODEML_BASE, seqfile="seq.txt", treefile="tree.txt", outfile="mlc", seqtype=2, model=2, aaRatefile="rand.dat",
+               fix_alpha=1, alpha=0.5, ncatG=4, fix_blength=2, cleandata=1)
+    for k in ("CodonFreq", "NSsites", "fix_kappa", "kappa", "fix_omega", "omega", "icode"):
+        ctl.pop(k, None)
+    res = run_ref("codeml", ctl, {"seq.txt": os.path.join(d, "seq.txt"), "tree.txt": tree, "rand.dat": os.path.join(d, "rand.dat")})
+    shutil.rmtree(d)
+    finish(name, res, "aa", 32,
+           dict(program="codeml", model=dict(kind="aa_synth_gamma", alpha=0.5, ncatG=4), x=[],
+                generator=dict(fn="aa_gamma_problem", n_tips=32, n_patt=n_patt, seed=20260928)),
+           sample=sample)
+
+
 def case_brown():
     x = [float(v) for v in "0.053057 0.017471 0.041370 0.053761 0.057580 0.100159 0.138990 9.389630".split()]
     ctl = dict(BASEML_BASE, seqfile="brown.nuc", treefile="brown.trees", outfile="mlb", model=4, ncatG=1)
@@ -712,6 +733,7 @@ CASES = {
     # BASELINE configs[3] / configs[1] at full size (reference: ~2 min and 6.8 GB / ~2 s): lnL + strided log f_h sample
     "syn_codon_m0_full": lambda: case_syn_codon(1_000_000, "syn_codon_m0_full", sample=997),
     "syn_nuc_gtr_g4_full": lambda: case_syn_nuc(100_000, "syn_nuc_gtr_g4_full", sample=97),
+    "syn_aa_g4_full": case_syn_aa, "syn_aa_g4": lambda: case_syn_aa(3000, "syn_aa_g4", sample=None),
     # the NSsites sweep on the C4 data at full size (reference: 3 min ... 20 min each, 7 GB)
     "syn_codon_m1a_full": lambda: case_syn_codon_ns("m1a"), "syn_codon_m2a_full": lambda: case_syn_codon_ns("m2a"),
     "syn_codon_m7_full": lambda: case_syn_codon_ns("m7"), "syn_codon_m8_full": lambda: case_syn_codon_ns("m8"),

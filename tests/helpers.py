@@ -120,6 +120,9 @@ def problem_from_golden(g) -> Problem:
     tree = parse_newick(g["tree"], names=g.get("names"))
     m = g["model"]
     kind = m["kind"]
+    if kind == "aa_synth_gamma":          # the synthetic 20-state model: everything comes from the generator
+        gen = dict(g["generator"])
+        return getattr(synth, gen.pop("fn"))(**gen)
     if kind == "codon_m0":
         kw = {}
         if amb is not None:

@@ -15,7 +15,7 @@ from paml_amd.problem import Tree
 pytestmark = pytest.mark.gpu
 
 GOLDEN = ["hiv_m0", "hiv_m1a", "hiv_m2a", "hiv_m7", "hiv_m8", "syn_codon_m0", "syn_nuc_gtr_g4", "brown_hky85",
-          "stewart_lg_g4", "mhc_m0_scaled"]
+          "stewart_lg_g4", "mhc_m0_scaled", "syn_aa_g4"]
 
 
 def check(pb, lnl_rtol=1e-10, lnf_atol=1e-9, flags=0):
@@ -228,7 +228,7 @@ def test_large_size_properties_20_states():
     assert abs(out2["lnL"] - out["lnL"]) < 1e-9 * abs(out["lnL"])
 
 
-@pytest.mark.parametrize("name", ["syn_nuc_gtr_g4_full", "syn_codon_m0_full"])
+@pytest.mark.parametrize("name", ["syn_nuc_gtr_g4_full", "syn_aa_g4_full", "syn_codon_m0_full"])
 def test_full_size_against_reference(name):
     """BASELINE configs[1] and configs[3] at full size against the reference binary's own numbers for the same seeded
     data (tests/golden/*_full.json: lnL, sum and a strided sample of per-pattern log f_h)."""

@@ -7,7 +7,7 @@ import helpers
 import oracle
 
 CASES = ["hiv_m0", "hiv_m1a", "hiv_m2a", "hiv_m7", "hiv_m8", "syn_codon_m0", "syn_nuc_gtr_g4", "brown_hky85",
-         "stewart_lg_g4", "mhc_m0_scaled",
+         "stewart_lg_g4", "mhc_m0_scaled", "syn_aa_g4",
          # 4000-pattern versions of the north_star sweep's class tables (M2a's and M8's run through NSsites = 3, M7)
          "syn_codon_m2a_as_m3_4000", "syn_codon_m8_as_m3_4000", "syn_codon_m7_4000"]
 
@@ -60,7 +60,7 @@ def test_oracle_branch_derivatives_match_pinned_lnl(n, K, kind):
             assert abs(ddl[i] - (f(t + e) - 2 * f(t) + f(t - e)) / e ** 2) <= 2e-3 * max(1.0, abs(ddl[i]))
 
 
-@pytest.mark.parametrize("name", ["syn_nuc_gtr_g4_full", "syn_codon_m0_full"])
+@pytest.mark.parametrize("name", ["syn_nuc_gtr_g4_full", "syn_aa_g4_full", "syn_codon_m0_full"])
 def test_oracle_matches_reference_full_size(name):
     """BASELINE configs[1] / configs[3] at full size (32 taxa x 1e5 nucleotide, 16 taxa x 1e6 codon patterns): the
     reference binary was run once on the seeded generator's data (make_golden.py); its lnL, the sum and a strided
