@@ -31,6 +31,12 @@ int pamlh_n_trees(const pamlh *p);
 /* "dN & dS for each branch" (DetailOutput codeml.c:1349-1404) under the codon models without site classes: out[n_branches][6] = t, N, S,
  * omega, dN, dS at the parameter vector x; n_branches = n_nodes - 1, in the order of the branch lengths in x (first appearance in the tree file) */
 int pamlh_dnds(pamlh *p, const double *x, double *out);
+/* Comparison of the trees of a tree file from the per-pattern log likelihoods of their analyses (rell treesub.c:5844-6009: the table
+ * "tree li Dli +- SE pKH pSH pRELL" of a run with several trees).  lnf [n_trees][n_patt], w pattern counts, gene_off n_genes + 1 offsets
+ * (NULL: one gene); n_rep = 0: the reference's number of bootstrap replicates; outputs have n_trees entries each (pKH, pSH = -1 for the best
+ * tree, whose index goes to *best).  li, Dli, SE, pKH are deterministic; pSH and pRELL come from seeded resampling. */
+int pamlh_tree_comparison(int n_trees, int n_patt, const double *w, const double *lnf, int n_genes, const int *gene_off, int n_rep,
+                          unsigned long long seed, double *li, double *dli, double *se, double *pkh, double *psh, double *prell, int *best);
 void pamlh_free(pamlh *p);
 const char *pamlh_error(const pamlh *p);
 

@@ -1,6 +1,7 @@
 /* pamlh_lnl — command-line driver: one likelihood evaluation of a codeml/baseml analysis on the MI355X.
  *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [--ancestral] [--gpus N] [--tree K] [x0 x1 ...]
- *   (--tree K: the K-th tree of the tree file, 1-based; the reference walks through all of them, Forestry codeml.c:635)
+ *   (--tree K: the K-th tree of the tree file, 1-based; --all-trees: every tree in turn — the reference's loop, Forestry codeml.c:635 —
+ *    each optimised from the control file's initial values, then the comparison table of rell(), treesub.c:5844)
  * Reads the control file, the sequence and tree files it names, and the parameter vector from the command line,
  * else from in.codeml / in.baseml beside the ctl (the reference's "-1 x..." single-evaluation recipe, treesub.c:4057),
  * else the ctl's initial values; evaluates lnL through libpaml_amd.so; prints `lnL = ...` like the reference and
@@ -55,15 +56,51 @@ int main(int argc, char **argv)
    pamlh *p;
    char err[512];
    double x[4096], lnL, *lnf;
-   int np, ntime, npatt, i, nx = 0, optimize = 0, ancestral = 0, gpus = 0, rank = 0, itree = 0;
+   int np, ntime, npatt, i, nx = 0, optimize = 0, ancestral = 0, gpus = 0, rank = 0, itree = 0, all_trees = 0;
    unsigned char comm_id[PAML_AMD_COMM_ID_BYTES];
-   if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [--ancestral] [--gpus N] [--tree K] [x...]\n", argv[0]); return 2; }
+   if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [--ancestral] [--gpus N] [--tree K | --all-trees] [x...]\n", argv[0]); return 2; }
    for (i = 3; i < argc && nx < 4096; i++) {
       if (!strcmp(argv[i], "--optimize")) optimize = 1;
       else if (!strcmp(argv[i], "--ancestral")) ancestral = 1;
       else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
       else if (!strcmp(argv[i], "--tree") && i + 1 < argc) itree = atoi(argv[++i]) - 1;
+      else if (!strcmp(argv[i], "--all-trees")) all_trees = 1;
       else x[nx++] = atof(argv[i]);
+   }
+   if (all_trees) {      /* every tree of the file: maximum likelihood on each, then the comparison of rell() from the per-pattern values */
+      int nt = 1, t, npt = 0, ng = 1;
+      double *all = NULL, *w = NULL, *res;
+      const int *goff = NULL;
+      for (t = 0; t < nt; t++) {
+         int n_eval = 0;
+         if (pamlh_load_tree(&p, argv[2], argv[1], t, err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
+         pamlh_dims(p, NULL, NULL, &npatt, NULL, NULL, NULL, NULL, NULL, &np, &ntime);
+         if (t == 0) {
+            nt = pamlh_n_trees(p); npt = npatt;
+            all = (double *)malloc((size_t)nt * npt * sizeof(double)); w = (double *)malloc(npt * sizeof(double));
+            memcpy(w, pamlh_weights(p), npt * sizeof(double));
+            ng = pamlh_genes(p, &goff, NULL, NULL, NULL);
+            if (ng > 1) { int *cp = (int *)malloc((ng + 1) * sizeof(int)); memcpy(cp, goff, (ng + 1) * sizeof(int)); goff = cp; } else goff = NULL;
+         }
+         pamlh_default_x(p, x, 4096);
+         if (np > 0 && pamlh_optimize(p, x, &lnL, 500, 1e-10, 0, &n_eval) < 0) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
+         if (pamlh_set_x(p, x, np) || pamlh_eval_gpu(p, &lnL, all + (size_t)t * npt)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
+         printf("TREE # %2d:  lnL(ntime:%3d  np:%3d): %13.6f\n", t + 1, ntime, np, lnL);
+         for (i = 0; i < np; i++) printf(" %.6f", x[i]);
+         printf("\n");
+         pamlh_free(p);
+      }
+      if (nt > 1) {
+         int best = 0;
+         res = (double *)malloc((size_t)6 * nt * sizeof(double));
+         if (pamlh_tree_comparison(nt, npt, w, all, ng, goff, 0, 20260927ULL, res, res + nt, res + 2 * nt, res + 3 * nt, res + 4 * nt, res + 5 * nt, &best)) return 1;
+         printf("\nTree comparisons (Kishino & Hasegawa 1989; Shimodaira & Hasegawa 1999)\n\n%6s %12s %9s %9s%8s%10s%9s\n\n", "tree", "li", "Dli", " +- SE", "pKH", "pSH", "pRELL");
+         for (t = 0; t < nt; t++)
+            printf("%6d%c%12.3f %9.3f %9.3f%8.3f%10.3f%9.3f\n", t + 1, t == best ? '*' : ' ', res[t], res[nt + t], res[2 * nt + t], res[3 * nt + t], res[4 * nt + t], res[5 * nt + t]);
+         free(res);
+      }
+      free(all); free(w);
+      return 0;
    }
    if (gpus > 0 && spawn_ranks(gpus, &rank, comm_id)) { fprintf(stderr, "error: could not start %d ranks (GPUs visible: %d; librccl.so.1 present?)\n", gpus, paml_amd_device_count()); return 1; }
    if (pamlh_load_tree(&p, argv[2], argv[1], itree, err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }

@@ -822,3 +822,89 @@ done:
    free(lo); free(hi); free(h); free(xs); free(ls); free(lf); free(H); free(A); free(Ai); free(freev);
    return rc;
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Comparison of the trees of a tree file from their per-pattern log likelihoods (rell treesub.c:5844-6009): the consumer of
+ * the `lnf` values of several analyses of the same alignment.
+ *   li, Dli = li - l(best), SE of Dli from the sitewise differences, pKH = 1 - Phi(-Dli / SE)   (Kishino & Hasegawa 1989),
+ *   pRELL   = share of the bootstrap replicates (sites resampled within each gene, likelihoods re-weighted, not re-estimated) in
+ *             which the tree is the best (ties shared),
+ *   pSH     = Shimodaira & Hasegawa (1999): replicates centred per tree; share in which max_j l*_j - l*_i exceeds l(best) - l_i.
+ * lnf: [n_trees][n_patt]; w: pattern counts; gene_off: n_genes + 1 pattern offsets (NULL: one gene); n_rep: 0 = the reference's
+ * choice (10 000 below 10^5 sites).  The replicates come from a generator of this file (xoshiro256**, seeded): pRELL and pSH agree
+ * with the reference's to Monte-Carlo accuracy, the other columns digit for digit.  pKH = pSH = -1 for the best tree. */
+static unsigned long long tc_s[4];
+static unsigned long long tc_next(void)
+{
+   const unsigned long long r = ((tc_s[1] * 5) << 7 | (tc_s[1] * 5) >> 57) * 9, t = tc_s[1] << 17;
+   tc_s[2] ^= tc_s[0]; tc_s[3] ^= tc_s[1]; tc_s[1] ^= tc_s[2]; tc_s[0] ^= tc_s[3]; tc_s[2] ^= t;
+   tc_s[3] = tc_s[3] << 45 | tc_s[3] >> 19;
+   return r;
+}
+int pamlh_tree_comparison(int n_trees, int n_patt, const double *w, const double *lnf, int n_genes, const int *gene_off, int n_rep,
+                          unsigned long long seed, double *li, double *dli, double *se, double *pkh, double *psh, double *prell, int *best)
+{
+   int t, h, r, g, k, ml = 0, nbest, one_gene[2];
+   long ls = 0;
+   double *rep, *mx, y;
+   int *sitelist, *cnt, *btrees;
+   if (n_trees < 2 || n_patt < 1 || !w || !lnf || n_genes < 1) return -1;
+   one_gene[0] = 0; one_gene[1] = n_patt;
+   if (!gene_off) { gene_off = one_gene; n_genes = 1; }
+   for (h = 0; h < n_patt; h++) ls += (long)w[h];
+   if (n_rep <= 0) n_rep = ls < 100000 ? 10000 : 50;
+   for (t = 0; t < n_trees; t++) {
+      for (h = 0, li[t] = 0; h < n_patt; h++) li[t] += w[h] * lnf[(size_t)t * n_patt + h];
+      if (t && li[t] > li[ml]) ml = t;
+   }
+   for (t = 0; t < n_trees; t++) {
+      const double mdl = (li[t] - li[ml]) / ls;
+      dli[t] = li[t] - li[ml];
+      for (h = 0, se[t] = 0; h < n_patt; h++) {
+         y = lnf[(size_t)t * n_patt + h] - lnf[(size_t)ml * n_patt + h];
+         se[t] += w[h] * (y - mdl) * (y - mdl);
+      }
+      se[t] = t == ml ? 0 : sqrt(se[t]);
+      pkh[t] = (t == ml || fabs(se[t]) < 1e-6) ? -1 : 1 - pamlh_cdf_normal(-dli[t] / se[t]);
+      prell[t] = psh[t] = 0;
+   }
+   /* bootstrap: sites drawn with replacement inside every gene */
+   {  unsigned long long z = seed + 0x9E3779B97F4A7C15ULL;
+      for (k = 0; k < 4; k++) { unsigned long long v = (z += 0x9E3779B97F4A7C15ULL); v = (v ^ v >> 30) * 0xBF58476D1CE4E5B9ULL; v = (v ^ v >> 27) * 0x94D049BB133111EBULL; tc_s[k] = v ^ v >> 31; } }
+   rep = (double *)calloc((size_t)n_trees * n_rep, sizeof(double));
+   mx = (double *)malloc(n_rep * sizeof(double));
+   sitelist = (int *)malloc((size_t)ls * sizeof(int));
+   cnt = (int *)malloc(n_patt * sizeof(int));
+   btrees = (int *)malloc(n_trees * sizeof(int));
+   for (h = 0, k = 0; h < n_patt; h++) for (r = 0; r < (int)w[h]; r++) sitelist[k++] = h;
+   for (r = 0; r < n_rep; r++) {
+      long s0 = 0;
+      memset(cnt, 0, n_patt * sizeof(int));
+      for (g = 0; g < n_genes; g++) {
+         long lg = 0, j;
+         for (h = gene_off[g]; h < gene_off[g + 1]; h++) lg += (long)w[h];
+         for (j = 0; j < lg; j++) cnt[sitelist[s0 + (long)((tc_next() >> 11) * (1.0 / 9007199254740992.0) * lg)]]++;
+         s0 += lg;
+      }
+      for (h = 0; h < n_patt; h++)
+         if (cnt[h]) for (t = 0; t < n_trees; t++) rep[(size_t)t * n_rep + r] += cnt[h] * lnf[(size_t)t * n_patt + h];
+      for (t = 1, nbest = 1, btrees[0] = 0, y = rep[r]; t < n_trees; t++) {
+         if (fabs(rep[(size_t)t * n_rep + r] - y) < 1e-5) btrees[nbest++] = t;
+         else if (rep[(size_t)t * n_rep + r] > y) { nbest = 1; btrees[0] = t; y = rep[(size_t)t * n_rep + r]; }
+      }
+      for (t = 0; t < nbest; t++) prell[btrees[t]] += 1.0 / ((double)n_rep * nbest);
+   }
+   for (t = 0; t < n_trees; t++) {      /* S-H: centre each tree's replicates */
+      for (r = 0, y = 0; r < n_rep; r++) y += rep[(size_t)t * n_rep + r];
+      for (r = 0, y /= n_rep; r < n_rep; r++) rep[(size_t)t * n_rep + r] -= y;
+   }
+   for (r = 0; r < n_rep; r++) for (t = 1, mx[r] = rep[r]; t < n_trees; t++) if (rep[(size_t)t * n_rep + r] > mx[r]) mx[r] = rep[(size_t)t * n_rep + r];
+   for (t = 0; t < n_trees; t++) {
+      for (r = 0; r < n_rep; r++) if (mx[r] - rep[(size_t)t * n_rep + r] > li[ml] - li[t]) psh[t] += 1.0 / n_rep;
+      if (t == ml || fabs(se[t]) < 1e-6) psh[t] = -1;
+   }
+   if (best) *best = ml;
+   free(rep); free(mx); free(sitelist); free(cnt); free(btrees);
+   return 0;
+}

@@ -68,6 +68,24 @@ def _arr(ptr, dtype, n):
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(n,)).copy()
 
 
+def tree_comparison(lnf, w, gene_off=None, n_rep=0, seed=1):
+    """pamlh_tree_comparison: lnf [n_trees][n_patt], w pattern counts -> dict of li, dli, se, pKH, pSH, pRELL (arrays) and best."""
+    L = lib()
+    lnf = np.ascontiguousarray(lnf, dtype=np.float64)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    nt, npatt = lnf.shape
+    go = np.ascontiguousarray(gene_off, dtype=np.int32) if gene_off is not None else None
+    out = [np.zeros(nt) for _ in range(6)]
+    best = C.c_int()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))      # noqa: E731
+    L.pamlh_tree_comparison.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_void_p, C.c_int, C.c_ulonglong] + [C.POINTER(C.c_double)] * 6 + [C.POINTER(C.c_int)]
+    rc = L.pamlh_tree_comparison(nt, npatt, dp(w), dp(lnf), (len(go) - 1) if go is not None else 1, go.ctypes.data if go is not None else None, n_rep, seed,
+                                 *[dp(a) for a in out], C.byref(best))
+    if rc != 0:
+        raise RuntimeError("pamlh_tree_comparison: bad arguments")
+    return dict(zip(("li", "dli", "se", "pKH", "pSH", "pRELL"), out), best=best.value)
+
+
 class Analysis:
     def __init__(self, ctl_path, program="codeml", tree_index=0):
         L = lib()

@@ -238,6 +238,35 @@ def case_syn_aa(n_patt=100_000, name="syn_aa_g4_full", sample=97):
            sample=sample)
 
 
+def case_tree_comparison():
+    """Two trees in one tree file (examples/stewart.trees with its header corrected to "6 2"), LG + G4 with alpha estimated on each: the
+    reference evaluates both, writes both sets of per-pattern log f_h to `lnf` and prints the comparison table of rell()."""
+    trees = open(EX + "/stewart.trees").read().replace("6  1", "6  2", 1)
+    ctl = dict(CODEML_BASE, seqfile="stewart.aa", treefile="two.trees", outfile="mlc", seqtype=2, model=2, aaRatefile="lg.dat",
+               fix_alpha=0, alpha=0.5, ncatG=4, cleandata=0)
+    res = run_ref("codeml", ctl, {"stewart.aa": EX + "/stewart.aa", "two.trees": trees, "lg.dat": DAT + "/lg.dat"})
+    hdr = [int(v) for v in [ln for ln in res["lnf"] if ln.split()][0].split()]
+    blocks, cur = [], None
+    for ln in res["lnf"][1:]:
+        t = ln.split()
+        if len(t) == 1 and t[0].isdigit():
+            cur = []
+            blocks.append(cur)
+        elif len(t) >= 6 and cur is not None:
+            cur.append((float(t[1]), float(t[2])))
+    assert len(blocks) == 2 and all(len(b) == hdr[2] for b in blocks), (hdr, [len(b) for b in blocks])
+    tab = re.findall(r"^\s*(\d+)(\*?)\s+(-?[0-9.]+)\s+(-?[0-9.]+)\s+(-?[0-9.]+)\s+(-?[0-9.]+)\s+(-?[0-9.]+)\s+(-?[0-9.]+)\s*$",
+                     res["main"][res["main"].index("Tree comparisons"):], re.M)
+    g = dict(name="stewart_two_trees", program="codeml", ls=hdr[1], n_patt=hdr[2], lnL=float(tab[0][2]),
+             counts=[c for c, _ in blocks[0]], logf=[[v for _, v in b] for b in blocks],
+             table=[dict(tree=int(r[0]), best=bool(r[1]), li=float(r[2]), dli=float(r[3]), se=float(r[4]), pKH=float(r[5]), pSH=float(r[6]), pRELL=float(r[7])) for r in tab],
+             n_rep=int(re.search(r"Number of replicates: (\d+)", res["main"]).group(1)),
+             mle_lnL=[float(v) for v in re.findall(r"lnL\(ntime:[^)]*\):\s*(-?[0-9.]+)", res["main"])])
+    with open(os.path.join(HERE, g["name"] + ".json"), "w") as f:
+        json.dump(g, f, separators=(",", ":"))
+    print("   stewart_two_trees:", g["table"])
+
+
 def case_brown():
     x = [float(v) for v in "0.053057 0.017471 0.041370 0.053761 0.057580 0.100159 0.138990 9.389630".split()]
     ctl = dict(BASEML_BASE, seqfile="brown.nuc", treefile="brown.trees", outfile="mlb", model=4, ncatG=1)
@@ -733,6 +762,7 @@ CASES = {
     # BASELINE configs[3] / configs[1] at full size (reference: ~2 min and 6.8 GB / ~2 s): lnL + strided log f_h sample
     "syn_codon_m0_full": lambda: case_syn_codon(1_000_000, "syn_codon_m0_full", sample=997),
     "syn_nuc_gtr_g4_full": lambda: case_syn_nuc(100_000, "syn_nuc_gtr_g4_full", sample=97),
+    "stewart_two_trees": case_tree_comparison,
     "syn_aa_g4_full": case_syn_aa, "syn_aa_g4": lambda: case_syn_aa(3000, "syn_aa_g4", sample=None),
     # the NSsites sweep on the C4 data at full size (reference: 3 min ... 20 min each, 7 GB)
     "syn_codon_m1a_full": lambda: case_syn_codon_ns("m1a"), "syn_codon_m2a_full": lambda: case_syn_codon_ns("m2a"),

@@ -245,6 +245,25 @@ def test_c_host_shards_an_alignment_with_several_genes_on_cpu():
         assert distributed.total_fixed_order(tot) == ref
 
 
+def test_tree_comparison_matches_the_reference_table():
+    """rell() (treesub.c:5844-6009) restated as pamlh_tree_comparison: fed with the per-pattern log f_h the reference wrote to `lnf` for the
+    two trees of stewart.trees (LG + G4, parameters estimated on each), it gives the reference's table — li, Dli, SE and the
+    Kishino-Hasegawa P value to the printed digits; the bootstrap columns (10 000 replicates from another generator) to Monte-Carlo accuracy."""
+    g = helpers.load_golden("stewart_two_trees")
+    r = hostlib.tree_comparison(np.array(g["logf"]), np.array(g["counts"]), seed=7)
+    assert r["best"] == 1
+    for t, row in enumerate(g["table"]):
+        assert abs(r["li"][t] - row["li"]) < 6e-4 and abs(r["dli"][t] - row["dli"]) < 6e-4 and abs(r["se"][t] - row["se"]) < 6e-4
+        assert abs(r["pKH"][t] - row["pKH"]) < 6e-4
+        assert abs(r["pSH"][t] - row["pSH"]) < 0.012 and abs(r["pRELL"][t] - row["pRELL"]) < 0.012      # 3 sigma of 10 000 draws at p = 0.08
+    assert abs(r["pRELL"].sum() - 1) < 1e-9
+    r2 = hostlib.tree_comparison(np.array(g["logf"]), np.array(g["counts"]), seed=7)
+    assert np.array_equal(r2["pRELL"], r["pRELL"]) and np.array_equal(r2["pSH"], r["pSH"])      # seeded
+    # stratified resampling: with the patterns cut into two "genes" the deterministic columns do not move
+    r3 = hostlib.tree_comparison(np.array(g["logf"]), np.array(g["counts"]), gene_off=[0, 40, len(g["counts"])], seed=7)
+    assert np.array_equal(r3["se"], r["se"]) and abs(r3["pRELL"][0] - r["pRELL"][0]) < 0.02
+
+
 def test_c_host_rejects_what_it_does_not_support(tmp_path):
     ctl = tmp_path / "x.ctl"
     ctl.write_text("seqfile = %s\ntreefile = %s\nseqtype = 1\nmodel = 1\nNSsites = 2\n" %
@@ -604,6 +623,28 @@ def test_c_host_plfun_seam():
     x[a.ntime + 1] = 0.9          # p0 + p1 > 1
     assert a.plfun(x) == 1e300
     assert a.plfun(x[:-1]) == 1e300
+
+
+@pytest.mark.gpu
+def test_driver_all_trees_and_their_comparison(tmp_path):
+    """`pamlh_lnl codeml <ctl> --all-trees`: both trees of stewart.trees (header corrected to two) maximised from the control file's
+    initial values — the reference's -1038.351723 and -1028.130…  — and the comparison table of rell() computed from the per-pattern
+    values the engine returned: li, Dli, SE, pKH as the reference printed them (golden stewart_two_trees)."""
+    g = helpers.load_golden("stewart_two_trees")
+    data = os.path.join(helpers.GOLDEN, "data")
+    (tmp_path / "two.trees").write_text(open(os.path.join(data, "stewart.trees")).read().replace("6  1", "6  2", 1))
+    ctl = open(os.path.join(CTL, "stewart_lg_g4.ctl")).read().replace("../data/stewart.aa", os.path.join(data, "stewart.aa"))
+    ctl = ctl.replace("../data/lg.dat", os.path.join(data, "lg.dat")).replace("../data/stewart.trees", str(tmp_path / "two.trees"))
+    (tmp_path / "two.ctl").write_text(ctl)
+    out = subprocess.run([hostlib.DRIVER_PATH, "codeml", str(tmp_path / "two.ctl"), "--all-trees"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    lnls = [float(v) for v in re.findall(r"TREE #\s*\d+:\s+lnL\([^)]*\):\s*(-?[0-9.]+)", out.stdout)]
+    assert len(lnls) == 2 and all(abs(a - b) < 5e-5 for a, b in zip(lnls, g["mle_lnL"])), (lnls, g["mle_lnL"])
+    rows = re.findall(r"^\s*(\d+)(\*?)\s+(-?[0-9.]+)\s+(-?[0-9.]+)\s+(-?[0-9.]+)\s+(-?[0-9.]+)\s+(-?[0-9.]+)\s+(-?[0-9.]+)\s*$", out.stdout, re.M)
+    assert len(rows) == 2 and rows[1][1] == "*"
+    for r, ref in zip(rows, g["table"]):
+        assert abs(float(r[2]) - ref["li"]) < 2e-3 and abs(float(r[3]) - ref["dli"]) < 2e-3 and abs(float(r[4]) - ref["se"]) < 2e-3
+        assert abs(float(r[5]) - ref["pKH"]) < 2e-3 and abs(float(r[7]) - ref["pRELL"]) < 0.012
 
 
 @pytest.mark.gpu
