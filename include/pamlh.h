@@ -28,6 +28,11 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
  * other (Forestry codeml.c:635, baseml.c:451) — and the number of trees the file holds */
 int pamlh_load_tree(pamlh **out, const char *ctl_path, const char *program, int tree_index, char *err, int errcap);
 int pamlh_n_trees(const pamlh *p);
+/* ... and with control-file options replaced or added: overrides = "key = value" lines separated by newlines or ';' (NULL: none).  A
+ * control file that lists several site models ("NSsites = 0 1 2 7 8": the reference runs them in turn, the insmodel loop codeml.c:657-906) is one analysis
+ * per model here: overrides = "NSsites = 2".  pamlh_ctl_option returns an option's text as the control file (or an override) gave it. */
+int pamlh_load_with(pamlh **out, const char *ctl_path, const char *program, int tree_index, const char *overrides, char *err, int errcap);
+const char *pamlh_ctl_option(const pamlh *p, const char *key);
 /* "dN & dS for each branch" (DetailOutput codeml.c:1349-1404) under the codon models without site classes: out[n_branches][6] = t, N, S,
  * omega, dN, dS at the parameter vector x; n_branches = n_nodes - 1, in the order of the branch lengths in x (first appearance in the tree file) */
 int pamlh_dnds(pamlh *p, const double *x, double *out);

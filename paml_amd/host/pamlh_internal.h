@@ -118,6 +118,7 @@ double pamlh_quantile_beta(double prob, double p, double q);
 /* io (pamlh_io.c) */
 int pamlh_read_ctl(pamlh *p, const char *path);
 const char *pamlh_opt(const pamlh *p, const char *key);
+int pamlh_ctl_override(pamlh *p, const char *text);
 double pamlh_optd(const pamlh *p, const char *key, double dflt);
 int pamlh_read_seqs(pamlh *p);
 int pamlh_read_tree(pamlh *p);

@@ -58,6 +58,33 @@ int pamlh_read_ctl(pamlh *p, const char *path)
    return 0;
 }
 
+/* "key = value" lines (newline or ';' between them) replace the control file's options of the same name, or are added */
+int pamlh_ctl_override(pamlh *p, const char *text)
+{
+   const char *c = text;
+   while (*c) {
+      char line[1200], *eq, *k, *v, *e;
+      size_t n = strcspn(c, "\n;");
+      int i;
+      if (n >= sizeof(line)) return pamlh_fail(p, "option override too long");
+      memcpy(line, c, n); line[n] = 0;
+      c += n + (c[n] != 0);
+      eq = strchr(line, '=');
+      if (!eq) { for (k = line; isspace((unsigned char)*k); k++) {} if (*k) return pamlh_fail(p, "option override without '=': %s", line); continue; }
+      *eq = 0;
+      for (k = line; isspace((unsigned char)*k); k++) {}
+      for (e = k + strlen(k); e > k && isspace((unsigned char)e[-1]);) *--e = 0;
+      for (v = eq + 1; isspace((unsigned char)*v); v++) {}
+      for (e = v + strlen(v); e > v && isspace((unsigned char)e[-1]);) *--e = 0;
+      if (!*k) return pamlh_fail(p, "option override without a name");
+      for (i = 0; i < p->ctl.n; i++) if (strncmp(p->ctl.key[i], k, 8) == 0) break;
+      if (i == p->ctl.n) { if (p->ctl.n >= PAMLH_MAXOPT) return pamlh_fail(p, "too many options"); p->ctl.n++; }
+      snprintf(p->ctl.key[i], 32, "%s", k);
+      snprintf(p->ctl.val[i], 1024, "%s", v);
+   }
+   return 0;
+}
+
 const char *pamlh_opt(const pamlh *p, const char *key)
 {
    int i;

@@ -1,6 +1,7 @@
 /* pamlh_lnl — command-line driver: one likelihood evaluation of a codeml/baseml analysis on the MI355X.
  *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [--ancestral] [--gpus N] [--tree K] [x0 x1 ...]
- *   (--tree K: the K-th tree of the tree file, 1-based; --all-trees: every tree in turn — the reference's loop, Forestry codeml.c:635 —
+ *   (--set "key = value": replaces an option of the control file, e.g. one of the site models of an "NSsites = 0 1 2 7 8" list;
+ *    --tree K: the K-th tree of the tree file, 1-based; --all-trees: every tree in turn — the reference's loop, Forestry codeml.c:635 —
  *    each optimised from the control file's initial values, then the comparison table of rell(), treesub.c:5844)
  * Reads the control file, the sequence and tree files it names, and the parameter vector from the command line,
  * else from in.codeml / in.baseml beside the ctl (the reference's "-1 x..." single-evaluation recipe, treesub.c:4057),
@@ -57,14 +58,19 @@ int main(int argc, char **argv)
    char err[512];
    double x[4096], lnL, *lnf;
    int np, ntime, npatt, i, nx = 0, optimize = 0, ancestral = 0, gpus = 0, rank = 0, itree = 0, all_trees = 0;
+   char over[2048] = "";
    unsigned char comm_id[PAML_AMD_COMM_ID_BYTES];
-   if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [--ancestral] [--gpus N] [--tree K | --all-trees] [x...]\n", argv[0]); return 2; }
+   if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [--ancestral] [--gpus N] [--tree K | --all-trees] [--set 'key = value'] [x...]\n", argv[0]); return 2; }
    for (i = 3; i < argc && nx < 4096; i++) {
       if (!strcmp(argv[i], "--optimize")) optimize = 1;
       else if (!strcmp(argv[i], "--ancestral")) ancestral = 1;
       else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
       else if (!strcmp(argv[i], "--tree") && i + 1 < argc) itree = atoi(argv[++i]) - 1;
       else if (!strcmp(argv[i], "--all-trees")) all_trees = 1;
+      else if (!strcmp(argv[i], "--set") && i + 1 < argc) {      /* --set "NSsites = 2": replaces the control file's option */
+         if (strlen(over) + strlen(argv[i + 1]) + 2 >= sizeof(over)) { fprintf(stderr, "error: too many --set options\n"); return 2; }
+         strcat(over, argv[++i]); strcat(over, "\n");
+      }
       else x[nx++] = atof(argv[i]);
    }
    if (all_trees) {      /* every tree of the file: maximum likelihood on each, then the comparison of rell() from the per-pattern values */
@@ -73,7 +79,7 @@ int main(int argc, char **argv)
       const int *goff = NULL;
       for (t = 0; t < nt; t++) {
          int n_eval = 0;
-         if (pamlh_load_tree(&p, argv[2], argv[1], t, err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
+         if (pamlh_load_with(&p, argv[2], argv[1], t, over, err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
          pamlh_dims(p, NULL, NULL, &npatt, NULL, NULL, NULL, NULL, NULL, &np, &ntime);
          if (t == 0) {
             nt = pamlh_n_trees(p); npt = npatt;
@@ -103,7 +109,7 @@ int main(int argc, char **argv)
       return 0;
    }
    if (gpus > 0 && spawn_ranks(gpus, &rank, comm_id)) { fprintf(stderr, "error: could not start %d ranks (GPUs visible: %d; librccl.so.1 present?)\n", gpus, paml_amd_device_count()); return 1; }
-   if (pamlh_load_tree(&p, argv[2], argv[1], itree, err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
+   if (pamlh_load_with(&p, argv[2], argv[1], itree, over, err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
    if (gpus > 0 && pamlh_set_shard(p, rank, gpus, comm_id)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
    pamlh_dims(p, NULL, NULL, &npatt, NULL, NULL, NULL, NULL, NULL, &np, &ntime);
    if (gpus > 0 && (ancestral || pamlh_mgene(p) == 1)) { fprintf(stderr, "error: --gpus gives lnL and estimates; per-site outputs and Mgene = 1 need the whole alignment on one GPU\n"); return 1; }

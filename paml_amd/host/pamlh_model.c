@@ -284,6 +284,14 @@ int pamlh_load(pamlh **out, const char *ctl_path, const char *program, char *err
  * the loop over trees in Forestry codeml.c:635 / baseml.c:451); here every tree is an analysis of its own */
 int pamlh_load_tree(pamlh **out, const char *ctl_path, const char *program, int tree_index, char *err, int errcap)
 {
+   return pamlh_load_with(out, ctl_path, program, tree_index, NULL, err, errcap);
+}
+
+/* ... and with control-file options replaced or added: `overrides` holds "key = value" lines (separated by newlines or ';').  A control
+ * file that lists several site models ("NSsites = 0 1 2 7 8": the reference runs them one after the other, the insmodel loop codeml.c:657-906) is run here one
+ * model per analysis: overrides = "NSsites = 2". */
+int pamlh_load_with(pamlh **out, const char *ctl_path, const char *program, int tree_index, const char *overrides, char *err, int errcap)
+{
    pamlh *p = (pamlh *)calloc(1, sizeof(pamlh));
    const char *v, *slash;
    int rc = 0;
@@ -294,6 +302,7 @@ int pamlh_load_tree(pamlh **out, const char *ctl_path, const char *program, int 
    if (slash) { size_t n = (size_t)(slash - ctl_path); memcpy(p->dir, ctl_path, n); p->dir[n] = 0; }
    else strcpy(p->dir, ".");
    if ((rc = pamlh_read_ctl(p, ctl_path))) goto bad;
+   if (overrides && (rc = pamlh_ctl_override(p, overrides))) goto bad;
    if (!(v = pamlh_opt(p, "seqfile"))) { rc = pamlh_fail(p, "no seqfile in the control file"); goto bad; }
    resolve(p, v, p->seqfile, sizeof(p->seqfile));
    if (!(v = pamlh_opt(p, "treefile"))) { rc = pamlh_fail(p, "no treefile in the control file"); goto bad; }
@@ -1656,6 +1665,7 @@ int pamlh_model_feasible(const pamlh *p)
 
 /* `method` of the control file (0: all parameters at once, 1: one branch at a time) */
 int pamlh_n_trees(const pamlh *p) { return p->ntrees; }
+const char *pamlh_ctl_option(const pamlh *p, const char *key) { return pamlh_opt(p, key); }
 int pamlh_method(const pamlh *p) { return (int)pamlh_optd(p, "method", 0); }
 
 /* the engine behind this analysis (NULL before the first evaluation): counters, profiling */

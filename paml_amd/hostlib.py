@@ -46,6 +46,9 @@ def lib():
         L.pamlh_load.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.pamlh_load_tree.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
         L.pamlh_n_trees.argtypes = [C.c_void_p]
+        L.pamlh_load_with.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+        L.pamlh_ctl_option.argtypes = [C.c_void_p, C.c_char_p]
+        L.pamlh_ctl_option.restype = C.c_char_p
         L.pamlh_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.pamlh_dnds.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.pamlh_free.argtypes = [C.c_void_p]
@@ -87,11 +90,11 @@ def tree_comparison(lnf, w, gene_off=None, n_rep=0, seed=1):
 
 
 class Analysis:
-    def __init__(self, ctl_path, program="codeml", tree_index=0):
+    def __init__(self, ctl_path, program="codeml", tree_index=0, overrides=None):
         L = lib()
         h = C.c_void_p()
         err = C.create_string_buffer(512)
-        if L.pamlh_load_tree(C.byref(h), os.fsencode(ctl_path), program.encode(), tree_index, err, 512) != 0:
+        if L.pamlh_load_with(C.byref(h), os.fsencode(ctl_path), program.encode(), tree_index, overrides.encode() if overrides else None, err, 512) != 0:
             raise RuntimeError("pamlh_load: " + err.value.decode())
         self._h, self._L = h, L
         d = [C.c_int() for _ in range(10)]
@@ -116,6 +119,10 @@ class Analysis:
         d = [C.c_int() for _ in range(10)]
         self._L.pamlh_dims(self._h, *[C.byref(v) for v in d])
         self.n_patt = d[2].value
+
+    def ctl_option(self, key):
+        v = self._L.pamlh_ctl_option(self._h, key.encode())
+        return v.decode() if v is not None else None
 
     def n_trees(self):
         return self._L.pamlh_n_trees(self._h)

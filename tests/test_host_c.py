@@ -264,6 +264,23 @@ def test_tree_comparison_matches_the_reference_table():
     assert np.array_equal(r3["se"], r["se"]) and abs(r3["pRELL"][0] - r["pRELL"][0]) < 0.02
 
 
+def test_c_host_control_file_overrides_pick_a_model_of_a_list(tmp_path):
+    """A control file listing several site models ("NSsites = 0 1 2 7 8", examples/HIVNSsites/codeml.ctl — the reference runs them in turn)
+    loads as its first model; pamlh_load_with replaces options, so every model of the list is one analysis: the same problem as the
+    single-model control files of the goldens."""
+    ctl = open(os.path.join(CTL, "hiv_ns0.ctl")).read().replace("NSsites = 0", "NSsites = 0 1 2 7 8").replace("../data/", os.path.join(helpers.GOLDEN, "data") + "/")
+    (tmp_path / "list.ctl").write_text(ctl)
+    a = hostlib.Analysis(str(tmp_path / "list.ctl"), "codeml")
+    assert a.ctl_option("NSsites") == "0 1 2 7 8" and a.np == helpers.load_golden("hiv_m0")["x"].__len__()
+    for ns, gname in ((1, "hiv_m1a"), (2, "hiv_m2a"), (8, "hiv_m8")):
+        g = helpers.load_golden(gname)
+        b = hostlib.Analysis(str(tmp_path / "list.ctl"), "codeml", overrides="NSsites = %d; ncatG = 10" % ns)
+        assert b.np == len(g["x"]) and b.ctl_option("NSsites") == str(ns)
+        assert abs(oracle.evaluate(b.problem(np.array(g["x"])))["lnL"] - g["lnL"]) <= 2e-6
+    with pytest.raises(RuntimeError, match="without '='"):
+        hostlib.Analysis(str(tmp_path / "list.ctl"), "codeml", overrides="NSsites 2")
+
+
 def test_c_host_rejects_what_it_does_not_support(tmp_path):
     ctl = tmp_path / "x.ctl"
     ctl.write_text("seqfile = %s\ntreefile = %s\nseqtype = 1\nmodel = 1\nNSsites = 2\n" %
