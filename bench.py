@@ -91,6 +91,12 @@ def main():
     if args.clock_probe:
         return clock_probe(args)
 
+    # ONE JSON line on stdout: libraries underneath print there too (RCCL's version banner comes out of C stdio when the process ends, after
+    # the line), so file descriptor 1 is pointed at stderr for the duration and the line is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -269,7 +275,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(pbc, args.cpu_sample)
         out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
