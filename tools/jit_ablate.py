@@ -17,10 +17,12 @@ pb = synth.codon_m0_problem(n_tips=16, n_patt=n_patt)
 if K > 1:
     import numpy as np
     pb = synth.codon_nssites_problem(pb, 2.0, np.linspace(0.05, 1.5, K), np.full(K, 1.0 / K))
+if os.environ.get("ABL_CONST_TIPS"):      # every pattern the same column: the tip-row gathers become broadcasts (no LDS bank conflicts)
+    pb.z[:] = pb.z[:, :1]
 eng = engine.engine_for(pb)
 d = torch.zeros(64, dtype=torch.float64, device="cuda")
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
-for i in range(3):
+for i in range(10):
     eng.eval_device(pb.tree.branch, d.data_ptr())
 torch.cuda.synchronize()
 eng.profile(True)
