@@ -1064,7 +1064,13 @@ def test_host_bivariate_normal_and_autod_gamma_numerics():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ctl,prog,seed", [("hiv_ns2.ctl", "codeml", 1), ("hiv_ns8.ctl", "codeml", 2), ("lyso_bsa.ctl", "codeml", 3),
-                                           ("horai_mg4.ctl", "baseml", 4), ("brown_hky85_g4.ctl", "baseml", 5)])
+                                           ("horai_mg4.ctl", "baseml", 4), ("brown_hky85_g4.ctl", "baseml", 5),
+                                           # the model options of round 2: free-ratio and fixed-omega branch models, other genetic codes, AAClasses per
+                                           # branch label, the mutation-selection model, omega from amino-acid distances, gamma shapes per gene,
+                                           # frequency sets per branch, site classes on the 192-taxon tree with scaling nodes
+                                           ("lysos_free.ctl", "codeml", 6), ("lysos_branch_fix.ctl", "codeml", 7), ("hiv_ns0_icode5.ctl", "codeml", 8),
+                                           ("mtcdna_aaclass_branch.ctl", "codeml", 9), ("hiv_fmutsel.ctl", "codeml", 10), ("mtcdnapri_aadist1.ctl", "codeml", 11),
+                                           ("horai_mg4_malpha.ctl", "baseml", 12), ("brown_hky85_nhomo3.ctl", "baseml", 13), ("mhc_ns2.ctl", "codeml", 14)])
 def test_differential_against_the_reference_binary_at_random_parameters(ctl, prog, seed, tmp_path):
     """Beyond the committed vectors: the unmodified reference binary (oracle/_ref, when it travelled with the repository) and the
     engine evaluate the same control file at a RANDOM parameter vector inside the bounds; lnL must agree to the printed digits."""
@@ -1080,6 +1086,10 @@ def test_differential_against_the_reference_binary_at_random_parameters(ctl, pro
     text = open(os.path.join(CTL, ctl)).read()
     for name in re.findall(r"\.\./data/(\S+)", text):
         shutil.copy(os.path.join(helpers.GOLDEN, "data", name), tmp_path / name)
+    for name in ("OmegaAA.dat", "grantham.dat", "miyata.dat"):      # read by fixed names from the working directory (aaDist models)
+        for d in (CTL, os.path.join(helpers.GOLDEN, "data")):
+            if os.path.exists(os.path.join(d, name)):
+                shutil.copy(os.path.join(d, name), tmp_path / name)
     main = "mlc" if prog == "codeml" else "mlb"
     (tmp_path / (prog + ".ctl")).write_text(text.replace("../data/", "") + "\noutfile = %s\nnoisy = 0\nverbose = 0\nrunmode = 0\ngetSE = 0\nRateAncestor = 0\n" % main)
     (tmp_path / ("in." + prog)).write_text("-1 " + " ".join("%.6f" % v for v in x) + "\n")
