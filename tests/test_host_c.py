@@ -1072,6 +1072,17 @@ def test_host_bivariate_normal_and_autod_gamma_numerics():
                                            ("mtcdna_aaclass_branch.ctl", "codeml", 9), ("hiv_fmutsel.ctl", "codeml", 10), ("mtcdnapri_aadist1.ctl", "codeml", 11),
                                            ("horai_mg4_malpha.ctl", "baseml", 12), ("brown_hky85_nhomo3.ctl", "baseml", 13), ("mhc_ns2.ctl", "codeml", 14)])
 def test_differential_against_the_reference_binary_at_random_parameters(ctl, prog, seed, tmp_path):
+    _differential(ctl, prog, seed, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname,prog,ctl", [c for c in CASES if "clock" not in c[2] and "tipdate" not in c[2]])
+def test_differential_over_every_golden_control_file(gname, prog, ctl, tmp_path):
+    """... and the same for every control file of the golden cases (the clock models aside: their parameters are ordered ages)."""
+    _differential(ctl, prog, 100 + sum(map(ord, ctl)), tmp_path)
+
+
+def _differential(ctl, prog, seed, tmp_path):
     """Beyond the committed vectors: the unmodified reference binary (oracle/_ref, when it travelled with the repository) and the
     engine evaluate the same control file at a RANDOM parameter vector inside the bounds; lnL must agree to the printed digits."""
     import shutil
@@ -1098,4 +1109,7 @@ def test_differential_against_the_reference_binary_at_random_parameters(ctl, pro
     assert m, r.stdout[-2000:]
     ref = float(m[-1])
     got, _ = a.eval_gpu(x, want_lnf=False)
-    assert abs(got - ref) <= 2e-6 * max(1.0, abs(ref) / 1000), (got, ref)
+    # M9 - M13: the reference inverts the mixture's CDF by a line search on (CDF - p)^2 that starts from the previous call's classes and stops
+    # at ~1e-5 in omega (DiscreteNSsites codeml.c:2862-2935); its lnL moves by a few 1e-3 with the starting point (see the hiv_m11 golden's note)
+    tol = 5e-3 if re.search(r"hiv_ns(9|1[0-3])\.ctl", ctl) else 2e-6 * max(1.0, abs(ref) / 1000)
+    assert abs(got - ref) <= tol, (got, ref)
