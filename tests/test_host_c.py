@@ -1110,6 +1110,6 @@ def _differential(ctl, prog, seed, tmp_path):
     ref = float(m[-1])
     got, _ = a.eval_gpu(x, want_lnf=False)
     # M9 - M13: the reference inverts the mixture's CDF by a line search on (CDF - p)^2 that starts from the previous call's classes and stops
-    # at ~1e-5 in omega (DiscreteNSsites codeml.c:2862-2935); its lnL moves by a few 1e-3 with the starting point (see the hiv_m11 golden's note)
+    # at ~1e-5 in omega (Quantile(CDFdN_dS, ...) in DiscreteNSsites, codeml.c:2877); its lnL moves by a few 1e-3 with the starting point (see the hiv_m11 golden's note)
     tol = 5e-3 if re.search(r"hiv_ns(9|1[0-3])\.ctl", ctl) else 2e-6 * max(1.0, abs(ref) / 1000)
     assert abs(got - ref) <= tol, (got, ref)
