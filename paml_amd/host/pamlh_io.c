@@ -497,7 +497,8 @@ int pamlh_read_tree(pamlh *p)
    char *buf, *s;
    long len;
    int ns = p->ns, nn = 0, i, depth = 0, cur = -1, nb = 0, maxn = 2 * p->ns;
-   int *stack, *father, *nson, *sonbuf, last = -1;
+   int *stack, *father, *nson, *sonbuf, last = -1, *label2, any_clade = 0;
+   unsigned char *labelled;
    if (!f) return pamlh_fail(p, "cannot open tree file %s", p->treefile);
    fseek(f, 0, SEEK_END); len = ftell(f); fseek(f, 0, SEEK_SET);
    buf = (char *)malloc(len + 1);
@@ -524,7 +525,8 @@ int pamlh_read_tree(pamlh *p)
    p->label = (int *)calloc(maxn, sizeof(int));
    p->tree_branch = (double *)malloc(maxn * sizeof(double));
    p->branch_node = (int *)malloc(maxn * sizeof(int));
-   for (i = 0; i < maxn; i++) { father[i] = -1; p->tree_branch[i] = -1; }
+   label2 = (int *)malloc(maxn * sizeof(int)); labelled = (unsigned char *)calloc(maxn, 1);
+   for (i = 0; i < maxn; i++) { father[i] = -1; p->tree_branch[i] = -1; label2[i] = -1; }
    nn = ns;
    for (; *s && *s != ';'; ) {
       if (isspace((unsigned char)*s)) { s++; continue; }
@@ -540,7 +542,12 @@ int pamlh_read_tree(pamlh *p)
       else if (*s == ',') { s++; last = -1; }
       else if (*s == ')') { last = stack[--depth]; s++; }
       else if (*s == ':' ) { char *e; double v = strtod(s + 1, &e); if (last >= 0) p->tree_branch[last] = v; s = e; }
-      else if (*s == '#' || *s == '$') { char *e; double v = strtod(s + 1, &e); if (last >= 0 && *s == '#') p->label[last] = (int)v; s = e; }
+      else if (*s == '#' || *s == '$') {      /* '#k': the label of this branch; '$k': of every branch of the clade without a label of its own */
+         char *e; double v = strtod(s + 1, &e);
+         if (last >= 0 && *s == '#') { p->label[last] = (int)v; labelled[last] = 1; }
+         else if (last >= 0) { label2[last] = (int)v; any_clade = 1; }
+         s = e;
+      }
       else if (*s == '[') { while (*s && *s != ']') s++; if (*s) s++; }
       else if (last >= 0 && cur != last && (isalnum((unsigned char)*s) || *s == '_' || *s == '.') && s[-1] == ')') {
          while (*s && !strchr(",():;#$[ \t\r\n", *s)) s++;    /* internal node name / support value: ignored */
@@ -575,6 +582,19 @@ int pamlh_read_tree(pamlh *p)
    for (i = 0; i < nb; i++) { int c = p->branch_node[i], fa = father[c]; sonbuf[p->sons_ptr[fa] + nson[fa]++] = c; }   /* appearance order = sons[] order */
    p->sons = sonbuf;
    p->father = father;
+   if (any_clade) {      /* clade labels (DownTreeCladeLabel treesub.c:2960-2976): walking down from the root with label 0, a '$k' node switches the
+                          * current label to k for its whole clade; every branch without a '#' of its own takes the current label */
+      int sp = 0, *cur = (int *)malloc(nn * sizeof(int));
+      stack[sp] = p->root; cur[sp++] = 0;
+      while (sp) {
+         const int x = stack[--sp], lab = label2[x] != -1 ? label2[x] : cur[sp];
+         int j;
+         if (x != p->root && !labelled[x]) p->label[x] = lab;
+         for (j = p->sons_ptr[x]; j < p->sons_ptr[x + 1]; j++) { stack[sp] = p->sons[j]; cur[sp++] = lab; }
+      }
+      free(cur);
+   }
+   free(label2); free(labelled);
    /* SetNodeScale (treesub.c:7177-7197) */
    {
       const int every = p->is_codeml ? (p->seqtype == 1 ? 15 : 50) : 100;

@@ -720,6 +720,9 @@ CASES = {
     "hiv2_tipdate_ymd": lambda: case_mle("hiv2_tipdate_ymd", dict(seqfile="HIV2ge.ymd.txt", treefile="HIV2ge.ymd.tree", model=4, clock=1, TipDate="1 36500", kappa=2, fix_alpha=0, alpha=0.5, ncatG=5, cleandata=0),
                                          {"HIV2ge.ymd.txt": ymd_names(open(EX + "/TipDate.HIV2/HIV2ge.txt").read()), "HIV2ge.ymd.tree": ymd_names(open(os.path.join(HERE, "data", "HIV2ge.tree1")).read())},
                                          33, "nuc_tipdate", prog="baseml", seqtype="nuc"),
+    # clade labels: '$k' labels every branch of a clade that has no '#' of its own (nested: the inner label wins)
+    "lysos_clade_label": lambda: case_mle("lysos_clade_label", dict(seqfile="lysozymeSmall.txt", treefile="lysozymeSmall.clade.trees", model=2, NSsites=0, kappa=2, omega=.4, cleandata=0),
+                                          {"lysozymeSmall.txt": EX + "/lysozyme/lysozymeSmall.txt", "lysozymeSmall.clade.trees": os.path.join(HERE, "data", "lysozymeSmall.clade.trees")}, 7, "codon_branch"),
     "brown_hky85_clock": case_brown_clock,
     "hiv_m0_f3x4mg": lambda: case_mle("hiv_m0_f3x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=5, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),
     "hiv_m0_f1x4mg": lambda: case_mle("hiv_m0_f1x4mg", dict(seqfile="HIVenvSweden.txt", treefile="HIVenvSweden.trees", NSsites=0, CodonFreq=4, kappa=.3, omega=1.3), HIVF, 13, "codon_m0"),

@@ -19,7 +19,8 @@ CASES = [("brown_hky85", "baseml", "brown_hky85.ctl"), ("stewart_lg_g4", "codeml
          ("hiv_m7", "codeml", "hiv_ns7.ctl"), ("hiv_m8", "codeml", "hiv_ns8.ctl"), ("mhc_m0_scaled", "codeml", "mhc_m0.ctl"),
          ("mhc_m2a", "codeml", "mhc_ns2.ctl"), ("mhc_m8", "codeml", "mhc_ns8.ctl"),      # site classes on a tree with ten scaling nodes
          ("mtcdna_branch", "codeml", "mtcdna_branch.ctl"),
-         ("lysos_free", "codeml", "lysos_free.ctl"), ("lysos_branch_fix", "codeml", "lysos_branch_fix.ctl"),      # free-ratio model (model = 1): an omega and an eigen system for each of the 11 branches
+         ("lysos_free", "codeml", "lysos_free.ctl"), ("lysos_branch_fix", "codeml", "lysos_branch_fix.ctl"),
+         ("lysos_clade_label", "codeml", "lysos_clade_label.ctl"),      # '$' clade labels, nested, with a '#' inside      # free-ratio model (model = 1): an omega and an eigen system for each of the 11 branches
          # other genetic codes: invertebrate mt (62 sense codons), ciliate nuclear (63), the reference's "regularised" code (64)
          ("hiv_m0_icode4", "codeml", "hiv_ns0_icode4.ctl"), ("hiv_m0_icode5", "codeml", "hiv_ns0_icode5.ctl"), ("hiv_m0_icode11", "codeml", "hiv_ns0_icode11.ctl"),
          # aaDist = 7 (AAClasses): omega by class of amino-acid pair (ctl/OmegaAA.dat), alone and per branch label
@@ -279,6 +280,18 @@ def test_c_host_control_file_overrides_pick_a_model_of_a_list(tmp_path):
         assert abs(oracle.evaluate(b.problem(np.array(g["x"])))["lnL"] - g["lnL"]) <= 2e-6
     with pytest.raises(RuntimeError, match="without '='"):
         hostlib.Analysis(str(tmp_path / "list.ctl"), "codeml", overrides="NSsites 2")
+
+
+def test_c_host_clade_labels_spread_down_the_tree():
+    """'$k' after a clade labels all its branches that carry no '#' of their own, inner clade labels winning over outer ones
+    (DownTreeCladeLabel treesub.c:2960-2976): ((1, 2 #2) $1, ((3, 4) $2, 5), (6, 7)) is three branch types."""
+    a = hostlib.Analysis(os.path.join(CTL, "lysos_clade_label.ctl"), "codeml")
+    g = helpers.load_golden("lysos_clade_label")
+    pb = a.problem(np.array(g["x"]))
+    lab = {tuple(sorted(int(c) for c in pb.tree.sons[i])): int(pb.tree.label[i]) for i in range(pb.tree.n_tips, pb.tree.n_nodes)}
+    assert [int(v) for v in pb.tree.label[:7]] == [1, 2, 2, 2, 0, 0, 0]
+    assert lab[(0, 1)] == 1 and lab[(2, 3)] == 2 and lab[(5, 6)] == 0
+    assert a.np == 11 + 1 + 3
 
 
 def test_c_host_rejects_what_it_does_not_support(tmp_path):
