@@ -514,7 +514,9 @@ int pamlh_read_tree(pamlh *p)
          int hns = 0, hnt = 0;
          char c = *s;
          *s = 0;
-         if (sscanf(buf, "%d%d", &hns, &hnt) == 2 && hnt >= 1 && hnt < p->ntrees) p->ntrees = hnt;
+         const int nh = sscanf(buf, "%d%d", &hns, &hnt);      /* "ns ntree" (paml), or "ntree" alone (phylip / molphy style) */
+         if (nh == 1) hnt = hns;
+         if (nh >= 1 && hnt >= 1 && hnt < p->ntrees) p->ntrees = hnt;
          *s = c;
       }
       if (p->itree < 0 || p->itree >= p->ntrees) { free(buf); return pamlh_fail(p, "tree %d asked for, %s holds %d", p->itree + 1, p->treefile, p->ntrees); }
