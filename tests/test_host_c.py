@@ -1095,7 +1095,14 @@ def test_differential_over_every_golden_control_file(gname, prog, ctl, tmp_path)
     _differential(ctl, prog, 100 + sum(map(ord, ctl)), tmp_path)
 
 
-def _differential(ctl, prog, seed, tmp_path):
+@pytest.mark.parametrize("gname,prog,ctl", [c for c in CASES if "clock" not in c[2] and "tipdate" not in c[2] and not c[2].startswith("mhc_ns")])
+def test_differential_of_the_oracle_on_cpu(gname, prog, ctl, tmp_path):
+    """The CPU twin of the test above, for the container that holds the reference: the C host's problem at a random parameter vector
+    through the oracle against the reference binary's lnL for the same control file and vector (skipped where oracle/_ref is absent)."""
+    _differential(ctl, prog, 500 + sum(map(ord, ctl)), tmp_path, on_gpu=False)
+
+
+def _differential(ctl, prog, seed, tmp_path, on_gpu=True):
     """Beyond the committed vectors: the unmodified reference binary (oracle/_ref, when it travelled with the repository) and the
     engine evaluate the same control file at a RANDOM parameter vector inside the bounds; lnL must agree to the printed digits."""
     import shutil
@@ -1121,7 +1128,7 @@ def _differential(ctl, prog, seed, tmp_path):
     m = re.findall(r"lnL\(ntime:[^\n]*?(-[0-9]+\.[0-9]+)", open(tmp_path / main).read())
     assert m, r.stdout[-2000:]
     ref = float(m[-1])
-    got, _ = a.eval_gpu(x, want_lnf=False)
+    got = a.eval_gpu(x, want_lnf=False)[0] if on_gpu else oracle.evaluate(a.problem(x), want_lnf=False)["lnL"]
     # M9 - M13: the reference inverts the mixture's CDF by a line search on (CDF - p)^2 that starts from the previous call's classes and stops
     # at ~1e-5 in omega (Quantile(CDFdN_dS, ...) in DiscreteNSsites, codeml.c:2877); its lnL moves by a few 1e-3 with the starting point (see the hiv_m11 golden's note)
     tol = 5e-3 if re.search(r"hiv_ns(9|1[0-3])\.ctl", ctl) else 2e-6 * max(1.0, abs(ref) / 1000)
