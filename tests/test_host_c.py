@@ -1088,14 +1088,20 @@ def test_differential_against_the_reference_binary_at_random_parameters(ctl, pro
     _differential(ctl, prog, seed, tmp_path)
 
 
+# control files without a committed golden: checked only against the live reference binary, at random parameter vectors
+# (codon frequencies as parameters / the mutation-selection model together with branch models)
+DIFF_ONLY = [("-", "codeml", "lysos_branch_f3x4est.ctl"), ("-", "codeml", "lysos_free_fmutsel.ctl")]
+DIFF_CASES = [c for c in CASES if "clock" not in c[2] and "tipdate" not in c[2]] + DIFF_ONLY
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("gname,prog,ctl", [c for c in CASES if "clock" not in c[2] and "tipdate" not in c[2]])
+@pytest.mark.parametrize("gname,prog,ctl", DIFF_CASES)
 def test_differential_over_every_golden_control_file(gname, prog, ctl, tmp_path):
     """... and the same for every control file of the golden cases (the clock models aside: their parameters are ordered ages)."""
     _differential(ctl, prog, 100 + sum(map(ord, ctl)), tmp_path)
 
 
-@pytest.mark.parametrize("gname,prog,ctl", [c for c in CASES if "clock" not in c[2] and "tipdate" not in c[2] and not c[2].startswith("mhc_ns")])
+@pytest.mark.parametrize("gname,prog,ctl", [c for c in DIFF_CASES if not c[2].startswith("mhc_ns")])
 def test_differential_of_the_oracle_on_cpu(gname, prog, ctl, tmp_path):
     """The CPU twin of the test above, for the container that holds the reference: the C host's problem at a random parameter vector
     through the oracle against the reference binary's lnL for the same control file and vector (skipped where oracle/_ref is absent)."""
