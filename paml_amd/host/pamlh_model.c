@@ -381,7 +381,6 @@ int pamlh_load_with(pamlh **out, const char *ctl_path, const char *program, int 
       rc = 0;
       if (p->npi == 2) p->npi = 3 + p->n - 1;      /* FMutSel with estFreq: the codon fitnesses */
       else if (p->npi == -1) p->npi = p->n - 1;    /* Fcodon with estFreq */
-      if (p->npi && p->model && p->nssites) { rc = pamlh_fail(p, "estFreq / FMutSel with branch-site and clade models is not supported"); goto bad; }
       p->aadist = (int)pamlh_optd(p, "aaDist", 0);
       if (p->aadist < -6 || p->aadist > 7) { rc = pamlh_fail(p, "aaDist = %d is not supported (1..6 / -1..-6: distance files, 7: AAClasses)", p->aadist); goto bad; }
       if (p->aadist == 7) {
