@@ -9,7 +9,7 @@
  * (codeml.c:2757, baseml.c:1306) does: branch lengths, pi, eigen systems, site classes.  It then drives
  * libpaml_amd.so through include/paml_amd.h.  Scope (this round): codeml seqtype 1 (icode 0 and 1; CodonFreq 0-5 (incl. F1x4MG / F3x4MG); NSsites
  * 0-13 and 22 with model 0; with '#' labels in the tree the branch model (model 2, NSsites 0), the branch-site models A and B
- * (model 2, NSsites 2 / 3) and the clade models C and D (model 3, NSsites 2 / 3)) and seqtype 2 (aa models 0,1,2,3), baseml models JC69,K80,F81,F84,HKY85,T92,TN93,REV,UNREST; +Gamma, auto-discrete-gamma (rho), nhomo 1 (base frequencies as parameters); several genes
+ * (model 2, NSsites 2 / 3) and the clade models C and D (model 3, NSsites 2 / 3)) and seqtype 2 / 3 (aa models 0,1,2,3), baseml models JC69,K80,F81,F84,HKY85,T92,TN93,REV,UNREST; +Gamma, auto-discrete-gamma (rho), nhomo 1 (base frequencies as parameters); several genes
  * (option G / GC of the sequence file) with Mgene 0,1,2,3,4 for baseml, codeml M0 and aaml;
  * clock 0 and 1 (global clock: x holds the internal node ages); fix_blength 0, 2 (fixed) and 3 (proportional); cleandata 0/1; sequential and interleaved (I) PHYLIP, the P pattern format.  Anything else fails with a message
  * instead of guessing.

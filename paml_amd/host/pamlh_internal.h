@@ -51,6 +51,7 @@ struct pamlh {
    unsigned char *chara_map;
    double fb3x4[12], fb4[4], fcodon[64], pi_data[64];
    double fb61[64];
+   int translate;          /* seqtype = 3: the sequence file holds codons, the analysis is of their amino acids */
    int free_ratio;         /* codeml model = 1: run as the branch model with every branch its own label */
    int itree, ntrees;      /* which tree of the tree file this analysis uses; how many the file holds */
    /* codon frequencies as parameters (estFreq = 1) and the mutation-selection models FMutSel0 / FMutSel (CodonFreq 6, 7) */
@@ -119,6 +120,7 @@ double pamlh_quantile_beta(double prob, double p, double q);
 int pamlh_read_ctl(pamlh *p, const char *path);
 const char *pamlh_opt(const pamlh *p, const char *key);
 int pamlh_ctl_override(pamlh *p, const char *text);
+const char *pamlh_genetic_code(int icode);      /* 64 characters, codons in T C A G order, '*' = stop; NULL: no such code */
 double pamlh_optd(const pamlh *p, const char *key, double dflt);
 int pamlh_read_seqs(pamlh *p);
 int pamlh_read_tree(pamlh *p);

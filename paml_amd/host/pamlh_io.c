@@ -204,10 +204,10 @@ int pamlh_read_seqs(pamlh *p)
    FILE *f = open_seqfile(p, &seqmem);
    char *line;
    size_t cap = 1 << 16;
-   int ns, lsraw, i, j, k, h, readpattern = 0, interleaved = 0, any_amb = 0, n31 = (p->seqtype == 1 ? 3 : 1);
+   int ns, lsraw, i, j, k, h, readpattern = 0, interleaved = 0, any_amb = 0, n31 = (p->seqtype == 1 || p->translate ? 3 : 1);
    int *pos, *site_gene = NULL;
-   const char *alpha = p->seqtype == 2 ? AAs : BASEs;
-   const int nbasic = p->seqtype == 2 ? 20 : 4;
+   const char *alpha = (p->seqtype == 2 && !p->translate) ? AAs : BASEs;
+   int nbasic = (p->seqtype == 2 && !p->translate) ? 20 : 4;
    char *seq;
    if (!f) return p->err[0] ? -1 : pamlh_fail(p, "cannot open sequence file %s", p->seqfile);
    line = (char *)malloc(cap);
@@ -310,7 +310,7 @@ int pamlh_read_seqs(pamlh *p)
          }
          {
             char ch = (char)toupper((unsigned char)*q++);
-            if (p->seqtype != 2 && ch == 'U') ch = 'T';
+            if (alpha == BASEs && ch == 'U') ch = 'T';
             if (ch == '.') {
                if (j == 0) { fclose(f); return pamlh_fail(p, ". in the first sequence"); }
                seq[(size_t)j * lsraw + k] = seq[k];
@@ -328,6 +328,31 @@ int pamlh_read_seqs(pamlh *p)
    for (j = 0; j < ns; j++)
       if (pos[j] != lsraw) { fclose(f); return pamlh_fail(p, "sequence %d has %d of %d characters", j + 1, pos[j], lsraw); }
    free(pos);
+   if (p->translate) {
+      /* seqtype = 3: every codon becomes its amino acid (DNA2protein / Codon2AA tools.c:777-828): the amino acids of all the codons an
+       * ambiguous triplet stands for, stop codons aside; exactly one -> that amino acid, none or several -> '-' (missing) */
+      static const char NUCS[] = "TCAGYRMKSWHBVD-N?";
+      static const int MASK[] = {1, 2, 4, 8, 3, 12, 6, 9, 10, 5, 7, 11, 14, 13, 15, 15, 15};
+      const char *code = pamlh_genetic_code(p->icode);
+      const int lc = lsraw / 3;
+      if (!code) { fclose(f); return pamlh_fail(p, "genetic code icode = %d is not supported", p->icode); }
+      if (site_gene) { fclose(f); return pamlh_fail(p, "seqtype = 3 with option G is not supported"); }
+      any_amb = 0;
+      for (j = 0; j < ns; j++)
+         for (h = 0; h < lc; h++) {
+            int m[3], b0, b1, b2, aa = -1, many = 0;
+            for (k = 0; k < 3; k++) { const char *q = strchr(NUCS, seq[(size_t)j * lsraw + h * 3 + k]); m[k] = q && *q ? MASK[q - NUCS] : 15; }
+            for (b0 = 0; b0 < 4; b0++) for (b1 = 0; b1 < 4; b1++) for (b2 = 0; b2 < 4; b2++)
+               if ((m[0] >> b0 & 1) && (m[1] >> b1 & 1) && (m[2] >> b2 & 1)) {
+                  const char a = code[b0 * 16 + b1 * 4 + b2];
+                  if (a == '*') continue;
+                  if (aa < 0) aa = a; else if (a != aa) many = 1;
+               }
+            seq[(size_t)j * lc + h] = (aa < 0 || many) ? '-' : (char)aa;      /* (compacting in place: position j * lc + h <= j * lsraw + 3 h) */
+            if (aa < 0 || many) any_amb = 1;
+         }
+      lsraw = lc; n31 = 1; alpha = AAs; nbasic = 20;
+   }
    /* pattern counts of the P format: npatt numbers after the sequences (treesub.c:954-983) */
    {
       const int nsite = lsraw / n31;

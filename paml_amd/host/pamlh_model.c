@@ -24,6 +24,7 @@ static const char *const GENETIC_CODES[N_GENETIC_CODES] = {
    "FFLLSSSSYY**CC*WLLLSPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG", "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSGGVVVVAAAADDEEGGGG",
    "FFLLSSSSYY*QCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG", "RRRRNNNNDDDDCCCCQQQQEEEEGGGGHHHHIIIILLLLKKKKMMMMFFFFPPPPSSSSTTTT"};
 
+const char *pamlh_genetic_code(int icode) { return icode >= 0 && icode < N_GENETIC_CODES ? GENETIC_CODES[icode] : NULL; }
 static int nuc_nkappa(const pamlh *p);
 /* days from 1970-01-01 to y-m-d in the proleptic Gregorian calendar (era arithmetic: 400-year cycles of 146 097 days, years starting in March) */
 static long days_from_civil(int y, int m, int d)
@@ -308,6 +309,7 @@ int pamlh_load_with(pamlh **out, const char *ctl_path, const char *program, int 
    if (!(v = pamlh_opt(p, "treefile"))) { rc = pamlh_fail(p, "no treefile in the control file"); goto bad; }
    resolve(p, v, p->treefile, sizeof(p->treefile));
    p->seqtype = p->is_codeml ? (int)pamlh_optd(p, "seqtype", 1) : 0;
+   if (p->seqtype == 3) { p->translate = 1; p->seqtype = 2; p->icode = (int)pamlh_optd(p, "icode", 0); }      /* codons translated on reading, then an amino-acid analysis (ReadSeq treesub.c:886-892) */
    p->codonfreq = (int)pamlh_optd(p, "CodonFreq", 0);
    p->model = (int)pamlh_optd(p, "model", 0);
    p->nssites = (int)pamlh_optd(p, "NSsites", 0);
