@@ -958,8 +958,7 @@ def test_c_host_rejects_option_combinations_it_does_not_cover(tmp_path):
         load("brown_hky85_clock.ctl", "baseml", TipDate="1 100")             # names without dates
     with pytest.raises(RuntimeError, match="branch rate labels"):
         load("brown_hky85_clock.ctl", "baseml", clock=2)                     # local clocks without '#' labels
-    with pytest.raises(RuntimeError, match="branch models"):
-        load("mtcdna_branch.ctl", "codeml", CodonFreq=6)                      # FMutSel0 + branch model
+    assert load("mtcdna_branch.ctl", "codeml", CodonFreq=6).np == 12 + 3      # FMutSel0 + branch model: three mutation-bias parameters more
     with pytest.raises(RuntimeError, match="Malpha"):
         load("brown_hky85_g4.ctl", "baseml", Malpha=1)                        # one gene
     with pytest.raises(RuntimeError, match="nhomo"):
