@@ -32,6 +32,18 @@ def test_abi_exports_match_header(lib_path):
     assert sorted(engine.EXPORTS) == [d for d in declared]
 
 
+def test_host_library_exports_match_its_header():
+    """libpamlh.so (the C host above the ABI) exports every function include/pamlh.h declares."""
+    from paml_amd import hostlib
+    L = hostlib.lib()
+    hdr = open(os.path.join(helpers.REPO, "include", "pamlh.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(pamlh_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 50
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, missing
+
+
 def _gpu_visible():
     try:
         import torch
