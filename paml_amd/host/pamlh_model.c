@@ -324,6 +324,15 @@ int pamlh_load_with(pamlh **out, const char *ctl_path, const char *program, int 
    p->ncatG = (int)pamlh_optd(p, "ncatG", 4);
    p->cleandata_opt = (int)pamlh_optd(p, "cleandata", 0);
    p->fix_blength = (int)pamlh_optd(p, "fix_blength", 0);
+   /* options that would change the analysis and are not covered: refused, never ignored */
+   {
+      const int runmode = (int)pamlh_optd(p, "runmode", 0), ndata = (int)pamlh_optd(p, "ndata", 1);
+      if (runmode != 0) { rc = pamlh_fail(p, "runmode = %d is not supported (0: the trees of the tree file; tree search and pairwise comparisons are outside this library)", runmode); goto bad; }
+      if (ndata > 1) { rc = pamlh_fail(p, "ndata = %d is not supported (one data set per sequence file)", ndata); goto bad; }
+      if ((int)pamlh_optd(p, "hkyREV", 0)) { rc = pamlh_fail(p, "hkyREV = 1 is not supported"); goto bad; }
+      if ((int)pamlh_optd(p, "nparK", 0)) { rc = pamlh_fail(p, "nparK = %d is not supported", (int)pamlh_optd(p, "nparK", 0)); goto bad; }
+      if ((int)pamlh_optd(p, "bootstrap", 0)) { rc = pamlh_fail(p, "bootstrap resampling of the alignment is not supported"); goto bad; }
+   }
    p->fix_rho = (int)pamlh_optd(p, "fix_rho", 1);
    p->rho0 = pamlh_optd(p, "rho", 0);
    if (!p->fix_rho && p->rho0 == 0) p->rho0 = 0.001;      /* "init rho reset" (baseml.c:1087) */

@@ -961,6 +961,12 @@ def test_c_host_rejects_option_combinations_it_does_not_cover(tmp_path):
     assert load("mtcdna_branch.ctl", "codeml", CodonFreq=6).np == 12 + 3      # FMutSel0 + branch model: three mutation-bias parameters more
     with pytest.raises(RuntimeError, match="Malpha"):
         load("brown_hky85_g4.ctl", "baseml", Malpha=1)                        # one gene
+    # options that change the analysis are refused, never silently ignored
+    for kw, msg in ((dict(runmode=2), "runmode"), (dict(runmode=-2), "runmode"), (dict(ndata=5), "ndata"), (dict(nparK=1), "nparK"), (dict(bootstrap=100), "bootstrap")):
+        with pytest.raises(RuntimeError, match=msg):
+            load("brown_hky85_g4.ctl", "baseml", **kw)
+    with pytest.raises(RuntimeError, match="hkyREV"):
+        load("hiv_ns0.ctl", "codeml", hkyREV=1)
     with pytest.raises(RuntimeError, match="nhomo"):
         load("brown_hky85.ctl", "baseml", nhomo=2, model=7)                   # a kappa per branch needs K80 / F84 / HKY85
     with pytest.raises(RuntimeError, match="grantham.dat"):
