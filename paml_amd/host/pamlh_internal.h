@@ -46,6 +46,7 @@ struct pamlh {
    int m2a_rel;            /* NSsites = 22 */
    int mgene;              /* Mgene: 0 rates, 2 different pi, 3 different kappa (& omega), 4 both */
    double piG[PAMLH_MAXGENE][64];   /* frequencies of every gene (com.piG) */
+   double fb3x4G[PAMLH_MAXGENE][12], fb4G[PAMLH_MAXGENE][4];      /* position x nucleotide / nucleotide frequencies of every gene (the MG-style models, com.f3x4[igene]) */
    double rgene[PAMLH_MAXGENE];     /* com.rgene: rate of every gene relative to the first */
    int *gene_eigen_of;     /* [ngene][K][n_labels] when ngene > 1 */
    unsigned char *chara_map;

@@ -211,7 +211,10 @@ static void freqs_codon_range(pamlh *p, int h0, int h1, double *pi_out)
 static void freqs_codon(pamlh *p)
 {
    int g;
-   for (g = 0; g < p->ngene && p->ngene > 1; g++) freqs_codon_range(p, p->posG[g], p->posG[g + 1], p->piG[g]);
+   for (g = 0; g < p->ngene && p->ngene > 1; g++) {
+      freqs_codon_range(p, p->posG[g], p->posG[g + 1], p->piG[g]);
+      memcpy(p->fb3x4G[g], p->fb3x4, sizeof(p->fb3x4)); memcpy(p->fb4G[g], p->fb4, sizeof(p->fb4));
+   }
    freqs_codon_range(p, 0, p->npatt, p->pi_data);      /* last: leaves the whole-data tables in fb3x4 / fb4 / fcodon */
    if (p->ngene <= 1) memcpy(p->piG[0], p->pi_data, p->n * sizeof(double));
 }
@@ -479,7 +482,6 @@ int pamlh_load_with(pamlh **out, const char *ctl_path, const char *program, int 
       if (p->mgene >= 3 && (p->fix_kappa || (p->seqtype == 1 && p->fix_omega))) { rc = pamlh_fail(p, "Mgene = %d needs free kappa (and omega)", p->mgene); goto bad; }
       if (p->seqtype == 2 && p->mgene >= 3) { rc = pamlh_fail(p, "Mgene = %d has no meaning for the amino-acid models here", p->mgene); goto bad; }
       if (p->seqtype == 2 && p->mgene == 2 && p->aa_model != 3 && p->aa_model != 1) { rc = pamlh_fail(p, "Mgene = 2 needs frequencies from the data (amino-acid model 1 or 3)"); goto bad; }
-      if (p->seqtype == 1 && p->mg && p->mgene >= 2) { rc = pamlh_fail(p, "F1x4MG / F3x4MG with gene-specific frequencies is not supported"); goto bad; }
       if (p->seqtype == 1 && p->mgene == 2 && p->codonfreq == 0) { rc = pamlh_fail(p, "Mgene = 2 with equal codon frequencies"); goto bad; }
       if (p->seqtype == 0 && p->mgene >= 2 && p->model == UNREST) { rc = pamlh_fail(p, "Mgene >= 2 does not work with UNREST"); goto bad; }
       if (p->seqtype == 0 && ((p->mgene >= 2 && p->model == JC69) || (p->mgene >= 3 && p->model == F81) || ((p->mgene == 2 || p->mgene == 4) && p->model == K80))) {
@@ -1167,7 +1169,11 @@ static int set_x_genes(pamlh *p, const double *x, int np, int k, double *Q)
       if (p->seqtype == 1) {
          const double *kp = x + k + (per_gene ? g * 2 : 0);
          const double kappa = p->fix_kappa ? p->kappa0 : kp[0], w = p->fix_omega ? p->omega0 : kp[!p->fix_kappa];
-         const double mr = codon_q_pi(p, pis, kappa, w, Q);
+         double mr, keep3[12], keep4[4];
+         memcpy(keep3, p->fb3x4, sizeof(keep3)); memcpy(keep4, p->fb4, sizeof(keep4));
+         if (p->mg && own_pi) { memcpy(p->fb3x4, p->fb3x4G[g], sizeof(keep3)); memcpy(p->fb4, p->fb4G[g], sizeof(keep4)); }      /* F1x4MG / F3x4MG: the gene's own tables (SetPGene codeml.c: com.pf3x4 = com.f3x4[igene]) */
+         mr = codon_q_pi(p, pis, kappa, w, Q);
+         memcpy(p->fb3x4, keep3, sizeof(keep3)); memcpy(p->fb4, keep4, sizeof(keep4));
          set_eig_uvroot(p, g, Q, pis, mr);
          p->kappa = kappa; p->omega = w; p->class_w[g] = w;
       }

@@ -1097,6 +1097,7 @@ def test_differential_against_the_reference_binary_at_random_parameters(ctl, pro
 # (codon frequencies as parameters / the mutation-selection model together with branch models)
 DIFF_ONLY = [("-", "codeml", "lysos_branch_f3x4est.ctl"), ("-", "codeml", "lysos_free_fmutsel.ctl"),
              ("-", "codeml", "lyso_bsa_f3x4est.ctl"), ("-", "codeml", "ecp_cmc_fmutsel0.ctl"),      # ... and with branch-site model A, clade model C
+             ("-", "codeml", "lysin_mg2_f3x4mg.ctl"), ("-", "codeml", "lysin_mg4_f3x4mg.ctl"),      # F3x4MG with the genes' own frequency tables (Mgene = 2, 4)
              ("-", "codeml", "lysos_seqtype3.ctl")]      # seqtype = 3: codons translated on reading, JTT + G4 on the amino acids
 DIFF_CASES = [c for c in CASES if "clock" not in c[2] and "tipdate" not in c[2]] + DIFF_ONLY
 
