@@ -1116,6 +1116,14 @@ def test_differential_of_the_oracle_on_cpu(gname, prog, ctl, tmp_path):
     _differential(ctl, prog, 500 + sum(map(ord, ctl)), tmp_path, on_gpu=False)
 
 
+@pytest.mark.parametrize("prog,ctl", [("baseml", "brown_hky85_clock.ctl"), ("baseml", "brown_hky85_clock2.ctl"), ("baseml", "hiv2_tipdate.ctl"),
+                                      ("baseml", "hiv2_tipdate_clock2.ctl"), ("codeml", "lysos_m0_clock.ctl")])
+def test_differential_of_the_clock_models_on_cpu(prog, ctl, tmp_path):
+    """The clock models (their parameters are node ages: a random vector would put nodes above their ancestors) at the host's own initial
+    values against the reference binary: global and local clocks, dated tips, and the codon model M0 under a global clock."""
+    _differential(ctl, prog, None, tmp_path, on_gpu=False)
+
+
 def _differential(ctl, prog, seed, tmp_path, on_gpu=True):
     """Beyond the committed vectors: the unmodified reference binary (oracle/_ref, when it travelled with the repository) and the
     engine evaluate the same control file at a RANDOM parameter vector inside the bounds; lnL must agree to the printed digits."""
@@ -1125,9 +1133,12 @@ def _differential(ctl, prog, seed, tmp_path, on_gpu=True):
         pytest.skip("oracle/_ref/%s is not here (it is built from /root/reference in the build container)" % prog)
     a = hostlib.Analysis(os.path.join(CTL, ctl), prog)
     lo, hi = a.bounds()
-    rng = np.random.default_rng(seed)
-    x = a.default_x() * np.where(hi <= 1, rng.uniform(0.7, 1.0, a.np), rng.uniform(0.7, 1.4, a.np))     # (proportions only shrink: they stay feasible)
-    x = np.round(np.clip(x, lo * 1.5, np.minimum(hi * 0.9, 50)), 6)           # in.codeml carries six decimals
+    if seed is None:
+        x = np.round(a.default_x(), 6)
+    else:
+        rng = np.random.default_rng(seed)
+        x = a.default_x() * np.where(hi <= 1, rng.uniform(0.7, 1.0, a.np), rng.uniform(0.7, 1.4, a.np))     # (proportions only shrink: they stay feasible)
+        x = np.round(np.clip(x, lo * 1.5, np.minimum(hi * 0.9, 50)), 6)           # in.codeml carries six decimals
     text = open(os.path.join(CTL, ctl)).read()
     for name in re.findall(r"\.\./data/(\S+)", text):
         shutil.copy(os.path.join(helpers.GOLDEN, "data", name), tmp_path / name)
