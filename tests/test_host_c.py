@@ -1124,6 +1124,30 @@ def test_differential_of_the_clock_models_on_cpu(prog, ctl, tmp_path):
     _differential(ctl, prog, None, tmp_path, on_gpu=False)
 
 
+@pytest.mark.parametrize("variant", ["baseml model = %d" % m for m in range(9)] + ["rooted tree, no clock", "stewart cleandata = 1", "lysozyme cleandata = 1"])
+def test_differential_of_option_variants_on_cpu(variant, tmp_path):
+    """Variants of the golden control files, written on the fly: every baseml substitution model (JC69, K80, F81, F84, HKY85, T92, TN93, REV,
+    UNREST) with gamma rates on brown.nuc, a rooted tree analysed without a clock (one branch more than the unrooted tree: the reference
+    warns and goes on), and cleandata = 1 on alignments with ambiguity characters (sites removed) — random parameters, live reference."""
+    if variant.startswith("baseml"):
+        base, prog, sub = "brown_hky85_g4.ctl", "baseml", ("model = 4", variant[7:])
+    elif variant.startswith("rooted"):
+        base, prog, sub = "lysos_m0_clock.ctl", "codeml", ("clock = 1", "clock = 0")
+    elif variant.startswith("stewart"):
+        base, prog, sub = "stewart_lg_g4.ctl", "codeml", ("cleandata = 0", "cleandata = 1")
+    else:
+        base, prog, sub = "lysos_free.ctl", "codeml", ("cleandata = 0", "cleandata = 1")
+    txt = open(os.path.join(CTL, base)).read()
+    assert sub[0] in txt
+    name = "variant_%d.ctl" % (abs(hash(variant)) % 10 ** 8)
+    path = os.path.join(CTL, name)      # beside the others: the ../data/ paths stay valid
+    open(path, "w").write(txt.replace(sub[0], sub[1]))
+    try:
+        _differential(name, prog, 40 + sum(map(ord, variant)), tmp_path, on_gpu=False)
+    finally:
+        os.remove(path)
+
+
 def _differential(ctl, prog, seed, tmp_path, on_gpu=True):
     """Beyond the committed vectors: the unmodified reference binary (oracle/_ref, when it travelled with the repository) and the
     engine evaluate the same control file at a RANDOM parameter vector inside the bounds; lnL must agree to the printed digits."""
