@@ -605,7 +605,7 @@ genes_ok:
          else if (p->nssites == 13) nr += 6;                                      /* M13: p0, p1, mu2, s0, s1, s2 */
          else if (p->nssites == 0) nr += !p->fix_omega;
          else if (p->nssites == 1) nr += 2;
-         else if (p->nssites == 2) nr += 4;
+         else if (p->nssites == 2) nr += 3 + !p->fix_omega;      /* M2a: p0 p1 w0 [w2]; fix_omega fixes w2 (omega_fix, codeml.c:1596) */
          else if (p->nssites == 7) nr += 2;
          else if (p->nssites == 8) nr += 3 + !p->fix_omega;
       }
@@ -825,7 +825,7 @@ int pamlh_default_x(const pamlh *p, double *x, int cap)
       }
       else if (p->nssites == 0) { if (!p->fix_omega) x[k++] = p->omega0; }
       else if (p->nssites == 1) { x[k++] = 0.6; x[k++] = 0.1; }
-      else if (p->nssites == 2) { x[k++] = 0.5; x[k++] = 0.3; x[k++] = 0.1; x[k++] = 2.5; }
+      else if (p->nssites == 2) { x[k++] = 0.5; x[k++] = 0.3; x[k++] = 0.1; if (!p->fix_omega) x[k++] = 2.5; }
       else if (p->nssites == 7) { x[k++] = 0.5; x[k++] = 1.5; }
       else if (p->nssites == 8) { x[k++] = 0.9; x[k++] = 0.5; x[k++] = 1.5; if (!p->fix_omega) x[k++] = 2.5; }
    }
@@ -1350,7 +1350,7 @@ int pamlh_set_x(pamlh *p, const double *x, int np)
          double w[16], f[16], mr, wmean = 0;
          int K;
          if (p->nssites == 1) { f[0] = x[k]; w[0] = x[k + 1]; f[1] = 1 - f[0]; w[1] = 1; K = 2; k += 2; }
-         else if (p->nssites == 2) { f[0] = x[k]; f[1] = x[k + 1]; f[2] = 1 - f[0] - f[1]; w[0] = x[k + 2]; w[1] = 1; w[2] = x[k + 3]; K = 3; k += 4; }
+         else if (p->nssites == 2) { f[0] = x[k]; f[1] = x[k + 1]; f[2] = 1 - f[0] - f[1]; w[0] = x[k + 2]; w[1] = 1; w[2] = p->fix_omega ? p->omega0 : x[k + 3]; K = 3; k += 3 + !p->fix_omega; }
          else if (p->nssites == 5) {      /* M5 (gamma): medians of K equal-probability bins of gamma(a, b), kept inside (1e-7, 99) (DiscreteNSsites codeml.c:2873-2880) */
             K = p->ncatG;
             if (K > 16) { free(Q); return pamlh_fail(p, "ncatG too large"); }
@@ -1792,7 +1792,7 @@ int pamlh_param_name(const pamlh *p, int i, char *buf, int cap)
          }
          else if (p->nssites == 0) { if (!p->fix_omega) NAME("omega%s", sfx); }
          else if (p->nssites == 1) { NAME("p0"); NAME("w0"); }
-         else if (p->nssites == 2) { NAME("p0"); NAME("p1"); NAME("w0"); NAME("w2"); }
+         else if (p->nssites == 2) { NAME("p0"); NAME("p1"); NAME("w0"); if (!p->fix_omega) NAME("w2"); }
          else if (p->nssites == 3) { for (j = 0; j < p->ncatG - 1; j++) NAME("p%d", j); for (j = 0; j < p->ncatG; j++) NAME("w%d", j); }
          else if (p->nssites == 4) { for (j = 0; j < 4; j++) NAME("p%d", j); }
          else if (p->nssites == 5) { NAME("a (gamma)"); NAME("b (gamma)"); }

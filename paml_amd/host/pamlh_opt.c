@@ -322,7 +322,7 @@ int pamlh_bounds(const pamlh *p, double *lo, double *hi)
       else if (p->nssites == 1) { lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 1e-6; hi[k++] = 1; }
       else if (p->nssites == 2) {
          lo[k] = 1e-6; hi[k++] = 1 - 1e-6; lo[k] = 1e-6; hi[k++] = 1 - 1e-6;
-         lo[k] = 1e-6; hi[k++] = 1; lo[k] = p->m2a_rel ? 1e-6 : 1; hi[k++] = 999;
+         lo[k] = 1e-6; hi[k++] = 1; if (!p->fix_omega) { lo[k] = p->m2a_rel ? 1e-6 : 1; hi[k++] = 999; }
       }
       else if (p->nssites == 7) { lo[k] = 0.005; hi[k++] = 99; lo[k] = 0.005; hi[k++] = 99; }
       else if (p->nssites == 8) {

@@ -1124,24 +1124,37 @@ def test_differential_of_the_clock_models_on_cpu(prog, ctl, tmp_path):
     _differential(ctl, prog, None, tmp_path, on_gpu=False)
 
 
-@pytest.mark.parametrize("variant", ["baseml model = %d" % m for m in range(9)] + ["rooted tree, no clock", "stewart cleandata = 1", "lysozyme cleandata = 1"])
+VARIANTS = {      # name: (control file, program, (text, replacement) ...)
+    "rooted tree, no clock": ("lysos_m0_clock.ctl", "codeml", ("clock = 1", "clock = 0")),
+    "stewart cleandata = 1": ("stewart_lg_g4.ctl", "codeml", ("cleandata = 0", "cleandata = 1")),
+    "lysozyme cleandata = 1": ("lysos_free.ctl", "codeml", ("cleandata = 0", "cleandata = 1")),
+    "M0 kappa fixed": ("hiv_ns0.ctl", "codeml", ("fix_kappa = 0", "fix_kappa = 1")),
+    "M0 omega fixed": ("hiv_ns0.ctl", "codeml", ("fix_omega = 0", "fix_omega = 1")),
+    "M2a w2 fixed at 1": ("hiv_ns2.ctl", "codeml", ("fix_omega = 0", "fix_omega = 1"), ("omega = 1.3", "omega = 1")),      # the null of the M2a test with w2 = 1
+    "M8 ws fixed at 1": ("hiv_ns8.ctl", "codeml", ("fix_omega = 0", "fix_omega = 1"), ("omega = 1.3", "omega = 1")),       # M8a
+    "M1a fix_omega ignored": ("hiv_ns1.ctl", "codeml", ("fix_omega = 0", "fix_omega = 1")),
+    "M7 fix_omega ignored": ("hiv_ns7.ctl", "codeml", ("fix_omega = 0", "fix_omega = 1")),
+}
+VARIANTS.update({"baseml model = %d" % m: ("brown_hky85_g4.ctl", "baseml", ("model = 4", "model = %d" % m)) for m in range(9)})
+VARIANTS.update({"aa model = %d" % m: ("stewart_lg_g4.ctl", "codeml", ("model = 2", "model = %d" % m)) for m in range(4)})
+VARIANTS.update({"CodonFreq = %d, M0" % c: ("hiv_ns0.ctl", "codeml", ("CodonFreq = 2", "CodonFreq = %d" % c)) for c in (0, 1, 3)})
+VARIANTS.update({"CodonFreq = %d, M8" % c: ("hiv_ns8.ctl", "codeml", ("CodonFreq = 2", "CodonFreq = %d" % c)) for c in (0, 1, 3)})
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
 def test_differential_of_option_variants_on_cpu(variant, tmp_path):
     """Variants of the golden control files, written on the fly: every baseml substitution model (JC69, K80, F81, F84, HKY85, T92, TN93, REV,
-    UNREST) with gamma rates on brown.nuc, a rooted tree analysed without a clock (one branch more than the unrooted tree: the reference
-    warns and goes on), and cleandata = 1 on alignments with ambiguity characters (sites removed) — random parameters, live reference."""
-    if variant.startswith("baseml"):
-        base, prog, sub = "brown_hky85_g4.ctl", "baseml", ("model = 4", variant[7:])
-    elif variant.startswith("rooted"):
-        base, prog, sub = "lysos_m0_clock.ctl", "codeml", ("clock = 1", "clock = 0")
-    elif variant.startswith("stewart"):
-        base, prog, sub = "stewart_lg_g4.ctl", "codeml", ("cleandata = 0", "cleandata = 1")
-    else:
-        base, prog, sub = "lysos_free.ctl", "codeml", ("cleandata = 0", "cleandata = 1")
+    UNREST) with gamma rates on brown.nuc, the amino-acid models 0-3, CodonFreq 0 / 1 / 3, fixed kappa / omega (M2a with w2 = 1 and M8a among
+    them), a rooted tree analysed without a clock (one branch more than the unrooted tree: the reference warns and goes on), and
+    cleandata = 1 on alignments with ambiguity characters (sites removed) — random parameters, live reference."""
+    base, prog = VARIANTS[variant][:2]
     txt = open(os.path.join(CTL, base)).read()
-    assert sub[0] in txt
+    for a_, b_ in VARIANTS[variant][2:]:
+        assert a_ in txt, (base, a_)
+        txt = txt.replace(a_, b_)
     name = "variant_%d.ctl" % (abs(hash(variant)) % 10 ** 8)
     path = os.path.join(CTL, name)      # beside the others: the ../data/ paths stay valid
-    open(path, "w").write(txt.replace(sub[0], sub[1]))
+    open(path, "w").write(txt)
     try:
         _differential(name, prog, 40 + sum(map(ord, variant)), tmp_path, on_gpu=False)
     finally:
