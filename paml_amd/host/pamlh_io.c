@@ -49,10 +49,14 @@ int pamlh_read_ctl(pamlh *p, const char *path)
       while (isspace((unsigned char)*v)) v++;
       e = v + strlen(v);
       while (e > v && isspace((unsigned char)e[-1])) *--e = 0;
-      if (!*k || p->ctl.n >= PAMLH_MAXOPT) continue;
-      snprintf(p->ctl.key[p->ctl.n], 32, "%s", k);
-      snprintf(p->ctl.val[p->ctl.n], 1024, "%s", v);
-      p->ctl.n++;
+      if (!*k) continue;
+      {      /* an option given twice: the later line wins, as in the reference's sequential GetOptions */
+         int i;
+         for (i = 0; i < p->ctl.n; i++) if (strncmp(p->ctl.key[i], k, 8) == 0) break;
+         if (i == p->ctl.n) { if (p->ctl.n >= PAMLH_MAXOPT) continue; p->ctl.n++; }
+         snprintf(p->ctl.key[i], 32, "%s", k);
+         snprintf(p->ctl.val[i], 1024, "%s", v);
+      }
    }
    fclose(f);
    return 0;

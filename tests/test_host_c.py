@@ -1135,6 +1135,17 @@ VARIANTS = {      # name: (control file, program, (text, replacement) ...)
     "M1a fix_omega ignored": ("hiv_ns1.ctl", "codeml", ("fix_omega = 0", "fix_omega = 1")),
     "M7 fix_omega ignored": ("hiv_ns7.ctl", "codeml", ("fix_omega = 0", "fix_omega = 1")),
 }
+VARIANTS.update({
+    "clade model C, last omega fixed": ("ecp_cmc.ctl", "codeml", ("fix_omega = 0", "fix_omega = 1")),
+    "M3 with 5 classes": ("hiv_ns3.ctl", "codeml", ("ncatG = 3", "ncatG = 5")),
+    "M7 with 5 classes": ("hiv_ns7.ctl", "codeml", ("ncatG = 10", "ncatG = 5")),
+    "M0 + gamma": ("hiv_ns0.ctl", "codeml", ("ncatG = 10", "ncatG = 4\n fix_alpha = 0\n alpha = 0.7")),
+    "baseml alpha fixed": ("brown_hky85_g4.ctl", "baseml", ("fix_alpha = 0.5", "fix_alpha = 1")),
+    "mt code, M8 with 5 classes": ("mtcdna_m0.ctl", "codeml", ("NSsites = 0", "NSsites = 8\n ncatG = 5")),
+    "aa model without gamma": ("stewart_lg_g4.ctl", "codeml", ("fix_alpha = 0", "fix_alpha = 1"), ("alpha = 0.5", "alpha = 0")),
+    # an option given twice: the later line wins (the reference reads the control file line by line)
+    "Mgene = 3 + gamma, options repeated": ("horai_mg3.ctl", "baseml", ("Mgene = 3", "Mgene = 3\n fix_alpha = 0\n alpha = 0.5\n ncatG = 4")),
+})
 VARIANTS.update({"baseml model = %d" % m: ("brown_hky85_g4.ctl", "baseml", ("model = 4", "model = %d" % m)) for m in range(9)})
 VARIANTS.update({"aa model = %d" % m: ("stewart_lg_g4.ctl", "codeml", ("model = 2", "model = %d" % m)) for m in range(4)})
 VARIANTS.update({"CodonFreq = %d, M0" % c: ("hiv_ns0.ctl", "codeml", ("CodonFreq = 2", "CodonFreq = %d" % c)) for c in (0, 1, 3)})
