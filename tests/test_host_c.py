@@ -1143,6 +1143,16 @@ VARIANTS.update({
     "baseml alpha fixed": ("brown_hky85_g4.ctl", "baseml", ("fix_alpha = 0.5", "fix_alpha = 1")),
     "mt code, M8 with 5 classes": ("mtcdna_m0.ctl", "codeml", ("NSsites = 0", "NSsites = 8\n ncatG = 5")),
     "aa model without gamma": ("stewart_lg_g4.ctl", "codeml", ("fix_alpha = 0", "fix_alpha = 1"), ("alpha = 0.5", "alpha = 0")),
+    "branch-site model B": ("lyso_bsa.ctl", "codeml", ("NSsites = 2", "NSsites = 3")),
+    "F3x4MG + M2a": ("hiv_ns2.ctl", "codeml", ("CodonFreq = 2", "CodonFreq = 5")),
+    "F1x4MG + M7": ("hiv_ns7.ctl", "codeml", ("CodonFreq = 2", "CodonFreq = 4")),
+    "aaDist = 2 (Miyata, geometric)": ("mtcdnapri_aadist1.ctl", "codeml", ("aaDist = 1", "aaDist = 2")),
+    "aaDist = -1 (Grantham, linear)": ("mtcdnapri_aadist1.ctl", "codeml", ("aaDist = 1", "aaDist = -1")),
+    "nhomo = 1 with REV": ("brown_hky85_nhomo1.ctl", "baseml", ("model = 4", "model = 7")),
+    "nhomo = 2 with F84": ("brown_hky85_nhomo2.ctl", "baseml", ("model = 4", "model = 3")),
+    "Mgene = 4 with REV": ("horai_mg4.ctl", "baseml", ("model = 4", "model = 7")),
+    "Mgene = 2 with TN93": ("horai_mg2.ctl", "baseml", ("model = 4", "model = 6")),
+    "Mgene = 3, codons, F1x4": ("lysin_mg3.ctl", "codeml", ("CodonFreq = 2", "CodonFreq = 1")),
     # an option given twice: the later line wins (the reference reads the control file line by line)
     "Mgene = 3 + gamma, options repeated": ("horai_mg3.ctl", "baseml", ("Mgene = 3", "Mgene = 3\n fix_alpha = 0\n alpha = 0.5\n ncatG = 4")),
 })
