@@ -1,4 +1,4 @@
-// device_common.h — device-side definitions shared by the ahead-of-time kernels (kernels.h) and the
+// device_common.h — device-side definitions shared by the ahead-of-time kernels (kernels_*.h) and the
 // per-tree specialised kernels that jit.h generates and compiles with hiprtc.  No host/STL headers here.
 #pragma once
 #ifndef __HIPCC_RTC__   // hiprtc pre-includes the HIP device runtime

@@ -1,0 +1,102 @@
+// engine_comm.hip — site patterns sharded over several GPUs: shard bounds, the RCCL communicator of the ranks' engines.
+// Built for gfx950 only (one of the translation units of libpaml_amd.so, see engine_state.h).
+#include "engine_state.h"
+
+extern "C" {
+
+// ---- pattern shards over several GPUs ---------------------------------------------------------------------------------
+int paml_amd_device_count(void)
+{
+   int n = 0;
+   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int paml_amd_set_device(int device) { return hipSetDevice(device) == hipSuccess ? 0 : PAML_AMD_EHIP; }
+
+int paml_amd_shard_bounds(long n_patt_global, int world, int rank, long *first, long *count)
+{
+   if (n_patt_global < 1 || world < 1 || rank < 0 || rank >= world || !first || !count) return PAML_AMD_EINVAL;
+   const long chunk = red_chunk(n_patt_global), nb = (n_patt_global + chunk - 1) / chunk;
+   const long c0 = nb * rank / world, c1 = nb * (rank + 1) / world;      // chunks [c0, c1): as even as whole chunks allow
+   *first = std::min(n_patt_global, c0 * chunk);
+   *count = std::min(n_patt_global, c1 * chunk) - *first;
+   return 0;
+}
+
+int paml_amd_comm_unique_id(void *id128)
+{
+   if (!id128) return PAML_AMD_EINVAL;
+   static_assert(sizeof(ncclUniqueId) == PAML_AMD_COMM_ID_BYTES, "paml_amd.h states the size of ncclUniqueId");
+   if (!rccl().load()) return PAML_AMD_EUNSUPPORTED;
+   ncclUniqueId id;
+   if (rccl().GetUniqueId(&id) != ncclSuccess) return PAML_AMD_EHIP;
+   memcpy(id128, &id, sizeof(id));
+   return 0;
+}
+
+int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id128, long n_patt_global, long first_pattern)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return fail(e, PAML_AMD_EINVAL, "comm_init: bad arguments");
+   if (e->comm) return fail(e, PAML_AMD_EINVAL, "comm_init: the engine already has a communicator");
+   const int chunk = red_chunk(n_patt_global);
+   if (first_pattern < 0 || first_pattern + e->n_patt > n_patt_global || first_pattern % chunk != 0 ||
+       (first_pattern + e->n_patt != n_patt_global && e->n_patt % chunk != 0))
+      return fail(e, PAML_AMD_EINVAL, "comm_init: the shard must start and (unless it is the last) end at multiples of " +
+                                         std::to_string(chunk) + " patterns (paml_amd_shard_bounds)");
+   HIPCHK(hipStreamSynchronize(e->stream));
+   if (id128) {      // world == 1 with an id: a one-rank communicator (exercises the collective path on a single GPU)
+      if (!rccl().load()) return fail(e, PAML_AMD_EUNSUPPORTED, "comm_init: " + rccl().err);
+      ncclUniqueId id;
+      memcpy(&id, id128, sizeof(id));
+      const ncclResult_t nr = rccl().CommInitRank(&e->comm, world, id, rank);
+      if (nr != ncclSuccess) {
+         e->comm = nullptr;
+         return fail(e, PAML_AMD_EHIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(nr));
+      }
+   }
+   e->rank = rank; e->world = world;
+   e->n_patt_global = n_patt_global; e->first_patt = first_pattern;
+   e->chunk = chunk;
+   e->nb_global = (int)((n_patt_global + chunk - 1) / chunk);
+   e->first_chunk = (int)(first_pattern / chunk);
+   e->d_partial.release();      // re-zeroed at its new size by the next evaluation
+   return 0;
+}
+
+int paml_amd_comm_destroy(paml_amd_engine *e)
+{
+   if (e) e->pipe_ok = false;
+   if (!e) return PAML_AMD_EINVAL;
+   HIPCHK(hipStreamSynchronize(e->stream));
+   if (e->comm) (void)rccl().CommDestroy(e->comm);
+   e->comm = nullptr;
+   e->rank = 0; e->world = 1; e->n_patt_global = e->n_patt; e->first_patt = 0;
+   e->chunk = red_chunk(e->n_patt); e->nb_global = (e->n_patt + e->chunk - 1) / e->chunk; e->first_chunk = 0;
+   e->d_partial.release();
+   return 0;
+}
+
+int paml_amd_get_partial_sums(paml_amd_engine *e, double *out, int cap)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !out) return fail(e, PAML_AMD_EINVAL, "get_partial_sums: null argument");
+   if (e->n_eval == 0 || !e->d_partial.p || cap < e->nb_global) return fail(e, PAML_AMD_EINVAL, "get_partial_sums: nothing evaluated yet, or cap < number of chunks");
+   const double *src = e->comm ? e->d_partial_tot.p : e->d_partial.p;
+   HIPCHK(hipMemcpyAsync(out, src, (size_t)e->nb_global * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return e->nb_global;
+}
+
+int paml_amd_comm_info(const paml_amd_engine *e, int *rank, int *world, long *n_patt_global, long *first_pattern, int *chunk)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   if (rank) *rank = e->rank;
+   if (world) *world = e->world;
+   if (n_patt_global) *n_patt_global = e->n_patt_global;
+   if (first_pattern) *first_pattern = e->first_patt;
+   if (chunk) *chunk = e->chunk;
+   return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,434 @@
+// engine_core.hip — life cycle of the engine and its data: create / destroy, set_tips / set_tree / set_pi / set_eigen_* / set_classes,
+// read-back of P(t), partials and scale factors (parity / debugging), stage timing, counters.
+// Built for gfx950 only (one of the translation units of libpaml_amd.so, see engine_state.h).
+#include "engine_state.h"
+
+extern "C" {
+
+int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt, int max_classes, int n_genes,
+                    unsigned flags)
+{
+   if (!out) return PAML_AMD_EINVAL;
+   *out = nullptr;
+   if (n_states < 2 || n_states > 64 || n_tips < 2 || n_patt < 1 || max_classes < 1 || n_genes < 1) return PAML_AMD_EINVAL;
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return PAML_AMD_EHIP;   // no CPU fallback, by design
+   paml_amd_engine *e = new (std::nothrow) paml_amd_engine();
+   if (!e) return PAML_AMD_ENOMEM;
+   e->n = n_states; e->n_tips = n_tips; e->n_patt = n_patt; e->max_classes = max_classes; e->n_genes = n_genes;
+   e->flags = flags;
+   e->env.read();
+   if (hipGetDevice(&e->device) != hipSuccess ||
+       hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || e->n_cu < 1) {
+      delete e;
+      return PAML_AMD_EHIP;
+   }
+   e->n_patt_global = n_patt;
+   e->chunk = red_chunk(n_patt);
+   e->nb_global = (n_patt + e->chunk - 1) / e->chunk;
+   {  // per-tree specialised kernels: on request, or by default once the data set is large enough to repay the compile
+      const char *j = getenv("PAML_AMD_JIT");
+      e->jit_enabled = (flags & PAML_AMD_JIT) != 0 || (j && j[0] == '1') || (!j && (long)n_patt * max_classes >= 65536);
+      e->jit_forced = (flags & PAML_AMD_JIT) != 0 || (j && j[0] == '1');
+      if (j && j[0] == '0') e->jit_enabled = false;
+   }
+   // 20 states: the specialised MFMA kernel trimmed to 2 row blocks x 5 k-blocks beats the scalar-operand kernel 2-3x; the
+   // MFMA interpreters (64 MFMAs per product whatever n) do not, so small or keep-partials engines stay on valu20
+   // 20 states: the per-tree kernel on v_mfma_f64_4x4x4 (no padding: 25 block products per 16 patterns) for one gene and trees whose
+   // internal branches' P(t) fit in LDS; else the 16x16x4 kernel trimmed to 2 row blocks x 5 k-blocks (2-3x the scalar-operand
+   // kernel); the MFMA interpreters (64 MFMAs per product whatever n) do not pay, so small or keep-partials engines stay on valu20
+   e->want_m20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_genes == 1 && n_tips <= 49 && !e->env.no_m20 && !e->env.valu20;
+   const bool mfma20 = n_states == 20 && !e->want_m20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_tips <= 95 && !e->env.valu20;
+   if (n_states == 4) e->kk = KK_VALU4;
+   else if (n_states == 5) e->kk = KK_VALU5;
+   else if (n_states == 20 && !mfma20) e->kk = KK_VALU20;
+   else e->kk = KK_MFMA64;
+   e->mfma_dma = n_tips <= MFMA_ZT && !e->env.force_gather;
+   e->mfma_waves = e->mfma_dma ? DMA_WAVES : GATHER_WAVES;
+   e->tile_patt = e->kk == KK_MFMA64 ? e->mfma_waves * 16 : 256;
+   *out = e;
+   return 0;
+}
+
+void paml_amd_destroy(paml_amd_engine *e)
+{
+   if (!e) return;
+   (void)hipStreamSynchronize(e->stream);
+   if (e->jit_job && e->jit_job->th.joinable()) e->jit_job->th.join();
+   if (e->s2) {
+      (void)hipStreamSynchronize(e->s2);
+      (void)hipStreamDestroy(e->s2);
+      for (hipEvent_t ev : {e->ev_entry[0], e->ev_entry[1], e->ev_pmat}) if (ev) (void)hipEventDestroy(ev);
+   }
+   delete e;
+}
+
+const char *paml_amd_last_error(const paml_amd_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+const char *paml_amd_kernel_name(const paml_amd_engine *e)
+{
+   if (!e) return "";
+   switch (e->kk) {
+   case KK_VALU4: return e->use_jit ? (e->fused && e->fused_mfma4 ? "mfma4_jit" : "valu4_jit") : "valu4";
+   case KK_VALU5: return e->use_jit ? "valu5_jit" : "valu5";
+   case KK_VALU20: return e->use_jit ? (e->m20 ? "mfma4x20_jit" : "valu20_jit") : "valu20";
+   default: return e->use_jit ? "mfma64_jit" : (e->mfma_dma ? "mfma64_stream" : "mfma64_gather");
+   }
+}
+
+int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream)
+{
+   if (e) e->pipe_ok = false;
+   if (!e) return PAML_AMD_EINVAL;
+   (void)hipStreamSynchronize(e->stream);
+   e->stream = (hipStream_t)hip_stream;
+   return 0;
+}
+
+int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata, int n_codes, const int *n_chara,
+                      const unsigned char *chara_map, const double *weights, const int *gene_off)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !z || !weights) return fail(e, PAML_AMD_EINVAL, "set_tips: null argument");
+   const int n = e->n;
+   std::vector<int> nch;
+   std::vector<unsigned char> cmap;
+   if (cleandata || !n_chara || !chara_map) {
+      if (!cleandata) return fail(e, PAML_AMD_EINVAL, "set_tips: cleandata=0 needs n_chara/chara_map");
+      n_codes = n;
+      nch.assign(n, 1);
+      cmap.assign((size_t)n * n, 0);
+      for (int i = 0; i < n; i++) cmap[(size_t)i * n] = (unsigned char)i;
+   }
+   else {
+      if (n_codes < 1 || n_codes > 256) return fail(e, PAML_AMD_EINVAL, "set_tips: n_codes out of range");
+      nch.assign(n_chara, n_chara + n_codes);
+      cmap.assign(chara_map, chara_map + (size_t)n_codes * n);
+      for (int c = 0; c < n_codes; c++) {
+         if (nch[c] < 0 || nch[c] > n) return fail(e, PAML_AMD_EINVAL, "set_tips: n_chara out of range");
+         for (int k = 0; k < nch[c]; k++)
+            if (cmap[(size_t)c * n + k] >= n) return fail(e, PAML_AMD_EINVAL, "set_tips: chara_map state out of range");
+      }
+   }
+   const size_t nz = (size_t)e->n_tips * e->n_patt;
+   for (size_t i = 0; i < nz; i++)
+      if (z[i] >= n_codes) return fail(e, PAML_AMD_EINVAL, "set_tips: character code >= n_codes");
+   e->cleandata = cleandata ? 1 : 0;
+   e->n_codes = n_codes;
+   e->gene_off.assign(e->n_genes + 1, 0);
+   if (gene_off) e->gene_off.assign(gene_off, gene_off + e->n_genes + 1);
+   else {
+      if (e->n_genes != 1) return fail(e, PAML_AMD_EINVAL, "set_tips: gene_off required when n_genes > 1");
+      e->gene_off[1] = e->n_patt;
+   }
+   if (e->gene_off[0] != 0 || e->gene_off[e->n_genes] != e->n_patt)
+      return fail(e, PAML_AMD_EINVAL, "set_tips: gene_off must span [0, n_patt]");
+   for (int g = 0; g < e->n_genes; g++)
+      if (e->gene_off[g + 1] < e->gene_off[g]) return fail(e, PAML_AMD_EINVAL, "set_tips: gene_off must not decrease");      // (a pattern shard may hold nothing of a gene)
+   HIPCHK(upload(e->d_z, z, nz, e->stream));
+   HIPCHK(upload(e->d_weights, weights, (size_t)e->n_patt, e->stream));
+   HIPCHK(upload(e->d_n_chara, nch.data(), nch.size(), e->stream));
+   HIPCHK(upload(e->d_chara_map, cmap.data(), cmap.size(), e->stream));
+   HIPCHK(upload(e->d_gene_off, e->gene_off.data(), e->gene_off.size(), e->stream));
+   if (e->kk == KK_VALU4 || e->kk == KK_VALU5 || e->kk == KK_VALU20) {      // pattern-major copy of the codes for the per-tree kernels
+      e->zpm_words = ((e->n_tips + 3) / 4 + 3) / 4 * 4;
+      HIPCHK(e->d_zpm.ensure((size_t)e->n_patt * e->zpm_words));
+      launch_zpm(e->d_z.p, (long)e->n_patt, e->n_tips, e->n_patt, e->zpm_words, e->d_zpm.p, e->stream);
+   }
+   HIPCHK(hipStreamSynchronize(e->stream));
+   int r = build_tiles(e);
+   if (r) return r;
+   {  // state sets of the character codes as bit masks (tip ends of a branch in the branch-local evaluation)
+      std::vector<unsigned long long> mask(n_codes, 0);
+      for (int c = 0; c < n_codes; c++)
+         for (int k = 0; k < nch[c]; k++) mask[c] |= 1ull << cmap[(size_t)c * n + k];
+      HIPCHK(upload(e->d_code_mask, mask.data(), mask.size(), e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+   }
+   e->have_tips = true;
+   e->partials_valid = false;
+   e->bl.valid = false;
+   return 0;
+}
+
+int paml_amd_set_tree(paml_amd_engine *e, int n_nodes, int root, const int *sons_ptr, const int *sons, const int *label,
+                      const unsigned char *scale_node)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !sons_ptr || !sons) return fail(e, PAML_AMD_EINVAL, "set_tree: null argument");
+   if (n_nodes <= e->n_tips || root < 0 || root >= n_nodes) return fail(e, PAML_AMD_EINVAL, "set_tree: bad sizes");
+   TreeDesc t;
+   t.n_tips = e->n_tips; t.n_nodes = n_nodes; t.root = root;
+   t.sons_ptr.assign(sons_ptr, sons_ptr + n_nodes + 1);
+   if (t.sons_ptr[0] != 0) return fail(e, PAML_AMD_EINVAL, "set_tree: sons_ptr[0] != 0");
+   for (int i = 0; i < n_nodes; i++)
+      if (t.sons_ptr[i + 1] < t.sons_ptr[i]) return fail(e, PAML_AMD_EINVAL, "set_tree: sons_ptr not monotone");
+   t.sons.assign(sons, sons + t.sons_ptr[n_nodes]);
+   std::vector<int> seen(n_nodes, 0);
+   for (int s : t.sons) {
+      if (s < 0 || s >= n_nodes || s == root || seen[s]++) return fail(e, PAML_AMD_EINVAL, "set_tree: bad son index");
+   }
+   for (int i = 0; i < n_nodes; i++) {
+      if (i != root && !seen[i]) return fail(e, PAML_AMD_EINVAL, "set_tree: node without father");
+      if (i >= e->n_tips && t.is_leaf(i)) return fail(e, PAML_AMD_EINVAL, "set_tree: internal node without sons");
+      if (i < e->n_tips && i != root && !t.is_leaf(i)) return fail(e, PAML_AMD_EINVAL, "set_tree: tip with sons");
+   }
+   t.label.assign(n_nodes, 0);
+   if (label) t.label.assign(label, label + n_nodes);
+   t.scale_node.assign(n_nodes, 0);
+   t.scale_slot.assign(n_nodes, -1);
+   if (scale_node) {
+      for (int i = 0; i < n_nodes; i++) {
+         t.scale_node[i] = scale_node[i] ? 1 : 0;
+         if (t.scale_node[i]) t.scale_slot[i] = t.n_scale++;
+      }
+   }
+   std::vector<unsigned char> leaf(n_nodes);
+   for (int i = 0; i < n_nodes; i++) leaf[i] = t.is_leaf(i) ? 1 : 0;
+   e->tree = std::move(t);
+   HIPCHK(upload(e->d_label, e->tree.label.data(), e->tree.label.size(), e->stream));
+   HIPCHK(upload(e->d_is_leaf, leaf.data(), leaf.size(), e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   e->have_tree = true;
+   e->prog_valid = false;
+   e->partials_valid = false;
+   e->bl.valid = false;
+   return 0;
+}
+
+int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !pi || (n_pi != 1 && n_pi != e->n_genes)) return fail(e, PAML_AMD_EINVAL, "set_pi: bad arguments");
+   const int n = e->n;
+   std::vector<double> buf;
+   if (e->kk == KK_MFMA64) {
+      buf.assign((size_t)n_pi * 64, 0.0);
+      for (int g = 0; g < n_pi; g++)
+         for (int j = 0; j < n; j++) buf[(size_t)g * 64 + (j & 3) * 16 + (j >> 2)] = pi[(size_t)g * n + j];
+   }
+   else
+      buf.assign(pi, pi + (size_t)n_pi * n);
+   HIPCHK(upload(e->d_pi, buf.data(), buf.size(), e->stream));
+   HIPCHK(upload(e->d_pi_plain, pi, (size_t)n_pi * n, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   e->n_pi = n_pi;
+   e->have_pi = true;
+   return 0;
+}
+
+static EigenHost *eigen_slot(paml_amd_engine *e, int set_id)
+{
+   if (!e || set_id < 0 || set_id > 4096) return nullptr;
+   if ((size_t)set_id >= e->eigen.size()) e->eigen.resize(set_id + 1);
+   e->eigen_dirty = true;
+   e->partials_valid = false;
+   e->bl.valid = false;
+   return &e->eigen[set_id];
+}
+
+int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, const double *V, const double *Root)
+{
+   if (e) e->pipe_ok = false;
+   EigenHost *h = eigen_slot(e, set_id);
+   if (!h || !U || !V || !Root) return fail(e, PAML_AMD_EINVAL, "set_eigen_uvroot: bad arguments");
+   const size_t n = e->n;
+   HIPCHK(upload(h->U, U, n * n, e->stream));
+   HIPCHK(upload(h->V, V, n * n, e->stream));
+   HIPCHK(upload(h->Root, Root, n, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   h->kind = PAML_AMD_EIGEN_UVROOT;
+   return 0;
+}
+
+int paml_amd_set_eigen_cijk(paml_amd_engine *e, int set_id, int nR, const double *Cijk, const double *Root)
+{
+   if (e) e->pipe_ok = false;
+   EigenHost *h = eigen_slot(e, set_id);
+   if (!h || !Cijk || !Root || nR < 1 || nR > 64) return fail(e, PAML_AMD_EINVAL, "set_eigen_cijk: bad arguments");
+   const size_t n = e->n;
+   HIPCHK(upload(h->Cijk, Cijk, n * n * nR, e->stream));
+   HIPCHK(upload(h->Root, Root, (size_t)nR, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   h->kind = PAML_AMD_EIGEN_CIJK;
+   h->nR = nR;
+   return 0;
+}
+
+int paml_amd_set_eigen_k80(paml_amd_engine *e, int set_id, double kappa)
+{
+   if (e) e->pipe_ok = false;
+   if (e && e->n != 4) return fail(e, PAML_AMD_EINVAL, "set_eigen_k80: needs 4 states");
+   EigenHost *h = eigen_slot(e, set_id);
+   if (!h) return fail(e, PAML_AMD_EINVAL, "set_eigen_k80: bad arguments");
+   h->kind = PAML_AMD_EIGEN_K80;
+   h->kappa = kappa;
+   return 0;
+}
+
+int paml_amd_set_eigen_jc69like(paml_amd_engine *e, int set_id)
+{
+   if (e) e->pipe_ok = false;
+   EigenHost *h = eigen_slot(e, set_id);
+   if (!h) return fail(e, PAML_AMD_EINVAL, "set_eigen_jc69like: bad arguments");
+   h->kind = PAML_AMD_EIGEN_JC69LIKE;
+   return 0;
+}
+
+int paml_amd_set_eigen_qmat(paml_amd_engine *e, int set_id, const double *Q)
+{
+   if (e) e->pipe_ok = false;
+   EigenHost *h = eigen_slot(e, set_id);
+   if (!h || !Q) return fail(e, PAML_AMD_EINVAL, "set_eigen_qmat: bad arguments");
+   if (e->n > 8) return fail(e, PAML_AMD_EUNSUPPORTED, "set_eigen_qmat: at most 8 states");
+   HIPCHK(upload(h->U, Q, (size_t)e->n * e->n, e->stream));      // the U slot carries Q
+   HIPCHK(hipStreamSynchronize(e->stream));
+   h->kind = PAML_AMD_EIGEN_QMAT;
+   return 0;
+}
+
+int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freqK, const double *rate, int n_labels,
+                         const int *eigen_of, const double *qfactor)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || K < 1 || K > e->max_classes || n_labels < 1 || !eigen_of)
+      return fail(e, PAML_AMD_EINVAL, "set_classes: bad arguments");
+   if (mode != PAML_AMD_MODE_LFUN && mode != PAML_AMD_MODE_LFUNDG) return fail(e, PAML_AMD_EINVAL, "set_classes: bad mode");
+   if (mode == PAML_AMD_MODE_LFUN && K != 1) return fail(e, PAML_AMD_EINVAL, "set_classes: lfun mode needs K = 1");
+   if (e->have_tree)
+      for (int lab : e->tree.label)
+         if (lab < 0 || lab >= n_labels) return fail(e, PAML_AMD_EINVAL, "set_classes: tree label >= n_labels");
+   std::vector<double> f(K, 1.0), r(K, 1.0), q((size_t)K * n_labels, 1.0);
+   if (freqK) f.assign(freqK, freqK + K);
+   if (rate) r.assign(rate, rate + K);
+   if (qfactor) q.assign(qfactor, qfactor + (size_t)K * n_labels);
+   HIPCHK(upload(e->d_freqK, f.data(), f.size(), e->stream));
+   HIPCHK(upload(e->d_rate, r.data(), r.size(), e->stream));
+   e->rate_per_gene = false;
+   HIPCHK(upload(e->d_qfactor, q.data(), q.size(), e->stream));
+   HIPCHK(upload(e->d_eigen_of, eigen_of, (size_t)e->n_genes * K * n_labels, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   e->mode = mode; e->K = K; e->n_labels = n_labels;
+   e->have_classes = true;
+   e->partials_valid = false;
+   e->bl.valid = false;
+   return 0;
+}
+
+int paml_amd_set_gene_class_rates(paml_amd_engine *e, const double *rate)
+{
+   if (!e || !e->have_classes) return fail(e, PAML_AMD_EINVAL, "set_gene_class_rates before set_classes");
+   e->pipe_ok = false;
+   if (!rate) { e->rate_per_gene = false; return 0; }      // back to the rates of set_classes needs a new set_classes
+   HIPCHK(upload(e->d_rate, rate, (size_t)e->n_genes * e->K, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   e->rate_per_gene = true;
+   e->partials_valid = false;
+   e->bl.valid = false;
+   return 0;
+}
+
+int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double *P)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !P || !e->d_rowmajor.p) return fail(e, PAML_AMD_EINVAL, "get_pmat: nothing evaluated yet");
+   if (!e->pmat_valid)
+      return fail(e, PAML_AMD_EINVAL, "get_pmat: the P(t) buffers hold the re-rooted matrices of eval_branch / node_posterior; run an evaluation first");
+   if (gene < 0 || gene >= e->n_genes || iclass < 0 || iclass >= e->K || node < 0 || node >= e->tree.n_nodes ||
+       node == e->tree.root)
+      return fail(e, PAML_AMD_EINVAL, "get_pmat: index out of range");
+   const size_t nn2 = (size_t)e->n * e->n;
+   const double *src = e->d_rowmajor.p + ((size_t)(gene * e->K + iclass) * e->tree.n_nodes + node) * nn2;
+   HIPCHK(hipMemcpyAsync(P, src, nn2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
+int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !conP) return fail(e, PAML_AMD_EINVAL, "get_partials: null argument");
+   if (!(e->flags & PAML_AMD_KEEP_PARTIALS) || !e->partials_valid)
+      return fail(e, PAML_AMD_EINVAL, "get_partials: needs PAML_AMD_KEEP_PARTIALS and a completed evaluation");
+   if (node < e->n_tips || node >= e->tree.n_nodes || iclass < 0 || iclass >= e->K)
+      return fail(e, PAML_AMD_EINVAL, "get_partials: index out of range");
+   const int n = e->n, n_int = e->tree.n_nodes - e->n_tips;
+   if (e->kk != KK_MFMA64) {
+      const double *src = e->d_partials.p + ((size_t)iclass * n_int + (node - e->n_tips)) * e->n_patt * n;
+      HIPCHK(hipMemcpyAsync(conP, src, (size_t)e->n_patt * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      return 0;
+   }
+   const int MW = e->mfma_waves;
+   const size_t groups = (size_t)e->n_tiles * MW;
+   std::vector<double> raw(groups * 1024);
+   const double *src = e->d_partials.p + ((size_t)iclass * n_int + (node - e->n_tips)) * groups * 1024;
+   HIPCHK(hipMemcpyAsync(raw.data(), src, raw.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   // native [group][m][lane] -> [h][state]; lane = (state & 3) * 16 + (h & 15), m = state >> 2
+   std::vector<int2> tiles;
+   for (int g = 0; g < e->n_genes; g++)
+      for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += e->tile_patt) tiles.push_back(make_int2(g, h));
+   for (size_t t = 0; t < tiles.size(); t++) {
+      const int hend = e->gene_off[tiles[t].x + 1];
+      for (int w = 0; w < MW; w++)
+         for (int hl = 0; hl < 16; hl++) {
+            const int h = tiles[t].y + w * 16 + hl;
+            if (h >= hend) continue;
+            const double *grp = raw.data() + (t * MW + w) * 1024;
+            for (int j = 0; j < n; j++) conP[(size_t)h * n + j] = grp[(j >> 2) * 64 + (j & 3) * 16 + hl];
+         }
+   }
+   return 0;
+}
+
+int paml_amd_get_scale(paml_amd_engine *e, int node, int iclass, double *scale)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !scale) return fail(e, PAML_AMD_EINVAL, "get_scale: null argument");
+   if (!(e->flags & PAML_AMD_KEEP_PARTIALS) || !e->partials_valid)
+      return fail(e, PAML_AMD_EINVAL, "get_scale: needs PAML_AMD_KEEP_PARTIALS and a completed evaluation");
+   if (node < 0 || node >= e->tree.n_nodes || iclass < 0 || iclass >= e->K || e->tree.scale_slot[node] < 0)
+      return fail(e, PAML_AMD_EINVAL, "get_scale: not a scaling node");
+   const double *src = e->d_scalef.p + ((size_t)iclass * e->tree.n_scale + e->tree.scale_slot[node]) * e->n_patt;
+   HIPCHK(hipMemcpyAsync(scale, src, (size_t)e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
+int paml_amd_profile(paml_amd_engine *e, int enable)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   e->profiling = enable != 0;
+   return 0;
+}
+
+int paml_amd_profile_read(paml_amd_engine *e, double *ms_pmat, double *ms_prune, double *ms_reduce, long *n_evals)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   HIPCHK(hipStreamSynchronize(e->stream));
+   double acc[3] = {0, 0, 0};
+   for (size_t i = 0; i + 5 < e->ev_used.size(); i += 6)
+      for (int k = 0; k < 3; k++) {
+         float ms = 0;
+         if (hipEventElapsedTime(&ms, e->ev_used[i + 2 * k], e->ev_used[i + 2 * k + 1]) == hipSuccess) acc[k] += ms;
+      }
+   for (auto ev : e->ev_used) e->ev_pool.push_back(ev);
+   e->ev_used.clear();
+   if (ms_pmat) *ms_pmat = acc[0];
+   if (ms_prune) *ms_prune = acc[1];
+   if (ms_reduce) *ms_reduce = acc[2];
+   if (n_evals) *n_evals = e->prof_evals;
+   e->prof_evals = 0;
+   return 0;
+}
+
+int paml_amd_counters(const paml_amd_engine *e, long *n_eval, long *n_pmat)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   if (n_eval) *n_eval = e->n_eval;
+   if (n_pmat) *n_pmat = e->n_pmat;
+   return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,627 @@
+// engine_eval.hip — one likelihood evaluation: batched P(t) (Kernel A), the fused pruning kernel chosen for the problem (Kernel B:
+// per-tree specialised, streamed or full interpreter), the reduction (Kernel C) and the exchange step over the ranks; and the
+// entry points built on it (paml_amd_eval, _eval_batch, _eval_device, _eval_dirty, _eval_adg).
+// Built for gfx950 only (one of the translation units of libpaml_amd.so, see engine_state.h).
+#include "engine_state.h"
+#include "kernels_pmat.h"
+#include "kernels_prune.h"
+#include "kernels_reduce.h"
+
+namespace paml_amd {
+
+int build_tiles(paml_amd_engine *e)
+{
+   std::vector<int2> tiles;
+   for (int g = 0; g < e->n_genes; g++)
+      for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += e->tile_patt) tiles.push_back(make_int2(g, h));
+   e->n_tiles = (int)tiles.size();
+   HIPCHK(upload(e->d_tiles, tiles.data(), tiles.size(), e->stream));
+   const int tf = e->kk == KK_MFMA64 ? GATHER_WAVES * 16 : 256;
+   std::vector<int2> tfull;
+   for (int g = 0; g < e->n_genes; g++)
+      for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += tf) tfull.push_back(make_int2(g, h));
+   e->n_tiles_full = (int)tfull.size();
+   HIPCHK(upload(e->d_tiles_full, tfull.data(), tfull.size(), e->stream));
+   if (e->kk == KK_MFMA64 && e->tile_patt >= 128 && e->d_z.p && e->d_weights.p) {   // code blocks of the specialised kernel
+      e->zt_bytes = jit_zpieces(e->n_tips, e->tile_patt) * 2048;
+      HIPCHK(e->d_ztiles.ensure((size_t)e->n_tiles * e->zt_bytes));
+      hipLaunchKernelGGL(ztile_kernel, dim3(e->n_tiles), dim3(e->tile_patt), 0, e->stream, e->d_tiles.p, e->d_gene_off.p, e->d_z.p, (long)e->n_patt,
+                         e->d_weights.p, e->n_tips, e->zt_bytes, e->d_ztiles.p);
+   }
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
+// The one-pattern-per-lane interpreter: the register-stack instantiation that fits the program, else the scratch one.
+static void launch_valu(paml_amd_engine *e, int max_stack, int n_blocks, const PruneArgs &pr, hipStream_t s)
+{
+   const dim3 g(n_blocks), b(256);
+   switch (e->kk) {
+   case KK_VALU4:
+      if (max_stack <= 4) hipLaunchKernelGGL((prune_valu<4, 4, true>), g, b, 0, s, pr);
+      else hipLaunchKernelGGL((prune_valu<4, VALU_MAXD_SMALL>), g, b, 0, s, pr);
+      break;
+   case KK_VALU5:
+      if (max_stack <= 4) hipLaunchKernelGGL((prune_valu<5, 4, true>), g, b, 0, s, pr);
+      else hipLaunchKernelGGL((prune_valu<5, VALU_MAXD_SMALL>), g, b, 0, s, pr);
+      break;
+   default:      // 20 states: a register stack costs > 256 VGPRs (one wave per SIMD) and measures 2x slower than scratch
+      hipLaunchKernelGGL((prune_valu<20, VALU_MAXD_20>), g, b, 0, s, pr);
+      break;
+   }
+}
+
+void launch_pmat(const PmatArgs &pa, const InlineVec &iv, int n_nodes, int psets, bool small, hipStream_t s)
+{
+   if (small) hipLaunchKernelGGL(pmat_small_kernel, dim3((n_nodes * psets + 7) / 8), dim3(256), 0, s, pa, iv);
+   else hipLaunchKernelGGL(pmat_kernel, dim3(n_nodes, psets), dim3(256), 2 * 4096 * sizeof(double), s, pa, iv);
+}
+
+void launch_prune_full(paml_amd_engine *e, int max_stack, int n_blocks, const PruneArgs &pr, hipStream_t s)
+{
+   if (e->kk == KK_MFMA64) hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, s, pr);
+   else launch_valu(e, max_stack, n_blocks, pr, s);
+}
+
+void launch_zpm(const unsigned char *z, long z_stride, int n_tips, int n_patt, int zw, unsigned int *out, hipStream_t s)
+{
+   hipLaunchKernelGGL(zpm_kernel, dim3((n_patt + 255) / 256), dim3(256), 0, s, z, z_stride, n_tips, n_patt, zw, out);
+}
+
+// The specialised kernel for `key`: reuse the loaded module or generate + compile + load it.  A compile failure is
+// not fatal (the interpreter kernels take over) unless PAML_AMD_JIT_STRICT is set.
+template <class GEN>
+static int ensure_jit(paml_amd_engine *e, const std::string &key, GEN gen, bool *ok)
+{
+   *ok = false;
+   if (e->jit.fn && e->jit.key == key) { *ok = true; return 0; }
+   if (e->jit.mod) (void)hipModuleUnload(e->jit.mod);
+   e->jit = JitKernel();
+   std::string log;
+   const std::string src = gen();
+   if (!e->env.jit_dump.empty()) {
+      FILE *f = fopen(e->env.jit_dump.c_str(), "w");
+      if (f) { fputs(src.c_str(), f); fclose(f); }
+   }
+   if (jit_compile(src, &e->jit, &log) == 0) {
+      e->jit.key = key;
+      *ok = true;
+   }
+   else {
+      e->err = "jit: " + log;
+      if (e->env.jit_strict) return fail(e, PAML_AMD_EHIP, e->err);
+   }
+   return 0;
+}
+
+int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
+                double *d_lnL_out, bool want_lnf, const BatchSpec *bs, bool want_pipe, bool want_fhk)
+{
+   if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes))
+      return fail(e, PAML_AMD_EINVAL, "eval before set_tips/set_tree/set_pi/set_classes");
+   if (e->eigen.empty()) return fail(e, PAML_AMD_EINVAL, "eval before any set_eigen_*");
+   const bool keep = (e->flags & PAML_AMD_KEEP_PARTIALS) != 0;
+   if (clean && (!keep || !e->partials_valid))
+      return fail(e, PAML_AMD_EINVAL, "eval_dirty needs PAML_AMD_KEEP_PARTIALS and a previous full evaluation");
+   const int B = bs ? bs->B : 1, Km = e->K;          // Km: classes of the model; K: classes the kernels see
+   const int n = e->n, nn = e->tree.n_nodes, K = Km * B, G = e->n_genes;
+   const int psets = G * K;
+   if (B > 1 && (keep || clean)) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_batch: not with PAML_AMD_KEEP_PARTIALS");
+
+   // program (tree walk) — rebuilt when the tree or the clean set changes
+   const bool new_prog = !e->prog_valid || clean;
+   if (new_prog) {
+      e->prog = build_program(e->tree, keep, clean);
+      e->prog_valid = (clean == nullptr);
+      const int maxd = e->kk == KK_VALU20 ? VALU_MAXD_20 : VALU_MAXD_SMALL;
+      if (e->kk != KK_MFMA64 && e->prog.max_stack > maxd) {
+         e->prog_valid = false;
+         return fail(e, PAML_AMD_EUNSUPPORTED, "tree needs a deeper partial stack than this kernel provides");
+      }
+   }
+   // the fast path of consecutive eval_device calls (see pipe_ok): nothing but branch lengths / gene rates may have changed
+   // (worth its event traffic only where the pruning kernel is long: the 21..64-state kernels on >= 10^5 pattern-classes)
+   want_pipe = want_pipe && e->kk == KK_MFMA64 && (long)e->n_patt * e->K >= 100000;
+   const bool pipe = want_pipe && e->pipe_ok && !bs && !clean && !keep && !new_prog && !e->eigen_dirty && !e->env.no_pipeline;
+   if (want_pipe && !e->s2) {
+      HIPCHK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&e->ev_entry[0], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->ev_entry[1], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->ev_pmat, hipEventDisableTiming));
+   }
+   hipStream_t ps = e->stream;                    // stream of the uploads and of the P(t) kernel
+   if (pipe) {
+      // the side stream may overwrite the other P set once everything the main stream held in front of the PREVIOUS pruning
+      // kernel is done: that set's last reader (the kernel before it), and the previous evaluation's own uploads and P(t)
+      ps = e->s2;
+      if (e->have_prev_entry) HIPCHK(hipStreamWaitEvent(e->s2, e->ev_entry[e->entry_sel ^ 1], 0));
+   }
+   std::vector<EigenDev> tab;
+   if (e->eigen_dirty) {
+      tab.resize(e->eigen.size());
+      for (size_t i = 0; i < e->eigen.size(); i++) {
+         const EigenHost &h = e->eigen[i];
+         if (h.kind < 0) return fail(e, PAML_AMD_EINVAL, "eigen set " + std::to_string(i) + " was never set");
+         tab[i] = EigenDev{h.kind, h.nR, h.kappa, h.U.p, h.V.p, h.Root.p, h.Cijk.p};
+      }
+   }
+
+   // branch lengths and gene rates of a single evaluation ride in the kernel arguments of P(t) (InlineVec): no copy at all
+   InlineVec iv;
+   iv.n_branch = iv.n_rate = 0;
+   const bool use_inline = B == 1 && nn + G <= PMAT_INLINE_MAX;
+   if (use_inline) {
+      iv.n_branch = nn; iv.n_rate = G;
+      memcpy(iv.v, branch, (size_t)nn * sizeof(double));
+      for (int g = 0; g < G; g++) iv.v[nn + g] = gene_rate ? gene_rate[g] : 1.0;
+   }
+   // the other small inputs (and the batched ones) go through the pinned arena: async H2D, no host stall
+   if (!use_inline || bs || !tab.empty() || new_prog) {
+      const size_t L = (size_t)e->n_labels;
+      const size_t need = (size_t)B * nn * 8 + (size_t)B * G * 8 + tab.size() * sizeof(EigenDev) +
+                          (bs ? (size_t)B * (G * Km * L * 4 + Km * L * 8 + 2 * Km * 8) + 64 : 0) +
+                          (new_prog ? e->prog.ops.size() * sizeof(Op) + e->prog.stream.size() * sizeof(int) : 0) + 256;
+      HIPCHK(e->stage.begin(need));
+      DevBuf<double> &dbr = pipe ? e->d2_branch : e->d_branch, &dgr = pipe ? e->d2_gene_rate : e->d_gene_rate;   // (the side stream has its own)
+      HIPCHK(dbr.ensure((size_t)B * nn));
+      HIPCHK(dgr.ensure((size_t)B * G));
+      if (!use_inline) {
+         const double *hb = e->stage.put(branch, (size_t)B * nn);
+         HIPCHK(hipMemcpyAsync(dbr.p, hb, (size_t)B * nn * 8, hipMemcpyHostToDevice, ps));
+         std::vector<double> gr((size_t)B * G, 1.0);
+         if (gene_rate) gr.assign(gene_rate, gene_rate + (size_t)B * G);
+         const double *hg = e->stage.put(gr.data(), gr.size());
+         HIPCHK(hipMemcpyAsync(dgr.p, hg, gr.size() * 8, hipMemcpyHostToDevice, ps));
+      }
+      if (bs) {      // per-element class tables
+         if (bs->eigen_of) {
+            const size_t cnt = (size_t)B * G * Km * L;
+            for (size_t i = 0; i < cnt; i++)
+               if (bs->eigen_of[i] < 0 || bs->eigen_of[i] >= (int)e->eigen.size())
+                  return fail(e, PAML_AMD_EINVAL, "eval_batch: eigen_of entry out of range");
+            HIPCHK(e->d_b_eigen_of.ensure(cnt));
+            const int *h = e->stage.put(bs->eigen_of, cnt);
+            HIPCHK(hipMemcpyAsync(e->d_b_eigen_of.p, h, cnt * 4, hipMemcpyHostToDevice, e->stream));
+         }
+         const double *src[3] = {bs->qfactor, bs->freqK, bs->rate};
+         DevBuf<double> *dst[3] = {&e->d_b_qfactor, &e->d_b_freqK, &e->d_b_rate};
+         const size_t cnt[3] = {(size_t)B * Km * L, (size_t)B * Km, (size_t)B * Km * (e->rate_per_gene ? G : 1)};
+         for (int i = 0; i < 3; i++)
+            if (src[i]) {
+               HIPCHK(dst[i]->ensure(cnt[i]));
+               const double *h = e->stage.put(src[i], cnt[i]);
+               HIPCHK(hipMemcpyAsync(dst[i]->p, h, cnt[i] * 8, hipMemcpyHostToDevice, e->stream));
+            }
+      }
+      if (!tab.empty()) {
+         HIPCHK(e->d_eigen.ensure(tab.size()));
+         const EigenDev *ht = e->stage.put(tab.data(), tab.size());
+         HIPCHK(hipMemcpyAsync(e->d_eigen.p, ht, tab.size() * sizeof(EigenDev), hipMemcpyHostToDevice, e->stream));
+         e->eigen_dirty = false;
+      }
+      if (new_prog) {
+         HIPCHK(e->d_ops.ensure(e->prog.ops.size()));
+         const Op *ho = e->stage.put(e->prog.ops.data(), e->prog.ops.size());
+         HIPCHK(hipMemcpyAsync(e->d_ops.p, ho, e->prog.ops.size() * sizeof(Op), hipMemcpyHostToDevice, e->stream));
+         HIPCHK(e->d_stream.ensure(e->prog.stream.size() + 2));
+         if (!e->prog.stream.empty()) {
+            const int *hs = e->stage.put(e->prog.stream.data(), e->prog.stream.size());
+            HIPCHK(hipMemcpyAsync(e->d_stream.p, hs, e->prog.stream.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+         }
+      }
+      HIPCHK(e->stage.end(ps));
+   }
+
+   // P(t) storage (pipelined: the set the previous evaluation did not use)
+   if (pipe) {
+      std::swap(e->d_rowmajor, e->d2_rowmajor); std::swap(e->d_pint, e->d2_pint); std::swap(e->d_ptip, e->d2_ptip); std::swap(e->d_pcol, e->d2_pcol);
+   }
+   HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
+   if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
+   if (e->kk == KK_MFMA64) HIPCHK(e->d_pcol.ensure((size_t)psets * nn * 64));
+   HIPCHK(e->d_ptip.ensure((size_t)psets * nn * tip_words(e)));
+   HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
+   // kernel choice for the 21..64-state path:
+   //   jit    — straight-line kernel specialised for this tree (jit.h), 128 patterns per workgroup
+   //   stream — the interpreter over the same operand stream (lean programs only), 128 patterns per workgroup
+   //   gather — the full interpreter (keep-partials STORE/LOAD, deep stacks, > MFMA_ZT tips, > 64 codes), 64 per workgroup
+   if (e->kk == KK_MFMA64) {
+      bool lean = e->prog.max_stack <= MFMA_RS && e->n_tips <= MFMA_ZT && e->n_codes <= 64 && !e->env.force_gather;
+      // small data sets (at most a quarter of the CUs get a 128-pattern tile): the 64-pattern workgroups of the gather kernel —
+      // one wave per SIMD, twice as many workgroups — finish a tile in 0.63 of the time (13 taxa x 79 codon patterns: 42 against 66 us,
+      // a batched gradient of 25 evaluations 0.125 against 0.151 ms; profiles/r02_small_latency.jsonl)
+      if ((e->n_patt + 127) / 128 <= e->n_cu / 4 && !e->env.force_stream) lean = false;
+      for (const Op &o : e->prog.ops)
+         if (o.code == OP_PUSH || o.code == OP_SCALE || o.code == OP_STORE || o.code == OP_LOAD) lean = false;
+      bool jit_ok = false;
+      // waves per workgroup of the per-tree kernel: 8 (two per SIMD, 128 patterns per tile).  PAML_AMD_JIT_WAVES=12 builds the
+      // three-per-SIMD variant (192-pattern tiles, <= 168 VGPRs): measured SLOWER on MI355X (1.659 against 1.622 ms at C4, 4.73 against
+      // 4.63 ms with three classes — 40 spilled dwords and a third more LDS / DMA traffic per step), kept as a generator parameter
+      int jw = 8;
+      if (e->env.jit_waves == 12 && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, 192) && jit_zbuffers(e->n_tips, 192) == 2) jw = 12;
+      if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16)) {
+         const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "w" + std::to_string(jw) + ":" + jit_program_key(e->prog, e->n_tips);
+         const bool background = e->prog.ops.size() > 120 &&      /* (roughly: more than 60 taxa, more than 3 s of compilation) */ !e->jit_forced && !e->env.jit_sync && !(e->jit.fn && e->jit.key == key);
+         if (!background) {
+            int r = ensure_jit(e, key, [&]() { return jit_generate(e->prog, e->n_tips, n, e->n_codes, jw); }, &jit_ok);
+            if (r) return r;
+         }
+         else {
+            paml_amd_engine::JitJob *job = e->jit_job.get();
+            if (job && job->state.load() >= 2 && job->th.joinable()) job->th.join();
+            if (job && job->state.load() == 2 && job->key == key) {          // the code object is there: load it and change over
+               if (e->jit.mod) (void)hipModuleUnload(e->jit.mod);
+               e->jit = JitKernel();
+               if (hipModuleLoadData(&e->jit.mod, job->code.data()) == hipSuccess && hipModuleGetFunction(&e->jit.fn, e->jit.mod, "prune_jit") == hipSuccess) {
+                  e->jit.key = key;
+                  jit_ok = true;
+               }
+               else e->jit_failed_key = key;
+               e->jit_job.reset();
+            }
+            else if (job && job->state.load() >= 2) {                        // failed, or compiled for another tree
+               if (job->state.load() == 3 && job->key == key) { e->jit_failed_key = key; e->err = "jit: " + job->log; }
+               e->jit_job.reset();
+               job = nullptr;
+            }
+            if (!jit_ok && !e->jit_job && e->jit_failed_key != key) {
+               e->jit_job.reset(new paml_amd_engine::JitJob());
+               job = e->jit_job.get();
+               job->key = key;
+               job->src = jit_generate(e->prog, e->n_tips, n, e->n_codes, jw);
+               job->state.store(1);
+               job->th = std::thread([job]() { job->state.store(jit_compile_code(job->src, &job->code, &job->log) == 0 ? 2 : 3); });
+            }
+         }
+      }
+      e->use_jit = jit_ok;
+      const bool big_tiles = jit_ok || lean;
+      const int want_waves = jit_ok ? jw : (lean ? DMA_WAVES : GATHER_WAVES);
+      if (big_tiles != e->mfma_dma || want_waves != e->mfma_waves) {
+         e->mfma_dma = big_tiles;
+         e->mfma_waves = want_waves;
+         e->tile_patt = e->mfma_waves * 16;
+         int r = build_tiles(e);
+         if (r) return r;
+         e->partials_valid = false;
+         if (clean) return fail(e, PAML_AMD_EINVAL, "eval_dirty: kernel layout changed; run a full evaluation first");
+      }
+   }
+   if (e->kk != KK_MFMA64) {      // 4 / 5 / 20 states: the interpreter unrolled for this tree
+      bool jit_ok = false, fused = false;
+      // (20 states: the unrolled walk needs > 256 VGPRs and runs at one wave per SIMD, slower than the interpreter)
+      if (e->jit_enabled && !keep && n <= 5 && jit_valu_supported(e->prog)) {
+         // the fused form (classes inside, LDS tip tables, reduction in the epilogue) when the model fits it
+         const ValuFusedPlan pl = jit_valu_fused_plan(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk);
+         if (pl.ok && G == 1 && e->n_pi == 1 && e->d_zpm.p && !e->env.no_fused) {
+            // 4 states: the matrix-core form (v_mfma_f64_4x4x4) is an experiment kept behind PAML_AMD_MFMA4=1 — same issue slots as
+            // the FMA form (an FP64 MFMA of 256 MACs takes 16 cycles, sixteen v_fma_f64 of a wave 64) and four times the
+            // integer work per pattern (a lane is a (state, pattern) pair): 0.32 of peak against 0.64, profiles/r02_valu_fused_shapes.txt
+            const bool m4 = n == 4 && e->env.mfma4;
+            int r = ensure_jit(e, std::string(m4 ? "m4" : "vf") + std::to_string(n) + "c" + std::to_string(e->n_codes) + "k" + std::to_string(Km) + "r" + std::to_string(pl.R) + "w" +
+                                     std::to_string(pl.CW) + (pl.cherry ? "y:" : "n:") + jit_program_key(e->prog, e->n_tips),
+                               [&]() { return m4 ? jit_generate_mfma4(e->prog, e->n_tips, e->n_codes, Km, e->chunk)
+                                                 : jit_generate_valu_fused(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk); }, &jit_ok);
+            e->fused_mfma4 = jit_ok && m4;
+            if (r) return r;
+            fused = jit_ok;
+            e->fused_threads = 256 * pl.CW;
+         }
+         if (!jit_ok) {
+            int r = ensure_jit(e, "v" + std::to_string(n) + ":" + jit_program_key(e->prog, e->n_tips),
+                               [&]() { return jit_generate_valu(e->prog, n); }, &jit_ok);
+            if (r) return r;
+         }
+      }
+      e->m20 = false;
+      if (e->want_m20 && !clean && jit_m20_supported(e->prog, e->n_tips, G)) {
+         int r = ensure_jit(e, "m20c" + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate_m20(e->prog, e->n_tips, e->n_codes); }, &jit_ok);
+         if (r) return r;
+         e->m20 = jit_ok;
+      }
+      e->use_jit = jit_ok;
+      e->fused = fused;
+   }
+   const bool use_dma = e->mfma_dma;
+   const int n_blocks = e->n_tiles * K;
+   const int n_int = nn - e->n_tips;
+   if (keep) {
+      size_t words = e->kk == KK_MFMA64 ? (size_t)K * n_int * e->n_tiles * e->mfma_waves * 1024
+                                        : (size_t)K * n_int * e->n_patt * n;
+      HIPCHK(e->d_partials.ensure(words));
+      HIPCHK(e->d_scalef.ensure((size_t)K * std::max(1, e->tree.n_scale) * e->n_patt));
+   }
+   int overflow = 0;
+   if (e->kk == KK_MFMA64 && e->prog.max_stack > MFMA_RS) {
+      overflow = e->prog.max_stack - MFMA_RS;
+      HIPCHK(e->d_stack.ensure((size_t)n_blocks * overflow * e->mfma_waves * 1024));
+   }
+
+   // Kernel A: batched P(t)
+   PmatArgs pa{};
+   pa.n = n; pa.n_nodes = nn; pa.root = e->tree.root; pa.K = Km; pa.n_genes = G; pa.n_labels = e->n_labels;
+   pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : ((e->kk == KK_VALU20 && e->use_jit && e->m20) ? 2 : 0);
+   pa.label = e->d_label.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = pipe ? e->d2_branch.p : e->d_branch.p; pa.rate = e->d_rate.p;
+   pa.gene_rate = pipe ? e->d2_gene_rate.p : e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
+   pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
+   pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
+   pa.B = B; pa.branch_bs = nn; pa.gene_rate_bs = G; pa.pcol = e->kk == KK_MFMA64 ? e->d_pcol.p : nullptr;
+   if (bs && bs->eigen_of) { pa.eigen_of = e->d_b_eigen_of.p; pa.eigen_of_bs = (long)G * Km * e->n_labels; }
+   if (bs && bs->qfactor) { pa.qfactor = e->d_b_qfactor.p; pa.qfactor_bs = (long)Km * e->n_labels; }
+   pa.rate_gs = e->rate_per_gene ? Km : 0;
+   if (bs && bs->rate) { pa.rate = e->d_b_rate.p; pa.rate_bs = e->rate_per_gene ? (long)G * Km : Km; }
+   mark_on(e, ps);
+   bool small_pmat = e->kk != KK_MFMA64 && n <= 5;
+   for (const EigenHost &h : e->eigen) small_pmat = small_pmat && h.kind != PAML_AMD_EIGEN_QMAT;
+   if (small_pmat) hipLaunchKernelGGL(pmat_small_kernel, dim3((nn * psets + 7) / 8), dim3(256), 0, ps, pa, iv);
+   else hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), ps, pa, iv);
+   mark_on(e, ps);
+   if (pipe) {      // the pruning kernel (main stream) starts when this P(t) is there
+      HIPCHK(hipEventRecord(e->ev_pmat, e->s2));
+      HIPCHK(hipStreamWaitEvent(e->stream, e->ev_pmat, 0));
+   }
+   if (want_pipe) {      // "everything on the main stream in front of this pruning kernel": what the next pipelined evaluation waits for
+      HIPCHK(hipEventRecord(e->ev_entry[e->entry_sel], e->stream));
+      e->entry_sel ^= 1;
+      e->have_prev_entry = true;
+   }
+   e->n_pmat += (long)psets * (nn - 1);
+
+   // Kernel B: fused pruning
+   PruneArgs pr{};
+   pr.ops = e->d_ops.p; pr.z = e->d_z.p; pr.z_stride = e->n_patt; pr.tiles = e->d_tiles.p; pr.n_tiles = e->n_tiles;
+   pr.gene_off = e->d_gene_off.p; pr.weights = e->d_weights.p; pr.ztiles = e->d_ztiles.p; pr.zt_bytes = e->zt_bytes;
+   pr.n = n; pr.n_tips = e->n_tips; pr.n_nodes = nn; pr.K = K; pr.n_genes = G; pr.n_codes = e->n_codes;
+   pr.cleandata = e->cleandata; pr.n_pi = e->n_pi; pr.mode = e->mode; pr.n_scale = e->tree.n_scale;
+   pr.keep = keep ? 1 : 0; pr.n_patt = e->n_patt;
+   pr.pi = e->d_pi.p; pr.pint = e->kk == KK_MFMA64 ? e->d_pint.p : e->d_rowmajor.p; pr.ptip = e->d_ptip.p;
+   if (e->use_jit && e->tree.n_scale) HIPCHK(e->d_fscale.ensure((size_t)K * e->n_patt));
+   pr.fscale = e->d_fscale.p; pr.pcol = e->d_pcol.p;
+   pr.fhK = e->d_fhK.p; pr.partials = e->d_partials.p; pr.scalef = e->d_scalef.p; pr.stack_scratch = e->d_stack.p;
+   pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
+   pr.first_tip = e->prog.first_tip;
+   pr.stream = e->d_stream.p; pr.n_stream = (int)(e->prog.stream.size() / 2); pr.tip_words = (long)tip_words(e);
+   // the reduction's geometry (the fused kernels form the partial sums themselves; the others leave them to reduce_stage1)
+   const int chunk = e->chunk, nbg = e->nb_global;
+   const int nb = (e->n_patt + chunk - 1) / chunk;
+   if ((size_t)nbg * B > e->d_partial.cap) {
+      HIPCHK(e->d_partial.ensure((size_t)nbg * B));
+      HIPCHK(hipMemsetAsync(e->d_partial.p, 0, e->d_partial.cap * sizeof(double), e->stream));
+   }
+   if ((size_t)B * RED_TICKET_WORDS > e->d_red_counter.cap) {
+      HIPCHK(e->d_red_counter.ensure((size_t)std::max(B, 64) * RED_TICKET_WORDS));
+      HIPCHK(hipMemsetAsync(e->d_red_counter.p, 0, e->d_red_counter.cap * sizeof(int), e->stream));
+   }
+   HIPCHK(e->d_out.ensure(B));
+   if (want_lnf) HIPCHK(e->d_lnf.ensure((size_t)B * e->n_patt));
+   double *const lnl_out = d_lnL_out ? d_lnL_out : e->d_out.p;
+   const bool fused = e->kk != KK_MFMA64 && e->use_jit && e->fused;
+   pr.zpm = e->d_zpm.p; pr.zpm_words = e->zpm_words;
+   if (fused) {
+      pr.zpm = e->d_zpm.p; pr.zpm_words = e->zpm_words; pr.Km = Km; pr.chunk = chunk; pr.first_chunk = e->first_chunk; pr.nb_stride = nbg;
+      pr.want_fhk = (want_fhk || e->tree.n_scale) ? 1 : 0;
+      pr.freqK = (bs && bs->freqK) ? e->d_b_freqK.p : e->d_freqK.p; pr.freqK_bs = (bs && bs->freqK) ? Km : 0;
+      pr.lnf = want_lnf ? e->d_lnf.p : nullptr;
+      pr.red_partial = e->d_partial.p; pr.red_out = lnl_out;
+      // the total: a one-block stage-2 launch (default), or PAML_AMD_TAIL=1: the workgroup that finishes last forms it (tickets)
+      pr.red_counter = (e->comm || !e->env.tail) ? nullptr : e->d_red_counter.p;
+   }
+   const int prof_stride = std::max((int)e->prog.ops.size() + 3, e->env.prof_tiles ? 96 : 0);      // experiments only
+   if (!e->env.prof_ops.empty()) {
+      // per-op stamps: a fresh buffer and a dump after every launch; the workgroup timeline: one buffer, overwritten by every
+      // launch and written out when the engine goes (nothing between the launches, so that the clock is the production clock)
+      const size_t words = (size_t)3 * n_blocks * prof_stride;
+      if (!e->env.prof_tiles || words != e->prof_words) {
+         if (e->d_prof) (void)hipFree(e->d_prof);
+         e->d_prof = nullptr;
+         HIPCHK(hipMalloc((void **)&e->d_prof, words * 8));
+         HIPCHK(hipMemsetAsync(e->d_prof, 0, words * 8, e->stream));
+         e->prof_words = words; e->prof_blocks = n_blocks; e->prof_stride = prof_stride;
+      }
+      pr.prof = e->d_prof;
+      pr.prof_stride = prof_stride;
+      pr.prof_tid = e->env.prof_tid;
+   }
+   mark(e);
+   switch (e->kk) {
+   case KK_MFMA64:
+      if (e->use_jit) {
+         void *params[] = {&pr};
+         const int grid = std::min(n_blocks, e->n_cu);     // persistent: one 130 KB-LDS workgroup per CU walks the tiles
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, grid, 1, 1, e->mfma_waves * 64, 1, 1, 0, e->stream, params, nullptr));
+      }
+      else if (use_dma) {
+         const size_t lds = (size_t)4 * 4096 * sizeof(double) + (size_t)e->n_tips * 128;
+         if (!e->stream_attr_set) {
+            HIPCHK(hipFuncSetAttribute((const void *)prune_mfma64_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            e->stream_attr_set = true;
+         }
+         hipLaunchKernelGGL(prune_mfma64_stream, dim3(n_blocks), dim3(512), lds, e->stream, pr);
+      }
+      else
+         hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, e->stream, pr);
+      break;
+   case KK_VALU4:
+   case KK_VALU5:
+   case KK_VALU20:
+      if (fused) {
+         void *params[] = {&pr};
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, nb, B, 1, e->fused_threads, 1, 1, 0, e->stream, params, nullptr));
+      }
+      else if (e->use_jit && e->m20) {      // persistent: a multiple of the class count, every workgroup keeps its class's P(t) in LDS
+         void *params[] = {&pr};
+         const int grid = std::min(std::max(K, e->n_cu / K * K), e->n_tiles * K);
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::max(grid / K, 1) * K, 1, 1, 512, 1, 1, 0, e->stream, params, nullptr));
+      }
+      else if (e->use_jit) {
+         void *params[] = {&pr};
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, n_blocks, 1, 1, 256, 1, 1, 0, e->stream, params, nullptr));
+      }
+      else
+         launch_valu(e, e->prog.max_stack, n_blocks, pr, e->stream);
+      break;
+   }
+   mark(e);
+   if (pr.prof && !e->env.prof_tiles) {
+      std::vector<unsigned long long> hp((size_t)3 * n_blocks * prof_stride);
+      HIPCHK(hipMemcpyAsync(hp.data(), e->d_prof, hp.size() * 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      FILE *f = fopen(e->env.prof_ops.c_str(), "wb");
+      if (f) {
+         int hdr[2] = {n_blocks, prof_stride};
+         fwrite(hdr, sizeof(int), 2, f);
+         std::vector<int> codes;
+         for (auto &o : e->prog.ops) codes.push_back(o.code);
+         codes.resize(prof_stride - 3, 0);
+         fwrite(codes.data(), sizeof(int), codes.size(), f);
+         fwrite(hp.data(), 8, hp.size(), f);
+         fclose(f);
+      }
+   }
+
+   // Kernel C: mixture + log + weighted sum.  Stage 1 leaves one partial sum per chunk of patterns at the chunk's global
+   // position; with a communicator the ranks' (disjoint, zero elsewhere) arrays are summed over RCCL — adding zeros is exact,
+   // so every rank then holds the same array whatever the number of ranks — and stage 2 adds it up in a fixed order.  On one
+   // GPU the workgroup that finishes last forms the total itself (red_block_finish): no second launch.
+   ReduceArgs ra{};
+   ra.fhK = e->d_fhK.p; ra.weights = e->d_weights.p; ra.freqK = e->d_freqK.p; ra.lnf = want_lnf ? e->d_lnf.p : nullptr;
+   ra.partial = e->d_partial.p; ra.out = lnl_out;
+   ra.raw = ((e->kk == KK_MFMA64 && e->use_jit) || (e->kk == KK_VALU20 && e->use_jit && e->m20)) ? 1 : 0; ra.fscale = e->d_fscale.p;
+   ra.n_patt = e->n_patt; ra.K = Km; ra.mode = e->mode; ra.n_scale = e->tree.n_scale; ra.chunk = chunk;
+   ra.first_chunk = e->first_chunk; ra.nb_stride = nbg;
+   // (measured on MI355X, 32 taxa x 10^5 nucleotide patterns: 28.2 us per evaluation with the separate one-block launch against
+   //  30.2 with tickets — the agent-scope store + two atomics + coherent reads cross the XCDs' L2s and cost more than a launch)
+   const bool tail = !e->comm && e->env.tail;
+   ra.counter = tail ? e->d_red_counter.p : nullptr;
+   if (bs && bs->freqK) { ra.freqK = e->d_b_freqK.p; ra.freqK_bs = Km; }
+   mark(e);
+   if (!fused) hipLaunchKernelGGL(reduce_stage1, dim3(nb, B), dim3(256), 0, e->stream, ra);
+   if (e->comm) {
+      HIPCHK(e->d_partial_tot.ensure((size_t)nbg * B));
+      const ncclResult_t nr = rccl().AllReduce(e->d_partial.p, e->d_partial_tot.p, (size_t)nbg * B, ncclDouble, ncclSum, e->comm, e->stream);
+      if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
+      hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)e->d_partial_tot.p, nbg, ra.out);
+   }
+   else if (!tail && nbg > 1) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)e->d_partial.p, nbg, ra.out);      // (one block per element: stage 1 wrote the total)
+   mark(e);
+   HIPCHK(hipGetLastError());
+   if (e->profiling) e->prof_evals++;
+   e->n_eval++;
+   if (keep && !clean) e->partials_valid = true;
+   e->pmat_valid = true;
+   e->pipe_ok = want_pipe;      // (every other entry point clears it)
+   return 0;
+}
+
+}  // namespace paml_amd
+
+extern "C" {
+
+int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, double *lnL, double *lnf,
+                  double *fhK)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !branch || !lnL) return fail(e, PAML_AMD_EINVAL, "eval: null argument");
+   int r = ensure_hout(e, 1);
+   if (r) return r;
+   r = launch_eval(e, branch, gene_rate, nullptr, e->h_out, lnf != nullptr, nullptr, false, fhK != nullptr);
+   if (r) return r;
+   if (lnf) HIPCHK(hipMemcpyAsync(lnf, e->d_lnf.p, (size_t)e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   if (fhK)
+      HIPCHK(hipMemcpyAsync(fhK, e->d_fhK.p, (size_t)e->K * e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   *lnL = e->h_out[0];
+   return 0;
+}
+
+int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, const double *gene_rate, const int *eigen_of,
+                        const double *qfactor, const double *freqK, const double *rate, double *lnL, double *lnf)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !branch || !lnL || n_batch < 1) return fail(e, PAML_AMD_EINVAL, "eval_batch: bad arguments");
+   if ((long)n_batch * e->K * e->n_genes > 65535) return fail(e, PAML_AMD_EINVAL, "eval_batch: n_batch * K * n_genes > 65535");
+   BatchSpec bs{n_batch, eigen_of, qfactor, freqK, rate};
+   int r = ensure_hout(e, n_batch);
+   if (r) return r;
+   r = launch_eval(e, branch, gene_rate, nullptr, e->h_out, lnf != nullptr, &bs, false, false);
+   if (r) return r;
+   if (lnf)
+      HIPCHK(hipMemcpyAsync(lnf, e->d_lnf.p, (size_t)n_batch * e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   memcpy(lnL, e->h_out, (size_t)n_batch * sizeof(double));
+   return 0;
+}
+
+int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *gene_rate, const double *MK, const int *pose, int ls,
+                      double *lnL)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !branch || !MK || !pose || !lnL || ls < 1) return fail(e, PAML_AMD_EINVAL, "eval_adg: bad arguments");
+   if (e->mode != PAML_AMD_MODE_LFUNDG) return fail(e, PAML_AMD_EINVAL, "eval_adg: needs the lfundG class mode");
+   if (e->world > 1) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_adg: the rate chain runs over the sites in order and does not shard (SURVEY 8e)");
+   const int K = e->K, np = e->n_patt;
+   for (int i = 0; i < ls; i++)
+      if (pose[i] < 0 || pose[i] >= np) return fail(e, PAML_AMD_EINVAL, "eval_adg: pose entry out of range");
+   int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, false);      // fx_r on the device
+   if (r) return r;
+   std::vector<double> fhK((size_t)K * np), w(np), b1(K), b2(K);
+   HIPCHK(hipMemcpyAsync(fhK.data(), e->d_fhK.p, fhK.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipMemcpyAsync(w.data(), e->d_weights.p, w.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   // the chain over sites in their original order is sequential: host (treesub.c:7456-7492)
+   double l = 0;
+   if (e->tree.n_scale)
+      for (int h = 0; h < np; h++) {
+         const double fh = fhK[h];
+         if (!(w[h] > 0)) continue;
+         l += fh * w[h];
+         fhK[h] = 1;
+         for (int ir = 1; ir < K; ir++) fhK[(size_t)ir * np + h] = exp(fhK[(size_t)ir * np + h] - fh);
+      }
+   for (int il = 0; il < ls; il++) {
+      const int h = pose[il];
+      if (il == 0)
+         for (int ir = 0; ir < K; ir++) b1[ir] = fhK[(size_t)ir * np + h];
+      else {
+         for (int ir = 0; ir < K; ir++) {
+            double fh = 0;
+            for (int j = 0; j < K; j++) fh += MK[ir * K + j] * b1[j];
+            b2[ir] = fh * fhK[(size_t)ir * np + h];
+         }
+         b1 = b2;
+      }
+      double fh = 0;
+      for (int ir = 0; ir < K; ir++) fh += b1[ir];
+      if (fh < 1e-90) fh = 1e-300;
+      for (int ir = 0; ir < K; ir++) b1[ir] /= fh;
+      l += log(fh);
+   }
+   std::vector<double> fk(K);
+   HIPCHK(hipMemcpy(fk.data(), e->d_freqK.p, K * sizeof(double), hipMemcpyDeviceToHost));
+   double fh = 0;
+   for (int ir = 0; ir < K; ir++) fh += fk[ir] * b1[ir];
+   *lnL = l + log(fh);
+   return 0;
+}
+
+int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL)
+{
+   if (!e || !branch || !d_lnL) return fail(e, PAML_AMD_EINVAL, "eval_device: null argument");
+   return launch_eval(e, branch, gene_rate, nullptr, d_lnL, false, nullptr, true, false);
+}
+
+int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
+                        double *lnL)
+{
+   if (e) e->pipe_ok = false;
+   if (!e || !branch || !lnL || !clean) return fail(e, PAML_AMD_EINVAL, "eval_dirty: null argument");
+   int r = ensure_hout(e, 1);
+   if (r) return r;
+   r = launch_eval(e, branch, gene_rate, clean, e->h_out, false);
+   if (r) return r;
+   HIPCHK(hipStreamSynchronize(e->stream));
+   *lnL = e->h_out[0];
+   return 0;
+}
+
+}  // extern "C"

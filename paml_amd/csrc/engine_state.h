@@ -1,0 +1,442 @@
+// engine_state.h — the engine object behind the C ABI (include/paml_amd.h) and the helpers its translation units share:
+//   engine_core.hip     create / destroy, the set_* entry points, read-back of P(t) / partials / scale factors, profiling
+//   engine_comm.hip     pattern shards over several GPUs: shard bounds, the RCCL communicator, the collective stream
+//   engine_eval.hip     one evaluation (batched P(t), fused pruning, reduction) and the entry points built on it
+//   engine_branch.hip   branch-local lnL(t), dlnL, ddlnL on resident partials; node posteriors
+//   engine_beb.hip      the BEB grid integral
+//   engine_jitdbg.hip   per-tree kernel generation without an engine (tests, build-time prebuild)
+//   engine_compress.hip site-pattern compression on the device (stand-alone)
+// Built for gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <atomic>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed by paml_amd_comm_* (see Rccl below)
+
+#include "../../include/paml_amd.h"
+#include "jit.h"
+#include "kernel_args.h"
+#include "program.h"
+
+namespace paml_amd {
+static_assert(JIT_SCRATCH_BASE == MFMA_RS, "the per-tree kernel addresses the interpreter's overflow-stack scratch");
+
+enum KernelKind { KK_VALU4, KK_VALU5, KK_VALU20, KK_MFMA64 };
+constexpr int DMA_WAVES = 8;           // mfma64 "stream" kernel: 128 patterns per workgroup, 1 workgroup per CU
+constexpr int GATHER_WAVES = 4;        // mfma64 "gather" kernel: 64 patterns per workgroup, 2 per CU
+constexpr int VALU_MAXD_SMALL = 16, VALU_MAXD_20 = 8;
+
+template <typename T>
+struct DevBuf {
+   T *p = nullptr;
+   size_t cap = 0;
+   hipError_t ensure(size_t n)
+   {
+      if (n <= cap) return hipSuccess;
+      if (p) (void)hipFree(p);
+      p = nullptr;
+      cap = 0;
+      hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
+      if (e == hipSuccess) cap = n;
+      return e;
+   }
+   void release()
+   {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+      cap = 0;
+   }
+};
+
+// Pinned host arena for the small per-evaluation inputs, so the H2D copies are truly asynchronous and
+// the source stays valid until an event says the copies are done.
+struct Staging {
+   char *p = nullptr;
+   size_t cap = 0, used = 0;
+   hipEvent_t ev = nullptr;
+   bool pending = false;
+   hipError_t begin(size_t need)
+   {
+      if (pending) { hipError_t r = hipEventSynchronize(ev); if (r != hipSuccess) return r; pending = false; }
+      if (need > cap) {
+         if (p) (void)hipHostFree(p);
+         p = nullptr; cap = 0;
+         hipError_t r = hipHostMalloc((void **)&p, need * 2, hipHostMallocDefault);
+         if (r != hipSuccess) return r;
+         cap = need * 2;
+      }
+      if (!ev) { hipError_t r = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (r != hipSuccess) return r; }
+      used = 0;
+      return hipSuccess;
+   }
+   template <typename T>
+   T *put(const T *src, size_t n)
+   {
+      used = (used + 15) & ~(size_t)15;
+      T *dst = (T *)(p + used);
+      memcpy(dst, src, n * sizeof(T));
+      used += n * sizeof(T);
+      return dst;
+   }
+   hipError_t end(hipStream_t s) { pending = true; return hipEventRecord(ev, s); }
+   void release()
+   {
+      if (pending && ev) (void)hipEventSynchronize(ev);
+      if (p) (void)hipHostFree(p);
+      if (ev) (void)hipEventDestroy(ev);
+      p = nullptr; ev = nullptr; cap = 0; pending = false;
+   }
+};
+
+struct EigenHost {
+   int kind = -1, nR = 0;
+   double kappa = 0;
+   DevBuf<double> U, V, Root, Cijk;
+};
+
+// RCCL, bound at run time: libpaml_amd.so keeps loading on hosts without the collective library (single-GPU use needs none
+// of it), and a process that already holds a copy of librccl.so.1 (PyTorch ships one) shares that copy — dlopen matches by
+// soname — instead of getting a second one.
+struct Rccl {
+   void *h = nullptr;
+   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+   decltype(&ncclCommInitRank) CommInitRank = nullptr;
+   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+   decltype(&ncclAllReduce) AllReduce = nullptr;
+   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+   std::string err;
+   bool load()
+   {
+      if (h) return true;
+      const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+      for (const char *nm : names)
+         if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+      if (!h) { err = std::string("dlopen librccl.so.1: ") + dlerror(); return false; }
+      GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+      CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+      CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+      AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+      GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+      if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
+         err = "librccl.so.1 lacks an expected symbol";
+         h = nullptr;
+         return false;
+      }
+      return true;
+   }
+};
+inline Rccl &rccl()
+{
+   static Rccl r;      // (process-wide on purpose: one binding of the library, no engine state)
+   return r;
+}
+
+// Patterns per partial sum of the lnL reduction.  A function of the GLOBAL pattern count only: with shards cut at multiples
+// of it, every rank's partial sums are entries of one global array whose fixed-order total does not depend on the number
+// of ranks (paml_amd_comm_init).  At most ~1024 partials.
+inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global + 1023) / 1024 + 255) / 256 * 256); }
+
+// Environment switches, read once when the engine is created.
+struct EnvCfg {
+   bool force_stream = false;
+   bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false, no_m20 = false;
+   int jit_waves = 0;
+   std::string jit_dump, prof_ops;
+   int prof_tid = 0;
+   bool prof_tiles = false;      // the dump is a workgroup timeline (jit.h proft) instead of per-op stamps
+   void read()
+   {
+      no_pipeline = getenv("PAML_AMD_NO_PIPELINE") != nullptr;
+      force_gather = getenv("PAML_AMD_FORCE_GATHER") != nullptr;
+      force_stream = getenv("PAML_AMD_FORCE_STREAM") != nullptr;      // experiments: the stream interpreter also on small data sets
+      jit_sync = getenv("PAML_AMD_JIT_SYNC") != nullptr;
+      jit_strict = getenv("PAML_AMD_JIT_STRICT") != nullptr;
+      valu20 = getenv("PAML_AMD_VALU20") != nullptr;
+      no_fused = getenv("PAML_AMD_NO_FUSED") != nullptr;
+      mfma4 = getenv("PAML_AMD_MFMA4") != nullptr;
+      no_m20 = getenv("PAML_AMD_NO_M20") != nullptr;
+      tail = getenv("PAML_AMD_TAIL") != nullptr;
+      if (const char *v = getenv("PAML_AMD_JIT_WAVES")) jit_waves = atoi(v);        // experiment: the last workgroup forms the total instead of a stage-2 launch
+      if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
+      if (const char *v = getenv("PAML_AMD_PROF_OPS")) prof_ops = v;
+      if (const char *v = getenv("PAML_AMD_PROF_TID")) prof_tid = atoi(v);
+      prof_tiles = getenv("PAML_AMD_PROF_TILES") != nullptr;
+   }
+};
+
+}  // namespace paml_amd
+
+using namespace paml_amd;
+
+struct paml_amd_engine {
+   int n = 0, n_tips = 0, n_patt = 0, max_classes = 0, n_genes = 1;
+   unsigned flags = 0;
+   KernelKind kk = KK_MFMA64;
+   bool mfma_dma = true;     // which mfma64 variant (dma needs n_tips <= MFMA_ZT)
+   int mfma_waves = DMA_WAVES;
+   int tile_patt = 64;
+   hipStream_t stream = nullptr;
+   std::string err;
+   EnvCfg env;
+   int device = 0, n_cu = 0;          // the device the engine was created on, its CU count (persistent grids)
+   bool stream_attr_set = false;      // > 64 KB dynamic LDS of prune_mfma64_stream requested on this device
+   unsigned long long *d_prof = nullptr;   // PAML_AMD_PROF_OPS stamps
+   size_t prof_words = 0;
+   int prof_blocks = 0, prof_stride = 0;
+
+   // pattern shards over several GPUs (paml_amd_comm_init): this engine holds patterns [first_patt, first_patt + n_patt) of
+   // n_patt_global; the reduction's partial sums live at their global positions and are summed over the ranks
+   ncclComm_t comm = nullptr;
+   int rank = 0, world = 1;
+   long n_patt_global = 0, first_patt = 0;
+   int chunk = 256, nb_global = 1, first_chunk = 0;
+   DevBuf<double> d_partial_tot, d_btot;
+   DevBuf<unsigned int> d_zpm;        // fused 4 / 5-state kernel: tip codes pattern-major
+   int zpm_words = 0;
+   DevBuf<int> d_red_counter;         // "last workgroup adds up the partial sums" tickets, one per batch element
+   long bpart_rows = 0; int bpart_cols = 0;      // shape of the last eval_branch's partial-sum array
+   double *h_out = nullptr;           // pinned, device-visible: the synchronous entry points have lnL written straight to the host
+   size_t h_out_cap = 0;
+   bool fused = false;                // the selected kernel forms the reduction itself
+   bool fused_mfma4 = false;
+   bool rate_per_gene = false;      // paml_amd_set_gene_class_rates: class rates [n_genes][K]
+   bool want_m20 = false, m20 = false;      // 20 states on v_mfma_f64_4x4x4 (jit_generate_m20)
+   int fused_threads = 256;
+   bool pmat_valid = false;           // d_rowmajor holds the P(t) of an evaluation in the tree's own orientation
+   // branch-local evaluation: resident partials on both sides of every edge, re-used from call to call (eval_branch)
+   struct BranchCache {
+      bool valid = false;
+      int K = 0;
+      std::vector<int> up;            // up[v]: the neighbour v's stored partial looks away from
+      std::vector<char> ok;           // the stored partial of internal node v is current
+      std::vector<double> br, gr;     // branch lengths (by lower node) and gene rates the partials were formed with
+   } bl;
+   DevBuf<double> d_bl_partials, d_bl_scalef, d_bl_frag;
+   DevBuf<unsigned long long> d_code_mask;      // per character code: bit s = state s belongs to it
+   long n_branch_eval = 0, n_branch_nodes = 0;
+
+   // data
+   bool have_tips = false, have_tree = false, have_pi = false, have_classes = false;
+   int cleandata = 1, n_codes = 0;
+   DevBuf<unsigned char> d_z, d_chara_map, d_is_leaf, d_ztiles;
+   int zt_bytes = 0;
+   DevBuf<int> d_n_chara, d_gene_off, d_label, d_eigen_of, d_b_eigen_of;
+   DevBuf<int2> d_tiles, d_tiles_full;   // tile table of the selected kernel / of the full (gather or valu) kernel
+   int n_tiles_full = 0;
+   DevBuf<double> d_pi_plain;
+   DevBuf<double> d_weights, d_pi, d_freqK, d_rate, d_qfactor, d_branch, d_gene_rate;
+   std::vector<int> gene_off;
+   int n_tiles = 0, n_pi = 1;
+
+   TreeDesc tree;
+   Program prog;
+   bool prog_valid = false;
+   DevBuf<Op> d_ops;
+   DevBuf<int> d_stream;
+   Staging stage;
+   JitKernel jit;            // per-tree specialised kernel (jit.h), valid when jit.fn != nullptr
+   bool jit_enabled = false, use_jit = false;
+   // Consecutive paml_amd_eval_device calls (the loop of a benchmark or of an optimiser's independent evaluations) build the
+   // NEXT evaluation's P(t) on a side stream while the previous pruning kernel is still running: its few workgroups fit the CUs
+   // that go idle in that kernel's last round.  Two sets of P buffers alternate; the side stream waits for everything the main
+   // stream had queued before the previous evaluation (the last readers of the set it is about to overwrite).  Any other API
+   // call switches the fast path off until the next eval_device has run in order.
+   bool pipe_ok = false;
+   hipStream_t s2 = nullptr;
+   hipEvent_t ev_entry[2] = {nullptr, nullptr}, ev_pmat = nullptr;
+   int entry_sel = 0;
+   bool have_prev_entry = false;
+   DevBuf<double> d2_rowmajor, d2_pint, d2_ptip, d2_pcol, d2_branch, d2_gene_rate;
+   bool jit_forced = false;  // asked for by flag / environment (as opposed to switched on by the problem's size)
+   // a large tree's kernel takes many seconds to compile: that happens on a worker thread while the interpreter kernels
+   // serve the evaluations, and the engine changes over when the code object is there
+   struct JitJob {
+      std::thread th;
+      std::atomic<int> state{0};      // 0 idle, 1 compiling, 2 code ready, 3 failed
+      std::string key, src, log;
+      std::vector<char> code;
+   };
+   std::unique_ptr<JitJob> jit_job;
+   std::string jit_failed_key;
+
+   std::vector<EigenHost> eigen;
+   DevBuf<EigenDev> d_eigen;
+   bool eigen_dirty = true;
+
+   int mode = PAML_AMD_MODE_LFUN, K = 1, n_labels = 1;
+
+   // per-evaluation buffers
+   DevBuf<double> d_b_qfactor, d_b_freqK, d_b_rate;
+   DevBuf<double> d_beb_f, d_beb_part, d_beb_g, d_beb_out, d_beb_pcl;      // BEB grid integral
+   DevBuf<int> d_beb_iw;
+   DevBuf<double> d_rowmajor, d_pint, d_ptip, d_pcol, d_fhK, d_fscale, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
+   DevBuf<double> d_expA, d_expB, d_expSA, d_expSB, d_deriv, d_tt, d_bpartial, d_bout;   // branch-local evaluation
+   DevBuf<int> d_label_eff;
+   DevBuf<Op> d_ops_tmp;
+   bool partials_valid = false;
+
+   // profiling
+   bool profiling = false;
+   std::vector<hipEvent_t> ev_pool;
+   std::vector<hipEvent_t> ev_used;   // sextuples per eval
+   long prof_evals = 0;
+   long n_eval = 0, n_pmat = 0;
+
+   ~paml_amd_engine()
+   {
+      for (auto &e : eigen) { e.U.release(); e.V.release(); e.Root.release(); e.Cijk.release(); }
+      stage.release();
+      if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
+      if (h_out) (void)hipHostFree(h_out);
+      if (d_prof && env.prof_tiles && prof_words) {      // the last launch's workgroup timeline
+         std::vector<unsigned long long> hp(prof_words);
+         if (hipMemcpy(hp.data(), d_prof, prof_words * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = fopen(env.prof_ops.c_str(), "wb")) {
+               const int hdr[2] = {prof_blocks, prof_stride};
+               fwrite(hdr, sizeof(int), 2, f);
+               std::vector<int> codes(prof_stride - 3, 0);
+               fwrite(codes.data(), sizeof(int), codes.size(), f);
+               fwrite(hp.data(), 8, hp.size(), f);
+               fclose(f);
+            }
+      }
+      if (d_prof) (void)hipFree(d_prof);
+      if (jit.mod) (void)hipModuleUnload(jit.mod);
+      for (auto ev : ev_pool) (void)hipEventDestroy(ev);
+      for (auto ev : ev_used) (void)hipEventDestroy(ev);
+      DevBuf<unsigned char> *b1[] = {&d_z, &d_chara_map, &d_is_leaf, &d_ztiles};
+      for (auto b : b1) b->release();
+      DevBuf<int> *b2[] = {&d_n_chara, &d_gene_off, &d_label, &d_eigen_of, &d_b_eigen_of, &d_beb_iw};
+      for (auto b : b2) b->release();
+      d_tiles.release();
+      d_tiles_full.release();
+      d_zpm.release();
+      d_red_counter.release();
+      d_bl_partials.release(); d_bl_scalef.release(); d_bl_frag.release(); d_code_mask.release();
+      d_ops.release();
+      d_ops_tmp.release();
+      d_label_eff.release();
+      d_stream.release();
+      d_eigen.release();
+      d_pi_plain.release();
+      DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
+                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_rowmajor, &d2_pint, &d2_ptip, &d2_pcol, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot,
+                              &d_expA, &d_expB, &d_expSA, &d_expSB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
+      for (auto b : b3) b->release();
+   }
+};
+
+namespace paml_amd {
+
+inline int fail(paml_amd_engine *e, int code, const std::string &msg)
+{
+   if (e) e->err = msg;
+   return code;
+}
+
+#define HIPCHK(call)                                                                                         \
+   do {                                                                                                      \
+      hipError_t _r = (call);                                                                                \
+      if (_r != hipSuccess)                                                                                  \
+         return fail(e, _r == hipErrorOutOfMemory ? PAML_AMD_ENOMEM : PAML_AMD_EHIP,                         \
+                     std::string(#call) + ": " + hipGetErrorString(_r));                                     \
+   } while (0)
+
+template <typename T>
+inline hipError_t upload(DevBuf<T> &b, const T *src, size_t n, hipStream_t s)
+{
+   hipError_t r = b.ensure(n);
+   if (r != hipSuccess) return r;
+   if (n == 0) return hipSuccess;
+   // pageable source: the runtime stages the copy, so the host buffer may be reused on return
+   return hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+}
+
+inline int tipw(const paml_amd_engine *e) { return e->kk == KK_MFMA64 ? 64 : e->n; }
+// doubles per tip table: mfma64 pads tables of <= 64 codes to one 32 KB stream block
+inline size_t tip_words(const paml_amd_engine *e)
+{
+   if (e->kk != KK_MFMA64) return (size_t)e->n_codes * e->n;
+   return e->n_codes <= 64 ? 4096 : (size_t)e->n_codes * 64;
+}
+inline int pint_words(const paml_amd_engine *e) { return e->kk == KK_MFMA64 ? 4096 : e->n * e->n; }
+
+inline hipEvent_t get_event(paml_amd_engine *e)
+{
+   hipEvent_t ev;
+   if (!e->ev_pool.empty()) {
+      ev = e->ev_pool.back();
+      e->ev_pool.pop_back();
+   }
+   else if (hipEventCreate(&ev) != hipSuccess)
+      return nullptr;
+   e->ev_used.push_back(ev);
+   return ev;
+}
+
+inline void mark_on(paml_amd_engine *e, hipStream_t s)
+{
+   if (!e->profiling) return;
+   hipEvent_t ev = get_event(e);
+   if (ev) (void)hipEventRecord(ev, s);
+}
+inline void mark(paml_amd_engine *e) { mark_on(e, e->stream); }
+
+// Pinned host memory the kernels can write: the synchronous entry points get their scalars without a device-to-host copy.
+inline int ensure_hout(paml_amd_engine *e, size_t n)
+{
+   if (n <= e->h_out_cap) return 0;
+   if (e->h_out) (void)hipHostFree(e->h_out);
+   e->h_out = nullptr; e->h_out_cap = 0;
+   HIPCHK(hipHostMalloc((void **)&e->h_out, std::max<size_t>(n, 64) * sizeof(double), hipHostMallocDefault));
+   e->h_out_cap = std::max<size_t>(n, 64);
+   return 0;
+}
+
+}  // namespace paml_amd
+
+// ---- defined in engine_eval.hip, the translation unit that holds the P(t), pruning and reduction kernels -------------------
+namespace paml_amd {
+
+// Batched evaluations: B parameter sets run as K*B classes of one launch (class index = b*K + iclass), so the pruning
+// kernels are unchanged; P(t) and the reduction index the per-element inputs.  Null members = shared set_classes values.
+struct BatchSpec {
+   int B;
+   const int *eigen_of;      // [B][n_genes][K][n_labels]
+   const double *qfactor;    // [B][K][n_labels]
+   const double *freqK;      // [B][K]
+   const double *rate;       // [B][K]
+};
+
+int build_tiles(paml_amd_engine *e);
+int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean, double *d_lnL_out, bool want_lnf,
+                const BatchSpec *bs = nullptr, bool want_pipe = false, bool want_fhk = true);
+// launches for the other translation units (a __global__ function has one home)
+void launch_pmat(const PmatArgs &pa, const InlineVec &iv, int n_nodes, int psets, bool small, hipStream_t s);
+void launch_prune_full(paml_amd_engine *e, int max_stack, int n_blocks, const PruneArgs &pr, hipStream_t s);      // gather (21..64 states) or valu interpreter
+void launch_zpm(const unsigned char *z, long z_stride, int n_tips, int n_patt, int zw, unsigned int *out, hipStream_t s);
+
+// the table of eigen systems as the kernels read it (uploaded when a set_eigen_* call has changed one)
+inline int eigen_table(paml_amd_engine *e, std::vector<EigenDev> &tab)
+{
+   tab.resize(e->eigen.size());
+   for (size_t i = 0; i < e->eigen.size(); i++) {
+      const EigenHost &h = e->eigen[i];
+      if (h.kind < 0) return fail(e, PAML_AMD_EINVAL, "eigen set " + std::to_string(i) + " was never set");
+      tab[i] = EigenDev{h.kind, h.nR, h.kappa, h.U.p, h.V.p, h.Root.p, h.Cijk.p};
+   }
+   return 0;
+}
+
+}  // namespace paml_amd

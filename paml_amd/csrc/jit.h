@@ -1,6 +1,6 @@
 // jit.h — per-tree specialised pruning kernel.
 //
-// The interpreter kernels (kernels.h) pay for their generality on every op: a switch dispatch, scalar
+// The interpreter kernels (kernels_prune.h) pay for their generality on every op: a switch dispatch, scalar
 // loads of the op and stream tables, and — worst on CDNA4, where FP64 MFMA and VALU share the SIMD's
 // issue — dozens of v_mov per op that the compiler needs to merge the loop-carried partials.  For a fixed
 // tree the op sequence is known when paml_amd_set_tree returns, so this header unrolls it: it emits one
@@ -42,7 +42,7 @@ struct JitKernel {
 // Stack slots of the 61-state kernel that live in register arrays (each 32 VGPRs); deeper slots are spilled to global scratch.
 // MFMA_RS (the interpreter's register slots) sizes the scratch: the engine allocates max_stack - MFMA_RS slots per workgroup.
 constexpr int JIT_REG_SLOTS = 4;
-constexpr int JIT_SCRATCH_BASE = 2;      // = MFMA_RS (checked in engine.hip): scratch slot k holds stack slot k + 2
+constexpr int JIT_SCRATCH_BASE = 2;      // = MFMA_RS (checked in engine_state.h): scratch slot k holds stack slot k + 2
 
 // Which programs the generator covers.
 inline int jit_zpieces(int n_tips, int tp = 128) { return ((n_tips + 1) * tp + 2047) / 2048; }   // 2 KB units of a tile's code block (tp patterns per tile)

@@ -1,0 +1,134 @@
+// kernel_args.h — argument structures of the hand-written kernels (kernels_*.h), visible to every translation unit of the
+// engine: the kernels themselves are defined in exactly one (engine_eval.hip: P(t), pruning, reduction; engine_branch.hip:
+// branch-local derivatives, node posteriors; engine_beb.hip: the BEB grid), the others launch them through the wrappers
+// engine_state.h declares.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_common.h"
+#include "program.h"
+
+namespace paml_amd {
+
+struct EigenDev {
+   int kind, nR;
+   double kappa;
+   const double *U, *V, *Root, *Cijk;
+};
+
+// Kernel A (kernels_pmat.h): batched P(t)
+struct PmatArgs {
+   int n, n_nodes, root, K, n_genes, n_labels, n_codes, layout;   // layout 0: VALU (row-major), 1: mfma64, 2: as 0 with the tip rows in m20 order
+   const int *label;             // [n_nodes]
+   const unsigned char *is_leaf; // [n_nodes]
+   const double *branch;         // [n_nodes]
+   const double *rate;           // [K]
+   const double *gene_rate;      // [n_genes]
+   const int *eigen_of;          // [n_genes][K][n_labels]
+   const double *qfactor;        // [K][n_labels]
+   const EigenDev *eigen;
+   const int *n_chara;           // [n_codes]
+   const unsigned char *chara_map; // [n_codes][n]
+   double *rowmajor;             // [pset][n_nodes][n*n]
+   double *pint;                 // layout 1: [pset][n_nodes][4096]
+   double *ptip;                 // [pset][n_nodes][tip_words]   rows of n (VALU) or 64 (mfma64) doubles per code
+   long tip_words;
+   double *pcol;                 // layout 1: [pset][n_nodes][64], column 60 per (q, m) (null: not wanted)
+   // batched evaluations (paml_amd_eval_batch): B parameter sets in one launch, laid out as K*B classes; element b reads
+   // branch + b*branch_bs etc. (a stride of 0 = shared with the other elements)
+   int B;
+   long branch_bs, gene_rate_bs, eigen_of_bs, qfactor_bs, rate_bs;
+   int rate_gs;                   // class rates per gene (Malpha: a gamma shape per gene): rate[bat][gene][class], else 0
+};
+
+// Branch lengths and gene rates handed over INSIDE the kernel arguments (single evaluations of trees with up to ~440 nodes):
+// the launch itself carries them, so an evaluation needs no host-to-device copy and no staging buffer to keep alive.
+#define PMAT_INLINE_MAX 440
+struct InlineVec {
+   int n_branch, n_rate;          // 0, 0: read PmatArgs::branch / gene_rate instead
+   double v[PMAT_INLINE_MAX];     // branch[n_branch], then gene_rate[n_rate]
+};
+
+// Kernel C (kernels_reduce.h)
+struct ReduceArgs {
+   double *fhK;        // [K][n_patt]; with `raw` it arrives as floored root sums and leaves as fx_r's values
+   const double *weights, *freqK;
+   const double *fscale; // raw + n_scale: summed scale factors [K][n_patt]
+   int raw;
+   long freqK_bs;        // batched evaluations: blockIdx.y = batch element; its classes, partial sums and output follow
+                         // element 0's at strides K*n_patt, gridDim.x and 1; freqK at freqK_bs (0 = shared)
+   double *lnf;        // optional [n_patt]
+   double *partial;    // partial sums at their GLOBAL positions: element (batch b, chunk first_chunk + blockIdx.x) at
+                       // b * nb_stride + first_chunk + blockIdx.x (one engine: first_chunk = 0, nb_stride = gridDim.x)
+   double *out;        // scalar
+   int n_patt, K, mode, n_scale, chunk;
+   int first_chunk, nb_stride;
+   int *counter;       // [batch] tickets of red_block_finish (null: the total is formed by reduce_stage2 after the all-reduce)
+};
+
+// Branch-local evaluation (kernels_branch.h)
+struct DerivArgs {
+   int n, K, n_genes, n_labels, n_t, label, rate_gs;      // rate_gs: as PmatArgs
+   const double *t;            // [n_t]
+   const double *rate, *gene_rate, *qfactor;
+   const int *eigen_of;
+   const EigenDev *eigen;
+   double *out;                // [pset][n_t][3][n*n]
+   double *frag;               // non-null: also [pset][n_t][3][4096], each matrix in MFMA A-operand order (as pmat_kernel's pint)
+};
+
+struct BranchArgs {
+   int n, K, n_genes, n_patt, n_t, n_pi, b_is_tip, n_codes;
+   const double *A, *B;        // partial of class ir: A + ir * cls_stride, layout [n_patt][n] (the keep-partials layout of prune_valu)
+   long cls_stride;
+   const double *SA, *SB;      // scale factors: SA[(ir * n_scale + k) * n_patt + h] summed over the n_scale slots (SB unused) — null: none
+   int n_scale;
+   const unsigned char *zb;    // tip b: codes [n_patt]
+   const int *n_chara;
+   const unsigned char *chara_map;
+   const double *pi, *freqK, *weights, *PdP;   // PdP: [pset][n_t][3][n*n]
+   const int *gene_off;
+   double *partial;            // [gridDim.x][n_t][3]
+};
+
+struct BranchMfmaArgs {
+   int n, K, n_genes, n_patt, n_pi, n_tips, n_int, n_tiles, n_scale, n_t, it;
+   int a_node, b_node;                 // the branch's two ends; b may be a tip (then its "partial" is the code's state set)
+   const int2 *tiles;                  // 64-pattern tiles (gene, first pattern)
+   const int *gene_off;
+   const double *partials;             // [K][n_int][n_tiles * 4][1024]
+   const double *scalef;               // [K][n_scale][n_patt] or null
+   const unsigned char *zb;            // tip b: codes [n_patt]
+   const unsigned long long *code_mask; // tip b: bit s set = state s belongs to the code
+   const double *pi;                   // [n_pi][4][16]
+   const double *freqK, *weights;
+   const double *frag;                 // [pset][n_t][3][4096]
+   double *partial;                    // [n_tiles][n_t][3] (this launch fills trial length `it`)
+};
+
+// Node posteriors (kernels_branch.h)
+struct PostArgs {
+   int n, K, n_genes, n_patt, n_pi;
+   const double *L, *S;        // [K][n_patt][n], summed scale factors [K][n_patt] or null
+   const double *pi, *freqK;
+   const int *gene_off;
+   double *post;               // [n_patt][n]
+};
+
+// BEB grid integral (kernels_beb.h)
+#define BEB_MAXK 32
+#define BEB_MAXCLS 8
+struct BebArgs {
+   int n_patt, K, n_grid, n_cls, n_pblk, patt_per_blk;
+   int log_form;             // fhK holds logarithms (trees with scaling nodes)
+   const double *fhK, *weights;
+   double *f;                // [K][n_patt] scaled copy
+   const double *pcl;        // [n_grid][n_cls]
+   const int *iw;            // [n_grid][n_cls]
+   const double *w_class;    // [K]
+   double *part;             // [n_grid][n_pblk]
+   double *lnfxs, *wg, *fx;  // [n_grid], [n_grid], [1]
+   double *pr_last, *mean_w, *sd_w;   // [n_patt]
+};
+
+}  // namespace paml_amd

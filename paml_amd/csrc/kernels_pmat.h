@@ -1,0 +1,317 @@
+// kernels_pmat.h — Kernel A: batched construction of the transition-probability matrices (gfx950).  Wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernel_args.h"
+
+namespace paml_amd {
+
+// ------------------------------------------------------------------------------------------------
+// Kernel A: batched P(t) — one workgroup per (node, gene x class).
+//   UVROOT : P = I + sum_k (U[:,k] expm1(t Root_k)) V[k,:], t<1e-100 -> I, entries <0 -> 0  (tools.c:516-546)
+//   CIJK   : P_ij = delta_ij + sum_{k>=1} Cijk[i][j][k] expm1(t Root_k), no clamp           (baseml.c:1572-1589)
+//   K80    : closed form (tools.c:578-604);  JC69LIKE: closed form (codeml.c:3585-3595)
+// with t = branch * rateSite * rgene [* Qfactor]  (codeml.c:3547-3551, treesub.c:7587).
+// Outputs, all for the branch above `node`:
+//   rowmajor  [n*n]                P[from*n+to]           (get_pmat; matmul operand of the VALU kernels)
+//   frag      [8][4][64][2]        MFMA A-operand order   (mfma64 kernel; see prune_mfma64)
+//   tip table [n_codes][...]       column sums over each character code's state set
+//                                  (codeml.c:3555-3567), [code][n] for VALU, [code][q][m] for mfma64
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double pmat_time(const PmatArgs &a, const InlineVec &iv, int bat, int node, int gene, int iclass)
+{
+   // t = branch * rateSite * rgene (codeml.c:3547-3551)
+   const double br = iv.n_branch ? iv.v[node] : a.branch[bat * a.branch_bs + node];
+   const double gr = iv.n_branch ? iv.v[iv.n_branch + gene] : a.gene_rate[bat * a.gene_rate_bs + gene];
+   return (br * a.rate[bat * a.rate_bs + gene * a.rate_gs + iclass]) * gr;
+}
+
+// Models with at most 5 states (the one-pattern-per-lane kernels): 32 threads per matrix, eight matrices per workgroup, no
+// 64 x 64 staging — the general kernel below spends 9 us on the 244 4 x 4 matrices of a 32-taxon Gamma-4 evaluation.
+// Same arithmetic and summation order as pmat_kernel.  Rate-matrix (UNREST) sets stay with the general kernel.
+__global__ __launch_bounds__(256) void pmat_small_kernel(PmatArgs a, InlineVec iv)
+{
+   __shared__ double sP[8][32];
+   const int n = a.n, sub = threadIdx.x >> 5, t5 = threadIdx.x & 31;
+   const int KB = a.K * a.B, n_mat = a.n_nodes * a.n_genes * KB;
+   const int m = blockIdx.x * 8 + sub;
+   const bool on = m < n_mat;
+   const int node = on ? m % a.n_nodes : 0, pset = on ? m / a.n_nodes : 0;
+   const int gene = pset / KB, bat = (pset % KB) / a.K, iclass = pset % a.K;
+   const bool active = on && node != a.root;
+   const int i = t5 / n, j = t5 % n;
+   const bool ent = active && t5 < n * n;
+   double p = 0;
+   int lab = 0;
+   if (active) lab = a.label[node];
+   if (ent) {
+      const EigenDev es = a.eigen[a.eigen_of[bat * a.eigen_of_bs + (gene * a.K + iclass) * a.n_labels + lab]];
+      double t = pmat_time(a, iv, bat, node, gene, iclass);
+      if (es.kind == PAML_AMD_EIGEN_UVROOT) {
+         t *= a.qfactor[bat * a.qfactor_bs + iclass * a.n_labels + lab];
+         if (t < 1e-100) p = (i == j) ? 1.0 : 0.0;
+         else {
+            double acc = 0;
+            for (int k = 0; k < n; k++) acc = fma(es.U[i * n + k] * expm1(t * es.Root[k]), es.V[k * n + j], acc);
+            p = acc + (i == j ? 1.0 : 0.0);
+            p = p < 0 ? 0.0 : p;
+         }
+      }
+      else if (es.kind == PAML_AMD_EIGEN_CIJK) {
+         const double *c = es.Cijk + ((long)i * n + j) * es.nR;
+         double sacc = 0;
+         for (int k = 0; k < es.nR; k++) sacc += c[k] * (k >= 1 ? expm1(t * es.Root[k]) : 0.0);
+         if (i == j) sacc += 1.0;
+         p = sacc;
+      }
+      else if (es.kind == PAML_AMD_EIGEN_K80) {
+         const double kappa = es.kappa;
+         const double e1 = expm1(-4 * t / (kappa + 2));
+         const bool jc = fabs(kappa - 1) < 1e-20;
+         const double e2 = jc ? 0.0 : expm1(-2 * t * (kappa + 1) / (kappa + 2));
+         if (jc) p = (i == j) ? 1. + 3 / 4.0 * e1 : -e1 / 4;
+         else if (i == j) p = 1 + (e1 + 2 * e2) / 4;
+         else if ((i ^ j) == 1) p = (e1 - 2 * e2) / 4;
+         else p = -e1 / 4;
+      }
+      else {   // JC69-like
+         const double pii = 1. / n + (1. - 1. / n) * exp(-n / (n - 1.) * t);
+         p = i == j ? pii : (1. - pii) / (n - 1.);
+      }
+   }
+   sP[sub][t5] = p;
+   __syncthreads();
+   if (!active) return;
+   const long slot = (long)pset * a.n_nodes + node;
+   if (ent) a.rowmajor[slot * n * n + t5] = p;
+   if (a.is_leaf[node]) {
+      double *pt = a.ptip + slot * a.tip_words;
+      for (int idx = t5; idx < a.n_codes * n; idx += 32) {
+         const int code = idx / n, jj = idx % n;
+         const int nc = a.n_chara[code];
+         const unsigned char *map = a.chara_map + code * n;
+         double s2 = 0;
+         for (int k = 0; k < nc; k++) s2 += sP[sub][jj * n + map[k]];
+         pt[idx] = s2;
+      }
+   }
+}
+
+__global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a, InlineVec iv)
+{
+   extern __shared__ __attribute__((aligned(16))) double smem[];
+   double *sA = smem;            // [64][64]  U*expm1 -> later the finished P (padded with zeros)
+   double *sB = smem + 4096;     // [64][64]  V
+   const int node = blockIdx.x, pset = blockIdx.y;
+   if (node == a.root) return;
+   const int tid = threadIdx.x, n = a.n;
+   const int KB = a.K * a.B;
+   const int gene = pset / KB, bat = (pset % KB) / a.K, iclass = pset % a.K;
+   const int lab = a.label[node];
+   const EigenDev es = a.eigen[a.eigen_of[bat * a.eigen_of_bs + (gene * a.K + iclass) * a.n_labels + lab]];
+   double t = pmat_time(a, iv, bat, node, gene, iclass);
+
+   // tip branches: the ambiguity map (tools.c:20 nChara / CharaMap) comes to LDS now, so that the column-table loop at
+   // the end does not chase two dependent global loads per entry
+   __shared__ unsigned char sMap[256 * 64];
+   __shared__ int sNch[256];
+   const bool leaf = a.is_leaf[node] != 0;
+   if (leaf) {
+      for (int idx = tid; idx < a.n_codes * n; idx += 256) sMap[idx] = a.chara_map[idx];
+      for (int idx = tid; idx < a.n_codes; idx += 256) sNch[idx] = a.n_chara[idx];
+   }
+
+   const int j = tid & 63, rg = tid >> 6;   // this thread: column j, rows rg*16 .. rg*16+15
+   double acc[16];
+#pragma unroll
+   for (int r = 0; r < 16; r++) acc[r] = 0;
+
+   if (es.kind == PAML_AMD_EIGEN_UVROOT) {
+      t *= a.qfactor[bat * a.qfactor_bs + iclass * a.n_labels + lab];
+      if (t < 1e-100) {
+#pragma unroll
+         for (int r = 0; r < 16; r++) acc[r] = (rg * 16 + r == j) ? 1.0 : 0.0;
+      }
+      else {
+         for (int idx = tid; idx < 4096; idx += 256) {
+            int i = idx >> 6, k = idx & 63;
+            double ue = 0, v = 0;
+            if (i < n && k < n) {
+               ue = es.U[i * n + k] * expm1(t * es.Root[k]);
+               v = es.V[i * n + k];        // here (i,k) index V as [k'][j'] = [i][k]
+            }
+            sA[k * 64 + i] = ue;           // transposed: the four rows of a register tile are contiguous for every k
+            sB[idx] = v;
+         }
+         __syncthreads();
+         {
+            // 4 x 4 register tile per thread: four 16-byte LDS reads feed sixteen FMAs; every element still accumulates
+            // k ascending (PMatUVRoot's order, tools.c:525-537)
+            const int ti = tid >> 4, tj = tid & 15;
+            double c[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+               for (int cc = 0; cc < 4; cc++) c[r][cc] = 0;
+            for (int k = 0; k < n; k++) {
+               const double2 a0 = *(const double2 *)&sA[k * 64 + 4 * ti], a1 = *(const double2 *)&sA[k * 64 + 4 * ti + 2];
+               const double2 b0 = *(const double2 *)&sB[k * 64 + 4 * tj], b1 = *(const double2 *)&sB[k * 64 + 4 * tj + 2];
+               const double av[4] = {a0.x, a0.y, a1.x, a1.y}, bv[4] = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+               for (int r = 0; r < 4; r++)
+#pragma unroll
+                  for (int cc = 0; cc < 4; cc++) c[r][cc] = fma(av[r], bv[cc], c[r][cc]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+               for (int cc = 0; cc < 4; cc++) sA[(4 * ti + r) * 64 + 4 * tj + cc] = c[r][cc];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = sA[(rg * 16 + r) * 64 + j];
+         }
+#pragma unroll
+         for (int r = 0; r < 16; r++) {
+            int i = rg * 16 + r;
+            double p = acc[r] + (i == j ? 1.0 : 0.0);
+            acc[r] = (i < n && j < n) ? (p < 0 ? 0.0 : p) : 0.0;
+         }
+         __syncthreads();
+      }
+   }
+   else if (es.kind == PAML_AMD_EIGEN_CIJK) {
+      double e[64];
+      const int nR = es.nR;
+      for (int idx = tid; idx < 64; idx += 256) sB[idx] = (idx >= 1 && idx < nR) ? expm1(t * es.Root[idx]) : 0.0;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+         int i = rg * 16 + r;
+         double s = 0;
+         if (i < n && j < n) {
+            const double *c = es.Cijk + ((long)i * n + j) * nR;
+            for (int k = 0; k < nR; k++) s += c[k] * sB[k];
+            if (i == j) s += 1.0;
+         }
+         acc[r] = s;
+      }
+      (void)e;
+      __syncthreads();
+   }
+   else if (es.kind == PAML_AMD_EIGEN_K80) {
+      const double kappa = es.kappa;
+      const double e1 = expm1(-4 * t / (kappa + 2));
+      const bool jc = fabs(kappa - 1) < 1e-20;
+      const double e2 = jc ? 0.0 : expm1(-2 * t * (kappa + 1) / (kappa + 2));
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+         int i = rg * 16 + r;
+         double p = 0;
+         if (i < 4 && j < 4) {
+            if (jc) p = (i == j) ? 1. + 3 / 4.0 * e1 : -e1 / 4;
+            else if (i == j) p = 1 + (e1 + 2 * e2) / 4;
+            else if ((i ^ j) == 1) p = (e1 - 2 * e2) / 4;
+            else p = -e1 / 4;
+         }
+         acc[r] = p;
+      }
+   }
+   else if (es.kind == PAML_AMD_EIGEN_QMAT) {
+      // UNREST: P = e^{Qt} by matexp(Qt, n, 7, 5) (tools.c:4879): B = Qt/32, e^B by seven Taylor terms, then five squarings.
+      // n <= 8: one thread per entry, four n x n scratch matrices in LDS.
+      double *T0 = sA, *T1 = sA + 64, *T2 = sA + 128, *Bm = sA + 192;
+      const int i = tid / n, jj = tid % n;
+      const bool on = tid < n * n;
+      if (on) {
+         const double v = es.U[tid] * t * (1.0 / 32);
+         Bm[tid] = v; T1[tid] = v;
+         T0[tid] = v + (i == jj ? 1.0 : 0.0);
+      }
+      __syncthreads();
+      double factor = 1;
+      double *Tp = T1, *Tn = T2;              // B^(k-1) and B^k
+      for (int term = 2; term <= 7; term++) {
+         double s = 0;
+         if (on)
+            for (int k2 = 0; k2 < n; k2++) s += Tp[i * n + k2] * Bm[k2 * n + jj];
+         factor /= term;
+         if (on) { Tn[tid] = s; T0[tid] += s * factor; }
+         __syncthreads();
+         double *sw = Tp; Tp = Tn; Tn = sw;
+      }
+      double *Sa = T0, *Sb = T1;
+      for (int sq = 0; sq < 5; sq++) {
+         double s = 0;
+         if (on)
+            for (int k2 = 0; k2 < n; k2++) s += Sa[i * n + k2] * Sa[k2 * n + jj];
+         __syncthreads();
+         if (on) Sb[tid] = s;
+         __syncthreads();
+         double *sw = Sa; Sa = Sb; Sb = sw;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+         const int ii = rg * 16 + r;
+         acc[r] = (ii < n && j < n) ? Sa[ii * n + j] : 0.0;
+      }
+      __syncthreads();
+   }
+   else {   // JC69-like (aa Poisson): no Qfactor (treesub.c:7584-7585)
+      const double pii = 1. / n + (1. - 1. / n) * exp(-n / (n - 1.) * t);
+      const double pij = (1. - pii) / (n - 1.);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+         int i = rg * 16 + r;
+         acc[r] = (i < n && j < n) ? (i == j ? pii : pij) : 0.0;
+      }
+   }
+
+   // finished P (zero padded to 64x64) into LDS
+#pragma unroll
+   for (int r = 0; r < 16; r++) sA[(rg * 16 + r) * 64 + j] = acc[r];
+   __syncthreads();
+
+   const long slot = (long)pset * a.n_nodes + node;
+   double *rm = a.rowmajor + slot * n * n;
+   for (int idx = tid; idx < n * n; idx += 256) rm[idx] = sA[(idx / n) * 64 + (idx % n)];
+
+   if (a.layout == 1 && !leaf) {
+      // MFMA A-operand order: element ((kb2*4 + jb)*64 + lane)*2 + e  =  P[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)]
+      double *pf = a.pint + slot * 4096;
+      for (int idx = tid; idx < 4096; idx += 256) {
+         int e = idx & 1, lane = (idx >> 1) & 63, jb = (idx >> 7) & 3, kb2 = idx >> 9;
+         pf[idx] = sA[(jb * 16 + (lane & 15)) * 64 + 4 * (2 * kb2 + e) + (lane >> 4)];
+      }
+      // column 60 in the order a lane's accumulators want it, pcol[q][m] = P[4m + q][60]: with 61 states the last
+      // k-block holds this one column, and the specialised kernel adds its rank-1 term on the vector pipe instead of
+      // spending four MFMAs on it
+      if (a.pcol && tid < 64) a.pcol[slot * 64 + tid] = sA[(4 * (tid & 15) + (tid >> 4)) * 64 + 60];
+   }
+   if (leaf) {
+      const int tipw = a.layout == 1 ? 64 : n;
+      double *pt = a.ptip + slot * a.tip_words;
+      for (int idx = tid; idx < a.n_codes * tipw; idx += 256) {
+         int code = idx / tipw, w = idx % tipw, jj;
+         if (a.layout == 1) {
+            // row (code, q) = 128 bytes = 8 pieces of two states; piece p is stored in slot p ^ ((row >> 1) & 7) so
+            // that lanes gathering different rows from an LDS copy of this table spread over the banks
+            const int q = w >> 4, slot = (w & 15) >> 1, row = code * 4 + q;
+            const int m = ((slot ^ TIP_SWZ(row)) << 1) | (w & 1);
+            jj = 4 * m + q;
+         }
+         else if (a.layout == 2) jj = 4 * (w % 5) + w / 5;      // 20 states on 4x4x4 MFMAs: [code][state & 3][state >> 2], a lane's five states contiguous
+         else jj = w;
+         double s = 0;
+         if (jj < n) {
+            const int nc = sNch[code];
+            const unsigned char *map = sMap + code * n;
+            for (int k = 0; k < nc; k++) s += sA[jj * 64 + map[k]];
+         }
+         pt[idx] = s;
+      }
+   }
+}
+
+}  // namespace paml_amd

@@ -1,0 +1,607 @@
+// kernels_prune.h — Kernel B: fused Felsenstein pruning (FP64 MFMA path for 21..64 states, one-pattern-per-lane path for
+// 4 / 5 / 20 states) and the two layout kernels that prepare the tip codes for the per-tree kernels.  Wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernel_args.h"
+
+namespace paml_amd {
+
+// ------------------------------------------------------------------------------------------------
+// Pruning kernels: arguments shared by the MFMA and VALU variants.
+// ------------------------------------------------------------------------------------------------
+// ---- mfma64: 21..64 states, FP64 MFMA -----------------------------------------------------------
+// One wave owns 16 patterns for the whole tree.  A partial is 16 doubles per lane: lane l holds, for
+// pattern (l & 15), the states 4m + (l >> 4), m = 0..15.  That is simultaneously
+//   * the B operand of v_mfma_f64_16x16x4_f64 for k-block kb = m  (B[k = l>>4][n = l&15]), and
+//   * the D layout of the instruction for row block jb = m>>2, register m&3  (row = (l>>4) + 4 reg),
+// so cur' = P . cur chains from node to node entirely in registers: no transposes, no LDS traffic for
+// partials.  The A operand (P) is staged once per workgroup per branch into LDS in exactly the order
+// lanes consume it (pmat_kernel's `frag` layout), double-buffered so the next branch's P streams in
+// under the current MFMAs.  Tip branches are gathers from L2-resident column tables.
+// Shared op bodies of the two mfma64 kernels (textual, so every register array keeps static indices).
+#define MFMA_EPI_INTO(DST)                                                                                       \
+   do {                                                                                                         \
+      if (pop < 0) {                                                                                            \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = acc[m >> 2][m & 3];                            \
+      }                                                                                                         \
+      else if (pop == 0) {                                                                                      \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = s0[m] * acc[m >> 2][m & 3];                    \
+      }                                                                                                         \
+      else if (pop == 1) {                                                                                      \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = s1[m] * acc[m >> 2][m & 3];                    \
+      }                                                                                                         \
+      else {                                                                                                    \
+         const double *sp2 = a.stack_scratch +                                                                  \
+                             (((long)blockIdx.x * a.stack_overflow_slots + (pop - MFMA_RS)) * WAVES + wave) * 1024; \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = sp2[m * 64 + lane] * acc[m >> 2][m & 3];       \
+      }                                                                                                         \
+   } while (0)
+
+#define MFMA_EPILOGUE()                                                                                          \
+   do {                                                                                                         \
+      const int pop = mm_pop_slot(op), push = mm_push_slot(op);                                                 \
+      if (push < 0) MFMA_EPI_INTO(cur);                                                                         \
+      else if (push == 0) MFMA_EPI_INTO(s0);                                                                    \
+      else if (push == 1) MFMA_EPI_INTO(s1);                                                                    \
+      else {                                                                                                    \
+         double tmpv[16];                                                                                       \
+         MFMA_EPI_INTO(tmpv);                                                                                   \
+         double *sp3 = a.stack_scratch +                                                                        \
+                       (((long)blockIdx.x * a.stack_overflow_slots + (push - MFMA_RS)) * WAVES + wave) * 1024;  \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) sp3[m * 64 + lane] = tmpv[m];                           \
+      }                                                                                                         \
+   } while (0)
+
+#define MFMA_CORE_CASES()                                                                                        \
+   case OP_INIT_ONES: {                                                                                         \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] = (4 * m + q < n) ? 1.0 : 0.0;                      \
+   } break;                                                                                                     \
+   case OP_INIT_TIP: {                                                                                          \
+      const int code = TIP_CODE(op.a);                                                                          \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] = (a.cleandata && 4 * m + q == code) ? 1.0 : 0.0;   \
+   } break;
+
+#define MFMA_EXT_CASES()                                                                                         \
+   case OP_PUSH: {                                                                                              \
+      if (op.b == 0) { _Pragma("unroll") for (int m = 0; m < 16; m++) s0[m] = cur[m]; }                         \
+      else if (op.b == 1) { _Pragma("unroll") for (int m = 0; m < 16; m++) s1[m] = cur[m]; }                    \
+      else {                                                                                                    \
+         double *sp = a.stack_scratch +                                                                         \
+                      (((long)blockIdx.x * a.stack_overflow_slots + (op.b - MFMA_RS)) * WAVES + wave) * 1024;   \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) sp[m * 64 + lane] = cur[m];                             \
+      }                                                                                                         \
+   } break;                                                                                                     \
+   case OP_SCALE: {                                                                                             \
+      double mx = 0;                                                                                            \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) mx = cur[m] > mx ? cur[m] : mx;                            \
+      double o = __shfl_xor(mx, 16);                                                                            \
+      mx = o > mx ? o : mx;                                                                                     \
+      o = __shfl_xor(mx, 32);                                                                                   \
+      mx = o > mx ? o : mx;                                                                                     \
+      double fac;                                                                                               \
+      if (mx < 1e-300) {                                                                                        \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] = (4 * m + q < n) ? 1.0 : 0.0;                   \
+         fac = -800;                                                                                            \
+      }                                                                                                         \
+      else {                                                                                                    \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] /= mx;                                           \
+         fac = log(mx);                                                                                         \
+      }                                                                                                         \
+      lnscale += fac;                                                                                           \
+      if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + op.b) * a.n_patt + h] = fac;          \
+   } break;                                                                                                     \
+   case OP_STORE: {  /* native layout [class][node][16-pattern group][m][lane] */                               \
+      double *dst = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) +    \
+                                  ((long)tile * WAVES + wave)) * 1024;                                          \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) dst[m * 64 + lane] = cur[m];                               \
+   } break;                                                                                                     \
+   case OP_LOAD: {                                                                                              \
+      const double *src = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) + \
+                                        ((long)tile * WAVES + wave)) * 1024;                                    \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] = src[m * 64 + lane];                               \
+   } break;
+
+#define MFMA_ROOT_CASE()                                                                                         \
+   case OP_ROOT: {                                                                                              \
+      const double *pq = a.pi + (long)(a.n_pi > 1 ? gene : 0) * 64 + q * 16;                                    \
+      double f = 0;                                                                                             \
+      _Pragma("unroll") for (int m = 0; m < 16; m++) f = fma(pq[m], cur[m], f);                                 \
+      f += __shfl_xor(f, 16);                                                                                   \
+      f += __shfl_xor(f, 32);                                                                                   \
+      if (a.keep && a.n_scale) { /* stored factors summed in slot order (treesub.c:7746-7747) */                \
+         lnscale = 0;                                                                                           \
+         if (valid)                                                                                             \
+            for (int k = 0; k < a.n_scale; k++) lnscale += a.scalef[((long)iclass * a.n_scale + k) * a.n_patt + h]; \
+      }                                                                                                         \
+      if (q == 0 && valid) {                                                                                    \
+         double out = 0;                                                                                        \
+         if (a.weights[h] > 0) out = root_value(a, f, lnscale);                                                 \
+         a.fhK[(long)iclass * a.n_patt + h] = out;                                                              \
+      }                                                                                                         \
+   } break;
+
+// register-stack-only epilogue (programs with max_stack <= MFMA_RS)
+#define MFMA_EPI_REG(DST)                                                                                        \
+   do {                                                                                                         \
+      if (pop < 0) {                                                                                            \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = acc[m >> 2][m & 3];                            \
+      }                                                                                                         \
+      else if (pop == 0) {                                                                                      \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = s0[m] * acc[m >> 2][m & 3];                    \
+      }                                                                                                         \
+      else {                                                                                                    \
+         _Pragma("unroll") for (int m = 0; m < 16; m++) DST[m] = s1[m] * acc[m >> 2][m & 3];                    \
+      }                                                                                                         \
+   } while (0)
+#define MFMA_EPILOGUE_REG()                                                                                      \
+   do {                                                                                                         \
+      const int pop = mm_pop_slot(op), push = mm_push_slot(op);                                                 \
+      if (push < 0) MFMA_EPI_REG(cur);                                                                          \
+      else if (push == 0) MFMA_EPI_REG(s0);                                                                     \
+      else MFMA_EPI_REG(s1);                                                                                    \
+   } while (0)
+
+#ifdef PROF_OPS
+#define PROF_STAMP(slot) \
+   if (a.prof && tid == a.prof_tid) a.prof[(long)blockIdx.x * a.prof_stride + (slot)] = __builtin_amdgcn_s_memtime()
+// sub-stamps inside an op: plane 1 / 2 of the dump (same [block][op] indexing)
+#define PROF_SUB(plane, ip) \
+   if (a.prof && tid == a.prof_tid) a.prof[((long)(plane)*gridDim.x + blockIdx.x) * a.prof_stride + 1 + (ip)] = __builtin_amdgcn_s_memtime()
+#else
+#define PROF_STAMP(slot)
+#define PROF_SUB(plane, ip)
+#endif
+
+// ---- mfma64 "gather": tip columns gathered straight from the L2-resident tables into registers.
+// Used for trees with more than MFMA_ZT tips; 4 waves (64 patterns) per workgroup, 2 workgroups per CU.
+__device__ __forceinline__ void tip_gather(const double *Ptip, long tipstride, int tip, int code, int q, double2 (&v)[8])
+{
+   const int row = code * 4 + q, swz = TIP_SWZ(row);
+   const double2 *pt = (const double2 *)(Ptip + (long)tip * tipstride + row * 16);
+#pragma unroll
+   for (int i = 0; i < 8; i++) v[i] = pt[i ^ swz];     // piece i lives in slot i ^ swz (see pmat_kernel)
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_gather(PruneArgs a)
+{
+   __shared__ __attribute__((aligned(16))) double sP[2][4096];
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int q = lane >> 4, hl = lane & 15;
+   const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;
+   const int hend = as_const(a.gene_off)[gene + 1];
+   const int h = h0 + wave * 16 + hl;
+   const bool valid = h < hend;
+   const int hc = valid ? h : hend - 1;
+   const long pset = (long)gene * a.K + iclass;
+   const double *Pint = a.pint + pset * a.n_nodes * 4096;
+   const long tipstride = a.tip_words;
+   const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
+   const int n = a.n;
+
+   PROF_STAMP(a.prof_stride - 1);
+   if (a.first_matmul >= 0) stage_p<WAVES>(Pint + (long)a.first_matmul * 4096, sP[0], wave, lane);
+
+   double cur[16], s0[16], s1[16];   // every program writes cur/s0/s1 (INIT/SET/PUSH) before reading them
+   double lnscale = 0;
+   int buf = 0;
+#define TIP_CODE(tip) ((int)a.z[(long)(tip)*a.z_stride + hc])
+   PROF_STAMP(0);
+   const int lane0 = lane;
+   for (int ip = 0;; ip++) {
+      const Op op = fetch_op(a.ops, ip);
+      PROF_STAMP(1 + ip);
+      if (op.code == OP_END) break;
+      int lane = lane0;             // opaque per-iteration copy: keeps LICM from hoisting (and spilling) lane math
+      asm volatile("" : "+v"(lane));
+      const int q = lane >> 4;
+      switch (op.code) {
+         MFMA_CORE_CASES()
+         MFMA_EXT_CASES()
+         MFMA_ROOT_CASE()
+      case OP_EXPORT: {
+         if (valid) {
+            double *dst = a.export_buf + ((long)iclass * a.n_patt + h) * n;
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+               if (4 * m + q < n) dst[4 * m + q] = cur[m];
+            if (a.export_scale && q == 0) a.export_scale[(long)iclass * a.n_patt + h] = lnscale;
+         }
+      } break;
+      case OP_MUL_TIP:
+      case OP_SET_TIP: {
+         double2 v[8];
+         tip_gather(Ptip, tipstride, op.a, TIP_CODE(op.a), q, v);
+         if (op.code == OP_SET_TIP) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x; cur[2 * i + 1] = v[i].y; }
+         }
+         else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur[2 * i] *= v[i].x; cur[2 * i + 1] *= v[i].y; }
+         }
+      } break;
+      case OP_SET_TIP2:
+      case OP_MUL_TIP2: {
+         const int c1 = TIP_CODE(op.a), c2 = TIP_CODE(op.b);
+         double2 v[8], w[8];
+         tip_gather(Ptip, tipstride, op.a, c1, q, v);
+         tip_gather(Ptip, tipstride, op.b, c2, q, w);
+         if (op.code == OP_SET_TIP2) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x * w[i].x; cur[2 * i + 1] = v[i].y * w[i].y; }
+         }
+         else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+               cur[2 * i] = (cur[2 * i] * v[i].x) * w[i].x;
+               cur[2 * i + 1] = (cur[2 * i + 1] * v[i].y) * w[i].y;
+            }
+         }
+      } break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+         __syncthreads();   // this branch's P has landed in sP[buf]; every wave is done reading sP[buf^1]
+         if (op.c >= 0) stage_p<WAVES>(Pint + (long)op.c * 4096, sP[buf ^ 1], wave, lane);
+         v4d acc[4];
+         mfma_matvec(sP[buf], lane, cur, acc);
+         MFMA_EPILOGUE();
+         buf ^= 1;
+      } break;
+      default: break;
+      }
+   }
+#undef TIP_CODE
+}
+
+// ---- mfma64 "stream": the production kernel (<= MFMA_ZT tips, <= 64 character codes, register stack).
+// Every operand the tree walk consumes — the P of an internal branch in MFMA order, or the whole column
+// table of a tip branch — is one 32 KB block, and the program fixes the order in which blocks are used.
+// 8 waves (128 patterns) per workgroup share a ring of four 32 KB LDS buffers that a linear LDS-DMA
+// stream keeps filled three blocks ahead of use (4 x buffer_load_dwordx4 ... lds per wave per block),
+// so neither P nor tip data is ever waited for at L2 latency, no VGPRs hold data in flight, and every
+// DMA instruction is a fully coalesced 1 KB line burst.  Tip factors are then LDS gathers (rows are
+// XOR-swizzled by pmat_kernel so random rows spread over the banks); one s_barrier per step.
+__global__ __launch_bounds__(512, 2) void prune_mfma64_stream(PruneArgs a)
+{
+   constexpr int WAVES = 8, TP = 128;
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem_stream[];
+   double *ring = (double *)smem_stream;                        // [4][4096]
+   unsigned char *sZ = (unsigned char *)(ring + 4 * 4096);      // [n_tips][128]
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int hl = lane & 15;
+   const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;
+   const int hend = as_const(a.gene_off)[gene + 1];
+   const int hw = wave * 16 + hl;          // pattern within the tile
+   const int h = h0 + hw;
+   const bool valid = h < hend;
+   const long pset = (long)gene * a.K + iclass;
+   const double *Pint = a.pint + pset * a.n_nodes * 4096;
+   const long tipstride = 4096;            // one 32 KB block per tip (n_codes <= 64)
+   const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
+   const int n = a.n;
+   const StreamBlk *stream = (const StreamBlk *)a.stream;
+   const int nblk = a.n_stream;
+
+   PROF_STAMP(a.prof_stride - 1);
+   int issued = 0, consumed = 0;
+#define STREAM_ISSUE()                                                                                           \
+   do {                                                                                                         \
+      const long long sb = ((const CONST_AS long long *)(unsigned long long)stream)[issued];                    \
+      const int is_tip = (int)(sb & 0xffffffff), node = (int)(sb >> 32);                                        \
+      const double *src = is_tip ? Ptip + (long)node * tipstride : Pint + (long)node * 4096;                    \
+      stage_p<WAVES>(src, ring + (issued & 3) * 4096, wave, lane);                                              \
+      issued++;                                                                                                 \
+   } while (0)
+   for (int i = 0; i < 3; i++)
+      if (issued < nblk) STREAM_ISSUE();
+   {
+      const int nz = a.n_tips * TP;
+      for (int idx = tid; idx < nz; idx += WAVES * 64) {
+         const int tip = idx / TP, hh = idx % TP;
+         const int hx = h0 + hh < hend ? h0 + hh : hend - 1;
+         sZ[idx] = a.z[(long)tip * a.z_stride + hx];
+      }
+   }
+   __syncthreads();   // publish sZ (INIT_TIP may read it before the first stream step)
+
+   double cur[16], s0[16], s1[16];   // every program writes cur/s0/s1 (INIT/SET/PUSH) before reading them
+   double lnscale = 0;
+#define TIP_CODE(tip) ((int)sZ[(tip)*TP + hw])
+   // consume the next c blocks of the stream: they have landed for every wave after this returns, and the
+   // buffers used by the previous step are refilled with the blocks 3..4 ahead
+#ifdef ABL_NO_BARRIER
+#define STREAM_BARRIER()
+#else
+#define STREAM_BARRIER() __syncthreads()
+#endif
+#define STREAM_STEP(c)                                                                                           \
+   do {                                                                                                         \
+      wait_blocks_in_flight(issued - (consumed + (c)));                                                         \
+      STREAM_BARRIER();                                                                                         \
+      while (issued < consumed + 4 && issued < nblk) STREAM_ISSUE();                                            \
+   } while (0)
+
+   PROF_STAMP(0);
+   const int lane0 = lane;
+   for (int ip = 0;; ip++) {
+      const Op op = fetch_op(a.ops, ip);
+      PROF_STAMP(1 + ip);
+      if (op.code == OP_END) break;
+      // re-derive every per-lane address from an opaque copy of the lane id inside the loop: cheap VALU,
+      // and nothing loop-invariant is left for LICM to hoist into (spilled) VGPRs
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      const int q = lane >> 4;
+      switch (op.code) {
+         MFMA_CORE_CASES()
+         MFMA_ROOT_CASE()
+      case OP_MUL_TIP:
+      case OP_SET_TIP: {
+         double2 v[8];
+         STREAM_STEP(1);
+         tip_lds(ring + (consumed & 3) * 4096, TIP_CODE(op.a), q, lane, v);
+         consumed += 1;
+         if (op.code == OP_SET_TIP) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x; cur[2 * i + 1] = v[i].y; }
+         }
+         else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur[2 * i] *= v[i].x; cur[2 * i + 1] *= v[i].y; }
+         }
+      } break;
+      case OP_SET_TIP2:
+      case OP_MUL_TIP2: {
+         double2 v[8], w[8];
+         STREAM_STEP(2);
+         tip_lds(ring + (consumed & 3) * 4096, TIP_CODE(op.a), q, lane, v);
+         tip_lds(ring + ((consumed + 1) & 3) * 4096, TIP_CODE(op.b), q, lane, w);
+         consumed += 2;
+         if (op.code == OP_SET_TIP2) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { cur[2 * i] = v[i].x * w[i].x; cur[2 * i + 1] = v[i].y * w[i].y; }
+         }
+         else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+               cur[2 * i] = (cur[2 * i] * v[i].x) * w[i].x;
+               cur[2 * i + 1] = (cur[2 * i + 1] * v[i].y) * w[i].y;
+            }
+         }
+      } break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         STREAM_STEP(1);
+         PROF_SUB(1, ip);
+         v4d acc[4];
+         mfma_matvec(ring + (consumed & 3) * 4096, lane, cur, acc);
+         consumed += 1;
+         PROF_SUB(2, ip);
+         MFMA_EPILOGUE_REG();
+      } break;
+      default: break;
+      }
+   }
+#undef TIP_CODE
+#undef STREAM_STEP
+#undef STREAM_ISSUE
+}
+
+// ---- valu<N>: 4 / 5 / 20 states, one pattern per lane ------------------------------------------
+// The partial lives in N registers; P(t) entries are wave-uniform, so the compiler fetches them with
+// scalar loads (s_load) and feeds v_fma_f64 from SGPRs: no LDS, no barriers.  The whole tree is walked
+// per lane, so only tips (1 B) and the result (8 B) touch HBM unless keep-partials is on.
+// REGSTK: the partial stack is addressed through unrolled wave-uniform compares, so it stays in registers; the plain
+// form indexes stk[op.b] dynamically, which the compiler can only do through scratch memory (measured on the 20-state
+// kernel: 680 MB of scratch writes per launch at 1e5 patterns).  The engine picks the shallowest instantiation that
+// fits the tree's stack depth.
+template <int N, int MAXD, bool REGSTK = false>
+__global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
+{
+   const int tid = threadIdx.x;
+   const int tile = blockIdx.x % a.n_tiles, iclass = blockIdx.x / a.n_tiles;
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y;
+   const int hend = as_const(a.gene_off)[gene + 1];
+   const int h = h0 + tid;
+   const bool valid = h < hend;
+   const int hc = valid ? h : hend - 1;
+   const long pset = (long)gene * a.K + iclass;
+   const double *Pint = a.pint + pset * a.n_nodes * (N * N);
+   const long tipstride = a.tip_words;
+   const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
+
+   double cur[N];
+   double stk[MAXD][N];
+   double lnscale = 0;
+#pragma unroll
+   for (int j = 0; j < N; j++) cur[j] = 0;
+
+   for (int ip = 0;; ip++) {
+      const Op op = fetch_op(a.ops, ip);
+      if (op.code == OP_END) break;
+      switch (op.code) {
+      case OP_INIT_ONES: {
+#pragma unroll
+         for (int j = 0; j < N; j++) cur[j] = 1.0;
+      } break;
+      case OP_INIT_TIP: {
+         const int code = a.z[(long)op.a * a.z_stride + hc];
+#pragma unroll
+         for (int j = 0; j < N; j++) cur[j] = (a.cleandata && j == code) ? 1.0 : 0.0;
+      } break;
+      case OP_MUL_TIP: {
+         const int code = a.z[(long)op.a * a.z_stride + hc];
+         const double *pt = Ptip + (long)op.a * tipstride + code * N;
+#pragma unroll
+         for (int j = 0; j < N; j++) cur[j] *= pt[j];
+      } break;
+      case OP_SET_TIP: {
+         const int code = a.z[(long)op.a * a.z_stride + hc];
+         const double *pt = Ptip + (long)op.a * tipstride + code * N;
+#pragma unroll
+         for (int j = 0; j < N; j++) cur[j] = pt[j];
+      } break;
+      case OP_SET_TIP2:
+      case OP_MUL_TIP2: {
+         const int c1 = a.z[(long)op.a * a.z_stride + hc], c2 = a.z[(long)op.b * a.z_stride + hc];
+         const double *p1 = Ptip + (long)op.a * tipstride + c1 * N;
+         const double *p2 = Ptip + (long)op.b * tipstride + c2 * N;
+         if (op.code == OP_SET_TIP2) {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] = p1[j] * p2[j];
+         }
+         else {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] = (cur[j] * p1[j]) * p2[j];
+         }
+      } break;
+      case OP_PUSH: {
+         if constexpr (REGSTK) {
+#pragma unroll
+            for (int d = 0; d < MAXD; d++)
+               if (op.b == d) {
+#pragma unroll
+                  for (int j = 0; j < N; j++) stk[d][j] = cur[j];
+               }
+         }
+         else {
+#pragma unroll
+            for (int j = 0; j < N; j++) stk[op.b][j] = cur[j];
+         }
+      } break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         const CONST_AS double *P = as_const(Pint + (long)op.a * (N * N));
+         double out[N];
+#pragma unroll
+         for (int j = 0; j < N; j++) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) t = fma(P[j * N + k], cur[k], t);
+            out[j] = t;
+         }
+         const int pop = mm_pop_slot(op), push = mm_push_slot(op);
+         if constexpr (REGSTK) {
+#pragma unroll
+            for (int d = 0; d < MAXD; d++)
+               if (pop == d) {
+#pragma unroll
+                  for (int j = 0; j < N; j++) out[j] = stk[d][j] * out[j];
+               }
+#pragma unroll
+            for (int d = 0; d < MAXD; d++)
+               if (push == d) {
+#pragma unroll
+                  for (int j = 0; j < N; j++) stk[d][j] = out[j];
+               }
+         }
+         else {
+            if (pop >= 0) {
+#pragma unroll
+               for (int j = 0; j < N; j++) out[j] = stk[pop][j] * out[j];
+            }
+            if (push >= 0) {
+#pragma unroll
+               for (int j = 0; j < N; j++) stk[push][j] = out[j];
+            }
+         }
+         if (push < 0) {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] = out[j];
+         }
+      } break;
+      case OP_SCALE: {
+         double mx = 0;
+#pragma unroll
+         for (int j = 0; j < N; j++) mx = cur[j] > mx ? cur[j] : mx;
+         double fac;
+         if (mx < 1e-300) {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] = 1.0;
+            fac = -800;
+         }
+         else {
+#pragma unroll
+            for (int j = 0; j < N; j++) cur[j] /= mx;
+            fac = log(mx);
+         }
+         lnscale += fac;
+         if (a.keep && valid) a.scalef[((long)iclass * a.n_scale + op.b) * a.n_patt + h] = fac;
+      } break;
+      case OP_STORE: {
+         if (valid) {
+            double *dst = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * a.n_patt + h) * N;
+#pragma unroll
+            for (int j = 0; j < N; j++) dst[j] = cur[j];
+         }
+      } break;
+      case OP_LOAD: {
+         const double *src = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * a.n_patt + hc) * N;
+#pragma unroll
+         for (int j = 0; j < N; j++) cur[j] = src[j];
+      } break;
+      case OP_EXPORT: {
+         if (valid) {
+            double *dst = a.export_buf + ((long)iclass * a.n_patt + h) * N;
+#pragma unroll
+            for (int j = 0; j < N; j++) dst[j] = cur[j];
+            if (a.export_scale) a.export_scale[(long)iclass * a.n_patt + h] = lnscale;
+         }
+      } break;
+      case OP_ROOT: {
+         const double *pi = a.pi + (long)(a.n_pi > 1 ? gene : 0) * N;
+         double f = 0;
+#pragma unroll
+         for (int j = 0; j < N; j++) f = fma(pi[j], cur[j], f);
+         if (a.keep && a.n_scale) {
+            lnscale = 0;
+            if (valid)
+               for (int k = 0; k < a.n_scale; k++) lnscale += a.scalef[((long)iclass * a.n_scale + k) * a.n_patt + h];
+         }
+         if (valid) {
+            double out = 0;
+            if (a.weights[h] > 0) out = root_value(a, f, lnscale);
+            a.fhK[(long)iclass * a.n_patt + h] = out;
+         }
+      } break;
+      default: break;
+      }
+   }
+}
+
+// Tile blocks of the specialised kernel (PruneArgs::ztiles): per 128-pattern tile the tip codes of its patterns, one
+// 128-byte row per tip, then a row of weight > 0 flags; patterns past the tile's gene read as code 0 / flag 0.
+__global__ __launch_bounds__(256) void ztile_kernel(const int2 *tiles, const int *gene_off, const unsigned char *z, long z_stride,
+                                                    const double *weights, int n_tips, int zt_bytes, unsigned char *out)
+{
+   const int t = blockIdx.x, i = threadIdx.x, tp = blockDim.x;      // one thread per pattern of the tile (128 or 192)
+   const int g = tiles[t].x, h = tiles[t].y + i, hend = gene_off[g + 1];
+   unsigned char *o = out + (long)t * zt_bytes;
+   for (int tip = 0; tip < n_tips; tip++) o[tip * tp + i] = h < hend ? z[tip * z_stride + h] : (unsigned char)0;
+   o[n_tips * tp + i] = (h < hend && weights[h] > 0) ? 1 : 0;
+   for (int k = (n_tips + 1) * tp + i; k < zt_bytes; k += tp) o[k] = 0;
+}
+
+// Tip codes pattern-major for the fused one-pattern-per-lane kernels: row h = zw dwords, byte t = code of tip t.
+__global__ __launch_bounds__(256) void zpm_kernel(const unsigned char *z, long z_stride, int n_tips, int n_patt, int zw, unsigned int *out)
+{
+   const long h = (long)blockIdx.x * 256 + threadIdx.x;
+   if (h >= n_patt) return;
+   for (int w = 0; w < zw; w++) {
+      unsigned int v = 0;
+      for (int b = 0; b < 4; b++) {
+         const int t = 4 * w + b;
+         if (t < n_tips) v |= (unsigned int)z[t * z_stride + h] << (8 * b);
+      }
+      out[h * zw + w] = v;
+   }
+}
+
+}  // namespace paml_amd

@@ -15,7 +15,7 @@ import numpy as np
 
 
 def red_chunk(n_patt_global: int) -> int:
-    """Patterns per partial sum: a function of the global pattern count alone (engine.hip: red_chunk)."""
+    """Patterns per partial sum: a function of the global pattern count alone (engine_state.h: red_chunk)."""
     return max(256, (((n_patt_global + 1023) // 1024) + 255) // 256 * 256)
 
 

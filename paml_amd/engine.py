@@ -35,19 +35,35 @@ class EngineError(RuntimeError):
     pass
 
 
+UNITS = ("engine_core", "engine_comm", "engine_eval", "engine_branch", "engine_beb", "engine_jitdbg", "engine_compress")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.h", "program.h", "device_common.h", "jit.h")]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "paml_amd.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
-        return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per translation unit, in
+    parallel, then the shared library."""
+    import glob
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(_HERE), "include", "paml_amd.h")]
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH,
-           os.path.join(CSRC, "engine.hip"), "-lhiprtc", "-ldl"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objdir = os.path.join(os.path.dirname(LIB_PATH), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for u in UNITS:
+        src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(objdir, u + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(newest_hdr, os.path.getmtime(src)):
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+    objs = [os.path.join(objdir, u + ".o") for u in UNITS]
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(o) <= os.path.getmtime(LIB_PATH) for o in objs):
+        return LIB_PATH
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-lhiprtc", "-ldl"])
     return LIB_PATH
 
 
