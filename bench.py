@@ -108,13 +108,21 @@ def main():
                          % (world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    # PAML_AMD_BENCH_ONE_GPU=1 (tests): every rank on GPU 0, gloo as the courier — with PAML_AMD_RCCL_LIB naming the tests'
+    # shared-memory stand-in for RCCL this runs the whole N > 1 path on a one-GPU box (real RCCL refuses two ranks per device)
+    one_gpu = os.environ.get("PAML_AMD_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # torch.distributed carries the 128-byte RCCL id to the ranks and does the barrier / max-over-ranks of the timing; the
     # data-path exchange is the engine's own (paml_amd_comm_init).  PAML_AMD_BENCH_FORCE_DIST=1: the collective path in a
     # one-rank communicator on a single-GPU box.
     force_comm = os.environ.get("PAML_AMD_BENCH_FORCE_DIST") == "1"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from paml_amd import distributed, engine, models, synth
     if not os.path.exists(engine.LIB_PATH):
@@ -130,7 +138,7 @@ def main():
 
     def max_over_ranks(dt):
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return dt
@@ -141,6 +149,7 @@ def main():
         eng.set_stream(stream.cuda_stream)
         for i in range(warmup):
             eng.eval_device(branch, d.data_ptr() + 8 * i)
+        eng.flush()
         fence()
         if profile:
             eng.profile(True)
@@ -148,6 +157,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             eng.eval_device(branch, d.data_ptr() + 8 * (warmup + i))
+        eng.flush()      # (the stream waits for the totals still on the collective stream; nothing to do on one GPU)
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
         vals = d.cpu().numpy()

@@ -65,7 +65,9 @@ const char *paml_amd_last_error(const paml_amd_engine *e);
  *
  * paml_amd_shard_bounds (host only, no GPU): the contiguous block [*first, *first + *count) of n_patt_global patterns that
  *   rank `rank` of `world` owns.  Blocks are cut at multiples of the reduction chunk (a function of n_patt_global alone,
- *   >= 256 patterns), so the partial sums of every rank are entries of ONE global array.
+ *   >= 256 patterns), so the partial sums of every rank are entries of ONE global array.  More ranks than chunks
+ *   (paml_amd_max_ranks) would leave ranks without patterns: PAML_AMD_EUNSUPPORTED, for every rank alike, so that the ranks of
+ *   a job fail together before any of them enters a collective call.
  * paml_amd_comm_unique_id: rank 0 obtains the 128-byte RCCL id (ncclGetUniqueId) and hands it to the other ranks by any
  *   means (a pipe, a file, MPI, torch.distributed's store).
  * paml_amd_comm_init: collective over the ranks (ncclCommInitRank).  The engine was created for its shard's n_patt and holds
@@ -74,13 +76,18 @@ const char *paml_amd_last_error(const paml_amd_engine *e);
  *   independent of `world` (the ranks' zero-padded partial-sum arrays are added — exact — and summed in one fixed order).
  *   lnf / fhK / partials / posteriors stay per-shard.  world = 1 with a non-NULL id makes a one-rank communicator (the
  *   collective path on a single GPU); world = 1 with id = NULL only sets the global chunking.  eval_adg does not shard.
- * The RCCL library (librccl.so.1) is bound at run time on first use; PAML_AMD_EUNSUPPORTED when it is not installed. */
+ *   The exchange step (all-reduce of the partial sums + their fixed-order total) runs on a stream of the engine's own, ordered
+ *   by events: consecutive paml_amd_eval_device calls prune evaluation i + 1 while evaluation i is being reduced.  Every other
+ *   entry point, and paml_amd_flush, joins the engine's stream to the totals still on their way.
+ * The RCCL library (librccl.so.1, or the one PAML_AMD_RCCL_LIB names) is bound at run time on first use; PAML_AMD_EUNSUPPORTED
+ * when it is not installed. */
 /* GPUs visible to this process, and the one the calling thread's next paml_amd_create uses (hipSetDevice): a host written in C
  * — one process per GPU, as `pamlh_lnl --gpus N` forks them — needs no HIP headers. */
 int paml_amd_device_count(void);
 int paml_amd_set_device(int device);
 #define PAML_AMD_COMM_ID_BYTES 128
 int paml_amd_shard_bounds(long n_patt_global, int world, int rank, long *first, long *count);
+int paml_amd_max_ranks(long n_patt_global);      /* the number of reduction chunks = the largest world shard_bounds accepts */
 int paml_amd_comm_unique_id(void *id128);
 int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id128, long n_patt_global, long first_pattern);
 int paml_amd_comm_destroy(paml_amd_engine *e);
@@ -140,8 +147,11 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
 
 /* Same evaluation without the final device->host copy or synchronisation: lnL (the total over the
  * ranks when the engine has a communicator) is left in d_lnL (a device pointer, e.g. a torch tensor)
- * on the engine's stream. */
+ * on the engine's stream.  With a communicator the totals of the last two calls may still be on the collective stream:
+ * paml_amd_flush makes the engine's stream wait for them (one call after a run of eval_device calls, before the caller
+ * synchronises the stream or reads d_lnL on it); without a communicator it does nothing. */
 int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL);
+int paml_amd_flush(paml_amd_engine *e);
 
 /* Re-evaluate after a change that leaves the partials of the nodes with clean[node] != 0 valid
  * (com.oldconP, codeml.c:112, treespace.c:250): those subtrees are read back instead of recomputed.

@@ -38,7 +38,7 @@ static int beb_front(paml_amd_engine *e, const char *who, int n_grid, int n_cls,
 int paml_amd_beb_grid(paml_amd_engine *e, int n_grid, int n_cls, const double *pcl, const int *iw, const double *w_class,
                       double *ln_fx, double *pr_last, double *mean_w, double *sd_w)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || n_grid < 1 || n_cls < 1 || !pcl || !iw || !w_class || !pr_last || !mean_w || !sd_w)
       return fail(e, PAML_AMD_EINVAL, "beb_grid: bad arguments");
    if (e->K > BEB_MAXK) return fail(e, PAML_AMD_EUNSUPPORTED, "beb_grid: more than 32 classes");
@@ -58,7 +58,7 @@ int paml_amd_beb_grid(paml_amd_engine *e, int n_grid, int n_cls, const double *p
 
 int paml_amd_beb_grid_classes(paml_amd_engine *e, int n_grid, int n_cls, const double *pcl, const int *iw, double *ln_fx, double *post)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || n_grid < 1 || n_cls < 1 || n_cls > BEB_MAXCLS || !pcl || !iw || !post)
       return fail(e, PAML_AMD_EINVAL, "beb_grid_classes: bad arguments (at most 8 mixture classes per grid point)");
    BebArgs a;

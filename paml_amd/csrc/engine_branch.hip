@@ -125,7 +125,7 @@ extern "C" {
 int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *t, const double *branch,
                          const double *gene_rate, double *lnL, double *dlnL, double *ddlnL)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !t || !branch || !lnL || !dlnL || !ddlnL || n_t < 1 || n_t > 64)
       return fail(e, PAML_AMD_EINVAL, "eval_branch: bad arguments");
    if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes) || e->eigen.empty())
@@ -359,9 +359,13 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       hipLaunchKernelGGL(branch_kernel, dim3(nb), dim3(256), 0, st, ba);
    }
    HIPCHK(hipGetLastError());
-   if (e->comm) {      // the exchange step of the branch-local evaluation
-      const ncclResult_t nr = rccl().AllReduce(e->d_bpartial.p, e->d_bpartial.p, (size_t)nbg * n_out, ncclDouble, ncclSum, e->comm, st);
+   if (e->comm) {      // the exchange step of the branch-local evaluation, on the communicator's own stream like every collective
+      HIPCHK(hipEventRecord(e->ev_part[0], st));
+      HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[0], 0));
+      const ncclResult_t nr = rccl().AllReduce(e->d_bpartial.p, e->d_bpartial.p, (size_t)nbg * n_out, ncclDouble, ncclSum, e->comm, e->sc);
       if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
+      HIPCHK(hipEventRecord(e->ev_done[0], e->sc));
+      HIPCHK(hipStreamWaitEvent(st, e->ev_done[0], 0));
    }
    hipLaunchKernelGGL(branch_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)e->d_bpartial.p, (int)nbg, n_out, e->d_bout.p);
    HIPCHK(hipGetLastError());
@@ -396,7 +400,7 @@ int paml_amd_get_branch_partials(paml_amd_engine *e, double *out, long cap, long
 
 int paml_amd_node_posterior(paml_amd_engine *e, int node, const double *branch, const double *gene_rate, double *post)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !branch || !post) return fail(e, PAML_AMD_EINVAL, "node_posterior: null argument");
    if (!(e->have_tips && e->have_tree && e->have_pi && e->have_classes) || e->eigen.empty())
       return fail(e, PAML_AMD_EINVAL, "node_posterior before set_tips/set_tree/set_pi/set_classes/set_eigen");

@@ -17,10 +17,20 @@ int paml_amd_shard_bounds(long n_patt_global, int world, int rank, long *first, 
 {
    if (n_patt_global < 1 || world < 1 || rank < 0 || rank >= world || !first || !count) return PAML_AMD_EINVAL;
    const long chunk = red_chunk(n_patt_global), nb = (n_patt_global + chunk - 1) / chunk;
+   // Fewer reduction chunks than ranks would leave ranks without patterns: refused — for EVERY rank alike (the answer depends on
+   // n_patt_global and world only), so that all ranks of a job fail together before any of them enters a collective call.
+   if (world > nb) return PAML_AMD_EUNSUPPORTED;
    const long c0 = nb * rank / world, c1 = nb * (rank + 1) / world;      // chunks [c0, c1): as even as whole chunks allow
    *first = std::min(n_patt_global, c0 * chunk);
    *count = std::min(n_patt_global, c1 * chunk) - *first;
    return 0;
+}
+
+int paml_amd_max_ranks(long n_patt_global)
+{
+   if (n_patt_global < 1) return 0;
+   const long chunk = red_chunk(n_patt_global);
+   return (int)std::min<long>((n_patt_global + chunk - 1) / chunk, 1 << 20);
 }
 
 int paml_amd_comm_unique_id(void *id128)
@@ -36,7 +46,7 @@ int paml_amd_comm_unique_id(void *id128)
 
 int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id128, long n_patt_global, long first_pattern)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return fail(e, PAML_AMD_EINVAL, "comm_init: bad arguments");
    if (e->comm) return fail(e, PAML_AMD_EINVAL, "comm_init: the engine already has a communicator");
    const int chunk = red_chunk(n_patt_global);
@@ -55,34 +65,47 @@ int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id12
          return fail(e, PAML_AMD_EHIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(nr));
       }
    }
+   if (e->comm && !e->sc) {      // the stream and the events of the exchange step
+      HIPCHK(hipStreamCreateWithFlags(&e->sc, hipStreamNonBlocking));
+      for (int b = 0; b < 2; b++) {
+         HIPCHK(hipEventCreateWithFlags(&e->ev_part[b], hipEventDisableTiming));
+         HIPCHK(hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
+      }
+   }
+   e->done_pending[0] = e->done_pending[1] = false;
+   e->red_slot = e->last_slot = 0;
    e->rank = rank; e->world = world;
    e->n_patt_global = n_patt_global; e->first_patt = first_pattern;
    e->chunk = chunk;
    e->nb_global = (int)((n_patt_global + chunk - 1) / chunk);
    e->first_chunk = (int)(first_pattern / chunk);
-   e->d_partial.release();      // re-zeroed at its new size by the next evaluation
+   e->d_partial.release();      // re-zeroed at their new size by the next evaluations
+   e->d_partial1.release();
    return 0;
 }
 
 int paml_amd_comm_destroy(paml_amd_engine *e)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e) return PAML_AMD_EINVAL;
    HIPCHK(hipStreamSynchronize(e->stream));
+   if (e->sc) HIPCHK(hipStreamSynchronize(e->sc));
    if (e->comm) (void)rccl().CommDestroy(e->comm);
    e->comm = nullptr;
+   e->red_slot = e->last_slot = 0;
    e->rank = 0; e->world = 1; e->n_patt_global = e->n_patt; e->first_patt = 0;
    e->chunk = red_chunk(e->n_patt); e->nb_global = (e->n_patt + e->chunk - 1) / e->chunk; e->first_chunk = 0;
    e->d_partial.release();
+   e->d_partial1.release();
    return 0;
 }
 
 int paml_amd_get_partial_sums(paml_amd_engine *e, double *out, int cap)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !out) return fail(e, PAML_AMD_EINVAL, "get_partial_sums: null argument");
-   if (e->n_eval == 0 || !e->d_partial.p || cap < e->nb_global) return fail(e, PAML_AMD_EINVAL, "get_partial_sums: nothing evaluated yet, or cap < number of chunks");
-   const double *src = e->comm ? e->d_partial_tot.p : e->d_partial.p;
+   if (e->n_eval == 0 || !e->part_slot(e->last_slot).p || cap < e->nb_global) return fail(e, PAML_AMD_EINVAL, "get_partial_sums: nothing evaluated yet, or cap < number of chunks");
+   const double *src = e->comm ? e->tot_slot(e->last_slot).p : e->d_partial.p;
    HIPCHK(hipMemcpyAsync(out, src, (size_t)e->nb_global * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
    return e->nb_global;

@@ -78,7 +78,7 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
 
 int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e) return PAML_AMD_EINVAL;
    (void)hipStreamSynchronize(e->stream);
    e->stream = (hipStream_t)hip_stream;
@@ -88,7 +88,7 @@ int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream)
 int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata, int n_codes, const int *n_chara,
                       const unsigned char *chara_map, const double *weights, const int *gene_off)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !z || !weights) return fail(e, PAML_AMD_EINVAL, "set_tips: null argument");
    const int n = e->n;
    std::vector<int> nch;
@@ -154,7 +154,7 @@ int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata,
 int paml_amd_set_tree(paml_amd_engine *e, int n_nodes, int root, const int *sons_ptr, const int *sons, const int *label,
                       const unsigned char *scale_node)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !sons_ptr || !sons) return fail(e, PAML_AMD_EINVAL, "set_tree: null argument");
    if (n_nodes <= e->n_tips || root < 0 || root >= n_nodes) return fail(e, PAML_AMD_EINVAL, "set_tree: bad sizes");
    TreeDesc t;
@@ -198,7 +198,7 @@ int paml_amd_set_tree(paml_amd_engine *e, int n_nodes, int root, const int *sons
 
 int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !pi || (n_pi != 1 && n_pi != e->n_genes)) return fail(e, PAML_AMD_EINVAL, "set_pi: bad arguments");
    const int n = e->n;
    std::vector<double> buf;
@@ -229,7 +229,7 @@ static EigenHost *eigen_slot(paml_amd_engine *e, int set_id)
 
 int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, const double *V, const double *Root)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    EigenHost *h = eigen_slot(e, set_id);
    if (!h || !U || !V || !Root) return fail(e, PAML_AMD_EINVAL, "set_eigen_uvroot: bad arguments");
    const size_t n = e->n;
@@ -243,7 +243,7 @@ int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, c
 
 int paml_amd_set_eigen_cijk(paml_amd_engine *e, int set_id, int nR, const double *Cijk, const double *Root)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    EigenHost *h = eigen_slot(e, set_id);
    if (!h || !Cijk || !Root || nR < 1 || nR > 64) return fail(e, PAML_AMD_EINVAL, "set_eigen_cijk: bad arguments");
    const size_t n = e->n;
@@ -257,7 +257,7 @@ int paml_amd_set_eigen_cijk(paml_amd_engine *e, int set_id, int nR, const double
 
 int paml_amd_set_eigen_k80(paml_amd_engine *e, int set_id, double kappa)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (e && e->n != 4) return fail(e, PAML_AMD_EINVAL, "set_eigen_k80: needs 4 states");
    EigenHost *h = eigen_slot(e, set_id);
    if (!h) return fail(e, PAML_AMD_EINVAL, "set_eigen_k80: bad arguments");
@@ -268,7 +268,7 @@ int paml_amd_set_eigen_k80(paml_amd_engine *e, int set_id, double kappa)
 
 int paml_amd_set_eigen_jc69like(paml_amd_engine *e, int set_id)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    EigenHost *h = eigen_slot(e, set_id);
    if (!h) return fail(e, PAML_AMD_EINVAL, "set_eigen_jc69like: bad arguments");
    h->kind = PAML_AMD_EIGEN_JC69LIKE;
@@ -277,7 +277,7 @@ int paml_amd_set_eigen_jc69like(paml_amd_engine *e, int set_id)
 
 int paml_amd_set_eigen_qmat(paml_amd_engine *e, int set_id, const double *Q)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    EigenHost *h = eigen_slot(e, set_id);
    if (!h || !Q) return fail(e, PAML_AMD_EINVAL, "set_eigen_qmat: bad arguments");
    if (e->n > 8) return fail(e, PAML_AMD_EUNSUPPORTED, "set_eigen_qmat: at most 8 states");
@@ -290,7 +290,7 @@ int paml_amd_set_eigen_qmat(paml_amd_engine *e, int set_id, const double *Q)
 int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freqK, const double *rate, int n_labels,
                          const int *eigen_of, const double *qfactor)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || K < 1 || K > e->max_classes || n_labels < 1 || !eigen_of)
       return fail(e, PAML_AMD_EINVAL, "set_classes: bad arguments");
    if (mode != PAML_AMD_MODE_LFUN && mode != PAML_AMD_MODE_LFUNDG) return fail(e, PAML_AMD_EINVAL, "set_classes: bad mode");
@@ -304,6 +304,7 @@ int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freq
    if (qfactor) q.assign(qfactor, qfactor + (size_t)K * n_labels);
    HIPCHK(upload(e->d_freqK, f.data(), f.size(), e->stream));
    HIPCHK(upload(e->d_rate, r.data(), r.size(), e->stream));
+   e->class_rate = r;
    e->rate_per_gene = false;
    HIPCHK(upload(e->d_qfactor, q.data(), q.size(), e->stream));
    HIPCHK(upload(e->d_eigen_of, eigen_of, (size_t)e->n_genes * K * n_labels, e->stream));
@@ -318,8 +319,16 @@ int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freq
 int paml_amd_set_gene_class_rates(paml_amd_engine *e, const double *rate)
 {
    if (!e || !e->have_classes) return fail(e, PAML_AMD_EINVAL, "set_gene_class_rates before set_classes");
-   e->pipe_ok = false;
-   if (!rate) { e->rate_per_gene = false; return 0; }      // back to the rates of set_classes needs a new set_classes
+   enter(e);
+   if (!rate) {      // back to the class rates of set_classes (kept on the host for this)
+      if (!e->rate_per_gene) return 0;
+      HIPCHK(upload(e->d_rate, e->class_rate.data(), e->class_rate.size(), e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      e->rate_per_gene = false;
+      e->partials_valid = false;
+      e->bl.valid = false;
+      return 0;
+   }
    HIPCHK(upload(e->d_rate, rate, (size_t)e->n_genes * e->K, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
    e->rate_per_gene = true;
@@ -330,7 +339,7 @@ int paml_amd_set_gene_class_rates(paml_amd_engine *e, const double *rate)
 
 int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double *P)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !P || !e->d_rowmajor.p) return fail(e, PAML_AMD_EINVAL, "get_pmat: nothing evaluated yet");
    if (!e->pmat_valid)
       return fail(e, PAML_AMD_EINVAL, "get_pmat: the P(t) buffers hold the re-rooted matrices of eval_branch / node_posterior; run an evaluation first");
@@ -346,7 +355,7 @@ int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double
 
 int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !conP) return fail(e, PAML_AMD_EINVAL, "get_partials: null argument");
    if (!(e->flags & PAML_AMD_KEEP_PARTIALS) || !e->partials_valid)
       return fail(e, PAML_AMD_EINVAL, "get_partials: needs PAML_AMD_KEEP_PARTIALS and a completed evaluation");
@@ -384,7 +393,7 @@ int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP
 
 int paml_amd_get_scale(paml_amd_engine *e, int node, int iclass, double *scale)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !scale) return fail(e, PAML_AMD_EINVAL, "get_scale: null argument");
    if (!(e->flags & PAML_AMD_KEEP_PARTIALS) || !e->partials_valid)
       return fail(e, PAML_AMD_EINVAL, "get_scale: needs PAML_AMD_KEEP_PARTIALS and a completed evaluation");

@@ -384,10 +384,26 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // the reduction's geometry (the fused kernels form the partial sums themselves; the others leave them to reduce_stage1)
    const int chunk = e->chunk, nbg = e->nb_global;
    const int nb = (e->n_patt + chunk - 1) / chunk;
-   if ((size_t)nbg * B > e->d_partial.cap) {
-      HIPCHK(e->d_partial.ensure((size_t)nbg * B));
-      HIPCHK(hipMemsetAsync(e->d_partial.p, 0, e->d_partial.cap * sizeof(double), e->stream));
+   // the slot of partial sums this evaluation fills: with a communicator two slots alternate (the exchange step of the previous
+   // evaluation may still be reading the other one on the collective stream); the slot's previous all-reduce has to be over
+   // before anything writes it again
+   const int slot = e->comm ? e->red_slot : 0;
+   DevBuf<double> &dpart = e->part_slot(slot);
+   if ((size_t)nbg * B > dpart.cap) {
+      if (e->comm && e->sc) HIPCHK(hipStreamSynchronize(e->sc));      // (reallocation: nothing may still be reading the old buffer)
+      HIPCHK(dpart.ensure((size_t)nbg * B));
+      HIPCHK(hipMemsetAsync(dpart.p, 0, dpart.cap * sizeof(double), e->stream));
    }
+   bool slot_waited = false;
+   auto wait_slot = [&]() -> int {      // main stream: the all-reduce that last read this slot (two evaluations ago) is done
+      if (slot_waited) return 0;
+      slot_waited = true;
+      if (e->comm && e->done_pending[slot]) {
+         e->done_pending[slot] = false;
+         HIPCHK(hipStreamWaitEvent(e->stream, e->ev_done[slot], 0));
+      }
+      return 0;
+   };
    if ((size_t)B * RED_TICKET_WORDS > e->d_red_counter.cap) {
       HIPCHK(e->d_red_counter.ensure((size_t)std::max(B, 64) * RED_TICKET_WORDS));
       HIPCHK(hipMemsetAsync(e->d_red_counter.p, 0, e->d_red_counter.cap * sizeof(int), e->stream));
@@ -402,7 +418,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       pr.want_fhk = (want_fhk || e->tree.n_scale) ? 1 : 0;
       pr.freqK = (bs && bs->freqK) ? e->d_b_freqK.p : e->d_freqK.p; pr.freqK_bs = (bs && bs->freqK) ? Km : 0;
       pr.lnf = want_lnf ? e->d_lnf.p : nullptr;
-      pr.red_partial = e->d_partial.p; pr.red_out = lnl_out;
+      pr.red_partial = dpart.p; pr.red_out = lnl_out;
+      if (int rc = wait_slot()) return rc;      // (this kernel writes the partial sums itself)
       // the total: a one-block stage-2 launch (default), or PAML_AMD_TAIL=1: the workgroup that finishes last forms it (tickets)
       pr.red_counter = (e->comm || !e->env.tail) ? nullptr : e->d_red_counter.p;
    }
@@ -485,7 +502,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // GPU the workgroup that finishes last forms the total itself (red_block_finish): no second launch.
    ReduceArgs ra{};
    ra.fhK = e->d_fhK.p; ra.weights = e->d_weights.p; ra.freqK = e->d_freqK.p; ra.lnf = want_lnf ? e->d_lnf.p : nullptr;
-   ra.partial = e->d_partial.p; ra.out = lnl_out;
+   ra.partial = dpart.p; ra.out = lnl_out;
    ra.raw = ((e->kk == KK_MFMA64 && e->use_jit) || (e->kk == KK_VALU20 && e->use_jit && e->m20)) ? 1 : 0; ra.fscale = e->d_fscale.p;
    ra.n_patt = e->n_patt; ra.K = Km; ra.mode = e->mode; ra.n_scale = e->tree.n_scale; ra.chunk = chunk;
    ra.first_chunk = e->first_chunk; ra.nb_stride = nbg;
@@ -495,14 +512,28 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    ra.counter = tail ? e->d_red_counter.p : nullptr;
    if (bs && bs->freqK) { ra.freqK = e->d_b_freqK.p; ra.freqK_bs = Km; }
    mark(e);
+   if (int rc = wait_slot()) return rc;
    if (!fused) hipLaunchKernelGGL(reduce_stage1, dim3(nb, B), dim3(256), 0, e->stream, ra);
    if (e->comm) {
-      HIPCHK(e->d_partial_tot.ensure((size_t)nbg * B));
-      const ncclResult_t nr = rccl().AllReduce(e->d_partial.p, e->d_partial_tot.p, (size_t)nbg * B, ncclDouble, ncclSum, e->comm, e->stream);
+      // the exchange step, off the pruning stream: the collective stream takes over when this evaluation's partial sums are there
+      // (ev_part), all-reduces them into the slot's second buffer and forms the fixed-order total; the next evaluation's P(t) and
+      // pruning kernel follow on the main stream without waiting for any of it
+      DevBuf<double> &dtot = e->tot_slot(slot);
+      if ((size_t)nbg * B > dtot.cap) {
+         HIPCHK(hipStreamSynchronize(e->sc));
+         HIPCHK(dtot.ensure((size_t)nbg * B));
+      }
+      HIPCHK(hipEventRecord(e->ev_part[slot], e->stream));
+      HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[slot], 0));
+      const ncclResult_t nr = rccl().AllReduce(dpart.p, dtot.p, (size_t)nbg * B, ncclDouble, ncclSum, e->comm, e->sc);
       if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
-      hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)e->d_partial_tot.p, nbg, ra.out);
+      hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->sc, (const double *)dtot.p, nbg, ra.out);
+      HIPCHK(hipEventRecord(e->ev_done[slot], e->sc));
+      e->done_pending[slot] = true;
+      e->last_slot = slot;
+      e->red_slot = slot ^ 1;
    }
-   else if (!tail && nbg > 1) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)e->d_partial.p, nbg, ra.out);      // (one block per element: stage 1 wrote the total)
+   else if (!tail && nbg > 1) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)dpart.p, nbg, ra.out);      // (one block per element: stage 1 wrote the total)
    mark(e);
    HIPCHK(hipGetLastError());
    if (e->profiling) e->prof_evals++;
@@ -520,7 +551,7 @@ extern "C" {
 int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, double *lnL, double *lnf,
                   double *fhK)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !branch || !lnL) return fail(e, PAML_AMD_EINVAL, "eval: null argument");
    int r = ensure_hout(e, 1);
    if (r) return r;
@@ -529,6 +560,7 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
    if (lnf) HIPCHK(hipMemcpyAsync(lnf, e->d_lnf.p, (size_t)e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    if (fhK)
       HIPCHK(hipMemcpyAsync(fhK, e->d_fhK.p, (size_t)e->K * e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   if (int rc = join_comm(e)) return rc;
    HIPCHK(hipStreamSynchronize(e->stream));
    *lnL = e->h_out[0];
    return 0;
@@ -537,7 +569,7 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
 int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, const double *gene_rate, const int *eigen_of,
                         const double *qfactor, const double *freqK, const double *rate, double *lnL, double *lnf)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !branch || !lnL || n_batch < 1) return fail(e, PAML_AMD_EINVAL, "eval_batch: bad arguments");
    if ((long)n_batch * e->K * e->n_genes > 65535) return fail(e, PAML_AMD_EINVAL, "eval_batch: n_batch * K * n_genes > 65535");
    BatchSpec bs{n_batch, eigen_of, qfactor, freqK, rate};
@@ -547,6 +579,7 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
    if (r) return r;
    if (lnf)
       HIPCHK(hipMemcpyAsync(lnf, e->d_lnf.p, (size_t)n_batch * e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   if (int rc = join_comm(e)) return rc;
    HIPCHK(hipStreamSynchronize(e->stream));
    memcpy(lnL, e->h_out, (size_t)n_batch * sizeof(double));
    return 0;
@@ -555,7 +588,7 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
 int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *gene_rate, const double *MK, const int *pose, int ls,
                       double *lnL)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !branch || !MK || !pose || !lnL || ls < 1) return fail(e, PAML_AMD_EINVAL, "eval_adg: bad arguments");
    if (e->mode != PAML_AMD_MODE_LFUNDG) return fail(e, PAML_AMD_EINVAL, "eval_adg: needs the lfundG class mode");
    if (e->world > 1) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_adg: the rate chain runs over the sites in order and does not shard (SURVEY 8e)");
@@ -610,15 +643,22 @@ int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double 
    return launch_eval(e, branch, gene_rate, nullptr, d_lnL, false, nullptr, true, false);
 }
 
+int paml_amd_flush(paml_amd_engine *e)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   return join_comm(e);
+}
+
 int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,
                         double *lnL)
 {
-   if (e) e->pipe_ok = false;
+   enter(e);
    if (!e || !branch || !lnL || !clean) return fail(e, PAML_AMD_EINVAL, "eval_dirty: null argument");
    int r = ensure_hout(e, 1);
    if (r) return r;
    r = launch_eval(e, branch, gene_rate, clean, e->h_out, false);
    if (r) return r;
+   if (int rc = join_comm(e)) return rc;
    HIPCHK(hipStreamSynchronize(e->stream));
    *lnL = e->h_out[0];
    return 0;

@@ -119,9 +119,11 @@ struct Rccl {
    bool load()
    {
       if (h) return true;
-      const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+      // PAML_AMD_RCCL_LIB names the library instead (an RCCL build elsewhere; the tests' shared-memory stand-in that lets two ranks
+      // share one GPU, tests/shim/rccl_shim.cpp)
+      const char *names[] = {getenv("PAML_AMD_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
       for (const char *nm : names)
-         if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+         if (nm && *nm && (h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
       if (!h) { err = std::string("dlopen librccl.so.1: ") + dlerror(); return false; }
       GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
       CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
@@ -202,6 +204,17 @@ struct paml_amd_engine {
    long n_patt_global = 0, first_patt = 0;
    int chunk = 256, nb_global = 1, first_chunk = 0;
    DevBuf<double> d_partial_tot, d_btot;
+   // The exchange step runs on its own stream `sc`, ordered by events, so that evaluation i + 1 prunes while evaluation i's partial
+   // sums are all-reduced and added up: two slots of (partial sums, their all-reduced copy) alternate; slot b's next writer (two
+   // evaluations later) waits for ev_done[b].  The caller's stream is joined to the outstanding totals by paml_amd_flush and by
+   // every entry point other than paml_amd_eval_device (join_comm).
+   hipStream_t sc = nullptr;
+   hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+   bool done_pending[2] = {false, false};
+   int red_slot = 0, last_slot = 0;
+   DevBuf<double> d_partial1, d_partial_tot1;
+   DevBuf<double> &part_slot(int b) { return b ? d_partial1 : d_partial; }
+   DevBuf<double> &tot_slot(int b) { return b ? d_partial_tot1 : d_partial_tot; }
    DevBuf<unsigned int> d_zpm;        // fused 4 / 5-state kernel: tip codes pattern-major
    int zpm_words = 0;
    DevBuf<int> d_red_counter;         // "last workgroup adds up the partial sums" tickets, one per batch element
@@ -211,6 +224,7 @@ struct paml_amd_engine {
    bool fused = false;                // the selected kernel forms the reduction itself
    bool fused_mfma4 = false;
    bool rate_per_gene = false;      // paml_amd_set_gene_class_rates: class rates [n_genes][K]
+   std::vector<double> class_rate;  // the [K] rates of set_classes (what set_gene_class_rates(NULL) goes back to)
    bool want_m20 = false, m20 = false;      // 20 states on v_mfma_f64_4x4x4 (jit_generate_m20)
    int fused_threads = 256;
    bool pmat_valid = false;           // d_rowmajor holds the P(t) of an evaluation in the tree's own orientation
@@ -298,6 +312,8 @@ struct paml_amd_engine {
       for (auto &e : eigen) { e.U.release(); e.V.release(); e.Root.release(); e.Cijk.release(); }
       stage.release();
       if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
+      if (sc) { (void)hipStreamSynchronize(sc); (void)hipStreamDestroy(sc); }
+      for (hipEvent_t ev : {ev_part[0], ev_part[1], ev_done[0], ev_done[1]}) if (ev) (void)hipEventDestroy(ev);
       if (h_out) (void)hipHostFree(h_out);
       if (d_prof && env.prof_tiles && prof_words) {      // the last launch's workgroup timeline
          std::vector<unsigned long long> hp(prof_words);
@@ -331,7 +347,7 @@ struct paml_amd_engine {
       d_eigen.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_rowmajor, &d2_pint, &d2_ptip, &d2_pcol, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot,
+                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_rowmajor, &d2_pint, &d2_ptip, &d2_pcol, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot, &d_partial1, &d_partial_tot1,
                               &d_expA, &d_expB, &d_expSA, &d_expSB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
    }
@@ -392,6 +408,25 @@ inline void mark_on(paml_amd_engine *e, hipStream_t s)
    if (ev) (void)hipEventRecord(ev, s);
 }
 inline void mark(paml_amd_engine *e) { mark_on(e, e->stream); }
+
+// The caller's stream waits for the totals still on their way on the collective stream (no-op without a communicator).
+inline int join_comm(paml_amd_engine *e)
+{
+   for (int b = 0; b < 2; b++)
+      if (e->done_pending[b]) {
+         e->done_pending[b] = false;
+         if (hipStreamWaitEvent(e->stream, e->ev_done[b], 0) != hipSuccess) return fail(e, PAML_AMD_EHIP, "hipStreamWaitEvent(collective stream)");
+      }
+   return 0;
+}
+// Every entry point except paml_amd_eval_device starts here: the fast path of consecutive eval_device calls ends, the stream is
+// joined to the collective stream.
+inline void enter(paml_amd_engine *e)
+{
+   if (!e) return;
+   e->pipe_ok = false;
+   (void)join_comm(e);
+}
 
 // Pinned host memory the kernels can write: the synchronous entry points get their scalars without a device-to-host copy.
 inline int ensure_hout(paml_amd_engine *e, size_t n)

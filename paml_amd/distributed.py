@@ -1,8 +1,8 @@
 """Pattern sharding across ranks: site patterns are independent given the tree, the P(t) matrices, pi and the
 class table, so each rank (one process per GPU) owns a contiguous block of patterns and ONE exchange step gives lnL.
 
-On the GPUs the exchange lives INSIDE the engine (include/paml_amd.h: paml_amd_comm_init; RCCL over xGMI on the engine's
-stream): `sharded_engine` builds a rank's engine over its shard and joins the communicator, after which every eval* call
+On the GPUs the exchange lives INSIDE the engine (include/paml_amd.h: paml_amd_comm_init; RCCL over xGMI on a stream of the
+engine's own, so that the next evaluation prunes while this one's partial sums are reduced): `sharded_engine` builds a rank's engine over its shard and joins the communicator, after which every eval* call
 returns the total.  torch.distributed is only the courier of the 128-byte RCCL id (any backend).
 
 The shard boundaries come from the C ABI (paml_amd_shard_bounds, host-only), and the helpers below restate the engine's
@@ -41,9 +41,7 @@ def sharded_engine(pb, flags=0, world=None, rank=None, force_comm=False):
     if world is None:
         import torch.distributed as dist
         world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
-    lo, hi = shard_bounds(pb.n_patt, world, rank)
-    if hi <= lo:
-        raise ValueError("rank %d of %d has no patterns (%d patterns in all)" % (rank, world, pb.n_patt))
+    lo, hi = shard_bounds(pb.n_patt, world, rank)      # (raises on EVERY rank alike when there are more ranks than reduction chunks)
     sub = pb.slice_patterns(lo, hi) if (lo, hi) != (0, pb.n_patt) else pb
     eng = engine.engine_for(sub, flags=flags)
     uid = None

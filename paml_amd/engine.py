@@ -26,7 +26,7 @@ EXPORTS = [
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
-    "paml_amd_device_count", "paml_amd_set_device", "paml_amd_shard_bounds", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_get_partial_sums", "paml_amd_branch_counters",
+    "paml_amd_device_count", "paml_amd_set_device", "paml_amd_shard_bounds", "paml_amd_max_ranks", "paml_amd_flush", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_get_partial_sums", "paml_amd_branch_counters",
     "paml_amd_jit_prebuild", "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
@@ -103,6 +103,8 @@ def lib():
         L.paml_amd_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
         L.paml_amd_counters.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
         L.paml_amd_shard_bounds.argtypes = [C.c_long, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.paml_amd_max_ranks.argtypes = [C.c_long]
+        L.paml_amd_flush.argtypes = [C.c_void_p]
         L.paml_amd_comm_unique_id.argtypes = [C.c_void_p]
         L.paml_amd_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long]
         L.paml_amd_comm_destroy.argtypes = [C.c_void_p]
@@ -311,6 +313,10 @@ class Engine:
         g = None if gene_rate is None else np.ascontiguousarray(gene_rate, dtype=np.float64)
         self._chk(self._L.paml_amd_eval_device(self._h, _p(b), _p(g), C.c_void_p(d_lnL_ptr)))
 
+    def flush(self):
+        """After a run of eval_device calls: the engine's stream waits for the totals still on the collective stream."""
+        self._chk(self._L.paml_amd_flush(self._h))
+
     def eval_dirty(self, branch, clean, gene_rate=None):
         b = np.ascontiguousarray(branch, dtype=np.float64)
         c = np.ascontiguousarray(clean, dtype=np.uint8)
@@ -389,8 +395,14 @@ def shard_bounds(n_patt_global, world, rank):
     first, count = C.c_long(), C.c_long()
     rc = lib().paml_amd_shard_bounds(int(n_patt_global), int(world), int(rank), C.byref(first), C.byref(count))
     if rc != 0:
-        raise EngineError("paml_amd_shard_bounds failed (%d)" % rc)
+        raise EngineError("paml_amd_shard_bounds(%d patterns, world %d) failed (%d): at most %d ranks for this many patterns"
+                          % (n_patt_global, world, rc, lib().paml_amd_max_ranks(int(n_patt_global))))
     return first.value, count.value
+
+
+def max_ranks(n_patt_global):
+    """The largest number of ranks the patterns can be sharded over (= the number of reduction chunks)."""
+    return lib().paml_amd_max_ranks(int(n_patt_global))
 
 
 def comm_unique_id():

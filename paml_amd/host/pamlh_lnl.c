@@ -1,5 +1,5 @@
 /* pamlh_lnl — command-line driver: one likelihood evaluation of a codeml/baseml analysis on the MI355X.
- *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [--ancestral] [--gpus N] [--tree K] [x0 x1 ...]
+ *   usage: pamlh_lnl <codeml|baseml> <file.ctl> [--optimize] [--ancestral] [--gpus N [--devices a,b,...]] [--tree K] [x0 x1 ...]
  *   (--set "key = value": replaces an option of the control file, e.g. one of the site models of an "NSsites = 0 1 2 7 8" list;
  *    --tree K: the K-th tree of the tree file, 1-based; --all-trees: every tree in turn — the reference's loop, Forestry codeml.c:635 —
  *    each optimised from the control file's initial values, then the comparison table of rell(), treesub.c:5844)
@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -20,30 +21,80 @@
 /* --gpus N: one process per GPU.  The parent becomes rank 0; it forks ranks 1 .. N-1 BEFORE anything touches the GPU, obtains the
  * RCCL id and hands it to them through pipes.  Every rank reads the same files, keeps its block of site patterns
  * (pamlh_set_shard) and runs the same code: the all-reduced lnL has the same bits on every rank, so the ranks stay in step
- * without further communication.  Only rank 0 prints. */
-static int spawn_ranks(int world, int *rank_out, unsigned char *id)
+ * without further communication.  Only rank 0 prints.  --devices a,b,...: the GPU of each rank (default: rank r on GPU r).
+ * What can go wrong is checked where every rank sees the same answer (more ranks than GPUs: before the fork, by a probe process,
+ * since the parent must not initialise HIP before forking; more ranks than reduction chunks: paml_amd_shard_bounds refuses for every
+ * rank alike).  A rank that dies on its own (its GPU fails) takes the job with it: rank 0 ends the others and exits non-zero
+ * instead of waiting in a collective call for ever. */
+#define MAX_RANKS 64
+static pid_t child_pid[MAX_RANKS];
+static int n_children = 0, ranks_done = 0;
+
+static void end_children(void)      /* atexit of rank 0: an error path left ranks behind */
 {
-   int r, fds[64][2];
+   int i, st;
+   if (ranks_done) return;
+   for (i = 0; i < n_children; i++) if (child_pid[i] > 0) kill(child_pid[i], SIGTERM);
+   for (i = 0; i < n_children; i++) if (child_pid[i] > 0) waitpid(child_pid[i], &st, 0);
+   n_children = 0;
+}
+
+static void on_sigchld(int sig)     /* a rank ended: fine when it is over, fatal while rank 0 is still working */
+{
+   int st, i;
+   pid_t pid;
+   (void)sig;
+   while ((pid = waitpid(-1, &st, WNOHANG)) > 0) {
+      for (i = 0; i < n_children; i++) if (child_pid[i] == pid) child_pid[i] = 0;
+      if (!ranks_done && (!WIFEXITED(st) || WEXITSTATUS(st))) {
+         static const char msg[] = "error: a rank ended abnormally; stopping the others\n";
+         if (write(2, msg, sizeof(msg) - 1) < 0) {}
+         for (i = 0; i < n_children; i++) if (child_pid[i] > 0) kill(child_pid[i], SIGTERM);
+         _exit(1);
+      }
+   }
+}
+
+static int probe_device_count(void)      /* in a short-lived process: the parent stays clear of HIP until it has forked its ranks */
+{
+   int st = 0;
+   const pid_t pid = fork();
+   if (pid < 0) return -1;
+   if (pid == 0) { int n = paml_amd_device_count(); _exit(n > 250 ? 250 : n); }
+   if (waitpid(pid, &st, 0) != pid || !WIFEXITED(st)) return -1;
+   return WEXITSTATUS(st);
+}
+
+static int spawn_ranks(int world, const int *device, int *rank_out, unsigned char *id)
+{
+   int r, fds[MAX_RANKS][2];
+   const int ndev = probe_device_count();
    pid_t pid;
    *rank_out = 0;
-   if (world > 64) world = 64;
+   if (world > MAX_RANKS) { fprintf(stderr, "error: --gpus %d: at most %d ranks\n", world, MAX_RANKS); return -1; }
+   for (r = 0; r < world; r++)
+      if (device[r] < 0 || device[r] >= ndev) { fprintf(stderr, "error: rank %d wants GPU %d but %d are visible\n", r, device[r], ndev); return -1; }
    for (r = 1; r < world; r++) {
       if (pipe(fds[r])) return -1;
       pid = fork();
       if (pid < 0) return -1;
       if (pid == 0) {            /* child = rank r: wait for the id */
          int k;
+         n_children = 0;
          for (k = 1; k <= r; k++) close(fds[k][1]);
          *rank_out = r;
-         if (paml_amd_set_device(r)) { fprintf(stderr, "rank %d: no GPU %d\n", r, r); _exit(1); }
+         if (paml_amd_set_device(device[r])) { fprintf(stderr, "rank %d: no GPU %d\n", r, device[r]); _exit(1); }
          if (read(fds[r][0], id, PAML_AMD_COMM_ID_BYTES) != PAML_AMD_COMM_ID_BYTES) _exit(1);
          close(fds[r][0]);
          if (!freopen("/dev/null", "w", stdout)) _exit(1);
          return 0;
       }
+      child_pid[n_children++] = pid;
       close(fds[r][0]);
    }
-   if (paml_amd_set_device(0)) return -1;
+   atexit(end_children);
+   signal(SIGCHLD, on_sigchld);
+   if (paml_amd_set_device(device[0])) return -1;
    if (paml_amd_comm_unique_id(id)) return -1;
    for (r = 1; r < world; r++) {
       if (write(fds[r][1], id, PAML_AMD_COMM_ID_BYTES) != PAML_AMD_COMM_ID_BYTES) return -1;
@@ -60,11 +111,18 @@ int main(int argc, char **argv)
    int np, ntime, npatt, i, nx = 0, optimize = 0, ancestral = 0, gpus = 0, rank = 0, itree = 0, all_trees = 0;
    char over[2048] = "";
    unsigned char comm_id[PAML_AMD_COMM_ID_BYTES];
+   int device[MAX_RANKS];
+   for (i = 0; i < MAX_RANKS; i++) device[i] = i;
    if (argc < 3) { fprintf(stderr, "usage: %s <codeml|baseml> <ctl> [--optimize] [--ancestral] [--gpus N] [--tree K | --all-trees] [--set 'key = value'] [x...]\n", argv[0]); return 2; }
    for (i = 3; i < argc && nx < 4096; i++) {
       if (!strcmp(argv[i], "--optimize")) optimize = 1;
       else if (!strcmp(argv[i], "--ancestral")) ancestral = 1;
       else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+      else if (!strcmp(argv[i], "--devices") && i + 1 < argc) {      /* the GPU of each rank, e.g. "4,5,6,7" */
+         int k = 0;
+         char *tok = strtok(argv[++i], ",");
+         for (; tok && k < MAX_RANKS; tok = strtok(NULL, ",")) device[k++] = atoi(tok);
+      }
       else if (!strcmp(argv[i], "--tree") && i + 1 < argc) itree = atoi(argv[++i]) - 1;
       else if (!strcmp(argv[i], "--all-trees")) all_trees = 1;
       else if (!strcmp(argv[i], "--set") && i + 1 < argc) {      /* --set "NSsites = 2": replaces the control file's option */
@@ -108,7 +166,7 @@ int main(int argc, char **argv)
       free(all); free(w);
       return 0;
    }
-   if (gpus > 0 && spawn_ranks(gpus, &rank, comm_id)) { fprintf(stderr, "error: could not start %d ranks (GPUs visible: %d; librccl.so.1 present?)\n", gpus, paml_amd_device_count()); return 1; }
+   if (gpus > 0 && spawn_ranks(gpus, device, &rank, comm_id)) { fprintf(stderr, "error: could not start %d ranks (GPUs visible: %d; librccl.so.1 present?)\n", gpus, paml_amd_device_count()); return 1; }
    if (pamlh_load_with(&p, argv[2], argv[1], itree, over, err, sizeof(err))) { fprintf(stderr, "error: %s\n", err); return 1; }
    if (gpus > 0 && pamlh_set_shard(p, rank, gpus, comm_id)) { fprintf(stderr, "error: %s\n", pamlh_error(p)); return 1; }
    pamlh_dims(p, NULL, NULL, &npatt, NULL, NULL, NULL, NULL, NULL, &np, &ntime);
@@ -176,8 +234,11 @@ int main(int argc, char **argv)
       fflush(stdout);
       free(lnf);
       pamlh_free(p);
-      if (rank == 0)
+      if (rank == 0) {      /* the result is out: from here on the ranks just end (on_sigchld reaps them too; ECHILD ends the loop) */
+         ranks_done = 1;
+         signal(SIGCHLD, SIG_DFL);
          while (wait(&st) > 0) bad |= !WIFEXITED(st) || WEXITSTATUS(st);
+      }
       return bad ? 1 : 0;
    }
    {  /* codon models without site classes: the reference's "dN & dS for each branch" table (codeml.c:1361-1404) */

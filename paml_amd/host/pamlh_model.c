@@ -1641,7 +1641,9 @@ int pamlh_set_shard(pamlh *p, int rank, int world, const void *id128)
    int i;
    unsigned char *z;
    if (p->eng) return pamlh_fail(p, "set_shard: call before the first evaluation");
-   if (paml_amd_shard_bounds(p->npatt, world, rank, &first, &count) || count < 1) return pamlh_fail(p, "set_shard: rank %d of %d gets no patterns (%d in all)", rank, world, p->npatt);
+   /* (refused for every rank alike — the answer depends on npatt and world only — so the ranks of a job fail together, before any collective call) */
+   if (paml_amd_shard_bounds(p->npatt, world, rank, &first, &count) || count < 1)
+      return pamlh_fail(p, "set_shard: %d site patterns can be sharded over at most %d GPUs (asked for %d)", p->npatt, paml_amd_max_ranks(p->npatt), world);
    z = (unsigned char *)malloc((size_t)p->ns * count);
    for (i = 0; i < p->ns; i++) memcpy(z + (size_t)i * count, p->z + (size_t)i * p->npatt + first, count);
    memmove(p->w, p->w + first, count * sizeof(double));

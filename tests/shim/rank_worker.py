@@ -1,0 +1,87 @@
+"""One rank of a world-size-N job with every rank on GPU 0 (test infrastructure; run by tests/test_multirank_gpu.py with
+PAML_AMD_RCCL_LIB pointing at librccl_shim.so).  usage: rank_worker.py <rank> <world> <exchange dir> <case>
+Builds the case's problem (seeded: the same on every rank), takes its pattern shard, joins the communicator — the id travels through
+a file of the exchange directory — and writes what the engine's entry points return, as hexadecimal doubles, to out<rank>.json."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def problem(case):
+    import helpers
+    from paml_amd import synth
+    if case == "codon_jit":      # the per-tree MFMA kernel (forced at this size), one class
+        return synth.codon_m0_problem(n_tips=16, n_patt=6000), 2
+    if case == "codon_k3":       # 61 states, three classes, interpreter kernels, scaling nodes
+        return helpers.random_problem(61, 10, 3000, K=3, seed=11, scale_every=3), 0
+    if case == "nuc_fused":      # 4 states: the fused kernel forms the partial sums itself
+        return synth.nuc_gtr_gamma_problem(n_tips=32, n_patt=9000), 2
+    if case == "aa20":
+        return helpers.random_problem(20, 12, 5000, K=2, seed=12), 0
+    raise SystemExit("unknown case " + case)
+
+
+def run(pb, eng, n_dev=7):
+    import torch
+    out = {}
+    br = pb.tree.branch
+    out["eval"] = float(eng.eval(br, pb.gene_rate)["lnL"]).hex()
+    d = torch.zeros(n_dev, dtype=torch.float64, device="cuda")
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    for i in range(n_dev):      # consecutive evaluations: the exchange step of i overlaps the pruning of i + 1 (two slots of partial sums)
+        eng.eval_device(br * (1.0 + 0.01 * i), d.data_ptr() + 8 * i, pb.gene_rate)
+    eng.flush()
+    torch.cuda.current_stream().synchronize()      # (the stream alone, not the device: flush is what joins the collective stream)
+    out["eval_device"] = [float(v).hex() for v in d.cpu().numpy()]
+    B = np.stack([br, br * 1.1, br * 0.9])
+    gr = None if pb.gene_rate is None else np.stack([pb.gene_rate] * 3)
+    out["eval_batch"] = [float(v).hex() for v in eng.eval_batch(B, gene_rate=gr)]
+    b = pb.tree.n_tips + 1
+    ts = np.array([br[b], br[b] * 1.5 + 0.01])
+    l, dl, ddl = eng.eval_branch(b, ts, br, pb.gene_rate)
+    out["eval_branch"] = [float(v).hex() for v in np.concatenate([l, dl, ddl])]
+    out["eval_again"] = float(eng.eval(br, pb.gene_rate)["lnL"]).hex()
+    out["kernel"] = eng.kernel_name
+    return out
+
+
+def main():
+    rank, world, xdir, case = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    from paml_amd import distributed, engine
+    pb, flags = problem(case)
+    if world == 1:      # the reference run: one engine over everything, no communicator
+        eng = engine.engine_for(pb, flags=flags)
+        res = run(pb, eng)
+    else:
+        idfile = os.path.join(xdir, "id")
+        if rank == 0:
+            uid = engine.comm_unique_id()
+            with open(idfile + ".tmp", "wb") as f:
+                f.write(uid)
+            os.rename(idfile + ".tmp", idfile)
+        else:
+            t0 = time.time()
+            while not os.path.exists(idfile):
+                time.sleep(0.05)
+                if time.time() - t0 > 120:
+                    raise SystemExit("rank %d: no id from rank 0" % rank)
+            uid = open(idfile, "rb").read()
+        lo, hi = distributed.shard_bounds(pb.n_patt, world, rank)
+        eng = engine.engine_for(pb.slice_patterns(lo, hi), flags=flags)
+        eng.comm_init(rank, world, uid, pb.n_patt, lo)
+        res = run(pb, eng)
+        res["shard"] = [lo, hi]
+    eng.close()
+    with open(os.path.join(xdir, "out%d.json" % rank), "w") as f:
+        json.dump(res, f)
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 import helpers
@@ -54,18 +55,46 @@ def _worker(rank, world, port, out, genes=1):
 
 
 def test_shard_bounds_cover_and_align():
-    for n, w in [(1000, 2), (1_000_000, 8), (1_000_000, 3), (79, 4), (129, 2), (4_000_000, 8), (100_000, 8)]:
+    for n, w in [(1000, 2), (1_000_000, 8), (1_000_000, 3), (79, 1), (600, 3), (4_000_000, 8), (100_000, 8)]:
         ch = distributed.red_chunk(n)
         assert ch % 256 == 0 and -(-n // ch) <= 1024
         spans = [distributed.shard_bounds(n, w, r) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         for (a, b), (c, d) in zip(spans, spans[1:]):
             assert b == c and a <= b
-        assert all(lo % ch == 0 for lo, hi in spans if hi > lo)
+        assert all(lo % ch == 0 and hi > lo for lo, hi in spans)      # no rank without patterns
         sizes = [hi - lo for lo, hi in spans]
         assert max(sizes) - min(sizes) <= ch or n < ch * w      # as even as whole chunks allow
     # the C ABI rejects nonsense
     assert engine.lib().paml_amd_shard_bounds(0, 1, 0, None, None) != 0
+    # more ranks than reduction chunks would leave ranks without patterns (and the others waiting for them in a collective call):
+    # refused for EVERY rank alike, so that all ranks of a job fail together
+    import ctypes as C
+    for n, w in [(79, 4), (129, 2), (200, 2), (1000, 8)]:
+        assert engine.max_ranks(n) < w
+        for r in range(w):
+            first, count = C.c_long(), C.c_long()
+            assert engine.lib().paml_amd_shard_bounds(n, w, r, C.byref(first), C.byref(count)) != 0
+        with pytest.raises(engine.EngineError):
+            distributed.shard_bounds(n, w, 0)
+    assert engine.max_ranks(1_000_000) >= 8 and engine.max_ranks(100_000) >= 8 and engine.max_ranks(79) == 1
+
+
+def test_rccl_stand_in_of_the_tests_builds_and_exports_what_the_engine_binds():
+    """tests/shim/librccl_shim.so (the shared-memory stand-in that lets the -m gpu tier run world > 1 on one GPU) builds with
+    hipcc and exports exactly the five symbols engine_state.h's Rccl binds; the id round trip needs no GPU."""
+    import ctypes as C
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.check_call(["make", "-C", os.path.join(here, "shim")], stdout=subprocess.DEVNULL)
+    L = C.CDLL(os.path.join(here, "shim", "librccl_shim.so"))
+    for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclGetErrorString"):
+        assert hasattr(L, sym)
+    src = open(os.path.join(here, "..", "paml_amd", "csrc", "engine_state.h")).read()
+    assert src.count('dlsym(h, "nccl') == 5
+    uid = C.create_string_buffer(128)
+    assert L.ncclGetUniqueId(uid) == 0 and uid.raw.startswith(b"paml_amd_rccl_shim:/")
+    os.unlink("/dev/shm" + uid.raw.split(b":")[1].rstrip(b"\0").decode())
 
 
 def test_reduction_scheme_is_independent_of_world_size():

@@ -1,0 +1,108 @@
+"""world > 1 on the GPU box of the test tier, which has ONE GPU: every rank on GPU 0, the collective library replaced by the
+shared-memory stand-in tests/shim/librccl_shim.so (PAML_AMD_RCCL_LIB; real RCCL refuses two ranks per device).  Everything
+else is the production path: paml_amd_comm_init(world = 2, 3), the exchange step on the engine's collective stream with its two
+slots of partial sums, `bench.py --gpus 2` under torch.distributed.run (gloo as the courier of the id), `pamlh_lnl --gpus 2`
+with its fork / pipe hand-over.  The all-reduced results must have the bits of the one-engine run (the ranks' zero-padded
+partial-sum arrays are added — exact — and totalled in one fixed order) and match the reference's goldens."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+SHIM = os.path.join(HERE, "shim", "librccl_shim.so")
+WORKER = os.path.join(HERE, "shim", "rank_worker.py")
+
+
+def shim_env():
+    if not os.path.exists(SHIM):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "shim")])
+    return dict(os.environ, PAML_AMD_RCCL_LIB=SHIM)
+
+
+def run_ranks(world, case, tmp_path):
+    xdir = tmp_path / ("%s_w%d" % (case, world))
+    xdir.mkdir()
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(xdir), case], env=shim_env(),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600)[0].decode())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d of %d failed:\n%s" % (r, world, outs[r][-3000:])
+    return [json.load(open(xdir / ("out%d.json" % r))) for r in range(world)]
+
+
+@pytest.mark.parametrize("case", ["codon_jit", "codon_k3", "nuc_fused", "aa20"])
+def test_ranks_on_one_gpu_match_the_single_engine_bit_for_bit(case, tmp_path):
+    one = run_ranks(1, case, tmp_path)[0]
+    for world in (2, 3):
+        res = run_ranks(world, case, tmp_path)
+        for r in res:
+            for key in ("eval", "eval_device", "eval_batch", "eval_again"):
+                assert r[key] == one[key], (case, world, key, r[key], one[key])
+            # branch-local sums: per-block partials at global block positions, same fixed order -> same bits as well
+            assert r["eval_branch"] == one["eval_branch"], (case, world)
+            assert r["kernel"] == one["kernel"]
+        assert res[0]["shard"][1] == res[1]["shard"][0]
+    # the evaluations of the eval_device run differ from each other (different branch lengths) and the first equals eval
+    assert one["eval_device"][0] == one["eval"] and len(set(one["eval_device"])) == len(one["eval_device"])
+
+
+def test_bench_on_two_ranks_of_one_gpu(tmp_path):
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one process per rank), but both ranks on
+    GPU 0 (PAML_AMD_BENCH_ONE_GPU=1: gloo carries the id and the timing's barrier / max).  Strong scaling of the same patterns:
+    lnL_hex equals the one-rank run's."""
+    env = dict(shim_env(), PAML_AMD_BENCH_ONE_GPU="1")
+    common = ["--steps", "4", "--warmup", "2", "--patterns", "40000", "--no-cpu-baseline", "--sweep-steps", "2"]
+    r1 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--no-extras"] + common, env=env, cwd=REPO,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r1.returncode == 0, r1.stderr.decode()[-3000:]
+    one = json.loads(r1.stdout.decode().strip().splitlines()[-1])
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29631", os.path.join(REPO, "bench.py"), "--gpus", "2"] + common, env=env, cwd=REPO,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert r2.returncode == 0, r2.stderr.decode()[-3000:]
+    lines = [ln for ln in r2.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["lnL_hex"] == one["lnL_hex"]
+    assert two["config"]["patterns_rank0"] < 40000
+    assert [s["model"] for s in two["sweep"]] == ["M0", "M1a", "M2a", "M7", "M8"]
+    assert two["weak"]["patterns_per_gpu"] == 40000 and two["weak"]["value"] > 0
+    assert two["ms_per_step_readback"] > 0
+
+
+def test_pamlh_lnl_on_two_ranks_of_one_gpu(tmp_path):
+    """The C driver's --gpus path: the parent forks rank 1 before touching the GPU, hands the id over a pipe, both ranks read the same
+    files and keep their shard; lnL is the reference's."""
+    from paml_amd import hostlib
+    g = helpers.load_golden("mtcdna_branch")      # 607 site patterns: three reduction chunks
+    ctl = os.path.join(helpers.GOLDEN, "ctl", "mtcdna_branch.ctl")
+    cmd = [hostlib.DRIVER_PATH, "codeml", ctl] + ["%.6f" % v for v in g["x"]]
+    r1 = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r1.returncode == 0, r1.stdout.decode()
+    (tmp_path / "w2").mkdir()
+    r2 = subprocess.run(cmd + ["--gpus", "2", "--devices", "0,0"], cwd=tmp_path / "w2", env=shim_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r2.returncode == 0, r2.stdout.decode()
+
+    def lnl(txt):
+        return txt.split("lnL  =")[1].split()[0]
+    assert lnl(r2.stdout.decode()) == lnl(r1.stdout.decode())
+    assert abs(float(lnl(r2.stdout.decode())) - g["lnL"]) <= 2e-6
+    assert "sharded over 2 GPUs" in r2.stdout.decode()
+    # more ranks than reduction chunks: every rank refuses, nobody is left waiting in a collective call
+    r9 = subprocess.run(cmd + ["--gpus", "8", "--devices", "0,0,0,0,0,0,0,0"], cwd=tmp_path / "w2", env=shim_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r9.returncode != 0 and "at most" in r9.stdout.decode()
