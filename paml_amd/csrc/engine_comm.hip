@@ -66,7 +66,11 @@ int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id12
       }
    }
    if (e->comm && !e->sc) {      // the stream and the events of the exchange step
-      HIPCHK(hipStreamCreateWithFlags(&e->sc, hipStreamNonBlocking));
+      // lowest priority: when the all-reduce and the next evaluation's pruning kernel become ready together, the pruning
+      // kernel's workgroups get the CUs first (the collective's few workgroups fit into that kernel's tail)
+      int prio_least = 0, prio_greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+      HIPCHK(hipStreamCreateWithPriority(&e->sc, hipStreamNonBlocking, prio_least));
       for (int b = 0; b < 2; b++) {
          HIPCHK(hipEventCreateWithFlags(&e->ev_part[b], hipEventDisableTiming));
          HIPCHK(hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));

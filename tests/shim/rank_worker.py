@@ -7,6 +7,7 @@ import os
 import sys
 import time
 
+import torch  # noqa: F401  (before the engine library: torch ships its own copy of the HIP runtime, see tests/conftest.py)
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
