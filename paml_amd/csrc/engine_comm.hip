@@ -66,11 +66,9 @@ int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id12
       }
    }
    if (e->comm && !e->sc) {      // the stream and the events of the exchange step
-      // lowest priority: when the all-reduce and the next evaluation's pruning kernel become ready together, the pruning
-      // kernel's workgroups get the CUs first (the collective's few workgroups fit into that kernel's tail)
-      int prio_least = 0, prio_greatest = 0;
-      (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-      HIPCHK(hipStreamCreateWithPriority(&e->sc, hipStreamNonBlocking, prio_least));
+      // (default priority: measured on MI355X, a LOWEST-priority collective stream is not served while the main stream has work
+      //  queued, and every evaluation then waits ~0.17 ms for the all-reduce of two evaluations ago — profiles/r03_comm_overhead.txt)
+      HIPCHK(hipStreamCreateWithFlags(&e->sc, hipStreamNonBlocking));
       for (int b = 0; b < 2; b++) {
          HIPCHK(hipEventCreateWithFlags(&e->ev_part[b], hipEventDisableTiming));
          HIPCHK(hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));

@@ -18,6 +18,7 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    e->n = n_states; e->n_tips = n_tips; e->n_patt = n_patt; e->max_classes = max_classes; e->n_genes = n_genes;
    e->flags = flags;
    e->env.read();
+   if (e->env.comm_cus >= 0) e->comm_cus = e->env.comm_cus;
    if (hipGetDevice(&e->device) != hipSuccess ||
        hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || e->n_cu < 1) {
       delete e;

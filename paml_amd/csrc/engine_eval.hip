@@ -444,7 +444,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    case KK_MFMA64:
       if (e->use_jit) {
          void *params[] = {&pr};
-         const int grid = std::min(n_blocks, e->n_cu);     // persistent: one 130 KB-LDS workgroup per CU walks the tiles
+         const int grid = std::min(n_blocks, e->cus_for_pruning());     // persistent: one 130 KB-LDS workgroup per CU walks the tiles
          HIPCHK(hipModuleLaunchKernel(e->jit.fn, grid, 1, 1, e->mfma_waves * 64, 1, 1, 0, e->stream, params, nullptr));
       }
       else if (use_dma) {
@@ -467,7 +467,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
       else if (e->use_jit && e->m20) {      // persistent: a multiple of the class count, every workgroup keeps its class's P(t) in LDS
          void *params[] = {&pr};
-         const int grid = std::min(std::max(K, e->n_cu / K * K), e->n_tiles * K);
+         const int grid = std::min(std::max(K, e->cus_for_pruning() / K * K), e->n_tiles * K);
          HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::max(grid / K, 1) * K, 1, 1, 512, 1, 1, 0, e->stream, params, nullptr));
       }
       else if (e->use_jit) {

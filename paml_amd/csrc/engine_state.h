@@ -153,7 +153,7 @@ inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global
 struct EnvCfg {
    bool force_stream = false;
    bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false, no_m20 = false;
-   int jit_waves = 0;
+   int jit_waves = 0, comm_cus = -1;
    std::string jit_dump, prof_ops;
    int prof_tid = 0;
    bool prof_tiles = false;      // the dump is a workgroup timeline (jit.h proft) instead of per-op stamps
@@ -169,6 +169,7 @@ struct EnvCfg {
       mfma4 = getenv("PAML_AMD_MFMA4") != nullptr;
       no_m20 = getenv("PAML_AMD_NO_M20") != nullptr;
       tail = getenv("PAML_AMD_TAIL") != nullptr;
+      if (const char *v = getenv("PAML_AMD_COMM_CUS")) comm_cus = atoi(v);
       if (const char *v = getenv("PAML_AMD_JIT_WAVES")) jit_waves = atoi(v);        // experiment: the last workgroup forms the total instead of a stage-2 launch
       if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
       if (const char *v = getenv("PAML_AMD_PROF_OPS")) prof_ops = v;
@@ -212,6 +213,12 @@ struct paml_amd_engine {
    hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
    bool done_pending[2] = {false, false};
    int red_slot = 0, last_slot = 0;
+   // CUs the persistent pruning kernels leave free while the engine has a communicator: their workgroups fill a CU (two waves
+   // per SIMD at 256 VGPRs, 130 KB of LDS), so the collective's workgroups would otherwise wait for the kernel's tail — or, when
+   // they win the race for a CU at its start, hold back one pruning workgroup for as long as the all-reduce waits for its peers.
+   // Free at the benchmark's sizes: 10^6 / N patterns in 128-pattern tiles take 31 / 16 / 8 / 4 rounds on 254 CUs as on 256.
+   int comm_cus = 2;
+   int cus_for_pruning() const { return comm ? std::max(1, n_cu - comm_cus) : n_cu; }
    DevBuf<double> d_partial1, d_partial_tot1;
    DevBuf<double> &part_slot(int b) { return b ? d_partial1 : d_partial; }
    DevBuf<double> &tot_slot(int b) { return b ? d_partial_tot1 : d_partial_tot; }
