@@ -114,6 +114,18 @@ int paml_amd_set_tree(paml_amd_engine *e, int n_nodes, int root, const int *sons
 /* com.pi (n_pi = 1) or com.piG per gene (n_pi = n_genes), row-major [n_pi][n_states]. */
 int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi);
 
+/* The same decomposition done ON THE DEVICE, for a batch of reversible rate matrices at once — what eigenQREV (tools.c:5023-5110,
+ * called by eigenQcodon codeml.c:3229 for every omega class of every trial point) does on one CPU core, 0.3-0.9 ms per 61 x 61
+ * matrix.  Q[n_sets][n*n] row-major (only the lower triangle is read, like eigenQREV), pi[n_sets][n], scale[n_sets] (NULL = 1):
+ * set set_ids[i] becomes Root = w / scale (descending), U = diag(1/sqrt pi) R, V = R^T diag(sqrt pi) with
+ * diag(sqrt pi) Q diag(1/sqrt pi) = R diag(w) R^T; states with pi = 0 are left out (Root 0, unit rows / columns).  One workgroup
+ * per matrix (cyclic Jacobi in LDS, FP64): a gradient's or a line search's several hundred decompositions take about the time
+ * of one, and U, V, Root never cross PCIe.  Asynchronous on the engine's stream.  paml_amd_get_eigen reads a set back (parity);
+ * paml_amd_eigen_counters: matrices decomposed so far and the Jacobi sweeps each matrix of the last batch took. */
+int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, const double *Q, const double *pi, const double *scale);
+int paml_amd_get_eigen(paml_amd_engine *e, int set_id, double *U, double *V, double *Root);
+int paml_amd_eigen_counters(paml_amd_engine *e, long *n_decomposed, int *sweeps_last_batch, int cap);
+
 /* Eigen systems, mirroring U,V,Root / _UU,_VV,_Root[NBTYPE+2] (codeml.c:185, treesub.c:9250) and
  * Cijk,Root,nR (baseml.c:123-124).  set_id is dense from 0.  Small H2D copies, typically per evaluation. */
 int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, const double *V, const double *Root);

@@ -1,0 +1,130 @@
+// eigen_kernels.h — batched eigen-decomposition of reversible rate matrices on the device (gfx950), FP64.
+//
+// What eigenQREV (tools.c:5023-5110) does on the host for every omega class of every trial point of an optimisation
+// (eigenQcodon codeml.c:3229 calls it; 0.3-0.9 ms of one CPU core at n = 61):  Q = S diag(pi) is similar to the symmetric
+// A = diag(sqrt pi) Q diag(1 / sqrt pi);  A = R diag(w) R^T;  Root = w (descending), U = diag(1 / sqrt pi) R, V = R^T diag(sqrt pi).
+// States of frequency zero are left out of the eigen problem and get Root = 0 and unit rows / columns (tools.c:5040-5105).
+//
+// One workgroup (4 waves) per matrix, A and R^T in LDS, cyclic Jacobi in the parallel (round-robin tournament) order: in a round the
+// N / 2 disjoint pairs (p, q) are rotated together — the rotation angles from the 2 x 2 blocks (N / 2 lanes), then the row
+// combinations of A and R^T (lane = column: conflict-free rows of stride 65), then the column combinations of A (lane = row).
+// N - 1 rounds visit every pair once (a sweep); 9-10 sweeps bring the off-diagonal part of a 61 x 61 codon matrix below
+// 1e-16 ||A|| (quadratic convergence).  Every matrix of a batch has its own workgroup: a gradient's or a line search's several
+// hundred decompositions take the time of one, ~1 ms, and U, V, Root are written straight into the engine's eigen sets — they never
+// cross PCIe.  This is latency-class work (LDS round trips and barriers, ~25 MFLOP per matrix); nothing here wants the matrix cores.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace paml_amd {
+
+struct EigenQrevArgs {
+   int n;
+   const double *Q;          // [n_sets][n * n] rate matrices (row-major; only the lower triangle is read, as eigenQREV does)
+   const double *pi;         // [n_sets][n]
+   const double *scale;      // [n_sets]: Root = w / scale (the mean rate eigenQcodon divides by)
+   double *const *U;         // [n_sets] device pointers of the eigen sets' buffers
+   double *const *V;
+   double *const *Root;
+   int *sweeps;              // [n_sets] sweeps used (diagnostics; null: not wanted)
+};
+
+constexpr int EIG_LD = 65;                                           // row stride of the LDS matrices (doubles)
+constexpr size_t EIG_LDS_BYTES = (size_t)(2 * 64 * EIG_LD + 64 + 64 + 32 + 32) * sizeof(double) + 4 * 64 * sizeof(int);
+
+__global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
+{
+   extern __shared__ double eig_sm[];
+   double *sA = eig_sm, *sV = sA + 64 * EIG_LD, *sSp = sV + 64 * EIG_LD, *sW = sSp + 64, *sC = sW + 64, *sS = sC + 32;
+   int *sP = (int *)(sS + 32), *sQ = sP + 64, *sRank = sQ + 64, *sFlag = sRank + 64;
+   __shared__ double sRed[4];
+   const int n = a.n, N = (n + 1) & ~1, set = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+   const double *Q = a.Q + (size_t)set * n * n, *pi = a.pi + (size_t)set * n;
+
+   if (tid < 64) sSp[tid] = (tid < n && pi[tid] > 1e-100) ? sqrt(pi[tid]) : 0.0;      // 0: the state is left out
+   __syncthreads();
+   double nrm = 0;
+   for (int idx = tid; idx < 64 * 64; idx += 256) {
+      const int i = idx >> 6, j = idx & 63;
+      double v = 0;
+      if (i < n && j < n) {
+         const int r = i > j ? i : j, c = i > j ? j : i;
+         if (sSp[r] > 0 && sSp[c] > 0) v = Q[r * n + c] * sSp[r] / sSp[c];
+      }
+      sA[i * EIG_LD + j] = v;
+      sV[i * EIG_LD + j] = i == j ? 1.0 : 0.0;
+      nrm += v * v;
+   }
+   for (int off = 32; off; off >>= 1) nrm += __shfl_xor(nrm, off);
+   if (lane == 0) sRed[wv] = nrm;
+   __syncthreads();
+   const double thr = 1e-16 * sqrt((sRed[0] + sRed[1]) + (sRed[2] + sRed[3]));
+
+   int sweep = 0;
+   for (; sweep < 40; sweep++) {
+      double big = 0;
+      for (int r = 0; r < N - 1; r++) {
+         if (tid < N / 2) {      // the rotation of pair tid of this round
+            int p = tid == 0 ? r : (r + tid) % (N - 1), q = tid == 0 ? N - 1 : (r - tid + (N - 1)) % (N - 1);
+            if (p > q) { const int t = p; p = q; q = t; }
+            const double apq = sA[p * EIG_LD + q];
+            double c = 1, s = 0;
+            if (fabs(apq) > 1e-300) {
+               big = fmax(big, fabs(apq));
+               const double theta = (sA[q * EIG_LD + q] - sA[p * EIG_LD + p]) / (2 * apq);
+               const double t = fabs(theta) > 1e150 ? 0.5 / theta : copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1));
+               c = 1 / sqrt(t * t + 1);
+               s = t * c;
+            }
+            sP[tid] = p; sQ[tid] = q; sC[tid] = c; sS[tid] = s;
+         }
+         __syncthreads();
+         for (int k = wv; k < N / 2; k += 4) {      // rows p, q of A and of R^T: lane = column
+            const double c = sC[k], s = sS[k];
+            if (s == 0 || lane >= N) continue;
+            const int p = sP[k] * EIG_LD + lane, q = sQ[k] * EIG_LD + lane;
+            const double ap = sA[p], aq = sA[q], vp = sV[p], vq = sV[q];
+            sA[p] = c * ap - s * aq; sA[q] = s * ap + c * aq;
+            sV[p] = c * vp - s * vq; sV[q] = s * vp + c * vq;
+         }
+         __syncthreads();
+         for (int k = wv; k < N / 2; k += 4) {      // columns p, q of A: lane = row
+            const double c = sC[k], s = sS[k];
+            if (s == 0 || lane >= N) continue;
+            const int p = lane * EIG_LD + sP[k], q = lane * EIG_LD + sQ[k];
+            const double ap = sA[p], aq = sA[q];
+            sA[p] = c * ap - s * aq; sA[q] = s * ap + c * aq;
+         }
+         __syncthreads();
+      }
+      if (wv == 0) {      // the largest off-diagonal element this sweep met
+         for (int off = 32; off; off >>= 1) big = fmax(big, __shfl_xor(big, off));
+         if (lane == 0) sFlag[0] = big <= thr;
+      }
+      __syncthreads();
+      if (sFlag[0]) { sweep++; break; }
+   }
+
+   // roots descending (ties: by position), then U = R / sqrt(pi), V = R^T sqrt(pi); left-out states: unit rows / columns, Root = 0
+   if (tid < 64) sW[tid] = tid < n ? sA[tid * EIG_LD + tid] : 0.0;
+   __syncthreads();
+   if (tid < n) {
+      const double w = sW[tid];
+      int rk = 0;
+      for (int j = 0; j < n; j++) rk += (sW[j] > w || (sW[j] == w && j < tid)) ? 1 : 0;
+      sRank[tid] = rk;
+      a.Root[set][rk] = w / a.scale[set];
+   }
+   __syncthreads();
+   double *U = a.U[set], *V = a.V[set];
+   for (int idx = tid; idx < n * 64; idx += 256) {
+      const int p = idx >> 6, i = idx & 63;      // eigenvector p = row p of R^T
+      if (i >= n) continue;
+      const double sp = sSp[i] > 0 ? sSp[i] : 1.0, v = sV[p * EIG_LD + i];
+      const int rk = sRank[p];
+      V[rk * n + i] = v * sp;
+      U[i * n + rk] = v / sp;
+   }
+   if (a.sweeps && tid == 0) a.sweeps[set] = sweep;
+}
+
+}  // namespace paml_amd

@@ -2,6 +2,7 @@
 // read-back of P(t), partials and scale factors (parity / debugging), stage timing, counters.
 // Built for gfx950 only (one of the translation units of libpaml_amd.so, see engine_state.h).
 #include "engine_state.h"
+#include "eigen_kernels.h"
 
 extern "C" {
 
@@ -240,6 +241,78 @@ int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, c
    HIPCHK(hipStreamSynchronize(e->stream));
    h->kind = PAML_AMD_EIGEN_UVROOT;
    return 0;
+}
+
+int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, const double *Q, const double *pi, const double *scale)
+{
+   enter(e);
+   if (!e || n_sets < 1 || !set_ids || !Q || !pi) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: bad arguments");
+   const size_t n = e->n;
+   int max_id = -1;
+   for (int i = 0; i < n_sets; i++) {
+      if (set_ids[i] < 0 || set_ids[i] > 4096) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: set id out of range");
+      for (int j = 0; j < i; j++)
+         if (set_ids[j] == set_ids[i]) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: a set id appears twice");
+      max_id = std::max(max_id, set_ids[i]);
+   }
+   if (!eigen_slot(e, max_id)) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: bad arguments");      // (sizes the table once: the slots below do not move)
+   std::vector<double *> ptr((size_t)3 * n_sets);
+   for (int i = 0; i < n_sets; i++) {
+      EigenHost *h = eigen_slot(e, set_ids[i]);
+      HIPCHK(h->U.ensure(n * n));
+      HIPCHK(h->V.ensure(n * n));
+      HIPCHK(h->Root.ensure(n));
+      h->kind = PAML_AMD_EIGEN_UVROOT;
+      ptr[i] = h->U.p; ptr[n_sets + i] = h->V.p; ptr[2 * (size_t)n_sets + i] = h->Root.p;
+   }
+   std::vector<double> ones;
+   if (!scale) { ones.assign(n_sets, 1.0); scale = ones.data(); }
+   HIPCHK(upload(e->d_eq_q, Q, (size_t)n_sets * n * n, e->stream));
+   HIPCHK(upload(e->d_eq_pi, pi, (size_t)n_sets * n, e->stream));
+   HIPCHK(upload(e->d_eq_scale, scale, (size_t)n_sets, e->stream));
+   HIPCHK(upload(e->d_eq_ptr, ptr.data(), ptr.size(), e->stream));
+   HIPCHK(e->d_eq_sweeps.ensure(n_sets));
+   if (!e->eigen_attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void *)eigen_qrev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EIG_LDS_BYTES));
+      e->eigen_attr_set = true;
+   }
+   EigenQrevArgs a{};
+   a.n = (int)n; a.Q = e->d_eq_q.p; a.pi = e->d_eq_pi.p; a.scale = e->d_eq_scale.p;
+   a.U = e->d_eq_ptr.p; a.V = e->d_eq_ptr.p + n_sets; a.Root = e->d_eq_ptr.p + 2 * (size_t)n_sets; a.sweeps = e->d_eq_sweeps.p;
+   hipLaunchKernelGGL(eigen_qrev_kernel, dim3(n_sets), dim3(256), EIG_LDS_BYTES, e->stream, a);
+   HIPCHK(hipGetLastError());
+   // (the host arrays were pageable: the runtime has staged them on return; the evaluations that follow on the engine's stream see the sets)
+   e->n_eigen_device += n_sets;
+   e->eq_last_batch = n_sets;
+   return 0;
+}
+
+int paml_amd_get_eigen(paml_amd_engine *e, int set_id, double *U, double *V, double *Root)
+{
+   enter(e);
+   if (!e || set_id < 0 || (size_t)set_id >= e->eigen.size() || e->eigen[set_id].kind != PAML_AMD_EIGEN_UVROOT)
+      return fail(e, PAML_AMD_EINVAL, "get_eigen: not a U / V / Root set");
+   const EigenHost &h = e->eigen[set_id];
+   const size_t n = e->n;
+   if (U) HIPCHK(hipMemcpyAsync(U, h.U.p, n * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   if (V) HIPCHK(hipMemcpyAsync(V, h.V.p, n * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   if (Root) HIPCHK(hipMemcpyAsync(Root, h.Root.p, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return 0;
+}
+
+int paml_amd_eigen_counters(paml_amd_engine *e, long *n_decomposed, int *sweeps_last_batch, int cap)
+{
+   enter(e);
+   if (!e) return PAML_AMD_EINVAL;
+   if (n_decomposed) *n_decomposed = e->n_eigen_device;
+   int m = 0;
+   if (sweeps_last_batch && e->d_eq_sweeps.p && e->eq_last_batch > 0) {
+      m = std::min(cap, e->eq_last_batch);
+      HIPCHK(hipMemcpyAsync(sweeps_last_batch, e->d_eq_sweeps.p, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+   }
+   return m;
 }
 
 int paml_amd_set_eigen_cijk(paml_amd_engine *e, int set_id, int nR, const double *Cijk, const double *Root)

@@ -24,7 +24,7 @@ JIT = 2
 EXPORTS = [
     "paml_amd_set_gene_class_rates", "paml_amd_get_branch_partials", "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
-    "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
+    "paml_amd_set_eigen_qrev_batch", "paml_amd_get_eigen", "paml_amd_eigen_counters", "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_device_count", "paml_amd_set_device", "paml_amd_shard_bounds", "paml_amd_max_ranks", "paml_amd_flush", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_get_partial_sums", "paml_amd_branch_counters",
     "paml_amd_jit_prebuild", "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
@@ -89,6 +89,9 @@ def lib():
         L.paml_amd_set_pi.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.paml_amd_set_eigen_uvroot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.paml_amd_set_eigen_cijk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.paml_amd_set_eigen_qrev_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.paml_amd_get_eigen.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.paml_amd_eigen_counters.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.c_int]
         L.paml_amd_set_eigen_k80.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.paml_amd_set_eigen_jc69like.argtypes = [C.c_void_p, C.c_int]
         L.paml_amd_set_classes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -312,6 +315,24 @@ class Engine:
         b = np.ascontiguousarray(branch, dtype=np.float64)
         g = None if gene_rate is None else np.ascontiguousarray(gene_rate, dtype=np.float64)
         self._chk(self._L.paml_amd_eval_device(self._h, _p(b), _p(g), C.c_void_p(d_lnL_ptr)))
+
+    def set_eigen_qrev_batch(self, set_ids, Q, pi, scale=None):
+        """Decompose the reversible rate matrices Q[k] (frequencies pi[k]) on the device into eigen sets set_ids[k]; Root is divided by scale[k]."""
+        ids = np.ascontiguousarray(set_ids, dtype=np.int32)
+        Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(len(ids), self.n, self.n)
+        pi = np.ascontiguousarray(pi, dtype=np.float64).reshape(len(ids), self.n)
+        sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64).reshape(len(ids))
+        self._chk(self._L.paml_amd_set_eigen_qrev_batch(self._h, len(ids), _p(ids), _p(Q), _p(pi), _p(sc)))
+
+    def get_eigen(self, set_id):
+        U, V, R = np.empty((self.n, self.n)), np.empty((self.n, self.n)), np.empty(self.n)
+        self._chk(self._L.paml_amd_get_eigen(self._h, int(set_id), _p(U), _p(V), _p(R)))
+        return U, V, R
+
+    def eigen_counters(self, cap=4096):
+        n, sw = C.c_long(), np.zeros(cap, dtype=np.int32)
+        m = self._L.paml_amd_eigen_counters(self._h, C.byref(n), _p(sw), cap)
+        return {"n_decomposed": n.value, "sweeps": sw[:max(m, 0)].copy()}
 
     def flush(self):
         """After a run of eval_device calls: the engine's stream waits for the totals still on the collective stream."""

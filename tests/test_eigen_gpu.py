@@ -1,0 +1,109 @@
+"""The batched eigen-decomposition on the device (paml_amd_set_eigen_qrev_batch, eigen_kernels.h) against the host path it
+replaces on the hot loop of small-data optimisation (eigenQREV tools.c:5023-5110 under eigenQcodon codeml.c:3229; here
+numpy's LAPACK symmetric solver through models.eigen_rev): roots to 1e-12, U diag(Root) V = Q and U V = I, P(t) of an evaluation
+to 1e-13, lnL unchanged to 1e-12 relative.  Eigenvectors themselves are not compared: they are unique only up to sign and to
+rotations inside an eigenspace, and P(t) does not depend on the choice."""
+import numpy as np
+import pytest
+
+import helpers
+from paml_amd import models, synth
+from paml_amd.engine import engine_for
+
+pytestmark = pytest.mark.gpu
+
+
+def random_f3x4(rng, zero=False):
+    fb = rng.dirichlet(np.ones(4) * 4, size=3)
+    if zero:                       # a nucleotide never seen at a position: 16 (minus stops) codons of frequency zero
+        fb[2, 3] = 0
+        fb[2] /= fb[2].sum()
+    return models.f3x4(fb)
+
+
+def test_codon_matrices_decomposed_on_the_device():
+    rng = np.random.default_rng(7)
+    pb = synth.codon_m0_problem(n_tips=6, n_patt=300)
+    eng = engine_for(pb)
+    cases = [(2.0, 0.4, False), (3.5, 1e-4, False), (1.0, 1.0, False), (8.0, 7.5, False), (2.0, 0.0, False), (2.5, 0.3, True), (0.7, 2.2, True)]
+    cases += [(float(rng.uniform(0.5, 10)), float(rng.uniform(0, 3)), False) for _ in range(40)]
+    Qs, pis, mrs = [], [], []
+    for kappa, omega, zero in cases:
+        pi = random_f3x4(rng, zero)
+        Q, mr = models.codon_q(kappa, omega, pi)
+        Qs.append(Q); pis.append(pi); mrs.append(mr)
+    ids = np.arange(len(cases)) + 3            # (not from 0: the table grows, set 0 stays the problem's own)
+    eng.set_eigen_qrev_batch(ids, np.array(Qs), np.array(pis), np.array(mrs))
+    cnt = eng.eigen_counters()
+    assert cnt["n_decomposed"] == len(cases) and len(cnt["sweeps"]) == len(cases)
+    assert cnt["sweeps"].max() <= 13 and cnt["sweeps"].min() >= 3, cnt["sweeps"]
+    for k, (Q, pi, mr) in enumerate(zip(Qs, pis, mrs)):
+        U, V, R = eng.get_eigen(int(ids[k]))
+        live = pi > 1e-100
+        sp = np.sqrt(pi[live])
+        A = (Q[np.ix_(live, live)] * sp[:, None] / sp[None, :])
+        A = np.tril(A) + np.tril(A, -1).T
+        w = np.sort(np.concatenate([np.linalg.eigvalsh(A), np.zeros((~live).sum())]))[::-1] / mr
+        scale = np.abs(A).max() / mr
+        assert np.all(np.diff(R) <= 0), "roots descending"
+        assert np.max(np.abs(R - w)) <= 1e-12 * scale, (k, np.max(np.abs(R - w)))
+        assert abs(R[0]) <= 1e-13 * scale                                   # the zero root first (what pmat_deriv_kernel relies on)
+        Qs_ = Q.copy()
+        Qs_[~live, :] = 0; Qs_[:, ~live] = 0                                # the chain never enters or leaves a left-out state
+        assert np.max(np.abs(U @ np.diag(R) @ V - Qs_ / mr)) <= 2e-13 * scale, k
+        assert np.max(np.abs(U @ V - np.eye(61))) <= 2e-13, k
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_pmat_and_lnl_with_device_eigen_match_the_host_path(K):
+    base = synth.codon_m0_problem(n_tips=10, n_patt=1500)
+    kappa = 2.3
+    omegas, freqs = ([0.4], [1.0]) if K == 1 else ([0.05, 1.0, 3.1], [0.6, 0.3, 0.1])
+    pb = synth.codon_nssites_problem(base, kappa, omegas, freqs) if K > 1 else base
+    if K == 1:
+        U, V, root, mr = models.codon_m0_eigen(kappa, omegas[0], base.pi[0])
+        pb.eigen = [dict(kind=helpers.EIGEN_UVROOT, U=U, V=V, Root=root)]
+    eng = engine_for(pb)
+    host = eng.eval(pb.tree.branch, want_lnf=True)
+    node = pb.tree.n_tips + 1
+    P_host = [eng.get_pmat(0, k, node) for k in range(K)] + [eng.get_pmat(0, k, 0) for k in range(K)]
+    pi = base.pi[0]
+    scale = models.codon_q(kappa, float(np.dot(freqs, omegas)), pi)[1]
+    Qs = [models.codon_q(kappa, w, pi)[0] for w in omegas]
+    eng.set_eigen_qrev_batch(np.arange(K), np.array(Qs), np.array([pi] * K), np.array([scale] * K))
+    dev = eng.eval(pb.tree.branch, want_lnf=True)
+    P_dev = [eng.get_pmat(0, k, node) for k in range(K)] + [eng.get_pmat(0, k, 0) for k in range(K)]
+    for a, b in zip(P_host, P_dev):
+        assert np.max(np.abs(a - b)) <= 1e-13
+    assert abs(dev["lnL"] - host["lnL"]) <= 1e-12 * abs(host["lnL"])
+    assert np.max(np.abs(dev["lnf"] - host["lnf"])) <= 1e-11
+    # the branch-local derivatives read the same sets (plain exp, first root forced to zero)
+    b = pb.tree.n_tips + 2
+    ts = np.array([pb.tree.branch[b], 0.3])
+    l1, d1, dd1 = eng.eval_branch(b, ts, pb.tree.branch)
+    eng2 = engine_for(pb)
+    l0, d0, dd0 = eng2.eval_branch(b, ts, pb.tree.branch)
+    assert np.allclose(l1, l0, rtol=1e-12, atol=0) and np.allclose(d1, d0, rtol=1e-9, atol=1e-8) and np.allclose(dd1, dd0, rtol=1e-9, atol=1e-7)
+
+
+@pytest.mark.parametrize("n", [4, 20])
+def test_small_reversible_matrices(n):
+    """n = 4 (GTR) and n = 20 (a random reversible amino-acid matrix): the same kernel, N = n pairs-per-round smaller."""
+    rng = np.random.default_rng(n)
+    pb = helpers.random_problem(n, 6, 200, K=1, seed=5)
+    eng = engine_for(pb)
+    m = 9
+    Qs, pis = [], []
+    for _ in range(m):
+        pi = rng.dirichlet(np.ones(n) * 3)
+        S = rng.uniform(0.05, 2.0, size=(n, n))
+        S = np.tril(S, -1) + np.tril(S, -1).T
+        Q = S * pi[None, :]
+        Q[np.diag_indices(n)] = -Q.sum(axis=1)
+        Qs.append(Q); pis.append(pi)
+    eng.set_eigen_qrev_batch(np.arange(m) + 1, np.array(Qs), np.array(pis))
+    for k in range(m):
+        U, V, R = eng.get_eigen(k + 1)
+        assert np.max(np.abs(U @ np.diag(R) @ V - Qs[k])) <= 1e-13 * np.abs(Qs[k]).max() * n
+        assert np.max(np.abs(U @ V - np.eye(n))) <= 1e-13
+        assert abs(R[0]) < 1e-13 and np.all(np.diff(R) <= 0)
