@@ -18,7 +18,18 @@ typedef struct {
    int kind, nR;
    double kappa;
    double *U, *V, *Root, *Cijk;
+   /* a reversible rate matrix whose decomposition is left to the device (paml_amd_set_eigen_qrev_batch): Q[n*n], its frequencies
+    * and the scale Root is divided by; `lazy`: U, V, Root above have not been formed on the host (pamlh_eig_host does it on demand) */
+   double *Q, *qpi, scale;
+   int lazy;
 } pamlh_eig;
+
+/* decompositions waiting for ONE device call: the eigen systems of all the candidates of a batched evaluation */
+typedef struct {
+   int n, cnt, cap;
+   int *ids;
+   double *Q, *pi, *scale;
+} pamlh_eig_batch;
 
 struct pamlh {
    char err[512], dir[1024];
@@ -107,6 +118,10 @@ int pamlh_nh_nrate(const pamlh *p);      /* nhomo >= 2: rate parameters, frequen
 int pamlh_nh_npi(const pamlh *p);
 void pamlh_eigen_sym(double *A, int n, double *w, double *R);
 void pamlh_eigen_qrev(const double *Q, const double *pi, int n, double *Root, double *U, double *V);
+void pamlh_eig_host(pamlh_eig *e, int n);
+void pamlh_eig_release(pamlh_eig *e);
+int pamlh_upload_eigen_sets(pamlh *p, paml_amd_engine *eng, int base, pamlh_eig_batch *batch);
+int pamlh_eig_batch_flush(pamlh *p, paml_amd_engine *eng, pamlh_eig_batch *batch);
 double pamlh_gammp(double a, double x);
 double pamlh_quantile_gamma(double p, double alpha, double beta);
 void pamlh_discrete_gamma(double *freqK, double *rK, double alpha, int K);

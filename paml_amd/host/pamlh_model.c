@@ -649,7 +649,7 @@ void pamlh_free(pamlh *p)
    free(p->rate_label); free(p->nh_label); free(p->tip_age); free(p->age_low);
    free(p->sons_ptr); free(p->sons); free(p->label); free(p->branch_node); free(p->father); free(p->tree_branch); free(p->scale);
    free(p->branch); free(p->pi); free(p->freqK); free(p->rate); free(p->eigen_of);
-   for (i = 0; i < PAMLH_MAXEIG; i++) { free(p->eig[i].U); free(p->eig[i].V); free(p->eig[i].Root); free(p->eig[i].Cijk); }
+   for (i = 0; i < PAMLH_MAXEIG; i++) pamlh_eig_release(&p->eig[i]);
    free(p->gene_eigen_of);
    free(p);
 }
@@ -699,6 +699,7 @@ int pamlh_eigen(const pamlh *p, int i, int *kind, int *nR, double *kappa, const 
                 const double **Root, const double **Cijk)
 {
    if (i < 0 || i >= p->n_eigen) return -1;
+   if (U || V || Root) pamlh_eig_host((pamlh_eig *)&p->eig[i], p->n);      /* (formed on demand when the device does the decompositions) */
    if (kind) *kind = p->eig[i].kind;
    if (nR) *nR = p->eig[i].nR;
    if (kappa) *kappa = p->eig[i].kappa;
@@ -867,15 +868,91 @@ int pamlh_read_inx(const pamlh *p, double *x, int cap)
    return k;
 }
 
+/* Where the decomposition of Q = S diag(pi) happens.  20- and 61-state models: on the DEVICE — the host keeps Q, pi and the scale,
+ * and the upload (pamlh_upload_eigen_sets) hands all waiting matrices to paml_amd_set_eigen_qrev_batch in one call; U, V, Root are
+ * formed on the host only when something asks for them (pamlh_eig_host: the accessor of the oracle-based tests, tables).
+ * 4 states (and PAMLH_HOST_EIGEN=1, the A/B switch): on the host at once, as before. */
+static int host_eigen_forced(void)
+{
+   static int v = -1;
+   if (v < 0) v = getenv("PAMLH_HOST_EIGEN") != NULL;
+   return v;
+}
+
+void pamlh_eig_release(pamlh_eig *e)
+{
+   free(e->U); free(e->V); free(e->Root); free(e->Cijk); free(e->Q); free(e->qpi);
+   e->U = e->V = e->Root = e->Cijk = e->Q = e->qpi = NULL;
+   e->lazy = 0;
+}
+
+void pamlh_eig_host(pamlh_eig *e, int n)
+{
+   int k;
+   if (!e->lazy || !e->Q) return;
+   if (!e->U) { e->U = (double *)malloc((size_t)n * n * 8); e->V = (double *)malloc((size_t)n * n * 8); e->Root = (double *)malloc(n * 8); }
+   pamlh_eigen_qrev(e->Q, e->qpi, n, e->Root, e->U, e->V);
+   for (k = 0; k < n; k++) e->Root[k] /= e->scale;
+   e->lazy = 0;
+}
+
 static void set_eig_uvroot(pamlh *p, int i, const double *Q, const double *pi, double scale)
 {
    const int n = p->n;
-   int k;
    pamlh_eig *e = &p->eig[i];
-   if (!e->U) { e->U = (double *)malloc((size_t)n * n * 8); e->V = (double *)malloc((size_t)n * n * 8); e->Root = (double *)malloc(n * 8); }
    e->kind = PAML_AMD_EIGEN_UVROOT;
-   pamlh_eigen_qrev(Q, pi, n, e->Root, e->U, e->V);
-   for (k = 0; k < n; k++) e->Root[k] /= scale;
+   if (!e->Q) { e->Q = (double *)malloc((size_t)n * n * 8); e->qpi = (double *)malloc(n * 8); }
+   memcpy(e->Q, Q, (size_t)n * n * 8);
+   memcpy(e->qpi, pi, n * 8);
+   e->scale = scale;
+   e->lazy = 1;
+   if (n <= 5 || host_eigen_forced()) pamlh_eig_host(e, n);
+}
+
+/* The eigen systems of the model state go to the engine as sets base, base + 1, ...: reversible rate matrices still waiting for
+ * their decomposition are collected — into `batch` when the caller gathers several model states for one device call
+ * (pamlh_eig_batch_flush), else into a batch of their own — everything else is sent as it is. */
+static void eig_batch_add(pamlh_eig_batch *b, int id, const pamlh_eig *e, int n)
+{
+   if (b->cnt == b->cap) {
+      b->cap = b->cap ? 2 * b->cap : 64;
+      b->ids = (int *)realloc(b->ids, b->cap * sizeof(int));
+      b->Q = (double *)realloc(b->Q, (size_t)b->cap * n * n * 8);
+      b->pi = (double *)realloc(b->pi, (size_t)b->cap * n * 8);
+      b->scale = (double *)realloc(b->scale, b->cap * 8);
+   }
+   b->n = n;
+   b->ids[b->cnt] = id;
+   memcpy(b->Q + (size_t)b->cnt * n * n, e->Q, (size_t)n * n * 8);
+   memcpy(b->pi + (size_t)b->cnt * n, e->qpi, n * 8);
+   b->scale[b->cnt++] = e->scale;
+}
+
+int pamlh_eig_batch_flush(pamlh *p, paml_amd_engine *eng, pamlh_eig_batch *b)
+{
+   int rc = 0;
+   if (b->cnt && (rc = paml_amd_set_eigen_qrev_batch(eng, b->cnt, b->ids, b->Q, b->pi, b->scale))) pamlh_fail(p, "%s", paml_amd_last_error(eng));
+   free(b->ids); free(b->Q); free(b->pi); free(b->scale);
+   memset(b, 0, sizeof(*b));
+   return rc;
+}
+
+int pamlh_upload_eigen_sets(pamlh *p, paml_amd_engine *eng, int base, pamlh_eig_batch *batch)
+{
+   pamlh_eig_batch own;
+   int i, rc = 0;
+   memset(&own, 0, sizeof(own));
+   for (i = 0; i < p->n_eigen && !rc; i++) {
+      pamlh_eig *e = &p->eig[i];
+      if (e->kind == PAML_AMD_EIGEN_UVROOT && e->lazy && e->Q) eig_batch_add(batch ? batch : &own, base + i, e, p->n);
+      else if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(eng, base + i, e->U, e->V, e->Root);
+      else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(eng, base + i, e->nR, e->Cijk, e->Root);
+      else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(eng, base + i, e->kappa);
+      else if (e->kind == PAML_AMD_EIGEN_QMAT) rc = paml_amd_set_eigen_qmat(eng, base + i, e->U);
+      else rc = paml_amd_set_eigen_jc69like(eng, base + i);
+   }
+   if (rc) { pamlh_fail(p, "%s", paml_amd_last_error(eng)); free(own.ids); free(own.Q); free(own.pi); free(own.scale); return rc; }
+   return batch ? 0 : pamlh_eig_batch_flush(p, eng, &own);
 }
 
 /* aaDist = 7 (AAClasses): OmegaAA.dat beside the control file — "nclass", then for classes 1 .. nclass-1 a line "k: XY XY ...",
@@ -1589,7 +1666,7 @@ int pamlh_gene_subset(const pamlh *p, int g, pamlh **out)
    q->freqK = (double *)calloc(64, sizeof(double));
    q->rate = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    q->eigen_of = (int *)calloc(64 * PAMLH_MAXEIG, sizeof(int));
-   for (i = 0; i < PAMLH_MAXEIG; i++) q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = NULL;
+   for (i = 0; i < PAMLH_MAXEIG; i++) { q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = q->eig[i].Q = q->eig[i].qpi = NULL; q->eig[i].lazy = 0; }
    /* frequencies of this gene alone, then the one-gene parameter count */
    if (q->seqtype == 1) freqs_codon(q); else freqs_base_aa(q);
    if (q->seqtype == 0 && q->model == T92) { q->pi_data[0] = q->pi_data[2] = (q->pi_data[0] + q->pi_data[2]) / 2; q->pi_data[1] = q->pi_data[3] = (q->pi_data[1] + q->pi_data[3]) / 2; }
@@ -1615,7 +1692,7 @@ pamlh *pamlh_state_clone(const pamlh *p)
    q->freqK = (double *)calloc(64, sizeof(double));
    q->rate = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    q->eigen_of = (int *)calloc(64 * PAMLH_MAXEIG, sizeof(int));
-   for (i = 0; i < PAMLH_MAXEIG; i++) q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = NULL;
+   for (i = 0; i < PAMLH_MAXEIG; i++) { q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = q->eig[i].Q = q->eig[i].qpi = NULL; q->eig[i].lazy = 0; }
    return q;
 }
 
@@ -1623,7 +1700,7 @@ void pamlh_state_free(pamlh *q)
 {
    int i;
    if (!q) return;
-   for (i = 0; i < PAMLH_MAXEIG; i++) { free(q->eig[i].U); free(q->eig[i].V); free(q->eig[i].Root); free(q->eig[i].Cijk); }
+   for (i = 0; i < PAMLH_MAXEIG; i++) pamlh_eig_release(&q->eig[i]);
    free(q->branch); free(q->pi); free(q->freqK); free(q->rate); free(q->eigen_of); free(q->gene_eigen_of);
    free(q);
 }
@@ -1691,18 +1768,10 @@ void *pamlh_engine_handle(const pamlh *p) { return p ? (void *)p->eng : NULL; }
 
 int pamlh_engine_model(pamlh *p)
 {
-   int i, rc;
+   int rc;
    if ((rc = pamlh_engine_ready(p))) return rc;
    if ((rc = paml_amd_set_pi(p->eng, p->n_pi, p->pi))) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
-   for (i = 0; i < p->n_eigen; i++) {
-      const pamlh_eig *e = &p->eig[i];
-      if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, i, e->U, e->V, e->Root);
-      else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(p->eng, i, e->nR, e->Cijk, e->Root);
-      else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(p->eng, i, e->kappa);
-      else if (e->kind == PAML_AMD_EIGEN_QMAT) rc = paml_amd_set_eigen_qmat(p->eng, i, e->U);
-      else rc = paml_amd_set_eigen_jc69like(p->eng, i);
-      if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
-   }
+   if ((rc = pamlh_upload_eigen_sets(p, p->eng, 0, NULL))) return rc;
    if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->ngene > 1 ? p->gene_eigen_of : p->eigen_of,
                                   p->use_qf ? p->qfactor : NULL)) ||
        (p->malpha && (rc = paml_amd_set_gene_class_rates(p->eng, p->rate))))
@@ -1715,15 +1784,7 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
    int i, rc;
    if ((rc = pamlh_engine_ready(p))) return rc;
    if ((rc = paml_amd_set_pi(p->eng, p->n_pi, p->pi))) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
-   for (i = 0; i < p->n_eigen; i++) {
-      const pamlh_eig *e = &p->eig[i];
-      if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, i, e->U, e->V, e->Root);
-      else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(p->eng, i, e->nR, e->Cijk, e->Root);
-      else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(p->eng, i, e->kappa);
-      else if (e->kind == PAML_AMD_EIGEN_QMAT) rc = paml_amd_set_eigen_qmat(p->eng, i, e->U);
-      else rc = paml_amd_set_eigen_jc69like(p->eng, i);
-      if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
-   }
+   if ((rc = pamlh_upload_eigen_sets(p, p->eng, 0, NULL))) return rc;
    if ((rc = paml_amd_set_classes(p->eng, p->mode, p->K, p->freqK, p->rate, p->n_labels, p->ngene > 1 ? p->gene_eigen_of : p->eigen_of,
                                   p->use_qf ? p->qfactor : NULL)) ||
        (p->malpha && (rc = paml_amd_set_gene_class_rates(p->eng, p->rate))))
@@ -1961,14 +2022,7 @@ int pamlh_neb(pamlh *p, double *post, double *mean_w)
    for (i = 0; p->scale && i < p->nnode; i++) if (p->scale[i]) logf = 1;      /* fhK = log f + scale factors (fx_r treesub.c:7744-7749) */
    if ((rc = pamlh_engine_ready(p))) { free(fhK); return rc; }
    if ((rc = paml_amd_set_pi(p->eng, 1, p->pi))) { free(fhK); return pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); }
-   for (i = 0; i < p->n_eigen; i++) {
-      const pamlh_eig *e = &p->eig[i];
-      if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, i, e->U, e->V, e->Root);
-      else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(p->eng, i, e->nR, e->Cijk, e->Root);
-      else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(p->eng, i, e->kappa);
-      else rc = paml_amd_set_eigen_jc69like(p->eng, i);
-      if (rc) { free(fhK); return pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); }
-   }
+   if ((rc = pamlh_upload_eigen_sets(p, p->eng, 0, NULL))) { free(fhK); return rc; }
    if ((rc = paml_amd_set_classes(p->eng, p->mode, K, p->freqK, p->rate, p->n_labels, p->eigen_of, p->use_qf ? p->qfactor : NULL)) ||
        (rc = paml_amd_eval(p->eng, p->branch, NULL, &lnL, NULL, fhK))) {
       free(fhK);
@@ -2032,7 +2086,7 @@ int pamlh_beb(pamlh *p, const double *x, double *pr_pos, double *mean_w, double 
    fhK = (double *)malloc((size_t)K * np * sizeof(double));
    if ((rc = pamlh_engine_ready(p))) { free(fhK); return rc; }
    rc = paml_amd_set_pi(p->eng, 1, p->pi);
-   for (k = 0; k < K && !rc; k++) rc = paml_amd_set_eigen_uvroot(p->eng, k, p->eig[k].U, p->eig[k].V, p->eig[k].Root);
+   if (!rc && pamlh_upload_eigen_sets(p, p->eng, 0, NULL)) { free(fhK); return -1; }      /* the K grid omegas: one batch of decompositions on the device */
    if (!rc) rc = paml_amd_set_classes(p->eng, p->mode, K, p->freqK, p->rate, 1, p->eigen_of, NULL);
    if (!rc) rc = paml_amd_eval(p->eng, p->branch, NULL, &lnL, NULL, NULL);      /* fhK stays on the device */
    if (rc) { free(fhK); return pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); }
@@ -2112,10 +2166,22 @@ int pamlh_beb_acd(pamlh *p, const double *x, double *post)
    rc = paml_amd_set_tips(e, p->z, p->cleandata, p->n_codes, p->n_chara, p->chara_map, p->w, NULL);
    if (!rc) rc = paml_amd_set_tree(e, p->nnode, p->root, p->sons_ptr, p->sons, p->label, p->scale);
    if (!rc) rc = paml_amd_set_pi(e, 1, p->pi);
-   for (k = 0; k < KW && !rc; k++) {
-      codon_q(p, kappa, wv[k], Q);
-      pamlh_eigen_qrev(Q, p->pi, n, R, U, V);
-      rc = paml_amd_set_eigen_uvroot(e, k, U, V, R);
+   if (host_eigen_forced())
+      for (k = 0; k < KW && !rc; k++) {
+         codon_q(p, kappa, wv[k], Q);
+         pamlh_eigen_qrev(Q, p->pi, n, R, U, V);
+         rc = paml_amd_set_eigen_uvroot(e, k, U, V, R);
+      }
+   else if (!rc) {      /* the grid's omegas: one batch of decompositions on the device */
+      double *Qs = (double *)malloc((size_t)KW * n * n * sizeof(double)), *pis = (double *)malloc((size_t)KW * n * sizeof(double));
+      int ids[KWMAX];
+      for (k = 0; k < KW; k++) {
+         codon_q(p, kappa, wv[k], Qs + (size_t)k * n * n);
+         memcpy(pis + (size_t)k * n, p->pi, n * sizeof(double));
+         ids[k] = k;
+      }
+      rc = paml_amd_set_eigen_qrev_batch(e, KW, ids, Qs, pis, NULL);
+      free(Qs); free(pis);
    }
    if (!rc) rc = paml_amd_set_classes(e, PAML_AMD_MODE_LFUNDG, KC, fk, rt, 2, eo, qf);
    if (!rc) rc = paml_amd_eval(e, p->branch, NULL, &lnL, NULL, NULL);

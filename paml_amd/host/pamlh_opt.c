@@ -15,20 +15,6 @@
 
 #include "pamlh_internal.h"
 
-static int upload_eigen(pamlh *p, int base)
-{
-   int i, rc = 0;
-   for (i = 0; i < p->n_eigen && !rc; i++) {
-      const pamlh_eig *e = &p->eig[i];
-      if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(p->eng, base + i, e->U, e->V, e->Root);
-      else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(p->eng, base + i, e->nR, e->Cijk, e->Root);
-      else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(p->eng, base + i, e->kappa);
-      else if (e->kind == PAML_AMD_EIGEN_QMAT) rc = paml_amd_set_eigen_qmat(p->eng, base + i, e->U);
-      else rc = paml_amd_set_eigen_jc69like(p->eng, base + i);
-   }
-   return rc ? pamlh_fail(p, "%s", paml_amd_last_error(p->eng)) : 0;
-}
-
 /* lnL at nb parameter vectors xs[nb][np] in one launch.  Vectors whose substitution-model part (x[ntime..np)) is equal
  * share one model set-up (eigen decompositions are the host's expensive part); a vector the model rejects
  * (e.g. class proportions summing above 1) gets lnL = -1e300. */
@@ -50,6 +36,8 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
    int *eo = NULL, *rep_eo = NULL, use_qf = 0;
    double *qf = NULL, *rep_qf = NULL, *gr = NULL;
    const int G = p->ngene;
+   pamlh_eig_batch ebatch;
+   memset(&ebatch, 0, sizeof(ebatch));
    if ((rc = pamlh_engine_ready(p))) goto done;
    if (!p->fix_rho || p->rho0 != 0) {      /* lfunAdG ends in a sequential chain over the sites on the host: one evaluation at a time */
       for (b = 0; b < nb; b++) {
@@ -87,8 +75,8 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       }
       else if (q->K != K || q->n_labels * G != L || q->n_eigen != n_eigen || q->mode != mode) { rc = pamlh_fail(p, "internal: model shape changed inside a batch"); goto done; }
       if ((nrep + 1) * n_eigen > 4096) { rc = pamlh_fail(p, "batch needs more than 4096 eigen systems"); goto done; }
-      q->eng = p->eng;
-      if ((rc = upload_eigen(q, nrep * n_eigen))) { pamlh_fail(p, "%s", pamlh_error(q)); goto done; }
+      /* (reversible rate matrices are only collected here: all the candidates' decompositions are ONE device call below) */
+      if ((rc = pamlh_upload_eigen_sets(q, p->eng, nrep * n_eigen, &ebatch))) { pamlh_fail(p, "%s", pamlh_error(q)); goto done; }
       memcpy(rep_fk + (size_t)nrep * K, q->freqK, K * sizeof(double));
       memcpy(rep_rt + (size_t)nrep * RK, q->rate, RK * sizeof(double));
       for (i = 0; i < K * L; i++) rep_eo[(size_t)nrep * K * L + i] = nrep * n_eigen + (G > 1 ? q->gene_eigen_of[i] : q->eigen_of[i]);
@@ -96,6 +84,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
       cand_rep[c] = nrep++;
    }
    if (!nrep) { for (b = 0; b < nb; b++) lnL[b] = -1e300; goto done; }
+   if ((rc = pamlh_eig_batch_flush(p, p->eng, &ebatch))) goto done;
    fk = (double *)malloc((size_t)nb * K * sizeof(double));
    rt = (double *)malloc((size_t)nb * RK * sizeof(double));
    eo = (int *)malloc((size_t)nb * K * L * sizeof(int));
@@ -170,6 +159,7 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
    for (b = 0; b < nb; b++)
       if (cand_of[b] < 0 || cand_rep[cand_of[b]] < 0 || !(lnL[b] == lnL[b])) lnL[b] = -1e300;
 done:
+   free(ebatch.ids); free(ebatch.Q); free(ebatch.pi); free(ebatch.scale);
    for (c = 0; c < ncand; c++) pamlh_state_free(ws[c]);
    free(ws); free(cand_of); free(cand_elem); free(cand_rep); free(br); free(fk); free(rt); free(eo); free(rep_fk); free(rep_rt); free(rep_eo); free(qf); free(rep_qf); free(gr);
    return rc;

@@ -76,7 +76,7 @@ def test_pmat_and_lnl_with_device_eigen_match_the_host_path(K):
     for a, b in zip(P_host, P_dev):
         assert np.max(np.abs(a - b)) <= 1e-13
     assert abs(dev["lnL"] - host["lnL"]) <= 1e-12 * abs(host["lnL"])
-    assert np.max(np.abs(dev["lnf"] - host["lnf"])) <= 1e-11
+    assert np.max(np.abs(dev["lnf"] - host["lnf"])) <= 1e-10
     # the branch-local derivatives read the same sets (plain exp, first root forced to zero)
     b = pb.tree.n_tips + 2
     ts = np.array([pb.tree.branch[b], 0.3])

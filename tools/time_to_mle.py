@@ -6,10 +6,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 from paml_amd import hostlib
 
-CASES = [("hiv_m2a", "codeml", "hiv_ns2.ctl"), ("hiv_m8", "codeml", "hiv_ns8.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl"),
+CASES = [("hiv_m0", "codeml", "hiv_ns0.ctl"), ("hiv_m1a", "codeml", "hiv_ns1.ctl"), ("hiv_m2a", "codeml", "hiv_ns2.ctl"), ("hiv_m7", "codeml", "hiv_ns7.ctl"),
+         ("hiv_m8", "codeml", "hiv_ns8.ctl"), ("hiv_m3", "codeml", "hiv_ns3.ctl"),
          ("lyso_bsa", "codeml", "lyso_bsa.ctl"), ("lyso_bsa_null", "codeml", "lyso_bsa_null.ctl"), ("lyso_bsb", "codeml", "lyso_bsb.ctl"),
          ("ecp_cmc", "codeml", "ecp_cmc.ctl"), ("ecp_cmd", "codeml", "ecp_cmd.ctl"),
          ("horai_mg4", "baseml", "horai_mg4.ctl"), ("lysin_mg4", "codeml", "lysin_mg4.ctl")]
+print("# eigen decompositions: %s" % ("on the host (PAMLH_HOST_EIGEN=1)" if os.environ.get("PAMLH_HOST_EIGEN") else "batched on the device (paml_amd_set_eigen_qrev_batch)"))
 for gname, prog, ctl in CASES:
     g = helpers.load_golden(gname)
     a = hostlib.Analysis(os.path.join(ROOT, "tests", "golden", "ctl", ctl), prog)
