@@ -17,8 +17,9 @@ program) every run is checked against.  Default `--scaling strong`: the SAME 10^
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 Rank 0 prints ONE JSON line; beside the headline it carries `roofline`, `cpu_baseline` (N = 1), the NSsites `sweep`
-(K = 1, 2, 3, 10, 11 classes with the M0 / M1a / M2a / M7 / M8 tables of the goldens) and, at N = 1, the 20-state `aa20` and the 4-state `c2`
-configuration (BASELINE configs[1]).
+(K = 1, 2, 3, 10, 11 classes with the M0 / M1a / M2a / M7 / M8 tables of the goldens) and, at N = 1, every other BASELINE configuration:
+`c1` (configs[0], brown HKY85), `c2` + `c2_batch` (configs[1], 4 states), `c3` (configs[2], stewart LG+G4) with `aa20` (its model class
+at scale), `c5` (configs[4], HIV NSsites 0 1 2 7 8: latency per evaluation and time to the MLEs).
 """
 from __future__ import annotations
 
@@ -279,7 +280,13 @@ def main():
         out["roofline"]["clock"] = ck
     if rank == 0 and world == 1 and extras:
         out["c2"] = bench_c2(engine, synth, timed, args)
+        out["c2_batch"] = bench_c2_batch(engine, synth, fence)
         out["aa20"] = bench_aa20(engine, synth, timed, args)
+        for key, fn in (("c1", bench_c1), ("c3", bench_c3), ("c5", bench_c5)):      # the small-data configurations: latency, not throughput
+            try:
+                out[key] = fn(engine, timed, fence)
+            except Exception as ex:      # (the C host library or a data file missing: reported, the headline stands)
+                out[key] = {"error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         pbc = pb if pb.K == 1 else None
         out["cpu_baseline"] = cpu_baseline(pbc, args.cpu_sample)
@@ -320,15 +327,165 @@ def bench_c2(engine, synth, timed, args):
     if ref is not None and not abs(lnl - ref) <= 2e-6 + 1e-12 * abs(ref):
         raise SystemExit("bench: C2 lnL %.9f differs from the reference's %.6f" % (lnl, ref))
     kms = prof["ms_prune"] / max(1, prof["n_evals"])
-    bpp = algorithmic_bytes_per_pattern(4, 32, pb.K)
     fpp = algorithmic_flops_per_pattern(4, 32) * pb.K
+    # what the kernel really moves: 32 B of tip codes + 8 B of weight per pattern (the partials never leave the registers; confirmed by the
+    # FETCH_SIZE / WRITE_SIZE passes in profiles/): 2 % of the HBM peak — the bound of this kernel is the FP64 vector issue rate, and at
+    # 10^5 patterns x 4 classes the launch is too short to fill the chip (3 waves per SIMD): a latency figure
+    real_bytes = pb.n_tips + 8
+    tf = fpp * pb.n_patt / (kms * 1e-3) / 1e12
     return {"workload": "baseml GTR+G4, 32 taxa x 100000 nucleotide patterns (BASELINE configs[1])", "kernel": name, "lnL": lnl,
             "lnL_reference": ref, "ms_per_eval": dt / steps * 1e3, "site_patterns_per_s": pb.n_patt * steps / dt, "kernel_ms": kms,
-            "roofline": {"bound": "hbm", "achieved": bpp * pb.n_patt / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bpp * pb.n_patt / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_pattern": bpp,
-                         "note": "materialised-partials bytes (SURVEY 8d): the fused kernel keeps partials in registers, so this exceeds the HBM "
-                                 "peak; real traffic is in profiles/",
-                         "valu_tflops": fpp * pb.n_patt / (kms * 1e-3) / 1e12, "valu_frac": fpp * pb.n_patt / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}}
+            "roofline": {"bound": "valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                         "flop_per_pattern": fpp, "hbm_real_bytes": real_bytes * pb.n_patt,
+                         "hbm_real_frac": real_bytes * pb.n_patt / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "BASELINE calls this configuration HBM-bound; the fused kernel keeps the partials in registers, so its HBM traffic is the "
+                                 "tip codes and weights only (hbm_real_frac of 8 TB/s) and the binding resource is FP64 vector issue. One evaluation "
+                                 "of 10^5 patterns is latency-class work: c2_batch is the same kernel with a gradient's worth of evaluations"}}
+
+
+def bench_c2_batch(engine, synth, fence):
+    """A gradient's worth of evaluations of configs[1] in ONE launch (paml_amd_eval_batch, what gradientB's 2 np calls of com.plfun —
+    tools.c:6561 — become): 2 x 61 branch lengths perturbed up and down, 122 elements x 4 classes x 10^5 patterns."""
+    pb = synth.nuc_gtr_gamma_problem(n_tips=32, n_patt=100_000)
+    eng = engine.engine_for(pb)
+    br = pb.tree.branch
+    idx = [i for i in range(pb.tree.n_nodes) if i != pb.tree.root]
+    B = np.repeat(br[None, :], 2 * len(idx), axis=0)
+    for k, i in enumerate(idx):
+        B[2 * k, i] *= 1 + 1e-6
+        B[2 * k + 1, i] *= 1 - 1e-6
+    base = eng.eval(br)["lnL"]
+    for _ in range(3):
+        vals = eng.eval_batch(B)
+    fence()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        vals = eng.eval_batch(B)
+    fence()
+    dt = (time.perf_counter() - t0) / reps
+    name = eng.kernel_name
+    eng.close()
+    if not np.all(np.abs(vals - base) < 1e-3 * abs(base)):
+        raise SystemExit("bench: c2_batch values off: %r vs %r" % (vals[:4].tolist(), base))
+    fpp = algorithmic_flops_per_pattern(4, 32) * pb.K
+    tf = fpp * pb.n_patt * len(B) / dt / 1e12
+    return {"workload": "configs[1] data, %d evaluations per launch (central differences over the %d branch lengths)" % (len(B), len(idx)), "kernel": name,
+            "ms_per_batch": dt * 1e3, "ms_per_eval": dt / len(B) * 1e3, "site_patterns_per_s": pb.n_patt * len(B) / dt,
+            "roofline": {"bound": "valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                         "note": "whole call incl. the host read-back of the %d values" % len(B)}}
+
+
+def _latency(eng, pb, timed, fence, steps=300):
+    """ms per evaluation of a small problem: queued back to back (device value) and with the scalar read back every time."""
+    dt, lnl, _ = timed(eng, pb.tree.branch.copy(), steps, 10)
+    c0 = eng.counters()
+    for _ in range(5):
+        eng.eval(pb.tree.branch, pb.gene_rate)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        v = eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]
+    fence()
+    dts = time.perf_counter() - t0
+    c1 = eng.counters()
+    return {"lnL": v, "ms_per_eval_back_to_back": dt / steps * 1e3, "ms_per_eval_sync": dts / steps * 1e3,
+            "n_pmat_per_eval": (c1["n_pmat"] - c0["n_pmat"]) // (steps + 5), "kernel": eng.kernel_name}
+
+
+def _host_case(gname, prog, ctl):
+    from paml_amd import hostlib
+    path = os.path.join(GOLDEN, "ctl", ctl)
+    with open(os.path.join(GOLDEN, gname + ".json")) as f:
+        g = json.load(f)
+    return hostlib.Analysis(path, prog), g
+
+
+def bench_c1(engine, timed, fence):
+    """BASELINE configs[0]: baseml HKY85 on brown.nuc (5 taxa, the reference's plumbing case) — latency of one evaluation."""
+    a, g = _host_case("brown_hky85", "baseml", "brown_hky85.ctl")
+    pb = a.problem(np.array(g["x"]))
+    eng = engine.engine_for(pb)
+    r = _latency(eng, pb, timed, fence)
+    eng.close()
+    if abs(r["lnL"] - g["lnL"]) > 2e-6:
+        raise SystemExit("bench: c1 lnL %.9f differs from the reference's %.6f" % (r["lnL"], g["lnL"]))
+    r.update(workload="baseml HKY85, brown.nuc (5 taxa, %d patterns) (BASELINE configs[0])" % pb.n_patt, lnL_reference=g["lnL"])
+    return r
+
+
+def bench_c3(engine, timed, fence):
+    """BASELINE configs[2]: codeml seqtype 2, LG + Gamma4 on stewart.aa (6 taxa, 20 states) — latency of one evaluation."""
+    a, g = _host_case("stewart_lg_g4", "codeml", "stewart_lg_g4.ctl")
+    pb = a.problem(np.array(g["x"]))
+    eng = engine.engine_for(pb)
+    r = _latency(eng, pb, timed, fence)
+    eng.close()
+    if abs(r["lnL"] - g["lnL"]) > 2e-6:
+        raise SystemExit("bench: c3 lnL %.9f differs from the reference's %.6f" % (r["lnL"], g["lnL"]))
+    r.update(workload="codeml seqtype 2 LG+G4, stewart.aa (6 taxa, %d patterns) (BASELINE configs[2])" % pb.n_patt, lnL_reference=g["lnL"])
+    return r
+
+
+def bench_c5(engine, timed, fence):
+    """BASELINE configs[4]: codeml NSsites = 0 1 2 7 8 on the HIVNSsites example (13 taxa, 79 patterns): per model the latency of one
+    evaluation (omega-class x branch batched P(t): 23 / 46 / 69 / 230 / 253 matrices), and the time from the control file's initial values
+    to the maximum-likelihood estimates with the C host's optimiser (batched gradients and line searches, eigen-decompositions batched on the
+    device), checked against the lnL the reference's own optimiser printed; beside it the unmodified reference program's wall time for M0."""
+    models_ = [("M0", "hiv_m0", "hiv_ns0.ctl"), ("M1a", "hiv_m1a", "hiv_ns1.ctl"), ("M2a", "hiv_m2a", "hiv_ns2.ctl"),
+               ("M7", "hiv_m7", "hiv_ns7.ctl"), ("M8", "hiv_m8", "hiv_ns8.ctl")]
+    rows = []
+    for name, gname, ctl in models_:
+        a, g = _host_case(gname, "codeml", ctl)
+        pb = a.problem(np.array(g["x"]))
+        eng = engine.engine_for(pb)
+        r = _latency(eng, pb, timed, fence, steps=200)
+        eng.close()
+        if abs(r["lnL"] - g["lnL"]) > 2e-6:
+            raise SystemExit("bench: c5 %s lnL %.9f differs from the reference's %.6f" % (name, r["lnL"], g["lnL"]))
+        a.eval_gpu(a.default_x(), want_lnf=False)      # (engine creation outside the clock)
+        t0 = time.perf_counter()
+        opt = a.optimize(a.default_x())
+        r.update(model=name, classes=pb.K, lnL_reference=g["lnL"], mle_seconds=time.perf_counter() - t0, mle_lnL=opt["lnL"], mle_evaluations=opt["n_eval"],
+                 mle_converged=bool(opt["converged"]), mle_ms_per_evaluation=(time.perf_counter() - t0) / max(1, opt["n_eval"]) * 1e3)
+        if abs(opt["lnL"] - g["lnL"]) > 5e-6:
+            raise SystemExit("bench: c5 %s optimiser ended at %.9f, the reference's at %.6f" % (name, opt["lnL"], g["lnL"]))
+        rows.append(r)
+    out = {"workload": "codeml NSsites = 0 1 2 7 8, HIVenvSweden (13 taxa, 79 patterns) (BASELINE configs[4])", "models": rows,
+           "mle_seconds_total": sum(r["mle_seconds"] for r in rows)}
+    ref = reference_mle_seconds_hiv_m0()
+    if ref is not None:
+        out["reference_cpu"] = ref
+    return out
+
+
+def reference_mle_seconds_hiv_m0():
+    """Wall time of the unmodified reference program (oracle/_ref/codeml, one core) for the same M0 analysis; None when the binary is not there."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(REPO, "oracle", "_ref", "codeml")
+    data = os.path.join(GOLDEN, "data")
+    if not (os.path.isfile(exe) and os.access(exe, os.X_OK)):
+        return None
+    d = tempfile.mkdtemp(prefix="paml_amd_ref_")
+    try:
+        with open(os.path.join(d, "codeml.ctl"), "w") as f:
+            f.write("seqfile = %s/HIVenvSweden.txt\ntreefile = %s/HIVenvSweden.trees\noutfile = mlc\nnoisy = 0\nverbose = 0\nrunmode = 0\nseqtype = 1\n"
+                    "CodonFreq = 2\nmodel = 0\nNSsites = 0\nicode = 0\nfix_kappa = 0\nkappa = .3\nfix_omega = 0\nomega = 1.3\nncatG = 10\ngetSE = 0\n"
+                    "RateAncestor = 0\nSmall_Diff = .45e-6\ncleandata = 1\nfix_blength = 0\n" % (data, data))
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "codeml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 20, timeout=300)
+        dt = time.perf_counter() - t0
+        txt = open(os.path.join(d, "mlc")).read() if os.path.exists(os.path.join(d, "mlc")) else ""
+        if r.returncode != 0 or "lnL(ntime" not in txt:
+            return None
+        return {"model": "M0", "seconds": dt, "lnL": float(txt.split("lnL(ntime")[1].split("):")[1].split()[0]), "cores": 1,
+                "what": "oracle/_ref/codeml (the unmodified reference, gcc -O3): the same control file, its own ming2"}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def bench_aa20(engine, synth, timed, args):

@@ -78,21 +78,37 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
             sP[tid] = p; sQ[tid] = q; sC[tid] = c; sS[tid] = s;
          }
          __syncthreads();
-         for (int k = wv; k < N / 2; k += 4) {      // rows p, q of A and of R^T: lane = column
-            const double c = sC[k], s = sS[k];
-            if (s == 0 || lane >= N) continue;
-            const int p = sP[k] * EIG_LD + lane, q = sQ[k] * EIG_LD + lane;
-            const double ap = sA[p], aq = sA[q], vp = sV[p], vq = sV[q];
-            sA[p] = c * ap - s * aq; sA[q] = s * ap + c * aq;
-            sV[p] = c * vp - s * vq; sV[q] = s * vp + c * vq;
-         }
-         __syncthreads();
-         for (int k = wv; k < N / 2; k += 4) {      // columns p, q of A: lane = row
-            const double c = sC[k], s = sS[k];
-            if (s == 0 || lane >= N) continue;
-            const int p = lane * EIG_LD + sP[k], q = lane * EIG_LD + sQ[k];
-            const double ap = sA[p], aq = sA[q];
-            sA[p] = c * ap - s * aq; sA[q] = s * ap + c * aq;
+         // rows p, q of A and of R^T (lane = column), then columns p, q of A (lane = row).  A wave owns the pairs wv, wv + 4, ...
+         // (at most 8): the pairs of a round are disjoint, so all their loads are issued before the first store — one LDS
+         // round trip per phase instead of one per pair.
+         {
+            double c[8], s[8], ap[8], aq[8], vp[8], vq[8];
+            int ip[8], iq[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+               const int k = wv + 4 * u;
+               const bool on = k < N / 2 && lane < N;
+               c[u] = on ? sC[k] : 1.0; s[u] = on ? sS[k] : 0.0;
+               ip[u] = (on ? sP[k] : 0) * EIG_LD + lane; iq[u] = (on ? sQ[k] : 0) * EIG_LD + lane;
+               if (s[u] != 0) { ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]]; vp[u] = sV[ip[u]]; vq[u] = sV[iq[u]]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+               if (s[u] != 0) {
+                  sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u];
+                  sV[ip[u]] = c[u] * vp[u] - s[u] * vq[u]; sV[iq[u]] = s[u] * vp[u] + c[u] * vq[u];
+               }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+               const int k = wv + 4 * u;
+               const bool on = k < N / 2 && lane < N;
+               ip[u] = lane * EIG_LD + (on ? sP[k] : 0); iq[u] = lane * EIG_LD + (on ? sQ[k] : 0);
+               if (s[u] != 0) { ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+               if (s[u] != 0) { sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u]; }
          }
          __syncthreads();
       }

@@ -56,6 +56,12 @@ int pamlh_read_ctl(pamlh *p, const char *path)
          if (i == p->ctl.n) { if (p->ctl.n >= PAMLH_MAXOPT) continue; p->ctl.n++; }
          snprintf(p->ctl.key[i], 32, "%s", k);
          snprintf(p->ctl.val[i], 1024, "%s", v);
+         /* file-name options: the reference reads ONE token (sscanf "%s", codeml.c:1735) — anything after it on the line is ignored */
+         if (!strncmp(k, "seqfile", 7) || !strncmp(k, "treefile", 8) || !strncmp(k, "outfile", 7) || !strncmp(k, "aaRatefile", 10)) {
+            char *t = p->ctl.val[i];
+            while (*t && !isspace((unsigned char)*t)) t++;
+            *t = 0;
+         }
       }
    }
    fclose(f);

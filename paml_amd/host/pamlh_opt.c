@@ -190,7 +190,7 @@ int pamlh_simplex_groups(const pamlh *p, int *start, int *len, int cap)
    const int k0 = p->ntime + (p->ngene - 1);
    if (p->ngene > 1) return 0;
    if (p->seqtype == 1) {
-      const int k = k0 + !p->fix_kappa;
+      const int k = k0 + !p->fix_kappa + p->npi;      /* (x: kappa, the npi codon-frequency parameters, then the site-class proportions: pamlh_set_x) */
       int m = 0;
       if (p->aadist == 7) m = 0;
       else if (p->model >= 2 && p->nssites) m = 2;

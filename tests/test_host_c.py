@@ -346,6 +346,22 @@ def test_driver_binary_end_to_end(tmp_path):
 
 
 @pytest.mark.gpu
+def test_c_host_optimiser_with_frequency_parameters_and_site_classes():
+    """x holds kappa, then the npi codon-frequency parameters, then the site-class proportions: the optimiser's log-ratio transform of
+    (p0, p1) must sit behind the frequency parameters (pamlh_simplex_groups).  FMutSel0 + M2a on the HIV data: the search ends at the
+    lnL the reference's optimiser printed, with the mutation-bias ratios untouched by the transform (they are not a simplex)."""
+    g = helpers.load_golden("hiv_fmutsel0_m2a")
+    a = hostlib.Analysis(os.path.join(CTL, "hiv_fmutsel0_m2a.ctl"), "codeml")
+    r = a.optimize(a.default_x())
+    assert r["converged"]
+    assert abs(r["lnL"] - g["mle_lnL"]) <= 2e-5, (r["lnL"], g["mle_lnL"])
+    lo, hi = a.bounds()
+    assert ((r["x"] >= lo) & (r["x"] <= hi)).all()
+    xg = np.array(g["x"])
+    assert np.allclose(r["x"][a.ntime:], xg[a.ntime:], rtol=2e-2, atol=2e-3), (r["x"][a.ntime:], xg[a.ntime:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("gname,prog,ctl", [CASES[0], CASES[1], CASES[2], CASES[4]])
 def test_c_host_optimiser_finds_the_reference_mle(gname, prog, ctl):
     """pamlh_optimize (BFGS, gradients and line searches as batches on the GPU) started from the control file's initial
