@@ -331,7 +331,7 @@ def bench_c2(engine, synth, timed, args):
     # what the kernel really moves: 32 B of tip codes + 8 B of weight per pattern (the partials never leave the registers; confirmed by the
     # FETCH_SIZE / WRITE_SIZE passes in profiles/): 2 % of the HBM peak — the bound of this kernel is the FP64 vector issue rate, and at
     # 10^5 patterns x 4 classes the launch is too short to fill the chip (3 waves per SIMD): a latency figure
-    real_bytes = pb.n_tips + 8
+    real_bytes = pb.tree.n_tips + 8
     tf = fpp * pb.n_patt / (kms * 1e-3) / 1e12
     return {"workload": "baseml GTR+G4, 32 taxa x 100000 nucleotide patterns (BASELINE configs[1])", "kernel": name, "lnL": lnl,
             "lnL_reference": ref, "ms_per_eval": dt / steps * 1e3, "site_patterns_per_s": pb.n_patt * steps / dt, "kernel_ms": kms,

@@ -120,8 +120,9 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
    }
    // the fast path of consecutive eval_device calls (see pipe_ok): nothing but branch lengths / gene rates may have changed
-   // (worth its event traffic only where the pruning kernel is long: the 21..64-state kernels on >= 10^5 pattern-classes)
-   want_pipe = want_pipe && e->kk == KK_MFMA64 && (long)e->n_patt * e->K >= 100000;
+   // (worth its event traffic only where the pruning kernel is long: the 21..64-state kernels and the 20-state matrix-core kernel on
+   //  >= 10^5 pattern-classes)
+   want_pipe = want_pipe && (e->kk == KK_MFMA64 || (e->kk == KK_VALU20 && e->want_m20)) && (long)e->n_patt * e->K >= 100000;
    const bool pipe = want_pipe && e->pipe_ok && !bs && !clean && !keep && !new_prog && !e->eigen_dirty && !e->env.no_pipeline;
    if (want_pipe && !e->s2) {
       HIPCHK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));

@@ -928,10 +928,39 @@ static void eig_batch_add(pamlh_eig_batch *b, int id, const pamlh_eig *e, int n)
    b->scale[b->cnt++] = e->scale;
 }
 
+/* Few matrices: the host's cores, one matrix each, are as fast as the device's fixed ~2 ms (one Jacobi run, however many matrices ride
+ * in it: profiles/r03_eigen.txt) — M0 / M1a / M2a searches have 1-3 eigen systems per trial point.  From PAMLH_DEVICE_EIGEN_MIN matrices
+ * on (default 16: a gradient or a line search of the M3 / M7 / M8 / branch-site models, the BEB grids) the batch goes to the device. */
+static int device_eigen_min(void)
+{
+   static int v = -1;
+   if (v < 0) { const char *e = getenv("PAMLH_DEVICE_EIGEN_MIN"); v = e ? atoi(e) : 16; }
+   return v;
+}
+
 int pamlh_eig_batch_flush(pamlh *p, paml_amd_engine *eng, pamlh_eig_batch *b)
 {
    int rc = 0;
-   if (b->cnt && (rc = paml_amd_set_eigen_qrev_batch(eng, b->cnt, b->ids, b->Q, b->pi, b->scale))) pamlh_fail(p, "%s", paml_amd_last_error(eng));
+   if (b->cnt && b->cnt < device_eigen_min()) {
+      const int n = b->n, m = b->cnt;
+      double *uvr = (double *)malloc((size_t)m * (2 * n * n + n) * sizeof(double));
+      int i, k;
+#pragma omp parallel for schedule(dynamic) num_threads(m < 16 ? m : 16) if (m > 1)
+      for (i = 0; i < m; i++) {
+         double *U = uvr + (size_t)i * (2 * n * n + n), *V = U + (size_t)n * n, *R = V + (size_t)n * n;
+         int kk;
+         pamlh_eigen_qrev(b->Q + (size_t)i * n * n, b->pi + (size_t)i * n, n, R, U, V);
+         for (kk = 0; kk < n; kk++) R[kk] /= b->scale[i];
+      }
+      for (i = 0; i < m && !rc; i++) {
+         const double *U = uvr + (size_t)i * (2 * n * n + n);
+         rc = paml_amd_set_eigen_uvroot(eng, b->ids[i], U, U + (size_t)n * n, U + (size_t)2 * n * n);
+      }
+      (void)k;
+      free(uvr);
+      if (rc) pamlh_fail(p, "%s", paml_amd_last_error(eng));
+   }
+   else if (b->cnt && (rc = paml_amd_set_eigen_qrev_batch(eng, b->cnt, b->ids, b->Q, b->pi, b->scale))) pamlh_fail(p, "%s", paml_amd_last_error(eng));
    free(b->ids); free(b->Q); free(b->pi); free(b->scale);
    memset(b, 0, sizeof(*b));
    return rc;
