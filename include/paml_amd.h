@@ -157,11 +157,14 @@ int paml_amd_set_gene_class_rates(paml_amd_engine *e, const double *rate);
 int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, double *lnL, double *lnf,
                   double *fhK);
 
-/* Same evaluation without the final device->host copy or synchronisation: lnL (the total over the
- * ranks when the engine has a communicator) is left in d_lnL (a device pointer, e.g. a torch tensor)
- * on the engine's stream.  With a communicator the totals of the last two calls may still be on the collective stream:
- * paml_amd_flush makes the engine's stream wait for them (one call after a run of eval_device calls, before the caller
- * synchronises the stream or reads d_lnL on it); without a communicator it does nothing. */
+/* Same evaluation without the final device->host copy or synchronisation: lnL (the total over the ranks when the engine has a
+ * communicator) is left in d_lnL (a device pointer, e.g. a torch tensor).  Consecutive calls are pipelined: the next
+ * evaluation's P(t) is built on a side stream under this one's pruning kernel, and — large problems on the matrix-core kernels,
+ * or any engine with a communicator — this evaluation's reduction (and exchange step) runs on a side stream while the engine's
+ * stream goes on to the next pruning kernel.  The totals of the last two calls may therefore still be on the side stream:
+ * paml_amd_flush makes the engine's stream wait for them.  Call it once after a run of eval_device calls, before synchronising
+ * the stream or reading d_lnL on it (a device-wide synchronisation covers the side stream too); every other entry point
+ * of the engine does it implicitly. */
 int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL);
 int paml_amd_flush(paml_amd_engine *e);
 

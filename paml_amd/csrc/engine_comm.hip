@@ -65,15 +65,9 @@ int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id12
          return fail(e, PAML_AMD_EHIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(nr));
       }
    }
-   if (e->comm && !e->sc) {      // the stream and the events of the exchange step
-      // (default priority: measured on MI355X, a LOWEST-priority collective stream is not served while the main stream has work
-      //  queued, and every evaluation then waits ~0.17 ms for the all-reduce of two evaluations ago — profiles/r03_comm_overhead.txt)
-      HIPCHK(hipStreamCreateWithFlags(&e->sc, hipStreamNonBlocking));
-      for (int b = 0; b < 2; b++) {
-         HIPCHK(hipEventCreateWithFlags(&e->ev_part[b], hipEventDisableTiming));
-         HIPCHK(hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
-      }
-   }
+   if (e->comm)
+      if (int rc = ensure_side_stream(e)) return rc;
+   if (e->sc) HIPCHK(hipStreamSynchronize(e->sc));
    e->done_pending[0] = e->done_pending[1] = false;
    e->red_slot = e->last_slot = 0;
    e->rank = rank; e->world = world;
@@ -107,7 +101,7 @@ int paml_amd_get_partial_sums(paml_amd_engine *e, double *out, int cap)
    enter(e);
    if (!e || !out) return fail(e, PAML_AMD_EINVAL, "get_partial_sums: null argument");
    if (e->n_eval == 0 || !e->part_slot(e->last_slot).p || cap < e->nb_global) return fail(e, PAML_AMD_EINVAL, "get_partial_sums: nothing evaluated yet, or cap < number of chunks");
-   const double *src = e->comm ? e->tot_slot(e->last_slot).p : e->d_partial.p;
+   const double *src = e->comm ? e->tot_slot(e->last_slot).p : e->part_slot(e->last_slot).p;
    HIPCHK(hipMemcpyAsync(out, src, (size_t)e->nb_global * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
    return e->nb_global;

@@ -385,26 +385,39 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // the reduction's geometry (the fused kernels form the partial sums themselves; the others leave them to reduce_stage1)
    const int chunk = e->chunk, nbg = e->nb_global;
    const int nb = (e->n_patt + chunk - 1) / chunk;
-   // the slot of partial sums this evaluation fills: with a communicator two slots alternate (the exchange step of the previous
-   // evaluation may still be reading the other one on the collective stream); the slot's previous all-reduce has to be over
-   // before anything writes it again
-   const int slot = e->comm ? e->red_slot : 0;
+   // Off the pruning stream: in a run of paml_amd_eval_device calls the reduction of evaluation i (mixture + log + chunk sums, the
+   // exchange step over the ranks if any, the fixed-order total) runs on the engine's side stream while the main stream goes
+   // straight on to the pruning kernel of evaluation i + 1 — two kernel boundaries and their dependency latencies leave the
+   // critical path (profiles/r03_timeline.txt: 23 us of a 0.23 ms evaluation at the 8-GPU shard size).  Two slots of (class
+   // likelihoods, partial sums, their all-reduced copy) alternate; whoever writes a slot again first waits for its ev_done.
+   const bool fusedk = e->kk != KK_MFMA64 && e->use_jit && e->fused;      // the kernel forms the partial sums itself
+   const bool offload = want_pipe && !fusedk && !keep && !clean && !bs && !want_lnf && !e->tree.n_scale && !e->env.no_offload;
+   if (!offload && !e->comm)
+      if (int rc = join_comm(e)) return rc;
+   const int slot = (e->comm || offload) ? e->red_slot : 0;
    DevBuf<double> &dpart = e->part_slot(slot);
    if ((size_t)nbg * B > dpart.cap) {
-      if (e->comm && e->sc) HIPCHK(hipStreamSynchronize(e->sc));      // (reallocation: nothing may still be reading the old buffer)
+      if (e->sc) HIPCHK(hipStreamSynchronize(e->sc));      // (reallocation: nothing may still be reading the old buffer)
       HIPCHK(dpart.ensure((size_t)nbg * B));
       HIPCHK(hipMemsetAsync(dpart.p, 0, dpart.cap * sizeof(double), e->stream));
    }
+   DevBuf<double> &dfhk = (offload && slot) ? e->d_fhK1 : e->d_fhK;
+   if (offload && slot) HIPCHK(dfhk.ensure((size_t)K * e->n_patt));
+   pr.fhK = dfhk.p;
    bool slot_waited = false;
-   auto wait_slot = [&]() -> int {      // main stream: the all-reduce that last read this slot (two evaluations ago) is done
+   auto wait_slot = [&]() -> int {      // main stream: the reduction that last read this slot (two evaluations ago) is done
       if (slot_waited) return 0;
       slot_waited = true;
-      if (e->comm && e->done_pending[slot]) {
+      if ((e->comm || offload) && e->done_pending[slot]) {
          e->done_pending[slot] = false;
          HIPCHK(hipStreamWaitEvent(e->stream, e->ev_done[slot], 0));
       }
       return 0;
    };
+   if (offload) {
+      if (int rc = ensure_side_stream(e)) return rc;
+      if (int rc = wait_slot()) return rc;      // (the pruning kernel writes this slot's class likelihoods)
+   }
    if ((size_t)B * RED_TICKET_WORDS > e->d_red_counter.cap) {
       HIPCHK(e->d_red_counter.ensure((size_t)std::max(B, 64) * RED_TICKET_WORDS));
       HIPCHK(hipMemsetAsync(e->d_red_counter.p, 0, e->d_red_counter.cap * sizeof(int), e->stream));
@@ -502,21 +515,27 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // so every rank then holds the same array whatever the number of ranks — and stage 2 adds it up in a fixed order.  On one
    // GPU the workgroup that finishes last forms the total itself (red_block_finish): no second launch.
    ReduceArgs ra{};
-   ra.fhK = e->d_fhK.p; ra.weights = e->d_weights.p; ra.freqK = e->d_freqK.p; ra.lnf = want_lnf ? e->d_lnf.p : nullptr;
+   ra.fhK = dfhk.p; ra.weights = e->d_weights.p; ra.freqK = e->d_freqK.p; ra.lnf = want_lnf ? e->d_lnf.p : nullptr;
    ra.partial = dpart.p; ra.out = lnl_out;
    ra.raw = ((e->kk == KK_MFMA64 && e->use_jit) || (e->kk == KK_VALU20 && e->use_jit && e->m20)) ? 1 : 0; ra.fscale = e->d_fscale.p;
    ra.n_patt = e->n_patt; ra.K = Km; ra.mode = e->mode; ra.n_scale = e->tree.n_scale; ra.chunk = chunk;
    ra.first_chunk = e->first_chunk; ra.nb_stride = nbg;
    // (measured on MI355X, 32 taxa x 10^5 nucleotide patterns: 28.2 us per evaluation with the separate one-block launch against
    //  30.2 with tickets — the agent-scope store + two atomics + coherent reads cross the XCDs' L2s and cost more than a launch)
-   const bool tail = !e->comm && e->env.tail;
+   const bool tail = !e->comm && !offload && e->env.tail;
    ra.counter = tail ? e->d_red_counter.p : nullptr;
    if (bs && bs->freqK) { ra.freqK = e->d_b_freqK.p; ra.freqK_bs = Km; }
-   mark(e);
+   hipStream_t rs = e->stream;      // the stream of the reduction
+   if (offload) {
+      HIPCHK(hipEventRecord(e->ev_part[slot], e->stream));
+      HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[slot], 0));
+      rs = e->sc;
+   }
+   mark_on(e, rs);
    if (int rc = wait_slot()) return rc;
-   if (!fused) hipLaunchKernelGGL(reduce_stage1, dim3(nb, B), dim3(256), 0, e->stream, ra);
+   if (!fused) hipLaunchKernelGGL(reduce_stage1, dim3(nb, B), dim3(256), 0, rs, ra);
    if (e->comm) {
-      // the exchange step, off the pruning stream: the collective stream takes over when this evaluation's partial sums are there
+      // the exchange step, off the pruning stream: the side stream takes over when this evaluation's partial sums are there
       // (ev_part), all-reduces them into the slot's second buffer and forms the fixed-order total; the next evaluation's P(t) and
       // pruning kernel follow on the main stream without waiting for any of it
       DevBuf<double> &dtot = e->tot_slot(slot);
@@ -524,18 +543,22 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          HIPCHK(hipStreamSynchronize(e->sc));
          HIPCHK(dtot.ensure((size_t)nbg * B));
       }
-      HIPCHK(hipEventRecord(e->ev_part[slot], e->stream));
-      HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[slot], 0));
+      if (!offload) {
+         HIPCHK(hipEventRecord(e->ev_part[slot], e->stream));
+         HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[slot], 0));
+      }
       const ncclResult_t nr = rccl().AllReduce(dpart.p, dtot.p, (size_t)nbg * B, ncclDouble, ncclSum, e->comm, e->sc);
       if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
       hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->sc, (const double *)dtot.p, nbg, ra.out);
+   }
+   else if (!tail && nbg > 1) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, rs, (const double *)dpart.p, nbg, ra.out);      // (one block per element: stage 1 wrote the total)
+   if (e->comm || offload) {
       HIPCHK(hipEventRecord(e->ev_done[slot], e->sc));
       e->done_pending[slot] = true;
       e->last_slot = slot;
       e->red_slot = slot ^ 1;
    }
-   else if (!tail && nbg > 1) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->stream, (const double *)dpart.p, nbg, ra.out);      // (one block per element: stage 1 wrote the total)
-   mark(e);
+   mark_on(e, rs);
    HIPCHK(hipGetLastError());
    if (e->profiling) e->prof_evals++;
    e->n_eval++;

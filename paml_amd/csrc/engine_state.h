@@ -152,6 +152,7 @@ inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global
 // Environment switches, read once when the engine is created.
 struct EnvCfg {
    bool force_stream = false;
+   bool no_offload = false;
    bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false, no_m20 = false;
    int jit_waves = 0, comm_cus = -1;
    std::string jit_dump, prof_ops;
@@ -160,6 +161,7 @@ struct EnvCfg {
    void read()
    {
       no_pipeline = getenv("PAML_AMD_NO_PIPELINE") != nullptr;
+      no_offload = getenv("PAML_AMD_NO_OFFLOAD") != nullptr;      // experiments: the reduction stays on the pruning stream
       force_gather = getenv("PAML_AMD_FORCE_GATHER") != nullptr;
       force_stream = getenv("PAML_AMD_FORCE_STREAM") != nullptr;      // experiments: the stream interpreter also on small data sets
       jit_sync = getenv("PAML_AMD_JIT_SYNC") != nullptr;
@@ -219,7 +221,7 @@ struct paml_amd_engine {
    // Free at the benchmark's sizes: 10^6 / N patterns in 128-pattern tiles take 31 / 16 / 8 / 4 rounds on 254 CUs as on 256.
    int comm_cus = 2;
    int cus_for_pruning() const { return comm ? std::max(1, n_cu - comm_cus) : n_cu; }
-   DevBuf<double> d_partial1, d_partial_tot1;
+   DevBuf<double> d_partial1, d_partial_tot1, d_fhK1;
    DevBuf<double> &part_slot(int b) { return b ? d_partial1 : d_partial; }
    DevBuf<double> &tot_slot(int b) { return b ? d_partial_tot1 : d_partial_tot; }
    DevBuf<unsigned int> d_zpm;        // fused 4 / 5-state kernel: tip codes pattern-major
@@ -362,7 +364,7 @@ struct paml_amd_engine {
       d_eq_q.release(); d_eq_pi.release(); d_eq_scale.release(); d_eq_ptr.release(); d_eq_sweeps.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_rowmajor, &d2_pint, &d2_ptip, &d2_pcol, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot, &d_partial1, &d_partial_tot1,
+                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_rowmajor, &d2_pint, &d2_ptip, &d2_pcol, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot, &d_partial1, &d_partial_tot1, &d_fhK1,
                               &d_expA, &d_expB, &d_expSA, &d_expSB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
    }
@@ -424,7 +426,21 @@ inline void mark_on(paml_amd_engine *e, hipStream_t s)
 }
 inline void mark(paml_amd_engine *e) { mark_on(e, e->stream); }
 
-// The caller's stream waits for the totals still on their way on the collective stream (no-op without a communicator).
+// The engine's side stream (reductions of consecutive eval_device calls, the exchange step over the ranks) and its events.
+inline int ensure_side_stream(paml_amd_engine *e)
+{
+   if (e->sc) return 0;
+   // (default priority: measured on MI355X, a LOWEST-priority stream is not served while the main stream has work queued, and
+   //  every evaluation then waits ~0.17 ms for the all-reduce of two evaluations ago — profiles/r03_comm_overhead.txt)
+   if (hipStreamCreateWithFlags(&e->sc, hipStreamNonBlocking) != hipSuccess) return fail(e, PAML_AMD_EHIP, "hipStreamCreate(side stream)");
+   for (int b = 0; b < 2; b++)
+      if (hipEventCreateWithFlags(&e->ev_part[b], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming) != hipSuccess)
+         return fail(e, PAML_AMD_EHIP, "hipEventCreate(side stream)");
+   return 0;
+}
+
+// The caller's stream waits for the totals still on their way on the side stream (no-op when there are none).
 inline int join_comm(paml_amd_engine *e)
 {
    for (int b = 0; b < 2; b++)

@@ -751,6 +751,52 @@ def test_eval_device_pipeline_matches_in_order_evaluations():
     assert np.array_equal(P, eng.get_pmat(0, 0, 3))
 
 
+@pytest.mark.parametrize("n,K,n_patt", [(61, 2, 60000), (20, 2, 60000)])
+def test_eval_device_reduction_on_the_side_stream(n, K, n_patt):
+    """Large problems on the matrix-core kernels: in a run of eval_device calls the reduction of evaluation i (class mixture, log,
+    chunk sums, fixed-order total) runs on the engine's side stream while the main stream goes on to the pruning kernel of
+    evaluation i + 1 — two slots of class likelihoods / partial sums alternate.  Ten queued evaluations with different branch
+    lengths, paml_amd_flush, a synchronisation of the STREAM only: every value has the bits of the plain evaluation, and so it has
+    with the reduction kept on the pruning stream (PAML_AMD_NO_OFFLOAD)."""
+    import os
+    import torch
+    pb = helpers.random_problem(n, 8, n_patt, K=K, seed=77)
+    rng = np.random.default_rng(9)
+    brs = [pb.tree.branch * rng.uniform(0.7, 1.3, pb.tree.n_nodes) for _ in range(10)]
+    ref = engine_for(pb)
+    want = [ref.eval(b, pb.gene_rate)["lnL"] for b in brs]
+    sub = pb.slice_patterns(0, 2000)
+    assert abs(engine_for(sub).eval(brs[0], pb.gene_rate)["lnL"] - oracle.evaluate(_with_branches(sub, brs[0]))["lnL"]) <= 1e-9 * abs(want[0])
+    for env in (None, "1"):
+        if env:
+            os.environ["PAML_AMD_NO_OFFLOAD"] = env
+        try:
+            eng = engine_for(pb)
+        finally:
+            os.environ.pop("PAML_AMD_NO_OFFLOAD", None)
+        st = torch.cuda.Stream()
+        eng.set_stream(st.cuda_stream)
+        out = torch.zeros(10, dtype=torch.float64, device="cuda")
+        for i, b in enumerate(brs):
+            eng.eval_device(b, out.data_ptr() + 8 * i, pb.gene_rate)
+        eng.flush()
+        st.synchronize()
+        assert out.cpu().numpy().tolist() == want, env
+        # another entry point after the run joins the side stream by itself
+        for i, b in enumerate(brs[:3]):
+            eng.eval_device(b, out.data_ptr() + 8 * i, pb.gene_rate)
+        assert eng.eval(brs[5], pb.gene_rate)["lnL"] == want[5]
+        assert len(eng.partial_sums()) >= 1
+        eng.close()
+
+
+def _with_branches(pb, br):
+    q = copy.copy(pb)
+    q.tree = copy.deepcopy(pb.tree)
+    q.tree.branch = np.asarray(br, dtype=np.float64).copy()
+    return q
+
+
 # ---- pattern shards over several GPUs: the engine's own exchange step (paml_amd_comm_*) ------------------------------------
 def _stage2(partials):
     """reduce_stage2's fixed-order total (pure additions: exactly reproducible on the host)."""
