@@ -159,9 +159,9 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
 
 /* Same evaluation without the final device->host copy or synchronisation: lnL (the total over the ranks when the engine has a
  * communicator) is left in d_lnL (a device pointer, e.g. a torch tensor).  Consecutive calls are pipelined: the next
- * evaluation's P(t) is built on a side stream under this one's pruning kernel, and — large problems on the matrix-core kernels,
- * or any engine with a communicator — this evaluation's reduction (and exchange step) runs on a side stream while the engine's
- * stream goes on to the next pruning kernel.  The totals of the last two calls may therefore still be on the side stream:
+ * evaluation's P(t) is built on a side stream under this one's pruning kernel, and with a communicator this evaluation's
+ * exchange step (all-reduce + fixed-order total) runs on a side stream while the engine's stream goes on to the next
+ * pruning kernel.  The totals of the last two calls may therefore still be on the side stream:
  * paml_amd_flush makes the engine's stream wait for them.  Call it once after a run of eval_device calls, before synchronising
  * the stream or reading d_lnL on it (a device-wide synchronisation covers the side stream too); every other entry point
  * of the engine does it implicitly. */

@@ -64,14 +64,19 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
       double big = 0;
       for (int r = 0; r < N - 1; r++) {
          if (tid < N / 2) {      // the rotation of pair tid of this round
-            int p = tid == 0 ? r : (r + tid) % (N - 1), q = tid == 0 ? N - 1 : (r - tid + (N - 1)) % (N - 1);
+            int p = r + tid, q = r - tid;
+            if (p >= N - 1) p -= N - 1;
+            if (q < 0) q += N - 1;
+            if (tid == 0) { p = r; q = N - 1; }
             if (p > q) { const int t = p; p = q; q = t; }
             const double apq = sA[p * EIG_LD + q];
             double c = 1, s = 0;
             if (fabs(apq) > 1e-300) {
+               // t = tan(phi) with t^2 + 2 theta t - 1 = 0, theta = (aqq - app) / (2 apq): the smaller root, written without theta
+               // (one division, one square root): t = 2 apq / (d + sgn(d) sqrt(d^2 + (2 apq)^2)), d = aqq - app
                big = fmax(big, fabs(apq));
-               const double theta = (sA[q * EIG_LD + q] - sA[p * EIG_LD + p]) / (2 * apq);
-               const double t = fabs(theta) > 1e150 ? 0.5 / theta : copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1));
+               const double d = sA[q * EIG_LD + q] - sA[p * EIG_LD + p], a2 = 2 * apq;
+               const double t = a2 / (d + copysign(sqrt(d * d + a2 * a2), d));
                c = 1 / sqrt(t * t + 1);
                s = t * c;
             }
@@ -79,36 +84,38 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
          }
          __syncthreads();
          // rows p, q of A and of R^T (lane = column), then columns p, q of A (lane = row).  A wave owns the pairs wv, wv + 4, ...
-         // (at most 8): the pairs of a round are disjoint, so all their loads are issued before the first store — one LDS
-         // round trip per phase instead of one per pair.
+         // (at most 8).  The pairs of a round are disjoint, so all their loads are issued before the first store — one LDS round
+         // trip per phase instead of one per pair; the loads are unconditional for that (a unit without a pair reads a harmless
+         // address and stores nothing).
          {
             double c[8], s[8], ap[8], aq[8], vp[8], vq[8];
             int ip[8], iq[8];
+            bool on[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-               const int k = wv + 4 * u;
-               const bool on = k < N / 2 && lane < N;
-               c[u] = on ? sC[k] : 1.0; s[u] = on ? sS[k] : 0.0;
-               ip[u] = (on ? sP[k] : 0) * EIG_LD + lane; iq[u] = (on ? sQ[k] : 0) * EIG_LD + lane;
-               if (s[u] != 0) { ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]]; vp[u] = sV[ip[u]]; vq[u] = sV[iq[u]]; }
+               const int k = wv + 4 * u, kk = k < N / 2 ? k : 0;
+               on[u] = k < N / 2 && lane < N && sS[kk] != 0;
+               c[u] = sC[kk]; s[u] = sS[kk];
+               ip[u] = sP[kk] * EIG_LD + lane; iq[u] = sQ[kk] * EIG_LD + lane;
+               ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]]; vp[u] = sV[ip[u]]; vq[u] = sV[iq[u]];
             }
 #pragma unroll
             for (int u = 0; u < 8; u++)
-               if (s[u] != 0) {
+               if (on[u]) {
                   sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u];
                   sV[ip[u]] = c[u] * vp[u] - s[u] * vq[u]; sV[iq[u]] = s[u] * vp[u] + c[u] * vq[u];
                }
             __syncthreads();
+            const int lrow = (lane < N ? lane : 0) * EIG_LD;
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-               const int k = wv + 4 * u;
-               const bool on = k < N / 2 && lane < N;
-               ip[u] = lane * EIG_LD + (on ? sP[k] : 0); iq[u] = lane * EIG_LD + (on ? sQ[k] : 0);
-               if (s[u] != 0) { ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]]; }
+               const int k = wv + 4 * u, kk = k < N / 2 ? k : 0;
+               ip[u] = lrow + sP[kk]; iq[u] = lrow + sQ[kk];
+               ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]];
             }
 #pragma unroll
             for (int u = 0; u < 8; u++)
-               if (s[u] != 0) { sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u]; }
+               if (on[u]) { sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u]; }
          }
          __syncthreads();
       }

@@ -385,13 +385,14 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // the reduction's geometry (the fused kernels form the partial sums themselves; the others leave them to reduce_stage1)
    const int chunk = e->chunk, nbg = e->nb_global;
    const int nb = (e->n_patt + chunk - 1) / chunk;
-   // Off the pruning stream: in a run of paml_amd_eval_device calls the reduction of evaluation i (mixture + log + chunk sums, the
-   // exchange step over the ranks if any, the fixed-order total) runs on the engine's side stream while the main stream goes
-   // straight on to the pruning kernel of evaluation i + 1 — two kernel boundaries and their dependency latencies leave the
-   // critical path (profiles/r03_timeline.txt: 23 us of a 0.23 ms evaluation at the 8-GPU shard size).  Two slots of (class
-   // likelihoods, partial sums, their all-reduced copy) alternate; whoever writes a slot again first waits for its ev_done.
+   // PAML_AMD_OFFLOAD=1 (experiment): in a run of paml_amd_eval_device calls the whole reduction of evaluation i (mixture + log +
+   // chunk sums, the exchange step, the fixed-order total) runs on the engine's side stream while the main stream goes straight on
+   // to the pruning kernel of evaluation i + 1, two slots of class likelihoods alternating.  Measured on MI355X at the 8-GPU shard
+   // size (profiles/r03_comm_overhead.txt): 0.2351 ms per evaluation against 0.2281 with the two small kernels left on the main
+   // stream — the event record / wait pairs that order the streams cost what the kernel boundaries they remove did.  Not the default;
+   // with a communicator only the all-reduce and the total go to the side stream.
    const bool fusedk = e->kk != KK_MFMA64 && e->use_jit && e->fused;      // the kernel forms the partial sums itself
-   const bool offload = want_pipe && !fusedk && !keep && !clean && !bs && !want_lnf && !e->tree.n_scale && !e->env.no_offload;
+   const bool offload = want_pipe && !fusedk && !keep && !clean && !bs && !want_lnf && !e->tree.n_scale && e->env.offload;
    if (!offload && !e->comm)
       if (int rc = join_comm(e)) return rc;
    const int slot = (e->comm || offload) ? e->red_slot : 0;

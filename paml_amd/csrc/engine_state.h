@@ -152,7 +152,7 @@ inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global
 // Environment switches, read once when the engine is created.
 struct EnvCfg {
    bool force_stream = false;
-   bool no_offload = false;
+   bool offload = false;
    bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false, no_m20 = false;
    int jit_waves = 0, comm_cus = -1;
    std::string jit_dump, prof_ops;
@@ -161,7 +161,7 @@ struct EnvCfg {
    void read()
    {
       no_pipeline = getenv("PAML_AMD_NO_PIPELINE") != nullptr;
-      no_offload = getenv("PAML_AMD_NO_OFFLOAD") != nullptr;      // experiments: the reduction stays on the pruning stream
+      offload = getenv("PAML_AMD_OFFLOAD") != nullptr;      // experiment (measured no faster, profiles/r03_comm_overhead.txt): the reduction of eval_device on the side stream
       force_gather = getenv("PAML_AMD_FORCE_GATHER") != nullptr;
       force_stream = getenv("PAML_AMD_FORCE_STREAM") != nullptr;      // experiments: the stream interpreter also on small data sets
       jit_sync = getenv("PAML_AMD_JIT_SYNC") != nullptr;

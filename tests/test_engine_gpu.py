@@ -753,11 +753,10 @@ def test_eval_device_pipeline_matches_in_order_evaluations():
 
 @pytest.mark.parametrize("n,K,n_patt", [(61, 2, 60000), (20, 2, 60000)])
 def test_eval_device_reduction_on_the_side_stream(n, K, n_patt):
-    """Large problems on the matrix-core kernels: in a run of eval_device calls the reduction of evaluation i (class mixture, log,
-    chunk sums, fixed-order total) runs on the engine's side stream while the main stream goes on to the pruning kernel of
-    evaluation i + 1 — two slots of class likelihoods / partial sums alternate.  Ten queued evaluations with different branch
-    lengths, paml_amd_flush, a synchronisation of the STREAM only: every value has the bits of the plain evaluation, and so it has
-    with the reduction kept on the pruning stream (PAML_AMD_NO_OFFLOAD)."""
+    """Large problems on the matrix-core kernels, runs of eval_device calls: ten queued evaluations with different branch lengths,
+    paml_amd_flush, a synchronisation of the STREAM only — every value has the bits of the plain evaluation; and so it has with the
+    reduction of evaluation i moved to the engine's side stream under the pruning kernel of evaluation i + 1 (PAML_AMD_OFFLOAD=1: two
+    slots of class likelihoods / partial sums alternate)."""
     import os
     import torch
     pb = helpers.random_problem(n, 8, n_patt, K=K, seed=77)
@@ -767,13 +766,13 @@ def test_eval_device_reduction_on_the_side_stream(n, K, n_patt):
     want = [ref.eval(b, pb.gene_rate)["lnL"] for b in brs]
     sub = pb.slice_patterns(0, 2000)
     assert abs(engine_for(sub).eval(brs[0], pb.gene_rate)["lnL"] - oracle.evaluate(_with_branches(sub, brs[0]))["lnL"]) <= 1e-9 * abs(want[0])
-    for env in (None, "1"):
+    for env in (None, "1"):      # "1": PAML_AMD_OFFLOAD, the reduction on the side stream (an experiment kept behind the switch)
         if env:
-            os.environ["PAML_AMD_NO_OFFLOAD"] = env
+            os.environ["PAML_AMD_OFFLOAD"] = env
         try:
             eng = engine_for(pb)
         finally:
-            os.environ.pop("PAML_AMD_NO_OFFLOAD", None)
+            os.environ.pop("PAML_AMD_OFFLOAD", None)
         st = torch.cuda.Stream()
         eng.set_stream(st.cuda_stream)
         out = torch.zeros(10, dtype=torch.float64, device="cuda")
