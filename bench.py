@@ -364,6 +364,12 @@ def bench_c2_batch(engine, synth, fence):
         vals = eng.eval_batch(B)
     fence()
     dt = (time.perf_counter() - t0) / reps
+    eng.profile(True)
+    for _ in range(5):
+        eng.eval_batch(B)
+    prof = eng.profile_read()
+    eng.profile(False)
+    kms = prof["ms_prune"] / max(1, prof["n_evals"])
     name = eng.kernel_name
     eng.close()
     if not np.all(np.abs(vals - base) < 1e-3 * abs(base)):
@@ -371,9 +377,11 @@ def bench_c2_batch(engine, synth, fence):
     fpp = algorithmic_flops_per_pattern(4, 32) * pb.K
     tf = fpp * pb.n_patt * len(B) / dt / 1e12
     return {"workload": "configs[1] data, %d evaluations per launch (central differences over the %d branch lengths)" % (len(B), len(idx)), "kernel": name,
-            "ms_per_batch": dt * 1e3, "ms_per_eval": dt / len(B) * 1e3, "site_patterns_per_s": pb.n_patt * len(B) / dt,
+            "ms_per_batch": dt * 1e3, "ms_per_eval": dt / len(B) * 1e3, "site_patterns_per_s": pb.n_patt * len(B) / dt, "kernel_ms": kms,
             "roofline": {"bound": "valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                         "note": "whole call incl. the host read-back of the %d values" % len(B)}}
+                         "kernel_frac": fpp * pb.n_patt * len(B) / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "note": "frac: the whole call (upload of the %d x %d branch lengths, P(t), the fused kernel, the host read-back of the %d values); "
+                                 "kernel_frac: the fused pruning + reduction kernel alone (HIP events)" % (len(B), pb.tree.n_nodes, len(B))}}
 
 
 def _latency(eng, pb, timed, fence, steps=300):

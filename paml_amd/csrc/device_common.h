@@ -75,6 +75,8 @@ struct PruneArgs {
    double *red_partial;
    double *red_out;             // [batch]
    int *red_counter;            // [batch] zeroed; non-null: the last workgroup to finish adds the partials up (one GPU)
+   int nb_local;                // chunks of this engine: a workgroup walks the chunks blockIdx.x, blockIdx.x + gridDim.x, ... (batched
+                                // evaluations run fewer, longer workgroups per element: the LDS tables are filled once per workgroup)
 };
 
 __device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)

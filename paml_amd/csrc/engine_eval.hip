@@ -433,7 +433,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       pr.want_fhk = (want_fhk || e->tree.n_scale) ? 1 : 0;
       pr.freqK = (bs && bs->freqK) ? e->d_b_freqK.p : e->d_freqK.p; pr.freqK_bs = (bs && bs->freqK) ? Km : 0;
       pr.lnf = want_lnf ? e->d_lnf.p : nullptr;
-      pr.red_partial = dpart.p; pr.red_out = lnl_out;
+      pr.red_partial = dpart.p; pr.red_out = lnl_out; pr.nb_local = nb;
       if (int rc = wait_slot()) return rc;      // (this kernel writes the partial sums itself)
       // the total: a one-block stage-2 launch (default), or PAML_AMD_TAIL=1: the workgroup that finishes last forms it (tickets)
       pr.red_counter = (e->comm || !e->env.tail) ? nullptr : e->d_red_counter.p;
@@ -478,7 +478,11 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    case KK_VALU20:
       if (fused) {
          void *params[] = {&pr};
-         HIPCHK(hipModuleLaunchKernel(e->jit.fn, nb, B, 1, e->fused_threads, 1, 1, 0, e->stream, params, nullptr));
+         // single evaluations: one workgroup per chunk; batched ones: about two resident workgroups per CU in all, each walking every
+         // gx-th chunk of its element (the LDS tables of an element's P(t) are filled once per workgroup, not once per 256 patterns)
+         int gx = nb;
+         if (B > 1 && !pr.red_counter && !e->fused_mfma4) gx = std::max(1, std::min(nb, 2 * e->n_cu / B));
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, gx, B, 1, e->fused_threads, 1, 1, 0, e->stream, params, nullptr));
       }
       else if (e->use_jit && e->m20) {      // persistent: a multiple of the class count, every workgroup keeps its class's P(t) in LDS
          void *params[] = {&pr};

@@ -534,9 +534,12 @@ inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, 
          }
       s << "   }\n   __syncthreads();\n";
    }
-   s << "   const long c_lo = (long)blockIdx.x * a.chunk, c_hi = (c_lo + a.chunk < (long)a.n_patt) ? c_lo + a.chunk : (long)a.n_patt;\n";
    s << "   const CONST_AS double *fK = as_const(a.freqK + bat * a.freqK_bs);\n";
    s << "   const CONST_AS double *pi = as_const(a.pi);\n";
+   // the workgroup's chunks: its own (gridDim.x = number of chunks: single evaluations), or every gridDim.x-th one (batched
+   // evaluations: fewer, longer workgroups per element, so that the tables above are filled once per ~100 chunks)
+   s << "   for (int cb = blockIdx.x; cb < a.nb_local; cb += gridDim.x) {\n";
+   s << "   const long c_lo = (long)cb * a.chunk, c_hi = (c_lo + a.chunk < (long)a.n_patt) ? c_lo + a.chunk : (long)a.n_patt;\n";
    s << "   double acc = 0;\n";
    s << "   for (long h0 = c_lo; h0 < c_hi; h0 += " << 256 * R << ") {\n";
    auto sfx = [&](int r) { return R > 1 ? "_" + std::to_string(r) : std::string(); };
@@ -674,8 +677,8 @@ inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, 
    if (CW > 1) s << "      __syncthreads();\n";      // sF is reused by the next sub-tile
    s << "   }\n";      // sub-tiles
    if (CW > 1) s << "   if (cw > 0) acc = 0;\n";
-   s << "   red_block_finish<" << CW << ">(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + blockIdx.x, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat * RED_TICKET_WORDS : nullptr);\n";
-   s << "}\n";
+   s << "   red_block_finish<" << CW << ">(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + cb, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat * RED_TICKET_WORDS : nullptr);\n";
+   s << "   }\n}\n";
    return s.str();
 }
 
