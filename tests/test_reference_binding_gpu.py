@@ -22,6 +22,8 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_GPU = os.path.join(REPO, "oracle", "_ref", "codeml_gpu")
 REF_CPU = os.path.join(REPO, "oracle", "_ref", "codeml")
+BASEML_GPU = os.path.join(REPO, "oracle", "_ref", "baseml_gpu")
+BASEML_CPU = os.path.join(REPO, "oracle", "_ref", "baseml")
 DATA = os.path.join(helpers.GOLDEN, "data")
 
 HIV_CTL = """seqfile = %(data)s/HIVenvSweden.txt
@@ -78,11 +80,11 @@ fix_blength = 2
 """
 
 
-def run(exe, ctl, d, env=None):
+def run(exe, ctl, d, env=None, ctl_name="codeml.ctl"):
     d.mkdir()
-    (d / "codeml.ctl").write_text(ctl % {"data": DATA})
+    (d / ctl_name).write_text(ctl % {"data": DATA})
     t0 = time.perf_counter()
-    r = subprocess.run([exe, "codeml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 20, timeout=1500, env=env)
+    r = subprocess.run([exe, ctl_name], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 20, timeout=1500, env=env)
     dt = time.perf_counter() - t0
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
@@ -122,3 +124,47 @@ def test_patched_reference_codeml_on_mhc_with_ambiguities_and_scaling_nodes(tmp_
     assert len(lnf) == g["n_patt"]
     assert np.max(np.abs(lnf - np.array(g["logf"]))) < 2e-4      # the golden's kappa, omega are these MLEs printed with 6 decimals
     print("\nMHC M0 (192 taxa, fix_blength = 2) through the reference's own ming2: %.2f s, %s lfun" % (dt, nfun))
+
+
+BASEML_CTL = """seqfile = %%(data)s/brown.nuc
+treefile = %%(data)s/brown.trees
+outfile = mlc
+noisy = 2
+verbose = 0
+runmode = 0
+model = %d
+Mgene = 0
+fix_kappa = 0
+kappa = 5
+fix_alpha = %d
+alpha = %s
+Malpha = 0
+ncatG = 5
+fix_rho = 1
+rho = 0.
+nparK = 0
+clock = 0
+nhomo = 0
+getSE = 0
+RateAncestor = 0
+Small_Diff = 7e-6
+cleandata = 1
+method = 0
+"""
+
+
+@pytest.mark.parametrize("model,fix_alpha,alpha,published", [(4, 1, "0", -2665.422858), (0, 1, "0", None), (7, 0, "0.5", None), (6, 0, "0.5", None)])
+def test_patched_reference_baseml_matches_the_unmodified_program(model, fix_alpha, alpha, published, tmp_path):
+    """integration/baseml_plfun.patch (oracle/_ref/baseml_gpu): the reference's baseml with com.plfun on the engine — HKY85 (Cijk form;
+    brown.nuc's published -2665.422858), JC69 (the closed form of PMatK80), REV + gamma and TN93 + gamma (lfundG: class rates through
+    SetPSiteClass, RootTN93 / eigenQREVbase per call) — against the unmodified program on the same control file, its own ming2 in both."""
+    if not (os.path.isfile(BASEML_GPU) and os.access(BASEML_GPU, os.X_OK)):
+        pytest.skip("oracle/_ref/baseml_gpu is not built (make -C oracle, needs /root/reference)")
+    ctl = BASEML_CTL % (model, fix_alpha, alpha)
+    lnl, lnf, _, dt, out = run(BASEML_GPU, ctl, tmp_path / "gpu", ctl_name="baseml.ctl")
+    cl, clnf, _, cdt, _ = run(BASEML_CPU, ctl, tmp_path / "cpu", ctl_name="baseml.ctl")
+    assert len(lnl) == 1 and len(cl) == 1, out[-1500:]
+    assert abs(lnl[0] - cl[0]) <= 5e-6, (lnl, cl)
+    if published is not None:
+        assert abs(lnl[0] - published) <= 5e-6
+    assert len(lnf) == len(clnf) > 20 and np.max(np.abs(lnf - clnf)) < 2e-4

@@ -7,6 +7,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 B="python $PWD/bench.py --no-cpu-baseline --no-extras"      # bench.py with its default step counts, headline only
 C2="python $PWD/tools/c2_probe.py"
+M20="python $PWD/tools/m20_probe.py"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $B > $out/bench_under_rocprof.json 2>$out/stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o f -- $B > /dev/null 2>&1
@@ -16,7 +17,6 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_IN
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c2 -o s -- $C2 > $out/c2_under_rocprof.jsonl 2>$out/stats_c2.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_c2_fetch -o f -- $C2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_c2_write -o w -- $C2 > /dev/null 2>&1
-M20="python $PWD/tools/m20_probe.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_m20 -o s -- $M20 > $out/m20_under_rocprof.txt 2>$out/stats_m20.err
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $out/pmc_m20_lds -o l -- $M20 > /dev/null 2>&1
 cd - > /dev/null
