@@ -6,8 +6,8 @@
 // States of frequency zero are left out of the eigen problem and get Root = 0 and unit rows / columns (tools.c:5040-5105).
 //
 // One workgroup (4 waves) per matrix, A and R^T in LDS, cyclic Jacobi in the parallel (round-robin tournament) order: in a round the
-// N / 2 disjoint pairs (p, q) are rotated together — the rotation angles from the 2 x 2 blocks (N / 2 lanes), then the row
-// combinations of A and R^T (lane = column: conflict-free rows of stride 65), then the column combinations of A (lane = row).
+// N / 2 disjoint pairs (p, q) are rotated together — a wave works out the angles of its 8 pairs from their 2 x 2 blocks, combines
+// their rows of A and R^T (lane = column: conflict-free rows of stride 65) and, after a barrier, their columns of A (lane = row).
 // N - 1 rounds visit every pair once (a sweep); 9-10 sweeps bring the off-diagonal part of a 61 x 61 codon matrix below
 // 1e-16 ||A|| (quadratic convergence).  Every matrix of a batch has its own workgroup: a gradient's or a line search's several
 // hundred decompositions take the time of one, ~1 ms, and U, V, Root are written straight into the engine's eigen sets — they never
@@ -29,13 +29,13 @@ struct EigenQrevArgs {
 };
 
 constexpr int EIG_LD = 65;                                           // row stride of the LDS matrices (doubles)
-constexpr size_t EIG_LDS_BYTES = (size_t)(2 * 64 * EIG_LD + 64 + 64 + 32 + 32) * sizeof(double) + 4 * 64 * sizeof(int);
+constexpr size_t EIG_LDS_BYTES = (size_t)(2 * 64 * EIG_LD + 64 + 64) * sizeof(double) + 64 * sizeof(int);
 
 __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
 {
    extern __shared__ double eig_sm[];
-   double *sA = eig_sm, *sV = sA + 64 * EIG_LD, *sSp = sV + 64 * EIG_LD, *sW = sSp + 64, *sC = sW + 64, *sS = sC + 32;
-   int *sP = (int *)(sS + 32), *sQ = sP + 64, *sRank = sQ + 64, *sFlag = sRank + 64;
+   double *sA = eig_sm, *sV = sA + 64 * EIG_LD, *sSp = sV + 64 * EIG_LD, *sW = sSp + 64;
+   int *sRank = (int *)(sW + 64);
    __shared__ double sRed[4];
    const int n = a.n, N = (n + 1) & ~1, set = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
    const double *Q = a.Q + (size_t)set * n * n, *pi = a.pi + (size_t)set * n;
@@ -59,72 +59,82 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
    __syncthreads();
    const double thr = 1e-16 * sqrt((sRed[0] + sRed[1]) + (sRed[2] + sRed[3]));
 
+   // A wave owns the pairs wv, wv + 4, ... of a round (at most 8) through all three steps, so the rotation angles never leave its
+   // registers: lanes 0-7 compute them (from the 2 x 2 blocks the previous round left in LDS), v_readlane hands them to the wave.
+   // Two barriers per round: before the rows are combined (the previous round's column pass is complete), and between the row and
+   // the column pass.
    int sweep = 0;
    for (; sweep < 40; sweep++) {
       double big = 0;
       for (int r = 0; r < N - 1; r++) {
-         if (tid < N / 2) {      // the rotation of pair tid of this round
-            int p = r + tid, q = r - tid;
-            if (p >= N - 1) p -= N - 1;
-            if (q < 0) q += N - 1;
-            if (tid == 0) { p = r; q = N - 1; }
-            if (p > q) { const int t = p; p = q; q = t; }
-            const double apq = sA[p * EIG_LD + q];
-            double c = 1, s = 0;
-            if (fabs(apq) > 1e-300) {
-               // t = tan(phi) with t^2 + 2 theta t - 1 = 0, theta = (aqq - app) / (2 apq): the smaller root, written without theta
-               // (one division, one square root): t = 2 apq / (d + sgn(d) sqrt(d^2 + (2 apq)^2)), d = aqq - app
-               big = fmax(big, fabs(apq));
-               const double d = sA[q * EIG_LD + q] - sA[p * EIG_LD + p], a2 = 2 * apq;
-               const double t = a2 / (d + copysign(sqrt(d * d + a2 * a2), d));
-               c = 1 / sqrt(t * t + 1);
-               s = t * c;
-            }
-            sP[tid] = p; sQ[tid] = q; sC[tid] = c; sS[tid] = s;
-         }
-         __syncthreads();
-         // rows p, q of A and of R^T (lane = column), then columns p, q of A (lane = row).  A wave owns the pairs wv, wv + 4, ...
-         // (at most 8).  The pairs of a round are disjoint, so all their loads are issued before the first store — one LDS round
-         // trip per phase instead of one per pair; the loads are unconditional for that (a unit without a pair reads a harmless
-         // address and stores nothing).
+         double cl = 1, sl = 0;
+         int pl = 0, ql = 0;
          {
-            double c[8], s[8], ap[8], aq[8], vp[8], vq[8];
-            int ip[8], iq[8];
-            bool on[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-               const int k = wv + 4 * u, kk = k < N / 2 ? k : 0;
-               on[u] = k < N / 2 && lane < N && sS[kk] != 0;
-               c[u] = sC[kk]; s[u] = sS[kk];
-               ip[u] = sP[kk] * EIG_LD + lane; iq[u] = sQ[kk] * EIG_LD + lane;
-               ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]]; vp[u] = sV[ip[u]]; vq[u] = sV[iq[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-               if (on[u]) {
-                  sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u];
-                  sV[ip[u]] = c[u] * vp[u] - s[u] * vq[u]; sV[iq[u]] = s[u] * vp[u] + c[u] * vq[u];
+            const int k = wv + 4 * (lane & 7);      // the pair this lane works out (lanes 8-63 repeat lanes 0-7: no divergence)
+            if (k < N / 2) {
+               int p = r + k, q = r - k;
+               if (p >= N - 1) p -= N - 1;
+               if (q < 0) q += N - 1;
+               if (k == 0) { p = r; q = N - 1; }
+               if (p > q) { const int t = p; p = q; q = t; }
+               pl = p; ql = q;
+               const double apq = sA[p * EIG_LD + q];
+               if (fabs(apq) > 1e-300) {
+                  // t = tan(phi), the smaller root of t^2 + 2 theta t - 1 = 0 with theta = (aqq - app) / (2 apq), written without theta:
+                  // t = 2 apq / (d + sgn(d) sqrt(d^2 + (2 apq)^2)), d = aqq - app.  Reciprocal and reciprocal square root from the
+                  // hardware approximations + Newton steps: t only steers the convergence (a step suffices), c = 1 / sqrt(1 + t^2)
+                  // must make the rotation orthogonal to the last bit (two steps); s = t c.
+                  big = fmax(big, fabs(apq));
+                  const double d = sA[q * EIG_LD + q] - sA[p * EIG_LD + p], a2 = 2 * apq, x = d * d + a2 * a2;
+                  double y = __builtin_amdgcn_rsq(x);
+                  y = y * (1.5 - 0.5 * x * y * y);
+                  const double den = d + copysign(x * y, d);
+                  double rc = __builtin_amdgcn_rcp(den);
+                  rc = rc * (2.0 - den * rc);
+                  const double t = a2 * rc, x1 = 1.0 + t * t;
+                  double c = __builtin_amdgcn_rsq(x1);
+                  c = c * (1.5 - 0.5 * x1 * c * c);
+                  c = c * (1.5 - 0.5 * x1 * c * c);
+                  cl = c; sl = t * c;
                }
-            __syncthreads();
-            const int lrow = (lane < N ? lane : 0) * EIG_LD;
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-               const int k = wv + 4 * u, kk = k < N / 2 ? k : 0;
-               ip[u] = lrow + sP[kk]; iq[u] = lrow + sQ[kk];
-               ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]];
             }
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-               if (on[u]) { sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u]; }
          }
+         double c[8], s[8], ap[8], aq[8], vp[8], vq[8];
+         int ip[8], iq[8], kp[8], kq[8];
+         bool on[8];
+         const int lcol = lane < N ? lane : 0;
+#pragma unroll
+         for (int u = 0; u < 8; u++) {      // rows p, q of A and of R^T: lane = column; all loads before the first store (disjoint pairs)
+            c[u] = __shfl(cl, u); s[u] = __shfl(sl, u);
+            kp[u] = __shfl(pl, u); kq[u] = __shfl(ql, u);
+            on[u] = lane < N && s[u] != 0;
+            ip[u] = kp[u] * EIG_LD + lcol; iq[u] = kq[u] * EIG_LD + lcol;
+            ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]]; vp[u] = sV[ip[u]]; vq[u] = sV[iq[u]];
+         }
+#pragma unroll
+         for (int u = 0; u < 8; u++)
+            if (on[u]) {
+               sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u];
+               sV[ip[u]] = c[u] * vp[u] - s[u] * vq[u]; sV[iq[u]] = s[u] * vp[u] + c[u] * vq[u];
+            }
+         __syncthreads();
+#pragma unroll
+         for (int u = 0; u < 8; u++) {      // columns p, q of A: lane = row
+            ip[u] = lcol * EIG_LD + kp[u]; iq[u] = lcol * EIG_LD + kq[u];
+            ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]];
+         }
+#pragma unroll
+         for (int u = 0; u < 8; u++)
+            if (on[u]) { sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u]; }
          __syncthreads();
       }
-      if (wv == 0) {      // the largest off-diagonal element this sweep met
-         for (int off = 32; off; off >>= 1) big = fmax(big, __shfl_xor(big, off));
-         if (lane == 0) sFlag[0] = big <= thr;
-      }
+      // the largest off-diagonal element this sweep met (lanes 0-7 of every wave hold their pairs')
+      for (int off = 4; off; off >>= 1) big = fmax(big, __shfl_xor(big, off));
+      if (lane == 0) sRed[wv] = big;
       __syncthreads();
-      if (sFlag[0]) { sweep++; break; }
+      const bool done = fmax(fmax(sRed[0], sRed[1]), fmax(sRed[2], sRed[3])) <= thr;
+      __syncthreads();
+      if (done) { sweep++; break; }
    }
 
    // roots descending (ties: by position), then U = R / sqrt(pi), V = R^T sqrt(pi); left-out states: unit rows / columns, Root = 0
