@@ -327,8 +327,9 @@ struct paml_amd_engine {
    {
       for (auto &e : eigen) { e.U.release(); e.V.release(); e.Root.release(); e.Cijk.release(); }
       stage.release();
+      if (sc) (void)hipStreamSynchronize(sc);      // (no collective may still be in flight when its communicator goes)
       if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
-      if (sc) { (void)hipStreamSynchronize(sc); (void)hipStreamDestroy(sc); }
+      if (sc) (void)hipStreamDestroy(sc);
       for (hipEvent_t ev : {ev_part[0], ev_part[1], ev_done[0], ev_done[1]}) if (ev) (void)hipEventDestroy(ev);
       if (h_out) (void)hipHostFree(h_out);
       if (d_prof && env.prof_tiles && prof_words) {      // the last launch's workgroup timeline
