@@ -504,7 +504,11 @@ __device__ __forceinline__ void jit_root_lds(const PruneArgs &a, const v4d (&x)[
    if (q == 0 && valid) {
       // fx_r treesub.c:7731-7749 / lfun 7782-7798: the floor here, log + scale factors in the reduction kernel
       if (f <= 0) f = (a.mode == PAML_AMD_MODE_LFUN ? 1e-80 : 1e-300);
+#ifdef JIT_NT_STORE      // experiment: the class likelihoods streamed past L2 (nothing dirty left for the end-of-kernel release)
+      __builtin_nontemporal_store(flag ? f : 0.0, a.fhK + (long)iclass * a.n_patt + h);
+#else
       a.fhK[(long)iclass * a.n_patt + h] = flag ? f : 0.0;
+#endif
       if (a.n_scale) a.fscale[(long)iclass * a.n_patt + h] = lnscale;
    }
 }

@@ -116,6 +116,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    // DMA rounds per block: a P has chunks pair * 4 + row block (< KB2 * 4 used), a tip table TCH chunks; `waves` chunks per round
    const int P_ROUNDS = (KB2 * 4 + waves - 1) / waves, T_ROUNDS = (TCH + waves - 1) / waves;
    s << "#define JIT_KB2 " << KB2 << "\n#define JIT_RB " << RB << "\n#define JIT_TCH " << TCH << "\n#define JIT_WAVES " << waves << "\n";
+   if (getenv("PAML_AMD_JIT_NT_STORE")) s << "#define JIT_NT_STORE 1\n";         // experiment: non-temporal stores of the class likelihoods
    if (getenv("PAML_AMD_JIT_ABL_NOSEED")) s << "#define JIT_ABL_NOSEED 1\n";      // timing experiment: the rank-1 seed without its LDS reads and multiplies
    if (getenv("PAML_AMD_JIT_ABL_NOBAR")) s << "#define JIT_ABL_NOBAR 1\n";      // timing experiment: no workgroup barriers (results are garbage)
    const char *abl_skew = getenv("PAML_AMD_JIT_ABL_SKEW");                       // ... and waves 4-7 start this many x 64 cycles late

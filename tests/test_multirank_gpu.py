@@ -21,6 +21,13 @@ SHIM = os.path.join(HERE, "shim", "librccl_shim.so")
 WORKER = os.path.join(HERE, "shim", "rank_worker.py")
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def shim_env():
     if not os.path.exists(SHIM):
         subprocess.check_call(["make", "-C", os.path.join(HERE, "shim")])
@@ -72,7 +79,7 @@ def test_bench_on_two_ranks_of_one_gpu(tmp_path):
     assert r1.returncode == 0, r1.stderr.decode()[-3000:]
     one = json.loads(r1.stdout.decode().strip().splitlines()[-1])
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", "29631", os.path.join(REPO, "bench.py"), "--gpus", "2"] + common, env=env, cwd=REPO,
+                         "--master-port", str(free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2"] + common, env=env, cwd=REPO,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert r2.returncode == 0, r2.stderr.decode()[-3000:]
     lines = [ln for ln in r2.stdout.decode().splitlines() if ln.startswith("{")]
