@@ -570,7 +570,7 @@ def profiles_evidence(flop_per_launch):
     ev = {}
     if flop_per_launch is None:
         return ev
-    stats = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_kernel_stats.csv")))
+    stats = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_kernel_stats.csv")))      # (the headline command's, not the probes')
     if stats:
         try:
             with open(stats[-1]) as f:
@@ -581,7 +581,7 @@ def profiles_evidence(flop_per_launch):
                                          "frac": flop_per_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
         except (OSError, KeyError, ValueError):
             pass
-    pmc = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")))
+    pmc = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc.json")))
     if pmc:
         try:
             with open(pmc[-1]) as f:
