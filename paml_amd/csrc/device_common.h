@@ -779,6 +779,30 @@ __device__ __forceinline__ void m20h_matvec2(const double *sPn, const double *sP
    for (int m = 0; m < 4; m++) { y0[m] = b0[m]; y1[m] = b1[m]; }
    y0[4] = s0; y1[4] = s1;
 }
+// the same product for ONE pattern group (the half units at the end of a workgroup's range, jit_generate_m20)
+__device__ __forceinline__ void m20h_matvec1(const double *sPn, const double *sPnext, int lane, double (&Ab)[5], const double (&x0)[5], double (&y0)[5])
+{
+   double As[5];
+   m20h_read_small(m20_lds_addr(sPn), lane, As);
+   m20_wait<5>(Ab);
+   m20_v4d b0 = {0, 0, 0, 0};
+   double s0 = 0;
+   b0 = M20_MFMA16(Ab[0], x0[0], b0);
+   b0 = M20_MFMA16(Ab[1], x0[1], b0);
+   m20_wait<0>(As);
+   s0 = M20_MFMA(As[0], x0[0], s0);
+   b0 = M20_MFMA16(Ab[2], x0[2], b0);
+   s0 = M20_MFMA(As[1], x0[1], s0);
+   b0 = M20_MFMA16(Ab[3], x0[3], b0);
+   s0 = M20_MFMA(As[2], x0[2], s0);
+   b0 = M20_MFMA16(Ab[4], x0[4], b0);
+   m20h_read_big(m20_lds_addr(sPnext), lane, Ab);
+   s0 = M20_MFMA(As[3], x0[3], s0);
+   s0 = M20_MFMA(As[4], x0[4], s0);
+#pragma unroll
+   for (int m = 0; m < 4; m++) y0[m] = b0[m];
+   y0[4] = s0;
+}
 // tip factors: row `code` of the tip's table, stored [code][st][m] (pmat_kernel layout 2) so that this lane's five states
 // 4 m + st are 40 contiguous bytes and the four lanes of a pattern read one 160-byte row
 __device__ __forceinline__ void m20_tip(const double *T, int row, int code, int st, double (&v)[5])      // row = doubles per code (20, or 21 in LDS)

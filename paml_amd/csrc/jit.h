@@ -954,7 +954,19 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    // from an LDS ticket: the two waves of a SIMD do not advance at the same pace (the older wave wins the MFMA arbitration), and
    // with fixed slots the kernel ended 20 % after its fastest waves had finished.  The first unit of a wave is its own slot; the
    // next one is drawn a unit ahead, so that its tip codes arrive while the current unit is walked.
-   s << "#define M20_FETCH_CODES(U) { int un_ = (U) < uend ? (U) : uend - 1; un_ = un_ < 0 ? 0 : un_; const int h0n = as_const(a.tiles)[un_ >> 3].y + (un_ & 7) * 32; \\\n"
+   // Work inside a workgroup is handed out per wave by an LDS ticket, in units of 32 patterns (two 16-pattern groups share every
+   // operand fetch): the two waves of a SIMD do not advance at the same pace (the older wave wins the MFMA arbitration, 7 units
+   // against 5-6), and with fixed slots the kernel ended 20 % after its fastest waves had finished.  The LAST units of a
+   // workgroup's range are handed out as half units — one 16-pattern group, a second copy of the walk without the other group's
+   // instructions: when the tickets run out a wave is at most half a unit from its end instead of a whole one
+   // (profiles/r03_20state.txt: the tail was 6 % of the span).  Ticket t < nfull: the full unit ubase + t; else the half
+   // (t - nfull) & 1 of unit ubase + nfull + (t - nfull) / 2.  A wave's first ticket is its own number; the next one is drawn a
+   // unit ahead, so that its tip codes arrive while the current unit is walked.
+   const int SPLIT = (hybrid && !getenv("PAML_AMD_M20_NOSPLIT")) ? 8 : 0;
+   s << "#define M20_UNIT_OF(T) ((T) < nfull ? ubase + (T) : ubase + nfull + (((T) - nfull) >> 1))\n";
+   s << "#define M20_HALF_OF(T) ((T) < nfull ? -1 : (((T) - nfull) & 1))\n";
+   s << "#define M20_FETCH_CODES(T) { int tn_ = (T) < nt ? (T) : nt - 1; tn_ = tn_ < 0 ? 0 : tn_; const int un_ = M20_UNIT_OF(tn_), hf_ = M20_HALF_OF(tn_); \\\n"
+        "      const int h0n = as_const(a.tiles)[un_ >> 3].y + (un_ & 7) * 32 + (hf_ > 0 ? 16 : 0); \\\n"
         "      long hn = h0n + col; if (hn >= hend) hn = hend - 1; const uint4 *zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
         "      _Pragma(\"unroll\") for (int i = 0; i < ZW / 4; i++) { const uint4 t = zp[i]; zn_0[4 * i] = t.x; zn_0[4 * i + 1] = t.y; zn_0[4 * i + 2] = t.z; zn_0[4 * i + 3] = t.w; } \\\n"
         "      hn = h0n + 16 + col; if (hn >= hend) hn = hend - 1; zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
@@ -970,21 +982,24 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    // 10^5 patterns over 64 workgroups are 48 or 49 units each, where whole tiles were 48 or 56
    s << "   const int total_units = min(a.n_tiles * 8, (hend + 31) / 32);\n";
    s << "   const int ubase = (int)((long)first * total_units / stride), uend = (int)((long)(first + 1) * total_units / stride);\n";
-   s << "   if (threadIdx.x == 0) sTicket = ubase + 8;      /* units ubase .. ubase + 7 are the waves' own first ones */\n   __syncthreads();\n";
-   s << "   int u = ubase + wv, unext = M20_TICKET();\n";
+   s << "   const int nfull = max(0, (uend - ubase) - " << SPLIT << "), nt = nfull + 2 * ((uend - ubase) - nfull);\n";
+   s << "   if (threadIdx.x == 0) sTicket = 8;      /* tickets 0 .. 7 are the waves' own first ones */\n   __syncthreads();\n";
+   s << "   int u = wv, unext = M20_TICKET();\n";
    s << "   M20_FETCH_CODES(u)\n";
-   s << "   while (u < uend) {\n";
-   s << "      const int h0 = as_const(a.tiles)[u >> 3].y + (u & 7) * 32;\n";
+   s << "   while (u < nt) {\n";
+   s << "      const int unit = M20_UNIT_OF(u), half = M20_HALF_OF(u);\n";
+   s << "      const int h0 = as_const(a.tiles)[unit >> 3].y + (unit & 7) * 32 + (half > 0 ? 16 : 0);\n";
    s << "      unsigned int zw_0[ZW], zw_1[ZW];\n";
    s << "      _Pragma(\"unroll\") for (int i = 0; i < ZW; i++) { zw_0[i] = zn_0[i]; zw_1[i] = zn_1[i]; }\n";
    s << "      M20_FETCH_CODES(unext)\n";
    s << "      const int unext2 = M20_TICKET();\n";
-   for (int g = 0; g < 2; g++) {
+   auto emit_body = [&](const int G) {      // the walk over one unit: G = 2 pattern groups, or (half units) group 0 alone
+   for (int g = 0; g < G; g++) {
       s << "      const long h_" << g << " = h0 + " << 16 * g << " + col;\n      const bool valid_" << g << " = h_" << g << " < hend;\n";
       s << "      double lnscale_" << g << " = 0;\n      (void)lnscale_" << g << ";\n";
    }
    const int NA = p.max_stack + 2;
-   for (int g = 0; g < 2; g++)
+   for (int g = 0; g < G; g++)
       for (int i = 0; i < NA; i++) s << "      double A" << i << "_" << g << "[5];\n";
    std::vector<int> freeA;
    for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
@@ -1005,7 +1020,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    auto emit_loads = [&](size_t i) {      // the rows of tip step i -> T<i>a_<g>, T<i>b_<g>
       const Op &o = p.ops[i];
       const bool two = o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2;
-      for (int g = 0; g < 2; g++) {
+      for (int g = 0; g < G; g++) {
          auto codeof = [&](int t) {
             return "(int)((zw_" + std::to_string(g) + "[" + std::to_string(t >> 2) + "] >> " + std::to_string((t & 3) * 8) + ") & 0xffu)";
          };
@@ -1042,19 +1057,19 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       }
       switch (o.code) {
       case OP_INIT_ONES:
-         for (int g = 0; g < 2; g++) s << "      " << LOOP << name(curin, g) << "[m] = 1.0;\n";
+         for (int g = 0; g < G; g++) s << "      " << LOOP << name(curin, g) << "[m] = 1.0;\n";
          break;
       case OP_SET_TIP:
-         for (int g = 0; g < 2; g++) s << "      " << LOOP << name(curin, g) << "[m] = T" << iop << "a_" << g << "[m];\n";
+         for (int g = 0; g < G; g++) s << "      " << LOOP << name(curin, g) << "[m] = T" << iop << "a_" << g << "[m];\n";
          break;
       case OP_MUL_TIP:
-         for (int g = 0; g < 2; g++) s << "      " << LOOP << name(curin, g) << "[m] *= T" << iop << "a_" << g << "[m];\n";
+         for (int g = 0; g < G; g++) s << "      " << LOOP << name(curin, g) << "[m] *= T" << iop << "a_" << g << "[m];\n";
          break;
       case OP_SET_TIP2:
-         for (int g = 0; g < 2; g++) s << "      " << LOOP << name(curin, g) << "[m] = T" << iop << "a_" << g << "[m] * T" << iop << "b_" << g << "[m];\n";
+         for (int g = 0; g < G; g++) s << "      " << LOOP << name(curin, g) << "[m] = T" << iop << "a_" << g << "[m] * T" << iop << "b_" << g << "[m];\n";
          break;
       case OP_MUL_TIP2:
-         for (int g = 0; g < 2; g++)
+         for (int g = 0; g < G; g++)
             s << "      " << LOOP << name(curin, g) << "[m] = (" << name(curin, g) << "[m] * T" << iop << "a_" << g << "[m]) * T" << iop << "b_" << g << "[m];\n";
          break;
       case OP_PUSH: slot[o.b] = cur; cur = -1; break;
@@ -1064,13 +1079,16 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
          emit_loads_after(imm, 1);
          emit_loads_after(imm + 1, 2);
          s << "      __builtin_amdgcn_sched_barrier(0);\n";
-         s << "      " << (hybrid ? "m20h_matvec2" : "m20_matvec2") << "(sP + " << imm * 400 << ", sP + " << ((imm + 1) % nmm) * 400 << ", " << (hybrid ? "lane" : "aoff") << ", Acol, " << name(curin, 0) << ", " << name(out, 0) << ", "
-           << name(curin, 1) << ", " << name(out, 1) << ");\n";
+         if (G == 2)
+            s << "      " << (hybrid ? "m20h_matvec2" : "m20_matvec2") << "(sP + " << imm * 400 << ", sP + " << ((imm + 1) % nmm) * 400 << ", " << (hybrid ? "lane" : "aoff") << ", Acol, " << name(curin, 0) << ", " << name(out, 0) << ", "
+              << name(curin, 1) << ", " << name(out, 1) << ");\n";
+         else
+            s << "      m20h_matvec1(sP + " << imm * 400 << ", sP + " << ((imm + 1) % nmm) * 400 << ", lane, Acol, " << name(curin, 0) << ", " << name(out, 0) << ");\n";
          s << "      __builtin_amdgcn_sched_barrier(0);\n";
          imm++;
          release(curin);
          if (pop >= 0) {
-            for (int g = 0; g < 2; g++) s << "      " << LOOP << name(out, g) << "[m] = " << name(slot[pop], g) << "[m] * " << name(out, g) << "[m];\n";
+            for (int g = 0; g < G; g++) s << "      " << LOOP << name(out, g) << "[m] = " << name(slot[pop], g) << "[m] * " << name(out, g) << "[m];\n";
             release(slot[pop]);
             slot[pop] = -1;
          }
@@ -1078,12 +1096,12 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
          else cur = out;
          break;
       case OP_SCALE:
-         for (int g = 0; g < 2; g++)
+         for (int g = 0; g < G; g++)
             s << "      { const double fac = m20_scale(" << name(curin, g) << "); lnscale_" << g << " += fac;\n"
               << "        if (a.keep && st == 0 && valid_" << g << ") a.scalef[((long)iclass * a.n_scale + " << o.b << ") * a.n_patt + h_" << g << "] = fac; }\n";
          break;
       case OP_ROOT:
-         for (int g = 0; g < 2; g++)
+         for (int g = 0; g < G; g++)
             s << "      m20_root(a, " << name(curin, g) << ", pis, lnscale_" << g << ", iclass, h_" << g << ", st == 0 && valid_" << g << ");\n";
          release(cur);
          cur = -1;
@@ -1091,6 +1109,15 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       default: break;
       }
    }
+   };      // emit_body
+   if (SPLIT) {
+      s << "      if (half < 0) {\n";
+      emit_body(2);
+      s << "      } else {\n";
+      emit_body(1);
+      s << "      }\n";
+   }
+   else emit_body(2);
    if (proft) s << "      if (a.prof && tid == " << pt << " && ptc < a.prof_stride - 4) { a.prof[(long)blockIdx.x * a.prof_stride + 1 + ptc] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 1] = __builtin_amdgcn_s_memtime(); }\n      ptc++;\n";
    s << "      u = unext; unext = unext2;\n";
    s << "   }\n}\n";
