@@ -255,7 +255,7 @@ int pamlh_read_seqs(pamlh *p)
          const int nsite = lsraw / n31;
          int ch, ng = 0, tot = 0;
          char *q;
-         if (readpattern) { fclose(f); free(line); return pamlh_fail(p, "option G with the P pattern format is not supported"); }
+         /* (with the P format the numbers on the G line are PATTERNS per gene, the patterns of a gene standing together: treesub.c:640-665) */
          do ch = fgetc(f); while (ch != EOF && !isalnum(ch));
          if (toupper(ch) != 'G' || fscanf(f, "%d", &ng) != 1 || ng < 1 || ng > PAMLH_MAXGENE) { fclose(f); free(line); return pamlh_fail(p, "option G: expecting 'G <number of genes (<= %d)>'", PAMLH_MAXGENE); }
          site_gene = (int *)malloc(nsite * sizeof(int));
@@ -274,6 +274,7 @@ int pamlh_read_seqs(pamlh *p)
             if (tot != nsite) { fclose(f); free(line); free(site_gene); return pamlh_fail(p, "option G: gene lengths sum to %d, not %d%s", tot, nsite, n31 == 3 ? " (gene lengths are in codons)" : ""); }
          }
          else {                                  /* one mark per site */
+            if (readpattern) { fclose(f); free(line); free(site_gene); return pamlh_fail(p, "option PG: use the number of patterns in each gene, not site marks"); }
             for (h = 0; h < nsite; h++) {
                int m;
                if (ng > 9) { if (fscanf(f, "%d", &m) != 1) m = -1; }
@@ -430,7 +431,7 @@ int pamlh_read_seqs(pamlh *p)
          p->posG[0] = 0; p->posG[1] = np; p->lgene[0] = nkeep;
          if (kg) {
             for (k = 0; k < p->ngene; k++) p->lgene[k] = 0;
-            for (h = 0; h < nkeep; h++) p->lgene[kg[h]]++;
+            for (h = 0; h < nkeep; h++) p->lgene[kg[h]] += readpattern ? (int)(cnt[keep[h]] + 0.5) : 1;      /* sites of the gene */
             for (k = 0, h = 0; k < p->ngene; k++) {
                if (!p->lgene[k]) return pamlh_fail(p, "gene %d does not have any sites", k + 1);
                p->posG[k] = h;

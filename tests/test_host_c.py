@@ -1132,6 +1132,43 @@ def test_differential_of_the_oracle_on_cpu(gname, prog, ctl, tmp_path):
     _differential(ctl, prog, 500 + sum(map(ord, ctl)), tmp_path, on_gpu=False)
 
 
+@pytest.mark.parametrize("ctl", ["horai_mg0.ctl", "horai_mg2.ctl", "horai_mg4.ctl"])
+def test_pattern_format_with_genes(ctl, tmp_path):
+    """Option G with the P format (treesub.c:640-665, 954-983: the numbers on the G line are PATTERNS per gene, the site counts follow the
+    sequences): horai.nuc's four genes written as their compressed patterns.  The host reads it to the same problem as the plain file
+    (same lnL through the oracle at a random parameter vector), and where the reference binary is here it prints that lnL for the
+    pattern file too."""
+    a = hostlib.Analysis(os.path.join(CTL, ctl), "baseml")
+    pb = a.problem(a.default_x())
+    assert pb.n_genes == 4
+    go = np.asarray(pb.gene_off)
+    with open(tmp_path / "horai_pg.nuc", "w") as f:
+        f.write("%d %d GP\nG 4 %s\n" % (pb.tree.n_tips, pb.n_patt, " ".join(str(int(go[g + 1] - go[g])) for g in range(4))))
+        for i in range(pb.tree.n_tips):
+            f.write("s%d  %s\n" % (i + 1, "".join("TCAG"[c] for c in pb.z[i])))
+        f.write(" ".join(str(int(w)) for w in pb.weights) + "\n")
+    import shutil
+    shutil.copy(os.path.join(helpers.GOLDEN, "data", "horai.trees"), tmp_path / "horai.trees")
+    text = open(os.path.join(CTL, ctl)).read().replace("../data/horai.nuc", "horai_pg.nuc").replace("../data/", "")
+    (tmp_path / "baseml.ctl").write_text(text + "\noutfile = mlb\nnoisy = 0\nverbose = 0\nrunmode = 0\ngetSE = 0\nRateAncestor = 0\n")
+    b = hostlib.Analysis(str(tmp_path / "baseml.ctl"), "baseml")
+    assert (b.n_patt, b.np, b.ls) == (a.n_patt, a.np, a.ls)
+    rng = np.random.default_rng(11)
+    lo, hi = a.bounds()
+    x = np.round(np.clip(a.default_x() * rng.uniform(0.7, 1.4, a.np), lo * 1.5, np.minimum(hi * 0.9, 50)), 6)
+    pa, pbb = a.problem(x), b.problem(x)
+    assert np.array_equal(pa.z, pbb.z) and np.array_equal(pa.weights, pbb.weights) and np.array_equal(pa.gene_off, pbb.gene_off)
+    la, lb = oracle.evaluate(pa, want_lnf=False)["lnL"], oracle.evaluate(pbb, want_lnf=False)["lnL"]
+    assert abs(la - lb) <= 1e-9 * abs(la)
+    exe = os.path.join(helpers.REPO, "oracle", "_ref", "baseml")
+    if os.access(exe, os.X_OK):
+        (tmp_path / "in.baseml").write_text("-1 " + " ".join("%.6f" % v for v in x) + "\n")
+        r = subprocess.run([exe, "baseml.ctl"], cwd=tmp_path, capture_output=True, text=True, input="\n" * 50, timeout=600)
+        m = re.findall(r"lnL\(ntime:[^\n]*?(-[0-9]+\.[0-9]+)", open(tmp_path / "mlb").read())
+        assert m, r.stdout[-2000:]
+        assert abs(lb - float(m[-1])) <= 2e-6 * max(1.0, abs(lb) / 1000), (lb, m[-1])
+
+
 @pytest.mark.parametrize("prog,ctl", [("baseml", "brown_hky85_clock.ctl"), ("baseml", "brown_hky85_clock2.ctl"), ("baseml", "hiv2_tipdate.ctl"),
                                       ("baseml", "hiv2_tipdate_clock2.ctl"), ("codeml", "lysos_m0_clock.ctl")])
 def test_differential_of_the_clock_models_on_cpu(prog, ctl, tmp_path):
