@@ -6,6 +6,9 @@ and the optimiser ming2 (tools.c:6595).  The engine is fed com.z, nChara / Chara
 from the reference's globals.  Checked: the lnL values the reference's ming2 ends at and prints — HIV NSsites 0 and 2 (-1137.688190,
 -1106.445004: examples/HIVNSsites), MHC M0 (-8225.154790: examples/MHC.Swanson2002MBE/README.txt, 192 taxa, ambiguity codes, ten
 scaling nodes) — and the per-pattern `lnf` file against the unmodified binary's on the same control file.
+codeml / baseml perturb their starting values with a clock-seeded generator (SetSeed(-1, 0) in main), so every run of the optimiser
+takes another path and ends within its convergence tolerance of the optimum, not at identical digits: lnL is compared to 2e-5 (the
+published values have six decimals), per-pattern values to 1e-3.
 Test infrastructure: nothing in the product depends on oracle/_ref."""
 import os
 import re
@@ -25,6 +28,7 @@ REF_CPU = os.path.join(REPO, "oracle", "_ref", "codeml")
 BASEML_GPU = os.path.join(REPO, "oracle", "_ref", "baseml_gpu")
 BASEML_CPU = os.path.join(REPO, "oracle", "_ref", "baseml")
 DATA = os.path.join(helpers.GOLDEN, "data")
+TOL = 2e-5      # |lnL - published|: what a run of the reference's optimiser from its randomised starting values reproduces
 
 HIV_CTL = """seqfile = %(data)s/HIVenvSweden.txt
 treefile = %(data)s/HIVenvSweden.trees
@@ -104,25 +108,25 @@ def test_patched_reference_codeml_reaches_the_published_lnl_on_hiv(tmp_path):
     need_binaries()
     lnl, lnf, nfun, dt, out = run(REF_GPU, HIV_CTL, tmp_path / "gpu")
     assert len(lnl) == 2, out[-2000:]
-    assert abs(lnl[0] - (-1137.688190)) <= 5e-6 and abs(lnl[1] - (-1106.445004)) <= 5e-6, lnl
+    assert abs(lnl[0] - (-1137.688190)) <= TOL and abs(lnl[1] - (-1106.445004)) <= TOL, lnl
     assert len(lnf) == 2 * 79                             # the lnf file holds both models' per-pattern values, one after the other
     # the unmodified program on the same control file: the same optimum, the same per-pattern values at it
     cl, clnf, cnfun, cdt, _ = run(REF_CPU, HIV_CTL, tmp_path / "cpu")
-    assert np.allclose(lnl, cl, rtol=0, atol=5e-6)
-    assert np.max(np.abs(lnf - clnf)) < 2e-4          # (two ming2 runs end within their convergence tolerance of each other)
+    assert np.allclose(lnl, cl, rtol=0, atol=2 * TOL)
+    assert np.max(np.abs(lnf - clnf)) < 1e-3          # (two ming2 runs end within their convergence tolerance of each other)
     print("\nHIV NSsites 0 2 through the reference's own ming2: engine %.2f s (%s lfun), unmodified CPU program %.2f s (%s lfun)" % (dt, nfun, cdt, cnfun))
     # PAML_AMD_OFF=1: the same binary leaves com.plfun alone (the reference's own lfun / lfundG)
     ol, _, _, _, _ = run(REF_GPU, HIV_CTL.replace("NSsites = 0 2", "NSsites = 0"), tmp_path / "off", env=dict(os.environ, PAML_AMD_OFF="1"))
-    assert abs(ol[0] - (-1137.688190)) <= 5e-6
+    assert abs(ol[0] - (-1137.688190)) <= TOL
 
 
 def test_patched_reference_codeml_on_mhc_with_ambiguities_and_scaling_nodes(tmp_path):
     need_binaries()
     lnl, lnf, nfun, dt, out = run(REF_GPU, MHC_CTL, tmp_path / "gpu")
-    assert len(lnl) == 1 and abs(lnl[0] - (-8225.154790)) <= 5e-6, (lnl, out[-1500:])
+    assert len(lnl) == 1 and abs(lnl[0] - (-8225.154790)) <= TOL, (lnl, out[-1500:])
     g = helpers.load_golden("mhc_m0_scaled")
     assert len(lnf) == g["n_patt"]
-    assert np.max(np.abs(lnf - np.array(g["logf"]))) < 2e-4      # the golden's kappa, omega are these MLEs printed with 6 decimals
+    assert np.max(np.abs(lnf - np.array(g["logf"]))) < 1e-3      # the golden's kappa, omega are these MLEs printed with 6 decimals
     print("\nMHC M0 (192 taxa, fix_blength = 2) through the reference's own ming2: %.2f s, %s lfun" % (dt, nfun))
 
 
@@ -164,7 +168,7 @@ def test_patched_reference_baseml_matches_the_unmodified_program(model, fix_alph
     lnl, lnf, _, dt, out = run(BASEML_GPU, ctl, tmp_path / "gpu", ctl_name="baseml.ctl")
     cl, clnf, _, cdt, _ = run(BASEML_CPU, ctl, tmp_path / "cpu", ctl_name="baseml.ctl")
     assert len(lnl) == 1 and len(cl) == 1, out[-1500:]
-    assert abs(lnl[0] - cl[0]) <= 5e-6, (lnl, cl)
+    assert abs(lnl[0] - cl[0]) <= 2 * TOL, (lnl, cl)
     if published is not None:
-        assert abs(lnl[0] - published) <= 5e-6
-    assert len(lnf) == len(clnf) > 20 and np.max(np.abs(lnf - clnf)) < 2e-4
+        assert abs(lnl[0] - published) <= TOL
+    assert len(lnf) == len(clnf) > 20 and np.max(np.abs(lnf - clnf)) < 1e-3
