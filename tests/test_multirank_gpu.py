@@ -90,6 +90,9 @@ def test_bench_on_two_ranks_of_one_gpu(tmp_path):
     assert [s["model"] for s in two["sweep"]] == ["M0", "M1a", "M2a", "M7", "M8"]
     assert two["weak"]["patterns_per_gpu"] == 40000 and two["weak"]["value"] > 0
     assert two["ms_per_step_readback"] > 0
+    rep = two["c5_replicas"]      # configs[4] at N > 1: one NSsites model per rank, independent replicas
+    assert sorted(m[0] for r in rep["per_rank"] for m in r["models"]) == ["M0", "M1a", "M2a", "M7", "M8"] and all(r["error"] is None for r in rep["per_rank"])
+    assert 0 < rep["seconds"] == max(r["seconds"] for r in rep["per_rank"])
 
 
 def test_pamlh_lnl_on_two_ranks_of_one_gpu(tmp_path):
