@@ -419,3 +419,39 @@ def test_plfun_seam_example_compiles_and_links(tmp_path):
         assert run.returncode == 0 and "-lnL =" in run.stdout
     else:
         assert run.returncode == 1 and "no GPU" in run.stderr
+
+
+def test_reference_binding_patches_apply_and_link():
+    """integration/{codeml,baseml}_plfun.patch against the reference sources where they lie (build container only): they apply without
+    fuzz or rejects, touch nothing outside `#ifdef PAML_AMD`, and the recipe of oracle/Makefile links the patched programs against
+    libpaml_amd.so (running them needs the GPU: tests/test_reference_binding_gpu.py)."""
+    import shutil
+    import subprocess
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref) or not shutil.which("patch"):
+        pytest.skip("the reference sources are not here")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for prog in ("codeml", "baseml"):
+        patch = os.path.join(repo, "integration", prog + "_plfun.patch")
+        r = subprocess.run(["patch", "--dry-run", "-o", "/dev/null", os.path.join(ref, prog + ".c"), patch], capture_output=True, text=True)
+        assert r.returncode == 0 and "fuzz" not in r.stdout and "FAILED" not in r.stdout, r.stdout + r.stderr
+        added = [ln[1:] for ln in open(patch) if ln.startswith("+") and not ln.startswith("+++")]
+        removed = [ln for ln in open(patch) if ln.startswith("-") and not ln.startswith("---")]
+        assert not removed, "the patch only adds lines"
+        depth, outside = 0, []
+        for ln in added:
+            t = ln.strip()
+            if t.startswith("#ifdef PAML_AMD"):
+                depth += 1
+            elif t.startswith("#endif") and depth:
+                depth -= 1
+            elif t.startswith("#else") and depth:
+                pass
+            elif depth == 0 and t:
+                outside.append(ln)
+        assert not outside, outside[:3]
+        exe = os.path.join(repo, "oracle", "_ref", prog + "_gpu")
+        assert subprocess.run(["make", "-C", os.path.join(repo, "oracle"), "_ref/" + prog + "_gpu"], capture_output=True).returncode == 0
+        assert os.access(exe, os.X_OK)
+        ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+        assert "libpaml_amd.so" in ldd and "not found" not in ldd.split("libpaml_amd.so")[1].split("\n")[0]
