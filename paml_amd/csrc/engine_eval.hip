@@ -316,7 +316,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
       e->m20 = false;
       if (e->want_m20 && !clean && jit_m20_supported(e->prog, e->n_tips, G)) {
-         int r = ensure_jit(e, "m20c" + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate_m20(e->prog, e->n_tips, e->n_codes); }, &jit_ok);
+         int r = ensure_jit(e, std::string(getenv("PAML_AMD_M20_W12") ? "m20w12c" : "m20c") + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate_m20(e->prog, e->n_tips, e->n_codes); }, &jit_ok);
          if (r) return r;
          e->m20 = jit_ok;
       }
@@ -487,7 +487,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       else if (e->use_jit && e->m20) {      // persistent: a multiple of the class count, every workgroup keeps its class's P(t) in LDS
          void *params[] = {&pr};
          const int grid = std::min(std::max(K, e->cus_for_pruning() / K * K), e->n_tiles * K);
-         HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::max(grid / K, 1) * K, 1, 1, 512, 1, 1, 0, e->stream, params, nullptr));
+         static const int m20_threads = getenv("PAML_AMD_M20_W12") ? 768 : 512;      // (experiment: jit_generate_m20)
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::max(grid / K, 1) * K, 1, 1, m20_threads, 1, 1, 0, e->stream, params, nullptr));
       }
       else if (e->use_jit) {
          void *params[] = {&pr};

@@ -908,7 +908,10 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       if (strstr(abl, "noa")) s << "#define M20_ABL_NOA 1\n";
    }
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
-   s << "extern \"C\" __global__ __launch_bounds__(512) void prune_jit(PruneArgs a)\n{\n";
+   // experiment (PAML_AMD_M20_W12=1): 12 waves per workgroup, every unit a half unit (one 16-pattern group per wave, three waves per SIMD)
+   const bool w12 = getenv("PAML_AMD_M20_W12") != nullptr;
+   const int NTH = w12 ? 768 : 512;
+   s << "extern \"C\" __global__ __launch_bounds__(" << NTH << ") void prune_jit(PruneArgs a)\n{\n";
    // tip tables: as many as fit beside the P(t) blocks go to LDS (in order of use), the others are gathered from L1 / L2
    const int tip_bytes = n_codes * 168;      // rows padded to 21 doubles in LDS: with 20, codes c and c + 8 share all their banks
    const int room = 158 * 1024 - nmm * 3200;
@@ -937,10 +940,10 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    }
    else
    for (int k = 0; k < nmm; k++)
-      s << "   for (int i = tid; i < 400; i += 512) sP[" << k * 400 << " + i] = Pall[" << (long)mm_nodes[k] * 400 << " + i];\n";
+      s << "   for (int i = tid; i < 400; i += " << NTH << ") sP[" << k * 400 << " + i] = Pall[" << (long)mm_nodes[k] * 400 << " + i];\n";
    for (int t = 0; t < n_tips; t++)
       if (lds_slot[t] >= 0)
-         s << "   for (int i = tid; i < NC * 20; i += 512) sT[" << lds_slot[t] << " * NC * 21 + (i / 20) * 21 + i % 20] = Ptip[(long)" << t << " * a.tip_words + i];\n";
+         s << "   for (int i = tid; i < NC * 20; i += " << NTH << ") sT[" << lds_slot[t] << " * NC * 21 + (i / 20) * 21 + i % 20] = Ptip[(long)" << t << " * a.tip_words + i];\n";
    s << "   __syncthreads();\n";
    s << "   const int aoff = (lane & 3) * 20 + (lane >> 4);      /* A operand: lane 16 k + 4 b + i <- P[4I + i][4K + k] */\n";
    s << "   double pis[5];\n   _Pragma(\"unroll\") for (int m = 0; m < 5; m++) pis[m] = a.pi[4 * m + st];\n";
@@ -962,7 +965,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    // (profiles/r03_20state.txt: the tail was 6 % of the span).  Ticket t < nfull: the full unit ubase + t; else the half
    // (t - nfull) & 1 of unit ubase + nfull + (t - nfull) / 2.  A wave's first ticket is its own number; the next one is drawn a
    // unit ahead, so that its tip codes arrive while the current unit is walked.
-   const int SPLIT = (hybrid && !getenv("PAML_AMD_M20_NOSPLIT")) ? 8 : 0;
+   const int SPLIT = w12 ? (1 << 20) : (hybrid && !getenv("PAML_AMD_M20_NOSPLIT")) ? 8 : 0;
    s << "#define M20_UNIT_OF(T) ((T) < nfull ? ubase + (T) : ubase + nfull + (((T) - nfull) >> 1))\n";
    s << "#define M20_HALF_OF(T) ((T) < nfull ? -1 : (((T) - nfull) & 1))\n";
    s << "#define M20_FETCH_CODES(T) { int tn_ = (T) < nt ? (T) : nt - 1; tn_ = tn_ < 0 ? 0 : tn_; const int un_ = M20_UNIT_OF(tn_), hf_ = M20_HALF_OF(tn_); \\\n"
@@ -983,7 +986,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    s << "   const int total_units = min(a.n_tiles * 8, (hend + 31) / 32);\n";
    s << "   const int ubase = (int)((long)first * total_units / stride), uend = (int)((long)(first + 1) * total_units / stride);\n";
    s << "   const int nfull = max(0, (uend - ubase) - " << SPLIT << "), nt = nfull + 2 * ((uend - ubase) - nfull);\n";
-   s << "   if (threadIdx.x == 0) sTicket = 8;      /* tickets 0 .. 7 are the waves' own first ones */\n   __syncthreads();\n";
+   s << "   if (threadIdx.x == 0) sTicket = " << NTH / 64 << ";      /* the first tickets are the waves' own */\n   __syncthreads();\n";
    s << "   int u = wv, unext = M20_TICKET();\n";
    s << "   M20_FETCH_CODES(u)\n";
    s << "   while (u < nt) {\n";
@@ -1110,7 +1113,8 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       }
    }
    };      // emit_body
-   if (SPLIT) {
+   if (w12) emit_body(1);
+   else if (SPLIT) {
       s << "      if (half < 0) {\n";
       emit_body(2);
       s << "      } else {\n";
