@@ -373,6 +373,20 @@ def test_valu_jit_source_compiles_for_gfx950(lib_path, n_states):
     assert src.count("jv_scale<N>") == int(pb.scale_node.sum())
 
 
+@pytest.mark.parametrize("n_tips", [6, 16, 32])
+def test_m20_jit_source_compiles_for_gfx950(lib_path, n_tips):
+    """The 20-state matrix-core kernel (jit_generate_m20) is generated and hiprtc-compiled without a GPU: the walk over a unit appears
+    twice — two pattern groups sharing every operand fetch, and the single-group copy the last units of a workgroup's range run as half
+    units — with one product per internal branch in each."""
+    from paml_amd.problem import balanced_tree
+    t = balanced_tree(n_tips)
+    src = engine.debug_jit(t, compile=True, n_states=20, fused=(4, 20))
+    n_mm = n_tips - 3
+    assert src.count("m20h_matvec2(") == n_mm and src.count("m20h_matvec1(") == n_mm
+    assert "M20_HALF_OF" in src and "if (half < 0) {" in src
+    assert src.count("m20_root(") == 3      # two groups + the single-group copy
+
+
 def test_product_paths_fail_loudly_without_a_gpu(lib_path):
     """No CPU fallback anywhere in the product: on a host without a HIP device (this test's container) engine creation, the C
     host's evaluation and the device pattern compression all return an error instead of computing something else."""
