@@ -68,7 +68,7 @@ int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id12
    if (e->comm)
       if (int rc = ensure_side_stream(e)) return rc;
    if (e->sc) HIPCHK(hipStreamSynchronize(e->sc));
-   e->done_pending[0] = e->done_pending[1] = false;
+   for (bool &b : e->done_pending) b = false;
    e->red_slot = e->last_slot = 0;
    e->rank = rank; e->world = world;
    e->n_patt_global = n_patt_global; e->first_patt = first_pattern;
@@ -76,7 +76,7 @@ int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id12
    e->nb_global = (int)((n_patt_global + chunk - 1) / chunk);
    e->first_chunk = (int)(first_pattern / chunk);
    e->d_partial.release();      // re-zeroed at their new size by the next evaluations
-   e->d_partial1.release();
+   for (auto &b : e->d_partial_s) b.release();
    return 0;
 }
 
@@ -92,7 +92,7 @@ int paml_amd_comm_destroy(paml_amd_engine *e)
    e->rank = 0; e->world = 1; e->n_patt_global = e->n_patt; e->first_patt = 0;
    e->chunk = red_chunk(e->n_patt); e->nb_global = (e->n_patt + e->chunk - 1) / e->chunk; e->first_chunk = 0;
    e->d_partial.release();
-   e->d_partial1.release();
+   for (auto &b : e->d_partial_s) b.release();
    return 0;
 }
 

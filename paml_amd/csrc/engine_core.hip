@@ -20,6 +20,7 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    e->flags = flags;
    e->env.read();
    if (e->env.comm_cus >= 0) e->comm_cus = e->env.comm_cus;
+   if (e->env.lanes) e->n_lanes = std::min(std::max(e->env.lanes, 2), (int)paml_amd_engine::MAXL);
    if (hipGetDevice(&e->device) != hipSuccess ||
        hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || e->n_cu < 1) {
       delete e;
@@ -57,10 +58,16 @@ void paml_amd_destroy(paml_amd_engine *e)
    if (!e) return;
    (void)hipStreamSynchronize(e->stream);
    if (e->jit_job && e->jit_job->th.joinable()) e->jit_job->th.join();
+   for (hipStream_t s : e->sb)
+      if (s) {
+         (void)hipStreamSynchronize(s);
+         (void)hipStreamDestroy(s);
+      }
    if (e->s2) {
       (void)hipStreamSynchronize(e->s2);
       (void)hipStreamDestroy(e->s2);
       for (hipEvent_t ev : {e->ev_entry[0], e->ev_entry[1], e->ev_pmat}) if (ev) (void)hipEventDestroy(ev);
+      for (hipEvent_t ev : e->ev_setread) if (ev) (void)hipEventDestroy(ev);
    }
    delete e;
 }
@@ -482,6 +489,7 @@ int paml_amd_get_scale(paml_amd_engine *e, int node, int iclass, double *scale)
 int paml_amd_profile(paml_amd_engine *e, int enable)
 {
    if (!e) return PAML_AMD_EINVAL;
+   enter(e);      // (a run of eval_device calls ends here: the per-kernel events are taken on the engine's stream, one evaluation at a time)
    e->profiling = enable != 0;
    return 0;
 }

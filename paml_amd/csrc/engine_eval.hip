@@ -124,8 +124,19 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    //  >= 10^5 pattern-classes)
    want_pipe = want_pipe && (e->kk == KK_MFMA64 || (e->kk == KK_VALU20 && e->want_m20)) && (long)e->n_patt * e->K >= 100000;
    const bool pipe = want_pipe && e->pipe_ok && !bs && !clean && !keep && !new_prog && !e->eigen_dirty && !e->env.no_pipeline;
+   // Two pruning streams (paml_amd_engine::sb): from the second evaluation of such a run on, the evaluations alternate between the
+   // engine's stream and `sb`, so that the persistent workgroups of evaluation i + 1 take the CUs as those of evaluation i leave
+   // them — no kernel boundary, reduction or half-empty last round of tiles between two pruning kernels.  lane = reduction slot.
+   const bool dual = pipe && e->dual_ok && !e->profiling;
+   const int lane = dual ? e->red_slot : 0;
+   if (dual && lane && !e->sb[lane - 1]) HIPCHK(create_engine_stream(&e->sb[lane - 1]));
+   if (dual)
+      if (int rc = ensure_side_stream(e)) return rc;
+   hipStream_t const ms = lane ? e->sb[lane - 1] : e->stream;      // the stream of this evaluation's pruning kernel and partial sums
    if (want_pipe && !e->s2) {
-      HIPCHK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
+      for (hipEvent_t &ev : e->ev_setread) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      for (int i = 0; i < paml_amd_engine::NPSET - 1; i++) e->spare[i].id = i + 1;
+      HIPCHK(create_engine_stream(&e->s2));
       HIPCHK(hipEventCreateWithFlags(&e->ev_entry[0], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&e->ev_entry[1], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&e->ev_pmat, hipEventDisableTiming));
@@ -135,8 +146,14 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       // the side stream may overwrite the other P set once everything the main stream held in front of the PREVIOUS pruning
       // kernel is done: that set's last reader (the kernel before it), and the previous evaluation's own uploads and P(t)
       ps = e->s2;
-      if (e->have_prev_entry) HIPCHK(hipStreamWaitEvent(e->s2, e->ev_entry[e->entry_sel ^ 1], 0));
+      // (two pruning streams: only the run's first such evaluation — the uploads in front of the run; after that the side stream
+      //  waits for nothing but the last reader of the set it is about to overwrite, four evaluations back)
+      if (e->have_prev_entry && !(dual && e->dual_run)) HIPCHK(hipStreamWaitEvent(e->s2, e->ev_entry[e->entry_sel ^ 1], 0));
+      const int nid = e->spare[e->spare_head].id;
+      if (dual && e->setread_rec[nid]) HIPCHK(hipStreamWaitEvent(e->s2, e->ev_setread[nid], 0));
    }
+   const bool skip_entry = dual && e->dual_run;      // (nothing waits for this evaluation's entry event)
+   e->dual_run = dual;
    std::vector<EigenDev> tab;
    if (e->eigen_dirty) {
       tab.resize(e->eigen.size());
@@ -215,7 +232,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
 
    // P(t) storage (pipelined: the set the previous evaluation did not use)
    if (pipe) {
-      std::swap(e->d_rowmajor, e->d2_rowmajor); std::swap(e->d_pint, e->d2_pint); std::swap(e->d_ptip, e->d2_ptip); std::swap(e->d_pcol, e->d2_pcol);
+      paml_amd_engine::PSet &sp = e->spare[e->spare_head];      // the set used longest ago
+      std::swap(e->d_rowmajor, sp.rowmajor); std::swap(e->d_pint, sp.pint); std::swap(e->d_ptip, sp.ptip); std::swap(e->d_pcol, sp.pcol);
+      std::swap(e->pset, sp.id);
+      e->spare_head = (e->spare_head + 1) % (paml_amd_engine::NPSET - 1);
    }
    HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
    if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
@@ -359,10 +379,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    mark_on(e, ps);
    if (pipe) {      // the pruning kernel (main stream) starts when this P(t) is there
       HIPCHK(hipEventRecord(e->ev_pmat, e->s2));
-      HIPCHK(hipStreamWaitEvent(e->stream, e->ev_pmat, 0));
+      HIPCHK(hipStreamWaitEvent(ms, e->ev_pmat, 0));
    }
-   if (want_pipe) {      // "everything on the main stream in front of this pruning kernel": what the next pipelined evaluation waits for
-      HIPCHK(hipEventRecord(e->ev_entry[e->entry_sel], e->stream));
+   if (want_pipe && !skip_entry) {      // "everything on the main stream in front of this pruning kernel": what the next pipelined evaluation waits for
+      HIPCHK(hipEventRecord(e->ev_entry[e->entry_sel], ms));
       e->entry_sel ^= 1;
       e->have_prev_entry = true;
    }
@@ -393,25 +413,26 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // with a communicator only the all-reduce and the total go to the side stream.
    const bool fusedk = e->kk != KK_MFMA64 && e->use_jit && e->fused;      // the kernel forms the partial sums itself
    const bool offload = want_pipe && !fusedk && !keep && !clean && !bs && !want_lnf && !e->tree.n_scale && e->env.offload;
-   if (!offload && !e->comm)
+   const bool side_total = e->comm || dual;      // the (all-reduce and the) fixed-order total on the side stream `sc`
+   if (!offload && !side_total)
       if (int rc = join_comm(e)) return rc;
-   const int slot = (e->comm || offload) ? e->red_slot : 0;
+   const int slot = (side_total || offload) ? e->red_slot : 0;
    DevBuf<double> &dpart = e->part_slot(slot);
    if ((size_t)nbg * B > dpart.cap) {
       if (e->sc) HIPCHK(hipStreamSynchronize(e->sc));      // (reallocation: nothing may still be reading the old buffer)
       HIPCHK(dpart.ensure((size_t)nbg * B));
-      HIPCHK(hipMemsetAsync(dpart.p, 0, dpart.cap * sizeof(double), e->stream));
+      HIPCHK(hipMemsetAsync(dpart.p, 0, dpart.cap * sizeof(double), ms));
    }
-   DevBuf<double> &dfhk = (offload && slot) ? e->d_fhK1 : e->d_fhK;
-   if (offload && slot) HIPCHK(dfhk.ensure((size_t)K * e->n_patt));
+   DevBuf<double> &dfhk = e->fhk_slot((offload || dual) ? slot : 0);
+   if ((offload || dual) && slot) HIPCHK(dfhk.ensure((size_t)K * e->n_patt));
    pr.fhK = dfhk.p;
    bool slot_waited = false;
    auto wait_slot = [&]() -> int {      // main stream: the reduction that last read this slot (two evaluations ago) is done
       if (slot_waited) return 0;
       slot_waited = true;
-      if ((e->comm || offload) && e->done_pending[slot]) {
+      if ((side_total || offload) && e->done_pending[slot]) {
          e->done_pending[slot] = false;
-         HIPCHK(hipStreamWaitEvent(e->stream, e->ev_done[slot], 0));
+         HIPCHK(hipStreamWaitEvent(ms, e->ev_done[slot], 0));
       }
       return 0;
    };
@@ -421,7 +442,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    }
    if ((size_t)B * RED_TICKET_WORDS > e->d_red_counter.cap) {
       HIPCHK(e->d_red_counter.ensure((size_t)std::max(B, 64) * RED_TICKET_WORDS));
-      HIPCHK(hipMemsetAsync(e->d_red_counter.p, 0, e->d_red_counter.cap * sizeof(int), e->stream));
+      HIPCHK(hipMemsetAsync(e->d_red_counter.p, 0, e->d_red_counter.cap * sizeof(int), ms));
    }
    HIPCHK(e->d_out.ensure(B));
    if (want_lnf) HIPCHK(e->d_lnf.ensure((size_t)B * e->n_patt));
@@ -446,21 +467,24 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       if (!e->env.prof_tiles || words != e->prof_words) {
          if (e->d_prof) (void)hipFree(e->d_prof);
          e->d_prof = nullptr;
-         HIPCHK(hipMalloc((void **)&e->d_prof, words * 8));
-         HIPCHK(hipMemsetAsync(e->d_prof, 0, words * 8, e->stream));
+         HIPCHK(hipMalloc((void **)&e->d_prof, paml_amd_engine::MAXL * words * 8));      // (pruning streams: one timeline per lane)
+         HIPCHK(hipMemsetAsync(e->d_prof, 0, paml_amd_engine::MAXL * words * 8, ms));
          e->prof_words = words; e->prof_blocks = n_blocks; e->prof_stride = prof_stride;
       }
-      pr.prof = e->d_prof;
+      pr.prof = e->d_prof + (size_t)lane * words;
       pr.prof_stride = prof_stride;
       pr.prof_tid = e->env.prof_tid;
    }
    mark(e);
+   // CUs of the persistent kernels: a few stay free for the small kernels beside them (the collective; with two pruning streams
+   // the reduction and the next P(t), which would otherwise queue behind the next evaluation's persistent workgroups)
+   const int cus = (e->comm || (want_pipe && e->env.dual)) ? std::max(1, e->n_cu - e->comm_cus) : e->n_cu;
    switch (e->kk) {
    case KK_MFMA64:
       if (e->use_jit) {
          void *params[] = {&pr};
-         const int grid = std::min(n_blocks, e->cus_for_pruning());     // persistent: one 130 KB-LDS workgroup per CU walks the tiles
-         HIPCHK(hipModuleLaunchKernel(e->jit.fn, grid, 1, 1, e->mfma_waves * 64, 1, 1, 0, e->stream, params, nullptr));
+         const int grid = std::min(n_blocks, cus);     // persistent: one 130 KB-LDS workgroup per CU walks the tiles
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, grid, 1, 1, e->mfma_waves * 64, 1, 1, 0, ms, params, nullptr));
       }
       else if (use_dma) {
          const size_t lds = (size_t)4 * 4096 * sizeof(double) + (size_t)e->n_tips * 128;
@@ -468,10 +492,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
             HIPCHK(hipFuncSetAttribute((const void *)prune_mfma64_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             e->stream_attr_set = true;
          }
-         hipLaunchKernelGGL(prune_mfma64_stream, dim3(n_blocks), dim3(512), lds, e->stream, pr);
+         hipLaunchKernelGGL(prune_mfma64_stream, dim3(n_blocks), dim3(512), lds, ms, pr);
       }
       else
-         hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, e->stream, pr);
+         hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, ms, pr);
       break;
    case KK_VALU4:
    case KK_VALU5:
@@ -482,27 +506,31 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          // gx-th chunk of its element (the LDS tables of an element's P(t) are filled once per workgroup, not once per 256 patterns)
          int gx = nb;
          if (B > 1 && !pr.red_counter && !e->fused_mfma4) gx = std::max(1, std::min(nb, 2 * e->n_cu / B));
-         HIPCHK(hipModuleLaunchKernel(e->jit.fn, gx, B, 1, e->fused_threads, 1, 1, 0, e->stream, params, nullptr));
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, gx, B, 1, e->fused_threads, 1, 1, 0, ms, params, nullptr));
       }
       else if (e->use_jit && e->m20) {      // persistent: a multiple of the class count, every workgroup keeps its class's P(t) in LDS
          void *params[] = {&pr};
-         const int grid = std::min(std::max(K, e->cus_for_pruning() / K * K), e->n_tiles * K);
+         const int grid = std::min(std::max(K, cus / K * K), e->n_tiles * K);
          static const int m20_threads = getenv("PAML_AMD_M20_W12") ? 768 : 512;      // (experiment: jit_generate_m20)
-         HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::max(grid / K, 1) * K, 1, 1, m20_threads, 1, 1, 0, e->stream, params, nullptr));
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::max(grid / K, 1) * K, 1, 1, m20_threads, 1, 1, 0, ms, params, nullptr));
       }
       else if (e->use_jit) {
          void *params[] = {&pr};
-         HIPCHK(hipModuleLaunchKernel(e->jit.fn, n_blocks, 1, 1, 256, 1, 1, 0, e->stream, params, nullptr));
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, n_blocks, 1, 1, 256, 1, 1, 0, ms, params, nullptr));
       }
       else
-         launch_valu(e, e->prog.max_stack, n_blocks, pr, e->stream);
+         launch_valu(e, e->prog.max_stack, n_blocks, pr, ms);
       break;
    }
    mark(e);
+   if (want_pipe && e->env.dual) {      // this P set's last reader so far
+      HIPCHK(hipEventRecord(e->ev_setread[e->pset], ms));
+      e->setread_rec[e->pset] = true;
+   }
    if (pr.prof && !e->env.prof_tiles) {
       std::vector<unsigned long long> hp((size_t)3 * n_blocks * prof_stride);
-      HIPCHK(hipMemcpyAsync(hp.data(), e->d_prof, hp.size() * 8, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
+      HIPCHK(hipMemcpyAsync(hp.data(), e->d_prof, hp.size() * 8, hipMemcpyDeviceToHost, ms));
+      HIPCHK(hipStreamSynchronize(ms));
       FILE *f = fopen(e->env.prof_ops.c_str(), "wb");
       if (f) {
          int hdr[2] = {n_blocks, prof_stride};
@@ -528,41 +556,43 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    ra.first_chunk = e->first_chunk; ra.nb_stride = nbg;
    // (measured on MI355X, 32 taxa x 10^5 nucleotide patterns: 28.2 us per evaluation with the separate one-block launch against
    //  30.2 with tickets — the agent-scope store + two atomics + coherent reads cross the XCDs' L2s and cost more than a launch)
-   const bool tail = !e->comm && !offload && e->env.tail;
+   const bool tail = !side_total && !offload && e->env.tail;
    ra.counter = tail ? e->d_red_counter.p : nullptr;
    if (bs && bs->freqK) { ra.freqK = e->d_b_freqK.p; ra.freqK_bs = Km; }
-   hipStream_t rs = e->stream;      // the stream of the reduction
+   hipStream_t rs = ms;      // the stream of the reduction
    if (offload) {
-      HIPCHK(hipEventRecord(e->ev_part[slot], e->stream));
+      HIPCHK(hipEventRecord(e->ev_part[slot], ms));
       HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[slot], 0));
       rs = e->sc;
    }
    mark_on(e, rs);
    if (int rc = wait_slot()) return rc;
    if (!fused) hipLaunchKernelGGL(reduce_stage1, dim3(nb, B), dim3(256), 0, rs, ra);
-   if (e->comm) {
+   if (side_total) {
       // the exchange step, off the pruning stream: the side stream takes over when this evaluation's partial sums are there
       // (ev_part), all-reduces them into the slot's second buffer and forms the fixed-order total; the next evaluation's P(t) and
       // pruning kernel follow on the main stream without waiting for any of it
-      DevBuf<double> &dtot = e->tot_slot(slot);
-      if ((size_t)nbg * B > dtot.cap) {
+      DevBuf<double> &dtot = e->comm ? e->tot_slot(slot) : dpart;      // (one GPU, two pruning streams: only the total moves to `sc`)
+      if (e->comm && (size_t)nbg * B > dtot.cap) {
          HIPCHK(hipStreamSynchronize(e->sc));
          HIPCHK(dtot.ensure((size_t)nbg * B));
       }
       if (!offload) {
-         HIPCHK(hipEventRecord(e->ev_part[slot], e->stream));
+         HIPCHK(hipEventRecord(e->ev_part[slot], ms));
          HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[slot], 0));
       }
-      const ncclResult_t nr = rccl().AllReduce(dpart.p, dtot.p, (size_t)nbg * B, ncclDouble, ncclSum, e->comm, e->sc);
-      if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
+      if (e->comm) {
+         const ncclResult_t nr = rccl().AllReduce(dpart.p, dtot.p, (size_t)nbg * B, ncclDouble, ncclSum, e->comm, e->sc);
+         if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
+      }
       hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->sc, (const double *)dtot.p, nbg, ra.out);
    }
    else if (!tail && nbg > 1) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, rs, (const double *)dpart.p, nbg, ra.out);      // (one block per element: stage 1 wrote the total)
-   if (e->comm || offload) {
+   if (side_total || offload) {
       HIPCHK(hipEventRecord(e->ev_done[slot], e->sc));
       e->done_pending[slot] = true;
       e->last_slot = slot;
-      e->red_slot = slot ^ 1;
+      e->red_slot = (slot + 1) % e->n_lanes;
    }
    mark_on(e, rs);
    HIPCHK(hipGetLastError());
@@ -571,6 +601,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    if (keep && !clean) e->partials_valid = true;
    e->pmat_valid = true;
    e->pipe_ok = want_pipe;      // (every other entry point clears it)
+   // two pruning streams from the next call on: persistent kernels only (they are what holds every CU to its end), nothing shared
+   // between consecutive evaluations but the two slots (class likelihoods, partial sums, P sets)
+   e->dual_ok = want_pipe && e->env.dual && !e->env.offload && e->use_jit && (e->kk == KK_MFMA64 || (e->kk == KK_VALU20 && e->m20)) && !overflow &&
+                !e->tree.n_scale && !keep && !clean && !bs && !want_lnf && nbg > 1 && (e->env.prof_ops.empty() || e->env.prof_tiles);
    return 0;
 }
 

@@ -153,8 +153,9 @@ inline int red_chunk(long n_global) { return (int)std::max<long>(256, ((n_global
 struct EnvCfg {
    bool force_stream = false;
    bool offload = false;
+   bool dual = true;
    bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false, no_m20 = false;
-   int jit_waves = 0, comm_cus = -1;
+   int jit_waves = 0, comm_cus = -1, lanes = 0;
    std::string jit_dump, prof_ops;
    int prof_tid = 0;
    bool prof_tiles = false;      // the dump is a workgroup timeline (jit.h proft) instead of per-op stamps
@@ -162,6 +163,7 @@ struct EnvCfg {
    {
       no_pipeline = getenv("PAML_AMD_NO_PIPELINE") != nullptr;
       offload = getenv("PAML_AMD_OFFLOAD") != nullptr;      // experiment (measured no faster, profiles/r03_comm_overhead.txt): the reduction of eval_device on the side stream
+      if (const char *v = getenv("PAML_AMD_DUAL")) dual = atoi(v) != 0;      // 0: one pruning stream (consecutive evaluations' kernels never overlap)
       force_gather = getenv("PAML_AMD_FORCE_GATHER") != nullptr;
       force_stream = getenv("PAML_AMD_FORCE_STREAM") != nullptr;      // experiments: the stream interpreter also on small data sets
       jit_sync = getenv("PAML_AMD_JIT_SYNC") != nullptr;
@@ -172,6 +174,7 @@ struct EnvCfg {
       no_m20 = getenv("PAML_AMD_NO_M20") != nullptr;
       tail = getenv("PAML_AMD_TAIL") != nullptr;
       if (const char *v = getenv("PAML_AMD_COMM_CUS")) comm_cus = atoi(v);
+      if (const char *v = getenv("PAML_AMD_LANES")) lanes = atoi(v);      // evaluations of a run in flight at once (2 .. 4; default 2: three measured 5 % slower, four 25 %)
       if (const char *v = getenv("PAML_AMD_JIT_WAVES")) jit_waves = atoi(v);        // experiment: the last workgroup forms the total instead of a stage-2 launch
       if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
       if (const char *v = getenv("PAML_AMD_PROF_OPS")) prof_ops = v;
@@ -212,18 +215,20 @@ struct paml_amd_engine {
    // evaluations later) waits for ev_done[b].  The caller's stream is joined to the outstanding totals by paml_amd_flush and by
    // every entry point other than paml_amd_eval_device (join_comm).
    hipStream_t sc = nullptr;
-   hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-   bool done_pending[2] = {false, false};
+   static constexpr int MAXL = 4;     // slots of (class likelihoods, partial sums, all-reduced copy): the evaluations in flight
+   int n_lanes = 2;                   // ... in use (PAML_AMD_LANES), taken in rotation
+   hipEvent_t ev_part[MAXL] = {}, ev_done[MAXL] = {};
+   bool done_pending[MAXL] = {};
    int red_slot = 0, last_slot = 0;
    // CUs the persistent pruning kernels leave free while the engine has a communicator: their workgroups fill a CU (two waves
    // per SIMD at 256 VGPRs, 130 KB of LDS), so the collective's workgroups would otherwise wait for the kernel's tail — or, when
    // they win the race for a CU at its start, hold back one pruning workgroup for as long as the all-reduce waits for its peers.
    // Free at the benchmark's sizes: 10^6 / N patterns in 128-pattern tiles take 31 / 16 / 8 / 4 rounds on 254 CUs as on 256.
    int comm_cus = 2;
-   int cus_for_pruning() const { return comm ? std::max(1, n_cu - comm_cus) : n_cu; }
-   DevBuf<double> d_partial1, d_partial_tot1, d_fhK1;
-   DevBuf<double> &part_slot(int b) { return b ? d_partial1 : d_partial; }
-   DevBuf<double> &tot_slot(int b) { return b ? d_partial_tot1 : d_partial_tot; }
+   DevBuf<double> d_partial_s[MAXL - 1], d_partial_tot_s[MAXL - 1], d_fhK_s[MAXL - 1];      // slots 1 .. (slot 0: d_partial, d_partial_tot, d_fhK)
+   DevBuf<double> &part_slot(int b) { return b ? d_partial_s[b - 1] : d_partial; }
+   DevBuf<double> &tot_slot(int b) { return b ? d_partial_tot_s[b - 1] : d_partial_tot; }
+   DevBuf<double> &fhk_slot(int b) { return b ? d_fhK_s[b - 1] : d_fhK; }
    DevBuf<unsigned int> d_zpm;        // fused 4 / 5-state kernel: tip codes pattern-major
    int zpm_words = 0;
    DevBuf<int> d_red_counter;         // "last workgroup adds up the partial sums" tickets, one per batch element
@@ -280,7 +285,25 @@ struct paml_amd_engine {
    hipEvent_t ev_entry[2] = {nullptr, nullptr}, ev_pmat = nullptr;
    int entry_sel = 0;
    bool have_prev_entry = false;
-   DevBuf<double> d2_rowmajor, d2_pint, d2_ptip, d2_pcol, d2_branch, d2_gene_rate;
+   // P(t) storage of the runs of eval_device calls: NPSET sets in rotation (the current one in d_rowmajor / d_pint / d_ptip / d_pcol,
+   // the others in `spare`, oldest first from spare_head), so that the side stream can build the P(t) of the evaluations to come
+   // while several pruning kernels are in flight (pruning streams, below) — it only has the CUs those leave it.
+   static constexpr int NPSET = 6;
+   struct PSet { DevBuf<double> rowmajor, pint, ptip, pcol; int id = 0; } spare[NPSET - 1];
+   int spare_head = 0;
+   DevBuf<double> d2_branch, d2_gene_rate;
+   // The persistent pruning kernels (per-tree MFMA kernel, 20-state matrix-core kernel) hold every CU until their last round of
+   // tiles, which is rarely full, and a kernel boundary + the two reduction kernels + their stream events (~20-25 us) sit between
+   // two of them on one stream.  From the second eval_device of a run on, the evaluations therefore ALTERNATE between the engine's
+   // stream and a second pruning stream `sb` (lane = reduction slot: its own class likelihoods and partial sums, the total on
+   // `sc`): the workgroups of evaluation i + 1 are queued while evaluation i runs and take each CU the moment it is released.
+   // Same kernels, same arguments, same bits; PAML_AMD_DUAL=0 goes back to one stream.  ev_setread[s]: the last pruning kernel
+   // that read P set s so far (all the side stream waits for before it overwrites the set: P(t) runs up to two evaluations ahead).
+   hipStream_t sb[MAXL - 1] = {};      // pruning streams of lanes 1 .. (lane 0: the engine's stream)
+   hipEvent_t ev_setread[NPSET] = {};
+   bool setread_rec[NPSET] = {};
+   int pset = 0;                 // id of the current P set (spare[].id: of the others)
+   bool dual_ok = false, dual_run = false;      // dual_run: the run's first two-stream evaluation (which still waits for the run's uploads) is behind us
    bool jit_forced = false;  // asked for by flag / environment (as opposed to switched on by the problem's size)
    // a large tree's kernel takes many seconds to compile: that happens on a worker thread while the interpreter kernels
    // serve the evaluations, and the engine changes over when the code object is there
@@ -330,12 +353,15 @@ struct paml_amd_engine {
       if (sc) (void)hipStreamSynchronize(sc);      // (no collective may still be in flight when its communicator goes)
       if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
       if (sc) (void)hipStreamDestroy(sc);
-      for (hipEvent_t ev : {ev_part[0], ev_part[1], ev_done[0], ev_done[1]}) if (ev) (void)hipEventDestroy(ev);
+      for (int b = 0; b < MAXL; b++) {
+         if (ev_part[b]) (void)hipEventDestroy(ev_part[b]);
+         if (ev_done[b]) (void)hipEventDestroy(ev_done[b]);
+      }
       if (h_out) (void)hipHostFree(h_out);
-      if (d_prof && env.prof_tiles && prof_words) {      // the last launch's workgroup timeline
+      for (int ln = 0; ln < MAXL && d_prof && env.prof_tiles && prof_words; ln++) {      // the last launch's workgroup timeline (of each pruning stream: <dump>, <dump>.1 ..)
          std::vector<unsigned long long> hp(prof_words);
-         if (hipMemcpy(hp.data(), d_prof, prof_words * 8, hipMemcpyDeviceToHost) == hipSuccess)
-            if (FILE *f = fopen(env.prof_ops.c_str(), "wb")) {
+         if (hipMemcpy(hp.data(), d_prof + (size_t)ln * prof_words, prof_words * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = fopen((env.prof_ops + (ln ? "." + std::to_string(ln) : std::string())).c_str(), "wb")) {
                const int hdr[2] = {prof_blocks, prof_stride};
                fwrite(hdr, sizeof(int), 2, f);
                std::vector<int> codes(prof_stride - 3, 0);
@@ -365,9 +391,11 @@ struct paml_amd_engine {
       d_eq_q.release(); d_eq_pi.release(); d_eq_scale.release(); d_eq_ptr.release(); d_eq_sweeps.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_rowmajor, &d2_pint, &d2_ptip, &d2_pcol, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot, &d_partial1, &d_partial_tot1, &d_fhK1,
+                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot,
                               &d_expA, &d_expB, &d_expSA, &d_expSB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
+      for (auto &sp : spare) { sp.rowmajor.release(); sp.pint.release(); sp.ptip.release(); sp.pcol.release(); }
+      for (int b = 0; b < MAXL - 1; b++) { d_partial_s[b].release(); d_partial_tot_s[b].release(); d_fhK_s[b].release(); }
    }
 };
 
@@ -427,14 +455,26 @@ inline void mark_on(paml_amd_engine *e, hipStream_t s)
 }
 inline void mark(paml_amd_engine *e) { mark_on(e, e->stream); }
 
+// The engine's own streams are created at the HIGHEST priority: their kernels are the small ones (P(t), partial sums, the exchange
+// step) that should take a CU the moment one is released, ahead of the next evaluation's queued pruning workgroups; and the runtime
+// keeps a pool of hardware queues per priority level, so they do not share a queue with the caller's (normal-priority) stream.
+// Measured on MI355X: the same per-evaluation times as with normal priority (profiles/r03_dual_stream.txt); streams with a CU mask
+// (a hardware queue of their own each) are 3x slower; a LOWEST-priority side stream is not served while the main stream has work
+// queued (profiles/r03_comm_overhead.txt).
+inline hipError_t create_engine_stream(hipStream_t *s)
+{
+   int least = 0, greatest = 0;
+   if (getenv("PAML_AMD_STREAM_PRIO_NORMAL") || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)      // (experiments)
+      return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+   return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
 // The engine's side stream (reductions of consecutive eval_device calls, the exchange step over the ranks) and its events.
 inline int ensure_side_stream(paml_amd_engine *e)
 {
    if (e->sc) return 0;
-   // (default priority: measured on MI355X, a LOWEST-priority stream is not served while the main stream has work queued, and
-   //  every evaluation then waits ~0.17 ms for the all-reduce of two evaluations ago — profiles/r03_comm_overhead.txt)
-   if (hipStreamCreateWithFlags(&e->sc, hipStreamNonBlocking) != hipSuccess) return fail(e, PAML_AMD_EHIP, "hipStreamCreate(side stream)");
-   for (int b = 0; b < 2; b++)
+   if (create_engine_stream(&e->sc) != hipSuccess) return fail(e, PAML_AMD_EHIP, "hipStreamCreate(side stream)");
+   for (int b = 0; b < paml_amd_engine::MAXL; b++)
       if (hipEventCreateWithFlags(&e->ev_part[b], hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming) != hipSuccess)
          return fail(e, PAML_AMD_EHIP, "hipEventCreate(side stream)");
@@ -444,7 +484,7 @@ inline int ensure_side_stream(paml_amd_engine *e)
 // The caller's stream waits for the totals still on their way on the side stream (no-op when there are none).
 inline int join_comm(paml_amd_engine *e)
 {
-   for (int b = 0; b < 2; b++)
+   for (int b = 0; b < paml_amd_engine::MAXL; b++)
       if (e->done_pending[b]) {
          e->done_pending[b] = false;
          if (hipStreamWaitEvent(e->stream, e->ev_done[b], 0) != hipSuccess) return fail(e, PAML_AMD_EHIP, "hipStreamWaitEvent(collective stream)");

@@ -20,6 +20,8 @@ def problem(case):
     from paml_amd import synth
     if case == "codon_jit":      # the per-tree MFMA kernel (forced at this size), one class
         return synth.codon_m0_problem(n_tips=16, n_patt=6000), 2
+    if case == "codon_big":      # large enough per rank for the runs of eval_device calls to alternate between two pruning streams
+        return synth.codon_m0_problem(n_tips=16, n_patt=250_000), 0
     if case == "codon_k3":       # 61 states, three classes, interpreter kernels, scaling nodes
         return helpers.random_problem(61, 10, 3000, K=3, seed=11, scale_every=3), 0
     if case == "nuc_fused":      # 4 states: the fused kernel forms the partial sums itself

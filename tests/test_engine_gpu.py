@@ -754,9 +754,9 @@ def test_eval_device_pipeline_matches_in_order_evaluations():
 @pytest.mark.parametrize("n,K,n_patt", [(61, 2, 60000), (20, 2, 60000)])
 def test_eval_device_reduction_on_the_side_stream(n, K, n_patt):
     """Large problems on the matrix-core kernels, runs of eval_device calls: ten queued evaluations with different branch lengths,
-    paml_amd_flush, a synchronisation of the STREAM only — every value has the bits of the plain evaluation; and so it has with the
-    reduction of evaluation i moved to the engine's side stream under the pruning kernel of evaluation i + 1 (PAML_AMD_OFFLOAD=1: two
-    slots of class likelihoods / partial sums alternate)."""
+    paml_amd_flush, a synchronisation of the STREAM only — every value has the bits of the plain evaluation, whether the pruning
+    kernels of consecutive evaluations alternate between two streams (the default: two slots of class likelihoods / partial sums),
+    stay on one, or the reduction of evaluation i moves to the engine's side stream (PAML_AMD_OFFLOAD=1)."""
     import os
     import torch
     pb = helpers.random_problem(n, 8, n_patt, K=K, seed=77)
@@ -766,13 +766,21 @@ def test_eval_device_reduction_on_the_side_stream(n, K, n_patt):
     want = [ref.eval(b, pb.gene_rate)["lnL"] for b in brs]
     sub = pb.slice_patterns(0, 2000)
     assert abs(engine_for(sub).eval(brs[0], pb.gene_rate)["lnL"] - oracle.evaluate(_with_branches(sub, brs[0]))["lnL"]) <= 1e-9 * abs(want[0])
-    for env in (None, "1"):      # "1": PAML_AMD_OFFLOAD, the reduction on the side stream (an experiment kept behind the switch)
+    # default: the evaluations of the run alternate between two pruning streams; PAML_AMD_DUAL=0: one pruning stream;
+    # PAML_AMD_OFFLOAD: one pruning stream, the whole reduction on the side stream (an experiment kept behind the switch)
+    # "comm": the same inside a one-rank RCCL communicator (the exchange step of every evaluation on the side stream as well)
+    dual0, off1 = ("PAML_AMD_DUAL", "0"), ("PAML_AMD_OFFLOAD", "1")
+    for comm, env in ((False, None), (False, dual0), (False, off1), (True, None), (True, dual0)):
         if env:
-            os.environ["PAML_AMD_OFFLOAD"] = env
+            os.environ[env[0]] = env[1]
         try:
             eng = engine_for(pb)
         finally:
-            os.environ.pop("PAML_AMD_OFFLOAD", None)
+            if env:
+                os.environ.pop(env[0], None)
+        if comm:
+            from paml_amd import engine as E
+            eng.comm_init(0, 1, E.comm_unique_id(), pb.n_patt, 0)
         st = torch.cuda.Stream()
         eng.set_stream(st.cuda_stream)
         out = torch.zeros(10, dtype=torch.float64, device="cuda")
@@ -780,7 +788,7 @@ def test_eval_device_reduction_on_the_side_stream(n, K, n_patt):
             eng.eval_device(b, out.data_ptr() + 8 * i, pb.gene_rate)
         eng.flush()
         st.synchronize()
-        assert out.cpu().numpy().tolist() == want, env
+        assert out.cpu().numpy().tolist() == want, (comm, env)
         # another entry point after the run joins the side stream by itself
         for i, b in enumerate(brs[:3]):
             eng.eval_device(b, out.data_ptr() + 8 * i, pb.gene_rate)

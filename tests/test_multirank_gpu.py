@@ -68,6 +68,17 @@ def test_ranks_on_one_gpu_match_the_single_engine_bit_for_bit(case, tmp_path):
     assert one["eval_device"][0] == one["eval"] and len(set(one["eval_device"])) == len(one["eval_device"])
 
 
+def test_two_ranks_with_overlapping_pruning_kernels(tmp_path):
+    """125 000 codon patterns per rank: the evaluations of the eval_device run alternate between two pruning streams on every rank
+    while their exchange steps queue up on the collective stream — same bits as the single engine."""
+    one = run_ranks(1, "codon_big", tmp_path)[0]
+    res = run_ranks(2, "codon_big", tmp_path)
+    for r in res:
+        for key in ("eval", "eval_device", "eval_batch", "eval_again", "eval_branch", "kernel"):
+            assert r[key] == one[key], (key, r[key], one[key])
+    assert one["kernel"] == "mfma64_jit" and len(set(one["eval_device"])) == len(one["eval_device"])
+
+
 def test_bench_on_two_ranks_of_one_gpu(tmp_path):
     """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one process per rank), but both ranks on
     GPU 0 (PAML_AMD_BENCH_ONE_GPU=1: gloo carries the id and the timing's barrier / max).  Strong scaling of the same patterns:

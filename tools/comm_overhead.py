@@ -44,10 +44,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--patterns", type=int, default=1_000_000)
+    ap.add_argument("--ranks", default="1,2,4,8", help="the N whose shard sizes are timed")
     args = ap.parse_args()
     full = synth.codon_m0_problem(n_tips=16, n_patt=args.patterns, estimate_pi=True)
     rows = []
-    for N in (1, 2, 4, 8):
+    for N in [int(v) for v in args.ranks.split(",")]:
         lo, hi = distributed.shard_bounds(full.n_patt, N, 0)
         pb = full.slice_patterns(lo, hi) if N > 1 else full
         row = {"N": N, "patterns_per_rank": hi - lo}
