@@ -202,7 +202,13 @@ def main():
             "lnL": lnl, "lnL_hex": float(lnl).hex(), "lnL_reference": ref_lnl,
             "roofline": {"bound": "mfma", "kernel": "prune_jit", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
-                         "flop_per_pattern": flops_pp, "kernel_ms": ms_kernel, "timing": "HIP events on the engine's stream, rank 0, per launch",
+                         "flop_per_pattern": flops_pp, "kernel_ms": ms_kernel,
+                         "timing": "HIP events on the engine's stream, rank 0, per launch, one launch at a time",
+                         # (in the timed region consecutive launches alternate between two streams and overlap: a CU released by
+                         #  launch i goes straight to launch i + 1, so ms_per_step can be SHORTER than kernel_ms; the kernel's own
+                         #  figure — and the rocprofv3 statistics in profiles/ — are taken with the launches one after the other)
+                         "launches_overlap_in_timed_region": os.environ.get("PAML_AMD_DUAL", "1") != "0",
+                         "achieved_per_step": flops_pp * pb.n_patt / (dt / args.steps) / 1e12,
                          # (consecutive evaluations build P(t) on a side stream under the previous kernel's last round: the
                          #  event pair around it then spans its wait for free CUs, which is not kernel time)
                          "pmat_ms": (prof["ms_pmat"] / max(1, prof["n_evals"])) if prof["ms_pmat"] < 0.5 * prof["ms_prune"] else None,

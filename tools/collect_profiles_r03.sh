@@ -5,6 +5,11 @@
 out=$PWD/gpurun_out/r3prof
 mkdir -p $out
 export TMPDIR=/tmp
+# Per-kernel figures: the launches one after the other.  By default consecutive evaluations alternate between two pruning streams
+# and their kernels overlap — a kernel's "duration" in a trace then includes its wait for the CUs of the one before (about twice
+# the evaluation period) and the per-dispatch counters of overlapping dispatches mix.  profiles/r03_dual_stream.txt has the
+# overlapped timeline (tools/collect_dual_r03.sh).
+export PAML_AMD_DUAL=0
 B="python $PWD/bench.py --no-cpu-baseline --no-extras"      # bench.py with its default step counts, headline only
 C2="python $PWD/tools/c2_probe.py"
 M20="python $PWD/tools/m20_probe.py"

@@ -1,4 +1,6 @@
-"""experiment: b2b time per evaluation of a sequence of engines, e.g. 8p,8p,1p,8c,8p (N = shard divisor, p plain / c one-rank communicator)"""
+"""Back-to-back time per evaluation of a sequence of engines in one process, e.g. 8p,8c,4p,1p: N = the shard divisor of the headline
+workload (10^6 / N codon patterns, 16 taxa, M0), p plain / c inside a one-rank RCCL communicator.  Every evaluation of a run has its
+own result slot; all must be equal.  Used with PAML_AMD_DUAL / PAML_AMD_LANES / PAML_AMD_COMM_CUS for profiles/r03_dual_stream.txt."""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from paml_amd import distributed, engine, synth

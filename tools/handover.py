@@ -1,4 +1,4 @@
-"""experiment: how long a CU stays empty between a retiring pruning workgroup of evaluation K-1 and the workgroup of evaluation K that
+"""How long a CU stays empty between a retiring pruning workgroup of evaluation K-1 and the workgroup of evaluation K that
 takes it (two pruning streams).  usage: _handover.py <dump> (reads <dump> and <dump>.1 of a PAML_AMD_PROF_TILES run)"""
 import sys
 import numpy as np

@@ -1,3 +1,5 @@
+"""Rows of a rocprofv3 --kernel-trace run in start order: start, end, duration (us), kernel, stream, queue.
+usage: raw_timeline.py <dir with *kernel_trace.csv> <rows> [first row]"""
 import csv, glob, os, sys
 rows = []
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
