@@ -159,12 +159,13 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
 
 /* Same evaluation without the final device->host copy or synchronisation: lnL (the total over the ranks when the engine has a
  * communicator) is left in d_lnL (a device pointer, e.g. a torch tensor).  Consecutive calls are pipelined: the next
- * evaluation's P(t) is built on a side stream under this one's pruning kernel, and with a communicator this evaluation's
- * exchange step (all-reduce + fixed-order total) runs on a side stream while the engine's stream goes on to the next
- * pruning kernel.  The totals of the last two calls may therefore still be on the side stream:
+ * evaluations' P(t) are built on a side stream, the pruning kernels of consecutive evaluations (large problems on the
+ * matrix-core kernels) alternate between the engine's stream and a second stream of the engine's own so that one takes the CUs
+ * as the other releases them, and the fixed-order total — with a communicator the exchange step in front of it — runs on a
+ * third.  The values of a run are written in call order, but the last of them may still be on the engine's own streams:
  * paml_amd_flush makes the engine's stream wait for them.  Call it once after a run of eval_device calls, before synchronising
- * the stream or reading d_lnL on it (a device-wide synchronisation covers the side stream too); every other entry point
- * of the engine does it implicitly. */
+ * the stream or reading d_lnL on it (a device-wide synchronisation covers the engine's streams too); every other entry point
+ * of the engine does it implicitly.  Give every evaluation of a run its own d_lnL slot if all values are wanted. */
 int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL);
 int paml_amd_flush(paml_amd_engine *e);
 
