@@ -53,8 +53,10 @@ static void launch_valu(paml_amd_engine *e, int max_stack, int n_blocks, const P
 
 void launch_pmat(const PmatArgs &pa, const InlineVec &iv, int n_nodes, int psets, bool small, hipStream_t s)
 {
+   const int gx = (n_nodes + std::max(pa.npb, 1) - 1) / std::max(pa.npb, 1);
    if (small) hipLaunchKernelGGL(pmat_small_kernel, dim3((n_nodes * psets + 7) / 8), dim3(256), 0, s, pa, iv);
-   else hipLaunchKernelGGL(pmat_kernel, dim3(n_nodes, psets), dim3(256), 2 * 4096 * sizeof(double), s, pa, iv);
+   else if (pa.n <= 32 && pa.layout != 1) hipLaunchKernelGGL(pmat_kernel_t<32>, dim3(gx, psets), dim3(256), 2 * 32 * 32 * sizeof(double), s, pa, iv);
+   else hipLaunchKernelGGL(pmat_kernel_t<64>, dim3(gx, psets), dim3(256), 2 * 4096 * sizeof(double), s, pa, iv);
 }
 
 void launch_prune_full(paml_amd_engine *e, int max_stack, int n_blocks, const PruneArgs &pr, hipStream_t s)
@@ -370,12 +372,17 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    if (bs && bs->eigen_of) { pa.eigen_of = e->d_b_eigen_of.p; pa.eigen_of_bs = (long)G * Km * e->n_labels; }
    if (bs && bs->qfactor) { pa.qfactor = e->d_b_qfactor.p; pa.qfactor_bs = (long)Km * e->n_labels; }
    pa.rate_gs = e->rate_per_gene ? Km : 0;
+   // PAML_AMD_PMAT_NPB=n (experiment): in a run of evaluations, where P(t) is built ahead on the side stream with the few CUs the
+   // pruning kernels leave it, n nodes per workgroup with the eigen vectors kept on chip from node to node.  Measured on MI355X with
+   // n = 8: 20 states 0.1887 against 0.1884 ms per evaluation, 61 states SLOWER (0.211 against 0.203 ms at the 8-GPU shard size,
+   // 1.547 against 1.534 at 10^6 patterns: fewer workgroups, each eight times longer, and the pruning kernel waits for the last)
+   static const int npb_run = getenv("PAML_AMD_PMAT_NPB") ? atoi(getenv("PAML_AMD_PMAT_NPB")) : 1;
+   pa.npb = pipe ? npb_run : 1;
    if (bs && bs->rate) { pa.rate = e->d_b_rate.p; pa.rate_bs = e->rate_per_gene ? (long)G * Km : Km; }
    mark_on(e, ps);
    bool small_pmat = e->kk != KK_MFMA64 && n <= 5;
    for (const EigenHost &h : e->eigen) small_pmat = small_pmat && h.kind != PAML_AMD_EIGEN_QMAT;
-   if (small_pmat) hipLaunchKernelGGL(pmat_small_kernel, dim3((nn * psets + 7) / 8), dim3(256), 0, ps, pa, iv);
-   else hipLaunchKernelGGL(pmat_kernel, dim3(nn, psets), dim3(256), 2 * 4096 * sizeof(double), ps, pa, iv);
+   launch_pmat(pa, iv, nn, psets, small_pmat, ps);
    mark_on(e, ps);
    if (pipe) {      // the pruning kernel (main stream) starts when this P(t) is there
       HIPCHK(hipEventRecord(e->ev_pmat, e->s2));

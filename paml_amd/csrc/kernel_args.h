@@ -39,6 +39,7 @@ struct PmatArgs {
    int B;
    long branch_bs, gene_rate_bs, eigen_of_bs, qfactor_bs, rate_bs;
    int rate_gs;                   // class rates per gene (Malpha: a gamma shape per gene): rate[bat][gene][class], else 0
+   int npb;                       // nodes per workgroup of pmat_kernel_t (0 = 1)
 };
 
 // Branch lengths and gene rates handed over INSIDE the kernel arguments (single evaluations of trees with up to ~440 nodes):

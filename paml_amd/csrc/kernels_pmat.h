@@ -98,219 +98,248 @@ __global__ __launch_bounds__(256) void pmat_small_kernel(PmatArgs a, InlineVec i
    }
 }
 
-__global__ __launch_bounds__(256) void pmat_kernel(PmatArgs a, InlineVec iv)
+// LD: the side of the padded square the matrices live in while they are built — 64, or 32 for models of at most 32 states that
+// do not want the MFMA operand layout (20 states: 25 KB of LDS per workgroup instead of 81, so that six of them share a CU; in a
+// run of evaluations P(t) only ever gets the few CUs the persistent pruning kernels leave free).  Same arithmetic per entry.
+template <int LD>
+__global__ __launch_bounds__(256) void pmat_kernel_t(PmatArgs a, InlineVec iv)
 {
    extern __shared__ __attribute__((aligned(16))) double smem[];
-   double *sA = smem;            // [64][64]  U*expm1 -> later the finished P (padded with zeros)
-   double *sB = smem + 4096;     // [64][64]  V
-   const int node = blockIdx.x, pset = blockIdx.y;
-   if (node == a.root) return;
+   constexpr int ROWS = LD * LD / 256, TL = LD / 4;      // rows per thread of the finished matrix; 4 x 4 register tiles per side
+   double *sA = smem;            // [LD][LD]  U*expm1 -> later the finished P (padded with zeros)
+   double *sB = smem + LD * LD;  // [LD][LD]  V
+   // A workgroup builds the matrices of a.npb consecutive nodes of one parameter set: 1 by default (one node per workgroup, the
+   // lowest latency); more is an experiment (engine_eval.hip, PAML_AMD_PMAT_NPB) — U stays in registers and V in LDS while the
+   // eigen set does not change, which takes the chain of dependent global loads out of every node but the first.
+   const int pset = blockIdx.y, npb = a.npb > 0 ? a.npb : 1;
    const int tid = threadIdx.x, n = a.n;
    const int KB = a.K * a.B;
    const int gene = pset / KB, bat = (pset % KB) / a.K, iclass = pset % a.K;
-   const int lab = a.label[node];
-   const EigenDev es = a.eigen[a.eigen_of[bat * a.eigen_of_bs + (gene * a.K + iclass) * a.n_labels + lab]];
-   double t = pmat_time(a, iv, bat, node, gene, iclass);
-
-   // tip branches: the ambiguity map (tools.c:20 nChara / CharaMap) comes to LDS now, so that the column-table loop at
-   // the end does not chase two dependent global loads per entry
-   __shared__ unsigned char sMap[256 * 64];
+   // tip branches: the ambiguity map (tools.c:20 nChara / CharaMap) comes to LDS, so that the column-table loop at the end does
+   // not chase two dependent global loads per entry
+   __shared__ unsigned char sMap[256 * LD];
    __shared__ int sNch[256];
-   const bool leaf = a.is_leaf[node] != 0;
-   if (leaf) {
-      for (int idx = tid; idx < a.n_codes * n; idx += 256) sMap[idx] = a.chara_map[idx];
-      for (int idx = tid; idx < a.n_codes; idx += 256) sNch[idx] = a.n_chara[idx];
-   }
-
-   const int j = tid & 63, rg = tid >> 6;   // this thread: column j, rows rg*16 .. rg*16+15
-   double acc[16];
-#pragma unroll
-   for (int r = 0; r < 16; r++) acc[r] = 0;
-
-   if (es.kind == PAML_AMD_EIGEN_UVROOT) {
-      t *= a.qfactor[bat * a.qfactor_bs + iclass * a.n_labels + lab];
-      if (t < 1e-100) {
-#pragma unroll
-         for (int r = 0; r < 16; r++) acc[r] = (rg * 16 + r == j) ? 1.0 : 0.0;
+   __shared__ double sE[64];
+   bool map_loaded = false;
+   int cur = -1, uv_of = -1;      // eigen set held in `es`; ... whose U is in ureg and V in sB
+   EigenDev es{};
+   double ureg[ROWS];
+   const int node_end = min(a.n_nodes, ((int)blockIdx.x + 1) * npb);
+   for (int node = blockIdx.x * npb; node < node_end; node++) {
+      if (node == a.root) continue;
+      const int lab = a.label[node];
+      const int ei = a.eigen_of[bat * a.eigen_of_bs + (gene * a.K + iclass) * a.n_labels + lab];
+      if (ei != cur) { es = a.eigen[ei]; cur = ei; }
+      double t = pmat_time(a, iv, bat, node, gene, iclass);
+      const bool leaf = a.is_leaf[node] != 0;
+      if (leaf && !map_loaded) {      // (read after the barriers below)
+         for (int idx = tid; idx < a.n_codes * n; idx += 256) sMap[idx] = a.chara_map[idx];
+         for (int idx = tid; idx < a.n_codes; idx += 256) sNch[idx] = a.n_chara[idx];
+         map_loaded = true;
       }
-      else {
-         for (int idx = tid; idx < 4096; idx += 256) {
-            int i = idx >> 6, k = idx & 63;
-            double ue = 0, v = 0;
-            if (i < n && k < n) {
-               ue = es.U[i * n + k] * expm1(t * es.Root[k]);
-               v = es.V[i * n + k];        // here (i,k) index V as [k'][j'] = [i][k]
-            }
-            sA[k * 64 + i] = ue;           // transposed: the four rows of a register tile are contiguous for every k
-            sB[idx] = v;
+
+      const int j = tid % LD, rg = tid / LD;   // this thread: column j, rows rg*ROWS .. rg*ROWS+ROWS-1
+      double acc[ROWS];
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) acc[r] = 0;
+
+      if (es.kind == PAML_AMD_EIGEN_UVROOT) {
+         t *= a.qfactor[bat * a.qfactor_bs + iclass * a.n_labels + lab];
+         if (t < 1e-100) {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) acc[r] = (rg * ROWS + r == j) ? 1.0 : 0.0;
          }
-         __syncthreads();
-         {
-            // 4 x 4 register tile per thread: four 16-byte LDS reads feed sixteen FMAs; every element still accumulates
-            // k ascending (PMatUVRoot's order, tools.c:525-537)
-            const int ti = tid >> 4, tj = tid & 15;
-            double c[4][4];
+         else {
+            // expm1(t * Root[k]) once per k (not per (i, k))
+            if (tid < 64) sE[tid] = tid < n ? expm1(t * es.Root[tid]) : 0.0;
+            if (uv_of != cur) {
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+               for (int m = 0; m < ROWS; m++) {
+                  const int idx = tid + 256 * m, i = idx / LD, k = idx % LD;
+                  const bool in = i < n && k < n;
+                  ureg[m] = in ? es.U[i * n + k] : 0.0;
+                  sB[idx] = in ? es.V[i * n + k] : 0.0;        // here (i,k) index V as [k'][j'] = [i][k]
+               }
+               uv_of = cur;
+            }
+            __syncthreads();
 #pragma unroll
-               for (int cc = 0; cc < 4; cc++) c[r][cc] = 0;
-            for (int k = 0; k < n; k++) {
-               const double2 a0 = *(const double2 *)&sA[k * 64 + 4 * ti], a1 = *(const double2 *)&sA[k * 64 + 4 * ti + 2];
-               const double2 b0 = *(const double2 *)&sB[k * 64 + 4 * tj], b1 = *(const double2 *)&sB[k * 64 + 4 * tj + 2];
-               const double av[4] = {a0.x, a0.y, a1.x, a1.y}, bv[4] = {b0.x, b0.y, b1.x, b1.y};
+            for (int m = 0; m < ROWS; m++) {
+               const int idx = tid + 256 * m, i = idx / LD, k = idx % LD;
+               sA[k * LD + i] = ureg[m] * sE[k];           // transposed: the four rows of a register tile are contiguous for every k
+            }
+            __syncthreads();
+            {
+               // 4 x 4 register tile per thread: four 16-byte LDS reads feed sixteen FMAs; every element still accumulates
+               // k ascending (PMatUVRoot's order, tools.c:525-537)
+               const int ti = tid / TL, tj = tid % TL;
+               const bool tile = tid < TL * TL;
+               double c[4][4];
 #pragma unroll
                for (int r = 0; r < 4; r++)
 #pragma unroll
-                  for (int cc = 0; cc < 4; cc++) c[r][cc] = fma(av[r], bv[cc], c[r][cc]);
+                  for (int cc = 0; cc < 4; cc++) c[r][cc] = 0;
+               for (int k = 0; k < n && tile; k++) {
+                  const double2 a0 = *(const double2 *)&sA[k * LD + 4 * ti], a1 = *(const double2 *)&sA[k * LD + 4 * ti + 2];
+                  const double2 b0 = *(const double2 *)&sB[k * LD + 4 * tj], b1 = *(const double2 *)&sB[k * LD + 4 * tj + 2];
+                  const double av[4] = {a0.x, a0.y, a1.x, a1.y}, bv[4] = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+                  for (int r = 0; r < 4; r++)
+#pragma unroll
+                     for (int cc = 0; cc < 4; cc++) c[r][cc] = fma(av[r], bv[cc], c[r][cc]);
+               }
+               __syncthreads();
+#pragma unroll
+               for (int r = 0; r < 4; r++)
+#pragma unroll
+                  for (int cc = 0; cc < 4; cc++)
+                     if (tile) sA[(4 * ti + r) * LD + 4 * tj + cc] = c[r][cc];
+               __syncthreads();
+#pragma unroll
+               for (int r = 0; r < ROWS; r++) acc[r] = sA[(rg * ROWS + r) * LD + j];
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+               int i = rg * ROWS + r;
+               double p = acc[r] + (i == j ? 1.0 : 0.0);
+               acc[r] = (i < n && j < n) ? (p < 0 ? 0.0 : p) : 0.0;
             }
             __syncthreads();
+         }
+      }
+      else if (es.kind == PAML_AMD_EIGEN_CIJK) {
+         uv_of = -1;
+         double e[64];
+         const int nR = es.nR;
+         for (int idx = tid; idx < 64; idx += 256) sB[idx] = (idx >= 1 && idx < nR) ? expm1(t * es.Root[idx]) : 0.0;
+         __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+         for (int r = 0; r < ROWS; r++) {
+            int i = rg * ROWS + r;
+            double s = 0;
+            if (i < n && j < n) {
+               const double *c = es.Cijk + ((long)i * n + j) * nR;
+               for (int k = 0; k < nR; k++) s += c[k] * sB[k];
+               if (i == j) s += 1.0;
+            }
+            acc[r] = s;
+         }
+         (void)e;
+         __syncthreads();
+      }
+      else if (es.kind == PAML_AMD_EIGEN_K80) {
+         const double kappa = es.kappa;
+         const double e1 = expm1(-4 * t / (kappa + 2));
+         const bool jc = fabs(kappa - 1) < 1e-20;
+         const double e2 = jc ? 0.0 : expm1(-2 * t * (kappa + 1) / (kappa + 2));
 #pragma unroll
-               for (int cc = 0; cc < 4; cc++) sA[(4 * ti + r) * 64 + 4 * tj + cc] = c[r][cc];
+         for (int r = 0; r < ROWS; r++) {
+            int i = rg * ROWS + r;
+            double p = 0;
+            if (i < 4 && j < 4) {
+               if (jc) p = (i == j) ? 1. + 3 / 4.0 * e1 : -e1 / 4;
+               else if (i == j) p = 1 + (e1 + 2 * e2) / 4;
+               else if ((i ^ j) == 1) p = (e1 - 2 * e2) / 4;
+               else p = -e1 / 4;
+            }
+            acc[r] = p;
+         }
+      }
+      else if (es.kind == PAML_AMD_EIGEN_QMAT) {
+         // UNREST: P = e^{Qt} by matexp(Qt, n, 7, 5) (tools.c:4879): B = Qt/32, e^B by seven Taylor terms, then five squarings.
+         // n <= 8: one thread per entry, four n x n scratch matrices in LDS.
+         double *T0 = sA, *T1 = sA + 64, *T2 = sA + 128, *Bm = sA + 192;
+         const int i = tid / n, jj = tid % n;
+         const bool on = tid < n * n;
+         if (on) {
+            const double v = es.U[tid] * t * (1.0 / 32);
+            Bm[tid] = v; T1[tid] = v;
+            T0[tid] = v + (i == jj ? 1.0 : 0.0);
+         }
+         __syncthreads();
+         double factor = 1;
+         double *Tp = T1, *Tn = T2;              // B^(k-1) and B^k
+         for (int term = 2; term <= 7; term++) {
+            double s = 0;
+            if (on)
+               for (int k2 = 0; k2 < n; k2++) s += Tp[i * n + k2] * Bm[k2 * n + jj];
+            factor /= term;
+            if (on) { Tn[tid] = s; T0[tid] += s * factor; }
             __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = sA[(rg * 16 + r) * 64 + j];
+            double *sw = Tp; Tp = Tn; Tn = sw;
+         }
+         double *Sa = T0, *Sb = T1;
+         for (int sq = 0; sq < 5; sq++) {
+            double s = 0;
+            if (on)
+               for (int k2 = 0; k2 < n; k2++) s += Sa[i * n + k2] * Sa[k2 * n + jj];
+            __syncthreads();
+            if (on) Sb[tid] = s;
+            __syncthreads();
+            double *sw = Sa; Sa = Sb; Sb = sw;
          }
 #pragma unroll
-         for (int r = 0; r < 16; r++) {
-            int i = rg * 16 + r;
-            double p = acc[r] + (i == j ? 1.0 : 0.0);
-            acc[r] = (i < n && j < n) ? (p < 0 ? 0.0 : p) : 0.0;
+         for (int r = 0; r < ROWS; r++) {
+            const int ii = rg * ROWS + r;
+            acc[r] = (ii < n && j < n) ? Sa[ii * n + j] : 0.0;
          }
          __syncthreads();
       }
-   }
-   else if (es.kind == PAML_AMD_EIGEN_CIJK) {
-      double e[64];
-      const int nR = es.nR;
-      for (int idx = tid; idx < 64; idx += 256) sB[idx] = (idx >= 1 && idx < nR) ? expm1(t * es.Root[idx]) : 0.0;
-      __syncthreads();
+      else {   // JC69-like (aa Poisson): no Qfactor (treesub.c:7584-7585)
+         const double pii = 1. / n + (1. - 1. / n) * exp(-n / (n - 1.) * t);
+         const double pij = (1. - pii) / (n - 1.);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-         int i = rg * 16 + r;
-         double s = 0;
-         if (i < n && j < n) {
-            const double *c = es.Cijk + ((long)i * n + j) * nR;
-            for (int k = 0; k < nR; k++) s += c[k] * sB[k];
-            if (i == j) s += 1.0;
+         for (int r = 0; r < ROWS; r++) {
+            int i = rg * ROWS + r;
+            acc[r] = (i < n && j < n) ? (i == j ? pii : pij) : 0.0;
          }
-         acc[r] = s;
       }
-      (void)e;
-      __syncthreads();
-   }
-   else if (es.kind == PAML_AMD_EIGEN_K80) {
-      const double kappa = es.kappa;
-      const double e1 = expm1(-4 * t / (kappa + 2));
-      const bool jc = fabs(kappa - 1) < 1e-20;
-      const double e2 = jc ? 0.0 : expm1(-2 * t * (kappa + 1) / (kappa + 2));
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-         int i = rg * 16 + r;
-         double p = 0;
-         if (i < 4 && j < 4) {
-            if (jc) p = (i == j) ? 1. + 3 / 4.0 * e1 : -e1 / 4;
-            else if (i == j) p = 1 + (e1 + 2 * e2) / 4;
-            else if ((i ^ j) == 1) p = (e1 - 2 * e2) / 4;
-            else p = -e1 / 4;
-         }
-         acc[r] = p;
-      }
-   }
-   else if (es.kind == PAML_AMD_EIGEN_QMAT) {
-      // UNREST: P = e^{Qt} by matexp(Qt, n, 7, 5) (tools.c:4879): B = Qt/32, e^B by seven Taylor terms, then five squarings.
-      // n <= 8: one thread per entry, four n x n scratch matrices in LDS.
-      double *T0 = sA, *T1 = sA + 64, *T2 = sA + 128, *Bm = sA + 192;
-      const int i = tid / n, jj = tid % n;
-      const bool on = tid < n * n;
-      if (on) {
-         const double v = es.U[tid] * t * (1.0 / 32);
-         Bm[tid] = v; T1[tid] = v;
-         T0[tid] = v + (i == jj ? 1.0 : 0.0);
-      }
-      __syncthreads();
-      double factor = 1;
-      double *Tp = T1, *Tn = T2;              // B^(k-1) and B^k
-      for (int term = 2; term <= 7; term++) {
-         double s = 0;
-         if (on)
-            for (int k2 = 0; k2 < n; k2++) s += Tp[i * n + k2] * Bm[k2 * n + jj];
-         factor /= term;
-         if (on) { Tn[tid] = s; T0[tid] += s * factor; }
-         __syncthreads();
-         double *sw = Tp; Tp = Tn; Tn = sw;
-      }
-      double *Sa = T0, *Sb = T1;
-      for (int sq = 0; sq < 5; sq++) {
-         double s = 0;
-         if (on)
-            for (int k2 = 0; k2 < n; k2++) s += Sa[i * n + k2] * Sa[k2 * n + jj];
-         __syncthreads();
-         if (on) Sb[tid] = s;
-         __syncthreads();
-         double *sw = Sa; Sa = Sb; Sb = sw;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-         const int ii = rg * 16 + r;
-         acc[r] = (ii < n && j < n) ? Sa[ii * n + j] : 0.0;
-      }
-      __syncthreads();
-   }
-   else {   // JC69-like (aa Poisson): no Qfactor (treesub.c:7584-7585)
-      const double pii = 1. / n + (1. - 1. / n) * exp(-n / (n - 1.) * t);
-      const double pij = (1. - pii) / (n - 1.);
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-         int i = rg * 16 + r;
-         acc[r] = (i < n && j < n) ? (i == j ? pii : pij) : 0.0;
-      }
-   }
 
-   // finished P (zero padded to 64x64) into LDS
+      // finished P (zero padded to LD x LD) into LDS
 #pragma unroll
-   for (int r = 0; r < 16; r++) sA[(rg * 16 + r) * 64 + j] = acc[r];
-   __syncthreads();
+      for (int r = 0; r < ROWS; r++) sA[(rg * ROWS + r) * LD + j] = acc[r];
+      __syncthreads();
 
-   const long slot = (long)pset * a.n_nodes + node;
-   double *rm = a.rowmajor + slot * n * n;
-   for (int idx = tid; idx < n * n; idx += 256) rm[idx] = sA[(idx / n) * 64 + (idx % n)];
+      const long slot = (long)pset * a.n_nodes + node;
+      double *rm = a.rowmajor + slot * n * n;
+      for (int idx = tid; idx < n * n; idx += 256) rm[idx] = sA[(idx / n) * LD + (idx % n)];
 
-   if (a.layout == 1 && !leaf) {
-      // MFMA A-operand order: element ((kb2*4 + jb)*64 + lane)*2 + e  =  P[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)]
-      double *pf = a.pint + slot * 4096;
-      for (int idx = tid; idx < 4096; idx += 256) {
-         int e = idx & 1, lane = (idx >> 1) & 63, jb = (idx >> 7) & 3, kb2 = idx >> 9;
-         pf[idx] = sA[(jb * 16 + (lane & 15)) * 64 + 4 * (2 * kb2 + e) + (lane >> 4)];
-      }
-      // column 60 in the order a lane's accumulators want it, pcol[q][m] = P[4m + q][60]: with 61 states the last
-      // k-block holds this one column, and the specialised kernel adds its rank-1 term on the vector pipe instead of
-      // spending four MFMAs on it
-      if (a.pcol && tid < 64) a.pcol[slot * 64 + tid] = sA[(4 * (tid & 15) + (tid >> 4)) * 64 + 60];
-   }
-   if (leaf) {
-      const int tipw = a.layout == 1 ? 64 : n;
-      double *pt = a.ptip + slot * a.tip_words;
-      for (int idx = tid; idx < a.n_codes * tipw; idx += 256) {
-         int code = idx / tipw, w = idx % tipw, jj;
-         if (a.layout == 1) {
-            // row (code, q) = 128 bytes = 8 pieces of two states; piece p is stored in slot p ^ ((row >> 1) & 7) so
-            // that lanes gathering different rows from an LDS copy of this table spread over the banks
-            const int q = w >> 4, slot = (w & 15) >> 1, row = code * 4 + q;
-            const int m = ((slot ^ TIP_SWZ(row)) << 1) | (w & 1);
-            jj = 4 * m + q;
+      if constexpr (LD == 64) if (a.layout == 1 && !leaf) {
+         // MFMA A-operand order: element ((kb2*4 + jb)*64 + lane)*2 + e  =  P[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)]
+         double *pf = a.pint + slot * 4096;
+         for (int idx = tid; idx < 4096; idx += 256) {
+            int e = idx & 1, lane = (idx >> 1) & 63, jb = (idx >> 7) & 3, kb2 = idx >> 9;
+            pf[idx] = sA[(jb * 16 + (lane & 15)) * 64 + 4 * (2 * kb2 + e) + (lane >> 4)];
          }
-         else if (a.layout == 2) jj = 4 * (w % 5) + w / 5;      // 20 states on 4x4x4 MFMAs: [code][state & 3][state >> 2], a lane's five states contiguous
-         else jj = w;
-         double s = 0;
-         if (jj < n) {
-            const int nc = sNch[code];
-            const unsigned char *map = sMap + code * n;
-            for (int k = 0; k < nc; k++) s += sA[jj * 64 + map[k]];
-         }
-         pt[idx] = s;
+         // column 60 in the order a lane's accumulators want it, pcol[q][m] = P[4m + q][60]: with 61 states the last
+         // k-block holds this one column, and the specialised kernel adds its rank-1 term on the vector pipe instead of
+         // spending four MFMAs on it
+         if (a.pcol && tid < 64) a.pcol[slot * 64 + tid] = sA[(4 * (tid & 15) + (tid >> 4)) * 64 + 60];
       }
+      if (leaf) {
+         const int tipw = a.layout == 1 ? 64 : n;
+         double *pt = a.ptip + slot * a.tip_words;
+         for (int idx = tid; idx < a.n_codes * tipw; idx += 256) {
+            int code = idx / tipw, w = idx % tipw, jj;
+            if (a.layout == 1) {
+               // row (code, q) = 128 bytes = 8 pieces of two states; piece p is stored in slot p ^ ((row >> 1) & 7) so
+               // that lanes gathering different rows from an LDS copy of this table spread over the banks
+               const int q = w >> 4, slot = (w & 15) >> 1, row = code * 4 + q;
+               const int m = ((slot ^ TIP_SWZ(row)) << 1) | (w & 1);
+               jj = 4 * m + q;
+            }
+            else if (a.layout == 2) jj = 4 * (w % 5) + w / 5;      // 20 states on 4x4x4 MFMAs: [code][state & 3][state >> 2], a lane's five states contiguous
+            else jj = w;
+            double s = 0;
+            if (jj < n) {
+               const int nc = sNch[code];
+               const unsigned char *map = sMap + code * n;
+               for (int k = 0; k < nc; k++) s += sA[jj * LD + map[k]];
+            }
+            pt[idx] = s;
+         }
+      }
+      __syncthreads();      // (the next node's matrices go over this one's)
    }
 }
 
