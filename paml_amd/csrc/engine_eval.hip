@@ -517,7 +517,18 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
       else if (e->use_jit && e->m20) {      // persistent: a multiple of the class count, every workgroup keeps its class's P(t) in LDS
          void *params[] = {&pr};
-         const int grid = std::min(std::max(K, cus / K * K), e->n_tiles * K);
+         int grid = std::min(std::max(K, cus / K * K), e->n_tiles * K);
+         // Runs of evaluations on two pruning streams: the small kernels beside this one (partial sums, the next P(t)) are
+         // dispatched to shader engines in turn, and a workgroup sent to an engine whose CUs all hold a persistent workgroup
+         // waits for the end of this kernel even if the engine next door has room (measured: both then end WITH this kernel and
+         // the next pruning kernel, which needs them, cannot be queued ahead).  7/8 of the CUs leave every shader engine one
+         // free; taken when it costs this kernel nothing, i.e. when a wave still walks the same number of 32-pattern units
+         // (10^5 patterns x 4 classes: 7 at 56 workgroups per class as at 63).  0.1885 -> 0.182 ms per evaluation (32 taxa).
+         if (dual || (want_pipe && e->env.dual && !e->profiling)) {
+            const int units = std::min(e->n_tiles * 8, (e->n_patt + 31) / 32), g78 = e->n_cu * 7 / 8 / K * K;
+            auto rounds = [&](int g) { return ((units + g / K - 1) / (g / K) + 7) / 8; };
+            if (g78 >= K && g78 < grid && rounds(g78) == rounds(grid)) grid = g78;
+         }
          static const int m20_threads = getenv("PAML_AMD_M20_W12") ? 768 : 512;      // (experiment: jit_generate_m20)
          HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::max(grid / K, 1) * K, 1, 1, m20_threads, 1, 1, 0, ms, params, nullptr));
       }
