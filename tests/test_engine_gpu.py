@@ -770,7 +770,8 @@ def test_eval_device_reduction_on_the_side_stream(n, K, n_patt):
     # PAML_AMD_OFFLOAD: one pruning stream, the whole reduction on the side stream (an experiment kept behind the switch)
     # "comm": the same inside a one-rank RCCL communicator (the exchange step of every evaluation on the side stream as well)
     dual0, off1 = ("PAML_AMD_DUAL", "0"), ("PAML_AMD_OFFLOAD", "1")
-    for comm, env in ((False, None), (False, dual0), (False, off1), (True, None), (True, dual0)):
+    lanes3 = ("PAML_AMD_LANES", "3")      # (an experiment switch: three evaluations in flight, three slots)
+    for comm, env in ((False, None), (False, dual0), (False, off1), (True, None), (True, dual0), (False, lanes3), (True, lanes3)):
         if env:
             os.environ[env[0]] = env[1]
         try:
