@@ -466,7 +466,9 @@ inline hipError_t create_engine_stream(hipStream_t *s)
    int least = 0, greatest = 0;
    if (getenv("PAML_AMD_STREAM_PRIO_NORMAL") || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)      // (experiments)
       return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-   return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+   if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest) == hipSuccess) return hipSuccess;
+   (void)hipGetLastError();
+   return hipStreamCreateWithFlags(s, hipStreamNonBlocking);      // (a runtime without stream priorities: the measured times are the same)
 }
 
 // The engine's side stream (reductions of consecutive eval_device calls, the exchange step over the ranks) and its events.
