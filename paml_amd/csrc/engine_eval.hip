@@ -483,9 +483,13 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       pr.prof_tid = e->env.prof_tid;
    }
    mark(e);
-   // CUs of the persistent kernels: a few stay free for the small kernels beside them (the collective; with two pruning streams
-   // the reduction and the next P(t), which would otherwise queue behind the next evaluation's persistent workgroups)
-   const int cus = (e->comm || (want_pipe && e->env.dual)) ? std::max(1, e->n_cu - e->comm_cus) : e->n_cu;
+   // CUs of the persistent kernels.  One pruning stream inside a communicator: a few stay free for the collective (engine_state.h,
+   // comm_cus).  Runs of evaluations on two pruning streams: all of them — CUs left free by one kernel are taken at once by the
+   // first workgroups of the next, so a reservation reserves nothing there and only costs tiles per CU (measured, 16 taxa x 10^6
+   // codon patterns: 1.524-1.526 ms per evaluation on 256 CUs against 1.534-1.542 on 254; the same at the 8-GPU shard size, with
+   // and without a communicator); the small kernels run when workgroups retire.
+   const bool two_streams = want_pipe && e->env.dual && !e->profiling;
+   const int cus = (e->comm && !two_streams) ? std::max(1, e->n_cu - e->comm_cus) : e->n_cu;
    switch (e->kk) {
    case KK_MFMA64:
       if (e->use_jit) {
@@ -524,7 +528,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          // the next pruning kernel, which needs them, cannot be queued ahead).  7/8 of the CUs leave every shader engine one
          // free; taken when it costs this kernel nothing, i.e. when a wave still walks the same number of 32-pattern units
          // (10^5 patterns x 4 classes: 7 at 56 workgroups per class as at 63).  0.1885 -> 0.182 ms per evaluation (32 taxa).
-         if (dual || (want_pipe && e->env.dual && !e->profiling)) {
+         if (two_streams) {
             const int units = std::min(e->n_tiles * 8, (e->n_patt + 31) / 32), g78 = e->n_cu * 7 / 8 / K * K;
             auto rounds = [&](int g) { return ((units + g / K - 1) / (g / K) + 7) / 8; };
             if (g78 >= K && g78 < grid && rounds(g78) == rounds(grid)) grid = g78;

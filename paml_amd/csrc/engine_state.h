@@ -220,7 +220,8 @@ struct paml_amd_engine {
    hipEvent_t ev_part[MAXL] = {}, ev_done[MAXL] = {};
    bool done_pending[MAXL] = {};
    int red_slot = 0, last_slot = 0;
-   // CUs the persistent pruning kernels leave free while the engine has a communicator: their workgroups fill a CU (two waves
+   // CUs the persistent pruning kernels of SINGLE evaluations leave free while the engine has a communicator (runs of evaluations
+   // on two pruning streams take every CU, see engine_eval.hip): their workgroups fill a CU (two waves
    // per SIMD at 256 VGPRs, 130 KB of LDS), so the collective's workgroups would otherwise wait for the kernel's tail — or, when
    // they win the race for a CU at its start, hold back one pruning workgroup for as long as the all-reduce waits for its peers.
    // Free at the benchmark's sizes: 10^6 / N patterns in 128-pattern tiles take 31 / 16 / 8 / 4 rounds on 254 CUs as on 256.
