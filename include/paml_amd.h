@@ -92,6 +92,15 @@ int paml_amd_comm_unique_id(void *id128);
 int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id128, long n_patt_global, long first_pattern);
 int paml_amd_comm_destroy(paml_amd_engine *e);
 int paml_amd_comm_info(const paml_amd_engine *e, int *rank, int *world, long *n_patt_global, long *first_pattern, int *chunk);
+/* Diagnostics of the exchange step (no reference counterpart; what `bench.py --gpus N` prints so that a scaling run explains
+ * itself).  enable != 0 switches timed events on for the evaluations that follow (also: PAML_AMD_COMM_STATS=1), 0 off.  With
+ * non-NULL outputs it reports, over the last *n (<= 64) evaluations whose exchange step ran on the engine's collective stream
+ * — the caller has flushed and synchronised the stream —
+ *   exchange_us:  partial sums ready -> total formed (the all-reduce over the ranks + the fixed-order total), mean and maximum;
+ *   lane_wait_us: how long an evaluation's pruning stream stood in front of the previous exchange of its slot (0 when the
+ *                 exchange had finished before the stream got there), mean and maximum. */
+int paml_amd_comm_stats(paml_amd_engine *e, int enable, int *n, double *exchange_us_mean, double *exchange_us_max,
+                        double *lane_wait_us_mean, double *lane_wait_us_max);
 
 /* Launch all work on this hipStream_t (default: the null stream). */
 int paml_amd_set_stream(paml_amd_engine *e, void *hip_stream);
@@ -218,14 +227,20 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
  * of the reference.  Like the reference (ReRootTree treespace.c:236 marks the nodes on the path, com.oldconP[a] = 0 at
  * line 250; updateconP treesub.c:7982 recomputes only those), the engine keeps the partials of BOTH sides of every edge
  * it has visited resident in HBM between calls: moving to a neighbouring branch recomputes the one or two nodes on the
- * path, a changed branch length only the partials that look across it.  The contraction reads the two resident partials
- * (on the matrix cores for 21..64 states), builds P, dP, ddP for all trial lengths in one batched kernel, and there is
- * one host synchronisation per call.  Scaling nodes keep rescaling; their factors are stored with the partials.
+ * path, a changed branch length only the partials that look across it.  The contraction reads the two resident partials;
+ * for 21..64 states with (U, V, Root) eigen systems and one gene it works in the eigen basis (f(t) = sum_k e^{mu_k t} z_k w_k,
+ * w = V A, z = U^T (pi o B): two matrix-core products per pattern for any number of trial lengths and derivatives, the
+ * coefficients z_k w_k kept for further calls on the same branch), otherwise it builds P, dP, ddP for all trial lengths in one
+ * batched kernel as lfuntdd does.  One host synchronisation per call.  Scaling nodes keep rescaling; their factors are stored
+ * with the partials.
  * Any set_tips / set_tree / set_eigen_* / set_classes call drops the resident partials. */
 int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *t, const double *branch,
                          const double *gene_rate, double *lnL, double *dlnL, double *ddlnL);
 /* Work done by paml_amd_eval_branch so far: calls, and internal-node partials recomputed (a full tree costs n_nodes - n_tips). */
 int paml_amd_branch_counters(const paml_amd_engine *e, long *n_calls, long *n_nodes_recomputed);
+/* eval_branch calls so far that were served from the stored eigen-basis coefficients of the branch (21..64 states: a further
+ * trial length on the branch just evaluated needs no matrix product; kernels_branch.h). */
+long paml_amd_branch_coef_hits(const paml_amd_engine *e);
 /* Parity accessor: the per-block partial sums of the last eval_branch, [rows][cols = 3 n_t] at their global block positions
  * (after the all-reduce when a communicator is attached) — summed in a fixed order they give lnL, dlnL, ddlnL with the same bits
  * for every number of ranks.  out = NULL: the shape only. */

@@ -206,6 +206,15 @@ __device__ __forceinline__ void wait_blocks_in_flight(int n)   // allow the n ne
    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// a tip's factors gathered straight from its (L2-resident) column table in global memory
+__device__ __forceinline__ void tip_gather(const double *Ptip, long tipstride, int tip, int code, int q, double2 (&v)[8])
+{
+   const int row = code * 4 + q, swz = TIP_SWZ(row);
+   const double2 *pt = (const double2 *)(Ptip + (long)tip * tipstride + row * 16);
+#pragma unroll
+   for (int i = 0; i < 8; i++) v[i] = pt[i ^ swz];     // piece i lives in slot i ^ swz (see pmat_kernel)
+}
+
 __device__ __forceinline__ void tip_lds(const double *tab, int code, int q, int lane, double2 (&v)[8])
 {
 #ifdef ABL_NO_TIPLOAD

@@ -7,6 +7,17 @@
 namespace paml_amd {
 namespace {
 
+// the contraction kernel's instantiations: [how A is obtained][B is a tip]
+typedef void (*beig_fn)(BranchEigArgs);
+beig_fn const beig_kernels[6][2] = {
+   {branch_eig_kernel<0, false, false, false>, branch_eig_kernel<0, false, false, true>},      // A resident
+   {branch_eig_kernel<1, true, false, false>, branch_eig_kernel<1, true, false, true>},        // one son, internal
+   {branch_eig_kernel<1, false, false, false>, branch_eig_kernel<1, false, false, true>},      // one son, a tip
+   {branch_eig_kernel<2, true, true, false>, branch_eig_kernel<2, true, true, true>},          // two internal sons
+   {branch_eig_kernel<2, true, false, false>, branch_eig_kernel<2, true, false, true>},        // an internal son and a tip
+   {branch_eig_kernel<2, false, false, false>, branch_eig_kernel<2, false, false, true>},      // two tips
+};
+
 // Run `prog` with the full-featured kernels (gather / valu) over all patterns and classes, reading the P(t) buffers
 // of the last pmat launch; OP_EXPORT writes to export_buf.  Used by the branch-local evaluation.
 int run_prune_full(paml_amd_engine *e, const Program &prog, double *export_buf, double *export_scale)
@@ -167,6 +178,8 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    if (!bc.valid || (int)bc.up.size() != nn || bc.K != K || bc.gr != gr) {
       bc.up.assign(nn, -2); bc.ok.assign(nn, 0); bc.br.assign(nn, -1.0); bc.gr = gr; bc.K = K;
       bc.valid = true;
+      bc.coef_ok = false;
+      bc.frag_ok.clear();
    }
    {  // branch lengths that changed since the partials were formed
       std::vector<int> changed;
@@ -240,6 +253,187 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       e->eigen_dirty = false;
    }
    HIPCHK(upload(e->d_gene_rate, gr.data(), gr.size(), st));
+   // ---- the eigen-basis form (kernels_branch.h): matrix-core engines with one gene and (U, V, Root) eigen systems ------------------
+   bool eig = mfma && G == 1 && e->n_pi == 1 && !e->env.no_branch_eig && (size_t)(K * BEIG_NT * 192 + 8 * 3 * BEIG_NT) * 8 <= 150 * 1024;
+   for (const EigenHost &h : e->eigen) eig = eig && h.kind == PAML_AMD_EIGEN_UVROOT;
+   if (eig) {
+      const int n_groups = e->n_tiles_full * GATHER_WAVES, n_out = 3 * n_t;
+      const int chunk = e->chunk, cg = chunk / 16, nb_local = (e->n_patt + chunk - 1) / chunk, nbg = e->nb_global;
+      const bool hit = bc.coef_ok && bc.coef_node == node_b && clean[A] && (b_tip || clean[Bn]) && !e->env.no_coef_cache;
+      if (!e->beig_attr_set) {
+         for (auto &row : beig_kernels)
+            for (auto fn : row) HIPCHK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+         HIPCHK(hipFuncSetAttribute((const void *)branch_poly_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+         e->beig_attr_set = true;
+      }
+      HIPCHK(e->d_bl_coef.ensure((size_t)K * n_groups * 1024));
+      const int NL = e->n_labels, lab_b = T.label[node_b];
+      if ((size_t)NL * K * 2 * 4096 > e->d_bl_efrag.cap || (size_t)NL * K * e->n_codes * 64 > e->d_bl_ztab.cap || (int)bc.frag_ok.size() != NL) {
+         HIPCHK(e->d_bl_efrag.ensure((size_t)NL * K * 2 * 4096));
+         HIPCHK(e->d_bl_ztab.ensure((size_t)NL * K * e->n_codes * 64));
+         bc.frag_ok.assign(NL, 0);
+      }
+      if (lab_b < 0 || lab_b >= NL) return fail(e, PAML_AMD_EINVAL, "eval_branch: branch label out of range");
+      double *const efrag = e->d_bl_efrag.p + (size_t)lab_b * K * 2 * 4096, *const ztab = e->d_bl_ztab.p + (size_t)lab_b * K * e->n_codes * 64;
+      HIPCHK(e->d_bl_etab.ensure((size_t)K * n_t * 192));
+      HIPCHK(e->d_bpartial.ensure((size_t)nbg * n_out));
+      HIPCHK(e->d_bout.ensure((size_t)n_out));
+      HIPCHK(e->d_tt.ensure(n_t));
+      e->bpart_rows = nbg; e->bpart_cols = n_out;
+      if (nbg != nb_local) HIPCHK(hipMemsetAsync(e->d_bpartial.p, 0, (size_t)nbg * n_out * sizeof(double), st));      // (the other ranks' rows)
+      int n_sons = 0, son[2] = {-1, -1};
+      Program prog;
+      bool run_pmat = false;
+      if (!hit && any_dirty) {
+         // A itself is formed inside the contraction kernel when it has one or two sons in the tree seen from the branch (what
+         // changes when minbranches moves on to a neighbouring branch); everything else that is dirty goes through the interpreter
+         std::vector<int> roots;
+         if (!clean[A]) {
+            const int ns = tr.sons_ptr[A + 1] - tr.sons_ptr[A];
+            if (!scaled && (ns == 1 || ns == 2)) {
+               for (int j = tr.sons_ptr[A]; j < tr.sons_ptr[A + 1]; j++) son[n_sons++] = tr.sons[j];
+               if (n_sons == 2 && T.is_leaf(son[0]) && !T.is_leaf(son[1])) std::swap(son[0], son[1]);      // (an internal son first: its product initialises the partial)
+               for (int j = 0; j < n_sons; j++)
+                  if (!T.is_leaf(son[j]) && !clean[son[j]]) roots.push_back(son[j]);
+            }
+            else roots.push_back(A);
+         }
+         if (!b_tip && !clean[Bn]) roots.push_back(Bn);
+         for (int rt : roots) {
+            tr.root = rt;
+            Program ps = build_program(tr, true, clean.data());
+            for (const Op &o : ps.ops)
+               if (o.code != OP_ROOT && o.code != OP_END) prog.ops.push_back(o);
+            prog.max_stack = std::max(prog.max_stack, ps.max_stack);
+         }
+         tr.root = A;
+         run_pmat = true;
+      }
+      const bool run_prog = !prog.ops.empty();
+      if (run_prog) {
+         prog.ops.push_back({OP_END, 0, 0, -1});
+         int next = -1;
+         for (int i = (int)prog.ops.size() - 1; i >= 0; i--)
+            if (prog.ops[i].code == OP_MATMUL || prog.ops[i].code == OP_MATMUL_POP) { prog.ops[i].c = next; next = prog.ops[i].a; }
+         prog.first_matmul = next;
+      }
+      // the call's small inputs: one pinned arena, asynchronous copies
+      HIPCHK(e->stage.begin((size_t)n_t * 8 + (run_pmat ? (size_t)nn * 12 : 0) + (run_prog ? prog.ops.size() * sizeof(Op) : 0) + 256));
+      {
+         const double *ht = e->stage.put(t, (size_t)n_t);
+         HIPCHK(hipMemcpyAsync(e->d_tt.p, ht, (size_t)n_t * 8, hipMemcpyHostToDevice, st));
+      }
+      if (run_pmat) {
+         HIPCHK(e->d_label_eff.ensure(nn));
+         HIPCHK(e->d_branch.ensure(nn));
+         const int *hl = e->stage.put(lab_eff.data(), (size_t)nn);
+         HIPCHK(hipMemcpyAsync(e->d_label_eff.p, hl, (size_t)nn * 4, hipMemcpyHostToDevice, st));
+         const double *hb = e->stage.put(br_eff.data(), (size_t)nn);
+         HIPCHK(hipMemcpyAsync(e->d_branch.p, hb, (size_t)nn * 8, hipMemcpyHostToDevice, st));
+      }
+      if (run_prog) {
+         HIPCHK(e->d_ops_tmp.ensure(prog.ops.size()));
+         const Op *ho = e->stage.put(prog.ops.data(), prog.ops.size());
+         HIPCHK(hipMemcpyAsync(e->d_ops_tmp.p, ho, prog.ops.size() * sizeof(Op), hipMemcpyHostToDevice, st));
+      }
+      HIPCHK(e->stage.end(st));
+      if (run_pmat) {
+         HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
+         HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
+         HIPCHK(e->d_ptip.ensure((size_t)psets * nn * tip_words(e)));
+         PmatArgs pa{};
+         pa.n = n; pa.n_nodes = nn; pa.root = A; pa.K = K; pa.n_genes = G; pa.n_labels = e->n_labels;
+         pa.n_codes = e->n_codes; pa.layout = 1;
+         pa.label = e->d_label_eff.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
+         pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
+         pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
+         pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
+         pa.B = 1; pa.rate_gs = e->rate_per_gene ? K : 0;
+         InlineVec iv;
+         iv.n_branch = iv.n_rate = 0;
+         launch_pmat(pa, iv, nn, psets, false, st);
+         e->n_pmat += (long)psets * (nn - 2);
+         e->prog_valid = false;      // d_branch / P buffers now hold re-oriented edge data: the next eval rebuilds
+         e->pmat_valid = false;
+      }
+      if (run_prog) {
+         const int n_blocks = e->n_tiles_full * K;
+         int overflow = 0;
+         if (prog.max_stack > MFMA_RS) {
+            overflow = prog.max_stack - MFMA_RS;
+            HIPCHK(e->d_stack.ensure((size_t)n_blocks * overflow * GATHER_WAVES * 1024));
+         }
+         PruneArgs pr{};
+         pr.ops = e->d_ops_tmp.p; pr.z = e->d_z.p; pr.z_stride = e->n_patt; pr.tiles = e->d_tiles_full.p; pr.n_tiles = e->n_tiles_full;
+         pr.gene_off = e->d_gene_off.p; pr.weights = e->d_weights.p;
+         pr.n = n; pr.n_tips = e->n_tips; pr.n_nodes = nn; pr.K = K; pr.n_genes = G; pr.n_codes = e->n_codes;
+         pr.cleandata = e->cleandata; pr.n_pi = e->n_pi; pr.mode = e->mode; pr.n_scale = T.n_scale; pr.keep = 1; pr.n_patt = e->n_patt;
+         pr.pi = e->d_pi.p; pr.pint = e->d_pint.p; pr.ptip = e->d_ptip.p;
+         HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
+         pr.fhK = e->d_fhK.p; pr.partials = e->d_bl_partials.p; pr.scalef = e->d_bl_scalef.p; pr.stack_scratch = e->d_stack.p;
+         pr.stack_overflow_slots = overflow; pr.first_matmul = prog.first_matmul; pr.n_int = n_int;
+         pr.first_tip = -1; pr.tip_words = (long)tip_words(e);
+         launch_prune_full(e, prog.max_stack, n_blocks, pr, st);
+      }
+      EigPrepArgs ea{};
+      ea.n = n; ea.K = K; ea.n_labels = e->n_labels; ea.n_t = n_t; ea.label = T.label[node_b]; ea.n_codes = e->n_codes;
+      ea.rate_gs = e->rate_per_gene ? K : 0; ea.only_etab = (hit || bc.frag_ok[lab_b]) ? 1 : 0;      // (the operand-order matrices depend on the eigen systems only)
+      bc.frag_ok[lab_b] = 1;
+      ea.t = e->d_tt.p; ea.rate = e->d_rate.p; ea.gene_rate = e->d_gene_rate.p; ea.qfactor = e->d_qfactor.p; ea.pi = e->d_pi_plain.p;
+      ea.eigen_of = e->d_eigen_of.p; ea.eigen = e->d_eigen.p; ea.code_mask = e->d_code_mask.p;
+      ea.efrag = efrag; ea.ztab = ztab; ea.etab = e->d_bl_etab.p;
+      hipLaunchKernelGGL(branch_eigprep_kernel, dim3(K), dim3(256), 0, st, ea);
+      const bool feval = !hit && K == 1 && n_t <= BEIG_NT;
+      if (!hit) {
+         BranchEigArgs ba{};
+         ba.n = n; ba.K = K; ba.n_patt = e->n_patt; ba.n_tips = e->n_tips; ba.n_int = n_int; ba.n_nodes = nn; ba.n_groups = n_groups;
+         ba.n_scale = T.n_scale; ba.n_t = n_t; ba.n_codes = e->n_codes; ba.a_node = A; ba.b_node = Bn;
+         ba.n_sons = n_sons; ba.son[0] = son[0]; ba.son[1] = son[1]; ba.feval = feval ? 1 : 0;
+         ba.chunk_groups = cg; ba.nb_local = nb_local; ba.first_chunk = e->first_chunk; ba.n_out = n_out;
+         ba.partials = e->d_bl_partials.p; ba.scalef = scaled ? e->d_bl_scalef.p : nullptr; ba.z = e->d_z.p;
+         ba.pint = e->d_pint.p; ba.ptip = e->d_ptip.p; ba.tip_words = (long)tip_words(e);
+         ba.efrag = efrag; ba.ztab = ztab; ba.etab = e->d_bl_etab.p;
+         ba.freqK = e->d_freqK.p; ba.weights = e->d_weights.p; ba.coef = e->d_bl_coef.p; ba.partial = e->d_bpartial.p;
+         const bool i0 = n_sons > 0 && !T.is_leaf(son[0]), i1 = n_sons > 1 && !T.is_leaf(son[1]);
+         const int variant = n_sons == 0 ? 0 : (n_sons == 1 ? (i0 ? 1 : 2) : (i1 ? 3 : (i0 ? 4 : 5)));      // (two sons: the internal one, if any, comes first)
+         hipLaunchKernelGGL(beig_kernels[variant][b_tip ? 1 : 0], dim3(std::min(nb_local, e->n_cu), K), dim3(512), BEIG_LDS_BYTES, st, ba);
+         for (int v = e->n_tips; v < nn; v++) { bc.up[v] = up[v]; bc.ok[v] = 1; }
+         e->n_branch_nodes += (long)std::count(clean.begin() + e->n_tips, clean.end(), 0);
+         bc.coef_ok = true;
+         bc.coef_node = node_b;
+      }
+      else e->n_branch_coef_hits++;
+      if (!feval) {
+         BranchPolyArgs pa{};
+         pa.K = K; pa.n_patt = e->n_patt; pa.n_groups = n_groups; pa.n_scale = T.n_scale; pa.n_t = n_t;
+         pa.chunk_groups = cg; pa.nb_local = nb_local; pa.first_chunk = e->first_chunk; pa.n_out = n_out;
+         pa.coef = e->d_bl_coef.p; pa.etab = e->d_bl_etab.p; pa.scalef = scaled ? e->d_bl_scalef.p : nullptr; pa.weights = e->d_weights.p;
+         pa.partial = e->d_bpartial.p;
+         for (int it0 = 0; it0 < n_t; it0 += BEIG_NT) {
+            pa.it0 = it0; pa.nt_here = std::min(BEIG_NT, n_t - it0);
+            const size_t lds = ((size_t)K * pa.nt_here * 192 + 8 * 3 * BEIG_NT) * 8;
+            hipLaunchKernelGGL(branch_poly_kernel, dim3(std::min(nb_local, 4 * e->n_cu)), dim3(512), lds, st, pa);
+         }
+      }
+      HIPCHK(hipGetLastError());
+      if (e->comm) {
+         HIPCHK(hipEventRecord(e->ev_part[0], st));
+         HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[0], 0));
+         const ncclResult_t nr = rccl().AllReduce(e->d_bpartial.p, e->d_bpartial.p, (size_t)nbg * n_out, ncclDouble, ncclSum, e->comm, e->sc);
+         if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
+         HIPCHK(hipEventRecord(e->ev_done[0], e->sc));
+         HIPCHK(hipStreamWaitEvent(st, e->ev_done[0], 0));
+      }
+      hipLaunchKernelGGL(branch_total_kernel, dim3(n_out), dim3(1024), 0, st, (const double *)e->d_bpartial.p, nbg, n_out, e->d_bout.p);
+      HIPCHK(hipGetLastError());
+      if (int r = ensure_hout(e, (size_t)n_out)) return r;
+      HIPCHK(hipMemcpyAsync(e->h_out, e->d_bout.p, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));      // the one host synchronisation of the call
+      for (int i = 0; i < n_t; i++) { lnL[i] = e->h_out[3 * i]; dlnL[i] = e->h_out[3 * i + 1]; ddlnL[i] = e->h_out[3 * i + 2]; }
+      e->n_branch_eval++;
+      return 0;
+   }
+   bc.coef_ok = false;      // (the P / dP / ddP form below recomputes partials without the coefficients)
    if (any_dirty) {
       // the dirty partials: one program per side, run back to back in one launch of the full-featured kernels
       Program prog;
@@ -387,6 +581,8 @@ int paml_amd_branch_counters(const paml_amd_engine *e, long *n_calls, long *n_no
    if (n_nodes_recomputed) *n_nodes_recomputed = e->n_branch_nodes;
    return 0;
 }
+
+long paml_amd_branch_coef_hits(const paml_amd_engine *e) { return e ? e->n_branch_coef_hits : -1; }
 
 int paml_amd_get_branch_partials(paml_amd_engine *e, double *out, long cap, long *rows, int *cols)
 {

@@ -69,6 +69,7 @@ int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id12
       if (int rc = ensure_side_stream(e)) return rc;
    if (e->sc) HIPCHK(hipStreamSynchronize(e->sc));
    for (bool &b : e->done_pending) b = false;
+   for (bool &b : e->join_pending) b = false;
    e->red_slot = e->last_slot = 0;
    e->rank = rank; e->world = world;
    e->n_patt_global = n_patt_global; e->first_patt = first_pattern;
@@ -105,6 +106,34 @@ int paml_amd_get_partial_sums(paml_amd_engine *e, double *out, int cap)
    HIPCHK(hipMemcpyAsync(out, src, (size_t)e->nb_global * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
    return e->nb_global;
+}
+
+int paml_amd_comm_stats(paml_amd_engine *e, int enable, int *n, double *ex_mean, double *ex_max, double *lw_mean, double *lw_max)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   if (n && ex_mean && ex_max && lw_mean && lw_max) {
+      const int cnt = (int)std::min<long>(e->st_count, paml_amd_engine::NSTAT);
+      double se = 0, me = 0, sw = 0, mw = 0;
+      int got = 0;
+      for (int k = 0; k < cnt; k++) {
+         const int i = (int)((e->st_count - 1 - k) % paml_amd_engine::NSTAT);
+         float ms = 0;
+         if (hipEventElapsedTime(&ms, e->st_part[i], e->st_done[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+         double w = 0;
+         if (e->st_waited[i]) {
+            float wm = 0;
+            if (hipEventElapsedTime(&wm, e->st_w0[i], e->st_w1[i]) == hipSuccess) w = wm * 1e3;
+            else (void)hipGetLastError();
+         }
+         se += ms * 1e3; me = std::max(me, (double)ms * 1e3); sw += w; mw = std::max(mw, w);
+         got++;
+      }
+      *n = got;
+      *ex_mean = got ? se / got : 0; *ex_max = me; *lw_mean = got ? sw / got : 0; *lw_max = mw;
+   }
+   e->comm_stats = enable != 0;
+   if (!enable) e->st_count = 0;
+   return 0;
 }
 
 int paml_amd_comm_info(const paml_amd_engine *e, int *rank, int *world, long *n_patt_global, long *first_pattern, int *chunk)

@@ -19,6 +19,7 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    e->n = n_states; e->n_tips = n_tips; e->n_patt = n_patt; e->max_classes = max_classes; e->n_genes = n_genes;
    e->flags = flags;
    e->env.read();
+   e->comm_stats = e->env.comm_stats;
    if (e->env.comm_cus >= 0) e->comm_cus = e->env.comm_cus;
    if (e->env.lanes) e->n_lanes = std::min(std::max(e->env.lanes, 2), (int)paml_amd_engine::MAXL);
    if (hipGetDevice(&e->device) != hipSuccess ||

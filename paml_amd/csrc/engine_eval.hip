@@ -424,6 +424,12 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    if (!offload && !side_total)
       if (int rc = join_comm(e)) return rc;
    const int slot = (side_total || offload) ? e->red_slot : 0;
+   if (e->comm_stats && !e->st_part[0])
+      for (int i = 0; i < paml_amd_engine::NSTAT; i++) {
+         HIPCHK(hipEventCreate(&e->st_part[i])); HIPCHK(hipEventCreate(&e->st_done[i]));
+         HIPCHK(hipEventCreate(&e->st_w0[i])); HIPCHK(hipEventCreate(&e->st_w1[i]));
+      }
+   if (e->comm_stats) e->st_waited[e->st_count % paml_amd_engine::NSTAT] = false;
    DevBuf<double> &dpart = e->part_slot(slot);
    if ((size_t)nbg * B > dpart.cap) {
       if (e->sc) HIPCHK(hipStreamSynchronize(e->sc));      // (reallocation: nothing may still be reading the old buffer)
@@ -437,9 +443,16 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    auto wait_slot = [&]() -> int {      // main stream: the reduction that last read this slot (two evaluations ago) is done
       if (slot_waited) return 0;
       slot_waited = true;
-      if ((side_total || offload) && e->done_pending[slot]) {
+      if (e->done_pending[slot]) {
          e->done_pending[slot] = false;
-         HIPCHK(hipStreamWaitEvent(ms, e->ev_done[slot], 0));
+         // (the caller's stream, once joined to that total by flush / enter, is already behind it; any other stream waits here)
+         if (ms != e->stream || e->join_pending[slot]) {
+            const int si = (int)(e->st_count % paml_amd_engine::NSTAT);
+            if (e->comm_stats) HIPCHK(hipEventRecord(e->st_w0[si], ms));
+            HIPCHK(hipStreamWaitEvent(ms, e->ev_done[slot], 0));
+            if (e->comm_stats) { HIPCHK(hipEventRecord(e->st_w1[si], ms)); e->st_waited[si] = true; }
+            if (ms == e->stream) e->join_pending[slot] = false;
+         }
       }
       return 0;
    };
@@ -603,6 +616,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          HIPCHK(hipEventRecord(e->ev_part[slot], ms));
          HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[slot], 0));
       }
+      if (e->comm_stats) HIPCHK(hipEventRecord(e->st_part[e->st_count % paml_amd_engine::NSTAT], e->sc));      // (on `sc`, behind the wait: "partial sums ready")
       if (e->comm) {
          const ncclResult_t nr = rccl().AllReduce(dpart.p, dtot.p, (size_t)nbg * B, ncclDouble, ncclSum, e->comm, e->sc);
          if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
@@ -611,8 +625,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    }
    else if (!tail && nbg > 1) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, rs, (const double *)dpart.p, nbg, ra.out);      // (one block per element: stage 1 wrote the total)
    if (side_total || offload) {
+      if (e->comm_stats && side_total) { HIPCHK(hipEventRecord(e->st_done[e->st_count % paml_amd_engine::NSTAT], e->sc)); e->st_count++; }
       HIPCHK(hipEventRecord(e->ev_done[slot], e->sc));
       e->done_pending[slot] = true;
+      e->join_pending[slot] = true;
       e->last_slot = slot;
       e->red_slot = (slot + 1) % e->n_lanes;
    }

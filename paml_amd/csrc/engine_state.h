@@ -154,11 +154,14 @@ struct EnvCfg {
    bool force_stream = false;
    bool offload = false;
    bool dual = true;
+   bool no_coef_cache = false;      // PAML_AMD_NO_COEF_CACHE (measurements): every eval_branch call forms the coefficients again
+   bool no_branch_eig = false;      // PAML_AMD_NO_BRANCH_EIG: eval_branch in the P / dP / ddP form (round 2's kernels) also where the eigen-basis form applies
    bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false, no_m20 = false;
    int jit_waves = 0, comm_cus = -1, lanes = 0;
    std::string jit_dump, prof_ops;
    int prof_tid = 0;
    bool prof_tiles = false;      // the dump is a workgroup timeline (jit.h proft) instead of per-op stamps
+   bool comm_stats = false;
    void read()
    {
       no_pipeline = getenv("PAML_AMD_NO_PIPELINE") != nullptr;
@@ -172,8 +175,11 @@ struct EnvCfg {
       no_fused = getenv("PAML_AMD_NO_FUSED") != nullptr;
       mfma4 = getenv("PAML_AMD_MFMA4") != nullptr;
       no_m20 = getenv("PAML_AMD_NO_M20") != nullptr;
+      no_branch_eig = getenv("PAML_AMD_NO_BRANCH_EIG") != nullptr;
+      no_coef_cache = getenv("PAML_AMD_NO_COEF_CACHE") != nullptr;
       tail = getenv("PAML_AMD_TAIL") != nullptr;
       if (const char *v = getenv("PAML_AMD_COMM_CUS")) comm_cus = atoi(v);
+      comm_stats = getenv("PAML_AMD_COMM_STATS") != nullptr;
       if (const char *v = getenv("PAML_AMD_LANES")) lanes = atoi(v);      // evaluations of a run in flight at once (2 .. 4; default 2: three measured 5 % slower, four 25 %)
       if (const char *v = getenv("PAML_AMD_JIT_WAVES")) jit_waves = atoi(v);        // experiment: the last workgroup forms the total instead of a stage-2 launch
       if (const char *v = getenv("PAML_AMD_JIT_DUMP")) jit_dump = v;
@@ -218,7 +224,19 @@ struct paml_amd_engine {
    static constexpr int MAXL = 4;     // slots of (class likelihoods, partial sums, all-reduced copy): the evaluations in flight
    int n_lanes = 2;                   // ... in use (PAML_AMD_LANES), taken in rotation
    hipEvent_t ev_part[MAXL] = {}, ev_done[MAXL] = {};
-   bool done_pending[MAXL] = {};
+   // Two facts per slot.  done_pending: an exchange step queued on `sc` may still be reading the slot's buffers — whoever writes the
+   // slot next makes ITS stream wait for ev_done (wait_slot in launch_eval).  join_pending: the caller's stream has not been made to
+   // wait for that total yet (paml_amd_flush / enter).  A flush in the middle of a run clears only the second: the slot's next
+   // writer may run on a pruning stream the flush did not touch.
+   bool done_pending[MAXL] = {}, join_pending[MAXL] = {};
+   // PAML_AMD_COMM_STATS=1 / paml_amd_comm_stats: timed events around the exchange step of the last evaluations of a run (a ring):
+   // exchange = partial sums ready -> total formed (all-reduce + stage 2 on `sc`), lane wait = how long the evaluation's pruning
+   // stream sat in front of its slot's previous exchange.  Off by default (timed events cost a few microseconds each).
+   static constexpr int NSTAT = 64;
+   bool comm_stats = false;
+   hipEvent_t st_part[NSTAT] = {}, st_done[NSTAT] = {}, st_w0[NSTAT] = {}, st_w1[NSTAT] = {};
+   bool st_waited[NSTAT] = {};
+   long st_count = 0;
    int red_slot = 0, last_slot = 0;
    // CUs the persistent pruning kernels of SINGLE evaluations leave free while the engine has a communicator (runs of evaluations
    // on two pruning streams take every CU, see engine_eval.hip): their workgroups fill a CU (two waves
@@ -250,8 +268,15 @@ struct paml_amd_engine {
       std::vector<int> up;            // up[v]: the neighbour v's stored partial looks away from
       std::vector<char> ok;           // the stored partial of internal node v is current
       std::vector<double> br, gr;     // branch lengths (by lower node) and gene rates the partials were formed with
+      // eigen-basis form (kernels_branch.h): the coefficients c_k of the branch `coef_node` are in d_bl_coef, formed from the current
+      // partials of its two ends — further trial lengths on that branch need no matrix product
+      bool coef_ok = false;
+      int coef_node = -1;
+      std::vector<char> frag_ok;      // per branch label: V / U^T diag(pi) in operand order and the tips' z rows are in d_bl_efrag / d_bl_ztab
    } bl;
-   DevBuf<double> d_bl_partials, d_bl_scalef, d_bl_frag;
+   DevBuf<double> d_bl_partials, d_bl_scalef, d_bl_frag, d_bl_coef, d_bl_efrag, d_bl_ztab, d_bl_etab;
+   bool beig_attr_set = false;
+   long n_branch_coef_hits = 0;      // eval_branch calls served from the stored coefficients
    DevBuf<unsigned long long> d_code_mask;      // per character code: bit s = state s belongs to it
    long n_branch_eval = 0, n_branch_nodes = 0;
 
@@ -358,6 +383,9 @@ struct paml_amd_engine {
          if (ev_part[b]) (void)hipEventDestroy(ev_part[b]);
          if (ev_done[b]) (void)hipEventDestroy(ev_done[b]);
       }
+      for (int i = 0; i < NSTAT; i++)
+         for (hipEvent_t ev : {st_part[i], st_done[i], st_w0[i], st_w1[i]})
+            if (ev) (void)hipEventDestroy(ev);
       if (h_out) (void)hipHostFree(h_out);
       for (int ln = 0; ln < MAXL && d_prof && env.prof_tiles && prof_words; ln++) {      // the last launch's workgroup timeline (of each pruning stream: <dump>, <dump>.1 ..)
          std::vector<unsigned long long> hp(prof_words);
@@ -384,6 +412,7 @@ struct paml_amd_engine {
       d_zpm.release();
       d_red_counter.release();
       d_bl_partials.release(); d_bl_scalef.release(); d_bl_frag.release(); d_code_mask.release();
+      d_bl_coef.release(); d_bl_efrag.release(); d_bl_ztab.release(); d_bl_etab.release();
       d_ops.release();
       d_ops_tmp.release();
       d_label_eff.release();
@@ -476,11 +505,15 @@ inline hipError_t create_engine_stream(hipStream_t *s)
 inline int ensure_side_stream(paml_amd_engine *e)
 {
    if (e->sc) return 0;
-   if (create_engine_stream(&e->sc) != hipSuccess) return fail(e, PAML_AMD_EHIP, "hipStreamCreate(side stream)");
+   hipStream_t sc = nullptr;
+   if (create_engine_stream(&sc) != hipSuccess) return fail(e, PAML_AMD_EHIP, "hipStreamCreate(side stream)");
    for (int b = 0; b < paml_amd_engine::MAXL; b++)
-      if (hipEventCreateWithFlags(&e->ev_part[b], hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming) != hipSuccess)
+      if ((!e->ev_part[b] && hipEventCreateWithFlags(&e->ev_part[b], hipEventDisableTiming) != hipSuccess) ||
+          (!e->ev_done[b] && hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming) != hipSuccess)) {
+         (void)hipStreamDestroy(sc);      // (a later call starts over: `sc` is only published with all its events)
          return fail(e, PAML_AMD_EHIP, "hipEventCreate(side stream)");
+      }
+   e->sc = sc;
    return 0;
 }
 
@@ -488,8 +521,8 @@ inline int ensure_side_stream(paml_amd_engine *e)
 inline int join_comm(paml_amd_engine *e)
 {
    for (int b = 0; b < paml_amd_engine::MAXL; b++)
-      if (e->done_pending[b]) {
-         e->done_pending[b] = false;
+      if (e->join_pending[b]) {
+         e->join_pending[b] = false;      // (done_pending stays: the slot's next writer may be another stream, see launch_eval's wait_slot)
          if (hipStreamWaitEvent(e->stream, e->ev_done[b], 0) != hipSuccess) return fail(e, PAML_AMD_EHIP, "hipStreamWaitEvent(collective stream)");
       }
    return 0;

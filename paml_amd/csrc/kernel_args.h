@@ -107,6 +107,50 @@ struct BranchMfmaArgs {
    double *partial;                    // [n_tiles][n_t][3] (this launch fills trial length `it`)
 };
 
+// Branch-local evaluation in the eigen basis (kernels_branch.h: branch_eigprep_kernel, branch_eig_kernel, branch_poly_kernel).
+// With P(t) = U diag(e^{mu_k t}) V the contraction of lfuntdd factorises:
+//   f(t) = sum_i pi_i B_i (P(t) A)_i = sum_k e^{mu_k t} z_k w_k,   w = V A,   z = U^T (pi o B),
+// and f', f'' take mu_k e^{mu_k t}, mu_k^2 e^{mu_k t}: TWO matrix products per pattern whatever the number of trial lengths and
+// derivatives (the P / dP / ddP form needs three per trial length), and the 64 coefficients c_k = z_k w_k per pattern and class,
+// kept in HBM, serve every further trial length on the same branch with no matrix product at all.
+#define BEIG_NT 4      /* trial lengths evaluated per launch (more: further launches of the polynomial kernel on the stored coefficients) */
+struct EigPrepArgs {
+   int n, K, n_labels, n_t, label, n_codes, rate_gs, only_etab;
+   const double *t;                     // [n_t]
+   const double *rate, *gene_rate, *qfactor, *pi;      // pi: plain [n]
+   const int *eigen_of;                 // [K][n_labels] (one gene)
+   const EigenDev *eigen;
+   const unsigned long long *code_mask; // [n_codes]
+   double *efrag;                       // [K][2][4096]: V, then U^T diag(pi), both in MFMA A-operand order (rows = eigen index k)
+   double *ztab;                        // [K][n_codes][64]: z of a tip's code, element q*16 + m = z_{4m+q}
+   double *etab;                        // [K][n_t][3][64]: e^{mu t}, mu e^{mu t}, mu^2 e^{mu t}, element q*16 + m = k = 4m+q (k = 0: 1, 0, 0)
+};
+
+struct BranchEigArgs {
+   int n, K, n_patt, n_tips, n_int, n_nodes, n_groups, n_scale, n_t, n_codes;
+   int a_node, b_node;                  // the branch's two ends; b may be a tip
+   int n_sons, son[2];                  // n_sons > 0: A's partial is formed here from its sons in the tree seen from the branch (then stored)
+   int feval;                           // K == 1: lnL, dlnL, ddlnL of the n_t (<= BEIG_NT) trial lengths are formed in the same pass
+   int chunk_groups, nb_local, first_chunk, n_out;      // partial sums: one row of n_out = 3 n_t per chunk of 16 * chunk_groups patterns, at global chunk positions
+   double *partials;                    // [K][n_int][n_groups][1024]  (read; A's slot written when n_sons > 0)
+   const double *scalef;                // [K][n_scale][n_patt] or null
+   const unsigned char *z;              // [n_tips][n_patt]
+   const double *pint;                  // [K][n_nodes][4096]
+   const double *ptip;                  // [K][n_nodes][tip_words]
+   long tip_words;
+   const double *efrag, *ztab, *etab;
+   const double *freqK, *weights;
+   double *coef;                        // [K][n_groups][1024]: c_k (x freqK x the class's scale factor relative to the pattern's largest)
+   double *partial;                     // [nb_global][n_out]
+};
+
+struct BranchPolyArgs {
+   int K, n_patt, n_groups, n_scale, n_t, it0, nt_here;      // this launch: trial lengths it0 .. it0 + nt_here - 1 of n_t
+   int chunk_groups, nb_local, first_chunk, n_out;
+   const double *coef, *etab, *scalef, *weights;
+   double *partial;
+};
+
 // Node posteriors (kernels_branch.h)
 struct PostArgs {
    int n, K, n_genes, n_patt, n_pi;

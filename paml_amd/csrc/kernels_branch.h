@@ -271,6 +271,354 @@ __global__ __launch_bounds__(256) void branch_reduce_kernel(const double *partia
    }
 }
 
+// ---- the contraction in the eigen basis (21..64 states, one gene, (U, V, Root) eigen systems) -------------------------------------
+// lfuntdd's f_h(t) = sum_i pi_i B_i sum_j P_ij(t) A_j with P(t) = U diag(e^{mu_k t}) V is  sum_k e^{mu_k t} z_k w_k  with
+// w = V A and z = U^T (pi o B): two matrix products per pattern for ANY number of trial lengths and for f, f', f'' alike (the
+// reference's form, and round 2's kernel, spend three per trial length: P, dP, ddP), and the coefficients c_k = z_k w_k — one
+// 64-vector per pattern and class, kept in HBM beside the partials — serve every further trial length on the same branch with
+// no matrix product at all (minbranches asks for l, l', l'' at t0 and then for up to four trial lengths per Newton step, on the
+// same branch: treesub.c:8039-8117).  B a tip: z is a table row of the tip's code, one product per pattern.
+//
+// branch_eigprep_kernel   per class: V and U^T diag(pi) in MFMA A-operand order, the tips' z rows, e^{mu t} {1, mu, mu^2} per trial length
+// branch_eig_kernel       persistent workgroups (8 waves, one class per blockIdx.y, its <= 4 matrices resident in LDS for the launch);
+//                         a wave owns 16 patterns at a time: A (read, or formed from its sons' partials / tip rows and written back —
+//                         the one node whose orientation changes when minbranches moves to the next branch), w = V A, z, c -> HBM;
+//                         with one class also f, f', f'' of up to BEIG_NT trial lengths and the chunk's three sums per trial length
+// branch_poly_kernel      f, f', f'' from the stored coefficients: the class mixture, more than BEIG_NT trial lengths, every later call
+// branch_total_kernel     fixed-order total of the chunk rows (after the all-reduce over the ranks, when there are ranks)
+// Chunks are the evaluation's reduction chunks (a function of the GLOBAL pattern count): row r of `partial` is chunk r of the whole
+// alignment whatever the number of ranks, and a chunk's sum is formed in one fixed order (a wave's patterns in sequence, the 64
+// lanes by butterfly, the 8 waves pairwise).
+__global__ __launch_bounds__(256) void branch_eigprep_kernel(EigPrepArgs a)
+{
+   const int iclass = blockIdx.x, n = a.n, tid = threadIdx.x;
+   const EigenDev es = a.eigen[a.eigen_of[iclass * a.n_labels + a.label]];
+   const double base = a.gene_rate[0] * a.rate[iclass] * a.qfactor[iclass * a.n_labels + a.label];      // treesub.c:8479: rgene * _rateSite * Qfactor (x Root[k])
+   double *et = a.etab + (long)iclass * a.n_t * 192;
+   for (int idx = tid; idx < a.n_t * 64; idx += 256) {
+      const int it = idx >> 6, el = idx & 63, k = 4 * (el & 15) + (el >> 4);
+      double e0 = 0, e1 = 0, e2 = 0;
+      if (k == 0) e0 = 1.0;      // (the k = 0 term is exp(0) and drops out of the derivatives, as in lfuntdd)
+      else if (k < n) {
+         const double mu = base * es.Root[k];
+         e0 = exp(a.t[it] * mu); e1 = e0 * mu; e2 = e1 * mu;
+      }
+      et[(it * 3 + 0) * 64 + el] = e0; et[(it * 3 + 1) * 64 + el] = e1; et[(it * 3 + 2) * 64 + el] = e2;
+   }
+   if (a.only_etab) return;
+   // element ((kb2*4 + jb)*64 + lane)*2 + e  =  M[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)], zero padded (pmat_kernel's order)
+   double *fv = a.efrag + (long)iclass * 2 * 4096, *fu = fv + 4096;
+   for (int idx = tid; idx < 4096; idx += 256) {
+      const int e = idx & 1, lane = (idx >> 1) & 63, jb = (idx >> 7) & 3, kb2 = idx >> 9;
+      const int r = jb * 16 + (lane & 15), c = 4 * (2 * kb2 + e) + (lane >> 4);
+      const bool in = r < n && c < n;
+      fv[idx] = in ? es.V[r * n + c] : 0.0;                    // w_k = sum_j V[k][j] A_j
+      fu[idx] = in ? es.U[c * n + r] * a.pi[c] : 0.0;          // z_k = sum_i U[i][k] pi_i B_i
+   }
+   double *zt = a.ztab + (long)iclass * a.n_codes * 64;
+   for (int idx = tid; idx < a.n_codes * 64; idx += 256) {
+      const int code = idx >> 6, el = idx & 63, k = 4 * (el & 15) + (el >> 4);
+      const unsigned long long mask = a.code_mask[code];
+      double s = 0;
+      if (k < n)
+         for (int i = 0; i < n; i++)
+            if ((mask >> i) & 1ull) s += es.U[i * n + k] * a.pi[i];
+      zt[idx] = s;
+   }
+}
+
+__device__ __forceinline__ void beig_load(const double *p, int lane, v4d (&x)[4])
+{
+#pragma unroll
+   for (int m = 0; m < 16; m++) x[m >> 2][m & 3] = p[m * 64 + lane];
+}
+__device__ __forceinline__ void beig_store(double *p, int lane, const v4d (&x)[4])
+{
+#pragma unroll
+   for (int m = 0; m < 16; m++) p[m * 64 + lane] = x[m >> 2][m & 3];
+}
+// g[d] += sum_m c_m E_d[k = 4m + q]: the lane's share of f, f', f'' for one trial length (et: [3][64] in LDS, element q*16 + m)
+__device__ __forceinline__ void beig_poly(const v4d (&c)[4], const double *et, int q, double (&g)[3])
+{
+#pragma unroll
+   for (int d = 0; d < 3; d++) {
+      const v4d *e = (const v4d *)(et + d * 64 + q * 16);
+      double s = g[d];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+         const v4d ev = e[i];
+         s = fma(c[i].x, ev.x, s); s = fma(c[i].y, ev.y, s); s = fma(c[i].z, ev.z, s); s = fma(c[i].w, ev.w, s);
+      }
+      g[d] = s;
+   }
+}
+// The lanes' shares of f, f', f'' for up to four trial lengths -> lane (q, pattern) ends up with the pattern's totals of trial length
+// it = q: a reduce-scatter over the four state-quarter lanes of a pattern (nine exchanges where four all-reduces take twenty-four),
+// after which the logarithm and the divisions are done once per pattern and trial length, not by every lane for every trial length.
+__device__ __forceinline__ void beig_scatter(const double (&g)[BEIG_NT][3], int q, double (&t)[3])
+{
+   static_assert(BEIG_NT == 4, "one trial length per state-quarter lane");
+   const bool hi = (q & 2) != 0, odd = (q & 1) != 0;
+#pragma unroll
+   for (int d = 0; d < 3; d++) {
+      const double k0 = (hi ? g[2][d] : g[0][d]) + __shfl_xor(hi ? g[0][d] : g[2][d], 32);
+      const double k1 = (hi ? g[3][d] : g[1][d]) + __shfl_xor(hi ? g[1][d] : g[3][d], 32);
+      t[d] = (odd ? k1 : k0) + __shfl_xor(odd ? k0 : k1, 16);
+   }
+}
+// the pattern's three terms for the lane's trial length: log f (+ the scale factors), f'/f, (f f'' - f'^2)/f^2, weighted (treesub.c:8285-8292)
+__device__ __forceinline__ void beig_terms(const double (&t)[3], bool take, double w, double smax, double (&acc)[3])
+{
+   if (take) {
+      acc[0] += (log(t[0]) + smax) * w;
+      acc[1] += t[1] / t[0] * w;
+      acc[2] += (t[0] * t[2] - t[1] * t[1]) / (t[0] * t[0]) * w;
+   }
+}
+// a chunk's sums: over the wave's sixteen patterns by butterfly (lane 16 q holds trial length q), the eight waves pairwise; every
+// thread of the workgroup comes here
+__device__ __forceinline__ void beig_chunk_store(const double (&acc)[3], int nt, double *sRed, int wave, int lane, double *row)
+{
+#pragma unroll
+   for (int d = 0; d < 3; d++) {
+      double v = acc[d];
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if ((lane & 15) == 0) sRed[wave * (3 * BEIG_NT) + (lane >> 4) * 3 + d] = v;
+   }
+   __syncthreads();
+   if ((int)threadIdx.x < 3 * nt) {
+      const double *r = sRed + threadIdx.x;
+      constexpr int S = 3 * BEIG_NT;
+      row[threadIdx.x] = ((r[0] + r[S]) + (r[2 * S] + r[3 * S])) + ((r[4 * S] + r[5 * S]) + (r[6 * S] + r[7 * S]));
+   }
+   __syncthreads();
+}
+// the pattern's summed scale factors per class, relative to the largest (lfuntdd_SiteClass treesub.c:8316-8332 uses its own pivot)
+__device__ __forceinline__ double beig_smax(const double *scalef, int K, int n_scale, int n_patt, int hc)
+{
+   double smax = -1e300;
+   for (int ir = 0; ir < K; ir++) {
+      double s = 0;
+      for (int k = 0; k < n_scale; k++) s += scalef[((long)ir * n_scale + k) * n_patt + hc];
+      smax = s > smax ? s : smax;
+   }
+   return smax;
+}
+
+#define BEIG_LDS_BYTES ((4 * 4096 + BEIG_NT * 192 + 8 * 3 * BEIG_NT) * 8)
+// NS: sons A's partial is formed from (0: A is resident), S0I / S1I: that son is an internal node (else a tip), BTIP: B is a tip —
+// compile-time, so that every instantiation is straight-line code the register allocator can fit into 256 VGPRs without spilling
+template <int NS, bool S0I, bool S1I, bool BTIP>
+__global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
+{
+   constexpr int WAVES = 8;
+   extern __shared__ __attribute__((aligned(16))) double beig_smem[];
+   double *sV = beig_smem, *sUt = sV + 4096, *sP0 = sUt + 4096, *sP1 = sP0 + 4096, *sE = sP1 + 4096, *sRed = sE + BEIG_NT * 192;
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int q = lane >> 4, hl = lane & 15;
+   const int iclass = blockIdx.y;
+   constexpr bool b_tip = BTIP, s0_int = NS > 0 && S0I, s1_int = NS > 1 && S1I;
+   const double *ef = a.efrag + (long)iclass * 2 * 4096;
+   const double *Pint = a.pint + (long)iclass * a.n_nodes * 4096;
+   const double *Ptip = a.ptip + (long)iclass * a.n_nodes * a.tip_words;
+   stage_p<WAVES>(ef, sV, wave, lane);
+   if (!b_tip) stage_p<WAVES>(ef + 4096, sUt, wave, lane);
+   if (s0_int) stage_p<WAVES>(Pint + (long)a.son[0] * 4096, sP0, wave, lane);
+   if (s1_int) stage_p<WAVES>(Pint + (long)a.son[1] * 4096, sP1, wave, lane);
+   if (a.feval)
+      for (int idx = tid; idx < a.n_t * 192; idx += WAVES * 64) sE[idx] = a.etab[(long)iclass * a.n_t * 192 + idx];
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+   __syncthreads();
+
+   const long G = a.n_groups;
+   double *pclass = a.partials + (long)iclass * a.n_int * G * 1024;
+   double *cclass = a.coef + (long)iclass * G * 1024;
+   const double *zt = a.ztab + (long)iclass * a.n_codes * 64 + q * 16;
+   const double fk = a.freqK[iclass];
+   // The operand a group's work starts with — A itself, or the partial of A's first internal son — is requested one group ahead
+   // (`pf`), and so are the character codes of the tips involved; the other operands (second son, B, tip rows) at points where a
+   // product in front of their use hides their latency, and the two waves of a SIMD overlap the rest.
+   const double *first_base = NS == 0 ? pclass + (long)(a.a_node - a.n_tips) * G * 1024
+                                      : (s0_int ? pclass + (long)(a.son[0] - a.n_tips) * G * 1024 : nullptr);
+   constexpr bool t0 = NS > 0 && !S0I, t1 = NS > 1 && !S1I;      // tip sons
+   const unsigned char *z0 = a.z + (long)(t0 ? a.son[0] : 0) * a.n_patt, *z1 = a.z + (long)(t1 ? a.son[1] : 0) * a.n_patt,
+                       *zb = a.z + (long)(b_tip ? a.b_node : 0) * a.n_patt;
+   auto g_begin = [&](int lc) { return lc * a.chunk_groups + wave; };
+   auto g_stop = [&](int lc) { return min((lc + 1) * a.chunk_groups, a.n_groups); };
+   v4d pf[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+   int c0 = 0, c1 = 0, cb = 0;
+   if ((int)blockIdx.x < a.nb_local && g_begin(blockIdx.x) < g_stop(blockIdx.x)) {
+      const int g = g_begin(blockIdx.x), hc = min(g * 16 + hl, a.n_patt - 1);
+      if (first_base) beig_load(first_base + (long)g * 1024, lane, pf);
+      if (t0) c0 = z0[hc];
+      if (t1) c1 = z1[hc];
+      if (b_tip) cb = zb[hc];
+   }
+   for (int lc = blockIdx.x; lc < a.nb_local; lc += gridDim.x) {
+      double acc[3] = {0, 0, 0};
+      const int g_end = g_stop(lc);
+      for (int g = g_begin(lc); g < g_end; g += WAVES) {
+         int gn = g + WAVES;      // this wave's next group (possibly in the workgroup's next chunk), -1: none
+         if (gn >= g_end) {
+            const int ln = lc + gridDim.x;
+            gn = (ln < a.nb_local && g_begin(ln) < g_stop(ln)) ? g_begin(ln) : -1;
+         }
+         const int h = g * 16 + hl;
+         const bool valid = h < a.n_patt;
+         const int hc = valid ? h : a.n_patt - 1, hn = gn >= 0 ? min(gn * 16 + hl, a.n_patt - 1) : 0;
+         int c0n = 0, c1n = 0, cbn = 0;
+         if (gn >= 0) {
+            if (t0) c0n = z0[hn];
+            if (t1) c1n = z1[hn];
+            if (b_tip) cbn = zb[hn];
+         }
+         v4d s1[4], bb[4], w[4], zz[4];
+         double2 v1[8];
+         if constexpr (NS == 0) {
+            if constexpr (b_tip) {
+               const v4d *zp = (const v4d *)(zt + (long)cb * 64);
+#pragma unroll
+               for (int i = 0; i < 4; i++) zz[i] = zp[i];
+            }
+            else beig_load(pclass + ((long)(a.b_node - a.n_tips) * G + g) * 1024, lane, bb);
+            jit_matvec<false, 4, 16>(sV, lane, pf, w);
+            if (gn >= 0) beig_load(first_base + (long)gn * 1024, lane, pf);
+         }
+         else {
+            // A's partial in the tree seen from this branch: the product of its sons' messages (ConditionalPNode, codeml.c:3545-3576)
+            v4d x[4];
+            if constexpr (s1_int) beig_load(pclass + ((long)(a.son[1] - a.n_tips) * G + g) * 1024, lane, s1);
+            if constexpr (t1) tip_gather(Ptip, a.tip_words, a.son[1], c1, q, v1);
+            if constexpr (s0_int) {
+               jit_matvec<false, 4, 16>(sP0, lane, pf, x);
+               if (gn >= 0) beig_load(first_base + (long)gn * 1024, lane, pf);
+            }
+            else {
+               double2 v[8];
+               tip_gather(Ptip, a.tip_words, a.son[0], c0, q, v);
+#pragma unroll
+               for (int i = 0; i < 8; i++) { x[i >> 1][(2 * i) & 3] = v[i].x; x[i >> 1][(2 * i + 1) & 3] = v[i].y; }
+            }
+            if constexpr (NS > 1) {
+               if constexpr (s1_int) {
+                  v4d y[4];
+                  jit_matvec<false, 4, 16>(sP1, lane, s1, y);
+#pragma unroll
+                  for (int i = 0; i < 4; i++) x[i] = x[i] * y[i];
+               }
+               else {
+#pragma unroll
+                  for (int i = 0; i < 8; i++) { x[i >> 1][(2 * i) & 3] *= v1[i].x; x[i >> 1][(2 * i + 1) & 3] *= v1[i].y; }
+               }
+            }
+            if constexpr (b_tip) {
+               const v4d *zp = (const v4d *)(zt + (long)cb * 64);
+#pragma unroll
+               for (int i = 0; i < 4; i++) zz[i] = zp[i];
+            }
+            else beig_load(pclass + ((long)(a.b_node - a.n_tips) * G + g) * 1024, lane, bb);
+            beig_store(pclass + ((long)(a.a_node - a.n_tips) * G + g) * 1024, lane, x);
+            jit_matvec<false, 4, 16>(sV, lane, x, w);
+         }
+         if constexpr (!b_tip) jit_matvec<false, 4, 16>(sUt, lane, bb, zz);
+         double wgt = fk, smax = 0;
+         if (a.scalef) {
+            smax = beig_smax(a.scalef, a.K, a.n_scale, a.n_patt, hc);
+            double s = 0;
+            for (int k = 0; k < a.n_scale; k++) s += a.scalef[((long)iclass * a.n_scale + k) * a.n_patt + hc];
+            wgt = fk * exp(s - smax);
+         }
+         v4d c[4];
+#pragma unroll
+         for (int i = 0; i < 4; i++) c[i] = (w[i] * zz[i]) * wgt;
+         beig_store(cclass + (long)g * 1024, lane, c);
+         if (a.feval) {
+            double g4[BEIG_NT][3];
+#pragma unroll
+            for (int it = 0; it < BEIG_NT; it++) {
+               g4[it][0] = g4[it][1] = g4[it][2] = 0;
+               if (it < a.n_t) beig_poly(c, sE + it * 192, q, g4[it]);
+            }
+            double t3[3];
+            beig_scatter(g4, q, t3);
+            const double wt = a.weights[hc];
+            beig_terms(t3, valid && q < a.n_t && wt > 0, wt, smax, acc);
+         }
+         c0 = c0n; c1 = c1n; cb = cbn;
+      }
+      if (a.feval) beig_chunk_store(acc, a.n_t, sRed, wave, lane, a.partial + (long)(a.first_chunk + lc) * a.n_out);
+   }
+}
+
+// dynamic LDS: K x nt_here x 192 doubles of e^{mu t} tables + the reduction scratch
+__global__ __launch_bounds__(512) void branch_poly_kernel(BranchPolyArgs a)
+{
+   constexpr int WAVES = 8;
+   extern __shared__ __attribute__((aligned(16))) double bpoly_smem[];
+   double *sE = bpoly_smem, *sRed = sE + (long)a.K * a.nt_here * 192;
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int q = lane >> 4, hl = lane & 15;
+   for (int idx = tid; idx < a.K * a.nt_here * 192; idx += WAVES * 64) {
+      const int ir = idx / (a.nt_here * 192), r = idx % (a.nt_here * 192);
+      sE[idx] = a.etab[((long)ir * a.n_t + a.it0) * 192 + r];
+   }
+   __syncthreads();
+   const long G = a.n_groups;
+   for (int lc = blockIdx.x; lc < a.nb_local; lc += gridDim.x) {
+      double acc[3] = {0, 0, 0};
+      const int g_end = min((lc + 1) * a.chunk_groups, a.n_groups);
+      v4d pf[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};      // the coefficients one (class, group) step ahead
+      if (lc * a.chunk_groups + wave < g_end) beig_load(a.coef + (long)(lc * a.chunk_groups + wave) * 1024, lane, pf);
+      for (int g = lc * a.chunk_groups + wave; g < g_end; g += WAVES) {
+         const int h = g * 16 + hl;
+         const bool valid = h < a.n_patt;
+         const int hc = valid ? h : a.n_patt - 1;
+         double gs[BEIG_NT][3];
+#pragma unroll
+         for (int it = 0; it < BEIG_NT; it++) gs[it][0] = gs[it][1] = gs[it][2] = 0;
+         for (int ir = 0; ir < a.K; ir++) {
+            v4d c[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) c[i] = pf[i];
+            if (ir + 1 < a.K) beig_load(a.coef + ((long)(ir + 1) * G + g) * 1024, lane, pf);
+            else if (g + WAVES < g_end) beig_load(a.coef + (long)(g + WAVES) * 1024, lane, pf);
+#pragma unroll
+            for (int it = 0; it < BEIG_NT; it++)
+               if (it < a.nt_here) beig_poly(c, sE + ((long)ir * a.nt_here + it) * 192, q, gs[it]);
+         }
+         const double smax = a.scalef ? beig_smax(a.scalef, a.K, a.n_scale, a.n_patt, hc) : 0.0;
+         const double wt = a.weights[hc];
+         double t3[3];
+         beig_scatter(gs, q, t3);
+         beig_terms(t3, valid && q < a.nt_here && wt > 0, wt, smax, acc);
+      }
+      beig_chunk_store(acc, a.nt_here, sRed, wave, lane, a.partial + (long)(a.first_chunk + lc) * a.n_out + a.it0 * 3);
+   }
+}
+
+// one workgroup per output: the fixed-order total of column o of the chunk rows
+__global__ __launch_bounds__(1024) void branch_total_kernel(const double *partial, int nb, int n_out, double *out)
+{
+   __shared__ double sw[16];
+   const int o = blockIdx.x;
+   double acc = 0;
+   for (int i = threadIdx.x; i < nb; i += 1024) acc += partial[(long)i * n_out + o];
+#pragma unroll
+   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+   if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      double t[16];
+      for (int i = 0; i < 16; i++) t[i] = sw[i];
+      for (int s = 1; s < 16; s <<= 1)
+         for (int i = 0; i + s < 16; i += 2 * s) t[i] += t[i + s];
+      out[o] = t[0];
+   }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Marginal posterior of the states at a node (PostProbNode treesub.c:6142, AncestralMarginal 6288): with the tree rooted
 // at the node, L[k][h][i] = exported partial of class k; post[h][i] = sum_k freqK_k pi_i L[k][h][i] e^{S_k} / sum_i(...).

@@ -155,13 +155,6 @@ namespace paml_amd {
 
 // ---- mfma64 "gather": tip columns gathered straight from the L2-resident tables into registers.
 // Used for trees with more than MFMA_ZT tips; 4 waves (64 patterns) per workgroup, 2 workgroups per CU.
-__device__ __forceinline__ void tip_gather(const double *Ptip, long tipstride, int tip, int code, int q, double2 (&v)[8])
-{
-   const int row = code * 4 + q, swz = TIP_SWZ(row);
-   const double2 *pt = (const double2 *)(Ptip + (long)tip * tipstride + row * 16);
-#pragma unroll
-   for (int i = 0; i < 8; i++) v[i] = pt[i ^ swz];     // piece i lives in slot i ^ swz (see pmat_kernel)
-}
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_gather(PruneArgs a)

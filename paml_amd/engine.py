@@ -26,7 +26,7 @@ EXPORTS = [
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_qrev_batch", "paml_amd_get_eigen", "paml_amd_eigen_counters", "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
-    "paml_amd_device_count", "paml_amd_set_device", "paml_amd_shard_bounds", "paml_amd_max_ranks", "paml_amd_flush", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_get_partial_sums", "paml_amd_branch_counters",
+    "paml_amd_device_count", "paml_amd_set_device", "paml_amd_shard_bounds", "paml_amd_max_ranks", "paml_amd_flush", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_comm_stats", "paml_amd_get_partial_sums", "paml_amd_branch_counters", "paml_amd_branch_coef_hits",
     "paml_amd_jit_prebuild", "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
@@ -166,6 +166,18 @@ class Engine:
         ng, fp = C.c_long(), C.c_long()
         self._L.paml_amd_comm_info(self._h, C.byref(r), C.byref(w), C.byref(ng), C.byref(fp), C.byref(ch))
         return dict(rank=r.value, world=w.value, n_patt_global=ng.value, first_pattern=fp.value, chunk=ch.value)
+
+    def comm_stats(self, enable=True, read=False):
+        """Timed events around the exchange step (paml_amd_comm_stats).  read=True returns the figures of the last <= 64
+        evaluations (flush and synchronise first): dict(n, exchange_us, exchange_us_max, lane_wait_us, lane_wait_us_max)."""
+        self._L.paml_amd_comm_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)] + [C.POINTER(C.c_double)] * 4
+        if not read:
+            self._chk(self._L.paml_amd_comm_stats(self._h, int(bool(enable)), None, None, None, None, None))
+            return None
+        n = C.c_int()
+        v = [C.c_double() for _ in range(4)]
+        self._chk(self._L.paml_amd_comm_stats(self._h, int(bool(enable)), C.byref(n), *[C.byref(x) for x in v]))
+        return dict(n=n.value, exchange_us=v[0].value, exchange_us_max=v[1].value, lane_wait_us=v[2].value, lane_wait_us_max=v[3].value)
 
     def partial_sums(self):
         """Per-chunk partial sums of the last evaluation at their global positions (paml_amd_get_partial_sums)."""
@@ -368,7 +380,9 @@ class Engine:
         a, b = C.c_long(), C.c_long()
         self._L.paml_amd_branch_counters.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
         self._L.paml_amd_branch_counters(self._h, C.byref(a), C.byref(b))
-        return dict(n_calls=a.value, n_nodes=b.value)
+        self._L.paml_amd_branch_coef_hits.restype = C.c_long
+        self._L.paml_amd_branch_coef_hits.argtypes = [C.c_void_p]
+        return dict(n_calls=a.value, n_nodes=b.value, coef_hits=self._L.paml_amd_branch_coef_hits(self._h))
 
     def node_posterior(self, node, branch, gene_rate=None):
         """Posterior probabilities of the states at an internal node, [n_patt][n] (paml_amd_node_posterior)."""

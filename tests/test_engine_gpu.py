@@ -983,3 +983,95 @@ def test_eval_branch_partial_cache_cycles_like_minbranches(n, K, scale):
     l, _, _ = eng.eval_branch(b, np.array([t.branch[b]]), t.branch, pb.gene_rate)
     assert abs(l[0] - oracle.eval_branch(pb, b, np.array([t.branch[b]]))[0][0]) <= 1e-11 * abs(base)
     assert 0 < eng.branch_counters()["n_nodes"] - before < n_int
+
+
+@pytest.mark.parametrize("K,amb,scale", [(1, False, None), (1, True, None), (3, False, None), (2, True, 3)])
+def test_eval_branch_eigen_basis_walk_cache_and_many_trial_lengths(K, amb, scale, monkeypatch):
+    """61 states: the contraction in the eigen basis (kernels_branch.h).  A minbranches-style walk with several calls per branch —
+    the first forms the coefficients (A from its sons inside the kernel when only its orientation changed), the later ones are
+    served from them — with 1, 4 and 7 trial lengths (more than one launch handles), against the oracle and against the
+    P / dP / ddP form of the same engine build (PAML_AMD_NO_BRANCH_EIG)."""
+    pb = helpers.random_problem(61, 11, 700, K=K, seed=900 + K, ambiguity=amb, scale_every=scale)
+    eng = engine_for(pb)
+    monkeypatch.setenv("PAML_AMD_NO_BRANCH_EIG", "1")
+    old = engine_for(pb)
+    monkeypatch.delenv("PAML_AMD_NO_BRANCH_EIG")
+    t = pb.tree
+    order = []
+
+    def pre(i):
+        for c in t.sons[i]:
+            order.append(c)
+            pre(c)
+    pre(t.root)
+    rng = np.random.default_rng(3)
+    calls = 0
+    for b in order:
+        for nt in (1, 4, 7):
+            ts = np.concatenate([[t.branch[b]], t.branch[b] * rng.uniform(0.3, 2.0, nt - 1) + 1e-3])
+            l, dl, ddl = eng.eval_branch(b, ts, t.branch, pb.gene_rate)
+            rl, rdl, rddl = oracle.eval_branch(pb, b, ts)
+            ol, odl, oddl = old.eval_branch(b, ts, t.branch, pb.gene_rate)
+            calls += 1
+            assert np.allclose(l, rl, rtol=1e-11, atol=0), (b, nt, l, rl)
+            assert np.allclose(dl, rdl, rtol=1e-9, atol=1e-9), (b, nt, dl, rdl)
+            assert np.allclose(ddl, rddl, rtol=1e-9, atol=1e-8), (b, nt, ddl, rddl)
+            assert np.allclose(l, ol, rtol=1e-12, atol=0) and np.allclose(dl, odl, rtol=1e-9, atol=1e-9) and np.allclose(ddl, oddl, rtol=1e-9, atol=1e-8)
+        # the same trial lengths again: served from the coefficients, bit for bit what the forming call returned for them
+        l2, dl2, ddl2 = eng.eval_branch(b, ts[:4], t.branch, pb.gene_rate)
+        calls += 1
+        l4, dl4, ddl4 = eng.eval_branch(b, ts[:4], t.branch, pb.gene_rate)
+        calls += 1
+        assert (l2 == l4).all() and (dl2 == dl4).all() and (ddl2 == ddl4).all()
+        assert np.allclose(l2, l[:4], rtol=1e-13, atol=0)
+        t.branch[b] = float(ts[-1]) if rng.random() < 0.6 else t.branch[b]
+    c = eng.branch_counters()
+    assert c["n_calls"] == calls and c["coef_hits"] == calls - len(order), c      # one forming call per branch
+    assert old.branch_counters()["coef_hits"] == 0
+    base = eng.eval(t.branch, pb.gene_rate)["lnL"]
+    l, _, _ = eng.eval_branch(order[2], np.array([t.branch[order[2]]]), t.branch, pb.gene_rate)
+    assert abs(l[0] - base) <= 1e-11 * abs(base)
+
+
+def test_eval_branch_at_1e5_patterns_against_the_oracle():
+    """The branch-local evaluation at a size where every workgroup walks several chunks: 16 taxa x 131 072 codon patterns, a tip
+    branch, an internal branch and a move to its neighbour (A re-formed inside the kernel), four trial lengths, against the oracle."""
+    pb = synth.codon_m0_problem(n_tips=16, n_patt=131_072)
+    eng = engine_for(pb)
+    t = pb.tree
+    base = eng.eval(t.branch)["lnL"]
+    internal = [v for v in range(t.n_tips, t.n_nodes) if v != t.root]
+    for b in (3, internal[0], internal[1], internal[-1]):
+        ts = np.array([t.branch[b], 0.5 * t.branch[b], 0.05, 0.8])
+        l, dl, ddl = eng.eval_branch(b, ts, t.branch)
+        rl, rdl, rddl = oracle.eval_branch(pb, b, ts)
+        assert np.allclose(l, rl, rtol=1e-12, atol=0), (b, l, rl)
+        assert np.allclose(dl, rdl, rtol=1e-9, atol=1e-7) and np.allclose(ddl, rddl, rtol=1e-9, atol=1e-6), (b, dl, rdl, ddl, rddl)
+        assert abs(l[0] - base) <= 1e-12 * abs(base)
+    assert eng.branch_counters()["n_nodes"] < 2 * (t.n_nodes - t.n_tips)
+
+
+def test_eval_branch_full_size_c4_reproduces_the_reference_lnl():
+    """BASELINE configs[3] at full size through the branch-local path: l(t_current) on any branch is the tree's lnL, which the
+    unmodified reference printed for this data (-15822122.733473, golden syn_codon_m0_full); 7.2 GB of partials resident, the walk
+    re-forms one or two nodes per call, the derivatives agree with central differences of l along the branch."""
+    g = helpers.load_golden("syn_codon_m0_full")
+    pb = helpers.problem_from_golden(g)
+    assert pb.n_patt == 1_000_000
+    eng = engine_for(pb)
+    t = pb.tree
+    internal = [v for v in range(t.n_tips, t.n_nodes) if v != t.root]
+    for b in (0, internal[0], internal[1], 7, internal[-1]):
+        t0 = t.branch[b]
+        hstep = 1e-4
+        ts = np.array([t0, t0 - hstep, t0 + hstep])
+        l, dl, ddl = eng.eval_branch(b, ts, t.branch)
+        assert abs(l[0] - g["lnL"]) <= 2e-6 + 1e-12 * abs(g["lnL"]), (b, l[0], g["lnL"])
+        fd1 = (l[2] - l[1]) / (2 * hstep)
+        fd2 = (l[2] - 2 * l[0] + l[1]) / hstep ** 2
+        # (central differences over 2e-4: their own truncation error, third derivative x h^2 / 6 with a third derivative of ~1e8 on
+        #  the short branches, sets the tolerance; the derivatives are pinned by the oracle at 131 072 patterns above)
+        assert abs(dl[0] - fd1) <= 1e-3 * abs(fd1) + 1.0, (b, dl[0], fd1)
+        assert abs(ddl[0] - fd2) <= 2e-2 * abs(fd2) + 100.0, (b, ddl[0], fd2)
+    c = eng.branch_counters()
+    assert c["n_nodes"] <= (t.n_nodes - t.n_tips) + 3 * 4

@@ -28,16 +28,16 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def shim_env():
+def shim_env(**extra):
     if not os.path.exists(SHIM):
         subprocess.check_call(["make", "-C", os.path.join(HERE, "shim")])
-    return dict(os.environ, PAML_AMD_RCCL_LIB=SHIM)
+    return dict(os.environ, PAML_AMD_RCCL_LIB=SHIM, **extra)
 
 
-def run_ranks(world, case, tmp_path):
-    xdir = tmp_path / ("%s_w%d" % (case, world))
+def run_ranks(world, case, tmp_path, **extra_env):
+    xdir = tmp_path / ("%s_w%d%s" % (case, world, "".join("_" + v for v in extra_env.values())))
     xdir.mkdir()
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(xdir), case], env=shim_env(),
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(xdir), case], env=shim_env(**extra_env),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     try:
@@ -77,6 +77,17 @@ def test_two_ranks_with_overlapping_pruning_kernels(tmp_path):
         for key in ("eval", "eval_device", "eval_batch", "eval_again", "eval_branch", "kernel"):
             assert r[key] == one[key], (key, r[key], one[key])
     assert one["kernel"] == "mfma64_jit" and len(set(one["eval_device"])) == len(one["eval_device"])
+
+
+def test_two_ranks_with_a_collective_that_needs_a_cu_and_waits_for_its_peers(tmp_path):
+    """The stand-in's device mode: ncclAllReduce returns at once; a kernel on the collective stream — 512 threads, 64 KB of LDS, a CU of
+    its own — publishes the rank's partial sums, spins until the peer's have arrived and 20 us have passed, and adds them up.  The
+    persistent pruning kernels of both ranks (two pruning streams each) compete with it for the CUs.  Same bits as the one engine."""
+    one = run_ranks(1, "codon_big", tmp_path)[0]
+    res = run_ranks(2, "codon_big", tmp_path, PAML_AMD_SHIM_DEVICE_US="20")
+    for r in res:
+        for key in ("eval", "eval_device", "eval_batch", "eval_again", "eval_branch", "kernel"):
+            assert r[key] == one[key], (key, r[key], one[key])
 
 
 def test_bench_on_two_ranks_of_one_gpu(tmp_path):
