@@ -216,6 +216,28 @@ def main():
         }
         out["roofline"].update(profiles_evidence(flops_pp * pb.n_patt if (world == 1 and args.patterns == 1_000_000 and args.taxa == 16) else None))
 
+    # ---- N > 1 (or a forced one-rank communicator): what the exchange step did, per evaluation, so that a scaling run explains itself:
+    # exchange_us = partial sums ready -> total formed (all-reduce over the ranks + fixed-order total, on the engine's collective stream);
+    # lane_wait_us = how long an evaluation's pruning stream stood in front of its slot's previous exchange (the event pair that
+    # measures it costs ~12 us itself: that is the floor).  64 evaluations with timed events, AFTER the timed region.
+    if world > 1 or force_comm:
+        eng.comm_stats(True)
+        dst = torch.zeros(64, dtype=torch.float64, device="cuda")
+        for i in range(64):
+            eng.eval_device(branch, dst.data_ptr() + 8 * i)
+        eng.flush()
+        fence()
+        st = eng.comm_stats(False, read=True)
+        box = [st]
+        if world > 1:
+            box = [None] * world
+            dist.all_gather_object(box, st)
+        if rank == 0:
+            out["exchange"] = {"evaluations": st["n"], "exchange_us": max(b["exchange_us"] for b in box), "exchange_us_max": max(b["exchange_us_max"] for b in box),
+                               "lane_wait_us": max(b["lane_wait_us"] for b in box), "lane_wait_us_max": max(b["lane_wait_us_max"] for b in box),
+                               "per_rank": box, "pruning_streams": 2 if os.environ.get("PAML_AMD_DUAL", "1") != "0" else 1,
+                               "note": "means over the evaluations, maximum over the ranks; lane_wait_us includes ~12 us of its own event pair"}
+
     extras = not args.no_extras
     if extras:
         # the same loop with the scalar read back to the host after every evaluation (what a serial optimiser waits for)
@@ -315,6 +337,11 @@ def main():
         out["c2"] = bench_c2(engine, synth, timed, args)
         out["c2_batch"] = bench_c2_batch(engine, synth, fence)
         out["aa20"] = bench_aa20(engine, synth, timed, args)
+        if pb.n == 61:
+            try:
+                out["branch"] = bench_branch(engine, pb_full if args.scaling == "strong" else pb, lnl)
+            except Exception as ex:      # noqa: BLE001  (reported, the headline stands)
+                out["branch"] = {"error": repr(ex)}
         for key, fn in (("c1", bench_c1), ("c3", bench_c3), ("c5", bench_c5)):      # the small-data configurations: latency, not throughput
             try:
                 out[key] = fn(engine, timed, fence)
@@ -529,6 +556,87 @@ def reference_mle_seconds_hiv_m0():
         return None
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def bench_branch(engine, pb, lnl_full):
+    """The branch-local evaluation (paml_amd_eval_branch = lfuntdd / lfunt on resident partials, what minbranches calls per Newton step:
+    treesub.c:8039-8117, 8204-8296) on the headline data.  Wall time per call — every call ends with its one host synchronisation —
+    as minbranches issues them, and the contraction kernel's own duration by HIP events.
+      form: the first evaluation on a branch (the eigen-basis coefficients are formed: two matrix products per pattern, A and B read,
+            the coefficients written);  walk: moving to the next branch of the pre-order walk first (the re-oriented node re-formed
+            inside the same kernel);  hit: further trial lengths on the branch (from the stored coefficients, no matrix product).
+    Roofline of the forming kernel on an internal branch: max(HBM, FP64 matrix) of the algorithm as built — 3 x 512 B and
+    2 x 2 x 61^2 flop per pattern (the reference's P / dP / ddP form would be 3 x 2 x 61^2 flop per trial length)."""
+    import numpy as np
+    t = pb.tree
+    order = []
+
+    def pre(i):
+        for c in t.sons[i]:
+            order.append(c)
+            pre(c)
+    pre(t.root)
+    father = t.father()
+    internal = [b for b in order if b >= t.n_tips and father[b] >= t.n_tips] or [b for b in order if b >= t.n_tips]
+    tips = [b for b in order if b < t.n_tips]
+
+    def call(eng, b, ts):
+        t0 = time.perf_counter()
+        l, dl, ddl = eng.eval_branch(b, np.asarray(ts, dtype=np.float64), t.branch)
+        return (time.perf_counter() - t0) * 1e3, l
+
+    eng = engine.engine_for(pb)
+    eng.eval(t.branch)
+    ms_first, l = call(eng, order[0], [t.branch[order[0]]])
+    if abs(l[0] - lnl_full) > 1e-11 * abs(lnl_full):
+        raise SystemExit("bench: eval_branch gives lnL %.9f, the evaluation %.9f" % (l[0], lnl_full))
+    c0 = eng.branch_counters()
+    form, hit1, hit4 = [], [], []
+    for cycle in range(2):
+        for b in order:
+            ms, l = call(eng, b, [t.branch[b]])
+            form.append(ms)
+            if abs(l[0] - lnl_full) > 1e-11 * abs(lnl_full):
+                raise SystemExit("bench: eval_branch on branch %d gives lnL %.9f, the evaluation %.9f" % (b, l[0], lnl_full))
+            hit1.append(call(eng, b, [t.branch[b] * 1.02])[0])
+            hit4.append(call(eng, b, t.branch[b] * (1 + 0.05 * np.arange(1, 5)))[0])
+    c1 = eng.branch_counters()
+    eng.close()
+    os.environ["PAML_AMD_NO_COEF_CACHE"] = "1"      # (measurement switch: every call forms the coefficients again)
+    try:
+        eng = engine.engine_for(pb)
+    finally:
+        del os.environ["PAML_AMD_NO_COEF_CACHE"]
+    res = {}
+    for name, b in (("internal", internal[0]), ("tip", tips[0])):
+        call(eng, b, [t.branch[b]])
+        for nt in (1, 4):
+            ts = t.branch[b] * (1 + 0.05 * np.arange(nt))
+            ms = [call(eng, b, ts)[0] for _ in range(10)]
+            eng.profile(True)
+            call(eng, b, ts)
+            kms = [0.0] * 5
+            for i in range(5):
+                call(eng, b, ts)
+                kms[i] = eng.branch_kernel_ms()
+            eng.profile(False)
+            res["same_%s_branch_form_nt%d_ms" % (name, nt)] = float(np.mean(ms))
+            res["same_%s_branch_form_nt%d_kernel_ms" % (name, nt)] = float(np.mean(kms))
+    eng.close()
+    n_int = t.n_nodes - t.n_tips
+    kms = res["same_internal_branch_form_nt1_kernel_ms"]
+    hbm_bytes, flops = 3 * 512.0 * pb.n_patt, 2 * 2 * 61.0 * 61.0 * pb.n_patt
+    t_hbm, t_mfma = hbm_bytes / 8e12 * 1e3, flops / (FP64_PEAK_TFLOPS * 1e12) * 1e3
+    return dict(workload="eval_branch (lfuntdd) on the headline data, %d taxa x %d codon patterns, M0; %.1f GB of partials + %.2f GB of coefficients resident"
+                         % (t.n_tips, pb.n_patt, 512e-9 * pb.n_patt * n_int, 512e-9 * pb.n_patt),
+                first_call_ms=ms_first, walk_form_nt1_ms=float(np.mean(form)), walk_form_nt1_ms_max=float(np.max(form)),
+                walk_hit_nt1_ms=float(np.mean(hit1)), walk_hit_nt4_ms=float(np.mean(hit4)),
+                nodes_reformed_per_walk_call=(c1["n_nodes"] - c0["n_nodes"]) / len(form), coef_hits=c1["coef_hits"], **res,
+                roofline=dict(kernel="branch_eig_kernel<0,.,.,false> (both partials resident, internal branch, nt = 1)", bound="hbm" if t_hbm >= t_mfma else "mfma",
+                              kernel_ms=kms, bytes_per_pattern=1536, flop_per_pattern=4 * 61 * 61, bound_ms=max(t_hbm, t_mfma),
+                              achieved=hbm_bytes / (kms * 1e-3) / 1e9, peak=8000.0, unit="GB/s", frac=max(t_hbm, t_mfma) / kms,
+                              mfma_tflops=flops / (kms * 1e-3) / 1e12,
+                              timing="HIP events on the engine's stream around the contraction kernel, one launch at a time"))
 
 
 def bench_aa20(engine, synth, timed, args):

@@ -241,6 +241,10 @@ int paml_amd_branch_counters(const paml_amd_engine *e, long *n_calls, long *n_no
 /* eval_branch calls so far that were served from the stored eigen-basis coefficients of the branch (21..64 states: a further
  * trial length on the branch just evaluated needs no matrix product; kernels_branch.h). */
 long paml_amd_branch_coef_hits(const paml_amd_engine *e);
+/* With paml_amd_profile(e, 1): milliseconds (HIP events on the engine's stream) between the first and the last contraction kernel of
+ * the last eval_branch call — the coefficient-forming kernel and / or the polynomial kernel(s); < 0 when the call took the
+ * P / dP / ddP form or profiling was off. */
+double paml_amd_branch_kernel_ms(paml_amd_engine *e);
 /* Parity accessor: the per-block partial sums of the last eval_branch, [rows][cols = 3 n_t] at their global block positions
  * (after the all-reduce when a communicator is attached) — summed in a fixed order they give lnL, dlnL, ddlnL with the same bits
  * for every number of ranks.  out = NULL: the shape only. */

@@ -88,6 +88,25 @@ __device__ __forceinline__ double root_value(const PruneArgs &a, double f, doubl
 }
 
 
+// Resident partials of the 21..64-state kernels (keep-partials STORE / LOAD, the branch-local evaluation, its coefficients): per
+// 16-pattern group 1024 doubles, element (m, lane) = state 4m + (lane >> 4) of pattern lane & 15 at ((m >> 1) * 64 + lane) * 2 + (m & 1)
+// — a lane's two consecutive m are one 16-byte access, a wave instruction moves 1 KB (eight per partial; 8-byte accesses, sixteen
+// per partial, are issue-bound well below the HBM rate: MI355X_MICROARCH.md, store tail).
+typedef double part2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void part_load(const double *p, int lane, double (&x)[16])
+{
+   const part2_t *p2 = (const part2_t *)p + lane;
+#pragma unroll
+   for (int i = 0; i < 8; i++) { const part2_t v = p2[i * 64]; x[2 * i] = v.x; x[2 * i + 1] = v.y; }
+}
+__device__ __forceinline__ void part_store(double *p, int lane, const double (&x)[16])
+{
+   part2_t *p2 = (part2_t *)p + lane;
+#pragma unroll
+   for (int i = 0; i < 8; i++) p2[i * 64] = (part2_t){x[2 * i], x[2 * i + 1]};
+}
+__host__ __device__ inline int part_index(int m, int lane) { return (((m >> 1) * 64 + lane) << 1) | (m & 1); }
+
 #define MFMA_RS 2      // register stack slots; deeper slots spill to global scratch
 #define MFMA_ZT 128    // most tips whose codes the dma kernel keeps in LDS
 

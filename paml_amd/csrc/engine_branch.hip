@@ -9,14 +9,17 @@ namespace {
 
 // the contraction kernel's instantiations: [how A is obtained][B is a tip]
 typedef void (*beig_fn)(BranchEigArgs);
-beig_fn const beig_kernels[6][2] = {
-   {branch_eig_kernel<0, false, false, false>, branch_eig_kernel<0, false, false, true>},      // A resident
-   {branch_eig_kernel<1, true, false, false>, branch_eig_kernel<1, true, false, true>},        // one son, internal
-   {branch_eig_kernel<1, false, false, false>, branch_eig_kernel<1, false, false, true>},      // one son, a tip
-   {branch_eig_kernel<2, true, true, false>, branch_eig_kernel<2, true, true, true>},          // two internal sons
-   {branch_eig_kernel<2, true, false, false>, branch_eig_kernel<2, true, false, true>},        // an internal son and a tip
-   {branch_eig_kernel<2, false, false, false>, branch_eig_kernel<2, false, false, true>},      // two tips
+#define BEIG_ROW(NS, S0, S1) {{branch_eig_kernel<NS, S0, S1, false, false>, branch_eig_kernel<NS, S0, S1, false, true>}, \
+                              {branch_eig_kernel<NS, S0, S1, true, false>, branch_eig_kernel<NS, S0, S1, true, true>}}
+beig_fn const beig_kernels[6][2][2] = {      // [how A is obtained][B is a tip][61 states]
+   BEIG_ROW(0, false, false),      // A resident
+   BEIG_ROW(1, true, false),       // one son, internal
+   BEIG_ROW(1, false, false),      // one son, a tip
+   BEIG_ROW(2, true, true),        // two internal sons
+   BEIG_ROW(2, true, false),       // an internal son and a tip
+   BEIG_ROW(2, false, false),      // two tips
 };
+#undef BEIG_ROW
 
 // Run `prog` with the full-featured kernels (gather / valu) over all patterns and classes, reading the P(t) buffers
 // of the last pmat launch; OP_EXPORT writes to export_buf.  Used by the branch-local evaluation.
@@ -93,6 +96,7 @@ int rerooted_pmat(paml_amd_engine *e, int new_root, int cut_son, const double *b
    if (gene_rate) gr.assign(gene_rate, gene_rate + G);
    HIPCHK(upload(e->d_branch, br.data(), br.size(), e->stream));
    HIPCHK(upload(e->d_gene_rate, gr.data(), gr.size(), e->stream));
+   e->bl_gr_sent = false;
    HIPCHK(upload(e->d_label_eff, lab.data(), lab.size(), e->stream));
    if (e->eigen_dirty) {
       std::vector<EigenDev> tab(e->eigen.size());
@@ -180,6 +184,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       bc.valid = true;
       bc.coef_ok = false;
       bc.frag_ok.clear();
+      e->bl_gr_sent = false;
    }
    {  // branch lengths that changed since the partials were formed
       std::vector<int> changed;
@@ -252,7 +257,9 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       HIPCHK(upload(e->d_eigen, tab.data(), tab.size(), st));
       e->eigen_dirty = false;
    }
-   HIPCHK(upload(e->d_gene_rate, gr.data(), gr.size(), st));
+   // (d_gene_rate is shared with the ordinary evaluation, which rewrites it: sent again unless the last writer was this function with the same rates)
+   if (!e->bl_gr_sent) { HIPCHK(upload(e->d_gene_rate, gr.data(), gr.size(), st)); }
+   e->bl_gr_sent = true;
    // ---- the eigen-basis form (kernels_branch.h): matrix-core engines with one gene and (U, V, Root) eigen systems ------------------
    bool eig = mfma && G == 1 && e->n_pi == 1 && !e->env.no_branch_eig && (size_t)(K * BEIG_NT * 192 + 8 * 3 * BEIG_NT) * 8 <= 150 * 1024;
    for (const EigenHost &h : e->eigen) eig = eig && h.kind == PAML_AMD_EIGEN_UVROOT;
@@ -262,13 +269,16 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       const bool hit = bc.coef_ok && bc.coef_node == node_b && clean[A] && (b_tip || clean[Bn]) && !e->env.no_coef_cache;
       if (!e->beig_attr_set) {
          for (auto &row : beig_kernels)
-            for (auto fn : row) HIPCHK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            for (auto &r2 : row)
+               for (auto fn : r2) HIPCHK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
          HIPCHK(hipFuncSetAttribute((const void *)branch_poly_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
          e->beig_attr_set = true;
       }
       HIPCHK(e->d_bl_coef.ensure((size_t)K * n_groups * 1024));
       const int NL = e->n_labels, lab_b = T.label[node_b];
-      if ((size_t)NL * K * 2 * 4096 > e->d_bl_efrag.cap || (size_t)NL * K * e->n_codes * 64 > e->d_bl_ztab.cap || (int)bc.frag_ok.size() != NL) {
+      if ((size_t)NL * K * 2 * 4096 > e->d_bl_efrag.cap || (size_t)NL * K * e->n_codes * 64 > e->d_bl_ztab.cap || (size_t)NL * K * 128 > e->d_bl_ecol.cap ||
+          (int)bc.frag_ok.size() != NL) {
+         HIPCHK(e->d_bl_ecol.ensure((size_t)NL * K * 128));
          HIPCHK(e->d_bl_efrag.ensure((size_t)NL * K * 2 * 4096));
          HIPCHK(e->d_bl_ztab.ensure((size_t)NL * K * e->n_codes * 64));
          bc.frag_ok.assign(NL, 0);
@@ -348,6 +358,8 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
          pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
          pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
+         HIPCHK(e->d_pcol.ensure((size_t)psets * nn * 64));
+         pa.pcol = e->d_pcol.p;
          pa.B = 1; pa.rate_gs = e->rate_per_gene ? K : 0;
          InlineVec iv;
          iv.n_branch = iv.n_rate = 0;
@@ -381,9 +393,16 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       bc.frag_ok[lab_b] = 1;
       ea.t = e->d_tt.p; ea.rate = e->d_rate.p; ea.gene_rate = e->d_gene_rate.p; ea.qfactor = e->d_qfactor.p; ea.pi = e->d_pi_plain.p;
       ea.eigen_of = e->d_eigen_of.p; ea.eigen = e->d_eigen.p; ea.code_mask = e->d_code_mask.p;
-      ea.efrag = efrag; ea.ztab = ztab; ea.etab = e->d_bl_etab.p;
+      ea.efrag = efrag; ea.ztab = ztab; ea.etab = e->d_bl_etab.p; ea.ecol = n == 61 ? e->d_bl_ecol.p + (size_t)lab_b * K * 128 : nullptr;
       hipLaunchKernelGGL(branch_eigprep_kernel, dim3(K), dim3(256), 0, st, ea);
-      const bool feval = !hit && K == 1 && n_t <= BEIG_NT;
+      static const bool exp_nofeval = getenv("PAML_AMD_BEIG_NOFEVAL") != nullptr;      // (timing experiments, profiles/r04_branch.txt)
+      const bool feval = !hit && K == 1 && n_t <= BEIG_NT && !exp_nofeval;
+      e->bk_timed = false;
+      if (e->profiling) {
+         for (hipEvent_t &ev : e->ev_bk)
+            if (!ev) HIPCHK(hipEventCreate(&ev));
+         HIPCHK(hipEventRecord(e->ev_bk[0], st));
+      }
       if (!hit) {
          BranchEigArgs ba{};
          ba.n = n; ba.K = K; ba.n_patt = e->n_patt; ba.n_tips = e->n_tips; ba.n_int = n_int; ba.n_nodes = nn; ba.n_groups = n_groups;
@@ -393,10 +412,13 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          ba.partials = e->d_bl_partials.p; ba.scalef = scaled ? e->d_bl_scalef.p : nullptr; ba.z = e->d_z.p;
          ba.pint = e->d_pint.p; ba.ptip = e->d_ptip.p; ba.tip_words = (long)tip_words(e);
          ba.efrag = efrag; ba.ztab = ztab; ba.etab = e->d_bl_etab.p;
+         ba.ecol = e->d_bl_ecol.p + (size_t)lab_b * K * 128; ba.pcol = e->d_pcol.p;
+         static const bool exp_nostore = getenv("PAML_AMD_BEIG_NOSTORE") != nullptr;      // (timing experiment: results of later calls are garbage)
+         ba.no_store = exp_nostore ? 1 : 0;
          ba.freqK = e->d_freqK.p; ba.weights = e->d_weights.p; ba.coef = e->d_bl_coef.p; ba.partial = e->d_bpartial.p;
          const bool i0 = n_sons > 0 && !T.is_leaf(son[0]), i1 = n_sons > 1 && !T.is_leaf(son[1]);
          const int variant = n_sons == 0 ? 0 : (n_sons == 1 ? (i0 ? 1 : 2) : (i1 ? 3 : (i0 ? 4 : 5)));      // (two sons: the internal one, if any, comes first)
-         hipLaunchKernelGGL(beig_kernels[variant][b_tip ? 1 : 0], dim3(std::min(nb_local, e->n_cu), K), dim3(512), BEIG_LDS_BYTES, st, ba);
+         hipLaunchKernelGGL(beig_kernels[variant][b_tip ? 1 : 0][n == 61 ? 1 : 0], dim3(std::min(nb_local, e->n_cu), K), dim3(512), BEIG_LDS_BYTES, st, ba);
          for (int v = e->n_tips; v < nn; v++) { bc.up[v] = up[v]; bc.ok[v] = 1; }
          e->n_branch_nodes += (long)std::count(clean.begin() + e->n_tips, clean.end(), 0);
          bc.coef_ok = true;
@@ -416,6 +438,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          }
       }
       HIPCHK(hipGetLastError());
+      if (e->profiling) { HIPCHK(hipEventRecord(e->ev_bk[1], st)); e->bk_timed = true; }
       if (e->comm) {
          HIPCHK(hipEventRecord(e->ev_part[0], st));
          HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[0], 0));
@@ -424,10 +447,9 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          HIPCHK(hipEventRecord(e->ev_done[0], e->sc));
          HIPCHK(hipStreamWaitEvent(st, e->ev_done[0], 0));
       }
-      hipLaunchKernelGGL(branch_total_kernel, dim3(n_out), dim3(1024), 0, st, (const double *)e->d_bpartial.p, nbg, n_out, e->d_bout.p);
-      HIPCHK(hipGetLastError());
       if (int r = ensure_hout(e, (size_t)n_out)) return r;
-      HIPCHK(hipMemcpyAsync(e->h_out, e->d_bout.p, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+      hipLaunchKernelGGL(branch_total_kernel, dim3(n_out), dim3(1024), 0, st, (const double *)e->d_bpartial.p, nbg, n_out, e->h_out);      // (pinned, device-visible: no copy)
+      HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(st));      // the one host synchronisation of the call
       for (int i = 0; i < n_t; i++) { lnL[i] = e->h_out[3 * i]; dlnL[i] = e->h_out[3 * i + 1]; ddlnL[i] = e->h_out[3 * i + 2]; }
       e->n_branch_eval++;
@@ -583,6 +605,13 @@ int paml_amd_branch_counters(const paml_amd_engine *e, long *n_calls, long *n_no
 }
 
 long paml_amd_branch_coef_hits(const paml_amd_engine *e) { return e ? e->n_branch_coef_hits : -1; }
+
+double paml_amd_branch_kernel_ms(paml_amd_engine *e)
+{
+   float ms = -1;
+   if (!e || !e->bk_timed || hipEventElapsedTime(&ms, e->ev_bk[0], e->ev_bk[1]) != hipSuccess) { (void)hipGetLastError(); return -1; }
+   return ms;
+}
 
 int paml_amd_get_branch_partials(paml_amd_engine *e, double *out, long cap, long *rows, int *cols)
 {

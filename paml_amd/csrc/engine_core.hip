@@ -456,7 +456,7 @@ int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP
    const double *src = e->d_partials.p + ((size_t)iclass * n_int + (node - e->n_tips)) * groups * 1024;
    HIPCHK(hipMemcpyAsync(raw.data(), src, raw.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
-   // native [group][m][lane] -> [h][state]; lane = (state & 3) * 16 + (h & 15), m = state >> 2
+   // native [group] x part_index(m, lane) -> [h][state]; lane = (state & 3) * 16 + (h & 15), m = state >> 2
    std::vector<int2> tiles;
    for (int g = 0; g < e->n_genes; g++)
       for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += e->tile_patt) tiles.push_back(make_int2(g, h));
@@ -467,7 +467,7 @@ int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP
             const int h = tiles[t].y + w * 16 + hl;
             if (h >= hend) continue;
             const double *grp = raw.data() + (t * MW + w) * 1024;
-            for (int j = 0; j < n; j++) conP[(size_t)h * n + j] = grp[(j >> 2) * 64 + (j & 3) * 16 + hl];
+            for (int j = 0; j < n; j++) conP[(size_t)h * n + j] = grp[part_index(j >> 2, (j & 3) * 16 + hl)];
          }
    }
    return 0;

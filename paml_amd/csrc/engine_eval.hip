@@ -183,6 +183,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
                           (new_prog ? e->prog.ops.size() * sizeof(Op) + e->prog.stream.size() * sizeof(int) : 0) + 256;
       HIPCHK(e->stage.begin(need));
       DevBuf<double> &dbr = pipe ? e->d2_branch : e->d_branch, &dgr = pipe ? e->d2_gene_rate : e->d_gene_rate;   // (the side stream has its own)
+      e->bl_gr_sent = false;
       HIPCHK(dbr.ensure((size_t)B * nn));
       HIPCHK(dgr.ensure((size_t)B * G));
       if (!use_inline) {

@@ -274,8 +274,11 @@ struct paml_amd_engine {
       int coef_node = -1;
       std::vector<char> frag_ok;      // per branch label: V / U^T diag(pi) in operand order and the tips' z rows are in d_bl_efrag / d_bl_ztab
    } bl;
-   DevBuf<double> d_bl_partials, d_bl_scalef, d_bl_frag, d_bl_coef, d_bl_efrag, d_bl_ztab, d_bl_etab;
+   DevBuf<double> d_bl_partials, d_bl_scalef, d_bl_frag, d_bl_coef, d_bl_efrag, d_bl_ztab, d_bl_etab, d_bl_ecol;
    bool beig_attr_set = false;
+   bool bl_gr_sent = false;           // d_gene_rate holds the gene rates of the branch cache (cleared by whoever else writes the buffer)
+   hipEvent_t ev_bk[2] = {};          // paml_amd_profile on: around the contraction kernel(s) of the last eval_branch (paml_amd_branch_kernel_ms)
+   bool bk_timed = false;
    long n_branch_coef_hits = 0;      // eval_branch calls served from the stored coefficients
    DevBuf<unsigned long long> d_code_mask;      // per character code: bit s = state s belongs to it
    long n_branch_eval = 0, n_branch_nodes = 0;
@@ -383,6 +386,8 @@ struct paml_amd_engine {
          if (ev_part[b]) (void)hipEventDestroy(ev_part[b]);
          if (ev_done[b]) (void)hipEventDestroy(ev_done[b]);
       }
+      for (hipEvent_t ev : ev_bk)
+         if (ev) (void)hipEventDestroy(ev);
       for (int i = 0; i < NSTAT; i++)
          for (hipEvent_t ev : {st_part[i], st_done[i], st_w0[i], st_w1[i]})
             if (ev) (void)hipEventDestroy(ev);
@@ -412,7 +417,7 @@ struct paml_amd_engine {
       d_zpm.release();
       d_red_counter.release();
       d_bl_partials.release(); d_bl_scalef.release(); d_bl_frag.release(); d_code_mask.release();
-      d_bl_coef.release(); d_bl_efrag.release(); d_bl_ztab.release(); d_bl_etab.release();
+      d_bl_coef.release(); d_bl_efrag.release(); d_bl_ztab.release(); d_bl_etab.release(); d_bl_ecol.release();
       d_ops.release();
       d_ops_tmp.release();
       d_label_eff.release();

@@ -124,12 +124,14 @@ struct EigPrepArgs {
    double *efrag;                       // [K][2][4096]: V, then U^T diag(pi), both in MFMA A-operand order (rows = eigen index k)
    double *ztab;                        // [K][n_codes][64]: z of a tip's code, element q*16 + m = z_{4m+q}
    double *etab;                        // [K][n_t][3][64]: e^{mu t}, mu e^{mu t}, mu^2 e^{mu t}, element q*16 + m = k = 4m+q (k = 0: 1, 0, 0)
+   double *ecol;                        // 61 states: [K][2][64] column 60 of V and of U^T diag(pi), element q*16 + m = row 4m+q (null: not wanted)
 };
 
 struct BranchEigArgs {
    int n, K, n_patt, n_tips, n_int, n_nodes, n_groups, n_scale, n_t, n_codes;
    int a_node, b_node;                  // the branch's two ends; b may be a tip
    int n_sons, son[2];                  // n_sons > 0: A's partial is formed here from its sons in the tree seen from the branch (then stored)
+   int no_store;                        // timing experiment: the coefficients are not written
    int feval;                           // K == 1: lnL, dlnL, ddlnL of the n_t (<= BEIG_NT) trial lengths are formed in the same pass
    int chunk_groups, nb_local, first_chunk, n_out;      // partial sums: one row of n_out = 3 n_t per chunk of 16 * chunk_groups patterns, at global chunk positions
    double *partials;                    // [K][n_int][n_groups][1024]  (read; A's slot written when n_sons > 0)
@@ -139,6 +141,7 @@ struct BranchEigArgs {
    const double *ptip;                  // [K][n_nodes][tip_words]
    long tip_words;
    const double *efrag, *ztab, *etab;
+   const double *ecol, *pcol;           // 61 states: column 60 of V / U^T diag(pi) ([K][2][64]) and of every P ([K][n_nodes][64])
    const double *freqK, *weights;
    double *coef;                        // [K][n_groups][1024]: c_k (x freqK x the class's scale factor relative to the pattern's largest)
    double *partial;                     // [nb_global][n_out]

@@ -199,8 +199,7 @@ __global__ __launch_bounds__(256, 2) void branch_mfma_kernel(BranchMfmaArgs a)
    for (int ir = 0; ir < a.K; ir++) {
       double cur[16], bv[16];
       const double *pa = a.partials + (((long)ir * a.n_int + (a.a_node - a.n_tips)) * groups + grp) * 1024;
-#pragma unroll
-      for (int m = 0; m < 16; m++) cur[m] = pa[m * 64 + lane];
+      part_load(pa, lane, cur);
       if (b_tip) {
          const unsigned long long mask = a.code_mask[a.zb[hc]];
 #pragma unroll
@@ -208,8 +207,7 @@ __global__ __launch_bounds__(256, 2) void branch_mfma_kernel(BranchMfmaArgs a)
       }
       else {
          const double *pb = a.partials + (((long)ir * a.n_int + (a.b_node - a.n_tips)) * groups + grp) * 1024;
-#pragma unroll
-         for (int m = 0; m < 16; m++) bv[m] = pb[m * 64 + lane];
+         part_load(pb, lane, bv);
       }
 #pragma unroll
       for (int m = 0; m < 16; m++) bv[m] *= pq[m];
@@ -315,6 +313,10 @@ __global__ __launch_bounds__(256) void branch_eigprep_kernel(EigPrepArgs a)
       fv[idx] = in ? es.V[r * n + c] : 0.0;                    // w_k = sum_j V[k][j] A_j
       fu[idx] = in ? es.U[c * n + r] * a.pi[c] : 0.0;          // z_k = sum_i U[i][k] pi_i B_i
    }
+   if (a.ecol && tid < 128) {      // 61 states: column 60 of both matrices as the lanes' accumulators want it (rank-1 tail of the product, jit_col_seed)
+      const int k = 4 * (tid & 15) + ((tid & 63) >> 4);
+      a.ecol[(long)iclass * 128 + tid] = k < n ? (tid < 64 ? es.V[k * n + 60] : es.U[60 * n + k] * a.pi[60]) : 0.0;
+   }
    double *zt = a.ztab + (long)iclass * a.n_codes * 64;
    for (int idx = tid; idx < a.n_codes * 64; idx += 256) {
       const int code = idx >> 6, el = idx & 63, k = 4 * (el & 15) + (el >> 4);
@@ -327,15 +329,17 @@ __global__ __launch_bounds__(256) void branch_eigprep_kernel(EigPrepArgs a)
    }
 }
 
-__device__ __forceinline__ void beig_load(const double *p, int lane, v4d (&x)[4])
+__device__ __forceinline__ void beig_load(const double *p, int lane, v4d (&x)[4])      // (part_load's layout, straight into the MFMA tuples)
 {
+   const part2_t *p2 = (const part2_t *)p + lane;
 #pragma unroll
-   for (int m = 0; m < 16; m++) x[m >> 2][m & 3] = p[m * 64 + lane];
+   for (int i = 0; i < 8; i++) { const part2_t v = p2[i * 64]; x[i >> 1][(2 * i) & 3] = v.x; x[i >> 1][(2 * i + 1) & 3] = v.y; }
 }
 __device__ __forceinline__ void beig_store(double *p, int lane, const v4d (&x)[4])
 {
+   part2_t *p2 = (part2_t *)p + lane;
 #pragma unroll
-   for (int m = 0; m < 16; m++) p[m * 64 + lane] = x[m >> 2][m & 3];
+   for (int i = 0; i < 8; i++) p2[i * 64] = (part2_t){x[i >> 1][(2 * i) & 3], x[i >> 1][(2 * i + 1) & 3]};
 }
 // g[d] += sum_m c_m E_d[k = 4m + q]: the lane's share of f, f', f'' for one trial length (et: [3][64] in LDS, element q*16 + m)
 __device__ __forceinline__ void beig_poly(const v4d (&c)[4], const double *et, int q, double (&g)[3])
@@ -406,15 +410,18 @@ __device__ __forceinline__ double beig_smax(const double *scalef, int K, int n_s
    return smax;
 }
 
-#define BEIG_LDS_BYTES ((4 * 4096 + BEIG_NT * 192 + 8 * 3 * BEIG_NT) * 8)
+#define BEIG_LDS_BYTES ((4 * 4096 + BEIG_NT * 192 + 8 * 3 * BEIG_NT + 4 * 64) * 8)
 // NS: sons A's partial is formed from (0: A is resident), S0I / S1I: that son is an internal node (else a tip), BTIP: B is a tip —
 // compile-time, so that every instantiation is straight-line code the register allocator can fit into 256 VGPRs without spilling
-template <int NS, bool S0I, bool S1I, bool BTIP>
+// T61: 61 states — the sixteenth k-block of every matrix holds the single column 60; its rank-1 term seeds the accumulators on the
+// vector pipe and the block's four MFMAs are dropped (60 instead of 64 per product, as in the per-tree pruning kernel)
+template <int NS, bool S0I, bool S1I, bool BTIP, bool T61>
 __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
 {
    constexpr int WAVES = 8;
    extern __shared__ __attribute__((aligned(16))) double beig_smem[];
-   double *sV = beig_smem, *sUt = sV + 4096, *sP0 = sUt + 4096, *sP1 = sP0 + 4096, *sE = sP1 + 4096, *sRed = sE + BEIG_NT * 192;
+   double *sV = beig_smem, *sUt = sV + 4096, *sP0 = sUt + 4096, *sP1 = sP0 + 4096, *sE = sP1 + 4096, *sRed = sE + BEIG_NT * 192,
+          *sCol = sRed + 8 * 3 * BEIG_NT;      // [V, U^T, P of son 0, P of son 1][64]
    const int tid = threadIdx.x, lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int q = lane >> 4, hl = lane & 15;
@@ -429,8 +436,16 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
    if (s1_int) stage_p<WAVES>(Pint + (long)a.son[1] * 4096, sP1, wave, lane);
    if (a.feval)
       for (int idx = tid; idx < a.n_t * 192; idx += WAVES * 64) sE[idx] = a.etab[(long)iclass * a.n_t * 192 + idx];
+   if (T61 && tid < 256) {
+      const int which = tid >> 6, el = tid & 63;
+      double v = 0;
+      if (which < 2) v = a.ecol[(long)iclass * 128 + tid];
+      else if (which == 2 ? s0_int : s1_int) v = a.pcol[((long)iclass * a.n_nodes + a.son[which - 2]) * 64 + el];
+      sCol[tid] = v;
+   }
    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    __syncthreads();
+#define BEIG_MATVEC(MAT, IDX, X, Y) jit_matvec<T61, 4, 16>((MAT), lane, (X), (Y), JitNoSide(), sCol + (IDX) * 64, T61 ? jit_x60((X), lane) : 0.0)
 
    const long G = a.n_groups;
    double *pclass = a.partials + (long)iclass * a.n_int * G * 1024;
@@ -467,13 +482,15 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
          }
          const int h = g * 16 + hl;
          const bool valid = h < a.n_patt;
-         const int hc = valid ? h : a.n_patt - 1, hn = gn >= 0 ? min(gn * 16 + hl, a.n_patt - 1) : 0;
+         // (no next group: the prefetches re-read this one — unconditional, so that the compiler counts the loads in flight
+         //  instead of draining them at a control-flow join)
+         const int gp = gn >= 0 ? gn : g;
+         const int hc = valid ? h : a.n_patt - 1, hn = min(gp * 16 + hl, a.n_patt - 1);
+         const double wt = a.weights[hc];      // (first: a load issued behind the coefficient stores would wait for them)
          int c0n = 0, c1n = 0, cbn = 0;
-         if (gn >= 0) {
-            if (t0) c0n = z0[hn];
-            if (t1) c1n = z1[hn];
-            if (b_tip) cbn = zb[hn];
-         }
+         if (t0) c0n = z0[hn];
+         if (t1) c1n = z1[hn];
+         if (b_tip) cbn = zb[hn];
          v4d s1[4], bb[4], w[4], zz[4];
          double2 v1[8];
          if constexpr (NS == 0) {
@@ -483,8 +500,8 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
                for (int i = 0; i < 4; i++) zz[i] = zp[i];
             }
             else beig_load(pclass + ((long)(a.b_node - a.n_tips) * G + g) * 1024, lane, bb);
-            jit_matvec<false, 4, 16>(sV, lane, pf, w);
-            if (gn >= 0) beig_load(first_base + (long)gn * 1024, lane, pf);
+            BEIG_MATVEC(sV, 0, pf, w);
+            beig_load(first_base + (long)gp * 1024, lane, pf);
          }
          else {
             // A's partial in the tree seen from this branch: the product of its sons' messages (ConditionalPNode, codeml.c:3545-3576)
@@ -492,8 +509,8 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
             if constexpr (s1_int) beig_load(pclass + ((long)(a.son[1] - a.n_tips) * G + g) * 1024, lane, s1);
             if constexpr (t1) tip_gather(Ptip, a.tip_words, a.son[1], c1, q, v1);
             if constexpr (s0_int) {
-               jit_matvec<false, 4, 16>(sP0, lane, pf, x);
-               if (gn >= 0) beig_load(first_base + (long)gn * 1024, lane, pf);
+               BEIG_MATVEC(sP0, 2, pf, x);
+               beig_load(first_base + (long)gp * 1024, lane, pf);
             }
             else {
                double2 v[8];
@@ -504,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
             if constexpr (NS > 1) {
                if constexpr (s1_int) {
                   v4d y[4];
-                  jit_matvec<false, 4, 16>(sP1, lane, s1, y);
+                  BEIG_MATVEC(sP1, 3, s1, y);
 #pragma unroll
                   for (int i = 0; i < 4; i++) x[i] = x[i] * y[i];
                }
@@ -520,9 +537,9 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
             }
             else beig_load(pclass + ((long)(a.b_node - a.n_tips) * G + g) * 1024, lane, bb);
             beig_store(pclass + ((long)(a.a_node - a.n_tips) * G + g) * 1024, lane, x);
-            jit_matvec<false, 4, 16>(sV, lane, x, w);
+            BEIG_MATVEC(sV, 0, x, w);
          }
-         if constexpr (!b_tip) jit_matvec<false, 4, 16>(sUt, lane, bb, zz);
+         if constexpr (!b_tip) BEIG_MATVEC(sUt, 1, bb, zz);
          double wgt = fk, smax = 0;
          if (a.scalef) {
             smax = beig_smax(a.scalef, a.K, a.n_scale, a.n_patt, hc);
@@ -533,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
          v4d c[4];
 #pragma unroll
          for (int i = 0; i < 4; i++) c[i] = (w[i] * zz[i]) * wgt;
-         beig_store(cclass + (long)g * 1024, lane, c);
+         if (!a.no_store) beig_store(cclass + (long)g * 1024, lane, c);
          if (a.feval) {
             double g4[BEIG_NT][3];
 #pragma unroll
@@ -543,13 +560,13 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
             }
             double t3[3];
             beig_scatter(g4, q, t3);
-            const double wt = a.weights[hc];
             beig_terms(t3, valid && q < a.n_t && wt > 0, wt, smax, acc);
          }
          c0 = c0n; c1 = c1n; cb = cbn;
       }
       if (a.feval) beig_chunk_store(acc, a.n_t, sRed, wave, lane, a.partial + (long)(a.first_chunk + lc) * a.n_out);
    }
+#undef BEIG_MATVEC
 }
 
 // dynamic LDS: K x nt_here x 192 doubles of e^{mu t} tables + the reduction scratch

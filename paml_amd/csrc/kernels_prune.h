@@ -91,15 +91,15 @@ namespace paml_amd {
       lnscale += fac;                                                                                           \
       if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + op.b) * a.n_patt + h] = fac;          \
    } break;                                                                                                     \
-   case OP_STORE: {  /* native layout [class][node][16-pattern group][m][lane] */                               \
+   case OP_STORE: {  /* native layout [class][node][16-pattern group] x part_index(m, lane) */                  \
       double *dst = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) +    \
                                   ((long)tile * WAVES + wave)) * 1024;                                          \
-      _Pragma("unroll") for (int m = 0; m < 16; m++) dst[m * 64 + lane] = cur[m];                               \
+      part_store(dst, lane, cur);                                                                               \
    } break;                                                                                                     \
    case OP_LOAD: {                                                                                              \
       const double *src = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) + \
                                         ((long)tile * WAVES + wave)) * 1024;                                    \
-      _Pragma("unroll") for (int m = 0; m < 16; m++) cur[m] = src[m * 64 + lane];                               \
+      part_load(src, lane, cur);                                                                                \
    } break;
 
 #define MFMA_ROOT_CASE()                                                                                         \

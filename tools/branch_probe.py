@@ -57,7 +57,7 @@ def main():
             hit.append(ms)
     c1 = eng.branch_counters()
     res = dict(walk_form_nt1_ms=float(np.mean(form)), walk_form_nt1_ms_max=float(np.max(form)), walk_hit_nt4_ms=float(np.mean(hit)))
-    b = order[-1]
+    b = [v for v in order if v >= t.n_tips][-1]      # an internal branch: both ends' partials are read
     res["same_branch_hit_nt1_ms"], _ = timed(lambda: eng.eval_branch(b, np.array([t.branch[b] * 1.01]), t.branch), 10)
     res["same_branch_hit_nt4_ms"], _ = timed(lambda: eng.eval_branch(b, t.branch[b] * (1 + 0.05 * np.arange(4)), t.branch), 10)
     eng.close()
