@@ -611,14 +611,17 @@ int pamlh_minbranches(pamlh *p, double *x, double e, double *lnL, int verbose)
    for (icycle = 0; icycle < maxcycle; icycle++) {
       for (ib = 0; ib < p->nbranch; ib++) {
          const int b = p->branch_node[ib];
-         double t0 = br[b], t = t0, L0 = 0, Lt = 0;
+         double t0 = br[b], t = t0, L0 = 0, Lt = 0, d0 = 0, dd0 = 0;
+         int have0 = 0;      /* l, l', l'' at t0 are known from the batch of trial lengths that found t0 (every call returns all three) */
          for (icb = 0; icb < ncycleb; icb++) {
             double pn, step, s;
             int found = 0;
-            ts[0] = t0;
-            if (paml_amd_eval_branch(p->eng, b, 1, ts, br, p->ngene > 1 ? p->rgene : NULL, y, dy, ddy)) { rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); goto done; }
-            L0 = y[0];
-            pn = dy[0] / fabs(ddy[0]);                       /* = -dl / |ddl| with l = -lnL */
+            if (!have0) {
+               ts[0] = t0;
+               if (paml_amd_eval_branch(p->eng, b, 1, ts, br, p->ngene > 1 ? p->rgene : NULL, y, dy, ddy)) { rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); goto done; }
+               L0 = y[0]; d0 = dy[0]; dd0 = ddy[0];
+            }
+            pn = d0 / fabs(dd0);                             /* = -dl / |ddl| with l = -lnL */
             if (!(fabs(pn) >= smallv)) step = 0;             /* (also catches NaN) */
             else if (pn < 0) step = fmin(1, (tb0 - t0) / pn);
             else step = fmin(1, (tb1 - t0) / pn);
@@ -629,11 +632,11 @@ int pamlh_minbranches(pamlh *p, double *x, double e, double *lnL, int verbose)
                for (k = 0; k < 4 && sk > smallv; k++, sk /= 4) ts[nt++] = t0 + sk * pn;
                if (paml_amd_eval_branch(p->eng, b, nt, ts, br, p->ngene > 1 ? p->rgene : NULL, y, dy, ddy)) { rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); goto done; }
                for (k = 0; k < nt; k++)
-                  if (y[k] > L0) { t = ts[k]; Lt = y[k]; found = 1; break; }
+                  if (y[k] > L0) { t = ts[k]; Lt = y[k]; d0 = dy[k]; dd0 = ddy[k]; found = 1; break; }
             }
             if (!found) { t = t0; Lt = L0; break; }
             if (fabs(t - t0) < e * fabs(1 + t) && fabs(Lt - L0) < e) break;
-            t0 = t; L0 = Lt;
+            t0 = t; L0 = Lt; have0 = 1;
          }
          br[b] = t;
          L = Lt; have_L = 1;

@@ -172,3 +172,85 @@ def test_patched_reference_baseml_matches_the_unmodified_program(model, fix_alph
     if published is not None:
         assert abs(lnl[0] - published) <= TOL
     assert len(lnf) == len(clnf) > 20 and np.max(np.abs(lnf - clnf)) < 1e-3
+
+
+# ---- every model family the binding takes over, pinned to the reference's printed digits -------------------------------------------------
+# The deterministic single-evaluation mode (`in.codeml` / `in.baseml` starting with -1 = "these are the parameters, do not
+# iterate") through the PATCHED program, on the control files of the golden cases: the lnL it prints (the first com.plfun call: eigen
+# systems decomposed on the device from the rate matrices eigenQcodon built) against the unmodified program's to 2e-6 (six printed
+# decimals), and the `lnf` file (the second call, com.print < 0: host eigen systems, uploaded) to 2e-8 (ten decimals).
+CTL_OF = {"hiv_m0": "hiv_ns0", "hiv_m1a": "hiv_ns1", "hiv_m2a": "hiv_ns2", "hiv_m3": "hiv_ns3", "hiv_m7": "hiv_ns7", "hiv_m8": "hiv_ns8"}
+SINGLE = [("codeml", n) for n in ("hiv_m0", "hiv_m2a", "hiv_m3", "hiv_m8", "lysos_branch_fix", "lysos_clade_label", "mtcdna_branch", "lyso_bsa", "lyso_bsa_null",
+                                  "lyso_bsb", "ecp_cmc", "ecp_cmd", "ecp_m2arel", "lysin_mg0", "lysin_mg2", "lysin_mg3", "lysin_mg4", "stewart_lg_g4")] + \
+         [("baseml", n) for n in ("brown_hky85", "brown_t92_g4", "horai_mg0", "horai_mg0_g5")]
+
+
+def single_evaluation(prog, name, d, exe, extra_ctl="", env=None):
+    g = helpers.load_golden(name)
+    ctl = open(os.path.join(helpers.GOLDEN, "ctl", CTL_OF.get(name, name) + ".ctl")).read()
+    ctl = ctl.replace("../data/", DATA + "/").replace("../ctl/", os.path.join(helpers.GOLDEN, "ctl") + "/")
+    ctl += "\noutfile = mlc\nnoisy = 3\ngetSE = 0\nRateAncestor = 0\n" + extra_ctl
+    d.mkdir()
+    (d / (prog + ".ctl")).write_text(ctl)
+    (d / ("in." + prog)).write_text("-1 " + " ".join("%.6f" % v for v in g["x"]) + "\n")
+    r = subprocess.run([exe, prog + ".ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=900, env=env)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    m = re.findall(r"lnL\s*=\s*(-?[0-9.]+)", out)
+    assert m, out[-3000:]
+    lnf = np.array([float(ln.split()[2]) for ln in (d / "lnf").read_text().splitlines() if re.match(r"\s*\d+\s+\d+(\.\d+)?\s+-\d", ln)])
+    return g, float(m[-1]), lnf, out
+
+
+@pytest.mark.parametrize("prog,name", SINGLE)
+def test_single_evaluation_through_the_patched_reference_matches_the_printed_digits(prog, name, tmp_path):
+    exe = REF_GPU if prog == "codeml" else BASEML_GPU
+    if not (os.path.isfile(exe) and os.access(exe, os.X_OK)):
+        pytest.skip("oracle/_ref/%s_gpu is not built (make -C oracle, needs /root/reference)" % prog)
+    g, lnl, lnf, out = single_evaluation(prog, name, tmp_path / "gpu", exe)
+    assert "paml_amd" not in out, out[-2000:]
+    assert abs(lnl - g["lnL"]) <= 2e-6, (name, lnl, g["lnL"])
+    assert len(lnf) == g["n_patt"] and np.max(np.abs(lnf - np.array(g["logf"]))) <= 2e-8, (name, float(np.max(np.abs(lnf - np.array(g["logf"])))))
+    # the engine really was behind com.plfun: with PAML_AMD_OFF the same binary prints the same digits from the reference's own functions
+    if name in ("lyso_bsa", "lysin_mg2", "horai_mg0"):
+        g2, lnl2, lnf2, out2 = single_evaluation(prog, name, tmp_path / "off", exe, env=dict(os.environ, PAML_AMD_OFF="1"))
+        assert abs(lnl2 - g["lnL"]) <= 2e-6
+
+
+OPT_CASES = [("lyso_bsa", "", -1035.533916), ("ecp_cmc", "", None), ("lysin_mg2", "", None), ("lysos_branch_fix", "", None),
+             ("hiv_m0", "method = 1\n", -1137.688190), ("hiv_m2a", "method = 1\n", -1106.445004), ("lyso_bsa", "method = 1\n", -1035.533916)]
+
+
+@pytest.mark.parametrize("name,extra,published", OPT_CASES)
+def test_patched_reference_optimises_the_wider_model_families(name, extra, published, tmp_path):
+    """The reference's own optimisers on the engine: ming2 (method = 0) and minB / minbranches (method = 1: every lfunt / lfuntdd call is
+    paml_amd_eval_branch) for branch-site model A on the lysozyme data (examples/lysozyme: -1035.533916), clade model C (examples/CladeModelCD),
+    the two partitions of examples/lysin with Mgene = 2, a two-ratio branch model, and the HIV site models with method = 1; the optimum
+    is the golden's `mle_lnL` (the unmodified program's) or the published value."""
+    need_binaries()
+    g = helpers.load_golden(name)
+    ctl = open(os.path.join(helpers.GOLDEN, "ctl", CTL_OF.get(name, name) + ".ctl")).read()
+    ctl = ctl.replace("../data/", DATA + "/").replace("../ctl/", os.path.join(helpers.GOLDEN, "ctl") + "/")
+    ctl += "\noutfile = mlc\nnoisy = 3\ngetSE = 0\nRateAncestor = 0\n" + extra
+    d = tmp_path / "gpu"
+    d.mkdir()
+    (d / "codeml.ctl").write_text(ctl)
+    t0 = time.perf_counter()
+    r = subprocess.run([REF_GPU, "codeml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=1500)
+    dt = time.perf_counter() - t0
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    lnl = [float(m.group(1)) for m in re.finditer(r"lnL\(ntime:\s*\d+\s+np:\s*\d+\):\s+(-?\d+\.\d+)", (d / "mlc").read_text())]
+    want = published if published is not None else g.get("mle_lnL", g["lnL"])
+    assert len(lnl) == 1 and abs(lnl[0] - want) <= 5e-5, (name, extra, lnl, want, out[-1500:])
+    print("\n%s %s through the reference's own optimiser on the engine: lnL %.6f in %.2f s" % (name, extra.strip(), lnl[0], dt))
+
+
+def test_hiv_site_models_through_the_patched_reference_are_fast(tmp_path):
+    """HIV NSsites = 0 2 through codeml_gpu: with the rate matrices decomposed on the device only when they changed, and the class table
+    / frequencies / per-pattern values moved only when needed, the reference's own ming2 spends its time in its own code."""
+    need_binaries()
+    lnl, lnf, nfun, dt, out = run(REF_GPU, HIV_CTL, tmp_path / "gpu")
+    assert abs(lnl[0] - (-1137.688190)) <= TOL and abs(lnl[1] - (-1106.445004)) <= TOL, lnl
+    print("\nHIV NSsites 0 2 through codeml_gpu: %.2f s (%s lfun)" % (dt, nfun))
+    assert dt < 3.0
