@@ -218,7 +218,10 @@ def test_single_evaluation_through_the_patched_reference_matches_the_printed_dig
 
 
 OPT_CASES = [("lyso_bsa", "", -1035.533916), ("ecp_cmc", "", None), ("lysin_mg2", "", None), ("lysos_branch_fix", "", None),
-             ("hiv_m0", "method = 1\n", -1137.688190), ("hiv_m2a", "method = 1\n", -1106.445004), ("lyso_bsa", "method = 1\n", -1035.533916)]
+             ("hiv_m0", "method = 1\n", -1137.688190), ("hiv_m2a", "method = 1\n", -1106.445004),
+             # (branch-site A under method = 1 stops at -1035.530508 — the UNMODIFIED program does exactly that on this control file, 12 s on
+             #  a core here; the published -1035.533916 is the method = 0 optimum above)
+             ("lyso_bsa", "method = 1\n", -1035.530508)]
 
 
 @pytest.mark.parametrize("name,extra,published", OPT_CASES)
