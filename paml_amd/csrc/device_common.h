@@ -290,6 +290,44 @@ __device__ __forceinline__ void jit_col_seed(const double *col, int lane, double
    }
 }
 
+// ---- 61 states without the row padding (JIT_ROWTAIL; pmat_kernel layout 3) ---------------------------------------------------------
+// Rows 0..47 of P are three 16 x 16 x 4 row blocks; rows 48..59 go through v_mfma_f64_4x4x4 (three row quartets m' = 12, 13, 14:
+// an instruction does the quartet's 4 x 4 block of one k-block for all sixteen patterns in a quarter of a 16 x 16 x 4's pipe
+// time, its result lands in the lanes' element m' — the partial's own layout, as in the 20-state kernel), row 60 is a dot product
+// on the vector pipe, rows 61..63 do not exist: 45 + 45 / 4 = 56.25 instead of 60 big-instruction times per product.
+// In the operand block the fourth row block's 1 KB slot of every k-block pair holds instead, for e = 0, 1 and m' = 12, 13, 14,
+// the sixteen words [k][i] = P[4 m' + i][4 (2 kb2 + e) + k] at doubles (e * 3 + m' - 12) * 16 .., and from double 96 on
+// [q][e] = P[60][4 (2 kb2 + e) + q] (column 60 itself arrives through the rank-1 seed).
+#ifdef JIT_ROWTAIL
+#define JIT_RT 1
+#else
+#define JIT_RT 0
+#endif
+struct JitRowTail {
+   double a4[3];      // the k-block's three 4 x 4 x 4 operands (m' = 12, 13, 14); the pair's second k-block re-uses the registers
+   double r60;        // the lane's share of row 60
+};
+__device__ __forceinline__ unsigned jit_lds_addr(const double *p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)p; }
+template <int OFF>
+__device__ __forceinline__ double jit_lds64(unsigned addr)
+{
+   double v;
+   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+   return v;
+}
+// request the three small operands of k-block 2 KB2 + E (base = LDS byte address of the block + the lane's (k, i) word)
+template <int KB2, int E>
+__device__ __forceinline__ void jit_rt_fetch(unsigned base, JitRowTail &rt)
+{
+   constexpr int S = (KB2 * 4 + 3) * 1024 + E * 384;
+   rt.a4[0] = jit_lds64<S + 0 * 128>(base); rt.a4[1] = jit_lds64<S + 1 * 128>(base); rt.a4[2] = jit_lds64<S + 2 * 128>(base);
+}
+__device__ __forceinline__ void jit_rt_wait(JitRowTail &rt)      // the operands have arrived (LDS returns in order); nothing that uses them moves above
+{
+   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rt.a4[0]), "+v"(rt.a4[1]), "+v"(rt.a4[2]));
+}
+#define JIT_MFMA4(A, B, C) __builtin_amdgcn_mfma_f64_4x4x4f64((A), (B), (C), 0, 0, 0)
+
 // RB row blocks of 16 and KB k-blocks of 4 cover the model's states (4, 16 for 61; 2, 5 for 20): blocks beyond them are
 // zero padding in P and are neither fetched nor multiplied; accumulators of skipped row blocks stay 0.
 template <bool TAIL61 = false, int RB = 4, int KB = 16, class SIDE = JitNoSide>
@@ -301,33 +339,73 @@ __device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const 
    if constexpr (TAIL61) jit_col_seed(col, lane, x60, z);
    double2 af[2][4];
    constexpr int KB2 = (KB + 1) / 2;
+   constexpr bool RT = JIT_RT && TAIL61 && RB == 4 && KB == 16;      // rows 48..60 without the padding (see JitRowTail)
+   constexpr int RBM = RT ? 3 : RB;
+   JitRowTail rt;
+   const unsigned rtbase = jit_lds_addr(sPbuf) + (((lane >> 4) << 2) + (lane & 3)) * 8;
+   const double2 *sp60 = (const double2 *)(sPbuf + 3 * 128 + 96) + (lane >> 4);      // (+ kb2 * 256 double2: the pair's slot)
 #pragma unroll
    for (int jb = RB; jb < 4; jb++) y[jb] = (v4d){0, 0, 0, 0};
+   if constexpr (RT) { y[3] = z[3]; rt.r60 = 0; }
 #pragma unroll
-   for (int jb = 0; jb < RB; jb++) af[0][jb] = sp[jb * 64 + lane];
+   for (int jb = 0; jb < RBM; jb++) af[0][jb] = sp[jb * 64 + lane];
+#define JIT_RT_STEP(KB2V)                                                                                              \
+   if constexpr (RT) {                                                                                                \
+      const double2 p60 = sp60[(KB2V) * 256];                                                                         \
+      jit_rt_fetch<KB2V, 0>(rtbase, rt);                                                                              \
+      rt.r60 = fma(p60.x, x[(2 * (KB2V)) >> 2][(2 * (KB2V)) & 3], rt.r60);                                            \
+      if ((KB2V) != 7) rt.r60 = fma(p60.y, x[(2 * (KB2V) + 1) >> 2][(2 * (KB2V) + 1) & 3], rt.r60);                   \
+   }
+#define JIT_RT_FETCH1(KB2V) if constexpr (RT) { jit_rt_fetch<KB2V, 1>(rtbase, rt); }
+#define JIT_RT_SW(M)                                                                                                   \
+   switch (kb2) {                                                                                                     \
+   case 0: M(0) break; case 1: M(1) break; case 2: M(2) break; case 3: M(3) break;                                    \
+   case 4: M(4) break; case 5: M(5) break; case 6: M(6) break; default: M(7) break;                                   \
+   }
 #pragma unroll
    for (int kb2 = 0; kb2 < KB2; kb2++) {
       if (kb2 + 1 < KB2) {
 #pragma unroll
-         for (int jb = 0; jb < RB; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
+         for (int jb = 0; jb < RBM; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
+      }
+      if constexpr (RT) {      // (a literal pair index for the asm offsets)
+         switch (kb2) {
+         case 0: JIT_RT_STEP(0) break; case 1: JIT_RT_STEP(1) break; case 2: JIT_RT_STEP(2) break; case 3: JIT_RT_STEP(3) break;
+         case 4: JIT_RT_STEP(4) break; case 5: JIT_RT_STEP(5) break; case 6: JIT_RT_STEP(6) break; default: JIT_RT_STEP(7) break;
+         }
       }
       __builtin_amdgcn_sched_barrier(0);
       const double b0 = x[(2 * kb2) >> 2][(2 * kb2) & 3], b1 = x[(2 * kb2 + 1) >> 2][(2 * kb2 + 1) & 3];
       if (kb2 == 0) {
 #pragma unroll
-         for (int jb = 0; jb < RB; jb++)
+         for (int jb = 0; jb < RBM; jb++)
             y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][jb].x, b0, z[jb], 0, 0, 0);
       }
       else {
 #pragma unroll
-         for (int jb = 0; jb < RB; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
+         for (int jb = 0; jb < RBM; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
+      }
+      if constexpr (RT) {
+         jit_rt_wait(rt);
+         y[3].x = JIT_MFMA4(rt.a4[0], b0, y[3].x); y[3].y = JIT_MFMA4(rt.a4[1], b0, y[3].y); y[3].z = JIT_MFMA4(rt.a4[2], b0, y[3].z);
+         if (kb2 != 7) { JIT_RT_SW(JIT_RT_FETCH1) }      // (sources are read at issue: the registers take the pair's second k-block)
       }
       side(kb2);
       if (!(TAIL61 && kb2 == 7) && 2 * kb2 + 1 < KB) {
 #pragma unroll
-         for (int jb = 0; jb < RB; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+         for (int jb = 0; jb < RBM; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+         if constexpr (RT) {
+            jit_rt_wait(rt);
+            y[3].x = JIT_MFMA4(rt.a4[0], b1, y[3].x); y[3].y = JIT_MFMA4(rt.a4[1], b1, y[3].y); y[3].z = JIT_MFMA4(rt.a4[2], b1, y[3].z);
+         }
       }
       __builtin_amdgcn_sched_barrier(0);
+   }
+   if constexpr (RT) {      // row 60: the four state-quarter lanes' shares, onto the q = 0 lane's element 15 (states 61..63 stay 0)
+      double r = rt.r60;
+      r += __shfl_xor(r, 16);
+      r += __shfl_xor(r, 32);
+      y[3].w = lane < 16 ? y[3].w + r : 0.0;
    }
 }
 
@@ -347,15 +425,24 @@ __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, c
    v4d z[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
    if constexpr (TAIL61) jit_col_seed(col, lane, x60, z);
    double2 af[2][4];
+   constexpr bool RT = JIT_RT && TAIL61 && RB == 4 && KB == 16;      // rows 48..60 without the padding (see JitRowTail)
+   constexpr int RBM = RT ? 3 : RB;
+   JitRowTail rt;
+   const unsigned rtbase = jit_lds_addr(sPbuf) + (((lane >> 4) << 2) + (lane & 3)) * 8;
+   const double2 *sp60 = (const double2 *)(sPbuf + 3 * 128 + 96) + (lane >> 4);
    const int rowa = ca * 4 + q, rowb = cb * 4 + q, swa = TIP_SWZ(rowa), swb = TIP_SWZ(rowb);
    const char *pa = (const char *)ta + rowa * 128, *pb = (const char *)tb + rowb * 128;
-   double2 tv[2][PPI], tw[2][PPI];
+   // (row-tail form: the tip rows fetched in an iteration are multiplied at its end — two more small-MFMA groups per iteration hide
+   //  the LDS latency that the four-row-block form hides by deferring the products to the next iteration — half the staging registers)
+   constexpr int TB = (JIT_RT && TAIL61 && RB == 4 && KB == 16) ? 1 : 2;
+   double2 tv[TB][PPI], tw[TB][PPI];
 #pragma unroll
    for (int jb = RB; jb < 4; jb++) y[jb] = (v4d){0, 0, 0, 0};
 #pragma unroll
    for (int jb = 0; jb < 4; jb++) t[jb] = (v4d){0, 0, 0, 0};
+   if constexpr (RT) { y[3] = z[3]; rt.r60 = 0; }
 #pragma unroll
-   for (int jb = 0; jb < RB; jb++) af[0][jb] = sp[jb * 64 + lane];
+   for (int jb = 0; jb < RBM; jb++) af[0][jb] = sp[jb * 64 + lane];
 #pragma unroll
    for (int kb2 = 0; kb2 < KB2; kb2++) {
       if (kb2 == MID) {
@@ -364,15 +451,21 @@ __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, c
       }
       if (kb2 + 1 < KB2) {
 #pragma unroll
-         for (int jb = 0; jb < RB; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
+         for (int jb = 0; jb < RBM; jb++) af[(kb2 + 1) & 1][jb] = sp[((kb2 + 1) * 4 + jb) * 64 + lane];
+      }
+      if constexpr (RT) {
+         switch (kb2) {
+         case 0: JIT_RT_STEP(0) break; case 1: JIT_RT_STEP(1) break; case 2: JIT_RT_STEP(2) break; case 3: JIT_RT_STEP(3) break;
+         case 4: JIT_RT_STEP(4) break; case 5: JIT_RT_STEP(5) break; case 6: JIT_RT_STEP(6) break; default: JIT_RT_STEP(7) break;
+         }
       }
       if (kb2 >= MID) {
 #pragma unroll
          for (int e = 0; e < PPI; e++) {
             const int p = PPI * (kb2 - MID) + e;
             if (p < NP) {
-               tv[kb2 & 1][e] = *(const double2 *)(pa + ((p ^ swa) * 16));
-               tw[kb2 & 1][e] = *(const double2 *)(pb + ((p ^ swb) * 16));
+               tv[kb2 & (TB - 1)][e] = *(const double2 *)(pa + ((p ^ swa) * 16));
+               tw[kb2 & (TB - 1)][e] = *(const double2 *)(pb + ((p ^ swb) * 16));
             }
          }
       }
@@ -380,14 +473,19 @@ __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, c
       const double b0 = x[(2 * kb2) >> 2][(2 * kb2) & 3], b1 = x[(2 * kb2 + 1) >> 2][(2 * kb2 + 1) & 3];
       if (kb2 == 0) {
 #pragma unroll
-         for (int jb = 0; jb < RB; jb++)
+         for (int jb = 0; jb < RBM; jb++)
             y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][jb].x, b0, z[jb], 0, 0, 0);
       }
       else {
 #pragma unroll
-         for (int jb = 0; jb < RB; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
+         for (int jb = 0; jb < RBM; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].x, b0, y[jb], 0, 0, 0);
       }
-      if (kb2 > MID) {      // products of the rows fetched one iteration ago
+      if constexpr (RT) {
+         jit_rt_wait(rt);
+         y[3].x = JIT_MFMA4(rt.a4[0], b0, y[3].x); y[3].y = JIT_MFMA4(rt.a4[1], b0, y[3].y); y[3].z = JIT_MFMA4(rt.a4[2], b0, y[3].z);
+         if (kb2 != 7) { JIT_RT_SW(JIT_RT_FETCH1) }      // (sources are read at issue: the registers take the pair's second k-block)
+      }
+      if (TB == 2 && kb2 > MID) {      // products of the rows fetched one iteration ago
 #pragma unroll
          for (int e = 0; e < PPI; e++) {
             const int p = PPI * (kb2 - 1 - MID) + e;
@@ -400,12 +498,32 @@ __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, c
       side(kb2);
       if (!(TAIL61 && kb2 == 7) && 2 * kb2 + 1 < KB) {
 #pragma unroll
-         for (int jb = 0; jb < RB; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+         for (int jb = 0; jb < RBM; jb++) y[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2 & 1][jb].y, b1, y[jb], 0, 0, 0);
+         if constexpr (RT) {
+            jit_rt_wait(rt);
+            y[3].x = JIT_MFMA4(rt.a4[0], b1, y[3].x); y[3].y = JIT_MFMA4(rt.a4[1], b1, y[3].y); y[3].z = JIT_MFMA4(rt.a4[2], b1, y[3].z);
+         }
+      }
+      if (TB == 1 && kb2 >= MID) {      // products of the rows fetched at the top of this iteration
+#pragma unroll
+         for (int e = 0; e < PPI; e++) {
+            const int p = PPI * (kb2 - MID) + e;
+            if (p < NP) {
+               t[p >> 1][(2 * p) & 3] = tv[0][e].x * tw[0][e].x;
+               t[p >> 1][(2 * p + 1) & 3] = tv[0][e].y * tw[0][e].y;
+            }
+         }
       }
       __builtin_amdgcn_sched_barrier(0);
    }
+   if constexpr (RT) {
+      double r = rt.r60;
+      r += __shfl_xor(r, 16);
+      r += __shfl_xor(r, 32);
+      y[3].w = lane < 16 ? y[3].w + r : 0.0;
+   }
 #pragma unroll
-   for (int e = 0; e < PPI; e++) {
+   for (int e = 0; e < PPI && TB == 2; e++) {
       const int p = PPI * (KB2 - 1 - MID) + e;
       if (p < NP) {
          t[p >> 1][(2 * p) & 3] = tv[(KB2 - 1) & 1][e].x * tw[(KB2 - 1) & 1][e].x;

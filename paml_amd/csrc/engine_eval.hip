@@ -55,7 +55,7 @@ void launch_pmat(const PmatArgs &pa, const InlineVec &iv, int n_nodes, int psets
 {
    const int gx = (n_nodes + std::max(pa.npb, 1) - 1) / std::max(pa.npb, 1);
    if (small) hipLaunchKernelGGL(pmat_small_kernel, dim3((n_nodes * psets + 7) / 8), dim3(256), 0, s, pa, iv);
-   else if (pa.n <= 32 && pa.layout != 1) hipLaunchKernelGGL(pmat_kernel_t<32>, dim3(gx, psets), dim3(256), 2 * 32 * 32 * sizeof(double), s, pa, iv);
+   else if (pa.n <= 32 && pa.layout != 1 && pa.layout != 3) hipLaunchKernelGGL(pmat_kernel_t<32>, dim3(gx, psets), dim3(256), 2 * 32 * 32 * sizeof(double), s, pa, iv);
    else hipLaunchKernelGGL(pmat_kernel_t<64>, dim3(gx, psets), dim3(256), 2 * 4096 * sizeof(double), s, pa, iv);
 }
 
@@ -264,7 +264,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       int jw = 8;
       if (e->env.jit_waves == 12 && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, 192) && jit_zbuffers(e->n_tips, 192) == 2) jw = 12;
       if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16)) {
-         const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "w" + std::to_string(jw) + ":" + jit_program_key(e->prog, e->n_tips);
+         const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "w" + std::to_string(jw) + (jit_rowtail(n) ? "r:" : ":") + jit_program_key(e->prog, e->n_tips);
          const bool background = e->prog.ops.size() > 120 &&      /* (roughly: more than 60 taxa, more than 3 s of compilation) */ !e->jit_forced && !e->env.jit_sync && !(e->jit.fn && e->jit.key == key);
          if (!background) {
             int r = ensure_jit(e, key, [&]() { return jit_generate(e->prog, e->n_tips, n, e->n_codes, jw); }, &jit_ok);
@@ -364,7 +364,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // Kernel A: batched P(t)
    PmatArgs pa{};
    pa.n = n; pa.n_nodes = nn; pa.root = e->tree.root; pa.K = Km; pa.n_genes = G; pa.n_labels = e->n_labels;
-   pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : ((e->kk == KK_VALU20 && e->use_jit && e->m20) ? 2 : 0);
+   pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? ((e->use_jit && jit_rowtail(n)) ? 3 : 1) : ((e->kk == KK_VALU20 && e->use_jit && e->m20) ? 2 : 0);
    pa.label = e->d_label.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = pipe ? e->d2_branch.p : e->d_branch.p; pa.rate = e->d_rate.p;
    pa.gene_rate = pipe ? e->d2_gene_rate.p : e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
    pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;

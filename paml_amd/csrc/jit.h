@@ -62,6 +62,13 @@ inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 
    return true;
 }
 
+// 61 states: rows 48..60 of every product without the padded rows 61..63 (device_common.h, JitRowTail; pmat_kernel layout 3) —
+// built and measured in round 4 (profiles/r04_61state.txt): bit-compatible results, 6 % fewer matrix-pipe cycles per product, and
+// no faster (1.573 against 1.569 ms at 16 taxa x 10^6 patterns): the 45 extra operand fetches, the row-60 dot product and their waits
+// take out of the shared issue port what the dropped rows put in.  Kept behind PAML_AMD_JIT_ROWTAIL=1; the default is the
+// four-row-block form.
+inline bool jit_rowtail(int n_states) { return n_states == 61 && getenv("PAML_AMD_JIT_ROWTAIL") && !getenv("PAML_AMD_JIT_NOTAIL"); }
+
 inline std::string jit_program_key(const Program &p, int n_tips)
 {
    std::ostringstream k;
@@ -116,6 +123,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    // DMA rounds per block: a P has chunks pair * 4 + row block (< KB2 * 4 used), a tip table TCH chunks; `waves` chunks per round
    const int P_ROUNDS = (KB2 * 4 + waves - 1) / waves, T_ROUNDS = (TCH + waves - 1) / waves;
    s << "#define JIT_KB2 " << KB2 << "\n#define JIT_RB " << RB << "\n#define JIT_TCH " << TCH << "\n#define JIT_WAVES " << waves << "\n";
+   if (jit_rowtail(n_states)) s << "#define JIT_ROWTAIL 1\n";
    if (getenv("PAML_AMD_JIT_NT_STORE")) s << "#define JIT_NT_STORE 1\n";         // experiment: non-temporal stores of the class likelihoods
    if (getenv("PAML_AMD_JIT_ABL_NOSEED")) s << "#define JIT_ABL_NOSEED 1\n";      // timing experiment: the rank-1 seed without its LDS reads and multiplies
    if (getenv("PAML_AMD_JIT_ABL_NOBAR")) s << "#define JIT_ABL_NOBAR 1\n";      // timing experiment: no workgroup barriers (results are garbage)

@@ -18,7 +18,7 @@ struct EigenDev {
 
 // Kernel A (kernels_pmat.h): batched P(t)
 struct PmatArgs {
-   int n, n_nodes, root, K, n_genes, n_labels, n_codes, layout;   // layout 0: VALU (row-major), 1: mfma64, 2: as 0 with the tip rows in m20 order
+   int n, n_nodes, root, K, n_genes, n_labels, n_codes, layout;   // layout 0: VALU (row-major), 1: mfma64, 2: as 0 with the tip rows in m20 order, 3: as 1 with rows 48..60 of a 61-state P in the per-tree kernel's row-tail form
    const int *label;             // [n_nodes]
    const unsigned char *is_leaf; // [n_nodes]
    const double *branch;         // [n_nodes]

@@ -304,12 +304,24 @@ __global__ __launch_bounds__(256) void pmat_kernel_t(PmatArgs a, InlineVec iv)
       double *rm = a.rowmajor + slot * n * n;
       for (int idx = tid; idx < n * n; idx += 256) rm[idx] = sA[(idx / n) * LD + (idx % n)];
 
-      if constexpr (LD == 64) if (a.layout == 1 && !leaf) {
+      if constexpr (LD == 64) if ((a.layout == 1 || a.layout == 3) && !leaf) {
          // MFMA A-operand order: element ((kb2*4 + jb)*64 + lane)*2 + e  =  P[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)]
+         // layout 3 (61 states, per-tree kernel without the row padding: device_common.h, JitRowTail): the fourth row block's slot of
+         // every k-block pair holds the 4 x 4 x 4 operands of rows 48..59 and the pair's eight entries of row 60
          double *pf = a.pint + slot * 4096;
          for (int idx = tid; idx < 4096; idx += 256) {
             int e = idx & 1, lane = (idx >> 1) & 63, jb = (idx >> 7) & 3, kb2 = idx >> 9;
-            pf[idx] = sA[(jb * 16 + (lane & 15)) * 64 + 4 * (2 * kb2 + e) + (lane >> 4)];
+            double v = sA[(jb * 16 + (lane & 15)) * 64 + 4 * (2 * kb2 + e) + (lane >> 4)];
+            if (a.layout == 3 && jb == 3) {
+               const int li = idx & 127;
+               if (li < 96) {
+                  const int blk = li >> 4, w = li & 15;      // blk = e' * 3 + (m' - 12); w = k * 4 + i
+                  v = sA[(4 * (12 + blk % 3) + (w & 3)) * 64 + 4 * (2 * kb2 + blk / 3) + (w >> 2)];
+               }
+               else if (li < 104) v = sA[60 * 64 + 4 * (2 * kb2 + (li & 1)) + ((li - 96) >> 1)];
+               else v = 0.0;
+            }
+            pf[idx] = v;
          }
          // column 60 in the order a lane's accumulators want it, pcol[q][m] = P[4m + q][60]: with 61 states the last
          // k-block holds this one column, and the specialised kernel adds its rank-1 term on the vector pipe instead of
@@ -317,11 +329,12 @@ __global__ __launch_bounds__(256) void pmat_kernel_t(PmatArgs a, InlineVec iv)
          if (a.pcol && tid < 64) a.pcol[slot * 64 + tid] = sA[(4 * (tid & 15) + (tid >> 4)) * 64 + 60];
       }
       if (leaf) {
-         const int tipw = a.layout == 1 ? 64 : n;
+         const bool mf = a.layout == 1 || a.layout == 3;
+         const int tipw = mf ? 64 : n;
          double *pt = a.ptip + slot * a.tip_words;
          for (int idx = tid; idx < a.n_codes * tipw; idx += 256) {
             int code = idx / tipw, w = idx % tipw, jj;
-            if (a.layout == 1) {
+            if (mf) {
                // row (code, q) = 128 bytes = 8 pieces of two states; piece p is stored in slot p ^ ((row >> 1) & 7) so
                // that lanes gathering different rows from an LDS copy of this table spread over the banks
                const int q = w >> 4, slot = (w & 15) >> 1, row = code * 4 + q;
