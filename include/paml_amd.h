@@ -130,7 +130,8 @@ int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi);
  * diag(sqrt pi) Q diag(1/sqrt pi) = R diag(w) R^T; states with pi = 0 are left out (Root 0, unit rows / columns).  One workgroup
  * per matrix (cyclic Jacobi in LDS, FP64): a gradient's or a line search's several hundred decompositions take about the time
  * of one, and U, V, Root never cross PCIe.  Asynchronous on the engine's stream.  paml_amd_get_eigen reads a set back (parity);
- * paml_amd_eigen_counters: matrices decomposed so far and the Jacobi sweeps each matrix of the last batch took. */
+ * paml_amd_eigen_counters: matrices decomposed so far and the Jacobi sweeps each matrix of the last batch took (-1: the limit of 40
+ * sweeps was reached without convergence — decompose that matrix on the host instead). */
 int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, const double *Q, const double *pi, const double *scale);
 int paml_amd_get_eigen(paml_amd_engine *e, int set_id, double *U, double *V, double *Root);
 int paml_amd_eigen_counters(paml_amd_engine *e, long *n_decomposed, int *sweeps_last_batch, int cap);

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
    // Two barriers per round: before the rows are combined (the previous round's column pass is complete), and between the row and
    // the column pass.
    int sweep = 0;
+   bool converged = false;
    for (; sweep < 40; sweep++) {
       double big = 0;
       for (int r = 0; r < N - 1; r++) {
@@ -85,7 +86,11 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
                   // hardware approximations + Newton steps: t only steers the convergence (a step suffices), c = 1 / sqrt(1 + t^2)
                   // must make the rotation orthogonal to the last bit (two steps); s = t c.
                   big = fmax(big, fabs(apq));
-                  const double d = sA[q * EIG_LD + q] - sA[p * EIG_LD + p], a2 = 2 * apq, x = d * d + a2 * a2;
+                  // (d and a2 are brought to order one first: with app == aqq and |apq| below 1e-154 the squares would underflow to 0,
+                  //  the reciprocal square root of 0 is infinite and the Newton step makes a NaN of it — degenerate spectra do this in
+                  //  their late sweeps; the scale cancels in t)
+                  const double d0 = sA[q * EIG_LD + q] - sA[p * EIG_LD + p], a20 = 2 * apq, sc = 1.0 / fmax(fabs(d0), fabs(a20));
+                  const double d = d0 * sc, a2 = a20 * sc, x = d * d + a2 * a2;
                   double y = __builtin_amdgcn_rsq(x);
                   y = y * (1.5 - 0.5 * x * y * y);
                   const double den = d + copysign(x * y, d);
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
       __syncthreads();
       const bool done = fmax(fmax(sRed[0], sRed[1]), fmax(sRed[2], sRed[3])) <= thr;
       __syncthreads();
-      if (done) { sweep++; break; }
+      if (done) { sweep++; converged = true; break; }
    }
 
    // roots descending (ties: by position), then U = R / sqrt(pi), V = R^T sqrt(pi); left-out states: unit rows / columns, Root = 0
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
       V[rk * n + i] = v * sp;
       U[i * n + rk] = v / sp;
    }
-   if (a.sweeps && tid == 0) a.sweeps[set] = sweep;
+   if (a.sweeps && tid == 0) a.sweeps[set] = converged ? sweep : -1;      // (-1: the sweep limit was reached: paml_amd_eigen_counters shows it, the host falls back)
 }
 
 }  // namespace paml_amd

@@ -440,6 +440,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    DevBuf<double> &dfhk = e->fhk_slot((offload || dual) ? slot : 0);
    if ((offload || dual) && slot) HIPCHK(dfhk.ensure((size_t)K * e->n_patt));
    pr.fhK = dfhk.p;
+   e->last_fhk = (offload || dual) ? slot : 0;
    bool slot_waited = false;
    auto wait_slot = [&]() -> int {      // main stream: the reduction that last read this slot (two evaluations ago) is done
       if (slot_waited) return 0;

@@ -237,7 +237,7 @@ struct paml_amd_engine {
    hipEvent_t st_part[NSTAT] = {}, st_done[NSTAT] = {}, st_w0[NSTAT] = {}, st_w1[NSTAT] = {};
    bool st_waited[NSTAT] = {};
    long st_count = 0;
-   int red_slot = 0, last_slot = 0;
+   int red_slot = 0, last_slot = 0, last_fhk = 0;      // last_fhk: the class-likelihood buffer the last evaluation wrote (fhk_slot)
    // CUs the persistent pruning kernels of SINGLE evaluations leave free while the engine has a communicator (runs of evaluations
    // on two pruning streams take every CU, see engine_eval.hip): their workgroups fill a CU (two waves
    // per SIMD at 256 VGPRs, 130 KB of LDS), so the collective's workgroups would otherwise wait for the kernel's tail — or, when

@@ -13,16 +13,16 @@ for taxa, n_patt in ((90, 200_000), (96, 200_000), (128, 200_000), (192, 100_000
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     t0 = time.perf_counter()
     eng.eval_device(pb.tree.branch, d_lnl.data_ptr())
-    torch.cuda.synchronize()
+    eng.flush(); torch.cuda.synchronize()
     t_first = time.perf_counter() - t0       # includes generating and compiling the tree's kernel
     for _ in range(2):
         eng.eval_device(pb.tree.branch, d_lnl.data_ptr())
-    torch.cuda.synchronize()
+    eng.flush(); torch.cuda.synchronize()
     eng.profile(True)
     t0 = time.perf_counter()
     for _ in range(5):
         eng.eval_device(pb.tree.branch, d_lnl.data_ptr())
-    torch.cuda.synchronize()
+    eng.flush(); torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     p = eng.profile_read(); eng.profile(False)
     kms = p["ms_prune"] / max(1, p["n_evals"])

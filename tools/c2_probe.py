@@ -29,11 +29,11 @@ def run(n_patt, steps):
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     for i in range(5):
         eng.eval_device(br, d.data_ptr())
-    torch.cuda.synchronize()
+    eng.flush(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         eng.eval_device(br, d.data_ptr() + 8 * i)
-    torch.cuda.synchronize()
+    eng.flush(); torch.cuda.synchronize()
     dt_dev = (time.perf_counter() - t0) / steps
     assert float(d[-1].item()) == r["lnL"]
     eng.profile(True)

@@ -24,12 +24,12 @@ d = torch.zeros(64, dtype=torch.float64, device="cuda")
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 for i in range(10):
     eng.eval_device(pb.tree.branch, d.data_ptr())
-torch.cuda.synchronize()
+eng.flush(); torch.cuda.synchronize()
 eng.profile(True)
 t0 = time.perf_counter()
 for i in range(20):
     eng.eval_device(pb.tree.branch, d.data_ptr() + 8 * i)
-torch.cuda.synchronize()
+eng.flush(); torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20
 p = eng.profile_read()
 print(json.dumps(dict(tag=os.environ.get("ABL_TAG", ""), K=K, ms_per_eval=dt * 1e3, kernel_ms=p["ms_prune"] / p["n_evals"], lnL=float(d[0].item()),
