@@ -337,6 +337,10 @@ def main():
         out["c2"] = bench_c2(engine, synth, timed, args)
         out["c2_batch"] = bench_c2_batch(engine, synth, fence)
         out["aa20"] = bench_aa20(engine, synth, timed, args)
+        try:
+            out["fallbacks"] = bench_fallbacks(engine, synth, timed, pb_full if (args.scaling == "strong" and pb.n == 61) else None)
+        except Exception as ex:      # noqa: BLE001  (reported, the headline stands)
+            out["fallbacks"] = {"error": repr(ex)}
         if pb.n == 61:
             try:
                 out["branch"] = bench_branch(engine, pb_full if args.scaling == "strong" else pb, lnl)
@@ -393,11 +397,19 @@ def bench_c2(engine, synth, timed, args):
     # 10^5 patterns x 4 classes the launch is too short to fill the chip (3 waves per SIMD): a latency figure
     real_bytes = pb.tree.n_tips + 8
     tf = fpp * pb.n_patt / (kms * 1e-3) / 1e12
+    counted = None      # HBM bytes per launch of this very workload by the counters (profiles/rNN_c2_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes)
+    try:
+        with open(sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_c2_pmc.json")))[-1]) as f:
+            counted = json.load(f)
+    except (IndexError, OSError, ValueError):
+        pass
     return {"workload": "baseml GTR+G4, 32 taxa x 100000 nucleotide patterns (BASELINE configs[1])", "kernel": name, "lnL": lnl,
             "lnL_reference": ref, "ms_per_eval": dt / steps * 1e3, "site_patterns_per_s": pb.n_patt * steps / dt, "kernel_ms": kms,
             "roofline": {"bound": "valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                         "flop_per_pattern": fpp, "hbm_real_bytes": real_bytes * pb.n_patt,
-                         "hbm_real_frac": real_bytes * pb.n_patt / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "flop_per_pattern": fpp, "hbm_algorithmic_bytes": real_bytes * pb.n_patt,
+                         "hbm_counted_bytes": counted["hbm_bytes_per_launch"] if counted else None,
+                         "hbm_counted_from": counted["source"] if counted else None,
+                         "hbm_real_frac": (counted["hbm_bytes_per_launch"] if counted else real_bytes * pb.n_patt) / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "BASELINE calls this configuration HBM-bound; the fused kernel keeps the partials in registers, so its HBM traffic is the "
                                  "tip codes and weights only (hbm_real_frac of 8 TB/s) and the binding resource is FP64 vector issue. One evaluation "
                                  "of 10^5 patterns is latency-class work: c2_batch is the same kernel with a gradient's worth of evaluations"}}
@@ -637,6 +649,58 @@ def bench_branch(engine, pb, lnl_full):
                               achieved=hbm_bytes / (kms * 1e-3) / 1e9, peak=8000.0, unit="GB/s", frac=max(t_hbm, t_mfma) / kms,
                               mfma_tflops=flops / (kms * 1e-3) / 1e12,
                               timing="HIP events on the engine's stream around the contraction kernel, one launch at a time"))
+
+
+def bench_fallbacks(engine, synth, timed, pb_c4):
+    """What runs where the fast paths do not apply (engine_core.hip / engine_eval.hip choose per problem): kernel name, time per
+    evaluation back to back and the fraction of the FP64 peak (matrix or vector pipe: the same 78.6 TFLOP/s) of the ALGORITHMIC flops,
+    whole evaluation.  The fast paths' own figures are the headline, `sweep`, `c2`, `aa20` blocks."""
+    import dataclasses
+    from paml_amd.problem import balanced_tree
+    rows = []
+
+    def frac(pb, ms):
+        return algorithmic_flops_per_pattern(pb.n, pb.tree.n_tips) * pb.K * pb.n_patt / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+
+    def run(case, pb, flags=0, steps=10, why=""):
+        eng = engine.engine_for(pb, flags=flags)
+        dt, lnl, _ = timed(eng, pb.tree.branch.copy(), steps, 3)
+        ms = dt / steps * 1e3
+        row = dict(case=case, why=why, kernel=eng.kernel_name, ms_per_eval=ms, frac_of_fp64_peak=frac(pb, ms), lnL=lnl)
+        rows.append(row)
+        return eng, row
+
+    # 1. a tree too large for a kernel to be compiled while the caller waits: the interpreter serves, the per-tree kernel takes over
+    pb = synth.codon_m0_problem(n_tips=192, n_patt=65_536, seed=192)
+    eng, row = run("codon M0, 192 taxa x 65536 patterns", pb, why="per-tree kernel of > 120 ops is compiled on a worker thread; the streaming interpreter serves meanwhile")
+    t0 = time.perf_counter()
+    while eng.kernel_name != "mfma64_jit" and time.perf_counter() - t0 < 60:
+        time.sleep(0.5)
+        eng.eval(pb.tree.branch)
+    row["seconds_until_compiled_kernel"] = time.perf_counter() - t0
+    if eng.kernel_name == "mfma64_jit":
+        dt, lnl2, _ = timed(eng, pb.tree.branch.copy(), 10, 3)
+        row["then"] = dict(kernel=eng.kernel_name, ms_per_eval=dt / 10 * 1e3, frac_of_fp64_peak=frac(pb, dt / 10 * 1e3), lnL=lnl2,
+                           same_lnL_to_1e12=bool(abs(lnl2 - row["lnL"]) <= 1e-12 * abs(lnl2)))
+    eng.close()
+    # 2. several genes (option G) on 4 states
+    pb = synth.nuc_gtr_gamma_problem(n_tips=32, n_patt=100_000)
+    q = pb.n_patt // 4
+    pbg = dataclasses.replace(pb, gene_off=np.array([0, q, 2 * q, 3 * q, pb.n_patt], dtype=np.int32), gene_rate=np.array([1.0, 0.7, 1.3, 1.9]),
+                              eigen_of=None, qfactor=None)
+    eng, _ = run("baseml GTR+G4, 32 taxa x 100000 patterns in 4 genes", pbg, steps=50, why="the fused 4-state kernel holds one gene's P(t) tables per workgroup")
+    eng.close()
+    # 3. 20 states with more taxa than the matrix-core kernel's LDS holds tables for
+    pb = synth.aa_gamma_problem(n_tips=60, n_patt=100_000, seed=60)
+    eng, _ = run("codeml seqtype 2 + G4, 60 taxa x 100000 patterns", pb, steps=10, why="> 49 taxa: the internal branches' P(t) no longer fit the 20-state kernel's LDS")
+    eng.close()
+    # 4. every internal node's partial kept (method = 1 / eval_dirty): a full evaluation writes 7.2 GB
+    if pb_c4 is not None:
+        eng, row = run("codon M0, 16 taxa x 1000000 patterns, PAML_AMD_KEEP_PARTIALS", pb_c4, flags=engine.KEEP_PARTIALS, steps=5,
+                       why="STORE / LOAD of resident partials are interpreter ops")
+        row["hbm_write_GB"] = 512e-9 * pb_c4.n_patt * (pb_c4.tree.n_nodes - pb_c4.tree.n_tips)
+        eng.close()
+    return rows
 
 
 def bench_aa20(engine, synth, timed, args):
