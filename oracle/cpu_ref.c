@@ -482,6 +482,12 @@ int orc_node_posterior(const orc_problem *pb, int node, double *post)
    return 0;
 }
 
+/* lfuntdd / lfuntdd_SiteClass restated (treesub.c:8204-8296, 8403-8541): P, dP, ddP from the eigen system, then the contraction with
+ * the partials of the branch's two ends.  PINNING: the reference prints neither dl nor ddl, so this function is pinned (a) by l(t) = the
+ * pinned lnL at the current length and by central differences of that pinned lnL along the branch (tests/test_oracle_golden.py), and
+ * (b) through the reference itself: its own minbranches, run on the engine through integration/treesub_branch_seam.patch, follows the
+ * Newton steps these derivatives dictate and ends at the unmodified program's printed optimum (HIV M0 / M2a, and -1035.530508 for
+ * branch-site A under method = 1: tests/test_reference_binding_gpu.py), while the engine's values are held to this function's. */
 int orc_eval_branch(const orc_problem *pb, int node_b, int n_t, const double *t, double *lnL, double *dlnL, double *ddlnL)
 {
    int n = pb->n, np = pb->n_patt, K = pb->K, i, j, k, it, ig, ir, a;

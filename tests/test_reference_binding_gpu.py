@@ -249,6 +249,18 @@ def test_patched_reference_optimises_the_wider_model_families(name, extra, publi
     print("\n%s %s through the reference's own optimiser on the engine: lnL %.6f in %.2f s" % (name, extra.strip(), lnl[0], dt))
 
 
+def test_patched_baseml_with_method_1_matches_the_unmodified_program(tmp_path):
+    """baseml through minB / minbranches on the engine (4 states: the P / dP / ddP form of paml_amd_eval_branch), HKY85 + gamma on
+    brown.nuc, against the unmodified program with the same control file."""
+    if not (os.path.isfile(BASEML_GPU) and os.access(BASEML_GPU, os.X_OK)):
+        pytest.skip("oracle/_ref/baseml_gpu is not built (make -C oracle, needs /root/reference)")
+    ctl = (BASEML_CTL % (4, 0, "0.5")).replace("method = 0", "method = 1")
+    lnl, lnf, _, dt, out = run(BASEML_GPU, ctl, tmp_path / "gpu", ctl_name="baseml.ctl")
+    cl, clnf, _, cdt, _ = run(BASEML_CPU, ctl, tmp_path / "cpu", ctl_name="baseml.ctl")
+    assert len(lnl) == 1 and len(cl) == 1 and abs(lnl[0] - cl[0]) <= 2 * TOL, (lnl, cl, out[-1500:])
+    assert np.max(np.abs(lnf - clnf)) < 1e-3
+
+
 def test_hiv_site_models_through_the_patched_reference_are_fast(tmp_path):
     """HIV NSsites = 0 2 through codeml_gpu: with the rate matrices decomposed on the device only when they changed, and the class table
     / frequencies / per-pattern values moved only when needed, the reference's own ming2 spends its time in its own code."""
