@@ -286,11 +286,12 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       if (lab_b < 0 || lab_b >= NL) return fail(e, PAML_AMD_EINVAL, "eval_branch: branch label out of range");
       double *const efrag = e->d_bl_efrag.p + (size_t)lab_b * K * 2 * 4096, *const ztab = e->d_bl_ztab.p + (size_t)lab_b * K * e->n_codes * 64;
       HIPCHK(e->d_bl_etab.ensure((size_t)K * n_t * 192));
-      HIPCHK(e->d_bpartial.ensure((size_t)nbg * n_out));
+      const int nrows = nbg * 8;      // a row per wave and chunk (kernels_branch.h): the sums of an eighth of a reduction chunk
+      HIPCHK(e->d_bpartial.ensure((size_t)nrows * n_out));
       HIPCHK(e->d_bout.ensure((size_t)n_out));
       HIPCHK(e->d_tt.ensure(n_t));
-      e->bpart_rows = nbg; e->bpart_cols = n_out;
-      if (nbg != nb_local) HIPCHK(hipMemsetAsync(e->d_bpartial.p, 0, (size_t)nbg * n_out * sizeof(double), st));      // (the other ranks' rows)
+      e->bpart_rows = nrows; e->bpart_cols = n_out;
+      if (nbg != nb_local || chunk * nb_local != e->n_patt) HIPCHK(hipMemsetAsync(e->d_bpartial.p, 0, (size_t)nrows * n_out * sizeof(double), st));      // (the other ranks' rows; rows past the last pattern)
       int n_sons = 0, son[2] = {-1, -1};
       Program prog;
       bool run_pmat = false;
@@ -442,13 +443,13 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       if (e->comm) {
          HIPCHK(hipEventRecord(e->ev_part[0], st));
          HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[0], 0));
-         const ncclResult_t nr = rccl().AllReduce(e->d_bpartial.p, e->d_bpartial.p, (size_t)nbg * n_out, ncclDouble, ncclSum, e->comm, e->sc);
+         const ncclResult_t nr = rccl().AllReduce(e->d_bpartial.p, e->d_bpartial.p, (size_t)nrows * n_out, ncclDouble, ncclSum, e->comm, e->sc);
          if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
          HIPCHK(hipEventRecord(e->ev_done[0], e->sc));
          HIPCHK(hipStreamWaitEvent(st, e->ev_done[0], 0));
       }
       if (int r = ensure_hout(e, (size_t)n_out)) return r;
-      hipLaunchKernelGGL(branch_total_kernel, dim3(n_out), dim3(1024), 0, st, (const double *)e->d_bpartial.p, nbg, n_out, e->h_out);      // (pinned, device-visible: no copy)
+      hipLaunchKernelGGL(branch_total_kernel, dim3(n_out), dim3(256), 0, st, (const double *)e->d_bpartial.p, nrows, n_out, e->h_out);      // (pinned, device-visible: no copy)
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(st));      // the one host synchronisation of the call
       for (int i = 0; i < n_t; i++) { lnL[i] = e->h_out[3 * i]; dlnL[i] = e->h_out[3 * i + 1]; ddlnL[i] = e->h_out[3 * i + 2]; }

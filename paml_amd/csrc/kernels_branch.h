@@ -379,24 +379,18 @@ __device__ __forceinline__ void beig_terms(const double (&t)[3], bool take, doub
       acc[2] += (t[0] * t[2] - t[1] * t[1]) / (t[0] * t[0]) * w;
    }
 }
-// a chunk's sums: over the wave's sixteen patterns by butterfly (lane 16 q holds trial length q), the eight waves pairwise; every
-// thread of the workgroup comes here
-__device__ __forceinline__ void beig_chunk_store(const double (&acc)[3], int nt, double *sRed, int wave, int lane, double *row)
+// a row's sums (a wave's run of patterns inside a reduction chunk): over the wave's sixteen pattern columns by butterfly — lane 16 q
+// holds trial length q — straight to the row of the partial-sum array: no workgroup barrier anywhere in the walk, the waves of a
+// workgroup drift as the matrix-pipe arbitration lets them
+__device__ __forceinline__ void beig_row_store(const double (&acc)[3], int nt, int lane, double *row)
 {
 #pragma unroll
    for (int d = 0; d < 3; d++) {
       double v = acc[d];
 #pragma unroll
       for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-      if ((lane & 15) == 0) sRed[wave * (3 * BEIG_NT) + (lane >> 4) * 3 + d] = v;
+      if ((lane & 15) == 0 && (lane >> 4) < nt) row[(lane >> 4) * 3 + d] = v;
    }
-   __syncthreads();
-   if ((int)threadIdx.x < 3 * nt) {
-      const double *r = sRed + threadIdx.x;
-      constexpr int S = 3 * BEIG_NT;
-      row[threadIdx.x] = ((r[0] + r[S]) + (r[2 * S] + r[3 * S])) + ((r[4 * S] + r[5 * S]) + (r[6 * S] + r[7 * S]));
-   }
-   __syncthreads();
 }
 // the pattern's summed scale factors per class, relative to the largest (lfuntdd_SiteClass treesub.c:8316-8332 uses its own pivot)
 __device__ __forceinline__ double beig_smax(const double *scalef, int K, int n_scale, int n_patt, int hc)
@@ -460,13 +454,19 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
    constexpr bool t0 = NS > 0 && !S0I, t1 = NS > 1 && !S1I;      // tip sons
    const unsigned char *z0 = a.z + (long)(t0 ? a.son[0] : 0) * a.n_patt, *z1 = a.z + (long)(t1 ? a.son[1] : 0) * a.n_patt,
                        *zb = a.z + (long)(b_tip ? a.b_node : 0) * a.n_patt;
-   auto g_begin = [&](int lc) { return lc * a.chunk_groups + wave; };
-   auto g_stop = [&](int lc) { return min((lc + 1) * a.chunk_groups, a.n_groups); };
+   // a workgroup takes reduction chunks, each of its eight waves a contiguous eighth of the chunk (a ROW of the partial-sum array)
+   const int rg = a.chunk_groups / WAVES;
+   auto g_begin = [&](int lc) { return lc * a.chunk_groups + wave * rg; };
+   auto g_stop = [&](int lc) { return min(lc * a.chunk_groups + (wave + 1) * rg, a.n_groups); };
    v4d pf[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+   v4d pb[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};      // both partials resident: B is requested a group ahead as well
+   constexpr bool pb_ahead = NS == 0 && !b_tip;
+   const double *b_base = pclass + (long)((pb_ahead ? a.b_node : a.n_tips) - a.n_tips) * G * 1024;
    int c0 = 0, c1 = 0, cb = 0;
    if ((int)blockIdx.x < a.nb_local && g_begin(blockIdx.x) < g_stop(blockIdx.x)) {
       const int g = g_begin(blockIdx.x), hc = min(g * 16 + hl, a.n_patt - 1);
       if (first_base) beig_load(first_base + (long)g * 1024, lane, pf);
+      if (pb_ahead) beig_load(b_base + (long)g * 1024, lane, pb);
       if (t0) c0 = z0[hc];
       if (t1) c1 = z1[hc];
       if (b_tip) cb = zb[hc];
@@ -474,8 +474,8 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
    for (int lc = blockIdx.x; lc < a.nb_local; lc += gridDim.x) {
       double acc[3] = {0, 0, 0};
       const int g_end = g_stop(lc);
-      for (int g = g_begin(lc); g < g_end; g += WAVES) {
-         int gn = g + WAVES;      // this wave's next group (possibly in the workgroup's next chunk), -1: none
+      for (int g = g_begin(lc); g < g_end; g++) {
+         int gn = g + 1;      // this wave's next group (possibly in the workgroup's next chunk), -1: none
          if (gn >= g_end) {
             const int ln = lc + gridDim.x;
             gn = (ln < a.nb_local && g_begin(ln) < g_stop(ln)) ? g_begin(ln) : -1;
@@ -499,9 +499,12 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
 #pragma unroll
                for (int i = 0; i < 4; i++) zz[i] = zp[i];
             }
-            else beig_load(pclass + ((long)(a.b_node - a.n_tips) * G + g) * 1024, lane, bb);
             BEIG_MATVEC(sV, 0, pf, w);
             beig_load(first_base + (long)gp * 1024, lane, pf);
+            if constexpr (pb_ahead) {      // (the second product here, so that its operand's registers take the next group's B at once)
+               BEIG_MATVEC(sUt, 1, pb, zz);
+               beig_load(b_base + (long)gp * 1024, lane, pb);
+            }
          }
          else {
             // A's partial in the tree seen from this branch: the product of its sons' messages (ConditionalPNode, codeml.c:3545-3576)
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
             beig_store(pclass + ((long)(a.a_node - a.n_tips) * G + g) * 1024, lane, x);
             BEIG_MATVEC(sV, 0, x, w);
          }
-         if constexpr (!b_tip) BEIG_MATVEC(sUt, 1, bb, zz);
+         if constexpr (!b_tip && !pb_ahead) BEIG_MATVEC(sUt, 1, bb, zz);
          double wgt = fk, smax = 0;
          if (a.scalef) {
             smax = beig_smax(a.scalef, a.K, a.n_scale, a.n_patt, hc);
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
          }
          c0 = c0n; c1 = c1n; cb = cbn;
       }
-      if (a.feval) beig_chunk_store(acc, a.n_t, sRed, wave, lane, a.partial + (long)(a.first_chunk + lc) * a.n_out);
+      if (a.feval) beig_row_store(acc, a.n_t, lane, a.partial + ((long)(a.first_chunk + lc) * WAVES + wave) * a.n_out);
    }
 #undef BEIG_MATVEC
 }
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(512) void branch_poly_kernel(BranchPolyArgs a)
 {
    constexpr int WAVES = 8;
    extern __shared__ __attribute__((aligned(16))) double bpoly_smem[];
-   double *sE = bpoly_smem, *sRed = sE + (long)a.K * a.nt_here * 192;
+   double *sE = bpoly_smem;
    const int tid = threadIdx.x, lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int q = lane >> 4, hl = lane & 15;
@@ -586,10 +589,10 @@ __global__ __launch_bounds__(512) void branch_poly_kernel(BranchPolyArgs a)
    const long G = a.n_groups;
    for (int lc = blockIdx.x; lc < a.nb_local; lc += gridDim.x) {
       double acc[3] = {0, 0, 0};
-      const int g_end = min((lc + 1) * a.chunk_groups, a.n_groups);
+      const int rg = a.chunk_groups / WAVES, g0 = lc * a.chunk_groups + wave * rg, g_end = min(g0 + rg, a.n_groups);
       v4d pf[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};      // the coefficients one (class, group) step ahead
-      if (lc * a.chunk_groups + wave < g_end) beig_load(a.coef + (long)(lc * a.chunk_groups + wave) * 1024, lane, pf);
-      for (int g = lc * a.chunk_groups + wave; g < g_end; g += WAVES) {
+      if (g0 < g_end) beig_load(a.coef + (long)g0 * 1024, lane, pf);
+      for (int g = g0; g < g_end; g++) {
          const int h = g * 16 + hl;
          const bool valid = h < a.n_patt;
          const int hc = valid ? h : a.n_patt - 1;
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(512) void branch_poly_kernel(BranchPolyArgs a)
 #pragma unroll
             for (int i = 0; i < 4; i++) c[i] = pf[i];
             if (ir + 1 < a.K) beig_load(a.coef + ((long)(ir + 1) * G + g) * 1024, lane, pf);
-            else if (g + WAVES < g_end) beig_load(a.coef + (long)(g + WAVES) * 1024, lane, pf);
+            else if (g + 1 < g_end) beig_load(a.coef + (long)(g + 1) * 1024, lane, pf);
 #pragma unroll
             for (int it = 0; it < BEIG_NT; it++)
                if (it < a.nt_here) beig_poly(c, sE + ((long)ir * a.nt_here + it) * 192, q, gs[it]);
@@ -612,28 +615,23 @@ __global__ __launch_bounds__(512) void branch_poly_kernel(BranchPolyArgs a)
          beig_scatter(gs, q, t3);
          beig_terms(t3, valid && q < a.nt_here && wt > 0, wt, smax, acc);
       }
-      beig_chunk_store(acc, a.nt_here, sRed, wave, lane, a.partial + (long)(a.first_chunk + lc) * a.n_out + a.it0 * 3);
+      beig_row_store(acc, a.nt_here, lane, a.partial + ((long)(a.first_chunk + lc) * WAVES + wave) * a.n_out + a.it0 * 3);
    }
 }
 
-// one workgroup per output: the fixed-order total of column o of the chunk rows
-__global__ __launch_bounds__(1024) void branch_total_kernel(const double *partial, int nb, int n_out, double *out)
+// one workgroup per output: the fixed-order total of column o of the rows, in reduce_stage2's order (256 lanes sum the rows i, i + 256,
+// ... in turn, the butterfly, the four waves pairwise: paml_amd/distributed.py total_fixed_order restates it on the host)
+__global__ __launch_bounds__(256) void branch_total_kernel(const double *partial, int nb, int n_out, double *out)
 {
-   __shared__ double sw[16];
+   __shared__ double sw[4];
    const int o = blockIdx.x;
    double acc = 0;
-   for (int i = threadIdx.x; i < nb; i += 1024) acc += partial[(long)i * n_out + o];
+   for (int i = threadIdx.x; i < nb; i += 256) acc += partial[(long)i * n_out + o];
 #pragma unroll
    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
    __syncthreads();
-   if (threadIdx.x == 0) {
-      double t[16];
-      for (int i = 0; i < 16; i++) t[i] = sw[i];
-      for (int s = 1; s < 16; s <<= 1)
-         for (int i = 0; i + s < 16; i += 2 * s) t[i] += t[i + s];
-      out[o] = t[0];
-   }
+   if (threadIdx.x == 0) out[o] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
