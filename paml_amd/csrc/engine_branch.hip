@@ -290,7 +290,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       HIPCHK(e->d_bpartial.ensure((size_t)nrows * n_out));
       HIPCHK(e->d_bout.ensure((size_t)n_out));
       HIPCHK(e->d_tt.ensure(n_t));
-      e->bpart_rows = nrows; e->bpart_cols = n_out;
+      e->bpart_rows = nrows; e->bpart_cols = n_out; e->bpart_colmajor = true;
       if (nbg != nb_local || chunk * nb_local != e->n_patt) HIPCHK(hipMemsetAsync(e->d_bpartial.p, 0, (size_t)nrows * n_out * sizeof(double), st));      // (the other ranks' rows; rows past the last pattern)
       int n_sons = 0, son[2] = {-1, -1};
       Program prog;
@@ -409,17 +409,18 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          ba.n = n; ba.K = K; ba.n_patt = e->n_patt; ba.n_tips = e->n_tips; ba.n_int = n_int; ba.n_nodes = nn; ba.n_groups = n_groups;
          ba.n_scale = T.n_scale; ba.n_t = n_t; ba.n_codes = e->n_codes; ba.a_node = A; ba.b_node = Bn;
          ba.n_sons = n_sons; ba.son[0] = son[0]; ba.son[1] = son[1]; ba.feval = feval ? 1 : 0;
-         ba.chunk_groups = cg; ba.nb_local = nb_local; ba.first_chunk = e->first_chunk; ba.n_out = n_out;
+         ba.chunk_groups = cg; ba.nb_local = nb_local; ba.first_chunk = e->first_chunk; ba.n_out = n_out; ba.n_rows = nrows;
          ba.partials = e->d_bl_partials.p; ba.scalef = scaled ? e->d_bl_scalef.p : nullptr; ba.z = e->d_z.p;
          ba.pint = e->d_pint.p; ba.ptip = e->d_ptip.p; ba.tip_words = (long)tip_words(e);
          ba.efrag = efrag; ba.ztab = ztab; ba.etab = e->d_bl_etab.p;
          ba.ecol = e->d_bl_ecol.p + (size_t)lab_b * K * 128; ba.pcol = e->d_pcol.p;
-         static const bool exp_nostore = getenv("PAML_AMD_BEIG_NOSTORE") != nullptr;      // (timing experiment: results of later calls are garbage)
-         ba.no_store = exp_nostore ? 1 : 0;
+         static const int exp_abl = (getenv("PAML_AMD_BEIG_NOSTORE") ? 1 : 0) | (getenv("PAML_AMD_BEIG_NOMFMA") ? 2 : 0);      // (timing experiments: results are garbage)
+         ba.no_store = exp_abl;
          ba.freqK = e->d_freqK.p; ba.weights = e->d_weights.p; ba.coef = e->d_bl_coef.p; ba.partial = e->d_bpartial.p;
          const bool i0 = n_sons > 0 && !T.is_leaf(son[0]), i1 = n_sons > 1 && !T.is_leaf(son[1]);
          const int variant = n_sons == 0 ? 0 : (n_sons == 1 ? (i0 ? 1 : 2) : (i1 ? 3 : (i0 ? 4 : 5)));      // (two sons: the internal one, if any, comes first)
-         hipLaunchKernelGGL(beig_kernels[variant][b_tip ? 1 : 0][n == 61 ? 1 : 0], dim3(std::min(nb_local, e->n_cu), K), dim3(512), BEIG_LDS_BYTES, st, ba);
+         beig_fn const fn = beig_kernels[variant][b_tip ? 1 : 0][n == 61 ? 1 : 0];
+         hipLaunchKernelGGL(fn, dim3(std::min(nb_local, e->n_cu), K), dim3(512), BEIG_LDS_BYTES, st, ba);
          for (int v = e->n_tips; v < nn; v++) { bc.up[v] = up[v]; bc.ok[v] = 1; }
          e->n_branch_nodes += (long)std::count(clean.begin() + e->n_tips, clean.end(), 0);
          bc.coef_ok = true;
@@ -429,7 +430,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       if (!feval) {
          BranchPolyArgs pa{};
          pa.K = K; pa.n_patt = e->n_patt; pa.n_groups = n_groups; pa.n_scale = T.n_scale; pa.n_t = n_t;
-         pa.chunk_groups = cg; pa.nb_local = nb_local; pa.first_chunk = e->first_chunk; pa.n_out = n_out;
+         pa.chunk_groups = cg; pa.nb_local = nb_local; pa.first_chunk = e->first_chunk; pa.n_out = n_out; pa.n_rows = nrows;
          pa.coef = e->d_bl_coef.p; pa.etab = e->d_bl_etab.p; pa.scalef = scaled ? e->d_bl_scalef.p : nullptr; pa.weights = e->d_weights.p;
          pa.partial = e->d_bpartial.p;
          for (int it0 = 0; it0 < n_t; it0 += BEIG_NT) {
@@ -544,7 +545,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    const bool sharded = e->comm != nullptr || e->n_patt_global != e->n_patt;      // (also: shard geometry without a communicator, for tests)
    const long nbg = sharded ? (e->n_patt_global + blk - 1) / blk : nb_local, fb = sharded ? e->first_patt / blk : 0;
    HIPCHK(e->d_bpartial.ensure((size_t)nbg * n_out));
-   e->bpart_rows = nbg; e->bpart_cols = n_out;
+   e->bpart_rows = nbg; e->bpart_cols = n_out; e->bpart_colmajor = false;
    if (sharded) HIPCHK(hipMemsetAsync(e->d_bpartial.p, 0, (size_t)nbg * n_out * sizeof(double), st));
    double *const bpart = e->d_bpartial.p + (size_t)fb * n_out;
    if (mfma) {
@@ -620,7 +621,13 @@ int paml_amd_get_branch_partials(paml_amd_engine *e, double *out, long cap, long
    *rows = e->bpart_rows; *cols = e->bpart_cols;
    if (!out) return 0;
    if (cap < e->bpart_rows * e->bpart_cols || !e->d_bpartial.p) return fail(e, PAML_AMD_EINVAL, "get_branch_partials: no branch evaluation yet, or the buffer is too small");
-   HIPCHK(hipMemcpy(out, e->d_bpartial.p, (size_t)e->bpart_rows * e->bpart_cols * sizeof(double), hipMemcpyDeviceToHost));
+   if (!e->bpart_colmajor) { HIPCHK(hipMemcpy(out, e->d_bpartial.p, (size_t)e->bpart_rows * e->bpart_cols * sizeof(double), hipMemcpyDeviceToHost)); }
+   else {
+      std::vector<double> t((size_t)e->bpart_rows * e->bpart_cols);
+      HIPCHK(hipMemcpy(t.data(), e->d_bpartial.p, t.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (long r = 0; r < e->bpart_rows; r++)
+         for (int c = 0; c < e->bpart_cols; c++) out[r * e->bpart_cols + c] = t[(size_t)c * e->bpart_rows + r];
+   }
    return 0;
 }
 

@@ -252,6 +252,7 @@ struct paml_amd_engine {
    int zpm_words = 0;
    DevBuf<int> d_red_counter;         // "last workgroup adds up the partial sums" tickets, one per batch element
    long bpart_rows = 0; int bpart_cols = 0;      // shape of the last eval_branch's partial-sum array
+   bool bpart_colmajor = false;                  // ... stored [column][row] (the eigen-basis kernels), handed out [row][column] either way
    double *h_out = nullptr;           // pinned, device-visible: the synchronous entry points have lnL written straight to the host
    size_t h_out_cap = 0;
    bool fused = false;                // the selected kernel forms the reduction itself

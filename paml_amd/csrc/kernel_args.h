@@ -133,7 +133,8 @@ struct BranchEigArgs {
    int n_sons, son[2];                  // n_sons > 0: A's partial is formed here from its sons in the tree seen from the branch (then stored)
    int no_store;                        // timing experiment: the coefficients are not written
    int feval;                           // K == 1: lnL, dlnL, ddlnL of the n_t (<= BEIG_NT) trial lengths are formed in the same pass
-   int chunk_groups, nb_local, first_chunk, n_out;      // partial sums: one row of n_out = 3 n_t per chunk of 16 * chunk_groups patterns, at global chunk positions
+   int chunk_groups, nb_local, first_chunk, n_out;      // partial sums [n_out = 3 n_t columns][n_rows]: a row per wave's eighth of a chunk of 16 * chunk_groups patterns, at global positions
+   long n_rows;
    double *partials;                    // [K][n_int][n_groups][1024]  (read; A's slot written when n_sons > 0)
    const double *scalef;                // [K][n_scale][n_patt] or null
    const unsigned char *z;              // [n_tips][n_patt]
@@ -150,6 +151,7 @@ struct BranchEigArgs {
 struct BranchPolyArgs {
    int K, n_patt, n_groups, n_scale, n_t, it0, nt_here;      // this launch: trial lengths it0 .. it0 + nt_here - 1 of n_t
    int chunk_groups, nb_local, first_chunk, n_out;
+   long n_rows;
    const double *coef, *etab, *scalef, *weights;
    double *partial;
 };

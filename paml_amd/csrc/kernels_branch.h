@@ -283,10 +283,10 @@ __global__ __launch_bounds__(256) void branch_reduce_kernel(const double *partia
 //                         the one node whose orientation changes when minbranches moves to the next branch), w = V A, z, c -> HBM;
 //                         with one class also f, f', f'' of up to BEIG_NT trial lengths and the chunk's three sums per trial length
 // branch_poly_kernel      f, f', f'' from the stored coefficients: the class mixture, more than BEIG_NT trial lengths, every later call
-// branch_total_kernel     fixed-order total of the chunk rows (after the all-reduce over the ranks, when there are ranks)
-// Chunks are the evaluation's reduction chunks (a function of the GLOBAL pattern count): row r of `partial` is chunk r of the whole
-// alignment whatever the number of ranks, and a chunk's sum is formed in one fixed order (a wave's patterns in sequence, the 64
-// lanes by butterfly, the 8 waves pairwise).
+// branch_total_kernel     fixed-order total of the rows (after the all-reduce over the ranks, when there are ranks)
+// A row of `partial` ([column][row]) is the sum over one wave's eighth of a reduction chunk of the evaluation (a function of the GLOBAL
+// pattern count: the same rows whatever the number of ranks), formed in one fixed order (the wave's patterns in sequence, then the
+// sixteen pattern columns by butterfly); no workgroup barrier anywhere in the walk.
 __global__ __launch_bounds__(256) void branch_eigprep_kernel(EigPrepArgs a)
 {
    const int iclass = blockIdx.x, n = a.n, tid = threadIdx.x;
@@ -382,14 +382,15 @@ __device__ __forceinline__ void beig_terms(const double (&t)[3], bool take, doub
 // a row's sums (a wave's run of patterns inside a reduction chunk): over the wave's sixteen pattern columns by butterfly — lane 16 q
 // holds trial length q — straight to the row of the partial-sum array: no workgroup barrier anywhere in the walk, the waves of a
 // workgroup drift as the matrix-pipe arbitration lets them
-__device__ __forceinline__ void beig_row_store(const double (&acc)[3], int nt, int lane, double *row)
+// (the array is [column][row]: the total's lanes then read consecutive rows of a column)
+__device__ __forceinline__ void beig_row_store(const double (&acc)[3], int nt, int lane, double *row, long n_rows)
 {
 #pragma unroll
    for (int d = 0; d < 3; d++) {
       double v = acc[d];
 #pragma unroll
       for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-      if ((lane & 15) == 0 && (lane >> 4) < nt) row[(lane >> 4) * 3 + d] = v;
+      if ((lane & 15) == 0 && (lane >> 4) < nt) row[((lane >> 4) * 3 + d) * n_rows] = v;
    }
 }
 // the pattern's summed scale factors per class, relative to the largest (lfuntdd_SiteClass treesub.c:8316-8332 uses its own pivot)
@@ -439,7 +440,11 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
    }
    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    __syncthreads();
-#define BEIG_MATVEC(MAT, IDX, X, Y) jit_matvec<T61, 4, 16>((MAT), lane, (X), (Y), JitNoSide(), sCol + (IDX) * 64, T61 ? jit_x60((X), lane) : 0.0)
+#define BEIG_MATVEC(MAT, IDX, X, Y)                                                                                             \
+   do {                                                                                                                         \
+      if (a.no_store & 2) { _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) (Y)[i_] = (X)[i_]; }      /* timing experiment: no products */ \
+      else jit_matvec<T61, 4, 16>((MAT), lane, (X), (Y), JitNoSide(), sCol + (IDX) * 64, T61 ? jit_x60((X), lane) : 0.0);       \
+   } while (0)
 
    const long G = a.n_groups;
    double *pclass = a.partials + (long)iclass * a.n_int * G * 1024;
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
          v4d c[4];
 #pragma unroll
          for (int i = 0; i < 4; i++) c[i] = (w[i] * zz[i]) * wgt;
-         if (!a.no_store) beig_store(cclass + (long)g * 1024, lane, c);
+         if (!(a.no_store & 1)) beig_store(cclass + (long)g * 1024, lane, c);
          if (a.feval) {
             double g4[BEIG_NT][3];
 #pragma unroll
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void branch_eig_kernel(BranchEigArgs a)
          }
          c0 = c0n; c1 = c1n; cb = cbn;
       }
-      if (a.feval) beig_row_store(acc, a.n_t, lane, a.partial + ((long)(a.first_chunk + lc) * WAVES + wave) * a.n_out);
+      if (a.feval) beig_row_store(acc, a.n_t, lane, a.partial + ((long)(a.first_chunk + lc) * WAVES + wave), a.n_rows);
    }
 #undef BEIG_MATVEC
 }
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(512) void branch_poly_kernel(BranchPolyArgs a)
          beig_scatter(gs, q, t3);
          beig_terms(t3, valid && q < a.nt_here && wt > 0, wt, smax, acc);
       }
-      beig_row_store(acc, a.nt_here, lane, a.partial + ((long)(a.first_chunk + lc) * WAVES + wave) * a.n_out + a.it0 * 3);
+      beig_row_store(acc, a.nt_here, lane, a.partial + ((long)(a.first_chunk + lc) * WAVES + wave) + (long)a.it0 * 3 * a.n_rows, a.n_rows);
    }
 }
 
@@ -626,7 +631,15 @@ __global__ __launch_bounds__(256) void branch_total_kernel(const double *partial
    __shared__ double sw[4];
    const int o = blockIdx.x;
    double acc = 0;
-   for (int i = threadIdx.x; i < nb; i += 256) acc += partial[(long)i * n_out + o];
+   const double *col = partial + (long)o * nb;      // ([column][row])
+   for (int i0 = threadIdx.x; i0 < nb; i0 += 256 * 8) {      // eight loads in flight, added in the order i, i + 256, ...
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = i0 + 256 * k < nb ? col[i0 + 256 * k] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+         if (i0 + 256 * k < nb) acc += v[k];
+   }
 #pragma unroll
    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;

@@ -29,6 +29,7 @@ def timed(f, reps=1):
 
 def main():
     n_patt = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    nocheck = bool(os.environ.get("PROBE_NOCHECK"))      # timing ablations return garbage
     pb = synth.codon_m0_problem(n_tips=16, n_patt=n_patt, estimate_pi=True)
     eng = engine.engine_for(pb)
     t = pb.tree
@@ -44,14 +45,14 @@ def main():
     pre(t.root)
     b0 = order[0]
     ms_first, (l, dl, ddl) = timed(lambda: eng.eval_branch(b0, np.array([t.branch[b0]]), t.branch))
-    assert abs(l[0] - full) <= 1e-11 * abs(full), (l[0], full)
+    assert nocheck or abs(l[0] - full) <= 1e-11 * abs(full), (l[0], full)
     c0 = eng.branch_counters()
     form, hit = [], []
     for cycle in range(2):
         for b in order:
             ms, (l, dl, ddl) = timed(lambda: eng.eval_branch(b, np.array([t.branch[b]]), t.branch))
             form.append(ms)
-            assert abs(l[0] - full) <= 1e-11 * abs(full)
+            assert nocheck or abs(l[0] - full) <= 1e-11 * abs(full)
             ts = t.branch[b] * (1 + 0.05 * np.arange(1, 5))
             ms, _ = timed(lambda: eng.eval_branch(b, ts, t.branch))
             hit.append(ms)
@@ -66,7 +67,7 @@ def main():
     del os.environ["PAML_AMD_NO_COEF_CACHE"]
     eng.eval_branch(b, np.array([t.branch[b]]), t.branch)
     res["same_branch_form_nt1_ms"], (l, _, _) = timed(lambda: eng.eval_branch(b, np.array([t.branch[b]]), t.branch), 10)
-    assert abs(l[0] - full) <= 1e-11 * abs(full)
+    assert nocheck or abs(l[0] - full) <= 1e-11 * abs(full)
     res["same_branch_form_nt4_ms"], _ = timed(lambda: eng.eval_branch(b, t.branch[b] * (1 + 0.05 * np.arange(4)), t.branch), 10)
     tipb = 3
     eng.eval_branch(tipb, np.array([t.branch[tipb]]), t.branch)

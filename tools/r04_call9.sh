@@ -6,7 +6,7 @@ timeout 1200 python -m pytest tests/test_engine_gpu.py tests/test_multirank_gpu.
 grep "passed\|failed" $out/t_branch.txt | tail -2; grep -B30 "Error" $out/t_branch.txt | head -60
 R=$PWD
 cd /tmp
-true
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/branch_stats -o s -- python $R/tools/branch_probe.py > $out/branch_probe_rocprof.json 2>$out/branch_stats.err
 cd - >/dev/null
 find $out/branch_stats -name "*kernel_stats.csv" -exec cp {} $out/branch_eig_kernel_stats.csv \;
 rm -rf $out/branch_stats
