@@ -25,7 +25,8 @@ static int beb_front(paml_amd_engine *e, const char *who, int n_grid, int n_cls,
    HIPCHK(e->d_beb_out.ensure(out_per_patt * np));
    HIPCHK(upload(e->d_beb_pcl, pcl, (size_t)n_grid * n_cls, e->stream));
    HIPCHK(upload(e->d_beb_iw, iw, (size_t)n_grid * n_cls, e->stream));
-   a.fhK = e->fhk_slot(e->last_fhk).p; a.weights = e->d_weights.p;      // (a run of eval_device calls may have left the last evaluation's in another slot) a.f = e->d_beb_f.p; a.pcl = e->d_beb_pcl.p; a.iw = e->d_beb_iw.p;
+   // (the class likelihoods of the LAST evaluation: a run of eval_device calls may have left them in another slot than d_fhK)
+   a.fhK = e->fhk_slot(e->last_fhk).p; a.weights = e->d_weights.p; a.f = e->d_beb_f.p; a.pcl = e->d_beb_pcl.p; a.iw = e->d_beb_iw.p;
    a.part = e->d_beb_part.p; a.lnfxs = e->d_beb_g.p; a.wg = e->d_beb_g.p + n_grid; a.fx = e->d_beb_g.p + 2 * n_grid;
    a.w_class = e->d_beb_g.p + 2 * n_grid + 1;
    a.pr_last = e->d_beb_out.p; a.mean_w = a.pr_last + np; a.sd_w = a.mean_w + np;
