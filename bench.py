@@ -221,13 +221,17 @@ def main():
     # lane_wait_us = how long an evaluation's pruning stream stood in front of its slot's previous exchange (the event pair that
     # measures it costs ~12 us itself: that is the floor).  64 evaluations with timed events, AFTER the timed region.
     if world > 1 or force_comm:
-        eng.comm_stats(True)
-        dst = torch.zeros(64, dtype=torch.float64, device="cuda")
-        for i in range(64):
-            eng.eval_device(branch, dst.data_ptr() + 8 * i)
-        eng.flush()
-        fence()
-        st = eng.comm_stats(False, read=True)
+        try:      # (diagnostics: whatever goes wrong here, the headline above stands)
+            eng.comm_stats(True)
+            dst = torch.zeros(64, dtype=torch.float64, device="cuda")
+            for i in range(64):
+                eng.eval_device(branch, dst.data_ptr() + 8 * i)
+            eng.flush()
+            fence()
+            st = eng.comm_stats(False, read=True)
+        except Exception as ex:      # noqa: BLE001
+            st = {"n": 0, "exchange_us": -1.0, "exchange_us_max": -1.0, "lane_wait_us": -1.0, "lane_wait_us_max": -1.0, "error": repr(ex)}
+            fence()
         box = [st]
         if world > 1:
             box = [None] * world
