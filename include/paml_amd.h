@@ -75,7 +75,12 @@ const char *paml_amd_last_error(const paml_amd_engine *e);
  *   eval_dirty / eval_branch return totals over all ranks, identical bits on every rank; the lnL of eval* is moreover
  *   independent of `world` (the ranks' zero-padded partial-sum arrays are added — exact — and summed in one fixed order).
  *   lnf / fhK / partials / posteriors stay per-shard.  world = 1 with a non-NULL id makes a one-rank communicator (the
- *   collective path on a single GPU); world = 1 with id = NULL only sets the global chunking.  eval_adg does not shard.
+ *   collective path on a single GPU); world = 1 with id = NULL only sets the global chunking.
+ *   eval_adg (the rate chain runs over the sites in order): pose[] holds GLOBAL pattern indices, the same on every rank; the
+ *   shards' class likelihoods are gathered over the ranks and every rank runs the chain — the same bits as a single engine.
+ *   beb_grid / beb_grid_classes: a grid point's log-likelihood is a sum over all patterns, so the shards' sums are all-reduced
+ *   before the grid weights are formed; every rank passes the same grid and gets the posteriors of ITS patterns and the
+ *   global ln_fx.  node_posterior and the host's NEB work per pattern and need no exchange.
  *   The exchange step (all-reduce of the partial sums + their fixed-order total) runs on a stream of the engine's own, ordered
  *   by events: consecutive paml_amd_eval_device calls prune evaluation i + 1 while evaluation i is being reduced.  Every other
  *   entry point, and paml_amd_flush, joins the engine's stream to the totals still on their way.

@@ -32,6 +32,21 @@ static int beb_front(paml_amd_engine *e, const char *who, int n_grid, int n_cls,
    a.pr_last = e->d_beb_out.p; a.mean_w = a.pr_last + np; a.sd_w = a.mean_w + np;
    hipLaunchKernelGGL(beb_scale, dim3((np + 255) / 256), dim3(256), 0, e->stream, a);
    hipLaunchKernelGGL(beb_lnfx, dim3(a.n_pblk, (n_grid + 63) / 64), dim3(256), 0, e->stream, a);
+   if (e->comm && e->world > 1) {
+      // Pattern shards: a grid point's log-likelihood is a sum over ALL patterns, so the shards' sums are added over the
+      // ranks before the grid weights are formed; everything per pattern (beb_scale, beb_post) stays on the shard.  Every rank
+      // calls with the same grid; each gets the posteriors of its own patterns and the same ln_fx.
+      a.phase = 1;
+      hipLaunchKernelGGL(beb_finish, dim3(1), dim3(256), 0, e->stream, a);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(e->ev_part[0], e->stream));
+      HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[0], 0));
+      const ncclResult_t nr = rccl().AllReduce(a.lnfxs, a.lnfxs, (size_t)n_grid, ncclDouble, ncclSum, e->comm, e->sc);
+      if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string(who) + ": ncclAllReduce: " + rccl().GetErrorString(nr));
+      HIPCHK(hipEventRecord(e->ev_done[0], e->sc));
+      HIPCHK(hipStreamWaitEvent(e->stream, e->ev_done[0], 0));
+      a.phase = 2;
+   }
    hipLaunchKernelGGL(beb_finish, dim3(1), dim3(256), 0, e->stream, a);
    return 0;
 }

@@ -695,20 +695,44 @@ int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *ge
    enter(e);
    if (!e || !branch || !MK || !pose || !lnL || ls < 1) return fail(e, PAML_AMD_EINVAL, "eval_adg: bad arguments");
    if (e->mode != PAML_AMD_MODE_LFUNDG) return fail(e, PAML_AMD_EINVAL, "eval_adg: needs the lfundG class mode");
-   if (e->world > 1) return fail(e, PAML_AMD_EUNSUPPORTED, "eval_adg: the rate chain runs over the sites in order and does not shard (SURVEY 8e)");
-   const int K = e->K, np = e->n_patt;
+   // With pattern shards pose[] holds GLOBAL pattern indices, the same on every rank: the class likelihoods are computed
+   // on the shards, gathered over the ranks, and every rank runs the (sequential, short) chain over the sites itself.
+   const bool sharded = e->comm && e->world > 1;
+   const int K = e->K, npl = e->n_patt;
+   const long np = sharded ? e->n_patt_global : npl;
    for (int i = 0; i < ls; i++)
       if (pose[i] < 0 || pose[i] >= np) return fail(e, PAML_AMD_EINVAL, "eval_adg: pose entry out of range");
    int r = launch_eval(e, branch, gene_rate, nullptr, nullptr, false);      // fx_r on the device
    if (r) return r;
+   if (int rc = join_comm(e)) return rc;
    std::vector<double> fhK((size_t)K * np), w(np), b1(K), b2(K);
-   HIPCHK(hipMemcpyAsync(fhK.data(), e->d_fhK.p, fhK.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-   HIPCHK(hipMemcpyAsync(w.data(), e->d_weights.p, w.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   const double *src = e->fhk_slot(e->last_fhk).p;
+   if (sharded) {
+      // the gather: every rank puts its columns into a zeroed [K + 1][n_patt_global] table (class likelihoods, then the weights) and
+      // the tables are added — x + 0 is exact, so every rank ends with the bits a single engine would hold
+      HIPCHK(e->d_adg_all.ensure((size_t)(K + 1) * np));
+      HIPCHK(hipMemsetAsync(e->d_adg_all.p, 0, (size_t)(K + 1) * np * sizeof(double), e->stream));
+      HIPCHK(hipMemcpy2DAsync(e->d_adg_all.p + e->first_patt, (size_t)np * sizeof(double), src, (size_t)npl * sizeof(double),
+                              (size_t)npl * sizeof(double), (size_t)K, hipMemcpyDeviceToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(e->d_adg_all.p + (size_t)K * np + e->first_patt, e->d_weights.p, (size_t)npl * sizeof(double),
+                            hipMemcpyDeviceToDevice, e->stream));
+      HIPCHK(hipEventRecord(e->ev_part[0], e->stream));
+      HIPCHK(hipStreamWaitEvent(e->sc, e->ev_part[0], 0));
+      const ncclResult_t nr = rccl().AllReduce(e->d_adg_all.p, e->d_adg_all.p, (size_t)(K + 1) * np, ncclDouble, ncclSum, e->comm, e->sc);
+      if (nr != ncclSuccess) return fail(e, PAML_AMD_EHIP, std::string("eval_adg: ncclAllReduce: ") + rccl().GetErrorString(nr));
+      HIPCHK(hipEventRecord(e->ev_done[0], e->sc));
+      HIPCHK(hipStreamWaitEvent(e->stream, e->ev_done[0], 0));
+      HIPCHK(hipMemcpyAsync(fhK.data(), e->d_adg_all.p, fhK.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(w.data(), e->d_adg_all.p + (size_t)K * np, w.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   } else {
+      HIPCHK(hipMemcpyAsync(fhK.data(), src, fhK.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(w.data(), e->d_weights.p, w.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   }
    HIPCHK(hipStreamSynchronize(e->stream));
    // the chain over sites in their original order is sequential: host (treesub.c:7456-7492)
    double l = 0;
    if (e->tree.n_scale)
-      for (int h = 0; h < np; h++) {
+      for (long h = 0; h < np; h++) {
          const double fh = fhK[h];
          if (!(w[h] > 0)) continue;
          l += fh * w[h];

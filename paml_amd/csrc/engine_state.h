@@ -362,6 +362,7 @@ struct paml_amd_engine {
    // per-evaluation buffers
    DevBuf<double> d_b_qfactor, d_b_freqK, d_b_rate;
    DevBuf<double> d_beb_f, d_beb_part, d_beb_g, d_beb_out, d_beb_pcl;      // BEB grid integral
+   DevBuf<double> d_adg_all;      // eval_adg with pattern shards: [K + 1][n_patt_global] gathered class likelihoods and weights
    DevBuf<int> d_beb_iw;
    DevBuf<double> d_rowmajor, d_pint, d_ptip, d_pcol, d_fhK, d_fscale, d_lnf, d_partial, d_out, d_partials, d_scalef, d_stack;
    DevBuf<double> d_expA, d_expB, d_expSA, d_expSB, d_deriv, d_tt, d_bpartial, d_bout;   // branch-local evaluation
@@ -427,7 +428,7 @@ struct paml_amd_engine {
       d_eq_q.release(); d_eq_pi.release(); d_eq_scale.release(); d_eq_ptr.release(); d_eq_sweeps.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
-                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot,
+                              &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_adg_all, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot,
                               &d_expA, &d_expB, &d_expSA, &d_expSB, &d_deriv, &d_tt, &d_bpartial, &d_bout};
       for (auto b : b3) b->release();
       for (auto &sp : spare) { sp.rowmajor.release(); sp.pint.release(); sp.ptip.release(); sp.pcol.release(); }

@@ -171,6 +171,7 @@ struct PostArgs {
 struct BebArgs {
    int n_patt, K, n_grid, n_cls, n_pblk, patt_per_blk;
    int log_form;             // fhK holds logarithms (trees with scaling nodes)
+   int phase;                // beb_finish: 0 = sums and weights; 1 = the shard's sums only; 2 = weights from sums (all-reduced over the ranks in between)
    const double *fhK, *weights;
    double *f;                // [K][n_patt] scaled copy
    const double *pcl;        // [n_grid][n_cls]

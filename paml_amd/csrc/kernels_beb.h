@@ -13,7 +13,7 @@ namespace paml_amd {
 //   beb_scale:   f[k][h] = fhK[k][h] / max_k fhK[k][h]                       (codeml.c:6297-6305); with scaling nodes fhK holds
 //                log f + the scale factors and f[k][h] = exp(fhK[k][h] - max_k fhK[k][h])            (codeml.c:6286-6294)
 //   beb_lnfx:    part[g][b] = sum over block b's patterns of w_h log sum_c pcl[g][c] f[iw[g][c]][h]
-//   beb_finish:  lnfXs[g] = sum_b part[g][b] (fixed order);  fX = log sum_g exp(lnfXs[g]);  wg[g] = exp(lnfXs[g] - fX)
+//   beb_finish:  lnfXs[g] = sum_b part[g][b] (fixed order; with pattern shards all-reduced over the ranks here);  fX = log sum_g exp(lnfXs[g]);  wg[g] = exp(lnfXs[g] - fX)
 //   beb_post:    per pattern, sums over the grid of the class posteriors, omega and omega^2
 // One pattern per lane with its K class values in registers; the grid tables are wave-uniform (scalar loads).
 // ------------------------------------------------------------------------------------------------
@@ -60,11 +60,16 @@ __global__ __launch_bounds__(256) void beb_finish(BebArgs a)     // one block
    __shared__ double sred[256];
    double mx = -1e300;
    for (int g = threadIdx.x; g < a.n_grid; g += 256) {
-      double s = 0;
-      for (int b = 0; b < a.n_pblk; b++) s += a.part[(long)g * a.n_pblk + b];
-      a.lnfxs[g] = s;
+      double s;
+      if (a.phase == 2) s = a.lnfxs[g];      // (the sums over ALL shards: paml_amd_beb_grid's exchange step)
+      else {
+         s = 0;
+         for (int b = 0; b < a.n_pblk; b++) s += a.part[(long)g * a.n_pblk + b];
+         a.lnfxs[g] = s;
+      }
       mx = fmax(mx, s);
    }
+   if (a.phase == 1) return;
    sred[threadIdx.x] = mx;
    __syncthreads();
    for (int st = 128; st >= 1; st >>= 1) {

@@ -50,6 +50,19 @@ def run(pb, eng, n_dev=7):
     ts = np.array([br[b], br[b] * 1.5 + 0.01])
     l, dl, ddl = eng.eval_branch(b, ts, br, pb.gene_rate)
     out["eval_branch"] = [float(v).hex() for v in np.concatenate([l, dl, ddl])]
+    if pb.K > 1:      # what does not reduce to a sum of per-pattern terms: the auto-discrete-gamma chain over the sites, the BEB grid weights
+        rng = np.random.default_rng(5)
+        MK = rng.dirichlet(np.ones(pb.K), size=pb.K)
+        pose = rng.integers(0, pb.n_patt, size=4000).astype(np.int32)      # GLOBAL pattern indices, the same on every rank
+        out["eval_adg"] = float(eng.eval_adg(br, MK, pose, pb.gene_rate)).hex()
+        eng.eval(br, pb.gene_rate, want_fhk=True)
+        ncls, ngrid = 3, 60
+        pcl = rng.dirichlet(np.ones(ncls), size=ngrid)
+        iw = rng.integers(0, pb.K, size=(ngrid, ncls)).astype(np.int32)
+        b = eng.beb_grid(pcl, iw, np.linspace(0.2, 3.0, pb.K))
+        c = eng.beb_grid_classes(pcl, iw)
+        out["beb"] = dict(ln_fx=b["ln_fx"], pr_last=b["pr_last"].tolist(), mean_w=b["mean_w"].tolist(), sd_w=b["sd_w"].tolist(),
+                          ln_fx_classes=c["ln_fx"], post=c["post"].tolist())
     out["eval_again"] = float(eng.eval(br, pb.gene_rate)["lnL"]).hex()
     out["kernel"] = eng.kernel_name
     return out

@@ -9,6 +9,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 import helpers
@@ -63,9 +64,21 @@ def test_ranks_on_one_gpu_match_the_single_engine_bit_for_bit(case, tmp_path):
             # branch-local sums: per-block partials at global block positions, same fixed order -> same bits as well
             assert r["eval_branch"] == one["eval_branch"], (case, world)
             assert r["kernel"] == one["kernel"]
+            if "eval_adg" in one:
+                # the rate chain over the sites: class likelihoods gathered over the ranks (x + 0 is exact), the chain on every rank
+                assert r["eval_adg"] == one["eval_adg"], (case, world)
+                # the BEB grid: the shards' per-grid-point sums are all-reduced (a different summation order than the one engine's:
+                # agreement to rounding, not bits); each rank holds the posteriors of its own patterns
+                lo, hi = r["shard"]
+                assert abs(r["beb"]["ln_fx"] - one["beb"]["ln_fx"]) <= 1e-11 * abs(one["beb"]["ln_fx"])
+                assert abs(r["beb"]["ln_fx_classes"] - one["beb"]["ln_fx"]) <= 1e-11 * abs(one["beb"]["ln_fx"])
+                for key in ("pr_last", "mean_w", "sd_w"):
+                    assert np.allclose(r["beb"][key], one["beb"][key][lo:hi], rtol=1e-9, atol=1e-13), (case, world, key)
+                assert np.allclose(np.array(r["beb"]["post"]), np.array(one["beb"]["post"])[:, lo:hi], rtol=1e-9, atol=1e-13)
         assert res[0]["shard"][1] == res[1]["shard"][0]
     # the evaluations of the eval_device run differ from each other (different branch lengths) and the first equals eval
     assert one["eval_device"][0] == one["eval"] and len(set(one["eval_device"])) == len(one["eval_device"])
+    assert ("eval_adg" in one) == (case != "codon_jit")      # (every case with rate or site classes)
 
 
 def test_two_ranks_with_overlapping_pruning_kernels(tmp_path):
