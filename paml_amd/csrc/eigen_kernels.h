@@ -5,13 +5,17 @@
 // A = diag(sqrt pi) Q diag(1 / sqrt pi);  A = R diag(w) R^T;  Root = w (descending), U = diag(1 / sqrt pi) R, V = R^T diag(sqrt pi).
 // States of frequency zero are left out of the eigen problem and get Root = 0 and unit rows / columns (tools.c:5040-5105).
 //
-// One workgroup (4 waves) per matrix, A and R^T in LDS, cyclic Jacobi in the parallel (round-robin tournament) order: in a round the
+// One workgroup (EIG_NW waves) per matrix, A and R^T in LDS, cyclic Jacobi in the parallel (round-robin tournament) order: in a round the
 // N / 2 disjoint pairs (p, q) are rotated together — a wave works out the angles of its 8 pairs from their 2 x 2 blocks, combines
 // their rows of A and R^T (lane = column: conflict-free rows of stride 65) and, after a barrier, their columns of A (lane = row).
 // N - 1 rounds visit every pair once (a sweep); 9-10 sweeps bring the off-diagonal part of a 61 x 61 codon matrix below
 // 1e-16 ||A|| (quadratic convergence).  Every matrix of a batch has its own workgroup: a gradient's or a line search's several
-// hundred decompositions take the time of one, ~1 ms, and U, V, Root are written straight into the engine's eigen sets — they never
-// cross PCIe.  This is latency-class work (LDS round trips and barriers, ~25 MFLOP per matrix); nothing here wants the matrix cores.
+// hundred decompositions take the time of one, ~0.8 ms, and U, V, Root are written straight into the engine's eigen sets — they never
+// cross PCIe.  This is latency-class work (~25 MFLOP per matrix; nothing here wants the matrix cores) and it is bound by the LDS
+// pipeline of the one CU a matrix lives on: a round moves 6 KB per pair, 85 us per sweep with 8 waves as with 16 (4 waves: 115 us).
+// What an optimiser can save is sweeps: with the warm start (EigenQrevArgs::R0) a matrix that moved by a finite-difference step
+// takes 3 sweeps (two that rotate, one that only looks: pairs the stopping rule accepts are branched around), 0.26 ms; after a
+// line-search step of 5 % 5 sweeps, 0.43 ms (tools/eigen_probe.py).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,24 +30,62 @@ struct EigenQrevArgs {
    double *const *V;
    double *const *Root;
    int *sweeps;              // [n_sets] sweeps used (diagnostics; null: not wanted)
+   // warm start (paml_amd_set_eigen_warm_start): R0[set] = the eigenvectors R^T[64][64] (rows, in the order of the roots) the set's
+   // previous decomposition left, or null — the Jacobi sweeps then start from R0^T A R0, which is nearly diagonal when the matrix
+   // moved a little (a finite-difference step, a line search): 2-4 sweeps instead of 9-10.  Rout[set]: where this one's go (may be R0[set]).
+   const double *const *R0;  // [n_sets] or null
+   double *const *Rout;      // [n_sets] or null
 };
 
 constexpr int EIG_LD = 65;                                           // row stride of the LDS matrices (doubles)
-constexpr size_t EIG_LDS_BYTES = (size_t)(2 * 64 * EIG_LD + 64 + 64) * sizeof(double) + 64 * sizeof(int);
+constexpr size_t EIG_LDS_BYTES = (size_t)(3 * 64 * EIG_LD + 64 + 64) * sizeof(double) + 64 * sizeof(int);
 
-__global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
+__device__ __forceinline__ double eig_readlane(double x, int l)
+{
+   const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+   return __hiloint2double(hi, lo);
+}
+
+// C[4 x 4 tile of thread] = X Y (TRANS_Y: X Y^T) over 64 x 64 LDS matrices of stride EIG_LD: thread t owns rows 4 (t >> 4) .. + 3,
+// columns 4 (t & 15) .. + 3
+template <bool TRANS_Y>
+__device__ __forceinline__ void eig_mm_tile(const double *X, const double *Y, int tid, double (&c)[4][4])
+{
+   const int r0 = (tid >> 4) * 4, c0 = (tid & 15) * 4;
+#pragma unroll
+   for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) c[a][b] = 0;
+   for (int k = 0; k < 64; k++) {
+      double x[4], y[4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) x[a] = X[(r0 + a) * EIG_LD + k];
+#pragma unroll
+      for (int b = 0; b < 4; b++) y[b] = TRANS_Y ? Y[(c0 + b) * EIG_LD + k] : Y[k * EIG_LD + c0 + b];
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+         for (int b = 0; b < 4; b++) c[a][b] = fma(x[a], y[b], c[a][b]);
+   }
+}
+
+constexpr int EIG_NW = 8;                  // waves per matrix
+constexpr int EIG_NT = 64 * EIG_NW;        // threads
+constexpr int EIG_PW = 32 / EIG_NW;        // pairs of a round per wave
+
+__global__ __launch_bounds__(EIG_NT) void eigen_qrev_kernel(EigenQrevArgs a)
 {
    extern __shared__ double eig_sm[];
-   double *sA = eig_sm, *sV = sA + 64 * EIG_LD, *sSp = sV + 64 * EIG_LD, *sW = sSp + 64;
+   double *sA = eig_sm, *sV = sA + 64 * EIG_LD, *sT = sV + 64 * EIG_LD, *sSp = sT + 64 * EIG_LD, *sW = sSp + 64;
    int *sRank = (int *)(sW + 64);
-   __shared__ double sRed[4];
+   __shared__ double sRed[EIG_NW];
    const int n = a.n, N = (n + 1) & ~1, set = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
    const double *Q = a.Q + (size_t)set * n * n, *pi = a.pi + (size_t)set * n;
 
    if (tid < 64) sSp[tid] = (tid < n && pi[tid] > 1e-100) ? sqrt(pi[tid]) : 0.0;      // 0: the state is left out
    __syncthreads();
    double nrm = 0;
-   for (int idx = tid; idx < 64 * 64; idx += 256) {
+   for (int idx = tid; idx < 64 * 64; idx += EIG_NT) {
       const int i = idx >> 6, j = idx & 63;
       double v = 0;
       if (i < n && j < n) {
@@ -57,7 +99,45 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
    for (int off = 32; off; off >>= 1) nrm += __shfl_xor(nrm, off);
    if (lane == 0) sRed[wv] = nrm;
    __syncthreads();
-   const double thr = 1e-16 * sqrt((sRed[0] + sRed[1]) + (sRed[2] + sRed[3]));
+   double nrm2 = 0;
+   for (int w = 0; w < EIG_NW; w++) nrm2 += sRed[w];
+   const double thr = 1e-16 * sqrt(nrm2);
+
+   if (const double *r0 = a.R0 ? a.R0[set] : nullptr) {
+      // warm start: sV <- R0^T (rows = the previous eigenvectors), sA <- R0^T A R0.  Any orthogonal R0 gives the right answer — the
+      // sweeps below run to the same threshold; a good one gives it sooner.  Left-out states: unit rows of R0^T meet zero rows of A,
+      // the products are exact zeros and those rows stay out as in the cold start.
+      __syncthreads();
+      for (int idx = tid; idx < 64 * 64; idx += EIG_NT) {
+         const int i = idx >> 6, j = idx & 63;
+         sV[i * EIG_LD + j] = (i < n && j < n) ? r0[idx] : (i == j ? 1.0 : 0.0);
+      }
+      __syncthreads();
+      double c[4][4];
+      const int tr = (tid >> 4) * 4, tc = (tid & 15) * 4;
+      if (tid < 256) {      // (16 x 16 tiles of 4 x 4)
+         eig_mm_tile<false>(sV, sA, tid, c);      // T = R0^T A
+#pragma unroll
+         for (int x = 0; x < 4; x++)
+#pragma unroll
+            for (int y = 0; y < 4; y++) sT[(tr + x) * EIG_LD + tc + y] = c[x][y];
+      }
+      __syncthreads();
+      if (tid < 256) eig_mm_tile<true>(sT, sV, tid, c);       // B = T R0
+      __syncthreads();      // (sA is an operand of the first product)
+      if (tid < 256) {
+#pragma unroll
+         for (int x = 0; x < 4; x++)
+#pragma unroll
+            for (int y = 0; y < 4; y++) sA[(tr + x) * EIG_LD + tc + y] = c[x][y];
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 64 * 64; idx += EIG_NT) {      // exactly symmetric: the lower triangle from the upper
+         const int i = idx >> 6, j = idx & 63;
+         if (i > j) sA[i * EIG_LD + j] = sA[j * EIG_LD + i];
+      }
+      __syncthreads();
+   }
 
    // A wave owns the pairs wv, wv + 4, ... of a round (at most 8) through all three steps, so the rotation angles never leave its
    // registers: lanes 0-7 compute them (from the 2 x 2 blocks the previous round left in LDS), v_readlane hands them to the wave.
@@ -71,7 +151,7 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
          double cl = 1, sl = 0;
          int pl = 0, ql = 0;
          {
-            const int k = wv + 4 * (lane & 7);      // the pair this lane works out (lanes 8-63 repeat lanes 0-7: no divergence)
+            const int k = wv + EIG_NW * (lane & (EIG_PW - 1));      // the pair this lane works out (the other lanes repeat the first EIG_PW: no divergence)
             if (k < N / 2) {
                int p = r + k, q = r - k;
                if (p >= N - 1) p -= N - 1;
@@ -80,12 +160,12 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
                if (p > q) { const int t = p; p = q; q = t; }
                pl = p; ql = q;
                const double apq = sA[p * EIG_LD + q];
-               if (fabs(apq) > 1e-300) {
+               big = fmax(big, fabs(apq));
+               if (fabs(apq) > thr) {      // (an element the stopping rule accepts is left alone: its pair costs no LDS traffic below)
                   // t = tan(phi), the smaller root of t^2 + 2 theta t - 1 = 0 with theta = (aqq - app) / (2 apq), written without theta:
                   // t = 2 apq / (d + sgn(d) sqrt(d^2 + (2 apq)^2)), d = aqq - app.  Reciprocal and reciprocal square root from the
                   // hardware approximations + Newton steps: t only steers the convergence (a step suffices), c = 1 / sqrt(1 + t^2)
                   // must make the rotation orthogonal to the last bit (two steps); s = t c.
-                  big = fmax(big, fabs(apq));
                   // (d and a2 are brought to order one first: with app == aqq and |apq| below 1e-154 the squares would underflow to 0,
                   //  the reciprocal square root of 0 is infinite and the Newton step makes a NaN of it — degenerate spectra do this in
                   //  their late sweeps; the scale cancels in t)
@@ -104,40 +184,45 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
                }
             }
          }
-         double c[8], s[8], ap[8], aq[8], vp[8], vq[8];
-         int ip[8], iq[8], kp[8], kq[8];
-         bool on[8];
+         double c[EIG_PW], s[EIG_PW], ap[EIG_PW], aq[EIG_PW], vp[EIG_PW], vq[EIG_PW];
+         int ip[EIG_PW], iq[EIG_PW], kp[EIG_PW], kq[EIG_PW];
+         bool on[EIG_PW];      // wave-uniform (the angles come out of v_readlane): pairs that are not rotated are branched around
          const int lcol = lane < N ? lane : 0;
 #pragma unroll
-         for (int u = 0; u < 8; u++) {      // rows p, q of A and of R^T: lane = column; all loads before the first store (disjoint pairs)
-            c[u] = __shfl(cl, u); s[u] = __shfl(sl, u);
-            kp[u] = __shfl(pl, u); kq[u] = __shfl(ql, u);
-            on[u] = lane < N && s[u] != 0;
-            ip[u] = kp[u] * EIG_LD + lcol; iq[u] = kq[u] * EIG_LD + lcol;
-            ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]]; vp[u] = sV[ip[u]]; vq[u] = sV[iq[u]];
+         for (int u = 0; u < EIG_PW; u++) {      // rows p, q of A and of R^T: lane = column; all loads before the first store (disjoint pairs)
+            c[u] = eig_readlane(cl, u); s[u] = eig_readlane(sl, u);
+            kp[u] = __builtin_amdgcn_readlane(pl, u); kq[u] = __builtin_amdgcn_readlane(ql, u);
+            on[u] = s[u] != 0;
+            if (on[u]) {
+               ip[u] = kp[u] * EIG_LD + lcol; iq[u] = kq[u] * EIG_LD + lcol;
+               ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]]; vp[u] = sV[ip[u]]; vq[u] = sV[iq[u]];
+            }
          }
 #pragma unroll
-         for (int u = 0; u < 8; u++)
-            if (on[u]) {
+         for (int u = 0; u < EIG_PW; u++)
+            if (on[u] && lane < N) {
                sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u];
                sV[ip[u]] = c[u] * vp[u] - s[u] * vq[u]; sV[iq[u]] = s[u] * vp[u] + c[u] * vq[u];
             }
          __syncthreads();
 #pragma unroll
-         for (int u = 0; u < 8; u++) {      // columns p, q of A: lane = row
-            ip[u] = lcol * EIG_LD + kp[u]; iq[u] = lcol * EIG_LD + kq[u];
-            ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]];
-         }
+         for (int u = 0; u < EIG_PW; u++)      // columns p, q of A: lane = row
+            if (on[u]) {
+               ip[u] = lcol * EIG_LD + kp[u]; iq[u] = lcol * EIG_LD + kq[u];
+               ap[u] = sA[ip[u]]; aq[u] = sA[iq[u]];
+            }
 #pragma unroll
-         for (int u = 0; u < 8; u++)
-            if (on[u]) { sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u]; }
+         for (int u = 0; u < EIG_PW; u++)
+            if (on[u] && lane < N) { sA[ip[u]] = c[u] * ap[u] - s[u] * aq[u]; sA[iq[u]] = s[u] * ap[u] + c[u] * aq[u]; }
          __syncthreads();
       }
       // the largest off-diagonal element this sweep met (lanes 0-7 of every wave hold their pairs')
-      for (int off = 4; off; off >>= 1) big = fmax(big, __shfl_xor(big, off));
+      for (int off = EIG_PW / 2; off; off >>= 1) big = fmax(big, __shfl_xor(big, off));
       if (lane == 0) sRed[wv] = big;
       __syncthreads();
-      const bool done = fmax(fmax(sRed[0], sRed[1]), fmax(sRed[2], sRed[3])) <= thr;
+      double bigall = 0;
+      for (int w = 0; w < EIG_NW; w++) bigall = fmax(bigall, sRed[w]);
+      const bool done = bigall <= thr;
       __syncthreads();
       if (done) { sweep++; converged = true; break; }
    }
@@ -153,12 +238,13 @@ __global__ __launch_bounds__(256) void eigen_qrev_kernel(EigenQrevArgs a)
       a.Root[set][rk] = w / a.scale[set];
    }
    __syncthreads();
-   double *U = a.U[set], *V = a.V[set];
-   for (int idx = tid; idx < n * 64; idx += 256) {
+   double *U = a.U[set], *V = a.V[set], *Rout = a.Rout ? a.Rout[set] : nullptr;
+   for (int idx = tid; idx < n * 64; idx += EIG_NT) {
       const int p = idx >> 6, i = idx & 63;      // eigenvector p = row p of R^T
+      const int rk = sRank[p];
+      if (Rout) Rout[rk * 64 + i] = i < n ? sV[p * EIG_LD + i] : 0.0;
       if (i >= n) continue;
       const double sp = sSp[i] > 0 ? sSp[i] : 1.0, v = sV[p * EIG_LD + i];
-      const int rk = sRank[p];
       V[rk * n + i] = v * sp;
       U[i * n + rk] = v / sp;
    }

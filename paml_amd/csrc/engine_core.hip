@@ -264,14 +264,30 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
       max_id = std::max(max_id, set_ids[i]);
    }
    if (!eigen_slot(e, max_id)) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: bad arguments");      // (sizes the table once: the slots below do not move)
-   std::vector<double *> ptr((size_t)3 * n_sets);
+   std::vector<double *> ptr((size_t)5 * n_sets, nullptr);
    for (int i = 0; i < n_sets; i++) {
       EigenHost *h = eigen_slot(e, set_ids[i]);
       HIPCHK(h->U.ensure(n * n));
       HIPCHK(h->V.ensure(n * n));
       HIPCHK(h->Root.ensure(n));
-      h->kind = PAML_AMD_EIGEN_UVROOT;
       ptr[i] = h->U.p; ptr[n_sets + i] = h->V.p; ptr[2 * (size_t)n_sets + i] = h->Root.p;
+      if (e->eigen_warm) {
+         // start from the set's previous eigenvectors when it has some for the same set of states; every EIG_WARM_RUN-th
+         // decomposition starts cold again, so that rounding in the accumulated rotations cannot build up
+         constexpr int EIG_WARM_RUN = 16;
+         unsigned long long mask = 0;
+         for (size_t s = 0; s < n; s++)
+            if (pi[(size_t)i * n + s] > 1e-100) mask |= 1ull << s;
+         HIPCHK(h->Rt.ensure(64 * 64));
+         const bool warm = h->kind == PAML_AMD_EIGEN_UVROOT && h->warm_run >= 0 && h->warm_run < EIG_WARM_RUN - 1 && h->live_mask == mask;
+         ptr[3 * (size_t)n_sets + i] = warm ? h->Rt.p : nullptr;
+         ptr[4 * (size_t)n_sets + i] = h->Rt.p;
+         h->warm_run = warm ? h->warm_run + 1 : 0;
+         h->live_mask = mask;
+         e->n_eigen_warm += warm;
+      }
+      else h->warm_run = -1;
+      h->kind = PAML_AMD_EIGEN_UVROOT;
    }
    std::vector<double> ones;
    if (!scale) { ones.assign(n_sets, 1.0); scale = ones.data(); }
@@ -287,11 +303,20 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
    EigenQrevArgs a{};
    a.n = (int)n; a.Q = e->d_eq_q.p; a.pi = e->d_eq_pi.p; a.scale = e->d_eq_scale.p;
    a.U = e->d_eq_ptr.p; a.V = e->d_eq_ptr.p + n_sets; a.Root = e->d_eq_ptr.p + 2 * (size_t)n_sets; a.sweeps = e->d_eq_sweeps.p;
-   hipLaunchKernelGGL(eigen_qrev_kernel, dim3(n_sets), dim3(256), EIG_LDS_BYTES, e->stream, a);
+   if (e->eigen_warm) { a.R0 = e->d_eq_ptr.p + 3 * (size_t)n_sets; a.Rout = e->d_eq_ptr.p + 4 * (size_t)n_sets; }
+   hipLaunchKernelGGL(eigen_qrev_kernel, dim3(n_sets), dim3(EIG_NT), EIG_LDS_BYTES, e->stream, a);
    HIPCHK(hipGetLastError());
    // (the host arrays were pageable: the runtime has staged them on return; the evaluations that follow on the engine's stream see the sets)
    e->n_eigen_device += n_sets;
    e->eq_last_batch = n_sets;
+   return 0;
+}
+
+int paml_amd_set_eigen_warm_start(paml_amd_engine *e, int on, long *n_warm)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   if (n_warm) *n_warm = e->n_eigen_warm;
+   if (on >= 0) e->eigen_warm = on != 0;
    return 0;
 }
 

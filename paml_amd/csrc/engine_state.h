@@ -103,6 +103,11 @@ struct EigenHost {
    int kind = -1, nR = 0;
    double kappa = 0;
    DevBuf<double> U, V, Root, Cijk;
+   // warm start of the device decomposition (paml_amd_set_eigen_warm_start): the last decomposition's eigenvectors R^T[64][64], how
+   // many decompositions in a row started from their predecessor's, and which states that one left out (pi = 0)
+   DevBuf<double> Rt;
+   int warm_run = -1;
+   unsigned long long live_mask = 0;
 };
 
 // RCCL, bound at run time: libpaml_amd.so keeps loading on hosts without the collective library (single-GPU use needs none
@@ -353,6 +358,8 @@ struct paml_amd_engine {
    DevBuf<double *> d_eq_ptr;
    DevBuf<int> d_eq_sweeps;
    bool eigen_attr_set = false;
+   bool eigen_warm = false;      // paml_amd_set_eigen_warm_start
+   long n_eigen_warm = 0;
    long n_eigen_device = 0;
    int eq_last_batch = 0;
    bool eigen_dirty = true;

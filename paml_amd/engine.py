@@ -24,7 +24,7 @@ JIT = 2
 EXPORTS = [
     "paml_amd_set_gene_class_rates", "paml_amd_get_branch_partials", "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
-    "paml_amd_set_eigen_qrev_batch", "paml_amd_get_eigen", "paml_amd_eigen_counters", "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
+    "paml_amd_set_eigen_qrev_batch", "paml_amd_set_eigen_warm_start", "paml_amd_get_eigen", "paml_amd_eigen_counters", "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_device_count", "paml_amd_set_device", "paml_amd_shard_bounds", "paml_amd_max_ranks", "paml_amd_flush", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_comm_stats", "paml_amd_get_partial_sums", "paml_amd_branch_counters", "paml_amd_branch_coef_hits", "paml_amd_branch_kernel_ms",
     "paml_amd_jit_prebuild", "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
@@ -331,6 +331,13 @@ class Engine:
         b = np.ascontiguousarray(branch, dtype=np.float64)
         g = None if gene_rate is None else np.ascontiguousarray(gene_rate, dtype=np.float64)
         self._chk(self._L.paml_amd_eval_device(self._h, _p(b), _p(g), C.c_void_p(d_lnL_ptr)))
+
+    def set_eigen_warm_start(self, on=-1):
+        """paml_amd_set_eigen_warm_start: switch (1 / 0; -1 leaves it), returns the number of warm-started decompositions so far."""
+        n = C.c_long()
+        self._L.paml_amd_set_eigen_warm_start.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_long)]
+        self._chk(self._L.paml_amd_set_eigen_warm_start(self._h, int(on), C.byref(n)))
+        return n.value
 
     def set_eigen_qrev_batch(self, set_ids, Q, pi, scale=None):
         """Decompose the reversible rate matrices Q[k] (frequencies pi[k]) on the device into eigen sets set_ids[k]; Root is divided by scale[k]."""

@@ -107,3 +107,70 @@ def test_small_reversible_matrices(n):
         assert np.max(np.abs(U @ np.diag(R) @ V - Qs[k])) <= 1e-13 * np.abs(Qs[k]).max() * n
         assert np.max(np.abs(U @ V - np.eye(n))) <= 1e-13
         assert abs(R[0]) < 1e-13 and np.all(np.diff(R) <= 0)
+
+
+def test_warm_started_decompositions_along_an_optimisers_path():
+    """paml_amd_set_eigen_warm_start: three sets (omega classes) decomposed again and again while kappa and the omegas move the way an
+    optimiser moves them — finite-difference steps of 1e-6 relative, line-search steps of a few per cent.  From the second call on the
+    sweeps start from the previous eigenvectors: fewer sweeps, the same accuracy as the cold start (roots against LAPACK, U diag(Root) V
+    = Q, U V = I), through the periodic cold restarts and a change of the set of states with frequency zero; off by default."""
+    rng = np.random.default_rng(3)
+    pb = synth.codon_m0_problem(n_tips=6, n_patt=300)
+    eng = engine_for(pb)
+    assert eng.set_eigen_warm_start() == 0
+    pi = random_f3x4(rng)
+    kappa, om = 2.0, np.array([0.1, 1.0, 2.5])
+    ids = np.array([1, 2, 3])
+
+    def send(pi_):
+        Qs, mrs = zip(*[models.codon_q(kappa, w, pi_) for w in om])
+        eng.set_eigen_qrev_batch(ids, np.array(Qs), np.array([pi_] * 3), np.array(mrs))
+        return Qs, mrs, eng.eigen_counters()["sweeps"].copy()
+
+    def check(Qs, mrs, pi_):
+        for k in range(3):
+            U, V, R = eng.get_eigen(int(ids[k]))
+            live = pi_ > 1e-100
+            sp = np.sqrt(pi_[live])
+            A = Qs[k][np.ix_(live, live)] * sp[:, None] / sp[None, :]
+            A = np.tril(A) + np.tril(A, -1).T
+            w = np.sort(np.concatenate([np.linalg.eigvalsh(A), np.zeros((~live).sum())]))[::-1] / mrs[k]
+            scale = np.abs(A).max() / mrs[k]
+            Qz = Qs[k].copy()
+            Qz[~live, :] = 0; Qz[:, ~live] = 0
+            assert np.max(np.abs(R - w)) <= 1e-12 * scale and np.all(np.diff(R) <= 0) and abs(R[0]) <= 1e-13 * scale
+            assert np.max(np.abs(U @ np.diag(R) @ V - Qz / mrs[k])) <= 2e-13 * scale
+            assert np.max(np.abs(U @ V - np.eye(61))) <= 2e-13
+
+    Qs, mrs, cold = send(pi)
+    check(Qs, mrs, pi)
+    eng.set_eigen_warm_start(1)
+    Qs, mrs, sw = send(pi)                               # first call after switching on: nothing to start from yet
+    assert (sw == cold).all() and eng.set_eigen_warm_start() == 0
+    small, large = [], []
+    for it in range(70):
+        fd = it % 5 != 4
+        step = 1e-6 if fd else 0.05
+        kappa *= 1 + step * rng.choice([-1, 1])
+        om[[0, 2]] *= 1 + step * rng.choice([-1, 1], size=2)
+        Qs, mrs, sw = send(pi)
+        (small if fd else large).append(sw)
+        if it % 7 == 0 or it > 60:
+            check(Qs, mrs, pi)
+    small, large = np.array(small), np.array(large)
+    n_warm = eng.set_eigen_warm_start()
+    assert 3 * 60 <= n_warm < 3 * 70                      # all but the periodic cold restarts
+    # (the set with omega = 1 does not move on the omega steps: kappa moves it)
+    assert np.median(small) <= 3 and np.median(large) <= 5 and small.min() >= 1, (np.median(small), np.median(large))
+    assert (small >= cold.min()).sum() <= 3 * 5           # the cold restarts (every 16th decomposition of a set) are the only slow ones
+    # a codon position loses a nucleotide: other states are left out now, the next decomposition starts cold and is right
+    pi0 = random_f3x4(rng, zero=True)
+    Qs, mrs, sw = send(pi0)
+    assert eng.set_eigen_warm_start() == n_warm and (sw >= cold.min() - 2).all()
+    check(Qs, mrs, pi0)
+    Qs, mrs, sw = send(pi0)                               # the same matrices again, warm: converged at once
+    assert eng.set_eigen_warm_start() == n_warm + 3 and sw.max() <= 2
+    check(Qs, mrs, pi0)
+    eng.set_eigen_warm_start(0)
+    Qs, mrs, sw = send(pi0)
+    assert eng.set_eigen_warm_start() == n_warm + 3 and (sw >= cold.min() - 2).all()

@@ -268,4 +268,4 @@ def test_hiv_site_models_through_the_patched_reference_are_fast(tmp_path):
     lnl, lnf, nfun, dt, out = run(REF_GPU, HIV_CTL, tmp_path / "gpu")
     assert abs(lnl[0] - (-1137.688190)) <= TOL and abs(lnl[1] - (-1106.445004)) <= TOL, lnl
     print("\nHIV NSsites 0 2 through codeml_gpu: %.2f s (%s lfun)" % (dt, nfun))
-    assert dt < 3.0
+    assert dt < 2.0          # (1.2 s typical; the starting values are the reference's random ones)
