@@ -75,6 +75,47 @@ def check_lnl(what, lnl, name, n_patt, seed_default):
     return ref
 
 
+class HeadlineGuard:
+    """N > 1: the blocks behind the headline (NSsites sweep, weak line, replicas) open further communicators and run further
+    collectives.  Should one of them throw or hang on some rank, the headline that WAS measured still gets out: a rank that throws
+    reports and leaves; after `seconds` every rank's timer fires, rank 0 writes the line as it stands with `extras_error`, and
+    all leave with status 0 (os._exit: a rank stuck inside a collective cannot be unwound)."""
+
+    def __init__(self, out, fd, rank, seconds):
+        import threading
+        self.out, self.fd, self.rank, self.lock, self.done = out, fd, rank, threading.Lock(), False
+        self.timer = threading.Timer(seconds, self.fire, ("the blocks after the headline did not finish within %g s" % seconds,))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def fire(self, why):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+        if self.rank == 0 and self.out is not None:
+            for _ in range(3):      # (the main thread may be adding a block to the dict)
+                try:
+                    line = json.dumps(dict(self.out, extras_error=why), default=str)
+                    break
+                except RuntimeError:
+                    line = None
+            if line is not None:
+                os.write(self.fd, (line + "\n").encode())
+        sys.stderr.write("bench: rank %d: %s\n" % (self.rank, why))
+        sys.stderr.flush()
+        os._exit(0)
+
+    def finish(self):
+        """The normal end: False if the timer has already taken over (the caller then must not print)."""
+        with self.lock:
+            if self.done:
+                return False
+            self.done = True
+        self.timer.cancel()
+        return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,118 +257,124 @@ def main():
         }
         out["roofline"].update(profiles_evidence(flops_pp * pb.n_patt if (world == 1 and args.patterns == 1_000_000 and args.taxa == 16) else None))
 
-    # ---- N > 1 (or a forced one-rank communicator): what the exchange step did, per evaluation, so that a scaling run explains itself:
-    # exchange_us = partial sums ready -> total formed (all-reduce over the ranks + fixed-order total, on the engine's collective stream);
-    # lane_wait_us = how long an evaluation's pruning stream stood in front of its slot's previous exchange (the event pair that
-    # measures it costs ~12 us itself: that is the floor).  64 evaluations with timed events, AFTER the timed region.
-    if world > 1 or force_comm:
-        try:      # (diagnostics: whatever goes wrong here, the headline above stands)
-            eng.comm_stats(True)
-            dst = torch.zeros(64, dtype=torch.float64, device="cuda")
-            for i in range(64):
-                eng.eval_device(branch, dst.data_ptr() + 8 * i)
-            eng.flush()
-            fence()
-            st = eng.comm_stats(False, read=True)
-        except Exception as ex:      # noqa: BLE001
-            st = {"n": 0, "exchange_us": -1.0, "exchange_us_max": -1.0, "lane_wait_us": -1.0, "lane_wait_us_max": -1.0, "error": repr(ex)}
-            fence()
-        box = [st]
-        if world > 1:
-            box = [None] * world
-            dist.all_gather_object(box, st)
-        if rank == 0:
-            out["exchange"] = {"evaluations": st["n"], "exchange_us": max(b["exchange_us"] for b in box), "exchange_us_max": max(b["exchange_us_max"] for b in box),
-                               "lane_wait_us": max(b["lane_wait_us"] for b in box), "lane_wait_us_max": max(b["lane_wait_us_max"] for b in box),
-                               "per_rank": box, "pruning_streams": 2 if os.environ.get("PAML_AMD_DUAL", "1") != "0" else 1,
-                               "note": "means over the evaluations, maximum over the ranks; lane_wait_us includes ~12 us of its own event pair"}
-
-    extras = not args.no_extras
-    if extras:
-        # the same loop with the scalar read back to the host after every evaluation (what a serial optimiser waits for)
-        for _ in range(2):
-            eng.eval(branch)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            v = eng.eval(branch)["lnL"]
-        fence()
-        dt_rb = max_over_ranks(time.perf_counter() - t0)
-        if v != lnl:
-            raise SystemExit("bench: eval and eval_device disagree (%r vs %r)" % (v, lnl))
-        if rank == 0:
-            out["ms_per_step_readback"] = dt_rb / args.steps * 1e3
-    eng.close()
-
-    # ---- NSsites sweep on the same (sharded) data: the north_star's target workload -----------------------------------
-    if extras and args.scaling == "strong":
-        sweep = []
-        for name, ns, ncat, par, gname in SWEEP:
-            if ns == 0:
-                if rank == 0:
-                    sweep.append(dict(model=name, classes=1, ms_per_eval=out["ms_per_step"], lnL=lnl, lnL_reference=ref_lnl,
-                                      pattern_classes_per_s=out["value"]))
-                continue
-            freqs, omegas = models.nssites_classes(ns, par, ncat)
-            pbk = synth.codon_nssites_problem(pb, 2.0, omegas, freqs)            # this rank's shard, K classes
-            ek = engine.engine_for(pbk)
-            uid = None
-            if world > 1 or force_comm:
-                uid = engine.comm_unique_id() if rank == 0 else None
-                if world > 1:
-                    uid = distributed._store_broadcast_bytes(uid)
-            ek.comm_init(rank, world, uid, n_full, lo)
-            dtk, lk, _ = timed(ek, branch, args.sweep_steps, 2)
-            _, _, pk = timed(ek, branch, 3, 0, profile=True)
-            ek.close()
-            refk = check_lnl(name, lk, gname, n_full, args.taxa == 16)
+    # N > 1: whatever happens in the blocks behind the headline, the headline gets out (HeadlineGuard)
+    guard = HeadlineGuard(out, real_stdout, rank, float(os.environ.get("PAML_AMD_BENCH_EXTRAS_S", "300"))) if world > 1 else None
+    try:
+        # ---- N > 1 (or a forced one-rank communicator): what the exchange step did, per evaluation, so that a scaling run explains itself:
+        # exchange_us = partial sums ready -> total formed (all-reduce over the ranks + fixed-order total, on the engine's collective stream);
+        # lane_wait_us = how long an evaluation's pruning stream stood in front of its slot's previous exchange (the event pair that
+        # measures it costs ~12 us itself: that is the floor).  64 evaluations with timed events, AFTER the timed region.
+        if world > 1 or force_comm:
+            try:      # (diagnostics: whatever goes wrong here, the headline above stands)
+                eng.comm_stats(True)
+                dst = torch.zeros(64, dtype=torch.float64, device="cuda")
+                for i in range(64):
+                    eng.eval_device(branch, dst.data_ptr() + 8 * i)
+                eng.flush()
+                fence()
+                st = eng.comm_stats(False, read=True)
+            except Exception as ex:      # noqa: BLE001
+                st = {"n": 0, "exchange_us": -1.0, "exchange_us_max": -1.0, "lane_wait_us": -1.0, "lane_wait_us_max": -1.0, "error": repr(ex)}
+                fence()
+            box = [st]
+            if world > 1:
+                box = [None] * world
+                dist.all_gather_object(box, st)
             if rank == 0:
-                K = len(freqs)
-                kms = pk["ms_prune"] / max(1, pk["n_evals"])
-                sweep.append(dict(model=name, classes=K, ms_per_eval=dtk / args.sweep_steps * 1e3, lnL=lk, lnL_reference=refk,
-                                  pattern_classes_per_s=n_full * K * args.sweep_steps / dtk, kernel_ms=kms,
-                                  roofline_frac=algorithmic_flops_per_pattern(61, args.taxa) * K * pb.n_patt / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS))
-        if rank == 0:
-            out["sweep"] = sweep
-            tot_ms = sum(s["ms_per_eval"] for s in sweep)
-            out["sweep_total"] = {"classes": sum(s["classes"] for s in sweep), "ms": tot_ms,
-                                  "site_patterns_per_s": n_full * len(sweep) / (tot_ms * 1e-3)}
+                out["exchange"] = {"evaluations": st["n"], "exchange_us": max(b["exchange_us"] for b in box), "exchange_us_max": max(b["exchange_us_max"] for b in box),
+                                   "lane_wait_us": max(b["lane_wait_us"] for b in box), "lane_wait_us_max": max(b["lane_wait_us_max"] for b in box),
+                                   "per_rank": box, "pruning_streams": 2 if os.environ.get("PAML_AMD_DUAL", "1") != "0" else 1,
+                                   "note": "means over the evaluations, maximum over the ranks; lane_wait_us includes ~12 us of its own event pair"}
+        extras = not args.no_extras
+        if extras:
+            # the same loop with the scalar read back to the host after every evaluation (what a serial optimiser waits for)
+            for _ in range(2):
+                eng.eval(branch)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                v = eng.eval(branch)["lnL"]
+            fence()
+            dt_rb = max_over_ranks(time.perf_counter() - t0)
+            if v != lnl:
+                raise SystemExit("bench: eval and eval_device disagree (%r vs %r)" % (v, lnl))
+            if rank == 0:
+                out["ms_per_step_readback"] = dt_rb / args.steps * 1e3
+        eng.close()
 
-    # ---- second line at N > 1: weak scaling (10^6 patterns per GPU) -----------------------------------------------------
-    if extras and world > 1 and args.scaling == "strong":
-        pbw, ew, _ = weak_engine(args, world, rank, engine, distributed, synth, force_comm)
-        dtw, lw, _ = timed(ew, pbw.tree.branch.copy(), args.steps, args.warmup)
-        ew.close()
-        if rank == 0:
-            out["weak"] = {"scaling": "weak", "patterns_per_gpu": args.patterns, "value": args.patterns * world * args.steps / dtw,
-                           "unit": "site-patterns/s", "ms_per_step": dtw / args.steps * 1e3, "lnL": lw}
-
-    # ---- N > 1, BASELINE configs[4] (HIV NSsites 0 1 2 7 8, 79 patterns): too small to shard — one reduction chunk — so the GPUs
-    # are used as REPLICAS: the five models are independent analyses, model m runs on rank m mod N (no collective on the data path);
-    # the job's time is the slowest rank's.  At N = 1 the same five searches run one after the other (`c5`).
-    if extras and world > 1 and args.scaling == "strong":
-        t_rank, rows = 0.0, []
-        try:
-            for m, (name, gname, ctl) in enumerate(C5_MODELS):
-                if m % world != rank:
+        # ---- NSsites sweep on the same (sharded) data: the north_star's target workload -----------------------------------
+        if extras and args.scaling == "strong":
+            sweep = []
+            for name, ns, ncat, par, gname in SWEEP:
+                if ns == 0:
+                    if rank == 0:
+                        sweep.append(dict(model=name, classes=1, ms_per_eval=out["ms_per_step"], lnL=lnl, lnL_reference=ref_lnl,
+                                          pattern_classes_per_s=out["value"]))
                     continue
-                a, g = _host_case(gname, "codeml", ctl)
-                a.eval_gpu(a.default_x(), want_lnf=False)
-                t0 = time.perf_counter()
-                opt = a.optimize(a.default_x())
-                dtm = time.perf_counter() - t0
-                if abs(opt["lnL"] - g["lnL"]) > 5e-6:
-                    raise SystemExit("bench: c5 %s optimiser ended at %.9f, the reference's at %.6f" % (name, opt["lnL"], g["lnL"]))
-                t_rank += dtm
-                rows.append((name, dtm))
-            err = None
-        except Exception as ex:      # noqa: BLE001  (the C host library missing: reported, the headline stands)
-            err = repr(ex)
-        box = [None] * world
-        dist.all_gather_object(box, (rank, t_rank, rows, err))
-        if rank == 0:
-            out["c5_replicas"] = {"workload": "codeml NSsites = 0 1 2 7 8 on HIVenvSweden, one model per rank (m mod N): independent replicas, no collective",
-                                  "seconds": max(b[1] for b in box), "per_rank": [{"rank": b[0], "seconds": b[1], "models": b[2], "error": b[3]} for b in box]}
+                freqs, omegas = models.nssites_classes(ns, par, ncat)
+                pbk = synth.codon_nssites_problem(pb, 2.0, omegas, freqs)            # this rank's shard, K classes
+                ek = engine.engine_for(pbk)
+                uid = None
+                if world > 1 or force_comm:
+                    uid = engine.comm_unique_id() if rank == 0 else None
+                    if world > 1:
+                        uid = distributed._store_broadcast_bytes(uid)
+                ek.comm_init(rank, world, uid, n_full, lo)
+                dtk, lk, _ = timed(ek, branch, args.sweep_steps, 2)
+                _, _, pk = timed(ek, branch, 3, 0, profile=True)
+                ek.close()
+                refk = check_lnl(name, lk, gname, n_full, args.taxa == 16)
+                if rank == 0:
+                    K = len(freqs)
+                    kms = pk["ms_prune"] / max(1, pk["n_evals"])
+                    sweep.append(dict(model=name, classes=K, ms_per_eval=dtk / args.sweep_steps * 1e3, lnL=lk, lnL_reference=refk,
+                                      pattern_classes_per_s=n_full * K * args.sweep_steps / dtk, kernel_ms=kms,
+                                      roofline_frac=algorithmic_flops_per_pattern(61, args.taxa) * K * pb.n_patt / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS))
+            if rank == 0:
+                out["sweep"] = sweep
+                tot_ms = sum(s["ms_per_eval"] for s in sweep)
+                out["sweep_total"] = {"classes": sum(s["classes"] for s in sweep), "ms": tot_ms,
+                                      "site_patterns_per_s": n_full * len(sweep) / (tot_ms * 1e-3)}
+
+        # ---- second line at N > 1: weak scaling (10^6 patterns per GPU) -----------------------------------------------------
+        if extras and world > 1 and args.scaling == "strong":
+            pbw, ew, _ = weak_engine(args, world, rank, engine, distributed, synth, force_comm)
+            dtw, lw, _ = timed(ew, pbw.tree.branch.copy(), args.steps, args.warmup)
+            ew.close()
+            if rank == 0:
+                out["weak"] = {"scaling": "weak", "patterns_per_gpu": args.patterns, "value": args.patterns * world * args.steps / dtw,
+                               "unit": "site-patterns/s", "ms_per_step": dtw / args.steps * 1e3, "lnL": lw}
+
+        # ---- N > 1, BASELINE configs[4] (HIV NSsites 0 1 2 7 8, 79 patterns): too small to shard — one reduction chunk — so the GPUs
+        # are used as REPLICAS: the five models are independent analyses, model m runs on rank m mod N (no collective on the data path);
+        # the job's time is the slowest rank's.  At N = 1 the same five searches run one after the other (`c5`).
+        if extras and world > 1 and args.scaling == "strong":
+            t_rank, rows = 0.0, []
+            try:
+                for m, (name, gname, ctl) in enumerate(C5_MODELS):
+                    if m % world != rank:
+                        continue
+                    a, g = _host_case(gname, "codeml", ctl)
+                    a.eval_gpu(a.default_x(), want_lnf=False)
+                    t0 = time.perf_counter()
+                    opt = a.optimize(a.default_x())
+                    dtm = time.perf_counter() - t0
+                    if abs(opt["lnL"] - g["lnL"]) > 5e-6:
+                        raise SystemExit("bench: c5 %s optimiser ended at %.9f, the reference's at %.6f" % (name, opt["lnL"], g["lnL"]))
+                    t_rank += dtm
+                    rows.append((name, dtm))
+                err = None
+            except Exception as ex:      # noqa: BLE001  (the C host library missing: reported, the headline stands)
+                err = repr(ex)
+            box = [None] * world
+            dist.all_gather_object(box, (rank, t_rank, rows, err))
+            if rank == 0:
+                out["c5_replicas"] = {"workload": "codeml NSsites = 0 1 2 7 8 on HIVenvSweden, one model per rank (m mod N): independent replicas, no collective",
+                                      "seconds": max(b[1] for b in box), "per_rank": [{"rank": b[0], "seconds": b[1], "models": b[2], "error": b[3]} for b in box]}
+    except (Exception, SystemExit) as ex:      # noqa: BLE001
+        if guard is None:
+            raise
+        guard.fire("rank %d, after the headline: %r" % (rank, ex))
 
     # ---- N = 1: the 4-state configuration and the CPU baseline -----------------------------------------------------------
     if rank == 0 and world == 1 and extras and pb.n == 61:
@@ -359,11 +406,18 @@ def main():
         pbc = pb if pb.K == 1 else None
         out["cpu_baseline"] = cpu_baseline(pbc, args.cpu_sample)
         out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+    if guard is not None and not guard.finish():
+        time.sleep(60)      # (the timer thread is writing the line and ends the process)
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
+        import threading
+        bye = threading.Timer(60, os._exit, (0,))      # (the line is out: a rank that left early must not keep the others in this barrier)
+        bye.daemon = True
+        bye.start()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
 
 
 def weak_engine(args, world, rank, engine, distributed, synth, force_comm):
