@@ -329,17 +329,39 @@ __global__ __launch_bounds__(256) void branch_eigprep_kernel(EigPrepArgs a)
    }
 }
 
+// The partials and coefficients of a call are streamed through once (0.5 GB each at 16 taxa x 10^6 patterns) and nothing of them is
+// read again before the caches have turned over: non-temporal accesses.  BEIG_STREAM (tools/build_variant.sh): bit 0 = the stores,
+// bit 1 = the loads.  Measured on MI355X (gpurun_out/r04b/branch_nt.txt -> profiles/r04_branch.txt): the coefficient-forming kernel
+// is indifferent (0.445 / 0.443 / 0.447 / 0.444 ms per call for 0 / 1 / 2 / 3), the polynomial kernel on the stored coefficients
+// gains 8-15 % from the loads (a further trial length 0.198 -> 0.182 ms, four 0.168 -> 0.150, in the walk 0.215 -> 0.183).
+#ifndef BEIG_STREAM
+#define BEIG_STREAM 3
+#endif
 __device__ __forceinline__ void beig_load(const double *p, int lane, v4d (&x)[4])      // (part_load's layout, straight into the MFMA tuples)
 {
    const part2_t *p2 = (const part2_t *)p + lane;
 #pragma unroll
-   for (int i = 0; i < 8; i++) { const part2_t v = p2[i * 64]; x[i >> 1][(2 * i) & 3] = v.x; x[i >> 1][(2 * i + 1) & 3] = v.y; }
+   for (int i = 0; i < 8; i++) {
+#if BEIG_STREAM & 2
+      const part2_t v = __builtin_nontemporal_load(p2 + i * 64);
+#else
+      const part2_t v = p2[i * 64];
+#endif
+      x[i >> 1][(2 * i) & 3] = v.x; x[i >> 1][(2 * i + 1) & 3] = v.y;
+   }
 }
 __device__ __forceinline__ void beig_store(double *p, int lane, const v4d (&x)[4])
 {
    part2_t *p2 = (part2_t *)p + lane;
 #pragma unroll
-   for (int i = 0; i < 8; i++) p2[i * 64] = (part2_t){x[i >> 1][(2 * i) & 3], x[i >> 1][(2 * i + 1) & 3]};
+   for (int i = 0; i < 8; i++) {
+      const part2_t v = (part2_t){x[i >> 1][(2 * i) & 3], x[i >> 1][(2 * i + 1) & 3]};
+#if BEIG_STREAM & 1
+      __builtin_nontemporal_store(v, p2 + i * 64);
+#else
+      p2[i * 64] = v;
+#endif
+   }
 }
 // g[d] += sum_m c_m E_d[k = 4m + q]: the lane's share of f, f', f'' for one trial length (et: [3][64] in LDS, element q*16 + m)
 __device__ __forceinline__ void beig_poly(const v4d (&c)[4], const double *et, int q, double (&g)[3])

@@ -928,13 +928,17 @@ static void eig_batch_add(pamlh_eig_batch *b, int id, const pamlh_eig *e, int n)
    b->scale[b->cnt++] = e->scale;
 }
 
-/* Few matrices: the host's cores, one matrix each, are as fast as the device's fixed ~2 ms (one Jacobi run, however many matrices ride
- * in it: profiles/r03_eigen.txt) — M0 / M1a / M2a searches have 1-3 eigen systems per trial point.  From PAMLH_DEVICE_EIGEN_MIN matrices
- * on (default 16: a gradient or a line search of the M3 / M7 / M8 / branch-site models, the BEB grids) the batch goes to the device. */
+/* Where a batch of rate matrices is decomposed: on the device from PAMLH_DEVICE_EIGEN_MIN matrices on.  Round 3 left batches of fewer
+ * than 16 (the 1-3 eigen systems per trial point of M0 / M1a / M2a) to the host's cores — one cold Jacobi run on the device costs
+ * ~1.2 ms however many matrices ride in it, a core's Householder + QL 0.56 ms.  With the warm start a search now switches on
+ * (pamlh_optimize; 3-5 sweeps instead of 9-10) the device is as fast for the small batches too — time to the MLEs, MI355X,
+ * threshold 16 / 4 / 1: HIV M1a 0.05 / 0.04 / 0.04 s, M7 0.13 / 0.13 / 0.11, M8 0.23 / 0.21 / 0.21, everything else equal
+ * (profiles/r04_time_to_mle.txt) — and ONE path decomposes every matrix of a run: the base point of a gradient and its perturbed
+ * points no longer come from two algorithms whose U, V, Root differ in the last bits.  Default 1. */
 static int device_eigen_min(void)
 {
    static int v = -1;
-   if (v < 0) { const char *e = getenv("PAMLH_DEVICE_EIGEN_MIN"); v = e ? atoi(e) : 16; }
+   if (v < 0) { const char *e = getenv("PAMLH_DEVICE_EIGEN_MIN"); v = e ? atoi(e) : 1; }
    return v;
 }
 

@@ -434,9 +434,16 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
    double *xs = (double *)malloc((size_t)(2 * n + NC) * n * sizeof(double)), *ls = (double *)malloc((2 * n + NC) * sizeof(double));
    unsigned char *fixed = (unsigned char *)malloc(n);
    double f, fnew = 0, as[16], f_restart = 1e300;
-   int it, i, j, k, rc = 0, n_eval = 0, reset = 1, small_steps = 0, status = 1, restarts = 0, fresh = 1;
+   int it, i, j, k, rc = 0, n_eval = 0, reset = 1, small_steps = 0, status = 1, restarts = 0, fresh = 1, warm = 0;
    if (n == 0) { rc = batch_eval(p, 1, x, lnL); status = 0; goto done; }
    if (pamlh_bounds(p, lo, hi)) { rc = pamlh_fail(p, "internal: bounds do not match np"); goto done; }
+   /* A search moves the rate matrices a little at a time — a finite-difference step, a line-search step — and every eigen set is
+    * decomposed again and again: the device's Jacobi sweeps start from the set's previous eigenvectors while the search runs
+    * (paml_amd_set_eigen_warm_start: 3-5 sweeps instead of 9-10; PAMLH_EIGEN_WARM=0 keeps them cold).  Off again at the end: what
+    * follows (the final evaluation's tables, standard errors, BEB) does not depend on the path the search took. */
+   if ((rc = pamlh_engine_ready(p))) goto done;
+   warm = !(getenv("PAMLH_EIGEN_WARM") && atoi(getenv("PAMLH_EIGEN_WARM")) == 0);
+   if (warm) paml_amd_set_eigen_warm_start(p->eng, 1, NULL);
    {
       int start[PAMLH_MAXEIG + 4], len[PAMLH_MAXEIG + 4];
       const int ng = pamlh_simplex_groups(p, start, len, PAMLH_MAXEIG + 4);
@@ -582,6 +589,7 @@ int pamlh_optimize(pamlh *p, double *x, double *lnL, int max_iter, double tol, i
    /* leave the model state at the estimate */
    if (pamlh_set_x(p, x, n)) rc = -1;
 done:
+   if (warm && p->eng) paml_amd_set_eigen_warm_start(p->eng, 0, NULL);
    p->opt_transformed = 0;
    if (n_eval_out) *n_eval_out = n_eval;
    free(lo); free(hi); free(g); free(g0); free(d); free(s); free(y); free(Hy); free(H); free(xs); free(ls); free(fixed);
