@@ -214,7 +214,14 @@ __device__ __forceinline__ void mfma_matvec(const double *sPbuf, int lane, const
 // XOR swizzle of the eight 16-byte pieces of a tip-table row (row = code * 4 + state quarter): lanes of one
 // ds_read_b128 group read rows of 16 different patterns, i.e. random codes; mixing the code's low and middle bits into
 // the slot spreads them over all 8 slots of their bank half instead of 4.
+// (TIP_SWZ_OFF: build-time experiment — plain rows, the eight pieces at immediate offsets of one address register: eight fewer
+//  vector instructions per gathered row against more bank conflicts.  Measured slower, 1.577 against 1.555 ms per launch at 16 taxa x
+//  10^6 codon patterns (profiles/r04_61state.txt); PAML_AMD_EXTRA_FLAGS=-DTIP_SWZ_OFF=1, see engine.py build())
+#ifdef TIP_SWZ_OFF
+#define TIP_SWZ(row) 0
+#else
 #define TIP_SWZ(row) ((((row) >> 2) ^ ((row) >> 5)) & 7)
+#endif
 struct StreamBlk { int is_tip, node; };
 
 __device__ __forceinline__ void wait_blocks_in_flight(int n)   // allow the n newest blocks (4 loads each) to fly

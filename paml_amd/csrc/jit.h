@@ -124,6 +124,9 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    const int P_ROUNDS = (KB2 * 4 + waves - 1) / waves, T_ROUNDS = (TCH + waves - 1) / waves;
    s << "#define JIT_KB2 " << KB2 << "\n#define JIT_RB " << RB << "\n#define JIT_TCH " << TCH << "\n#define JIT_WAVES " << waves << "\n";
    if (jit_rowtail(n_states)) s << "#define JIT_ROWTAIL 1\n";
+#ifdef TIP_SWZ_OFF
+   s << "#define TIP_SWZ_OFF 1\n";      // (the library's P(t) kernel writes the tip tables without the swizzle: the per-tree kernel must read them so)
+#endif
    if (getenv("PAML_AMD_JIT_NT_STORE")) s << "#define JIT_NT_STORE 1\n";         // experiment: non-temporal stores of the class likelihoods
    if (getenv("PAML_AMD_JIT_ABL_NOSEED")) s << "#define JIT_ABL_NOSEED 1\n";      // timing experiment: the rank-1 seed without its LDS reads and multiplies
    if (getenv("PAML_AMD_JIT_ABL_NOBAR")) s << "#define JIT_ABL_NOBAR 1\n";      // timing experiment: no workgroup barriers (results are garbage)
@@ -1138,6 +1141,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
 
 inline std::string jit_source_dir()
 {
+   if (const char *e = getenv("PAML_AMD_CSRC")) return e;      // (a variant library built somewhere else: tools/build_variant.sh, PAML_AMD_LIB)
    Dl_info info;
    if (dladdr((const void *)&jit_source_dir, &info) && info.dli_fname) {
       std::string so = info.dli_fname;                 // .../paml_amd/lib/libpaml_amd.so

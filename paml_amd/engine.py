@@ -39,6 +39,9 @@ class EngineError(RuntimeError):
 # 220 - 256 to 186 - 224 — the logarithm's constants are no longer hoisted out of the main loops — and changes no timing: measured
 # A / B on one box, profiles/r04_branch.txt)
 UNIT_FLAGS = {}
+# kernel experiments: a variant library beside the default one — PAML_AMD_LIB=<dir>/libpaml_amd.so PAML_AMD_EXTRA_FLAGS="-DX=1" python -c
+# "from paml_amd import engine; engine.build()" compiles every unit with the extra flags into <dir> (objects in <dir>/obj)
+EXTRA_FLAGS = os.environ.get("PAML_AMD_EXTRA_FLAGS", "").split()
 UNITS = ("engine_core", "engine_comm", "engine_eval", "engine_branch", "engine_beb", "engine_jitdbg", "engine_compress")
 
 
@@ -56,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for u in UNITS:
         src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(objdir, u + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(newest_hdr, os.path.getmtime(src)):
-            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + UNIT_FLAGS.get(u, []) + ["-c", src, "-o", obj])
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + UNIT_FLAGS.get(u, []) + EXTRA_FLAGS + ["-c", src, "-o", obj])
     objs = [os.path.join(objdir, u + ".o") for u in UNITS]
     if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(o) <= os.path.getmtime(LIB_PATH) for o in objs):
         return LIB_PATH
