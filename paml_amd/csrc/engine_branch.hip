@@ -123,7 +123,7 @@ int rerooted_pmat(paml_amd_engine *e, int new_root, int cut_son, const double *b
    {
       InlineVec iv;
       iv.n_branch = iv.n_rate = 0;
-      launch_pmat(pa, iv, nn, psets, false, e->stream);
+      launch_pmat(pa, iv, nn, psets, false, e->stream, pmat_on_matrix_cores(e, pa));
    }
    e->n_pmat += (long)psets * (nn - 1);
    e->prog_valid = false;      // d_branch / P buffers now hold the re-rooted edge data: the next eval rebuilds
@@ -364,7 +364,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          pa.B = 1; pa.rate_gs = e->rate_per_gene ? K : 0;
          InlineVec iv;
          iv.n_branch = iv.n_rate = 0;
-         launch_pmat(pa, iv, nn, psets, false, st);
+         launch_pmat(pa, iv, nn, psets, false, st, pmat_on_matrix_cores(e, pa));
          e->n_pmat += (long)psets * (nn - 2);
          e->prog_valid = false;      // d_branch / P buffers now hold re-oriented edge data: the next eval rebuilds
          e->pmat_valid = false;
@@ -498,7 +498,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       {
          InlineVec iv;
          iv.n_branch = iv.n_rate = 0;
-         launch_pmat(pa, iv, nn, psets, false, st);
+         launch_pmat(pa, iv, nn, psets, false, st, pmat_on_matrix_cores(e, pa));
       }
       e->n_pmat += (long)psets * (nn - 2);
       e->prog_valid = false;      // d_branch / P buffers now hold re-oriented edge data: the next eval rebuilds

@@ -51,10 +51,21 @@ static void launch_valu(paml_amd_engine *e, int max_stack, int n_blocks, const P
    }
 }
 
-void launch_pmat(const PmatArgs &pa, const InlineVec &iv, int n_nodes, int psets, bool small, hipStream_t s)
+// 21..64 states in the mfma64 layout, every eigen system a (U, V, Root) one: four workgroups per matrix on the matrix cores
+// (pmat_mfma_kernel; PAML_AMD_PMAT_MFMA=0: pmat_kernel_t<64>, one workgroup per matrix on the vector units)
+bool pmat_on_matrix_cores(const paml_amd_engine *e, const PmatArgs &pa)
+{
+   static const bool off = getenv("PAML_AMD_PMAT_MFMA") && atoi(getenv("PAML_AMD_PMAT_MFMA")) == 0;
+   bool ok = e->kk == KK_MFMA64 && pa.layout == 1 && e->n_codes <= 256 && !off;
+   for (const EigenHost &h : e->eigen) ok = ok && h.kind == PAML_AMD_EIGEN_UVROOT;
+   return ok;
+}
+
+void launch_pmat(const PmatArgs &pa, const InlineVec &iv, int n_nodes, int psets, bool small, hipStream_t s, bool mfma)
 {
    const int gx = (n_nodes + std::max(pa.npb, 1) - 1) / std::max(pa.npb, 1);
-   if (small) hipLaunchKernelGGL(pmat_small_kernel, dim3((n_nodes * psets + 7) / 8), dim3(256), 0, s, pa, iv);
+   if (mfma) hipLaunchKernelGGL(pmat_mfma_kernel, dim3(n_nodes, psets, 4), dim3(256), 0, s, pa, iv);
+   else if (small) hipLaunchKernelGGL(pmat_small_kernel, dim3((n_nodes * psets + 7) / 8), dim3(256), 0, s, pa, iv);
    else if (pa.n <= 32 && pa.layout != 1 && pa.layout != 3) hipLaunchKernelGGL(pmat_kernel_t<32>, dim3(gx, psets), dim3(256), 2 * 32 * 32 * sizeof(double), s, pa, iv);
    else hipLaunchKernelGGL(pmat_kernel_t<64>, dim3(gx, psets), dim3(256), 2 * 4096 * sizeof(double), s, pa, iv);
 }
@@ -383,7 +394,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    mark_on(e, ps);
    bool small_pmat = e->kk != KK_MFMA64 && n <= 5;
    for (const EigenHost &h : e->eigen) small_pmat = small_pmat && h.kind != PAML_AMD_EIGEN_QMAT;
-   launch_pmat(pa, iv, nn, psets, small_pmat, ps);
+   launch_pmat(pa, iv, nn, psets, small_pmat, ps, pmat_on_matrix_cores(e, pa));
    mark_on(e, ps);
    if (pipe) {      // the pruning kernel (main stream) starts when this P(t) is there
       HIPCHK(hipEventRecord(e->ev_pmat, e->s2));

@@ -583,7 +583,8 @@ int build_tiles(paml_amd_engine *e);
 int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean, double *d_lnL_out, bool want_lnf,
                 const BatchSpec *bs = nullptr, bool want_pipe = false, bool want_fhk = true);
 // launches for the other translation units (a __global__ function has one home)
-void launch_pmat(const PmatArgs &pa, const InlineVec &iv, int n_nodes, int psets, bool small, hipStream_t s);
+void launch_pmat(const PmatArgs &pa, const InlineVec &iv, int n_nodes, int psets, bool small, hipStream_t s, bool mfma = false);
+bool pmat_on_matrix_cores(const paml_amd_engine *e, const PmatArgs &pa);
 void launch_prune_full(paml_amd_engine *e, int max_stack, int n_blocks, const PruneArgs &pr, hipStream_t s);      // gather (21..64 states) or valu interpreter
 void launch_zpm(const unsigned char *z, long z_stride, int n_tips, int n_patt, int zw, unsigned int *out, hipStream_t s);
 

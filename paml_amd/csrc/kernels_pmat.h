@@ -356,4 +356,99 @@ __global__ __launch_bounds__(256) void pmat_kernel_t(PmatArgs a, InlineVec iv)
    }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Kernel A on the matrix cores (round 4): the (U, V, Root) models of 21..64 states in the mfma64 layout — one workgroup per (node,
+// parameter set, 16-ROW BLOCK of P), four per matrix.  pmat_kernel_t<64> takes 21 us for a matrix however few there are (13 taxa:
+// 23 matrices on 256 CUs; profiles/r04_small_timeline.txt): U and V staged through LDS, a 61-step loop of LDS reads, the three
+// output layouts gathered from LDS with 16-way bank conflicts, one workgroup's serial chain.  Here a wave owns a 16 x 16 block of
+// the row block: its A operands are U's rows times expm1(t Root_k) and its B operands V's columns, both straight from global memory
+// (L2) in the instruction's own lane order, sixteen v_mfma_f64_16x16x4 (k ascending, as PMatUVRoot accumulates, tools.c:525-537),
+// `+ I`, the clamp, and the row block goes to LDS (row stride 65: conflict-free for the column-order outputs).  Every output
+// layout is complete per row block — rowmajor rows, the prune kernels' A-operand order [k-block pair][ROW BLOCK][lane][2], the
+// q-major entries of column 60, the rows jj = 4m + q of the tips' column tables — so the four workgroups of a matrix share nothing.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv)
+{
+   __shared__ double sE[64];
+   __shared__ double sP[16 * 65];
+   __shared__ unsigned char sMap[256 * 64];
+   __shared__ int sNch[256];
+   const int node = blockIdx.x, pset = blockIdx.y, rb = blockIdx.z;
+   if (node == a.root) return;
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = a.n;
+   const int KB = a.K * a.B;
+   const int gene = pset / KB, bat = (pset % KB) / a.K, iclass = pset % a.K;
+   const int lab = a.label[node];
+   const EigenDev es = a.eigen[a.eigen_of[bat * a.eigen_of_bs + (gene * a.K + iclass) * a.n_labels + lab]];
+   const double t = pmat_time(a, iv, bat, node, gene, iclass) * a.qfactor[bat * a.qfactor_bs + iclass * a.n_labels + lab];
+   const bool leaf = a.is_leaf[node] != 0;
+   // this lane's operands of the sixteen k-blocks: A = U[16 rb + (lane & 15)][4 kb + (lane >> 4)], B = V[4 kb + (lane >> 4)][16 wave + (lane & 15)]
+   const int ai = rb * 16 + (lane & 15), bj = wave * 16 + (lane & 15), kq = lane >> 4;
+   double ua[16], vb[16];
+#pragma unroll
+   for (int kb = 0; kb < 16; kb++) {
+      const int k = 4 * kb + kq;
+      ua[kb] = (ai < n && k < n) ? es.U[ai * n + k] : 0.0;
+      vb[kb] = (bj < n && k < n) ? es.V[k * n + bj] : 0.0;
+   }
+   if (tid < 64) sE[tid] = (tid < n && !(t < 1e-100)) ? expm1(t * es.Root[tid]) : 0.0;      // (t < 1e-100: P = I, tools.c:521)
+   if (leaf) {      // the ambiguity map (tools.c:20 nChara / CharaMap) for the column tables below
+      for (int idx = tid; idx < a.n_codes * n; idx += 256) sMap[idx] = a.chara_map[idx];
+      for (int idx = tid; idx < a.n_codes; idx += 256) sNch[idx] = a.n_chara[idx];
+   }
+   __syncthreads();
+   typedef double pm_v4d __attribute__((ext_vector_type(4)));
+   pm_v4d acc = {0, 0, 0, 0};
+#pragma unroll
+   for (int kb = 0; kb < 16; kb++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[kb] * sE[4 * kb + kq], vb[kb], acc, 0, 0, 0);
+   // accumulator element r of this lane = P[16 rb + 4 r + (lane >> 4)][16 wave + (lane & 15)]
+#pragma unroll
+   for (int r = 0; r < 4; r++) {
+      const int il = 4 * r + kq, i = rb * 16 + il;
+      double p = acc[r] + (i == bj ? 1.0 : 0.0);
+      p = (i < n && bj < n) ? (p < 0 ? 0.0 : p) : 0.0;
+      sP[il * 65 + bj] = p;
+   }
+   __syncthreads();
+
+   const long slot = (long)pset * a.n_nodes + node;
+   {
+      double *rm = a.rowmajor + slot * n * n;
+      for (int idx = tid; idx < 16 * n; idx += 256) {
+         const int il = idx / n, j = idx % n, i = rb * 16 + il;
+         if (i < n) rm[i * n + j] = sP[il * 65 + j];
+      }
+   }
+   if (!leaf) {
+      // MFMA A-operand order: element ((kb2*4 + jb)*64 + lane)*2 + e  =  P[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)]; jb = rb here
+      double *pf = a.pint + slot * 4096;
+      for (int idx = tid; idx < 1024; idx += 256) {
+         const int e = idx & 1, ln = (idx >> 1) & 63, kb2 = idx >> 7;
+         pf[((kb2 * 4 + rb) * 64 + ln) * 2 + e] = sP[(ln & 15) * 65 + 4 * (2 * kb2 + e) + (ln >> 4)];
+      }
+      // column 60 as pcol[q][m] = P[4m + q][60] (the per-tree kernel's rank-1 term): the rows of this block
+      if (a.pcol && tid < 64) {
+         const int row = 4 * (tid & 15) + (tid >> 4);
+         if ((row >> 4) == rb) a.pcol[slot * 64 + tid] = sP[(row & 15) * 65 + 60];
+      }
+   }
+   else {
+      // column sums over each character code's state set (codeml.c:3555-3567), table [code][q][slot] with the XOR swizzle of the
+      // pieces (pmat_kernel_t): the entries whose row jj = 4m + q lies in this block
+      double *pt = a.ptip + slot * a.tip_words;
+      for (int idx = tid; idx < a.n_codes * 16; idx += 256) {
+         const int code = idx >> 4, il = idx & 15, jj = rb * 16 + il, q = jj & 3, m = jj >> 2;
+         const int row = code * 4 + q, w = q * 16 + ((((m >> 1) ^ TIP_SWZ(row)) & 7) << 1) + (m & 1);
+         double s2 = 0;
+         if (jj < n) {
+            const int nc = sNch[code];
+            const unsigned char *map = sMap + code * n;
+            for (int k = 0; k < nc; k++) s2 += sP[il * 65 + map[k]];
+         }
+         pt[code * 64 + w] = s2;
+      }
+   }
+}
+
 }  // namespace paml_amd
