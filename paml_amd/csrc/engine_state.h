@@ -161,6 +161,7 @@ struct EnvCfg {
    bool dual = true;
    bool no_coef_cache = false;      // PAML_AMD_NO_COEF_CACHE (measurements): every eval_branch call forms the coefficients again
    bool no_branch_eig = false;      // PAML_AMD_NO_BRANCH_EIG: eval_branch in the P / dP / ddP form (round 2's kernels) also where the eigen-basis form applies
+   bool no_coop = false;            // PAML_AMD_COOP=0: small data sets on the gather kernel (one wave per 16-pattern group) instead of prune_mfma64_coop
    bool no_pipeline = false, force_gather = false, jit_sync = false, jit_strict = false, valu20 = false, no_fused = false, mfma4 = false, tail = false, no_m20 = false;
    int jit_waves = 0, comm_cus = -1, lanes = 0;
    std::string jit_dump, prof_ops;
@@ -170,6 +171,7 @@ struct EnvCfg {
    void read()
    {
       no_pipeline = getenv("PAML_AMD_NO_PIPELINE") != nullptr;
+      if (const char *v = getenv("PAML_AMD_COOP")) no_coop = atoi(v) == 0;
       offload = getenv("PAML_AMD_OFFLOAD") != nullptr;      // experiment (measured no faster, profiles/r03_comm_overhead.txt): the reduction of eval_device on the side stream
       if (const char *v = getenv("PAML_AMD_DUAL")) dual = atoi(v) != 0;      // 0: one pruning stream (consecutive evaluations' kernels never overlap)
       force_gather = getenv("PAML_AMD_FORCE_GATHER") != nullptr;
@@ -310,6 +312,7 @@ struct paml_amd_engine {
    Staging stage;
    JitKernel jit;            // per-tree specialised kernel (jit.h), valid when jit.fn != nullptr
    bool jit_enabled = false, use_jit = false;
+   bool coop = false;        // the last evaluation ran prune_mfma64_coop (small data sets: four waves per 16-pattern group)
    // Consecutive paml_amd_eval_device calls (the loop of a benchmark or of an optimiser's independent evaluations) build the
    // NEXT evaluation's P(t) on a side stream while the previous pruning kernel is still running: its few workgroups fit the CUs
    // that go idle in that kernel's last round.  Two sets of P buffers alternate; the side stream waits for everything the main

@@ -251,6 +251,183 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_gather(PruneArgs a
 #undef TIP_CODE
 }
 
+// ---- mfma64 "coop": small data sets (round 4).  When every 16-pattern group of the data can have a CU to itself, what an evaluation
+// costs is the length of ONE wave's walk through the tree — in the gather kernel 64 dependent MFMAs per branch (5 800 cycles with the
+// barrier and the operand hand-over; 13 taxa x 79 codon patterns: 39 us per launch, profiles/r04_small_timeline.txt).  Here the four
+// waves of a workgroup share ONE group: wave w owns row block w of every product — states 16 w .. 16 w + 15 of every partial, four
+// doubles per lane instead of sixteen — so a product is 16 MFMAs per wave; the operand partial is put together in LDS (each wave
+// publishes its quarter, one barrier — the one the staged P(t) block needs anyway), tip rows are gathered a quarter per wave, the
+// group's character codes come to LDS once: 25 us for the same launch.  Accumulation order per row block (k-blocks ascending into
+// one accumulator) and the root sum (wave 0, the gather kernel's own code) are the other kernels': same bits.  Workgroup b: 16-pattern
+// group (b & 3) of 64-pattern tile (b >> 2) % n_tiles — the gather kernel's tile table, so the engine changes between the two kernels
+// (a batched gradient has many more groups) without rebuilding anything.  No keep-partials ops, at most COOP_SLOTS stack slots.
+// (Also built and measured SLOWER, 37.7 us: the A operands and the next tip step's rows straight from global memory into registers two
+// products ahead, no LDS staging of P — the compiler waits for every outstanding load at each use inside the op loop.)
+constexpr int COOP_SLOTS = 8;
+constexpr int COOP_ZT = 512;      // tips whose codes are staged in LDS (more: read from global memory)
+
+__global__ __launch_bounds__(256) void prune_mfma64_coop(PruneArgs a)
+{
+   __shared__ __attribute__((aligned(16))) double sP[2][4096];
+   __shared__ __attribute__((aligned(16))) double sX[2][1024];      // the operand partial, [m >> 1][lane][m & 1]
+   __shared__ double sR[4][16];
+   __shared__ unsigned char sZc[COOP_ZT * 16];
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int q = lane >> 4, hl = lane & 15;
+   const int sub = blockIdx.x & 3, tile = (blockIdx.x >> 2) % a.n_tiles, iclass = (blockIdx.x >> 2) / a.n_tiles;
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y + 16 * sub;
+   const int hend = as_const(a.gene_off)[gene + 1];
+   if (h0 >= hend) return;
+   const int h = h0 + hl;
+   const bool valid = h < hend;
+   const int hc = valid ? h : hend - 1;
+   const long pset = (long)gene * a.K + iclass;
+   const double *Pint = a.pint + pset * a.n_nodes * 4096;
+   const long tipstride = a.tip_words;
+   const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;
+   const int n = a.n;
+   if (a.first_matmul >= 0) stage_p<4>(Pint + (long)a.first_matmul * 4096, sP[0], wave, lane);
+   const bool zl = a.n_tips <= COOP_ZT;
+   if (zl) {
+      for (int i = tid; i < a.n_tips * 16; i += 256) sZc[i] = a.z[(long)(i >> 4) * a.z_stride + min(h0 + (i & 15), hend - 1)];
+      __syncthreads();
+   }
+#define TIP_CODE(tip) (zl ? (int)sZc[(tip)*16 + hl] : (int)a.z[(long)(tip)*a.z_stride + hc])
+   // this wave's quarter (elements m = 4 wave + r) of the row (code, q) of a tip's column table: pieces 2 wave, 2 wave + 1
+#define COOP_TIP(tip, V0, V1)                                                                                     \
+   do {                                                                                                         \
+      const int row_ = TIP_CODE(tip) * 4 + q, swz_ = TIP_SWZ(row_);                                             \
+      const double2 *pt_ = (const double2 *)(Ptip + (long)(tip)*tipstride + row_ * 16);                         \
+      V0 = pt_[(2 * wave) ^ swz_]; V1 = pt_[(2 * wave + 1) ^ swz_];                                             \
+   } while (0)
+#define COOP_SLOT(SLOT, STMT)                                                                                     \
+   switch (SLOT) {                                                                                              \
+   case 0: { double(&S)[4] = st[0]; STMT } break; case 1: { double(&S)[4] = st[1]; STMT } break;                \
+   case 2: { double(&S)[4] = st[2]; STMT } break; case 3: { double(&S)[4] = st[3]; STMT } break;                \
+   case 4: { double(&S)[4] = st[4]; STMT } break; case 5: { double(&S)[4] = st[5]; STMT } break;                \
+   case 6: { double(&S)[4] = st[6]; STMT } break; default: { double(&S)[4] = st[7]; STMT } break;               \
+   }
+   double cur[4] = {0, 0, 0, 0}, st[COOP_SLOTS][4];
+   double lnscale = 0;
+   int buf = 0, xb = 0;
+   for (int ip = 0;; ip++) {
+      const Op op = fetch_op(a.ops, ip);
+      if (op.code == OP_END) break;
+      switch (op.code) {
+      case OP_INIT_ONES: {
+#pragma unroll
+         for (int r = 0; r < 4; r++) cur[r] = (4 * (4 * wave + r) + q < n) ? 1.0 : 0.0;
+      } break;
+      case OP_INIT_TIP: {
+         const int code = TIP_CODE(op.a);
+#pragma unroll
+         for (int r = 0; r < 4; r++) cur[r] = (a.cleandata && 4 * (4 * wave + r) + q == code) ? 1.0 : 0.0;
+      } break;
+      case OP_SET_TIP:
+      case OP_MUL_TIP: {
+         double2 v0, v1;
+         COOP_TIP(op.a, v0, v1);
+         if (op.code == OP_SET_TIP) { cur[0] = v0.x; cur[1] = v0.y; cur[2] = v1.x; cur[3] = v1.y; }
+         else { cur[0] *= v0.x; cur[1] *= v0.y; cur[2] *= v1.x; cur[3] *= v1.y; }
+      } break;
+      case OP_SET_TIP2:
+      case OP_MUL_TIP2: {
+         double2 v0, v1, w0, w1;
+         COOP_TIP(op.a, v0, v1);
+         COOP_TIP(op.b, w0, w1);
+         if (op.code == OP_SET_TIP2) { cur[0] = v0.x * w0.x; cur[1] = v0.y * w0.y; cur[2] = v1.x * w1.x; cur[3] = v1.y * w1.y; }
+         else {
+            cur[0] = (cur[0] * v0.x) * w0.x; cur[1] = (cur[1] * v0.y) * w0.y;
+            cur[2] = (cur[2] * v1.x) * w1.x; cur[3] = (cur[3] * v1.y) * w1.y;
+         }
+      } break;
+      case OP_PUSH: {
+         COOP_SLOT(op.b, { _Pragma("unroll") for (int r = 0; r < 4; r++) S[r] = cur[r]; })
+      } break;
+      case OP_SCALE: {      // NodeScale treesub.c:7200-7230: the maximum over all the states of the pattern = over the four waves' quarters
+         double mx = 0;
+#pragma unroll
+         for (int r = 0; r < 4; r++) mx = cur[r] > mx ? cur[r] : mx;
+         double o = __shfl_xor(mx, 16);
+         mx = o > mx ? o : mx;
+         o = __shfl_xor(mx, 32);
+         mx = o > mx ? o : mx;
+         if (q == 0) sR[wave][hl] = mx;
+         __syncthreads();
+#pragma unroll
+         for (int w2 = 0; w2 < 4; w2++) { const double v = sR[w2][hl]; mx = v > mx ? v : mx; }
+         __syncthreads();
+         double fac;
+         if (mx < 1e-300) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) cur[r] = (4 * (4 * wave + r) + q < n) ? 1.0 : 0.0;
+            fac = -800;
+         }
+         else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) cur[r] /= mx;
+            fac = log(mx);
+         }
+         lnscale += fac;
+      } break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         double2 *xs = (double2 *)sX[xb];
+         xs[(2 * wave) * 64 + lane] = make_double2(cur[0], cur[1]);
+         xs[(2 * wave + 1) * 64 + lane] = make_double2(cur[2], cur[3]);
+         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+         __syncthreads();      // the operand partial is complete, this branch's P has landed in sP[buf], every wave is done with sP[buf ^ 1]
+         if (op.c >= 0) stage_p<4>(Pint + (long)op.c * 4096, sP[buf ^ 1], wave, lane);
+         const double2 *xr = (const double2 *)sX[xb], *sp = (const double2 *)sP[buf];
+         double2 xv[8], af[8];
+#pragma unroll
+         for (int p = 0; p < 8; p++) { xv[p] = xr[p * 64 + lane]; af[p] = sp[(p * 4 + wave) * 64 + lane]; }
+         v4d acc = {0, 0, 0, 0};
+#pragma unroll
+         for (int kb2 = 0; kb2 < 8; kb2++) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2].x, xv[kb2].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kb2].y, xv[kb2].y, acc, 0, 0, 0);
+         }
+         const int pop = mm_pop_slot(op), push = mm_push_slot(op);
+         double y[4] = {acc[0], acc[1], acc[2], acc[3]};
+         if (pop >= 0) { COOP_SLOT(pop, { _Pragma("unroll") for (int r = 0; r < 4; r++) y[r] = S[r] * y[r]; }) }
+         if (push >= 0) { COOP_SLOT(push, { _Pragma("unroll") for (int r = 0; r < 4; r++) S[r] = y[r]; }) }
+         else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) cur[r] = y[r];
+         }
+         buf ^= 1; xb ^= 1;
+      } break;
+      case OP_ROOT: {      // the whole partial to wave 0, which sums it as the other kernels do (MFMA_ROOT_CASE)
+         double2 *xs = (double2 *)sX[xb];
+         xs[(2 * wave) * 64 + lane] = make_double2(cur[0], cur[1]);
+         xs[(2 * wave + 1) * 64 + lane] = make_double2(cur[2], cur[3]);
+         __syncthreads();
+         if (wave == 0) {
+            const double2 *xr = (const double2 *)sX[xb];
+            const double *pq = a.pi + (long)(a.n_pi > 1 ? gene : 0) * 64 + q * 16;
+            double f = 0;
+#pragma unroll
+            for (int p = 0; p < 8; p++) { const double2 v = xr[p * 64 + lane]; f = fma(pq[2 * p], v.x, f); f = fma(pq[2 * p + 1], v.y, f); }
+            f += __shfl_xor(f, 16);
+            f += __shfl_xor(f, 32);
+            if (q == 0 && valid) {
+               double out = 0;
+               if (a.weights[h] > 0) out = root_value(a, f, lnscale);
+               a.fhK[(long)iclass * a.n_patt + h] = out;
+            }
+         }
+         xb ^= 1;
+      } break;
+      default: break;
+      }
+   }
+#undef TIP_CODE
+#undef COOP_TIP
+#undef COOP_SLOT
+}
+
 // ---- mfma64 "stream": the production kernel (<= MFMA_ZT tips, <= 64 character codes, register stack).
 // Every operand the tree walk consumes — the P of an internal branch in MFMA order, or the whole column
 // table of a tip branch — is one 32 KB block, and the program fixes the order in which blocks are used.

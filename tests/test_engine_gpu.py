@@ -406,7 +406,7 @@ def test_large_tree_kernel_is_compiled_in_the_background(monkeypatch):
     eng = Engine(pb.n, pb.tree.n_tips, pb.n_patt, max_classes=64).load(pb)      # 1100 x 64 >= 65536: on by size
     ref = oracle.evaluate(pb)["lnL"]
     first = eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]
-    assert eng.kernel_name == "mfma64_gather", eng.kernel_name
+    assert eng.kernel_name in ("mfma64_gather", "mfma64_coop"), eng.kernel_name      # (the interpreter kernels: 69 groups of 16 patterns get a CU each)
     assert abs(first - ref) <= 1e-10 * abs(ref)
     t0 = time.time()
     while eng.kernel_name != "mfma64_jit" and time.time() - t0 < 120:
@@ -467,7 +467,7 @@ def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch
     if n == 61 and n_tips in (130, 200):
         assert eng.kernel_name == "mfma64_jit"             # one tip-code block
     if n == 61 and n_tips == 230:
-        assert eng.kernel_name == "mfma64_gather"          # beyond the LDS budget of the specialised kernel
+        assert eng.kernel_name in ("mfma64_gather", "mfma64_coop")      # beyond the LDS budget of the specialised kernel: the interpreters
     if n == 61 and n_tips == 90 and jit:
         assert eng.kernel_name == "mfma64_jit"
 
