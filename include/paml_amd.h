@@ -40,9 +40,14 @@ enum {
    PAML_AMD_KEEP_PARTIALS = 1,  /* keep every internal node's partials resident: needed by
                                    paml_amd_get_partials / dirty-node re-evaluation
                                    (com.conPSiteClass = 1 memory model, codeml.c:2343-2346) */
-   PAML_AMD_JIT = 2             /* compile a pruning kernel specialised for the tree (hiprtc, a few seconds per
+   PAML_AMD_JIT = 2,            /* compile a pruning kernel specialised for the tree (hiprtc, a few seconds per
                                    new topology) even for small data sets; large ones do so by default
                                    (env PAML_AMD_JIT=0/1 overrides) */
+   PAML_AMD_SHARD = 4           /* this engine will hold one rank's SHARD of a larger alignment (paml_amd_comm_init with
+                                   n_patt_global > n_patt): kernels whose summation order differs are then never chosen by
+                                   the shard's own size, so that lnL keeps the same bits for every number of ranks.  (Only
+                                   20-state data sets of at most 4096 patterns are affected: without the flag they take the
+                                   latency path of small data; paml_amd_comm_init refuses such an engine as a shard.) */
 };
 
 /* eigen-system kinds = the branches of GetPMatBranch (treesub.c:7503-7592) */

@@ -49,6 +49,8 @@ int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id12
    enter(e);
    if (!e || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return fail(e, PAML_AMD_EINVAL, "comm_init: bad arguments");
    if (e->comm) return fail(e, PAML_AMD_EINVAL, "comm_init: the engine already has a communicator");
+   if (e->small20 && n_patt_global != e->n_patt)
+      return fail(e, PAML_AMD_EINVAL, "comm_init: this 20-state engine chose its kernels by its own (small) size; create the engines of shards with PAML_AMD_SHARD");
    const int chunk = red_chunk(n_patt_global);
    if (first_pattern < 0 || first_pattern + e->n_patt > n_patt_global || first_pattern % chunk != 0 ||
        (first_pattern + e->n_patt != n_patt_global && e->n_patt % chunk != 0))

@@ -42,7 +42,15 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    // internal branches' P(t) fit in LDS; else the 16x16x4 kernel trimmed to 2 row blocks x 5 k-blocks (2-3x the scalar-operand
    // kernel); the MFMA interpreters (64 MFMAs per product whatever n) do not pay, so small or keep-partials engines stay on valu20
    e->want_m20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_genes == 1 && n_tips <= 49 && !e->env.no_m20 && !e->env.valu20;
-   const bool mfma20 = n_states == 20 && !e->want_m20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_tips <= 95 && !e->env.valu20;
+   // ... and SMALL 20-state data sets (at most 4096 patterns, round 4): what counts there is the length of one wave's walk, and the
+   // cooperative form of the MFMA interpreter (prune_mfma64_coop: four waves per 16-pattern group, 16 MFMAs per wave and branch on
+   // the zero-padded matrices) walks a branch in a sixth of the time of the scalar-operand kernel's 400 dependent FMAs per lane
+   // (stewart.aa, 6 taxa x 98 patterns x 4 classes: 40 -> 22 us per evaluation, profiles/r04_small_timeline.txt)
+   // (its sums are ordered differently from the scalar-operand kernel's: an engine that holds a SHARD of a larger alignment must not
+   //  choose by its own size — PAML_AMD_SHARD; paml_amd_comm_init checks)
+   const bool small20 = n_states == 20 && !e->want_m20 && !(flags & (PAML_AMD_KEEP_PARTIALS | PAML_AMD_SHARD)) && n_patt <= 4096 && !e->env.valu20 && !e->env.no_coop;
+   e->small20 = small20;
+   const bool mfma20 = small20 || (n_states == 20 && !e->want_m20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_tips <= 95 && !e->env.valu20);
    if (n_states == 4) e->kk = KK_VALU4;
    else if (n_states == 5) e->kk = KK_VALU5;
    else if (n_states == 20 && !mfma20) e->kk = KK_VALU20;

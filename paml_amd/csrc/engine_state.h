@@ -312,6 +312,7 @@ struct paml_amd_engine {
    Staging stage;
    JitKernel jit;            // per-tree specialised kernel (jit.h), valid when jit.fn != nullptr
    bool jit_enabled = false, use_jit = false;
+   bool small20 = false;     // 20 states on the MFMA interpreters because the data set is small (engine_core.hip): not as a shard of a larger one
    bool coop = false;        // the last evaluation ran prune_mfma64_coop (small data sets: four waves per 16-pattern group)
    // Consecutive paml_amd_eval_device calls (the loop of a benchmark or of an optimiser's independent evaluations) build the
    // NEXT evaluation's P(t) on a side stream while the previous pruning kernel is still running: its few workgroups fit the CUs

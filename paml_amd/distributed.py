@@ -43,7 +43,7 @@ def sharded_engine(pb, flags=0, world=None, rank=None, force_comm=False):
         world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
     lo, hi = shard_bounds(pb.n_patt, world, rank)      # (raises on EVERY rank alike when there are more ranks than reduction chunks)
     sub = pb.slice_patterns(lo, hi) if (lo, hi) != (0, pb.n_patt) else pb
-    eng = engine.engine_for(sub, flags=flags)
+    eng = engine.engine_for(sub, flags=flags | (engine.SHARD if sub is not pb else 0))
     uid = None
     if world > 1 or force_comm:
         uid = engine.comm_unique_id() if rank == 0 else None

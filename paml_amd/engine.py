@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("PAML_AMD_LIB") or os.path.join(_HERE, "lib", "libpaml
 CSRC = os.path.join(_HERE, "csrc")
 KEEP_PARTIALS = 1
 JIT = 2
+SHARD = 4      # the engine holds one rank's shard of a larger alignment (include/paml_amd.h)
 
 EXPORTS = [
     "paml_amd_set_gene_class_rates", "paml_amd_get_branch_partials", "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",

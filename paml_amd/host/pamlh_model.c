@@ -1772,7 +1772,8 @@ int pamlh_engine_ready(pamlh *p)
 {
    int rc;
    if (p->eng) return 0;
-   if ((rc = paml_amd_create(&p->eng, p->n, p->ns, p->npatt, 64, p->ngene, 0))) return pamlh_fail(p, "paml_amd_create failed (%d): no GPU?", rc);
+   if ((rc = paml_amd_create(&p->eng, p->n, p->ns, p->npatt, 64, p->ngene, (p->shard_world > 0 && p->npatt_global != p->npatt) ? PAML_AMD_SHARD : 0)))
+      return pamlh_fail(p, "paml_amd_create failed (%d): no GPU?", rc);
    if ((rc = paml_amd_set_tips(p->eng, p->z, p->cleandata, p->n_codes, p->n_chara, p->chara_map, p->w, p->ngene > 1 ? p->posG : NULL)) ||
        (rc = paml_amd_set_tree(p->eng, p->nnode, p->root, p->sons_ptr, p->sons, p->label, p->scale)))
       return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));

@@ -90,7 +90,7 @@ def main():
                     raise SystemExit("rank %d: no id from rank 0" % rank)
             uid = open(idfile, "rb").read()
         lo, hi = distributed.shard_bounds(pb.n_patt, world, rank)
-        eng = engine.engine_for(pb.slice_patterns(lo, hi), flags=flags)
+        eng = engine.engine_for(pb.slice_patterns(lo, hi), flags=flags | engine.SHARD)      # (a shard: kernels not chosen by its own size)
         eng.comm_init(rank, world, uid, pb.n_patt, lo)
         res = run(pb, eng)
         res["shard"] = [lo, hi]

@@ -9,7 +9,7 @@ import pytest
 import helpers
 import oracle
 from paml_amd import synth
-from paml_amd.engine import JIT, KEEP_PARTIALS, engine_for
+from paml_amd.engine import JIT, KEEP_PARTIALS, SHARD, engine_for
 from paml_amd.problem import Tree
 
 pytestmark = pytest.mark.gpu
@@ -832,7 +832,7 @@ def test_sharded_partial_sums_are_world_size_invariant(n, K, genes):
         for r in range(world):
             lo, hi = distributed.shard_bounds(pb.n_patt, world, r)
             sub = pb.slice_patterns(lo, hi)
-            e = engine_for(sub)
+            e = engine_for(sub, flags=SHARD)
             e.comm_init(0, 1, None, pb.n_patt, lo)      # global chunking only: no communicator on a one-GPU box
             local = e.eval(sub.tree.branch, sub.gene_rate)["lnL"]
             ps = e.partial_sums()
@@ -866,7 +866,7 @@ def test_branch_local_sums_are_world_size_invariant(n, n_tips, n_patt, K):
             if hi == lo:
                 continue
             sub = pb.slice_patterns(lo, hi)
-            e = engine_for(sub)
+            e = engine_for(sub, flags=SHARD)
             e.comm_init(0, 1, None, pb.n_patt, lo)      # shard geometry only
             e.eval_branch(b, ts, sub.tree.branch)
             tot += e.branch_partials()
