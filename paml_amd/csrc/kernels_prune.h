@@ -301,6 +301,23 @@ __global__ __launch_bounds__(256) void prune_mfma64_coop(PruneArgs a)
       const double2 *pt_ = (const double2 *)(Ptip + (long)(tip)*tipstride + row_ * 16);                         \
       V0 = pt_[(2 * wave) ^ swz_]; V1 = pt_[(2 * wave + 1) ^ swz_];                                             \
    } while (0)
+   // the rows of the NEXT tip step (tips ta, tb; -1: not requested), asked for when the product in front of it starts
+   double2 tv0 = {0, 0}, tv1 = {0, 0}, tw0 = {0, 0}, tw1 = {0, 0};
+   int ta = -1, tb = -1;
+#define COOP_TIP_AHEAD(FROM)                                                                                      \
+   do {                                                                                                         \
+      ta = tb = -1;                                                                                             \
+      for (int k_ = (FROM); zl; k_++) {                                                                         \
+         const Op o_ = fetch_op(a.ops, k_);                                                                     \
+         if (o_.code == OP_END || o_.code == OP_MATMUL || o_.code == OP_MATMUL_POP) break;                      \
+         const bool two_ = o_.code == OP_SET_TIP2 || o_.code == OP_MUL_TIP2;                                    \
+         if (two_ || o_.code == OP_SET_TIP || o_.code == OP_MUL_TIP) {                                          \
+            ta = o_.a; COOP_TIP(ta, tv0, tv1);                                                                  \
+            if (two_) { tb = o_.b; COOP_TIP(tb, tw0, tw1); }                                                    \
+            break;                                                                                              \
+         }                                                                                                      \
+      }                                                                                                         \
+   } while (0)
 #define COOP_SLOT(SLOT, STMT)                                                                                     \
    switch (SLOT) {                                                                                              \
    case 0: { double(&S)[4] = st[0]; STMT } break; case 1: { double(&S)[4] = st[1]; STMT } break;                \
@@ -326,21 +343,21 @@ __global__ __launch_bounds__(256) void prune_mfma64_coop(PruneArgs a)
       } break;
       case OP_SET_TIP:
       case OP_MUL_TIP: {
-         double2 v0, v1;
-         COOP_TIP(op.a, v0, v1);
-         if (op.code == OP_SET_TIP) { cur[0] = v0.x; cur[1] = v0.y; cur[2] = v1.x; cur[3] = v1.y; }
-         else { cur[0] *= v0.x; cur[1] *= v0.y; cur[2] *= v1.x; cur[3] *= v1.y; }
+         if (ta != op.a) COOP_TIP(op.a, tv0, tv1);      // (not requested ahead)
+         if (op.code == OP_SET_TIP) { cur[0] = tv0.x; cur[1] = tv0.y; cur[2] = tv1.x; cur[3] = tv1.y; }
+         else { cur[0] *= tv0.x; cur[1] *= tv0.y; cur[2] *= tv1.x; cur[3] *= tv1.y; }
+         ta = tb = -1;
       } break;
       case OP_SET_TIP2:
       case OP_MUL_TIP2: {
-         double2 v0, v1, w0, w1;
-         COOP_TIP(op.a, v0, v1);
-         COOP_TIP(op.b, w0, w1);
-         if (op.code == OP_SET_TIP2) { cur[0] = v0.x * w0.x; cur[1] = v0.y * w0.y; cur[2] = v1.x * w1.x; cur[3] = v1.y * w1.y; }
+         if (ta != op.a) COOP_TIP(op.a, tv0, tv1);
+         if (tb != op.b) COOP_TIP(op.b, tw0, tw1);
+         if (op.code == OP_SET_TIP2) { cur[0] = tv0.x * tw0.x; cur[1] = tv0.y * tw0.y; cur[2] = tv1.x * tw1.x; cur[3] = tv1.y * tw1.y; }
          else {
-            cur[0] = (cur[0] * v0.x) * w0.x; cur[1] = (cur[1] * v0.y) * w0.y;
-            cur[2] = (cur[2] * v1.x) * w1.x; cur[3] = (cur[3] * v1.y) * w1.y;
+            cur[0] = (cur[0] * tv0.x) * tw0.x; cur[1] = (cur[1] * tv0.y) * tw0.y;
+            cur[2] = (cur[2] * tv1.x) * tw1.x; cur[3] = (cur[3] * tv1.y) * tw1.y;
          }
+         ta = tb = -1;
       } break;
       case OP_PUSH: {
          COOP_SLOT(op.b, { _Pragma("unroll") for (int r = 0; r < 4; r++) S[r] = cur[r]; })
@@ -378,6 +395,7 @@ __global__ __launch_bounds__(256) void prune_mfma64_coop(PruneArgs a)
          xs[(2 * wave + 1) * 64 + lane] = make_double2(cur[2], cur[3]);
          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
          __syncthreads();      // the operand partial is complete, this branch's P has landed in sP[buf], every wave is done with sP[buf ^ 1]
+         COOP_TIP_AHEAD(ip + 1);      // the tip step behind this product, if there is one: its rows arrive under the MFMAs
          if (op.c >= 0) stage_p<4>(Pint + (long)op.c * 4096, sP[buf ^ 1], wave, lane);
          const double2 *xr = (const double2 *)sX[xb], *sp = (const double2 *)sP[buf];
          double2 xv[8], af[8];
@@ -425,6 +443,7 @@ __global__ __launch_bounds__(256) void prune_mfma64_coop(PruneArgs a)
    }
 #undef TIP_CODE
 #undef COOP_TIP
+#undef COOP_TIP_AHEAD
 #undef COOP_SLOT
 }
 
