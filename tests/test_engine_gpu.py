@@ -1075,3 +1075,39 @@ def test_eval_branch_full_size_c4_reproduces_the_reference_lnl():
         assert abs(ddl[0] - fd2) <= 2e-2 * abs(fd2) + 100.0, (b, ddl[0], fd2)
     c = eng.branch_counters()
     assert c["n_nodes"] <= (t.n_nodes - t.n_tips) + 3 * 4
+
+
+@pytest.mark.parametrize("n,n_tips,n_patt,K,kw", [(61, 13, 79, 1, {}), (61, 10, 300, 3, dict(scale_every=3)), (61, 24, 150, 2, dict(ambiguity=True)),
+                                                  (40, 9, 200, 2, {}), (61, 60, 40, 1, dict(scale_every=7, ambiguity=True))])
+def test_small_data_cooperative_kernel_has_the_bits_of_the_gather_kernel(n, n_tips, n_patt, K, kw, monkeypatch):
+    """Small data sets (every 16-pattern group can have a CU) run prune_mfma64_coop — four waves per group, a row block of every
+    product each — instead of one wave per group; per row block the k-blocks accumulate in the same order and the root sum is the
+    gather kernel's code, so the two kernels give the SAME bits (the engine changes between them with the size of a launch: an
+    evaluation, then a batched gradient), and both agree with the oracle."""
+    monkeypatch.setenv("PAML_AMD_JIT", "0")
+    pb = helpers.random_problem(n, n_tips, n_patt, K=K, seed=700 + n_tips, **kw)
+    eng, out, ref = check(pb)
+    assert eng.kernel_name == "mfma64_coop"
+    monkeypatch.setenv("PAML_AMD_COOP", "0")
+    eng0 = engine_for(pb)
+    out0 = eng0.eval(pb.tree.branch, pb.gene_rate, want_lnf=True, want_fhk=True)
+    assert eng0.kernel_name == "mfma64_gather"
+    assert out0["lnL"] == out["lnL"] and np.array_equal(out0["lnf"], out["lnf"]) and np.array_equal(out0["fhK"], out["fhK"])
+    # batched evaluations: two parameter sets still fit the cooperative form, a hundred do not (the same engine changes kernel)
+    for nb in (2, 100):
+        br = np.stack([pb.tree.branch * (1 + 0.01 * i) for i in range(nb)])
+        assert np.array_equal(eng.eval_batch(br), eng0.eval_batch(br))
+
+
+def test_small_20_state_data_take_the_matrix_core_interpreter_unless_they_are_a_shard():
+    """20 states, at most 4096 patterns: the cooperative MFMA interpreter on zero-padded matrices instead of the scalar-operand kernel
+    (a branch in a sixth of the time); its sums are ordered differently, so an engine that holds a SHARD of a larger alignment must
+    say so (PAML_AMD_SHARD) — paml_amd_comm_init refuses one that chose by its own size."""
+    pb = helpers.random_problem(20, 7, 300, K=4, seed=41)
+    eng, out, ref = check(pb)
+    assert eng.kernel_name == "mfma64_coop"
+    assert eng._L.paml_amd_comm_init(eng._h, 0, 1, None, 100000, 0) != 0 and b"PAML_AMD_SHARD" in eng._L.paml_amd_last_error(eng._h)
+    shard, outs, _ = check(pb, flags=SHARD)
+    assert shard.kernel_name == "valu20"
+    shard.comm_init(0, 1, None, 100000 // 256 * 256 + 300, 100000 // 256 * 256)
+    assert abs(outs["lnL"] - out["lnL"]) <= 1e-11 * abs(out["lnL"])
