@@ -261,8 +261,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void prune_mfma64_gather(PruneArgs a
 // one accumulator) and the root sum (wave 0, the gather kernel's own code) are the other kernels': same bits.  Workgroup b: 16-pattern
 // group (b & 3) of 64-pattern tile (b >> 2) % n_tiles — the gather kernel's tile table, so the engine changes between the two kernels
 // (a batched gradient has many more groups) without rebuilding anything.  No keep-partials ops, at most COOP_SLOTS stack slots.
-// (Also built and measured SLOWER, 37.7 us: the A operands and the next tip step's rows straight from global memory into registers two
-// products ahead, no LDS staging of P — the compiler waits for every outstanding load at each use inside the op loop.)
+// (Also built and measured, profiles/r04_small_timeline.txt: the A operands and the next tip step's rows straight from global memory into
+// registers two products ahead, no LDS staging of P — slower, 37.7 us: the compiler waits for every outstanding load at each use inside
+// the op loop; P(t) in a wave-private ring of three with counted waits and the tip rows as LDS-DMA gathers a product ahead, the
+// look-aheads resolved on the host — 3 % faster, same bits, not worth its dozen counted waits.  A dependent MFMA chain costs nothing
+// extra (tools/mfma_f64_chain.hip): of a product step's 4 400 cycles the 16 MFMAs are 1 024, the rest is the op loop's serial chain
+// of 100 - 300-cycle latencies that one wave per SIMD cannot hide.)
 constexpr int COOP_SLOTS = 8;
 constexpr int COOP_ZT = 512;      // tips whose codes are staged in LDS (more: read from global memory)
 
