@@ -532,9 +532,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          hipLaunchKernelGGL(prune_mfma64_stream, dim3(n_blocks), dim3(512), lds, ms, pr);
       }
       else {
-         // small data sets — every 16-pattern group can have a CU (two rounds at most): four waves per group (prune_mfma64_coop)
+         // small data sets — every 16-pattern group can have a CU (ONE round: the kernel's 90 KB of LDS leave room for one workgroup
+         // per CU, and two rounds of its 25 us walks lose to one round of the gather kernel's 39): four waves per group (prune_mfma64_coop)
          bool coop = !keep && !clean && !e->env.no_coop && e->tile_patt == 64 && e->prog.max_stack <= COOP_SLOTS &&
-                     (long)e->n_tiles * 4 * K <= 2L * e->n_cu && !e->env.prof_ops.size();
+                     (long)e->n_tiles * 4 * K <= (long)e->n_cu && !e->env.prof_ops.size();
          for (const Op &o : e->prog.ops) coop = coop && o.code != OP_STORE && o.code != OP_LOAD && o.code != OP_EXPORT;
          e->coop = coop;
          if (coop) hipLaunchKernelGGL(prune_mfma64_coop, dim3(e->n_tiles * 4 * K), dim3(256), 0, ms, pr);
