@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void pmat_kernel_t(PmatArgs a, InlineVec iv)
 // 23 matrices on 256 CUs; profiles/r04_small_timeline.txt): U and V staged through LDS, a 61-step loop of LDS reads, the three
 // output layouts gathered from LDS with 16-way bank conflicts, one workgroup's serial chain.  Here a wave owns a 16 x 16 block of
 // the row block: its A operands are U's rows times expm1(t Root_k) and its B operands V's columns, both straight from global memory
-// (L2) in the instruction's own lane order, sixteen v_mfma_f64_16x16x4 (k ascending, as PMatUVRoot accumulates, tools.c:525-537),
+// (L2) in the instruction's own lane order (the A operands, the same for the four waves, a quarter per wave and shared through LDS), sixteen v_mfma_f64_16x16x4 (k ascending, as PMatUVRoot accumulates, tools.c:525-537),
 // `+ I`, the clamp, and the row block goes to LDS (row stride 65: conflict-free for the column-order outputs).  Every output
 // layout is complete per row block — rowmajor rows, the prune kernels' A-operand order [k-block pair][ROW BLOCK][lane][2], the
 // q-major entries of column 60, the rows jj = 4m + q of the tips' column tables — so the four workgroups of a matrix share nothing.
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv
 {
    __shared__ double sE[64];
    __shared__ double sP[16 * 65];
+   __shared__ double sA[16 * 64];      // the row block's A operands [k-block][lane]: every wave needs all of them, each loads a quarter
    __shared__ unsigned char sMap[256 * 64];
    __shared__ int sNch[256];
    const int node = blockIdx.x, pset = blockIdx.y, rb = blockIdx.z;
@@ -385,23 +386,31 @@ __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv
    const bool leaf = a.is_leaf[node] != 0;
    // this lane's operands of the sixteen k-blocks: A = U[16 rb + (lane & 15)][4 kb + (lane >> 4)], B = V[4 kb + (lane >> 4)][16 wave + (lane & 15)]
    const int ai = rb * 16 + (lane & 15), bj = wave * 16 + (lane & 15), kq = lane >> 4;
-   double ua[16], vb[16];
+   // (the four waves' A operands are the same sixteen values per lane: wave w fetches k-blocks 4 w .. 4 w + 3 and they are shared through
+   //  LDS — 40 KB instead of 64 KB of L2 reads per workgroup, which is what a launch of a thousand workgroups (M8: 253 matrices) waits for)
+   double ua4[4], vb[16];
 #pragma unroll
    for (int kb = 0; kb < 16; kb++) {
       const int k = 4 * kb + kq;
-      ua[kb] = (ai < n && k < n) ? es.U[ai * n + k] : 0.0;
       vb[kb] = (bj < n && k < n) ? es.V[k * n + bj] : 0.0;
+   }
+#pragma unroll
+   for (int i = 0; i < 4; i++) {
+      const int k = 4 * (4 * wave + i) + kq;
+      ua4[i] = (ai < n && k < n) ? es.U[ai * n + k] : 0.0;
    }
    if (tid < 64) sE[tid] = (tid < n && !(t < 1e-100)) ? expm1(t * es.Root[tid]) : 0.0;      // (t < 1e-100: P = I, tools.c:521)
    if (leaf) {      // the ambiguity map (tools.c:20 nChara / CharaMap) for the column tables below
       for (int idx = tid; idx < a.n_codes * n; idx += 256) sMap[idx] = a.chara_map[idx];
       for (int idx = tid; idx < a.n_codes; idx += 256) sNch[idx] = a.n_chara[idx];
    }
+#pragma unroll
+   for (int i = 0; i < 4; i++) sA[(4 * wave + i) * 64 + lane] = ua4[i];
    __syncthreads();
    typedef double pm_v4d __attribute__((ext_vector_type(4)));
    pm_v4d acc = {0, 0, 0, 0};
 #pragma unroll
-   for (int kb = 0; kb < 16; kb++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[kb] * sE[4 * kb + kq], vb[kb], acc, 0, 0, 0);
+   for (int kb = 0; kb < 16; kb++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[kb * 64 + lane] * sE[4 * kb + kq], vb[kb], acc, 0, 0, 0);
    // accumulator element r of this lane = P[16 rb + 4 r + (lane >> 4)][16 wave + (lane & 15)]
 #pragma unroll
    for (int r = 0; r < 4; r++) {
