@@ -469,3 +469,13 @@ def test_reference_binding_patches_apply_and_link():
         assert os.access(exe, os.X_OK)
         ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
         assert "libpaml_amd.so" in ldd and "not found" not in ldd.split("libpaml_amd.so")[1].split("\n")[0]
+
+
+def test_create_flags_of_the_python_mirror_are_the_headers():
+    """paml_amd/engine.py restates the create flags of include/paml_amd.h (KEEP_PARTIALS, JIT, SHARD)."""
+    import re
+    from paml_amd import engine
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "paml_amd.h")).read()
+    for name, value in (("PAML_AMD_KEEP_PARTIALS", engine.KEEP_PARTIALS), ("PAML_AMD_JIT", engine.JIT), ("PAML_AMD_SHARD", engine.SHARD)):
+        m = re.search(r"\b%s\s*=\s*(\d+)" % name, text)
+        assert m and int(m.group(1)) == value, name
