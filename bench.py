@@ -88,15 +88,21 @@ class HeadlineGuard:
         self.timer.daemon = True
         self.timer.start()
 
-    def fire(self, why):
+    def fire(self, why, correctness=False):
+        """`correctness`: one of the bench's own parity gates failed behind the headline (an lnL that differs from the reference's or
+        from the one-rank bits) — the line still gets out, flagged `correctness_failed`, and the process ends with status 3; a hang or
+        an infrastructure exception (a collective that failed, a missing library) is tolerated with status 0."""
         with self.lock:
             if self.done:
                 return
             self.done = True
         if self.rank == 0 and self.out is not None:
+            extra = {"extras_error": why}
+            if correctness:
+                extra["correctness_failed"] = True
             for _ in range(3):      # (the main thread may be adding a block to the dict)
                 try:
-                    line = json.dumps(dict(self.out, extras_error=why), default=str)
+                    line = json.dumps(dict(self.out, **extra), default=str)
                     break
                 except RuntimeError:
                     line = None
@@ -104,7 +110,7 @@ class HeadlineGuard:
                 os.write(self.fd, (line + "\n").encode())
         sys.stderr.write("bench: rank %d: %s\n" % (self.rank, why))
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(3 if correctness else 0)
 
     def finish(self):
         """The normal end: False if the timer has already taken over (the caller then must not print)."""
@@ -132,6 +138,10 @@ def main():
     args = ap.parse_args()
     if args.clock_probe:
         return clock_probe(args)
+    # `python bench.py --gpus N` with no launcher around it (no RANK / WORLD_SIZE in the environment): the bench starts its own N
+    # ranks — one process per GPU through torch.distributed.run on 127.0.0.1 — and hands on rank 0's line
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args.gpus)
 
     # ONE JSON line on stdout: libraries underneath print there too (RCCL's version banner comes out of C stdio when the process ends, after
     # the line), so file descriptor 1 is pointed at stderr for the duration and the line is written to the real stdout at the end
@@ -146,10 +156,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (world, args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d (or with no launcher at all: "
+                         "bench.py --gpus N starts its own ranks)" % (world, args.gpus, args.gpus))
+    if os.environ.get("PAML_AMD_BENCH_LAUNCH_PROBE") == "1":      # (tests, no GPU needed: which launch convention brought this rank here)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"launch_probe": True, "world": world, "self_launched": os.environ.get("PAML_AMD_BENCH_SELF_LAUNCHED") == "1",
+                                               "master_addr": os.environ.get("MASTER_ADDR")}) + "\n").encode())
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    if world > 1 and os.environ.get("PAML_AMD_BENCH_ONE_GPU") != "1" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s) (one rank per GPU; PAML_AMD_BENCH_ONE_GPU=1 with PAML_AMD_RCCL_LIB "
+                         "naming the tests' stand-in runs every rank on GPU 0)" % (world, torch.cuda.device_count()))
     # PAML_AMD_BENCH_ONE_GPU=1 (tests): every rank on GPU 0, gloo as the courier — with PAML_AMD_RCCL_LIB naming the tests'
     # shared-memory stand-in for RCCL this runs the whole N > 1 path on a one-GPU box (real RCCL refuses two ranks per device)
     one_gpu = os.environ.get("PAML_AMD_BENCH_ONE_GPU") == "1"
@@ -264,6 +282,11 @@ def main():
         # exchange_us = partial sums ready -> total formed (all-reduce over the ranks + fixed-order total, on the engine's collective stream);
         # lane_wait_us = how long an evaluation's pruning stream stood in front of its slot's previous exchange (the event pair that
         # measures it costs ~12 us itself: that is the floor).  64 evaluations with timed events, AFTER the timed region.
+        if (world > 1 or force_comm) and rank == 0:
+            try:      # which librccl the exchange step is bound to (torch ships its own copy; PAML_AMD_RCCL_LIB names another)
+                out["config"]["collective_library"] = engine.comm_library()
+            except Exception as ex:      # noqa: BLE001
+                out["config"]["collective_library"] = repr(ex)
         if world > 1 or force_comm:
             try:      # (diagnostics: whatever goes wrong here, the headline above stands)
                 eng.comm_stats(True)
@@ -374,7 +397,8 @@ def main():
     except (Exception, SystemExit) as ex:      # noqa: BLE001
         if guard is None:
             raise
-        guard.fire("rank %d, after the headline: %r" % (rank, ex))
+        # (the bench's own parity gates raise SystemExit("bench: ..."): a wrong number is not an infrastructure failure)
+        guard.fire("rank %d, after the headline: %r" % (rank, ex), correctness=isinstance(ex, SystemExit))
 
     # ---- N = 1: the 4-state configuration and the CPU baseline -----------------------------------------------------------
     if rank == 0 and world == 1 and extras and pb.n == 61:
@@ -418,6 +442,30 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         bye.cancel()
+
+
+def self_launch(n):
+    """Start the N ranks of `bench.py --gpus N` from a bare `python bench.py --gpus N`: torch.distributed.run, one node, rendezvous on
+    127.0.0.1 at a free port, the same command-line arguments.  The ranks' stderr passes through; of their stdout only JSON lines do
+    (rank 0 prints the one line).  Returns the launcher's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, PAML_AMD_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: what RCCL across processes needs on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    for ln in lines[-1:]:
+        sys.stdout.write(ln + "\n")
+    sys.stdout.flush()
+    if r.returncode != 0 or not lines:
+        raise SystemExit(r.returncode or 1)
+    return 0
 
 
 def weak_engine(args, world, rank, engine, distributed, synth, force_comm):

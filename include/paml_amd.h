@@ -102,6 +102,11 @@ int paml_amd_comm_unique_id(void *id128);
 int paml_amd_comm_init(paml_amd_engine *e, int rank, int world, const void *id128, long n_patt_global, long first_pattern);
 int paml_amd_comm_destroy(paml_amd_engine *e);
 int paml_amd_comm_info(const paml_amd_engine *e, int *rank, int *world, long *n_patt_global, long *first_pattern, int *chunk);
+/* Which collective library the engine's exchange step is bound to (no reference counterpart): the path of the shared object that
+ * holds ncclAllReduce (dladdr), loading it first if no communicator has been made yet — PyTorch ships a librccl of its own, and a
+ * process that has imported torch shares THAT copy (dlopen matches by soname).  Returns the length written (truncated to cap - 1),
+ * PAML_AMD_EUNSUPPORTED when no library could be bound. */
+int paml_amd_comm_library(char *path, int cap);
 /* Diagnostics of the exchange step (no reference counterpart; what `bench.py --gpus N` prints so that a scaling run explains
  * itself).  enable != 0 switches timed events on for the evaluations that follow (also: PAML_AMD_COMM_STATS=1), 0 off.  With
  * non-NULL outputs it reports, over the last *n (<= 64) evaluations whose exchange step ran on the engine's collective stream

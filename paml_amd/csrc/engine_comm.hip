@@ -110,6 +110,18 @@ int paml_amd_get_partial_sums(paml_amd_engine *e, double *out, int cap)
    return e->nb_global;
 }
 
+int paml_amd_comm_library(char *path, int cap)
+{
+   if (!path || cap < 1) return PAML_AMD_EINVAL;
+   if (!rccl().load()) return PAML_AMD_EUNSUPPORTED;
+   Dl_info info;
+   const char *nm = (dladdr((const void *)rccl().AllReduce, &info) && info.dli_fname) ? info.dli_fname : "?";
+   const int len = (int)std::min<size_t>(strlen(nm), (size_t)cap - 1);
+   memcpy(path, nm, len);
+   path[len] = 0;
+   return len;
+}
+
 int paml_amd_comm_stats(paml_amd_engine *e, int enable, int *n, double *ex_mean, double *ex_max, double *lw_mean, double *lw_max)
 {
    if (!e) return PAML_AMD_EINVAL;

@@ -71,6 +71,10 @@ def run(pb, eng, n_dev=7):
 def main():
     rank, world, xdir, case = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     from paml_amd import distributed, engine
+    real = os.environ.get("PAML_AMD_WORKER_REAL_RCCL") == "1"      # one GPU per rank, the real collective library (multi-GPU boxes)
+    if real and world > 1:
+        torch.cuda.set_device(rank)
+        assert engine.lib().paml_amd_set_device(rank) == 0
     pb, flags = problem(case)
     if world == 1:      # the reference run: one engine over everything, no communicator
         eng = engine.engine_for(pb, flags=flags)
@@ -94,6 +98,17 @@ def main():
         eng.comm_init(rank, world, uid, pb.n_patt, lo)
         res = run(pb, eng)
         res["shard"] = [lo, hi]
+        if real:      # what the exchange step did on real hardware: timed events over a run of evaluations, and which library it was
+            eng.comm_stats(True)
+            d = torch.zeros(16, dtype=torch.float64, device="cuda")
+            for i in range(16):
+                eng.eval_device(pb.tree.branch, d.data_ptr() + 8 * i, pb.gene_rate)
+            eng.flush()
+            torch.cuda.current_stream().synchronize()
+            res["comm_stats"] = eng.comm_stats(False, read=True)
+            res["comm_library"] = engine.comm_library()
+            res["device"] = torch.cuda.current_device()
+            res["run16"] = [float(v).hex() for v in d.cpu().numpy()]
     eng.close()
     with open(os.path.join(xdir, "out%d.json" % rank), "w") as f:
         json.dump(res, f)

@@ -49,8 +49,45 @@ def test_guard_reports_an_exception_and_the_normal_end_prints_once():
     r = run(0, 5, "throw")
     assert r.returncode == 0
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert "parity" in line["extras_error"]
+    assert "parity" in line["extras_error"] and "correctness_failed" not in line
     r = run(0, 0.2, "ok")
     assert r.returncode == 0
     lines = r.stdout.strip().splitlines()
     assert len(lines) == 1 and "extras_error" not in json.loads(lines[0])
+
+
+def test_guard_flags_a_failed_parity_gate_and_exits_non_zero():
+    """A wrong number behind the headline is not an infrastructure failure: the line still gets out, flagged, and the status is 3."""
+    script = SCRIPT.replace('g.fire("rank %%d: %%r" %% (int(sys.argv[1]), ex))', 'g.fire("rank %%d: %%r" %% (int(sys.argv[1]), ex), correctness=isinstance(ex, SystemExit))')
+    r = subprocess.run([sys.executable, "-c", script % REPO, "0", "5", "throw"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["correctness_failed"] is True and "parity" in line["extras_error"] and line["value"] == 1.5
+
+
+def _probe(cmd, **env):
+    e = dict(os.environ, PAML_AMD_BENCH_LAUNCH_PROBE="1", **env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run(cmd, env=e, cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment (how the driver starts the N = 1 bench) re-executes itself
+    under torch.distributed.run with two ranks on 127.0.0.1; with the launcher around it (the documented convention) it does not."""
+    bench = os.path.join(REPO, "bench.py")
+    p = _probe([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert p == {"launch_probe": True, "world": 2, "self_launched": True, "master_addr": "127.0.0.1"}
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    p = _probe([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), bench, "--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert p["world"] == 2 and p["self_launched"] is False
+    p = _probe([sys.executable, bench, "--gpus", "1", "--steps", "1", "--warmup", "0"])
+    assert p["world"] == 1 and p["self_launched"] is False

@@ -35,10 +35,18 @@ def shim_env(**extra):
     return dict(os.environ, PAML_AMD_RCCL_LIB=SHIM, **extra)
 
 
-def run_ranks(world, case, tmp_path, **extra_env):
-    xdir = tmp_path / ("%s_w%d%s" % (case, world, "".join("_" + v for v in extra_env.values())))
+def real_env(**extra):
+    """The production environment of a multi-GPU node: the real collective library (whatever librccl.so.1 resolves to), one GPU per rank."""
+    env = dict(os.environ, PAML_AMD_WORKER_REAL_RCCL="1", **extra)
+    env.pop("PAML_AMD_RCCL_LIB", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def run_ranks(world, case, tmp_path, real=False, **extra_env):
+    xdir = tmp_path / ("%s_w%d%s%s" % (case, world, "_real" if real else "", "".join("_" + v for v in extra_env.values())))
     xdir.mkdir()
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(xdir), case], env=shim_env(**extra_env),
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(xdir), case], env=real_env(**extra_env) if real else shim_env(**extra_env),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     try:
@@ -154,3 +162,73 @@ def test_pamlh_lnl_on_two_ranks_of_one_gpu(tmp_path):
     # more ranks than reduction chunks: every rank refuses, nobody is left waiting in a collective call
     r9 = subprocess.run(cmd + ["--gpus", "8", "--devices", "0,0,0,0,0,0,0,0"], cwd=tmp_path / "w2", env=shim_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r9.returncode != 0 and "at most" in r9.stdout.decode()
+
+
+# ---- multi-GPU boxes: the same checks on the REAL collective library, one GPU per rank ------------------------------------------------
+def gpus_here():
+    from paml_amd import engine
+    return engine.device_count()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("case", ["codon_big", "nuc_fused", "codon_k3"])
+def test_ranks_on_real_rccl_one_gpu_each_have_the_bits_of_one_engine(world, case, tmp_path):
+    """What the stand-in emulates on the one-GPU test tier, on hardware when there is more than one GPU: `world` ranks, GPU r for rank r,
+    RCCL over xGMI.  lnL (eval, runs of eval_device on two pruning streams, eval_batch), the branch-local sums and, with classes, the
+    rate chain are those of the one-engine run, bit for bit; the exchange step's timed events are there; the library is a real librccl."""
+    if gpus_here() < world:
+        pytest.skip("needs %d GPUs, this box shows %d" % (world, gpus_here()))
+    one = run_ranks(1, case, tmp_path)[0]
+    res = run_ranks(world, case, tmp_path, real=True)
+    for r, out in enumerate(res):
+        for key in ("eval", "eval_device", "eval_batch", "eval_again", "eval_branch"):
+            assert out[key] == one[key], (case, world, r, key, out[key], one[key])
+        if "eval_adg" in one:
+            assert out["eval_adg"] == one["eval_adg"]
+        assert out["device"] == r
+        assert all(v == one["eval"] for v in out["run16"]), (out["run16"], one["eval"])
+        assert out["comm_stats"]["n"] > 0 and out["comm_stats"]["exchange_us"] > 0
+        assert "rccl" in os.path.basename(out["comm_library"]).lower() and "shim" not in out["comm_library"]
+    assert [o["shard"][0] for o in res[1:]] == [o["shard"][1] for o in res[:-1]]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launches_itself_on_real_gpus(world, tmp_path):
+    """`python bench.py --gpus N` with no launcher around it, on N real GPUs: one line, the one-rank bits, the collective library named."""
+    if gpus_here() < world:
+        pytest.skip("needs %d GPUs, this box shows %d" % (world, gpus_here()))
+    common = ["--steps", "4", "--warmup", "2", "--patterns", "200000", "--no-cpu-baseline", "--sweep-steps", "2"]
+    env = real_env()
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r1 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--no-extras"] + common, env=env, cwd=REPO,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r1.returncode == 0, r1.stderr.decode()[-3000:]
+    one = json.loads(r1.stdout.decode().strip().splitlines()[-1])
+    rn = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(world)] + common, env=env, cwd=REPO,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert rn.returncode == 0, rn.stderr.decode()[-3000:]
+    lines = [ln for ln in rn.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    many = json.loads(lines[0])
+    assert many["n_gpus"] == world and many["lnL_hex"] == one["lnL_hex"] and "extras_error" not in many
+    assert "rccl" in many["config"]["collective_library"].lower()
+    assert many["exchange"]["evaluations"] > 0
+
+
+def test_bench_launches_itself_on_two_ranks_of_one_gpu(tmp_path):
+    """The same self-launch on the one-GPU tier: `python bench.py --gpus 2`, no torch.distributed.run in the command, both ranks on GPU 0
+    through the stand-in (PAML_AMD_BENCH_ONE_GPU=1).  One line; strong scaling of the same patterns: the one-rank bits."""
+    env = dict(shim_env(), PAML_AMD_BENCH_ONE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--steps", "3", "--warmup", "1", "--patterns", "40000", "--no-cpu-baseline", "--no-extras"]
+    r1 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1"] + common, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r1.returncode == 0, r1.stderr.decode()[-3000:]
+    r2 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"] + common, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r2.returncode == 0, r2.stderr.decode()[-3000:]
+    lines = [ln for ln in r2.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    one, two = json.loads(r1.stdout.decode().strip().splitlines()[-1]), json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["lnL_hex"] == one["lnL_hex"]
+    assert two["config"]["collective_library"].endswith("librccl_shim.so")
