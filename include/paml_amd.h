@@ -32,7 +32,9 @@ enum {
    PAML_AMD_EINVAL = -1,    /* bad argument / call order */
    PAML_AMD_ENOMEM = -2,    /* device or host allocation failed */
    PAML_AMD_EHIP = -3,      /* HIP runtime error (no device, launch failure ...) */
-   PAML_AMD_EUNSUPPORTED = -4
+   PAML_AMD_EUNSUPPORTED = -4,
+   PAML_AMD_ENOCONV = -5    /* a device eigen-decomposition (paml_amd_set_eigen_qrev_batch) hit its sweep limit: reported by the next
+                               evaluation; decompose on the host and pass U, V, Root (paml_amd_set_eigen_uvroot) */
 };
 
 /* create flags */
@@ -146,7 +148,10 @@ int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi);
  * per matrix (cyclic Jacobi in LDS, FP64, ~0.8 ms): a gradient's or a line search's several hundred decompositions take about the time
  * of one, and U, V, Root never cross PCIe.  Asynchronous on the engine's stream.  paml_amd_get_eigen reads a set back (parity);
  * paml_amd_eigen_counters: matrices decomposed so far and the Jacobi sweeps each matrix of the last batch took (-1: the limit of 40
- * sweeps was reached without convergence — decompose that matrix on the host instead). */
+ * sweeps was reached without convergence — decompose that matrix on the host instead).  The decomposition is asynchronous, so a set
+ * that did not converge is reported by the next synchronous evaluation (paml_amd_eval, _eval_batch, _eval_dirty, _eval_branch), which
+ * returns PAML_AMD_ENOCONV instead of a likelihood formed from unconverged eigenvectors; the C host (pamlh_*.c) and the reference-side
+ * binding (integration/codeml_plfun.patch) then decompose on the host and evaluate again. */
 int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, const double *Q, const double *pi, const double *scale);
 /* Warm start for the above (on = 1; 0 = off, the default; -1 = leave as is; *n_warm, if not NULL, receives the number of
  * decompositions that started warm so far): a set decomposed again starts its Jacobi sweeps from the eigenvectors of its previous

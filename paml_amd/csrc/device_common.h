@@ -77,6 +77,11 @@ struct PruneArgs {
    int *red_counter;            // [batch] zeroed; non-null: the last workgroup to finish adds the partials up (one GPU)
    int nb_local;                // chunks of this engine: a workgroup walks the chunks blockIdx.x, blockIdx.x + gridDim.x, ... (batched
                                 // evaluations run fewer, longer workgroups per element: the LDS tables are filled once per workgroup)
+   // resident partials of the 21..64-state kernels (STORE / LOAD): ONE layout whatever kernel writes or reads them — per class and internal
+   // node `part_groups` 16-pattern groups in the order of the 64-pattern tile table (group = 4 x tile + wave there); a kernel with larger
+   // tiles finds the group of its tile's first 16 patterns in tile_group0[tile] (a 128-pattern tile is two consecutive 64-pattern tiles of its gene)
+   const int *tile_group0;
+   int part_groups;
 };
 
 __device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)
@@ -555,6 +560,22 @@ __device__ __forceinline__ void jit_mul_mem(v4d (&y)[4], const double *sp)   // 
       y[jb].x *= sp[(jb * 4 + 0) * 64]; y[jb].y *= sp[(jb * 4 + 1) * 64]; y[jb].z *= sp[(jb * 4 + 2) * 64]; y[jb].w *= sp[(jb * 4 + 3) * 64];
    }
 }
+
+// STORE / LOAD of a resident partial (keep-partials mode; layout: part_load / part_store above — element m of the partial is y[m >> 2][m & 3],
+// a lane's elements 2 i, 2 i + 1 one 16-byte access, a wave instruction 1 KB).  Compiler-visible memory operations, like the spills.
+__device__ __forceinline__ void jit_store(const v4d (&y)[4], double *p, int lane)
+{
+   part2_t *p2 = (part2_t *)p + lane;
+#pragma unroll
+   for (int i = 0; i < 8; i++) p2[i * 64] = (part2_t){y[i >> 1][(2 * i) & 3], y[i >> 1][(2 * i + 1) & 3]};
+}
+__device__ __forceinline__ void jit_load(v4d (&y)[4], const double *p, int lane)
+{
+   const part2_t *p2 = (const part2_t *)p + lane;
+#pragma unroll
+   for (int i = 0; i < 8; i++) { const part2_t v = p2[i * 64]; y[i >> 1][(2 * i) & 3] = v.x; y[i >> 1][(2 * i + 1) & 3] = v.y; }
+}
+#define JIT_PART_PTR(NODE) (a.partials + (((long)iclass * a.n_int + ((NODE) - a.n_tips)) * a.part_groups + tg0 + wave) * 1024)
 
 __device__ __forceinline__ void jit_mul(v4d (&y)[4], const v4d (&s)[4])   // y = s * y  (codeml.c:3573)
 {

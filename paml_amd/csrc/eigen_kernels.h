@@ -30,6 +30,8 @@ struct EigenQrevArgs {
    double *const *V;
    double *const *Root;
    int *sweeps;              // [n_sets] sweeps used (diagnostics; null: not wanted)
+   int max_sweeps;           // the sweep limit (40; PAML_AMD_EIGEN_SWEEP_LIMIT lowers it: the tests' way to a decomposition that does not converge)
+   int *fail;                // pinned host word, set when a set reached the sweep limit (checked by the next synchronous evaluation)
    // warm start (paml_amd_set_eigen_warm_start): R0[set] = the eigenvectors R^T[64][64] (rows, in the order of the roots) the set's
    // previous decomposition left, or null — the Jacobi sweeps then start from R0^T A R0, which is nearly diagonal when the matrix
    // moved a little (a finite-difference step, a line search): 2-4 sweeps instead of 9-10.  Rout[set]: where this one's go (may be R0[set]).
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(EIG_NT) void eigen_qrev_kernel(EigenQrevArgs a)
    // the column pass.
    int sweep = 0;
    bool converged = false;
-   for (; sweep < 40; sweep++) {
+   for (; sweep < a.max_sweeps; sweep++) {
       double big = 0;
       for (int r = 0; r < N - 1; r++) {
          double cl = 1, sl = 0;
@@ -248,7 +250,8 @@ __global__ __launch_bounds__(EIG_NT) void eigen_qrev_kernel(EigenQrevArgs a)
       V[rk * n + i] = v * sp;
       U[i * n + rk] = v / sp;
    }
-   if (a.sweeps && tid == 0) a.sweeps[set] = converged ? sweep : -1;      // (-1: the sweep limit was reached: paml_amd_eigen_counters shows it, the host falls back)
+   if (a.sweeps && tid == 0) a.sweeps[set] = converged ? sweep : -1;      // (-1: the sweep limit was reached: paml_amd_eigen_counters shows it)
+   if (!converged && a.fail && tid == 0) __hip_atomic_store(a.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // ... and the next evaluation returns PAML_AMD_ENOCONV
 }
 
 }  // namespace paml_amd

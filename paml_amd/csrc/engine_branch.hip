@@ -173,6 +173,14 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    // branch re-orients only the nodes on the path between the two branches; a changed branch length invalidates only the
    // partials that look across it.  Nothing else is recomputed.
    paml_amd_engine::BranchCache &bc = e->bl;
+   // The cache's bookkeeping (which partials, coefficients and operand tables are current) is updated where the kernels that fill them are
+   // queued; should anything after that fail — a launch, the exchange step, the final synchronisation — the call returns its error and the
+   // whole cache is dropped, so that the next call cannot take a "hit" on buffers that were never written.
+   struct DropCacheOnError {
+      paml_amd_engine::BranchCache &c;
+      bool ok = false;
+      ~DropCacheOnError() { if (!ok) c.valid = false; }
+   } cache_guard{bc};
    const size_t words = mfma ? (size_t)K * n_int * e->n_tiles_full * GATHER_WAVES * 1024 : (size_t)K * n_int * e->n_patt * n;
    if (words > e->d_bl_partials.cap) { HIPCHK(e->d_bl_partials.ensure(words)); bc.valid = false; }
    const bool scaled = T.n_scale > 0;
@@ -385,7 +393,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
          pr.fhK = e->d_fhK.p; pr.partials = e->d_bl_partials.p; pr.scalef = e->d_bl_scalef.p; pr.stack_scratch = e->d_stack.p;
          pr.stack_overflow_slots = overflow; pr.first_matmul = prog.first_matmul; pr.n_int = n_int;
-         pr.first_tip = -1; pr.tip_words = (long)tip_words(e);
+         pr.first_tip = -1; pr.tip_words = (long)tip_words(e); pr.part_groups = e->part_groups();
          launch_prune_full(e, prog.max_stack, n_blocks, pr, st);
       }
       EigPrepArgs ea{};
@@ -396,7 +404,13 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       ea.eigen_of = e->d_eigen_of.p; ea.eigen = e->d_eigen.p; ea.code_mask = e->d_code_mask.p;
       ea.efrag = efrag; ea.ztab = ztab; ea.etab = e->d_bl_etab.p; ea.ecol = n == 61 ? e->d_bl_ecol.p + (size_t)lab_b * K * 128 : nullptr;
       hipLaunchKernelGGL(branch_eigprep_kernel, dim3(K), dim3(256), 0, st, ea);
-      static const bool exp_nofeval = getenv("PAML_AMD_BEIG_NOFEVAL") != nullptr;      // (timing experiments, profiles/r04_branch.txt)
+      // (timing experiments of profiles/r04_branch.txt — NOFEVAL, and NOSTORE / NOMFMA whose results are garbage — exist only in a library
+      //  built with PAML_AMD_EXTRA_FLAGS=-DPAML_AMD_BEIG_EXPERIMENTS; the production library does not read these variables)
+#ifdef PAML_AMD_BEIG_EXPERIMENTS
+      static const bool exp_nofeval = getenv("PAML_AMD_BEIG_NOFEVAL") != nullptr;
+#else
+      const bool exp_nofeval = false;
+#endif
       const bool feval = !hit && K == 1 && n_t <= BEIG_NT && !exp_nofeval;
       e->bk_timed = false;
       if (e->profiling) {
@@ -414,8 +428,10 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          ba.pint = e->d_pint.p; ba.ptip = e->d_ptip.p; ba.tip_words = (long)tip_words(e);
          ba.efrag = efrag; ba.ztab = ztab; ba.etab = e->d_bl_etab.p;
          ba.ecol = e->d_bl_ecol.p + (size_t)lab_b * K * 128; ba.pcol = e->d_pcol.p;
-         static const int exp_abl = (getenv("PAML_AMD_BEIG_NOSTORE") ? 1 : 0) | (getenv("PAML_AMD_BEIG_NOMFMA") ? 2 : 0);      // (timing experiments: results are garbage)
+#ifdef PAML_AMD_BEIG_EXPERIMENTS
+         static const int exp_abl = (getenv("PAML_AMD_BEIG_NOSTORE") ? 1 : 0) | (getenv("PAML_AMD_BEIG_NOMFMA") ? 2 : 0);
          ba.no_store = exp_abl;
+#endif
          ba.freqK = e->d_freqK.p; ba.weights = e->d_weights.p; ba.coef = e->d_bl_coef.p; ba.partial = e->d_bpartial.p;
          const bool i0 = n_sons > 0 && !T.is_leaf(son[0]), i1 = n_sons > 1 && !T.is_leaf(son[1]);
          const int variant = n_sons == 0 ? 0 : (n_sons == 1 ? (i0 ? 1 : 2) : (i1 ? 3 : (i0 ? 4 : 5)));      // (two sons: the internal one, if any, comes first)
@@ -453,8 +469,10 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       hipLaunchKernelGGL(branch_total_kernel, dim3(n_out), dim3(256), 0, st, (const double *)e->d_bpartial.p, nrows, n_out, e->h_out);      // (pinned, device-visible: no copy)
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(st));      // the one host synchronisation of the call
+      if (int rc = eigen_fail_check(e)) return rc;
       for (int i = 0; i < n_t; i++) { lnL[i] = e->h_out[3 * i]; dlnL[i] = e->h_out[3 * i + 1]; ddlnL[i] = e->h_out[3 * i + 2]; }
       e->n_branch_eval++;
+      cache_guard.ok = true;
       return 0;
    }
    bc.coef_ok = false;      // (the P / dP / ddP form below recomputes partials without the coefficients)
@@ -518,7 +536,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       pr.pi = e->d_pi.p; pr.pint = mfma ? e->d_pint.p : e->d_rowmajor.p; pr.ptip = e->d_ptip.p;
       pr.fhK = e->d_fhK.p; pr.partials = e->d_bl_partials.p; pr.scalef = e->d_bl_scalef.p; pr.stack_scratch = e->d_stack.p;
       pr.stack_overflow_slots = overflow; pr.first_matmul = prog.first_matmul; pr.n_int = n_int;
-      pr.first_tip = -1; pr.tip_words = (long)tip_words(e);
+      pr.first_tip = -1; pr.tip_words = (long)tip_words(e); pr.part_groups = e->part_groups();
       launch_prune_full(e, prog.max_stack, n_blocks, pr, st);
       HIPCHK(hipGetLastError());
       for (int v = e->n_tips; v < nn; v++) { bc.up[v] = up[v]; bc.ok[v] = 1; }
@@ -593,8 +611,10 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    }
    HIPCHK(hipMemcpyAsync(e->h_out, e->d_bout.p, (size_t)n_t * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
    HIPCHK(hipStreamSynchronize(st));      // the one host synchronisation of the call
+   if (int rc = eigen_fail_check(e)) return rc;
    for (int i = 0; i < n_t; i++) { lnL[i] = e->h_out[3 * i]; dlnL[i] = e->h_out[3 * i + 1]; ddlnL[i] = e->h_out[3 * i + 2]; }
    e->n_branch_eval++;
+   cache_guard.ok = true;
    return 0;
 }
 

@@ -304,13 +304,19 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
    HIPCHK(upload(e->d_eq_scale, scale, (size_t)n_sets, e->stream));
    HIPCHK(upload(e->d_eq_ptr, ptr.data(), ptr.size(), e->stream));
    HIPCHK(e->d_eq_sweeps.ensure(n_sets));
+   if (!e->h_eig_fail) {
+      HIPCHK(hipHostMalloc((void **)&e->h_eig_fail, 64, hipHostMallocDefault));
+      *e->h_eig_fail = 0;
+   }
    if (!e->eigen_attr_set) {
       HIPCHK(hipFuncSetAttribute((const void *)eigen_qrev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EIG_LDS_BYTES));
       e->eigen_attr_set = true;
    }
    EigenQrevArgs a{};
    a.n = (int)n; a.Q = e->d_eq_q.p; a.pi = e->d_eq_pi.p; a.scale = e->d_eq_scale.p;
-   a.U = e->d_eq_ptr.p; a.V = e->d_eq_ptr.p + n_sets; a.Root = e->d_eq_ptr.p + 2 * (size_t)n_sets; a.sweeps = e->d_eq_sweeps.p;
+   a.U = e->d_eq_ptr.p; a.V = e->d_eq_ptr.p + n_sets; a.Root = e->d_eq_ptr.p + 2 * (size_t)n_sets; a.sweeps = e->d_eq_sweeps.p; a.fail = e->h_eig_fail;
+   static const int sweep_limit = getenv("PAML_AMD_EIGEN_SWEEP_LIMIT") ? std::max(1, atoi(getenv("PAML_AMD_EIGEN_SWEEP_LIMIT"))) : 40;
+   a.max_sweeps = sweep_limit;
    if (e->eigen_warm) { a.R0 = e->d_eq_ptr.p + 3 * (size_t)n_sets; a.Rout = e->d_eq_ptr.p + 4 * (size_t)n_sets; }
    hipLaunchKernelGGL(eigen_qrev_kernel, dim3(n_sets), dim3(EIG_NT), EIG_LDS_BYTES, e->stream, a);
    HIPCHK(hipGetLastError());
@@ -483,8 +489,8 @@ int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP
       HIPCHK(hipStreamSynchronize(e->stream));
       return 0;
    }
-   const int MW = e->mfma_waves;
-   const size_t groups = (size_t)e->n_tiles * MW;
+   const int MW = GATHER_WAVES;      // (the resident partials' one layout: groups in the order of the 64-pattern tile table)
+   const size_t groups = (size_t)e->part_groups();
    std::vector<double> raw(groups * 1024);
    const double *src = e->d_partials.p + ((size_t)iclass * n_int + (node - e->n_tips)) * groups * 1024;
    HIPCHK(hipMemcpyAsync(raw.data(), src, raw.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -492,7 +498,7 @@ int paml_amd_get_partials(paml_amd_engine *e, int node, int iclass, double *conP
    // native [group] x part_index(m, lane) -> [h][state]; lane = (state & 3) * 16 + (h & 15), m = state >> 2
    std::vector<int2> tiles;
    for (int g = 0; g < e->n_genes; g++)
-      for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += e->tile_patt) tiles.push_back(make_int2(g, h));
+      for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += MW * 16) tiles.push_back(make_int2(g, h));
    for (size_t t = 0; t < tiles.size(); t++) {
       const int hend = e->gene_off[tiles[t].x + 1];
       for (int w = 0; w < MW; w++)

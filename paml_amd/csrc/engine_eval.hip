@@ -22,6 +22,16 @@ int build_tiles(paml_amd_engine *e)
       for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += tf) tfull.push_back(make_int2(g, h));
    e->n_tiles_full = (int)tfull.size();
    HIPCHK(upload(e->d_tiles_full, tfull.data(), tfull.size(), e->stream));
+   if (e->kk == KK_MFMA64) {      // where a tile's resident partials live: the groups of the 64-pattern tiles it covers (consecutive within a gene)
+      std::vector<int> g0(tiles.size());
+      size_t k = 0;
+      int base = 0;                // 64-pattern tiles of the genes before
+      for (int g = 0; g < e->n_genes; g++) {
+         for (int h = e->gene_off[g]; h < e->gene_off[g + 1]; h += e->tile_patt) g0[k++] = (base + (h - e->gene_off[g]) / tf) * GATHER_WAVES;
+         base += (e->gene_off[g + 1] - e->gene_off[g] + tf - 1) / tf;
+      }
+      HIPCHK(upload(e->d_tile_group0, g0.data(), g0.size(), e->stream));
+   }
    if (e->kk == KK_MFMA64 && e->tile_patt >= 128 && e->d_z.p && e->d_weights.p) {   // code blocks of the specialised kernel
       e->zt_bytes = jit_zpieces(e->n_tips, e->tile_patt) * 2048;
       HIPCHK(e->d_ztiles.ensure((size_t)e->n_tiles * e->zt_bytes));
@@ -274,7 +284,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       // 4.63 ms with three classes — 40 spilled dwords and a third more LDS / DMA traffic per step), kept as a generator parameter
       int jw = 8;
       if (e->env.jit_waves == 12 && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, 192) && jit_zbuffers(e->n_tips, 192) == 2) jw = 12;
-      if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16)) {
+      if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16, e->jit_forced)) {
          const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "w" + std::to_string(jw) + (jit_rowtail(n) ? "r:" : ":") + jit_program_key(e->prog, e->n_tips);
          const bool background = e->prog.ops.size() > 120 &&      /* (roughly: more than 60 taxa, more than 3 s of compilation) */ !e->jit_forced && !e->env.jit_sync && !(e->jit.fn && e->jit.key == key);
          if (!background) {
@@ -317,9 +327,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          e->mfma_waves = want_waves;
          e->tile_patt = e->mfma_waves * 16;
          int r = build_tiles(e);
-         if (r) return r;
-         e->partials_valid = false;
-         if (clean) return fail(e, PAML_AMD_EINVAL, "eval_dirty: kernel layout changed; run a full evaluation first");
+         if (r) return r;      // (the resident partials have ONE layout whatever the tile size, PruneArgs::part_groups: they stay valid)
       }
    }
    if (e->kk != KK_MFMA64) {      // 4 / 5 / 20 states: the interpreter unrolled for this tree
@@ -361,7 +369,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    const int n_blocks = e->n_tiles * K;
    const int n_int = nn - e->n_tips;
    if (keep) {
-      size_t words = e->kk == KK_MFMA64 ? (size_t)K * n_int * e->n_tiles * e->mfma_waves * 1024
+      size_t words = e->kk == KK_MFMA64 ? (size_t)K * n_int * e->part_groups() * 1024
                                         : (size_t)K * n_int * e->n_patt * n;
       HIPCHK(e->d_partials.ensure(words));
       HIPCHK(e->d_scalef.ensure((size_t)K * std::max(1, e->tree.n_scale) * e->n_patt));
@@ -420,6 +428,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.fhK = e->d_fhK.p; pr.partials = e->d_partials.p; pr.scalef = e->d_scalef.p; pr.stack_scratch = e->d_stack.p;
    pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
    pr.first_tip = e->prog.first_tip;
+   pr.tile_group0 = e->d_tile_group0.p; pr.part_groups = e->part_groups();
    pr.stream = e->d_stream.p; pr.n_stream = (int)(e->prog.stream.size() / 2); pr.tip_words = (long)tip_words(e);
    // the reduction's geometry (the fused kernels form the partial sums themselves; the others leave them to reduce_stage1)
    const int chunk = e->chunk, nbg = e->nb_global;
@@ -685,6 +694,7 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
       HIPCHK(hipMemcpyAsync(fhK, e->d_fhK.p, (size_t)e->K * e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    if (int rc = join_comm(e)) return rc;
    HIPCHK(hipStreamSynchronize(e->stream));
+   if (int rc = eigen_fail_check(e)) return rc;
    *lnL = e->h_out[0];
    return 0;
 }
@@ -704,6 +714,7 @@ int paml_amd_eval_batch(paml_amd_engine *e, int n_batch, const double *branch, c
       HIPCHK(hipMemcpyAsync(lnf, e->d_lnf.p, (size_t)n_batch * e->n_patt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    if (int rc = join_comm(e)) return rc;
    HIPCHK(hipStreamSynchronize(e->stream));
+   if (int rc = eigen_fail_check(e)) return rc;
    memcpy(lnL, e->h_out, (size_t)n_batch * sizeof(double));
    return 0;
 }
@@ -807,6 +818,7 @@ int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *
    if (r) return r;
    if (int rc = join_comm(e)) return rc;
    HIPCHK(hipStreamSynchronize(e->stream));
+   if (int rc = eigen_fail_check(e)) return rc;
    *lnL = e->h_out[0];
    return 0;
 }

@@ -106,7 +106,8 @@ int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_p
    if (scale_node)
       for (int i = 0; i < n_nodes; i++)
          if (scale_node[i]) { t.scale_node[i] = 1; t.scale_slot[i] = t.n_scale++; }
-   const Program p = build_program(t, false, nullptr);
+   // (PAML_AMD_PREBUILD_KEEP=1: the kernel of a PAML_AMD_KEEP_PARTIALS engine, every internal node's partial stored)
+   const Program p = build_program(t, n_states > 20 && getenv("PAML_AMD_PREBUILD_KEEP") != nullptr, nullptr);
    std::string text;
    // the same choices launch_eval makes for an engine of these sizes
    if (n_states == 20 && jit_m20_supported(p, n_tips, 1)) text = jit_generate_m20(p, n_tips, n_codes);

@@ -299,6 +299,8 @@ struct paml_amd_engine {
    DevBuf<int> d_n_chara, d_gene_off, d_label, d_eigen_of, d_b_eigen_of;
    DevBuf<int2> d_tiles, d_tiles_full;   // tile table of the selected kernel / of the full (gather or valu) kernel
    int n_tiles_full = 0;
+   DevBuf<int> d_tile_group0;            // mfma64: per tile of the selected kernel, the resident-partial group of its first 16 patterns (PruneArgs::tile_group0)
+   int part_groups() const { return n_tiles_full * GATHER_WAVES; }      // 16-pattern groups per (class, node) of the resident partials: the 64-pattern tile table's
    DevBuf<double> d_pi_plain;
    DevBuf<double> d_weights, d_pi, d_freqK, d_rate, d_qfactor, d_branch, d_gene_rate;
    std::vector<int> gene_off;
@@ -361,6 +363,7 @@ struct paml_amd_engine {
    DevBuf<double> d_eq_q, d_eq_pi, d_eq_scale;
    DevBuf<double *> d_eq_ptr;
    DevBuf<int> d_eq_sweeps;
+   int *h_eig_fail = nullptr;      // pinned, device-visible: a decomposition that hit its sweep limit sets it (eigen_fail_check)
    bool eigen_attr_set = false;
    bool eigen_warm = false;      // paml_amd_set_eigen_warm_start
    long n_eigen_warm = 0;
@@ -405,6 +408,7 @@ struct paml_amd_engine {
          for (hipEvent_t ev : {st_part[i], st_done[i], st_w0[i], st_w1[i]})
             if (ev) (void)hipEventDestroy(ev);
       if (h_out) (void)hipHostFree(h_out);
+      if (h_eig_fail) (void)hipHostFree(h_eig_fail);
       for (int ln = 0; ln < MAXL && d_prof && env.prof_tiles && prof_words; ln++) {      // the last launch's workgroup timeline (of each pruning stream: <dump>, <dump>.1 ..)
          std::vector<unsigned long long> hp(prof_words);
          if (hipMemcpy(hp.data(), d_prof + (size_t)ln * prof_words, prof_words * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -427,6 +431,7 @@ struct paml_amd_engine {
       for (auto b : b2) b->release();
       d_tiles.release();
       d_tiles_full.release();
+      d_tile_group0.release();
       d_zpm.release();
       d_red_counter.release();
       d_bl_partials.release(); d_bl_scalef.release(); d_bl_frag.release(); d_code_mask.release();
@@ -566,6 +571,16 @@ inline int ensure_hout(paml_amd_engine *e, size_t n)
    HIPCHK(hipHostMalloc((void **)&e->h_out, std::max<size_t>(n, 64) * sizeof(double), hipHostMallocDefault));
    e->h_out_cap = std::max<size_t>(n, 64);
    return 0;
+}
+
+// After the host synchronisation of an evaluation: did a device eigen-decomposition queued in front of it reach its sweep limit?
+// The likelihood just formed then came from unconverged eigenvectors: an error instead of a number.
+inline int eigen_fail_check(paml_amd_engine *e)
+{
+   if (!e->h_eig_fail || !*(volatile int *)e->h_eig_fail) return 0;
+   *(volatile int *)e->h_eig_fail = 0;
+   return fail(e, PAML_AMD_ENOCONV, "a device eigen-decomposition (set_eigen_qrev_batch) reached its sweep limit without converging: "
+                                    "decompose on the host and pass U, V, Root with paml_amd_set_eigen_uvroot (paml_amd_eigen_counters names the sets of the last batch)");
 }
 
 }  // namespace paml_amd

@@ -51,13 +51,15 @@ inline int jit_zpieces(int n_tips, int tp = 128) { return ((n_tips + 1) * tp + 2
 inline bool jit_lds_fits(int n_tips, int zb, int tp = 128) { return 4 * 32768 + zb * jit_zpieces(n_tips, tp) * 2048 + 4 * 64 * 8 + (4 * 64 + 32) * 8 + 1024 <= 160 * 1024; }
 inline int jit_zbuffers(int n_tips, int tp = 128) { return jit_lds_fits(n_tips, 2, tp) ? 2 : 1; }
 
-inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6, int tp = 128)
+// (STORE — every internal node's partial kept, PAML_AMD_KEEP_PARTIALS — is part of the tree's one program.  LOAD programs differ with the
+//  set of clean nodes: a kernel per set would be compiled again and again, so they go to the interpreter unless `allow_load`.)
+inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6, int tp = 128, bool allow_load = false)
 {
    if (n_codes > 64 || p.ops.size() > 1000 || n_pi > 4) return false;
    if (!jit_lds_fits(n_tips, jit_zbuffers(n_tips, tp), tp)) return false;
    if (p.stream.size() / 2 < 4) return false;                       // trees this small go to the interpreter
    for (const Op &o : p.ops)
-      if (o.code == OP_STORE || o.code == OP_LOAD) return false;   // keep-partials layouts stay with the interpreter
+      if (o.code == OP_LOAD && !allow_load) return false;
    (void)max_arrays;      // stack slots beyond JIT_REG_SLOTS register arrays go to global scratch
    return true;
 }
@@ -240,8 +242,13 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    consumed = peel ? 2 : 0;
 
    if (proft) s << "   int ptc = 0; if (a.prof && tid == 0) { a.prof[(long)blockIdx.x * a.prof_stride] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 2] = __builtin_amdgcn_s_memtime(); }\n";
+   bool resident = false;      // the program stores or loads resident partials (keep-partials mode)
+   for (const Op &o : p.ops) resident = resident || o.code == OP_STORE || o.code == OP_LOAD;
    s << "   int ptile = 1;\n   for (;; ptile = 0) {\n";
-   s << "   JIT2_ADVANCE(" << nblk << ")\n   work += gridDim.x;\n   JIT2_NEXT_SET()\n";
+   s << "   JIT2_ADVANCE(" << nblk << ")\n";
+   // (n_tile is still this tile's number here; the groups of a tile's waves that start past its gene's end belong to nobody: not stored)
+   if (resident) s << "   const int tg0 = as_const(a.tile_group0)[n_tile];\n   const bool wave_in = h0 + wave * 16 < hend;\n";
+   s << "   work += gridDim.x;\n   JIT2_NEXT_SET()\n";
    z_pending = !zsingle;
 
    // register arrays: a free list; `cur` names the array holding the partial under construction
@@ -355,6 +362,13 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       case OP_SCALE:
          s << "   { const double fac = jit_scale(" << name(cur) << ", q, n); lnscale += fac;\n"
            << "     if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + " << o.b << ") * a.n_patt + h] = fac; }\n";
+         break;
+      case OP_STORE:
+         s << "   if (wave_in) jit_store(" << name(cur) << ", JIT_PART_PTR(" << o.a << "), lane);\n";
+         break;
+      case OP_LOAD:
+         if (cur < 0) cur = alloc();
+         s << "   jit_load(" << name(cur) << ", JIT_PART_PTR(" << o.a << "), lane);\n";
          break;
       case OP_ROOT:
          s << "   jit_root_lds(a, " << name(cur) << ", lnscale, sPi + (a.n_pi > 1 ? gene : 0) * 64, " << code(n_tips)

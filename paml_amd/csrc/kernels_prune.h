@@ -91,13 +91,13 @@ namespace paml_amd {
       lnscale += fac;                                                                                           \
       if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + op.b) * a.n_patt + h] = fac;          \
    } break;                                                                                                     \
-   case OP_STORE: {  /* native layout [class][node][16-pattern group] x part_index(m, lane) */                  \
-      double *dst = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) +    \
+   case OP_STORE: {  /* native layout [class][node][16-pattern group] x part_index(m, lane) (PruneArgs::part_groups) */ \
+      double *dst = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * (long)a.part_groups +          \
                                   ((long)tile * WAVES + wave)) * 1024;                                          \
       part_store(dst, lane, cur);                                                                               \
    } break;                                                                                                     \
    case OP_LOAD: {                                                                                              \
-      const double *src = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * ((long)a.n_tiles * WAVES) + \
+      const double *src = a.partials + (((long)iclass * a.n_int + (op.a - a.n_tips)) * (long)a.part_groups +    \
                                         ((long)tile * WAVES + wave)) * 1024;                                    \
       part_load(src, lane, cur);                                                                                \
    } break;

@@ -141,6 +141,7 @@ double pamlh_optd(const pamlh *p, const char *key, double dflt);
 int pamlh_read_seqs(pamlh *p);
 int pamlh_read_tree(pamlh *p);
 int pamlh_fail(pamlh *p, const char *fmt, ...);
+int pamlh_force_host_eigen(void);
 int pamlh_engine_ready(pamlh *p);
 int pamlh_engine_model(pamlh *p);      /* pi, eigen systems and class tables of the current model state -> engine */
 int pamlh_model_feasible(const pamlh *p);

@@ -872,11 +872,19 @@ int pamlh_read_inx(const pamlh *p, double *x, int cap)
  * and the upload (pamlh_upload_eigen_sets) hands all waiting matrices to paml_amd_set_eigen_qrev_batch in one call; U, V, Root are
  * formed on the host only when something asks for them (pamlh_eig_host: the accessor of the oracle-based tests, tables).
  * 4 states (and PAMLH_HOST_EIGEN=1, the A/B switch): on the host at once, as before. */
+static int host_eigen_runtime;      /* set when a device decomposition did not converge (PAML_AMD_ENOCONV): from then on the host decomposes */
 static int host_eigen_forced(void)
 {
    static int v = -1;
    if (v < 0) v = getenv("PAMLH_HOST_EIGEN") != NULL;
-   return v;
+   return v || host_eigen_runtime;
+}
+int pamlh_force_host_eigen(void)      /* returns 0 when the host was decomposing already (nothing left to fall back to) */
+{
+   if (host_eigen_forced()) return 0;
+   fprintf(stderr, "pamlh: a device eigen-decomposition did not converge: the rate matrices are decomposed on the host from here on\n");
+   host_eigen_runtime = 1;
+   return 1;
 }
 
 void pamlh_eig_release(pamlh_eig *e)
@@ -1828,6 +1836,10 @@ int pamlh_eval_gpu(pamlh *p, double *lnL, double *lnf)
       rc = paml_amd_eval_adg(p->eng, p->branch, NULL, p->MK, p->pose, p->n_pose, lnL);
    }
    else rc = paml_amd_eval(p->eng, p->branch, p->ngene > 1 ? p->rgene : NULL, lnL, lnf, NULL);
+   if (rc == PAML_AMD_ENOCONV && pamlh_force_host_eigen()) {      /* the matrices are still here (pamlh_eig::Q): host decomposition, once more */
+      for (i = 0; i < p->n_eigen; i++) pamlh_eig_host(&p->eig[i], p->n);
+      return pamlh_eval_gpu(p, lnL, lnf);
+   }
    if (rc) return pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
    return 0;
 }

@@ -18,14 +18,22 @@
 /* lnL at nb parameter vectors xs[nb][np] in one launch.  Vectors whose substitution-model part (x[ntime..np)) is equal
  * share one model set-up (eigen decompositions are the host's expensive part); a vector the model rejects
  * (e.g. class proportions summing above 1) gets lnL = -1e300. */
-static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, double *lnf);
+static int eval_batch_lnf_once(pamlh *p, int nb, const double *xs, double *lnL, double *lnf);
+/* (a device eigen-decomposition that did not converge — PAML_AMD_ENOCONV from the evaluation behind it — sends the whole batch round again
+ *  with the rate matrices decomposed on the host) */
+static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, double *lnf)
+{
+   int rc = eval_batch_lnf_once(p, nb, xs, lnL, lnf);
+   if (rc == PAML_AMD_ENOCONV && pamlh_force_host_eigen()) rc = eval_batch_lnf_once(p, nb, xs, lnL, lnf);
+   return rc;
+}
 
 int pamlh_eval_batch_gpu(pamlh *p, int nb, const double *xs, double *lnL) { return eval_batch_lnf(p, nb, xs, lnL, NULL); }
 
 /* ... with the per-pattern log f_h of every vector, lnf[nb][npatt], when lnf is not NULL.
  * The model set-ups of the distinct substitution-parameter vectors (eigen decompositions: the host's expensive part, one per
  * site class) are independent of each other and run on all host cores, each on its own copy of the model state. */
-static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, double *lnf)
+static int eval_batch_lnf_once(pamlh *p, int nb, const double *xs, double *lnL, double *lnf)
 {
    const int np = p->np, nt = p->ntime, nm = np - nt, nn = p->nnode;
    int *cand_of = (int *)malloc(nb * sizeof(int)), *cand_elem = (int *)malloc(nb * sizeof(int)), *cand_rep = (int *)malloc(nb * sizeof(int));
@@ -122,8 +130,11 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
          grp[b] = gsel;
       }
       if (ngrp == 1) {
-         if ((rc = paml_amd_set_pi(p->eng, n_pi, gpi[0])) || (rc = paml_amd_eval_batch(p->eng, nb, br, gr, eo, use_qf ? qf : NULL, fk, rt, lnL, lnf)))
+         if ((rc = paml_amd_set_pi(p->eng, n_pi, gpi[0])) || (rc = paml_amd_eval_batch(p->eng, nb, br, gr, eo, use_qf ? qf : NULL, fk, rt, lnL, lnf))) {
+            const int code = rc;
             rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+            if (code == PAML_AMD_ENOCONV) rc = code;
+         }
       }
       else {
          double *sbr = (double *)malloc((size_t)nb * nn * sizeof(double)), *sfk = (double *)malloc((size_t)nb * K * sizeof(double)), *srt = (double *)malloc((size_t)nb * RK * sizeof(double));
@@ -143,7 +154,9 @@ static int eval_batch_lnf(pamlh *p, int nb, const double *xs, double *lnL, doubl
                idx[m++] = b;
             }
             if ((rc = paml_amd_set_pi(p->eng, n_pi, gpi[gsel])) || (rc = paml_amd_eval_batch(p->eng, m, sbr, sgr, seo, use_qf ? sqf : NULL, sfk, srt, sl, slf))) {
+               const int code = rc;
                rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng));
+               if (code == PAML_AMD_ENOCONV) rc = code;
                break;
             }
             for (i = 0; i < m; i++) {

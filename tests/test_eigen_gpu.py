@@ -174,3 +174,59 @@ def test_warm_started_decompositions_along_an_optimisers_path():
     eng.set_eigen_warm_start(0)
     Qs, mrs, sw = send(pi0)
     assert eng.set_eigen_warm_start() == n_warm + 3 and (sw >= cold.min() - 2).all()
+
+
+NOCONV_SCRIPT = r"""
+import json, os, sys
+import torch  # noqa: F401
+import numpy as np
+sys.path.insert(0, %(repo)r)
+sys.path.insert(0, os.path.join(%(repo)r, "tests"))
+import helpers
+from paml_amd import engine, hostlib, models, synth
+pb = synth.codon_m0_problem(n_tips=6, n_patt=300)
+eng = engine.engine_for(pb)
+ok = eng.eval(pb.tree.branch)["lnL"]
+Q, mr = models.codon_q(2.0, 0.4, pb.pi)
+eng.set_eigen_qrev_batch([0], np.array([Q]), np.array([pb.pi]), np.array([mr]))      # one sweep allowed: not converged
+try:
+    eng.eval(pb.tree.branch)
+    code = None
+except engine.EngineError as ex:
+    code = str(ex)
+sweeps = eng.eigen_counters()["sweeps"].tolist()
+again = None
+try:      # the flag was consumed: with a host decomposition in the set's place the engine evaluates again
+    eng.set_eigen(0, pb.eigen[0])
+    again = eng.eval(pb.tree.branch)["lnL"]
+except engine.EngineError as ex:
+    again = str(ex)
+# the C host on the same engine library: HIV M2a at the golden's parameters — device decomposition fails, host takes over, same lnL
+g = helpers.load_golden("hiv_m2a")
+a = hostlib.Analysis(os.path.join(helpers.GOLDEN, "ctl", "hiv_ns2.ctl"), "codeml")
+l1 = a.eval_gpu(np.array(g["x"]), want_lnf=False)[0]
+xs = np.stack([np.array(g["x"]), np.array(g["x"]) * 1.01])
+lb = a.eval_batch_gpu(xs)
+print(json.dumps({"first": ok, "code": code, "sweeps": sweeps, "again": again, "host_lnL": l1, "golden": g["lnL"], "batch": lb.tolist()}))
+"""
+
+
+def test_a_device_decomposition_that_does_not_converge_is_reported_and_the_host_takes_over(tmp_path):
+    """The sweep limit of the device Jacobi (40) lowered to 1 through PAML_AMD_EIGEN_SWEEP_LIMIT, in a process of its own: the evaluation behind
+    an unconverged decomposition returns PAML_AMD_ENOCONV (-5) instead of a likelihood, paml_amd_eigen_counters names the set (-1), and the C
+    host (pamlh_eval_gpu, the batched evaluation) falls back to its own eigen-decomposition and returns the reference's lnL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", NOCONV_SCRIPT % {"repo": repo}], env=dict(os.environ, PAML_AMD_EIGEN_SWEEP_LIMIT="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert out["code"] is not None and "(code -5)" in out["code"] and "sweep limit" in out["code"]
+    assert out["sweeps"] == [-1]
+    assert isinstance(out["again"], float) and abs(out["again"] - out["first"]) <= 1e-9 * abs(out["first"])
+    assert abs(out["host_lnL"] - out["golden"]) <= 2e-6
+    assert abs(out["batch"][0] - out["golden"]) <= 2e-6 and out["batch"][1] < out["batch"][0]
+    assert b"decomposed on the host from here on" in r.stderr

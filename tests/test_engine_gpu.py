@@ -155,6 +155,76 @@ def test_keep_partials_and_dirty_eval(n):
     assert abs(lnl_dirty - ref2["lnL"]) <= 1e-10 * abs(ref2["lnL"])
 
 
+@pytest.mark.parametrize("n_genes,scale_every", [(1, None), (3, 4)])
+def test_keep_partials_on_the_per_tree_kernel(n_genes, scale_every):
+    """PAML_AMD_KEEP_PARTIALS on the per-tree MFMA kernel (jit.h: OP_STORE as coalesced 1 KB wave stores; OP_LOAD when the kernel is asked
+    for): every internal node's partial (com.conP, codeml.c:3531-3582) against the oracle, read back through the ONE resident layout the
+    128-pattern per-tree kernel and the 64-pattern interpreter share — then a dirty evaluation by the interpreter (LOAD of what the per-tree
+    kernel stored), one by a per-tree kernel with LOADs, and a full one by the interpreter, all the same bits per pattern."""
+    pb = helpers.random_problem(61, 12, 1500, K=2, seed=77, scale_every=scale_every, n_genes=n_genes)      # (genes: 128-pattern tiles that start off the 64-pattern grid)
+    ref = oracle.evaluate(pb, want_partials=True)
+    eng, out, _ = check(pb, flags=KEEP_PARTIALS | JIT)
+    assert eng.kernel_name == "mfma64_jit"
+    t = pb.tree
+    got = {(node, ic): eng.get_partials(node, ic) for node in range(t.n_tips, t.n_nodes) for ic in range(pb.K)}
+    for (node, ic), g in got.items():
+        assert np.allclose(g, ref["partials"][ic, node - t.n_tips], rtol=1e-11, atol=1e-300), (node, ic)
+    father = t.father()
+    br = t.branch.copy()
+    br[2] *= 1.3
+    clean = np.ones(t.n_nodes, dtype=np.uint8)
+    node = 2
+    while node != -1:
+        clean[node] = 0
+        node = father[node]
+    pb2 = helpers.random_problem(61, 12, 1500, K=2, seed=77, scale_every=scale_every, n_genes=n_genes)
+    pb2.tree.branch[:] = br
+    ref2 = oracle.evaluate(pb2, want_partials=True)
+    lnl_jit_load = eng.eval_dirty(br, clean, pb.gene_rate)                      # forced per-tree kernel: LOADs inside it
+    assert eng.kernel_name == "mfma64_jit" and abs(lnl_jit_load - ref2["lnL"]) <= 1e-10 * abs(ref2["lnL"])
+    for node in range(t.n_tips, t.n_nodes):
+        assert np.allclose(eng.get_partials(node, 1), ref2["partials"][1, node - t.n_tips], rtol=1e-11, atol=1e-300), node
+    eng.close()
+    eng3 = engine_for(pb, flags=KEEP_PARTIALS)      # small data, no per-tree kernel: the interpreter stores
+    eng3.eval(t.branch, pb.gene_rate)
+    assert eng3.kernel_name != "mfma64_jit"
+    for (node, ic), g in got.items():
+        assert np.array_equal(eng3.get_partials(node, ic), g), (node, ic)      # same arithmetic order per pattern: same bits
+    l3 = eng3.eval_dirty(br, clean, pb.gene_rate)
+    assert abs(l3 - ref2["lnL"]) <= 1e-10 * abs(ref2["lnL"])
+    eng3.close()
+
+
+def test_dirty_evaluation_by_the_interpreter_after_a_full_one_by_the_per_tree_kernel():
+    """A data set large enough for the per-tree kernel to be chosen by size (not asked for): the full keep-partials evaluation runs on it
+    (128-pattern tiles), eval_dirty — a program with LOADs, different for every set of clean nodes — on the interpreter (64-pattern
+    tiles), reading what the per-tree kernel stored: one resident layout, nothing invalidated by the change of kernel."""
+    pb = helpers.random_problem(61, 10, 33000, K=2, seed=78)
+    t = pb.tree
+    eng = engine_for(pb, flags=KEEP_PARTIALS)
+    out = eng.eval(t.branch, pb.gene_rate)
+    assert eng.kernel_name == "mfma64_jit"
+    ref = oracle.evaluate(pb, want_partials=True)
+    assert abs(out["lnL"] - ref["lnL"]) <= 1e-10 * abs(ref["lnL"])
+    for node in (t.n_tips, t.n_nodes - 1):
+        assert np.allclose(eng.get_partials(node, 1), ref["partials"][1, node - t.n_tips], rtol=1e-11, atol=1e-300), node
+    father = t.father()
+    br = t.branch.copy()
+    br[1] *= 0.6
+    clean = np.ones(t.n_nodes, dtype=np.uint8)
+    node = 1
+    while node != -1:
+        clean[node] = 0
+        node = father[node]
+    lnl_dirty = eng.eval_dirty(br, clean, pb.gene_rate)
+    assert eng.kernel_name in ("mfma64_gather", "mfma64_coop")
+    pb.tree.branch[:] = br
+    ref2 = oracle.evaluate(pb)
+    assert abs(lnl_dirty - ref2["lnL"]) <= 1e-10 * abs(ref2["lnL"])
+    # ... and back: a full evaluation (per-tree kernel again), the same value as a fresh engine's
+    assert eng.eval(br, pb.gene_rate)["lnL"] == engine_for(pb).eval(br, pb.gene_rate)["lnL"] and eng.kernel_name == "mfma64_jit"
+
+
 def test_young_ancestor_root_is_tip():
     """Rooted tree whose root is an observed sequence (codeml.c:3535-3543)."""
     from paml_amd.problem import Tree

@@ -261,6 +261,70 @@ def test_patched_baseml_with_method_1_matches_the_unmodified_program(tmp_path):
     assert np.max(np.abs(lnf - clnf)) < 1e-3
 
 
+def _num_tokens(text):
+    out = []
+    for tok in text.split():
+        try:
+            out.append(float(tok.strip("(),")))
+        except ValueError:
+            out.append(tok)
+    return out
+
+
+@pytest.mark.parametrize("prog,name,extra", [("codeml", "hiv_m0", ""), ("codeml", "stewart_lg_g4", ""), ("codeml", "hiv_m2a", "method = 1\n"), ("baseml", "brown_hky85", "")])
+def test_rate_ancestor_through_the_patched_reference_reads_host_partials(prog, name, extra, tmp_path):
+    """RateAncestor = 1: AncestralSeqs (treesub.c:7071) -> ProbSitePattern / PostProbNode -> updateconP read the HOST's nodes[].conP, which the
+    engine behind com.plfun never fills.  The binding steps aside for the reconstruction (gpu_suspend: one evaluation by the reference's own
+    function, then updateconP is the reference's again): the `rst` file of the patched program equals the unmodified program's, number by
+    number, with one site class, with gamma rates, and with method = 1 (conditional probabilities kept per site class)."""
+    exe, cpu = (REF_GPU, REF_CPU) if prog == "codeml" else (BASEML_GPU, BASEML_CPU)
+    if not (os.path.isfile(exe) and os.access(exe, os.X_OK)):
+        pytest.skip("oracle/_ref/%s_gpu is not built (make -C oracle, needs /root/reference)" % prog)
+    g, lnl, lnf, out = single_evaluation(prog, name, tmp_path / "gpu", exe, extra_ctl="RateAncestor = 1\n" + extra)
+    assert "sum!=1" not in out and abs(lnl - g["lnL"]) <= 2e-6
+    g2, lnl2, lnf2, out2 = single_evaluation(prog, name, tmp_path / "cpu", cpu, extra_ctl="RateAncestor = 1\n" + extra)
+    a, b = _num_tokens((tmp_path / "gpu" / "rst").read_text()), _num_tokens((tmp_path / "cpu" / "rst").read_text())
+    assert len(a) == len(b) > 500
+    for x, y in zip(a, b):
+        if isinstance(x, float) and isinstance(y, float):
+            assert abs(x - y) <= 2e-4 + 1e-6 * abs(y), (x, y)
+        else:
+            assert x == y, (x, y)
+
+
+@pytest.mark.parametrize("name,extra", [("hiv_m0", ""), ("hiv_m2a", ""), ("hiv_m8", ""), ("lyso_bsa", ""), ("ecp_cmc", ""), ("lysin_mg2", ""), ("stewart_lg_g4", ""),
+                                        ("hiv_m2a", "method = 1\n")])
+def test_batched_gradient_equals_the_serial_one(name, extra, tmp_path):
+    """integration/tools_gradient_seam.patch: gradientB (tools.c:6561) hands its np .. 2 np perturbed vectors to the binding, which evaluates them
+    in ONE paml_amd_eval_batch (one paml_amd_set_eigen_qrev_batch for the rate matrices the perturbed kappa / omega / proportions change).
+    PAML_AMD_GRADIENT_CHECK=1 makes the binding evaluate the same vectors one by one afterwards and print the largest difference: the
+    batched values are those of the serial calls (same kernels, same eigen systems) to 1e-9, for every gradient of an optimisation."""
+    need_binaries()
+    ctl = open(os.path.join(helpers.GOLDEN, "ctl", CTL_OF.get(name, name) + ".ctl")).read()
+    ctl = ctl.replace("../data/", DATA + "/").replace("../ctl/", os.path.join(helpers.GOLDEN, "ctl") + "/")
+    ctl += "\noutfile = mlc\nnoisy = 3\ngetSE = 0\nRateAncestor = 0\n" + extra
+    d = tmp_path / "gpu"
+    d.mkdir()
+    (d / "codeml.ctl").write_text(ctl)
+    r = subprocess.run([REF_GPU, "codeml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=1500,
+                       env=dict(os.environ, PAML_AMD_GRADIENT_CHECK="1"))
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    checks = [(int(m.group(1)), int(m.group(2)), float(m.group(3))) for m in re.finditer(r"gradient check: (\d+) vectors, (\d+) model parts, max \|batched - serial\| = ([0-9.e+-]+)", out)]
+    assert len(checks) >= 3, out[-2000:]                         # every gradient of the run went through the batch
+    assert max(c[2] for c in checks) <= 1e-9, max(checks, key=lambda c: c[2])
+    assert max(c[1] for c in checks) >= 2                         # ... with perturbed substitution parameters among the vectors
+    g = helpers.load_golden(name)
+    lnl = [float(m.group(1)) for m in re.finditer(r"lnL\(ntime:\s*\d+\s+np:\s*\d+\):\s+(-?\d+\.\d+)", (d / "mlc").read_text())]
+    assert len(lnl) == 1 and abs(lnl[0] - g.get("mle_lnL", g["lnL"])) <= 5e-5, (lnl, g.get("mle_lnL", g["lnL"]))
+
+
+def test_batched_gradient_can_be_switched_off(tmp_path):
+    need_binaries()
+    lnl, lnf, nfun, dt, out = run(REF_GPU, HIV_CTL.replace("NSsites = 0 2", "NSsites = 0"), tmp_path / "gpu", env=dict(os.environ, PAML_AMD_NO_BATCH_GRADIENT="1", PAML_AMD_GRADIENT_CHECK="1"))
+    assert abs(lnl[0] - (-1137.688190)) <= TOL and "gradient check" not in out
+
+
 def test_hiv_site_models_through_the_patched_reference_are_fast(tmp_path):
     """HIV NSsites = 0 2 through codeml_gpu: with the rate matrices decomposed on the device only when they changed, and the class table
     / frequencies / per-pattern values moved only when needed, the reference's own ming2 spends its time in its own code."""
@@ -268,4 +332,4 @@ def test_hiv_site_models_through_the_patched_reference_are_fast(tmp_path):
     lnl, lnf, nfun, dt, out = run(REF_GPU, HIV_CTL, tmp_path / "gpu")
     assert abs(lnl[0] - (-1137.688190)) <= TOL and abs(lnl[1] - (-1106.445004)) <= TOL, lnl
     print("\nHIV NSsites 0 2 through codeml_gpu: %.2f s (%s lfun)" % (dt, nfun))
-    assert dt < 2.0          # (1.2 s typical; the starting values are the reference's random ones)
+    assert dt < 1.5          # (gradients batched through integration/tools_gradient_seam.patch; the starting values are the reference's random ones)
