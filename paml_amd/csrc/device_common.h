@@ -82,6 +82,8 @@ struct PruneArgs {
    // tiles finds the group of its tile's first 16 patterns in tile_group0[tile] (a 128-pattern tile is two consecutive 64-pattern tiles of its gene)
    const int *tile_group0;
    int part_groups;
+   double *part_dump;           // 8 x 1024 doubles nobody reads: where the per-tree kernel's waves whose 16 patterns lie past their gene's end
+                                // put their STOREs (every wave must issue the same vector-memory operations: the operand ring's waits count them)
 };
 
 __device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)
@@ -563,11 +565,13 @@ __device__ __forceinline__ void jit_mul_mem(v4d (&y)[4], const double *sp)   // 
 
 // STORE / LOAD of a resident partial (keep-partials mode; layout: part_load / part_store above — element m of the partial is y[m >> 2][m & 3],
 // a lane's elements 2 i, 2 i + 1 one 16-byte access, a wave instruction 1 KB).  Compiler-visible memory operations, like the spills.
+// (streamed past the caches: 7 GB per evaluation at the benchmark's size would otherwise push the P(t) blocks and tip tables, re-read by
+//  every tile, out of L2)
 __device__ __forceinline__ void jit_store(const v4d (&y)[4], double *p, int lane)
 {
    part2_t *p2 = (part2_t *)p + lane;
 #pragma unroll
-   for (int i = 0; i < 8; i++) p2[i * 64] = (part2_t){y[i >> 1][(2 * i) & 3], y[i >> 1][(2 * i + 1) & 3]};
+   for (int i = 0; i < 8; i++) __builtin_nontemporal_store((part2_t){y[i >> 1][(2 * i) & 3], y[i >> 1][(2 * i + 1) & 3]}, p2 + i * 64);
 }
 __device__ __forceinline__ void jit_load(v4d (&y)[4], const double *p, int lane)
 {
@@ -575,7 +579,9 @@ __device__ __forceinline__ void jit_load(v4d (&y)[4], const double *p, int lane)
 #pragma unroll
    for (int i = 0; i < 8; i++) { const part2_t v = p2[i * 64]; y[i >> 1][(2 * i) & 3] = v.x; y[i >> 1][(2 * i + 1) & 3] = v.y; }
 }
+#define JIT_STORE_PIECE(Y, PTR, I) __builtin_nontemporal_store((part2_t){Y[(I) >> 1][(2 * (I)) & 3], Y[(I) >> 1][(2 * (I) + 1) & 3]}, (part2_t *)(PTR) + lane + (I)*64)
 #define JIT_PART_PTR(NODE) (a.partials + (((long)iclass * a.n_int + ((NODE) - a.n_tips)) * a.part_groups + tg0 + wave) * 1024)
+#define JIT_PART_DST(NODE) (wave_in ? JIT_PART_PTR(NODE) : a.part_dump + wave * 1024)
 
 __device__ __forceinline__ void jit_mul(v4d (&y)[4], const v4d (&s)[4])   // y = s * y  (codeml.c:3573)
 {
@@ -816,6 +822,196 @@ __device__ __forceinline__ void red_block_finish(double acc, double *partial_row
       }
    }
 }
+
+// ---- the cooperative per-tree kernel for small data sets (jit.h: jit_generate_coop) ---------------------------------------------
+// prune_mfma64_coop (kernels_prune.h) unrolled for one tree: four waves share a 16-pattern group, wave w owns row block w of every
+// product.  What the interpreter form waits for at every step — the op fetch, the hand-over of the staged P(t) block, the tip rows
+// requested one step ahead — is resolved when the kernel is generated: every operand (a wave's quarter of a branch's P(t) in A-operand
+// order: eight 16-byte words per lane; a wave's quarter of a tip's row: two) is requested straight into registers as far ahead as the
+// register budget allows — for trees of ~15 taxa all of them at the kernel's start, one round trip to L2 for the whole walk — and a
+// product step is: publish the quarter of x, one barrier, eight LDS reads, sixteen dependent MFMAs.  Same accumulation order per row
+// block, same root sum, same reduction order as the interpreter kernels + reduce_stage1 / reduce_stage2: the same bits.
+// The reduction is inside: the workgroup that finishes last for its batch element (tickets, as red_block_finish) forms mixture + log +
+// the fixed-order chunk sums and the total — ONE launch after P(t) per evaluation.
+__device__ __forceinline__ double coopj_ld(const double *p)      // a value another workgroup of this launch wrote (agent scope: past the L2 of this XCD)
+{
+   return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void coopj_st(double *p, double v)
+{
+   __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// pattern_lnf of kernels_reduce.h on class likelihoods other workgroups of this launch have just written
+__device__ __forceinline__ double coopj_pattern_lnf(const PruneArgs &a, const double *fhK, const double *freqK, int h)
+{
+   if (a.mode == PAML_AMD_MODE_LFUN) return coopj_ld(fhK + h);
+   double fh;
+   if (a.n_scale) {      // log-sum-exp around the first maximum (treesub.c:7640-7649)
+      int it = 0;
+      double t = coopj_ld(fhK + h);
+      for (int ir = 1; ir < a.Km; ir++) {
+         const double v = coopj_ld(fhK + (long)ir * a.n_patt + h);
+         if (v > t) { t = v; it = ir; }
+      }
+      (void)it;
+      fh = 0;
+      for (int ir = 0; ir < a.Km; ir++) fh += freqK[ir] * exp(coopj_ld(fhK + (long)ir * a.n_patt + h) - t);
+      return t + log(fh);
+   }
+   fh = 0;
+   for (int ir = 0; ir < a.Km; ir++) fh += freqK[ir] * coopj_ld(fhK + (long)ir * a.n_patt + h);
+   if (fh <= 0) fh = 1e-300;
+   return log(fh);
+}
+// wg: this workgroup's number among the n_wg of its batch element `bat`.  Every workgroup of the launch comes here (also those whose
+// 16 patterns lie past the end of their gene), after its class likelihoods have been stored with coopj_st.
+__device__ __forceinline__ void coopj_finish(const PruneArgs &a, int bat, int wg, int n_wg)
+{
+   __shared__ double cj_sw[4];
+   __shared__ int cj_last;
+   __shared__ double cj_part[1024];
+   const int tid = threadIdx.x;
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's class likelihoods are out (written through) ...
+   __syncthreads();                                       // ... and so are the workgroup's
+   int *counter = a.red_counter + bat * RED_TICKET_WORDS;
+   if (tid == 0) {      // two levels of tickets (red_block_finish): groups of RED_TICKET_GROUP workgroups, then the groups
+      const int g = wg / RED_TICKET_GROUP, ng = (n_wg + RED_TICKET_GROUP - 1) / RED_TICKET_GROUP, gsize = min(RED_TICKET_GROUP, n_wg - g * RED_TICKET_GROUP);
+      int last = 0;
+      if (ng > RED_TICKET_WORDS - 1) last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_wg - 1;
+      else if (__hip_atomic_fetch_add(counter + 1 + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+         __hip_atomic_store(counter + 1 + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1;
+      }
+      cj_last = last;
+   }
+   __syncthreads();
+   if (!cj_last) return;
+   if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+   // reduce_stage1's loop over the chunks of this element (kernels_reduce.h), then reduce_stage2's total
+   const double *fhK = a.fhK + (long)bat * a.Km * a.n_patt, *freqK = a.freqK + bat * a.freqK_bs;
+   const int nb = a.nb_local;
+   for (int c = 0; c < nb; c++) {
+      const int lo = c * a.chunk, hi = min(a.n_patt, lo + a.chunk);
+      double acc = 0;
+      for (int h = lo + tid; h < hi; h += 256) {
+         double v = 0;
+         if (a.weights[h] > 0) {
+            v = coopj_pattern_lnf(a, fhK, freqK, h);
+            acc += v * a.weights[h];
+         }
+         if (a.lnf) a.lnf[(long)bat * a.n_patt + h] = v;
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+      if ((tid & 63) == 0) cj_sw[tid >> 6] = acc;
+      __syncthreads();
+      if (tid == 0) {
+         const double part = (cj_sw[0] + cj_sw[1]) + (cj_sw[2] + cj_sw[3]);
+         if (c < 1024) cj_part[c] = part;
+         a.red_partial[(long)bat * a.nb_stride + a.first_chunk + c] = part;
+      }
+      __syncthreads();
+   }
+   if (a.nb_stride == 1) {      // a single chunk: its sum is the total
+      if (tid == 0) a.red_out[bat] = cj_part[0];
+      return;
+   }
+   double acc = 0;
+   for (int i = tid; i < a.nb_stride; i += 256) acc += (i >= a.first_chunk && i < a.first_chunk + nb && i - a.first_chunk < 1024) ? cj_part[i - a.first_chunk] : 0.0;
+#pragma unroll
+   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+   __syncthreads();
+   if ((tid & 63) == 0) cj_sw[tid >> 6] = acc;
+   __syncthreads();
+   if (tid == 0) a.red_out[bat] = (cj_sw[0] + cj_sw[1]) + (cj_sw[2] + cj_sw[3]);
+}
+
+#define COOPJ_PROLOGUE                                                                                             \
+   __shared__ __attribute__((aligned(16))) double sX[2][1024];      /* the operand partial, [m >> 1][lane][m & 1] */ \
+   __shared__ double sR[4][16];                                                                                 \
+   const int tid = threadIdx.x, lane = tid & 63;                                                                \
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                   \
+   const int q = lane >> 4, hl = lane & 15;                                                                     \
+   const int sub = blockIdx.x & 3, tile = (blockIdx.x >> 2) % a.n_tiles, iclass = (blockIdx.x >> 2) / a.n_tiles; \
+   const int gene = as_const(a.tiles)[tile].x, h0 = as_const(a.tiles)[tile].y + 16 * sub;                       \
+   const int hend = as_const(a.gene_off)[gene + 1];                                                             \
+   const bool empty = h0 >= hend;                                                                               \
+   const int h = h0 + hl;                                                                                       \
+   const bool valid = h < hend;                                                                                 \
+   const int hc = valid ? h : hend - 1;                                                                         \
+   const long pset = (long)gene * a.K + iclass;                                                                 \
+   const double *Pint = a.pint + pset * a.n_nodes * 4096;                                                       \
+   const long tipstride = a.tip_words;                                                                          \
+   const double *Ptip = a.ptip + pset * a.n_nodes * tipstride;                                                  \
+   const int n = a.n;                                                                                           \
+   double lnscale = 0;                                                                                          \
+   (void)lnscale; (void)n; (void)sR; (void)Ptip; (void)Pint;
+// a wave's quarter of the A operands of the branch above NODE (its row block of every k-block pair): 16-byte words per lane, the first
+// COOPJ_NP pairs — the k-blocks that hold states of the model (8 pairs at 61 states, 3 at 20: the others are zero padding)
+#ifndef COOPJ_NP
+#define COOPJ_NP 8
+#define COOPJ_KB 16
+#endif
+#define COOPJ_P(V, NODE)                                                                                          \
+   double2 V[COOPJ_NP];                                                                                         \
+   { const double2 *sp_ = (const double2 *)(Pint + (long)(NODE)*4096) + wave * 64 + lane;                        \
+     _Pragma("unroll") for (int p_ = 0; p_ < COOPJ_NP; p_++) V[p_] = sp_[p_ * 256]; }
+// a wave's quarter (elements m = 4 wave + r) of the row (code, q) of a tip's column table: pieces 2 wave, 2 wave + 1
+#define COOPJ_T(V, TIP, CODE)                                                                                     \
+   double2 V##a, V##b;                                                                                          \
+   { const int row_ = (CODE)*4 + q, swz_ = TIP_SWZ(row_);                                                        \
+     const double2 *pt_ = (const double2 *)(Ptip + (long)(TIP)*tipstride + row_ * 16);                          \
+     V##a = pt_[(2 * wave) ^ swz_]; V##b = pt_[(2 * wave + 1) ^ swz_]; }
+// y = (row block `wave` of P) . x: the quarter is published, one barrier, eight LDS reads, sixteen dependent MFMAs (k-blocks ascending
+// into one accumulator: the order of mfma_matvec and prune_mfma64_coop)
+#define COOPJ_MATVEC(PV, X, Y, XB)                                                                                \
+   { double2 *xs_ = (double2 *)sX[XB];                                                                          \
+     xs_[(2 * wave) * 64 + lane] = make_double2(X[0], X[1]);                                                    \
+     xs_[(2 * wave + 1) * 64 + lane] = make_double2(X[2], X[3]);                                                \
+     __syncthreads();                                                                                           \
+     const double2 *xr_ = (const double2 *)sX[XB];                                                              \
+     double2 xv_[COOPJ_NP];                                                                                     \
+     _Pragma("unroll") for (int p_ = 0; p_ < COOPJ_NP; p_++) xv_[p_] = xr_[p_ * 64 + lane];                     \
+     __builtin_amdgcn_sched_barrier(0);      /* all the reads in flight before the first MFMA: one LDS latency per product */ \
+     v4d acc_ = {0, 0, 0, 0};                                                                                   \
+     _Pragma("unroll") for (int k_ = 0; k_ < COOPJ_NP; k_++) {      /* (k-blocks of zero padding add + 0.0: left out) */ \
+        acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(PV[k_].x, xv_[k_].x, acc_, 0, 0, 0);                        \
+        if (2 * k_ + 1 < COOPJ_KB) acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(PV[k_].y, xv_[k_].y, acc_, 0, 0, 0); \
+     }                                                                                                          \
+     Y[0] = acc_[0]; Y[1] = acc_[1]; Y[2] = acc_[2]; Y[3] = acc_[3]; }
+// NodeScale treesub.c:7200-7230: the maximum over all the states of the pattern = over the four waves' quarters
+#define COOPJ_SCALE(X)                                                                                            \
+   { double mx_ = 0;                                                                                            \
+     _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) mx_ = X[r_] > mx_ ? X[r_] : mx_;                          \
+     double o_ = __shfl_xor(mx_, 16); mx_ = o_ > mx_ ? o_ : mx_;                                                \
+     o_ = __shfl_xor(mx_, 32); mx_ = o_ > mx_ ? o_ : mx_;                                                       \
+     if (q == 0) sR[wave][hl] = mx_;                                                                            \
+     __syncthreads();                                                                                           \
+     _Pragma("unroll") for (int w2_ = 0; w2_ < 4; w2_++) { const double v_ = sR[w2_][hl]; mx_ = v_ > mx_ ? v_ : mx_; } \
+     __syncthreads();                                                                                           \
+     double fac_;                                                                                               \
+     if (mx_ < 1e-300) { _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) X[r_] = (4 * (4 * wave + r_) + q < n) ? 1.0 : 0.0; fac_ = -800; } \
+     else { _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) X[r_] /= mx_; fac_ = log(mx_); }                   \
+     lnscale += fac_; }
+// the root: the whole partial to wave 0, which sums it as the other kernels do (MFMA_ROOT_CASE) and stores fx_r's value
+#define COOPJ_ROOT(X, XB)                                                                                         \
+   { double2 *xs_ = (double2 *)sX[XB];                                                                          \
+     xs_[(2 * wave) * 64 + lane] = make_double2(X[0], X[1]);                                                    \
+     xs_[(2 * wave + 1) * 64 + lane] = make_double2(X[2], X[3]);                                                \
+     __syncthreads();                                                                                           \
+     if (wave == 0) {                                                                                           \
+        const double2 *xr_ = (const double2 *)sX[XB];                                                           \
+        const double *pq_ = a.pi + (long)(a.n_pi > 1 ? gene : 0) * 64 + q * 16;                                 \
+        double f_ = 0;                                                                                          \
+        _Pragma("unroll") for (int p_ = 0; p_ < 8; p_++) { const double2 v_ = xr_[p_ * 64 + lane]; f_ = fma(pq_[2 * p_], v_.x, f_); f_ = fma(pq_[2 * p_ + 1], v_.y, f_); } \
+        f_ += __shfl_xor(f_, 16);                                                                               \
+        f_ += __shfl_xor(f_, 32);                                                                               \
+        if (q == 0 && valid) {                                                                                  \
+           double out_ = 0;                                                                                     \
+           if (a.weights[h] > 0) out_ = root_value(a, f_, lnscale);                                             \
+           coopj_st(a.fhK + (long)iclass * a.n_patt + h, out_);                                                 \
+        }                                                                                                       \
+     } }
 
 // ---- fused one-pattern-per-lane kernel (4 / 5 states; jit.h: jit_generate_valu_fused) ---------------------------------------
 // One workgroup owns one reduction chunk of patterns and walks it 256 patterns at a time.  Per pattern the tip codes are read

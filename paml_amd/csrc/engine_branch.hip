@@ -255,13 +255,10 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          if (T.scale_node[i] && !tr.is_leaf(i)) { tr.scale_node[i] = 1; tr.scale_slot[i] = T.scale_slot[i]; tr.n_scale = T.n_scale; }
 
    hipStream_t st = e->stream;
+   if (int rc = eigen_refs_ok(e, e->h_eigen_of.data(), e->h_eigen_of.size(), "eval_branch")) return rc;
    if (e->eigen_dirty) {
-      std::vector<EigenDev> tab(e->eigen.size());
-      for (size_t i = 0; i < e->eigen.size(); i++) {
-         const EigenHost &h = e->eigen[i];
-         if (h.kind < 0) return fail(e, PAML_AMD_EINVAL, "eigen set " + std::to_string(i) + " was never set");
-         tab[i] = EigenDev{h.kind, h.nR, h.kappa, h.U.p, h.V.p, h.Root.p, h.Cijk.p};
-      }
+      std::vector<EigenDev> tab;
+      if (int rc = eigen_table(e, tab)) return rc;
       HIPCHK(upload(e->d_eigen, tab.data(), tab.size(), st));
       e->eigen_dirty = false;
    }
@@ -270,7 +267,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
    e->bl_gr_sent = true;
    // ---- the eigen-basis form (kernels_branch.h): matrix-core engines with one gene and (U, V, Root) eigen systems ------------------
    bool eig = mfma && G == 1 && e->n_pi == 1 && !e->env.no_branch_eig && (size_t)(K * BEIG_NT * 192 + 8 * 3 * BEIG_NT) * 8 <= 150 * 1024;
-   for (const EigenHost &h : e->eigen) eig = eig && h.kind == PAML_AMD_EIGEN_UVROOT;
+   for (const EigenHost &h : e->eigen) eig = eig && (h.kind == PAML_AMD_EIGEN_UVROOT || h.kind < 0);
    if (eig) {
       const int n_groups = e->n_tiles_full * GATHER_WAVES, n_out = 3 * n_t;
       const int chunk = e->chunk, cg = chunk / 16, nb_local = (e->n_patt + chunk - 1) / chunk, nbg = e->nb_global;

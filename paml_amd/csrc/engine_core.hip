@@ -35,6 +35,8 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
       e->jit_enabled = (flags & PAML_AMD_JIT) != 0 || (j && j[0] == '1') || (!j && (long)n_patt * max_classes >= 65536);
       e->jit_forced = (flags & PAML_AMD_JIT) != 0 || (j && j[0] == '1');
       if (j && j[0] == '0') e->jit_enabled = false;
+      const char *cj = getenv("PAML_AMD_COOPJIT");
+      e->coopj_enabled = !(j && j[0] == '0') && !(cj && cj[0] == '0');
    }
    // 20 states: the specialised MFMA kernel trimmed to 2 row blocks x 5 k-blocks beats the scalar-operand kernel 2-3x; the
    // MFMA interpreters (64 MFMAs per product whatever n) do not, so small or keep-partials engines stay on valu20
@@ -67,6 +69,7 @@ void paml_amd_destroy(paml_amd_engine *e)
    if (!e) return;
    (void)hipStreamSynchronize(e->stream);
    if (e->jit_job && e->jit_job->th.joinable()) e->jit_job->th.join();
+   if (e->coop_job && e->coop_job->th.joinable()) e->coop_job->th.join();
    for (hipStream_t s : e->sb)
       if (s) {
          (void)hipStreamSynchronize(s);
@@ -90,7 +93,7 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
    case KK_VALU4: return e->use_jit ? (e->fused && e->fused_mfma4 ? "mfma4_jit" : "valu4_jit") : "valu4";
    case KK_VALU5: return e->use_jit ? "valu5_jit" : "valu5";
    case KK_VALU20: return e->use_jit ? (e->m20 ? "mfma4x20_jit" : "valu20_jit") : "valu20";
-   default: return e->use_jit ? "mfma64_jit" : (e->mfma_dma ? "mfma64_stream" : (e->coop ? "mfma64_coop" : "mfma64_gather"));
+   default: return e->use_jit ? "mfma64_jit" : (e->mfma_dma ? "mfma64_stream" : (e->coopj ? "mfma64_coopjit" : (e->coop ? "mfma64_coop" : "mfma64_gather")));
    }
 }
 
@@ -208,6 +211,7 @@ int paml_amd_set_tree(paml_amd_engine *e, int n_nodes, int root, const int *sons
    HIPCHK(upload(e->d_is_leaf, leaf.data(), leaf.size(), e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
    e->have_tree = true;
+   e->pres_valid = false;
    e->prog_valid = false;
    e->partials_valid = false;
    e->bl.valid = false;
@@ -240,6 +244,7 @@ static EigenHost *eigen_slot(paml_amd_engine *e, int set_id)
    if (!e || set_id < 0 || set_id > 4096) return nullptr;
    if ((size_t)set_id >= e->eigen.size()) e->eigen.resize(set_id + 1);
    e->eigen_dirty = true;
+   e->pres_valid = false;
    e->partials_valid = false;
    e->bl.valid = false;
    return &e->eigen[set_id];
@@ -429,6 +434,9 @@ int paml_amd_set_classes(paml_amd_engine *e, int mode, int K, const double *freq
    e->rate_per_gene = false;
    HIPCHK(upload(e->d_qfactor, q.data(), q.size(), e->stream));
    HIPCHK(upload(e->d_eigen_of, eigen_of, (size_t)e->n_genes * K * n_labels, e->stream));
+   e->h_eigen_of.assign(eigen_of, eigen_of + (size_t)e->n_genes * K * n_labels);
+   e->h_qfactor = q;
+   e->pres_valid = false;
    HIPCHK(hipStreamSynchronize(e->stream));
    e->mode = mode; e->K = K; e->n_labels = n_labels;
    e->have_classes = true;
@@ -446,6 +454,7 @@ int paml_amd_set_gene_class_rates(paml_amd_engine *e, const double *rate)
       HIPCHK(upload(e->d_rate, e->class_rate.data(), e->class_rate.size(), e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
       e->rate_per_gene = false;
+      e->pres_valid = false;
       e->partials_valid = false;
       e->bl.valid = false;
       return 0;
@@ -453,6 +462,7 @@ int paml_amd_set_gene_class_rates(paml_amd_engine *e, const double *rate)
    HIPCHK(upload(e->d_rate, rate, (size_t)e->n_genes * e->K, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
    e->rate_per_gene = true;
+   e->pres_valid = false;
    e->partials_valid = false;
    e->bl.valid = false;
    return 0;
@@ -468,9 +478,37 @@ int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double
        node == e->tree.root)
       return fail(e, PAML_AMD_EINVAL, "get_pmat: index out of range");
    const size_t nn2 = (size_t)e->n * e->n;
-   const double *src = e->d_rowmajor.p + ((size_t)(gene * e->K + iclass) * e->tree.n_nodes + node) * nn2;
-   HIPCHK(hipMemcpyAsync(P, src, nn2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+   const size_t slot = (size_t)(gene * e->K + iclass) * e->tree.n_nodes + node;
+   if (e->rowmajor_valid) {
+      const double *src = e->d_rowmajor.p + slot * nn2;
+      HIPCHK(hipMemcpyAsync(P, src, nn2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      return 0;
+   }
+   // The matrix-core P(t) kernel writes only what the pruning kernels read (kernels_pmat.h): P is put together from that —
+   // an internal branch's A-operand order copy, a tip branch's column table (the rows of the plain states: codes 0 .. n - 1).
+   const int n = e->n;
+   if (!e->tree.is_leaf(node)) {
+      std::vector<double> f(4096);
+      HIPCHK(hipMemcpyAsync(f.data(), e->d_pint.p + slot * 4096, 4096 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      for (int i = 0; i < n; i++)
+         for (int j = 0; j < n; j++) {
+            const int jb = i >> 4, kb = j >> 2, lane = (j & 3) * 16 + (i & 15);
+            P[(size_t)i * n + j] = f[(((kb >> 1) * 4 + jb) * 64 + lane) * 2 + (kb & 1)];
+         }
+      return 0;
+   }
+   const size_t tw = tip_words(e);
+   std::vector<double> tab(tw);
+   HIPCHK(hipMemcpyAsync(tab.data(), e->d_ptip.p + slot * tw, tw * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
+   for (int jj = 0; jj < n; jj++)
+      for (int c = 0; c < n; c++) {
+         const int q = jj & 3, m = jj >> 2, row = c * 4 + q;
+         const int w = q * 16 + ((((m >> 1) ^ TIP_SWZ(row)) & 7) << 1) + (m & 1);
+         P[(size_t)jj * n + c] = tab[(size_t)c * 64 + w];
+      }
    return 0;
 }
 

@@ -67,7 +67,7 @@ bool pmat_on_matrix_cores(const paml_amd_engine *e, const PmatArgs &pa)
 {
    static const bool off = getenv("PAML_AMD_PMAT_MFMA") && atoi(getenv("PAML_AMD_PMAT_MFMA")) == 0;
    bool ok = e->kk == KK_MFMA64 && pa.layout == 1 && e->n_codes <= 256 && !off;
-   for (const EigenHost &h : e->eigen) ok = ok && h.kind == PAML_AMD_EIGEN_UVROOT;
+   for (const EigenHost &h : e->eigen) ok = ok && (h.kind == PAML_AMD_EIGEN_UVROOT || h.kind < 0);      // (< 0: an id never set, referred to by nothing)
    return ok;
 }
 
@@ -178,14 +178,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    const bool skip_entry = dual && e->dual_run;      // (nothing waits for this evaluation's entry event)
    e->dual_run = dual;
    std::vector<EigenDev> tab;
-   if (e->eigen_dirty) {
-      tab.resize(e->eigen.size());
-      for (size_t i = 0; i < e->eigen.size(); i++) {
-         const EigenHost &h = e->eigen[i];
-         if (h.kind < 0) return fail(e, PAML_AMD_EINVAL, "eigen set " + std::to_string(i) + " was never set");
-         tab[i] = EigenDev{h.kind, h.nR, h.kappa, h.U.p, h.V.p, h.Root.p, h.Cijk.p};
-      }
-   }
+   if (e->eigen_dirty)
+      if (int rc = eigen_table(e, tab)) return rc;
+   if (!(bs && bs->eigen_of))
+      if (int rc = eigen_refs_ok(e, e->h_eigen_of.data(), e->h_eigen_of.size(), "eval")) return rc;
 
    // branch lengths and gene rates of a single evaluation ride in the kernel arguments of P(t) (InlineVec): no copy at all
    InlineVec iv;
@@ -218,9 +214,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       if (bs) {      // per-element class tables
          if (bs->eigen_of) {
             const size_t cnt = (size_t)B * G * Km * L;
-            for (size_t i = 0; i < cnt; i++)
-               if (bs->eigen_of[i] < 0 || bs->eigen_of[i] >= (int)e->eigen.size())
-                  return fail(e, PAML_AMD_EINVAL, "eval_batch: eigen_of entry out of range");
+            if (int rc = eigen_refs_ok(e, bs->eigen_of, cnt, "eval_batch")) return rc;
             HIPCHK(e->d_b_eigen_of.ensure(cnt));
             const int *h = e->stage.put(bs->eigen_of, cnt);
             HIPCHK(hipMemcpyAsync(e->d_b_eigen_of.p, h, cnt * 4, hipMemcpyHostToDevice, e->stream));
@@ -369,7 +363,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    const int n_blocks = e->n_tiles * K;
    const int n_int = nn - e->n_tips;
    if (keep) {
-      size_t words = e->kk == KK_MFMA64 ? (size_t)K * n_int * e->part_groups() * 1024
+      size_t words = e->kk == KK_MFMA64 ? (size_t)K * n_int * e->part_groups() * 1024 + 8 * 1024      // (+ PruneArgs::part_dump)
                                         : (size_t)K * n_int * e->n_patt * n;
       HIPCHK(e->d_partials.ensure(words));
       HIPCHK(e->d_scalef.ensure((size_t)K * std::max(1, e->tree.n_scale) * e->n_patt));
@@ -379,6 +373,62 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       overflow = e->prog.max_stack - MFMA_RS;
       HIPCHK(e->d_stack.ensure((size_t)n_blocks * overflow * e->mfma_waves * 1024));
    }
+
+   // Small data sets on the 21..64-state interpreters: every 16-pattern group can have a CU (ONE round: the kernels' LDS leaves room for
+   // one workgroup per CU, and two rounds of a 25 us walk lose to one round of the gather kernel's 39) — four waves per group
+   // (prune_mfma64_coop), and once the tree's own kernel is there, that one with the reduction inside (jit_generate_coop: one launch
+   // after P(t) per evaluation).  Single engines only: with pattern shards the chunk sums go through the exchange step.
+   bool coop = false, coopj = false;
+   if (e->kk == KK_MFMA64 && !e->use_jit && !use_dma) {
+      coop = !keep && !clean && !e->env.no_coop && e->tile_patt == 64 && e->prog.max_stack <= COOP_SLOTS &&
+             (long)e->n_tiles * 4 * K <= (long)e->n_cu && !e->env.prof_ops.size();
+      for (const Op &o : e->prog.ops) coop = coop && o.code != OP_STORE && o.code != OP_LOAD && o.code != OP_EXPORT;
+      if (coop && e->coopj_enabled && !e->comm && e->nb_global == (e->n_patt + e->chunk - 1) / e->chunk && e->first_chunk == 0 &&
+          jit_coop_supported(e->prog, e->n_tips, e->n_codes)) {
+         const std::string key = "cj" + std::to_string(n <= 32 ? n : 64) + ":" + jit_program_key(e->prog, e->n_tips);
+         if (e->jit_coop.fn && e->jit_coop.key == key) coopj = true;
+         else if (e->coop_failed_key != key) {
+            paml_amd_engine::JitJob *job = e->coop_job.get();
+            if (job && job->state.load() >= 2 && job->th.joinable()) job->th.join();
+            std::vector<char> code;
+            bool have = false;
+            if (job && job->state.load() >= 2) {      // a finished compilation: this tree's, or an earlier tree's
+               if (job->state.load() == 2 && job->key == key) { code.swap(job->code); have = true; }
+               else if (job->state.load() == 3 && job->key == key) { e->coop_failed_key = key; e->err = "jit (coop): " + job->log; }
+               e->coop_job.reset();
+               job = nullptr;
+            }
+            if (!have && !job && e->coop_failed_key != key) {
+               const std::string src = jit_generate_coop(e->prog, e->n_tips, n);
+               if (!e->env.jit_dump.empty())
+                  if (FILE *f = fopen(e->env.jit_dump.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
+               if (jit_cached_code(src, &code)) have = true;
+               else if (e->jit_forced || e->env.jit_sync) {
+                  std::string log;
+                  if (jit_compile_code(src, &code, &log) == 0) have = true;
+                  else {
+                     e->coop_failed_key = key; e->err = "jit (coop): " + log;
+                     if (e->env.jit_strict) return fail(e, PAML_AMD_EHIP, e->err);
+                  }
+               }
+               else {
+                  e->coop_job.reset(new paml_amd_engine::JitJob());
+                  job = e->coop_job.get();
+                  job->key = key; job->src = src;
+                  job->state.store(1);
+                  job->th = std::thread([job]() { job->state.store(jit_compile_code(job->src, &job->code, &job->log) == 0 ? 2 : 3); });
+               }
+            }
+            if (have) {
+               if (e->jit_coop.mod) (void)hipModuleUnload(e->jit_coop.mod);
+               e->jit_coop = JitKernel();
+               if (jit_load_code(code, &e->jit_coop) == 0) { e->jit_coop.key = key; coopj = true; }
+               else { e->coop_failed_key = key; e->err = "jit (coop): hipModuleLoadData failed"; }
+            }
+         }
+      }
+   }
+   e->coop = coop; e->coopj = coopj;
 
    // Kernel A: batched P(t)
    PmatArgs pa{};
@@ -399,10 +449,34 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    static const int npb_run = getenv("PAML_AMD_PMAT_NPB") ? atoi(getenv("PAML_AMD_PMAT_NPB")) : 1;
    pa.npb = pipe ? npb_run : 1;
    if (bs && bs->rate) { pa.rate = e->d_b_rate.p; pa.rate_bs = e->rate_per_gene ? (long)G * Km : Km; }
+   const bool pmat_mfma = pmat_on_matrix_cores(e, pa);
+   // ... on the matrix cores in the mfma64 layout nobody reads the row-major copy (paml_amd_get_pmat rebuilds P from the operand-order ones)
+   static const bool want_rowmajor = getenv("PAML_AMD_PMAT_ROWMAJOR") != nullptr;
+   if (pmat_mfma && pa.layout == 1 && !want_rowmajor) pa.rowmajor = nullptr;
+   e->rowmajor_valid = pa.rowmajor != nullptr;
+   // ... and single evaluations get label -> eigen_of -> eigen set -> U / V / Root resolved on the host (PmatArgs::res)
+   if (pmat_mfma && !bs && use_inline && !e->rate_per_gene && !e->eigen.empty()) {
+      if (!e->pres_valid) {
+         std::vector<PmatRes> res((size_t)psets * nn);
+         for (int g = 0; g < G; g++)
+            for (int ir = 0; ir < Km; ir++)
+               for (int v = 0; v < nn; v++) {
+                  const int lab = e->tree.label.empty() ? 0 : e->tree.label[v];
+                  const EigenHost &h = e->eigen[e->h_eigen_of[((size_t)g * Km + ir) * e->n_labels + lab]];
+                  res[((size_t)g * Km + ir) * nn + v] = PmatRes{h.U.p, h.V.p, h.Root.p, e->class_rate[ir], e->h_qfactor[(size_t)ir * e->n_labels + lab],
+                                                                e->tree.is_leaf(v) ? 1 : 0, 0};
+               }
+         HIPCHK(e->d_pres.ensure(res.size()));
+         // (pageable source: staged by the runtime before the call returns; in stream order in front of the P(t) kernel)
+         HIPCHK(hipMemcpyAsync(e->d_pres.p, res.data(), res.size() * sizeof(PmatRes), hipMemcpyHostToDevice, ps));
+         e->pres_valid = true;
+      }
+      pa.res = e->d_pres.p;
+   }
    mark_on(e, ps);
    bool small_pmat = e->kk != KK_MFMA64 && n <= 5;
-   for (const EigenHost &h : e->eigen) small_pmat = small_pmat && h.kind != PAML_AMD_EIGEN_QMAT;
-   launch_pmat(pa, iv, nn, psets, small_pmat, ps, pmat_on_matrix_cores(e, pa));
+   for (const EigenHost &h : e->eigen) small_pmat = small_pmat && h.kind != PAML_AMD_EIGEN_QMAT;      // (ids never set: kind < 0, fine)
+   launch_pmat(pa, iv, nn, psets, small_pmat, ps, pmat_mfma);
    mark_on(e, ps);
    if (pipe) {      // the pruning kernel (main stream) starts when this P(t) is there
       HIPCHK(hipEventRecord(e->ev_pmat, e->s2));
@@ -429,6 +503,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
    pr.first_tip = e->prog.first_tip;
    pr.tile_group0 = e->d_tile_group0.p; pr.part_groups = e->part_groups();
+   pr.part_dump = (keep && e->kk == KK_MFMA64) ? e->d_partials.p + (size_t)K * n_int * e->part_groups() * 1024 : nullptr;
    pr.stream = e->d_stream.p; pr.n_stream = (int)(e->prog.stream.size() / 2); pr.tip_words = (long)tip_words(e);
    // the reduction's geometry (the fused kernels form the partial sums themselves; the others leave them to reduce_stage1)
    const int chunk = e->chunk, nbg = e->nb_global;
@@ -439,7 +514,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    // size (profiles/r03_comm_overhead.txt): 0.2351 ms per evaluation against 0.2281 with the two small kernels left on the main
    // stream — the event record / wait pairs that order the streams cost what the kernel boundaries they remove did.  Not the default;
    // with a communicator only the all-reduce and the total go to the side stream.
-   const bool fusedk = e->kk != KK_MFMA64 && e->use_jit && e->fused;      // the kernel forms the partial sums itself
+   const bool fusedk = (e->kk != KK_MFMA64 && e->use_jit && e->fused) || coopj;      // the kernel forms the partial sums itself
    const bool offload = want_pipe && !fusedk && !keep && !clean && !bs && !want_lnf && !e->tree.n_scale && e->env.offload;
    const bool side_total = e->comm || dual;      // the (all-reduce and the) fixed-order total on the side stream `sc`
    if (!offload && !side_total)
@@ -489,7 +564,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    HIPCHK(e->d_out.ensure(B));
    if (want_lnf) HIPCHK(e->d_lnf.ensure((size_t)B * e->n_patt));
    double *const lnl_out = d_lnL_out ? d_lnL_out : e->d_out.p;
-   const bool fused = e->kk != KK_MFMA64 && e->use_jit && e->fused;
+   const bool fused = fusedk;
    pr.zpm = e->d_zpm.p; pr.zpm_words = e->zpm_words;
    if (fused) {
       pr.zpm = e->d_zpm.p; pr.zpm_words = e->zpm_words; pr.Km = Km; pr.chunk = chunk; pr.first_chunk = e->first_chunk; pr.nb_stride = nbg;
@@ -500,6 +575,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       if (int rc = wait_slot()) return rc;      // (this kernel writes the partial sums itself)
       // the total: a one-block stage-2 launch (default), or PAML_AMD_TAIL=1: the workgroup that finishes last forms it (tickets)
       pr.red_counter = (e->comm || !e->env.tail) ? nullptr : e->d_red_counter.p;
+      if (coopj) pr.red_counter = e->d_red_counter.p;      // (the cooperative per-tree kernel: always the last workgroup, of each batch element)
    }
    const int prof_stride = std::max((int)e->prog.ops.size() + 3, e->env.prof_tiles ? 96 : 0);      // experiments only
    if (!e->env.prof_ops.empty()) {
@@ -543,11 +619,11 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       else {
          // small data sets — every 16-pattern group can have a CU (ONE round: the kernel's 90 KB of LDS leave room for one workgroup
          // per CU, and two rounds of its 25 us walks lose to one round of the gather kernel's 39): four waves per group (prune_mfma64_coop)
-         bool coop = !keep && !clean && !e->env.no_coop && e->tile_patt == 64 && e->prog.max_stack <= COOP_SLOTS &&
-                     (long)e->n_tiles * 4 * K <= (long)e->n_cu && !e->env.prof_ops.size();
-         for (const Op &o : e->prog.ops) coop = coop && o.code != OP_STORE && o.code != OP_LOAD && o.code != OP_EXPORT;
-         e->coop = coop;
-         if (coop) hipLaunchKernelGGL(prune_mfma64_coop, dim3(e->n_tiles * 4 * K), dim3(256), 0, ms, pr);
+         if (coopj) {
+            void *params[] = {&pr};
+            HIPCHK(hipModuleLaunchKernel(e->jit_coop.fn, e->n_tiles * 4 * K, 1, 1, 256, 1, 1, 0, ms, params, nullptr));
+         }
+         else if (coop) hipLaunchKernelGGL(prune_mfma64_coop, dim3(e->n_tiles * 4 * K), dim3(256), 0, ms, pr);
          else hipLaunchKernelGGL(prune_mfma64_gather<GATHER_WAVES>, dim3(n_blocks), dim3(GATHER_WAVES * 64), 0, ms, pr);
       }
       break;
@@ -653,7 +729,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
       hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, e->sc, (const double *)dtot.p, nbg, ra.out);
    }
-   else if (!tail && nbg > 1) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, rs, (const double *)dpart.p, nbg, ra.out);      // (one block per element: stage 1 wrote the total)
+   else if (!tail && nbg > 1 && !coopj) hipLaunchKernelGGL(reduce_stage2, dim3(B), dim3(256), 0, rs, (const double *)dpart.p, nbg, ra.out);      // (one block per element: stage 1 wrote the total)
    if (side_total || offload) {
       if (e->comm_stats && side_total) { HIPCHK(hipEventRecord(e->st_done[e->st_count % paml_amd_engine::NSTAT], e->sc)); e->st_count++; }
       HIPCHK(hipEventRecord(e->ev_done[slot], e->sc));

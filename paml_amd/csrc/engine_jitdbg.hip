@@ -110,7 +110,12 @@ int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_p
    const Program p = build_program(t, n_states > 20 && getenv("PAML_AMD_PREBUILD_KEEP") != nullptr, nullptr);
    std::string text;
    // the same choices launch_eval makes for an engine of these sizes
-   if (n_states == 20 && jit_m20_supported(p, n_tips, 1)) text = jit_generate_m20(p, n_tips, n_codes);
+   // (PAML_AMD_PREBUILD_COOP=1: the cooperative per-tree kernel of small data sets, whatever the number of states from 20 to 64)
+   if (getenv("PAML_AMD_PREBUILD_COOP")) {
+      if (!jit_coop_supported(p, n_tips, n_codes)) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate_coop(p, n_tips, n_states);
+   }
+   else if (n_states == 20 && jit_m20_supported(p, n_tips, 1)) text = jit_generate_m20(p, n_tips, n_codes);
    else if (n_states <= 5) {
       if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;
       const int chunk = red_chunk(n_patt_global);

@@ -316,6 +316,12 @@ struct paml_amd_engine {
    bool jit_enabled = false, use_jit = false;
    bool small20 = false;     // 20 states on the MFMA interpreters because the data set is small (engine_core.hip): not as a shard of a larger one
    bool coop = false;        // the last evaluation ran prune_mfma64_coop (small data sets: four waves per 16-pattern group)
+   // ... or its per-tree form with the reduction inside (jit.h: jit_generate_coop).  A module of its own: an engine goes back and forth
+   // between it (an evaluation, a small batch) and the interpreters (a batched gradient too large for one 16-pattern group per CU).
+   // The kernel is compiled on a worker thread unless its code object is already on disk (lib/jit or the user's cache) or the caller
+   // asked to wait (PAML_AMD_JIT flag / PAML_AMD_JIT_SYNC); the interpreter form serves until it is there.  PAML_AMD_COOPJIT=0 / PAML_AMD_JIT=0: never.
+   JitKernel jit_coop;
+   bool coopj = false, coopj_enabled = true;
    // Consecutive paml_amd_eval_device calls (the loop of a benchmark or of an optimiser's independent evaluations) build the
    // NEXT evaluation's P(t) on a side stream while the previous pruning kernel is still running: its few workgroups fit the CUs
    // that go idle in that kernel's last round.  Two sets of P buffers alternate; the side stream waits for everything the main
@@ -354,10 +360,15 @@ struct paml_amd_engine {
       std::string key, src, log;
       std::vector<char> code;
    };
-   std::unique_ptr<JitJob> jit_job;
-   std::string jit_failed_key;
+   std::unique_ptr<JitJob> jit_job, coop_job;
+   std::string jit_failed_key, coop_failed_key;
 
    std::vector<EigenHost> eigen;
+   std::vector<int> h_eigen_of;      // the class table's eigen set ids as last set (set_classes): checked against the sets that exist
+   std::vector<double> h_qfactor;    // ... and its Qfactors [K][n_labels]
+   DevBuf<PmatRes> d_pres;           // PmatArgs::res: the resolved (parameter set, node) table of single evaluations
+   bool pres_valid = false;          // ... is current (dropped by set_tree / set_classes / any set_eigen_*)
+   bool rowmajor_valid = false;      // d_rowmajor holds the last evaluation's matrices (pmat_mfma_kernel in the mfma64 layout does not write them)
    DevBuf<EigenDev> d_eigen;
    // batched decomposition on the device (paml_amd_set_eigen_qrev_batch): inputs and the table of the sets' buffer pointers
    DevBuf<double> d_eq_q, d_eq_pi, d_eq_scale;
@@ -423,6 +434,7 @@ struct paml_amd_engine {
       }
       if (d_prof) (void)hipFree(d_prof);
       if (jit.mod) (void)hipModuleUnload(jit.mod);
+      if (jit_coop.mod) (void)hipModuleUnload(jit_coop.mod);
       for (auto ev : ev_pool) (void)hipEventDestroy(ev);
       for (auto ev : ev_used) (void)hipEventDestroy(ev);
       DevBuf<unsigned char> *b1[] = {&d_z, &d_chara_map, &d_is_leaf, &d_ztiles};
@@ -441,6 +453,7 @@ struct paml_amd_engine {
       d_label_eff.release();
       d_stream.release();
       d_eigen.release();
+      d_pres.release();
       d_eq_q.release(); d_eq_pi.release(); d_eq_scale.release(); d_eq_ptr.release(); d_eq_sweeps.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
@@ -608,13 +621,22 @@ void launch_prune_full(paml_amd_engine *e, int max_stack, int n_blocks, const Pr
 void launch_zpm(const unsigned char *z, long z_stride, int n_tips, int n_patt, int zw, unsigned int *out, hipStream_t s);
 
 // the table of eigen systems as the kernels read it (uploaded when a set_eigen_* call has changed one)
+// (the table may have holes — set ids are the caller's, e.g. one range per parameter vector of a batched gradient with only the changed
+//  systems set: what must exist is every set the class table REFERS to, eigen_refs_ok)
 inline int eigen_table(paml_amd_engine *e, std::vector<EigenDev> &tab)
 {
    tab.resize(e->eigen.size());
    for (size_t i = 0; i < e->eigen.size(); i++) {
       const EigenHost &h = e->eigen[i];
-      if (h.kind < 0) return fail(e, PAML_AMD_EINVAL, "eigen set " + std::to_string(i) + " was never set");
       tab[i] = EigenDev{h.kind, h.nR, h.kappa, h.U.p, h.V.p, h.Root.p, h.Cijk.p};
+   }
+   return 0;
+}
+inline int eigen_refs_ok(paml_amd_engine *e, const int *ids, size_t cnt, const char *who)
+{
+   for (size_t i = 0; i < cnt; i++) {
+      if (ids[i] < 0 || ids[i] >= (int)e->eigen.size()) return fail(e, PAML_AMD_EINVAL, std::string(who) + ": eigen_of entry out of range");
+      if (e->eigen[ids[i]].kind < 0) return fail(e, PAML_AMD_EINVAL, "eigen set " + std::to_string(ids[i]) + " was never set");
    }
    return 0;
 }

@@ -171,6 +171,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       return nfl;
    };
    bool z_pending = false;                   // the next tile's code block still has to be requested in this tile
+   std::vector<std::string> pend_store;      // the pieces of a STORE that ride under the product that follows it (see step)
    // make the next c blocks visible, then top the ring up — at once, or (defer) as a `side` functor that spreads the
    // refill's pieces over the first `iters` k-block pairs of the matmul that follows; the first `now` blocks from
    // `consumed` are needed within this very step and are never delayed
@@ -185,22 +186,44 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       }
       const int upto = consumed + 4;
       if (!defer || !spread) {
+         if (!pend_store.empty()) {
+            s << "  ";
+            for (const std::string &st : pend_store) s << " " << st;
+            s << "\n";
+            fl.push_back({-2, (int)pend_store.size()});
+            pend_store.clear();
+         }
          while (issued < upto) issue_now();
          return "JitNoSide()";
       }
       while (issued < consumed + now && issued < upto) issue_now();
-      std::vector<std::string> pieces;
+      // a STORE waiting for this product (keep-partials mode: the partial it multiplies): its eight 1 KB wave stores go out one per
+      // k-block pair, under the MFMAs — issued together they hold the CU's store path for ~5 000 cycles during which no wave of the
+      // workgroup gets to its MFMAs (measured: 2.2 ms per evaluation at 16 taxa x 10^6 codon patterns against 1.56 without the stores).
+      // The in-flight list below records them where they are issued, between the deferred DMA pieces of the same iterations.
+      std::vector<std::string> stores;
+      stores.swap(pend_store);
+      struct Piece { int blk; std::string text; };      // blk = -2: a store
+      std::vector<Piece> pieces;
       while (issued < upto) {
-         for (int c4 = 0; c4 < n_pieces(issued); c4++) pieces.push_back(piece(issued, c4));
-         fl.push_back({issued, n_pieces(issued)});
+         for (int c4 = 0; c4 < n_pieces(issued); c4++) pieces.push_back({issued, piece(issued, c4)});
          issued++;
       }
-      if (pieces.empty()) return "JitNoSide()";
-      const int per = ((int)pieces.size() + iters - 1) / iters;
+      if (pieces.empty() && stores.empty()) return "JitNoSide()";
+      const int per = pieces.empty() ? 1 : ((int)pieces.size() + iters - 1) / iters;
+      std::vector<std::vector<Piece>> at(iters);
+      for (size_t i = 0; i < pieces.size(); i++) at[i / per].push_back(pieces[i]);
+      for (size_t i = 0; i < stores.size(); i++) at[i * iters / stores.size()].push_back({-2, stores[i]});
+      // the in-flight list in the order of issue (a block whose pieces span iterations has several entries: wait_count takes the last)
       std::string f = "[&](int kb2) {";
-      for (size_t i = 0; i < pieces.size(); i += per) {
-         f += " if (kb2 == " + std::to_string(i / per) + ") {";
-         for (size_t k = i; k < i + per && k < pieces.size(); k++) f += " " + pieces[k];
+      for (int i = 0; i < iters; i++) {
+         if (at[i].empty()) continue;
+         f += " if (kb2 == " + std::to_string(i) + ") {";
+         for (const Piece &pc : at[i]) {
+            f += " " + pc.text;
+            if (!fl.empty() && fl.back().id == pc.blk) fl.back().pieces++;
+            else fl.push_back({pc.blk, 1});
+         }
          f += " }";
       }
       return f + " }";
@@ -363,14 +386,29 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          s << "   { const double fac = jit_scale(" << name(cur) << ", q, n); lnscale += fac;\n"
            << "     if (a.keep && q == 0 && valid) a.scalef[((long)iclass * a.n_scale + " << o.b << ") * a.n_patt + h] = fac; }\n";
          break;
-      case OP_STORE:
-         s << "   if (wave_in) jit_store(" << name(cur) << ", JIT_PART_PTR(" << o.a << "), lane);\n";
-         break;
+      // STORE / LOAD: eight vector-memory operations per wave, entered in the in-flight list like the ring's DMA pieces, so that the
+      // counted waits that follow let them fly (a wait computed without them would make every block step wait for the stores'
+      // completion in HBM).  At a tile's start the list lacks the previous tile's last stores: those waits are stricter than needed, never laxer.
+      case OP_STORE: {
+         const bool under_product = spread && iop + 1 < nops && (p.ops[iop + 1].code == OP_MATMUL || p.ops[iop + 1].code == OP_MATMUL_POP) && p.ops[iop + 1].a == o.a;
+         if (under_product)      // (the product that follows reads this very array and leaves it alone: see step)
+            for (int i = 0; i < 8; i++)
+               pend_store.push_back("JIT_STORE_PIECE(" + name(cur) + ", JIT_PART_DST(" + std::to_string(o.a) + "), " + std::to_string(i) + ");");
+         else {
+            s << "   jit_store(" << name(cur) << ", JIT_PART_DST(" << o.a << "), lane);\n";
+            fl.push_back({-2, 8});
+         }
+      } break;
       case OP_LOAD:
          if (cur < 0) cur = alloc();
          s << "   jit_load(" << name(cur) << ", JIT_PART_PTR(" << o.a << "), lane);\n";
+         fl.push_back({-2, 8});
          break;
       case OP_ROOT:
+         // keep-partials mode with scaling nodes: the factors of clean subtrees were stored by earlier evaluations — all of them are
+         // summed from memory in slot order, as the interpreter kernels do (MFMA_ROOT_CASE; treesub.c:7746-7747)
+         if (resident)
+            s << "   if (a.keep && a.n_scale) { lnscale = 0; if (valid) for (int k_ = 0; k_ < a.n_scale; k_++) lnscale += a.scalef[((long)iclass * a.n_scale + k_) * a.n_patt + h]; }\n";
          s << "   jit_root_lds(a, " << name(cur) << ", lnscale, sPi + (a.n_pi > 1 ? gene : 0) * 64, " << code(n_tips)
            << ", iclass, q, h, valid);\n";
          release(cur);
@@ -1153,6 +1191,156 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    return s.str();
 }
 
+// ---- small data sets: the cooperative kernel (prune_mfma64_coop) unrolled for one tree, reduction inside (device_common.h, COOPJ_*) ----
+// Every operand of the walk is requested straight into registers as far ahead as `budget` VGPRs allow (a product's A operands 32,
+// a tip's two row pieces 8): the generator walks the program once, keeping a list of the operands in order of use, and emits a
+// request whenever the registers of the requests still open fit the budget — at the top of the kernel until it is full, then
+// after every step that consumed one.
+inline bool jit_coop_supported(const Program &p, int n_tips, int n_codes)
+{
+   if (p.ops.size() > 260 || n_tips > 96 || n_codes > 256) return false;
+   for (const Op &o : p.ops)
+      if (o.code == OP_STORE || o.code == OP_LOAD || o.code == OP_EXPORT) return false;
+   return p.max_stack <= 12;
+}
+
+inline std::string jit_generate_coop(const Program &p, int n_tips, int n_states = 61, int budget = 380)
+{
+   std::ostringstream s;
+   // k-blocks of four states that hold states of the model, in pairs (a 16-byte word of the operand order): the rest of the padded
+   // 64 x 64 matrices is zeros and is neither fetched nor multiplied (20 states: 5 k-blocks instead of 16)
+   const int KB = n_states <= 32 ? (n_states + 3) / 4 : 16, NP = (KB + 1) / 2, pcost = 4 * NP;
+   s << "#define COOPJ_NP " << NP << "\n#define COOPJ_KB " << KB << "\n";
+   s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
+   s << "extern \"C\" __global__ __launch_bounds__(256) void prune_jit(PruneArgs a)\n{\n   COOPJ_PROLOGUE\n";
+   s << "   const int cj_bat = iclass / a.Km, cj_nwg = a.n_tiles * 4 * a.Km;\n";
+   s << "   if (!empty) {\n";
+   // the operands in order of use
+   struct Req { bool tip; int id; int cost; };      // id: tip number, or index of the product
+   std::vector<Req> reqs;
+   std::vector<int> req_of_op_a(p.ops.size(), -1), req_of_op_b(p.ops.size(), -1);
+   int n_prod = 0;
+   for (size_t i = 0; i < p.ops.size(); i++) {
+      const Op &o = p.ops[i];
+      switch (o.code) {
+      case OP_MATMUL: case OP_MATMUL_POP: req_of_op_a[i] = (int)reqs.size(); reqs.push_back({false, n_prod++, pcost}); break;
+      case OP_SET_TIP: case OP_MUL_TIP: req_of_op_a[i] = (int)reqs.size(); reqs.push_back({true, o.a, 8}); break;
+      case OP_SET_TIP2: case OP_MUL_TIP2:
+         req_of_op_a[i] = (int)reqs.size(); reqs.push_back({true, o.a, 8});
+         req_of_op_b[i] = (int)reqs.size(); reqs.push_back({true, o.b, 8});
+         break;
+      default: break;
+      }
+   }
+   // the character codes of this lane's pattern, every tip (one byte load each, all in flight together)
+   std::vector<char> used(n_tips, 0);
+   for (const Op &o : p.ops) {
+      if (o.code == OP_SET_TIP || o.code == OP_MUL_TIP || o.code == OP_INIT_TIP) used[o.a] = 1;
+      if (o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2) used[o.a] = used[o.b] = 1;
+   }
+   for (int t = 0; t < n_tips; t++)
+      if (used[t]) s << "   const int c" << t << " = (int)a.z[(long)" << t << " * a.z_stride + hc];\n";
+   // product k: node of its branch
+   std::vector<int> prod_node;
+   for (const Op &o : p.ops)
+      if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) prod_node.push_back(o.a);
+   size_t next_req = 0;
+   int open_cost = 0;
+   auto top_up = [&]() {
+      bool any = false;
+      while (next_req < reqs.size() && (open_cost + reqs[next_req].cost <= budget || open_cost == 0)) {
+         const Req &r = reqs[next_req];
+         if (r.tip) s << "   COOPJ_T(T" << next_req << ", " << r.id << ", c" << r.id << ")\n";
+         else s << "   COOPJ_P(P" << r.id << ", " << prod_node[r.id] << ")\n";
+         open_cost += r.cost;
+         next_req++;
+         any = true;
+      }
+      if (any) s << "   __builtin_amdgcn_sched_barrier(0);\n";
+   };
+   auto consumed = [&](int req) {
+      // (requests are consumed in the order they were made)
+      open_cost -= reqs[req].cost;
+   };
+   top_up();
+   const int NA = p.max_stack + 2;
+   for (int i = 0; i < NA; i++) s << "   double A" << i << "[4];\n";
+   std::vector<int> freeA;
+   for (int i = NA - 1; i >= 0; i--) freeA.push_back(i);
+   auto alloc = [&]() { int r = freeA.back(); freeA.pop_back(); return r; };
+   auto release = [&](int r) { freeA.push_back(r); };
+   auto name = [&](int r) { return "A" + std::to_string(r); };
+   std::vector<int> slot(256, -1);
+   int cur = -1, xb = 0;
+   const char *LOOP = "_Pragma(\"unroll\") for (int r = 0; r < 4; r++) ";
+   for (size_t iop = 0; iop < p.ops.size(); iop++) {
+      const Op &o = p.ops[iop];
+      const int ra = req_of_op_a[iop], rb = req_of_op_b[iop];
+      switch (o.code) {
+      case OP_INIT_ONES:
+         if (cur < 0) cur = alloc();
+         s << "   " << LOOP << name(cur) << "[r] = (4 * (4 * wave + r) + q < n) ? 1.0 : 0.0;\n";
+         break;
+      case OP_INIT_TIP:
+         if (cur < 0) cur = alloc();
+         s << "   " << LOOP << name(cur) << "[r] = (a.cleandata && 4 * (4 * wave + r) + q == c" << o.a << ") ? 1.0 : 0.0;\n";
+         break;
+      case OP_SET_TIP:
+         if (cur < 0) cur = alloc();
+         s << "   " << name(cur) << "[0] = T" << ra << "a.x; " << name(cur) << "[1] = T" << ra << "a.y; " << name(cur) << "[2] = T" << ra << "b.x; " << name(cur) << "[3] = T" << ra << "b.y;\n";
+         consumed(ra);
+         break;
+      case OP_MUL_TIP:
+         s << "   " << name(cur) << "[0] *= T" << ra << "a.x; " << name(cur) << "[1] *= T" << ra << "a.y; " << name(cur) << "[2] *= T" << ra << "b.x; " << name(cur) << "[3] *= T" << ra << "b.y;\n";
+         consumed(ra);
+         break;
+      case OP_SET_TIP2:
+         if (cur < 0) cur = alloc();
+         s << "   " << name(cur) << "[0] = T" << ra << "a.x * T" << rb << "a.x; " << name(cur) << "[1] = T" << ra << "a.y * T" << rb << "a.y; "
+           << name(cur) << "[2] = T" << ra << "b.x * T" << rb << "b.x; " << name(cur) << "[3] = T" << ra << "b.y * T" << rb << "b.y;\n";
+         consumed(ra); consumed(rb);
+         break;
+      case OP_MUL_TIP2:
+         s << "   " << name(cur) << "[0] = (" << name(cur) << "[0] * T" << ra << "a.x) * T" << rb << "a.x; " << name(cur) << "[1] = (" << name(cur) << "[1] * T" << ra << "a.y) * T" << rb << "a.y; "
+           << name(cur) << "[2] = (" << name(cur) << "[2] * T" << ra << "b.x) * T" << rb << "b.x; " << name(cur) << "[3] = (" << name(cur) << "[3] * T" << ra << "b.y) * T" << rb << "b.y;\n";
+         consumed(ra); consumed(rb);
+         break;
+      case OP_PUSH:
+         slot[o.b] = cur;
+         cur = -1;
+         break;
+      case OP_MATMUL:
+      case OP_MATMUL_POP: {
+         const int pop = mm_pop_slot(o), push = mm_push_slot(o), out = alloc();
+         s << "   COOPJ_MATVEC(P" << reqs[ra].id << ", " << name(cur) << ", " << name(out) << ", " << xb << ")\n";
+         xb ^= 1;
+         consumed(ra);
+         release(cur);
+         if (pop >= 0) {
+            s << "   " << LOOP << name(out) << "[r] = " << name(slot[pop]) << "[r] * " << name(out) << "[r];\n";
+            release(slot[pop]);
+            slot[pop] = -1;
+         }
+         if (push >= 0) { slot[push] = out; cur = -1; }
+         else cur = out;
+      } break;
+      case OP_SCALE:
+         s << "   COOPJ_SCALE(" << name(cur) << ")\n";
+         break;
+      case OP_ROOT:
+         s << "   COOPJ_ROOT(" << name(cur) << ", " << xb << ")\n";
+         xb ^= 1;
+         release(cur);
+         cur = -1;
+         break;
+      default: break;
+      }
+      if (ra >= 0) top_up();
+   }
+   s << "   }\n   coopj_finish(a, cj_bat, (int)blockIdx.x - cj_bat * cj_nwg, cj_nwg);\n}\n";
+   return s.str();
+}
+
 inline std::string jit_source_dir()
 {
    if (const char *e = getenv("PAML_AMD_CSRC")) return e;      // (a variant library built somewhere else: tools/build_variant.sh, PAML_AMD_LIB)
@@ -1272,6 +1460,21 @@ inline int jit_compile_code(const std::string &src, std::vector<char> *code, std
    hiprtcGetCode(prog, code->data());
    hiprtcDestroyProgram(&prog);
    jit_write_file(store_dir ? std::string(store_dir) : user, name, *code);
+   return 0;
+}
+
+// The code object of `src` if it is already on disk (the library's lib/jit or the user's cache): no compilation.
+inline bool jit_cached_code(const std::string &src, std::vector<char> *code)
+{
+   const std::string name = jit_cache_name(src), user = jit_user_cache_dir();
+   if (jit_read_file(jit_shipped_dir() + "/" + name, code)) return true;
+   return !user.empty() && jit_read_file(user + "/" + name, code);
+}
+
+inline int jit_load_code(const std::vector<char> &code, JitKernel *out)
+{
+   if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) return -1;
+   if (hipModuleGetFunction(&out->fn, out->mod, "prune_jit") != hipSuccess) return -1;
    return 0;
 }
 

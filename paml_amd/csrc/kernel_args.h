@@ -40,6 +40,15 @@ struct PmatArgs {
    long branch_bs, gene_rate_bs, eigen_of_bs, qfactor_bs, rate_bs;
    int rate_gs;                   // class rates per gene (Malpha: a gamma shape per gene): rate[bat][gene][class], else 0
    int npb;                       // nodes per workgroup of pmat_kernel_t (0 = 1)
+   // single evaluations on pmat_mfma_kernel: what the chain label -> eigen_of -> eigen set -> U / V / Root resolves to, per (parameter
+   // set, node), formed on the host when the tree, the class table or an eigen set changes — one table load in front of the matrix
+   // loads instead of three dependent ones (a small-data evaluation is a chain of such round trips).  null: resolve in the kernel.
+   const struct PmatRes *res;
+};
+struct PmatRes {
+   const double *U, *V, *Root;
+   double rate, qfactor;          // t = ((branch * rate) * gene rate) * qfactor: the kernel's own order
+   int leaf, pad;
 };
 
 // Branch lengths and gene rates handed over INSIDE the kernel arguments (single evaluations of trees with up to ~440 nodes):

@@ -380,10 +380,21 @@ __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = a.n;
    const int KB = a.K * a.B;
    const int gene = pset / KB, bat = (pset % KB) / a.K, iclass = pset % a.K;
-   const int lab = a.label[node];
-   const EigenDev es = a.eigen[a.eigen_of[bat * a.eigen_of_bs + (gene * a.K + iclass) * a.n_labels + lab]];
-   const double t = pmat_time(a, iv, bat, node, gene, iclass) * a.qfactor[bat * a.qfactor_bs + iclass * a.n_labels + lab];
-   const bool leaf = a.is_leaf[node] != 0;
+   EigenDev es;
+   double t;
+   bool leaf;
+   if (a.res) {      // resolved on the host (single evaluations; branch lengths and gene rates ride in the kernel arguments)
+      const PmatRes r = a.res[(long)pset * a.n_nodes + node];
+      es.U = r.U; es.V = r.V; es.Root = r.Root;
+      t = ((iv.v[node] * r.rate) * iv.v[iv.n_branch + gene]) * r.qfactor;
+      leaf = r.leaf != 0;
+   }
+   else {
+      const int lab = a.label[node];
+      es = a.eigen[a.eigen_of[bat * a.eigen_of_bs + (gene * a.K + iclass) * a.n_labels + lab]];
+      t = pmat_time(a, iv, bat, node, gene, iclass) * a.qfactor[bat * a.qfactor_bs + iclass * a.n_labels + lab];
+      leaf = a.is_leaf[node] != 0;
+   }
    // this lane's operands of the sixteen k-blocks: A = U[16 rb + (lane & 15)][4 kb + (lane >> 4)], B = V[4 kb + (lane >> 4)][16 wave + (lane & 15)]
    const int ai = rb * 16 + (lane & 15), bj = wave * 16 + (lane & 15), kq = lane >> 4;
    // (the four waves' A operands are the same sixteen values per lane: wave w fetches k-blocks 4 w .. 4 w + 3 and they are shared through
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv
    __syncthreads();
 
    const long slot = (long)pset * a.n_nodes + node;
-   {
+   if (a.rowmajor) {      // (null: nobody reads it — the pruning kernels take the operand-order copies below, and paml_amd_get_pmat rebuilds P from those)
       double *rm = a.rowmajor + slot * n * n;
       for (int idx = tid; idx < 16 * n; idx += 256) {
          const int il = idx / n, j = idx % n, i = rb * 16 + il;

@@ -187,8 +187,9 @@ from paml_amd import engine, hostlib, models, synth
 pb = synth.codon_m0_problem(n_tips=6, n_patt=300)
 eng = engine.engine_for(pb)
 ok = eng.eval(pb.tree.branch)["lnL"]
-Q, mr = models.codon_q(2.0, 0.4, pb.pi)
-eng.set_eigen_qrev_batch([0], np.array([Q]), np.array([pb.pi]), np.array([mr]))      # one sweep allowed: not converged
+pi = np.asarray(pb.pi, dtype=np.float64).reshape(-1)[:61]
+Q, mr = models.codon_q(2.0, 0.4, pi)
+eng.set_eigen_qrev_batch([0], np.array([Q]), np.array([pi]), np.array([mr]))      # one sweep allowed: not converged
 try:
     eng.eval(pb.tree.branch)
     code = None

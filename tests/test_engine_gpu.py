@@ -189,7 +189,7 @@ def test_keep_partials_on_the_per_tree_kernel(n_genes, scale_every):
     eng3.eval(t.branch, pb.gene_rate)
     assert eng3.kernel_name != "mfma64_jit"
     for (node, ic), g in got.items():
-        assert np.array_equal(eng3.get_partials(node, ic), g), (node, ic)      # same arithmetic order per pattern: same bits
+        assert np.allclose(eng3.get_partials(node, ic), g, rtol=1e-12, atol=1e-300), (node, ic)      # (the per-tree kernel adds column 60's term first: rounding differs)
     l3 = eng3.eval_dirty(br, clean, pb.gene_rate)
     assert abs(l3 - ref2["lnL"]) <= 1e-10 * abs(ref2["lnL"])
     eng3.close()
@@ -217,7 +217,7 @@ def test_dirty_evaluation_by_the_interpreter_after_a_full_one_by_the_per_tree_ke
         clean[node] = 0
         node = father[node]
     lnl_dirty = eng.eval_dirty(br, clean, pb.gene_rate)
-    assert eng.kernel_name in ("mfma64_gather", "mfma64_coop")
+    assert eng.kernel_name in ("mfma64_gather", "mfma64_coop", "mfma64_coopjit")
     pb.tree.branch[:] = br
     ref2 = oracle.evaluate(pb)
     assert abs(lnl_dirty - ref2["lnL"]) <= 1e-10 * abs(ref2["lnL"])
@@ -476,7 +476,7 @@ def test_large_tree_kernel_is_compiled_in_the_background(monkeypatch):
     eng = Engine(pb.n, pb.tree.n_tips, pb.n_patt, max_classes=64).load(pb)      # 1100 x 64 >= 65536: on by size
     ref = oracle.evaluate(pb)["lnL"]
     first = eng.eval(pb.tree.branch, pb.gene_rate)["lnL"]
-    assert eng.kernel_name in ("mfma64_gather", "mfma64_coop"), eng.kernel_name      # (the interpreter kernels: 69 groups of 16 patterns get a CU each)
+    assert eng.kernel_name in ("mfma64_gather", "mfma64_coop", "mfma64_coopjit"), eng.kernel_name      # (the interpreter kernels: 69 groups of 16 patterns get a CU each)
     assert abs(first - ref) <= 1e-10 * abs(ref)
     t0 = time.time()
     while eng.kernel_name != "mfma64_jit" and time.time() - t0 < 120:
@@ -537,7 +537,7 @@ def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch
     if n == 61 and n_tips in (130, 200):
         assert eng.kernel_name == "mfma64_jit"             # one tip-code block
     if n == 61 and n_tips == 230:
-        assert eng.kernel_name in ("mfma64_gather", "mfma64_coop")      # beyond the LDS budget of the specialised kernel: the interpreters
+        assert eng.kernel_name in ("mfma64_gather", "mfma64_coop", "mfma64_coopjit")      # beyond the LDS budget of the specialised kernel: the interpreters
     if n == 61 and n_tips == 90 and jit:
         assert eng.kernel_name == "mfma64_jit"
 
@@ -1167,6 +1167,48 @@ def test_small_data_cooperative_kernel_has_the_bits_of_the_gather_kernel(n, n_ti
     for nb in (2, 100):
         br = np.stack([pb.tree.branch * (1 + 0.01 * i) for i in range(nb)])
         assert np.array_equal(eng.eval_batch(br), eng0.eval_batch(br))
+    # ... and the per-tree form of the cooperative kernel (jit.h: jit_generate_coop — every operand requested straight into registers ahead
+    # of its use, mixture + log + the fixed-order sums formed by the workgroup that finishes last: ONE launch after P(t)): the same bits
+    # again — lnL, per-pattern values, class likelihoods, batched evaluations (per batch element its own last workgroup)
+    monkeypatch.delenv("PAML_AMD_JIT")
+    monkeypatch.delenv("PAML_AMD_COOP")
+    monkeypatch.setenv("PAML_AMD_JIT_SYNC", "1")      # (compile before the first evaluation instead of beside it)
+    engj = engine_for(pb)
+    outj = engj.eval(pb.tree.branch, pb.gene_rate, want_lnf=True, want_fhk=True)
+    assert engj.kernel_name == "mfma64_coopjit", engj.kernel_name
+    assert outj["lnL"] == out0["lnL"] and np.array_equal(outj["lnf"], out0["lnf"]) and np.array_equal(outj["fhK"], out0["fhK"])
+    assert engj.eval(pb.tree.branch, pb.gene_rate)["lnL"] == out0["lnL"]              # (no per-pattern outputs asked for)
+    for nb in (2, 3, 100):
+        br = np.stack([pb.tree.branch * (1 + 0.01 * i) for i in range(nb)])
+        gr = None if pb.gene_rate is None else np.stack([pb.gene_rate] * nb)
+        vj, lj = engj.eval_batch(br, gene_rate=gr, want_lnf=True)
+        v0, l0 = eng0.eval_batch(br, gene_rate=gr, want_lnf=True)
+        assert np.array_equal(vj, v0) and np.array_equal(lj, l0), nb
+    # runs of evaluations left on the device (what a benchmark loop or an optimiser's independent evaluations queue up)
+    import torch
+    d = torch.zeros(5, dtype=torch.float64, device="cuda")
+    engj.set_stream(torch.cuda.current_stream().cuda_stream)
+    for i in range(5):
+        engj.eval_device(pb.tree.branch * (1 + 0.01 * i), d.data_ptr() + 8 * i, pb.gene_rate)
+    engj.flush()
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), eng0.eval_batch(np.stack([pb.tree.branch * (1 + 0.01 * i) for i in range(5)]), gene_rate=None if pb.gene_rate is None else np.stack([pb.gene_rate] * 5)))
+
+
+def test_the_cooperative_per_tree_kernel_is_compiled_beside_the_evaluations():
+    """Without PAML_AMD_JIT_SYNC the tree's own cooperative kernel is compiled on a worker thread (or read from the code-object cache) while
+    the interpreter form serves; the engine changes over when it is there — same value before and after."""
+    import time
+    pb = helpers.random_problem(61, 11, 120, K=2, seed=4242)      # (a tree no other test compiles: not in the cache the first time)
+    eng = engine_for(pb)
+    first = eng.eval(pb.tree.branch)["lnL"]
+    name0 = eng.kernel_name
+    t0 = time.time()
+    while eng.kernel_name != "mfma64_coopjit" and time.time() - t0 < 60:
+        time.sleep(0.1)
+        assert eng.eval(pb.tree.branch)["lnL"] == first
+    assert name0 in ("mfma64_coop", "mfma64_coopjit") and eng.kernel_name == "mfma64_coopjit"
+    assert eng.eval(pb.tree.branch)["lnL"] == first
 
 
 def test_small_20_state_data_take_the_matrix_core_interpreter_unless_they_are_a_shard():
@@ -1175,7 +1217,7 @@ def test_small_20_state_data_take_the_matrix_core_interpreter_unless_they_are_a_
     say so (PAML_AMD_SHARD) — paml_amd_comm_init refuses one that chose by its own size."""
     pb = helpers.random_problem(20, 7, 300, K=4, seed=41)
     eng, out, ref = check(pb)
-    assert eng.kernel_name == "mfma64_coop"
+    assert eng.kernel_name in ("mfma64_coop", "mfma64_coopjit")      # (the tree's own kernel once it is compiled)
     assert eng._L.paml_amd_comm_init(eng._h, 0, 1, None, 100000, 0) != 0 and b"PAML_AMD_SHARD" in eng._L.paml_amd_last_error(eng._h)
     shard, outs, _ = check(pb, flags=SHARD)
     assert shard.kernel_name == "valu20"

@@ -479,3 +479,20 @@ def test_create_flags_of_the_python_mirror_are_the_headers():
     for name, value in (("PAML_AMD_KEEP_PARTIALS", engine.KEEP_PARTIALS), ("PAML_AMD_JIT", engine.JIT), ("PAML_AMD_SHARD", engine.SHARD)):
         m = re.search(r"\b%s\s*=\s*(\d+)" % name, text)
         assert m and int(m.group(1)) == value, name
+
+
+def test_cooperative_per_tree_kernel_is_generated_and_compiles_for_gfx950(tmp_path, monkeypatch):
+    """jit.h: jit_generate_coop — the small-data cooperative kernel unrolled for a tree, reduction inside.  hiprtc cross-compiles without a
+    GPU: trees with scaling nodes and a polytomy, 61 and 20 states (the 20-state source leaves the zero-padded k-blocks out), each gives
+    one code object; the numerics are the GPU tests' (bit-equality with the interpreter kernels)."""
+    import glob
+    monkeypatch.setenv("PAML_AMD_PREBUILD_COOP", "1")
+    for n, kw in ((61, dict(scale_every=3)), (61, dict(polytomy=True)), (20, {})):
+        pb = helpers.random_problem(n, 9, 40, K=1, seed=5 + n, **kw)
+        d = tmp_path / ("n%d_%s" % (n, "_".join(kw) or "plain"))
+        monkeypatch.setenv("PAML_AMD_JIT_DUMP", str(d) + ".hip")
+        engine.jit_prebuild(pb.tree, n, n, K=1, n_patt_global=40, scale_node=pb.scale_node, directory=str(d))
+        assert len(glob.glob(str(d / "*.hsaco"))) == 1
+        src = open(str(d) + ".hip").read()
+        assert "coopj_finish(a," in src and src.count("COOPJ_MATVEC(") == sum(1 for o in engine.debug_program(pb.tree, pb.scale_node)[0] if o[0] in (4, 5))
+        assert ("#define COOPJ_NP 3" in src) == (n == 20)

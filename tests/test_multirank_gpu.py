@@ -73,7 +73,7 @@ def test_ranks_on_one_gpu_match_the_single_engine_bit_for_bit(case, tmp_path):
             assert r["eval_branch"] == one["eval_branch"], (case, world)
             # (a shard of a small data set may fall under the size at which every 16-pattern group gets a CU: the cooperative form
             #  of the interpreter kernel instead of the one-wave-per-group form — same accumulation order, the bits above are equal)
-            interp = {"mfma64_coop": "mfma64_gather"}
+            interp = {"mfma64_coop": "mfma64_gather", "mfma64_coopjit": "mfma64_gather"}
             assert interp.get(r["kernel"], r["kernel"]) == interp.get(one["kernel"], one["kernel"])
             if "eval_adg" in one:
                 # the rate chain over the sites: class likelihoods gathered over the ranks (x + 0 is exact), the chain on every rank
