@@ -790,15 +790,18 @@ def bench_fallbacks(engine, synth, timed, pb_c4):
     # 1. a tree too large for a kernel to be compiled while the caller waits: the interpreter serves, the per-tree kernel takes over
     pb = synth.codon_m0_problem(n_tips=192, n_patt=65_536, seed=192)
     eng, row = run("codon M0, 192 taxa x 65536 patterns", pb, why="per-tree kernel of > 120 ops is compiled on a worker thread; the streaming interpreter serves meanwhile")
+    # (two builds on the worker thread: a quick one — the compiler without the passes that are quadratic on so large a basic block — then the full one)
     t0 = time.perf_counter()
-    while eng.kernel_name != "mfma64_jit" and time.perf_counter() - t0 < 60:
-        time.sleep(0.5)
-        eng.eval(pb.tree.branch)
-    row["seconds_until_compiled_kernel"] = time.perf_counter() - t0
-    if eng.kernel_name == "mfma64_jit":
-        dt, lnl2, _ = timed(eng, pb.tree.branch.copy(), 10, 3)
-        row["then"] = dict(kernel=eng.kernel_name, ms_per_eval=dt / 10 * 1e3, frac_of_fp64_peak=frac(pb, dt / 10 * 1e3), lnL=lnl2,
-                           same_lnL_to_1e12=bool(abs(lnl2 - row["lnL"]) <= 1e-12 * abs(lnl2)))
+    for want, key in (("mfma64_jit_quick", "then_quick_build"), ("mfma64_jit", "then")):
+        while eng.kernel_name not in (want, "mfma64_jit") and time.perf_counter() - t0 < 90:
+            time.sleep(0.25)
+            eng.eval(pb.tree.branch)
+        if eng.kernel_name in (want, "mfma64_jit") and key not in row and not (key == "then_quick_build" and eng.kernel_name == "mfma64_jit"):
+            secs = time.perf_counter() - t0
+            dt, lnl2, _ = timed(eng, pb.tree.branch.copy(), 10, 3)
+            row[key] = dict(kernel=eng.kernel_name, seconds_until_this_kernel=secs, ms_per_eval=dt / 10 * 1e3, frac_of_fp64_peak=frac(pb, dt / 10 * 1e3), lnL=lnl2,
+                            same_lnL_to_1e12=bool(abs(lnl2 - row["lnL"]) <= 1e-12 * abs(lnl2)))
+    row["seconds_until_compiled_kernel"] = (row.get("then_quick_build") or row.get("then") or {}).get("seconds_until_this_kernel")
     eng.close()
     # 2. several genes (option G) on 4 states
     pb = synth.nuc_gtr_gamma_problem(n_tips=32, n_patt=100_000)

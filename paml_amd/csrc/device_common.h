@@ -563,6 +563,17 @@ __device__ __forceinline__ void jit_mul_mem(v4d (&y)[4], const double *sp)   // 
    }
 }
 
+// (JIT_STORE_MODE, experiments through PAML_AMD_JIT_STORE: 0 = nontemporal, 1 = plain, 2 = no store at all — timing only, the resident partials stay unwritten)
+#ifndef JIT_STORE_MODE
+#define JIT_STORE_MODE 0
+#endif
+#if JIT_STORE_MODE == 0
+#define JIT_STORE16(V, P) __builtin_nontemporal_store((V), (P))
+#elif JIT_STORE_MODE == 1
+#define JIT_STORE16(V, P) (*(P) = (V))
+#else
+#define JIT_STORE16(V, P) ((void)0)
+#endif
 // STORE / LOAD of a resident partial (keep-partials mode; layout: part_load / part_store above — element m of the partial is y[m >> 2][m & 3],
 // a lane's elements 2 i, 2 i + 1 one 16-byte access, a wave instruction 1 KB).  Compiler-visible memory operations, like the spills.
 // (streamed past the caches: 7 GB per evaluation at the benchmark's size would otherwise push the P(t) blocks and tip tables, re-read by
@@ -571,7 +582,7 @@ __device__ __forceinline__ void jit_store(const v4d (&y)[4], double *p, int lane
 {
    part2_t *p2 = (part2_t *)p + lane;
 #pragma unroll
-   for (int i = 0; i < 8; i++) __builtin_nontemporal_store((part2_t){y[i >> 1][(2 * i) & 3], y[i >> 1][(2 * i + 1) & 3]}, p2 + i * 64);
+   for (int i = 0; i < 8; i++) JIT_STORE16(((part2_t){y[i >> 1][(2 * i) & 3], y[i >> 1][(2 * i + 1) & 3]}), p2 + i * 64);
 }
 __device__ __forceinline__ void jit_load(v4d (&y)[4], const double *p, int lane)
 {
@@ -579,7 +590,7 @@ __device__ __forceinline__ void jit_load(v4d (&y)[4], const double *p, int lane)
 #pragma unroll
    for (int i = 0; i < 8; i++) { const part2_t v = p2[i * 64]; y[i >> 1][(2 * i) & 3] = v.x; y[i >> 1][(2 * i + 1) & 3] = v.y; }
 }
-#define JIT_STORE_PIECE(Y, PTR, I) __builtin_nontemporal_store((part2_t){Y[(I) >> 1][(2 * (I)) & 3], Y[(I) >> 1][(2 * (I) + 1) & 3]}, (part2_t *)(PTR) + lane + (I)*64)
+#define JIT_STORE_PIECE(Y, PTR, I) JIT_STORE16(((part2_t){Y[(I) >> 1][(2 * (I)) & 3], Y[(I) >> 1][(2 * (I) + 1) & 3]}), (part2_t *)(PTR) + lane + (I)*64)
 #define JIT_PART_PTR(NODE) (a.partials + (((long)iclass * a.n_int + ((NODE) - a.n_tips)) * a.part_groups + tg0 + wave) * 1024)
 #define JIT_PART_DST(NODE) (wave_in ? JIT_PART_PTR(NODE) : a.part_dump + wave * 1024)
 
@@ -841,25 +852,38 @@ __device__ __forceinline__ void coopj_st(double *p, double v)
 {
    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// pattern_lnf of kernels_reduce.h on class likelihoods other workgroups of this launch have just written
+// pattern_lnf of kernels_reduce.h on class likelihoods other workgroups of this launch have just written.  The coherent loads go out
+// eight at a time (one after the other they are a chain of K round trips past the L2: M8's eleven classes), the sums keep the class order.
 __device__ __forceinline__ double coopj_pattern_lnf(const PruneArgs &a, const double *fhK, const double *freqK, int h)
 {
    if (a.mode == PAML_AMD_MODE_LFUN) return coopj_ld(fhK + h);
-   double fh;
+   const int K = a.Km;
+   double fh = 0;
    if (a.n_scale) {      // log-sum-exp around the first maximum (treesub.c:7640-7649)
-      int it = 0;
       double t = coopj_ld(fhK + h);
-      for (int ir = 1; ir < a.Km; ir++) {
-         const double v = coopj_ld(fhK + (long)ir * a.n_patt + h);
-         if (v > t) { t = v; it = ir; }
+      for (int i0 = 1; i0 < K; i0 += 8) {
+         double v[8];
+#pragma unroll
+         for (int j = 0; j < 8; j++) v[j] = i0 + j < K ? coopj_ld(fhK + (long)(i0 + j) * a.n_patt + h) : t;
+#pragma unroll
+         for (int j = 0; j < 8; j++) if (i0 + j < K && v[j] > t) t = v[j];
       }
-      (void)it;
-      fh = 0;
-      for (int ir = 0; ir < a.Km; ir++) fh += freqK[ir] * exp(coopj_ld(fhK + (long)ir * a.n_patt + h) - t);
+      for (int i0 = 0; i0 < K; i0 += 8) {
+         double v[8];
+#pragma unroll
+         for (int j = 0; j < 8; j++) v[j] = i0 + j < K ? coopj_ld(fhK + (long)(i0 + j) * a.n_patt + h) : t;
+#pragma unroll
+         for (int j = 0; j < 8; j++) if (i0 + j < K) fh += freqK[i0 + j] * exp(v[j] - t);
+      }
       return t + log(fh);
    }
-   fh = 0;
-   for (int ir = 0; ir < a.Km; ir++) fh += freqK[ir] * coopj_ld(fhK + (long)ir * a.n_patt + h);
+   for (int i0 = 0; i0 < K; i0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = i0 + j < K ? coopj_ld(fhK + (long)(i0 + j) * a.n_patt + h) : 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) if (i0 + j < K) fh += freqK[i0 + j] * v[j];
+   }
    if (fh <= 0) fh = 1e-300;
    return log(fh);
 }

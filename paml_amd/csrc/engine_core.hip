@@ -93,7 +93,7 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
    case KK_VALU4: return e->use_jit ? (e->fused && e->fused_mfma4 ? "mfma4_jit" : "valu4_jit") : "valu4";
    case KK_VALU5: return e->use_jit ? "valu5_jit" : "valu5";
    case KK_VALU20: return e->use_jit ? (e->m20 ? "mfma4x20_jit" : "valu20_jit") : "valu20";
-   default: return e->use_jit ? "mfma64_jit" : (e->mfma_dma ? "mfma64_stream" : (e->coopj ? "mfma64_coopjit" : (e->coop ? "mfma64_coop" : "mfma64_gather")));
+   default: return e->use_jit ? (e->jit_stage == 1 ? "mfma64_jit_quick" : "mfma64_jit") : (e->mfma_dma ? "mfma64_stream" : (e->coopj ? "mfma64_coopjit" : (e->coop ? "mfma64_coop" : "mfma64_gather")));
    }
 }
 

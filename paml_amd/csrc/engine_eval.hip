@@ -280,37 +280,66 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       if (e->env.jit_waves == 12 && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, 192) && jit_zbuffers(e->n_tips, 192) == 2) jw = 12;
       if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16, e->jit_forced)) {
          const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "w" + std::to_string(jw) + (jit_rowtail(n) ? "r:" : ":") + jit_program_key(e->prog, e->n_tips);
-         const bool background = e->prog.ops.size() > 120 &&      /* (roughly: more than 60 taxa, more than 3 s of compilation) */ !e->jit_forced && !e->env.jit_sync && !(e->jit.fn && e->jit.key == key);
+         // Large trees (> 120 ops: roughly more than 60 taxa): the kernel is one basic block of tens of thousands of instructions and takes
+         // the compiler many seconds.  Unless the caller asked to wait (PAML_AMD_JIT flag / PAML_AMD_JIT_SYNC: one full build), it is built on
+         // a worker thread in two stages while the interpreter kernels serve — first without the three passes that are quadratic on such a
+         // block (JIT_BIG_FLAGS: 192 taxa 8 s instead of 19.5 on the GPU box's host, a kernel at 0.63 of the FP64 peak), then in full (0.70),
+         // and the engine changes over each time a code object is there.  Code objects found on disk are loaded at once, the full one first.
+         const bool big = e->prog.ops.size() > 120;
+         const bool background = big && !e->jit_forced && !e->env.jit_sync;
          if (!background) {
-            int r = ensure_jit(e, key, [&]() { return jit_generate(e->prog, e->n_tips, n, e->n_codes, jw); }, &jit_ok);
+            int r = ensure_jit(e, key, [&]() { return jit_strip_big(jit_generate(e->prog, e->n_tips, n, e->n_codes, jw)); }, &jit_ok);
             if (r) return r;
+            if (jit_ok) e->jit_stage = 2;
          }
          else {
-            paml_amd_engine::JitJob *job = e->jit_job.get();
-            if (job && job->state.load() >= 2 && job->th.joinable()) job->th.join();
-            if (job && job->state.load() == 2 && job->key == key) {          // the code object is there: load it and change over
+            auto load = [&](const std::vector<char> &code, int stage) {
                if (e->jit.mod) (void)hipModuleUnload(e->jit.mod);
                e->jit = JitKernel();
-               if (hipModuleLoadData(&e->jit.mod, job->code.data()) == hipSuccess && hipModuleGetFunction(&e->jit.fn, e->jit.mod, "prune_jit") == hipSuccess) {
-                  e->jit.key = key;
-                  jit_ok = true;
+               if (jit_load_code(code, &e->jit) == 0) { e->jit.key = key; e->jit_stage = stage; return true; }
+               e->jit = JitKernel();
+               e->jit_stage = 0;
+               return false;
+            };
+            if (!(e->jit.fn && e->jit.key == key)) e->jit_stage = 0;      // (another tree's kernel, or none)
+            paml_amd_engine::JitJob *job = e->jit_job.get();
+            if (job && job->state.load() >= 2 && job->th.joinable()) job->th.join();
+            if (job && job->state.load() >= 2) {
+               if (job->key == key && job->state.load() == 2) {          // a code object is there: load it and change over
+                  if (!load(job->code, job->stage)) (job->stage == 1 ? e->jit_failed_key : e->jit_stage2_failed_key) = key;
                }
-               else e->jit_failed_key = key;
-               e->jit_job.reset();
-            }
-            else if (job && job->state.load() >= 2) {                        // failed, or compiled for another tree
-               if (job->state.load() == 3 && job->key == key) { e->jit_failed_key = key; e->err = "jit: " + job->log; }
+               else if (job->key == key) {                               // failed
+                  (job->stage == 1 ? e->jit_failed_key : e->jit_stage2_failed_key) = key;
+                  e->err = "jit: " + job->log;
+               }
                e->jit_job.reset();
                job = nullptr;
             }
-            if (!jit_ok && !e->jit_job && e->jit_failed_key != key) {
-               e->jit_job.reset(new paml_amd_engine::JitJob());
-               job = e->jit_job.get();
-               job->key = key;
-               job->src = jit_generate(e->prog, e->n_tips, n, e->n_codes, jw);
-               job->state.store(1);
-               job->th = std::thread([job]() { job->state.store(jit_compile_code(job->src, &job->code, &job->log) == 0 ? 2 : 3); });
+            if (!job && e->jit_stage < 2 && e->jit_failed_key != key && !(e->jit_stage == 1 && e->jit_stage2_failed_key == key)) {
+               const std::string quick = jit_generate(e->prog, e->n_tips, n, e->n_codes, jw), full = jit_strip_big(quick);
+               std::vector<char> code;
+               if (e->jit_stage == 0) {
+                  if (jit_cached_code(full, &code)) (void)load(code, 2);
+                  else if (jit_cached_code(quick, &code)) (void)load(code, 1);
+               }
+               if (e->jit_stage < 2 && !getenv("PAML_AMD_JIT_ONE_STAGE")) {
+                  e->jit_job.reset(new paml_amd_engine::JitJob());
+                  job = e->jit_job.get();
+                  job->key = key;
+                  job->stage = e->jit_stage + 1;
+                  job->src = job->stage == 1 ? quick : full;
+                  job->state.store(1);
+                  job->th = std::thread([job]() { job->state.store(jit_compile_code(job->src, &job->code, &job->log) == 0 ? 2 : 3); });
+               }
+               else if (e->jit_stage == 0) {      // PAML_AMD_JIT_ONE_STAGE (measurements): the full build only, in the background
+                  e->jit_job.reset(new paml_amd_engine::JitJob());
+                  job = e->jit_job.get();
+                  job->key = key; job->stage = 2; job->src = full;
+                  job->state.store(1);
+                  job->th = std::thread([job]() { job->state.store(jit_compile_code(job->src, &job->code, &job->log) == 0 ? 2 : 3); });
+               }
             }
+            jit_ok = e->jit.fn && e->jit.key == key;
          }
       }
       e->use_jit = jit_ok;

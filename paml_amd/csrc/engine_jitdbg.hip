@@ -128,6 +128,7 @@ int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_p
       if (const char *v = getenv("PAML_AMD_JIT_WAVES")) if (atoi(v) == 12 && jit_zbuffers(n_tips, 192) == 2) jw = 12;
       if (!jit_supported(p, n_tips, n_codes, 1, 6, jw * 16)) return PAML_AMD_EUNSUPPORTED;
       text = jit_generate(p, n_tips, n_states, n_codes, jw);
+      if (!getenv("PAML_AMD_PREBUILD_QUICK")) text = jit_strip_big(text);      // (large trees: the full build, what an engine looks for first)
    }
    if (const char *dump = getenv("PAML_AMD_JIT_DUMP")) {
       FILE *f = fopen(dump, "w");

@@ -357,11 +357,14 @@ struct paml_amd_engine {
    struct JitJob {
       std::thread th;
       std::atomic<int> state{0};      // 0 idle, 1 compiling, 2 code ready, 3 failed
+      int stage = 2;                  // large trees: 1 = the quick build (JIT_BIG_FLAGS), 2 = the full one that replaces it
       std::string key, src, log;
       std::vector<char> code;
    };
    std::unique_ptr<JitJob> jit_job, coop_job;
    std::string jit_failed_key, coop_failed_key;
+   int jit_stage = 0;                 // which build of the large tree's kernel `jit` holds (0: none / a kernel compiled while the caller waited)
+   std::string jit_stage2_failed_key;
 
    std::vector<EigenHost> eigen;
    std::vector<int> h_eigen_of;      // the class table's eigen set ids as last set (set_classes): checked against the sets that exist

@@ -129,6 +129,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
 #ifdef TIP_SWZ_OFF
    s << "#define TIP_SWZ_OFF 1\n";      // (the library's P(t) kernel writes the tip tables without the swizzle: the per-tree kernel must read them so)
 #endif
+   if (const char *v = getenv("PAML_AMD_JIT_STORE")) s << "#define JIT_STORE_MODE " << atoi(v) << "\n";      // experiment: how STORE writes (device_common.h)
    if (getenv("PAML_AMD_JIT_NT_STORE")) s << "#define JIT_NT_STORE 1\n";         // experiment: non-temporal stores of the class likelihoods
    if (getenv("PAML_AMD_JIT_ABL_NOSEED")) s << "#define JIT_ABL_NOSEED 1\n";      // timing experiment: the rank-1 seed without its LDS reads and multiplies
    if (getenv("PAML_AMD_JIT_ABL_NOBAR")) s << "#define JIT_ABL_NOBAR 1\n";      // timing experiment: no workgroup barriers (results are garbage)
@@ -440,7 +441,9 @@ inline std::string jit_generate(const Program &p, int n_tips, int n_states = 61,
       first = got;
       src = jit_generate_impl(p, n_tips, n_states, n_codes, first, &got, waves);
    }
-   return got == first ? src : std::string("#error \"jit schedule does not close\"\n");
+   if (got != first) return std::string("#error \"jit schedule does not close\"\n");
+   if (p.ops.size() > 120) src = "// JIT_BIG: compiled with JIT_BIG_FLAGS (jit_compile_code)\n" + src;
+   return src;
 }
 
 // The one-pattern-per-lane kernels (4 / 5 / 20 states) specialised the same way: the op interpreter of prune_valu<N>
@@ -1364,6 +1367,28 @@ inline std::string jit_source_dir()
 //                              PAML_AMD_JIT_CACHE=0 (or empty) switches it off.
 inline const char *jit_opt_level() { return getenv("PAML_AMD_JIT_OPT") ? getenv("PAML_AMD_JIT_OPT") : "-O3"; }      // experiments: -O1 / -O2
 
+// Kernels of large trees (the generator marks their source): one basic block of tens of thousands of instructions, on which three
+// passes of the compiler are quadratic and gain nothing here — measured on the 192-taxon kernel (340 KB of code), this container's CPU:
+// GPU Load and Store Vectorizer 56 s of 82 (every access is already 16 bytes wide), Machine CSE 6 s, Machine Copy Propagation 3 s.
+// Without them 23 s, the same registers and 115 spilled dwords against 106 (tools/README.md, profiles/r05_big_trees.txt).
+static const char *const JIT_BIG_FLAGS[] = {"-mllvm", "-amdgpu-load-store-vectorizer=0", "-mllvm", "-disable-machine-cse", "-mllvm", "-disable-copyprop"};
+inline bool jit_is_big(const std::string &src) { return src.compare(0, 10, "// JIT_BIG") == 0 && !getenv("PAML_AMD_JIT_BIG_DEFAULT_FLAGS"); }
+inline std::string jit_strip_big(const std::string &src)      // the same kernel for the compiler's full pipeline (no marker line)
+{
+   return src.compare(0, 10, "// JIT_BIG") == 0 ? src.substr(src.find('\n') + 1) : src;
+}
+inline std::vector<std::string> jit_big_flags(const std::string &src)      // (PAML_AMD_JIT_BIG_FLAGS="-mllvm -x ...": experiments)
+{
+   std::vector<std::string> f;
+   if (!jit_is_big(src)) return f;
+   if (const char *v = getenv("PAML_AMD_JIT_BIG_FLAGS")) {
+      std::istringstream is(v);
+      for (std::string w; is >> w;) f.push_back(w);
+   }
+   else f.assign(std::begin(JIT_BIG_FLAGS), std::end(JIT_BIG_FLAGS));
+   return f;
+}
+
 inline std::string jit_cache_name(const std::string &src)
 {
    unsigned long long h = 1469598103934665603ull;
@@ -1374,6 +1399,7 @@ inline std::string jit_cache_name(const std::string &src)
       if (f) { char buf[4096]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) mix(std::string(buf, n)); fclose(f); }
    }
    mix(jit_opt_level());
+   for (const std::string &o : jit_big_flags(src)) mix(o);
    int major = 0, minor = 0;
    (void)hiprtcVersion(&major, &minor);
    mix("hiprtc" + std::to_string(major) + "." + std::to_string(minor));
@@ -1442,8 +1468,10 @@ inline int jit_compile_code(const std::string &src, std::vector<char> *code, std
       return -1;
    }
    const std::string inc = "-I" + jit_source_dir();
-   const char *opts[] = {"--offload-arch=gfx950", jit_opt_level(), "-std=c++17", inc.c_str()};
-   const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+   std::vector<const char *> opts = {"--offload-arch=gfx950", jit_opt_level(), "-std=c++17", inc.c_str()};
+   std::vector<std::string> big = jit_big_flags(src);
+   for (const std::string &o : big) opts.push_back(o.c_str());
+   const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
    size_t ls = 0;
    hiprtcGetProgramLogSize(prog, &ls);
    if (ls > 1) {
