@@ -1197,6 +1197,75 @@ __device__ __forceinline__ void m20h_matvec1(const double *sPn, const double *sP
    for (int m = 0; m < 4; m++) y0[m] = b0[m];
    y0[4] = s0;
 }
+// ---- trees with more internal branches than LDS holds P(t) blocks for (> 46: more than 49 taxa) --------------------------------------
+// The first branches of the walk stay in LDS as above; the others' operands come straight from the operand-order copy pmat_kernel_t<32>
+// leaves in global memory (layout 2: [kb][lane] for rows 0-15, then [kb][k][i] for rows 16-19 — the LDS block, 3 200 bytes per branch,
+// L2-resident): ten 8-byte loads per lane, requested one product ahead like the LDS ones (the big five into the registers the
+// previous product has just read, the small five into a second set), ordinary loads whose waits the compiler counts.
+// CG / NG: this / the next product's operands are in global memory (Pc / Pn then point there, else into LDS).
+template <bool CG, bool NG>
+__device__ __forceinline__ void m20h_matvec2x(const double *Pc, const double *Pn, int lane, double (&Ab)[5], double (&AsN)[5], const double (&x0)[5], double (&y0)[5],
+                                              const double (&x1)[5], double (&y1)[5])
+{
+   double As[5];
+   if constexpr (!CG) { m20h_read_small(m20_lds_addr(Pc), lane, As); m20_wait<5>(Ab); }
+   else {
+#pragma unroll
+      for (int i = 0; i < 5; i++) As[i] = AsN[i];
+   }
+   m20_v4d b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+   double s0 = 0, s1 = 0;
+   b0 = M20_MFMA16(Ab[0], x0[0], b0); b1 = M20_MFMA16(Ab[0], x1[0], b1);
+   b0 = M20_MFMA16(Ab[1], x0[1], b0); b1 = M20_MFMA16(Ab[1], x1[1], b1);
+   if constexpr (!CG) m20_wait<0>(As);
+   s0 = M20_MFMA(As[0], x0[0], s0); s1 = M20_MFMA(As[0], x1[0], s1);
+   b0 = M20_MFMA16(Ab[2], x0[2], b0); b1 = M20_MFMA16(Ab[2], x1[2], b1);
+   s0 = M20_MFMA(As[1], x0[1], s0); s1 = M20_MFMA(As[1], x1[1], s1);
+   b0 = M20_MFMA16(Ab[3], x0[3], b0); b1 = M20_MFMA16(Ab[3], x1[3], b1);
+   s0 = M20_MFMA(As[2], x0[2], s0); s1 = M20_MFMA(As[2], x1[2], s1);
+   b0 = M20_MFMA16(Ab[4], x0[4], b0); b1 = M20_MFMA16(Ab[4], x1[4], b1);
+   if constexpr (!NG) m20h_read_big(m20_lds_addr(Pn), lane, Ab);
+   else {
+#pragma unroll
+      for (int i = 0; i < 5; i++) { Ab[i] = Pn[i * 64 + lane]; AsN[i] = Pn[320 + i * 16 + ((lane >> 4) << 2) + (lane & 3)]; }
+   }
+   s0 = M20_MFMA(As[3], x0[3], s0); s1 = M20_MFMA(As[3], x1[3], s1);
+   s0 = M20_MFMA(As[4], x0[4], s0); s1 = M20_MFMA(As[4], x1[4], s1);
+#pragma unroll
+   for (int m = 0; m < 4; m++) { y0[m] = b0[m]; y1[m] = b1[m]; }
+   y0[4] = s0; y1[4] = s1;
+}
+template <bool CG, bool NG>
+__device__ __forceinline__ void m20h_matvec1x(const double *Pc, const double *Pn, int lane, double (&Ab)[5], double (&AsN)[5], const double (&x0)[5], double (&y0)[5])
+{
+   double As[5];
+   if constexpr (!CG) { m20h_read_small(m20_lds_addr(Pc), lane, As); m20_wait<5>(Ab); }
+   else {
+#pragma unroll
+      for (int i = 0; i < 5; i++) As[i] = AsN[i];
+   }
+   m20_v4d b0 = {0, 0, 0, 0};
+   double s0 = 0;
+   b0 = M20_MFMA16(Ab[0], x0[0], b0);
+   b0 = M20_MFMA16(Ab[1], x0[1], b0);
+   if constexpr (!CG) m20_wait<0>(As);
+   s0 = M20_MFMA(As[0], x0[0], s0);
+   b0 = M20_MFMA16(Ab[2], x0[2], b0);
+   s0 = M20_MFMA(As[1], x0[1], s0);
+   b0 = M20_MFMA16(Ab[3], x0[3], b0);
+   s0 = M20_MFMA(As[2], x0[2], s0);
+   b0 = M20_MFMA16(Ab[4], x0[4], b0);
+   if constexpr (!NG) m20h_read_big(m20_lds_addr(Pn), lane, Ab);
+   else {
+#pragma unroll
+      for (int i = 0; i < 5; i++) { Ab[i] = Pn[i * 64 + lane]; AsN[i] = Pn[320 + i * 16 + ((lane >> 4) << 2) + (lane & 3)]; }
+   }
+   s0 = M20_MFMA(As[3], x0[3], s0);
+   s0 = M20_MFMA(As[4], x0[4], s0);
+#pragma unroll
+   for (int m = 0; m < 4; m++) y0[m] = b0[m];
+   y0[4] = s0;
+}
 // tip factors: row `code` of the tip's table, stored [code][st][m] (pmat_kernel layout 2) so that this lane's five states
 // 4 m + st are 40 contiguous bytes and the four lanes of a pattern read one 160-byte row
 __device__ __forceinline__ void m20_tip(const double *T, int row, int code, int st, double (&v)[5])      // row = doubles per code (20, or 21 in LDS)

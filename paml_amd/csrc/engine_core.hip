@@ -43,7 +43,11 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    // 20 states: the per-tree kernel on v_mfma_f64_4x4x4 (no padding: 25 block products per 16 patterns) for one gene and trees whose
    // internal branches' P(t) fit in LDS; else the 16x16x4 kernel trimmed to 2 row blocks x 5 k-blocks (2-3x the scalar-operand
    // kernel); the MFMA interpreters (64 MFMAs per product whatever n) do not pay, so small or keep-partials engines stay on valu20
-   e->want_m20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_genes == 1 && n_tips <= 49 && !e->env.no_m20 && !e->env.valu20;
+   // (round 5: trees with more internal branches than LDS holds P(t) blocks for — more than 49 taxa — read the others' operands from
+   //  global memory: up to M20_MAX_TIPS taxa — measured at 60: 0.42 of the FP64 peak against the padded 16x16x4 kernel's 0.39; the
+   //  packed tip codes of a unit live in registers, 64 VGPRs at 60 taxa, and beyond 64 taxa the walk would spill more than it gains)
+   constexpr int M20_MAX_TIPS = 64;
+   e->want_m20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_genes == 1 && n_tips <= (getenv("PAML_AMD_M20_49") ? 49 : M20_MAX_TIPS) && !e->env.no_m20 && !e->env.valu20;
    // ... and SMALL 20-state data sets (at most 4096 patterns, round 4): what counts there is the length of one wave's walk, and the
    // cooperative form of the MFMA interpreter (prune_mfma64_coop: four waves per 16-pattern group, 16 MFMAs per wave and branch on
    // the zero-padded matrices) walks a branch in a sixth of the time of the scalar-operand kernel's 400 dependent FMAs per lane

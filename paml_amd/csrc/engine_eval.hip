@@ -257,6 +257,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    }
    HIPCHK(e->d_rowmajor.ensure((size_t)psets * nn * n * n));
    if (e->kk == KK_MFMA64) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 4096));
+   if (e->kk == KK_VALU20 && e->want_m20) HIPCHK(e->d_pint.ensure((size_t)psets * nn * 400));      // (20 states on the matrix cores: the operand-order copies, pmat layout 2)
    if (e->kk == KK_MFMA64) HIPCHK(e->d_pcol.ensure((size_t)psets * nn * 64));
    HIPCHK(e->d_ptip.ensure((size_t)psets * nn * tip_words(e)));
    HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
@@ -381,7 +382,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
       e->m20 = false;
       if (e->want_m20 && !clean && jit_m20_supported(e->prog, e->n_tips, G)) {
-         int r = ensure_jit(e, std::string(getenv("PAML_AMD_M20_W12") ? "m20w12c" : "m20c") + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate_m20(e->prog, e->n_tips, e->n_codes); }, &jit_ok);
+         int r = ensure_jit(e, std::string(getenv("PAML_AMD_M20_W12") ? "m20w12c" : getenv("PAML_AMD_M20_HALF") ? "m20hc" : "m20c") + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate_m20(e->prog, e->n_tips, e->n_codes); }, &jit_ok);
          if (r) return r;
          e->m20 = jit_ok;
       }
@@ -528,6 +529,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.pi = e->d_pi.p; pr.pint = e->kk == KK_MFMA64 ? e->d_pint.p : e->d_rowmajor.p; pr.ptip = e->d_ptip.p;
    if (e->use_jit && e->tree.n_scale) HIPCHK(e->d_fscale.ensure((size_t)K * e->n_patt));
    pr.fscale = e->d_fscale.p; pr.pcol = e->d_pcol.p;
+   if (e->kk == KK_VALU20 && e->use_jit && e->m20) { pr.pint = e->d_pint.p; pr.pcol = e->d_rowmajor.p; }      // (operand-order P(t); the row-major copies for the all-4x4x4 experiment)
    pr.fhK = e->d_fhK.p; pr.partials = e->d_partials.p; pr.scalef = e->d_scalef.p; pr.stack_scratch = e->d_stack.p;
    pr.stack_overflow_slots = overflow; pr.first_matmul = e->prog.first_matmul; pr.n_int = n_int;
    pr.first_tip = e->prog.first_tip;

@@ -959,8 +959,10 @@ inline bool jit_m20_supported(const Program &p, int n_tips, int n_genes, int *n_
       if (o.code == OP_INIT_TIP) return false;
    }
    if (n_slots) *n_slots = nmm;
-   return nmm >= 1 && nmm * 3200 <= 150 * 1024 && p.max_stack + 2 <= 9;
+   // (trees with more internal branches than LDS holds P(t) blocks for — M20_LDS_NODES — read the others' operands from global memory)
+   return nmm >= 1 && nmm <= 200 && p.max_stack + 2 <= 9;
 }
+constexpr int M20_LDS_NODES = 46;      // P(t) blocks (3 200 bytes each) kept in LDS for the whole launch
 
 inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
 {
@@ -980,7 +982,10 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    s << "extern \"C\" __global__ __launch_bounds__(" << NTH << ") void prune_jit(PruneArgs a)\n{\n";
    // tip tables: as many as fit beside the P(t) blocks go to LDS (in order of use), the others are gathered from L1 / L2
    const int tip_bytes = n_codes * 168;      // rows padded to 21 doubles in LDS: with 20, codes c and c + 8 share all their banks
-   const int room = 158 * 1024 - nmm * 3200;
+   // 16x16x4 + 4x4x4 (m20h_matvec2), else all on 4x4x4 — the latter only for trees whose P(t) all fit in LDS (it reads row-major blocks)
+   const bool hybrid = !getenv("PAML_AMD_M20_NOHYBRID") || nmm > M20_LDS_NODES;
+   const int NL = hybrid ? std::min(nmm, M20_LDS_NODES) : nmm;      // products 0 .. NL - 1: operands in LDS; the others: in global memory, operand order
+   const int room = 158 * 1024 - NL * 3200;
    const int n_lds_max = getenv("PAML_AMD_M20_NOLDSTIP") ? 0 : std::max(0, room / tip_bytes);
    std::vector<int> lds_slot(n_tips, -1);
    int n_lds = 0;
@@ -989,23 +994,18 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       if (o.code == OP_SET_TIP || o.code == OP_MUL_TIP) take(o.a);
       if (o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2) { take(o.a); take(o.b); }
    }
-   s << "   constexpr int NMM = " << nmm << ", NC = " << n_codes << ", NLT = " << std::max(1, n_lds) << ";\n";
+   s << "   constexpr int NMM = " << NL << ", NC = " << n_codes << ", NLT = " << std::max(1, n_lds) << ";\n";
    s << "   __shared__ __attribute__((aligned(16))) double sP[NMM * 400];\n";
    s << "   __shared__ __attribute__((aligned(16))) double sT[NLT * NC * 21];\n";
    s << "   __shared__ int sTicket;\n";
    s << "   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, st = lane >> 4, col = lane & 15;\n";
    if (getenv("PAML_AMD_PROF_TILES")) s << "   if (a.prof && tid == 0) a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 3] = __builtin_amdgcn_s_memrealtime();      /* kernel entry, before the LDS fill */\n";
    s << "   const int iclass = blockIdx.x % a.K, first = blockIdx.x / a.K, stride = gridDim.x / a.K;\n";
-   s << "   const double *Pall = a.pint + (long)iclass * a.n_nodes * 400;\n";
+   // (a.pint: the branches' P(t) in operand order — [kb][lane] <- P[lane & 15][4 kb + (lane >> 4)], then [kb][k][i] <- P[16 + i][4 kb + k],
+   //  written so by pmat_kernel_t<32> in layout 2; a.pcol: the row-major copies, which the all-4x4x4 form reads)
+   s << "   const double *Pall = " << (hybrid ? "a.pint" : "a.pcol") << " + (long)iclass * a.n_nodes * 400;\n";
    s << "   const double *Ptip = a.ptip + (long)iclass * a.n_nodes * a.tip_words;\n";
-   const bool hybrid = !getenv("PAML_AMD_M20_NOHYBRID");      // rows 0-15 on v_mfma_f64_16x16x4, rows 16-19 on 4x4x4 (m20h_matvec2); else all on 4x4x4
-   if (hybrid) {      // operand order: [kb][lane] <- P[lane & 15][4 kb + (lane >> 4)], then [kb][k][i] <- P[16 + i][4 kb + k]
-      s << "   const int fsrc = tid < 320 ? (tid & 15) * 20 + 4 * (tid >> 6) + ((tid >> 4) & 3) : (16 + ((tid - 320) & 3)) * 20 + 4 * ((tid - 320) >> 4) + (((tid - 320) >> 2) & 3);\n";
-      for (int k = 0; k < nmm; k++)
-         s << "   if (tid < 400) sP[" << k * 400 << " + tid] = Pall[" << (long)mm_nodes[k] * 400 << " + fsrc];\n";
-   }
-   else
-   for (int k = 0; k < nmm; k++)
+   for (int k = 0; k < NL; k++)
       s << "   for (int i = tid; i < 400; i += " << NTH << ") sP[" << k * 400 << " + i] = Pall[" << (long)mm_nodes[k] * 400 << " + i];\n";
    for (int t = 0; t < n_tips; t++)
       if (lds_slot[t] >= 0)
@@ -1031,7 +1031,9 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    // (profiles/r03_20state.txt: the tail was 6 % of the span).  Ticket t < nfull: the full unit ubase + t; else the half
    // (t - nfull) & 1 of unit ubase + nfull + (t - nfull) / 2.  A wave's first ticket is its own number; the next one is drawn a
    // unit ahead, so that its tip codes arrive while the current unit is walked.
-   const int SPLIT = w12 ? (1 << 20) : (hybrid && !getenv("PAML_AMD_M20_NOSPLIT")) ? 8 : 0;
+   // (PAML_AMD_M20_HALF=1, experiment: every unit a half unit — one 16-pattern group per wave, half the partial arrays: deep trees whose
+   //  two-group walk spills)
+   const int SPLIT = (w12 || getenv("PAML_AMD_M20_HALF")) ? (1 << 20) : (hybrid && !getenv("PAML_AMD_M20_NOSPLIT")) ? 8 : 0;
    s << "#define M20_UNIT_OF(T) ((T) < nfull ? ubase + (T) : ubase + nfull + (((T) - nfull) >> 1))\n";
    s << "#define M20_HALF_OF(T) ((T) < nfull ? -1 : (((T) - nfull) & 1))\n";
    s << "#define M20_FETCH_CODES(T) { int tn_ = (T) < nt ? (T) : nt - 1; tn_ = tn_ < 0 ? 0 : tn_; const int un_ = M20_UNIT_OF(tn_), hf_ = M20_HALF_OF(tn_); \\\n"
@@ -1041,7 +1043,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
         "      hn = h0n + 16 + col; if (hn >= hend) hn = hend - 1; zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
         "      _Pragma(\"unroll\") for (int i = 0; i < ZW / 4; i++) { const uint4 t = zp[i]; zn_1[4 * i] = t.x; zn_1[4 * i + 1] = t.y; zn_1[4 * i + 2] = t.z; zn_1[4 * i + 3] = t.w; } }\n";
    s << "#define M20_TICKET() __builtin_amdgcn_readfirstlane(lane == 0 ? __hip_atomic_fetch_add(&sTicket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0)\n";
-   if (hybrid) s << "   double Acol[5];\n   m20h_read_big(m20_lds_addr(sP), lane, Acol);      /* the first product's big operands (a unit's last product fetches them for the next unit) */\n   (void)aoff;\n";
+   if (hybrid) s << "   double Acol[5], AsN[5] = {0, 0, 0, 0, 0};\n   (void)AsN;\n   m20h_read_big(m20_lds_addr(sP), lane, Acol);      /* the first product's big operands (a unit's last product fetches them for the next unit) */\n   (void)aoff;\n";
    else s << "   double Acol[5];\n   m20_acol_asm<0>(m20_lds_addr(sP) + aoff * 8, Acol);      /* first column of the first product (a unit's last product fetches it for the next unit) */\n";
    const bool proft = getenv("PAML_AMD_PROF_TILES") != nullptr;      // experiments: workgroup timeline (tools/prof_tiles.py)
    const char *ptid = getenv("PAML_AMD_PROF_TID");                   // ... stamped by this thread (default 0)
@@ -1148,11 +1150,18 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
          emit_loads_after(imm, 1);
          emit_loads_after(imm + 1, 2);
          s << "      __builtin_amdgcn_sched_barrier(0);\n";
-         if (G == 2)
-            s << "      " << (hybrid ? "m20h_matvec2" : "m20_matvec2") << "(sP + " << imm * 400 << ", sP + " << ((imm + 1) % nmm) * 400 << ", " << (hybrid ? "lane" : "aoff") << ", Acol, " << name(curin, 0) << ", " << name(out, 0) << ", "
-              << name(curin, 1) << ", " << name(out, 1) << ");\n";
-         else
-            s << "      m20h_matvec1(sP + " << imm * 400 << ", sP + " << ((imm + 1) % nmm) * 400 << ", lane, Acol, " << name(curin, 0) << ", " << name(out, 0) << ");\n";
+         {
+            const int nxt = (imm + 1) % nmm;
+            auto opnd = [&](int k) { return k < NL ? "sP + " + std::to_string(k * 400) : "Pall + " + std::to_string((long)mm_nodes[k] * 400); };
+            const std::string tpl = std::string("<") + (imm >= NL ? "true" : "false") + ", " + (nxt >= NL ? "true" : "false") + ">";
+            if (!hybrid && G == 2)
+               s << "      m20_matvec2(sP + " << imm * 400 << ", sP + " << nxt * 400 << ", aoff, Acol, " << name(curin, 0) << ", " << name(out, 0) << ", " << name(curin, 1) << ", " << name(out, 1) << ");\n";
+            else if (G == 2)
+               s << "      m20h_matvec2x" << tpl << "(" << opnd(imm) << ", " << opnd(nxt) << ", lane, Acol, AsN, " << name(curin, 0) << ", " << name(out, 0) << ", "
+                 << name(curin, 1) << ", " << name(out, 1) << ");\n";
+            else
+               s << "      m20h_matvec1x" << tpl << "(" << opnd(imm) << ", " << opnd(nxt) << ", lane, Acol, AsN, " << name(curin, 0) << ", " << name(out, 0) << ");\n";
+         }
          s << "      __builtin_amdgcn_sched_barrier(0);\n";
          imm++;
          release(curin);
@@ -1179,7 +1188,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       }
    }
    };      // emit_body
-   if (w12) emit_body(1);
+   if (w12 || getenv("PAML_AMD_M20_HALF")) emit_body(1);
    else if (SPLIT) {
       s << "      if (half < 0) {\n";
       emit_body(2);

@@ -304,6 +304,17 @@ __global__ __launch_bounds__(256) void pmat_kernel_t(PmatArgs a, InlineVec iv)
       double *rm = a.rowmajor + slot * n * n;
       for (int idx = tid; idx < n * n; idx += 256) rm[idx] = sA[(idx / n) * LD + (idx % n)];
 
+      if constexpr (LD == 32) if (a.layout == 2 && !leaf && a.pint) {
+         // 20 states on the matrix cores (jit_generate_m20): the branch's 400 entries in the order the kernel's lanes consume them — rows
+         // 0-15 as v_mfma_f64_16x16x4 A operands [kb][lane] = P[lane & 15][4 kb + (lane >> 4)], rows 16-19 as 4x4x4 operands
+         // [kb][k][i] = P[16 + i][4 kb + k] — so that the pruning kernel fills its LDS with a plain copy and reads the branches LDS has no
+         // room for straight from here (device_common.h: m20h_matvec2x)
+         double *pf = a.pint + slot * 400;
+         for (int idx = tid; idx < 400; idx += 256) {
+            const int j = idx - 320;
+            pf[idx] = idx < 320 ? sA[(idx & 15) * LD + 4 * (idx >> 6) + ((idx >> 4) & 3)] : sA[(16 + (j & 3)) * LD + 4 * (j >> 4) + ((j >> 2) & 3)];
+         }
+      }
       if constexpr (LD == 64) if ((a.layout == 1 || a.layout == 3) && !leaf) {
          // MFMA A-operand order: element ((kb2*4 + jb)*64 + lane)*2 + e  =  P[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)]
          // layout 3 (61 states, per-tree kernel without the row padding: device_common.h, JitRowTail): the fourth row block's slot of

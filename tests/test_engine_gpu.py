@@ -530,6 +530,21 @@ def test_per_tree_kernel_spills_deep_stacks(monkeypatch):
     assert "jit_spill(" in _engine.debug_jit(t, compile=False)
 
 
+@pytest.mark.parametrize("n_tips,K,scale_every", [(50, 2, None), (60, 4, None), (64, 1, 30)])
+def test_20_state_matrix_core_kernel_beyond_the_lds_capacity(n_tips, K, scale_every, monkeypatch):
+    """20 states on v_mfma_f64_16x16x4 + 4x4x4 (jit_generate_m20) keeps the P(t) of 46 internal branches in LDS; larger trees (more than 49
+    taxa) read the other branches' operands from the operand-order copy the P(t) kernel leaves in global memory (m20h_matvec2x), one
+    product ahead.  lnL and every per-pattern value against the oracle; the same values as the 16x16x4 kernel on padded matrices."""
+    monkeypatch.setenv("PAML_AMD_JIT", "1")
+    pb = helpers.random_problem(20, n_tips, 1300, K=K, seed=900 + n_tips, scale_every=scale_every)
+    eng, out, ref = check(pb)
+    assert eng.kernel_name == "mfma4x20_jit", eng.kernel_name
+    monkeypatch.setenv("PAML_AMD_NO_M20", "1")
+    eng2, out2, _ = check(pb)
+    assert eng2.kernel_name != "mfma4x20_jit"
+    assert abs(out2["lnL"] - out["lnL"]) <= 1e-11 * abs(out["lnL"])
+
+
 @pytest.mark.parametrize("n,n_tips,n_patt,K,jit", [(61, 90, 300, 1, True), (61, 130, 140, 1, True), (61, 200, 300, 2, True), (61, 230, 130, 1, True), (61, 7, 1, 2, False),
                                                    (61, 12, 129, 20, True), (33, 9, 200, 2, False), (4, 150, 1000, 1, True),
                                                    (5, 40, 777, 2, True), (20, 60, 500, 1, False)])
