@@ -1235,9 +1235,19 @@ def test_differential_of_option_variants_on_cpu(variant, tmp_path):
         os.remove(path)
 
 
+# NSsites 9 .. 13 (M9 - M13) in the differential tests: the reference places the omega classes by inverting the mixture's CDF with a line search on
+# (CDF - p)^2 that starts from the PREVIOUS call's classes and stops at ~1e-5 in omega (Quantile(CDFdN_dS, ...) in DiscreteNSsites,
+# codeml.c:2877): its printed lnL moves by a few 1e-3 with the starting point (see the hiv_m11 golden's note), so for these five models the
+# live binary pins the engine to 5e-3 only; every other model to the printed digits (2e-6).  Tighter pins for M9 - M13 are the goldens with
+# fixed class tables (tests/golden/hiv_m9 .. hiv_m13: the classes the reference itself used).
+TOL_LNL_PRINTED_DIGITS = 2e-6
+TOL_LNL_M9_TO_M13_AGAINST_THE_LIVE_BINARY = 5e-3
+
+
 def _differential(ctl, prog, seed, tmp_path, on_gpu=True):
     """Beyond the committed vectors: the unmodified reference binary (oracle/_ref, when it travelled with the repository) and the
-    engine evaluate the same control file at a RANDOM parameter vector inside the bounds; lnL must agree to the printed digits."""
+    engine evaluate the same control file at a RANDOM parameter vector inside the bounds; lnL must agree to the printed digits
+    (TOL_LNL_PRINTED_DIGITS) — to TOL_LNL_M9_TO_M13_AGAINST_THE_LIVE_BINARY = 5e-3 for NSsites 9 .. 13, see above."""
     import shutil
     exe = os.path.join(helpers.REPO, "oracle", "_ref", prog)
     if not os.access(exe, os.X_OK):
@@ -1265,7 +1275,5 @@ def _differential(ctl, prog, seed, tmp_path, on_gpu=True):
     assert m, r.stdout[-2000:]
     ref = float(m[-1])
     got = a.eval_gpu(x, want_lnf=False)[0] if on_gpu else oracle.evaluate(a.problem(x), want_lnf=False)["lnL"]
-    # M9 - M13: the reference inverts the mixture's CDF by a line search on (CDF - p)^2 that starts from the previous call's classes and stops
-    # at ~1e-5 in omega (Quantile(CDFdN_dS, ...) in DiscreteNSsites, codeml.c:2877); its lnL moves by a few 1e-3 with the starting point (see the hiv_m11 golden's note)
-    tol = 5e-3 if re.search(r"hiv_ns(9|1[0-3])\.ctl", ctl) else 2e-6 * max(1.0, abs(ref) / 1000)
+    tol = TOL_LNL_M9_TO_M13_AGAINST_THE_LIVE_BINARY if re.search(r"hiv_ns(9|1[0-3])\.ctl", ctl) else TOL_LNL_PRINTED_DIGITS * max(1.0, abs(ref) / 1000)
     assert abs(got - ref) <= tol, (got, ref)
