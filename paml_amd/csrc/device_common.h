@@ -1390,6 +1390,17 @@ __device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5
               rz_ ? (const void *)(sZ + ((zsel ^ 1) & (JIT_ZB - 1)) * ((ZP)*2048) + pi_ * 256) : (const void *)sDump, lane * 4, pi_ * 256);  \
       }                                                                                                         \
    }
+/* half mode (trees of more than 207 tips, jit.h: jit_zplan): a tile's codes are two blocks of (ZP)*2048 bytes, [tile][half]; HALF of tile
+ * TILE -> the one sZ buffer */
+#define JIT2_ISSUE_ZH(ZP, TILE, HALF)                                                                             \
+   {                                                                                                            \
+      _Pragma("unroll") for (int c_ = 0; c_ < ((ZP)*8 + JIT_WAVES - 1) / JIT_WAVES; c_++) {                      \
+         const int pi_ = c_ * JIT_WAVES + wave;                                                                 \
+         const bool rz_ = pi_ < (ZP)*8;                                                                         \
+         dma4(make_rsrc(a.ztiles + ((long)(TILE)*2 + (HALF)) * ((ZP)*2048), rz_ ? (ZP)*2048 : 0),                \
+              rz_ ? (const void *)(sZ + pi_ * 256) : (const void *)sDump, lane * 4, pi_ * 256);                  \
+      }                                                                                                         \
+   }
 #define JIT2_BUF(J) (ring + (((J) + roff) & 3) * 4096)
 /* the column-60 table that travels with a P block (61 states): 512 bytes, fetched as one dword DMA piece per thread so
  * that every wave issues the same number of vector-memory instructions — waves 0 and 1 carry the data, the descriptor

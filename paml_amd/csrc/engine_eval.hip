@@ -33,10 +33,16 @@ int build_tiles(paml_amd_engine *e)
       HIPCHK(upload(e->d_tile_group0, g0.data(), g0.size(), e->stream));
    }
    if (e->kk == KK_MFMA64 && e->tile_patt >= 128 && e->d_z.p && e->d_weights.p) {   // code blocks of the specialised kernel
-      e->zt_bytes = jit_zpieces(e->n_tips, e->tile_patt) * 2048;
+      // (trees of more than 207 tips: two halves per tile, the rows in the order the tree's walk consumes them — jit_zplan; the tree's
+      //  program is known by the time a kernel with 128-pattern tiles has been chosen, and launch_eval comes back here when it changes)
+      JitZPlan zp;
+      const bool half = !e->prog.ops.empty() && (zp = jit_zplan(e->prog, e->n_tips, e->tile_patt)).half;
+      e->zt_bytes = half ? 2 * zp.ZP * 2048 : jit_zpieces(e->n_tips, e->tile_patt) * 2048;
+      e->zt_key = half ? jit_program_key(e->prog, e->n_tips) : std::string();
+      if (half) HIPCHK(upload(e->d_ztip_of, zp.tip_of.data(), zp.tip_of.size(), e->stream));
       HIPCHK(e->d_ztiles.ensure((size_t)e->n_tiles * e->zt_bytes));
       hipLaunchKernelGGL(ztile_kernel, dim3(e->n_tiles), dim3(e->tile_patt), 0, e->stream, e->d_tiles.p, e->d_gene_off.p, e->d_z.p, (long)e->n_patt,
-                         e->d_weights.p, e->n_tips, e->zt_bytes, e->d_ztiles.p);
+                         e->d_weights.p, e->n_tips, e->zt_bytes, e->d_ztiles.p, half ? (const int *)e->d_ztip_of.p : (const int *)nullptr, half ? zp.H : 0);
    }
    HIPCHK(hipStreamSynchronize(e->stream));
    return 0;
@@ -352,6 +358,11 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          e->tile_patt = e->mfma_waves * 16;
          int r = build_tiles(e);
          if (r) return r;      // (the resident partials have ONE layout whatever the tile size, PruneArgs::part_groups: they stay valid)
+      }
+      else if (jit_ok && e->tile_patt >= 128 && (e->n_tips > 200 || !e->zt_key.empty())) {      // half mode: the code blocks' rows follow the tree's program
+         const JitZPlan zp = jit_zplan(e->prog, e->n_tips, e->tile_patt);
+         if ((zp.half ? jit_program_key(e->prog, e->n_tips) : std::string()) != e->zt_key)
+            if (int r = build_tiles(e)) return r;
       }
    }
    if (e->kk != KK_MFMA64) {      // 4 / 5 / 20 states: the interpreter unrolled for this tree

@@ -299,6 +299,8 @@ struct paml_amd_engine {
    DevBuf<int> d_n_chara, d_gene_off, d_label, d_eigen_of, d_b_eigen_of;
    DevBuf<int2> d_tiles, d_tiles_full;   // tile table of the selected kernel / of the full (gather or valu) kernel
    int n_tiles_full = 0;
+   DevBuf<int> d_ztip_of;               // half mode of the per-tree kernel's code blocks (jit_zplan): row -> tip
+   std::string zt_key;                  // ... of the program the rows were laid out for ("" = tip order)
    DevBuf<int> d_tile_group0;            // mfma64: per tile of the selected kernel, the resident-partial group of its first 16 patterns (PruneArgs::tile_group0)
    int part_groups() const { return n_tiles_full * GATHER_WAVES; }      // 16-pattern groups per (class, node) of the resident partials: the 64-pattern tile table's
    DevBuf<double> d_pi_plain;
@@ -447,6 +449,7 @@ struct paml_amd_engine {
       d_tiles.release();
       d_tiles_full.release();
       d_tile_group0.release();
+      d_ztip_of.release();
       d_zpm.release();
       d_red_counter.release();
       d_bl_partials.release(); d_bl_scalef.release(); d_bl_frag.release(); d_code_mask.release();

@@ -53,10 +53,63 @@ inline int jit_zbuffers(int n_tips, int tp = 128) { return jit_lds_fits(n_tips, 
 
 // (STORE — every internal node's partial kept, PAML_AMD_KEEP_PARTIALS — is part of the tree's one program.  LOAD programs differ with the
 //  set of clean nodes: a kernel per set would be compiled again and again, so they go to the interpreter unless `allow_load`.)
+// Where a tile's tip codes live in LDS.  Up to 95 tips two blocks (the next tile's arrive while this one is walked), up to 207 one
+// (replaced between tiles); beyond that — up to 413 tips — the block is cut in two HALVES by order of use: the rows (one per tip, then the
+// weight flags) are laid out in the order the walk consumes them, the first half is resident while the walk uses it and the second
+// half replaces it at the crossing (one wait for the DMA per tile and half: nothing beside a tile's hundreds of products).
+struct JitZPlan {
+   int bufs = 2;             // LDS buffers (2: double-buffered; 1: one block or one half)
+   bool half = false;
+   int ZP = 0;               // 2 KB units per buffer
+   int H = 0;                // rows in the first half (half mode); all rows otherwise
+   std::vector<int> row;     // tip (or n_tips: the flags) -> row in its buffer's order
+   std::vector<int> tip_of;  // row (over both halves) -> tip
+};
+inline JitZPlan jit_zplan(const Program &p, int n_tips, int tp = 128)
+{
+   JitZPlan z;
+   z.row.resize(n_tips + 1);
+   z.tip_of.resize(n_tips + 1);
+   for (int t = 0; t <= n_tips; t++) z.row[t] = z.tip_of[t] = t;
+   z.H = n_tips + 1;
+   z.ZP = jit_zpieces(n_tips, tp);
+   if (jit_lds_fits(n_tips, 2, tp)) { z.bufs = 2; return z; }
+   z.bufs = 1;
+   if (jit_lds_fits(n_tips, 1, tp)) return z;
+   // halves: rows in order of use; the cut at an op boundary at or after the middle
+   z.half = true;
+   std::vector<int> order;
+   std::vector<char> seen(n_tips + 1, 0);
+   std::vector<int> op_start;      // index into `order` where each tip-reading op starts
+   for (const Op &o : p.ops) {
+      const bool one = o.code == OP_SET_TIP || o.code == OP_MUL_TIP || o.code == OP_INIT_TIP, two = o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2;
+      if (!one && !two) continue;
+      op_start.push_back((int)order.size());
+      if (!seen[o.a]) { seen[o.a] = 1; order.push_back(o.a); }
+      if (two && !seen[o.b]) { seen[o.b] = 1; order.push_back(o.b); }
+   }
+   for (int t = 0; t < n_tips; t++)
+      if (!seen[t]) order.push_back(t);      // (tips the program never reads: rows nobody looks at)
+   order.push_back(n_tips);                  // the weight flags: read by ROOT, last
+   int H = (n_tips + 2) / 2;
+   for (int st : op_start)
+      if (st >= H) { H = st; break; }
+   z.H = H;
+   for (int r = 0; r <= n_tips; r++) { z.tip_of[r] = order[r]; z.row[order[r]] = r < H ? r : r - H; }
+   const int rows = std::max(H, n_tips + 1 - H);
+   z.ZP = (rows * tp + 2047) / 2048;
+   return z;
+}
+inline bool jit_zfits(const Program &p, int n_tips, int tp = 128)
+{
+   const JitZPlan z = jit_zplan(p, n_tips, tp);
+   return 4 * 32768 + z.bufs * z.ZP * 2048 + 4 * 64 * 8 + (4 * 64 + 32) * 8 + 1024 <= 160 * 1024;
+}
+
 inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6, int tp = 128, bool allow_load = false)
 {
-   if (n_codes > 64 || p.ops.size() > 1000 || n_pi > 4) return false;
-   if (!jit_lds_fits(n_tips, jit_zbuffers(n_tips, tp), tp)) return false;
+   if (n_codes > 64 || p.ops.size() > 1400 || n_pi > 4) return false;
+   if (!jit_zfits(p, n_tips, tp)) return false;
    if (p.stream.size() / 2 < 4) return false;                       // trees this small go to the interpreter
    for (const Op &o : p.ops)
       if (o.code == OP_LOAD && !allow_load) return false;
@@ -94,7 +147,8 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    std::ostringstream s;
    const int nblk = (int)p.stream.size() / 2;
    const int TP = waves * 16;
-   const int ZP = jit_zpieces(n_tips, TP), ZR = (ZP * 8 + waves - 1) / waves;      // code block: 2 KB units; DMA rounds per wave
+   const JitZPlan zpl = jit_zplan(p, n_tips, TP);
+   const int ZP = zpl.ZP, ZR = (ZP * 8 + waves - 1) / waves;      // code block (or half): 2 KB units; DMA rounds per wave
    const size_t nops = p.ops.size();
    // states beyond n are zero padding: only RB row blocks and KB k-blocks of every P take part (4 and 16 at 61 states)
    const int RB = (n_states + 15) / 16, KB = (n_states + 3) / 4, KB2 = (KB + 1) / 2, NPc = KB2;   // NPc: 16-byte pieces per tip-table row
@@ -116,7 +170,8 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       if (p.ops[i].code == OP_SET_TIP || p.ops[i].code == OP_MUL_TIP || p.ops[i].code == OP_SET_TIP2 || p.ops[i].code == OP_MUL_TIP2)
          tail_blocks = true;
    // one code block only (large trees): it is replaced between tiles, so nothing of the next tile can start early
-   const bool zsingle = jit_zbuffers(n_tips, TP) == 1;
+   const bool zsingle = zpl.bufs == 1, zhalf = zpl.half;
+   bool crossed = false;      // (half mode) the second half of the tile's codes has replaced the first
    const bool peel = fuse_tips && !getenv("PAML_AMD_JIT_NOPEEL") && nops > 2 && p.ops[0].code == OP_SET_TIP2 && last_mm > 1 &&
                      p.ops[1].code != OP_MUL_TIP && p.ops[1].code != OP_MUL_TIP2 && !tail_blocks && !zsingle;
 
@@ -234,8 +289,23 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          s << "   if (a.prof && tid == a.prof_tid && ptile) a.prof[(long)blockIdx.x * a.prof_stride + 1 + " << iop
            << "] = __builtin_amdgcn_s_memtime();\n";
    };
-   auto code = [&](int tip) { return "JIT2_CODE(" + std::to_string(ZP) + ", " + std::to_string(tip) + ")"; };
-   auto ncode = [&](int tip) { return "JIT2_NCODE(" + std::to_string(ZP) + ", " + std::to_string(tip) + ")"; };
+   auto code = [&](int tip) { return "JIT2_CODE(" + std::to_string(ZP) + ", " + std::to_string(zpl.row[tip]) + ")"; };
+   auto ncode = [&](int tip) { return "JIT2_NCODE(" + std::to_string(ZP) + ", " + std::to_string(zpl.row[tip]) + ")"; };
+   const std::string issue_z = zhalf ? "JIT2_ISSUE_ZH(" + std::to_string(ZP) + ", n_tile, 0)" : "JIT2_ISSUE_Z(" + std::to_string(ZP) + ")";
+   // (half mode) the rows of the second half are needed from here on: every wave is done with the first half, the second comes over it
+   auto cross_if = [&](std::initializer_list<int> tips) {
+      if (!zhalf || crossed) return;
+      bool need = false;
+      for (int t : tips) {
+         int r = -1;
+         for (int k = 0; k <= n_tips; k++) if (zpl.tip_of[k] == t) r = k;
+         need = need || r >= zpl.H;
+      }
+      if (!need) return;
+      s << "   __syncthreads();\n   JIT2_ISSUE_ZH(" << ZP << ", cur_tile, 1)\n   JIT_WAIT(0); __syncthreads();\n";
+      fl.clear();
+      crossed = true;
+   };
    auto buf = [&](int blk) { return "JIT2_BUF(" + std::to_string(blk) + ")"; };
    auto colarg = [&](int blk) { return tail61 ? ", JIT2_COL(" + std::to_string(blk) + "), x60" : std::string(); };
 
@@ -246,7 +316,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    auto spill_ptr = [&](int slot_no) { return "JIT_SPILL_PTR(" + std::to_string(slot_no - JIT_SCRATCH_BASE) + ")"; };
    for (int i = 0; i < NA; i++) s << "   v4d A" << i << "[4];\n";
    if (peel) s << "   v4d AS[4];\n";       // the first cherry of a tile, produced under the predecessor's last matmul
-   s << "   JIT2_NEXT_SET()\n   JIT2_ISSUE_Z(" << ZP << ")\n";
+   s << "   JIT2_NEXT_SET()\n   " << issue_z << "\n";
    fl.push_back({-1, ZR});
    issued = nblk;                           // numbered as the blocks after the (empty) predecessor's
    for (int i = 0; i < first; i++) issue_now();
@@ -272,6 +342,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    s << "   JIT2_ADVANCE(" << nblk << ")\n";
    // (n_tile is still this tile's number here; the groups of a tile's waves that start past its gene's end belong to nobody: not stored)
    if (resident) s << "   const int tg0 = as_const(a.tile_group0)[n_tile];\n   const bool wave_in = h0 + wave * 16 < hend;\n";
+   if (zhalf) s << "   const int cur_tile = n_tile;\n";
    s << "   work += gridDim.x;\n   JIT2_NEXT_SET()\n";
    z_pending = !zsingle;
 
@@ -297,15 +368,18 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          break;
       case OP_INIT_TIP:
          if (cur < 0) cur = alloc();
+         cross_if({o.a});
          s << "   jit_init_tip(" << name(cur) << ", " << code(o.a) << ", q, a.cleandata);\n";
          break;
       case OP_SET_TIP:
          if (cur < 0) cur = alloc();
+         cross_if({o.a});
          step(1);
          s << "   jit_tip_set<" << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane);\n";
          consumed += 1;
          break;
       case OP_MUL_TIP:
+         cross_if({o.a});
          step(1);
          s << "   jit_tip_mul<" << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane);\n";
          consumed += 1;
@@ -313,6 +387,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       case OP_SET_TIP2:
       case OP_MUL_TIP2:
          if (cur < 0) cur = alloc();
+         cross_if({o.a, o.b});
          step(2);
          s << "   " << (o.code == OP_SET_TIP2 ? "jit_tip2_set<" : "jit_tip2_mul<") << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a)
            << ", " << buf(consumed + 1) << ", " << code(o.b) << ", q, lane);\n";
@@ -335,6 +410,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          // a cherry right after a pushed matmul: its two tip gathers ride under this matmul's second half
          const bool fuse = fuse_tips && push >= 0 && iop + 1 < nops && p.ops[iop + 1].code == OP_SET_TIP2;
          const bool fuse_next = peel && (int)iop == last_mm;     // ... or the next tile's first cherry under the last matmul
+         if (fuse) cross_if({p.ops[iop + 1].a, p.ops[iop + 1].b});
          // (tip tables the ring could not hold earlier are requested in the first k-block pairs and awaited at the midpoint)
          // (the cross-lane read of x[60] is issued before the step's wait + barrier so that its latency hides there)
          if (tail61) s << "   { const double x60 = jit_x60(" << name(cur) << ", lane);\n";
@@ -408,6 +484,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       case OP_ROOT:
          // keep-partials mode with scaling nodes: the factors of clean subtrees were stored by earlier evaluations — all of them are
          // summed from memory in slot order, as the interpreter kernels do (MFMA_ROOT_CASE; treesub.c:7746-7747)
+         cross_if({n_tips});      // (the weight flags: the last row)
          if (resident)
             s << "   if (a.keep && a.n_scale) { lnscale = 0; if (valid) for (int k_ = 0; k_ < a.n_scale; k_++) lnscale += a.scalef[((long)iclass * a.n_scale + k_) * a.n_patt + h]; }\n";
          s << "   jit_root_lds(a, " << name(cur) << ", lnscale, sPi + (a.n_pi > 1 ? gene : 0) * 64, " << code(n_tips)
@@ -423,8 +500,8 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       s << "   __syncthreads();\n   JIT2_ISSUE_Z(" << ZP << ")\n";
       fl.push_back({-1, ZR});
    }
-   if (zsingle) {      // all waves are done with this tile's codes: fetch the next tile's over them, and wait (once per tile)
-      s << "   __syncthreads();\n   JIT2_ISSUE_Z(" << ZP << ")\n   JIT_WAIT(0); __syncthreads();\n";
+   if (zsingle) {      // all waves are done with this tile's codes: fetch the next tile's (first half) over them, and wait (once per tile)
+      s << "   __syncthreads();\n   " << issue_z << "\n   JIT_WAIT(0); __syncthreads();\n";
       fl.clear();
    }
    if (proft) s << "   if (a.prof && tid == 0 && ptc < a.prof_stride - 4) { a.prof[(long)blockIdx.x * a.prof_stride + 1 + ptc] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 1] = __builtin_amdgcn_s_memtime(); }\n   ptc++;\n";

@@ -550,7 +550,8 @@ def test_20_state_matrix_core_kernel_beyond_the_lds_capacity(n_tips, K, scale_ev
                                                    (5, 40, 777, 2, True), (20, 60, 500, 1, False)])
 def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch):
     """Edges of the kernel selection: many tips (the specialised 61-state kernel keeps two tip-code blocks in LDS up to 95 tips,
-    one — replaced between tiles — up to 207, and hands larger trees to the interpreter), one pattern, many classes, a state count between the
+    one — replaced between tiles — up to 207, and beyond that two HALVES per tile in the order the walk consumes the tips, the second
+    replacing the first at the crossing: jit_zplan), one pattern, many classes, a state count between the
     specialised sizes (padded MFMA path), ragged last tiles — each with the specialised kernels forced on or off."""
     monkeypatch.setenv("PAML_AMD_JIT", "1" if jit else "0")
     pb = helpers.random_problem(n, n_tips, n_patt, K=K, seed=500 + n + n_tips, ambiguity=(n_patt % 2 == 1), scale_every=40 if n_tips > 90 else None)
@@ -558,7 +559,11 @@ def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch
     if n == 61 and n_tips in (130, 200):
         assert eng.kernel_name == "mfma64_jit"             # one tip-code block
     if n == 61 and n_tips == 230:
-        assert eng.kernel_name in ("mfma64_gather", "mfma64_coop", "mfma64_coopjit")      # beyond the LDS budget of the specialised kernel: the interpreters
+        assert eng.kernel_name == "mfma64_jit"             # two half blocks of tip codes per tile
+        # ... the same values from the interpreter kernels
+        monkeypatch.setenv("PAML_AMD_JIT", "0")
+        eng0, out0, _ = check(pb)
+        assert eng0.kernel_name in ("mfma64_gather", "mfma64_coop") and abs(out0["lnL"] - out["lnL"]) <= 1e-11 * abs(out["lnL"])
     if n == 61 and n_tips == 90 and jit:
         assert eng.kernel_name == "mfma64_jit"
 
