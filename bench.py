@@ -790,7 +790,7 @@ def bench_fallbacks(engine, synth, timed, pb_c4):
     # 1. a tree too large for a kernel to be compiled while the caller waits: the interpreter serves, the per-tree kernel takes over
     pb = synth.codon_m0_problem(n_tips=192, n_patt=65_536, seed=192)
     eng, row = run("codon M0, 192 taxa x 65536 patterns", pb, why="per-tree kernel of > 120 ops is compiled on a worker thread; the streaming interpreter serves meanwhile")
-    # (two builds on the worker thread: a quick one — the compiler without the passes that are quadratic on so large a basic block — then the full one)
+    # (round 5: the generator cuts the walk into basic blocks, one full build; the quick-then-full pair of builds is what PAML_AMD_JIT_SPLIT=0 still does)
     t0 = time.perf_counter()
     for want, key in (("mfma64_jit_quick", "then_quick_build"), ("mfma64_jit", "then")):
         while eng.kernel_name not in (want, "mfma64_jit") and time.perf_counter() - t0 < 90:

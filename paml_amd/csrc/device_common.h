@@ -707,6 +707,8 @@ __device__ __forceinline__ void jit_root_lds(const PruneArgs &a, const v4d (&x)[
 // Explicit counted wait for the LDS-DMA stream (loads retire in issue order): at most N vector-memory operations of this
 // wave may still be in flight afterwards.
 #define JIT_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+// a never-taken uniform branch: ends a basic block of the per-tree kernel's straight-line code (jit.h, split_mode)
+#define JIT_SPLIT() if (__builtin_expect(a.n_tiles == 0x7fffffff, 0)) asm volatile("s_trap 2");
 
 // ---- building blocks of the specialised one-pattern-per-lane kernels (4 / 5 / 20 states; jit.h: jit_generate_valu) ----
 // Same arithmetic as prune_valu<N>: P(t) entries are wave-uniform and come through the constant address space (s_load ->

@@ -287,11 +287,12 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       if (e->env.jit_waves == 12 && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, 192) && jit_zbuffers(e->n_tips, 192) == 2) jw = 12;
       if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16, e->jit_forced)) {
          const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "w" + std::to_string(jw) + (jit_rowtail(n) ? "r:" : ":") + jit_program_key(e->prog, e->n_tips);
-         // Large trees (> 120 ops: roughly more than 60 taxa): the kernel is one basic block of tens of thousands of instructions and takes
-         // the compiler many seconds.  Unless the caller asked to wait (PAML_AMD_JIT flag / PAML_AMD_JIT_SYNC: one full build), it is built on
-         // a worker thread in two stages while the interpreter kernels serve — first without the three passes that are quadratic on such a
-         // block (JIT_BIG_FLAGS: 192 taxa 8 s instead of 19.5 on the GPU box's host, a kernel at 0.63 of the FP64 peak), then in full (0.70),
-         // and the engine changes over each time a code object is there.  Code objects found on disk are loaded at once, the full one first.
+         // Large trees (> 120 ops: roughly more than 35 taxa): tens of thousands of instructions, many seconds of compiler time.  Unless the
+         // caller asked to wait (PAML_AMD_JIT flag / PAML_AMD_JIT_SYNC), the kernel is built on a worker thread while the interpreter kernels
+         // serve, and the engine changes over when the code object is there; one found on disk is loaded at once.  Round 5: the generator
+         // cuts such a walk into basic blocks (jit_split_mode), which is what the hardware wants and makes the full build as quick as the
+         // build without the three passes that are quadratic on one giant block (JIT_BIG_FLAGS) — that two-stage build (quick kernel at 0.63
+         // of the FP64 peak first, the full one after) remains for PAML_AMD_JIT_SPLIT=0 / asm.
          const bool big = e->prog.ops.size() > 120;
          const bool background = big && !e->jit_forced && !e->env.jit_sync;
          if (!background) {
@@ -329,7 +330,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
                   if (jit_cached_code(full, &code)) (void)load(code, 2);
                   else if (jit_cached_code(quick, &code)) (void)load(code, 1);
                }
-               if (e->jit_stage < 2 && !getenv("PAML_AMD_JIT_ONE_STAGE")) {
+               if (e->jit_stage < 2 && !getenv("PAML_AMD_JIT_ONE_STAGE") && quick != full) {
                   e->jit_job.reset(new paml_amd_engine::JitJob());
                   job = e->jit_job.get();
                   job->key = key;

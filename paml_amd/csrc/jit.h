@@ -142,6 +142,17 @@ inline std::string jit_program_key(const Program &p, int n_tips)
 // own first cherry was done that way by its predecessor; the first tile's is peeled in front of the loop).
 // `first` = operand blocks of a tile already requested when the loop body starts (the body's last step leaves the
 // same number of the next tile's in flight; *first_out reports it so that jit_generate can make the two agree).
+// A tile's walk is one straight line of code — several hundred KB for a large tree — and the hardware runs such a line several times
+// slower than the same instructions with a branch every few ops (230 tips, 256 tiles per launch: 5.8 ms against 1.03 ms; an `s_branch` to
+// the next instruction does as well as a compiler-visible one: profiles/r05_big_tree_split.txt).  Programs of more than JIT_SPLIT_OPS ops
+// get a never-taken uniform branch (JIT_SPLIT) every eighth op; the compiler then also works on blocks of a few thousand instructions
+// instead of one of 10^5 (192 taxa: 28 s instead of 130 on this container's core).   0: none, 1: s_branch, 2: JIT_SPLIT
+static const size_t JIT_SPLIT_OPS = 120;
+inline int jit_split_mode(size_t nops)
+{
+   if (const char *v = getenv("PAML_AMD_JIT_SPLIT")) return !strcmp(v, "asm") ? 1 : !strcmp(v, "br") ? 2 : 0;
+   return nops > JIT_SPLIT_OPS ? 2 : 0;
+}
 inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states, int n_codes, int first, int *first_out, int waves = 8)
 {
    std::ostringstream s;
@@ -284,10 +295,15 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
       }
       return f + " }";
    };
+   const int prof_every = getenv("PAML_AMD_PROF_EVERY") ? std::max(1, atoi(getenv("PAML_AMD_PROF_EVERY"))) : 1;      // (experiments: a stamp at every n-th op only)
+   const int split_mode = jit_split_mode(nops);      // (large trees: a branch every `split_every` ops, see jit_split_mode)
+   const int split_every = getenv("PAML_AMD_JIT_SPLIT_EVERY") ? std::max(1, atoi(getenv("PAML_AMD_JIT_SPLIT_EVERY"))) : 8;
    auto stamp = [&](size_t iop) {
-      if (prof)
+      if (prof && iop % prof_every == 0)
          s << "   if (a.prof && tid == a.prof_tid && ptile) a.prof[(long)blockIdx.x * a.prof_stride + 1 + " << iop
            << "] = __builtin_amdgcn_s_memtime();\n";
+      else if (!prof && split_mode && iop && iop % split_every == 0)
+         s << (split_mode == 1 ? "   asm volatile(\"s_branch 0\");\n" : "   JIT_SPLIT()\n");
    };
    auto code = [&](int tip) { return "JIT2_CODE(" + std::to_string(ZP) + ", " + std::to_string(zpl.row[tip]) + ")"; };
    auto ncode = [&](int tip) { return "JIT2_NCODE(" + std::to_string(ZP) + ", " + std::to_string(zpl.row[tip]) + ")"; };
@@ -519,7 +535,8 @@ inline std::string jit_generate(const Program &p, int n_tips, int n_states = 61,
       src = jit_generate_impl(p, n_tips, n_states, n_codes, first, &got, waves);
    }
    if (got != first) return std::string("#error \"jit schedule does not close\"\n");
-   if (p.ops.size() > 120) src = "// JIT_BIG: compiled with JIT_BIG_FLAGS (jit_compile_code)\n" + src;
+   // (one basic block of > 120 ops: the quick build first.  With the block splits the full passes take no longer than the quick ones.)
+   if (p.ops.size() > 120 && jit_split_mode(p.ops.size()) != 2) src = "// JIT_BIG: compiled with JIT_BIG_FLAGS (jit_compile_code)\n" + src;
    return src;
 }
 

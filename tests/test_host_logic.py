@@ -382,7 +382,7 @@ def test_m20_jit_source_compiles_for_gfx950(lib_path, n_tips):
     t = balanced_tree(n_tips)
     src = engine.debug_jit(t, compile=True, n_states=20, fused=(4, 20))
     n_mm = n_tips - 3
-    assert src.count("m20h_matvec2(") == n_mm and src.count("m20h_matvec1(") == n_mm
+    assert src.count("m20h_matvec2x<") == n_mm and src.count("m20h_matvec1x<") == n_mm      # (<current / next operands from global memory>)
     assert "M20_HALF_OF" in src and "if (half < 0) {" in src
     assert src.count("m20_root(") == 3      # two groups + the single-group copy
 
