@@ -320,6 +320,52 @@ def test_batched_gradient_equals_the_serial_one(name, extra, tmp_path):
     assert len(lnl) == 1 and abs(lnl[0] - g.get("mle_lnL", g["lnL"])) <= 5e-5, (lnl, g.get("mle_lnL", g["lnL"]))
 
 
+@pytest.mark.parametrize("name,what", [("hiv_m2a", "fx_r"), ("hiv_m8", "fx_r"), ("lyso_bsa", "121 omega sets"), ("ecp_cmc", "omega sets"), ("ecp_cmd", "omega sets")])
+def test_neb_and_beb_tables_through_the_engine_equal_the_reference_code_paths(name, what, tmp_path):
+    """After the iteration the reference calls fx_r directly for the NEB table (lfunNSsites_rate, codeml.c:5268) and for the BEB grid of M2a / M8
+    (get_grid_para_like_M2M8, codeml.c:6280), and for branch-site model A / the clade models runs one ConditionalPNode pass per omega set of
+    the grid with an eigen-decomposition per branch (get_grid_para_like_ACD; 1.3 s of the 1.7 s lysozyme run).  The binding takes those over
+    (gpu_fx_r; gpu_beb_collect / gpu_beb_flush: 21 decompositions and ONE paml_amd_eval_batch of 121 elements): the same binary with
+    PAML_AMD_NO_BEB=1 leaves them to the reference's own code, from the same optimum; the `rst` files (every NEB / BEB posterior the program
+    prints) and the main file's BEB section agree number by number."""
+    need_binaries()
+    ctl = open(os.path.join(helpers.GOLDEN, "ctl", CTL_OF.get(name, name) + ".ctl")).read()
+    ctl = ctl.replace("../data/", DATA + "/").replace("../ctl/", os.path.join(helpers.GOLDEN, "ctl") + "/")
+    ctl += "\noutfile = mlc\nnoisy = 3\ngetSE = 0\nRateAncestor = 0\n"
+    res = {}
+    for tag, env in (("engine", {}), ("host", {"PAML_AMD_NO_BEB": "1"})):
+        d = tmp_path / tag
+        d.mkdir()
+        (d / "codeml.ctl").write_text(ctl)
+        t0 = time.perf_counter()
+        r = subprocess.run([REF_GPU, "codeml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=1500,
+                           env=dict(os.environ, PAML_AMD_TIMING="1", **env))
+        dt = time.perf_counter() - t0
+        out = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, out[-3000:]
+        mlc = (d / "mlc").read_text()
+        assert "Bayes Empirical Bayes" in mlc
+        res[tag] = ((d / "rst").read_text(), mlc[mlc.index("Bayes Empirical Bayes"):].split("Time used")[0], out, dt)
+    timing = [ln for ln in res["engine"][2].splitlines() if ln.startswith("paml_amd timing")][-1]
+    host_timing = [ln for ln in res["host"][2].splitlines() if ln.startswith("paml_amd timing")][-1]
+    if what == "fx_r":      # NEB + the BEB grid, one evaluation each
+        assert re.search(r"fx_r \(NEB, BEB grid of M2a / M8\) 2 calls", timing), timing
+    else:
+        n_sets = int(re.search(r"clade models (\d+) omega sets", timing).group(1))
+        assert n_sets >= 111 and (what != "121 omega sets" or n_sets == 121), timing
+        assert re.search(r"fx_r \(NEB, BEB grid of M2a / M8\) 1 calls", timing), timing
+    assert re.search(r"fx_r \(NEB, BEB grid of M2a / M8\) 0 calls", host_timing) and " 0 omega sets" in host_timing, host_timing
+    for k in (0, 1):
+        a, b = _num_tokens(res["engine"][k]), _num_tokens(res["host"][k])
+        assert len(a) == len(b) > 100
+        for x, y in zip(a, b):
+            if isinstance(x, float) and isinstance(y, float):
+                assert abs(x - y) <= 2e-4 + 1e-6 * abs(y), (name, x, y)
+            else:
+                assert x == y, (name, x, y)
+    print("\n%s through codeml_gpu: %.2f s with the NEB / BEB evaluations on the engine, %.2f s with the reference's own" % (name, res["engine"][3], res["host"][3]))
+
+
 def test_batched_gradient_can_be_switched_off(tmp_path):
     need_binaries()
     lnl, lnf, nfun, dt, out = run(REF_GPU, HIV_CTL.replace("NSsites = 0 2", "NSsites = 0"), tmp_path / "gpu", env=dict(os.environ, PAML_AMD_NO_BATCH_GRADIENT="1", PAML_AMD_GRADIENT_CHECK="1"))
