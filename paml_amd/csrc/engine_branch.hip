@@ -117,7 +117,7 @@ int rerooted_pmat(paml_amd_engine *e, int new_root, int cut_son, const double *b
    pa.n_codes = e->n_codes; pa.layout = e->kk == KK_MFMA64 ? 1 : 0;
    pa.label = e->d_label_eff.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
    pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
-   pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
+   pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p; pa.plain_codes = e->plain_codes;
    pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
    pa.B = 1; pa.rate_gs = e->rate_per_gene ? K : 0;
    {
@@ -362,7 +362,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          pa.n_codes = e->n_codes; pa.layout = 1;
          pa.label = e->d_label_eff.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
          pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
-         pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
+         pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p; pa.plain_codes = e->plain_codes;
          pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
          HIPCHK(e->d_pcol.ensure((size_t)psets * nn * 64));
          pa.pcol = e->d_pcol.p;
@@ -507,7 +507,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       pa.n_codes = e->n_codes; pa.layout = mfma ? 1 : 0;
       pa.label = e->d_label_eff.p; pa.is_leaf = e->d_is_leaf.p; pa.branch = e->d_branch.p; pa.rate = e->d_rate.p;
       pa.gene_rate = e->d_gene_rate.p; pa.eigen_of = e->d_eigen_of.p; pa.qfactor = e->d_qfactor.p;
-      pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p;
+      pa.eigen = e->d_eigen.p; pa.n_chara = e->d_n_chara.p; pa.chara_map = e->d_chara_map.p; pa.plain_codes = e->plain_codes;
       pa.rowmajor = e->d_rowmajor.p; pa.pint = e->d_pint.p; pa.ptip = e->d_ptip.p; pa.tip_words = (long)tip_words(e);
       pa.B = 1; pa.rate_gs = e->rate_per_gene ? K : 0;
       {

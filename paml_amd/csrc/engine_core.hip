@@ -140,6 +140,8 @@ int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata,
       if (z[i] >= n_codes) return fail(e, PAML_AMD_EINVAL, "set_tips: character code >= n_codes");
    e->cleandata = cleandata ? 1 : 0;
    e->n_codes = n_codes;
+   e->plain_codes = 0;      // the leading codes that are one state each, the code itself (every code of clean data; the sense codons / amino acids / bases otherwise)
+   while (e->plain_codes < std::min(n, n_codes) && nch[e->plain_codes] == 1 && cmap[(size_t)e->plain_codes * n] == e->plain_codes) e->plain_codes++;
    e->gene_off.assign(e->n_genes + 1, 0);
    if (gene_off) e->gene_off.assign(gene_off, gene_off + e->n_genes + 1);
    else {

@@ -373,6 +373,7 @@ struct paml_amd_engine {
    std::vector<double> h_qfactor;    // ... and its Qfactors [K][n_labels]
    DevBuf<PmatRes> d_pres;           // PmatArgs::res: the resolved (parameter set, node) table of single evaluations
    bool pres_valid = false;          // ... is current (dropped by set_tree / set_classes / any set_eigen_*)
+   int plain_codes = 0;             // set_tips: codes below this are single states equal to the code
    bool rowmajor_valid = false;      // d_rowmajor holds the last evaluation's matrices (pmat_mfma_kernel in the mfma64 layout does not write them)
    DevBuf<EigenDev> d_eigen;
    // batched decomposition on the device (paml_amd_set_eigen_qrev_batch): inputs and the table of the sets' buffer pointers

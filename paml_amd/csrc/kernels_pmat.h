@@ -422,7 +422,11 @@ __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv
       ua4[i] = (ai < n && k < n) ? es.U[ai * n + k] : 0.0;
    }
    if (tid < 64) sE[tid] = (tid < n && !(t < 1e-100)) ? expm1(t * es.Root[tid]) : 0.0;      // (t < 1e-100: P = I, tools.c:521)
-   if (leaf) {      // the ambiguity map (tools.c:20 nChara / CharaMap) for the column tables below
+   // the ambiguity map (tools.c:20 nChara / CharaMap) for the column tables below — only where there ARE ambiguity codes: the first
+   // a.plain_codes codes are single states equal to the code (all of them with cleandata), and staging 3.7 KB byte by byte in front of
+   // the matrix product was 1.8 of the kernel's 6.8 us at 23 matrices, 2.4 of 16.8 at 253 (profiles/r05_pmat_phases.txt)
+   const int plain = a.plain_codes;
+   if (leaf && a.n_codes > plain) {
       for (int idx = tid; idx < a.n_codes * n; idx += 256) sMap[idx] = a.chara_map[idx];
       for (int idx = tid; idx < a.n_codes; idx += 256) sNch[idx] = a.n_chara[idx];
    }
@@ -454,9 +458,10 @@ __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv
    if (!leaf) {
       // MFMA A-operand order: element ((kb2*4 + jb)*64 + lane)*2 + e  =  P[jb*16 + (lane&15)][4*(2*kb2+e) + (lane>>4)]; jb = rb here
       double *pf = a.pint + slot * 4096;
-      for (int idx = tid; idx < 1024; idx += 256) {
-         const int e = idx & 1, ln = (idx >> 1) & 63, kb2 = idx >> 7;
-         pf[((kb2 * 4 + rb) * 64 + ln) * 2 + e] = sP[(ln & 15) * 65 + 4 * (2 * kb2 + e) + (ln >> 4)];
+      for (int idx = tid; idx < 512; idx += 256) {      // (a lane's pair e = 0, 1 is one 16-byte store)
+         const int ln = idx & 63, kb2 = idx >> 6;
+         const double *sp = sP + (ln & 15) * 65 + 8 * kb2 + (ln >> 4);
+         *(double2 *)(pf + ((kb2 * 4 + rb) * 64 + ln) * 2) = make_double2(sp[0], sp[4]);
       }
       // column 60 as pcol[q][m] = P[4m + q][60] (the per-tree kernel's rank-1 term): the rows of this block
       if (a.pcol && tid < 64) {
@@ -468,16 +473,22 @@ __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv
       // column sums over each character code's state set (codeml.c:3555-3567), table [code][q][slot] with the XOR swizzle of the
       // pieces (pmat_kernel_t): the entries whose row jj = 4m + q lies in this block
       double *pt = a.ptip + slot * a.tip_words;
-      for (int idx = tid; idx < a.n_codes * 16; idx += 256) {
-         const int code = idx >> 4, il = idx & 15, jj = rb * 16 + il, q = jj & 3, m = jj >> 2;
-         const int row = code * 4 + q, w = q * 16 + ((((m >> 1) ^ TIP_SWZ(row)) & 7) << 1) + (m & 1);
-         double s2 = 0;
-         if (jj < n) {
-            const int nc = sNch[code];
-            const unsigned char *map = sMap + code * n;
-            for (int k = 0; k < nc; k++) s2 += sP[il * 65 + map[k]];
+      for (int idx = tid; idx < a.n_codes * 8; idx += 256) {      // (rows jj and jj + 4 — m and m + 1, same q — are neighbours: one 16-byte store)
+         const int code = idx >> 3, q = idx & 3, mh = (idx >> 2) & 1, il = q + 8 * mh, jj = rb * 16 + il, m = jj >> 2;
+         const int row = code * 4 + q, w = q * 16 + ((((m >> 1) ^ TIP_SWZ(row)) & 7) << 1);
+         double s2[2] = {0, 0};
+#pragma unroll
+         for (int h = 0; h < 2; h++) {
+            const int ilh = il + 4 * h;
+            if (jj + 4 * h >= n) continue;
+            if (code < plain) s2[h] = sP[ilh * 65 + code];
+            else {
+               const int nc = sNch[code];
+               const unsigned char *map = sMap + code * n;
+               for (int k = 0; k < nc; k++) s2[h] += sP[ilh * 65 + map[k]];
+            }
          }
-         pt[code * 64 + w] = s2;
+         *(double2 *)(pt + code * 64 + w) = make_double2(s2[0], s2[1]);
       }
    }
 }

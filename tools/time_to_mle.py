@@ -19,7 +19,7 @@ for gname, prog, ctl in CASES:
     t0 = time.perf_counter()
     r = a.optimize(a.default_x())
     dt = time.perf_counter() - t0
-    line = "%-14s np %3d  lnL %.6f (reference %.6f)  %5d evaluations  %.2f s" % (gname, a.np, r["lnL"], g.get("mle_lnL", g["lnL"]), r["n_eval"], dt)
+    line = "%-14s np %3d  lnL %.6f (reference %.6f)  %5d evaluations  %.3f s" % (gname, a.np, r["lnL"], g.get("mle_lnL", g["lnL"]), r["n_eval"], dt)
     if gname in ("lyso_bsa", "ecp_cmc", "ecp_cmd"):
         t0 = time.perf_counter()
         a.beb_acd(r["x"])
