@@ -379,6 +379,12 @@ __global__ __launch_bounds__(256) void pmat_kernel_t(PmatArgs a, InlineVec iv)
 // layout is complete per row block — rowmajor rows, the prune kernels' A-operand order [k-block pair][ROW BLOCK][lane][2], the
 // q-major entries of column 60, the rows jj = 4m + q of the tips' column tables — so the four workgroups of a matrix share nothing.
 // ------------------------------------------------------------------------------------------------
+typedef double pm_v2d __attribute__((ext_vector_type(2)));
+// Large launches (PmatArgs::nt_stores: from 128 matrices on) send the output blocks out with streaming stores: they are read by the NEXT
+// kernel, on every XCD, and through a write-back L2 they only start for memory at this kernel's end — 253 matrices (13 MB): the kernel
+// 14.2 -> 11.6 us, the walk behind it 17.3 -> 18.8 (its first reads now miss), the evaluation 31.8 -> 30.4; at 23 matrices the walk loses
+// what this kernel gains and more (20.7 -> 22.1), so small launches keep plain stores (profiles/r05_pmat_phases.txt).
+#define PMAT_ST2(P, X, Y) do { if (a.nt_stores) __builtin_nontemporal_store((pm_v2d){X, Y}, (pm_v2d *)(P)); else *(pm_v2d *)(P) = (pm_v2d){X, Y}; } while (0)
 __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv)
 {
    __shared__ double sE[64];
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv
       for (int idx = tid; idx < 512; idx += 256) {      // (a lane's pair e = 0, 1 is one 16-byte store)
          const int ln = idx & 63, kb2 = idx >> 6;
          const double *sp = sP + (ln & 15) * 65 + 8 * kb2 + (ln >> 4);
-         *(double2 *)(pf + ((kb2 * 4 + rb) * 64 + ln) * 2) = make_double2(sp[0], sp[4]);
+         PMAT_ST2(pf + ((kb2 * 4 + rb) * 64 + ln) * 2, sp[0], sp[4]);
       }
       // column 60 as pcol[q][m] = P[4m + q][60] (the per-tree kernel's rank-1 term): the rows of this block
       if (a.pcol && tid < 64) {
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv
                for (int k = 0; k < nc; k++) s2[h] += sP[ilh * 65 + map[k]];
             }
          }
-         *(double2 *)(pt + code * 64 + w) = make_double2(s2[0], s2[1]);
+         PMAT_ST2(pt + code * 64 + w, s2[0], s2[1]);
       }
    }
 }
