@@ -450,15 +450,21 @@ def self_launch(n):
     (rank 0 prints the one line).  Returns the launcher's exit status."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, PAML_AMD_BENCH_SELF_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: what RCCL across processes needs on this driver)
     env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    for attempt in range(4):      # (the port is free when it is picked; a second or two later, when the launcher binds it, it may not be)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        err = r.stderr.decode(errors="replace")
+        if r.returncode != 0 and attempt < 3 and ("EADDRINUSE" in err or "address already in use" in err.lower()):
+            continue
+        sys.stderr.write(err)
+        break
     lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
     for ln in lines[-1:]:
         sys.stdout.write(ln + "\n")

@@ -82,9 +82,8 @@ void launch_pmat(const PmatArgs &pa, const InlineVec &iv, int n_nodes, int psets
    const int gx = (n_nodes + std::max(pa.npb, 1) - 1) / std::max(pa.npb, 1);
    if (mfma) {
       static const int nt_env = getenv("PAML_AMD_PMAT_NT") ? atoi(getenv("PAML_AMD_PMAT_NT")) : -1;      // (experiments: 0 / 1 for every launch)
-      PmatArgs pb = pa;
-      pb.nt_stores = nt_env >= 0 ? nt_env : ((long)n_nodes * psets >= 128);
-      hipLaunchKernelGGL(pmat_mfma_kernel, dim3(n_nodes, psets, 4), dim3(256), 0, s, pb, iv);
+      if (nt_env >= 0 ? nt_env != 0 : (long)n_nodes * psets >= 128) hipLaunchKernelGGL(pmat_mfma_kernel<true>, dim3(n_nodes, psets, 4), dim3(256), 0, s, pa, iv);
+      else hipLaunchKernelGGL(pmat_mfma_kernel<false>, dim3(n_nodes, psets, 4), dim3(256), 0, s, pa, iv);
    }
    else if (small) hipLaunchKernelGGL(pmat_small_kernel, dim3((n_nodes * psets + 7) / 8), dim3(256), 0, s, pa, iv);
    else if (pa.n <= 32 && pa.layout != 1 && pa.layout != 3) hipLaunchKernelGGL(pmat_kernel_t<32>, dim3(gx, psets), dim3(256), 2 * 32 * 32 * sizeof(double), s, pa, iv);

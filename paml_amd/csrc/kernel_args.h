@@ -30,7 +30,6 @@ struct PmatArgs {
    const int *n_chara;           // [n_codes]
    const unsigned char *chara_map; // [n_codes][n]
    int plain_codes;               // codes 0 .. plain_codes - 1 are single states equal to the code (pmat_mfma_kernel: no map needed for them)
-   int nt_stores;                 // pmat_mfma_kernel: streaming stores for the output blocks (launch_pmat: large launches)
    double *rowmajor;             // [pset][n_nodes][n*n]
    double *pint;                 // layout 1: [pset][n_nodes][4096]
    double *ptip;                 // [pset][n_nodes][tip_words]   rows of n (VALU) or 64 (mfma64) doubles per code

@@ -380,11 +380,13 @@ __global__ __launch_bounds__(256) void pmat_kernel_t(PmatArgs a, InlineVec iv)
 // q-major entries of column 60, the rows jj = 4m + q of the tips' column tables — so the four workgroups of a matrix share nothing.
 // ------------------------------------------------------------------------------------------------
 typedef double pm_v2d __attribute__((ext_vector_type(2)));
-// Large launches (PmatArgs::nt_stores: from 128 matrices on) send the output blocks out with streaming stores: they are read by the NEXT
+// Large launches (launch_pmat: from 128 matrices on) send the output blocks out with streaming stores: they are read by the NEXT
 // kernel, on every XCD, and through a write-back L2 they only start for memory at this kernel's end — 253 matrices (13 MB): the kernel
 // 14.2 -> 11.6 us, the walk behind it 17.3 -> 18.8 (its first reads now miss), the evaluation 31.8 -> 30.4; at 23 matrices the walk loses
 // what this kernel gains and more (20.7 -> 22.1), so small launches keep plain stores (profiles/r05_pmat_phases.txt).
-#define PMAT_ST2(P, X, Y) do { if (a.nt_stores) __builtin_nontemporal_store((pm_v2d){X, Y}, (pm_v2d *)(P)); else *(pm_v2d *)(P) = (pm_v2d){X, Y}; } while (0)
+// (two instantiations: behind a run-time flag the compiler merges the two stores into the plain one)
+#define PMAT_ST2(P, X, Y) do { if (NT) __builtin_nontemporal_store((pm_v2d){X, Y}, (pm_v2d *)(P)); else *(pm_v2d *)(P) = (pm_v2d){X, Y}; } while (0)
+template <bool NT>
 __global__ __launch_bounds__(256) void pmat_mfma_kernel(PmatArgs a, InlineVec iv)
 {
    __shared__ double sE[64];
