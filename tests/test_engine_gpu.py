@@ -545,7 +545,8 @@ def test_20_state_matrix_core_kernel_beyond_the_lds_capacity(n_tips, K, scale_ev
     assert abs(out2["lnL"] - out["lnL"]) <= 1e-11 * abs(out["lnL"])
 
 
-@pytest.mark.parametrize("n,n_tips,n_patt,K,jit", [(61, 90, 300, 1, True), (61, 130, 140, 1, True), (61, 200, 300, 2, True), (61, 230, 130, 1, True), (61, 7, 1, 2, False),
+@pytest.mark.parametrize("n,n_tips,n_patt,K,jit", [(61, 90, 300, 1, True), (61, 130, 140, 1, True), (61, 200, 300, 2, True), (61, 230, 130, 1, True), (61, 208, 129, 1, True),
+                                                   (61, 300, 129, 1, True), (61, 410, 140, 2, True), (61, 7, 1, 2, False),
                                                    (61, 12, 129, 20, True), (33, 9, 200, 2, False), (4, 150, 1000, 1, True),
                                                    (5, 40, 777, 2, True), (20, 60, 500, 1, False)])
 def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch):
@@ -558,7 +559,7 @@ def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch
     eng, out, ref = check(pb)
     if n == 61 and n_tips in (130, 200):
         assert eng.kernel_name == "mfma64_jit"             # one tip-code block
-    if n == 61 and n_tips == 230:
+    if n == 61 and n_tips > 207:      # (208: the first size in halves; 410: next to the limit of ~413; random topologies, ambiguity codes, scaling nodes)
         assert eng.kernel_name == "mfma64_jit"             # two half blocks of tip codes per tile
         # ... the same values from the interpreter kernels
         monkeypatch.setenv("PAML_AMD_JIT", "0")
