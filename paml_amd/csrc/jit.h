@@ -147,7 +147,9 @@ inline std::string jit_program_key(const Program &p, int n_tips)
 // the next instruction does as well as a compiler-visible one: profiles/r05_big_tree_split.txt).  Programs of more than JIT_SPLIT_OPS ops
 // get a never-taken uniform branch (JIT_SPLIT) every eighth op; the compiler then also works on blocks of a few thousand instructions
 // instead of one of 10^5 (192 taxa: 28 s instead of 130 on this container's core).   0: none, 1: s_branch, 2: JIT_SPLIT
-static const size_t JIT_SPLIT_OPS = 120;
+// Small programs get the compiler-visible form too: no front-end effect there (a bare s_branch changes nothing at 16 taxa), but the
+// compiler's schedule of the shorter blocks measures 0.6 % faster (kernel 1.554 -> 1.544 ms at 16 taxa x 10^6 patterns, two runs each).
+static const size_t JIT_SPLIT_OPS = 8;
 inline int jit_split_mode(size_t nops)
 {
    if (const char *v = getenv("PAML_AMD_JIT_SPLIT")) return !strcmp(v, "asm") ? 1 : !strcmp(v, "br") ? 2 : 0;
