@@ -546,7 +546,7 @@ def test_20_state_matrix_core_kernel_beyond_the_lds_capacity(n_tips, K, scale_ev
 
 
 @pytest.mark.parametrize("n,n_tips,n_patt,K,jit", [(61, 90, 300, 1, True), (61, 130, 140, 1, True), (61, 200, 300, 2, True), (61, 230, 130, 1, True), (61, 208, 129, 1, True),
-                                                   (61, 300, 129, 1, True), (61, 410, 140, 2, True), (61, 7, 1, 2, False),
+                                                   (61, 410, 140, 2, True), (61, 7, 1, 2, False),
                                                    (61, 12, 129, 20, True), (33, 9, 200, 2, False), (4, 150, 1000, 1, True),
                                                    (5, 40, 777, 2, True), (20, 60, 500, 1, False)])
 def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch):
