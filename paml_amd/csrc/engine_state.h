@@ -18,6 +18,7 @@
 #include <string>
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -200,6 +201,27 @@ struct EnvCfg {
 
 using namespace paml_amd;
 
+// Worker threads that are still compiling when the PROCESS exits — a caller that never destroys its engine, like the reference with the
+// binding patched in, after a run shorter than the compilation: exit() would run the static destructors of hiprtc / comgr under them
+// (a segmentation fault after the results were written).  Every job's thread is listed here, and an atexit handler — registered after
+// the list's own statics, so it runs before they go — joins what is still running.
+inline void worker_threads_list(std::thread *th, bool add)
+{
+   static std::mutex m;
+   static std::vector<std::thread *> live;
+   static const bool registered = (atexit([]() { worker_threads_list(nullptr, false); }), true);
+   (void)registered;
+   std::vector<std::thread *> to_join;
+   {
+      std::lock_guard<std::mutex> lk(m);
+      if (th && add) live.push_back(th);
+      else if (th) live.erase(std::remove(live.begin(), live.end(), th), live.end());
+      else to_join = live;      // the process is exiting
+   }
+   for (std::thread *t : to_join)
+      if (t->joinable()) t->join();
+}
+
 struct paml_amd_engine {
    int n = 0, n_tips = 0, n_patt = 0, max_classes = 0, n_genes = 1;
    unsigned flags = 0;
@@ -362,6 +384,8 @@ struct paml_amd_engine {
       int stage = 2;                  // large trees: 1 = the quick build (JIT_BIG_FLAGS), 2 = the full one that replaces it
       std::string key, src, log;
       std::vector<char> code;
+      JitJob() { worker_threads_list(&th, true); }
+      ~JitJob() { if (th.joinable()) th.join(); worker_threads_list(&th, false); }
    };
    std::unique_ptr<JitJob> jit_job, coop_job;
    std::string jit_failed_key, coop_failed_key;

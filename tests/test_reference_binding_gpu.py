@@ -217,6 +217,17 @@ def test_single_evaluation_through_the_patched_reference_matches_the_printed_dig
         assert abs(lnl2 - g["lnL"]) <= 2e-6
 
 
+def test_a_run_shorter_than_its_background_compilation_exits_cleanly(tmp_path):
+    """A small data set's cooperative per-tree kernel is compiled on a worker thread while the interpreter serves; a single evaluation
+    is over long before (0.3 s against ~1 s), and the reference never destroys its engine: exit() used to run hiprtc's static
+    destructors under the compiling thread (SIGSEGV after the results were written — seen only where no earlier run had left the code
+    object in the cache).  The library now joins its worker threads at exit.  PAML_AMD_JIT_CACHE=0: nothing cached, every run compiles."""
+    need_binaries()
+    for i in range(2):
+        g, lnl, lnf, out = single_evaluation("codeml", "lysos_branch_fix", tmp_path / ("run%d" % i), REF_GPU, env=dict(os.environ, PAML_AMD_JIT_CACHE="0"))
+        assert abs(lnl - g["lnL"]) <= 2e-6
+
+
 OPT_CASES = [("lyso_bsa", "", -1035.533916), ("ecp_cmc", "", None), ("lysin_mg2", "", None), ("lysos_branch_fix", "", None),
              ("hiv_m0", "method = 1\n", -1137.688190), ("hiv_m2a", "method = 1\n", -1106.445004),
              # (branch-site A under method = 1 stops at -1035.530508 — the UNMODIFIED program does exactly that on this control file, 12 s on
