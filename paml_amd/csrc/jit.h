@@ -122,6 +122,18 @@ inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 
 // no faster (1.573 against 1.569 ms at 16 taxa x 10^6 patterns): the 45 extra operand fetches, the row-60 dot product and their waits
 // take out of the shared issue port what the dropped rows put in.  Kept behind PAML_AMD_JIT_ROWTAIL=1; the default is the
 // four-row-block form.
+// Timing experiments whose kernels compute garbage (ablations: no barriers, no rank-1 seed, skewed waves, resident partials not stored,
+// tip factors / operands left out): read only by a library built with -DPAML_AMD_JIT_EXPERIMENTS (PAML_AMD_EXTRA_FLAGS + engine.build(),
+// tools/build_variant.sh); a production library ignores the variables.
+inline const char *jit_experiment_env(const char *name)
+{
+#ifdef PAML_AMD_JIT_EXPERIMENTS
+   return getenv(name);
+#else
+   (void)name;
+   return nullptr;
+#endif
+}
 inline bool jit_rowtail(int n_states) { return n_states == 61 && getenv("PAML_AMD_JIT_ROWTAIL") && !getenv("PAML_AMD_JIT_NOTAIL"); }
 
 inline std::string jit_program_key(const Program &p, int n_tips)
@@ -197,11 +209,13 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
 #ifdef TIP_SWZ_OFF
    s << "#define TIP_SWZ_OFF 1\n";      // (the library's P(t) kernel writes the tip tables without the swizzle: the per-tree kernel must read them so)
 #endif
-   if (const char *v = getenv("PAML_AMD_JIT_STORE")) s << "#define JIT_STORE_MODE " << atoi(v) << "\n";      // experiment: how STORE writes (device_common.h)
+   // how STORE writes (device_common.h): 0 spread under the next product (default), 1 at the op; 2 — not at all, the ceiling measurement — is an experiment
+   if (const char *v = getenv("PAML_AMD_JIT_STORE"))
+      if (atoi(v) != 2 || jit_experiment_env("PAML_AMD_JIT_STORE")) s << "#define JIT_STORE_MODE " << atoi(v) << "\n";
    if (getenv("PAML_AMD_JIT_NT_STORE")) s << "#define JIT_NT_STORE 1\n";         // experiment: non-temporal stores of the class likelihoods
-   if (getenv("PAML_AMD_JIT_ABL_NOSEED")) s << "#define JIT_ABL_NOSEED 1\n";      // timing experiment: the rank-1 seed without its LDS reads and multiplies
-   if (getenv("PAML_AMD_JIT_ABL_NOBAR")) s << "#define JIT_ABL_NOBAR 1\n";      // timing experiment: no workgroup barriers (results are garbage)
-   const char *abl_skew = getenv("PAML_AMD_JIT_ABL_SKEW");                       // ... and waves 4-7 start this many x 64 cycles late
+   if (jit_experiment_env("PAML_AMD_JIT_ABL_NOSEED")) s << "#define JIT_ABL_NOSEED 1\n";      // timing experiment: the rank-1 seed without its LDS reads and multiplies
+   if (jit_experiment_env("PAML_AMD_JIT_ABL_NOBAR")) s << "#define JIT_ABL_NOBAR 1\n";      // timing experiment: no workgroup barriers (results are garbage)
+   const char *abl_skew = jit_experiment_env("PAML_AMD_JIT_ABL_SKEW");                       // ... and waves 4-7 start this many x 64 cycles late
    if (zsingle) s << "#define JIT_ZB 1\n";
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
    s << "extern \"C\" __global__ __launch_bounds__(" << waves * 64 << ", " << waves / 4 << ") void prune_jit(PruneArgs a)\n{\n";
@@ -1067,7 +1081,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    std::vector<int> mm_nodes;
    for (const Op &o : p.ops)
       if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) { mm_nodes.push_back(o.a); nmm++; }
-   if (const char *abl = getenv("PAML_AMD_M20_ABL")) {      // timing experiments (results are garbage)
+   if (const char *abl = jit_experiment_env("PAML_AMD_M20_ABL")) {      // timing experiments (results are garbage)
       if (strstr(abl, "notip")) s << "#define M20_ABL_NOTIP 1\n";
       if (strstr(abl, "noa")) s << "#define M20_ABL_NOA 1\n";
    }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The keep-partials evaluation at the benchmark's size (16 taxa x 10^6 codon patterns, every internal node's partial stored: 7.2 GB per
-evaluation) under the store variants of the per-tree kernel.  usage: PAML_AMD_JIT_STORE=<0|1|2> python tools/keep_probe.py [n_evals]"""
+evaluation) under the store variants of the per-tree kernel.  usage: PAML_AMD_JIT_STORE=<0|1|2> python tools/keep_probe.py [n_evals]
+(2, no stores at all, only with a library built with -DPAML_AMD_JIT_EXPERIMENTS)"""
 import os
 import sys
 import time
