@@ -23,6 +23,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed by paml_amd_comm_* (see Rccl below)
 
 #include "../../include/paml_amd.h"
@@ -208,15 +209,17 @@ using namespace paml_amd;
 inline void worker_threads_list(std::thread *th, bool add)
 {
    static std::mutex m;
-   static std::vector<std::thread *> live;
+   static std::vector<std::pair<std::thread *, pid_t>> live;      // (the process that started the thread: a fork()ed child has the list, not the threads)
    static const bool registered = (atexit([]() { worker_threads_list(nullptr, false); }), true);
    (void)registered;
    std::vector<std::thread *> to_join;
    {
       std::lock_guard<std::mutex> lk(m);
-      if (th && add) live.push_back(th);
-      else if (th) live.erase(std::remove(live.begin(), live.end(), th), live.end());
-      else to_join = live;      // the process is exiting
+      if (th && add) live.emplace_back(th, getpid());
+      else if (th) live.erase(std::remove_if(live.begin(), live.end(), [th](const std::pair<std::thread *, pid_t> &e) { return e.first == th; }), live.end());
+      else      // the process is exiting
+         for (const auto &e : live)
+            if (e.second == getpid()) to_join.push_back(e.first);
    }
    for (std::thread *t : to_join)
       if (t->joinable()) t->join();
