@@ -205,6 +205,11 @@ int paml_amd_eval(paml_amd_engine *e, const double *branch, const double *gene_r
  * of the engine does it implicitly.  Give every evaluation of a run its own d_lnL slot if all values are wanted. */
 int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double *gene_rate, double *d_lnL);
 int paml_amd_flush(paml_amd_engine *e);
+/* The device eigen-decompositions queued so far (paml_amd_set_eigen_qrev_batch): waits for the engine's stream and returns
+ * PAML_AMD_ENOCONV if one of them reached its sweep limit — what every synchronous entry point (eval, eval_batch, eval_dirty, eval_branch,
+ * eval_adg, beb_grid*, node_posterior) reports by itself; for callers of eval_device, which never synchronises.  paml_amd_flush reports
+ * a failure that has already been recorded, without waiting. */
+int paml_amd_eigen_status(paml_amd_engine *e);
 
 /* Re-evaluate after a change that leaves the partials of the nodes with clean[node] != 0 valid
  * (com.oldconP, codeml.c:112, treespace.c:250): those subtrees are read back instead of recomputed.

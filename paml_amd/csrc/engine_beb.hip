@@ -69,7 +69,7 @@ int paml_amd_beb_grid(paml_amd_engine *e, int n_grid, int n_cls, const double *p
    HIPCHK(hipMemcpyAsync(sd_w, a.sd_w, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    if (ln_fx) HIPCHK(hipMemcpyAsync(ln_fx, a.fx, sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
-   return 0;
+   return eigen_fail_check(e);      // (the grid's class likelihoods come from eigen systems a set_eigen_qrev_batch may have left unconverged)
 }
 
 int paml_amd_beb_grid_classes(paml_amd_engine *e, int n_grid, int n_cls, const double *pcl, const int *iw, double *ln_fx, double *post)
@@ -85,7 +85,7 @@ int paml_amd_beb_grid_classes(paml_amd_engine *e, int n_grid, int n_cls, const d
    HIPCHK(hipMemcpyAsync(post, a.pr_last, (size_t)n_cls * np * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    if (ln_fx) HIPCHK(hipMemcpyAsync(ln_fx, a.fx, sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
-   return 0;
+   return eigen_fail_check(e);      // (the grid's class likelihoods come from eigen systems a set_eigen_qrev_batch may have left unconverged)
 }
 
 }  // extern "C"

@@ -680,7 +680,7 @@ int paml_amd_node_posterior(paml_amd_engine *e, int node, const double *branch, 
    HIPCHK(hipGetLastError());
    HIPCHK(hipMemcpyAsync(post, e->d_expB.p, (size_t)e->n_patt * n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    HIPCHK(hipStreamSynchronize(e->stream));
-   return 0;
+   return eigen_fail_check(e);
 }
 
 }  // extern "C"

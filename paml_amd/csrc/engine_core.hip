@@ -163,6 +163,7 @@ int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata,
       launch_zpm(e->d_z.p, (long)e->n_patt, e->n_tips, e->n_patt, e->zpm_words, e->d_zpm.p, e->stream);
    }
    HIPCHK(hipStreamSynchronize(e->stream));
+   e->tile_stash.built_for = 0;      // (the other tile size's tables described the previous data)
    int r = build_tiles(e);
    if (r) return r;
    {  // state sets of the character codes as bit masks (tip ends of a branch in the branch-local evaluation)
@@ -484,7 +485,8 @@ int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double
        node == e->tree.root)
       return fail(e, PAML_AMD_EINVAL, "get_pmat: index out of range");
    const size_t nn2 = (size_t)e->n * e->n;
-   const size_t slot = (size_t)(gene * e->K + iclass) * e->tree.n_nodes + node;
+   // (after a batched evaluation the kernels saw K x B classes per gene: element 0's matrices)
+   const size_t slot = ((size_t)gene * e->K * std::max(1, e->pmat_B) + iclass) * e->tree.n_nodes + node;
    if (e->rowmajor_valid) {
       const double *src = e->d_rowmajor.p + slot * nn2;
       HIPCHK(hipMemcpyAsync(P, src, nn2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -505,6 +507,10 @@ int paml_amd_get_pmat(paml_amd_engine *e, int gene, int iclass, int node, double
          }
       return 0;
    }
+   // (... which holds for every code table the reference builds — the states come first — but is the caller's choice at this boundary)
+   if (e->plain_codes < n)
+      return fail(e, PAML_AMD_EUNSUPPORTED, "get_pmat: a tip branch's matrix is rebuilt from the tip's column table, which needs the codes 0 .. n-1 to be the "
+                                            "single states (set_tips); PAML_AMD_PMAT_ROWMAJOR=1 keeps the row-major copies");
    const size_t tw = tip_words(e);
    std::vector<double> tab(tw);
    HIPCHK(hipMemcpyAsync(tab.data(), e->d_ptip.p + slot * tw, tw * sizeof(double), hipMemcpyDeviceToHost, e->stream));

@@ -45,6 +45,7 @@ int build_tiles(paml_amd_engine *e)
                          e->d_weights.p, e->n_tips, e->zt_bytes, e->d_ztiles.p, half ? (const int *)e->d_ztip_of.p : (const int *)nullptr, half ? zp.H : 0);
    }
    HIPCHK(hipStreamSynchronize(e->stream));
+   e->tiles_built_for = e->tile_patt;
    return 0;
 }
 
@@ -302,23 +303,31 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          if (!background) {
             int r = ensure_jit(e, key, [&]() { return jit_strip_big(jit_generate(e->prog, e->n_tips, n, e->n_codes, jw)); }, &jit_ok);
             if (r) return r;
-            if (jit_ok) e->jit_stage = 2;
+            if (jit_ok) { e->jit_stage = 2; e->jit.stage = 2; }
          }
          else {
+            // (a code object is loaded beside the kernel in use and replaces it only when the load succeeded: a full build that does not
+            //  load leaves the quick one serving, and its key is remembered so that it is not built again and again)
             auto load = [&](const std::vector<char> &code, int stage) {
+               JitKernel nk;
+               if (jit_load_code(code, &nk) != 0) {
+                  if (nk.mod) (void)hipModuleUnload(nk.mod);
+                  return false;
+               }
                if (e->jit.mod) (void)hipModuleUnload(e->jit.mod);
-               e->jit = JitKernel();
-               if (jit_load_code(code, &e->jit) == 0) { e->jit.key = key; e->jit_stage = stage; return true; }
-               e->jit = JitKernel();
-               e->jit_stage = 0;
-               return false;
+               e->jit = nk;
+               e->jit.key = key; e->jit.stage = stage; e->jit_stage = stage;
+               return true;
             };
-            if (!(e->jit.fn && e->jit.key == key)) e->jit_stage = 0;      // (another tree's kernel, or none)
+            e->jit_stage = (e->jit.fn && e->jit.key == key) ? e->jit.stage : 0;      // (another tree's kernel, or none: stage 0)
             paml_amd_engine::JitJob *job = e->jit_job.get();
             if (job && job->state.load() >= 2 && job->th.joinable()) job->th.join();
             if (job && job->state.load() >= 2) {
                if (job->key == key && job->state.load() == 2) {          // a code object is there: load it and change over
-                  if (!load(job->code, job->stage)) (job->stage == 1 ? e->jit_failed_key : e->jit_stage2_failed_key) = key;
+                  if (!load(job->code, job->stage)) {
+                     (job->stage == 1 ? e->jit_failed_key : e->jit_stage2_failed_key) = key;
+                     e->err = "jit: hipModuleLoadData failed";
+                  }
                }
                else if (job->key == key) {                               // failed
                   (job->stage == 1 ? e->jit_failed_key : e->jit_stage2_failed_key) = key;
@@ -327,26 +336,22 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
                e->jit_job.reset();
                job = nullptr;
             }
-            if (!job && e->jit_stage < 2 && e->jit_failed_key != key && !(e->jit_stage == 1 && e->jit_stage2_failed_key == key)) {
+            auto may_build = [&](int stage) { return (stage == 1 ? e->jit_failed_key : e->jit_stage2_failed_key) != key; };
+            // two-stage build (generators without block splits only): the quick kernel first, the full one replaces it; else the one build
+            const bool two = jit_split_mode(e->prog.ops.size()) != 2 && !getenv("PAML_AMD_JIT_ONE_STAGE");
+            const int next = (e->jit_stage == 0 && two && may_build(1)) ? 1 : 2;
+            if (!job && e->jit_stage < 2 && may_build(next)) {
                const std::string quick = jit_generate(e->prog, e->n_tips, n, e->n_codes, jw), full = jit_strip_big(quick);
                std::vector<char> code;
-               if (e->jit_stage == 0) {
-                  if (jit_cached_code(full, &code)) (void)load(code, 2);
-                  else if (jit_cached_code(quick, &code)) (void)load(code, 1);
+               if (e->jit_stage == 0) {      // a code object on disk is loaded at once
+                  if (may_build(2) && jit_cached_code(full, &code)) { if (!load(code, 2)) e->jit_stage2_failed_key = key; }
+                  else if (next == 1 && quick != full && jit_cached_code(quick, &code)) { if (!load(code, 1)) e->jit_failed_key = key; }
                }
-               if (e->jit_stage < 2 && !getenv("PAML_AMD_JIT_ONE_STAGE") && quick != full) {
+               const int st = (e->jit_stage == 0 && next == 1 && quick != full) ? 1 : 2;
+               if (e->jit_stage < st && may_build(st)) {
                   e->jit_job.reset(new paml_amd_engine::JitJob());
                   job = e->jit_job.get();
-                  job->key = key;
-                  job->stage = e->jit_stage + 1;
-                  job->src = job->stage == 1 ? quick : full;
-                  job->state.store(1);
-                  job->th = std::thread([job]() { job->state.store(jit_compile_code(job->src, &job->code, &job->log) == 0 ? 2 : 3); });
-               }
-               else if (e->jit_stage == 0) {      // PAML_AMD_JIT_ONE_STAGE (measurements): the full build only, in the background
-                  e->jit_job.reset(new paml_amd_engine::JitJob());
-                  job = e->jit_job.get();
-                  job->key = key; job->stage = 2; job->src = full;
+                  job->key = key; job->stage = st; job->src = st == 1 ? quick : full;
                   job->state.store(1);
                   job->th = std::thread([job]() { job->state.store(jit_compile_code(job->src, &job->code, &job->log) == 0 ? 2 : 3); });
                }
@@ -358,11 +363,20 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       const bool big_tiles = jit_ok || lean;
       const int want_waves = jit_ok ? jw : (lean ? DMA_WAVES : GATHER_WAVES);
       if (big_tiles != e->mfma_dma || want_waves != e->mfma_waves) {
+         // (the tables of the tile size being left are kept: an engine that alternates between two kernels swaps them, see TileStash)
+         e->swap_tile_stash();
          e->mfma_dma = big_tiles;
          e->mfma_waves = want_waves;
          e->tile_patt = e->mfma_waves * 16;
-         int r = build_tiles(e);
-         if (r) return r;      // (the resident partials have ONE layout whatever the tile size, PruneArgs::part_groups: they stay valid)
+         bool have = e->tiles_built_for == e->tile_patt && e->d_tiles.p;
+         if (have && jit_ok && e->tile_patt >= 128 && (e->n_tips > 200 || !e->zt_key.empty())) {      // half mode: rows in the program's order
+            const JitZPlan zp = jit_zplan(e->prog, e->n_tips, e->tile_patt);
+            have = (zp.half ? jit_program_key(e->prog, e->n_tips) : std::string()) == e->zt_key;
+         }
+         if (!have) {
+            int r = build_tiles(e);
+            if (r) return r;      // (the resident partials have ONE layout whatever the tile size, PruneArgs::part_groups: they stay valid)
+         }
       }
       else if (jit_ok && e->tile_patt >= 128 && (e->n_tips > 200 || !e->zt_key.empty())) {      // half mode: the code blocks' rows follow the tree's program
          const JitZPlan zp = jit_zplan(e->prog, e->n_tips, e->tile_patt);
@@ -409,7 +423,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    const int n_blocks = e->n_tiles * K;
    const int n_int = nn - e->n_tips;
    if (keep) {
-      size_t words = e->kk == KK_MFMA64 ? (size_t)K * n_int * e->part_groups() * 1024 + 8 * 1024      // (+ PruneArgs::part_dump)
+      size_t words = e->kk == KK_MFMA64 ? (size_t)K * n_int * e->part_groups() * 1024 + (size_t)std::max(e->mfma_waves, 8) * 1024      // (+ PruneArgs::part_dump: a row per wave)
                                         : (size_t)K * n_int * e->n_patt * n;
       HIPCHK(e->d_partials.ensure(words));
       HIPCHK(e->d_scalef.ensure((size_t)K * std::max(1, e->tree.n_scale) * e->n_patt));
@@ -500,6 +514,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    static const bool want_rowmajor = getenv("PAML_AMD_PMAT_ROWMAJOR") != nullptr;
    if (pmat_mfma && pa.layout == 1 && !want_rowmajor) pa.rowmajor = nullptr;
    e->rowmajor_valid = pa.rowmajor != nullptr;
+   e->pmat_B = B;
    // ... and single evaluations get label -> eigen_of -> eigen set -> U / V / Root resolved on the host (PmatArgs::res)
    if (pmat_mfma && !bs && use_inline && !e->rate_per_gene && !e->eigen.empty()) {
       if (!e->pres_valid) {
@@ -882,6 +897,7 @@ int paml_amd_eval_adg(paml_amd_engine *e, const double *branch, const double *ge
       HIPCHK(hipMemcpyAsync(w.data(), e->d_weights.p, w.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
    }
    HIPCHK(hipStreamSynchronize(e->stream));
+   if (int rc = eigen_fail_check(e)) return rc;
    // the chain over sites in their original order is sequential: host (treesub.c:7456-7492)
    double l = 0;
    if (e->tree.n_scale)
@@ -927,7 +943,18 @@ int paml_amd_eval_device(paml_amd_engine *e, const double *branch, const double 
 int paml_amd_flush(paml_amd_engine *e)
 {
    if (!e) return PAML_AMD_EINVAL;
-   return join_comm(e);
+   if (int rc = join_comm(e)) return rc;
+   // (no host synchronisation here: a decomposition that has ALREADY reported its sweep limit is returned now, one still running is
+   //  caught by the next synchronous entry point — paml_amd_eigen_status waits for it)
+   return eigen_fail_check(e);
+}
+
+int paml_amd_eigen_status(paml_amd_engine *e)
+{
+   if (!e) return PAML_AMD_EINVAL;
+   if (int rc = join_comm(e)) return rc;
+   HIPCHK(hipStreamSynchronize(e->stream));
+   return eigen_fail_check(e);
 }
 
 int paml_amd_eval_dirty(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean,

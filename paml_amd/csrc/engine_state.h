@@ -327,6 +327,24 @@ struct paml_amd_engine {
    DevBuf<int> d_ztip_of;               // half mode of the per-tree kernel's code blocks (jit_zplan): row -> tip
    std::string zt_key;                  // ... of the program the rows were laid out for ("" = tip order)
    DevBuf<int> d_tile_group0;            // mfma64: per tile of the selected kernel, the resident-partial group of its first 16 patterns (PruneArgs::tile_group0)
+   // The tables of the OTHER tile size once built: a keep-partials engine alternates between the per-tree kernel (128-pattern tiles: full
+   // evaluations) and the interpreter (64: eval_dirty's LOAD programs it has no kernel for yet, node posteriors) — the change-over swaps
+   // the two sets instead of uploading, re-laying the code blocks and synchronising twice (build_tiles).  Dropped by set_tips.
+   struct TileStash {
+      int built_for = 0;                 // the tile size the set was built for (0: nothing there)
+      int n_tiles = 0, zt_bytes = 0;
+      std::string zt_key;
+      DevBuf<int2> tiles;
+      DevBuf<int> group0, ztip_of;
+      DevBuf<unsigned char> ztiles;
+   } tile_stash;
+   int tiles_built_for = 0;              // the tile size the current set (d_tiles, d_tile_group0, d_ztiles ...) was built for
+   void swap_tile_stash()
+   {
+      TileStash &t = tile_stash;
+      std::swap(t.built_for, tiles_built_for); std::swap(t.n_tiles, n_tiles); std::swap(t.zt_bytes, zt_bytes); std::swap(t.zt_key, zt_key);
+      std::swap(t.tiles, d_tiles); std::swap(t.group0, d_tile_group0); std::swap(t.ztip_of, d_ztip_of); std::swap(t.ztiles, d_ztiles);
+   }
    int part_groups() const { return n_tiles_full * GATHER_WAVES; }      // 16-pattern groups per (class, node) of the resident partials: the 64-pattern tile table's
    DevBuf<double> d_pi_plain;
    DevBuf<double> d_weights, d_pi, d_freqK, d_rate, d_qfactor, d_branch, d_gene_rate;
@@ -401,6 +419,7 @@ struct paml_amd_engine {
    DevBuf<PmatRes> d_pres;           // PmatArgs::res: the resolved (parameter set, node) table of single evaluations
    bool pres_valid = false;          // ... is current (dropped by set_tree / set_classes / any set_eigen_*)
    int plain_codes = 0;             // set_tips: codes below this are single states equal to the code
+   int pmat_B = 1;                   // batch elements of the evaluation whose P(t) the buffers hold (get_pmat: element 0)
    bool rowmajor_valid = false;      // d_rowmajor holds the last evaluation's matrices (pmat_mfma_kernel in the mfma64 layout does not write them)
    DevBuf<EigenDev> d_eigen;
    // batched decomposition on the device (paml_amd_set_eigen_qrev_batch): inputs and the table of the sets' buffer pointers
@@ -477,6 +496,7 @@ struct paml_amd_engine {
       d_tiles.release();
       d_tiles_full.release();
       d_tile_group0.release();
+      tile_stash.tiles.release(); tile_stash.group0.release(); tile_stash.ztip_of.release(); tile_stash.ztiles.release();
       d_ztip_of.release();
       d_zpm.release();
       d_red_counter.release();

@@ -37,6 +37,7 @@ struct JitKernel {
    hipFunction_t fn = nullptr;
    std::string key;
    size_t n_ops = 0;
+   int stage = 0;            // large trees, two-stage build: which build this is (1 quick, 2 full; 0: compiled while the caller waited)
 };
 
 // Stack slots of the 61-state kernel that live in register arrays (each 32 VGPRs); deeper slots are spilled to global scratch.

@@ -202,13 +202,43 @@ try:      # the flag was consumed: with a host decomposition in the set's place 
     again = eng.eval(pb.tree.branch)["lnL"]
 except engine.EngineError as ex:
     again = str(ex)
+# the other entry points that end with a host synchronisation report it too (round 6): node_posterior, eval_adg (a two-class
+# mixture of the same model: lfundG mode), the BEB grid; and paml_amd_eigen_status for callers of eval_device, which never synchronises
+others = {}
+def attempt(name, f):
+    eng.set_eigen_qrev_batch([0], np.array([Q]), np.array([pi]), np.array([mr]))
+    try:
+        f()
+        others[name] = None
+    except engine.EngineError as ex:
+        others[name] = str(ex)
+    eng.set_eigen(0, pb.eigen[0])
+    eng.eval(pb.tree.branch)      # (and nothing stays latched for the evaluation after it)
+attempt("node_posterior", lambda: eng.node_posterior(pb.tree.root, pb.tree.branch))
+d_out = torch.zeros(1, dtype=torch.float64, device="cuda")
+def dev():
+    eng.eval_device(pb.tree.branch, d_out.data_ptr())
+    eng.eigen_status()
+attempt("eigen_status", dev)
+pb2 = synth.codon_nssites_problem(pb, 2.0, [0.2, 1.0], [0.6, 0.4])
+eng2 = engine.engine_for(pb2)
+eng2.eval(pb2.tree.branch)
+pi2 = np.asarray(pb2.pi, dtype=np.float64).reshape(-1)[:61]
+def adg():
+    eng2.set_eigen_qrev_batch([0], np.array([Q]), np.array([pi2]), np.array([mr]))
+    eng2.eval_adg(pb2.tree.branch, np.full((2, 2), 0.5), np.arange(pb2.n_patt, dtype=np.int32))
+try:
+    adg()
+    others["eval_adg"] = None
+except engine.EngineError as ex:
+    others["eval_adg"] = str(ex)
 # the C host on the same engine library: HIV M2a at the golden's parameters — device decomposition fails, host takes over, same lnL
 g = helpers.load_golden("hiv_m2a")
 a = hostlib.Analysis(os.path.join(helpers.GOLDEN, "ctl", "hiv_ns2.ctl"), "codeml")
 l1 = a.eval_gpu(np.array(g["x"]), want_lnf=False)[0]
 xs = np.stack([np.array(g["x"]), np.array(g["x"]) * 1.01])
 lb = a.eval_batch_gpu(xs)
-print(json.dumps({"first": ok, "code": code, "sweeps": sweeps, "again": again, "host_lnL": l1, "golden": g["lnL"], "batch": lb.tolist()}))
+print(json.dumps({"first": ok, "code": code, "sweeps": sweeps, "again": again, "host_lnL": l1, "golden": g["lnL"], "batch": lb.tolist(), "others": others}))
 """
 
 
@@ -231,3 +261,5 @@ def test_a_device_decomposition_that_does_not_converge_is_reported_and_the_host_
     assert abs(out["host_lnL"] - out["golden"]) <= 2e-6
     assert abs(out["batch"][0] - out["golden"]) <= 2e-6 and out["batch"][1] < out["batch"][0]
     assert b"decomposed on the host from here on" in r.stderr
+    for name in ("node_posterior", "eigen_status", "eval_adg"):
+        assert out["others"][name] is not None and "(code -5)" in out["others"][name], (name, out["others"][name])
