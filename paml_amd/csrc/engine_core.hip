@@ -47,7 +47,7 @@ int paml_amd_create(paml_amd_engine **out, int n_states, int n_tips, int n_patt,
    //  global memory: up to M20_MAX_TIPS taxa — measured at 60: 0.42 of the FP64 peak against the padded 16x16x4 kernel's 0.39; the
    //  packed tip codes of a unit live in registers, 64 VGPRs at 60 taxa, and beyond 64 taxa the walk would spill more than it gains)
    constexpr int M20_MAX_TIPS = 64;
-   e->want_m20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_genes == 1 && n_tips <= (getenv("PAML_AMD_M20_49") ? 49 : M20_MAX_TIPS) && !e->env.no_m20 && !e->env.valu20;
+   e->want_m20 = n_states == 20 && e->jit_enabled && !(flags & PAML_AMD_KEEP_PARTIALS) && n_tips <= (getenv("PAML_AMD_M20_49") ? 49 : M20_MAX_TIPS) && !e->env.no_m20 && !e->env.valu20;
    // ... and SMALL 20-state data sets (at most 4096 patterns, round 4): what counts there is the length of one wave's walk, and the
    // cooperative form of the MFMA interpreter (prune_mfma64_coop: four waves per 16-pattern group, 16 MFMAs per wave and branch on
    // the zero-padded matrices) walks a branch in a sixth of the time of the scalar-operand kernel's 400 dependent FMAs per lane
@@ -94,8 +94,8 @@ const char *paml_amd_kernel_name(const paml_amd_engine *e)
 {
    if (!e) return "";
    switch (e->kk) {
-   case KK_VALU4: return e->use_jit ? (e->fused && e->fused_mfma4 ? "mfma4_jit" : "valu4_jit") : "valu4";
-   case KK_VALU5: return e->use_jit ? "valu5_jit" : "valu5";
+   case KK_VALU4: return e->use_jit ? (e->fused ? (e->fused_mfma4 ? "mfma4_jit" : "valu4_fused_jit") : "valu4_jit") : "valu4";
+   case KK_VALU5: return e->use_jit ? (e->fused ? "valu5_fused_jit" : "valu5_jit") : "valu5";
    case KK_VALU20: return e->use_jit ? (e->m20 ? "mfma4x20_jit" : "valu20_jit") : "valu20";
    default: return e->use_jit ? (e->jit_stage == 1 ? "mfma64_jit_quick" : "mfma64_jit") : (e->mfma_dma ? "mfma64_stream" : (e->coopj ? "mfma64_coopjit" : (e->coop ? "mfma64_coop" : "mfma64_gather")));
    }

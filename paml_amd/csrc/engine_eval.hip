@@ -390,15 +390,23 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       if (e->jit_enabled && !keep && n <= 5 && jit_valu_supported(e->prog)) {
          // the fused form (classes inside, LDS tip tables, reduction in the epilogue) when the model fits it
          const ValuFusedPlan pl = jit_valu_fused_plan(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk);
-         if (pl.ok && G == 1 && e->n_pi == 1 && e->d_zpm.p && !e->env.no_fused) {
+         // Several genes (round 6): the fused form exists (jit_generate_valu_fused with G > 1: one gene's tables at a time, refilled where a
+         // workgroup's chunks cross into the next gene; same bits) and is NOT the default: on MI355X it measures no faster than the unfused
+         // kernel + reduce_stage1, which serve genes for free — a workgroup is one (tile, class) there — 32 taxa x 10^5 patterns x Gamma-4 in 4
+         // genes: one evaluation 0.050 ms fused against 0.030 unfused, a gradient's 122 evaluations in one launch 1.77 against 1.77 ms (one
+         // gene, fused: 0.029 / 1.33).  Why the several-genes form of the same inner loop runs 1.6 x slower than the one-gene form OUTSIDE
+         // the profiler (within 4 % of it under rocprofv3, equal instruction counts) was bisected to the table fill living inside the
+         // chunk loop and not resolved: profiles/r06_genes_4state.txt.  PAML_AMD_VF_GENES=1 switches it on (tests, measurements).
+         static const bool vf_genes = getenv("PAML_AMD_VF_GENES") && atoi(getenv("PAML_AMD_VF_GENES")) != 0;
+         if (pl.ok && (G == 1 ? e->n_pi == 1 : (vf_genes && (e->n_pi == 1 || e->n_pi == G))) && e->d_zpm.p && !e->env.no_fused && !(G > 1 && n == 4 && e->env.mfma4) && G <= 64) {
             // 4 states: the matrix-core form (v_mfma_f64_4x4x4) is an experiment kept behind PAML_AMD_MFMA4=1 — same issue slots as
             // the FMA form (an FP64 MFMA of 256 MACs takes 16 cycles, sixteen v_fma_f64 of a wave 64) and four times the
             // integer work per pattern (a lane is a (state, pattern) pair): 0.32 of peak against 0.64, profiles/r02_valu_fused_shapes.txt
             const bool m4 = n == 4 && e->env.mfma4;
             int r = ensure_jit(e, std::string(m4 ? "m4" : "vf") + std::to_string(n) + "c" + std::to_string(e->n_codes) + "k" + std::to_string(Km) + "r" + std::to_string(pl.R) + "w" +
-                                     std::to_string(pl.CW) + (pl.cherry ? "y:" : "n:") + jit_program_key(e->prog, e->n_tips),
+                                     std::to_string(pl.CW) + (pl.cherry ? "y" : "n") + (G > 1 ? "g" + std::to_string(G) + ":" : ":") + jit_program_key(e->prog, e->n_tips),
                                [&]() { return m4 ? jit_generate_mfma4(e->prog, e->n_tips, e->n_codes, Km, e->chunk)
-                                                 : jit_generate_valu_fused(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk); }, &jit_ok);
+                                                 : jit_generate_valu_fused(e->prog, n, e->n_tips, e->n_codes, Km, e->chunk, G); }, &jit_ok);
             e->fused_mfma4 = jit_ok && m4;
             if (r) return r;
             fused = jit_ok;
@@ -412,7 +420,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       }
       e->m20 = false;
       if (e->want_m20 && !clean && jit_m20_supported(e->prog, e->n_tips, G)) {
-         int r = ensure_jit(e, std::string(getenv("PAML_AMD_M20_W12") ? "m20w12c" : getenv("PAML_AMD_M20_HALF") ? "m20hc" : "m20c") + std::to_string(e->n_codes) + ":" + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate_m20(e->prog, e->n_tips, e->n_codes); }, &jit_ok);
+         int r = ensure_jit(e, std::string(getenv("PAML_AMD_M20_W12") ? "m20w12c" : getenv("PAML_AMD_M20_HALF") ? "m20hc" : "m20c") + std::to_string(e->n_codes) + (G > 1 ? "g:" : ":") + jit_program_key(e->prog, e->n_tips), [&]() { return jit_generate_m20(e->prog, e->n_tips, e->n_codes, G > 1 ? 2 : 1); }, &jit_ok);
          if (r) return r;
          e->m20 = jit_ok;
       }
@@ -709,13 +717,14 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          // the next pruning kernel, which needs them, cannot be queued ahead).  7/8 of the CUs leave every shader engine one
          // free; taken when it costs this kernel nothing, i.e. when a wave still walks the same number of 32-pattern units
          // (10^5 patterns x 4 classes: 7 at 56 workgroups per class as at 63).  0.1885 -> 0.182 ms per evaluation (32 taxa).
-         if (two_streams) {
+         if (two_streams && G == 1) {
             const int units = std::min(e->n_tiles * 8, (e->n_patt + 31) / 32), g78 = e->n_cu * 7 / 8 / K * K;
             auto rounds = [&](int g) { return ((units + g / K - 1) / (g / K) + 7) / 8; };
             if (g78 >= K && g78 < grid && rounds(g78) == rounds(grid)) grid = g78;
          }
          static const int m20_threads = getenv("PAML_AMD_M20_W12") ? 768 : 512;      // (experiment: jit_generate_m20)
-         HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::max(grid / K, 1) * K, 1, 1, m20_threads, 1, 1, 0, ms, params, nullptr));
+         // (several genes: a workgroup serves one (gene, class); the kernel deals a class's workgroups to the genes, at least one each)
+         HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::max(grid / K, G > 1 ? G : 1) * K, 1, 1, m20_threads, 1, 1, 0, ms, params, nullptr));
       }
       else if (e->use_jit) {
          void *params[] = {&pr};

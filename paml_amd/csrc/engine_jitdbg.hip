@@ -3,6 +3,9 @@
 // Built for gfx950 only (one of the translation units of libpaml_amd.so, see engine_state.h).
 #include "engine_state.h"
 
+// PAML_AMD_PREBUILD_GENES=G (G > 1): the several-genes form of the 4- / 5-state fused kernel and of the 20-state matrix-core kernel
+static int prebuild_genes() { const char *v = getenv("PAML_AMD_PREBUILD_GENES"); return v && atoi(v) > 1 ? atoi(v) : 1; }
+
 extern "C" {
 
 int paml_amd_debug_program(int n_tips, int n_nodes, int root, const int *sons_ptr, const int *sons,
@@ -55,14 +58,14 @@ int paml_amd_debug_jit(int n_tips, int n_nodes, int root, const int *sons_ptr, c
       text = jit_generate(p, n_tips, n_states - 64, n_states - 64);
    }
    else if (fusedK && n_states == 20) {
-      if (!jit_m20_supported(p, n_tips, 1)) return PAML_AMD_EUNSUPPORTED;
-      text = jit_generate_m20(p, n_tips, fusedNC);
+      if (!jit_m20_supported(p, n_tips, prebuild_genes())) return PAML_AMD_EUNSUPPORTED;
+      text = jit_generate_m20(p, n_tips, fusedNC, prebuild_genes());
    }
    else if (fusedK) {
       const int chunk = (compile_all >> 2) & 0x3f ? ((compile_all >> 2) & 0x3f) * 256 : 256;      // bits 2..7: reduction chunk / 256
       if (!jit_valu_fused_plan(p, n_states, n_tips, fusedNC, fusedK, chunk).ok) return PAML_AMD_EUNSUPPORTED;
       text = (n_states == 4 && getenv("PAML_AMD_MFMA4")) ? jit_generate_mfma4(p, n_tips, fusedNC, fusedK, chunk)
-                                                              : jit_generate_valu_fused(p, n_states, n_tips, fusedNC, fusedK, chunk);
+                                                              : jit_generate_valu_fused(p, n_states, n_tips, fusedNC, fusedK, chunk, prebuild_genes());
    }
    else if (n_states == 4 || n_states == 5 || n_states == 20) {
       if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;
@@ -115,13 +118,13 @@ int paml_amd_jit_prebuild(int n_states, int n_tips, int n_codes, int K, long n_p
       if (!jit_coop_supported(p, n_tips, n_codes)) return PAML_AMD_EUNSUPPORTED;
       text = jit_generate_coop(p, n_tips, n_states);
    }
-   else if (n_states == 20 && jit_m20_supported(p, n_tips, 1)) text = jit_generate_m20(p, n_tips, n_codes);
+   else if (n_states == 20 && jit_m20_supported(p, n_tips, prebuild_genes())) text = jit_generate_m20(p, n_tips, n_codes, prebuild_genes());
    else if (n_states <= 5) {
       if (!jit_valu_supported(p)) return PAML_AMD_EUNSUPPORTED;
       const int chunk = red_chunk(n_patt_global);
       text = !jit_valu_fused_plan(p, n_states, n_tips, n_codes, K, chunk).ok ? jit_generate_valu(p, n_states)
              : (n_states == 4 && getenv("PAML_AMD_MFMA4"))                     ? jit_generate_mfma4(p, n_tips, n_codes, K, chunk)
-                                                                               : jit_generate_valu_fused(p, n_states, n_tips, n_codes, K, chunk);
+                                                                               : jit_generate_valu_fused(p, n_states, n_tips, n_codes, K, chunk, prebuild_genes());
    }
    else {
       int jw = 8;

@@ -679,50 +679,96 @@ inline ValuFusedPlan jit_valu_fused_plan(const Program &p, int N, int n_tips, in
    return pl;
 }
 
-inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, int n_codes, int K, int chunk)
+// Several genes (option G: com.posG / com.rgene / com.piG; G > 1 here): a gene has its own P(t) — gene rate, per Mgene also its own
+// eigen system and frequencies — so the LDS tables are one gene's.  A chunk is walked gene segment by gene segment: the tables are
+// refilled where the gene changes (a workgroup's chunks ascend, so at most G + 1 times), and the 256-pattern sub-tile a boundary falls
+// into is walked once per gene with the other gene's lanes switched off — every pattern keeps the lane and the turn it has in
+// reduce_stage1's order, so the chunk sums keep their bits.  With G == 1 the generated text is the single-gene kernel's, unchanged.
+inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, int n_codes, int K, int chunk, int G = 1)
 {
    const ValuFusedPlan pl = jit_valu_fused_plan(p, N, n_tips, n_codes, K, chunk);
+   const bool MG = G > 1;
    std::ostringstream s;
-   const int R = pl.R, CW = pl.CW;
+   const int R = MG ? 1 : pl.R, CW = pl.CW;
    const int NC = n_codes, ROWW = n_tips * NC * N, CHW = pl.cherry ? pl.n_cherry * NC * NC * N : 0, TABW = ROWW + CHW;   // doubles per class
    const int ZW = ((n_tips + 3) / 4 + 3) / 4 * 4;      // dwords of packed codes per pattern
    const int NTH = 256 * CW;
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
+   // the LDS tables: the tips are nodes 0 .. NT-1, so a class's rows are one contiguous run of pmat's output; for a cherry the products of
+   // its two tips' rows.  Several genes: the fill is needed inside the loop over the chunks, where — inlined — the compiler computes its
+   // thirty-odd loop-invariant addresses once, in front of that loop, and keeps them in registers through the whole walk (142 VGPRs
+   // instead of 111: one workgroup per CU instead of two); it is a function of its own there, called where the gene changes.
+   std::ostringstream fill;      // the body, in terms of `ptip0` (the tables of the element's class 0) and `cstride` (doubles per class)
+   {
+      fill << "   for (int ir = 0; ir < K; ir++) {\n"
+           << "      const double *src = ptip0 + ir * cstride;\n"
+           << "      for (int i = threadIdx.x; i < ROWW; i += NTH) sTab[ir * TABW + i] = src[i];\n"
+           << "   }\n   __syncthreads();\n";
+      if (pl.cherry) {
+         int c = 0;
+         fill << "   for (int i = threadIdx.x; i < K * NC * NC * N; i += NTH) {\n"
+              << "      const int ir = i / (NC * NC * N), r = i % (NC * NC * N), ca = r / (NC * N), cb = (r / N) % NC, j = r % N;\n"
+              << "      const double *rw = sTab + ir * TABW;\n";
+         for (const Op &o : p.ops)
+            if (o.code == OP_SET_TIP2) {
+               fill << "      sTab[ir * TABW + ROWW + " << c * NC * NC * N << " + r] = rw[(" << o.a << " * NC + ca) * N + j] * rw[(" << o.b << " * NC + cb) * N + j];\n";
+               c++;
+            }
+         fill << "   }\n   __syncthreads();\n";
+      }
+   }
+   const std::string consts = "constexpr int N = " + std::to_string(N) + ", NC = " + std::to_string(NC) + ", K = " + std::to_string(K) + ", NT = " + std::to_string(n_tips) +
+                              ", ROWW = " + std::to_string(ROWW) + ", TABW = " + std::to_string(TABW) + ", ZW = " + std::to_string(ZW) + ", CW = " + std::to_string(CW) +
+                              ", NTH = " + std::to_string(NTH) + ";\n";
+   if (MG) {
+      s << consts << "__shared__ __attribute__((aligned(16))) double sTab[K * TABW];\n";
+      s << "__device__ __attribute__((noinline)) void vf_fill(const double *ptip0, long cstride)\n{\n" << fill.str() << "}\n";
+   }
    s << "extern \"C\" __global__ __launch_bounds__(" << NTH << (R > 1 ? ", 2" : "") << ") void prune_jit(PruneArgs a)\n{\n";
-   s << "   constexpr int N = " << N << ", NC = " << NC << ", K = " << K << ", NT = " << n_tips << ", ROWW = " << ROWW << ", TABW = " << TABW
-     << ", ZW = " << ZW << ", CW = " << CW << ", NTH = " << NTH << ";\n   (void)NT;\n";
-   s << "   __shared__ __attribute__((aligned(16))) double sTab[K * TABW];\n";
+   if (!MG) {
+      s << "   " << consts << "   (void)NT;\n";
+      s << "   __shared__ __attribute__((aligned(16))) double sTab[K * TABW];\n";
+   }
    if (CW > 1) s << "   __shared__ double sF[K * 256];\n";
    s << "   const int tid = threadIdx.x & 255, cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), bat = blockIdx.y;\n   (void)cw;\n";
    s << "   const long cls0 = (long)bat * K;\n";
-   // tables: the tips are nodes 0 .. NT-1, so a class's rows are one contiguous run of pmat's output
-   s << "   for (int ir = 0; ir < K; ir++) {\n"
-        "      const double *src = a.ptip + (cls0 + ir) * a.n_nodes * a.tip_words;\n"
-        "      for (int i = threadIdx.x; i < ROWW; i += NTH) sTab[ir * TABW + i] = src[i];\n"
-        "   }\n   __syncthreads();\n";
-   if (pl.cherry) {
-      int c = 0;
-      s << "   for (int i = threadIdx.x; i < K * NC * NC * N; i += NTH) {\n"
-           "      const int ir = i / (NC * NC * N), r = i % (NC * NC * N), ca = r / (NC * N), cb = (r / N) % NC, j = r % N;\n"
-           "      const double *rw = sTab + ir * TABW;\n";
-      for (const Op &o : p.ops)
-         if (o.code == OP_SET_TIP2) {
-            s << "      sTab[ir * TABW + ROWW + " << c * NC * NC * N << " + r] = rw[(" << o.a << " * NC + ca) * N + j] * rw[(" << o.b << " * NC + cb) * N + j];\n";
-            c++;
-         }
-      s << "   }\n   __syncthreads();\n";
-   }
+   auto emit_fill = [&](const char *ind, const char *pset0) {      // pset0: parameter set of the batch element's class 0 (gene x all classes + cls0)
+      if (MG) s << ind << "vf_fill(a.ptip + (" << pset0 << ") * a.n_nodes * a.tip_words, (long)a.n_nodes * a.tip_words);\n";
+      else s << "   { const double *ptip0 = a.ptip + (" << pset0 << ") * a.n_nodes * a.tip_words; const long cstride = (long)a.n_nodes * a.tip_words;\n" << fill.str() << "   }\n";
+   };
+   if (!MG) emit_fill("   ", "cls0");
    s << "   const CONST_AS double *fK = as_const(a.freqK + bat * a.freqK_bs);\n";
-   s << "   const CONST_AS double *pi = as_const(a.pi);\n";
+   if (!MG) s << "   const CONST_AS double *pi = as_const(a.pi);\n";
+   else {
+      // the G + 1 gene offsets sit in scalar registers for the whole launch (independent loads, one round trip): finding a chunk's
+      // gene is a chain of scalar compares — a search through memory cost every chunk a string of dependent scalar loads with
+      // nothing to overlap them (measured: the batched 4-gene launch 14 % slower than the one-gene one, a single evaluation 13 us)
+      s << "   int tab_gene = -1;\n   const CONST_AS int *goff = as_const(a.gene_off);\n";
+      for (int g = 0; g <= G; g++) s << "   const long go" << g << " = " << "goff[" << g << "];\n";
+   }
    // the workgroup's chunks: its own (gridDim.x = number of chunks: single evaluations), or every gridDim.x-th one (batched
    // evaluations: fewer, longer workgroups per element, so that the tables above are filled once per ~100 chunks)
    s << "   for (int cb = blockIdx.x; cb < a.nb_local; cb += gridDim.x) {\n";
    s << "   const long c_lo = (long)cb * a.chunk, c_hi = (c_lo + a.chunk < (long)a.n_patt) ? c_lo + a.chunk : (long)a.n_patt;\n";
    s << "   double acc = 0;\n";
-   s << "   for (long h0 = c_lo; h0 < c_hi; h0 += " << 256 * R << ") {\n";
+   if (MG) {
+      s << "   int gene = 0; long g_lo = go0, g_hi = go1;\n";
+      for (int g = 1; g < G; g++) s << "   if (c_lo >= go" << g << ") { gene = " << g << "; g_lo = go" << g << "; g_hi = go" << g + 1 << "; }\n";
+      s << "   for (;;) {\n";
+      s << "   const long seg_lo = g_lo > c_lo ? g_lo : c_lo, seg_hi = g_hi < c_hi ? g_hi : c_hi;\n";
+      s << "   if (seg_lo < seg_hi) {\n";
+      s << "   const long gset0 = (long)gene * a.K + cls0;\n";
+      s << "   const CONST_AS double *pi = as_const(a.pi + (a.n_pi > 1 ? gene : 0) * N);\n";
+      s << "   for (long h0 = c_lo + (seg_lo - c_lo) / 256 * 256; h0 < seg_hi; h0 += 256) {\n";
+   }
+   else s << "   for (long h0 = c_lo; h0 < c_hi; h0 += " << 256 * R << ") {\n";
    auto sfx = [&](int r) { return R > 1 ? "_" + std::to_string(r) : std::string(); };
    for (int r = 0; r < R; r++) {
       const std::string x = sfx(r);
+      if (MG)
+         s << "      const long h" << x << " = h0 + " << 256 * r << " + tid;\n      const bool valid" << x << " = h" << x << " >= seg_lo && h" << x << " < seg_hi;\n      const long hc" << x
+           << " = h" << x << " < c_hi ? h" << x << " : c_hi - 1;\n";      // (any pattern of the chunk: its codes are loaded before the gene's tables are known to be there)
+      else
       s << "      const long h" << x << " = h0 + " << 256 * r << " + tid;\n      const bool valid" << x << " = h" << x << " < c_hi;\n      const long hc" << x
         << " = valid" << x << " ? h" << x << " : c_hi - 1;\n";
       s << "      unsigned int zw" << x << "[ZW];\n";
@@ -732,6 +778,11 @@ inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, 
            << "] = t.z; zw" << x << "[" << 4 * i + 3 << "] = t.w; }\n";
       s << "      }\n";
       s << "      const double wt" << x << " = a.weights[hc" << x << "];\n";
+      if (MG) {      // the tables of this segment's gene (the codes and the weight above are already on their way)
+         s << "      if (gene != tab_gene) {\n         __syncthreads();\n";
+         emit_fill("         ", "gset0");
+         s << "         tab_gene = gene;\n      }\n";
+      }
       // per-pattern table offsets (in doubles), formed once and used by every class
       s << "#define zw zw" << x << "\n";
       int c = 0;
@@ -758,7 +809,7 @@ inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, 
       s << "      double fh" << x << " = 0, v" << x << " = 0;\n";
    }
    s << "      _Pragma(\"unroll 1\") for (int ir = " << (CW > 1 ? "cw" : "0") << "; ir < K; ir += CW) {\n";
-   s << "         const double *Pint = a.pint + (cls0 + ir) * a.n_nodes * (N * N);\n";
+   s << "         const double *Pint = a.pint + (" << (MG ? "gset0" : "cls0") << " + ir) * a.n_nodes * (N * N);\n";
    s << "         const double *tab = sTab + ir * TABW;\n";
    const int NA = p.max_stack + 2;
    for (int r = 0; r < R; r++) {
@@ -854,6 +905,11 @@ inline std::string jit_generate_valu_fused(const Program &p, int N, int n_tips, 
    }
    if (CW > 1) s << "      __syncthreads();\n";      // sF is reused by the next sub-tile
    s << "   }\n";      // sub-tiles
+   if (MG) {      // on to the chunk's next gene segment
+      s << "   }\n   if (g_hi >= c_hi || gene + 1 >= " << G << ") break;\n   gene++; g_lo = g_hi;\n   g_hi = ";
+      for (int g = 1; g < G - 1; g++) s << "gene == " << g << " ? go" << g + 1 << " : ";
+      s << "go" << G << ";\n   }\n";
+   }
    if (CW > 1) s << "   if (cw > 0) acc = 0;\n";
    s << "   red_block_finish<" << CW << ">(acc, a.red_partial + (long)bat * a.nb_stride, a.first_chunk + cb, a.nb_stride, a.red_out + bat, a.red_counter ? a.red_counter + bat * RED_TICKET_WORDS : nullptr);\n";
    s << "   }\n}\n";
@@ -1063,7 +1119,8 @@ inline std::string jit_generate_mfma4(const Program &p, int n_tips, int n_codes,
 // reduction kernel does the mixture.  One gene; trees whose internal branches fit in LDS (<= 46).
 inline bool jit_m20_supported(const Program &p, int n_tips, int n_genes, int *n_slots = nullptr)
 {
-   if (!jit_valu_supported(p, 64) || n_genes != 1) return false;
+   (void)n_genes;      // (several genes, round 6: a workgroup serves one (gene, class) — jit_generate_m20)
+   if (!jit_valu_supported(p, 64) || n_tips > 64) return false;      // (tip codes: one 16-byte word per lane, 4 lanes per pattern)
    int nmm = 0;
    for (const Op &o : p.ops) {
       if (o.code == OP_MATMUL || o.code == OP_MATMUL_POP) nmm++;
@@ -1075,9 +1132,12 @@ inline bool jit_m20_supported(const Program &p, int n_tips, int n_genes, int *n_
 }
 constexpr int M20_LDS_NODES = 46;      // P(t) blocks (3 200 bytes each) kept in LDS for the whole launch
 
-inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
+// Several genes (G > 1): a gene has its own P(t), so a persistent workgroup serves one (gene, class): the workgroups of a class are dealt
+// to the genes in proportion to their 32-pattern units (at least one each), and a gene's workgroups cut ITS units into contiguous ranges.
+inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes, int G = 1)
 {
    std::ostringstream s;
+   const bool MG = G > 1;
    int nmm = 0;
    std::vector<int> mm_nodes;
    for (const Op &o : p.ops)
@@ -1095,7 +1155,10 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    const int tip_bytes = n_codes * 168;      // rows padded to 21 doubles in LDS: with 20, codes c and c + 8 share all their banks
    // 16x16x4 + 4x4x4 (m20h_matvec2), else all on 4x4x4 — the latter only for trees whose P(t) all fit in LDS (it reads row-major blocks)
    const bool hybrid = !getenv("PAML_AMD_M20_NOHYBRID") || nmm > M20_LDS_NODES;
-   const int NL = hybrid ? std::min(nmm, M20_LDS_NODES) : nmm;      // products 0 .. NL - 1: operands in LDS; the others: in global memory, operand order
+   // (experiments: PAML_AMD_M20_NL = P(t) blocks kept in LDS — the rest of LDS takes tip tables; PAML_AMD_M20_GA = products ahead of their
+   //  use at which rows gathered from L2 are requested)
+   const int lds_nodes = getenv("PAML_AMD_M20_NL") ? std::max(0, std::min(M20_LDS_NODES, atoi(getenv("PAML_AMD_M20_NL")))) : M20_LDS_NODES;
+   const int NL = hybrid ? std::min(nmm, lds_nodes) : nmm;      // products 0 .. NL - 1: operands in LDS; the others: in global memory, operand order
    const int room = 158 * 1024 - NL * 3200;
    const int n_lds_max = getenv("PAML_AMD_M20_NOLDSTIP") ? 0 : std::max(0, room / tip_bytes);
    std::vector<int> lds_slot(n_tips, -1);
@@ -1105,17 +1168,35 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       if (o.code == OP_SET_TIP || o.code == OP_MUL_TIP) take(o.a);
       if (o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2) { take(o.a); take(o.b); }
    }
-   s << "   constexpr int NMM = " << NL << ", NC = " << n_codes << ", NLT = " << std::max(1, n_lds) << ";\n";
+   s << "   constexpr int NMM = " << std::max(1, NL) << ", NC = " << n_codes << ", NLT = " << std::max(1, n_lds) << ";\n";
    s << "   __shared__ __attribute__((aligned(16))) double sP[NMM * 400];\n";
    s << "   __shared__ __attribute__((aligned(16))) double sT[NLT * NC * 21];\n";
    s << "   __shared__ int sTicket;\n";
    s << "   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, st = lane >> 4, col = lane & 15;\n";
    if (getenv("PAML_AMD_PROF_TILES")) s << "   if (a.prof && tid == 0) a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 3] = __builtin_amdgcn_s_memrealtime();      /* kernel entry, before the LDS fill */\n";
-   s << "   const int iclass = blockIdx.x % a.K, first = blockIdx.x / a.K, stride = gridDim.x / a.K;\n";
+   if (!MG) s << "   const int iclass = blockIdx.x % a.K, first = blockIdx.x / a.K, stride = gridDim.x / a.K;\n   constexpr int gene = 0, tile0 = 0;\n   const int hbeg = 0;\n   (void)hbeg;\n";
+   else {
+      // gene g's workgroups (of this class): [g + rest * cum(g) / tot, g + 1 + rest * cum(g + 1) / tot), cum = units of the genes before,
+      // rest = workgroups per class beyond one per gene (the host launches at least G per class)
+      s << "   const int iclass = blockIdx.x % a.K, wgc = blockIdx.x / a.K, W = gridDim.x / a.K;\n";
+      s << "   int gene = 0, first = 0, stride = 1, tile0 = 0;\n";
+      s << "   { const CONST_AS int *go = as_const(a.gene_off);\n";
+      s << "     long tot = 0; for (int g = 0; g < a.n_genes; g++) tot += (go[g + 1] - go[g] + 31) / 32;\n";
+      s << "     if (tot < 1) tot = 1;\n";
+      s << "     const long rest = W - a.n_genes; long cu = 0; int t0 = 0;\n";
+      s << "     for (int g = 0; g < a.n_genes; g++) {\n";
+      s << "        const long ug = (go[g + 1] - go[g] + 31) / 32;\n";
+      s << "        const int lo = g + (int)(rest * cu / tot), hi = g + 1 + (int)(rest * (cu + ug) / tot);\n";
+      s << "        if (wgc >= lo && wgc < hi) { gene = g; first = wgc - lo; stride = hi - lo; tile0 = t0; }\n";
+      s << "        cu += ug; t0 += (go[g + 1] - go[g] + 255) / 256;\n";
+      s << "     } }\n";
+      s << "   const int hbeg = as_const(a.gene_off)[gene];\n";
+      s << "   if (as_const(a.gene_off)[gene + 1] <= hbeg) return;      /* (a shard that holds nothing of this gene) */\n";
+   }
    // (a.pint: the branches' P(t) in operand order — [kb][lane] <- P[lane & 15][4 kb + (lane >> 4)], then [kb][k][i] <- P[16 + i][4 kb + k],
    //  written so by pmat_kernel_t<32> in layout 2; a.pcol: the row-major copies, which the all-4x4x4 form reads)
-   s << "   const double *Pall = " << (hybrid ? "a.pint" : "a.pcol") << " + (long)iclass * a.n_nodes * 400;\n";
-   s << "   const double *Ptip = a.ptip + (long)iclass * a.n_nodes * a.tip_words;\n";
+   s << "   const double *Pall = " << (hybrid ? "a.pint" : "a.pcol") << " + ((long)gene * a.K + iclass) * a.n_nodes * 400;\n";
+   s << "   const double *Ptip = a.ptip + ((long)gene * a.K + iclass) * a.n_nodes * a.tip_words;\n";
    for (int k = 0; k < NL; k++)
       s << "   for (int i = tid; i < 400; i += " << NTH << ") sP[" << k * 400 << " + i] = Pall[" << (long)mm_nodes[k] * 400 << " + i];\n";
    for (int t = 0; t < n_tips; t++)
@@ -1123,13 +1204,17 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
          s << "   for (int i = tid; i < NC * 20; i += " << NTH << ") sT[" << lds_slot[t] << " * NC * 21 + (i / 20) * 21 + i % 20] = Ptip[(long)" << t << " * a.tip_words + i];\n";
    s << "   __syncthreads();\n";
    s << "   const int aoff = (lane & 3) * 20 + (lane >> 4);      /* A operand: lane 16 k + 4 b + i <- P[4I + i][4K + k] */\n";
-   s << "   double pis[5];\n   _Pragma(\"unroll\") for (int m = 0; m < 5; m++) pis[m] = a.pi[4 * m + st];\n";
+   s << "   double pis[5];\n   _Pragma(\"unroll\") for (int m = 0; m < 5; m++) pis[m] = a.pi[(a.n_pi > 1 ? gene : 0) * 20 + 4 * m + st];\n";
    // tip codes: pattern-major, four per dword (PruneArgs::zpm); the NEXT tile's are fetched while this tile is walked, so that no
    // tip row's address waits on a global load
+   // (round 6: the four state-quarter lanes of a pattern used to hold the same ZW dwords each — 64 VGPRs for the two groups of a unit and
+   //  the next unit's at 60 taxa, and the walk spilled; now lane (st, col) holds the pattern's 16-byte word number st, the codes of tips
+   //  16 st .. 16 st + 15, and a tip step fetches its dword from the owner lane with one ds_bpermute_b32: 16 VGPRs whatever the tree)
    const int ZW = ((n_tips + 3) / 4 + 3) / 4 * 4;
    s << "   constexpr int ZW = " << ZW << ";\n";
-   s << "   const int hend = as_const(a.gene_off)[1];\n";
-   s << "   unsigned int zn_0[ZW], zn_1[ZW];\n";
+   s << "   const int hend = as_const(a.gene_off)[gene + 1];\n";
+   s << "   const int zq = st < ZW / 4 ? st : ZW / 4 - 1, bp0 = col * 4;\n";
+   s << "   unsigned int zn_0[4], zn_1[4];\n";
    // Work inside a workgroup is handed out per wave in units of 32 patterns
    // from an LDS ticket: the two waves of a SIMD do not advance at the same pace (the older wave wins the MFMA arbitration), and
    // with fixed slots the kernel ended 20 % after its fastest waves had finished.  The first unit of a wave is its own slot; the
@@ -1148,13 +1233,15 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    s << "#define M20_UNIT_OF(T) ((T) < nfull ? ubase + (T) : ubase + nfull + (((T) - nfull) >> 1))\n";
    s << "#define M20_HALF_OF(T) ((T) < nfull ? -1 : (((T) - nfull) & 1))\n";
    s << "#define M20_FETCH_CODES(T) { int tn_ = (T) < nt ? (T) : nt - 1; tn_ = tn_ < 0 ? 0 : tn_; const int un_ = M20_UNIT_OF(tn_), hf_ = M20_HALF_OF(tn_); \\\n"
-        "      const int h0n = as_const(a.tiles)[un_ >> 3].y + (un_ & 7) * 32 + (hf_ > 0 ? 16 : 0); \\\n"
+        "      const int h0n = as_const(a.tiles)[tile0 + (un_ >> 3)].y + (un_ & 7) * 32 + (hf_ > 0 ? 16 : 0); \\\n"
         "      long hn = h0n + col; if (hn >= hend) hn = hend - 1; const uint4 *zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
-        "      _Pragma(\"unroll\") for (int i = 0; i < ZW / 4; i++) { const uint4 t = zp[i]; zn_0[4 * i] = t.x; zn_0[4 * i + 1] = t.y; zn_0[4 * i + 2] = t.z; zn_0[4 * i + 3] = t.w; } \\\n"
+        "      { const uint4 t = zp[zq]; zn_0[0] = t.x; zn_0[1] = t.y; zn_0[2] = t.z; zn_0[3] = t.w; } \\\n"
         "      hn = h0n + 16 + col; if (hn >= hend) hn = hend - 1; zp = (const uint4 *)(a.zpm + hn * ZW); \\\n"
-        "      _Pragma(\"unroll\") for (int i = 0; i < ZW / 4; i++) { const uint4 t = zp[i]; zn_1[4 * i] = t.x; zn_1[4 * i + 1] = t.y; zn_1[4 * i + 2] = t.z; zn_1[4 * i + 3] = t.w; } }\n";
+        "      { const uint4 t = zp[zq]; zn_1[0] = t.x; zn_1[1] = t.y; zn_1[2] = t.z; zn_1[3] = t.w; } }\n";
    s << "#define M20_TICKET() __builtin_amdgcn_readfirstlane(lane == 0 ? __hip_atomic_fetch_add(&sTicket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0)\n";
-   if (hybrid) s << "   double Acol[5], AsN[5] = {0, 0, 0, 0, 0};\n   (void)AsN;\n   m20h_read_big(m20_lds_addr(sP), lane, Acol);      /* the first product's big operands (a unit's last product fetches them for the next unit) */\n   (void)aoff;\n";
+   if (hybrid && NL > 0) s << "   double Acol[5], AsN[5] = {0, 0, 0, 0, 0};\n   (void)AsN;\n   m20h_read_big(m20_lds_addr(sP), lane, Acol);      /* the first product's big operands (a unit's last product fetches them for the next unit) */\n   (void)aoff;\n";
+   else if (hybrid)      // (no P(t) block in LDS: the first product's operands come from global memory like every other's)
+      s << "   double Acol[5], AsN[5];\n   { const double *Pn_ = Pall + " << (long)mm_nodes[0] * 400 << "; _Pragma(\"unroll\") for (int i = 0; i < 5; i++) { Acol[i] = Pn_[i * 64 + lane]; AsN[i] = Pn_[320 + i * 16 + ((lane >> 4) << 2) + (lane & 3)]; } }\n   (void)aoff; (void)sP;\n";
    else s << "   double Acol[5];\n   m20_acol_asm<0>(m20_lds_addr(sP) + aoff * 8, Acol);      /* first column of the first product (a unit's last product fetches it for the next unit) */\n";
    const bool proft = getenv("PAML_AMD_PROF_TILES") != nullptr;      // experiments: workgroup timeline (tools/prof_tiles.py)
    const char *ptid = getenv("PAML_AMD_PROF_TID");                   // ... stamped by this thread (default 0)
@@ -1162,7 +1249,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    if (proft) s << "   int ptc = 0; if (a.prof && tid == " << pt << ") { a.prof[(long)blockIdx.x * a.prof_stride] = __builtin_amdgcn_s_memrealtime(); a.prof[(long)blockIdx.x * a.prof_stride + a.prof_stride - 2] = __builtin_amdgcn_s_memtime(); }\n";
    // the class's units (32 patterns each, numbered through its 256-pattern tiles) are cut into one contiguous range per workgroup:
    // 10^5 patterns over 64 workgroups are 48 or 49 units each, where whole tiles were 48 or 56
-   s << "   const int total_units = min(a.n_tiles * 8, (hend + 31) / 32);\n";
+   s << "   const int total_units = " << (MG ? "(hend - hbeg + 31) / 32" : "min(a.n_tiles * 8, (hend + 31) / 32)") << ";\n";
    s << "   const int ubase = (int)((long)first * total_units / stride), uend = (int)((long)(first + 1) * total_units / stride);\n";
    s << "   const int nfull = max(0, (uend - ubase) - " << SPLIT << "), nt = nfull + 2 * ((uend - ubase) - nfull);\n";
    s << "   if (threadIdx.x == 0) sTicket = " << NTH / 64 << ";      /* the first tickets are the waves' own */\n   __syncthreads();\n";
@@ -1170,9 +1257,9 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
    s << "   M20_FETCH_CODES(u)\n";
    s << "   while (u < nt) {\n";
    s << "      const int unit = M20_UNIT_OF(u), half = M20_HALF_OF(u);\n";
-   s << "      const int h0 = as_const(a.tiles)[unit >> 3].y + (unit & 7) * 32 + (half > 0 ? 16 : 0);\n";
-   s << "      unsigned int zw_0[ZW], zw_1[ZW];\n";
-   s << "      _Pragma(\"unroll\") for (int i = 0; i < ZW; i++) { zw_0[i] = zn_0[i]; zw_1[i] = zn_1[i]; }\n";
+   s << "      const int h0 = as_const(a.tiles)[tile0 + (unit >> 3)].y + (unit & 7) * 32 + (half > 0 ? 16 : 0);\n";
+   s << "      unsigned int zw_0[4], zw_1[4];\n";
+   s << "      _Pragma(\"unroll\") for (int i = 0; i < 4; i++) { zw_0[i] = zn_0[i]; zw_1[i] = zn_1[i]; }\n";
    s << "      M20_FETCH_CODES(unext)\n";
    s << "      const int unext2 = M20_TICKET();\n";
    auto emit_body = [&](const int G) {      // the walk over one unit: G = 2 pattern groups, or (half units) group 0 alone
@@ -1204,7 +1291,8 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       const bool two = o.code == OP_SET_TIP2 || o.code == OP_MUL_TIP2;
       for (int g = 0; g < G; g++) {
          auto codeof = [&](int t) {
-            return "(int)((zw_" + std::to_string(g) + "[" + std::to_string(t >> 2) + "] >> " + std::to_string((t & 3) * 8) + ") & 0xffu)";
+            return "(int)(((unsigned)__builtin_amdgcn_ds_bpermute(bp0 + " + std::to_string((t >> 4) * 64) + ", (int)zw_" + std::to_string(g) + "[" + std::to_string((t >> 2) & 3) + "]) >> " +
+                   std::to_string((t & 3) * 8) + ") & 0xffu)";
          };
          s << "      double T" << i << "a_" << g << "[5]; m20_tip(" << tip_src(o.a) << ", " << codeof(o.a) << ", st, T" << i << "a_" << g << ");\n";
          if (two) s << "      double T" << i << "b_" << g << "[5]; m20_tip(" << tip_src(o.b) << ", " << codeof(o.b) << ", st, T" << i << "b_" << g << ");\n";
@@ -1227,7 +1315,8 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
          if (is_tip(p.ops[j]) && !loaded[j] && (which & (all_lds(p.ops[j]) ? 1 : 2))) emit_loads(j);
    };
    emit_loads_after(-1, 3);
-   emit_loads_after(0, 2);
+   const bool ga1 = getenv("PAML_AMD_M20_GA") && atoi(getenv("PAML_AMD_M20_GA")) == 1;
+   if (!ga1) emit_loads_after(0, 2);
    std::vector<int> slot(256, -1);
    int cur = -1, imm = 0;
    for (size_t iop = 0; iop < nops; iop++) {
@@ -1259,7 +1348,7 @@ inline std::string jit_generate_m20(const Program &p, int n_tips, int n_codes)
       case OP_MATMUL_POP:
          pop = mm_pop_slot(o); push = mm_push_slot(o); out = alloc();
          emit_loads_after(imm, 1);
-         emit_loads_after(imm + 1, 2);
+         emit_loads_after(ga1 ? imm : imm + 1, 2);
          s << "      __builtin_amdgcn_sched_barrier(0);\n";
          {
             const int nxt = (imm + 1) % nmm;

@@ -263,6 +263,28 @@ def random_problem(n, n_tips, n_patt, K=1, seed=0, ambiguity=False, scale_every=
                    mode=mode, **kw)
 
 
+def give_genes_their_own_models(pb, seed=0):
+    """Mgene = 2 .. 4 (com.piG, a rate matrix per gene; treesub.c:487 option G): every gene of `pb` gets its own reversible model —
+    frequencies pi[g] and eigen system g, eigen_of[g][class][label] = g."""
+    rng = np.random.default_rng(seed)
+    n, G = pb.n, pb.n_genes
+    pis, eig = [], []
+    for g in range(G):
+        pi = rng.dirichlet(np.full(n, 3.0))
+        S = np.triu(rng.gamma(1.0, 1.0, size=(n, n)), 1)
+        S = S + S.T
+        Q = S * pi[None, :]
+        Q[np.diag_indices(n)] = -Q.sum(axis=1)
+        Q /= -np.dot(pi, np.diag(Q))
+        U, V, root = models.eigen_rev(Q, pi)
+        pis.append(pi)
+        eig.append(dict(kind=EIGEN_UVROOT, U=U, V=V, Root=root))
+    pb.pi = np.ascontiguousarray(np.stack(pis))
+    pb.eigen = eig
+    pb.eigen_of = np.ascontiguousarray(np.broadcast_to(np.arange(G, dtype=np.int32)[:, None, None], (G, pb.K, pb.n_labels)))
+    return pb
+
+
 def ymd_names(text):
     """The HIV-2 TipDate data (tests/golden/data/HIV2ge.*) name their sequences by isolate + sampling year (P03h1995): turn the year into a
     calendar date, P03h_1995-MM-DD, month and day drawn from the name — the yyyy-mm-dd flavour of TipDate (golden hiv2_tipdate_ymd was

@@ -590,6 +590,44 @@ def test_specialised_kernels_via_flag(n, n_tips, n_patt, K, genes, amb, every):
     assert abs(got[1] - r1) <= 1e-10 * abs(r1)
 
 
+@pytest.mark.parametrize("n,n_tips,n_patt,K,cuts,own,kw", [
+    (4, 12, 3000, 4, [0, 700, 1536, 3000], False, {}),                        # a boundary inside a 256-pattern sub-tile, one on a chunk edge
+    (4, 32, 5000, 4, [0, 100, 130, 2600, 5000], True, {}),                    # two boundaries inside one sub-tile; the genes' own models (Mgene 2-4)
+    (4, 9, 2000, 1, [0, 999, 2000], True, dict(ambiguity=True)),
+    (4, 20, 1500, 3, [0, 400, 1500], False, dict(scale_every=4)),             # scaling nodes: the mixture by log-sum-exp from the stored class values
+    (5, 9, 1200, 2, [0, 513, 1200], True, {}),
+    (20, 14, 3000, 3, [0, 1000, 1031, 3000], True, dict(ambiguity=True)),     # a gene of 31 patterns: one ragged unit
+    (20, 33, 2600, 1, [0, 1300, 2600], False, dict(scale_every=9)),
+    (20, 60, 1400, 2, [0, 500, 1400], True, {}),                              # beyond the LDS capacity and several genes
+])
+def test_several_genes_on_the_per_tree_kernels(n, n_tips, n_patt, K, cuts, own, kw, monkeypatch):
+    """Option G (com.posG / com.rgene / com.piG, treesub.c:487) on the per-tree kernels (round 6): the 20-state matrix-core kernel serves
+    several genes (a workgroup = one (gene, class)); the 4- / 5-state fused kernel has a several-genes form behind PAML_AMD_VF_GENES=1 (not
+    the default: it measures no faster than the unfused per-tree kernel, which stays the default and is what the second half checks).
+    lnL, every log f_h and fhK against the oracle, the kernel names, and for the fused kernel the bits of the unfused kernel +
+    reduce_stage1 (same lane and turn per pattern whatever the gene boundaries)."""
+    pb = helpers.random_problem(n, n_tips, n_patt, K=K, seed=4000 + n + n_tips, n_genes=len(cuts) - 1, **kw)
+    pb.gene_off = np.array(cuts, dtype=np.int32)
+    if own:
+        helpers.give_genes_their_own_models(pb, seed=n_tips)
+    monkeypatch.setenv("PAML_AMD_VF_GENES", "1")
+    eng, out, ref = check(pb, flags=JIT)
+    want = {4: "valu4_fused_jit", 5: "valu5_fused_jit", 20: "mfma4x20_jit"}[n]
+    assert eng.kernel_name == want, eng.kernel_name
+    br = np.stack([pb.tree.branch, pb.tree.branch * 1.07, pb.tree.branch * 0.9])
+    got = eng.eval_batch(br, gene_rate=np.tile(pb.gene_rate, (3, 1)))
+    assert got[0] == out["lnL"]
+    q = copy.copy(pb)
+    q.tree = Tree(pb.tree.n_tips, pb.tree.n_nodes, pb.tree.root, pb.tree.sons, br[2].copy(), pb.tree.label)
+    r2 = oracle.evaluate(q)["lnL"]
+    assert abs(got[2] - r2) <= 1e-10 * abs(r2)
+    if n <= 5:
+        monkeypatch.delenv("PAML_AMD_VF_GENES")
+        eng0, out0, _ = check(pb, flags=JIT)
+        assert eng0.kernel_name == "valu%d_jit" % n
+        assert out0["lnL"] == out["lnL"] and np.array_equal(out0["lnf"], out["lnf"])
+
+
 @pytest.mark.parametrize("n,K,every", [(4, 4, None), (4, 3, 3), (61, 2, None)])
 def test_eval_adg_matches_oracle(n, K, every):
     """paml_amd_eval_adg (lfunAdG: fx_r on the device, the rate chain over the sites on the host) against the oracle."""
