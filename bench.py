@@ -820,6 +820,20 @@ def bench_fallbacks(engine, synth, timed, pb_c4):
     pb = synth.aa_gamma_problem(n_tips=60, n_patt=100_000, seed=60)
     eng, _ = run("codeml seqtype 2 + G4, 60 taxa x 100000 patterns", pb, steps=10, why="> 49 taxa: the internal branches' P(t) no longer fit the 20-state kernel's LDS")
     eng.close()
+    # 3b. 20 states, several genes (round 6: a workgroup of the matrix-core kernel serves one (gene, class))
+    pb = synth.aa_gamma_problem(n_tips=32, n_patt=100_000)
+    t3 = pb.n_patt // 3
+    pbg = dataclasses.replace(pb, gene_off=np.array([0, t3, 2 * t3, pb.n_patt], dtype=np.int32), gene_rate=np.array([0.8, 1.0, 1.5]), eigen_of=None, qfactor=None)
+    eng, _ = run("codeml seqtype 2 + G4, 32 taxa x 100000 patterns in 3 genes", pbg, steps=30, why="option G: the genes' own P(t) sets; the one-gene figure is the aa20 block")
+    eng.close()
+    # 3c. more than 64 character codes at 61 states (round 6): 61 sense codons + 12 ambiguous triplets; the per-tree kernel's ring block has a
+    # tip's rows of 64 codes, the lanes of rarer codes add up the rows of the code's states (jit_tip_overflow)
+    if pb_c4 is not None:
+        pba = synth.with_ambiguous_codons(pb_c4)
+        eng, row = run("codon M0, 16 taxa x 1000000 patterns, 73 character codes (cleandata = 0)", pba, steps=10,
+                       why="fully missing triplets in 1.5 % of the cells (a fast row), 11 partly resolved triplets in 0.05 % each, nine of them beyond the 64 rows of a block")
+        row["n_codes"] = int(pba.n_codes)
+        eng.close()
     # 4. every internal node's partial kept (method = 1 / eval_dirty): a full evaluation writes 7.2 GB
     if pb_c4 is not None:
         eng, row = run("codon M0, 16 taxa x 1000000 patterns, PAML_AMD_KEEP_PARTIALS", pb_c4, flags=engine.KEEP_PARTIALS, steps=5,

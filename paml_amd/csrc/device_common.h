@@ -84,6 +84,8 @@ struct PruneArgs {
    int part_groups;
    double *part_dump;           // 8 x 1024 doubles nobody reads: where the per-tree kernel's waves whose 16 patterns lie past their gene's end
                                 // put their STOREs (every wave must issue the same vector-memory operations: the operand ring's waits count them)
+   const unsigned long long *code_mask;      // [n_codes] state sets of the character codes as bit masks (tools.c:20 nChara / CharaMap): the per-tree
+                                             // kernel's codes beyond the 64 a ring block has rows for (JIT_AMB_OVERFLOW)
 };
 
 __device__ __forceinline__ double root_value(const PruneArgs &a, double f, double lnscale)
@@ -262,6 +264,65 @@ __device__ __forceinline__ void tip_lds(const double *tab, int code, int q, int 
 }
 
 
+// ---- more than 64 character codes (JIT_AMB_OVERFLOW: defined by the generator when the data set has them) ----------------------------
+// A ring block holds a tip's rows of the codes 0 .. 63 (32 KB).  61 sense codons leave three of them to ambiguous triplets; a data set
+// with more (SetMapAmbiguity treesub.c:1218-1286: every distinct ambiguous triplet of a cleandata = 0 alignment is a code of its own) keeps
+// the others out of the block — paml_amd_set_tips numbers the ambiguous codes by frequency x set size, so the ones left out are the rare
+// and the small — and a lane that meets one adds up the rows of the code's states itself: the states are single-state codes < 64, the sum
+// runs over them in ascending order from 0, the order in which pmat_mfma_kernel forms a table row from CharaMap (codeml.c:3560-3567;
+// the engine takes this path only when every such code lists its states in ascending order, as SetMapAmbiguity does) — the same bits.
+// The state set is a 64-bit mask: from LDS (the unused three quarters of sPi, when there is one frequency vector) or one global load;
+// then as many LDS row reads as the set has states, inside a divergent branch that most waves skip.  (A global load here is younger
+// than every DMA piece in flight, so the counted waits of the operand ring stay valid.)
+struct JitAmb {
+   const unsigned long long *mask_g;      // [n_codes] in global memory
+   __attribute__((address_space(3))) const unsigned long long *mask_s;      // codes 64 .. in LDS (index code - 64), read when `lds`
+   bool lds;      // (typed as an LDS pointer: through a generic one the compiler merges the two reads into ONE flat load of a selected address,
+                  //  and a flat load's wait drains the ring's DMA stream — measured: + 11 % per evaluation for 0.45 % of the cells)
+};
+#ifdef JIT_AMB_OVERFLOW
+#define JIT_FASTCODE(C) ((C) & 63)
+// (inlined at every tip step: as a function of its own — tried — the fast path is no faster and the rare path pays the call: 1.89 against 1.73 ms)
+template <int NP>
+__device__ __forceinline__ void jit_tip_overflow(const JitAmb &amb, const double *tab, int code, int q, double2 (&v)[8])
+{
+#pragma unroll
+   for (int p = 0; p < 8; p++) v[p] = make_double2(0.0, 0.0);
+   unsigned long long m;
+   if (amb.lds) m = amb.mask_s[code - 64];
+   else m = amb.mask_g[code];
+   // two states per turn, their rows requested together (half the LDS round trips of one state after the other; four per turn spill);
+   // a turn's missing state adds + 0.0, which changes nothing, and the additions keep the ascending order
+   while (m) {
+      int st[2];
+      bool on[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+         on[u] = m != 0;
+         st[u] = on[u] ? __builtin_ctzll(m) : 0;
+         m = on[u] ? (m & (m - 1)) : 0;
+      }
+      double2 t[2][NP];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+         const int row = st[u] * 4 + q, swz = TIP_SWZ(row);
+         const char *base = (const char *)tab + row * 128;
+#pragma unroll
+         for (int p = 0; p < NP; p++) t[u][p] = *(const double2 *)(base + ((p ^ swz) * 16));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+         for (int p = 0; p < NP; p++) {
+            v[p].x += on[u] ? t[u][p].x : 0.0;
+            v[p].y += on[u] ? t[u][p].y : 0.0;
+         }
+   }
+}
+#else
+#define JIT_FASTCODE(C) (C)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Building blocks of the per-tree specialised kernel (jit.h emits a straight-line sequence of these).
 // A partial is a v4d[4]: element m (state 4m + q of this lane's pattern) is x[m >> 2][m & 3] — exactly
@@ -432,8 +493,13 @@ __device__ __forceinline__ void jit_matvec(const double *sPbuf, int lane, const 
 template <int MIDWAIT, bool TAIL61 = false, int RB = 4, int KB = 16, class SIDE = JitNoSide>
 __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, const v4d (&x)[4], v4d (&y)[4], const double *ta, int ca,
                                                 const double *tb, int cb, int q, v4d (&t)[4], SIDE side = SIDE(), const double *col = nullptr,
-                                                double x60 = 0)
+                                                double x60 = 0, JitAmb amb = JitAmb())
 {
+   (void)amb;
+#ifdef JIT_AMB_OVERFLOW
+   const int ca_full = ca, cb_full = cb;      // (the rows gathered under the MFMAs are those of the codes & 63; lanes with a code beyond them redo theirs below)
+   ca &= 63; cb &= 63;
+#endif
    constexpr int KB2 = (KB + 1) / 2, NP = KB2, MID = KB2 / 2, GI = KB2 - MID, PPI = (NP + GI - 1) / GI;
    const double2 *sp = (const double2 *)sPbuf;
    v4d z[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -544,6 +610,23 @@ __device__ __forceinline__ void jit_matvec_tip2(const double *sPbuf, int lane, c
          t[p >> 1][(2 * p + 1) & 3] = tv[(KB2 - 1) & 1][e].y * tw[(KB2 - 1) & 1][e].y;
       }
    }
+#ifdef JIT_AMB_OVERFLOW
+   if (ca_full >= 64 || cb_full >= 64) {      // (both tables are still resident: the ring's refills go to slots of blocks consumed before this step)
+      double2 va[8], vb[8];
+      if (ca_full >= 64) jit_tip_overflow<NP>(amb, ta, ca_full, q, va);
+      else {
+#pragma unroll
+         for (int p = 0; p < 8; p++) va[p] = p < NP ? *(const double2 *)(pa + ((p ^ swa) * 16)) : make_double2(0.0, 0.0);
+      }
+      if (cb_full >= 64) jit_tip_overflow<NP>(amb, tb, cb_full, q, vb);
+      else {
+#pragma unroll
+         for (int p = 0; p < 8; p++) vb[p] = p < NP ? *(const double2 *)(pb + ((p ^ swb) * 16)) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int p = 0; p < 8; p++) { t[p >> 1][(2 * p) & 3] = va[p].x * vb[p].x; t[p >> 1][(2 * p + 1) & 3] = va[p].y * vb[p].y; }
+   }
+#endif
 }
 
 // Partials of stack slots beyond the register arrays live in global scratch (trees with a deep partial stack): one coalesced
@@ -615,48 +698,52 @@ __device__ __forceinline__ void jit_init_tip(v4d (&y)[4], int code, int q, int c
 // Tip factors: NP = number of 16-byte pieces (two states each) of a table row that carry states of the model (8 at 61
 // states, 3 at 20); the rest of the row is zero padding and is not read.
 template <int NP>
-__device__ __forceinline__ void tip_lds_n(const double *tab, int code, int q, double2 (&v)[8])
+__device__ __forceinline__ void tip_lds_n(const double *tab, int code, int q, double2 (&v)[8], JitAmb amb = JitAmb())
 {
-   const int row = code * 4 + q, swz = TIP_SWZ(row);
+   (void)amb;
+   const int row = JIT_FASTCODE(code) * 4 + q, swz = TIP_SWZ(row);
    const char *base = (const char *)tab + row * 128;
 #pragma unroll
    for (int p = 0; p < 8; p++) v[p] = p < NP ? *(const double2 *)(base + ((p ^ swz) * 16)) : make_double2(0.0, 0.0);
+#ifdef JIT_AMB_OVERFLOW
+   if (code >= 64) jit_tip_overflow<NP>(amb, tab, code, q, v);
+#endif
 }
 
 template <int NP = 8>
-__device__ __forceinline__ void jit_tip_set(v4d (&y)[4], const double *tab, int code, int q, int lane)
+__device__ __forceinline__ void jit_tip_set(v4d (&y)[4], const double *tab, int code, int q, int lane, JitAmb amb = JitAmb())
 {
    double2 v[8];
-   tip_lds_n<NP>(tab, code, q, v);
+   tip_lds_n<NP>(tab, code, q, v, amb);
 #pragma unroll
    for (int i = 0; i < 8; i++) { y[i >> 1][(2 * i) & 3] = v[i].x; y[i >> 1][(2 * i + 1) & 3] = v[i].y; }
 }
 
 template <int NP = 8>
-__device__ __forceinline__ void jit_tip_mul(v4d (&y)[4], const double *tab, int code, int q, int lane)
+__device__ __forceinline__ void jit_tip_mul(v4d (&y)[4], const double *tab, int code, int q, int lane, JitAmb amb = JitAmb())
 {
    double2 v[8];
-   tip_lds_n<NP>(tab, code, q, v);
+   tip_lds_n<NP>(tab, code, q, v, amb);
 #pragma unroll
    for (int i = 0; i < NP; i++) { y[i >> 1][(2 * i) & 3] *= v[i].x; y[i >> 1][(2 * i + 1) & 3] *= v[i].y; }
 }
 
 template <int NP = 8>
-__device__ __forceinline__ void jit_tip2_set(v4d (&y)[4], const double *ta, int ca, const double *tb, int cb, int q, int lane)
+__device__ __forceinline__ void jit_tip2_set(v4d (&y)[4], const double *ta, int ca, const double *tb, int cb, int q, int lane, JitAmb amb = JitAmb())
 {
    double2 v[8], w[8];
-   tip_lds_n<NP>(ta, ca, q, v);
-   tip_lds_n<NP>(tb, cb, q, w);
+   tip_lds_n<NP>(ta, ca, q, v, amb);
+   tip_lds_n<NP>(tb, cb, q, w, amb);
 #pragma unroll
    for (int i = 0; i < 8; i++) { y[i >> 1][(2 * i) & 3] = v[i].x * w[i].x; y[i >> 1][(2 * i + 1) & 3] = v[i].y * w[i].y; }
 }
 
 template <int NP = 8>
-__device__ __forceinline__ void jit_tip2_mul(v4d (&y)[4], const double *ta, int ca, const double *tb, int cb, int q, int lane)
+__device__ __forceinline__ void jit_tip2_mul(v4d (&y)[4], const double *ta, int ca, const double *tb, int cb, int q, int lane, JitAmb amb = JitAmb())
 {
    double2 v[8], w[8];
-   tip_lds_n<NP>(ta, ca, q, v);
-   tip_lds_n<NP>(tb, cb, q, w);
+   tip_lds_n<NP>(ta, ca, q, v, amb);
+   tip_lds_n<NP>(tb, cb, q, w, amb);
 #pragma unroll
    for (int i = 0; i < NP; i++) {
       y[i >> 1][(2 * i) & 3] = (y[i >> 1][(2 * i) & 3] * v[i].x) * w[i].x;
@@ -1342,6 +1429,13 @@ __device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5
 #ifndef JIT_ZB
 #define JIT_ZB 2
 #endif
+/* doubles per tip table: one 32 KB block up to 64 codes; with more (JIT_AMB_OVERFLOW) the table goes on behind its first 64 rows,
+ * which are what the ring fetches */
+#ifdef JIT_AMB_OVERFLOW
+#define JIT_TIPW a.tip_words
+#else
+#define JIT_TIPW 4096
+#endif
 #define JIT2_PROLOGUE(ZP)                                                                                        \
    __shared__ __attribute__((aligned(16))) double ring[4 * 4096];                                               \
    __shared__ __attribute__((aligned(16))) unsigned char sZ[JIT_ZB * (ZP)*2048];                                 \
@@ -1373,7 +1467,7 @@ __device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5
       n_gene = as_const(a.tiles)[n_tile].x; n_h0 = as_const(a.tiles)[n_tile].y;                                 \
       n_hend = as_const(a.gene_off)[n_gene + 1];                                                                \
       nPint = a.pint + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 4096;                                      \
-      nPtip = a.ptip + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 4096;                                      \
+      nPtip = a.ptip + ((long)n_gene * a.K + n_iclass) * a.n_nodes * JIT_TIPW;                                  \
       nPcol = a.pcol + ((long)n_gene * a.K + n_iclass) * a.n_nodes * 64;                                        \
    }   /* past the last tile the n_* values stay: the (unused) prefetches keep reading valid memory */
 #define JIT2_ADVANCE(NBLK)                                                                                       \
@@ -1432,9 +1526,9 @@ __device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5
 #define JIT2_REAL_P ((ch_ >> 2) < JIT_KB2 && (ch_ & 3) < JIT_RB)
 #define JIT2_REAL_T (ch_ < JIT_TCH)
 #define JIT2_PIECE_P(J, NODE, C) JIT2_PIECE(Pint + (long)(NODE)*4096, J, C, JIT2_REAL_P)
-#define JIT2_PIECE_T(J, NODE, C) JIT2_PIECE(Ptip + (long)(NODE)*4096, J, C, JIT2_REAL_T)
+#define JIT2_PIECE_T(J, NODE, C) JIT2_PIECE(Ptip + (long)(NODE)*JIT_TIPW, J, C, JIT2_REAL_T)
 #define JIT2_PIECE_NP(J, NODE, C) JIT2_PIECE(nPint + (long)(NODE)*4096, J, C, JIT2_REAL_P)
-#define JIT2_PIECE_NT(J, NODE, C) JIT2_PIECE(nPtip + (long)(NODE)*4096, J, C, JIT2_REAL_T)
+#define JIT2_PIECE_NT(J, NODE, C) JIT2_PIECE(nPtip + (long)(NODE)*JIT_TIPW, J, C, JIT2_REAL_T)
 #define JIT2_CODE(ZP, TIP) ((int)sZ[zsel * ((ZP)*2048) + (TIP)*JIT_TP + hw])
 #define JIT2_NCODE(ZP, TIP) ((int)sZ[((zsel ^ 1) & (JIT_ZB - 1)) * ((ZP)*2048) + (TIP)*JIT_TP + hw])
 

@@ -138,6 +138,38 @@ int paml_amd_set_tips(paml_amd_engine *e, const unsigned char *z, int cleandata,
    const size_t nz = (size_t)e->n_tips * e->n_patt;
    for (size_t i = 0; i < nz; i++)
       if (z[i] >= n_codes) return fail(e, PAML_AMD_EINVAL, "set_tips: character code >= n_codes");
+   // More than 64 codes at 21 .. 64 states (61 sense codons + more than three ambiguous triplets, SetMapAmbiguity treesub.c:1218-1286): the
+   // per-tree kernel's ring block holds a tip's rows of the codes 0 .. 63, and a lane whose code is beyond them adds up the rows of the
+   // code's states itself (jit_tip_overflow) — as many LDS reads as the set has states.  Which ambiguous codes get the fast rows is the
+   // engine's choice: the codes past the single states are renumbered by (cells that hold the code) x (states of its set), descending,
+   // so that "missing" and whatever else is frequent sit below 64.  Invisible to the caller: codes only index the tip tables.
+   std::vector<unsigned char> zperm;
+   if (e->kk == KK_MFMA64 && n_codes > 64) {
+      int plain = 0;
+      while (plain < std::min(n, n_codes) && nch[plain] == 1 && cmap[(size_t)plain * n] == plain) plain++;
+      std::vector<long> cnt(n_codes, 0);
+      for (size_t i = 0; i < nz; i++) cnt[z[i]]++;
+      std::vector<int> order;      // old code numbers, in their new order
+      for (int c = 0; c < n_codes; c++) order.push_back(c);
+      std::stable_sort(order.begin() + plain, order.end(), [&](int x, int y) { return cnt[x] * nch[x] > cnt[y] * nch[y]; });
+      std::vector<unsigned char> new_of(n_codes);
+      std::vector<int> nch2(n_codes);
+      std::vector<unsigned char> cmap2((size_t)n_codes * n, 0);
+      for (int c = 0; c < n_codes; c++) {
+         new_of[order[c]] = (unsigned char)c;
+         nch2[c] = nch[order[c]];
+         memcpy(&cmap2[(size_t)c * n], &cmap[(size_t)order[c] * n], n);
+      }
+      nch.swap(nch2);
+      cmap.swap(cmap2);
+      zperm.resize(nz);
+      for (size_t i = 0; i < nz; i++) zperm[i] = new_of[z[i]];
+      z = zperm.data();
+   }
+   e->amb_ascending = true;
+   for (int c = 64; c < n_codes; c++)
+      for (int k = 1; k < nch[c]; k++)
+         if (cmap[(size_t)c * n + k] <= cmap[(size_t)c * n + k - 1]) e->amb_ascending = false;
    e->cleandata = cleandata ? 1 : 0;
    e->n_codes = n_codes;
    e->plain_codes = 0;      // the leading codes that are one state each, the code itself (every code of clean data; the sense codons / amino acids / bases otherwise)

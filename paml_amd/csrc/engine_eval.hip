@@ -290,7 +290,8 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       // 4.63 ms with three classes — 40 spilled dwords and a third more LDS / DMA traffic per step), kept as a generator parameter
       int jw = 8;
       if (e->env.jit_waves == 12 && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, 192) && jit_zbuffers(e->n_tips, 192) == 2) jw = 12;
-      if (e->jit_enabled && !e->env.force_gather && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16, e->jit_forced)) {
+      // (more than 64 codes: the per-tree kernel sums the rows of a code's states in ascending order — e->amb_ascending, set_tips)
+      if (e->jit_enabled && !e->env.force_gather && (e->n_codes <= 64 || e->amb_ascending) && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16, e->jit_forced)) {
          const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "w" + std::to_string(jw) + (jit_rowtail(n) ? "r:" : ":") + jit_program_key(e->prog, e->n_tips);
          // Large trees (> 120 ops: roughly more than 35 taxa): tens of thousands of instructions, many seconds of compiler time.  Unless the
          // caller asked to wait (PAML_AMD_JIT flag / PAML_AMD_JIT_SYNC), the kernel is built on a worker thread while the interpreter kernels
@@ -574,6 +575,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
    pr.first_tip = e->prog.first_tip;
    pr.tile_group0 = e->d_tile_group0.p; pr.part_groups = e->part_groups();
    pr.part_dump = (keep && e->kk == KK_MFMA64) ? e->d_partials.p + (size_t)K * n_int * e->part_groups() * 1024 : nullptr;
+   pr.code_mask = e->d_code_mask.p;
    pr.stream = e->d_stream.p; pr.n_stream = (int)(e->prog.stream.size() / 2); pr.tip_words = (long)tip_words(e);
    // the reduction's geometry (the fused kernels form the partial sums themselves; the others leave them to reduce_stage1)
    const int chunk = e->chunk, nbg = e->nb_global;

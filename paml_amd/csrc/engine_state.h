@@ -419,6 +419,7 @@ struct paml_amd_engine {
    DevBuf<PmatRes> d_pres;           // PmatArgs::res: the resolved (parameter set, node) table of single evaluations
    bool pres_valid = false;          // ... is current (dropped by set_tree / set_classes / any set_eigen_*)
    int plain_codes = 0;             // set_tips: codes below this are single states equal to the code
+   bool amb_ascending = true;       // set_tips: every code from 64 on lists its states in ascending order (what the per-tree kernel's overflow path sums in)
    int pmat_B = 1;                   // batch elements of the evaluation whose P(t) the buffers hold (get_pmat: element 0)
    bool rowmajor_valid = false;      // d_rowmajor holds the last evaluation's matrices (pmat_mfma_kernel in the mfma64 layout does not write them)
    DevBuf<EigenDev> d_eigen;

@@ -109,7 +109,7 @@ inline bool jit_zfits(const Program &p, int n_tips, int tp = 128)
 
 inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6, int tp = 128, bool allow_load = false)
 {
-   if (n_codes > 64 || p.ops.size() > 1400 || n_pi > 4) return false;
+   if (n_codes > 256 || p.ops.size() > 1400 || n_pi > 4) return false;      // (more than 64 codes: JIT_AMB_OVERFLOW, device_common.h)
    if (!jit_zfits(p, n_tips, tp)) return false;
    if (p.stream.size() / 2 < 4) return false;                       // trees this small go to the interpreter
    for (const Op &o : p.ops)
@@ -218,9 +218,16 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    if (jit_experiment_env("PAML_AMD_JIT_ABL_NOBAR")) s << "#define JIT_ABL_NOBAR 1\n";      // timing experiment: no workgroup barriers (results are garbage)
    const char *abl_skew = jit_experiment_env("PAML_AMD_JIT_ABL_SKEW");                       // ... and waves 4-7 start this many x 64 cycles late
    if (zsingle) s << "#define JIT_ZB 1\n";
+   const bool amb_over = n_codes > 64;      // codes beyond the 64 a ring block has rows for: summed from the rows of their states (device_common.h)
+   if (amb_over) s << "#define JIT_AMB_OVERFLOW 1\n";
+   const std::string ambarg = amb_over ? ", amb" : "";
    s << "#include \"device_common.h\"\nusing namespace paml_amd;\n";
    s << "extern \"C\" __global__ __launch_bounds__(" << waves * 64 << ", " << waves / 4 << ") void prune_jit(PruneArgs a)\n{\n";
    s << "   JIT2_PROLOGUE(" << ZP << ")\n";
+   if (amb_over) {      // the state sets of the codes 64 .. : into the three quarters of sPi a single frequency vector leaves unused (192 x 8 bytes)
+      s << "   if (a.n_pi == 1) for (int i = tid; i < a.n_codes - 64; i += JIT_WAVES * 64) ((unsigned long long *)sPi)[64 + i] = a.code_mask[64 + i];\n";
+      s << "   const JitAmb amb{a.code_mask, (__attribute__((address_space(3))) const unsigned long long *)(sPi + 64), a.n_pi == 1};\n";
+   }
    if (abl_skew) s << "   if (wave >= 4) { for (int i_ = 0; i_ < " << atoi(abl_skew) << "; i_++) __builtin_amdgcn_s_sleep(1); }\n";
    s << "   roff = " << ((4 - nblk % 4) & 3) << ";\n";
 
@@ -356,7 +363,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    if (peel) {
       const int nw = wait_count(nblk + 1);
       s << "   JIT_WAIT(" << nw << "); __syncthreads();\n";
-      s << "   jit_tip2_set<" << NPc << ">(AS, " << buf(nblk) << ", " << ncode(p.ops[0].a) << ", " << buf(nblk + 1) << ", " << ncode(p.ops[0].b) << ", q, lane);\n";
+      s << "   jit_tip2_set<" << NPc << ">(AS, " << buf(nblk) << ", " << ncode(p.ops[0].a) << ", " << buf(nblk + 1) << ", " << ncode(p.ops[0].b) << ", q, lane" << ambarg << ");\n";
    }
    if (zsingle) {      // everything requested so far has to be there when the loop starts: the same state the loop's end leaves
       s << "   JIT_WAIT(0); __syncthreads();\n";
@@ -408,13 +415,13 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          if (cur < 0) cur = alloc();
          cross_if({o.a});
          step(1);
-         s << "   jit_tip_set<" << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane);\n";
+         s << "   jit_tip_set<" << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane" << ambarg << ");\n";
          consumed += 1;
          break;
       case OP_MUL_TIP:
          cross_if({o.a});
          step(1);
-         s << "   jit_tip_mul<" << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane);\n";
+         s << "   jit_tip_mul<" << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane" << ambarg << ");\n";
          consumed += 1;
          break;
       case OP_SET_TIP2:
@@ -423,7 +430,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          cross_if({o.a, o.b});
          step(2);
          s << "   " << (o.code == OP_SET_TIP2 ? "jit_tip2_set<" : "jit_tip2_mul<") << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a)
-           << ", " << buf(consumed + 1) << ", " << code(o.b) << ", q, lane);\n";
+           << ", " << buf(consumed + 1) << ", " << code(o.b) << ", q, lane" << ambarg << ");\n";
          consumed += 2;
          break;
       case OP_PUSH:
@@ -455,7 +462,8 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
             const int mid = wait_count(consumed + 2);
             s << "   jit_matvec_tip2<" << (mid < 0 ? 63 : mid) << (tail61 ? ", true, " : ", false, ") << RB << ", " << KB << ">(" << buf(consumed) << ", lane, " << name(cur)
               << ", " << name(out) << ", " << buf(consumed + 1) << ", " << (fuse ? code(nx.a) : ncode(nx.a)) << ", " << buf(consumed + 2) << ", "
-              << (fuse ? code(nx.b) : ncode(nx.b)) << ", q, " << name(tgt) << ", " << side << colarg(consumed) << ");" << (tail61 ? " }" : "") << "\n";
+              << (fuse ? code(nx.b) : ncode(nx.b)) << ", q, " << name(tgt) << ", " << side << colarg(consumed) << (amb_over ? (tail61 ? ", amb" : ", nullptr, 0.0, amb") : "") << ");"
+              << (tail61 ? " }" : "") << "\n";
             consumed += 3;
          }
          else {

@@ -82,6 +82,33 @@ def codon_m0_problem(n_tips=16, n_patt=1000, kappa=2.0, omega=0.4, seed=20260926
                    eigen=[dict(kind=EIGEN_UVROOT, U=U, V=V, Root=root)], mode=MODE_LFUN)
 
 
+def with_ambiguous_codons(base: Problem, missing_rate=0.015, partial_rate=0.0005, sizes=(2, 2, 2, 3, 4, 4, 4, 4, 4, 16, 16), seed=7) -> Problem:
+    """`base` (clean codon data) as a cleandata = 0 alignment: the 61 sense codons, then one code per distinct ambiguous triplet the way
+    SetMapAmbiguity numbers them (treesub.c:1218-1286) — here len(sizes) partially resolved triplets (state sets of 2 .. 16 codons, each
+    in `partial_rate` of the cells) and, LAST, the fully missing one (every codon, `missing_rate` of the cells): 61 + 12 = 73 codes."""
+    import dataclasses
+    rng = np.random.default_rng(seed)
+    n = base.n
+    n_codes = n + len(sizes) + 1
+    n_chara = np.ones(n_codes, dtype=np.int32)
+    cmap = np.zeros((n_codes, n), dtype=np.uint8)
+    cmap[:n, 0] = np.arange(n)
+    for k, sz in enumerate(sizes):
+        first = int(rng.integers(0, n - sz + 1))
+        n_chara[n + k] = sz
+        cmap[n + k, :sz] = np.arange(first, first + sz)      # (neighbouring codons: what an unresolved third or second position gives)
+    n_chara[n_codes - 1] = n
+    cmap[n_codes - 1] = np.arange(n)
+    z = base.z.copy()
+    u = rng.random(z.shape)
+    z[u < missing_rate] = n_codes - 1
+    lo = missing_rate
+    for k in range(len(sizes)):
+        z[(u >= lo) & (u < lo + partial_rate)] = n + k
+        lo += partial_rate
+    return dataclasses.replace(base, z=z, cleandata=0, n_chara=n_chara, chara_map=cmap, eigen_of=None, qfactor=None)
+
+
 def codon_nssites_problem(base: Problem, kappa: float, omegas, freqs) -> Problem:
     """Same data/tree as `base`, K omega classes sharing one Qfactor_NS scale (codeml.c:2590-2600,
     treesub.c:7675-7685): class ir uses U,V,Root of Q(omega_ir) with Root / (1/Qfactor_NS)."""

@@ -180,7 +180,7 @@ def problem_from_golden(g) -> Problem:
 
 
 def random_problem(n, n_tips, n_patt, K=1, seed=0, ambiguity=False, scale_every=None, n_genes=1, polytomy=False,
-                   mode=None):
+                   mode=None, n_amb=0, amb_rate=0.08):
     """Random reversible model + random tree + random tips: a parity case with no biological meaning."""
     rng = np.random.default_rng(seed)
     pi = rng.dirichlet(np.full(n, 3.0))
@@ -244,7 +244,17 @@ def random_problem(n, n_tips, n_patt, K=1, seed=0, ambiguity=False, scale_every=
         cmap[n + 1, :2] = [1, 3 % n]
         n_chara[n + 2] = 3
         cmap[n + 2, :3] = [0, 2 % n, (n - 1)]
-        amb = rng.random((n_tips, n_patt)) < 0.08
+        # n_amb further ambiguity codes (SetMapAmbiguity treesub.c:1218-1286 makes one of every distinct ambiguous triplet): random state
+        # sets of 2 .. 16 states in ascending order; with 61 states, n + 3 + n_amb > 64 codes cross the per-tree kernel's ring block
+        if n_amb:
+            n_chara = np.concatenate([n_chara, np.zeros(n_amb, dtype=np.int32)])
+            cmap = np.concatenate([cmap, np.zeros((n_amb, n), dtype=np.uint8)])
+            for c in range(n_codes, n_codes + n_amb):
+                size = int(rng.integers(2, min(n, 16) + 1))
+                n_chara[c] = size
+                cmap[c, :size] = np.sort(rng.choice(n, size=size, replace=False))
+            n_codes += n_amb
+        amb = rng.random((n_tips, n_patt)) < amb_rate
         z = np.where(amb, rng.integers(n, n_codes, size=(n_tips, n_patt)), z).astype(np.uint8)
         kw.update(cleandata=0, n_chara=n_chara, chara_map=cmap)
     if K > 1:

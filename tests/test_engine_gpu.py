@@ -590,6 +590,38 @@ def test_specialised_kernels_via_flag(n, n_tips, n_patt, K, genes, amb, every):
     assert abs(got[1] - r1) <= 1e-10 * abs(r1)
 
 
+@pytest.mark.parametrize("n,n_tips,n_patt,K,n_amb,kw", [(61, 13, 700, 2, 20, {}), (61, 40, 300, 1, 60, dict(scale_every=12)), (64, 9, 400, 1, 9, {}),
+                                                       (61, 16, 2000, 1, 150, dict(amb_rate=0.3)), (33, 10, 300, 2, 40, {}), (61, 12, 500, 3, 12, dict(n_genes=2))])
+def test_more_than_64_character_codes_on_the_per_tree_kernel(n, n_tips, n_patt, K, n_amb, kw, monkeypatch):
+    """61 sense codons + more than three distinct ambiguous triplets (SetMapAmbiguity treesub.c:1218-1286; the ambiguous-tip branch of
+    ConditionalPNode, codeml.c:3560-3567): up to round 5 such data fell to the gather interpreter.  The per-tree kernel's ring block has
+    a tip's rows of 64 codes; lanes whose code lies beyond add up the rows of the code's states themselves (jit_tip_overflow), and the engine
+    numbers the ambiguous codes by frequency x set size so that those are the rare ones.  lnL, every log f_h and fhK against the oracle
+    to 1e-10 — check() crosses the 64 codes — on the per-tree kernel, equal to the interpreter's values, and a keep-partials engine too."""
+    pb = helpers.random_problem(n, n_tips, n_patt, K=K, seed=6400 + n_tips, ambiguity=True, n_amb=n_amb, **kw)
+    assert pb.n_codes > 64 and len(np.unique(pb.z)) > 64
+    eng, out, ref = check(pb, flags=JIT)
+    assert eng.kernel_name == "mfma64_jit", eng.kernel_name
+    monkeypatch.setenv("PAML_AMD_JIT", "0")
+    eng0, out0, _ = check(pb)
+    assert eng0.kernel_name in ("mfma64_gather", "mfma64_coop", "mfma64_coopjit")
+    assert abs(out0["lnL"] - out["lnL"]) <= 1e-12 * abs(out["lnL"]) and np.max(np.abs(out0["lnf"] - out["lnf"])) < 1e-11
+    monkeypatch.setenv("PAML_AMD_JIT", "1")
+    engk, outk, _ = check(pb, flags=KEEP_PARTIALS)
+    assert engk.kernel_name == "mfma64_jit" and outk["lnL"] == out["lnL"]
+
+
+def test_more_than_64_codes_with_unordered_state_sets_stay_on_the_interpreter():
+    """The per-tree kernel's overflow path adds a code's rows in ascending state order — the order of SetMapAmbiguity's CharaMap; a caller
+    whose map lists a set's states in another order gets the interpreter (whose table rows are summed in the caller's order), same values."""
+    pb = helpers.random_problem(61, 10, 300, K=1, seed=77, ambiguity=True, n_amb=10)
+    for c in range(pb.n, pb.n_codes):      # (every ambiguous set: whichever of them the engine numbers from 64 on is then out of order)
+        k = pb.n_chara[c]
+        pb.chara_map[c, :k] = pb.chara_map[c, :k][::-1]
+    eng, out, ref = check(pb, flags=JIT)
+    assert eng.kernel_name != "mfma64_jit"
+
+
 @pytest.mark.parametrize("n,n_tips,n_patt,K,cuts,own,kw", [
     (4, 12, 3000, 4, [0, 700, 1536, 3000], False, {}),                        # a boundary inside a 256-pattern sub-tile, one on a chunk edge
     (4, 32, 5000, 4, [0, 100, 130, 2600, 5000], True, {}),                    # two boundaries inside one sub-tile; the genes' own models (Mgene 2-4)
