@@ -183,6 +183,11 @@ CTL_OF = {"hiv_m0": "hiv_ns0", "hiv_m1a": "hiv_ns1", "hiv_m2a": "hiv_ns2", "hiv_
 SINGLE = [("codeml", n) for n in ("hiv_m0", "hiv_m2a", "hiv_m3", "hiv_m8", "lysos_branch_fix", "lysos_clade_label", "mtcdna_branch", "lyso_bsa", "lyso_bsa_null",
                                   "lyso_bsb", "ecp_cmc", "ecp_cmd", "ecp_m2arel", "lysin_mg0", "lysin_mg2", "lysin_mg3", "lysin_mg4", "stewart_lg_g4")] + \
          [("baseml", n) for n in ("brown_hky85", "brown_t92_g4", "horai_mg0", "horai_mg0_g5")]
+# round 6: the baseml binding takes nhomo 1 .. 5 (an eigen system per branch: treesub.c:7512-7519), Mgene 2 .. 4 (SetPGene), clock 1 / 2
+# (GetBranchRate folded into lengths and gene rates; TipDate), UNREST (Q + matexp), rho != 0 (lfunAdG: paml_amd_eval_adg)
+SINGLE += [("baseml", n) for n in ("brown_f84", "brown_hky85_nhomo1", "brown_hky85_nhomo2", "brown_hky85_nhomo3", "brown_hky85_nhomo5", "brown_f84_nhomo4",
+                                  "brown_t92_nhomo3_g4", "brown_hky85_clock", "brown_hky85_clock2", "hiv2_tipdate", "hiv2_tipdate_clock2", "brown_unrest",
+                                  "horai_mg2", "horai_mg3", "horai_mg4", "brown_hky85_adg")]
 
 
 def single_evaluation(prog, name, d, exe, extra_ctl="", env=None):
@@ -207,12 +212,15 @@ def test_single_evaluation_through_the_patched_reference_matches_the_printed_dig
     exe = REF_GPU if prog == "codeml" else BASEML_GPU
     if not (os.path.isfile(exe) and os.access(exe, os.X_OK)):
         pytest.skip("oracle/_ref/%s_gpu is not built (make -C oracle, needs /root/reference)" % prog)
-    g, lnl, lnf, out = single_evaluation(prog, name, tmp_path / "gpu", exe)
+    g, lnl, lnf, out = single_evaluation(prog, name, tmp_path / "gpu", exe, env=dict(os.environ, PAML_AMD_ANNOUNCE="1"))
     assert "paml_amd" not in out, out[-2000:]
+    if prog == "baseml":      # (the engine answered, not the reference's own function the binding falls back to for what it does not take)
+        assert "engine behind com.plfun" in out, out[-2000:]
     assert abs(lnl - g["lnL"]) <= 2e-6, (name, lnl, g["lnL"])
-    assert len(lnf) == g["n_patt"] and np.max(np.abs(lnf - np.array(g["logf"]))) <= 2e-8, (name, float(np.max(np.abs(lnf - np.array(g["logf"])))))
+    if g.get("logf"):      # (lfunAdG's sites are not independent: no per-pattern values)
+        assert len(lnf) == g["n_patt"] and np.max(np.abs(lnf - np.array(g["logf"]))) <= 2e-8, (name, float(np.max(np.abs(lnf - np.array(g["logf"])))))
     # the engine really was behind com.plfun: with PAML_AMD_OFF the same binary prints the same digits from the reference's own functions
-    if name in ("lyso_bsa", "lysin_mg2", "horai_mg0"):
+    if name in ("lyso_bsa", "lysin_mg2", "horai_mg0", "brown_hky85_nhomo3", "brown_hky85_clock2", "horai_mg4"):
         g2, lnl2, lnf2, out2 = single_evaluation(prog, name, tmp_path / "off", exe, env=dict(os.environ, PAML_AMD_OFF="1"))
         assert abs(lnl2 - g["lnL"]) <= 2e-6
 
@@ -373,6 +381,34 @@ def test_neb_and_beb_tables_through_the_engine_equal_the_reference_code_paths(na
             decimals = len(ys.split(".")[1]) if "." in ys and "e" not in ys.lower() else 0
             assert abs(fx - fy) <= 1.01 * 10.0 ** (-decimals) + 1e-6 * abs(fy), (name, x, y)
     print("\n%s at its estimates through codeml_gpu: %.2f s with the NEB / BEB evaluations on the engine, %.2f s with the reference's own" % (name, res["engine"][3], res["host"][3]))
+
+
+@pytest.mark.parametrize("name,extra", [("brown_hky85", ""), ("brown_t92_g4", ""), ("horai_mg0_g5", ""), ("horai_mg3", ""), ("brown_hky85_clock", ""), ("hiv2_tipdate_clock2", "")])
+def test_baseml_batched_gradient_equals_the_serial_one(name, extra, tmp_path):
+    """Round 6: baseml's gradientB through the seam too (lfun_gpu_batch of integration/baseml_plfun.patch): one paml_amd_eval_batch per gradient —
+    kappa / rate parameters / alpha perturbed (an eigen set per distinct model part), several genes with their own systems, node ages and
+    local-clock rates perturbed under the clock models (every vector its own branch lengths through SetBranch + GetBranchRate).  The batched
+    values are those of the serial calls to 1e-9 for every gradient of a run, and the run ends at the unmodified program's optimum."""
+    if not (os.path.isfile(BASEML_GPU) and os.access(BASEML_GPU, os.X_OK)):
+        pytest.skip("oracle/_ref/baseml_gpu is not built (make -C oracle, needs /root/reference)")
+    ctl = open(os.path.join(helpers.GOLDEN, "ctl", name + ".ctl")).read()
+    ctl = ctl.replace("../data/", DATA + "/").replace("../ctl/", os.path.join(helpers.GOLDEN, "ctl") + "/")
+    ctl += "\noutfile = mlc\nnoisy = 3\ngetSE = 0\nRateAncestor = 0\n" + extra
+    res = {}
+    for tag, exe, env in (("gpu", BASEML_GPU, dict(os.environ, PAML_AMD_GRADIENT_CHECK="1")), ("cpu", BASEML_CPU, None)):
+        d = tmp_path / tag
+        d.mkdir()
+        (d / "baseml.ctl").write_text(ctl)
+        r = subprocess.run([exe, "baseml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=1500, env=env)
+        out = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, out[-3000:]
+        lnl = [float(m.group(1)) for m in re.finditer(r"lnL\(ntime:\s*\d+\s+np:\s*\d+\):\s+(-?\d+\.\d+)", (d / "mlc").read_text())]
+        res[tag] = (lnl, out)
+    out = res["gpu"][1]
+    checks = [(int(m.group(1)), int(m.group(2)), float(m.group(3))) for m in re.finditer(r"gradient check: (\d+) vectors, (\d+) model parts, max \|batched - serial\| = ([0-9.e+-]+)", out)]
+    assert len(checks) >= 3, out[-2000:]
+    assert max(c[2] for c in checks) <= 1e-9, max(checks, key=lambda c: c[2])
+    assert len(res["gpu"][0]) == len(res["cpu"][0]) >= 1 and abs(res["gpu"][0][0] - res["cpu"][0][0]) <= 5e-5, (res["gpu"][0], res["cpu"][0])
 
 
 def test_batched_gradient_can_be_switched_off(tmp_path):
