@@ -179,10 +179,15 @@ def test_patched_reference_baseml_matches_the_unmodified_program(model, fix_alph
 # iterate") through the PATCHED program, on the control files of the golden cases: the lnL it prints (the first com.plfun call: eigen
 # systems decomposed on the device from the rate matrices eigenQcodon built) against the unmodified program's to 2e-6 (six printed
 # decimals), and the `lnf` file (the second call, com.print < 0: host eigen systems, uploaded) to 2e-8 (ten decimals).
-CTL_OF = {"hiv_m0": "hiv_ns0", "hiv_m1a": "hiv_ns1", "hiv_m2a": "hiv_ns2", "hiv_m3": "hiv_ns3", "hiv_m7": "hiv_ns7", "hiv_m8": "hiv_ns8"}
+CTL_OF = {"hiv_m0_f1x4mg": "hiv_ns0_cf4", "hiv_m0_f3x4mg": "hiv_ns0_cf5", "hiv_m0": "hiv_ns0", "hiv_m1a": "hiv_ns1", "hiv_m2a": "hiv_ns2", "hiv_m3": "hiv_ns3", "hiv_m7": "hiv_ns7", "hiv_m8": "hiv_ns8"}
 SINGLE = [("codeml", n) for n in ("hiv_m0", "hiv_m2a", "hiv_m3", "hiv_m8", "lysos_branch_fix", "lysos_clade_label", "mtcdna_branch", "lyso_bsa", "lyso_bsa_null",
                                   "lyso_bsb", "ecp_cmc", "ecp_cmd", "ecp_m2arel", "lysin_mg0", "lysin_mg2", "lysin_mg3", "lysin_mg4", "stewart_lg_g4")] + \
          [("baseml", n) for n in ("brown_hky85", "brown_t92_g4", "horai_mg0", "horai_mg0_g5")]
+# round 6: the codeml binding takes the mutation-selection models, aaDist / AAClasses, codon frequencies as parameters, REVaa and the codon-based
+# amino-acid models (what libpamlh already served on the engine; goldens of round 2)
+SINGLE += [("codeml", n) for n in ("hiv_fmutsel", "hiv_fmutsel0", "hiv_fmutsel_est", "hiv_fmutsel0_est", "hiv_fmutsel0_m2a", "hiv_f3x4_est", "hiv_f1x4mg_est", "hiv_f3x4_est_m7",
+                                   "hiv_m0_f1x4mg", "hiv_m0_f3x4mg", "mtcdnapri_aadist1", "mtcdnapri_aadist_m2", "mtcdna_aaclass_m0", "mtcdna_aaclass_branch",
+                                   "mtcdnapri_revaa", "mtcdnapri_revaa0", "mtcdnapri_fromcodon", "mtcdnapri_fromcodon0", "stewart_eqinput")]
 # round 6: the baseml binding takes nhomo 1 .. 5 (an eigen system per branch: treesub.c:7512-7519), Mgene 2 .. 4 (SetPGene), clock 1 / 2
 # (GetBranchRate folded into lengths and gene rates; TipDate), UNREST (Q + matexp), rho != 0 (lfunAdG: paml_amd_eval_adg)
 SINGLE += [("baseml", n) for n in ("brown_f84", "brown_hky85_nhomo1", "brown_hky85_nhomo2", "brown_hky85_nhomo3", "brown_hky85_nhomo5", "brown_f84_nhomo4",
@@ -197,6 +202,8 @@ def single_evaluation(prog, name, d, exe, extra_ctl="", env=None):
     ctl += "\noutfile = mlc\nnoisy = 3\ngetSE = 0\nRateAncestor = 0\n" + extra_ctl
     d.mkdir()
     (d / (prog + ".ctl")).write_text(ctl)
+    for dat in ("grantham.dat", "miyata.dat", "OmegaAA.dat"):      # (aaDist: the reference opens these by name in the working directory)
+        (d / dat).write_text(open(os.path.join(helpers.GOLDEN, "ctl", dat)).read())
     (d / ("in." + prog)).write_text("-1 " + " ".join("%.6f" % v for v in g["x"]) + "\n")
     r = subprocess.run([exe, prog + ".ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=900, env=env)
     out = r.stdout.decode(errors="replace")
@@ -214,8 +221,7 @@ def test_single_evaluation_through_the_patched_reference_matches_the_printed_dig
         pytest.skip("oracle/_ref/%s_gpu is not built (make -C oracle, needs /root/reference)" % prog)
     g, lnl, lnf, out = single_evaluation(prog, name, tmp_path / "gpu", exe, env=dict(os.environ, PAML_AMD_ANNOUNCE="1"))
     assert "paml_amd" not in out, out[-2000:]
-    if prog == "baseml":      # (the engine answered, not the reference's own function the binding falls back to for what it does not take)
-        assert "engine behind com.plfun" in out, out[-2000:]
+    assert "engine behind com.plfun" in out, out[-2000:]      # (the engine answered, not the reference's own function the binding falls back to for what it does not take)
     assert abs(lnl - g["lnL"]) <= 2e-6, (name, lnl, g["lnL"])
     if g.get("logf"):      # (lfunAdG's sites are not independent: no per-pattern values)
         assert len(lnf) == g["n_patt"] and np.max(np.abs(lnf - np.array(g["logf"]))) <= 2e-8, (name, float(np.max(np.abs(lnf - np.array(g["logf"])))))
@@ -409,6 +415,40 @@ def test_baseml_batched_gradient_equals_the_serial_one(name, extra, tmp_path):
     assert len(checks) >= 3, out[-2000:]
     assert max(c[2] for c in checks) <= 1e-9, max(checks, key=lambda c: c[2])
     assert len(res["gpu"][0]) == len(res["cpu"][0]) >= 1 and abs(res["gpu"][0][0] - res["cpu"][0][0]) <= 5e-5, (res["gpu"][0], res["cpu"][0])
+
+
+@pytest.mark.parametrize("prog,ctl_name,extra", [("codeml", "lysos_m0_clock", ""), ("codeml", "lysos_m0_clock", "clock = 2\n"), ("codeml", "stewart_lg_g4", "fix_rho = 0\nrho = 0.2\n"),
+                                                 ("baseml", "brown_hky85_adg", "")])
+def test_clock_models_and_correlated_rates_through_the_patched_reference(prog, ctl_name, extra, tmp_path):
+    """Round 6: codon M0 under the global and the local clock (SetBranch's node ages, GetBranchRate folded into the lengths handed over; the
+    batched gradient perturbs ages and rates), and rho != 0 (lfunAdG: fx_r on the engine, the chain over the sites in paml_amd_eval_adg) for
+    amino-acid and nucleotide data — the reference's own ming2 on the engine against the unmodified program on the same control file."""
+    exe, cpu = (REF_GPU, REF_CPU) if prog == "codeml" else (BASEML_GPU, BASEML_CPU)
+    if not (os.path.isfile(exe) and os.access(exe, os.X_OK)):
+        pytest.skip("oracle/_ref/%s_gpu is not built (make -C oracle, needs /root/reference)" % prog)
+    ctl = open(os.path.join(helpers.GOLDEN, "ctl", ctl_name + ".ctl")).read()
+    ctl = ctl.replace("../data/", DATA + "/").replace("../ctl/", os.path.join(helpers.GOLDEN, "ctl") + "/")
+    ctl += "\noutfile = mlc\nnoisy = 3\ngetSE = 0\nRateAncestor = 0\n" + extra
+    if "clock = 2" in extra:      # the local clock wants its rate classes marked in the tree: one clade with a rate of its own
+        tree = open(os.path.join(DATA, "lysozymeSmall.rooted.trees")).read().replace("((3,4),5)", "((3,4) #1,5) #1")
+        assert "#1" in tree
+        ctl += "treefile = local.trees\n"
+    res = {}
+    for tag, e, env in (("gpu", exe, dict(os.environ, PAML_AMD_ANNOUNCE="1")), ("cpu", cpu, None)):
+        d = tmp_path / tag
+        d.mkdir()
+        (d / (prog + ".ctl")).write_text(ctl)
+        if "clock = 2" in extra:
+            (d / "local.trees").write_text(tree)
+        t0 = time.perf_counter()
+        r = subprocess.run([e, prog + ".ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=1500, env=env)
+        out = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, out[-3000:]
+        lnl = [float(m.group(1)) for m in re.finditer(r"lnL\(ntime:\s*\d+\s+np:\s*\d+\):\s+(-?\d+\.\d+)", (d / "mlc").read_text())]
+        res[tag] = (lnl, out, time.perf_counter() - t0)
+    assert "engine behind com.plfun" in res["gpu"][1], res["gpu"][1][-2000:]
+    assert len(res["gpu"][0]) == len(res["cpu"][0]) == 1 and abs(res["gpu"][0][0] - res["cpu"][0][0]) <= 5e-5, (res["gpu"][0], res["cpu"][0])
+    print("\n%s %s %s: lnL %.6f, engine %.2f s, unmodified program %.2f s" % (prog, ctl_name, extra.strip(), res["gpu"][0][0], res["gpu"][2], res["cpu"][2]))
 
 
 def test_batched_gradient_can_be_switched_off(tmp_path):
