@@ -733,6 +733,16 @@ def bench_branch(engine, pb, lnl_full):
             hit1.append(call(eng, b, [t.branch[b] * 1.02])[0])
             hit4.append(call(eng, b, t.branch[b] * (1 + 0.05 * np.arange(1, 5)))[0])
     c1 = eng.branch_counters()
+    # the hit path's kernel alone (branch_poly_kernel on the stored coefficients: 512 B read per pattern), HIP events around it
+    bh = internal[0]
+    call(eng, bh, [t.branch[bh]])
+    eng.profile(True)
+    hit_k = []
+    for i in range(6):
+        call(eng, bh, [t.branch[bh] * (1.01 + 0.002 * i)])
+        hit_k.append(eng.branch_kernel_ms())
+    eng.profile(False)
+    hit_kernel_ms = float(np.mean(hit_k[1:]))
     eng.close()
     os.environ["PAML_AMD_NO_COEF_CACHE"] = "1"      # (measurement switch: every call forms the coefficients again)
     try:
@@ -766,6 +776,7 @@ def bench_branch(engine, pb, lnl_full):
                                 "allocation and first touch of the resident buffers" % n_int,
                 walk_form_nt1_ms=float(np.mean(form)), walk_form_nt1_ms_max=float(np.max(form)),
                 walk_hit_nt1_ms=float(np.mean(hit1)), walk_hit_nt4_ms=float(np.mean(hit4)),
+                hit_kernel_ms=hit_kernel_ms, hit_kernel_GBs=512.0 * pb.n_patt / (hit_kernel_ms * 1e-3) / 1e9, hit_kernel_frac_of_hbm=512.0 * pb.n_patt / (hit_kernel_ms * 1e-3) / 8e12,
                 nodes_reformed_per_walk_call=(c1["n_nodes"] - c0["n_nodes"]) / len(form), coef_hits=c1["coef_hits"], **res,
                 roofline=dict(kernel="branch_eig_kernel<0,.,.,false> (both partials resident, internal branch, nt = 1)", bound="hbm" if t_hbm >= t_mfma else "mfma",
                               kernel_ms=kms, bytes_per_pattern=1536, flop_per_pattern=4 * 61 * 61, bound_ms=max(t_hbm, t_mfma),
