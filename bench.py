@@ -411,6 +411,10 @@ def main():
     if rank == 0 and world == 1 and extras:
         out["c2"] = bench_c2(engine, synth, timed, args)
         out["c2_batch"] = bench_c2_batch(engine, synth, fence)
+        try:
+            out["c2_large"] = bench_c2_large(engine, synth, timed, args)
+        except Exception as ex:      # (its own guard: a host short of memory for the 10^7-pattern copy must not cost the blocks behind it)
+            out["c2_large"] = {"error": repr(ex)}
         out["aa20"] = bench_aa20(engine, synth, timed, args)
         try:
             out["fallbacks"] = bench_fallbacks(engine, synth, timed, pb_full if (args.scaling == "strong" and pb.n == 61) else None)
@@ -525,6 +529,49 @@ def bench_c2(engine, synth, timed, args):
                          "note": "BASELINE calls this configuration HBM-bound; the fused kernel keeps the partials in registers, so its HBM traffic is the "
                                  "tip codes and weights only (hbm_real_frac of 8 TB/s) and the binding resource is FP64 vector issue. One evaluation "
                                  "of 10^5 patterns is latency-class work: c2_batch is the same kernel with a gradient's worth of evaluations"}}
+
+
+def bench_c2_large(engine, synth, timed, args):
+    """The 4-state kernel in its steady state: BASELINE configs[1]'s model and tree on 10^7 patterns (the 10^6-pattern synthetic alignment ten
+    times over — weights stay 1; lnL must be ten times the one-copy value), where a launch is long enough to fill the chip.  BASELINE calls
+    the 4-state case bandwidth-bound: in the materialised-partials contract (7 720 B per pattern with Gamma-4) this kernel's
+    rate is far above the HBM peak, because no partial ever leaves the registers — what HBM really moves is the tip codes and the weights
+    (hbm_counted_*: rocprofv3 FETCH_SIZE / WRITE_SIZE of this very workload, profiles/rNN_c2large_pmc.json); the binding resource is the
+    FP64 vector pipe (frac)."""
+    import dataclasses
+    one = synth.nuc_gtr_gamma_problem(n_tips=32, n_patt=1_000_000)
+    e1 = engine.engine_for(one)
+    lnl1 = e1.eval(one.tree.branch)["lnL"]
+    e1.close()
+    rep = 10
+    pb = dataclasses.replace(one, z=np.ascontiguousarray(np.tile(one.z, (1, rep))), weights=np.tile(one.weights, rep), gene_off=None, eigen_of=None, qfactor=None)
+    eng = engine.engine_for(pb)
+    steps = 30
+    dt, lnl, _ = timed(eng, pb.tree.branch.copy(), steps, 5)
+    _, _, prof = timed(eng, pb.tree.branch.copy(), 10, 0, profile=True)
+    name = eng.kernel_name
+    eng.close()
+    if not abs(lnl - rep * lnl1) <= 1e-11 * abs(lnl):
+        raise SystemExit("bench: c2_large lnL %.9f is not %d x the one-copy value %.9f" % (lnl, rep, lnl1))
+    kms = prof["ms_prune"] / max(1, prof["n_evals"])
+    fpp = algorithmic_flops_per_pattern(4, 32) * pb.K
+    contract = algorithmic_bytes_per_pattern(4, 32, pb.K)
+    counted = None
+    try:
+        with open(sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_c2large_pmc.json")))[-1]) as f:
+            counted = json.load(f)
+    except (IndexError, OSError, ValueError):
+        pass
+    real = counted["hbm_bytes_per_launch"] if counted else (pb.tree.n_tips + 8) * pb.n_patt
+    return {"workload": "baseml GTR+G4, 32 taxa x %d nucleotide patterns (configs[1]'s model at steady-state size)" % pb.n_patt, "kernel": name, "lnL": lnl,
+            "lnL_check": "%d x the 10^6-pattern value to 1e-11" % rep, "ms_per_eval": dt / steps * 1e3, "site_patterns_per_s": pb.n_patt * steps / dt, "kernel_ms": kms,
+            "roofline": {"bound": "valu", "achieved": fpp * pb.n_patt / (kms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fpp * pb.n_patt / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "hbm_contract_GBs": contract * pb.n_patt / (kms * 1e-3) / 1e9, "hbm_contract_bytes_per_pattern": contract,
+                         "hbm_counted_bytes": real, "hbm_counted_GBs": real / (kms * 1e-3) / 1e9, "hbm_counted_frac_of_peak": real / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "hbm_counted_from": counted["source"] if counted else "not counted: 32 B of codes + 8 B of weight per pattern assumed",
+                         "note": "hbm_contract_GBs: the materialised-partials bytes of SURVEY 8(d) over the kernel's time — above the 8 TB/s peak because "
+                                 "the fused kernel never writes a partial; hbm_counted_*: what the counters see"}}
 
 
 def bench_c2_batch(engine, synth, fence):

@@ -398,7 +398,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          // gene, fused: 0.029 / 1.33).  Why the several-genes form of the same inner loop runs 1.6 x slower than the one-gene form OUTSIDE
          // the profiler (within 4 % of it under rocprofv3, equal instruction counts) was bisected to the table fill living inside the
          // chunk loop and not resolved: profiles/r06_genes_4state.txt.  PAML_AMD_VF_GENES=1 switches it on (tests, measurements).
-         static const bool vf_genes = getenv("PAML_AMD_VF_GENES") && atoi(getenv("PAML_AMD_VF_GENES")) != 0;
+         const bool vf_genes = getenv("PAML_AMD_VF_GENES") && atoi(getenv("PAML_AMD_VF_GENES")) != 0;      // (read per call: tests switch it)
          if (pl.ok && (G == 1 ? e->n_pi == 1 : (vf_genes && (e->n_pi == 1 || e->n_pi == G))) && e->d_zpm.p && !e->env.no_fused && !(G > 1 && n == 4 && e->env.mfma4) && G <= 64) {
             // 4 states: the matrix-core form (v_mfma_f64_4x4x4) is an experiment kept behind PAML_AMD_MFMA4=1 — same issue slots as
             // the FMA form (an FP64 MFMA of 256 MACs takes 16 cycles, sixteen v_fma_f64 of a wave 64) and four times the
