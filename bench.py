@@ -764,10 +764,24 @@ def bench_branch(engine, pb, lnl_full):
     # what the first call is made of: the same work with the buffers in place — every branch length moved, so every resident partial is
     # formed again (the interpreter's keep-partials walk over the whole tree + the contraction) — against the first call, which also
     # allocates the partials and coefficients (hipMalloc of ~8 GB and its first-touch)
-    brx = t.branch * (1.0 + 1e-7)
-    t0 = time.perf_counter()
-    eng.eval_branch(order[0], np.array([brx[order[0]]]), brx)
-    ms_refill = (time.perf_counter() - t0) * 1e3
+    # From the second refill at a branch on the forest runs on a per-tree kernel of its own (compiled on a worker thread the first time a
+    # tree shape is seen, from the kernel cache afterwards; engine_branch.hip) — both are timed: the interpreter's, then the kernel's.
+    def refill(scale):
+        brx = t.branch * scale
+        t0 = time.perf_counter()
+        eng.eval_branch(order[0], np.array([brx[order[0]]]), brx)
+        return (time.perf_counter() - t0) * 1e3
+    ms_refill = refill(1.0 + 1e-7)
+    ms_refill_interp, t_wait = ms_refill, time.perf_counter()
+    n0 = eng.branch_counters()["refill_kernels"]
+    while eng.branch_counters()["refill_kernels"] == n0 and time.perf_counter() - t_wait < float(os.environ.get("BENCH_REFILL_WAIT_S", "90")):
+        ms = refill(1.0 + 1e-7 * (2 + (time.perf_counter() - t_wait)))
+        if eng.branch_counters()["refill_kernels"] == n0:
+            ms_refill_interp = min(ms_refill_interp, ms)
+            time.sleep(0.5)
+    refill_on_kernel = eng.branch_counters()["refill_kernels"] > n0
+    if refill_on_kernel:
+        ms_refill = min(refill(1.0 + 3e-7 + 1e-8 * i) for i in range(4))
     call(eng, order[0], [t.branch[order[0]]])      # (back to the benchmark's lengths)
     c0 = eng.branch_counters()
     form, hit1, hit4 = [], [], []
@@ -818,9 +832,10 @@ def bench_branch(engine, pb, lnl_full):
     t_hbm, t_mfma = hbm_bytes / 8e12 * 1e3, flops / (FP64_PEAK_TFLOPS * 1e12) * 1e3
     return dict(workload="eval_branch (lfuntdd) on the headline data, %d taxa x %d codon patterns, M0; %.1f GB of partials + %.2f GB of coefficients resident"
                          % (t.n_tips, pb.n_patt, 512e-9 * pb.n_patt * n_int, 512e-9 * pb.n_patt),
-                first_call_ms=ms_first, refill_call_ms=ms_refill,
-                first_call_note="first_call_ms = refill_call_ms (all %d internal partials formed again by the keep-partials interpreter + the contraction) + the "
-                                "allocation and first touch of the resident buffers" % n_int,
+                first_call_ms=ms_first, refill_call_ms=ms_refill, refill_call_interpreter_ms=ms_refill_interp, refill_on_per_tree_kernel=refill_on_kernel,
+                first_call_note="first_call_ms = a refill by the interpreter (all %d internal partials formed again by the keep-partials walk + the contraction) + the "
+                                "allocation and first touch of the resident buffers; refill_call_ms: the same work from the second time on, on the forest's "
+                                "per-tree kernel when it was there within the wait (refill_on_per_tree_kernel)" % n_int,
                 walk_form_nt1_ms=float(np.mean(form)), walk_form_nt1_ms_max=float(np.max(form)),
                 walk_hit_nt1_ms=float(np.mean(hit1)), walk_hit_nt4_ms=float(np.mean(hit4)),
                 hit_kernel_ms=hit_kernel_ms, hit_kernel_GBs=512.0 * pb.n_patt / (hit_kernel_ms * 1e-3) / 1e9, hit_kernel_frac_of_hbm=512.0 * pb.n_patt / (hit_kernel_ms * 1e-3) / 8e12,

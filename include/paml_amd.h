@@ -274,6 +274,10 @@ int paml_amd_branch_counters(const paml_amd_engine *e, long *n_calls, long *n_no
 /* eval_branch calls so far that were served from the stored eigen-basis coefficients of the branch (21..64 states: a further
  * trial length on the branch just evaluated needs no matrix product; kernels_branch.h). */
 long paml_amd_branch_coef_hits(const paml_amd_engine *e);
+/* eval_branch calls so far in which most of the tree was dirty (every branch length moved: minB's round after ming2, treesub.c:7982) and
+ * the forest of dirty subtrees ran on a per-tree kernel of its own instead of the interpreter (compiled in the background from the second
+ * request of the same forest on; at once with PAML_AMD_JIT). */
+long paml_amd_branch_refill_kernels(const paml_amd_engine *e);
 /* With paml_amd_profile(e, 1): milliseconds (HIP events on the engine's stream) between the first and the last contraction kernel of
  * the last eval_branch call — the coefficient-forming kernel and / or the polynomial kernel(s); < 0 when the call took the
  * P / dP / ddP form or profiling was off. */

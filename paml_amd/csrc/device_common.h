@@ -1486,14 +1486,17 @@ __device__ __forceinline__ void m20_root(const PruneArgs &a, const double (&x)[5
               rz_ ? (const void *)(sZ + ((zsel ^ 1) & (JIT_ZB - 1)) * ((ZP)*2048) + pi_ * 256) : (const void *)sDump, lane * 4, pi_ * 256);  \
       }                                                                                                         \
    }
-/* half mode (trees of more than 207 tips, jit.h: jit_zplan): a tile's codes are two blocks of (ZP)*2048 bytes, [tile][half]; HALF of tile
- * TILE -> the one sZ buffer */
-#define JIT2_ISSUE_ZH(ZP, TILE, HALF)                                                                             \
+/* piece mode (trees of more than 207 tips, jit.h: jit_zplan): a tile's codes are JIT_ZPIECES blocks of (ZP)*2048 bytes, [tile][piece];
+ * PIECE of tile TILE -> the one sZ buffer */
+#ifndef JIT_ZPIECES
+#define JIT_ZPIECES 2
+#endif
+#define JIT2_ISSUE_ZH(ZP, TILE, PIECE)                                                                            \
    {                                                                                                            \
       _Pragma("unroll") for (int c_ = 0; c_ < ((ZP)*8 + JIT_WAVES - 1) / JIT_WAVES; c_++) {                      \
          const int pi_ = c_ * JIT_WAVES + wave;                                                                 \
          const bool rz_ = pi_ < (ZP)*8;                                                                         \
-         dma4(make_rsrc(a.ztiles + ((long)(TILE)*2 + (HALF)) * ((ZP)*2048), rz_ ? (ZP)*2048 : 0),                \
+         dma4(make_rsrc(a.ztiles + ((long)(TILE)*JIT_ZPIECES + (PIECE)) * ((ZP)*2048), rz_ ? (ZP)*2048 : 0),     \
               rz_ ? (const void *)(sZ + pi_ * 256) : (const void *)sDump, lane * 4, pi_ * 256);                  \
       }                                                                                                         \
    }

@@ -182,7 +182,7 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
       ~DropCacheOnError() { if (!ok) c.valid = false; }
    } cache_guard{bc};
    const size_t words = mfma ? (size_t)K * n_int * e->n_tiles_full * GATHER_WAVES * 1024 : (size_t)K * n_int * e->n_patt * n;
-   if (words > e->d_bl_partials.cap) { HIPCHK(e->d_bl_partials.ensure(words)); bc.valid = false; }
+   if (words + (mfma ? 8 * 1024 : 0) > e->d_bl_partials.cap) { HIPCHK(e->d_bl_partials.ensure(words + (mfma ? 8 * 1024 : 0))); bc.valid = false; }      // (+ PruneArgs::part_dump)
    const bool scaled = T.n_scale > 0;
    if (scaled && (size_t)K * T.n_scale * e->n_patt > e->d_bl_scalef.cap) { HIPCHK(e->d_bl_scalef.ensure((size_t)K * T.n_scale * e->n_patt)); bc.valid = false; }
    std::vector<double> gr(G, 1.0);
@@ -374,7 +374,80 @@ int paml_amd_eval_branch(paml_amd_engine *e, int node_b, int n_t, const double *
          e->prog_valid = false;      // d_branch / P buffers now hold re-oriented edge data: the next eval rebuilds
          e->pmat_valid = false;
       }
-      if (run_prog) {
+      // A refill — every branch length moved since the partials were formed (minB's round after ming2 has moved kappa / omega, the first
+      // call of a search): the forest of dirty subtrees is most of the tree, and the program is the same every time it happens at this
+      // branch.  From the second time on it runs on a per-tree kernel of its own (round 6: STOREs in the resident layout, as a
+      // keep-partials evaluation — 128-pattern tiles, the operand ring — instead of the 64-pattern interpreter), compiled on the worker
+      // thread while the interpreter serves, or at once when the caller asked for per-tree kernels.
+      bool refill_done = false;
+      if (run_prog && e->jit_enabled && !e->env.force_gather && e->n_tips <= 207 && (e->n_codes <= 64 || e->amb_ascending)) {
+         int n_store = 0;
+         for (const Op &o : prog.ops) n_store += o.code == OP_STORE;
+         Program full = prog;
+         finish_program(full);
+         if (2 * n_store >= n_int && jit_supported(full, e->n_tips, e->n_codes, e->n_pi, 6, 128, true)) {
+            const std::string key = "b" + std::to_string(n) + "c" + std::to_string(e->n_codes) + ":" + jit_program_key(full, e->n_tips);
+            bool have = e->jit_recall(key);
+            if (!have && e->bjit_failed_key != key) {
+               paml_amd_engine::JitJob *job = e->bjit_job.get();
+               if (job && job->state.load() >= 2) {
+                  if (job->th.joinable()) job->th.join();
+                  if (job->state.load() == 2 && job->key == key) {
+                     JitKernel nk;
+                     if (jit_load_code(job->code, &nk) == 0) { nk.key = key; e->jit_retire(); e->jit = nk; have = true; }
+                     else { if (nk.mod) (void)hipModuleUnload(nk.mod); e->bjit_failed_key = key; }
+                  }
+                  else if (job->key == key) { e->bjit_failed_key = key; e->err = "jit (refill): " + job->log; }
+                  e->bjit_job.reset();
+                  job = nullptr;
+               }
+               if (!have && !job && e->bjit_failed_key != key && (e->jit_forced || e->env.jit_sync || e->jit_count_request(key) >= 2)) {
+                  const std::string src = jit_generate(full, e->n_tips, n, e->n_codes, 8);
+                  std::vector<char> code;
+                  if (jit_cached_code(src, &code) || ((e->jit_forced || e->env.jit_sync) && jit_compile_code(src, &code, &e->err) == 0)) {
+                     JitKernel nk;
+                     if (jit_load_code(code, &nk) == 0) { nk.key = key; e->jit_retire(); e->jit = nk; have = true; }
+                     else { if (nk.mod) (void)hipModuleUnload(nk.mod); e->bjit_failed_key = key; }
+                  }
+                  else if (e->jit_forced || e->env.jit_sync) e->bjit_failed_key = key;
+                  else {
+                     e->bjit_job.reset(new paml_amd_engine::JitJob());
+                     job = e->bjit_job.get();
+                     job->key = key; job->src = src;
+                     job->state.store(1);
+                     job->th = std::thread([job]() { job->state.store(jit_compile_code(job->src, &job->code, &job->log) == 0 ? 2 : 3); });
+                  }
+               }
+            }
+            if (have) {
+               e->use_jit = true;      // (kernel_name: the last pruning kernel was a per-tree one)
+               if (int rc = select_tiles(e, true, 8, true)) return rc;
+               const int n_blocks = e->n_tiles * K;
+               int overflow = 0;
+               if (full.max_stack > MFMA_RS) {
+                  overflow = full.max_stack - MFMA_RS;
+                  HIPCHK(e->d_stack.ensure((size_t)n_blocks * overflow * 8 * 1024));
+               }
+               if (T.n_scale) HIPCHK(e->d_fscale.ensure((size_t)K * e->n_patt));
+               PruneArgs pr{};
+               pr.ops = nullptr; pr.z = e->d_z.p; pr.z_stride = e->n_patt; pr.tiles = e->d_tiles.p; pr.n_tiles = e->n_tiles;
+               pr.gene_off = e->d_gene_off.p; pr.weights = e->d_weights.p; pr.ztiles = e->d_ztiles.p; pr.zt_bytes = e->zt_bytes;
+               pr.n = n; pr.n_tips = e->n_tips; pr.n_nodes = nn; pr.K = K; pr.n_genes = G; pr.n_codes = e->n_codes;
+               pr.cleandata = e->cleandata; pr.n_pi = e->n_pi; pr.mode = e->mode; pr.n_scale = T.n_scale; pr.keep = 1; pr.n_patt = e->n_patt;
+               pr.pi = e->d_pi.p; pr.pint = e->d_pint.p; pr.ptip = e->d_ptip.p; pr.pcol = e->d_pcol.p; pr.fscale = e->d_fscale.p;
+               HIPCHK(e->d_fhK.ensure((size_t)K * e->n_patt));
+               pr.fhK = e->d_fhK.p; pr.partials = e->d_bl_partials.p; pr.scalef = e->d_bl_scalef.p; pr.stack_scratch = e->d_stack.p;
+               pr.stack_overflow_slots = overflow; pr.first_matmul = full.first_matmul; pr.n_int = n_int; pr.first_tip = full.first_tip;
+               pr.tip_words = (long)tip_words(e); pr.tile_group0 = e->d_tile_group0.p; pr.part_groups = e->part_groups();
+               pr.part_dump = e->d_bl_partials.p + words; pr.code_mask = e->d_code_mask.p;
+               void *params[] = {&pr};
+               HIPCHK(hipModuleLaunchKernel(e->jit.fn, std::min(n_blocks, e->n_cu), 1, 1, 8 * 64, 1, 1, 0, st, params, nullptr));
+               refill_done = true;
+               e->n_branch_refill_jit++;
+            }
+         }
+      }
+      if (run_prog && !refill_done) {
          const int n_blocks = e->n_tiles_full * K;
          int overflow = 0;
          if (prog.max_stack > MFMA_RS) {
@@ -624,6 +697,8 @@ int paml_amd_branch_counters(const paml_amd_engine *e, long *n_calls, long *n_no
 }
 
 long paml_amd_branch_coef_hits(const paml_amd_engine *e) { return e ? e->n_branch_coef_hits : -1; }
+
+long paml_amd_branch_refill_kernels(const paml_amd_engine *e) { return e ? e->n_branch_refill_jit : -1; }
 
 double paml_amd_branch_kernel_ms(paml_amd_engine *e)
 {

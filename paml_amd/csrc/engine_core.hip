@@ -74,6 +74,7 @@ void paml_amd_destroy(paml_amd_engine *e)
    (void)hipStreamSynchronize(e->stream);
    if (e->jit_job && e->jit_job->th.joinable()) e->jit_job->th.join();
    if (e->coop_job && e->coop_job->th.joinable()) e->coop_job->th.join();
+   if (e->bjit_job && e->bjit_job->th.joinable()) e->bjit_job->th.join();
    for (hipStream_t s : e->sb)
       if (s) {
          (void)hipStreamSynchronize(s);

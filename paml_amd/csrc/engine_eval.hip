@@ -37,15 +37,46 @@ int build_tiles(paml_amd_engine *e)
       //  program is known by the time a kernel with 128-pattern tiles has been chosen, and launch_eval comes back here when it changes)
       JitZPlan zp;
       const bool half = !e->prog.ops.empty() && (zp = jit_zplan(e->prog, e->n_tips, e->tile_patt)).half;
-      e->zt_bytes = half ? 2 * zp.ZP * 2048 : jit_zpieces(e->n_tips, e->tile_patt) * 2048;
+      e->zt_bytes = half ? zp.pieces * zp.ZP * 2048 : jit_zpieces(e->n_tips, e->tile_patt) * 2048;
       e->zt_key = half ? jit_program_key(e->prog, e->n_tips) : std::string();
-      if (half) HIPCHK(upload(e->d_ztip_of, zp.tip_of.data(), zp.tip_of.size(), e->stream));
+      if (half) {      // (row -> tip, then row -> position in the block)
+         std::vector<int> both(zp.tip_of);
+         both.insert(both.end(), zp.row_at.begin(), zp.row_at.end());
+         HIPCHK(upload(e->d_ztip_of, both.data(), both.size(), e->stream));
+      }
       HIPCHK(e->d_ztiles.ensure((size_t)e->n_tiles * e->zt_bytes));
       hipLaunchKernelGGL(ztile_kernel, dim3(e->n_tiles), dim3(e->tile_patt), 0, e->stream, e->d_tiles.p, e->d_gene_off.p, e->d_z.p, (long)e->n_patt,
-                         e->d_weights.p, e->n_tips, e->zt_bytes, e->d_ztiles.p, half ? (const int *)e->d_ztip_of.p : (const int *)nullptr, half ? zp.H : 0);
+                         e->d_weights.p, e->n_tips, e->zt_bytes, e->d_ztiles.p, half ? (const int *)e->d_ztip_of.p : (const int *)nullptr,
+                         half ? (const int *)e->d_ztip_of.p + (e->n_tips + 1) : (const int *)nullptr);
    }
    HIPCHK(hipStreamSynchronize(e->stream));
    e->tiles_built_for = e->tile_patt;
+   return 0;
+}
+
+// The tile tables of the kernel about to run (21 .. 64 states): 128-pattern tiles with their code blocks (per-tree kernel, streaming
+// interpreter) or 64-pattern ones.  A change of tile size swaps the current set with the stashed one (built once each, engine_state.h
+// TileStash) — the resident partials have ONE layout whatever the tile size (PruneArgs::part_groups), they stay valid.
+int select_tiles(paml_amd_engine *e, bool big_tiles, int want_waves, bool jit_ok)
+{
+   if (big_tiles != e->mfma_dma || want_waves != e->mfma_waves) {
+      e->swap_tile_stash();
+      e->mfma_dma = big_tiles;
+      e->mfma_waves = want_waves;
+      e->tile_patt = e->mfma_waves * 16;
+      bool have = e->tiles_built_for == e->tile_patt && e->d_tiles.p;
+      if (have && jit_ok && e->tile_patt >= 128 && (e->n_tips > 200 || !e->zt_key.empty())) {      // piece mode: rows in the program's order
+         const JitZPlan zp = jit_zplan(e->prog, e->n_tips, e->tile_patt);
+         have = (zp.half ? jit_program_key(e->prog, e->n_tips) : std::string()) == e->zt_key;
+      }
+      if (!have)
+         if (int r = build_tiles(e)) return r;
+   }
+   else if (jit_ok && e->tile_patt >= 128 && (e->n_tips > 200 || !e->zt_key.empty())) {      // piece mode: the code blocks' rows follow the tree's program
+      const JitZPlan zp = jit_zplan(e->prog, e->n_tips, e->tile_patt);
+      if ((zp.half ? jit_program_key(e->prog, e->n_tips) : std::string()) != e->zt_key)
+         if (int r = build_tiles(e)) return r;
+   }
    return 0;
 }
 
@@ -108,9 +139,8 @@ template <class GEN>
 static int ensure_jit(paml_amd_engine *e, const std::string &key, GEN gen, bool *ok)
 {
    *ok = false;
-   if (e->jit.fn && e->jit.key == key) { *ok = true; return 0; }
-   if (e->jit.mod) (void)hipModuleUnload(e->jit.mod);
-   e->jit = JitKernel();
+   if (e->jit_recall(key)) { *ok = true; return 0; }      // (the kernel in use, or one of this engine's other programs kept loaded)
+   e->jit_retire();
    std::string log;
    const std::string src = gen();
    if (!e->env.jit_dump.empty()) {
@@ -291,7 +321,12 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       int jw = 8;
       if (e->env.jit_waves == 12 && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, 192) && jit_zbuffers(e->n_tips, 192) == 2) jw = 12;
       // (more than 64 codes: the per-tree kernel sums the rows of a code's states in ascending order — e->amb_ascending, set_tips)
-      if (e->jit_enabled && !e->env.force_gather && (e->n_codes <= 64 || e->amb_ascending) && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16, e->jit_forced)) {
+      // LOAD programs (paml_amd_eval_dirty: one per set of clean nodes) get a kernel too (round 6) — compiled on the worker thread from the
+      // SECOND time a set is asked for (minbranches' walk repeats its sets cycle after cycle; a set seen once is not worth 0.5 s of compiler),
+      // the interpreter serving meanwhile; code-block pieces follow one program's order, so trees beyond 207 tips keep the interpreter there
+      bool has_load = false;
+      for (const Op &o : e->prog.ops) has_load = has_load || o.code == OP_LOAD;
+      if (e->jit_enabled && !e->env.force_gather && !(has_load && e->n_tips > 207) && (e->n_codes <= 64 || e->amb_ascending) && jit_supported(e->prog, e->n_tips, e->n_codes, e->n_pi, 6, jw * 16, true)) {
          const std::string key = "m" + std::to_string(n) + "c" + std::to_string(e->n_codes) + "w" + std::to_string(jw) + (jit_rowtail(n) ? "r:" : ":") + jit_program_key(e->prog, e->n_tips);
          // Large trees (> 120 ops: roughly more than 35 taxa): tens of thousands of instructions, many seconds of compiler time.  Unless the
          // caller asked to wait (PAML_AMD_JIT flag / PAML_AMD_JIT_SYNC), the kernel is built on a worker thread while the interpreter kernels
@@ -300,8 +335,10 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
          // build without the three passes that are quadratic on one giant block (JIT_BIG_FLAGS) — that two-stage build (quick kernel at 0.63
          // of the FP64 peak first, the full one after) remains for PAML_AMD_JIT_SPLIT=0 / asm.
          const bool big = e->prog.ops.size() > 120;
-         const bool background = big && !e->jit_forced && !e->env.jit_sync;
-         if (!background) {
+         const bool background = (big || has_load) && !e->jit_forced && !e->env.jit_sync;
+         const bool wanted = !has_load || e->jit_forced || e->env.jit_sync || e->jit_recall(key) || e->jit_count_request(key) >= 2;
+         if (!wanted) jit_ok = false;
+         else if (!background) {
             int r = ensure_jit(e, key, [&]() { return jit_strip_big(jit_generate(e->prog, e->n_tips, n, e->n_codes, jw)); }, &jit_ok);
             if (r) return r;
             if (jit_ok) { e->jit_stage = 2; e->jit.stage = 2; }
@@ -315,11 +352,12 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
                   if (nk.mod) (void)hipModuleUnload(nk.mod);
                   return false;
                }
-               if (e->jit.mod) (void)hipModuleUnload(e->jit.mod);
+               e->jit_retire();
                e->jit = nk;
                e->jit.key = key; e->jit.stage = stage; e->jit_stage = stage;
                return true;
             };
+            (void)e->jit_recall(key);      // (one of this engine's other programs, kept loaded)
             e->jit_stage = (e->jit.fn && e->jit.key == key) ? e->jit.stage : 0;      // (another tree's kernel, or none: stage 0)
             paml_amd_engine::JitJob *job = e->jit_job.get();
             if (job && job->state.load() >= 2 && job->th.joinable()) job->th.join();
@@ -363,27 +401,7 @@ int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rat
       e->use_jit = jit_ok;
       const bool big_tiles = jit_ok || lean;
       const int want_waves = jit_ok ? jw : (lean ? DMA_WAVES : GATHER_WAVES);
-      if (big_tiles != e->mfma_dma || want_waves != e->mfma_waves) {
-         // (the tables of the tile size being left are kept: an engine that alternates between two kernels swaps them, see TileStash)
-         e->swap_tile_stash();
-         e->mfma_dma = big_tiles;
-         e->mfma_waves = want_waves;
-         e->tile_patt = e->mfma_waves * 16;
-         bool have = e->tiles_built_for == e->tile_patt && e->d_tiles.p;
-         if (have && jit_ok && e->tile_patt >= 128 && (e->n_tips > 200 || !e->zt_key.empty())) {      // half mode: rows in the program's order
-            const JitZPlan zp = jit_zplan(e->prog, e->n_tips, e->tile_patt);
-            have = (zp.half ? jit_program_key(e->prog, e->n_tips) : std::string()) == e->zt_key;
-         }
-         if (!have) {
-            int r = build_tiles(e);
-            if (r) return r;      // (the resident partials have ONE layout whatever the tile size, PruneArgs::part_groups: they stay valid)
-         }
-      }
-      else if (jit_ok && e->tile_patt >= 128 && (e->n_tips > 200 || !e->zt_key.empty())) {      // half mode: the code blocks' rows follow the tree's program
-         const JitZPlan zp = jit_zplan(e->prog, e->n_tips, e->tile_patt);
-         if ((zp.half ? jit_program_key(e->prog, e->n_tips) : std::string()) != e->zt_key)
-            if (int r = build_tiles(e)) return r;
-      }
+      if (int r = select_tiles(e, big_tiles, want_waves, jit_ok)) return r;
    }
    if (e->kk != KK_MFMA64) {      // 4 / 5 / 20 states: the interpreter unrolled for this tree
       bool jit_ok = false, fused = false;

@@ -313,6 +313,7 @@ struct paml_amd_engine {
    hipEvent_t ev_bk[2] = {};          // paml_amd_profile on: around the contraction kernel(s) of the last eval_branch (paml_amd_branch_kernel_ms)
    bool bk_timed = false;
    long n_branch_coef_hits = 0;      // eval_branch calls served from the stored coefficients
+   long n_branch_refill_jit = 0;     // eval_branch calls whose forest of dirty subtrees ran on a per-tree kernel (a refill, engine_branch.hip)
    DevBuf<unsigned long long> d_code_mask;      // per character code: bit s = state s belongs to it
    long n_branch_eval = 0, n_branch_nodes = 0;
 
@@ -358,6 +359,41 @@ struct paml_amd_engine {
    DevBuf<int> d_stream;
    Staging stage;
    JitKernel jit;            // per-tree specialised kernel (jit.h), valid when jit.fn != nullptr
+   // Kernels of this engine's OTHER programs, kept loaded (round 6): a keep-partials engine alternates between its full program and the LOAD
+   // programs of paml_amd_eval_dirty (com.oldconP: one per set of clean nodes, treespace.c:250), eval_branch between the tree seen from a
+   // branch and the ordinary one — the kernel being left is retired here instead of unloaded, and recalled by its key.
+   std::vector<JitKernel> jit_pool;
+   std::vector<std::pair<std::string, int>> jit_seen;      // LOAD programs: how often a key has been asked for (a kernel is compiled from the second time on)
+   void jit_retire()
+   {
+      if (jit.mod && jit.fn) {
+         if (jit_pool.size() >= 8) { (void)hipModuleUnload(jit_pool.front().mod); jit_pool.erase(jit_pool.begin()); }
+         jit_pool.push_back(jit);
+      }
+      else if (jit.mod) (void)hipModuleUnload(jit.mod);
+      jit = JitKernel();
+   }
+   bool jit_recall(const std::string &key)
+   {
+      if (jit.fn && jit.key == key) return true;
+      for (size_t i = 0; i < jit_pool.size(); i++)
+         if (jit_pool[i].key == key && jit_pool[i].fn) {
+            const JitKernel k = jit_pool[i];
+            jit_pool.erase(jit_pool.begin() + i);
+            jit_retire();
+            jit = k;
+            return true;
+         }
+      return false;
+   }
+   int jit_count_request(const std::string &key)
+   {
+      for (auto &kv : jit_seen)
+         if (kv.first == key) return ++kv.second;
+      if (jit_seen.size() >= 64) jit_seen.erase(jit_seen.begin());
+      jit_seen.emplace_back(key, 1);
+      return 1;
+   }
    bool jit_enabled = false, use_jit = false;
    bool small20 = false;     // 20 states on the MFMA interpreters because the data set is small (engine_core.hip): not as a shard of a larger one
    bool coop = false;        // the last evaluation ran prune_mfma64_coop (small data sets: four waves per 16-pattern group)
@@ -408,7 +444,8 @@ struct paml_amd_engine {
       JitJob() { worker_threads_list(&th, true); }
       ~JitJob() { if (th.joinable()) th.join(); worker_threads_list(&th, false); }
    };
-   std::unique_ptr<JitJob> jit_job, coop_job;
+   std::unique_ptr<JitJob> jit_job, coop_job, bjit_job;      // (bjit: the branch-local evaluation's refill program, engine_branch.hip)
+   std::string bjit_failed_key;
    std::string jit_failed_key, coop_failed_key;
    int jit_stage = 0;                 // which build of the large tree's kernel `jit` holds (0: none / a kernel compiled while the caller waited)
    std::string jit_stage2_failed_key;
@@ -487,6 +524,8 @@ struct paml_amd_engine {
       }
       if (d_prof) (void)hipFree(d_prof);
       if (jit.mod) (void)hipModuleUnload(jit.mod);
+      for (JitKernel &k : jit_pool)
+         if (k.mod) (void)hipModuleUnload(k.mod);
       if (jit_coop.mod) (void)hipModuleUnload(jit_coop.mod);
       for (auto ev : ev_pool) (void)hipEventDestroy(ev);
       for (auto ev : ev_used) (void)hipEventDestroy(ev);
@@ -667,6 +706,7 @@ struct BatchSpec {
 };
 
 int build_tiles(paml_amd_engine *e);
+int select_tiles(paml_amd_engine *e, bool big_tiles, int want_waves, bool jit_ok);
 int launch_eval(paml_amd_engine *e, const double *branch, const double *gene_rate, const unsigned char *clean, double *d_lnL_out, bool want_lnf,
                 const BatchSpec *bs = nullptr, bool want_pipe = false, bool want_fhk = true);
 // launches for the other translation units (a __global__ function has one home)

@@ -55,29 +55,34 @@ inline int jit_zbuffers(int n_tips, int tp = 128) { return jit_lds_fits(n_tips, 
 // (STORE — every internal node's partial kept, PAML_AMD_KEEP_PARTIALS — is part of the tree's one program.  LOAD programs differ with the
 //  set of clean nodes: a kernel per set would be compiled again and again, so they go to the interpreter unless `allow_load`.)
 // Where a tile's tip codes live in LDS.  Up to 95 tips two blocks (the next tile's arrive while this one is walked), up to 207 one
-// (replaced between tiles); beyond that — up to 413 tips — the block is cut in two HALVES by order of use: the rows (one per tip, then the
-// weight flags) are laid out in the order the walk consumes them, the first half is resident while the walk uses it and the second
-// half replaces it at the crossing (one wait for the DMA per tile and half: nothing beside a tile's hundreds of products).
+// (replaced between tiles); beyond that the block is cut into PIECES by order of use: the rows (one per tip, then the weight flags) are
+// laid out in the order the walk consumes them — every tip is read exactly once —, a piece is resident while the walk uses it and the
+// next replaces it at the crossing (one wait for the DMA per tile and piece: nothing beside a tile's hundreds of products).  Round 5
+// had two pieces (up to ~413 tips); round 6: as many as the tree needs (the reference's limit is NS 5000, codeml.c:19).
+constexpr int JIT_ZP_MAX = 13;      // 2 KB units of LDS left for ONE code buffer beside the ring (27 392 bytes): 208 rows of 128 patterns
 struct JitZPlan {
-   int bufs = 2;             // LDS buffers (2: double-buffered; 1: one block or one half)
-   bool half = false;
+   int bufs = 2;             // LDS buffers (2: double-buffered; 1: one block or one piece)
+   bool half = false;        // piece mode (the name is round 5's, when there were two)
+   int pieces = 1;           // ... so many
    int ZP = 0;               // 2 KB units per buffer
-   int H = 0;                // rows in the first half (half mode); all rows otherwise
-   std::vector<int> row;     // tip (or n_tips: the flags) -> row in its buffer's order
-   std::vector<int> tip_of;  // row (over both halves) -> tip
+   std::vector<int> row;     // tip (or n_tips: the flags) -> row in its piece
+   std::vector<int> piece;   // tip (or n_tips) -> its piece
+   std::vector<int> tip_of;  // row (over all pieces, in order of use) -> tip
+   std::vector<int> row_at;  // row (over all pieces) -> row position in the tile's block: piece x (rows a buffer holds) + row in the piece
 };
 inline JitZPlan jit_zplan(const Program &p, int n_tips, int tp = 128)
 {
    JitZPlan z;
    z.row.resize(n_tips + 1);
+   z.piece.assign(n_tips + 1, 0);
    z.tip_of.resize(n_tips + 1);
-   for (int t = 0; t <= n_tips; t++) z.row[t] = z.tip_of[t] = t;
-   z.H = n_tips + 1;
+   z.row_at.resize(n_tips + 1);
+   for (int t = 0; t <= n_tips; t++) z.row[t] = z.tip_of[t] = z.row_at[t] = t;
    z.ZP = jit_zpieces(n_tips, tp);
    if (jit_lds_fits(n_tips, 2, tp)) { z.bufs = 2; return z; }
    z.bufs = 1;
    if (jit_lds_fits(n_tips, 1, tp)) return z;
-   // halves: rows in order of use; the cut at an op boundary at or after the middle
+   // pieces: rows in order of use, cut at op boundaries (the rows of one op — a cherry has two — stay together)
    z.half = true;
    std::vector<int> order;
    std::vector<char> seen(n_tips + 1, 0);
@@ -92,13 +97,37 @@ inline JitZPlan jit_zplan(const Program &p, int n_tips, int tp = 128)
    for (int t = 0; t < n_tips; t++)
       if (!seen[t]) order.push_back(t);      // (tips the program never reads: rows nobody looks at)
    order.push_back(n_tips);                  // the weight flags: read by ROOT, last
-   int H = (n_tips + 2) / 2;
-   for (int st : op_start)
-      if (st >= H) { H = st; break; }
-   z.H = H;
-   for (int r = 0; r <= n_tips; r++) { z.tip_of[r] = order[r]; z.row[order[r]] = r < H ? r : r - H; }
-   const int rows = std::max(H, n_tips + 1 - H);
-   z.ZP = (rows * tp + 2047) / 2048;
+   const int total = n_tips + 1, cap = JIT_ZP_MAX * 2048 / tp;      // rows a buffer holds at most
+   const int npc = std::max(2, (total + cap - 1) / cap);
+   const int want = (total + npc - 1) / npc;      // even pieces (two: the halves of round 5), each cut moved up to the next op boundary
+   std::vector<int> first(1, 0);      // first row of every piece
+   while (total - first.back() > (first.size() == 1 && npc == 2 ? want : std::min(cap, std::max(want, 1)))) {
+      int cut = first.back() + want;
+      int at = -1;
+      for (int st : op_start)
+         if (st >= cut) { at = st; break; }
+      if (at < 0 || at - first.back() > cap) {      // no boundary at or after the even cut within the buffer: the last one before it
+         at = -1;
+         for (int st : op_start)
+            if (st > first.back() && st <= first.back() + cap) at = st;
+         if (at < 0) at = std::min(total - 1, first.back() + cap);      // (cannot happen: an op has at most two rows)
+      }
+      if (at >= total) break;
+      first.push_back(at);
+   }
+   first.push_back(total);
+   z.pieces = (int)first.size() - 1;
+   int rows_max = 0;
+   for (int k = 0; k < z.pieces; k++) rows_max = std::max(rows_max, first[k + 1] - first[k]);
+   z.ZP = (rows_max * tp + 2047) / 2048;
+   const int rows_buf = z.ZP * 2048 / tp;
+   for (int k = 0; k < z.pieces; k++)
+      for (int r = first[k]; r < first[k + 1]; r++) {
+         z.tip_of[r] = order[r];
+         z.row[order[r]] = r - first[k];
+         z.piece[order[r]] = k;
+         z.row_at[r] = k * rows_buf + (r - first[k]);
+      }
    return z;
 }
 inline bool jit_zfits(const Program &p, int n_tips, int tp = 128)
@@ -109,7 +138,7 @@ inline bool jit_zfits(const Program &p, int n_tips, int tp = 128)
 
 inline bool jit_supported(const Program &p, int n_tips, int n_codes, int n_pi = 1, int max_arrays = 6, int tp = 128, bool allow_load = false)
 {
-   if (n_codes > 256 || p.ops.size() > 1400 || n_pi > 4) return false;      // (more than 64 codes: JIT_AMB_OVERFLOW, device_common.h)
+   if (n_codes > 256 || p.ops.size() > 8000 || n_pi > 4) return false;      // (more than 64 codes: JIT_AMB_OVERFLOW, device_common.h)
    if (!jit_zfits(p, n_tips, tp)) return false;
    if (p.stream.size() / 2 < 4) return false;                       // trees this small go to the interpreter
    for (const Op &o : p.ops)
@@ -197,7 +226,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          tail_blocks = true;
    // one code block only (large trees): it is replaced between tiles, so nothing of the next tile can start early
    const bool zsingle = zpl.bufs == 1, zhalf = zpl.half;
-   bool crossed = false;      // (half mode) the second half of the tile's codes has replaced the first
+   int cur_piece = 0;         // (piece mode) the piece of the tile's codes that is in LDS
    const bool peel = fuse_tips && !getenv("PAML_AMD_JIT_NOPEEL") && nops > 2 && p.ops[0].code == OP_SET_TIP2 && last_mm > 1 &&
                      p.ops[1].code != OP_MUL_TIP && p.ops[1].code != OP_MUL_TIP2 && !tail_blocks && !zsingle;
 
@@ -218,6 +247,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    if (jit_experiment_env("PAML_AMD_JIT_ABL_NOBAR")) s << "#define JIT_ABL_NOBAR 1\n";      // timing experiment: no workgroup barriers (results are garbage)
    const char *abl_skew = jit_experiment_env("PAML_AMD_JIT_ABL_SKEW");                       // ... and waves 4-7 start this many x 64 cycles late
    if (zsingle) s << "#define JIT_ZB 1\n";
+   if (zhalf) s << "#define JIT_ZPIECES " << zpl.pieces << "\n";
    const bool amb_over = n_codes > 64;      // codes beyond the 64 a ring block has rows for: summed from the rows of their states (device_common.h)
    if (amb_over) s << "#define JIT_AMB_OVERFLOW 1\n";
    const std::string ambarg = amb_over ? ", amb" : "";
@@ -267,6 +297,12 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    // refill's pieces over the first `iters` k-block pairs of the matmul that follows; the first `now` blocks from
    // `consumed` are needed within this very step and are never delayed
    auto step = [&](int c, bool defer = false, int iters = 8, int now = 1) -> std::string {
+      // (a step whose blocks the ring has not been asked for yet — a cherry right after the tile's first one, as the forests of the branch-local
+      //  refill have them: the top-up of the step before stopped short of it.  Every wave is done with the slots they go to after a barrier.)
+      if (issued < consumed + c) {
+         s << "   JIT_SYNC();\n";
+         while (issued < consumed + c) issue_now();
+      }
       const int nw = wait_count(consumed + c - 1);
       if (nw >= 0) s << "   JIT_WAIT(" << nw << ");";
       s << "   JIT_SYNC();\n";
@@ -332,19 +368,16 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    auto code = [&](int tip) { return "JIT2_CODE(" + std::to_string(ZP) + ", " + std::to_string(zpl.row[tip]) + ")"; };
    auto ncode = [&](int tip) { return "JIT2_NCODE(" + std::to_string(ZP) + ", " + std::to_string(zpl.row[tip]) + ")"; };
    const std::string issue_z = zhalf ? "JIT2_ISSUE_ZH(" + std::to_string(ZP) + ", n_tile, 0)" : "JIT2_ISSUE_Z(" + std::to_string(ZP) + ")";
-   // (half mode) the rows of the second half are needed from here on: every wave is done with the first half, the second comes over it
+   // (piece mode) rows of a later piece are needed from here on: every wave is done with the piece in LDS, the next comes over it
    auto cross_if = [&](std::initializer_list<int> tips) {
-      if (!zhalf || crossed) return;
-      bool need = false;
-      for (int t : tips) {
-         int r = -1;
-         for (int k = 0; k <= n_tips; k++) if (zpl.tip_of[k] == t) r = k;
-         need = need || r >= zpl.H;
+      if (!zhalf) return;
+      int need = cur_piece;
+      for (int t : tips) need = std::max(need, zpl.piece[t]);
+      while (cur_piece < need) {
+         cur_piece++;
+         s << "   __syncthreads();\n   JIT2_ISSUE_ZH(" << ZP << ", cur_tile, " << cur_piece << ")\n   JIT_WAIT(0); __syncthreads();\n";
+         fl.clear();
       }
-      if (!need) return;
-      s << "   __syncthreads();\n   JIT2_ISSUE_ZH(" << ZP << ", cur_tile, 1)\n   JIT_WAIT(0); __syncthreads();\n";
-      fl.clear();
-      crossed = true;
    };
    auto buf = [&](int blk) { return "JIT2_BUF(" + std::to_string(blk) + ")"; };
    auto colarg = [&](int blk) { return tail61 ? ", JIT2_COL(" + std::to_string(blk) + "), x60" : std::string(); };
@@ -397,22 +430,29 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
    int cur = peel ? AS : -1;
 
    if (prof) s << "   if (a.prof && tid == a.prof_tid && ptile) a.prof[(long)blockIdx.x * a.prof_stride] = __builtin_amdgcn_s_memtime();\n";
+   // An op that starts a partial while one is still held: a forest of subtrees (the branch-local refill, engine_branch.hip) — the previous
+   // subtree's root was stored and is done.  (Not written over in place: after a first subtree that is a lone cherry the array is AS, which the
+   // tile's last product fills for the NEXT tile while this tile's later partials would still live in it.)
+   auto start_partial = [&]() {
+      if (cur >= 0) release(cur);
+      cur = alloc();
+   };
    for (size_t iop = 0; iop < nops; iop++) {
       const Op &o = p.ops[iop];
       stamp(iop);
       if (iop == 0 && peel) continue;      // done by the predecessor
       switch (o.code) {
       case OP_INIT_ONES:
-         if (cur < 0) cur = alloc();
+         start_partial();
          s << "   jit_init_ones(" << name(cur) << ", q, n);\n";
          break;
       case OP_INIT_TIP:
-         if (cur < 0) cur = alloc();
+         start_partial();
          cross_if({o.a});
          s << "   jit_init_tip(" << name(cur) << ", " << code(o.a) << ", q, a.cleandata);\n";
          break;
       case OP_SET_TIP:
-         if (cur < 0) cur = alloc();
+         start_partial();
          cross_if({o.a});
          step(1);
          s << "   jit_tip_set<" << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a) << ", q, lane" << ambarg << ");\n";
@@ -426,7 +466,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          break;
       case OP_SET_TIP2:
       case OP_MUL_TIP2:
-         if (cur < 0) cur = alloc();
+         if (o.code == OP_SET_TIP2 || cur < 0) start_partial();
          cross_if({o.a, o.b});
          step(2);
          s << "   " << (o.code == OP_SET_TIP2 ? "jit_tip2_set<" : "jit_tip2_mul<") << NPc << ">(" << name(cur) << ", " << buf(consumed) << ", " << code(o.a)
@@ -448,7 +488,11 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          const int pop = mm_pop_slot(o), push = mm_push_slot(o);
          const int out = alloc();
          // a cherry right after a pushed matmul: its two tip gathers ride under this matmul's second half
-         const bool fuse = fuse_tips && push >= 0 && iop + 1 < nops && p.ops[iop + 1].code == OP_SET_TIP2;
+         // (piece mode: a cherry whose codes lie in the NEXT piece is not folded under this product — the crossing then happens at the cherry's
+         //  own step.  Folded, the 1 000-tip tree of tests/test_engine_gpu.py came out wrong in every pattern, by about one scale factor;
+         //  crossings at unfused steps are right, and there are at most pieces - 1 of them per tile.)
+         const bool fuse = fuse_tips && push >= 0 && iop + 1 < nops && p.ops[iop + 1].code == OP_SET_TIP2 &&
+                           !(zhalf && std::max(zpl.piece[p.ops[iop + 1].a], zpl.piece[p.ops[iop + 1].b]) > cur_piece);
          const bool fuse_next = peel && (int)iop == last_mm;     // ... or the next tile's first cherry under the last matmul
          if (fuse) cross_if({p.ops[iop + 1].a, p.ops[iop + 1].b});
          // (tip tables the ring could not hold earlier are requested in the first k-block pairs and awaited at the midpoint)
@@ -518,7 +562,7 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          }
       } break;
       case OP_LOAD:
-         if (cur < 0) cur = alloc();
+         start_partial();
          s << "   jit_load(" << name(cur) << ", JIT_PART_PTR(" << o.a << "), lane);\n";
          fl.push_back({-2, 8});
          break;
@@ -1675,6 +1719,9 @@ inline void jit_write_file(const std::string &dir, const std::string &name, cons
 inline int jit_compile_code(const std::string &src, std::vector<char> *code, std::string *log, const char *store_dir = nullptr)
 {
    const std::string name = jit_cache_name(src), user = jit_user_cache_dir();
+   if (const char *d = getenv("PAML_AMD_JIT_SRC_DIR")) {      // debugging: every source that reaches the compiler (or its cache), by cache name
+      if (FILE *f = fopen((std::string(d) + "/" + name + ".hip").c_str(), "wb")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
+   }
    if (!store_dir) {
       if (jit_read_file(jit_shipped_dir() + "/" + name, code)) return 0;
       if (!user.empty() && jit_read_file(user + "/" + name, code)) return 0;

@@ -771,10 +771,11 @@ __global__ __launch_bounds__(256) void prune_valu(PruneArgs a)
 
 // Tile blocks of the specialised kernel (PruneArgs::ztiles): per 128-pattern tile the tip codes of its patterns, one
 // 128-byte row per tip, then a row of weight > 0 flags; patterns past the tile's gene read as code 0 / flag 0.
-// tip_of (trees of more than 207 tips, jit.h: jit_zplan): the rows in the order the walk consumes them — row r holds tip tip_of[r]
-// (n_tips: the flags) — cut after the first H rows into two blocks of zt_bytes / 2 each.  null: rows in tip order, one block.
+// tip_of / row_at (trees of more than 207 tips, jit.h: jit_zplan): the rows in the order the walk consumes them — row r holds tip
+// tip_of[r] (n_tips: the flags) and sits at row position row_at[r] of the tile's block (the block is cut into pieces of equal size, a
+// piece's rows from its start).  null: rows in tip order, one block.
 __global__ __launch_bounds__(256) void ztile_kernel(const int2 *tiles, const int *gene_off, const unsigned char *z, long z_stride,
-                                                    const double *weights, int n_tips, int zt_bytes, unsigned char *out, const int *tip_of, int H)
+                                                    const double *weights, int n_tips, int zt_bytes, unsigned char *out, const int *tip_of, const int *row_at)
 {
    const int t = blockIdx.x, i = threadIdx.x, tp = blockDim.x;      // one thread per pattern of the tile (128 or 192)
    const int g = tiles[t].x, h = tiles[t].y + i, hend = gene_off[g + 1];
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(256) void ztile_kernel(const int2 *tiles, const int
    __syncthreads();
    for (int r = 0; r <= n_tips; r++) {
       const int tip = tip_of ? tip_of[r] : r;
-      const long at = (tip_of && r >= H) ? (long)(zt_bytes / 2) + (long)(r - H) * tp : (long)r * tp;
+      const long at = (long)(tip_of ? row_at[r] : r) * tp;
       unsigned char v = 0;
       if (h < hend) v = tip < n_tips ? z[tip * z_stride + h] : (unsigned char)(weights[h] > 0 ? 1 : 0);
       o[at + i] = v;

@@ -101,6 +101,45 @@ inline void emit(const TreeDesc &t, int node, const unsigned char *clean, bool k
 }
 }  // namespace detail
 
+// What the kernels read beside the ops: prefetch links (see Op), the operand stream, the first MATMUL / tip.  (Also for programs put
+// together from several build_program results: the branch-local evaluation's forest of dirty subtrees, engine_branch.hip.)
+inline void finish_program(Program &p)
+{
+   // prefetch links (see Op): walk backwards remembering the next MATMUL's son and the next tip
+   {
+      int next_mm = -1, next_tip = -1;
+      for (int i = (int)p.ops.size() - 1; i >= 0; i--) {
+         Op &o = p.ops[i];
+         switch (o.code) {
+         case OP_MATMUL: case OP_MATMUL_POP: o.c = next_mm; next_mm = o.a; break;
+         case OP_MUL_TIP: case OP_SET_TIP: o.c = next_tip; next_tip = o.a; break;
+         case OP_SET_TIP2: case OP_MUL_TIP2: o.c = next_tip; next_tip = o.a; break;   // a is consumed first, then b
+         default: break;
+         }
+      }
+      p.first_matmul = next_mm;
+      p.first_tip = next_tip;
+   }
+   p.stream.clear();
+   for (const Op &o : p.ops) {
+      switch (o.code) {
+      case OP_MATMUL: case OP_MATMUL_POP: p.stream.push_back(0); p.stream.push_back(o.a); break;
+      case OP_MUL_TIP: case OP_SET_TIP: p.stream.push_back(1); p.stream.push_back(o.a); break;
+      case OP_SET_TIP2: case OP_MUL_TIP2:
+         p.stream.push_back(1); p.stream.push_back(o.a); p.stream.push_back(1); p.stream.push_back(o.b); break;
+      default: break;
+      }
+   }
+   // link every MATMUL to the next one so the kernel can prefetch its P while computing
+   int next = -1;
+   for (int i = (int)p.ops.size() - 1; i >= 0; i--) {
+      if (p.ops[i].code == OP_MATMUL || p.ops[i].code == OP_MATMUL_POP) {
+         p.ops[i].c = next;
+         next = p.ops[i].a;
+      }
+   }
+}
+
 inline Program build_program(const TreeDesc &t, bool keep_partials, const unsigned char *clean)
 {
    Program p;
@@ -131,38 +170,7 @@ inline Program build_program(const TreeDesc &t, bool keep_partials, const unsign
       }
       p.ops.swap(f);
    }
-   // prefetch links (see Op): walk backwards remembering the next MATMUL's son and the next tip
-   {
-      int next_mm = -1, next_tip = -1;
-      for (int i = (int)p.ops.size() - 1; i >= 0; i--) {
-         Op &o = p.ops[i];
-         switch (o.code) {
-         case OP_MATMUL: case OP_MATMUL_POP: o.c = next_mm; next_mm = o.a; break;
-         case OP_MUL_TIP: case OP_SET_TIP: o.c = next_tip; next_tip = o.a; break;
-         case OP_SET_TIP2: case OP_MUL_TIP2: o.c = next_tip; next_tip = o.a; break;   // a is consumed first, then b
-         default: break;
-         }
-      }
-      p.first_matmul = next_mm;
-      p.first_tip = next_tip;
-   }
-   for (const Op &o : p.ops) {
-      switch (o.code) {
-      case OP_MATMUL: case OP_MATMUL_POP: p.stream.push_back(0); p.stream.push_back(o.a); break;
-      case OP_MUL_TIP: case OP_SET_TIP: p.stream.push_back(1); p.stream.push_back(o.a); break;
-      case OP_SET_TIP2: case OP_MUL_TIP2:
-         p.stream.push_back(1); p.stream.push_back(o.a); p.stream.push_back(1); p.stream.push_back(o.b); break;
-      default: break;
-      }
-   }
-   // link every MATMUL to the next one so the kernel can prefetch its P while computing
-   int next = -1;
-   for (int i = (int)p.ops.size() - 1; i >= 0; i--) {
-      if (p.ops[i].code == OP_MATMUL || p.ops[i].code == OP_MATMUL_POP) {
-         p.ops[i].c = next;
-         next = p.ops[i].a;
-      }
-   }
+   finish_program(p);
    return p;
 }
 

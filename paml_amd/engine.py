@@ -27,7 +27,7 @@ EXPORTS = [
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
     "paml_amd_set_eigen_qrev_batch", "paml_amd_set_eigen_warm_start", "paml_amd_get_eigen", "paml_amd_eigen_counters", "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
-    "paml_amd_device_count", "paml_amd_set_device", "paml_amd_shard_bounds", "paml_amd_max_ranks", "paml_amd_flush", "paml_amd_eigen_status", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_comm_library", "paml_amd_comm_stats", "paml_amd_get_partial_sums", "paml_amd_branch_counters", "paml_amd_branch_coef_hits", "paml_amd_branch_kernel_ms",
+    "paml_amd_device_count", "paml_amd_set_device", "paml_amd_shard_bounds", "paml_amd_max_ranks", "paml_amd_flush", "paml_amd_eigen_status", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_comm_library", "paml_amd_comm_stats", "paml_amd_get_partial_sums", "paml_amd_branch_counters", "paml_amd_branch_coef_hits", "paml_amd_branch_refill_kernels", "paml_amd_branch_kernel_ms",
     "paml_amd_jit_prebuild", "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
 ]
 
@@ -402,7 +402,10 @@ class Engine:
         self._L.paml_amd_branch_counters(self._h, C.byref(a), C.byref(b))
         self._L.paml_amd_branch_coef_hits.restype = C.c_long
         self._L.paml_amd_branch_coef_hits.argtypes = [C.c_void_p]
-        return dict(n_calls=a.value, n_nodes=b.value, coef_hits=self._L.paml_amd_branch_coef_hits(self._h))
+        self._L.paml_amd_branch_refill_kernels.restype = C.c_long
+        self._L.paml_amd_branch_refill_kernels.argtypes = [C.c_void_p]
+        return dict(n_calls=a.value, n_nodes=b.value, coef_hits=self._L.paml_amd_branch_coef_hits(self._h),
+                    refill_kernels=self._L.paml_amd_branch_refill_kernels(self._h))
 
     def branch_kernel_ms(self):
         """Duration of the last eval_branch's contraction kernels by HIP events (needs profile(True)); < 0: not timed."""

@@ -197,7 +197,7 @@ def test_keep_partials_on_the_per_tree_kernel(n_genes, scale_every):
 
 def test_dirty_evaluation_by_the_interpreter_after_a_full_one_by_the_per_tree_kernel():
     """A data set large enough for the per-tree kernel to be chosen by size (not asked for): the full keep-partials evaluation runs on it
-    (128-pattern tiles), eval_dirty — a program with LOADs, different for every set of clean nodes — on the interpreter (64-pattern
+    (128-pattern tiles), eval_dirty — a program with LOADs, different for every set of clean nodes — at first on the interpreter (64-pattern
     tiles), reading what the per-tree kernel stored: one resident layout, nothing invalidated by the change of kernel."""
     pb = helpers.random_problem(61, 10, 33000, K=2, seed=78)
     t = pb.tree
@@ -222,7 +222,30 @@ def test_dirty_evaluation_by_the_interpreter_after_a_full_one_by_the_per_tree_ke
     ref2 = oracle.evaluate(pb)
     assert abs(lnl_dirty - ref2["lnL"]) <= 1e-10 * abs(ref2["lnL"])
     # ... and back: a full evaluation (per-tree kernel again), the same value as a fresh engine's
-    assert eng.eval(br, pb.gene_rate)["lnL"] == engine_for(pb).eval(br, pb.gene_rate)["lnL"] and eng.kernel_name == "mfma64_jit"
+    full = engine_for(pb).eval(br, pb.gene_rate)["lnL"]
+    assert eng.eval(br, pb.gene_rate)["lnL"] == full and eng.kernel_name == "mfma64_jit"
+    # Round 6: the SECOND time the same set of clean nodes is asked for, its LOAD program gets a per-tree kernel of its own (compiled on the
+    # worker thread, the interpreter serving until it is there); full and dirty evaluations then alternate between two kernels that both
+    # stay loaded, and between two tile tables that both stay built
+    import time
+    t0 = time.time()
+    names = set()
+    while time.time() - t0 < 120:
+        v = eng.eval_dirty(br, clean, pb.gene_rate)
+        names.add(eng.kernel_name)
+        assert abs(v - ref2["lnL"]) <= 1e-10 * abs(ref2["lnL"])
+        if eng.kernel_name == "mfma64_jit":
+            break
+        time.sleep(0.2)
+    assert eng.kernel_name == "mfma64_jit", names
+    for _ in range(3):
+        assert eng.eval(br, pb.gene_rate)["lnL"] == full and eng.kernel_name == "mfma64_jit"
+        assert abs(eng.eval_dirty(br, clean, pb.gene_rate) - ref2["lnL"]) <= 1e-10 * abs(ref2["lnL"]) and eng.kernel_name == "mfma64_jit"
+    t1 = time.time()
+    for _ in range(20):
+        eng.eval(br, pb.gene_rate)
+        eng.eval_dirty(br, clean, pb.gene_rate)
+    assert time.time() - t1 < 2.0      # (no compilation, no module load, no tile rebuild inside the alternation)
 
 
 def test_young_ancestor_root_is_tip():
@@ -546,7 +569,7 @@ def test_20_state_matrix_core_kernel_beyond_the_lds_capacity(n_tips, K, scale_ev
 
 
 @pytest.mark.parametrize("n,n_tips,n_patt,K,jit", [(61, 90, 300, 1, True), (61, 130, 140, 1, True), (61, 200, 300, 2, True), (61, 230, 130, 1, True), (61, 208, 129, 1, True),
-                                                   (61, 410, 140, 2, True), (61, 7, 1, 2, False),
+                                                   (61, 410, 140, 2, True), (61, 620, 150, 2, True), (61, 1000, 130, 1, True), (61, 7, 1, 2, False),
                                                    (61, 12, 129, 20, True), (33, 9, 200, 2, False), (4, 150, 1000, 1, True),
                                                    (5, 40, 777, 2, True), (20, 60, 500, 1, False)])
 def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch):
@@ -559,8 +582,8 @@ def test_size_limits_and_kernel_fallbacks(n, n_tips, n_patt, K, jit, monkeypatch
     eng, out, ref = check(pb)
     if n == 61 and n_tips in (130, 200):
         assert eng.kernel_name == "mfma64_jit"             # one tip-code block
-    if n == 61 and n_tips > 207:      # (208: the first size in halves; 410: next to the limit of ~413; random topologies, ambiguity codes, scaling nodes)
-        assert eng.kernel_name == "mfma64_jit"             # two half blocks of tip codes per tile
+    if n == 61 and n_tips > 207:      # (208: the first size in pieces; 410: two pieces' limit; 620 / 1000 (round 6): three / five pieces; random topologies, ambiguity codes, scaling nodes)
+        assert eng.kernel_name == "mfma64_jit"             # a tile's tip codes in pieces, one in LDS at a time
         # ... the same values from the interpreter kernels
         monkeypatch.setenv("PAML_AMD_JIT", "0")
         eng0, out0, _ = check(pb)
@@ -1198,6 +1221,32 @@ def test_eval_branch_eigen_basis_walk_cache_and_many_trial_lengths(K, amb, scale
     base = eng.eval(t.branch, pb.gene_rate)["lnL"]
     l, _, _ = eng.eval_branch(order[2], np.array([t.branch[order[2]]]), t.branch, pb.gene_rate)
     assert abs(l[0] - base) <= 1e-11 * abs(base)
+
+
+@pytest.mark.parametrize("K,amb,scale", [(1, False, None), (2, True, None), (1, False, 4)])
+def test_eval_branch_refill_on_a_per_tree_kernel(K, amb, scale):
+    """Round 6: when every branch length has moved since the resident partials were formed (minB's round after ming2 moved kappa / omega;
+    updateconP treesub.c:7982 then recomputes every node) the branch-local evaluation's forest of dirty subtrees runs on a per-tree kernel of
+    its own — STOREs in the resident layout from 128-pattern tiles — instead of the interpreter.  Forced here (PAML_AMD_JIT flag: compiled
+    while the caller waits); l, l', l'' against the oracle at two branches after two refills, equal to the interpreter engine's values."""
+    pb = helpers.random_problem(61, 12, 900, K=K, seed=1300 + K, ambiguity=amb, scale_every=scale)
+    t = pb.tree
+    eng, ref_eng = engine_for(pb, flags=JIT), engine_for(pb)
+    rng = np.random.default_rng(9)
+    internal = [v for v in range(t.n_tips, t.n_nodes) if v != t.root]
+    for rnd in range(2):
+        t.branch[:] = np.where(np.arange(t.n_nodes) == t.root, 0.0, t.branch * rng.uniform(0.7, 1.4, t.n_nodes))      # every length moves: a refill
+        for b in (internal[1], 2):
+            ts = np.array([t.branch[b], 0.04, 0.6])
+            l, dl, ddl = eng.eval_branch(b, ts, t.branch, pb.gene_rate)
+            if b == internal[1]:
+                assert eng.kernel_name == "mfma64_jit" and eng.branch_counters()["refill_kernels"] == rnd + 1, eng.kernel_name      # (the refill's pruning kernel)
+            rl, rdl, rddl = oracle.eval_branch(pb, b, ts)
+            il, idl, iddl = ref_eng.eval_branch(b, ts, t.branch, pb.gene_rate)
+            assert np.allclose(l, rl, rtol=1e-11, atol=0), (rnd, b, l, rl)
+            assert np.allclose(dl, rdl, rtol=1e-9, atol=1e-9) and np.allclose(ddl, rddl, rtol=1e-9, atol=1e-8)
+            assert np.allclose(l, il, rtol=1e-12, atol=0) and np.allclose(dl, idl, rtol=1e-9, atol=1e-9)
+    assert abs(eng.eval(t.branch, pb.gene_rate)["lnL"] - oracle.evaluate(pb)["lnL"]) <= 1e-10 * abs(oracle.evaluate(pb)["lnL"])
 
 
 def test_eval_branch_at_1e5_patterns_against_the_oracle():
