@@ -84,11 +84,20 @@ fix_blength = 2
 """
 
 
+def run_program(argv, cwd, newlines, env=None, limit=int(os.environ.get("PAML_AMD_TEST_RUN_LIMIT_S", "600"))):
+    """One run of a reference binary (patched or not), its prompts answered with empty lines.  A run that does not end within `limit` seconds
+    fails the test with the tail of what it printed, instead of holding the suite."""
+    try:
+        return subprocess.run(argv, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * newlines, timeout=limit, env=env)
+    except subprocess.TimeoutExpired as e:
+        raise AssertionError("%s did not end within %d s; its output ends with:\n%s" % (argv[0], limit, (e.stdout or b"").decode(errors="replace")[-3000:]))
+
+
 def run(exe, ctl, d, env=None, ctl_name="codeml.ctl"):
     d.mkdir()
     (d / ctl_name).write_text(ctl % {"data": DATA})
     t0 = time.perf_counter()
-    r = subprocess.run([exe, ctl_name], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 20, timeout=1500, env=env)
+    r = run_program([exe, ctl_name], d, 20, env=env)
     dt = time.perf_counter() - t0
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
@@ -205,7 +214,7 @@ def single_evaluation(prog, name, d, exe, extra_ctl="", env=None):
     for dat in ("grantham.dat", "miyata.dat", "OmegaAA.dat"):      # (aaDist: the reference opens these by name in the working directory)
         (d / dat).write_text(open(os.path.join(helpers.GOLDEN, "ctl", dat)).read())
     (d / ("in." + prog)).write_text("-1 " + " ".join("%.6f" % v for v in g["x"]) + "\n")
-    r = subprocess.run([exe, prog + ".ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=900, env=env)
+    r = run_program([exe, prog + ".ctl"], d, 50, env=env)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
     m = re.findall(r"lnL\s*=\s*(-?[0-9.]+)", out)
@@ -264,7 +273,7 @@ def test_patched_reference_optimises_the_wider_model_families(name, extra, publi
     d.mkdir()
     (d / "codeml.ctl").write_text(ctl)
     t0 = time.perf_counter()
-    r = subprocess.run([REF_GPU, "codeml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=1500)
+    r = run_program([REF_GPU, "codeml.ctl"], d, 50)
     dt = time.perf_counter() - t0
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
@@ -332,7 +341,7 @@ def test_batched_gradient_equals_the_serial_one(name, extra, tmp_path):
     d = tmp_path / "gpu"
     d.mkdir()
     (d / "codeml.ctl").write_text(ctl)
-    r = subprocess.run([REF_GPU, "codeml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=1500,
+    r = run_program([REF_GPU, "codeml.ctl"], d, 50,
                        env=dict(os.environ, PAML_AMD_GRADIENT_CHECK="1"))
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
@@ -405,7 +414,7 @@ def test_baseml_batched_gradient_equals_the_serial_one(name, extra, tmp_path):
         d = tmp_path / tag
         d.mkdir()
         (d / "baseml.ctl").write_text(ctl)
-        r = subprocess.run([exe, "baseml.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=1500, env=env)
+        r = run_program([exe, "baseml.ctl"], d, 50, env=env)
         out = r.stdout.decode(errors="replace")
         assert r.returncode == 0, out[-3000:]
         lnl = [float(m.group(1)) for m in re.finditer(r"lnL\(ntime:\s*\d+\s+np:\s*\d+\):\s+(-?\d+\.\d+)", (d / "mlc").read_text())]
@@ -441,7 +450,7 @@ def test_clock_models_and_correlated_rates_through_the_patched_reference(prog, c
         if "clock = 2" in extra:
             (d / "local.trees").write_text(tree)
         t0 = time.perf_counter()
-        r = subprocess.run([e, prog + ".ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * 50, timeout=1500, env=env)
+        r = run_program([e, prog + ".ctl"], d, 50, env=env)
         out = r.stdout.decode(errors="replace")
         assert r.returncode == 0, out[-3000:]
         lnl = [float(m.group(1)) for m in re.finditer(r"lnL\(ntime:\s*\d+\s+np:\s*\d+\):\s+(-?\d+\.\d+)", (d / "mlc").read_text())]

@@ -31,6 +31,9 @@ for w in c2 c2large branch; do
   pmc $w FETCH_SIZE $C; pmc $w WRITE_SIZE $C
 done
 cd - > /dev/null
+# the memory-side ceiling of the forming kernel's traffic mix (2 x 0.5 GB read, 0.5 GB written), and bench.py's branch block alone
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/hbm_mix_peak tools/hbm_mix_peak.hip && /tmp/hbm_mix_peak > $out/hbm_mix_peak.txt 2>&1
+python tools/refill_probe.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" > $out/branch_block.json
 {
   echo "# bench.py headline (16 taxa x 1e6 codon patterns, M0), PAML_AMD_DUAL=0: FETCH_SIZE / WRITE_SIZE (KiB per dispatch, separate passes), MFMA"
   for d in pmc_fetch pmc_write pmc_mfma; do python tools/pmc_summary.py $out/$d; done
@@ -75,4 +78,4 @@ for sect, (fn, kernel, wl) in what.items():
     json.dump(d, open(out + "/" + fn, "w"), indent=1)
 PY
 rm -rf $out/stats; find $out -maxdepth 1 -type d -name "pmc_*" -exec rm -rf {} +; rm -f $out/pmc_*.out $out/pmc_*.err $out/stats.out $out/stats.err
-ls $out; head -4 $out/kernel_stats.csv | cut -c1-160; cat $out/pmc_summary.txt | cut -c1-300; for f in $out/*_under_rocprof.txt; do echo "== $f"; cat $f; done
+cat $out/hbm_mix_peak.txt; ls $out; head -4 $out/kernel_stats.csv | cut -c1-160; cat $out/pmc_summary.txt | cut -c1-300; for f in $out/*_under_rocprof.txt; do echo "== $f"; cat $f; done
