@@ -830,6 +830,19 @@ def bench_branch(engine, pb, lnl_full):
     kms = res["same_internal_branch_form_nt1_kernel_ms"]
     hbm_bytes, flops = 3 * 512.0 * pb.n_patt, 2 * 2 * 61.0 * 61.0 * pb.n_patt
     t_hbm, t_mfma = hbm_bytes / 8e12 * 1e3, flops / (FP64_PEAK_TFLOPS * 1e12) * 1e3
+    # the forming kernel's counted HBM bytes (profiles/rNN_branch_pmc.json) and the memory-side ceiling of its traffic mix — two arrays read, one
+    # written, 8 KB per wave and array, by a kernel that does nothing else (tools/hbm_mix_peak.hip -> profiles/rNN_hbm_mix_peak.txt)
+    traffic = ceiling = None
+    try:
+        with open(sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_branch_pmc.json")))[-1]) as f:
+            traffic = [v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items() if "eig_kernel<0, false" in k][0]
+    except (IndexError, OSError, KeyError, ValueError):
+        pass
+    try:
+        with open(sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_hbm_mix_peak.txt")))[-1]) as f:
+            ceiling = max(float(ln.split("=")[1].split("TB/s")[0]) for ln in f if "TB/s" in ln) * 1e3
+    except (IndexError, OSError, ValueError):
+        pass
     return dict(workload="eval_branch (lfuntdd) on the headline data, %d taxa x %d codon patterns, M0; %.1f GB of partials + %.2f GB of coefficients resident"
                          % (t.n_tips, pb.n_patt, 512e-9 * pb.n_patt * n_int, 512e-9 * pb.n_patt),
                 first_call_ms=ms_first, refill_call_ms=ms_refill, refill_call_interpreter_ms=ms_refill_interp, refill_on_per_tree_kernel=refill_on_kernel,
@@ -843,7 +856,11 @@ def bench_branch(engine, pb, lnl_full):
                 roofline=dict(kernel="branch_eig_kernel<0,.,.,false> (both partials resident, internal branch, nt = 1)", bound="hbm" if t_hbm >= t_mfma else "mfma",
                               kernel_ms=kms, bytes_per_pattern=1536, flop_per_pattern=4 * 61 * 61, bound_ms=max(t_hbm, t_mfma),
                               achieved=hbm_bytes / (kms * 1e-3) / 1e9, peak=8000.0, unit="GB/s", frac=max(t_hbm, t_mfma) / kms,
-                              mfma_tflops=flops / (kms * 1e-3) / 1e12,
+                              mfma_tflops=flops / (kms * 1e-3) / 1e12, mfma_frac=t_mfma / kms, traffic=traffic,
+                              streaming_ceiling_GBs=ceiling, frac_of_streaming_ceiling=(hbm_bytes / (kms * 1e-3) / 1e9 / ceiling) if ceiling else None,
+                              note="two bounds of the same length: 1536 B per pattern at 8 TB/s = %.3f ms, 14 884 flop per pattern at %.1f TFLOP/s = %.3f ms; "
+                                   "streaming_ceiling_GBs: what a kernel with this traffic and no arithmetic reaches on this chip (tools/hbm_mix_peak.hip)"
+                                   % (t_hbm, FP64_PEAK_TFLOPS, t_mfma),
                               timing="HIP events on the engine's stream around the contraction kernel, one launch at a time"))
 
 
@@ -887,7 +904,24 @@ def bench_fallbacks(engine, synth, timed, pb_c4):
     q = pb.n_patt // 4
     pbg = dataclasses.replace(pb, gene_off=np.array([0, q, 2 * q, 3 * q, pb.n_patt], dtype=np.int32), gene_rate=np.array([1.0, 0.7, 1.3, 1.9]),
                               eigen_of=None, qfactor=None)
-    eng, _ = run("baseml GTR+G4, 32 taxa x 100000 patterns in 4 genes", pbg, steps=50, why="the fused 4-state kernel holds one gene's P(t) tables per workgroup")
+    eng, row = run("baseml GTR+G4, 32 taxa x 100000 patterns in 4 genes", pbg, steps=50,
+                   why="the fused 4-state kernel holds one gene's P(t) tables per workgroup; its several-genes form (PAML_AMD_VF_GENES=1) is built, "
+                       "bit-equal and no faster than this (profiles/r06_genes_4state.txt)")
+    # ... and a gradient's 122 evaluations of it in one launch (the c2_batch block's call, with genes)
+    idx = [i for i in range(pbg.tree.n_nodes) if i != pbg.tree.root]
+    Bm = np.repeat(pbg.tree.branch[None, :], 2 * len(idx), axis=0)
+    for k, i in enumerate(idx):
+        Bm[2 * k, i] *= 1 + 1e-6
+        Bm[2 * k + 1, i] *= 1 - 1e-6
+    for _ in range(2):
+        vals = eng.eval_batch(Bm)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        vals = eng.eval_batch(Bm)
+    dtb = (time.perf_counter() - t0) / 10
+    if not np.all(np.abs(vals - row["lnL"]) < 1e-3 * abs(row["lnL"])):
+        raise SystemExit("bench: batched several-genes values off: %r vs %r" % (vals[:4].tolist(), row["lnL"]))
+    row["batch_of_122"] = dict(kernel=eng.kernel_name, ms_per_batch=dtb * 1e3, frac_of_fp64_peak=frac(pbg, dtb * 1e3 / len(Bm)))
     eng.close()
     # 3. 20 states with more taxa than the matrix-core kernel's LDS holds tables for
     pb = synth.aa_gamma_problem(n_tips=60, n_patt=100_000, seed=60)
@@ -910,7 +944,8 @@ def bench_fallbacks(engine, synth, timed, pb_c4):
     # 4. every internal node's partial kept (method = 1 / eval_dirty): a full evaluation writes 7.2 GB
     if pb_c4 is not None:
         eng, row = run("codon M0, 16 taxa x 1000000 patterns, PAML_AMD_KEEP_PARTIALS", pb_c4, flags=engine.KEEP_PARTIALS, steps=5,
-                       why="every internal node's partial is also written to HBM (round 5: STORE inside the per-tree kernel; eval_dirty's LOAD programs stay on the interpreter)")
+                       why="every internal node's partial is also written to HBM (STORE inside the per-tree kernel; round 6: eval_dirty's LOAD programs and eval_branch's refills "
+                           "get per-tree kernels of their own from their second request on — branch.refill_call_ms)")
         row["hbm_write_GB"] = 512e-9 * pb_c4.n_patt * (pb_c4.tree.n_nodes - pb_c4.tree.n_tips)
         eng.close()
     return rows

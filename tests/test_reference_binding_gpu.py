@@ -86,11 +86,29 @@ fix_blength = 2
 
 def run_program(argv, cwd, newlines, env=None, limit=int(os.environ.get("PAML_AMD_TEST_RUN_LIMIT_S", "600"))):
     """One run of a reference binary (patched or not), its prompts answered with empty lines.  A run that does not end within `limit` seconds
-    fails the test with the tail of what it printed, instead of holding the suite."""
+    fails the test with what its threads were waiting in (/proc) and the tail of what it printed, instead of holding the suite."""
+    p = subprocess.Popen(argv, cwd=cwd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
     try:
-        return subprocess.run(argv, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, input=b"\n" * newlines, timeout=limit, env=env)
-    except subprocess.TimeoutExpired as e:
-        raise AssertionError("%s did not end within %d s; its output ends with:\n%s" % (argv[0], limit, (e.stdout or b"").decode(errors="replace")[-3000:]))
+        out, _ = p.communicate(b"\n" * newlines, timeout=limit)
+        return subprocess.CompletedProcess(argv, p.returncode, out, None)
+    except subprocess.TimeoutExpired:
+        where = []
+        for tid in sorted(os.listdir("/proc/%d/task" % p.pid)):
+            row = [tid]
+            for f in ("comm", "wchan", "syscall"):
+                try:
+                    row.append(open("/proc/%d/task/%s/%s" % (p.pid, tid, f)).read().strip()[:60])
+                except OSError as e:
+                    row.append("?%s" % e.errno)
+            try:
+                row.append([l.split(":")[1].strip() for l in open("/proc/%d/task/%s/status" % (p.pid, tid)) if l.startswith("State")][0])
+            except (OSError, IndexError):
+                pass
+            where.append(" ".join(row))
+        p.kill()
+        out, _ = p.communicate()
+        raise AssertionError("%s did not end within %d s; threads (tid comm wchan syscall state):\n%s\nits output ends with:\n%s"
+                             % (argv[0], limit, "\n".join(where), (out or b"").decode(errors="replace")[-2500:]))
 
 
 def run(exe, ctl, d, env=None, ctl_name="codeml.ctl"):

@@ -63,7 +63,7 @@ what = {"bench.py": ("pmc.json", "prune_jit", "bench.py headline (16 taxa x 1e6 
         "branch": ("branch_pmc.json", None, "tools/branch_quick.py (eval_branch at 16 taxa x 1e6 codon patterns)")}
 for sect, (fn, kernel, wl) in what.items():
     ks = vals.get(sect, {})
-    rows = {k: v for k, v in ks.items() if (kernel is None and "branch" in k) or k == kernel}
+    rows = {k: v for k, v in ks.items() if (kernel is None and ("branch" in k or "eig_kernel" in k)) or k == kernel}      # (pmc_summary.py keeps the tail of a long kernel name)
     res = {}
     for k, b in rows.items():
         if "FETCH_SIZE" in b and "WRITE_SIZE" in b:
