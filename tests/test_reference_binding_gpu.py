@@ -84,7 +84,7 @@ fix_blength = 2
 """
 
 
-def run_program(argv, cwd, newlines, env=None, limit=int(os.environ.get("PAML_AMD_TEST_RUN_LIMIT_S", "600"))):
+def run_program(argv, cwd, newlines, env=None, limit=int(os.environ.get("PAML_AMD_TEST_RUN_LIMIT_S", "300"))):
     """One run of a reference binary (patched or not), its prompts answered with empty lines.  A run that does not end within `limit` seconds
     fails the test with what its threads were waiting in (/proc) and the tail of what it printed, instead of holding the suite."""
     p = subprocess.Popen(argv, cwd=cwd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
