@@ -354,7 +354,8 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
       *e->h_eig_fail = 0;
    }
    if (!e->eigen_attr_set) {
-      HIPCHK(hipFuncSetAttribute((const void *)eigen_qrev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EIG_LDS_BYTES));
+      for (const void *fn : {(const void *)eigen_qrev_kernel<0>, (const void *)eigen_qrev_kernel<20>, (const void *)eigen_qrev_kernel<60>, (const void *)eigen_qrev_kernel<62>})
+         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EIG_LDS_BYTES));
       e->eigen_attr_set = true;
    }
    EigenQrevArgs a{};
@@ -363,7 +364,13 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
    static const int sweep_limit = getenv("PAML_AMD_EIGEN_SWEEP_LIMIT") ? std::max(1, atoi(getenv("PAML_AMD_EIGEN_SWEEP_LIMIT"))) : 40;
    a.max_sweeps = sweep_limit;
    if (e->eigen_warm) { a.R0 = e->d_eq_ptr.p + 3 * (size_t)n_sets; a.Rout = e->d_eq_ptr.p + 4 * (size_t)n_sets; }
-   hipLaunchKernelGGL(eigen_qrev_kernel, dim3(n_sets), dim3(EIG_NT), EIG_LDS_BYTES, e->stream, a);
+   // (the orders with a register form: R^T in a ninth wave's registers; PAML_AMD_EIGEN_LDS=1: the any-order form for them too)
+   static const bool lds_form = getenv("PAML_AMD_EIGEN_LDS") != nullptr;
+   const int N_even = ((int)n + 1) & ~1;
+   if (N_even == 62 && !lds_form) hipLaunchKernelGGL(eigen_qrev_kernel<62>, dim3(n_sets), dim3(EIG_NT), EIG_LDS_BYTES, e->stream, a);
+   else if (N_even == 60 && !lds_form) hipLaunchKernelGGL(eigen_qrev_kernel<60>, dim3(n_sets), dim3(EIG_NT), EIG_LDS_BYTES, e->stream, a);
+   else if (N_even == 20 && !lds_form) hipLaunchKernelGGL(eigen_qrev_kernel<20>, dim3(n_sets), dim3(EIG_NT), EIG_LDS_BYTES, e->stream, a);
+   else hipLaunchKernelGGL(eigen_qrev_kernel<0>, dim3(n_sets), dim3(EIG_NT), EIG_LDS_BYTES, e->stream, a);
    HIPCHK(hipGetLastError());
    // (the host arrays were pageable: the runtime has staged them on return; the evaluations that follow on the engine's stream see the sets)
    e->n_eigen_device += n_sets;

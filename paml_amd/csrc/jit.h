@@ -489,10 +489,13 @@ inline std::string jit_generate_impl(const Program &p, int n_tips, int n_states,
          const int out = alloc();
          // a cherry right after a pushed matmul: its two tip gathers ride under this matmul's second half
          // (piece mode: a cherry whose codes lie in the NEXT piece is not folded under this product — the crossing then happens at the cherry's
-         //  own step.  Folded, the 1 000-tip tree of tests/test_engine_gpu.py came out wrong in every pattern, by about one scale factor;
-         //  crossings at unfused steps are right, and there are at most pieces - 1 of them per tile.)
+         //  own step; there are at most pieces - 1 of them per tile.  The folded form is kept behind PAML_AMD_JIT_FOLD_CROSSING=1: one run of the
+         //  1 000-tip tree of tests/test_engine_gpu.py came out wrong with it during development and could not be reproduced — the identical
+         //  generated source gives the oracle's value on the final build — so the form every full test run has exercised is the default.)
+         const bool crossing_cherry = zhalf && iop + 1 < nops && p.ops[iop + 1].code == OP_SET_TIP2 &&
+                                      std::max(zpl.piece[p.ops[iop + 1].a], zpl.piece[p.ops[iop + 1].b]) > cur_piece;
          const bool fuse = fuse_tips && push >= 0 && iop + 1 < nops && p.ops[iop + 1].code == OP_SET_TIP2 &&
-                           !(zhalf && std::max(zpl.piece[p.ops[iop + 1].a], zpl.piece[p.ops[iop + 1].b]) > cur_piece);
+                           (!crossing_cherry || getenv("PAML_AMD_JIT_FOLD_CROSSING"));
          const bool fuse_next = peel && (int)iop == last_mm;     // ... or the next tile's first cherry under the last matmul
          if (fuse) cross_if({p.ops[iop + 1].a, p.ops[iop + 1].b});
          // (tip tables the ring could not hold earlier are requested in the first k-block pairs and awaited at the midpoint)
