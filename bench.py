@@ -425,7 +425,7 @@ def main():
                 out["branch"] = bench_branch(engine, pb_full if args.scaling == "strong" else pb, lnl)
             except Exception as ex:      # noqa: BLE001  (reported, the headline stands)
                 out["branch"] = {"error": repr(ex)}
-        for key, fn in (("c1", bench_c1), ("c3", bench_c3), ("c5", bench_c5)):      # the small-data configurations: latency, not throughput
+        for key, fn in (("c1", bench_c1), ("c3", bench_c3), ("c5", bench_c5), ("eigen", bench_eigen)):      # the small-data configurations: latency, not throughput
             try:
                 out[key] = fn(engine, timed, fence)
             except Exception as ex:      # (the C host library or a data file missing: reported, the headline stands)
@@ -668,6 +668,39 @@ def bench_c3(engine, timed, fence):
         raise SystemExit("bench: c3 lnL %.9f differs from the reference's %.6f" % (r["lnL"], g["lnL"]))
     r.update(workload="codeml seqtype 2 LG+G4, stewart.aa (6 taxa, %d patterns) (BASELINE configs[2])" % pb.n_patt, lnL_reference=g["lnL"])
     return r
+
+
+def bench_eigen(engine, timed, fence):
+    """What a search's trial point waits for before its P(t): paml_amd_set_eigen_qrev_batch (eigenQREV tools.c:5023 under eigenQcodon
+    codeml.c:3229) on one 61 x 61 codon matrix, the call plus the wait for its result — cold, and warm-started from the previous
+    decomposition after a finite-difference step (1e-6 relative) and after a line-search step (5 %), as tools/eigen_probe.py does."""
+    from paml_amd import models, synth
+    pb = synth.codon_m0_problem(n_tips=6, n_patt=300)
+    eng = engine.engine_for(pb)
+    rng = np.random.default_rng(1)
+    pi = pb.pi[0]
+    out = {"workload": "one 61 x 61 reversible codon matrix per call (call + wait), median of 30"}
+    for warm in (0, 1):
+        eng.set_eigen_warm_start(warm)
+        for name, step in (("fd", 1e-6), ("linesearch", 0.05)):
+            if not warm and name == "linesearch":
+                continue
+            kappa, om, ts, sw = 2.0, 0.4, [], []
+            for it in range(36):
+                kappa *= 1 + step * rng.choice([-1, 1])
+                om *= 1 + step * rng.choice([-1, 1])
+                Q, mr = models.codon_q(kappa, om, pi)
+                fence()
+                t0 = time.perf_counter()
+                eng.set_eigen_qrev_batch(np.array([1]), np.array([Q]), np.array([pi]), np.array([mr]))
+                eng.flush()
+                fence()
+                ts.append(time.perf_counter() - t0)
+                sw.append(int(eng.eigen_counters()["sweeps"].max()))
+            out["warm_%s_ms" % name if warm else "cold_ms"] = float(np.median(ts[6:]) * 1e3)
+            out["warm_%s_sweeps" % name if warm else "cold_sweeps"] = float(np.median(sw[6:]))
+    eng.close()
+    return out
 
 
 def bench_c5(engine, timed, fence):

@@ -95,8 +95,8 @@ __device__ __forceinline__ void eig_vrot(double (&v)[NS], double c, double sn)
 template <int NS, int R, int K0, int... K>
 __device__ __forceinline__ void eig_vrots(double (&v)[NS], const double *cs, std::integer_sequence<int, K...>)
 {
-   // (all the angles of the half round first: 8-byte reads of one address by every lane — a 16-byte read of one address is not a broadcast
-   //  on this LDS: measured ~60 cycles of the LDS pipeline each)
+   // (all the angles of the half round first: 8-byte reads of one address by every lane — as double2, 16-byte reads of one address from
+   //  this double-aligned array, they measured ~60 cycles of the LDS pipeline each: profiles/r06_eigen.txt)
    const double c[sizeof...(K)] = {cs[K0 + K]...}, sn[sizeof...(K)] = {cs[32 + K0 + K]...};
    (eig_vrot<NS, R, K0 + K>(v, c[K], sn[K]), ...);
 }
