@@ -101,11 +101,13 @@ def run_program(argv, cwd, newlines, env=None, limit=int(os.environ.get("PAML_AM
                 row = [tid]
                 for f in ("comm", "wchan", "syscall"):
                     try:
-                        row.append(open("/proc/%d/task/%s/%s" % (p.pid, tid, f)).read().strip()[:60])
+                        with open("/proc/%d/task/%s/%s" % (p.pid, tid, f)) as fh:
+                            row.append(fh.read().strip()[:60])
                     except OSError as e:
                         row.append("?%s" % e.errno)
                 try:
-                    row.append([l.split(":")[1].strip() for l in open("/proc/%d/task/%s/status" % (p.pid, tid)) if l.startswith("State")][0])
+                    with open("/proc/%d/task/%s/status" % (p.pid, tid)) as fh:
+                        row.append([l.split(":")[1].strip() for l in fh if l.startswith("State")][0])
                 except (OSError, IndexError):
                     pass
                 where.append(" ".join(row))
