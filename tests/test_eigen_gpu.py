@@ -111,6 +111,40 @@ def test_small_reversible_matrices(n):
         assert abs(R[0]) < 1e-13 and np.all(np.diff(R) <= 0)
 
 
+@pytest.mark.parametrize("n", [4, 20, 33, 60, 61])
+def test_degenerate_spectra_and_scales(n):
+    """What a Jacobi iteration can trip over, in both forms of the kernel: one eigenvalue of multiplicity n - 1 (equal rates, equal
+    frequencies) at three scales (x 1, 1e-150, 1e150: the angle formula's squares must neither underflow nor overflow), two groups of
+    states that never exchange (a block-diagonal matrix: half of the off-diagonal elements are zero from the start), the zero matrix
+    (converged before the first sweep)."""
+    rng = np.random.default_rng(100 + n)
+    pb = helpers.random_problem(n, 6, 200, K=1, seed=5)
+    eng = engine_for(pb)
+    flat = np.full(n, 1.0 / n)
+    J = np.full((n, n), 1.0 / n)
+    J[np.diag_indices(n)] = 0
+    J[np.diag_indices(n)] = -J.sum(axis=1)
+    h = n // 2
+    S = rng.uniform(0.1, 2.0, size=(n, n))
+    S = np.tril(S, -1) + np.tril(S, -1).T
+    S[:h, h:] = 0; S[h:, :h] = 0
+    pib = rng.dirichlet(np.ones(n) * 3)
+    B = S * pib[None, :]
+    B[np.diag_indices(n)] = -B.sum(axis=1)
+    Qs = [J, J * 1e-150, J * 1e150, B, np.zeros((n, n))]
+    pis = [flat, flat, flat, pib, flat]
+    eng.set_eigen_qrev_batch(np.arange(len(Qs)) + 1, np.array(Qs), np.array(pis))
+    sw = eng.eigen_counters()["sweeps"]
+    assert sw.min() >= 0 and sw.max() <= 10 and sw[4] == 0, sw
+    for k, Q in enumerate(Qs):
+        U, V, R = eng.get_eigen(k + 1)
+        scale = max(np.abs(Q).max(), 1e-300)
+        assert np.all(np.diff(R) <= 0), k
+        assert np.max(np.abs(U @ np.diag(R) @ V - Q)) <= 1e-13 * n * scale, (k, np.max(np.abs(U @ np.diag(R) @ V - Q)) / scale)
+        assert np.max(np.abs(U @ V - np.eye(n))) <= 1e-13, k
+    assert abs(eng.get_eigen(1)[2][0]) <= 1e-15 and np.allclose(eng.get_eigen(1)[2][1:], -1.0, rtol=0, atol=1e-13)      # roots 0, -1 (n - 1 times)
+
+
 def test_warm_started_decompositions_along_an_optimisers_path():
     """paml_amd_set_eigen_warm_start: three sets (omega classes) decomposed again and again while kappa and the omegas move the way an
     optimiser moves them — finite-difference steps of 1e-6 relative, line-search steps of a few per cent.  From the second call on the
