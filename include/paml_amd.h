@@ -145,7 +145,7 @@ int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi);
  * matrix.  Q[n_sets][n*n] row-major (only the lower triangle is read, like eigenQREV), pi[n_sets][n], scale[n_sets] (NULL = 1):
  * set set_ids[i] becomes Root = w / scale (descending), U = diag(1/sqrt pi) R, V = R^T diag(sqrt pi) with
  * diag(sqrt pi) Q diag(1/sqrt pi) = R diag(w) R^T; states with pi = 0 are left out (Root 0, unit rows / columns).  One workgroup
- * per matrix (cyclic Jacobi in LDS, FP64, ~0.8 ms): a gradient's or a line search's several hundred decompositions take about the time
+ * per matrix (cyclic Jacobi in LDS, FP64, ~0.5 ms cold): a gradient's or a line search's several hundred decompositions take about the time
  * of one, and U, V, Root never cross PCIe.  Asynchronous on the engine's stream.  paml_amd_get_eigen reads a set back (parity);
  * paml_amd_eigen_counters: matrices decomposed so far and the Jacobi sweeps each matrix of the last batch took (-1: the limit of 40
  * sweeps was reached without convergence — decompose that matrix on the host instead).  The decomposition is asynchronous, so a set
@@ -154,11 +154,13 @@ int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi);
  * binding (integration/codeml_plfun.patch) then decompose on the host and evaluate again. */
 int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, const double *Q, const double *pi, const double *scale);
 /* Warm start for the above (on = 1; 0 = off, the default; -1 = leave as is; *n_warm, if not NULL, receives the number of
- * decompositions that started warm so far): a set decomposed again starts its Jacobi sweeps from the eigenvectors of its previous
- * matrix — 2-4 sweeps instead of 9-10 when the matrix moved by a finite-difference step or a line-search step, which is what an
- * optimiser sends (0.78 ms per call cold, 0.26 ms after a finite-difference step, 0.43 ms after a 5 % step: tools/eigen_probe.py).  The answer is a decomposition of the NEW
- * matrix to the same threshold either way; its last bits then depend on the matrices the set held before, which is why the
- * default is off.  Every 16th decomposition of a set, and any whose pi has other zero entries than the last, starts cold. */
+ * decompositions that started warm so far): a decomposition starts its Jacobi sweeps from the eigenvectors of the NEAREST matrix any set
+ * of the engine was last decomposed for (told by a signature of eight weighted row sums; round 6 — until then: the set's own previous
+ * matrix) — the set's predecessor along a line search, the base point's sets for the perturbed points of a gradient: 2 sweeps after a
+ * finite-difference step, 4 after a 5 % step, instead of 8-9 (0.52 ms per call cold, 0.19 ms after a finite-difference step, 0.31 ms
+ * after a 5 % step: tools/eigen_probe.py).  The answer is a decomposition of the NEW matrix to the same threshold either way; its last
+ * bits then depend on the matrices the engine held before, which is why the default is off.  Every 16th decomposition of a chain, and
+ * any whose pi has other zero entries than every candidate's, starts cold. */
 int paml_amd_set_eigen_warm_start(paml_amd_engine *e, int on, long *n_warm);
 int paml_amd_get_eigen(paml_amd_engine *e, int set_id, double *U, double *V, double *Root);
 int paml_amd_eigen_counters(paml_amd_engine *e, long *n_decomposed, int *sweeps_last_batch, int cap);

@@ -318,6 +318,37 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
    }
    if (!eigen_slot(e, max_id)) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: bad arguments");      // (sizes the table once: the slots below do not move)
    std::vector<double *> ptr((size_t)5 * n_sets, nullptr);
+   // Warm start: a decomposition starts from the eigenvectors of the NEAREST matrix any set of the engine was last decomposed for — its
+   // own predecessor along a line search, the base point's sets for the perturbed points of a gradient (1e-6 away: two sweeps, where
+   // the slot's own predecessor, a point of the previous iterate, takes four to six) — told by a signature of eight weighted sums over
+   // the lower triangle's rows (the triangle the kernel reads).  A bad choice costs sweeps, never the result: every orthogonal start
+   // with the same left-out states runs to the same stopping rule.  Every EIG_WARM_RUN-th decomposition of a chain starts cold again,
+   // so that rounding in the accumulated rotations cannot build up.
+   constexpr int EIG_WARM_RUN = 16;
+   struct Pick { int src = -1; unsigned long long mask = 0; double sig[8]; };
+   std::vector<Pick> pick(e->eigen_warm ? n_sets : 0);
+   if (e->eigen_warm) {
+      for (int i = 0; i < n_sets; i++) {
+         Pick &pk = pick[i];
+         const double *Qi = Q + (size_t)i * n * n, *pii = pi + (size_t)i * n;
+         for (size_t s = 0; s < n; s++)
+            if (pii[s] > 1e-100) pk.mask |= 1ull << s;
+         for (int k = 0; k < 8; k++) {
+            const size_t r = n - 1 - (size_t)k * (n / 9);
+            double acc = 0;
+            for (size_t j = 0; j < r; j++) acc += Qi[r * n + j] * (1.0 + 0.37 * (double)((j * 7 + k) % 5));
+            pk.sig[k] = acc;
+         }
+         double best = 0.25;      // (further than this: no better than a cold start)
+         for (size_t sidx = 0; sidx < e->eigen.size(); sidx++) {
+            const EigenHost &c = e->eigen[sidx];
+            if (c.kind != PAML_AMD_EIGEN_UVROOT || c.warm_run < 0 || c.warm_run >= EIG_WARM_RUN - 1 || c.live_mask != pk.mask || !c.Rt[c.rt_cur].p) continue;
+            double d = 0;
+            for (int k = 0; k < 8; k++) d = std::max(d, std::fabs(c.sig[k] - pk.sig[k]) / (std::fabs(c.sig[k]) + std::fabs(pk.sig[k]) + 1e-300));
+            if (d < best || (d == best && (int)sidx == set_ids[i])) { best = d; pk.src = (int)sidx; }
+         }
+      }
+   }
    for (int i = 0; i < n_sets; i++) {
       EigenHost *h = eigen_slot(e, set_ids[i]);
       HIPCHK(h->U.ensure(n * n));
@@ -325,23 +356,41 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
       HIPCHK(h->Root.ensure(n));
       ptr[i] = h->U.p; ptr[n_sets + i] = h->V.p; ptr[2 * (size_t)n_sets + i] = h->Root.p;
       if (e->eigen_warm) {
-         // start from the set's previous eigenvectors when it has some for the same set of states; every EIG_WARM_RUN-th
-         // decomposition starts cold again, so that rounding in the accumulated rotations cannot build up
-         constexpr int EIG_WARM_RUN = 16;
-         unsigned long long mask = 0;
-         for (size_t s = 0; s < n; s++)
-            if (pi[(size_t)i * n + s] > 1e-100) mask |= 1ull << s;
-         HIPCHK(h->Rt.ensure(64 * 64));
-         const bool warm = h->kind == PAML_AMD_EIGEN_UVROOT && h->warm_run >= 0 && h->warm_run < EIG_WARM_RUN - 1 && h->live_mask == mask;
-         ptr[3 * (size_t)n_sets + i] = warm ? h->Rt.p : nullptr;
-         ptr[4 * (size_t)n_sets + i] = h->Rt.p;
-         h->warm_run = warm ? h->warm_run + 1 : 0;
-         h->live_mask = mask;
-         e->n_eigen_warm += warm;
+         HIPCHK(h->Rt[0].ensure(64 * 64));
+         HIPCHK(h->Rt[1].ensure(64 * 64));
       }
-      else h->warm_run = -1;
-      h->kind = PAML_AMD_EIGEN_UVROOT;
    }
+   if (e->eigen_warm) {
+      // (the sources are read as they were BEFORE this batch — rt_cur and warm_run of a set that is itself in the batch change below)
+      std::vector<int> run(n_sets, 0);
+      for (int i = 0; i < n_sets; i++) {
+         const Pick &pk = pick[i];
+         if (pk.src >= 0) {
+            const EigenHost &c = e->eigen[pk.src];
+            ptr[3 * (size_t)n_sets + i] = c.Rt[c.rt_cur].p;
+            run[i] = c.warm_run + 1;
+            e->n_eigen_warm++;
+         }
+      }
+      for (int i = 0; i < n_sets; i++) {
+         EigenHost *h = &e->eigen[set_ids[i]];
+         ptr[4 * (size_t)n_sets + i] = h->Rt[h->rt_cur ^ 1].p;
+      }
+      for (int i = 0; i < n_sets; i++) {
+         EigenHost *h = &e->eigen[set_ids[i]];
+         h->rt_cur ^= 1;
+         h->warm_run = run[i];
+         h->live_mask = pick[i].mask;
+         memcpy(h->sig, pick[i].sig, sizeof(h->sig));
+         h->kind = PAML_AMD_EIGEN_UVROOT;
+      }
+   }
+   else
+      for (int i = 0; i < n_sets; i++) {
+         EigenHost *h = &e->eigen[set_ids[i]];
+         h->warm_run = -1;
+         h->kind = PAML_AMD_EIGEN_UVROOT;
+      }
    std::vector<double> ones;
    if (!scale) { ones.assign(n_sets, 1.0); scale = ones.data(); }
    HIPCHK(upload(e->d_eq_q, Q, (size_t)n_sets * n * n, e->stream));

@@ -106,10 +106,14 @@ struct EigenHost {
    double kappa = 0;
    DevBuf<double> U, V, Root, Cijk;
    // warm start of the device decomposition (paml_amd_set_eigen_warm_start): the last decomposition's eigenvectors R^T[64][64], how
-   // many decompositions in a row started from their predecessor's, and which states that one left out (pi = 0)
-   DevBuf<double> Rt;
+   // many decompositions in a row started from a predecessor's, and which states that one left out (pi = 0)
+   // Two buffers: a decomposition reads its start from buffers the batch does not write (Rt[rt_cur] of ANY set: the one whose last matrix
+   // is nearest, by the signature sig[] of a few weighted row sums) and leaves its own eigenvectors in Rt[rt_cur ^ 1].
+   DevBuf<double> Rt[2];
+   int rt_cur = 0;
    int warm_run = -1;
    unsigned long long live_mask = 0;
+   double sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // RCCL, bound at run time: libpaml_amd.so keeps loading on hosts without the collective library (single-GPU use needs none

@@ -212,6 +212,48 @@ def test_warm_started_decompositions_along_an_optimisers_path():
     assert eng.set_eigen_warm_start() == n_warm + 3 and (sw >= cold.min() - 2).all()
 
 
+def test_a_gradients_perturbed_points_start_from_the_base_points_sets():
+    """Round 6: a warm start comes from the NEAREST matrix any set was last decomposed for.  The base point's three omega classes are
+    decomposed into sets 1-3; the perturbed points of a gradient (kappa or one omega moved by 1e-6 relative) go to sets the engine has
+    never seen (4 ...) in one batch: each starts from the base point's set of the same class — two sweeps, the right answer — and the
+    next iterate's base point (5 % away) from the nearest of them all."""
+    rng = np.random.default_rng(9)
+    pb = synth.codon_m0_problem(n_tips=6, n_patt=300)
+    eng = engine_for(pb)
+    pi = random_f3x4(rng)
+    kappa, om = 2.0, np.array([0.1, 1.0, 2.5])
+
+    def mats(k, w):
+        return zip(*[models.codon_q(k, x, pi) for x in w])
+
+    def check(ids, Qs, mrs):
+        for sid, Q, mr in zip(ids, Qs, mrs):
+            U, V, R = eng.get_eigen(int(sid))
+            scale = np.abs(Q).max() / mr
+            assert np.max(np.abs(U @ np.diag(R) @ V - Q / mr)) <= 2e-13 * scale and np.max(np.abs(U @ V - np.eye(61))) <= 2e-13
+
+    eng.set_eigen_warm_start(1)
+    Qs, mrs = mats(kappa, om)
+    eng.set_eigen_qrev_batch(np.array([1, 2, 3]), np.array(Qs), np.array([pi] * 3), np.array(mrs))
+    cold = eng.eigen_counters()["sweeps"].copy()
+    assert cold.min() >= 6 and eng.set_eigen_warm_start() == 0
+    pert = [(kappa * (1 + 1e-6), om)] + [(kappa, om * (1 + 1e-6 * (np.arange(3) == j))) for j in range(3)]
+    allQ, allmr = [], []
+    for k, w in pert:
+        q, m = mats(k, w)
+        allQ += q; allmr += m
+    ids = np.arange(len(allQ)) + 4
+    eng.set_eigen_qrev_batch(ids, np.array(allQ), np.array([pi] * len(allQ)), np.array(allmr))
+    sw = eng.eigen_counters()["sweeps"]
+    assert eng.set_eigen_warm_start() == len(allQ) and sw.max() <= 3, sw      # (the unmoved classes: the same matrix again, 0 sweeps)
+    check(ids, allQ, allmr)
+    Qn, mrn = mats(kappa * 1.05, om * 0.95)
+    eng.set_eigen_qrev_batch(np.array([1, 2, 3]), np.array(Qn), np.array([pi] * 3), np.array(mrn))
+    sw = eng.eigen_counters()["sweeps"]
+    assert sw.max() < cold.min() and eng.set_eigen_warm_start() == len(allQ) + 3, (sw, cold)
+    check([1, 2, 3], Qn, mrn)
+
+
 NOCONV_SCRIPT = r"""
 import json, os, sys
 import torch  # noqa: F401
