@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "pamlh_internal.h"
 
@@ -33,8 +34,21 @@ int pamlh_eval_batch_gpu(pamlh *p, int nb, const double *xs, double *lnL) { retu
 /* ... with the per-pattern log f_h of every vector, lnf[nb][npatt], when lnf is not NULL.
  * The model set-ups of the distinct substitution-parameter vectors (eigen decompositions: the host's expensive part, one per
  * site class) are independent of each other and run on all host cores, each on its own copy of the model state. */
+/* PAMLH_TIMING=1: where a search's wall time goes, by phase of the batched evaluation, printed when the process ends. */
+static double tm_acc[5];
+static long tm_n;
+static int tm_on = -1;
+static double tm_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static void tm_report(void)
+{
+   fprintf(stderr, "pamlh timing: %ld batched evaluations; model set-ups %.1f ms, collecting eigen systems %.1f, eigen call %.1f, tables %.1f, "
+           "set_classes + set_pi + eval_batch (P(t), pruning, the wait) %.1f\n", tm_n, tm_acc[0] * 1e3, tm_acc[1] * 1e3, tm_acc[2] * 1e3, tm_acc[3] * 1e3, tm_acc[4] * 1e3);
+}
+#define TM(k) do { if (tm_on > 0) { const double t_ = tm_now(); tm_acc[k] += t_ - tm_t; tm_t = t_; } } while (0)
+
 static int eval_batch_lnf_once(pamlh *p, int nb, const double *xs, double *lnL, double *lnf)
 {
+   double tm_t = 0;
    const int np = p->np, nt = p->ntime, nm = np - nt, nn = p->nnode;
    int *cand_of = (int *)malloc(nb * sizeof(int)), *cand_elem = (int *)malloc(nb * sizeof(int)), *cand_rep = (int *)malloc(nb * sizeof(int));
    int ncand = 0, nrep = 0, b, c, i, rc = 0, K = 0, L = 1, n_eigen = 0, mode = 0, n_pi = 1, RK = 0;
@@ -47,6 +61,8 @@ static int eval_batch_lnf_once(pamlh *p, int nb, const double *xs, double *lnL, 
    pamlh_eig_batch ebatch;
    memset(&ebatch, 0, sizeof(ebatch));
    if ((rc = pamlh_engine_ready(p))) goto done;
+   if (tm_on < 0) { tm_on = getenv("PAMLH_TIMING") != NULL; if (tm_on) atexit(tm_report); }
+   if (tm_on > 0) { tm_t = tm_now(); tm_n++; }
    if (!p->fix_rho || p->rho0 != 0) {      /* lfunAdG ends in a sequential chain over the sites on the host: one evaluation at a time */
       for (b = 0; b < nb; b++) {
          if (pamlh_set_x(p, xs + (size_t)b * np, np) || !pamlh_model_feasible(p)) { lnL[b] = -1e300; continue; }
@@ -68,6 +84,7 @@ static int eval_batch_lnf_once(pamlh *p, int nb, const double *xs, double *lnL, 
       if (q && (pamlh_set_x(q, xs + (size_t)cand_elem[c] * np, np) || !pamlh_model_feasible(q))) { pamlh_state_free(q); q = NULL; }
       ws[c] = q;
    }
+   TM(0);
    for (c = 0; c < ncand; c++) {       /* accepted set-ups become the batch's eigen sets and class tables, in order */
       pamlh *q = ws[c];
       cand_rep[c] = -1;
@@ -92,7 +109,9 @@ static int eval_batch_lnf_once(pamlh *p, int nb, const double *xs, double *lnL, 
       cand_rep[c] = nrep++;
    }
    if (!nrep) { for (b = 0; b < nb; b++) lnL[b] = -1e300; goto done; }
+   TM(1);
    if ((rc = pamlh_eig_batch_flush(p, p->eng, &ebatch))) goto done;
+   TM(2);
    fk = (double *)malloc((size_t)nb * K * sizeof(double));
    rt = (double *)malloc((size_t)nb * RK * sizeof(double));
    eo = (int *)malloc((size_t)nb * K * L * sizeof(int));
@@ -112,6 +131,7 @@ static int eval_batch_lnf_once(pamlh *p, int nb, const double *xs, double *lnL, 
       }
       if (gr) { gr[(size_t)b * G] = 1; for (i = 1; i < G; i++) gr[(size_t)b * G + i] = x[nt + i - 1]; }
    }
+   TM(3);
    /* (with several genes the tables are [gene][class]: one label, and L counts the genes) */
    if ((rc = paml_amd_set_classes(p->eng, mode, K, rep_fk, rep_rt, G > 1 ? 1 : L, rep_eo, use_qf ? rep_qf : NULL)) ||
        (p->malpha && (rc = paml_amd_set_gene_class_rates(p->eng, rep_rt)))) { rc = pamlh_fail(p, "%s", paml_amd_last_error(p->eng)); goto done; }
@@ -167,6 +187,7 @@ static int eval_batch_lnf_once(pamlh *p, int nb, const double *xs, double *lnL, 
          free(sbr); free(sfk); free(srt); free(sqf); free(sgr); free(sl); free(slf); free(seo); free(idx);
       }
       free(grp); free(gpi);
+      TM(4);
       if (rc) goto done;
    }
    for (b = 0; b < nb; b++)
