@@ -488,13 +488,15 @@ def test_eval_batch_per_element_eigen_sets():
         assert abs(got[b] - ref) <= 1e-10 * abs(ref), (b, got[b], ref)
 
 
-def test_large_tree_kernel_is_compiled_in_the_background(monkeypatch):
+def test_large_tree_kernel_is_compiled_in_the_background(monkeypatch, tmp_path):
     """A 150-tip tree's kernel takes ten seconds to compile.  When the specialised kernels are switched on by the problem's size (not
     forced), the compile runs on a worker thread: the first evaluations come from the interpreter kernel, later ones from the
-    per-tree kernel, and both agree with the oracle."""
+    per-tree kernel, and both agree with the oracle.  (A code-object cache of its own: on a box that has run the suite before, the
+    user's cache would hand the finished kernel to the first evaluation.)"""
     import time
     from paml_amd.engine import Engine
     monkeypatch.delenv("PAML_AMD_JIT", raising=False)
+    monkeypatch.setenv("PAML_AMD_JIT_CACHE", str(tmp_path))
     pb = helpers.random_problem(61, 150, 1100, K=1, seed=91)
     eng = Engine(pb.n, pb.tree.n_tips, pb.n_patt, max_classes=64).load(pb)      # 1100 x 64 >= 65536: on by size
     ref = oracle.evaluate(pb)["lnL"]
