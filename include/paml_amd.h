@@ -153,6 +153,14 @@ int paml_amd_set_pi(paml_amd_engine *e, int n_pi, const double *pi);
  * returns PAML_AMD_ENOCONV instead of a likelihood formed from unconverged eigenvectors; the C host (pamlh_*.c) and the reference-side
  * binding (integration/codeml_plfun.patch) then decompose on the host and evaluate again. */
 int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, const double *Q, const double *pi, const double *scale);
+/* The same with the matrices handed over as the elements they can have: nnz positions (row[k] >= col[k]: the lower triangle and the
+ * diagonal — what eigenQREV reads, tools.c:5048-5060 — each position once), shared by the batch, and vals[n_sets][nnz]; every other
+ * element is zero.  A codon matrix has 263 elements below its diagonal (single-nucleotide changes between sense codons, universal
+ * code) + 61 on it of 3 721: 2.6 KB instead of 30 KB per matrix cross from pageable host memory, which is what a batch call's host time
+ * is (tools/eigen_call_cost.py).  Same decomposition; the stopping threshold's norm is summed in another order, so the last bits may
+ * differ from the dense call's. */
+int paml_amd_set_eigen_qrev_batch_sparse(paml_amd_engine *e, int n_sets, const int *set_ids, int nnz, const int *row, const int *col,
+                                         const double *vals, const double *pi, const double *scale);
 /* Warm start for the above (on = 1; 0 = off, the default; -1 = leave as is; *n_warm, if not NULL, receives the number of
  * decompositions that started warm so far): a decomposition starts its Jacobi sweeps from the eigenvectors of the NEAREST matrix any set
  * of the engine was last decomposed for (told by a signature of eight weighted row sums; round 6 — until then: the set's own previous

@@ -26,7 +26,10 @@ namespace paml_amd {
 
 struct EigenQrevArgs {
    int n;
-   const double *Q;          // [n_sets][n * n] rate matrices (row-major; only the lower triangle is read, as eigenQREV does)
+   const double *Q;          // [n_sets][n * n] rate matrices (row-major; only the lower triangle is read, as eigenQREV does) — or, nnz > 0,
+                             // [n_sets][nnz] the elements at (rc[2k], rc[2k + 1]), row >= column, everything else zero
+   int nnz;
+   const int *rc;
    const double *pi;         // [n_sets][n]
    const double *scale;      // [n_sets]: Root = w / scale (the mean rate eigenQcodon divides by)
    double *const *U;         // [n_sets] device pointers of the eigen sets' buffers
@@ -137,6 +140,23 @@ __global__ __launch_bounds__(EIG_NT) void eigen_qrev_kernel(EigenQrevArgs a)
    if (tid < 64) sSp[tid] = (tid < n && pi[tid] > 1e-100) ? sqrt(pi[tid]) : 0.0;      // 0: the state is left out
    __syncthreads();
    double nrm = 0;
+   if (a.nnz > 0) {      // the sparse hand-over: zeros, then the elements (each lower-triangle element also to its mirror image)
+      for (int idx = tid; idx < 64 * 64; idx += NTH) {
+         const int i = idx >> 6, j = idx & 63;
+         sA[i * EIG_LD + j] = 0.0;
+         sV[i * EIG_LD + j] = i == j ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      const double *vals = a.Q + (size_t)set * a.nnz;
+      for (int k = tid; k < a.nnz; k += NTH) {
+         const int r = a.rc[2 * k], c = a.rc[2 * k + 1];
+         const double v = (sSp[r] > 0 && sSp[c] > 0) ? vals[k] * sSp[r] / sSp[c] : 0.0;
+         sA[r * EIG_LD + c] = v;
+         sA[c * EIG_LD + r] = v;
+         nrm += r == c ? v * v : 2 * v * v;
+      }
+   }
+   else
    for (int idx = tid; idx < 64 * 64; idx += NTH) {
       const int i = idx >> 6, j = idx & 63;
       double v = 0;

@@ -304,11 +304,17 @@ int paml_amd_set_eigen_uvroot(paml_amd_engine *e, int set_id, const double *U, c
    return 0;
 }
 
-int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, const double *Q, const double *pi, const double *scale)
+// Q dense ([n_sets][n * n]) or, nnz > 0, as the elements (row[k] >= col[k]: lower triangle and diagonal) every matrix of the batch may have:
+// vals[n_sets][nnz] — a codon matrix has 263 + 61 of 3 721, and the 30 KB per matrix from pageable memory were what a batch call's host time
+// went to (tools/eigen_call_cost.py)
+static int eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, const double *Q, int nnz, const int *row, const int *col, const double *vals,
+                            const double *pi, const double *scale)
 {
    enter(e);
-   if (!e || n_sets < 1 || !set_ids || !Q || !pi) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: bad arguments");
+   if (!e || n_sets < 1 || !set_ids || !pi || (nnz > 0 ? !row || !col || !vals : !Q)) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: bad arguments");
    const size_t n = e->n;
+   for (int k = 0; k < nnz; k++)
+      if (row[k] < col[k] || col[k] < 0 || row[k] >= (int)n) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch_sparse: an element outside the lower triangle");
    int max_id = -1;
    for (int i = 0; i < n_sets; i++) {
       if (set_ids[i] < 0 || set_ids[i] > 4096) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: set id out of range");
@@ -327,25 +333,45 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
    constexpr int EIG_WARM_RUN = 16;
    struct Pick { int src = -1; unsigned long long mask = 0; double sig[8]; };
    std::vector<Pick> pick(e->eigen_warm ? n_sets : 0);
+   struct Cand { int idx; unsigned long long mask; double sig[8]; };
+   std::vector<Cand> cands;      // the sets a start can come from, side by side (the search below is n_sets x their number)
    if (e->eigen_warm) {
+      for (size_t sidx = 0; sidx < e->eigen.size(); sidx++) {
+         const EigenHost &c = e->eigen[sidx];
+         if (c.kind != PAML_AMD_EIGEN_UVROOT || c.warm_run < 0 || c.warm_run >= EIG_WARM_RUN - 1 || !c.Rt[c.rt_cur].p) continue;
+         Cand cd;
+         cd.idx = (int)sidx; cd.mask = c.live_mask;
+         memcpy(cd.sig, c.sig, sizeof(cd.sig));
+         cands.push_back(cd);
+      }
       for (int i = 0; i < n_sets; i++) {
          Pick &pk = pick[i];
-         const double *Qi = Q + (size_t)i * n * n, *pii = pi + (size_t)i * n;
+         const double *pii = pi + (size_t)i * n;
          for (size_t s = 0; s < n; s++)
             if (pii[s] > 1e-100) pk.mask |= 1ull << s;
-         for (int k = 0; k < 8; k++) {
-            const size_t r = n - 1 - (size_t)k * (n / 9);
-            double acc = 0;
-            for (size_t j = 0; j < r; j++) acc += Qi[r * n + j] * (1.0 + 0.37 * (double)((j * 7 + k) % 5));
-            pk.sig[k] = acc;
+         if (nnz > 0) {      // (the same sums over the elements handed over: row r's elements left of the diagonal)
+            const double *vi = vals + (size_t)i * nnz;
+            for (int k = 0; k < 8; k++) pk.sig[k] = 0;
+            for (int x = 0; x < nnz; x++)
+               if (row[x] != col[x])
+                  for (int k = 0; k < 8; k++)
+                     if ((size_t)row[x] == n - 1 - (size_t)k * (n / 9)) pk.sig[k] += vi[x] * (1.0 + 0.37 * (double)(((size_t)col[x] * 7 + k) % 5));
+         }
+         else {
+            const double *Qi = Q + (size_t)i * n * n;
+            for (int k = 0; k < 8; k++) {
+               const size_t r = n - 1 - (size_t)k * (n / 9);
+               double acc = 0;
+               for (size_t j = 0; j < r; j++) acc += Qi[r * n + j] * (1.0 + 0.37 * (double)((j * 7 + k) % 5));
+               pk.sig[k] = acc;
+            }
          }
          double best = 0.25;      // (further than this: no better than a cold start)
-         for (size_t sidx = 0; sidx < e->eigen.size(); sidx++) {
-            const EigenHost &c = e->eigen[sidx];
-            if (c.kind != PAML_AMD_EIGEN_UVROOT || c.warm_run < 0 || c.warm_run >= EIG_WARM_RUN - 1 || c.live_mask != pk.mask || !c.Rt[c.rt_cur].p) continue;
+         for (const Cand &c : cands) {
+            if (c.mask != pk.mask) continue;
             double d = 0;
-            for (int k = 0; k < 8; k++) d = std::max(d, std::fabs(c.sig[k] - pk.sig[k]) / (std::fabs(c.sig[k]) + std::fabs(pk.sig[k]) + 1e-300));
-            if (d < best || (d == best && (int)sidx == set_ids[i])) { best = d; pk.src = (int)sidx; }
+            for (int k = 0; k < 8 && d <= best; k++) d = std::max(d, std::fabs(c.sig[k] - pk.sig[k]) / (std::fabs(c.sig[k]) + std::fabs(pk.sig[k]) + 1e-300));
+            if (d < best || (d == best && c.idx == set_ids[i])) { best = d; pk.src = c.idx; }
          }
       }
    }
@@ -393,7 +419,13 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
       }
    std::vector<double> ones;
    if (!scale) { ones.assign(n_sets, 1.0); scale = ones.data(); }
-   HIPCHK(upload(e->d_eq_q, Q, (size_t)n_sets * n * n, e->stream));
+   if (nnz > 0) {
+      HIPCHK(upload(e->d_eq_q, vals, (size_t)n_sets * nnz, e->stream));
+      std::vector<int> rc2((size_t)2 * nnz);
+      for (int k = 0; k < nnz; k++) { rc2[2 * k] = row[k]; rc2[2 * k + 1] = col[k]; }
+      HIPCHK(upload(e->d_eq_rc, rc2.data(), rc2.size(), e->stream));
+   }
+   else HIPCHK(upload(e->d_eq_q, Q, (size_t)n_sets * n * n, e->stream));
    HIPCHK(upload(e->d_eq_pi, pi, (size_t)n_sets * n, e->stream));
    HIPCHK(upload(e->d_eq_scale, scale, (size_t)n_sets, e->stream));
    HIPCHK(upload(e->d_eq_ptr, ptr.data(), ptr.size(), e->stream));
@@ -409,6 +441,7 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
    }
    EigenQrevArgs a{};
    a.n = (int)n; a.Q = e->d_eq_q.p; a.pi = e->d_eq_pi.p; a.scale = e->d_eq_scale.p;
+   a.nnz = nnz; a.rc = nnz > 0 ? e->d_eq_rc.p : nullptr;
    a.U = e->d_eq_ptr.p; a.V = e->d_eq_ptr.p + n_sets; a.Root = e->d_eq_ptr.p + 2 * (size_t)n_sets; a.sweeps = e->d_eq_sweeps.p; a.fail = e->h_eig_fail;
    static const int sweep_limit = getenv("PAML_AMD_EIGEN_SWEEP_LIMIT") ? std::max(1, atoi(getenv("PAML_AMD_EIGEN_SWEEP_LIMIT"))) : 40;
    a.max_sweeps = sweep_limit;
@@ -425,6 +458,18 @@ int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set
    e->n_eigen_device += n_sets;
    e->eq_last_batch = n_sets;
    return 0;
+}
+
+int paml_amd_set_eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, const double *Q, const double *pi, const double *scale)
+{
+   return eigen_qrev_batch(e, n_sets, set_ids, Q, 0, nullptr, nullptr, nullptr, pi, scale);
+}
+
+int paml_amd_set_eigen_qrev_batch_sparse(paml_amd_engine *e, int n_sets, const int *set_ids, int nnz, const int *row, const int *col, const double *vals,
+                                         const double *pi, const double *scale)
+{
+   if (nnz < 1) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch_sparse: no elements");
+   return eigen_qrev_batch(e, n_sets, set_ids, nullptr, nnz, row, col, vals, pi, scale);
 }
 
 int paml_amd_set_eigen_warm_start(paml_amd_engine *e, int on, long *n_warm)

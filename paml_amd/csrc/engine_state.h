@@ -467,6 +467,7 @@ struct paml_amd_engine {
    // batched decomposition on the device (paml_amd_set_eigen_qrev_batch): inputs and the table of the sets' buffer pointers
    DevBuf<double> d_eq_q, d_eq_pi, d_eq_scale;
    DevBuf<double *> d_eq_ptr;
+   DevBuf<int> d_eq_rc;      // (row, col) of the elements of a sparse hand-over
    DevBuf<int> d_eq_sweeps;
    int *h_eig_fail = nullptr;      // pinned, device-visible: a decomposition that hit its sweep limit sets it (eigen_fail_check)
    bool eigen_attr_set = false;
@@ -552,7 +553,7 @@ struct paml_amd_engine {
       d_stream.release();
       d_eigen.release();
       d_pres.release();
-      d_eq_q.release(); d_eq_pi.release(); d_eq_scale.release(); d_eq_ptr.release(); d_eq_sweeps.release();
+      d_eq_q.release(); d_eq_pi.release(); d_eq_scale.release(); d_eq_ptr.release(); d_eq_rc.release(); d_eq_sweeps.release();
       d_pi_plain.release();
       DevBuf<double> *b3[] = {&d_weights, &d_pi, &d_freqK, &d_rate, &d_qfactor, &d_branch, &d_gene_rate, &d_rowmajor,
                               &d_pint, &d_ptip, &d_pcol, &d_fhK, &d_fscale, &d_lnf, &d_b_qfactor, &d_b_freqK, &d_b_rate, &d_beb_f, &d_beb_part, &d_beb_g, &d_beb_out, &d_beb_pcl, &d_adg_all, &d_partial, &d_out, &d_partials, &d_scalef, &d_stack, &d2_branch, &d2_gene_rate, &d_partial_tot, &d_btot,

@@ -25,7 +25,7 @@ SHARD = 4      # the engine holds one rank's shard of a larger alignment (includ
 EXPORTS = [
     "paml_amd_set_gene_class_rates", "paml_amd_get_branch_partials", "paml_amd_create", "paml_amd_destroy", "paml_amd_last_error", "paml_amd_set_stream", "paml_amd_set_tips",
     "paml_amd_set_tree", "paml_amd_set_pi", "paml_amd_set_eigen_uvroot", "paml_amd_set_eigen_cijk",
-    "paml_amd_set_eigen_qrev_batch", "paml_amd_set_eigen_warm_start", "paml_amd_get_eigen", "paml_amd_eigen_counters", "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
+    "paml_amd_set_eigen_qrev_batch", "paml_amd_set_eigen_qrev_batch_sparse", "paml_amd_set_eigen_warm_start", "paml_amd_get_eigen", "paml_amd_eigen_counters", "paml_amd_set_eigen_k80", "paml_amd_set_eigen_jc69like", "paml_amd_set_eigen_qmat", "paml_amd_set_classes", "paml_amd_eval",
     "paml_amd_eval_batch", "paml_amd_eval_adg", "paml_amd_beb_grid", "paml_amd_beb_grid_classes", "paml_amd_compress_patterns", "paml_amd_eval_device", "paml_amd_eval_dirty", "paml_amd_eval_branch", "paml_amd_node_posterior", "paml_amd_get_pmat", "paml_amd_get_partials", "paml_amd_get_scale",
     "paml_amd_device_count", "paml_amd_set_device", "paml_amd_shard_bounds", "paml_amd_max_ranks", "paml_amd_flush", "paml_amd_eigen_status", "paml_amd_comm_unique_id", "paml_amd_comm_init", "paml_amd_comm_destroy", "paml_amd_comm_info", "paml_amd_comm_library", "paml_amd_comm_stats", "paml_amd_get_partial_sums", "paml_amd_branch_counters", "paml_amd_branch_coef_hits", "paml_amd_branch_refill_kernels", "paml_amd_branch_kernel_ms",
     "paml_amd_jit_prebuild", "paml_amd_profile", "paml_amd_profile_read", "paml_amd_counters", "paml_amd_kernel_name", "paml_amd_debug_program", "paml_amd_debug_jit",
@@ -98,6 +98,7 @@ def lib():
         L.paml_amd_set_eigen_uvroot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.paml_amd_set_eigen_cijk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.paml_amd_set_eigen_qrev_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.paml_amd_set_eigen_qrev_batch_sparse.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.paml_amd_get_eigen.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.paml_amd_eigen_counters.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.c_int]
         L.paml_amd_set_eigen_k80.argtypes = [C.c_void_p, C.c_int, C.c_double]
@@ -350,6 +351,15 @@ class Engine:
         pi = np.ascontiguousarray(pi, dtype=np.float64).reshape(len(ids), self.n)
         sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64).reshape(len(ids))
         self._chk(self._L.paml_amd_set_eigen_qrev_batch(self._h, len(ids), _p(ids), _p(Q), _p(pi), _p(sc)))
+
+    def set_eigen_qrev_batch_sparse(self, set_ids, row, col, vals, pi, scale=None):
+        """As set_eigen_qrev_batch, the matrices given by their elements at (row[k] >= col[k]), vals[set][k]; everything else zero."""
+        ids = np.ascontiguousarray(set_ids, dtype=np.int32)
+        row = np.ascontiguousarray(row, dtype=np.int32); col = np.ascontiguousarray(col, dtype=np.int32)
+        vals = np.ascontiguousarray(vals, dtype=np.float64).reshape(len(ids), len(row))
+        pi = np.ascontiguousarray(pi, dtype=np.float64).reshape(len(ids), self.n)
+        sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64).reshape(len(ids))
+        self._chk(self._L.paml_amd_set_eigen_qrev_batch_sparse(self._h, len(ids), _p(ids), len(row), _p(row), _p(col), _p(vals), _p(pi), _p(sc)))
 
     def get_eigen(self, set_id):
         U, V, R = np.empty((self.n, self.n)), np.empty((self.n, self.n)), np.empty(self.n)

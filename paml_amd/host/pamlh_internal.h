@@ -29,6 +29,9 @@ typedef struct {
    int n, cnt, cap;
    int *ids;
    double *Q, *pi, *scale;
+   /* codon matrices travel as the elements they can have (paml_amd_set_eigen_qrev_batch_sparse): Q then holds [cnt][nnz] values */
+   int nnz;
+   const int *row, *col;
 } pamlh_eig_batch;
 
 struct pamlh {

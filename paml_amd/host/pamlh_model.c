@@ -920,20 +920,67 @@ static void set_eig_uvroot(pamlh *p, int i, const double *Q, const double *pi, d
 /* The eigen systems of the model state go to the engine as sets base, base + 1, ...: reversible rate matrices still waiting for
  * their decomposition are collected — into `batch` when the caller gathers several model states for one device call
  * (pamlh_eig_batch_flush), else into a batch of their own — everything else is sent as it is. */
-static void eig_batch_add(pamlh_eig_batch *b, int id, const pamlh_eig *e, int n)
+/* The elements a codon rate matrix can have, at and below its diagonal: pairs of sense codons one nucleotide apart (codon_q_cls fills
+ * nothing else: 263 of them under the universal code) and the diagonal.  One table per genetic code and process; PAMLH_DENSE_Q=1: the
+ * matrices travel whole, as they did before round 6; PAMLH_CHECK_SPARSE=1: every matrix is looked through for anything outside. */
+static int codon_pattern(const pamlh *p, const int **row, const int **col)
 {
-   if (b->cnt == b->cap) {
-      b->cap = b->cap ? 2 * b->cap : 64;
-      b->ids = (int *)realloc(b->ids, b->cap * sizeof(int));
-      b->Q = (double *)realloc(b->Q, (size_t)b->cap * n * n * 8);
-      b->pi = (double *)realloc(b->pi, (size_t)b->cap * n * 8);
-      b->scale = (double *)realloc(b->scale, b->cap * 8);
+   static char have[65];
+   static int nnz, r[64 * 10 + 64], c[64 * 10 + 64];
+   static int dense = -1;
+   if (dense < 0) dense = getenv("PAMLH_DENSE_Q") != NULL;
+   if (dense || p->seqtype != 1 || p->n < 21) return 0;
+#pragma omp critical(pamlh_codon_pattern)
+   if (memcmp(have, p->code, 64)) {
+      int from61[64], i, j, k, m = 0;
+      for (k = 0; k < 64; k++) if (p->code[k] != '*') from61[m++] = k;
+      nnz = 0;
+      if (m == p->n)
+         for (i = 0; i < m; i++)
+            for (j = 0; j <= i; j++) {
+               const int c1 = from61[i], c2 = from61[j];
+               const int nd = (c1 / 16 != c2 / 16) + ((c1 / 4) % 4 != (c2 / 4) % 4) + (c1 % 4 != c2 % 4);
+               if (nd <= 1) { r[nnz] = i; c[nnz++] = j; }
+            }
+      memcpy(have, p->code, 64);
    }
-   b->n = n;
-   b->ids[b->cnt] = id;
-   memcpy(b->Q + (size_t)b->cnt * n * n, e->Q, (size_t)n * n * 8);
-   memcpy(b->pi + (size_t)b->cnt * n, e->qpi, n * 8);
-   b->scale[b->cnt++] = e->scale;
+   *row = r; *col = c;
+   return nnz;
+}
+
+static void eig_batch_add(const pamlh *p, pamlh_eig_batch *b, int id, const pamlh_eig *e, int n)
+{
+   if (!b->cnt) b->nnz = codon_pattern(p, &b->row, &b->col);
+   {
+      const size_t per = b->nnz ? (size_t)b->nnz : (size_t)n * n;
+      if (b->cnt == b->cap) {
+         b->cap = b->cap ? 2 * b->cap : 64;
+         b->ids = (int *)realloc(b->ids, b->cap * sizeof(int));
+         b->Q = (double *)realloc(b->Q, (size_t)b->cap * per * 8);
+         b->pi = (double *)realloc(b->pi, (size_t)b->cap * n * 8);
+         b->scale = (double *)realloc(b->scale, b->cap * 8);
+      }
+      b->n = n;
+      b->ids[b->cnt] = id;
+      if (b->nnz) {
+         double *v = b->Q + (size_t)b->cnt * per;
+         int k;
+         for (k = 0; k < b->nnz; k++) v[k] = e->Q[b->row[k] * n + b->col[k]];
+         static int check = -1;
+         if (check < 0) check = getenv("PAMLH_CHECK_SPARSE") != NULL;
+         if (check) {
+            int i, j, at = 0;
+            for (i = 0; i < n; i++)
+               for (j = 0; j <= i; j++) {
+                  if (at < b->nnz && b->row[at] == i && b->col[at] == j) { at++; continue; }
+                  if (e->Q[i * n + j] != 0) { fprintf(stderr, "pamlh: a codon matrix has an element at (%d, %d) the pattern does not\n", i, j); abort(); }
+               }
+         }
+      }
+      else memcpy(b->Q + (size_t)b->cnt * per, e->Q, per * 8);
+      memcpy(b->pi + (size_t)b->cnt * n, e->qpi, n * 8);
+      b->scale[b->cnt++] = e->scale;
+   }
 }
 
 /* Where a batch of rate matrices is decomposed: on the device from PAMLH_DEVICE_EIGEN_MIN matrices on.  Round 3 left batches of fewer
@@ -953,6 +1000,18 @@ static int device_eigen_min(void)
 int pamlh_eig_batch_flush(pamlh *p, paml_amd_engine *eng, pamlh_eig_batch *b)
 {
    int rc = 0;
+   if (b->cnt && b->nnz && b->cnt < device_eigen_min()) {      /* (the host's solver wants whole matrices) */
+      const int n = b->n, m = b->cnt;
+      double *full = (double *)calloc((size_t)m * n * n, 8);
+      int i, k;
+      for (i = 0; i < m; i++)
+         for (k = 0; k < b->nnz; k++) {
+            const double v = b->Q[(size_t)i * b->nnz + k];
+            full[((size_t)i * n + b->row[k]) * n + b->col[k]] = v;
+            full[((size_t)i * n + b->col[k]) * n + b->row[k]] = v;      /* (only the lower triangle is read) */
+         }
+      free(b->Q); b->Q = full; b->nnz = 0;
+   }
    if (b->cnt && b->cnt < device_eigen_min()) {
       const int n = b->n, m = b->cnt;
       double *uvr = (double *)malloc((size_t)m * (2 * n * n + n) * sizeof(double));
@@ -972,7 +1031,8 @@ int pamlh_eig_batch_flush(pamlh *p, paml_amd_engine *eng, pamlh_eig_batch *b)
       free(uvr);
       if (rc) pamlh_fail(p, "%s", paml_amd_last_error(eng));
    }
-   else if (b->cnt && (rc = paml_amd_set_eigen_qrev_batch(eng, b->cnt, b->ids, b->Q, b->pi, b->scale))) pamlh_fail(p, "%s", paml_amd_last_error(eng));
+   else if (b->cnt && (rc = b->nnz ? paml_amd_set_eigen_qrev_batch_sparse(eng, b->cnt, b->ids, b->nnz, b->row, b->col, b->Q, b->pi, b->scale)
+                                    : paml_amd_set_eigen_qrev_batch(eng, b->cnt, b->ids, b->Q, b->pi, b->scale))) pamlh_fail(p, "%s", paml_amd_last_error(eng));
    free(b->ids); free(b->Q); free(b->pi); free(b->scale);
    memset(b, 0, sizeof(*b));
    return rc;
@@ -985,7 +1045,7 @@ int pamlh_upload_eigen_sets(pamlh *p, paml_amd_engine *eng, int base, pamlh_eig_
    memset(&own, 0, sizeof(own));
    for (i = 0; i < p->n_eigen && !rc; i++) {
       pamlh_eig *e = &p->eig[i];
-      if (e->kind == PAML_AMD_EIGEN_UVROOT && e->lazy && e->Q) eig_batch_add(batch ? batch : &own, base + i, e, p->n);
+      if (e->kind == PAML_AMD_EIGEN_UVROOT && e->lazy && e->Q) eig_batch_add(p, batch ? batch : &own, base + i, e, p->n);
       else if (e->kind == PAML_AMD_EIGEN_UVROOT) rc = paml_amd_set_eigen_uvroot(eng, base + i, e->U, e->V, e->Root);
       else if (e->kind == PAML_AMD_EIGEN_CIJK) rc = paml_amd_set_eigen_cijk(eng, base + i, e->nR, e->Cijk, e->Root);
       else if (e->kind == PAML_AMD_EIGEN_K80) rc = paml_amd_set_eigen_k80(eng, base + i, e->kappa);

@@ -254,6 +254,37 @@ def test_a_gradients_perturbed_points_start_from_the_base_points_sets():
     check([1, 2, 3], Qn, mrn)
 
 
+def test_matrices_handed_over_as_their_elements():
+    """paml_amd_set_eigen_qrev_batch_sparse: codon matrices as the 263 + 61 elements a single nucleotide change can put at or below the
+    diagonal (what the C host sends: 2.6 KB per matrix instead of 30 KB) against the same matrices handed over whole: the same roots to
+    1e-13 of the scale, U diag(Root) V = Q and U V = I; a state of frequency zero; an element above the diagonal is refused."""
+    rng = np.random.default_rng(21)
+    pb = synth.codon_m0_problem(n_tips=6, n_patt=300)
+    eng = engine_for(pb)
+    pis = [random_f3x4(rng), random_f3x4(rng, zero=True), random_f3x4(rng)]
+    Qs, mrs = zip(*[models.codon_q(k, w, pi) for (k, w), pi in zip(((2.0, 0.4), (5.0, 0.01), (0.8, 3.0)), pis)])
+    may = np.zeros((61, 61), dtype=bool)
+    for Q in Qs:
+        may |= Q != 0
+    may |= may.T
+    row, col = np.nonzero(np.tril(may))
+    assert len(row) <= 263 + 61 and (row >= col).all()
+    vals = np.array([Q[row, col] for Q in Qs])
+    eng.set_eigen_qrev_batch(np.array([1, 2, 3]), np.array(Qs), np.array(pis), np.array(mrs))
+    dense = [eng.get_eigen(k) for k in (1, 2, 3)]
+    eng.set_eigen_qrev_batch_sparse(np.array([4, 5, 6]), row, col, vals, np.array(pis), np.array(mrs))
+    for k in range(3):
+        U, V, R = eng.get_eigen(4 + k)
+        live = pis[k] > 1e-100
+        Qz = Qs[k].copy()
+        Qz[~live, :] = 0; Qz[:, ~live] = 0
+        scale = np.abs(Qz).max() / mrs[k]
+        assert np.max(np.abs(R - dense[k][2])) <= 1e-13 * scale and np.all(np.diff(R) <= 0)
+        assert np.max(np.abs(U @ np.diag(R) @ V - Qz / mrs[k])) <= 2e-13 * scale and np.max(np.abs(U @ V - np.eye(61))) <= 2e-13
+    with pytest.raises(Exception, match="lower triangle"):
+        eng.set_eigen_qrev_batch_sparse(np.array([7]), col[:5], row[:5] + 1, vals[:1, :5], np.array(pis[:1]), np.array(mrs[:1]))
+
+
 NOCONV_SCRIPT = r"""
 import json, os, sys
 import torch  # noqa: F401
