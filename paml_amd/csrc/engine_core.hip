@@ -313,8 +313,13 @@ static int eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, 
    enter(e);
    if (!e || n_sets < 1 || !set_ids || !pi || (nnz > 0 ? !row || !col || !vals : !Q)) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: bad arguments");
    const size_t n = e->n;
-   for (int k = 0; k < nnz; k++)
-      if (row[k] < col[k] || col[k] < 0 || row[k] >= (int)n) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch_sparse: an element outside the lower triangle");
+   if (nnz > 0) {
+      std::vector<char> seen(n * n, 0);
+      for (int k = 0; k < nnz; k++) {
+         if (row[k] < col[k] || col[k] < 0 || row[k] >= (int)n) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch_sparse: an element outside the lower triangle");
+         if (seen[(size_t)row[k] * n + col[k]]++) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch_sparse: an element appears twice");
+      }
+   }
    int max_id = -1;
    for (int i = 0; i < n_sets; i++) {
       if (set_ids[i] < 0 || set_ids[i] > 4096) return fail(e, PAML_AMD_EINVAL, "set_eigen_qrev_batch: set id out of range");

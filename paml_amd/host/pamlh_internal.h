@@ -22,6 +22,10 @@ typedef struct {
     * and the scale Root is divided by; `lazy`: U, V, Root above have not been formed on the host (pamlh_eig_host does it on demand) */
    double *Q, *qpi, scale;
    int lazy;
+   /* a codon matrix's elements at the positions it can have (codon_pairs: what goes to paml_amd_set_eigen_qrev_batch_sparse), picked out
+    * by the thread that built Q, while it is in its cache */
+   double *qv;
+   int qv_n;
 } pamlh_eig;
 
 /* decompositions waiting for ONE device call: the eigen systems of all the candidates of a batched evaluation */

@@ -889,8 +889,9 @@ int pamlh_force_host_eigen(void)      /* returns 0 when the host was decomposing
 
 void pamlh_eig_release(pamlh_eig *e)
 {
-   free(e->U); free(e->V); free(e->Root); free(e->Cijk); free(e->Q); free(e->qpi);
-   e->U = e->V = e->Root = e->Cijk = e->Q = e->qpi = NULL;
+   free(e->U); free(e->V); free(e->Root); free(e->Cijk); free(e->Q); free(e->qpi); free(e->qv);
+   e->U = e->V = e->Root = e->Cijk = e->Q = e->qpi = e->qv = NULL;
+   e->qv_n = 0;
    e->lazy = 0;
 }
 
@@ -904,6 +905,7 @@ void pamlh_eig_host(pamlh_eig *e, int n)
    e->lazy = 0;
 }
 
+static int codon_pattern(const pamlh *p, const int **row, const int **col);
 static void set_eig_uvroot(pamlh *p, int i, const double *Q, const double *pi, double scale)
 {
    const int n = p->n;
@@ -914,38 +916,71 @@ static void set_eig_uvroot(pamlh *p, int i, const double *Q, const double *pi, d
    memcpy(e->qpi, pi, n * 8);
    e->scale = scale;
    e->lazy = 1;
+   {
+      const int *row, *col;
+      const int nnz = codon_pattern(p, &row, &col);
+      int k;
+      if (nnz && !e->qv) e->qv = (double *)malloc(704 * sizeof(double));
+      for (k = 0; k < nnz; k++) e->qv[k] = Q[row[k] * n + col[k]];
+      e->qv_n = nnz;
+   }
    if (n <= 5 || host_eigen_forced()) pamlh_eig_host(e, n);
 }
 
 /* The eigen systems of the model state go to the engine as sets base, base + 1, ...: reversible rate matrices still waiting for
  * their decomposition are collected — into `batch` when the caller gathers several model states for one device call
  * (pamlh_eig_batch_flush), else into a batch of their own — everything else is sent as it is. */
-/* The elements a codon rate matrix can have, at and below its diagonal: pairs of sense codons one nucleotide apart (codon_q_cls fills
- * nothing else: 263 of them under the universal code) and the diagonal.  One table per genetic code and process; PAMLH_DENSE_Q=1: the
- * matrices travel whole, as they did before round 6; PAMLH_CHECK_SPARSE=1: every matrix is looked through for anything outside. */
-static int codon_pattern(const pamlh *p, const int **row, const int **col)
+/* Per genetic code (a model's code never changes; several models of a process may differ in theirs): the pairs of sense codons one
+ * nucleotide apart, i > j — the only off-diagonal elements codon_q_cls fills: 263 under the universal code — and, for the hand-over of a
+ * rate matrix as its elements (paml_amd_set_eigen_qrev_batch_sparse), those positions and the diagonal in row-major order. */
+typedef struct {
+   int ready, npair, nnz;
+   int i[640], j[640], c1[640], c2[640], row[704], col[704];
+} codon_pairs_t;
+static const codon_pairs_t *codon_pairs(const pamlh *p)
 {
-   static char have[65];
-   static int nnz, r[64 * 10 + 64], c[64 * 10 + 64];
-   static int dense = -1;
-   if (dense < 0) dense = getenv("PAMLH_DENSE_Q") != NULL;
-   if (dense || p->seqtype != 1 || p->n < 21) return 0;
-#pragma omp critical(pamlh_codon_pattern)
-   if (memcmp(have, p->code, 64)) {
-      int from61[64], i, j, k, m = 0;
-      for (k = 0; k < 64; k++) if (p->code[k] != '*') from61[m++] = k;
-      nnz = 0;
-      if (m == p->n)
+   static codon_pairs_t tab[32];
+   static char codes[32][65];
+   int slot, k, i, j;
+   codon_pairs_t *t = NULL;
+#pragma omp critical(pamlh_codon_pairs)
+   {
+      for (slot = 0; slot < 32 && tab[slot].ready; slot++)
+         if (!memcmp(codes[slot], p->code, 64)) break;
+      if (slot == 32) slot = 31;      /* (more codes than there are: the last slot is made again) */
+      t = &tab[slot];
+      if (!t->ready || memcmp(codes[slot], p->code, 64)) {
+         int from61[64], m = 0;
+         for (k = 0; k < 64; k++) if (p->code[k] != '*') from61[m++] = k;
+         t->npair = t->nnz = 0;
          for (i = 0; i < m; i++)
             for (j = 0; j <= i; j++) {
                const int c1 = from61[i], c2 = from61[j];
                const int nd = (c1 / 16 != c2 / 16) + ((c1 / 4) % 4 != (c2 / 4) % 4) + (c1 % 4 != c2 % 4);
-               if (nd <= 1) { r[nnz] = i; c[nnz++] = j; }
+               if (nd == 1) { t->i[t->npair] = i; t->j[t->npair] = j; t->c1[t->npair] = c1; t->c2[t->npair++] = c2; }
+               if (nd <= 1) { t->row[t->nnz] = i; t->col[t->nnz++] = j; }
             }
-      memcpy(have, p->code, 64);
+         memcpy(codes[slot], p->code, 64);
+         t->ready = 1;
+      }
    }
-   *row = r; *col = c;
-   return nnz;
+   return t;
+}
+
+/* The elements a codon rate matrix can have, at and below its diagonal (above).  PAMLH_DENSE_Q=1: the matrices travel whole, as they
+ * did before round 6; PAMLH_CHECK_SPARSE=1: every matrix is looked through for anything outside. */
+static int codon_pattern(const pamlh *p, const int **row, const int **col)
+{
+   static int dense = -1;
+   const codon_pairs_t *cp;
+   int m = 0, k;
+   if (dense < 0) dense = getenv("PAMLH_DENSE_Q") != NULL;
+   if (dense || p->seqtype != 1 || p->n < 21) return 0;
+   for (k = 0; k < 64; k++) m += p->code[k] != '*';
+   if (m != p->n) return 0;
+   cp = codon_pairs(p);
+   *row = cp->row; *col = cp->col;
+   return cp->nnz;
 }
 
 static void eig_batch_add(const pamlh *p, pamlh_eig_batch *b, int id, const pamlh_eig *e, int n)
@@ -965,7 +1000,8 @@ static void eig_batch_add(const pamlh *p, pamlh_eig_batch *b, int id, const paml
       if (b->nnz) {
          double *v = b->Q + (size_t)b->cnt * per;
          int k;
-         for (k = 0; k < b->nnz; k++) v[k] = e->Q[b->row[k] * n + b->col[k]];
+         if (e->qv_n == b->nnz) memcpy(v, e->qv, (size_t)b->nnz * 8);
+         else for (k = 0; k < b->nnz; k++) v[k] = e->Q[b->row[k] * n + b->col[k]];
          static int check = -1;
          if (check < 0) check = getenv("PAMLH_CHECK_SPARSE") != NULL;
          if (check) {
@@ -1124,18 +1160,20 @@ static double codon_q(const pamlh *p, double kappa, double omega, double *Q) { r
  * omega = b exp(-a d) / b (1 - a d) (GetOmega codeml.c:3020) */
 static double codon_q_cls(const pamlh *p, const double *pi, double kappa, double omega, const double *wcls, double *Q)
 {
-   int from61[64], i, j, k, n = p->n, m = 0;
+   /* the pairs of sense codons one nucleotide apart (i > j): 263 of the 1 830 pairs under the universal code — from the genetic code's
+    * table, not found again for every matrix of every trial point */
+   const codon_pairs_t *cp = codon_pairs(p);
+   const int npair = cp->npair, *pi_ = cp->i, *pj_ = cp->j, *pc1 = cp->c1, *pc2 = cp->c2;
+   int i, j, k, n = p->n, x;
    double mr = 0;
-   for (k = 0; k < 64; k++) if (p->code[k] != '*') from61[m++] = k;
    memset(Q, 0, (size_t)n * n * sizeof(double));
-   for (i = 1; i < n; i++)
-      for (j = 0; j < i; j++) {
-         const int c1 = from61[i], c2 = from61[j];
+   for (x = 0; x < npair; x++) {
+         const int c1 = pc1[x], c2 = pc2[x];
          const int f[3] = {c1 / 16, (c1 / 4) % 4, c1 % 4}, t[3] = {c2 / 16, (c2 / 4) % 4, c2 % 4};
-         int nd = 0, pos = 0;
+         int pos = 0;
          double q = 1;
-         for (k = 0; k < 3; k++) if (f[k] != t[k]) { nd++; pos = k; }
-         if (nd != 1) continue;
+         i = pi_[x]; j = pj_[x];
+         for (k = 0; k < 3; k++) if (f[k] != t[k]) pos = k;
          if (f[pos] + t[pos] == 1 || f[pos] + t[pos] == 5) q = kappa;
          if (p->mg) {      /* divide by the frequencies of the two unchanged nucleotides: the rate depends on the target nucleotide only */
             const int b1 = (pos + 1) % 3, b2 = (pos + 2) % 3;
@@ -1767,7 +1805,7 @@ int pamlh_gene_subset(const pamlh *p, int g, pamlh **out)
    q->freqK = (double *)calloc(64, sizeof(double));
    q->rate = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    q->eigen_of = (int *)calloc(64 * PAMLH_MAXEIG, sizeof(int));
-   for (i = 0; i < PAMLH_MAXEIG; i++) { q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = q->eig[i].Q = q->eig[i].qpi = NULL; q->eig[i].lazy = 0; }
+   for (i = 0; i < PAMLH_MAXEIG; i++) { q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = q->eig[i].Q = q->eig[i].qpi = q->eig[i].qv = NULL; q->eig[i].lazy = q->eig[i].qv_n = 0; }
    /* frequencies of this gene alone, then the one-gene parameter count */
    if (q->seqtype == 1) freqs_codon(q); else freqs_base_aa(q);
    if (q->seqtype == 0 && q->model == T92) { q->pi_data[0] = q->pi_data[2] = (q->pi_data[0] + q->pi_data[2]) / 2; q->pi_data[1] = q->pi_data[3] = (q->pi_data[1] + q->pi_data[3]) / 2; }
@@ -1793,7 +1831,7 @@ pamlh *pamlh_state_clone(const pamlh *p)
    q->freqK = (double *)calloc(64, sizeof(double));
    q->rate = (double *)calloc(64 * PAMLH_MAXGENE, sizeof(double));
    q->eigen_of = (int *)calloc(64 * PAMLH_MAXEIG, sizeof(int));
-   for (i = 0; i < PAMLH_MAXEIG; i++) { q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = q->eig[i].Q = q->eig[i].qpi = NULL; q->eig[i].lazy = 0; }
+   for (i = 0; i < PAMLH_MAXEIG; i++) { q->eig[i].U = q->eig[i].V = q->eig[i].Root = q->eig[i].Cijk = q->eig[i].Q = q->eig[i].qpi = q->eig[i].qv = NULL; q->eig[i].lazy = q->eig[i].qv_n = 0; }
    return q;
 }
 

@@ -283,6 +283,8 @@ def test_matrices_handed_over_as_their_elements():
         assert np.max(np.abs(U @ np.diag(R) @ V - Qz / mrs[k])) <= 2e-13 * scale and np.max(np.abs(U @ V - np.eye(61))) <= 2e-13
     with pytest.raises(Exception, match="lower triangle"):
         eng.set_eigen_qrev_batch_sparse(np.array([7]), col[:5], row[:5] + 1, vals[:1, :5], np.array(pis[:1]), np.array(mrs[:1]))
+    with pytest.raises(Exception, match="appears twice"):
+        eng.set_eigen_qrev_batch_sparse(np.array([7]), np.array([3, 3]), np.array([1, 1]), vals[:1, :2], np.array(pis[:1]), np.array(mrs[:1]))
 
 
 NOCONV_SCRIPT = r"""
