@@ -424,16 +424,26 @@ static int eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, 
       }
    std::vector<double> ones;
    if (!scale) { ones.assign(n_sets, 1.0); scale = ones.data(); }
+   // one upload for what the kernel reads besides the matrices — frequencies, scales, the table of pointers — and, sparse hand-over, one
+   // for the values; the elements' positions only when they differ from the ones the device holds (an upload from pageable memory is
+   // ~8 us of the host's time each, and a search makes a few hundred of these calls)
+   const size_t npi = (size_t)n_sets * n, nsc = (size_t)n_sets, nptr = ptr.size();
+   std::vector<double> pack(npi + nsc + nptr);
+   memcpy(pack.data(), pi, npi * sizeof(double));
+   memcpy(pack.data() + npi, scale, nsc * sizeof(double));
+   static_assert(sizeof(double *) == sizeof(double), "the pointers ride in the same buffer");
+   memcpy(pack.data() + npi + nsc, ptr.data(), nptr * sizeof(double *));
+   HIPCHK(upload(e->d_eq_pi, pack.data(), pack.size(), e->stream));
    if (nnz > 0) {
       HIPCHK(upload(e->d_eq_q, vals, (size_t)n_sets * nnz, e->stream));
       std::vector<int> rc2((size_t)2 * nnz);
       for (int k = 0; k < nnz; k++) { rc2[2 * k] = row[k]; rc2[2 * k + 1] = col[k]; }
-      HIPCHK(upload(e->d_eq_rc, rc2.data(), rc2.size(), e->stream));
+      if (rc2 != e->h_eq_rc) {
+         HIPCHK(upload(e->d_eq_rc, rc2.data(), rc2.size(), e->stream));
+         e->h_eq_rc.swap(rc2);
+      }
    }
    else HIPCHK(upload(e->d_eq_q, Q, (size_t)n_sets * n * n, e->stream));
-   HIPCHK(upload(e->d_eq_pi, pi, (size_t)n_sets * n, e->stream));
-   HIPCHK(upload(e->d_eq_scale, scale, (size_t)n_sets, e->stream));
-   HIPCHK(upload(e->d_eq_ptr, ptr.data(), ptr.size(), e->stream));
    HIPCHK(e->d_eq_sweeps.ensure(n_sets));
    if (!e->h_eig_fail) {
       HIPCHK(hipHostMalloc((void **)&e->h_eig_fail, 64, hipHostMallocDefault));
@@ -445,12 +455,13 @@ static int eigen_qrev_batch(paml_amd_engine *e, int n_sets, const int *set_ids, 
       e->eigen_attr_set = true;
    }
    EigenQrevArgs a{};
-   a.n = (int)n; a.Q = e->d_eq_q.p; a.pi = e->d_eq_pi.p; a.scale = e->d_eq_scale.p;
+   double *const *dptr = (double *const *)(e->d_eq_pi.p + npi + nsc);
+   a.n = (int)n; a.Q = e->d_eq_q.p; a.pi = e->d_eq_pi.p; a.scale = e->d_eq_pi.p + npi;
    a.nnz = nnz; a.rc = nnz > 0 ? e->d_eq_rc.p : nullptr;
-   a.U = e->d_eq_ptr.p; a.V = e->d_eq_ptr.p + n_sets; a.Root = e->d_eq_ptr.p + 2 * (size_t)n_sets; a.sweeps = e->d_eq_sweeps.p; a.fail = e->h_eig_fail;
+   a.U = dptr; a.V = dptr + n_sets; a.Root = dptr + 2 * (size_t)n_sets; a.sweeps = e->d_eq_sweeps.p; a.fail = e->h_eig_fail;
    static const int sweep_limit = getenv("PAML_AMD_EIGEN_SWEEP_LIMIT") ? std::max(1, atoi(getenv("PAML_AMD_EIGEN_SWEEP_LIMIT"))) : 40;
    a.max_sweeps = sweep_limit;
-   if (e->eigen_warm) { a.R0 = e->d_eq_ptr.p + 3 * (size_t)n_sets; a.Rout = e->d_eq_ptr.p + 4 * (size_t)n_sets; }
+   if (e->eigen_warm) { a.R0 = dptr + 3 * (size_t)n_sets; a.Rout = dptr + 4 * (size_t)n_sets; }
    // (the orders with a register form: R^T in a ninth wave's registers; PAML_AMD_EIGEN_LDS=1: the any-order form for them too)
    static const bool lds_form = getenv("PAML_AMD_EIGEN_LDS") != nullptr;
    const int N_even = ((int)n + 1) & ~1;

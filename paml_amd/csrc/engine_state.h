@@ -468,6 +468,7 @@ struct paml_amd_engine {
    DevBuf<double> d_eq_q, d_eq_pi, d_eq_scale;
    DevBuf<double *> d_eq_ptr;
    DevBuf<int> d_eq_rc;      // (row, col) of the elements of a sparse hand-over
+   std::vector<int> h_eq_rc; // ... as the device holds them
    DevBuf<int> d_eq_sweeps;
    int *h_eig_fail = nullptr;      // pinned, device-visible: a decomposition that hit its sweep limit sets it (eigen_fail_check)
    bool eigen_attr_set = false;
