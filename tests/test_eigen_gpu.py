@@ -287,6 +287,47 @@ def test_matrices_handed_over_as_their_elements():
         eng.set_eigen_qrev_batch_sparse(np.array([7]), np.array([3, 3]), np.array([1, 1]), vals[:1, :2], np.array(pis[:1]), np.array(mrs[:1]))
 
 
+def test_warm_starts_from_other_sets_stay_right_through_a_random_schedule():
+    """The bookkeeping behind the nearest-matrix warm start (two eigenvector buffers per set, chains that restart cold, sets of states
+    left out): 40 batches of random size over 14 set ids, matrices drawn from a small family (so that near and far neighbours, exact
+    repeats and other zero patterns of pi all occur), dense and sparse calls mixed — every decomposition is checked."""
+    rng = np.random.default_rng(33)
+    pb = synth.codon_m0_problem(n_tips=6, n_patt=300)
+    eng = engine_for(pb)
+    pis = [random_f3x4(rng), random_f3x4(rng, zero=True)]
+    eng.set_eigen_warm_start(1)
+    may = np.zeros((61, 61), dtype=bool)
+    for pi in pis:
+        may |= models.codon_q(2.0, 0.5, pi)[0] != 0
+    may |= may.T
+    row, col = np.nonzero(np.tril(may))
+    n_cold = 0
+    for it in range(40):
+        ids = rng.choice(np.arange(1, 15), size=int(rng.integers(1, 13)), replace=False)
+        which = rng.integers(0, 2, size=len(ids)) * (it % 3 == 0)
+        kap = 2.0 * (1 + 0.05 * rng.integers(-2, 3, size=len(ids))) * (1 + 1e-6 * rng.integers(-1, 2, size=len(ids)))
+        om = 0.4 * (1 + 0.1 * rng.integers(-2, 3, size=len(ids)))
+        Qs, mrs = zip(*[models.codon_q(k, w, pis[p_]) for k, w, p_ in zip(kap, om, which)])
+        P = np.array([pis[p_] for p_ in which])
+        if it % 2:
+            eng.set_eigen_qrev_batch_sparse(ids, row, col, np.array([Q[row, col] for Q in Qs]), P, np.array(mrs))
+        else:
+            eng.set_eigen_qrev_batch(ids, np.array(Qs), P, np.array(mrs))
+        sw = eng.eigen_counters()["sweeps"]
+        assert sw.min() >= 0 and sw.max() <= 11, sw
+        n_cold += int((sw >= 7).sum())
+        for sid, Q, mr, p_ in zip(ids, Qs, mrs, which):
+            U, V, R = eng.get_eigen(int(sid))
+            live = pis[p_] > 1e-100
+            Qz = Q.copy()
+            Qz[~live, :] = 0; Qz[:, ~live] = 0
+            scale = np.abs(Qz).max() / mr
+            assert np.all(np.diff(R) <= 0) and abs(R[0]) <= 1e-13 * scale
+            assert np.max(np.abs(U @ np.diag(R) @ V - Qz / mr)) <= 3e-13 * scale, (it, sid)
+            assert np.max(np.abs(U @ V - np.eye(61))) <= 3e-13, (it, sid)
+    assert 0 < n_cold < 120 and eng.set_eigen_warm_start() > 150      # most started warm, some chains restarted cold
+
+
 NOCONV_SCRIPT = r"""
 import json, os, sys
 import torch  # noqa: F401
