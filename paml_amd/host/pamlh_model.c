@@ -936,6 +936,7 @@ static void set_eig_uvroot(pamlh *p, int i, const double *Q, const double *pi, d
 typedef struct {
    int ready, npair, nnz;
    int i[640], j[640], c1[640], c2[640], row[704], col[704];
+   int nbr_ptr[65], nbr[1280];      /* row by row, ascending: the columns a row has elements in (its neighbours one nucleotide away) */
 } codon_pairs_t;
 static const codon_pairs_t *codon_pairs(const pamlh *p)
 {
@@ -960,6 +961,14 @@ static const codon_pairs_t *codon_pairs(const pamlh *p)
                if (nd == 1) { t->i[t->npair] = i; t->j[t->npair] = j; t->c1[t->npair] = c1; t->c2[t->npair++] = c2; }
                if (nd <= 1) { t->row[t->nnz] = i; t->col[t->nnz++] = j; }
             }
+         for (i = 0, k = 0; i < m; i++) {
+            t->nbr_ptr[i] = k;
+            for (j = 0; j < m; j++) {
+               const int c1 = from61[i], c2 = from61[j];
+               if ((c1 / 16 != c2 / 16) + ((c1 / 4) % 4 != (c2 / 4) % 4) + (c1 % 4 != c2 % 4) == 1) t->nbr[k++] = j;
+            }
+         }
+         t->nbr_ptr[m] = k;
          memcpy(codes[slot], p->code, 64);
          t->ready = 1;
       }
@@ -1197,8 +1206,14 @@ static double codon_q_cls(const pamlh *p, const double *pi, double kappa, double
          }
          Q[i * n + j] = Q[j * n + i] = q;
       }
-   for (i = 0; i < n; i++) for (j = 0; j < n; j++) Q[i * n + j] *= pi[j];
-   for (i = 0; i < n; i++) { double s = 0; for (j = 0; j < n; j++) if (j != i) s += Q[i * n + j]; Q[i * n + i] = -s; mr += pi[i] * s; }
+   /* times the target's frequency, the diagonal from the row sums — over the elements a row has, in the order of the columns: the same
+    * sums, to the bit, as over the whole row (the other elements are zeros) */
+   for (i = 0; i < n; i++) {
+      double s = 0;
+      for (x = cp->nbr_ptr[i]; x < cp->nbr_ptr[i + 1]; x++) { j = cp->nbr[x]; Q[i * n + j] *= pi[j]; s += Q[i * n + j]; }
+      Q[i * n + i] = -s;
+      mr += pi[i] * s;
+   }
    return mr;
 }
 
